@@ -1,0 +1,147 @@
+"""ctypes binding of libarrow_amd.so (include/arrow_amd.h).
+
+The shared library is the product: hand-written HIP kernels for gfx950 behind a C ABI.
+There is no fallback of any kind — if the library is missing or no GPU is present the
+calls raise.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+(or `python -m arrow_amd.build`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libarrow_amd.so")
+
+# arrow::StatusCode twins (include/arrow_amd.h)
+ARX_OK = 0
+ARX_OUT_OF_MEMORY = -1
+ARX_INVALID = -4
+ARX_INDEX_ERROR = -7
+ARX_NOT_IMPLEMENTED = -10
+ARX_DEVICE_ERROR = -100
+
+FILTER_DROP, FILTER_EMIT_NULL = 0, 1
+SORT_ASCENDING, SORT_DESCENDING = 0, 1
+NULLS_AT_START, NULLS_AT_END = 0, 1
+
+
+class ArrowAmdError(Exception):
+    """Base class; subclasses mirror pyarrow.lib.ArrowInvalid & friends."""
+
+
+class ArrowInvalid(ArrowAmdError, ValueError):
+    pass
+
+
+class ArrowIndexError(ArrowAmdError, IndexError):
+    pass
+
+
+class ArrowNotImplementedError(ArrowAmdError, NotImplementedError):
+    pass
+
+
+class ArrowDeviceError(ArrowAmdError, RuntimeError):
+    pass
+
+
+class ArrowMemoryError(ArrowAmdError, MemoryError):
+    pass
+
+
+_ERRORS = {
+    ARX_INVALID: ArrowInvalid,
+    ARX_INDEX_ERROR: ArrowIndexError,
+    ARX_NOT_IMPLEMENTED: ArrowNotImplementedError,
+    ARX_DEVICE_ERROR: ArrowDeviceError,
+    ARX_OUT_OF_MEMORY: ArrowMemoryError,
+}
+
+
+class ArxSpan(C.Structure):
+    """struct ArxSpan of include/arrow_amd.h (device twin of arrow::ArraySpan)."""
+
+    _fields_ = [
+        ("validity", C.c_void_p),
+        ("data", C.c_void_p),
+        ("offset", C.c_int64),
+        ("length", C.c_int64),
+        ("null_count", C.c_int64),
+    ]
+
+
+_p, _i64, _int, _u64, _u32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_uint32, C.c_size_t
+_span = C.POINTER(ArxSpan)
+
+# name -> (restype, argtypes); must list every symbol declared in include/arrow_amd.h
+SIGNATURES = {
+    "arx_last_error": (C.c_char_p, []),
+    "arx_abi_version": (_int, []),
+    "arx_device_count": (_int, []),
+    "arx_set_option": (_int, [C.c_char_p, _i64]),
+    "arx_filter_workspace_bytes": (_sz, [_i64]),
+    "arx_filter_count": (_int, [_span, _int, _p, _sz, C.POINTER(_i64), _p]),
+    "arx_filter_count_async": (_int, [_span, _int, _p, _sz, _p]),
+    "arx_filter_exec": (_int, [_span, _int, _span, _int, _p, _i64, _p, _p, _p]),
+    "arx_mask_to_indices": (_int, [_span, _int, _p, _i64, _int, _p, _p, _p]),
+    "arx_take_workspace_bytes": (_sz, []),
+    "arx_check_index_bounds": (_int, [_span, _int, _u64, _p, _sz, _p]),
+    "arx_take": (_int, [_span, _int, _span, _int, _p, _p, _p, _p]),
+    "arx_cast_f64_f32": (_int, [_p, _i64, _p, _p]),
+    "arx_greater_f64": (_int, [_p, _p, _i64, _p, _p]),
+    "arx_greater_f64_array_scalar": (_int, [_p, C.c_double, _i64, _p, _p]),
+    "arx_greater_f64_scalar_array": (_int, [C.c_double, _p, _i64, _p, _p]),
+    "arx_greater_i64": (_int, [_p, _p, _i64, _p, _p]),
+    "arx_add_i64": (_int, [_p, _p, _i64, _p, _p]),
+    "arx_add_f64": (_int, [_p, _p, _i64, _p, _p]),
+    "arx_bitmap_copy": (_int, [_p, _i64, _i64, _p, _p]),
+    "arx_bitmap_and": (_int, [_p, _i64, _p, _i64, _i64, _p, _p]),
+    "arx_bitmap_popcount": (_int, [_p, _i64, _i64, _p, _sz, C.POINTER(_i64), _p]),
+    "arx_sort_indices_workspace_bytes": (_sz, [_i64]),
+    "arx_sort_indices_64": (_int, [_span, _int, _int, _int, _p, _sz, _p, _p]),
+    "arx_groupby_state_bytes": (_sz, [_i64]),
+    "arx_groupby_init": (_int, [_p, _i64, _p]),
+    "arx_groupby_sum_i64_consume": (_int, [_p, _i64, _span, _span, _p]),
+    "arx_groupby_sum_i64_merge": (_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p]),
+    "arx_groupby_num_groups": (_int, [_p, C.POINTER(_i64), _p]),
+    "arx_groupby_sum_i64_export": (_int, [_p, _p, _p, _p, _p, _p, _p]),
+    "arx_groupby_sum_i64_finalize": (_int, [_p, _p, _i64, _int, _u32, _p, _p]),
+    "arx_groupby_partition_workspace_bytes": (_sz, [_int]),
+    "arx_groupby_partition": (_int, [_p, _p, _p, _p, _p, _i64, _int, _p, _sz, _p, _p, _p, _p, _p,
+                                     _p, _p]),
+}
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """dlopen the library and attach the prototypes.  Raises if it is not built."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ArrowDeviceError(
+            f"{path} is not built: arrow_amd has no CPU fallback. "
+            "Run `python -m arrow_amd.build` (needs hipcc, gfx950).")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.arx_abi_version() != 1:
+        raise ArrowDeviceError("libarrow_amd.so ABI version mismatch")
+    return lib
+
+
+def get_lib():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def check(rc: int) -> None:
+    """Turn an ArxStatus into the matching exception (message from arx_last_error)."""
+    if rc == ARX_OK:
+        return
+    msg = get_lib().arx_last_error().decode("utf-8", "replace")
+    raise _ERRORS.get(rc, ArrowAmdError)(msg)

@@ -1,0 +1,671 @@
+"""Host-side mirror of the arrow::compute API surface for the hot path, over device arrays.
+
+Same names, argument meaning and error behaviour as the reference:
+  FunctionRegistry / Function / Kernel        cpp/src/arrow/compute/registry.h:46, function.h:146-378,
+                                              kernel.h:556-769
+  CallFunction                                cpp/src/arrow/compute/exec.cc:1362-1390
+  Filter / Take / SortIndices / Cast wrappers cpp/src/arrow/compute/api_vector.cc:334-423, cast.cc:239
+  FilterOptions / TakeOptions / ...           cpp/src/arrow/compute/api_vector.h:37-104,
+                                              api_aggregate.h:48-59
+Every kernel `exec` here only allocates outputs, applies the reference's host-side decisions
+(output validity allocation, null_count bookkeeping, shape dispatch) and calls the C ABI of
+libarrow_amd.so (include/arrow_amd.h).  There is no CPU compute path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (ArrowIndexError, ArrowInvalid, ArrowNotImplementedError, check)  # noqa: F401
+from .array import (Array, DataType, Scalar, alloc, bitmap_nbytes, bool_, current_stream, float32,
+                    float64, int32, int64, kUnknownNullCount, uint16, uint32, uint64,
+                    INDEX_TYPE_ID)
+
+# --------------------------------------------------------------------------- options
+class FunctionOptions:
+    pass
+
+
+class FilterOptions(FunctionOptions):
+    """api_vector.h:37-52.  null_selection_behavior: 'drop' | 'emit_null'."""
+
+    def __init__(self, null_selection_behavior: str = "drop"):
+        if null_selection_behavior not in ("drop", "emit_null"):
+            raise ArrowInvalid(f"invalid null_selection_behavior {null_selection_behavior!r}")
+        self.null_selection_behavior = null_selection_behavior
+
+    @property
+    def code(self) -> int:
+        return _lib.FILTER_EMIT_NULL if self.null_selection_behavior == "emit_null" else _lib.FILTER_DROP
+
+
+class TakeOptions(FunctionOptions):
+    """api_vector.h:54-63."""
+
+    def __init__(self, boundscheck: bool = True):
+        self.boundscheck = bool(boundscheck)
+
+
+class CastOptions(FunctionOptions):
+    def __init__(self, to_type: DataType, allow_float_truncate: bool = False):
+        self.to_type = to_type
+        self.allow_float_truncate = allow_float_truncate
+
+
+class ArraySortOptions(FunctionOptions):
+    """api_vector.h:93-104."""
+
+    def __init__(self, order: str = "ascending", null_placement: str = "at_end"):
+        if order not in ("ascending", "descending"):
+            raise ArrowInvalid(f"invalid sort order {order!r}")
+        if null_placement not in ("at_start", "at_end"):
+            raise ArrowInvalid(f"invalid null placement {null_placement!r}")
+        self.order = order
+        self.null_placement = null_placement
+
+
+class SortOptions(FunctionOptions):
+    """api_vector.h:106-: sort_keys = [(name, order)]; for a plain Array only the order is used."""
+
+    def __init__(self, sort_keys=(("", "ascending"),), null_placement: str = "at_end"):
+        self.sort_keys = list(sort_keys)
+        self.null_placement = null_placement
+
+
+class ScalarAggregateOptions(FunctionOptions):
+    """api_aggregate.h:48-59."""
+
+    def __init__(self, skip_nulls: bool = True, min_count: int = 1):
+        self.skip_nulls = bool(skip_nulls)
+        self.min_count = int(min_count)
+
+
+# --------------------------------------------------------------------------- scratch space
+_tls = threading.local()
+
+
+def _workspace(device: torch.device, nbytes: int, slot: str = "ws") -> torch.Tensor:
+    """Per-thread, per-device scratch buffer (the C ABI never allocates)."""
+    cache = getattr(_tls, "cache", None)
+    if cache is None:
+        cache = _tls.cache = {}
+    key = (slot, str(device))
+    buf = cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = cache[key] = alloc(max(nbytes, 1 << 16), device)
+    return buf
+
+
+def _lib_and_stream(device: torch.device):
+    return _lib.get_lib(), current_stream(device)
+
+
+# --------------------------------------------------------------------------- kernels (exec)
+def _propagate_validity(args, length: int, device):
+    """NullHandling::INTERSECTION (PropagateNullsSpans, exec.cc:1222-1281) on the device.
+    Returns (validity buffer or None, null_count)."""
+    arrs = [a for a in args if isinstance(a, Array) and a.may_have_nulls()]
+    for a in args:
+        if isinstance(a, Scalar) and not a.is_valid:
+            buf = alloc(bitmap_nbytes(length), device, zero=True)  # all null
+            return buf, length
+    if not arrs:
+        return None, 0
+    lib, stream = _lib_and_stream(device)
+    if len(arrs) == 1 and arrs[0].offset == 0:
+        return arrs[0].validity, arrs[0].null_count  # zero-copy share
+    out = alloc(bitmap_nbytes(length), device)
+    first = arrs[0]
+    if len(arrs) == 1:
+        check(lib.arx_bitmap_copy(first.validity.data_ptr(), first.offset, length, out.data_ptr(), stream))
+        return out, first.null_count
+    check(lib.arx_bitmap_and(first.validity.data_ptr(), first.offset, arrs[1].validity.data_ptr(),
+                             arrs[1].offset, length, out.data_ptr(), stream))
+    for a in arrs[2:]:
+        check(lib.arx_bitmap_and(out.data_ptr(), 0, a.validity.data_ptr(), a.offset, length,
+                                 out.data_ptr(), stream))
+    return out, kUnknownNullCount
+
+
+def _exec_array_filter(args, options):
+    """PrimitiveFilterExec (vector_selection_filter_internal.cc:445-510)."""
+    values, mask = args
+    options = options or FilterOptions()
+    if mask.type != bool_:
+        raise ArrowNotImplementedError("filter: the selection must be a boolean array")
+    if values.type.bit_width < 8:
+        raise ArrowNotImplementedError("filter on boolean values is not on the gfx950 path yet")
+    if values.length != mask.length:  # ExecSpanIterator::Init, exec.cc:349-355
+        raise ArrowInvalid("Array arguments must all be the same length")
+    dev = values.device
+    lib, stream = _lib_and_stream(dev)
+    n = mask.length
+    ws_bytes = lib.arx_filter_workspace_bytes(n)
+    ws = _workspace(dev, ws_bytes)
+    mspan, vspan = mask.span(), values.span()
+    out_len = C.c_int64(0)
+    check(lib.arx_filter_count(C.byref(mspan), options.code, ws.data_ptr(), ws.numel(),
+                               C.byref(out_len), stream))
+    s = out_len.value
+    filter_null_count_is_zero = mask.null_count == 0
+    drop = options.code == _lib.FILTER_DROP
+    null_count = 0 if (values.null_count == 0 and (drop or filter_null_count_is_zero)) else kUnknownNullCount
+    allocate_validity = values.null_count != 0 or not filter_null_count_is_zero
+    w = values.type.byte_width
+    out_data = alloc(s * w, dev)
+    out_valid = alloc(bitmap_nbytes(s), dev) if allocate_validity else None
+    check(lib.arx_filter_exec(C.byref(vspan), w, C.byref(mspan), options.code, ws.data_ptr(), s,
+                              out_data.data_ptr(), None if out_valid is None else out_valid.data_ptr(),
+                              stream))
+    return Array(values.type, s, [out_valid, out_data], null_count, 0)
+
+
+def get_take_indices(mask: Array, null_selection_behavior: str = "drop") -> Array:
+    """GetTakeIndices (vector_selection_take_internal.cc:258-305): uint16 for <= 65535 rows."""
+    options = FilterOptions(null_selection_behavior)
+    if mask.type != bool_:
+        raise ArrowNotImplementedError("GetTakeIndices needs a boolean array")
+    dev = mask.device
+    lib, stream = _lib_and_stream(dev)
+    n = mask.length
+    if n > 0xFFFFFFFF:
+        raise ArrowNotImplementedError(
+            "Filter length exceeds UINT32_MAX, consider a different strategy for selecting elements")
+    ws = _workspace(dev, lib.arx_filter_workspace_bytes(n))
+    mspan = mask.span()
+    out_len = C.c_int64(0)
+    check(lib.arx_filter_count(C.byref(mspan), options.code, ws.data_ptr(), ws.numel(),
+                               C.byref(out_len), stream))
+    s = out_len.value
+    itype = uint16 if n <= 65535 else uint32
+    emit = options.code == _lib.FILTER_EMIT_NULL and mask.may_have_nulls()
+    out = alloc(s * itype.byte_width, dev)
+    out_valid = alloc(bitmap_nbytes(s), dev) if emit else None
+    check(lib.arx_mask_to_indices(C.byref(mspan), options.code, ws.data_ptr(), s, itype.byte_width,
+                                  out.data_ptr(), None if out_valid is None else out_valid.data_ptr(),
+                                  stream))
+    return Array(itype, s, [out_valid, out], kUnknownNullCount if emit else 0, 0)
+
+
+class _LazyCount:
+    """null_count = length - valid_count, resolved on first read (take sets it exactly, :377)."""
+
+    def __init__(self, length, counter):
+        self.length, self.counter = length, counter
+
+    def __call__(self):
+        return int(self.length - int(self.counter.cpu().view(torch.int64)[0]))
+
+
+def _exec_array_take(args, options):
+    """FixedWidthTakeExec (vector_selection_take_internal.cc:405-468)."""
+    values, indices = args
+    options = options or TakeOptions()
+    if indices.type.name not in INDEX_TYPE_ID:
+        raise ArrowNotImplementedError(f"take: unsupported index type {indices.type.name}")
+    if values.type.bit_width < 8:
+        raise ArrowNotImplementedError("take on boolean values is not on the gfx950 path yet")
+    dev = values.device
+    lib, stream = _lib_and_stream(dev)
+    tid = INDEX_TYPE_ID[indices.type.name]
+    ispan, vspan = indices.span(), values.span()
+    if options.boundscheck:
+        ws = _workspace(dev, lib.arx_take_workspace_bytes(), "take")
+        check(lib.arx_check_index_bounds(C.byref(ispan), tid, values.length, ws.data_ptr(), ws.numel(),
+                                         stream))
+    m = indices.length
+    w = values.type.byte_width
+    allocate_validity = values.may_have_nulls() or indices.may_have_nulls()
+    out_data = alloc(m * w, dev)
+    out_valid = alloc(bitmap_nbytes(m), dev) if allocate_validity else None
+    counter = None
+    if allocate_validity:
+        counter = torch.zeros(8, dtype=torch.uint8, device=dev)
+    check(lib.arx_take(C.byref(vspan), w, C.byref(ispan), tid, out_data.data_ptr(),
+                       None if out_valid is None else out_valid.data_ptr(),
+                       None if counter is None else counter.data_ptr(), stream))
+    out = Array(values.type, m, [out_valid, out_data], 0, 0)
+    if allocate_validity:
+        out.set_lazy_null_count(_LazyCount(m, counter))
+    return out
+
+
+def _exec_cast_f64_f32(args, options):
+    """CastFloatingToFloating (scalar_cast_numeric.cc:56-60) under ScalarExecutor."""
+    (arr,) = args
+    dev = arr.device
+    lib, stream = _lib_and_stream(dev)
+    out = alloc(arr.length * 4, dev)
+    check(lib.arx_cast_f64_f32(arr.values_ptr(), arr.length, out.data_ptr(), stream))
+    validity, nc = _propagate_validity([arr], arr.length, dev)
+    return Array(float32, arr.length, [validity, out], nc, 0)
+
+
+def _scalar_value(x):
+    return x.value if isinstance(x, Scalar) else x
+
+
+def _exec_greater(args, options):
+    """CompareKernel<..., Greater>::Exec (scalar_compare.cc:259-298)."""
+    left, right = args
+    arr = left if isinstance(left, Array) else right
+    dev = arr.device
+    lib, stream = _lib_and_stream(dev)
+    n = arr.length
+    out = alloc(bitmap_nbytes(n), dev, zero=True)
+    t = arr.type
+    if isinstance(left, Array) and isinstance(right, Array):
+        if left.length != right.length:
+            raise ArrowInvalid("Array arguments must all be the same length")
+        fn = lib.arx_greater_f64 if t == float64 else lib.arx_greater_i64
+        check(fn(left.values_ptr(), right.values_ptr(), n, out.data_ptr(), stream))
+    elif isinstance(left, Array):
+        check(lib.arx_greater_f64_array_scalar(left.values_ptr(), float(_scalar_value(right) or 0.0), n,
+                                               out.data_ptr(), stream))
+    else:
+        check(lib.arx_greater_f64_scalar_array(float(_scalar_value(left) or 0.0), right.values_ptr(), n,
+                                               out.data_ptr(), stream))
+    validity, nc = _propagate_validity([left, right], n, dev)
+    return Array(bool_, n, [validity, out], nc, 0)
+
+
+def _exec_add(args, options):
+    """ScalarBinary<..., Add> (codegen_internal.h:814, base_arithmetic_internal.h:45-80)."""
+    left, right = args
+    if left.length != right.length:
+        raise ArrowInvalid("Array arguments must all be the same length")
+    dev = left.device
+    lib, stream = _lib_and_stream(dev)
+    n = left.length
+    out = alloc(n * 8, dev)
+    fn = lib.arx_add_i64 if left.type == int64 else lib.arx_add_f64
+    check(fn(left.values_ptr(), right.values_ptr(), n, out.data_ptr(), stream))
+    validity, nc = _propagate_validity([left, right], n, dev)
+    return Array(left.type, n, [validity, out], nc, 0)
+
+
+def _exec_array_sort_indices(args, options):
+    """ArraySortIndices::Exec (vector_array_sort.cc:524-540): uint64 indices, never null."""
+    (arr,) = args
+    options = options or ArraySortOptions()
+    dev = arr.device
+    lib, stream = _lib_and_stream(dev)
+    n = arr.length
+    ws_bytes = lib.arx_sort_indices_workspace_bytes(n)
+    ws = _workspace(dev, ws_bytes + 256, "sort")
+    base = ws.data_ptr()
+    aligned = (base + 255) & ~255
+    out = alloc(n * 8, dev)
+    span = arr.span()
+    check(lib.arx_sort_indices_64(C.byref(span), int(arr.type == int64),
+                                  _lib.SORT_DESCENDING if options.order == "descending" else _lib.SORT_ASCENDING,
+                                  _lib.NULLS_AT_START if options.null_placement == "at_start" else _lib.NULLS_AT_END,
+                                  aligned, ws.numel() - (aligned - base), out.data_ptr(), stream))
+    return Array(uint64, n, [None, out], 0, 0)
+
+
+# --------------------------------------------------------------------------- registry
+class Kernel:
+    """arrow::compute::Kernel twin: a signature (tuple of DataType or None = any) + exec."""
+
+    def __init__(self, in_types, exec_fn, out_type=None):
+        self.in_types = tuple(in_types)
+        self.exec = exec_fn
+        self.out_type = out_type
+
+    def matches(self, types) -> bool:
+        if len(types) != len(self.in_types):
+            return False
+        return all(want is None or (callable(want) and want(t)) or want == t
+                   for want, t in zip(self.in_types, types))
+
+
+class Function:
+    SCALAR, VECTOR, SCALAR_AGGREGATE, HASH_AGGREGATE, META = range(5)  # function.h:146-168
+
+    def __init__(self, name: str, kind: int, arity: int, default_options=None, meta_impl=None):
+        self.name = name
+        self.kind = kind
+        self.arity = arity
+        self.default_options = default_options
+        self.kernels: list[Kernel] = []
+        self._meta_impl = meta_impl
+
+    def add_kernel(self, kernel: Kernel) -> None:
+        if len(kernel.in_types) != self.arity:  # function.cc:448-455
+            raise ArrowInvalid(f"Added kernel accepts {len(kernel.in_types)} arguments but the "
+                               f"function {self.name} accepts {self.arity}")
+        self.kernels.append(kernel)
+
+    @property
+    def num_kernels(self) -> int:
+        return len(self.kernels)
+
+    def dispatch_exact(self, types) -> Kernel:
+        """DispatchExactImpl (function.cc:122-157): the LAST matching kernel wins."""
+        for k in reversed(self.kernels):
+            if k.matches(types):
+                return k
+        names = ", ".join(t.name for t in types)
+        raise ArrowNotImplementedError(
+            f"Function '{self.name}' has no kernel matching input types ({names})")
+
+    def execute(self, args, options=None):
+        if len(args) != self.arity:
+            raise ArrowInvalid(f"Function '{self.name}' accepts {self.arity} arguments but "
+                               f"{len(args)} passed")
+        options = options if options is not None else self.default_options
+        if self.kind == Function.META:
+            return self._meta_impl(args, options)
+        if self.kind == Function.HASH_AGGREGATE:  # function.cc:325-326
+            raise ArrowNotImplementedError("Direct execution of HASH_AGGREGATE functions")
+        types = [a.type for a in args]
+        return self.dispatch_exact(types).exec(args, options)
+
+
+class FunctionRegistry:
+    """registry.h:46: name -> Function, aliases, no overwrite unless asked."""
+
+    def __init__(self):
+        self._fns: dict[str, Function] = {}
+        self._lock = threading.Lock()
+
+    def add_function(self, fn: Function, allow_overwrite: bool = False) -> None:
+        with self._lock:
+            if fn.name in self._fns and not allow_overwrite:
+                raise KeyError(f"Already have a function registered with name: {fn.name}")
+            self._fns[fn.name] = fn
+
+    def add_alias(self, target: str, source: str) -> None:
+        with self._lock:
+            if source not in self._fns:
+                raise KeyError(f"No function registered with name: {source}")
+            self._fns[target] = self._fns[source]
+
+    def get_function(self, name: str) -> Function:
+        try:
+            return self._fns[name]
+        except KeyError:
+            raise KeyError(f"No function registered with name: {name}") from None
+
+    def get_function_names(self):
+        return sorted(self._fns)
+
+    @property
+    def num_functions(self) -> int:
+        return len(self._fns)
+
+
+class ExecBatch:
+    """exec.h:174-261: a list of equal-length Arrays / Scalars plus the length."""
+
+    def __init__(self, values, length: int | None = None):
+        self.values = list(values)
+        if length is None:
+            lens = [v.length for v in self.values if isinstance(v, Array)]
+            length = lens[0] if lens else 1
+        self.length = length
+
+    def __getitem__(self, i):
+        return self.values[i]
+
+    @property
+    def num_values(self):
+        return len(self.values)
+
+
+class RecordBatch:
+    """Just enough of arrow::RecordBatch for the Filter/Take meta-function shape dispatch."""
+
+    def __init__(self, columns: dict):
+        self.columns = dict(columns)
+        lens = {c.length for c in self.columns.values()}
+        if len(lens) > 1:
+            raise ArrowInvalid("columns of a RecordBatch must have equal length")
+        self.num_rows = lens.pop() if lens else 0
+
+
+_FIXED_WIDTH = lambda t: t.bit_width >= 8  # noqa: E731
+_INTEGER = lambda t: t.name in INDEX_TYPE_ID  # noqa: E731
+
+
+def _filter_meta(args, options):
+    """FilterMetaFunction::ExecuteImpl (vector_selection_filter_internal.cc:1043-1072)."""
+    values, mask = args
+    options = options or FilterOptions()
+    if isinstance(values, RecordBatch):
+        # FilterRecordBatch :925-960 — mask -> indices once, then Take per column
+        if mask.length != values.num_rows:
+            raise ArrowInvalid("Filter inputs must all be the same length")
+        indices = get_take_indices(mask, options.null_selection_behavior)
+        take_opts = TakeOptions(boundscheck=False)
+        return RecordBatch({k: call_function("take", [c, indices], take_opts)
+                            for k, c in values.columns.items()})
+    return call_function("array_filter", [values, mask], options)
+
+
+def _take_meta(args, options):
+    """TakeMetaFunction::ExecuteImpl (vector_selection_take_internal.cc:660-701), AAA and RAR."""
+    values, indices = args
+    options = options or TakeOptions()
+    if isinstance(values, RecordBatch):
+        return RecordBatch({k: call_function("array_take", [c, indices], options)
+                            for k, c in values.columns.items()})
+    return call_function("array_take", [values, indices], options)
+
+
+def _cast_meta(args, options):
+    """CastMetaFunction::ExecuteImpl (cast.cc:95-126): dispatch on the target type."""
+    (arr,) = args
+    if options is None or options.to_type is None:
+        raise ArrowInvalid("Cast requires that options.to_type is set")
+    if arr.type == options.to_type:
+        return arr
+    return _cast_table_lookup(options.to_type).execute([arr], options)
+
+
+_cast_table: dict[str, Function] = {}
+
+
+def _cast_table_lookup(to_type: DataType) -> Function:
+    """GetCastFunction (cast.cc:207-214): casts live in a private table, not the registry."""
+    try:
+        return _cast_table[to_type.name]
+    except KeyError:
+        raise ArrowNotImplementedError(f"Unsupported cast to {to_type.name} (no available cast "
+                                       "function for target type)") from None
+
+
+def _sort_indices_meta(args, options):
+    """SortIndicesMetaFunction::ExecuteImpl (vector_sort.cc:856-924) for Array input."""
+    (arr,) = args
+    options = options or SortOptions()
+    order = options.sort_keys[0][1] if options.sort_keys else "ascending"
+    return call_function("array_sort_indices", [arr], ArraySortOptions(order, options.null_placement))
+
+
+def _build_registry() -> FunctionRegistry:
+    reg = FunctionRegistry()
+
+    f = Function("array_filter", Function.VECTOR, 2, FilterOptions())
+    f.add_kernel(Kernel((_FIXED_WIDTH, bool_), _exec_array_filter))
+    reg.add_function(f)
+    reg.add_function(Function("filter", Function.META, 2, FilterOptions(), _filter_meta))
+
+    f = Function("array_take", Function.VECTOR, 2, TakeOptions())
+    f.add_kernel(Kernel((_FIXED_WIDTH, _INTEGER), _exec_array_take))
+    reg.add_function(f)
+    reg.add_function(Function("take", Function.META, 2, TakeOptions(), _take_meta))
+
+    c = Function("cast_float", Function.SCALAR, 1)
+    c.add_kernel(Kernel((float64,), _exec_cast_f64_f32, float32))
+    _cast_table["float"] = c
+    reg.add_function(Function("cast", Function.META, 1, None, _cast_meta))
+
+    f = Function("greater", Function.SCALAR, 2)
+    f.add_kernel(Kernel((float64, float64), _exec_greater, bool_))
+    f.add_kernel(Kernel((int64, int64), _exec_greater, bool_))
+    reg.add_function(f)
+
+    f = Function("add", Function.SCALAR, 2)
+    f.add_kernel(Kernel((int64, int64), _exec_add, int64))
+    f.add_kernel(Kernel((float64, float64), _exec_add, float64))
+    reg.add_function(f)
+
+    f = Function("array_sort_indices", Function.VECTOR, 1, ArraySortOptions())
+    f.add_kernel(Kernel((uint64,), _exec_array_sort_indices, uint64))
+    f.add_kernel(Kernel((int64,), _exec_array_sort_indices, uint64))
+    reg.add_function(f)
+    reg.add_function(Function("sort_indices", Function.META, 1, SortOptions(), _sort_indices_meta))
+
+    f = Function("hash_sum", Function.HASH_AGGREGATE, 2, ScalarAggregateOptions())
+    f.add_kernel(Kernel((int64, uint32), None, int64))
+    reg.add_function(f)
+    return reg
+
+
+_registry = None
+
+
+def get_function_registry() -> FunctionRegistry:
+    """GetFunctionRegistry (registry.cc:301-304): the process-wide singleton."""
+    global _registry
+    if _registry is None:
+        _registry = _build_registry()
+    return _registry
+
+
+def call_function(name: str, args, options=None, registry: FunctionRegistry | None = None):
+    """CallFunction (exec.cc:1362-1370): registry lookup + Function::Execute."""
+    reg = registry or get_function_registry()
+    return reg.get_function(name).execute(list(args), options)
+
+
+# --------------------------------------------------------------------------- typed wrappers
+def filter(values, mask, null_selection_behavior: str = "drop"):  # noqa: A001
+    """compute::Filter (api_vector.cc:412-416)."""
+    return call_function("filter", [values, mask], FilterOptions(null_selection_behavior))
+
+
+def take(values, indices, boundscheck: bool = True):
+    """compute::Take (api_vector.cc:419-423)."""
+    return call_function("take", [values, indices], TakeOptions(boundscheck))
+
+
+def cast(arr, to_type: DataType):
+    """compute::Cast (cast.cc:239-248)."""
+    return call_function("cast", [arr], CastOptions(to_type))
+
+
+def _wrap_scalar(x, like: Array):
+    if isinstance(x, (Array, Scalar)):
+        return x
+    return Scalar(x, like.type, x is not None)
+
+
+def greater(left, right):
+    like = left if isinstance(left, Array) else right
+    left, right = _wrap_scalar(left, like), _wrap_scalar(right, like)
+    return call_function("greater", [left, right])
+
+
+def add(left, right):
+    return call_function("add", [left, right])
+
+
+def sort_indices(arr, order: str = "ascending", null_placement: str = "at_end"):
+    """compute::SortIndices (api_vector.cc:334-347)."""
+    return call_function("sort_indices", [arr], SortOptions([("", order)], null_placement))
+
+
+# --------------------------------------------------------------------------- group-by
+def _next_pow2(n: int) -> int:
+    p = 1
+    while p < n:
+        p <<= 1
+    return p
+
+
+class GroupBySum:
+    """The fused device operator standing where Acero's GroupByNode drives
+    Grouper::Consume + hash_sum {resize, consume, merge, finalize}
+    (acero/groupby_aggregate_node.cc:210-337, compute/kernel.h:720-769).
+
+    capacity: slots of the open-addressing table (power of two, > expected distinct keys).
+    """
+
+    def __init__(self, capacity: int, device=None, options: ScalarAggregateOptions | None = None):
+        from .array import default_device
+
+        self.device = torch.device(device) if device is not None else default_device()
+        self.capacity = _next_pow2(max(2, int(capacity)))
+        self.options = options or ScalarAggregateOptions()
+        lib, stream = _lib_and_stream(self.device)
+        self.state = alloc(lib.arx_groupby_state_bytes(self.capacity), self.device)
+        check(lib.arx_groupby_init(self.state.data_ptr(), self.capacity, stream))
+
+    def consume(self, keys: Array, values: Array) -> None:
+        if keys.type != int32 or values.type != int64:
+            raise ArrowNotImplementedError("GroupBySum: int32 keys and int64 values only")
+        lib, stream = _lib_and_stream(self.device)
+        ks, vs = keys.span(), values.span()
+        check(lib.arx_groupby_sum_i64_consume(self.state.data_ptr(), self.capacity, C.byref(ks),
+                                              C.byref(vs), stream))
+
+    def num_groups(self) -> int:
+        lib, stream = _lib_and_stream(self.device)
+        n = C.c_int64(0)
+        check(lib.arx_groupby_num_groups(self.state.data_ptr(), C.byref(n), stream))
+        return n.value
+
+    def export(self):
+        """Partial aggregates: dict of device tensors keys(i32) key_is_valid(u8) sums(i64)
+        counts(i64) no_nulls(u8), num_groups entries each, unspecified order."""
+        lib, stream = _lib_and_stream(self.device)
+        g = self.num_groups()
+        dev = self.device
+        cols = dict(keys=torch.empty(max(g, 1), dtype=torch.int32, device=dev),
+                    key_is_valid=torch.empty(max(g, 1), dtype=torch.uint8, device=dev),
+                    sums=torch.empty(max(g, 1), dtype=torch.int64, device=dev),
+                    counts=torch.empty(max(g, 1), dtype=torch.int64, device=dev),
+                    no_nulls=torch.empty(max(g, 1), dtype=torch.uint8, device=dev))
+        check(lib.arx_groupby_sum_i64_export(self.state.data_ptr(), cols["keys"].data_ptr(),
+                                             cols["key_is_valid"].data_ptr(), cols["sums"].data_ptr(),
+                                             cols["counts"].data_ptr(), cols["no_nulls"].data_ptr(),
+                                             stream))
+        return {k: v[:g] for k, v in cols.items()}
+
+    def merge(self, partial: dict) -> None:
+        """Fold another state's partial aggregates in (Merge, hash_aggregate_numeric.cc:85-107)."""
+        lib, stream = _lib_and_stream(self.device)
+        g = int(partial["keys"].numel())
+        if g == 0:
+            return
+        check(lib.arx_groupby_sum_i64_merge(self.state.data_ptr(), self.capacity,
+                                            partial["keys"].data_ptr(), partial["key_is_valid"].data_ptr(),
+                                            partial["sums"].data_ptr(), partial["counts"].data_ptr(),
+                                            partial["no_nulls"].data_ptr(), g, stream))
+
+    def finalize(self):
+        """Returns (keys, key_is_valid, sums, valid) device tensors (valid: u8, 0 = null sum)."""
+        lib, stream = _lib_and_stream(self.device)
+        p = self.export()
+        g = int(p["keys"].numel())
+        valid = torch.empty(max(g, 1), dtype=torch.uint8, device=self.device)
+        check(lib.arx_groupby_sum_i64_finalize(p["counts"].data_ptr(), p["no_nulls"].data_ptr(), g,
+                                               int(self.options.skip_nulls), self.options.min_count,
+                                               valid.data_ptr(), stream))
+        return p["keys"], p["key_is_valid"], p["sums"], valid[:g]
+
+
+def group_by_sum(keys: Array, values: Array, capacity: int | None = None,
+                 options: ScalarAggregateOptions | None = None):
+    """Table.group_by(k).aggregate([(v, 'sum')]) for one int32 key and one int64 value."""
+    cap = capacity or max(16, 2 * keys.length + 2)
+    op = GroupBySum(cap, keys.device, options)
+    op.consume(keys, values)
+    return op.finalize()

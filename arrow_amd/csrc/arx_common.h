@@ -1,0 +1,161 @@
+// Shared device/host helpers for the gfx950 kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/arrow_amd.h"
+
+namespace arx {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;             // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kTileRows = 4096;         // one wave tile = 64 lanes x one 64-bit mask word
+constexpr int kTilesPerGroup = 64;      // count-kernel workgroup = 64 wave tiles
+
+// ---------------------------------------------------------------------------
+// Error plumbing (host)
+// ---------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+// Per-file tuning-knob hooks used by arx_set_option (return 1 if the name was recognised).
+int set_selection_option(const char* name, int64_t value);
+int set_sort_option(const char* name, int64_t value);
+int set_groupby_option(const char* name, int64_t value);
+
+#define ARX_HIP(call)                                          \
+  do {                                                         \
+    hipError_t e__ = (call);                                   \
+    if (e__ != hipSuccess) return ::arx::hip_fail(e__, #call); \
+  } while (0)
+
+#define ARX_CHECK_LAUNCH(name)                                   \
+  do {                                                           \
+    hipError_t e__ = hipGetLastError();                          \
+    if (e__ != hipSuccess) return ::arx::hip_fail(e__, name);    \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------------------
+// Bitmap view: a bitmap with an arbitrary bit offset, read as aligned u64 words.
+// `logical word i` = bits [64 i, 64 i + 64) of the logical bitmap (after offset).
+// A NULL bitmap reads as all ones.  Bits at positions >= length read as zero.
+// (Twin of the CPU-side BitBlockCounter/ShiftWord machinery,
+//  cpp/src/arrow/util/bit_block_counter.h:42-47.)
+// ---------------------------------------------------------------------------
+struct Bits {
+  const uint64_t* base;  // 8-byte aligned word holding the first logical bit (or NULL)
+  int64_t nphys;         // number of physical words covering the logical range
+  int64_t length;        // logical length in bits
+  int shift;             // position of logical bit 0 inside base[0]
+};
+
+static inline Bits make_bits(const void* bitmap, int64_t bit_offset, int64_t length) {
+  Bits b;
+  b.length = length;
+  if (bitmap == nullptr) {
+    b.base = nullptr;
+    b.nphys = 0;
+    b.shift = 0;
+    return b;
+  }
+  const uint64_t byte_addr = reinterpret_cast<uint64_t>(bitmap) + static_cast<uint64_t>(bit_offset >> 3);
+  const int bit_in_byte = static_cast<int>(bit_offset & 7);
+  const uint64_t aligned = byte_addr & ~uint64_t(7);
+  b.base = reinterpret_cast<const uint64_t*>(aligned);
+  b.shift = static_cast<int>((byte_addr - aligned) * 8) + bit_in_byte;
+  b.nphys = (static_cast<int64_t>(b.shift) + length + 63) >> 6;
+  return b;
+}
+
+__device__ __forceinline__ uint64_t low_mask64(int n) {  // n in [0,64]
+  return n >= 64 ? ~uint64_t(0) : ((uint64_t(1) << n) - 1);
+}
+
+// Logical word `w` of the bitmap (see Bits).  Safe for any w >= 0.
+__device__ __forceinline__ uint64_t load_word(const Bits& b, int64_t w) {
+  const int64_t first = w << 6;
+  if (first >= b.length) return 0;
+  const int64_t remain = b.length - first;
+  uint64_t v;
+  if (b.base == nullptr) {
+    v = ~uint64_t(0);
+  } else {
+    v = b.base[w] >> b.shift;
+    if (b.shift != 0 && (w + 1) < b.nphys) v |= b.base[w + 1] << (64 - b.shift);
+  }
+  if (remain < 64) v &= low_mask64(static_cast<int>(remain));
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// Wave-level primitives (64 lanes)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t n = __shfl_up(v, d, 64);
+    if (lane >= d) v += n;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+__device__ __forceinline__ uint64_t wave_reduce_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+  uint32_t lo = __shfl(static_cast<uint32_t>(v), src, 64);
+  uint32_t hi = __shfl(static_cast<uint32_t>(v >> 32), src, 64);
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+// Software parallel-bit-extract: gathers the bits of x selected by m into the low
+// popcount(m) bits, preserving order (Hacker's Delight 7-4 "compress").
+__device__ __forceinline__ uint64_t pext64(uint64_t x, uint64_t m) {
+  x &= m;
+  uint64_t mk = ~m << 1;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    uint64_t mp = mk ^ (mk << 1);
+    mp ^= mp << 2;
+    mp ^= mp << 4;
+    mp ^= mp << 8;
+    mp ^= mp << 16;
+    mp ^= mp << 32;
+    const uint64_t mv = mp & m;
+    m = (m ^ mv) | (mv >> (1 << i));
+    const uint64_t t = x & mv;
+    x = (x ^ t) | (t >> (1 << i));
+    mk &= ~mp;
+  }
+  return x;
+}
+
+// Spread the low 32 bits of x to the even bit positions of a 64-bit word.
+__device__ __forceinline__ uint64_t spread32(uint64_t x) {
+  x &= 0xffffffffull;
+  x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+  x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+  x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace arx

@@ -1,0 +1,380 @@
+// Streaming element-wise kernels for gfx950: cast f64->f32, greater, add, and the validity
+// plumbing (bitmap copy / and / popcount) the ScalarExecutor does on the host.
+//
+// What they restate:
+//   CastPrimitive<FloatType,DoubleType>::Exec   cpp/src/arrow/compute/kernels/scalar_cast_internal.cc:41-53
+//   ComparePrimitiveArrayArray/ArrayScalar/ScalarArray  cpp/src/arrow/compute/kernels/scalar_compare.cc:165-247
+//   Greater::Call                               same file :58-64
+//   Add::Call (wrap-around for ints)            cpp/src/arrow/compute/kernels/base_arithmetic_internal.h:45-80
+//   PropagateNullsSpans / BitmapAnd / CopyBitmap cpp/src/arrow/compute/exec.cc:1222-1281, util/bitmap_ops.cc
+//
+// All of them are HBM-bound streams: every lane moves 16 bytes per load instruction
+// (1 KiB per wave instruction), 4 independent loads in flight, grid-stride over a grid of
+// 256 CUs x 8 workgroups.
+#include "arx_common.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace arx {
+
+constexpr int kStreamBlocks = 256 * 8;
+
+static inline unsigned stream_grid(int64_t work_items_per_block_iter, int64_t n) {
+  const int64_t blocks = ceil_div(n, work_items_per_block_iter);
+  return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(blocks, kStreamBlocks)));
+}
+
+// ------------------------------------------------------------------ cast f64 -> f32
+// Per wave iteration: 4 x (64 lanes x 2 doubles) = 512 rows.
+template <bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void cast_f64_f32_kernel(const double* __restrict__ in,
+                                                              int64_t n, float* __restrict__ out) {
+  constexpr int U = 4;
+  const int64_t rows_per_block = kBlock * 2 * U;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * rows_per_block;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * rows_per_block; base < n; base += stride) {
+    double2 v[U];
+    int64_t r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      r[u] = base + (u * kBlock + threadIdx.x) * 2;
+      if (r[u] + 1 < n) {
+        if constexpr (ALIGNED) {
+          v[u] = *reinterpret_cast<const double2*>(in + r[u]);
+        } else {
+          v[u].x = in[r[u]];
+          v[u].y = in[r[u] + 1];
+        }
+      } else if (r[u] < n) {
+        v[u].x = in[r[u]];
+        v[u].y = 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r[u] + 1 < n) {
+        float2 o;
+        o.x = static_cast<float>(v[u].x);  // v_cvt_f32_f64: IEEE round-to-nearest-even
+        o.y = static_cast<float>(v[u].y);
+        if constexpr (ALIGNED) {
+          *reinterpret_cast<float2*>(out + r[u]) = o;
+        } else {
+          out[r[u]] = o.x;
+          out[r[u] + 1] = o.y;
+        }
+      } else if (r[u] < n) {
+        out[r[u]] = static_cast<float>(v[u].x);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ compare (greater)
+// Each wave step covers 128 rows: lane l holds rows 2l, 2l+1 (one 16-byte load per operand).
+// The two ballots (even rows / odd rows) are interleaved with scalar bit-spreads into two
+// 64-bit output words, LSB-first like bit_util::PackBits (cpp/src/arrow/util/bit_util.h:270).
+enum OperandKind { kArray = 0, kScalar = 1 };
+
+template <typename T>
+struct Pair {
+  T x, y;
+};
+
+template <typename T, bool ALIGNED>
+__device__ __forceinline__ Pair<T> load_pair(const T* p, int64_t r, int64_t n) {
+  Pair<T> v;
+  v.x = T(0);
+  v.y = T(0);
+  if (r + 1 < n) {
+    if constexpr (ALIGNED) {
+      const uint4 q = *reinterpret_cast<const uint4*>(p + r);
+      const T* t = reinterpret_cast<const T*>(&q);
+      v.x = t[0];
+      v.y = t[1];
+    } else {
+      v.x = p[r];
+      v.y = p[r + 1];
+    }
+  } else if (r < n) {
+    v.x = p[r];
+  }
+  return v;
+}
+
+template <typename T, int LK, int RK, bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void greater_kernel(const T* __restrict__ left, T lscalar,
+                                                         const T* __restrict__ right, T rscalar,
+                                                         int64_t n, uint64_t* __restrict__ out) {
+  constexpr int U = 4;
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t rows_per_iter = 128 * U;
+  const int64_t niter = (n + rows_per_iter - 1) / rows_per_iter;
+  for (int64_t it = wave_g; it < niter; it += nwaves) {
+    const int64_t base = it * rows_per_iter;
+    Pair<T> l[U], r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = base + u * 128 + lane * 2;
+      if constexpr (LK == kArray) {
+        l[u] = load_pair<T, ALIGNED>(left, row, n);
+      } else {
+        l[u].x = lscalar;
+        l[u].y = lscalar;
+      }
+      if constexpr (RK == kArray) {
+        r[u] = load_pair<T, ALIGNED>(right, row, n);
+      } else {
+        r[u].x = rscalar;
+        r[u].y = rscalar;
+      }
+    }
+    uint64_t words[2 * U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = base + u * 128 + lane * 2;
+      const bool b0 = (row < n) && (l[u].x > r[u].x);
+      const bool b1 = (row + 1 < n) && (l[u].y > r[u].y);
+      const uint64_t e = __ballot(b0);
+      const uint64_t o = __ballot(b1);
+      words[2 * u] = spread32(e) | (spread32(o) << 1);
+      words[2 * u + 1] = spread32(e >> 32) | (spread32(o >> 32) << 1);
+    }
+    // 2U output words per iteration: lanes 0..2U-1 store one each
+    const int64_t w0 = base >> 6;
+    const int64_t nwords = (n + 63) >> 6;
+    uint64_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * U; ++k) {
+      if (lane == k) mine = words[k];
+    }
+    if (lane < 2 * U && (w0 + lane) < nwords) out[w0 + lane] = mine;
+  }
+}
+
+// ------------------------------------------------------------------ add
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void add_kernel(const T* __restrict__ left,
+                                                     const T* __restrict__ right, int64_t n,
+                                                     T* __restrict__ out) {
+  static_assert(sizeof(T) == 8, "64-bit element types");
+  constexpr int U = 4;
+  const int64_t rows_per_block = kBlock * 2 * U;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * rows_per_block;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * rows_per_block; base < n; base += stride) {
+    Pair<T> l[U], r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = base + (u * kBlock + threadIdx.x) * 2;
+      l[u] = load_pair<T, ALIGNED>(left, row, n);
+      r[u] = load_pair<T, ALIGNED>(right, row, n);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = base + (u * kBlock + threadIdx.x) * 2;
+      T sx, sy;
+      if constexpr (std::is_integral<T>::value) {
+        // unchecked add wraps (SafeSignedAdd, base_arithmetic_internal.h)
+        sx = static_cast<T>(static_cast<uint64_t>(l[u].x) + static_cast<uint64_t>(r[u].x));
+        sy = static_cast<T>(static_cast<uint64_t>(l[u].y) + static_cast<uint64_t>(r[u].y));
+      } else {
+        sx = l[u].x + r[u].x;
+        sy = l[u].y + r[u].y;
+      }
+      if (row + 1 < n) {
+        if constexpr (ALIGNED) {
+          Pair<T> o{sx, sy};
+          *reinterpret_cast<uint4*>(out + row) = *reinterpret_cast<const uint4*>(&o);
+        } else {
+          out[row] = sx;
+          out[row + 1] = sy;
+        }
+      } else if (row < n) {
+        out[row] = sx;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ bitmaps
+template <bool AND>
+__global__ __launch_bounds__(kBlock) void bitmap_kernel(Bits a, Bits b, int64_t nwords,
+                                                        uint64_t* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < nwords;
+       w += stride) {
+    uint64_t v = load_word(a, w);
+    if constexpr (AND) v &= load_word(b, w);
+    out[w] = v;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void popcount_kernel(Bits a, int64_t nwords,
+                                                          unsigned long long* total) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint64_t c = 0;
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < nwords;
+       w += stride) {
+    c += __popcll(load_word(a, w));
+  }
+  c = wave_reduce_sum_u64(c);
+  if (lane_id() == 0 && c != 0) atomicAdd(total, static_cast<unsigned long long>(c));
+}
+
+template <typename T, int LK, int RK>
+static int launch_greater(const T* left, T ls, const T* right, T rs, int64_t n, uint64_t* out,
+                          hipStream_t st) {
+  if (n < 0 || out == nullptr || (LK == kArray && left == nullptr && n > 0) ||
+      (RK == kArray && right == nullptr && n > 0)) {
+    set_error("bad arguments to greater");
+    return ARX_INVALID;
+  }
+  if (n == 0) return ARX_OK;
+  const bool aligned = (LK != kArray || (reinterpret_cast<uint64_t>(left) & 15) == 0) &&
+                       (RK != kArray || (reinterpret_cast<uint64_t>(right) & 15) == 0);
+  const unsigned grid = stream_grid(kWavesPerBlock * 128 * 4, n);
+  if (aligned) {
+    hipLaunchKernelGGL((greater_kernel<T, LK, RK, true>), dim3(grid), dim3(kBlock), 0, st, left, ls,
+                       right, rs, n, out);
+  } else {
+    hipLaunchKernelGGL((greater_kernel<T, LK, RK, false>), dim3(grid), dim3(kBlock), 0, st, left,
+                       ls, right, rs, n, out);
+  }
+  ARX_CHECK_LAUNCH("greater_kernel");
+  return ARX_OK;
+}
+
+template <typename T>
+static int launch_add(const T* left, const T* right, int64_t n, T* out, hipStream_t st) {
+  if (n < 0 || (n > 0 && (left == nullptr || right == nullptr || out == nullptr))) {
+    set_error("bad arguments to add");
+    return ARX_INVALID;
+  }
+  if (n == 0) return ARX_OK;
+  const bool aligned = ((reinterpret_cast<uint64_t>(left) | reinterpret_cast<uint64_t>(right) |
+                         reinterpret_cast<uint64_t>(out)) & 15) == 0;
+  const unsigned grid = stream_grid(kBlock * 2 * 4, n);
+  if (aligned) {
+    hipLaunchKernelGGL((add_kernel<T, true>), dim3(grid), dim3(kBlock), 0, st, left, right, n, out);
+  } else {
+    hipLaunchKernelGGL((add_kernel<T, false>), dim3(grid), dim3(kBlock), 0, st, left, right, n, out);
+  }
+  ARX_CHECK_LAUNCH("add_kernel");
+  return ARX_OK;
+}
+
+}  // namespace arx
+
+using namespace arx;
+
+extern "C" {
+
+int arx_cast_f64_f32(const double* in, int64_t length, float* out, void* stream) {
+  if (length < 0 || (length > 0 && (in == nullptr || out == nullptr))) {
+    set_error("bad arguments to arx_cast_f64_f32");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  hipStream_t st = as_stream(stream);
+  const bool aligned =
+      (reinterpret_cast<uint64_t>(in) & 15) == 0 && (reinterpret_cast<uint64_t>(out) & 7) == 0;
+  const unsigned grid = stream_grid(kBlock * 2 * 4, length);
+  if (aligned) {
+    hipLaunchKernelGGL((cast_f64_f32_kernel<true>), dim3(grid), dim3(kBlock), 0, st, in, length, out);
+  } else {
+    hipLaunchKernelGGL((cast_f64_f32_kernel<false>), dim3(grid), dim3(kBlock), 0, st, in, length, out);
+  }
+  ARX_CHECK_LAUNCH("cast_f64_f32_kernel");
+  return ARX_OK;
+}
+
+int arx_greater_f64(const double* left, const double* right, int64_t length, uint64_t* out_bits,
+                    void* stream) {
+  return launch_greater<double, kArray, kArray>(left, 0.0, right, 0.0, length, out_bits,
+                                                as_stream(stream));
+}
+int arx_greater_f64_array_scalar(const double* left, double right, int64_t length,
+                                 uint64_t* out_bits, void* stream) {
+  return launch_greater<double, kArray, kScalar>(left, 0.0, nullptr, right, length, out_bits,
+                                                 as_stream(stream));
+}
+int arx_greater_f64_scalar_array(double left, const double* right, int64_t length,
+                                 uint64_t* out_bits, void* stream) {
+  return launch_greater<double, kScalar, kArray>(nullptr, left, right, 0.0, length, out_bits,
+                                                 as_stream(stream));
+}
+int arx_greater_i64(const int64_t* left, const int64_t* right, int64_t length, uint64_t* out_bits,
+                    void* stream) {
+  return launch_greater<int64_t, kArray, kArray>(left, 0, right, 0, length, out_bits,
+                                                 as_stream(stream));
+}
+
+int arx_add_i64(const int64_t* left, const int64_t* right, int64_t length, int64_t* out,
+                void* stream) {
+  return launch_add<int64_t>(left, right, length, out, as_stream(stream));
+}
+int arx_add_f64(const double* left, const double* right, int64_t length, double* out,
+                void* stream) {
+  return launch_add<double>(left, right, length, out, as_stream(stream));
+}
+
+int arx_bitmap_copy(const void* bits, int64_t bit_offset, int64_t length, void* out, void* stream) {
+  if (length < 0 || bit_offset < 0 || (length > 0 && out == nullptr)) {
+    set_error("bad arguments to arx_bitmap_copy");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  const Bits a = make_bits(bits, bit_offset, length);
+  const int64_t nwords = ceil_div(length, 64);
+  const unsigned grid = stream_grid(kBlock, nwords);
+  hipLaunchKernelGGL((bitmap_kernel<false>), dim3(grid), dim3(kBlock), 0, as_stream(stream), a, a,
+                     nwords, static_cast<uint64_t*>(out));
+  ARX_CHECK_LAUNCH("bitmap_kernel");
+  return ARX_OK;
+}
+
+int arx_bitmap_and(const void* left, int64_t left_offset, const void* right, int64_t right_offset,
+                   int64_t length, void* out, void* stream) {
+  if (length < 0 || left_offset < 0 || right_offset < 0 || (length > 0 && out == nullptr)) {
+    set_error("bad arguments to arx_bitmap_and");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  const Bits a = make_bits(left, left_offset, length);
+  const Bits b = make_bits(right, right_offset, length);
+  const int64_t nwords = ceil_div(length, 64);
+  const unsigned grid = stream_grid(kBlock, nwords);
+  hipLaunchKernelGGL((bitmap_kernel<true>), dim3(grid), dim3(kBlock), 0, as_stream(stream), a, b,
+                     nwords, static_cast<uint64_t*>(out));
+  ARX_CHECK_LAUNCH("bitmap_kernel");
+  return ARX_OK;
+}
+
+int arx_bitmap_popcount(const void* bits, int64_t bit_offset, int64_t length, void* ws,
+                        size_t ws_bytes, int64_t* out_count, void* stream) {
+  if (length < 0 || bit_offset < 0 || out_count == nullptr || ws == nullptr || ws_bytes < 8) {
+    set_error("bad arguments to arx_bitmap_popcount");
+    return ARX_INVALID;
+  }
+  if (length == 0) {
+    *out_count = 0;
+    return ARX_OK;
+  }
+  hipStream_t st = as_stream(stream);
+  const Bits a = make_bits(bits, bit_offset, length);
+  const int64_t nwords = ceil_div(length, 64);
+  ARX_HIP(hipMemsetAsync(ws, 0, 8, st));
+  const unsigned grid = stream_grid(kBlock, nwords);
+  hipLaunchKernelGGL(popcount_kernel, dim3(grid), dim3(kBlock), 0, st, a, nwords,
+                     static_cast<unsigned long long*>(ws));
+  ARX_CHECK_LAUNCH("popcount_kernel");
+  int64_t total = 0;
+  ARX_HIP(hipMemcpyAsync(&total, ws, 8, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  *out_count = total;
+  return ARX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,391 @@
+// array_sort_indices for 64-bit integer keys on gfx950: stable LSB radix sort,
+// 8 passes x 8-bit digits over (key, 32-bit row id) pairs.
+//
+// What it restates (semantics only):
+//   ArraySortIndices<UInt64Type,*>::Exec       cpp/src/arrow/compute/kernels/vector_array_sort.cc:524-540
+//   ArrayCompareSorter (std::stable_sort)       same file :144-178
+//   ArrayCountOrCompareSorter                   same file :404-446  (both branches are stable and
+//                                               give the same permutation)
+//   PartitionNullsOnly<StablePartitioner>       cpp/src/arrow/compute/kernels/vector_sort_internal.h:225-293
+// The result is the unique stable argsort: ascending by key with ties in row order;
+// descending = ascending on ~key (ties still in row order, as `rhs < lhs` + stable_sort gives);
+// nulls keep row order and sit at the end or the start.
+//
+// Per pass (digit = bits [shift, shift+8)):
+//   radix_hist_kernel    : one workgroup per chunk of tiles -> hist[digit][chunk]
+//   radix_scan_kernel    : exclusive scan of hist in digit-major order (single workgroup)
+//   radix_scatter_kernel : per tile of 4096 keys: wave-level multi-split ranking (8 ballots per
+//                          key), workgroup scan of the 4 x 256 wave counters, reorder through LDS,
+//                          then coalesced runs to the destination.
+// HBM traffic per row per pass: 8 (hist) + 12 (read) + 12 (write) bytes.
+#include "arx_common.h"
+
+#include <string.h>
+
+#include <algorithm>
+
+namespace arx {
+
+constexpr int kSortItems = 16;
+constexpr int kSortTile = kBlock * kSortItems;  // 4096 keys
+constexpr int kDigits = 256;
+constexpr int kMaxChunks = 2048;
+
+// Provided by selection.hip: ascending row numbers of the set (or clear) bits of a bitmap.
+int selection_bit_positions(const void* bitmap, int64_t bit_offset, int64_t length, bool invert,
+                            void* ws, size_t ws_bytes, uint32_t* out, int64_t* out_count_host,
+                            hipStream_t st);
+size_t selection_workspace_bytes(int64_t length);
+
+__device__ __forceinline__ uint64_t key_transform(uint64_t k, bool is_signed, bool descending) {
+  if (is_signed) k ^= 0x8000000000000000ull;  // two's complement -> unsigned order
+  if (descending) k = ~k;                      // reverses the order, ties stay in row order
+  return k;
+}
+
+// keys_out[i] = transform(values[rows[i]]) , idx_out[i] = rows[i]  (rows == NULL -> identity)
+__global__ __launch_bounds__(kBlock) void sort_prep_kernel(const uint64_t* __restrict__ values,
+                                                           const uint32_t* __restrict__ rows,
+                                                           int64_t n, int is_signed, int descending,
+                                                           uint64_t* __restrict__ keys_out,
+                                                           uint32_t* __restrict__ idx_out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t r = rows ? rows[i] : static_cast<uint32_t>(i);
+    keys_out[i] = key_transform(values[r], is_signed != 0, descending != 0);
+    idx_out[i] = r;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void widen_kernel(const uint32_t* __restrict__ in, int64_t n,
+                                                       uint64_t* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    out[i] = in[i];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t* __restrict__ keys,
+                                                            int64_t n, int shift,
+                                                            int64_t chunk_keys, int64_t nchunks,
+                                                            uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[kDigits];
+  const int64_t chunk = blockIdx.x;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t begin = chunk * chunk_keys;
+  const int64_t end = begin + chunk_keys < n ? begin + chunk_keys : n;
+  for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) {
+    const uint32_t d = static_cast<uint32_t>(keys[i] >> shift) & 255u;
+    atomicAdd(&h[d], 1u);
+  }
+  __syncthreads();
+  hist[static_cast<int64_t>(threadIdx.x) * nchunks + chunk] = h[threadIdx.x];
+}
+
+// In-place exclusive scan of m = 256 * nchunks counters (digit-major).  Single workgroup.
+__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t* __restrict__ hist, int64_t m) {
+  __shared__ uint32_t wave_tot[16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t per = (m + 1023) / 1024;
+  const int64_t b = tid * per;
+  const int64_t e = b + per < m ? b + per : m;
+  uint32_t s = 0;
+  for (int64_t i = b; i < e; ++i) s += hist[i];
+  const uint32_t incl = wave_inclusive_scan_u32(s);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t prefix = incl - s;
+  for (int k = 0; k < wave; ++k) prefix += wave_tot[k];
+  for (int64_t i = b; i < e; ++i) {
+    const uint32_t v = hist[i];
+    hist[i] = prefix;
+    prefix += v;
+  }
+}
+
+struct __attribute__((aligned(16))) SortLds {
+  uint64_t keys[kSortTile];
+  uint32_t idx[kSortTile];
+  uint32_t wave_cnt[kWavesPerBlock][kDigits];
+  uint32_t digit_start[kDigits];
+  uint32_t cursor[kDigits];
+  uint32_t wave_tot[kWavesPerBlock];
+};
+
+// last_pass: write idx widened to uint64 into out_final (keys are no longer needed)
+__global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in, int64_t n, int shift,
+    int64_t chunk_tiles, int64_t nchunks, const uint32_t* __restrict__ hist_scanned,
+    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out, uint64_t* __restrict__ out_final,
+    int last_pass) {
+  __shared__ SortLds lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t chunk = blockIdx.x;
+  lds.cursor[tid] = hist_scanned[static_cast<int64_t>(tid) * nchunks + chunk];
+  __syncthreads();
+
+  const int64_t tile_begin = chunk * chunk_tiles;
+  const int64_t ntiles_total = (n + kSortTile - 1) / kSortTile;
+  const int64_t tile_end =
+      tile_begin + chunk_tiles < ntiles_total ? tile_begin + chunk_tiles : ntiles_total;
+
+  for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
+    const int64_t base = tile * kSortTile;
+    const int64_t remain = n - base;
+    const int nv = remain < kSortTile ? static_cast<int>(remain) : kSortTile;
+
+    // 1. load: wave-striped so that (wave, item, lane) order == row order (stability)
+    uint64_t key[kSortItems];
+    uint32_t idx[kSortItems];
+    uint32_t rank[kSortItems];
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+      const int p = wave * (kSortItems * 64) + i * 64 + lane;
+      if (p < nv) {
+        key[i] = keys_in[base + p];
+        idx[i] = idx_in[base + p];
+      } else {
+        key[i] = ~uint64_t(0);  // sorts last inside the tile, never written
+        idx[i] = 0;
+      }
+    }
+    // 2. zero the per-wave digit counters
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) lds.wave_cnt[w][tid] = 0;
+    __syncthreads();
+
+    // 3. wave-level multi-split: rank of each key among equal digits seen so far by this wave
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+      const uint32_t d = static_cast<uint32_t>(key[i] >> shift) & 255u;
+      uint64_t peers = ~uint64_t(0);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+      }
+      const uint32_t prev = lds.wave_cnt[wave][d];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int leader = __ffsll(static_cast<unsigned long long>(peers)) - 1;
+      if (lane == leader) lds.wave_cnt[wave][d] = prev + __popcll(peers);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      rank[i] = prev + __popcll(peers & ((uint64_t(1) << lane) - 1));
+    }
+    __syncthreads();
+
+    // 4. workgroup scan: thread t owns digit t
+    uint32_t c[kWavesPerBlock];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+      c[w] = lds.wave_cnt[w][tid];
+      tot += c[w];
+    }
+    const uint32_t incl = wave_inclusive_scan_u32(tot);
+    if (lane == 63) lds.wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t dbase = incl - tot;
+    for (int k = 0; k < wave; ++k) dbase += lds.wave_tot[k];
+    lds.digit_start[tid] = dbase;
+    uint32_t run = dbase;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+      lds.wave_cnt[w][tid] = run;
+      run += c[w];
+    }
+    __syncthreads();
+
+    // 5. reorder through LDS
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+      const uint32_t d = static_cast<uint32_t>(key[i] >> shift) & 255u;
+      const uint32_t pos = lds.wave_cnt[wave][d] + rank[i];
+      lds.keys[pos] = key[i];
+      lds.idx[pos] = idx[i];
+    }
+    __syncthreads();
+
+    // 6. coalesced runs to the destination
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+      const int p = k * kBlock + tid;
+      if (p < nv) {
+        const uint64_t kk = lds.keys[p];
+        const uint32_t d = static_cast<uint32_t>(kk >> shift) & 255u;
+        const uint32_t dst = lds.cursor[d] + (static_cast<uint32_t>(p) - lds.digit_start[d]);
+        if (last_pass) {
+          out_final[dst] = lds.idx[p];
+        } else {
+          keys_out[dst] = kk;
+          idx_out[dst] = lds.idx[p];
+        }
+      }
+    }
+    __syncthreads();
+    // 7. advance the per-digit cursors of this chunk
+    lds.cursor[tid] += tot;
+    __syncthreads();
+  }
+}
+
+struct SortPlan {
+  int64_t n;          // rows to sort (non-null)
+  int64_t ntiles;
+  int64_t chunk_tiles;
+  int64_t nchunks;
+  size_t off_keys_a, off_keys_b, off_idx_a, off_idx_b, off_hist, off_rows, off_sel_ws, total;
+};
+
+static SortPlan make_plan(int64_t length) {
+  SortPlan p{};
+  p.n = length;
+  p.ntiles = ceil_div(std::max<int64_t>(length, 1), kSortTile);
+  p.chunk_tiles = std::max<int64_t>(1, ceil_div(p.ntiles, kMaxChunks));
+  p.nchunks = ceil_div(p.ntiles, p.chunk_tiles);
+  auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
+  const size_t n = static_cast<size_t>(std::max<int64_t>(length, 1));
+  size_t o = 0;
+  p.off_keys_a = o; o = align(o + n * 8);
+  p.off_keys_b = o; o = align(o + n * 8);
+  p.off_idx_a = o; o = align(o + n * 4);
+  p.off_idx_b = o; o = align(o + n * 4);
+  p.off_hist = o; o = align(o + static_cast<size_t>(kDigits) * kMaxChunks * 4);
+  p.off_rows = o; o = align(o + n * 4);  // row ids of the non-null / null partitions
+  p.off_sel_ws = o; o = align(o + selection_workspace_bytes(length));
+  p.total = o;
+  return p;
+}
+
+int set_sort_option(const char*, int64_t) { return 0; }
+
+}  // namespace arx
+
+using namespace arx;
+
+extern "C" {
+
+size_t arx_sort_indices_workspace_bytes(int64_t length) {
+  if (length < 0) length = 0;
+  return make_plan(length).total;
+}
+
+int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int null_placement,
+                        void* ws, size_t ws_bytes, uint64_t* out_indices, void* stream) {
+  if (values == nullptr) {
+    set_error("values is NULL");
+    return ARX_INVALID;
+  }
+  const int64_t len = values->length;
+  if (len < 0 || values->offset < 0) {
+    set_error("negative length/offset");
+    return ARX_INVALID;
+  }
+  if (len == 0) return ARX_OK;
+  if (len > static_cast<int64_t>(UINT32_MAX)) {
+    set_error("arx_sort_indices_64: more than UINT32_MAX rows is not implemented");
+    return ARX_NOT_IMPLEMENTED;
+  }
+  if (order != ARX_SORT_ASCENDING && order != ARX_SORT_DESCENDING) {
+    set_error("bad sort order %d", order);
+    return ARX_INVALID;
+  }
+  if (null_placement != ARX_NULLS_AT_START && null_placement != ARX_NULLS_AT_END) {
+    set_error("bad null placement %d", null_placement);
+    return ARX_INVALID;
+  }
+  if (values->data == nullptr || out_indices == nullptr || ws == nullptr) {
+    set_error("values/out/ws buffer is NULL");
+    return ARX_INVALID;
+  }
+  SortPlan plan = make_plan(len);
+  if (ws_bytes < plan.total) {
+    set_error("sort workspace too small: %zu < %zu", ws_bytes, plan.total);
+    return ARX_INVALID;
+  }
+  if ((reinterpret_cast<uint64_t>(ws) & 255) != 0) {
+    set_error("sort workspace must be 256-byte aligned");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  uint8_t* w = static_cast<uint8_t*>(ws);
+  uint64_t* keys_a = reinterpret_cast<uint64_t*>(w + plan.off_keys_a);
+  uint64_t* keys_b = reinterpret_cast<uint64_t*>(w + plan.off_keys_b);
+  uint32_t* idx_a = reinterpret_cast<uint32_t*>(w + plan.off_idx_a);
+  uint32_t* idx_b = reinterpret_cast<uint32_t*>(w + plan.off_idx_b);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(w + plan.off_hist);
+  uint32_t* rows = reinterpret_cast<uint32_t*>(w + plan.off_rows);
+  void* sel_ws = w + plan.off_sel_ws;
+  const size_t sel_ws_bytes = plan.total - plan.off_sel_ws;
+
+  const uint64_t* vals = static_cast<const uint64_t*>(values->data) + values->offset;
+  const bool has_nulls = values->null_count != 0 && values->validity != nullptr;
+
+  // ---- null partition (PartitionNullsOnly, stable): row ids of nulls keep row order
+  int64_t n_valid = len;
+  const uint32_t* valid_rows = nullptr;
+  if (has_nulls) {
+    int64_t n_null = 0;
+    int rc = selection_bit_positions(values->validity, values->offset, len, /*invert=*/true, sel_ws,
+                                     sel_ws_bytes, rows, &n_null, st);
+    if (rc != ARX_OK) return rc;
+    n_valid = len - n_null;
+    if (n_null > 0) {
+      uint64_t* null_dst = null_placement == ARX_NULLS_AT_START ? out_indices : out_indices + n_valid;
+      const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_null, kBlock), 2048));
+      hipLaunchKernelGGL(widen_kernel, dim3(g), dim3(kBlock), 0, st, rows, n_null, null_dst);
+      ARX_CHECK_LAUNCH("widen_kernel");
+    }
+    if (n_valid > 0 && n_null > 0) {
+      int64_t got = 0;
+      rc = selection_bit_positions(values->validity, values->offset, len, /*invert=*/false, sel_ws,
+                                   sel_ws_bytes, rows, &got, st);
+      if (rc != ARX_OK) return rc;
+      valid_rows = rows;
+    }
+  }
+  if (n_valid == 0) return ARX_OK;
+  uint64_t* final_dst =
+      (has_nulls && null_placement == ARX_NULLS_AT_START) ? out_indices + (len - n_valid) : out_indices;
+
+  // ---- (key, row id) pairs
+  plan = make_plan(n_valid);
+  {
+    const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_valid, kBlock), 2048));
+    hipLaunchKernelGGL(sort_prep_kernel, dim3(g), dim3(kBlock), 0, st, vals, valid_rows, n_valid,
+                       is_signed, order == ARX_SORT_DESCENDING, keys_a, idx_a);
+    ARX_CHECK_LAUNCH("sort_prep_kernel");
+  }
+  const int64_t chunk_keys = plan.chunk_tiles * kSortTile;
+  const unsigned nch = static_cast<unsigned>(plan.nchunks);
+  uint64_t* kin = keys_a;
+  uint64_t* kout = keys_b;
+  uint32_t* iin = idx_a;
+  uint32_t* iout = idx_b;
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = pass * 8;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nch), dim3(kBlock), 0, st, kin, n_valid, shift,
+                       chunk_keys, plan.nchunks, hist);
+    ARX_CHECK_LAUNCH("radix_hist_kernel");
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, hist,
+                       static_cast<int64_t>(kDigits) * plan.nchunks);
+    ARX_CHECK_LAUNCH("radix_scan_kernel");
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nch), dim3(kBlock), 0, st, kin, iin, n_valid, shift,
+                       plan.chunk_tiles, plan.nchunks, hist, kout, iout, final_dst, pass == 7 ? 1 : 0);
+    ARX_CHECK_LAUNCH("radix_scatter_kernel");
+    std::swap(kin, kout);
+    std::swap(iin, iout);
+  }
+  return ARX_OK;
+}
+
+}  // extern "C"

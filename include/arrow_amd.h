@@ -1,0 +1,270 @@
+/*
+ * arrow_amd.h — the C ABI of libarrow_amd.so: MI355X (gfx950) execution of the
+ * arrow::compute vectorized-kernel hot path (filter, take, cast, compare,
+ * sort_indices, hash_sum group-by).
+ *
+ * This is the drop-in boundary.  Arrow's kernels are C++ function
+ * pointers of type  ArrayKernelExec = Status(*)(KernelContext*, const ExecSpan&, ExecResult*)
+ * (cpp/src/arrow/compute/kernel.h:556) registered with Function::AddKernel
+ * (cpp/src/arrow/compute/function.h:316,346,378).  A registration shim (see
+ * arrow_amd/csrc/arrow_plugin.cc and INTEGRATION.md) unpacks ExecSpan/ArraySpan
+ * (cpp/src/arrow/array/data.h:525-553) into the plain structs below and calls
+ * these entry points; nothing here mentions an Arrow C++ type, a torch type or a
+ * HIP type (streams travel as void*).
+ *
+ * Conventions
+ *  - All data pointers are DEVICE pointers (HBM) unless a parameter is documented
+ *    as "host".  The layout of an array is Arrow's columnar format
+ *    (docs/source/format/Columnar.rst): a validity bitmap (LSB-first, 1 = valid,
+ *    may be NULL = all valid) plus a fixed-width values buffer, plus a logical
+ *    element `offset` that applies to both — the same fields as
+ *    struct ArrowArray in cpp/src/arrow/c/abi.h:44-65.
+ *  - Bitmaps are read and written in aligned 64-bit words: every bitmap buffer
+ *    must be addressable through the enclosing 8-byte-aligned words (true of any
+ *    hipMalloc/Arrow allocation; Arrow pads buffers to 64 bytes,
+ *    cpp/src/arrow/memory_pool.h).  Output bitmaps start at bit 0 and their
+ *    padding bits up to the next 64-bit boundary are written as 0.
+ *  - Every function returns ARX_OK (0) or a negative ArxStatus; the message is
+ *    available from arx_last_error() (thread-local).  No exceptions cross the
+ *    boundary.  Status codes mirror arrow::StatusCode (cpp/src/arrow/status.h:83-107).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All
+ *    kernels are enqueued on it; functions documented as "synchronous" also wait
+ *    for it.  No function allocates device memory: scratch space is caller
+ *    provided (`*_workspace_bytes` + `ws`), so the calls are re-entrant and safe
+ *    from several host threads with distinct workspaces/streams (the threading
+ *    contract of Kernel::exec).
+ */
+#ifndef ARROW_AMD_H_
+#define ARROW_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARX_ABI_VERSION 1
+
+/* arrow::StatusCode twins (cpp/src/arrow/status.h:83-107). */
+typedef enum ArxStatus {
+  ARX_OK = 0,
+  ARX_OUT_OF_MEMORY = -1,
+  ARX_INVALID = -4,          /* Status::Invalid       */
+  ARX_INDEX_ERROR = -7,      /* Status::IndexError    */
+  ARX_NOT_IMPLEMENTED = -10, /* Status::NotImplemented*/
+  ARX_DEVICE_ERROR = -100    /* a hip* call failed    */
+} ArxStatus;
+
+/* FilterOptions::NullSelectionBehavior (cpp/src/arrow/compute/api_vector.h:37-52). */
+enum { ARX_FILTER_DROP = 0, ARX_FILTER_EMIT_NULL = 1 };
+/* SortOrder / NullPlacement (cpp/src/arrow/compute/ordering.h). */
+enum { ARX_SORT_ASCENDING = 0, ARX_SORT_DESCENDING = 1 };
+enum { ARX_NULLS_AT_START = 0, ARX_NULLS_AT_END = 1 };
+
+/* Integer index types accepted by take (match::Integer(),
+ * cpp/src/arrow/compute/kernels/vector_selection_take_internal.cc:718). */
+enum {
+  ARX_UINT8 = 0, ARX_INT8 = 1, ARX_UINT16 = 2, ARX_INT16 = 3,
+  ARX_UINT32 = 4, ARX_INT32 = 5, ARX_UINT64 = 6, ARX_INT64 = 7
+};
+
+/* One fixed-width (or boolean) array: the device twin of arrow::ArraySpan
+ * (cpp/src/arrow/array/data.h:553) restricted to {validity, values}.
+ * For boolean arrays `data` is a bitmap and `offset` is a bit offset into it. */
+typedef struct ArxSpan {
+  const void* validity; /* bitmap or NULL */
+  const void* data;     /* values buffer (NOT pre-offset) */
+  int64_t offset;       /* logical element offset into both buffers */
+  int64_t length;       /* logical length */
+  int64_t null_count;   /* exact, 0, or -1 = unknown (kUnknownNullCount) */
+} ArxSpan;
+
+const char* arx_last_error(void);
+int arx_abi_version(void);
+/* Number of HIP devices visible, or a negative ArxStatus. */
+int arx_device_count(void);
+/* Process-wide tuning knobs for A/B measurements (e.g. "filter_batch", "filter_dense").
+ * Never changes results.  Not part of the reference interface. */
+int arx_set_option(const char* name, int64_t value);
+
+/* ---------------------------------------------------------------------------
+ * Filter  — replaces PrimitiveFilterExec / PrimitiveFilterImpl<W>::Exec
+ * (cpp/src/arrow/compute/kernels/vector_selection_filter_internal.cc:445-510, 238-372)
+ * and GetFilterOutputSize (same file :62-114).
+ *
+ * Two-phase, exactly like the reference: (1) count the output rows so the caller
+ * can allocate, (2) compact.  Phase 1 leaves per-tile output offsets in `ws`,
+ * which phase 2 (and arx_mask_to_indices) consume.
+ * ------------------------------------------------------------------------- */
+
+/* Bytes of scratch needed for a mask of `length` rows. */
+size_t arx_filter_workspace_bytes(int64_t length);
+
+/* Phase 1 (synchronous): *out_length (host) = number of emitted rows of `mask`
+ * (boolean ArxSpan) under `null_selection`.  Fills `ws`. */
+int arx_filter_count(const ArxSpan* mask, int null_selection, void* ws, size_t ws_bytes,
+                     int64_t* out_length, void* stream);
+
+/* Phase 1, asynchronous flavour: as above but the total stays on the device
+ * (first 8 bytes of ws); use when the output capacity is already known. */
+int arx_filter_count_async(const ArxSpan* mask, int null_selection, void* ws,
+                           size_t ws_bytes, void* stream);
+
+/* Phase 2 (asynchronous): out_data[0..S) = values at emitted rows (byte_width in
+ * {1,2,4,8,16}); out_validity (may be NULL when neither input can be null:
+ * the `allocate_validity` rule at :472) receives S bits.  A row emitted because
+ * the mask slot is null (EMIT_NULL) is zero-filled and marked null (:398-407);
+ * a selected row whose value is null keeps its source bytes (:267-272).
+ * `ws` must come from arx_filter_count* on the same mask/null_selection;
+ * `out_length` is the S that arx_filter_count returned (only needed when
+ * out_validity != NULL: its ceil(S/64) words are cleared first). */
+int arx_filter_exec(const ArxSpan* values, int byte_width, const ArxSpan* mask,
+                    int null_selection, const void* ws, int64_t out_length, void* out_data,
+                    void* out_validity, void* stream);
+
+/* GetTakeIndices — replaces GetTakeIndicesFromBitmapImpl<UInt16/UInt32>
+ * (cpp/src/arrow/compute/kernels/vector_selection_take_internal.cc:62-168,258-305).
+ * index_width is 2 (length <= 65535) or 4; EMIT_NULL writes 0 + null for null
+ * mask slots (out_validity required then, otherwise may be NULL). */
+int arx_mask_to_indices(const ArxSpan* mask, int null_selection, const void* ws,
+                        int64_t out_length, int index_width, void* out_indices,
+                        void* out_validity, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Take — replaces FixedWidthTakeExec / Gather<W,Idx,false>
+ * (vector_selection_take_internal.cc:339-468, gather_internal.h:47-251) and
+ * CheckIndexBounds (cpp/src/arrow/util/int_util.cc:530-587).
+ * ------------------------------------------------------------------------- */
+size_t arx_take_workspace_bytes(void);
+
+/* Synchronous.  ARX_INDEX_ERROR + "Index N out of bounds" (N = the first
+ * offending valid index, int_util.cc:554) if any non-null index is <0 or
+ * >= upper_limit. */
+int arx_check_index_bounds(const ArxSpan* indices, int index_type, uint64_t upper_limit,
+                           void* ws, size_t ws_bytes, void* stream);
+
+/* Asynchronous gather.  out_data[i] = values[indices[i]]; every null output slot
+ * (null index or null source value) is zero-filled (WriteZero,
+ * gather_internal.h:114-153).  out_validity may be NULL iff neither input has a
+ * validity buffer.  If valid_count (device int64*, may be NULL) is given it is
+ * incremented by the number of valid output rows (caller zeroes it). */
+int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int index_type,
+             void* out_data, void* out_validity, int64_t* valid_count, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Cast float64 -> float32 — replaces CastPrimitive<FloatType,DoubleType>::Exec
+ * (cpp/src/arrow/compute/kernels/scalar_cast_internal.cc:41-53): every slot is
+ * converted (null slots included), IEEE round-to-nearest-even.
+ * `in` is pre-offset (points at element 0).
+ * ------------------------------------------------------------------------- */
+int arx_cast_f64_f32(const double* in, int64_t length, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Compare — replaces ComparePrimitiveArrayArray/ArrayScalar/ScalarArray<DoubleType,
+ * Greater> (cpp/src/arrow/compute/kernels/scalar_compare.cc:165-247): bit i =
+ * left[i] > right[i] (any NaN -> 0), LSB-first, computed on all slots.
+ * Pointers are pre-offset.  out_bits: ceil(length/64) 64-bit words.
+ * ------------------------------------------------------------------------- */
+int arx_greater_f64(const double* left, const double* right, int64_t length,
+                    uint64_t* out_bits, void* stream);
+int arx_greater_f64_array_scalar(const double* left, double right, int64_t length,
+                                 uint64_t* out_bits, void* stream);
+int arx_greater_f64_scalar_array(double left, const double* right, int64_t length,
+                                 uint64_t* out_bits, void* stream);
+int arx_greater_i64(const int64_t* left, const int64_t* right, int64_t length,
+                    uint64_t* out_bits, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Arithmetic — replaces ScalarBinary<Int64,Int64,Int64,Add> / <Double,...>
+ * (cpp/src/arrow/compute/kernels/base_arithmetic_internal.h:45-80,
+ * codegen_internal.h:814): unchecked integer add wraps around.
+ * ------------------------------------------------------------------------- */
+int arx_add_i64(const int64_t* left, const int64_t* right, int64_t length, int64_t* out,
+                void* stream);
+int arx_add_f64(const double* left, const double* right, int64_t length, double* out,
+                void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Validity plumbing — what ScalarExecutor's null propagation does on the host
+ * (PropagateNullsSpans, cpp/src/arrow/compute/exec.cc:1222-1281; BitmapAnd /
+ * CopyBitmap, cpp/src/arrow/util/bitmap_ops.cc).  Inputs carry bit offsets,
+ * outputs start at bit 0 and are zero-padded to a 64-bit boundary.
+ * ------------------------------------------------------------------------- */
+int arx_bitmap_copy(const void* bits, int64_t bit_offset, int64_t length, void* out,
+                    void* stream);
+int arx_bitmap_and(const void* left, int64_t left_offset, const void* right,
+                   int64_t right_offset, int64_t length, void* out, void* stream);
+/* Synchronous popcount of [bit_offset, bit_offset+length) (CountSetBits). */
+int arx_bitmap_popcount(const void* bits, int64_t bit_offset, int64_t length, void* ws,
+                        size_t ws_bytes, int64_t* out_count, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * array_sort_indices (uint64/int64 keys) — replaces ArraySortIndices<UInt64Type,
+ * UInt64Type>::Exec -> ArrayCountOrCompareSorter / ArrayCompareSorter
+ * (cpp/src/arrow/compute/kernels/vector_array_sort.cc:144-178,404-446,524-540):
+ * a STABLE argsort producing uint64 indices; nulls are stably partitioned to the
+ * end or the start (PartitionNullsOnly, vector_sort_internal.h:225-293);
+ * descending keeps ties in ascending index order (rhs < lhs comparator).
+ * ------------------------------------------------------------------------- */
+size_t arx_sort_indices_workspace_bytes(int64_t length);
+int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int null_placement,
+                        void* ws, size_t ws_bytes, uint64_t* out_indices, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Group-by hash_sum(int64) BY int32 key — replaces, as one fused device operator,
+ * Grouper::Consume (cpp/src/arrow/compute/row/grouper.cc:662-815) +
+ * HashAggregateKernel{resize,consume,merge,finalize} of
+ * GroupedReducingAggregator<Int64Type,GroupedSumImpl> (compute/kernel.h:720-769,
+ * kernels/hash_aggregate_numeric.cc:44-187,273-293) as driven by
+ * GroupByNode::Consume/Merge/Finalize (acero/groupby_aggregate_node.cc:210-337).
+ *
+ * The state is an open-addressing table in HBM owned by the caller:
+ * arx_groupby_state_bytes(capacity) bytes, capacity = a power of two > the
+ * number of distinct keys (+1 for the null-key group).  Group order in the
+ * output is unspecified, exactly as for the reference under threads
+ * (python/pyarrow/table.pxi:5632-5634); parity is defined on the key-sorted result.
+ * ------------------------------------------------------------------------- */
+size_t arx_groupby_state_bytes(int64_t capacity);
+/* Synchronous: clears the table (HashAggregateKernel::init + resize). */
+int arx_groupby_init(void* state, int64_t capacity, void* stream);
+/* consume: for every row, state[key].sum += value (wrap-around), count++,
+ * a null value clears no_nulls; a null key is its own group.  Asynchronous. */
+int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* keys_i32,
+                                const ArxSpan* values_i64, void* stream);
+/* merge: fold partial aggregates (keys, key_is_valid, sums, counts, no_nulls; one byte
+ * per group for the two flags, either may be NULL = all 1) of another state / another
+ * GPU into this one (Merge, hash_aggregate_numeric.cc:85-107).  Asynchronous. */
+int arx_groupby_sum_i64_merge(void* state, int64_t capacity, const int32_t* keys,
+                              const uint8_t* key_is_valid, const int64_t* sums,
+                              const int64_t* counts, const uint8_t* no_nulls,
+                              int64_t num_groups, void* stream);
+/* Synchronous: number of groups currently in the table (host int64); ARX_INVALID if the
+ * table overflowed. */
+int arx_groupby_num_groups(void* state, int64_t* out_num_groups, void* stream);
+/* export: dense partial-aggregate columns, arx_groupby_num_groups entries each, in an
+ * unspecified order (Grouper::GetUniques + the aggregator state).  Synchronous on entry
+ * (reads the header), kernels asynchronous. */
+int arx_groupby_sum_i64_export(void* state, int32_t* out_keys, uint8_t* out_key_is_valid,
+                               int64_t* out_sums, int64_t* out_counts, uint8_t* out_no_nulls,
+                               void* stream);
+/* finalize (Finalize, hash_aggregate_numeric.cc:130-152, ScalarAggregateOptions
+ * {skip_nulls, min_count}): out_valid[g] (one byte) = counts[g] >= min_count &&
+ * (skip_nulls || no_nulls[g]); the sums column is returned as is.  Asynchronous. */
+int arx_groupby_sum_i64_finalize(const int64_t* counts, const uint8_t* no_nulls,
+                                 int64_t num_groups, int skip_nulls, uint32_t min_count,
+                                 uint8_t* out_valid, void* stream);
+/* Radix partition of partial aggregates by hash(key) % num_parts for the multi-GPU
+ * exchange: rows are written grouped by destination (order inside a
+ * destination unspecified); out_part_counts = device int64[num_parts].  Asynchronous. */
+size_t arx_groupby_partition_workspace_bytes(int num_parts);
+int arx_groupby_partition(const int32_t* keys, const uint8_t* key_is_valid, const int64_t* sums,
+                          const int64_t* counts, const uint8_t* no_nulls, int64_t num_groups,
+                          int num_parts, void* ws, size_t ws_bytes, int32_t* out_keys,
+                          uint8_t* out_key_is_valid, int64_t* out_sums, int64_t* out_counts,
+                          uint8_t* out_no_nulls, int64_t* out_part_counts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARROW_AMD_H_ */

@@ -1,0 +1,222 @@
+"""ctypes/numpy front-end of oracle/arx_oracle.c — TEST INFRASTRUCTURE ONLY.
+
+Arrays are described by plain numpy pieces: `values` (1-D numpy array of the physical
+type), `valid` (uint8 numpy bitmap bytes or None) and an element `offset`.  Bitmaps are
+LSB-first like Arrow's.  See the C file for the reference citations.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libarx_oracle.so")
+
+INDEX_TYPES = {
+    np.dtype("uint8"): 0, np.dtype("int8"): 1, np.dtype("uint16"): 2, np.dtype("int16"): 3,
+    np.dtype("uint32"): 4, np.dtype("int32"): 5, np.dtype("uint64"): 6, np.dtype("int64"): 7,
+}
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "arx_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        L = _lib
+        p, i64, i32, u64, u32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_uint32
+        L.arxo_filter_output_size.restype = i64
+        L.arxo_filter_output_size.argtypes = [p, p, i64, i64, i32]
+        L.arxo_filter.restype = i64
+        L.arxo_filter.argtypes = [p, i32, p, i64, p, p, i64, i64, i32, p, p]
+        L.arxo_mask_to_indices.restype = i64
+        L.arxo_mask_to_indices.argtypes = [p, p, i64, i64, i32, i32, p, p]
+        L.arxo_check_index_bounds.restype = i32
+        L.arxo_check_index_bounds.argtypes = [p, i32, p, i64, i64, u64, p, p]
+        L.arxo_take.restype = i64
+        L.arxo_take.argtypes = [p, i32, p, i64, p, i32, p, i64, i64, p, p]
+        L.arxo_cast_f64_f32.restype = None
+        L.arxo_cast_f64_f32.argtypes = [p, i64, p]
+        L.arxo_greater_f64.restype = None
+        L.arxo_greater_f64.argtypes = [p, i32, p, i32, i64, p]
+        L.arxo_greater_i64.restype = None
+        L.arxo_greater_i64.argtypes = [p, p, i64, p]
+        L.arxo_add_i64.restype = None
+        L.arxo_add_i64.argtypes = [p, p, i64, p]
+        L.arxo_add_f64.restype = None
+        L.arxo_add_f64.argtypes = [p, p, i64, p]
+        L.arxo_bitmap_and.restype = None
+        L.arxo_bitmap_and.argtypes = [p, i64, p, i64, i64, p]
+        L.arxo_bitmap_popcount.restype = i64
+        L.arxo_bitmap_popcount.argtypes = [p, i64, i64]
+        L.arxo_sort_indices_64.restype = i32
+        L.arxo_sort_indices_64.argtypes = [p, p, i64, i64, i32, i32, i32, p]
+        L.arxo_groupby_sum_i64.restype = i64
+        L.arxo_groupby_sum_i64.argtypes = [p, p, i64, p, p, i64, i64, i32, u32, p, p, p, p, p, p]
+    return _lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def bitmap_bytes(nbits: int) -> int:
+    """Bytes of an output bitmap, padded to 64-bit words like the device library."""
+    return ((nbits + 63) // 64) * 8
+
+
+# ---------------------------------------------------------------- bit helpers (numpy)
+def pack_bits(bools) -> np.ndarray:
+    """bool array -> LSB-first bitmap bytes padded to 8-byte multiples."""
+    b = np.asarray(bools, dtype=bool)
+    out = np.zeros(bitmap_bytes(len(b)), dtype=np.uint8)
+    packed = np.packbits(b, bitorder="little")
+    out[: len(packed)] = packed
+    return out
+
+
+def unpack_bits(bitmap: np.ndarray, offset: int, length: int) -> np.ndarray:
+    bits = np.unpackbits(np.asarray(bitmap, dtype=np.uint8), bitorder="little")
+    return bits[offset: offset + length].astype(bool)
+
+
+# ---------------------------------------------------------------- kernels
+def filter_output_size(mask, mask_valid, mask_off, length, null_selection) -> int:
+    return int(lib().arxo_filter_output_size(_ptr(mask), _ptr(mask_valid), mask_off, length,
+                                             null_selection))
+
+
+def filter(values, values_valid, values_off, mask, mask_valid, mask_off, length, null_selection,
+           want_validity: bool):
+    """Returns (out_values, out_valid_bitmap_or_None)."""
+    w = values.dtype.itemsize
+    n = filter_output_size(mask, mask_valid, mask_off, length, null_selection)
+    out = np.zeros(n, dtype=values.dtype)
+    ov = np.zeros(bitmap_bytes(n), dtype=np.uint8) if want_validity else None
+    got = lib().arxo_filter(_ptr(values), w, _ptr(values_valid), values_off, _ptr(mask),
+                            _ptr(mask_valid), mask_off, length, null_selection, _ptr(out), _ptr(ov))
+    assert got == n
+    return out, ov
+
+
+def mask_to_indices(mask, mask_valid, mask_off, length, null_selection, want_validity: bool):
+    n = filter_output_size(mask, mask_valid, mask_off, length, null_selection)
+    dt = np.uint16 if length <= 65535 else np.uint32
+    out = np.zeros(n, dtype=dt)
+    ov = np.zeros(bitmap_bytes(n), dtype=np.uint8) if want_validity else None
+    got = lib().arxo_mask_to_indices(_ptr(mask), _ptr(mask_valid), mask_off, length, null_selection,
+                                     out.dtype.itemsize, _ptr(out), _ptr(ov))
+    assert got == n
+    return out, ov
+
+
+def check_index_bounds(indices, idx_valid, idx_off, length, upper_limit):
+    """Returns None if in bounds, else the first offending index (python int)."""
+    t = INDEX_TYPES[indices.dtype]
+    bs, bu = C.c_int64(0), C.c_uint64(0)
+    rc = lib().arxo_check_index_bounds(_ptr(indices), t, _ptr(idx_valid), idx_off, length,
+                                       upper_limit, C.byref(bs), C.byref(bu))
+    if rc == 0:
+        return None
+    return int(bs.value) if (t & 1) else int(bu.value)
+
+
+def take(values, values_valid, values_off, indices, idx_valid, idx_off, length,
+         want_validity: bool):
+    """Returns (out_values, out_valid_bitmap_or_None, valid_count)."""
+    w = values.dtype.itemsize
+    out = np.zeros(length, dtype=values.dtype)
+    ov = np.zeros(bitmap_bytes(length), dtype=np.uint8) if want_validity else None
+    vc = lib().arxo_take(_ptr(values), w, _ptr(values_valid), values_off, _ptr(indices),
+                         INDEX_TYPES[indices.dtype], _ptr(idx_valid), idx_off, length, _ptr(out),
+                         _ptr(ov))
+    return out, ov, int(vc)
+
+
+def cast_f64_f32(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.empty(len(a), dtype=np.float32)
+    lib().arxo_cast_f64_f32(_ptr(a), len(a), _ptr(out))
+    return out
+
+
+def greater_f64(left, right) -> np.ndarray:
+    """left/right: float64 arrays or python floats (scalar broadcast).  Returns bitmap bytes."""
+    ls, rs = np.isscalar(left), np.isscalar(right)
+    la = np.array([left], dtype=np.float64) if ls else np.ascontiguousarray(left, dtype=np.float64)
+    ra = np.array([right], dtype=np.float64) if rs else np.ascontiguousarray(right, dtype=np.float64)
+    n = len(ra) if ls else len(la)
+    out = np.zeros(bitmap_bytes(n), dtype=np.uint8)
+    lib().arxo_greater_f64(_ptr(la), int(ls), _ptr(ra), int(rs), n, _ptr(out))
+    return out
+
+
+def greater_i64(left, right) -> np.ndarray:
+    la = np.ascontiguousarray(left, dtype=np.int64)
+    ra = np.ascontiguousarray(right, dtype=np.int64)
+    out = np.zeros(bitmap_bytes(len(la)), dtype=np.uint8)
+    lib().arxo_greater_i64(_ptr(la), _ptr(ra), len(la), _ptr(out))
+    return out
+
+
+def add(left, right) -> np.ndarray:
+    la, ra = np.ascontiguousarray(left), np.ascontiguousarray(right)
+    out = np.empty_like(la)
+    if la.dtype == np.int64:
+        lib().arxo_add_i64(_ptr(la), _ptr(ra), len(la), _ptr(out))
+    else:
+        lib().arxo_add_f64(_ptr(la), _ptr(ra), len(la), _ptr(out))
+    return out
+
+
+def bitmap_and(a, a_off, b, b_off, n) -> np.ndarray:
+    out = np.zeros(bitmap_bytes(n), dtype=np.uint8)
+    lib().arxo_bitmap_and(_ptr(a), a_off, _ptr(b), b_off, n, _ptr(out))
+    return out
+
+
+def bitmap_popcount(a, off, n) -> int:
+    return int(lib().arxo_bitmap_popcount(_ptr(a), off, n))
+
+
+def sort_indices_64(values, valid, offset, length, descending=False, nulls_at_start=False):
+    assert values.dtype in (np.uint64, np.int64)
+    out = np.empty(length, dtype=np.uint64)
+    rc = lib().arxo_sort_indices_64(_ptr(values), _ptr(valid), offset, length,
+                                    int(values.dtype == np.int64), int(descending),
+                                    0 if nulls_at_start else 1, _ptr(out))
+    assert rc == 0
+    return out
+
+
+def groupby_sum_i64(keys, key_valid, key_off, values, val_valid, val_off, length,
+                    skip_nulls=True, min_count=1):
+    """Returns dict(keys, key_is_valid, sums, counts, no_nulls, valid) in first-occurrence order."""
+    n = max(length, 1)
+    ok = np.zeros(n, dtype=np.int32)
+    okv = np.zeros(n, dtype=np.uint8)
+    os_ = np.zeros(n, dtype=np.int64)
+    oc = np.zeros(n, dtype=np.int64)
+    onn = np.zeros(n, dtype=np.uint8)
+    ov = np.zeros(n, dtype=np.uint8)
+    ng = lib().arxo_groupby_sum_i64(_ptr(keys), _ptr(key_valid), key_off, _ptr(values),
+                                    _ptr(val_valid), val_off, length, int(skip_nulls), min_count,
+                                    _ptr(ok), _ptr(okv), _ptr(os_), _ptr(oc), _ptr(onn), _ptr(ov))
+    assert ng >= 0
+    return dict(keys=ok[:ng], key_is_valid=okv[:ng], sums=os_[:ng], counts=oc[:ng],
+                no_nulls=onn[:ng], valid=ov[:ng])

@@ -1,0 +1,251 @@
+"""Parity checks shared by the GPU tests (real library, -m gpu) and the emulator tests
+(kernel sources under the CPU SIMT emulator).  Every check runs the op through
+arrow_amd.compute -> C ABI and compares with the C oracle (bit-exact) and, when the wheel
+is importable, with the reference's own build (pyarrow)."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+from . import util
+from .util import HostArray, assert_equal, device_bitmap_to_bool, oracle_bitmap_to_bool, pa, pc
+
+
+def _logical_valid(arr):
+    if arr.validity is None:
+        return np.ones(arr.length, dtype=bool), True
+    bits, pad_ok = device_bitmap_to_bool(arr.validity, arr.length)
+    return bits, pad_ok
+
+
+def _data_np(arr, dtype):
+    raw = arr.data.cpu().numpy()
+    return raw[: arr.length * np.dtype(dtype).itemsize].view(dtype)
+
+
+# ------------------------------------------------------------------ filter
+def check_filter(amd, values: HostArray, mask: HostArray, null_selection: str, use_pyarrow=True):
+    code = 1 if null_selection == "emit_null" else 0
+    dv, dm = values.to_device(amd), mask.to_device(amd)
+    out = amd.compute.filter(dv, dm, null_selection)
+    want_vals, want_bm = O.filter(values.data_bytes(), values.valid_bitmap(), values.offset,
+                                  mask.data_bytes(), mask.valid_bitmap(), mask.offset, mask.length,
+                                  code, True)
+    tag = f"filter[{values.dtype},n={values.length},{null_selection},voff={values.offset},moff={mask.offset}]"
+    assert out.length == len(want_vals), f"{tag}: length {out.length} vs {len(want_vals)}"
+    assert out.offset == 0
+    assert_equal(_data_np(out, values.dtype), want_vals, tag + " data bytes")
+    got_valid, pad_ok = _logical_valid(out)
+    assert_equal(got_valid, oracle_bitmap_to_bool(want_bm, out.length), tag + " validity")
+    assert pad_ok, tag + ": padding bits of the validity bitmap are not zero"
+    # allocate_validity rule + null_count bookkeeping (vector_selection_filter_internal.cc:462-472)
+    if dv.null_count == 0 and dm.null_count == 0:
+        assert out.validity is None and out.null_count == 0
+    if use_pyarrow and pc is not None:
+        ref = pc.filter(values.to_pyarrow(), mask.to_pyarrow(), null_selection_behavior=null_selection)
+        assert len(ref) == out.length
+        rvalid = ~np.asarray(ref.is_null())
+        assert_equal(got_valid, rvalid, tag + " validity vs pyarrow")
+        rvals = ref.fill_null(0).to_numpy(zero_copy_only=False)
+        assert_equal(_data_np(out, values.dtype)[got_valid], rvals[rvalid], tag + " values vs pyarrow")
+    return out
+
+
+def check_mask_to_indices(amd, mask: HostArray, null_selection: str):
+    code = 1 if null_selection == "emit_null" else 0
+    dm = mask.to_device(amd)
+    out = amd.compute.get_take_indices(dm, null_selection)
+    want, want_bm = O.mask_to_indices(mask.data_bytes(), mask.valid_bitmap(), mask.offset, mask.length,
+                                      code, True)
+    tag = f"get_take_indices[n={mask.length},{null_selection},off={mask.offset}]"
+    assert out.length == len(want), tag
+    assert out.type.np_dtype == want.dtype, f"{tag}: index type {out.type.name} vs {want.dtype}"
+    assert_equal(_data_np(out, want.dtype), want, tag + " indices")
+    got_valid, pad_ok = _logical_valid(out)
+    assert_equal(got_valid, oracle_bitmap_to_bool(want_bm, out.length), tag + " validity")
+    assert pad_ok
+    return out
+
+
+# ------------------------------------------------------------------ take
+def check_take(amd, values: HostArray, indices: HostArray, boundscheck=True, use_pyarrow=True):
+    dv, di = values.to_device(amd), indices.to_device(amd)
+    out = amd.compute.take(dv, di, boundscheck=boundscheck)
+    want, want_bm, want_vc = O.take(values.data_bytes(), values.valid_bitmap(), values.offset,
+                                    np.ascontiguousarray(indices.values), indices.valid_bitmap(),
+                                    indices.offset, indices.length, True)
+    tag = f"take[{values.dtype},idx={indices.dtype},m={indices.length},voff={values.offset},ioff={indices.offset}]"
+    assert out.length == indices.length
+    assert_equal(_data_np(out, values.dtype), want, tag + " data bytes")
+    got_valid, pad_ok = _logical_valid(out)
+    assert_equal(got_valid, oracle_bitmap_to_bool(want_bm, out.length), tag + " validity")
+    assert pad_ok
+    assert out.null_count == indices.length - want_vc, tag + " null_count"
+    if use_pyarrow and pc is not None:
+        ref = pc.take(values.to_pyarrow(), indices.to_pyarrow(), boundscheck=boundscheck)
+        rvalid = ~np.asarray(ref.is_null())
+        assert_equal(got_valid, rvalid, tag + " validity vs pyarrow")
+        assert ref.null_count == out.null_count
+        rvals = ref.fill_null(0).to_numpy(zero_copy_only=False)
+        assert_equal(_data_np(out, values.dtype)[got_valid], rvals[rvalid], tag + " values vs pyarrow")
+    return out
+
+
+def check_take_out_of_bounds(amd, values: HostArray, indices: HostArray):
+    dv, di = values.to_device(amd), indices.to_device(amd)
+    bad = O.check_index_bounds(np.ascontiguousarray(indices.values), indices.valid_bitmap(),
+                               indices.offset, indices.length, values.length)
+    assert bad is not None, "test case must contain an out-of-bounds index"
+    with pytest.raises(amd.ArrowIndexError) as ei:
+        amd.compute.take(dv, di)
+    assert str(ei.value) == f"Index {bad} out of bounds", str(ei.value)
+    if pc is not None:
+        with pytest.raises(pa.lib.ArrowIndexError) as ri:
+            pc.take(values.to_pyarrow(), indices.to_pyarrow())
+        assert str(ri.value) == str(ei.value)
+
+
+# ------------------------------------------------------------------ cast / compare / add
+def _bits_equal_f32(got, want):
+    g, w = got.view(np.uint32), want.view(np.uint32)
+    both_nan = np.isnan(got) & np.isnan(want)
+    return (g == w) | both_nan
+
+
+def check_cast_f64_f32(amd, arr: HostArray, use_pyarrow=True):
+    d = arr.to_device(amd)
+    out = amd.compute.cast(d, amd.array.float32)
+    want = O.cast_f64_f32(arr.logical_values())
+    got = _data_np(out, np.float32)
+    tag = f"cast_f64_f32[n={arr.length},off={arr.offset}]"
+    ok = _bits_equal_f32(got, want)
+    assert ok.all(), f"{tag}: {int((~ok).sum())} mismatches, first at {int(np.nonzero(~ok)[0][0])}"
+    # tolerance stated by north_star: <= 1 ULP; we require 0 ULP except NaN payloads
+    got_valid, pad_ok = _logical_valid(out)
+    assert_equal(got_valid, arr.logical_valid(), tag + " validity")
+    # offset-0 inputs share the bitmap zero-copy (like the reference executor), so bits past
+    # `length` are the caller's; freshly written bitmaps must be zero padded
+    assert pad_ok or out.validity is d.validity
+    if use_pyarrow and pc is not None:
+        ref = pc.cast(arr.to_pyarrow(), pa.float32())
+        rv = ref.fill_null(0).to_numpy(zero_copy_only=False)
+        v = arr.logical_valid()
+        ok = _bits_equal_f32(got[v], rv[v])
+        assert ok.all(), tag + " vs pyarrow"
+    return out
+
+
+def check_greater_f64(amd, left, right, use_pyarrow=True):
+    """left/right: HostArray or python float (scalar broadcast)."""
+    dl = left.to_device(amd) if isinstance(left, HostArray) else left
+    dr = right.to_device(amd) if isinstance(right, HostArray) else right
+    out = amd.compute.greater(dl, dr)
+    lv = left.logical_values() if isinstance(left, HostArray) else float(left)
+    rv = right.logical_values() if isinstance(right, HostArray) else float(right)
+    n = out.length
+    if lv is not None and np.isscalar(lv) and np.isscalar(rv):
+        raise AssertionError("at least one side must be an array")
+    i64 = isinstance(left, HostArray) and left.dtype == np.int64
+    want_bm = O.greater_i64(lv, rv) if i64 else O.greater_f64(lv, rv)
+    got_bits, pad_ok = device_bitmap_to_bool(out.data, n)
+    tag = f"greater[n={n}]"
+    assert_equal(got_bits, oracle_bitmap_to_bool(want_bm, n), tag + " bits")
+    assert pad_ok, tag + ": padding bits not zero (scalar_compare.cc:175-188 + zeroed bitmap)"
+    want_valid = np.ones(n, dtype=bool)
+    for side in (left, right):
+        if isinstance(side, HostArray):
+            want_valid &= side.logical_valid()
+    got_valid, pad2 = _logical_valid(out)
+    assert_equal(got_valid, want_valid, tag + " validity")
+    assert pad2
+    if use_pyarrow and pc is not None:
+        pl = left.to_pyarrow() if isinstance(left, HostArray) else pa.scalar(float(left), pa.float64())
+        pr = right.to_pyarrow() if isinstance(right, HostArray) else pa.scalar(float(right), pa.float64())
+        ref = pc.greater(pl, pr)
+        rvalid = ~np.asarray(ref.is_null())
+        assert_equal(got_valid, rvalid, tag + " validity vs pyarrow")
+        rbits = ref.fill_null(False).to_numpy(zero_copy_only=False)
+        assert_equal(got_bits[got_valid], rbits[rvalid], tag + " bits vs pyarrow")
+    return out
+
+
+def check_add(amd, left: HostArray, right: HostArray, use_pyarrow=True):
+    out = amd.compute.add(left.to_device(amd), right.to_device(amd))
+    want = O.add(left.logical_values(), right.logical_values())
+    got = _data_np(out, left.dtype)
+    tag = f"add[{left.dtype},n={left.length}]"
+    if left.dtype.kind == "f":
+        assert_equal(got.view(np.uint64), want.view(np.uint64), tag)
+    else:
+        assert_equal(got, want, tag)
+    got_valid, _ = _logical_valid(out)
+    assert_equal(got_valid, left.logical_valid() & right.logical_valid(), tag + " validity")
+    if use_pyarrow and pc is not None and left.dtype.kind == "f":
+        ref = pc.add(left.to_pyarrow(), right.to_pyarrow())
+        rv = ref.fill_null(0).to_numpy(zero_copy_only=False)
+        assert_equal(got[got_valid].view(np.uint64), rv[got_valid].view(np.uint64), tag + " vs pyarrow")
+    return out
+
+
+# ------------------------------------------------------------------ sort
+def check_sort_indices(amd, arr: HostArray, order="ascending", null_placement="at_end",
+                       use_pyarrow=True):
+    d = arr.to_device(amd)
+    out = amd.compute.sort_indices(d, order, null_placement)
+    want = O.sort_indices_64(np.ascontiguousarray(arr.values), arr.valid_bitmap(), arr.offset,
+                             arr.length, descending=(order == "descending"),
+                             nulls_at_start=(null_placement == "at_start"))
+    got = _data_np(out, np.uint64)
+    tag = f"sort_indices[{arr.dtype},n={arr.length},{order},{null_placement},off={arr.offset}]"
+    assert out.validity is None and out.null_count == 0
+    assert_equal(got, want, tag)
+    if use_pyarrow and pc is not None:
+        ref = pc.array_sort_indices(arr.to_pyarrow(), order=order, null_placement=null_placement)
+        assert_equal(got, ref.to_numpy(), tag + " vs pyarrow")
+    return out
+
+
+# ------------------------------------------------------------------ group-by
+def _sorted_groups(keys, key_valid, sums, valid):
+    """Canonical form: rows sorted by (key_is_null, key) -> list of tuples (tests sort too,
+    acero/hash_aggregate_test.cc:262-280)."""
+    rows = []
+    for k, kv, s, v in zip(keys.tolist(), key_valid.tolist(), sums.tolist(), valid.tolist()):
+        rows.append((0 if kv else 1, k if kv else 0, s if v else None))
+    rows.sort(key=lambda r: (r[0], r[1]))
+    return rows
+
+
+def check_groupby_sum(amd, keys: HostArray, values: HostArray, skip_nulls=True, min_count=1,
+                      capacity=None, use_pyarrow=True, batches=1):
+    opts = amd.compute.ScalarAggregateOptions(skip_nulls, min_count)
+    dk, dv = keys.to_device(amd), values.to_device(amd)
+    cap = capacity or max(16, 2 * keys.length + 2)
+    op = amd.compute.GroupBySum(cap, dk.device, opts)
+    n = keys.length
+    step = max(1, (n + batches - 1) // batches)
+    for b in range(0, max(n, 1), step):  # several consume calls, like ExecBatches arriving
+        op.consume(dk.slice(b, min(step, n - b)), dv.slice(b, min(step, n - b)))
+    gk, gkv, gs, gvalid = op.finalize()
+    got = _sorted_groups(gk.cpu().numpy(), gkv.cpu().numpy(), gs.cpu().numpy(), gvalid.cpu().numpy())
+    w = O.groupby_sum_i64(np.ascontiguousarray(keys.values), keys.valid_bitmap(), keys.offset,
+                          np.ascontiguousarray(values.values), values.valid_bitmap(), values.offset,
+                          n, skip_nulls, min_count)
+    want = _sorted_groups(w["keys"], w["key_is_valid"], w["sums"], w["valid"])
+    tag = f"groupby_sum[n={n},skip_nulls={skip_nulls},min_count={min_count}]"
+    assert len(got) == len(want), f"{tag}: {len(got)} groups vs {len(want)}"
+    for i, (g, x) in enumerate(zip(got, want)):
+        assert g == x, f"{tag}: group {i}: got {g} want {x}"
+    if use_pyarrow and pa is not None and n > 0:
+        t = pa.table({"k": keys.to_pyarrow(), "v": values.to_pyarrow()})
+        r = t.group_by("k", use_threads=False).aggregate(
+            [("v", "sum", pc.ScalarAggregateOptions(skip_nulls=skip_nulls, min_count=min_count))])
+        rk, rs = r.column("k").combine_chunks(), r.column("v_sum").combine_chunks()
+        ref = _sorted_groups(rk.fill_null(0).to_numpy(zero_copy_only=False),
+                             ~np.asarray(rk.is_null()),
+                             rs.fill_null(0).to_numpy(zero_copy_only=False),
+                             ~np.asarray(rs.is_null()))
+        assert got == ref, tag + " vs pyarrow Table.group_by"
+    return got

@@ -1,0 +1,278 @@
+"""Kernel-logic parity on the CPU: the *unchanged* kernel sources of arrow_amd/csrc compiled for
+the host against tests/emu/hip_emu.h (a fiber-based SIMT emulator) and driven through the same
+arrow_amd.compute -> C ABI path as on the GPU.  These are not GPU compute calls and not a CPU
+fallback of the product: the emulated library is built and loaded by the tests only.
+Sizes are small (the emulator context-switches at every wave collective)."""
+import numpy as np
+import pytest
+
+from . import parity_cases as P
+from . import util as U
+
+pytestmark = pytest.mark.emu
+
+
+def rng_for(*key):
+    return np.random.default_rng([U.kRandomSeed, *[abs(hash(k)) % (1 << 31) for k in key]])
+
+
+# ------------------------------------------------------------------ filter
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 129, 4095, 4096, 4097, 9000])
+def test_filter_int64_lengths(emu_ctx, n, sel):
+    rng = rng_for("f64len", n, sel)
+    v = U.random_array(rng, np.int64, n, null_p=0.1)
+    m = U.random_mask(rng, n, 0.3, null_p=0.05)
+    P.check_filter(emu_ctx, v, m, sel)
+
+
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+@pytest.mark.parametrize("true_p", [0.0, 0.1, 0.5, 0.999, 1.0])
+@pytest.mark.parametrize("vnull,mnull", [(0.0, 0.0), (0.1, 0.0), (0.0, 0.05), (0.999, 0.5), (1.0, 1.0)])
+def test_filter_int64_probabilities(emu_ctx, true_p, vnull, mnull, sel):
+    """The grid of FilterRandomTest (vector_selection_test.cc:2241-2260), n scaled for the emulator."""
+    rng = rng_for("fprob", true_p, vnull, mnull, sel)
+    n = 5000
+    v = U.random_array(rng, np.int64, n, null_p=vnull)
+    m = U.random_mask(rng, n, true_p, null_p=mnull)
+    P.check_filter(emu_ctx, v, m, sel)
+
+
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+@pytest.mark.parametrize("voff,moff", [(1, 0), (0, 3), (7, 13), (64, 65), (3, 4099)])
+def test_filter_offsets(emu_ctx, voff, moff, sel):
+    """Sliced inputs with non-zero, non-byte-aligned offsets (vector_selection_test.cc:286-302)."""
+    rng = rng_for("foff", voff, moff, sel)
+    n = 6000
+    v = U.random_array(rng, np.int64, n, null_p=0.2, offset=voff, tail=5)
+    m = U.random_mask(rng, n, 0.4, null_p=0.1, offset=moff, tail=9)
+    P.check_filter(emu_ctx, v, m, sel)
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.uint16, np.int32, np.float32, np.float64, np.uint64])
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+def test_filter_widths(emu_ctx, dtype, sel):
+    rng = rng_for("fw", str(dtype), sel)
+    n = 8200
+    v = U.random_array(rng, dtype, n, null_p=0.1, offset=3)
+    m = U.random_mask(rng, n, 0.5, null_p=0.05, offset=1)
+    P.check_filter(emu_ctx, v, m, sel, use_pyarrow=True)
+
+
+def test_filter_dense_and_batch_variants(emu_ctx):
+    """The tuning knobs must never change results."""
+    lib = emu_ctx._lib.get_lib()
+    rng = rng_for("fvariants")
+    v = U.random_array(rng, np.int64, 9000, null_p=0.1, offset=2)
+    m = U.random_mask(rng, 9000, 0.1, null_p=0.05)
+    try:
+        for batch in (1, 4):
+            for dense in (0, 1):
+                assert lib.arx_set_option(b"filter_batch", batch) == 0
+                assert lib.arx_set_option(b"filter_dense", dense) == 0
+                for sel in ("drop", "emit_null"):
+                    P.check_filter(emu_ctx, v, m, sel, use_pyarrow=False)
+    finally:
+        lib.arx_set_option(b"filter_batch", 4)
+        lib.arx_set_option(b"filter_dense", 0)
+
+
+def test_filter_no_nulls_has_no_validity(emu_ctx):
+    rng = rng_for("fnn")
+    v = U.random_array(rng, np.int64, 5000)
+    m = U.random_mask(rng, 5000, 0.5)
+    out = P.check_filter(emu_ctx, v, m, "drop")
+    assert out.validity is None and out.null_count == 0
+
+
+def test_filter_length_mismatch_is_invalid(emu_ctx):
+    """vector_selection_test.cc:338-341."""
+    v = U.HostArray(np.array([7, 8, 9], dtype=np.int64), None, 0, 3).to_device(emu_ctx)
+    m = U.HostArray(np.zeros(0, dtype=bool), None, 0, 0).to_device(emu_ctx)
+    for sel in ("drop", "emit_null"):
+        with pytest.raises(emu_ctx.ArrowInvalid):
+            emu_ctx.compute.filter(v, m, sel)
+
+
+# ------------------------------------------------------------------ GetTakeIndices
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+@pytest.mark.parametrize("n,off", [(0, 0), (1, 0), (100, 5), (4097, 0), (9000, 3), (70000, 1)])
+def test_mask_to_indices(emu_ctx, n, off, sel):
+    rng = rng_for("m2i", n, off, sel)
+    m = U.random_mask(rng, n, 0.2 if n < 20000 else 0.02, null_p=0.05, offset=off, tail=3)
+    P.check_mask_to_indices(emu_ctx, m, sel)
+
+
+def test_record_batch_filter_is_take_of_indices(emu_ctx):
+    """FilterRecordBatch (vector_selection_filter_internal.cc:925-960): filter(v, m) must equal
+    take(v, GetTakeIndices(m)) — the identity the reference's ValidateFilter relies on (:345-373)."""
+    amd = emu_ctx
+    rng = rng_for("rb")
+    n = 5000
+    a = U.random_array(rng, np.int64, n, null_p=0.1)
+    b = U.random_array(rng, np.int32, n, null_p=0.0)
+    m = U.random_mask(rng, n, 0.3, null_p=0.1)
+    for sel in ("drop", "emit_null"):
+        rb = amd.compute.RecordBatch({"a": a.to_device(amd), "b": b.to_device(amd)})
+        out = amd.compute.filter(rb, m.to_device(amd), sel)
+        for name, col in (("a", a), ("b", b)):
+            direct = amd.compute.filter(col.to_device(amd), m.to_device(amd), sel)
+            assert out.columns[name].to_pylist() == direct.to_pylist()
+
+
+# ------------------------------------------------------------------ take
+@pytest.mark.parametrize("idx_dtype", [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32,
+                                       np.uint64, np.int64])
+def test_take_index_types(emu_ctx, idx_dtype):
+    """TakeRandomTest shape (values 1025, indices 257; vector_selection_test.cc:2282-2315)."""
+    rng = rng_for("tk", str(idx_dtype))
+    nv = 100 if np.dtype(idx_dtype).itemsize == 1 else 1025
+    v = U.random_array(rng, np.int64, nv, null_p=0.1, offset=3)
+    i = U.random_array(rng, idx_dtype, 257, null_p=0.1, offset=5, lo=0, hi=nv - 1)
+    P.check_take(emu_ctx, v, i)
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int16, np.float32, np.float64])
+@pytest.mark.parametrize("vnull,inull", [(0.0, 0.0), (0.1, 0.0), (0.0, 0.3), (1.0, 0.0), (0.5, 1.0)])
+def test_take_widths_and_nulls(emu_ctx, dtype, vnull, inull):
+    rng = rng_for("tkw", str(dtype), vnull, inull)
+    v = U.random_array(rng, dtype, 3000, null_p=vnull)
+    i = U.random_array(rng, np.int32, 1500, null_p=inull, lo=0, hi=2999)
+    P.check_take(emu_ctx, v, i)
+
+
+def test_take_empty_and_no_boundscheck(emu_ctx):
+    rng = rng_for("tke")
+    v = U.random_array(rng, np.int64, 50)
+    P.check_take(emu_ctx, v, U.HostArray(np.zeros(0, dtype=np.int32), None, 0, 0))
+    i = U.random_array(rng, np.uint32, 700, lo=0, hi=49)
+    P.check_take(emu_ctx, v, i, boundscheck=False)
+
+
+@pytest.mark.parametrize("bad", [9, -1])
+def test_take_out_of_bounds(emu_ctx, bad):
+    """IndexError naming the first offender (vector_selection_test.cc:1545-1556; int_util.cc:554)."""
+    v = U.HostArray(np.arange(5, dtype=np.int64), None, 0, 5)
+    idx = np.array([0, bad, 0, 77], dtype=np.int64)
+    P.check_take_out_of_bounds(emu_ctx, v, U.HostArray(idx, None, 0, 4))
+
+
+def test_take_null_index_is_not_bounds_checked(emu_ctx):
+    v = U.HostArray(np.arange(5, dtype=np.int64), None, 0, 5)
+    idx = U.HostArray(np.array([1, 99, 2], dtype=np.int32), np.array([True, False, True]), 0, 3)
+    out = P.check_take(emu_ctx, v, idx)
+    assert out.to_pylist() == [1, None, 2]
+
+
+# ------------------------------------------------------------------ cast / compare / add
+def _cast_inputs(rng, n):
+    x = rng.standard_normal(n)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e39, -1e39, 3.4028235677973366e38,
+                        1e-40, -1e-46, 1.0000000596046448, 1.00000017881393433, 2.0 ** -126, 2.0 ** -150])
+    x[: len(special)] = special[: min(len(special), n)]
+    big = rng.integers(0, n, size=n // 20)
+    x[big] *= 1e40
+    tiny = rng.integers(0, n, size=n // 20)
+    x[tiny] *= 1e-42
+    return x
+
+
+@pytest.mark.parametrize("n,off", [(0, 0), (1, 0), (13, 1), (2048, 0), (2049, 3), (5000, 2)])
+def test_cast_f64_f32(emu_ctx, n, off):
+    rng = rng_for("cast", n, off)
+    x = _cast_inputs(rng, n + off + 2) if n else np.zeros(off + 2)
+    valid = rng.random(len(x)) > 0.1 if n % 2 else None
+    P.check_cast_f64_f32(emu_ctx, U.HostArray(x, valid, off, n))
+
+
+@pytest.mark.parametrize("n,off", [(1, 0), (64, 0), (127, 1), (513, 0), (3000, 5)])
+def test_greater_f64_array_array(emu_ctx, n, off):
+    rng = rng_for("gt", n, off)
+    a = U.random_array(rng, np.float64, n, null_p=0.1, offset=off)
+    b = U.random_array(rng, np.float64, n, null_p=0.1 if n % 2 else 0.0, offset=2 * off)
+    a.values[rng.integers(0, len(a.values), 5)] = np.nan
+    b.values[::7] = a.values[: len(b.values)][::7] if len(a.values) >= len(b.values) else 0.0
+    P.check_greater_f64(emu_ctx, a, b)
+
+
+def test_greater_scalar_forms_and_i64(emu_ctx):
+    rng = rng_for("gts")
+    a = U.random_array(rng, np.float64, 1000, null_p=0.1, offset=1)
+    P.check_greater_f64(emu_ctx, a, 0.25)
+    P.check_greater_f64(emu_ctx, -0.5, a)
+    P.check_greater_f64(emu_ctx, a, float("nan"))
+    x = U.random_array(rng, np.int64, 777, lo=-5, hi=5)
+    y = U.random_array(rng, np.int64, 777, lo=-5, hi=5)
+    P.check_greater_f64(emu_ctx, x, y)
+
+
+def test_add(emu_ctx):
+    rng = rng_for("add")
+    x = U.random_array(rng, np.int64, 3001, null_p=0.1, offset=1)   # full range: wraps
+    y = U.random_array(rng, np.int64, 3001, offset=3)
+    P.check_add(emu_ctx, x, y)
+    a = U.random_array(rng, np.float64, 1000, null_p=0.1)
+    b = U.random_array(rng, np.float64, 1000, null_p=0.1)
+    P.check_add(emu_ctx, a, b)
+
+
+# ------------------------------------------------------------------ sort
+@pytest.mark.parametrize("order", ["ascending", "descending"])
+@pytest.mark.parametrize("placement", ["at_end", "at_start"])
+def test_sort_small_range_with_ties_and_nulls(emu_ctx, order, placement):
+    """Stability on ties + null placement (vector_sort_test.cc:640-960)."""
+    rng = rng_for("sort1", order, placement)
+    a = U.random_array(rng, np.uint64, 700, null_p=0.2, offset=3, lo=0, hi=7)
+    P.check_sort_indices(emu_ctx, a, order, placement)
+
+
+@pytest.mark.parametrize("dtype", [np.uint64, np.int64])
+@pytest.mark.parametrize("n", [1, 2, 255, 4096, 4097, 9000])
+def test_sort_full_range(emu_ctx, dtype, n):
+    rng = rng_for("sort2", str(dtype), n)
+    a = U.random_array(rng, dtype, n)
+    P.check_sort_indices(emu_ctx, a, "ascending" if n % 2 else "descending", "at_end")
+
+
+def test_sort_all_null_and_empty(emu_ctx):
+    a = U.HostArray(np.arange(10, dtype=np.uint64), np.zeros(10, dtype=bool), 0, 10)
+    P.check_sort_indices(emu_ctx, a)
+    P.check_sort_indices(emu_ctx, U.HostArray(np.zeros(0, dtype=np.uint64), None, 0, 0))
+
+
+# ------------------------------------------------------------------ group-by
+@pytest.mark.parametrize("skip_nulls,min_count", [(True, 1), (False, 1), (True, 0), (True, 3), (False, 0)])
+def test_groupby_sum_options(emu_ctx, skip_nulls, min_count):
+    """min_count / keep-nulls semantics (acero/hash_aggregate_test.cc:3481-3530)."""
+    rng = rng_for("gb", skip_nulls, min_count)
+    k = U.random_array(rng, np.int32, 3000, null_p=0.05, offset=1, lo=-20, hi=20)
+    v = U.random_array(rng, np.int64, 3000, null_p=0.2, offset=2)
+    P.check_groupby_sum(emu_ctx, k, v, skip_nulls, min_count, batches=3)
+
+
+def test_groupby_sum_wraparound_many_groups(emu_ctx):
+    rng = rng_for("gbwrap")
+    k = U.random_array(rng, np.int32, 5000, lo=0, hi=1500)
+    v = U.random_array(rng, np.int64, 5000)  # full int64 range: sums wrap (to_unsigned add)
+    P.check_groupby_sum(emu_ctx, k, v)
+
+
+def test_groupby_sum_golden_sum_only(emu_ctx):
+    """SumOnly (acero/hash_aggregate_test.cc:839-883) restated on int64 values: null key is its own
+    group; a group whose values are all null sums to null."""
+    keys = [1, 1, 2, 3, None, 1, 2, 2, None, 3]
+    vals = [10, None, None, 1, 30, 5, None, 20, 40, None]
+    k = U.HostArray(np.array([0 if x is None else x for x in keys], dtype=np.int32),
+                    np.array([x is not None for x in keys]), 0, len(keys))
+    v = U.HostArray(np.array([0 if x is None else x for x in vals], dtype=np.int64),
+                    np.array([x is not None for x in vals]), 0, len(vals))
+    got = P.check_groupby_sum(emu_ctx, k, v)
+    assert got == [(0, 1, 15), (0, 2, 20), (0, 3, 1), (1, 0, 70)]
+
+
+def test_hash_sum_direct_call_is_rejected(emu_ctx):
+    """acero/hash_aggregate_test.cc:646-665 / function.cc:325-326."""
+    a = U.HostArray(np.arange(4, dtype=np.int64), None, 0, 4).to_device(emu_ctx)
+    g = U.HostArray(np.zeros(4, dtype=np.uint32), None, 0, 4).to_device(emu_ctx)
+    with pytest.raises(emu_ctx.ArrowNotImplementedError, match="Direct execution of HASH_AGGREGATE"):
+        emu_ctx.compute.call_function("hash_sum", [a, g])

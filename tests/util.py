@@ -1,0 +1,119 @@
+"""Shared helpers of the parity tests: host-side array descriptions, conversions to the device
+arrays / pyarrow / oracle inputs, seeded generators (in the spirit of arrow/testing/random.h)."""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+from oracle import oracle as O
+
+try:  # the reference's own build, when the wheel is in the image
+    import pyarrow as pa
+    import pyarrow.compute as pc
+except Exception:  # pragma: no cover
+    pa = pc = None
+
+kRandomSeed = 0x0FF1CE  # compute/kernels/test_util_internal.h:119
+
+
+@dataclasses.dataclass
+class HostArray:
+    """A (possibly sliced) fixed-width or boolean Arrow array held in numpy pieces."""
+    values: np.ndarray            # full buffer incl. `offset` leading elements (bool: bool array)
+    valid: np.ndarray | None      # bool array over the full buffer (True = valid) or None
+    offset: int
+    length: int
+
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+    @property
+    def is_bool(self):
+        return self.values.dtype == np.bool_
+
+    # logical views
+    def logical_values(self):
+        return self.values[self.offset: self.offset + self.length]
+
+    def logical_valid(self):
+        if self.valid is None:
+            return np.ones(self.length, dtype=bool)
+        return self.valid[self.offset: self.offset + self.length]
+
+    # oracle inputs
+    def data_bytes(self):
+        return O.pack_bits(self.values) if self.is_bool else np.ascontiguousarray(self.values)
+
+    def valid_bitmap(self):
+        return None if self.valid is None else O.pack_bits(self.valid)
+
+    def null_count(self):
+        return 0 if self.valid is None else int((~self.logical_valid()).sum())
+
+    def to_device(self, amd):
+        full = amd.Array.from_numpy(self.values, self.valid)
+        if self.offset == 0 and self.length == len(self.values):
+            return full
+        out = full.slice(self.offset, self.length)
+        return out
+
+    def to_pyarrow(self):
+        mask = None if self.valid is None else ~self.valid
+        arr = pa.array(self.values, mask=mask)
+        return arr.slice(self.offset, self.length)
+
+
+def random_array(rng, dtype, length, null_p=0.0, offset=0, tail=0, lo=None, hi=None) -> HostArray:
+    """length logical elements preceded by `offset` and followed by `tail` garbage elements."""
+    n = offset + length + tail
+    dt = np.dtype(dtype)
+    if dt == np.bool_:
+        vals = rng.random(n) < 0.5
+    elif dt.kind == "f":
+        vals = rng.standard_normal(n).astype(dt)
+    else:
+        info = np.iinfo(dt)
+        lo_ = info.min if lo is None else lo
+        hi_ = info.max if hi is None else hi
+        vals = rng.integers(lo_, hi_, size=n, dtype=dt, endpoint=True)
+    valid = None
+    if null_p > 0:
+        valid = rng.random(n) >= null_p
+    return HostArray(vals, valid, offset, length)
+
+
+def random_mask(rng, length, true_p, null_p=0.0, offset=0, tail=0) -> HostArray:
+    n = offset + length + tail
+    vals = rng.random(n) < true_p
+    valid = (rng.random(n) >= null_p) if null_p > 0 else None
+    return HostArray(vals, valid, offset, length)
+
+
+def device_bitmap_to_bool(buf, length):
+    """torch uint8 buffer holding an LSB-first bitmap -> (bool[length], padding_is_zero)."""
+    raw = buf.cpu().numpy()
+    nbytes = ((length + 63) // 64) * 8
+    bits = np.unpackbits(raw[:nbytes], bitorder="little")
+    return bits[:length].astype(bool), not bits[length:].any()
+
+
+def oracle_bitmap_to_bool(bm, length):
+    return O.unpack_bits(bm, 0, length)
+
+
+def first_mismatch(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return f"shape {a.shape} vs {b.shape}"
+    bad = np.nonzero(a != b)[0]
+    if len(bad) == 0:
+        return None
+    i = int(bad[0])
+    return f"{len(bad)} mismatches, first at {i}: got {a[i]!r} want {b[i]!r} (ctx got {a[max(0,i-2):i+3]} want {b[max(0,i-2):i+3]})"
+
+
+def assert_equal(got, want, what=""):
+    msg = first_mismatch(got, want)
+    assert msg is None, f"{what}: {msg}"
