@@ -19,7 +19,7 @@ import threading
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, tracing
 from ._lib import (ArrowIndexError, ArrowInvalid, ArrowNotImplementedError, check)  # noqa: F401
 from .array import (Array, DataType, Scalar, alloc, bitmap_nbytes, bool_, current_stream, float32,
                     float64, int32, int64, kUnknownNullCount, uint16, uint32, uint64,
@@ -158,9 +158,10 @@ def _exec_array_filter(args, options):
     w = values.type.byte_width
     out_data = alloc(s * w, dev)
     out_valid = alloc(bitmap_nbytes(s), dev) if allocate_validity else None
-    check(lib.arx_filter_exec(C.byref(vspan), w, C.byref(mspan), options.code, ws.data_ptr(), s,
-                              out_data.data_ptr(), None if out_valid is None else out_valid.data_ptr(),
-                              stream))
+    with tracing.span("arx_filter_exec"):
+        check(lib.arx_filter_exec(C.byref(vspan), w, C.byref(mspan), options.code, ws.data_ptr(), s,
+                                  out_data.data_ptr(),
+                                  None if out_valid is None else out_valid.data_ptr(), stream))
     return Array(values.type, s, [out_valid, out_data], null_count, 0)
 
 
@@ -185,9 +186,10 @@ def get_take_indices(mask: Array, null_selection_behavior: str = "drop") -> Arra
     emit = options.code == _lib.FILTER_EMIT_NULL and mask.may_have_nulls()
     out = alloc(s * itype.byte_width, dev)
     out_valid = alloc(bitmap_nbytes(s), dev) if emit else None
-    check(lib.arx_mask_to_indices(C.byref(mspan), options.code, ws.data_ptr(), s, itype.byte_width,
-                                  out.data_ptr(), None if out_valid is None else out_valid.data_ptr(),
-                                  stream))
+    with tracing.span("arx_mask_to_indices"):
+        check(lib.arx_mask_to_indices(C.byref(mspan), options.code, ws.data_ptr(), s, itype.byte_width,
+                                      out.data_ptr(),
+                                      None if out_valid is None else out_valid.data_ptr(), stream))
     return Array(itype, s, [out_valid, out], kUnknownNullCount if emit else 0, 0)
 
 
@@ -225,9 +227,10 @@ def _exec_array_take(args, options):
     counter = None
     if allocate_validity:
         counter = torch.zeros(8, dtype=torch.uint8, device=dev)
-    check(lib.arx_take(C.byref(vspan), w, C.byref(ispan), tid, out_data.data_ptr(),
-                       None if out_valid is None else out_valid.data_ptr(),
-                       None if counter is None else counter.data_ptr(), stream))
+    with tracing.span("arx_take"):
+        check(lib.arx_take(C.byref(vspan), w, C.byref(ispan), tid, out_data.data_ptr(),
+                           None if out_valid is None else out_valid.data_ptr(),
+                           None if counter is None else counter.data_ptr(), stream))
     out = Array(values.type, m, [out_valid, out_data], 0, 0)
     if allocate_validity:
         out.set_lazy_null_count(_LazyCount(m, counter))
@@ -240,7 +243,8 @@ def _exec_cast_f64_f32(args, options):
     dev = arr.device
     lib, stream = _lib_and_stream(dev)
     out = alloc(arr.length * 4, dev)
-    check(lib.arx_cast_f64_f32(arr.values_ptr(), arr.length, out.data_ptr(), stream))
+    with tracing.span("arx_cast_f64_f32"):
+        check(lib.arx_cast_f64_f32(arr.values_ptr(), arr.length, out.data_ptr(), stream))
     validity, nc = _propagate_validity([arr], arr.length, dev)
     return Array(float32, arr.length, [validity, out], nc, 0)
 
@@ -262,7 +266,8 @@ def _exec_greater(args, options):
         if left.length != right.length:
             raise ArrowInvalid("Array arguments must all be the same length")
         fn = lib.arx_greater_f64 if t == float64 else lib.arx_greater_i64
-        check(fn(left.values_ptr(), right.values_ptr(), n, out.data_ptr(), stream))
+        with tracing.span("arx_greater"):
+            check(fn(left.values_ptr(), right.values_ptr(), n, out.data_ptr(), stream))
     elif isinstance(left, Array):
         check(lib.arx_greater_f64_array_scalar(left.values_ptr(), float(_scalar_value(right) or 0.0), n,
                                                out.data_ptr(), stream))

@@ -1,0 +1,341 @@
+"""Parity tests proper: the HIP kernels on a real MI355X through arrow_amd.compute -> C ABI,
+against the C oracle (bit-exact) and the reference's own build (pyarrow) on the same seeded
+inputs.  Run with `pytest -m gpu` on the GPU box."""
+import numpy as np
+import pytest
+
+from . import parity_cases as P
+from . import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def rng_for(*key):
+    return np.random.default_rng([U.kRandomSeed, *[abs(hash(str(k))) % (1 << 31) for k in key]])
+
+
+# ------------------------------------------------------------------ filter
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 4095, 4096, 4097, 262144, 262145, 1_000_003])
+def test_filter_int64_lengths(gpu_ctx, n, sel):
+    rng = rng_for("f64len", n, sel)
+    v = U.random_array(rng, np.int64, n, null_p=0.1)
+    m = U.random_mask(rng, n, 0.3, null_p=0.05)
+    P.check_filter(gpu_ctx, v, m, sel)
+
+
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+@pytest.mark.parametrize("true_p", [0.0, 0.1, 0.5, 0.999, 1.0])
+@pytest.mark.parametrize("vnull,mnull", [(0.0, 0.0), (0.01, 0.0), (0.1, 0.05), (0.999, 0.5), (1.0, 1.0)])
+def test_filter_random_grid(gpu_ctx, true_p, vnull, mnull, sel):
+    """FilterRandomTest's grid (vector_selection_test.cc:2241-2260) at 300k rows."""
+    rng = rng_for("fprob", true_p, vnull, mnull, sel)
+    n = 300_007
+    v = U.random_array(rng, np.int64, n, null_p=vnull)
+    m = U.random_mask(rng, n, true_p, null_p=mnull)
+    P.check_filter(gpu_ctx, v, m, sel)
+
+
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+@pytest.mark.parametrize("voff,moff", [(1, 0), (0, 3), (7, 13), (64, 65), (3, 4099), (100001, 77)])
+def test_filter_offsets(gpu_ctx, voff, moff, sel):
+    rng = rng_for("foff", voff, moff, sel)
+    n = 500_000
+    v = U.random_array(rng, np.int64, n, null_p=0.2, offset=voff, tail=5)
+    m = U.random_mask(rng, n, 0.4, null_p=0.1, offset=moff, tail=9)
+    P.check_filter(gpu_ctx, v, m, sel)
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.uint16, np.int32, np.float32, np.float64, np.uint64])
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+def test_filter_widths(gpu_ctx, dtype, sel):
+    rng = rng_for("fw", dtype, sel)
+    n = 400_003
+    v = U.random_array(rng, dtype, n, null_p=0.1, offset=3)
+    m = U.random_mask(rng, n, 0.5, null_p=0.05, offset=1)
+    P.check_filter(gpu_ctx, v, m, sel)
+
+
+def test_filter_tuning_variants_agree(gpu_ctx):
+    lib = gpu_ctx._lib.get_lib()
+    rng = rng_for("fvariants")
+    v = U.random_array(rng, np.int64, 2_000_003, null_p=0.1, offset=2)
+    m = U.random_mask(rng, 2_000_003, 0.1, null_p=0.05)
+    try:
+        for batch in (1, 4):
+            for dense in (0, 1):
+                assert lib.arx_set_option(b"filter_batch", batch) == 0
+                assert lib.arx_set_option(b"filter_dense", dense) == 0
+                for sel in ("drop", "emit_null"):
+                    P.check_filter(gpu_ctx, v, m, sel, use_pyarrow=False)
+    finally:
+        lib.arx_set_option(b"filter_batch", 4)
+        lib.arx_set_option(b"filter_dense", 0)
+
+
+def test_filter_10m_rows_config1(gpu_ctx):
+    """BASELINE config 1 shape: 10M-row int64, 50 % selectivity."""
+    rng = rng_for("cfg1")
+    n = 10_000_000
+    v = U.random_array(rng, np.int64, n)
+    m = U.random_mask(rng, n, 0.5)
+    out = P.check_filter(gpu_ctx, v, m, "drop")
+    assert out.validity is None and out.null_count == 0
+
+
+def test_filter_length_mismatch_is_invalid(gpu_ctx):
+    v = U.HostArray(np.array([7, 8, 9], dtype=np.int64), None, 0, 3).to_device(gpu_ctx)
+    m = U.HostArray(np.zeros(0, dtype=bool), None, 0, 0).to_device(gpu_ctx)
+    for sel in ("drop", "emit_null"):
+        with pytest.raises(gpu_ctx.ArrowInvalid):
+            gpu_ctx.compute.filter(v, m, sel)
+
+
+# ------------------------------------------------------------------ GetTakeIndices
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+@pytest.mark.parametrize("n,off", [(0, 0), (1, 0), (100, 5), (65535, 0), (65536, 3), (3_000_001, 1)])
+def test_mask_to_indices(gpu_ctx, n, off, sel):
+    rng = rng_for("m2i", n, off, sel)
+    m = U.random_mask(rng, n, 0.2, null_p=0.05, offset=off, tail=3)
+    P.check_mask_to_indices(gpu_ctx, m, sel)
+
+
+def test_record_batch_filter_is_take_of_indices(gpu_ctx):
+    amd = gpu_ctx
+    rng = rng_for("rb")
+    n = 1_000_000
+    a = U.random_array(rng, np.int64, n, null_p=0.1)
+    b = U.random_array(rng, np.int32, n)
+    m = U.random_mask(rng, n, 0.3, null_p=0.1)
+    for sel in ("drop", "emit_null"):
+        rb = amd.compute.RecordBatch({"a": a.to_device(amd), "b": b.to_device(amd)})
+        out = amd.compute.filter(rb, m.to_device(amd), sel)
+        for name, col in (("a", a), ("b", b)):
+            direct = amd.compute.filter(col.to_device(amd), m.to_device(amd), sel)
+            gv, gm = out.columns[name].to_numpy()
+            dv, dmk = direct.to_numpy()
+            gm = np.ones(len(gv), bool) if gm is None else gm
+            dmk = np.ones(len(dv), bool) if dmk is None else dmk
+            assert (gm == dmk).all() and (gv[gm] == dv[dmk]).all()
+
+
+# ------------------------------------------------------------------ take
+@pytest.mark.parametrize("idx_dtype", [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32,
+                                       np.uint64, np.int64])
+def test_take_index_types(gpu_ctx, idx_dtype):
+    rng = rng_for("tk", idx_dtype)
+    small = np.dtype(idx_dtype).itemsize == 1
+    nv = 100 if small else (30_000 if np.dtype(idx_dtype).itemsize == 2 else 1_000_000)
+    v = U.random_array(rng, np.int64, nv, null_p=0.1, offset=3)
+    i = U.random_array(rng, idx_dtype, 300_001, null_p=0.1, offset=5, lo=0, hi=nv - 1)
+    P.check_take(gpu_ctx, v, i)
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int16, np.float32, np.float64])
+@pytest.mark.parametrize("vnull,inull", [(0.0, 0.0), (0.1, 0.0), (0.0, 0.3), (1.0, 0.0), (0.5, 1.0)])
+def test_take_widths_and_nulls(gpu_ctx, dtype, vnull, inull):
+    rng = rng_for("tkw", dtype, vnull, inull)
+    v = U.random_array(rng, dtype, 300_000, null_p=vnull)
+    i = U.random_array(rng, np.int32, 150_001, null_p=inull, lo=0, hi=299_999)
+    P.check_take(gpu_ctx, v, i)
+
+
+def test_take_monotonic_indices_from_filter(gpu_ctx):
+    """The Filter+Take benchmark shape: indices = GetTakeIndices(mask) (monotonic uint32)."""
+    amd = gpu_ctx
+    rng = rng_for("tkmono")
+    n = 5_000_000
+    v = U.random_array(rng, np.int64, n, null_p=0.1)
+    m = U.random_mask(rng, n, 0.1)
+    idx = amd.compute.get_take_indices(m.to_device(amd))
+    iv, _ = idx.to_numpy()
+    P.check_take(gpu_ctx, v, U.HostArray(iv, None, 0, len(iv)), boundscheck=False)
+
+
+def test_take_empty_and_no_boundscheck(gpu_ctx):
+    rng = rng_for("tke")
+    v = U.random_array(rng, np.int64, 50)
+    P.check_take(gpu_ctx, v, U.HostArray(np.zeros(0, dtype=np.int32), None, 0, 0))
+    i = U.random_array(rng, np.uint32, 70_000, lo=0, hi=49)
+    P.check_take(gpu_ctx, v, i, boundscheck=False)
+
+
+@pytest.mark.parametrize("bad", [9, -1])
+def test_take_out_of_bounds(gpu_ctx, bad):
+    v = U.HostArray(np.arange(5, dtype=np.int64), None, 0, 5)
+    idx = np.array([0, bad, 0, 77], dtype=np.int64)
+    P.check_take_out_of_bounds(gpu_ctx, v, U.HostArray(idx, None, 0, 4))
+
+
+def test_take_out_of_bounds_first_offender_large(gpu_ctx):
+    rng = rng_for("oob")
+    idx = rng.integers(0, 1000, size=2_000_000).astype(np.int32)
+    idx[1_234_567] = 1000
+    idx[1_900_000] = -7
+    v = U.HostArray(np.arange(1000, dtype=np.int64), None, 0, 1000)
+    P.check_take_out_of_bounds(gpu_ctx, v, U.HostArray(idx, None, 0, len(idx)))
+
+
+def test_take_null_index_is_not_bounds_checked(gpu_ctx):
+    v = U.HostArray(np.arange(5, dtype=np.int64), None, 0, 5)
+    idx = U.HostArray(np.array([1, 99, 2], dtype=np.int32), np.array([True, False, True]), 0, 3)
+    out = P.check_take(gpu_ctx, v, idx)
+    assert out.to_pylist() == [1, None, 2]
+
+
+# ------------------------------------------------------------------ cast / compare / add
+def _cast_inputs(rng, n):
+    x = rng.standard_normal(n)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e39, -1e39, 3.4028235677973366e38,
+                        1e-40, -1e-46, 1.0000000596046448, 1.00000017881393433, 2.0 ** -126, 2.0 ** -150])
+    x[: min(len(special), n)] = special[: min(len(special), n)]
+    x[rng.integers(0, n, size=n // 20)] *= 1e40
+    x[rng.integers(0, n, size=n // 20)] *= 1e-42
+    return x
+
+
+@pytest.mark.parametrize("n,off", [(0, 0), (1, 0), (13, 1), (2048, 0), (2049, 3), (4_000_001, 2)])
+def test_cast_f64_f32(gpu_ctx, n, off):
+    rng = rng_for("cast", n, off)
+    x = _cast_inputs(rng, n + off + 2) if n else np.zeros(off + 2)
+    valid = rng.random(len(x)) > 0.1 if n % 2 else None
+    P.check_cast_f64_f32(gpu_ctx, U.HostArray(x, valid, off, n))
+
+
+def test_cast_f64_f32_ties_to_even_exhaustive_mantissa_tail(gpu_ctx):
+    """Every 29-bit tail pattern class around a float32 rounding boundary: RNE ties."""
+    base = np.float64(1.0).view(np.uint64) if False else np.array([1.0]).view(np.uint64)[0]
+    tails = np.arange(0, 1 << 20, dtype=np.uint64) << np.uint64(9)
+    bits = (base + tails).astype(np.uint64)
+    x = bits.view(np.float64)
+    P.check_cast_f64_f32(gpu_ctx, U.HostArray(x.copy(), None, 0, len(x)))
+
+
+@pytest.mark.parametrize("n,off", [(1, 0), (64, 0), (127, 1), (513, 0), (3_000_001, 5)])
+def test_greater_f64_array_array(gpu_ctx, n, off):
+    rng = rng_for("gt", n, off)
+    a = U.random_array(rng, np.float64, n, null_p=0.1, offset=off)
+    b = U.random_array(rng, np.float64, n, null_p=0.1 if n % 2 else 0.0, offset=2 * off)
+    a.values[rng.integers(0, len(a.values), 5)] = np.nan
+    k = min(len(a.values), len(b.values))
+    b.values[:k:7] = a.values[:k:7]
+    P.check_greater_f64(gpu_ctx, a, b)
+
+
+def test_greater_scalar_forms_and_i64(gpu_ctx):
+    rng = rng_for("gts")
+    a = U.random_array(rng, np.float64, 1_000_000, null_p=0.1, offset=1)
+    P.check_greater_f64(gpu_ctx, a, 0.25)
+    P.check_greater_f64(gpu_ctx, -0.5, a)
+    P.check_greater_f64(gpu_ctx, a, float("nan"))
+    x = U.random_array(rng, np.int64, 777_777, lo=-5, hi=5)
+    y = U.random_array(rng, np.int64, 777_777, lo=-5, hi=5)
+    P.check_greater_f64(gpu_ctx, x, y)
+
+
+def test_add(gpu_ctx):
+    rng = rng_for("add")
+    x = U.random_array(rng, np.int64, 3_000_001, null_p=0.1, offset=1)
+    y = U.random_array(rng, np.int64, 3_000_001, offset=3)
+    P.check_add(gpu_ctx, x, y)
+    a = U.random_array(rng, np.float64, 1_000_000, null_p=0.1)
+    b = U.random_array(rng, np.float64, 1_000_000, null_p=0.1)
+    P.check_add(gpu_ctx, a, b)
+
+
+# ------------------------------------------------------------------ sort
+@pytest.mark.parametrize("order", ["ascending", "descending"])
+@pytest.mark.parametrize("placement", ["at_end", "at_start"])
+def test_sort_small_range_with_ties_and_nulls(gpu_ctx, order, placement):
+    rng = rng_for("sort1", order, placement)
+    a = U.random_array(rng, np.uint64, 200_003, null_p=0.2, offset=3, lo=0, hi=7)
+    P.check_sort_indices(gpu_ctx, a, order, placement)
+
+
+@pytest.mark.parametrize("dtype", [np.uint64, np.int64])
+@pytest.mark.parametrize("n", [1, 2, 255, 4096, 4097, 1_000_003])
+def test_sort_full_range(gpu_ctx, dtype, n):
+    rng = rng_for("sort2", dtype, n)
+    a = U.random_array(rng, dtype, n)
+    P.check_sort_indices(gpu_ctx, a, "ascending" if n % 2 else "descending", "at_end")
+
+
+def test_sort_multi_chunk(gpu_ctx):
+    """> 2048 tiles so that a chunk holds several tiles (cursor carry between tiles)."""
+    rng = rng_for("sort3")
+    n = 4096 * 2048 * 2 + 12345
+    a = U.random_array(rng, np.uint64, n, null_p=0.01)
+    P.check_sort_indices(gpu_ctx, a, "ascending", "at_end", use_pyarrow=False)
+
+
+def test_sort_all_null_and_empty(gpu_ctx):
+    a = U.HostArray(np.arange(10, dtype=np.uint64), np.zeros(10, dtype=bool), 0, 10)
+    P.check_sort_indices(gpu_ctx, a)
+    P.check_sort_indices(gpu_ctx, U.HostArray(np.zeros(0, dtype=np.uint64), None, 0, 0))
+
+
+# ------------------------------------------------------------------ group-by
+@pytest.mark.parametrize("skip_nulls,min_count", [(True, 1), (False, 1), (True, 0), (True, 3), (False, 0)])
+def test_groupby_sum_options(gpu_ctx, skip_nulls, min_count):
+    rng = rng_for("gb", skip_nulls, min_count)
+    k = U.random_array(rng, np.int32, 300_000, null_p=0.05, offset=1, lo=-20, hi=20)
+    v = U.random_array(rng, np.int64, 300_000, null_p=0.2, offset=2)
+    P.check_groupby_sum(gpu_ctx, k, v, skip_nulls, min_count, batches=3)
+
+
+def test_groupby_sum_wraparound_many_groups(gpu_ctx):
+    rng = rng_for("gbwrap")
+    n = 2_000_000
+    k = U.random_array(rng, np.int32, n, lo=0, hi=200_000)
+    v = U.random_array(rng, np.int64, n)
+    P.check_groupby_sum(gpu_ctx, k, v, capacity=1 << 19)
+
+
+def test_groupby_sum_golden_sum_only(gpu_ctx):
+    keys = [1, 1, 2, 3, None, 1, 2, 2, None, 3]
+    vals = [10, None, None, 1, 30, 5, None, 20, 40, None]
+    k = U.HostArray(np.array([0 if x is None else x for x in keys], dtype=np.int32),
+                    np.array([x is not None for x in keys]), 0, len(keys))
+    v = U.HostArray(np.array([0 if x is None else x for x in vals], dtype=np.int64),
+                    np.array([x is not None for x in vals]), 0, len(vals))
+    got = P.check_groupby_sum(gpu_ctx, k, v)
+    assert got == [(0, 1, 15), (0, 2, 20), (0, 3, 1), (1, 0, 70)]
+
+
+def test_groupby_table_overflow_is_reported(gpu_ctx):
+    amd = gpu_ctx
+    k = amd.Array.from_numpy(np.arange(100, dtype=np.int32))
+    v = amd.Array.from_numpy(np.ones(100, dtype=np.int64))
+    op = amd.compute.GroupBySum(16, k.device)
+    op.consume(k, v)
+    with pytest.raises(amd.ArrowInvalid, match="full"):
+        op.num_groups()
+
+
+# ------------------------------------------------------------------ size-independent properties
+def test_large_filter_properties(gpu_ctx):
+    """2^28 rows (beyond the oracle's comfortable range): count == popcount, output is the
+    subsequence (checked via a checksum of selected rows), take(indices) == filter."""
+    import torch
+
+    amd = gpu_ctx
+    n = 1 << 28
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    vals = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device="cuda", generator=g)
+    sel = torch.rand(n, device="cuda", generator=g) < 0.1
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device="cuda")
+    bits = (sel.view(-1, 8).to(torch.uint8) * w).sum(dim=1, dtype=torch.uint8)
+    values = amd.Array(amd.array.int64, n, [None, vals.view(torch.uint8)], 0, 0)
+    mask = amd.Array(amd.array.bool_, n, [None, bits], 0, 0)
+    out = amd.compute.filter(values, mask)
+    s = int(sel.sum())
+    assert out.length == s
+    got = out.data[: s * 8].view(torch.int64)
+    want = vals[sel]
+    assert torch.equal(got, want)
+    idx = amd.compute.get_take_indices(mask)
+    assert idx.length == s and idx.type.name == "uint32"
+    want_idx = torch.nonzero(sel).view(-1).to(torch.int64)
+    assert torch.equal(idx.data[: s * 4].view(torch.int32).to(torch.int64) & 0xFFFFFFFF, want_idx)
+    tk = amd.compute.take(values, idx, boundscheck=False)
+    assert torch.equal(tk.data[: s * 8].view(torch.int64), want)

@@ -1,0 +1,276 @@
+"""Pins the oracle (oracle/arx_oracle.c) before anything trusts it:
+ 1. against golden vectors transcribed from the reference's unit tests
+    (tests/golden/reference_vectors.json, each with its file:line);
+ 2. against the reference's own build — pyarrow 25.0.0 (libarrow.so.2500) — on seeded random
+    grids shaped like the reference's randomized tests (FilterRandomTest, TakeRandomTest, ...);
+ 3. against fixtures generated from pyarrow by tests/golden/make_golden.py (so the pin survives
+    on a machine without the wheel).
+CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+from . import util as U
+from .util import pa, pc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "reference_vectors.json")))
+
+
+def from_list(xs, dtype):
+    valid = np.array([x is not None for x in xs], dtype=bool)
+    fill = False if dtype == np.bool_ else 0
+    vals = np.array([fill if x is None else x for x in xs], dtype=dtype)
+    return U.HostArray(vals, None if valid.all() else valid, 0, len(xs))
+
+
+def to_list(vals, bm, n):
+    valid = O.unpack_bits(bm, 0, n) if bm is not None else np.ones(n, bool)
+    return [v if ok else None for v, ok in zip(vals.tolist(), valid.tolist())]
+
+
+def o_filter(v: U.HostArray, m: U.HostArray, sel):
+    code = 1 if sel == "emit_null" else 0
+    vals, bm = O.filter(v.data_bytes(), v.valid_bitmap(), v.offset, m.data_bytes(), m.valid_bitmap(),
+                        m.offset, m.length, code, True)
+    return to_list(vals, bm, len(vals))
+
+
+# ------------------------------------------------------------------ 1. golden vectors
+@pytest.mark.parametrize("case", GOLD["get_take_indices"], ids=lambda c: c["cite"])
+def test_golden_get_take_indices(case):
+    m = from_list(case["mask"], np.bool_)
+    code = 1 if case["sel"] == "emit_null" else 0
+    vals, bm = O.mask_to_indices(m.data_bytes(), m.valid_bitmap(), 0, m.length, code, True)
+    assert vals.dtype == np.uint16
+    assert to_list(vals, bm, len(vals)) == case["want"]
+
+
+@pytest.mark.parametrize("case", GOLD["filter_emit_null"], ids=lambda c: c["cite"])
+@pytest.mark.parametrize("dtype", [np.int8, np.int32, np.int64, np.float64])
+def test_golden_filter(case, dtype):
+    v, m = from_list(case["values"], dtype), from_list(case["mask"], np.bool_)
+    assert o_filter(v, m, "emit_null") == case["want"]
+    # AssertFilter also checks DROP == the expectation with mask-null rows removed (:258-284)
+    drop_want = []
+    it = iter(case["want"])
+    for x in case["mask"]:
+        if x is None:
+            next(it)
+        elif x:
+            drop_want.append(next(it))
+    assert o_filter(v, m, "drop") == drop_want
+
+
+def test_golden_filter_sliced_mask():
+    c = GOLD["filter_sliced_mask"]
+    v = from_list(c["values"], np.int64)
+    full = from_list(c["mask_full"], np.bool_)
+    m = U.HostArray(full.values, full.valid, c["mask_offset"], c["mask_length"])
+    assert o_filter(v, m, "drop") == c["want"] == o_filter(v, m, "emit_null")
+
+
+@pytest.mark.parametrize("case", GOLD["take"], ids=lambda c: c["cite"])
+@pytest.mark.parametrize("idx_dtype", [np.int8, np.uint32, np.int64])
+def test_golden_take(case, idx_dtype):
+    v, i = from_list(case["values"], np.int8), from_list(case["indices"], idx_dtype)
+    vals, bm, vc = O.take(v.data_bytes(), v.valid_bitmap(), 0, np.ascontiguousarray(i.values),
+                          i.valid_bitmap(), 0, i.length, True)
+    got = to_list(vals, bm, i.length)
+    assert got == case["want"]
+    assert vc == sum(x is not None for x in case["want"])
+    # null slots are zero-filled (WriteZero, gather_internal.h:114-153)
+    assert all(vals[k] == 0 for k, x in enumerate(case["want"]) if x is None)
+
+
+@pytest.mark.parametrize("case", GOLD["take_index_error"], ids=lambda c: c["cite"])
+def test_golden_take_index_error(case):
+    i = from_list(case["indices"], np.int8)
+    bad = O.check_index_bounds(np.ascontiguousarray(i.values), None, 0, i.length, len(case["values"]))
+    assert bad == case["bad"]
+
+
+def test_golden_cast():
+    c = GOLD["cast_f64_f32"]
+    assert O.cast_f64_f32(np.array(c["values"])).tolist() == [float(np.float32(x)) for x in c["want"]]
+
+
+# ------------------------------------------------------------------ 2. the reference's own build
+needs_pa = pytest.mark.skipif(pa is None, reason="pyarrow wheel not importable")
+
+
+def rng_for(*key):
+    return np.random.default_rng([U.kRandomSeed, *[abs(hash(str(k))) % (1 << 31) for k in key]])
+
+
+def pa_to_list(a):
+    return a.to_pylist()
+
+
+@needs_pa
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+@pytest.mark.parametrize("null_p", [0.0, 0.01, 0.1, 0.999, 1.0])
+@pytest.mark.parametrize("true_p", [0.0, 0.1, 0.999, 1.0])
+def test_filter_vs_pyarrow_random_grid(true_p, null_p, sel):
+    """FilterRandomTest (vector_selection_test.cc:2241-2260): len 1024(+), differing offsets."""
+    rng = rng_for("pf", true_p, null_p, sel)
+    for dtype, voff, moff in ((np.int64, 0, 0), (np.int32, 3, 5), (np.int8, 1, 64), (np.float64, 7, 2)):
+        v = U.random_array(rng, dtype, 1500, null_p=null_p, offset=voff, tail=2)
+        m = U.random_mask(rng, 1500, true_p, null_p=null_p / 2, offset=moff, tail=1)
+        ref = pc.filter(v.to_pyarrow(), m.to_pyarrow(), null_selection_behavior=sel)
+        got = o_filter(v, m, sel)
+        rl = ref.to_pylist()
+        if np.dtype(dtype).kind == "f":
+            assert len(got) == len(rl)
+            for g, r in zip(got, rl):
+                assert (g is None) == (r is None) and (g is None or g == r or (g != g and r != r))
+        else:
+            assert got == rl
+
+
+@needs_pa
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+def test_mask_to_indices_vs_pyarrow(sel):
+    """indices_nonzero / filter(iota) give the reference's GetTakeIndices result."""
+    rng = rng_for("pm2i", sel)
+    for n, off in ((0, 0), (1, 0), (1000, 3), (70000, 1)):
+        m = U.random_mask(rng, n, 0.3, null_p=0.1, offset=off)
+        code = 1 if sel == "emit_null" else 0
+        vals, bm = O.mask_to_indices(m.data_bytes(), m.valid_bitmap(), m.offset, n, code, True)
+        iota = pa.array(np.arange(n, dtype=vals.dtype))
+        ref = pc.filter(iota, m.to_pyarrow(), null_selection_behavior=sel)
+        assert to_list(vals, bm, len(vals)) == ref.to_pylist()
+
+
+@needs_pa
+@pytest.mark.parametrize("idx_dtype", [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32,
+                                       np.uint64, np.int64])
+@pytest.mark.parametrize("null_p", [0.0, 0.01, 0.1, 0.5, 1.0])
+def test_take_vs_pyarrow_random(idx_dtype, null_p):
+    """TakeRandomTest (vector_selection_test.cc:2282-2315): values 1025 (127 for 8-bit), indices 257."""
+    rng = rng_for("pt", idx_dtype, null_p)
+    nv = 127 if np.dtype(idx_dtype).itemsize == 1 else 1025
+    for dtype in (np.int64, np.int16):
+        v = U.random_array(rng, dtype, nv, null_p=null_p, offset=2)
+        i = U.random_array(rng, idx_dtype, 257, null_p=null_p / 2, offset=1, lo=0, hi=nv - 1)
+        vals, bm, vc = O.take(v.data_bytes(), v.valid_bitmap(), v.offset, np.ascontiguousarray(i.values),
+                              i.valid_bitmap(), i.offset, i.length, True)
+        ref = pc.take(v.to_pyarrow(), i.to_pyarrow())
+        assert to_list(vals, bm, i.length) == ref.to_pylist()
+        assert ref.null_count == i.length - vc
+
+
+@needs_pa
+def test_bounds_message_vs_pyarrow():
+    v = pa.array(np.arange(10))
+    for idx in ([0, 10, 3, -4], [0, -1, 12], [2**40, 1]):
+        i = np.array(idx, dtype=np.int64)
+        bad = O.check_index_bounds(i, None, 0, len(i), 10)
+        with pytest.raises(pa.lib.ArrowIndexError) as e:
+            pc.take(v, pa.array(i))
+        assert str(e.value) == f"Index {bad} out of bounds"
+
+
+@needs_pa
+def test_cast_and_compare_vs_pyarrow():
+    rng = rng_for("pcast")
+    x = rng.standard_normal(20000)
+    x[:8] = [0.0, -0.0, np.inf, -np.inf, np.nan, 1e39, 1e-46, 3.4028235677973366e38]
+    x[100:2000] *= 1e40
+    x[2000:4000] *= 1e-42
+    got = O.cast_f64_f32(x)
+    ref = pc.cast(pa.array(x), pa.float32(), safe=False).to_numpy()
+    same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+    assert same.all()
+    y = rng.standard_normal(20000)
+    y[::5] = x[::5]
+    bits = O.unpack_bits(O.greater_f64(x, y), 0, len(x))
+    assert (bits == pc.greater(pa.array(x), pa.array(y)).to_numpy(zero_copy_only=False)).all()
+    assert (O.unpack_bits(O.greater_f64(x, 0.5), 0, len(x))
+            == pc.greater(pa.array(x), pa.scalar(0.5)).to_numpy(zero_copy_only=False)).all()
+    a = rng.integers(-2**63, 2**63 - 1, size=5000, dtype=np.int64)
+    b = rng.integers(-2**63, 2**63 - 1, size=5000, dtype=np.int64)
+    assert (O.add(a, b) == pc.add(pa.array(a), pa.array(b)).to_numpy()).all()  # unchecked add wraps
+
+
+@needs_pa
+@pytest.mark.parametrize("order", ["ascending", "descending"])
+@pytest.mark.parametrize("placement", ["at_end", "at_start"])
+@pytest.mark.parametrize("dtype,lo,hi,n", [(np.uint64, 0, 5, 700), (np.uint64, None, None, 3000),
+                                            (np.int64, -3, 3, 2000), (np.int64, None, None, 3000)])
+def test_sort_indices_vs_pyarrow(dtype, lo, hi, n, order, placement):
+    """Both the counting-sort (small range, len >= 1024) and the stable_sort branch
+    (vector_array_sort.cc:404-446) must give the oracle's permutation."""
+    rng = rng_for("psort", dtype, lo, n, order, placement)
+    a = U.random_array(rng, dtype, n, null_p=0.15, offset=3, lo=lo, hi=hi)
+    got = O.sort_indices_64(np.ascontiguousarray(a.values), a.valid_bitmap(), a.offset, n,
+                            descending=(order == "descending"), nulls_at_start=(placement == "at_start"))
+    ref = pc.array_sort_indices(a.to_pyarrow(), order=order, null_placement=placement).to_numpy()
+    assert (got == ref).all()
+
+
+@needs_pa
+@pytest.mark.parametrize("skip_nulls,min_count", [(True, 1), (False, 1), (True, 0), (True, 4), (False, 0)])
+@pytest.mark.parametrize("use_threads", [False, True])
+def test_groupby_sum_vs_pyarrow(skip_nulls, min_count, use_threads):
+    """RunGroupBy with use_threads in {false,true}, key-sorted comparison
+    (acero/hash_aggregate_test.cc:262-280, 398-412)."""
+    rng = rng_for("pgb", skip_nulls, min_count)
+    n = 20000
+    k = U.random_array(rng, np.int32, n, null_p=0.05, offset=2, lo=-50, hi=50)
+    v = U.random_array(rng, np.int64, n, null_p=0.2, offset=1)
+    w = O.groupby_sum_i64(np.ascontiguousarray(k.values), k.valid_bitmap(), k.offset,
+                          np.ascontiguousarray(v.values), v.valid_bitmap(), v.offset, n,
+                          skip_nulls, min_count)
+    got = sorted(((0 if kv else 1, int(kk) if kv else 0, int(s) if ok else None)
+                  for kk, kv, s, ok in zip(w["keys"], w["key_is_valid"], w["sums"], w["valid"])),
+                 key=lambda r: (r[0], r[1]))
+    t = pa.table({"k": k.to_pyarrow(), "v": v.to_pyarrow()})
+    r = t.group_by("k", use_threads=use_threads).aggregate(
+        [("v", "sum", pc.ScalarAggregateOptions(skip_nulls=skip_nulls, min_count=min_count))])
+    ref = sorted(((1 if kk is None else 0, 0 if kk is None else kk, s)
+                  for kk, s in zip(r.column("k").to_pylist(), r.column("v_sum").to_pylist())),
+                 key=lambda r_: (r_[0], r_[1]))
+    assert got == ref
+
+
+# ------------------------------------------------------------------ 3. committed pyarrow fixtures
+def test_oracle_vs_committed_pyarrow_fixtures():
+    path = os.path.join(HERE, "golden", "pyarrow_golden.npz")
+    z = np.load(path)
+    n = int(z["n"])
+    vals, valid, mask, mvalid = z["values"], z["values_valid"], z["mask"], z["mask_valid"]
+    v = U.HostArray(vals, valid, 0, n)
+    m = U.HostArray(mask, mvalid, 0, n)
+    for sel in ("drop", "emit_null"):
+        code = 1 if sel == "emit_null" else 0
+        ov, obm = O.filter(v.data_bytes(), v.valid_bitmap(), 0, m.data_bytes(), m.valid_bitmap(), 0, n,
+                           code, True)
+        ovalid = O.unpack_bits(obm, 0, len(ov))
+        assert (ovalid == z[f"filter_{sel}_valid"]).all()
+        assert (ov[ovalid] == z[f"filter_{sel}_values"][ovalid]).all()
+    idx, ivalid = z["indices"], z["indices_valid"]
+    tv, tbm, _ = O.take(v.data_bytes(), v.valid_bitmap(), 0, idx, O.pack_bits(ivalid), 0, len(idx), True)
+    tvalid = O.unpack_bits(tbm, 0, len(idx))
+    assert (tvalid == z["take_valid"]).all() and (tv[tvalid] == z["take_values"][tvalid]).all()
+    assert (O.cast_f64_f32(z["f64"]).view(np.uint32) == z["cast_f32"].view(np.uint32)).all()
+    assert (O.unpack_bits(O.greater_f64(z["f64"], z["f64_b"]), 0, len(z["f64"])) == z["greater"]).all()
+    for order in ("ascending", "descending"):
+        for placement in ("at_end", "at_start"):
+            got = O.sort_indices_64(z["sort_keys"], O.pack_bits(z["sort_valid"]), 0, len(z["sort_keys"]),
+                                    descending=(order == "descending"),
+                                    nulls_at_start=(placement == "at_start"))
+            assert (got == z[f"sort_{order}_{placement}"]).all()
+    w = O.groupby_sum_i64(z["gb_keys"], O.pack_bits(z["gb_keys_valid"]), 0, z["gb_vals"],
+                          O.pack_bits(z["gb_vals_valid"]), 0, len(z["gb_keys"]))
+    got = sorted(((0 if kv else 1, int(kk) if kv else 0, int(s) if ok else None)
+                  for kk, kv, s, ok in zip(w["keys"], w["key_is_valid"], w["sums"], w["valid"])),
+                 key=lambda r: (r[0], r[1]))
+    want = sorted(((int(a), int(b), None if not c else int(d))
+                   for a, b, c, d in zip(z["gb_ref_isnull"], z["gb_ref_key"], z["gb_ref_valid"],
+                                         z["gb_ref_sum"])), key=lambda r: (r[0], r[1]))
+    assert got == want
