@@ -1,0 +1,537 @@
+// arrow_plugin.cc — the reference-side host shim: registers MI355X kernels on Arrow's OWN live
+// FunctionRegistry so that CallFunction("filter" | "take" | "greater" | "array_sort_indices", ...)
+// — and therefore pyarrow.compute, Acero, and every other caller — dispatches to the HIP kernels
+// of libarrow_amd.so through the C ABI of include/arrow_amd.h.  Compiled with g++ against the
+// installed Arrow (headers + libarrow.so.2500 of the pyarrow wheel); no Arrow source is patched.
+//
+// Mechanism (verified in SURVEY.md Appendix C): Function::AddKernel on the live function; the
+// LAST matching kernel wins in DispatchExactImpl (cpp/src/arrow/compute/function.cc:122-157).
+// Each added kernel is a COPY of the stock kernel (same NullHandling / MemAllocation /
+// chunking flags, cpp/src/arrow/compute/kernel.h:561-660) with `signature`, `init` and `exec`
+// replaced.  `init` chains to the stock init so the stock state object exists; `exec` hands
+// shapes this shim does not cover (run-end-encoded filters, boolean values, scalars, tiny
+// inputs, ...) to the stock exec with that state, exactly as the reference would have run them.
+//
+// This round the arrays the Arrow API hands over live in HOST memory (ArraySpan::buffers[i].data,
+// cpp/src/arrow/array/data.h:525-553), so every call stages through HBM over PCIe: correct and
+// drop-in, but bandwidth-bound by the link, not by HBM.  Device-resident ExecBatches
+// (a kROCM arrow::Device/MemoryManager/Buffer, cpp/src/arrow/device.h:43-280) are row (f1) of
+// SURVEY.md section 8 and are what bench.py measures through arrow_amd.compute.
+#include <arrow/api.h>
+#include <arrow/compute/api.h>
+#include <arrow/compute/initialize.h>
+#include <arrow/compute/kernel.h>
+#include <arrow/compute/registry.h>
+#include <arrow/util/bit_util.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/arrow_amd.h"
+
+namespace cp = arrow::compute;
+using arrow::ArrayData;
+using arrow::ArraySpan;
+using arrow::Buffer;
+using arrow::Status;
+using arrow::Type;
+
+namespace {
+
+std::atomic<int64_t> g_gpu_calls{0};
+std::atomic<int64_t> g_stock_calls{0};
+std::atomic<int64_t> g_min_rows{1 << 16};
+thread_local std::string t_error;
+
+Status FromArx(int rc) {
+  if (rc == ARX_OK) return Status::OK();
+  const std::string msg = arx_last_error();
+  switch (rc) {
+    case ARX_INVALID: return Status::Invalid(msg);
+    case ARX_INDEX_ERROR: return Status::IndexError(msg);
+    case ARX_NOT_IMPLEMENTED: return Status::NotImplemented(msg);
+    case ARX_OUT_OF_MEMORY: return Status::OutOfMemory(msg);
+    default: return Status::UnknownError(msg);
+  }
+}
+
+#define HIP_RETURN_NOT_OK(call)                                                        \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess)                                                             \
+      return Status::IOError("HIP: ", hipGetErrorString(e__), " in " #call);           \
+  } while (0)
+
+// ---------------------------------------------------------------- per-thread device scratch
+// Kernel::exec may be called concurrently from Acero's thread pool with the same const Kernel*
+// (SURVEY.md 8b): every host thread owns a stream and a handful of growable HBM staging slots.
+class DeviceScratch {
+ public:
+  ~DeviceScratch() {
+    for (auto& s : slots_) {
+      if (s.ptr) (void)hipFree(s.ptr);
+    }
+    if (stream_) (void)hipStreamDestroy(stream_);
+  }
+  Status Stream(hipStream_t* out) {
+    if (!stream_) HIP_RETURN_NOT_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    *out = stream_;
+    return Status::OK();
+  }
+  Status Get(int slot, size_t bytes, void** out) {
+    if (slots_.size() <= static_cast<size_t>(slot)) slots_.resize(slot + 1);
+    Slot& s = slots_[slot];
+    bytes = (bytes + 255) & ~size_t(255);
+    if (s.size < bytes) {
+      if (s.ptr) HIP_RETURN_NOT_OK(hipFree(s.ptr));
+      s.ptr = nullptr;
+      s.size = 0;
+      const size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 20);
+      HIP_RETURN_NOT_OK(hipMalloc(&s.ptr, want));
+      s.size = want;
+    }
+    *out = s.ptr;
+    return Status::OK();
+  }
+
+ private:
+  struct Slot { void* ptr = nullptr; size_t size = 0; };
+  std::vector<Slot> slots_;
+  hipStream_t stream_ = nullptr;
+};
+thread_local DeviceScratch t_scratch;
+
+enum Slot { kValues = 0, kValidity, kArg2, kArg2Validity, kOutData, kOutValidity, kWs, kCounter };
+
+// Upload the logical range of a fixed-width (or boolean) ArraySpan.  The device copy keeps the
+// sub-byte part of the offset (offset % 8) so that one logical offset addresses both buffers.
+Status Upload(const ArraySpan& a, int byte_width_or_0_for_bool, int data_slot, int validity_slot,
+              hipStream_t st, ArxSpan* out) {
+  const int64_t o8 = a.offset % 8;
+  const int64_t first = a.offset - o8;
+  out->offset = o8;
+  out->length = a.length;
+  out->null_count = a.null_count;
+  out->validity = nullptr;
+  out->data = nullptr;
+  const int64_t span_elems = o8 + a.length;
+  if (a.buffers[1].data != nullptr && a.length > 0) {
+    const uint8_t* src;
+    size_t bytes;
+    if (byte_width_or_0_for_bool == 0) {
+      src = a.buffers[1].data + first / 8;
+      bytes = static_cast<size_t>(arrow::bit_util::BytesForBits(span_elems));
+    } else {
+      src = a.buffers[1].data + first * byte_width_or_0_for_bool;
+      bytes = static_cast<size_t>(span_elems) * byte_width_or_0_for_bool;
+    }
+    void* d = nullptr;
+    ARROW_RETURN_NOT_OK(t_scratch.Get(data_slot, bytes + 16, &d));
+    HIP_RETURN_NOT_OK(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, st));
+    out->data = d;
+  }
+  if (a.buffers[0].data != nullptr && a.null_count != 0 && a.length > 0) {
+    const size_t bytes = static_cast<size_t>(arrow::bit_util::BytesForBits(span_elems));
+    void* d = nullptr;
+    ARROW_RETURN_NOT_OK(t_scratch.Get(validity_slot, bytes + 16, &d));
+    HIP_RETURN_NOT_OK(hipMemcpyAsync(d, a.buffers[0].data + first / 8, bytes, hipMemcpyHostToDevice, st));
+    out->validity = d;
+  } else if (a.null_count != 0 && a.buffers[0].data == nullptr) {
+    out->null_count = 0;  // no bitmap: all valid
+  }
+  return Status::OK();
+}
+
+bool IsHost(const ArraySpan& a) {
+  for (int i = 0; i < 2; ++i) {
+    if (a.buffers[i].owner != nullptr && *a.buffers[i].owner != nullptr &&
+        !(*a.buffers[i].owner)->is_cpu()) {
+      return false;
+    }
+  }
+  return true;
+}
+
+int FixedByteWidth(const arrow::DataType& t) {
+  switch (t.id()) {
+    case Type::INT8: case Type::UINT8: return 1;
+    case Type::INT16: case Type::UINT16: case Type::HALF_FLOAT: return 2;
+    case Type::INT32: case Type::UINT32: case Type::FLOAT: case Type::DATE32: case Type::TIME32: return 4;
+    case Type::INT64: case Type::UINT64: case Type::DOUBLE: case Type::DATE64: case Type::TIME64:
+    case Type::TIMESTAMP: case Type::DURATION: return 8;
+    default: return 0;
+  }
+}
+
+// ---------------------------------------------------------------- state = stock state + options
+template <typename Options>
+struct ShimState : public cp::KernelState {
+  std::unique_ptr<cp::KernelState> stock;
+  Options options;
+};
+
+struct StockKernel {
+  cp::KernelInit init;
+  cp::ArrayKernelExec exec = nullptr;
+};
+
+// run the stock exec with the stock state installed
+Status RunStock(const StockKernel& k, cp::KernelState* stock_state, cp::KernelContext* ctx,
+                const cp::ExecSpan& batch, cp::ExecResult* out) {
+  g_stock_calls.fetch_add(1, std::memory_order_relaxed);
+  cp::KernelState* mine = ctx->state();
+  ctx->SetState(stock_state);
+  Status st = k.exec(ctx, batch, out);
+  ctx->SetState(mine);
+  return st;
+}
+
+// ---------------------------------------------------------------- filter
+StockKernel g_stock_filter;
+
+arrow::Result<std::unique_ptr<cp::KernelState>> FilterInit(cp::KernelContext* ctx,
+                                                           const cp::KernelInitArgs& args) {
+  auto state = std::make_unique<ShimState<cp::FilterOptions>>();
+  if (g_stock_filter.init) {
+    ARROW_ASSIGN_OR_RAISE(state->stock, g_stock_filter.init(ctx, args));
+  }
+  if (args.options != nullptr) {
+    state->options = *static_cast<const cp::FilterOptions*>(args.options);
+  }
+  return state;
+}
+
+// PrimitiveFilterExec (vector_selection_filter_internal.cc:445-510) with the loop on the GPU.
+Status FilterExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResult* out) {
+  auto* state = static_cast<ShimState<cp::FilterOptions>*>(ctx->state());
+  const ArraySpan& values = batch[0].array;
+  const ArraySpan& filter = batch[1].array;
+  const int w = FixedByteWidth(*values.type);
+  if (w == 0 || filter.type->id() != Type::BOOL || values.length < g_min_rows.load() ||
+      !IsHost(values) || !IsHost(filter)) {
+    return RunStock(g_stock_filter, state->stock.get(), ctx, batch, out);
+  }
+  const int null_sel = state->options.null_selection_behavior == cp::FilterOptions::EMIT_NULL
+                           ? ARX_FILTER_EMIT_NULL : ARX_FILTER_DROP;
+  hipStream_t st;
+  ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+  ArxSpan dv{}, dm{};
+  ARROW_RETURN_NOT_OK(Upload(values, w, kValues, kValidity, st, &dv));
+  ARROW_RETURN_NOT_OK(Upload(filter, 0, kArg2, kArg2Validity, st, &dm));
+  const size_t ws_bytes = arx_filter_workspace_bytes(filter.length);
+  void* ws = nullptr;
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kWs, ws_bytes, &ws));
+  int64_t out_len = 0;
+  ARROW_RETURN_NOT_OK(FromArx(arx_filter_count(&dm, null_sel, ws, ws_bytes, &out_len, st)));
+
+  ArrayData* out_arr = out->array_data().get();
+  const bool filter_null_count_is_zero = filter.null_count == 0;
+  if (values.null_count == 0 && (null_sel == ARX_FILTER_DROP || filter_null_count_is_zero)) {
+    out_arr->null_count = 0;
+  } else {
+    out_arr->null_count = arrow::kUnknownNullCount;
+  }
+  const bool allocate_validity = values.null_count != 0 || !filter_null_count_is_zero;
+  out_arr->length = out_len;
+  out_arr->buffers.resize(2);
+  ARROW_ASSIGN_OR_RAISE(out_arr->buffers[1], ctx->Allocate(out_len * w));
+  void* d_out = nullptr;
+  void* d_out_valid = nullptr;
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kOutData, static_cast<size_t>(out_len) * w + 16, &d_out));
+  const size_t vbytes = static_cast<size_t>((out_len + 63) / 64) * 8;
+  if (allocate_validity) {
+    ARROW_ASSIGN_OR_RAISE(out_arr->buffers[0], ctx->AllocateBitmap(out_len));
+    ARROW_RETURN_NOT_OK(t_scratch.Get(kOutValidity, vbytes + 16, &d_out_valid));
+  } else {
+    out_arr->buffers[0] = nullptr;
+  }
+  ARROW_RETURN_NOT_OK(FromArx(arx_filter_exec(&dv, w, &dm, null_sel, ws, out_len, d_out, d_out_valid, st)));
+  if (out_len > 0) {
+    HIP_RETURN_NOT_OK(hipMemcpyAsync(out_arr->buffers[1]->mutable_data(), d_out,
+                                     static_cast<size_t>(out_len) * w, hipMemcpyDeviceToHost, st));
+    if (allocate_validity) {
+      HIP_RETURN_NOT_OK(hipMemcpyAsync(out_arr->buffers[0]->mutable_data(), d_out_valid,
+                                       static_cast<size_t>(arrow::bit_util::BytesForBits(out_len)),
+                                       hipMemcpyDeviceToHost, st));
+    }
+  }
+  HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+  g_gpu_calls.fetch_add(1, std::memory_order_relaxed);
+  return Status::OK();
+}
+
+// ---------------------------------------------------------------- take
+StockKernel g_stock_take;
+
+arrow::Result<std::unique_ptr<cp::KernelState>> TakeInit(cp::KernelContext* ctx,
+                                                         const cp::KernelInitArgs& args) {
+  auto state = std::make_unique<ShimState<cp::TakeOptions>>();
+  if (g_stock_take.init) {
+    ARROW_ASSIGN_OR_RAISE(state->stock, g_stock_take.init(ctx, args));
+  }
+  if (args.options != nullptr) state->options = *static_cast<const cp::TakeOptions*>(args.options);
+  return state;
+}
+
+int IndexTypeId(const arrow::DataType& t) {
+  switch (t.id()) {
+    case Type::UINT8: return ARX_UINT8;
+    case Type::INT8: return ARX_INT8;
+    case Type::UINT16: return ARX_UINT16;
+    case Type::INT16: return ARX_INT16;
+    case Type::UINT32: return ARX_UINT32;
+    case Type::INT32: return ARX_INT32;
+    case Type::UINT64: return ARX_UINT64;
+    case Type::INT64: return ARX_INT64;
+    default: return -1;
+  }
+}
+
+// FixedWidthTakeExec (vector_selection_take_internal.cc:405-468) with the gather on the GPU.
+Status TakeExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResult* out) {
+  auto* state = static_cast<ShimState<cp::TakeOptions>*>(ctx->state());
+  const ArraySpan& values = batch[0].array;
+  const ArraySpan& indices = batch[1].array;
+  const int w = FixedByteWidth(*values.type);
+  const int tid = IndexTypeId(*indices.type);
+  static const int kIdxWidth[8] = {1, 1, 2, 2, 4, 4, 8, 8};
+  if (w == 0 || tid < 0 || indices.length < g_min_rows.load() || !IsHost(values) || !IsHost(indices)) {
+    return RunStock(g_stock_take, state->stock.get(), ctx, batch, out);
+  }
+  hipStream_t st;
+  ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+  ArxSpan dv{}, di{};
+  ARROW_RETURN_NOT_OK(Upload(values, w, kValues, kValidity, st, &dv));
+  ARROW_RETURN_NOT_OK(Upload(indices, kIdxWidth[tid], kArg2, kArg2Validity, st, &di));
+  if (state->options.boundscheck) {
+    void* ws = nullptr;
+    ARROW_RETURN_NOT_OK(t_scratch.Get(kWs, arx_take_workspace_bytes(), &ws));
+    ARROW_RETURN_NOT_OK(FromArx(arx_check_index_bounds(&di, tid, static_cast<uint64_t>(values.length), ws,
+                                                       arx_take_workspace_bytes(), st)));
+  }
+  const int64_t m = indices.length;
+  const bool allocate_validity = values.MayHaveNulls() || indices.MayHaveNulls();
+  ArrayData* out_arr = out->array_data().get();
+  out_arr->length = m;
+  out_arr->buffers.resize(2);
+  ARROW_ASSIGN_OR_RAISE(out_arr->buffers[1], ctx->Allocate(m * w));
+  void* d_out = nullptr;
+  void* d_out_valid = nullptr;
+  void* d_counter = nullptr;
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kOutData, static_cast<size_t>(m) * w + 16, &d_out));
+  if (allocate_validity) {
+    ARROW_ASSIGN_OR_RAISE(out_arr->buffers[0], ctx->AllocateBitmap(m));
+    ARROW_RETURN_NOT_OK(t_scratch.Get(kOutValidity, static_cast<size_t>((m + 63) / 64) * 8 + 16, &d_out_valid));
+    ARROW_RETURN_NOT_OK(t_scratch.Get(kCounter, 64, &d_counter));
+    HIP_RETURN_NOT_OK(hipMemsetAsync(d_counter, 0, 8, st));
+  } else {
+    out_arr->buffers[0] = nullptr;
+  }
+  ARROW_RETURN_NOT_OK(FromArx(arx_take(&dv, w, &di, tid, d_out, d_out_valid,
+                                       static_cast<int64_t*>(d_counter), st)));
+  HIP_RETURN_NOT_OK(hipMemcpyAsync(out_arr->buffers[1]->mutable_data(), d_out, static_cast<size_t>(m) * w,
+                                   hipMemcpyDeviceToHost, st));
+  int64_t valid_count = m;
+  if (allocate_validity) {
+    HIP_RETURN_NOT_OK(hipMemcpyAsync(out_arr->buffers[0]->mutable_data(), d_out_valid,
+                                     static_cast<size_t>(arrow::bit_util::BytesForBits(m)),
+                                     hipMemcpyDeviceToHost, st));
+    HIP_RETURN_NOT_OK(hipMemcpyAsync(&valid_count, d_counter, 8, hipMemcpyDeviceToHost, st));
+  }
+  HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+  out_arr->null_count = m - valid_count;
+  g_gpu_calls.fetch_add(1, std::memory_order_relaxed);
+  return Status::OK();
+}
+
+// ---------------------------------------------------------------- greater(double, double)
+StockKernel g_stock_greater;
+
+// ComparePrimitiveArrayArray<DoubleType, Greater> (scalar_compare.cc:165-190); validity is
+// handled by the ScalarExecutor (NullHandling::INTERSECTION), the output bitmap is preallocated.
+Status GreaterExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResult* out) {
+  if (!batch[0].is_array() || !batch[1].is_array() || !out->is_array_span() ||
+      out->array_span()->offset != 0 || batch.length < g_min_rows.load() ||
+      !IsHost(batch[0].array) || !IsHost(batch[1].array)) {
+    g_stock_calls.fetch_add(1, std::memory_order_relaxed);
+    return g_stock_greater.exec(ctx, batch, out);
+  }
+  const ArraySpan& l = batch[0].array;
+  const ArraySpan& r = batch[1].array;
+  const int64_t n = batch.length;
+  hipStream_t st;
+  ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+  void *dl = nullptr, *dr = nullptr, *dout = nullptr;
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kValues, static_cast<size_t>(n) * 8, &dl));
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kArg2, static_cast<size_t>(n) * 8, &dr));
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kOutData, static_cast<size_t>((n + 63) / 64) * 8, &dout));
+  HIP_RETURN_NOT_OK(hipMemcpyAsync(dl, l.GetValues<double>(1), static_cast<size_t>(n) * 8, hipMemcpyHostToDevice, st));
+  HIP_RETURN_NOT_OK(hipMemcpyAsync(dr, r.GetValues<double>(1), static_cast<size_t>(n) * 8, hipMemcpyHostToDevice, st));
+  ARROW_RETURN_NOT_OK(FromArx(arx_greater_f64(static_cast<const double*>(dl), static_cast<const double*>(dr), n,
+                                              static_cast<uint64_t*>(dout), st)));
+  ArraySpan* o = out->array_span_mutable();
+  HIP_RETURN_NOT_OK(hipMemcpyAsync(o->buffers[1].data, dout, static_cast<size_t>(arrow::bit_util::BytesForBits(n)),
+                                   hipMemcpyDeviceToHost, st));
+  HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+  g_gpu_calls.fetch_add(1, std::memory_order_relaxed);
+  return Status::OK();
+}
+
+// ---------------------------------------------------------------- array_sort_indices(uint64|int64)
+StockKernel g_stock_sort_u64, g_stock_sort_i64;
+
+arrow::Result<std::unique_ptr<cp::KernelState>> SortInitImpl(const StockKernel& stock,
+                                                             cp::KernelContext* ctx,
+                                                             const cp::KernelInitArgs& args) {
+  auto state = std::make_unique<ShimState<cp::ArraySortOptions>>();
+  if (stock.init) {
+    ARROW_ASSIGN_OR_RAISE(state->stock, stock.init(ctx, args));
+  }
+  if (args.options != nullptr) state->options = *static_cast<const cp::ArraySortOptions*>(args.options);
+  return state;
+}
+arrow::Result<std::unique_ptr<cp::KernelState>> SortInitU64(cp::KernelContext* c, const cp::KernelInitArgs& a) {
+  return SortInitImpl(g_stock_sort_u64, c, a);
+}
+arrow::Result<std::unique_ptr<cp::KernelState>> SortInitI64(cp::KernelContext* c, const cp::KernelInitArgs& a) {
+  return SortInitImpl(g_stock_sort_i64, c, a);
+}
+
+// ArraySortIndices::Exec (vector_array_sort.cc:524-540): output uint64 is preallocated.
+Status SortExecImpl(const StockKernel& stock, bool is_signed, cp::KernelContext* ctx,
+                    const cp::ExecSpan& batch, cp::ExecResult* out) {
+  auto* state = static_cast<ShimState<cp::ArraySortOptions>*>(ctx->state());
+  const ArraySpan& values = batch[0].array;
+  if (values.length < g_min_rows.load() || !IsHost(values)) {
+    return RunStock(stock, state->stock.get(), ctx, batch, out);
+  }
+  hipStream_t st;
+  ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+  ArxSpan dv{};
+  ARROW_RETURN_NOT_OK(Upload(values, 8, kValues, kValidity, st, &dv));
+  const int64_t n = values.length;
+  const size_t ws_bytes = arx_sort_indices_workspace_bytes(n);
+  void *ws = nullptr, *dout = nullptr;
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kWs, ws_bytes, &ws));
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kOutData, static_cast<size_t>(n) * 8, &dout));
+  const int order = state->options.order == cp::SortOrder::Descending ? ARX_SORT_DESCENDING : ARX_SORT_ASCENDING;
+  const int placement = state->options.null_placement == cp::NullPlacement::AtStart ? ARX_NULLS_AT_START
+                                                                                    : ARX_NULLS_AT_END;
+  ARROW_RETURN_NOT_OK(FromArx(arx_sort_indices_64(&dv, is_signed ? 1 : 0, order, placement, ws, ws_bytes,
+                                                  static_cast<uint64_t*>(dout), st)));
+  uint64_t* host_out = nullptr;
+  if (out->is_array_span()) {
+    host_out = out->array_span_mutable()->GetValues<uint64_t>(1);
+  } else {
+    host_out = out->array_data()->GetMutableValues<uint64_t>(1);
+  }
+  HIP_RETURN_NOT_OK(hipMemcpyAsync(host_out, dout, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost, st));
+  HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+  g_gpu_calls.fetch_add(1, std::memory_order_relaxed);
+  return Status::OK();
+}
+Status SortExecU64(cp::KernelContext* c, const cp::ExecSpan& b, cp::ExecResult* o) {
+  return SortExecImpl(g_stock_sort_u64, false, c, b, o);
+}
+Status SortExecI64(cp::KernelContext* c, const cp::ExecSpan& b, cp::ExecResult* o) {
+  return SortExecImpl(g_stock_sort_i64, true, c, b, o);
+}
+
+// ---------------------------------------------------------------- registration
+std::vector<std::shared_ptr<arrow::DataType>> FilterValueTypes() {
+  return {arrow::int8(), arrow::uint8(), arrow::int16(), arrow::uint16(), arrow::int32(), arrow::uint32(),
+          arrow::int64(), arrow::uint64(), arrow::float32(), arrow::float64(), arrow::date32(),
+          arrow::date64()};
+}
+
+Status RegisterVector(cp::FunctionRegistry* reg, const std::string& name,
+                      const std::vector<std::shared_ptr<arrow::DataType>>& first_types,
+                      const std::vector<cp::InputType>& second, cp::KernelInit init,
+                      cp::ArrayKernelExec exec, StockKernel* stock) {
+  ARROW_ASSIGN_OR_RAISE(auto fn, reg->GetFunction(name));
+  if (fn->kind() != cp::Function::VECTOR) return Status::Invalid(name, " is not a vector function");
+  auto* vfn = static_cast<cp::VectorFunction*>(fn.get());
+  for (const auto& t : first_types) {
+    std::vector<arrow::TypeHolder> probe{t};
+    std::vector<cp::InputType> in{cp::InputType(t)};
+    if (!second.empty()) {
+      // probe with a concrete second argument type
+      probe.push_back(name == "array_filter" ? arrow::boolean() : arrow::int32());
+    }
+    ARROW_ASSIGN_OR_RAISE(const cp::Kernel* k0, vfn->DispatchExact(probe));
+    cp::VectorKernel copy = *static_cast<const cp::VectorKernel*>(k0);
+    if (stock->exec == nullptr) {
+      stock->exec = copy.exec;
+      stock->init = copy.init;
+    } else if (stock->exec != copy.exec) {
+      continue;  // a different stock kernel handles this type: leave it alone
+    }
+    for (const auto& s : second) in.push_back(s);
+    copy.signature = cp::KernelSignature::Make(in, copy.signature->out_type());
+    copy.init = init;
+    copy.exec = exec;
+    ARROW_RETURN_NOT_OK(vfn->AddKernel(std::move(copy)));
+  }
+  return Status::OK();
+}
+
+Status RegisterAll() {
+  ARROW_RETURN_NOT_OK(cp::Initialize());
+  const int ndev = arx_device_count();
+  if (ndev < 1) {
+    return Status::Invalid("arrow_amd: no HIP device visible (", arx_last_error(),
+                           "); nothing registered, Arrow keeps its stock kernels");
+  }
+  cp::FunctionRegistry* reg = cp::GetFunctionRegistry();
+  ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_filter", FilterValueTypes(), {cp::InputType(arrow::boolean())},
+                                     FilterInit, FilterExec, &g_stock_filter));
+  ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_take", FilterValueTypes(),
+                                     {cp::InputType(cp::match::Integer())}, TakeInit, TakeExec,
+                                     &g_stock_take));
+  ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_sort_indices", {arrow::uint64()}, {}, SortInitU64, SortExecU64,
+                                     &g_stock_sort_u64));
+  ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_sort_indices", {arrow::int64()}, {}, SortInitI64, SortExecI64,
+                                     &g_stock_sort_i64));
+  {
+    ARROW_ASSIGN_OR_RAISE(auto fn, reg->GetFunction("greater"));
+    auto* sfn = static_cast<cp::ScalarFunction*>(fn.get());
+    ARROW_ASSIGN_OR_RAISE(const cp::Kernel* k0, sfn->DispatchExact({arrow::float64(), arrow::float64()}));
+    cp::ScalarKernel copy = *static_cast<const cp::ScalarKernel*>(k0);
+    g_stock_greater.exec = copy.exec;
+    g_stock_greater.init = copy.init;
+    copy.exec = GreaterExec;
+    ARROW_RETURN_NOT_OK(sfn->AddKernel(std::move(copy)));
+  }
+  return Status::OK();
+}
+
+std::once_flag g_once;
+Status g_register_status;
+
+}  // namespace
+
+extern "C" {
+
+// Registers the MI355X kernels on Arrow's global registry (idempotent).  0 on success.
+int arrow_amd_register(void) {
+  std::call_once(g_once, [] { g_register_status = RegisterAll(); });
+  if (!g_register_status.ok()) {
+    t_error = g_register_status.ToString();
+    return -1;
+  }
+  return 0;
+}
+const char* arrow_amd_plugin_last_error(void) { return t_error.c_str(); }
+int64_t arrow_amd_plugin_gpu_calls(void) { return g_gpu_calls.load(); }
+int64_t arrow_amd_plugin_stock_calls(void) { return g_stock_calls.load(); }
+// Inputs shorter than this stay on the stock CPU kernels (PCIe staging does not pay).
+void arrow_amd_plugin_set_min_rows(int64_t n) { g_min_rows.store(n); }
+
+}  // extern "C"

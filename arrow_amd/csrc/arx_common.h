@@ -90,6 +90,21 @@ __device__ __forceinline__ uint64_t load_word(const Bits& b, int64_t w) {
   return v;
 }
 
+// Branch-free variant for hot loops (no control flow => the compiler can keep several of these
+// loads in flight).  Requires b.base != NULL and b.nphys >= 1.
+__device__ __forceinline__ uint64_t load_word_nb(const Bits& b, int64_t w) {
+  const int64_t last = b.nphys - 1;
+  const int64_t i0 = w < last ? w : last;
+  const int64_t i1 = (w + 1) < last ? (w + 1) : last;
+  const uint64_t lo = b.base[i0];
+  const uint64_t hi = b.base[i1];
+  const uint64_t v = (lo >> b.shift) | ((hi << 1) << (63 - b.shift));
+  const int64_t remain = b.length - (w << 6);
+  const uint64_t m = remain >= 64 ? ~uint64_t(0)
+                                  : (remain <= 0 ? uint64_t(0) : ((uint64_t(1) << remain) - 1));
+  return v & m;
+}
+
 // ---------------------------------------------------------------------------
 // Wave-level primitives (64 lanes)
 // ---------------------------------------------------------------------------
@@ -143,6 +158,19 @@ __device__ __forceinline__ uint64_t pext64(uint64_t x, uint64_t m) {
     mk &= ~mp;
   }
   return x;
+}
+
+// Raw buffer descriptor over [base, base + bytes): loads whose offset falls outside return 0
+// WITHOUT touching memory, which turns "skip this lane" into a plain offset select (no exec
+// masking, no branch) and lets the compiler keep several loads in flight with counted vmcnt.
+// `base` must be wave-uniform (the descriptor lives in SGPRs).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), /*stride=*/0,
+                                           static_cast<int>(bytes), /*flags=*/0x00020000);
+}
+constexpr uint32_t kBufferSkip = 0x80000000u;  // an offset no descriptor of ours covers
+__device__ __forceinline__ uint4 buffer_load_b128(__amdgpu_buffer_rsrc_t r, uint32_t byte_offset) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_offset, 0, 0));
 }
 
 // Spread the low 32 bits of x to the even bit positions of a 64-bit word.

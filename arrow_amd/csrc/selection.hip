@@ -224,40 +224,173 @@ __device__ __forceinline__ void flush_region(const uint8_t* ring, uint8_t* gbase
   }
 }
 
-// W     : element width in bytes
-// IOTA  : emit row numbers instead of loaded values (GetTakeIndices)
-// B     : iterations whose loads are issued back to back before any is consumed
-// DENSE : load every granule (pure stream) instead of only granules holding an emitted row
-template <int W, bool IOTA, int B, bool DENSE>
+// One batch of B wave-iterations: which rows of this lane's granules are emitted, their output
+// ranks, and the (in-flight) granule loads.
+template <int W, int B>
+struct Batch {
+  using E = typename ElemT<W>::type;
+  static constexpr int R = 16 / W;
+  uint32_t bits[B];
+  uint32_t zbits[B];
+  uint32_t rank[B];
+  E v[B][R];
+};
+
+// Word `widx_base + q` of a per-lane 64-bit value, where q = lane / (64 / R) differs between lane
+// groups: R wave-uniform v_readlane pairs + selects instead of a ds_bpermute round trip.
+template <int R, bool EMIT>
+__device__ __forceinline__ void select_words(uint64_t Ew, uint32_t p, uint64_t Zw,
+                                             int widx_base, int lane, uint64_t* wE, uint32_t* wp,
+                                             uint64_t* wZ) {
+  constexpr int kLanesPerWord = 64 / R;
+  const int q_mine = lane / kLanesPerWord;
+  uint64_t e = 0, z = 0;
+  uint32_t pp = 0;
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int src = widx_base + q;  // wave-uniform
+    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(Ew), src);
+    const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(Ew >> 32), src);
+    const uint32_t pq = __builtin_amdgcn_readlane(p, src);
+    uint64_t zq = 0;
+    if constexpr (EMIT) {
+      const uint32_t zlo = __builtin_amdgcn_readlane(static_cast<uint32_t>(Zw), src);
+      const uint32_t zhi = __builtin_amdgcn_readlane(static_cast<uint32_t>(Zw >> 32), src);
+      zq = (static_cast<uint64_t>(zhi) << 32) | zlo;
+    }
+    if (q == q_mine) {
+      e = (static_cast<uint64_t>(hi) << 32) | lo;
+      pp = pq;
+      z = zq;
+    }
+  }
+  *wE = e;
+  *wp = pp;
+  *wZ = z;
+}
+
+struct TileCtx {
+  uint64_t Ew, Zw;
+  uint32_t p;
+  int lane;
+  int64_t tile_row0;
+  const uint8_t* values;
+  __amdgpu_buffer_rsrc_t rsrc;  // the 4096 values of this tile (aligned path)
+};
+
+// Issue phase: ranks + granule loads of iterations [j0, j0 + B)
+template <int W, bool IOTA, bool EMIT, bool ALIGNED, int B>
+__device__ __forceinline__ void issue_batch(const TileCtx& c, int j0, Batch<W, B>& b) {
+  using E = typename ElemT<W>::type;
+  constexpr int R = 16 / W;
+  constexpr int kRowsPerIter = kWave * R;
+#pragma unroll
+  for (int i = 0; i < B; ++i) {
+    const int j = j0 + i;
+    const int row_in_tile = j * kRowsPerIter + c.lane * R;
+    const int bpos = row_in_tile & 63;
+    uint64_t wE, wZ;
+    uint32_t wp;
+    select_words<R, EMIT>(c.Ew, c.p, c.Zw, j * R, c.lane, &wE, &wp, &wZ);
+    b.bits[i] = static_cast<uint32_t>(wE >> bpos) & ((1u << R) - 1u);
+    b.zbits[i] = static_cast<uint32_t>(wZ >> bpos) & ((1u << R) - 1u);
+    b.rank[i] = wp + __popcll(wE & low_mask64(bpos));
+    if constexpr (IOTA) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) b.v[i][r] = static_cast<E>(c.tile_row0 + row_in_tile + r);
+    } else {
+      const int64_t row = c.tile_row0 + row_in_tile;
+      const uint8_t* src = c.values + row * static_cast<int64_t>(W);
+      if constexpr (ALIGNED) {
+        // One 16-byte buffer load per lane.  Lanes with no emitted row get an out-of-range offset:
+        // the hardware returns 0 without a memory access, so 128-byte lines holding no selected
+        // row are never fetched from HBM, and there is no branch to wait at.
+        const uint32_t voff = b.bits[i] != 0 ? static_cast<uint32_t>(row_in_tile * W) : kBufferSkip;
+        const uint4 q = buffer_load_b128(c.rsrc, voff);
+        if constexpr (W == 16) {
+          b.v[i][0] = q;
+        } else {
+          const E* qe = reinterpret_cast<const E*>(&q);
+#pragma unroll
+          for (int r = 0; r < R; ++r) b.v[i][r] = qe[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          b.v[i][r] = zero_elem<W>();
+          if ((b.bits[i] >> r) & 1u) {
+            if constexpr (W == 16) {
+              const uint64_t* s64 = reinterpret_cast<const uint64_t*>(src + r * W);
+              const uint64_t lo64 = s64[0], hi64 = s64[1];
+              b.v[i][r] = make_uint4(static_cast<uint32_t>(lo64), static_cast<uint32_t>(lo64 >> 32),
+                                     static_cast<uint32_t>(hi64), static_cast<uint32_t>(hi64 >> 32));
+            } else {
+              b.v[i][r] = *reinterpret_cast<const E*>(src + r * W);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// Consume phase: emitted elements go to the LDS ring at their output rank
+template <int W, int B, int RING>
+__device__ __forceinline__ void consume_batch(const Batch<W, B>& b, uint8_t* ring, int64_t a0) {
+  using E = typename ElemT<W>::type;
+  constexpr int R = 16 / W;
+#pragma unroll
+  for (int i = 0; i < B; ++i) {
+    if (b.bits[i] != 0) {
+      uint32_t rk = b.rank[i];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if ((b.bits[i] >> r) & 1u) {
+          E e = b.v[i][r];
+          if ((b.zbits[i] >> r) & 1u) e = zero_elem<W>();
+          const int ro = static_cast<int>((a0 + static_cast<int64_t>(rk) * W) & (RING - 1));
+          *reinterpret_cast<E*>(ring + ro) = e;
+          ++rk;
+        }
+      }
+    }
+  }
+}
+
+// W       : element width in bytes
+// IOTA    : emit row numbers instead of loaded values (GetTakeIndices)
+// EMIT    : FilterOptions::EMIT_NULL with a nullable mask (null mask slots emit zero-filled nulls)
+// ALIGNED : the values pointer is 16-byte aligned (one buffer_load_dwordx4 per lane)
+// B       : wave-iterations per batch (loads of a batch are issued back to back)
+// PIPE    : software pipeline - the loads of batch k+1 are in flight while batch k is consumed
+template <int W, bool IOTA, bool EMIT, bool ALIGNED, int B, bool PIPE>
 __global__ __launch_bounds__(kBlock) void compact_kernel(CompactArgs a) {
   using E = typename ElemT<W>::type;
   constexpr int R = 16 / W;                // rows per lane per iteration (one 16-byte granule)
   constexpr int kRowsPerIter = kWave * R;  // rows per wave iteration
   constexpr int kIters = kTileRows / kRowsPerIter;
   constexpr int kWordsPerIter = kRowsPerIter / 64;  // == R
-  constexpr int RING = (B <= 2) ? 4096 : 8192;      // pending < 2 KiB + B KiB
+  constexpr int kBatches = kIters / B;
+  constexpr int RING = (B <= 2) ? 4096 : 8192;  // pending < 2 KiB + B KiB
   static_assert(kIters % B == 0, "batch must divide the iteration count");
+  static_assert(!PIPE || kBatches % 2 == 0, "pipelined form walks the batches in pairs");
 
   __shared__ CompactLds<RING> lds;
 
   const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
   if (t >= a.ntiles) return;  // wave-uniform; no workgroup barrier below
-  const bool emit = a.emit_null != 0;
 
   // ---- per-lane mask words of this tile
   const int64_t w = t * 64 + lane;
   uint64_t mv;
-  const uint64_t Ew = emit_word(a.mask, a.mvalid, w, emit, a.invert != 0, &mv);
+  const uint64_t Ew = emit_word(a.mask, a.mvalid, w, EMIT, a.invert != 0, &mv);
   const uint32_t k = __popcll(Ew);
   const uint32_t incl = wave_inclusive_scan_u32(k);
   const uint32_t p = incl - k;  // emitted rows in this tile before this lane's word
   const uint32_t total = __shfl(incl, 63, 64);
   if (total == 0) return;
-
-  // rows emitted only because the mask slot is null: zero-filled (WriteNull)
-  const uint64_t Zw = emit ? (Ew & ~mv) : 0;
 
   // ---- output offset of this tile: group prefix + counts of earlier tiles in the group
   const int64_t grp = t >> 6;
@@ -265,87 +398,29 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(CompactArgs a) {
   const uint32_t cprev = lane < tin ? a.tile_counts[grp * kTilesPerGroup + lane] : 0u;
   const int64_t off = a.group_excl[grp] + wave_reduce_sum_u32(cprev);
 
-  // ---- LDS ring: logical byte x of the ring <-> global byte (gbase + x)
+  // ---- LDS ring: logical byte x of the ring <-> global byte (gbase + x); gbase is 2 KiB aligned
   uint8_t* ring = lds.ring[wave];
-  const uint64_t G0 = reinterpret_cast<uint64_t>(a.out_data) + static_cast<uint64_t>(off) * W;
-  const int64_t a0 = static_cast<int64_t>(G0 & (kFlushBytes - 1));
-  uint8_t* gbase = reinterpret_cast<uint8_t*>(G0 - a0);
+  const int64_t a0 =
+      static_cast<int64_t>((reinterpret_cast<uint64_t>(a.out_data) + static_cast<uint64_t>(off) * W) &
+                           (kFlushBytes - 1));
+  uint8_t* gbase = a.out_data + (off * static_cast<int64_t>(W) - a0);  // stays a global pointer
   int64_t flushed = 0;
 
-  const int64_t tile_row0 = t * kTileRows;
+  TileCtx c;
+  c.Ew = Ew;
+  c.Zw = EMIT ? (Ew & ~mv) : 0;  // rows emitted only because the mask slot is null: zero-filled
+  c.p = p;
+  c.lane = lane;
+  c.tile_row0 = t * kTileRows;
+  c.values = a.values;
+  c.rsrc = make_rsrc(IOTA ? nullptr : a.values + c.tile_row0 * static_cast<int64_t>(W),
+                     static_cast<uint32_t>(kTileRows * W));
 
-  for (int j0 = 0; j0 < kIters; j0 += B) {
-    uint32_t bits[B], zbits[B], rank[B];
-    E v[B][R];
-    // -- issue phase: ranks + loads of B iterations
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const int row_in_tile = (j0 + b) * kRowsPerIter + lane * R;
-      const int widx = row_in_tile >> 6;
-      const int bpos = row_in_tile & 63;
-      const uint64_t wE = shfl_u64(Ew, widx);
-      const uint32_t wp = __shfl(p, widx, 64);
-      bits[b] = static_cast<uint32_t>(wE >> bpos) & ((1u << R) - 1u);
-      zbits[b] = 0;
-      if (emit) zbits[b] = static_cast<uint32_t>(shfl_u64(Zw, widx) >> bpos) & ((1u << R) - 1u);
-      rank[b] = wp + __popcll(wE & low_mask64(bpos));
-      if constexpr (IOTA) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) v[b][r] = static_cast<E>(tile_row0 + row_in_tile + r);
-      } else {
-        const int64_t row = tile_row0 + row_in_tile;
-        const uint8_t* src = a.values + row * static_cast<int64_t>(W);
-        if (a.values_aligned16) {
-          // one 16-byte load per lane.  Sparse mode: lanes with no emitted row issue nothing,
-          // so untouched 64-byte sectors are never fetched from HBM.
-          const bool do_load = DENSE ? (row < a.length) : (bits[b] != 0);
-          uint4 q = make_uint4(0, 0, 0, 0);
-          if (do_load) q = *reinterpret_cast<const uint4*>(src);
-          if constexpr (W == 16) {
-            v[b][0] = q;
-          } else {
-            const E* qe = reinterpret_cast<const E*>(&q);
-#pragma unroll
-            for (int r = 0; r < R; ++r) v[b][r] = qe[r];
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            v[b][r] = zero_elem<W>();
-            if ((bits[b] >> r) & 1u) {
-              if constexpr (W == 16) {
-                const uint64_t* s64 = reinterpret_cast<const uint64_t*>(src + r * W);
-                const uint64_t lo64 = s64[0], hi64 = s64[1];
-                v[b][r] = make_uint4(static_cast<uint32_t>(lo64), static_cast<uint32_t>(lo64 >> 32),
-                                     static_cast<uint32_t>(hi64), static_cast<uint32_t>(hi64 >> 32));
-              } else {
-                v[b][r] = *reinterpret_cast<const E*>(src + r * W);
-              }
-            }
-          }
-        }
-      }
-    }
-    // -- consume phase: emitted elements go to the ring at their output rank
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      if (bits[b] != 0) {
-        uint32_t rk = rank[b];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          if ((bits[b] >> r) & 1u) {
-            E e = v[b][r];
-            if ((zbits[b] >> r) & 1u) e = zero_elem<W>();
-            const int ro = static_cast<int>((a0 + static_cast<int64_t>(rk) * W) & (RING - 1));
-            *reinterpret_cast<E*>(ring + ro) = e;
-            ++rk;
-          }
-        }
-      }
-    }
-
-    // ---- wave-uniform flush decision: elements emitted through iteration j0 + B - 1
-    const uint32_t cum = (j0 + B < kIters) ? __shfl(p, (j0 + B) * kWordsPerIter, 64) : total;
+  auto flush_check = [&](int next_batch) {
+    // wave-uniform: elements emitted through the batches consumed so far
+    const uint32_t cum = next_batch < kBatches
+                             ? __builtin_amdgcn_readlane(p, next_batch * B * kWordsPerIter)
+                             : total;
     const int64_t written = a0 + static_cast<int64_t>(cum) * W;
     if (written - flushed >= kFlushBytes) {
       wave_lds_sync();
@@ -354,6 +429,58 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(CompactArgs a) {
         flushed += kFlushBytes;
       }
       wave_lds_sync();
+    }
+  };
+
+  // GetTakeIndices at low selectivity: when the whole tile's output fits the ring, every lane
+  // just walks the set bits of its own mask word (a handful of iterations) instead of the
+  // 4096-row sweep below.
+  bool tile_done = false;
+  if constexpr (IOTA) {
+    if (a0 + static_cast<int64_t>(total) * W <= RING) {  // wave-uniform
+      uint64_t m = Ew;
+      uint32_t rk = p;
+      while (m != 0) {
+        const int bpos = __ffsll(static_cast<unsigned long long>(m)) - 1;
+        m &= m - 1;
+        E val = static_cast<E>(c.tile_row0 + lane * 64 + bpos);
+        if constexpr (EMIT) {
+          if ((c.Zw >> bpos) & 1ull) val = 0;
+        }
+        *reinterpret_cast<E*>(ring + a0 + static_cast<int64_t>(rk) * W) = val;
+        ++rk;
+      }
+      tile_done = true;
+    }
+  }
+
+  if (tile_done) {
+    // nothing else to stage
+  } else if constexpr (PIPE) {
+    // two batches of loads in flight; the last pair is peeled so that the loop body has no
+    // conditional issue (the vmcnt bookkeeping stays exact: 2B loads outstanding at each wait)
+    Batch<W, B> b0, b1;
+    issue_batch<W, IOTA, EMIT, ALIGNED, B>(c, 0, b0);
+    int jb = 0;
+    for (; jb + 2 < kBatches; jb += 2) {
+      issue_batch<W, IOTA, EMIT, ALIGNED, B>(c, (jb + 1) * B, b1);
+      consume_batch<W, B, RING>(b0, ring, a0);
+      flush_check(jb + 1);
+      issue_batch<W, IOTA, EMIT, ALIGNED, B>(c, (jb + 2) * B, b0);
+      consume_batch<W, B, RING>(b1, ring, a0);
+      flush_check(jb + 2);
+    }
+    issue_batch<W, IOTA, EMIT, ALIGNED, B>(c, (jb + 1) * B, b1);
+    consume_batch<W, B, RING>(b0, ring, a0);
+    flush_check(jb + 1);
+    consume_batch<W, B, RING>(b1, ring, a0);
+    flush_check(jb + 2);
+  } else {
+    for (int jb = 0; jb < kBatches; ++jb) {
+      Batch<W, B> b0;
+      issue_batch<W, IOTA, EMIT, ALIGNED, B>(c, jb * B, b0);
+      consume_batch<W, B, RING>(b0, ring, a0);
+      flush_check(jb + 1);
     }
   }
 
@@ -376,21 +503,21 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(CompactArgs a) {
 
     const uint64_t vv = load_word(a.vvalid, w);
     const uint64_t Vs = vv & mv;  // DROP: emitted rows have mv = 1; EMIT_NULL: null mask -> null
-    uint64_t c;
+    uint64_t cbits;
     if (__any((Ew & ~Vs) != 0)) {
-      c = pext64(Vs, Ew);
+      cbits = pext64(Vs, Ew);
     } else {
-      c = low_mask64(static_cast<int>(k));
+      cbits = low_mask64(static_cast<int>(k));
     }
     const int64_t obit = (off & 63) + p;  // bit position inside the tile-local LDS bitmap
     const int word = static_cast<int>(obit >> 6);
     const int sh = static_cast<int>(obit & 63);
     if (k != 0) {
       atomicOr(reinterpret_cast<unsigned long long*>(&vb[word]),
-               static_cast<unsigned long long>(c << sh));
+               static_cast<unsigned long long>(cbits << sh));
       if (sh != 0 && (sh + static_cast<int>(k)) > 64) {
         atomicOr(reinterpret_cast<unsigned long long*>(&vb[word + 1]),
-                 static_cast<unsigned long long>(c >> (64 - sh)));
+                 static_cast<unsigned long long>(cbits >> (64 - sh)));
       }
     }
     wave_lds_sync();
@@ -432,68 +559,70 @@ struct TakeArgs {
   unsigned long long* valid_count; // may be NULL
 };
 
-template <typename IdxT>
-__device__ __forceinline__ uint64_t load_index(const uint8_t* p, int64_t i) {
-  return static_cast<uint64_t>(reinterpret_cast<const IdxT*>(p)[i]);
-}
-
-template <int W, typename IdxT>
+// Every load below is unconditional: lanes that must not gather (row past the end, null index,
+// null source value) read a harmless in-bounds address instead — their own output slot — and the
+// result is discarded.  With no branches the compiler issues the U index loads, then the U
+// validity probes, then the U gathers back to back (3 dependent round trips per 64*U rows).
+template <int W, typename IdxT, bool HAS_IV, bool HAS_SV>
 __global__ __launch_bounds__(kBlock) void take_kernel(TakeArgs a) {
   using E = typename ElemT<W>::type;
-  constexpr int U = 4;  // independent gathers in flight per lane
+  constexpr int U = 8;  // independent gathers in flight per lane
   const int lane = lane_id();
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock +
+                         __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nchunks = (a.length + 64 * U - 1) / (64 * U);
+  const int64_t last = a.length - 1;
+  const IdxT* __restrict__ indices = reinterpret_cast<const IdxT*>(a.indices);
+  const E* __restrict__ values = reinterpret_cast<const E*>(a.values);
+  E* __restrict__ out = reinterpret_cast<E*>(a.out_data);
   uint64_t nvalid = 0;
   for (int64_t c = wave_g; c < nchunks; c += nwaves) {
     const int64_t base = c * (64 * U);
+    int64_t pos[U];
     uint64_t idx[U];
     bool ok[U];
-    E val[U];
-    // index validity words for the U x 64 rows of this chunk (wave-uniform addresses)
-    uint64_t ivw[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) ivw[u] = load_word(a.ivalid, (base >> 6) + u);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t pos = base + u * 64 + lane;
-      const bool in = pos < a.length;
-      idx[u] = in ? load_index<IdxT>(a.indices, pos) : 0;
-      ok[u] = in && ((ivw[u] >> lane) & 1ull);
+      const int64_t p = base + u * 64 + lane;
+      pos[u] = p <= last ? p : last;  // clamped: always a readable/writable slot
+      idx[u] = static_cast<uint64_t>(indices[pos[u]]);
     }
-    if (a.src_valid_bytes != nullptr) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ok[u] = (base + u * 64 + lane) <= last;
+      if constexpr (HAS_IV) {
+        const uint64_t wbits = load_word_nb(a.ivalid, (base >> 6) + u);
+        ok[u] = ok[u] && ((wbits >> lane) & 1ull);
+      }
+    }
+    if constexpr (HAS_SV) {
+      uint8_t vb[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (ok[u]) {
-          const uint64_t bit = static_cast<uint64_t>(a.src_valid_offset) + idx[u];
-          ok[u] = (a.src_valid_bytes[bit >> 3] >> (bit & 7)) & 1;
-        }
+        const uint64_t bit = ok[u] ? static_cast<uint64_t>(a.src_valid_offset) + idx[u] : 0;
+        vb[u] = a.src_valid_bytes[bit >> 3];
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t bit = static_cast<uint64_t>(a.src_valid_offset) + idx[u];
+        ok[u] = ok[u] && ((vb[u] >> (bit & 7)) & 1);
+      }
+    }
+    E val[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const E* src = ok[u] ? (values + idx[u]) : (out + pos[u]);
+      val[u] = *src;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (ok[u]) {
-        if constexpr (W == 16) {
-          const uint64_t* s64 = reinterpret_cast<const uint64_t*>(a.values + idx[u] * 16);
-          const uint64_t lo64 = s64[0], hi64 = s64[1];
-          val[u] = make_uint4(static_cast<uint32_t>(lo64), static_cast<uint32_t>(lo64 >> 32),
-                              static_cast<uint32_t>(hi64), static_cast<uint32_t>(hi64 >> 32));
-        } else {
-          val[u] = reinterpret_cast<const E*>(a.values)[idx[u]];
-        }
-      } else {
-        val[u] = zero_elem<W>();
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t pos = base + u * 64 + lane;
-      if (pos < a.length) reinterpret_cast<E*>(a.out_data)[pos] = val[u];
-      const uint64_t vb = __ballot(ok[u]);
-      nvalid += __popcll(vb);
-      if (a.out_validity != nullptr && lane == 0 && (base + u * 64) < a.length) {
-        a.out_validity[(base >> 6) + u] = vb;
+      const int64_t p = base + u * 64 + lane;
+      if (p <= last) out[p] = ok[u] ? val[u] : zero_elem<W>();
+      const uint64_t vbal = __ballot(ok[u]);
+      nvalid += __popcll(vbal);
+      if (a.out_validity != nullptr && lane == 0 && (base + u * 64) <= last) {
+        a.out_validity[(base >> 6) + u] = vbal;
       }
     }
   }
@@ -601,33 +730,33 @@ static int launch_count(const ArxSpan* mask, int null_selection, void* ws, size_
   return ARX_OK;
 }
 
-// Tuning knobs (arx_set_option): filter_batch in {1,4}, filter_dense in {0,1}.
+// Tuning knobs (arx_set_option): filter_batch in {1,4}, filter_pipe in {0,1}.  Results never change.
 static int g_filter_batch = 4;
-static int g_filter_dense = 0;
+static int g_filter_pipe = 1;
+
+template <int W, bool IOTA, bool EMIT, bool ALIGNED>
+static void launch_compact_e(const CompactArgs& a, unsigned grid, hipStream_t st) {
+  constexpr int kIters = kTileRows / (kWave * (16 / W));
+  constexpr int kBig = kIters >= 8 ? 4 : 2;  // batch size of the pipelined form (even #batches)
+  if (ALIGNED && g_filter_batch >= 4 && g_filter_pipe) {
+    hipLaunchKernelGGL((compact_kernel<W, IOTA, EMIT, ALIGNED, kBig, true>), dim3(grid),
+                       dim3(kBlock), 0, st, a);
+  } else {
+    // the plain form: one iteration at a time (also the only form of the unaligned path)
+    hipLaunchKernelGGL((compact_kernel<W, IOTA, EMIT, ALIGNED, 1, false>), dim3(grid), dim3(kBlock),
+                       0, st, a);
+  }
+}
 
 template <int W, bool IOTA>
 static void launch_compact_w(const CompactArgs& a, unsigned grid, hipStream_t st) {
-  const int batch = (kTileRows / (kWave * (16 / W))) % 4 == 0 ? g_filter_batch : 1;
-  if constexpr (IOTA) {
-    if (batch >= 4) {
-      hipLaunchKernelGGL((compact_kernel<W, true, 4, false>), dim3(grid), dim3(kBlock), 0, st, a);
-    } else {
-      hipLaunchKernelGGL((compact_kernel<W, true, 1, false>), dim3(grid), dim3(kBlock), 0, st, a);
-    }
+  const bool aligned = IOTA || a.values_aligned16 != 0;
+  if (a.emit_null) {
+    if (aligned) launch_compact_e<W, IOTA, true, true>(a, grid, st);
+    else if constexpr (!IOTA) launch_compact_e<W, IOTA, true, false>(a, grid, st);
   } else {
-    if (batch >= 4) {
-      if (g_filter_dense) {
-        hipLaunchKernelGGL((compact_kernel<W, false, 4, true>), dim3(grid), dim3(kBlock), 0, st, a);
-      } else {
-        hipLaunchKernelGGL((compact_kernel<W, false, 4, false>), dim3(grid), dim3(kBlock), 0, st, a);
-      }
-    } else {
-      if (g_filter_dense) {
-        hipLaunchKernelGGL((compact_kernel<W, false, 1, true>), dim3(grid), dim3(kBlock), 0, st, a);
-      } else {
-        hipLaunchKernelGGL((compact_kernel<W, false, 1, false>), dim3(grid), dim3(kBlock), 0, st, a);
-      }
-    }
+    if (aligned) launch_compact_e<W, IOTA, false, true>(a, grid, st);
+    else if constexpr (!IOTA) launch_compact_e<W, IOTA, false, false>(a, grid, st);
   }
 }
 
@@ -663,8 +792,8 @@ int set_selection_option(const char* name, int64_t value) {
     g_filter_batch = value >= 4 ? 4 : 1;
     return 1;
   }
-  if (strcmp(name, "filter_dense") == 0) {
-    g_filter_dense = value != 0;
+  if (strcmp(name, "filter_pipe") == 0) {
+    g_filter_pipe = value != 0;
     return 1;
   }
   return 0;
@@ -942,15 +1071,24 @@ int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int 
     set_error("take: inputs may have nulls but out_validity is NULL");
     return ARX_INVALID;
   }
-  const int64_t nchunks = ceil_div(indices->length, 256);
+  const int64_t nchunks = ceil_div(indices->length, 512);
   const int64_t blocks = std::min<int64_t>(ceil_div(nchunks, kWavesPerBlock), 256 * 32);
   const dim3 grid(static_cast<unsigned>(blocks)), block(kBlock);
-#define ARX_TAKE_W(WW)                                                                        \
-  switch (iw) {                                                                               \
-    case 1: hipLaunchKernelGGL((take_kernel<WW, uint8_t>), grid, block, 0, st, a); break;     \
-    case 2: hipLaunchKernelGGL((take_kernel<WW, uint16_t>), grid, block, 0, st, a); break;    \
-    case 4: hipLaunchKernelGGL((take_kernel<WW, uint32_t>), grid, block, 0, st, a); break;    \
-    default: hipLaunchKernelGGL((take_kernel<WW, uint64_t>), grid, block, 0, st, a); break;   \
+  const bool has_iv = a.ivalid.base != nullptr;
+  const bool has_sv = a.src_valid_bytes != nullptr;
+#define ARX_TAKE_V(WW, IT)                                                                     \
+  do {                                                                                         \
+    if (has_iv && has_sv) hipLaunchKernelGGL((take_kernel<WW, IT, true, true>), grid, block, 0, st, a);        \
+    else if (has_iv) hipLaunchKernelGGL((take_kernel<WW, IT, true, false>), grid, block, 0, st, a);            \
+    else if (has_sv) hipLaunchKernelGGL((take_kernel<WW, IT, false, true>), grid, block, 0, st, a);            \
+    else hipLaunchKernelGGL((take_kernel<WW, IT, false, false>), grid, block, 0, st, a);                       \
+  } while (0)
+#define ARX_TAKE_W(WW)                      \
+  switch (iw) {                             \
+    case 1: ARX_TAKE_V(WW, uint8_t); break; \
+    case 2: ARX_TAKE_V(WW, uint16_t); break;\
+    case 4: ARX_TAKE_V(WW, uint32_t); break;\
+    default: ARX_TAKE_V(WW, uint64_t); break;\
   }
   switch (byte_width) {
     case 1: ARX_TAKE_W(1); break;
@@ -963,6 +1101,7 @@ int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int 
       return ARX_NOT_IMPLEMENTED;
   }
 #undef ARX_TAKE_W
+#undef ARX_TAKE_V
   ARX_CHECK_LAUNCH("take_kernel");
   return ARX_OK;
 }

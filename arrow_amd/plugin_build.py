@@ -1,0 +1,44 @@
+"""Builds arrow_amd/libarrow_amd_plugin.so: the C++ registration shim (csrc/arrow_plugin.cc)
+compiled with g++ against the installed Arrow (headers + libarrow of the pyarrow wheel) and
+linked to libarrow_amd.so.  Optional: needs the pyarrow wheel; the C ABI does not."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "libarrow_amd_plugin.so")
+SRC = os.path.join(HERE, "csrc", "arrow_plugin.cc")
+
+
+def build_plugin(force: bool = False, verbose: bool = True) -> str:
+    import pyarrow as pa
+
+    d = os.path.dirname(pa.__file__)
+    libs = pa.get_libraries()
+    so = {name: None for name in ("arrow", "arrow_compute")}
+    for f in sorted(os.listdir(d)):
+        for name in so:
+            if f.startswith(f"lib{name}.so.") and f.count(".") == 2:
+                so[name] = os.path.join(d, f)
+    if not all(so.values()):
+        raise RuntimeError(f"libarrow/libarrow_compute not found in {d} ({libs})")
+    core = os.path.join(HERE, "libarrow_amd.so")
+    if not os.path.exists(core):
+        raise RuntimeError("build libarrow_amd.so first")
+    deps = [SRC, core, os.path.join(os.path.dirname(HERE), "include", "arrow_amd.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(x) for x in deps):
+        return OUT
+    cmd = ["g++", "-std=c++20", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
+           "-I", pa.get_include(), "-I", "/opt/rocm/include", SRC, "-o", OUT,
+           so["arrow"], so["arrow_compute"], core, "-L/opt/rocm/lib", "-lamdhip64",
+           f"-Wl,-rpath,{d}", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_plugin(force="--force" in sys.argv))

@@ -84,7 +84,7 @@ const char* arx_last_error(void);
 int arx_abi_version(void);
 /* Number of HIP devices visible, or a negative ArxStatus. */
 int arx_device_count(void);
-/* Process-wide tuning knobs for A/B measurements (e.g. "filter_batch", "filter_dense").
+/* Process-wide tuning knobs for A/B measurements (e.g. "filter_batch", "filter_pipe").
  * Never changes results.  Not part of the reference interface. */
 int arx_set_option(const char* name, int64_t value);
 

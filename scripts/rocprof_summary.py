@@ -1,0 +1,50 @@
+"""Summarise rocprofv3 (rocpd sqlite) output: per-kernel duration stats from a --kernel-trace run
+and per-kernel counter means from --pmc runs.  Usage:
+  python scripts/rocprof_summary.py trace <results.db> [name-filter]
+  python scripts/rocprof_summary.py pmc   <results.db> [name-filter]
+Only dispatches longer than 1/4 of the kernel's longest dispatch are averaged in the `big_*`
+columns (bench.py also launches the same kernels on a small parity sample)."""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name if len(name) <= 88 else name[:85] + "..."
+
+
+def trace(db, flt):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, duration from kernels").fetchall()
+    agg = defaultdict(list)
+    for n, d in rows:
+        if flt in n:
+            agg[n].append(d)
+    total = sum(sum(v) for v in agg.values())
+    print(f"{'kernel':90s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'big_n':>6s} {'big_avg_us':>11s} {'big_min_us':>11s} {'pct':>6s}")
+    for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        big = [x for x in v if x >= max(v) / 4]
+        print(f"{short(n):90s} {len(v):6d} {sum(v) / 1e6:10.3f} {sum(v) / len(v) / 1e3:10.1f} {len(big):6d} "
+              f"{sum(big) / len(big) / 1e3:11.1f} {min(big) / 1e3:11.1f} {100 * sum(v) / total:6.1f}")
+
+
+def pmc(db, flt):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select kernel_name, counter_name, value, duration from counters_collection").fetchall()
+    agg = defaultdict(list)
+    for n, c, v, d in rows:
+        if flt in n:
+            agg[(n, c)].append((v, d))
+    print(f"{'kernel':90s} {'counter':>14s} {'n':>5s} {'big_n':>6s} {'big_mean_value':>16s} {'big_avg_us':>11s}")
+    for (n, c), v in sorted(agg.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
+        dmax = max(x[1] for x in v)
+        big = [x for x in v if x[1] >= dmax / 4]
+        print(f"{short(n):90s} {c:>14s} {len(v):5d} {len(big):6d} {sum(x[0] for x in big) / len(big):16.1f} "
+              f"{sum(x[1] for x in big) / len(big) / 1e3:11.1f}")
+
+
+if __name__ == "__main__":
+    mode, db = sys.argv[1], sys.argv[2]
+    flt = sys.argv[3] if len(sys.argv) > 3 else "arx::"
+    (trace if mode == "trace" else pmc)(db, flt)

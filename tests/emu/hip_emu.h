@@ -164,6 +164,20 @@ template <typename T> inline T __shfl_up(T v, unsigned d, int = 64) {
 template <typename T> inline T __shfl_xor(T v, int m, int = 64) {
   return hipemu::exchange(v, hipemu::my_lane() ^ m);
 }
+// buffer descriptors: out-of-range offsets read as zero without touching memory
+struct __amdgpu_buffer_rsrc_t { const uint8_t* base; uint32_t num; };
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num, int) {
+  return __amdgpu_buffer_rsrc_t{static_cast<const uint8_t*>(p), static_cast<uint32_t>(num)};
+}
+inline uint4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, int) {
+  uint4 v{0, 0, 0, 0};
+  const uint64_t o = static_cast<uint64_t>(voff) + soff;
+  if (o + 16 <= r.num) memcpy(&v, r.base + o, 16);
+  return v;
+}
+// only ever applied to wave-uniform values in the kernels
+template <typename T> inline T __builtin_amdgcn_readfirstlane(T v) { return v; }
+inline uint32_t __builtin_amdgcn_readlane(uint32_t v, int src) { return hipemu::exchange(v, src); }
 inline uint64_t __ballot(bool p) { return hipemu::ballot(p); }
 inline bool __any(bool p) { return hipemu::ballot(p) != 0; }
 inline bool __all(bool p) { return hipemu::ballot(!p) == 0; }

@@ -1,0 +1,70 @@
+"""The drop-in proper: libarrow_amd_plugin.so registers the MI355X kernels on Arrow's own live
+FunctionRegistry and unmodified pyarrow.compute calls dispatch to them.  Runs in a subprocess so
+the registry of the test session itself stays stock."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = textwrap.dedent(r'''
+    import ctypes, sys
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    from arrow_amd.plugin_build import build_plugin
+    so = build_plugin()
+    rng = np.random.default_rng(5)
+    n = 1_000_003
+    vals = pa.array(rng.integers(-2**62, 2**62, n), mask=rng.random(n) < 0.1)
+    mask = pa.array(rng.random(n) < 0.3, mask=rng.random(n) < 0.05)
+    idx = pa.array(rng.integers(0, n, 300_000).astype(np.int32), mask=rng.random(300_000) < 0.1)
+    f64a, f64b = pa.array(rng.standard_normal(n)), pa.array(rng.standard_normal(n), mask=rng.random(n) < 0.1)
+    keys = pa.array(rng.integers(0, 2**63, n).astype(np.uint64), mask=rng.random(n) < 0.05)
+    small = pa.array(np.arange(100))
+    def run():
+        return dict(
+            f_drop=pc.filter(vals, mask), f_emit=pc.filter(vals, mask, null_selection_behavior="emit_null"),
+            f_slice=pc.filter(vals.slice(3), mask.slice(3)),
+            f_i32=pc.filter(vals.cast(pa.int64()).slice(0, 200_000).cast(pa.int32(), safe=False), mask.slice(0, 200_000)),
+            take=pc.take(vals, idx), take_nb=pc.take(vals, idx, boundscheck=False),
+            table=pa.table({"v": vals, "w": f64a}).filter(mask),
+            gt=pc.greater(f64a, f64b), sort=pc.array_sort_indices(keys),
+            sort_d=pc.array_sort_indices(keys, order="descending", null_placement="at_start"),
+            small=pc.filter(small, pa.array(np.arange(100) % 2 == 0)),
+            boolv=pc.filter(mask, mask),
+        )
+    stock = run()
+    lib = ctypes.CDLL(so)
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_gpu_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_stock_calls.restype = ctypes.c_int64
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(1000))
+    ours = run()
+    gpu_calls = lib.arrow_amd_plugin_gpu_calls()
+    for k in stock:
+        assert ours[k].equals(stock[k]), k
+        if hasattr(ours[k], "null_count"):
+            assert ours[k].null_count == stock[k].null_count, k
+    assert gpu_calls >= 12, gpu_calls            # every large call above took the HIP path
+    assert lib.arrow_amd_plugin_stock_calls() >= 2  # tiny / boolean-valued inputs went to the stock kernels
+    try:
+        pc.take(vals, pa.array(np.array([0, n, 1] * 1000, dtype=np.int64)))
+        raise SystemExit("expected IndexError")
+    except pa.lib.ArrowIndexError as e:
+        assert str(e) == f"Index {n} out of bounds", str(e)
+    print("PLUGIN_OK gpu_calls=%d stock_calls=%d" % (gpu_calls, lib.arrow_amd_plugin_stock_calls()))
+''')
+
+
+def test_pyarrow_compute_dispatches_to_the_hip_kernels():
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "PLUGIN_OK" in r.stdout

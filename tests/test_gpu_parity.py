@@ -63,14 +63,14 @@ def test_filter_tuning_variants_agree(gpu_ctx):
     m = U.random_mask(rng, 2_000_003, 0.1, null_p=0.05)
     try:
         for batch in (1, 4):
-            for dense in (0, 1):
+            for pipe in (0, 1):
                 assert lib.arx_set_option(b"filter_batch", batch) == 0
-                assert lib.arx_set_option(b"filter_dense", dense) == 0
+                assert lib.arx_set_option(b"filter_pipe", pipe) == 0
                 for sel in ("drop", "emit_null"):
                     P.check_filter(gpu_ctx, v, m, sel, use_pyarrow=False)
     finally:
         lib.arx_set_option(b"filter_batch", 4)
-        lib.arx_set_option(b"filter_dense", 0)
+        lib.arx_set_option(b"filter_pipe", 1)
 
 
 def test_filter_10m_rows_config1(gpu_ctx):
