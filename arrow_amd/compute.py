@@ -405,6 +405,107 @@ class FunctionRegistry:
         return len(self._fns)
 
 
+# --------------------------------------------------------------------------- hash_sum kernel
+class GroupedSumInt64State:
+    """KernelState of hash_sum(int64, uint32): the device twin of
+    GroupedReducingAggregator<Int64Type, GroupedSumImpl> (hash_aggregate_numeric.cc:44-187).
+    Dense per-group arrays in HBM: sums, counts, null_seen (the complement of `no_nulls_`)."""
+
+    def __init__(self, options: ScalarAggregateOptions | None, device):
+        self.options = options or ScalarAggregateOptions()
+        self.device = torch.device(device)
+        self.num_groups = 0
+        self.sums = torch.zeros(0, dtype=torch.int64, device=self.device)
+        self.counts = torch.zeros(0, dtype=torch.int64, device=self.device)
+        self.null_seen = torch.zeros(0, dtype=torch.int32, device=self.device)
+
+
+def _hash_sum_init(options, device=None):
+    """HashAggregateInit<Impl> (hash_aggregate_internal.h:54-63)."""
+    from .array import default_device
+
+    return GroupedSumInt64State(options, device if device is not None else default_device())
+
+
+def _grow(t: torch.Tensor, n: int) -> torch.Tensor:
+    if t.numel() >= n:
+        return t
+    out = torch.zeros(max(n, 2 * t.numel()), dtype=t.dtype, device=t.device)
+    out[: t.numel()].copy_(t)  # device-to-device buffer growth (TypedBufferBuilder::Append)
+    return out
+
+
+def _hash_sum_resize(state: GroupedSumInt64State, new_num_groups: int) -> None:
+    """Resize (:61-68): new groups start at sum 0, count 0, no nulls seen."""
+    state.sums = _grow(state.sums, new_num_groups)
+    state.counts = _grow(state.counts, new_num_groups)
+    state.null_seen = _grow(state.null_seen, new_num_groups)
+    state.num_groups = new_num_groups
+
+
+def _hash_sum_consume(state: GroupedSumInt64State, batch) -> None:
+    """Consume (:70-83): batch = [values (Array | Scalar), group_ids (uint32 Array)]."""
+    values, gids = batch[0], batch[1]
+    if gids.type != uint32:
+        raise ArrowInvalid("hash_sum: group ids must be uint32")
+    lib, stream = _lib_and_stream(state.device)
+    n = gids.length
+    if isinstance(values, Scalar):
+        span = _lib.ArxSpan(None, None, 0, n, 0 if values.is_valid else n)
+        is_scalar, sv = 1, int(values.value or 0)
+    else:
+        if values.type != int64:
+            raise ArrowNotImplementedError("hash_sum on the gfx950 path takes int64 values")
+        if values.length != n:
+            raise ArrowInvalid("Array arguments must all be the same length")
+        span, is_scalar, sv = values.span(), 0, 0
+    check(lib.arx_hash_sum_i64_consume(C.byref(span), is_scalar, sv, gids.values_ptr(), n,
+                                       state.sums.data_ptr(), state.counts.data_ptr(),
+                                       state.null_seen.data_ptr(), stream))
+
+
+def _hash_sum_merge(state: GroupedSumInt64State, other: GroupedSumInt64State, group_id_mapping) -> None:
+    """Merge (:85-107): group_id_mapping[other_g] = group id in `state` (uint32 Array)."""
+    lib, stream = _lib_and_stream(state.device)
+    g = group_id_mapping.length
+    if g != other.num_groups:
+        raise ArrowInvalid("group_id_mapping length must equal the other state's group count")
+    check(lib.arx_hash_sum_i64_merge(state.sums.data_ptr(), state.counts.data_ptr(),
+                                     state.null_seen.data_ptr(), other.sums.data_ptr(),
+                                     other.counts.data_ptr(), other.null_seen.data_ptr(),
+                                     group_id_mapping.values_ptr(), g, stream))
+
+
+def _hash_sum_finalize(state: GroupedSumInt64State) -> Array:
+    """Finalize (:130-152): int64 Array of num_groups sums; the validity bitmap is only
+    materialised when a group is null (Finish :109-128) or skip_nulls is false."""
+    lib, stream = _lib_and_stream(state.device)
+    g = state.num_groups
+    bits = alloc(bitmap_nbytes(g), state.device, zero=True)
+    counter = torch.zeros(8, dtype=torch.uint8, device=state.device)
+    check(lib.arx_hash_sum_i64_finalize(state.counts.data_ptr(), state.null_seen.data_ptr(), g,
+                                        int(state.options.skip_nulls), state.options.min_count,
+                                        bits.data_ptr(), counter.data_ptr(), stream))
+    data = state.sums[:g].contiguous().view(torch.uint8)
+    nulls = g - int(counter.cpu().view(torch.int64)[0])
+    if state.options.skip_nulls and nulls == 0:
+        return Array(int64, g, [None, data], 0, 0)
+    return Array(int64, g, [bits, data], nulls if state.options.skip_nulls else kUnknownNullCount, 0)
+
+
+class HashAggregateKernel:
+    """compute/kernel.h:739-769: {signature, init, resize, consume, merge, finalize}."""
+
+    def __init__(self, in_types, init, resize, consume, merge, finalize, out_type=None):
+        self.in_types = tuple(in_types)
+        self.init, self.resize, self.consume = init, resize, consume
+        self.merge, self.finalize = merge, finalize
+        self.out_type = out_type
+        self.exec = None
+
+    matches = Kernel.matches
+
+
 class ExecBatch:
     """exec.h:174-261: a list of equal-length Arrays / Scalars plus the length."""
 
@@ -528,7 +629,8 @@ def _build_registry() -> FunctionRegistry:
     reg.add_function(Function("sort_indices", Function.META, 1, SortOptions(), _sort_indices_meta))
 
     f = Function("hash_sum", Function.HASH_AGGREGATE, 2, ScalarAggregateOptions())
-    f.add_kernel(Kernel((int64, uint32), None, int64))
+    f.add_kernel(HashAggregateKernel((int64, uint32), _hash_sum_init, _hash_sum_resize,
+                                     _hash_sum_consume, _hash_sum_merge, _hash_sum_finalize, int64))
     reg.add_function(f)
     return reg
 

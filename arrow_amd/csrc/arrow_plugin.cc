@@ -23,6 +23,7 @@
 #include <arrow/compute/kernel.h>
 #include <arrow/compute/registry.h>
 #include <arrow/util/bit_util.h>
+#include <arrow/util/bitmap_ops.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -48,6 +49,22 @@ namespace {
 std::atomic<int64_t> g_gpu_calls{0};
 std::atomic<int64_t> g_stock_calls{0};
 std::atomic<int64_t> g_min_rows{1 << 16};
+
+// per-function call counters: which exec actually ran (the GPU tests assert on these so that a
+// silent route through the stock CPU kernel is a test failure, not a pass)
+enum Fn { kFnFilter = 0, kFnTake, kFnGreater, kFnSort, kFnCast, kFnHashSum, kNumFn };
+const char* const kFnNames[kNumFn] = {"array_filter", "array_take", "greater", "array_sort_indices",
+                                      "cast", "hash_sum"};
+std::atomic<int64_t> g_fn_gpu[kNumFn];
+std::atomic<int64_t> g_fn_stock[kNumFn];
+void CountGpu(Fn f) {
+  g_gpu_calls.fetch_add(1, std::memory_order_relaxed);
+  g_fn_gpu[f].fetch_add(1, std::memory_order_relaxed);
+}
+void CountStock(Fn f) {
+  g_stock_calls.fetch_add(1, std::memory_order_relaxed);
+  g_fn_stock[f].fetch_add(1, std::memory_order_relaxed);
+}
 thread_local std::string t_error;
 
 Status FromArx(int rc) {
@@ -183,9 +200,9 @@ struct StockKernel {
 };
 
 // run the stock exec with the stock state installed
-Status RunStock(const StockKernel& k, cp::KernelState* stock_state, cp::KernelContext* ctx,
+Status RunStock(Fn fn, const StockKernel& k, cp::KernelState* stock_state, cp::KernelContext* ctx,
                 const cp::ExecSpan& batch, cp::ExecResult* out) {
-  g_stock_calls.fetch_add(1, std::memory_order_relaxed);
+  CountStock(fn);
   cp::KernelState* mine = ctx->state();
   ctx->SetState(stock_state);
   Status st = k.exec(ctx, batch, out);
@@ -216,7 +233,7 @@ Status FilterExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecRes
   const int w = FixedByteWidth(*values.type);
   if (w == 0 || filter.type->id() != Type::BOOL || values.length < g_min_rows.load() ||
       !IsHost(values) || !IsHost(filter)) {
-    return RunStock(g_stock_filter, state->stock.get(), ctx, batch, out);
+    return RunStock(kFnFilter, g_stock_filter, state->stock.get(), ctx, batch, out);
   }
   const int null_sel = state->options.null_selection_behavior == cp::FilterOptions::EMIT_NULL
                            ? ARX_FILTER_EMIT_NULL : ARX_FILTER_DROP;
@@ -263,7 +280,7 @@ Status FilterExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecRes
     }
   }
   HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
-  g_gpu_calls.fetch_add(1, std::memory_order_relaxed);
+  CountGpu(kFnFilter);
   return Status::OK();
 }
 
@@ -303,7 +320,7 @@ Status TakeExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResul
   const int tid = IndexTypeId(*indices.type);
   static const int kIdxWidth[8] = {1, 1, 2, 2, 4, 4, 8, 8};
   if (w == 0 || tid < 0 || indices.length < g_min_rows.load() || !IsHost(values) || !IsHost(indices)) {
-    return RunStock(g_stock_take, state->stock.get(), ctx, batch, out);
+    return RunStock(kFnTake, g_stock_take, state->stock.get(), ctx, batch, out);
   }
   hipStream_t st;
   ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
@@ -347,7 +364,7 @@ Status TakeExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResul
   }
   HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
   out_arr->null_count = m - valid_count;
-  g_gpu_calls.fetch_add(1, std::memory_order_relaxed);
+  CountGpu(kFnTake);
   return Status::OK();
 }
 
@@ -360,7 +377,7 @@ Status GreaterExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecRe
   if (!batch[0].is_array() || !batch[1].is_array() || !out->is_array_span() ||
       out->array_span()->offset != 0 || batch.length < g_min_rows.load() ||
       !IsHost(batch[0].array) || !IsHost(batch[1].array)) {
-    g_stock_calls.fetch_add(1, std::memory_order_relaxed);
+    CountStock(kFnGreater);
     return g_stock_greater.exec(ctx, batch, out);
   }
   const ArraySpan& l = batch[0].array;
@@ -380,7 +397,7 @@ Status GreaterExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecRe
   HIP_RETURN_NOT_OK(hipMemcpyAsync(o->buffers[1].data, dout, static_cast<size_t>(arrow::bit_util::BytesForBits(n)),
                                    hipMemcpyDeviceToHost, st));
   HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
-  g_gpu_calls.fetch_add(1, std::memory_order_relaxed);
+  CountGpu(kFnGreater);
   return Status::OK();
 }
 
@@ -410,7 +427,7 @@ Status SortExecImpl(const StockKernel& stock, bool is_signed, cp::KernelContext*
   auto* state = static_cast<ShimState<cp::ArraySortOptions>*>(ctx->state());
   const ArraySpan& values = batch[0].array;
   if (values.length < g_min_rows.load() || !IsHost(values)) {
-    return RunStock(stock, state->stock.get(), ctx, batch, out);
+    return RunStock(kFnSort, stock, state->stock.get(), ctx, batch, out);
   }
   hipStream_t st;
   ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
@@ -434,7 +451,7 @@ Status SortExecImpl(const StockKernel& stock, bool is_signed, cp::KernelContext*
   }
   HIP_RETURN_NOT_OK(hipMemcpyAsync(host_out, dout, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost, st));
   HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
-  g_gpu_calls.fetch_add(1, std::memory_order_relaxed);
+  CountGpu(kFnSort);
   return Status::OK();
 }
 Status SortExecU64(cp::KernelContext* c, const cp::ExecSpan& b, cp::ExecResult* o) {
@@ -442,6 +459,219 @@ Status SortExecU64(cp::KernelContext* c, const cp::ExecSpan& b, cp::ExecResult* 
 }
 Status SortExecI64(cp::KernelContext* c, const cp::ExecSpan& b, cp::ExecResult* o) {
   return SortExecImpl(g_stock_sort_i64, true, c, b, o);
+}
+
+// ---------------------------------------------------------------- cast(float64 -> float32)
+// Cast kernels live in a private table (GetCastFunction, cpp/src/arrow/compute/cast.cc:207-214)
+// whose DispatchExact returns the FIRST exact-type match (cast.cc:170-205), so an added kernel
+// would never be chosen.  The public route is the one the registry offers: re-register the
+// "cast" MetaFunction (AddFunction(..., allow_overwrite=true), registry.h:69) with a wrapper that
+// takes float64 -> float32 arrays and hands every other cast to the stock meta-function.
+// Semantics: CastPrimitive<FloatType,DoubleType>::Exec (scalar_cast_internal.cc:41-53): every slot
+// converted; validity shared or copied like NullHandling::INTERSECTION does for one input.
+class RocmCastMetaFunction : public cp::MetaFunction {
+ public:
+  explicit RocmCastMetaFunction(std::shared_ptr<cp::Function> stock)
+      : cp::MetaFunction("cast", cp::Arity::Unary(), stock->doc(), stock->default_options()),
+        stock_(std::move(stock)) {}
+
+  arrow::Result<arrow::Datum> ExecuteImpl(const std::vector<arrow::Datum>& args,
+                                          const cp::FunctionOptions* options,
+                                          cp::ExecContext* ctx) const override {
+    const auto* cast_options = static_cast<const cp::CastOptions*>(options);
+    if (cast_options != nullptr && cast_options->to_type.type != nullptr &&
+        cast_options->to_type.id() == Type::FLOAT && args.size() == 1 && args[0].is_array() &&
+        args[0].array()->type->id() == Type::DOUBLE && args[0].length() >= g_min_rows.load()) {
+      ArraySpan in(*args[0].array());
+      if (IsHost(in)) return CastF64F32(*args[0].array(), ctx);
+    }
+    CountStock(kFnCast);
+    return stock_->Execute(args, options, ctx);
+  }
+
+ private:
+  static arrow::Result<arrow::Datum> CastF64F32(const ArrayData& in, cp::ExecContext* ctx) {
+    const int64_t n = in.length;
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    void *din = nullptr, *dout = nullptr;
+    ARROW_RETURN_NOT_OK(t_scratch.Get(kValues, static_cast<size_t>(n) * 8 + 16, &din));
+    ARROW_RETURN_NOT_OK(t_scratch.Get(kOutData, static_cast<size_t>(n) * 4 + 16, &dout));
+    ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> out_values,
+                          arrow::AllocateBuffer(n * 4, ctx->memory_pool()));
+    HIP_RETURN_NOT_OK(hipMemcpyAsync(din, in.GetValues<double>(1), static_cast<size_t>(n) * 8,
+                                     hipMemcpyHostToDevice, st));
+    ARROW_RETURN_NOT_OK(FromArx(arx_cast_f64_f32(static_cast<const double*>(din), n,
+                                                 static_cast<float*>(dout), st)));
+    HIP_RETURN_NOT_OK(hipMemcpyAsync(out_values->mutable_data(), dout, static_cast<size_t>(n) * 4,
+                                     hipMemcpyDeviceToHost, st));
+    std::shared_ptr<Buffer> validity;
+    if (in.null_count != 0 && in.buffers[0] != nullptr) {
+      if (in.offset == 0) {
+        validity = in.buffers[0];  // zero-copy, as PropagateNulls does (exec.cc:1222-1281)
+      } else {
+        ARROW_ASSIGN_OR_RAISE(validity, arrow::internal::CopyBitmap(ctx->memory_pool(),
+                                                                    in.buffers[0]->data(),
+                                                                    in.offset, n));
+      }
+    }
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    CountGpu(kFnCast);
+    const int64_t null_count = validity ? in.null_count.load() : 0;
+    return arrow::Datum(ArrayData::Make(arrow::float32(), n, {std::move(validity), std::move(out_values)},
+                                        null_count));
+  }
+
+  std::shared_ptr<cp::Function> stock_;
+};
+
+// ---------------------------------------------------------------- hash_sum(int64, uint32)
+// The HashAggregateKernel vtable (compute/kernel.h:720-769) of
+// GroupedReducingAggregator<Int64Type,GroupedSumImpl> (hash_aggregate_numeric.cc:44-187) with the
+// per-group state in HBM.  Acero's GroupByNode drives it unchanged
+// (acero/groupby_aggregate_node.cc:210-337): resize after every Grouper::Consume, consume with
+// the dense uint32 group ids, merge thread-local states through a group_id_mapping, finalize.
+struct DeviceSumState : public cp::KernelState {
+  cp::ScalarAggregateOptions options;
+  int64_t num_groups = 0;
+  int64_t capacity = 0;
+  int64_t* sums = nullptr;
+  int64_t* counts = nullptr;
+  uint32_t* null_seen = nullptr;
+  ~DeviceSumState() override {
+    if (sums) (void)hipFree(sums);
+    if (counts) (void)hipFree(counts);
+    if (null_seen) (void)hipFree(null_seen);
+  }
+};
+
+arrow::Result<std::unique_ptr<cp::KernelState>> HashSumInit(cp::KernelContext*,
+                                                            const cp::KernelInitArgs& args) {
+  auto state = std::make_unique<DeviceSumState>();
+  if (args.options != nullptr) {
+    state->options = *static_cast<const cp::ScalarAggregateOptions*>(args.options);
+  }
+  return state;
+}
+
+template <typename T>
+Status GrowDevice(T** ptr, int64_t old_n, int64_t new_cap, hipStream_t st) {
+  T* fresh = nullptr;
+  HIP_RETURN_NOT_OK(hipMalloc(reinterpret_cast<void**>(&fresh), static_cast<size_t>(new_cap) * sizeof(T)));
+  HIP_RETURN_NOT_OK(hipMemsetAsync(fresh, 0, static_cast<size_t>(new_cap) * sizeof(T), st));
+  if (old_n > 0) {
+    HIP_RETURN_NOT_OK(hipMemcpyAsync(fresh, *ptr, static_cast<size_t>(old_n) * sizeof(T),
+                                     hipMemcpyDeviceToDevice, st));
+  }
+  HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+  if (*ptr) HIP_RETURN_NOT_OK(hipFree(*ptr));
+  *ptr = fresh;
+  return Status::OK();
+}
+
+// Resize (:61-68): new groups start at sum 0 / count 0 / no null seen.
+Status HashSumResize(cp::KernelContext* ctx, int64_t new_num_groups) {
+  auto* s = static_cast<DeviceSumState*>(ctx->state());
+  if (new_num_groups > s->capacity) {
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    const int64_t cap = std::max<int64_t>({new_num_groups, 2 * s->capacity, 1024});
+    ARROW_RETURN_NOT_OK(GrowDevice(&s->sums, s->num_groups, cap, st));
+    ARROW_RETURN_NOT_OK(GrowDevice(&s->counts, s->num_groups, cap, st));
+    ARROW_RETURN_NOT_OK(GrowDevice(&s->null_seen, s->num_groups, cap, st));
+    s->capacity = cap;
+  }
+  s->num_groups = new_num_groups;
+  return Status::OK();
+}
+
+// Consume (:70-83): batch = {values (array | scalar), group ids (uint32 array)}.
+Status HashSumConsume(cp::KernelContext* ctx, const cp::ExecSpan& batch) {
+  auto* s = static_cast<DeviceSumState*>(ctx->state());
+  const ArraySpan& gids = batch[1].array;
+  const int64_t n = gids.length;
+  if (n == 0) return Status::OK();
+  hipStream_t st;
+  ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+  ArxSpan dg{};
+  ARROW_RETURN_NOT_OK(Upload(gids, 4, kArg2, kArg2Validity, st, &dg));
+  const uint32_t* d_gids = static_cast<const uint32_t*>(dg.data) + dg.offset;
+  ArxSpan dv{};
+  int is_scalar = 0;
+  int64_t scalar_value = 0;
+  if (batch[0].is_array()) {
+    ARROW_RETURN_NOT_OK(Upload(batch[0].array, 8, kValues, kValidity, st, &dv));
+  } else {
+    const arrow::Scalar& sc = *batch[0].scalar;
+    is_scalar = 1;
+    dv.length = n;
+    dv.null_count = sc.is_valid ? 0 : n;
+    if (sc.is_valid) scalar_value = static_cast<const arrow::Int64Scalar&>(sc).value;
+  }
+  ARROW_RETURN_NOT_OK(FromArx(arx_hash_sum_i64_consume(&dv, is_scalar, scalar_value, d_gids, n, s->sums,
+                                                       s->counts, s->null_seen, st)));
+  HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+  CountGpu(kFnHashSum);
+  return Status::OK();
+}
+
+// Merge (:85-107).
+Status HashSumMerge(cp::KernelContext* ctx, cp::KernelState&& other_state, const ArrayData& mapping) {
+  auto* s = static_cast<DeviceSumState*>(ctx->state());
+  auto* other = static_cast<DeviceSumState*>(&other_state);
+  const int64_t g = mapping.length;
+  if (g == 0) return Status::OK();
+  hipStream_t st;
+  ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+  void* d_map = nullptr;
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kArg2, static_cast<size_t>(g) * 4 + 16, &d_map));
+  HIP_RETURN_NOT_OK(hipMemcpyAsync(d_map, mapping.GetValues<uint32_t>(1), static_cast<size_t>(g) * 4,
+                                   hipMemcpyHostToDevice, st));
+  ARROW_RETURN_NOT_OK(FromArx(arx_hash_sum_i64_merge(s->sums, s->counts, s->null_seen, other->sums,
+                                                     other->counts, other->null_seen,
+                                                     static_cast<const uint32_t*>(d_map), g, st)));
+  HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+  return Status::OK();
+}
+
+// Finalize (:130-152) + Finish (:109-128).
+Status HashSumFinalize(cp::KernelContext* ctx, arrow::Datum* out) {
+  auto* s = static_cast<DeviceSumState*>(ctx->state());
+  const int64_t g = s->num_groups;
+  arrow::MemoryPool* pool = ctx->memory_pool();
+  ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> values, arrow::AllocateBuffer(g * 8, pool));
+  std::shared_ptr<Buffer> bitmap;
+  int64_t null_count = 0;
+  if (g > 0) {
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    void *d_bits = nullptr, *d_counter = nullptr;
+    const size_t words = static_cast<size_t>((g + 63) / 64);
+    ARROW_RETURN_NOT_OK(t_scratch.Get(kOutValidity, words * 8 + 16, &d_bits));
+    ARROW_RETURN_NOT_OK(t_scratch.Get(kCounter, 64, &d_counter));
+    HIP_RETURN_NOT_OK(hipMemsetAsync(d_counter, 0, 8, st));
+    ARROW_RETURN_NOT_OK(FromArx(arx_hash_sum_i64_finalize(s->counts, s->null_seen, g,
+                                                          s->options.skip_nulls ? 1 : 0,
+                                                          s->options.min_count, d_bits,
+                                                          static_cast<int64_t*>(d_counter), st)));
+    ARROW_ASSIGN_OR_RAISE(bitmap, arrow::AllocateBitmap(g, pool));
+    int64_t valid_count = 0;
+    HIP_RETURN_NOT_OK(hipMemcpyAsync(values->mutable_data(), s->sums, static_cast<size_t>(g) * 8,
+                                     hipMemcpyDeviceToHost, st));
+    HIP_RETURN_NOT_OK(hipMemcpyAsync(bitmap->mutable_data(), d_bits,
+                                     static_cast<size_t>(arrow::bit_util::BytesForBits(g)),
+                                     hipMemcpyDeviceToHost, st));
+    HIP_RETURN_NOT_OK(hipMemcpyAsync(&valid_count, d_counter, 8, hipMemcpyDeviceToHost, st));
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    null_count = g - valid_count;
+    if (s->options.skip_nulls) {
+      if (null_count == 0) bitmap = nullptr;  // Finish allocates a bitmap only when a group is null
+    } else {
+      null_count = arrow::kUnknownNullCount;
+    }
+  }
+  *out = arrow::Datum(ArrayData::Make(arrow::int64(), g, {std::move(bitmap), std::move(values)}, null_count));
+  return Status::OK();
 }
 
 // ---------------------------------------------------------------- registration
@@ -509,6 +739,26 @@ Status RegisterAll() {
     copy.exec = GreaterExec;
     ARROW_RETURN_NOT_OK(sfn->AddKernel(std::move(copy)));
   }
+  {
+    ARROW_ASSIGN_OR_RAISE(auto stock_cast, reg->GetFunction("cast"));
+    ARROW_RETURN_NOT_OK(reg->AddFunction(std::make_shared<RocmCastMetaFunction>(std::move(stock_cast)),
+                                         /*allow_overwrite=*/true));
+  }
+  {
+    ARROW_ASSIGN_OR_RAISE(auto fn, reg->GetFunction("hash_sum"));
+    if (fn->kind() != cp::Function::HASH_AGGREGATE) return Status::Invalid("hash_sum is not a hash aggregate");
+    auto* hfn = static_cast<cp::HashAggregateFunction*>(fn.get());
+    ARROW_ASSIGN_OR_RAISE(const cp::Kernel* k0, hfn->DispatchExact({arrow::int64(), arrow::uint32()}));
+    cp::HashAggregateKernel copy = *static_cast<const cp::HashAggregateKernel*>(k0);
+    copy.signature = cp::KernelSignature::Make({cp::InputType(arrow::int64()), cp::InputType(arrow::uint32())},
+                                               copy.signature->out_type());
+    copy.init = HashSumInit;
+    copy.resize = HashSumResize;
+    copy.consume = HashSumConsume;
+    copy.merge = HashSumMerge;
+    copy.finalize = HashSumFinalize;
+    ARROW_RETURN_NOT_OK(hfn->AddKernel(std::move(copy)));
+  }
   return Status::OK();
 }
 
@@ -531,6 +781,14 @@ int arrow_amd_register(void) {
 const char* arrow_amd_plugin_last_error(void) { return t_error.c_str(); }
 int64_t arrow_amd_plugin_gpu_calls(void) { return g_gpu_calls.load(); }
 int64_t arrow_amd_plugin_stock_calls(void) { return g_stock_calls.load(); }
+// Calls of `function` ("array_filter", "array_take", "greater", "array_sort_indices", "cast",
+// "hash_sum") that ran on the GPU (gpu != 0) or were handed to the stock CPU kernel; -1 = unknown name.
+int64_t arrow_amd_plugin_calls(const char* function, int gpu) {
+  for (int i = 0; i < kNumFn; ++i) {
+    if (std::strcmp(function, kFnNames[i]) == 0) return (gpu ? g_fn_gpu[i] : g_fn_stock[i]).load();
+  }
+  return -1;
+}
 // Inputs shorter than this stay on the stock CPU kernels (PCIe staging does not pay).
 void arrow_amd_plugin_set_min_rows(int64_t n) { g_min_rows.store(n); }
 

@@ -247,6 +247,68 @@ __global__ __launch_bounds__(kBlock) void partition_scatter_kernel(
   }
 }
 
+
+// ---- HashAggregateKernel path: dense group ids come from the caller's Grouper
+// (GroupedReducingAggregator<Int64Type,GroupedSumImpl>::Consume / Merge,
+//  cpp/src/arrow/compute/kernels/hash_aggregate_numeric.cc:70-107; VisitGroupedValues,
+//  hash_aggregate_internal.h:140-176).  State = three dense device arrays indexed by group id.
+__global__ __launch_bounds__(kBlock) void hash_sum_dense_consume_kernel(
+    const int64_t* __restrict__ values, int64_t scalar_value, int values_is_scalar, Bits vvalid,
+    const uint32_t* __restrict__ group_ids, int64_t n, unsigned long long* __restrict__ sums,
+    unsigned long long* __restrict__ counts, unsigned int* __restrict__ null_seen) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t g = group_ids[i];
+    const bool ok = (load_word(vvalid, i >> 6) >> (i & 63)) & 1ull;
+    if (ok) {
+      const int64_t v = values_is_scalar ? scalar_value : values[i];
+      atomicAdd(&sums[g], static_cast<unsigned long long>(v));
+      atomicAdd(&counts[g], 1ull);
+    } else {
+      atomicOr(&null_seen[g], 1u);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hash_sum_dense_merge_kernel(
+    const int64_t* __restrict__ other_sums, const int64_t* __restrict__ other_counts,
+    const uint32_t* __restrict__ other_null_seen, const uint32_t* __restrict__ mapping, int64_t n,
+    unsigned long long* __restrict__ sums, unsigned long long* __restrict__ counts,
+    unsigned int* __restrict__ null_seen) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t g = mapping[i];
+    atomicAdd(&sums[g], static_cast<unsigned long long>(other_sums[i]));
+    atomicAdd(&counts[g], static_cast<unsigned long long>(other_counts[i]));
+    if (other_null_seen[i] & 1u) atomicOr(&null_seen[g], 1u);
+  }
+}
+
+// One 64-bit validity word per lane-iteration: bit g = counts[g] >= min_count && (skip_nulls ||
+// !null_seen[g])  (Finish + Finalize, hash_aggregate_numeric.cc:109-152).
+__global__ __launch_bounds__(kBlock) void hash_sum_dense_finalize_kernel(
+    const int64_t* __restrict__ counts, const uint32_t* __restrict__ null_seen, int64_t n,
+    int skip_nulls, uint32_t min_count, uint64_t* __restrict__ out_bits,
+    unsigned long long* __restrict__ valid_count) {
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwords = (n + 63) >> 6;
+  uint64_t nvalid = 0;
+  for (int64_t w = wave_g; w < nwords; w += nwaves) {
+    const int64_t i = (w << 6) + lane;
+    bool ok = false;
+    if (i < n) {
+      ok = counts[i] >= static_cast<int64_t>(min_count);
+      if (!skip_nulls) ok = ok && (null_seen[i] & 1u) == 0;
+    }
+    const uint64_t bal = __ballot(ok);
+    if (lane == 0) out_bits[w] = bal;
+    nvalid += __popcll(bal);
+  }
+  if (valid_count != nullptr && lane == 0 && nvalid != 0) atomicAdd(valid_count, nvalid);
+}
+
 static inline unsigned gb_grid(int64_t n) {
   return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock), 256 * 16)));
 }
@@ -399,6 +461,88 @@ int arx_groupby_sum_i64_finalize(const int64_t* counts, const uint8_t* no_nulls,
   hipLaunchKernelGGL(groupby_finalize_kernel, dim3(gb_grid(num_groups)), dim3(kBlock), 0,
                      as_stream(stream), counts, no_nulls, num_groups, skip_nulls, min_count, out_valid);
   ARX_CHECK_LAUNCH("groupby_finalize_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_sum_i64_consume(const ArxSpan* values, int values_is_scalar, int64_t scalar_value,
+                             const uint32_t* group_ids, int64_t length, int64_t* sums,
+                             int64_t* counts, uint32_t* null_seen, void* stream) {
+  if (values == nullptr || length < 0) {
+    set_error("bad arguments to arx_hash_sum_i64_consume");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  if (group_ids == nullptr || sums == nullptr || counts == nullptr || null_seen == nullptr ||
+      (!values_is_scalar && values->data == nullptr)) {
+    set_error("NULL buffer passed to arx_hash_sum_i64_consume");
+    return ARX_INVALID;
+  }
+  if (!values_is_scalar && values->length != length) {
+    set_error("Array arguments must all be the same length (values %lld vs group ids %lld)",
+              static_cast<long long>(values->length), static_cast<long long>(length));
+    return ARX_INVALID;
+  }
+  const int64_t* v = values_is_scalar ? nullptr
+                                      : static_cast<const int64_t*>(values->data) + values->offset;
+  // a null scalar is described by null_count != 0 with a NULL bitmap: every row is null
+  Bits vb = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, length);
+  int scalar_null = values_is_scalar && values->null_count != 0;
+  hipStream_t st = as_stream(stream);
+  if (scalar_null) {
+    // all rows null: only the null_seen flags change; express as a zero-length validity
+    vb.base = nullptr;
+    vb.length = 0;  // load_word returns 0 for every word => every row reads as null
+  }
+  hipLaunchKernelGGL(hash_sum_dense_consume_kernel, dim3(gb_grid(length)), dim3(kBlock), 0, st, v,
+                     scalar_value, values_is_scalar, vb, group_ids, length,
+                     reinterpret_cast<unsigned long long*>(sums),
+                     reinterpret_cast<unsigned long long*>(counts), null_seen);
+  ARX_CHECK_LAUNCH("hash_sum_dense_consume_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_sum_i64_merge(int64_t* sums, int64_t* counts, uint32_t* null_seen,
+                           const int64_t* other_sums, const int64_t* other_counts,
+                           const uint32_t* other_null_seen, const uint32_t* group_id_mapping,
+                           int64_t other_num_groups, void* stream) {
+  if (other_num_groups < 0) {
+    set_error("negative other_num_groups");
+    return ARX_INVALID;
+  }
+  if (other_num_groups == 0) return ARX_OK;
+  if (sums == nullptr || counts == nullptr || null_seen == nullptr || other_sums == nullptr ||
+      other_counts == nullptr || other_null_seen == nullptr || group_id_mapping == nullptr) {
+    set_error("NULL buffer passed to arx_hash_sum_i64_merge");
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(hash_sum_dense_merge_kernel, dim3(gb_grid(other_num_groups)), dim3(kBlock), 0,
+                     as_stream(stream), other_sums, other_counts, other_null_seen, group_id_mapping,
+                     other_num_groups, reinterpret_cast<unsigned long long*>(sums),
+                     reinterpret_cast<unsigned long long*>(counts), null_seen);
+  ARX_CHECK_LAUNCH("hash_sum_dense_merge_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_sum_i64_finalize(const int64_t* counts, const uint32_t* null_seen, int64_t num_groups,
+                              int skip_nulls, uint32_t min_count, void* out_validity,
+                              int64_t* valid_count, void* stream) {
+  if (num_groups < 0) {
+    set_error("negative num_groups");
+    return ARX_INVALID;
+  }
+  if (num_groups == 0) return ARX_OK;
+  if (counts == nullptr || null_seen == nullptr || out_validity == nullptr) {
+    set_error("NULL buffer passed to arx_hash_sum_i64_finalize");
+    return ARX_INVALID;
+  }
+  const int64_t nwords = ceil_div(num_groups, 64);
+  const unsigned grid = static_cast<unsigned>(
+      std::max<int64_t>(1, std::min<int64_t>(ceil_div(nwords, kWavesPerBlock), 2048)));
+  hipLaunchKernelGGL(hash_sum_dense_finalize_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                     counts, null_seen, num_groups, skip_nulls, min_count,
+                     static_cast<uint64_t*>(out_validity),
+                     reinterpret_cast<unsigned long long*>(valid_count));
+  ARX_CHECK_LAUNCH("hash_sum_dense_finalize_kernel");
   return ARX_OK;
 }
 

@@ -264,6 +264,30 @@ int arx_groupby_partition(const int32_t* keys, const uint8_t* key_is_valid, cons
                           uint8_t* out_key_is_valid, int64_t* out_sums, int64_t* out_counts,
                           uint8_t* out_no_nulls, int64_t* out_part_counts, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * hash_sum(int64, uint32 group id) — the HashAggregateKernel boundary itself
+ * (compute/kernel.h:720-769): the caller's Grouper already produced dense group ids.
+ * Replaces GroupedReducingAggregator<Int64Type,GroupedSumImpl>::{Consume,Merge,Finalize}
+ * (compute/kernels/hash_aggregate_numeric.cc:70-152).  State = three dense device arrays of
+ * num_groups entries that the caller owns, zero-initialises and grows (Resize, :61-68):
+ * sums (wrap-around int64), counts, null_seen (bit 0 set once a null value hit the group;
+ * the reference keeps the complement, `no_nulls`).  All asynchronous.
+ * ------------------------------------------------------------------------- */
+/* values: int64 ArxSpan of `length` rows, or (values_is_scalar != 0) a broadcast scalar
+ * `scalar_value` whose validity is values->null_count == 0 (hash_aggregate_internal.h:165-175). */
+int arx_hash_sum_i64_consume(const ArxSpan* values, int values_is_scalar, int64_t scalar_value,
+                             const uint32_t* group_ids, int64_t length, int64_t* sums,
+                             int64_t* counts, uint32_t* null_seen, void* stream);
+int arx_hash_sum_i64_merge(int64_t* sums, int64_t* counts, uint32_t* null_seen,
+                           const int64_t* other_sums, const int64_t* other_counts,
+                           const uint32_t* other_null_seen, const uint32_t* group_id_mapping,
+                           int64_t other_num_groups, void* stream);
+/* out_validity: ceil(num_groups/64) words, bit g = counts[g] >= min_count &&
+ * (skip_nulls || !null_seen[g]); valid_count (device, caller-zeroed, may be NULL) += popcount. */
+int arx_hash_sum_i64_finalize(const int64_t* counts, const uint32_t* null_seen, int64_t num_groups,
+                              int skip_nulls, uint32_t min_count, void* out_validity,
+                              int64_t* valid_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,8 +6,8 @@
  * cpu_baseline leg.  Nothing under arrow_amd/ may import, link or call this file.
  *
  * Pinned: every function here is checked against the reference's own build
- * (pyarrow 25.0.0 = libarrow.so.2500, see oracle/pin_against_pyarrow.py and
- * tests/test_oracle_*.py) and against golden vectors transcribed from the
+ * (pyarrow 25.0.0 = libarrow.so.2500, see tests/test_oracle_pin.py and
+ * tests/golden/make_golden.py) and against golden vectors transcribed from the
  * reference's unit tests (tests/golden/reference_vectors.json).
  *
  * Each function cites the reference source it follows (paths relative to
@@ -344,4 +344,59 @@ int64_t arxo_groupby_sum_i64(const int32_t* keys, const uint8_t* key_valid, int6
   }
   free(slot_gid);
   return ng;
+}
+
+/* ---------------------------------------------------------------------------
+ * hash_sum(int64, uint32 group id) with dense ids — the HashAggregateKernel vtable
+ * of GroupedReducingAggregator<Int64Type,GroupedSumImpl>
+ * (compute/kernels/hash_aggregate_numeric.cc):
+ *   Consume :70-83   (VisitGroupedValues, hash_aggregate_internal.h:140-176: a scalar
+ *                     value argument is broadcast; a null scalar nulls every row)
+ *   Merge   :85-107  (group_id_mapping[other_g] -> this group)
+ *   Finalize:130-152 + Finish :109-128
+ * State: sums/counts/no_nulls(one byte per group) of num_groups entries.
+ * ------------------------------------------------------------------------- */
+void arxo_hash_sum_i64_consume(const int64_t* values, const uint8_t* val_valid, int64_t val_off,
+                               int values_is_scalar, int64_t scalar_value, int scalar_is_valid,
+                               const uint32_t* group_ids, int64_t length, int64_t* sums,
+                               int64_t* counts, uint8_t* no_nulls) {
+  for (int64_t i = 0; i < length; ++i) {
+    const uint32_t g = group_ids[i];
+    int ok;
+    int64_t v;
+    if (values_is_scalar) { ok = scalar_is_valid; v = scalar_value; }
+    else { ok = is_valid(val_valid, val_off, i); v = ok ? values[val_off + i] : 0; }
+    if (ok) {
+      sums[g] = (int64_t)((uint64_t)sums[g] + (uint64_t)v);
+      counts[g] += 1;
+    } else {
+      no_nulls[g] = 0;
+    }
+  }
+}
+
+void arxo_hash_sum_i64_merge(int64_t* sums, int64_t* counts, uint8_t* no_nulls,
+                             const int64_t* other_sums, const int64_t* other_counts,
+                             const uint8_t* other_no_nulls, const uint32_t* mapping,
+                             int64_t other_num_groups) {
+  for (int64_t og = 0; og < other_num_groups; ++og) {
+    const uint32_t g = mapping[og];
+    counts[g] += other_counts[og];
+    sums[g] = (int64_t)((uint64_t)sums[g] + (uint64_t)other_sums[og]);
+    no_nulls[g] = (uint8_t)(no_nulls[g] && other_no_nulls[og]);
+  }
+}
+
+/* out_valid: one byte per group.  Returns the null count. */
+int64_t arxo_hash_sum_i64_finalize(const int64_t* counts, const uint8_t* no_nulls,
+                                   int64_t num_groups, int skip_nulls, uint32_t min_count,
+                                   uint8_t* out_valid) {
+  int64_t nulls = 0;
+  for (int64_t g = 0; g < num_groups; ++g) {
+    int v = counts[g] >= (int64_t)min_count;
+    if (!skip_nulls) v = v && no_nulls[g];
+    out_valid[g] = (uint8_t)v;
+    nulls += !v;
+  }
+  return nulls;
 }

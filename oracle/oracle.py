@@ -65,6 +65,12 @@ def lib():
         L.arxo_sort_indices_64.argtypes = [p, p, i64, i64, i32, i32, i32, p]
         L.arxo_groupby_sum_i64.restype = i64
         L.arxo_groupby_sum_i64.argtypes = [p, p, i64, p, p, i64, i64, i32, u32, p, p, p, p, p, p]
+        L.arxo_hash_sum_i64_consume.restype = None
+        L.arxo_hash_sum_i64_consume.argtypes = [p, p, i64, i32, i64, i32, p, i64, p, p, p]
+        L.arxo_hash_sum_i64_merge.restype = None
+        L.arxo_hash_sum_i64_merge.argtypes = [p, p, p, p, p, p, p, i64]
+        L.arxo_hash_sum_i64_finalize.restype = i64
+        L.arxo_hash_sum_i64_finalize.argtypes = [p, p, i64, i32, u32, p]
     return _lib
 
 
@@ -220,3 +226,50 @@ def groupby_sum_i64(keys, key_valid, key_off, values, val_valid, val_off, length
     assert ng >= 0
     return dict(keys=ok[:ng], key_is_valid=okv[:ng], sums=os_[:ng], counts=oc[:ng],
                 no_nulls=onn[:ng], valid=ov[:ng])
+
+
+class HashSumState:
+    """GroupedReducingAggregator<Int64Type, GroupedSumImpl> with dense group ids:
+    resize / consume / merge / finalize (hash_aggregate_numeric.cc:61-152)."""
+
+    def __init__(self, skip_nulls=True, min_count=1):
+        self.skip_nulls, self.min_count = bool(skip_nulls), int(min_count)
+        self.sums = np.zeros(0, np.int64)
+        self.counts = np.zeros(0, np.int64)
+        self.no_nulls = np.zeros(0, np.uint8)
+
+    @property
+    def num_groups(self):
+        return len(self.sums)
+
+    def resize(self, n):
+        add = n - self.num_groups
+        self.sums = np.concatenate([self.sums, np.zeros(add, np.int64)])
+        self.counts = np.concatenate([self.counts, np.zeros(add, np.int64)])
+        self.no_nulls = np.concatenate([self.no_nulls, np.ones(add, np.uint8)])
+
+    def consume(self, values, val_valid, val_off, group_ids, scalar=None):
+        """scalar: None, or (value, is_valid) to broadcast instead of `values`."""
+        gids = np.ascontiguousarray(group_ids, dtype=np.uint32)
+        if scalar is None:
+            lib().arxo_hash_sum_i64_consume(_ptr(values), _ptr(val_valid), val_off, 0, 0, 0,
+                                            _ptr(gids), len(gids), _ptr(self.sums),
+                                            _ptr(self.counts), _ptr(self.no_nulls))
+        else:
+            lib().arxo_hash_sum_i64_consume(None, None, 0, 1, int(scalar[0]), int(scalar[1]),
+                                            _ptr(gids), len(gids), _ptr(self.sums),
+                                            _ptr(self.counts), _ptr(self.no_nulls))
+
+    def merge(self, other: "HashSumState", mapping):
+        m = np.ascontiguousarray(mapping, dtype=np.uint32)
+        lib().arxo_hash_sum_i64_merge(_ptr(self.sums), _ptr(self.counts), _ptr(self.no_nulls),
+                                      _ptr(other.sums), _ptr(other.counts), _ptr(other.no_nulls),
+                                      _ptr(m), len(m))
+
+    def finalize(self):
+        """(sums int64[G], valid bool[G], null_count)."""
+        v = np.zeros(max(self.num_groups, 1), np.uint8)
+        nulls = lib().arxo_hash_sum_i64_finalize(_ptr(self.counts), _ptr(self.no_nulls),
+                                                 self.num_groups, int(self.skip_nulls),
+                                                 self.min_count, _ptr(v))
+        return self.sums.copy(), v[: self.num_groups].astype(bool), int(nulls)

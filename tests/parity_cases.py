@@ -249,3 +249,93 @@ def check_groupby_sum(amd, keys: HostArray, values: HostArray, skip_nulls=True, 
                              ~np.asarray(rs.is_null()))
         assert got == ref, tag + " vs pyarrow Table.group_by"
     return got
+
+
+# ------------------------------------------------------------------ hash_sum kernel vtable
+def check_hash_sum_kernel(amd, rng, n=5000, num_groups=37, null_p=0.2, skip_nulls=True, min_count=1,
+                          use_pyarrow=True):
+    """Drives hash_sum's HashAggregateKernel {init, resize, consume, merge, finalize} the way
+    GroupByNode does (acero/groupby_aggregate_node.cc:210-337): two thread-local states fed
+    batches with dense uint32 group ids, merged through a group_id_mapping, finalized.
+    Compared with the oracle's restatement and with the reference (pyarrow Table.group_by)."""
+    k = amd.compute.get_function_registry().get_function("hash_sum").dispatch_exact(
+        [amd.array.int64, amd.array.uint32])
+    opts = amd.compute.ScalarAggregateOptions(skip_nulls, min_count)
+    vals = util.random_array(rng, np.int64, n, null_p=null_p, offset=3)
+    gid_a = rng.integers(0, num_groups, size=n).astype(np.uint32)
+    # state B sees only a subset of the groups, numbered differently (like another thread's grouper)
+    nb = max(1, num_groups // 2)
+    perm = rng.permutation(num_groups)[:nb].astype(np.uint32)     # B's group j == A's group perm[j]
+    gid_b_local = rng.integers(0, nb, size=n).astype(np.uint32)
+    vals_b = util.random_array(rng, np.int64, n, null_p=null_p, offset=0)
+
+    dev_vals, dev_vals_b = vals.to_device(amd), vals_b.to_device(amd)
+    ga = HostArray(gid_a, None, 0, n).to_device(amd)
+    gb = HostArray(gid_b_local, None, 0, n).to_device(amd)
+    sa, sb = k.init(opts, dev_vals.device), k.init(opts, dev_vals.device)
+    half = n // 2
+    k.resize(sa, num_groups // 2 + 1)          # groups appear over time: resize grows the state
+    first = gid_a[:half] < (num_groups // 2 + 1)
+    # batch 1 only touches already-resized groups
+    sel = np.nonzero(first)[0]
+    if len(sel):
+        b1v = HostArray(vals.values[vals.offset:vals.offset + half][first].copy(),
+                        None if vals.valid is None else vals.valid[vals.offset:vals.offset + half][first].copy(),
+                        0, len(sel)).to_device(amd)
+        b1g = HostArray(gid_a[:half][first].copy(), None, 0, len(sel)).to_device(amd)
+        k.consume(sa, [b1v, b1g])
+    k.resize(sa, num_groups)
+    rest = np.nonzero(~first)[0]
+    if len(rest):
+        b2v = HostArray(vals.values[vals.offset:vals.offset + half][~first].copy(),
+                        None if vals.valid is None else vals.valid[vals.offset:vals.offset + half][~first].copy(),
+                        0, len(rest)).to_device(amd)
+        b2g = HostArray(gid_a[:half][~first].copy(), None, 0, len(rest)).to_device(amd)
+        k.consume(sa, [b2v, b2g])
+    k.consume(sa, [dev_vals.slice(half, n - half), ga.slice(half, n - half)])   # sliced: offsets != 0
+    k.resize(sb, nb)
+    k.consume(sb, [dev_vals_b, gb])
+    k.consume(sb, [amd.array.Scalar(7, amd.array.int64), gb.slice(0, 100)])     # broadcast scalar
+    k.consume(sb, [amd.array.Scalar(None, amd.array.int64, False), gb.slice(100, 3)])  # null scalar
+    k.merge(sa, sb, HostArray(perm, None, 0, nb).to_device(amd))
+    out = k.finalize(sa)
+
+    # oracle restatement of the very same call sequence
+    oa, ob = O.HashSumState(skip_nulls, min_count), O.HashSumState(skip_nulls, min_count)
+    oa.resize(num_groups)
+    oa.consume(np.ascontiguousarray(vals.values), vals.valid_bitmap(), vals.offset, gid_a)
+    ob.resize(nb)
+    ob.consume(np.ascontiguousarray(vals_b.values), vals_b.valid_bitmap(), vals_b.offset, gid_b_local)
+    ob.consume(None, None, 0, gid_b_local[:100], scalar=(7, True))
+    ob.consume(None, None, 0, gid_b_local[100:103], scalar=(0, False))
+    oa.merge(ob, perm)
+    want_sums, want_valid, want_nulls = oa.finalize()
+
+    tag = f"hash_sum_kernel[n={n},G={num_groups},skip_nulls={skip_nulls},min_count={min_count}]"
+    assert out.length == num_groups and out.type == amd.array.int64
+    got_valid, pad_ok = _logical_valid(out)
+    assert pad_ok, tag + ": validity padding bits not zero"
+    assert_equal(got_valid, want_valid, tag + " validity")
+    assert_equal(_data_np(out, np.int64)[got_valid], want_sums[want_valid], tag + " sums")
+    if skip_nulls:
+        assert out.null_count == want_nulls, tag
+        if want_nulls == 0:
+            assert out.validity is None  # Finish only allocates a bitmap when a group is null
+    if use_pyarrow and pa is not None:
+        # the reference, end to end: same rows keyed by the global group id
+        keys = np.concatenate([gid_a, perm[gid_b_local], perm[gid_b_local[:100]], perm[gid_b_local[100:103]]])
+        allv = pa.concat_arrays([vals.to_pyarrow(), vals_b.to_pyarrow(),
+                                 pa.array(np.full(100, 7, dtype=np.int64)),
+                                 pa.array([None] * 3, type=pa.int64())])
+        t = pa.table({"k": pa.array(keys.astype(np.int64)), "v": allv})
+        r = t.group_by("k", use_threads=False).aggregate(
+            [("v", "sum", pc.ScalarAggregateOptions(skip_nulls=skip_nulls, min_count=min_count))])
+        rk = r.column("k").combine_chunks().to_numpy()
+        rs = r.column("v_sum").combine_chunks()
+        rvalid = ~np.asarray(rs.is_null())
+        rsum = rs.fill_null(0).to_numpy(zero_copy_only=False)
+        for kk, vv, ok in zip(rk.tolist(), rsum.tolist(), rvalid.tolist()):
+            assert bool(got_valid[kk]) == ok, f"{tag}: group {kk} validity vs pyarrow"
+            if ok:
+                assert int(_data_np(out, np.int64)[kk]) == vv, f"{tag}: group {kk} sum vs pyarrow"
+    return out

@@ -276,3 +276,16 @@ def test_hash_sum_direct_call_is_rejected(emu_ctx):
     g = U.HostArray(np.zeros(4, dtype=np.uint32), None, 0, 4).to_device(emu_ctx)
     with pytest.raises(emu_ctx.ArrowNotImplementedError, match="Direct execution of HASH_AGGREGATE"):
         emu_ctx.compute.call_function("hash_sum", [a, g])
+
+
+@pytest.mark.parametrize("skip_nulls,min_count", [(True, 1), (False, 1), (True, 0), (True, 40), (False, 0)])
+def test_hash_sum_kernel_vtable(emu_ctx, skip_nulls, min_count):
+    """hash_sum(int64, uint32) through its HashAggregateKernel vtable: resize / consume (arrays,
+    slices, broadcast + null scalars) / merge via group_id_mapping / finalize
+    (hash_aggregate_numeric.cc:61-152; driven like groupby_aggregate_node.cc:210-337)."""
+    P.check_hash_sum_kernel(emu_ctx, rng_for("hsk", skip_nulls, min_count), n=3000, num_groups=37,
+                            skip_nulls=skip_nulls, min_count=min_count)
+
+
+def test_hash_sum_kernel_no_nulls_has_no_bitmap(emu_ctx):
+    P.check_hash_sum_kernel(emu_ctx, rng_for("hsk0"), n=1500, num_groups=11, null_p=0.0)

@@ -26,6 +26,8 @@ SCRIPT = textwrap.dedent(r'''
     f64a, f64b = pa.array(rng.standard_normal(n)), pa.array(rng.standard_normal(n), mask=rng.random(n) < 0.1)
     keys = pa.array(rng.integers(0, 2**63, n).astype(np.uint64), mask=rng.random(n) < 0.05)
     small = pa.array(np.arange(100))
+    gtab = pa.table({"k": pa.array(rng.integers(-500, 500, n).astype(np.int32), mask=rng.random(n) < 0.01),
+                     "v": pa.array(rng.integers(-2**63, 2**63 - 1, n), mask=rng.random(n) < 0.1)})
     def run():
         return dict(
             f_drop=pc.filter(vals, mask), f_emit=pc.filter(vals, mask, null_selection_behavior="emit_null"),
@@ -37,6 +39,11 @@ SCRIPT = textwrap.dedent(r'''
             sort_d=pc.array_sort_indices(keys, order="descending", null_placement="at_start"),
             small=pc.filter(small, pa.array(np.arange(100) % 2 == 0)),
             boolv=pc.filter(mask, mask),
+            cast=pc.cast(f64b, pa.float32(), safe=False), cast_slice=pc.cast(f64b.slice(5), pa.float32()),
+            cast_other=pc.cast(f64a.slice(0, 5000), pa.int64(), safe=False),
+            gb=gtab.group_by("k", use_threads=False).aggregate([("v", "sum")]).sort_by("k"),
+            gb_threads=gtab.group_by("k", use_threads=True).aggregate(
+                [("v", "sum", pc.ScalarAggregateOptions(skip_nulls=False, min_count=2))]).sort_by("k"),
         )
     stock = run()
     lib = ctypes.CDLL(so)
@@ -47,18 +54,27 @@ SCRIPT = textwrap.dedent(r'''
     lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(1000))
     ours = run()
     gpu_calls = lib.arrow_amd_plugin_gpu_calls()
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    fns = ["array_filter", "array_take", "greater", "array_sort_indices", "cast", "hash_sum"]
+    stats = {f: (lib.arrow_amd_plugin_calls(f.encode(), 1), lib.arrow_amd_plugin_calls(f.encode(), 0)) for f in fns}
     for k in stock:
-        assert ours[k].equals(stock[k]), k
+        assert ours[k].equals(stock[k]), (k, stats)
         if hasattr(ours[k], "null_count"):
             assert ours[k].null_count == stock[k].null_count, k
-    assert gpu_calls >= 12, gpu_calls            # every large call above took the HIP path
-    assert lib.arrow_amd_plugin_stock_calls() >= 2  # tiny / boolean-valued inputs went to the stock kernels
+    # every large call above took the HIP path: (gpu, stock) calls per function
+    want_gpu = {"array_filter": 4, "array_take": 4, "greater": 1, "array_sort_indices": 2, "cast": 2,
+                "hash_sum": 2}
+    for f, wmin in want_gpu.items():
+        assert stats[f][0] >= wmin, (f, stats)
+    assert stats["array_filter"][1] >= 2, stats   # tiny / boolean-valued inputs went to the stock kernels
+    assert stats["cast"][1] >= 1, stats           # float64 -> int64 is not ours: stock meta-function
     try:
         pc.take(vals, pa.array(np.array([0, n, 1] * 1000, dtype=np.int64)))
         raise SystemExit("expected IndexError")
     except pa.lib.ArrowIndexError as e:
         assert str(e) == f"Index {n} out of bounds", str(e)
-    print("PLUGIN_OK gpu_calls=%d stock_calls=%d" % (gpu_calls, lib.arrow_amd_plugin_stock_calls()))
+    print("PLUGIN_OK gpu_calls=%d stock_calls=%d %r" % (gpu_calls, lib.arrow_amd_plugin_stock_calls(), stats))
 ''')
 
 

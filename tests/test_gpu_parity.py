@@ -339,3 +339,16 @@ def test_large_filter_properties(gpu_ctx):
     assert torch.equal(idx.data[: s * 4].view(torch.int32).to(torch.int64) & 0xFFFFFFFF, want_idx)
     tk = amd.compute.take(values, idx, boundscheck=False)
     assert torch.equal(tk.data[: s * 8].view(torch.int64), want)
+
+
+@pytest.mark.parametrize("skip_nulls,min_count", [(True, 1), (False, 1), (True, 0), (True, 40), (False, 0)])
+def test_hash_sum_kernel_vtable(gpu_ctx, skip_nulls, min_count):
+    """hash_sum(int64, uint32) through its HashAggregateKernel vtable: resize / consume (arrays,
+    slices, broadcast + null scalars) / merge via group_id_mapping / finalize
+    (hash_aggregate_numeric.cc:61-152; driven like groupby_aggregate_node.cc:210-337)."""
+    P.check_hash_sum_kernel(gpu_ctx, rng_for("hsk", skip_nulls, min_count), n=400000, num_groups=5003,
+                            skip_nulls=skip_nulls, min_count=min_count)
+
+
+def test_hash_sum_kernel_no_nulls_has_no_bitmap(gpu_ctx):
+    P.check_hash_sum_kernel(gpu_ctx, rng_for("hsk0"), n=200000, num_groups=11, null_p=0.0)
