@@ -715,7 +715,11 @@ Status RegisterVector(cp::FunctionRegistry* reg, const std::string& name,
 Status RegisterAll() {
   ARROW_RETURN_NOT_OK(cp::Initialize());
   const int ndev = arx_device_count();
-  if (ndev < 1) {
+  // ARROW_AMD_PLUGIN_DRY_RUN=1: register without a device so the registration logic itself can be
+  // exercised on a GPU-less box (tests/test_plugin_registration.py); any call large enough to be
+  // routed to the HIP kernels then fails loudly with a HIP error — nothing computes on the CPU here.
+  const char* dry = std::getenv("ARROW_AMD_PLUGIN_DRY_RUN");
+  if (ndev < 1 && !(dry != nullptr && dry[0] == '1')) {
     return Status::Invalid("arrow_amd: no HIP device visible (", arx_last_error(),
                            "); nothing registered, Arrow keeps its stock kernels");
   }
@@ -750,8 +754,11 @@ Status RegisterAll() {
     auto* hfn = static_cast<cp::HashAggregateFunction*>(fn.get());
     ARROW_ASSIGN_OR_RAISE(const cp::Kernel* k0, hfn->DispatchExact({arrow::int64(), arrow::uint32()}));
     cp::HashAggregateKernel copy = *static_cast<const cp::HashAggregateKernel*>(k0);
+    // the stock signature's output resolver casts the kernel state to the reference's
+    // GroupedAggregator (hash_aggregate_internal.h:88-91) — ours is not one: state the type
+    // (FindAccumulatorType<Int64Type> = int64, aggregate_internal.h:41-44)
     copy.signature = cp::KernelSignature::Make({cp::InputType(arrow::int64()), cp::InputType(arrow::uint32())},
-                                               copy.signature->out_type());
+                                               cp::OutputType(arrow::int64()));
     copy.init = HashSumInit;
     copy.resize = HashSumResize;
     copy.consume = HashSumConsume;

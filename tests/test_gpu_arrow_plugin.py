@@ -67,7 +67,7 @@ SCRIPT = textwrap.dedent(r'''
                 "hash_sum": 2}
     for f, wmin in want_gpu.items():
         assert stats[f][0] >= wmin, (f, stats)
-    assert stats["array_filter"][1] >= 2, stats   # tiny / boolean-valued inputs went to the stock kernels
+    assert stats["array_filter"][1] >= 1, stats   # the tiny input was handed to the stock kernel (boolean values never reach the shim)
     assert stats["cast"][1] >= 1, stats           # float64 -> int64 is not ours: stock meta-function
     try:
         pc.take(vals, pa.array(np.array([0, n, 1] * 1000, dtype=np.int64)))
