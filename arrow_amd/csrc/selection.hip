@@ -545,6 +545,107 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(CompactArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------ K3': sparse compaction
+// The form used when few rows are selected (S <= N/4): instead of sweeping all 4096 rows of the
+// tile, every lane walks the set bits of its own mask word and appends the row numbers to a
+// per-wave LDS list at their output rank; the wave then gathers 64 selected rows per step —
+// lane j loads values[row_j] (8 bytes) and stores out[off + s + j], a fully coalesced 512-byte
+// run — so the instruction count scales with the rows emitted, not the rows scanned.  HBM
+// traffic is the same as K3 (128-byte lines without a selected row are never touched).
+// Steps are aligned to 64-bit words of the OUTPUT bitmap, so the output validity of a step is
+// one __ballot: full words are stored, the tile's first/last partial words are OR-ed in.
+struct __attribute__((aligned(16))) SparseLds {
+  uint16_t sel[kWavesPerBlock][kTileRows];  // row-in-tile of the s-th emitted row
+  uint64_t vs[kWavesPerBlock][64];          // values_valid & mask_valid words of the tile
+  uint64_t zw[kWavesPerBlock][64];          // rows emitted only because the mask slot is null
+};
+
+template <int W, bool EMIT>
+__global__ __launch_bounds__(kBlock) void compact_sparse_kernel(CompactArgs a) {
+  using E = typename ElemT<W>::type;
+  constexpr int U = 4;  // gather steps in flight
+  __shared__ SparseLds lds;
+
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  if (t >= a.ntiles) return;  // wave-uniform; no workgroup barrier below
+
+  const int64_t w = t * 64 + lane;
+  uint64_t mv;
+  const uint64_t Ew = emit_word(a.mask, a.mvalid, w, EMIT, a.invert != 0, &mv);
+  const uint32_t k = __popcll(Ew);
+  const uint32_t incl = wave_inclusive_scan_u32(k);
+  const uint32_t p = incl - k;
+  const int total = static_cast<int>(__shfl(incl, 63, 64));
+  if (total == 0) return;
+
+  const int64_t grp = t >> 6;
+  const int tin = static_cast<int>(t & 63);
+  const uint32_t cprev = lane < tin ? a.tile_counts[grp * kTilesPerGroup + lane] : 0u;
+  const int64_t off = a.group_excl[grp] + wave_reduce_sum_u32(cprev);
+
+  // ---- 1. row list + validity words into LDS
+  uint16_t* sel = lds.sel[wave];
+  {
+    uint64_t m = Ew;
+    uint32_t rk = p;
+    while (m != 0) {
+      const int bpos = __ffsll(static_cast<unsigned long long>(m)) - 1;
+      m &= m - 1;
+      sel[rk++] = static_cast<uint16_t>(lane * 64 + bpos);
+    }
+  }
+  const bool want_validity = a.out_validity != nullptr;
+  if (want_validity) lds.vs[wave][lane] = load_word(a.vvalid, w) & mv;
+  if constexpr (EMIT) lds.zw[wave][lane] = Ew & ~mv;
+  wave_lds_sync();
+
+  // ---- 2. gather, 64 emitted rows per step, steps aligned to output bitmap words
+  const E* __restrict__ values = reinterpret_cast<const E*>(a.values) + t * kTileRows;
+  E* __restrict__ out = reinterpret_cast<E*>(a.out_data);
+  const int head = static_cast<int>(off & 63);      // the first step starts `head` bits into a word
+  const int nsteps = (head + total + 63) >> 6;
+  const int64_t word0 = off >> 6;
+  for (int i0 = 0; i0 < nsteps; i0 += U) {
+    int s[U];
+    bool act[U];
+    int r[U];
+    E v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s[u] = (i0 + u) * 64 + lane - head;  // emitted-row number inside the tile
+      act[u] = s[u] >= 0 && s[u] < total;
+      r[u] = act[u] ? sel[s[u]] : sel[0];  // inactive lanes re-read a row the wave reads anyway
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = values[r[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if ((i0 + u) >= nsteps) break;  // wave-uniform
+      E e = v[u];
+      if constexpr (EMIT) {
+        if ((lds.zw[wave][r[u] >> 6] >> (r[u] & 63)) & 1ull) e = zero_elem<W>();
+      }
+      if (act[u]) out[off + s[u]] = e;
+      if (want_validity) {
+        const bool vbit = act[u] && ((lds.vs[wave][r[u] >> 6] >> (r[u] & 63)) & 1ull);
+        const uint64_t bal = __ballot(vbit);
+        const uint64_t owned = __ballot(act[u]);
+        if (lane == 0) {
+          uint64_t* dst = a.out_validity + word0 + i0 + u;
+          if (owned == ~uint64_t(0)) {
+            *dst = bal;  // the whole output word belongs to this tile
+          } else if (bal != 0) {
+            atomicOr(reinterpret_cast<unsigned long long*>(dst), static_cast<unsigned long long>(bal));
+          }
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ take
 struct TakeArgs {
   const uint8_t* values;   // pre-offset to element 0
@@ -559,10 +660,11 @@ struct TakeArgs {
   unsigned long long* valid_count; // may be NULL
 };
 
-// Every load below is unconditional: lanes that must not gather (row past the end, null index,
-// null source value) read a harmless in-bounds address instead — their own output slot — and the
-// result is discarded.  With no branches the compiler issues the U index loads, then the U
-// validity probes, then the U gathers back to back (3 dependent round trips per 64*U rows).
+// Every load below is unconditional: lanes that must not gather (row past the end, null index)
+// read a harmless in-bounds address instead — their own output slot — and the result is
+// discarded.  With no branches the compiler issues the U index loads, then the U value gathers
+// and the U source-validity probes back to back: 2 dependent round trips per 64*U rows (the
+// value of a null source slot is loaded and dropped — it is addressable memory).
 template <int W, typename IdxT, bool HAS_IV, bool HAS_SV>
 __global__ __launch_bounds__(kBlock) void take_kernel(TakeArgs a) {
   using E = typename ElemT<W>::type;
@@ -596,6 +698,12 @@ __global__ __launch_bounds__(kBlock) void take_kernel(TakeArgs a) {
         ok[u] = ok[u] && ((wbits >> lane) & 1ull);
       }
     }
+    E val[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const E* src = ok[u] ? (values + idx[u]) : (out + pos[u]);
+      val[u] = *src;
+    }
     if constexpr (HAS_SV) {
       uint8_t vb[U];
 #pragma unroll
@@ -608,12 +716,6 @@ __global__ __launch_bounds__(kBlock) void take_kernel(TakeArgs a) {
         const uint64_t bit = static_cast<uint64_t>(a.src_valid_offset) + idx[u];
         ok[u] = ok[u] && ((vb[u] >> (bit & 7)) & 1);
       }
-    }
-    E val[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const E* src = ok[u] ? (values + idx[u]) : (out + pos[u]);
-      val[u] = *src;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -733,6 +835,7 @@ static int launch_count(const ArxSpan* mask, int null_selection, void* ws, size_
 // Tuning knobs (arx_set_option): filter_batch in {1,4}, filter_pipe in {0,1}.  Results never change.
 static int g_filter_batch = 4;
 static int g_filter_pipe = 1;
+static int g_filter_sparse = -1;  // -1 = by selectivity (S <= N/4), 0 = never, 1 = always
 
 template <int W, bool IOTA, bool EMIT, bool ALIGNED>
 static void launch_compact_e(const CompactArgs& a, unsigned grid, hipStream_t st) {
@@ -760,8 +863,36 @@ static void launch_compact_w(const CompactArgs& a, unsigned grid, hipStream_t st
   }
 }
 
-static int launch_compact(bool iota, int W, const CompactArgs& a, hipStream_t st) {
+template <int W>
+static void launch_sparse_w(const CompactArgs& a, unsigned grid, hipStream_t st) {
+  if (a.emit_null) {
+    hipLaunchKernelGGL((compact_sparse_kernel<W, true>), dim3(grid), dim3(kBlock), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((compact_sparse_kernel<W, false>), dim3(grid), dim3(kBlock), 0, st, a);
+  }
+}
+
+// out_length < 0: unknown -> the sweeping form
+static int launch_compact(bool iota, int W, const CompactArgs& a, hipStream_t st,
+                          int64_t out_length = -1) {
   const unsigned grid = static_cast<unsigned>(ceil_div(a.ntiles, kWavesPerBlock));
+  const bool sparse = !iota && !a.invert &&
+                      (g_filter_sparse == 1 ||
+                       (g_filter_sparse < 0 && out_length >= 0 && out_length * 4 <= a.length));
+  if (sparse) {
+    switch (W) {
+      case 1: launch_sparse_w<1>(a, grid, st); break;
+      case 2: launch_sparse_w<2>(a, grid, st); break;
+      case 4: launch_sparse_w<4>(a, grid, st); break;
+      case 8: launch_sparse_w<8>(a, grid, st); break;
+      case 16: launch_sparse_w<16>(a, grid, st); break;
+      default:
+        set_error("unsupported byte width %d for the gfx950 filter", W);
+        return ARX_NOT_IMPLEMENTED;
+    }
+    ARX_CHECK_LAUNCH("compact_sparse_kernel");
+    return ARX_OK;
+  }
   if (iota) {
     switch (W) {
       case 2: launch_compact_w<2, true>(a, grid, st); break;
@@ -794,6 +925,10 @@ int set_selection_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "filter_pipe") == 0) {
     g_filter_pipe = value != 0;
+    return 1;
+  }
+  if (strcmp(name, "filter_sparse") == 0) {
+    g_filter_sparse = value < 0 ? -1 : (value != 0);
     return 1;
   }
   return 0;
@@ -928,7 +1063,7 @@ int arx_filter_exec(const ArxSpan* values, int byte_width, const ArxSpan* mask, 
   }
   rc = zero_out_validity(out_validity, out_length, st);
   if (rc != ARX_OK) return rc;
-  return launch_compact(false, byte_width, a, st);
+  return launch_compact(false, byte_width, a, st, out_length);
 }
 
 int arx_mask_to_indices(const ArxSpan* mask, int null_selection, const void* ws, int64_t out_length,

@@ -289,3 +289,32 @@ def test_hash_sum_kernel_vtable(emu_ctx, skip_nulls, min_count):
 
 def test_hash_sum_kernel_no_nulls_has_no_bitmap(emu_ctx):
     P.check_hash_sum_kernel(emu_ctx, rng_for("hsk0"), n=1500, num_groups=11, null_p=0.0)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_filter_forced_sweep_and_sparse_forms(emu_ctx, mode):
+    """filter_sparse = 0 forces the sweeping compaction, 1 the gather form, for EVERY selectivity,
+    null density, offset, width and length class: both must be bit-exact (auto picks by S/N)."""
+    lib = emu_ctx._lib.get_lib()
+    assert lib.arx_set_option(b"filter_sparse", mode) == 0
+    try:
+        for n in (1, 63, 64, 65, 4095, 4096, 4097, 9000):
+            for sel in ("drop", "emit_null"):
+                rng = rng_for("fform", n, sel)
+                v = U.random_array(rng, np.int64, n, null_p=0.1, offset=n % 5)
+                m = U.random_mask(rng, n, 0.3, null_p=0.05, offset=n % 3)
+                P.check_filter(emu_ctx, v, m, sel, use_pyarrow=False)
+        for true_p in (0.0, 0.02, 0.5, 1.0):
+            for vnull, mnull in ((0.0, 0.0), (0.2, 0.0), (0.0, 0.3), (1.0, 1.0)):
+                for sel in ("drop", "emit_null"):
+                    rng = rng_for("fform2", true_p, vnull, mnull, sel)
+                    v = U.random_array(rng, np.int64, 20000, null_p=vnull, offset=7)
+                    m = U.random_mask(rng, 20000, true_p, null_p=mnull, offset=13)
+                    P.check_filter(emu_ctx, v, m, sel, use_pyarrow=False)
+        for dtype in (np.int8, np.uint16, np.float32, np.float64):
+            rng = rng_for("fform3", str(dtype))
+            v = U.random_array(rng, dtype, 12345, null_p=0.1, offset=3)
+            m = U.random_mask(rng, 12345, 0.15, null_p=0.05, offset=1)
+            P.check_filter(emu_ctx, v, m, "emit_null", use_pyarrow=False)
+    finally:
+        lib.arx_set_option(b"filter_sparse", -1)
