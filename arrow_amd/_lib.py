@@ -21,6 +21,8 @@ ARX_INDEX_ERROR = -7
 ARX_NOT_IMPLEMENTED = -10
 ARX_DEVICE_ERROR = -100
 
+ABI_VERSION = 2  # ARX_ABI_VERSION of include/arrow_amd.h
+
 FILTER_DROP, FILTER_EMIT_NULL = 0, 1
 SORT_ASCENDING, SORT_DESCENDING = 0, 1
 NULLS_AT_START, NULLS_AT_END = 0, 1
@@ -102,7 +104,8 @@ SIGNATURES = {
     "arx_sort_indices_64": (_int, [_span, _int, _int, _int, _p, _sz, _p, _p]),
     "arx_groupby_state_bytes": (_sz, [_i64]),
     "arx_groupby_init": (_int, [_p, _i64, _p]),
-    "arx_groupby_sum_i64_consume": (_int, [_p, _i64, _span, _span, _p]),
+    "arx_groupby_consume_workspace_bytes": (_sz, [_i64, _i64]),
+    "arx_groupby_sum_i64_consume": (_int, [_p, _i64, _span, _span, _p, _sz, _p]),
     "arx_groupby_sum_i64_merge": (_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p]),
     "arx_groupby_num_groups": (_int, [_p, C.POINTER(_i64), _p]),
     "arx_groupby_sum_i64_export": (_int, [_p, _p, _p, _p, _p, _p, _p]),
@@ -130,7 +133,7 @@ def load(path: str | None = None):
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.arx_abi_version() != 1:
+    if lib.arx_abi_version() != ABI_VERSION:
         raise ArrowDeviceError("libarrow_amd.so ABI version mismatch")
     return lib
 

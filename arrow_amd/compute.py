@@ -720,8 +720,14 @@ class GroupBySum:
             raise ArrowNotImplementedError("GroupBySum: int32 keys and int64 values only")
         lib, stream = _lib_and_stream(self.device)
         ks, vs = keys.span(), values.span()
+        ws_bytes = lib.arx_groupby_consume_workspace_bytes(keys.length, self.capacity)
+        ws_ptr, ws_len = None, 0
+        if ws_bytes:
+            ws = _workspace(self.device, ws_bytes + 256, "groupby")
+            ws_ptr = (ws.data_ptr() + 255) & ~255
+            ws_len = ws.numel() - (ws_ptr - ws.data_ptr())
         check(lib.arx_groupby_sum_i64_consume(self.state.data_ptr(), self.capacity, C.byref(ks),
-                                              C.byref(vs), stream))
+                                              C.byref(vs), ws_ptr, ws_len, stream))
 
     def num_groups(self) -> int:
         lib, stream = _lib_and_stream(self.device)

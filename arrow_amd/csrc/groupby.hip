@@ -17,6 +17,8 @@
 // 64-bit atomic adds (integer sums are associative and commutative, so any order is bit-exact).
 #include "arx_common.h"
 
+#include <string.h>
+
 #include <algorithm>
 
 namespace arx {
@@ -127,39 +129,60 @@ __global__ __launch_bounds__(kBlock) void groupby_merge_kernel(
   }
 }
 
+// One workgroup per 4096 consecutive slots: count the occupied ones, reserve the output range
+// with ONE atomic per workgroup, then write them out (order unspecified, as for the reference).
+constexpr int kExportSlotsPerBlock = kBlock * 16;
+
 __global__ __launch_bounds__(kBlock) void groupby_export_kernel(
     GroupbyView v, int32_t* __restrict__ out_keys, uint8_t* __restrict__ out_key_is_valid,
     int64_t* __restrict__ out_sums, int64_t* __restrict__ out_counts,
     uint8_t* __restrict__ out_no_nulls) {
-  const int lane = lane_id();
+  __shared__ uint32_t wave_tot[kWavesPerBlock];
+  __shared__ unsigned long long base_s;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
   const int64_t nslots = v.capacity + 1;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  const int64_t rounds = (nslots + stride - 1) / stride;
-  for (int64_t r = 0; r < rounds; ++r) {
-    const int64_t s = r * stride + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    bool occ = false;
-    unsigned long long tagged = 0;
-    if (s < v.capacity) {
-      tagged = v.keys[s];
-      occ = tagged != 0;
-    } else if (s == v.capacity) {
-      occ = v.hdr->null_used != 0;
+  const int64_t s0 = static_cast<int64_t>(blockIdx.x) * kExportSlotsPerBlock;
+  unsigned long long tagged[16];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t sl = s0 + i * kBlock + tid;
+    tagged[i] = 0;
+    if (sl < v.capacity) {
+      tagged[i] = v.keys[sl];
+    } else if (sl == v.capacity) {
+      tagged[i] = v.hdr->null_used != 0 ? 1ull : 0ull;  // any non-zero marker
     }
-    const uint64_t bal = __ballot(occ);
-    if (bal == 0) continue;  // wave-uniform
-    unsigned long long base = 0;
-    const int leader = __ffsll(static_cast<unsigned long long>(bal)) - 1;
-    if (lane == leader) base = atomicAdd(&v.hdr->export_cursor, static_cast<unsigned long long>(__popcll(bal)));
-    base = shfl_u64(base, leader);
-    if (occ) {
-      const int64_t pos = static_cast<int64_t>(base) + __popcll(bal & ((uint64_t(1) << lane) - 1));
-      out_keys[pos] = s < v.capacity ? static_cast<int32_t>(static_cast<uint32_t>(tagged)) : 0;
-      out_key_is_valid[pos] = s < v.capacity ? 1 : 0;
-      out_sums[pos] = static_cast<int64_t>(v.sums[s]);
-      out_counts[pos] = static_cast<int64_t>(v.counts[s]);
-      out_no_nulls[pos] = (v.flags[s] & 1u) ? 0 : 1;
-    }
+    mine += tagged[i] != 0 ? 1u : 0u;
   }
+  const uint32_t incl = wave_inclusive_scan_u32(mine);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t pre = incl - mine;
+  uint32_t total = 0;
+  for (int k = 0; k < kWavesPerBlock; ++k) {
+    if (k < wave) pre += wave_tot[k];
+    total += wave_tot[k];
+  }
+  if (total == 0) return;  // workgroup-uniform
+  if (tid == 0) base_s = atomicAdd(&v.hdr->export_cursor, static_cast<unsigned long long>(total));
+  __syncthreads();
+  int64_t pos = static_cast<int64_t>(base_s) + pre;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (tagged[i] == 0) continue;
+    const int64_t sl = s0 + i * kBlock + tid;
+    const bool is_key = sl < v.capacity;
+    out_keys[pos] = is_key ? static_cast<int32_t>(static_cast<uint32_t>(tagged[i])) : 0;
+    out_key_is_valid[pos] = is_key ? 1 : 0;
+    out_sums[pos] = static_cast<int64_t>(v.sums[sl]);
+    out_counts[pos] = static_cast<int64_t>(v.counts[sl]);
+    out_no_nulls[pos] = (v.flags[sl] & 1u) ? 0 : 1;
+    ++pos;
+  }
+  (void)nslots;
 }
 
 __global__ __launch_bounds__(kBlock) void groupby_finalize_kernel(const int64_t* __restrict__ counts,
@@ -313,13 +336,672 @@ static inline unsigned gb_grid(int64_t n) {
   return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock), 256 * 16)));
 }
 
+// =====================================================================================
+// Radix-partitioned consume (the fast path of arx_groupby_sum_i64_consume).
+//
+// Device-scope atomics into the HBM table top out at ~12 Grows/s whatever the table size
+// (profiles/: exp_groupby_atomics) — the atomic units, not HBM, are the bound.  So rows are first
+// partitioned by the top `bits` bits of a bijective 32-bit hash of the key until one partition's
+// groups fit an LDS table (4096 slots, 64 KiB), aggregated there with LDS atomics, and only the
+// per-partition partial aggregates (one row per group) touch the HBM table:
+//   K0 gbp_null_rows    rows with a null key or a null value take the slow path (HBM atomics)
+//   K1 gbp_hist         per-chunk level-1 digit counts + global per-partition counts  (4 B/row)
+//   K2 gbp_scan_a/_b    partition starts, level-1 chunk offsets, level-2 cursors, tile map
+//   K3 gbp_scatter<1>   level 1: chunked, exact offsets (no atomics)            (12 + 12 B/row)
+//   K4 gbp_scatter<2>   level 2 inside every level-1 partition, one returning atomic per
+//                       (tile, digit) on a cursor only that partition's tiles touch (12 + 12 B/row)
+//   K5 gbp_aggregate    one workgroup per partition: LDS open-addressing table keyed by the low
+//                       hash bits (the hash is a bijection, so low bits + partition id = key),
+//                       ds_add_u64 sums / ds_add_u32 counts, then a flush of <= 4096 partials
+//                       into the HBM table                                           (12 B/row)
+// Row order inside a partition is irrelevant (integer sums commute), so ranking uses LDS atomics.
+// =====================================================================================
+constexpr int kGbThreads = 512;
+constexpr int kGbTile = 4096;             // rows per scatter tile (8 per thread)
+constexpr int kGbRowsPerThread = kGbTile / kGbThreads;
+constexpr int kGbMaxBins = 256;           // per level
+constexpr int kGbMaxBits = 14;
+constexpr int kGbMaxChunks = 2048;
+constexpr int kGbSlots = 4096;            // LDS table slots per partition
+constexpr int kGbAggChunk = 1 << 16;      // rows per aggregate work unit
+constexpr uint32_t kGbHashMul = 0x9E3779B1u;     // odd => k -> k * M mod 2^32 is a bijection
+constexpr uint32_t kGbHashInv = 0x0E8B2F51u;     // M * Minv == 1 mod 2^32
+static_assert(static_cast<uint32_t>(kGbHashMul * kGbHashInv) == 1u, "hash inverse");
+
+__device__ __forceinline__ uint32_t gbp_hash(int32_t key) {
+  return static_cast<uint32_t>(key) * kGbHashMul;
+}
+
+struct GbpArgs {
+  const int32_t* keys;     // element 0 of this slice
+  const int64_t* values;
+  Bits kvalid, vvalid;     // logical bitmaps of this slice (base == NULL: all valid)
+  int64_t n;               // rows in this slice
+  int bits, b1, b2;        // partition bits: total, level 1, level 2 (b2 == 0: one level)
+  int64_t chunk_rows;      // level-1 chunk (a multiple of kGbTile)
+  int64_t nchunks;
+  uint32_t* part_count;    // [2^bits]
+  uint32_t* part_start;    // [2^bits + 1]
+  uint32_t* cursor2;       // [2^bits]
+  uint32_t* hist1;         // [2^b1 * nchunks], digit-major
+  uint32_t* l1_start;      // [2^b1 + 1]
+  uint32_t* l2_tile_start; // [2^b1 + 1]
+  uint32_t* agg_unit_start; // [2^bits + 1]: aggregate work units (<= kGbAggChunk rows) before partition p
+  int32_t* keys_a;
+  int64_t* vals_a;
+  int32_t* keys_b;
+  int64_t* vals_b;
+};
+
+template <bool HAS_NULLS>
+__device__ __forceinline__ bool gbp_streamed(const GbpArgs& a, int64_t r) {
+  if constexpr (!HAS_NULLS) {
+    return true;
+  } else {
+    const uint64_t kv = load_word(a.kvalid, r >> 6);
+    const uint64_t vv = load_word(a.vvalid, r >> 6);
+    return ((kv & vv) >> (r & 63)) & 1ull;
+  }
+}
+
+// ---- K0: rows that are not fully valid.  Null key => the null-key group (wave-reduced, one
+// atomic per wave); valid key + null value => the group must exist and gets its null flag.
+__global__ __launch_bounds__(kBlock) void gbp_null_rows_kernel(GroupbyView v, GbpArgs a) {
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwords = (a.n + 63) >> 6;
+  unsigned long long nsum = 0, ncnt = 0;
+  bool nflag = false, nseen = false;
+  for (int64_t w = wave_g; w < nwords; w += nwaves) {
+    const uint64_t kv = load_word(a.kvalid, w);
+    const uint64_t vv = load_word(a.vvalid, w);
+    const uint64_t in_range = load_word(Bits{nullptr, 0, a.n, 0}, w);
+    const uint64_t bad = ~(kv & vv) & in_range;
+    if (bad == 0) continue;  // wave-uniform
+    if ((bad >> lane) & 1ull) {
+      const int64_t r = (w << 6) + lane;
+      const bool kok = (kv >> lane) & 1ull;
+      const bool vok = (vv >> lane) & 1ull;
+      if (kok) {  // => value is null
+        const int64_t slot = gb_find_or_insert(v, a.keys[r]);
+        if (slot < 0) atomicExch(&v.hdr->overflow, 1u);
+        else atomicOr(&v.flags[slot], 1u);
+      } else {
+        nseen = true;
+        if (vok) {
+          nsum += static_cast<unsigned long long>(a.values[r]);
+          ncnt += 1;
+        } else {
+          nflag = true;
+        }
+      }
+    }
+  }
+  const bool any_seen = __any(nseen);
+  if (!any_seen) return;
+  nsum = wave_reduce_sum_u64(nsum);
+  ncnt = wave_reduce_sum_u64(ncnt);
+  const bool any_flag = __any(nflag);
+  if (lane == 0) {
+    const int64_t slot = gb_null_slot(v);
+    if (ncnt != 0) {
+      atomicAdd(&v.sums[slot], nsum);
+      atomicAdd(&v.counts[slot], ncnt);
+    }
+    if (any_flag) atomicOr(&v.flags[slot], 1u);
+  }
+}
+
+// ---- K1: histogram.  One workgroup per level-1 chunk.
+template <bool HAS_NULLS>
+__global__ __launch_bounds__(kGbThreads) void gbp_hist_kernel(GbpArgs a) {
+  __shared__ uint32_t h[1 << kGbMaxBits];
+  const int tid = threadIdx.x;
+  const int nparts = 1 << a.bits;
+  for (int i = tid; i < nparts; i += kGbThreads) h[i] = 0;
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * a.chunk_rows;
+  const int64_t end = begin + a.chunk_rows < a.n ? begin + a.chunk_rows : a.n;
+  const int shift = 32 - a.bits;
+  constexpr int U = 8;  // independent key loads in flight per thread
+  int64_t r = begin + tid;
+  for (; r + (U - 1) * kGbThreads < end; r += U * kGbThreads) {
+    int32_t kk[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      kk[u] = a.keys[r + u * kGbThreads];
+      ok[u] = gbp_streamed<HAS_NULLS>(a, r + u * kGbThreads);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ok[u]) atomicAdd(&h[gbp_hash(kk[u]) >> shift], 1u);
+    }
+  }
+  for (; r < end; r += kGbThreads) {
+    if (gbp_streamed<HAS_NULLS>(a, r)) atomicAdd(&h[gbp_hash(a.keys[r]) >> shift], 1u);
+  }
+  __syncthreads();
+  for (int i = tid; i < nparts; i += kGbThreads) {
+    const uint32_t c = h[i];
+    if (c != 0) atomicAdd(&a.part_count[i], c);
+  }
+  const int nb1 = 1 << a.b1;
+  const int per = 1 << a.b2;
+  for (int d = tid; d < nb1; d += kGbThreads) {
+    uint32_t sum = 0;
+    for (int j = 0; j < per; ++j) sum += h[(d << a.b2) + j];
+    a.hist1[static_cast<int64_t>(d) * a.nchunks + blockIdx.x] = sum;
+  }
+}
+
+// ---- K2a: one workgroup.  part_start = exclusive scan of part_count; level-1 starts; level-2
+// cursors; the level-2 tile map (how many tiles each level-1 partition needs).
+__global__ __launch_bounds__(1024) void gbp_scan_a_kernel(GbpArgs a) {
+  __shared__ uint32_t ps[(1 << kGbMaxBits) + 1];
+  __shared__ uint32_t wave_tot[16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nparts = 1 << a.bits;
+  const int per = (nparts + 1023) / 1024;
+  const int b = tid * per;
+  const int e = b + per < nparts ? b + per : nparts;
+  uint32_t sum = 0;
+  for (int i = b; i < e; ++i) sum += a.part_count[i];
+  const uint32_t incl = wave_inclusive_scan_u32(sum);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t prefix = incl - sum;
+  for (int k = 0; k < wave; ++k) prefix += wave_tot[k];
+  for (int i = b; i < e; ++i) {
+    ps[i] = prefix;
+    prefix += a.part_count[i];
+  }
+  if (tid == 1023) ps[nparts] = prefix;
+  __syncthreads();
+  for (int i = tid; i <= nparts; i += 1024) {
+    const uint32_t s0 = ps[i];
+    a.part_start[i] = s0;
+    if (i < nparts) a.cursor2[i] = s0;
+  }
+  const int nb1 = 1 << a.b1;
+  for (int d = tid; d <= nb1; d += 1024) a.l1_start[d] = ps[d == nb1 ? nparts : (d << a.b2)];
+  // tile map of level 2 (nb1 <= 256 entries): exclusive scan of ceil(size / tile)
+  __syncthreads();
+  uint32_t tiles = 0;
+  if (tid < nb1) {
+    const uint32_t lo = ps[tid << a.b2];
+    const uint32_t hi = ps[(tid + 1) == nb1 ? nparts : ((tid + 1) << a.b2)];
+    tiles = (hi - lo + kGbTile - 1) / kGbTile;
+  }
+  const uint32_t tincl = wave_inclusive_scan_u32(tiles);
+  __syncthreads();
+  if (lane == 63) wave_tot[wave] = tincl;
+  __syncthreads();
+  uint32_t tprefix = tincl - tiles;
+  for (int k = 0; k < wave; ++k) tprefix += wave_tot[k];
+  if (tid < nb1) a.l2_tile_start[tid] = tprefix;
+  if (tid == nb1 - 1) a.l2_tile_start[nb1] = tprefix + tiles;
+  // aggregate work units: every partition is cut into pieces of <= kGbAggChunk rows
+  __syncthreads();
+  uint32_t usum = 0;
+  for (int i = b; i < e; ++i) usum += (ps[i + 1] - ps[i] + kGbAggChunk - 1) / kGbAggChunk;
+  const uint32_t uincl = wave_inclusive_scan_u32(usum);
+  if (lane == 63) wave_tot[wave] = uincl;
+  __syncthreads();
+  uint32_t uprefix = uincl - usum;
+  for (int k = 0; k < wave; ++k) uprefix += wave_tot[k];
+  for (int i = b; i < e; ++i) {
+    a.agg_unit_start[i] = uprefix;
+    uprefix += (ps[i + 1] - ps[i] + kGbAggChunk - 1) / kGbAggChunk;
+  }
+  if (tid == 1023) a.agg_unit_start[nparts] = uprefix;
+}
+
+// ---- K2b: one workgroup per level-1 digit: hist1[d][*] -> exclusive offsets (+ l1_start[d]).
+__global__ __launch_bounds__(1024) void gbp_scan_b_kernel(GbpArgs a) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  uint32_t* row = a.hist1 + static_cast<int64_t>(blockIdx.x) * a.nchunks;
+  if (tid == 0) carry_s = a.l1_start[blockIdx.x];
+  __syncthreads();
+  for (int64_t base = 0; base < a.nchunks; base += 1024) {
+    const int64_t i = base + tid;
+    const uint32_t x = i < a.nchunks ? row[i] : 0u;
+    const uint32_t incl = wave_inclusive_scan_u32(x);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t prefix = incl - x;
+    for (int k = 0; k < wave; ++k) prefix += wave_tot[k];
+    const uint32_t carry = carry_s;
+    if (i < a.nchunks) row[i] = carry + prefix;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + prefix + x;
+    __syncthreads();
+  }
+}
+
+// ---- K3/K4: scatter one tile through LDS.
+struct __attribute__((aligned(16))) GbpScatterLds {
+  uint64_t vals[kGbTile];
+  uint32_t keys[kGbTile];
+  uint32_t cnt[kGbMaxBins];
+  uint32_t start[kGbMaxBins];
+  uint32_t gbase[kGbMaxBins];
+  uint32_t cursor[kGbMaxBins];
+  uint32_t wave_tot[kGbThreads / 64];
+};
+
+// LEVEL 1: input = the caller's arrays (validity applies), digit = top b1 bits, offsets from the
+//          chunk cursors.   LEVEL 2: input = level-1 output, digit = next b2 bits, offsets from
+//          cursor2 atomics.
+template <int LEVEL, bool HAS_NULLS>
+__device__ __forceinline__ void gbp_scatter_tile(const GbpArgs& a, GbpScatterLds& lds,
+                                                 const int32_t* __restrict__ kin,
+                                                 const int64_t* __restrict__ vin, int64_t row0,
+                                                 int nrows, uint32_t part_hi,
+                                                 int32_t* __restrict__ kout,
+                                                 int64_t* __restrict__ vout) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nb = LEVEL == 1 ? (1 << a.b1) : (1 << a.b2);
+  const int dshift = LEVEL == 1 ? (32 - a.b1) : (32 - a.bits);
+  const uint32_t dmask = static_cast<uint32_t>(nb - 1);
+  if (tid < nb) lds.cnt[tid] = 0;
+  __syncthreads();
+
+  int32_t key[kGbRowsPerThread];
+  int64_t val[kGbRowsPerThread];
+  int dig[kGbRowsPerThread];
+  uint32_t rank[kGbRowsPerThread];
+#pragma unroll
+  for (int i = 0; i < kGbRowsPerThread; ++i) {
+    const int p = i * kGbThreads + tid;
+    dig[i] = -1;
+    key[i] = 0;
+    val[i] = 0;
+    if (p < nrows) {
+      bool ok = true;
+      if constexpr (LEVEL == 1 && HAS_NULLS) ok = gbp_streamed<true>(a, row0 + p);
+      if (ok) {
+        key[i] = kin[row0 + p];
+        val[i] = vin[row0 + p];
+        dig[i] = static_cast<int>((gbp_hash(key[i]) >> dshift) & dmask);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kGbRowsPerThread; ++i) {
+    rank[i] = 0;
+    if (dig[i] >= 0) rank[i] = atomicAdd(&lds.cnt[dig[i]], 1u);
+  }
+  __syncthreads();
+
+  // exclusive scan of the bin counts (nb <= 256 = 4 waves) + global run bases
+  uint32_t c = 0;
+  if (tid < nb) c = lds.cnt[tid];
+  const uint32_t incl = wave_inclusive_scan_u32(c);
+  if (lane == 63) lds.wave_tot[wave] = incl;
+  __syncthreads();
+  if (tid < nb) {
+    uint32_t pre = incl - c;
+    for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
+    lds.start[tid] = pre;
+    if constexpr (LEVEL == 1) {
+      const uint32_t g = lds.cursor[tid];
+      lds.gbase[tid] = g;
+      lds.cursor[tid] = g + c;
+    } else {
+      lds.gbase[tid] = c != 0 ? atomicAdd(&a.cursor2[(part_hi << a.b2) + tid], c) : 0u;
+    }
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int i = 0; i < kGbRowsPerThread; ++i) {
+    if (dig[i] >= 0) {
+      const uint32_t pos = lds.start[dig[i]] + rank[i];
+      lds.keys[pos] = static_cast<uint32_t>(key[i]);
+      lds.vals[pos] = static_cast<uint64_t>(val[i]);
+    }
+  }
+  __syncthreads();
+
+  const int total = static_cast<int>(lds.start[nb - 1] + lds.cnt[nb - 1]);
+  for (int p = tid; p < total; p += kGbThreads) {
+    const uint32_t k = lds.keys[p];
+    const uint32_t d = (gbp_hash(static_cast<int32_t>(k)) >> dshift) & dmask;
+    const uint32_t dst = lds.gbase[d] + (static_cast<uint32_t>(p) - lds.start[d]);
+    kout[dst] = static_cast<int32_t>(k);
+    vout[dst] = static_cast<int64_t>(lds.vals[p]);
+  }
+  __syncthreads();
+}
+
+template <bool HAS_NULLS>
+__global__ __launch_bounds__(kGbThreads) void gbp_scatter1_kernel(GbpArgs a) {
+  __shared__ GbpScatterLds lds;
+  const int tid = threadIdx.x;
+  const int nb = 1 << a.b1;
+  if (tid < nb) lds.cursor[tid] = a.hist1[static_cast<int64_t>(tid) * a.nchunks + blockIdx.x];
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * a.chunk_rows;
+  const int64_t end = begin + a.chunk_rows < a.n ? begin + a.chunk_rows : a.n;
+  for (int64_t row0 = begin; row0 < end; row0 += kGbTile) {
+    const int nrows = static_cast<int>(end - row0 < kGbTile ? end - row0 : kGbTile);
+    gbp_scatter_tile<1, HAS_NULLS>(a, lds, a.keys, a.values, row0, nrows, 0, a.keys_a, a.vals_a);
+  }
+}
+
+__global__ __launch_bounds__(kGbThreads) void gbp_scatter2_kernel(GbpArgs a) {
+  __shared__ GbpScatterLds lds;
+  __shared__ uint32_t part_s;
+  const int tid = threadIdx.x;
+  const int nb1 = 1 << a.b1;
+  const uint32_t g = blockIdx.x;
+  if (g >= a.l2_tile_start[nb1]) return;  // over-provisioned grid
+  // which level-1 partition owns tile g: the last p with l2_tile_start[p] <= g
+  if (tid < 64) {
+    uint32_t below = 0;
+    for (int p = tid; p < nb1; p += 64) below += (a.l2_tile_start[p] <= g) ? 1u : 0u;
+    below = wave_reduce_sum_u32(below);
+    if (tid == 0) part_s = below - 1;
+  }
+  __syncthreads();
+  const uint32_t p = part_s;
+  const int64_t lo = a.l1_start[p];
+  const int64_t hi = a.l1_start[p + 1];
+  const int64_t row0 = lo + static_cast<int64_t>(g - a.l2_tile_start[p]) * kGbTile;
+  const int nrows = static_cast<int>(hi - row0 < kGbTile ? hi - row0 : kGbTile);
+  gbp_scatter_tile<2, false>(a, lds, a.keys_a, a.vals_a, row0, nrows, p, a.keys_b, a.vals_b);
+}
+
+// ---- K5: LDS aggregation.  One workgroup per work unit = <= kGbAggChunk rows of ONE partition
+// (DIRECT: of the caller's rows — the plan with bits == 0 used when all groups fit one table).
+struct __attribute__((aligned(16))) GbpAggLds {
+  unsigned long long sums[kGbSlots];
+  uint32_t tags[kGbSlots];   // 0 = empty, else the low (32 - bits) bits of the key hash
+  uint32_t cnts[kGbSlots];
+  unsigned long long zsum;   // the one key whose tag is 0 has its own accumulator
+  uint32_t zcnt;
+  uint32_t part, row_lo, row_hi;
+};
+
+template <bool DIRECT, bool HAS_NULLS>
+__global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v, GbpArgs a,
+                                                                   const int32_t* __restrict__ keys,
+                                                                   const int64_t* __restrict__ vals) {
+  __shared__ GbpAggLds t;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  int64_t lo, hi;
+  uint32_t q = 0;
+  if constexpr (DIRECT) {
+    lo = static_cast<int64_t>(blockIdx.x) * kGbAggChunk;
+    hi = lo + kGbAggChunk < a.n ? lo + kGbAggChunk : a.n;
+  } else {
+    // which partition owns work unit u: the last q with agg_unit_start[q] <= u.  Two rounds of a
+    // 64-lane search (coarse stride, then inside the stride) by the first wave.
+    const uint32_t u = blockIdx.x;
+    const int nparts = 1 << a.bits;
+    if (u >= a.agg_unit_start[nparts]) return;  // over-provisioned grid (workgroup-uniform)
+    if (tid < 64) {
+      const int stride = (nparts + 63) / 64;
+      const int c = lane * stride < nparts ? lane * stride : nparts;
+      const uint64_t le = __ballot(lane * stride < nparts && a.agg_unit_start[c] <= u);
+      const int coarse = (63 - __builtin_clzll(le)) * stride;  // le != 0: agg_unit_start[0] == 0
+      uint32_t below = 0;
+      for (int j = lane; j < stride; j += 64) {
+        const int idx = coarse + j;
+        below += (idx < nparts && a.agg_unit_start[idx] <= u) ? 1u : 0u;
+      }
+      below = wave_reduce_sum_u32(below);
+      if (lane == 0) {
+        const uint32_t part = static_cast<uint32_t>(coarse) + below - 1;
+        const uint32_t first = a.part_start[part] + (u - a.agg_unit_start[part]) * kGbAggChunk;
+        const uint32_t end = a.part_start[part + 1];
+        t.part = part;
+        t.row_lo = first;
+        t.row_hi = first + kGbAggChunk < end ? first + kGbAggChunk : end;
+      }
+    }
+  }
+  for (int i = tid; i < kGbSlots; i += kGbThreads) {
+    t.sums[i] = 0;
+    t.tags[i] = 0;
+    t.cnts[i] = 0;
+  }
+  if (tid == 0) {
+    t.zsum = 0;
+    t.zcnt = 0;
+  }
+  __syncthreads();
+  if constexpr (!DIRECT) {
+    q = t.part;
+    lo = t.row_lo;
+    hi = t.row_hi;
+  }
+  const int low_bits = 32 - a.bits;
+  const uint32_t low_mask = a.bits == 0 ? 0xFFFFFFFFu : ((1u << low_bits) - 1u);
+  const int hshift = low_bits > 12 ? low_bits - 12 : 0;
+  constexpr int U = 4;  // rows in flight per thread
+  const int64_t span = hi - lo;
+  const int64_t nit = (span + kGbThreads - 1) / kGbThreads;
+  for (int64_t it0 = 0; it0 < nit; it0 += U) {
+    int32_t kbuf[U];
+    unsigned long long vbuf[U];
+    bool okbuf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t rr = lo + (it0 + u) * kGbThreads + tid;
+      okbuf[u] = rr < hi;
+      if constexpr (DIRECT && HAS_NULLS) {
+        if (okbuf[u]) okbuf[u] = gbp_streamed<true>(a, rr);  // rows with a null were handled by K0
+      }
+      const int64_t rc = rr < hi ? rr : hi - 1;  // clamped: always readable
+      kbuf[u] = keys[rc];
+      vbuf[u] = static_cast<unsigned long long>(vals[rc]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    if (!okbuf[u]) continue;
+    const int32_t key = kbuf[u];
+    const unsigned long long val = vbuf[u];
+    const uint32_t kp = gbp_hash(key);
+    const uint32_t tag = kp & low_mask;
+    if (tag == 0) {
+      atomicAdd(&t.zsum, val);
+      atomicAdd(&t.zcnt, 1u);
+      continue;
+    }
+    uint32_t h = (kp >> hshift) & (kGbSlots - 1);
+    int probes = 0;
+    for (; probes < kGbSlots; ++probes) {
+      uint32_t cur = t.tags[h];
+      if (cur == 0) {
+        cur = atomicCAS(&t.tags[h], 0u, tag);
+        if (cur == 0) cur = tag;
+      }
+      if (cur == tag) break;
+      h = (h + 1) & (kGbSlots - 1);
+    }
+    if (probes < kGbSlots) {
+      atomicAdd(&t.sums[h], val);
+      atomicAdd(&t.cnts[h], 1u);
+    } else {  // more groups than the LDS table holds: slow path, still exact
+      const int64_t slot = gb_find_or_insert(v, key);
+      if (slot < 0) {
+        atomicExch(&v.hdr->overflow, 1u);
+      } else {
+        atomicAdd(&v.sums[slot], val);
+        atomicAdd(&v.counts[slot], 1ull);
+      }
+    }
+    }
+  }
+  __syncthreads();
+  const uint32_t hi_bits = a.bits == 0 ? 0u : (q << low_bits);
+  for (int i = tid; i < kGbSlots + 1; i += kGbThreads) {
+    uint32_t tag;
+    unsigned long long sum;
+    uint32_t cnt;
+    if (i < kGbSlots) {
+      tag = t.tags[i];
+      if (tag == 0) continue;
+      sum = t.sums[i];
+      cnt = t.cnts[i];
+    } else {
+      if (t.zcnt == 0) continue;
+      tag = 0;
+      sum = t.zsum;
+      cnt = t.zcnt;
+    }
+    const int32_t key = static_cast<int32_t>((hi_bits | tag) * kGbHashInv);
+    const int64_t slot = gb_find_or_insert(v, key);
+    if (slot < 0) {
+      atomicExch(&v.hdr->overflow, 1u);
+      continue;
+    }
+    atomicAdd(&v.sums[slot], sum);
+    atomicAdd(&v.counts[slot], static_cast<unsigned long long>(cnt));
+  }
+}
+
+// ---- plan: how a slice of rows is laid out in the caller's workspace
+struct GbpPlan {
+  int bits, b1, b2;
+  int64_t slice_rows, chunk_rows, nchunks;
+  size_t off_keys_a, off_vals_a, off_keys_b, off_vals_b, off_part_count, off_part_start,
+      off_cursor2, off_hist1, off_l1_start, off_l2_tile_start, off_agg_unit_start, total;
+};
+
+static int g_gbp_min_rows = 1 << 17;  // below this the direct HBM-atomics kernel is used
+static int g_gbp_bits = -1;           // -1 = from the capacity hint
+
+static int gbp_bits_for(int64_t capacity) {
+  if (g_gbp_bits >= 0) return std::min(g_gbp_bits, kGbMaxBits);
+  // capacity = slots of the HBM table ~ 2x the distinct keys expected; aim at <= 2048 groups
+  // per 4096-slot LDS table.  bits == 0: everything fits one table, no partitioning at all.
+  const int64_t groups = std::max<int64_t>(1, capacity / 2);
+  int bits = 0;
+  while (bits < kGbMaxBits && (groups >> bits) > 2048) ++bits;
+  return bits;
+}
+
+static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity) {
+  GbpPlan p{};
+  p.bits = gbp_bits_for(capacity);
+  if (p.bits <= 8) {
+    p.b1 = p.bits;
+    p.b2 = 0;
+  } else {
+    p.b1 = (p.bits + 1) / 2;
+    p.b2 = p.bits - p.b1;
+  }
+  p.slice_rows = slice_rows;
+  const int64_t ntiles = ceil_div(std::max<int64_t>(slice_rows, 1), kGbTile);
+  const int64_t chunk_tiles = std::max<int64_t>(1, ceil_div(ntiles, kGbMaxChunks));
+  p.chunk_rows = chunk_tiles * kGbTile;
+  p.nchunks = ceil_div(ntiles, chunk_tiles);
+  auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
+  const size_t n = static_cast<size_t>(std::max<int64_t>(slice_rows, 1));
+  const size_t nparts = size_t(1) << p.bits;
+  const size_t nb1 = size_t(1) << p.b1;
+  size_t o = 0;
+  p.off_keys_a = o; o = align(o + (p.bits ? n * 4 : 0));
+  p.off_vals_a = o; o = align(o + (p.bits ? n * 8 : 0));
+  p.off_keys_b = o; o = align(o + (p.b2 ? n * 4 : 0));
+  p.off_vals_b = o; o = align(o + (p.b2 ? n * 8 : 0));
+  p.off_part_count = o; o = align(o + nparts * 4);
+  p.off_part_start = o; o = align(o + (nparts + 1) * 4);
+  p.off_cursor2 = o; o = align(o + nparts * 4);
+  p.off_hist1 = o; o = align(o + nb1 * static_cast<size_t>(kGbMaxChunks) * 4);
+  p.off_l1_start = o; o = align(o + (nb1 + 1) * 4);
+  p.off_l2_tile_start = o; o = align(o + (nb1 + 1) * 4);
+  p.off_agg_unit_start = o; o = align(o + (nparts + 1) * 4);
+  p.total = o;
+  return p;
+}
+
+constexpr int64_t kGbMaxSlice = int64_t(1) << 30;  // row positions inside a slice are 32-bit
+
+// Largest slice (multiple of the tile) whose plan fits `ws_bytes`; 0 if not even one chunk fits.
+static int64_t gbp_slice_for(size_t ws_bytes, int64_t n, int64_t capacity) {
+  int64_t hi = std::min<int64_t>(n, kGbMaxSlice);
+  if (gbp_plan(hi, capacity).total <= ws_bytes) return hi;
+  const size_t fixed = gbp_plan(kGbTile, capacity).total;
+  if (fixed > ws_bytes) return 0;
+  const GbpPlan probe = gbp_plan(kGbTile, capacity);
+  if (probe.bits == 0) return hi;  // no row scratch at all
+  const int two = probe.b2 ? 2 : 1;
+  int64_t rows = static_cast<int64_t>((ws_bytes - fixed) / (12 * two));
+  rows = rows / kGbTile * kGbTile;
+  while (rows > 0 && gbp_plan(rows, capacity).total > ws_bytes) rows -= kGbTile;
+  return std::min(rows, hi);
+}
+
+template <bool HAS_NULLS>
+static int gbp_run_slice(const GroupbyView& v, GbpArgs a, const GbpPlan& plan, hipStream_t st) {
+  if (HAS_NULLS) {
+    hipLaunchKernelGGL(gbp_null_rows_kernel, dim3(gb_grid(a.n / 8 + 1)), dim3(kBlock), 0, st, v, a);
+    ARX_CHECK_LAUNCH("gbp_null_rows_kernel");
+  }
+  if (a.bits == 0) {
+    const unsigned units = static_cast<unsigned>(ceil_div(a.n, kGbAggChunk));
+    hipLaunchKernelGGL((gbp_aggregate_kernel<true, HAS_NULLS>), dim3(units), dim3(kGbThreads), 0, st, v, a,
+                       a.keys, a.values);
+    ARX_CHECK_LAUNCH("gbp_aggregate_kernel");
+    return ARX_OK;
+  }
+  const unsigned nch = static_cast<unsigned>(a.nchunks);
+  const int nparts = 1 << a.bits;
+  ARX_HIP(hipMemsetAsync(a.part_count, 0, static_cast<size_t>(nparts) * 4, st));
+  hipLaunchKernelGGL((gbp_hist_kernel<HAS_NULLS>), dim3(nch), dim3(kGbThreads), 0, st, a);
+  ARX_CHECK_LAUNCH("gbp_hist_kernel");
+  hipLaunchKernelGGL(gbp_scan_a_kernel, dim3(1), dim3(1024), 0, st, a);
+  ARX_CHECK_LAUNCH("gbp_scan_a_kernel");
+  hipLaunchKernelGGL(gbp_scan_b_kernel, dim3(1u << a.b1), dim3(1024), 0, st, a);
+  ARX_CHECK_LAUNCH("gbp_scan_b_kernel");
+  hipLaunchKernelGGL((gbp_scatter1_kernel<HAS_NULLS>), dim3(nch), dim3(kGbThreads), 0, st, a);
+  ARX_CHECK_LAUNCH("gbp_scatter1_kernel");
+  const int32_t* fk = a.keys_a;
+  const int64_t* fv = a.vals_a;
+  if (a.b2 > 0) {
+    const unsigned grid2 = static_cast<unsigned>(ceil_div(a.n, kGbTile) + (int64_t(1) << a.b1));
+    hipLaunchKernelGGL(gbp_scatter2_kernel, dim3(grid2), dim3(kGbThreads), 0, st, a);
+    ARX_CHECK_LAUNCH("gbp_scatter2_kernel");
+    fk = a.keys_b;
+    fv = a.vals_b;
+  }
+  const unsigned units = static_cast<unsigned>(ceil_div(a.n, kGbAggChunk) + nparts);
+  hipLaunchKernelGGL((gbp_aggregate_kernel<false, false>), dim3(units), dim3(kGbThreads), 0, st, v, a, fk, fv);
+  ARX_CHECK_LAUNCH("gbp_aggregate_kernel");
+  return ARX_OK;
+}
+
 static int read_header(void* state, GroupbyHeader* h, hipStream_t st) {
   ARX_HIP(hipMemcpyAsync(h, state, sizeof(GroupbyHeader), hipMemcpyDeviceToHost, st));
   ARX_HIP(hipStreamSynchronize(st));
   return ARX_OK;
 }
 
-int set_groupby_option(const char*, int64_t) { return 0; }
+int set_groupby_option(const char* name, int64_t value) {
+  if (strcmp(name, "groupby_partition_min_rows") == 0) {
+    g_gbp_min_rows = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, INT32_MAX)));
+    return 1;
+  }
+  if (strcmp(name, "groupby_partition_bits") == 0) {
+    g_gbp_bits = static_cast<int>(value);
+    return 1;
+  }
+  return 0;
+}
 
 }  // namespace arx
 
@@ -364,8 +1046,14 @@ static int state_capacity(void* state, int64_t* cap, hipStream_t st) {
   return ARX_OK;
 }
 
+size_t arx_groupby_consume_workspace_bytes(int64_t length, int64_t capacity) {
+  if (length < g_gbp_min_rows || length <= 0) return 0;
+  return gbp_plan(std::min<int64_t>(length, kGbMaxSlice), capacity).total;
+}
+
 int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* keys_i32,
-                                const ArxSpan* values_i64, void* stream) {
+                                const ArxSpan* values_i64, void* ws, size_t ws_bytes,
+                                void* stream) {
   if (state == nullptr || keys_i32 == nullptr || values_i64 == nullptr) {
     set_error("NULL argument to arx_groupby_sum_i64_consume");
     return ARX_INVALID;
@@ -381,10 +1069,50 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
   GroupbyView v = gb_view(state, capacity);
   const int32_t* k = static_cast<const int32_t*>(keys_i32->data) + keys_i32->offset;
   const int64_t* val = static_cast<const int64_t*>(values_i64->data) + values_i64->offset;
-  const Bits kb = make_bits(keys_i32->null_count != 0 ? keys_i32->validity : nullptr,
-                            keys_i32->offset, n);
-  const Bits vb = make_bits(values_i64->null_count != 0 ? values_i64->validity : nullptr,
-                            values_i64->offset, n);
+  const void* kbm = keys_i32->null_count != 0 ? keys_i32->validity : nullptr;
+  const void* vbm = values_i64->null_count != 0 ? values_i64->validity : nullptr;
+
+  // ---- partitioned path: needs scratch; slices bound the scratch and keep positions 32-bit
+  const int64_t slice = (ws != nullptr && n >= g_gbp_min_rows && (reinterpret_cast<uint64_t>(ws) & 255) == 0)
+                            ? gbp_slice_for(ws_bytes, n, capacity)
+                            : 0;
+  if (slice >= kGbTile && slice >= std::min<int64_t>(n, 1 << 16)) {
+    uint8_t* w = static_cast<uint8_t*>(ws);
+    for (int64_t r0 = 0; r0 < n; r0 += slice) {
+      const int64_t m = std::min(slice, n - r0);
+      const GbpPlan plan = gbp_plan(m, capacity);
+      GbpArgs a{};
+      a.keys = k + r0;
+      a.values = val + r0;
+      a.kvalid = make_bits(kbm, keys_i32->offset + r0, m);
+      a.vvalid = make_bits(vbm, values_i64->offset + r0, m);
+      a.n = m;
+      a.bits = plan.bits;
+      a.b1 = plan.b1;
+      a.b2 = plan.b2;
+      a.chunk_rows = plan.chunk_rows;
+      a.nchunks = plan.nchunks;
+      a.keys_a = reinterpret_cast<int32_t*>(w + plan.off_keys_a);
+      a.vals_a = reinterpret_cast<int64_t*>(w + plan.off_vals_a);
+      a.keys_b = reinterpret_cast<int32_t*>(w + plan.off_keys_b);
+      a.vals_b = reinterpret_cast<int64_t*>(w + plan.off_vals_b);
+      a.part_count = reinterpret_cast<uint32_t*>(w + plan.off_part_count);
+      a.part_start = reinterpret_cast<uint32_t*>(w + plan.off_part_start);
+      a.cursor2 = reinterpret_cast<uint32_t*>(w + plan.off_cursor2);
+      a.hist1 = reinterpret_cast<uint32_t*>(w + plan.off_hist1);
+      a.l1_start = reinterpret_cast<uint32_t*>(w + plan.off_l1_start);
+      a.l2_tile_start = reinterpret_cast<uint32_t*>(w + plan.off_l2_tile_start);
+      a.agg_unit_start = reinterpret_cast<uint32_t*>(w + plan.off_agg_unit_start);
+      const int rc = (kbm != nullptr || vbm != nullptr) ? gbp_run_slice<true>(v, a, plan, st)
+                                                        : gbp_run_slice<false>(v, a, plan, st);
+      if (rc != ARX_OK) return rc;
+    }
+    return ARX_OK;
+  }
+
+  // ---- direct path (small batches / no scratch): every row goes to the HBM table
+  const Bits kb = make_bits(kbm, keys_i32->offset, n);
+  const Bits vb = make_bits(vbm, values_i64->offset, n);
   hipLaunchKernelGGL(groupby_consume_kernel, dim3(gb_grid(n)), dim3(kBlock), 0, st, v, k, kb, val, vb, n);
   ARX_CHECK_LAUNCH("groupby_consume_kernel");
   return ARX_OK;
@@ -440,7 +1168,8 @@ int arx_groupby_sum_i64_export(void* state, int32_t* out_keys, uint8_t* out_key_
   if (rc != ARX_OK) return rc;
   GroupbyView v = gb_view(state, cap);
   ARX_HIP(hipMemsetAsync(&v.hdr->export_cursor, 0, sizeof(unsigned long long), st));
-  hipLaunchKernelGGL(groupby_export_kernel, dim3(gb_grid(cap + 1)), dim3(kBlock), 0, st, v, out_keys,
+  const unsigned egrid = static_cast<unsigned>(ceil_div(cap + 1, kExportSlotsPerBlock));
+  hipLaunchKernelGGL(groupby_export_kernel, dim3(egrid), dim3(kBlock), 0, st, v, out_keys,
                      out_key_is_valid, out_sums, out_counts, out_no_nulls);
   ARX_CHECK_LAUNCH("groupby_export_kernel");
   return ARX_OK;

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ARX_ABI_VERSION 1
+#define ARX_ABI_VERSION 2
 
 /* arrow::StatusCode twins (cpp/src/arrow/status.h:83-107). */
 typedef enum ArxStatus {
@@ -229,9 +229,16 @@ size_t arx_groupby_state_bytes(int64_t capacity);
 /* Synchronous: clears the table (HashAggregateKernel::init + resize). */
 int arx_groupby_init(void* state, int64_t capacity, void* stream);
 /* consume: for every row, state[key].sum += value (wrap-around), count++,
- * a null value clears no_nulls; a null key is its own group.  Asynchronous. */
+ * a null value clears no_nulls; a null key is its own group.  Asynchronous.
+ * `ws` (256-byte aligned, arx_groupby_consume_workspace_bytes; may be smaller, or NULL) is the
+ * scratch of the radix-partitioned path: rows are partitioned by key hash until a partition's
+ * groups fit an LDS table, aggregated there, and only per-partition partial aggregates touch the
+ * HBM table.  With ws == NULL (or a batch below the partitioning threshold) every row goes
+ * straight to the HBM table with device atomics — same results, ~12 Grows/s at best. */
+size_t arx_groupby_consume_workspace_bytes(int64_t length, int64_t capacity);
 int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* keys_i32,
-                                const ArxSpan* values_i64, void* stream);
+                                const ArxSpan* values_i64, void* ws, size_t ws_bytes,
+                                void* stream);
 /* merge: fold partial aggregates (keys, key_is_valid, sums, counts, no_nulls; one byte
  * per group for the two flags, either may be NULL = all 1) of another state / another
  * GPU into this one (Merge, hash_aggregate_numeric.cc:85-107).  Asynchronous. */

@@ -318,3 +318,28 @@ def test_filter_forced_sweep_and_sparse_forms(emu_ctx, mode):
             P.check_filter(emu_ctx, v, m, "emit_null", use_pyarrow=False)
     finally:
         lib.arx_set_option(b"filter_sparse", -1)
+
+
+@pytest.mark.parametrize("bits", [0, 1, 5, 9, 11])
+def test_groupby_partitioned_path(emu_ctx, bits):
+    """The radix-partitioned consume (hist -> scatter level 1 [-> level 2] -> LDS aggregate -> flush)
+    forced on, for one-level (bits <= 8) and two-level plans, with null keys / null values /
+    wrap-around, several consume calls, and keys that overflow one partition's LDS table."""
+    lib = emu_ctx._lib.get_lib()
+    assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
+    assert lib.arx_set_option(b"groupby_partition_bits", bits) == 0
+    try:
+        rng = rng_for("gbp", bits)
+        n = 20000
+        k = U.random_array(rng, np.int32, n, null_p=0.02, offset=3, lo=-2**31, hi=2**31 - 1)
+        k.values[: n // 2] = k.values[: n // 2] % 1777          # many repeats + distinct tail
+        v = U.random_array(rng, np.int64, n, null_p=0.1, offset=1)
+        P.check_groupby_sum(emu_ctx, k, v, skip_nulls=(bits % 2 == 1), min_count=1, batches=2,
+                            use_pyarrow=(bits == 9))
+        # no nulls at all (the HAS_NULLS = false kernels)
+        k2 = U.random_array(rng, np.int32, n, lo=0, hi=50000)
+        v2 = U.random_array(rng, np.int64, n)
+        P.check_groupby_sum(emu_ctx, k2, v2, use_pyarrow=False)
+    finally:
+        lib.arx_set_option(b"groupby_partition_min_rows", 1 << 17)
+        lib.arx_set_option(b"groupby_partition_bits", -1)
