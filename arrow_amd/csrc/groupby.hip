@@ -62,8 +62,17 @@ __device__ __forceinline__ uint64_t gb_hash(int32_t key) {
   return static_cast<uint64_t>(static_cast<uint32_t>(key)) * 0x9E3779B185EBCA87ull;
 }
 
-// Slot of `key`, inserting it if absent.  Returns -1 if the table is full.
-__device__ __forceinline__ int64_t gb_find_or_insert(const GroupbyView& v, int32_t key) {
+// Adds this thread's count of newly inserted keys to the header: one atomic per wave (a per-key
+// atomic on the single counter serialises ~1 ns apiece — 10 ms for 10M new groups).
+__device__ __forceinline__ void gb_publish_new_groups(const GroupbyView& v, uint32_t mine) {
+  const uint32_t tot = wave_reduce_sum_u32(mine);
+  if (lane_id() == 0 && tot != 0) atomicAdd(&v.hdr->num_groups, static_cast<unsigned long long>(tot));
+}
+
+// Slot of `key`, inserting it if absent (*inserted += 1 then; the caller publishes the total with
+// gb_publish_new_groups).  Returns -1 if the table is full.
+__device__ __forceinline__ int64_t gb_find_or_insert(const GroupbyView& v, int32_t key,
+                                                     uint32_t* inserted) {
   const unsigned long long tagged = (1ull << 32) | static_cast<uint32_t>(key);
   const uint64_t mask = static_cast<uint64_t>(v.capacity) - 1;
   uint64_t h = v.lg == 0 ? 0 : (gb_hash(key) >> (64 - v.lg));
@@ -73,7 +82,7 @@ __device__ __forceinline__ int64_t gb_find_or_insert(const GroupbyView& v, int32
     if (cur == 0) {
       const unsigned long long old = atomicCAS(&v.keys[h], 0ull, tagged);
       if (old == 0) {
-        atomicAdd(&v.hdr->num_groups, 1ull);
+        *inserted += 1;
         return static_cast<int64_t>(h);
       }
       if (old == tagged) return static_cast<int64_t>(h);
@@ -94,10 +103,11 @@ __global__ __launch_bounds__(kBlock) void groupby_consume_kernel(GroupbyView v,
                                                                  const int64_t* __restrict__ values,
                                                                  Bits vvalid, int64_t n) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint32_t fresh = 0;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     const bool kv = (load_word(kvalid, i >> 6) >> (i & 63)) & 1ull;
     const bool vv = (load_word(vvalid, i >> 6) >> (i & 63)) & 1ull;
-    const int64_t slot = kv ? gb_find_or_insert(v, keys[i]) : gb_null_slot(v);
+    const int64_t slot = kv ? gb_find_or_insert(v, keys[i], &fresh) : gb_null_slot(v);
     if (slot < 0) {
       atomicExch(&v.hdr->overflow, 1u);
       continue;
@@ -109,6 +119,7 @@ __global__ __launch_bounds__(kBlock) void groupby_consume_kernel(GroupbyView v,
       atomicOr(&v.flags[slot], 1u);
     }
   }
+  gb_publish_new_groups(v, fresh);
 }
 
 __global__ __launch_bounds__(kBlock) void groupby_merge_kernel(
@@ -116,9 +127,10 @@ __global__ __launch_bounds__(kBlock) void groupby_merge_kernel(
     const int64_t* __restrict__ sums, const int64_t* __restrict__ counts,
     const uint8_t* __restrict__ no_nulls, int64_t n) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint32_t fresh = 0;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     const bool kv = key_is_valid == nullptr || key_is_valid[i] != 0;
-    const int64_t slot = kv ? gb_find_or_insert(v, keys[i]) : gb_null_slot(v);
+    const int64_t slot = kv ? gb_find_or_insert(v, keys[i], &fresh) : gb_null_slot(v);
     if (slot < 0) {
       atomicExch(&v.hdr->overflow, 1u);
       continue;
@@ -127,6 +139,7 @@ __global__ __launch_bounds__(kBlock) void groupby_merge_kernel(
     atomicAdd(&v.counts[slot], static_cast<unsigned long long>(counts[i]));
     if (no_nulls != nullptr && no_nulls[i] == 0) atomicOr(&v.flags[slot], 1u);
   }
+  gb_publish_new_groups(v, fresh);
 }
 
 // One workgroup per 4096 consecutive slots: count the occupied ones, reserve the output range
@@ -413,6 +426,7 @@ __global__ __launch_bounds__(kBlock) void gbp_null_rows_kernel(GroupbyView v, Gb
   const int64_t nwords = (a.n + 63) >> 6;
   unsigned long long nsum = 0, ncnt = 0;
   bool nflag = false, nseen = false;
+  uint32_t fresh = 0;
   for (int64_t w = wave_g; w < nwords; w += nwaves) {
     const uint64_t kv = load_word(a.kvalid, w);
     const uint64_t vv = load_word(a.vvalid, w);
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void gbp_null_rows_kernel(GroupbyView v, Gb
       const bool kok = (kv >> lane) & 1ull;
       const bool vok = (vv >> lane) & 1ull;
       if (kok) {  // => value is null
-        const int64_t slot = gb_find_or_insert(v, a.keys[r]);
+        const int64_t slot = gb_find_or_insert(v, a.keys[r], &fresh);
         if (slot < 0) atomicExch(&v.hdr->overflow, 1u);
         else atomicOr(&v.flags[slot], 1u);
       } else {
@@ -438,6 +452,7 @@ __global__ __launch_bounds__(kBlock) void gbp_null_rows_kernel(GroupbyView v, Gb
       }
     }
   }
+  gb_publish_new_groups(v, fresh);
   const bool any_seen = __any(nseen);
   if (!any_seen) return;
   nsum = wave_reduce_sum_u64(nsum);
@@ -790,6 +805,7 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
   const int low_bits = 32 - a.bits;
   const uint32_t low_mask = a.bits == 0 ? 0xFFFFFFFFu : ((1u << low_bits) - 1u);
   const int hshift = low_bits > 12 ? low_bits - 12 : 0;
+  uint32_t fresh = 0;   // keys this thread inserted into the HBM table
   constexpr int U = 4;  // rows in flight per thread
   const int64_t span = hi - lo;
   const int64_t nit = (span + kGbThreads - 1) / kGbThreads;
@@ -835,7 +851,7 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
       atomicAdd(&t.sums[h], val);
       atomicAdd(&t.cnts[h], 1u);
     } else {  // more groups than the LDS table holds: slow path, still exact
-      const int64_t slot = gb_find_or_insert(v, key);
+      const int64_t slot = gb_find_or_insert(v, key, &fresh);
       if (slot < 0) {
         atomicExch(&v.hdr->overflow, 1u);
       } else {
@@ -863,7 +879,7 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
       cnt = t.zcnt;
     }
     const int32_t key = static_cast<int32_t>((hi_bits | tag) * kGbHashInv);
-    const int64_t slot = gb_find_or_insert(v, key);
+    const int64_t slot = gb_find_or_insert(v, key, &fresh);
     if (slot < 0) {
       atomicExch(&v.hdr->overflow, 1u);
       continue;
@@ -871,6 +887,7 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
     atomicAdd(&v.sums[slot], sum);
     atomicAdd(&v.counts[slot], static_cast<unsigned long long>(cnt));
   }
+  gb_publish_new_groups(v, fresh);
 }
 
 // ---- plan: how a slice of rows is laid out in the caller's workspace

@@ -83,26 +83,36 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t* __re
   hist[static_cast<int64_t>(threadIdx.x) * nchunks + chunk] = h[threadIdx.x];
 }
 
-// In-place exclusive scan of m = 256 * nchunks counters (digit-major).  Single workgroup.
-__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t* __restrict__ hist, int64_t m) {
-  __shared__ uint32_t wave_tot[16];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int64_t per = (m + 1023) / 1024;
-  const int64_t b = tid * per;
-  const int64_t e = b + per < m ? b + per : m;
+// In-place exclusive scan of the 256 x nchunks counters (digit-major), two small kernels:
+//   radix_digit_totals_kernel : one workgroup per digit -> total of its row of counters
+//   radix_scan_kernel         : one workgroup per digit: exclusive scan of the 256 totals (every
+//                               workgroup redoes it, 256 values) + coalesced scan of its own row.
+__global__ __launch_bounds__(64) void radix_digit_totals_kernel(const uint32_t* __restrict__ hist,
+                                                                 int64_t nchunks,
+                                                                 uint32_t* __restrict__ totals) {
+  const int lane = threadIdx.x;
+  const uint32_t* row = hist + static_cast<int64_t>(blockIdx.x) * nchunks;
   uint32_t s = 0;
-  for (int64_t i = b; i < e; ++i) s += hist[i];
-  const uint32_t incl = wave_inclusive_scan_u32(s);
-  if (lane == 63) wave_tot[wave] = incl;
-  __syncthreads();
-  uint32_t prefix = incl - s;
-  for (int k = 0; k < wave; ++k) prefix += wave_tot[k];
-  for (int64_t i = b; i < e; ++i) {
-    const uint32_t v = hist[i];
-    hist[i] = prefix;
-    prefix += v;
+  for (int64_t i = lane; i < nchunks; i += 64) s += row[i];
+  s = wave_reduce_sum_u32(s);
+  if (lane == 0) totals[blockIdx.x] = s;
+}
+
+// one wave per digit
+__global__ __launch_bounds__(64) void radix_scan_kernel(uint32_t* __restrict__ hist, int64_t nchunks,
+                                                        const uint32_t* __restrict__ totals) {
+  const int lane = threadIdx.x;
+  // start of this digit = sum of the totals of the smaller digits
+  uint32_t t = 0;
+  for (int d = lane; d < static_cast<int>(blockIdx.x); d += 64) t += totals[d];
+  uint32_t carry = wave_reduce_sum_u32(t);
+  uint32_t* row = hist + static_cast<int64_t>(blockIdx.x) * nchunks;
+  for (int64_t base = 0; base < nchunks; base += 64) {
+    const int64_t i = base + lane;
+    const uint32_t x = i < nchunks ? row[i] : 0u;
+    const uint32_t incl = wave_inclusive_scan_u32(x);
+    if (i < nchunks) row[i] = carry + incl - x;
+    carry += __shfl(incl, 63, 64);
   }
 }
 
@@ -243,7 +253,7 @@ struct SortPlan {
   int64_t ntiles;
   int64_t chunk_tiles;
   int64_t nchunks;
-  size_t off_keys_a, off_keys_b, off_idx_a, off_idx_b, off_hist, off_rows, off_sel_ws, total;
+  size_t off_keys_a, off_keys_b, off_idx_a, off_idx_b, off_hist, off_totals, off_rows, off_sel_ws, total;
 };
 
 static SortPlan make_plan(int64_t length) {
@@ -260,6 +270,7 @@ static SortPlan make_plan(int64_t length) {
   p.off_idx_a = o; o = align(o + n * 4);
   p.off_idx_b = o; o = align(o + n * 4);
   p.off_hist = o; o = align(o + static_cast<size_t>(kDigits) * kMaxChunks * 4);
+  p.off_totals = o; o = align(o + static_cast<size_t>(kDigits) * 4);
   p.off_rows = o; o = align(o + n * 4);  // row ids of the non-null / null partitions
   p.off_sel_ws = o; o = align(o + selection_workspace_bytes(length));
   p.total = o;
@@ -323,6 +334,7 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
   uint32_t* idx_a = reinterpret_cast<uint32_t*>(w + plan.off_idx_a);
   uint32_t* idx_b = reinterpret_cast<uint32_t*>(w + plan.off_idx_b);
   uint32_t* hist = reinterpret_cast<uint32_t*>(w + plan.off_hist);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(w + plan.off_totals);
   uint32_t* rows = reinterpret_cast<uint32_t*>(w + plan.off_rows);
   void* sel_ws = w + plan.off_sel_ws;
   const size_t sel_ws_bytes = plan.total - plan.off_sel_ws;
@@ -376,8 +388,10 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
     hipLaunchKernelGGL(radix_hist_kernel, dim3(nch), dim3(kBlock), 0, st, kin, n_valid, shift,
                        chunk_keys, plan.nchunks, hist);
     ARX_CHECK_LAUNCH("radix_hist_kernel");
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, hist,
-                       static_cast<int64_t>(kDigits) * plan.nchunks);
+    hipLaunchKernelGGL(radix_digit_totals_kernel, dim3(kDigits), dim3(64), 0, st, hist, plan.nchunks,
+                       totals);
+    ARX_CHECK_LAUNCH("radix_digit_totals_kernel");
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(kDigits), dim3(64), 0, st, hist, plan.nchunks, totals);
     ARX_CHECK_LAUNCH("radix_scan_kernel");
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(nch), dim3(kBlock), 0, st, kin, iin, n_valid, shift,
                        plan.chunk_tiles, plan.nchunks, hist, kout, iout, final_dst, pass == 7 ? 1 : 0);
