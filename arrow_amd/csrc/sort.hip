@@ -248,12 +248,61 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
   }
 }
 
+
+// ---- multi-GPU sort support: splitter histogram + stable partition by destination
+__global__ __launch_bounds__(kBlock) void sort_key_hist_kernel(const uint64_t* __restrict__ values,
+                                                               Bits valid, int64_t n, int is_signed,
+                                                               int descending, int bits,
+                                                               unsigned long long* __restrict__ hist) {
+  __shared__ uint32_t h[4096];
+  const int nb = 1 << bits;
+  for (int i = threadIdx.x; i < nb; i += kBlock) h[i] = 0;
+  __syncthreads();
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1ull;
+    if (ok) {
+      const uint64_t tk = key_transform(values[i], is_signed != 0, descending != 0);
+      atomicAdd(&h[tk >> (64 - bits)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += kBlock) {
+    if (h[i] != 0) atomicAdd(&hist[i], static_cast<unsigned long long>(h[i]));
+  }
+}
+
+// dkeys[i] = destination of row rows[i] (number of splitter bins <= its bin), idx[i] = the row
+__global__ __launch_bounds__(kBlock) void sort_dest_prep_kernel(const uint64_t* __restrict__ values,
+                                                                const uint32_t* __restrict__ rows,
+                                                                int64_t n, int is_signed, int descending,
+                                                                int bits,
+                                                                const uint32_t* __restrict__ split,
+                                                                int nsplit, uint64_t* __restrict__ dkeys,
+                                                                uint32_t* __restrict__ idx_out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t r = rows ? rows[i] : static_cast<uint32_t>(i);
+    const uint64_t tk = key_transform(values[r], is_signed != 0, descending != 0);
+    const uint32_t bin = static_cast<uint32_t>(tk >> (64 - bits));
+    uint32_t d = 0;
+    for (int j = 0; j < nsplit; ++j) d += (split[j] <= bin) ? 1u : 0u;
+    dkeys[i] = d;
+    idx_out[i] = r;
+  }
+}
+
+__global__ void widen_counts_kernel(const uint32_t* __restrict__ in, int n, int64_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+
 struct SortPlan {
   int64_t n;          // rows to sort (non-null)
   int64_t ntiles;
   int64_t chunk_tiles;
   int64_t nchunks;
-  size_t off_keys_a, off_keys_b, off_idx_a, off_idx_b, off_hist, off_totals, off_rows, off_sel_ws, total;
+  size_t off_keys_a, off_keys_b, off_idx_a, off_idx_b, off_hist, off_totals, off_split, off_rows, off_sel_ws, total;
 };
 
 static SortPlan make_plan(int64_t length) {
@@ -271,6 +320,7 @@ static SortPlan make_plan(int64_t length) {
   p.off_idx_b = o; o = align(o + n * 4);
   p.off_hist = o; o = align(o + static_cast<size_t>(kDigits) * kMaxChunks * 4);
   p.off_totals = o; o = align(o + static_cast<size_t>(kDigits) * 4);
+  p.off_split = o; o = align(o + static_cast<size_t>(kDigits) * 4);
   p.off_rows = o; o = align(o + n * 4);  // row ids of the non-null / null partitions
   p.off_sel_ws = o; o = align(o + selection_workspace_bytes(length));
   p.total = o;
@@ -400,6 +450,125 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
     std::swap(iin, iout);
   }
   return ARX_OK;
+}
+
+int arx_sort_key_histogram(const ArxSpan* values, int is_signed, int order, int bits,
+                           uint64_t* out_hist, void* stream) {
+  if (values == nullptr || out_hist == nullptr || bits < 1 || bits > 12) {
+    set_error("bad arguments to arx_sort_key_histogram (bits in [1,12])");
+    return ARX_INVALID;
+  }
+  const int64_t n = values->length;
+  if (n == 0) return ARX_OK;
+  if (values->data == nullptr) {
+    set_error("values buffer is NULL");
+    return ARX_INVALID;
+  }
+  const uint64_t* vals = static_cast<const uint64_t*>(values->data) + values->offset;
+  const Bits vb = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
+  const unsigned g = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock * 16), 2048)));
+  hipLaunchKernelGGL(sort_key_hist_kernel, dim3(g), dim3(kBlock), 0, as_stream(stream), vals, vb, n,
+                     is_signed, order == ARX_SORT_DESCENDING, bits,
+                     reinterpret_cast<unsigned long long*>(out_hist));
+  ARX_CHECK_LAUNCH("sort_key_hist_kernel");
+  return ARX_OK;
+}
+
+int arx_sort_partition_by_bins(const ArxSpan* values, int is_signed, int order, int bits,
+                               const uint32_t* splitter_bins, int num_parts, void* ws, size_t ws_bytes,
+                               uint64_t* out_keys, uint32_t* out_rows, int64_t* out_counts,
+                               int64_t* out_num_valid, void* stream) {
+  if (values == nullptr || num_parts < 1 || num_parts > kDigits || bits < 1 || bits > 12 ||
+      out_counts == nullptr || out_num_valid == nullptr || (num_parts > 1 && splitter_bins == nullptr)) {
+    set_error("bad arguments to arx_sort_partition_by_bins");
+    return ARX_INVALID;
+  }
+  const int64_t len = values->length;
+  if (len > static_cast<int64_t>(UINT32_MAX)) {
+    set_error("arx_sort_partition_by_bins: more than UINT32_MAX rows per shard is not implemented");
+    return ARX_NOT_IMPLEMENTED;
+  }
+  hipStream_t st = as_stream(stream);
+  ARX_HIP(hipMemsetAsync(out_counts, 0, static_cast<size_t>(num_parts) * 8, st));
+  *out_num_valid = 0;
+  if (len == 0) return ARX_OK;
+  SortPlan plan = make_plan(len);
+  if (ws == nullptr || ws_bytes < plan.total || (reinterpret_cast<uint64_t>(ws) & 255) != 0 ||
+      values->data == nullptr || out_keys == nullptr || out_rows == nullptr) {
+    set_error("arx_sort_partition_by_bins: NULL buffer or workspace too small / unaligned");
+    return ARX_INVALID;
+  }
+  uint8_t* w = static_cast<uint8_t*>(ws);
+  uint64_t* keys_a = reinterpret_cast<uint64_t*>(w + plan.off_keys_a);
+  uint64_t* keys_b = reinterpret_cast<uint64_t*>(w + plan.off_keys_b);
+  uint32_t* idx_a = reinterpret_cast<uint32_t*>(w + plan.off_idx_a);
+  uint32_t* idx_b = reinterpret_cast<uint32_t*>(w + plan.off_idx_b);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(w + plan.off_hist);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(w + plan.off_totals);
+  uint32_t* split = reinterpret_cast<uint32_t*>(w + plan.off_split);
+  uint32_t* rows = reinterpret_cast<uint32_t*>(w + plan.off_rows);
+  void* sel_ws = w + plan.off_sel_ws;
+  const size_t sel_ws_bytes = plan.total - plan.off_sel_ws;
+  const uint64_t* vals = static_cast<const uint64_t*>(values->data) + values->offset;
+  const bool has_nulls = values->null_count != 0 && values->validity != nullptr;
+  int64_t n_valid = len;
+  const uint32_t* valid_rows = nullptr;
+  if (has_nulls) {
+    int64_t got = 0;
+    const int rc = selection_bit_positions(values->validity, values->offset, len, /*invert=*/false, sel_ws,
+                                           sel_ws_bytes, rows, &got, st);
+    if (rc != ARX_OK) return rc;
+    n_valid = got;
+    if (n_valid < len) valid_rows = rows;
+  }
+  *out_num_valid = n_valid;
+  if (n_valid == 0) return ARX_OK;
+  if (num_parts > 1) {
+    ARX_HIP(hipMemcpyAsync(split, splitter_bins, static_cast<size_t>(num_parts - 1) * 4,
+                           hipMemcpyHostToDevice, st));
+    ARX_HIP(hipStreamSynchronize(st));  // the caller's host array may go away after we return
+  }
+  plan = make_plan(n_valid);
+  const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_valid, kBlock), 2048));
+  hipLaunchKernelGGL(sort_dest_prep_kernel, dim3(g), dim3(kBlock), 0, st, vals, valid_rows, n_valid,
+                     is_signed, order == ARX_SORT_DESCENDING, bits, split, num_parts - 1, keys_a, idx_a);
+  ARX_CHECK_LAUNCH("sort_dest_prep_kernel");
+  // one stable radix pass on the destination digit carries the row ids into destination-major order
+  const int64_t chunk_keys = plan.chunk_tiles * kSortTile;
+  const unsigned nch = static_cast<unsigned>(plan.nchunks);
+  hipLaunchKernelGGL(radix_hist_kernel, dim3(nch), dim3(kBlock), 0, st, keys_a, n_valid, 0, chunk_keys,
+                     plan.nchunks, hist);
+  hipLaunchKernelGGL(radix_digit_totals_kernel, dim3(kDigits), dim3(64), 0, st, hist, plan.nchunks, totals);
+  hipLaunchKernelGGL(widen_counts_kernel, dim3(1), dim3(kDigits), 0, st, totals, num_parts, out_counts);
+  hipLaunchKernelGGL(radix_scan_kernel, dim3(kDigits), dim3(64), 0, st, hist, plan.nchunks, totals);
+  hipLaunchKernelGGL(radix_scatter_kernel, dim3(nch), dim3(kBlock), 0, st, keys_a, idx_a, n_valid, 0,
+                     plan.chunk_tiles, plan.nchunks, hist, keys_b, idx_b, static_cast<uint64_t*>(nullptr), 0);
+  ARX_CHECK_LAUNCH("radix partition pass");
+  // transformed keys and row ids in destination-major, row-order-preserving order
+  hipLaunchKernelGGL(sort_prep_kernel, dim3(g), dim3(kBlock), 0, st, vals, idx_b, n_valid, is_signed,
+                     order == ARX_SORT_DESCENDING, out_keys, out_rows);
+  ARX_CHECK_LAUNCH("sort_prep_kernel");
+  return ARX_OK;
+}
+
+int arx_bitmap_to_indices(const void* bits, int64_t bit_offset, int64_t length, int invert, void* ws,
+                          size_t ws_bytes, uint32_t* out_indices, int64_t* out_count, void* stream) {
+  if (out_count == nullptr || length < 0 || bit_offset < 0) {
+    set_error("bad arguments to arx_bitmap_to_indices");
+    return ARX_INVALID;
+  }
+  *out_count = 0;
+  if (length == 0) return ARX_OK;
+  if (bits == nullptr || ws == nullptr || out_indices == nullptr) {
+    set_error("NULL buffer passed to arx_bitmap_to_indices");
+    return ARX_INVALID;
+  }
+  if (length > static_cast<int64_t>(UINT32_MAX)) {
+    set_error("arx_bitmap_to_indices: more than UINT32_MAX bits is not implemented");
+    return ARX_NOT_IMPLEMENTED;
+  }
+  return selection_bit_positions(bits, bit_offset, length, invert != 0, ws, ws_bytes, out_indices,
+                                 out_count, as_stream(stream));
 }
 
 }  // extern "C"

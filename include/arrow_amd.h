@@ -212,6 +212,35 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
                         void* ws, size_t ws_bytes, uint64_t* out_indices, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Multi-GPU sort_indices: every rank owns a contiguous row shard; the sort
+ * needs ONE exchange step.  These are the device pieces around it:
+ *   arx_sort_key_histogram      counts of the top `bits` (<= 12) bits of the order-transformed key
+ *                               over the non-null rows, added into out_hist (device u64[2^bits],
+ *                               caller-zeroed); an all-reduce of it yields the splitters;
+ *   arx_sort_partition_by_bins  rows -> destination rank d = #{j : splitter_bins[j] <= bin(row)},
+ *                               a STABLE partition (row order kept inside a destination, which is
+ *                               what keeps the global sort stable): out_keys = transformed keys,
+ *                               out_rows = local row ids, both destination-major; out_counts
+ *                               (device int64[num_parts]); *out_num_valid (host) = non-null rows.
+ *                               ws = arx_sort_indices_workspace_bytes(length), 256-byte aligned.
+ *                               Synchronous when the shard has nulls or num_parts > 1.
+ *   arx_bitmap_to_indices       ascending positions of the set (invert: clear) bits — the null
+ *                               rows of a shard (PartitionNullsOnly keeps them in row order).
+ *                               ws = arx_filter_workspace_bytes(length).  Synchronous.
+ * The receiving rank sorts the transformed keys it was sent with arx_sort_indices_64
+ * (unsigned, ascending: the transform already encodes sign and order).
+ * ------------------------------------------------------------------------- */
+int arx_sort_key_histogram(const ArxSpan* values, int is_signed, int order, int bits,
+                           uint64_t* out_hist, void* stream);
+int arx_sort_partition_by_bins(const ArxSpan* values, int is_signed, int order, int bits,
+                               const uint32_t* splitter_bins /* host */, int num_parts, void* ws,
+                               size_t ws_bytes, uint64_t* out_keys, uint32_t* out_rows,
+                               int64_t* out_counts, int64_t* out_num_valid /* host */, void* stream);
+int arx_bitmap_to_indices(const void* bits, int64_t bit_offset, int64_t length, int invert, void* ws,
+                          size_t ws_bytes, uint32_t* out_indices, int64_t* out_count /* host */,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------
  * Group-by hash_sum(int64) BY int32 key — replaces, as one fused device operator,
  * Grouper::Consume (cpp/src/arrow/compute/row/grouper.cc:662-815) +
  * HashAggregateKernel{resize,consume,merge,finalize} of

@@ -4,6 +4,8 @@ inputs.  Run with `pytest -m gpu` on the GPU box."""
 import numpy as np
 import pytest
 
+from oracle import oracle as O
+
 from . import parity_cases as P
 from . import util as U
 
@@ -406,3 +408,20 @@ def test_groupby_partitioned_path(gpu_ctx, bits):
     finally:
         lib.arx_set_option(b"groupby_partition_min_rows", 1 << 17)
         lib.arx_set_option(b"groupby_partition_bits", -1)
+
+
+@pytest.mark.parametrize("order,placement", [("ascending", "at_end"), ("descending", "at_start")])
+def test_sharded_sort_single_rank_pieces(gpu_ctx, order, placement):
+    """The device pieces of the multi-GPU sort (splitter histogram, stable partition by
+    destination, null-row positions) on one rank: the result must equal the plain sort."""
+    from arrow_amd import parallel
+
+    rng = rng_for("shsort", order, placement)
+    n = 1_500_001
+    a = U.random_array(rng, np.uint64, n, null_p=0.03, offset=5)
+    a.values[a.offset:a.offset + n:4] %= 1000
+    rows, start = parallel.sharded_sort_indices(a.to_device(gpu_ctx), order, placement)
+    want = O.sort_indices_64(np.ascontiguousarray(a.values), a.valid_bitmap(), a.offset, n,
+                             descending=(order == "descending"), nulls_at_start=(placement == "at_start"))
+    assert start == 0
+    assert (rows.cpu().numpy().astype(np.uint64) == want).all()

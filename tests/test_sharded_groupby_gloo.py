@@ -88,3 +88,73 @@ def test_sharded_group_by_sum_world2_gloo(tmp_path, skip_nulls, min_count):
             got[key] = int(s) if ok else None
     assert got == want
     assert all(len(r["keys"]) > 0 for r in ranks), "every rank should own part of the key space"
+
+
+SORT_WORKER = textwrap.dedent(r'''
+    import os, sys, pickle
+    import numpy as np
+    import torch, torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import arrow_amd
+    from arrow_amd import _lib, array, parallel
+    from tests.emu.build_emu import build
+    from tests import util as U
+    _lib._lib = _lib.load(build())
+    array.set_default_device("cpu")
+    rng = np.random.default_rng(77 + rank)
+    n = 5000 + 700 * rank
+    dt = np.int64 if SIGNED else np.uint64
+    a = U.random_array(rng, dt, n, null_p=0.05, offset=rank + 1)
+    a.values[a.offset:a.offset + n:3] = (a.values[a.offset:a.offset + n:3] % 40).astype(dt)  # many ties across ranks
+    rows, start = parallel.sharded_sort_indices(a.to_device(arrow_amd), ORDER, PLACEMENT)
+    mine = dict(rows=rows.numpy(), start=start, vals=a.values[a.offset:a.offset + n].copy(),
+                valid=None if a.valid is None else a.valid[a.offset:a.offset + n].copy())
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    if rank == 0:
+        with open(OUT, "wb") as f:
+            pickle.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+@pytest.mark.parametrize("signed,order,placement", [(False, "ascending", "at_end"), (True, "descending", "at_start"),
+                                                    (False, "descending", "at_end")])
+def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement):
+    """One-exchange multi-rank sort_indices == the oracle's stable argsort of the concatenation."""
+    import pickle
+
+    import numpy as np
+
+    from oracle import oracle as O
+
+    out = str(tmp_path / "sort.pkl")
+    code = (f"ROOT = {ROOT!r}\nOUT = {out!r}\nSIGNED = {signed!r}\nORDER = {order!r}\nPLACEMENT = {placement!r}\n"
+            + SORT_WORKER)
+    port = 31500 + (os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    ranks = pickle.load(open(out, "rb"))
+    vals = np.concatenate([r["vals"] for r in ranks])
+    valid = np.concatenate([np.ones(len(r["vals"]), bool) if r["valid"] is None else r["valid"] for r in ranks])
+    want = O.sort_indices_64(np.ascontiguousarray(vals), O.pack_bits(valid), 0, len(vals),
+                             descending=(order == "descending"), nulls_at_start=(placement == "at_start"))
+    assert ranks[0]["start"] == 0 and ranks[1]["start"] == len(ranks[0]["rows"])
+    got = np.concatenate([r["rows"] for r in ranks]).astype(np.uint64)
+    assert (got == want).all()
+    assert min(len(r["rows"]) for r in ranks) > len(vals) // 4, "splitters should balance the ranks"
