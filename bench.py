@@ -307,6 +307,11 @@ def run_extras(amd, device):
     return out
 
 
+def _sync(device):
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
 def measure_hash_sum(rank, world, device, rows_total, groups, steps, warmup):
     """Sharded group-by: each rank owns rows_total // world contiguous rows.  Returns
     (seconds per step [max over ranks], rows actually processed, groups out, checksum)."""
@@ -335,11 +340,11 @@ def measure_hash_sum(rank, world, device, rows_total, groups, steps, warmup):
         res = step()
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize(device)
+    _sync(device)
     t0 = time.perf_counter()
     for _ in range(steps):
         res = step()
-    torch.cuda.synchronize(device)
+    _sync(device)
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0

@@ -158,3 +158,45 @@ def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement):
     got = np.concatenate([r["rows"] for r in ranks]).astype(np.uint64)
     assert (got == want).all()
     assert min(len(r["rows"]) for r in ranks) > len(vals) // 4, "splitters should balance the ranks"
+
+
+BENCH_WORKER = textwrap.dedent(r'''
+    import os, sys, json
+    import torch, torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arrow_amd import _lib, array
+    from tests.emu.build_emu import build
+    _lib._lib = _lib.load(build())
+    array.set_default_device("cpu")
+    import bench
+    sec, rows, groups_out, checksum, ok = bench.measure_hash_sum(rank, world, torch.device("cpu"), 40000, 700, 1, 1)
+    assert ok and rows == 40000 and groups_out == 700, (ok, rows, groups_out)
+    if rank == 0:
+        print("BENCH_HASH_SUM_OK", json.dumps(dict(rows=rows, groups=groups_out)))
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_bench_measure_hash_sum_world2_gloo():
+    """bench.py's own multi-rank hash_sum leg (the code the driver's --gpus N run executes),
+    world_size 2 over gloo: rows sharded, partials exchanged, checksum == sum of all values."""
+    code = f"ROOT = {ROOT!r}\n" + BENCH_WORKER
+    port = 33500 + (os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    assert any("BENCH_HASH_SUM_OK" in l for l in logs)
