@@ -18,10 +18,13 @@
 // (a kROCM arrow::Device/MemoryManager/Buffer, cpp/src/arrow/device.h:43-280) are row (f1) of
 // SURVEY.md section 8 and are what bench.py measures through arrow_amd.compute.
 #include <arrow/api.h>
+#include <arrow/c/abi.h>
+#include <arrow/c/bridge.h>
 #include <arrow/compute/api.h>
 #include <arrow/compute/initialize.h>
 #include <arrow/compute/kernel.h>
 #include <arrow/compute/registry.h>
+#include <arrow/device.h>
 #include <arrow/util/bit_util.h>
 #include <arrow/util/bitmap_ops.h>
 
@@ -187,6 +190,165 @@ int FixedByteWidth(const arrow::DataType& t) {
   }
 }
 
+// ---------------------------------------------------------------- device-resident arrays
+// A minimal kROCM arrow::Device / MemoryManager / Buffer (interfaces: cpp/src/arrow/device.h:43-280,
+// buffer.h:52-; pattern: cpp/src/arrow/gpu/cuda_memory.{h,cc}) so that Arrow arrays can LIVE in
+// HBM: ArraySpan::buffers[i].data is null for such buffers (buffer.h:221-226) and the kernels
+// below read the device address from buffers[i].owner->address() — no staging, outputs are
+// RocmBuffers too.  The C Device Data interface (c/abi.h ARROW_DEVICE_ROCM, c/bridge.h) is how
+// arrays enter/leave: RegisterDeviceMapper(kROCM) lets ImportDeviceArray (and therefore
+// pyarrow.Array._import_from_c_device) build arrays on this memory manager.
+class RocmMemoryManager;
+
+class RocmDevice : public arrow::Device {
+ public:
+  explicit RocmDevice(int id) : arrow::Device(/*is_cpu=*/false), id_(id) {}
+  const char* type_name() const override { return "arrow_amd::RocmDevice"; }
+  std::string ToString() const override { return "RocmDevice(gfx950, device_id=" + std::to_string(id_) + ")"; }
+  bool Equals(const arrow::Device& other) const override {
+    return other.device_type() == device_type() && other.device_id() == id_;
+  }
+  int64_t device_id() const override { return id_; }
+  arrow::DeviceAllocationType device_type() const override { return arrow::DeviceAllocationType::kROCM; }
+  std::shared_ptr<arrow::MemoryManager> default_memory_manager() override;
+
+ private:
+  int id_;
+};
+
+// an owned hipMalloc allocation
+class RocmBuffer : public arrow::MutableBuffer {
+ public:
+  RocmBuffer(uint8_t* ptr, int64_t size, std::shared_ptr<arrow::MemoryManager> mm)
+      : arrow::MutableBuffer(ptr, size, std::move(mm)), ptr_(ptr) {}
+  ~RocmBuffer() override {
+    if (ptr_) (void)hipFree(ptr_);
+  }
+
+ private:
+  uint8_t* ptr_;
+};
+
+class RocmMemoryManager : public arrow::MemoryManager {
+ public:
+  explicit RocmMemoryManager(const std::shared_ptr<arrow::Device>& device) : arrow::MemoryManager(device) {}
+
+  arrow::Result<std::shared_ptr<arrow::io::RandomAccessFile>> GetBufferReader(std::shared_ptr<Buffer>) override {
+    return Status::NotImplemented("RocmMemoryManager::GetBufferReader");
+  }
+  arrow::Result<std::shared_ptr<arrow::io::OutputStream>> GetBufferWriter(std::shared_ptr<Buffer>) override {
+    return Status::NotImplemented("RocmMemoryManager::GetBufferWriter");
+  }
+  arrow::Result<std::unique_ptr<Buffer>> AllocateBuffer(int64_t size) override {
+    void* p = nullptr;
+    // padded like Arrow's pools (64 bytes) so that whole-word bitmap stores stay inside
+    const size_t bytes = (static_cast<size_t>(std::max<int64_t>(size, 1)) + 63) & ~size_t(63);
+    const hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return Status::OutOfMemory("hipMalloc of ", bytes, " bytes: ", hipGetErrorString(e));
+    return std::unique_ptr<Buffer>(new RocmBuffer(static_cast<uint8_t*>(p), size, shared_from_this()));
+  }
+
+ protected:
+  arrow::Result<std::shared_ptr<Buffer>> CopyBufferFrom(const std::shared_ptr<Buffer>& buf,
+                                                        const std::shared_ptr<arrow::MemoryManager>& from) override {
+    ARROW_ASSIGN_OR_RAISE(auto out, CopyNonOwnedFrom(*buf, from));
+    return std::shared_ptr<Buffer>(std::move(out));
+  }
+  arrow::Result<std::shared_ptr<Buffer>> CopyBufferTo(const std::shared_ptr<Buffer>& buf,
+                                                      const std::shared_ptr<arrow::MemoryManager>& to) override {
+    ARROW_ASSIGN_OR_RAISE(auto out, CopyNonOwnedTo(*buf, to));
+    return std::shared_ptr<Buffer>(std::move(out));
+  }
+  arrow::Result<std::unique_ptr<Buffer>> CopyNonOwnedFrom(const Buffer& buf,
+                                                          const std::shared_ptr<arrow::MemoryManager>& from) override {
+    if (!from->is_cpu()) return nullptr;  // unsupported pair: let Arrow try the other direction
+    ARROW_ASSIGN_OR_RAISE(auto out, AllocateBuffer(buf.size()));
+    if (buf.size() > 0) {
+      HIP_RETURN_NOT_OK(hipMemcpy(reinterpret_cast<void*>(out->mutable_address()), buf.data(),
+                                  static_cast<size_t>(buf.size()), hipMemcpyHostToDevice));
+    }
+    return out;
+  }
+  arrow::Result<std::unique_ptr<Buffer>> CopyNonOwnedTo(const Buffer& buf,
+                                                        const std::shared_ptr<arrow::MemoryManager>& to) override {
+    if (!to->is_cpu()) return nullptr;
+    ARROW_ASSIGN_OR_RAISE(auto out, to->AllocateBuffer(buf.size()));
+    if (buf.size() > 0) {
+      HIP_RETURN_NOT_OK(hipMemcpy(out->mutable_data(), reinterpret_cast<const void*>(buf.address()),
+                                  static_cast<size_t>(buf.size()), hipMemcpyDeviceToHost));
+    }
+    return out;
+  }
+};
+
+std::shared_ptr<arrow::MemoryManager> RocmDevice::default_memory_manager() {
+  static std::mutex mu;
+  static std::vector<std::shared_ptr<arrow::MemoryManager>> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache.size() <= static_cast<size_t>(id_)) cache.resize(id_ + 1);
+  if (!cache[id_]) cache[id_] = std::make_shared<RocmMemoryManager>(shared_from_this());
+  return cache[id_];
+}
+
+arrow::Result<std::shared_ptr<arrow::MemoryManager>> RocmMemoryManagerFor(int64_t device_id) {
+  static std::mutex mu;
+  static std::vector<std::shared_ptr<RocmDevice>> devices;
+  std::lock_guard<std::mutex> lock(mu);
+  if (device_id < 0) device_id = 0;
+  if (devices.size() <= static_cast<size_t>(device_id)) devices.resize(device_id + 1);
+  if (!devices[device_id]) devices[device_id] = std::make_shared<RocmDevice>(static_cast<int>(device_id));
+  return devices[device_id]->default_memory_manager();
+}
+
+// true if any buffer of the span lives on a kROCM device
+bool OnRocm(const ArraySpan& a) {
+  for (int i = 0; i < 2; ++i) {
+    if (a.buffers[i].owner != nullptr && *a.buffers[i].owner != nullptr &&
+        (*a.buffers[i].owner)->device_type() == arrow::DeviceAllocationType::kROCM) {
+      return true;
+    }
+  }
+  return false;
+}
+
+// ArxSpan over device-resident buffers: addresses come from the owning Buffer, not from .data
+Status DeviceSpan(const ArraySpan& a, ArxSpan* out) {
+  out->offset = a.offset;
+  out->length = a.length;
+  out->validity = nullptr;
+  out->data = nullptr;
+  for (int i = 0; i < 2; ++i) {
+    const auto* owner = a.buffers[i].owner;
+    if (owner == nullptr || *owner == nullptr) continue;
+    if ((*owner)->device_type() != arrow::DeviceAllocationType::kROCM) {
+      return Status::Invalid("arrow_amd: mixed host / device buffers in one array");
+    }
+    (i == 0 ? out->validity : out->data) = reinterpret_cast<const void*>((*owner)->address());
+  }
+  // The executor zeroes ArraySpan::null_count when buffers[0].data is null — which it is for
+  // every non-CPU buffer (Buffer::data(), buffer.h:221-226) — so the presence of the validity
+  // BUFFER is the only signal left: report "unknown" and let the kernels read the bitmap.
+  out->null_count = out->validity == nullptr ? 0 : (a.null_count > 0 ? a.null_count : arrow::kUnknownNullCount);
+  return Status::OK();
+}
+
+arrow::Result<std::shared_ptr<Buffer>> AllocDevice(int64_t bytes) {
+  ARROW_ASSIGN_OR_RAISE(auto mm, RocmMemoryManagerFor(0));
+  ARROW_ASSIGN_OR_RAISE(auto buf, mm->AllocateBuffer(bytes));
+  return std::shared_ptr<Buffer>(std::move(buf));
+}
+
+// exact null count of a device bitmap (a device array must never need a CPU popcount later)
+arrow::Result<int64_t> DeviceNullCount(const Buffer& bitmap, int64_t length, hipStream_t st) {
+  if (length == 0) return 0;
+  void* ws = nullptr;
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kCounter, 64, &ws));
+  int64_t set_bits = 0;
+  ARROW_RETURN_NOT_OK(FromArx(arx_bitmap_popcount(reinterpret_cast<const void*>(bitmap.address()), 0, length, ws,
+                                                  64, &set_bits, st)));
+  return length - set_bits;
+}
+
 // ---------------------------------------------------------------- state = stock state + options
 template <typename Options>
 struct ShimState : public cp::KernelState {
@@ -231,12 +393,51 @@ Status FilterExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecRes
   const ArraySpan& values = batch[0].array;
   const ArraySpan& filter = batch[1].array;
   const int w = FixedByteWidth(*values.type);
+  const int null_sel = state->options.null_selection_behavior == cp::FilterOptions::EMIT_NULL
+                           ? ARX_FILTER_EMIT_NULL : ARX_FILTER_DROP;
+  const bool on_device = OnRocm(values) || OnRocm(filter);
+  if (on_device) {
+    // device-resident ExecBatch: no staging, the output stays in HBM
+    if (w == 0 || filter.type->id() != Type::BOOL) {
+      return Status::NotImplemented("arrow_amd: filter of ", values.type->ToString(),
+                                    " on device-resident arrays");
+    }
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    ArxSpan dv{}, dm{};
+    ARROW_RETURN_NOT_OK(DeviceSpan(values, &dv));
+    ARROW_RETURN_NOT_OK(DeviceSpan(filter, &dm));
+    const size_t ws_bytes = arx_filter_workspace_bytes(filter.length);
+    void* ws = nullptr;
+    ARROW_RETURN_NOT_OK(t_scratch.Get(kWs, ws_bytes, &ws));
+    int64_t out_len = 0;
+    ARROW_RETURN_NOT_OK(FromArx(arx_filter_count(&dm, null_sel, ws, ws_bytes, &out_len, st)));
+    ArrayData* out_arr = out->array_data().get();
+    const bool allocate_validity = dv.null_count != 0 || dm.null_count != 0;
+    out_arr->length = out_len;
+    out_arr->buffers.resize(2);
+    ARROW_ASSIGN_OR_RAISE(out_arr->buffers[1], AllocDevice(out_len * w));
+    out_arr->buffers[0] = nullptr;
+    void* d_valid = nullptr;
+    if (allocate_validity) {
+      ARROW_ASSIGN_OR_RAISE(out_arr->buffers[0], AllocDevice(((out_len + 63) / 64) * 8));
+      d_valid = reinterpret_cast<void*>(out_arr->buffers[0]->mutable_address());
+    }
+    ARROW_RETURN_NOT_OK(FromArx(arx_filter_exec(&dv, w, &dm, null_sel, ws, out_len,
+                                                reinterpret_cast<void*>(out_arr->buffers[1]->mutable_address()),
+                                                d_valid, st)));
+    out_arr->null_count = 0;
+    if (allocate_validity) {
+      ARROW_ASSIGN_OR_RAISE(out_arr->null_count, DeviceNullCount(*out_arr->buffers[0], out_len, st));
+    }
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    CountGpu(kFnFilter);
+    return Status::OK();
+  }
   if (w == 0 || filter.type->id() != Type::BOOL || values.length < g_min_rows.load() ||
       !IsHost(values) || !IsHost(filter)) {
     return RunStock(kFnFilter, g_stock_filter, state->stock.get(), ctx, batch, out);
   }
-  const int null_sel = state->options.null_selection_behavior == cp::FilterOptions::EMIT_NULL
-                           ? ARX_FILTER_EMIT_NULL : ARX_FILTER_DROP;
   hipStream_t st;
   ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
   ArxSpan dv{}, dm{};
@@ -319,6 +520,49 @@ Status TakeExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResul
   const int w = FixedByteWidth(*values.type);
   const int tid = IndexTypeId(*indices.type);
   static const int kIdxWidth[8] = {1, 1, 2, 2, 4, 4, 8, 8};
+  if (OnRocm(values) || OnRocm(indices)) {
+    if (w == 0 || tid < 0) {
+      return Status::NotImplemented("arrow_amd: take of ", values.type->ToString(), " by ",
+                                    indices.type->ToString(), " on device-resident arrays");
+    }
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    ArxSpan dv{}, di{};
+    ARROW_RETURN_NOT_OK(DeviceSpan(values, &dv));
+    ARROW_RETURN_NOT_OK(DeviceSpan(indices, &di));
+    if (state->options.boundscheck) {
+      void* ws = nullptr;
+      ARROW_RETURN_NOT_OK(t_scratch.Get(kWs, arx_take_workspace_bytes(), &ws));
+      ARROW_RETURN_NOT_OK(FromArx(arx_check_index_bounds(&di, tid, static_cast<uint64_t>(values.length), ws,
+                                                         arx_take_workspace_bytes(), st)));
+    }
+    const int64_t m = indices.length;
+    const bool allocate_validity = dv.null_count != 0 || di.null_count != 0;
+    ArrayData* out_arr = out->array_data().get();
+    out_arr->length = m;
+    out_arr->buffers.resize(2);
+    ARROW_ASSIGN_OR_RAISE(out_arr->buffers[1], AllocDevice(m * w));
+    out_arr->buffers[0] = nullptr;
+    void* d_valid = nullptr;
+    void* d_counter = nullptr;
+    if (allocate_validity) {
+      ARROW_ASSIGN_OR_RAISE(out_arr->buffers[0], AllocDevice(((m + 63) / 64) * 8));
+      d_valid = reinterpret_cast<void*>(out_arr->buffers[0]->mutable_address());
+      ARROW_RETURN_NOT_OK(t_scratch.Get(kCounter, 64, &d_counter));
+      HIP_RETURN_NOT_OK(hipMemsetAsync(d_counter, 0, 8, st));
+    }
+    ARROW_RETURN_NOT_OK(FromArx(arx_take(&dv, w, &di, tid,
+                                         reinterpret_cast<void*>(out_arr->buffers[1]->mutable_address()), d_valid,
+                                         static_cast<int64_t*>(d_counter), st)));
+    int64_t valid_count = m;
+    if (allocate_validity) {
+      HIP_RETURN_NOT_OK(hipMemcpyAsync(&valid_count, d_counter, 8, hipMemcpyDeviceToHost, st));
+    }
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    out_arr->null_count = m - valid_count;
+    CountGpu(kFnTake);
+    return Status::OK();
+  }
   if (w == 0 || tid < 0 || indices.length < g_min_rows.load() || !IsHost(values) || !IsHost(indices)) {
     return RunStock(kFnTake, g_stock_take, state->stock.get(), ctx, batch, out);
   }
@@ -481,15 +725,46 @@ class RocmCastMetaFunction : public cp::MetaFunction {
     const auto* cast_options = static_cast<const cp::CastOptions*>(options);
     if (cast_options != nullptr && cast_options->to_type.type != nullptr &&
         cast_options->to_type.id() == Type::FLOAT && args.size() == 1 && args[0].is_array() &&
-        args[0].array()->type->id() == Type::DOUBLE && args[0].length() >= g_min_rows.load()) {
+        args[0].array()->type->id() == Type::DOUBLE) {
       ArraySpan in(*args[0].array());
-      if (IsHost(in)) return CastF64F32(*args[0].array(), ctx);
+      if (OnRocm(in)) return CastF64F32Device(*args[0].array());
+      if (args[0].length() >= g_min_rows.load() && IsHost(in)) return CastF64F32(*args[0].array(), ctx);
     }
     CountStock(kFnCast);
     return stock_->Execute(args, options, ctx);
   }
 
  private:
+  // device-resident input: output values (and a re-based validity bitmap if offset != 0) in HBM
+  static arrow::Result<arrow::Datum> CastF64F32Device(const ArrayData& in) {
+    const int64_t n = in.length;
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    ARROW_ASSIGN_OR_RAISE(auto out_values, AllocDevice(n * 4));
+    const double* src = reinterpret_cast<const double*>(in.buffers[1]->address()) + in.offset;
+    ARROW_RETURN_NOT_OK(FromArx(arx_cast_f64_f32(src, n, reinterpret_cast<float*>(out_values->mutable_address()), st)));
+    std::shared_ptr<Buffer> validity;
+    if (in.buffers[0] != nullptr && in.null_count != 0) {
+      if (in.offset == 0) {
+        validity = in.buffers[0];
+      } else {
+        ARROW_ASSIGN_OR_RAISE(validity, AllocDevice(((n + 63) / 64) * 8));
+        ARROW_RETURN_NOT_OK(FromArx(arx_bitmap_copy(reinterpret_cast<const void*>(in.buffers[0]->address()), in.offset,
+                                                    n, reinterpret_cast<void*>(validity->mutable_address()), st)));
+      }
+    }
+    int64_t null_count = 0;
+    if (validity) {
+      null_count = in.null_count.load();
+      if (null_count < 0) {
+        ARROW_ASSIGN_OR_RAISE(null_count, DeviceNullCount(*validity, n, st));
+      }
+    }
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    CountGpu(kFnCast);
+    return arrow::Datum(ArrayData::Make(arrow::float32(), n, {std::move(validity), std::move(out_values)}, null_count));
+  }
+
   static arrow::Result<arrow::Datum> CastF64F32(const ArrayData& in, cp::ExecContext* ctx) {
     const int64_t n = in.length;
     hipStream_t st;
@@ -723,6 +998,11 @@ Status RegisterAll() {
     return Status::Invalid("arrow_amd: no HIP device visible (", arx_last_error(),
                            "); nothing registered, Arrow keeps its stock kernels");
   }
+  // arrays can now be imported onto the MI355X through the C Device Data interface
+  {
+    const Status st = arrow::RegisterDeviceMapper(arrow::DeviceAllocationType::kROCM, RocmMemoryManagerFor);
+    if (!st.ok() && !st.IsKeyError()) return st;  // KeyError: somebody registered kROCM before us
+  }
   cp::FunctionRegistry* reg = cp::GetFunctionRegistry();
   ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_filter", FilterValueTypes(), {cp::InputType(arrow::boolean())},
                                      FilterInit, FilterExec, &g_stock_filter));
@@ -795,6 +1075,57 @@ int64_t arrow_amd_plugin_calls(const char* function, int gpu) {
     if (std::strcmp(function, kFnNames[i]) == 0) return (gpu ? g_fn_gpu[i] : g_fn_stock[i]).load();
   }
   return -1;
+}
+// Host array (C Data interface, consumed) -> the same array with its buffers in HBM, exported
+// through the C Device Data interface (device_type = ARROW_DEVICE_ROCM).  Fixed-width / boolean
+// arrays without children.  0 on success.
+int arrow_amd_copy_to_device(struct ArrowArray* in, struct ArrowSchema* schema, struct ArrowDeviceArray* out) {
+  auto run = [&]() -> Status {
+    ARROW_ASSIGN_OR_RAISE(auto host, arrow::ImportArray(in, schema));
+    if (!host->data()->child_data.empty() || host->data()->dictionary != nullptr || host->data()->buffers.size() != 2) {
+      return Status::NotImplemented("arrow_amd_copy_to_device: ", host->type()->ToString());
+    }
+    ARROW_ASSIGN_OR_RAISE(auto mm, RocmMemoryManagerFor(0));
+    std::vector<std::shared_ptr<Buffer>> bufs(2);
+    for (int i = 0; i < 2; ++i) {
+      const auto& b = host->data()->buffers[i];
+      if (b != nullptr) {
+        ARROW_ASSIGN_OR_RAISE(bufs[i], arrow::MemoryManager::CopyBuffer(b, mm));
+      }
+    }
+    // null_count must be exact: nothing may popcount a device bitmap on the CPU later
+    auto data = ArrayData::Make(host->type(), host->length(), std::move(bufs), host->null_count(), host->offset());
+    return arrow::ExportDeviceArray(*arrow::MakeArray(data), nullptr, out);
+  };
+  const Status st = run();
+  if (!st.ok()) {
+    t_error = st.ToString();
+    return -1;
+  }
+  return 0;
+}
+// Device array (C Device Data interface, consumed) -> host array (C Data interface).
+int arrow_amd_copy_to_host(struct ArrowDeviceArray* in, struct ArrowSchema* schema, struct ArrowArray* out,
+                           struct ArrowSchema* out_schema) {
+  auto run = [&]() -> Status {
+    ARROW_ASSIGN_OR_RAISE(auto dev, arrow::ImportDeviceArray(in, schema));
+    std::vector<std::shared_ptr<Buffer>> bufs(dev->data()->buffers.size());
+    for (size_t i = 0; i < bufs.size(); ++i) {
+      const auto& b = dev->data()->buffers[i];
+      if (b != nullptr) {
+        ARROW_ASSIGN_OR_RAISE(bufs[i], arrow::MemoryManager::CopyBuffer(b, arrow::default_cpu_memory_manager()));
+      }
+    }
+    auto data = ArrayData::Make(dev->type(), dev->length(), std::move(bufs), dev->data()->null_count.load(),
+                                dev->offset());
+    return arrow::ExportArray(*arrow::MakeArray(data), out, out_schema);
+  };
+  const Status st = run();
+  if (!st.ok()) {
+    t_error = st.ToString();
+    return -1;
+  }
+  return 0;
 }
 // Inputs shorter than this stay on the stock CPU kernels (PCIe staging does not pay).
 void arrow_amd_plugin_set_min_rows(int64_t n) { g_min_rows.store(n); }

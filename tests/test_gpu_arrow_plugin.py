@@ -84,3 +84,77 @@ def test_pyarrow_compute_dispatches_to_the_hip_kernels():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "PLUGIN_OK" in r.stdout
+
+
+DEVICE_SCRIPT = textwrap.dedent(r'''
+    import ctypes, sys
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(n) for n in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(n) for n in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    rng = np.random.default_rng(11)
+    n = 3_000_001
+    vals = pa.array(rng.integers(-2**62, 2**62, n), mask=rng.random(n) < 0.1)
+    mask = pa.array(rng.random(n) < 0.1, mask=rng.random(n) < 0.02)
+    idx = pa.array(rng.integers(0, n, 500_000).astype(np.uint32), mask=rng.random(500_000) < 0.05)
+    f64 = pa.array(rng.standard_normal(n), mask=rng.random(n) < 0.1)
+    want = dict(f=pc.filter(vals, mask), fe=pc.filter(vals, mask, null_selection_behavior="emit_null"),
+                fs=pc.filter(vals.slice(7), mask.slice(7)), t=pc.take(vals, idx),
+                c=pc.cast(f64, pa.float32()), cs=pc.cast(f64.slice(9), pa.float32()))
+    stock_before = sum(lib.arrow_amd_plugin_calls(f, 0) for f in (b"array_filter", b"array_take", b"cast"))
+
+    d_vals, d_mask, d_idx, d_f64 = to_device(vals), to_device(mask), to_device(idx), to_device(f64)
+    assert not d_vals.is_cpu and d_vals.device_type == pa.DeviceAllocationType.ROCM, d_vals.device_type
+    got = dict(f=pc.filter(d_vals, d_mask), fe=pc.filter(d_vals, d_mask, null_selection_behavior="emit_null"),
+               fs=pc.filter(d_vals.slice(7), d_mask.slice(7)), t=pc.take(d_vals, d_idx),
+               c=pc.cast(d_f64, pa.float32()), cs=pc.cast(d_f64.slice(9), pa.float32()))
+    for k, w in want.items():
+        assert not got[k].is_cpu, ("output left the device", k)     # outputs stay in HBM
+        h = to_host(got[k])               # (pyarrow refuses .null_count on non-CPU data)
+        assert h.is_cpu, k
+        if not h.equals(w):
+            hv, wv = h.fill_null(0).to_numpy(zero_copy_only=False), w.fill_null(0).to_numpy(zero_copy_only=False)
+            bad = np.nonzero((hv != wv) | (np.asarray(h.is_null()) != np.asarray(w.is_null())))[0] if len(h) == len(w) else []
+            raise SystemExit(f"MISMATCH {k}: len {len(h)} vs {len(w)}, nulls {h.null_count} vs {w.null_count}, "
+                             f"first bad {bad[:5]}, offset {h.offset}")
+        assert h.null_count == w.null_count, (k, h.null_count, w.null_count)
+    # a chain that never leaves the device: filter -> cast
+    chain = to_host(pc.cast(pc.filter(d_f64, d_mask), pa.float32()))
+    assert chain.equals(pc.cast(pc.filter(f64, mask), pa.float32()))
+    assert sum(lib.arrow_amd_plugin_calls(f, 0) for f in (b"array_filter", b"array_take", b"cast")) == stock_before
+    assert lib.arrow_amd_plugin_calls(b"array_filter", 1) >= 4 and lib.arrow_amd_plugin_calls(b"array_take", 1) >= 1
+    try:
+        pc.take(d_vals, to_device(pa.array(np.array([0, n], dtype=np.int64))))
+        raise SystemExit("expected IndexError")
+    except pa.lib.ArrowIndexError as e:
+        assert str(e) == f"Index {n} out of bounds", str(e)
+    print("DEVICE_OK")
+''')
+
+
+def test_device_resident_arrays_through_callfunction():
+    """SURVEY.md 8 (f1): pyarrow arrays whose buffers live in HBM (kROCM MemoryManager of the
+    plugin, imported through the C Device Data interface) go through Arrow's own CallFunction to
+    the HIP kernels with no staging; results stay on the device and equal the stock CPU results."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + DEVICE_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "DEVICE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
