@@ -29,7 +29,8 @@ namespace arx {
 constexpr int kSortItems = 16;
 constexpr int kSortTile = kBlock * kSortItems;  // 4096 keys
 constexpr int kDigits = 256;
-constexpr int kMaxChunks = 2048;
+constexpr int kMaxChunks = 16384;  // upper bound (sizes the histogram table)
+static int g_sort_chunks = 2048;    // chunks actually used (arx_set_option "sort_chunks")
 
 // Provided by selection.hip: ascending row numbers of the set (or clear) bits of a bitmap.
 int selection_bit_positions(const void* bitmap, int64_t bit_offset, int64_t length, bool invert,
@@ -309,7 +310,7 @@ static SortPlan make_plan(int64_t length) {
   SortPlan p{};
   p.n = length;
   p.ntiles = ceil_div(std::max<int64_t>(length, 1), kSortTile);
-  p.chunk_tiles = std::max<int64_t>(1, ceil_div(p.ntiles, kMaxChunks));
+  p.chunk_tiles = std::max<int64_t>(1, ceil_div(p.ntiles, g_sort_chunks));
   p.nchunks = ceil_div(p.ntiles, p.chunk_tiles);
   auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
   const size_t n = static_cast<size_t>(std::max<int64_t>(length, 1));
@@ -327,7 +328,13 @@ static SortPlan make_plan(int64_t length) {
   return p;
 }
 
-int set_sort_option(const char*, int64_t) { return 0; }
+int set_sort_option(const char* name, int64_t value) {
+  if (strcmp(name, "sort_chunks") == 0) {
+    g_sort_chunks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, kMaxChunks)));
+    return 1;
+  }
+  return 0;
+}
 
 }  // namespace arx
 
