@@ -700,7 +700,7 @@ __device__ __forceinline__ void gbp_scatter_tile(const GbpArgs& a, GbpScatterLds
 }
 
 template <bool HAS_NULLS>
-__global__ __launch_bounds__(kGbThreads) void gbp_scatter1_kernel(GbpArgs a) {
+__global__ __launch_bounds__(kGbThreads, 6) void gbp_scatter1_kernel(GbpArgs a) {
   __shared__ GbpScatterLds lds;
   const int tid = threadIdx.x;
   const int nb = 1 << a.b1;
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(kGbThreads) void gbp_scatter1_kernel(GbpArgs a) {
   }
 }
 
-__global__ __launch_bounds__(kGbThreads) void gbp_scatter2_kernel(GbpArgs a) {
+__global__ __launch_bounds__(kGbThreads, 6) void gbp_scatter2_kernel(GbpArgs a) {
   __shared__ GbpScatterLds lds;
   __shared__ uint32_t part_s;
   const int tid = threadIdx.x;

@@ -555,10 +555,12 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(CompactArgs a) {
 // traffic is the same as K3 (128-byte lines without a selected row are never touched).
 // Steps are aligned to 64-bit words of the OUTPUT bitmap, so the output validity of a step is
 // one __ballot: full words are stored, the tile's first/last partial words are OR-ed in.
+constexpr int kSparseWindow = 1024;  // emitted rows staged per round (a tile emits ~410 at 10 %)
+
 struct __attribute__((aligned(16))) SparseLds {
-  uint16_t sel[kWavesPerBlock][kTileRows];  // row-in-tile of the s-th emitted row
-  uint64_t vs[kWavesPerBlock][64];          // values_valid & mask_valid words of the tile
-  uint64_t zw[kWavesPerBlock][64];          // rows emitted only because the mask slot is null
+  uint16_t sel[kWavesPerBlock][kSparseWindow];  // row-in-tile of the s-th emitted row of the window
+  uint64_t vs[kWavesPerBlock][64];              // values_valid & mask_valid words of the tile
+  uint64_t zw[kWavesPerBlock][64];              // rows emitted only because the mask slot is null
 };
 
 template <int W, bool EMIT>
@@ -586,63 +588,74 @@ __global__ __launch_bounds__(kBlock) void compact_sparse_kernel(CompactArgs a) {
   const uint32_t cprev = lane < tin ? a.tile_counts[grp * kTilesPerGroup + lane] : 0u;
   const int64_t off = a.group_excl[grp] + wave_reduce_sum_u32(cprev);
 
-  // ---- 1. row list + validity words into LDS
   uint16_t* sel = lds.sel[wave];
-  {
-    uint64_t m = Ew;
-    uint32_t rk = p;
-    while (m != 0) {
-      const int bpos = __ffsll(static_cast<unsigned long long>(m)) - 1;
-      m &= m - 1;
-      sel[rk++] = static_cast<uint16_t>(lane * 64 + bpos);
-    }
-  }
   const bool want_validity = a.out_validity != nullptr;
   if (want_validity) lds.vs[wave][lane] = load_word(a.vvalid, w) & mv;
   if constexpr (EMIT) lds.zw[wave][lane] = Ew & ~mv;
-  wave_lds_sync();
 
-  // ---- 2. gather, 64 emitted rows per step, steps aligned to output bitmap words
   const E* __restrict__ values = reinterpret_cast<const E*>(a.values) + t * kTileRows;
   E* __restrict__ out = reinterpret_cast<E*>(a.out_data);
-  const int head = static_cast<int>(off & 63);      // the first step starts `head` bits into a word
+  const int head = static_cast<int>(off & 63);  // the first step starts `head` bits into a word
   const int nsteps = (head + total + 63) >> 6;
   const int64_t word0 = off >> 6;
-  for (int i0 = 0; i0 < nsteps; i0 += U) {
-    int s[U];
-    bool act[U];
-    int r[U];
-    E v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      s[u] = (i0 + u) * 64 + lane - head;  // emitted-row number inside the tile
-      act[u] = s[u] >= 0 && s[u] < total;
-      r[u] = act[u] ? sel[s[u]] : sel[0];  // inactive lanes re-read a row the wave reads anyway
+  constexpr int kStepsPerWindow = kSparseWindow / 64;
+
+  // Emitted rows are staged window by window (kSparseWindow rows = kStepsPerWindow output words);
+  // window r covers the steps [r * 16, r * 16 + 16), i.e. the emitted rows
+  // [r * 1024 - head, (r + 1) * 1024 - head).  One window is enough up to 25 % selectivity.
+  uint64_t m = Ew;   // bits of this lane's word not yet listed
+  uint32_t rk = p;   // output rank (inside the tile) of the next unlisted bit
+  for (int step0 = 0; step0 < nsteps; step0 += kStepsPerWindow) {
+    const int win_lo = step0 * 64 - head;          // first emitted row of the window (may be < 0)
+    const int win_hi = win_lo + kSparseWindow;     // one past the last
+    // ---- 1. list the rows of this window
+    while (m != 0 && static_cast<int>(rk) < win_hi) {
+      const int bpos = __ffsll(static_cast<unsigned long long>(m)) - 1;
+      m &= m - 1;
+      sel[static_cast<int>(rk) - win_lo] = static_cast<uint16_t>(lane * 64 + bpos);
+      ++rk;
     }
+    wave_lds_sync();
+    // ---- 2. gather, 64 emitted rows per step, steps aligned to output bitmap words
+    const int step_end = (step0 + kStepsPerWindow) < nsteps ? (step0 + kStepsPerWindow) : nsteps;
+    const int first_listed = win_lo < 0 ? 0 : win_lo;  // a row the wave lists anyway
+    for (int i0 = step0; i0 < step_end; i0 += U) {
+      int s[U];
+      bool act[U];
+      int r[U];
+      E v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = values[r[u]];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if ((i0 + u) >= nsteps) break;  // wave-uniform
-      E e = v[u];
-      if constexpr (EMIT) {
-        if ((lds.zw[wave][r[u] >> 6] >> (r[u] & 63)) & 1ull) e = zero_elem<W>();
+      for (int u = 0; u < U; ++u) {
+        s[u] = (i0 + u) * 64 + lane - head;  // emitted-row number inside the tile
+        act[u] = s[u] >= 0 && s[u] < total && (i0 + u) < step_end;
+        r[u] = sel[(act[u] ? s[u] : first_listed) - win_lo];
       }
-      if (act[u]) out[off + s[u]] = e;
-      if (want_validity) {
-        const bool vbit = act[u] && ((lds.vs[wave][r[u] >> 6] >> (r[u] & 63)) & 1ull);
-        const uint64_t bal = __ballot(vbit);
-        const uint64_t owned = __ballot(act[u]);
-        if (lane == 0) {
-          uint64_t* dst = a.out_validity + word0 + i0 + u;
-          if (owned == ~uint64_t(0)) {
-            *dst = bal;  // the whole output word belongs to this tile
-          } else if (bal != 0) {
-            atomicOr(reinterpret_cast<unsigned long long*>(dst), static_cast<unsigned long long>(bal));
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = values[r[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if ((i0 + u) >= step_end) break;  // wave-uniform
+        E e = v[u];
+        if constexpr (EMIT) {
+          if ((lds.zw[wave][r[u] >> 6] >> (r[u] & 63)) & 1ull) e = zero_elem<W>();
+        }
+        if (act[u]) out[off + s[u]] = e;
+        if (want_validity) {
+          const bool vbit = act[u] && ((lds.vs[wave][r[u] >> 6] >> (r[u] & 63)) & 1ull);
+          const uint64_t bal = __ballot(vbit);
+          const uint64_t owned = __ballot(act[u]);
+          if (lane == 0) {
+            uint64_t* dst = a.out_validity + word0 + i0 + u;
+            if (owned == ~uint64_t(0)) {
+              *dst = bal;  // the whole output word belongs to this tile
+            } else if (bal != 0) {
+              atomicOr(reinterpret_cast<unsigned long long*>(dst), static_cast<unsigned long long>(bal));
+            }
           }
         }
       }
     }
+    wave_lds_sync();  // the next window overwrites the list
   }
 }
 

@@ -121,13 +121,12 @@ struct __attribute__((aligned(16))) SortLds {
   uint64_t keys[kSortTile];
   uint32_t idx[kSortTile];
   uint32_t wave_cnt[kWavesPerBlock][kDigits];
-  uint32_t digit_start[kDigits];
   uint32_t cursor[kDigits];
   uint32_t wave_tot[kWavesPerBlock];
 };
 
 // last_pass: write idx widened to uint64 into out_final (keys are no longer needed)
-__global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
+__global__ __launch_bounds__(kBlock, 3) void radix_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in, int64_t n, int shift,
     int64_t chunk_tiles, int64_t nchunks, const uint32_t* __restrict__ hist_scanned,
     uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out, uint64_t* __restrict__ out_final,
@@ -170,27 +169,35 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     for (int w = 0; w < kWavesPerBlock; ++w) lds.wave_cnt[w][tid] = 0;
     __syncthreads();
 
-    // 3. wave-level multi-split: rank of each key among equal digits seen so far by this wave
+    // 3. wave-level multi-split: rank of each key among equal digits seen so far by this wave.
+    // Lanes holding the same digit find each other with 8 ballots; the lowest such lane adds the
+    // group's size to the wave's digit counter with ONE returning LDS atomic and the group reads
+    // the old value back with a shuffle.  LDS operations of a wave execute in order, so the four
+    // atomics of a batch are issued back to back (one round trip per 4 keys, not two per key) and
+    // still see each other's updates; lane order inside a group keeps the sort stable.
 #pragma unroll
-    for (int i = 0; i < kSortItems; ++i) {
-      const uint32_t d = static_cast<uint32_t>(key[i] >> shift) & 255u;
-      uint64_t peers = ~uint64_t(0);
+    for (int i0 = 0; i0 < kSortItems; i0 += 4) {
+      uint32_t prev[4];
+      int leader[4];
+      uint32_t below[4];
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        peers &= bit ? bal : ~bal;
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t d = static_cast<uint32_t>(key[i0 + j] >> shift) & 255u;
+        uint64_t peers = ~uint64_t(0);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const bool bit = (d >> b) & 1u;
+          const uint64_t bal = __ballot(bit);
+          peers &= bit ? bal : ~bal;
+        }
+        leader[j] = __ffsll(static_cast<unsigned long long>(peers)) - 1;
+        below[j] = __popcll(peers & ((uint64_t(1) << lane) - 1));
+        prev[j] = 0;
+        if (lane == leader[j]) prev[j] = atomicAdd(&lds.wave_cnt[wave][d], static_cast<uint32_t>(__popcll(peers)));
+        __builtin_amdgcn_wave_barrier();  // keeps the four updates in program order
       }
-      const uint32_t prev = lds.wave_cnt[wave][d];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int leader = __ffsll(static_cast<unsigned long long>(peers)) - 1;
-      if (lane == leader) lds.wave_cnt[wave][d] = prev + __popcll(peers);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      rank[i] = prev + __popcll(peers & ((uint64_t(1) << lane) - 1));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rank[i0 + j] = __shfl(prev[j], leader[j], 64) + below[j];
     }
     __syncthreads();
 
@@ -207,7 +214,6 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     __syncthreads();
     uint32_t dbase = incl - tot;
     for (int k = 0; k < wave; ++k) dbase += lds.wave_tot[k];
-    lds.digit_start[tid] = dbase;
     uint32_t run = dbase;
 #pragma unroll
     for (int w = 0; w < kWavesPerBlock; ++w) {
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
       if (p < nv) {
         const uint64_t kk = lds.keys[p];
         const uint32_t d = static_cast<uint32_t>(kk >> shift) & 255u;
-        const uint32_t dst = lds.cursor[d] + (static_cast<uint32_t>(p) - lds.digit_start[d]);
+        const uint32_t dst = lds.cursor[d] + (static_cast<uint32_t>(p) - lds.wave_cnt[0][d]);  // wave 0's run start = the digit's start
         if (last_pass) {
           out_final[dst] = lds.idx[p];
         } else {
