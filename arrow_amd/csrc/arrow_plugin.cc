@@ -645,6 +645,119 @@ Status GreaterExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecRe
   return Status::OK();
 }
 
+// The kernel actually registered for greater(double, double): NullHandling::COMPUTED_NO_PREALLOCATE +
+// MemAllocation::NO_PREALLOCATE, because the ScalarExecutor's own preallocation and null
+// propagation (exec.cc:846-861,1222-1281) run on the CPU and cannot touch device buffers.
+//  * device-resident inputs: compare, validity intersection and null count all on the MI355X,
+//    output bitmap + validity stay in HBM (so compare -> filter chains never leave the device);
+//  * host inputs: allocate what the executor would have preallocated, propagate nulls with Arrow's
+//    own bitmap utilities, then run the preallocated-style exec above (HIP staging path for large
+//    arrays, Arrow's stock kernel for scalars / small inputs).
+Status GreaterExecNP(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResult* out) {
+  const int64_t n = batch.length;
+  ArrayData* out_arr = out->array_data().get();
+  out_arr->buffers.resize(2);
+  const bool dev0 = batch[0].is_array() && OnRocm(batch[0].array);
+  const bool dev1 = batch[1].is_array() && OnRocm(batch[1].array);
+  if (dev0 || dev1) {
+    for (int i = 0; i < 2; ++i) {
+      if (batch[i].is_array() ? !OnRocm(batch[i].array) : !batch[i].scalar->is_valid) {
+        return Status::NotImplemented("arrow_amd: greater on device-resident arrays needs device arrays or "
+                                      "valid scalars on both sides");
+      }
+    }
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    ARROW_ASSIGN_OR_RAISE(out_arr->buffers[1], AllocDevice(((n + 63) / 64) * 8));
+    uint64_t* dout = reinterpret_cast<uint64_t*>(out_arr->buffers[1]->mutable_address());
+    ArxSpan sp[2] = {};
+    const double* ptr[2] = {nullptr, nullptr};
+    double sc[2] = {0.0, 0.0};
+    for (int i = 0; i < 2; ++i) {
+      if (batch[i].is_array()) {
+        ARROW_RETURN_NOT_OK(DeviceSpan(batch[i].array, &sp[i]));
+        ptr[i] = static_cast<const double*>(sp[i].data) + sp[i].offset;
+      } else {
+        sc[i] = static_cast<const arrow::DoubleScalar&>(*batch[i].scalar).value;
+      }
+    }
+    int rc;
+    if (ptr[0] && ptr[1]) rc = arx_greater_f64(ptr[0], ptr[1], n, dout, st);
+    else if (ptr[0]) rc = arx_greater_f64_array_scalar(ptr[0], sc[1], n, dout, st);
+    else rc = arx_greater_f64_scalar_array(sc[0], ptr[1], n, dout, st);
+    ARROW_RETURN_NOT_OK(FromArx(rc));
+    // validity = intersection of the inputs' validity bitmaps, re-based to offset 0
+    const ArxSpan* with_nulls[2];
+    int nv = 0;
+    for (int i = 0; i < 2; ++i) {
+      if (ptr[i] && sp[i].validity != nullptr) with_nulls[nv++] = &sp[i];
+    }
+    out_arr->buffers[0] = nullptr;
+    out_arr->null_count = 0;
+    if (nv > 0 && n > 0) {
+      ARROW_ASSIGN_OR_RAISE(out_arr->buffers[0], AllocDevice(((n + 63) / 64) * 8));
+      void* dv = reinterpret_cast<void*>(out_arr->buffers[0]->mutable_address());
+      if (nv == 1) {
+        ARROW_RETURN_NOT_OK(FromArx(arx_bitmap_copy(with_nulls[0]->validity, with_nulls[0]->offset, n, dv, st)));
+      } else {
+        ARROW_RETURN_NOT_OK(FromArx(arx_bitmap_and(with_nulls[0]->validity, with_nulls[0]->offset,
+                                                   with_nulls[1]->validity, with_nulls[1]->offset, n, dv, st)));
+      }
+      ARROW_ASSIGN_OR_RAISE(out_arr->null_count, DeviceNullCount(*out_arr->buffers[0], n, st));
+    }
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    CountGpu(kFnGreater);
+    return Status::OK();
+  }
+
+  // ---- host inputs: what ScalarExecutor::PrepareOutput + PropagateNulls would have done
+  arrow::MemoryPool* pool = ctx->memory_pool();
+  ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> data, ctx->AllocateBitmap(n));
+  std::shared_ptr<Buffer> validity;
+  int64_t null_count = 0;
+  bool null_scalar = false;
+  const ArraySpan* with_nulls[2];
+  int nv = 0;
+  for (int i = 0; i < 2; ++i) {
+    if (batch[i].is_scalar()) {
+      null_scalar = null_scalar || !batch[i].scalar->is_valid;
+    } else if (batch[i].array.MayHaveNulls()) {
+      with_nulls[nv++] = &batch[i].array;
+    }
+  }
+  if (null_scalar) {
+    ARROW_ASSIGN_OR_RAISE(validity, ctx->AllocateBitmap(n));  // zero-initialised: every slot null
+    null_count = n;
+  } else if (nv == 1) {
+    ARROW_ASSIGN_OR_RAISE(validity, arrow::internal::CopyBitmap(pool, with_nulls[0]->buffers[0].data,
+                                                                with_nulls[0]->offset, n));
+    null_count = with_nulls[0]->null_count;  // may be kUnknownNullCount
+  } else if (nv == 2) {
+    ARROW_ASSIGN_OR_RAISE(validity, arrow::internal::BitmapAnd(pool, with_nulls[0]->buffers[0].data,
+                                                               with_nulls[0]->offset, with_nulls[1]->buffers[0].data,
+                                                               with_nulls[1]->offset, n, 0));
+    null_count = arrow::kUnknownNullCount;
+  }
+  cp::ExecResult tmp;
+  ArraySpan span;
+  span.type = out_arr->type.get();
+  span.length = n;
+  span.offset = 0;
+  span.null_count = null_count;
+  if (validity) {
+    span.buffers[0].data = validity->mutable_data();
+    span.buffers[0].size = validity->size();
+  }
+  span.buffers[1].data = data->mutable_data();
+  span.buffers[1].size = data->size();
+  tmp.value = std::move(span);
+  ARROW_RETURN_NOT_OK(GreaterExec(ctx, batch, &tmp));
+  out_arr->buffers[0] = std::move(validity);
+  out_arr->buffers[1] = std::move(data);
+  out_arr->null_count = null_count;
+  return Status::OK();
+}
+
 // ---------------------------------------------------------------- array_sort_indices(uint64|int64)
 StockKernel g_stock_sort_u64, g_stock_sort_i64;
 
@@ -1020,7 +1133,9 @@ Status RegisterAll() {
     cp::ScalarKernel copy = *static_cast<const cp::ScalarKernel*>(k0);
     g_stock_greater.exec = copy.exec;
     g_stock_greater.init = copy.init;
-    copy.exec = GreaterExec;
+    copy.exec = GreaterExecNP;
+    copy.null_handling = cp::NullHandling::COMPUTED_NO_PREALLOCATE;
+    copy.mem_allocation = cp::MemAllocation::NO_PREALLOCATE;
     ARROW_RETURN_NOT_OK(sfn->AddKernel(std::move(copy)));
   }
   {

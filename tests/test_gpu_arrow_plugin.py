@@ -136,6 +136,19 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
             raise SystemExit(f"MISMATCH {k}: len {len(h)} vs {len(w)}, nulls {h.null_count} vs {w.null_count}, "
                              f"first bad {bad[:5]}, offset {h.offset}")
         assert h.null_count == w.null_count, (k, h.null_count, w.null_count)
+    # compare on the device: bitmap + intersected validity stay in HBM and feed a filter directly
+    f64b = pa.array(rng.standard_normal(n), mask=rng.random(n) < 0.07)
+    d_f64b = to_device(f64b)
+    for dev_mask, host_mask in ((pc.greater(d_f64, d_f64b), pc.greater(f64, f64b)),
+                                (pc.greater(d_f64.slice(5, n - 11), d_f64b.slice(11, n - 11)), pc.greater(f64.slice(5, n - 11), f64b.slice(11, n - 11))),
+                                (pc.greater(d_f64, 0.25), pc.greater(f64, 0.25)),
+                                (pc.greater(-0.5, d_f64b), pc.greater(-0.5, f64b))):
+        assert not dev_mask.is_cpu
+        hm = to_host(dev_mask)
+        assert hm.equals(host_mask) and hm.null_count == host_mask.null_count
+    sel = to_host(pc.filter(d_vals, pc.greater(d_f64, d_f64b)))
+    assert sel.equals(pc.filter(vals, pc.greater(f64, f64b)))
+    assert lib.arrow_amd_plugin_calls(b"greater", 1) >= 5
     # a chain that never leaves the device: filter -> cast
     chain = to_host(pc.cast(pc.filter(d_f64, d_mask), pa.float32()))
     assert chain.equals(pc.cast(pc.filter(f64, mask), pa.float32()))
