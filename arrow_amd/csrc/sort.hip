@@ -30,6 +30,7 @@ constexpr int kSortItems = 16;
 constexpr int kSortTile = kBlock * kSortItems;  // 4096 keys
 constexpr int kDigits = 256;
 constexpr int kMaxChunks = 16384;  // upper bound (sizes the histogram table)
+static int g_sort_fuse_prep = 1;    // first pass reads the caller's column directly (no prep pass)
 static int g_sort_chunks = 2048;    // chunks actually used (arx_set_option "sort_chunks")
 
 // Provided by selection.hip: ascending row numbers of the set (or clear) bits of a bitmap.
@@ -66,10 +67,17 @@ __global__ __launch_bounds__(kBlock) void widen_kernel(const uint32_t* __restric
   }
 }
 
+// raw: 0 = keys are already order-transformed; else bit0 set = raw column values, transformed on
+// the fly (bit1 = signed, bit2 = descending) — the first pass reads the caller's array directly.
+__device__ __forceinline__ uint64_t load_sort_key(const uint64_t* __restrict__ keys, int64_t i, int raw) {
+  const uint64_t k = keys[i];
+  return raw ? key_transform(k, (raw & 2) != 0, (raw & 4) != 0) : k;
+}
+
 __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t* __restrict__ keys,
                                                             int64_t n, int shift,
                                                             int64_t chunk_keys, int64_t nchunks,
-                                                            uint32_t* __restrict__ hist) {
+                                                            uint32_t* __restrict__ hist, int raw) {
   __shared__ uint32_t h[kDigits];
   const int64_t chunk = blockIdx.x;
   h[threadIdx.x] = 0;
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t* __re
   const int64_t begin = chunk * chunk_keys;
   const int64_t end = begin + chunk_keys < n ? begin + chunk_keys : n;
   for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) {
-    const uint32_t d = static_cast<uint32_t>(keys[i] >> shift) & 255u;
+    const uint32_t d = static_cast<uint32_t>(load_sort_key(keys, i, raw) >> shift) & 255u;
     atomicAdd(&h[d], 1u);
   }
   __syncthreads();
@@ -126,11 +134,14 @@ struct __attribute__((aligned(16))) SortLds {
 };
 
 // last_pass: write idx widened to uint64 into out_final (keys are no longer needed)
+// RAW: first pass over the caller's column (transform on load, row id = position); `raw` then carries
+// the transform flags (bit1 = signed, bit2 = descending).
+template <bool RAW>
 __global__ __launch_bounds__(kBlock, 3) void radix_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in, int64_t n, int shift,
     int64_t chunk_tiles, int64_t nchunks, const uint32_t* __restrict__ hist_scanned,
     uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out, uint64_t* __restrict__ out_final,
-    int last_pass) {
+    int last_pass, int raw) {
   __shared__ SortLds lds;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -157,8 +168,13 @@ __global__ __launch_bounds__(kBlock, 3) void radix_scatter_kernel(
     for (int i = 0; i < kSortItems; ++i) {
       const int p = wave * (kSortItems * 64) + i * 64 + lane;
       if (p < nv) {
-        key[i] = keys_in[base + p];
-        idx[i] = idx_in[base + p];
+        if constexpr (RAW) {
+          key[i] = key_transform(keys_in[base + p], (raw & 2) != 0, (raw & 4) != 0);
+          idx[i] = static_cast<uint32_t>(base + p);  // first pass: row id = position
+        } else {
+          key[i] = keys_in[base + p];
+          idx[i] = idx_in[base + p];
+        }
       } else {
         key[i] = ~uint64_t(0);  // sorts last inside the tile, never written
         idx[i] = 0;
@@ -335,6 +351,10 @@ static SortPlan make_plan(int64_t length) {
 }
 
 int set_sort_option(const char* name, int64_t value) {
+  if (strcmp(name, "sort_fuse_prep") == 0) {
+    g_sort_fuse_prep = value != 0;
+    return 1;
+  }
   if (strcmp(name, "sort_chunks") == 0) {
     g_sort_chunks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, kMaxChunks)));
     return 1;
@@ -432,9 +452,13 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
   uint64_t* final_dst =
       (has_nulls && null_placement == ARX_NULLS_AT_START) ? out_indices + (len - n_valid) : out_indices;
 
-  // ---- (key, row id) pairs
+  // ---- (key, row id) pairs.  With no nulls the first pass reads the caller's column directly
+  // (transform applied on load, row id = position); otherwise a prep pass gathers the valid rows.
   plan = make_plan(n_valid);
-  {
+  const int raw_first = (valid_rows == nullptr && g_sort_fuse_prep)
+                            ? (1 | (is_signed ? 2 : 0) | (order == ARX_SORT_DESCENDING ? 4 : 0))
+                            : 0;
+  if (!raw_first) {
     const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_valid, kBlock), 2048));
     hipLaunchKernelGGL(sort_prep_kernel, dim3(g), dim3(kBlock), 0, st, vals, valid_rows, n_valid,
                        is_signed, order == ARX_SORT_DESCENDING, keys_a, idx_a);
@@ -442,25 +466,37 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
   }
   const int64_t chunk_keys = plan.chunk_tiles * kSortTile;
   const unsigned nch = static_cast<unsigned>(plan.nchunks);
-  uint64_t* kin = keys_a;
+  const uint64_t* kin = raw_first ? vals : keys_a;
   uint64_t* kout = keys_b;
-  uint32_t* iin = idx_a;
+  const uint32_t* iin = idx_a;
   uint32_t* iout = idx_b;
   for (int pass = 0; pass < 8; ++pass) {
     const int shift = pass * 8;
+    const int raw = pass == 0 ? raw_first : 0;
     hipLaunchKernelGGL(radix_hist_kernel, dim3(nch), dim3(kBlock), 0, st, kin, n_valid, shift,
-                       chunk_keys, plan.nchunks, hist);
+                       chunk_keys, plan.nchunks, hist, raw);
     ARX_CHECK_LAUNCH("radix_hist_kernel");
     hipLaunchKernelGGL(radix_digit_totals_kernel, dim3(kDigits), dim3(64), 0, st, hist, plan.nchunks,
                        totals);
     ARX_CHECK_LAUNCH("radix_digit_totals_kernel");
     hipLaunchKernelGGL(radix_scan_kernel, dim3(kDigits), dim3(64), 0, st, hist, plan.nchunks, totals);
     ARX_CHECK_LAUNCH("radix_scan_kernel");
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nch), dim3(kBlock), 0, st, kin, iin, n_valid, shift,
-                       plan.chunk_tiles, plan.nchunks, hist, kout, iout, final_dst, pass == 7 ? 1 : 0);
+    if (raw) {
+      hipLaunchKernelGGL((radix_scatter_kernel<true>), dim3(nch), dim3(kBlock), 0, st, kin, iin, n_valid, shift,
+                         plan.chunk_tiles, plan.nchunks, hist, kout, iout, final_dst, 0, raw);
+    } else {
+      hipLaunchKernelGGL((radix_scatter_kernel<false>), dim3(nch), dim3(kBlock), 0, st, kin, iin, n_valid,
+                         shift, plan.chunk_tiles, plan.nchunks, hist, kout, iout, final_dst, pass == 7 ? 1 : 0,
+                         0);
+    }
     ARX_CHECK_LAUNCH("radix_scatter_kernel");
-    std::swap(kin, kout);
-    std::swap(iin, iout);
+    // ping-pong between the two scratch pairs (the caller's column is only ever read)
+    uint64_t* knext = (kout == keys_b) ? keys_a : keys_b;
+    uint32_t* inext = (iout == idx_b) ? idx_a : idx_b;
+    kin = kout;
+    iin = iout;
+    kout = knext;
+    iout = inext;
   }
   return ARX_OK;
 }
@@ -550,12 +586,12 @@ int arx_sort_partition_by_bins(const ArxSpan* values, int is_signed, int order, 
   const int64_t chunk_keys = plan.chunk_tiles * kSortTile;
   const unsigned nch = static_cast<unsigned>(plan.nchunks);
   hipLaunchKernelGGL(radix_hist_kernel, dim3(nch), dim3(kBlock), 0, st, keys_a, n_valid, 0, chunk_keys,
-                     plan.nchunks, hist);
+                     plan.nchunks, hist, 0);
   hipLaunchKernelGGL(radix_digit_totals_kernel, dim3(kDigits), dim3(64), 0, st, hist, plan.nchunks, totals);
   hipLaunchKernelGGL(widen_counts_kernel, dim3(1), dim3(kDigits), 0, st, totals, num_parts, out_counts);
   hipLaunchKernelGGL(radix_scan_kernel, dim3(kDigits), dim3(64), 0, st, hist, plan.nchunks, totals);
-  hipLaunchKernelGGL(radix_scatter_kernel, dim3(nch), dim3(kBlock), 0, st, keys_a, idx_a, n_valid, 0,
-                     plan.chunk_tiles, plan.nchunks, hist, keys_b, idx_b, static_cast<uint64_t*>(nullptr), 0);
+  hipLaunchKernelGGL((radix_scatter_kernel<false>), dim3(nch), dim3(kBlock), 0, st, keys_a, idx_a, n_valid, 0,
+                     plan.chunk_tiles, plan.nchunks, hist, keys_b, idx_b, static_cast<uint64_t*>(nullptr), 0, 0);
   ARX_CHECK_LAUNCH("radix partition pass");
   // transformed keys and row ids in destination-major, row-order-preserving order
   hipLaunchKernelGGL(sort_prep_kernel, dim3(g), dim3(kBlock), 0, st, vals, idx_b, n_valid, is_signed,
