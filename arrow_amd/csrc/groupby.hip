@@ -218,22 +218,29 @@ __device__ __forceinline__ int gb_dest(int32_t key, bool valid, int num_parts) {
   return static_cast<int>((h >> 32) % static_cast<uint64_t>(num_parts));
 }
 
+// Both kernels give every workgroup a contiguous chunk of kPartChunk rows and keep the
+// per-destination counters in LDS: one global atomic per (workgroup, destination) instead of one
+// per (wave, destination) — with 10M partial aggregates and 8 destinations the latter is
+// 1.25M atomics on 8 addresses (~5 ms each pass), the former 20K.
+constexpr int kPartChunk = kBlock * 32;
+constexpr int kPartMaxParts = 1024;
+
 __global__ __launch_bounds__(kBlock) void partition_count_kernel(const int32_t* __restrict__ keys,
                                                                  const uint8_t* __restrict__ key_is_valid,
                                                                  int64_t n, int num_parts,
                                                                  unsigned long long* part_counts) {
-  const int lane = lane_id();
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  const int64_t rounds = (n + stride - 1) / stride;
-  for (int64_t r = 0; r < rounds; ++r) {
-    const int64_t i = r * stride + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int d = i < n ? gb_dest(keys[i], key_is_valid == nullptr || key_is_valid[i] != 0, num_parts) : -1;
-    for (int p = 0; p < num_parts; ++p) {
-      const uint64_t bal = __ballot(d == p);
-      if (bal != 0 && lane == (__ffsll(static_cast<unsigned long long>(bal)) - 1)) {
-        atomicAdd(&part_counts[p], static_cast<unsigned long long>(__popcll(bal)));
-      }
-    }
+  __shared__ uint32_t cnt[kPartMaxParts];
+  for (int p = threadIdx.x; p < num_parts; p += kBlock) cnt[p] = 0;
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * kPartChunk;
+  const int64_t end = begin + kPartChunk < n ? begin + kPartChunk : n;
+  for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) {
+    const int d = gb_dest(keys[i], key_is_valid == nullptr || key_is_valid[i] != 0, num_parts);
+    atomicAdd(&cnt[d], 1u);
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < num_parts; p += kBlock) {
+    if (cnt[p] != 0) atomicAdd(&part_counts[p], static_cast<unsigned long long>(cnt[p]));
   }
 }
 
@@ -256,33 +263,36 @@ __global__ __launch_bounds__(kBlock) void partition_scatter_kernel(
     int32_t* __restrict__ out_keys, uint8_t* __restrict__ out_key_is_valid,
     int64_t* __restrict__ out_sums, int64_t* __restrict__ out_counts,
     uint8_t* __restrict__ out_no_nulls) {
-  const int lane = lane_id();
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  const int64_t rounds = (n + stride - 1) / stride;
-  for (int64_t r = 0; r < rounds; ++r) {
-    const int64_t i = r * stride + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const bool kv = i < n && (key_is_valid == nullptr || key_is_valid[i] != 0);
-    const int d = i < n ? gb_dest(keys[i], kv, num_parts) : -1;
-    int64_t pos = -1;
-    for (int p = 0; p < num_parts; ++p) {
-      const uint64_t bal = __ballot(d == p);
-      if (bal == 0) continue;
-      const int leader = __ffsll(static_cast<unsigned long long>(bal)) - 1;
-      unsigned long long base = 0;
-      if (lane == leader) base = atomicAdd(&cursors[p], static_cast<unsigned long long>(__popcll(bal)));
-      base = shfl_u64(base, leader);
-      if (d == p) pos = static_cast<int64_t>(base) + __popcll(bal & ((uint64_t(1) << lane) - 1));
-    }
-    if (pos >= 0) {
-      out_keys[pos] = keys[i];
-      out_key_is_valid[pos] = kv ? 1 : 0;
-      out_sums[pos] = sums[i];
-      out_counts[pos] = counts[i];
-      out_no_nulls[pos] = no_nulls == nullptr ? 1 : no_nulls[i];
-    }
+  __shared__ uint32_t cnt[kPartMaxParts];
+  __shared__ unsigned long long base[kPartMaxParts];
+  for (int p = threadIdx.x; p < num_parts; p += kBlock) cnt[p] = 0;
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * kPartChunk;
+  const int64_t end = begin + kPartChunk < n ? begin + kPartChunk : n;
+  // pass 1 over the chunk: how many rows go to each destination
+  for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) {
+    const int d = gb_dest(keys[i], key_is_valid == nullptr || key_is_valid[i] != 0, num_parts);
+    atomicAdd(&cnt[d], 1u);
+  }
+  __syncthreads();
+  // reserve this workgroup's output ranges, then reuse cnt[] as the running cursor inside them
+  for (int p = threadIdx.x; p < num_parts; p += kBlock) {
+    base[p] = cnt[p] != 0 ? atomicAdd(&cursors[p], static_cast<unsigned long long>(cnt[p])) : 0ull;
+    cnt[p] = 0;
+  }
+  __syncthreads();
+  // pass 2 (the chunk is L2-resident): write the rows (order inside a destination is unspecified)
+  for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) {
+    const bool kv = key_is_valid == nullptr || key_is_valid[i] != 0;
+    const int d = gb_dest(keys[i], kv, num_parts);
+    const int64_t pos = static_cast<int64_t>(base[d]) + atomicAdd(&cnt[d], 1u);
+    out_keys[pos] = keys[i];
+    out_key_is_valid[pos] = kv ? 1 : 0;
+    out_sums[pos] = sums[i];
+    out_counts[pos] = counts[i];
+    out_no_nulls[pos] = no_nulls == nullptr ? 1 : no_nulls[i];
   }
 }
-
 
 // ---- HashAggregateKernel path: dense group ids come from the caller's Grouper
 // (GroupedReducingAggregator<Int64Type,GroupedSumImpl>::Consume / Merge,
@@ -1312,16 +1322,16 @@ int arx_groupby_partition(const int32_t* keys, const uint8_t* key_is_valid, cons
   unsigned long long* cursors = part_counts + num_parts;
   ARX_HIP(hipMemsetAsync(ws, 0, static_cast<size_t>(num_parts) * 16, st));
   if (num_groups > 0) {
-    hipLaunchKernelGGL(partition_count_kernel, dim3(gb_grid(num_groups)), dim3(kBlock), 0, st, keys,
-                       key_is_valid, num_groups, num_parts, part_counts);
+    hipLaunchKernelGGL(partition_count_kernel, dim3(static_cast<unsigned>(ceil_div(num_groups, kPartChunk))),
+                       dim3(kBlock), 0, st, keys, key_is_valid, num_groups, num_parts, part_counts);
     ARX_CHECK_LAUNCH("partition_count_kernel");
   }
   hipLaunchKernelGGL(partition_offsets_kernel, dim3(1), dim3(64), 0, st, part_counts, num_parts,
                      cursors, out_part_counts);
   ARX_CHECK_LAUNCH("partition_offsets_kernel");
   if (num_groups > 0) {
-    hipLaunchKernelGGL(partition_scatter_kernel, dim3(gb_grid(num_groups)), dim3(kBlock), 0, st, keys,
-                       key_is_valid, sums, counts, no_nulls, num_groups, num_parts, cursors, out_keys,
+    hipLaunchKernelGGL(partition_scatter_kernel, dim3(static_cast<unsigned>(ceil_div(num_groups, kPartChunk))),
+                       dim3(kBlock), 0, st, keys, key_is_valid, sums, counts, no_nulls, num_groups, num_parts, cursors, out_keys,
                        out_key_is_valid, out_sums, out_counts, out_no_nulls);
     ARX_CHECK_LAUNCH("partition_scatter_kernel");
   }

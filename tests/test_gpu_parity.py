@@ -425,3 +425,49 @@ def test_sharded_sort_single_rank_pieces(gpu_ctx, order, placement):
                              descending=(order == "descending"), nulls_at_start=(placement == "at_start"))
     assert start == 0
     assert (rows.cpu().numpy().astype(np.uint64) == want).all()
+
+
+def test_groupby_virtual_ranks_on_one_gpu(gpu_ctx):
+    """The multi-GPU hash_sum data path with P = 4 virtual ranks on one device: per-rank local
+    aggregate -> device partition of the partials by hash(key) % P -> exchange (slicing stands in
+    for the all-to-all) -> merge -> finalize; the union must be the oracle's result and every key
+    must be owned by exactly one rank."""
+    import torch
+
+    from arrow_amd import parallel
+
+    amd = gpu_ctx
+    P_, n = 4, 600_000
+    rng = rng_for("vranks")
+    shards = []
+    for r in range(P_):
+        k = U.random_array(rng, np.int32, n + 1000 * r, null_p=0.01, offset=r, lo=-40000, hi=40000)
+        v = U.random_array(rng, np.int64, n + 1000 * r, null_p=0.1, offset=1)
+        shards.append((k, v))
+    parts, counts = [], []
+    for k, v in shards:
+        local = amd.compute.GroupBySum(1 << 18, k.to_device(amd).device)
+        local.consume(k.to_device(amd), v.to_device(amd))
+        pr, cnt = parallel.partition_partials(local.export(), P_, local.device)
+        parts.append(pr)
+        counts.append([int(x) for x in cnt.cpu().tolist()])
+    got = {}
+    for dst in range(P_):
+        owned = amd.compute.GroupBySum(1 << 18, parts[0]["keys"].device)
+        for src in range(P_):
+            lo = sum(counts[src][:dst])
+            hi = lo + counts[src][dst]
+            owned.merge({name: col[lo:hi].contiguous() for name, col in parts[src].items()})
+        gk, gkv, gs, gvalid = owned.finalize()
+        for key, kv, s, ok in zip(gk.cpu().tolist(), gkv.cpu().tolist(), gs.cpu().tolist(), gvalid.cpu().tolist()):
+            ident = (bool(kv), key if kv else 0)
+            assert ident not in got, f"key {ident} owned by two virtual ranks"
+            got[ident] = s if ok else None
+    keys = np.concatenate([k.values[k.offset:k.offset + k.length] for k, _ in shards])
+    kval = np.concatenate([np.ones(k.length, bool) if k.valid is None else k.valid[k.offset:k.offset + k.length] for k, _ in shards])
+    vals = np.concatenate([v.values[v.offset:v.offset + v.length] for _, v in shards])
+    vval = np.concatenate([np.ones(v.length, bool) if v.valid is None else v.valid[v.offset:v.offset + v.length] for _, v in shards])
+    w = O.groupby_sum_i64(keys, O.pack_bits(kval), 0, vals, O.pack_bits(vval), 0, len(keys))
+    want = {(bool(kv), int(k) if kv else 0): (int(s) if ok else None)
+            for k, kv, s, ok in zip(w["keys"], w["key_is_valid"], w["sums"], w["valid"])}
+    assert got == want

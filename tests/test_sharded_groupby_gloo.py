@@ -12,6 +12,15 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+@pytest.fixture(autouse=True, scope="module")
+def _emulated_library_is_built_once():
+    """Build the emulated kernel library in THIS process before any rank starts: two ranks
+    compiling the same objects concurrently would race."""
+    from tests.emu.build_emu import build
+
+    build()
+
 WORKER = textwrap.dedent(r'''
     import os, sys, pickle
     import numpy as np
