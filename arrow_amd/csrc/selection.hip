@@ -848,7 +848,7 @@ static int launch_count(const ArxSpan* mask, int null_selection, void* ws, size_
 // Tuning knobs (arx_set_option): filter_batch in {1,4}, filter_pipe in {0,1}.  Results never change.
 static int g_filter_batch = 4;
 static int g_filter_pipe = 1;
-static int g_filter_sparse = -1;  // -1 = by selectivity (S <= N/4), 0 = never, 1 = always
+static int g_filter_sparse = -1;  // -1 = auto (see launch_compact), 0 = never, 1 = always
 
 template <int W, bool IOTA, bool EMIT, bool ALIGNED>
 static void launch_compact_e(const CompactArgs& a, unsigned grid, hipStream_t st) {
@@ -889,9 +889,14 @@ static void launch_sparse_w(const CompactArgs& a, unsigned grid, hipStream_t st)
 static int launch_compact(bool iota, int W, const CompactArgs& a, hipStream_t st,
                           int64_t out_length = -1) {
   const unsigned grid = static_cast<unsigned>(ceil_div(a.ntiles, kWavesPerBlock));
+  // Measured on MI355X (profiles/r01_c_filter_selectivity_sweep.txt): for 8- and 16-byte values the
+  // gather form wins at EVERY selectivity (1.94 vs 2.46 ms at 25 %, 2.38 vs 2.84 ms at 50 %, equal
+  // at 100 %); narrower values keep the sweeping form above 25 % (its 16-byte granules carry
+  // 4-16 rows per lane, the gather form would issue 1-4 byte accesses).
   const bool sparse = !iota && !a.invert &&
                       (g_filter_sparse == 1 ||
-                       (g_filter_sparse < 0 && out_length >= 0 && out_length * 4 <= a.length));
+                       (g_filter_sparse < 0 &&
+                        (W >= 8 || (out_length >= 0 && out_length * 4 <= a.length))));
   if (sparse) {
     switch (W) {
       case 1: launch_sparse_w<1>(a, grid, st); break;

@@ -210,7 +210,7 @@ def run_filter_take(args, rank, world, device):
             "rows": n, "selected_rows": int(selected), "parallelism": "replicas" if world > 1 else "single-gpu",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "compact_sparse_kernel<8> (arx_filter_exec)" if selected * 4 <= n else "compact_kernel<8> (arx_filter_exec)",
+            "bound": "hbm", "kernel": "compact_sparse_kernel<8> (arx_filter_exec)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "algorithmic_bytes_per_launch": int(alg_bytes),
