@@ -30,6 +30,9 @@ constexpr int kSortItems = 16;
 constexpr int kSortTile = kBlock * kSortItems;  // 4096 keys
 constexpr int kDigits = 256;
 constexpr int kMaxChunks = 16384;  // upper bound (sizes the histogram table)
+static int g_sort_msd = -1;            // -1 = auto (n >= g_sort_msd_min_rows), 0 = never, 1 = whenever possible
+static int g_sort_msd_min_rows = 1 << 22;
+static int g_sort_msd_global_bits = 14;  // (= kMsdMaxBits) cap of the two global levels (tests lower it to reach level 3)
 static int g_sort_fuse_prep = 1;    // first pass reads the caller's column directly (no prep pass)
 static int g_sort_chunks = 2048;    // chunks actually used (arx_set_option "sort_chunks")
 
@@ -320,12 +323,461 @@ __global__ void widen_counts_kernel(const uint32_t* __restrict__ in, int n, int6
   if (i < n) out[i] = in[i];
 }
 
+
+// =====================================================================================
+// MSD-hybrid path of arx_sort_indices_64 (large inputs).
+//
+// The stable argsort is the unique ascending order of the COMPOSITE (transformed key, row id), so
+// no individual pass has to be stable as long as the last step orders by the composite.  That
+// allows most-significant-digit partitioning with cheap LDS-atomic ranking (the group-by's
+// scatter, ~4 TB/s) instead of eight stable least-significant-digit passes (256 B/row of traffic):
+//   M1 msd_hist      top `bits` (<= 14) bits: per-chunk level-1 counts + global bucket counts (8 B/row)
+//   M2 msd_scan_a/b  bucket starts, level-1 chunk offsets, level-2 cursors and tile map
+//   M3 msd_scatter1  level 1 (b1 bits), chunked, exact offsets                       (12+12 B/row)
+//   M4 msd_scatter2  level 2 (b2 bits) inside every level-1 bucket, cursor atomics   (12+12 B/row)
+//   M5 msd_local     level 3 (b3 <= 9 bits): one workgroup per level-2 bucket partitions it in place
+//                    of its own range (histogram pass + scatter pass, second read L2-warm)
+//   M6 msd_final     buckets now hold ~32-256 rows sharing their top bits: every row counts the
+//                    bucket members with a smaller (key, row id) — its final position — inside an
+//                    LDS window with a halo, and writes its row id there as uint64      (12+8 B/row)
+// A bucket larger than the halo (heavily duplicated keys) raises a flag and the caller falls back
+// to the LSD path, which has no such limit.
+// =====================================================================================
+constexpr int kMsdThreads = 512;
+constexpr int kMsdTile = 4096;
+constexpr int kMsdRows = kMsdTile / kMsdThreads;  // 8 per thread
+constexpr int kMsdMaxBits = 14;
+constexpr int kMsdMaxChunks = 2048;
+constexpr int kMsdCore = 2048;   // rows finalised per workgroup of msd_final
+constexpr int kMsdHalo = 512;    // a bucket must fit in the halo on either side
+constexpr int kMsdWindow = kMsdCore + 2 * kMsdHalo;
+
+struct MsdArgs {
+  const uint64_t* src_keys;   // level-1 input: raw column (raw != 0) or transformed keys
+  const uint32_t* src_idx;    // level-1 input row ids (unused when raw)
+  int raw;                    // 0, or 1 | (signed ? 2 : 0) | (descending ? 4 : 0)
+  int64_t n;
+  int bits, b1, b2, b3;       // bits = b1 + b2 (global levels), b3 = local level
+  int64_t chunk_rows, nchunks;
+  uint32_t* part_count;       // [2^bits]
+  uint32_t* part_start;       // [2^bits + 1]
+  uint32_t* cursor2;          // [2^bits]
+  uint32_t* hist1;            // [2^b1 * nchunks]
+  uint32_t* l1_start;         // [2^b1 + 1]
+  uint32_t* l2_tile_start;    // [2^b1 + 1]
+  uint64_t* keys_x;           // level-1 output, level-3 output
+  uint32_t* idx_x;
+  uint64_t* keys_y;           // level-2 output
+  uint32_t* idx_y;
+  uint64_t* out_final;
+  unsigned int* overflow;
+};
+
+template <bool RAW>
+__device__ __forceinline__ uint64_t msd_load_key(const MsdArgs& a, int64_t i) {
+  if constexpr (RAW) {
+    return key_transform(a.src_keys[i], (a.raw & 2) != 0, (a.raw & 4) != 0);
+  } else {
+    return a.src_keys[i];
+  }
+}
+
+template <bool RAW>
+__global__ __launch_bounds__(kMsdThreads) void msd_hist_kernel(MsdArgs a) {
+  __shared__ uint32_t h[1 << kMsdMaxBits];
+  const int tid = threadIdx.x;
+  const int nparts = 1 << a.bits;
+  for (int i = tid; i < nparts; i += kMsdThreads) h[i] = 0;
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * a.chunk_rows;
+  const int64_t end = begin + a.chunk_rows < a.n ? begin + a.chunk_rows : a.n;
+  const int shift = 64 - a.bits;
+  constexpr int U = 8;
+  int64_t r = begin + tid;
+  for (; r + (U - 1) * kMsdThreads < end; r += U * kMsdThreads) {
+    uint64_t kk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) kk[u] = msd_load_key<RAW>(a, r + u * kMsdThreads);
+#pragma unroll
+    for (int u = 0; u < U; ++u) atomicAdd(&h[kk[u] >> shift], 1u);
+  }
+  for (; r < end; r += kMsdThreads) atomicAdd(&h[msd_load_key<RAW>(a, r) >> shift], 1u);
+  __syncthreads();
+  for (int i = tid; i < nparts; i += kMsdThreads) {
+    const uint32_t c = h[i];
+    if (c != 0) atomicAdd(&a.part_count[i], c);
+  }
+  const int nb1 = 1 << a.b1;
+  const int per = 1 << a.b2;
+  for (int d = tid; d < nb1; d += kMsdThreads) {
+    uint32_t sum = 0;
+    for (int j = 0; j < per; ++j) sum += h[(d << a.b2) + j];
+    a.hist1[static_cast<int64_t>(d) * a.nchunks + blockIdx.x] = sum;
+  }
+}
+
+// one workgroup: bucket starts (exclusive scan), level-1 starts, level-2 cursors + tile map
+__global__ __launch_bounds__(1024) void msd_scan_a_kernel(MsdArgs a) {
+  __shared__ uint32_t ps[(1 << kMsdMaxBits) + 1];
+  __shared__ uint32_t wave_tot[16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nparts = 1 << a.bits;
+  const int per = (nparts + 1023) / 1024;
+  const int b = tid * per < nparts ? tid * per : nparts;
+  const int e = b + per < nparts ? b + per : nparts;
+  uint32_t sum = 0;
+  for (int i = b; i < e; ++i) sum += a.part_count[i];
+  const uint32_t incl = wave_inclusive_scan_u32(sum);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t prefix = incl - sum;
+  for (int k = 0; k < wave; ++k) prefix += wave_tot[k];
+  for (int i = b; i < e; ++i) {
+    ps[i] = prefix;
+    prefix += a.part_count[i];
+  }
+  if (tid == 1023) ps[nparts] = prefix;
+  __syncthreads();
+  for (int i = tid; i <= nparts; i += 1024) {
+    const uint32_t s0 = ps[i];
+    a.part_start[i] = s0;
+    if (i < nparts) a.cursor2[i] = s0;
+  }
+  const int nb1 = 1 << a.b1;
+  for (int d = tid; d <= nb1; d += 1024) a.l1_start[d] = ps[d == nb1 ? nparts : (d << a.b2)];
+  __syncthreads();
+  uint32_t tiles = 0;
+  if (tid < nb1) {
+    const uint32_t lo = ps[tid << a.b2];
+    const uint32_t hi = ps[(tid + 1) == nb1 ? nparts : ((tid + 1) << a.b2)];
+    tiles = (hi - lo + kMsdTile - 1) / kMsdTile;
+  }
+  const uint32_t tincl = wave_inclusive_scan_u32(tiles);
+  __syncthreads();
+  if (lane == 63) wave_tot[wave] = tincl;
+  __syncthreads();
+  uint32_t tprefix = tincl - tiles;
+  for (int k = 0; k < wave; ++k) tprefix += wave_tot[k];
+  if (tid < nb1) a.l2_tile_start[tid] = tprefix;
+  if (tid == nb1 - 1) a.l2_tile_start[nb1] = tprefix + tiles;
+}
+
+// one workgroup per level-1 digit: hist1[d][*] -> exclusive offsets (+ l1_start[d])
+__global__ __launch_bounds__(64) void msd_scan_b_kernel(MsdArgs a) {
+  const int lane = threadIdx.x;
+  uint32_t* row = a.hist1 + static_cast<int64_t>(blockIdx.x) * a.nchunks;
+  uint32_t carry = a.l1_start[blockIdx.x];
+  for (int64_t base = 0; base < a.nchunks; base += 64) {
+    const int64_t i = base + lane;
+    const uint32_t x = i < a.nchunks ? row[i] : 0u;
+    const uint32_t incl = wave_inclusive_scan_u32(x);
+    if (i < a.nchunks) row[i] = carry + incl - x;
+    carry += __shfl(incl, 63, 64);
+  }
+}
+
+template <int MAXBINS>
+struct __attribute__((aligned(16))) MsdScatterLds {
+  uint64_t keys[kMsdTile];
+  uint32_t idx[kMsdTile];
+  uint32_t cnt[MAXBINS];
+  uint32_t start[MAXBINS];
+  uint32_t gbase[MAXBINS];
+  uint32_t cursor[MAXBINS];
+  uint32_t wave_tot[kMsdThreads / 64];
+};
+
+// Scatter one tile of <= 4096 (key, row id) pairs by digit = (key >> dshift) & (nb - 1).
+// MODE 0: run bases from lds.cursor (advanced per tile);  MODE 1: from a global cursor array
+// (one returning atomic per digit);  the destination arrays are absolute.
+template <bool RAW, int MODE, int MAXBINS>
+__device__ __forceinline__ void msd_scatter_tile(const MsdArgs& a, MsdScatterLds<MAXBINS>& lds,
+                                                 const uint64_t* __restrict__ kin,
+                                                 const uint32_t* __restrict__ iin, int64_t row0,
+                                                 int nrows, int nb, int dshift,
+                                                 uint32_t* __restrict__ gcursor, uint32_t dst0,
+                                                 uint64_t* __restrict__ kout, uint32_t* __restrict__ iout) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t dmask = static_cast<uint32_t>(nb - 1);
+  if (tid < nb) lds.cnt[tid] = 0;
+  __syncthreads();
+  uint64_t key[kMsdRows];
+  uint32_t idx[kMsdRows];
+  int dig[kMsdRows];
+  uint32_t rank[kMsdRows];
+#pragma unroll
+  for (int i = 0; i < kMsdRows; ++i) {
+    const int p = i * kMsdThreads + tid;
+    dig[i] = -1;
+    key[i] = 0;
+    idx[i] = 0;
+    if (p < nrows) {
+      if constexpr (RAW) {
+        key[i] = key_transform(kin[row0 + p], (a.raw & 2) != 0, (a.raw & 4) != 0);
+        idx[i] = static_cast<uint32_t>(row0 + p);
+      } else {
+        key[i] = kin[row0 + p];
+        idx[i] = iin[row0 + p];
+      }
+      dig[i] = static_cast<int>(static_cast<uint32_t>(key[i] >> dshift) & dmask);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kMsdRows; ++i) {
+    rank[i] = 0;
+    if (dig[i] >= 0) rank[i] = atomicAdd(&lds.cnt[dig[i]], 1u);
+  }
+  __syncthreads();
+  uint32_t c = 0;
+  if (tid < nb) c = lds.cnt[tid];
+  const uint32_t incl = wave_inclusive_scan_u32(c);
+  if (lane == 63) lds.wave_tot[wave] = incl;
+  __syncthreads();
+  if (tid < nb) {
+    uint32_t pre = incl - c;
+    for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
+    lds.start[tid] = pre;
+    if constexpr (MODE == 0) {
+      const uint32_t g = lds.cursor[tid];
+      lds.gbase[tid] = g;
+      lds.cursor[tid] = g + c;
+    } else {
+      lds.gbase[tid] = c != 0 ? atomicAdd(&gcursor[tid], c) : 0u;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kMsdRows; ++i) {
+    if (dig[i] >= 0) {
+      const uint32_t pos = lds.start[dig[i]] + rank[i];
+      lds.keys[pos] = key[i];
+      lds.idx[pos] = idx[i];
+    }
+  }
+  __syncthreads();
+  for (int p = tid; p < nrows; p += kMsdThreads) {
+    const uint64_t k = lds.keys[p];
+    const uint32_t d = static_cast<uint32_t>(k >> dshift) & dmask;
+    const uint32_t dst = dst0 + lds.gbase[d] + (static_cast<uint32_t>(p) - lds.start[d]);
+    kout[dst] = k;
+    iout[dst] = lds.idx[p];
+  }
+  __syncthreads();
+}
+
+template <bool RAW>
+__global__ __launch_bounds__(kMsdThreads, 6) void msd_scatter1_kernel(MsdArgs a) {
+  __shared__ MsdScatterLds<128> lds;
+  const int tid = threadIdx.x;
+  const int nb = 1 << a.b1;
+  if (tid < nb) lds.cursor[tid] = a.hist1[static_cast<int64_t>(tid) * a.nchunks + blockIdx.x];
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * a.chunk_rows;
+  const int64_t end = begin + a.chunk_rows < a.n ? begin + a.chunk_rows : a.n;
+  for (int64_t row0 = begin; row0 < end; row0 += kMsdTile) {
+    const int nrows = static_cast<int>(end - row0 < kMsdTile ? end - row0 : kMsdTile);
+    msd_scatter_tile<RAW, 0, 128>(a, lds, a.src_keys, a.src_idx, row0, nrows, nb, 64 - a.b1, nullptr, 0u,
+                                  a.keys_x, a.idx_x);
+  }
+}
+
+__global__ __launch_bounds__(kMsdThreads, 6) void msd_scatter2_kernel(MsdArgs a) {
+  __shared__ MsdScatterLds<128> lds;
+  __shared__ uint32_t part_s;
+  const int tid = threadIdx.x;
+  const int nb1 = 1 << a.b1;
+  const uint32_t g = blockIdx.x;
+  if (g >= a.l2_tile_start[nb1]) return;  // over-provisioned grid
+  if (tid < 64) {
+    uint32_t below = 0;
+    for (int p = tid; p < nb1; p += 64) below += (a.l2_tile_start[p] <= g) ? 1u : 0u;
+    below = wave_reduce_sum_u32(below);
+    if (tid == 0) part_s = below - 1;
+  }
+  __syncthreads();
+  const uint32_t p = part_s;
+  const int64_t lo = a.l1_start[p];
+  const int64_t hi = a.l1_start[p + 1];
+  const int64_t row0 = lo + static_cast<int64_t>(g - a.l2_tile_start[p]) * kMsdTile;
+  const int nrows = static_cast<int>(hi - row0 < kMsdTile ? hi - row0 : kMsdTile);
+  msd_scatter_tile<false, 1, 128>(a, lds, a.keys_x, a.idx_x, row0, nrows, 1 << a.b2, 64 - a.bits,
+                                  a.cursor2 + (static_cast<size_t>(p) << a.b2), 0u, a.keys_y, a.idx_y);
+}
+
+// level 3: one workgroup per level-2 bucket, (keys_y, idx_y) -> (keys_x, idx_x) inside the
+// bucket's own range
+__global__ __launch_bounds__(kMsdThreads) void msd_local_kernel(MsdArgs a) {
+  __shared__ MsdScatterLds<512> lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t q = blockIdx.x;
+  const int64_t lo = a.part_start[q];
+  const int64_t hi = a.part_start[q + 1];
+  if (lo == hi) return;  // workgroup-uniform
+  const int nb = 1 << a.b3;
+  const int dshift = 64 - a.bits - a.b3;
+  const uint32_t dmask = static_cast<uint32_t>(nb - 1);
+  // histogram of the bucket -> running cursors (relative to the bucket start)
+  if (tid < nb) lds.cnt[tid] = 0;
+  __syncthreads();
+  for (int64_t r = lo + tid; r < hi; r += kMsdThreads) {
+    atomicAdd(&lds.cnt[static_cast<uint32_t>(a.keys_y[r] >> dshift) & dmask], 1u);
+  }
+  __syncthreads();
+  uint32_t c = 0;
+  if (tid < nb) c = lds.cnt[tid];
+  const uint32_t incl = wave_inclusive_scan_u32(c);
+  if (lane == 63) lds.wave_tot[wave] = incl;
+  __syncthreads();
+  if (tid < nb) {
+    uint32_t pre = incl - c;
+    for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
+    lds.cursor[tid] = pre;
+  }
+  __syncthreads();
+  for (int64_t row0 = lo; row0 < hi; row0 += kMsdTile) {
+    const int nrows = static_cast<int>(hi - row0 < kMsdTile ? hi - row0 : kMsdTile);
+    msd_scatter_tile<false, 0, 512>(a, lds, a.keys_y, a.idx_y, row0, nrows, nb, dshift, nullptr,
+                                    static_cast<uint32_t>(lo), a.keys_x, a.idx_x);
+  }
+}
+
+__device__ __forceinline__ int wave_inclusive_scan_max_i32(int v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int n = __shfl_up(v, d, 64);
+    if (lane >= d) v = v > n ? v : n;
+  }
+  return v;
+}
+
+struct __attribute__((aligned(16))) MsdFinalLds {
+  uint64_t keys[kMsdWindow];
+  uint32_t idx[kMsdWindow];
+  int16_t start[kMsdWindow];  // first window position of the row's bucket
+  int16_t endp[kMsdWindow];   // one past its last
+  int wave_val[4];
+};
+
+// final: position of every row inside its bucket = number of members with a smaller (key, id)
+__global__ __launch_bounds__(256) void msd_final_kernel(MsdArgs a, const uint64_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ idx, int pshift) {
+  __shared__ MsdFinalLds w;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t core0 = static_cast<int64_t>(blockIdx.x) * kMsdCore;
+  const int64_t wb = core0 - kMsdHalo > 0 ? core0 - kMsdHalo : 0;
+  const int64_t we = core0 + kMsdCore + kMsdHalo < a.n ? core0 + kMsdCore + kMsdHalo : a.n;
+  const int wlen = static_cast<int>(we - wb);
+  for (int i = tid; i < wlen; i += 256) {
+    w.keys[i] = keys[wb + i];
+    w.idx[i] = idx[wb + i];
+  }
+  __syncthreads();
+  // bucket boundaries: head[i] = the row starts a new prefix.  Every thread owns a contiguous strip.
+  constexpr int S = (kMsdWindow + 255) / 256;
+  const int s0 = tid * S < wlen ? tid * S : wlen;
+  const int s1 = s0 + S < wlen ? s0 + S : wlen;
+  // forward: start[i] = last head position <= i
+  {
+    int cur = -1;
+    for (int i = s0; i < s1; ++i) {
+      const bool head = i == 0 || (w.keys[i] >> pshift) != (w.keys[i - 1] >> pshift);
+      if (head) cur = i;
+      w.start[i] = static_cast<int16_t>(cur);
+    }
+    const int incl = wave_inclusive_scan_max_i32(cur);
+    if (lane == 63) w.wave_val[wave] = incl;
+    __syncthreads();
+    int carry = __shfl_up(incl, 1, 64);
+    if (lane == 0) carry = -1;
+    for (int k = 0; k < wave; ++k) carry = carry > w.wave_val[k] ? carry : w.wave_val[k];
+    for (int i = s0; i < s1; ++i) {
+      if (w.start[i] < 0) w.start[i] = static_cast<int16_t>(carry);
+    }
+    __syncthreads();
+  }
+  // backward: endp[i] = first head position > i (or wlen)
+  {
+    int cur = wlen + 1;  // "none"
+    for (int i = s1 - 1; i >= s0; --i) {
+      w.endp[i] = static_cast<int16_t>(cur > wlen ? -1 : cur);
+      const bool head = i == 0 || (w.keys[i] >> pshift) != (w.keys[i - 1] >> pshift);
+      if (head) cur = i;
+    }
+    // suffix minimum over the threads AFTER this one = prefix max of the negated value, reversed
+    const int neg = -cur;
+    int v = neg;
+    // inclusive max-scan from the high lanes down: reverse lane order with shfl_down
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int n2 = __shfl_down(v, d, 64);
+      if (lane + d < 64) v = v > n2 ? v : n2;
+    }
+    if (lane == 0) w.wave_val[wave] = v;  // max of -cur over the whole wave
+    __syncthreads();
+    int carry = __shfl_down(v, 1, 64);   // lanes after this one, same wave
+    if (lane == 63) carry = -(wlen + 1);
+    for (int k = wave + 1; k < 4; ++k) carry = carry > w.wave_val[k] ? carry : w.wave_val[k];
+    int after = -carry;                   // first head position in the strips after this thread
+    if (after > wlen) after = wlen;
+    for (int i = s0; i < s1; ++i) {
+      if (w.endp[i] < 0) w.endp[i] = static_cast<int16_t>(after);
+    }
+    __syncthreads();
+  }
+  // rank inside the bucket
+  const int c_lo = static_cast<int>(core0 - wb);
+  const int c_hi = static_cast<int>((core0 + kMsdCore < a.n ? core0 + kMsdCore : a.n) - wb);
+  bool bad = false;
+  for (int i = c_lo + tid; i < c_hi; i += 256) {
+    const int bs = w.start[i];
+    const int be = w.endp[i];
+    if ((bs == 0 && wb > 0) || (be == wlen && we < a.n)) {
+      bad = true;  // the bucket may continue outside the window
+      continue;
+    }
+    const uint64_t ki = w.keys[i];
+    const uint32_t ii = w.idx[i];
+    int rank = 0;
+    // four members per step: the LDS reads are independent (rows past the bucket end re-read its
+    // last member and are masked out), so their latency overlaps
+    for (int j = bs; j < be; j += 4) {
+      uint64_t kj[4];
+      uint32_t ij[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int jj = (j + u) < be ? (j + u) : (be - 1);
+        kj[u] = w.keys[jj];
+        ij[u] = w.idx[jj];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool less = kj[u] < ki || (kj[u] == ki && ij[u] < ii);
+        rank += (less && (j + u) < be) ? 1 : 0;
+      }
+    }
+    a.out_final[wb + bs + rank] = ii;
+  }
+  if (__any(bad) && lane == 0) atomicOr(a.overflow, 1u);
+}
+
+// part_count + part_start + cursor2 (2^14 + 1 each), hist1 (128 x 2048), l1_start, l2_tile_start, flag
+constexpr size_t kMsdTableBytes = (3 * ((size_t(1) << kMsdMaxBits) + 64) + size_t(128) * kMsdMaxChunks + 2 * 192 + 64) * 4;
+
 struct SortPlan {
   int64_t n;          // rows to sort (non-null)
   int64_t ntiles;
   int64_t chunk_tiles;
   int64_t nchunks;
-  size_t off_keys_a, off_keys_b, off_idx_a, off_idx_b, off_hist, off_totals, off_split, off_rows, off_sel_ws, total;
+  size_t off_keys_a, off_keys_b, off_idx_a, off_idx_b, off_hist, off_totals, off_split, off_msd, off_rows, off_sel_ws, total;
 };
 
 static SortPlan make_plan(int64_t length) {
@@ -344,6 +796,7 @@ static SortPlan make_plan(int64_t length) {
   p.off_hist = o; o = align(o + static_cast<size_t>(kDigits) * kMaxChunks * 4);
   p.off_totals = o; o = align(o + static_cast<size_t>(kDigits) * 4);
   p.off_split = o; o = align(o + static_cast<size_t>(kDigits) * 4);
+  p.off_msd = o; o = align(o + kMsdTableBytes);
   p.off_rows = o; o = align(o + n * 4);  // row ids of the non-null / null partitions
   p.off_sel_ws = o; o = align(o + selection_workspace_bytes(length));
   p.total = o;
@@ -351,6 +804,18 @@ static SortPlan make_plan(int64_t length) {
 }
 
 int set_sort_option(const char* name, int64_t value) {
+  if (strcmp(name, "sort_msd") == 0) {
+    g_sort_msd = value < 0 ? -1 : (value != 0);
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_global_bits") == 0) {
+    g_sort_msd_global_bits = static_cast<int>(std::max<int64_t>(2, std::min<int64_t>(value, kMsdMaxBits)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_min_rows") == 0) {
+    g_sort_msd_min_rows = static_cast<int>(std::max<int64_t>(256, std::min<int64_t>(value, INT32_MAX)));
+    return 1;
+  }
   if (strcmp(name, "sort_fuse_prep") == 0) {
     g_sort_fuse_prep = value != 0;
     return 1;
@@ -360,6 +825,83 @@ int set_sort_option(const char* name, int64_t value) {
     return 1;
   }
   return 0;
+}
+
+// Runs the MSD-hybrid path.  *overflowed = 1 if a bucket did not fit the final window (the caller
+// then falls back to the LSD path).  Synchronous (reads the flag back).
+static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n,
+                        uint64_t* keys_x, uint32_t* idx_x, uint64_t* keys_y, uint32_t* idx_y,
+                        uint8_t* tables, uint64_t* out_final, hipStream_t st, int* overflowed) {
+  MsdArgs a{};
+  a.src_keys = src_keys;
+  a.src_idx = src_idx;
+  a.raw = raw;
+  a.n = n;
+  int lg = 0;
+  while ((int64_t(1) << (lg + 1)) <= n) ++lg;
+  int total = lg - 4;  // ~16-32 rows per final bucket
+  total = std::max(2, std::min(total, kMsdMaxBits + 9));
+  a.bits = std::max(2, std::min(total, g_sort_msd_global_bits));
+  total = std::min(total, a.bits + 9);
+  a.b1 = (a.bits + 1) / 2;
+  a.b2 = a.bits - a.b1;
+  a.b3 = total - a.bits;
+  const int64_t ntiles = ceil_div(n, kMsdTile);
+  const int64_t chunk_tiles = std::max<int64_t>(1, ceil_div(ntiles, kMsdMaxChunks));
+  a.chunk_rows = chunk_tiles * kMsdTile;
+  a.nchunks = ceil_div(ntiles, chunk_tiles);
+  const size_t np = (size_t(1) << kMsdMaxBits) + 64;
+  uint32_t* t = reinterpret_cast<uint32_t*>(tables);
+  a.part_count = t;
+  a.part_start = t + np;
+  a.cursor2 = t + 2 * np;
+  a.hist1 = t + 3 * np;
+  a.l1_start = a.hist1 + size_t(128) * kMsdMaxChunks;
+  a.l2_tile_start = a.l1_start + 192;
+  a.overflow = a.l2_tile_start + 192;
+  a.keys_x = keys_x;
+  a.idx_x = idx_x;
+  a.keys_y = keys_y;
+  a.idx_y = idx_y;
+  a.out_final = out_final;
+  const int nparts = 1 << a.bits;
+  ARX_HIP(hipMemsetAsync(a.part_count, 0, static_cast<size_t>(nparts) * 4, st));
+  ARX_HIP(hipMemsetAsync(a.overflow, 0, 4, st));
+  const unsigned nch = static_cast<unsigned>(a.nchunks);
+  if (raw) {
+    hipLaunchKernelGGL((msd_hist_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((msd_hist_kernel<false>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  }
+  ARX_CHECK_LAUNCH("msd_hist_kernel");
+  hipLaunchKernelGGL(msd_scan_a_kernel, dim3(1), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(msd_scan_b_kernel, dim3(1u << a.b1), dim3(64), 0, st, a);
+  ARX_CHECK_LAUNCH("msd_scan kernels");
+  if (raw) {
+    hipLaunchKernelGGL((msd_scatter1_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((msd_scatter1_kernel<false>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  }
+  ARX_CHECK_LAUNCH("msd_scatter1_kernel");
+  const unsigned grid2 = static_cast<unsigned>(ceil_div(n, kMsdTile) + (int64_t(1) << a.b1));
+  hipLaunchKernelGGL(msd_scatter2_kernel, dim3(grid2), dim3(kMsdThreads), 0, st, a);
+  ARX_CHECK_LAUNCH("msd_scatter2_kernel");
+  const uint64_t* fk = keys_y;
+  const uint32_t* fi = idx_y;
+  if (a.b3 > 0) {
+    hipLaunchKernelGGL(msd_local_kernel, dim3(static_cast<unsigned>(nparts)), dim3(kMsdThreads), 0, st, a);
+    ARX_CHECK_LAUNCH("msd_local_kernel");
+    fk = keys_x;
+    fi = idx_x;
+  }
+  hipLaunchKernelGGL(msd_final_kernel, dim3(static_cast<unsigned>(ceil_div(n, kMsdCore))), dim3(256), 0, st, a,
+                     fk, fi, 64 - (a.bits + a.b3));
+  ARX_CHECK_LAUNCH("msd_final_kernel");
+  unsigned int flag = 0;
+  ARX_HIP(hipMemcpyAsync(&flag, a.overflow, 4, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  *overflowed = flag != 0;
+  return ARX_OK;
 }
 
 }  // namespace arx
@@ -451,6 +993,32 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
   if (n_valid == 0) return ARX_OK;
   uint64_t* final_dst =
       (has_nulls && null_placement == ARX_NULLS_AT_START) ? out_indices + (len - n_valid) : out_indices;
+
+  // ---- large inputs: MSD-hybrid path; falls through to the LSD passes if a bucket overflowed
+  // auto: 4M..256M rows, where it measured 1.5-2x faster than the LSD passes (with 23 partition
+  // bits the final buckets of a 1B-row input hold ~128 rows and the counting step loses: 101 vs 80 ms)
+  const bool try_msd = g_sort_msd != 0 && n_valid < (int64_t(1) << 32) - kMsdTile &&
+                       (g_sort_msd == 1 ? n_valid >= 256
+                                        : (n_valid >= g_sort_msd_min_rows && n_valid <= (int64_t(1) << 28)));
+  if (try_msd) {
+    uint8_t* tables = w + plan.off_msd;
+    int overflowed = 0;
+    int rc;
+    if (valid_rows == nullptr) {
+      const int raw = 1 | (is_signed ? 2 : 0) | (order == ARX_SORT_DESCENDING ? 4 : 0);
+      rc = run_msd_sort(vals, nullptr, raw, n_valid, keys_a, idx_a, keys_b, idx_b, tables, final_dst, st,
+                        &overflowed);
+    } else {
+      const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_valid, kBlock), 2048));
+      hipLaunchKernelGGL(sort_prep_kernel, dim3(g), dim3(kBlock), 0, st, vals, valid_rows, n_valid,
+                         is_signed, order == ARX_SORT_DESCENDING, keys_a, idx_a);
+      ARX_CHECK_LAUNCH("sort_prep_kernel");
+      rc = run_msd_sort(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables, final_dst, st,
+                        &overflowed);
+    }
+    if (rc != ARX_OK) return rc;
+    if (!overflowed) return ARX_OK;
+  }
 
   // ---- (key, row id) pairs.  With no nulls the first pass reads the caller's column directly
   // (transform applied on load, row id = position); otherwise a prep pass gathers the valid rows.

@@ -161,6 +161,11 @@ template <typename T> inline T __shfl_up(T v, unsigned d, int = 64) {
   const int src = lane - static_cast<int>(d);
   return hipemu::exchange(v, src < 0 ? lane : src);
 }
+template <typename T> inline T __shfl_down(T v, unsigned d, int = 64) {
+  const int lane = hipemu::my_lane();
+  const int src = lane + static_cast<int>(d);
+  return hipemu::exchange(v, src > 63 ? lane : src);
+}
 template <typename T> inline T __shfl_xor(T v, int m, int = 64) {
   return hipemu::exchange(v, hipemu::my_lane() ^ m);
 }

@@ -471,3 +471,29 @@ def test_groupby_virtual_ranks_on_one_gpu(gpu_ctx):
     want = {(bool(kv), int(k) if kv else 0): (int(s) if ok else None)
             for k, kv, s, ok in zip(w["keys"], w["key_is_valid"], w["sums"], w["valid"])}
     assert got == want
+
+
+@pytest.mark.parametrize("global_bits", [14, 4])
+def test_sort_msd_hybrid_path(gpu_ctx, global_bits):
+    """The MSD-hybrid sort forced on (two global levels [+ the in-bucket level when the global
+    bits are capped] + the windowed final ranking): full-range keys, heavy ties (bucket overflow ->
+    LSD fallback), nulls (prep + MSD), descending, signed."""
+    lib = gpu_ctx._lib.get_lib()
+    assert lib.arx_set_option(b"sort_msd", 1) == 0
+    assert lib.arx_set_option(b"sort_msd_global_bits", global_bits) == 0
+    try:
+        n = 6000011
+        rng = rng_for("msd", global_bits)
+        for dtype, order, placement, null_p in ((np.uint64, "ascending", "at_end", 0.0),
+                                               (np.int64, "descending", "at_start", 0.03),
+                                               (np.uint64, "descending", "at_end", 0.0)):
+            a = U.random_array(rng, dtype, n, null_p=null_p, offset=3)
+            a.values[a.offset:a.offset + n - 1:5] = a.values[a.offset + 1:a.offset + n:5]  # ties
+            P.check_sort_indices(gpu_ctx, a, order, placement, use_pyarrow=(dtype == np.int64))
+        ties = U.random_array(rng, np.uint64, n, lo=0, hi=7)       # 7 distinct keys: buckets overflow
+        P.check_sort_indices(gpu_ctx, ties, "ascending", "at_end", use_pyarrow=False)
+        small = U.random_array(rng, np.uint64, 300)
+        P.check_sort_indices(gpu_ctx, small, "ascending", "at_end", use_pyarrow=False)
+    finally:
+        lib.arx_set_option(b"sort_msd", -1)
+        lib.arx_set_option(b"sort_msd_global_bits", 14)
