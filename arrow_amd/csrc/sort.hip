@@ -349,7 +349,7 @@ constexpr int kMsdRows = kMsdTile / kMsdThreads;  // 8 per thread
 constexpr int kMsdMaxBits = 14;
 constexpr int kMsdMaxChunks = 2048;
 constexpr int kMsdCore = 2048;   // rows finalised per workgroup of msd_final
-constexpr int kMsdHalo = 512;    // a bucket must fit in the halo on either side
+constexpr int kMsdHalo = 256;    // a bucket must fit in the halo on either side
 constexpr int kMsdWindow = kMsdCore + 2 * kMsdHalo;
 
 struct MsdArgs {
@@ -660,18 +660,17 @@ __device__ __forceinline__ int wave_inclusive_scan_max_i32(int v) {
 struct __attribute__((aligned(16))) MsdFinalLds {
   uint64_t keys[kMsdWindow];
   uint32_t idx[kMsdWindow];
-  int16_t start[kMsdWindow];  // first window position of the row's bucket
-  int16_t endp[kMsdWindow];   // one past its last
-  int wave_val[4];
+  uint64_t head[kMsdWindow / 64 + 1];  // bit i of word w: window row 64 w + i starts a new bucket
 };
 
-// final: position of every row inside its bucket = number of members with a smaller (key, id)
+// final: position of every row inside its bucket = number of members with a smaller (key, id).
+// Bucket boundaries come from a bitmap of "prefix changes here" flags (one ballot per 64 rows):
+// the start of row i's bucket is the last set bit at or below i, its end the first set bit above.
 __global__ __launch_bounds__(256) void msd_final_kernel(MsdArgs a, const uint64_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ idx, int pshift) {
   __shared__ MsdFinalLds w;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
   const int64_t core0 = static_cast<int64_t>(blockIdx.x) * kMsdCore;
   const int64_t wb = core0 - kMsdHalo > 0 ? core0 - kMsdHalo : 0;
   const int64_t we = core0 + kMsdCore + kMsdHalo < a.n ? core0 + kMsdCore + kMsdHalo : a.n;
@@ -681,65 +680,30 @@ __global__ __launch_bounds__(256) void msd_final_kernel(MsdArgs a, const uint64_
     w.idx[i] = idx[wb + i];
   }
   __syncthreads();
-  // bucket boundaries: head[i] = the row starts a new prefix.  Every thread owns a contiguous strip.
-  constexpr int S = (kMsdWindow + 255) / 256;
-  const int s0 = tid * S < wlen ? tid * S : wlen;
-  const int s1 = s0 + S < wlen ? s0 + S : wlen;
-  // forward: start[i] = last head position <= i
-  {
-    int cur = -1;
-    for (int i = s0; i < s1; ++i) {
-      const bool head = i == 0 || (w.keys[i] >> pshift) != (w.keys[i - 1] >> pshift);
-      if (head) cur = i;
-      w.start[i] = static_cast<int16_t>(cur);
-    }
-    const int incl = wave_inclusive_scan_max_i32(cur);
-    if (lane == 63) w.wave_val[wave] = incl;
-    __syncthreads();
-    int carry = __shfl_up(incl, 1, 64);
-    if (lane == 0) carry = -1;
-    for (int k = 0; k < wave; ++k) carry = carry > w.wave_val[k] ? carry : w.wave_val[k];
-    for (int i = s0; i < s1; ++i) {
-      if (w.start[i] < 0) w.start[i] = static_cast<int16_t>(carry);
-    }
-    __syncthreads();
+  constexpr int kWords = kMsdWindow / 64;
+  for (int base = 0; base < kWords * 64; base += 256) {
+    const int i = base + tid;
+    const bool head = i < wlen && (i == 0 || (w.keys[i] >> pshift) != (w.keys[i - 1] >> pshift));
+    const uint64_t bal = __ballot(head);
+    if (lane == 0) w.head[i >> 6] = bal;
   }
-  // backward: endp[i] = first head position > i (or wlen)
-  {
-    int cur = wlen + 1;  // "none"
-    for (int i = s1 - 1; i >= s0; --i) {
-      w.endp[i] = static_cast<int16_t>(cur > wlen ? -1 : cur);
-      const bool head = i == 0 || (w.keys[i] >> pshift) != (w.keys[i - 1] >> pshift);
-      if (head) cur = i;
-    }
-    // suffix minimum over the threads AFTER this one = prefix max of the negated value, reversed
-    const int neg = -cur;
-    int v = neg;
-    // inclusive max-scan from the high lanes down: reverse lane order with shfl_down
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int n2 = __shfl_down(v, d, 64);
-      if (lane + d < 64) v = v > n2 ? v : n2;
-    }
-    if (lane == 0) w.wave_val[wave] = v;  // max of -cur over the whole wave
-    __syncthreads();
-    int carry = __shfl_down(v, 1, 64);   // lanes after this one, same wave
-    if (lane == 63) carry = -(wlen + 1);
-    for (int k = wave + 1; k < 4; ++k) carry = carry > w.wave_val[k] ? carry : w.wave_val[k];
-    int after = -carry;                   // first head position in the strips after this thread
-    if (after > wlen) after = wlen;
-    for (int i = s0; i < s1; ++i) {
-      if (w.endp[i] < 0) w.endp[i] = static_cast<int16_t>(after);
-    }
-    __syncthreads();
-  }
-  // rank inside the bucket
+  __syncthreads();
+  const int nwords = (wlen + 63) >> 6;
   const int c_lo = static_cast<int>(core0 - wb);
   const int c_hi = static_cast<int>((core0 + kMsdCore < a.n ? core0 + kMsdCore : a.n) - wb);
   bool bad = false;
   for (int i = c_lo + tid; i < c_hi; i += 256) {
-    const int bs = w.start[i];
-    const int be = w.endp[i];
+    // bucket start: last head bit at or below i
+    int wd = i >> 6;
+    const int bit = i & 63;
+    uint64_t m = w.head[wd] & (bit == 63 ? ~uint64_t(0) : ((uint64_t(2) << bit) - 1));
+    while (m == 0) m = w.head[--wd];  // terminates: row 0 of the window is always a head
+    const int bs = (wd << 6) + 63 - __builtin_clzll(m);
+    // bucket end: first head bit above i (or the window end)
+    wd = i >> 6;
+    m = bit == 63 ? 0 : (w.head[wd] & ~((uint64_t(2) << bit) - 1));
+    while (m == 0 && ++wd < nwords) m = w.head[wd];
+    const int be = m != 0 ? (wd << 6) + (__ffsll(static_cast<unsigned long long>(m)) - 1) : wlen;
     if ((bs == 0 && wb > 0) || (be == wlen && we < a.n)) {
       bad = true;  // the bucket may continue outside the window
       continue;
