@@ -32,6 +32,7 @@ constexpr int kDigits = 256;
 constexpr int kMaxChunks = 16384;  // upper bound (sizes the histogram table)
 static int g_sort_msd = -1;            // -1 = auto (n >= g_sort_msd_min_rows), 0 = never, 1 = whenever possible
 static int g_sort_msd_min_rows = 1 << 22;
+static int64_t g_sort_msd_segment_rows = int64_t(1) << 28;  // above this: an extra top-bits level cuts segments
 static int g_sort_msd_global_bits = 14;  // (= kMsdMaxBits) cap of the two global levels (tests lower it to reach level 3)
 static int g_sort_fuse_prep = 1;    // first pass reads the caller's column directly (no prep pass)
 static int g_sort_chunks = 2048;    // chunks actually used (arx_set_option "sort_chunks")
@@ -358,6 +359,7 @@ struct MsdArgs {
   int raw;                    // 0, or 1 | (signed ? 2 : 0) | (descending ? 4 : 0)
   int64_t n;
   int bits, b1, b2, b3;       // bits = b1 + b2 (global levels), b3 = local level
+  int kshift;                 // top bits already equal inside this segment: digits are taken from key << kshift
   int64_t chunk_rows, nchunks;
   uint32_t* part_count;       // [2^bits]
   uint32_t* part_start;       // [2^bits + 1]
@@ -399,9 +401,9 @@ __global__ __launch_bounds__(kMsdThreads) void msd_hist_kernel(MsdArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) kk[u] = msd_load_key<RAW>(a, r + u * kMsdThreads);
 #pragma unroll
-    for (int u = 0; u < U; ++u) atomicAdd(&h[kk[u] >> shift], 1u);
+    for (int u = 0; u < U; ++u) atomicAdd(&h[(kk[u] << a.kshift) >> shift], 1u);
   }
-  for (; r < end; r += kMsdThreads) atomicAdd(&h[msd_load_key<RAW>(a, r) >> shift], 1u);
+  for (; r < end; r += kMsdThreads) atomicAdd(&h[(msd_load_key<RAW>(a, r) << a.kshift) >> shift], 1u);
   __syncthreads();
   for (int i = tid; i < nparts; i += kMsdThreads) {
     const uint32_t c = h[i];
@@ -523,7 +525,7 @@ __device__ __forceinline__ void msd_scatter_tile(const MsdArgs& a, MsdScatterLds
         key[i] = kin[row0 + p];
         idx[i] = iin[row0 + p];
       }
-      dig[i] = static_cast<int>(static_cast<uint32_t>(key[i] >> dshift) & dmask);
+      dig[i] = static_cast<int>(static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask);
     }
   }
 #pragma unroll
@@ -561,7 +563,7 @@ __device__ __forceinline__ void msd_scatter_tile(const MsdArgs& a, MsdScatterLds
   __syncthreads();
   for (int p = tid; p < nrows; p += kMsdThreads) {
     const uint64_t k = lds.keys[p];
-    const uint32_t d = static_cast<uint32_t>(k >> dshift) & dmask;
+    const uint32_t d = static_cast<uint32_t>((k << a.kshift) >> dshift) & dmask;
     const uint32_t dst = dst0 + lds.gbase[d] + (static_cast<uint32_t>(p) - lds.start[d]);
     kout[dst] = k;
     iout[dst] = lds.idx[p];
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(kMsdThreads) void msd_local_kernel(MsdArgs a) {
   if (tid < nb) lds.cnt[tid] = 0;
   __syncthreads();
   for (int64_t r = lo + tid; r < hi; r += kMsdThreads) {
-    atomicAdd(&lds.cnt[static_cast<uint32_t>(a.keys_y[r] >> dshift) & dmask], 1u);
+    atomicAdd(&lds.cnt[static_cast<uint32_t>((a.keys_y[r] << a.kshift) >> dshift) & dmask], 1u);
   }
   __syncthreads();
   uint32_t c = 0;
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(256) void msd_final_kernel(MsdArgs a, const uint64_
   constexpr int kWords = kMsdWindow / 64;
   for (int base = 0; base < kWords * 64; base += 256) {
     const int i = base + tid;
-    const bool head = i < wlen && (i == 0 || (w.keys[i] >> pshift) != (w.keys[i - 1] >> pshift));
+    const bool head = i < wlen && (i == 0 || ((w.keys[i] << a.kshift) >> pshift) != ((w.keys[i - 1] << a.kshift) >> pshift));
     const uint64_t bal = __ballot(head);
     if (lane == 0) w.head[i >> 6] = bal;
   }
@@ -772,6 +774,10 @@ int set_sort_option(const char* name, int64_t value) {
     g_sort_msd = value < 0 ? -1 : (value != 0);
     return 1;
   }
+  if (strcmp(name, "sort_msd_segment_rows") == 0) {
+    g_sort_msd_segment_rows = std::max<int64_t>(1024, value);
+    return 1;
+  }
   if (strcmp(name, "sort_msd_global_bits") == 0) {
     g_sort_msd_global_bits = static_cast<int>(std::max<int64_t>(2, std::min<int64_t>(value, kMsdMaxBits)));
     return 1;
@@ -795,8 +801,12 @@ int set_sort_option(const char* name, int64_t value) {
 // then falls back to the LSD path).  Synchronous (reads the flag back).
 static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n,
                         uint64_t* keys_x, uint32_t* idx_x, uint64_t* keys_y, uint32_t* idx_y,
-                        uint8_t* tables, uint64_t* out_final, hipStream_t st, int* overflowed) {
+                        uint8_t* tables, uint64_t* out_final, hipStream_t st, int* overflowed,
+                        int kshift = 0) {
+  *overflowed = 0;
+  if (n == 0) return ARX_OK;
   MsdArgs a{};
+  a.kshift = kshift;
   a.src_keys = src_keys;
   a.src_idx = src_idx;
   a.raw = raw;
@@ -804,7 +814,7 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   int lg = 0;
   while ((int64_t(1) << (lg + 1)) <= n) ++lg;
   int total = lg - 4;  // ~16-32 rows per final bucket
-  total = std::max(2, std::min(total, kMsdMaxBits + 9));
+  total = std::max(2, std::min(total, std::min(kMsdMaxBits + 9, 64 - kshift)));
   a.bits = std::max(2, std::min(total, g_sort_msd_global_bits));
   total = std::min(total, a.bits + 9);
   a.b1 = (a.bits + 1) / 2;
@@ -865,6 +875,76 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   ARX_HIP(hipMemcpyAsync(&flag, a.overflow, 4, hipMemcpyDeviceToHost, st));
   ARX_HIP(hipStreamSynchronize(st));
   *overflowed = flag != 0;
+  return ARX_OK;
+}
+
+
+// Inputs beyond ~2^28 rows: one extra unstable level on the top b0 bits cuts the array into
+// 2^b0 segments of ~2^27 rows (32 B/row), then every segment runs the pipeline above on the bits
+// below (kshift = b0).  Synchronous.
+static int run_msd_sort_segmented(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n,
+                                  uint64_t* keys_p, uint32_t* idx_p, uint64_t* keys_q, uint32_t* idx_q,
+                                  uint8_t* tables, uint64_t* out_final, hipStream_t st, int* overflowed) {
+  int b0 = 1;
+  while ((n >> b0) > (int64_t(1) << 27) && b0 < 7) ++b0;
+  MsdArgs a{};
+  a.src_keys = src_keys;
+  a.src_idx = src_idx;
+  a.raw = raw;
+  a.n = n;
+  a.kshift = 0;
+  a.bits = b0;
+  a.b1 = b0;
+  a.b2 = 0;
+  a.b3 = 0;
+  const int64_t ntiles = ceil_div(n, kMsdTile);
+  const int64_t chunk_tiles = std::max<int64_t>(1, ceil_div(ntiles, kMsdMaxChunks));
+  a.chunk_rows = chunk_tiles * kMsdTile;
+  a.nchunks = ceil_div(ntiles, chunk_tiles);
+  const size_t np = (size_t(1) << kMsdMaxBits) + 64;
+  uint32_t* t = reinterpret_cast<uint32_t*>(tables);
+  a.part_count = t;
+  a.part_start = t + np;
+  a.cursor2 = t + 2 * np;
+  a.hist1 = t + 3 * np;
+  a.l1_start = a.hist1 + size_t(128) * kMsdMaxChunks;
+  a.l2_tile_start = a.l1_start + 192;
+  a.overflow = a.l2_tile_start + 192;
+  a.keys_x = keys_p;
+  a.idx_x = idx_p;
+  const int nseg = 1 << b0;
+  ARX_HIP(hipMemsetAsync(a.part_count, 0, static_cast<size_t>(nseg) * 4, st));
+  const unsigned nch = static_cast<unsigned>(a.nchunks);
+  if (raw) {
+    hipLaunchKernelGGL((msd_hist_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((msd_hist_kernel<false>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  }
+  hipLaunchKernelGGL(msd_scan_a_kernel, dim3(1), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(msd_scan_b_kernel, dim3(1u << a.b1), dim3(64), 0, st, a);
+  if (raw) {
+    hipLaunchKernelGGL((msd_scatter1_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((msd_scatter1_kernel<false>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  }
+  ARX_CHECK_LAUNCH("msd level 0");
+  uint32_t seg_start[129];
+  ARX_HIP(hipMemcpyAsync(seg_start, a.part_start, static_cast<size_t>(nseg + 1) * 4, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  *overflowed = 0;
+  for (int sgm = 0; sgm < nseg; ++sgm) {
+    const int64_t lo = seg_start[sgm];
+    const int64_t m = static_cast<int64_t>(seg_start[sgm + 1]) - lo;
+    int ovf = 0;
+    // the segment's rows live in (keys_p, idx_p): levels ping-pong p -> q -> p -> q
+    const int rc = run_msd_sort(keys_p + lo, idx_p + lo, 0, m, keys_q + lo, idx_q + lo, keys_p + lo, idx_p + lo,
+                                tables, out_final + lo, st, &ovf, b0);
+    if (rc != ARX_OK) return rc;
+    if (ovf) {
+      *overflowed = 1;
+      return ARX_OK;
+    }
+  }
   return ARX_OK;
 }
 
@@ -959,26 +1039,30 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
       (has_nulls && null_placement == ARX_NULLS_AT_START) ? out_indices + (len - n_valid) : out_indices;
 
   // ---- large inputs: MSD-hybrid path; falls through to the LSD passes if a bucket overflowed
-  // auto: 4M..256M rows, where it measured 1.5-2x faster than the LSD passes (with 23 partition
-  // bits the final buckets of a 1B-row input hold ~128 rows and the counting step loses: 101 vs 80 ms)
+  // auto: from 4M rows up; beyond 2^28 rows an extra level on the top bits cuts ~2^27-row segments
+  // (with only 23 partition bits the final buckets of a 1B-row input would hold ~128 rows)
   const bool try_msd = g_sort_msd != 0 && n_valid < (int64_t(1) << 32) - kMsdTile &&
-                       (g_sort_msd == 1 ? n_valid >= 256
-                                        : (n_valid >= g_sort_msd_min_rows && n_valid <= (int64_t(1) << 28)));
+                       (g_sort_msd == 1 ? n_valid >= 256 : n_valid >= g_sort_msd_min_rows);
+  const bool segmented = n_valid > g_sort_msd_segment_rows;
   if (try_msd) {
     uint8_t* tables = w + plan.off_msd;
     int overflowed = 0;
     int rc;
     if (valid_rows == nullptr) {
       const int raw = 1 | (is_signed ? 2 : 0) | (order == ARX_SORT_DESCENDING ? 4 : 0);
-      rc = run_msd_sort(vals, nullptr, raw, n_valid, keys_a, idx_a, keys_b, idx_b, tables, final_dst, st,
-                        &overflowed);
+      rc = segmented ? run_msd_sort_segmented(vals, nullptr, raw, n_valid, keys_a, idx_a, keys_b, idx_b, tables,
+                                              final_dst, st, &overflowed)
+                     : run_msd_sort(vals, nullptr, raw, n_valid, keys_a, idx_a, keys_b, idx_b, tables, final_dst, st,
+                                    &overflowed);
     } else {
       const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_valid, kBlock), 2048));
       hipLaunchKernelGGL(sort_prep_kernel, dim3(g), dim3(kBlock), 0, st, vals, valid_rows, n_valid,
                          is_signed, order == ARX_SORT_DESCENDING, keys_a, idx_a);
       ARX_CHECK_LAUNCH("sort_prep_kernel");
-      rc = run_msd_sort(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables, final_dst, st,
-                        &overflowed);
+      rc = segmented ? run_msd_sort_segmented(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables,
+                                              final_dst, st, &overflowed)
+                     : run_msd_sort(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables, final_dst, st,
+                                    &overflowed);
     }
     if (rc != ARX_OK) return rc;
     if (!overflowed) return ARX_OK;

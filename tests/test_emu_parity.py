@@ -345,13 +345,16 @@ def test_groupby_partitioned_path(emu_ctx, bits):
         lib.arx_set_option(b"groupby_partition_bits", -1)
 
 
-@pytest.mark.parametrize("global_bits", [14, 4])
+@pytest.mark.parametrize("global_bits", [14, 4, -14])
 def test_sort_msd_hybrid_path(emu_ctx, global_bits):
     """The MSD-hybrid sort forced on (two global levels [+ the in-bucket level when the global
     bits are capped] + the windowed final ranking): full-range keys, heavy ties (bucket overflow ->
     LSD fallback), nulls (prep + MSD), descending, signed."""
     lib = emu_ctx._lib.get_lib()
     assert lib.arx_set_option(b"sort_msd", 1) == 0
+    if global_bits < 0:   # the segmented form: an extra level on the top bits, then one pipeline per segment
+        global_bits = -global_bits
+        assert lib.arx_set_option(b"sort_msd_segment_rows", 4096) == 0
     assert lib.arx_set_option(b"sort_msd_global_bits", global_bits) == 0
     try:
         n = 30000
@@ -369,3 +372,4 @@ def test_sort_msd_hybrid_path(emu_ctx, global_bits):
     finally:
         lib.arx_set_option(b"sort_msd", -1)
         lib.arx_set_option(b"sort_msd_global_bits", 14)
+        lib.arx_set_option(b"sort_msd_segment_rows", 1 << 28)
