@@ -339,3 +339,55 @@ def check_hash_sum_kernel(amd, rng, n=5000, num_groups=37, null_p=0.2, skip_null
             if ok:
                 assert int(_data_np(out, np.int64)[kk]) == vv, f"{tag}: group {kk} sum vs pyarrow"
     return out
+
+
+# ------------------------------------------------------------------ null_count bookkeeping
+def check_null_count_bookkeeping(amd, rng, n=10_000):
+    """the same logical array described in every way Arrow allows —
+    exact null_count, kUnknownNullCount (-1), a validity buffer that is present but all-valid
+    (null_count 0), and NO validity buffer with an unknown count (vector_selection_test.cc:625) —
+    must filter / take identically, and the outputs must follow the reference's rules:
+    filter: validity allocated iff an input may have nulls (:472), null_count 0 or unknown
+    (:462-467); take: exact null_count (vector_selection_take_internal.cc:377)."""
+    vals = util.random_array(rng, np.int64, n, null_p=0.2, offset=2)
+    mask = util.random_mask(rng, n, 0.3, null_p=0.1, offset=1)
+    idx = HostArray(rng.integers(0, n, 4000).astype(np.int32), rng.random(4000) >= 0.1, 0, 4000)
+    for sel in ("drop", "emit_null"):
+        ref_f = check_filter(amd, vals, mask, sel, use_pyarrow=False)
+        ref_t = check_take(amd, vals, idx, boundscheck=True, use_pyarrow=False)
+        base_v, base_m, base_i = vals.to_device(amd), mask.to_device(amd), idx.to_device(amd)
+        unk = lambda a: amd.Array(a.type, a.length, a.buffers, -1, a.offset)  # noqa: E731
+        out = amd.compute.filter(unk(base_v), unk(base_m), sel)
+        assert out.length == ref_f.length
+        assert_equal(_data_np(out, np.int64), _data_np(ref_f, np.int64), "filter with unknown null counts")
+        assert_equal(_logical_valid(out)[0], _logical_valid(ref_f)[0], "filter validity with unknown null counts")
+        assert out.null_count == -1 and out.validity is not None
+        tk = amd.compute.take(unk(base_v), unk(base_i))
+        assert_equal(_logical_valid(tk)[0], _logical_valid(ref_t)[0], "take validity with unknown null counts")
+        assert tk.null_count == ref_t.null_count == int((~_logical_valid(ref_t)[0]).sum())
+    # validity buffers present but all valid: null_count 0 => treated as no nulls, no output bitmap
+    allv = util.random_array(rng, np.int64, n, offset=3)
+    allm = util.random_mask(rng, n, 0.4)
+    dv = HostArray(allv.values, np.ones(len(allv.values), bool), allv.offset, n).to_device(amd)
+    dm = HostArray(allm.values, np.ones(len(allm.values), bool), allm.offset, n).to_device(amd)
+    assert dv.validity is not None and dm.validity is not None
+    dv0 = amd.Array(dv.type, dv.length, dv.buffers, 0, dv.offset)
+    dm0 = amd.Array(dm.type, dm.length, dm.buffers, 0, dm.offset)
+    out = amd.compute.filter(dv0, dm0, "emit_null")
+    want, _ = O.filter(allv.data_bytes(), None, allv.offset, allm.data_bytes(), None, allm.offset, n, 1, True)
+    assert out.validity is None and out.null_count == 0 and out.length == len(want)
+    assert_equal(_data_np(out, np.int64), want, "filter of all-valid arrays that carry bitmaps")
+    # ... and the same bitmaps with an UNKNOWN count: may have nulls => a bitmap comes out, all set
+    out = amd.compute.filter(amd.Array(dv.type, dv.length, dv.buffers, -1, dv.offset), dm0, "drop")
+    assert out.validity is not None and bool(_logical_valid(out)[0].all())
+    assert_equal(_data_np(out, np.int64), O.filter(allv.data_bytes(), None, allv.offset, allm.data_bytes(), None,
+                                                    allm.offset, n, 0, True)[0], "filter, unknown count, all valid")
+    # no validity buffer + unknown null_count (vector_selection_test.cc:625): no nulls, no bitmap read
+    nv = amd.Array(dv.type, dv.length, [None, dv.buffers[1]], -1, dv.offset)
+    nm = amd.Array(dm.type, dm.length, [None, dm.buffers[1]], -1, dm.offset)
+    out = amd.compute.filter(nv, nm, "emit_null")
+    assert out.length == len(want)
+    assert_equal(_data_np(out, np.int64), want, "filter without bitmaps but unknown null_count")
+    tk = amd.compute.take(nv, amd.Array(base_i.type, 100, [None, base_i.buffers[1]], -1, 0))
+    assert tk.validity is None and tk.null_count == 0
+    assert_equal(_data_np(tk, np.int64), allv.logical_values()[idx.values[:100]], "take without bitmaps")

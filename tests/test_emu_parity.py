@@ -373,3 +373,7 @@ def test_sort_msd_hybrid_path(emu_ctx, global_bits):
         lib.arx_set_option(b"sort_msd", -1)
         lib.arx_set_option(b"sort_msd_global_bits", 14)
         lib.arx_set_option(b"sort_msd_segment_rows", 1 << 28)
+
+
+def test_null_count_bookkeeping(emu_ctx):
+    P.check_null_count_bookkeeping(emu_ctx, rng_for("nullcount"))
