@@ -155,7 +155,6 @@ __global__ __launch_bounds__(kBlock) void groupby_export_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int64_t nslots = v.capacity + 1;
   const int64_t s0 = static_cast<int64_t>(blockIdx.x) * kExportSlotsPerBlock;
   unsigned long long tagged[16];
   uint32_t mine = 0;
@@ -195,7 +194,6 @@ __global__ __launch_bounds__(kBlock) void groupby_export_kernel(
     out_no_nulls[pos] = (v.flags[sl] & 1u) ? 0 : 1;
     ++pos;
   }
-  (void)nslots;
 }
 
 __global__ __launch_bounds__(kBlock) void groupby_finalize_kernel(const int64_t* __restrict__ counts,

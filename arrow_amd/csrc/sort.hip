@@ -649,16 +649,6 @@ __global__ __launch_bounds__(kMsdThreads) void msd_local_kernel(MsdArgs a) {
   }
 }
 
-__device__ __forceinline__ int wave_inclusive_scan_max_i32(int v) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int n = __shfl_up(v, d, 64);
-    if (lane >= d) v = v > n ? v : n;
-  }
-  return v;
-}
-
 struct __attribute__((aligned(16))) MsdFinalLds {
   uint64_t keys[kMsdWindow];
   uint32_t idx[kMsdWindow];

@@ -3,7 +3,7 @@
 # a known byte count: selectivity 1.0 touches every value line exactly once).
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/${RUN_TAG:-run6}
+OUT=gpurun_out/${RUN_TAG:-record}
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== headline bench"
