@@ -17,6 +17,8 @@
 // drop-in, but bandwidth-bound by the link, not by HBM.  Device-resident ExecBatches
 // (a kROCM arrow::Device/MemoryManager/Buffer, cpp/src/arrow/device.h:43-280) are row (f1) of
 // SURVEY.md section 8 and are what bench.py measures through arrow_amd.compute.
+#include <arrow/acero/exec_plan.h>
+#include <arrow/acero/options.h>
 #include <arrow/api.h>
 #include <arrow/c/abi.h>
 #include <arrow/c/bridge.h>
@@ -26,7 +28,10 @@
 #include <arrow/compute/registry.h>
 #include <arrow/device.h>
 #include <arrow/util/bit_util.h>
+#include <arrow/util/bitmap_builders.h>
 #include <arrow/util/bitmap_ops.h>
+#include <arrow/acero/util.h>
+#include <arrow/acero/query_context.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -1062,6 +1067,237 @@ Status HashSumFinalize(cp::KernelContext* ctx, arrow::Datum* out) {
   return Status::OK();
 }
 
+// ---------------------------------------------------------------- Acero: fused group-by node
+// Whole-operator replacement: an ExecNode registered with
+// default_exec_factory_registry()->AddFactory("aggregate_rocm", ...) (acero/exec_plan.h:353-373;
+// names must be new, exec_plan.cc:1132-1142) that takes the place of GroupByNode
+// (acero/groupby_aggregate_node.cc:210-337) for `hash_sum(int64) GROUP BY int32`: instead of a CPU
+// Grouper feeding dense ids to the aggregate kernel, keys and values go to the fused device
+// operator (arx_groupby_*: hash partition -> LDS tables -> HBM table).  Batches without nulls are
+// appended to device staging buffers and consumed in ONE partitioned pass at InputFinished; a batch
+// with nulls is consumed on arrival.  Output = key column ++ aggregate column like
+// GroupByNode::Finalize (:300-333), row order unspecified (as the reference with threads).
+namespace ac = arrow::acero;
+
+class RocmGroupBySumNode : public ac::ExecNode {
+ public:
+  RocmGroupBySumNode(ac::ExecPlan* plan, std::vector<ac::ExecNode*> inputs,
+                     std::shared_ptr<arrow::Schema> out_schema, int key_idx, int val_idx,
+                     cp::ScalarAggregateOptions options)
+      : ac::ExecNode(plan, std::move(inputs), {"input"}, std::move(out_schema)),
+        key_idx_(key_idx), val_idx_(val_idx), options_(std::move(options)) {}
+
+  ~RocmGroupBySumNode() override {
+    for (void* p : {state_, d_keys_, d_vals_}) {
+      if (p) (void)hipFree(p);
+    }
+  }
+
+  static arrow::Result<ac::ExecNode*> Make(ac::ExecPlan* plan, std::vector<ac::ExecNode*> inputs,
+                                           const ac::ExecNodeOptions& options) {
+    if (inputs.size() != 1) return Status::Invalid("aggregate_rocm takes exactly one input");
+    const auto* opts = dynamic_cast<const ac::AggregateNodeOptions*>(&options);
+    if (opts == nullptr) return Status::TypeError("aggregate_rocm expects AggregateNodeOptions");
+    if (opts->keys.size() != 1 || !opts->segment_keys.empty() || opts->aggregates.size() != 1 ||
+        opts->aggregates[0].function != "hash_sum" || opts->aggregates[0].target.size() != 1) {
+      return Status::NotImplemented("aggregate_rocm: one key, no segment keys, one hash_sum aggregate");
+    }
+    const auto& in_schema = *inputs[0]->output_schema();
+    ARROW_ASSIGN_OR_RAISE(auto kpath, opts->keys[0].FindOne(in_schema));
+    ARROW_ASSIGN_OR_RAISE(auto vpath, opts->aggregates[0].target[0].FindOne(in_schema));
+    if (kpath.indices().size() != 1 || vpath.indices().size() != 1) {
+      return Status::NotImplemented("aggregate_rocm: nested field references");
+    }
+    const int ki = kpath[0], vi = vpath[0];
+    if (in_schema.field(ki)->type()->id() != Type::INT32 || in_schema.field(vi)->type()->id() != Type::INT64) {
+      return Status::NotImplemented("aggregate_rocm: hash_sum(int64) GROUP BY int32 only, got key ",
+                                    in_schema.field(ki)->type()->ToString(), " value ",
+                                    in_schema.field(vi)->type()->ToString());
+    }
+    cp::ScalarAggregateOptions agg_opts;
+    if (opts->aggregates[0].options != nullptr) {
+      const auto* so = dynamic_cast<const cp::ScalarAggregateOptions*>(opts->aggregates[0].options.get());
+      if (so == nullptr) return Status::TypeError("aggregate_rocm: hash_sum takes ScalarAggregateOptions");
+      agg_opts = *so;
+    }
+    auto out_schema = arrow::schema({in_schema.field(ki), arrow::field(opts->aggregates[0].name, arrow::int64())});
+    return plan->EmplaceNode<RocmGroupBySumNode>(plan, std::move(inputs), std::move(out_schema), ki, vi, agg_opts);
+  }
+
+  const char* kind_name() const override { return "RocmGroupBySumNode"; }
+
+  Status InputReceived(ac::ExecNode*, cp::ExecBatch batch) override {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      ARROW_RETURN_NOT_OK(Consume(batch));
+    }
+    if (counter_.Increment()) return Finish();
+    return Status::OK();
+  }
+  Status InputFinished(ac::ExecNode*, int total_batches) override {
+    if (counter_.SetTotal(total_batches)) return Finish();
+    return Status::OK();
+  }
+  Status StartProducing() override { return Status::OK(); }
+  void PauseProducing(ac::ExecNode*, int32_t) override {}
+  void ResumeProducing(ac::ExecNode*, int32_t) override {}
+
+ protected:
+  Status StopProducingImpl() override { return Status::OK(); }
+
+ private:
+  static constexpr int64_t kMaxCapacity = int64_t(1) << 28;
+
+  Status EnsureState(int64_t more_rows) {
+    // capacity: a power of two above twice the distinct keys possible so far
+    const int64_t bound = std::min<int64_t>(kMaxCapacity, 2 * (rows_seen_ + more_rows) + 2);
+    int64_t cap = 1 << 16;
+    while (cap < bound) cap <<= 1;
+    if (state_ != nullptr && cap <= capacity_) return Status::OK();
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    void* fresh = nullptr;
+    HIP_RETURN_NOT_OK(hipMalloc(&fresh, arx_groupby_state_bytes(cap)));
+    ARROW_RETURN_NOT_OK(FromArx(arx_groupby_init(fresh, cap, st)));
+    if (state_ != nullptr) {  // rehash: export the old table's partial aggregates, merge them
+      int64_t g = 0;
+      ARROW_RETURN_NOT_OK(FromArx(arx_groupby_num_groups(state_, &g, st)));
+      if (g > 0) {
+        void *k, *kv, *s, *c, *nn;
+        ARROW_RETURN_NOT_OK(t_scratch.Get(kValues, g * 4 + 16, &k));
+        ARROW_RETURN_NOT_OK(t_scratch.Get(kValidity, g + 16, &kv));
+        ARROW_RETURN_NOT_OK(t_scratch.Get(kArg2, g * 8 + 16, &s));
+        ARROW_RETURN_NOT_OK(t_scratch.Get(kArg2Validity, g * 8 + 16, &c));
+        ARROW_RETURN_NOT_OK(t_scratch.Get(kOutValidity, g + 16, &nn));
+        ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_export(state_, (int32_t*)k, (uint8_t*)kv, (int64_t*)s,
+                                                               (int64_t*)c, (uint8_t*)nn, st)));
+        ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_merge(fresh, cap, (const int32_t*)k, (const uint8_t*)kv,
+                                                              (const int64_t*)s, (const int64_t*)c,
+                                                              (const uint8_t*)nn, g, st)));
+      }
+      HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+      HIP_RETURN_NOT_OK(hipFree(state_));
+    }
+    state_ = fresh;
+    capacity_ = cap;
+    return Status::OK();
+  }
+
+  Status Consume(const cp::ExecBatch& batch) {
+    const int64_t n = batch.length;
+    if (n == 0) return Status::OK();
+    if (!batch[key_idx_].is_array() || !batch[val_idx_].is_array()) {
+      return Status::NotImplemented("aggregate_rocm: scalar columns");
+    }
+    const ArrayData& k = *batch[key_idx_].array();
+    const ArrayData& v = *batch[val_idx_].array();
+    const bool nulls = (k.GetNullCount() != 0) || (v.GetNullCount() != 0);
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    if (!nulls) {
+      // append to the device staging buffers; consumed in one partitioned pass at the end
+      if (staged_ + n > staged_cap_) {
+        const int64_t cap = std::max<int64_t>(2 * staged_cap_, std::max<int64_t>(staged_ + n, 1 << 20));
+        void *nk = nullptr, *nv = nullptr;
+        HIP_RETURN_NOT_OK(hipMalloc(&nk, cap * 4));
+        HIP_RETURN_NOT_OK(hipMalloc(&nv, cap * 8));
+        if (staged_ > 0) {
+          HIP_RETURN_NOT_OK(hipMemcpy(nk, d_keys_, staged_ * 4, hipMemcpyDeviceToDevice));
+          HIP_RETURN_NOT_OK(hipMemcpy(nv, d_vals_, staged_ * 8, hipMemcpyDeviceToDevice));
+        }
+        if (d_keys_) HIP_RETURN_NOT_OK(hipFree(d_keys_));
+        if (d_vals_) HIP_RETURN_NOT_OK(hipFree(d_vals_));
+        d_keys_ = nk;
+        d_vals_ = nv;
+        staged_cap_ = cap;
+      }
+      HIP_RETURN_NOT_OK(hipMemcpy(static_cast<int32_t*>(d_keys_) + staged_, k.GetValues<int32_t>(1), n * 4,
+                                  hipMemcpyHostToDevice));
+      HIP_RETURN_NOT_OK(hipMemcpy(static_cast<int64_t*>(d_vals_) + staged_, v.GetValues<int64_t>(1), n * 8,
+                                  hipMemcpyHostToDevice));
+      staged_ += n;
+      return Status::OK();
+    }
+    ARROW_RETURN_NOT_OK(EnsureState(staged_ + n));
+    ArxSpan dk{}, dv{};
+    ARROW_RETURN_NOT_OK(Upload(ArraySpan(k), 4, kValues, kValidity, st, &dk));
+    ARROW_RETURN_NOT_OK(Upload(ArraySpan(v), 8, kArg2, kArg2Validity, st, &dv));
+    ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_consume(state_, capacity_, &dk, &dv, nullptr, 0, st)));
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    rows_seen_ += n;
+    CountGpu(kFnHashSum);
+    return Status::OK();
+  }
+
+  Status Finish() {
+    std::lock_guard<std::mutex> lock(mu_);
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    ARROW_RETURN_NOT_OK(EnsureState(staged_));
+    if (staged_ > 0) {
+      ArxSpan dk{nullptr, d_keys_, 0, staged_, 0}, dv{nullptr, d_vals_, 0, staged_, 0};
+      const size_t ws_bytes = arx_groupby_consume_workspace_bytes(staged_, capacity_);
+      void* ws = nullptr;
+      if (ws_bytes > 0) {
+        ARROW_RETURN_NOT_OK(t_scratch.Get(kWs, ws_bytes + 256, &ws));
+        ws = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~uintptr_t(255));
+      }
+      ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_consume(state_, capacity_, &dk, &dv, ws, ws_bytes, st)));
+      rows_seen_ += staged_;
+      staged_ = 0;
+      CountGpu(kFnHashSum);
+    }
+    int64_t g = 0;
+    ARROW_RETURN_NOT_OK(FromArx(arx_groupby_num_groups(state_, &g, st)));
+    arrow::MemoryPool* pool = plan_->query_context()->memory_pool();
+    ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> keys, arrow::AllocateBuffer(g * 4, pool));
+    ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> sums, arrow::AllocateBuffer(g * 8, pool));
+    std::vector<uint8_t> key_valid(g), sum_valid(g);
+    if (g > 0) {
+      void *k, *kv, *s, *c, *nn, *ok;
+      ARROW_RETURN_NOT_OK(t_scratch.Get(kValues, g * 4 + 16, &k));
+      ARROW_RETURN_NOT_OK(t_scratch.Get(kValidity, g + 16, &kv));
+      ARROW_RETURN_NOT_OK(t_scratch.Get(kArg2, g * 8 + 16, &s));
+      ARROW_RETURN_NOT_OK(t_scratch.Get(kArg2Validity, g * 8 + 16, &c));
+      ARROW_RETURN_NOT_OK(t_scratch.Get(kOutValidity, g + 16, &nn));
+      ARROW_RETURN_NOT_OK(t_scratch.Get(kOutData, g + 16, &ok));
+      ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_export(state_, (int32_t*)k, (uint8_t*)kv, (int64_t*)s,
+                                                             (int64_t*)c, (uint8_t*)nn, st)));
+      ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_finalize((const int64_t*)c, (const uint8_t*)nn, g,
+                                                               options_.skip_nulls ? 1 : 0, options_.min_count,
+                                                               (uint8_t*)ok, st)));
+      HIP_RETURN_NOT_OK(hipMemcpyAsync(keys->mutable_data(), k, g * 4, hipMemcpyDeviceToHost, st));
+      HIP_RETURN_NOT_OK(hipMemcpyAsync(sums->mutable_data(), s, g * 8, hipMemcpyDeviceToHost, st));
+      HIP_RETURN_NOT_OK(hipMemcpyAsync(key_valid.data(), kv, g, hipMemcpyDeviceToHost, st));
+      HIP_RETURN_NOT_OK(hipMemcpyAsync(sum_valid.data(), ok, g, hipMemcpyDeviceToHost, st));
+      HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    }
+    ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> kbits, arrow::internal::BytesToBits(key_valid, pool));
+    ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> sbits, arrow::internal::BytesToBits(sum_valid, pool));
+    std::vector<std::shared_ptr<Buffer>> kbufs{std::move(kbits), std::move(keys)};
+    std::vector<std::shared_ptr<Buffer>> sbufs{std::move(sbits), std::move(sums)};
+    cp::ExecBatch out({arrow::Datum(ArrayData::Make(arrow::int32(), g, std::move(kbufs))),
+                       arrow::Datum(ArrayData::Make(arrow::int64(), g, std::move(sbufs)))},
+                      g);
+    const int64_t batch_size = 32768;
+    const int nb = static_cast<int>(std::max<int64_t>(1, (g + batch_size - 1) / batch_size));
+    for (int i = 0; i < nb; ++i) {
+      ARROW_RETURN_NOT_OK(output_->InputReceived(this, out.Slice(i * batch_size, batch_size)));
+    }
+    return output_->InputFinished(this, nb);
+  }
+
+  const int key_idx_, val_idx_;
+  const cp::ScalarAggregateOptions options_;
+  std::mutex mu_;
+  ac::AtomicCounter counter_;
+  void* state_ = nullptr;
+  int64_t capacity_ = 0;
+  void* d_keys_ = nullptr;
+  void* d_vals_ = nullptr;
+  int64_t staged_ = 0, staged_cap_ = 0, rows_seen_ = 0;
+};
+
 // ---------------------------------------------------------------- registration
 std::vector<std::shared_ptr<arrow::DataType>> FilterValueTypes() {
   return {arrow::int8(), arrow::uint8(), arrow::int16(), arrow::uint16(), arrow::int32(), arrow::uint32(),
@@ -1160,6 +1396,10 @@ Status RegisterAll() {
     copy.merge = HashSumMerge;
     copy.finalize = HashSumFinalize;
     ARROW_RETURN_NOT_OK(hfn->AddKernel(std::move(copy)));
+  }
+  {
+    const Status st = ac::default_exec_factory_registry()->AddFactory("aggregate_rocm", RocmGroupBySumNode::Make);
+    if (!st.ok() && !st.IsKeyError()) return st;
   }
   return Status::OK();
 }

@@ -17,13 +17,13 @@ def build_plugin(force: bool = False, verbose: bool = True) -> str:
 
     d = os.path.dirname(pa.__file__)
     libs = pa.get_libraries()
-    so = {name: None for name in ("arrow", "arrow_compute")}
+    so = {name: None for name in ("arrow", "arrow_compute", "arrow_acero")}
     for f in sorted(os.listdir(d)):
         for name in so:
             if f.startswith(f"lib{name}.so.") and f.count(".") == 2:
                 so[name] = os.path.join(d, f)
     if not all(so.values()):
-        raise RuntimeError(f"libarrow/libarrow_compute not found in {d} ({libs})")
+        raise RuntimeError(f"libarrow/libarrow_compute/libarrow_acero not found in {d} ({libs})")
     core = os.path.join(HERE, "libarrow_amd.so")
     if not os.path.exists(core):
         raise RuntimeError("build libarrow_amd.so first")
@@ -32,7 +32,7 @@ def build_plugin(force: bool = False, verbose: bool = True) -> str:
         return OUT
     cmd = ["g++", "-std=c++20", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
            "-I", pa.get_include(), "-I", "/opt/rocm/include", SRC, "-o", OUT,
-           so["arrow"], so["arrow_compute"], core, "-L/opt/rocm/lib", "-lamdhip64",
+           so["arrow"], so["arrow_compute"], so["arrow_acero"], core, "-L/opt/rocm/lib", "-lamdhip64",
            f"-Wl,-rpath,{d}", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -171,3 +171,61 @@ def test_device_resident_arrays_through_callfunction():
     code = f"ROOT = {ROOT!r}\n" + DEVICE_SCRIPT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "DEVICE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+ACERO_SCRIPT = textwrap.dedent(r'''
+    import ctypes, sys
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    from pyarrow import acero
+    sys.path.insert(0, ROOT)
+    from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    rng = np.random.default_rng(21)
+
+    def fused(table, opts=None, name="v_sum"):
+        decl = acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(table)),
+            acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_sum", opts, name)], keys=["k"])),
+        ])
+        return decl.to_table()
+
+    def same(got, want):
+        got, want = got.sort_by("k"), want.select(["k", "v_sum"]).sort_by("k")
+        assert got.schema.names == ["k", "v_sum"], got.schema
+        assert got.equals(want), (got.slice(0, 5), want.slice(0, 5))
+
+    n = 3_000_000
+    # no nulls: every batch is staged on the device, one radix-partitioned consume at the end
+    t = pa.table({"x": pa.array(rng.random(n)), "k": pa.array(rng.integers(-70000, 70000, n).astype(np.int32)),
+                  "v": pa.array(rng.integers(-2**63, 2**63 - 1, n))})
+    same(fused(t), t.group_by("k", use_threads=False).aggregate([("v", "sum")]))
+    # nulls in keys and values: consumed batch by batch; options honoured
+    tn = pa.table({"k": pa.array(rng.integers(-300, 300, n).astype(np.int32), mask=rng.random(n) < 0.01),
+                   "v": pa.array(rng.integers(-2**63, 2**63 - 1, n), mask=rng.random(n) < 0.2)})
+    same(fused(tn), tn.group_by("k", use_threads=False).aggregate([("v", "sum")]))
+    o = pc.ScalarAggregateOptions(skip_nulls=False, min_count=3)
+    same(fused(tn, o), tn.group_by("k", use_threads=False).aggregate([("v", "sum", o)]))
+    # mixed: some chunks with nulls, some without, several chunks
+    tm = pa.concat_tables([t.select(["k", "v"]).slice(0, 500_000), tn.slice(0, 400_000), t.select(["k", "v"]).slice(500_000, 700_000)])
+    same(fused(tm), tm.group_by("k", use_threads=False).aggregate([("v", "sum")]))
+    empty = pa.table({"k": pa.array([], pa.int32()), "v": pa.array([], pa.int64())})
+    assert fused(empty).num_rows == 0
+    try:
+        fused(pa.table({"k": pa.array([1.0]), "v": pa.array([1], pa.int64())}))
+        raise SystemExit("expected NotImplemented")
+    except pa.lib.ArrowNotImplementedError:
+        pass
+    print("ACERO_OK")
+''')
+
+
+def test_acero_fused_group_by_node():
+    """SURVEY.md 8(b) "whole-operator replacement": the exec-node factory `aggregate_rocm` drives the
+    fused device group-by from an ordinary Acero plan; results equal Table.group_by's."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + ACERO_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "ACERO_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

@@ -67,6 +67,20 @@ SCRIPT = textwrap.dedent(r'''
                 assert "HIP" in str(e) or "hip" in str(e), str(e)
             else:
                 raise SystemExit("a HIP-path call succeeded without a GPU")
+    # the Acero factory of the fused group-by is registered under a NEW name (duplicates are
+    # rejected, acero/exec_plan.cc:1132-1142); without a device running it must fail loudly
+    from pyarrow import acero
+    tab = pa.table({"k": pa.array([1, 2, 1], pa.int32()), "v": pa.array([1, 2, 3], pa.int64())})
+    decl = acero.Declaration.from_sequence([
+        acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
+        acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"]))])
+    if not torch.cuda.is_available():
+        try:
+            decl.to_table()
+        except (OSError, pa.ArrowException) as e:
+            assert "HIP" in str(e) or "hip" in str(e), str(e)
+        else:
+            raise SystemExit("aggregate_rocm ran without a GPU")
     print("REGISTRATION_OK")
 ''')
 
