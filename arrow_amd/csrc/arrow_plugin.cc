@@ -364,6 +364,7 @@ struct ShimState : public cp::KernelState {
 struct StockKernel {
   cp::KernelInit init;
   cp::ArrayKernelExec exec = nullptr;
+  cp::VectorKernel::ChunkedExec exec_chunked = nullptr;
 };
 
 // run the stock exec with the stock state installed
@@ -816,11 +817,73 @@ Status SortExecImpl(const StockKernel& stock, bool is_signed, cp::KernelContext*
   CountGpu(kFnSort);
   return Status::OK();
 }
+// The registered kernels are MemAllocation::NO_PREALLOCATE twins (the stock ones preallocate the
+// uint64 output from the CPU pool, vector_array_sort.cc:656-657): device-resident input sorts in
+// HBM and the indices stay there; host input gets the buffer the executor would have preallocated
+// and runs the preallocated-style exec above.
+Status SortExecNP(const StockKernel& stock, bool is_signed, cp::KernelContext* ctx, const cp::ExecSpan& batch,
+                  cp::ExecResult* out) {
+  const ArraySpan& values = batch[0].array;
+  const int64_t n = values.length;
+  ArrayData* out_arr = out->array_data().get();
+  out_arr->buffers.resize(2);
+  out_arr->buffers[0] = nullptr;
+  out_arr->length = n;
+  out_arr->null_count = 0;
+  if (OnRocm(values)) {
+    auto* state = static_cast<ShimState<cp::ArraySortOptions>*>(ctx->state());
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    ArxSpan dv{};
+    ARROW_RETURN_NOT_OK(DeviceSpan(values, &dv));
+    const size_t ws_bytes = arx_sort_indices_workspace_bytes(n);
+    void* ws = nullptr;
+    ARROW_RETURN_NOT_OK(t_scratch.Get(kWs, ws_bytes, &ws));
+    ARROW_ASSIGN_OR_RAISE(out_arr->buffers[1], AllocDevice(n * 8));
+    const int order = state->options.order == cp::SortOrder::Descending ? ARX_SORT_DESCENDING : ARX_SORT_ASCENDING;
+    const int placement = state->options.null_placement == cp::NullPlacement::AtStart ? ARX_NULLS_AT_START
+                                                                                      : ARX_NULLS_AT_END;
+    ARROW_RETURN_NOT_OK(FromArx(arx_sort_indices_64(&dv, is_signed ? 1 : 0, order, placement, ws, ws_bytes,
+                                                    reinterpret_cast<uint64_t*>(out_arr->buffers[1]->mutable_address()),
+                                                    st)));
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    CountGpu(kFnSort);
+    return Status::OK();
+  }
+  ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> data, ctx->Allocate(n * 8));
+  // the VectorExecutor hands vector kernels an ArrayData (exec.cc:1103-1111): same shape here
+  cp::ExecResult tmp;
+  tmp.value = ArrayData::Make(out_arr->type, n, {nullptr, data}, /*null_count=*/0);
+  ARROW_RETURN_NOT_OK(SortExecImpl(stock, is_signed, ctx, batch, &tmp));
+  out_arr->buffers[1] = std::move(data);
+  return Status::OK();
+}
+// Chunked input goes to the stock exec_chunked (ArraySortIndicesChunked), which expects the
+// preallocated output our NO_PREALLOCATE twin no longer gets from the executor: allocate it here.
+Status SortChunkedNP(const StockKernel& stock, cp::KernelContext* ctx, const cp::ExecBatch& batch, arrow::Datum* out) {
+  auto* state = static_cast<ShimState<cp::ArraySortOptions>*>(ctx->state());
+  ArrayData* out_arr = out->mutable_array();
+  out_arr->buffers.resize(2);
+  out_arr->buffers[0] = nullptr;
+  ARROW_ASSIGN_OR_RAISE(out_arr->buffers[1], ctx->Allocate(batch.length * 8));
+  out_arr->null_count = 0;
+  CountStock(kFnSort);
+  ctx->SetState(state->stock.get());
+  const Status st = stock.exec_chunked(ctx, batch, out);
+  ctx->SetState(state);
+  return st;
+}
+Status SortChunkedU64(cp::KernelContext* c, const cp::ExecBatch& b, arrow::Datum* o) {
+  return SortChunkedNP(g_stock_sort_u64, c, b, o);
+}
+Status SortChunkedI64(cp::KernelContext* c, const cp::ExecBatch& b, arrow::Datum* o) {
+  return SortChunkedNP(g_stock_sort_i64, c, b, o);
+}
 Status SortExecU64(cp::KernelContext* c, const cp::ExecSpan& b, cp::ExecResult* o) {
-  return SortExecImpl(g_stock_sort_u64, false, c, b, o);
+  return SortExecNP(g_stock_sort_u64, false, c, b, o);
 }
 Status SortExecI64(cp::KernelContext* c, const cp::ExecSpan& b, cp::ExecResult* o) {
-  return SortExecImpl(g_stock_sort_i64, true, c, b, o);
+  return SortExecNP(g_stock_sort_i64, true, c, b, o);
 }
 
 // ---------------------------------------------------------------- cast(float64 -> float32)
@@ -1324,6 +1387,7 @@ Status RegisterVector(cp::FunctionRegistry* reg, const std::string& name,
     if (stock->exec == nullptr) {
       stock->exec = copy.exec;
       stock->init = copy.init;
+      stock->exec_chunked = copy.exec_chunked;
     } else if (stock->exec != copy.exec) {
       continue;  // a different stock kernel handles this type: leave it alone
     }
@@ -1331,6 +1395,10 @@ Status RegisterVector(cp::FunctionRegistry* reg, const std::string& name,
     copy.signature = cp::KernelSignature::Make(in, copy.signature->out_type());
     copy.init = init;
     copy.exec = exec;
+    if (name == "array_sort_indices") {
+      copy.mem_allocation = cp::MemAllocation::NO_PREALLOCATE;
+      if (copy.exec_chunked != nullptr) copy.exec_chunked = (stock == &g_stock_sort_u64) ? SortChunkedU64 : SortChunkedI64;
+    }
     ARROW_RETURN_NOT_OK(vfn->AddKernel(std::move(copy)));
   }
   return Status::OK();

@@ -149,6 +149,13 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
     sel = to_host(pc.filter(d_vals, pc.greater(d_f64, d_f64b)))
     assert sel.equals(pc.filter(vals, pc.greater(f64, f64b)))
     assert lib.arrow_amd_plugin_calls(b"greater", 1) >= 5
+    # sort on the device: uint64 indices stay in HBM and feed take
+    skeys = pa.array(rng.integers(0, 2**63, n).astype(np.uint64), mask=rng.random(n) < 0.03)
+    d_skeys = to_device(skeys)
+    d_perm = pc.array_sort_indices(d_skeys, order="descending", null_placement="at_start")
+    assert not d_perm.is_cpu
+    assert to_host(d_perm).equals(pc.array_sort_indices(skeys, order="descending", null_placement="at_start"))
+    assert to_host(pc.take(d_skeys, d_perm)).equals(pc.take(skeys, pc.array_sort_indices(skeys, order="descending", null_placement="at_start")))
     # a chain that never leaves the device: filter -> cast
     chain = to_host(pc.cast(pc.filter(d_f64, d_mask), pa.float32()))
     assert chain.equals(pc.cast(pc.filter(f64, mask), pa.float32()))

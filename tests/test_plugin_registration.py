@@ -34,6 +34,10 @@ SCRIPT = textwrap.dedent(r'''
               pa.table({"x": fn, "y": g}).filter(pc.field("x") > pc.field("y")).column("x").combine_chunks()]
         return gt + [pc.filter(a, m), pc.take(a, pa.array([5, 1, 999])), pc.greater(f, pa.array(f.to_numpy()[::-1].copy())),
                 pc.array_sort_indices(pa.array(np.arange(1000)[::-1].astype(np.uint64))),
+                pc.array_sort_indices(pa.array((np.arange(1000) % 13).astype(np.int64), mask=np.arange(1000) % 9 == 0),
+                                      order="descending", null_placement="at_start"),
+                pc.sort_indices(pa.table({"a": pa.array((np.arange(1000) % 7).astype(np.uint64))}), sort_keys=[("a", "descending")]),
+                pc.array_sort_indices(pa.chunked_array([pa.array(np.arange(10, dtype=np.uint64)), pa.array(np.arange(5, dtype=np.uint64))])),
                 pc.cast(f, pa.float32(), safe=False), pc.cast(f.slice(3), pa.int64(), safe=False)]
     before = pc.get_function("array_filter").num_kernels
     stock = run()
