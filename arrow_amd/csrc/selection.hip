@@ -563,7 +563,8 @@ struct __attribute__((aligned(16))) SparseLds {
   uint64_t zw[kWavesPerBlock][64];              // rows emitted only because the mask slot is null
 };
 
-template <int W, bool EMIT>
+// IOTA: emit row numbers instead of gathered values (GetTakeIndices)
+template <int W, bool EMIT, bool IOTA>
 __global__ __launch_bounds__(kBlock) void compact_sparse_kernel(CompactArgs a) {
   using E = typename ElemT<W>::type;
   constexpr int U = 4;  // gather steps in flight
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(kBlock) void compact_sparse_kernel(CompactArgs a) {
   if (want_validity) lds.vs[wave][lane] = load_word(a.vvalid, w) & mv;
   if constexpr (EMIT) lds.zw[wave][lane] = Ew & ~mv;
 
-  const E* __restrict__ values = reinterpret_cast<const E*>(a.values) + t * kTileRows;
+  const E* __restrict__ values = IOTA ? nullptr : reinterpret_cast<const E*>(a.values) + t * kTileRows;
   E* __restrict__ out = reinterpret_cast<E*>(a.out_data);
   const int head = static_cast<int>(off & 63);  // the first step starts `head` bits into a word
   const int nsteps = (head + total + 63) >> 6;
@@ -631,7 +632,13 @@ __global__ __launch_bounds__(kBlock) void compact_sparse_kernel(CompactArgs a) {
         r[u] = sel[(act[u] ? s[u] : first_listed) - win_lo];
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = values[r[u]];
+      for (int u = 0; u < U; ++u) {
+        if constexpr (IOTA) {
+          if constexpr (W <= 8) v[u] = static_cast<E>(t * kTileRows + r[u]);
+        } else {
+          v[u] = values[r[u]];
+        }
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if ((i0 + u) >= step_end) break;  // wave-uniform
@@ -876,12 +883,12 @@ static void launch_compact_w(const CompactArgs& a, unsigned grid, hipStream_t st
   }
 }
 
-template <int W>
+template <int W, bool IOTA = false>
 static void launch_sparse_w(const CompactArgs& a, unsigned grid, hipStream_t st) {
   if (a.emit_null) {
-    hipLaunchKernelGGL((compact_sparse_kernel<W, true>), dim3(grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((compact_sparse_kernel<W, true, IOTA>), dim3(grid), dim3(kBlock), 0, st, a);
   } else {
-    hipLaunchKernelGGL((compact_sparse_kernel<W, false>), dim3(grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((compact_sparse_kernel<W, false, IOTA>), dim3(grid), dim3(kBlock), 0, st, a);
   }
 }
 
@@ -897,6 +904,14 @@ static int launch_compact(bool iota, int W, const CompactArgs& a, hipStream_t st
                       (g_filter_sparse == 1 ||
                        (g_filter_sparse < 0 &&
                         (W >= 8 || (out_length >= 0 && out_length * 4 <= a.length))));
+  // GetTakeIndices: the gather form (row numbers instead of gathered values) unless the bitmap is
+  // being inverted for the sort's null partition
+  if (iota && !a.invert && g_filter_sparse != 0 && (W == 2 || W == 4)) {
+    if (W == 2) launch_sparse_w<2, true>(a, grid, st);
+    else launch_sparse_w<4, true>(a, grid, st);
+    ARX_CHECK_LAUNCH("compact_sparse_kernel<IOTA>");
+    return ARX_OK;
+  }
   if (sparse) {
     switch (W) {
       case 1: launch_sparse_w<1>(a, grid, st); break;
