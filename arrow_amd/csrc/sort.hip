@@ -32,7 +32,8 @@ constexpr int kDigits = 256;
 constexpr int kMaxChunks = 16384;  // upper bound (sizes the histogram table)
 static int g_sort_msd = -1;            // -1 = auto (n >= g_sort_msd_min_rows), 0 = never, 1 = whenever possible
 static int g_sort_msd_min_rows = 1 << 22;
-static int64_t g_sort_msd_segment_rows = int64_t(1) << 28;  // above this: an extra top-bits level cuts segments
+static int g_sort_msd_fused = 1;       // finish LDS-sized level-2 buckets in one workgroup (msd_bucket_kernel)
+static int64_t g_sort_msd_segment_rows = int64_t(1) << 27;  // above this: an extra top-bits level cuts segments
 static int g_sort_msd_global_bits = 14;  // (= kMsdMaxBits) cap of the two global levels (tests lower it to reach level 3)
 static int g_sort_fuse_prep = 1;    // first pass reads the caller's column directly (no prep pass)
 static int g_sort_chunks = 2048;    // chunks actually used (arx_set_option "sort_chunks")
@@ -725,6 +726,111 @@ __global__ __launch_bounds__(256) void msd_final_kernel(MsdArgs a, const uint64_
   if (__any(bad) && lane == 0) atomicOr(a.overflow, 1u);
 }
 
+// M5+M6 fused, for level-2 buckets that fit LDS (<= kBktCap rows, i.e. inputs / segments up to 2^27
+// rows): one workgroup loads its bucket into registers, partitions it by the next b3 (<= 10) bits
+// straight into LDS (count -> scan -> LDS-atomic cursors), then every row counts the members of its
+// sub-bucket with a smaller (key, row id) and writes its row id at that position of the output.
+// No level-3 round trip through HBM, no halo re-reads: 12 B/row in, 8 B/row out.
+constexpr int kBktThreads = 1024;
+constexpr int kBktRows = 10;                       // per thread
+constexpr int kBktCap = kBktThreads * kBktRows;    // 10240 rows = 120 KiB of LDS
+constexpr int kBktMaxBins = 1024;
+
+struct __attribute__((aligned(16))) MsdBucketLds {
+  uint64_t keys[kBktCap];
+  uint32_t idx[kBktCap];
+  uint32_t cnt[kBktMaxBins];     // counts, then running cursors
+  uint32_t start[kBktMaxBins + 1];
+  uint32_t wave_tot[kBktThreads / 64];
+};
+
+__global__ __launch_bounds__(kBktThreads) void msd_bucket_kernel(MsdArgs a, const uint64_t* __restrict__ keys,
+                                                                 const uint32_t* __restrict__ idx) {
+  __shared__ MsdBucketLds w;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t q = blockIdx.x;
+  const int64_t lo = a.part_start[q];
+  const int m = static_cast<int>(static_cast<int64_t>(a.part_start[q + 1]) - lo);
+  if (m == 0) return;  // workgroup-uniform
+  if (m > kBktCap) {
+    if (tid == 0) atomicOr(a.overflow, 2u);
+    return;
+  }
+  const int nb = 1 << a.b3;
+  const int dshift = 64 - a.bits - a.b3;
+  const uint32_t dmask = static_cast<uint32_t>(nb - 1);
+  for (int i = tid; i < nb; i += kBktThreads) w.cnt[i] = 0;
+  __syncthreads();
+  uint64_t key[kBktRows];
+  uint32_t id[kBktRows];
+  int dig[kBktRows];
+#pragma unroll
+  for (int i = 0; i < kBktRows; ++i) {
+    const int p = i * kBktThreads + tid;
+    dig[i] = -1;
+    key[i] = 0;
+    id[i] = 0;
+    if (p < m) {
+      key[i] = keys[lo + p];
+      id[i] = idx[lo + p];
+      dig[i] = a.b3 == 0 ? 0 : static_cast<int>(static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kBktRows; ++i) {
+    if (dig[i] >= 0) atomicAdd(&w.cnt[dig[i]], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of nb <= 1024 counters: one per thread
+  uint32_t c = tid < nb ? w.cnt[tid] : 0u;
+  const uint32_t incl = wave_inclusive_scan_u32(c);
+  if (lane == 63) w.wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t pre = incl - c;
+  for (int k = 0; k < wave; ++k) pre += w.wave_tot[k];
+  if (tid < nb) {
+    w.start[tid] = pre;
+    w.cnt[tid] = pre;  // running cursor
+  }
+  if (tid == 0) w.start[nb] = static_cast<uint32_t>(m);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kBktRows; ++i) {
+    if (dig[i] >= 0) {
+      const uint32_t pos = atomicAdd(&w.cnt[dig[i]], 1u);
+      w.keys[pos] = key[i];
+      w.idx[pos] = id[i];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < m; i += kBktThreads) {
+    const uint64_t ki = w.keys[i];
+    const uint32_t ii = w.idx[i];
+    const uint32_t d = a.b3 == 0 ? 0u : (static_cast<uint32_t>((ki << a.kshift) >> dshift) & dmask);
+    const int bs = static_cast<int>(w.start[d]);
+    const int be = static_cast<int>(w.start[d + 1]);
+    int rank = 0;
+    for (int j = bs; j < be; j += 4) {
+      uint64_t kj[4];
+      uint32_t ij[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int jj = (j + u) < be ? (j + u) : (be - 1);
+        kj[u] = w.keys[jj];
+        ij[u] = w.idx[jj];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool less = kj[u] < ki || (kj[u] == ki && ij[u] < ii);
+        rank += (less && (j + u) < be) ? 1 : 0;
+      }
+    }
+    a.out_final[lo + bs + rank] = ii;
+  }
+}
+
 // part_count + part_start + cursor2 (2^14 + 1 each), hist1 (128 x 2048), l1_start, l2_tile_start, flag
 constexpr size_t kMsdTableBytes = (3 * ((size_t(1) << kMsdMaxBits) + 64) + size_t(128) * kMsdMaxChunks + 2 * 192 + 64) * 4;
 
@@ -762,6 +868,10 @@ static SortPlan make_plan(int64_t length) {
 int set_sort_option(const char* name, int64_t value) {
   if (strcmp(name, "sort_msd") == 0) {
     g_sort_msd = value < 0 ? -1 : (value != 0);
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_fused") == 0) {
+    g_sort_msd_fused = value != 0;
     return 1;
   }
   if (strcmp(name, "sort_msd_segment_rows") == 0) {
@@ -850,17 +960,26 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   const unsigned grid2 = static_cast<unsigned>(ceil_div(n, kMsdTile) + (int64_t(1) << a.b1));
   hipLaunchKernelGGL(msd_scatter2_kernel, dim3(grid2), dim3(kMsdThreads), 0, st, a);
   ARX_CHECK_LAUNCH("msd_scatter2_kernel");
-  const uint64_t* fk = keys_y;
-  const uint32_t* fi = idx_y;
-  if (a.b3 > 0) {
-    hipLaunchKernelGGL(msd_local_kernel, dim3(static_cast<unsigned>(nparts)), dim3(kMsdThreads), 0, st, a);
-    ARX_CHECK_LAUNCH("msd_local_kernel");
-    fk = keys_x;
-    fi = idx_x;
+  // level-2 buckets that fit LDS: finish each one in a single workgroup (b3 may use 10 bits there)
+  const bool fused = g_sort_msd_fused != 0 && (n >> a.bits) <= 8192;
+  if (fused) {
+    a.b3 = std::max(0, std::min(std::min(lg - 3 - a.bits, 10), 64 - kshift - a.bits));  // ~8 rows per sub-bucket
+    hipLaunchKernelGGL(msd_bucket_kernel, dim3(static_cast<unsigned>(nparts)), dim3(kBktThreads), 0, st, a, keys_y,
+                       idx_y);
+    ARX_CHECK_LAUNCH("msd_bucket_kernel");
+  } else {
+    const uint64_t* fk = keys_y;
+    const uint32_t* fi = idx_y;
+    if (a.b3 > 0) {
+      hipLaunchKernelGGL(msd_local_kernel, dim3(static_cast<unsigned>(nparts)), dim3(kMsdThreads), 0, st, a);
+      ARX_CHECK_LAUNCH("msd_local_kernel");
+      fk = keys_x;
+      fi = idx_x;
+    }
+    hipLaunchKernelGGL(msd_final_kernel, dim3(static_cast<unsigned>(ceil_div(n, kMsdCore))), dim3(256), 0, st, a,
+                       fk, fi, 64 - (a.bits + a.b3));
+    ARX_CHECK_LAUNCH("msd_final_kernel");
   }
-  hipLaunchKernelGGL(msd_final_kernel, dim3(static_cast<unsigned>(ceil_div(n, kMsdCore))), dim3(256), 0, st, a,
-                     fk, fi, 64 - (a.bits + a.b3));
-  ARX_CHECK_LAUNCH("msd_final_kernel");
   unsigned int flag = 0;
   ARX_HIP(hipMemcpyAsync(&flag, a.overflow, 4, hipMemcpyDeviceToHost, st));
   ARX_HIP(hipStreamSynchronize(st));

@@ -345,23 +345,24 @@ def test_groupby_partitioned_path(emu_ctx, bits):
         lib.arx_set_option(b"groupby_partition_bits", -1)
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("global_bits", [14, 4, -14])
-def test_sort_msd_hybrid_path(emu_ctx, global_bits):
+def test_sort_msd_hybrid_path(emu_ctx, global_bits, fused):
     """The MSD-hybrid sort forced on (two global levels [+ the in-bucket level when the global
     bits are capped] + the windowed final ranking): full-range keys, heavy ties (bucket overflow ->
     LSD fallback), nulls (prep + MSD), descending, signed."""
     lib = emu_ctx._lib.get_lib()
     assert lib.arx_set_option(b"sort_msd", 1) == 0
+    assert lib.arx_set_option(b"sort_msd_fused", fused) == 0   # 1: LDS-resident bucket finish; 0: local + windowed final
     if global_bits < 0:   # the segmented form: an extra level on the top bits, then one pipeline per segment
         global_bits = -global_bits
         assert lib.arx_set_option(b"sort_msd_segment_rows", 4096) == 0
     assert lib.arx_set_option(b"sort_msd_global_bits", global_bits) == 0
     try:
-        n = 30000
-        rng = rng_for("msd", global_bits)
+        n = 14000   # (the emulator runs every workgroup as fibers on one core)
+        rng = rng_for("msd", global_bits, fused)
         for dtype, order, placement, null_p in ((np.uint64, "ascending", "at_end", 0.0),
-                                               (np.int64, "descending", "at_start", 0.03),
-                                               (np.uint64, "descending", "at_end", 0.0)):
+                                               (np.int64, "descending", "at_start", 0.03)):
             a = U.random_array(rng, dtype, n, null_p=null_p, offset=3)
             a.values[a.offset:a.offset + n - 1:5] = a.values[a.offset + 1:a.offset + n:5]  # ties
             P.check_sort_indices(emu_ctx, a, order, placement, use_pyarrow=(dtype == np.int64))
@@ -372,7 +373,8 @@ def test_sort_msd_hybrid_path(emu_ctx, global_bits):
     finally:
         lib.arx_set_option(b"sort_msd", -1)
         lib.arx_set_option(b"sort_msd_global_bits", 14)
-        lib.arx_set_option(b"sort_msd_segment_rows", 1 << 28)
+        lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
+        lib.arx_set_option(b"sort_msd_fused", 1)
 
 
 def test_null_count_bookkeeping(emu_ctx):
