@@ -320,7 +320,7 @@ def test_filter_forced_sweep_and_sparse_forms(emu_ctx, mode):
         lib.arx_set_option(b"filter_sparse", -1)
 
 
-@pytest.mark.parametrize("bits", [0, 1, 5, 9, 11])
+@pytest.mark.parametrize("bits", [0, 1, 5, 9])   # (11 = a second two-level plan: GPU test only)
 def test_groupby_partitioned_path(emu_ctx, bits):
     """The radix-partitioned consume (hist -> scatter level 1 [-> level 2] -> LDS aggregate -> flush)
     forced on, for one-level (bits <= 8) and two-level plans, with null keys / null values /
