@@ -84,8 +84,9 @@ const char* arx_last_error(void);
 int arx_abi_version(void);
 /* Number of HIP devices visible, or a negative ArxStatus. */
 int arx_device_count(void);
-/* Process-wide tuning knobs for A/B measurements (e.g. "filter_batch", "filter_pipe").
- * Never changes results.  Not part of the reference interface. */
+/* Process-wide tuning knobs for A/B measurements ("filter_sparse", "groupby_partition_bits",
+ * "sort_msd", ...; the list is in DESIGN.md 4.8).  Never changes results.  Not part of the
+ * reference interface. */
 int arx_set_option(const char* name, int64_t value);
 
 /* ---------------------------------------------------------------------------
