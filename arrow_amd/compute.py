@@ -293,6 +293,10 @@ def _exec_add(args, options):
     return Array(left.type, n, [validity, out], nc, 0)
 
 
+# ARX_KEY_* of include/arrow_amd.h
+_SORT_KEY_TYPE = {"uint64": 0, "int64": 1, "uint32": 2, "int32": 3, "double": 4, "float": 5}
+
+
 def _exec_array_sort_indices(args, options):
     """ArraySortIndices::Exec (vector_array_sort.cc:524-540): uint64 indices, never null."""
     (arr,) = args
@@ -306,7 +310,7 @@ def _exec_array_sort_indices(args, options):
     aligned = (base + 255) & ~255
     out = alloc(n * 8, dev)
     span = arr.span()
-    check(lib.arx_sort_indices_64(C.byref(span), int(arr.type == int64),
+    check(lib.arx_sort_indices(C.byref(span), _SORT_KEY_TYPE[arr.type.name],
                                   _lib.SORT_DESCENDING if options.order == "descending" else _lib.SORT_ASCENDING,
                                   _lib.NULLS_AT_START if options.null_placement == "at_start" else _lib.NULLS_AT_END,
                                   aligned, ws.numel() - (aligned - base), out.data_ptr(), stream))
@@ -623,8 +627,8 @@ def _build_registry() -> FunctionRegistry:
     reg.add_function(f)
 
     f = Function("array_sort_indices", Function.VECTOR, 1, ArraySortOptions())
-    f.add_kernel(Kernel((uint64,), _exec_array_sort_indices, uint64))
-    f.add_kernel(Kernel((int64,), _exec_array_sort_indices, uint64))
+    for key_type in (uint64, int64, uint32, int32, float64, float32):
+        f.add_kernel(Kernel((key_type,), _exec_array_sort_indices, uint64))
     reg.add_function(f)
     reg.add_function(Function("sort_indices", Function.META, 1, SortOptions(), _sort_indices_meta))
 

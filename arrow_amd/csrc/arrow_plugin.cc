@@ -765,7 +765,7 @@ Status GreaterExecNP(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::Exec
 }
 
 // ---------------------------------------------------------------- array_sort_indices(uint64|int64)
-StockKernel g_stock_sort_u64, g_stock_sort_i64;
+StockKernel g_stock_sort[6];  // indexed by ARX_KEY_* (uint64, int64, uint32, int32, float64, float32)
 
 arrow::Result<std::unique_ptr<cp::KernelState>> SortInitImpl(const StockKernel& stock,
                                                              cp::KernelContext* ctx,
@@ -777,15 +777,13 @@ arrow::Result<std::unique_ptr<cp::KernelState>> SortInitImpl(const StockKernel& 
   if (args.options != nullptr) state->options = *static_cast<const cp::ArraySortOptions*>(args.options);
   return state;
 }
-arrow::Result<std::unique_ptr<cp::KernelState>> SortInitU64(cp::KernelContext* c, const cp::KernelInitArgs& a) {
-  return SortInitImpl(g_stock_sort_u64, c, a);
-}
-arrow::Result<std::unique_ptr<cp::KernelState>> SortInitI64(cp::KernelContext* c, const cp::KernelInitArgs& a) {
-  return SortInitImpl(g_stock_sort_i64, c, a);
+template <int K>
+arrow::Result<std::unique_ptr<cp::KernelState>> SortInitT(cp::KernelContext* c, const cp::KernelInitArgs& a) {
+  return SortInitImpl(g_stock_sort[K], c, a);
 }
 
 // ArraySortIndices::Exec (vector_array_sort.cc:524-540): output uint64 is preallocated.
-Status SortExecImpl(const StockKernel& stock, bool is_signed, cp::KernelContext* ctx,
+Status SortExecImpl(const StockKernel& stock, int key_type, cp::KernelContext* ctx,
                     const cp::ExecSpan& batch, cp::ExecResult* out) {
   auto* state = static_cast<ShimState<cp::ArraySortOptions>*>(ctx->state());
   const ArraySpan& values = batch[0].array;
@@ -795,7 +793,8 @@ Status SortExecImpl(const StockKernel& stock, bool is_signed, cp::KernelContext*
   hipStream_t st;
   ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
   ArxSpan dv{};
-  ARROW_RETURN_NOT_OK(Upload(values, 8, kValues, kValidity, st, &dv));
+  const int key_width = (key_type == ARX_KEY_UINT32 || key_type == ARX_KEY_INT32 || key_type == ARX_KEY_FLOAT32) ? 4 : 8;
+  ARROW_RETURN_NOT_OK(Upload(values, key_width, kValues, kValidity, st, &dv));
   const int64_t n = values.length;
   const size_t ws_bytes = arx_sort_indices_workspace_bytes(n);
   void *ws = nullptr, *dout = nullptr;
@@ -804,7 +803,7 @@ Status SortExecImpl(const StockKernel& stock, bool is_signed, cp::KernelContext*
   const int order = state->options.order == cp::SortOrder::Descending ? ARX_SORT_DESCENDING : ARX_SORT_ASCENDING;
   const int placement = state->options.null_placement == cp::NullPlacement::AtStart ? ARX_NULLS_AT_START
                                                                                     : ARX_NULLS_AT_END;
-  ARROW_RETURN_NOT_OK(FromArx(arx_sort_indices_64(&dv, is_signed ? 1 : 0, order, placement, ws, ws_bytes,
+  ARROW_RETURN_NOT_OK(FromArx(arx_sort_indices(&dv, key_type, order, placement, ws, ws_bytes,
                                                   static_cast<uint64_t*>(dout), st)));
   uint64_t* host_out = nullptr;
   if (out->is_array_span()) {
@@ -821,7 +820,7 @@ Status SortExecImpl(const StockKernel& stock, bool is_signed, cp::KernelContext*
 // uint64 output from the CPU pool, vector_array_sort.cc:656-657): device-resident input sorts in
 // HBM and the indices stay there; host input gets the buffer the executor would have preallocated
 // and runs the preallocated-style exec above.
-Status SortExecNP(const StockKernel& stock, bool is_signed, cp::KernelContext* ctx, const cp::ExecSpan& batch,
+Status SortExecNP(const StockKernel& stock, int key_type, cp::KernelContext* ctx, const cp::ExecSpan& batch,
                   cp::ExecResult* out) {
   const ArraySpan& values = batch[0].array;
   const int64_t n = values.length;
@@ -843,7 +842,7 @@ Status SortExecNP(const StockKernel& stock, bool is_signed, cp::KernelContext* c
     const int order = state->options.order == cp::SortOrder::Descending ? ARX_SORT_DESCENDING : ARX_SORT_ASCENDING;
     const int placement = state->options.null_placement == cp::NullPlacement::AtStart ? ARX_NULLS_AT_START
                                                                                       : ARX_NULLS_AT_END;
-    ARROW_RETURN_NOT_OK(FromArx(arx_sort_indices_64(&dv, is_signed ? 1 : 0, order, placement, ws, ws_bytes,
+    ARROW_RETURN_NOT_OK(FromArx(arx_sort_indices(&dv, key_type, order, placement, ws, ws_bytes,
                                                     reinterpret_cast<uint64_t*>(out_arr->buffers[1]->mutable_address()),
                                                     st)));
     HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
@@ -854,7 +853,7 @@ Status SortExecNP(const StockKernel& stock, bool is_signed, cp::KernelContext* c
   // the VectorExecutor hands vector kernels an ArrayData (exec.cc:1103-1111): same shape here
   cp::ExecResult tmp;
   tmp.value = ArrayData::Make(out_arr->type, n, {nullptr, data}, /*null_count=*/0);
-  ARROW_RETURN_NOT_OK(SortExecImpl(stock, is_signed, ctx, batch, &tmp));
+  ARROW_RETURN_NOT_OK(SortExecImpl(stock, key_type, ctx, batch, &tmp));
   out_arr->buffers[1] = std::move(data);
   return Status::OK();
 }
@@ -873,17 +872,13 @@ Status SortChunkedNP(const StockKernel& stock, cp::KernelContext* ctx, const cp:
   ctx->SetState(state);
   return st;
 }
-Status SortChunkedU64(cp::KernelContext* c, const cp::ExecBatch& b, arrow::Datum* o) {
-  return SortChunkedNP(g_stock_sort_u64, c, b, o);
+template <int K>
+Status SortChunkedT(cp::KernelContext* c, const cp::ExecBatch& b, arrow::Datum* o) {
+  return SortChunkedNP(g_stock_sort[K], c, b, o);
 }
-Status SortChunkedI64(cp::KernelContext* c, const cp::ExecBatch& b, arrow::Datum* o) {
-  return SortChunkedNP(g_stock_sort_i64, c, b, o);
-}
-Status SortExecU64(cp::KernelContext* c, const cp::ExecSpan& b, cp::ExecResult* o) {
-  return SortExecNP(g_stock_sort_u64, false, c, b, o);
-}
-Status SortExecI64(cp::KernelContext* c, const cp::ExecSpan& b, cp::ExecResult* o) {
-  return SortExecNP(g_stock_sort_i64, true, c, b, o);
+template <int K>
+Status SortExecT(cp::KernelContext* c, const cp::ExecSpan& b, cp::ExecResult* o) {
+  return SortExecNP(g_stock_sort[K], K, c, b, o);
 }
 
 // ---------------------------------------------------------------- cast(float64 -> float32)
@@ -1371,7 +1366,8 @@ std::vector<std::shared_ptr<arrow::DataType>> FilterValueTypes() {
 Status RegisterVector(cp::FunctionRegistry* reg, const std::string& name,
                       const std::vector<std::shared_ptr<arrow::DataType>>& first_types,
                       const std::vector<cp::InputType>& second, cp::KernelInit init,
-                      cp::ArrayKernelExec exec, StockKernel* stock) {
+                      cp::ArrayKernelExec exec, StockKernel* stock,
+                      cp::VectorKernel::ChunkedExec chunked = nullptr) {
   ARROW_ASSIGN_OR_RAISE(auto fn, reg->GetFunction(name));
   if (fn->kind() != cp::Function::VECTOR) return Status::Invalid(name, " is not a vector function");
   auto* vfn = static_cast<cp::VectorFunction*>(fn.get());
@@ -1397,7 +1393,7 @@ Status RegisterVector(cp::FunctionRegistry* reg, const std::string& name,
     copy.exec = exec;
     if (name == "array_sort_indices") {
       copy.mem_allocation = cp::MemAllocation::NO_PREALLOCATE;
-      if (copy.exec_chunked != nullptr) copy.exec_chunked = (stock == &g_stock_sort_u64) ? SortChunkedU64 : SortChunkedI64;
+      if (copy.exec_chunked != nullptr) copy.exec_chunked = chunked;
     }
     ARROW_RETURN_NOT_OK(vfn->AddKernel(std::move(copy)));
   }
@@ -1426,10 +1422,16 @@ Status RegisterAll() {
   ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_take", FilterValueTypes(),
                                      {cp::InputType(cp::match::Integer())}, TakeInit, TakeExec,
                                      &g_stock_take));
-  ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_sort_indices", {arrow::uint64()}, {}, SortInitU64, SortExecU64,
-                                     &g_stock_sort_u64));
-  ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_sort_indices", {arrow::int64()}, {}, SortInitI64, SortExecI64,
-                                     &g_stock_sort_i64));
+#define ARX_REGISTER_SORT(K, TYPE)                                                                           \
+  ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_sort_indices", {TYPE}, {}, SortInitT<K>, SortExecT<K>,         \
+                                     &g_stock_sort[K], SortChunkedT<K>))
+  ARX_REGISTER_SORT(ARX_KEY_UINT64, arrow::uint64());
+  ARX_REGISTER_SORT(ARX_KEY_INT64, arrow::int64());
+  ARX_REGISTER_SORT(ARX_KEY_UINT32, arrow::uint32());
+  ARX_REGISTER_SORT(ARX_KEY_INT32, arrow::int32());
+  ARX_REGISTER_SORT(ARX_KEY_FLOAT64, arrow::float64());
+  ARX_REGISTER_SORT(ARX_KEY_FLOAT32, arrow::float32());
+#undef ARX_REGISTER_SORT
   {
     ARROW_ASSIGN_OR_RAISE(auto fn, reg->GetFunction("greater"));
     auto* sfn = static_cast<cp::ScalarFunction*>(fn.get());

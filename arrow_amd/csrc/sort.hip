@@ -44,22 +44,89 @@ int selection_bit_positions(const void* bitmap, int64_t bit_offset, int64_t leng
                             hipStream_t st);
 size_t selection_workspace_bytes(int64_t length);
 
+// Order transform: any supported key -> uint64 whose unsigned order is the requested order.
+// `xf` = kXfRaw | (descending ? kXfDesc : 0) | key_type << 4   (key_type: ARX_KEY_* of the C ABI).
+// Signed integers flip the sign bit; 32-bit keys sit in the top half; floats use the usual
+// sign-magnitude trick with -0.0 canonicalised to +0.0 (they compare equal in the reference, so
+// they must tie); NaNs never get here (they are partitioned next to the nulls first).
+// Descending sorts ~key, which keeps ties in row order.
+constexpr int kXfRaw = 1;
+constexpr int kXfDesc = 4;
+__host__ __device__ __forceinline__ int make_xf(int key_type, bool descending) {
+  return kXfRaw | (descending ? kXfDesc : 0) | (key_type << 4);
+}
+__device__ __forceinline__ uint64_t load_key_typed(const void* base, int64_t i, int xf) {
+  uint64_t k;
+  switch ((xf >> 4) & 7) {
+    case 0: k = static_cast<const uint64_t*>(base)[i]; break;
+    case 1: k = static_cast<const uint64_t*>(base)[i] ^ 0x8000000000000000ull; break;
+    case 2: k = static_cast<uint64_t>(static_cast<const uint32_t*>(base)[i]) << 32; break;
+    case 3: k = static_cast<uint64_t>(static_cast<const uint32_t*>(base)[i] ^ 0x80000000u) << 32; break;
+    case 4: {
+      uint64_t b = static_cast<const uint64_t*>(base)[i];
+      if ((b << 1) == 0) b = 0;
+      k = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+      break;
+    }
+    default: {
+      uint32_t b = static_cast<const uint32_t*>(base)[i];
+      if ((b << 1) == 0) b = 0;
+      const uint32_t t = (b >> 31) ? ~b : (b | 0x80000000u);
+      k = static_cast<uint64_t>(t) << 32;
+      break;
+    }
+  }
+  if (xf & kXfDesc) k = ~k;
+  return k;
+}
+// legacy form for the 64-bit-only multi-GPU helpers
 __device__ __forceinline__ uint64_t key_transform(uint64_t k, bool is_signed, bool descending) {
-  if (is_signed) k ^= 0x8000000000000000ull;  // two's complement -> unsigned order
-  if (descending) k = ~k;                      // reverses the order, ties stay in row order
+  if (is_signed) k ^= 0x8000000000000000ull;
+  if (descending) k = ~k;
   return k;
 }
 
+// One wave per 64 rows: bit = valid && !isnan (the rows that are sorted) / valid && isnan.
+__global__ __launch_bounds__(kBlock) void sort_float_classify_kernel(const void* __restrict__ values,
+                                                                     int is_f32, Bits valid, int64_t n,
+                                                                     uint64_t* __restrict__ sortable_bits,
+                                                                     uint64_t* __restrict__ nan_bits) {
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwords = (n + 63) >> 6;
+  for (int64_t w = wave_g; w < nwords; w += nwaves) {
+    const int64_t i = (w << 6) + lane;
+    bool ok = false, nan = false;
+    if (i < n) {
+      ok = (load_word(valid, w) >> lane) & 1ull;
+      if (is_f32) {
+        const uint32_t b = static_cast<const uint32_t*>(values)[i];
+        nan = (b & 0x7fffffffu) > 0x7f800000u;
+      } else {
+        const uint64_t b = static_cast<const uint64_t*>(values)[i];
+        nan = (b & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
+      }
+    }
+    const uint64_t s_bits = __ballot(ok && !nan);
+    const uint64_t n_bits = __ballot(ok && nan);
+    if (lane == 0) {
+      sortable_bits[w] = s_bits;
+      nan_bits[w] = n_bits;
+    }
+  }
+}
+
 // keys_out[i] = transform(values[rows[i]]) , idx_out[i] = rows[i]  (rows == NULL -> identity)
-__global__ __launch_bounds__(kBlock) void sort_prep_kernel(const uint64_t* __restrict__ values,
+__global__ __launch_bounds__(kBlock) void sort_prep_kernel(const void* __restrict__ values,
                                                            const uint32_t* __restrict__ rows,
-                                                           int64_t n, int is_signed, int descending,
+                                                           int64_t n, int xf, int /*unused*/,
                                                            uint64_t* __restrict__ keys_out,
                                                            uint32_t* __restrict__ idx_out) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     const uint32_t r = rows ? rows[i] : static_cast<uint32_t>(i);
-    keys_out[i] = key_transform(values[r], is_signed != 0, descending != 0);
+    keys_out[i] = load_key_typed(values, r, xf);
     idx_out[i] = r;
   }
 }
@@ -75,8 +142,7 @@ __global__ __launch_bounds__(kBlock) void widen_kernel(const uint32_t* __restric
 // raw: 0 = keys are already order-transformed; else bit0 set = raw column values, transformed on
 // the fly (bit1 = signed, bit2 = descending) — the first pass reads the caller's array directly.
 __device__ __forceinline__ uint64_t load_sort_key(const uint64_t* __restrict__ keys, int64_t i, int raw) {
-  const uint64_t k = keys[i];
-  return raw ? key_transform(k, (raw & 2) != 0, (raw & 4) != 0) : k;
+  return raw ? load_key_typed(keys, i, raw) : keys[i];
 }
 
 __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t* __restrict__ keys,
@@ -174,7 +240,7 @@ __global__ __launch_bounds__(kBlock, 3) void radix_scatter_kernel(
       const int p = wave * (kSortItems * 64) + i * 64 + lane;
       if (p < nv) {
         if constexpr (RAW) {
-          key[i] = key_transform(keys_in[base + p], (raw & 2) != 0, (raw & 4) != 0);
+          key[i] = load_key_typed(keys_in, base + p, raw);
           idx[i] = static_cast<uint32_t>(base + p);  // first pass: row id = position
         } else {
           key[i] = keys_in[base + p];
@@ -357,7 +423,7 @@ constexpr int kMsdWindow = kMsdCore + 2 * kMsdHalo;
 struct MsdArgs {
   const uint64_t* src_keys;   // level-1 input: raw column (raw != 0) or transformed keys
   const uint32_t* src_idx;    // level-1 input row ids (unused when raw)
-  int raw;                    // 0, or 1 | (signed ? 2 : 0) | (descending ? 4 : 0)
+  int raw;                    // 0, or make_xf(key_type, descending)
   int64_t n;
   int bits, b1, b2, b3;       // bits = b1 + b2 (global levels), b3 = local level
   int kshift;                 // top bits already equal inside this segment: digits are taken from key << kshift
@@ -379,7 +445,7 @@ struct MsdArgs {
 template <bool RAW>
 __device__ __forceinline__ uint64_t msd_load_key(const MsdArgs& a, int64_t i) {
   if constexpr (RAW) {
-    return key_transform(a.src_keys[i], (a.raw & 2) != 0, (a.raw & 4) != 0);
+    return load_key_typed(a.src_keys, i, a.raw);
   } else {
     return a.src_keys[i];
   }
@@ -465,6 +531,23 @@ __global__ __launch_bounds__(1024) void msd_scan_a_kernel(MsdArgs a) {
   for (int k = 0; k < wave; ++k) tprefix += wave_tot[k];
   if (tid < nb1) a.l2_tile_start[tid] = tprefix;
   if (tid == nb1 - 1) a.l2_tile_start[nb1] = tprefix + tiles;
+  // largest bucket -> overflow[1]: lets the host skip the scatter passes when the top bits are
+  // too skewed for the LDS-resident finish (it then goes straight to the LSD passes)
+  uint32_t mx = 0;
+  for (int i = b; i < e; ++i) mx = mx > a.part_count[i] ? mx : a.part_count[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = __shfl_xor(mx, d, 64);
+    mx = mx > o ? mx : o;
+  }
+  __syncthreads();
+  if (lane == 0) wave_tot[wave] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t m = 0;
+    for (int k = 0; k < 16; ++k) m = m > wave_tot[k] ? m : wave_tot[k];
+    a.overflow[1] = m;
+  }
 }
 
 // one workgroup per level-1 digit: hist1[d][*] -> exclusive offsets (+ l1_start[d])
@@ -520,7 +603,7 @@ __device__ __forceinline__ void msd_scatter_tile(const MsdArgs& a, MsdScatterLds
     idx[i] = 0;
     if (p < nrows) {
       if constexpr (RAW) {
-        key[i] = key_transform(kin[row0 + p], (a.raw & 2) != 0, (a.raw & 4) != 0);
+        key[i] = load_key_typed(kin, row0 + p, a.raw);
         idx[i] = static_cast<uint32_t>(row0 + p);
       } else {
         key[i] = kin[row0 + p];
@@ -839,7 +922,7 @@ struct SortPlan {
   int64_t ntiles;
   int64_t chunk_tiles;
   int64_t nchunks;
-  size_t off_keys_a, off_keys_b, off_idx_a, off_idx_b, off_hist, off_totals, off_split, off_msd, off_rows, off_sel_ws, total;
+  size_t off_keys_a, off_keys_b, off_idx_a, off_idx_b, off_hist, off_totals, off_split, off_msd, off_float_bits, off_rows, off_sel_ws, total;
 };
 
 static SortPlan make_plan(int64_t length) {
@@ -859,6 +942,7 @@ static SortPlan make_plan(int64_t length) {
   p.off_totals = o; o = align(o + static_cast<size_t>(kDigits) * 4);
   p.off_split = o; o = align(o + static_cast<size_t>(kDigits) * 4);
   p.off_msd = o; o = align(o + kMsdTableBytes);
+  p.off_float_bits = o; o = align(o + 2 * (n / 64 + 2) * 8);  // sortable / NaN bitmaps of float keys
   p.off_rows = o; o = align(o + n * 4);  // row ids of the non-null / null partitions
   p.off_sel_ws = o; o = align(o + selection_workspace_bytes(length));
   p.total = o;
@@ -951,6 +1035,18 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   hipLaunchKernelGGL(msd_scan_a_kernel, dim3(1), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(msd_scan_b_kernel, dim3(1u << a.b1), dim3(64), 0, st, a);
   ARX_CHECK_LAUNCH("msd_scan kernels");
+  const bool fused = g_sort_msd_fused != 0 && (n >> a.bits) <= 8192;
+  if (fused) {
+    // skewed top bits (e.g. normally distributed floats): a bucket would not fit LDS -> do not
+    // waste the scatter passes, the caller runs the LSD passes instead
+    unsigned int max_part = 0;
+    ARX_HIP(hipMemcpyAsync(&max_part, a.overflow + 1, 4, hipMemcpyDeviceToHost, st));
+    ARX_HIP(hipStreamSynchronize(st));
+    if (max_part > static_cast<unsigned int>(kBktCap)) {
+      *overflowed = 1;
+      return ARX_OK;
+    }
+  }
   if (raw) {
     hipLaunchKernelGGL((msd_scatter1_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
   } else {
@@ -961,7 +1057,6 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   hipLaunchKernelGGL(msd_scatter2_kernel, dim3(grid2), dim3(kMsdThreads), 0, st, a);
   ARX_CHECK_LAUNCH("msd_scatter2_kernel");
   // level-2 buckets that fit LDS: finish each one in a single workgroup (b3 may use 10 bits there)
-  const bool fused = g_sort_msd_fused != 0 && (n >> a.bits) <= 8192;
   if (fused) {
     a.b3 = std::max(0, std::min(std::min(lg - 3 - a.bits, 10), 64 - kshift - a.bits));  // ~8 rows per sub-bucket
     hipLaunchKernelGGL(msd_bucket_kernel, dim3(static_cast<unsigned>(nparts)), dim3(kBktThreads), 0, st, a, keys_y,
@@ -1068,11 +1163,15 @@ size_t arx_sort_indices_workspace_bytes(int64_t length) {
   return make_plan(length).total;
 }
 
-int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int null_placement,
-                        void* ws, size_t ws_bytes, uint64_t* out_indices, void* stream) {
+int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_placement, void* ws,
+                     size_t ws_bytes, uint64_t* out_indices, void* stream) {
   if (values == nullptr) {
     set_error("values is NULL");
     return ARX_INVALID;
+  }
+  if (key_type < ARX_KEY_UINT64 || key_type > ARX_KEY_FLOAT32) {
+    set_error("arx_sort_indices: unsupported key type %d", key_type);
+    return ARX_NOT_IMPLEMENTED;
   }
   const int64_t len = values->length;
   if (len < 0 || values->offset < 0) {
@@ -1081,7 +1180,7 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
   }
   if (len == 0) return ARX_OK;
   if (len > static_cast<int64_t>(UINT32_MAX)) {
-    set_error("arx_sort_indices_64: more than UINT32_MAX rows is not implemented");
+    set_error("arx_sort_indices: more than UINT32_MAX rows is not implemented");
     return ARX_NOT_IMPLEMENTED;
   }
   if (order != ARX_SORT_ASCENDING && order != ARX_SORT_DESCENDING) {
@@ -1114,59 +1213,81 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
   uint32_t* hist = reinterpret_cast<uint32_t*>(w + plan.off_hist);
   uint32_t* totals = reinterpret_cast<uint32_t*>(w + plan.off_totals);
   uint32_t* rows = reinterpret_cast<uint32_t*>(w + plan.off_rows);
+  uint64_t* sortable_bits = reinterpret_cast<uint64_t*>(w + plan.off_float_bits);
+  uint64_t* nan_bits = sortable_bits + ceil_div(len, 64);
   void* sel_ws = w + plan.off_sel_ws;
   const size_t sel_ws_bytes = plan.total - plan.off_sel_ws;
 
-  const uint64_t* vals = static_cast<const uint64_t*>(values->data) + values->offset;
+  const bool is_float = key_type == ARX_KEY_FLOAT64 || key_type == ARX_KEY_FLOAT32;
+  const int key_width = (key_type == ARX_KEY_UINT32 || key_type == ARX_KEY_INT32 || key_type == ARX_KEY_FLOAT32) ? 4 : 8;
+  const uint8_t* vals = static_cast<const uint8_t*>(values->data) + values->offset * key_width;
   const bool has_nulls = values->null_count != 0 && values->validity != nullptr;
+  const int xf = make_xf(key_type, order == ARX_SORT_DESCENDING);
 
-  // ---- null partition (PartitionNullsOnly, stable): row ids of nulls keep row order
-  int64_t n_valid = len;
-  const uint32_t* valid_rows = nullptr;
+  // ---- null-like partition (PartitionNulls, stable): nulls, and for floats NaNs, keep row order
+  // and sit at the end (values, NaNs, nulls) or the start (nulls, NaNs, values)
+  int64_t n_null = 0, n_nan = 0;
+  if (is_float) {
+    const Bits vb = make_bits(has_nulls ? values->validity : nullptr, values->offset, len);
+    const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(ceil_div(len, 64), kWavesPerBlock), 2048));
+    hipLaunchKernelGGL(sort_float_classify_kernel, dim3(g), dim3(kBlock), 0, st, vals,
+                       key_type == ARX_KEY_FLOAT32 ? 1 : 0, vb, len, sortable_bits, nan_bits);
+    ARX_CHECK_LAUNCH("sort_float_classify_kernel");
+  }
   if (has_nulls) {
-    int64_t n_null = 0;
-    int rc = selection_bit_positions(values->validity, values->offset, len, /*invert=*/true, sel_ws,
-                                     sel_ws_bytes, rows, &n_null, st);
+    const int rc = selection_bit_positions(values->validity, values->offset, len, /*invert=*/true, sel_ws,
+                                           sel_ws_bytes, rows, &n_null, st);
     if (rc != ARX_OK) return rc;
-    n_valid = len - n_null;
     if (n_null > 0) {
-      uint64_t* null_dst = null_placement == ARX_NULLS_AT_START ? out_indices : out_indices + n_valid;
+      uint64_t* null_dst = null_placement == ARX_NULLS_AT_START ? out_indices : out_indices + (len - n_null);
       const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_null, kBlock), 2048));
       hipLaunchKernelGGL(widen_kernel, dim3(g), dim3(kBlock), 0, st, rows, n_null, null_dst);
       ARX_CHECK_LAUNCH("widen_kernel");
     }
-    if (n_valid > 0 && n_null > 0) {
-      int64_t got = 0;
-      rc = selection_bit_positions(values->validity, values->offset, len, /*invert=*/false, sel_ws,
-                                   sel_ws_bytes, rows, &got, st);
-      if (rc != ARX_OK) return rc;
-      valid_rows = rows;
+  }
+  if (is_float) {
+    const int rc = selection_bit_positions(nan_bits, 0, len, /*invert=*/false, sel_ws, sel_ws_bytes, rows, &n_nan, st);
+    if (rc != ARX_OK) return rc;
+    if (n_nan > 0) {
+      uint64_t* nan_dst = null_placement == ARX_NULLS_AT_START ? out_indices + n_null
+                                                               : out_indices + (len - n_null - n_nan);
+      const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_nan, kBlock), 2048));
+      hipLaunchKernelGGL(widen_kernel, dim3(g), dim3(kBlock), 0, st, rows, n_nan, nan_dst);
+      ARX_CHECK_LAUNCH("widen_kernel");
     }
   }
+  const int64_t n_valid = len - n_null - n_nan;
   if (n_valid == 0) return ARX_OK;
-  uint64_t* final_dst =
-      (has_nulls && null_placement == ARX_NULLS_AT_START) ? out_indices + (len - n_valid) : out_indices;
+  const uint32_t* valid_rows = nullptr;
+  if (n_valid < len) {
+    int64_t got = 0;
+    const int rc = is_float ? selection_bit_positions(sortable_bits, 0, len, false, sel_ws, sel_ws_bytes, rows, &got, st)
+                            : selection_bit_positions(values->validity, values->offset, len, false, sel_ws,
+                                                      sel_ws_bytes, rows, &got, st);
+    if (rc != ARX_OK) return rc;
+    valid_rows = rows;
+  }
+  uint64_t* final_dst = null_placement == ARX_NULLS_AT_START ? out_indices + (len - n_valid) : out_indices;
 
   // ---- large inputs: MSD-hybrid path; falls through to the LSD passes if a bucket overflowed
-  // auto: from 4M rows up; beyond 2^28 rows an extra level on the top bits cuts ~2^27-row segments
-  // (with only 23 partition bits the final buckets of a 1B-row input would hold ~128 rows)
+  // auto: from 4M rows up; beyond 2^27 rows an extra level on the top bits cuts ~2^27-row segments
   const bool try_msd = g_sort_msd != 0 && n_valid < (int64_t(1) << 32) - kMsdTile &&
                        (g_sort_msd == 1 ? n_valid >= 256 : n_valid >= g_sort_msd_min_rows);
   const bool segmented = n_valid > g_sort_msd_segment_rows;
+  const unsigned gprep = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_valid, kBlock), 2048));
   if (try_msd) {
     uint8_t* tables = w + plan.off_msd;
     int overflowed = 0;
     int rc;
     if (valid_rows == nullptr) {
-      const int raw = 1 | (is_signed ? 2 : 0) | (order == ARX_SORT_DESCENDING ? 4 : 0);
-      rc = segmented ? run_msd_sort_segmented(vals, nullptr, raw, n_valid, keys_a, idx_a, keys_b, idx_b, tables,
+      const uint64_t* src = reinterpret_cast<const uint64_t*>(vals);
+      rc = segmented ? run_msd_sort_segmented(src, nullptr, xf, n_valid, keys_a, idx_a, keys_b, idx_b, tables,
                                               final_dst, st, &overflowed)
-                     : run_msd_sort(vals, nullptr, raw, n_valid, keys_a, idx_a, keys_b, idx_b, tables, final_dst, st,
+                     : run_msd_sort(src, nullptr, xf, n_valid, keys_a, idx_a, keys_b, idx_b, tables, final_dst, st,
                                     &overflowed);
     } else {
-      const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_valid, kBlock), 2048));
-      hipLaunchKernelGGL(sort_prep_kernel, dim3(g), dim3(kBlock), 0, st, vals, valid_rows, n_valid,
-                         is_signed, order == ARX_SORT_DESCENDING, keys_a, idx_a);
+      hipLaunchKernelGGL(sort_prep_kernel, dim3(gprep), dim3(kBlock), 0, st, vals, valid_rows, n_valid, xf, 0,
+                         keys_a, idx_a);
       ARX_CHECK_LAUNCH("sort_prep_kernel");
       rc = segmented ? run_msd_sort_segmented(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables,
                                               final_dst, st, &overflowed)
@@ -1177,27 +1298,26 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
     if (!overflowed) return ARX_OK;
   }
 
-  // ---- (key, row id) pairs.  With no nulls the first pass reads the caller's column directly
-  // (transform applied on load, row id = position); otherwise a prep pass gathers the valid rows.
+  // ---- LSD passes over (key, row id) pairs.  With no null-likes the first pass reads the caller's
+  // column directly (transform applied on load, row id = position); otherwise a prep pass gathers
+  // the sortable rows.  32-bit keys live in the top half of the transformed key: 4 passes.
   plan = make_plan(n_valid);
-  const int raw_first = (valid_rows == nullptr && g_sort_fuse_prep)
-                            ? (1 | (is_signed ? 2 : 0) | (order == ARX_SORT_DESCENDING ? 4 : 0))
-                            : 0;
+  const int raw_first = (valid_rows == nullptr && g_sort_fuse_prep) ? xf : 0;
   if (!raw_first) {
-    const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_valid, kBlock), 2048));
-    hipLaunchKernelGGL(sort_prep_kernel, dim3(g), dim3(kBlock), 0, st, vals, valid_rows, n_valid,
-                       is_signed, order == ARX_SORT_DESCENDING, keys_a, idx_a);
+    hipLaunchKernelGGL(sort_prep_kernel, dim3(gprep), dim3(kBlock), 0, st, vals, valid_rows, n_valid, xf, 0,
+                       keys_a, idx_a);
     ARX_CHECK_LAUNCH("sort_prep_kernel");
   }
   const int64_t chunk_keys = plan.chunk_tiles * kSortTile;
   const unsigned nch = static_cast<unsigned>(plan.nchunks);
-  const uint64_t* kin = raw_first ? vals : keys_a;
+  const uint64_t* kin = raw_first ? reinterpret_cast<const uint64_t*>(vals) : keys_a;
   uint64_t* kout = keys_b;
   const uint32_t* iin = idx_a;
   uint32_t* iout = idx_b;
-  for (int pass = 0; pass < 8; ++pass) {
+  const int first_pass = key_width == 4 ? 4 : 0;
+  for (int pass = first_pass; pass < 8; ++pass) {
     const int shift = pass * 8;
-    const int raw = pass == 0 ? raw_first : 0;
+    const int raw = pass == first_pass ? raw_first : 0;
     hipLaunchKernelGGL(radix_hist_kernel, dim3(nch), dim3(kBlock), 0, st, kin, n_valid, shift,
                        chunk_keys, plan.nchunks, hist, raw);
     ARX_CHECK_LAUNCH("radix_hist_kernel");
@@ -1208,7 +1328,7 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
     ARX_CHECK_LAUNCH("radix_scan_kernel");
     if (raw) {
       hipLaunchKernelGGL((radix_scatter_kernel<true>), dim3(nch), dim3(kBlock), 0, st, kin, iin, n_valid, shift,
-                         plan.chunk_tiles, plan.nchunks, hist, kout, iout, final_dst, 0, raw);
+                         plan.chunk_tiles, plan.nchunks, hist, kout, iout, final_dst, pass == 7 ? 1 : 0, raw);
     } else {
       hipLaunchKernelGGL((radix_scatter_kernel<false>), dim3(nch), dim3(kBlock), 0, st, kin, iin, n_valid,
                          shift, plan.chunk_tiles, plan.nchunks, hist, kout, iout, final_dst, pass == 7 ? 1 : 0,
@@ -1224,6 +1344,12 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
     iout = inext;
   }
   return ARX_OK;
+}
+
+int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int null_placement,
+                        void* ws, size_t ws_bytes, uint64_t* out_indices, void* stream) {
+  return arx_sort_indices(values, is_signed ? ARX_KEY_INT64 : ARX_KEY_UINT64, order, null_placement, ws,
+                          ws_bytes, out_indices, stream);
 }
 
 int arx_sort_key_histogram(const ArxSpan* values, int is_signed, int order, int bits,
@@ -1319,8 +1445,9 @@ int arx_sort_partition_by_bins(const ArxSpan* values, int is_signed, int order, 
                      plan.chunk_tiles, plan.nchunks, hist, keys_b, idx_b, static_cast<uint64_t*>(nullptr), 0, 0);
   ARX_CHECK_LAUNCH("radix partition pass");
   // transformed keys and row ids in destination-major, row-order-preserving order
-  hipLaunchKernelGGL(sort_prep_kernel, dim3(g), dim3(kBlock), 0, st, vals, idx_b, n_valid, is_signed,
-                     order == ARX_SORT_DESCENDING, out_keys, out_rows);
+  hipLaunchKernelGGL(sort_prep_kernel, dim3(g), dim3(kBlock), 0, st, static_cast<const void*>(vals), idx_b, n_valid,
+                     make_xf(is_signed ? ARX_KEY_INT64 : ARX_KEY_UINT64, order == ARX_SORT_DESCENDING), 0, out_keys,
+                     out_rows);
   ARX_CHECK_LAUNCH("sort_prep_kernel");
   return ARX_OK;
 }

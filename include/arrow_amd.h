@@ -208,7 +208,18 @@ int arx_bitmap_popcount(const void* bits, int64_t bit_offset, int64_t length, vo
  * end or the start (PartitionNullsOnly, vector_sort_internal.h:225-293);
  * descending keeps ties in ascending index order (rhs < lhs comparator).
  * ------------------------------------------------------------------------- */
+/* Key types of arx_sort_indices (the physical types AddArraySortingKernels registers,
+ * vector_array_sort.cc:554-610, that are on the gfx950 path).  For floating point keys NaNs are
+ * "null-likes" (PartitionNulls, vector_sort_internal.h): values, NaNs, nulls (at_end) or nulls,
+ * NaNs, values (at_start) whatever the order; -0.0 and 0.0 tie. */
+enum {
+  ARX_KEY_UINT64 = 0, ARX_KEY_INT64 = 1, ARX_KEY_UINT32 = 2, ARX_KEY_INT32 = 3,
+  ARX_KEY_FLOAT64 = 4, ARX_KEY_FLOAT32 = 5
+};
 size_t arx_sort_indices_workspace_bytes(int64_t length);
+int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_placement, void* ws,
+                     size_t ws_bytes, uint64_t* out_indices, void* stream);
+/* 64-bit integer keys (is_signed: 0 = uint64, 1 = int64): same as arx_sort_indices. */
 int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int null_placement,
                         void* ws, size_t ws_bytes, uint64_t* out_indices, void* stream);
 

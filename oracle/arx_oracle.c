@@ -282,6 +282,78 @@ int arxo_sort_indices_64(const uint64_t* values, const uint8_t* valid, int64_t o
 }
 
 /* ---------------------------------------------------------------------------
+ * array_sort_indices for the other fixed-width key types (uint32/int32/float64/float32) —
+ * ArraySortIndices<*, T>::Exec (vector_array_sort.cc:524-540) with PartitionNulls
+ * (vector_sort_internal.h:225-293): for floating point keys NaNs are "null-likes": they are
+ * stably partitioned next to the nulls — values, NaNs, nulls (at_end) or nulls, NaNs, values
+ * (at_start) — whatever the sort order; -0.0 and 0.0 compare equal (plain `<`), so they keep row
+ * order.  key_type: 0 uint64, 1 int64, 2 uint32, 3 int32, 4 float64, 5 float32.
+ * ------------------------------------------------------------------------- */
+#include <math.h>
+
+typedef struct { double f; uint64_t u; int64_t s; uint64_t idx; } TypedKey;
+
+static int typed_less(const TypedKey* a, const TypedKey* b, int key_type) {
+  switch (key_type) {
+    case 0: case 2: return a->u < b->u;
+    case 1: case 3: return a->s < b->s;
+    default: return a->f < b->f;
+  }
+}
+
+static void typed_merge_sort(TypedKey* a, TypedKey* tmp, int64_t n, int key_type, int descending) {
+  if (n < 2) return;
+  const int64_t h = n / 2;
+  typed_merge_sort(a, tmp, h, key_type, descending);
+  typed_merge_sort(a + h, tmp, n - h, key_type, descending);
+  int64_t i = 0, j = h, k = 0;
+  while (i < h && j < n) {
+    const int right_first = descending ? typed_less(&a[i], &a[j], key_type) : typed_less(&a[j], &a[i], key_type);
+    if (right_first) tmp[k++] = a[j++]; else tmp[k++] = a[i++];
+  }
+  while (i < h) tmp[k++] = a[i++];
+  while (j < n) tmp[k++] = a[j++];
+  memcpy(a, tmp, (size_t)n * sizeof(TypedKey));
+}
+
+int arxo_sort_indices(const void* values, int key_type, const uint8_t* valid, int64_t off, int64_t n,
+                      int order, int null_placement, uint64_t* out) {
+  TypedKey* a = (TypedKey*)malloc((size_t)(n > 0 ? n : 1) * sizeof(TypedKey));
+  TypedKey* tmp = (TypedKey*)malloc((size_t)(n > 0 ? n : 1) * sizeof(TypedKey));
+  uint64_t* nans = (uint64_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(uint64_t));
+  uint64_t* nulls = (uint64_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(uint64_t));
+  if (!a || !tmp || !nans || !nulls) { free(a); free(tmp); free(nans); free(nulls); return -1; }
+  int64_t nv = 0, nnan = 0, nnull = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (!is_valid(valid, off, i)) { nulls[nnull++] = (uint64_t)i; continue; }
+    TypedKey t; t.f = 0; t.u = 0; t.s = 0; t.idx = (uint64_t)i;
+    switch (key_type) {
+      case 0: t.u = ((const uint64_t*)values)[off + i]; break;
+      case 1: t.s = ((const int64_t*)values)[off + i]; break;
+      case 2: t.u = ((const uint32_t*)values)[off + i]; break;
+      case 3: t.s = ((const int32_t*)values)[off + i]; break;
+      case 4: t.f = ((const double*)values)[off + i]; break;
+      default: t.f = (double)((const float*)values)[off + i]; break;
+    }
+    if (key_type >= 4 && isnan(t.f)) { nans[nnan++] = (uint64_t)i; continue; }
+    a[nv++] = t;
+  }
+  typed_merge_sort(a, tmp, nv, key_type, order == 1);
+  int64_t o = 0;
+  if (null_placement == 0) {   /* nulls, NaNs, values */
+    for (int64_t i = 0; i < nnull; ++i) out[o++] = nulls[i];
+    for (int64_t i = 0; i < nnan; ++i) out[o++] = nans[i];
+    for (int64_t i = 0; i < nv; ++i) out[o++] = a[i].idx;
+  } else {                     /* values, NaNs, nulls */
+    for (int64_t i = 0; i < nv; ++i) out[o++] = a[i].idx;
+    for (int64_t i = 0; i < nnan; ++i) out[o++] = nans[i];
+    for (int64_t i = 0; i < nnull; ++i) out[o++] = nulls[i];
+  }
+  free(a); free(tmp); free(nans); free(nulls);
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------
  * Group-by hash_sum(int64) BY int32 — the composition
  *   Grouper::Consume (compute/row/grouper.cc:662-815): dense uint32 group ids in
  *     first-occurrence order; a null key is its own group (:448-458 of key_hash);

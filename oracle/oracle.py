@@ -63,6 +63,8 @@ def lib():
         L.arxo_bitmap_popcount.argtypes = [p, i64, i64]
         L.arxo_sort_indices_64.restype = i32
         L.arxo_sort_indices_64.argtypes = [p, p, i64, i64, i32, i32, i32, p]
+        L.arxo_sort_indices.restype = i32
+        L.arxo_sort_indices.argtypes = [p, i32, p, i64, i64, i32, i32, p]
         L.arxo_groupby_sum_i64.restype = i64
         L.arxo_groupby_sum_i64.argtypes = [p, p, i64, p, p, i64, i64, i32, u32, p, p, p, p, p, p]
         L.arxo_hash_sum_i64_consume.restype = None
@@ -206,6 +208,19 @@ def sort_indices_64(values, valid, offset, length, descending=False, nulls_at_st
     rc = lib().arxo_sort_indices_64(_ptr(values), _ptr(valid), offset, length,
                                     int(values.dtype == np.int64), int(descending),
                                     0 if nulls_at_start else 1, _ptr(out))
+    assert rc == 0
+    return out
+
+
+SORT_KEY_TYPES = {np.dtype("uint64"): 0, np.dtype("int64"): 1, np.dtype("uint32"): 2, np.dtype("int32"): 3,
+                  np.dtype("float64"): 4, np.dtype("float32"): 5}
+
+
+def sort_indices(values, valid, offset, length, descending=False, nulls_at_start=False):
+    """array_sort_indices for any supported key type (NaNs next to the nulls, -0.0 == 0.0)."""
+    out = np.empty(length, dtype=np.uint64)
+    rc = lib().arxo_sort_indices(_ptr(values), SORT_KEY_TYPES[values.dtype], _ptr(valid), offset, length,
+                                 int(descending), 0 if nulls_at_start else 1, _ptr(out))
     assert rc == 0
     return out
 

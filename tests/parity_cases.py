@@ -194,9 +194,9 @@ def check_sort_indices(amd, arr: HostArray, order="ascending", null_placement="a
                        use_pyarrow=True):
     d = arr.to_device(amd)
     out = amd.compute.sort_indices(d, order, null_placement)
-    want = O.sort_indices_64(np.ascontiguousarray(arr.values), arr.valid_bitmap(), arr.offset,
-                             arr.length, descending=(order == "descending"),
-                             nulls_at_start=(null_placement == "at_start"))
+    want = O.sort_indices(np.ascontiguousarray(arr.values), arr.valid_bitmap(), arr.offset,
+                          arr.length, descending=(order == "descending"),
+                          nulls_at_start=(null_placement == "at_start"))
     got = _data_np(out, np.uint64)
     tag = f"sort_indices[{arr.dtype},n={arr.length},{order},{null_placement},off={arr.offset}]"
     assert out.validity is None and out.null_count == 0

@@ -37,6 +37,8 @@ SCRIPT = textwrap.dedent(r'''
             table=pa.table({"v": vals, "w": f64a}).filter(mask),
             gt=pc.greater(f64a, f64b), sort=pc.array_sort_indices(keys),
             sort_d=pc.array_sort_indices(keys, order="descending", null_placement="at_start"),
+            sort_f64=pc.array_sort_indices(f64b, order="descending", null_placement="at_start"),
+            sort_i32=pc.array_sort_indices(vals.slice(0, 400_000).cast(pa.int64()).cast(pa.int32(), safe=False)),
             small=pc.filter(small, pa.array(np.arange(100) % 2 == 0)),
             boolv=pc.filter(mask, mask),
             cast=pc.cast(f64b, pa.float32(), safe=False), cast_slice=pc.cast(f64b.slice(5), pa.float32()),
@@ -63,7 +65,7 @@ SCRIPT = textwrap.dedent(r'''
         if hasattr(ours[k], "null_count"):
             assert ours[k].null_count == stock[k].null_count, k
     # every large call above took the HIP path: (gpu, stock) calls per function
-    want_gpu = {"array_filter": 4, "array_take": 4, "greater": 1, "array_sort_indices": 2, "cast": 2,
+    want_gpu = {"array_filter": 4, "array_take": 4, "greater": 1, "array_sort_indices": 4, "cast": 2,
                 "hash_sum": 2}
     for f, wmin in want_gpu.items():
         assert stats[f][0] >= wmin, (f, stats)

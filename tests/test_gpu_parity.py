@@ -508,3 +508,31 @@ def test_sort_msd_hybrid_path(gpu_ctx, global_bits, fused):
 
 def test_null_count_bookkeeping(gpu_ctx):
     P.check_null_count_bookkeeping(gpu_ctx, rng_for("nullcount"))
+
+
+@pytest.mark.parametrize("msd", [0, 1])
+@pytest.mark.parametrize("dtype", [np.uint32, np.int32, np.float64, np.float32])
+def test_sort_32bit_and_float_keys(gpu_ctx, dtype, msd):
+    """array_sort_indices on the other fixed-width key types: 32-bit integers (4 LSD passes), floats
+    with NaNs as null-likes next to the nulls whatever the order, -0.0 tying with 0.0, infinities."""
+    lib = gpu_ctx._lib.get_lib()
+    assert lib.arx_set_option(b"sort_msd", 1 if msd else 0) == 0
+    try:
+        rng = rng_for("sort32f", str(dtype), msd)
+        n = 5000003
+        for order, placement, null_p in (("ascending", "at_end", 0.05), ("descending", "at_start", 0.05),
+                                         ("descending", "at_end", 0.0)):
+            a = U.random_array(rng, dtype, n, null_p=null_p, offset=2)
+            v = a.values
+            if np.dtype(dtype).kind == "f":
+                v[::7] = np.nan
+                v[::11] = 0.0
+                v[1::11] = -0.0
+                v[::13] = np.inf
+                v[5::13] = -np.inf
+                v[::3] = np.round(v[::3])          # ties
+            else:
+                v[::3] = v[::3] % 17               # ties
+            P.check_sort_indices(gpu_ctx, a, order, placement)
+    finally:
+        lib.arx_set_option(b"sort_msd", -1)

@@ -38,6 +38,9 @@ SCRIPT = textwrap.dedent(r'''
                                       order="descending", null_placement="at_start"),
                 pc.sort_indices(pa.table({"a": pa.array((np.arange(1000) % 7).astype(np.uint64))}), sort_keys=[("a", "descending")]),
                 pc.array_sort_indices(pa.chunked_array([pa.array(np.arange(10, dtype=np.uint64)), pa.array(np.arange(5, dtype=np.uint64))])),
+                pc.array_sort_indices(pa.array([1.5, float("nan"), None, -0.0, 0.0, float("inf"), float("nan")]), order="descending"),
+                pc.array_sort_indices(pa.array(np.arange(300, dtype=np.int32)[::-1].copy())),
+                pc.array_sort_indices(pa.array(np.linspace(-3, 3, 200).astype(np.float32)), null_placement="at_start"),
                 pc.cast(f, pa.float32(), safe=False), pc.cast(f.slice(3), pa.int64(), safe=False)]
     before = pc.get_function("array_filter").num_kernels
     stock = run()
