@@ -536,3 +536,67 @@ def test_sort_32bit_and_float_keys(gpu_ctx, dtype, msd):
             P.check_sort_indices(gpu_ctx, a, order, placement)
     finally:
         lib.arx_set_option(b"sort_msd", -1)
+
+
+def test_sort_virtual_ranks_on_one_gpu(gpu_ctx):
+    """The multi-GPU sort_indices data path with P = 4 virtual ranks on one device: splitter
+    histogram (summed over the shards), stable partition by destination on every shard, the
+    exchange emulated by slicing (receive buffers concatenated in source-rank order), local stable
+    sort + gather.  The concatenation over ranks must be the oracle's argsort of the whole array."""
+    import ctypes as C
+
+    import torch
+
+    amd = gpu_ctx
+    lib = amd._lib.get_lib()
+    from arrow_amd.array import alloc, current_stream
+
+    P_, bits = 4, 12
+    rng = rng_for("vsort")
+    shards = [U.random_array(rng, np.uint64, 300_000 + 7_001 * r, null_p=0.02, offset=r + 1) for r in range(P_)]
+    for a in shards:
+        a.values[a.offset:a.offset + a.length:3] %= 50          # ties across shards
+    dev = [a.to_device(amd) for a in shards]
+    stream = current_stream(dev[0].device)
+    offsets = np.cumsum([0] + [a.length for a in shards])
+    hist = torch.zeros(1 << bits, dtype=torch.int64, device=dev[0].device)
+    for d in dev:
+        sp = d.span()
+        amd._lib.check(lib.arx_sort_key_histogram(C.byref(sp), 0, 0, bits, hist.data_ptr(), stream))
+    cum = torch.cumsum(hist, 0).cpu().numpy()
+    total = int(cum[-1])
+    split = [int(np.searchsorted(cum, (total * p + P_ - 1) // P_) + 1) for p in range(1, P_)]
+    split_arr = (C.c_uint32 * len(split))(*split)
+    sent = []   # per source: (keys, global rows, counts)
+    for r, d in enumerate(dev):
+        n = d.length
+        ws = alloc(lib.arx_sort_indices_workspace_bytes(n) + 256, d.device)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        keys = torch.empty(n, dtype=torch.int64, device=d.device)
+        rows = torch.empty(n, dtype=torch.int32, device=d.device)
+        counts = torch.zeros(P_, dtype=torch.int64, device=d.device)
+        nv = C.c_int64(0)
+        sp = d.span()
+        amd._lib.check(lib.arx_sort_partition_by_bins(C.byref(sp), 0, 0, bits, split_arr, P_, ws_ptr,
+                                                      ws.numel() - (ws_ptr - ws.data_ptr()), keys.data_ptr(),
+                                                      rows.data_ptr(), counts.data_ptr(), C.byref(nv), stream))
+        torch.cuda.synchronize()
+        sent.append((keys[: nv.value], rows[: nv.value].to(torch.int64) + int(offsets[r]), counts.cpu().tolist()))
+    out = []
+    for dst in range(P_):
+        ks, gs = [], []
+        for keys, grows, counts in sent:       # source-rank order
+            lo = sum(counts[:dst])
+            ks.append(keys[lo: lo + counts[dst]])
+            gs.append(grows[lo: lo + counts[dst]])
+        k, g = torch.cat(ks).contiguous(), torch.cat(gs).contiguous()
+        karr = amd.Array(amd.array.uint64, k.numel(), [None, k.view(torch.uint8)], 0, 0)
+        perm = amd.compute.sort_indices(karr).data[: k.numel() * 8].view(torch.int64)
+        out.append(g[perm])
+        assert k.numel() > total // (2 * P_), "splitters should balance the virtual ranks"
+    got = torch.cat(out).cpu().numpy().astype(np.uint64)
+    vals = np.concatenate([a.values[a.offset:a.offset + a.length] for a in shards])
+    valid = np.concatenate([np.ones(a.length, bool) if a.valid is None else a.valid[a.offset:a.offset + a.length] for a in shards])
+    want = O.sort_indices_64(np.ascontiguousarray(vals), O.pack_bits(valid), 0, len(vals))
+    n_valid = int(valid.sum())
+    assert (got == want[:n_valid]).all()        # nulls travel separately (row numbers only)
