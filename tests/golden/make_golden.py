@@ -42,6 +42,26 @@ for order in ("ascending", "descending"):
     for placement in ("at_end", "at_start"):
         out[f"sort_{order}_{placement}"] = pc.array_sort_indices(
             pa.array(sk, mask=~sv), order=order, null_placement=placement).to_numpy()
+# array_sort_indices on the other key types: NaNs are null-likes next to the nulls, -0.0 ties 0.0
+for name, dt in (("u32", np.uint32), ("i32", np.int32), ("f64", np.float64), ("f32", np.float32)):
+    if np.dtype(dt).kind == "f":
+        tk = rng.standard_normal(1500).astype(dt)
+        tk[::7] = np.nan
+        tk[::11] = 0.0
+        tk[1::11] = -0.0
+        tk[::13] = np.inf
+        tk[5::13] = -np.inf
+        tk[::3] = np.round(tk[::3])
+    else:
+        info = np.iinfo(dt)
+        tk = rng.integers(info.min, info.max, size=1500, dtype=dt, endpoint=True)
+        tk[::3] = tk[::3] % 9
+    tv = rng.random(1500) >= 0.1
+    out[f"tsort_{name}_keys"], out[f"tsort_{name}_valid"] = tk, tv
+    for order in ("ascending", "descending"):
+        for placement in ("at_end", "at_start"):
+            out[f"tsort_{name}_{order}_{placement}"] = pc.array_sort_indices(
+                pa.array(tk, mask=~tv), order=order, null_placement=placement).to_numpy()
 gk = rng.integers(-30, 30, size=4000).astype(np.int32)
 gkv = rng.random(4000) >= 0.03
 gv = rng.integers(-2**63, 2**63 - 1, size=4000, dtype=np.int64)

@@ -274,3 +274,38 @@ def test_oracle_vs_committed_pyarrow_fixtures():
                    for a, b, c, d in zip(z["gb_ref_isnull"], z["gb_ref_key"], z["gb_ref_valid"],
                                          z["gb_ref_sum"])), key=lambda r: (r[0], r[1]))
     assert got == want
+
+
+# ------------------------------------------------------------------ sort: other key types
+@pytest.mark.parametrize("name", ["u32", "i32", "f64", "f32"])
+def test_golden_typed_sort_fixture(name):
+    """Fixtures generated from the reference build (tests/golden/make_golden.py): 32-bit and
+    floating point keys, NaNs next to the nulls whatever the order, -0.0 tying with 0.0."""
+    z = np.load(os.path.join(HERE, "golden", "pyarrow_golden.npz"))
+    keys, valid = z[f"tsort_{name}_keys"], z[f"tsort_{name}_valid"]
+    for order in ("ascending", "descending"):
+        for placement in ("at_end", "at_start"):
+            got = O.sort_indices(np.ascontiguousarray(keys), O.pack_bits(valid), 0, len(keys),
+                                 descending=(order == "descending"), nulls_at_start=(placement == "at_start"))
+            assert (got == z[f"tsort_{name}_{order}_{placement}"]).all(), (name, order, placement)
+
+
+@pytest.mark.skipif(pc is None, reason="pyarrow wheel not importable")
+@pytest.mark.parametrize("dtype", [np.uint32, np.int32, np.float64, np.float32, np.uint64, np.int64])
+def test_typed_sort_vs_pyarrow(dtype):
+    rng = rng_for("tsortpin", str(dtype))
+    n = 20000
+    a = U.random_array(rng, dtype, n, null_p=0.07, offset=5)
+    if np.dtype(dtype).kind == "f":
+        a.values[::5] = np.nan
+        a.values[::9] = -0.0
+        a.values[1::9] = 0.0
+        a.values[::4] = np.round(a.values[::4])
+    else:
+        a.values[::4] = a.values[::4] % 21
+    for order in ("ascending", "descending"):
+        for placement in ("at_end", "at_start"):
+            got = O.sort_indices(np.ascontiguousarray(a.values), a.valid_bitmap(), a.offset, n,
+                                 descending=(order == "descending"), nulls_at_start=(placement == "at_start"))
+            ref = pc.array_sort_indices(a.to_pyarrow(), order=order, null_placement=placement).to_numpy()
+            assert (got == ref).all(), (dtype, order, placement)
