@@ -32,6 +32,7 @@ constexpr int kDigits = 256;
 constexpr int kMaxChunks = 16384;  // upper bound (sizes the histogram table)
 static int g_sort_msd = -1;            // -1 = auto (n >= g_sort_msd_min_rows), 0 = never, 1 = whenever possible
 static int g_sort_msd_min_rows = 1 << 22;
+static int g_sort_msd_sampled = 1;     // skewed keys: bucket boundaries from a sorted sample
 static int g_sort_msd_fused = 1;       // finish LDS-sized level-2 buckets in one workgroup (msd_bucket_kernel)
 static int64_t g_sort_msd_segment_rows = int64_t(1) << 27;  // above this: an extra top-bits level cuts segments
 static int g_sort_msd_global_bits = 14;  // (= kMsdMaxBits) cap of the two global levels (tests lower it to reach level 3)
@@ -427,6 +428,7 @@ struct MsdArgs {
   int64_t n;
   int bits, b1, b2, b3;       // bits = b1 + b2 (global levels), b3 = local level
   int kshift;                 // top bits already equal inside this segment: digits are taken from key << kshift
+  const uint64_t* spl;        // sampled-splitter mode: 2^bits - 1 ascending splitters (else NULL)
   int64_t chunk_rows, nchunks;
   uint32_t* part_count;       // [2^bits]
   uint32_t* part_start;       // [2^bits + 1]
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(kMsdThreads) void msd_hist_kernel(MsdArgs a) {
 
 // one workgroup: bucket starts (exclusive scan), level-1 starts, level-2 cursors + tile map
 __global__ __launch_bounds__(1024) void msd_scan_a_kernel(MsdArgs a) {
-  __shared__ uint32_t ps[(1 << kMsdMaxBits) + 1];
+  __shared__ uint32_t ps[(1 << 15) + 1];  // up to 2^15 buckets (sampled-splitter mode)
   __shared__ uint32_t wave_tot[16];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -573,12 +575,22 @@ struct __attribute__((aligned(16))) MsdScatterLds {
   uint32_t gbase[MAXBINS];
   uint32_t cursor[MAXBINS];
   uint32_t wave_tot[kMsdThreads / 64];
+  uint64_t spl[256];  // sampled-splitter mode: the nb - 1 splitters of this level / bucket
 };
+
+// number of splitters <= key (upper bound) among spl[0, nsp), nsp = 2^k - 1
+__device__ __forceinline__ uint32_t msd_search(const uint64_t* spl, int nsp, uint64_t key) {
+  uint32_t lo = 0;
+  for (int half = (nsp + 1) >> 1; half >= 1; half >>= 1) {
+    if (spl[lo + half - 1] <= key) lo += half;
+  }
+  return lo;
+}
 
 // Scatter one tile of <= 4096 (key, row id) pairs by digit = (key >> dshift) & (nb - 1).
 // MODE 0: run bases from lds.cursor (advanced per tile);  MODE 1: from a global cursor array
 // (one returning atomic per digit);  the destination arrays are absolute.
-template <bool RAW, int MODE, int MAXBINS>
+template <bool RAW, int MODE, int MAXBINS, bool SPL = false>
 __device__ __forceinline__ void msd_scatter_tile(const MsdArgs& a, MsdScatterLds<MAXBINS>& lds,
                                                  const uint64_t* __restrict__ kin,
                                                  const uint32_t* __restrict__ iin, int64_t row0,
@@ -609,7 +621,11 @@ __device__ __forceinline__ void msd_scatter_tile(const MsdArgs& a, MsdScatterLds
         key[i] = kin[row0 + p];
         idx[i] = iin[row0 + p];
       }
-      dig[i] = static_cast<int>(static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask);
+      if constexpr (SPL) {
+        dig[i] = static_cast<int>(msd_search(lds.spl, nb - 1, key[i]));
+      } else {
+        dig[i] = static_cast<int>(static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask);
+      }
     }
   }
 #pragma unroll
@@ -647,7 +663,8 @@ __device__ __forceinline__ void msd_scatter_tile(const MsdArgs& a, MsdScatterLds
   __syncthreads();
   for (int p = tid; p < nrows; p += kMsdThreads) {
     const uint64_t k = lds.keys[p];
-    const uint32_t d = static_cast<uint32_t>((k << a.kshift) >> dshift) & dmask;
+    const uint32_t d = SPL ? msd_search(lds.spl, nb - 1, k)
+                           : (static_cast<uint32_t>((k << a.kshift) >> dshift) & dmask);
     const uint32_t dst = dst0 + lds.gbase[d] + (static_cast<uint32_t>(p) - lds.start[d]);
     kout[dst] = k;
     iout[dst] = lds.idx[p];
@@ -692,6 +709,139 @@ __global__ __launch_bounds__(kMsdThreads, 6) void msd_scatter2_kernel(MsdArgs a)
   const int nrows = static_cast<int>(hi - row0 < kMsdTile ? hi - row0 : kMsdTile);
   msd_scatter_tile<false, 1, 128>(a, lds, a.keys_x, a.idx_x, row0, nrows, 1 << a.b2, 64 - a.bits,
                                   a.cursor2 + (static_cast<size_t>(p) << a.b2), 0u, a.keys_y, a.idx_y);
+}
+
+// ---------------------------------------------------------------- sampled-splitter mode
+// When the top bits are skewed (normally distributed floats, clustered ids) equal-width buckets
+// overflow.  Then the bucket boundaries come from the data: a regular sample of 32 keys per bucket
+// is sorted (LSD passes on <= 1M keys) and every 32nd becomes a splitter; bucket(key) = number of
+// splitters <= key, found by a 7/8-step search over the 127/255 splitters of one level held in LDS.
+//   S1 msd_sample        sample keys (jittered stride)
+//   S2 (LSD passes)      sort the sample;  msd_pick_splitters: every (m / 2^bits)-th
+//   S3 msd_hist1_s       level-1 counts per chunk (search among the 2^b1 - 1 level-1 splitters)
+//   S4 msd_scatter1_s    level 1;   msd_hist2_s: per level-1 bucket, counts of its 2^b2 sub-buckets
+//   S5 msd_scatter2_s    level 2;   msd_bucket<SPL>: sub-buckets by linear interpolation inside the
+//                        bucket's key range (monotonic, so sub-bucket order = key order)
+template <bool RAW>
+__global__ __launch_bounds__(kBlock) void msd_sample_kernel(MsdArgs a, int64_t m, uint64_t* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= m) return;
+  const int64_t stride = a.n / m;  // >= 4
+  const uint64_t jitter = (static_cast<uint64_t>(i) * 0x9E3779B97F4A7C15ull) >> 33;
+  const int64_t pos = i * stride + static_cast<int64_t>(jitter % static_cast<uint64_t>(stride));
+  out[i] = msd_load_key<RAW>(a, pos);
+}
+
+__global__ __launch_bounds__(kBlock) void msd_pick_splitters_kernel(const uint64_t* __restrict__ sorted,
+                                                                    int64_t m, int nparts,
+                                                                    uint64_t* __restrict__ spl) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j < nparts - 1) spl[j] = sorted[static_cast<int64_t>(j + 1) * (m / nparts)];
+}
+
+// level-1 histogram: like msd_hist with bits = b1, digit by search
+template <bool RAW>
+__global__ __launch_bounds__(kMsdThreads) void msd_hist1_s_kernel(MsdArgs a) {
+  __shared__ uint32_t h[256];
+  __shared__ uint64_t l1[256];
+  const int tid = threadIdx.x;
+  const int nb1 = 1 << a.b1;
+  const int per = 1 << a.b2;
+  if (tid < nb1) h[tid] = 0;
+  if (tid < nb1 - 1) l1[tid] = a.spl[(tid + 1) * per - 1];
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * a.chunk_rows;
+  const int64_t end = begin + a.chunk_rows < a.n ? begin + a.chunk_rows : a.n;
+  constexpr int U = 8;
+  int64_t r = begin + tid;
+  for (; r + (U - 1) * kMsdThreads < end; r += U * kMsdThreads) {
+    uint64_t kk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) kk[u] = msd_load_key<RAW>(a, r + u * kMsdThreads);
+#pragma unroll
+    for (int u = 0; u < U; ++u) atomicAdd(&h[msd_search(l1, nb1 - 1, kk[u])], 1u);
+  }
+  for (; r < end; r += kMsdThreads) atomicAdd(&h[msd_search(l1, nb1 - 1, msd_load_key<RAW>(a, r))], 1u);
+  __syncthreads();
+  if (tid < nb1) {
+    const uint32_t c = h[tid];
+    if (c != 0) atomicAdd(&a.part_count[tid], c);
+    a.hist1[static_cast<int64_t>(tid) * a.nchunks + blockIdx.x] = c;
+  }
+}
+
+template <bool RAW>
+__global__ __launch_bounds__(kMsdThreads, 6) void msd_scatter1_s_kernel(MsdArgs a) {
+  __shared__ MsdScatterLds<128> lds;
+  const int tid = threadIdx.x;
+  const int nb = 1 << a.b1;
+  const int per = 1 << a.b2;
+  if (tid < nb) lds.cursor[tid] = a.hist1[static_cast<int64_t>(tid) * a.nchunks + blockIdx.x];
+  if (tid < nb - 1) lds.spl[tid] = a.spl[(tid + 1) * per - 1];
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * a.chunk_rows;
+  const int64_t end = begin + a.chunk_rows < a.n ? begin + a.chunk_rows : a.n;
+  for (int64_t row0 = begin; row0 < end; row0 += kMsdTile) {
+    const int nrows = static_cast<int>(end - row0 < kMsdTile ? end - row0 : kMsdTile);
+    msd_scatter_tile<RAW, 0, 128, true>(a, lds, a.src_keys, a.src_idx, row0, nrows, nb, 0, nullptr, 0u,
+                                        a.keys_x, a.idx_x);
+  }
+}
+
+// which level-1 bucket owns tile g (shared by the level-2 kernels)
+__device__ __forceinline__ uint32_t msd_tile_owner(const MsdArgs& a, uint32_t g, uint32_t* part_s) {
+  const int tid = threadIdx.x;
+  const int nb1 = 1 << a.b1;
+  if (tid < 64) {
+    uint32_t below = 0;
+    for (int p = tid; p < nb1; p += 64) below += (a.l2_tile_start[p] <= g) ? 1u : 0u;
+    below = wave_reduce_sum_u32(below);
+    if (tid == 0) *part_s = below - 1;
+  }
+  __syncthreads();
+  return *part_s;
+}
+
+// level-2 counts: one tile of one level-1 bucket per workgroup -> part_count[p * 2^b2 + d]
+__global__ __launch_bounds__(kMsdThreads) void msd_hist2_s_kernel(MsdArgs a) {
+  __shared__ uint32_t h[256];
+  __shared__ uint64_t l2[256];
+  __shared__ uint32_t part_s;
+  const int tid = threadIdx.x;
+  const int nb1 = 1 << a.b1;
+  const int nb2 = 1 << a.b2;
+  const uint32_t g = blockIdx.x;
+  if (g >= a.l2_tile_start[nb1]) return;
+  const uint32_t p = msd_tile_owner(a, g, &part_s);
+  if (tid < nb2) h[tid] = 0;
+  if (tid < nb2 - 1) l2[tid] = a.spl[(static_cast<size_t>(p) << a.b2) + tid];
+  __syncthreads();
+  const int64_t lo = a.l1_start[p];
+  const int64_t hi = a.l1_start[p + 1];
+  const int64_t row0 = lo + static_cast<int64_t>(g - a.l2_tile_start[p]) * kMsdTile;
+  const int64_t end = row0 + kMsdTile < hi ? row0 + kMsdTile : hi;
+  for (int64_t r = row0 + tid; r < end; r += kMsdThreads) atomicAdd(&h[msd_search(l2, nb2 - 1, a.keys_x[r])], 1u);
+  __syncthreads();
+  if (tid < nb2 && h[tid] != 0) atomicAdd(&a.part_count[(static_cast<size_t>(p) << a.b2) + tid], h[tid]);
+}
+
+__global__ __launch_bounds__(kMsdThreads) void msd_scatter2_s_kernel(MsdArgs a) {
+  __shared__ MsdScatterLds<256> lds;
+  __shared__ uint32_t part_s;
+  const int tid = threadIdx.x;
+  const int nb1 = 1 << a.b1;
+  const int nb2 = 1 << a.b2;
+  const uint32_t g = blockIdx.x;
+  if (g >= a.l2_tile_start[nb1]) return;
+  const uint32_t p = msd_tile_owner(a, g, &part_s);
+  if (tid < nb2 - 1) lds.spl[tid] = a.spl[(static_cast<size_t>(p) << a.b2) + tid];
+  __syncthreads();
+  const int64_t lo = a.l1_start[p];
+  const int64_t hi = a.l1_start[p + 1];
+  const int64_t row0 = lo + static_cast<int64_t>(g - a.l2_tile_start[p]) * kMsdTile;
+  const int nrows = static_cast<int>(hi - row0 < kMsdTile ? hi - row0 : kMsdTile);
+  msd_scatter_tile<false, 1, 256, true>(a, lds, a.keys_x, a.idx_x, row0, nrows, nb2, 0,
+                                        a.cursor2 + (static_cast<size_t>(p) << a.b2), 0u, a.keys_y, a.idx_y);
 }
 
 // level 3: one workgroup per level-2 bucket, (keys_y, idx_y) -> (keys_x, idx_x) inside the
@@ -827,6 +977,7 @@ struct __attribute__((aligned(16))) MsdBucketLds {
   uint32_t wave_tot[kBktThreads / 64];
 };
 
+template <bool SPL>
 __global__ __launch_bounds__(kBktThreads) void msd_bucket_kernel(MsdArgs a, const uint64_t* __restrict__ keys,
                                                                  const uint32_t* __restrict__ idx) {
   __shared__ MsdBucketLds w;
@@ -844,6 +995,24 @@ __global__ __launch_bounds__(kBktThreads) void msd_bucket_kernel(MsdArgs a, cons
   const int nb = 1 << a.b3;
   const int dshift = 64 - a.bits - a.b3;
   const uint32_t dmask = static_cast<uint32_t>(nb - 1);
+  // sampled-splitter mode: sub-bucket = linear interpolation inside [lo, hi), the bucket's key range
+  uint64_t klo = 0;
+  double kinv = 0.0;
+  if constexpr (SPL) {
+    const uint32_t nparts = 1u << a.bits;
+    klo = q > 0 ? a.spl[q - 1] : 0;
+    const uint64_t khi = q + 1 < nparts ? a.spl[q] : ~uint64_t(0);
+    const double range = static_cast<double>(khi - klo) + 1.0;
+    kinv = static_cast<double>(nb) / range;
+  }
+  auto digit_of = [&](uint64_t k) -> uint32_t {
+    if constexpr (SPL) {
+      const uint32_t d = static_cast<uint32_t>(static_cast<double>(k - klo) * kinv);
+      return d < static_cast<uint32_t>(nb) ? d : static_cast<uint32_t>(nb - 1);
+    } else {
+      return a.b3 == 0 ? 0u : (static_cast<uint32_t>((k << a.kshift) >> dshift) & dmask);
+    }
+  };
   for (int i = tid; i < nb; i += kBktThreads) w.cnt[i] = 0;
   __syncthreads();
   uint64_t key[kBktRows];
@@ -858,7 +1027,7 @@ __global__ __launch_bounds__(kBktThreads) void msd_bucket_kernel(MsdArgs a, cons
     if (p < m) {
       key[i] = keys[lo + p];
       id[i] = idx[lo + p];
-      dig[i] = a.b3 == 0 ? 0 : static_cast<int>(static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask);
+      dig[i] = static_cast<int>(digit_of(key[i]));
     }
   }
 #pragma unroll
@@ -891,7 +1060,7 @@ __global__ __launch_bounds__(kBktThreads) void msd_bucket_kernel(MsdArgs a, cons
   for (int i = tid; i < m; i += kBktThreads) {
     const uint64_t ki = w.keys[i];
     const uint32_t ii = w.idx[i];
-    const uint32_t d = a.b3 == 0 ? 0u : (static_cast<uint32_t>((ki << a.kshift) >> dshift) & dmask);
+    const uint32_t d = digit_of(ki);
     const int bs = static_cast<int>(w.start[d]);
     const int be = static_cast<int>(w.start[d + 1]);
     int rank = 0;
@@ -915,7 +1084,9 @@ __global__ __launch_bounds__(kBktThreads) void msd_bucket_kernel(MsdArgs a, cons
 }
 
 // part_count + part_start + cursor2 (2^14 + 1 each), hist1 (128 x 2048), l1_start, l2_tile_start, flag
-constexpr size_t kMsdTableBytes = (3 * ((size_t(1) << kMsdMaxBits) + 64) + size_t(128) * kMsdMaxChunks + 2 * 192 + 64) * 4;
+constexpr int kMsdSplBits = 15;  // sampled-splitter mode: up to 2^15 buckets
+constexpr size_t kMsdTableWords = (size_t(1) << kMsdSplBits) + 64;
+constexpr size_t kMsdTableBytes = (3 * kMsdTableWords + size_t(128) * kMsdMaxChunks + 2 * 192 + 64) * 4 + (size_t(1) << kMsdSplBits) * 8;
 
 struct SortPlan {
   int64_t n;          // rows to sort (non-null)
@@ -952,6 +1123,10 @@ static SortPlan make_plan(int64_t length) {
 int set_sort_option(const char* name, int64_t value) {
   if (strcmp(name, "sort_msd") == 0) {
     g_sort_msd = value < 0 ? -1 : (value != 0);
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_sampled") == 0) {
+    g_sort_msd_sampled = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 2)));
     return 1;
   }
   if (strcmp(name, "sort_msd_fused") == 0) {
@@ -1008,7 +1183,7 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   const int64_t chunk_tiles = std::max<int64_t>(1, ceil_div(ntiles, kMsdMaxChunks));
   a.chunk_rows = chunk_tiles * kMsdTile;
   a.nchunks = ceil_div(ntiles, chunk_tiles);
-  const size_t np = (size_t(1) << kMsdMaxBits) + 64;
+  const size_t np = kMsdTableWords;
   uint32_t* t = reinterpret_cast<uint32_t*>(tables);
   a.part_count = t;
   a.part_start = t + np;
@@ -1059,8 +1234,8 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   // level-2 buckets that fit LDS: finish each one in a single workgroup (b3 may use 10 bits there)
   if (fused) {
     a.b3 = std::max(0, std::min(std::min(lg - 3 - a.bits, 10), 64 - kshift - a.bits));  // ~8 rows per sub-bucket
-    hipLaunchKernelGGL(msd_bucket_kernel, dim3(static_cast<unsigned>(nparts)), dim3(kBktThreads), 0, st, a, keys_y,
-                       idx_y);
+    hipLaunchKernelGGL((msd_bucket_kernel<false>), dim3(static_cast<unsigned>(nparts)), dim3(kBktThreads), 0, st, a,
+                       keys_y, idx_y);
     ARX_CHECK_LAUNCH("msd_bucket_kernel");
   } else {
     const uint64_t* fk = keys_y;
@@ -1082,6 +1257,140 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   return ARX_OK;
 }
 
+
+// The sampled-splitter pipeline (n <= 2^27 + slack rows, >= 2^18).  `lsd_*` = scratch of the LSD
+// kernels used to sort the sample.  Synchronous.
+static int run_msd_sort_sampled(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n,
+                                uint64_t* keys_x, uint32_t* idx_x, uint64_t* keys_y, uint32_t* idx_y,
+                                uint8_t* tables, uint32_t* lsd_hist, uint32_t* lsd_totals, uint64_t* out_final,
+                                hipStream_t st, int* overflowed) {
+  *overflowed = 0;
+  if (n == 0) return ARX_OK;
+  int bits = 2;
+  while (bits < kMsdSplBits && (n >> bits) > 4096) ++bits;
+  if ((n >> bits) > 6144) {  // even 2^15 buckets would average too close to the LDS capacity
+    *overflowed = 1;
+    return ARX_OK;
+  }
+  const int nparts = 1 << bits;
+  int64_t m = 32 * static_cast<int64_t>(nparts);   // sample size: 32 keys per bucket
+  while (m * 4 > n && m > nparts) m >>= 1;
+  if (m * 4 > n) {
+    *overflowed = 1;
+    return ARX_OK;
+  }
+  MsdArgs a{};
+  a.src_keys = src_keys;
+  a.src_idx = src_idx;
+  a.raw = raw;
+  a.n = n;
+  a.kshift = 0;
+  a.bits = bits;
+  a.b2 = std::min(8, bits / 2 + (bits & 1));
+  a.b1 = bits - a.b2;            // <= 7
+  int per_bucket_lg = 0;
+  while ((int64_t(8) << per_bucket_lg) < (n >> bits) && per_bucket_lg < 10) ++per_bucket_lg;
+  a.b3 = per_bucket_lg;          // ~8 rows per interpolated sub-bucket
+  const int64_t ntiles = ceil_div(n, kMsdTile);
+  const int64_t chunk_tiles = std::max<int64_t>(1, ceil_div(ntiles, kMsdMaxChunks));
+  a.chunk_rows = chunk_tiles * kMsdTile;
+  a.nchunks = ceil_div(ntiles, chunk_tiles);
+  const size_t np = kMsdTableWords;
+  uint32_t* t = reinterpret_cast<uint32_t*>(tables);
+  a.part_count = t;
+  a.part_start = t + np;
+  a.cursor2 = t + 2 * np;
+  a.hist1 = t + 3 * np;
+  a.l1_start = a.hist1 + size_t(128) * kMsdMaxChunks;
+  a.l2_tile_start = a.l1_start + 192;
+  a.overflow = a.l2_tile_start + 192;
+  uint64_t* spl = reinterpret_cast<uint64_t*>(a.overflow + 64);
+  a.spl = spl;
+  a.keys_x = keys_x;
+  a.idx_x = idx_x;
+  a.keys_y = keys_y;
+  a.idx_y = idx_y;
+  a.out_final = out_final;
+
+  // ---- S1/S2: sample, sort the sample with the LSD kernels (scratch: the not-yet-used x buffers)
+  // (x is written by level 1 only after the splitters have been picked; y may alias the source)
+  uint64_t* s0 = keys_x;
+  uint64_t* s1 = keys_x + m;
+  uint32_t* i0 = idx_x;
+  uint32_t* i1 = idx_x + m;
+  const unsigned gs = static_cast<unsigned>(ceil_div(m, kBlock));
+  if (raw) {
+    hipLaunchKernelGGL((msd_sample_kernel<true>), dim3(gs), dim3(kBlock), 0, st, a, m, s0);
+  } else {
+    hipLaunchKernelGGL((msd_sample_kernel<false>), dim3(gs), dim3(kBlock), 0, st, a, m, s0);
+  }
+  ARX_CHECK_LAUNCH("msd_sample_kernel");
+  {
+    const int64_t stiles = ceil_div(m, kSortTile);
+    const int64_t sct = std::max<int64_t>(1, ceil_div(stiles, g_sort_chunks));
+    const int64_t snch = ceil_div(stiles, sct);
+    for (int pass = 0; pass < 8; ++pass) {
+      hipLaunchKernelGGL(radix_hist_kernel, dim3(static_cast<unsigned>(snch)), dim3(kBlock), 0, st, s0, m, pass * 8,
+                         sct * kSortTile, snch, lsd_hist, 0);
+      hipLaunchKernelGGL(radix_digit_totals_kernel, dim3(kDigits), dim3(64), 0, st, lsd_hist, snch, lsd_totals);
+      hipLaunchKernelGGL(radix_scan_kernel, dim3(kDigits), dim3(64), 0, st, lsd_hist, snch, lsd_totals);
+      hipLaunchKernelGGL((radix_scatter_kernel<false>), dim3(static_cast<unsigned>(snch)), dim3(kBlock), 0, st, s0,
+                         i0, m, pass * 8, sct, snch, lsd_hist, s1, i1, static_cast<uint64_t*>(nullptr), 0, 0);
+      std::swap(s0, s1);
+      std::swap(i0, i1);
+    }
+    ARX_CHECK_LAUNCH("sample sort");
+  }
+  hipLaunchKernelGGL(msd_pick_splitters_kernel, dim3(static_cast<unsigned>(ceil_div(nparts, kBlock))), dim3(kBlock),
+                     0, st, s0, m, nparts, spl);
+  ARX_CHECK_LAUNCH("msd_pick_splitters_kernel");
+
+  // ---- S3/S4: level 1
+  MsdArgs a1 = a;   // the scan kernels see level 1 as a single-level plan
+  a1.bits = a.b1;
+  a1.b2 = 0;
+  const unsigned nch = static_cast<unsigned>(a.nchunks);
+  const int nb1 = 1 << a.b1;
+  ARX_HIP(hipMemsetAsync(a.part_count, 0, static_cast<size_t>(nb1) * 4, st));
+  ARX_HIP(hipMemsetAsync(a.overflow, 0, 8, st));
+  if (raw) {
+    hipLaunchKernelGGL((msd_hist1_s_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((msd_hist1_s_kernel<false>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  }
+  hipLaunchKernelGGL(msd_scan_a_kernel, dim3(1), dim3(1024), 0, st, a1);
+  hipLaunchKernelGGL(msd_scan_b_kernel, dim3(static_cast<unsigned>(nb1)), dim3(64), 0, st, a1);
+  if (raw) {
+    hipLaunchKernelGGL((msd_scatter1_s_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((msd_scatter1_s_kernel<false>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  }
+  ARX_CHECK_LAUNCH("msd sampled level 1");
+
+  // ---- level-2 counts, bucket starts, cursors; bail out if a bucket cannot fit LDS
+  const unsigned grid2 = static_cast<unsigned>(ceil_div(n, kMsdTile) + nb1);
+  ARX_HIP(hipMemsetAsync(a.part_count, 0, static_cast<size_t>(nparts) * 4, st));
+  hipLaunchKernelGGL(msd_hist2_s_kernel, dim3(grid2), dim3(kMsdThreads), 0, st, a);
+  hipLaunchKernelGGL(msd_scan_a_kernel, dim3(1), dim3(1024), 0, st, a);
+  ARX_CHECK_LAUNCH("msd sampled level-2 counts");
+  unsigned int max_part = 0;
+  ARX_HIP(hipMemcpyAsync(&max_part, a.overflow + 1, 4, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  if (max_part > static_cast<unsigned int>(kBktCap)) {  // > 10240 copies of one key, typically
+    *overflowed = 1;
+    return ARX_OK;
+  }
+  hipLaunchKernelGGL(msd_scatter2_s_kernel, dim3(grid2), dim3(kMsdThreads), 0, st, a);
+  ARX_CHECK_LAUNCH("msd_scatter2_s_kernel");
+  hipLaunchKernelGGL((msd_bucket_kernel<true>), dim3(static_cast<unsigned>(nparts)), dim3(kBktThreads), 0, st, a,
+                     keys_y, idx_y);
+  ARX_CHECK_LAUNCH("msd_bucket_kernel");
+  unsigned int flag = 0;
+  ARX_HIP(hipMemcpyAsync(&flag, a.overflow, 4, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  *overflowed = flag != 0;
+  return ARX_OK;
+}
 
 // Inputs beyond ~2^28 rows: one extra unstable level on the top b0 bits cuts the array into
 // 2^b0 segments of ~2^27 rows (32 B/row), then every segment runs the pipeline above on the bits
@@ -1105,7 +1414,7 @@ static int run_msd_sort_segmented(const uint64_t* src_keys, const uint32_t* src_
   const int64_t chunk_tiles = std::max<int64_t>(1, ceil_div(ntiles, kMsdMaxChunks));
   a.chunk_rows = chunk_tiles * kMsdTile;
   a.nchunks = ceil_div(ntiles, chunk_tiles);
-  const size_t np = (size_t(1) << kMsdMaxBits) + 64;
+  const size_t np = kMsdTableWords;
   uint32_t* t = reinterpret_cast<uint32_t*>(tables);
   a.part_count = t;
   a.part_start = t + np;
@@ -1275,7 +1584,7 @@ int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_pl
                        (g_sort_msd == 1 ? n_valid >= 256 : n_valid >= g_sort_msd_min_rows);
   const bool segmented = n_valid > g_sort_msd_segment_rows;
   const unsigned gprep = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_valid, kBlock), 2048));
-  if (try_msd) {
+  if (try_msd && g_sort_msd_sampled != 2) {
     uint8_t* tables = w + plan.off_msd;
     int overflowed = 0;
     int rc;
@@ -1296,6 +1605,29 @@ int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_pl
     }
     if (rc != ARX_OK) return rc;
     if (!overflowed) return ARX_OK;
+  }
+  // skewed top bits: bucket boundaries from a sorted sample instead of equal-width prefixes
+  // (sort_msd_sampled = 2 forces this form first, for the tests)
+  // (32-bit keys: their 4 LSD passes measured faster than this form, 5.2 vs 7.4 ms at 2^27 rows)
+  if ((try_msd || g_sort_msd_sampled == 2) && g_sort_msd_sampled != 0 && (key_width == 8 || g_sort_msd_sampled == 2)) {
+    uint8_t* tables = w + plan.off_msd;
+    int overflowed = 0;
+    int rc = ARX_OK;
+    if (n_valid >= (g_sort_msd_sampled == 2 ? 1024 : (int64_t(1) << 18)) && n_valid <= (int64_t(3) << 26)) {
+      if (valid_rows == nullptr) {
+        rc = run_msd_sort_sampled(reinterpret_cast<const uint64_t*>(vals), nullptr, xf, n_valid, keys_a, idx_a,
+                                  keys_b, idx_b, tables, hist, totals, final_dst, st, &overflowed);
+      } else {
+        hipLaunchKernelGGL(sort_prep_kernel, dim3(gprep), dim3(kBlock), 0, st, vals, valid_rows, n_valid, xf, 0,
+                           keys_a, idx_a);
+        ARX_CHECK_LAUNCH("sort_prep_kernel");
+        // source = (keys_a, idx_a); x = (keys_b, idx_b) also hosts the sample; y may reuse the source
+        rc = run_msd_sort_sampled(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables, hist, totals,
+                                  final_dst, st, &overflowed);
+      }
+      if (rc != ARX_OK) return rc;
+      if (!overflowed) return ARX_OK;
+    }
   }
 
   // ---- LSD passes over (key, row id) pairs.  With no null-likes the first pass reads the caller's

@@ -600,3 +600,31 @@ def test_sort_virtual_ranks_on_one_gpu(gpu_ctx):
     want = O.sort_indices_64(np.ascontiguousarray(vals), O.pack_bits(valid), 0, len(vals))
     n_valid = int(valid.sum())
     assert (got == want[:n_valid]).all()        # nulls travel separately (row numbers only)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.uint64, np.int32])
+def test_sort_msd_sampled_splitters(gpu_ctx, dtype):
+    """The sampled-splitter form of the MSD sort forced on: skewed keys (normal floats, clustered
+    integers), duplicates-heavy columns (a bucket overflows -> LSD fallback), nulls, descending."""
+    lib = gpu_ctx._lib.get_lib()
+    assert lib.arx_set_option(b"sort_msd_sampled", 2) == 0
+    try:
+        rng = rng_for("sampled", str(dtype))
+        n = 4000003
+        for order, placement, null_p in (("ascending", "at_end", 0.0), ("descending", "at_start", 0.04)):
+            a = U.random_array(rng, dtype, n, null_p=null_p, offset=1)
+            v = a.values
+            if np.dtype(dtype).kind == "f":
+                v[::50] = np.nan
+                v[::17] = -0.0
+            elif np.dtype(dtype) == np.uint64:
+                v[:] = (np.abs(rng.standard_normal(len(v))) * 1e6).astype(np.uint64) + (v % 3) * 10**12   # clustered
+            else:
+                v[:] = (rng.standard_normal(len(v)) * 1000).astype(np.int32)                               # many ties
+            P.check_sort_indices(gpu_ctx, a, order, placement, use_pyarrow=(order == "ascending"))
+        dup = U.random_array(rng, dtype, n, lo=None if np.dtype(dtype).kind == "f" else 0, hi=None if np.dtype(dtype).kind == "f" else 3)
+        if np.dtype(dtype).kind == "f":
+            dup.values[:] = np.round(dup.values)
+        P.check_sort_indices(gpu_ctx, dup, "ascending", "at_end", use_pyarrow=False)
+    finally:
+        lib.arx_set_option(b"sort_msd_sampled", 1)
