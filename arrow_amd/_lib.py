@@ -73,8 +73,22 @@ class ArxSpan(C.Structure):
     ]
 
 
+class ArxBinarySpan(C.Structure):
+    """struct ArxBinarySpan of include/arrow_amd.h (binary / utf8 values, int32 offsets)."""
+
+    _fields_ = [
+        ("validity", C.c_void_p),
+        ("offsets", C.c_void_p),
+        ("data", C.c_void_p),
+        ("offset", C.c_int64),
+        ("length", C.c_int64),
+        ("null_count", C.c_int64),
+    ]
+
+
 _p, _i64, _int, _u64, _u32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_uint32, C.c_size_t
 _span = C.POINTER(ArxSpan)
+_bspan = C.POINTER(ArxBinarySpan)
 
 # name -> (restype, argtypes); must list every symbol declared in include/arrow_amd.h
 SIGNATURES = {
@@ -90,6 +104,9 @@ SIGNATURES = {
     "arx_take_workspace_bytes": (_sz, []),
     "arx_check_index_bounds": (_int, [_span, _int, _u64, _p, _sz, _p]),
     "arx_take": (_int, [_span, _int, _span, _int, _p, _p, _p, _p]),
+    "arx_binary_take_workspace_bytes": (_sz, [_i64]),
+    "arx_binary_take_offsets": (_int, [_bspan, _span, _int, _p, _sz, _p, _p, _p, C.POINTER(_i64), _p]),
+    "arx_binary_take_data": (_int, [_bspan, _span, _int, _p, _p, _p]),
     "arx_cast_f64_f32": (_int, [_p, _i64, _p, _p]),
     "arx_greater_f64": (_int, [_p, _p, _i64, _p, _p]),
     "arx_greater_f64_array_scalar": (_int, [_p, C.c_double, _i64, _p, _p]),

@@ -79,10 +79,20 @@ uint64 = DataType("uint64", 64, np.uint64)
 float32 = DataType("float", 32, np.float32)
 float64 = DataType("double", 64, np.float64)
 
+# base binary types (int32 offsets): buffers = [validity, offsets, data]
+binary = DataType("binary", 0, None)
+utf8 = DataType("string", 0, None)
+string = utf8
+
 _ALL_TYPES = [bool_, int8, uint8, int16, uint16, int32, uint32, int64, uint64, float32, float64]
 _BY_NAME = {t.name: t for t in _ALL_TYPES}
-_BY_NAME.update({"float32": float32, "float64": float64, "boolean": bool_})
+_BY_NAME.update({"float32": float32, "float64": float64, "boolean": bool_, "binary": binary,
+                 "string": utf8, "utf8": utf8})
 _BY_NP = {t.np_dtype: t for t in _ALL_TYPES}
+
+
+def is_base_binary(t: DataType) -> bool:
+    return t.name in ("binary", "string")
 
 # index type ids of include/arrow_amd.h
 INDEX_TYPE_ID = {"uint8": 0, "int8": 1, "uint16": 2, "int16": 3, "uint32": 4, "int32": 5,
@@ -196,6 +206,12 @@ class Array:
         return _lib.ArxSpan(_ptr(self.buffers[0]), _ptr(self.buffers[1]), self.offset, self.length,
                             self.null_count)
 
+    def binary_span(self) -> _lib.ArxBinarySpan:
+        """ArxBinarySpan of a binary / utf8 array (buffers = [validity, offsets, data])."""
+        assert is_base_binary(self.type)
+        return _lib.ArxBinarySpan(_ptr(self.buffers[0]), _ptr(self.buffers[1]), _ptr(self.buffers[2]),
+                                  self.offset, self.length, self.null_count)
+
     def values_ptr(self) -> int:
         """Device address of logical element 0 (fixed-width, non-boolean types)."""
         assert self.type.bit_width >= 8
@@ -246,6 +262,16 @@ class Array:
         t = type_from_name(str(arr.type))
         vb, db = arr.buffers()[0], arr.buffers()[1]
         n, off = len(arr), arr.offset
+        if is_base_binary(t):
+            offs = np.frombuffer(db, dtype=np.int32)[: off + n + 1] if db is not None else np.zeros(1, np.int32)
+            nbytes = int(offs[-1]) if len(offs) else 0
+            bb = arr.buffers()[2]
+            host = np.frombuffer(bb, dtype=np.uint8)[:nbytes] if bb is not None and nbytes else np.zeros(0, np.uint8)
+            vbuf = None
+            if vb is not None:
+                vbuf = to_device(np.frombuffer(vb, dtype=np.uint8)[: (off + n + 7) // 8], device)
+            return Array(t, n, [vbuf, to_device(offs, device), to_device(host, device)],
+                         arr.null_count if vb is not None else 0, off)
         if t == bool_:
             need = (off + n + 7) // 8
         else:
@@ -276,11 +302,24 @@ class Array:
     def to_pyarrow(self):
         import pyarrow as pa
 
+        if is_base_binary(self.type):
+            offs = self.buffers[1].cpu().numpy().view(np.int32)[: self.offset + self.length + 1]
+            nbytes = int(offs[-1]) if len(offs) else 0
+            data = self.buffers[2].cpu().numpy()[:nbytes] if self.buffers[2] is not None else np.zeros(0, np.uint8)
+            vb = None
+            if self.buffers[0] is not None:
+                vb = pa.py_buffer(self.buffers[0].cpu().numpy()[: (self.offset + self.length + 7) // 8].tobytes())
+            pt = pa.binary() if self.type.name == "binary" else pa.string()
+            return pa.Array.from_buffers(pt, self.length,
+                                         [vb, pa.py_buffer(offs.tobytes()), pa.py_buffer(data.tobytes())],
+                                         offset=self.offset)
         values, valid = self.to_numpy()
         mask = None if valid is None else ~valid
         return pa.array(values, type=pa.type_for_alias(_PA_ALIAS[self.type.name]), mask=mask)
 
     def to_pylist(self):
+        if is_base_binary(self.type):
+            return self.to_pyarrow().to_pylist()
         values, valid = self.to_numpy()
         if valid is None:
             return values.tolist()

@@ -237,6 +237,58 @@ def _exec_array_take(args, options):
     return out
 
 
+def _exec_binary_take(args, options):
+    """TakeExec for base binary (vector_selection_take_internal.cc, VarBinary take): offsets,
+    validity and the byte total first (the reference grows a builder), then the bytes."""
+    values, indices = args
+    options = options or TakeOptions()
+    if indices.type.name not in INDEX_TYPE_ID:
+        raise ArrowNotImplementedError(f"take: unsupported index type {indices.type.name}")
+    dev = values.device
+    lib, stream = _lib_and_stream(dev)
+    tid = INDEX_TYPE_ID[indices.type.name]
+    ispan, vspan = indices.span(), values.binary_span()
+    if options.boundscheck:
+        ws = _workspace(dev, lib.arx_take_workspace_bytes(), "take")
+        check(lib.arx_check_index_bounds(C.byref(ispan), tid, values.length, ws.data_ptr(), ws.numel(),
+                                         stream))
+    m = indices.length
+    allocate_validity = values.may_have_nulls() or indices.may_have_nulls()
+    out_offsets = alloc((m + 1) * 4, dev)
+    out_valid = alloc(bitmap_nbytes(m), dev) if allocate_validity else None
+    counter = torch.zeros(8, dtype=torch.uint8, device=dev) if allocate_validity else None
+    ws = _workspace(dev, lib.arx_binary_take_workspace_bytes(m), "binary_take")
+    total = C.c_int64(0)
+    with tracing.span("arx_binary_take_offsets"):
+        check(lib.arx_binary_take_offsets(C.byref(vspan), C.byref(ispan), tid, ws.data_ptr(), ws.numel(),
+                                          out_offsets.data_ptr(),
+                                          None if out_valid is None else out_valid.data_ptr(),
+                                          None if counter is None else counter.data_ptr(),
+                                          C.byref(total), stream))
+    out_data = alloc(total.value, dev)
+    with tracing.span("arx_binary_take_data"):
+        check(lib.arx_binary_take_data(C.byref(vspan), C.byref(ispan), tid, out_offsets.data_ptr(),
+                                       out_data.data_ptr() if total.value else None, stream))
+    out = Array(values.type, m, [out_valid, out_offsets, out_data], 0, 0)
+    if allocate_validity:
+        out.set_lazy_null_count(_LazyCount(m, counter))
+    return out
+
+
+def _exec_binary_filter(args, options):
+    """BinaryFilterImpl (vector_selection_filter_internal.cc:517-800) as take(GetTakeIndices(mask)):
+    the same output by construction (GetTakeIndices emits exactly the slots the filter keeps, with
+    nulls for EMIT_NULL)."""
+    values, mask = args
+    options = options or FilterOptions()
+    if mask.type != bool_:
+        raise ArrowNotImplementedError("filter: the selection must be a boolean array")
+    if values.length != mask.length:
+        raise ArrowInvalid("Array arguments must all be the same length")
+    indices = get_take_indices(mask, options.null_selection_behavior)
+    return _exec_binary_take([values, indices], TakeOptions(boundscheck=False))
+
+
 def _exec_cast_f64_f32(args, options):
     """CastFloatingToFloating (scalar_cast_numeric.cc:56-60) under ScalarExecutor."""
     (arr,) = args
@@ -541,6 +593,7 @@ class RecordBatch:
 
 _FIXED_WIDTH = lambda t: t.bit_width >= 8  # noqa: E731
 _INTEGER = lambda t: t.name in INDEX_TYPE_ID  # noqa: E731
+_BASE_BINARY = lambda t: t.name in ("binary", "string")  # noqa: E731
 
 
 def _filter_meta(args, options):
@@ -603,11 +656,13 @@ def _build_registry() -> FunctionRegistry:
 
     f = Function("array_filter", Function.VECTOR, 2, FilterOptions())
     f.add_kernel(Kernel((_FIXED_WIDTH, bool_), _exec_array_filter))
+    f.add_kernel(Kernel((_BASE_BINARY, bool_), _exec_binary_filter))
     reg.add_function(f)
     reg.add_function(Function("filter", Function.META, 2, FilterOptions(), _filter_meta))
 
     f = Function("array_take", Function.VECTOR, 2, TakeOptions())
     f.add_kernel(Kernel((_FIXED_WIDTH, _INTEGER), _exec_array_take))
+    f.add_kernel(Kernel((_BASE_BINARY, _INTEGER), _exec_binary_take))
     reg.add_function(f)
     reg.add_function(Function("take", Function.META, 2, TakeOptions(), _take_meta))
 

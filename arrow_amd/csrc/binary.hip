@@ -1,0 +1,286 @@
+// Take (and therefore Filter) on base-binary values — binary / utf8 with int32 offsets — for gfx950.
+//
+// What it restates (semantics only):
+//   TakeExec for base binary / VarBinaryTakeImpl   cpp/src/arrow/compute/kernels/vector_selection_take_internal.cc
+//   BinaryFilterImpl (filter == take of GetTakeIndices for these types)
+//                                                  cpp/src/arrow/compute/kernels/vector_selection_filter_internal.cc:517-800
+// Out slot i is valid iff index i is valid and the source value is valid; a valid slot appends
+// the source bytes, a null slot appends nothing; out offsets start at 0.
+//
+// Data layout: Arrow's variable-size binary layout as is (validity bitmap, int32 offsets[n+1],
+// data bytes; docs/source/format/Columnar.rst).  Three kernels + one copy:
+//   bin_lengths   : length of every output slot (0 for null slots), output validity by ballot,
+//                   per-workgroup byte totals (64-bit)
+//   bin_scan_blocks: exclusive scan of the workgroup totals (one workgroup)
+//   bin_offsets   : exclusive scan inside each workgroup's 4096 slots + its base -> out offsets
+//   bin_copy      : one thread per output slot copies its bytes (consecutive slots write
+//                   consecutive ranges)
+#include "arx_common.h"
+
+#include <algorithm>
+
+namespace arx {
+
+constexpr int kBinRows = kBlock * 16;  // output slots per workgroup
+
+struct BinTakeArgs {
+  const int32_t* offsets;   // element 0 of the logical values array
+  const uint8_t* data;
+  const uint8_t* src_valid_bytes;  // source validity bitmap bytes or NULL
+  int64_t src_valid_offset;
+  const uint8_t* indices;   // pre-offset to element 0
+  int index_type;
+  Bits ivalid;
+  int64_t length;           // number of indices
+};
+
+__device__ __forceinline__ uint64_t bin_load_index(const uint8_t* p, int type, int64_t i) {
+  switch (type) {
+    case ARX_UINT8: return p[i];
+    case ARX_INT8: return static_cast<uint8_t>(reinterpret_cast<const int8_t*>(p)[i]);
+    case ARX_UINT16: return reinterpret_cast<const uint16_t*>(p)[i];
+    case ARX_INT16: return static_cast<uint16_t>(reinterpret_cast<const int16_t*>(p)[i]);
+    case ARX_UINT32: return reinterpret_cast<const uint32_t*>(p)[i];
+    case ARX_INT32: return static_cast<uint32_t>(reinterpret_cast<const int32_t*>(p)[i]);
+    default: return reinterpret_cast<const uint64_t*>(p)[i];
+  }
+}
+
+// slot i: is it valid, and which source row
+__device__ __forceinline__ bool bin_slot(const BinTakeArgs& a, int64_t i, uint64_t* idx) {
+  bool ok = (load_word(a.ivalid, i >> 6) >> (i & 63)) & 1ull;
+  *idx = 0;
+  if (ok) {
+    *idx = bin_load_index(a.indices, a.index_type, i);
+    if (a.src_valid_bytes != nullptr) {
+      const uint64_t bit = static_cast<uint64_t>(a.src_valid_offset) + *idx;
+      ok = (a.src_valid_bytes[bit >> 3] >> (bit & 7)) & 1;
+    }
+  }
+  return ok;
+}
+
+__global__ __launch_bounds__(kBlock) void bin_lengths_kernel(BinTakeArgs a, int32_t* __restrict__ lens,
+                                                             uint64_t* __restrict__ out_validity,
+                                                             unsigned long long* __restrict__ valid_count,
+                                                             long long* __restrict__ block_sums) {
+  __shared__ long long wave_sum[kWavesPerBlock];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kBinRows;
+  long long mine = 0;
+  uint64_t nvalid = 0;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int64_t i = base + it * kBlock + tid;
+    bool ok = false;
+    int32_t len = 0;
+    if (i < a.length) {
+      uint64_t idx;
+      ok = bin_slot(a, i, &idx);
+      if (ok) len = a.offsets[idx + 1] - a.offsets[idx];
+      lens[i] = len;
+    }
+    mine += len;
+    const uint64_t bal = __ballot(ok);
+    nvalid += __popcll(bal);
+    if (out_validity != nullptr && lane == 0 && (i - lane) < a.length) out_validity[(i - lane) >> 6] = bal;
+  }
+  // workgroup total (64-bit)
+  long long s = mine;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+  if (lane == 0) wave_sum[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    long long t = 0;
+    for (int k = 0; k < kWavesPerBlock; ++k) t += wave_sum[k];
+    block_sums[blockIdx.x] = t;
+  }
+  if (valid_count != nullptr && lane == 0 && nvalid != 0) atomicAdd(valid_count, static_cast<unsigned long long>(nvalid));
+}
+
+// in-place exclusive scan of nblocks 64-bit totals; total -> sums[nblocks]
+__global__ __launch_bounds__(1024) void bin_scan_blocks_kernel(long long* sums, int64_t nblocks) {
+  __shared__ long long wave_tot[16];
+  __shared__ long long carry_s;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nblocks; base += 1024) {
+    const int64_t i = base + tid;
+    const long long v = i < nblocks ? sums[i] : 0;
+    long long x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const long long n = __shfl_up(x, d, 64);
+      if (lane >= d) x += n;
+    }
+    if (lane == 63) wave_tot[wave] = x;
+    __syncthreads();
+    long long pre = 0;
+    for (int k = 0; k < wave; ++k) pre += wave_tot[k];
+    const long long carry = carry_s;
+    if (i < nblocks) sums[i] = carry + pre + x - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + pre + x;
+    __syncthreads();
+  }
+  if (tid == 0) sums[nblocks] = carry_s;
+}
+
+// lens (in out_offsets) -> exclusive offsets, per workgroup of 4096 slots
+__global__ __launch_bounds__(kBlock) void bin_offsets_kernel(int32_t* __restrict__ out_offsets, int64_t length,
+                                                             const long long* __restrict__ block_base) {
+  __shared__ uint32_t wave_tot[kWavesPerBlock];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kBinRows;
+  // thread t owns 16 CONSECUTIVE slots so that the scan order is the slot order
+  uint32_t v[16];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int64_t i = base + tid * 16 + k;
+    v[k] = i < length ? static_cast<uint32_t>(out_offsets[i]) : 0u;
+    mine += v[k];
+  }
+  const uint32_t incl = wave_inclusive_scan_u32(mine);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t pre = incl - mine;
+  for (int k = 0; k < wave; ++k) pre += wave_tot[k];
+  long long run = block_base[blockIdx.x] + pre;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int64_t i = base + tid * 16 + k;
+    if (i < length) out_offsets[i] = static_cast<int32_t>(run);
+    run += v[k];
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == kBlock - 1) out_offsets[length] = static_cast<int32_t>(block_base[gridDim.x]);
+}
+
+__global__ __launch_bounds__(kBlock) void bin_copy_kernel(BinTakeArgs a, const int32_t* __restrict__ out_offsets,
+                                                          uint8_t* __restrict__ out_data) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.length; i += stride) {
+    const int32_t o0 = out_offsets[i];
+    const int32_t len = out_offsets[i + 1] - o0;
+    if (len == 0) continue;
+    uint64_t idx;
+    (void)bin_slot(a, i, &idx);  // len > 0 => the slot is valid
+    const uint8_t* __restrict__ src = a.data + a.offsets[idx];
+    uint8_t* __restrict__ dst = out_data + o0;
+    int k = 0;
+    if (((reinterpret_cast<uint64_t>(src) | reinterpret_cast<uint64_t>(dst)) & 3) == 0) {
+      for (; k + 4 <= len; k += 4) *reinterpret_cast<uint32_t*>(dst + k) = *reinterpret_cast<const uint32_t*>(src + k);
+    }
+    for (; k < len; ++k) dst[k] = src[k];
+  }
+}
+
+static int make_args(const ArxBinarySpan* values, const ArxSpan* indices, int index_type, BinTakeArgs* a) {
+  if (values == nullptr || indices == nullptr) {
+    set_error("values/indices is NULL");
+    return ARX_INVALID;
+  }
+  if (index_type < 0 || index_type > 7) {
+    set_error("Unsupported index type %d for take", index_type);
+    return ARX_NOT_IMPLEMENTED;
+  }
+  if (indices->length > 0 && (indices->data == nullptr || values->offsets == nullptr)) {
+    set_error("indices data / values offsets buffer is NULL");
+    return ARX_INVALID;
+  }
+  static const int widths[8] = {1, 1, 2, 2, 4, 4, 8, 8};
+  a->offsets = values->offsets + values->offset;
+  a->data = static_cast<const uint8_t*>(values->data);
+  a->src_valid_bytes = values->null_count != 0 ? static_cast<const uint8_t*>(values->validity) : nullptr;
+  a->src_valid_offset = values->offset;
+  a->indices = static_cast<const uint8_t*>(indices->data) + indices->offset * widths[index_type];
+  a->index_type = index_type;
+  a->ivalid = make_bits(indices->null_count != 0 ? indices->validity : nullptr, indices->offset, indices->length);
+  a->length = indices->length;
+  return ARX_OK;
+}
+
+}  // namespace arx
+
+using namespace arx;
+
+extern "C" {
+
+size_t arx_binary_take_workspace_bytes(int64_t num_indices) {
+  if (num_indices < 0) num_indices = 0;
+  return static_cast<size_t>(ceil_div(num_indices, kBinRows) + 2) * 8 + 64;
+}
+
+int arx_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices, int index_type, void* ws,
+                            size_t ws_bytes, int32_t* out_offsets, void* out_validity, int64_t* valid_count,
+                            int64_t* out_total_bytes, void* stream) {
+  BinTakeArgs a{};
+  const int rc = make_args(values, indices, index_type, &a);
+  if (rc != ARX_OK) return rc;
+  if (out_offsets == nullptr || out_total_bytes == nullptr) {
+    set_error("out_offsets / out_total_bytes is NULL");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  *out_total_bytes = 0;
+  if (a.length == 0) {
+    ARX_HIP(hipMemsetAsync(out_offsets, 0, 4, st));
+    return ARX_OK;
+  }
+  if (ws == nullptr || ws_bytes < arx_binary_take_workspace_bytes(a.length) || (reinterpret_cast<uint64_t>(ws) & 7) != 0) {
+    set_error("binary take workspace too small / unaligned");
+    return ARX_INVALID;
+  }
+  const bool needs_validity = a.src_valid_bytes != nullptr || a.ivalid.base != nullptr;
+  if (needs_validity && out_validity == nullptr) {
+    set_error("take: inputs may have nulls but out_validity is NULL");
+    return ARX_INVALID;
+  }
+  const int64_t nblocks = ceil_div(a.length, kBinRows);
+  long long* sums = static_cast<long long*>(ws);
+  hipLaunchKernelGGL(bin_lengths_kernel, dim3(static_cast<unsigned>(nblocks)), dim3(kBlock), 0, st, a, out_offsets,
+                     static_cast<uint64_t*>(out_validity), reinterpret_cast<unsigned long long*>(valid_count), sums);
+  ARX_CHECK_LAUNCH("bin_lengths_kernel");
+  hipLaunchKernelGGL(bin_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, sums, nblocks);
+  ARX_CHECK_LAUNCH("bin_scan_blocks_kernel");
+  long long total = 0;
+  ARX_HIP(hipMemcpyAsync(&total, sums + nblocks, 8, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  if (total > 2147483647LL) {
+    // the reference's offset builder overflows the same way (int32 offsets)
+    set_error("offset overflow while taking from a binary array: %lld bytes do not fit int32 offsets", total);
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(bin_offsets_kernel, dim3(static_cast<unsigned>(nblocks)), dim3(kBlock), 0, st, out_offsets,
+                     a.length, sums);
+  ARX_CHECK_LAUNCH("bin_offsets_kernel");
+  *out_total_bytes = total;
+  return ARX_OK;
+}
+
+int arx_binary_take_data(const ArxBinarySpan* values, const ArxSpan* indices, int index_type,
+                         const int32_t* out_offsets, void* out_data, void* stream) {
+  BinTakeArgs a{};
+  const int rc = make_args(values, indices, index_type, &a);
+  if (rc != ARX_OK) return rc;
+  if (a.length == 0) return ARX_OK;
+  if (out_offsets == nullptr) {
+    set_error("out_offsets is NULL");
+    return ARX_INVALID;
+  }
+  if (out_data == nullptr || values->data == nullptr) return ARX_OK;  // nothing to copy (total bytes 0)
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(a.length, kBlock), 256 * 32)));
+  hipLaunchKernelGGL(bin_copy_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), a, out_offsets,
+                     static_cast<uint8_t*>(out_data));
+  ARX_CHECK_LAUNCH("bin_copy_kernel");
+  return ARX_OK;
+}
+
+}  // extern "C"

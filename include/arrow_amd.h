@@ -154,6 +154,34 @@ int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int 
              void* out_data, void* out_validity, int64_t* valid_count, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Take / Filter on base-binary values (binary, utf8: int32 offsets) — replaces TakeExec for base
+ * binary (cpp/src/arrow/compute/kernels/vector_selection_take_internal.cc) and, through
+ * GetTakeIndices, BinaryFilterImpl (vector_selection_filter_internal.cc:517-800): out slot i is
+ * valid iff the index and the source value are; a valid slot appends the source bytes, a null slot
+ * nothing; out offsets start at 0.  Two steps because the data size is data dependent (the
+ * reference grows a builder):
+ *   arx_binary_take_offsets (synchronous): out_offsets[0..M] (device int32), out_validity,
+ *     valid_count (device, caller-zeroed, may be NULL), *out_total_bytes (host); ARX_INVALID
+ *     "offset overflow" if the bytes do not fit int32 offsets.
+ *   arx_binary_take_data (asynchronous): the bytes, into out_data[0 .. total).
+ * A filter is arx_mask_to_indices followed by these two.
+ * ------------------------------------------------------------------------- */
+typedef struct ArxBinarySpan {
+  const void* validity;    /* bitmap or NULL */
+  const int32_t* offsets;  /* offsets buffer (NOT pre-offset): length + offset + 1 entries */
+  const void* data;        /* value bytes */
+  int64_t offset;
+  int64_t length;
+  int64_t null_count;
+} ArxBinarySpan;
+size_t arx_binary_take_workspace_bytes(int64_t num_indices);
+int arx_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices, int index_type, void* ws,
+                            size_t ws_bytes, int32_t* out_offsets, void* out_validity, int64_t* valid_count,
+                            int64_t* out_total_bytes, void* stream);
+int arx_binary_take_data(const ArxBinarySpan* values, const ArxSpan* indices, int index_type,
+                         const int32_t* out_offsets, void* out_data, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Cast float64 -> float32 — replaces CastPrimitive<FloatType,DoubleType>::Exec
  * (cpp/src/arrow/compute/kernels/scalar_cast_internal.cc:41-53): every slot is
  * converted (null slots included), IEEE round-to-nearest-even.

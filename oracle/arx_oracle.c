@@ -183,6 +183,52 @@ int64_t arxo_take(const uint8_t* values, int byte_width, const uint8_t* values_v
 }
 
 /* ---------------------------------------------------------------------------
+ * Take on base-binary values (binary / utf8, int32 offsets) — VarBinaryTakeImpl /
+ * TakeExec for base binary (compute/kernels/vector_selection_take_internal.cc, Selection CRTP in
+ * vector_selection_internal.cc): out slot i is valid iff index i is valid AND the source value is
+ * valid; a valid slot appends the source bytes, a null slot appends nothing (its offsets are
+ * equal), out offsets start at 0.  Total bytes must fit int32 (the reference raises on overflow).
+ * The same rule is what Filter produces for base-binary values
+ * (vector_selection_filter_internal.cc:517-800: BinaryFilterImpl): filter == take(GetTakeIndices).
+ * `offsets` is the buffer start (values_off applied here).  out_offsets: length+1 entries.
+ * Returns total bytes, or -1 on int32 overflow.
+ * ------------------------------------------------------------------------- */
+int64_t arxo_binary_take(const int32_t* offsets, const uint8_t* data, const uint8_t* values_valid,
+                         int64_t values_off, const void* indices, int index_type,
+                         const uint8_t* idx_valid, int64_t idx_off, int64_t length,
+                         int32_t* out_offsets, uint8_t* out_data, uint8_t* out_valid,
+                         int64_t* out_valid_count) {
+  const uint8_t* ibase = (const uint8_t*)indices + idx_off * index_width_of(index_type);
+  int64_t total = 0, valid_count = 0;
+  if (out_valid) memset(out_valid, 0, (size_t)((length + 7) / 8));
+  for (int64_t i = 0; i < length; ++i) {
+    out_offsets[i] = (int32_t)total;
+    int ok = is_valid(idx_valid, idx_off, i);
+    uint64_t idx = 0;
+    if (ok) {
+      idx = (uint64_t)load_index_signed(ibase, index_type, i);
+      if (index_type < 6) {
+        const int w = index_width_of(index_type);
+        if (w == 1) idx &= 0xffu; else if (w == 2) idx &= 0xffffu; else idx &= 0xffffffffu;
+      }
+      ok = is_valid(values_valid, values_off, (int64_t)idx);
+    }
+    if (ok) {
+      const int32_t b = offsets[values_off + (int64_t)idx];
+      const int32_t e = offsets[values_off + (int64_t)idx + 1];
+      if (out_data) memcpy(out_data + total, data + b, (size_t)(e - b));
+      total += e - b;
+      if (total > 2147483647LL) return -1;
+      if (out_valid) set_bit_to(out_valid, i, 1);
+      ++valid_count;
+    }
+  }
+  out_offsets[length] = (int32_t)total;
+  if (out_valid_count) *out_valid_count = valid_count;
+  return total;
+}
+
+/* ---------------------------------------------------------------------------
  * CastPrimitive<FloatType, DoubleType>::Exec — compute/kernels/scalar_cast_internal.cc:41-53
  * static_cast<float>(double) on every slot (IEEE RNE via cvtsd2ss on x86).
  * ------------------------------------------------------------------------- */

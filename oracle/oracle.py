@@ -47,6 +47,8 @@ def lib():
         L.arxo_check_index_bounds.argtypes = [p, i32, p, i64, i64, u64, p, p]
         L.arxo_take.restype = i64
         L.arxo_take.argtypes = [p, i32, p, i64, p, i32, p, i64, i64, p, p]
+        L.arxo_binary_take.restype = i64
+        L.arxo_binary_take.argtypes = [p, p, p, i64, p, i32, p, i64, i64, p, p, p, p]
         L.arxo_cast_f64_f32.restype = None
         L.arxo_cast_f64_f32.argtypes = [p, i64, p]
         L.arxo_greater_f64.restype = None
@@ -154,6 +156,28 @@ def take(values, values_valid, values_off, indices, idx_valid, idx_off, length,
                          INDEX_TYPES[indices.dtype], _ptr(idx_valid), idx_off, length, _ptr(out),
                          _ptr(ov))
     return out, ov, int(vc)
+
+
+def binary_take(offsets, data, values_valid, values_off, indices, idx_valid, idx_off, length):
+    """Take on binary/utf8 values (int32 offsets).  Returns (out_offsets int32[length+1],
+    out_data uint8[total], out_valid bitmap, valid_count)."""
+    out_off = np.zeros(length + 1, dtype=np.int32)
+    ov = np.zeros(bitmap_bytes(length), dtype=np.uint8)
+    vc = C.c_int64(0)
+    args = (_ptr(offsets), _ptr(data), _ptr(values_valid), values_off, _ptr(indices),
+            INDEX_TYPES[indices.dtype], _ptr(idx_valid), idx_off, length)
+    total = lib().arxo_binary_take(*args, _ptr(out_off), None, _ptr(ov), C.byref(vc))
+    assert total >= 0, "offset overflow"
+    out_data = np.zeros(max(total, 1), dtype=np.uint8)
+    lib().arxo_binary_take(*args, _ptr(out_off), _ptr(out_data), _ptr(ov), C.byref(vc))
+    return out_off, out_data[:total], ov, int(vc.value)
+
+
+def binary_filter(offsets, data, values_valid, values_off, mask, mask_valid, mask_off, length, null_selection):
+    """Filter on binary/utf8 values == take(GetTakeIndices(mask)) (BinaryFilterImpl)."""
+    idx, idx_bm = mask_to_indices(mask, mask_valid, mask_off, length, null_selection, True)
+    idx32 = idx.astype(np.uint32)
+    return binary_take(offsets, data, values_valid, values_off, idx32, idx_bm, 0, len(idx32))
 
 
 def cast_f64_f32(a: np.ndarray) -> np.ndarray:

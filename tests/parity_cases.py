@@ -107,6 +107,61 @@ def check_take_out_of_bounds(amd, values: HostArray, indices: HostArray):
         assert str(ri.value) == str(ei.value)
 
 
+# ------------------------------------------------------------------ binary / utf8 take + filter
+def _binary_out(out):
+    offs = out.buffers[1].cpu().numpy()[: (out.length + 1) * 4].view(np.int32)
+    total = int(offs[-1])
+    data = out.buffers[2].cpu().numpy()[:total]
+    return offs, data
+
+
+def _check_binary_result(out, want, tag, ref):
+    want_off, want_data, want_bm, want_vc = want
+    assert out.offset == 0
+    offs, data = _binary_out(out)
+    assert_equal(offs, want_off, tag + " offsets")
+    assert_equal(data, want_data, tag + " data bytes")
+    got_valid, pad_ok = _logical_valid(out)
+    assert_equal(got_valid, oracle_bitmap_to_bool(want_bm, out.length), tag + " validity")
+    assert pad_ok, tag + ": padding bits of the validity bitmap are not zero"
+    assert out.null_count == out.length - want_vc, tag + " null_count"
+    if ref is not None:
+        assert out.to_pyarrow().equals(ref), tag + " vs pyarrow"
+        # the reference's own buffers: offsets start at 0 and are dense, like ours
+        roffs = np.frombuffer(ref.buffers()[1], dtype=np.int32)[ref.offset: ref.offset + len(ref) + 1]
+        assert_equal(offs - offs[0], roffs - roffs[0], tag + " offsets vs pyarrow")
+
+
+def check_binary_take(amd, values, indices: HostArray, boundscheck=True, use_pyarrow=True):
+    dv, di = values.to_device(amd), indices.to_device(amd)
+    out = amd.compute.take(dv, di, boundscheck=boundscheck)
+    want = O.binary_take(values.offsets, values.data, values.valid_bitmap(), values.offset,
+                         np.ascontiguousarray(indices.values), indices.valid_bitmap(), indices.offset,
+                         indices.length)
+    tag = f"binary_take[idx={indices.dtype},m={indices.length},voff={values.offset},ioff={indices.offset}]"
+    assert out.length == indices.length and out.type == dv.type
+    ref = None
+    if use_pyarrow and pc is not None:
+        ref = pc.take(values.to_pyarrow(), indices.to_pyarrow(), boundscheck=boundscheck)
+    _check_binary_result(out, want, tag, ref)
+    return out
+
+
+def check_binary_filter(amd, values, mask: HostArray, null_selection: str, use_pyarrow=True):
+    code = 1 if null_selection == "emit_null" else 0
+    dv, dm = values.to_device(amd), mask.to_device(amd)
+    out = amd.compute.filter(dv, dm, null_selection)
+    want = O.binary_filter(values.offsets, values.data, values.valid_bitmap(), values.offset,
+                           mask.data_bytes(), mask.valid_bitmap(), mask.offset, mask.length, code)
+    tag = f"binary_filter[n={mask.length},{null_selection},voff={values.offset},moff={mask.offset}]"
+    assert out.length == len(want[0]) - 1, tag
+    ref = None
+    if use_pyarrow and pc is not None:
+        ref = pc.filter(values.to_pyarrow(), mask.to_pyarrow(), null_selection_behavior=null_selection)
+    _check_binary_result(out, want, tag, ref)
+    return out
+
+
 # ------------------------------------------------------------------ cast / compare / add
 def _bits_equal_f32(got, want):
     g, w = got.view(np.uint32), want.view(np.uint32)

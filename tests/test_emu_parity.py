@@ -434,3 +434,52 @@ def test_sort_msd_sampled_splitters(emu_ctx, dtype):
         P.check_sort_indices(emu_ctx, dup, "ascending", "at_end", use_pyarrow=False)
     finally:
         lib.arx_set_option(b"sort_msd_sampled", 1)
+
+
+# ------------------------------------------------------------------ binary / utf8 take + filter
+@pytest.mark.parametrize("idx_dtype", [np.uint8, np.int16, np.uint32, np.int64])
+@pytest.mark.parametrize("vnull,inull", [(0.0, 0.0), (0.2, 0.0), (0.0, 0.1), (0.3, 0.3)])
+def test_binary_take(emu_ctx, idx_dtype, vnull, inull):
+    """TestTakeKernelWithString (vector_selection_test.cc): values and index nulls, all index types."""
+    rng = rng_for("btake", str(idx_dtype), vnull, inull)
+    nv = 100 if np.dtype(idx_dtype).itemsize == 1 else 3000
+    v = U.random_binary(rng, nv, null_p=vnull, offset=3, tail=2, utf8=True)
+    i = U.random_array(rng, idx_dtype, 5000, null_p=inull, offset=1, lo=0, hi=nv - 1)
+    P.check_binary_take(emu_ctx, v, i)
+
+
+@pytest.mark.parametrize("m", [0, 1, 63, 64, 65, 4095, 4096, 4097, 8193])
+def test_binary_take_lengths(emu_ctx, m):
+    rng = rng_for("btakelen", m)
+    v = U.random_binary(rng, 500, null_p=0.1, max_len=40)
+    i = U.random_array(rng, np.int32, m, null_p=0.1, lo=0, hi=499)
+    P.check_binary_take(emu_ctx, v, i)
+
+
+def test_binary_take_empty_values_and_all_null(emu_ctx):
+    rng = rng_for("btakeedge")
+    v = U.random_binary(rng, 64, null_p=1.0)
+    i = U.random_array(rng, np.int32, 200, lo=0, hi=63)
+    out = P.check_binary_take(emu_ctx, v, i)
+    assert out.null_count == 200
+    v = U.random_binary(rng, 64, empty_p=1.0)      # only empty strings: zero data bytes
+    P.check_binary_take(emu_ctx, v, i)
+
+
+def test_binary_take_out_of_bounds(emu_ctx):
+    rng = rng_for("btakeoob")
+    v = U.random_binary(rng, 10)
+    idx = U.HostArray(np.array([0, 3, 10, 2], dtype=np.int32), None, 0, 4)
+    with pytest.raises(emu_ctx.ArrowIndexError, match="Index 10 out of bounds"):
+        emu_ctx.compute.take(v.to_device(emu_ctx), idx.to_device(emu_ctx))
+
+
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+@pytest.mark.parametrize("true_p,vnull,mnull", [(0.0, 0.1, 0.0), (0.3, 0.0, 0.0), (0.5, 0.2, 0.1), (1.0, 0.1, 0.05)])
+def test_binary_filter(emu_ctx, sel, true_p, vnull, mnull):
+    """TestFilterKernelWithString / FilterRandomTest on utf8 (vector_selection_test.cc)."""
+    rng = rng_for("bfilter", sel, true_p, vnull, mnull)
+    n = 6000
+    v = U.random_binary(rng, n, null_p=vnull, offset=5, tail=3)
+    m = U.random_mask(rng, n, true_p, null_p=mnull, offset=2, tail=1)
+    P.check_binary_filter(emu_ctx, v, m, sel)

@@ -628,3 +628,57 @@ def test_sort_msd_sampled_splitters(gpu_ctx, dtype):
         P.check_sort_indices(gpu_ctx, dup, "ascending", "at_end", use_pyarrow=False)
     finally:
         lib.arx_set_option(b"sort_msd_sampled", 1)
+
+
+# ------------------------------------------------------------------ binary / utf8 take + filter
+@pytest.mark.parametrize("idx_dtype", [np.uint8, np.int16, np.uint32, np.int64])
+@pytest.mark.parametrize("vnull,inull", [(0.0, 0.0), (0.2, 0.0), (0.0, 0.1), (0.3, 0.3)])
+def test_binary_take(gpu_ctx, idx_dtype, vnull, inull):
+    rng = rng_for("btake", idx_dtype, vnull, inull)
+    nv = 100 if np.dtype(idx_dtype).itemsize == 1 else 30_000
+    v = U.random_binary(rng, nv, null_p=vnull, offset=3, tail=2, utf8=True)
+    i = U.random_array(rng, idx_dtype, 200_003, null_p=inull, offset=1, lo=0, hi=nv - 1)
+    P.check_binary_take(gpu_ctx, v, i)
+
+
+@pytest.mark.parametrize("m", [0, 1, 63, 64, 65, 4095, 4096, 4097, 1_000_003])
+def test_binary_take_lengths(gpu_ctx, m):
+    rng = rng_for("btakelen", m)
+    v = U.random_binary(rng, 5000, null_p=0.1, max_len=40)
+    i = U.random_array(rng, np.int32, m, null_p=0.1, lo=0, hi=4999)
+    P.check_binary_take(gpu_ctx, v, i)
+
+
+def test_binary_take_edges(gpu_ctx):
+    rng = rng_for("btakeedge")
+    i = U.random_array(rng, np.int32, 20_000, lo=0, hi=63)
+    out = P.check_binary_take(gpu_ctx, U.random_binary(rng, 64, null_p=1.0), i)
+    assert out.null_count == 20_000
+    P.check_binary_take(gpu_ctx, U.random_binary(rng, 64, empty_p=1.0), i)
+    P.check_binary_take(gpu_ctx, U.random_binary(rng, 64, max_len=2000, empty_p=0.0), i)   # long values
+    v = U.random_binary(rng, 10)
+    idx = U.HostArray(np.array([0, 3, 10, 2], dtype=np.int32), None, 0, 4)
+    with pytest.raises(gpu_ctx.ArrowIndexError, match="Index 10 out of bounds"):
+        gpu_ctx.compute.take(v.to_device(gpu_ctx), idx.to_device(gpu_ctx))
+
+
+def test_binary_take_offset_overflow(gpu_ctx):
+    """2^20 copies of a 4 KiB value do not fit int32 offsets: an error, as in the reference
+    (the offset builder of the var-binary take overflows)."""
+    rng = rng_for("btakeovf")
+    v = U.random_binary(rng, 4, max_len=4096, empty_p=0.0)
+    v.offsets[:] = np.arange(len(v.offsets), dtype=np.int32) * 1024   # every value 1 KiB
+    v.data = np.zeros(int(v.offsets[-1]), np.uint8)
+    i = U.HostArray(np.zeros(1 << 22, np.int32), None, 0, 1 << 22)    # 4 GiB of output
+    with pytest.raises(gpu_ctx.ArrowInvalid, match="overflow"):
+        gpu_ctx.compute.take(v.to_device(gpu_ctx), i.to_device(gpu_ctx))
+
+
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+@pytest.mark.parametrize("true_p,vnull,mnull", [(0.0, 0.1, 0.0), (0.1, 0.0, 0.0), (0.5, 0.2, 0.1), (1.0, 0.1, 0.05)])
+def test_binary_filter(gpu_ctx, sel, true_p, vnull, mnull):
+    rng = rng_for("bfilter", sel, true_p, vnull, mnull)
+    n = 300_007
+    v = U.random_binary(rng, n, null_p=vnull, offset=5, tail=3)
+    m = U.random_mask(rng, n, true_p, null_p=mnull, offset=2, tail=1)
+    P.check_binary_filter(gpu_ctx, v, m, sel)

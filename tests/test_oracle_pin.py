@@ -309,3 +309,83 @@ def test_typed_sort_vs_pyarrow(dtype):
                                  descending=(order == "descending"), nulls_at_start=(placement == "at_start"))
             ref = pc.array_sort_indices(a.to_pyarrow(), order=order, null_placement=placement).to_numpy()
             assert (got == ref).all(), (dtype, order, placement)
+
+
+# ------------------------------------------------------------------ binary / utf8 take + filter
+def _bin_from_list(xs, utf8=True):
+    valid = np.array([x is not None for x in xs], dtype=bool)
+    enc = [b"" if x is None else (x.encode() if isinstance(x, str) else x) for x in xs]
+    offsets = np.zeros(len(xs) + 1, dtype=np.int32)
+    np.cumsum([len(e) for e in enc], out=offsets[1:])
+    data = np.frombuffer(b"".join(enc), dtype=np.uint8).copy()
+    return U.HostBinaryArray(offsets, data, None if valid.all() else valid, 0, len(xs), utf8)
+
+
+def _bin_to_list(res, n):
+    off, data, bm, _vc = res
+    valid = O.unpack_bits(bm, 0, n)
+    raw = data.tobytes()
+    return [raw[off[i]: off[i + 1]].decode() if valid[i] else None for i in range(n)]
+
+
+# TYPED_TEST(TestTakeKernelWithString, TakeString) vector_selection_test.cc:1661-1664
+@pytest.mark.parametrize("values,indices,want", [
+    (["a", "b", "c"], [0, 1, 0], ["a", "b", "a"]),
+    ([None, "b", "c"], [0, 1, 0], [None, "b", None]),
+    (["a", "b", "c"], [None, 1, 0], [None, "b", "a"]),
+])
+def test_golden_binary_take(values, indices, want):
+    v, i = _bin_from_list(values), from_list(indices, np.int32)
+    res = O.binary_take(v.offsets, v.data, v.valid_bitmap(), 0, i.values, i.valid_bitmap(), 0, i.length)
+    assert _bin_to_list(res, i.length) == want
+
+
+# TYPED_TEST(TestFilterKernelWithString, FilterString) vector_selection_test.cc:670-674 (EMIT_NULL is
+# the default of the test fixture's AssertFilter; DROP is checked alongside, :117-160)
+@pytest.mark.parametrize("values,mask,want_emit,want_drop", [
+    (["a", "b", "c"], [0, 1, 0], ["b"], ["b"]),
+    ([None, "b", "c"], [0, 1, 0], ["b"], ["b"]),
+    (["a", "b", "c"], [None, 1, 0], [None, "b"], ["b"]),
+])
+def test_golden_binary_filter(values, mask, want_emit, want_drop):
+    v, m = _bin_from_list(values), from_list(mask, np.bool_)
+    for code, want in ((1, want_emit), (0, want_drop)):
+        res = O.binary_filter(v.offsets, v.data, v.valid_bitmap(), 0, m.data_bytes(), m.valid_bitmap(), 0,
+                              m.length, code)
+        assert _bin_to_list(res, len(res[0]) - 1) == want
+
+
+def _assert_bin_equals_pyarrow(res, ref):
+    off, data, bm, vc = res
+    n = len(off) - 1
+    got = pa.Array.from_buffers(ref.type, n, [pa.py_buffer(bm.tobytes()), pa.py_buffer(off.tobytes()),
+                                              pa.py_buffer(data.tobytes())])
+    assert got.equals(ref)
+    assert n - vc == ref.null_count
+    roff = np.frombuffer(ref.buffers()[1], dtype=np.int32)[ref.offset: ref.offset + n + 1]
+    assert (off == roff - roff[0]).all()
+
+
+@pytest.mark.skipif(pc is None, reason="pyarrow wheel not in this image")
+@pytest.mark.parametrize("utf8", [True, False])
+@pytest.mark.parametrize("vnull,inull", [(0.0, 0.0), (0.2, 0.0), (0.0, 0.1), (0.5, 0.5)])
+def test_binary_take_vs_pyarrow(utf8, vnull, inull):
+    rng = np.random.default_rng([U.kRandomSeed, int(utf8), int(vnull * 100), int(inull * 100)])
+    v = U.random_binary(rng, 3000, null_p=vnull, offset=7, tail=3, utf8=utf8)
+    i = U.random_array(rng, np.int32, 10_000, null_p=inull, offset=2, lo=0, hi=2999)
+    res = O.binary_take(v.offsets, v.data, v.valid_bitmap(), v.offset, i.values, i.valid_bitmap(), i.offset,
+                        i.length)
+    _assert_bin_equals_pyarrow(res, pc.take(v.to_pyarrow(), i.to_pyarrow()))
+
+
+@pytest.mark.skipif(pc is None, reason="pyarrow wheel not in this image")
+@pytest.mark.parametrize("sel", ["drop", "emit_null"])
+@pytest.mark.parametrize("true_p,vnull,mnull", [(0.0, 0.1, 0.0), (0.3, 0.0, 0.0), (0.5, 0.2, 0.1), (1.0, 0.1, 0.05)])
+def test_binary_filter_vs_pyarrow(sel, true_p, vnull, mnull):
+    rng = np.random.default_rng([U.kRandomSeed, int(true_p * 100), int(vnull * 100), int(mnull * 100)])
+    n = 20_000
+    v = U.random_binary(rng, n, null_p=vnull, offset=5, tail=3)
+    m = U.random_mask(rng, n, true_p, null_p=mnull, offset=2, tail=1)
+    res = O.binary_filter(v.offsets, v.data, v.valid_bitmap(), v.offset, m.data_bytes(), m.valid_bitmap(),
+                          m.offset, m.length, 1 if sel == "emit_null" else 0)
+    _assert_bin_equals_pyarrow(res, pc.filter(v.to_pyarrow(), m.to_pyarrow(), null_selection_behavior=sel))

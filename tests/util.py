@@ -117,3 +117,54 @@ def first_mismatch(a, b):
 def assert_equal(got, want, what=""):
     msg = first_mismatch(got, want)
     assert msg is None, f"{what}: {msg}"
+
+
+@dataclasses.dataclass
+class HostBinaryArray:
+    """A (possibly sliced) binary / utf8 array: int32 offsets over the full buffer + bytes."""
+    offsets: np.ndarray           # int32[offset + length + tail + 1]
+    data: np.ndarray              # uint8 bytes
+    valid: np.ndarray | None      # bool over the full buffer or None
+    offset: int
+    length: int
+    utf8: bool = False
+
+    def valid_bitmap(self):
+        return None if self.valid is None else O.pack_bits(self.valid)
+
+    def null_count(self):
+        return 0 if self.valid is None else int((~self.valid[self.offset: self.offset + self.length]).sum())
+
+    def to_pyarrow(self):
+        n = len(self.offsets) - 1
+        vb = None if self.valid is None else pa.py_buffer(O.pack_bits(self.valid).tobytes())
+        arr = pa.Array.from_buffers(pa.string() if self.utf8 else pa.binary(), n,
+                                    [vb, pa.py_buffer(self.offsets.tobytes()), pa.py_buffer(self.data.tobytes())])
+        return arr.slice(self.offset, self.length)
+
+    def to_device(self, amd):
+        A = amd.array
+        n = len(self.offsets) - 1
+        vbuf = None if self.valid is None else A.to_device(A.pack_validity(self.valid))
+        t = A.utf8 if self.utf8 else A.binary
+        full = A.Array(t, n, [vbuf, A.to_device(self.offsets), A.to_device(self.data)],
+                       0 if self.valid is None else int(n - self.valid.sum()), 0)
+        if self.offset == 0 and self.length == n:
+            return full
+        return full.slice(self.offset, self.length)
+
+
+def random_binary(rng, length, null_p=0.0, offset=0, tail=0, max_len=24, utf8=False, empty_p=0.1) -> HostBinaryArray:
+    """RandomArrayGenerator::String-like (arrow/testing/random.h): lengths 0..max_len, some empty."""
+    n = offset + length + tail
+    lens = rng.integers(0, max_len, size=n, endpoint=True).astype(np.int64)
+    lens[rng.random(n) < empty_p] = 0
+    offsets = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(lens, out=offsets[1:])
+    total = int(offsets[-1])
+    if utf8:
+        data = rng.integers(0x20, 0x7E, size=total, endpoint=True).astype(np.uint8)
+    else:
+        data = rng.integers(0, 255, size=total, endpoint=True).astype(np.uint8)
+    valid = (rng.random(n) >= null_p) if null_p > 0 else None
+    return HostBinaryArray(offsets, data, valid, offset, length, utf8)
