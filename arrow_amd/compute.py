@@ -267,8 +267,8 @@ def _exec_binary_take(args, options):
                                           C.byref(total), stream))
     out_data = alloc(total.value, dev)
     with tracing.span("arx_binary_take_data"):
-        check(lib.arx_binary_take_data(C.byref(vspan), C.byref(ispan), tid, out_offsets.data_ptr(),
-                                       out_data.data_ptr() if total.value else None, stream))
+        check(lib.arx_binary_take_data(C.byref(vspan), m, ws.data_ptr(), ws.numel(), out_offsets.data_ptr(),
+                                       total.value, out_data.data_ptr(), stream))
     out = Array(values.type, m, [out_valid, out_offsets, out_data], 0, 0)
     if allocate_validity:
         out.set_lazy_null_count(_LazyCount(m, counter))

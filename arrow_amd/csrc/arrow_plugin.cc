@@ -133,7 +133,7 @@ class DeviceScratch {
 };
 thread_local DeviceScratch t_scratch;
 
-enum Slot { kValues = 0, kValidity, kArg2, kArg2Validity, kOutData, kOutValidity, kWs, kCounter };
+enum Slot { kValues = 0, kValidity, kArg2, kArg2Validity, kOutData, kOutValidity, kWs, kCounter, kBinWs };
 
 // Upload the logical range of a fixed-width (or boolean) ArraySpan.  The device copy keeps the
 // sub-byte part of the offset (offset % 8) so that one logical offset addresses both buffers.
@@ -487,6 +487,164 @@ Status FilterExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecRes
     }
   }
   HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+  CountGpu(kFnFilter);
+  return Status::OK();
+}
+
+int IndexTypeId(const arrow::DataType& t);
+
+// ---------------------------------------------------------------- binary / utf8 (device-resident)
+// TakeExec / FilterExec for base binary on arrays that live in HBM: the offsets/validity pass,
+// one 8-byte read-back of the byte total (the reference grows a builder instead), then the bytes.
+// Host-resident strings stay on the stock kernels (they would be PCIe-bound both ways).
+StockKernel g_stock_filter_bin, g_stock_take_bin;
+
+arrow::Result<std::unique_ptr<cp::KernelState>> BinaryFilterInit(cp::KernelContext* ctx,
+                                                                 const cp::KernelInitArgs& args) {
+  auto state = std::make_unique<ShimState<cp::FilterOptions>>();
+  if (g_stock_filter_bin.init) {
+    ARROW_ASSIGN_OR_RAISE(state->stock, g_stock_filter_bin.init(ctx, args));
+  }
+  if (args.options != nullptr) state->options = *static_cast<const cp::FilterOptions*>(args.options);
+  return state;
+}
+
+arrow::Result<std::unique_ptr<cp::KernelState>> BinaryTakeInit(cp::KernelContext* ctx,
+                                                               const cp::KernelInitArgs& args) {
+  auto state = std::make_unique<ShimState<cp::TakeOptions>>();
+  if (g_stock_take_bin.init) {
+    ARROW_ASSIGN_OR_RAISE(state->stock, g_stock_take_bin.init(ctx, args));
+  }
+  if (args.options != nullptr) state->options = *static_cast<const cp::TakeOptions*>(args.options);
+  return state;
+}
+
+bool OnRocm3(const ArraySpan& a) {
+  if (OnRocm(a)) return true;
+  return a.buffers[2].owner != nullptr && *a.buffers[2].owner != nullptr &&
+         (*a.buffers[2].owner)->device_type() == arrow::DeviceAllocationType::kROCM;
+}
+
+Status DeviceBinarySpan(const ArraySpan& a, ArxBinarySpan* out) {
+  const void* addr[3] = {nullptr, nullptr, nullptr};
+  for (int i = 0; i < 3; ++i) {
+    const auto* owner = a.buffers[i].owner;
+    if (owner == nullptr || *owner == nullptr) continue;
+    if ((*owner)->device_type() != arrow::DeviceAllocationType::kROCM) {
+      return Status::Invalid("arrow_amd: mixed host / device buffers in one array");
+    }
+    addr[i] = reinterpret_cast<const void*>((*owner)->address());
+  }
+  out->validity = addr[0];
+  out->offsets = static_cast<const int32_t*>(addr[1]);
+  out->data = addr[2];
+  out->offset = a.offset;
+  out->length = a.length;
+  out->null_count = addr[0] == nullptr ? 0 : (a.null_count > 0 ? a.null_count : arrow::kUnknownNullCount);
+  return Status::OK();
+}
+
+Status BinaryTakeOnDevice(const ArxBinarySpan& dv, const ArxSpan& di, int tid, hipStream_t st, ArrayData* out_arr) {
+  const int64_t m = di.length;
+  const bool allocate_validity = dv.null_count != 0 || di.null_count != 0;
+  out_arr->length = m;
+  out_arr->buffers.resize(3);
+  out_arr->buffers[0] = nullptr;
+  ARROW_ASSIGN_OR_RAISE(out_arr->buffers[1], AllocDevice((m + 1) * 4));
+  void* d_valid = nullptr;
+  void* d_counter = nullptr;
+  if (allocate_validity) {
+    ARROW_ASSIGN_OR_RAISE(out_arr->buffers[0], AllocDevice(((m + 63) / 64) * 8));
+    d_valid = reinterpret_cast<void*>(out_arr->buffers[0]->mutable_address());
+    ARROW_RETURN_NOT_OK(t_scratch.Get(kCounter, 64, &d_counter));
+    HIP_RETURN_NOT_OK(hipMemsetAsync(d_counter, 0, 8, st));
+  }
+  const size_t ws_bytes = arx_binary_take_workspace_bytes(m);
+  void* ws = nullptr;
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kBinWs, ws_bytes, &ws));
+  int32_t* d_off = reinterpret_cast<int32_t*>(out_arr->buffers[1]->mutable_address());
+  int64_t total = 0;
+  ARROW_RETURN_NOT_OK(FromArx(arx_binary_take_offsets(&dv, &di, tid, ws, ws_bytes, d_off, d_valid,
+                                                      static_cast<int64_t*>(d_counter), &total, st)));
+  ARROW_ASSIGN_OR_RAISE(out_arr->buffers[2], AllocDevice(total));
+  ARROW_RETURN_NOT_OK(FromArx(arx_binary_take_data(&dv, m, ws, ws_bytes, d_off, total,
+                                                   reinterpret_cast<void*>(out_arr->buffers[2]->mutable_address()),
+                                                   st)));
+  int64_t valid_count = m;
+  if (allocate_validity) {
+    HIP_RETURN_NOT_OK(hipMemcpyAsync(&valid_count, d_counter, 8, hipMemcpyDeviceToHost, st));
+  }
+  HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+  out_arr->null_count = m - valid_count;
+  return Status::OK();
+}
+
+bool IsInt32Binary(const arrow::DataType& t) { return t.id() == Type::STRING || t.id() == Type::BINARY; }
+
+Status BinaryTakeExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResult* out) {
+  auto* state = static_cast<ShimState<cp::TakeOptions>*>(ctx->state());
+  const ArraySpan& values = batch[0].array;
+  const ArraySpan& indices = batch[1].array;
+  if (!OnRocm3(values) && !OnRocm(indices)) {
+    return RunStock(kFnTake, g_stock_take_bin, state->stock.get(), ctx, batch, out);
+  }
+  const int tid = IndexTypeId(*indices.type);
+  if (tid < 0 || !IsInt32Binary(*values.type)) {
+    return Status::NotImplemented("arrow_amd: take of ", values.type->ToString(), " by ",
+                                  indices.type->ToString(), " on device-resident arrays");
+  }
+  hipStream_t st;
+  ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+  ArxBinarySpan dv{};
+  ArxSpan di{};
+  ARROW_RETURN_NOT_OK(DeviceBinarySpan(values, &dv));
+  ARROW_RETURN_NOT_OK(DeviceSpan(indices, &di));
+  if (state->options.boundscheck) {
+    void* ws = nullptr;
+    ARROW_RETURN_NOT_OK(t_scratch.Get(kWs, arx_take_workspace_bytes(), &ws));
+    ARROW_RETURN_NOT_OK(FromArx(arx_check_index_bounds(&di, tid, static_cast<uint64_t>(values.length), ws,
+                                                       arx_take_workspace_bytes(), st)));
+  }
+  ARROW_RETURN_NOT_OK(BinaryTakeOnDevice(dv, di, tid, st, out->array_data().get()));
+  CountGpu(kFnTake);
+  return Status::OK();
+}
+
+// BinaryFilterImpl == take(GetTakeIndices(filter)): the indices live in device scratch only
+Status BinaryFilterExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResult* out) {
+  auto* state = static_cast<ShimState<cp::FilterOptions>*>(ctx->state());
+  const ArraySpan& values = batch[0].array;
+  const ArraySpan& filter = batch[1].array;
+  if (!OnRocm3(values) && !OnRocm(filter)) {
+    return RunStock(kFnFilter, g_stock_filter_bin, state->stock.get(), ctx, batch, out);
+  }
+  if (filter.type->id() != Type::BOOL || !IsInt32Binary(*values.type)) {
+    return Status::NotImplemented("arrow_amd: filter of ", values.type->ToString(), " on device-resident arrays");
+  }
+  if (filter.length > 0xFFFFFFFFll) {
+    return Status::NotImplemented("Filter length exceeds UINT32_MAX, consider a different strategy for selecting elements");
+  }
+  const int null_sel = state->options.null_selection_behavior == cp::FilterOptions::EMIT_NULL
+                           ? ARX_FILTER_EMIT_NULL : ARX_FILTER_DROP;
+  hipStream_t st;
+  ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+  ArxBinarySpan dv{};
+  ArxSpan dm{};
+  ARROW_RETURN_NOT_OK(DeviceBinarySpan(values, &dv));
+  ARROW_RETURN_NOT_OK(DeviceSpan(filter, &dm));
+  const size_t ws_bytes = arx_filter_workspace_bytes(filter.length);
+  void* ws = nullptr;
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kWs, ws_bytes, &ws));
+  int64_t out_len = 0;
+  ARROW_RETURN_NOT_OK(FromArx(arx_filter_count(&dm, null_sel, ws, ws_bytes, &out_len, st)));
+  const bool emit = null_sel == ARX_FILTER_EMIT_NULL && dm.null_count != 0;
+  void* d_idx = nullptr;
+  void* d_idx_valid = nullptr;
+  ARROW_RETURN_NOT_OK(t_scratch.Get(kArg2, static_cast<size_t>(out_len) * 4 + 64, &d_idx));
+  if (emit) ARROW_RETURN_NOT_OK(t_scratch.Get(kArg2Validity, static_cast<size_t>((out_len + 63) / 64) * 8 + 64, &d_idx_valid));
+  ARROW_RETURN_NOT_OK(FromArx(arx_mask_to_indices(&dm, null_sel, ws, out_len, 4, d_idx, d_idx_valid, st)));
+  ArxSpan di{d_idx_valid, d_idx, 0, out_len, emit ? arrow::kUnknownNullCount : 0};
+  ARROW_RETURN_NOT_OK(BinaryTakeOnDevice(dv, di, ARX_UINT32, st, out->array_data().get()));
   CountGpu(kFnFilter);
   return Status::OK();
 }
@@ -1422,6 +1580,12 @@ Status RegisterAll() {
   ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_take", FilterValueTypes(),
                                      {cp::InputType(cp::match::Integer())}, TakeInit, TakeExec,
                                      &g_stock_take));
+  ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_filter", {arrow::utf8(), arrow::binary()},
+                                     {cp::InputType(arrow::boolean())}, BinaryFilterInit, BinaryFilterExec,
+                                     &g_stock_filter_bin));
+  ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_take", {arrow::utf8(), arrow::binary()},
+                                     {cp::InputType(cp::match::Integer())}, BinaryTakeInit, BinaryTakeExec,
+                                     &g_stock_take_bin));
 #define ARX_REGISTER_SORT(K, TYPE)                                                                           \
   ARROW_RETURN_NOT_OK(RegisterVector(reg, "array_sort_indices", {TYPE}, {}, SortInitT<K>, SortExecT<K>,         \
                                      &g_stock_sort[K], SortChunkedT<K>))
@@ -1502,17 +1666,18 @@ int64_t arrow_amd_plugin_calls(const char* function, int gpu) {
   return -1;
 }
 // Host array (C Data interface, consumed) -> the same array with its buffers in HBM, exported
-// through the C Device Data interface (device_type = ARROW_DEVICE_ROCM).  Fixed-width / boolean
-// arrays without children.  0 on success.
+// through the C Device Data interface (device_type = ARROW_DEVICE_ROCM).  Fixed-width, boolean
+// and binary / utf8 arrays without children.  0 on success.
 int arrow_amd_copy_to_device(struct ArrowArray* in, struct ArrowSchema* schema, struct ArrowDeviceArray* out) {
   auto run = [&]() -> Status {
     ARROW_ASSIGN_OR_RAISE(auto host, arrow::ImportArray(in, schema));
-    if (!host->data()->child_data.empty() || host->data()->dictionary != nullptr || host->data()->buffers.size() != 2) {
+    if (!host->data()->child_data.empty() || host->data()->dictionary != nullptr || host->data()->buffers.size() > 3) {
       return Status::NotImplemented("arrow_amd_copy_to_device: ", host->type()->ToString());
     }
     ARROW_ASSIGN_OR_RAISE(auto mm, RocmMemoryManagerFor(0));
-    std::vector<std::shared_ptr<Buffer>> bufs(2);
-    for (int i = 0; i < 2; ++i) {
+    const int nbuf = static_cast<int>(host->data()->buffers.size());
+    std::vector<std::shared_ptr<Buffer>> bufs(nbuf);
+    for (int i = 0; i < nbuf; ++i) {
       const auto& b = host->data()->buffers[i];
       if (b != nullptr) {
         ARROW_ASSIGN_OR_RAISE(bufs[i], arrow::MemoryManager::CopyBuffer(b, mm));

@@ -13,8 +13,7 @@
 //                   per-workgroup byte totals (64-bit)
 //   bin_scan_blocks: exclusive scan of the workgroup totals (one workgroup)
 //   bin_offsets   : exclusive scan inside each workgroup's 4096 slots + its base -> out offsets
-//   bin_copy      : one thread per output slot copies its bytes (consecutive slots write
-//                   consecutive ranges)
+//   bin_copy      : output-centric, one workgroup per 16 KiB of output bytes (dense dword stores)
 #include "arx_common.h"
 
 #include <algorithm>
@@ -61,6 +60,7 @@ __device__ __forceinline__ bool bin_slot(const BinTakeArgs& a, int64_t i, uint64
 }
 
 __global__ __launch_bounds__(kBlock) void bin_lengths_kernel(BinTakeArgs a, int32_t* __restrict__ lens,
+                                                             int32_t* __restrict__ src_start,
                                                              uint64_t* __restrict__ out_validity,
                                                              unsigned long long* __restrict__ valid_count,
                                                              long long* __restrict__ block_sums) {
@@ -70,19 +70,39 @@ __global__ __launch_bounds__(kBlock) void bin_lengths_kernel(BinTakeArgs a, int3
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kBinRows;
   long long mine = 0;
   uint64_t nvalid = 0;
-#pragma unroll 4
+  // three passes over 16 slots held in registers so that the 16 index loads, then the 16 pairs of
+  // dependent offset loads, are all in flight together
+  bool ok[16];
+  uint64_t idx[16];
+#pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int64_t i = base + it * kBlock + tid;
-    bool ok = false;
-    int32_t len = 0;
+    ok[it] = i < a.length && ((load_word(a.ivalid, i >> 6) >> (i & 63)) & 1ull);
+    idx[it] = ok[it] ? bin_load_index(a.indices, a.index_type, i) : 0;
+  }
+  if (a.src_valid_bytes != nullptr) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const uint64_t bit = static_cast<uint64_t>(a.src_valid_offset) + idx[it];
+      ok[it] = ok[it] && ((a.src_valid_bytes[bit >> 3] >> (bit & 7)) & 1);
+    }
+  }
+  int32_t start[16], end[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    start[it] = ok[it] ? a.offsets[idx[it]] : 0;
+    end[it] = ok[it] ? a.offsets[idx[it] + 1] : 0;
+  }
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int64_t i = base + it * kBlock + tid;
+    const int32_t len = end[it] - start[it];
     if (i < a.length) {
-      uint64_t idx;
-      ok = bin_slot(a, i, &idx);
-      if (ok) len = a.offsets[idx + 1] - a.offsets[idx];
       lens[i] = len;
+      src_start[i] = start[it];
     }
     mine += len;
-    const uint64_t bal = __ballot(ok);
+    const uint64_t bal = __ballot(ok[it]);
     nvalid += __popcll(bal);
     if (out_validity != nullptr && lane == 0 && (i - lane) < a.length) out_validity[(i - lane) >> 6] = bal;
   }
@@ -163,22 +183,77 @@ __global__ __launch_bounds__(kBlock) void bin_offsets_kernel(int32_t* __restrict
   if (blockIdx.x == gridDim.x - 1 && tid == kBlock - 1) out_offsets[length] = static_cast<int32_t>(block_base[gridDim.x]);
 }
 
-__global__ __launch_bounds__(kBlock) void bin_copy_kernel(BinTakeArgs a, const int32_t* __restrict__ out_offsets,
-                                                          uint8_t* __restrict__ out_data) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.length; i += stride) {
-    const int32_t o0 = out_offsets[i];
-    const int32_t len = out_offsets[i + 1] - o0;
-    if (len == 0) continue;
-    uint64_t idx;
-    (void)bin_slot(a, i, &idx);  // len > 0 => the slot is valid
-    const uint8_t* __restrict__ src = a.data + a.offsets[idx];
-    uint8_t* __restrict__ dst = out_data + o0;
-    int k = 0;
-    if (((reinterpret_cast<uint64_t>(src) | reinterpret_cast<uint64_t>(dst)) & 3) == 0) {
-      for (; k + 4 <= len; k += 4) *reinterpret_cast<uint32_t*>(dst + k) = *reinterpret_cast<const uint32_t*>(src + k);
+// Output-centric copy: one workgroup per kBinChunk output bytes.  It finds the rows overlapping
+// its byte range by binary search in out_offsets, stages their {out offset, source start} through
+// LDS in batches, and every lane then produces one output dword per step: the row of its first
+// byte by binary search in LDS, the following bytes by walking forward (empty rows are skipped).
+// Stores are dense dwords; loads are byte loads that consecutive lanes issue to consecutive
+// source bytes of the same value.
+constexpr int kBinChunk = 16384;   // output bytes per workgroup
+constexpr int kBinBatch = 2048;    // rows staged per pass
+
+__device__ __forceinline__ int64_t bin_row_of(const int32_t* __restrict__ out_offsets, int64_t m, int32_t pos) {
+  // largest r in [0, m) with out_offsets[r] <= pos  (pos < out_offsets[m])
+  int64_t lo = 0, hi = m;  // invariant: out_offsets[lo] <= pos < out_offsets[hi]
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (out_offsets[mid] <= pos) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void bin_copy_kernel(const uint8_t* __restrict__ data,
+                                                          const int32_t* __restrict__ src_start,
+                                                          const int32_t* __restrict__ out_offsets, int64_t m,
+                                                          int64_t total, uint8_t* __restrict__ out_data) {
+  __shared__ int32_t s_out[kBinBatch + 1];
+  __shared__ int32_t s_src[kBinBatch];
+  const int tid = threadIdx.x;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kBinChunk;
+  const int64_t b1 = b0 + kBinChunk < total ? b0 + kBinChunk : total;
+  const int64_t rlo = bin_row_of(out_offsets, m, static_cast<int32_t>(b0));
+  const int64_t rhi = bin_row_of(out_offsets, m, static_cast<int32_t>(b1 - 1));
+  for (int64_t rb = rlo; rb <= rhi; rb += kBinBatch) {
+    const int nb = static_cast<int>(rhi + 1 - rb < kBinBatch ? rhi + 1 - rb : kBinBatch);
+    __syncthreads();
+    for (int k = tid; k <= nb; k += kBlock) s_out[k] = out_offsets[rb + k];
+    for (int k = tid; k < nb; k += kBlock) s_src[k] = src_start[rb + k];
+    __syncthreads();
+    const int64_t lo = s_out[0] > b0 ? s_out[0] : b0;
+    const int64_t hi = s_out[nb] < b1 ? s_out[nb] : b1;
+    if (hi <= lo) continue;
+    const int64_t q0 = lo - static_cast<int64_t>((reinterpret_cast<uint64_t>(out_data) + lo) & 3);
+    for (int64_t q = q0 + 4 * tid; q < hi; q += 4 * kBlock) {
+      const int64_t first = q > lo ? q : lo;
+      // row of `first` inside the batch
+      int l = 0, h = nb;
+      while (h - l > 1) {
+        const int mid = (l + h) >> 1;
+        if (s_out[mid] <= first) l = mid; else h = mid;
+      }
+      int r = l;
+      int32_t r_out = s_out[r], r_end = s_out[r + 1], r_src = s_src[r];
+      uint32_t word = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t pos = q + j;
+        if (pos < lo || pos >= hi) continue;
+        while (pos >= r_end) {
+          ++r;
+          r_out = r_end;
+          r_end = s_out[r + 1];
+          r_src = s_src[r];
+        }
+        word |= static_cast<uint32_t>(data[static_cast<int64_t>(r_src) + (pos - r_out)]) << (8 * j);
+      }
+      if (q >= lo && q + 4 <= hi) {
+        *reinterpret_cast<uint32_t*>(out_data + q) = word;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (q + j >= lo && q + j < hi) out_data[q + j] = static_cast<uint8_t>(word >> (8 * j));
+      }
     }
-    for (; k < len; ++k) dst[k] = src[k];
   }
 }
 
@@ -213,9 +288,14 @@ using namespace arx;
 
 extern "C" {
 
+// workspace: [workgroup byte totals, 64-bit][source start of every output slot, int32]
+static size_t bin_sums_bytes(int64_t num_indices) {
+  return (static_cast<size_t>(ceil_div(num_indices, kBinRows) + 2) * 8 + 63) & ~static_cast<size_t>(63);
+}
+
 size_t arx_binary_take_workspace_bytes(int64_t num_indices) {
   if (num_indices < 0) num_indices = 0;
-  return static_cast<size_t>(ceil_div(num_indices, kBinRows) + 2) * 8 + 64;
+  return bin_sums_bytes(num_indices) + static_cast<size_t>(num_indices) * 4 + 64;
 }
 
 int arx_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices, int index_type, void* ws,
@@ -245,8 +325,9 @@ int arx_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices,
   }
   const int64_t nblocks = ceil_div(a.length, kBinRows);
   long long* sums = static_cast<long long*>(ws);
+  int32_t* src_start = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(ws) + bin_sums_bytes(a.length));
   hipLaunchKernelGGL(bin_lengths_kernel, dim3(static_cast<unsigned>(nblocks)), dim3(kBlock), 0, st, a, out_offsets,
-                     static_cast<uint64_t*>(out_validity), reinterpret_cast<unsigned long long*>(valid_count), sums);
+                     src_start, static_cast<uint64_t*>(out_validity), reinterpret_cast<unsigned long long*>(valid_count), sums);
   ARX_CHECK_LAUNCH("bin_lengths_kernel");
   hipLaunchKernelGGL(bin_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, sums, nblocks);
   ARX_CHECK_LAUNCH("bin_scan_blocks_kernel");
@@ -265,19 +346,27 @@ int arx_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices,
   return ARX_OK;
 }
 
-int arx_binary_take_data(const ArxBinarySpan* values, const ArxSpan* indices, int index_type,
-                         const int32_t* out_offsets, void* out_data, void* stream) {
-  BinTakeArgs a{};
-  const int rc = make_args(values, indices, index_type, &a);
-  if (rc != ARX_OK) return rc;
-  if (a.length == 0) return ARX_OK;
-  if (out_offsets == nullptr) {
-    set_error("out_offsets is NULL");
+int arx_binary_take_data(const ArxBinarySpan* values, int64_t num_indices, const void* ws, size_t ws_bytes,
+                         const int32_t* out_offsets, int64_t total_bytes, void* out_data, void* stream) {
+  if (values == nullptr) {
+    set_error("values is NULL");
     return ARX_INVALID;
   }
-  if (out_data == nullptr || values->data == nullptr) return ARX_OK;  // nothing to copy (total bytes 0)
-  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(a.length, kBlock), 256 * 32)));
-  hipLaunchKernelGGL(bin_copy_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), a, out_offsets,
+  if (num_indices <= 0 || total_bytes <= 0) return ARX_OK;
+  if (out_offsets == nullptr || out_data == nullptr || values->data == nullptr || ws == nullptr ||
+      ws_bytes < arx_binary_take_workspace_bytes(num_indices)) {
+    set_error("binary take: NULL buffer or workspace too small (pass the workspace of arx_binary_take_offsets)");
+    return ARX_INVALID;
+  }
+  if (total_bytes > 2147483647LL) {
+    set_error("binary take: total_bytes does not fit int32 offsets");
+    return ARX_INVALID;
+  }
+  const int32_t* src_start =
+      reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(ws) + bin_sums_bytes(num_indices));
+  const unsigned grid = static_cast<unsigned>(ceil_div(total_bytes, kBinChunk));
+  hipLaunchKernelGGL(bin_copy_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                     static_cast<const uint8_t*>(values->data), src_start, out_offsets, num_indices, total_bytes,
                      static_cast<uint8_t*>(out_data));
   ARX_CHECK_LAUNCH("bin_copy_kernel");
   return ARX_OK;

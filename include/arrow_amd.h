@@ -163,7 +163,9 @@ int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int 
  *   arx_binary_take_offsets (synchronous): out_offsets[0..M] (device int32), out_validity,
  *     valid_count (device, caller-zeroed, may be NULL), *out_total_bytes (host); ARX_INVALID
  *     "offset overflow" if the bytes do not fit int32 offsets.
- *   arx_binary_take_data (asynchronous): the bytes, into out_data[0 .. total).
+ *   arx_binary_take_data (asynchronous): the bytes, into out_data[0 .. total).  `ws` is the
+ *     workspace arx_binary_take_offsets filled (it holds the source position of every slot) and
+ *     must not be reused in between.
  * A filter is arx_mask_to_indices followed by these two.
  * ------------------------------------------------------------------------- */
 typedef struct ArxBinarySpan {
@@ -178,8 +180,8 @@ size_t arx_binary_take_workspace_bytes(int64_t num_indices);
 int arx_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices, int index_type, void* ws,
                             size_t ws_bytes, int32_t* out_offsets, void* out_validity, int64_t* valid_count,
                             int64_t* out_total_bytes, void* stream);
-int arx_binary_take_data(const ArxBinarySpan* values, const ArxSpan* indices, int index_type,
-                         const int32_t* out_offsets, void* out_data, void* stream);
+int arx_binary_take_data(const ArxBinarySpan* values, int64_t num_indices, const void* ws, size_t ws_bytes,
+                         const int32_t* out_offsets, int64_t total_bytes, void* out_data, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Cast float64 -> float32 — replaces CastPrimitive<FloatType,DoubleType>::Exec

@@ -483,3 +483,11 @@ def test_binary_filter(emu_ctx, sel, true_p, vnull, mnull):
     v = U.random_binary(rng, n, null_p=vnull, offset=5, tail=3)
     m = U.random_mask(rng, n, true_p, null_p=mnull, offset=2, tail=1)
     P.check_binary_filter(emu_ctx, v, m, sel)
+
+
+def test_binary_take_many_tiny_values(emu_ctx):
+    """0/1-byte values: a 16 KiB output chunk spans many more rows than one LDS batch holds."""
+    rng = rng_for("btaketiny")
+    v = U.random_binary(rng, 4000, null_p=0.1, max_len=1, empty_p=0.5)
+    i = U.random_array(rng, np.int32, 70000, null_p=0.05, lo=0, hi=3999)
+    P.check_binary_take(emu_ctx, v, i)

@@ -163,6 +163,33 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
     assert chain.equals(pc.cast(pc.filter(f64, mask), pa.float32()))
     assert sum(lib.arrow_amd_plugin_calls(f, 0) for f in (b"array_filter", b"array_take", b"cast")) == stock_before
     assert lib.arrow_amd_plugin_calls(b"array_filter", 1) >= 4 and lib.arrow_amd_plugin_calls(b"array_take", 1) >= 1
+    # utf8 / binary values in HBM: filter == take(GetTakeIndices) on the device, 3 buffers out
+    ns = 400_003
+    lens = rng.integers(0, 20, ns)
+    words = np.array(["".join(chr(97 + (i + j) % 26) for j in range(l)) for i, l in enumerate(lens[:5000])], dtype=object)
+    strs = pa.array(np.tile(words, ns // 5000 + 1)[:ns], type=pa.string(), mask=rng.random(ns) < 0.1)
+    smask = pa.array(rng.random(ns) < 0.3, mask=rng.random(ns) < 0.02)
+    sidx = pa.array(rng.integers(0, ns, 100_000).astype(np.int32), mask=rng.random(100_000) < 0.05)
+    d_strs, d_smask, d_sidx = to_device(strs), to_device(smask), to_device(sidx)
+    gpu_f, gpu_t = lib.arrow_amd_plugin_calls(b"array_filter", 1), lib.arrow_amd_plugin_calls(b"array_take", 1)
+    for typ in (pa.string(), pa.binary()):
+        hs = strs.cast(typ)
+        ds = to_device(hs)
+        cases = [(pc.filter(ds, d_smask), pc.filter(hs, smask)),
+                 (pc.filter(ds, d_smask, null_selection_behavior="emit_null"), pc.filter(hs, smask, null_selection_behavior="emit_null")),
+                 (pc.filter(ds.slice(13), d_smask.slice(13)), pc.filter(hs.slice(13), smask.slice(13))),
+                 (pc.take(ds, d_sidx), pc.take(hs, sidx)),
+                 (pc.take(ds.slice(5, 1000), to_device(pa.array([0, 999, 3], pa.int64()))), pc.take(hs.slice(5, 1000), pa.array([0, 999, 3])))]
+        for got_d, want_h in cases:
+            assert not got_d.is_cpu
+            h = to_host(got_d)
+            assert h.equals(want_h) and h.null_count == want_h.null_count, (typ, len(h), len(want_h))
+    assert lib.arrow_amd_plugin_calls(b"array_filter", 1) == gpu_f + 6 and lib.arrow_amd_plugin_calls(b"array_take", 1) == gpu_t + 4
+    try:
+        pc.take(d_strs, to_device(pa.array(np.array([0, ns], dtype=np.int64))))
+        raise SystemExit("expected IndexError")
+    except pa.lib.ArrowIndexError as e:
+        assert str(e) == f"Index {ns} out of bounds", str(e)
     try:
         pc.take(d_vals, to_device(pa.array(np.array([0, n], dtype=np.int64))))
         raise SystemExit("expected IndexError")

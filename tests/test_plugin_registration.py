@@ -32,6 +32,9 @@ SCRIPT = textwrap.dedent(r'''
               pc.greater(pa.chunked_array([fn.slice(0, 300), fn.slice(300)]), g),
               pc.greater(pa.array([], pa.float64()), pa.array([], pa.float64())),
               pa.table({"x": fn, "y": g}).filter(pc.field("x") > pc.field("y")).column("x").combine_chunks()]
+        strs = pa.array([None if i % 5 == 0 else "s" * (i % 7) for i in range(1000)])
+        gt += [pc.filter(strs, m), pc.take(strs, pa.array([5, 1, 999, None])),
+               pc.filter(strs.cast(pa.binary()), m, null_selection_behavior="emit_null")]
         return gt + [pc.filter(a, m), pc.take(a, pa.array([5, 1, 999])), pc.greater(f, pa.array(f.to_numpy()[::-1].copy())),
                 pc.array_sort_indices(pa.array(np.arange(1000)[::-1].astype(np.uint64))),
                 pc.array_sort_indices(pa.array((np.arange(1000) % 13).astype(np.int64), mask=np.arange(1000) % 9 == 0),
