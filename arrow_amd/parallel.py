@@ -121,6 +121,10 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = values.length
+    if world == 1:
+        # one shard: no splitters, no exchange — the single-GPU kernel path as is
+        perm = cp.call_function("array_sort_indices", [values], cp.ArraySortOptions(order, null_placement))
+        return perm.data[: n * 8].view(torch.int64), 0
     order_code = _lib.SORT_DESCENDING if order == "descending" else _lib.SORT_ASCENDING
     is_signed = int(values.type == int64)
 

@@ -245,6 +245,16 @@ def run_filter_take(args, rank, world, device):
                                   "checksum_matches_sum_of_values": ok}
         except Exception as e:  # never lose the headline line to the secondary measurement
             result["hash_sum"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        # configs[4]: array_sort_indices of a 2B-row uint64 array sharded over the N ranks
+        try:
+            torch.cuda.empty_cache()
+            sec, rows, ok = measure_sort(rank, world, device, args.sort_rows, 2, 1)
+            result["sort_indices"] = {"rows": rows, "n_gpus": world, "ms": round(sec * 1e3, 3),
+                                      "mrows_per_s": round(rows / sec / 1e6, 1), "scaling": "strong",
+                                      "algorithmic_GBps_per_gpu": round(16 * rows / world / sec / 1e9, 1),
+                                      "permutation_and_order_checks": ok}
+        except Exception as e:
+            result["sort_indices"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return result
 
 
@@ -363,6 +373,83 @@ def measure_hash_sum(rank, world, device, rows_total, groups, steps, warmup):
     return elapsed / steps, n * world, int(cs[2].item()), int(cs[0].item()), ok
 
 
+def measure_sort(rank, world, device, rows_total, steps, warmup):
+    """Sharded array_sort_indices (configs[4]): each rank owns rows_total // world contiguous rows of
+    a uint64 array; splitters -> one all-to-all -> local sort.  Returns (seconds per step [max over
+    ranks], rows processed, ok) where ok = the size-independent properties that can be checked
+    without a second exchange: the ranks' slices tile [0, N) and hold a permutation checksum of the
+    global row numbers (sum and sum of squares mod 2^64); on one rank also full sortedness."""
+    import arrow_amd as amd
+    from arrow_amd import parallel
+
+    n = rows_total // world
+    g = torch.Generator(device=device).manual_seed(1010 + rank)
+    keys = torch.empty(n, dtype=torch.int64, device=device)
+    chunk = 1 << 26
+    for b in range(0, n, chunk):
+        e = min(n, b + chunk)
+        keys[b:e] = torch.randint(-2**63, 2**63 - 1, (e - b,), dtype=torch.int64, device=device, generator=g)
+    ak = amd.Array(amd.array.uint64, n, [None, keys.view(torch.uint8)], 0, 0)
+
+    def step():
+        return parallel.sharded_sort_indices(ak)
+
+    for _ in range(warmup):
+        rows, start = step()
+    if world > 1:
+        torch.distributed.barrier()
+    _sync(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rows, start = step()
+    _sync(device)
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total = n * world
+    m = int(rows.numel())
+    s1, s2 = 0, 0
+    for b in range(0, m, chunk):          # wrap-around int64 arithmetic == mod 2^64
+        r = rows[b: b + chunk]
+        s1 += int(r.sum().item())
+        s2 += int((r * r).sum().item())
+    cs = torch.tensor([m, s1 % (1 << 63), s2 % (1 << 63)], dtype=torch.int64, device=device)
+    starts = torch.zeros(world, dtype=torch.int64, device=device)
+    starts[rank] = start
+    lens = torch.zeros(world, dtype=torch.int64, device=device)
+    lens[rank] = m
+    if world > 1:
+        torch.distributed.all_reduce(starts)
+        torch.distributed.all_reduce(lens)
+        parts = [torch.zeros_like(cs) for _ in range(world)]
+        torch.distributed.all_gather(parts, cs)
+    else:
+        parts = [cs]
+    mask64 = (1 << 64) - 1
+    got_s1 = sum(int(p[1].item()) for p in parts)
+    got_s2 = sum(int(p[2].item()) for p in parts)
+    ok = sum(int(p[0].item()) for p in parts) == total
+    # the per-rank values were reduced mod 2^63 from wrapped int64 sums: compare mod 2^63
+    want_s1 = (total * (total - 1) // 2)
+    want_s2 = ((total - 1) * total * (2 * total - 1) // 6)
+    ok = ok and (got_s1 - want_s1) % (1 << 63) == 0 and (got_s2 - want_s2) % (1 << 63) == 0
+    pos = 0
+    for r_ in range(world):
+        ok = ok and int(starts[r_].item()) == pos
+        pos += int(lens[r_].item())
+    if world == 1:
+        for b in range(0, m - 1, chunk):
+            e = min(m, b + chunk + 1)
+            kk = keys[rows[b:e]] ^ (-2**63)
+            ok = ok and bool((kk[1:] >= kk[:-1]).all())
+    del keys, ak, rows
+    return elapsed / steps, total, bool(ok)
+
+
 def run_hash_sum(args, rank, world, device):
     sec, rows, groups_out, checksum, ok = measure_hash_sum(rank, world, device, args.rows, args.groups,
                                                            args.steps, args.warmup)
@@ -391,6 +478,7 @@ def main():
     ap.add_argument("--rows", type=int, default=None)
     ap.add_argument("--groups", type=int, default=10_000_000)
     ap.add_argument("--hash-sum-rows", dest="hash_sum_rows", type=int, default=4_000_000_000)
+    ap.add_argument("--sort-rows", dest="sort_rows", type=int, default=2_000_000_000)
     ap.add_argument("--selectivity", type=float, default=0.10)
     ap.add_argument("--null-p", dest="null_p", type=float, default=0.10)
     ap.add_argument("--cpu-sample-rows", type=int, default=250_000_000)

@@ -154,3 +154,15 @@ def test_config5_sort_indices_1b_rows(gpu_ctx):
             ok = ok and (int(ku[0]) > prev_key or (int(ku[0]) == prev_key and int(ii[0]) > prev_idx))
         prev_key, prev_idx = int(ku[-1]), int(ii[-1])
     assert ok
+
+
+def test_config5_sort_indices_2b_rows_single_gpu(gpu_ctx):
+    """configs[4] at its full size on ONE GPU (the N=1 point of the 1/2/4/8 series), through the
+    bench's own leg: the result is a permutation of 0..N-1 (count, sum and sum of squares of the
+    row numbers) and the keys gathered through it are non-decreasing."""
+    import torch
+
+    import bench
+
+    sec, rows, ok = bench.measure_sort(0, 1, torch.device("cuda", 0), 2_000_000_000, 1, 0)
+    assert rows == 2_000_000_000 and ok

@@ -182,15 +182,17 @@ BENCH_WORKER = textwrap.dedent(r'''
     import bench
     sec, rows, groups_out, checksum, ok = bench.measure_hash_sum(rank, world, torch.device("cpu"), 40000, 700, 1, 1)
     assert ok and rows == 40000 and groups_out == 700, (ok, rows, groups_out)
+    sec, srows, sok = bench.measure_sort(rank, world, torch.device("cpu"), 30000, 1, 1)
+    assert sok and srows == 30000, (sok, srows)
     if rank == 0:
-        print("BENCH_HASH_SUM_OK", json.dumps(dict(rows=rows, groups=groups_out)))
+        print("BENCH_HASH_SUM_OK", json.dumps(dict(rows=rows, groups=groups_out, sort_rows=srows)))
     dist.barrier()
     dist.destroy_process_group()
 ''')
 
 
 def test_bench_measure_hash_sum_world2_gloo():
-    """bench.py's own multi-rank hash_sum leg (the code the driver's --gpus N run executes),
+    """bench.py's own multi-rank hash_sum and sort_indices legs (the code the driver's --gpus N run executes),
     world_size 2 over gloo: rows sharded, partials exchanged, checksum == sum of all values."""
     code = f"ROOT = {ROOT!r}\n" + BENCH_WORKER
     port = 33500 + (os.getpid() % 2000)
