@@ -321,11 +321,19 @@ def _exec_greater(args, options):
         with tracing.span("arx_greater"):
             check(fn(left.values_ptr(), right.values_ptr(), n, out.data_ptr(), stream))
     elif isinstance(left, Array):
-        check(lib.arx_greater_f64_array_scalar(left.values_ptr(), float(_scalar_value(right) or 0.0), n,
-                                               out.data_ptr(), stream))
+        if t == float64:
+            check(lib.arx_greater_f64_array_scalar(left.values_ptr(), float(_scalar_value(right) or 0.0), n,
+                                                   out.data_ptr(), stream))
+        else:
+            check(lib.arx_greater_i64_array_scalar(left.values_ptr(), int(_scalar_value(right) or 0), n,
+                                                   out.data_ptr(), stream))
     else:
-        check(lib.arx_greater_f64_scalar_array(float(_scalar_value(left) or 0.0), right.values_ptr(), n,
-                                               out.data_ptr(), stream))
+        if t == float64:
+            check(lib.arx_greater_f64_scalar_array(float(_scalar_value(left) or 0.0), right.values_ptr(), n,
+                                                   out.data_ptr(), stream))
+        else:
+            check(lib.arx_greater_i64_scalar_array(int(_scalar_value(left) or 0), right.values_ptr(), n,
+                                                   out.data_ptr(), stream))
     validity, nc = _propagate_validity([left, right], n, dev)
     return Array(bool_, n, [validity, out], nc, 0)
 
@@ -333,14 +341,23 @@ def _exec_greater(args, options):
 def _exec_add(args, options):
     """ScalarBinary<..., Add> (codegen_internal.h:814, base_arithmetic_internal.h:45-80)."""
     left, right = args
-    if left.length != right.length:
-        raise ArrowInvalid("Array arguments must all be the same length")
+    if not isinstance(left, Array):      # scalar + array: add commutes
+        left, right = right, left
     dev = left.device
     lib, stream = _lib_and_stream(dev)
     n = left.length
     out = alloc(n * 8, dev)
-    fn = lib.arx_add_i64 if left.type == int64 else lib.arx_add_f64
-    check(fn(left.values_ptr(), right.values_ptr(), n, out.data_ptr(), stream))
+    if isinstance(right, Array):
+        if left.length != right.length:
+            raise ArrowInvalid("Array arguments must all be the same length")
+        fn = lib.arx_add_i64 if left.type == int64 else lib.arx_add_f64
+        check(fn(left.values_ptr(), right.values_ptr(), n, out.data_ptr(), stream))
+    elif left.type == int64:
+        check(lib.arx_add_i64_array_scalar(left.values_ptr(), int(_scalar_value(right) or 0), n, out.data_ptr(),
+                                           stream))
+    else:
+        check(lib.arx_add_f64_array_scalar(left.values_ptr(), float(_scalar_value(right) or 0.0), n,
+                                           out.data_ptr(), stream))
     validity, nc = _propagate_validity([left, right], n, dev)
     return Array(left.type, n, [validity, out], nc, 0)
 
@@ -740,6 +757,8 @@ def greater(left, right):
 
 
 def add(left, right):
+    like = left if isinstance(left, Array) else right
+    left, right = _wrap_scalar(left, like), _wrap_scalar(right, like)
     return call_function("add", [left, right])
 
 

@@ -60,9 +60,9 @@ std::atomic<int64_t> g_min_rows{1 << 16};
 
 // per-function call counters: which exec actually ran (the GPU tests assert on these so that a
 // silent route through the stock CPU kernel is a test failure, not a pass)
-enum Fn { kFnFilter = 0, kFnTake, kFnGreater, kFnSort, kFnCast, kFnHashSum, kNumFn };
+enum Fn { kFnFilter = 0, kFnTake, kFnGreater, kFnSort, kFnCast, kFnHashSum, kFnAdd, kNumFn };
 const char* const kFnNames[kNumFn] = {"array_filter", "array_take", "greater", "array_sort_indices",
-                                      "cast", "hash_sum"};
+                                      "cast", "hash_sum", "add"};
 std::atomic<int64_t> g_fn_gpu[kNumFn];
 std::atomic<int64_t> g_fn_stock[kNumFn];
 void CountGpu(Fn f) {
@@ -922,6 +922,172 @@ Status GreaterExecNP(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::Exec
   return Status::OK();
 }
 
+// ---------------------------------------------------------------- greater(int64), add(int64|double)
+// The same NO_PREALLOCATE twin as GreaterExecNP, generic over the operation: device-resident
+// operands (arrays, or one valid scalar) run on the MI355X and the result stays in HBM; host
+// operands get exactly the buffers the ScalarExecutor would have preallocated and then go to
+// Arrow's stock kernel (these element-wise ops are PCIe-bound for host data).
+StockKernel g_stock_greater_i64, g_stock_add_i64, g_stock_add_f64;
+
+struct OpGreaterI64 {
+  using T = int64_t;
+  using ScalarT = arrow::Int64Scalar;
+  static constexpr bool kBitmapOut = true;
+  static constexpr Fn kFn = kFnGreater;
+  static StockKernel& stock() { return g_stock_greater_i64; }
+  static int aa(const T* l, const T* r, int64_t n, void* o, hipStream_t st) { return arx_greater_i64(l, r, n, static_cast<uint64_t*>(o), st); }
+  static int as(const T* l, T r, int64_t n, void* o, hipStream_t st) { return arx_greater_i64_array_scalar(l, r, n, static_cast<uint64_t*>(o), st); }
+  static int sa(T l, const T* r, int64_t n, void* o, hipStream_t st) { return arx_greater_i64_scalar_array(l, r, n, static_cast<uint64_t*>(o), st); }
+};
+struct OpAddI64 {
+  using T = int64_t;
+  using ScalarT = arrow::Int64Scalar;
+  static constexpr bool kBitmapOut = false;
+  static constexpr Fn kFn = kFnAdd;
+  static StockKernel& stock() { return g_stock_add_i64; }
+  static int aa(const T* l, const T* r, int64_t n, void* o, hipStream_t st) { return arx_add_i64(l, r, n, static_cast<T*>(o), st); }
+  static int as(const T* l, T r, int64_t n, void* o, hipStream_t st) { return arx_add_i64_array_scalar(l, r, n, static_cast<T*>(o), st); }
+  static int sa(T l, const T* r, int64_t n, void* o, hipStream_t st) { return arx_add_i64_array_scalar(r, l, n, static_cast<T*>(o), st); }
+};
+struct OpAddF64 {
+  using T = double;
+  using ScalarT = arrow::DoubleScalar;
+  static constexpr bool kBitmapOut = false;
+  static constexpr Fn kFn = kFnAdd;
+  static StockKernel& stock() { return g_stock_add_f64; }
+  static int aa(const T* l, const T* r, int64_t n, void* o, hipStream_t st) { return arx_add_f64(l, r, n, static_cast<T*>(o), st); }
+  static int as(const T* l, T r, int64_t n, void* o, hipStream_t st) { return arx_add_f64_array_scalar(l, r, n, static_cast<T*>(o), st); }
+  static int sa(T l, const T* r, int64_t n, void* o, hipStream_t st) { return arx_add_f64_array_scalar(r, l, n, static_cast<T*>(o), st); }
+};
+
+template <class Op>
+Status ScalarBinaryNP(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResult* out) {
+  using T = typename Op::T;
+  const int64_t n = batch.length;
+  ArrayData* out_arr = out->array_data().get();
+  out_arr->buffers.resize(2);
+  const bool dev0 = batch[0].is_array() && OnRocm(batch[0].array);
+  const bool dev1 = batch[1].is_array() && OnRocm(batch[1].array);
+  const int64_t data_bytes = Op::kBitmapOut ? ((n + 63) / 64) * 8 : n * static_cast<int64_t>(sizeof(T));
+  if (dev0 || dev1) {
+    for (int i = 0; i < 2; ++i) {
+      if (batch[i].is_array() ? !OnRocm(batch[i].array) : !batch[i].scalar->is_valid) {
+        return Status::NotImplemented("arrow_amd: ", kFnNames[Op::kFn], " on device-resident arrays needs device "
+                                      "arrays or valid scalars on both sides");
+      }
+    }
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    ARROW_ASSIGN_OR_RAISE(out_arr->buffers[1], AllocDevice(data_bytes));
+    void* dout = reinterpret_cast<void*>(out_arr->buffers[1]->mutable_address());
+    ArxSpan sp[2] = {};
+    const T* ptr[2] = {nullptr, nullptr};
+    T sc[2] = {T(0), T(0)};
+    for (int i = 0; i < 2; ++i) {
+      if (batch[i].is_array()) {
+        ARROW_RETURN_NOT_OK(DeviceSpan(batch[i].array, &sp[i]));
+        ptr[i] = static_cast<const T*>(sp[i].data) + sp[i].offset;
+      } else {
+        sc[i] = static_cast<const typename Op::ScalarT&>(*batch[i].scalar).value;
+      }
+    }
+    int rc;
+    if (ptr[0] && ptr[1]) rc = Op::aa(ptr[0], ptr[1], n, dout, st);
+    else if (ptr[0]) rc = Op::as(ptr[0], sc[1], n, dout, st);
+    else rc = Op::sa(sc[0], ptr[1], n, dout, st);
+    ARROW_RETURN_NOT_OK(FromArx(rc));
+    const ArxSpan* with_nulls[2];
+    int nv = 0;
+    for (int i = 0; i < 2; ++i) {
+      if (ptr[i] && sp[i].validity != nullptr) with_nulls[nv++] = &sp[i];
+    }
+    out_arr->buffers[0] = nullptr;
+    out_arr->null_count = 0;
+    if (nv > 0 && n > 0) {
+      ARROW_ASSIGN_OR_RAISE(out_arr->buffers[0], AllocDevice(((n + 63) / 64) * 8));
+      void* dv = reinterpret_cast<void*>(out_arr->buffers[0]->mutable_address());
+      if (nv == 1) {
+        ARROW_RETURN_NOT_OK(FromArx(arx_bitmap_copy(with_nulls[0]->validity, with_nulls[0]->offset, n, dv, st)));
+      } else {
+        ARROW_RETURN_NOT_OK(FromArx(arx_bitmap_and(with_nulls[0]->validity, with_nulls[0]->offset,
+                                                   with_nulls[1]->validity, with_nulls[1]->offset, n, dv, st)));
+      }
+      ARROW_ASSIGN_OR_RAISE(out_arr->null_count, DeviceNullCount(*out_arr->buffers[0], n, st));
+    }
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    CountGpu(Op::kFn);
+    return Status::OK();
+  }
+
+  // ---- host operands: ScalarExecutor::PrepareOutput + PropagateNulls, then Arrow's stock kernel
+  arrow::MemoryPool* pool = ctx->memory_pool();
+  std::shared_ptr<Buffer> data;
+  if (Op::kBitmapOut) {
+    ARROW_ASSIGN_OR_RAISE(data, ctx->AllocateBitmap(n));
+  } else {
+    ARROW_ASSIGN_OR_RAISE(data, ctx->Allocate(data_bytes));
+  }
+  std::shared_ptr<Buffer> validity;
+  int64_t null_count = 0;
+  bool null_scalar = false;
+  const ArraySpan* with_nulls[2];
+  int nv = 0;
+  for (int i = 0; i < 2; ++i) {
+    if (batch[i].is_scalar()) {
+      null_scalar = null_scalar || !batch[i].scalar->is_valid;
+    } else if (batch[i].array.MayHaveNulls()) {
+      with_nulls[nv++] = &batch[i].array;
+    }
+  }
+  if (null_scalar) {
+    ARROW_ASSIGN_OR_RAISE(validity, ctx->AllocateBitmap(n));
+    null_count = n;
+  } else if (nv == 1) {
+    ARROW_ASSIGN_OR_RAISE(validity, arrow::internal::CopyBitmap(pool, with_nulls[0]->buffers[0].data,
+                                                                with_nulls[0]->offset, n));
+    null_count = with_nulls[0]->null_count;
+  } else if (nv == 2) {
+    ARROW_ASSIGN_OR_RAISE(validity, arrow::internal::BitmapAnd(pool, with_nulls[0]->buffers[0].data,
+                                                               with_nulls[0]->offset, with_nulls[1]->buffers[0].data,
+                                                               with_nulls[1]->offset, n, 0));
+    null_count = arrow::kUnknownNullCount;
+  }
+  cp::ExecResult tmp;
+  ArraySpan span;
+  span.type = out_arr->type.get();
+  span.length = n;
+  span.offset = 0;
+  span.null_count = null_count;
+  if (validity) {
+    span.buffers[0].data = validity->mutable_data();
+    span.buffers[0].size = validity->size();
+  }
+  span.buffers[1].data = data->mutable_data();
+  span.buffers[1].size = data->size();
+  tmp.value = std::move(span);
+  CountStock(Op::kFn);
+  ARROW_RETURN_NOT_OK(Op::stock().exec(ctx, batch, &tmp));
+  out_arr->buffers[0] = std::move(validity);
+  out_arr->buffers[1] = std::move(data);
+  out_arr->null_count = null_count;
+  return Status::OK();
+}
+
+template <class Op>
+Status RegisterScalarBinaryNP(cp::FunctionRegistry* reg, const char* name, const std::shared_ptr<arrow::DataType>& t) {
+  ARROW_ASSIGN_OR_RAISE(auto fn, reg->GetFunction(name));
+  auto* sfn = static_cast<cp::ScalarFunction*>(fn.get());
+  ARROW_ASSIGN_OR_RAISE(const cp::Kernel* k0, sfn->DispatchExact({t, t}));
+  cp::ScalarKernel copy = *static_cast<const cp::ScalarKernel*>(k0);
+  Op::stock().exec = copy.exec;
+  Op::stock().init = copy.init;
+  copy.signature = cp::KernelSignature::Make({cp::InputType(t), cp::InputType(t)}, copy.signature->out_type());
+  copy.exec = ScalarBinaryNP<Op>;
+  copy.null_handling = cp::NullHandling::COMPUTED_NO_PREALLOCATE;
+  copy.mem_allocation = cp::MemAllocation::NO_PREALLOCATE;
+  return sfn->AddKernel(std::move(copy));
+}
+
 // ---------------------------------------------------------------- array_sort_indices(uint64|int64)
 StockKernel g_stock_sort[6];  // indexed by ARX_KEY_* (uint64, int64, uint32, int32, float64, float32)
 
@@ -1608,6 +1774,9 @@ Status RegisterAll() {
     copy.mem_allocation = cp::MemAllocation::NO_PREALLOCATE;
     ARROW_RETURN_NOT_OK(sfn->AddKernel(std::move(copy)));
   }
+  ARROW_RETURN_NOT_OK(RegisterScalarBinaryNP<OpGreaterI64>(reg, "greater", arrow::int64()));
+  ARROW_RETURN_NOT_OK(RegisterScalarBinaryNP<OpAddI64>(reg, "add", arrow::int64()));
+  ARROW_RETURN_NOT_OK(RegisterScalarBinaryNP<OpAddF64>(reg, "add", arrow::float64()));
   {
     ARROW_ASSIGN_OR_RAISE(auto stock_cast, reg->GetFunction("cast"));
     ARROW_RETURN_NOT_OK(reg->AddFunction(std::make_shared<RocmCastMetaFunction>(std::move(stock_cast)),
@@ -1658,7 +1827,7 @@ const char* arrow_amd_plugin_last_error(void) { return t_error.c_str(); }
 int64_t arrow_amd_plugin_gpu_calls(void) { return g_gpu_calls.load(); }
 int64_t arrow_amd_plugin_stock_calls(void) { return g_stock_calls.load(); }
 // Calls of `function` ("array_filter", "array_take", "greater", "array_sort_indices", "cast",
-// "hash_sum") that ran on the GPU (gpu != 0) or were handed to the stock CPU kernel; -1 = unknown name.
+// "hash_sum", "add") that ran on the GPU (gpu != 0) or were handed to the stock CPU kernel; -1 = unknown name.
 int64_t arrow_amd_plugin_calls(const char* function, int gpu) {
   for (int i = 0; i < kNumFn; ++i) {
     if (std::strcmp(function, kFnNames[i]) == 0) return (gpu ? g_fn_gpu[i] : g_fn_stock[i]).load();

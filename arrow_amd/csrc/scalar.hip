@@ -155,9 +155,9 @@ __global__ __launch_bounds__(kBlock) void greater_kernel(const T* __restrict__ l
 }
 
 // ------------------------------------------------------------------ add
-template <typename T, bool ALIGNED>
+template <typename T, bool ALIGNED, bool RSCALAR>
 __global__ __launch_bounds__(kBlock) void add_kernel(const T* __restrict__ left,
-                                                     const T* __restrict__ right, int64_t n,
+                                                     const T* __restrict__ right, T rscalar, int64_t n,
                                                      T* __restrict__ out) {
   static_assert(sizeof(T) == 8, "64-bit element types");
   constexpr int U = 4;
@@ -169,7 +169,11 @@ __global__ __launch_bounds__(kBlock) void add_kernel(const T* __restrict__ left,
     for (int u = 0; u < U; ++u) {
       const int64_t row = base + (u * kBlock + threadIdx.x) * 2;
       l[u] = load_pair<T, ALIGNED>(left, row, n);
-      r[u] = load_pair<T, ALIGNED>(right, row, n);
+      if constexpr (RSCALAR) {
+        r[u] = Pair<T>{rscalar, rscalar};
+      } else {
+        r[u] = load_pair<T, ALIGNED>(right, row, n);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -246,20 +250,20 @@ static int launch_greater(const T* left, T ls, const T* right, T rs, int64_t n, 
   return ARX_OK;
 }
 
-template <typename T>
-static int launch_add(const T* left, const T* right, int64_t n, T* out, hipStream_t st) {
-  if (n < 0 || (n > 0 && (left == nullptr || right == nullptr || out == nullptr))) {
+template <typename T, bool RSCALAR>
+static int launch_add(const T* left, const T* right, T rscalar, int64_t n, T* out, hipStream_t st) {
+  if (n < 0 || (n > 0 && (left == nullptr || (!RSCALAR && right == nullptr) || out == nullptr))) {
     set_error("bad arguments to add");
     return ARX_INVALID;
   }
   if (n == 0) return ARX_OK;
-  const bool aligned = ((reinterpret_cast<uint64_t>(left) | reinterpret_cast<uint64_t>(right) |
+  const bool aligned = ((reinterpret_cast<uint64_t>(left) | (RSCALAR ? 0 : reinterpret_cast<uint64_t>(right)) |
                          reinterpret_cast<uint64_t>(out)) & 15) == 0;
   const unsigned grid = stream_grid(kBlock * 2 * 4, n);
   if (aligned) {
-    hipLaunchKernelGGL((add_kernel<T, true>), dim3(grid), dim3(kBlock), 0, st, left, right, n, out);
+    hipLaunchKernelGGL((add_kernel<T, true, RSCALAR>), dim3(grid), dim3(kBlock), 0, st, left, right, rscalar, n, out);
   } else {
-    hipLaunchKernelGGL((add_kernel<T, false>), dim3(grid), dim3(kBlock), 0, st, left, right, n, out);
+    hipLaunchKernelGGL((add_kernel<T, false, RSCALAR>), dim3(grid), dim3(kBlock), 0, st, left, right, rscalar, n, out);
   }
   ARX_CHECK_LAUNCH("add_kernel");
   return ARX_OK;
@@ -313,11 +317,26 @@ int arx_greater_i64(const int64_t* left, const int64_t* right, int64_t length, u
 
 int arx_add_i64(const int64_t* left, const int64_t* right, int64_t length, int64_t* out,
                 void* stream) {
-  return launch_add<int64_t>(left, right, length, out, as_stream(stream));
+  return launch_add<int64_t, false>(left, right, 0, length, out, as_stream(stream));
 }
 int arx_add_f64(const double* left, const double* right, int64_t length, double* out,
                 void* stream) {
-  return launch_add<double>(left, right, length, out, as_stream(stream));
+  return launch_add<double, false>(left, right, 0.0, length, out, as_stream(stream));
+}
+
+int arx_add_i64_array_scalar(const int64_t* left, int64_t right, int64_t length, int64_t* out, void* stream) {
+  return launch_add<int64_t, true>(left, nullptr, right, length, out, as_stream(stream));
+}
+int arx_add_f64_array_scalar(const double* left, double right, int64_t length, double* out, void* stream) {
+  return launch_add<double, true>(left, nullptr, right, length, out, as_stream(stream));
+}
+int arx_greater_i64_array_scalar(const int64_t* left, int64_t right, int64_t length, uint64_t* out_bits,
+                                 void* stream) {
+  return launch_greater<int64_t, kArray, kScalar>(left, 0, nullptr, right, length, out_bits, as_stream(stream));
+}
+int arx_greater_i64_scalar_array(int64_t left, const int64_t* right, int64_t length, uint64_t* out_bits,
+                                 void* stream) {
+  return launch_greater<int64_t, kScalar, kArray>(nullptr, left, right, 0, length, out_bits, as_stream(stream));
 }
 
 int arx_bitmap_copy(const void* bits, int64_t bit_offset, int64_t length, void* out, void* stream) {

@@ -205,6 +205,10 @@ int arx_greater_f64_scalar_array(double left, const double* right, int64_t lengt
                                  uint64_t* out_bits, void* stream);
 int arx_greater_i64(const int64_t* left, const int64_t* right, int64_t length,
                     uint64_t* out_bits, void* stream);
+int arx_greater_i64_array_scalar(const int64_t* left, int64_t right, int64_t length,
+                                 uint64_t* out_bits, void* stream);
+int arx_greater_i64_scalar_array(int64_t left, const int64_t* right, int64_t length,
+                                 uint64_t* out_bits, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Arithmetic — replaces ScalarBinary<Int64,Int64,Int64,Add> / <Double,...>
@@ -215,6 +219,12 @@ int arx_add_i64(const int64_t* left, const int64_t* right, int64_t length, int64
                 void* stream);
 int arx_add_f64(const double* left, const double* right, int64_t length, double* out,
                 void* stream);
+/* array + valid scalar (ScalarBinary::ArrayScalar, codegen_internal.h; add commutes, so
+ * scalar + array is the same call) */
+int arx_add_i64_array_scalar(const int64_t* left, int64_t right, int64_t length, int64_t* out,
+                             void* stream);
+int arx_add_f64_array_scalar(const double* left, double right, int64_t length, double* out,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------
  * Validity plumbing — what ScalarExecutor's null propagation does on the host

@@ -244,6 +244,41 @@ def check_add(amd, left: HostArray, right: HostArray, use_pyarrow=True):
     return out
 
 
+def check_scalar_operand_ops(amd, rng, n=10_000):
+    """add / greater with one valid scalar operand (ScalarBinary::ArrayScalar / ScalarArray,
+    codegen_internal.h; ComparePrimitiveArrayScalar, scalar_compare.cc:189-247): equal to the
+    array-array oracle with the scalar broadcast, and to pyarrow."""
+    for dtype, scalars in ((np.int64, [0, 7, -3, 2**62, -2**63]), (np.float64, [0.0, -1.5, 1e308, float("inf")])):
+        arr = util.random_array(rng, dtype, n, null_p=0.1, offset=3, tail=2)
+        if dtype == np.int64:
+            arr.values[:4] = [2**63 - 1, -2**63, 2**62, -1]          # wrap-around at the edges
+        d = arr.to_device(amd)
+        vals, valid = arr.logical_values(), arr.logical_valid()
+        for sc in scalars:
+            full = np.full(n, sc, dtype=dtype)
+            for out in (amd.compute.add(d, sc), amd.compute.add(sc, d)):
+                got = _data_np(out, dtype)
+                assert_equal(got.view(np.uint64), O.add(vals, full).view(np.uint64), f"add[{dtype.__name__}, scalar {sc}]")
+                gv, pad = _logical_valid(out)
+                assert_equal(gv, valid, "add scalar validity")
+            cases = ((amd.compute.greater(d, sc), (vals, full)), (amd.compute.greater(sc, d), (full, vals)))
+            for out, (l, r) in cases:
+                want = O.greater_i64(l, r) if dtype == np.int64 else O.greater_f64(l, r)
+                bits, pad_ok = device_bitmap_to_bool(out.data, n)
+                assert_equal(bits, oracle_bitmap_to_bool(want, n), f"greater[{dtype.__name__}, scalar {sc}]")
+                assert pad_ok
+            if pc is not None and not (dtype == np.float64 and sc == 1e308):
+                pa_arr = arr.to_pyarrow()
+                psc = pa.scalar(sc, pa.int64() if dtype == np.int64 else pa.float64())
+                ref = pc.add(pa_arr, psc)
+                got = _data_np(amd.compute.add(d, sc), dtype)
+                rv = ref.fill_null(0).to_numpy(zero_copy_only=False)
+                assert_equal(got[valid].view(np.uint64), rv[valid].view(np.uint64), "add scalar vs pyarrow")
+                refg = pc.greater(psc, pa_arr).fill_null(False).to_numpy(zero_copy_only=False)
+                bits, _ = device_bitmap_to_bool(amd.compute.greater(sc, d).data, n)
+                assert_equal(bits[valid], refg[valid], "greater scalar vs pyarrow")
+
+
 # ------------------------------------------------------------------ sort
 def check_sort_indices(amd, arr: HostArray, order="ascending", null_placement="at_end",
                        use_pyarrow=True):

@@ -151,6 +151,23 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
     sel = to_host(pc.filter(d_vals, pc.greater(d_f64, d_f64b)))
     assert sel.equals(pc.filter(vals, pc.greater(f64, f64b)))
     assert lib.arrow_amd_plugin_calls(b"greater", 1) >= 5
+    # arithmetic and int64 compare on the device (wrap-around add, scalar operands)
+    i64b = pa.array(rng.integers(-2**63, 2**63 - 1, n), mask=rng.random(n) < 0.05)
+    d_i64b = to_device(i64b)
+    for dev_out, host_out in ((pc.add(d_vals, d_i64b), pc.add(vals, i64b)), (pc.add(d_vals, 17), pc.add(vals, 17)),
+                              (pc.add(-3, d_i64b), pc.add(-3, i64b)),
+                              (pc.add(d_vals.slice(3, n - 9), d_i64b.slice(9, n - 9)), pc.add(vals.slice(3, n - 9), i64b.slice(9, n - 9))),
+                              (pc.add(d_f64, d_f64b), pc.add(f64, f64b)), (pc.add(d_f64, 0.125), pc.add(f64, 0.125)),
+                              (pc.greater(d_vals, d_i64b), pc.greater(vals, i64b)), (pc.greater(d_vals, 0), pc.greater(vals, 0)),
+                              (pc.greater(12345, d_i64b), pc.greater(12345, i64b))):
+        assert not dev_out.is_cpu
+        ho = to_host(dev_out)
+        assert ho.equals(host_out) and ho.null_count == host_out.null_count
+    # the six device calls ran on the GPU; the six host references went to Arrow's stock kernel
+    assert lib.arrow_amd_plugin_calls(b"add", 1) == 6 and lib.arrow_amd_plugin_calls(b"add", 0) == 6
+    # compare -> filter -> add chain, all in HBM
+    chain2 = to_host(pc.add(pc.filter(d_vals, pc.greater(d_vals, d_i64b)), 1))
+    assert chain2.equals(pc.add(pc.filter(vals, pc.greater(vals, i64b)), 1))
     # sort on the device: uint64 indices stay in HBM and feed take
     skeys = pa.array(rng.integers(0, 2**63, n).astype(np.uint64), mask=rng.random(n) < 0.03)
     d_skeys = to_device(skeys)

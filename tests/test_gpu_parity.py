@@ -690,3 +690,7 @@ def test_binary_take_many_tiny_values(gpu_ctx):
     v = U.random_binary(rng, 4000, null_p=0.1, max_len=1, empty_p=0.5)
     i = U.random_array(rng, np.int32, 2000000, null_p=0.05, lo=0, hi=3999)
     P.check_binary_take(gpu_ctx, v, i)
+
+
+def test_add_and_greater_with_a_scalar_operand(gpu_ctx):
+    P.check_scalar_operand_ops(gpu_ctx, rng_for("scalarops"), n=300007)

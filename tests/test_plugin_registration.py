@@ -32,6 +32,14 @@ SCRIPT = textwrap.dedent(r'''
               pc.greater(pa.chunked_array([fn.slice(0, 300), fn.slice(300)]), g),
               pc.greater(pa.array([], pa.float64()), pa.array([], pa.float64())),
               pa.table({"x": fn, "y": g}).filter(pc.field("x") > pc.field("y")).column("x").combine_chunks()]
+        a2 = pa.array(np.arange(1000)[::-1].copy(), mask=np.arange(1000) % 4 == 0)
+        big = pa.array(np.array([2**63 - 1, -2**63, 5], dtype=np.int64))
+        gt += [pc.add(a, a2), pc.add(a.slice(3, 400), a2.slice(9, 400)), pc.add(a, 5), pc.add(5, a2), pc.add(big, big),
+               pc.add(a, pa.scalar(None, pa.int64())), pc.add(fn, g), pc.add(fn, 0.5), pc.add(f, g),
+               pc.add(pa.chunked_array([a.slice(0, 300), a.slice(300)]), a2), pc.add(pa.scalar(1), pa.scalar(2)),
+               pc.add(pa.array(np.arange(10, dtype=np.int32)), pa.array(np.arange(10, dtype=np.int64))),   # implicit cast
+               pc.greater(a, a2), pc.greater(a, 500), pc.greater(500, a2), pc.greater(a.slice(1, 10), a2.slice(2, 10)),
+               pc.greater(pa.array([], pa.int64()), pa.array([], pa.int64()))]
         strs = pa.array([None if i % 5 == 0 else "s" * (i % 7) for i in range(1000)])
         gt += [pc.filter(strs, m), pc.take(strs, pa.array([5, 1, 999, None])),
                pc.filter(strs.cast(pa.binary()), m, null_selection_behavior="emit_null")]
@@ -60,7 +68,7 @@ SCRIPT = textwrap.dedent(r'''
         assert x.equals(y), (i, x, y)
         if isinstance(x, pa.Array):
             assert x.null_count == y.null_count, i
-    for fn in (b"array_filter", b"array_take", b"greater", b"array_sort_indices", b"cast"):
+    for fn in (b"array_filter", b"array_take", b"greater", b"array_sort_indices", b"cast", b"add"):
         assert lib.arrow_amd_plugin_calls(fn, 0) >= 1, fn     # handed to Arrow's stock kernel
         assert lib.arrow_amd_plugin_calls(fn, 1) == 0, fn     # nothing claimed to be a GPU call
     assert lib.arrow_amd_plugin_calls(b"no_such_function", 0) == -1
