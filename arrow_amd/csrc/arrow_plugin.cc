@@ -316,6 +316,13 @@ bool OnRocm(const ArraySpan& a) {
   return false;
 }
 
+bool DataOnRocm(const ArrayData& a) {
+  for (const auto& b : a.buffers) {
+    if (b != nullptr && b->device_type() == arrow::DeviceAllocationType::kROCM) return true;
+  }
+  return false;
+}
+
 // ArxSpan over device-resident buffers: addresses come from the owning Buffer, not from .data
 Status DeviceSpan(const ArraySpan& a, ArxSpan* out) {
   out->offset = a.offset;
@@ -1573,7 +1580,15 @@ class RocmGroupBySumNode : public ac::ExecNode {
     }
     const ArrayData& k = *batch[key_idx_].array();
     const ArrayData& v = *batch[val_idx_].array();
-    const bool nulls = (k.GetNullCount() != 0) || (v.GetNullCount() != 0);
+    // device-resident batches (kROCM buffers): no staging over PCIe, and never a CPU popcount —
+    // a sliced device array with an unknown null count is treated as "may have nulls"
+    const bool on_device = DataOnRocm(k) || DataOnRocm(v);
+    if (on_device && !(DataOnRocm(k) && DataOnRocm(v))) {
+      return Status::Invalid("aggregate_rocm: key and value columns must both be host or both be device arrays");
+    }
+    const bool nulls = on_device ? (k.buffers[0] != nullptr && k.null_count.load() != 0) ||
+                                       (v.buffers[0] != nullptr && v.null_count.load() != 0)
+                                 : (k.GetNullCount() != 0) || (v.GetNullCount() != 0);
     hipStream_t st;
     ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
     if (!nulls) {
@@ -1593,11 +1608,33 @@ class RocmGroupBySumNode : public ac::ExecNode {
         d_vals_ = nv;
         staged_cap_ = cap;
       }
-      HIP_RETURN_NOT_OK(hipMemcpy(static_cast<int32_t*>(d_keys_) + staged_, k.GetValues<int32_t>(1), n * 4,
-                                  hipMemcpyHostToDevice));
-      HIP_RETURN_NOT_OK(hipMemcpy(static_cast<int64_t*>(d_vals_) + staged_, v.GetValues<int64_t>(1), n * 8,
-                                  hipMemcpyHostToDevice));
+      const void* ksrc = on_device ? reinterpret_cast<const void*>(k.buffers[1]->address() + k.offset * 4)
+                                   : static_cast<const void*>(k.GetValues<int32_t>(1));
+      const void* vsrc = on_device ? reinterpret_cast<const void*>(v.buffers[1]->address() + v.offset * 8)
+                                   : static_cast<const void*>(v.GetValues<int64_t>(1));
+      const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+      HIP_RETURN_NOT_OK(hipMemcpy(static_cast<int32_t*>(d_keys_) + staged_, ksrc, n * 4, kind));
+      HIP_RETURN_NOT_OK(hipMemcpy(static_cast<int64_t*>(d_vals_) + staged_, vsrc, n * 8, kind));
       staged_ += n;
+      return Status::OK();
+    }
+    if (on_device) {
+      ARROW_RETURN_NOT_OK(EnsureState(staged_ + n));
+      auto span_of = [](const ArrayData& a) {
+        ArxSpan sp{};
+        sp.validity = a.buffers[0] ? reinterpret_cast<const void*>(a.buffers[0]->address()) : nullptr;
+        sp.data = reinterpret_cast<const void*>(a.buffers[1]->address());
+        sp.offset = a.offset;
+        sp.length = a.length;
+        const int64_t nc = a.null_count.load();
+        sp.null_count = sp.validity == nullptr ? 0 : (nc > 0 ? nc : arrow::kUnknownNullCount);
+        return sp;
+      };
+      ArxSpan dk = span_of(k), dv = span_of(v);
+      ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_consume(state_, capacity_, &dk, &dv, nullptr, 0, st)));
+      HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+      rows_seen_ += n;
+      CountGpu(kFnHashSum);
       return Status::OK();
     }
     ARROW_RETURN_NOT_OK(EnsureState(staged_ + n));

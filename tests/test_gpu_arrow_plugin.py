@@ -282,3 +282,68 @@ def test_acero_fused_group_by_node():
     code = f"ROOT = {ROOT!r}\n" + ACERO_SCRIPT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "ACERO_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+ACERO_DEVICE_SCRIPT = textwrap.dedent(r'''
+    import ctypes, faulthandler, sys
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    from pyarrow import acero
+    faulthandler.enable()
+    sys.path.insert(0, ROOT)
+    from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(n) for n in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    rng = np.random.default_rng(5)
+    n = 1_000_003
+    for null_p in (0.0, 0.03):
+        mk = (lambda a: pa.array(a, mask=rng.random(n) < null_p)) if null_p else pa.array
+        k = mk(rng.integers(-5000, 5000, n).astype(np.int32))
+        v = mk(rng.integers(-2**63, 2**63 - 1, n))
+        w = mk(rng.integers(-100, 100, n))
+        host = pa.table({"k": k, "v": v, "w": w})
+        dev = pa.table({"k": to_device(k), "v": to_device(v), "w": to_device(w)})
+
+        def plan(table, agg):
+            return acero.Declaration.from_sequence([
+                acero.Declaration("table_source", acero.TableSourceNodeOptions(table)),
+                acero.Declaration("filter", acero.FilterNodeOptions(pc.field("w") > 10)),
+                acero.Declaration("project", acero.ProjectNodeOptions([pc.field("k"), pc.add(pc.field("v"), pc.field("w"))], ["k", "v"])),   # (`+` on expressions is add_checked)
+                acero.Declaration(agg, acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"])),
+            ])
+
+        want = plan(host, "aggregate").to_table(use_threads=False).select(["k", "v_sum"]).sort_by("k")
+        names = (b"greater", b"add", b"array_filter", b"hash_sum")
+        gpu0 = {f: lib.arrow_amd_plugin_calls(f, 1) for f in names}
+        stock0 = {f: lib.arrow_amd_plugin_calls(f, 0) for f in names}
+        for threads in (False, True):
+            got = plan(dev, "aggregate_rocm").to_table(use_threads=threads).sort_by("k")
+            assert got.schema.names == ["k", "v_sum"]
+            assert got.equals(want), (null_p, threads, got.slice(0, 5), want.slice(0, 5))
+        for f in names:   # FilterNode's expression, its per-column Filter, the projection and the group-by all ran on the GPU
+            assert lib.arrow_amd_plugin_calls(f, 1) > gpu0[f], f
+            assert lib.arrow_amd_plugin_calls(f, 0) == stock0[f], f
+    print("ACERO_DEVICE_OK")
+''')
+
+
+def test_acero_plan_over_a_device_resident_table():
+    """SURVEY.md 8 (f2): an ordinary Acero plan table_source -> filter(w > 10) -> project(k, v + w)
+    -> aggregate_rocm over a table whose columns live in HBM.  FilterNode (acero/filter_node.cc:73-108)
+    evaluates the expression through ExecuteScalarExpression (compute/expression.cc:722-798) and calls
+    Filter per column, ProjectNode evaluates `add`; every kernel they reach is one of ours and no
+    batch leaves the device until the (small) group-by result."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + ACERO_DEVICE_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "ACERO_DEVICE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
