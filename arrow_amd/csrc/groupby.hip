@@ -382,7 +382,7 @@ constexpr int kGbTile = 4096;             // rows per scatter tile (8 per thread
 constexpr int kGbRowsPerThread = kGbTile / kGbThreads;
 constexpr int kGbMaxBins = 256;           // per level
 constexpr int kGbMaxBits = 14;
-constexpr int kGbMaxChunks = 2048;
+constexpr int kGbMaxChunks = 4096;      // upper bound of level-1 chunks (sizes hist1)
 constexpr int kGbSlots = 4096;            // LDS table slots per partition
 constexpr int kGbAggChunk = 1 << 16;      // rows per aggregate work unit
 constexpr uint32_t kGbHashMul = 0x9E3779B1u;     // odd => k -> k * M mod 2^32 is a bijection
@@ -412,6 +412,7 @@ struct GbpArgs {
   int64_t* vals_a;
   int32_t* keys_b;
   int64_t* vals_b;
+  int agg_pipe;            // software-pipelined loads in the LDS aggregate kernel (A/B knob)
 };
 
 template <bool HAS_NULLS>
@@ -817,21 +818,35 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
   constexpr int U = 4;  // rows in flight per thread
   const int64_t span = hi - lo;
   const int64_t nit = (span + kGbThreads - 1) / kGbThreads;
-  for (int64_t it0 = 0; it0 < nit; it0 += U) {
-    int32_t kbuf[U];
-    unsigned long long vbuf[U];
-    bool okbuf[U];
+  // software pipeline: the loads of batch i+1 are issued before batch i goes through the LDS
+  // table, so the HBM latency overlaps the (serial, atomic) LDS work of the same wave
+  int32_t kbuf[U], knext[U];
+  unsigned long long vbuf[U], vnext[U];
+  bool okbuf[U], oknext[U];
+  auto load_batch = [&](int64_t it0, int32_t* kb, unsigned long long* vb, bool* ob) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t rr = lo + (it0 + u) * kGbThreads + tid;
-      okbuf[u] = rr < hi;
+      ob[u] = rr < hi;
       if constexpr (DIRECT && HAS_NULLS) {
-        if (okbuf[u]) okbuf[u] = gbp_streamed<true>(a, rr);  // rows with a null were handled by K0
+        if (ob[u]) ob[u] = gbp_streamed<true>(a, rr);  // rows with a null were handled by K0
       }
       const int64_t rc = rr < hi ? rr : hi - 1;  // clamped: always readable
-      kbuf[u] = keys[rc];
-      vbuf[u] = static_cast<unsigned long long>(vals[rc]);
+      kb[u] = keys[rc];
+      vb[u] = static_cast<unsigned long long>(vals[rc]);
     }
+  };
+  const bool pipe = a.agg_pipe != 0;  // A/B knob groupby_agg_pipe (uniform)
+  if (pipe && nit > 0) load_batch(0, knext, vnext, oknext);
+  for (int64_t it0 = 0; it0 < nit; it0 += U) {
+    if (!pipe) load_batch(it0, knext, vnext, oknext);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      kbuf[u] = knext[u];
+      vbuf[u] = vnext[u];
+      okbuf[u] = oknext[u];
+    }
+    if (pipe && it0 + U < nit) load_batch(it0 + U, knext, vnext, oknext);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
     if (!okbuf[u]) continue;
@@ -908,6 +923,8 @@ struct GbpPlan {
 
 static int g_gbp_min_rows = 1 << 17;  // below this the direct HBM-atomics kernel is used
 static int g_gbp_bits = -1;           // -1 = from the capacity hint
+static int g_gbp_agg_pipe = 1;
+static int g_gbp_chunks = 2048;       // level-1 chunks = workgroups of the hist / scatter1 kernels
 
 static int gbp_bits_for(int64_t capacity) {
   if (g_gbp_bits >= 0) return std::min(g_gbp_bits, kGbMaxBits);
@@ -931,7 +948,7 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity) {
   }
   p.slice_rows = slice_rows;
   const int64_t ntiles = ceil_div(std::max<int64_t>(slice_rows, 1), kGbTile);
-  const int64_t chunk_tiles = std::max<int64_t>(1, ceil_div(ntiles, kGbMaxChunks));
+  const int64_t chunk_tiles = std::max<int64_t>(1, ceil_div(ntiles, g_gbp_chunks));
   p.chunk_rows = chunk_tiles * kGbTile;
   p.nchunks = ceil_div(ntiles, chunk_tiles);
   auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
@@ -1019,6 +1036,14 @@ static int read_header(void* state, GroupbyHeader* h, hipStream_t st) {
 int set_groupby_option(const char* name, int64_t value) {
   if (strcmp(name, "groupby_partition_min_rows") == 0) {
     g_gbp_min_rows = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, INT32_MAX)));
+    return 1;
+  }
+  if (strcmp(name, "groupby_chunks") == 0) {
+    g_gbp_chunks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, kGbMaxChunks)));
+    return 1;
+  }
+  if (strcmp(name, "groupby_agg_pipe") == 0) {
+    g_gbp_agg_pipe = value != 0;
     return 1;
   }
   if (strcmp(name, "groupby_partition_bits") == 0) {
@@ -1128,6 +1153,7 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
       a.l1_start = reinterpret_cast<uint32_t*>(w + plan.off_l1_start);
       a.l2_tile_start = reinterpret_cast<uint32_t*>(w + plan.off_l2_tile_start);
       a.agg_unit_start = reinterpret_cast<uint32_t*>(w + plan.off_agg_unit_start);
+      a.agg_pipe = g_gbp_agg_pipe;
       const int rc = (kbm != nullptr || vbm != nullptr) ? gbp_run_slice<true>(v, a, plan, st)
                                                         : gbp_run_slice<false>(v, a, plan, st);
       if (rc != ARX_OK) return rc;
