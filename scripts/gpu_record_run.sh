@@ -4,7 +4,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/${RUN_TAG:-record}
-rm -rf $OUT; mkdir -p $OUT
+mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== headline bench"
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json
