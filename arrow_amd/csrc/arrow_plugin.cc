@@ -188,9 +188,15 @@ int FixedByteWidth(const arrow::DataType& t) {
   switch (t.id()) {
     case Type::INT8: case Type::UINT8: return 1;
     case Type::INT16: case Type::UINT16: case Type::HALF_FLOAT: return 2;
-    case Type::INT32: case Type::UINT32: case Type::FLOAT: case Type::DATE32: case Type::TIME32: return 4;
+    case Type::INT32: case Type::UINT32: case Type::FLOAT: case Type::DATE32: case Type::TIME32:
+    case Type::INTERVAL_MONTHS: case Type::DECIMAL32: return 4;
     case Type::INT64: case Type::UINT64: case Type::DOUBLE: case Type::DATE64: case Type::TIME64:
-    case Type::TIMESTAMP: case Type::DURATION: return 8;
+    case Type::TIMESTAMP: case Type::DURATION: case Type::INTERVAL_DAY_TIME: case Type::DECIMAL64: return 8;
+    case Type::DECIMAL128: case Type::INTERVAL_MONTH_DAY_NANO: return 16;
+    case Type::FIXED_SIZE_BINARY: {
+      const int w = static_cast<const arrow::FixedSizeBinaryType&>(t).byte_width();
+      return (w == 1 || w == 2 || w == 4 || w == 8 || w == 16) ? w : 0;  // other widths: stock kernel
+    }
     default: return 0;
   }
 }
@@ -1718,23 +1724,38 @@ class RocmGroupBySumNode : public ac::ExecNode {
 };
 
 // ---------------------------------------------------------------- registration
-std::vector<std::shared_ptr<arrow::DataType>> FilterValueTypes() {
+// A value type of array_filter / array_take: the concrete type used to find the stock kernel and
+// the matcher the added kernel is registered under (parametric types match by type id).
+struct ValueType {
+  std::shared_ptr<arrow::DataType> probe;
+  cp::InputType match;
+  ValueType(std::shared_ptr<arrow::DataType> t) : probe(t), match(t) {}  // NOLINT
+  ValueType(std::shared_ptr<arrow::DataType> t, Type::type id) : probe(std::move(t)), match(id) {}
+};
+
+std::vector<ValueType> FilterValueTypes() {
   return {arrow::int8(), arrow::uint8(), arrow::int16(), arrow::uint16(), arrow::int32(), arrow::uint32(),
-          arrow::int64(), arrow::uint64(), arrow::float32(), arrow::float64(), arrow::date32(),
-          arrow::date64()};
+          arrow::int64(), arrow::uint64(), arrow::float16(), arrow::float32(), arrow::float64(), arrow::date32(),
+          arrow::date64(), arrow::month_interval(), arrow::day_time_interval(), arrow::month_day_nano_interval(),
+          {arrow::time32(arrow::TimeUnit::SECOND), Type::TIME32},
+          {arrow::time64(arrow::TimeUnit::NANO), Type::TIME64},
+          {arrow::timestamp(arrow::TimeUnit::NANO), Type::TIMESTAMP},
+          {arrow::duration(arrow::TimeUnit::NANO), Type::DURATION},
+          {arrow::decimal128(38, 9), Type::DECIMAL128},
+          {arrow::fixed_size_binary(16), Type::FIXED_SIZE_BINARY}};
 }
 
 Status RegisterVector(cp::FunctionRegistry* reg, const std::string& name,
-                      const std::vector<std::shared_ptr<arrow::DataType>>& first_types,
+                      const std::vector<ValueType>& first_types,
                       const std::vector<cp::InputType>& second, cp::KernelInit init,
                       cp::ArrayKernelExec exec, StockKernel* stock,
                       cp::VectorKernel::ChunkedExec chunked = nullptr) {
   ARROW_ASSIGN_OR_RAISE(auto fn, reg->GetFunction(name));
   if (fn->kind() != cp::Function::VECTOR) return Status::Invalid(name, " is not a vector function");
   auto* vfn = static_cast<cp::VectorFunction*>(fn.get());
-  for (const auto& t : first_types) {
-    std::vector<arrow::TypeHolder> probe{t};
-    std::vector<cp::InputType> in{cp::InputType(t)};
+  for (const auto& vt : first_types) {
+    std::vector<arrow::TypeHolder> probe{vt.probe};
+    std::vector<cp::InputType> in{vt.match};
     if (!second.empty()) {
       // probe with a concrete second argument type
       probe.push_back(name == "array_filter" ? arrow::boolean() : arrow::int32());

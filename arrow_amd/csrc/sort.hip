@@ -35,6 +35,9 @@ static int g_sort_msd_min_rows = 1 << 22;
 static int g_sort_msd_sampled = 1;     // skewed keys: bucket boundaries from a sorted sample
 static int g_sort_msd_fused = 1;       // finish LDS-sized level-2 buckets in one workgroup (msd_bucket_kernel)
 static int64_t g_sort_msd_segment_rows = int64_t(1) << 27;  // above this: an extra top-bits level cuts segments
+static int g_sort_msd_final_rows_log2 = 3;  // log2 of the rows aimed at per final sub-bucket (rank loop length); 4 is 7-10 % slower at >= 2^30 rows
+static int g_sort_msd_small_bucket = 1;  // 512-thread / 5120-row bucket kernel when every bucket fits it
+static int g_sort_msd_seg_min_bits = 1;  // floor of the segment level's bits (more bins = fewer LDS atomic collisions)
 static int g_sort_msd_global_bits = 14;  // (= kMsdMaxBits) cap of the two global levels (tests lower it to reach level 3)
 static int g_sort_fuse_prep = 1;    // first pass reads the caller's column directly (no prep pass)
 static int g_sort_chunks = 2048;    // chunks actually used (arx_set_option "sort_chunks")
@@ -964,23 +967,29 @@ __global__ __launch_bounds__(256) void msd_final_kernel(MsdArgs a, const uint64_
 // straight into LDS (count -> scan -> LDS-atomic cursors), then every row counts the members of its
 // sub-bucket with a smaller (key, row id) and writes its row id at that position of the output.
 // No level-3 round trip through HBM, no halo re-reads: 12 B/row in, 8 B/row out.
+// Two sizes: 1024 threads / 10240 rows (120 KiB of LDS, one workgroup per CU) and 512 threads /
+// 5120 rows (two workgroups per CU, whose load / LDS / store phases overlap) — the host picks the
+// small one whenever the largest bucket fits it.
 constexpr int kBktThreads = 1024;
 constexpr int kBktRows = 10;                       // per thread
 constexpr int kBktCap = kBktThreads * kBktRows;    // 10240 rows = 120 KiB of LDS
+constexpr int kBktThreadsSmall = 512;
+constexpr int kBktCapSmall = kBktThreadsSmall * kBktRows;
 constexpr int kBktMaxBins = 1024;
 
+template <int T>
 struct __attribute__((aligned(16))) MsdBucketLds {
-  uint64_t keys[kBktCap];
-  uint32_t idx[kBktCap];
+  uint64_t keys[T * kBktRows];
+  uint32_t idx[T * kBktRows];
   uint32_t cnt[kBktMaxBins];     // counts, then running cursors
   uint32_t start[kBktMaxBins + 1];
-  uint32_t wave_tot[kBktThreads / 64];
+  uint32_t wave_tot[T / 64];
 };
 
-template <bool SPL>
-__global__ __launch_bounds__(kBktThreads) void msd_bucket_kernel(MsdArgs a, const uint64_t* __restrict__ keys,
-                                                                 const uint32_t* __restrict__ idx) {
-  __shared__ MsdBucketLds w;
+template <bool SPL, int T>
+__global__ __launch_bounds__(T) void msd_bucket_kernel(MsdArgs a, const uint64_t* __restrict__ keys,
+                                                       const uint32_t* __restrict__ idx) {
+  __shared__ MsdBucketLds<T> w;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -988,7 +997,7 @@ __global__ __launch_bounds__(kBktThreads) void msd_bucket_kernel(MsdArgs a, cons
   const int64_t lo = a.part_start[q];
   const int m = static_cast<int>(static_cast<int64_t>(a.part_start[q + 1]) - lo);
   if (m == 0) return;  // workgroup-uniform
-  if (m > kBktCap) {
+  if (m > T * kBktRows) {
     if (tid == 0) atomicOr(a.overflow, 2u);
     return;
   }
@@ -1013,14 +1022,14 @@ __global__ __launch_bounds__(kBktThreads) void msd_bucket_kernel(MsdArgs a, cons
       return a.b3 == 0 ? 0u : (static_cast<uint32_t>((k << a.kshift) >> dshift) & dmask);
     }
   };
-  for (int i = tid; i < nb; i += kBktThreads) w.cnt[i] = 0;
+  for (int i = tid; i < nb; i += T) w.cnt[i] = 0;
   __syncthreads();
   uint64_t key[kBktRows];
   uint32_t id[kBktRows];
   int dig[kBktRows];
 #pragma unroll
   for (int i = 0; i < kBktRows; ++i) {
-    const int p = i * kBktThreads + tid;
+    const int p = i * T + tid;
     dig[i] = -1;
     key[i] = 0;
     id[i] = 0;
@@ -1035,16 +1044,29 @@ __global__ __launch_bounds__(kBktThreads) void msd_bucket_kernel(MsdArgs a, cons
     if (dig[i] >= 0) atomicAdd(&w.cnt[dig[i]], 1u);
   }
   __syncthreads();
-  // exclusive scan of nb <= 1024 counters: one per thread
-  uint32_t c = tid < nb ? w.cnt[tid] : 0u;
-  const uint32_t incl = wave_inclusive_scan_u32(c);
+  // exclusive scan of nb <= 1024 counters: kBktMaxBins / T consecutive counters per thread
+  constexpr int CPT = kBktMaxBins / T;
+  uint32_t c[CPT];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int b = tid * CPT + k;
+    c[k] = b < nb ? w.cnt[b] : 0u;
+    mine += c[k];
+  }
+  const uint32_t incl = wave_inclusive_scan_u32(mine);
   if (lane == 63) w.wave_tot[wave] = incl;
   __syncthreads();
-  uint32_t pre = incl - c;
+  uint32_t pre = incl - mine;
   for (int k = 0; k < wave; ++k) pre += w.wave_tot[k];
-  if (tid < nb) {
-    w.start[tid] = pre;
-    w.cnt[tid] = pre;  // running cursor
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int b = tid * CPT + k;
+    if (b < nb) {
+      w.start[b] = pre;
+      w.cnt[b] = pre;  // running cursor
+    }
+    pre += c[k];
   }
   if (tid == 0) w.start[nb] = static_cast<uint32_t>(m);
   __syncthreads();
@@ -1057,7 +1079,7 @@ __global__ __launch_bounds__(kBktThreads) void msd_bucket_kernel(MsdArgs a, cons
     }
   }
   __syncthreads();
-  for (int i = tid; i < m; i += kBktThreads) {
+  for (int i = tid; i < m; i += T) {
     const uint64_t ki = w.keys[i];
     const uint32_t ii = w.idx[i];
     const uint32_t d = digit_of(ki);
@@ -1133,6 +1155,18 @@ int set_sort_option(const char* name, int64_t value) {
     g_sort_msd_fused = value != 0;
     return 1;
   }
+  if (strcmp(name, "sort_msd_final_rows_log2") == 0) {
+    g_sort_msd_final_rows_log2 = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, 8)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_small_bucket") == 0) {
+    g_sort_msd_small_bucket = value != 0;
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_seg_min_bits") == 0) {
+    g_sort_msd_seg_min_bits = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, 7)));
+    return 1;
+  }
   if (strcmp(name, "sort_msd_segment_rows") == 0) {
     g_sort_msd_segment_rows = std::max<int64_t>(1024, value);
     return 1;
@@ -1172,7 +1206,7 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   a.n = n;
   int lg = 0;
   while ((int64_t(1) << (lg + 1)) <= n) ++lg;
-  int total = lg - 4;  // ~16-32 rows per final bucket
+  int total = lg - g_sort_msd_final_rows_log2;  // default 3: ~8-16 rows per final bucket
   total = std::max(2, std::min(total, std::min(kMsdMaxBits + 9, 64 - kshift)));
   a.bits = std::max(2, std::min(total, g_sort_msd_global_bits));
   total = std::min(total, a.bits + 9);
@@ -1211,10 +1245,10 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   hipLaunchKernelGGL(msd_scan_b_kernel, dim3(1u << a.b1), dim3(64), 0, st, a);
   ARX_CHECK_LAUNCH("msd_scan kernels");
   const bool fused = g_sort_msd_fused != 0 && (n >> a.bits) <= 8192;
+  unsigned int max_part = 0;
   if (fused) {
     // skewed top bits (e.g. normally distributed floats): a bucket would not fit LDS -> do not
     // waste the scatter passes, the caller runs the LSD passes instead
-    unsigned int max_part = 0;
     ARX_HIP(hipMemcpyAsync(&max_part, a.overflow + 1, 4, hipMemcpyDeviceToHost, st));
     ARX_HIP(hipStreamSynchronize(st));
     if (max_part > static_cast<unsigned int>(kBktCap)) {
@@ -1233,9 +1267,15 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   ARX_CHECK_LAUNCH("msd_scatter2_kernel");
   // level-2 buckets that fit LDS: finish each one in a single workgroup (b3 may use 10 bits there)
   if (fused) {
-    a.b3 = std::max(0, std::min(std::min(lg - 3 - a.bits, 10), 64 - kshift - a.bits));  // ~8 rows per sub-bucket
-    hipLaunchKernelGGL((msd_bucket_kernel<false>), dim3(static_cast<unsigned>(nparts)), dim3(kBktThreads), 0, st, a,
-                       keys_y, idx_y);
+    a.b3 = std::max(0, std::min(std::min(lg - (g_sort_msd_final_rows_log2 - 1) - a.bits, 10),
+                                64 - kshift - a.bits));  // default: ~4-8 rows per sub-bucket
+    if (g_sort_msd_small_bucket != 0 && max_part <= static_cast<unsigned int>(kBktCapSmall)) {
+      hipLaunchKernelGGL((msd_bucket_kernel<false, kBktThreadsSmall>), dim3(static_cast<unsigned>(nparts)),
+                         dim3(kBktThreadsSmall), 0, st, a, keys_y, idx_y);
+    } else {
+      hipLaunchKernelGGL((msd_bucket_kernel<false, kBktThreads>), dim3(static_cast<unsigned>(nparts)),
+                         dim3(kBktThreads), 0, st, a, keys_y, idx_y);
+    }
     ARX_CHECK_LAUNCH("msd_bucket_kernel");
   } else {
     const uint64_t* fk = keys_y;
@@ -1382,8 +1422,13 @@ static int run_msd_sort_sampled(const uint64_t* src_keys, const uint32_t* src_id
   }
   hipLaunchKernelGGL(msd_scatter2_s_kernel, dim3(grid2), dim3(kMsdThreads), 0, st, a);
   ARX_CHECK_LAUNCH("msd_scatter2_s_kernel");
-  hipLaunchKernelGGL((msd_bucket_kernel<true>), dim3(static_cast<unsigned>(nparts)), dim3(kBktThreads), 0, st, a,
-                     keys_y, idx_y);
+  if (g_sort_msd_small_bucket != 0 && max_part <= static_cast<unsigned int>(kBktCapSmall)) {
+    hipLaunchKernelGGL((msd_bucket_kernel<true, kBktThreadsSmall>), dim3(static_cast<unsigned>(nparts)),
+                       dim3(kBktThreadsSmall), 0, st, a, keys_y, idx_y);
+  } else {
+    hipLaunchKernelGGL((msd_bucket_kernel<true, kBktThreads>), dim3(static_cast<unsigned>(nparts)),
+                       dim3(kBktThreads), 0, st, a, keys_y, idx_y);
+  }
   ARX_CHECK_LAUNCH("msd_bucket_kernel");
   unsigned int flag = 0;
   ARX_HIP(hipMemcpyAsync(&flag, a.overflow, 4, hipMemcpyDeviceToHost, st));
@@ -1400,6 +1445,7 @@ static int run_msd_sort_segmented(const uint64_t* src_keys, const uint32_t* src_
                                   uint8_t* tables, uint64_t* out_final, hipStream_t st, int* overflowed) {
   int b0 = 1;
   while ((n >> b0) > (int64_t(1) << 27) && b0 < 7) ++b0;
+  b0 = std::max(b0, std::min(g_sort_msd_seg_min_bits, 7));
   MsdArgs a{};
   a.src_keys = src_keys;
   a.src_idx = src_idx;

@@ -89,7 +89,8 @@ def test_pyarrow_compute_dispatches_to_the_hip_kernels():
 
 
 DEVICE_SCRIPT = textwrap.dedent(r'''
-    import ctypes, sys
+    import ctypes, sys, faulthandler
+    faulthandler.enable()
     import numpy as np
     import pyarrow as pa, pyarrow.compute as pc
     sys.path.insert(0, ROOT)
@@ -180,6 +181,39 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
     assert chain.equals(pc.cast(pc.filter(f64, mask), pa.float32()))
     assert sum(lib.arrow_amd_plugin_calls(f, 0) for f in (b"array_filter", b"array_take", b"cast")) == stock_before
     assert lib.arrow_amd_plugin_calls(b"array_filter", 1) >= 4 and lib.arrow_amd_plugin_calls(b"array_take", 1) >= 1
+    # drop_null = Filter(values, <validity bitmap as a boolean array>) (vector_selection.cc:79-91): the
+    # filter's data buffer IS the device validity buffer, so this is the device filter again
+    # (only for arrays with a known null count: Array::null_count() on a SLICED device array would
+    #  popcount HBM from the CPU inside Arrow itself)
+    for dv, hv in ((d_vals, vals), (d_f64, f64)):
+        got_d = pc.drop_null(dv)
+        assert not got_d.is_cpu
+        assert to_host(got_d).equals(pc.drop_null(hv))
+    # the other fixed-width classes of match::Primitive() + decimal128 / fixed_size_binary (widths 2..16 bytes)
+    import decimal
+    nw = 200_003
+    wmask = pa.array(rng.random(nw) < 0.4, mask=rng.random(nw) < 0.03)
+    widx = pa.array(rng.integers(0, nw, 50_000).astype(np.int64), mask=rng.random(50_000) < 0.05)
+    d_wmask, d_widx = to_device(wmask), to_device(widx)
+    raw = rng.integers(-2**62, 2**62, nw)
+    wides = [pa.array(raw, pa.timestamp("ns", tz="UTC"), mask=rng.random(nw) < 0.1),
+             pa.array(raw, pa.duration("us")), pa.array(raw, pa.time64("ns")),
+             pa.array((raw % 86400).astype(np.int32), pa.time32("s"), mask=rng.random(nw) < 0.1),
+             pa.array((raw % 1000).astype(np.float16)),
+             pa.Array.from_buffers(pa.decimal128(38, 4), nw // 2, [None, pa.py_buffer(raw[: nw // 2 * 2].tobytes())]),
+             pa.Array.from_buffers(pa.binary(16), nw // 2, [None, pa.py_buffer(raw[: nw // 2 * 2].tobytes())]),
+             pa.Array.from_buffers(pa.binary(2), nw, [None, pa.py_buffer(raw.astype(np.int16).tobytes())])]
+    for hv in wides:
+        dv = to_device(hv)
+        mlen = len(hv)
+        cases = [(pc.filter(dv, d_wmask.slice(0, mlen)), pc.filter(hv, wmask.slice(0, mlen))),
+                 (pc.filter(dv, d_wmask.slice(0, mlen), null_selection_behavior="emit_null"),
+                  pc.filter(hv, wmask.slice(0, mlen), null_selection_behavior="emit_null")),
+                 (pc.take(dv, to_device(pc.min_element_wise(widx, mlen - 1))), pc.take(hv, pc.min_element_wise(widx, mlen - 1)))]
+        for got_d, want_h in cases:
+            assert not got_d.is_cpu, hv.type
+            h = to_host(got_d)
+            assert h.equals(want_h) and h.null_count == want_h.null_count, (hv.type, len(h), len(want_h))
     # utf8 / binary values in HBM: filter == take(GetTakeIndices) on the device, 3 buffers out
     ns = 400_003
     lens = rng.integers(0, 20, ns)
@@ -201,7 +235,8 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
             assert not got_d.is_cpu
             h = to_host(got_d)
             assert h.equals(want_h) and h.null_count == want_h.null_count, (typ, len(h), len(want_h))
-    assert lib.arrow_amd_plugin_calls(b"array_filter", 1) == gpu_f + 6 and lib.arrow_amd_plugin_calls(b"array_take", 1) == gpu_t + 4
+    assert to_host(pc.drop_null(d_strs)).equals(pc.drop_null(strs))
+    assert lib.arrow_amd_plugin_calls(b"array_filter", 1) == gpu_f + 7 and lib.arrow_amd_plugin_calls(b"array_take", 1) == gpu_t + 4
     try:
         pc.take(d_strs, to_device(pa.array(np.array([0, ns], dtype=np.int64))))
         raise SystemExit("expected IndexError")

@@ -40,6 +40,16 @@ SCRIPT = textwrap.dedent(r'''
                pc.add(pa.array(np.arange(10, dtype=np.int32)), pa.array(np.arange(10, dtype=np.int64))),   # implicit cast
                pc.greater(a, a2), pc.greater(a, 500), pc.greater(500, a2), pc.greater(a.slice(1, 10), a2.slice(2, 10)),
                pc.greater(pa.array([], pa.int64()), pa.array([], pa.int64()))]
+        import decimal
+        ts = pa.array(np.arange(1000) * 1000, pa.timestamp("us", tz="UTC"), mask=np.arange(1000) % 6 == 0)
+        dec = pa.array([None if i % 8 == 0 else decimal.Decimal(i * 1001) / 1000 for i in range(1000)], pa.decimal128(20, 3))
+        fsb16 = pa.array([bytes([i % 251] * 16) for i in range(1000)], pa.binary(16))
+        fsb3 = pa.array([bytes([i % 251] * 3) for i in range(1000)], pa.binary(3))
+        wide = [ts, dec, fsb16, fsb3, pa.array(np.arange(1000, dtype=np.int32), pa.time32("s")),
+                pa.array(np.arange(1000), pa.duration("ns")), pa.array(np.arange(1000, dtype=np.float16))]
+        ix = pa.array([5, 1, 999, None, 0], pa.int16())
+        for wv in wide:
+            gt += [pc.filter(wv, m), pc.filter(wv, m, null_selection_behavior="emit_null"), pc.take(wv, ix)]
         strs = pa.array([None if i % 5 == 0 else "s" * (i % 7) for i in range(1000)])
         gt += [pc.filter(strs, m), pc.take(strs, pa.array([5, 1, 999, None])),
                pc.filter(strs.cast(pa.binary()), m, null_selection_behavior="emit_null")]
