@@ -57,6 +57,11 @@ namespace {
 std::atomic<int64_t> g_gpu_calls{0};
 std::atomic<int64_t> g_stock_calls{0};
 std::atomic<int64_t> g_min_rows{1 << 16};
+// Element-wise kernels (greater, cast) on HOST arrays move more bytes over PCIe than the CPU needs
+// time to compute them (100M rows, one MI355X box: greater 38 ms staged vs 24 ms stock; cast 27 vs
+// 33 ms; filter 17 vs 116 ms; sort 46 ms vs 14.8 s — scripts/exp_plugin_host_staging.py), so by
+// default they stay on Arrow's stock kernels; device-resident arrays always run on the GPU.
+std::atomic<int64_t> g_min_rows_streaming{INT64_MAX};
 
 // per-function call counters: which exec actually ran (the GPU tests assert on these so that a
 // silent route through the stock CPU kernel is a test failure, not a pass)
@@ -796,7 +801,7 @@ StockKernel g_stock_greater;
 // handled by the ScalarExecutor (NullHandling::INTERSECTION), the output bitmap is preallocated.
 Status GreaterExec(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResult* out) {
   if (!batch[0].is_array() || !batch[1].is_array() || !out->is_array_span() ||
-      out->array_span()->offset != 0 || batch.length < g_min_rows.load() ||
+      out->array_span()->offset != 0 || batch.length < g_min_rows_streaming.load() ||
       !IsHost(batch[0].array) || !IsHost(batch[1].array)) {
     CountStock(kFnGreater);
     return g_stock_greater.exec(ctx, batch, out);
@@ -1241,7 +1246,7 @@ class RocmCastMetaFunction : public cp::MetaFunction {
         args[0].array()->type->id() == Type::DOUBLE) {
       ArraySpan in(*args[0].array());
       if (OnRocm(in)) return CastF64F32Device(*args[0].array());
-      if (args[0].length() >= g_min_rows.load() && IsHost(in)) return CastF64F32(*args[0].array(), ctx);
+      if (args[0].length() >= g_min_rows_streaming.load() && IsHost(in)) return CastF64F32(*args[0].array(), ctx);
     }
     CountStock(kFnCast);
     return stock_->Execute(args, options, ctx);
@@ -1946,5 +1951,7 @@ int arrow_amd_copy_to_host(struct ArrowDeviceArray* in, struct ArrowSchema* sche
 }
 // Inputs shorter than this stay on the stock CPU kernels (PCIe staging does not pay).
 void arrow_amd_plugin_set_min_rows(int64_t n) { g_min_rows.store(n); }
+// The same threshold for the element-wise kernels (greater, cast); default: never stage them.
+void arrow_amd_plugin_set_min_rows_streaming(int64_t n) { g_min_rows_streaming.store(n); }
 
 }  // extern "C"

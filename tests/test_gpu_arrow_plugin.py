@@ -54,6 +54,9 @@ SCRIPT = textwrap.dedent(r'''
     lib.arrow_amd_plugin_stock_calls.restype = ctypes.c_int64
     assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
     lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(1000))
+    # element-wise kernels on host arrays stay on the CPU by default (PCIe moves more than the CPU
+    # computes); force the staging path so that it is covered too
+    lib.arrow_amd_plugin_set_min_rows_streaming(ctypes.c_int64(1000))
     ours = run()
     gpu_calls = lib.arrow_amd_plugin_gpu_calls()
     lib.arrow_amd_plugin_calls.restype = ctypes.c_int64

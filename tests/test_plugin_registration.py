@@ -86,6 +86,7 @@ SCRIPT = textwrap.dedent(r'''
     if not torch.cuda.is_available():
         # routed to the HIP path without a device: must raise, not compute somewhere else
         lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(10))
+        lib.arrow_amd_plugin_set_min_rows_streaming(ctypes.c_int64(10))
         for call in (lambda: pc.filter(a, m), lambda: pc.cast(f, pa.float32(), safe=False),
                      lambda: pa.table({"k": pa.array([1, 2, 1], pa.int32()), "v": pa.array([1, 2, 3], pa.int64())})
                      .group_by("k").aggregate([("v", "sum")])):
