@@ -232,6 +232,13 @@ def run_filter_take(args, rank, world, device):
         if args.extras:
             del out, idx, tk
             result["other_paths"] = run_extras(amd, device)
+    watchdog = None
+    if args.extras and world > 1:
+        # The sharded legs below are the only part of this file that depends on collectives with
+        # uneven splits; should one of them wedge on a node, the headline measured above must not be
+        # lost with it: after --extras-timeout seconds rank 0 prints the line it has and every rank exits.
+        watchdog = _ExtrasWatchdog(rank, result, args.extras_timeout)
+        watchdog.start()
     if args.extras:
         # the second half of BASELINE.json's metric: hash_sum group-by, 4B rows / 10M keys, rows
         # sharded over the N ranks (strong scaling), outside the timed region of `value`
@@ -257,7 +264,38 @@ def run_filter_take(args, rank, world, device):
                                       "permutation_and_order_checks": ok}
         except Exception as e:
             result["sort_indices"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if watchdog is not None:
+        watchdog.cancel()
     return result
+
+
+class _ExtrasWatchdog:
+    """Prints the headline line and ends the process if the multi-rank extras do not finish."""
+
+    def __init__(self, rank, result, seconds):
+        import threading
+
+        self.rank, self.result, self.seconds = rank, result, seconds
+        self.done = threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def start(self):
+        self.thread.start()
+
+    def cancel(self):
+        self.done.set()
+
+    def _run(self):
+        if self.done.wait(self.seconds):
+            return
+        if self.rank == 0:
+            line = dict(self.result)
+            for leg in ("hash_sum", "sort_indices"):
+                line.setdefault(leg, {"error": f"did not finish within {self.seconds} s (watchdog)"})
+            print(json.dumps(line), flush=True)
+        else:
+            time.sleep(2.0)   # let rank 0 print first
+        os._exit(0)
 
 
 def load_measured_traffic(n):
@@ -481,6 +519,7 @@ def main():
     ap.add_argument("--groups", type=int, default=10_000_000)
     ap.add_argument("--hash-sum-rows", dest="hash_sum_rows", type=int, default=4_000_000_000)
     ap.add_argument("--sort-rows", dest="sort_rows", type=int, default=2_000_000_000)
+    ap.add_argument("--extras-timeout", dest="extras_timeout", type=float, default=300.0)
     ap.add_argument("--selectivity", type=float, default=0.10)
     ap.add_argument("--null-p", dest="null_p", type=float, default=0.10)
     ap.add_argument("--cpu-sample-rows", type=int, default=250_000_000)
