@@ -1481,11 +1481,18 @@ namespace ac = arrow::acero;
 
 class RocmGroupBySumNode : public ac::ExecNode {
  public:
+  // one output column per requested aggregate; all of them read the same fused per-group state
+  // (wrap-around sum, count of valid values, "a null value was seen")
+  struct AggSpec {
+    bool is_count = false;               // hash_count (CountOptions::ONLY_VALID) instead of hash_sum
+    cp::ScalarAggregateOptions options;  // hash_sum: skip_nulls / min_count
+  };
+
   RocmGroupBySumNode(ac::ExecPlan* plan, std::vector<ac::ExecNode*> inputs,
                      std::shared_ptr<arrow::Schema> out_schema, int key_idx, int val_idx,
-                     cp::ScalarAggregateOptions options)
+                     std::vector<AggSpec> aggs)
       : ac::ExecNode(plan, std::move(inputs), {"input"}, std::move(out_schema)),
-        key_idx_(key_idx), val_idx_(val_idx), options_(std::move(options)) {}
+        key_idx_(key_idx), val_idx_(val_idx), aggs_(std::move(aggs)) {}
 
   ~RocmGroupBySumNode() override {
     for (void* p : {state_, d_keys_, d_vals_}) {
@@ -1498,30 +1505,53 @@ class RocmGroupBySumNode : public ac::ExecNode {
     if (inputs.size() != 1) return Status::Invalid("aggregate_rocm takes exactly one input");
     const auto* opts = dynamic_cast<const ac::AggregateNodeOptions*>(&options);
     if (opts == nullptr) return Status::TypeError("aggregate_rocm expects AggregateNodeOptions");
-    if (opts->keys.size() != 1 || !opts->segment_keys.empty() || opts->aggregates.size() != 1 ||
-        opts->aggregates[0].function != "hash_sum" || opts->aggregates[0].target.size() != 1) {
-      return Status::NotImplemented("aggregate_rocm: one key, no segment keys, one hash_sum aggregate");
+    if (opts->keys.size() != 1 || !opts->segment_keys.empty() || opts->aggregates.empty()) {
+      return Status::NotImplemented("aggregate_rocm: one key, no segment keys, at least one aggregate");
     }
     const auto& in_schema = *inputs[0]->output_schema();
     ARROW_ASSIGN_OR_RAISE(auto kpath, opts->keys[0].FindOne(in_schema));
-    ARROW_ASSIGN_OR_RAISE(auto vpath, opts->aggregates[0].target[0].FindOne(in_schema));
-    if (kpath.indices().size() != 1 || vpath.indices().size() != 1) {
-      return Status::NotImplemented("aggregate_rocm: nested field references");
+    if (kpath.indices().size() != 1) return Status::NotImplemented("aggregate_rocm: nested field references");
+    const int ki = kpath[0];
+    int vi = -1;
+    std::vector<AggSpec> aggs;
+    std::vector<std::shared_ptr<arrow::Field>> fields{in_schema.field(ki)};
+    for (const auto& agg : opts->aggregates) {
+      AggSpec spec;
+      if (agg.function == "hash_count") {
+        spec.is_count = true;
+        if (agg.options != nullptr) {
+          const auto* co = dynamic_cast<const cp::CountOptions*>(agg.options.get());
+          if (co == nullptr) return Status::TypeError("aggregate_rocm: hash_count takes CountOptions");
+          if (co->mode != cp::CountOptions::ONLY_VALID) {
+            return Status::NotImplemented("aggregate_rocm: hash_count with CountOptions::ONLY_VALID only");
+          }
+        }
+      } else if (agg.function == "hash_sum") {
+        if (agg.options != nullptr) {
+          const auto* so = dynamic_cast<const cp::ScalarAggregateOptions*>(agg.options.get());
+          if (so == nullptr) return Status::TypeError("aggregate_rocm: hash_sum takes ScalarAggregateOptions");
+          spec.options = *so;
+        }
+      } else {
+        return Status::NotImplemented("aggregate_rocm: hash_sum and hash_count only, got ", agg.function);
+      }
+      if (agg.target.size() != 1) return Status::NotImplemented("aggregate_rocm: unary aggregates only");
+      ARROW_ASSIGN_OR_RAISE(auto vpath, agg.target[0].FindOne(in_schema));
+      if (vpath.indices().size() != 1) return Status::NotImplemented("aggregate_rocm: nested field references");
+      if (vi >= 0 && vpath[0] != vi) {
+        return Status::NotImplemented("aggregate_rocm: all aggregates must read the same value column");
+      }
+      vi = vpath[0];
+      aggs.push_back(spec);
+      fields.push_back(arrow::field(agg.name, arrow::int64()));
     }
-    const int ki = kpath[0], vi = vpath[0];
     if (in_schema.field(ki)->type()->id() != Type::INT32 || in_schema.field(vi)->type()->id() != Type::INT64) {
       return Status::NotImplemented("aggregate_rocm: hash_sum(int64) GROUP BY int32 only, got key ",
                                     in_schema.field(ki)->type()->ToString(), " value ",
                                     in_schema.field(vi)->type()->ToString());
     }
-    cp::ScalarAggregateOptions agg_opts;
-    if (opts->aggregates[0].options != nullptr) {
-      const auto* so = dynamic_cast<const cp::ScalarAggregateOptions*>(opts->aggregates[0].options.get());
-      if (so == nullptr) return Status::TypeError("aggregate_rocm: hash_sum takes ScalarAggregateOptions");
-      agg_opts = *so;
-    }
-    auto out_schema = arrow::schema({in_schema.field(ki), arrow::field(opts->aggregates[0].name, arrow::int64())});
-    return plan->EmplaceNode<RocmGroupBySumNode>(plan, std::move(inputs), std::move(out_schema), ki, vi, agg_opts);
+    return plan->EmplaceNode<RocmGroupBySumNode>(plan, std::move(inputs), arrow::schema(std::move(fields)), ki, vi,
+                                                 std::move(aggs));
   }
 
   const char* kind_name() const override { return "RocmGroupBySumNode"; }
@@ -1681,10 +1711,10 @@ class RocmGroupBySumNode : public ac::ExecNode {
     ARROW_RETURN_NOT_OK(FromArx(arx_groupby_num_groups(state_, &g, st)));
     arrow::MemoryPool* pool = plan_->query_context()->memory_pool();
     ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> keys, arrow::AllocateBuffer(g * 4, pool));
-    ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> sums, arrow::AllocateBuffer(g * 8, pool));
-    std::vector<uint8_t> key_valid(g), sum_valid(g);
+    std::vector<uint8_t> key_valid(g);
+    std::vector<arrow::Datum> columns(1 + aggs_.size());
+    void *k = nullptr, *kv = nullptr, *s = nullptr, *c = nullptr, *nn = nullptr, *ok = nullptr;
     if (g > 0) {
-      void *k, *kv, *s, *c, *nn, *ok;
       ARROW_RETURN_NOT_OK(t_scratch.Get(kValues, g * 4 + 16, &k));
       ARROW_RETURN_NOT_OK(t_scratch.Get(kValidity, g + 16, &kv));
       ARROW_RETURN_NOT_OK(t_scratch.Get(kArg2, g * 8 + 16, &s));
@@ -1693,22 +1723,37 @@ class RocmGroupBySumNode : public ac::ExecNode {
       ARROW_RETURN_NOT_OK(t_scratch.Get(kOutData, g + 16, &ok));
       ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_export(state_, (int32_t*)k, (uint8_t*)kv, (int64_t*)s,
                                                              (int64_t*)c, (uint8_t*)nn, st)));
-      ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_finalize((const int64_t*)c, (const uint8_t*)nn, g,
-                                                               options_.skip_nulls ? 1 : 0, options_.min_count,
-                                                               (uint8_t*)ok, st)));
       HIP_RETURN_NOT_OK(hipMemcpyAsync(keys->mutable_data(), k, g * 4, hipMemcpyDeviceToHost, st));
-      HIP_RETURN_NOT_OK(hipMemcpyAsync(sums->mutable_data(), s, g * 8, hipMemcpyDeviceToHost, st));
       HIP_RETURN_NOT_OK(hipMemcpyAsync(key_valid.data(), kv, g, hipMemcpyDeviceToHost, st));
-      HIP_RETURN_NOT_OK(hipMemcpyAsync(sum_valid.data(), ok, g, hipMemcpyDeviceToHost, st));
-      HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
     }
+    for (size_t ai = 0; ai < aggs_.size(); ++ai) {
+      const AggSpec& spec = aggs_[ai];
+      ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> data, arrow::AllocateBuffer(g * 8, pool));
+      std::shared_ptr<Buffer> bits;
+      if (spec.is_count) {
+        // GroupedCountImpl (hash_aggregate.cc): the count of valid values, never null
+        if (g > 0) HIP_RETURN_NOT_OK(hipMemcpyAsync(data->mutable_data(), c, g * 8, hipMemcpyDeviceToHost, st));
+        HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+      } else {
+        std::vector<uint8_t> sum_valid(g);
+        if (g > 0) {
+          ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_finalize((const int64_t*)c, (const uint8_t*)nn, g,
+                                                                   spec.options.skip_nulls ? 1 : 0,
+                                                                   spec.options.min_count, (uint8_t*)ok, st)));
+          HIP_RETURN_NOT_OK(hipMemcpyAsync(data->mutable_data(), s, g * 8, hipMemcpyDeviceToHost, st));
+          HIP_RETURN_NOT_OK(hipMemcpyAsync(sum_valid.data(), ok, g, hipMemcpyDeviceToHost, st));
+        }
+        HIP_RETURN_NOT_OK(hipStreamSynchronize(st));  // `ok` is reused by the next aggregate
+        ARROW_ASSIGN_OR_RAISE(bits, arrow::internal::BytesToBits(sum_valid, pool));
+      }
+      std::vector<std::shared_ptr<Buffer>> bufs{std::move(bits), std::move(data)};
+      columns[1 + ai] = arrow::Datum(ArrayData::Make(arrow::int64(), g, std::move(bufs)));
+    }
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
     ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> kbits, arrow::internal::BytesToBits(key_valid, pool));
-    ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> sbits, arrow::internal::BytesToBits(sum_valid, pool));
     std::vector<std::shared_ptr<Buffer>> kbufs{std::move(kbits), std::move(keys)};
-    std::vector<std::shared_ptr<Buffer>> sbufs{std::move(sbits), std::move(sums)};
-    cp::ExecBatch out({arrow::Datum(ArrayData::Make(arrow::int32(), g, std::move(kbufs))),
-                       arrow::Datum(ArrayData::Make(arrow::int64(), g, std::move(sbufs)))},
-                      g);
+    columns[0] = arrow::Datum(ArrayData::Make(arrow::int32(), g, std::move(kbufs)));
+    cp::ExecBatch out(std::move(columns), g);
     const int64_t batch_size = 32768;
     const int nb = static_cast<int>(std::max<int64_t>(1, (g + batch_size - 1) / batch_size));
     for (int i = 0; i < nb; ++i) {
@@ -1718,7 +1763,7 @@ class RocmGroupBySumNode : public ac::ExecNode {
   }
 
   const int key_idx_, val_idx_;
-  const cp::ScalarAggregateOptions options_;
+  const std::vector<AggSpec> aggs_;
   std::mutex mu_;
   ac::AtomicCounter counter_;
   void* state_ = nullptr;

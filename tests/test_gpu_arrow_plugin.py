@@ -302,6 +302,28 @@ ACERO_SCRIPT = textwrap.dedent(r'''
     # mixed: some chunks with nulls, some without, several chunks
     tm = pa.concat_tables([t.select(["k", "v"]).slice(0, 500_000), tn.slice(0, 400_000), t.select(["k", "v"]).slice(500_000, 700_000)])
     same(fused(tm), tm.group_by("k", use_threads=False).aggregate([("v", "sum")]))
+    # several aggregates over the same value column share one fused pass: sum, count (valid values),
+    # a second sum with other options; host and device-resident input
+    o3 = pc.ScalarAggregateOptions(skip_nulls=False, min_count=3)
+    multi = acero.Declaration.from_sequence([
+        acero.Declaration("table_source", acero.TableSourceNodeOptions(tn)),
+        acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions(
+            [("v", "hash_sum", None, "s"), ("v", "hash_count", None, "c"), ("v", "hash_sum", o3, "s3")], keys=["k"])),
+    ]).to_table().sort_by("k")
+    ref = tn.group_by("k", use_threads=False).aggregate([("v", "sum"), ("v", "count"), ("v", "sum", o3)]).sort_by("k")
+    assert multi.schema.names == ["k", "s", "c", "s3"], multi.schema
+    assert multi.column("k").equals(ref.column("k"))
+    for ours, theirs in (("s", 1), ("c", 2), ("s3", 3)):     # (pyarrow puts the key column first)
+        assert multi.column(ours).equals(ref.column(theirs)), ours
+    assert multi.column("c").null_count == 0
+    try:
+        fused_bad = acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tn)),
+            acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_count", pc.CountOptions(mode="all"), "c")], keys=["k"]))])
+        fused_bad.to_table()
+        raise SystemExit("expected NotImplemented for CountOptions(mode=all)")
+    except pa.lib.ArrowNotImplementedError:
+        pass
     empty = pa.table({"k": pa.array([], pa.int32()), "v": pa.array([], pa.int64())})
     assert fused(empty).num_rows == 0
     try:
