@@ -41,6 +41,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/arrow_amd.h"
@@ -232,17 +233,102 @@ class RocmDevice : public arrow::Device {
   int id_;
 };
 
-// an owned hipMalloc allocation
+// Caching device allocator behind RocmMemoryManager: hipMalloc / hipFree cost tens of microseconds
+// each and serialise the device, which dominates Acero-sized (32K-row) batches — a filter
+// allocates two buffers per column per batch.  Freed blocks are kept on per-size-class free lists
+// (power-of-two classes below 1 MiB, 8 classes per octave above: <= 12.5 % slack) up to a byte
+// limit (ARROW_AMD_POOL_LIMIT_MB, default 32768).  Reuse is safe without stream ordering because
+// every shim synchronises its stream before it returns, i.e. before Arrow can drop a buffer.
+class DevicePool {
+ public:
+  static DevicePool& Get() {
+    static DevicePool* pool = new DevicePool();  // leaked on purpose: buffers may outlive static destruction
+    return *pool;
+  }
+  static size_t SizeClass(size_t bytes) {
+    bytes = std::max<size_t>(bytes, 256);
+    size_t p2 = 256;
+    while (p2 < bytes) p2 <<= 1;
+    if (p2 <= (size_t(1) << 20)) return p2;
+    const size_t step = p2 >> 4;  // (p2/2, p2] in 8 steps of p2/16
+    return (bytes + step - 1) / step * step;
+  }
+  Status Allocate(size_t bytes, void** out, size_t* cap) {
+    const size_t c = SizeClass(bytes);
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      auto it = free_.find(c);
+      if (it != free_.end() && !it->second.empty()) {
+        *out = it->second.back();
+        it->second.pop_back();
+        cached_bytes_ -= c;
+        ++hits_;
+        *cap = c;
+        return Status::OK();
+      }
+      ++misses_;
+    }
+    hipError_t e = hipMalloc(out, c);
+    if (e != hipSuccess) {
+      Trim();  // give the cached blocks back and retry once
+      e = hipMalloc(out, c);
+    }
+    if (e != hipSuccess) return Status::OutOfMemory("hipMalloc of ", c, " bytes: ", hipGetErrorString(e));
+    *cap = c;
+    return Status::OK();
+  }
+  void Release(void* p, size_t cap) {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      if (cached_bytes_ + cap <= limit_) {
+        free_[cap].push_back(p);
+        cached_bytes_ += cap;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+  void Trim() {
+    std::unordered_map<size_t, std::vector<void*>> drop;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      drop.swap(free_);
+      cached_bytes_ = 0;
+    }
+    for (auto& kv : drop) {
+      for (void* p : kv.second) (void)hipFree(p);
+    }
+  }
+  void Stats(int64_t* cached, int64_t* hits, int64_t* misses) {
+    std::lock_guard<std::mutex> lock(mu_);
+    *cached = static_cast<int64_t>(cached_bytes_);
+    *hits = hits_;
+    *misses = misses_;
+  }
+
+ private:
+  DevicePool() {
+    const char* env = std::getenv("ARROW_AMD_POOL_LIMIT_MB");
+    limit_ = (env != nullptr ? static_cast<size_t>(std::strtoull(env, nullptr, 10)) : size_t(32768)) << 20;
+  }
+  std::mutex mu_;
+  std::unordered_map<size_t, std::vector<void*>> free_;
+  size_t cached_bytes_ = 0, limit_ = 0;
+  int64_t hits_ = 0, misses_ = 0;
+};
+
+// an owned device allocation (returned to the pool on destruction)
 class RocmBuffer : public arrow::MutableBuffer {
  public:
-  RocmBuffer(uint8_t* ptr, int64_t size, std::shared_ptr<arrow::MemoryManager> mm)
-      : arrow::MutableBuffer(ptr, size, std::move(mm)), ptr_(ptr) {}
+  RocmBuffer(uint8_t* ptr, int64_t size, size_t capacity, std::shared_ptr<arrow::MemoryManager> mm)
+      : arrow::MutableBuffer(ptr, size, std::move(mm)), ptr_(ptr), capacity_(capacity) {}
   ~RocmBuffer() override {
-    if (ptr_) (void)hipFree(ptr_);
+    if (ptr_) DevicePool::Get().Release(ptr_, capacity_);
   }
 
  private:
   uint8_t* ptr_;
+  size_t capacity_;
 };
 
 class RocmMemoryManager : public arrow::MemoryManager {
@@ -257,11 +343,11 @@ class RocmMemoryManager : public arrow::MemoryManager {
   }
   arrow::Result<std::unique_ptr<Buffer>> AllocateBuffer(int64_t size) override {
     void* p = nullptr;
+    size_t cap = 0;
     // padded like Arrow's pools (64 bytes) so that whole-word bitmap stores stay inside
     const size_t bytes = (static_cast<size_t>(std::max<int64_t>(size, 1)) + 63) & ~size_t(63);
-    const hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return Status::OutOfMemory("hipMalloc of ", bytes, " bytes: ", hipGetErrorString(e));
-    return std::unique_ptr<Buffer>(new RocmBuffer(static_cast<uint8_t*>(p), size, shared_from_this()));
+    ARROW_RETURN_NOT_OK(DevicePool::Get().Allocate(bytes, &p, &cap));
+    return std::unique_ptr<Buffer>(new RocmBuffer(static_cast<uint8_t*>(p), size, cap, shared_from_this()));
   }
 
  protected:
@@ -1107,7 +1193,13 @@ Status RegisterScalarBinaryNP(cp::FunctionRegistry* reg, const char* name, const
 }
 
 // ---------------------------------------------------------------- array_sort_indices(uint64|int64)
-StockKernel g_stock_sort[6];  // indexed by ARX_KEY_* (uint64, int64, uint32, int32, float64, float32)
+// One slot per registered value type: 0-5 = the ARX_KEY_* types themselves, 6-11 = temporal types
+// sorted by their physical integer (date32, date64, timestamp, duration, time32, time64).
+constexpr int kSortSlots = 12;
+constexpr int kSortSlotKey[kSortSlots] = {ARX_KEY_UINT64, ARX_KEY_INT64, ARX_KEY_UINT32, ARX_KEY_INT32,
+                                          ARX_KEY_FLOAT64, ARX_KEY_FLOAT32, ARX_KEY_INT32, ARX_KEY_INT64,
+                                          ARX_KEY_INT64, ARX_KEY_INT64, ARX_KEY_INT32, ARX_KEY_INT64};
+StockKernel g_stock_sort[kSortSlots];
 
 arrow::Result<std::unique_ptr<cp::KernelState>> SortInitImpl(const StockKernel& stock,
                                                              cp::KernelContext* ctx,
@@ -1220,7 +1312,7 @@ Status SortChunkedT(cp::KernelContext* c, const cp::ExecBatch& b, arrow::Datum* 
 }
 template <int K>
 Status SortExecT(cp::KernelContext* c, const cp::ExecSpan& b, cp::ExecResult* o) {
-  return SortExecNP(g_stock_sort[K], K, c, b, o);
+  return SortExecNP(g_stock_sort[K], kSortSlotKey[K], c, b, o);
 }
 
 // ---------------------------------------------------------------- cast(float64 -> float32)
@@ -1869,6 +1961,12 @@ Status RegisterAll() {
   ARX_REGISTER_SORT(ARX_KEY_INT32, arrow::int32());
   ARX_REGISTER_SORT(ARX_KEY_FLOAT64, arrow::float64());
   ARX_REGISTER_SORT(ARX_KEY_FLOAT32, arrow::float32());
+  ARX_REGISTER_SORT(6, arrow::date32());
+  ARX_REGISTER_SORT(7, arrow::date64());
+  ARX_REGISTER_SORT(8, ValueType(arrow::timestamp(arrow::TimeUnit::NANO), Type::TIMESTAMP));
+  ARX_REGISTER_SORT(9, ValueType(arrow::duration(arrow::TimeUnit::NANO), Type::DURATION));
+  ARX_REGISTER_SORT(10, ValueType(arrow::time32(arrow::TimeUnit::SECOND), Type::TIME32));
+  ARX_REGISTER_SORT(11, ValueType(arrow::time64(arrow::TimeUnit::NANO), Type::TIME64));
 #undef ARX_REGISTER_SORT
   {
     ARROW_ASSIGN_OR_RAISE(auto fn, reg->GetFunction("greater"));
@@ -1994,6 +2092,12 @@ int arrow_amd_copy_to_host(struct ArrowDeviceArray* in, struct ArrowSchema* sche
   }
   return 0;
 }
+// The caching device allocator: bytes parked on free lists, allocations served from them / by hipMalloc.
+void arrow_amd_plugin_pool_stats(int64_t* cached_bytes, int64_t* hits, int64_t* misses) {
+  DevicePool::Get().Stats(cached_bytes, hits, misses);
+}
+// Returns every cached block to the driver.
+void arrow_amd_plugin_pool_trim(void) { DevicePool::Get().Trim(); }
 // Inputs shorter than this stay on the stock CPU kernels (PCIe staging does not pay).
 void arrow_amd_plugin_set_min_rows(int64_t n) { g_min_rows.store(n); }
 // The same threshold for the element-wise kernels (greater, cast); default: never stage them.

@@ -125,6 +125,12 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
     want = dict(f=pc.filter(vals, mask), fe=pc.filter(vals, mask, null_selection_behavior="emit_null"),
                 fs=pc.filter(vals.slice(7), mask.slice(7)), t=pc.take(vals, idx),
                 c=pc.cast(f64, pa.float32()), cs=pc.cast(f64.slice(9), pa.float32()))
+    want_chain = pc.cast(pc.filter(f64, mask), pa.float32())
+    # (pa.array(ndarray, type=...) itself calls `cast`: build these before the counters are read)
+    temporal_keys = [pa.array(rng.integers(-2**62, 2**62, n), pa.timestamp("us"), mask=rng.random(n) < 0.02),
+                     pa.array(rng.integers(-2**31, 2**31 - 1, n).astype(np.int32), pa.date32()),
+                     pa.array(rng.integers(0, 86400, n).astype(np.int32), pa.time32("s"), mask=rng.random(n) < 0.02),
+                     pa.array(rng.integers(-2**40, 2**40, n), pa.duration("ns"))]
     stock_before = sum(lib.arrow_amd_plugin_calls(f, 0) for f in (b"array_filter", b"array_take", b"cast"))
 
     d_vals, d_mask, d_idx, d_f64 = to_device(vals), to_device(mask), to_device(idx), to_device(f64)
@@ -179,10 +185,18 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
     assert not d_perm.is_cpu
     assert to_host(d_perm).equals(pc.array_sort_indices(skeys, order="descending", null_placement="at_start"))
     assert to_host(pc.take(d_skeys, d_perm)).equals(pc.take(skeys, pc.array_sort_indices(skeys, order="descending", null_placement="at_start")))
+    # temporal keys sort by their physical integers (timestamp/date64/duration/time64: int64; date32/time32: int32)
+    for tkeys in temporal_keys:
+        d_t = to_device(tkeys)
+        for order, place in (("ascending", "at_end"), ("descending", "at_start")):
+            got_p = pc.array_sort_indices(d_t, order=order, null_placement=place)
+            assert not got_p.is_cpu
+            assert to_host(got_p).equals(pc.array_sort_indices(tkeys, order=order, null_placement=place)), (tkeys.type, order)
     # a chain that never leaves the device: filter -> cast
     chain = to_host(pc.cast(pc.filter(d_f64, d_mask), pa.float32()))
-    assert chain.equals(pc.cast(pc.filter(f64, mask), pa.float32()))
-    assert sum(lib.arrow_amd_plugin_calls(f, 0) for f in (b"array_filter", b"array_take", b"cast")) == stock_before
+    assert chain.equals(want_chain)
+    stock_now = {f: lib.arrow_amd_plugin_calls(f, 0) for f in (b"array_filter", b"array_take", b"cast")}
+    assert sum(stock_now.values()) == stock_before, (stock_now, stock_before)
     assert lib.arrow_amd_plugin_calls(b"array_filter", 1) >= 4 and lib.arrow_amd_plugin_calls(b"array_take", 1) >= 1
     # drop_null = Filter(values, <validity bitmap as a boolean array>) (vector_selection.cc:79-91): the
     # filter's data buffer IS the device validity buffer, so this is the device filter again

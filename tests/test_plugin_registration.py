@@ -48,6 +48,10 @@ SCRIPT = textwrap.dedent(r'''
         wide = [ts, dec, fsb16, fsb3, pa.array(np.arange(1000, dtype=np.int32), pa.time32("s")),
                 pa.array(np.arange(1000), pa.duration("ns")), pa.array(np.arange(1000, dtype=np.float16))]
         ix = pa.array([5, 1, 999, None, 0], pa.int16())
+        for sv in (ts, pa.array(np.arange(1000, dtype=np.int32)[::-1].copy(), pa.date32()),
+                   pa.array(((np.arange(1000) * 7919) % 86400).astype(np.int32), pa.time32("s")), pa.array(-np.arange(1000), pa.duration("ms")),
+                   pa.array(np.arange(1000)[::-1].copy(), pa.date64()), pa.array(np.arange(1000) % 17, pa.time64("us"))):
+            gt += [pc.array_sort_indices(sv), pc.array_sort_indices(sv, order="descending", null_placement="at_start")]
         for wv in wide:
             gt += [pc.filter(wv, m), pc.filter(wv, m, null_selection_behavior="emit_null"), pc.take(wv, ix)]
         strs = pa.array([None if i % 5 == 0 else "s" * (i % 7) for i in range(1000)])
