@@ -924,6 +924,7 @@ struct GbpPlan {
 static int g_gbp_min_rows = 1 << 17;  // below this the direct HBM-atomics kernel is used
 static int g_gbp_bits = -1;           // -1 = from the capacity hint
 static int g_gbp_agg_pipe = 1;
+static int g_gbp_b1 = -1;             // level-1 bits override (-1: half of the partition bits)
 static int g_gbp_chunks = 2048;       // level-1 chunks = workgroups of the hist / scatter1 kernels
 
 static int gbp_bits_for(int64_t capacity) {
@@ -944,6 +945,7 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity) {
     p.b2 = 0;
   } else {
     p.b1 = (p.bits + 1) / 2;
+    if (g_gbp_b1 > 0) p.b1 = std::max(p.bits - 8, std::min(g_gbp_b1, std::min(8, p.bits - 1)));
     p.b2 = p.bits - p.b1;
   }
   p.slice_rows = slice_rows;
@@ -1040,6 +1042,10 @@ int set_groupby_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "groupby_chunks") == 0) {
     g_gbp_chunks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, kGbMaxChunks)));
+    return 1;
+  }
+  if (strcmp(name, "groupby_b1") == 0) {
+    g_gbp_b1 = static_cast<int>(value);
     return 1;
   }
   if (strcmp(name, "groupby_agg_pipe") == 0) {

@@ -14,17 +14,16 @@ vals = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=dev, gen
 kk = amd.Array(amd.array.int32, n, [None, keys.view(torch.uint8)], 0, 0)
 vv = amd.Array(amd.array.int64, n, [None, vals.view(torch.uint8)], 0, 0)
 cap = 1 << 25
+want = int(vals.sum().item())
 def run():
     st = GroupBySum(cap, dev)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record(); st.consume(kk, vv); e.record(); torch.cuda.synchronize()
+    ks, kv, sums, valid = st.finalize()
+    assert int(sums.sum().item()) == want and sums.numel() == groups, (int(sums.numel()))
     return s.elapsed_time(e)
-configs = [("base", {"groupby_agg_pipe": 0, "groupby_chunks": 2048}),
-           ("pipe", {"groupby_agg_pipe": 1, "groupby_chunks": 2048}),
-           ("pipe+1536", {"groupby_agg_pipe": 1, "groupby_chunks": 1536}),
-           ("pipe+2304", {"groupby_agg_pipe": 1, "groupby_chunks": 2304}),
-           ("pipe+3072", {"groupby_agg_pipe": 1, "groupby_chunks": 3072}),
-           ("pipe+768", {"groupby_agg_pipe": 1, "groupby_chunks": 768})]
+configs = [("bits auto(13)", {"groupby_partition_bits": -1}), ("bits=12", {"groupby_partition_bits": 12}),
+           ("bits=14", {"groupby_partition_bits": 14}), ("bits=12,b1=6", {"groupby_partition_bits": 12, "groupby_b1": 6})]
 run(); run()
 best = {}
 for rep in range(4):
