@@ -807,6 +807,66 @@ class GroupBySum:
         check(lib.arx_groupby_sum_i64_consume(self.state.data_ptr(), self.capacity, C.byref(ks),
                                               C.byref(vs), ws_ptr, ws_len, stream))
 
+    # -- hash_min / hash_max on the same table (GroupedMinMaxImpl, kernels/hash_aggregate.cc:330-419)
+    def consume_min_max(self, keys: Array, values: Array) -> None:
+        """Folds the rows into per-group extrema; does not touch the sums, so the same rows may also
+        go through consume()."""
+        if keys.type != int32 or values.type != int64:
+            raise ArrowNotImplementedError("GroupBySum: int32 keys and int64 values only")
+        lib, stream = _lib_and_stream(self.device)
+        if getattr(self, "minmax", None) is None:
+            self.minmax = alloc(lib.arx_groupby_minmax_bytes(self.capacity), self.device)
+            check(lib.arx_groupby_minmax_init(self.minmax.data_ptr(), self.capacity, stream))
+        ks, vs = keys.span(), values.span()
+        check(lib.arx_groupby_minmax_i64_consume(self.state.data_ptr(), self.minmax.data_ptr(), self.capacity,
+                                                 C.byref(ks), C.byref(vs), stream))
+
+    def export_min_max(self):
+        """Partial extrema: dict keys / key_is_valid / mins / maxs / no_nulls (device tensors)."""
+        lib, stream = _lib_and_stream(self.device)
+        g = self.num_groups()
+        dev = self.device
+        t = lambda dt: torch.empty(max(g, 1), dtype=dt, device=dev)  # noqa: E731
+        cols = dict(keys=t(torch.int32), key_is_valid=t(torch.uint8), sums=t(torch.int64), counts=t(torch.int64),
+                    no_nulls=t(torch.uint8), mins=t(torch.int64), maxs=t(torch.int64))
+        check(lib.arx_groupby_export(self.state.data_ptr(), self.minmax.data_ptr(), cols["keys"].data_ptr(),
+                                     cols["key_is_valid"].data_ptr(), cols["sums"].data_ptr(),
+                                     cols["counts"].data_ptr(), cols["no_nulls"].data_ptr(),
+                                     cols["mins"].data_ptr(), cols["maxs"].data_ptr(), stream))
+        return {k: v[:g] for k, v in cols.items()}
+
+    def merge_min_max(self, partial: dict) -> None:
+        """Merge of GroupedMinMaxImpl (hash_aggregate.cc:371-399) from export_min_max() of another state."""
+        lib, stream = _lib_and_stream(self.device)
+        if getattr(self, "minmax", None) is None:
+            self.minmax = alloc(lib.arx_groupby_minmax_bytes(self.capacity), self.device)
+            check(lib.arx_groupby_minmax_init(self.minmax.data_ptr(), self.capacity, stream))
+        g = int(partial["keys"].numel())
+        if g == 0:
+            return
+        check(lib.arx_groupby_minmax_merge(self.state.data_ptr(), self.minmax.data_ptr(), self.capacity,
+                                           partial["keys"].data_ptr(), partial["key_is_valid"].data_ptr(),
+                                           partial["mins"].data_ptr(), partial["maxs"].data_ptr(),
+                                           partial["no_nulls"].data_ptr(), g, stream))
+
+    def finalize_min_max(self):
+        """Returns (keys, key_is_valid, mins, maxs, valid) device tensors, `valid` by the options'
+        skip_nulls (min_count is not consulted by the reference's min/max)."""
+        lib, stream = _lib_and_stream(self.device)
+        if getattr(self, "minmax", None) is None:
+            raise ArrowInvalid("finalize_min_max without consume_min_max")
+        g = self.num_groups()
+        dev = self.device
+        t = lambda dt: torch.empty(max(g, 1), dtype=dt, device=dev)  # noqa: E731
+        keys, kv, sums, counts, nn = t(torch.int32), t(torch.uint8), t(torch.int64), t(torch.int64), t(torch.uint8)
+        mins, maxs, valid = t(torch.int64), t(torch.int64), t(torch.uint8)
+        check(lib.arx_groupby_export(self.state.data_ptr(), self.minmax.data_ptr(), keys.data_ptr(), kv.data_ptr(),
+                                     sums.data_ptr(), counts.data_ptr(), nn.data_ptr(), mins.data_ptr(),
+                                     maxs.data_ptr(), stream))
+        check(lib.arx_groupby_minmax_finalize(mins.data_ptr(), maxs.data_ptr(), nn.data_ptr(), g,
+                                              int(self.options.skip_nulls), valid.data_ptr(), stream))
+        return keys[:g], kv[:g], mins[:g], maxs[:g], valid[:g]
+
     def num_groups(self) -> int:
         lib, stream = _lib_and_stream(self.device)
         n = C.c_int64(0)

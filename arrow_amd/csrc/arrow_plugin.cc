@@ -1575,19 +1575,22 @@ class RocmGroupBySumNode : public ac::ExecNode {
  public:
   // one output column per requested aggregate; all of them read the same fused per-group state
   // (wrap-around sum, count of valid values, "a null value was seen")
+  enum AggKind { kSum, kCount, kMin, kMax };
   struct AggSpec {
-    bool is_count = false;               // hash_count (CountOptions::ONLY_VALID) instead of hash_sum
-    cp::ScalarAggregateOptions options;  // hash_sum: skip_nulls / min_count
+    AggKind kind = kSum;                 // hash_sum | hash_count (ONLY_VALID) | hash_min | hash_max
+    cp::ScalarAggregateOptions options;  // sum: skip_nulls / min_count; min/max: skip_nulls
   };
 
   RocmGroupBySumNode(ac::ExecPlan* plan, std::vector<ac::ExecNode*> inputs,
                      std::shared_ptr<arrow::Schema> out_schema, int key_idx, int val_idx,
                      std::vector<AggSpec> aggs)
       : ac::ExecNode(plan, std::move(inputs), {"input"}, std::move(out_schema)),
-        key_idx_(key_idx), val_idx_(val_idx), aggs_(std::move(aggs)) {}
+        key_idx_(key_idx), val_idx_(val_idx), aggs_(std::move(aggs)) {
+    for (const auto& a : aggs_) needs_minmax_ = needs_minmax_ || a.kind == kMin || a.kind == kMax;
+  }
 
   ~RocmGroupBySumNode() override {
-    for (void* p : {state_, d_keys_, d_vals_}) {
+    for (void* p : {state_, minmax_, d_keys_, d_vals_}) {
       if (p) (void)hipFree(p);
     }
   }
@@ -1609,8 +1612,15 @@ class RocmGroupBySumNode : public ac::ExecNode {
     std::vector<std::shared_ptr<arrow::Field>> fields{in_schema.field(ki)};
     for (const auto& agg : opts->aggregates) {
       AggSpec spec;
-      if (agg.function == "hash_count") {
-        spec.is_count = true;
+      if (agg.function == "hash_min" || agg.function == "hash_max") {
+        spec.kind = agg.function == "hash_min" ? kMin : kMax;
+        if (agg.options != nullptr) {
+          const auto* so = dynamic_cast<const cp::ScalarAggregateOptions*>(agg.options.get());
+          if (so == nullptr) return Status::TypeError("aggregate_rocm: ", agg.function, " takes ScalarAggregateOptions");
+          spec.options = *so;
+        }
+      } else if (agg.function == "hash_count") {
+        spec.kind = kCount;
         if (agg.options != nullptr) {
           const auto* co = dynamic_cast<const cp::CountOptions*>(agg.options.get());
           if (co == nullptr) return Status::TypeError("aggregate_rocm: hash_count takes CountOptions");
@@ -1625,7 +1635,8 @@ class RocmGroupBySumNode : public ac::ExecNode {
           spec.options = *so;
         }
       } else {
-        return Status::NotImplemented("aggregate_rocm: hash_sum and hash_count only, got ", agg.function);
+        return Status::NotImplemented("aggregate_rocm: hash_sum / hash_count / hash_min / hash_max only, got ",
+                                      agg.function);
       }
       if (agg.target.size() != 1) return Status::NotImplemented("aggregate_rocm: unary aggregates only");
       ARROW_ASSIGN_OR_RAISE(auto vpath, agg.target[0].FindOne(in_schema));
@@ -1679,8 +1690,13 @@ class RocmGroupBySumNode : public ac::ExecNode {
     hipStream_t st;
     ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
     void* fresh = nullptr;
+    void* fresh_mm = nullptr;
     HIP_RETURN_NOT_OK(hipMalloc(&fresh, arx_groupby_state_bytes(cap)));
     ARROW_RETURN_NOT_OK(FromArx(arx_groupby_init(fresh, cap, st)));
+    if (needs_minmax_) {
+      HIP_RETURN_NOT_OK(hipMalloc(&fresh_mm, arx_groupby_minmax_bytes(cap)));
+      ARROW_RETURN_NOT_OK(FromArx(arx_groupby_minmax_init(fresh_mm, cap, st)));
+    }
     if (state_ != nullptr) {  // rehash: export the old table's partial aggregates, merge them
       int64_t g = 0;
       ARROW_RETURN_NOT_OK(FromArx(arx_groupby_num_groups(state_, &g, st)));
@@ -1691,16 +1707,28 @@ class RocmGroupBySumNode : public ac::ExecNode {
         ARROW_RETURN_NOT_OK(t_scratch.Get(kArg2, g * 8 + 16, &s));
         ARROW_RETURN_NOT_OK(t_scratch.Get(kArg2Validity, g * 8 + 16, &c));
         ARROW_RETURN_NOT_OK(t_scratch.Get(kOutValidity, g + 16, &nn));
-        ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_export(state_, (int32_t*)k, (uint8_t*)kv, (int64_t*)s,
-                                                               (int64_t*)c, (uint8_t*)nn, st)));
+        void *mn = nullptr, *mx = nullptr;
+        if (needs_minmax_) {
+          ARROW_RETURN_NOT_OK(t_scratch.Get(kOutData, g * 8 + 16, &mn));
+          ARROW_RETURN_NOT_OK(t_scratch.Get(kBinWs, g * 8 + 16, &mx));
+        }
+        ARROW_RETURN_NOT_OK(FromArx(arx_groupby_export(state_, minmax_, (int32_t*)k, (uint8_t*)kv, (int64_t*)s,
+                                                       (int64_t*)c, (uint8_t*)nn, (int64_t*)mn, (int64_t*)mx, st)));
         ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_merge(fresh, cap, (const int32_t*)k, (const uint8_t*)kv,
                                                               (const int64_t*)s, (const int64_t*)c,
                                                               (const uint8_t*)nn, g, st)));
+        if (needs_minmax_) {
+          ARROW_RETURN_NOT_OK(FromArx(arx_groupby_minmax_merge(fresh, fresh_mm, cap, (const int32_t*)k,
+                                                               (const uint8_t*)kv, (const int64_t*)mn,
+                                                               (const int64_t*)mx, (const uint8_t*)nn, g, st)));
+        }
       }
       HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
       HIP_RETURN_NOT_OK(hipFree(state_));
+      if (minmax_) HIP_RETURN_NOT_OK(hipFree(minmax_));
     }
     state_ = fresh;
+    minmax_ = fresh_mm;
     capacity_ = cap;
     return Status::OK();
   }
@@ -1765,6 +1793,9 @@ class RocmGroupBySumNode : public ac::ExecNode {
       };
       ArxSpan dk = span_of(k), dv = span_of(v);
       ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_consume(state_, capacity_, &dk, &dv, nullptr, 0, st)));
+      if (needs_minmax_) {
+        ARROW_RETURN_NOT_OK(FromArx(arx_groupby_minmax_i64_consume(state_, minmax_, capacity_, &dk, &dv, st)));
+      }
       HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
       rows_seen_ += n;
       CountGpu(kFnHashSum);
@@ -1775,6 +1806,9 @@ class RocmGroupBySumNode : public ac::ExecNode {
     ARROW_RETURN_NOT_OK(Upload(ArraySpan(k), 4, kValues, kValidity, st, &dk));
     ARROW_RETURN_NOT_OK(Upload(ArraySpan(v), 8, kArg2, kArg2Validity, st, &dv));
     ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_consume(state_, capacity_, &dk, &dv, nullptr, 0, st)));
+    if (needs_minmax_) {
+      ARROW_RETURN_NOT_OK(FromArx(arx_groupby_minmax_i64_consume(state_, minmax_, capacity_, &dk, &dv, st)));
+    }
     HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
     rows_seen_ += n;
     CountGpu(kFnHashSum);
@@ -1795,6 +1829,9 @@ class RocmGroupBySumNode : public ac::ExecNode {
         ws = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~uintptr_t(255));
       }
       ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_consume(state_, capacity_, &dk, &dv, ws, ws_bytes, st)));
+      if (needs_minmax_) {
+        ARROW_RETURN_NOT_OK(FromArx(arx_groupby_minmax_i64_consume(state_, minmax_, capacity_, &dk, &dv, st)));
+      }
       rows_seen_ += staged_;
       staged_ = 0;
       CountGpu(kFnHashSum);
@@ -1806,6 +1843,7 @@ class RocmGroupBySumNode : public ac::ExecNode {
     std::vector<uint8_t> key_valid(g);
     std::vector<arrow::Datum> columns(1 + aggs_.size());
     void *k = nullptr, *kv = nullptr, *s = nullptr, *c = nullptr, *nn = nullptr, *ok = nullptr;
+    void *mn = nullptr, *mx = nullptr;
     if (g > 0) {
       ARROW_RETURN_NOT_OK(t_scratch.Get(kValues, g * 4 + 16, &k));
       ARROW_RETURN_NOT_OK(t_scratch.Get(kValidity, g + 16, &kv));
@@ -1813,8 +1851,12 @@ class RocmGroupBySumNode : public ac::ExecNode {
       ARROW_RETURN_NOT_OK(t_scratch.Get(kArg2Validity, g * 8 + 16, &c));
       ARROW_RETURN_NOT_OK(t_scratch.Get(kOutValidity, g + 16, &nn));
       ARROW_RETURN_NOT_OK(t_scratch.Get(kOutData, g + 16, &ok));
-      ARROW_RETURN_NOT_OK(FromArx(arx_groupby_sum_i64_export(state_, (int32_t*)k, (uint8_t*)kv, (int64_t*)s,
-                                                             (int64_t*)c, (uint8_t*)nn, st)));
+      if (needs_minmax_) {
+        ARROW_RETURN_NOT_OK(t_scratch.Get(kBinWs, g * 16 + 32, &mn));
+        mx = static_cast<uint8_t*>(mn) + ((g * 8 + 15) & ~int64_t(15));
+      }
+      ARROW_RETURN_NOT_OK(FromArx(arx_groupby_export(state_, minmax_, (int32_t*)k, (uint8_t*)kv, (int64_t*)s,
+                                                     (int64_t*)c, (uint8_t*)nn, (int64_t*)mn, (int64_t*)mx, st)));
       HIP_RETURN_NOT_OK(hipMemcpyAsync(keys->mutable_data(), k, g * 4, hipMemcpyDeviceToHost, st));
       HIP_RETURN_NOT_OK(hipMemcpyAsync(key_valid.data(), kv, g, hipMemcpyDeviceToHost, st));
     }
@@ -1822,10 +1864,25 @@ class RocmGroupBySumNode : public ac::ExecNode {
       const AggSpec& spec = aggs_[ai];
       ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> data, arrow::AllocateBuffer(g * 8, pool));
       std::shared_ptr<Buffer> bits;
-      if (spec.is_count) {
+      if (spec.kind == kCount) {
         // GroupedCountImpl (hash_aggregate.cc): the count of valid values, never null
         if (g > 0) HIP_RETURN_NOT_OK(hipMemcpyAsync(data->mutable_data(), c, g * 8, hipMemcpyDeviceToHost, st));
         HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+      } else if (spec.kind == kMin || spec.kind == kMax) {
+        // GroupedMinMaxImpl::Finalize (hash_aggregate.cc:401-419): null where the group saw no value
+        // (or, with !skip_nulls, saw a null); the reference writes the anti-extremum there, we write 0
+        // only into the validity — the data slot keeps the anti-extremum as well
+        std::vector<uint8_t> mm_valid(g);
+        if (g > 0) {
+          ARROW_RETURN_NOT_OK(FromArx(arx_groupby_minmax_finalize((const int64_t*)mn, (const int64_t*)mx,
+                                                                  (const uint8_t*)nn, g,
+                                                                  spec.options.skip_nulls ? 1 : 0, (uint8_t*)ok, st)));
+          HIP_RETURN_NOT_OK(hipMemcpyAsync(data->mutable_data(), spec.kind == kMin ? mn : mx, g * 8,
+                                           hipMemcpyDeviceToHost, st));
+          HIP_RETURN_NOT_OK(hipMemcpyAsync(mm_valid.data(), ok, g, hipMemcpyDeviceToHost, st));
+        }
+        HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+        ARROW_ASSIGN_OR_RAISE(bits, arrow::internal::BytesToBits(mm_valid, pool));
       } else {
         std::vector<uint8_t> sum_valid(g);
         if (g > 0) {
@@ -1856,6 +1913,8 @@ class RocmGroupBySumNode : public ac::ExecNode {
 
   const int key_idx_, val_idx_;
   const std::vector<AggSpec> aggs_;
+  bool needs_minmax_ = false;
+  void* minmax_ = nullptr;   // mins | maxes per slot (arx_groupby_minmax_bytes), only with hash_min / hash_max
   std::mutex mu_;
   ac::AtomicCounter counter_;
   void* state_ = nullptr;

@@ -149,7 +149,8 @@ constexpr int kExportSlotsPerBlock = kBlock * 16;
 __global__ __launch_bounds__(kBlock) void groupby_export_kernel(
     GroupbyView v, int32_t* __restrict__ out_keys, uint8_t* __restrict__ out_key_is_valid,
     int64_t* __restrict__ out_sums, int64_t* __restrict__ out_counts,
-    uint8_t* __restrict__ out_no_nulls) {
+    uint8_t* __restrict__ out_no_nulls, const long long* __restrict__ mins,
+    const long long* __restrict__ maxs, int64_t* __restrict__ out_mins, int64_t* __restrict__ out_maxs) {
   __shared__ uint32_t wave_tot[kWavesPerBlock];
   __shared__ unsigned long long base_s;
   const int tid = threadIdx.x;
@@ -192,6 +193,10 @@ __global__ __launch_bounds__(kBlock) void groupby_export_kernel(
     out_sums[pos] = static_cast<int64_t>(v.sums[sl]);
     out_counts[pos] = static_cast<int64_t>(v.counts[sl]);
     out_no_nulls[pos] = (v.flags[sl] & 1u) ? 0 : 1;
+    if (out_mins != nullptr) {  // same position as the other columns: one export, aligned columns
+      out_mins[pos] = mins[sl];
+      out_maxs[pos] = maxs[sl];
+    }
     ++pos;
   }
 }
@@ -289,6 +294,84 @@ __global__ __launch_bounds__(kBlock) void partition_scatter_kernel(
     out_sums[pos] = sums[i];
     out_counts[pos] = counts[i];
     out_no_nulls[pos] = no_nulls == nullptr ? 1 : no_nulls[i];
+  }
+}
+
+// ---- hash_min / hash_max on the same table (GroupedMinMaxImpl, kernels/hash_aggregate.cc:330-419):
+// mins start at INT64_MAX, maxes at INT64_MIN (AntiExtrema, :349-350); a valid value folds into both,
+// a null value sets the group's null flag (the same flag hash_sum keeps); the group exists either
+// way.  Integer min/max are associative and commutative: device atomics in any order are bit-exact.
+// "has_values" is not stored: a group saw a value iff min <= max.
+__global__ __launch_bounds__(kBlock) void groupby_minmax_init_kernel(long long* __restrict__ mins,
+                                                                     long long* __restrict__ maxs, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    mins[i] = INT64_MAX;
+    maxs[i] = INT64_MIN;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void groupby_minmax_consume_kernel(GroupbyView v, long long* __restrict__ mins,
+                                                                        long long* __restrict__ maxs,
+                                                                        const int32_t* __restrict__ keys, Bits kvalid,
+                                                                        const int64_t* __restrict__ values,
+                                                                        Bits vvalid, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint32_t fresh = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool kv = (load_word(kvalid, i >> 6) >> (i & 63)) & 1ull;
+    const bool vv = (load_word(vvalid, i >> 6) >> (i & 63)) & 1ull;
+    const int64_t slot = kv ? gb_find_or_insert(v, keys[i], &fresh) : gb_null_slot(v);
+    if (slot < 0) {
+      atomicExch(&v.hdr->overflow, 1u);
+      continue;
+    }
+    if (vv) {
+      const long long x = values[i];
+      // a plain read first: once a group's extrema have settled most rows change nothing
+      if (x < __hip_atomic_load(&mins[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mins[slot], x);
+      if (x > __hip_atomic_load(&maxs[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxs[slot], x);
+    } else {
+      atomicOr(&v.flags[slot], 1u);
+    }
+  }
+  gb_publish_new_groups(v, fresh);
+}
+
+// Merge (hash_aggregate.cc:371-399): extrema of another state's groups fold into this one
+__global__ __launch_bounds__(kBlock) void groupby_minmax_merge_kernel(
+    GroupbyView v, long long* __restrict__ mins, long long* __restrict__ maxs,
+    const int32_t* __restrict__ keys, const uint8_t* __restrict__ key_is_valid,
+    const int64_t* __restrict__ other_mins, const int64_t* __restrict__ other_maxs,
+    const uint8_t* __restrict__ no_nulls, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint32_t fresh = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool kv = key_is_valid == nullptr || key_is_valid[i] != 0;
+    const int64_t slot = kv ? gb_find_or_insert(v, keys[i], &fresh) : gb_null_slot(v);
+    if (slot < 0) {
+      atomicExch(&v.hdr->overflow, 1u);
+      continue;
+    }
+    atomicMin(&mins[slot], static_cast<long long>(other_mins[i]));
+    atomicMax(&maxs[slot], static_cast<long long>(other_maxs[i]));
+    if (no_nulls != nullptr && no_nulls[i] == 0) atomicOr(&v.flags[slot], 1u);
+  }
+  gb_publish_new_groups(v, fresh);
+}
+
+// valid = the group saw a value (and, unless skip_nulls, no null): Finalize, hash_aggregate.cc:401-410
+// (min_count is not consulted by the reference's min/max)
+__global__ __launch_bounds__(kBlock) void groupby_minmax_finalize_kernel(const int64_t* __restrict__ mins,
+                                                                         const int64_t* __restrict__ maxs,
+                                                                         const uint8_t* __restrict__ no_nulls,
+                                                                         int64_t n, int skip_nulls,
+                                                                         uint8_t* __restrict__ out_valid) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    bool ok = mins[i] <= maxs[i];
+    if (!skip_nulls) ok = ok && no_nulls[i] != 0;
+    out_valid[i] = ok ? 1 : 0;
   }
 }
 
@@ -1215,8 +1298,19 @@ int arx_groupby_num_groups(void* state, int64_t* out_num_groups, void* stream) {
 int arx_groupby_sum_i64_export(void* state, int32_t* out_keys, uint8_t* out_key_is_valid,
                                int64_t* out_sums, int64_t* out_counts, uint8_t* out_no_nulls,
                                void* stream) {
+  return arx_groupby_export(state, nullptr, out_keys, out_key_is_valid, out_sums, out_counts, out_no_nulls,
+                            nullptr, nullptr, stream);
+}
+
+int arx_groupby_export(void* state, const void* minmax, int32_t* out_keys, uint8_t* out_key_is_valid,
+                       int64_t* out_sums, int64_t* out_counts, uint8_t* out_no_nulls, int64_t* out_mins,
+                       int64_t* out_maxs, void* stream) {
   if (state == nullptr) {
     set_error("state is NULL");
+    return ARX_INVALID;
+  }
+  if ((out_mins != nullptr || out_maxs != nullptr) && (minmax == nullptr || out_mins == nullptr || out_maxs == nullptr)) {
+    set_error("arx_groupby_export: out_mins/out_maxs need the minmax buffer and each other");
     return ARX_INVALID;
   }
   hipStream_t st = as_stream(stream);
@@ -1226,9 +1320,105 @@ int arx_groupby_sum_i64_export(void* state, int32_t* out_keys, uint8_t* out_key_
   GroupbyView v = gb_view(state, cap);
   ARX_HIP(hipMemsetAsync(&v.hdr->export_cursor, 0, sizeof(unsigned long long), st));
   const unsigned egrid = static_cast<unsigned>(ceil_div(cap + 1, kExportSlotsPerBlock));
+  const long long* mins = static_cast<const long long*>(minmax);
+  const long long* maxs = mins == nullptr ? nullptr : mins + cap + 1;
   hipLaunchKernelGGL(groupby_export_kernel, dim3(egrid), dim3(kBlock), 0, st, v, out_keys,
-                     out_key_is_valid, out_sums, out_counts, out_no_nulls);
+                     out_key_is_valid, out_sums, out_counts, out_no_nulls, mins, maxs, out_mins, out_maxs);
   ARX_CHECK_LAUNCH("groupby_export_kernel");
+  return ARX_OK;
+}
+
+size_t arx_groupby_minmax_bytes(int64_t capacity) {
+  if (capacity < 1) capacity = 1;
+  return (static_cast<size_t>(capacity + 1) * 16 + 255) & ~size_t(255);
+}
+
+int arx_groupby_minmax_init(void* minmax, int64_t capacity, void* stream) {
+  if (minmax == nullptr || capacity < 1) {
+    set_error("bad arguments to arx_groupby_minmax_init");
+    return ARX_INVALID;
+  }
+  long long* mins = static_cast<long long*>(minmax);
+  hipLaunchKernelGGL(groupby_minmax_init_kernel, dim3(gb_grid(capacity + 1)), dim3(kBlock), 0, as_stream(stream),
+                     mins, mins + capacity + 1, capacity + 1);
+  ARX_CHECK_LAUNCH("groupby_minmax_init_kernel");
+  return ARX_OK;
+}
+
+int arx_groupby_minmax_i64_consume(void* state, void* minmax, int64_t capacity, const ArxSpan* keys_i32,
+                                   const ArxSpan* values_i64, void* stream) {
+  if (state == nullptr || minmax == nullptr || keys_i32 == nullptr || values_i64 == nullptr) {
+    set_error("NULL argument to arx_groupby_minmax_i64_consume");
+    return ARX_INVALID;
+  }
+  if (capacity < 1 || (capacity & (capacity - 1)) != 0) {
+    set_error("group-by capacity must be a power of two");
+    return ARX_INVALID;
+  }
+  if (keys_i32->length != values_i64->length) {
+    set_error("Array arguments must all be the same length (keys %lld vs values %lld)",
+              static_cast<long long>(keys_i32->length), static_cast<long long>(values_i64->length));
+    return ARX_INVALID;
+  }
+  const int64_t n = keys_i32->length;
+  if (n == 0) return ARX_OK;
+  if (keys_i32->data == nullptr || values_i64->data == nullptr) {
+    set_error("NULL data buffer passed to arx_groupby_minmax_i64_consume");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  GroupbyView v = gb_view(state, capacity);
+  long long* mins = static_cast<long long*>(minmax);
+  const Bits kb = make_bits(keys_i32->null_count != 0 ? keys_i32->validity : nullptr, keys_i32->offset, n);
+  const Bits vb = make_bits(values_i64->null_count != 0 ? values_i64->validity : nullptr, values_i64->offset, n);
+  hipLaunchKernelGGL(groupby_minmax_consume_kernel, dim3(gb_grid(n)), dim3(kBlock), 0, st, v, mins,
+                     mins + capacity + 1, static_cast<const int32_t*>(keys_i32->data) + keys_i32->offset, kb,
+                     static_cast<const int64_t*>(values_i64->data) + values_i64->offset, vb, n);
+  ARX_CHECK_LAUNCH("groupby_minmax_consume_kernel");
+  GroupbyHeader h;
+  const int rc = read_header(state, &h, st);
+  if (rc != ARX_OK) return rc;
+  if (h.overflow != 0) {
+    set_error("group-by table overflow: more distinct keys than capacity %lld", static_cast<long long>(capacity));
+    return ARX_INVALID;
+  }
+  return ARX_OK;
+}
+
+int arx_groupby_minmax_merge(void* state, void* minmax, int64_t capacity, const int32_t* keys,
+                             const uint8_t* key_is_valid, const int64_t* mins, const int64_t* maxs,
+                             const uint8_t* no_nulls, int64_t num_groups, void* stream) {
+  if (state == nullptr || minmax == nullptr || num_groups < 0) {
+    set_error("bad arguments to arx_groupby_minmax_merge");
+    return ARX_INVALID;
+  }
+  if (num_groups == 0) return ARX_OK;
+  if (keys == nullptr || mins == nullptr || maxs == nullptr) {
+    set_error("NULL partial-aggregate column");
+    return ARX_INVALID;
+  }
+  GroupbyView v = gb_view(state, capacity);
+  long long* m = static_cast<long long*>(minmax);
+  hipLaunchKernelGGL(groupby_minmax_merge_kernel, dim3(gb_grid(num_groups)), dim3(kBlock), 0, as_stream(stream),
+                     v, m, m + capacity + 1, keys, key_is_valid, mins, maxs, no_nulls, num_groups);
+  ARX_CHECK_LAUNCH("groupby_minmax_merge_kernel");
+  return ARX_OK;
+}
+
+int arx_groupby_minmax_finalize(const int64_t* mins, const int64_t* maxs, const uint8_t* no_nulls,
+                                int64_t num_groups, int skip_nulls, uint8_t* out_valid, void* stream) {
+  if (num_groups < 0) {
+    set_error("negative num_groups");
+    return ARX_INVALID;
+  }
+  if (num_groups == 0) return ARX_OK;
+  if (mins == nullptr || maxs == nullptr || out_valid == nullptr || (!skip_nulls && no_nulls == nullptr)) {
+    set_error("NULL argument to arx_groupby_minmax_finalize");
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(groupby_minmax_finalize_kernel, dim3(gb_grid(num_groups)), dim3(kBlock), 0, as_stream(stream),
+                     mins, maxs, no_nulls, num_groups, skip_nulls, out_valid);
+  ARX_CHECK_LAUNCH("groupby_minmax_finalize_kernel");
   return ARX_OK;
 }
 

@@ -336,6 +336,28 @@ int arx_groupby_num_groups(void* state, int64_t* out_num_groups, void* stream);
 int arx_groupby_sum_i64_export(void* state, int32_t* out_keys, uint8_t* out_key_is_valid,
                                int64_t* out_sums, int64_t* out_counts, uint8_t* out_no_nulls,
                                void* stream);
+/* hash_min / hash_max(int64) on the same table — GroupedMinMaxImpl (kernels/hash_aggregate.cc:
+ * 330-419): a second caller-owned buffer (arx_groupby_minmax_bytes) holds mins | maxes per slot,
+ * initialised to the anti-extrema (:349-350).  consume inserts the keys like the sum consume
+ * (a group exists even if all its values are null), folds valid values into both extrema and sets
+ * the group's null flag for null values; sums / counts are not touched, so it can run next to
+ * arx_groupby_sum_i64_consume on the same rows.  Synchronous (reads the overflow flag).
+ * arx_groupby_export is the sum export with the extrema as two more columns in the SAME group
+ * order (minmax / out_mins / out_maxs may all be NULL).  finalize: out_valid[g] = the group saw a
+ * value (min <= max) && (skip_nulls || no_nulls[g]) — min_count is not consulted (:401-410). */
+size_t arx_groupby_minmax_bytes(int64_t capacity);
+int arx_groupby_minmax_init(void* minmax, int64_t capacity, void* stream);
+int arx_groupby_minmax_i64_consume(void* state, void* minmax, int64_t capacity, const ArxSpan* keys_i32,
+                                   const ArxSpan* values_i64, void* stream);
+int arx_groupby_export(void* state, const void* minmax, int32_t* out_keys, uint8_t* out_key_is_valid,
+                       int64_t* out_sums, int64_t* out_counts, uint8_t* out_no_nulls, int64_t* out_mins,
+                       int64_t* out_maxs, void* stream);
+/* merge (hash_aggregate.cc:371-399): exported extrema of another state fold into this one. */
+int arx_groupby_minmax_merge(void* state, void* minmax, int64_t capacity, const int32_t* keys,
+                             const uint8_t* key_is_valid, const int64_t* mins, const int64_t* maxs,
+                             const uint8_t* no_nulls, int64_t num_groups, void* stream);
+int arx_groupby_minmax_finalize(const int64_t* mins, const int64_t* maxs, const uint8_t* no_nulls,
+                                int64_t num_groups, int skip_nulls, uint8_t* out_valid, void* stream);
 /* finalize (Finalize, hash_aggregate_numeric.cc:130-152, ScalarAggregateOptions
  * {skip_nulls, min_count}): out_valid[g] (one byte) = counts[g] >= min_count &&
  * (skip_nulls || no_nulls[g]); the sums column is returned as is.  Asynchronous. */

@@ -267,6 +267,38 @@ def groupby_sum_i64(keys, key_valid, key_off, values, val_valid, val_off, length
                 no_nulls=onn[:ng], valid=ov[:ng])
 
 
+def groupby_minmax_i64(keys, key_valid, key_off, values, val_valid, val_off, length, skip_nulls=True):
+    """GroupedMinMaxImpl<Int64Type> (kernels/hash_aggregate.cc:330-419) over an int32 key:
+    Resize :346-354 (mins = max(), maxes = lowest(), has_values = has_nulls = false), Consume
+    :356-369 (valid value -> min/max + has_values; null value -> has_nulls), Finalize :401-419
+    (valid = has_values, and with !skip_nulls also !has_nulls; min_count is not consulted).
+    Row-at-a-time, groups in first-occurrence order; the null key is one group.
+    Returns dict(keys, key_is_valid, mins, maxs, valid)."""
+    kv = unpack_bits(key_valid, key_off, length) if key_valid is not None else np.ones(length, bool)
+    vv = unpack_bits(val_valid, val_off, length) if val_valid is not None else np.ones(length, bool)
+    k = np.asarray(keys)[key_off: key_off + length]
+    v = np.asarray(values)[val_off: val_off + length]
+    index, out_keys, out_kv = {}, [], []
+    mins, maxs, has_values, has_nulls = [], [], [], []
+    i64 = np.iinfo(np.int64)
+    for i in range(length):
+        gkey = int(k[i]) if kv[i] else None
+        g = index.get(gkey)
+        if g is None:
+            g = index[gkey] = len(out_keys)
+            out_keys.append(0 if gkey is None else gkey)
+            out_kv.append(0 if gkey is None else 1)
+            mins.append(i64.max); maxs.append(i64.min); has_values.append(False); has_nulls.append(False)
+        if vv[i]:
+            x = int(v[i])
+            mins[g] = min(mins[g], x); maxs[g] = max(maxs[g], x); has_values[g] = True
+        else:
+            has_nulls[g] = True
+    valid = [hv and (skip_nulls or not hn) for hv, hn in zip(has_values, has_nulls)]
+    return dict(keys=np.array(out_keys, np.int32), key_is_valid=np.array(out_kv, np.uint8),
+                mins=np.array(mins, np.int64), maxs=np.array(maxs, np.int64), valid=np.array(valid, np.uint8))
+
+
 class HashSumState:
     """GroupedReducingAggregator<Int64Type, GroupedSumImpl> with dense group ids:
     resize / consume / merge / finalize (hash_aggregate_numeric.cc:61-152)."""

@@ -195,5 +195,6 @@ template <typename T> using emu_id_t = typename std::type_identity<T>::type;
 template <typename T> inline T atomicAdd(T* p, emu_id_t<T> v) { T o = *p; *p = o + v; return o; }
 template <typename T> inline T atomicOr(T* p, emu_id_t<T> v) { T o = *p; *p = o | v; return o; }
 template <typename T> inline T atomicMin(T* p, emu_id_t<T> v) { T o = *p; *p = std::min<T>(o, v); return o; }
+template <typename T> inline T atomicMax(T* p, emu_id_t<T> v) { T o = *p; *p = std::max<T>(o, v); return o; }
 template <typename T> inline T atomicExch(T* p, emu_id_t<T> v) { T o = *p; *p = v; return o; }
 template <typename T> inline T atomicCAS(T* p, emu_id_t<T> c, emu_id_t<T> v) { T o = *p; if (o == c) *p = v; return o; }

@@ -341,6 +341,48 @@ def check_groupby_sum(amd, keys: HostArray, values: HostArray, skip_nulls=True, 
     return got
 
 
+def check_groupby_min_max(amd, keys: HostArray, values: HostArray, skip_nulls=True, capacity=None,
+                          use_pyarrow=True, batches=1, with_sum=False):
+    """hash_min / hash_max on the fused table vs the oracle (and pyarrow's hash_min_max)."""
+    opts = amd.compute.ScalarAggregateOptions(skip_nulls, 1)
+    dk, dv = keys.to_device(amd), values.to_device(amd)
+    cap = capacity or max(16, 2 * keys.length + 2)
+    op = amd.compute.GroupBySum(cap, dk.device, opts)
+    n = keys.length
+    step = max(1, (n + batches - 1) // batches)
+    for b in range(0, max(n, 1), step):
+        ks, vs = dk.slice(b, min(step, n - b)), dv.slice(b, min(step, n - b))
+        if with_sum:
+            op.consume(ks, vs)          # the sum pass over the same rows must not disturb the extrema
+        op.consume_min_max(ks, vs)
+    gk, gkv, gmin, gmax, gvalid = (x.cpu().numpy() for x in op.finalize_min_max())
+    w = O.groupby_minmax_i64(np.ascontiguousarray(keys.values), keys.valid_bitmap(), keys.offset,
+                             np.ascontiguousarray(values.values), values.valid_bitmap(), values.offset, n, skip_nulls)
+
+    def rows(k, kv, mn, mx, valid):
+        out = [(int(a) if b else None, (int(c), int(d)) if e else None)
+               for a, b, c, d, e in zip(k, kv, mn, mx, valid)]
+        return sorted(out, key=lambda r: (r[0] is None, r[0] or 0))
+
+    got, want = rows(gk, gkv, gmin, gmax, gvalid), rows(w["keys"], w["key_is_valid"], w["mins"], w["maxs"], w["valid"])
+    tag = f"groupby_min_max[n={n},skip_nulls={skip_nulls},batches={batches}]"
+    assert len(got) == len(want), f"{tag}: {len(got)} groups vs {len(want)}"
+    for i, (g, x) in enumerate(zip(got, want)):
+        assert g == x, f"{tag}: group {i}: got {g} want {x}"
+    if with_sum:
+        _, _, sums, _ = op.finalize()   # every valid value is in exactly one group's sum
+        assert int(sums.sum().item()) == int(values.logical_values()[values.logical_valid()].astype(np.int64).sum())
+    if use_pyarrow and pa is not None and n > 0:
+        t = pa.table({"k": keys.to_pyarrow(), "v": values.to_pyarrow()})
+        r = t.group_by("k", use_threads=False).aggregate(
+            [("v", "min_max", pc.ScalarAggregateOptions(skip_nulls=skip_nulls, min_count=1))])
+        rk, rmm = r.column("k").combine_chunks(), r.column("v_min_max").combine_chunks()
+        ref = sorted(((a, None if b is None or b["min"] is None else (b["min"], b["max"]))
+                      for a, b in zip(rk.to_pylist(), rmm.to_pylist())), key=lambda r: (r[0] is None, r[0] or 0))
+        assert got == ref, tag + " vs pyarrow hash_min_max"
+    return got
+
+
 # ------------------------------------------------------------------ hash_sum kernel vtable
 def check_hash_sum_kernel(amd, rng, n=5000, num_groups=37, null_p=0.2, skip_nulls=True, min_count=1,
                           use_pyarrow=True):

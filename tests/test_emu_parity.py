@@ -6,6 +6,8 @@ Sizes are small (the emulator context-switches at every wave collective)."""
 import numpy as np
 import pytest
 
+from oracle import oracle as O
+
 from . import parity_cases as P
 from . import util as U
 
@@ -516,3 +518,45 @@ def test_sort_msd_bucket_variants_and_segment_fanout(emu_ctx, small_bucket, fina
         for k, v in {b"sort_msd": -1, b"sort_msd_small_bucket": 1, b"sort_msd_final_rows_log2": 3,
                      b"sort_msd_seg_min_bits": 1, b"sort_msd_segment_rows": 1 << 27}.items():
             lib.arx_set_option(k, v)
+
+
+# ------------------------------------------------------------------ hash_min / hash_max on the fused table
+@pytest.mark.parametrize("skip_nulls", [True, False])
+@pytest.mark.parametrize("knull,vnull,batches", [(0.0, 0.0, 1), (0.05, 0.2, 3), (1.0, 0.5, 1), (0.1, 1.0, 2)])
+def test_groupby_min_max(emu_ctx, skip_nulls, knull, vnull, batches):
+    """GroupedMinMaxImpl (hash_aggregate.cc:330-419): extrema at the int64 edges, null keys as one
+    group, groups whose values are all null, several consume calls."""
+    rng = rng_for("gbminmax", skip_nulls, knull, vnull, batches)
+    n = 4000
+    k = U.random_array(rng, np.int32, n, null_p=knull, offset=2, lo=-40, hi=40)
+    v = U.random_array(rng, np.int64, n, null_p=vnull, offset=1)
+    v.values[5:9] = [2**63 - 1, -2**63, 0, -1]
+    P.check_groupby_min_max(emu_ctx, k, v, skip_nulls, batches=batches)
+
+
+def test_groupby_min_max_next_to_sum(emu_ctx):
+    rng = rng_for("gbminmaxsum")
+    k = U.random_array(rng, np.int32, 3000, null_p=0.02, lo=0, hi=500)
+    v = U.random_array(rng, np.int64, 3000, null_p=0.1, lo=-1000, hi=1000)
+    P.check_groupby_min_max(emu_ctx, k, v, True, batches=2, with_sum=True)
+
+
+def test_groupby_min_max_merge_of_two_states(emu_ctx):
+    """Two states over halves of the rows, merged (Merge, hash_aggregate.cc:371-399) == one state."""
+    amd = emu_ctx
+    rng = rng_for("gbminmaxmerge")
+    n = 3000
+    k = U.random_array(rng, np.int32, n, null_p=0.03, lo=-60, hi=60)
+    v = U.random_array(rng, np.int64, n, null_p=0.15)
+    dk, dv = k.to_device(amd), v.to_device(amd)
+    a, b = amd.compute.GroupBySum(1024, dk.device), amd.compute.GroupBySum(1024, dk.device)
+    a.consume_min_max(dk.slice(0, 1700), dv.slice(0, 1700))
+    b.consume_min_max(dk.slice(1700), dv.slice(1700))
+    a.merge_min_max(b.export_min_max())
+    gk, gkv, gmin, gmax, gvalid = (x.cpu().numpy() for x in a.finalize_min_max())
+    w = O.groupby_minmax_i64(k.values, k.valid_bitmap(), 0, v.values, v.valid_bitmap(), 0, n, True)
+    key = lambda r: (r[0] is None, r[0] or 0)  # noqa: E731
+    got = sorted(((int(x) if y else None, (int(c), int(d)) if e else None) for x, y, c, d, e in zip(gk, gkv, gmin, gmax, gvalid)), key=key)
+    want = sorted(((int(x) if y else None, (int(c), int(d)) if e else None)
+                   for x, y, c, d, e in zip(w["keys"], w["key_is_valid"], w["mins"], w["maxs"], w["valid"])), key=key)
+    assert got == want

@@ -330,6 +330,21 @@ ACERO_SCRIPT = textwrap.dedent(r'''
     for ours, theirs in (("s", 1), ("c", 2), ("s3", 3)):     # (pyarrow puts the key column first)
         assert multi.column(ours).equals(ref.column(theirs)), ours
     assert multi.column("c").null_count == 0
+    # hash_min / hash_max (one more pass over the same fused table), mixed with sum and count; the
+    # batches with nulls are consumed on arrival, so the table is rehashed (export -> merge) on the way
+    for tab in (tn, tm, t.select(["k", "v"])):
+        mm = acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
+            acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions(
+                [("v", "hash_min", None, "lo"), ("v", "hash_sum", None, "s"), ("v", "hash_max", o3, "hi3"),
+                 ("v", "hash_count", None, "c"), ("v", "hash_max", None, "hi")], keys=["k"])),
+        ]).to_table().sort_by("k")
+        ref = tab.group_by("k", use_threads=False).aggregate(
+            [("v", "min"), ("v", "sum"), ("v", "max", o3), ("v", "count"), ("v", "max")]).sort_by("k")
+        assert mm.schema.names == ["k", "lo", "s", "hi3", "c", "hi"], mm.schema
+        assert mm.column("k").equals(ref.column("k"))
+        for i, name in enumerate(["lo", "s", "hi3", "c", "hi"]):
+            assert mm.column(name).equals(ref.column(1 + i)), (name, mm.column(name).slice(0, 5), ref.column(1 + i).slice(0, 5))
     try:
         fused_bad = acero.Declaration.from_sequence([
             acero.Declaration("table_source", acero.TableSourceNodeOptions(tn)),

@@ -694,3 +694,36 @@ def test_binary_take_many_tiny_values(gpu_ctx):
 
 def test_add_and_greater_with_a_scalar_operand(gpu_ctx):
     P.check_scalar_operand_ops(gpu_ctx, rng_for("scalarops"), n=300007)
+
+
+# ------------------------------------------------------------------ hash_min / hash_max on the fused table
+@pytest.mark.parametrize("skip_nulls", [True, False])
+@pytest.mark.parametrize("knull,vnull,batches,groups", [(0.0, 0.0, 1, 1000), (0.02, 0.2, 3, 100_000), (1.0, 0.5, 1, 10),
+                                                        (0.1, 1.0, 2, 50)])
+def test_groupby_min_max(gpu_ctx, skip_nulls, knull, vnull, batches, groups):
+    rng = rng_for("gbminmax", skip_nulls, knull, vnull, batches)
+    n = 400_003
+    k = U.random_array(rng, np.int32, n, null_p=knull, offset=2, lo=-groups, hi=groups)
+    v = U.random_array(rng, np.int64, n, null_p=vnull, offset=1)
+    v.values[5:9] = [2**63 - 1, -2**63, 0, -1]
+    P.check_groupby_min_max(gpu_ctx, k, v, skip_nulls, batches=batches, use_pyarrow=(groups <= 1000))
+
+
+def test_groupby_min_max_next_to_sum_and_merge(gpu_ctx):
+    amd = gpu_ctx
+    rng = rng_for("gbminmaxsum")
+    k = U.random_array(rng, np.int32, 300_000, null_p=0.02, lo=0, hi=5000)
+    v = U.random_array(rng, np.int64, 300_000, null_p=0.1, lo=-10**9, hi=10**9)
+    P.check_groupby_min_max(amd, k, v, True, batches=2, with_sum=True)
+    dk, dv = k.to_device(amd), v.to_device(amd)
+    a, b = amd.compute.GroupBySum(1 << 14, dk.device), amd.compute.GroupBySum(1 << 14, dk.device)
+    a.consume_min_max(dk.slice(0, 170_000), dv.slice(0, 170_000))
+    b.consume_min_max(dk.slice(170_000), dv.slice(170_000))
+    a.merge_min_max(b.export_min_max())
+    gk, gkv, gmin, gmax, gvalid = (x.cpu().numpy() for x in a.finalize_min_max())
+    w = O.groupby_minmax_i64(k.values, k.valid_bitmap(), 0, v.values, v.valid_bitmap(), 0, 300_000, True)
+    key = lambda r: (r[0] is None, r[0] or 0)  # noqa: E731
+    got = sorted(((int(x) if y else None, (int(c), int(d)) if e else None) for x, y, c, d, e in zip(gk, gkv, gmin, gmax, gvalid)), key=key)
+    want = sorted(((int(x) if y else None, (int(c), int(d)) if e else None)
+                   for x, y, c, d, e in zip(w["keys"], w["key_is_valid"], w["mins"], w["maxs"], w["valid"])), key=key)
+    assert got == want

@@ -389,3 +389,36 @@ def test_binary_filter_vs_pyarrow(sel, true_p, vnull, mnull):
     res = O.binary_filter(v.offsets, v.data, v.valid_bitmap(), v.offset, m.data_bytes(), m.valid_bitmap(),
                           m.offset, m.length, 1 if sel == "emit_null" else 0)
     _assert_bin_equals_pyarrow(res, pc.filter(v.to_pyarrow(), m.to_pyarrow(), null_selection_behavior=sel))
+
+
+# ------------------------------------------------------------------ hash_min_max (oracle.groupby_minmax_i64)
+def test_golden_groupby_min_max():
+    """TEST_P(GroupBy, MinMaxOnly), acero/hash_aggregate_test.cc:1591-1660, first aggregate: the
+    float64 arguments scaled by 8 (all exactly representable, order preserved) so that they are int64;
+    keys 1, 2, 3 and the null key; key 3 has only null values -> null min/max."""
+    arg = [8, None, 0, None, 32, 26, 1, -2, 6, None]
+    key = [1, 1, 2, 3, None, 1, 2, 2, None, 3]
+    v, k = from_list(arg, np.int64), from_list(key, np.int32)
+    w = O.groupby_minmax_i64(k.values, k.valid_bitmap(), 0, v.values, v.valid_bitmap(), 0, len(arg), True)
+    got = {(int(a) if b else None): ((int(c), int(d)) if e else None)
+           for a, b, c, d, e in zip(w["keys"], w["key_is_valid"], w["mins"], w["maxs"], w["valid"])}
+    assert got == {1: (8, 26), 2: (-2, 1), 3: None, None: (6, 32)}
+
+
+@pytest.mark.skipif(pc is None, reason="pyarrow wheel not in this image")
+@pytest.mark.parametrize("skip_nulls", [True, False])
+@pytest.mark.parametrize("knull,vnull", [(0.0, 0.0), (0.05, 0.3), (0.2, 0.95)])
+def test_groupby_min_max_vs_pyarrow(skip_nulls, knull, vnull):
+    rng = np.random.default_rng([U.kRandomSeed, int(skip_nulls), int(knull * 100), int(vnull * 100)])
+    n = 20_000
+    k = U.random_array(rng, np.int32, n, null_p=knull, offset=3, lo=-300, hi=300)
+    v = U.random_array(rng, np.int64, n, null_p=vnull, offset=1)
+    w = O.groupby_minmax_i64(k.values, k.valid_bitmap(), k.offset, v.values, v.valid_bitmap(), v.offset, n, skip_nulls)
+    got = {(int(a) if b else None): ((int(c), int(d)) if e else None)
+           for a, b, c, d, e in zip(w["keys"], w["key_is_valid"], w["mins"], w["maxs"], w["valid"])}
+    t = pa.table({"k": k.to_pyarrow(), "v": v.to_pyarrow()})
+    r = t.group_by("k", use_threads=False).aggregate(
+        [("v", "min_max", pc.ScalarAggregateOptions(skip_nulls=skip_nulls, min_count=5))])   # min_count is ignored
+    ref = {a: (None if b is None or b["min"] is None else (b["min"], b["max"]))
+           for a, b in zip(r.column("k").to_pylist(), r.column("v_min_max").to_pylist())}
+    assert got == ref
