@@ -22,7 +22,7 @@ import torch
 from . import _lib, tracing
 from ._lib import (ArrowIndexError, ArrowInvalid, ArrowNotImplementedError, check)  # noqa: F401
 from .array import (Array, DataType, Scalar, alloc, bitmap_nbytes, bool_, current_stream, float32,
-                    float64, int32, int64, kUnknownNullCount, uint16, uint32, uint64,
+                    float64, int32, int64, kUnknownNullCount, uint8, uint16, uint32, uint64,
                     INDEX_TYPE_ID)
 
 # --------------------------------------------------------------------------- options
@@ -911,6 +911,58 @@ class GroupBySum:
                                                int(self.options.skip_nulls), self.options.min_count,
                                                valid.data_ptr(), stream))
         return p["keys"], p["key_is_valid"], p["sums"], valid[:g]
+
+
+def _first_occurrence_groups(arr: Array, capacity: int | None, with_counts: bool):
+    """Distinct int32 values of `arr` in order of first appearance, from the fused group-by table:
+    the rows' own numbers go through the min reducer (first row of every group) and, for
+    value_counts, through the sum consume (whose `counts` column is the number of rows per group);
+    the G groups are then ordered by first row with array_sort_indices + take.  Everything
+    row-sized runs in the HIP kernels; torch only numbers the rows and flips one validity bit."""
+    if arr.type != int32:
+        raise ArrowNotImplementedError("unique / value_counts on the gfx950 path: int32 values only")
+    dev = arr.device
+    n = arr.length
+    if n == 0:
+        empty = Array(int32, 0, [None, alloc(0, dev)], 0, 0)
+        return empty, Array(int64, 0, [None, alloc(0, dev)], 0, 0)
+    rows = Array(int64, n, [None, torch.arange(n, dtype=torch.int64, device=dev).view(torch.uint8)], 0, 0)
+    op = GroupBySum(capacity or max(16, 2 * n + 2), dev)
+    if with_counts:
+        op.consume(arr, rows)
+    op.consume_min_max(arr, rows)
+    p = op.export_min_max()
+    g = int(p["keys"].numel())
+    as_arr = lambda t, col: Array(t, g, [None, col.contiguous().view(torch.uint8)], 0, 0)  # noqa: E731
+    order = call_function("array_sort_indices", [as_arr(int64, p["mins"])], ArraySortOptions())
+    keys = take(as_arr(int32, p["keys"]), order, boundscheck=False)
+    kvalid = take(as_arr(uint8, p["key_is_valid"]), order, boundscheck=False).data[:g]
+    validity, null_count = None, 0
+    null_pos = torch.nonzero(kvalid == 0)
+    if null_pos.numel():      # all nulls are one group: at most one bit to clear
+        pos = int(null_pos[0])
+        validity = torch.full((bitmap_nbytes(g),), 0xFF, dtype=torch.uint8, device=dev)
+        validity[g // 8:] = 0
+        if g % 8:
+            validity[g // 8] = (1 << (g % 8)) - 1
+        validity[pos // 8] = int(validity[pos // 8]) & ~(1 << (pos % 8))
+        null_count = 1
+    out = Array(int32, g, [validity, keys.data], null_count, 0)
+    counts = take(as_arr(int64, p["counts"]), order, boundscheck=False) if with_counts else None
+    return out, counts
+
+
+def unique(arr: Array, capacity: int | None = None) -> Array:
+    """compute::Unique (api_vector.cc; UniqueAction, kernels/vector_hash.cc:65-120) for int32:
+    distinct values in order of first appearance, the nulls as one entry.  `capacity`: slots of
+    the device hash table (default 2 * length + 2; pass ~2x the expected distinct count to save HBM)."""
+    return _first_occurrence_groups(arr, capacity, False)[0]
+
+
+def value_counts(arr: Array, capacity: int | None = None):
+    """compute::ValueCounts (ValueCountsAction, kernels/vector_hash.cc:125-190) for int32:
+    (values, counts int64) in order of first appearance; nulls are counted as one value."""
+    return _first_occurrence_groups(arr, capacity, True)
 
 
 def group_by_sum(keys: Array, values: Array, capacity: int | None = None,

@@ -299,6 +299,27 @@ def groupby_minmax_i64(keys, key_valid, key_off, values, val_valid, val_off, len
                 mins=np.array(mins, np.int64), maxs=np.array(maxs, np.int64), valid=np.array(valid, np.uint8))
 
 
+def unique_i32(values, valid_bitmap, offset, length, with_counts=False):
+    """UniqueAction / ValueCountsAction over RegularHashKernel (kernels/vector_hash.cc:65-120,274-330):
+    distinct values in order of first appearance; all nulls are one entry, placed where the first null
+    appeared; value_counts also counts every occurrence (nulls included).  Row-at-a-time.
+    Returns (values int32[g], is_valid bool[g][, counts int64[g]])."""
+    valid = unpack_bits(valid_bitmap, offset, length) if valid_bitmap is not None else np.ones(length, bool)
+    v = np.asarray(values)[offset: offset + length]
+    index, out, out_valid, counts = {}, [], [], []
+    for i in range(length):
+        key = int(v[i]) if valid[i] else None
+        g = index.get(key)
+        if g is None:
+            g = index[key] = len(out)
+            out.append(0 if key is None else key)
+            out_valid.append(key is not None)
+            counts.append(0)
+        counts[g] += 1
+    res = (np.array(out, np.int32), np.array(out_valid, bool))
+    return res + (np.array(counts, np.int64),) if with_counts else res
+
+
 class HashSumState:
     """GroupedReducingAggregator<Int64Type, GroupedSumImpl> with dense group ids:
     resize / consume / merge / finalize (hash_aggregate_numeric.cc:61-152)."""

@@ -383,6 +383,25 @@ def check_groupby_min_max(amd, keys: HostArray, values: HostArray, skip_nulls=Tr
     return got
 
 
+def check_unique_and_value_counts(amd, arr: HostArray, use_pyarrow=True):
+    """unique / value_counts (first-appearance order) vs the oracle and pyarrow."""
+    d = arr.to_device(amd)
+    want_v, want_ok, want_c = O.unique_i32(arr.values, arr.valid_bitmap(), arr.offset, arr.length, True)
+    u2, c = amd.compute.value_counts(d)
+    for u in (amd.compute.unique(d), u2):
+        vals, valid = u.to_numpy()
+        valid = np.ones(u.length, bool) if valid is None else valid
+        assert u.length == len(want_v), (u.length, len(want_v))
+        assert_equal(valid, want_ok, "unique validity")
+        assert_equal(vals[valid], want_v[want_ok], "unique values (first-appearance order)")
+        assert u.null_count == int((~want_ok).sum())
+    assert_equal(c.to_numpy()[0], want_c, "value_counts counts")
+    if use_pyarrow and pc is not None:
+        rc = pc.value_counts(arr.to_pyarrow())
+        assert u2.to_pyarrow().equals(rc.field("values")) and c.to_pyarrow().equals(rc.field("counts"))
+        assert u2.to_pyarrow().equals(pc.unique(arr.to_pyarrow()))
+
+
 # ------------------------------------------------------------------ hash_sum kernel vtable
 def check_hash_sum_kernel(amd, rng, n=5000, num_groups=37, null_p=0.2, skip_nulls=True, min_count=1,
                           use_pyarrow=True):

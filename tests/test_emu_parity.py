@@ -560,3 +560,12 @@ def test_groupby_min_max_merge_of_two_states(emu_ctx):
     want = sorted(((int(x) if y else None, (int(c), int(d)) if e else None)
                    for x, y, c, d, e in zip(w["keys"], w["key_is_valid"], w["mins"], w["maxs"], w["valid"])), key=key)
     assert got == want
+
+
+@pytest.mark.parametrize("null_p,offset", [(0.0, 0), (0.05, 3)])
+def test_unique_and_value_counts(emu_ctx, null_p, offset):
+    """UniqueAction / ValueCountsAction (vector_hash.cc): first-appearance order from the fused table."""
+    rng = rng_for("unique", null_p, offset)
+    a = U.random_array(rng, np.int32, 3000, null_p=null_p, offset=offset, tail=2, lo=-200, hi=200)
+    P.check_unique_and_value_counts(emu_ctx, a)          # (every sort launch costs seconds under the emulator)
+    P.check_unique_and_value_counts(emu_ctx, U.random_array(rng, np.int32, 0))

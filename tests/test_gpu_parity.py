@@ -727,3 +727,13 @@ def test_groupby_min_max_next_to_sum_and_merge(gpu_ctx):
     want = sorted(((int(x) if y else None, (int(c), int(d)) if e else None)
                    for x, y, c, d, e in zip(w["keys"], w["key_is_valid"], w["mins"], w["maxs"], w["valid"])), key=key)
     assert got == want
+
+
+@pytest.mark.parametrize("null_p,offset", [(0.0, 0), (0.05, 3), (1.0, 1)])
+def test_unique_and_value_counts(gpu_ctx, null_p, offset):
+    """UniqueAction / ValueCountsAction (vector_hash.cc): first-appearance order from the fused table."""
+    rng = rng_for("unique", null_p, offset)
+    a = U.random_array(rng, np.int32, 500003, null_p=null_p, offset=offset, tail=2, lo=-60000, hi=60000)
+    P.check_unique_and_value_counts(gpu_ctx, a)
+    P.check_unique_and_value_counts(gpu_ctx, U.random_array(rng, np.int32, 0))
+    P.check_unique_and_value_counts(gpu_ctx, U.random_array(rng, np.int32, 1, null_p=null_p))

@@ -422,3 +422,33 @@ def test_groupby_min_max_vs_pyarrow(skip_nulls, knull, vnull):
     ref = {a: (None if b is None or b["min"] is None else (b["min"], b["max"]))
            for a, b in zip(r.column("k").to_pylist(), r.column("v_min_max").to_pylist())}
     assert got == ref
+
+
+# ------------------------------------------------------------------ unique / value_counts (oracle.unique_i32)
+# TYPED_TEST(TestHashKernelPrimitive, Unique / ValueCounts), kernels/vector_hash_test.cc:159-186,188-215
+@pytest.mark.parametrize("values,want", [
+    ([2, None, 2, 1], [2, None, 1]),
+    ([None, None, 3, 1], [None, 3, 1]),
+    ([2, None, 3, 2], [2, None, 3]),            # [1, 2, null, 3, 2, null].Slice(1, 4)
+])
+def test_golden_unique(values, want):
+    a = from_list(values, np.int32)
+    v, ok = O.unique_i32(a.values, a.valid_bitmap(), 0, a.length)
+    assert [int(x) if y else None for x, y in zip(v, ok)] == want
+
+
+def test_golden_value_counts():
+    a = from_list([2, None, 2, 1, 2, 3, None], np.int32)     # vector_hash_test.cc:206-211
+    v, ok, c = O.unique_i32(a.values, a.valid_bitmap(), 0, a.length, True)
+    assert [int(x) if y else None for x, y in zip(v, ok)] == [2, None, 1, 3] and c.tolist() == [3, 2, 1, 1]
+
+
+@pytest.mark.skipif(pc is None, reason="pyarrow wheel not in this image")
+@pytest.mark.parametrize("null_p", [0.0, 0.1, 1.0])
+def test_unique_vs_pyarrow(null_p):
+    rng = np.random.default_rng([U.kRandomSeed, int(null_p * 100)])
+    a = U.random_array(rng, np.int32, 30_000, null_p=null_p, offset=5, lo=-500, hi=500)
+    v, ok, c = O.unique_i32(a.values, a.valid_bitmap(), a.offset, a.length, True)
+    ref = pc.value_counts(a.to_pyarrow())
+    assert [int(x) if y else None for x, y in zip(v, ok)] == ref.field("values").to_pylist()
+    assert c.tolist() == ref.field("counts").to_pylist()
