@@ -362,6 +362,39 @@ def _exec_add(args, options):
     return Array(left.type, n, [validity, out], nc, 0)
 
 
+def _exec_kleene(op_code):
+    def run(args, options):
+        """KleeneAndOp / KleeneOrOp (scalar_boolean.cc:138-260), array x array."""
+        left, right = args
+        if not (isinstance(left, Array) and isinstance(right, Array)):
+            raise ArrowNotImplementedError("and_kleene / or_kleene with a scalar operand is not on the gfx950 path")
+        if left.length != right.length:
+            raise ArrowInvalid("Array arguments must all be the same length")
+        dev = left.device
+        lib, stream = _lib_and_stream(dev)
+        n = left.length
+        out = alloc(bitmap_nbytes(n), dev, zero=True)
+        nulls = left.may_have_nulls() or right.may_have_nulls()
+        validity = alloc(bitmap_nbytes(n), dev, zero=True) if nulls else None
+        ls, rs = left.span(), right.span()
+        check(lib.arx_boolean_kleene(op_code, C.byref(ls), C.byref(rs), out.data_ptr(),
+                                     None if validity is None else validity.data_ptr(), stream))
+        return Array(bool_, n, [validity, out], kUnknownNullCount if nulls else 0, 0)
+    return run
+
+
+def _exec_invert(args, options):
+    """InvertOp (scalar_boolean.cc:39-50): data inverted, validity propagated."""
+    (arr,) = args
+    dev = arr.device
+    lib, stream = _lib_and_stream(dev)
+    n = arr.length
+    out = alloc(bitmap_nbytes(n), dev, zero=True)
+    check(lib.arx_boolean_invert(arr.data.data_ptr(), arr.offset, n, out.data_ptr(), stream))
+    validity, nc = _propagate_validity([arr], n, dev)
+    return Array(bool_, n, [validity, out], nc, 0)
+
+
 # ARX_KEY_* of include/arrow_amd.h
 _SORT_KEY_TYPE = {"uint64": 0, "int64": 1, "uint32": 2, "int32": 3, "double": 4, "float": 5}
 
@@ -698,6 +731,14 @@ def _build_registry() -> FunctionRegistry:
     f.add_kernel(Kernel((float64, float64), _exec_add, float64))
     reg.add_function(f)
 
+    for name, code in (("and_kleene", 0), ("or_kleene", 1)):
+        f = Function(name, Function.SCALAR, 2)
+        f.add_kernel(Kernel((bool_, bool_), _exec_kleene(code), bool_))
+        reg.add_function(f)
+    f = Function("invert", Function.SCALAR, 1)
+    f.add_kernel(Kernel((bool_,), _exec_invert, bool_))
+    reg.add_function(f)
+
     f = Function("array_sort_indices", Function.VECTOR, 1, ArraySortOptions())
     for key_type in (uint64, int64, uint32, int32, float64, float32):
         f.add_kernel(Kernel((key_type,), _exec_array_sort_indices, uint64))
@@ -760,6 +801,18 @@ def add(left, right):
     like = left if isinstance(left, Array) else right
     left, right = _wrap_scalar(left, like), _wrap_scalar(right, like)
     return call_function("add", [left, right])
+
+
+def and_kleene(left, right):
+    return call_function("and_kleene", [left, right])
+
+
+def or_kleene(left, right):
+    return call_function("or_kleene", [left, right])
+
+
+def invert(arr):
+    return call_function("invert", [arr])
 
 
 def sort_indices(arr, order: str = "ascending", null_placement: str = "at_end"):

@@ -66,9 +66,9 @@ std::atomic<int64_t> g_min_rows_streaming{INT64_MAX};
 
 // per-function call counters: which exec actually ran (the GPU tests assert on these so that a
 // silent route through the stock CPU kernel is a test failure, not a pass)
-enum Fn { kFnFilter = 0, kFnTake, kFnGreater, kFnSort, kFnCast, kFnHashSum, kFnAdd, kNumFn };
+enum Fn { kFnFilter = 0, kFnTake, kFnGreater, kFnSort, kFnCast, kFnHashSum, kFnAdd, kFnBoolean, kNumFn };
 const char* const kFnNames[kNumFn] = {"array_filter", "array_take", "greater", "array_sort_indices",
-                                      "cast", "hash_sum", "add"};
+                                      "cast", "hash_sum", "add", "boolean"};
 std::atomic<int64_t> g_fn_gpu[kNumFn];
 std::atomic<int64_t> g_fn_stock[kNumFn];
 void CountGpu(Fn f) {
@@ -1192,6 +1192,147 @@ Status RegisterScalarBinaryNP(cp::FunctionRegistry* reg, const char* name, const
   return sfn->AddKernel(std::move(copy));
 }
 
+// ---------------------------------------------------------------- and_kleene / or_kleene / invert
+// What Acero filter expressions like (a > 1) & (b > 2) evaluate to.  Same NO_PREALLOCATE twin:
+// device-resident boolean arrays run arx_boolean_kleene / arx_boolean_invert and stay in HBM; host
+// operands get the buffers the executor would have preallocated (data + validity bitmaps) and go to
+// Arrow's stock kernel.
+StockKernel g_stock_and_kleene, g_stock_or_kleene, g_stock_invert;
+
+template <int OP>
+Status KleeneExecNP(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResult* out) {
+  StockKernel& stock = OP == ARX_AND_KLEENE ? g_stock_and_kleene : g_stock_or_kleene;
+  const int64_t n = batch.length;
+  ArrayData* out_arr = out->array_data().get();
+  out_arr->buffers.resize(2);
+  const bool dev0 = batch[0].is_array() && OnRocm(batch[0].array);
+  const bool dev1 = batch[1].is_array() && OnRocm(batch[1].array);
+  if (dev0 || dev1) {
+    if (!(dev0 && dev1)) {
+      return Status::NotImplemented("arrow_amd: and_kleene / or_kleene on device-resident arrays needs device "
+                                    "arrays on both sides");
+    }
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    ArxSpan l{}, r{};
+    ARROW_RETURN_NOT_OK(DeviceSpan(batch[0].array, &l));
+    ARROW_RETURN_NOT_OK(DeviceSpan(batch[1].array, &r));
+    const int64_t bytes = ((n + 63) / 64) * 8;
+    ARROW_ASSIGN_OR_RAISE(out_arr->buffers[1], AllocDevice(bytes));
+    out_arr->buffers[0] = nullptr;
+    void* dvalid = nullptr;
+    const bool nulls = l.validity != nullptr || r.validity != nullptr;
+    if (nulls) {
+      ARROW_ASSIGN_OR_RAISE(out_arr->buffers[0], AllocDevice(bytes));
+      dvalid = reinterpret_cast<void*>(out_arr->buffers[0]->mutable_address());
+    }
+    ARROW_RETURN_NOT_OK(FromArx(arx_boolean_kleene(OP, &l, &r, reinterpret_cast<void*>(out_arr->buffers[1]->mutable_address()),
+                                                   dvalid, st)));
+    out_arr->null_count = 0;
+    if (nulls && n > 0) {
+      ARROW_ASSIGN_OR_RAISE(out_arr->null_count, DeviceNullCount(*out_arr->buffers[0], n, st));
+    }
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    CountGpu(kFnBoolean);
+    return Status::OK();
+  }
+  // host operands: NullHandling::COMPUTED_PREALLOCATE + MemAllocation::PREALLOCATE of the stock kernel
+  ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> data, ctx->AllocateBitmap(n));
+  ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> validity, ctx->AllocateBitmap(n));
+  cp::ExecResult tmp;
+  ArraySpan span;
+  span.type = out_arr->type.get();
+  span.length = n;
+  span.offset = 0;
+  span.null_count = arrow::kUnknownNullCount;
+  span.buffers[0].data = validity->mutable_data();
+  span.buffers[0].size = validity->size();
+  span.buffers[1].data = data->mutable_data();
+  span.buffers[1].size = data->size();
+  tmp.value = std::move(span);
+  CountStock(kFnBoolean);
+  ARROW_RETURN_NOT_OK(stock.exec(ctx, batch, &tmp));
+  out_arr->null_count = tmp.array_span()->null_count;
+  out_arr->buffers[0] = std::move(validity);
+  out_arr->buffers[1] = std::move(data);
+  return Status::OK();
+}
+
+Status InvertExecNP(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::ExecResult* out) {
+  const int64_t n = batch.length;
+  ArrayData* out_arr = out->array_data().get();
+  out_arr->buffers.resize(2);
+  if (batch[0].is_array() && OnRocm(batch[0].array)) {
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    ArxSpan a{};
+    ARROW_RETURN_NOT_OK(DeviceSpan(batch[0].array, &a));
+    const int64_t bytes = ((n + 63) / 64) * 8;
+    ARROW_ASSIGN_OR_RAISE(out_arr->buffers[1], AllocDevice(bytes));
+    ARROW_RETURN_NOT_OK(FromArx(arx_boolean_invert(a.data, a.offset, n,
+                                                   reinterpret_cast<void*>(out_arr->buffers[1]->mutable_address()), st)));
+    out_arr->buffers[0] = nullptr;
+    out_arr->null_count = 0;
+    if (a.validity != nullptr && n > 0) {
+      ARROW_ASSIGN_OR_RAISE(out_arr->buffers[0], AllocDevice(bytes));
+      ARROW_RETURN_NOT_OK(FromArx(arx_bitmap_copy(a.validity, a.offset, n,
+                                                  reinterpret_cast<void*>(out_arr->buffers[0]->mutable_address()), st)));
+      ARROW_ASSIGN_OR_RAISE(out_arr->null_count, DeviceNullCount(*out_arr->buffers[0], n, st));
+    }
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    CountGpu(kFnBoolean);
+    return Status::OK();
+  }
+  // host operand: NullHandling::INTERSECTION + PREALLOCATE
+  ARROW_ASSIGN_OR_RAISE(std::shared_ptr<Buffer> data, ctx->AllocateBitmap(n));
+  std::shared_ptr<Buffer> validity;
+  int64_t null_count = 0;
+  if (batch[0].is_scalar()) {
+    if (!batch[0].scalar->is_valid) {
+      ARROW_ASSIGN_OR_RAISE(validity, ctx->AllocateBitmap(n));
+      null_count = n;
+    }
+  } else if (batch[0].array.MayHaveNulls()) {
+    const ArraySpan& a = batch[0].array;
+    ARROW_ASSIGN_OR_RAISE(validity, arrow::internal::CopyBitmap(ctx->memory_pool(), a.buffers[0].data, a.offset, n));
+    null_count = a.null_count;
+  }
+  cp::ExecResult tmp;
+  ArraySpan span;
+  span.type = out_arr->type.get();
+  span.length = n;
+  span.offset = 0;
+  span.null_count = null_count;
+  if (validity) {
+    span.buffers[0].data = validity->mutable_data();
+    span.buffers[0].size = validity->size();
+  }
+  span.buffers[1].data = data->mutable_data();
+  span.buffers[1].size = data->size();
+  tmp.value = std::move(span);
+  CountStock(kFnBoolean);
+  ARROW_RETURN_NOT_OK(g_stock_invert.exec(ctx, batch, &tmp));
+  out_arr->buffers[0] = std::move(validity);
+  out_arr->buffers[1] = std::move(data);
+  out_arr->null_count = null_count;
+  return Status::OK();
+}
+
+Status RegisterBooleanNP(cp::FunctionRegistry* reg, const char* name, int arity, cp::ArrayKernelExec exec,
+                         StockKernel* stock) {
+  ARROW_ASSIGN_OR_RAISE(auto fn, reg->GetFunction(name));
+  auto* sfn = static_cast<cp::ScalarFunction*>(fn.get());
+  std::vector<arrow::TypeHolder> types(arity, arrow::boolean());
+  ARROW_ASSIGN_OR_RAISE(const cp::Kernel* k0, sfn->DispatchExact(types));
+  cp::ScalarKernel copy = *static_cast<const cp::ScalarKernel*>(k0);
+  stock->exec = copy.exec;
+  stock->init = copy.init;
+  copy.exec = exec;
+  copy.null_handling = cp::NullHandling::COMPUTED_NO_PREALLOCATE;
+  copy.mem_allocation = cp::MemAllocation::NO_PREALLOCATE;
+  return sfn->AddKernel(std::move(copy));
+}
+
 // ---------------------------------------------------------------- array_sort_indices(uint64|int64)
 // One slot per registered value type: 0-5 = the ARX_KEY_* types themselves, 6-11 = temporal types
 // sorted by their physical integer (date32, date64, timestamp, duration, time32, time64).
@@ -2042,6 +2183,9 @@ Status RegisterAll() {
   ARROW_RETURN_NOT_OK(RegisterScalarBinaryNP<OpGreaterI64>(reg, "greater", arrow::int64()));
   ARROW_RETURN_NOT_OK(RegisterScalarBinaryNP<OpAddI64>(reg, "add", arrow::int64()));
   ARROW_RETURN_NOT_OK(RegisterScalarBinaryNP<OpAddF64>(reg, "add", arrow::float64()));
+  ARROW_RETURN_NOT_OK(RegisterBooleanNP(reg, "and_kleene", 2, KleeneExecNP<ARX_AND_KLEENE>, &g_stock_and_kleene));
+  ARROW_RETURN_NOT_OK(RegisterBooleanNP(reg, "or_kleene", 2, KleeneExecNP<ARX_OR_KLEENE>, &g_stock_or_kleene));
+  ARROW_RETURN_NOT_OK(RegisterBooleanNP(reg, "invert", 1, InvertExecNP, &g_stock_invert));
   {
     ARROW_ASSIGN_OR_RAISE(auto stock_cast, reg->GetFunction("cast"));
     ARROW_RETURN_NOT_OK(reg->AddFunction(std::make_shared<RocmCastMetaFunction>(std::move(stock_cast)),
@@ -2092,7 +2236,7 @@ const char* arrow_amd_plugin_last_error(void) { return t_error.c_str(); }
 int64_t arrow_amd_plugin_gpu_calls(void) { return g_gpu_calls.load(); }
 int64_t arrow_amd_plugin_stock_calls(void) { return g_stock_calls.load(); }
 // Calls of `function` ("array_filter", "array_take", "greater", "array_sort_indices", "cast",
-// "hash_sum", "add") that ran on the GPU (gpu != 0) or were handed to the stock CPU kernel; -1 = unknown name.
+// "hash_sum", "add", "boolean" = and_kleene / or_kleene / invert) that ran on the GPU (gpu != 0) or were handed to the stock CPU kernel; -1 = unknown name.
 int64_t arrow_amd_plugin_calls(const char* function, int gpu) {
   for (int i = 0; i < kNumFn; ++i) {
     if (std::strcmp(function, kFnNames[i]) == 0) return (gpu ? g_fn_gpu[i] : g_fn_stock[i]).load();

@@ -215,6 +215,43 @@ __global__ __launch_bounds__(kBlock) void bitmap_kernel(Bits a, Bits b, int64_t 
   }
 }
 
+// and_kleene / or_kleene / invert on boolean arrays, one 64-bit word per lane-iteration
+// (KleeneAndOp / KleeneOrOp / InvertOp, kernels/scalar_boolean.cc:138-260): with
+//   x_true = x_valid & x_data,  x_false = x_valid & ~x_data
+//   and: data = l_true & r_true,  valid = l_false | r_false | (l_true & r_true)
+//   or : data = l_true | r_true,  valid = l_true | r_true | (l_false & r_false)
+// A NULL validity reads as all ones, padding bits past `length` come out zero (load_word).
+template <int OP>
+__global__ __launch_bounds__(kBlock) void kleene_kernel(Bits ld, Bits lv, Bits rd, Bits rv, int64_t nwords,
+                                                        uint64_t* __restrict__ out_data,
+                                                        uint64_t* __restrict__ out_valid) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < nwords; w += stride) {
+    const uint64_t l_valid = load_word(lv, w), r_valid = load_word(rv, w);
+    const uint64_t l_data = load_word(ld, w), r_data = load_word(rd, w);
+    const uint64_t lt = l_valid & l_data, lf = l_valid & ~l_data;
+    const uint64_t rt = r_valid & r_data, rf = r_valid & ~r_data;
+    uint64_t data, valid;
+    if constexpr (OP == ARX_AND_KLEENE) {
+      data = lt & rt;
+      valid = lf | rf | (lt & rt);
+    } else {
+      data = lt | rt;
+      valid = lt | rt | (lf & rf);
+    }
+    out_data[w] = data;
+    if (out_valid != nullptr) out_valid[w] = valid;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void invert_kernel(Bits a, Bits ones, int64_t nwords,
+                                                        uint64_t* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < nwords; w += stride) {
+    out[w] = ~load_word(a, w) & load_word(ones, w);  // `ones` only carries the tail mask
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void popcount_kernel(Bits a, int64_t nwords,
                                                           unsigned long long* total) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -368,6 +405,59 @@ int arx_bitmap_and(const void* left, int64_t left_offset, const void* right, int
   hipLaunchKernelGGL((bitmap_kernel<true>), dim3(grid), dim3(kBlock), 0, as_stream(stream), a, b,
                      nwords, static_cast<uint64_t*>(out));
   ARX_CHECK_LAUNCH("bitmap_kernel");
+  return ARX_OK;
+}
+
+int arx_boolean_kleene(int op, const ArxSpan* left, const ArxSpan* right, void* out_data, void* out_validity,
+                       void* stream) {
+  if (left == nullptr || right == nullptr || (op != ARX_AND_KLEENE && op != ARX_OR_KLEENE)) {
+    set_error("bad arguments to arx_boolean_kleene");
+    return ARX_INVALID;
+  }
+  if (left->length != right->length) {
+    set_error("Array arguments must all be the same length (%lld vs %lld)", static_cast<long long>(left->length),
+              static_cast<long long>(right->length));
+    return ARX_INVALID;
+  }
+  const int64_t n = left->length;
+  if (n == 0) return ARX_OK;
+  if (left->data == nullptr || right->data == nullptr || out_data == nullptr) {
+    set_error("NULL buffer passed to arx_boolean_kleene");
+    return ARX_INVALID;
+  }
+  const void* lvp = left->null_count != 0 ? left->validity : nullptr;
+  const void* rvp = right->null_count != 0 ? right->validity : nullptr;
+  if ((lvp != nullptr || rvp != nullptr) && out_validity == nullptr) {
+    set_error("arx_boolean_kleene: inputs may have nulls but out_validity is NULL");
+    return ARX_INVALID;
+  }
+  const Bits ld = make_bits(left->data, left->offset, n), lv = make_bits(lvp, left->offset, n);
+  const Bits rd = make_bits(right->data, right->offset, n), rv = make_bits(rvp, right->offset, n);
+  const int64_t nwords = ceil_div(n, 64);
+  const unsigned grid = stream_grid(kBlock, nwords);
+  if (op == ARX_AND_KLEENE) {
+    hipLaunchKernelGGL((kleene_kernel<ARX_AND_KLEENE>), dim3(grid), dim3(kBlock), 0, as_stream(stream), ld, lv, rd,
+                       rv, nwords, static_cast<uint64_t*>(out_data), static_cast<uint64_t*>(out_validity));
+  } else {
+    hipLaunchKernelGGL((kleene_kernel<ARX_OR_KLEENE>), dim3(grid), dim3(kBlock), 0, as_stream(stream), ld, lv, rd,
+                       rv, nwords, static_cast<uint64_t*>(out_data), static_cast<uint64_t*>(out_validity));
+  }
+  ARX_CHECK_LAUNCH("kleene_kernel");
+  return ARX_OK;
+}
+
+int arx_boolean_invert(const void* bits, int64_t bit_offset, int64_t length, void* out, void* stream) {
+  if (length < 0 || bit_offset < 0 || (length > 0 && (bits == nullptr || out == nullptr))) {
+    set_error("bad arguments to arx_boolean_invert");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  const Bits a = make_bits(bits, bit_offset, length);
+  const Bits ones = make_bits(nullptr, 0, length);
+  const int64_t nwords = ceil_div(length, 64);
+  hipLaunchKernelGGL(invert_kernel, dim3(stream_grid(kBlock, nwords)), dim3(kBlock), 0, as_stream(stream), a, ones,
+                     nwords, static_cast<uint64_t*>(out));
+  ARX_CHECK_LAUNCH("invert_kernel");
   return ARX_OK;
 }
 

@@ -236,6 +236,18 @@ int arx_bitmap_copy(const void* bits, int64_t bit_offset, int64_t length, void* 
                     void* stream);
 int arx_bitmap_and(const void* left, int64_t left_offset, const void* right,
                    int64_t right_offset, int64_t length, void* out, void* stream);
+/* Kleene logic on boolean arrays — KleeneAndOp / KleeneOrOp (array, array) and InvertOp,
+ * cpp/src/arrow/compute/kernels/scalar_boolean.cc:138-260.  left/right: boolean ArxSpans (data =
+ * LSB-first bitmap, offset in bits, validity NULL or null_count == 0 = no nulls).  out_data /
+ * out_validity start at bit 0, zero padded; out_validity may be NULL only when neither input can
+ * have nulls.  and: data = l_true & r_true, valid = l_false | r_false | (l_true & r_true);
+ * or: data = l_true | r_true, valid = l_true | r_true | (l_false & r_false).  Asynchronous. */
+#define ARX_AND_KLEENE 0
+#define ARX_OR_KLEENE 1
+int arx_boolean_kleene(int op, const ArxSpan* left, const ArxSpan* right, void* out_data, void* out_validity,
+                       void* stream);
+/* out bit i = !bits[bit_offset + i] (validity is the caller's: arx_bitmap_copy). */
+int arx_boolean_invert(const void* bits, int64_t bit_offset, int64_t length, void* out, void* stream);
 /* Synchronous popcount of [bit_offset, bit_offset+length) (CountSetBits). */
 int arx_bitmap_popcount(const void* bits, int64_t bit_offset, int64_t length, void* ws,
                         size_t ws_bytes, int64_t* out_count, void* stream);

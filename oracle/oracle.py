@@ -216,6 +216,21 @@ def add(left, right) -> np.ndarray:
     return out
 
 
+def kleene(op: str, l_data, l_valid, r_data, r_valid):
+    """and_kleene / or_kleene on boolean arrays given as numpy bool arrays (valid None = no nulls):
+    KleeneAndOp / KleeneOrOp, kernels/scalar_boolean.cc:179-196,240-257 — per slot, from the
+    truth table: and: false if either side is false, null if the rest involves a null; or: dual.
+    Returns (data bool[n], valid bool[n]); data under a null slot is what the reference's word
+    formula leaves there (and: 0; or: l_true | r_true)."""
+    l_data, r_data = np.asarray(l_data, bool), np.asarray(r_data, bool)
+    lv = np.ones(len(l_data), bool) if l_valid is None else np.asarray(l_valid, bool)
+    rv = np.ones(len(r_data), bool) if r_valid is None else np.asarray(r_valid, bool)
+    lt, lf, rt, rf = lv & l_data, lv & ~l_data, rv & r_data, rv & ~r_data
+    if op == "and":
+        return lt & rt, lf | rf | (lt & rt)
+    return lt | rt, lt | rt | (lf & rf)
+
+
 def bitmap_and(a, a_off, b, b_off, n) -> np.ndarray:
     out = np.zeros(bitmap_bytes(n), dtype=np.uint8)
     lib().arxo_bitmap_and(_ptr(a), a_off, _ptr(b), b_off, n, _ptr(out))

@@ -279,6 +279,37 @@ def check_scalar_operand_ops(amd, rng, n=10_000):
                 assert_equal(bits[valid], refg[valid], "greater scalar vs pyarrow")
 
 
+def check_kleene_and_invert(amd, left: HostArray, right: HostArray, use_pyarrow=True):
+    """and_kleene / or_kleene / invert on boolean arrays: data AND validity bitmaps equal the
+    oracle's word formula everywhere (also under null slots), values equal pyarrow's."""
+    dl, dr = left.to_device(amd), right.to_device(amd)
+    n = left.length
+    lv = None if left.valid is None else left.logical_valid()
+    rv = None if right.valid is None else right.logical_valid()
+    for op, fn, ref_fn in (("and", amd.compute.and_kleene, "and_kleene"), ("or", amd.compute.or_kleene, "or_kleene")):
+        out = fn(dl, dr)
+        want_data, want_valid = O.kleene(op, left.logical_values(), lv, right.logical_values(), rv)
+        bits, pad_ok = device_bitmap_to_bool(out.data, n)
+        assert_equal(bits, want_data, f"{op}_kleene data")
+        assert pad_ok
+        gv, pad2 = _logical_valid(out)
+        assert_equal(gv, want_valid, f"{op}_kleene validity")
+        assert pad2
+        if left.valid is None and right.valid is None:
+            assert out.validity is None and out.null_count == 0
+        if use_pyarrow and pc is not None:
+            ref = getattr(pc, ref_fn)(left.to_pyarrow(), right.to_pyarrow())
+            assert out.to_pyarrow().equals(ref), op
+    inv = amd.compute.invert(dl)
+    bits, pad_ok = device_bitmap_to_bool(inv.data, n)
+    assert_equal(bits, ~left.logical_values(), "invert data")
+    assert pad_ok
+    gv, _ = _logical_valid(inv)
+    assert_equal(gv, left.logical_valid(), "invert validity")
+    if use_pyarrow and pc is not None:
+        assert inv.to_pyarrow().equals(pc.invert(left.to_pyarrow()))
+
+
 # ------------------------------------------------------------------ sort
 def check_sort_indices(amd, arr: HostArray, order="ascending", null_placement="at_end",
                        use_pyarrow=True):

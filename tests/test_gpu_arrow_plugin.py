@@ -178,6 +178,19 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
     # compare -> filter -> add chain, all in HBM
     chain2 = to_host(pc.add(pc.filter(d_vals, pc.greater(d_vals, d_i64b)), 1))
     assert chain2.equals(pc.add(pc.filter(vals, pc.greater(vals, i64b)), 1))
+    # Kleene logic on device masks (what `&`, `|`, `~` on expressions mean) and a combined filter
+    ma, mb = pc.greater(d_vals, d_i64b), pc.greater(d_f64, d_f64b)
+    hma, hmb = pc.greater(vals, i64b), pc.greater(f64, f64b)
+    for dev_out, host_out in ((pc.and_kleene(ma, mb), pc.and_kleene(hma, hmb)), (pc.or_kleene(ma, mb), pc.or_kleene(hma, hmb)),
+                              (pc.invert(ma), pc.invert(hma)),
+                              (pc.and_kleene(ma.slice(3, n - 70), mb.slice(70, n - 70)), pc.and_kleene(hma.slice(3, n - 70), hmb.slice(70, n - 70))),
+                              (pc.or_kleene(d_mask, pc.invert(ma)), pc.or_kleene(mask, pc.invert(hma)))):
+        assert not dev_out.is_cpu
+        ho = to_host(dev_out)
+        assert ho.equals(host_out) and ho.null_count == host_out.null_count
+    assert lib.arrow_amd_plugin_calls(b"boolean", 1) == 6
+    both = to_host(pc.filter(d_vals, pc.and_kleene(ma, pc.invert(mb))))
+    assert both.equals(pc.filter(vals, pc.and_kleene(hma, pc.invert(hmb))))
     # sort on the device: uint64 indices stay in HBM and feed take
     skeys = pa.array(rng.integers(0, 2**63, n).astype(np.uint64), mask=rng.random(n) < 0.03)
     d_skeys = to_device(skeys)
@@ -406,13 +419,13 @@ ACERO_DEVICE_SCRIPT = textwrap.dedent(r'''
         def plan(table, agg):
             return acero.Declaration.from_sequence([
                 acero.Declaration("table_source", acero.TableSourceNodeOptions(table)),
-                acero.Declaration("filter", acero.FilterNodeOptions(pc.field("w") > 10)),
+                acero.Declaration("filter", acero.FilterNodeOptions((pc.field("w") > 10) & ~(pc.field("v") > 2**62))),
                 acero.Declaration("project", acero.ProjectNodeOptions([pc.field("k"), pc.add(pc.field("v"), pc.field("w"))], ["k", "v"])),   # (`+` on expressions is add_checked)
                 acero.Declaration(agg, acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"])),
             ])
 
         want = plan(host, "aggregate").to_table(use_threads=False).select(["k", "v_sum"]).sort_by("k")
-        names = (b"greater", b"add", b"array_filter", b"hash_sum")
+        names = (b"greater", b"add", b"array_filter", b"hash_sum", b"boolean")
         gpu0 = {f: lib.arrow_amd_plugin_calls(f, 1) for f in names}
         stock0 = {f: lib.arrow_amd_plugin_calls(f, 0) for f in names}
         for threads in (False, True):

@@ -737,3 +737,14 @@ def test_unique_and_value_counts(gpu_ctx, null_p, offset):
     P.check_unique_and_value_counts(gpu_ctx, a)
     P.check_unique_and_value_counts(gpu_ctx, U.random_array(rng, np.int32, 0))
     P.check_unique_and_value_counts(gpu_ctx, U.random_array(rng, np.int32, 1, null_p=null_p))
+
+
+@pytest.mark.parametrize("lnull,rnull,loff,roff", [(0.0, 0.0, 0, 0), (0.2, 0.0, 3, 0), (0.0, 0.3, 0, 65), (0.3, 0.3, 7, 13), (1.0, 0.5, 1, 2)])
+def test_kleene_and_or_invert(gpu_ctx, lnull, rnull, loff, roff):
+    """KleeneAndOp / KleeneOrOp / InvertOp (scalar_boolean.cc): the full truth table incl. nulls,
+    sliced operands with different bit offsets."""
+    rng = rng_for("kleene", lnull, rnull, loff, roff)
+    left = U.random_mask(rng, 1000003, 0.5, null_p=lnull, offset=loff, tail=3)
+    right = U.random_mask(rng, 1000003, 0.4, null_p=rnull, offset=roff, tail=5)
+    P.check_kleene_and_invert(gpu_ctx, left, right)
+    P.check_kleene_and_invert(gpu_ctx, U.random_mask(rng, 0, 0.5), U.random_mask(rng, 0, 0.5))

@@ -452,3 +452,31 @@ def test_unique_vs_pyarrow(null_p):
     ref = pc.value_counts(a.to_pyarrow())
     assert [int(x) if y else None for x, y in zip(v, ok)] == ref.field("values").to_pylist()
     assert c.tolist() == ref.field("counts").to_pylist()
+
+
+# ------------------------------------------------------------------ and_kleene / or_kleene (oracle.kleene)
+def test_golden_kleene_truth_table():
+    """TEST(TestBooleanKernel, KleeneAnd / KleeneOr), kernels/scalar_boolean_test.cc: the 3x3 table."""
+    tf = [True, True, True, False, False, False, None, None, None]
+    ft = [True, False, None, True, False, None, True, False, None]
+    l, r = from_list(tf, np.bool_), from_list(ft, np.bool_)
+    lv = None if l.valid is None else l.logical_valid()
+    rv = None if r.valid is None else r.logical_valid()
+    for op, want in (("and", [True, False, None, False, False, False, None, False, None]),
+                     ("or", [True, True, True, True, False, None, True, None, None])):
+        data, valid = O.kleene(op, l.logical_values(), lv, r.logical_values(), rv)
+        assert [bool(d) if v else None for d, v in zip(data, valid)] == want, op
+
+
+@pytest.mark.skipif(pc is None, reason="pyarrow wheel not in this image")
+@pytest.mark.parametrize("lnull,rnull", [(0.0, 0.0), (0.3, 0.0), (0.3, 0.4)])
+def test_kleene_vs_pyarrow(lnull, rnull):
+    rng = np.random.default_rng([U.kRandomSeed, int(lnull * 10), int(rnull * 10)])
+    l = U.random_mask(rng, 10_000, 0.5, null_p=lnull, offset=3)
+    r = U.random_mask(rng, 10_000, 0.5, null_p=rnull, offset=70)
+    lv = None if l.valid is None else l.logical_valid()
+    rv = None if r.valid is None else r.logical_valid()
+    for op, fn in (("and", pc.and_kleene), ("or", pc.or_kleene)):
+        data, valid = O.kleene(op, l.logical_values(), lv, r.logical_values(), rv)
+        ref = fn(l.to_pyarrow(), r.to_pyarrow())
+        assert [bool(d) if v else None for d, v in zip(data, valid)] == ref.to_pylist()

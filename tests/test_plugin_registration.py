@@ -54,6 +54,12 @@ SCRIPT = textwrap.dedent(r'''
             gt += [pc.array_sort_indices(sv), pc.array_sort_indices(sv, order="descending", null_placement="at_start")]
         for wv in wide:
             gt += [pc.filter(wv, m), pc.filter(wv, m, null_selection_behavior="emit_null"), pc.take(wv, ix)]
+        bm = pa.array(np.arange(1000) % 2 == 0, mask=np.arange(1000) % 9 == 0)
+        gt += [pc.and_kleene(m, bm), pc.or_kleene(m, bm), pc.and_kleene(bm.slice(3, 500), m.slice(70, 500)),
+               pc.and_kleene(bm, True), pc.or_kleene(False, bm), pc.and_kleene(bm, pa.scalar(None, pa.bool_())),
+               pc.or_kleene(pa.scalar(True), pa.scalar(None, pa.bool_())), pc.invert(bm), pc.invert(m.slice(5)),
+               pc.invert(pa.scalar(None, pa.bool_())), pc.and_kleene(pa.chunked_array([bm.slice(0, 300), bm.slice(300)]), m),
+               pa.table({"x": fn, "y": g}).filter((pc.field("x") > pc.field("y")) & ~(pc.field("x") > 0.5)).column("x").combine_chunks()]
         strs = pa.array([None if i % 5 == 0 else "s" * (i % 7) for i in range(1000)])
         gt += [pc.filter(strs, m), pc.take(strs, pa.array([5, 1, 999, None])),
                pc.filter(strs.cast(pa.binary()), m, null_selection_behavior="emit_null")]
@@ -82,7 +88,7 @@ SCRIPT = textwrap.dedent(r'''
         assert x.equals(y), (i, x, y)
         if isinstance(x, pa.Array):
             assert x.null_count == y.null_count, i
-    for fn in (b"array_filter", b"array_take", b"greater", b"array_sort_indices", b"cast", b"add"):
+    for fn in (b"array_filter", b"array_take", b"greater", b"array_sort_indices", b"cast", b"add", b"boolean"):
         assert lib.arrow_amd_plugin_calls(fn, 0) >= 1, fn     # handed to Arrow's stock kernel
         assert lib.arrow_amd_plugin_calls(fn, 1) == 0, fn     # nothing claimed to be a GPU call
     assert lib.arrow_amd_plugin_calls(b"no_such_function", 0) == -1
