@@ -338,6 +338,36 @@ def _exec_greater(args, options):
     return Array(bool_, n, [validity, out], nc, 0)
 
 
+_CMP_CODE = {"equal": 0, "not_equal": 1, "greater": 2, "greater_equal": 3, "less": 4, "less_equal": 5}
+
+
+def _exec_compare(op_name):
+    code = _CMP_CODE[op_name]
+
+    def run(args, options):
+        """CompareKernel<..., Op>::Exec (scalar_compare.cc:259-298) for Op in Equal ... LessEqual."""
+        left, right = args
+        arr = left if isinstance(left, Array) else right
+        dev = arr.device
+        lib, stream = _lib_and_stream(dev)
+        n = arr.length
+        if isinstance(left, Array) and isinstance(right, Array) and left.length != right.length:
+            raise ArrowInvalid("Array arguments must all be the same length")
+        out = alloc(bitmap_nbytes(n), dev, zero=True)
+        is_f = arr.type == float64
+        conv = float if is_f else int
+        lp = left.values_ptr() if isinstance(left, Array) else None
+        rp = right.values_ptr() if isinstance(right, Array) else None
+        ls = conv(_scalar_value(left) or 0) if lp is None else conv(0)
+        rs = conv(_scalar_value(right) or 0) if rp is None else conv(0)
+        fn = lib.arx_compare_f64 if is_f else lib.arx_compare_i64
+        with tracing.span("arx_compare"):
+            check(fn(code, lp, ls, rp, rs, n, out.data_ptr(), stream))
+        validity, nc = _propagate_validity([left, right], n, dev)
+        return Array(bool_, n, [validity, out], nc, 0)
+    return run
+
+
 def _exec_add(args, options):
     """ScalarBinary<..., Add> (codegen_internal.h:814, base_arithmetic_internal.h:45-80)."""
     left, right = args
@@ -726,6 +756,12 @@ def _build_registry() -> FunctionRegistry:
     f.add_kernel(Kernel((int64, int64), _exec_greater, bool_))
     reg.add_function(f)
 
+    for name in ("equal", "not_equal", "greater_equal", "less", "less_equal"):
+        f = Function(name, Function.SCALAR, 2)
+        f.add_kernel(Kernel((float64, float64), _exec_compare(name), bool_))
+        f.add_kernel(Kernel((int64, int64), _exec_compare(name), bool_))
+        reg.add_function(f)
+
     f = Function("add", Function.SCALAR, 2)
     f.add_kernel(Kernel((int64, int64), _exec_add, int64))
     f.add_kernel(Kernel((float64, float64), _exec_add, float64))
@@ -795,6 +831,19 @@ def greater(left, right):
     like = left if isinstance(left, Array) else right
     left, right = _wrap_scalar(left, like), _wrap_scalar(right, like)
     return call_function("greater", [left, right])
+
+
+def _compare_wrapper(name):
+    def fn(left, right):
+        like = left if isinstance(left, Array) else right
+        return call_function(name, [_wrap_scalar(left, like), _wrap_scalar(right, like)])
+    fn.__name__ = name
+    fn.__doc__ = f"compute::CallFunction(\"{name}\") (scalar_compare.cc:391-445)."
+    return fn
+
+
+equal, not_equal, greater_equal, less, less_equal = (_compare_wrapper(n) for n in
+                                                     ("equal", "not_equal", "greater_equal", "less", "less_equal"))
 
 
 def add(left, right):

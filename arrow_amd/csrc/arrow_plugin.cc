@@ -41,6 +41,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -66,9 +67,9 @@ std::atomic<int64_t> g_min_rows_streaming{INT64_MAX};
 
 // per-function call counters: which exec actually ran (the GPU tests assert on these so that a
 // silent route through the stock CPU kernel is a test failure, not a pass)
-enum Fn { kFnFilter = 0, kFnTake, kFnGreater, kFnSort, kFnCast, kFnHashSum, kFnAdd, kFnBoolean, kNumFn };
+enum Fn { kFnFilter = 0, kFnTake, kFnGreater, kFnSort, kFnCast, kFnHashSum, kFnAdd, kFnBoolean, kFnCompare, kNumFn };
 const char* const kFnNames[kNumFn] = {"array_filter", "array_take", "greater", "array_sort_indices",
-                                      "cast", "hash_sum", "add", "boolean"};
+                                      "cast", "hash_sum", "add", "boolean", "compare"};
 std::atomic<int64_t> g_fn_gpu[kNumFn];
 std::atomic<int64_t> g_fn_stock[kNumFn];
 void CountGpu(Fn f) {
@@ -1062,6 +1063,29 @@ struct OpAddF64 {
   static int aa(const T* l, const T* r, int64_t n, void* o, hipStream_t st) { return arx_add_f64(l, r, n, static_cast<T*>(o), st); }
   static int as(const T* l, T r, int64_t n, void* o, hipStream_t st) { return arx_add_f64_array_scalar(l, r, n, static_cast<T*>(o), st); }
   static int sa(T l, const T* r, int64_t n, void* o, hipStream_t st) { return arx_add_f64_array_scalar(r, l, n, static_cast<T*>(o), st); }
+};
+
+// equal / not_equal / greater_equal / less / less_equal for int64 and double (greater has its own
+// entries above): one stock-kernel slot per (function, type)
+StockKernel g_stock_compare[12];
+
+template <typename CT, typename ScalarType, int CMP, int SLOT>
+struct OpCompare {
+  using T = CT;
+  using ScalarT = ScalarType;
+  static constexpr bool kBitmapOut = true;
+  static constexpr Fn kFn = kFnCompare;
+  static StockKernel& stock() { return g_stock_compare[SLOT]; }
+  static int run(const T* l, T ls, const T* r, T rs, int64_t n, void* o, hipStream_t st) {
+    if constexpr (std::is_same<T, double>::value) {
+      return arx_compare_f64(CMP, l, ls, r, rs, n, static_cast<uint64_t*>(o), st);
+    } else {
+      return arx_compare_i64(CMP, l, ls, r, rs, n, static_cast<uint64_t*>(o), st);
+    }
+  }
+  static int aa(const T* l, const T* r, int64_t n, void* o, hipStream_t st) { return run(l, T(0), r, T(0), n, o, st); }
+  static int as(const T* l, T r, int64_t n, void* o, hipStream_t st) { return run(l, T(0), nullptr, r, n, o, st); }
+  static int sa(T l, const T* r, int64_t n, void* o, hipStream_t st) { return run(nullptr, l, r, T(0), n, o, st); }
 };
 
 template <class Op>
@@ -2183,6 +2207,17 @@ Status RegisterAll() {
   ARROW_RETURN_NOT_OK(RegisterScalarBinaryNP<OpGreaterI64>(reg, "greater", arrow::int64()));
   ARROW_RETURN_NOT_OK(RegisterScalarBinaryNP<OpAddI64>(reg, "add", arrow::int64()));
   ARROW_RETURN_NOT_OK(RegisterScalarBinaryNP<OpAddF64>(reg, "add", arrow::float64()));
+#define ARX_REGISTER_COMPARE(NAME, CMP, SLOT)                                                                          \
+  ARROW_RETURN_NOT_OK((RegisterScalarBinaryNP<OpCompare<int64_t, arrow::Int64Scalar, CMP, SLOT>>(reg, NAME,          \
+                                                                                               arrow::int64())));    \
+  ARROW_RETURN_NOT_OK((RegisterScalarBinaryNP<OpCompare<double, arrow::DoubleScalar, CMP, SLOT + 1>>(reg, NAME,      \
+                                                                                                  arrow::float64())))
+  ARX_REGISTER_COMPARE("equal", ARX_CMP_EQUAL, 0);
+  ARX_REGISTER_COMPARE("not_equal", ARX_CMP_NOT_EQUAL, 2);
+  ARX_REGISTER_COMPARE("greater_equal", ARX_CMP_GREATER_EQUAL, 4);
+  ARX_REGISTER_COMPARE("less", ARX_CMP_LESS, 6);
+  ARX_REGISTER_COMPARE("less_equal", ARX_CMP_LESS_EQUAL, 8);
+#undef ARX_REGISTER_COMPARE
   ARROW_RETURN_NOT_OK(RegisterBooleanNP(reg, "and_kleene", 2, KleeneExecNP<ARX_AND_KLEENE>, &g_stock_and_kleene));
   ARROW_RETURN_NOT_OK(RegisterBooleanNP(reg, "or_kleene", 2, KleeneExecNP<ARX_OR_KLEENE>, &g_stock_or_kleene));
   ARROW_RETURN_NOT_OK(RegisterBooleanNP(reg, "invert", 1, InvertExecNP, &g_stock_invert));
@@ -2236,7 +2271,8 @@ const char* arrow_amd_plugin_last_error(void) { return t_error.c_str(); }
 int64_t arrow_amd_plugin_gpu_calls(void) { return g_gpu_calls.load(); }
 int64_t arrow_amd_plugin_stock_calls(void) { return g_stock_calls.load(); }
 // Calls of `function` ("array_filter", "array_take", "greater", "array_sort_indices", "cast",
-// "hash_sum", "add", "boolean" = and_kleene / or_kleene / invert) that ran on the GPU (gpu != 0) or were handed to the stock CPU kernel; -1 = unknown name.
+// "hash_sum", "add", "boolean" = and_kleene / or_kleene / invert, "compare" = equal / not_equal /
+// greater_equal / less / less_equal) that ran on the GPU (gpu != 0) or were handed to the stock CPU kernel; -1 = unknown name.
 int64_t arrow_amd_plugin_calls(const char* function, int gpu) {
   for (int i = 0; i < kNumFn; ++i) {
     if (std::strcmp(function, kFnNames[i]) == 0) return (gpu ? g_fn_gpu[i] : g_fn_stock[i]).load();

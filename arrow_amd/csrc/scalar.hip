@@ -102,7 +102,18 @@ __device__ __forceinline__ Pair<T> load_pair(const T* p, int64_t r, int64_t n) {
   return v;
 }
 
-template <typename T, int LK, int RK, bool ALIGNED>
+// CMP: ARX_CMP_GREATER / GREATER_EQUAL / EQUAL / NOT_EQUAL (less / less_equal swap the operands at
+// the launch site); IEEE semantics for floats: every ordered comparison with a NaN is false,
+// not_equal is true (Equal / NotEqual / Greater / GreaterEqual, kernels/scalar_compare.cc:38-64)
+template <int CMP, typename T>
+__device__ __forceinline__ bool cmp_apply(T a, T b) {
+  if constexpr (CMP == ARX_CMP_GREATER) return a > b;
+  else if constexpr (CMP == ARX_CMP_GREATER_EQUAL) return a >= b;
+  else if constexpr (CMP == ARX_CMP_EQUAL) return a == b;
+  else return a != b;
+}
+
+template <typename T, int LK, int RK, bool ALIGNED, int CMP = ARX_CMP_GREATER>
 __global__ __launch_bounds__(kBlock) void greater_kernel(const T* __restrict__ left, T lscalar,
                                                          const T* __restrict__ right, T rscalar,
                                                          int64_t n, uint64_t* __restrict__ out) {
@@ -135,8 +146,8 @@ __global__ __launch_bounds__(kBlock) void greater_kernel(const T* __restrict__ l
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t row = base + u * 128 + lane * 2;
-      const bool b0 = (row < n) && (l[u].x > r[u].x);
-      const bool b1 = (row + 1 < n) && (l[u].y > r[u].y);
+      const bool b0 = (row < n) && cmp_apply<CMP>(l[u].x, r[u].x);
+      const bool b1 = (row + 1 < n) && cmp_apply<CMP>(l[u].y, r[u].y);
       const uint64_t e = __ballot(b0);
       const uint64_t o = __ballot(b1);
       words[2 * u] = spread32(e) | (spread32(o) << 1);
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void popcount_kernel(Bits a, int64_t nwords
   if (lane_id() == 0 && c != 0) atomicAdd(total, static_cast<unsigned long long>(c));
 }
 
-template <typename T, int LK, int RK>
+template <typename T, int LK, int RK, int CMP = ARX_CMP_GREATER>
 static int launch_greater(const T* left, T ls, const T* right, T rs, int64_t n, uint64_t* out,
                           hipStream_t st) {
   if (n < 0 || out == nullptr || (LK == kArray && left == nullptr && n > 0) ||
@@ -277,10 +288,10 @@ static int launch_greater(const T* left, T ls, const T* right, T rs, int64_t n, 
                        (RK != kArray || (reinterpret_cast<uint64_t>(right) & 15) == 0);
   const unsigned grid = stream_grid(kWavesPerBlock * 128 * 4, n);
   if (aligned) {
-    hipLaunchKernelGGL((greater_kernel<T, LK, RK, true>), dim3(grid), dim3(kBlock), 0, st, left, ls,
+    hipLaunchKernelGGL((greater_kernel<T, LK, RK, true, CMP>), dim3(grid), dim3(kBlock), 0, st, left, ls,
                        right, rs, n, out);
   } else {
-    hipLaunchKernelGGL((greater_kernel<T, LK, RK, false>), dim3(grid), dim3(kBlock), 0, st, left,
+    hipLaunchKernelGGL((greater_kernel<T, LK, RK, false, CMP>), dim3(grid), dim3(kBlock), 0, st, left,
                        ls, right, rs, n, out);
   }
   ARX_CHECK_LAUNCH("greater_kernel");
@@ -304,6 +315,32 @@ static int launch_add(const T* left, const T* right, T rscalar, int64_t n, T* ou
   }
   ARX_CHECK_LAUNCH("add_kernel");
   return ARX_OK;
+}
+
+// op in ARX_CMP_*; less / less_equal = greater / greater_equal with the operands swapped.
+// left / right NULL = that side is the scalar.
+template <typename T, int CMP>
+static int compare_shapes(const T* left, T ls, const T* right, T rs, int64_t n, uint64_t* out, hipStream_t st) {
+  if (left != nullptr && right != nullptr) return launch_greater<T, kArray, kArray, CMP>(left, ls, right, rs, n, out, st);
+  if (left != nullptr) return launch_greater<T, kArray, kScalar, CMP>(left, ls, nullptr, rs, n, out, st);
+  if (right != nullptr) return launch_greater<T, kScalar, kArray, CMP>(nullptr, ls, right, rs, n, out, st);
+  set_error("compare: at least one operand must be an array");
+  return ARX_INVALID;
+}
+
+template <typename T>
+static int compare_any(int op, const T* left, T ls, const T* right, T rs, int64_t n, uint64_t* out, hipStream_t st) {
+  switch (op) {
+    case ARX_CMP_EQUAL: return compare_shapes<T, ARX_CMP_EQUAL>(left, ls, right, rs, n, out, st);
+    case ARX_CMP_NOT_EQUAL: return compare_shapes<T, ARX_CMP_NOT_EQUAL>(left, ls, right, rs, n, out, st);
+    case ARX_CMP_GREATER: return compare_shapes<T, ARX_CMP_GREATER>(left, ls, right, rs, n, out, st);
+    case ARX_CMP_GREATER_EQUAL: return compare_shapes<T, ARX_CMP_GREATER_EQUAL>(left, ls, right, rs, n, out, st);
+    case ARX_CMP_LESS: return compare_shapes<T, ARX_CMP_GREATER>(right, rs, left, ls, n, out, st);
+    case ARX_CMP_LESS_EQUAL: return compare_shapes<T, ARX_CMP_GREATER_EQUAL>(right, rs, left, ls, n, out, st);
+    default:
+      set_error("unknown compare op %d", op);
+      return ARX_INVALID;
+  }
 }
 
 }  // namespace arx
@@ -350,6 +387,15 @@ int arx_greater_i64(const int64_t* left, const int64_t* right, int64_t length, u
                     void* stream) {
   return launch_greater<int64_t, kArray, kArray>(left, 0, right, 0, length, out_bits,
                                                  as_stream(stream));
+}
+
+int arx_compare_f64(int op, const double* left, double left_scalar, const double* right, double right_scalar,
+                    int64_t length, uint64_t* out_bits, void* stream) {
+  return compare_any<double>(op, left, left_scalar, right, right_scalar, length, out_bits, as_stream(stream));
+}
+int arx_compare_i64(int op, const int64_t* left, int64_t left_scalar, const int64_t* right, int64_t right_scalar,
+                    int64_t length, uint64_t* out_bits, void* stream) {
+  return compare_any<int64_t>(op, left, left_scalar, right, right_scalar, length, out_bits, as_stream(stream));
 }
 
 int arx_add_i64(const int64_t* left, const int64_t* right, int64_t length, int64_t* out,

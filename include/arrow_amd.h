@@ -210,6 +210,22 @@ int arx_greater_i64_array_scalar(const int64_t* left, int64_t right, int64_t len
 int arx_greater_i64_scalar_array(int64_t left, const int64_t* right, int64_t length,
                                  uint64_t* out_bits, void* stream);
 
+/* The whole comparison family — equal, not_equal, greater, greater_equal, less, less_equal
+ * (Equal ... LessEqual, cpp/src/arrow/compute/kernels/scalar_compare.cc:38-64; less / less_equal
+ * are registered there as the flipped greater / greater_equal, :436-445, and run here the same
+ * way).  left / right: pre-offset arrays, or NULL for "this side is the scalar" (then *_scalar is
+ * its value).  Floats: IEEE — NaN makes every ordered comparison and equal false, not_equal true. */
+#define ARX_CMP_EQUAL 0
+#define ARX_CMP_NOT_EQUAL 1
+#define ARX_CMP_GREATER 2
+#define ARX_CMP_GREATER_EQUAL 3
+#define ARX_CMP_LESS 4
+#define ARX_CMP_LESS_EQUAL 5
+int arx_compare_f64(int op, const double* left, double left_scalar, const double* right, double right_scalar,
+                    int64_t length, uint64_t* out_bits, void* stream);
+int arx_compare_i64(int op, const int64_t* left, int64_t left_scalar, const int64_t* right, int64_t right_scalar,
+                    int64_t length, uint64_t* out_bits, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Arithmetic — replaces ScalarBinary<Int64,Int64,Int64,Add> / <Double,...>
  * (cpp/src/arrow/compute/kernels/base_arithmetic_internal.h:45-80,

@@ -216,6 +216,20 @@ def add(left, right) -> np.ndarray:
     return out
 
 
+_CMP = {"equal": np.equal, "not_equal": np.not_equal, "greater": np.greater,
+        "greater_equal": np.greater_equal, "less": np.less, "less_equal": np.less_equal}
+
+
+def compare(op: str, left, right) -> np.ndarray:
+    """equal / not_equal / greater / greater_equal / less / less_equal on int64 or float64 operands
+    (arrays or python scalars): the Call bodies of Equal ... LessEqual, kernels/scalar_compare.cc:38-64
+    — C++ `==`, `!=`, `>`, `>=` (less / less_equal are the flipped forms, :436-445), i.e. IEEE for
+    floats: any ordered comparison or equality with a NaN is false, not_equal is true.  numpy's
+    element-wise operators are the same C operators.  Returns bool[n] computed on every slot."""
+    with np.errstate(invalid="ignore"):
+        return np.asarray(_CMP[op](left, right), dtype=bool)
+
+
 def kleene(op: str, l_data, l_valid, r_data, r_valid):
     """and_kleene / or_kleene on boolean arrays given as numpy bool arrays (valid None = no nulls):
     KleeneAndOp / KleeneOrOp, kernels/scalar_boolean.cc:179-196,240-257 — per slot, from the

@@ -279,6 +279,36 @@ def check_scalar_operand_ops(amd, rng, n=10_000):
                 assert_equal(bits[valid], refg[valid], "greater scalar vs pyarrow")
 
 
+def check_compare_family(amd, rng, n=10_000, use_pyarrow=True):
+    """equal ... less_equal on int64 and float64 (NaN, +-0, infinities), array x array and both
+    scalar orders, sliced operands: bits equal the oracle on every slot, nulls propagate."""
+    for dtype in (np.int64, np.float64):
+        a = util.random_array(rng, dtype, n, null_p=0.1, offset=3, tail=2, **({"lo": -50, "hi": 50} if dtype == np.int64 else {}))
+        b = util.random_array(rng, dtype, n, null_p=0.05, offset=1, tail=4, **({"lo": -50, "hi": 50} if dtype == np.int64 else {}))
+        if dtype == np.float64:
+            a.values[:] = np.round(a.values * 2) / 2
+            b.values[:] = np.round(b.values * 2) / 2          # many ties
+            a.values[3:9] = [np.nan, np.inf, -np.inf, 0.0, -0.0, np.nan]
+            b.values[1:7] = [np.nan, np.inf, 1.0, -0.0, 0.0, 2.0]
+        da, db = a.to_device(amd), b.to_device(amd)
+        la, lb = a.logical_values(), b.logical_values()
+        sc = dtype(0.5) if dtype == np.float64 else dtype(7)
+        for op in ("equal", "not_equal", "greater", "greater_equal", "less", "less_equal"):
+            fn = getattr(amd.compute, op)
+            cases = [(fn(da, db), O.compare(op, la, lb), a.logical_valid() & b.logical_valid()),
+                     (fn(da, sc.item()), O.compare(op, la, sc), a.logical_valid()),
+                     (fn(sc.item(), db), O.compare(op, sc, lb), b.logical_valid())]
+            for out, want_bits, want_valid in cases:
+                bits, pad_ok = device_bitmap_to_bool(out.data, n)
+                assert_equal(bits, want_bits, f"{op}[{dtype.__name__}] bits")
+                assert pad_ok
+                gv, _ = _logical_valid(out)
+                assert_equal(gv, want_valid, f"{op} validity")
+            if use_pyarrow and pc is not None:
+                ref = getattr(pc, op)(a.to_pyarrow(), b.to_pyarrow())
+                assert fn(da, db).to_pyarrow().equals(ref), op
+
+
 def check_kleene_and_invert(amd, left: HostArray, right: HostArray, use_pyarrow=True):
     """and_kleene / or_kleene / invert on boolean arrays: data AND validity bitmaps equal the
     oracle's word formula everywhere (also under null slots), values equal pyarrow's."""

@@ -580,3 +580,8 @@ def test_kleene_and_or_invert(emu_ctx, lnull, rnull, loff, roff):
     right = U.random_mask(rng, 5000, 0.4, null_p=rnull, offset=roff, tail=5)
     P.check_kleene_and_invert(emu_ctx, left, right)
     P.check_kleene_and_invert(emu_ctx, U.random_mask(rng, 0, 0.5), U.random_mask(rng, 0, 0.5))
+
+
+def test_compare_family(emu_ctx):
+    """Equal ... LessEqual (scalar_compare.cc:38-64): int64 and float64 incl. NaN / signed zeros / infinities."""
+    P.check_compare_family(emu_ctx, rng_for("cmpfamily"), n=3000)

@@ -178,6 +178,17 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
     # compare -> filter -> add chain, all in HBM
     chain2 = to_host(pc.add(pc.filter(d_vals, pc.greater(d_vals, d_i64b)), 1))
     assert chain2.equals(pc.add(pc.filter(vals, pc.greater(vals, i64b)), 1))
+    # the whole comparison family on device arrays (NaN-aware for doubles), scalars on either side
+    f64n = pa.array(np.where(rng.random(n) < 0.01, np.nan, np.round(rng.standard_normal(n) * 4) / 4), mask=rng.random(n) < 0.05)
+    d_f64n = to_device(f64n)
+    for cmp in (pc.equal, pc.not_equal, pc.greater_equal, pc.less, pc.less_equal):
+        for dev_out, host_out in ((cmp(d_vals, d_i64b), cmp(vals, i64b)), (cmp(d_vals, 12345), cmp(vals, 12345)),
+                                  (cmp(0.25, d_f64n), cmp(0.25, f64n)), (cmp(d_f64n, d_f64b), cmp(f64n, f64b)),
+                                  (cmp(d_f64n.slice(9, n - 20), d_f64n.slice(3, n - 20)), cmp(f64n.slice(9, n - 20), f64n.slice(3, n - 20)))):
+            assert not dev_out.is_cpu
+            ho = to_host(dev_out)
+            assert ho.equals(host_out) and ho.null_count == host_out.null_count, cmp
+    assert lib.arrow_amd_plugin_calls(b"compare", 1) == 25
     # Kleene logic on device masks (what `&`, `|`, `~` on expressions mean) and a combined filter
     ma, mb = pc.greater(d_vals, d_i64b), pc.greater(d_f64, d_f64b)
     hma, hmb = pc.greater(vals, i64b), pc.greater(f64, f64b)

@@ -480,3 +480,19 @@ def test_kleene_vs_pyarrow(lnull, rnull):
         data, valid = O.kleene(op, l.logical_values(), lv, r.logical_values(), rv)
         ref = fn(l.to_pyarrow(), r.to_pyarrow())
         assert [bool(d) if v else None for d, v in zip(data, valid)] == ref.to_pylist()
+
+
+# ------------------------------------------------------------------ the comparison family (oracle.compare)
+@pytest.mark.skipif(pc is None, reason="pyarrow wheel not in this image")
+@pytest.mark.parametrize("op", ["equal", "not_equal", "greater", "greater_equal", "less", "less_equal"])
+def test_compare_family_vs_pyarrow(op):
+    """Values follow TestCompareKernel's SimpleCompare cases (kernels/scalar_compare_test.cc): ties,
+    NaN on either side, signed zeros, infinities; int64 edges."""
+    f = np.array([0.0, -0.0, 1.5, np.nan, np.inf, -np.inf, 2.0, np.nan, -1.0, 1.5])
+    g = np.array([-0.0, 0.0, 1.5, 1.0, np.inf, np.inf, np.nan, np.nan, -2.0, 1.25])
+    i = np.array([0, -1, 2**63 - 1, -2**63, 5, 5, 7], dtype=np.int64)
+    j = np.array([0, 1, -2**63, 2**63 - 1, 5, 6, 7], dtype=np.int64)
+    for l, r in ((f, g), (i, j), (f, 1.5), (1.5, g), (i, 5), (5, j)):
+        pl = pa.array(l) if isinstance(l, np.ndarray) else pa.scalar(l)
+        pr = pa.array(r) if isinstance(r, np.ndarray) else pa.scalar(r)
+        assert O.compare(op, l, r).tolist() == getattr(pc, op)(pl, pr).to_pylist(), (op, l, r)

@@ -54,6 +54,10 @@ SCRIPT = textwrap.dedent(r'''
             gt += [pc.array_sort_indices(sv), pc.array_sort_indices(sv, order="descending", null_placement="at_start")]
         for wv in wide:
             gt += [pc.filter(wv, m), pc.filter(wv, m, null_selection_behavior="emit_null"), pc.take(wv, ix)]
+        for cmp in (pc.equal, pc.not_equal, pc.greater_equal, pc.less, pc.less_equal):
+            gt += [cmp(a, a2), cmp(a.slice(2, 300), a2.slice(5, 300)), cmp(a, 500), cmp(500, a2), cmp(fn, g), cmp(fn, 0.0),
+                   cmp(0.25, g), cmp(a, pa.scalar(None, pa.int64())), cmp(pa.chunked_array([fn.slice(0, 400), fn.slice(400)]), g),
+                   cmp(pa.array([float("nan"), 1.0, -0.0]), pa.array([float("nan"), 1.0, 0.0]))]
         bm = pa.array(np.arange(1000) % 2 == 0, mask=np.arange(1000) % 9 == 0)
         gt += [pc.and_kleene(m, bm), pc.or_kleene(m, bm), pc.and_kleene(bm.slice(3, 500), m.slice(70, 500)),
                pc.and_kleene(bm, True), pc.or_kleene(False, bm), pc.and_kleene(bm, pa.scalar(None, pa.bool_())),
@@ -88,7 +92,7 @@ SCRIPT = textwrap.dedent(r'''
         assert x.equals(y), (i, x, y)
         if isinstance(x, pa.Array):
             assert x.null_count == y.null_count, i
-    for fn in (b"array_filter", b"array_take", b"greater", b"array_sort_indices", b"cast", b"add", b"boolean"):
+    for fn in (b"array_filter", b"array_take", b"greater", b"array_sort_indices", b"cast", b"add", b"boolean", b"compare"):
         assert lib.arrow_amd_plugin_calls(fn, 0) >= 1, fn     # handed to Arrow's stock kernel
         assert lib.arrow_amd_plugin_calls(fn, 1) == 0, fn     # nothing claimed to be a GPU call
     assert lib.arrow_amd_plugin_calls(b"no_such_function", 0) == -1
