@@ -112,6 +112,9 @@ SIGNATURES = {
     "arx_greater_f64_array_scalar": (_int, [_p, C.c_double, _i64, _p, _p]),
     "arx_greater_f64_scalar_array": (_int, [C.c_double, _p, _i64, _p, _p]),
     "arx_greater_i64": (_int, [_p, _p, _i64, _p, _p]),
+    "arx_arith_i64": (_int, [_int, _p, _i64, _p, _i64, _i64, _p, _p]),
+    "arx_arith_f64": (_int, [_int, _p, C.c_double, _p, C.c_double, _i64, _p, _p]),
+    "arx_arith_checked_i64": (_int, [_int, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p]),
     "arx_compare_f64": (_int, [_int, _p, C.c_double, _p, C.c_double, _i64, _p, _p]),
     "arx_compare_i64": (_int, [_int, _p, _i64, _p, _i64, _i64, _p, _p]),
     "arx_greater_i64_array_scalar": (_int, [_p, _i64, _i64, _p, _p]),

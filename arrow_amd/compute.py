@@ -338,6 +338,49 @@ def _exec_greater(args, options):
     return Array(bool_, n, [validity, out], nc, 0)
 
 
+_ARITH_CODE = {"add": 0, "subtract": 1, "multiply": 2}
+
+
+def _exec_arith(op_name, checked):
+    code = _ARITH_CODE[op_name]
+
+    def run(args, options):
+        """ScalarBinary<..., Add|Subtract|Multiply> / ScalarBinaryNotNull<..., *Checked>
+        (codegen_internal.h:814-; base_arithmetic_internal.h:45-150,290-364)."""
+        left, right = args
+        arr = left if isinstance(left, Array) else right
+        dev = arr.device
+        lib, stream = _lib_and_stream(dev)
+        n = arr.length
+        if isinstance(left, Array) and isinstance(right, Array) and left.length != right.length:
+            raise ArrowInvalid("Array arguments must all be the same length")
+        is_f = arr.type == float64
+        conv = float if is_f else int
+        lp = left.values_ptr() if isinstance(left, Array) else None
+        rp = right.values_ptr() if isinstance(right, Array) else None
+        ls = conv(_scalar_value(left) or 0) if lp is None else conv(0)
+        rs = conv(_scalar_value(right) or 0) if rp is None else conv(0)
+        out = alloc(n * 8, dev)
+        validity, nc = _propagate_validity([left, right], n, dev)
+        null_scalar = any(isinstance(a, Scalar) and not a.is_valid for a in (left, right))
+        if is_f:
+            check(lib.arx_arith_f64(code, lp, ls, rp, rs, n, out.data_ptr(), stream))
+        elif not checked or null_scalar:      # a null scalar makes every slot null: nothing to check
+            check(lib.arx_arith_i64(code, lp, ls, rp, rs, n, out.data_ptr(), stream))
+        else:
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+            def vptr(a):
+                return (a.validity.data_ptr(), a.offset) if isinstance(a, Array) and a.may_have_nulls() else (None, 0)
+            (lvp, lvo), (rvp, rvo) = vptr(left), vptr(right)
+            check(lib.arx_arith_checked_i64(code, lp, ls, lvp, lvo, rp, rs, rvp, rvo, n, out.data_ptr(),
+                                            flag.data_ptr(), stream))
+            if int(flag.cpu()[0]) != 0:
+                raise ArrowInvalid("overflow")   # AddChecked::Call, base_arithmetic_internal.h:77
+        return Array(arr.type, n, [validity, out], nc, 0)
+    return run
+
+
 _CMP_CODE = {"equal": 0, "not_equal": 1, "greater": 2, "greater_equal": 3, "less": 4, "less_equal": 5}
 
 
@@ -766,6 +809,13 @@ def _build_registry() -> FunctionRegistry:
     f.add_kernel(Kernel((int64, int64), _exec_add, int64))
     f.add_kernel(Kernel((float64, float64), _exec_add, float64))
     reg.add_function(f)
+    for name, op, checked in (("subtract", "subtract", False), ("multiply", "multiply", False),
+                              ("add_checked", "add", True), ("subtract_checked", "subtract", True),
+                              ("multiply_checked", "multiply", True)):
+        f = Function(name, Function.SCALAR, 2)
+        f.add_kernel(Kernel((int64, int64), _exec_arith(op, checked), int64))
+        f.add_kernel(Kernel((float64, float64), _exec_arith(op, checked), float64))
+        reg.add_function(f)
 
     for name, code in (("and_kleene", 0), ("or_kleene", 1)):
         f = Function(name, Function.SCALAR, 2)
@@ -844,6 +894,8 @@ def _compare_wrapper(name):
 
 equal, not_equal, greater_equal, less, less_equal = (_compare_wrapper(n) for n in
                                                      ("equal", "not_equal", "greater_equal", "less", "less_equal"))
+subtract, multiply, add_checked, subtract_checked, multiply_checked = (
+    _compare_wrapper(n) for n in ("subtract", "multiply", "add_checked", "subtract_checked", "multiply_checked"))
 
 
 def add(left, right):

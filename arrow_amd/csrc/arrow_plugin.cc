@@ -140,7 +140,7 @@ class DeviceScratch {
 };
 thread_local DeviceScratch t_scratch;
 
-enum Slot { kValues = 0, kValidity, kArg2, kArg2Validity, kOutData, kOutValidity, kWs, kCounter, kBinWs };
+enum Slot { kValues = 0, kValidity, kArg2, kArg2Validity, kOutData, kOutValidity, kWs, kCounter, kBinWs, kFlag };
 
 // Upload the logical range of a fixed-width (or boolean) ArraySpan.  The device copy keeps the
 // sub-byte part of the offset (offset % 8) so that one logical offset addresses both buffers.
@@ -1035,6 +1035,7 @@ Status GreaterExecNP(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::Exec
 StockKernel g_stock_greater_i64, g_stock_add_i64, g_stock_add_f64;
 
 struct OpGreaterI64 {
+  static constexpr bool kChecked = false;
   using T = int64_t;
   using ScalarT = arrow::Int64Scalar;
   static constexpr bool kBitmapOut = true;
@@ -1045,6 +1046,7 @@ struct OpGreaterI64 {
   static int sa(T l, const T* r, int64_t n, void* o, hipStream_t st) { return arx_greater_i64_scalar_array(l, r, n, static_cast<uint64_t*>(o), st); }
 };
 struct OpAddI64 {
+  static constexpr bool kChecked = false;
   using T = int64_t;
   using ScalarT = arrow::Int64Scalar;
   static constexpr bool kBitmapOut = false;
@@ -1055,6 +1057,7 @@ struct OpAddI64 {
   static int sa(T l, const T* r, int64_t n, void* o, hipStream_t st) { return arx_add_i64_array_scalar(r, l, n, static_cast<T*>(o), st); }
 };
 struct OpAddF64 {
+  static constexpr bool kChecked = false;
   using T = double;
   using ScalarT = arrow::DoubleScalar;
   static constexpr bool kBitmapOut = false;
@@ -1074,6 +1077,7 @@ struct OpCompare {
   using T = CT;
   using ScalarT = ScalarType;
   static constexpr bool kBitmapOut = true;
+  static constexpr bool kChecked = false;
   static constexpr Fn kFn = kFnCompare;
   static StockKernel& stock() { return g_stock_compare[SLOT]; }
   static int run(const T* l, T ls, const T* r, T rs, int64_t n, void* o, hipStream_t st) {
@@ -1086,6 +1090,40 @@ struct OpCompare {
   static int aa(const T* l, const T* r, int64_t n, void* o, hipStream_t st) { return run(l, T(0), r, T(0), n, o, st); }
   static int as(const T* l, T r, int64_t n, void* o, hipStream_t st) { return run(l, T(0), nullptr, r, n, o, st); }
   static int sa(T l, const T* r, int64_t n, void* o, hipStream_t st) { return run(nullptr, l, r, T(0), n, o, st); }
+};
+
+// subtract / multiply and add_checked / subtract_checked / multiply_checked (int64, double): what
+// `+`, `-`, `*` on pyarrow / Acero expressions mean.  The checked int64 forms read an overflow flag
+// back after the kernel and fail with the reference's Status::Invalid("overflow").
+StockKernel g_stock_arith[10];
+
+template <typename CT, typename ScalarType, int OP, bool CHECKED, int SLOT>
+struct OpArith {
+  using T = CT;
+  using ScalarT = ScalarType;
+  static constexpr bool kBitmapOut = false;
+  static constexpr bool kChecked = CHECKED && std::is_same<CT, int64_t>::value;
+  static constexpr Fn kFn = kFnAdd;
+  static StockKernel& stock() { return g_stock_arith[SLOT]; }
+  static int run(const T* l, T ls, const T* r, T rs, int64_t n, void* o, hipStream_t st) {
+    if constexpr (std::is_same<T, double>::value) {
+      return arx_arith_f64(OP, l, ls, r, rs, n, static_cast<double*>(o), st);
+    } else {
+      return arx_arith_i64(OP, l, ls, r, rs, n, static_cast<int64_t*>(o), st);
+    }
+  }
+  static int aa(const T* l, const T* r, int64_t n, void* o, hipStream_t st) { return run(l, T(0), r, T(0), n, o, st); }
+  static int as(const T* l, T r, int64_t n, void* o, hipStream_t st) { return run(l, T(0), nullptr, r, n, o, st); }
+  static int sa(T l, const T* r, int64_t n, void* o, hipStream_t st) { return run(nullptr, l, r, T(0), n, o, st); }
+  static int checked(const T* l, T ls, const ArxSpan& lsp, const T* r, T rs, const ArxSpan& rsp, int64_t n, void* o,
+                     unsigned int* flag, hipStream_t st) {
+    if constexpr (std::is_same<T, int64_t>::value) {
+      return arx_arith_checked_i64(OP, l, ls, l ? lsp.validity : nullptr, lsp.offset, r, rs,
+                                   r ? rsp.validity : nullptr, rsp.offset, n, static_cast<int64_t*>(o), flag, st);
+    } else {
+      return ARX_NOT_IMPLEMENTED;
+    }
+  }
 };
 
 template <class Op>
@@ -1120,9 +1158,18 @@ Status ScalarBinaryNP(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::Exe
       }
     }
     int rc;
-    if (ptr[0] && ptr[1]) rc = Op::aa(ptr[0], ptr[1], n, dout, st);
-    else if (ptr[0]) rc = Op::as(ptr[0], sc[1], n, dout, st);
-    else rc = Op::sa(sc[0], ptr[1], n, dout, st);
+    unsigned int* d_flag = nullptr;
+    if constexpr (Op::kChecked) {
+      void* f = nullptr;
+      ARROW_RETURN_NOT_OK(t_scratch.Get(kFlag, 64, &f));
+      HIP_RETURN_NOT_OK(hipMemsetAsync(f, 0, 4, st));
+      d_flag = static_cast<unsigned int*>(f);
+      rc = Op::checked(ptr[0], sc[0], sp[0], ptr[1], sc[1], sp[1], n, dout, d_flag, st);
+    } else {
+      if (ptr[0] && ptr[1]) rc = Op::aa(ptr[0], ptr[1], n, dout, st);
+      else if (ptr[0]) rc = Op::as(ptr[0], sc[1], n, dout, st);
+      else rc = Op::sa(sc[0], ptr[1], n, dout, st);
+    }
     ARROW_RETURN_NOT_OK(FromArx(rc));
     const ArxSpan* with_nulls[2];
     int nv = 0;
@@ -1142,7 +1189,10 @@ Status ScalarBinaryNP(cp::KernelContext* ctx, const cp::ExecSpan& batch, cp::Exe
       }
       ARROW_ASSIGN_OR_RAISE(out_arr->null_count, DeviceNullCount(*out_arr->buffers[0], n, st));
     }
+    unsigned int flag = 0;
+    if (d_flag != nullptr) HIP_RETURN_NOT_OK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
     HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    if (flag != 0) return Status::Invalid("overflow");  // AddChecked::Call, base_arithmetic_internal.h:77
     CountGpu(Op::kFn);
     return Status::OK();
   }
@@ -2218,6 +2268,17 @@ Status RegisterAll() {
   ARX_REGISTER_COMPARE("less", ARX_CMP_LESS, 6);
   ARX_REGISTER_COMPARE("less_equal", ARX_CMP_LESS_EQUAL, 8);
 #undef ARX_REGISTER_COMPARE
+#define ARX_REGISTER_ARITH(NAME, OP, CHECKED, SLOT)                                                                     \
+  ARROW_RETURN_NOT_OK((RegisterScalarBinaryNP<OpArith<int64_t, arrow::Int64Scalar, OP, CHECKED, SLOT>>(reg, NAME,     \
+                                                                                                     arrow::int64()))); \
+  ARROW_RETURN_NOT_OK((RegisterScalarBinaryNP<OpArith<double, arrow::DoubleScalar, OP, CHECKED, SLOT + 1>>(            \
+      reg, NAME, arrow::float64())))
+  ARX_REGISTER_ARITH("subtract", ARX_ARITH_SUBTRACT, false, 0);
+  ARX_REGISTER_ARITH("multiply", ARX_ARITH_MULTIPLY, false, 2);
+  ARX_REGISTER_ARITH("add_checked", ARX_ARITH_ADD, true, 4);
+  ARX_REGISTER_ARITH("subtract_checked", ARX_ARITH_SUBTRACT, true, 6);
+  ARX_REGISTER_ARITH("multiply_checked", ARX_ARITH_MULTIPLY, true, 8);
+#undef ARX_REGISTER_ARITH
   ARROW_RETURN_NOT_OK(RegisterBooleanNP(reg, "and_kleene", 2, KleeneExecNP<ARX_AND_KLEENE>, &g_stock_and_kleene));
   ARROW_RETURN_NOT_OK(RegisterBooleanNP(reg, "or_kleene", 2, KleeneExecNP<ARX_OR_KLEENE>, &g_stock_or_kleene));
   ARROW_RETURN_NOT_OK(RegisterBooleanNP(reg, "invert", 1, InvertExecNP, &g_stock_invert));

@@ -213,6 +213,58 @@ __global__ __launch_bounds__(kBlock) void add_kernel(const T* __restrict__ left,
   }
 }
 
+// ------------------------------------------------------------------ add / subtract / multiply (+ checked)
+// Add / Subtract / Multiply and their *Checked forms (base_arithmetic_internal.h:45-120,290-364):
+// unchecked integer results wrap (the reference computes them in unsigned arithmetic), the checked
+// forms raise Status::Invalid("overflow") — but only for slots where BOTH operands are valid, since
+// the reference's ScalarBinaryNotNull never visits a null slot.  Floats: plain IEEE arithmetic in
+// both forms.  LK / RK: array or broadcast scalar, as for compare.
+template <typename T, int OP, bool CHECKED, int LK, int RK>
+__global__ __launch_bounds__(kBlock) void arith_kernel(const T* __restrict__ left, T lscalar,
+                                                       const T* __restrict__ right, T rscalar, Bits lvalid,
+                                                       Bits rvalid, int64_t n, T* __restrict__ out,
+                                                       unsigned int* __restrict__ overflow) {
+  constexpr int U = 4;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x * U;
+  bool bad = false;
+  for (int64_t base = (static_cast<int64_t>(blockIdx.x) * blockDim.x) * U + threadIdx.x; base < n; base += stride) {
+    T l[U], r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + static_cast<int64_t>(u) * blockDim.x;
+      const int64_t ic = i < n ? i : n - 1;
+      l[u] = LK == kArray ? left[ic] : lscalar;
+      r[u] = RK == kArray ? right[ic] : rscalar;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + static_cast<int64_t>(u) * blockDim.x;
+      if (i >= n) continue;
+      T res;
+      if constexpr (std::is_integral<T>::value) {
+        bool ovf;
+        if constexpr (OP == ARX_ARITH_ADD) ovf = __builtin_add_overflow(l[u], r[u], &res);
+        else if constexpr (OP == ARX_ARITH_SUBTRACT) ovf = __builtin_sub_overflow(l[u], r[u], &res);
+        else ovf = __builtin_mul_overflow(l[u], r[u], &res);  // res = the wrapped result in every case
+        if constexpr (CHECKED) {
+          if (ovf) {
+            const bool both = ((load_word(lvalid, i >> 6) & load_word(rvalid, i >> 6)) >> (i & 63)) & 1ull;
+            bad = bad || both;
+          }
+        }
+      } else {
+        if constexpr (OP == ARX_ARITH_ADD) res = l[u] + r[u];
+        else if constexpr (OP == ARX_ARITH_SUBTRACT) res = l[u] - r[u];
+        else res = l[u] * r[u];
+      }
+      out[i] = res;
+    }
+  }
+  if constexpr (CHECKED) {
+    if (bad) atomicOr(overflow, 1u);
+  }
+}
+
 // ------------------------------------------------------------------ bitmaps
 template <bool AND>
 __global__ __launch_bounds__(kBlock) void bitmap_kernel(Bits a, Bits b, int64_t nwords,
@@ -317,6 +369,43 @@ static int launch_add(const T* left, const T* right, T rscalar, int64_t n, T* ou
   return ARX_OK;
 }
 
+template <typename T, int OP, bool CHECKED>
+static int arith_shapes(const T* left, T ls, const T* right, T rs, const Bits& lv, const Bits& rv, int64_t n,
+                        T* out, unsigned int* overflow, hipStream_t st) {
+  const unsigned grid = stream_grid(kBlock * 4, n);
+#define ARX_ARITH_LAUNCH(LK, RK)                                                                                  \
+  hipLaunchKernelGGL((arith_kernel<T, OP, CHECKED, LK, RK>), dim3(grid), dim3(kBlock), 0, st, left, ls, right, rs, \
+                     lv, rv, n, out, overflow)
+  if (left != nullptr && right != nullptr) ARX_ARITH_LAUNCH(kArray, kArray);
+  else if (left != nullptr) ARX_ARITH_LAUNCH(kArray, kScalar);
+  else if (right != nullptr) ARX_ARITH_LAUNCH(kScalar, kArray);
+  else {
+    set_error("arithmetic: at least one operand must be an array");
+    return ARX_INVALID;
+  }
+#undef ARX_ARITH_LAUNCH
+  ARX_CHECK_LAUNCH("arith_kernel");
+  return ARX_OK;
+}
+
+template <typename T, bool CHECKED>
+static int arith_any(int op, const T* left, T ls, const T* right, T rs, const Bits& lv, const Bits& rv, int64_t n,
+                     T* out, unsigned int* overflow, hipStream_t st) {
+  if (n < 0 || (n > 0 && out == nullptr)) {
+    set_error("bad arguments to arithmetic");
+    return ARX_INVALID;
+  }
+  if (n == 0) return ARX_OK;
+  switch (op) {
+    case ARX_ARITH_ADD: return arith_shapes<T, ARX_ARITH_ADD, CHECKED>(left, ls, right, rs, lv, rv, n, out, overflow, st);
+    case ARX_ARITH_SUBTRACT: return arith_shapes<T, ARX_ARITH_SUBTRACT, CHECKED>(left, ls, right, rs, lv, rv, n, out, overflow, st);
+    case ARX_ARITH_MULTIPLY: return arith_shapes<T, ARX_ARITH_MULTIPLY, CHECKED>(left, ls, right, rs, lv, rv, n, out, overflow, st);
+    default:
+      set_error("unknown arithmetic op %d", op);
+      return ARX_INVALID;
+  }
+}
+
 // op in ARX_CMP_*; less / less_equal = greater / greater_equal with the operands swapped.
 // left / right NULL = that side is the scalar.
 template <typename T, int CMP>
@@ -396,6 +485,32 @@ int arx_compare_f64(int op, const double* left, double left_scalar, const double
 int arx_compare_i64(int op, const int64_t* left, int64_t left_scalar, const int64_t* right, int64_t right_scalar,
                     int64_t length, uint64_t* out_bits, void* stream) {
   return compare_any<int64_t>(op, left, left_scalar, right, right_scalar, length, out_bits, as_stream(stream));
+}
+
+int arx_arith_i64(int op, const int64_t* left, int64_t left_scalar, const int64_t* right, int64_t right_scalar,
+                  int64_t length, int64_t* out, void* stream) {
+  const Bits none = make_bits(nullptr, 0, length);
+  return arith_any<int64_t, false>(op, left, left_scalar, right, right_scalar, none, none, length, out, nullptr,
+                                   as_stream(stream));
+}
+int arx_arith_f64(int op, const double* left, double left_scalar, const double* right, double right_scalar,
+                  int64_t length, double* out, void* stream) {
+  const Bits none = make_bits(nullptr, 0, length);
+  return arith_any<double, false>(op, left, left_scalar, right, right_scalar, none, none, length, out, nullptr,
+                                  as_stream(stream));
+}
+int arx_arith_checked_i64(int op, const int64_t* left, int64_t left_scalar, const void* left_validity,
+                          int64_t left_offset, const int64_t* right, int64_t right_scalar,
+                          const void* right_validity, int64_t right_offset, int64_t length, int64_t* out,
+                          unsigned int* overflow_flag, void* stream) {
+  if (overflow_flag == nullptr) {
+    set_error("arx_arith_checked_i64: overflow_flag is NULL");
+    return ARX_INVALID;
+  }
+  const Bits lv = make_bits(left_validity, left_offset, length);
+  const Bits rv = make_bits(right_validity, right_offset, length);
+  return arith_any<int64_t, true>(op, left, left_scalar, right, right_scalar, lv, rv, length, out, overflow_flag,
+                                  as_stream(stream));
 }
 
 int arx_add_i64(const int64_t* left, const int64_t* right, int64_t length, int64_t* out,

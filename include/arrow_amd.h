@@ -235,6 +235,26 @@ int arx_add_i64(const int64_t* left, const int64_t* right, int64_t length, int64
                 void* stream);
 int arx_add_f64(const double* left, const double* right, int64_t length, double* out,
                 void* stream);
+/* add / subtract / multiply in one entry point (Add, Subtract, Multiply,
+ * base_arithmetic_internal.h:45-120,290-330): left / right are pre-offset arrays or NULL for
+ * "this side is the scalar".  Integer results wrap. */
+#define ARX_ARITH_ADD 0
+#define ARX_ARITH_SUBTRACT 1
+#define ARX_ARITH_MULTIPLY 2
+int arx_arith_i64(int op, const int64_t* left, int64_t left_scalar, const int64_t* right, int64_t right_scalar,
+                  int64_t length, int64_t* out, void* stream);
+int arx_arith_f64(int op, const double* left, double left_scalar, const double* right, double right_scalar,
+                  int64_t length, double* out, void* stream);
+/* add_checked / subtract_checked / multiply_checked(int64) (AddChecked ..., :70-120,341-364): the
+ * wrapped results are written like above and *overflow_flag (device uint32, caller-zeroed) is set
+ * if a slot where BOTH operands are valid overflowed — the reference visits only those slots
+ * (ScalarBinaryNotNull) and then fails with Status::Invalid("overflow"); the caller reads the flag
+ * after the stream has drained.  left/right_validity: bitmaps (bit offsets) or NULL = all valid.
+ * For doubles the checked functions are the plain ones. */
+int arx_arith_checked_i64(int op, const int64_t* left, int64_t left_scalar, const void* left_validity,
+                          int64_t left_offset, const int64_t* right, int64_t right_scalar,
+                          const void* right_validity, int64_t right_offset, int64_t length, int64_t* out,
+                          unsigned int* overflow_flag, void* stream);
 /* array + valid scalar (ScalarBinary::ArrayScalar, codegen_internal.h; add commutes, so
  * scalar + array is the same call) */
 int arx_add_i64_array_scalar(const int64_t* left, int64_t right, int64_t length, int64_t* out,

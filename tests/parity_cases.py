@@ -279,6 +279,57 @@ def check_scalar_operand_ops(amd, rng, n=10_000):
                 assert_equal(bits[valid], refg[valid], "greater scalar vs pyarrow")
 
 
+def check_arithmetic(amd, rng, n=8000, use_pyarrow=True):
+    """subtract / multiply and the *_checked forms, int64 (wrap-around, overflow only counted where
+    both operands are valid) and float64; array x array and both scalar orders."""
+    for dtype in (np.int64, np.float64):
+        kw = {"lo": -10**6, "hi": 10**6} if dtype == np.int64 else {}
+        a = util.random_array(rng, dtype, n, null_p=0.1, offset=3, tail=2, **kw)
+        b = util.random_array(rng, dtype, n, null_p=0.1, offset=1, tail=4, **kw)
+        da, db = a.to_device(amd), b.to_device(amd)
+        la, lb = a.logical_values(), b.logical_values()
+        both = a.logical_valid() & b.logical_valid()
+        sc = dtype(3)
+        for op in ("add", "subtract", "multiply"):
+            for checked in (False, True):
+                fn = getattr(amd.compute, op + ("_checked" if checked else ""))
+                for out, l, r, valid in ((fn(da, db), la, lb, both), (fn(da, sc.item()), la, sc, a.logical_valid()),
+                                         (fn(sc.item(), db), sc, lb, b.logical_valid())):
+                    want, ovf = O.arith(op, l, r, valid)
+                    assert not ovf
+                    got = _data_np(out, dtype)
+                    assert_equal(got.view(np.uint64)[valid], np.asarray(want).view(np.uint64)[valid], f"{op} checked={checked} {dtype.__name__}")
+                    gv, _ = _logical_valid(out)
+                    assert_equal(gv, valid, f"{op} validity")
+                if use_pyarrow and pc is not None:
+                    ref = getattr(pc, op + ("_checked" if checked else ""))(a.to_pyarrow(), b.to_pyarrow())
+                    assert fn(da, db).to_pyarrow().equals(ref), (op, checked)
+    # int64 edges: unchecked wraps; checked raises "overflow" — but not when the overflowing slot is null
+    edge = HostArray(np.array([2**63 - 1, -2**63, 2**62, 5, -7], dtype=np.int64), None, 0, 5)
+    one = HostArray(np.array([1, -1, 2, 3, 4], dtype=np.int64), None, 0, 5)
+    minus = HostArray(-one.values, None, 0, 5)
+    de = edge.to_device(amd)
+    others = {"add": one, "subtract": minus, "multiply": one}     # each overflows in its first slots
+    for op in ("add", "subtract", "multiply"):
+        do = others[op].to_device(amd)
+        want, ovf = O.arith(op, edge.values, others[op].values)
+        assert ovf
+        assert_equal(_data_np(getattr(amd.compute, op)(de, do), np.int64), want, op + " wraps")
+        with pytest.raises(amd.ArrowInvalid, match="overflow"):
+            getattr(amd.compute, op + "_checked")(de, do)
+    masked = HostArray(edge.values.copy(), np.array([False, False, False, True, True]), 0, 5)   # the overflowing slots are null
+    for op in ("add", "subtract", "multiply"):
+        do = others[op].to_device(amd)
+        out = getattr(amd.compute, op + "_checked")(masked.to_device(amd), do)
+        want, ovf = O.arith(op, masked.values, others[op].values, masked.valid)
+        assert not ovf
+        assert_equal(_data_np(out, np.int64)[masked.valid], want[masked.valid], op + "_checked with null overflow slots")
+    if pc is not None:
+        with pytest.raises(pa.lib.ArrowInvalid, match="overflow"):
+            pc.add_checked(edge.to_pyarrow(), one.to_pyarrow())
+        assert pc.add_checked(masked.to_pyarrow(), one.to_pyarrow()).to_pylist()[3:] == [8, -3]
+
+
 def check_compare_family(amd, rng, n=10_000, use_pyarrow=True):
     """equal ... less_equal on int64 and float64 (NaN, +-0, infinities), array x array and both
     scalar orders, sliced operands: bits equal the oracle on every slot, nulls propagate."""

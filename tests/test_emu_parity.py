@@ -585,3 +585,8 @@ def test_kleene_and_or_invert(emu_ctx, lnull, rnull, loff, roff):
 def test_compare_family(emu_ctx):
     """Equal ... LessEqual (scalar_compare.cc:38-64): int64 and float64 incl. NaN / signed zeros / infinities."""
     P.check_compare_family(emu_ctx, rng_for("cmpfamily"), n=3000)
+
+
+def test_subtract_multiply_and_checked_arithmetic(emu_ctx):
+    """Subtract / Multiply / *Checked (base_arithmetic_internal.h): wrap-around vs "overflow" on valid slots only."""
+    P.check_arithmetic(emu_ctx, rng_for("arith"), n=3000)

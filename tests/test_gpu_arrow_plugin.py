@@ -178,6 +178,23 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
     # compare -> filter -> add chain, all in HBM
     chain2 = to_host(pc.add(pc.filter(d_vals, pc.greater(d_vals, d_i64b)), 1))
     assert chain2.equals(pc.add(pc.filter(vals, pc.greater(vals, i64b)), 1))
+    # subtract / multiply / *_checked on device arrays (what `-`, `*`, `+` on expressions mean); overflow is an error
+    smalls = pa.array(rng.integers(-10**6, 10**6, n), mask=rng.random(n) < 0.05)
+    smalls2 = pa.array(rng.integers(-10**6, 10**6, n), mask=rng.random(n) < 0.05)
+    d_sm, d_sm2 = to_device(smalls), to_device(smalls2)
+    for ar in (pc.subtract, pc.multiply, pc.add_checked, pc.subtract_checked, pc.multiply_checked):
+        for dev_out, host_out in ((ar(d_sm, d_sm2), ar(smalls, smalls2)), (ar(d_sm, 3), ar(smalls, 3)), (ar(-7, d_sm2), ar(-7, smalls2)),
+                                  (ar(d_f64, d_f64b), ar(f64, f64b)), (ar(d_sm.slice(5, n - 9), d_sm2.slice(9, n - 9)), ar(smalls.slice(5, n - 9), smalls2.slice(9, n - 9)))):
+            assert not dev_out.is_cpu
+            ho = to_host(dev_out)
+            assert ho.equals(host_out) and ho.null_count == host_out.null_count, ar
+    assert to_host(pc.subtract(d_vals, d_i64b)).equals(pc.subtract(vals, i64b))          # wrap-around
+    for bad in (lambda: pc.add_checked(d_vals, d_i64b), lambda: pc.multiply_checked(d_vals, 4)):
+        try:
+            bad()
+            raise SystemExit("expected overflow")
+        except pa.lib.ArrowInvalid as e:
+            assert str(e) == "overflow", str(e)
     # the whole comparison family on device arrays (NaN-aware for doubles), scalars on either side
     f64n = pa.array(np.where(rng.random(n) < 0.01, np.nan, np.round(rng.standard_normal(n) * 4) / 4), mask=rng.random(n) < 0.05)
     d_f64n = to_device(f64n)
@@ -422,7 +439,7 @@ ACERO_DEVICE_SCRIPT = textwrap.dedent(r'''
     for null_p in (0.0, 0.03):
         mk = (lambda a: pa.array(a, mask=rng.random(n) < null_p)) if null_p else pa.array
         k = mk(rng.integers(-5000, 5000, n).astype(np.int32))
-        v = mk(rng.integers(-2**63, 2**63 - 1, n))
+        v = mk(rng.integers(-2**62, 2**62, n))          # (checked arithmetic in the projection: keep away from the edges)
         w = mk(rng.integers(-100, 100, n))
         host = pa.table({"k": k, "v": v, "w": w})
         dev = pa.table({"k": to_device(k), "v": to_device(v), "w": to_device(w)})
@@ -430,8 +447,8 @@ ACERO_DEVICE_SCRIPT = textwrap.dedent(r'''
         def plan(table, agg):
             return acero.Declaration.from_sequence([
                 acero.Declaration("table_source", acero.TableSourceNodeOptions(table)),
-                acero.Declaration("filter", acero.FilterNodeOptions((pc.field("w") > 10) & ~(pc.field("v") > 2**62))),
-                acero.Declaration("project", acero.ProjectNodeOptions([pc.field("k"), pc.add(pc.field("v"), pc.field("w"))], ["k", "v"])),   # (`+` on expressions is add_checked)
+                acero.Declaration("filter", acero.FilterNodeOptions((pc.field("w") > 10) & ~(pc.field("v") > 2**61))),
+                acero.Declaration("project", acero.ProjectNodeOptions([pc.field("k"), pc.field("v") - pc.field("w") * 2], ["k", "v"])),   # (`-`, `*` on expressions: subtract_checked, multiply_checked)
                 acero.Declaration(agg, acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"])),
             ])
 

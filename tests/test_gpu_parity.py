@@ -753,3 +753,8 @@ def test_kleene_and_or_invert(gpu_ctx, lnull, rnull, loff, roff):
 def test_compare_family(gpu_ctx):
     """Equal ... LessEqual (scalar_compare.cc:38-64): int64 and float64 incl. NaN / signed zeros / infinities."""
     P.check_compare_family(gpu_ctx, rng_for("cmpfamily"), n=300007)
+
+
+def test_subtract_multiply_and_checked_arithmetic(gpu_ctx):
+    """Subtract / Multiply / *Checked (base_arithmetic_internal.h): wrap-around vs "overflow" on valid slots only."""
+    P.check_arithmetic(gpu_ctx, rng_for("arith"), n=300007)

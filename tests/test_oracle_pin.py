@@ -496,3 +496,25 @@ def test_compare_family_vs_pyarrow(op):
         pl = pa.array(l) if isinstance(l, np.ndarray) else pa.scalar(l)
         pr = pa.array(r) if isinstance(r, np.ndarray) else pa.scalar(r)
         assert O.compare(op, l, r).tolist() == getattr(pc, op)(pl, pr).to_pylist(), (op, l, r)
+
+
+# ------------------------------------------------------------------ add / subtract / multiply (+ checked) (oracle.arith)
+@pytest.mark.skipif(pc is None, reason="pyarrow wheel not in this image")
+@pytest.mark.parametrize("op", ["add", "subtract", "multiply"])
+def test_arith_vs_pyarrow(op):
+    i = np.array([2**63 - 1, -2**63, 2**62, 5, -7, 0], dtype=np.int64)
+    j = np.array([1, -1, 2, 3, 4, 9], dtype=np.int64)
+    if op == "subtract":
+        j = -j
+    want, ovf = O.arith(op, i, j)
+    assert ovf and getattr(pc, op)(pa.array(i), pa.array(j)).to_pylist() == want.tolist()      # unchecked wraps
+    with pytest.raises(pa.lib.ArrowInvalid, match="overflow"):
+        getattr(pc, op + "_checked")(pa.array(i), pa.array(j))
+    valid = np.array([False, False, False, True, True, True])       # the overflowing slots are null: no error
+    want, ovf = O.arith(op, i, j, valid)
+    ref = getattr(pc, op + "_checked")(pa.array(i, mask=~valid), pa.array(j))
+    assert not ovf and ref.to_pylist()[3:] == want[3:].tolist()
+    f, g = np.array([1.5, np.inf, -0.0, 1e308]), np.array([2.25, -np.inf, 0.0, 1e308])
+    want, _ = O.arith(op, f, g)
+    got = getattr(pc, op + "_checked")(pa.array(f), pa.array(g)).to_numpy()
+    assert np.array_equal(want, got, equal_nan=True)
