@@ -51,9 +51,10 @@ class TakeOptions(FunctionOptions):
 
 
 class CastOptions(FunctionOptions):
-    def __init__(self, to_type: DataType, allow_float_truncate: bool = False):
+    def __init__(self, to_type: DataType, allow_float_truncate: bool = False, allow_int_overflow: bool = False):
         self.to_type = to_type
         self.allow_float_truncate = allow_float_truncate
+        self.allow_int_overflow = allow_int_overflow        # CastOptions::Unsafe sets it (cast.h:60-75)
 
 
 class ArraySortOptions(FunctionOptions):
@@ -299,6 +300,32 @@ def _exec_cast_f64_f32(args, options):
         check(lib.arx_cast_f64_f32(arr.values_ptr(), arr.length, out.data_ptr(), stream))
     validity, nc = _propagate_validity([arr], arr.length, dev)
     return Array(float32, arr.length, [validity, out], nc, 0)
+
+
+def _exec_cast_i64_i32(args, options):
+    """CastIntegerToInteger (scalar_cast_numeric.cc:46-54): IntegersCanFit unless allow_int_overflow."""
+    (arr,) = args
+    dev = arr.device
+    lib, stream = _lib_and_stream(dev)
+    n = arr.length
+    out = alloc(n * 4, dev)
+    ws = _workspace(dev, 64, "cast")
+    sp = arr.span()
+    check(lib.arx_cast_i64_i32(C.byref(sp), int(bool(getattr(options, "allow_int_overflow", False))), ws.data_ptr(),
+                               ws.numel(), out.data_ptr(), stream))
+    validity, nc = _propagate_validity([arr], n, dev)
+    return Array(int32, n, [validity, out], nc, 0)
+
+
+def _exec_cast_i32_i64(args, options):
+    (arr,) = args
+    dev = arr.device
+    lib, stream = _lib_and_stream(dev)
+    n = arr.length
+    out = alloc(n * 8, dev)
+    check(lib.arx_cast_i32_i64(arr.values_ptr(), n, out.data_ptr(), stream))
+    validity, nc = _propagate_validity([arr], n, dev)
+    return Array(int64, n, [validity, out], nc, 0)
 
 
 def _scalar_value(x):
@@ -792,6 +819,12 @@ def _build_registry() -> FunctionRegistry:
     c = Function("cast_float", Function.SCALAR, 1)
     c.add_kernel(Kernel((float64,), _exec_cast_f64_f32, float32))
     _cast_table["float"] = c
+    c = Function("cast_int32", Function.SCALAR, 1)
+    c.add_kernel(Kernel((int64,), _exec_cast_i64_i32, int32))
+    _cast_table["int32"] = c
+    c = Function("cast_int64", Function.SCALAR, 1)
+    c.add_kernel(Kernel((int32,), _exec_cast_i32_i64, int64))
+    _cast_table["int64"] = c
     reg.add_function(Function("cast", Function.META, 1, None, _cast_meta))
 
     f = Function("greater", Function.SCALAR, 2)
@@ -866,9 +899,9 @@ def take(values, indices, boundscheck: bool = True):
     return call_function("take", [values, indices], TakeOptions(boundscheck))
 
 
-def cast(arr, to_type: DataType):
-    """compute::Cast (cast.cc:239-248)."""
-    return call_function("cast", [arr], CastOptions(to_type))
+def cast(arr, to_type: DataType, safe: bool = True):
+    """compute::Cast (cast.cc:239-248); safe=False = CastOptions::Unsafe."""
+    return call_function("cast", [arr], CastOptions(to_type, allow_float_truncate=not safe, allow_int_overflow=not safe))
 
 
 def _wrap_scalar(x, like: Array):

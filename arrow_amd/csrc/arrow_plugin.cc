@@ -1555,11 +1555,59 @@ class RocmCastMetaFunction : public cp::MetaFunction {
       if (OnRocm(in)) return CastF64F32Device(*args[0].array());
       if (args[0].length() >= g_min_rows_streaming.load() && IsHost(in)) return CastF64F32(*args[0].array(), ctx);
     }
+    // integer casts on device-resident arrays: int64 -> int32 (IntegersCanFit unless allow_int_overflow)
+    // and int32 -> int64; host arrays stay on the stock kernels
+    if (cast_options != nullptr && cast_options->to_type.type != nullptr && args.size() == 1 && args[0].is_array()) {
+      const Type::type from = args[0].array()->type->id();
+      const Type::type to = cast_options->to_type.id();
+      if (((from == Type::INT64 && to == Type::INT32) || (from == Type::INT32 && to == Type::INT64)) &&
+          OnRocm(ArraySpan(*args[0].array()))) {
+        return CastIntegerDevice(*args[0].array(), to, cast_options->allow_int_overflow);
+      }
+    }
     CountStock(kFnCast);
     return stock_->Execute(args, options, ctx);
   }
 
  private:
+  static arrow::Result<arrow::Datum> CastIntegerDevice(const ArrayData& in, Type::type to, bool allow_int_overflow) {
+    const int64_t n = in.length;
+    hipStream_t st;
+    ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+    const int out_width = to == Type::INT32 ? 4 : 8;
+    ARROW_ASSIGN_OR_RAISE(auto out_values, AllocDevice(n * out_width));
+    ArxSpan sp{};
+    ARROW_RETURN_NOT_OK(DeviceSpan(ArraySpan(in), &sp));
+    if (to == Type::INT32) {
+      void* ws = nullptr;
+      ARROW_RETURN_NOT_OK(t_scratch.Get(kFlag, 64, &ws));
+      ARROW_RETURN_NOT_OK(FromArx(arx_cast_i64_i32(&sp, allow_int_overflow ? 1 : 0, ws, 64,
+                                                   reinterpret_cast<int32_t*>(out_values->mutable_address()), st)));
+    } else {
+      ARROW_RETURN_NOT_OK(FromArx(arx_cast_i32_i64(static_cast<const int32_t*>(sp.data) + sp.offset, n,
+                                                   reinterpret_cast<int64_t*>(out_values->mutable_address()), st)));
+    }
+    std::shared_ptr<Buffer> validity;
+    int64_t null_count = 0;
+    if (sp.validity != nullptr && n > 0) {
+      if (in.offset == 0) {
+        validity = in.buffers[0];
+      } else {
+        ARROW_ASSIGN_OR_RAISE(validity, AllocDevice(((n + 63) / 64) * 8));
+        ARROW_RETURN_NOT_OK(FromArx(arx_bitmap_copy(sp.validity, sp.offset, n,
+                                                    reinterpret_cast<void*>(validity->mutable_address()), st)));
+      }
+      null_count = in.null_count.load();
+      if (null_count < 0 || in.offset != 0) {
+        ARROW_ASSIGN_OR_RAISE(null_count, DeviceNullCount(*validity, n, st));
+      }
+    }
+    HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
+    CountGpu(kFnCast);
+    auto type = to == Type::INT32 ? arrow::int32() : arrow::int64();
+    return arrow::Datum(ArrayData::Make(std::move(type), n, {std::move(validity), std::move(out_values)}, null_count));
+  }
+
   // device-resident input: output values (and a re-based validity bitmap if offset != 0) in HBM
   static arrow::Result<arrow::Datum> CastF64F32Device(const ArrayData& in) {
     const int64_t n = in.length;

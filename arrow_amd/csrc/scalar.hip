@@ -70,6 +70,46 @@ __global__ __launch_bounds__(kBlock) void cast_f64_f32_kernel(const double* __re
   }
 }
 
+// ------------------------------------------------------------------ integer casts
+// CastIntegerToInteger (kernels/scalar_cast_numeric.cc:46-54): unless allow_int_overflow, IntegersCanFit
+// -> IntegersInRange (util/int_util.cc:594-665) rejects the first VALID slot (in row order) whose value
+// does not fit the target; then every slot is converted with static_cast (nulls included).
+// One pass: the cast is written regardless, the smallest offending row number goes to *first_bad.
+__global__ __launch_bounds__(kBlock) void cast_i64_i32_kernel(const int64_t* __restrict__ in, Bits valid, int64_t n,
+                                                              int32_t* __restrict__ out, int check,
+                                                              unsigned long long* __restrict__ first_bad) {
+  constexpr int U = 4;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x * U;
+  unsigned long long bad = ~0ull;
+  for (int64_t base = (static_cast<int64_t>(blockIdx.x) * blockDim.x) * U + threadIdx.x; base < n; base += stride) {
+    int64_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + static_cast<int64_t>(u) * blockDim.x;
+      v[u] = in[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + static_cast<int64_t>(u) * blockDim.x;
+      if (i >= n) continue;
+      out[i] = static_cast<int32_t>(v[u]);
+      if (check && (v[u] < INT32_MIN || v[u] > INT32_MAX)) {
+        const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1ull;
+        if (ok && static_cast<unsigned long long>(i) < bad) bad = static_cast<unsigned long long>(i);
+      }
+    }
+  }
+  if (check && bad != ~0ull) atomicMin(first_bad, bad);
+}
+
+__global__ __launch_bounds__(kBlock) void cast_i32_i64_kernel(const int32_t* __restrict__ in, int64_t n,
+                                                              int64_t* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    out[i] = static_cast<int64_t>(in[i]);
+  }
+}
+
 // ------------------------------------------------------------------ compare (greater)
 // Each wave step covers 128 rows: lane l holds rows 2l, 2l+1 (one 16-byte load per operand).
 // The two ballots (even rows / odd rows) are interleaved with scalar bit-spreads into two
@@ -454,6 +494,53 @@ int arx_cast_f64_f32(const double* in, int64_t length, float* out, void* stream)
     hipLaunchKernelGGL((cast_f64_f32_kernel<false>), dim3(grid), dim3(kBlock), 0, st, in, length, out);
   }
   ARX_CHECK_LAUNCH("cast_f64_f32_kernel");
+  return ARX_OK;
+}
+
+int arx_cast_i64_i32(const ArxSpan* values, int allow_int_overflow, void* ws, size_t ws_bytes, int32_t* out,
+                     void* stream) {
+  if (values == nullptr || values->length < 0) {
+    set_error("bad arguments to arx_cast_i64_i32");
+    return ARX_INVALID;
+  }
+  const int64_t n = values->length;
+  if (n == 0) return ARX_OK;
+  if (values->data == nullptr || out == nullptr || (!allow_int_overflow && (ws == nullptr || ws_bytes < 8))) {
+    set_error("NULL buffer / workspace passed to arx_cast_i64_i32");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  const int64_t* in = static_cast<const int64_t*>(values->data) + values->offset;
+  const Bits valid = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
+  unsigned long long* first_bad = static_cast<unsigned long long*>(ws);
+  if (!allow_int_overflow) ARX_HIP(hipMemsetAsync(first_bad, 0xFF, 8, st));
+  hipLaunchKernelGGL(cast_i64_i32_kernel, dim3(stream_grid(kBlock * 4, n)), dim3(kBlock), 0, st, in, valid, n, out,
+                     allow_int_overflow ? 0 : 1, first_bad);
+  ARX_CHECK_LAUNCH("cast_i64_i32_kernel");
+  if (allow_int_overflow) return ARX_OK;
+  unsigned long long bad = ~0ull;
+  ARX_HIP(hipMemcpyAsync(&bad, first_bad, 8, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  if (bad != ~0ull) {
+    long long v = 0;
+    ARX_HIP(hipMemcpyAsync(&v, in + bad, 8, hipMemcpyDeviceToHost, st));
+    ARX_HIP(hipStreamSynchronize(st));
+    // the text of IntegersInRange's GetErrorMessage, util/int_util.cc:607-611
+    set_error("Integer value %lld not in range: -2147483648 to 2147483647", v);
+    return ARX_INVALID;
+  }
+  return ARX_OK;
+}
+
+int arx_cast_i32_i64(const int32_t* values, int64_t length, int64_t* out, void* stream) {
+  if (length < 0 || (length > 0 && (values == nullptr || out == nullptr))) {
+    set_error("bad arguments to arx_cast_i32_i64");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  hipLaunchKernelGGL(cast_i32_i64_kernel, dim3(stream_grid(kBlock, length)), dim3(kBlock), 0, as_stream(stream), values,
+                     length, out);
+  ARX_CHECK_LAUNCH("cast_i32_i64_kernel");
   return ARX_OK;
 }
 

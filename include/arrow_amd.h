@@ -191,6 +191,15 @@ int arx_binary_take_data(const ArxBinarySpan* values, int64_t num_indices, const
  * ------------------------------------------------------------------------- */
 int arx_cast_f64_f32(const double* in, int64_t length, float* out, void* stream);
 
+/* Integer casts — CastIntegerToInteger (cpp/src/arrow/compute/kernels/scalar_cast_numeric.cc:46-54).
+ * int64 -> int32: unless allow_int_overflow, the first valid slot (row order) whose value does not fit
+ * fails with the reference's text "Integer value V not in range: -2147483648 to 2147483647"
+ * (IntegersInRange, util/int_util.cc:594-665; ARX_INVALID, synchronous; ws: >= 8 device bytes);
+ * every slot is converted with static_cast either way.  int32 -> int64 widens (asynchronous). */
+int arx_cast_i64_i32(const ArxSpan* values, int allow_int_overflow, void* ws, size_t ws_bytes, int32_t* out,
+                     void* stream);
+int arx_cast_i32_i64(const int32_t* values, int64_t length, int64_t* out, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Compare — replaces ComparePrimitiveArrayArray/ArrayScalar/ScalarArray<DoubleType,
  * Greater> (cpp/src/arrow/compute/kernels/scalar_compare.cc:165-247): bit i =

@@ -180,6 +180,22 @@ def binary_filter(offsets, data, values_valid, values_off, mask, mask_valid, mas
     return binary_take(offsets, data, values_valid, values_off, idx32, idx_bm, 0, len(idx32))
 
 
+def cast_i64_i32(values, valid=None, allow_int_overflow=False):
+    """CastIntegerToInteger int64 -> int32 (scalar_cast_numeric.cc:46-54): unless allow_int_overflow,
+    IntegersInRange (util/int_util.cc:594-665) fails on the first valid slot, in row order, whose value
+    is outside [INT32_MIN, INT32_MAX] with "Integer value V not in range: L to U"; then every slot is
+    static_cast (two's-complement truncation).  Returns (int32 array, error text or None)."""
+    v = np.asarray(values, dtype=np.int64)
+    ok = np.ones(len(v), bool) if valid is None else np.asarray(valid, bool)
+    err = None
+    if not allow_int_overflow:
+        for i in range(len(v)):
+            if ok[i] and not (-2**31 <= int(v[i]) <= 2**31 - 1):
+                err = f"Integer value {int(v[i])} not in range: -2147483648 to 2147483647"
+                break
+    return v.astype(np.int32), err
+
+
 def cast_f64_f32(a: np.ndarray) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.float64)
     out = np.empty(len(a), dtype=np.float32)

@@ -279,6 +279,47 @@ def check_scalar_operand_ops(amd, rng, n=10_000):
                 assert_equal(bits[valid], refg[valid], "greater scalar vs pyarrow")
 
 
+def check_integer_casts(amd, rng, n=9000, use_pyarrow=True):
+    """int64 -> int32 (checked / unsafe) and int32 -> int64."""
+    A = amd.array
+    a = util.random_array(rng, np.int64, n, null_p=0.1, offset=3, tail=2, lo=-2**31, hi=2**31 - 1)
+    a.values[a.offset: a.offset + 2] = [2**31 - 1, -2**31]
+    d = a.to_device(amd)
+    want, err = O.cast_i64_i32(a.logical_values(), a.logical_valid())
+    assert err is None
+    for safe in (True, False):
+        out = amd.compute.cast(d, A.int32, safe=safe)
+        assert_equal(_data_np(out, np.int32), want, f"cast i64->i32 safe={safe}")
+        gv, _ = _logical_valid(out)
+        assert_equal(gv, a.logical_valid(), "cast validity")
+    back = amd.compute.cast(amd.compute.cast(d, A.int32), A.int64)
+    assert_equal(_data_np(back, np.int64)[a.logical_valid()], a.logical_values()[a.logical_valid()], "i32->i64 round trip")
+    # out-of-range values: an error naming the FIRST offending valid slot; a null slot does not count
+    bad = HostArray(a.values.copy(), None if a.valid is None else a.valid.copy(), a.offset, a.length)
+    lv = bad.logical_valid()
+    first_valid = int(np.nonzero(lv)[0][10])
+    later = int(np.nonzero(lv)[0][500])
+    nulls = np.nonzero(~lv)[0]
+    bad.values[bad.offset + later] = -2**40
+    bad.values[bad.offset + first_valid] = 2**31
+    if len(nulls):
+        bad.values[bad.offset + int(nulls[0])] = 2**50          # before both, but null
+    want_bad, err = O.cast_i64_i32(bad.logical_values(), bad.logical_valid())
+    assert err == "Integer value 2147483648 not in range: -2147483648 to 2147483647"
+    db = bad.to_device(amd)
+    with pytest.raises(amd.ArrowInvalid) as ei:
+        amd.compute.cast(db, A.int32)
+    assert str(ei.value) == err, str(ei.value)
+    unsafe = amd.compute.cast(db, A.int32, safe=False)
+    assert_equal(_data_np(unsafe, np.int32), want_bad, "unsafe cast truncates")
+    if use_pyarrow and pc is not None:
+        with pytest.raises(pa.lib.ArrowInvalid) as ri:
+            pc.cast(bad.to_pyarrow(), pa.int32())
+        assert str(ri.value) == err
+        assert pc.cast(bad.to_pyarrow(), pa.int32(), safe=False).equals(unsafe.to_pyarrow())
+        assert pc.cast(a.to_pyarrow(), pa.int32()).equals(amd.compute.cast(d, A.int32).to_pyarrow())
+
+
 def check_arithmetic(amd, rng, n=8000, use_pyarrow=True):
     """subtract / multiply and the *_checked forms, int64 (wrap-around, overflow only counted where
     both operands are valid) and float64; array x array and both scalar orders."""

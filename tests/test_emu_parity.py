@@ -590,3 +590,8 @@ def test_compare_family(emu_ctx):
 def test_subtract_multiply_and_checked_arithmetic(emu_ctx):
     """Subtract / Multiply / *Checked (base_arithmetic_internal.h): wrap-around vs "overflow" on valid slots only."""
     P.check_arithmetic(emu_ctx, rng_for("arith"), n=3000)
+
+
+def test_integer_casts(emu_ctx):
+    """CastIntegerToInteger (scalar_cast_numeric.cc:46-54) + IntegersInRange's first-offender message."""
+    P.check_integer_casts(emu_ctx, rng_for("intcast"), n=4000)

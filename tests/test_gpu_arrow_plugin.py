@@ -195,6 +195,21 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
             raise SystemExit("expected overflow")
         except pa.lib.ArrowInvalid as e:
             assert str(e) == "overflow", str(e)
+    # integer casts on device arrays: int64 -> int32 checked (first offending valid slot named) / unsafe, int32 -> int64
+    casts_before = lib.arrow_amd_plugin_calls(b"cast", 1)
+    i32ok = to_host(pc.cast(d_sm, pa.int32()))
+    assert i32ok.equals(pc.cast(smalls, pa.int32()))
+    assert to_host(pc.cast(pc.cast(d_sm.slice(7), pa.int32()), pa.int64())).equals(smalls.slice(7))
+    try:
+        pc.cast(d_vals, pa.int32())
+        raise SystemExit("expected ArrowInvalid")
+    except pa.lib.ArrowInvalid as e:
+        try:
+            pc.cast(vals, pa.int32())
+        except pa.lib.ArrowInvalid as he:
+            assert str(e) == str(he), (str(e), str(he))
+    assert to_host(pc.cast(d_vals, pa.int32(), safe=False)).equals(pc.cast(vals, pa.int32(), safe=False))
+    assert lib.arrow_amd_plugin_calls(b"cast", 1) == casts_before + 5
     # the whole comparison family on device arrays (NaN-aware for doubles), scalars on either side
     f64n = pa.array(np.where(rng.random(n) < 0.01, np.nan, np.round(rng.standard_normal(n) * 4) / 4), mask=rng.random(n) < 0.05)
     d_f64n = to_device(f64n)

@@ -758,3 +758,8 @@ def test_compare_family(gpu_ctx):
 def test_subtract_multiply_and_checked_arithmetic(gpu_ctx):
     """Subtract / Multiply / *Checked (base_arithmetic_internal.h): wrap-around vs "overflow" on valid slots only."""
     P.check_arithmetic(gpu_ctx, rng_for("arith"), n=300007)
+
+
+def test_integer_casts(gpu_ctx):
+    """CastIntegerToInteger (scalar_cast_numeric.cc:46-54) + IntegersInRange's first-offender message."""
+    P.check_integer_casts(gpu_ctx, rng_for("intcast"), n=400003)
