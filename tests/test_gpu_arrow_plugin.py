@@ -197,6 +197,7 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
             assert str(e) == "overflow", str(e)
     # integer casts on device arrays: int64 -> int32 checked (first offending valid slot named) / unsafe, int32 -> int64
     casts_before = lib.arrow_amd_plugin_calls(b"cast", 1)
+    host_reference_casts = 3          # pc.cast on HOST arrays below goes to Arrow's stock kernel
     i32ok = to_host(pc.cast(d_sm, pa.int32()))
     assert i32ok.equals(pc.cast(smalls, pa.int32()))
     assert to_host(pc.cast(pc.cast(d_sm.slice(7), pa.int32()), pa.int64())).equals(smalls.slice(7))
@@ -251,8 +252,9 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
     # a chain that never leaves the device: filter -> cast
     chain = to_host(pc.cast(pc.filter(d_f64, d_mask), pa.float32()))
     assert chain.equals(want_chain)
+    # no device call above was handed to a stock kernel (host reference casts are: count them out)
     stock_now = {f: lib.arrow_amd_plugin_calls(f, 0) for f in (b"array_filter", b"array_take", b"cast")}
-    assert sum(stock_now.values()) == stock_before, (stock_now, stock_before)
+    assert sum(stock_now.values()) == stock_before + host_reference_casts, (stock_now, stock_before)
     assert lib.arrow_amd_plugin_calls(b"array_filter", 1) >= 4 and lib.arrow_amd_plugin_calls(b"array_take", 1) >= 1
     # drop_null = Filter(values, <validity bitmap as a boolean array>) (vector_selection.cc:79-91): the
     # filter's data buffer IS the device validity buffer, so this is the device filter again
