@@ -110,6 +110,7 @@ SIGNATURES = {
     "arx_cast_f64_f32": (_int, [_p, _i64, _p, _p]),
     "arx_cast_i64_i32": (_int, [_span, _int, _p, _sz, _p, _p]),
     "arx_cast_i32_i64": (_int, [_p, _i64, _p, _p]),
+    "arx_cast_i64_f64": (_int, [_span, _int, _p, _sz, _p, _p]),
     "arx_greater_f64": (_int, [_p, _p, _i64, _p, _p]),
     "arx_greater_f64_array_scalar": (_int, [_p, C.c_double, _i64, _p, _p]),
     "arx_greater_f64_scalar_array": (_int, [C.c_double, _p, _i64, _p, _p]),

@@ -317,6 +317,21 @@ def _exec_cast_i64_i32(args, options):
     return Array(int32, n, [validity, out], nc, 0)
 
 
+def _exec_cast_i64_f64(args, options):
+    """CastIntegerToFloating (scalar_cast_numeric.cc:270-279): exactness check unless allow_float_truncate."""
+    (arr,) = args
+    dev = arr.device
+    lib, stream = _lib_and_stream(dev)
+    n = arr.length
+    out = alloc(n * 8, dev)
+    ws = _workspace(dev, 64, "cast")
+    sp = arr.span()
+    check(lib.arx_cast_i64_f64(C.byref(sp), int(bool(getattr(options, "allow_float_truncate", False))), ws.data_ptr(),
+                               ws.numel(), out.data_ptr(), stream))
+    validity, nc = _propagate_validity([arr], n, dev)
+    return Array(float64, n, [validity, out], nc, 0)
+
+
 def _exec_cast_i32_i64(args, options):
     (arr,) = args
     dev = arr.device
@@ -825,6 +840,9 @@ def _build_registry() -> FunctionRegistry:
     c = Function("cast_int64", Function.SCALAR, 1)
     c.add_kernel(Kernel((int32,), _exec_cast_i32_i64, int64))
     _cast_table["int64"] = c
+    c = Function("cast_double", Function.SCALAR, 1)
+    c.add_kernel(Kernel((int64,), _exec_cast_i64_f64, float64))
+    _cast_table["double"] = c
     reg.add_function(Function("cast", Function.META, 1, None, _cast_meta))
 
     f = Function("greater", Function.SCALAR, 2)

@@ -1560,9 +1560,10 @@ class RocmCastMetaFunction : public cp::MetaFunction {
     if (cast_options != nullptr && cast_options->to_type.type != nullptr && args.size() == 1 && args[0].is_array()) {
       const Type::type from = args[0].array()->type->id();
       const Type::type to = cast_options->to_type.id();
-      if (((from == Type::INT64 && to == Type::INT32) || (from == Type::INT32 && to == Type::INT64)) &&
+      if (((from == Type::INT64 && (to == Type::INT32 || to == Type::DOUBLE)) || (from == Type::INT32 && to == Type::INT64)) &&
           OnRocm(ArraySpan(*args[0].array()))) {
-        return CastIntegerDevice(*args[0].array(), to, cast_options->allow_int_overflow);
+        return CastIntegerDevice(*args[0].array(), to,
+                                 to == Type::DOUBLE ? cast_options->allow_float_truncate : cast_options->allow_int_overflow);
       }
     }
     CountStock(kFnCast);
@@ -1570,7 +1571,7 @@ class RocmCastMetaFunction : public cp::MetaFunction {
   }
 
  private:
-  static arrow::Result<arrow::Datum> CastIntegerDevice(const ArrayData& in, Type::type to, bool allow_int_overflow) {
+  static arrow::Result<arrow::Datum> CastIntegerDevice(const ArrayData& in, Type::type to, bool unchecked) {
     const int64_t n = in.length;
     hipStream_t st;
     ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
@@ -1581,8 +1582,13 @@ class RocmCastMetaFunction : public cp::MetaFunction {
     if (to == Type::INT32) {
       void* ws = nullptr;
       ARROW_RETURN_NOT_OK(t_scratch.Get(kFlag, 64, &ws));
-      ARROW_RETURN_NOT_OK(FromArx(arx_cast_i64_i32(&sp, allow_int_overflow ? 1 : 0, ws, 64,
+      ARROW_RETURN_NOT_OK(FromArx(arx_cast_i64_i32(&sp, unchecked ? 1 : 0, ws, 64,
                                                    reinterpret_cast<int32_t*>(out_values->mutable_address()), st)));
+    } else if (to == Type::DOUBLE) {
+      void* ws = nullptr;
+      ARROW_RETURN_NOT_OK(t_scratch.Get(kFlag, 64, &ws));
+      ARROW_RETURN_NOT_OK(FromArx(arx_cast_i64_f64(&sp, unchecked ? 1 : 0, ws, 64,
+                                                   reinterpret_cast<double*>(out_values->mutable_address()), st)));
     } else {
       ARROW_RETURN_NOT_OK(FromArx(arx_cast_i32_i64(static_cast<const int32_t*>(sp.data) + sp.offset, n,
                                                    reinterpret_cast<int64_t*>(out_values->mutable_address()), st)));
@@ -1604,7 +1610,7 @@ class RocmCastMetaFunction : public cp::MetaFunction {
     }
     HIP_RETURN_NOT_OK(hipStreamSynchronize(st));
     CountGpu(kFnCast);
-    auto type = to == Type::INT32 ? arrow::int32() : arrow::int64();
+    auto type = to == Type::INT32 ? arrow::int32() : (to == Type::DOUBLE ? arrow::float64() : arrow::int64());
     return arrow::Datum(ArrayData::Make(std::move(type), n, {std::move(validity), std::move(out_values)}, null_count));
   }
 

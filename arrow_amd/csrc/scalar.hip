@@ -75,9 +75,10 @@ __global__ __launch_bounds__(kBlock) void cast_f64_f32_kernel(const double* __re
 // -> IntegersInRange (util/int_util.cc:594-665) rejects the first VALID slot (in row order) whose value
 // does not fit the target; then every slot is converted with static_cast (nulls included).
 // One pass: the cast is written regardless, the smallest offending row number goes to *first_bad.
-__global__ __launch_bounds__(kBlock) void cast_i64_i32_kernel(const int64_t* __restrict__ in, Bits valid, int64_t n,
-                                                              int32_t* __restrict__ out, int check,
-                                                              unsigned long long* __restrict__ first_bad) {
+template <typename OutT>
+__global__ __launch_bounds__(kBlock) void cast_i64_kernel(const int64_t* __restrict__ in, Bits valid, int64_t n,
+                                                          OutT* __restrict__ out, int check, int64_t lo, int64_t hi,
+                                                          unsigned long long* __restrict__ first_bad) {
   constexpr int U = 4;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x * U;
   unsigned long long bad = ~0ull;
@@ -92,8 +93,8 @@ __global__ __launch_bounds__(kBlock) void cast_i64_i32_kernel(const int64_t* __r
     for (int u = 0; u < U; ++u) {
       const int64_t i = base + static_cast<int64_t>(u) * blockDim.x;
       if (i >= n) continue;
-      out[i] = static_cast<int32_t>(v[u]);
-      if (check && (v[u] < INT32_MIN || v[u] > INT32_MAX)) {
+      out[i] = static_cast<OutT>(v[u]);
+      if (check && (v[u] < lo || v[u] > hi)) {
         const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1ull;
         if (ok && static_cast<unsigned long long>(i) < bad) bad = static_cast<unsigned long long>(i);
       }
@@ -472,6 +473,42 @@ static int compare_any(int op, const T* left, T ls, const T* right, T rs, int64_
   }
 }
 
+template <typename OutT>
+static int cast_i64_checked(const char* what, const ArxSpan* values, int unchecked, int64_t lo, int64_t hi, void* ws,
+                            size_t ws_bytes, OutT* out, void* stream) {
+  if (values == nullptr || values->length < 0) {
+    set_error("bad arguments to %s", what);
+    return ARX_INVALID;
+  }
+  const int64_t n = values->length;
+  if (n == 0) return ARX_OK;
+  if (values->data == nullptr || out == nullptr || (!unchecked && (ws == nullptr || ws_bytes < 8))) {
+    set_error("NULL buffer / workspace passed to %s", what);
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  const int64_t* in = static_cast<const int64_t*>(values->data) + values->offset;
+  const Bits valid = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
+  unsigned long long* first_bad = static_cast<unsigned long long*>(ws);
+  if (!unchecked) ARX_HIP(hipMemsetAsync(first_bad, 0xFF, 8, st));
+  hipLaunchKernelGGL((cast_i64_kernel<OutT>), dim3(stream_grid(kBlock * 4, n)), dim3(kBlock), 0, st, in, valid, n, out,
+                     unchecked ? 0 : 1, lo, hi, first_bad);
+  ARX_CHECK_LAUNCH("cast_i64_kernel");
+  if (unchecked) return ARX_OK;
+  unsigned long long bad = ~0ull;
+  ARX_HIP(hipMemcpyAsync(&bad, first_bad, 8, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  if (bad != ~0ull) {
+    long long v = 0;
+    ARX_HIP(hipMemcpyAsync(&v, in + bad, 8, hipMemcpyDeviceToHost, st));
+    ARX_HIP(hipStreamSynchronize(st));
+    // the text of IntegersInRange's GetErrorMessage, util/int_util.cc:607-611
+    set_error("Integer value %lld not in range: %lld to %lld", v, static_cast<long long>(lo), static_cast<long long>(hi));
+    return ARX_INVALID;
+  }
+  return ARX_OK;
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -499,37 +536,15 @@ int arx_cast_f64_f32(const double* in, int64_t length, float* out, void* stream)
 
 int arx_cast_i64_i32(const ArxSpan* values, int allow_int_overflow, void* ws, size_t ws_bytes, int32_t* out,
                      void* stream) {
-  if (values == nullptr || values->length < 0) {
-    set_error("bad arguments to arx_cast_i64_i32");
-    return ARX_INVALID;
-  }
-  const int64_t n = values->length;
-  if (n == 0) return ARX_OK;
-  if (values->data == nullptr || out == nullptr || (!allow_int_overflow && (ws == nullptr || ws_bytes < 8))) {
-    set_error("NULL buffer / workspace passed to arx_cast_i64_i32");
-    return ARX_INVALID;
-  }
-  hipStream_t st = as_stream(stream);
-  const int64_t* in = static_cast<const int64_t*>(values->data) + values->offset;
-  const Bits valid = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
-  unsigned long long* first_bad = static_cast<unsigned long long*>(ws);
-  if (!allow_int_overflow) ARX_HIP(hipMemsetAsync(first_bad, 0xFF, 8, st));
-  hipLaunchKernelGGL(cast_i64_i32_kernel, dim3(stream_grid(kBlock * 4, n)), dim3(kBlock), 0, st, in, valid, n, out,
-                     allow_int_overflow ? 0 : 1, first_bad);
-  ARX_CHECK_LAUNCH("cast_i64_i32_kernel");
-  if (allow_int_overflow) return ARX_OK;
-  unsigned long long bad = ~0ull;
-  ARX_HIP(hipMemcpyAsync(&bad, first_bad, 8, hipMemcpyDeviceToHost, st));
-  ARX_HIP(hipStreamSynchronize(st));
-  if (bad != ~0ull) {
-    long long v = 0;
-    ARX_HIP(hipMemcpyAsync(&v, in + bad, 8, hipMemcpyDeviceToHost, st));
-    ARX_HIP(hipStreamSynchronize(st));
-    // the text of IntegersInRange's GetErrorMessage, util/int_util.cc:607-611
-    set_error("Integer value %lld not in range: -2147483648 to 2147483647", v);
-    return ARX_INVALID;
-  }
-  return ARX_OK;
+  return cast_i64_checked<int32_t>("arx_cast_i64_i32", values, allow_int_overflow, INT32_MIN, INT32_MAX, ws, ws_bytes,
+                                   out, stream);
+}
+
+int arx_cast_i64_f64(const ArxSpan* values, int allow_float_truncate, void* ws, size_t ws_bytes, double* out,
+                     void* stream) {
+  // whole numbers are exact in a double up to 2^53 (FloatingIntegerBound<double>, scalar_cast_numeric.cc:213-215)
+  return cast_i64_checked<double>("arx_cast_i64_f64", values, allow_float_truncate, -(int64_t(1) << 53),
+                                  int64_t(1) << 53, ws, ws_bytes, out, stream);
 }
 
 int arx_cast_i32_i64(const int32_t* values, int64_t length, int64_t* out, void* stream) {

@@ -199,6 +199,11 @@ int arx_cast_f64_f32(const double* in, int64_t length, float* out, void* stream)
 int arx_cast_i64_i32(const ArxSpan* values, int allow_int_overflow, void* ws, size_t ws_bytes, int32_t* out,
                      void* stream);
 int arx_cast_i32_i64(const int32_t* values, int64_t length, int64_t* out, void* stream);
+/* int64 -> float64 — CastIntegerToFloating (scalar_cast_numeric.cc:270-279): unless
+ * allow_float_truncate, CheckIntegerFloatTruncateImpl (:218-227) applies the same range check with
+ * the bounds -2^53 .. 2^53 ("Integer value V not in range: -9007199254740992 to 9007199254740992"). */
+int arx_cast_i64_f64(const ArxSpan* values, int allow_float_truncate, void* ws, size_t ws_bytes, double* out,
+                     void* stream);
 
 /* ---------------------------------------------------------------------------
  * Compare — replaces ComparePrimitiveArrayArray/ArrayScalar/ScalarArray<DoubleType,

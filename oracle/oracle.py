@@ -196,6 +196,21 @@ def cast_i64_i32(values, valid=None, allow_int_overflow=False):
     return v.astype(np.int32), err
 
 
+def cast_i64_f64(values, valid=None, allow_float_truncate=False):
+    """CastIntegerToFloating int64 -> float64 (scalar_cast_numeric.cc:270-279): unless allow_float_truncate,
+    the IntegersInRange check with the bounds -2^53 .. 2^53 (:203-227); then static_cast<double> on every slot
+    (round-to-nearest-even, as numpy's astype).  Returns (float64 array, error text or None)."""
+    v = np.asarray(values, dtype=np.int64)
+    ok = np.ones(len(v), bool) if valid is None else np.asarray(valid, bool)
+    err = None
+    if not allow_float_truncate:
+        for i in range(len(v)):
+            if ok[i] and not (-2**53 <= int(v[i]) <= 2**53):
+                err = f"Integer value {int(v[i])} not in range: -9007199254740992 to 9007199254740992"
+                break
+    return v.astype(np.float64), err
+
+
 def cast_f64_f32(a: np.ndarray) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.float64)
     out = np.empty(len(a), dtype=np.float32)

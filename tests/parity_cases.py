@@ -320,6 +320,33 @@ def check_integer_casts(amd, rng, n=9000, use_pyarrow=True):
         assert pc.cast(a.to_pyarrow(), pa.int32()).equals(amd.compute.cast(d, A.int32).to_pyarrow())
 
 
+def check_cast_i64_f64(amd, rng, n=6000, use_pyarrow=True):
+    A = amd.array
+    a = util.random_array(rng, np.int64, n, null_p=0.1, offset=2, tail=1, lo=-2**53, hi=2**53)
+    a.values[a.offset: a.offset + 2] = [2**53, -2**53]
+    d = a.to_device(amd)
+    want, err = O.cast_i64_f64(a.logical_values(), a.logical_valid())
+    assert err is None
+    out = amd.compute.cast(d, A.float64)
+    assert_equal(_data_np(out, np.float64).view(np.uint64), want.view(np.uint64), "cast i64->f64")
+    bad = HostArray(a.values.copy(), a.valid.copy(), a.offset, a.length)
+    pos = int(np.nonzero(bad.logical_valid())[0][7])
+    bad.values[bad.offset + pos] = 2**53 + 1
+    want_bad, err = O.cast_i64_f64(bad.logical_values(), bad.logical_valid())
+    assert err == "Integer value 9007199254740993 not in range: -9007199254740992 to 9007199254740992"
+    with pytest.raises(amd.ArrowInvalid) as ei:
+        amd.compute.cast(bad.to_device(amd), A.float64)
+    assert str(ei.value) == err
+    unsafe = amd.compute.cast(bad.to_device(amd), A.float64, safe=False)
+    assert_equal(_data_np(unsafe, np.float64).view(np.uint64), want_bad.view(np.uint64), "unsafe i64->f64 rounds")
+    if use_pyarrow and pc is not None:
+        with pytest.raises(pa.lib.ArrowInvalid) as ri:
+            pc.cast(bad.to_pyarrow(), pa.float64())
+        assert str(ri.value) == err
+        assert pc.cast(bad.to_pyarrow(), pa.float64(), safe=False).equals(unsafe.to_pyarrow())
+        assert pc.cast(a.to_pyarrow(), pa.float64()).equals(out.to_pyarrow())
+
+
 def check_arithmetic(amd, rng, n=8000, use_pyarrow=True):
     """subtract / multiply and the *_checked forms, int64 (wrap-around, overflow only counted where
     both operands are valid) and float64; array x array and both scalar orders."""

@@ -595,3 +595,4 @@ def test_subtract_multiply_and_checked_arithmetic(emu_ctx):
 def test_integer_casts(emu_ctx):
     """CastIntegerToInteger (scalar_cast_numeric.cc:46-54) + IntegersInRange's first-offender message."""
     P.check_integer_casts(emu_ctx, rng_for("intcast"), n=4000)
+    P.check_cast_i64_f64(emu_ctx, rng_for("i64f64"), n=4000)

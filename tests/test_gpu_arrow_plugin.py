@@ -210,7 +210,10 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
         except pa.lib.ArrowInvalid as he:
             assert str(e) == str(he), (str(e), str(he))
     assert to_host(pc.cast(d_vals, pa.int32(), safe=False)).equals(pc.cast(vals, pa.int32(), safe=False))
-    assert lib.arrow_amd_plugin_calls(b"cast", 1) == casts_before + 4     # (the failing call is not counted)
+    assert to_host(pc.cast(d_sm, pa.float64())).equals(pc.cast(smalls, pa.float64()))
+    assert to_host(pc.cast(d_vals, pa.float64(), safe=False)).equals(pc.cast(vals, pa.float64(), safe=False))
+    host_reference_casts += 2
+    assert lib.arrow_amd_plugin_calls(b"cast", 1) == casts_before + 6     # (the failing call is not counted)
     # the whole comparison family on device arrays (NaN-aware for doubles), scalars on either side
     f64n = pa.array(np.where(rng.random(n) < 0.01, np.nan, np.round(rng.standard_normal(n) * 4) / 4), mask=rng.random(n) < 0.05)
     d_f64n = to_device(f64n)

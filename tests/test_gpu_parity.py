@@ -763,3 +763,4 @@ def test_subtract_multiply_and_checked_arithmetic(gpu_ctx):
 def test_integer_casts(gpu_ctx):
     """CastIntegerToInteger (scalar_cast_numeric.cc:46-54) + IntegersInRange's first-offender message."""
     P.check_integer_casts(gpu_ctx, rng_for("intcast"), n=400003)
+    P.check_cast_i64_f64(gpu_ctx, rng_for("i64f64"), n=400003)
