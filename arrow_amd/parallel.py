@@ -106,8 +106,9 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
 
       1. histogram of the top bits of the order-transformed keys -> all-reduce -> P-1 splitters;
       2. stable partition of the non-null rows by destination rank on the device;
-      3. ONE all-to-all(v) of (transformed key, global row) pairs; receive buffers concatenate in
-         source-rank order, so equal keys stay in global row order;
+      3. ONE all-to-all(v) of (transformed key, local row) pairs — 12 B per row; receive buffers
+         concatenate in source-rank order, so equal keys stay in global row order and the global row
+         numbers are rebuilt from the block's source rank;
       4. local stable radix sort (arx_sort_indices_64) + gather of the global rows;
       5. null rows travel (row numbers only) to the last / first rank.
     """
@@ -166,19 +167,24 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
                                          rows_part.data_ptr(), counts.data_ptr(), C.byref(n_valid), stream))
     nv = n_valid.value
     keys_part = keys_part[:nv]
-    # global row numbers (uint32 local ids reinterpreted: the int32 view is only ever widened)
-    gidx_part = (rows_part[:nv].to(torch.int64) & 0xFFFFFFFF) + shard_offset
+    rows_part = rows_part[:nv]      # LOCAL row numbers (uint32 in an int32 tensor)
 
-    # 3. the exchange
+    # 3. the exchange: 12 B per row (transformed key + local row); the receiver rebuilds global row
+    #    numbers from the source rank of every received block (blocks arrive in source-rank order)
+    offsets = [sum(lens_h[:r]) for r in range(world)]
     if world > 1:
         recv_counts = torch.empty_like(counts)
         dist.all_to_all_single(recv_counts, counts, group=group)
         send = [int(x) for x in counts.cpu().tolist()]
         recv = [int(x) for x in recv_counts.cpu().tolist()]
         keys_recv = _all_to_all_v(keys_part, send, recv, group)
-        gidx_recv = _all_to_all_v(gidx_part, send, recv, group)
+        rows_recv = _all_to_all_v(rows_part, send, recv, group)
+        base = torch.repeat_interleave(torch.tensor(offsets, dtype=torch.int64, device=device),
+                                       torch.tensor(recv, dtype=torch.int64, device=device))
+        gidx_recv = (rows_recv.to(torch.int64) & 0xFFFFFFFF) + base
     else:
-        keys_recv, gidx_recv = keys_part, gidx_part
+        keys_recv = keys_part
+        gidx_recv = (rows_part.to(torch.int64) & 0xFFFFFFFF) + shard_offset
 
     # 4. local stable sort of the transformed keys + gather of the global rows
     m = int(keys_recv.numel())
