@@ -1,4 +1,4 @@
-"""Builds arrow_amd/libarrow_amd_plugin.so: the C++ registration shim (csrc/arrow_plugin.cc)
+"""Builds arrow_amd/libarrow_amd_plugin.so: the C++ registration shim (csrc/arrow_plugin.cc + csrc/plugin/*.inc)
 compiled with g++ against the installed Arrow (headers + libarrow of the pyarrow wheel) and
 linked to libarrow_amd.so.  Optional: needs the pyarrow wheel; the C ABI does not."""
 from __future__ import annotations
@@ -27,7 +27,9 @@ def build_plugin(force: bool = False, verbose: bool = True) -> str:
     core = os.path.join(HERE, "libarrow_amd.so")
     if not os.path.exists(core):
         raise RuntimeError("build libarrow_amd.so first")
+    parts = os.path.join(HERE, "csrc", "plugin")
     deps = [SRC, core, os.path.join(os.path.dirname(HERE), "include", "arrow_amd.h")]
+    deps += [os.path.join(parts, f) for f in sorted(os.listdir(parts)) if f.endswith(".inc")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(x) for x in deps):
         return OUT
     cmd = ["g++", "-std=c++20", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
