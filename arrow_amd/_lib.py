@@ -145,6 +145,7 @@ SIGNATURES = {
     "arx_groupby_sum_i64_merge": (_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p]),
     "arx_groupby_num_groups": (_int, [_p, C.POINTER(_i64), _p]),
     "arx_groupby_sum_i64_export": (_int, [_p, _p, _p, _p, _p, _p, _p]),
+    "arx_groupby_lookup_i32": (_int, [_p, _i64, _span, _p, _p]),
     "arx_groupby_minmax_bytes": (_sz, [_i64]),
     "arx_groupby_minmax_init": (_int, [_p, _i64, _p]),
     "arx_groupby_minmax_i64_consume": (_int, [_p, _p, _i64, _span, _span, _p]),

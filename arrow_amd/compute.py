@@ -1118,19 +1118,17 @@ class GroupBySum:
         return p["keys"], p["key_is_valid"], p["sums"], valid[:g]
 
 
-def _first_occurrence_groups(arr: Array, capacity: int | None, with_counts: bool):
-    """Distinct int32 values of `arr` in order of first appearance, from the fused group-by table:
+def _groups_by_first_row(arr: Array, capacity: int | None, with_counts: bool):
+    """The distinct int32 values of `arr` ordered by first appearance, from the fused group-by table:
     the rows' own numbers go through the min reducer (first row of every group) and, for
     value_counts, through the sum consume (whose `counts` column is the number of rows per group);
     the G groups are then ordered by first row with array_sort_indices + take.  Everything
-    row-sized runs in the HIP kernels; torch only numbers the rows and flips one validity bit."""
+    row-sized runs in the HIP kernels; torch only numbers the rows.
+    Returns (keys int32 tensor[G], key_is_valid uint8 tensor[G], counts Array | None)."""
     if arr.type != int32:
-        raise ArrowNotImplementedError("unique / value_counts on the gfx950 path: int32 values only")
+        raise ArrowNotImplementedError("unique / value_counts / dictionary_encode on the gfx950 path: int32 values only")
     dev = arr.device
     n = arr.length
-    if n == 0:
-        empty = Array(int32, 0, [None, alloc(0, dev)], 0, 0)
-        return empty, Array(int64, 0, [None, alloc(0, dev)], 0, 0)
     rows = Array(int64, n, [None, torch.arange(n, dtype=torch.int64, device=dev).view(torch.uint8)], 0, 0)
     op = GroupBySum(capacity or max(16, 2 * n + 2), dev)
     if with_counts:
@@ -1140,11 +1138,19 @@ def _first_occurrence_groups(arr: Array, capacity: int | None, with_counts: bool
     g = int(p["keys"].numel())
     as_arr = lambda t, col: Array(t, g, [None, col.contiguous().view(torch.uint8)], 0, 0)  # noqa: E731
     order = call_function("array_sort_indices", [as_arr(int64, p["mins"])], ArraySortOptions())
-    keys = take(as_arr(int32, p["keys"]), order, boundscheck=False)
+    keys = take(as_arr(int32, p["keys"]), order, boundscheck=False).data[: g * 4].view(torch.int32)
     kvalid = take(as_arr(uint8, p["key_is_valid"]), order, boundscheck=False).data[:g]
+    counts = take(as_arr(int64, p["counts"]), order, boundscheck=False) if with_counts else None
+    return keys, kvalid, counts
+
+
+def _values_array(keys: torch.Tensor, kvalid: torch.Tensor) -> Array:
+    """int32 Array over `keys` whose only possible null (all nulls are one group) is cleared in a fresh bitmap."""
+    g = int(keys.numel())
+    dev = keys.device
     validity, null_count = None, 0
     null_pos = torch.nonzero(kvalid == 0)
-    if null_pos.numel():      # all nulls are one group: at most one bit to clear
+    if null_pos.numel():
         pos = int(null_pos[0])
         validity = torch.full((bitmap_nbytes(g),), 0xFF, dtype=torch.uint8, device=dev)
         validity[g // 8:] = 0
@@ -1152,9 +1158,56 @@ def _first_occurrence_groups(arr: Array, capacity: int | None, with_counts: bool
             validity[g // 8] = (1 << (g % 8)) - 1
         validity[pos // 8] = int(validity[pos // 8]) & ~(1 << (pos % 8))
         null_count = 1
-    out = Array(int32, g, [validity, keys.data], null_count, 0)
-    counts = take(as_arr(int64, p["counts"]), order, boundscheck=False) if with_counts else None
-    return out, counts
+    data = keys.contiguous().view(torch.uint8)
+    if data.numel() < 64:      # keep the 64-byte padding every device buffer has
+        padded = alloc(64, dev, zero=True)
+        padded[: data.numel()] = data
+        data = padded
+    return Array(int32, g, [validity, data], null_count, 0)
+
+
+def _first_occurrence_groups(arr: Array, capacity: int | None, with_counts: bool):
+    dev = arr.device
+    if arr.length == 0:
+        empty = Array(int32, 0, [None, alloc(0, dev)], 0, 0)
+        return empty, Array(int64, 0, [None, alloc(0, dev)], 0, 0)
+    keys, kvalid, counts = _groups_by_first_row(arr, capacity, with_counts)
+    return _values_array(keys, kvalid), counts
+
+
+def dictionary_encode(arr: Array, null_encoding: str = "mask", capacity: int | None = None):
+    """compute::DictionaryEncode (DictEncodeAction, kernels/vector_hash.cc:173-270) for int32:
+    (indices int32 Array, dictionary int32 Array); the dictionary holds the distinct values in order
+    of first appearance.  null_encoding "mask" (default): nulls stay null in the indices and are not
+    in the dictionary; "encode": the null is a dictionary entry like any value.
+    Groups -> first rows -> order (as unique), the positions merged back into a table as its "sums",
+    then one read-only lookup per row (arx_groupby_lookup_i32)."""
+    if null_encoding not in ("mask", "encode"):
+        raise ArrowInvalid("null_encoding must be 'mask' or 'encode'")
+    dev = arr.device
+    n = arr.length
+    if n == 0:
+        return (Array(int32, 0, [None, alloc(0, dev)], 0, 0), Array(int32, 0, [None, alloc(0, dev)], 0, 0))
+    keys, kvalid, _ = _groups_by_first_row(arr, capacity, False)
+    if null_encoding == "mask":
+        keep = kvalid != 0
+        keys, kvalid = keys[keep].contiguous(), kvalid[keep].contiguous()
+    g = int(keys.numel())
+    lib, stream = _lib_and_stream(dev)
+    table = GroupBySum(max(16, 2 * g + 2), dev)
+    if g:
+        ids = torch.arange(g, dtype=torch.int64, device=dev)
+        zeros = torch.zeros(g, dtype=torch.int64, device=dev)
+        check(lib.arx_groupby_sum_i64_merge(table.state.data_ptr(), table.capacity, keys.data_ptr(), kvalid.data_ptr(),
+                                            ids.data_ptr(), zeros.data_ptr(), None, g, stream))
+    out = alloc(n * 4, dev)
+    sp = arr.span()
+    check(lib.arx_groupby_lookup_i32(table.state.data_ptr(), table.capacity, C.byref(sp), out.data_ptr(), stream))
+    if null_encoding == "mask":
+        validity, nc = _propagate_validity([arr], n, dev)
+    else:
+        validity, nc = None, 0
+    return Array(int32, n, [validity, out], nc, 0), _values_array(keys, kvalid)
 
 
 def unique(arr: Array, capacity: int | None = None) -> Array:

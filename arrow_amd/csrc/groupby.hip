@@ -297,6 +297,36 @@ __global__ __launch_bounds__(kBlock) void partition_scatter_kernel(
   }
 }
 
+// ---- lookup: out[i] = the sum column of keys[i]'s group, -1 if the key is not in the table
+// (read-only probe; what dictionary_encode uses to turn rows into dictionary indices once the
+// groups' dense ids have been merged in as their "sums")
+__global__ __launch_bounds__(kBlock) void groupby_lookup_kernel(GroupbyView v, const int32_t* __restrict__ keys,
+                                                                Bits kvalid, int64_t n, int32_t* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const uint64_t mask = static_cast<uint64_t>(v.capacity) - 1;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool kv = (load_word(kvalid, i >> 6) >> (i & 63)) & 1ull;
+    int64_t slot = -1;
+    if (!kv) {
+      slot = v.hdr->null_used != 0 ? v.capacity : -1;
+    } else {
+      const int32_t key = keys[i];
+      const unsigned long long tagged = (1ull << 32) | static_cast<uint32_t>(key);
+      uint64_t h = v.lg == 0 ? 0 : (gb_hash(key) >> (64 - v.lg));
+      for (int64_t probes = 0; probes < v.capacity; ++probes) {
+        const unsigned long long cur = v.keys[h];
+        if (cur == tagged) {
+          slot = static_cast<int64_t>(h);
+          break;
+        }
+        if (cur == 0) break;
+        h = (h + 1) & mask;
+      }
+    }
+    out[i] = slot < 0 ? -1 : static_cast<int32_t>(v.sums[slot]);
+  }
+}
+
 // ---- hash_min / hash_max on the same table (GroupedMinMaxImpl, kernels/hash_aggregate.cc:330-419):
 // mins start at INT64_MAX, maxes at INT64_MIN (AntiExtrema, :349-350); a valid value folds into both,
 // a null value sets the group's null flag (the same flag hash_sum keeps); the group exists either
@@ -1325,6 +1355,25 @@ int arx_groupby_export(void* state, const void* minmax, int32_t* out_keys, uint8
   hipLaunchKernelGGL(groupby_export_kernel, dim3(egrid), dim3(kBlock), 0, st, v, out_keys,
                      out_key_is_valid, out_sums, out_counts, out_no_nulls, mins, maxs, out_mins, out_maxs);
   ARX_CHECK_LAUNCH("groupby_export_kernel");
+  return ARX_OK;
+}
+
+int arx_groupby_lookup_i32(void* state, int64_t capacity, const ArxSpan* keys_i32, int32_t* out, void* stream) {
+  if (state == nullptr || keys_i32 == nullptr || capacity < 1 || (capacity & (capacity - 1)) != 0) {
+    set_error("bad arguments to arx_groupby_lookup_i32");
+    return ARX_INVALID;
+  }
+  const int64_t n = keys_i32->length;
+  if (n == 0) return ARX_OK;
+  if (keys_i32->data == nullptr || out == nullptr) {
+    set_error("NULL buffer passed to arx_groupby_lookup_i32");
+    return ARX_INVALID;
+  }
+  GroupbyView v = gb_view(state, capacity);
+  const Bits kb = make_bits(keys_i32->null_count != 0 ? keys_i32->validity : nullptr, keys_i32->offset, n);
+  hipLaunchKernelGGL(groupby_lookup_kernel, dim3(gb_grid(n)), dim3(kBlock), 0, as_stream(stream), v,
+                     static_cast<const int32_t*>(keys_i32->data) + keys_i32->offset, kb, n, out);
+  ARX_CHECK_LAUNCH("groupby_lookup_kernel");
   return ARX_OK;
 }
 

@@ -407,6 +407,11 @@ int arx_groupby_sum_i64_export(void* state, int32_t* out_keys, uint8_t* out_key_
  * arx_groupby_export is the sum export with the extrema as two more columns in the SAME group
  * order (minmax / out_mins / out_maxs may all be NULL).  finalize: out_valid[g] = the group saw a
  * value (min <= max) && (skip_nulls || no_nulls[g]) — min_count is not consulted (:401-410). */
+/* Read-only probe: out[i] = (int32) the sum column of keys[i]'s group, -1 if the key (or, for a null
+ * key, the null group) is not in the table.  dictionary_encode (DictEncodeAction,
+ * kernels/vector_hash.cc:192-270) = unique in first-appearance order, the groups' positions merged
+ * back in as their "sums", then this lookup over the rows.  Asynchronous. */
+int arx_groupby_lookup_i32(void* state, int64_t capacity, const ArxSpan* keys_i32, int32_t* out, void* stream);
 size_t arx_groupby_minmax_bytes(int64_t capacity);
 int arx_groupby_minmax_init(void* minmax, int64_t capacity, void* stream);
 int arx_groupby_minmax_i64_consume(void* state, void* minmax, int64_t capacity, const ArxSpan* keys_i32,

@@ -404,6 +404,30 @@ def unique_i32(values, valid_bitmap, offset, length, with_counts=False):
     return res + (np.array(counts, np.int64),) if with_counts else res
 
 
+def dictionary_encode_i32(values, valid_bitmap, offset, length, encode_nulls=False):
+    """DictEncodeAction over RegularHashKernel (kernels/vector_hash.cc:173-270): index of every row in
+    the dictionary of distinct values (first-appearance order).  MASK (default): a null row gets a null
+    index and the null is not in the dictionary; ENCODE: the null is a dictionary entry.
+    Returns (indices int32[n], index_valid bool[n], dict_values int32[g], dict_valid bool[g])."""
+    valid = unpack_bits(valid_bitmap, offset, length) if valid_bitmap is not None else np.ones(length, bool)
+    v = np.asarray(values)[offset: offset + length]
+    index, dvals, dvalid = {}, [], []
+    idx = np.zeros(length, np.int32)
+    idx_valid = np.ones(length, bool)
+    for i in range(length):
+        key = int(v[i]) if valid[i] else None
+        if key is None and not encode_nulls:
+            idx_valid[i] = False
+            continue
+        g = index.get(key)
+        if g is None:
+            g = index[key] = len(dvals)
+            dvals.append(0 if key is None else key)
+            dvalid.append(key is not None)
+        idx[i] = g
+    return idx, idx_valid, np.array(dvals, np.int32), np.array(dvalid, bool)
+
+
 class HashSumState:
     """GroupedReducingAggregator<Int64Type, GroupedSumImpl> with dense group ids:
     resize / consume / merge / finalize (hash_aggregate_numeric.cc:61-152)."""

@@ -582,6 +582,25 @@ def check_unique_and_value_counts(amd, arr: HostArray, use_pyarrow=True):
         assert u2.to_pyarrow().equals(pc.unique(arr.to_pyarrow()))
 
 
+def check_dictionary_encode(amd, arr: HostArray, use_pyarrow=True):
+    d = arr.to_device(amd)
+    for mode in ("mask", "encode"):
+        idx, dic = amd.compute.dictionary_encode(d, null_encoding=mode)
+        wi, wiv, wd, wdv = O.dictionary_encode_i32(arr.values, arr.valid_bitmap(), arr.offset, arr.length, mode == "encode")
+        gi, giv = idx.to_numpy()
+        giv = np.ones(idx.length, bool) if giv is None else giv
+        assert_equal(giv, wiv, f"dictionary_encode[{mode}] index validity")
+        assert_equal(gi[giv], wi[wiv], f"dictionary_encode[{mode}] indices")
+        gd, gdv = dic.to_numpy()
+        gdv = np.ones(dic.length, bool) if gdv is None else gdv
+        assert dic.length == len(wd)
+        assert_equal(gdv, wdv, "dictionary validity")
+        assert_equal(gd[gdv], wd[wdv], "dictionary values (first-appearance order)")
+        if use_pyarrow and pc is not None and arr.length:
+            ref = pc.dictionary_encode(arr.to_pyarrow(), null_encoding=mode)
+            assert idx.to_pyarrow().equals(ref.indices) and dic.to_pyarrow().equals(ref.dictionary), mode
+
+
 # ------------------------------------------------------------------ hash_sum kernel vtable
 def check_hash_sum_kernel(amd, rng, n=5000, num_groups=37, null_p=0.2, skip_nulls=True, min_count=1,
                           use_pyarrow=True):

@@ -596,3 +596,12 @@ def test_integer_casts(emu_ctx):
     """CastIntegerToInteger (scalar_cast_numeric.cc:46-54) + IntegersInRange's first-offender message."""
     P.check_integer_casts(emu_ctx, rng_for("intcast"), n=4000)
     P.check_cast_i64_f64(emu_ctx, rng_for("i64f64"), n=4000)
+
+
+@pytest.mark.parametrize("null_p,offset", [(0.0, 0), (0.07, 3)])
+def test_dictionary_encode(emu_ctx, null_p, offset):
+    """DictEncodeAction (vector_hash.cc:173-270): MASK and ENCODE null handling, first-appearance dictionary."""
+    rng = rng_for("dictenc", null_p, offset)
+    a = U.random_array(rng, np.int32, 2500, null_p=null_p, offset=offset, tail=2, lo=-150, hi=150)
+    P.check_dictionary_encode(emu_ctx, a)
+    P.check_dictionary_encode(emu_ctx, U.random_array(rng, np.int32, 0))

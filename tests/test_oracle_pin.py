@@ -518,3 +518,17 @@ def test_arith_vs_pyarrow(op):
     want, _ = O.arith(op, f, g)
     got = getattr(pc, op + "_checked")(pa.array(f), pa.array(g)).to_numpy()
     assert np.array_equal(want, got, equal_nan=True)
+
+
+# ------------------------------------------------------------------ dictionary_encode (oracle.dictionary_encode_i32)
+@pytest.mark.skipif(pc is None, reason="pyarrow wheel not in this image")
+@pytest.mark.parametrize("mode", ["mask", "encode"])
+def test_dictionary_encode_vs_pyarrow(mode):
+    """TYPED_TEST(TestHashKernelPrimitive, DictEncode) shape (kernels/vector_hash_test.cc): {2, 1, 2, 1, 2, 3}
+    with a null in the middle, then a random grid."""
+    rng = np.random.default_rng([U.kRandomSeed, len(mode)])
+    for a in (from_list([2, 1, None, 1, 2, 3, None], np.int32), U.random_array(rng, np.int32, 20_000, null_p=0.1, offset=4, lo=-90, hi=90)):
+        idx, iv, dv, dvv = O.dictionary_encode_i32(a.values, a.valid_bitmap(), a.offset, a.length, mode == "encode")
+        ref = pc.dictionary_encode(a.to_pyarrow(), null_encoding=mode)
+        assert [int(x) if ok else None for x, ok in zip(idx, iv)] == ref.indices.to_pylist()
+        assert [int(x) if ok else None for x, ok in zip(dv, dvv)] == ref.dictionary.to_pylist()
