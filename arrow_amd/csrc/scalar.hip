@@ -371,12 +371,11 @@ __global__ __launch_bounds__(kBlock) void popcount_kernel(Bits a, int64_t nwords
 template <typename T, int LK, int RK, int CMP = ARX_CMP_GREATER>
 static int launch_greater(const T* left, T ls, const T* right, T rs, int64_t n, uint64_t* out,
                           hipStream_t st) {
-  if (n < 0 || out == nullptr || (LK == kArray && left == nullptr && n > 0) ||
-      (RK == kArray && right == nullptr && n > 0)) {
-    set_error("bad arguments to greater");
+  if (n == 0) return ARX_OK;  // empty arrays may come with NULL buffers
+  if (n < 0 || out == nullptr || (LK == kArray && left == nullptr) || (RK == kArray && right == nullptr)) {
+    set_error("bad arguments to compare");
     return ARX_INVALID;
   }
-  if (n == 0) return ARX_OK;
   const bool aligned = (LK != kArray || (reinterpret_cast<uint64_t>(left) & 15) == 0) &&
                        (RK != kArray || (reinterpret_cast<uint64_t>(right) & 15) == 0);
   const unsigned grid = stream_grid(kWavesPerBlock * 128 * 4, n);

@@ -1,0 +1,126 @@
+"""The C ABI's argument contract (include/arrow_amd.h), exercised directly through ctypes on the
+kernel sources built for the host (tests/emu): every entry point rejects NULL buffers, negative or
+mismatched lengths, unsupported widths / types and short or misaligned workspaces with a status
+code that mirrors arrow::StatusCode and a message in arx_last_error() — never a crash — and
+zero-length inputs are accepted everywhere."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.emu
+
+OK, INVALID, INDEX_ERROR, NOT_IMPLEMENTED = 0, -4, -7, -10
+
+
+def _span(L, data=None, validity=None, offset=0, length=0, null_count=0):
+    return L.ArxSpan(None if validity is None else validity.data_ptr(), None if data is None else data.data_ptr(),
+                     offset, length, null_count)
+
+
+def _buf(nbytes):
+    return torch.zeros(max(nbytes, 64), dtype=torch.uint8)
+
+
+def _err(lib):
+    lib.arx_last_error.restype = C.c_char_p
+    return lib.arx_last_error().decode()
+
+
+def test_filter_and_take_argument_checks(emu_ctx):
+    L = emu_ctx._lib
+    lib = L.get_lib()
+    n = 1000
+    vals, mask, ws, out = _buf(n * 8), _buf(n // 8 + 8), _buf(lib.arx_filter_workspace_bytes(n) + 64), _buf(n * 8)
+    m = _span(L, mask, length=n)
+    v = _span(L, vals, length=n)
+    cnt = C.c_int64(0)
+    assert lib.arx_filter_count(C.byref(m), 0, ws.data_ptr(), 8, C.byref(cnt), None) == INVALID      # workspace too small
+    assert "workspace" in _err(lib)
+    assert lib.arx_filter_count(None, 0, ws.data_ptr(), ws.numel(), C.byref(cnt), None) == INVALID
+    assert lib.arx_filter_count(C.byref(m), 7, ws.data_ptr(), ws.numel(), C.byref(cnt), None) == INVALID  # bad null selection
+    assert lib.arx_filter_count(C.byref(m), 0, ws.data_ptr(), ws.numel(), C.byref(cnt), None) == OK and cnt.value == 0
+    assert lib.arx_filter_exec(C.byref(v), 3, C.byref(m), 0, ws.data_ptr(), 0, out.data_ptr(), None, None) in (INVALID, NOT_IMPLEMENTED)  # width 3
+    short = _span(L, vals, length=n - 1)
+    assert lib.arx_filter_exec(C.byref(short), 8, C.byref(m), 0, ws.data_ptr(), 0, out.data_ptr(), None, None) == INVALID
+    assert "same length" in _err(lib)
+    idx = _buf(40)
+    i = _span(L, idx, length=10)
+    assert lib.arx_take(C.byref(v), 8, C.byref(i), 99, out.data_ptr(), None, None, None) == NOT_IMPLEMENTED  # index type
+    assert lib.arx_take(C.byref(v), 5, C.byref(i), 5, out.data_ptr(), None, None, None) == NOT_IMPLEMENTED   # byte width
+    assert lib.arx_take(C.byref(v), 8, C.byref(i), 5, None, None, None, None) == INVALID
+    tws = _buf(lib.arx_take_workspace_bytes() + 64)
+    idx.view(torch.int32)[3] = 5000
+    assert lib.arx_check_index_bounds(C.byref(i), 5, 1000, tws.data_ptr(), tws.numel(), None) == INDEX_ERROR
+    assert _err(lib) == "Index 5000 out of bounds"
+    idx.view(torch.int32)[3] = -1
+    assert lib.arx_check_index_bounds(C.byref(i), 5, 1000, tws.data_ptr(), tws.numel(), None) == INDEX_ERROR
+    assert _err(lib) == "Index -1 out of bounds"
+    empty = _span(L, idx, length=0)
+    assert lib.arx_take(C.byref(v), 8, C.byref(empty), 5, out.data_ptr(), None, None, None) == OK
+
+
+def test_sort_and_groupby_argument_checks(emu_ctx):
+    L = emu_ctx._lib
+    lib = L.get_lib()
+    n = 500
+    keys, out = _buf(n * 8), _buf(n * 8)
+    need = lib.arx_sort_indices_workspace_bytes(n)
+    ws = _buf(need + 512)
+    base = (ws.data_ptr() + 255) & ~255
+    v = _span(L, keys, length=n)
+    assert lib.arx_sort_indices(C.byref(v), 0, 0, 1, base, 16, out.data_ptr(), None) == INVALID          # short workspace
+    assert "workspace" in _err(lib)
+    assert lib.arx_sort_indices(C.byref(v), 0, 0, 1, base + 8, need, out.data_ptr(), None) == INVALID     # misaligned
+    assert lib.arx_sort_indices(C.byref(v), 42, 0, 1, base, need, out.data_ptr(), None) == NOT_IMPLEMENTED  # key type
+    assert lib.arx_sort_indices(C.byref(v), 0, 9, 1, base, need, out.data_ptr(), None) == INVALID          # order
+    assert lib.arx_sort_indices(C.byref(v), 0, 0, 9, base, need, out.data_ptr(), None) == INVALID          # null placement
+    assert lib.arx_sort_indices(C.byref(v), 0, 0, 1, base, need, None, None) == INVALID
+    assert lib.arx_sort_indices(C.byref(_span(L, keys, length=0)), 0, 0, 1, base, need, out.data_ptr(), None) == OK
+    cap = 64
+    state = _buf(lib.arx_groupby_state_bytes(cap))
+    assert lib.arx_groupby_init(state.data_ptr(), 48, None) == INVALID                                     # not a power of two
+    assert lib.arx_groupby_init(None, cap, None) == INVALID
+    assert lib.arx_groupby_init(state.data_ptr(), cap, None) == OK
+    k32, v64 = _buf(n * 4), _buf(n * 8)
+    ks, vs = _span(L, k32, length=n), _span(L, v64, length=n - 3)
+    assert lib.arx_groupby_sum_i64_consume(state.data_ptr(), cap, C.byref(ks), C.byref(vs), None, 0, None) == INVALID
+    assert "same length" in _err(lib)
+    # more distinct keys than slots: reported, not silently dropped
+    k32.view(torch.int32)[:n] = torch.arange(n, dtype=torch.int32)
+    vs = _span(L, v64, length=n)
+    rc = lib.arx_groupby_sum_i64_consume(state.data_ptr(), cap, C.byref(ks), C.byref(vs), None, 0, None)
+    g = C.c_int64(0)
+    assert rc == INVALID or lib.arx_groupby_num_groups(state.data_ptr(), C.byref(g), None) == INVALID
+    assert "capacity" in _err(lib) or "full" in _err(lib)
+    mm = _buf(lib.arx_groupby_minmax_bytes(cap))
+    assert lib.arx_groupby_minmax_i64_consume(state.data_ptr(), None, cap, C.byref(ks), C.byref(vs), None) == INVALID
+    assert lib.arx_groupby_export(state.data_ptr(), None, k32.data_ptr(), k32.data_ptr(), v64.data_ptr(), v64.data_ptr(),
+                                  k32.data_ptr(), v64.data_ptr(), v64.data_ptr(), None) == INVALID   # extrema wanted, no minmax buffer
+    del mm
+
+
+def test_scalar_kernel_argument_checks(emu_ctx):
+    L = emu_ctx._lib
+    lib = L.get_lib()
+    a, b, out = _buf(800), _buf(800), _buf(800)
+    assert lib.arx_compare_f64(2, None, 0.0, None, 0.0, 100, out.data_ptr(), None) == INVALID          # scalar x scalar
+    assert lib.arx_compare_i64(77, a.data_ptr(), 0, b.data_ptr(), 0, 100, out.data_ptr(), None) == INVALID   # unknown op
+    assert lib.arx_compare_i64(2, a.data_ptr(), 0, b.data_ptr(), 0, 0, None, None) == OK
+    assert lib.arx_arith_i64(9, a.data_ptr(), 0, b.data_ptr(), 0, 100, out.data_ptr(), None) == INVALID
+    assert lib.arx_arith_checked_i64(0, a.data_ptr(), 0, None, 0, b.data_ptr(), 0, None, 0, 100, out.data_ptr(), None, None) == INVALID  # no flag
+    assert lib.arx_cast_f64_f32(None, 10, out.data_ptr(), None) == INVALID
+    sp = _span(L, a, length=100)
+    assert lib.arx_cast_i64_i32(C.byref(sp), 0, None, 0, out.data_ptr(), None) == INVALID               # checked cast needs a workspace
+    assert lib.arx_cast_i64_i32(C.byref(sp), 1, None, 0, out.data_ptr(), None) == OK                    # unchecked does not
+    lm, rm = _span(L, a, length=100), _span(L, b, length=90)
+    assert lib.arx_boolean_kleene(0, C.byref(lm), C.byref(rm), out.data_ptr(), None, None) == INVALID   # length mismatch
+    rm = _span(L, b, validity=a, length=100, null_count=-1)
+    assert lib.arx_boolean_kleene(0, C.byref(lm), C.byref(rm), out.data_ptr(), None, None) == INVALID   # nulls but no out validity
+    assert lib.arx_boolean_kleene(5, C.byref(lm), C.byref(lm), out.data_ptr(), None, None) == INVALID
+    assert lib.arx_set_option(b"no_such_option", 1) != 0
+    bs = L.ArxBinarySpan(None, None, None, 0, 10, 0)
+    i = _span(L, a, length=5)
+    tot = C.c_int64(0)
+    assert lib.arx_binary_take_offsets(C.byref(bs), C.byref(i), 5, None, 0, out.data_ptr(), None, None, C.byref(tot), None) == INVALID
