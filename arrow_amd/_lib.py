@@ -128,6 +128,8 @@ SIGNATURES = {
     "arx_add_f64": (_int, [_p, _p, _i64, _p, _p]),
     "arx_bitmap_copy": (_int, [_p, _i64, _i64, _p, _p]),
     "arx_bitmap_and": (_int, [_p, _i64, _p, _i64, _i64, _p, _p]),
+    "arx_reduce_i64_init": (_int, [_p, _p]),
+    "arx_reduce_i64_consume": (_int, [_span, _p, _p]),
     "arx_boolean_kleene": (_int, [_int, _span, _span, _p, _p, _p]),
     "arx_boolean_invert": (_int, [_p, _i64, _i64, _p, _p]),
     "arx_bitmap_popcount": (_int, [_p, _i64, _i64, _p, _sz, C.POINTER(_i64), _p]),

@@ -973,6 +973,73 @@ def sort_indices(arr, order: str = "ascending", null_placement: str = "at_end"):
 
 
 # --------------------------------------------------------------------------- group-by
+# --------------------------------------------------------------------------- scalar aggregates (int64)
+class Int64Aggregator:
+    """SumImpl / CountImpl / MinMaxImpl over int64 batches (aggregate_basic.inc.cc:49-110,776-860):
+    consume() any number of device arrays, then sum() / count() / min_max() apply the options the
+    way Finalize does.  (mean is not offered: the reference accumulates it in doubles, in row order.)"""
+
+    def __init__(self, device=None, options: ScalarAggregateOptions | None = None):
+        from .array import default_device
+
+        self.device = torch.device(device) if device is not None else default_device()
+        self.options = options or ScalarAggregateOptions()
+        self.acc = torch.zeros(4, dtype=torch.int64, device=self.device)
+        self.rows = 0
+        self.nulls_observed = False
+        lib, stream = _lib_and_stream(self.device)
+        check(lib.arx_reduce_i64_init(self.acc.data_ptr(), stream))
+
+    def consume(self, arr: Array) -> None:
+        if arr.type != int64:
+            raise ArrowNotImplementedError("Int64Aggregator: int64 values only")
+        lib, stream = _lib_and_stream(self.device)
+        sp = arr.span()
+        check(lib.arx_reduce_i64_consume(C.byref(sp), self.acc.data_ptr(), stream))
+        self.rows += arr.length
+
+    def _state(self):
+        s, c, mn, mx = (int(x) for x in self.acc.cpu().tolist())
+        return s, c, mn, mx
+
+    def sum(self):
+        s, c, _, _ = self._state()
+        nulls = c < self.rows
+        if (not self.options.skip_nulls and nulls) or c < self.options.min_count:
+            return None
+        return s
+
+    def count(self, mode: str = "only_valid"):
+        _, c, _, _ = self._state()
+        return {"only_valid": c, "only_null": self.rows - c, "all": self.rows}[mode]
+
+    def min_max(self):
+        _, c, mn, mx = self._state()
+        nulls = c < self.rows
+        if (not self.options.skip_nulls and nulls) or c < max(1, self.options.min_count):
+            return None
+        return mn, mx
+
+
+def sum(arr: Array, skip_nulls: bool = True, min_count: int = 1):  # noqa: A001
+    """compute::Sum for int64 (wrap-around), None = null."""
+    agg = Int64Aggregator(arr.device, ScalarAggregateOptions(skip_nulls, min_count))
+    agg.consume(arr)
+    return agg.sum()
+
+
+def count(arr: Array, mode: str = "only_valid") -> int:
+    agg = Int64Aggregator(arr.device)
+    agg.consume(arr)
+    return agg.count(mode)
+
+
+def min_max(arr: Array, skip_nulls: bool = True, min_count: int = 1):
+    agg = Int64Aggregator(arr.device, ScalarAggregateOptions(skip_nulls, min_count))
+    agg.consume(arr)
+    return agg.min_max()
+
+
 def _next_pow2(n: int) -> int:
     p = 1
     while p < n:

@@ -306,6 +306,67 @@ __global__ __launch_bounds__(kBlock) void arith_kernel(const T* __restrict__ lef
   }
 }
 
+// ------------------------------------------------------------------ scalar aggregates over int64
+// One pass produces what SumImpl / CountImpl / MinMaxImpl (kernels/aggregate_basic.inc.cc:49-110,
+// 776-860) keep per column: the wrap-around sum of the valid values, their count, min and max.
+// acc = {sum, count, min, max} (4 x int64, device, arx_reduce_i64_init), accumulated across calls
+// like Consume / MergeFrom.  Per-thread partials -> wave shuffles -> 4 atomics per workgroup.
+__global__ __launch_bounds__(kBlock) void reduce_i64_kernel(const int64_t* __restrict__ in, Bits valid, int64_t n,
+                                                            unsigned long long* __restrict__ acc) {
+  __shared__ unsigned long long s_sum[kWavesPerBlock], s_cnt[kWavesPerBlock];
+  __shared__ long long s_min[kWavesPerBlock], s_max[kWavesPerBlock];
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  unsigned long long sum = 0, cnt = 0;
+  long long mn = INT64_MAX, mx = INT64_MIN;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1ull;
+    if (ok) {
+      const long long v = in[i];
+      sum += static_cast<unsigned long long>(v);
+      ++cnt;
+      mn = v < mn ? v : mn;
+      mx = v > mx ? v : mx;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    sum += __shfl_xor(sum, d, 64);
+    cnt += __shfl_xor(cnt, d, 64);
+    const long long omn = __shfl_xor(mn, d, 64), omx = __shfl_xor(mx, d, 64);
+    mn = omn < mn ? omn : mn;
+    mx = omx > mx ? omx : mx;
+  }
+  const int wave = threadIdx.x >> 6;
+  if (lane_id() == 0) {
+    s_sum[wave] = sum;
+    s_cnt[wave] = cnt;
+    s_min[wave] = mn;
+    s_max[wave] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < kWavesPerBlock; ++k) {
+      sum += s_sum[k];
+      cnt += s_cnt[k];
+      mn = s_min[k] < mn ? s_min[k] : mn;
+      mx = s_max[k] > mx ? s_max[k] : mx;
+    }
+    if (cnt != 0) {
+      atomicAdd(&acc[0], sum);
+      atomicAdd(&acc[1], cnt);
+      atomicMin(reinterpret_cast<long long*>(&acc[2]), mn);
+      atomicMax(reinterpret_cast<long long*>(&acc[3]), mx);
+    }
+  }
+}
+
+__global__ void reduce_i64_init_kernel(long long* acc) {
+  acc[0] = 0;
+  acc[1] = 0;
+  acc[2] = INT64_MAX;
+  acc[3] = INT64_MIN;
+}
+
 // ------------------------------------------------------------------ bitmaps
 template <bool AND>
 __global__ __launch_bounds__(kBlock) void bitmap_kernel(Bits a, Bits b, int64_t nwords,
@@ -667,6 +728,35 @@ int arx_bitmap_and(const void* left, int64_t left_offset, const void* right, int
   hipLaunchKernelGGL((bitmap_kernel<true>), dim3(grid), dim3(kBlock), 0, as_stream(stream), a, b,
                      nwords, static_cast<uint64_t*>(out));
   ARX_CHECK_LAUNCH("bitmap_kernel");
+  return ARX_OK;
+}
+
+int arx_reduce_i64_init(void* acc, void* stream) {
+  if (acc == nullptr) {
+    set_error("arx_reduce_i64_init: acc is NULL");
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(reduce_i64_init_kernel, dim3(1), dim3(1), 0, as_stream(stream), static_cast<long long*>(acc));
+  ARX_CHECK_LAUNCH("reduce_i64_init_kernel");
+  return ARX_OK;
+}
+
+int arx_reduce_i64_consume(const ArxSpan* values, void* acc, void* stream) {
+  if (values == nullptr || acc == nullptr || values->length < 0) {
+    set_error("bad arguments to arx_reduce_i64_consume");
+    return ARX_INVALID;
+  }
+  const int64_t n = values->length;
+  if (n == 0) return ARX_OK;
+  if (values->data == nullptr) {
+    set_error("NULL data buffer passed to arx_reduce_i64_consume");
+    return ARX_INVALID;
+  }
+  const Bits valid = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
+  hipLaunchKernelGGL(reduce_i64_kernel, dim3(stream_grid(kBlock * 8, n)), dim3(kBlock), 0, as_stream(stream),
+                     static_cast<const int64_t*>(values->data) + values->offset, valid, n,
+                     static_cast<unsigned long long*>(acc));
+  ARX_CHECK_LAUNCH("reduce_i64_kernel");
   return ARX_OK;
 }
 

@@ -286,6 +286,14 @@ int arx_bitmap_copy(const void* bits, int64_t bit_offset, int64_t length, void* 
                     void* stream);
 int arx_bitmap_and(const void* left, int64_t left_offset, const void* right,
                    int64_t right_offset, int64_t length, void* out, void* stream);
+/* Scalar aggregates over an int64 column in one pass — the state SumImpl / CountImpl / MinMaxImpl keep
+ * (cpp/src/arrow/compute/kernels/aggregate_basic.inc.cc:49-110,776-860): acc = {wrap-around sum of the
+ * valid values, their count, min, max} as 4 x int64 in device memory; init once, consume per batch
+ * (Consume / MergeFrom accumulate the same way).  The options (skip_nulls, min_count) are applied by
+ * the caller from count and the inputs' null counts, as Finalize does.  Asynchronous. */
+int arx_reduce_i64_init(void* acc, void* stream);
+int arx_reduce_i64_consume(const ArxSpan* values, void* acc, void* stream);
+
 /* Kleene logic on boolean arrays — KleeneAndOp / KleeneOrOp (array, array) and InvertOp,
  * cpp/src/arrow/compute/kernels/scalar_boolean.cc:138-260.  left/right: boolean ArxSpans (data =
  * LSB-first bitmap, offset in bits, validity NULL or null_count == 0 = no nulls).  out_data /

@@ -347,6 +347,38 @@ def check_cast_i64_f64(amd, rng, n=6000, use_pyarrow=True):
         assert pc.cast(a.to_pyarrow(), pa.float64()).equals(out.to_pyarrow())
 
 
+def check_scalar_aggregates(amd, rng, n=20_000):
+    """sum / count / min_max of int64 columns vs numpy (exact integer arithmetic) and pyarrow."""
+    for null_p, lo, hi in ((0.0, -1000, 1000), (0.2, None, None), (1.0, -5, 5)):
+        a = util.random_array(rng, np.int64, n, null_p=null_p, offset=3, tail=2, lo=lo, hi=hi)
+        d = a.to_device(amd)
+        vals, valid = a.logical_values(), a.logical_valid()
+        for skip_nulls in (True, False):
+            for min_count in (0, 1, n + 1):
+                exact = int(vals[valid].astype(object).sum()) if valid.any() else 0
+                want_sum = ((exact + 2**63) % 2**64) - 2**63
+                nulls = not valid.all()
+                cnt = int(valid.sum())
+                want = None if ((not skip_nulls and nulls) or cnt < min_count) else want_sum
+                assert amd.compute.sum(d, skip_nulls, min_count) == want, (null_p, skip_nulls, min_count)
+                want_mm = None if ((not skip_nulls and nulls) or cnt < max(1, min_count)) else (int(vals[valid].min()), int(vals[valid].max()))
+                assert amd.compute.min_max(d, skip_nulls, min_count) == want_mm
+                if pc is not None:
+                    opts = pc.ScalarAggregateOptions(skip_nulls=skip_nulls, min_count=min_count)
+                    assert pc.sum(a.to_pyarrow(), options=opts).as_py() == want
+                    ref = pc.min_max(a.to_pyarrow(), options=opts).as_py()
+                    assert (None if ref["min"] is None else (ref["min"], ref["max"])) == want_mm
+        assert amd.compute.count(d) == int(valid.sum()) and amd.compute.count(d, "only_null") == int((~valid).sum())
+        assert amd.compute.count(d, "all") == n
+    agg = amd.compute.Int64Aggregator(d.device)          # several batches accumulate like Consume / MergeFrom
+    a = util.random_array(rng, np.int64, n, null_p=0.1)
+    d = a.to_device(amd)
+    for b in range(0, n, 7001):
+        agg.consume(d.slice(b, 7001))
+    v = a.logical_values()[a.logical_valid()]
+    assert agg.sum() == ((int(v.astype(object).sum()) + 2**63) % 2**64) - 2**63 and agg.min_max() == (int(v.min()), int(v.max()))
+
+
 def check_arithmetic(amd, rng, n=8000, use_pyarrow=True):
     """subtract / multiply and the *_checked forms, int64 (wrap-around, overflow only counted where
     both operands are valid) and float64; array x array and both scalar orders."""

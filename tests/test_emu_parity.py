@@ -605,3 +605,8 @@ def test_dictionary_encode(emu_ctx, null_p, offset):
     a = U.random_array(rng, np.int32, 2500, null_p=null_p, offset=offset, tail=2, lo=-150, hi=150)
     P.check_dictionary_encode(emu_ctx, a)
     P.check_dictionary_encode(emu_ctx, U.random_array(rng, np.int32, 0))
+
+
+def test_scalar_aggregates_int64(emu_ctx):
+    """SumImpl / CountImpl / MinMaxImpl (aggregate_basic.inc.cc): wrap-around sum, options, batches."""
+    P.check_scalar_aggregates(emu_ctx, rng_for("scalaragg"), n=6000)
