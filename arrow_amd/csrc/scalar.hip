@@ -318,14 +318,24 @@ __global__ __launch_bounds__(kBlock) void reduce_i64_kernel(const int64_t* __res
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   unsigned long long sum = 0, cnt = 0;
   long long mn = INT64_MAX, mx = INT64_MIN;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1ull;
-    if (ok) {
-      const long long v = in[i];
-      sum += static_cast<unsigned long long>(v);
-      ++cnt;
-      mn = v < mn ? v : mn;
-      mx = v > mx ? v : mx;
+  // 4 unconditional loads in flight per lane (a null slot's value is loaded and dropped)
+  constexpr int U = 4;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; base < n; base += stride * U) {
+    long long v[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * stride;
+      const int64_t ic = i < n ? i : n - 1;
+      v[u] = in[ic];
+      ok[u] = i < n && ((load_word(valid, ic >> 6) >> (ic & 63)) & 1ull);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      sum += ok[u] ? static_cast<unsigned long long>(v[u]) : 0ull;
+      cnt += ok[u] ? 1ull : 0ull;
+      mn = (ok[u] && v[u] < mn) ? v[u] : mn;
+      mx = (ok[u] && v[u] > mx) ? v[u] : mx;
     }
   }
 #pragma unroll
@@ -753,7 +763,7 @@ int arx_reduce_i64_consume(const ArxSpan* values, void* acc, void* stream) {
     return ARX_INVALID;
   }
   const Bits valid = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
-  hipLaunchKernelGGL(reduce_i64_kernel, dim3(stream_grid(kBlock * 8, n)), dim3(kBlock), 0, as_stream(stream),
+  hipLaunchKernelGGL(reduce_i64_kernel, dim3(stream_grid(kBlock * 4, n)), dim3(kBlock), 0, as_stream(stream),
                      static_cast<const int64_t*>(values->data) + values->offset, valid, n,
                      static_cast<unsigned long long*>(acc));
   ARX_CHECK_LAUNCH("reduce_i64_kernel");
