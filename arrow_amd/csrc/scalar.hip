@@ -318,25 +318,37 @@ __global__ __launch_bounds__(kBlock) void reduce_i64_kernel(const int64_t* __res
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   unsigned long long sum = 0, cnt = 0;
   long long mn = INT64_MAX, mx = INT64_MIN;
-  // 4 unconditional loads in flight per lane (a null slot's value is loaded and dropped)
+  // 4 unconditional 16-byte loads (2 rows each) in flight per lane; a null slot's value is loaded and
+  // dropped.  `in` is 16-byte aligned here: the launcher peels an unaligned first row off.
   constexpr int U = 4;
-  for (int64_t base = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; base < n; base += stride * U) {
-    long long v[U];
-    bool ok[U];
+  const int64_t npairs = n >> 1;
+  const longlong2* __restrict__ in2 = reinterpret_cast<const longlong2*>(in);
+  auto fold = [&](long long v, bool ok) {
+    sum += ok ? static_cast<unsigned long long>(v) : 0ull;
+    cnt += ok ? 1ull : 0ull;
+    mn = (ok && v < mn) ? v : mn;
+    mx = (ok && v > mx) ? v : mx;
+  };
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; base < npairs; base += stride * U) {
+    longlong2 v[U];
+    uint32_t ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t i = base + u * stride;
-      const int64_t ic = i < n ? i : n - 1;
-      v[u] = in[ic];
-      ok[u] = i < n && ((load_word(valid, ic >> 6) >> (ic & 63)) & 1ull);
+      const int64_t p = base + u * stride;
+      const int64_t pc = p < npairs ? p : npairs - 1;
+      v[u] = in2[pc];
+      const int64_t r = pc * 2;   // even: both bits sit in the same 64-bit word
+      ok[u] = p < npairs ? static_cast<uint32_t>((load_word(valid, r >> 6) >> (r & 63)) & 3ull) : 0u;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      sum += ok[u] ? static_cast<unsigned long long>(v[u]) : 0ull;
-      cnt += ok[u] ? 1ull : 0ull;
-      mn = (ok[u] && v[u] < mn) ? v[u] : mn;
-      mx = (ok[u] && v[u] > mx) ? v[u] : mx;
+      fold(v[u].x, ok[u] & 1u);
+      fold(v[u].y, ok[u] & 2u);
     }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    fold(in[i], (load_word(valid, i >> 6) >> (i & 63)) & 1ull);
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -762,10 +774,20 @@ int arx_reduce_i64_consume(const ArxSpan* values, void* acc, void* stream) {
     set_error("NULL data buffer passed to arx_reduce_i64_consume");
     return ARX_INVALID;
   }
-  const Bits valid = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
-  hipLaunchKernelGGL(reduce_i64_kernel, dim3(stream_grid(kBlock * 4, n)), dim3(kBlock), 0, as_stream(stream),
-                     static_cast<const int64_t*>(values->data) + values->offset, valid, n,
-                     static_cast<unsigned long long*>(acc));
+  const void* vbits = values->null_count != 0 ? values->validity : nullptr;
+  const int64_t* in = static_cast<const int64_t*>(values->data) + values->offset;
+  // the kernel reads 16-byte pairs: peel a leading row that is only 8-byte aligned
+  const int64_t head = (reinterpret_cast<uint64_t>(in) & 15) != 0 ? 1 : 0;
+  if (head) {
+    const Bits v1 = make_bits(vbits, values->offset, 1);
+    hipLaunchKernelGGL(reduce_i64_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), in, v1, int64_t(1),
+                       static_cast<unsigned long long*>(acc));
+  }
+  if (n - head > 0) {
+    const Bits valid = make_bits(vbits, values->offset + head, n - head);
+    hipLaunchKernelGGL(reduce_i64_kernel, dim3(stream_grid(kBlock * 8, n - head)), dim3(kBlock), 0, as_stream(stream),
+                       in + head, valid, n - head, static_cast<unsigned long long*>(acc));
+  }
   ARX_CHECK_LAUNCH("reduce_i64_kernel");
   return ARX_OK;
 }

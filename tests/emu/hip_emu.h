@@ -38,6 +38,7 @@ struct dim3 {
 };
 struct __attribute__((aligned(16))) uint4 { uint32_t x, y, z, w; };
 struct __attribute__((aligned(16))) double2 { double x, y; };
+struct __attribute__((aligned(16))) longlong2 { long long x, y; };
 struct __attribute__((aligned(8))) float2 { float x, y; };
 struct __attribute__((aligned(8))) uint2 { uint32_t x, y; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
