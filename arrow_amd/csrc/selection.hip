@@ -666,6 +666,47 @@ __global__ __launch_bounds__(kBlock) void compact_sparse_kernel(CompactArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ expand (the inverse of a DROP filter)
+// out[r] = mask[r] ? dense[rank(r)] : 0, where rank(r) = number of set mask bits before r: what a
+// Parquet reader does when it spreads the non-null values of an optional column over their slots
+// (DefLevelsToBitmap + the "spaced" decode, cpp/src/parquet/level_conversion.cc, decoder.cc).
+// Same tiling and the same count / scan workspace as the compaction; one wave per 4096-row tile,
+// word-by-word so that stores are dense and the gathers from `dense` monotonic.
+template <int W>
+__global__ __launch_bounds__(kBlock) void expand_kernel(CompactArgs a) {
+  using E = typename ElemT<W>::type;
+  __shared__ uint64_t words[kWavesPerBlock][64];
+  __shared__ uint32_t before[kWavesPerBlock][64];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  if (t >= a.ntiles) return;  // wave-uniform; no workgroup barrier below
+  uint64_t mv;
+  const uint64_t mw = emit_word(a.mask, a.mvalid, t * 64 + lane, false, false, &mv);
+  const uint32_t k = __popcll(mw);
+  const uint32_t incl = wave_inclusive_scan_u32(k);
+  words[wave][lane] = mw;
+  before[wave][lane] = incl - k;
+  const int64_t grp = t >> 6;
+  const int tin = static_cast<int>(t & 63);
+  const uint32_t cprev = lane < tin ? a.tile_counts[grp * kTilesPerGroup + lane] : 0u;
+  const int64_t off = a.group_excl[grp] + wave_reduce_sum_u32(cprev);
+  wave_lds_sync();
+  const E* __restrict__ dense = reinterpret_cast<const E*>(a.values);
+  E* __restrict__ out = reinterpret_cast<E*>(a.out_data);
+  const int64_t row0 = t * kTileRows;
+  const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll 4
+  for (int j = 0; j < 64; ++j) {
+    const int64_t row = row0 + j * 64 + lane;
+    if (row >= a.length) break;  // lanes drop out only past the end of the array
+    const uint64_t wj = words[wave][j];
+    E e = zero_elem<W>();
+    if ((wj >> lane) & 1ull) e = dense[off + before[wave][j] + __popcll(wj & below)];
+    out[row] = e;
+  }
+}
+
 // ------------------------------------------------------------------ take
 struct TakeArgs {
   const uint8_t* values;   // pre-offset to element 0
@@ -1097,6 +1138,46 @@ int arx_filter_exec(const ArxSpan* values, int byte_width, const ArxSpan* mask, 
   rc = zero_out_validity(out_validity, out_length, st);
   if (rc != ARX_OK) return rc;
   return launch_compact(false, byte_width, a, st, out_length);
+}
+
+int arx_expand_by_mask(const void* dense, int byte_width, const ArxSpan* mask, const void* ws, void* out_data,
+                       void* stream) {
+  int rc = check_mask(mask, ARX_FILTER_DROP);
+  if (rc != ARX_OK) return rc;
+  if (ws == nullptr) {
+    set_error("ws is NULL (run arx_filter_count on the mask first)");
+    return ARX_INVALID;
+  }
+  if (mask->length == 0) return ARX_OK;
+  if (out_data == nullptr || (reinterpret_cast<uint64_t>(out_data) % byte_width) != 0 ||
+      (dense != nullptr && (reinterpret_cast<uint64_t>(dense) % byte_width) != 0)) {
+    set_error("expand: NULL or misaligned buffer");
+    return ARX_INVALID;
+  }
+  FilterWsView v = ws_view(const_cast<void*>(ws), mask->length);
+  CompactArgs a{};
+  a.values = static_cast<const uint8_t*>(dense);
+  a.mask = make_bits(mask->data, mask->offset, mask->length);
+  a.mvalid = make_bits(effective_validity(mask), mask->offset, mask->length);
+  a.length = mask->length;
+  a.ntiles = num_tiles(mask->length);
+  a.tile_counts = v.tile_counts;
+  a.group_excl = v.group_excl;
+  a.out_data = static_cast<uint8_t*>(out_data);
+  const unsigned grid = static_cast<unsigned>(ceil_div(a.ntiles, kWavesPerBlock));
+  hipStream_t st = as_stream(stream);
+  switch (byte_width) {
+    case 1: hipLaunchKernelGGL((expand_kernel<1>), dim3(grid), dim3(kBlock), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((expand_kernel<2>), dim3(grid), dim3(kBlock), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((expand_kernel<4>), dim3(grid), dim3(kBlock), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((expand_kernel<8>), dim3(grid), dim3(kBlock), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((expand_kernel<16>), dim3(grid), dim3(kBlock), 0, st, a); break;
+    default:
+      set_error("unsupported byte width %d for expand", byte_width);
+      return ARX_NOT_IMPLEMENTED;
+  }
+  ARX_CHECK_LAUNCH("expand_kernel");
+  return ARX_OK;
 }
 
 int arx_mask_to_indices(const ArxSpan* mask, int null_selection, const void* ws, int64_t out_length,

@@ -1,0 +1,344 @@
+"""Parquet column chunks decoded into HBM (first slice).
+
+Scope: flat columns of physical type INT32 / INT64 / FLOAT / DOUBLE, required or optional (max
+definition level <= 1, no repetition), data pages V1 and V2, encodings PLAIN and
+PLAIN_DICTIONARY / RLE_DICTIONARY, any page compression pyarrow's codecs can undo.
+
+Division of labour (what the reference does in cpp/src/parquet/column_reader.cc:740-1000 and
+decoder.cc on the CPU):
+  host  : file metadata (pyarrow.parquet metadata API), page headers (Thrift compact protocol,
+          cpp/src/parquet/parquet.thrift:811-845), page decompression, and ONE walk over the
+          variable-length run headers of the RLE / bit-packed hybrids (a few bytes per run);
+  device: definition levels -> validity bitmap, dictionary indices -> values (arx_rle_decode_*,
+          arx_take), and the spreading of the non-null values over their slots
+          (arx_filter_count + arx_expand_by_mask).  Encoded bytes cross PCIe, decoded columns never do.
+One device Array per row group (what pyarrow returns as the chunks of a ChunkedArray)."""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ArrowInvalid, ArrowNotImplementedError, check
+from .array import Array, alloc, bitmap_nbytes, current_stream, default_device, float32, float64, int32, int64, to_device
+
+# parquet.thrift enums
+_PAGE_DATA, _PAGE_INDEX, _PAGE_DICT, _PAGE_DATA_V2 = 0, 1, 2, 3
+_ENC_PLAIN, _ENC_PLAIN_DICT, _ENC_RLE, _ENC_BIT_PACKED, _ENC_RLE_DICT = 0, 2, 3, 4, 8
+_PHYSICAL = {"INT32": (int32, np.int32), "INT64": (int64, np.int64), "FLOAT": (float32, np.float32),
+             "DOUBLE": (float64, np.float64)}
+
+RUN_DTYPE = np.dtype([("out_start", "<u4"), ("kind", "<u4"), ("payload", "<u8")])   # struct ArxRleRun
+
+
+# --------------------------------------------------------------------------- Thrift compact protocol
+class _Thrift:
+    """Just enough of the compact protocol (thrift/protocol/TCompactProtocol) to read a PageHeader."""
+
+    def __init__(self, buf, pos=0):
+        self.b, self.p = buf, pos
+
+    def varint(self):
+        r, s = 0, 0
+        while True:
+            c = self.b[self.p]
+            self.p += 1
+            r |= (c & 0x7F) << s
+            if not c & 0x80:
+                return r
+            s += 7
+
+    def zigzag(self):
+        v = self.varint()
+        return (v >> 1) ^ -(v & 1)
+
+    def skip(self, t):
+        if t in (1, 2):
+            return
+        if t == 3:
+            self.p += 1
+        elif t in (4, 5, 6):
+            self.varint()
+        elif t == 7:
+            self.p += 8
+        elif t == 8:
+            n = self.varint()      # (not `self.p += self.varint()`: the left side would be read first)
+            self.p += n
+        elif t in (9, 10):
+            h = self.b[self.p]
+            self.p += 1
+            n = h >> 4
+            if n == 15:
+                n = self.varint()
+            for _ in range(n):
+                self.skip(h & 0x0F)
+        elif t == 11:
+            n = self.varint()
+            if n:
+                kv = self.b[self.p]
+                self.p += 1
+                for _ in range(n):
+                    self.skip(kv >> 4)
+                    self.skip(kv & 0x0F)
+        elif t == 12:
+            self.struct(None)
+        else:
+            raise ArrowInvalid(f"Parquet page header: unknown Thrift type {t}")
+
+    def struct(self, wanted):
+        """Reads one struct; `wanted` maps field id -> 'i' (integer), 'b' (bool) or a nested map."""
+        out, fid = {}, 0
+        while True:
+            h = self.b[self.p]
+            self.p += 1
+            if h == 0:
+                return out
+            t = h & 0x0F
+            fid = fid + (h >> 4) if h >> 4 else self.zigzag()
+            kind = None if wanted is None else wanted.get(fid)
+            if kind == "i" and t in (4, 5, 6):
+                out[fid] = self.zigzag()
+            elif kind == "b" and t in (1, 2):
+                out[fid] = t == 1
+            elif isinstance(kind, dict) and t == 12:
+                out[fid] = self.struct(kind)
+            else:
+                self.skip(t)
+
+
+_PAGE_HEADER = {1: "i", 2: "i", 3: "i",
+                5: {1: "i", 2: "i", 3: "i", 4: "i"},                 # DataPageHeader
+                7: {1: "i", 2: "i"},                                 # DictionaryPageHeader
+                8: {1: "i", 2: "i", 3: "i", 4: "i", 5: "i", 6: "i", 7: "b"}}   # DataPageHeaderV2
+
+
+def read_page_header(buf, pos):
+    """(header dict, position of the page payload)."""
+    t = _Thrift(buf, pos)
+    return t.struct(_PAGE_HEADER), t.p
+
+
+# --------------------------------------------------------------------------- run headers (host walk)
+def scan_rle_runs(data, bit_width: int, num_values: int, out_base: int = 0, byte_base: int = 0):
+    """Walks the run headers of an RLE / bit-packed hybrid block (rle_encoding_internal.h:40-90) until
+    `num_values` values are covered.  Returns (runs, ones): a RUN_DTYPE array whose out_start / payload
+    are shifted by out_base / byte_base (so blocks of several pages can share one table) and, for
+    bit_width == 1, the number of values equal to 1 (the non-null count of a definition-level block)."""
+    mv = memoryview(data)
+    runs, pos, done, ones = [], 0, 0, 0
+    vbytes = (bit_width + 7) // 8
+    while done < num_values:
+        if pos >= len(mv):
+            raise ArrowInvalid("Parquet: RLE block ended before all its values (corrupt data page?)")
+        h, s = 0, 0
+        while True:
+            c = mv[pos]
+            pos += 1
+            h |= (c & 0x7F) << s
+            if not c & 0x80:
+                break
+            s += 7
+        if h & 1:                                  # literal run: (h >> 1) groups of 8 bit-packed values
+            count = (h >> 1) * 8
+            nbytes = (h >> 1) * bit_width
+            runs.append((out_base + done, 1, byte_base + pos))
+            take = min(count, num_values - done)
+            if bit_width == 1:
+                bits = np.unpackbits(np.frombuffer(mv[pos: pos + (take + 7) // 8], dtype=np.uint8), bitorder="little")
+                ones += int(bits[:take].sum())
+            pos += nbytes
+            done += count
+        else:                                      # repeated run
+            count = h >> 1
+            if count == 0:
+                raise ArrowInvalid("Parquet: zero-length RLE run")
+            value = int.from_bytes(mv[pos: pos + vbytes], "little") if vbytes else 0
+            pos += vbytes
+            runs.append((out_base + done, 0, value))
+            if bit_width == 1 and value == 1:
+                ones += min(count, num_values - done)
+            done += count
+    return np.array(runs, dtype=RUN_DTYPE), ones
+
+
+# --------------------------------------------------------------------------- one column chunk
+def _decompress(codec: str, payload, uncompressed_size: int):
+    if codec == "UNCOMPRESSED":
+        return bytes(payload)
+    import pyarrow as pa
+
+    if codec == "LZ4":     # the legacy Hadoop-framed LZ4 of Parquet; pyarrow exposes no stand-alone codec for it
+        raise ArrowNotImplementedError("Parquet: legacy LZ4 (Hadoop framing) pages; LZ4_RAW is supported")
+    return pa.Codec(codec.lower()).decompress(bytes(payload), decompressed_size=uncompressed_size).to_pybytes()
+
+
+def _column_chunk_pages(raw, col):
+    """Yields (header, decompressed payload bytes) for every page of a column chunk; `raw` = the file bytes."""
+    start = col.data_page_offset
+    if col.has_dictionary_page and col.dictionary_page_offset is not None:
+        start = min(start, col.dictionary_page_offset)
+    pos, seen = start, 0
+    while seen < col.num_values:          # (SerializedPageReader::NextPage stops on the value count as well)
+        hdr, body = read_page_header(raw, pos)
+        csize = hdr[3]
+        payload = raw[body: body + csize]
+        pos = body + csize
+        if hdr[1] == _PAGE_DATA:
+            seen += hdr[5][1]
+        elif hdr[1] == _PAGE_DATA_V2:
+            seen += hdr[8][1]
+        yield hdr, payload
+
+
+def _device_runs(runs: np.ndarray, device):
+    return to_device(runs.view(np.uint8) if len(runs) else np.zeros(16, np.uint8), device)
+
+
+def read_column_chunk(raw, col, max_def_level: int, device=None) -> Array:
+    """Decodes one column chunk (all its pages) into a device Array."""
+    device = torch.device(device) if device is not None else default_device()
+    if col.physical_type not in _PHYSICAL:
+        raise ArrowNotImplementedError(f"Parquet physical type {col.physical_type} is not on the gfx950 path")
+    if max_def_level > 1:
+        raise ArrowNotImplementedError("Parquet: nested / repeated columns are not on the gfx950 path")
+    atype, np_dtype = _PHYSICAL[col.physical_type]
+    width = np.dtype(np_dtype).itemsize
+    lib, stream = _lib.get_lib(), current_stream(device)
+    codec = col.compression
+
+    dict_bytes, dict_count = None, 0
+    level_bytes, level_runs = bytearray(), []
+    index_bytes, index_runs, index_width = bytearray(), [], None
+    plain_bytes = bytearray()
+    rows, dense = 0, 0
+    for hdr, payload in _column_chunk_pages(raw, col):
+        ptype = hdr[1]
+        if ptype == _PAGE_DICT:
+            dh = hdr[7]
+            if dh.get(2, _ENC_PLAIN) not in (_ENC_PLAIN, _ENC_PLAIN_DICT):
+                raise ArrowNotImplementedError("Parquet: dictionary page encoding")
+            dict_bytes, dict_count = _decompress(codec, payload, hdr[2]), dh[1]
+            continue
+        if ptype == _PAGE_DATA:
+            dh = hdr[5]
+            nvals, enc = dh[1], dh[2]
+            page = _decompress(codec, payload, hdr[2])
+            pos = 0
+            if max_def_level > 0:
+                if dh[3] != _ENC_RLE:
+                    raise ArrowNotImplementedError("Parquet: BIT_PACKED definition levels")
+                (nbytes,) = struct.unpack_from("<i", page, 0)      # LevelDecoder::SetData, column_reader.cc:139
+                levels = page[4: 4 + nbytes]
+                pos = 4 + nbytes
+        elif ptype == _PAGE_DATA_V2:
+            dh = hdr[8]
+            nvals, enc = dh[1], dh[4]
+            dl, rl = dh.get(5, 0), dh.get(6, 0)
+            if rl:
+                raise ArrowNotImplementedError("Parquet: repetition levels")
+            levels = bytes(payload[:dl])                              # V2 levels are never compressed
+            body = payload[dl:]
+            page = _decompress(codec, body, hdr[2] - dl) if dh.get(7, True) else bytes(body)
+            pos = 0
+        else:
+            continue                                                  # index pages etc.
+        valid_here = nvals
+        if max_def_level > 0:
+            runs, ones = scan_rle_runs(levels, 1, nvals, out_base=rows, byte_base=len(level_bytes))
+            level_runs.append(runs)
+            level_bytes += levels
+            valid_here = ones
+        values = page[pos:]
+        if enc in (_ENC_PLAIN_DICT, _ENC_RLE_DICT):
+            bw = values[0] if len(values) else 0
+            if index_width is None:
+                index_width = bw
+            if valid_here:
+                runs, _ = scan_rle_runs(values[1:], bw, valid_here, out_base=dense, byte_base=len(index_bytes))
+                # every page may use its own bit width: keep it per run in the high half of `kind`
+                runs["kind"] |= np.uint32(bw << 8)
+                index_runs.append(runs)
+                index_bytes += values[1:]
+        elif enc == _ENC_PLAIN:
+            plain_bytes += values[: valid_here * width]
+        else:
+            raise ArrowNotImplementedError(f"Parquet encoding {enc} is not on the gfx950 path")
+        rows += nvals
+        dense += valid_here
+
+    if index_runs and len(plain_bytes):
+        raise ArrowNotImplementedError("Parquet: a column chunk mixing dictionary and PLAIN data pages")
+
+    # ---- dense values in HBM
+    if index_runs:
+        widths = {int(r["kind"][0]) >> 8 for r in index_runs}
+        if len(widths) != 1:
+            raise ArrowNotImplementedError("Parquet: dictionary index bit width changes between pages")
+        bw = widths.pop()
+        runs = np.concatenate(index_runs)
+        runs["kind"] &= np.uint32(0xFF)
+        d_bytes = to_device(np.frombuffer(bytes(index_bytes) or b"\0", dtype=np.uint8), device)
+        d_runs = _device_runs(runs, device)
+        idx = alloc(dense * 4, device)
+        check(lib.arx_rle_decode_u32(d_bytes.data_ptr(), len(index_bytes), d_runs.data_ptr(), len(runs), bw, dense,
+                                     idx.data_ptr(), stream))
+        d_dict = to_device(np.frombuffer(dict_bytes[: dict_count * width], dtype=np.uint8), device)
+        dvals = Array(atype, dict_count, [None, d_dict], 0, 0)
+        didx = Array(_lib_uint32(), dense, [None, idx], 0, 0)
+        from . import compute as cp
+
+        dense_arr = cp.take(dvals, didx, boundscheck=True)          # a corrupt index fails like the reference's bounds check
+        dense_buf = dense_arr.data
+    else:
+        dense_buf = to_device(np.frombuffer(bytes(plain_bytes) or b"\0" * width, dtype=np.uint8), device)
+
+    if max_def_level == 0 or dense == rows:
+        if max_def_level == 0 or rows == 0:
+            return Array(atype, rows, [None, dense_buf], 0, 0)
+        return Array(atype, rows, [None, dense_buf], 0, 0)          # optional column without a single null
+    # ---- validity bitmap from the definition levels, then spread the dense values over their slots
+    runs = np.concatenate(level_runs)
+    d_lbytes = to_device(np.frombuffer(bytes(level_bytes) or b"\0", dtype=np.uint8), device)
+    d_lruns = _device_runs(runs, device)
+    validity = alloc(bitmap_nbytes(rows), device, zero=True)
+    check(lib.arx_rle_decode_equals_bitmap(d_lbytes.data_ptr(), len(level_bytes), d_lruns.data_ptr(), len(runs), 1,
+                                           rows, max_def_level, validity.data_ptr(), stream))
+    mask = _lib.ArxSpan(None, validity.data_ptr(), 0, rows, 0)
+    ws = alloc(lib.arx_filter_workspace_bytes(rows) + 64, device)
+    cnt = C.c_int64(0)
+    check(lib.arx_filter_count(C.byref(mask), _lib.FILTER_DROP, ws.data_ptr(), ws.numel(), C.byref(cnt), stream))
+    if cnt.value != dense:
+        raise ArrowInvalid(f"Parquet: {cnt.value} non-null definition levels but {dense} values (corrupt page?)")
+    out = alloc(rows * width, device)
+    check(lib.arx_expand_by_mask(dense_buf.data_ptr(), width, C.byref(mask), ws.data_ptr(), out.data_ptr(), stream))
+    return Array(atype, rows, [validity, out], rows - dense, 0)
+
+
+def _lib_uint32():
+    from .array import uint32
+
+    return uint32
+
+
+def read_table(path: str, columns=None, device=None) -> dict:
+    """{column name: [device Array per row group]} for the flat numeric columns of a Parquet file."""
+    import pyarrow.parquet as pq
+
+    pf = pq.ParquetFile(path)
+    md = pf.metadata
+    with open(path, "rb") as f:
+        raw = f.read()
+    names = [md.schema.column(i).path for i in range(md.num_columns)]
+    wanted = names if columns is None else list(columns)
+    out = {}
+    for name in wanted:
+        ci = names.index(name)
+        max_def = md.schema.column(ci).max_definition_level
+        if md.schema.column(ci).max_repetition_level:
+            raise ArrowNotImplementedError("Parquet: repeated columns are not on the gfx950 path")
+        out[name] = [read_column_chunk(raw, md.row_group(rg).column(ci), max_def, device)
+                     for rg in range(md.num_row_groups)]
+    return out

@@ -473,6 +473,31 @@ int arx_hash_sum_i64_finalize(const int64_t* counts, const uint32_t* null_seen, 
                               int skip_nulls, uint32_t min_count, void* out_validity,
                               int64_t* valid_count, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Parquet page decode (first slice): the RLE / bit-packed hybrid of definition
+ * levels and dictionary indices — RleBitPackedDecoder, cpp/src/arrow/util/rle_encoding_internal.h:
+ * 40-90,462-; LevelDecoder::SetData, cpp/src/parquet/column_reader.cc:128-172.  The caller walks the
+ * (sequential, variable-length) run headers once on the host and passes a run table in device memory:
+ * out_start = index of the run's first value, kind 0 = repeated run (payload = the value), 1 = literal
+ * run (payload = byte offset of its first bit-packed group inside `bytes`).  Asynchronous.
+ *   arx_rle_decode_u32           : out[i] = value i                       (dictionary indices)
+ *   arx_rle_decode_equals_bitmap : bit i = (value i == equals), LSB-first (def levels -> validity)
+ * arx_expand_by_mask spreads `dense` (one element per set mask bit) over the mask's slots, zero
+ * elsewhere — the inverse of a DROP filter; ws = the workspace arx_filter_count filled for this
+ * mask (ARX_FILTER_DROP).  What the reader's "spaced" decode does for optional columns.
+ * ------------------------------------------------------------------------- */
+typedef struct ArxRleRun {
+  uint32_t out_start;
+  uint32_t kind;
+  uint64_t payload;
+} ArxRleRun;
+int arx_rle_decode_u32(const void* bytes, size_t nbytes, const ArxRleRun* runs, int64_t nruns, int bit_width,
+                       int64_t num_values, uint32_t* out, void* stream);
+int arx_rle_decode_equals_bitmap(const void* bytes, size_t nbytes, const ArxRleRun* runs, int64_t nruns,
+                                 int bit_width, int64_t num_values, uint32_t equals, void* out_bits, void* stream);
+int arx_expand_by_mask(const void* dense, int byte_width, const ArxSpan* mask, const void* ws, void* out_data,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -428,6 +428,69 @@ def dictionary_encode_i32(values, valid_bitmap, offset, length, encode_nulls=Fal
     return idx, idx_valid, np.array(dvals, np.int32), np.array(dvalid, bool)
 
 
+def rle_hybrid_encode(values, bit_width: int) -> bytes:
+    """A small writer of the RLE / bit-packed hybrid (rle_encoding_internal.h:40-90) for tests: runs of
+    >= 8 equal values become repeated runs, everything else literal runs of 8-value groups."""
+    v = [int(x) for x in values]
+    out = bytearray()
+
+    def varint(x):
+        while x >= 0x80:
+            out.append((x & 0x7F) | 0x80)
+            x >>= 7
+        out.append(x)
+
+    i, n, lit = 0, len(v), []
+
+    def flush_literals():
+        nonlocal lit
+        while lit:
+            groups = min((len(lit) + 7) // 8, 63)
+            chunk, lit = lit[: groups * 8], lit[groups * 8:]
+            chunk = chunk + [0] * (groups * 8 - len(chunk))
+            varint((groups << 1) | 1)
+            acc, nbits = 0, 0
+            for x in chunk:
+                acc |= x << nbits
+                nbits += bit_width
+            out.extend(acc.to_bytes(groups * bit_width, "little"))
+
+    while i < n:
+        j = i
+        while j < n and v[j] == v[i]:
+            j += 1
+        if j - i >= 8 and len(lit) % 8 == 0:
+            flush_literals()
+            varint((j - i) << 1)
+            out.extend(v[i].to_bytes((bit_width + 7) // 8, "little"))
+            i = j
+        else:
+            lit.append(v[i])
+            i += 1
+    flush_literals()
+    return bytes(out)
+
+
+def rle_hybrid_decode(data: bytes, runs, bit_width: int, num_values: int) -> np.ndarray:
+    """Value i of an RLE / bit-packed hybrid block given its run table (out_start, kind, payload):
+    repeated run -> the payload; literal run -> bits [k*bit_width, (k+1)*bit_width) after the run's
+    first byte, LSB first (RleBitPackedDecoder + BitReader, rle_encoding_internal.h, bit_stream_utils_internal.h).
+    Row-at-a-time restatement of what arx_rle_decode_u32 computes."""
+    out = np.zeros(num_values, dtype=np.uint32)
+    big = int.from_bytes(data, "little")
+    starts = [int(r["out_start"]) for r in runs]
+    import bisect
+
+    for i in range(num_values):
+        r = runs[bisect.bisect_right(starts, i) - 1]
+        if int(r["kind"]) == 0:
+            out[i] = int(r["payload"])
+        else:
+            bit = int(r["payload"]) * 8 + (i - int(r["out_start"])) * bit_width
+            out[i] = (big >> bit) & ((1 << bit_width) - 1)
+    return out
+
+
 class HashSumState:
     """GroupedReducingAggregator<Int64Type, GroupedSumImpl> with dense group ids:
     resize / consume / merge / finalize (hash_aggregate_numeric.cc:61-152)."""
