@@ -28,7 +28,10 @@ __device__ __forceinline__ uint32_t rle_value_at(const uint8_t* __restrict__ byt
     if (static_cast<int64_t>(runs[mid].out_start) <= i) lo = mid; else hi = mid;
   }
   const ArxRleRun r = runs[lo];
-  if (r.kind == 0) return static_cast<uint32_t>(r.payload);
+  if ((r.kind & 0xFFu) == 0) return static_cast<uint32_t>(r.payload);
+  // a run may carry its own bit width in bits 8.. of `kind`: the pages of one column chunk are decoded by
+  // one launch, and a growing dictionary gives later pages wider indices
+  if ((r.kind >> 8) != 0) bit_width = static_cast<int>(r.kind >> 8);
   const uint64_t bit = static_cast<uint64_t>(i - r.out_start) * static_cast<uint64_t>(bit_width);
   const uint64_t b0 = r.payload + (bit >> 3);
   uint64_t acc = 0;
@@ -82,6 +85,73 @@ static int rle_check(const void* bytes, const ArxRleRun* runs, int64_t nruns, in
 using namespace arx;
 
 extern "C" {
+
+// Host-side walk over the run headers (no device work): the only sequential part of the hybrid.
+int arx_rle_scan_runs(const void* data, size_t nbytes, int bit_width, int64_t num_values, uint32_t out_base,
+                      uint64_t byte_base, ArxRleRun* runs, int64_t max_runs, int64_t* num_runs, int64_t* ones) {
+  if (num_values < 0 || bit_width < 0 || bit_width > 32 || num_runs == nullptr || (num_values > 0 && data == nullptr)) {
+    set_error("bad arguments to arx_rle_scan_runs");
+    return ARX_INVALID;
+  }
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  const int vbytes = (bit_width + 7) / 8;
+  size_t pos = 0;
+  int64_t done = 0, nr = 0, count_ones = 0;
+  while (done < num_values) {
+    uint64_t h = 0;
+    int shift = 0;
+    for (;;) {
+      if (pos >= nbytes || shift > 56) {
+        set_error("Parquet: RLE block ended before all its values (corrupt data page?)");
+        return ARX_INVALID;
+      }
+      const uint8_t c = p[pos++];
+      h |= static_cast<uint64_t>(c & 0x7F) << shift;
+      if ((c & 0x80) == 0) break;
+      shift += 7;
+    }
+    if (runs != nullptr && nr >= max_runs) {
+      set_error("arx_rle_scan_runs: more than %lld runs", static_cast<long long>(max_runs));
+      return ARX_INVALID;
+    }
+    if (h & 1) {  // literal run: (h >> 1) groups of 8 bit-packed values
+      const int64_t groups = static_cast<int64_t>(h >> 1);
+      const int64_t count = groups * 8;
+      const size_t lbytes = static_cast<size_t>(groups) * bit_width;
+      if (groups == 0 || pos + lbytes > nbytes + 8) {  // (the last group may be cut short by some writers)
+        set_error("Parquet: literal run exceeds the RLE block (corrupt data page?)");
+        return ARX_INVALID;
+      }
+      if (runs != nullptr) runs[nr] = ArxRleRun{static_cast<uint32_t>(out_base + done), 1u, byte_base + pos};
+      if (ones != nullptr && bit_width == 1) {
+        const int64_t take = std::min<int64_t>(count, num_values - done);
+        for (int64_t b = 0; b < take; b += 8) {
+          uint8_t byte = (pos + (b >> 3)) < nbytes ? p[pos + (b >> 3)] : 0;
+          if (take - b < 8) byte &= static_cast<uint8_t>((1u << (take - b)) - 1u);
+          count_ones += __builtin_popcount(byte);
+        }
+      }
+      pos += lbytes;
+      done += count;
+    } else {  // repeated run
+      const int64_t count = static_cast<int64_t>(h >> 1);
+      if (count == 0 || pos + vbytes > nbytes) {
+        set_error("Parquet: bad repeated run (corrupt data page?)");
+        return ARX_INVALID;
+      }
+      uint64_t value = 0;
+      for (int k = 0; k < vbytes; ++k) value |= static_cast<uint64_t>(p[pos + k]) << (8 * k);
+      pos += vbytes;
+      if (runs != nullptr) runs[nr] = ArxRleRun{static_cast<uint32_t>(out_base + done), 0u, value};
+      if (ones != nullptr && bit_width == 1 && value == 1) count_ones += std::min<int64_t>(count, num_values - done);
+      done += count;
+    }
+    ++nr;
+  }
+  *num_runs = nr;
+  if (ones != nullptr) *ones = count_ones;
+  return ARX_OK;
+}
 
 int arx_rle_decode_u32(const void* bytes, size_t nbytes, const ArxRleRun* runs, int64_t nruns, int bit_width,
                        int64_t num_values, uint32_t* out, void* stream) {

@@ -124,44 +124,21 @@ def read_page_header(buf, pos):
 # --------------------------------------------------------------------------- run headers (host walk)
 def scan_rle_runs(data, bit_width: int, num_values: int, out_base: int = 0, byte_base: int = 0):
     """Walks the run headers of an RLE / bit-packed hybrid block (rle_encoding_internal.h:40-90) until
-    `num_values` values are covered.  Returns (runs, ones): a RUN_DTYPE array whose out_start / payload
-    are shifted by out_base / byte_base (so blocks of several pages can share one table) and, for
-    bit_width == 1, the number of values equal to 1 (the non-null count of a definition-level block)."""
-    mv = memoryview(data)
-    runs, pos, done, ones = [], 0, 0, 0
-    vbytes = (bit_width + 7) // 8
-    while done < num_values:
-        if pos >= len(mv):
-            raise ArrowInvalid("Parquet: RLE block ended before all its values (corrupt data page?)")
-        h, s = 0, 0
-        while True:
-            c = mv[pos]
-            pos += 1
-            h |= (c & 0x7F) << s
-            if not c & 0x80:
-                break
-            s += 7
-        if h & 1:                                  # literal run: (h >> 1) groups of 8 bit-packed values
-            count = (h >> 1) * 8
-            nbytes = (h >> 1) * bit_width
-            runs.append((out_base + done, 1, byte_base + pos))
-            take = min(count, num_values - done)
-            if bit_width == 1:
-                bits = np.unpackbits(np.frombuffer(mv[pos: pos + (take + 7) // 8], dtype=np.uint8), bitorder="little")
-                ones += int(bits[:take].sum())
-            pos += nbytes
-            done += count
-        else:                                      # repeated run
-            count = h >> 1
-            if count == 0:
-                raise ArrowInvalid("Parquet: zero-length RLE run")
-            value = int.from_bytes(mv[pos: pos + vbytes], "little") if vbytes else 0
-            pos += vbytes
-            runs.append((out_base + done, 0, value))
-            if bit_width == 1 and value == 1:
-                ones += min(count, num_values - done)
-            done += count
-    return np.array(runs, dtype=RUN_DTYPE), ones
+    `num_values` values are covered — the host function arx_rle_scan_runs of the library (the walk is
+    sequential and touches a few bytes per run).  Returns (runs, ones): a RUN_DTYPE array whose
+    out_start / payload are shifted by out_base / byte_base (so the pages of a chunk share one table)
+    and, for bit_width == 1, the number of values equal to 1 (the non-null count of a level block)."""
+    lib = _lib.get_lib()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    nbytes = len(buf)
+    ptr = buf.ctypes.data if nbytes else None
+    nr, ones = C.c_int64(0), C.c_int64(0)
+    check(lib.arx_rle_scan_runs(ptr, nbytes, bit_width, num_values, out_base, byte_base, None, 0,
+                                C.byref(nr), C.byref(ones)))                      # pass 1: count
+    runs = np.zeros(max(nr.value, 1), dtype=RUN_DTYPE)
+    check(lib.arx_rle_scan_runs(ptr, nbytes, bit_width, num_values, out_base, byte_base, runs.ctypes.data, nr.value,
+                                C.byref(nr), None))                               # pass 2: fill
+    return runs[: nr.value], ones.value
 
 
 # --------------------------------------------------------------------------- one column chunk
@@ -197,8 +174,12 @@ def _device_runs(runs: np.ndarray, device):
     return to_device(runs.view(np.uint8) if len(runs) else np.zeros(16, np.uint8), device)
 
 
-def read_column_chunk(raw, col, max_def_level: int, device=None) -> Array:
-    """Decodes one column chunk (all its pages) into a device Array."""
+def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | None = None) -> Array:
+    """Decodes one column chunk (all its pages) into a device Array.  `stats` (optional) accumulates
+    host_prep_s: seconds spent on the host before the first device call (headers, decompression, run walk)."""
+    import time
+
+    t_start = time.perf_counter()
     device = torch.device(device) if device is not None else default_device()
     if col.physical_type not in _PHYSICAL:
         raise ArrowNotImplementedError(f"Parquet physical type {col.physical_type} is not on the gfx950 path")
@@ -213,7 +194,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None) -> Array:
     level_bytes, level_runs = bytearray(), []
     index_bytes, index_runs, index_width = bytearray(), [], None
     plain_bytes = bytearray()
-    rows, dense = 0, 0
+    rows, dense, dense_from_dict = 0, 0, 0
     for hdr, payload in _column_chunk_pages(raw, col):
         ptype = hdr[1]
         if ptype == _PAGE_DICT:
@@ -253,15 +234,18 @@ def read_column_chunk(raw, col, max_def_level: int, device=None) -> Array:
             valid_here = ones
         values = page[pos:]
         if enc in (_ENC_PLAIN_DICT, _ENC_RLE_DICT):
+            if len(plain_bytes):
+                raise ArrowNotImplementedError("Parquet: a dictionary-encoded page after a PLAIN page in one column chunk")
             bw = values[0] if len(values) else 0
             if index_width is None:
                 index_width = bw
             if valid_here:
                 runs, _ = scan_rle_runs(values[1:], bw, valid_here, out_base=dense, byte_base=len(index_bytes))
-                # every page may use its own bit width: keep it per run in the high half of `kind`
+                # every page may use its own bit width (a growing dictionary): kept per run in kind >> 8
                 runs["kind"] |= np.uint32(bw << 8)
                 index_runs.append(runs)
                 index_bytes += values[1:]
+            dense_from_dict += valid_here
         elif enc == _ENC_PLAIN:
             plain_bytes += values[: valid_here * width]
         else:
@@ -269,31 +253,31 @@ def read_column_chunk(raw, col, max_def_level: int, device=None) -> Array:
         rows += nvals
         dense += valid_here
 
-    if index_runs and len(plain_bytes):
-        raise ArrowNotImplementedError("Parquet: a column chunk mixing dictionary and PLAIN data pages")
-
-    # ---- dense values in HBM
+    if stats is not None:
+        stats["host_prep_s"] = stats.get("host_prep_s", 0.0) + (time.perf_counter() - t_start)
+        stats["encoded_bytes"] = stats.get("encoded_bytes", 0) + len(level_bytes) + len(index_bytes) + len(plain_bytes) + len(dict_bytes or b"")
+    # ---- dense values in HBM.  A chunk may start dictionary-encoded and fall back to PLAIN once the
+    # dictionary outgrows its page (ColumnWriterImpl::FallbackToPlainEncoding, parquet/column_writer.cc):
+    # the dense buffer is then [values of the dictionary pages][values of the PLAIN pages].
+    dense_buf = alloc(dense * width, device)
     if index_runs:
-        widths = {int(r["kind"][0]) >> 8 for r in index_runs}
-        if len(widths) != 1:
-            raise ArrowNotImplementedError("Parquet: dictionary index bit width changes between pages")
-        bw = widths.pop()
-        runs = np.concatenate(index_runs)
-        runs["kind"] &= np.uint32(0xFF)
+        runs = np.concatenate(index_runs)      # every run carries its page's bit width in kind >> 8
+        bw = 0
         d_bytes = to_device(np.frombuffer(bytes(index_bytes) or b"\0", dtype=np.uint8), device)
         d_runs = _device_runs(runs, device)
-        idx = alloc(dense * 4, device)
-        check(lib.arx_rle_decode_u32(d_bytes.data_ptr(), len(index_bytes), d_runs.data_ptr(), len(runs), bw, dense,
-                                     idx.data_ptr(), stream))
+        idx = alloc(dense_from_dict * 4, device)
+        check(lib.arx_rle_decode_u32(d_bytes.data_ptr(), len(index_bytes), d_runs.data_ptr(), len(runs), bw,
+                                     dense_from_dict, idx.data_ptr(), stream))
         d_dict = to_device(np.frombuffer(dict_bytes[: dict_count * width], dtype=np.uint8), device)
         dvals = Array(atype, dict_count, [None, d_dict], 0, 0)
-        didx = Array(_lib_uint32(), dense, [None, idx], 0, 0)
+        didx = Array(_lib_uint32(), dense_from_dict, [None, idx], 0, 0)
         from . import compute as cp
 
-        dense_arr = cp.take(dvals, didx, boundscheck=True)          # a corrupt index fails like the reference's bounds check
-        dense_buf = dense_arr.data
-    else:
-        dense_buf = to_device(np.frombuffer(bytes(plain_bytes) or b"\0" * width, dtype=np.uint8), device)
+        part = cp.take(dvals, didx, boundscheck=True)               # a corrupt index fails like the reference's bounds check
+        dense_buf[: dense_from_dict * width] = part.data[: dense_from_dict * width]
+    if len(plain_bytes):
+        host = torch.from_numpy(np.frombuffer(bytes(plain_bytes), dtype=np.uint8).copy())
+        dense_buf[dense_from_dict * width: dense * width] = host.to(device)
 
     if max_def_level == 0 or dense == rows:
         if max_def_level == 0 or rows == 0:
@@ -323,7 +307,7 @@ def _lib_uint32():
     return uint32
 
 
-def read_table(path: str, columns=None, device=None) -> dict:
+def read_table(path: str, columns=None, device=None, stats: dict | None = None) -> dict:
     """{column name: [device Array per row group]} for the flat numeric columns of a Parquet file."""
     import pyarrow.parquet as pq
 
@@ -339,6 +323,6 @@ def read_table(path: str, columns=None, device=None) -> dict:
         max_def = md.schema.column(ci).max_definition_level
         if md.schema.column(ci).max_repetition_level:
             raise ArrowNotImplementedError("Parquet: repeated columns are not on the gfx950 path")
-        out[name] = [read_column_chunk(raw, md.row_group(rg).column(ci), max_def, device)
+        out[name] = [read_column_chunk(raw, md.row_group(rg).column(ci), max_def, device, stats)
                      for rg in range(md.num_row_groups)]
     return out

@@ -479,7 +479,8 @@ int arx_hash_sum_i64_finalize(const int64_t* counts, const uint32_t* null_seen, 
  * 40-90,462-; LevelDecoder::SetData, cpp/src/parquet/column_reader.cc:128-172.  The caller walks the
  * (sequential, variable-length) run headers once on the host and passes a run table in device memory:
  * out_start = index of the run's first value, kind 0 = repeated run (payload = the value), 1 = literal
- * run (payload = byte offset of its first bit-packed group inside `bytes`).  Asynchronous.
+ * run (payload = byte offset of its first bit-packed group inside `bytes`); bits 8.. of kind, when
+ * non-zero, override bit_width for that run (pages of one chunk may use different widths).  Asynchronous.
  *   arx_rle_decode_u32           : out[i] = value i                       (dictionary indices)
  *   arx_rle_decode_equals_bitmap : bit i = (value i == equals), LSB-first (def levels -> validity)
  * arx_expand_by_mask spreads `dense` (one element per set mask bit) over the mask's slots, zero
@@ -491,6 +492,12 @@ typedef struct ArxRleRun {
   uint32_t kind;
   uint64_t payload;
 } ArxRleRun;
+/* HOST function (no device work): walks the run headers of one block in host memory and fills the run
+ * table (runs may be NULL to only count: *num_runs, and for bit_width 1 *ones = number of values equal
+ * to 1, i.e. the non-null count of a definition-level block).  out_start / payload are shifted by
+ * out_base / byte_base so that several pages can share one table and one byte buffer. */
+int arx_rle_scan_runs(const void* data, size_t nbytes, int bit_width, int64_t num_values, uint32_t out_base,
+                      uint64_t byte_base, ArxRleRun* runs, int64_t max_runs, int64_t* num_runs, int64_t* ones);
 int arx_rle_decode_u32(const void* bytes, size_t nbytes, const ArxRleRun* runs, int64_t nruns, int bit_width,
                        int64_t num_values, uint32_t* out, void* stream);
 int arx_rle_decode_equals_bitmap(const void* bytes, size_t nbytes, const ArxRleRun* runs, int64_t nruns,

@@ -65,6 +65,33 @@ def test_parquet_decode_emulator(emu_ctx, tmp_path, variant, null_p):
 
 
 @pytest.mark.emu
+@pytest.mark.parametrize("null_p", [0.0, 0.2])
+def test_parquet_dictionary_fallback_to_plain(emu_ctx, tmp_path, null_p):
+    """A chunk whose dictionary outgrows its page: the first data pages are dictionary-encoded, the
+    rest PLAIN (what a 300k-distinct-value int64 column does at the default 1 MiB limit)."""
+    rng = np.random.default_rng(9)
+    n = 12_000
+    t = pa.table({"wide": pa.array(rng.integers(-2**62, 2**62, n), mask=(rng.random(n) < null_p) if null_p else None),
+                  "few": pa.array(rng.integers(0, 7, n))})
+    path = os.path.join(str(tmp_path), "fb.parquet")
+    pq.write_table(t, path, dictionary_pagesize_limit=8192, data_page_size=4096, compression="snappy")
+    col = pq.ParquetFile(path).metadata.row_group(0).column(0)
+    assert "PLAIN" in col.encodings and "RLE_DICTIONARY" in col.encodings
+    check_file(emu_ctx, path)
+
+
+@pytest.mark.emu
+def test_parquet_growing_dictionary_widens_the_indices(emu_ctx, tmp_path):
+    """New values keep arriving, so every page's indices are written with a wider bit width than the
+    page before: one launch decodes runs of different widths."""
+    n = 30_000
+    t = pa.table({"grow": pa.array(np.arange(n) // 4, mask=np.arange(n) % 11 == 0), "one": pa.array(np.zeros(n, dtype=np.int64))})
+    path = os.path.join(str(tmp_path), "grow.parquet")
+    pq.write_table(t, path, data_page_size=1024, compression="none")
+    check_file(emu_ctx, path)
+
+
+@pytest.mark.emu
 def test_parquet_edge_cases_emulator(emu_ctx, tmp_path):
     rng = np.random.default_rng(5)
     for n, null_p in ((0, 0.0), (1, 0.0), (1, 1.0), (70, 1.0), (5000, 0.999)):
@@ -80,6 +107,7 @@ def test_parquet_edge_cases_emulator(emu_ctx, tmp_path):
 @pytest.mark.parametrize("variant", range(len(VARIANTS)))
 @pytest.mark.parametrize("null_p", [0.0, 0.1])
 def test_parquet_decode_gpu(gpu_ctx, tmp_path, variant, null_p):
+    # (600k full-range int64 values also exercise the dictionary -> PLAIN fallback at the 1 MiB limit)
     _write_and_check(gpu_ctx, str(tmp_path), 600_000, null_p, VARIANTS[variant], 200 + variant)
 
 
