@@ -1,8 +1,9 @@
 """Parquet column chunks decoded into HBM (first slice).
 
-Scope: flat columns of physical type INT32 / INT64 / FLOAT / DOUBLE, required or optional (max
-definition level <= 1, no repetition), data pages V1 and V2, encodings PLAIN and
-PLAIN_DICTIONARY / RLE_DICTIONARY, any page compression pyarrow's codecs can undo.
+Scope: flat columns of physical type INT32 / INT64 / FLOAT / DOUBLE (PLAIN and PLAIN_DICTIONARY /
+RLE_DICTIONARY encodings, incl. the dictionary -> PLAIN fallback inside a chunk) and dictionary-encoded
+BYTE_ARRAY columns (utf8 / binary); required or optional (max definition level <= 1, no repetition),
+data pages V1 and V2, any page compression pyarrow's codecs can undo.
 
 Division of labour (what the reference does in cpp/src/parquet/column_reader.cc:740-1000 and
 decoder.cc on the CPU):
@@ -174,19 +175,40 @@ def _device_runs(runs: np.ndarray, device):
     return to_device(runs.view(np.uint8) if len(runs) else np.zeros(16, np.uint8), device)
 
 
-def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | None = None) -> Array:
+def _parse_byte_array_dictionary(page: bytes, count: int):
+    """PLAIN BYTE_ARRAY values (4-byte little-endian length + bytes each, PlainByteArrayDecoder in
+    parquet/decoder.cc) -> (int32 offsets[count + 1], data bytes).  Dictionary pages only: small."""
+    offsets = np.zeros(count + 1, dtype=np.int32)
+    parts, pos, total = [], 0, 0
+    for i in range(count):
+        (ln,) = struct.unpack_from("<i", page, pos)
+        if ln < 0 or pos + 4 + ln > len(page):
+            raise ArrowInvalid("Parquet: byte-array dictionary entry runs past the page (corrupt page?)")
+        parts.append(page[pos + 4: pos + 4 + ln])
+        pos += 4 + ln
+        total += ln
+        offsets[i + 1] = total
+    return offsets, b"".join(parts)
+
+
+def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | None = None,
+                      binary_type=None) -> Array:
     """Decodes one column chunk (all its pages) into a device Array.  `stats` (optional) accumulates
     host_prep_s: seconds spent on the host before the first device call (headers, decompression, run walk)."""
     import time
 
     t_start = time.perf_counter()
     device = torch.device(device) if device is not None else default_device()
-    if col.physical_type not in _PHYSICAL:
+    is_binary = col.physical_type == "BYTE_ARRAY" and binary_type is not None
+    if col.physical_type not in _PHYSICAL and not is_binary:
         raise ArrowNotImplementedError(f"Parquet physical type {col.physical_type} is not on the gfx950 path")
     if max_def_level > 1:
         raise ArrowNotImplementedError("Parquet: nested / repeated columns are not on the gfx950 path")
-    atype, np_dtype = _PHYSICAL[col.physical_type]
-    width = np.dtype(np_dtype).itemsize
+    if is_binary:
+        atype, width = binary_type, 1          # values live in the dictionary; data pages carry indices only
+    else:
+        atype, np_dtype = _PHYSICAL[col.physical_type]
+        width = np.dtype(np_dtype).itemsize
     lib, stream = _lib.get_lib(), current_stream(device)
     codec = col.compression
 
@@ -247,6 +269,9 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
                 index_bytes += values[1:]
             dense_from_dict += valid_here
         elif enc == _ENC_PLAIN:
+            if is_binary:
+                raise ArrowNotImplementedError("Parquet: PLAIN byte-array data pages (length-prefixed values need a "
+                                               "sequential walk); dictionary-encoded string columns are supported")
             plain_bytes += values[: valid_here * width]
         else:
             raise ArrowNotImplementedError(f"Parquet encoding {enc} is not on the gfx950 path")
@@ -256,6 +281,9 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     if stats is not None:
         stats["host_prep_s"] = stats.get("host_prep_s", 0.0) + (time.perf_counter() - t_start)
         stats["encoded_bytes"] = stats.get("encoded_bytes", 0) + len(level_bytes) + len(index_bytes) + len(plain_bytes) + len(dict_bytes or b"")
+    if is_binary:
+        return _finish_binary_chunk(lib, stream, device, atype, dict_bytes, dict_count, index_bytes, index_runs,
+                                    level_bytes, level_runs, rows, dense, max_def_level)
     # ---- dense values in HBM.  A chunk may start dictionary-encoded and fall back to PLAIN once the
     # dictionary outgrows its page (ColumnWriterImpl::FallbackToPlainEncoding, parquet/column_writer.cc):
     # the dense buffer is then [values of the dictionary pages][values of the PLAIN pages].
@@ -301,6 +329,46 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     return Array(atype, rows, [validity, out], rows - dense, 0)
 
 
+def _finish_binary_chunk(lib, stream, device, atype, dict_bytes, dict_count, index_bytes, index_runs, level_bytes,
+                         level_runs, rows, dense, max_def_level) -> Array:
+    """utf8 / binary column whose data pages are dictionary-encoded: indices are decoded (and, for an
+    optional column, spread over their slots with the validity bitmap as their own validity), then one
+    var-width take from the dictionary (arx_binary_take_*) builds offsets, validity and bytes in HBM."""
+    from . import compute as cp
+    from .array import uint32
+
+    offs, data = _parse_byte_array_dictionary(dict_bytes or b"", dict_count)
+    d_offs = to_device(offs, device)
+    d_data = to_device(np.frombuffer(data or b"\0", dtype=np.uint8), device)
+    dvals = Array(atype, dict_count, [None, d_offs, d_data], 0, 0)
+    idx = alloc(max(dense, 1) * 4, device)
+    if dense:
+        runs = np.concatenate(index_runs)
+        d_bytes = to_device(np.frombuffer(bytes(index_bytes) or b"\0", dtype=np.uint8), device)
+        d_runs = _device_runs(runs, device)
+        check(lib.arx_rle_decode_u32(d_bytes.data_ptr(), len(index_bytes), d_runs.data_ptr(), len(runs), 0, dense,
+                                     idx.data_ptr(), stream))
+    if max_def_level == 0 or dense == rows:
+        didx = Array(uint32, rows, [None, idx], 0, 0)
+        return cp.take(dvals, didx, boundscheck=True)
+    runs = np.concatenate(level_runs)
+    d_lbytes = to_device(np.frombuffer(bytes(level_bytes) or b"\0", dtype=np.uint8), device)
+    d_lruns = _device_runs(runs, device)
+    validity = alloc(bitmap_nbytes(rows), device, zero=True)
+    check(lib.arx_rle_decode_equals_bitmap(d_lbytes.data_ptr(), len(level_bytes), d_lruns.data_ptr(), len(runs), 1,
+                                           rows, max_def_level, validity.data_ptr(), stream))
+    mask = _lib.ArxSpan(None, validity.data_ptr(), 0, rows, 0)
+    ws = alloc(lib.arx_filter_workspace_bytes(rows) + 64, device)
+    cnt = C.c_int64(0)
+    check(lib.arx_filter_count(C.byref(mask), _lib.FILTER_DROP, ws.data_ptr(), ws.numel(), C.byref(cnt), stream))
+    if cnt.value != dense:
+        raise ArrowInvalid(f"Parquet: {cnt.value} non-null definition levels but {dense} values (corrupt page?)")
+    full = alloc(rows * 4, device)
+    check(lib.arx_expand_by_mask(idx.data_ptr(), 4, C.byref(mask), ws.data_ptr(), full.data_ptr(), stream))
+    didx = Array(uint32, rows, [validity, full], rows - dense, 0)
+    return cp.take(dvals, didx, boundscheck=True)
+
+
 def _lib_uint32():
     from .array import uint32
 
@@ -323,6 +391,11 @@ def read_table(path: str, columns=None, device=None, stats: dict | None = None) 
         max_def = md.schema.column(ci).max_definition_level
         if md.schema.column(ci).max_repetition_level:
             raise ArrowNotImplementedError("Parquet: repeated columns are not on the gfx950 path")
-        out[name] = [read_column_chunk(raw, md.row_group(rg).column(ci), max_def, device, stats)
+        binary_type = None
+        if md.schema.column(ci).physical_type == "BYTE_ARRAY":
+            from .array import binary, utf8
+
+            binary_type = utf8 if str(md.schema.column(ci).logical_type).upper().startswith("STRING") else binary
+        out[name] = [read_column_chunk(raw, md.row_group(rg).column(ci), max_def, device, stats, binary_type)
                      for rg in range(md.num_row_groups)]
     return out

@@ -26,14 +26,15 @@ def _table(rng, n, null_p):
         "f64": pa.array(np.round(rng.standard_normal(n), 2), mask=m()),
         "f32": pa.array(rng.standard_normal(n).astype(np.float32), mask=m()),
         "req": pa.array(rng.integers(0, 1000, n)),
+        "str": pa.array(np.array(["", "a", "bb", "gfx950", "MI355X", "ünïcödé", "x" * 40], dtype=object)[rng.integers(0, 7, n)], type=pa.string(), mask=m()),
     })
 
 
 VARIANTS = [dict(compression="snappy", data_page_version="1.0", use_dictionary=True),
-            dict(compression="none", data_page_version="1.0", use_dictionary=False),
+            dict(compression="none", data_page_version="1.0", use_dictionary=["str"]),
             dict(compression="zstd", data_page_version="2.0", use_dictionary=True),
-            dict(compression="none", data_page_version="2.0", use_dictionary=False, data_page_size=4096),
-            dict(compression="gzip", data_page_version="1.0", use_dictionary=["i64_few", "i32_runs"], data_page_size=2048)]
+            dict(compression="none", data_page_version="2.0", use_dictionary=["str"], data_page_size=4096),
+            dict(compression="gzip", data_page_version="1.0", use_dictionary=["i64_few", "i32_runs", "str"], data_page_size=2048)]
 
 
 def check_file(amd, path):
@@ -96,10 +97,13 @@ def test_parquet_edge_cases_emulator(emu_ctx, tmp_path):
     rng = np.random.default_rng(5)
     for n, null_p in ((0, 0.0), (1, 0.0), (1, 1.0), (70, 1.0), (5000, 0.999)):
         _write_and_check(emu_ctx, str(tmp_path), n, null_p, VARIANTS[0], n)
-    with pytest.raises(emu_ctx.ArrowNotImplementedError):
+    with pytest.raises(emu_ctx.ArrowNotImplementedError):     # PLAIN (not dictionary-encoded) strings
         path = os.path.join(str(tmp_path), "s.parquet")
-        pq.write_table(pa.table({"s": pa.array(["a", "b"])}), path)
+        pq.write_table(pa.table({"s": pa.array(["a", "b"])}), path, use_dictionary=False)
         emu_ctx.parquet.read_table(path)
+    path = os.path.join(str(tmp_path), "b.parquet")             # binary (not utf8) values, some empty, some null
+    pq.write_table(pa.table({"b": pa.array([b"\x00\x01", None, b"", b"\xff" * 9, None, b"\x00\x01"], pa.binary())}), path)
+    check_file(emu_ctx, path)
     del rng
 
 
