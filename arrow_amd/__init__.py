@@ -4,7 +4,7 @@
 device-resident arrays (`arrow_amd.array.Array`); all compute happens in libarrow_amd.so
 (hand-written HIP kernels behind the C ABI of include/arrow_amd.h).  No CPU fallback exists.
 """
-from . import array, compute, parquet  # noqa: F401
+from . import array, compute, ipc, parquet  # noqa: F401
 from ._lib import (ArrowAmdError, ArrowDeviceError, ArrowIndexError, ArrowInvalid,  # noqa: F401
                    ArrowNotImplementedError)
 from .array import Array, Scalar  # noqa: F401
