@@ -153,6 +153,36 @@ int arx_rle_scan_runs(const void* data, size_t nbytes, int bit_width, int64_t nu
   return ARX_OK;
 }
 
+// Host-side walk over PLAIN BYTE_ARRAY values (4-byte little-endian length + bytes each,
+// PlainByteArrayDecoder, cpp/src/parquet/decoder.cc): writes 2 * count + 1 offsets that describe the
+// block as alternating {length prefix, value} entries, so that a var-width take of the odd entries
+// (arx_binary_take_*) compacts the values on the device.
+int arx_plain_byte_array_offsets(const void* data, size_t nbytes, int64_t count, int32_t base, int32_t* out_offsets) {
+  if (count < 0 || out_offsets == nullptr || (count > 0 && data == nullptr)) {
+    set_error("bad arguments to arx_plain_byte_array_offsets");
+    return ARX_INVALID;
+  }
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  size_t pos = 0;
+  out_offsets[0] = base;
+  for (int64_t i = 0; i < count; ++i) {
+    if (pos + 4 > nbytes) {
+      set_error("Parquet: byte-array value %lld starts past the page (corrupt page?)", static_cast<long long>(i));
+      return ARX_INVALID;
+    }
+    const uint32_t len = static_cast<uint32_t>(p[pos]) | (static_cast<uint32_t>(p[pos + 1]) << 8) |
+                         (static_cast<uint32_t>(p[pos + 2]) << 16) | (static_cast<uint32_t>(p[pos + 3]) << 24);
+    if (len > nbytes - pos - 4 || static_cast<uint64_t>(base) + pos + 4 + len > 2147483647ull) {
+      set_error("Parquet: byte-array value %lld runs past the page or the int32 offset range", static_cast<long long>(i));
+      return ARX_INVALID;
+    }
+    out_offsets[2 * i + 1] = base + static_cast<int32_t>(pos + 4);
+    pos += 4 + len;
+    out_offsets[2 * i + 2] = base + static_cast<int32_t>(pos);
+  }
+  return ARX_OK;
+}
+
 int arx_rle_decode_u32(const void* bytes, size_t nbytes, const ArxRleRun* runs, int64_t nruns, int bit_width,
                        int64_t num_values, uint32_t* out, void* stream) {
   const int rc = rle_check(bytes, runs, nruns, bit_width, num_values);

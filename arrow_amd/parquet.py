@@ -1,8 +1,8 @@
 """Parquet column chunks decoded into HBM (first slice).
 
 Scope: flat columns of physical type INT32 / INT64 / FLOAT / DOUBLE (PLAIN and PLAIN_DICTIONARY /
-RLE_DICTIONARY encodings, incl. the dictionary -> PLAIN fallback inside a chunk) and dictionary-encoded
-BYTE_ARRAY columns (utf8 / binary); required or optional (max definition level <= 1, no repetition),
+RLE_DICTIONARY encodings, incl. the dictionary -> PLAIN fallback inside a chunk) and BYTE_ARRAY columns
+(utf8 / binary; dictionary-encoded and PLAIN pages); required or optional (max definition level <= 1, no repetition),
 data pages V1 and V2, any page compression pyarrow's codecs can undo.
 
 Division of labour (what the reference does in cpp/src/parquet/column_reader.cc:740-1000 and
@@ -216,6 +216,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     level_bytes, level_runs = bytearray(), []
     index_bytes, index_runs, index_width = bytearray(), [], None
     plain_bytes = bytearray()
+    plain_pages = []          # BYTE_ARRAY only: (page value bytes, number of values)
     rows, dense, dense_from_dict = 0, 0, 0
     for hdr, payload in _column_chunk_pages(raw, col):
         ptype = hdr[1]
@@ -256,7 +257,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
             valid_here = ones
         values = page[pos:]
         if enc in (_ENC_PLAIN_DICT, _ENC_RLE_DICT):
-            if len(plain_bytes):
+            if len(plain_bytes) or plain_pages:
                 raise ArrowNotImplementedError("Parquet: a dictionary-encoded page after a PLAIN page in one column chunk")
             bw = values[0] if len(values) else 0
             if index_width is None:
@@ -270,9 +271,9 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
             dense_from_dict += valid_here
         elif enc == _ENC_PLAIN:
             if is_binary:
-                raise ArrowNotImplementedError("Parquet: PLAIN byte-array data pages (length-prefixed values need a "
-                                               "sequential walk); dictionary-encoded string columns are supported")
-            plain_bytes += values[: valid_here * width]
+                plain_pages.append((bytes(values), valid_here))      # offsets are built once the dictionary size is known
+            else:
+                plain_bytes += values[: valid_here * width]
         else:
             raise ArrowNotImplementedError(f"Parquet encoding {enc} is not on the gfx950 path")
         rows += nvals
@@ -283,7 +284,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
         stats["encoded_bytes"] = stats.get("encoded_bytes", 0) + len(level_bytes) + len(index_bytes) + len(plain_bytes) + len(dict_bytes or b"")
     if is_binary:
         return _finish_binary_chunk(lib, stream, device, atype, dict_bytes, dict_count, index_bytes, index_runs,
-                                    level_bytes, level_runs, rows, dense, max_def_level)
+                                    level_bytes, level_runs, rows, dense, max_def_level, dense_from_dict, plain_pages)
     # ---- dense values in HBM.  A chunk may start dictionary-encoded and fall back to PLAIN once the
     # dictionary outgrows its page (ColumnWriterImpl::FallbackToPlainEncoding, parquet/column_writer.cc):
     # the dense buffer is then [values of the dictionary pages][values of the PLAIN pages].
@@ -330,24 +331,44 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
 
 
 def _finish_binary_chunk(lib, stream, device, atype, dict_bytes, dict_count, index_bytes, index_runs, level_bytes,
-                         level_runs, rows, dense, max_def_level) -> Array:
-    """utf8 / binary column whose data pages are dictionary-encoded: indices are decoded (and, for an
-    optional column, spread over their slots with the validity bitmap as their own validity), then one
-    var-width take from the dictionary (arx_binary_take_*) builds offsets, validity and bytes in HBM."""
+                         level_runs, rows, dense, max_def_level, dense_from_dict, plain_pages) -> Array:
+    """utf8 / binary column.  All values are gathered from ONE var-width "source" array by one take
+    (arx_binary_take_*), which builds offsets, validity and bytes in HBM:
+      * dictionary-encoded pages: source entries = the dictionary, indices = the decoded RLE indices;
+      * PLAIN pages (also after a dictionary -> PLAIN fallback): the page bytes are appended to the
+        source as alternating {4-byte length prefix, value} entries (offsets from one host walk,
+        arx_plain_byte_array_offsets) and the indices are simply the odd entries.
+    For an optional column the dense indices are first spread over their slots with the validity
+    bitmap (which becomes the indices' validity)."""
     from . import compute as cp
     from .array import uint32
 
     offs, data = _parse_byte_array_dictionary(dict_bytes or b"", dict_count)
-    d_offs = to_device(offs, device)
-    d_data = to_device(np.frombuffer(data or b"\0", dtype=np.uint8), device)
-    dvals = Array(atype, dict_count, [None, d_offs, d_data], 0, 0)
+    entries = dict_count
+    off_parts, data_parts, base = [offs], [data], len(data)
+    for page, count in plain_pages:
+        o = np.zeros(2 * count + 1, dtype=np.int32)
+        buf = np.frombuffer(page, dtype=np.uint8)
+        check(lib.arx_plain_byte_array_offsets(buf.ctypes.data if len(buf) else None, len(buf), count, base,
+                                               o.ctypes.data))
+        used = int(o[-1]) - base
+        off_parts.append(o[1:])
+        data_parts.append(page[:used])
+        base += used
+    d_offs = to_device(np.concatenate(off_parts), device)
+    d_data = to_device(np.frombuffer(b"".join(data_parts) or b"\0", dtype=np.uint8), device)
+    total_entries = entries + 2 * sum(c for _, c in plain_pages)
+    dvals = Array(atype, total_entries, [None, d_offs, d_data], 0, 0)
     idx = alloc(max(dense, 1) * 4, device)
-    if dense:
+    if dense_from_dict:
         runs = np.concatenate(index_runs)
         d_bytes = to_device(np.frombuffer(bytes(index_bytes) or b"\0", dtype=np.uint8), device)
         d_runs = _device_runs(runs, device)
-        check(lib.arx_rle_decode_u32(d_bytes.data_ptr(), len(index_bytes), d_runs.data_ptr(), len(runs), 0, dense,
-                                     idx.data_ptr(), stream))
+        check(lib.arx_rle_decode_u32(d_bytes.data_ptr(), len(index_bytes), d_runs.data_ptr(), len(runs), 0,
+                                     dense_from_dict, idx.data_ptr(), stream))
+    if dense > dense_from_dict:      # PLAIN values: the odd entries after the dictionary, in page order
+        odd = torch.arange(entries + 1, entries + 1 + 2 * (dense - dense_from_dict), 2, dtype=torch.int32, device=device)
+        idx[dense_from_dict * 4: dense * 4] = odd.view(torch.uint8)
     if max_def_level == 0 or dense == rows:
         didx = Array(uint32, rows, [None, idx], 0, 0)
         return cp.take(dvals, didx, boundscheck=True)

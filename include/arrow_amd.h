@@ -498,6 +498,10 @@ typedef struct ArxRleRun {
  * out_base / byte_base so that several pages can share one table and one byte buffer. */
 int arx_rle_scan_runs(const void* data, size_t nbytes, int bit_width, int64_t num_values, uint32_t out_base,
                       uint64_t byte_base, ArxRleRun* runs, int64_t max_runs, int64_t* num_runs, int64_t* ones);
+/* HOST function: PLAIN BYTE_ARRAY values (4-byte length + bytes each; PlainByteArrayDecoder,
+ * cpp/src/parquet/decoder.cc) described as 2 * count + 1 int32 offsets of alternating {length prefix,
+ * value} entries (shifted by `base`), so that a var-width take of the odd entries compacts the values. */
+int arx_plain_byte_array_offsets(const void* data, size_t nbytes, int64_t count, int32_t base, int32_t* out_offsets);
 int arx_rle_decode_u32(const void* bytes, size_t nbytes, const ArxRleRun* runs, int64_t nruns, int bit_width,
                        int64_t num_values, uint32_t* out, void* stream);
 int arx_rle_decode_equals_bitmap(const void* bytes, size_t nbytes, const ArxRleRun* runs, int64_t nruns,

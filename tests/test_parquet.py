@@ -31,7 +31,7 @@ def _table(rng, n, null_p):
 
 
 VARIANTS = [dict(compression="snappy", data_page_version="1.0", use_dictionary=True),
-            dict(compression="none", data_page_version="1.0", use_dictionary=["str"]),
+            dict(compression="none", data_page_version="1.0", use_dictionary=False),
             dict(compression="zstd", data_page_version="2.0", use_dictionary=True),
             dict(compression="none", data_page_version="2.0", use_dictionary=["str"], data_page_size=4096),
             dict(compression="gzip", data_page_version="1.0", use_dictionary=["i64_few", "i32_runs", "str"], data_page_size=2048)]
@@ -82,6 +82,27 @@ def test_parquet_dictionary_fallback_to_plain(emu_ctx, tmp_path, null_p):
 
 
 @pytest.mark.emu
+@pytest.mark.parametrize("null_p", [0.0, 0.25])
+def test_parquet_plain_and_fallback_strings(emu_ctx, tmp_path, null_p):
+    """PLAIN byte-array pages (length-prefixed values), alone and after a dictionary -> PLAIN fallback:
+    the page bytes become alternating {prefix, value} entries of the take's source array."""
+    rng = np.random.default_rng(13)
+    n = 9000
+    words = np.array([("w%d" % i) * (i % 5) for i in range(n)], dtype=object)        # many distinct values, some empty
+    mask = (rng.random(n) < null_p) if null_p else None
+    t = pa.table({"s": pa.array(words[rng.integers(0, n, n)], type=pa.string(), mask=mask),
+                  "b": pa.array([bytes([i % 251]) * (i % 7) for i in range(n)], type=pa.binary(), mask=mask)})
+    plain = os.path.join(str(tmp_path), "plain.parquet")
+    pq.write_table(t, plain, use_dictionary=False, data_page_size=2048, compression="snappy", row_group_size=5000)
+    check_file(emu_ctx, plain)
+    fb = os.path.join(str(tmp_path), "fallback.parquet")
+    pq.write_table(t, fb, dictionary_pagesize_limit=4096, data_page_size=2048, compression="zstd", data_page_version="2.0")
+    enc = pq.ParquetFile(fb).metadata.row_group(0).column(0).encodings
+    assert "PLAIN" in enc and "RLE_DICTIONARY" in enc
+    check_file(emu_ctx, fb)
+
+
+@pytest.mark.emu
 def test_parquet_growing_dictionary_widens_the_indices(emu_ctx, tmp_path):
     """New values keep arriving, so every page's indices are written with a wider bit width than the
     page before: one launch decodes runs of different widths."""
@@ -97,9 +118,9 @@ def test_parquet_edge_cases_emulator(emu_ctx, tmp_path):
     rng = np.random.default_rng(5)
     for n, null_p in ((0, 0.0), (1, 0.0), (1, 1.0), (70, 1.0), (5000, 0.999)):
         _write_and_check(emu_ctx, str(tmp_path), n, null_p, VARIANTS[0], n)
-    with pytest.raises(emu_ctx.ArrowNotImplementedError):     # PLAIN (not dictionary-encoded) strings
-        path = os.path.join(str(tmp_path), "s.parquet")
-        pq.write_table(pa.table({"s": pa.array(["a", "b"])}), path, use_dictionary=False)
+    with pytest.raises(emu_ctx.ArrowNotImplementedError):     # nested columns are out of scope
+        path = os.path.join(str(tmp_path), "l.parquet")
+        pq.write_table(pa.table({"l": pa.array([[1, 2], [3]])}), path)
         emu_ctx.parquet.read_table(path)
     path = os.path.join(str(tmp_path), "b.parquet")             # binary (not utf8) values, some empty, some null
     pq.write_table(pa.table({"b": pa.array([b"\x00\x01", None, b"", b"\xff" * 9, None, b"\x00\x01"], pa.binary())}), path)
