@@ -214,7 +214,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
 
     dict_bytes, dict_count = None, 0
     level_bytes, level_runs = bytearray(), []
-    index_bytes, index_runs, index_width = bytearray(), [], None
+    index_bytes, index_runs = bytearray(), []
     plain_bytes = bytearray()
     plain_pages = []          # BYTE_ARRAY only: (page value bytes, number of values)
     rows, dense, dense_from_dict = 0, 0, 0
@@ -260,8 +260,6 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
             if len(plain_bytes) or plain_pages:
                 raise ArrowNotImplementedError("Parquet: a dictionary-encoded page after a PLAIN page in one column chunk")
             bw = values[0] if len(values) else 0
-            if index_width is None:
-                index_width = bw
             if valid_here:
                 runs, _ = scan_rle_runs(values[1:], bw, valid_here, out_base=dense, byte_base=len(index_bytes))
                 # every page may use its own bit width (a growing dictionary): kept per run in kind >> 8
@@ -308,10 +306,8 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
         host = torch.from_numpy(np.frombuffer(bytes(plain_bytes), dtype=np.uint8).copy())
         dense_buf[dense_from_dict * width: dense * width] = host.to(device)
 
-    if max_def_level == 0 or dense == rows:
-        if max_def_level == 0 or rows == 0:
-            return Array(atype, rows, [None, dense_buf], 0, 0)
-        return Array(atype, rows, [None, dense_buf], 0, 0)          # optional column without a single null
+    if max_def_level == 0 or dense == rows:                         # required column, or optional without a single null
+        return Array(atype, rows, [None, dense_buf], 0, 0)
     # ---- validity bitmap from the definition levels, then spread the dense values over their slots
     runs = np.concatenate(level_runs)
     d_lbytes = to_device(np.frombuffer(bytes(level_bytes) or b"\0", dtype=np.uint8), device)
