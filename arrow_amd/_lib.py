@@ -104,6 +104,7 @@ SIGNATURES = {
     "arx_take_workspace_bytes": (_sz, []),
     "arx_check_index_bounds": (_int, [_span, _int, _u64, _p, _sz, _p]),
     "arx_take": (_int, [_span, _int, _span, _int, _p, _p, _p, _p]),
+    "arx_take_bits": (_int, [_span, _span, _int, _p, _p, _p, _p]),
     "arx_binary_take_workspace_bytes": (_sz, [_i64]),
     "arx_binary_take_offsets": (_int, [_bspan, _span, _int, _p, _sz, _p, _p, _p, C.POINTER(_i64), _p]),
     "arx_binary_take_data": (_int, [_bspan, _i64, _p, _sz, _p, _i64, _p, _p]),

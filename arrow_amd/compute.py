@@ -138,8 +138,8 @@ def _exec_array_filter(args, options):
     options = options or FilterOptions()
     if mask.type != bool_:
         raise ArrowNotImplementedError("filter: the selection must be a boolean array")
-    if values.type.bit_width < 8:
-        raise ArrowNotImplementedError("filter on boolean values is not on the gfx950 path yet")
+    if values.type == bool_:
+        return _exec_boolean_filter(args, options)
     if values.length != mask.length:  # ExecSpanIterator::Init, exec.cc:349-355
         raise ArrowInvalid("Array arguments must all be the same length")
     dev = values.device
@@ -210,12 +210,12 @@ def _exec_array_take(args, options):
     options = options or TakeOptions()
     if indices.type.name not in INDEX_TYPE_ID:
         raise ArrowNotImplementedError(f"take: unsupported index type {indices.type.name}")
-    if values.type.bit_width < 8:
-        raise ArrowNotImplementedError("take on boolean values is not on the gfx950 path yet")
     dev = values.device
     lib, stream = _lib_and_stream(dev)
     tid = INDEX_TYPE_ID[indices.type.name]
     ispan, vspan = indices.span(), values.span()
+    if values.type == bool_:
+        return _take_boolean(values, indices, options, lib, stream, tid, ispan, vspan)
     if options.boundscheck:
         ws = _workspace(dev, lib.arx_take_workspace_bytes(), "take")
         check(lib.arx_check_index_bounds(C.byref(ispan), tid, values.length, ws.data_ptr(), ws.numel(),
@@ -236,6 +236,36 @@ def _exec_array_take(args, options):
     if allocate_validity:
         out.set_lazy_null_count(_LazyCount(m, counter))
     return out
+
+
+def _take_boolean(values, indices, options, lib, stream, tid, ispan, vspan):
+    """Take on bit-packed boolean values (the 1-bit Gather of gather_internal.h)."""
+    dev = values.device
+    if options.boundscheck:
+        ws = _workspace(dev, lib.arx_take_workspace_bytes(), "take")
+        check(lib.arx_check_index_bounds(C.byref(ispan), tid, values.length, ws.data_ptr(), ws.numel(), stream))
+    m = indices.length
+    allocate_validity = values.may_have_nulls() or indices.may_have_nulls()
+    out_bits = alloc(bitmap_nbytes(m), dev, zero=True)
+    out_valid = alloc(bitmap_nbytes(m), dev, zero=True) if allocate_validity else None
+    counter = torch.zeros(8, dtype=torch.uint8, device=dev) if allocate_validity else None
+    check(lib.arx_take_bits(C.byref(vspan), C.byref(ispan), tid, out_bits.data_ptr(),
+                            None if out_valid is None else out_valid.data_ptr(),
+                            None if counter is None else counter.data_ptr(), stream))
+    out = Array(bool_, m, [out_valid, out_bits], 0, 0)
+    if allocate_validity:
+        out.set_lazy_null_count(_LazyCount(m, counter))
+    return out
+
+
+def _exec_boolean_filter(args, options):
+    """Filter on boolean values = take of GetTakeIndices(mask), like the var-width types."""
+    values, mask = args
+    options = options or FilterOptions()
+    if values.length != mask.length:
+        raise ArrowInvalid("Array arguments must all be the same length")
+    indices = get_take_indices(mask, options.null_selection_behavior)
+    return _exec_array_take([values, indices], TakeOptions(boundscheck=False))
 
 
 def _exec_binary_take(args, options):
@@ -821,12 +851,14 @@ def _build_registry() -> FunctionRegistry:
 
     f = Function("array_filter", Function.VECTOR, 2, FilterOptions())
     f.add_kernel(Kernel((_FIXED_WIDTH, bool_), _exec_array_filter))
+    f.add_kernel(Kernel((bool_, bool_), _exec_boolean_filter))
     f.add_kernel(Kernel((_BASE_BINARY, bool_), _exec_binary_filter))
     reg.add_function(f)
     reg.add_function(Function("filter", Function.META, 2, FilterOptions(), _filter_meta))
 
     f = Function("array_take", Function.VECTOR, 2, TakeOptions())
     f.add_kernel(Kernel((_FIXED_WIDTH, _INTEGER), _exec_array_take))
+    f.add_kernel(Kernel((bool_, _INTEGER), _exec_array_take))
     f.add_kernel(Kernel((_BASE_BINARY, _INTEGER), _exec_binary_take))
     reg.add_function(f)
     reg.add_function(Function("take", Function.META, 2, TakeOptions(), _take_meta))

@@ -792,6 +792,45 @@ __global__ __launch_bounds__(kBlock) void take_kernel(TakeArgs a) {
   if (a.valid_count != nullptr && lane == 0 && nvalid != 0) atomicAdd(a.valid_count, nvalid);
 }
 
+// Take on BOOLEAN values (bit-packed): out bit i = value bit idx[i], 0 for a null slot
+// (Gather</*kValueWidthInBits=*/1>, gather_internal.h; the bit twin of take_kernel).  One output word
+// per wave step: the value bits and the validity are both packed by ballot.
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void take_bits_kernel(TakeArgs a, int64_t value_bit_offset) {
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock +
+                         __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwords = (a.length + 63) >> 6;
+  const int64_t last = a.length - 1;
+  const IdxT* __restrict__ indices = reinterpret_cast<const IdxT*>(a.indices);
+  uint64_t* __restrict__ out = reinterpret_cast<uint64_t*>(a.out_data);
+  uint64_t nvalid = 0;
+  for (int64_t w = wave_g; w < nwords; w += nwaves) {
+    const int64_t p = (w << 6) + lane;
+    const int64_t pc = p <= last ? p : last;
+    const uint64_t idx = static_cast<uint64_t>(indices[pc]);
+    bool ok = p <= last && ((load_word(a.ivalid, w) >> lane) & 1ull);
+    if (ok && a.src_valid_bytes != nullptr) {
+      const uint64_t vb = static_cast<uint64_t>(a.src_valid_offset) + idx;
+      ok = (a.src_valid_bytes[vb >> 3] >> (vb & 7)) & 1;
+    }
+    bool bit = false;
+    if (ok) {
+      const uint64_t b = static_cast<uint64_t>(value_bit_offset) + idx;
+      bit = (a.values[b >> 3] >> (b & 7)) & 1;
+    }
+    const uint64_t data_bal = __ballot(bit);
+    const uint64_t valid_bal = __ballot(ok);
+    nvalid += __popcll(valid_bal);
+    if (lane == 0) {
+      out[w] = data_bal;
+      if (a.out_validity != nullptr) a.out_validity[w] = valid_bal;
+    }
+  }
+  if (a.valid_count != nullptr && lane == 0 && nvalid != 0) atomicAdd(a.valid_count, nvalid);
+}
+
 // ------------------------------------------------------------------ bounds check
 struct BoundsWs {
   unsigned long long first_bad_pos;  // min position of an offending index, ~0 if none
@@ -1352,6 +1391,51 @@ int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int 
 #undef ARX_TAKE_W
 #undef ARX_TAKE_V
   ARX_CHECK_LAUNCH("take_kernel");
+  return ARX_OK;
+}
+
+int arx_take_bits(const ArxSpan* values, const ArxSpan* indices, int index_type, void* out_bits, void* out_validity,
+                  int64_t* valid_count, void* stream) {
+  if (values == nullptr || indices == nullptr) {
+    set_error("values/indices is NULL");
+    return ARX_INVALID;
+  }
+  if (index_type < 0 || index_type > 7) {
+    set_error("Unsupported index type %d for take", index_type);
+    return ARX_NOT_IMPLEMENTED;
+  }
+  if (indices->length == 0) return ARX_OK;
+  if (out_bits == nullptr || indices->data == nullptr || values->data == nullptr) {
+    set_error("values/indices/out buffer is NULL");
+    return ARX_INVALID;
+  }
+  static const int widths[8] = {1, 1, 2, 2, 4, 4, 8, 8};
+  const int iw = widths[index_type];
+  TakeArgs a{};
+  a.values = static_cast<const uint8_t*>(values->data);
+  a.src_valid_bytes = static_cast<const uint8_t*>(effective_validity(values));
+  a.src_valid_offset = values->offset;
+  a.indices = static_cast<const uint8_t*>(indices->data) + indices->offset * iw;
+  a.ivalid = make_bits(effective_validity(indices), indices->offset, indices->length);
+  a.length = indices->length;
+  a.out_data = static_cast<uint8_t*>(out_bits);
+  a.out_validity = static_cast<uint64_t*>(out_validity);
+  a.valid_count = reinterpret_cast<unsigned long long*>(valid_count);
+  if ((a.src_valid_bytes != nullptr || a.ivalid.base != nullptr) && out_validity == nullptr) {
+    set_error("take: inputs may have nulls but out_validity is NULL");
+    return ARX_INVALID;
+  }
+  const int64_t nwords = ceil_div(indices->length, 64);
+  const dim3 grid(static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(nwords, kWavesPerBlock), 256 * 32))));
+  const dim3 block(kBlock);
+  hipStream_t st = as_stream(stream);
+  switch (iw) {
+    case 1: hipLaunchKernelGGL((take_bits_kernel<uint8_t>), grid, block, 0, st, a, values->offset); break;
+    case 2: hipLaunchKernelGGL((take_bits_kernel<uint16_t>), grid, block, 0, st, a, values->offset); break;
+    case 4: hipLaunchKernelGGL((take_bits_kernel<uint32_t>), grid, block, 0, st, a, values->offset); break;
+    default: hipLaunchKernelGGL((take_bits_kernel<uint64_t>), grid, block, 0, st, a, values->offset); break;
+  }
+  ARX_CHECK_LAUNCH("take_bits_kernel");
   return ARX_OK;
 }
 

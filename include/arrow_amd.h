@@ -152,6 +152,11 @@ int arx_check_index_bounds(const ArxSpan* indices, int index_type, uint64_t uppe
  * incremented by the number of valid output rows (caller zeroes it). */
 int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int index_type,
              void* out_data, void* out_validity, int64_t* valid_count, void* stream);
+/* The same for BOOLEAN values (bit-packed data buffer, values->offset in bits): out bit i = value bit
+ * idx[i], 0 for null slots (Gather with 1-bit values, gather_internal.h).  out_bits / out_validity:
+ * ceil(M/64) 64-bit words, zero padded.  A filter on boolean values is arx_mask_to_indices + this. */
+int arx_take_bits(const ArxSpan* values, const ArxSpan* indices, int index_type, void* out_bits, void* out_validity,
+                  int64_t* valid_count, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Take / Filter on base-binary values (binary, utf8: int32 offsets) — replaces TakeExec for base

@@ -162,6 +162,37 @@ def check_binary_filter(amd, values, mask: HostArray, null_selection: str, use_p
     return out
 
 
+def check_boolean_take_and_filter(amd, values: HostArray, indices: HostArray, mask: HostArray, use_pyarrow=True):
+    """take / filter on bit-packed boolean VALUES: bits and validity vs numpy and pyarrow."""
+    dv = values.to_device(amd)
+    out = amd.compute.take(dv, indices.to_device(amd))
+    idx = indices.logical_values().astype(np.int64)
+    iv = indices.logical_valid()
+    src_valid = values.logical_valid()
+    want_valid = iv & src_valid[np.where(iv, idx, 0)]
+    want_bits = np.where(want_valid, values.logical_values()[np.where(iv, idx, 0)], False)
+    bits, pad_ok = device_bitmap_to_bool(out.data, out.length)
+    assert_equal(bits, want_bits, "boolean take bits (null slots zero)")
+    assert pad_ok
+    gv, pad2 = _logical_valid(out)
+    assert_equal(gv, want_valid, "boolean take validity")
+    assert pad2 and out.null_count == int((~want_valid).sum())
+    if use_pyarrow and pc is not None:
+        assert out.to_pyarrow().equals(pc.take(values.to_pyarrow(), indices.to_pyarrow()))
+    for sel in ("drop", "emit_null"):
+        f = amd.compute.filter(dv, mask.to_device(amd), sel)
+        if use_pyarrow and pc is not None:
+            ref = pc.filter(values.to_pyarrow(), mask.to_pyarrow(), null_selection_behavior=sel)
+            assert f.to_pyarrow().equals(ref) and f.null_count == ref.null_count, sel
+        keep = mask.logical_values() & mask.logical_valid()
+        if sel == "drop":
+            assert f.length == int(keep.sum())
+            fb, _ = device_bitmap_to_bool(f.data, f.length)
+            fv, _ = _logical_valid(f)
+            assert_equal(fv, src_valid[keep], "boolean filter validity")
+            assert_equal(fb[fv], values.logical_values()[keep][fv], "boolean filter bits")
+
+
 # ------------------------------------------------------------------ cast / compare / add
 def _bits_equal_f32(got, want):
     g, w = got.view(np.uint32), want.view(np.uint32)

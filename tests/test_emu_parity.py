@@ -610,3 +610,15 @@ def test_dictionary_encode(emu_ctx, null_p, offset):
 def test_scalar_aggregates_int64(emu_ctx):
     """SumImpl / CountImpl / MinMaxImpl (aggregate_basic.inc.cc): wrap-around sum, options, batches."""
     P.check_scalar_aggregates(emu_ctx, rng_for("scalaragg"), n=6000)
+
+
+@pytest.mark.parametrize("idx_dtype", [np.uint8, np.int32, np.int64])
+@pytest.mark.parametrize("vnull,inull,voff", [(0.0, 0.0, 0), (0.2, 0.1, 5), (1.0, 0.5, 67)])
+def test_boolean_values_take_and_filter(emu_ctx, idx_dtype, vnull, inull, voff):
+    """filter / take on BOOLEAN values (1-bit Gather, gather_internal.h; PrimitiveFilter's bit-width-1 case)."""
+    rng = rng_for("booltake", str(idx_dtype), vnull, inull, voff)
+    nv = 200 if np.dtype(idx_dtype).itemsize == 1 else 5000
+    v = U.random_mask(rng, nv, 0.5, null_p=vnull, offset=voff, tail=3)
+    i = U.random_array(rng, idx_dtype, 5000, null_p=inull, offset=1, lo=0, hi=nv - 1)
+    m = U.random_mask(rng, nv, 0.3, null_p=0.05, offset=2)
+    P.check_boolean_take_and_filter(emu_ctx, v, i, m)
