@@ -1,8 +1,8 @@
 """Parquet column chunks decoded into HBM (first slice).
 
 Scope: flat columns of physical type INT32 / INT64 / FLOAT / DOUBLE (PLAIN and PLAIN_DICTIONARY /
-RLE_DICTIONARY encodings, incl. the dictionary -> PLAIN fallback inside a chunk) and BYTE_ARRAY columns
-(utf8 / binary; dictionary-encoded and PLAIN pages); required or optional (max definition level <= 1, no repetition),
+RLE_DICTIONARY encodings, incl. the dictionary -> PLAIN fallback inside a chunk), BOOLEAN (PLAIN, RLE) and
+BYTE_ARRAY columns (utf8 / binary; dictionary-encoded and PLAIN pages); required or optional (max definition level <= 1, no repetition),
 data pages V1 and V2, any page compression pyarrow's codecs can undo.
 
 Division of labour (what the reference does in cpp/src/parquet/column_reader.cc:740-1000 and
@@ -200,12 +200,17 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     t_start = time.perf_counter()
     device = torch.device(device) if device is not None else default_device()
     is_binary = col.physical_type == "BYTE_ARRAY" and binary_type is not None
-    if col.physical_type not in _PHYSICAL and not is_binary:
+    is_bool = col.physical_type == "BOOLEAN"
+    if col.physical_type not in _PHYSICAL and not is_binary and not is_bool:
         raise ArrowNotImplementedError(f"Parquet physical type {col.physical_type} is not on the gfx950 path")
     if max_def_level > 1:
         raise ArrowNotImplementedError("Parquet: nested / repeated columns are not on the gfx950 path")
     if is_binary:
         atype, width = binary_type, 1          # values live in the dictionary; data pages carry indices only
+    elif is_bool:
+        from .array import bool_
+
+        atype, width = bool_, 1                # bit-packed values (PLAIN) or the bit-width-1 hybrid (RLE)
     else:
         atype, np_dtype = _PHYSICAL[col.physical_type]
         width = np.dtype(np_dtype).itemsize
@@ -217,6 +222,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     index_bytes, index_runs = bytearray(), []
     plain_bytes = bytearray()
     plain_pages = []          # BYTE_ARRAY only: (page value bytes, number of values)
+    bool_bytes, bool_runs = bytearray(), []   # BOOLEAN only: every page becomes runs of one shared table
     rows, dense, dense_from_dict = 0, 0, 0
     for hdr, payload in _column_chunk_pages(raw, col):
         ptype = hdr[1]
@@ -267,6 +273,18 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
                 index_runs.append(runs)
                 index_bytes += values[1:]
             dense_from_dict += valid_here
+        elif is_bool and enc in (_ENC_PLAIN, _ENC_RLE):
+            if valid_here:
+                if enc == _ENC_PLAIN:      # LSB-first bit-packed values = one literal run of the hybrid's bit layout
+                    run = np.zeros(1, dtype=RUN_DTYPE)
+                    run["out_start"], run["kind"], run["payload"] = dense, 1, len(bool_bytes)
+                    bool_runs.append(run)
+                    bool_bytes += values[: (valid_here + 7) // 8]
+                else:                      # RLE: 4-byte length + hybrid, bit width 1 (parquet/decoder.cc, RleBooleanDecoder)
+                    (nb,) = struct.unpack_from("<i", values, 0)
+                    runs, _ = scan_rle_runs(values[4: 4 + nb], 1, valid_here, out_base=dense, byte_base=len(bool_bytes))
+                    bool_runs.append(runs)
+                    bool_bytes += values[4: 4 + nb]
         elif enc == _ENC_PLAIN:
             if is_binary:
                 plain_pages.append((bytes(values), valid_here))      # offsets are built once the dictionary size is known
@@ -280,6 +298,9 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     if stats is not None:
         stats["host_prep_s"] = stats.get("host_prep_s", 0.0) + (time.perf_counter() - t_start)
         stats["encoded_bytes"] = stats.get("encoded_bytes", 0) + len(level_bytes) + len(index_bytes) + len(plain_bytes) + len(dict_bytes or b"")
+    if is_bool:
+        return _finish_boolean_chunk(lib, stream, device, bool_bytes, bool_runs, level_bytes, level_runs, rows, dense,
+                                     max_def_level)
     if is_binary:
         return _finish_binary_chunk(lib, stream, device, atype, dict_bytes, dict_count, index_bytes, index_runs,
                                     level_bytes, level_runs, rows, dense, max_def_level, dense_from_dict, plain_pages)
@@ -324,6 +345,49 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     out = alloc(rows * width, device)
     check(lib.arx_expand_by_mask(dense_buf.data_ptr(), width, C.byref(mask), ws.data_ptr(), out.data_ptr(), stream))
     return Array(atype, rows, [validity, out], rows - dense, 0)
+
+
+def _validity_and_ws(lib, stream, device, level_bytes, level_runs, rows, dense, max_def_level):
+    """Definition levels -> (validity bitmap, mask span, count/scan workspace) for an optional column."""
+    runs = np.concatenate(level_runs)
+    d_lbytes = to_device(np.frombuffer(bytes(level_bytes) or b"\0", dtype=np.uint8), device)
+    d_lruns = _device_runs(runs, device)
+    validity = alloc(bitmap_nbytes(rows), device, zero=True)
+    check(lib.arx_rle_decode_equals_bitmap(d_lbytes.data_ptr(), len(level_bytes), d_lruns.data_ptr(), len(runs), 1,
+                                           rows, max_def_level, validity.data_ptr(), stream))
+    mask = _lib.ArxSpan(None, validity.data_ptr(), 0, rows, 0)
+    ws = alloc(lib.arx_filter_workspace_bytes(rows) + 64, device)
+    cnt = C.c_int64(0)
+    check(lib.arx_filter_count(C.byref(mask), _lib.FILTER_DROP, ws.data_ptr(), ws.numel(), C.byref(cnt), stream))
+    if cnt.value != dense:
+        raise ArrowInvalid(f"Parquet: {cnt.value} non-null definition levels but {dense} values (corrupt page?)")
+    return validity, mask, ws
+
+
+def _finish_boolean_chunk(lib, stream, device, bool_bytes, bool_runs, level_bytes, level_runs, rows, dense,
+                          max_def_level) -> Array:
+    """BOOLEAN column: the pages' values (PLAIN bit-packing = a literal run, or RLE) are decoded by the
+    hybrid decoder straight into a dense bitmap; an optional column then takes bit rank(r) for every valid
+    slot r — the ranks are 0..dense-1 spread over the slots by the validity bitmap (arx_expand_by_mask),
+    the gather is arx_take_bits."""
+    from . import compute as cp
+    from .array import bool_, uint32
+
+    dense_bits = alloc(bitmap_nbytes(max(dense, 1)), device, zero=True)
+    if dense:
+        runs = np.concatenate(bool_runs)
+        d_bytes = to_device(np.frombuffer(bytes(bool_bytes) or b"\0", dtype=np.uint8), device)
+        d_runs = _device_runs(runs, device)
+        check(lib.arx_rle_decode_equals_bitmap(d_bytes.data_ptr(), len(bool_bytes), d_runs.data_ptr(), len(runs), 1,
+                                               dense, 1, dense_bits.data_ptr(), stream))
+    if max_def_level == 0 or dense == rows:
+        return Array(bool_, rows, [None, dense_bits], 0, 0)
+    validity, mask, ws = _validity_and_ws(lib, stream, device, level_bytes, level_runs, rows, dense, max_def_level)
+    ranks = torch.arange(max(dense, 1), dtype=torch.int32, device=device)
+    full = alloc(rows * 4, device)
+    check(lib.arx_expand_by_mask(ranks.data_ptr(), 4, C.byref(mask), ws.data_ptr(), full.data_ptr(), stream))
+    didx = Array(uint32, rows, [validity, full], rows - dense, 0)
+    return cp.take(Array(bool_, dense, [None, dense_bits], 0, 0), didx, boundscheck=False)
 
 
 def _finish_binary_chunk(lib, stream, device, atype, dict_bytes, dict_count, index_bytes, index_runs, level_bytes,

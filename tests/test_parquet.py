@@ -26,6 +26,8 @@ def _table(rng, n, null_p):
         "f64": pa.array(np.round(rng.standard_normal(n), 2), mask=m()),
         "f32": pa.array(rng.standard_normal(n).astype(np.float32), mask=m()),
         "req": pa.array(rng.integers(0, 1000, n)),
+        "flag": pa.array(rng.random(n) < 0.3, type=pa.bool_(), mask=m()),
+        "flag_runs": pa.array(np.repeat(rng.random(n // 40 + 1) < 0.5, 40)[:n], type=pa.bool_(), mask=m()),
         "str": pa.array(np.array(["", "a", "bb", "gfx950", "MI355X", "ünïcödé", "x" * 40], dtype=object)[rng.integers(0, 7, n)], type=pa.string(), mask=m()),
     })
 
@@ -159,7 +161,7 @@ def test_ipc_file_and_stream_to_device(emu_ctx, tmp_path):
     """IPC bodies are Arrow layout already: columns land on the device buffer by buffer and come back equal
     (fixed width, boolean, utf8, nulls, several batches, LZ4 body compression)."""
     rng = np.random.default_rng(3)
-    t = _table(rng, 5000, 0.1).append_column("flag", pa.array(rng.random(5000) < 0.5, mask=rng.random(5000) < 0.05))
+    t = _table(rng, 5000, 0.1)
     for compression in (None, "lz4"):
         path = os.path.join(str(tmp_path), f"t_{compression}.arrow")
         opts = pa.ipc.IpcWriteOptions(compression=compression)
