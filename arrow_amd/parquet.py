@@ -330,18 +330,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     if max_def_level == 0 or dense == rows:                         # required column, or optional without a single null
         return Array(atype, rows, [None, dense_buf], 0, 0)
     # ---- validity bitmap from the definition levels, then spread the dense values over their slots
-    runs = np.concatenate(level_runs)
-    d_lbytes = to_device(np.frombuffer(bytes(level_bytes) or b"\0", dtype=np.uint8), device)
-    d_lruns = _device_runs(runs, device)
-    validity = alloc(bitmap_nbytes(rows), device, zero=True)
-    check(lib.arx_rle_decode_equals_bitmap(d_lbytes.data_ptr(), len(level_bytes), d_lruns.data_ptr(), len(runs), 1,
-                                           rows, max_def_level, validity.data_ptr(), stream))
-    mask = _lib.ArxSpan(None, validity.data_ptr(), 0, rows, 0)
-    ws = alloc(lib.arx_filter_workspace_bytes(rows) + 64, device)
-    cnt = C.c_int64(0)
-    check(lib.arx_filter_count(C.byref(mask), _lib.FILTER_DROP, ws.data_ptr(), ws.numel(), C.byref(cnt), stream))
-    if cnt.value != dense:
-        raise ArrowInvalid(f"Parquet: {cnt.value} non-null definition levels but {dense} values (corrupt page?)")
+    validity, mask, ws = _validity_and_ws(lib, stream, device, level_bytes, level_runs, rows, dense, max_def_level)
     out = alloc(rows * width, device)
     check(lib.arx_expand_by_mask(dense_buf.data_ptr(), width, C.byref(mask), ws.data_ptr(), out.data_ptr(), stream))
     return Array(atype, rows, [validity, out], rows - dense, 0)
@@ -349,18 +338,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
 
 def _validity_and_ws(lib, stream, device, level_bytes, level_runs, rows, dense, max_def_level):
     """Definition levels -> (validity bitmap, mask span, count/scan workspace) for an optional column."""
-    runs = np.concatenate(level_runs)
-    d_lbytes = to_device(np.frombuffer(bytes(level_bytes) or b"\0", dtype=np.uint8), device)
-    d_lruns = _device_runs(runs, device)
-    validity = alloc(bitmap_nbytes(rows), device, zero=True)
-    check(lib.arx_rle_decode_equals_bitmap(d_lbytes.data_ptr(), len(level_bytes), d_lruns.data_ptr(), len(runs), 1,
-                                           rows, max_def_level, validity.data_ptr(), stream))
-    mask = _lib.ArxSpan(None, validity.data_ptr(), 0, rows, 0)
-    ws = alloc(lib.arx_filter_workspace_bytes(rows) + 64, device)
-    cnt = C.c_int64(0)
-    check(lib.arx_filter_count(C.byref(mask), _lib.FILTER_DROP, ws.data_ptr(), ws.numel(), C.byref(cnt), stream))
-    if cnt.value != dense:
-        raise ArrowInvalid(f"Parquet: {cnt.value} non-null definition levels but {dense} values (corrupt page?)")
+    validity, mask, ws = _validity_and_ws(lib, stream, device, level_bytes, level_runs, rows, dense, max_def_level)
     return validity, mask, ws
 
 
@@ -432,18 +410,7 @@ def _finish_binary_chunk(lib, stream, device, atype, dict_bytes, dict_count, ind
     if max_def_level == 0 or dense == rows:
         didx = Array(uint32, rows, [None, idx], 0, 0)
         return cp.take(dvals, didx, boundscheck=True)
-    runs = np.concatenate(level_runs)
-    d_lbytes = to_device(np.frombuffer(bytes(level_bytes) or b"\0", dtype=np.uint8), device)
-    d_lruns = _device_runs(runs, device)
-    validity = alloc(bitmap_nbytes(rows), device, zero=True)
-    check(lib.arx_rle_decode_equals_bitmap(d_lbytes.data_ptr(), len(level_bytes), d_lruns.data_ptr(), len(runs), 1,
-                                           rows, max_def_level, validity.data_ptr(), stream))
-    mask = _lib.ArxSpan(None, validity.data_ptr(), 0, rows, 0)
-    ws = alloc(lib.arx_filter_workspace_bytes(rows) + 64, device)
-    cnt = C.c_int64(0)
-    check(lib.arx_filter_count(C.byref(mask), _lib.FILTER_DROP, ws.data_ptr(), ws.numel(), C.byref(cnt), stream))
-    if cnt.value != dense:
-        raise ArrowInvalid(f"Parquet: {cnt.value} non-null definition levels but {dense} values (corrupt page?)")
+    validity, mask, ws = _validity_and_ws(lib, stream, device, level_bytes, level_runs, rows, dense, max_def_level)
     full = alloc(rows * 4, device)
     check(lib.arx_expand_by_mask(idx.data_ptr(), 4, C.byref(mask), ws.data_ptr(), full.data_ptr(), stream))
     didx = Array(uint32, rows, [validity, full], rows - dense, 0)
