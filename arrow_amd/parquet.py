@@ -338,7 +338,18 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
 
 def _validity_and_ws(lib, stream, device, level_bytes, level_runs, rows, dense, max_def_level):
     """Definition levels -> (validity bitmap, mask span, count/scan workspace) for an optional column."""
-    validity, mask, ws = _validity_and_ws(lib, stream, device, level_bytes, level_runs, rows, dense, max_def_level)
+    runs = np.concatenate(level_runs)
+    d_lbytes = to_device(np.frombuffer(bytes(level_bytes) or b"\0", dtype=np.uint8), device)
+    d_lruns = _device_runs(runs, device)
+    validity = alloc(bitmap_nbytes(rows), device, zero=True)
+    check(lib.arx_rle_decode_equals_bitmap(d_lbytes.data_ptr(), len(level_bytes), d_lruns.data_ptr(), len(runs), 1,
+                                           rows, max_def_level, validity.data_ptr(), stream))
+    mask = _lib.ArxSpan(None, validity.data_ptr(), 0, rows, 0)
+    ws = alloc(lib.arx_filter_workspace_bytes(rows) + 64, device)
+    cnt = C.c_int64(0)
+    check(lib.arx_filter_count(C.byref(mask), _lib.FILTER_DROP, ws.data_ptr(), ws.numel(), C.byref(cnt), stream))
+    if cnt.value != dense:
+        raise ArrowInvalid(f"Parquet: {cnt.value} non-null definition levels but {dense} values (corrupt page?)")
     return validity, mask, ws
 
 
