@@ -34,6 +34,12 @@
 #include <arrow/acero/query_context.h>
 
 #include <hip/hip_runtime_api.h>
+#include <parquet/column_page.h>
+#include <parquet/column_reader.h>
+#include <parquet/file_reader.h>
+#include <parquet/metadata.h>
+#include <parquet/schema.h>
+#include <arrow/util/ubsan.h>
 
 #include <atomic>
 #include <cstdlib>
@@ -63,6 +69,7 @@ namespace {
 #include "plugin/cast.inc"
 #include "plugin/hash_aggregate.inc"
 #include "plugin/acero_node.inc"
+#include "plugin/parquet.inc"
 #include "plugin/registration.inc"
 
 }  // namespace
@@ -148,6 +155,26 @@ void arrow_amd_plugin_pool_stats(int64_t* cached_bytes, int64_t* hits, int64_t* 
 }
 // Returns every cached block to the driver.
 void arrow_amd_plugin_pool_trim(void) { DevicePool::Get().Trim(); }
+// One column chunk of a Parquet file decoded into a device-resident array (C Device Data interface):
+// the reference's PageReader for headers + decompression, the C-ABI kernels for everything per value.
+int arrow_amd_parquet_read_column(const char* path, int row_group, int column, struct ArrowDeviceArray* out,
+                                  struct ArrowSchema* out_schema) {
+  auto run = [&]() -> Status {
+    try {
+      ARROW_ASSIGN_OR_RAISE(auto data, ParquetChunkToDevice(path, row_group, column));
+      ARROW_RETURN_NOT_OK(arrow::ExportType(*data->type, out_schema));
+      return arrow::ExportDeviceArray(*arrow::MakeArray(data), nullptr, out);
+    } catch (const parquet::ParquetException& e) {
+      return Status::IOError("Parquet: ", e.what());
+    }
+  };
+  const Status st = run();
+  if (!st.ok()) {
+    t_error = st.ToString();
+    return -1;
+  }
+  return 0;
+}
 // Inputs shorter than this stay on the stock CPU kernels (PCIe staging does not pay).
 void arrow_amd_plugin_set_min_rows(int64_t n) { g_min_rows.store(n); }
 // The same threshold for the element-wise kernels (greater, cast); default: never stage them.

@@ -25,13 +25,13 @@ def build_plugin(force: bool = False, verbose: bool = True, emulated: bool | Non
 
     d = os.path.dirname(pa.__file__)
     libs = pa.get_libraries()
-    so = {name: None for name in ("arrow", "arrow_compute", "arrow_acero")}
+    so = {name: None for name in ("arrow", "arrow_compute", "arrow_acero", "parquet")}
     for f in sorted(os.listdir(d)):
         for name in so:
             if f.startswith(f"lib{name}.so.") and f.count(".") == 2:
                 so[name] = os.path.join(d, f)
     if not all(so.values()):
-        raise RuntimeError(f"libarrow/libarrow_compute/libarrow_acero not found in {d} ({libs})")
+        raise RuntimeError(f"libarrow/libarrow_compute/libarrow_acero/libparquet not found in {d} ({libs})")
     core = os.path.join(HERE, "libarrow_amd.so")
     if not os.path.exists(core):
         raise RuntimeError("build libarrow_amd.so first")
@@ -42,7 +42,7 @@ def build_plugin(force: bool = False, verbose: bool = True, emulated: bool | Non
         return OUT
     cmd = ["g++", "-std=c++20", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
            "-I", pa.get_include(), "-I", "/opt/rocm/include", SRC, "-o", OUT,
-           so["arrow"], so["arrow_compute"], so["arrow_acero"], core, "-L/opt/rocm/lib", "-lamdhip64",
+           so["arrow"], so["arrow_compute"], so["arrow_acero"], so["parquet"], core, "-L/opt/rocm/lib", "-lamdhip64",
            f"-Wl,-rpath,{d}", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -59,7 +59,7 @@ def _build_emulated_plugin(pa, force: bool, verbose: bool) -> str:
     emu_dir = os.path.join(root, "tests", "emu")
     out = os.path.join(emu_dir, "_build", "libarrow_amd_plugin_emu.so")
     d = os.path.dirname(pa.__file__)
-    so = {name: None for name in ("arrow", "arrow_compute", "arrow_acero")}
+    so = {name: None for name in ("arrow", "arrow_compute", "arrow_acero", "parquet")}
     for f in sorted(os.listdir(d)):
         for name in so:
             if f.startswith(f"lib{name}.so.") and f.count(".") == 2:
@@ -71,7 +71,7 @@ def _build_emulated_plugin(pa, force: bool, verbose: bool) -> str:
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(x) for x in deps):
         return out
     cmd = ["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-I", os.path.join(emu_dir, "plugin_hip"),
-           "-I", pa.get_include(), SRC, "-o", out, so["arrow"], so["arrow_compute"], so["arrow_acero"], core,
+           "-I", pa.get_include(), SRC, "-o", out, so["arrow"], so["arrow_compute"], so["arrow_acero"], so["parquet"], core,
            f"-Wl,-rpath,{d}", f"-Wl,-rpath,{os.path.dirname(core)}"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -40,3 +40,7 @@ def test_acero_plan_over_a_device_resident_table_emulated():
 
 def test_pyarrow_compute_dispatches_to_the_hip_kernels_emulated():
     _run(G.SCRIPT, "PLUGIN_OK", 0.04)
+
+
+def test_parquet_column_chunks_through_the_plugin_emulated():
+    _run(G.PARQUET_SCRIPT, "PARQUET_OK", 0.03)
