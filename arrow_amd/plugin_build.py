@@ -12,16 +12,8 @@ OUT = os.path.join(HERE, "libarrow_amd_plugin.so")
 SRC = os.path.join(HERE, "csrc", "arrow_plugin.cc")
 
 
-def build_plugin(force: bool = False, verbose: bool = True, emulated: bool | None = None) -> str:
-    """emulated (default: env ARROW_AMD_PLUGIN_EMULATED=1): TEST BUILD of the same sources against the
-    host-emulated kernel library and a host-memory stand-in for the HIP runtime (tests/emu), so that the
-    shim's device-resident paths can be exercised without a GPU.  Never the product build."""
+def build_plugin(force: bool = False, verbose: bool = True) -> str:
     import pyarrow as pa
-
-    if emulated is None:
-        emulated = os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1"
-    if emulated:
-        return _build_emulated_plugin(pa, force, verbose)
 
     d = os.path.dirname(pa.__file__)
     libs = pa.get_libraries()
@@ -48,35 +40,6 @@ def build_plugin(force: bool = False, verbose: bool = True, emulated: bool | Non
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return OUT
-
-
-def _build_emulated_plugin(pa, force: bool, verbose: bool) -> str:
-    root = os.path.dirname(HERE)
-    sys.path.insert(0, root)
-    from tests.emu.build_emu import build as build_emu
-
-    core = build_emu()
-    emu_dir = os.path.join(root, "tests", "emu")
-    out = os.path.join(emu_dir, "_build", "libarrow_amd_plugin_emu.so")
-    d = os.path.dirname(pa.__file__)
-    so = {name: None for name in ("arrow", "arrow_compute", "arrow_acero", "parquet")}
-    for f in sorted(os.listdir(d)):
-        for name in so:
-            if f.startswith(f"lib{name}.so.") and f.count(".") == 2:
-                so[name] = os.path.join(d, f)
-    parts = os.path.join(HERE, "csrc", "plugin")
-    deps = [SRC, core, os.path.join(root, "include", "arrow_amd.h"),
-            os.path.join(emu_dir, "plugin_hip", "hip", "hip_runtime_api.h")]
-    deps += [os.path.join(parts, f) for f in sorted(os.listdir(parts)) if f.endswith(".inc")]
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(x) for x in deps):
-        return out
-    cmd = ["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-I", os.path.join(emu_dir, "plugin_hip"),
-           "-I", pa.get_include(), SRC, "-o", out, so["arrow"], so["arrow_compute"], so["arrow_acero"], so["parquet"], core,
-           f"-Wl,-rpath,{d}", f"-Wl,-rpath,{os.path.dirname(core)}"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return out
 
 
 if __name__ == "__main__":

@@ -17,7 +17,10 @@ SCRIPT = textwrap.dedent(r'''
     import pyarrow as pa, pyarrow.compute as pc
     sys.path.insert(0, ROOT)
     SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))   # sizes shrink for the emulated run
-    from arrow_amd.plugin_build import build_plugin
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
     so = build_plugin()
     rng = np.random.default_rng(5)
     n = SC(1_000_003)
@@ -99,7 +102,10 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
     import pyarrow as pa, pyarrow.compute as pc
     sys.path.insert(0, ROOT)
     SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))   # sizes shrink for the emulated run
-    from arrow_amd.plugin_build import build_plugin
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
     lib = ctypes.CDLL(build_plugin())
     lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
     lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
@@ -349,7 +355,10 @@ ACERO_SCRIPT = textwrap.dedent(r'''
     from pyarrow import acero
     sys.path.insert(0, ROOT)
     SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
-    from arrow_amd.plugin_build import build_plugin
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
     lib = ctypes.CDLL(build_plugin())
     lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
     assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
@@ -446,7 +455,10 @@ ACERO_DEVICE_SCRIPT = textwrap.dedent(r'''
     faulthandler.enable()
     sys.path.insert(0, ROOT)
     SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
-    from arrow_amd.plugin_build import build_plugin
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
     lib = ctypes.CDLL(build_plugin())
     lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
     lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
@@ -511,7 +523,10 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
     faulthandler.enable()
     sys.path.insert(0, ROOT)
     SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
-    from arrow_amd.plugin_build import build_plugin
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
     lib = ctypes.CDLL(build_plugin())
     lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
     lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
