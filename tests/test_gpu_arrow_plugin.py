@@ -76,7 +76,7 @@ SCRIPT = textwrap.dedent(r'''
                 "hash_sum": 2}
     for f, wmin in want_gpu.items():
         assert stats[f][0] >= wmin, (f, stats)
-    assert stats["array_filter"][1] >= 1, stats   # the tiny input was handed to the stock kernel (boolean values never reach the shim)
+    assert stats["array_filter"][1] >= 1, stats   # the tiny input was handed to the stock kernel (so are host-resident boolean values)
     assert stats["cast"][1] >= 1, stats           # float64 -> int64 is not ours: stock meta-function
     try:
         pc.take(vals, pa.array(np.array([0, n, 1] * 1000, dtype=np.int64)))
@@ -276,6 +276,16 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
         got_d = pc.drop_null(dv)
         assert not got_d.is_cpu
         assert to_host(got_d).equals(pc.drop_null(hv))
+    # BOOLEAN (bit-packed) values on the device: the 1-bit gather
+    bvals = pa.array(rng.random(n) < 0.4, mask=rng.random(n) < 0.07)
+    d_bvals = to_device(bvals)
+    for got_d, want_h in ((pc.filter(d_bvals, d_mask), pc.filter(bvals, mask)),
+                          (pc.filter(d_bvals.slice(9), d_mask.slice(9), null_selection_behavior="emit_null"),
+                           pc.filter(bvals.slice(9), mask.slice(9), null_selection_behavior="emit_null")),
+                          (pc.take(d_bvals, d_idx), pc.take(bvals, idx))):
+        assert not got_d.is_cpu
+        hb = to_host(got_d)
+        assert hb.equals(want_h) and hb.null_count == want_h.null_count
     # the other fixed-width classes of match::Primitive() + decimal128 / fixed_size_binary (widths 2..16 bytes)
     import decimal
     nw = SC(200_003)
