@@ -565,7 +565,14 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
                       "grow": pa.array(np.arange(n) // 3, mask=m(null_p)),
                       "i32": pa.array(np.repeat(rng.integers(0, 9, n // 50 + 1), 50)[:n].astype(np.int32), mask=m(null_p)),
                       "f64": pa.array(np.round(rng.standard_normal(n), 2), mask=m(null_p)),
-                      "f32": pa.array(rng.standard_normal(n).astype(np.float32), mask=m(null_p))})
+                      "f32": pa.array(rng.standard_normal(n).astype(np.float32), mask=m(null_p)),
+                      "flag": pa.array(rng.random(n) < 0.3, type=pa.bool_(), mask=m(null_p)),
+                      "flag_runs": pa.array(np.repeat(rng.random(n // 40 + 1) < 0.5, 40)[:n], type=pa.bool_(), mask=m(null_p)),
+                      "str": pa.array(np.array(["", "a", "bb", "gfx950", "MI355X", "ünïcödé", "x" * 40], dtype=object)[rng.integers(0, 7, n)],
+                                      type=pa.string(), mask=m(null_p)),
+                      "str_wide": pa.array(np.array([("w%d" % i) * (i % 4) for i in range(n)], dtype=object)[rng.integers(0, n, n)],
+                                           type=pa.string(), mask=m(null_p)),
+                      "bin": pa.array([bytes([i % 251]) * (i % 6) for i in range(n)], type=pa.binary(), mask=m(null_p))})
         for variant in (dict(compression="snappy"), dict(compression="zstd", data_page_version="2.0", data_page_size=8192),
                         dict(compression="none", use_dictionary=False),
                         dict(compression="snappy", dictionary_pagesize_limit=16384, data_page_size=8192)):
