@@ -68,6 +68,7 @@ namespace {
 #include "plugin/sort.inc"
 #include "plugin/cast.inc"
 #include "plugin/hash_aggregate.inc"
+#include "plugin/scalar_aggregate.inc"
 #include "plugin/acero_node.inc"
 #include "plugin/parquet.inc"
 #include "plugin/registration.inc"

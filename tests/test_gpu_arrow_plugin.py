@@ -344,6 +344,30 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
         raise SystemExit("expected IndexError")
     except pa.lib.ArrowIndexError as e:
         assert str(e) == f"Index {n} out of bounds", str(e)
+    # scalar aggregates of int64 device columns (sum / count / min_max / min / max): the state is 32 B read back per batch
+    red0 = lib.arrow_amd_plugin_calls(b"reduce", 1)
+    all_null = pa.array([None] * 1000, pa.int64())
+    for h_arr in (vals, smalls, pa.array(rng.integers(-2**62, 2**62, n)), all_null, vals.slice(0, 0)):
+        d_arr = to_device(h_arr)
+        for opts in (None, pc.ScalarAggregateOptions(skip_nulls=False), pc.ScalarAggregateOptions(min_count=len(h_arr)),
+                     pc.ScalarAggregateOptions(min_count=0)):
+            for fn in ("sum", "min_max", "min", "max"):
+                g, w = pc.call_function(fn, [d_arr], opts), pc.call_function(fn, [h_arr], opts)
+                assert g.equals(w) and g.type == w.type, (fn, opts, g, w)
+        if len(h_arr) > 200:
+            for fn in ("sum", "min_max"):
+                assert pc.call_function(fn, [d_arr.slice(13, len(h_arr) - 100)]).equals(pc.call_function(fn, [h_arr.slice(13, len(h_arr) - 100)])), fn
+        for mode in ("only_valid", "only_null", "all"):
+            assert pc.count(d_arr, mode=mode).equals(pc.count(h_arr, mode=mode)), mode
+    chunks = pa.chunked_array([to_device(vals.slice(0, 1000)), to_device(vals.slice(1000))])       # merge of per-batch states
+    assert pc.sum(chunks).equals(pc.sum(vals)) and pc.min_max(chunks).equals(pc.min_max(vals))
+    assert lib.arrow_amd_plugin_calls(b"reduce", 1) > red0 + 80
+    assert pc.count(pa.array(["a", None])).as_py() == 1 and pc.sum(pa.array([1.5, 2.5])).as_py() == 4.0     # other types: stock
+    try:
+        pc.sum(pa.chunked_array([vals.slice(0, 10), d_vals]))
+        raise SystemExit("expected NotImplemented for a host+device aggregation")
+    except pa.lib.ArrowNotImplementedError:
+        pass
     print("DEVICE_OK")
 ''')
 
@@ -510,6 +534,19 @@ ACERO_DEVICE_SCRIPT = textwrap.dedent(r'''
         for f in names:   # FilterNode's expression, its per-column Filter, the projection and the group-by all ran on the GPU
             assert lib.arrow_amd_plugin_calls(f, 1) > gpu0[f], f
             assert lib.arrow_amd_plugin_calls(f, 0) == stock0[f], f
+
+        # no keys: Acero's own ScalarAggregateNode (acero/scalar_aggregate_node.cc) over device batches
+        def scalar_plan(table):
+            return acero.Declaration.from_sequence([
+                acero.Declaration("table_source", acero.TableSourceNodeOptions(table)),
+                acero.Declaration("filter", acero.FilterNodeOptions(pc.field("w") > 10)),
+                acero.Declaration("aggregate", acero.AggregateNodeOptions(
+                    [("v", "sum", None, "s"), ("v", "min_max", None, "mm"), ("v", "count", None, "c"), ("w", "max", None, "wmax"),
+                     ("w", "min", pc.ScalarAggregateOptions(skip_nulls=False), "wmin")]))])
+        red0 = lib.arrow_amd_plugin_calls(b"reduce", 1)
+        for threads in (False, True):
+            assert scalar_plan(dev).to_table(use_threads=threads).equals(scalar_plan(host).to_table(use_threads=threads)), (null_p, threads)
+        assert lib.arrow_amd_plugin_calls(b"reduce", 1) >= red0 + 10
     print("ACERO_DEVICE_OK")
 ''')
 

@@ -78,9 +78,16 @@ SCRIPT = textwrap.dedent(r'''
                pc.or_kleene(pa.scalar(True), pa.scalar(None, pa.bool_())), pc.invert(bm), pc.invert(m.slice(5)),
                pc.invert(pa.scalar(None, pa.bool_())), pc.and_kleene(pa.chunked_array([bm.slice(0, 300), bm.slice(300)]), m),
                pa.table({"x": fn, "y": g}).filter((pc.field("x") > pc.field("y")) & ~(pc.field("x") > 0.5)).column("x").combine_chunks()]
-        strs = pa.array([None if i % 5 == 0 else "s" * (i % 7) for i in range(1000)])
+        strs = strs_h = pa.array([None if i % 5 == 0 else "s" * (i % 7) for i in range(1000)])
         gt += [pc.filter(strs, m), pc.take(strs, pa.array([5, 1, 999, None])),
                pc.filter(strs.cast(pa.binary()), m, null_selection_behavior="emit_null")]
+        # scalar aggregates of HOST int64 data pass through our shim to the stock state (incl. chunked input, options, Acero)
+        an = pa.array(np.arange(1000) * 7 - 3000, mask=np.arange(1000) % 11 == 0)
+        for opts in (None, pc.ScalarAggregateOptions(skip_nulls=False), pc.ScalarAggregateOptions(min_count=995)):
+            gt += [pc.call_function(fname, [arr], opts) for fname in ("sum", "min_max", "min", "max") for arr in
+                   (an, a, an.slice(5, 0), pa.chunked_array([an.slice(0, 300), an.slice(300)]))]
+        gt += [pc.count(an, mode=mode) for mode in ("only_valid", "only_null", "all")] + [pc.count(strs_h), pc.sum(f), pc.mean(an)]
+        gt += [pa.table({"x": an}).group_by([]).aggregate([("x", "sum"), ("x", "min_max"), ("x", "count"), ("x", "max")]).to_pydict().__repr__()]
         return gt + [pc.filter(a, m), pc.take(a, pa.array([5, 1, 999])), pc.greater(f, pa.array(f.to_numpy()[::-1].copy())),
                 pc.array_sort_indices(pa.array(np.arange(1000)[::-1].astype(np.uint64))),
                 pc.array_sort_indices(pa.array((np.arange(1000) % 13).astype(np.int64), mask=np.arange(1000) % 9 == 0),
@@ -106,7 +113,7 @@ SCRIPT = textwrap.dedent(r'''
         assert (x == y) if isinstance(x, str) else x.equals(y), (i, x, y)
         if isinstance(x, pa.Array):
             assert x.null_count == y.null_count, i
-    for fn in (b"array_filter", b"array_take", b"greater", b"array_sort_indices", b"cast", b"add", b"boolean", b"compare"):
+    for fn in (b"array_filter", b"array_take", b"greater", b"array_sort_indices", b"cast", b"add", b"boolean", b"compare", b"reduce"):
         assert lib.arrow_amd_plugin_calls(fn, 0) >= 1, fn     # handed to Arrow's stock kernel
         assert lib.arrow_amd_plugin_calls(fn, 1) == 0, fn     # nothing claimed to be a GPU call
     assert lib.arrow_amd_plugin_calls(b"no_such_function", 0) == -1
