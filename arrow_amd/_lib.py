@@ -133,6 +133,8 @@ SIGNATURES = {
     "arx_add_i64": (_int, [_p, _p, _i64, _p, _p]),
     "arx_add_f64": (_int, [_p, _p, _i64, _p, _p]),
     "arx_bitmap_copy": (_int, [_p, _i64, _i64, _p, _p]),
+    "arx_bitmap_copy_at": (_int, [_p, _i64, _i64, _p, _i64, _p]),
+    "arx_binary_rebase_offsets": (_int, [_p, _i64, C.c_int32, _p, _p]),
     "arx_bitmap_and": (_int, [_p, _i64, _p, _i64, _i64, _p, _p]),
     "arx_reduce_i64_init": (_int, [_p, _p]),
     "arx_reduce_i64_consume": (_int, [_span, _p, _p]),

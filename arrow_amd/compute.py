@@ -13,6 +13,7 @@ libarrow_amd.so (include/arrow_amd.h).  There is no CPU compute path.
 """
 from __future__ import annotations
 
+import builtins
 import ctypes as C
 import threading
 
@@ -23,7 +24,7 @@ from . import _lib, tracing
 from ._lib import (ArrowIndexError, ArrowInvalid, ArrowNotImplementedError, check)  # noqa: F401
 from .array import (Array, DataType, Scalar, alloc, bitmap_nbytes, bool_, current_stream, float32,
                     float64, int32, int64, kUnknownNullCount, uint8, uint16, uint32, uint64,
-                    INDEX_TYPE_ID)
+                    INDEX_TYPE_ID, is_base_binary)
 
 # --------------------------------------------------------------------------- options
 class FunctionOptions:
@@ -1002,6 +1003,100 @@ def invert(arr):
 def sort_indices(arr, order: str = "ascending", null_placement: str = "at_end"):
     """compute::SortIndices (api_vector.cc:334-347)."""
     return call_function("sort_indices", [arr], SortOptions([("", order)], null_placement))
+
+
+def concat_arrays(arrays) -> Array:
+    """arrow::Concatenate (array/concatenate.cc: ConcatenateBitmaps, ConcatenateBuffers, PutOffsets) for
+    fixed-width, boolean and utf8/binary arrays: one output array, chunks glued at arbitrary bit positions.
+    What an operator that must see its whole input does first (OrderByNode, acero/order_by_node.cc:100-108)."""
+    arrays = list(arrays)
+    if not arrays:
+        raise ArrowInvalid("Must pass at least one array")
+    t = arrays[0].type
+    if any(a.type != t for a in arrays):
+        raise ArrowInvalid("arrays to be concatenated must be identically typed")
+    dev = arrays[0].device
+    lib, stream = _lib_and_stream(dev)
+    n = builtins.sum(a.length for a in arrays)
+    have_validity = any(a.validity is not None and a.null_count != 0 for a in arrays)
+    out_valid = alloc(bitmap_nbytes(n), dev, zero=True) if have_validity else None
+    pos = 0
+    if have_validity:
+        for a in arrays:
+            check(lib.arx_bitmap_copy_at((a.validity.data_ptr() if a.validity is not None and a.null_count != 0 else None), a.offset, a.length,
+                                         out_valid.data_ptr(), pos, stream))
+            pos += a.length
+    if is_base_binary(t):
+        # (two offsets per chunk come back to the host: where its bytes start and end)
+        ends = [a.buffers[1].view(torch.int32)[[a.offset, a.offset + a.length]].cpu().tolist() if a.length else [0, 0]
+                for a in arrays]
+        total = builtins.sum(e - b for b, e in ends)
+        if total > 2**31 - 1:
+            raise ArrowInvalid("offset overflow while concatenating arrays")
+        out_off = alloc((n + 1) * 4, dev, zero=True)
+        out_data = alloc(total, dev)
+        pos, base = 0, 0
+        for a, (b, e) in zip(arrays, ends):
+            if a.length == 0:
+                continue
+            check(lib.arx_binary_rebase_offsets(a.buffers[1].data_ptr() + a.offset * 4, a.length, base,
+                                                out_off.data_ptr() + pos * 4, stream))
+            if e > b:
+                out_data[base:base + e - b].copy_(a.buffers[2][b:e])
+            pos += a.length
+            base += e - b
+        out = Array(t, n, [out_valid, out_off, out_data], kUnknownNullCount if have_validity else 0, 0)
+    elif t == bool_:
+        out_bits = alloc(bitmap_nbytes(n), dev, zero=True)
+        pos = 0
+        for a in arrays:
+            check(lib.arx_bitmap_copy_at(a.data.data_ptr(), a.offset, a.length, out_bits.data_ptr(), pos, stream))
+            pos += a.length
+        out = Array(t, n, [out_valid, out_bits], kUnknownNullCount if have_validity else 0, 0)
+    else:
+        w = t.byte_width
+        out_data = alloc(n * w, dev)
+        pos = 0
+        for a in arrays:
+            out_data[pos * w:(pos + a.length) * w].copy_(a.data[a.offset * w:(a.offset + a.length) * w])
+            pos += a.length
+        out = Array(t, n, [out_valid, out_data], kUnknownNullCount if have_validity else 0, 0)
+    if have_validity:
+        known = [a.null_count for a in arrays]
+        if all(k >= 0 for k in known):
+            out._null_count = builtins.sum(known)
+    return out
+
+
+def sort_indices_by_keys(keys, orders=None, null_placement="at_end") -> Array:
+    """SortIndices(Table, SortOptions) for several sort keys (TableSorter / MultipleKeyRecordBatchSorter,
+    kernels/vector_sort.cc:850-954): lexicographic, stable, every key with its own order and its own null
+    placement (SortKey::null_placement, compute/ordering.h:50-61; one string = the SortOptions-wide override,
+    api_vector.h:132-143).  Least-significant key first, one stable device sort per key: perm = sort(k_last);
+    then perm = take(perm, sort(take(k, perm))) for each earlier key."""
+    keys = list(keys)
+    orders = list(orders) if orders is not None else ["ascending"] * len(keys)
+    places = [null_placement] * len(keys) if isinstance(null_placement, str) else list(null_placement)
+    if not keys or len(keys) != len(orders) or len(keys) != len(places):
+        raise ArrowInvalid("Must specify one or more sort keys")
+    perm = None
+    for key, order, place in zip(reversed(keys), reversed(orders), reversed(places)):
+        opts = ArraySortOptions(order, place)
+        if perm is None:
+            perm = call_function("array_sort_indices", [key], opts)
+        else:
+            step = call_function("array_sort_indices", [take(key, perm, boundscheck=False)], opts)
+            perm = take(perm, step, boundscheck=False)
+    return perm
+
+
+def order_by(columns, sort_keys, null_placement="at_end"):
+    """OrderByNode::DoFinish (acero/order_by_node.cc:100-108): concatenate the accumulated batches,
+    SortIndices on the sort keys, Take on every column.  `columns` = list of columns, each a list of chunks;
+    `sort_keys` = [(column index, "ascending" | "descending")]."""
+    whole = [concat_arrays(chunks) if len(chunks) != 1 or chunks[0].offset != 0 else chunks[0] for chunks in columns]
+    perm = sort_indices_by_keys([whole[i] for i, _ in sort_keys], [o for _, o in sort_keys], null_placement)
+    return [take(col, perm, boundscheck=False) for col in whole]
 
 
 # --------------------------------------------------------------------------- group-by

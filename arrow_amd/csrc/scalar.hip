@@ -402,6 +402,37 @@ __global__ __launch_bounds__(kBlock) void bitmap_kernel(Bits a, Bits b, int64_t 
   }
 }
 
+// Bit-granular concatenation: OR `length` bits of `src` into `dst` starting at bit `dst_off` (what
+// arrow::Concatenate does for validity / boolean data, array/concatenate.cc, when chunks are glued at
+// arbitrary bit positions).  One destination word per lane-iteration: interior words are stored whole,
+// the first and last word of the range are OR-ed (the destination is zero there, or holds the tail of
+// the previous chunk written by an earlier launch on the same stream).
+__global__ __launch_bounds__(kBlock) void bitmap_copy_at_kernel(Bits src, int64_t src_words, int64_t first_word,
+                                                                int64_t dst_words, int shift,
+                                                                uint64_t* __restrict__ dst) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; r < dst_words; r += stride) {
+    uint64_t v = r < src_words ? load_word(src, r) << shift : 0;
+    if (shift != 0 && r > 0) v |= load_word(src, r - 1) >> (64 - shift);
+    if (r == 0 || r == dst_words - 1) {
+      if (v != 0) atomicOr(reinterpret_cast<unsigned long long*>(dst + first_word + r), static_cast<unsigned long long>(v));
+    } else {
+      dst[first_word + r] = v;
+    }
+  }
+}
+
+// Offsets of one chunk of a utf8/binary array moved to their place in the concatenated array:
+// out[i] = in[i] - in[0] + base for i in [0, n] (Concatenate's PutOffsets, array/concatenate.cc).
+__global__ __launch_bounds__(kBlock) void rebase_offsets_kernel(const int32_t* __restrict__ in, int64_t n,
+                                                                int32_t base, int32_t* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int32_t first = in[0];
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i <= n; i += stride) {
+    out[i] = in[i] - first + base;
+  }
+}
+
 // and_kleene / or_kleene / invert on boolean arrays, one 64-bit word per lane-iteration
 // (KleeneAndOp / KleeneOrOp / InvertOp, kernels/scalar_boolean.cc:138-260): with
 //   x_true = x_valid & x_data,  x_false = x_valid & ~x_data
@@ -733,6 +764,34 @@ int arx_bitmap_copy(const void* bits, int64_t bit_offset, int64_t length, void* 
   hipLaunchKernelGGL((bitmap_kernel<false>), dim3(grid), dim3(kBlock), 0, as_stream(stream), a, a,
                      nwords, static_cast<uint64_t*>(out));
   ARX_CHECK_LAUNCH("bitmap_kernel");
+  return ARX_OK;
+}
+
+int arx_bitmap_copy_at(const void* bits, int64_t bit_offset, int64_t length, void* out, int64_t out_bit_offset,
+                       void* stream) {
+  if (length < 0 || bit_offset < 0 || out_bit_offset < 0 || (length > 0 && out == nullptr)) {
+    set_error("bad arguments to arx_bitmap_copy_at");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  const Bits a = make_bits(bits, bit_offset, length);
+  const int64_t first_word = out_bit_offset / 64;
+  const int64_t dst_words = (out_bit_offset + length - 1) / 64 - first_word + 1;
+  const unsigned grid = stream_grid(kBlock, dst_words);
+  hipLaunchKernelGGL(bitmap_copy_at_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), a, ceil_div(length, 64),
+                     first_word, dst_words, static_cast<int>(out_bit_offset % 64), static_cast<uint64_t*>(out));
+  ARX_CHECK_LAUNCH("bitmap_copy_at_kernel");
+  return ARX_OK;
+}
+
+int arx_binary_rebase_offsets(const int32_t* offsets, int64_t length, int32_t base, int32_t* out, void* stream) {
+  if (length < 0 || offsets == nullptr || out == nullptr) {
+    set_error("bad arguments to arx_binary_rebase_offsets");
+    return ARX_INVALID;
+  }
+  const unsigned grid = stream_grid(kBlock, length + 1);
+  hipLaunchKernelGGL(rebase_offsets_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), offsets, length, base, out);
+  ARX_CHECK_LAUNCH("rebase_offsets_kernel");
   return ARX_OK;
 }
 

@@ -291,6 +291,17 @@ int arx_bitmap_copy(const void* bits, int64_t bit_offset, int64_t length, void* 
                     void* stream);
 int arx_bitmap_and(const void* left, int64_t left_offset, const void* right,
                    int64_t right_offset, int64_t length, void* out, void* stream);
+/* Concatenation plumbing (arrow::Concatenate, cpp/src/arrow/array/concatenate.cc: ConcatenateBitmaps
+ * and PutOffsets) for operators that must see all their input at once (OrderByNode accumulates every
+ * batch, cpp/src/arrow/acero/order_by_node.cc:100-122).
+ * arx_bitmap_copy_at ORs bits [bit_offset, bit_offset+length) of `bits` (NULL = all ones) into `out`
+ * starting at bit `out_bit_offset`; the words of `out` from that bit on must be zero (memset once, then
+ * append chunk after chunk on one stream).  arx_binary_rebase_offsets writes
+ * out[i] = offsets[i] - offsets[0] + base for i in [0, length].  Asynchronous. */
+int arx_bitmap_copy_at(const void* bits, int64_t bit_offset, int64_t length, void* out,
+                       int64_t out_bit_offset, void* stream);
+int arx_binary_rebase_offsets(const int32_t* offsets, int64_t length, int32_t base, int32_t* out,
+                              void* stream);
 /* Scalar aggregates over an int64 column in one pass — the state SumImpl / CountImpl / MinMaxImpl keep
  * (cpp/src/arrow/compute/kernels/aggregate_basic.inc.cc:49-110,776-860): acc = {wrap-around sum of the
  * valid values, their count, min, max} as 4 x int64 in device memory; init once, consume per batch

@@ -333,6 +333,31 @@ def sort_indices(values, valid, offset, length, descending=False, nulls_at_start
     return out
 
 
+def sort_indices_multi(keys, descending=None, nulls_at_start=False):
+    """SortIndices(Table) with several sort keys (TableSorter, kernels/vector_sort.cc:850-954; row comparison
+    MultipleKeyComparator, vector_sort_internal.h): rows ordered lexicographically, key by key, each key with
+    its own direction and null placement (SortKey::null_placement, compute/ordering.h:50-61; one bool = the
+    same for all keys); within one key nulls then NaNs sit at the far end (at_end) or NaNs-after-nulls at the
+    front (at_start) regardless of the direction; ties keep their input order.  `keys` = [(values, valid
+    bool array or None)] over the logical rows.  numpy restatement: lexsort (stable) over, per key,
+    (class: value / NaN / null, dense rank of the value negated for descending)."""
+    descending = list(descending) if descending is not None else [False] * len(keys)
+    at_start = [bool(nulls_at_start)] * len(keys) if isinstance(nulls_at_start, (bool, np.bool_)) else list(nulls_at_start)
+    columns = []
+    for (values, valid), desc, nulls_at_start in zip(keys, descending, at_start):
+        values = np.asarray(values)
+        n = len(values)
+        is_null = np.zeros(n, bool) if valid is None else ~np.asarray(valid, bool)
+        is_nan = np.isnan(values) & ~is_null if values.dtype.kind == "f" else np.zeros(n, bool)
+        plain = np.where(is_null | is_nan, values.dtype.type(0), values)
+        _, rank = np.unique(plain, return_inverse=True)       # (-0.0 and 0.0 share a rank: they compare equal)
+        rank = rank.astype(np.int64)
+        rank = np.where(is_null | is_nan, 0, -rank if desc else rank)
+        cls = np.where(is_null, 0 if nulls_at_start else 2, np.where(is_nan, 1, 2 if nulls_at_start else 0))
+        columns += [cls, rank]
+    return np.lexsort(tuple(reversed(columns))).astype(np.uint64)
+
+
 def groupby_sum_i64(keys, key_valid, key_off, values, val_valid, val_off, length,
                     skip_nulls=True, min_count=1):
     """Returns dict(keys, key_is_valid, sums, counts, no_nulls, valid) in first-occurrence order."""

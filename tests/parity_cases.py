@@ -541,6 +541,69 @@ def check_sort_indices(amd, arr: HostArray, order="ascending", null_placement="a
 
 
 # ------------------------------------------------------------------ group-by
+def check_concat_arrays(amd, chunks, use_pyarrow=True):
+    """Concatenate (array/concatenate.cc): chunks glued at arbitrary bit positions; values and validity equal
+    the numpy concatenation of the logical rows, padding bits stay zero, pyarrow's result is the same array."""
+    dev = [c.to_device(amd) for c in chunks]
+    out = amd.compute.concat_arrays(dev)
+    n = sum(c.length for c in chunks)
+    assert out.length == n and out.offset == 0
+    any_nulls = any(c.null_count() for c in chunks)
+    want_valid = np.concatenate([c.logical_valid() for c in chunks]) if n else np.zeros(0, bool)
+    if out.validity is not None:
+        gv, pad_ok = _logical_valid(out)
+        assert_equal(gv, want_valid, "concat validity")
+        assert pad_ok
+        # (the sum of the chunks' counts when all are known, else unknown — as Concatenate leaves it)
+        assert out.null_count in (int((~want_valid).sum()), -1)
+    else:
+        assert not any_nulls and out.null_count == 0
+    if isinstance(chunks[0], util.HostBinaryArray):
+        offs, data = _binary_out(out)
+        want = [x for c in chunks for x in c.logical_values()]
+        got = [bytes(data[offs[i]:offs[i + 1]]) for i in range(n)]
+        assert got == want, "concat binary rows"      # (null rows keep their bytes, as Concatenate copies whole ranges)
+        assert offs[0] == 0
+    elif chunks[0].is_bool:
+        bits, pad_ok = device_bitmap_to_bool(out.data, n)
+        assert_equal(bits, np.concatenate([c.logical_values() for c in chunks]) if n else np.zeros(0, bool), "concat bits")
+        assert pad_ok
+    else:
+        assert_equal(_data_np(out, chunks[0].dtype), np.concatenate([c.logical_values() for c in chunks]), "concat data")
+    if use_pyarrow and pa is not None:
+        assert out.to_pyarrow().equals(pa.concat_arrays([c.to_pyarrow() for c in chunks]))
+
+
+def check_order_by(amd, columns, sort_keys, null_placement="at_end", use_pyarrow=True):
+    """OrderByNode::DoFinish (acero/order_by_node.cc:100-108): concatenate, SortIndices over several keys,
+    Take.  `columns` = [[chunk, ...], ...] of host arrays; `sort_keys` = [(column, order)]."""
+    dev_cols = [[c.to_device(amd) for c in col] for col in columns]
+    whole = [amd.compute.concat_arrays(col) for col in dev_cols]
+    perm = amd.compute.sort_indices_by_keys([whole[i] for i, _ in sort_keys], [o for _, o in sort_keys], null_placement)
+    logical = []
+    for i, order in sort_keys:
+        vals = np.concatenate([c.logical_values() for c in columns[i]])
+        valid = np.concatenate([c.logical_valid() for c in columns[i]])
+        logical.append((vals, valid))
+    places = [null_placement] * len(sort_keys) if isinstance(null_placement, str) else list(null_placement)
+    want = O.sort_indices_multi(logical, [o == "descending" for _, o in sort_keys], [p == "at_start" for p in places])
+    assert_equal(_data_np(perm, np.uint64), want, "multi-key sort indices")
+    got_cols = amd.compute.order_by(dev_cols, sort_keys, null_placement)
+    if use_pyarrow and pa is not None:
+        table = pa.table({f"c{i}": pa.chunked_array([c.to_pyarrow() for c in col]) for i, col in enumerate(columns)})
+        ref_idx = pc.sort_indices(table, sort_keys=[(f"c{i}", o, p) for (i, o), p in zip(sort_keys, places)])
+        assert_equal(want, ref_idx.to_numpy(), "oracle vs pyarrow sort_indices(table)")
+        ref = table.take(ref_idx)
+        for i, col in enumerate(got_cols):
+            g, w = col.to_pyarrow(), ref.column(i).combine_chunks()
+            if pa.types.is_floating(w.type):      # (NaN != NaN for Array.equals: compare the bit patterns)
+                assert np.array_equal(np.asarray(g.is_null()), np.asarray(w.is_null()))
+                g, w = (pc.fill_null(x, 0.0).to_numpy(zero_copy_only=False).view(np.uint64) for x in (g, w))
+                assert np.array_equal(g, w), ("order_by column", i)
+            else:
+                assert g.equals(w), ("order_by column", i)
+
+
 def _sorted_groups(keys, key_valid, sums, valid):
     """Canonical form: rows sorted by (key_is_null, key) -> list of tuples (tests sort too,
     acero/hash_aggregate_test.cc:262-280)."""

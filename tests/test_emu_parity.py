@@ -622,3 +622,48 @@ def test_boolean_values_take_and_filter(emu_ctx, idx_dtype, vnull, inull, voff):
     i = U.random_array(rng, idx_dtype, 5000, null_p=inull, offset=1, lo=0, hi=nv - 1)
     m = U.random_mask(rng, nv, 0.3, null_p=0.05, offset=2)
     P.check_boolean_take_and_filter(emu_ctx, v, i, m)
+
+
+@pytest.mark.parametrize("kind", ["int64", "int8", "bool", "utf8", "binary_nonull"])
+def test_concat_arrays(emu_ctx, kind):
+    """Concatenate (array/concatenate.cc): sliced chunks with and without validity, empty chunks, bit offsets
+    that are not multiples of 8 / 64."""
+    rng = rng_for("concat", kind)
+    specs = [(77, 0.2, 3), (0, 0.0, 0), (1, 0.0, 0), (130, 0.0, 65), (64, 1.0, 7), (300, 0.1, 0), (5, 0.5, 1)]
+    if kind == "bool":
+        chunks = [U.random_mask(rng, n, 0.5, null_p=p, offset=o, tail=2) for n, p, o in specs]
+    elif kind in ("utf8", "binary_nonull"):
+        chunks = [U.random_binary(rng, n, null_p=0.0 if kind == "binary_nonull" else p, offset=o, tail=2, utf8=kind == "utf8")
+                  for n, p, o in specs]
+    else:
+        chunks = [U.random_array(rng, np.dtype(kind).type, n, null_p=p, offset=o, tail=2) for n, p, o in specs]
+    P.check_concat_arrays(emu_ctx, chunks)
+    P.check_concat_arrays(emu_ctx, chunks[1:2])            # one empty chunk
+    P.check_concat_arrays(emu_ctx, [chunks[3]])            # a single sliced chunk without nulls
+
+
+@pytest.mark.parametrize("null_placement", ["at_end", "at_start"])
+def test_order_by_several_keys(emu_ctx, null_placement):
+    """OrderByNode::DoFinish with two and three sort keys of mixed direction (few distinct values per key so
+    that every later key and the input order decide ties), a float key with NaNs, payload columns riding along."""
+    rng = rng_for("orderby", null_placement)
+    sizes = [(300, 3), (0, 0), (157, 0), (41, 5)]
+    def col(make):
+        return [make(n, o) for n, o in sizes]
+    k0 = col(lambda n, o: U.random_array(rng, np.int32, n, null_p=0.1, offset=o, tail=1, lo=-3, hi=3))
+    k1 = col(lambda n, o: U.random_array(rng, np.int64, n, null_p=0.1, offset=o, tail=1, lo=0, hi=4))
+    def fkey(n, o):
+        a = U.random_array(rng, np.float64, n, null_p=0.1, offset=o, tail=1)
+        a.values[:] = np.round(a.values * 2) / 2
+        a.values[rng.random(len(a.values)) < 0.1] = np.nan
+        return a
+    k2 = col(fkey)
+    payload = col(lambda n, o: U.random_array(rng, np.int64, n, null_p=0.2, offset=o, tail=1))
+    strs = col(lambda n, o: U.random_binary(rng, n, null_p=0.1, offset=o, tail=1, utf8=True))
+    flags = col(lambda n, o: U.random_mask(rng, n, 0.5, null_p=0.1, offset=o, tail=1))
+    cols = [k0, k1, k2, payload, strs, flags]
+    P.check_order_by(emu_ctx, cols, [(0, "ascending"), (1, "descending")], null_placement)
+    P.check_order_by(emu_ctx, cols, [(2, "descending"), (0, "descending"), (1, "ascending")], null_placement)
+    P.check_order_by(emu_ctx, cols, [(1, "ascending")], null_placement)
+    other = "at_start" if null_placement == "at_end" else "at_end"
+    P.check_order_by(emu_ctx, cols, [(0, "descending"), (2, "ascending")], [null_placement, other])     # per-key placement

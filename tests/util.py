@@ -132,6 +132,16 @@ class HostBinaryArray:
     def valid_bitmap(self):
         return None if self.valid is None else O.pack_bits(self.valid)
 
+    def logical_valid(self):
+        if self.valid is None:
+            return np.ones(self.length, dtype=bool)
+        return self.valid[self.offset: self.offset + self.length]
+
+    def logical_values(self):
+        """The rows as Python bytes (null rows too: whatever their offsets span)."""
+        o = self.offsets
+        return [self.data[o[i]:o[i + 1]].tobytes() for i in range(self.offset, self.offset + self.length)]
+
     def null_count(self):
         return 0 if self.valid is None else int((~self.valid[self.offset: self.offset + self.length]).sum())
 
