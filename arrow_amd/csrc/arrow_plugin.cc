@@ -41,6 +41,7 @@
 #include <parquet/schema.h>
 #include <arrow/util/ubsan.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -70,6 +71,7 @@ namespace {
 #include "plugin/hash_aggregate.inc"
 #include "plugin/scalar_aggregate.inc"
 #include "plugin/acero_node.inc"
+#include "plugin/order_by_node.inc"
 #include "plugin/parquet.inc"
 #include "plugin/registration.inc"
 

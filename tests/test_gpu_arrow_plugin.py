@@ -563,6 +563,98 @@ def test_acero_plan_over_a_device_resident_table():
     assert r.returncode == 0 and "ACERO_DEVICE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+ORDER_BY_SCRIPT = textwrap.dedent(r'''
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))   # sizes shrink for the emulated run
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(n) for n in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(n) for n in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    from pyarrow import acero
+    rng = np.random.default_rng(3)
+    n = SC(1_000_003)
+    def mk(a, p=0.05): return pa.array(a, mask=rng.random(len(a)) < p)
+    k0 = mk(rng.integers(-5, 5, n).astype(np.int32)); k1 = mk(rng.integers(0, 50, n)); 
+    fk = np.round(rng.standard_normal(n)*2)/2; fk[rng.random(n)<0.05] = np.nan; k2 = mk(fk)
+    v = mk(rng.integers(-2**62, 2**62, n), 0.2); s = pa.array([None if i % 11 == 0 else "s%d" % (i % 1000) for i in range(n)]); b = mk(rng.random(n) < 0.5)
+    ts = pa.array(rng.integers(0, 10**6, n), pa.timestamp("us"))
+    cols = {"k0": k0, "k1": k1, "k2": k2, "v": v, "s": s, "b": b, "ts": ts}
+    host = pa.table(cols); dev = pa.table({k: to_device(a) for k, a in cols.items()})
+    def plan(t, node, keys, filt=True):
+        seq = [acero.Declaration("table_source", acero.TableSourceNodeOptions(t))]
+        if filt: seq.append(acero.Declaration("filter", acero.FilterNodeOptions(pc.field("k1") > 5)))
+        seq.append(acero.Declaration(node, acero.OrderByNodeOptions(keys)))
+        return acero.Declaration.from_sequence(seq)
+    def host_table(t):
+        return pa.table({name: pa.chunked_array([c if c.is_cpu else to_host(c) for c in t.column(name).chunks], t.schema.field(name).type) for name in t.schema.names})
+    def same(a, b):
+        assert a.schema == b.schema and a.num_rows == b.num_rows, (a.schema, b.schema, a.num_rows, b.num_rows)
+        for name in a.schema.names:
+            x, y = a.column(name).combine_chunks(), b.column(name).combine_chunks()
+            if pa.types.is_floating(x.type):
+                assert np.array_equal(np.asarray(x.is_null()), np.asarray(y.is_null()))
+                x, y = (pc.fill_null(z, 0.0).to_numpy(zero_copy_only=False).view(np.uint64) for z in (x, y))
+                assert np.array_equal(x, y), name
+            else:
+                assert x.equals(y), name
+    light = os.environ.get("ARROW_AMD_TEST_LIGHT") == "1"      # (every sort launch costs seconds under the emulator)
+    for keys in ([("k0", "ascending"), ("k1", "descending")], [("k2", "descending", "at_start"), ("k0", "ascending", "at_end"), ("ts", "ascending")], [("k1", "ascending")])[: 2 if light else 3]:
+        for filt in ((True,) if light else (True, False)):
+            want = plan(host, "order_by", keys, filt).to_table(use_threads=False)
+            for th in (False, True):
+                got = plan(dev, "order_by_rocm", keys, filt).to_table(use_threads=th)
+                assert not got.column("v").chunk(0).is_cpu
+                same(host_table(got), want)
+            goth = plan(host, "order_by_rocm", keys, filt).to_table(use_threads=True)
+            assert goth.column("v").chunk(0).is_cpu
+            same(goth, want)
+    print("gpu", lib.arrow_amd_plugin_calls(b"order_by",1))
+    # empty input
+    got = acero.Declaration.from_sequence([acero.Declaration("table_source", acero.TableSourceNodeOptions(dev)),
+        acero.Declaration("filter", acero.FilterNodeOptions(pc.field("k1") > 1000)),
+        acero.Declaration("order_by_rocm", acero.OrderByNodeOptions([("k0","ascending")]))]).to_table()
+    assert got.num_rows == 0 and got.schema == host.schema
+    # unsupported key type
+    try:
+        plan(dev, "order_by_rocm", [("s","ascending")]).to_table(); raise SystemExit("string key accepted")
+    except pa.ArrowNotImplementedError as ex: print("ok:", ex)
+    print("ORDER_BY_OK")
+''')
+
+
+def test_acero_order_by_over_a_device_resident_table():
+    """SURVEY.md 8 (f2): OrderByNode (acero/order_by_node.cc:100-108) as `order_by_rocm`: table_source ->
+    [filter] -> order_by_rocm over device-resident and host tables, one to three sort keys with their own
+    direction and null placement (int32 / int64 / float64 with NaNs / timestamp), payload columns of int64,
+    utf8, boolean; equal to the stock `order_by` over the host table, with and without threads."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + ORDER_BY_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "ORDER_BY_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 PARQUET_SCRIPT = textwrap.dedent(r'''
     import ctypes, faulthandler, os, sys, tempfile
     import numpy as np

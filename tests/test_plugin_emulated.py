@@ -44,3 +44,7 @@ def test_pyarrow_compute_dispatches_to_the_hip_kernels_emulated():
 
 def test_parquet_column_chunks_through_the_plugin_emulated():
     _run(G.PARQUET_SCRIPT, "PARQUET_OK", 0.03)
+
+
+def test_acero_order_by_node_emulated():
+    _run(G.ORDER_BY_SCRIPT, "ORDER_BY_OK", 0.02)

@@ -145,6 +145,14 @@ SCRIPT = textwrap.dedent(r'''
             assert "HIP" in str(e) or "hip" in str(e), str(e)
         else:
             raise SystemExit("aggregate_rocm ran without a GPU")
+        try:
+            acero.Declaration.from_sequence([
+                acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
+                acero.Declaration("order_by_rocm", acero.OrderByNodeOptions([("v", "descending")]))]).to_table()
+        except (OSError, pa.ArrowException) as e:
+            assert "HIP" in str(e) or "hip" in str(e), str(e)
+        else:
+            raise SystemExit("order_by_rocm ran without a GPU")
     print("REGISTRATION_OK")
 ''')
 
