@@ -80,6 +80,119 @@ static int rle_check(const void* bytes, const ArxRleRun* runs, int64_t nruns, in
   return ARX_OK;
 }
 
+
+// ---------------------------------------------------------------- DELTA_BINARY_PACKED
+// DeltaBitPackDecoder (cpp/src/parquet/decoder.cc; format: Encodings.md "Delta encoding"):
+//   header  := varint(block size) varint(miniblocks per block) varint(total values) zigzag(first value)
+//   block   := zigzag(min delta) bit_width[miniblocks] miniblock*
+//   value_i := value_{i-1} + min_delta(block of i) + unpack(miniblock of i)            (wrap-around)
+// The headers are walked once on the host (arx_delta_scan_miniblocks: one table entry per miniblock); every
+// miniblock holds the same number of deltas, so value i finds its entry by division.  The recurrence is a
+// prefix sum: per 4096-value tile the deltas are unpacked and summed (pass 1), the tile totals are scanned by
+// one block, then every tile is unpacked again, scanned with its carry and written (pass 2) — the packed page
+// is read twice, nothing intermediate per value is stored.
+constexpr int kDeltaTile = 4096;
+
+__device__ __forceinline__ long long delta_at(const uint64_t* __restrict__ words, const ArxDeltaMiniblock* __restrict__ mbs,
+                                              int64_t values_per_miniblock, long long first_value, int64_t i) {
+  if (i == 0) return first_value;
+  const int64_t j = i - 1;
+  const ArxDeltaMiniblock mb = mbs[j / values_per_miniblock];
+  if (mb.bit_width == 0) return static_cast<long long>(mb.min_delta);
+  const uint64_t bit = mb.bit_start + static_cast<uint64_t>(j % values_per_miniblock) * mb.bit_width;
+  const uint64_t w = bit >> 6;
+  const int s = static_cast<int>(bit & 63);
+  uint64_t v = words[w] >> s;
+  if (s + static_cast<int>(mb.bit_width) > 64) v |= words[w + 1] << (64 - s);
+  if (mb.bit_width < 64) v &= (uint64_t(1) << mb.bit_width) - 1;
+  return static_cast<long long>(static_cast<uint64_t>(mb.min_delta) + v);
+}
+
+__global__ __launch_bounds__(kBlock) void delta_tile_sums_kernel(const uint64_t* __restrict__ words,
+                                                                 const ArxDeltaMiniblock* __restrict__ mbs,
+                                                                 int64_t values_per_miniblock, long long first_value,
+                                                                 int64_t n, long long* __restrict__ tile_sums) {
+  __shared__ long long wave_sum[kWavesPerBlock];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kDeltaTile;
+  unsigned long long acc = 0;
+  for (int k = threadIdx.x; k < kDeltaTile; k += kBlock) {
+    const int64_t i = base + k;
+    if (i < n) acc += static_cast<unsigned long long>(delta_at(words, mbs, values_per_miniblock, first_value, i));
+  }
+  acc = wave_reduce_sum_u64(acc);
+  if (lane_id() == 0) wave_sum[threadIdx.x >> 6] = static_cast<long long>(acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) t += static_cast<unsigned long long>(wave_sum[w]);
+    tile_sums[blockIdx.x] = static_cast<long long>(t);
+  }
+}
+
+// in-place exclusive scan of the tile totals by one block (same shape as bin_scan_blocks_kernel)
+__global__ __launch_bounds__(1024) void delta_scan_tiles_kernel(long long* sums, int64_t ntiles) {
+  __shared__ long long wave_tot[16];
+  __shared__ long long carry_s;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < ntiles; base += 1024) {
+    const int64_t i = base + tid;
+    const unsigned long long v = i < ntiles ? static_cast<unsigned long long>(sums[i]) : 0;
+    unsigned long long x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long nb = __shfl_up(x, d, 64);
+      if (lane >= d) x += nb;
+    }
+    if (lane == 63) wave_tot[wave] = static_cast<long long>(x);
+    __syncthreads();
+    unsigned long long pre = 0;
+    for (int k = 0; k < wave; ++k) pre += static_cast<unsigned long long>(wave_tot[k]);
+    const unsigned long long carry = static_cast<unsigned long long>(carry_s);
+    if (i < ntiles) sums[i] = static_cast<long long>(carry + pre + x - v);
+    __syncthreads();
+    if (tid == 1023) carry_s = static_cast<long long>(carry + pre + x);
+    __syncthreads();
+  }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(kBlock) void delta_write_kernel(const uint64_t* __restrict__ words,
+                                                             const ArxDeltaMiniblock* __restrict__ mbs,
+                                                             int64_t values_per_miniblock, long long first_value,
+                                                             int64_t n, const long long* __restrict__ tile_carry,
+                                                             OutT* __restrict__ out) {
+  __shared__ long long wave_tot[kWavesPerBlock];
+  __shared__ long long carry_s;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kDeltaTile;
+  if (threadIdx.x == 0) carry_s = tile_carry[blockIdx.x];
+  __syncthreads();
+  for (int k0 = 0; k0 < kDeltaTile; k0 += kBlock) {      // block-uniform trip count
+    const int64_t i = base + k0 + threadIdx.x;
+    const unsigned long long v = i < n ? static_cast<unsigned long long>(delta_at(words, mbs, values_per_miniblock, first_value, i)) : 0;
+    unsigned long long x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long nb = __shfl_up(x, d, 64);
+      if (lane >= d) x += nb;
+    }
+    if (lane == 63) wave_tot[wave] = static_cast<long long>(x);
+    __syncthreads();
+    unsigned long long pre = 0;
+    for (int w = 0; w < wave; ++w) pre += static_cast<unsigned long long>(wave_tot[w]);
+    const unsigned long long carry = static_cast<unsigned long long>(carry_s);
+    if (i < n) out[i] = static_cast<OutT>(carry + pre + x);
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) carry_s = static_cast<long long>(carry + pre + x);
+    __syncthreads();
+  }
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -180,6 +293,125 @@ int arx_plain_byte_array_offsets(const void* data, size_t nbytes, int64_t count,
     pos += 4 + len;
     out_offsets[2 * i + 2] = base + static_cast<int32_t>(pos);
   }
+  return ARX_OK;
+}
+
+// Host-side walk over the headers of one DELTA_BINARY_PACKED block sequence (no device work).  Fills one
+// ArxDeltaMiniblock per miniblock that holds values; `byte_base` = where `data` sits in the buffer the device
+// will see (its bit positions are absolute in that buffer).  Returns the header fields and the bytes consumed
+// (DELTA_BYTE_ARRAY-style callers continue after them).
+int arx_delta_scan_miniblocks(const void* data, size_t nbytes, uint64_t byte_base, ArxDeltaMiniblock* out,
+                              int64_t max_miniblocks, int64_t* num_miniblocks, int64_t* values_per_miniblock,
+                              int64_t* total_values, int64_t* first_value, size_t* bytes_consumed) {
+  if (data == nullptr || num_miniblocks == nullptr || values_per_miniblock == nullptr || total_values == nullptr ||
+      first_value == nullptr) {
+    set_error("bad arguments to arx_delta_scan_miniblocks");
+    return ARX_INVALID;
+  }
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  size_t pos = 0;
+  bool bad = false;
+  auto varint = [&]() -> uint64_t {
+    uint64_t v = 0;
+    for (int shift = 0; shift < 70; shift += 7) {
+      if (pos >= nbytes) { bad = true; return 0; }
+      const uint8_t c = p[pos++];
+      v |= static_cast<uint64_t>(c & 0x7F) << shift;
+      if ((c & 0x80) == 0) return v;
+    }
+    bad = true;
+    return 0;
+  };
+  auto zigzag = [&]() -> int64_t {
+    const uint64_t u = varint();
+    return static_cast<int64_t>((u >> 1) ^ (~(u & 1) + 1));
+  };
+  const uint64_t block_size = varint();
+  const uint64_t per_block = varint();
+  const uint64_t total = varint();
+  const int64_t first = zigzag();
+  if (bad || per_block == 0 || block_size == 0 || block_size % 128 != 0 || block_size % per_block != 0 ||
+      (block_size / per_block) % 32 != 0 || total > (uint64_t(1) << 40)) {
+    set_error("Parquet: bad DELTA_BINARY_PACKED header (corrupt data page?)");
+    return ARX_INVALID;
+  }
+  const int64_t vpm = static_cast<int64_t>(block_size / per_block);
+  int64_t remaining = static_cast<int64_t>(total) - 1, nmb = 0;
+  while (remaining > 0) {
+    const int64_t min_delta = zigzag();
+    if (bad || pos + per_block > nbytes) {
+      set_error("Parquet: DELTA_BINARY_PACKED block header runs past the page (corrupt data page?)");
+      return ARX_INVALID;
+    }
+    const uint8_t* widths = p + pos;
+    pos += per_block;
+    for (uint64_t m = 0; m < per_block && remaining > 0; ++m) {
+      const uint32_t bw = widths[m];
+      const size_t mbytes = static_cast<size_t>(vpm) * bw / 8;
+      if (bw > 64 || pos + mbytes > nbytes) {
+        set_error("Parquet: DELTA_BINARY_PACKED miniblock runs past the page (corrupt data page?)");
+        return ARX_INVALID;
+      }
+      if (out != nullptr) {
+        if (nmb >= max_miniblocks) {
+          set_error("arx_delta_scan_miniblocks: more than %lld miniblocks", static_cast<long long>(max_miniblocks));
+          return ARX_INVALID;
+        }
+        out[nmb] = ArxDeltaMiniblock{(byte_base + pos) * 8, min_delta, bw, 0u};
+      }
+      ++nmb;
+      pos += mbytes;
+      remaining -= vpm;
+    }
+  }
+  *num_miniblocks = nmb;
+  *values_per_miniblock = vpm;
+  *total_values = static_cast<int64_t>(total);
+  *first_value = first;
+  if (bytes_consumed != nullptr) *bytes_consumed = pos;
+  return ARX_OK;
+}
+
+size_t arx_delta_decode_workspace_bytes(int64_t num_values) {
+  return (static_cast<size_t>(ceil_div(std::max<int64_t>(num_values, 1), kDeltaTile)) * 8 + 63) & ~static_cast<size_t>(63);
+}
+
+// bytes: the page buffer on the device, 8-byte aligned and readable 8 bytes past its last miniblock.
+int arx_delta_decode(const void* bytes, const ArxDeltaMiniblock* miniblocks, int64_t num_miniblocks,
+                     int64_t values_per_miniblock, int64_t first_value, int64_t num_values, int out_byte_width,
+                     void* ws, size_t ws_bytes, void* out, void* stream) {
+  if (num_values < 0 || num_miniblocks < 0 || (out_byte_width != 4 && out_byte_width != 8) ||
+      (reinterpret_cast<uintptr_t>(bytes) & 7) != 0) {
+    set_error("bad arguments to arx_delta_decode");
+    return ARX_INVALID;
+  }
+  if (num_values == 0) return ARX_OK;
+  if (out == nullptr || ws == nullptr || ws_bytes < arx_delta_decode_workspace_bytes(num_values) ||
+      (num_values > 1 && (bytes == nullptr || miniblocks == nullptr || values_per_miniblock <= 0 ||
+                          num_miniblocks * values_per_miniblock < num_values - 1))) {
+    set_error("arx_delta_decode: %lld values need their miniblocks, an output and %zu workspace bytes",
+              static_cast<long long>(num_values), arx_delta_decode_workspace_bytes(num_values));
+    return ARX_INVALID;
+  }
+  const int64_t ntiles = ceil_div(num_values, kDeltaTile);
+  const uint64_t* words = static_cast<const uint64_t*>(bytes);
+  long long* sums = static_cast<long long*>(ws);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(delta_tile_sums_kernel, dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, words, miniblocks,
+                     values_per_miniblock, static_cast<long long>(first_value), num_values, sums);
+  ARX_CHECK_LAUNCH("delta_tile_sums_kernel");
+  hipLaunchKernelGGL(delta_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, sums, ntiles);
+  ARX_CHECK_LAUNCH("delta_scan_tiles_kernel");
+  if (out_byte_width == 8) {
+    hipLaunchKernelGGL((delta_write_kernel<long long>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, words,
+                       miniblocks, values_per_miniblock, static_cast<long long>(first_value), num_values, sums,
+                       static_cast<long long*>(out));
+  } else {
+    hipLaunchKernelGGL((delta_write_kernel<int32_t>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, words,
+                       miniblocks, values_per_miniblock, static_cast<long long>(first_value), num_values, sums,
+                       static_cast<int32_t*>(out));
+  }
+  ARX_CHECK_LAUNCH("delta_write_kernel");
   return ARX_OK;
 }
 

@@ -1,7 +1,8 @@
 """Parquet column chunks decoded into HBM (first slice).
 
 Scope: flat columns of physical type INT32 / INT64 / FLOAT / DOUBLE (PLAIN and PLAIN_DICTIONARY /
-RLE_DICTIONARY encodings, incl. the dictionary -> PLAIN fallback inside a chunk), BOOLEAN (PLAIN, RLE) and
+RLE_DICTIONARY encodings, incl. the dictionary -> PLAIN fallback inside a chunk; DELTA_BINARY_PACKED for
+INT32 / INT64), BOOLEAN (PLAIN, RLE) and
 BYTE_ARRAY columns (utf8 / binary; dictionary-encoded and PLAIN pages); required or optional (max definition level <= 1, no repetition),
 data pages V1 and V2, any page compression pyarrow's codecs can undo.
 
@@ -29,10 +30,12 @@ from .array import Array, alloc, bitmap_nbytes, current_stream, default_device, 
 # parquet.thrift enums
 _PAGE_DATA, _PAGE_INDEX, _PAGE_DICT, _PAGE_DATA_V2 = 0, 1, 2, 3
 _ENC_PLAIN, _ENC_PLAIN_DICT, _ENC_RLE, _ENC_BIT_PACKED, _ENC_RLE_DICT = 0, 2, 3, 4, 8
+_ENC_DELTA_BINARY_PACKED = 5
 _PHYSICAL = {"INT32": (int32, np.int32), "INT64": (int64, np.int64), "FLOAT": (float32, np.float32),
              "DOUBLE": (float64, np.float64)}
 
 RUN_DTYPE = np.dtype([("out_start", "<u4"), ("kind", "<u4"), ("payload", "<u8")])   # struct ArxRleRun
+MINIBLOCK_DTYPE = np.dtype([("bit_start", "<u8"), ("min_delta", "<i8"), ("bit_width", "<u4"), ("reserved", "<u4")])   # struct ArxDeltaMiniblock
 
 
 # --------------------------------------------------------------------------- Thrift compact protocol
@@ -123,6 +126,39 @@ def read_page_header(buf, pos):
 
 
 # --------------------------------------------------------------------------- run headers (host walk)
+def scan_delta_miniblocks(data, byte_base: int = 0):
+    """Walks the block headers of one DELTA_BINARY_PACKED page (DeltaBitPackDecoder::InitHeader / InitBlock,
+    parquet/decoder.cc) with the host function arx_delta_scan_miniblocks.  Returns (miniblocks, values per
+    miniblock, total values, first value, bytes consumed); bit positions are shifted by byte_base."""
+    lib = _lib.get_lib()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    ptr = buf.ctypes.data if len(buf) else None
+    nmb, vpm, total, first, used = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_size_t(0)
+    check(lib.arx_delta_scan_miniblocks(ptr, len(buf), byte_base, None, 0, C.byref(nmb), C.byref(vpm), C.byref(total),
+                                        C.byref(first), C.byref(used)))           # pass 1: count
+    mbs = np.zeros(max(nmb.value, 1), dtype=MINIBLOCK_DTYPE)
+    check(lib.arx_delta_scan_miniblocks(ptr, len(buf), byte_base, mbs.ctypes.data, nmb.value, C.byref(nmb), C.byref(vpm),
+                                        C.byref(total), C.byref(first), C.byref(used)))     # pass 2: fill
+    return mbs[: nmb.value], vpm.value, total.value, first.value, used.value
+
+
+def decode_delta_binary_packed(data, byte_width: int = 8, device=None) -> Array:
+    """One DELTA_BINARY_PACKED block sequence (a data page's values) -> an int32 / int64 device array:
+    header walk on the host, unpack + prefix sum on the device (arx_delta_decode)."""
+    device = torch.device(device) if device is not None else default_device()
+    lib, stream = _lib.get_lib(), current_stream(device)
+    mbs, vpm, total, first, used = scan_delta_miniblocks(data)
+    atype, _ = _PHYSICAL["INT64" if byte_width == 8 else "INT32"]
+    out = alloc(total * byte_width, device)
+    d_bytes = to_device(np.frombuffer(bytes(data[:used]) + b"\0" * (16 + (-used % 8)), dtype=np.uint8), device)
+    table = mbs if len(mbs) else np.zeros(1, MINIBLOCK_DTYPE)
+    d_table = to_device(table.view(np.uint8), device)
+    ws = alloc(lib.arx_delta_decode_workspace_bytes(total), device)
+    check(lib.arx_delta_decode(d_bytes.data_ptr(), d_table.data_ptr(), len(mbs), vpm, first, total, byte_width,
+                               ws.data_ptr(), ws.numel(), out.data_ptr(), stream))
+    return Array(atype, total, [None, out], 0, 0)
+
+
 def scan_rle_runs(data, bit_width: int, num_values: int, out_base: int = 0, byte_base: int = 0):
     """Walks the run headers of an RLE / bit-packed hybrid block (rle_encoding_internal.h:40-90) until
     `num_values` values are covered — the host function arx_rle_scan_runs of the library (the walk is
@@ -223,6 +259,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     plain_bytes = bytearray()
     plain_pages = []          # BYTE_ARRAY only: (page value bytes, number of values)
     bool_bytes, bool_runs = bytearray(), []   # BOOLEAN only: every page becomes runs of one shared table
+    delta_bytes, delta_pages = bytearray(), []  # DELTA_BINARY_PACKED: (first dense slot, miniblocks, per miniblock, first value, count)
     rows, dense, dense_from_dict = 0, 0, 0
     for hdr, payload in _column_chunk_pages(raw, col):
         ptype = hdr[1]
@@ -290,6 +327,14 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
                 plain_pages.append((bytes(values), valid_here))      # offsets are built once the dictionary size is known
             else:
                 plain_bytes += values[: valid_here * width]
+        elif enc == _ENC_DELTA_BINARY_PACKED and col.physical_type in ("INT32", "INT64"):
+            if valid_here:
+                mbs, vpm, total, first, used = scan_delta_miniblocks(values, byte_base=len(delta_bytes))
+                if total != valid_here:
+                    raise ArrowInvalid(f"Parquet: DELTA_BINARY_PACKED page holds {total} values, its header says {valid_here}")
+                delta_pages.append((dense, mbs, vpm, first, valid_here))
+                delta_bytes += values[:used]
+                delta_bytes += b"\0" * (-len(delta_bytes) % 8)      # the next page starts on a 64-bit word
         else:
             raise ArrowNotImplementedError(f"Parquet encoding {enc} is not on the gfx950 path")
         rows += nvals
@@ -324,8 +369,23 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
         part = cp.take(dvals, didx, boundscheck=True)               # a corrupt index fails like the reference's bounds check
         dense_buf[: dense_from_dict * width] = part.data[: dense_from_dict * width]
     if len(plain_bytes):
+        if delta_pages:
+            raise ArrowNotImplementedError("Parquet: PLAIN and DELTA_BINARY_PACKED pages in one column chunk")
         host = torch.from_numpy(np.frombuffer(bytes(plain_bytes), dtype=np.uint8).copy())
         dense_buf[dense_from_dict * width: dense * width] = host.to(device)
+    if delta_pages:
+        # one byte buffer and one miniblock table for the chunk; a launch sequence (unpack + prefix sum) per page,
+        # because every page restarts the recurrence at its own first value
+        d_bytes = to_device(np.frombuffer(bytes(delta_bytes) + b"\0" * 16, dtype=np.uint8), device)
+        table = np.concatenate([p[1] for p in delta_pages]) if any(len(p[1]) for p in delta_pages) else np.zeros(1, MINIBLOCK_DTYPE)
+        d_table = to_device(table.view(np.uint8), device)
+        ws = alloc(lib.arx_delta_decode_workspace_bytes(max(p[4] for p in delta_pages)), device)
+        at = 0
+        for start, mbs, vpm, first, count in delta_pages:
+            check(lib.arx_delta_decode(d_bytes.data_ptr(), d_table.data_ptr() + at * MINIBLOCK_DTYPE.itemsize, len(mbs), vpm,
+                                       first, count, width, ws.data_ptr(), ws.numel(),
+                                       dense_buf.data_ptr() + start * width, stream))
+            at += len(mbs)
 
     if max_def_level == 0 or dense == rows:                         # required column, or optional without a single null
         return Array(atype, rows, [None, dense_buf], 0, 0)

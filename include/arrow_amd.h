@@ -514,6 +514,27 @@ typedef struct ArxRleRun {
  * out_base / byte_base so that several pages can share one table and one byte buffer. */
 int arx_rle_scan_runs(const void* data, size_t nbytes, int bit_width, int64_t num_values, uint32_t out_base,
                       uint64_t byte_base, ArxRleRun* runs, int64_t max_runs, int64_t* num_runs, int64_t* ones);
+/* DELTA_BINARY_PACKED (DeltaBitPackDecoder, cpp/src/parquet/decoder.cc; INT32 / INT64 columns and the
+ * length streams of DELTA_LENGTH_BYTE_ARRAY): value_i = value_{i-1} + min_delta(block) + unpack(miniblock),
+ * wrap-around.  arx_delta_scan_miniblocks is a HOST function: it walks the block headers of one page and
+ * fills one entry per miniblock that holds values (bit_start = absolute bit position in the buffer the device
+ * will see: data sits at byte_base in it).  arx_delta_decode unpacks + prefix-sums on the device: `bytes` must be
+ * 8-byte aligned and readable 8 bytes past the last miniblock; out_byte_width 4 (INT32) or 8 (INT64).
+ * Asynchronous. */
+typedef struct ArxDeltaMiniblock {
+  uint64_t bit_start;  /* first delta of the miniblock */
+  int64_t min_delta;   /* of its block */
+  uint32_t bit_width;  /* 0..64 */
+  uint32_t reserved;
+} ArxDeltaMiniblock;
+int arx_delta_scan_miniblocks(const void* data, size_t nbytes, uint64_t byte_base, ArxDeltaMiniblock* out,
+                              int64_t max_miniblocks, int64_t* num_miniblocks,
+                              int64_t* values_per_miniblock, int64_t* total_values, int64_t* first_value,
+                              size_t* bytes_consumed);
+size_t arx_delta_decode_workspace_bytes(int64_t num_values);
+int arx_delta_decode(const void* bytes, const ArxDeltaMiniblock* miniblocks, int64_t num_miniblocks,
+                     int64_t values_per_miniblock, int64_t first_value, int64_t num_values,
+                     int out_byte_width, void* ws, size_t ws_bytes, void* out, void* stream);
 /* HOST function: PLAIN BYTE_ARRAY values (4-byte length + bytes each; PlainByteArrayDecoder,
  * cpp/src/parquet/decoder.cc) described as 2 * count + 1 int32 offsets of alternating {length prefix,
  * value} entries (shifted by `base`), so that a var-width take of the odd entries compacts the values. */

@@ -561,3 +561,96 @@ class HashSumState:
                                                  self.num_groups, int(self.skip_nulls),
                                                  self.min_count, _ptr(v))
         return self.sums.copy(), v[: self.num_groups].astype(bool), int(nulls)
+
+
+def delta_binary_packed_encode(values, block_size: int = 128, miniblocks: int = 4) -> bytes:
+    """A writer of DELTA_BINARY_PACKED (Encodings.md "Delta encoding"; DeltaBitPackEncoder, parquet/encoder.cc)
+    for tests: any block size / miniblock count the format allows, int64 arithmetic modulo 2**64, trailing
+    miniblocks without values omitted (their widths stay in the block header, as the format prescribes)."""
+    M = (1 << 64) - 1
+    v = [int(x) & M for x in values]
+    out = bytearray()
+
+    def varint(x):
+        while x >= 0x80:
+            out.append((x & 0x7F) | 0x80)
+            x >>= 7
+        out.append(x)
+
+    def zigzag(x):          # x: signed python int in int64 range
+        varint(((x << 1) ^ (x >> 63)) & M)
+
+    def signed(u):
+        return u - (1 << 64) if u >> 63 else u
+
+    vpm = block_size // miniblocks
+    assert block_size % 128 == 0 and block_size % miniblocks == 0 and vpm % 32 == 0
+    varint(block_size)
+    varint(miniblocks)
+    varint(len(v))
+    zigzag(signed(v[0]) if v else 0)
+    deltas = [signed((v[i] - v[i - 1]) & M) for i in range(1, len(v))]
+    for b in range(0, len(deltas), block_size):
+        block = deltas[b: b + block_size]
+        min_delta = min(block)
+        zigzag(min_delta)
+        rel = [(d - min_delta) & M for d in block]
+        widths = []
+        for m in range(miniblocks):
+            part = rel[m * vpm: (m + 1) * vpm]
+            widths.append(max(part).bit_length() if part else 0)
+        out.extend(bytes(widths))
+        for m in range(miniblocks):
+            part = rel[m * vpm: (m + 1) * vpm]
+            if not part:
+                break
+            part = part + [0] * (vpm - len(part))
+            acc = 0
+            for k, x in enumerate(part):
+                acc |= x << (k * widths[m])
+            out.extend(acc.to_bytes(vpm * widths[m] // 8, "little"))
+    return bytes(out)
+
+
+def delta_binary_packed_decode(data: bytes):
+    """DeltaBitPackDecoder (parquet/decoder.cc: InitHeader, InitBlock, InitMiniBlock, GetInternal) restated
+    value by value: returns (int64 values with wrap-around, bytes consumed)."""
+    M = (1 << 64) - 1
+    pos = 0
+
+    def varint():
+        nonlocal pos
+        x, shift = 0, 0
+        while True:
+            c = data[pos]
+            pos += 1
+            x |= (c & 0x7F) << shift
+            if not c & 0x80:
+                return x
+            shift += 7
+
+    def zigzag():
+        u = varint()
+        return (u >> 1) ^ -(u & 1)
+
+    block_size, miniblocks, total = varint(), varint(), varint()
+    last = zigzag() & M
+    vpm = block_size // miniblocks
+    out = [last] if total else []
+    while len(out) < total:
+        min_delta = zigzag()
+        widths = data[pos: pos + miniblocks]
+        pos += miniblocks
+        for m in range(miniblocks):
+            if len(out) >= total:
+                break
+            w = widths[m]
+            nbytes = vpm * w // 8
+            acc = int.from_bytes(data[pos: pos + nbytes], "little")
+            pos += nbytes
+            for k in range(vpm):
+                if len(out) >= total:
+                    break
+                last = (last + min_delta + ((acc >> (k * w)) & ((1 << w) - 1))) & M
+                out.append(last)
+    return np.array(out, dtype=np.uint64).astype(np.int64), pos

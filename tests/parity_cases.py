@@ -604,6 +604,32 @@ def check_order_by(amd, columns, sort_keys, null_placement="at_end", use_pyarrow
                 assert g.equals(w), ("order_by column", i)
 
 
+def check_delta_decode(amd, rng, block_size=128, miniblocks=4):
+    """arx_delta_scan_miniblocks + arx_delta_decode against the restatement of DeltaBitPackDecoder: value counts
+    around block / miniblock / scan-tile boundaries, narrow, wide (wrap-around) and zero-width miniblocks."""
+    vpm = block_size // miniblocks
+    for n in (1, 2, vpm, vpm + 1, vpm + 2, block_size, block_size + 1, block_size + 2, 4095, 4096, 4097, 4098, 9001):
+        for kind in ("walk", "full", "const", "bursty"):
+            if kind == "walk":
+                v = np.cumsum(rng.integers(-40, 50, n))
+            elif kind == "full":
+                v = rng.integers(-2**63, 2**63 - 1, n)
+            elif kind == "const":
+                v = np.full(n, -3)
+            else:
+                v = np.where(rng.random(n) < 0.01, 2**50, 1).cumsum()
+            v = v.astype(np.int64)
+            page = O.delta_binary_packed_encode(v, block_size, miniblocks)
+            want, used = O.delta_binary_packed_decode(page + b"trailing bytes are not the decoder's")
+            assert used == len(page) and np.array_equal(want, v)
+            mbs, got_vpm, total, first, consumed = amd.parquet.scan_delta_miniblocks(page + b"xyz")
+            assert (got_vpm, total, first, consumed) == (vpm, n, int(v[0]), len(page)), (n, kind)
+            out64 = amd.parquet.decode_delta_binary_packed(page, 8)
+            assert_equal(_data_np(out64, np.int64), v, f"delta int64 {kind} n={n}")
+            out32 = amd.parquet.decode_delta_binary_packed(page, 4)
+            assert_equal(_data_np(out32, np.int32), v.astype(np.int32), f"delta int32 {kind} n={n}")
+
+
 def _sorted_groups(keys, key_valid, sums, valid):
     """Canonical form: rows sorted by (key_is_null, key) -> list of tuples (tests sort too,
     acero/hash_aggregate_test.cc:262-280)."""

@@ -124,3 +124,43 @@ def test_scalar_kernel_argument_checks(emu_ctx):
     i = _span(L, a, length=5)
     tot = C.c_int64(0)
     assert lib.arx_binary_take_offsets(C.byref(bs), C.byref(i), 5, None, 0, out.data_ptr(), None, None, C.byref(tot), None) == INVALID
+
+
+def test_concatenate_and_delta_argument_checks(emu_ctx):
+    L = emu_ctx._lib
+    lib = L.get_lib()
+    src, dst = _buf(64), _buf(64)
+    assert lib.arx_bitmap_copy_at(src.data_ptr(), -1, 10, dst.data_ptr(), 0, None) == INVALID
+    assert lib.arx_bitmap_copy_at(src.data_ptr(), 0, 10, None, 0, None) == INVALID
+    assert lib.arx_bitmap_copy_at(src.data_ptr(), 0, 10, dst.data_ptr(), -3, None) == INVALID
+    assert lib.arx_bitmap_copy_at(None, 0, 0, None, 0, None) == OK                                    # nothing to append
+    assert lib.arx_bitmap_copy_at(None, 0, 70, dst.data_ptr(), 3, None) == OK                           # NULL source = all ones
+    bits = np.unpackbits(dst.numpy()[:16], bitorder="little")
+    assert bits[:3].sum() == 0 and bits[3:73].all() and bits[73:].sum() == 0
+    assert lib.arx_binary_rebase_offsets(None, 4, 0, dst.data_ptr(), None) == INVALID
+    assert lib.arx_binary_rebase_offsets(src.data_ptr(), -1, 0, dst.data_ptr(), None) == INVALID
+    # DELTA_BINARY_PACKED: corrupt headers are refused by the host walk, never read past the page
+    nmb, vpm, total, first, used = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_size_t(0)
+    def scan(page):
+        buf = np.frombuffer(page, dtype=np.uint8)
+        return lib.arx_delta_scan_miniblocks(buf.ctypes.data, len(buf), 0, None, 0, C.byref(nmb), C.byref(vpm), C.byref(total),
+                                             C.byref(first), C.byref(used))
+    from oracle import oracle as O
+    good = O.delta_binary_packed_encode(np.arange(1000) * 3)
+    assert scan(good) == OK and (total.value, first.value, used.value) == (1000, 0, len(good))
+    assert scan(good[: len(good) - 5]) == INVALID and "past the page" in _err(lib)                     # truncated miniblock
+    assert scan(good[:2]) == INVALID                                                                  # truncated header
+    assert scan(b"\x07\x04\x05\x00") == INVALID and "header" in _err(lib)                             # block size 7
+    assert scan(b"\x80\x01\x00\x05\x00") == INVALID                                                   # zero miniblocks
+    assert scan(b"\x80\x01\x04\x01\x02") == OK and (nmb.value, total.value, first.value) == (0, 1, 1)   # one value: no blocks
+    assert lib.arx_delta_scan_miniblocks(None, 0, 0, None, 0, C.byref(nmb), C.byref(vpm), C.byref(total), C.byref(first), None) == INVALID
+    out, ws = _buf(8000), _buf(lib.arx_delta_decode_workspace_bytes(1000) + 64)
+    page = _buf(len(good) + 64)
+    mbs = _buf(24 * 40)
+    assert lib.arx_delta_decode(page.data_ptr(), mbs.data_ptr(), 32, 32, 0, 1000, 3, ws.data_ptr(), ws.numel(), out.data_ptr(), None) == INVALID  # width 3
+    assert lib.arx_delta_decode(page.data_ptr() + 1, mbs.data_ptr(), 32, 32, 0, 1000, 8, ws.data_ptr(), ws.numel(), out.data_ptr(), None) == INVALID  # misaligned page
+    assert lib.arx_delta_decode(page.data_ptr(), mbs.data_ptr(), 3, 32, 0, 1000, 8, ws.data_ptr(), ws.numel(), out.data_ptr(), None) == INVALID  # too few miniblocks
+    assert lib.arx_delta_decode(page.data_ptr(), mbs.data_ptr(), 32, 32, 0, 1000, 8, ws.data_ptr(), 8, out.data_ptr(), None) == INVALID      # short workspace
+    assert lib.arx_delta_decode(None, None, 0, 0, 0, 0, 8, None, 0, None, None) == OK                  # nothing to decode
+    assert lib.arx_delta_decode(None, None, 0, 0, 42, 1, 8, ws.data_ptr(), ws.numel(), out.data_ptr(), None) == OK   # a single value: the header's
+    assert out.view(torch.int64)[0].item() == 42

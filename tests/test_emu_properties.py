@@ -75,3 +75,21 @@ def test_groupby_property(emu_ctx, n, groups, knull, vnull, skip_nulls, min_coun
     v = U.random_array(rng, np.int64, n, null_p=vnull, offset=1)
     P.check_groupby_sum(emu_ctx, k, v, skip_nulls, min_count, batches=batches, use_pyarrow=False)
     P.check_groupby_min_max(emu_ctx, k, v, skip_nulls, batches=batches, use_pyarrow=False)
+
+
+@settings(max_examples=120, **COMMON)
+@given(kind=st.sampled_from(["int16", "int64", "bool", "utf8"]),
+       specs=st.lists(st.tuples(st.one_of(st.integers(0, 70), st.sampled_from([63, 64, 65, 128, 500])), nulls,
+                                st.integers(0, 130)), min_size=1, max_size=6),
+       seed=st.integers(0, 2**31 - 1))
+def test_concat_arrays_property(emu_ctx, kind, specs, seed):
+    """Concatenate: any number of chunks of any length (also empty) glued at any bit position, with and without
+    validity; the numpy concatenation of the logical rows is the oracle."""
+    rng = np.random.default_rng(seed)
+    if kind == "bool":
+        chunks = [U.random_mask(rng, n, 0.5, null_p=p, offset=o, tail=1) for n, p, o in specs]
+    elif kind == "utf8":
+        chunks = [U.random_binary(rng, n, null_p=p, offset=o, tail=1, utf8=True, max_len=9) for n, p, o in specs]
+    else:
+        chunks = [U.random_array(rng, np.dtype(kind).type, n, null_p=p, offset=o, tail=1) for n, p, o in specs]
+    P.check_concat_arrays(emu_ctx, chunks, use_pyarrow=False)

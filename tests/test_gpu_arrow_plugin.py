@@ -716,6 +716,23 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
                     h = to_host(d)
                     w = ref.column(name).combine_chunks()
                     assert h.equals(w) and h.null_count == w.null_count, (variant, null_p, rg, name, h.slice(0, 5), w.slice(0, 5))
+        # DELTA_BINARY_PACKED integer columns (sorted ids, a random walk, wrap-around deltas, constants)
+        dt = pa.table({"sorted64": pa.array(np.sort(rng.integers(0, 2**40, n)), mask=m(null_p)),
+                       "walk32": pa.array(np.cumsum(rng.integers(-50, 60, n)).astype(np.int32), mask=m(null_p)),
+                       "full64": pa.array(rng.integers(-2**63, 2**63 - 1, n), mask=m(null_p)),
+                       "const32": pa.array(np.full(n, 7, dtype=np.int32), mask=m(null_p))})
+        for variant in (dict(compression="snappy"), dict(compression="none", data_page_version="2.0", data_page_size=4096)):
+            path = os.path.join(tempfile.mkdtemp(), "d.parquet")
+            pq.write_table(dt, path, row_group_size=n // 2 + 11, use_dictionary=False,
+                           column_encoding={name: "DELTA_BINARY_PACKED" for name in dt.schema.names}, **variant)
+            pf = pq.ParquetFile(path)
+            for rg in range(pf.metadata.num_row_groups):
+                ref = pf.read_row_group(rg)
+                for ci, name in enumerate(dt.schema.names):
+                    assert "DELTA_BINARY_PACKED" in pf.metadata.row_group(rg).column(ci).encodings
+                    h = to_host(read_column(path, rg, ci))
+                    w = ref.column(name).combine_chunks()
+                    assert h.equals(w) and h.null_count == w.null_count, ("delta", variant, null_p, rg, name)
     assert lib.arrow_amd_plugin_calls(b"parquet", 1) > 0
     # a nested column is refused, not mis-decoded
     path = os.path.join(tempfile.mkdtemp(), "l.parquet")

@@ -11,6 +11,7 @@ import pytest
 
 from oracle import oracle as O
 
+from . import parity_cases as PC
 from . import util as U
 from .util import pa
 
@@ -136,6 +137,102 @@ def test_parquet_edge_cases_emulator(emu_ctx, tmp_path):
 def test_parquet_decode_gpu(gpu_ctx, tmp_path, variant, null_p):
     # (600k full-range int64 values also exercise the dictionary -> PLAIN fallback at the 1 MiB limit)
     _write_and_check(gpu_ctx, str(tmp_path), 600_000, null_p, VARIANTS[variant], 200 + variant)
+
+
+def _delta_table(rng, n, null_p):
+    mask = (lambda: rng.random(n) < null_p) if null_p else (lambda: None)
+    walk = np.cumsum(rng.integers(-50, 60, n))                                   # small deltas: narrow miniblocks
+    return pa.table({
+        "sorted64": pa.array(np.sort(rng.integers(0, 2**40, n)), mask=mask()),
+        "walk32": pa.array(walk.astype(np.int32), mask=mask()),
+        "full64": pa.array(rng.integers(-2**63, 2**63 - 1, n), mask=mask()),       # deltas wrap around: 64-bit miniblocks
+        "const32": pa.array(np.full(n, 7, dtype=np.int32), mask=mask()),           # all deltas equal: bit width 0
+        "ticks": pa.array(np.arange(n) * 1000 + rng.integers(0, 3, n), mask=mask()),                  # timestamp-like: near-constant deltas
+        "step64": pa.array(np.where(np.arange(n) % 700 == 0, 2**45, 3).cumsum(), mask=mask()),
+    })
+
+
+def _write_delta_and_check(amd, tmp_path, n, null_p, seed, **kw):
+    rng = np.random.default_rng(seed)
+    t = _delta_table(rng, n, null_p)
+    path = os.path.join(tmp_path, "delta.parquet")
+    pq.write_table(t, path, use_dictionary=False, column_encoding={name: "DELTA_BINARY_PACKED" for name in t.schema.names},
+                   row_group_size=max(1, n // 2 + 7), **kw)
+    md = pq.ParquetFile(path).metadata
+    assert all("DELTA_BINARY_PACKED" in md.row_group(0).column(i).encodings for i in range(md.num_columns))
+    check_file(amd, path)
+
+
+@pytest.mark.emu
+@pytest.mark.parametrize("null_p", [0.0, 0.2])
+@pytest.mark.parametrize("n,kw", [(9000, dict(data_page_size=2048, compression="snappy")),
+                                  (4097, dict(data_page_version="2.0", compression="none")), (1, {}), (130, {})])
+def test_parquet_delta_binary_packed_emulator(emu_ctx, tmp_path, n, kw, null_p):
+    """DELTA_BINARY_PACKED INT32 / INT64 pages (DeltaBitPackDecoder): header walk on the host, unpack + prefix
+    sum in the kernels; sorted, random-walk, wrap-around, constant and bursty columns, many small pages."""
+    _write_delta_and_check(emu_ctx, str(tmp_path), n, null_p, 31 + n, **kw)
+
+
+@pytest.mark.gpu
+def test_delta_decode_kernel_vs_restatement_gpu(gpu_ctx):
+    PC.check_delta_decode(gpu_ctx, np.random.default_rng(5), 128, 4)
+    PC.check_delta_decode(gpu_ctx, np.random.default_rng(6), 512, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("null_p", [0.0, 0.1])
+def test_parquet_delta_binary_packed_gpu(gpu_ctx, tmp_path, null_p):
+    _write_delta_and_check(gpu_ctx, str(tmp_path), 600_000, null_p, 77, compression="snappy")
+    _write_delta_and_check(gpu_ctx, str(tmp_path), 70_001, null_p, 78, data_page_version="2.0", data_page_size=8192)
+
+
+def _delta_page_bytes(path, column):
+    """The value bytes of every DELTA_BINARY_PACKED data page of one column chunk, read with this package's page walk."""
+    from arrow_amd import parquet as P
+
+    md = pq.ParquetFile(path).metadata
+    col = md.row_group(0).column(column)
+    raw = open(path, "rb").read()
+    pages = []
+    for hdr, payload in P._column_chunk_pages(raw, col):
+        if hdr[1] == P._PAGE_DATA:
+            assert hdr[5][2] == P._ENC_DELTA_BINARY_PACKED
+            pages.append((bytes(P._decompress(col.compression, payload, hdr[2])), hdr[5][1]))
+    return pages
+
+
+def test_delta_binary_packed_oracle_pinned_to_the_reference_writer(tmp_path):
+    """The restatement decodes the pages the reference's DeltaBitPackEncoder wrote to pyarrow's own values, and the
+    host header walk (arx_delta_scan_miniblocks) agrees with it on counts, first value and bytes consumed."""
+    from arrow_amd import parquet as P
+
+    rng = np.random.default_rng(3)
+    n = 3000
+    cols = {"a": np.sort(rng.integers(0, 2**40, n)), "b": rng.integers(-2**63, 2**63 - 1, n), "c": np.full(n, -5, dtype=np.int64),
+            "d": np.cumsum(rng.integers(-9, 9, n)).astype(np.int32)}
+    path = os.path.join(str(tmp_path), "pin.parquet")
+    required = pa.schema([pa.field(k, pa.from_numpy_dtype(v.dtype), nullable=False) for k, v in cols.items()])   # no level block
+    pq.write_table(pa.table({k: pa.array(v) for k, v in cols.items()}).cast(required), path, use_dictionary=False, compression="none",
+                   column_encoding={k: "DELTA_BINARY_PACKED" for k in cols}, data_page_size=4096)
+    for ci, (name, want) in enumerate(cols.items()):
+        got = []
+        for page, count in _delta_page_bytes(path, ci):
+            vals, used = O.delta_binary_packed_decode(page)
+            assert len(vals) == count
+            mbs, vpm, total, first, consumed = P.scan_delta_miniblocks(page)
+            assert (total, first, consumed) == (count, int(vals[0]), used) and vpm % 32 == 0
+            assert len(mbs) == -(-(count - 1) // vpm)
+            got.append(vals)
+        got = np.concatenate(got)
+        assert np.array_equal(got.astype(want.dtype), want), name
+
+
+@pytest.mark.emu
+@pytest.mark.parametrize("block_size,miniblocks", [(128, 4), (256, 8), (128, 1), (1024, 4)])
+def test_delta_decode_kernel_vs_restatement(emu_ctx, block_size, miniblocks):
+    """arx_delta_decode against the restatement on pages of block shapes the reference writer never produces
+    (the format allows any multiple of 128 with miniblocks of a multiple of 32 values), INT32 and INT64 output."""
+    PC.check_delta_decode(emu_ctx, np.random.default_rng(block_size + miniblocks), block_size, miniblocks)
 
 
 def test_rle_run_walk_and_decode_vs_numpy_restatement():
