@@ -576,25 +576,26 @@ def check_concat_arrays(amd, chunks, use_pyarrow=True):
 
 def check_order_by(amd, columns, sort_keys, null_placement="at_end", use_pyarrow=True):
     """OrderByNode::DoFinish (acero/order_by_node.cc:100-108): concatenate, SortIndices over several keys,
-    Take.  `columns` = [[chunk, ...], ...] of host arrays; `sort_keys` = [(column, order)]."""
-    dev_cols = [[c.to_device(amd) for c in col] for col in columns]
-    whole = [amd.compute.concat_arrays(col) for col in dev_cols]
-    perm = amd.compute.sort_indices_by_keys([whole[i] for i, _ in sort_keys], [o for _, o in sort_keys], null_placement)
+    Take.  `columns` = [[chunk, ...], ...] of host arrays; `sort_keys` = [(column, order)].  A row-number column
+    rides along: after the sort it IS the permutation, which must equal the oracle's (and pyarrow's) indices."""
+    n = sum(c.length for c in columns[0])
+    row_ids = HostArray(np.arange(n, dtype=np.int64), None, 0, n)
+    dev_cols = [[c.to_device(amd) for c in col] for col in columns] + [[row_ids.to_device(amd)]]
+    places = [null_placement] * len(sort_keys) if isinstance(null_placement, str) else list(null_placement)
     logical = []
     for i, order in sort_keys:
         vals = np.concatenate([c.logical_values() for c in columns[i]])
         valid = np.concatenate([c.logical_valid() for c in columns[i]])
         logical.append((vals, valid))
-    places = [null_placement] * len(sort_keys) if isinstance(null_placement, str) else list(null_placement)
     want = O.sort_indices_multi(logical, [o == "descending" for _, o in sort_keys], [p == "at_start" for p in places])
-    assert_equal(_data_np(perm, np.uint64), want, "multi-key sort indices")
     got_cols = amd.compute.order_by(dev_cols, sort_keys, null_placement)
+    assert_equal(_data_np(got_cols[-1], np.int64).astype(np.uint64), want, "multi-key sort permutation")
     if use_pyarrow and pa is not None:
         table = pa.table({f"c{i}": pa.chunked_array([c.to_pyarrow() for c in col]) for i, col in enumerate(columns)})
         ref_idx = pc.sort_indices(table, sort_keys=[(f"c{i}", o, p) for (i, o), p in zip(sort_keys, places)])
         assert_equal(want, ref_idx.to_numpy(), "oracle vs pyarrow sort_indices(table)")
         ref = table.take(ref_idx)
-        for i, col in enumerate(got_cols):
+        for i, col in enumerate(got_cols[:-1]):
             g, w = col.to_pyarrow(), ref.column(i).combine_chunks()
             if pa.types.is_floating(w.type):      # (NaN != NaN for Array.equals: compare the bit patterns)
                 assert np.array_equal(np.asarray(g.is_null()), np.asarray(w.is_null()))
