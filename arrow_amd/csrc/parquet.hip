@@ -193,6 +193,28 @@ __global__ __launch_bounds__(kBlock) void delta_write_kernel(const uint64_t* __r
   }
 }
 
+// ---------------------------------------------------------------- BYTE_STREAM_SPLIT
+// ByteStreamSplitDecoder (cpp/src/parquet/decoder.cc; arrow/util/byte_stream_split_internal.h): a page of n
+// W-byte values is stored as W streams of n bytes (stream k = byte k of every value).  One value per lane:
+// W coalesced byte loads (consecutive lanes read consecutive bytes of a stream), one W-byte store.
+template <int W>
+__global__ __launch_bounds__(kBlock) void byte_stream_split_kernel(const uint8_t* __restrict__ in, int64_t n,
+                                                                  uint8_t* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) v |= static_cast<uint64_t>(in[k * n + i]) << (8 * k);
+    if constexpr (W == 8) {
+      reinterpret_cast<uint64_t*>(out)[i] = v;
+    } else if constexpr (W == 4) {
+      reinterpret_cast<uint32_t*>(out)[i] = static_cast<uint32_t>(v);
+    } else {
+      reinterpret_cast<uint16_t*>(out)[i] = static_cast<uint16_t>(v);
+    }
+  }
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -412,6 +434,31 @@ int arx_delta_decode(const void* bytes, const ArxDeltaMiniblock* miniblocks, int
                        static_cast<int32_t*>(out));
   }
   ARX_CHECK_LAUNCH("delta_write_kernel");
+  return ARX_OK;
+}
+
+int arx_byte_stream_split_decode(const void* in, int64_t num_values, int byte_width, void* out, void* stream) {
+  if (num_values < 0 || (byte_width != 2 && byte_width != 4 && byte_width != 8)) {
+    set_error("arx_byte_stream_split_decode: %lld values of width %d", static_cast<long long>(num_values), byte_width);
+    return num_values < 0 ? ARX_INVALID : ARX_NOT_IMPLEMENTED;
+  }
+  if (num_values == 0) return ARX_OK;
+  if (in == nullptr || out == nullptr || (reinterpret_cast<uintptr_t>(out) % byte_width) != 0) {
+    set_error("arx_byte_stream_split_decode: NULL or misaligned buffer");
+    return ARX_INVALID;
+  }
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(num_values, kBlock), 256 * 8)));
+  const uint8_t* src = static_cast<const uint8_t*>(in);
+  uint8_t* dst = static_cast<uint8_t*>(out);
+  hipStream_t st = as_stream(stream);
+  if (byte_width == 8) {
+    hipLaunchKernelGGL((byte_stream_split_kernel<8>), dim3(grid), dim3(kBlock), 0, st, src, num_values, dst);
+  } else if (byte_width == 4) {
+    hipLaunchKernelGGL((byte_stream_split_kernel<4>), dim3(grid), dim3(kBlock), 0, st, src, num_values, dst);
+  } else {
+    hipLaunchKernelGGL((byte_stream_split_kernel<2>), dim3(grid), dim3(kBlock), 0, st, src, num_values, dst);
+  }
+  ARX_CHECK_LAUNCH("byte_stream_split_kernel");
   return ARX_OK;
 }
 

@@ -2,7 +2,7 @@
 
 Scope: flat columns of physical type INT32 / INT64 / FLOAT / DOUBLE (PLAIN and PLAIN_DICTIONARY /
 RLE_DICTIONARY encodings, incl. the dictionary -> PLAIN fallback inside a chunk; DELTA_BINARY_PACKED for
-INT32 / INT64), BOOLEAN (PLAIN, RLE) and
+INT32 / INT64; BYTE_STREAM_SPLIT), BOOLEAN (PLAIN, RLE) and
 BYTE_ARRAY columns (utf8 / binary; dictionary-encoded and PLAIN pages); required or optional (max definition level <= 1, no repetition),
 data pages V1 and V2, any page compression pyarrow's codecs can undo.
 
@@ -30,7 +30,7 @@ from .array import Array, alloc, bitmap_nbytes, current_stream, default_device, 
 # parquet.thrift enums
 _PAGE_DATA, _PAGE_INDEX, _PAGE_DICT, _PAGE_DATA_V2 = 0, 1, 2, 3
 _ENC_PLAIN, _ENC_PLAIN_DICT, _ENC_RLE, _ENC_BIT_PACKED, _ENC_RLE_DICT = 0, 2, 3, 4, 8
-_ENC_DELTA_BINARY_PACKED = 5
+_ENC_DELTA_BINARY_PACKED, _ENC_BYTE_STREAM_SPLIT = 5, 9
 _PHYSICAL = {"INT32": (int32, np.int32), "INT64": (int64, np.int64), "FLOAT": (float32, np.float32),
              "DOUBLE": (float64, np.float64)}
 
@@ -259,6 +259,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     plain_bytes = bytearray()
     plain_pages = []          # BYTE_ARRAY only: (page value bytes, number of values)
     bool_bytes, bool_runs = bytearray(), []   # BOOLEAN only: every page becomes runs of one shared table
+    split_pages = []                            # BYTE_STREAM_SPLIT: (first dense slot, page bytes, count)
     delta_bytes, delta_pages = bytearray(), []  # DELTA_BINARY_PACKED: (first dense slot, miniblocks, per miniblock, first value, count)
     rows, dense, dense_from_dict = 0, 0, 0
     for hdr, payload in _column_chunk_pages(raw, col):
@@ -327,6 +328,11 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
                 plain_pages.append((bytes(values), valid_here))      # offsets are built once the dictionary size is known
             else:
                 plain_bytes += values[: valid_here * width]
+        elif enc == _ENC_BYTE_STREAM_SPLIT and not is_binary and not is_bool:
+            if len(values) < valid_here * width:
+                raise ArrowInvalid("Parquet: BYTE_STREAM_SPLIT page shorter than its values")
+            if valid_here:
+                split_pages.append((dense, bytes(values[: valid_here * width]), valid_here))
         elif enc == _ENC_DELTA_BINARY_PACKED and col.physical_type in ("INT32", "INT64"):
             if valid_here:
                 mbs, vpm, total, first, used = scan_delta_miniblocks(values, byte_base=len(delta_bytes))
@@ -368,9 +374,17 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
 
         part = cp.take(dvals, didx, boundscheck=True)               # a corrupt index fails like the reference's bounds check
         dense_buf[: dense_from_dict * width] = part.data[: dense_from_dict * width]
+    if split_pages:
+        # ByteStreamSplitDecoder: every page is `width` byte streams; one transposing launch per page
+        d_split = to_device(np.frombuffer(b"".join(p[1] for p in split_pages), dtype=np.uint8), device)
+        at = 0
+        for start, data, count in split_pages:
+            check(lib.arx_byte_stream_split_decode(d_split.data_ptr() + at, count, width, dense_buf.data_ptr() + start * width,
+                                                   stream))
+            at += len(data)
     if len(plain_bytes):
-        if delta_pages:
-            raise ArrowNotImplementedError("Parquet: PLAIN and DELTA_BINARY_PACKED pages in one column chunk")
+        if delta_pages or split_pages:
+            raise ArrowNotImplementedError("Parquet: PLAIN and DELTA_BINARY_PACKED / BYTE_STREAM_SPLIT pages in one column chunk")
         host = torch.from_numpy(np.frombuffer(bytes(plain_bytes), dtype=np.uint8).copy())
         dense_buf[dense_from_dict * width: dense * width] = host.to(device)
     if delta_pages:

@@ -535,6 +535,10 @@ size_t arx_delta_decode_workspace_bytes(int64_t num_values);
 int arx_delta_decode(const void* bytes, const ArxDeltaMiniblock* miniblocks, int64_t num_miniblocks,
                      int64_t values_per_miniblock, int64_t first_value, int64_t num_values,
                      int out_byte_width, void* ws, size_t ws_bytes, void* out, void* stream);
+/* BYTE_STREAM_SPLIT (ByteStreamSplitDecoder, cpp/src/parquet/decoder.cc; arrow/util/byte_stream_split_internal.h):
+ * `in` holds byte_width streams of num_values bytes each (stream k = byte k of every value); out[i] is value i.
+ * byte_width 2, 4 or 8; `out` aligned to it.  Asynchronous. */
+int arx_byte_stream_split_decode(const void* in, int64_t num_values, int byte_width, void* out, void* stream);
 /* HOST function: PLAIN BYTE_ARRAY values (4-byte length + bytes each; PlainByteArrayDecoder,
  * cpp/src/parquet/decoder.cc) described as 2 * count + 1 int32 offsets of alternating {length prefix,
  * value} entries (shifted by `base`), so that a var-width take of the odd entries compacts the values. */

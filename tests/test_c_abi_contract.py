@@ -164,3 +164,12 @@ def test_concatenate_and_delta_argument_checks(emu_ctx):
     assert lib.arx_delta_decode(None, None, 0, 0, 0, 0, 8, None, 0, None, None) == OK                  # nothing to decode
     assert lib.arx_delta_decode(None, None, 0, 0, 42, 1, 8, ws.data_ptr(), ws.numel(), out.data_ptr(), None) == OK   # a single value: the header's
     assert out.view(torch.int64)[0].item() == 42
+    # BYTE_STREAM_SPLIT
+    assert lib.arx_byte_stream_split_decode(page.data_ptr(), 10, 3, out.data_ptr(), None) == NOT_IMPLEMENTED       # width 3
+    assert lib.arx_byte_stream_split_decode(page.data_ptr(), -1, 4, out.data_ptr(), None) == INVALID
+    assert lib.arx_byte_stream_split_decode(page.data_ptr(), 10, 8, out.data_ptr() + 4, None) == INVALID             # misaligned output
+    assert lib.arx_byte_stream_split_decode(None, 10, 8, out.data_ptr(), None) == INVALID
+    assert lib.arx_byte_stream_split_decode(None, 0, 8, None, None) == OK
+    page[:16] = torch.arange(16, dtype=torch.uint8)
+    assert lib.arx_byte_stream_split_decode(page.data_ptr(), 4, 4, out.data_ptr(), None) == OK
+    assert out[:16].tolist() == [0, 4, 8, 12, 1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15]

@@ -733,6 +733,21 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
                     h = to_host(read_column(path, rg, ci))
                     w = ref.column(name).combine_chunks()
                     assert h.equals(w) and h.null_count == w.null_count, ("delta", variant, null_p, rg, name)
+        # BYTE_STREAM_SPLIT floating-point and integer columns
+        st = pa.table({"f32": pa.array(rng.standard_normal(n).astype(np.float32), mask=m(null_p)),
+                       "f64": pa.array(rng.standard_normal(n) * 1e100, mask=m(null_p)),
+                       "i64": pa.array(rng.integers(-2**63, 2**63 - 1, n), mask=m(null_p))})
+        path = os.path.join(tempfile.mkdtemp(), "s.parquet")
+        pq.write_table(st, path, row_group_size=n // 2 + 11, use_dictionary=False, data_page_size=65536,
+                       column_encoding={name: "BYTE_STREAM_SPLIT" for name in st.schema.names})
+        pf = pq.ParquetFile(path)
+        for rg in range(pf.metadata.num_row_groups):
+            ref = pf.read_row_group(rg)
+            for ci, name in enumerate(st.schema.names):
+                assert "BYTE_STREAM_SPLIT" in pf.metadata.row_group(rg).column(ci).encodings
+                h = to_host(read_column(path, rg, ci))
+                w = ref.column(name).combine_chunks()
+                assert h.equals(w) and h.null_count == w.null_count, ("byte_stream_split", null_p, rg, name)
     assert lib.arrow_amd_plugin_calls(b"parquet", 1) > 0
     # a nested column is refused, not mis-decoded
     path = os.path.join(tempfile.mkdtemp(), "l.parquet")

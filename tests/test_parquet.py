@@ -186,6 +186,36 @@ def test_parquet_delta_binary_packed_gpu(gpu_ctx, tmp_path, null_p):
     _write_delta_and_check(gpu_ctx, str(tmp_path), 70_001, null_p, 78, data_page_version="2.0", data_page_size=8192)
 
 
+def _write_split_and_check(amd, tmp_path, n, null_p, seed, **kw):
+    rng = np.random.default_rng(seed)
+    mask = (lambda: rng.random(n) < null_p) if null_p else (lambda: None)
+    t = pa.table({"f32": pa.array(rng.standard_normal(n).astype(np.float32), mask=mask()),
+                  "f64": pa.array(rng.standard_normal(n) * 1e100, mask=mask()),
+                  "i32": pa.array(rng.integers(-2**31, 2**31 - 1, n).astype(np.int32), mask=mask()),
+                  "i64": pa.array(rng.integers(-2**63, 2**63 - 1, n), mask=mask())})
+    path = os.path.join(tmp_path, "bss.parquet")
+    pq.write_table(t, path, use_dictionary=False, column_encoding={name: "BYTE_STREAM_SPLIT" for name in t.schema.names},
+                   row_group_size=max(1, n // 2 + 7), **kw)
+    md = pq.ParquetFile(path).metadata
+    assert all("BYTE_STREAM_SPLIT" in md.row_group(0).column(i).encodings for i in range(md.num_columns))
+    check_file(amd, path)
+
+
+@pytest.mark.emu
+@pytest.mark.parametrize("null_p", [0.0, 0.2])
+@pytest.mark.parametrize("n,kw", [(9000, dict(data_page_size=2048, compression="snappy")), (1, {}),
+                                  (4097, dict(data_page_version="2.0", compression="none"))])
+def test_parquet_byte_stream_split_emulator(emu_ctx, tmp_path, n, kw, null_p):
+    """BYTE_STREAM_SPLIT pages (ByteStreamSplitDecoder): float, double, int32, int64 columns, many small pages."""
+    _write_split_and_check(emu_ctx, str(tmp_path), n, null_p, 51 + n, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("null_p", [0.0, 0.1])
+def test_parquet_byte_stream_split_gpu(gpu_ctx, tmp_path, null_p):
+    _write_split_and_check(gpu_ctx, str(tmp_path), 600_000, null_p, 79, compression="snappy")
+
+
 def _delta_page_bytes(path, column):
     """The value bytes of every DELTA_BINARY_PACKED data page of one column chunk, read with this package's page walk."""
     from arrow_amd import parquet as P
