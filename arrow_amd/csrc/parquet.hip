@@ -93,31 +93,42 @@ static int rle_check(const void* bytes, const ArxRleRun* runs, int64_t nruns, in
 // is read twice, nothing intermediate per value is stored.
 constexpr int kDeltaTile = 4096;
 
-__device__ __forceinline__ long long delta_at(const uint64_t* __restrict__ words, const ArxDeltaMiniblock* __restrict__ mbs,
-                                              int64_t values_per_miniblock, long long first_value, int64_t i) {
-  if (i == 0) return first_value;
-  const int64_t j = i - 1;
-  const ArxDeltaMiniblock mb = mbs[j / values_per_miniblock];
-  if (mb.bit_width == 0) return static_cast<long long>(mb.min_delta);
-  const uint64_t bit = mb.bit_start + static_cast<uint64_t>(j % values_per_miniblock) * mb.bit_width;
-  const uint64_t w = bit >> 6;
-  const int s = static_cast<int>(bit & 63);
-  uint64_t v = words[w] >> s;
-  if (s + static_cast<int>(mb.bit_width) > 64) v |= words[w + 1] << (64 - s);
-  if (mb.bit_width < 64) v &= (uint64_t(1) << mb.bit_width) - 1;
-  return static_cast<long long>(static_cast<uint64_t>(mb.min_delta) + v);
-}
+// The summand of position i: the page's first value at 0, then min_delta + the unpacked delta.
+struct DeltaSource {
+  const uint64_t* __restrict__ words;
+  const ArxDeltaMiniblock* __restrict__ mbs;
+  int64_t values_per_miniblock;
+  long long first_value;
+  __device__ __forceinline__ long long at(int64_t i) const {
+    if (i == 0) return first_value;
+    const int64_t j = i - 1;
+    const ArxDeltaMiniblock mb = mbs[j / values_per_miniblock];
+    if (mb.bit_width == 0) return static_cast<long long>(mb.min_delta);
+    const uint64_t bit = mb.bit_start + static_cast<uint64_t>(j % values_per_miniblock) * mb.bit_width;
+    const uint64_t w = bit >> 6;
+    const int s = static_cast<int>(bit & 63);
+    uint64_t v = words[w] >> s;
+    if (s + static_cast<int>(mb.bit_width) > 64) v |= words[w + 1] << (64 - s);
+    if (mb.bit_width < 64) v &= (uint64_t(1) << mb.bit_width) - 1;
+    return static_cast<long long>(static_cast<uint64_t>(mb.min_delta) + v);
+  }
+};
+// lengths -> offsets (DELTA_LENGTH_BYTE_ARRAY; offsets[0] = base, offsets[i] = offsets[i-1] + length[i-1]): the
+// same recurrence with the lengths as the deltas
+struct LengthSource {
+  const int32_t* __restrict__ lengths;
+  long long base;
+  __device__ __forceinline__ long long at(int64_t i) const { return i == 0 ? base : lengths[i - 1]; }
+};
 
-__global__ __launch_bounds__(kBlock) void delta_tile_sums_kernel(const uint64_t* __restrict__ words,
-                                                                 const ArxDeltaMiniblock* __restrict__ mbs,
-                                                                 int64_t values_per_miniblock, long long first_value,
-                                                                 int64_t n, long long* __restrict__ tile_sums) {
+template <typename Source>
+__global__ __launch_bounds__(kBlock) void delta_tile_sums_kernel(Source src, int64_t n, long long* __restrict__ tile_sums) {
   __shared__ long long wave_sum[kWavesPerBlock];
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kDeltaTile;
   unsigned long long acc = 0;
   for (int k = threadIdx.x; k < kDeltaTile; k += kBlock) {
     const int64_t i = base + k;
-    if (i < n) acc += static_cast<unsigned long long>(delta_at(words, mbs, values_per_miniblock, first_value, i));
+    if (i < n) acc += static_cast<unsigned long long>(src.at(i));
   }
   acc = wave_reduce_sum_u64(acc);
   if (lane_id() == 0) wave_sum[threadIdx.x >> 6] = static_cast<long long>(acc);
@@ -159,11 +170,8 @@ __global__ __launch_bounds__(1024) void delta_scan_tiles_kernel(long long* sums,
   }
 }
 
-template <typename OutT>
-__global__ __launch_bounds__(kBlock) void delta_write_kernel(const uint64_t* __restrict__ words,
-                                                             const ArxDeltaMiniblock* __restrict__ mbs,
-                                                             int64_t values_per_miniblock, long long first_value,
-                                                             int64_t n, const long long* __restrict__ tile_carry,
+template <typename OutT, typename Source>
+__global__ __launch_bounds__(kBlock) void delta_write_kernel(Source src, int64_t n, const long long* __restrict__ tile_carry,
                                                              OutT* __restrict__ out) {
   __shared__ long long wave_tot[kWavesPerBlock];
   __shared__ long long carry_s;
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void delta_write_kernel(const uint64_t* __r
   __syncthreads();
   for (int k0 = 0; k0 < kDeltaTile; k0 += kBlock) {      // block-uniform trip count
     const int64_t i = base + k0 + threadIdx.x;
-    const unsigned long long v = i < n ? static_cast<unsigned long long>(delta_at(words, mbs, values_per_miniblock, first_value, i)) : 0;
+    const unsigned long long v = i < n ? static_cast<unsigned long long>(src.at(i)) : 0;
     unsigned long long x = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -416,23 +424,47 @@ int arx_delta_decode(const void* bytes, const ArxDeltaMiniblock* miniblocks, int
     return ARX_INVALID;
   }
   const int64_t ntiles = ceil_div(num_values, kDeltaTile);
-  const uint64_t* words = static_cast<const uint64_t*>(bytes);
+  const DeltaSource src{static_cast<const uint64_t*>(bytes), miniblocks, values_per_miniblock, static_cast<long long>(first_value)};
   long long* sums = static_cast<long long*>(ws);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(delta_tile_sums_kernel, dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, words, miniblocks,
-                     values_per_miniblock, static_cast<long long>(first_value), num_values, sums);
+  hipLaunchKernelGGL((delta_tile_sums_kernel<DeltaSource>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, src,
+                     num_values, sums);
   ARX_CHECK_LAUNCH("delta_tile_sums_kernel");
   hipLaunchKernelGGL(delta_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, sums, ntiles);
   ARX_CHECK_LAUNCH("delta_scan_tiles_kernel");
   if (out_byte_width == 8) {
-    hipLaunchKernelGGL((delta_write_kernel<long long>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, words,
-                       miniblocks, values_per_miniblock, static_cast<long long>(first_value), num_values, sums,
-                       static_cast<long long*>(out));
+    hipLaunchKernelGGL((delta_write_kernel<long long, DeltaSource>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st,
+                       src, num_values, sums, static_cast<long long*>(out));
   } else {
-    hipLaunchKernelGGL((delta_write_kernel<int32_t>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, words,
-                       miniblocks, values_per_miniblock, static_cast<long long>(first_value), num_values, sums,
-                       static_cast<int32_t*>(out));
+    hipLaunchKernelGGL((delta_write_kernel<int32_t, DeltaSource>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st,
+                       src, num_values, sums, static_cast<int32_t*>(out));
   }
+  ARX_CHECK_LAUNCH("delta_write_kernel");
+  return ARX_OK;
+}
+
+// lengths[0..n) -> out[0..n]: out[0] = base, out[i] = base + lengths[0] + ... + lengths[i-1] (int32 offsets of a
+// utf8 / binary array).  ws: arx_delta_decode_workspace_bytes(n + 1).
+int arx_lengths_to_offsets_i32(const int32_t* lengths, int64_t n, int32_t base, int32_t* out, void* ws, size_t ws_bytes,
+                               void* stream) {
+  if (n < 0 || out == nullptr || (n > 0 && lengths == nullptr) || ws == nullptr ||
+      ws_bytes < arx_delta_decode_workspace_bytes(n + 1)) {
+    set_error("bad arguments to arx_lengths_to_offsets_i32 (%lld lengths, %zu workspace bytes needed)",
+              static_cast<long long>(n), arx_delta_decode_workspace_bytes(std::max<int64_t>(n, 0) + 1));
+    return ARX_INVALID;
+  }
+  const int64_t count = n + 1;
+  const int64_t ntiles = ceil_div(count, kDeltaTile);
+  const LengthSource src{lengths, static_cast<long long>(base)};
+  long long* sums = static_cast<long long*>(ws);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL((delta_tile_sums_kernel<LengthSource>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, src,
+                     count, sums);
+  ARX_CHECK_LAUNCH("delta_tile_sums_kernel");
+  hipLaunchKernelGGL(delta_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, sums, ntiles);
+  ARX_CHECK_LAUNCH("delta_scan_tiles_kernel");
+  hipLaunchKernelGGL((delta_write_kernel<int32_t, LengthSource>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, src,
+                     count, sums, out);
   ARX_CHECK_LAUNCH("delta_write_kernel");
   return ARX_OK;
 }

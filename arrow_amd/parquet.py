@@ -3,7 +3,7 @@
 Scope: flat columns of physical type INT32 / INT64 / FLOAT / DOUBLE (PLAIN and PLAIN_DICTIONARY /
 RLE_DICTIONARY encodings, incl. the dictionary -> PLAIN fallback inside a chunk; DELTA_BINARY_PACKED for
 INT32 / INT64; BYTE_STREAM_SPLIT), BOOLEAN (PLAIN, RLE) and
-BYTE_ARRAY columns (utf8 / binary; dictionary-encoded and PLAIN pages); required or optional (max definition level <= 1, no repetition),
+BYTE_ARRAY columns (utf8 / binary; dictionary-encoded, PLAIN and DELTA_LENGTH_BYTE_ARRAY pages); required or optional (max definition level <= 1, no repetition),
 data pages V1 and V2, any page compression pyarrow's codecs can undo.
 
 Division of labour (what the reference does in cpp/src/parquet/column_reader.cc:740-1000 and
@@ -30,7 +30,7 @@ from .array import Array, alloc, bitmap_nbytes, current_stream, default_device, 
 # parquet.thrift enums
 _PAGE_DATA, _PAGE_INDEX, _PAGE_DICT, _PAGE_DATA_V2 = 0, 1, 2, 3
 _ENC_PLAIN, _ENC_PLAIN_DICT, _ENC_RLE, _ENC_BIT_PACKED, _ENC_RLE_DICT = 0, 2, 3, 4, 8
-_ENC_DELTA_BINARY_PACKED, _ENC_BYTE_STREAM_SPLIT = 5, 9
+_ENC_DELTA_BINARY_PACKED, _ENC_DELTA_LENGTH_BYTE_ARRAY, _ENC_BYTE_STREAM_SPLIT = 5, 6, 9
 _PHYSICAL = {"INT32": (int32, np.int32), "INT64": (int64, np.int64), "FLOAT": (float32, np.float32),
              "DOUBLE": (float64, np.float64)}
 
@@ -325,9 +325,11 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
                     bool_bytes += values[4: 4 + nb]
         elif enc == _ENC_PLAIN:
             if is_binary:
-                plain_pages.append((bytes(values), valid_here))      # offsets are built once the dictionary size is known
+                plain_pages.append((bytes(values), valid_here, "plain"))      # offsets are built once the dictionary size is known
             else:
                 plain_bytes += values[: valid_here * width]
+        elif enc == _ENC_DELTA_LENGTH_BYTE_ARRAY and is_binary:
+            plain_pages.append((bytes(values), valid_here, "delta_length"))
         elif enc == _ENC_BYTE_STREAM_SPLIT and not is_binary and not is_bool:
             if len(values) < valid_here * width:
                 raise ArrowInvalid("Parquet: BYTE_STREAM_SPLIT page shorter than its values")
@@ -460,38 +462,68 @@ def _finish_binary_chunk(lib, stream, device, atype, dict_bytes, dict_count, ind
       * dictionary-encoded pages: source entries = the dictionary, indices = the decoded RLE indices;
       * PLAIN pages (also after a dictionary -> PLAIN fallback): the page bytes are appended to the
         source as alternating {4-byte length prefix, value} entries (offsets from one host walk,
-        arx_plain_byte_array_offsets) and the indices are simply the odd entries.
+        arx_plain_byte_array_offsets) and the indices are simply the odd entries;
+      * DELTA_LENGTH_BYTE_ARRAY pages: the bytes are appended as they are, the entries' offsets are the running
+        sum of the delta-decoded lengths (arx_delta_decode + arx_lengths_to_offsets_i32), indices consecutive.
     For an optional column the dense indices are first spread over their slots with the validity
     bitmap (which becomes the indices' validity)."""
     from . import compute as cp
     from .array import uint32
 
     offs, data = _parse_byte_array_dictionary(dict_bytes or b"", dict_count)
-    entries = dict_count
-    off_parts, data_parts, base = [offs], [data], len(data)
-    for page, count in plain_pages:
-        o = np.zeros(2 * count + 1, dtype=np.int32)
-        buf = np.frombuffer(page, dtype=np.uint8)
-        check(lib.arx_plain_byte_array_offsets(buf.ctypes.data if len(buf) else None, len(buf), count, base,
-                                               o.ctypes.data))
-        used = int(o[-1]) - base
-        off_parts.append(o[1:])
-        data_parts.append(page[:used])
-        base += used
-    d_offs = to_device(np.concatenate(off_parts), device)
-    d_data = to_device(np.frombuffer(b"".join(data_parts) or b"\0", dtype=np.uint8), device)
-    total_entries = entries + 2 * sum(c for _, c in plain_pages)
-    dvals = Array(atype, total_entries, [None, d_offs, d_data], 0, 0)
+    # ---- the source array: [dictionary entries][entries of every non-dictionary page, in page order]
+    total_entries = dict_count + sum(2 * c if kind == "plain" else c for _, c, kind in plain_pages)
+    d_offs = alloc((total_entries + 1) * 4, device)
+    d_offs[: (dict_count + 1) * 4] = to_device(offs.view(np.uint8), device)[: (dict_count + 1) * 4]
+    data_parts, base, epos = [data], len(data), dict_count
     idx = alloc(max(dense, 1) * 4, device)
+    ipos = dense_from_dict                                   # dense slot of the next non-dictionary value
+    for page, count, kind in plain_pages:
+        if kind == "plain":
+            # alternating {4-byte length prefix, value} entries; the values are the odd ones
+            o = np.zeros(2 * count + 1, dtype=np.int32)
+            buf = np.frombuffer(page, dtype=np.uint8)
+            check(lib.arx_plain_byte_array_offsets(buf.ctypes.data if len(buf) else None, len(buf), count, base, o.ctypes.data))
+            used = int(o[-1]) - base
+            if count:
+                d_offs[(epos + 1) * 4: (epos + 1 + 2 * count) * 4] = to_device(o[1:].view(np.uint8), device)[: 8 * count]
+                seq = torch.arange(epos + 1, epos + 1 + 2 * count, 2, dtype=torch.int32, device=device)
+                idx[ipos * 4: (ipos + count) * 4] = seq.view(torch.uint8)
+            data_parts.append(page[:used])
+            epos += 2 * count
+        else:
+            # DeltaLengthByteArrayDecoder (parquet/decoder.cc): DELTA_BINARY_PACKED lengths, then all the bytes; the
+            # offsets are the running sum of the lengths, built on the device right where the source array wants them
+            if count == 0:
+                continue
+            lengths = decode_delta_binary_packed(page, 4, device)
+            if lengths.length != count:
+                raise ArrowInvalid(f"Parquet: DELTA_LENGTH_BYTE_ARRAY page holds {lengths.length} lengths, its header says {count}")
+            _, _, _, _, header_bytes = scan_delta_miniblocks(page)
+            used = len(page) - header_bytes
+            ws = alloc(lib.arx_delta_decode_workspace_bytes(count + 1), device)
+            check(lib.arx_lengths_to_offsets_i32(lengths.data.data_ptr(), count, base, d_offs.data_ptr() + epos * 4,
+                                                 ws.data_ptr(), ws.numel(), stream))
+            seq = torch.arange(epos, epos + count, dtype=torch.int32, device=device)
+            idx[ipos * 4: (ipos + count) * 4] = seq.view(torch.uint8)
+            data_parts.append(page[header_bytes:])
+            epos += count
+        base += used
+        ipos += count
+    if base > 2**31 - 1:
+        raise ArrowInvalid("Parquet: column chunk exceeds the int32 offset range")
+    if any(kind == "delta_length" for _, _, kind in plain_pages):
+        end = int(d_offs.view(torch.int32)[total_entries].item())
+        if end != base:      # the lengths must add up to the bytes the pages carry
+            raise ArrowInvalid(f"Parquet: DELTA_LENGTH_BYTE_ARRAY lengths sum to {end - len(data)}, the pages carry {base - len(data)} bytes")
+    d_data = to_device(np.frombuffer(b"".join(data_parts) or b"\0", dtype=np.uint8), device)
+    dvals = Array(atype, total_entries, [None, d_offs, d_data], 0, 0)
     if dense_from_dict:
         runs = np.concatenate(index_runs)
         d_bytes = to_device(np.frombuffer(bytes(index_bytes) or b"\0", dtype=np.uint8), device)
         d_runs = _device_runs(runs, device)
         check(lib.arx_rle_decode_u32(d_bytes.data_ptr(), len(index_bytes), d_runs.data_ptr(), len(runs), 0,
                                      dense_from_dict, idx.data_ptr(), stream))
-    if dense > dense_from_dict:      # PLAIN values: the odd entries after the dictionary, in page order
-        odd = torch.arange(entries + 1, entries + 1 + 2 * (dense - dense_from_dict), 2, dtype=torch.int32, device=device)
-        idx[dense_from_dict * 4: dense * 4] = odd.view(torch.uint8)
     if max_def_level == 0 or dense == rows:
         didx = Array(uint32, rows, [None, idx], 0, 0)
         return cp.take(dvals, didx, boundscheck=True)

@@ -535,6 +535,11 @@ size_t arx_delta_decode_workspace_bytes(int64_t num_values);
 int arx_delta_decode(const void* bytes, const ArxDeltaMiniblock* miniblocks, int64_t num_miniblocks,
                      int64_t values_per_miniblock, int64_t first_value, int64_t num_values,
                      int out_byte_width, void* ws, size_t ws_bytes, void* out, void* stream);
+/* DELTA_LENGTH_BYTE_ARRAY (DeltaLengthByteArrayDecoder, cpp/src/parquet/decoder.cc): the lengths are a
+ * DELTA_BINARY_PACKED stream (arx_delta_decode, width 4), the offsets their running sum: out[0] = base,
+ * out[i] = out[i-1] + lengths[i-1], i in [1, n].  ws: arx_delta_decode_workspace_bytes(n + 1).  Asynchronous. */
+int arx_lengths_to_offsets_i32(const int32_t* lengths, int64_t n, int32_t base, int32_t* out, void* ws,
+                               size_t ws_bytes, void* stream);
 /* BYTE_STREAM_SPLIT (ByteStreamSplitDecoder, cpp/src/parquet/decoder.cc; arrow/util/byte_stream_split_internal.h):
  * `in` holds byte_width streams of num_values bytes each (stream k = byte k of every value); out[i] is value i.
  * byte_width 2, 4 or 8; `out` aligned to it.  Asynchronous. */

@@ -216,6 +216,38 @@ def test_parquet_byte_stream_split_gpu(gpu_ctx, tmp_path, null_p):
     _write_split_and_check(gpu_ctx, str(tmp_path), 600_000, null_p, 79, compression="snappy")
 
 
+def _write_delta_length_and_check(amd, tmp_path, n, null_p, seed, **kw):
+    rng = np.random.default_rng(seed)
+    mask = (lambda: rng.random(n) < null_p) if null_p else (lambda: None)
+    words = np.array([("w%d" % i) * (i % 5) for i in range(max(n, 1))], dtype=object)
+    t = pa.table({"s": pa.array(words[rng.integers(0, max(n, 1), n)], type=pa.string(), mask=mask()),
+                  "b": pa.array([bytes([i % 251]) * (i % 9) for i in range(n)], type=pa.binary(), mask=mask()),
+                  "empty": pa.array([""] * n, type=pa.string(), mask=mask()),
+                  "long": pa.array(["x" * int(k) for k in rng.integers(0, 300, n)], type=pa.string(), mask=mask())})
+    path = os.path.join(tmp_path, "dl.parquet")
+    pq.write_table(t, path, use_dictionary=False, column_encoding={name: "DELTA_LENGTH_BYTE_ARRAY" for name in t.schema.names},
+                   row_group_size=max(1, n // 2 + 7), **kw)
+    md = pq.ParquetFile(path).metadata
+    assert all("DELTA_LENGTH_BYTE_ARRAY" in md.row_group(0).column(i).encodings for i in range(md.num_columns))
+    check_file(amd, path)
+
+
+@pytest.mark.emu
+@pytest.mark.parametrize("null_p", [0.0, 0.2])
+@pytest.mark.parametrize("n,kw", [(6000, dict(data_page_size=2048, compression="snappy")), (1, {}), (33, {}),
+                                  (4097, dict(data_page_version="2.0", compression="none"))])
+def test_parquet_delta_length_byte_array_emulator(emu_ctx, tmp_path, n, kw, null_p):
+    """DELTA_LENGTH_BYTE_ARRAY pages (DeltaLengthByteArrayDecoder): delta-packed lengths -> offsets by a device prefix
+    sum, bytes appended as they are; utf8 and binary, empty strings, long values, many small pages, nulls."""
+    _write_delta_length_and_check(emu_ctx, str(tmp_path), n, null_p, 61 + n, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("null_p", [0.0, 0.1])
+def test_parquet_delta_length_byte_array_gpu(gpu_ctx, tmp_path, null_p):
+    _write_delta_length_and_check(gpu_ctx, str(tmp_path), 300_000, null_p, 83, compression="snappy")
+
+
 def _delta_page_bytes(path, column):
     """The value bytes of every DELTA_BINARY_PACKED data page of one column chunk, read with this package's page walk."""
     from arrow_amd import parquet as P
