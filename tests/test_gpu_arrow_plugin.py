@@ -733,6 +733,21 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
                     h = to_host(read_column(path, rg, ci))
                     w = ref.column(name).combine_chunks()
                     assert h.equals(w) and h.null_count == w.null_count, ("delta", variant, null_p, rg, name)
+        # DELTA_LENGTH_BYTE_ARRAY strings
+        lt = pa.table({"s": pa.array(np.array([("w%d" % i) * (i % 5) for i in range(n)], dtype=object)[rng.integers(0, n, n)],
+                                     type=pa.string(), mask=m(null_p)),
+                       "b": pa.array([bytes([i % 251]) * (i % 9) for i in range(n)], type=pa.binary(), mask=m(null_p))})
+        path = os.path.join(tempfile.mkdtemp(), "dl.parquet")
+        pq.write_table(lt, path, row_group_size=n // 2 + 11, use_dictionary=False, data_page_size=32768,
+                       column_encoding={name: "DELTA_LENGTH_BYTE_ARRAY" for name in lt.schema.names})
+        pf = pq.ParquetFile(path)
+        for rg in range(pf.metadata.num_row_groups):
+            ref = pf.read_row_group(rg)
+            for ci, name in enumerate(lt.schema.names):
+                assert "DELTA_LENGTH_BYTE_ARRAY" in pf.metadata.row_group(rg).column(ci).encodings
+                h = to_host(read_column(path, rg, ci))
+                w = ref.column(name).combine_chunks()
+                assert h.equals(w) and h.null_count == w.null_count, ("delta_length", null_p, rg, name)
         # BYTE_STREAM_SPLIT floating-point and integer columns
         st = pa.table({"f32": pa.array(rng.standard_normal(n).astype(np.float32), mask=m(null_p)),
                        "f64": pa.array(rng.standard_normal(n) * 1e100, mask=m(null_p)),
