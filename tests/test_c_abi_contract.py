@@ -173,3 +173,13 @@ def test_concatenate_and_delta_argument_checks(emu_ctx):
     page[:16] = torch.arange(16, dtype=torch.uint8)
     assert lib.arx_byte_stream_split_decode(page.data_ptr(), 4, 4, out.data_ptr(), None) == OK
     assert out[:16].tolist() == [0, 4, 8, 12, 1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15]
+    # DELTA_LENGTH_BYTE_ARRAY: lengths -> offsets
+    lens = torch.tensor([3, 0, 5, 1], dtype=torch.int32)
+    offs = torch.zeros(16, dtype=torch.int32)
+    assert lib.arx_lengths_to_offsets_i32(lens.data_ptr(), 4, 10, offs.data_ptr(), ws.data_ptr(), ws.numel(), None) == OK
+    assert offs[:5].tolist() == [10, 13, 13, 18, 19]
+    assert lib.arx_lengths_to_offsets_i32(None, 0, 7, offs.data_ptr(), ws.data_ptr(), ws.numel(), None) == OK and offs[0].item() == 7
+    assert lib.arx_lengths_to_offsets_i32(None, 4, 0, offs.data_ptr(), ws.data_ptr(), ws.numel(), None) == INVALID
+    assert lib.arx_lengths_to_offsets_i32(lens.data_ptr(), 4, 0, None, ws.data_ptr(), ws.numel(), None) == INVALID
+    assert lib.arx_lengths_to_offsets_i32(lens.data_ptr(), 4, 0, offs.data_ptr(), ws.data_ptr(), 0, None) == INVALID
+    assert lib.arx_lengths_to_offsets_i32(lens.data_ptr(), -1, 0, offs.data_ptr(), ws.data_ptr(), ws.numel(), None) == INVALID
