@@ -276,16 +276,6 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
         got_d = pc.drop_null(dv)
         assert not got_d.is_cpu
         assert to_host(got_d).equals(pc.drop_null(hv))
-    # BOOLEAN (bit-packed) values on the device: the 1-bit gather
-    bvals = pa.array(rng.random(n) < 0.4, mask=rng.random(n) < 0.07)
-    d_bvals = to_device(bvals)
-    for got_d, want_h in ((pc.filter(d_bvals, d_mask), pc.filter(bvals, mask)),
-                          (pc.filter(d_bvals.slice(9), d_mask.slice(9), null_selection_behavior="emit_null"),
-                           pc.filter(bvals.slice(9), mask.slice(9), null_selection_behavior="emit_null")),
-                          (pc.take(d_bvals, d_idx), pc.take(bvals, idx))):
-        assert not got_d.is_cpu
-        hb = to_host(got_d)
-        assert hb.equals(want_h) and hb.null_count == want_h.null_count
     # the other fixed-width classes of match::Primitive() + decimal128 / fixed_size_binary (widths 2..16 bytes)
     import decimal
     nw = SC(200_003)
@@ -344,30 +334,6 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
         raise SystemExit("expected IndexError")
     except pa.lib.ArrowIndexError as e:
         assert str(e) == f"Index {n} out of bounds", str(e)
-    # scalar aggregates of int64 device columns (sum / count / min_max / min / max): the state is 32 B read back per batch
-    red0 = lib.arrow_amd_plugin_calls(b"reduce", 1)
-    all_null = pa.array([None] * 1000, pa.int64())
-    for h_arr in (vals, smalls, pa.array(rng.integers(-2**62, 2**62, n)), all_null, vals.slice(0, 0)):
-        d_arr = to_device(h_arr)
-        for opts in (None, pc.ScalarAggregateOptions(skip_nulls=False), pc.ScalarAggregateOptions(min_count=len(h_arr)),
-                     pc.ScalarAggregateOptions(min_count=0)):
-            for fn in ("sum", "min_max", "min", "max"):
-                g, w = pc.call_function(fn, [d_arr], opts), pc.call_function(fn, [h_arr], opts)
-                assert g.equals(w) and g.type == w.type, (fn, opts, g, w)
-        if len(h_arr) > 200:
-            for fn in ("sum", "min_max"):
-                assert pc.call_function(fn, [d_arr.slice(13, len(h_arr) - 100)]).equals(pc.call_function(fn, [h_arr.slice(13, len(h_arr) - 100)])), fn
-        for mode in ("only_valid", "only_null", "all"):
-            assert pc.count(d_arr, mode=mode).equals(pc.count(h_arr, mode=mode)), mode
-    chunks = pa.chunked_array([to_device(vals.slice(0, 1000)), to_device(vals.slice(1000))])       # merge of per-batch states
-    assert pc.sum(chunks).equals(pc.sum(vals)) and pc.min_max(chunks).equals(pc.min_max(vals))
-    assert lib.arrow_amd_plugin_calls(b"reduce", 1) > red0 + 80
-    assert pc.count(pa.array(["a", None])).as_py() == 1 and pc.sum(pa.array([1.5, 2.5])).as_py() == 4.0     # other types: stock
-    try:
-        pc.sum(pa.chunked_array([vals.slice(0, 10), d_vals]))
-        raise SystemExit("expected NotImplemented for a host+device aggregation")
-    except pa.lib.ArrowNotImplementedError:
-        pass
     print("DEVICE_OK")
 ''')
 
@@ -535,18 +501,6 @@ ACERO_DEVICE_SCRIPT = textwrap.dedent(r'''
             assert lib.arrow_amd_plugin_calls(f, 1) > gpu0[f], f
             assert lib.arrow_amd_plugin_calls(f, 0) == stock0[f], f
 
-        # no keys: Acero's own ScalarAggregateNode (acero/scalar_aggregate_node.cc) over device batches
-        def scalar_plan(table):
-            return acero.Declaration.from_sequence([
-                acero.Declaration("table_source", acero.TableSourceNodeOptions(table)),
-                acero.Declaration("filter", acero.FilterNodeOptions(pc.field("w") > 10)),
-                acero.Declaration("aggregate", acero.AggregateNodeOptions(
-                    [("v", "sum", None, "s"), ("v", "min_max", None, "mm"), ("v", "count", None, "c"), ("w", "max", None, "wmax"),
-                     ("w", "min", pc.ScalarAggregateOptions(skip_nulls=False), "wmin")]))])
-        red0 = lib.arrow_amd_plugin_calls(b"reduce", 1)
-        for threads in (False, True):
-            assert scalar_plan(dev).to_table(use_threads=threads).equals(scalar_plan(host).to_table(use_threads=threads)), (null_p, threads)
-        assert lib.arrow_amd_plugin_calls(b"reduce", 1) >= red0 + 10
     print("ACERO_DEVICE_OK")
 ''')
 
@@ -561,6 +515,138 @@ def test_acero_plan_over_a_device_resident_table():
     code = f"ROOT = {ROOT!r}\n" + ACERO_DEVICE_SCRIPT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "ACERO_DEVICE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+BOOLEAN_VALUES_SCRIPT = textwrap.dedent(r'''
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))   # sizes shrink for the emulated run
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(n) for n in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(n) for n in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    rng = np.random.default_rng(29)
+    n = SC(3_000_001)
+    mask = pa.array(rng.random(n) < 0.1, mask=rng.random(n) < 0.02)
+    idx = pa.array(rng.integers(0, n, SC(500_000)).astype(np.uint32), mask=rng.random(SC(500_000)) < 0.05)
+    d_mask, d_idx = to_device(mask), to_device(idx)
+    gpu_f, gpu_t = lib.arrow_amd_plugin_calls(b"array_filter", 1), lib.arrow_amd_plugin_calls(b"array_take", 1)
+    # BOOLEAN (bit-packed) values on the device: the 1-bit gather
+    bvals = pa.array(rng.random(n) < 0.4, mask=rng.random(n) < 0.07)
+    d_bvals = to_device(bvals)
+    for got_d, want_h in ((pc.filter(d_bvals, d_mask), pc.filter(bvals, mask)),
+                          (pc.filter(d_bvals.slice(9), d_mask.slice(9), null_selection_behavior="emit_null"),
+                           pc.filter(bvals.slice(9), mask.slice(9), null_selection_behavior="emit_null")),
+                          (pc.take(d_bvals, d_idx), pc.take(bvals, idx))):
+        assert not got_d.is_cpu
+        hb = to_host(got_d)
+        assert hb.equals(want_h) and hb.null_count == want_h.null_count
+    assert lib.arrow_amd_plugin_calls(b"array_filter", 1) == gpu_f + 2 and lib.arrow_amd_plugin_calls(b"array_take", 1) == gpu_t + 1
+    print("BOOLEAN_VALUES_OK")
+''')
+
+
+AGGREGATE_SCRIPT = textwrap.dedent(r'''
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))   # sizes shrink for the emulated run
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(n) for n in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(n) for n in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    from pyarrow import acero
+    rng = np.random.default_rng(23)
+    n = SC(3_000_001)
+    vals = pa.array(rng.integers(-2**62, 2**62, n), mask=rng.random(n) < 0.1)
+    smalls = pa.array(rng.integers(-10**6, 10**6, n), mask=rng.random(n) < 0.05)
+    d_vals = to_device(vals)
+    # scalar aggregates of int64 device columns (sum / count / min_max / min / max): the state is 32 B read back per batch
+    red0 = lib.arrow_amd_plugin_calls(b"reduce", 1)
+    all_null = pa.array([None] * 1000, pa.int64())
+    for h_arr in (vals, smalls, pa.array(rng.integers(-2**62, 2**62, n)), all_null, vals.slice(0, 0)):
+        d_arr = to_device(h_arr)
+        for opts in (None, pc.ScalarAggregateOptions(skip_nulls=False), pc.ScalarAggregateOptions(min_count=len(h_arr)),
+                     pc.ScalarAggregateOptions(min_count=0)):
+            for fn in ("sum", "min_max", "min", "max"):
+                g, w = pc.call_function(fn, [d_arr], opts), pc.call_function(fn, [h_arr], opts)
+                assert g.equals(w) and g.type == w.type, (fn, opts, g, w)
+        if len(h_arr) > 200:
+            for fn in ("sum", "min_max"):
+                assert pc.call_function(fn, [d_arr.slice(13, len(h_arr) - 100)]).equals(pc.call_function(fn, [h_arr.slice(13, len(h_arr) - 100)])), fn
+        for mode in ("only_valid", "only_null", "all"):
+            assert pc.count(d_arr, mode=mode).equals(pc.count(h_arr, mode=mode)), mode
+    chunks = pa.chunked_array([to_device(vals.slice(0, 1000)), to_device(vals.slice(1000))])       # merge of per-batch states
+    assert pc.sum(chunks).equals(pc.sum(vals)) and pc.min_max(chunks).equals(pc.min_max(vals))
+    assert lib.arrow_amd_plugin_calls(b"reduce", 1) > red0 + 80
+    assert pc.count(pa.array(["a", None])).as_py() == 1 and pc.sum(pa.array([1.5, 2.5])).as_py() == 4.0     # other types: stock
+    try:
+        pc.sum(pa.chunked_array([vals.slice(0, 10), d_vals]))
+        raise SystemExit("expected NotImplemented for a host+device aggregation")
+    except pa.lib.ArrowNotImplementedError:
+        pass
+    # Acero's own ScalarAggregateNode (acero/scalar_aggregate_node.cc) over device batches: table_source -> filter -> aggregate
+    m = SC(1_000_003)
+    for null_p in (0.0, 0.03):
+        mk = (lambda a: pa.array(a, mask=rng.random(m) < null_p)) if null_p else pa.array
+        v, w = mk(rng.integers(-2**62, 2**62, m)), mk(rng.integers(-100, 100, m))
+        host = pa.table({"v": v, "w": w})
+        dev = pa.table({"v": to_device(v), "w": to_device(w)})
+
+        def scalar_plan(table):
+            return acero.Declaration.from_sequence([
+                acero.Declaration("table_source", acero.TableSourceNodeOptions(table)),
+                acero.Declaration("filter", acero.FilterNodeOptions(pc.field("w") > 10)),
+                acero.Declaration("aggregate", acero.AggregateNodeOptions(
+                    [("v", "sum", None, "s"), ("v", "min_max", None, "mm"), ("v", "count", None, "c"), ("w", "max", None, "wmax"),
+                     ("w", "min", pc.ScalarAggregateOptions(skip_nulls=False), "wmin")]))])
+        red0 = lib.arrow_amd_plugin_calls(b"reduce", 1)
+        for threads in (False, True):
+            assert scalar_plan(dev).to_table(use_threads=threads).equals(scalar_plan(host).to_table(use_threads=threads)), (null_p, threads)
+        assert lib.arrow_amd_plugin_calls(b"reduce", 1) >= red0 + 10
+    print("AGGREGATE_OK")
+''')
 
 
 ORDER_BY_SCRIPT = textwrap.dedent(r'''
@@ -644,17 +730,6 @@ ORDER_BY_SCRIPT = textwrap.dedent(r'''
 ''')
 
 
-def test_acero_order_by_over_a_device_resident_table():
-    """OrderByNode (acero/order_by_node.cc:100-108) as `order_by_rocm`: table_source ->
-    [filter] -> order_by_rocm over device-resident and host tables, one to three sort keys with their own
-    direction and null placement (int32 / int64 / float64 with NaNs / timestamp), payload columns of int64,
-    utf8, boolean; equal to the stock `order_by` over the host table, with and without threads."""
-    pytest.importorskip("pyarrow")
-    code = f"ROOT = {ROOT!r}\n" + ORDER_BY_SCRIPT
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert r.returncode == 0 and "ORDER_BY_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-
-
 PARQUET_SCRIPT = textwrap.dedent(r'''
     import ctypes, faulthandler, os, sys, tempfile
     import numpy as np
@@ -716,6 +791,51 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
                     h = to_host(d)
                     w = ref.column(name).combine_chunks()
                     assert h.equals(w) and h.null_count == w.null_count, (variant, null_p, rg, name, h.slice(0, 5), w.slice(0, 5))
+    assert lib.arrow_amd_plugin_calls(b"parquet", 1) > 0
+    # a nested column is refused, not mis-decoded
+    path = os.path.join(tempfile.mkdtemp(), "l.parquet")
+    pq.write_table(pa.table({"l": pa.array([[1, 2], [3]])}), path)
+    c_dev, c_schema = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72)
+    assert lib.arrow_amd_parquet_read_column(path.encode(), 0, 0, ctypes.addressof(c_dev), ctypes.addressof(c_schema)) != 0
+    assert b"nested" in lib.arrow_amd_plugin_last_error()
+    print("PARQUET_OK")
+''')
+
+
+PARQUET_ENCODINGS_SCRIPT = textwrap.dedent(r'''
+    import ctypes, faulthandler, os, sys, tempfile
+    import numpy as np
+    import pyarrow as pa, pyarrow.parquet as pq
+    faulthandler.enable()
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.arrow_amd_parquet_read_column.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(n) for n in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    def read_column(path, rg, col):
+        c_dev, c_schema = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72)
+        rc = lib.arrow_amd_parquet_read_column(path.encode(), rg, col, ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert rc == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+
+    rng = np.random.default_rng(17)
+    n = SC(1_000_003)
+    m = lambda p: (rng.random(n) < p) if p else None
+    for null_p in (0.0, 0.12):
         # DELTA_BINARY_PACKED integer columns (sorted ids, a random walk, wrap-around deltas, constants)
         dt = pa.table({"sorted64": pa.array(np.sort(rng.integers(0, 2**40, n)), mask=m(null_p)),
                        "walk32": pa.array(np.cumsum(rng.integers(-50, 60, n)).astype(np.int32), mask=m(null_p)),
@@ -764,20 +884,5 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
                 w = ref.column(name).combine_chunks()
                 assert h.equals(w) and h.null_count == w.null_count, ("byte_stream_split", null_p, rg, name)
     assert lib.arrow_amd_plugin_calls(b"parquet", 1) > 0
-    # a nested column is refused, not mis-decoded
-    path = os.path.join(tempfile.mkdtemp(), "l.parquet")
-    pq.write_table(pa.table({"l": pa.array([[1, 2], [3]])}), path)
-    c_dev, c_schema = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72)
-    assert lib.arrow_amd_parquet_read_column(path.encode(), 0, 0, ctypes.addressof(c_dev), ctypes.addressof(c_schema)) != 0
-    assert b"nested" in lib.arrow_amd_plugin_last_error()
-    print("PARQUET_OK")
+    print("PARQUET_ENCODINGS_OK")
 ''')
-
-
-def test_parquet_column_chunks_through_the_plugin():
-    """SURVEY.md 8 (f4): parquet::PageReader (headers, decompression) + the C-ABI kernels (levels,
-    indices, dictionary gather, null expansion) -> device-resident arrays equal to the reference's reader."""
-    pytest.importorskip("pyarrow")
-    code = f"ROOT = {ROOT!r}\n" + PARQUET_SCRIPT
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert r.returncode == 0 and "PARQUET_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

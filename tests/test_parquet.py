@@ -173,17 +173,6 @@ def test_parquet_delta_binary_packed_emulator(emu_ctx, tmp_path, n, kw, null_p):
     _write_delta_and_check(emu_ctx, str(tmp_path), n, null_p, 31 + n, **kw)
 
 
-@pytest.mark.gpu
-def test_delta_decode_kernel_vs_restatement_gpu(gpu_ctx):
-    PC.check_delta_decode(gpu_ctx, np.random.default_rng(5), 128, 4)
-    PC.check_delta_decode(gpu_ctx, np.random.default_rng(6), 512, 2)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("null_p", [0.0, 0.1])
-def test_parquet_delta_binary_packed_gpu(gpu_ctx, tmp_path, null_p):
-    _write_delta_and_check(gpu_ctx, str(tmp_path), 600_000, null_p, 77, compression="snappy")
-    _write_delta_and_check(gpu_ctx, str(tmp_path), 70_001, null_p, 78, data_page_version="2.0", data_page_size=8192)
 
 
 def _write_split_and_check(amd, tmp_path, n, null_p, seed, **kw):
@@ -209,11 +198,6 @@ def test_parquet_byte_stream_split_emulator(emu_ctx, tmp_path, n, kw, null_p):
     """BYTE_STREAM_SPLIT pages (ByteStreamSplitDecoder): float, double, int32, int64 columns, many small pages."""
     _write_split_and_check(emu_ctx, str(tmp_path), n, null_p, 51 + n, **kw)
 
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("null_p", [0.0, 0.1])
-def test_parquet_byte_stream_split_gpu(gpu_ctx, tmp_path, null_p):
-    _write_split_and_check(gpu_ctx, str(tmp_path), 600_000, null_p, 79, compression="snappy")
 
 
 def _write_delta_length_and_check(amd, tmp_path, n, null_p, seed, **kw):
@@ -241,11 +225,6 @@ def test_parquet_delta_length_byte_array_emulator(emu_ctx, tmp_path, n, kw, null
     sum, bytes appended as they are; utf8 and binary, empty strings, long values, many small pages, nulls."""
     _write_delta_length_and_check(emu_ctx, str(tmp_path), n, null_p, 61 + n, **kw)
 
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("null_p", [0.0, 0.1])
-def test_parquet_delta_length_byte_array_gpu(gpu_ctx, tmp_path, null_p):
-    _write_delta_length_and_check(gpu_ctx, str(tmp_path), 300_000, null_p, 83, compression="snappy")
 
 
 def _delta_page_bytes(path, column):

@@ -48,3 +48,15 @@ def test_parquet_column_chunks_through_the_plugin_emulated():
 
 def test_acero_order_by_node_emulated():
     _run(G.ORDER_BY_SCRIPT, "ORDER_BY_OK", 0.02)
+
+
+def test_scalar_aggregates_on_device_resident_columns_emulated():
+    _run(G.AGGREGATE_SCRIPT, "AGGREGATE_OK", 0.02)
+
+
+def test_parquet_delta_and_split_encodings_through_the_plugin_emulated():
+    _run(G.PARQUET_ENCODINGS_SCRIPT, "PARQUET_ENCODINGS_OK", 0.02)
+
+
+def test_boolean_values_filter_and_take_emulated():
+    _run(G.BOOLEAN_VALUES_SCRIPT, "BOOLEAN_VALUES_OK", 0.025)
