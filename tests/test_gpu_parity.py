@@ -773,8 +773,3 @@ def test_dictionary_encode(gpu_ctx, null_p, offset):
     a = U.random_array(rng, np.int32, 500003, null_p=null_p, offset=offset, tail=2, lo=-40000, hi=40000)
     P.check_dictionary_encode(gpu_ctx, a)
     P.check_dictionary_encode(gpu_ctx, U.random_array(rng, np.int32, 0))
-
-
-def test_scalar_aggregates_int64(gpu_ctx):
-    """SumImpl / CountImpl / MinMaxImpl (aggregate_basic.inc.cc): wrap-around sum, options, batches."""
-    P.check_scalar_aggregates(gpu_ctx, rng_for("scalaragg"), n=1000003)

@@ -78,6 +78,11 @@ def test_boolean_values_take_and_filter(gpu_ctx, idx_dtype, vnull, inull, voff):
     P.check_boolean_take_and_filter(gpu_ctx, v, i, m)
 
 
+def test_scalar_aggregates_int64(gpu_ctx):
+    """SumImpl / CountImpl / MinMaxImpl (aggregate_basic.inc.cc): wrap-around sum, options, batches."""
+    P.check_scalar_aggregates(gpu_ctx, rng_for("scalaragg"), n=1000003)
+
+
 # ------------------------------------------------------------------ concatenate / order_by (OrderByNode::DoFinish)
 @pytest.mark.parametrize("kind", ["int64", "int8", "bool", "utf8", "binary_nonull"])
 def test_concat_arrays(gpu_ctx, kind):
