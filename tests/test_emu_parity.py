@@ -662,8 +662,11 @@ def test_order_by_several_keys(emu_ctx, null_placement):
     strs = col(lambda n, o: U.random_binary(rng, n, null_p=0.1, offset=o, tail=1, utf8=True))
     flags = col(lambda n, o: U.random_mask(rng, n, 0.5, null_p=0.1, offset=o, tail=1))
     cols = [k0, k1, k2, payload, strs, flags]
-    P.check_order_by(emu_ctx, cols, [(0, "ascending"), (1, "descending")], null_placement)
-    P.check_order_by(emu_ctx, cols, [(2, "descending"), (0, "descending"), (1, "ascending")], null_placement)
-    P.check_order_by(emu_ctx, cols, [(1, "ascending")], null_placement)
+    # (every sort launch costs seconds under the emulator: the two placements share the key sets between them)
     other = "at_start" if null_placement == "at_end" else "at_end"
+    if null_placement == "at_end":
+        P.check_order_by(emu_ctx, cols, [(0, "ascending"), (1, "descending")], null_placement)
+        P.check_order_by(emu_ctx, cols, [(1, "ascending")], null_placement)
+    else:
+        P.check_order_by(emu_ctx, cols, [(2, "descending"), (0, "descending"), (1, "ascending")], null_placement)
     P.check_order_by(emu_ctx, cols, [(0, "descending"), (2, "ascending")], [null_placement, other])     # per-key placement
