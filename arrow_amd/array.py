@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import re
+
 import numpy as np
 import torch
 
@@ -91,6 +93,15 @@ _BY_NAME.update({"float32": float32, "float64": float64, "boolean": bool_, "bina
 _BY_NP = {t.np_dtype: t for t in _ALL_TYPES}
 
 
+# temporal types: the layout of their physical integer (what filter / take / sort / the Parquet decode move around)
+_TEMPORAL_64 = re.compile(r"^(timestamp\[(s|ms|us|ns)(, tz=.+)?\]|duration\[(s|ms|us|ns)\]|time64\[(us|ns)\]|date64\[ms\])$")
+_TEMPORAL_32 = re.compile(r"^(date32\[day\]|time32\[(s|ms)\])$")
+
+
+def is_temporal(t: DataType) -> bool:
+    return bool(_TEMPORAL_64.match(t.name) or _TEMPORAL_32.match(t.name))
+
+
 def is_base_binary(t: DataType) -> bool:
     return t.name in ("binary", "string")
 
@@ -103,6 +114,10 @@ def type_from_name(name: str) -> DataType:
     try:
         return _BY_NAME[str(name)]
     except KeyError:
+        if _TEMPORAL_64.match(str(name)):
+            return _BY_NAME.setdefault(str(name), DataType(str(name), 64, np.int64))
+        if _TEMPORAL_32.match(str(name)):
+            return _BY_NAME.setdefault(str(name), DataType(str(name), 32, np.int32))
         raise _lib.ArrowNotImplementedError(f"type {name} is not supported by arrow_amd") from None
 
 
@@ -315,6 +330,8 @@ class Array:
                                          offset=self.offset)
         values, valid = self.to_numpy()
         mask = None if valid is None else ~valid
+        if is_temporal(self.type):
+            return pa.array(values, mask=mask).view(_pa_temporal(self.type.name))
         return pa.array(values, type=pa.type_for_alias(_PA_ALIAS[self.type.name]), mask=mask)
 
     def to_pylist(self):
@@ -324,6 +341,17 @@ class Array:
         if valid is None:
             return values.tolist()
         return [v if ok else None for v, ok in zip(values.tolist(), valid.tolist())]
+
+
+def _pa_temporal(name: str):
+    import pyarrow as pa
+
+    kind, _, rest = name.partition("[")
+    unit, _, tz = rest.rstrip("]").partition(", tz=")
+    if kind == "timestamp":
+        return pa.timestamp(unit, tz=tz or None)
+    return {"duration": pa.duration, "time64": pa.time64, "time32": pa.time32}[kind](unit) if kind in ("duration", "time64", "time32") \
+        else (pa.date32() if kind == "date32" else pa.date64())
 
 
 _PA_ALIAS = {"bool": "bool", "int8": "int8", "uint8": "uint8", "int16": "int16", "uint16": "uint16",

@@ -39,6 +39,7 @@
 #include <parquet/file_reader.h>
 #include <parquet/metadata.h>
 #include <parquet/schema.h>
+#include <parquet/arrow/schema.h>
 #include <arrow/util/ubsan.h>
 
 #include <algorithm>

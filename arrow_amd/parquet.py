@@ -561,6 +561,20 @@ def read_table(path: str, columns=None, device=None, stats: dict | None = None) 
             from .array import binary, utf8
 
             binary_type = utf8 if str(md.schema.column(ci).logical_type).upper().startswith("STRING") else binary
-        out[name] = [read_column_chunk(raw, md.row_group(rg).column(ci), max_def, device, stats, binary_type)
-                     for rg in range(md.num_row_groups)]
+        chunks = [read_column_chunk(raw, md.row_group(rg).column(ci), max_def, device, stats, binary_type)
+                  for rg in range(md.num_row_groups)]
+        # logical types whose Arrow layout is the physical layout (timestamp, date32, time32 / time64): same bytes,
+        # labelled the way the reference's reader labels them (parquet/arrow/schema.cc)
+        if md.schema.column(ci).physical_type in ("INT32", "INT64") and "." not in name:
+            from .array import is_temporal, type_from_name
+
+            try:
+                logical = type_from_name(str(pf.schema_arrow.field(name).type))
+            except ArrowNotImplementedError:
+                logical = None
+            if logical is not None and is_temporal(logical):
+                for a in chunks:
+                    if a.type.bit_width == logical.bit_width:
+                        a.type = logical
+        out[name] = chunks
     return out

@@ -769,6 +769,9 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
                       "grow": pa.array(np.arange(n) // 3, mask=m(null_p)),
                       "i32": pa.array(np.repeat(rng.integers(0, 9, n // 50 + 1), 50)[:n].astype(np.int32), mask=m(null_p)),
                       "f64": pa.array(np.round(rng.standard_normal(n), 2), mask=m(null_p)),
+                      "ts": pa.array(rng.integers(0, 2**50, n), pa.timestamp("us", tz="UTC"), mask=m(null_p)),     # logical types with the
+                      "day": pa.array(rng.integers(0, 20000, n).astype(np.int32), pa.date32(), mask=m(null_p)),   # physical layout: labelled
+                      "tod": pa.array(rng.integers(0, 86_400_000, n).astype(np.int32), pa.time32("ms"), mask=m(null_p)),
                       "f32": pa.array(rng.standard_normal(n).astype(np.float32), mask=m(null_p)),
                       "flag": pa.array(rng.random(n) < 0.3, type=pa.bool_(), mask=m(null_p)),
                       "flag_runs": pa.array(np.repeat(rng.random(n // 40 + 1) < 0.5, 40)[:n], type=pa.bool_(), mask=m(null_p)),

@@ -27,6 +27,9 @@ def _table(rng, n, null_p):
         "f64": pa.array(np.round(rng.standard_normal(n), 2), mask=m()),
         "f32": pa.array(rng.standard_normal(n).astype(np.float32), mask=m()),
         "req": pa.array(rng.integers(0, 1000, n)),
+        "ts": pa.array(rng.integers(0, 2**50, n), pa.timestamp("us", tz="UTC"), mask=m()),      # logical types that share the
+        "day": pa.array(rng.integers(0, 20000, n).astype(np.int32), pa.date32(), mask=m()),    # physical layout
+        "tod": pa.array(rng.integers(0, 86_400_000, n).astype(np.int32), pa.time32("ms"), mask=m()),
         "flag": pa.array(rng.random(n) < 0.3, type=pa.bool_(), mask=m()),
         "flag_runs": pa.array(np.repeat(rng.random(n // 40 + 1) < 0.5, 40)[:n], type=pa.bool_(), mask=m()),
         "str": pa.array(np.array(["", "a", "bb", "gfx950", "MI355X", "ünïcödé", "x" * 40], dtype=object)[rng.integers(0, 7, n)], type=pa.string(), mask=m()),
