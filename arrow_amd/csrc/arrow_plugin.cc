@@ -181,6 +181,8 @@ int arrow_amd_parquet_read_column(const char* path, int row_group, int column, s
 }
 // Inputs shorter than this stay on the stock CPU kernels (PCIe staging does not pay).
 void arrow_amd_plugin_set_min_rows(int64_t n) { g_min_rows.store(n); }
+// Device-resident filters of at most n rows use one synchronisation instead of three (0 = off, the default).
+void arrow_amd_plugin_set_filter_morsel_rows(int64_t n) { g_filter_morsel_rows.store(n); }
 // The same threshold for the element-wise kernels (greater, cast); default: never stage them.
 void arrow_amd_plugin_set_min_rows_streaming(int64_t n) { g_min_rows_streaming.store(n); }
 

@@ -46,4 +46,15 @@ print({f.decode(): g1[f] - g0[f] for f in g0})
 got = got.sort_by("k")
 assert got.schema.names == ["k", "v_sum"]
 assert got.equals(want.select(["k", "v_sum"])), (got.slice(0, 5), want.slice(0, 5))
+# A/B of the single-synchronisation filter path (off by default until it has been measured here)
+lib.arrow_amd_plugin_set_filter_morsel_rows.argtypes = [ctypes.c_int64]
+for morsel in (0, 1 << 20, 0, 1 << 20):
+    lib.arrow_amd_plugin_set_filter_morsel_rows(morsel)
+    for threads in (False, True):
+        t0 = time.perf_counter()
+        again = plan(dev, "aggregate_rocm").to_table(use_threads=threads)
+        dt = time.perf_counter() - t0
+        assert again.sort_by("k").equals(got)
+        print("filter_morsel_rows=%d threads=%s: device plan %.1f ms" % (morsel, threads, dt * 1e3), flush=True)
+lib.arrow_amd_plugin_set_filter_morsel_rows(0)
 print("ACERO_DEVICE_OK")

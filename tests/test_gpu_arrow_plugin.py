@@ -567,6 +567,79 @@ BOOLEAN_VALUES_SCRIPT = textwrap.dedent(r'''
 ''')
 
 
+MORSEL_FILTER_SCRIPT = textwrap.dedent(r'''
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))   # sizes shrink for the emulated run
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(n) for n in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(n) for n in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    from pyarrow import acero
+    lib.arrow_amd_plugin_set_filter_morsel_rows.argtypes = [ctypes.c_int64]
+    rng = np.random.default_rng(31)
+    # single-synchronisation filter path (arrow_amd_plugin_set_filter_morsel_rows): same results as the default path
+    for n in (1, 63, 64, 65, 1000, 32768, SC(1_000_003)):
+        for vnull, mnull, true_p in ((0.0, 0.0, 0.1), (0.1, 0.0, 0.5), (0.1, 0.05, 0.3), (1.0, 0.5, 1.0), (0.0, 0.0, 0.0)):
+            mk = lambda a, p: pa.array(a, mask=rng.random(n) < p) if p else pa.array(a)
+            cols = [mk(rng.integers(-2**62, 2**62, n), vnull), mk(rng.integers(-100, 100, n).astype(np.int32), vnull),
+                    mk(rng.integers(0, 200, n).astype(np.uint8), vnull), mk(rng.standard_normal(n), vnull)]
+            mask = mk(rng.random(n) < true_p, mnull)
+            d_mask = to_device(mask)
+            for col in cols:
+                d_col = to_device(col)
+                for sel in ("drop", "emit_null"):
+                    want = pc.filter(col, mask, null_selection_behavior=sel)
+                    lib.arrow_amd_plugin_set_filter_morsel_rows(0)
+                    base = to_host(pc.filter(d_col, d_mask, null_selection_behavior=sel))
+                    lib.arrow_amd_plugin_set_filter_morsel_rows(1 << 21)
+                    got_d = pc.filter(d_col, d_mask, null_selection_behavior=sel)
+                    assert not got_d.is_cpu
+                    got = to_host(got_d)
+                    assert got.equals(want) and got.equals(base) and got.null_count == want.null_count, (n, vnull, mnull, true_p, col.type, sel)
+                    if n > 100:      # sliced operands
+                        got = to_host(pc.filter(d_col.slice(7, n - 20), d_mask.slice(13, n - 20), null_selection_behavior=sel))
+                        assert got.equals(pc.filter(col.slice(7, n - 20), mask.slice(13, n - 20), null_selection_behavior=sel))
+    # an Acero plan over a device table: every FilterNode batch is a morsel
+    m = SC(400_003)
+    k, v, w = (pa.array(rng.integers(-500, 500, m).astype(np.int32)), pa.array(rng.integers(-2**40, 2**40, m), mask=rng.random(m) < 0.05),
+               pa.array(rng.integers(-100, 100, m)))
+    host = pa.table({"k": k, "v": v, "w": w})
+    dev = pa.table({"k": to_device(k), "v": to_device(v), "w": to_device(w)})
+    def plan(t, agg):
+        return acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(t)),
+            acero.Declaration("filter", acero.FilterNodeOptions(pc.field("w") > 10)),
+            acero.Declaration(agg, acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"]))])
+    want = plan(host, "aggregate").to_table(use_threads=False).select(["k", "v_sum"]).sort_by("k")
+    for threads in (False, True):
+        assert plan(dev, "aggregate_rocm").to_table(use_threads=threads).sort_by("k").equals(want)
+    lib.arrow_amd_plugin_set_filter_morsel_rows(0)
+    print("MORSEL_FILTER_OK")
+''')
+
+
 AGGREGATE_SCRIPT = textwrap.dedent(r'''
     import ctypes, os, sys, faulthandler
     faulthandler.enable()

@@ -60,3 +60,7 @@ def test_parquet_delta_and_split_encodings_through_the_plugin_emulated():
 
 def test_boolean_values_filter_and_take_emulated():
     _run(G.BOOLEAN_VALUES_SCRIPT, "BOOLEAN_VALUES_OK", 0.025)
+
+
+def test_single_sync_filter_path_emulated():
+    _run(G.MORSEL_FILTER_SCRIPT, "MORSEL_FILTER_OK", 0.05)

@@ -36,6 +36,15 @@ def test_parquet_column_chunks_through_the_plugin():
     assert r.returncode == 0 and "PARQUET_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_single_sync_filter_path_on_device_resident_arrays():
+    """The opt-in single-synchronisation device filter (arrow_amd_plugin_set_filter_morsel_rows): worst-case allocation,
+    count -> compact back to back, one read-back — identical output to the default path and to the reference."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {G.ROOT!r}\n" + G.MORSEL_FILTER_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=G.ROOT)
+    assert r.returncode == 0 and "MORSEL_FILTER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_scalar_aggregates_on_device_resident_columns():
     """SumImpl / CountImpl / MinMaxImpl (aggregate_basic.inc.cc:49-110,776-860) as ScalarAggregateKernel shims: `sum`,
     `count`, `min_max`, `min`, `max` of int64 device columns with every option combination, chunked input (state
