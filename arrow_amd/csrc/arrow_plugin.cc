@@ -12,11 +12,13 @@
 // shapes this shim does not cover (run-end-encoded filters, boolean values, scalars, tiny
 // inputs, ...) to the stock exec with that state, exactly as the reference would have run them.
 //
-// This round the arrays the Arrow API hands over live in HOST memory (ArraySpan::buffers[i].data,
-// cpp/src/arrow/array/data.h:525-553), so every call stages through HBM over PCIe: correct and
-// drop-in, but bandwidth-bound by the link, not by HBM.  Device-resident ExecBatches
-// (a kROCM arrow::Device/MemoryManager/Buffer, cpp/src/arrow/device.h:43-280) are row (f1) of
-// SURVEY.md section 8 and are what bench.py measures through arrow_amd.compute.
+// Two kinds of input reach these kernels.  HOST arrays (ArraySpan::buffers[i].data, cpp/src/arrow/array/data.h:525-553)
+// are staged through HBM over PCIe where that pays (filter, take, sort; thresholds in plugin/common.inc) and handed
+// to the stock kernel otherwise.  DEVICE-RESIDENT arrays — buffers on the kROCM arrow::Device / MemoryManager of
+// plugin/device.inc (interfaces: cpp/src/arrow/device.h:43-280), entering and leaving through the C Device Data
+// interface — are computed in place and their outputs stay in HBM; that is the mode the
+// numbers in DESIGN.md are quoted for and the one whole Acero plans run in (rows f2-f4: exec-node factories,
+// sibling kernels, Parquet decode).
 #include <arrow/acero/exec_plan.h>
 #include <arrow/acero/options.h>
 #include <arrow/api.h>
