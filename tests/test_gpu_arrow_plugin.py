@@ -640,6 +640,107 @@ MORSEL_FILTER_SCRIPT = textwrap.dedent(r'''
 ''')
 
 
+SELECTION_META_SCRIPT = textwrap.dedent(r'''
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))   # sizes shrink for the emulated run
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(n) for n in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(n) for n in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    rng = np.random.default_rng(37)
+    n = SC(1_000_003)
+    mk = lambda a, p=0.05: pa.array(a, mask=rng.random(len(a)) < p)
+    cols = {"i64": mk(rng.integers(-2**62, 2**62, n)), "i32": mk(rng.integers(-100, 100, n).astype(np.int32)),
+            "f64": pa.array(rng.standard_normal(n)), "flag": mk(rng.random(n) < 0.5),
+            "s": pa.array(np.array(["", "a", "bb", "gfx950", "MI355X"], dtype=object)[rng.integers(0, 5, n)], type=pa.string(), mask=rng.random(n) < 0.1),
+            "ts": pa.array(rng.integers(0, 2**50, n), pa.timestamp("us"))}
+    mask = mk(rng.random(n) < 0.2, 0.03)
+    idx = mk(rng.integers(0, n, SC(200_000)), 0.02)
+    d_cols = {k: to_device(v) for k, v in cols.items()}
+    d_mask, d_idx = to_device(mask), to_device(idx)
+
+    def host_table(t):
+        return pa.table({name: pa.chunked_array([c if c.is_cpu else to_host(c) for c in t.column(name).chunks], t.schema.field(name).type)
+                         for name in t.schema.names})
+
+    # FilterMetaFunction / TakeMetaFunction shapes over device-resident data: record batch, table, chunked array.
+    # By NAME, as CallFunction / Acero / any C++ caller does: pyarrow's generated wrappers (pc.filter, pc.take) hold the
+    # function objects they found when pyarrow.compute was imported, so they see a re-registered meta-function only if
+    # the plugin was loaded first (and Table.filter / Table.take refuse non-CPU data on their own).
+    def dev_filter(values, selection, sel="drop"):
+        return pc.call_function("filter", [values, selection], pc.FilterOptions(null_selection_behavior=sel))
+
+    def dev_take(values, indices):
+        return pc.call_function("take", [values, indices])
+
+    h_batch, d_batch = pa.record_batch(cols), pa.record_batch(d_cols)
+    h_table, d_table = pa.table(cols), pa.table(d_cols)
+    f0, t0 = lib.arrow_amd_plugin_calls(b"array_filter", 1), lib.arrow_amd_plugin_calls(b"array_take", 1)
+    for sel in ("drop", "emit_null"):
+        want = pc.filter(h_table, mask, null_selection_behavior=sel)
+        got_b = dev_filter(d_batch, d_mask, sel)
+        assert isinstance(got_b, pa.RecordBatch) and not got_b.column(0).is_cpu
+        assert host_table(pa.Table.from_batches([got_b])).equals(want), sel
+        got_t = dev_filter(d_table, d_mask, sel)
+        assert isinstance(got_t, pa.Table) and host_table(got_t).equals(want), sel
+        got_c = dev_filter(d_table.column("i64"), d_mask, sel)
+        assert isinstance(got_c, pa.ChunkedArray) and to_host(got_c.chunk(0)).equals(want.column("i64").combine_chunks())
+    want = pc.take(h_table, idx)
+    assert host_table(pa.Table.from_batches([dev_take(d_batch, d_idx)])).equals(want)
+    assert host_table(dev_take(d_table, d_idx)).equals(want)
+    assert to_host(dev_take(d_table.column("s"), d_idx).chunk(0)).equals(want.column("s").combine_chunks())
+    ncols = len(cols)
+    assert lib.arrow_amd_plugin_calls(b"array_filter", 1) == f0 + 2 * (2 * ncols + 1)
+    assert lib.arrow_amd_plugin_calls(b"array_take", 1) >= t0 + 2 * ncols + 1
+    # bounds errors keep the reference's message
+    try:
+        dev_take(d_table, to_device(pa.array([0, n], pa.int64())))
+        raise SystemExit("expected IndexError")
+    except pa.lib.ArrowIndexError as e:
+        assert str(e) == f"Index {n} out of bounds", str(e)
+    # a device column in several chunks is refused (Concatenate runs on the CPU), not crashed on
+    two = pa.chunked_array([to_device(cols["i64"].slice(0, 1000)), to_device(cols["i64"].slice(1000, 1000))])
+    try:
+        dev_filter(two, to_device(mask.slice(0, 2000)))
+        raise SystemExit("expected NotImplemented")
+    except pa.lib.ArrowNotImplementedError as e:
+        assert "chunks" in str(e), str(e)
+    # host data: the stock meta-functions, untouched
+    assert pc.filter(h_table, mask).equals(h_table.filter(mask)) and pc.take(h_batch, idx).equals(pa.record_batch(cols).take(idx))
+    assert pc.filter(pa.chunked_array([cols["i64"].slice(0, 1000), cols["i64"].slice(1000, 1000)]), mask.slice(0, 2000)).length() > 0
+    # casts the device path does not cover are refused, not handed to a CPU kernel; same-type casts are zero-copy
+    try:
+        pc.cast(d_cols["i32"], pa.float32())
+        raise SystemExit("expected NotImplemented")
+    except pa.lib.ArrowNotImplementedError as e:
+        assert "device-resident" in str(e), str(e)
+    assert to_host(pc.cast(d_cols["i64"], pa.int64())).equals(cols["i64"])
+    print("SELECTION_META_OK")
+''')
+
+
 AGGREGATE_SCRIPT = textwrap.dedent(r'''
     import ctypes, os, sys, faulthandler
     faulthandler.enable()

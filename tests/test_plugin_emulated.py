@@ -64,3 +64,7 @@ def test_boolean_values_filter_and_take_emulated():
 
 def test_single_sync_filter_path_emulated():
     _run(G.MORSEL_FILTER_SCRIPT, "MORSEL_FILTER_OK", 0.05)
+
+
+def test_filter_and_take_of_device_batches_and_tables_emulated():
+    _run(G.SELECTION_META_SCRIPT, "SELECTION_META_OK", 0.02)

@@ -45,6 +45,16 @@ def test_single_sync_filter_path_on_device_resident_arrays():
     assert r.returncode == 0 and "MORSEL_FILTER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_filter_and_take_of_device_resident_batches_and_tables():
+    """FilterMetaFunction / TakeMetaFunction shapes (F4 / T4 of SURVEY.md 8a: record batch, table, chunked array) over
+    device-resident data: per-column array_filter / array_take in HBM, equal to the reference on the host copies;
+    multi-chunk device columns and uncovered device casts are refused instead of read from the CPU."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {G.ROOT!r}\n" + G.SELECTION_META_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=G.ROOT)
+    assert r.returncode == 0 and "SELECTION_META_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_scalar_aggregates_on_device_resident_columns():
     """SumImpl / CountImpl / MinMaxImpl (aggregate_basic.inc.cc:49-110,776-860) as ScalarAggregateKernel shims: `sum`,
     `count`, `min_max`, `min`, `max` of int64 device columns with every option combination, chunked input (state
