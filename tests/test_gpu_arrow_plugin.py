@@ -727,6 +727,23 @@ SELECTION_META_SCRIPT = textwrap.dedent(r'''
         raise SystemExit("expected NotImplemented")
     except pa.lib.ArrowNotImplementedError as e:
         assert "chunks" in str(e), str(e)
+    # sort_indices of a device table / record batch / chunked array: several keys, per-key direction and null placement;
+    # the indices stay in HBM and feed take (= an ORDER BY expressed as two function calls)
+    sk = [("i32", "ascending", "at_start"), ("ts", "descending", "at_end"), ("i64", "ascending", "at_end")]
+    for keys in (sk, sk[:1], sk[1:2]):
+        want_idx = pc.sort_indices(h_table, sort_keys=keys)
+        got_idx = pc.call_function("sort_indices", [d_table], pc.SortOptions(sort_keys=keys))
+        assert not got_idx.is_cpu and to_host(got_idx).equals(want_idx), keys
+        assert to_host(pc.call_function("sort_indices", [d_batch], pc.SortOptions(sort_keys=keys))).equals(want_idx), keys
+    assert host_table(dev_take(d_table, got_idx)).equals(pc.take(h_table, want_idx))
+    assert to_host(pc.call_function("sort_indices", [d_table.column("f64")], pc.SortOptions(sort_keys=[("", "descending")]))).equals(
+        pc.sort_indices(h_table.column("f64"), sort_keys=[("", "descending")]))
+    try:
+        pc.call_function("sort_indices", [d_table], pc.SortOptions(sort_keys=[("s", "ascending")]))
+        raise SystemExit("expected NotImplemented for a string sort key")
+    except pa.lib.ArrowNotImplementedError:
+        pass
+    assert pc.sort_indices(h_table, sort_keys=sk).equals(pc.call_function("sort_indices", [h_table], pc.SortOptions(sort_keys=sk)))   # host: stock
     # host data: the stock meta-functions, untouched
     assert pc.filter(h_table, mask).equals(h_table.filter(mask)) and pc.take(h_batch, idx).equals(pa.record_batch(cols).take(idx))
     assert pc.filter(pa.chunked_array([cols["i64"].slice(0, 1000), cols["i64"].slice(1000, 1000)]), mask.slice(0, 2000)).length() > 0
