@@ -93,3 +93,27 @@ def test_concat_arrays_property(emu_ctx, kind, specs, seed):
     else:
         chunks = [U.random_array(rng, np.dtype(kind).type, n, null_p=p, offset=o, tail=1) for n, p, o in specs]
     P.check_concat_arrays(emu_ctx, chunks, use_pyarrow=False)
+
+
+@settings(max_examples=150, **COMMON)
+@given(n=st.one_of(st.integers(1, 300), st.sampled_from([4095, 4096, 4097, 8193])),
+       shape=st.sampled_from([(128, 4), (128, 1), (256, 8), (256, 2), (512, 4)]),
+       spread=st.sampled_from([0, 1, 7, 1000, 2**31, 2**62]), byte_width=st.sampled_from([4, 8]),
+       seed=st.integers(0, 2**31 - 1))
+def test_delta_binary_packed_property(emu_ctx, n, shape, spread, byte_width, seed):
+    """DELTA_BINARY_PACKED: any legal block shape, any delta magnitude (0 = constant column, 2**62 = wrap-around),
+    counts around miniblock / block / scan-tile boundaries; the restated decoder is the oracle, the header walk must
+    agree with it on every field."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(seed)
+    deltas = rng.integers(-spread, spread, n, endpoint=True) if spread else np.zeros(n, dtype=np.int64)
+    values = np.cumsum(deltas.astype(np.uint64)).astype(np.int64) + rng.integers(-2**40, 2**40)   # (wraps modulo 2**64)
+    page = O.delta_binary_packed_encode(values, *shape)
+    want, used = O.delta_binary_packed_decode(page)
+    assert used == len(page) and np.array_equal(want, values)
+    mbs, vpm, total, first, consumed = emu_ctx.parquet.scan_delta_miniblocks(page + b"\x01\x02")
+    assert (vpm, total, first, consumed) == (shape[0] // shape[1], n, int(values[0]), len(page))
+    out = emu_ctx.parquet.decode_delta_binary_packed(page, byte_width)
+    got = out.data.cpu().numpy()[: n * byte_width].view(np.int64 if byte_width == 8 else np.int32)
+    assert np.array_equal(got, values if byte_width == 8 else values.astype(np.int32))
