@@ -454,6 +454,45 @@ def _exec_arith(op_name, checked):
     return run
 
 
+def _exec_divide(checked: bool):
+    def run(args, options):
+        """ScalarBinaryNotNull<..., Divide | DivideChecked> (base_arithmetic_internal.h:366-424): only slots where both
+        operands are valid are visited; the last failing slot names the error."""
+        left, right = args
+        arr = left if isinstance(left, Array) else right
+        dev = arr.device
+        lib, stream = _lib_and_stream(dev)
+        n = arr.length
+        if isinstance(left, Array) and isinstance(right, Array) and left.length != right.length:
+            raise ArrowInvalid("Array arguments must all be the same length")
+        is_f = arr.type == float64
+        conv = float if is_f else int
+        lp = left.values_ptr() if isinstance(left, Array) else None
+        rp = right.values_ptr() if isinstance(right, Array) else None
+        null_scalar = any(isinstance(a, Scalar) and not a.is_valid for a in (left, right))
+        ls = conv(_scalar_value(left) or 0) if lp is None else conv(0)
+        rs = conv(_scalar_value(right) or 0) if rp is None else conv(0)
+        if null_scalar:           # every slot is null: nothing is visited (keep the kernel away from a 0 divisor)
+            ls, rs = (ls, conv(1)) if rp is None else (ls, rs)
+        out = alloc(n * 8, dev)
+        validity, nc = _propagate_validity([left, right], n, dev)
+        errors = torch.zeros(2, dtype=torch.int64, device=dev)
+
+        def vptr(a):
+            return (a.validity.data_ptr(), a.offset) if isinstance(a, Array) and a.may_have_nulls() else (None, 0)
+        (lvp, lvo), (rvp, rvo) = vptr(left), vptr(right)
+        fn = lib.arx_divide_f64 if is_f else lib.arx_divide_i64
+        check(fn(lp, ls, lvp, lvo, rp, rs, rvp, rvo, n, 1 if checked else 0, out.data_ptr(), errors.data_ptr(), stream))
+        if not null_scalar:
+            last_overflow, last_zero = errors.cpu().tolist()
+            if last_zero > last_overflow:
+                raise ArrowInvalid("divide by zero")
+            if last_overflow:
+                raise ArrowInvalid("overflow")
+        return Array(arr.type, n, [validity, out], nc, 0)
+    return run
+
+
 _CMP_CODE = {"equal": 0, "not_equal": 1, "greater": 2, "greater_equal": 3, "less": 4, "less_equal": 5}
 
 
@@ -901,6 +940,12 @@ def _build_registry() -> FunctionRegistry:
         f.add_kernel(Kernel((float64, float64), _exec_arith(op, checked), float64))
         reg.add_function(f)
 
+    for name, checked in (("divide", False), ("divide_checked", True)):
+        f = Function(name, Function.SCALAR, 2)
+        f.add_kernel(Kernel((int64, int64), _exec_divide(checked), int64))
+        f.add_kernel(Kernel((float64, float64), _exec_divide(checked), float64))
+        reg.add_function(f)
+
     for name, code in (("and_kleene", 0), ("or_kleene", 1)):
         f = Function(name, Function.SCALAR, 2)
         f.add_kernel(Kernel((bool_, bool_), _exec_kleene(code), bool_))
@@ -980,6 +1025,7 @@ equal, not_equal, greater_equal, less, less_equal = (_compare_wrapper(n) for n i
                                                      ("equal", "not_equal", "greater_equal", "less", "less_equal"))
 subtract, multiply, add_checked, subtract_checked, multiply_checked = (
     _compare_wrapper(n) for n in ("subtract", "multiply", "add_checked", "subtract_checked", "multiply_checked"))
+divide, divide_checked = (_compare_wrapper(n) for n in ("divide", "divide_checked"))
 
 
 def add(left, right):

@@ -13,6 +13,8 @@
 // 256 CUs x 8 workgroups.
 #include "arx_common.h"
 
+#include <limits>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -306,6 +308,46 @@ __global__ __launch_bounds__(kBlock) void arith_kernel(const T* __restrict__ lef
   }
 }
 
+
+// ------------------------------------------------------------------ divide / divide_checked
+// Divide / DivideChecked (base_arithmetic_internal.h:366-424), visited only where both operands are valid
+// (ScalarBinaryNotNull).  int64: truncating division; a zero divisor is Status::Invalid("divide by zero") in BOTH
+// forms; INT64_MIN / -1 yields 0 in the unchecked form and Status::Invalid("overflow") in the checked one.  double:
+// IEEE division; the checked form fails on a zero divisor.  The reference overwrites its Status on every failing
+// slot, so the LAST failing slot decides the message: errors[0] / errors[1] keep 1 + the largest failing row index
+// of the overflow / zero-divisor kind.
+template <typename T, bool CHECKED, int LK, int RK>
+__global__ __launch_bounds__(kBlock) void divide_kernel(const T* __restrict__ left, T lscalar, const T* __restrict__ right,
+                                                        T rscalar, Bits lvalid, Bits rvalid, int64_t n, T* __restrict__ out,
+                                                        unsigned long long* __restrict__ errors) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  unsigned long long last_overflow = 0, last_zero = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const T l = LK == kArray ? left[i] : lscalar;
+    const T r = RK == kArray ? right[i] : rscalar;
+    T res = T(0);
+    bool zero = false, overflow = false;
+    if constexpr (std::is_integral<T>::value) {
+      if (r == 0) zero = true;
+      else if (l == std::numeric_limits<T>::min() && r == T(-1)) overflow = true;    // (result 0 in the unchecked form)
+      else res = l / r;
+    } else {
+      if (CHECKED && r == T(0)) zero = true;
+      else res = l / r;
+    }
+    if (zero || (CHECKED && overflow)) {
+      const bool both = ((load_word(lvalid, i >> 6) & load_word(rvalid, i >> 6)) >> (i & 63)) & 1ull;
+      if (both) {
+        if (zero) last_zero = static_cast<unsigned long long>(i) + 1;
+        else last_overflow = static_cast<unsigned long long>(i) + 1;
+      }
+    }
+    out[i] = res;
+  }
+  if (last_overflow != 0) atomicMax(errors, last_overflow);
+  if (last_zero != 0) atomicMax(errors + 1, last_zero);
+}
+
 // ------------------------------------------------------------------ scalar aggregates over int64
 // One pass produces what SumImpl / CountImpl / MinMaxImpl (kernels/aggregate_basic.inc.cc:49-110,
 // 776-860) keep per column: the wrap-around sum of the valid values, their count, min and max.
@@ -542,6 +584,39 @@ static int arith_shapes(const T* left, T ls, const T* right, T rs, const Bits& l
   return ARX_OK;
 }
 
+template <typename T>
+static int divide_any(const T* left, T ls, const void* lvalid, int64_t loff, const T* right, T rs, const void* rvalid,
+                      int64_t roff, int64_t n, int checked, T* out, uint64_t* errors, hipStream_t st) {
+  if (n < 0 || loff < 0 || roff < 0 || (n > 0 && (out == nullptr || errors == nullptr))) {
+    set_error("bad arguments to divide");
+    return ARX_INVALID;
+  }
+  if (n == 0) return ARX_OK;
+  if (left == nullptr && right == nullptr) {
+    set_error("divide: at least one operand must be an array");
+    return ARX_INVALID;
+  }
+  const Bits lv = make_bits(left != nullptr ? lvalid : nullptr, loff, n);
+  const Bits rv = make_bits(right != nullptr ? rvalid : nullptr, roff, n);
+  const unsigned grid = stream_grid(kBlock, n);
+  unsigned long long* err = reinterpret_cast<unsigned long long*>(errors);
+#define ARX_DIVIDE_LAUNCH(CHECKED, LK, RK)                                                                              \
+  hipLaunchKernelGGL((divide_kernel<T, CHECKED, LK, RK>), dim3(grid), dim3(kBlock), 0, st, left, ls, right, rs, lv, rv, \
+                     n, out, err)
+  if (checked) {
+    if (left != nullptr && right != nullptr) ARX_DIVIDE_LAUNCH(true, kArray, kArray);
+    else if (left != nullptr) ARX_DIVIDE_LAUNCH(true, kArray, kScalar);
+    else ARX_DIVIDE_LAUNCH(true, kScalar, kArray);
+  } else {
+    if (left != nullptr && right != nullptr) ARX_DIVIDE_LAUNCH(false, kArray, kArray);
+    else if (left != nullptr) ARX_DIVIDE_LAUNCH(false, kArray, kScalar);
+    else ARX_DIVIDE_LAUNCH(false, kScalar, kArray);
+  }
+#undef ARX_DIVIDE_LAUNCH
+  ARX_CHECK_LAUNCH("divide_kernel");
+  return ARX_OK;
+}
+
 template <typename T, bool CHECKED>
 static int arith_any(int op, const T* left, T ls, const T* right, T rs, const Bits& lv, const Bits& rv, int64_t n,
                      T* out, unsigned int* overflow, hipStream_t st) {
@@ -726,6 +801,19 @@ int arx_arith_checked_i64(int op, const int64_t* left, int64_t left_scalar, cons
   const Bits rv = make_bits(right_validity, right_offset, length);
   return arith_any<int64_t, true>(op, left, left_scalar, right, right_scalar, lv, rv, length, out, overflow_flag,
                                   as_stream(stream));
+}
+
+int arx_divide_i64(const int64_t* left, int64_t left_scalar, const void* left_validity, int64_t left_offset,
+                   const int64_t* right, int64_t right_scalar, const void* right_validity, int64_t right_offset,
+                   int64_t length, int checked, int64_t* out, uint64_t* errors, void* stream) {
+  return divide_any<int64_t>(left, left_scalar, left_validity, left_offset, right, right_scalar, right_validity,
+                             right_offset, length, checked, out, errors, as_stream(stream));
+}
+int arx_divide_f64(const double* left, double left_scalar, const void* left_validity, int64_t left_offset,
+                   const double* right, double right_scalar, const void* right_validity, int64_t right_offset,
+                   int64_t length, int checked, double* out, uint64_t* errors, void* stream) {
+  return divide_any<double>(left, left_scalar, left_validity, left_offset, right, right_scalar, right_validity,
+                            right_offset, length, checked, out, errors, as_stream(stream));
 }
 
 int arx_add_i64(const int64_t* left, const int64_t* right, int64_t length, int64_t* out,

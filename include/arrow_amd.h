@@ -274,6 +274,20 @@ int arx_arith_checked_i64(int op, const int64_t* left, int64_t left_scalar, cons
                           int64_t left_offset, const int64_t* right, int64_t right_scalar,
                           const void* right_validity, int64_t right_offset, int64_t length, int64_t* out,
                           unsigned int* overflow_flag, void* stream);
+/* divide / divide_checked (Divide, DivideChecked, base_arithmetic_internal.h:366-424), visited only where both
+ * operands are valid.  int64: truncating division; a zero divisor fails with "divide by zero" in both forms;
+ * INT64_MIN / -1 is 0 unchecked and "overflow" checked.  double: IEEE division, the checked form fails on a zero
+ * divisor.  errors: two device uint64 zeroed by the caller; after the stream has drained errors[0] / errors[1] hold
+ * 1 + the LAST failing row of the overflow / zero-divisor kind (the reference overwrites its Status on every
+ * failing slot, so the larger of the two names the message).  A NULL operand pointer broadcasts its scalar. */
+int arx_divide_i64(const int64_t* left, int64_t left_scalar, const void* left_validity, int64_t left_offset,
+                   const int64_t* right, int64_t right_scalar, const void* right_validity,
+                   int64_t right_offset, int64_t length, int checked, int64_t* out, uint64_t* errors,
+                   void* stream);
+int arx_divide_f64(const double* left, double left_scalar, const void* left_validity, int64_t left_offset,
+                   const double* right, double right_scalar, const void* right_validity,
+                   int64_t right_offset, int64_t length, int checked, double* out, uint64_t* errors,
+                   void* stream);
 /* array + valid scalar (ScalarBinary::ArrayScalar, codegen_internal.h; add commutes, so
  * scalar + array is the same call) */
 int arx_add_i64_array_scalar(const int64_t* left, int64_t right, int64_t length, int64_t* out,

@@ -271,6 +271,43 @@ def arith(op: str, left, right, both_valid=None):
     return wrapped, bool(ovf.any())
 
 
+def divide(left, right, both_valid=None, checked=False):
+    """divide / divide_checked on int64 or float64 operands (arrays or python scalars): Divide / DivideChecked,
+    base_arithmetic_internal.h:366-424, visited only where both operands are valid (ScalarBinaryNotNull).
+    int64: C++ truncating division; zero divisor -> "divide by zero" in both forms; INT64_MIN / -1 -> 0 unchecked,
+    "overflow" checked.  float64: IEEE division; the checked form fails on a zero divisor.  The Status is overwritten by
+    every failing slot, so the last one names the error.  Returns (result, error message or None); the result at slots
+    that are not visited or failed is unspecified (0 here)."""
+    la, ra = np.asarray(left), np.asarray(right)
+    is_f = la.dtype.kind == "f" or ra.dtype.kind == "f"
+    n = max(la.size if la.ndim else 1, ra.size if ra.ndim else 1)
+    lo, ro = np.broadcast_to(la, (n,)), np.broadcast_to(ra, (n,))
+    visit = np.ones(n, bool) if both_valid is None else np.asarray(both_valid, bool)
+    out = np.zeros(n, dtype=np.float64 if is_f else np.int64)
+    error = None
+    for i in range(n):
+        if is_f:
+            a, b = float(lo[i]), float(ro[i])
+            if checked and b == 0.0:
+                if visit[i]:
+                    error = "divide by zero"
+                continue
+            with np.errstate(all="ignore"):
+                out[i] = np.float64(a) / np.float64(b)
+        else:
+            a, b = int(lo[i]), int(ro[i])
+            if b == 0:
+                if visit[i]:
+                    error = "divide by zero"
+            elif a == -2**63 and b == -1:
+                if checked and visit[i]:
+                    error = "overflow"
+            else:
+                q = abs(a) // abs(b)
+                out[i] = q if (a < 0) == (b < 0) else -q
+    return out, error
+
+
 _CMP = {"equal": np.equal, "not_equal": np.not_equal, "greater": np.greater,
         "greater_equal": np.greater_equal, "less": np.less, "less_equal": np.less_equal}
 

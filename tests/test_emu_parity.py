@@ -670,3 +670,9 @@ def test_order_by_several_keys(emu_ctx, null_placement):
     else:
         P.check_order_by(emu_ctx, cols, [(2, "descending"), (0, "descending"), (1, "ascending")], null_placement)
     P.check_order_by(emu_ctx, cols, [(0, "descending"), (2, "ascending")], [null_placement, other])     # per-key placement
+
+
+def test_divide_and_divide_checked(emu_ctx):
+    """Divide / DivideChecked (base_arithmetic_internal.h:366-424): truncating int64 division, zero divisors, INT64_MIN / -1,
+    IEEE doubles, the last failing valid slot names the error, nulls hide failures."""
+    P.check_divide(emu_ctx, rng_for("divide"), n=3000)

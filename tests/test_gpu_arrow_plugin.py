@@ -758,6 +758,87 @@ SELECTION_META_SCRIPT = textwrap.dedent(r'''
 ''')
 
 
+DIVIDE_SCRIPT = textwrap.dedent(r'''
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))   # sizes shrink for the emulated run
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(n) for n in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(n) for n in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    from pyarrow import acero
+    rng = np.random.default_rng(41)
+    n = SC(2_000_003)
+    MIN = -2**63
+    mk = lambda a, p=0.08: pa.array(a, mask=rng.random(len(a)) < p)
+    li = mk(rng.integers(-2**62, 2**62, n)); ri_raw = rng.integers(-60, 60, n); ri_raw[ri_raw == 0] = 3
+    ri = mk(ri_raw)
+    lf = mk(np.round(rng.standard_normal(n) * 8) / 4); rf = mk(np.where(rng.random(n) < 0.2, 0.0, np.round(rng.standard_normal(n) * 4) / 2))
+    d_li, d_ri, d_lf, d_rf = to_device(li), to_device(ri), to_device(lf), to_device(rf)
+    g0 = lib.arrow_amd_plugin_calls(b"add", 1)
+    for fn in (pc.divide, pc.divide_checked):
+        for dev_out, host_out in ((fn(d_li, d_ri), fn(li, ri)), (fn(d_li, 7), fn(li, 7)), (fn(-1000003, d_ri), fn(-1000003, ri)),
+                                  (fn(d_li.slice(5, n - 9), d_ri.slice(9, n - 9)), fn(li.slice(5, n - 9), ri.slice(9, n - 9)))):
+            assert not dev_out.is_cpu
+            ho = to_host(dev_out)
+            assert ho.equals(host_out) and ho.null_count == host_out.null_count, fn
+    # doubles: IEEE division (inf / nan where the divisor is 0) unchecked; compare bit patterns
+    got, want = to_host(pc.divide(d_lf, d_rf)), pc.divide(lf, rf)
+    assert np.array_equal(np.asarray(got.is_null()), np.asarray(want.is_null()))
+    assert np.array_equal(pc.fill_null(got, 0.0).to_numpy().view(np.uint64), pc.fill_null(want, 0.0).to_numpy().view(np.uint64))
+    assert lib.arrow_amd_plugin_calls(b"add", 1) == g0 + 9
+    # errors: the LAST failing valid slot names the Status; failing values under nulls do not fail
+    def message(call):
+        try:
+            call()
+            return None
+        except pa.lib.ArrowInvalid as e:
+            return str(e)
+    zi = pa.array([5, MIN, 7, 1, 9], pa.int64()); zd = pa.array([1, -1, 0, 2, 3], pa.int64())
+    cases = [(zi, zd), (pa.array([5, 0, MIN]), pa.array([0, 1, -1])), (pa.array([MIN, 4]), pa.array([-1, 2])),
+             (pa.array([5, None, MIN]), pa.array([None, 0, 1])), (pa.array([1, 2]), pa.array([0, None]))]
+    for l, r in cases:
+        for fn in (pc.divide, pc.divide_checked):
+            want = message(lambda: fn(l, r))
+            got = message(lambda: fn(to_device(l), to_device(r)))
+            assert got == want, (l, r, fn, got, want)
+            if want is None:
+                assert to_host(fn(to_device(l), to_device(r))).equals(fn(l, r))
+    assert message(lambda: pc.divide(d_li, 0)) == "divide by zero" == message(lambda: pc.divide(li, 0))
+    assert message(lambda: pc.divide_checked(d_lf, d_rf)) == "divide by zero" == message(lambda: pc.divide_checked(lf, rf))
+    # `/` on an Acero expression means divide_checked? no: pyarrow maps it to `divide`; either way it stays on the device
+    t_host = pa.table({"a": li, "b": ri}); t_dev = pa.table({"a": d_li, "b": d_ri})
+    def plan(t):
+        return acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(t)),
+            acero.Declaration("project", acero.ProjectNodeOptions([pc.field("a") / pc.field("b")], ["q"])),
+            acero.Declaration("aggregate", acero.AggregateNodeOptions([("q", "sum", None, "s"), ("q", "count", None, "c")]))])
+    assert plan(t_dev).to_table(use_threads=False).equals(plan(t_host).to_table(use_threads=False))
+    print("DIVIDE_OK")
+''')
+
+
 AGGREGATE_SCRIPT = textwrap.dedent(r'''
     import ctypes, os, sys, faulthandler
     faulthandler.enable()

@@ -68,3 +68,7 @@ def test_single_sync_filter_path_emulated():
 
 def test_filter_and_take_of_device_batches_and_tables_emulated():
     _run(G.SELECTION_META_SCRIPT, "SELECTION_META_OK", 0.02)
+
+
+def test_divide_on_device_resident_arrays_emulated():
+    _run(G.DIVIDE_SCRIPT, "DIVIDE_OK", 0.02)

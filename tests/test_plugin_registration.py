@@ -61,7 +61,12 @@ SCRIPT = textwrap.dedent(r'''
         gt += [pc.subtract(big, pa.array(np.array([-1, 1, 0], dtype=np.int64))), pc.multiply(big, big),
                pc.add_checked(pa.array([2**63 - 1, 5], mask=np.array([True, False])), pa.array([1, 1])),   # the overflowing slot is null
                pa.table({"x": a, "y": a2}).filter((pc.field("x") - pc.field("y") * 2) < 0).column("x").combine_chunks()]
-        for bad in (lambda: pc.add_checked(big, big), lambda: pc.multiply_checked(big, 2), lambda: pc.subtract_checked(-2, big)):
+        d2 = pc.add(a2, 1)      # (no zero divisors)
+        gt += [pc.divide(a, d2), pc.divide_checked(a.slice(2, 300), d2.slice(5, 300)), pc.divide(a, 7), pc.divide(1000, d2), pc.divide(fn, g),
+               pc.divide(pa.array([-2**63, 7, -7]), pa.array([-1, 2, 2]))]
+        for bad in (lambda: pc.add_checked(big, big), lambda: pc.multiply_checked(big, 2), lambda: pc.subtract_checked(-2, big),
+                    lambda: pc.divide(a, 0), lambda: pc.divide_checked(pa.array([-2**63, 1]), pa.array([-1, 1])),
+                    lambda: pc.divide_checked(pa.array([1.5]), pa.array([0.0]))):
             try:
                 bad()
             except pa.lib.ArrowInvalid as e:

@@ -55,6 +55,15 @@ def test_filter_and_take_of_device_resident_batches_and_tables():
     assert r.returncode == 0 and "SELECTION_META_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_divide_on_device_resident_arrays():
+    """divide / divide_checked (int64, double) on device arrays through CallFunction: values, validity, and the error the
+    last failing valid slot names ("divide by zero" / "overflow"), equal to the reference; `/` in an Acero projection."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {G.ROOT!r}\n" + G.DIVIDE_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=G.ROOT)
+    assert r.returncode == 0 and "DIVIDE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_scalar_aggregates_on_device_resident_columns():
     """SumImpl / CountImpl / MinMaxImpl (aggregate_basic.inc.cc:49-110,776-860) as ScalarAggregateKernel shims: `sum`,
     `count`, `min_max`, `min`, `max` of int64 device columns with every option combination, chunked input (state
@@ -100,6 +109,11 @@ def test_boolean_values_take_and_filter(gpu_ctx, idx_dtype, vnull, inull, voff):
 def test_scalar_aggregates_int64(gpu_ctx):
     """SumImpl / CountImpl / MinMaxImpl (aggregate_basic.inc.cc): wrap-around sum, options, batches."""
     P.check_scalar_aggregates(gpu_ctx, rng_for("scalaragg"), n=1000003)
+
+
+def test_divide_and_divide_checked(gpu_ctx):
+    """Divide / DivideChecked (base_arithmetic_internal.h:366-424) through the C ABI against the oracle and pyarrow."""
+    P.check_divide(gpu_ctx, rng_for("divide"), n=300_007)
 
 
 # ------------------------------------------------------------------ concatenate / order_by (OrderByNode::DoFinish)
