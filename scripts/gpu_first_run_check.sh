@@ -11,3 +11,5 @@ timeout 1200 python -m pytest tests/test_zz_gpu_first_run.py tests/test_parquet.
 echo "pytest rc=$?"; tail -15 $OUT/pytest_first_run.log
 echo "== Parquet end to end (host prep vs device decode vs pyarrow)"
 timeout 600 python scripts/exp_parquet.py > $OUT/exp_parquet.log 2>&1; echo "exp_parquet rc=$?"; tail -8 $OUT/exp_parquet.log
+echo "== throughput of the kernels that have never been timed"
+timeout 600 python scripts/exp_new_kernels.py > $OUT/exp_new_kernels.log 2>&1; echo "exp_new_kernels rc=$?"; tail -10 $OUT/exp_new_kernels.log

@@ -117,3 +117,40 @@ def test_delta_binary_packed_property(emu_ctx, n, shape, spread, byte_width, see
     out = emu_ctx.parquet.decode_delta_binary_packed(page, byte_width)
     got = out.data.cpu().numpy()[: n * byte_width].view(np.int64 if byte_width == 8 else np.int32)
     assert np.array_equal(got, values if byte_width == 8 else values.astype(np.int32))
+
+
+@settings(max_examples=120, **COMMON)
+@given(n=lengths, loff=offsets, roff=offsets, lnull=nulls, rnull=nulls, zero_p=st.sampled_from([0.0, 0.0, 0.01, 0.5]),
+       kind=st.sampled_from(["i", "f"]), checked=st.booleans(), seed=st.integers(0, 2**31 - 1))
+def test_divide_property(emu_ctx, n, loff, roff, lnull, rnull, zero_p, kind, checked, seed):
+    """divide / divide_checked: any operand offsets, null densities and zero-divisor densities; either the oracle's error
+    (named by the last failing valid slot) or its values at every visited slot."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(seed)
+    if kind == "i":
+        l = U.random_array(rng, np.int64, n, null_p=lnull, offset=loff, tail=2)
+        r = U.random_array(rng, np.int64, n, null_p=rnull, offset=roff, tail=3, lo=-5, hi=5)
+        if n > 3:
+            l.values[loff + 1], r.values[roff + 1] = -2**63, -1
+    else:
+        l = U.random_array(rng, np.float64, n, null_p=lnull, offset=loff, tail=2)
+        r = U.random_array(rng, np.float64, n, null_p=rnull, offset=roff, tail=3)
+        r.values[:] = np.round(r.values * 2) / 2
+    r.values[rng.random(len(r.values)) < zero_p] = 0
+    if zero_p == 0.0:
+        r.values[r.values == 0] = 1
+    both = l.logical_valid() & r.logical_valid()
+    want, error = O.divide(l.logical_values(), r.logical_values(), both, checked)
+    fn = emu_ctx.compute.divide_checked if checked else emu_ctx.compute.divide
+    if error is not None:
+        with pytest.raises(emu_ctx.ArrowInvalid) as e:
+            fn(l.to_device(emu_ctx), r.to_device(emu_ctx))
+        assert str(e.value) == error
+        return
+    out = fn(l.to_device(emu_ctx), r.to_device(emu_ctx))
+    got = out.to_numpy()[0]
+    ok = both & ~(np.isnan(want) if kind == "f" else np.zeros(n, bool))
+    assert np.array_equal(got[ok], want[ok])
+    if kind == "f":
+        assert np.array_equal(np.isnan(got[both]), np.isnan(want[both]))
