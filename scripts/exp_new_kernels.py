@@ -14,17 +14,29 @@ import arrow_amd as amd  # noqa: E402
 from arrow_amd import compute as cp  # noqa: E402
 from oracle import oracle as O  # noqa: E402  (checker only)
 
-dev = torch.device("cuda", 0)
+EMU = os.environ.get("ARROW_AMD_EXP_EMULATED") == "1"      # dry run of this script's own logic on the SIMT emulator (tiny sizes)
+if EMU:
+    from tests.emu.build_emu import build
+    amd._lib._lib = amd._lib.load(build())
+    amd.array.set_default_device("cpu")
+dev = torch.device("cpu") if EMU else torch.device("cuda", 0)
+SHIFT = 14 if EMU else 0
 rng = np.random.default_rng(0)
 
 
+def sync():
+    if not EMU:
+        torch.cuda.synchronize(dev)
+
+
 def timed(fn, reps=5):
+    reps = 1 if EMU else reps
     fn()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     for _ in range(reps):
         out = fn()
-    torch.cuda.synchronize(dev)
+    sync()
     return (time.perf_counter() - t0) / reps * 1e3, out
 
 
@@ -33,7 +45,7 @@ def report(name, rows, ms, bytes_per_row):
           f"({bytes_per_row} B/row algorithmic)", flush=True)
 
 
-n = 1 << 27
+n = 1 << (27 - SHIFT)
 vals = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device=dev)
 valid = torch.randint(0, 256, (n // 8,), dtype=torch.uint8, device=dev)
 a = amd.Array(amd.array.int64, n, [valid, vals.view(torch.uint8)], -1, 0)
@@ -49,7 +61,7 @@ report("divide(int64, int64), left validity", n, ms, 24.25)
 ms, out = timed(lambda: cp.divide_checked(a, b))
 report("divide_checked(int64, int64)", n, ms, 24.25)
 
-m = 1 << 26
+m = 1 << (26 - SHIFT)
 k0 = amd.Array(amd.array.int32, m, [None, torch.randint(0, 100, (m,), dtype=torch.int32, device=dev).view(torch.uint8)], 0, 0)
 k1 = amd.Array(amd.array.int64, m, [None, torch.randint(0, 2**40, (m,), dtype=torch.int64, device=dev).view(torch.uint8)], 0, 0)
 pay = amd.Array(amd.array.int64, m, [None, torch.arange(m, dtype=torch.int64, device=dev).view(torch.uint8)], 0, 0)
@@ -58,12 +70,12 @@ s0 = cols[0].data.view(torch.int32)[:m]
 assert bool((s0[1:] >= s0[:-1]).all())
 report("order_by 2 keys (int32 asc, int64 desc) + payload", m, ms, 20 + 20)
 
-nd = 1 << 24
+nd = 1 << (24 - SHIFT // 2)
 walk = np.cumsum(rng.integers(-50, 60, nd)).astype(np.int64)
 page = O.delta_binary_packed_encode(walk[: 1 << 16])          # (the python encoder is slow: one 64K-value page, repeated)
-ms, out = timed(lambda: [amd.parquet.decode_delta_binary_packed(page, 8, dev) for _ in range(64)][-1], reps=3)
+ms, out = timed(lambda: [amd.parquet.decode_delta_binary_packed(page, 8, dev) for _ in range(2 if EMU else 64)][-1], reps=3)
 assert np.array_equal(out.to_numpy()[0], walk[: 1 << 16])
-report("DELTA_BINARY_PACKED decode, 64 pages of 64K int64 (incl. host header walk + upload)", 64 << 16, ms, 8 + len(page) / (1 << 16))
+report("DELTA_BINARY_PACKED, 64 pages x 64K int64 (+ host walk)", (2 if EMU else 64) << 16, ms, round(8 + len(page) / (1 << 16), 2))
 
 f = rng.standard_normal(nd)
 split = np.ascontiguousarray(f.view(np.uint8).reshape(nd, 8).T).reshape(-1)
