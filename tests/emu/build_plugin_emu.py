@@ -5,7 +5,7 @@ product build is arrow_amd/plugin_build.py."""
 import os
 import subprocess
 
-from .build_emu import build as build_emu
+from .build_emu import build as build_emu, build_lock
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -13,9 +13,15 @@ OUT = os.path.join(HERE, "_build", "libarrow_amd_plugin_emu.so")
 
 
 def build_plugin(force: bool = False, verbose: bool = True) -> str:
+    core = build_emu()
+    with build_lock():
+        return _build_plugin(core, force, verbose)
+
+
+def _build_plugin(core: str, force: bool, verbose: bool) -> str:
     import pyarrow as pa
 
-    core = build_emu()
+
     src = os.path.join(ROOT, "arrow_amd", "csrc", "arrow_plugin.cc")
     parts = os.path.join(ROOT, "arrow_amd", "csrc", "plugin")
     d = os.path.dirname(pa.__file__)
@@ -29,12 +35,14 @@ def build_plugin(force: bool = False, verbose: bool = True) -> str:
     deps += [os.path.join(parts, f) for f in sorted(os.listdir(parts)) if f.endswith(".inc")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(x) for x in deps):
         return OUT
+    tmp = OUT + f".tmp{os.getpid()}"
     cmd = ["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-I", os.path.join(HERE, "plugin_hip"),
-           "-I", pa.get_include(), src, "-o", OUT, so["arrow"], so["arrow_compute"], so["arrow_acero"], so["parquet"],
+           "-I", pa.get_include(), src, "-o", tmp, so["arrow"], so["arrow_compute"], so["arrow_acero"], so["parquet"],
            core, f"-Wl,-rpath,{d}", f"-Wl,-rpath,{os.path.dirname(core)}"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, OUT)
     return OUT
 
 
