@@ -6,7 +6,7 @@
 // before GPU minutes are spent.  Nothing under arrow_amd/ knows about it and the product
 // never loads the emulated library: only tests/ builds and dlopens it.
 //
-// Model: one workgroup at a time; every HIP thread is a ucontext fiber; wave collectives
+// Model: one workgroup at a time; every HIP thread is a fiber on its own stack; wave collectives
 // (__shfl*, __ballot, __any, wave_barrier) and __syncthreads are rendezvous points at which
 // fibers yield to a round-robin scheduler.  Lanes do NOT run in lockstep, so any cross-lane
 // LDS dependency that the real hardware gets "for free" must be marked in the source with
@@ -16,7 +16,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <ucontext.h>
 
 #include <algorithm>
 #include <functional>
@@ -65,8 +64,11 @@ struct Wave {
   unsigned gen = 0;
 };
 
+// A fiber's context is its saved stack pointer: the switch (hip_emu_runtime.cpp) pushes the callee-saved
+// registers and swaps stacks — no signal-mask system call per switch, which is what made
+// swapcontext() the dominant cost of the CPU tier.
 struct Fiber {
-  ucontext_t ctx;
+  void* sp = nullptr;
   dim3 tidx;
   int tid = 0;
   bool done = false;
@@ -75,7 +77,7 @@ struct Fiber {
 struct State {
   dim3 grid, block, bidx;
   Fiber* cur = nullptr;
-  ucontext_t sched;
+  void* sched_sp = nullptr;
   std::vector<Fiber> fibers;
   std::vector<Wave> waves;
   int block_nactive = 0, block_arrived = 0;

@@ -3,6 +3,36 @@
 
 #include "hip_emu.h"
 
+#if !defined(__x86_64__)
+#error "the emulator's context switch is written for x86-64 (System V ABI)"
+#endif
+
+// hipemu_switch(&save_sp, load_sp): push the callee-saved registers, store this stack pointer, adopt the other
+// one, pop its registers and return into it.  (MXCSR / x87 control words are never changed by the kernels.)
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch,.-hipemu_switch
+)");
+
 namespace hipemu {
 
 static State g_state;
@@ -22,7 +52,7 @@ static void* stack_for(size_t i) {
 
 void yield() {
   State& s = st();
-  swapcontext(&s.cur->ctx, &s.sched);
+  hipemu_switch(&s.cur->sp, s.sched_sp);
 }
 
 static void release_if_complete(Wave& w) {
@@ -39,7 +69,8 @@ static void trampoline() {
   release_if_complete(w);
   --s.block_nactive;
   if (s.block_nactive > 0 && s.block_arrived >= s.block_nactive) { s.block_arrived = 0; ++s.block_gen; }
-  swapcontext(&f->ctx, &s.sched);
+  hipemu_switch(&f->sp, s.sched_sp);   // never resumed
+  abort();
 }
 
 static void run_block(const std::function<void()>& body) {
@@ -56,11 +87,13 @@ static void run_block(const std::function<void()>& body) {
     f.tidx = dim3(t % s.block.x, (t / s.block.x) % s.block.y, t / (s.block.x * s.block.y));
     f.done = false;
     s.waves[t >> 6].nactive++;
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = stack_for(t);
-    f.ctx.uc_stack.ss_size = kStack;
-    f.ctx.uc_link = &s.sched;
-    makecontext(&f.ctx, trampoline, 0);
+    // first switch into the fiber: six zeroed register slots, then `ret` into trampoline with the stack
+    // pointer where a call would have left it (8 below a 16-byte boundary)
+    void** top = reinterpret_cast<void**>(static_cast<char*>(stack_for(t)) + kStack);
+    top[-1] = nullptr;                                   // trampoline's (unused) return address
+    top[-2] = reinterpret_cast<void*>(&trampoline);
+    for (int k = 3; k <= 8; ++k) top[-k] = nullptr;
+    f.sp = top - 8;
   }
   int remaining = nthreads;
   long spins = 0;
@@ -70,7 +103,7 @@ static void run_block(const std::function<void()>& body) {
       Fiber& f = s.fibers[t];
       if (f.done) continue;
       s.cur = &f;
-      swapcontext(&s.sched, &f.ctx);
+      hipemu_switch(&s.sched_sp, f.sp);
       if (!f.done) ++remaining;
     }
     if (++spins > 50000000L) { fprintf(stderr, "hipemu: deadlock in workgroup (%u,%u)\n", s.bidx.x, s.bidx.y); abort(); }
