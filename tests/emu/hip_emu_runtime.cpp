@@ -55,6 +55,12 @@ void yield() {
   hipemu_switch(&s.cur->sp, s.sched_sp);
 }
 
+// HIPEMU_SCHEDULE=reverse: workgroups run from the last to the first and the fibers of a workgroup are resumed
+// in descending thread order.  The hardware promises no order between workgroups (nor between the waves of one),
+// so every result must be identical under both schedules; a kernel that silently relies on "block 0 ran first"
+// or on ascending lane order between barriers shows up as a difference.
+static bool g_reverse = false;
+
 static void release_if_complete(Wave& w) {
   if (w.nactive > 0 && w.arrived >= w.nactive) { w.arrived = 0; ++w.gen; }
 }
@@ -99,8 +105,8 @@ static void run_block(const std::function<void()>& body) {
   long spins = 0;
   while (remaining > 0) {
     remaining = 0;
-    for (int t = 0; t < nthreads; ++t) {
-      Fiber& f = s.fibers[t];
+    for (int k = 0; k < nthreads; ++k) {
+      Fiber& f = s.fibers[g_reverse ? nthreads - 1 - k : k];
       if (f.done) continue;
       s.cur = &f;
       hipemu_switch(&s.sched_sp, f.sp);
@@ -115,12 +121,24 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   State& s = st();
   s.grid = grid;
   s.block = block;
+  const char* sched = getenv("HIPEMU_SCHEDULE");
+  g_reverse = sched != nullptr && strcmp(sched, "reverse") == 0;
   for (unsigned z = 0; z < grid.z; ++z)
     for (unsigned y = 0; y < grid.y; ++y)
       for (unsigned x = 0; x < grid.x; ++x) {
-        s.bidx = dim3(x, y, z);
+        s.bidx = g_reverse ? dim3(grid.x - 1 - x, grid.y - 1 - y, grid.z - 1 - z) : dim3(x, y, z);
         run_block(body);
       }
 }
 
 }  // namespace hipemu
+
+// Self-test hook for tests/test_emu_schedule.py: the order in which the (block, thread) pairs of a launch first run.
+extern "C" int hipemu_selftest_order(int* order, int nblocks, int nthreads) {
+  int n = 0;
+  hipemu::launch(dim3(nblocks), dim3(nthreads), [&]() {
+    order[n++] = static_cast<int>(blockIdx.x) * nthreads + static_cast<int>(threadIdx.x);
+    __syncthreads();
+  });
+  return n;
+}
