@@ -517,6 +517,7 @@ struct GbpArgs {
   uint32_t* part_count;    // [2^bits]
   uint32_t* part_start;    // [2^bits + 1]
   uint32_t* cursor2;       // [2^bits]
+  uint32_t* cursor1;       // [2^b1] level-1 running cursors (global-cursor form)
   uint32_t* hist1;         // [2^b1 * nchunks], digit-major
   uint32_t* l1_start;      // [2^b1 + 1]
   uint32_t* l2_tile_start; // [2^b1 + 1]
@@ -664,7 +665,11 @@ __global__ __launch_bounds__(1024) void gbp_scan_a_kernel(GbpArgs a) {
     if (i < nparts) a.cursor2[i] = s0;
   }
   const int nb1 = 1 << a.b1;
-  for (int d = tid; d <= nb1; d += 1024) a.l1_start[d] = ps[d == nb1 ? nparts : (d << a.b2)];
+  for (int d = tid; d <= nb1; d += 1024) {
+    const uint32_t s1 = ps[d == nb1 ? nparts : (d << a.b2)];
+    a.l1_start[d] = s1;
+    if (d < nb1) a.cursor1[d] = s1;
+  }
   // tile map of level 2 (nb1 <= 256 entries): exclusive scan of ceil(size / tile)
   __syncthreads();
   uint32_t tiles = 0;
@@ -737,7 +742,7 @@ struct __attribute__((aligned(16))) GbpScatterLds {
 // LEVEL 1: input = the caller's arrays (validity applies), digit = top b1 bits, offsets from the
 //          chunk cursors.   LEVEL 2: input = level-1 output, digit = next b2 bits, offsets from
 //          cursor2 atomics.
-template <int LEVEL, bool HAS_NULLS>
+template <int LEVEL, bool HAS_NULLS, bool GCUR = (LEVEL == 2)>
 __device__ __forceinline__ void gbp_scatter_tile(const GbpArgs& a, GbpScatterLds& lds,
                                                  const int32_t* __restrict__ kin,
                                                  const int64_t* __restrict__ vin, int64_t row0,
@@ -757,21 +762,21 @@ __device__ __forceinline__ void gbp_scatter_tile(const GbpArgs& a, GbpScatterLds
   int64_t val[kGbRowsPerThread];
   int dig[kGbRowsPerThread];
   uint32_t rank[kGbRowsPerThread];
+  // Loads are unconditional (rows past the tile's end re-read its last row, null rows are read and
+  // dropped): a guarded load makes the compiler wait for each one before issuing the next.
 #pragma unroll
   for (int i = 0; i < kGbRowsPerThread; ++i) {
     const int p = i * kGbThreads + tid;
-    dig[i] = -1;
-    key[i] = 0;
-    val[i] = 0;
-    if (p < nrows) {
-      bool ok = true;
-      if constexpr (LEVEL == 1 && HAS_NULLS) ok = gbp_streamed<true>(a, row0 + p);
-      if (ok) {
-        key[i] = kin[row0 + p];
-        val[i] = vin[row0 + p];
-        dig[i] = static_cast<int>((gbp_hash(key[i]) >> dshift) & dmask);
-      }
-    }
+    const int64_t r = row0 + (p < nrows ? p : nrows - 1);
+    key[i] = kin[r];
+    val[i] = vin[r];
+  }
+#pragma unroll
+  for (int i = 0; i < kGbRowsPerThread; ++i) {
+    const int p = i * kGbThreads + tid;
+    bool ok = p < nrows;
+    if constexpr (LEVEL == 1 && HAS_NULLS) ok = ok && gbp_streamed<true>(a, row0 + (p < nrows ? p : nrows - 1));
+    dig[i] = ok ? static_cast<int>((gbp_hash(key[i]) >> dshift) & dmask) : -1;
   }
 #pragma unroll
   for (int i = 0; i < kGbRowsPerThread; ++i) {
@@ -790,10 +795,12 @@ __device__ __forceinline__ void gbp_scatter_tile(const GbpArgs& a, GbpScatterLds
     uint32_t pre = incl - c;
     for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
     lds.start[tid] = pre;
-    if constexpr (LEVEL == 1) {
+    if constexpr (!GCUR) {
       const uint32_t g = lds.cursor[tid];
       lds.gbase[tid] = g;
       lds.cursor[tid] = g + c;
+    } else if constexpr (LEVEL == 1) {
+      lds.gbase[tid] = c != 0 ? atomicAdd(&a.cursor1[tid], c) : 0u;
     } else {
       lds.gbase[tid] = c != 0 ? atomicAdd(&a.cursor2[(part_hi << a.b2) + tid], c) : 0u;
     }
@@ -834,6 +841,16 @@ __global__ __launch_bounds__(kGbThreads, 6) void gbp_scatter1_kernel(GbpArgs a) 
     const int nrows = static_cast<int>(end - row0 < kGbTile ? end - row0 : kGbTile);
     gbp_scatter_tile<1, HAS_NULLS>(a, lds, a.keys, a.values, row0, nrows, 0, a.keys_a, a.vals_a);
   }
+}
+
+// Level 1 with global cursors (A/B knob groupby_l1_global): one tile per workgroup, one returning atomic per
+// (tile, digit) — consecutive tiles extend the same few output runs instead of every chunk owning its own.
+template <bool HAS_NULLS>
+__global__ __launch_bounds__(kGbThreads, 6) void gbp_scatter1g_kernel(GbpArgs a) {
+  __shared__ GbpScatterLds lds;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kGbTile;
+  const int nrows = static_cast<int>(a.n - row0 < kGbTile ? a.n - row0 : kGbTile);
+  gbp_scatter_tile<1, HAS_NULLS, true>(a, lds, a.keys, a.values, row0, nrows, 0, a.keys_a, a.vals_a);
 }
 
 __global__ __launch_bounds__(kGbThreads, 6) void gbp_scatter2_kernel(GbpArgs a) {
@@ -1031,7 +1048,7 @@ struct GbpPlan {
   int bits, b1, b2;
   int64_t slice_rows, chunk_rows, nchunks;
   size_t off_keys_a, off_vals_a, off_keys_b, off_vals_b, off_part_count, off_part_start,
-      off_cursor2, off_hist1, off_l1_start, off_l2_tile_start, off_agg_unit_start, total;
+      off_cursor2, off_cursor1, off_hist1, off_l1_start, off_l2_tile_start, off_agg_unit_start, total;
 };
 
 static int g_gbp_min_rows = 1 << 17;  // below this the direct HBM-atomics kernel is used
@@ -1039,6 +1056,7 @@ static int g_gbp_bits = -1;           // -1 = from the capacity hint
 static int g_gbp_agg_pipe = 1;
 static int g_gbp_b1 = -1;             // level-1 bits override (-1: half of the partition bits)
 static int g_gbp_chunks = 2048;       // level-1 chunks = workgroups of the hist / scatter1 kernels
+static int g_gbp_l1_global = 0;       // level 1 with global cursors (one tile per workgroup) instead of chunked exact offsets
 
 static int gbp_bits_for(int64_t capacity) {
   if (g_gbp_bits >= 0) return std::min(g_gbp_bits, kGbMaxBits);
@@ -1078,6 +1096,7 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity) {
   p.off_part_count = o; o = align(o + nparts * 4);
   p.off_part_start = o; o = align(o + (nparts + 1) * 4);
   p.off_cursor2 = o; o = align(o + nparts * 4);
+  p.off_cursor1 = o; o = align(o + nb1 * 4);
   p.off_hist1 = o; o = align(o + nb1 * static_cast<size_t>(kGbMaxChunks) * 4);
   p.off_l1_start = o; o = align(o + (nb1 + 1) * 4);
   p.off_l2_tile_start = o; o = align(o + (nb1 + 1) * 4);
@@ -1087,10 +1106,11 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity) {
 }
 
 constexpr int64_t kGbMaxSlice = int64_t(1) << 30;  // row positions inside a slice are 32-bit
+static int64_t g_gbp_max_slice = kGbMaxSlice;     // A/B knob groupby_max_slice_rows
 
 // Largest slice (multiple of the tile) whose plan fits `ws_bytes`; 0 if not even one chunk fits.
 static int64_t gbp_slice_for(size_t ws_bytes, int64_t n, int64_t capacity) {
-  int64_t hi = std::min<int64_t>(n, kGbMaxSlice);
+  int64_t hi = std::min<int64_t>(n, g_gbp_max_slice);
   if (gbp_plan(hi, capacity).total <= ws_bytes) return hi;
   const size_t fixed = gbp_plan(kGbTile, capacity).total;
   if (fixed > ws_bytes) return 0;
@@ -1125,7 +1145,12 @@ static int gbp_run_slice(const GroupbyView& v, GbpArgs a, const GbpPlan& plan, h
   ARX_CHECK_LAUNCH("gbp_scan_a_kernel");
   hipLaunchKernelGGL(gbp_scan_b_kernel, dim3(1u << a.b1), dim3(1024), 0, st, a);
   ARX_CHECK_LAUNCH("gbp_scan_b_kernel");
-  hipLaunchKernelGGL((gbp_scatter1_kernel<HAS_NULLS>), dim3(nch), dim3(kGbThreads), 0, st, a);
+  if (g_gbp_l1_global) {
+    hipLaunchKernelGGL((gbp_scatter1g_kernel<HAS_NULLS>), dim3(static_cast<unsigned>(ceil_div(a.n, kGbTile))),
+                       dim3(kGbThreads), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((gbp_scatter1_kernel<HAS_NULLS>), dim3(nch), dim3(kGbThreads), 0, st, a);
+  }
   ARX_CHECK_LAUNCH("gbp_scatter1_kernel");
   const int32_t* fk = a.keys_a;
   const int64_t* fv = a.vals_a;
@@ -1155,6 +1180,14 @@ int set_groupby_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "groupby_chunks") == 0) {
     g_gbp_chunks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, kGbMaxChunks)));
+    return 1;
+  }
+  if (strcmp(name, "groupby_max_slice_rows") == 0) {
+    g_gbp_max_slice = std::max<int64_t>(kGbTile, std::min<int64_t>(value, kGbMaxSlice)) / kGbTile * kGbTile;
+    return 1;
+  }
+  if (strcmp(name, "groupby_l1_global") == 0) {
+    g_gbp_l1_global = value != 0;
     return 1;
   }
   if (strcmp(name, "groupby_b1") == 0) {
@@ -1268,6 +1301,7 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
       a.part_count = reinterpret_cast<uint32_t*>(w + plan.off_part_count);
       a.part_start = reinterpret_cast<uint32_t*>(w + plan.off_part_start);
       a.cursor2 = reinterpret_cast<uint32_t*>(w + plan.off_cursor2);
+      a.cursor1 = reinterpret_cast<uint32_t*>(w + plan.off_cursor1);
       a.hist1 = reinterpret_cast<uint32_t*>(w + plan.off_hist1);
       a.l1_start = reinterpret_cast<uint32_t*>(w + plan.off_l1_start);
       a.l2_tile_start = reinterpret_cast<uint32_t*>(w + plan.off_l2_tile_start);

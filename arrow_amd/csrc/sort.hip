@@ -610,26 +610,29 @@ __device__ __forceinline__ void msd_scatter_tile(const MsdArgs& a, MsdScatterLds
   uint32_t idx[kMsdRows];
   int dig[kMsdRows];
   uint32_t rank[kMsdRows];
+  // Loads are unconditional (rows past the tile's end re-read its last row): a guarded load makes
+  // the compiler wait for each one before the next is issued, i.e. one HBM round trip per row.
 #pragma unroll
   for (int i = 0; i < kMsdRows; ++i) {
     const int p = i * kMsdThreads + tid;
-    dig[i] = -1;
-    key[i] = 0;
-    idx[i] = 0;
-    if (p < nrows) {
-      if constexpr (RAW) {
-        key[i] = load_key_typed(kin, row0 + p, a.raw);
-        idx[i] = static_cast<uint32_t>(row0 + p);
-      } else {
-        key[i] = kin[row0 + p];
-        idx[i] = iin[row0 + p];
-      }
-      if constexpr (SPL) {
-        dig[i] = static_cast<int>(msd_search(lds.spl, nb - 1, key[i]));
-      } else {
-        dig[i] = static_cast<int>(static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask);
-      }
+    const int64_t r = row0 + (p < nrows ? p : nrows - 1);
+    if constexpr (RAW) {
+      key[i] = load_key_typed(kin, r, a.raw);
+      idx[i] = static_cast<uint32_t>(r);
+    } else {
+      key[i] = kin[r];
+      idx[i] = iin[r];
     }
+  }
+#pragma unroll
+  for (int i = 0; i < kMsdRows; ++i) {
+    const int p = i * kMsdThreads + tid;
+    if constexpr (SPL) {
+      dig[i] = static_cast<int>(msd_search(lds.spl, nb - 1, key[i]));
+    } else {
+      dig[i] = static_cast<int>(static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask);
+    }
+    if (p >= nrows) dig[i] = -1;
   }
 #pragma unroll
   for (int i = 0; i < kMsdRows; ++i) {
@@ -1027,17 +1030,18 @@ __global__ __launch_bounds__(T) void msd_bucket_kernel(MsdArgs a, const uint64_t
   uint64_t key[kBktRows];
   uint32_t id[kBktRows];
   int dig[kBktRows];
+  // unconditional loads (clamped to the bucket's last row): all kBktRows round trips overlap
 #pragma unroll
   for (int i = 0; i < kBktRows; ++i) {
     const int p = i * T + tid;
-    dig[i] = -1;
-    key[i] = 0;
-    id[i] = 0;
-    if (p < m) {
-      key[i] = keys[lo + p];
-      id[i] = idx[lo + p];
-      dig[i] = static_cast<int>(digit_of(key[i]));
-    }
+    const int64_t r = lo + (p < m ? p : m - 1);
+    key[i] = keys[r];
+    id[i] = idx[r];
+  }
+#pragma unroll
+  for (int i = 0; i < kBktRows; ++i) {
+    const int p = i * T + tid;
+    dig[i] = p < m ? static_cast<int>(digit_of(key[i])) : -1;
   }
 #pragma unroll
   for (int i = 0; i < kBktRows; ++i) {
