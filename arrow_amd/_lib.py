@@ -21,7 +21,7 @@ ARX_INDEX_ERROR = -7
 ARX_NOT_IMPLEMENTED = -10
 ARX_DEVICE_ERROR = -100
 
-ABI_VERSION = 2  # ARX_ABI_VERSION of include/arrow_amd.h
+ABI_VERSION = 3  # ARX_ABI_VERSION of include/arrow_amd.h
 
 FILTER_DROP, FILTER_EMIT_NULL = 0, 1
 SORT_ASCENDING, SORT_DESCENDING = 0, 1
@@ -156,6 +156,10 @@ SIGNATURES = {
     "arx_sort_partition_by_bins": (_int, [_span, _int, _int, _int, _p, _int, _p, _sz, _p, _p, _p,
                                           C.POINTER(_i64), _p]),
     "arx_bitmap_to_indices": (_int, [_p, _i64, _i64, _int, _p, _sz, _p, C.POINTER(_i64), _p]),
+    "arx_sort_partition_records": (_int, [_span, _int, _int, _int, _int, _p, _int, _p, _sz, _p, _p, C.POINTER(_i64), _p]),
+    "arx_sort_unpack_records": (_int, [_p, _i64, _p, _int, _int, _p, _p, _p, _p]),
+    "arx_groupby_export_partitioned": (_int, [_p, _int, _p, _sz, _p, _p, _p]),
+    "arx_groupby_sum_i64_merge_records": (_int, [_p, _i64, _p, _i64, _p]),
     "arx_groupby_state_bytes": (_sz, [_i64]),
     "arx_groupby_init": (_int, [_p, _i64, _p]),
     "arx_groupby_consume_workspace_bytes": (_sz, [_i64, _i64]),

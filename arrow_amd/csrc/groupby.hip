@@ -297,6 +297,93 @@ __global__ __launch_bounds__(kBlock) void partition_scatter_kernel(
   }
 }
 
+// ---- export straight into the multi-GPU exchange layout: one 24-byte record per group, grouped by
+// destination rank.  Two sweeps over the table slots (count per destination, then
+// reserve-and-write per workgroup), so the dense column export and its re-read are never materialised.
+__device__ __forceinline__ bool gb_slot_group(const GroupbyView& v, int64_t sl, int32_t* key, bool* key_valid) {
+  if (sl < v.capacity) {
+    const unsigned long long t = v.keys[sl];
+    *key = static_cast<int32_t>(static_cast<uint32_t>(t));
+    *key_valid = true;
+    return t != 0;
+  }
+  *key = 0;
+  *key_valid = false;
+  return sl == v.capacity && v.hdr->null_used != 0;
+}
+
+__global__ __launch_bounds__(kBlock) void export_part_count_kernel(GroupbyView v, int num_parts,
+                                                                   unsigned long long* part_counts) {
+  __shared__ uint32_t cnt[kPartMaxParts];
+  for (int p = threadIdx.x; p < num_parts; p += kBlock) cnt[p] = 0;
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * kPartChunk;
+  for (int64_t sl = begin + threadIdx.x; sl < begin + kPartChunk && sl <= v.capacity; sl += kBlock) {
+    int32_t key;
+    bool kv;
+    if (gb_slot_group(v, sl, &key, &kv)) atomicAdd(&cnt[gb_dest(key, kv, num_parts)], 1u);
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < num_parts; p += kBlock) {
+    if (cnt[p] != 0) atomicAdd(&part_counts[p], static_cast<unsigned long long>(cnt[p]));
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void export_part_scatter_kernel(GroupbyView v, int num_parts,
+                                                                     unsigned long long* cursors,
+                                                                     ArxGroupPartial* __restrict__ out) {
+  __shared__ uint32_t cnt[kPartMaxParts];
+  __shared__ unsigned long long base[kPartMaxParts];
+  for (int p = threadIdx.x; p < num_parts; p += kBlock) cnt[p] = 0;
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * kPartChunk;
+  for (int64_t sl = begin + threadIdx.x; sl < begin + kPartChunk && sl <= v.capacity; sl += kBlock) {
+    int32_t key;
+    bool kv;
+    if (gb_slot_group(v, sl, &key, &kv)) atomicAdd(&cnt[gb_dest(key, kv, num_parts)], 1u);
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < num_parts; p += kBlock) {
+    base[p] = cnt[p] != 0 ? atomicAdd(&cursors[p], static_cast<unsigned long long>(cnt[p])) : 0ull;
+    cnt[p] = 0;
+  }
+  __syncthreads();
+  for (int64_t sl = begin + threadIdx.x; sl < begin + kPartChunk && sl <= v.capacity; sl += kBlock) {
+    int32_t key;
+    bool kv;
+    if (!gb_slot_group(v, sl, &key, &kv)) continue;
+    const int d = gb_dest(key, kv, num_parts);
+    const int64_t pos = static_cast<int64_t>(base[d]) + atomicAdd(&cnt[d], 1u);
+    ArxGroupPartial r;
+    r.sum = static_cast<int64_t>(v.sums[sl]);
+    r.count = static_cast<int64_t>(v.counts[sl]);
+    r.key = key;
+    r.key_is_valid = kv ? 1 : 0;
+    r.no_nulls = (v.flags[sl] & 1u) ? 0 : 1;
+    r.pad[0] = r.pad[1] = 0;
+    out[pos] = r;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void groupby_merge_records_kernel(GroupbyView v,
+                                                                       const ArxGroupPartial* __restrict__ rec,
+                                                                       int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint32_t fresh = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const ArxGroupPartial r = rec[i];
+    const int64_t slot = r.key_is_valid ? gb_find_or_insert(v, r.key, &fresh) : gb_null_slot(v);
+    if (slot < 0) {
+      atomicExch(&v.hdr->overflow, 1u);
+      continue;
+    }
+    atomicAdd(&v.sums[slot], static_cast<unsigned long long>(r.sum));
+    atomicAdd(&v.counts[slot], static_cast<unsigned long long>(r.count));
+    if (r.no_nulls == 0) atomicOr(&v.flags[slot], 1u);
+  }
+  gb_publish_new_groups(v, fresh);
+}
+
 // ---- lookup: out[i] = the sum column of keys[i]'s group, -1 if the key is not in the table
 // (read-only probe; what dictionary_encode uses to turn rows into dictionary indices once the
 // groups' dense ids have been merged in as their "sums")
@@ -1638,6 +1725,51 @@ int arx_groupby_partition(const int32_t* keys, const uint8_t* key_is_valid, cons
                        out_key_is_valid, out_sums, out_counts, out_no_nulls);
     ARX_CHECK_LAUNCH("partition_scatter_kernel");
   }
+  return ARX_OK;
+}
+
+int arx_groupby_export_partitioned(void* state, int num_parts, void* ws, size_t ws_bytes,
+                                   ArxGroupPartial* out_records, int64_t* out_part_counts, void* stream) {
+  if (state == nullptr || num_parts < 1 || num_parts > kPartMaxParts || ws == nullptr ||
+      ws_bytes < arx_groupby_partition_workspace_bytes(num_parts) || out_part_counts == nullptr ||
+      out_records == nullptr) {
+    set_error("bad arguments to arx_groupby_export_partitioned");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  GroupbyHeader h;
+  const int rc = read_header(state, &h, st);
+  if (rc != ARX_OK) return rc;
+  if (h.overflow) {
+    set_error("group-by table overflowed (capacity %lld)", static_cast<long long>(h.capacity));
+    return ARX_INVALID;
+  }
+  const GroupbyView v = gb_view(state, h.capacity);
+  unsigned long long* part_counts = static_cast<unsigned long long*>(ws);
+  unsigned long long* cursors = part_counts + num_parts;
+  ARX_HIP(hipMemsetAsync(ws, 0, static_cast<size_t>(num_parts) * 16, st));
+  const unsigned grid = static_cast<unsigned>(ceil_div(h.capacity + 1, kPartChunk));
+  hipLaunchKernelGGL(export_part_count_kernel, dim3(grid), dim3(kBlock), 0, st, v, num_parts, part_counts);
+  ARX_CHECK_LAUNCH("export_part_count_kernel");
+  hipLaunchKernelGGL(partition_offsets_kernel, dim3(1), dim3(64), 0, st, part_counts, num_parts, cursors,
+                     out_part_counts);
+  ARX_CHECK_LAUNCH("partition_offsets_kernel");
+  hipLaunchKernelGGL(export_part_scatter_kernel, dim3(grid), dim3(kBlock), 0, st, v, num_parts, cursors, out_records);
+  ARX_CHECK_LAUNCH("export_part_scatter_kernel");
+  return ARX_OK;
+}
+
+int arx_groupby_sum_i64_merge_records(void* state, int64_t capacity, const ArxGroupPartial* records,
+                                      int64_t num_records, void* stream) {
+  if (state == nullptr || num_records < 0 || (num_records > 0 && records == nullptr)) {
+    set_error("bad arguments to arx_groupby_sum_i64_merge_records");
+    return ARX_INVALID;
+  }
+  if (num_records == 0) return ARX_OK;
+  const GroupbyView v = gb_view(state, capacity);
+  hipLaunchKernelGGL(groupby_merge_records_kernel, dim3(gb_grid(num_records)), dim3(kBlock), 0, as_stream(stream),
+                     v, records, num_records);
+  ARX_CHECK_LAUNCH("groupby_merge_records_kernel");
   return ARX_OK;
 }
 

@@ -390,6 +390,72 @@ __global__ __launch_bounds__(kBlock) void sort_dest_prep_kernel(const uint64_t* 
   }
 }
 
+// ---- exchange records of the sharded sort: {order-transformed key, local row id}, 12 bytes
+// records[i] = {transform(values[rows[i]]), rows[i]}  (rows in destination-major, row-order-preserving order)
+__global__ __launch_bounds__(kBlock) void sort_pack_records_kernel(const uint64_t* __restrict__ values,
+                                                                   const uint32_t* __restrict__ rows, int64_t n,
+                                                                   int is_signed, int descending, int keyless,
+                                                                   ArxSortRecord* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t r = rows[i];
+    const uint64_t tk = keyless ? 0 : key_transform(values[r], is_signed != 0, descending != 0);
+    ArxSortRecord rec;
+    rec.key_lo = static_cast<uint32_t>(tk);
+    rec.key_hi = static_cast<uint32_t>(tk >> 32);
+    rec.row = r;
+    out[i] = rec;
+  }
+}
+
+// Receiver side: the concatenation of the blocks every source rank sent.  Block s holds valid[s] key records
+// and nulls[s] null-row records (nulls first when nulls_first); base[s] = global row number of the source's row 0.
+// Valid records are compacted in source order (keys + global rows), null rows likewise.
+constexpr int kSortMaxBlocks = 1024;
+__global__ __launch_bounds__(kBlock) void sort_unpack_records_kernel(const ArxSortRecord* __restrict__ rec, int64_t n,
+                                                                     const int64_t* __restrict__ meta, int nblocks,
+                                                                     int nulls_first, uint64_t* __restrict__ out_keys,
+                                                                     int64_t* __restrict__ out_rows,
+                                                                     int64_t* __restrict__ out_null_rows) {
+  __shared__ int64_t s_start[kSortMaxBlocks + 1], s_vpre[kSortMaxBlocks], s_npre[kSortMaxBlocks];
+  __shared__ int64_t s_valid[kSortMaxBlocks], s_nulls[kSortMaxBlocks], s_base[kSortMaxBlocks];
+  if (threadIdx.x == 0) {
+    int64_t st = 0, vp = 0, np = 0;
+    for (int b = 0; b < nblocks; ++b) {
+      s_start[b] = st;
+      s_vpre[b] = vp;
+      s_npre[b] = np;
+      s_valid[b] = meta[3 * b];
+      s_nulls[b] = meta[3 * b + 1];
+      s_base[b] = meta[3 * b + 2];
+      st += s_valid[b] + s_nulls[b];
+      vp += s_valid[b];
+      np += s_nulls[b];
+    }
+    s_start[nblocks] = st;
+  }
+  __syncthreads();
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int lo = 0, hi = nblocks;  // last block with start <= i
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_start[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int64_t j = i - s_start[lo];
+    const ArxSortRecord r = rec[i];
+    const int64_t grow = s_base[lo] + static_cast<int64_t>(r.row);
+    const bool is_null = nulls_first ? j < s_nulls[lo] : j >= s_valid[lo];
+    if (is_null) {
+      out_null_rows[s_npre[lo] + (nulls_first ? j : j - s_valid[lo])] = grow;
+    } else {
+      const int64_t q = s_vpre[lo] + (nulls_first ? j - s_nulls[lo] : j);
+      out_keys[q] = (static_cast<uint64_t>(r.key_hi) << 32) | r.key_lo;
+      out_rows[q] = grow;
+    }
+  }
+}
+
 __global__ void widen_counts_kernel(const uint32_t* __restrict__ in, int n, int64_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i];
@@ -1756,28 +1822,31 @@ int arx_sort_key_histogram(const ArxSpan* values, int is_signed, int order, int 
   return ARX_OK;
 }
 
-int arx_sort_partition_by_bins(const ArxSpan* values, int is_signed, int order, int bits,
+// Shared by the two forms below: the non-null rows in destination-major order (STABLE inside a destination)
+// as row ids in *rows_out (workspace memory), per-destination counts (device int64) in out_counts.
+static int sort_partition_rows(const ArxSpan* values, int is_signed, int order, int bits,
                                const uint32_t* splitter_bins, int num_parts, void* ws, size_t ws_bytes,
-                               uint64_t* out_keys, uint32_t* out_rows, int64_t* out_counts,
-                               int64_t* out_num_valid, void* stream) {
+                               int64_t* out_counts, int64_t* out_num_valid, hipStream_t st,
+                               const uint32_t** rows_out, SortPlan* plan_out) {
   if (values == nullptr || num_parts < 1 || num_parts > kDigits || bits < 1 || bits > 12 ||
       out_counts == nullptr || out_num_valid == nullptr || (num_parts > 1 && splitter_bins == nullptr)) {
-    set_error("bad arguments to arx_sort_partition_by_bins");
+    set_error("bad arguments to the sort partition");
     return ARX_INVALID;
   }
   const int64_t len = values->length;
   if (len > static_cast<int64_t>(UINT32_MAX)) {
-    set_error("arx_sort_partition_by_bins: more than UINT32_MAX rows per shard is not implemented");
+    set_error("sort partition: more than UINT32_MAX rows per shard is not implemented");
     return ARX_NOT_IMPLEMENTED;
   }
-  hipStream_t st = as_stream(stream);
   ARX_HIP(hipMemsetAsync(out_counts, 0, static_cast<size_t>(num_parts) * 8, st));
   *out_num_valid = 0;
+  *rows_out = nullptr;
   if (len == 0) return ARX_OK;
   SortPlan plan = make_plan(len);
+  *plan_out = plan;
   if (ws == nullptr || ws_bytes < plan.total || (reinterpret_cast<uint64_t>(ws) & 255) != 0 ||
-      values->data == nullptr || out_keys == nullptr || out_rows == nullptr) {
-    set_error("arx_sort_partition_by_bins: NULL buffer or workspace too small / unaligned");
+      values->data == nullptr) {
+    set_error("sort partition: NULL buffer or workspace too small / unaligned");
     return ARX_INVALID;
   }
   uint8_t* w = static_cast<uint8_t*>(ws);
@@ -1826,11 +1895,98 @@ int arx_sort_partition_by_bins(const ArxSpan* values, int is_signed, int order, 
   hipLaunchKernelGGL((radix_scatter_kernel<false>), dim3(nch), dim3(kBlock), 0, st, keys_a, idx_a, n_valid, 0,
                      plan.chunk_tiles, plan.nchunks, hist, keys_b, idx_b, static_cast<uint64_t*>(nullptr), 0, 0);
   ARX_CHECK_LAUNCH("radix partition pass");
+  *rows_out = idx_b;
+  return ARX_OK;
+}
+
+int arx_sort_partition_by_bins(const ArxSpan* values, int is_signed, int order, int bits,
+                               const uint32_t* splitter_bins, int num_parts, void* ws, size_t ws_bytes,
+                               uint64_t* out_keys, uint32_t* out_rows, int64_t* out_counts,
+                               int64_t* out_num_valid, void* stream) {
+  hipStream_t st = as_stream(stream);
+  const uint32_t* rows = nullptr;
+  SortPlan plan{};
+  const int rc = sort_partition_rows(values, is_signed, order, bits, splitter_bins, num_parts, ws, ws_bytes,
+                                     out_counts, out_num_valid, st, &rows, &plan);
+  if (rc != ARX_OK || rows == nullptr) return rc;
+  if (out_keys == nullptr || out_rows == nullptr) {
+    set_error("arx_sort_partition_by_bins: NULL output buffer");
+    return ARX_INVALID;
+  }
+  const int64_t n_valid = *out_num_valid;
+  const uint64_t* vals = static_cast<const uint64_t*>(values->data) + values->offset;
+  const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_valid, kBlock), 2048));
   // transformed keys and row ids in destination-major, row-order-preserving order
-  hipLaunchKernelGGL(sort_prep_kernel, dim3(g), dim3(kBlock), 0, st, static_cast<const void*>(vals), idx_b, n_valid,
+  hipLaunchKernelGGL(sort_prep_kernel, dim3(g), dim3(kBlock), 0, st, static_cast<const void*>(vals), rows, n_valid,
                      make_xf(is_signed ? ARX_KEY_INT64 : ARX_KEY_UINT64, order == ARX_SORT_DESCENDING), 0, out_keys,
                      out_rows);
   ARX_CHECK_LAUNCH("sort_prep_kernel");
+  return ARX_OK;
+}
+
+int arx_sort_partition_records(const ArxSpan* values, int is_signed, int order, int null_placement, int bits,
+                               const uint32_t* splitter_bins, int num_parts, void* ws, size_t ws_bytes,
+                               ArxSortRecord* out_records, int64_t* out_counts, int64_t* out_num_valid,
+                               void* stream) {
+  if (null_placement != ARX_NULLS_AT_START && null_placement != ARX_NULLS_AT_END) {
+    set_error("bad null placement %d", null_placement);
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  const uint32_t* rows = nullptr;
+  SortPlan plan{};
+  const int rc = sort_partition_rows(values, is_signed, order, bits, splitter_bins, num_parts, ws, ws_bytes,
+                                     out_counts, out_num_valid, st, &rows, &plan);
+  if (rc != ARX_OK) return rc;
+  const int64_t len = values->length;
+  if (len == 0) return ARX_OK;
+  if (out_records == nullptr) {
+    set_error("arx_sort_partition_records: NULL output buffer");
+    return ARX_INVALID;
+  }
+  const int64_t n_valid = *out_num_valid;
+  const int64_t n_null = len - n_valid;
+  const uint64_t* vals = static_cast<const uint64_t*>(values->data) + values->offset;
+  ArxSortRecord* valid_dst = null_placement == ARX_NULLS_AT_START ? out_records + n_null : out_records;
+  ArxSortRecord* null_dst = null_placement == ARX_NULLS_AT_START ? out_records : out_records + n_valid;
+  if (n_valid > 0) {
+    const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_valid, kBlock), 2048));
+    hipLaunchKernelGGL(sort_pack_records_kernel, dim3(g), dim3(kBlock), 0, st, vals, rows, n_valid, is_signed,
+                       order == ARX_SORT_DESCENDING ? 1 : 0, 0, valid_dst);
+    ARX_CHECK_LAUNCH("sort_pack_records_kernel");
+  }
+  if (n_null > 0) {
+    // null rows keep row order (PartitionNullsOnly) and travel as row numbers only
+    uint8_t* w = static_cast<uint8_t*>(ws);
+    uint32_t* nrows = reinterpret_cast<uint32_t*>(w + plan.off_rows);
+    void* sel_ws = w + plan.off_sel_ws;
+    int64_t got = 0;
+    const int rc2 = selection_bit_positions(values->validity, values->offset, len, /*invert=*/true, sel_ws,
+                                            plan.total - plan.off_sel_ws, nrows, &got, st);
+    if (rc2 != ARX_OK) return rc2;
+    const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_null, kBlock), 2048));
+    hipLaunchKernelGGL(sort_pack_records_kernel, dim3(g), dim3(kBlock), 0, st, vals, nrows, n_null, 0, 0, 1, null_dst);
+    ARX_CHECK_LAUNCH("sort_pack_records_kernel");
+  }
+  return ARX_OK;
+}
+
+int arx_sort_unpack_records(const ArxSortRecord* records, int64_t num_records, const int64_t* block_meta,
+                            int num_blocks, int nulls_first, uint64_t* out_keys, int64_t* out_rows,
+                            int64_t* out_null_rows, void* stream) {
+  if (num_records < 0 || num_blocks < 1 || num_blocks > kSortMaxBlocks || block_meta == nullptr) {
+    set_error("bad arguments to arx_sort_unpack_records");
+    return ARX_INVALID;
+  }
+  if (num_records == 0) return ARX_OK;
+  if (records == nullptr || out_keys == nullptr || out_rows == nullptr || out_null_rows == nullptr) {
+    set_error("arx_sort_unpack_records: NULL buffer");
+    return ARX_INVALID;
+  }
+  const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(num_records, kBlock), 2048));
+  hipLaunchKernelGGL(sort_unpack_records_kernel, dim3(g), dim3(kBlock), 0, as_stream(stream), records, num_records,
+                     block_meta, num_blocks, nulls_first, out_keys, out_rows, out_null_rows);
+  ARX_CHECK_LAUNCH("sort_unpack_records_kernel");
   return ARX_OK;
 }
 

@@ -5,8 +5,8 @@ hash_sum group-by — the GroupByNode structure (acero/groupby_aggregate_node.cc
 thread-local partial state -> Merge -> Finalize) with ranks in place of threads:
   1. each rank aggregates its contiguous row shard into a local table (no communication);
   2. the partial aggregates (one row per local group) are radix-partitioned by
-     hash(key) % world_size on the device (arx_groupby_partition);
-  3. ONE all-to-all exchanges the partials (counts first, then the five columns);
+     hash(key) % world_size on the device, straight out of the table (arx_groupby_export_partitioned);
+  3. ONE all-to-all(v) exchanges the partials as 24-byte records (after one exchange of the block sizes);
   4. each rank merges what it received (Merge semantics, hash_aggregate_numeric.cc:85-107)
      and finalizes its disjoint key range.  The global result is the concatenation.
 Filter / take / cast / compare do not shard: replicas only.
@@ -24,75 +24,77 @@ from .array import alloc, current_stream
 from .compute import GroupBySum, ScalarAggregateOptions
 
 
-def partition_partials(partial: dict, num_parts: int, device):
-    """arx_groupby_partition: rows grouped by destination + device int64[num_parts] counts."""
-    lib = _lib.get_lib()
-    stream = current_stream(device)
-    g = int(partial["keys"].numel())
-    ws = alloc(lib.arx_groupby_partition_workspace_bytes(num_parts), device)
-    out = dict(keys=torch.empty(max(g, 1), dtype=torch.int32, device=device),
-               key_is_valid=torch.empty(max(g, 1), dtype=torch.uint8, device=device),
-               sums=torch.empty(max(g, 1), dtype=torch.int64, device=device),
-               counts=torch.empty(max(g, 1), dtype=torch.int64, device=device),
-               no_nulls=torch.empty(max(g, 1), dtype=torch.uint8, device=device))
-    part_counts = torch.zeros(num_parts, dtype=torch.int64, device=device)
-    check(lib.arx_groupby_partition(partial["keys"].data_ptr(), partial["key_is_valid"].data_ptr(),
-                                    partial["sums"].data_ptr(), partial["counts"].data_ptr(),
-                                    partial["no_nulls"].data_ptr(), g, num_parts, ws.data_ptr(),
-                                    ws.numel(), out["keys"].data_ptr(), out["key_is_valid"].data_ptr(),
-                                    out["sums"].data_ptr(), out["counts"].data_ptr(),
-                                    out["no_nulls"].data_ptr(), part_counts.data_ptr(), stream))
-    return {k: v[:g] for k, v in out.items()}, part_counts
+RECORD_BYTES = 24   # sizeof(ArxGroupPartial)
+SORT_RECORD_BYTES = 12   # sizeof(ArxSortRecord)
 
 
-def exchange_partials(parts: dict, send_counts: torch.Tensor, group=None):
-    """The single all-to-all of the group-by: returns the partials this rank now owns."""
-    world = dist.get_world_size(group)
-    recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
-    send = [int(x) for x in send_counts.cpu().tolist()]
-    recv = [int(x) for x in recv_counts.cpu().tolist()]
-    total = sum(recv)
-    out = {}
-    for name, col in parts.items():
-        buf = torch.empty(max(total, 1), dtype=col.dtype, device=col.device)[:total]
-        src = col.contiguous()
-        if world == 1:
-            buf.copy_(src)
-        else:
-            dist.all_to_all_single(buf, src, output_split_sizes=recv, input_split_sizes=send,
-                                   group=group)
-        out[name] = buf
+def _host_counts(*tensors):
+    """ONE device->host read-back for the split sizes of an all-to-all(v) (NCCL wants them on the host)."""
+    flat = torch.cat([t.reshape(-1) for t in tensors]).cpu().tolist()
+    out, pos = [], 0
+    for t in tensors:
+        n = t.numel()
+        out.append([int(x) for x in flat[pos:pos + n]])
+        pos += n
     return out
+
+
+def _all_to_all_bytes(buf: torch.Tensor, send: list, recv: list, unit: int, group=None) -> torch.Tensor:
+    """all_to_all(v) of a uint8 buffer whose blocks are `send[p] * unit` bytes."""
+    total = sum(recv) * unit
+    out = torch.empty(max(total, 1), dtype=torch.uint8, device=buf.device)[:total]
+    dist.all_to_all_single(out, buf.contiguous(), output_split_sizes=[r * unit for r in recv],
+                           input_split_sizes=[c * unit for c in send], group=group)
+    return out
+
+
+def export_partitioned(local: GroupBySum, num_parts: int):
+    """arx_groupby_export_partitioned: the state's groups as 24-byte records grouped by destination
+    (hash(key) % num_parts) + device int64[num_parts] counts.  No dense column export in between."""
+    lib = _lib.get_lib()
+    device = local.device
+    stream = current_stream(device)
+    g = local.num_groups()
+    ws = alloc(lib.arx_groupby_partition_workspace_bytes(num_parts), device)
+    records = torch.empty(max(g, 1) * RECORD_BYTES, dtype=torch.uint8, device=device)
+    part_counts = torch.zeros(num_parts, dtype=torch.int64, device=device)
+    check(lib.arx_groupby_export_partitioned(local.state.data_ptr(), num_parts, ws.data_ptr(), ws.numel(),
+                                             records.data_ptr(), part_counts.data_ptr(), stream))
+    return records[: g * RECORD_BYTES], part_counts
+
+
+def merge_records(owned: GroupBySum, records: torch.Tensor) -> None:
+    lib = _lib.get_lib()
+    n = records.numel() // RECORD_BYTES
+    if n:
+        check(lib.arx_groupby_sum_i64_merge_records(owned.state.data_ptr(), owned.capacity, records.data_ptr(), n,
+                                                    current_stream(owned.device)))
 
 
 def sharded_group_by_sum(keys, values, capacity: int, options: ScalarAggregateOptions | None = None,
                          group=None):
     """keys/values: this rank's row shard (device Arrays).  Returns this rank's slice of the
-    result: (keys, key_is_valid, sums, valid) device tensors over a disjoint set of keys."""
+    result: (keys, key_is_valid, sums, valid) device tensors over a disjoint set of keys.
+
+    Collectives on the data path: one exchange of the per-destination counts and ONE all-to-all(v) of
+    the 24-byte partial-aggregate records (the survey's "one RCCL all-to-all", 8e)."""
     device = keys.device
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     local = GroupBySum(capacity, device, options)
     local.consume(keys, values)
     if world == 1:
         return local.finalize()
-    partial = local.export()
-    parts, counts = partition_partials(partial, world, device)
-    mine = exchange_partials(parts, counts, group)
-    owned = GroupBySum(max(16, 2 * int(mine["keys"].numel()) + 2), device, options)
-    owned.merge(mine)
+    records, counts = export_partitioned(local, world)
+    recv_counts = torch.empty_like(counts)
+    dist.all_to_all_single(recv_counts, counts, group=group)
+    send, recv = _host_counts(counts, recv_counts)
+    mine = _all_to_all_bytes(records, send, recv, RECORD_BYTES, group)
+    owned = GroupBySum(max(16, 2 * sum(recv) + 2), device, options)
+    merge_records(owned, mine)
     return owned.finalize()
 
 
 # --------------------------------------------------------------------------- sort_indices
-def _all_to_all_v(col: torch.Tensor, send: list, recv: list, group=None) -> torch.Tensor:
-    total = sum(recv)
-    buf = torch.empty(max(total, 1), dtype=col.dtype, device=col.device)[:total]
-    dist.all_to_all_single(buf, col.contiguous(), output_split_sizes=recv, input_split_sizes=send,
-                           group=group)
-    return buf
-
-
 def sharded_sort_indices(values, order: str = "ascending", null_placement: str = "at_end", group=None,
                          splitter_bits: int = 12):
     """array_sort_indices over a row-sharded array, one exchange step.
@@ -104,13 +106,15 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
     ArraySortIndices' result (stable; nulls at the end or the start in row order,
     vector_array_sort.cc:524-540, vector_sort_internal.h:225-293).
 
-      1. histogram of the top bits of the order-transformed keys -> all-reduce -> P-1 splitters;
-      2. stable partition of the non-null rows by destination rank on the device;
-      3. ONE all-to-all(v) of (transformed key, local row) pairs — 12 B per row; receive buffers
-         concatenate in source-rank order, so equal keys stay in global row order and the global row
-         numbers are rebuilt from the block's source rank;
-      4. local stable radix sort (arx_sort_indices_64) + gather of the global rows;
-      5. null rows travel (row numbers only) to the last / first rank.
+      1. ONE all-reduce: histogram of the top bits of the order-transformed keys (-> P-1 splitters, and every
+         rank's slice of the result) + the shard lengths (-> global row numbers) + the null counts;
+      2. stable partition of the non-null rows by destination rank on the device, packed as 12-byte
+         {transformed key, local row} records; the shard's null rows (row numbers only) ride in the same
+         buffer, in the block of the last (at_end) / first (at_start) rank;
+      3. one exchange of the block sizes and ONE all-to-all(v) of the records; blocks arrive in source-rank
+         order, so equal keys stay in global row order;
+      4. arx_sort_unpack_records rebuilds keys + global rows, then the local stable sort (arx_sort_indices_64)
+         and one gather of the global rows.
     """
     from . import compute as cp
     from .array import Array, int64, uint64
@@ -127,104 +131,77 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
         perm = cp.call_function("array_sort_indices", [values], cp.ArraySortOptions(order, null_placement))
         return perm.data[: n * 8].view(torch.int64), 0
     order_code = _lib.SORT_DESCENDING if order == "descending" else _lib.SORT_ASCENDING
+    placement_code = _lib.NULLS_AT_START if null_placement == "at_start" else _lib.NULLS_AT_END
     is_signed = int(values.type == int64)
+    nulls_first = null_placement == "at_start"
+    target = 0 if nulls_first else world - 1
 
-    # global row number of local row 0
-    lens = torch.zeros(world, dtype=torch.int64, device=device)
-    lens[rank] = n
-    if world > 1:
-        dist.all_reduce(lens, group=group)
-    lens_h = [int(x) for x in lens.cpu().tolist()]
-    shard_offset = sum(lens_h[:rank])
-
-    # 1. splitters
+    # 1. one all-reduce: [histogram (2^bits) | shard lengths (world) | valid rows per shard (world)]
     nbins = 1 << splitter_bits
-    hist = torch.zeros(nbins, dtype=torch.int64, device=device)
+    stats = torch.zeros(nbins + 2 * world, dtype=torch.int64, device=device)
     span = values.span()
-    check(lib.arx_sort_key_histogram(C.byref(span), is_signed, order_code, splitter_bits, hist.data_ptr(),
-                                     stream))
-    if world > 1:
-        dist.all_reduce(hist, group=group)
-    cum = torch.cumsum(hist, 0).cpu()
-    total_valid = int(cum[-1]) if nbins else 0
+    check(lib.arx_sort_key_histogram(C.byref(span), is_signed, order_code, splitter_bits, stats.data_ptr(), stream))
+    stats[nbins + rank] = n
+    stats[nbins + world + rank] = stats[:nbins].sum()
+    dist.all_reduce(stats, group=group)
+    stats_h = stats.cpu()
+    cum = torch.cumsum(stats_h[:nbins], 0)
+    lens_h = [int(x) for x in stats_h[nbins:nbins + world].tolist()]
+    valid_h = [int(x) for x in stats_h[nbins + world:].tolist()]
+    total_valid = int(cum[-1])
+    total_nulls = sum(lens_h) - total_valid
     split = []
     for p in range(1, world):
-        target = (total_valid * p + world - 1) // world
-        b = int(torch.searchsorted(cum, torch.tensor(target, dtype=cum.dtype)).item()) + 1 if total_valid else nbins
+        want = (total_valid * p + world - 1) // world
+        b = int(torch.searchsorted(cum, torch.tensor(want, dtype=cum.dtype)).item()) + 1 if total_valid else nbins
         split.append(min(b, nbins))
     split_arr = (C.c_uint32 * max(1, len(split)))(*split)
+    # what every rank will own (known without another collective): the bins below its splitter
+    edges = [0] + split + [nbins]
+    owned_valid = [int(cum[edges[r + 1] - 1]) - (int(cum[edges[r] - 1]) if edges[r] > 0 else 0)
+                   if edges[r + 1] > edges[r] else 0 for r in range(world)]
+    owned = [owned_valid[r] + (total_nulls if r == target else 0) for r in range(world)]
+    start = sum(owned[:rank])
+    offsets = [sum(lens_h[:r]) for r in range(world)]
 
-    # 2. stable partition by destination
+    # 2. stable partition by destination, packed records (+ this shard's null rows)
     ws_bytes = lib.arx_sort_indices_workspace_bytes(n) + 256
     ws = alloc(ws_bytes, device)
     ws_ptr = (ws.data_ptr() + 255) & ~255
-    keys_part = torch.empty(max(n, 1), dtype=torch.int64, device=device)
-    rows_part = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+    records = torch.empty(max(n, 1) * SORT_RECORD_BYTES, dtype=torch.uint8, device=device)
     counts = torch.zeros(world, dtype=torch.int64, device=device)
     n_valid = C.c_int64(0)
-    check(lib.arx_sort_partition_by_bins(C.byref(span), is_signed, order_code, splitter_bits, split_arr, world,
-                                         ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()), keys_part.data_ptr(),
-                                         rows_part.data_ptr(), counts.data_ptr(), C.byref(n_valid), stream))
-    nv = n_valid.value
-    keys_part = keys_part[:nv]
-    rows_part = rows_part[:nv]      # LOCAL row numbers (uint32 in an int32 tensor)
+    check(lib.arx_sort_partition_records(C.byref(span), is_signed, order_code, placement_code, splitter_bits,
+                                         split_arr, world, ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()),
+                                         records.data_ptr(), counts.data_ptr(), C.byref(n_valid), stream))
+    n_null = n - n_valid.value
 
-    # 3. the exchange: 12 B per row (transformed key + local row); the receiver rebuilds global row
-    #    numbers from the source rank of every received block (blocks arrive in source-rank order)
-    offsets = [sum(lens_h[:r]) for r in range(world)]
-    if world > 1:
-        recv_counts = torch.empty_like(counts)
-        dist.all_to_all_single(recv_counts, counts, group=group)
-        send = [int(x) for x in counts.cpu().tolist()]
-        recv = [int(x) for x in recv_counts.cpu().tolist()]
-        keys_recv = _all_to_all_v(keys_part, send, recv, group)
-        rows_recv = _all_to_all_v(rows_part, send, recv, group)
-        base = torch.repeat_interleave(torch.tensor(offsets, dtype=torch.int64, device=device),
-                                       torch.tensor(recv, dtype=torch.int64, device=device))
-        gidx_recv = (rows_recv.to(torch.int64) & 0xFFFFFFFF) + base
-    else:
-        keys_recv = keys_part
-        gidx_recv = (rows_part.to(torch.int64) & 0xFFFFFFFF) + shard_offset
+    # 3. block sizes, then the ONE data exchange
+    recv_counts = torch.empty_like(counts)
+    dist.all_to_all_single(recv_counts, counts, group=group)
+    send_valid, recv_valid = _host_counts(counts, recv_counts)
+    send = [send_valid[p] + (n_null if p == target else 0) for p in range(world)]
+    recv_nulls = [(lens_h[s] - valid_h[s]) if rank == target else 0 for s in range(world)]
+    recv = [recv_valid[s] + recv_nulls[s] for s in range(world)]
+    got = _all_to_all_bytes(records[: n * SORT_RECORD_BYTES], send, recv, SORT_RECORD_BYTES, group)
 
-    # 4. local stable sort of the transformed keys + gather of the global rows
-    m = int(keys_recv.numel())
-    if m > 0:
-        karr = Array(uint64, m, [None, keys_recv.contiguous().view(torch.uint8)], 0, 0)
+    # 4. unpack (keys + GLOBAL rows, compacted in source order), local stable sort, one gather
+    m_valid, m_null = sum(recv_valid), sum(recv_nulls)
+    meta = torch.tensor([[recv_valid[s], recv_nulls[s], offsets[s]] for s in range(world)], dtype=torch.int64).to(device)
+    keys_recv = torch.empty(max(m_valid, 1), dtype=torch.int64, device=device)
+    gidx_recv = torch.empty(max(m_valid, 1), dtype=torch.int64, device=device)
+    null_rows = torch.empty(max(m_null, 1), dtype=torch.int64, device=device)
+    check(lib.arx_sort_unpack_records(got.data_ptr(), m_valid + m_null, meta.data_ptr(), world, int(nulls_first),
+                                      keys_recv.data_ptr(), gidx_recv.data_ptr(), null_rows.data_ptr(), stream))
+    if m_valid > 0:
+        karr = Array(uint64, m_valid, [None, keys_recv.view(torch.uint8)], 0, 0)
         perm = cp.call_function("array_sort_indices", [karr], cp.ArraySortOptions("ascending", "at_end"))
-        garr = Array(int64, m, [None, gidx_recv.contiguous().view(torch.uint8)], 0, 0)
-        sorted_rows = cp.take(garr, perm, boundscheck=False).data[: m * 8].view(torch.int64)
+        garr = Array(int64, m_valid, [None, gidx_recv.view(torch.uint8)], 0, 0)
+        sorted_rows = cp.take(garr, perm, boundscheck=False).data[: m_valid * 8].view(torch.int64)
     else:
         sorted_rows = torch.empty(0, dtype=torch.int64, device=device)
-
-    # 5. nulls: row numbers only, to the last (at_end) or first (at_start) rank, in global row order
-    target = world - 1 if null_placement == "at_end" else 0
-    n_null = n - nv
-    null_rows = torch.empty(0, dtype=torch.int64, device=device)
-    if n_null > 0:
-        fws = alloc(lib.arx_filter_workspace_bytes(n) + 64, device)
-        fws_ptr = (fws.data_ptr() + 63) & ~63
-        out = torch.empty(n_null, dtype=torch.int32, device=device)
-        got = C.c_int64(0)
-        check(lib.arx_bitmap_to_indices(values.validity.data_ptr(), values.offset, n, 1, fws_ptr,
-                                        fws.numel() - (fws_ptr - fws.data_ptr()), out.data_ptr(),
-                                        C.byref(got), stream))
-        null_rows = (out[: got.value].to(torch.int64) & 0xFFFFFFFF) + shard_offset
-    if world > 1:
-        nsend = [0] * world
-        nsend[target] = int(null_rows.numel())
-        ncounts = torch.tensor(nsend, dtype=torch.int64, device=device)
-        nrecv_t = torch.empty_like(ncounts)
-        dist.all_to_all_single(nrecv_t, ncounts, group=group)
-        nrecv = [int(x) for x in nrecv_t.cpu().tolist()]
-        null_rows = _all_to_all_v(null_rows, nsend, nrecv, group)
-    if rank == target and null_rows.numel() > 0:
-        sorted_rows = torch.cat([sorted_rows, null_rows] if null_placement == "at_end"
-                                else [null_rows, sorted_rows])  # buffer concatenation only
-
-    # start of this rank's slice in the global order
-    mine = torch.zeros(world, dtype=torch.int64, device=device)
-    mine[rank] = sorted_rows.numel()
-    if world > 1:
-        dist.all_reduce(mine, group=group)
-    start = int(mine[:rank].sum().item())
+    if m_null > 0:
+        parts = [null_rows[:m_null], sorted_rows] if nulls_first else [sorted_rows, null_rows[:m_null]]
+        sorted_rows = torch.cat(parts)   # buffer concatenation only (the target rank, shards with nulls)
+    assert int(sorted_rows.numel()) == owned[rank], (int(sorted_rows.numel()), owned[rank])
     return sorted_rows, start

@@ -1,28 +1,42 @@
 #!/usr/bin/env python
 """bench.py — the headline benchmark of BASELINE.json, on synthetic data resident in HBM.
 
-Default workload (N=1): BASELINE.json configs[1] — Filter + Take on a 1B-row int64 array with a
-validity bitmap (10 % null), boolean mask with 10 % selectivity, FilterOptions::DROP:
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 (default): BASELINE.json configs[1] — Filter + Take on a 1B-row int64 array with a validity
+bitmap (10 % null), boolean mask with 10 % selectivity, FilterOptions::DROP:
     step = compute.filter(values, mask)                       # array_filter (count, scan, compact)
          + compute.get_take_indices(mask)                     # GetTakeIndices -> uint32[S]
          + compute.take(values, indices, boundscheck=False)   # the Table/RecordBatch filter path
 `value` = input rows per second through one whole step (Mrows/s), all N ranks together.
-Filter/take do not shard (north_star: "filter/take/cast stay single-GPU"): with --gpus N > 1
-every rank runs an independent replica on its own GPU ("replicas only", weak scaling).
-`--workload hash_sum` runs the sharded group-by instead (local aggregate -> partition ->
-one all-to-all -> merge), rows split across ranks.
+Filter/take do not shard (north_star: "filter/take/cast stay single-GPU"): with N > 1 every rank runs an
+independent replica on its own GPU ("replicas only", weak scaling).  The sharded paths ride in the same JSON
+line: `hash_sum` (configs[3]: 4B rows / 10M keys, rows split over the N ranks, local aggregate -> ONE
+all-to-all of 24-byte partials -> merge; strong scaling) and `sort_indices` (configs[4]: 2B uint64 rows,
+splitters -> ONE all-to-all of 12-byte records -> local sort).
+
+N > 1 without a launcher: `python bench.py --gpus N` starts the N ranks itself (one process per GPU,
+LOCAL_RANK -> device, rendezvous on 127.0.0.1 and a free port); under torchrun (WORLD_SIZE set) it is one rank.
+
+Inputs are SURVEY.md 8(d)'s counter-based streams r(i, seed) = splitmix64(seed + i), generated on the device
+(numpy twin: splitmix64_np) — values r(i,1), mask r(i,2) % 100 < 10, validity r(i,3) % 100 >= 10,
+group-by keys r(i,8) % 10M, values r(i,9), sort keys r(i,10), the cast mix of seed 6.
 
 One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the filter compaction,
 arx_filter_exec) in ALGORITHMIC bytes (8N + N/8 + N/8 + 8S + S/8) over its HIP-event
 duration measured live; `cpu_baseline` times the reference's own CPU kernels (pyarrow wheel =
-libarrow.so.2500, kind "reference"; the C oracle as kind "port" if the wheel is absent) on a
-bounded sample of the same data, one thread.
+libarrow.so, kind "reference"; the C oracle as kind "port" if the wheel is absent) on a bounded sample of the
+same data: one thread (how the kernel layer executes) and the multi-core Acero plan; `value` = the better.
+`--backend emu` (tests only) runs the same file on CPU tensors + gloo with the kernel sources under the
+SIMT emulator of tests/emu: it checks the launcher and the multi-rank plumbing, never performance.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,10 +50,46 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+EMU = False            # --backend emu
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+# ------------------------------------------------------------------ counter-based input streams
+_M1 = 0xBF58476D1CE4E5B9 - (1 << 64)
+_M2 = 0x94D049BB133111EB - (1 << 64)
+_GAMMA = 0x9E3779B97F4A7C15 - (1 << 64)
+
+
+def _lsr(z: torch.Tensor, k: int) -> torch.Tensor:
+    return (z >> k) & ((1 << (64 - k)) - 1)
+
+
+def splitmix64(first: int, count: int, seed: int, device) -> torch.Tensor:
+    """r(i, seed) for i in [first, first + count) as int64 bit patterns (two's complement of the uint64)."""
+    z = torch.arange(first, first + count, dtype=torch.int64, device=device) + seed
+    z = z + _GAMMA
+    z = (z ^ _lsr(z, 30)) * _M1
+    z = (z ^ _lsr(z, 27)) * _M2
+    return z ^ _lsr(z, 31)
+
+
+def splitmix64_np(first: int, count: int, seed: int) -> np.ndarray:
+    """Host twin of splitmix64 (uint64)."""
+    with np.errstate(over="ignore"):
+        z = np.arange(first, first + count, dtype=np.uint64) + np.uint64(seed % (1 << 64))
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def umod(z: torch.Tensor, m: int) -> torch.Tensor:
+    """(uint64 view of z) % m for an int64 tensor."""
+    r = torch.remainder(z, m)
+    return torch.where(z < 0, (r + ((1 << 64) % m)) % m, r)
 
 
 def pack_bits_device(bools: torch.Tensor) -> torch.Tensor:
@@ -48,36 +98,175 @@ def pack_bits_device(bools: torch.Tensor) -> torch.Tensor:
     return (bools.view(-1, 8).to(torch.uint8) * w).sum(dim=1, dtype=torch.uint8)
 
 
-def gen_filter_inputs(n: int, device, seed: int, null_p: float, true_p: float):
-    """values int64[n] (full range), validity bitmap (null_p nulls), mask bitmap (true_p set)."""
+CHUNK = 1 << 26
+
+
+def gen_filter_inputs(n: int, device, first_row: int, null_p: float, true_p: float, mask_null_p: float = 0.0):
+    """values int64[n] = r(i,1); validity bit = r(i,3) % 100 >= 100 null_p; mask bit = r(i,2) % 100 < 100 true_p;
+    mask validity (secondary config, vector_selection_benchmark.cc:59-75) bit = r(i,4) % 100 >= 100 mask_null_p."""
     from arrow_amd.array import alloc
 
-    g = torch.Generator(device=device).manual_seed(seed)
     n8 = (n + 7) // 8 * 8
+    nbytes = (n8 // 8 + 7) // 8 * 8
     values = alloc(n * 8, device)
-    validity = alloc((n8 // 8 + 7) // 8 * 8, device, zero=True)
-    mask = alloc((n8 // 8 + 7) // 8 * 8, device, zero=True)
+    validity = alloc(nbytes, device, zero=True)
+    mask = alloc(nbytes, device, zero=True)
+    mask_valid = alloc(nbytes, device, zero=True) if mask_null_p > 0 else None
     v64 = values[: n * 8].view(torch.int64)
-    chunk = 1 << 26
-    for b in range(0, n, chunk):
-        e = min(n, b + chunk)
-        v64[b:e] = torch.randint(-2**63, 2**63 - 1, (e - b,), dtype=torch.int64, device=device,
-                                 generator=g)
+    chunk = min(CHUNK, n8)
     for b in range(0, n8, chunk):
         e = min(n8, b + chunk)
-        r = torch.rand(e - b, device=device, generator=g)
-        if e > n:
-            r[n - b:] = 2.0
-        validity[b // 8: e // 8] = pack_bits_device(r >= null_p)
-        r = torch.rand(e - b, device=device, generator=g)
-        if e > n:
-            r[n - b:] = 2.0
-        mask[b // 8: e // 8] = pack_bits_device(r < true_p)
-    return values, validity, mask
+        live = min(e, n) - b
+        if live > 0:
+            v64[b:b + live] = splitmix64(first_row + b, live, 1, device)
+        in_range = torch.arange(b, e, device=device) < n
+
+        def bits(seed, thresh, ge):
+            r = umod(splitmix64(first_row + b, e - b, seed, device), 100)
+            return ((r >= thresh) if ge else (r < thresh)) & in_range
+
+        validity[b // 8: e // 8] = pack_bits_device(bits(3, int(round(100 * null_p)), True))
+        mask[b // 8: e // 8] = pack_bits_device(bits(2, int(round(100 * true_p)), False))
+        if mask_valid is not None:
+            mask_valid[b // 8: e // 8] = pack_bits_device(bits(4, int(round(100 * mask_null_p)), True))
+    return values, validity, mask, mask_valid
+
+
+def gen_cast_mix(n: int, device, first_row: int = 0, seed: int = 6) -> torch.Tensor:
+    """float64[n] of SURVEY.md 8(d) config 3a: 90 % N(0,1) (Box-Muller on the stream), 5 % magnitudes beyond
+    FLT_MAX, 4 % in float32's subnormal range, 1 % +-0 / +-inf / NaN."""
+    out = torch.empty(n, dtype=torch.float64, device=device)
+    two53 = float(1 << 53)
+    for b in range(0, n, CHUNK):
+        m = min(CHUNK, n - b)
+        cls = umod(splitmix64(first_row + b, m, seed, device), 100)
+        u1 = (_lsr(splitmix64(first_row + b, m, seed + 100, device), 11).to(torch.float64) + 1.0) / two53
+        u2 = _lsr(splitmix64(first_row + b, m, seed + 200, device), 11).to(torch.float64) / two53
+        g = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(6.283185307179586 * u2)
+        sign = torch.where(u2 < 0.5, -1.0, 1.0).to(torch.float64)
+        big = sign * 3.4028234663852886e38 * (1.0 + 1e6 * u1)                 # |x| > FLT_MAX -> +-inf in float32
+        sub = sign * 1.1754943508222875e-38 * u1                              # float32-subnormal results
+        k = umod(splitmix64(first_row + b, m, seed + 300, device), 5)
+        special = torch.where(k == 0, 0.0, torch.where(k == 1, -0.0, torch.where(k == 2, float("inf"),
+                              torch.where(k == 3, float("-inf"), float("nan"))))).to(torch.float64)
+        out[b:b + m] = torch.where(cls < 90, g, torch.where(cls < 95, big, torch.where(cls < 99, sub, special)))
+    return out
+
+
+def gen_normal(n: int, device, seed: int) -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.float64, device=device)
+    two53 = float(1 << 53)
+    for b in range(0, n, CHUNK):
+        m = min(CHUNK, n - b)
+        u1 = (_lsr(splitmix64(b, m, seed + 100, device), 11).to(torch.float64) + 1.0) / two53
+        u2 = _lsr(splitmix64(b, m, seed + 200, device), 11).to(torch.float64) / two53
+        out[b:b + m] = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(6.283185307179586 * u2)
+    return out
+
+
+def gen_stream(n: int, device, first_row: int, seed: int, modulo: int = 0, dtype=torch.int64) -> torch.Tensor:
+    out = torch.empty(n, dtype=dtype, device=device)
+    for b in range(0, n, CHUNK):
+        m = min(CHUNK, n - b)
+        z = splitmix64(first_row + b, m, seed, device)
+        out[b:b + m] = (umod(z, modulo) if modulo else z).to(dtype)
+    return out
+
+
+def gen_validity(n: int, device, first_row: int, seed: int, null_pct: int) -> torch.Tensor:
+    """LSB-first bitmap with null_pct % clear bits (r(i, seed) % 100 >= null_pct)."""
+    from arrow_amd.array import alloc
+
+    n8 = (n + 7) // 8 * 8
+    bm = alloc((n8 // 8 + 7) // 8 * 8, device, zero=True)
+    chunk = min(CHUNK, n8)
+    for b in range(0, n8, chunk):
+        e = min(n8, b + chunk)
+        ok = (umod(splitmix64(first_row + b, e - b, seed, device), 100) >= null_pct) & \
+             (torch.arange(b, e, device=device) < n)
+        bm[b // 8: e // 8] = pack_bits_device(ok)
+    return bm
+
+
+# ------------------------------------------------------------------ timers
+class _WallTimer:
+    """KernelTimer twin for the emulated backend (kernels run synchronously there)."""
+
+    def __init__(self):
+        self.events = {}
+
+    def start(self, name):
+        rec = [time.perf_counter(), None]
+        self.events.setdefault(name, []).append(rec)
+        return rec
+
+    def stop(self, rec):
+        rec[1] = time.perf_counter()
+
+    def elapsed_ms(self, name):
+        return [(e - s) * 1e3 for s, e in self.events.get(name, [])]
+
+
+def _sync(device):
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def _time_gpu(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    if EMU:
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps * 1e3
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def _barrier(world):
+    if world > 1:
+        torch.distributed.barrier()
+
+
+def _max_over_ranks(x: float, world, device) -> float:
+    if world > 1:
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+    return x
+
+
+def load_traffic(name: str, rows: int):
+    """HBM bytes per launch / per run from the committed PMC pass (profiles/<name>_traffic.json), or null."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", f"{name}_traffic.json")))
+        if int(d.get("rows", -1)) == int(rows):
+            return d.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+# ------------------------------------------------------------------ CPU baselines (reference kernels, same box)
+def _host_cores() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
 
 
 def cpu_baseline_filter_take(values, validity, mask, n_total: int, sample_rows: int, budget_s: float):
-    """Reference CPU kernels on the first `sample_rows` rows of the very same buffers."""
+    """Reference CPU kernels on the first `sample_rows` rows of the very same buffers: (i) one thread — how the
+    kernel layer executes a CallFunction (exec.cc:1144) — and (ii) the multi-core Acero plan
+    table_source -> filter -> sink (use_threads, pool = all cores).  `value` = the better of the two."""
     n = min(n_total, sample_rows)
     n -= n % 64
     hv = values[: n * 8].cpu().numpy()
@@ -88,23 +277,13 @@ def cpu_baseline_filter_take(values, validity, mask, n_total: int, sample_rows: 
         import pyarrow.compute as pc
     except Exception:
         pa = None
-    reps, t_total = 0, 0.0
-    if pa is not None:
-        varr = pa.Array.from_buffers(pa.int64(), n, [pa.py_buffer(hval), pa.py_buffer(hv)], null_count=-1)
-        marr = pa.Array.from_buffers(pa.bool_(), n, [None, pa.py_buffer(hm)], null_count=0)
-        table = pa.table({"v": varr})
-        while reps < 2 or (t_total < budget_s and reps < 8):
-            t0 = time.perf_counter()
-            a = pc.filter(varr, marr)          # array_filter: PrimitiveFilterExec
-            b = table.filter(marr)             # FilterTable: GetTakeIndices + Take
-            t_total += time.perf_counter() - t0
-            reps += 1
-            del a, b
-        kind, what = "reference", f"pyarrow {pa.__version__} (libarrow CPU kernels), pc.filter + Table.filter"
-    else:
-        from oracle import oracle as O
+    cores_all = _host_cores()
+    if pa is None:
+        from oracle import oracle as O      # checker used as the "port" baseline only when the wheel is absent
+
         n = min(n, 1 << 25)
         hv64 = hv[: n * 8].view(np.int64)
+        reps, t_total = 0, 0.0
         while reps < 2 or (t_total < budget_s and reps < 4):
             t0 = time.perf_counter()
             O.filter(hv64, hval, 0, hm, None, 0, n, 0, True)
@@ -112,31 +291,131 @@ def cpu_baseline_filter_take(values, validity, mask, n_total: int, sample_rows: 
             O.take(hv64, hval, 0, idx, None, 0, len(idx), True)
             t_total += time.perf_counter() - t0
             reps += 1
-        kind, what = "port", "oracle/arx_oracle.c filter + mask_to_indices + take"
-    mrows = n * reps / t_total / 1e6
-    return {"value": round(mrows, 2), "unit": "Mrows/s", "cores": 1, "kind": kind,
-            "sample": f"first {n} rows of the same HBM buffers, {reps} reps, {what}",
-            "host_cpus": os.cpu_count()}
+        return {"value": round(n * reps / t_total / 1e6, 2), "unit": "Mrows/s", "cores": 1, "kind": "port",
+                "sample": f"first {n} rows, {reps} reps, oracle/arx_oracle.c filter + mask_to_indices + take",
+                "host_cpus": cores_all}
+    from pyarrow import acero
+
+    varr = pa.Array.from_buffers(pa.int64(), n, [pa.py_buffer(hval), pa.py_buffer(hv)], null_count=-1)
+    marr = pa.Array.from_buffers(pa.bool_(), n, [None, pa.py_buffer(hm)], null_count=0)
+    table = pa.table({"v": varr})
+    saved = pa.cpu_count()
+    # (i) one thread
+    pa.set_cpu_count(1)
+    reps, t_total = 0, 0.0
+    while reps < 2 or (t_total < budget_s / 2 and reps < 8):
+        t0 = time.perf_counter()
+        a = pc.filter(varr, marr)          # array_filter: PrimitiveFilterExec
+        b = table.filter(marr)             # FilterTable: GetTakeIndices + Take
+        t_total += time.perf_counter() - t0
+        reps += 1
+        del a, b
+    single = n * reps / t_total / 1e6
+    # (ii) Acero, all cores: the same two results (filtered column twice) from one threaded plan per path
+    threads = max(1, min(cores_all, 64))
+    pa.set_cpu_count(threads)
+    tm = pa.table({"v": varr, "m": marr})
+    plan = acero.Declaration.from_sequence([
+        acero.Declaration("table_source", acero.TableSourceNodeOptions(tm)),
+        acero.Declaration("filter", acero.FilterNodeOptions(pc.field("m"))),
+        acero.Declaration("project", acero.ProjectNodeOptions([pc.field("v")], ["v"]))])
+    reps2, t2 = 0, 0.0
+    try:
+        while reps2 < 2 or (t2 < budget_s / 2 and reps2 < 8):
+            t0 = time.perf_counter()
+            a = plan.to_table(use_threads=True)
+            b = plan.to_table(use_threads=True)   # the step filters twice (array_filter + the take path)
+            t2 += time.perf_counter() - t0
+            reps2 += 1
+            del a, b
+        multi = n * reps2 / t2 / 1e6
+    except Exception as e:  # pragma: no cover - informational
+        multi, reps2 = 0.0, 0
+        log(f"[cpu_baseline] Acero plan failed: {e}")
+    pa.set_cpu_count(saved)
+    best = max(single, multi)
+    return {"value": round(best, 2), "unit": "Mrows/s", "cores": 1 if single >= multi else threads,
+            "kind": "reference",
+            "sample": f"first {n} rows of the same HBM buffers; pyarrow {pa.__version__} (libarrow CPU kernels)",
+            "single_thread_mrows_per_s": round(single, 2), "single_thread_what": f"pc.filter + Table.filter, {reps} reps",
+            "acero_mrows_per_s": round(multi, 2),
+            "acero_what": f"table_source -> filter -> project x2, use_threads, {threads} threads, {reps2} reps",
+            "host_cpus": cores_all, "simd": str(pa.runtime_info().simd_level)}
 
 
+def cpu_baseline_hash_sum(rows: int, groups: int, budget_s: float):
+    """pyarrow Table.group_by(k).aggregate(sum) (Acero GroupByNode + hash_sum) on a DOWN-SCALED prefix of the same
+    streams: single-thread and multi-thread (the reference's serial merge often makes threads slower; min reported)."""
+    try:
+        import pyarrow as pa
+    except Exception:
+        return None
+    n = rows
+    k = (splitmix64_np(0, n, 8) % np.uint64(groups)).astype(np.int32)
+    v = splitmix64_np(0, n, 9).view(np.int64)
+    t = pa.table({"k": pa.array(k), "v": pa.array(v)})
+    res = {}
+    saved = pa.cpu_count()
+    cores_all = _host_cores()
+    for name, threads in (("single_thread", 1), ("multi_thread", max(1, min(cores_all, 64)))):
+        pa.set_cpu_count(threads)
+        t0 = time.perf_counter()
+        out = t.group_by("k", use_threads=threads > 1).aggregate([("v", "sum")])
+        dt = time.perf_counter() - t0
+        res[name] = (n / dt / 1e6, threads, out.num_rows)
+        if dt > budget_s:
+            break
+    pa.set_cpu_count(saved)
+    best = max(res.values(), key=lambda x: x[0])
+    return {"value": round(best[0], 2), "unit": "Mrows/s", "cores": best[1], "kind": "reference",
+            "sample": f"DOWN-SCALED: first {n} rows of the same streams ({best[2]} groups), pyarrow {pa.__version__} "
+                      "Table.group_by(k).aggregate([(v, sum)])",
+            **{f"{nm}_mrows_per_s": round(x[0], 2) for nm, x in res.items()}, "host_cpus": cores_all}
+
+
+def cpu_baseline_sort(rows: int):
+    try:
+        import pyarrow as pa
+        import pyarrow.compute as pc
+    except Exception:
+        return None
+    k = splitmix64_np(0, rows, 10)
+    arr = pa.array(k)
+    saved = pa.cpu_count()
+    pa.set_cpu_count(1)
+    t0 = time.perf_counter()
+    out = pc.sort_indices(arr)
+    dt = time.perf_counter() - t0
+    pa.set_cpu_count(saved)
+    del out
+    return {"value": round(rows / dt / 1e6, 2), "unit": "Mrows/s", "cores": 1, "kind": "reference",
+            "sample": f"DOWN-SCALED: first {rows} rows of the same stream, pyarrow {pa.__version__} pc.sort_indices "
+                      "(std::stable_sort on indices, one thread)", "host_cpus": _host_cores()}
+
+
+# ------------------------------------------------------------------ parity spot check (outside the timed region)
 def parity_spot_check(amd, values, validity, mask, n_total: int):
-    """Outside the timed region: device filter+take on a prefix vs the C oracle."""
+    """Device filter+take on a prefix vs the C oracle (the checker; never the thing measured)."""
     from oracle import oracle as O
 
     n = min(n_total, 1 << 21)
     n -= n % 64
+    if n <= 0:
+        return True
     dv = amd.Array(amd.array.int64, n, [validity, values], -1, 0)
     dm = amd.Array(amd.array.bool_, n, [None, mask], 0, 0)
     out = amd.compute.filter(dv, dm)
     idx = amd.compute.get_take_indices(dm)
     tk = amd.compute.take(dv, idx, boundscheck=False)
-    torch.cuda.synchronize()
+    _sync(values.device)
     hv = values[: n * 8].cpu().numpy().view(np.int64)
     hval = validity[: n // 8].cpu().numpy()
     hm = mask[: n // 8].cpu().numpy()
+    # the inputs themselves must be the documented streams
+    ok = bool((hv.view(np.uint64) == splitmix64_np(int(getattr(values, "_first_row", 0)), n, 1)).all())
     want, want_bm = O.filter(hv, hval, 0, hm, None, 0, n, 0, True)
     got = out.data[: out.length * 8].cpu().numpy().view(np.int64)
-    ok = out.length == len(want) and bool((got == want).all())
+    ok = ok and out.length == len(want) and bool((got == want).all())
     gv = np.unpackbits(out.validity.cpu().numpy(), bitorder="little")[: out.length].astype(bool)
     ok = ok and bool((gv == O.unpack_bits(want_bm, 0, out.length)).all())
     gt = tk.data[: tk.length * 8].cpu().numpy().view(np.int64)
@@ -145,14 +424,16 @@ def parity_spot_check(amd, values, validity, mask, n_total: int):
     return ok
 
 
+# ------------------------------------------------------------------ legs
 def run_filter_take(args, rank, world, device):
     import arrow_amd as amd
     from arrow_amd import tracing
 
     n = args.rows
     t0 = time.time()
-    values, validity, mask = gen_filter_inputs(n, device, 1234 + rank, args.null_p, args.selectivity)
-    torch.cuda.synchronize(device)
+    first_row = rank * n     # every replica reads its own stretch of the streams
+    values, validity, mask, _ = gen_filter_inputs(n, device, first_row, args.null_p, args.selectivity)
+    _sync(device)
     log(f"[rank {rank}] generated {n} rows in {time.time() - t0:.1f}s")
     dv = amd.Array(amd.array.int64, n, [validity, values], -1, 0)
     dm = amd.Array(amd.array.bool_, n, [None, mask], 0, 0)
@@ -163,27 +444,22 @@ def run_filter_take(args, rank, world, device):
         tk = amd.compute.take(dv, idx, boundscheck=False)
         return out, idx, tk
 
+    out = idx = tk = None
     for _ in range(args.warmup):
         out, idx, tk = step()
-    selected = out.length if args.warmup else None
-    timer = tracing.KernelTimer(device)
+    timer = _WallTimer() if EMU else tracing.KernelTimer(device)
     tracing.install(timer)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize(device)
+    _barrier(world)
+    _sync(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, idx, tk = step()
-    torch.cuda.synchronize(device)
-    if world > 1:
-        torch.distributed.barrier()
+    _sync(device)
+    _barrier(world)
     elapsed = time.perf_counter() - t0
     tracing.install(None)
     selected = out.length
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = _max_over_ranks(elapsed, world, device)
 
     filt_ms = timer.elapsed_ms("arx_filter_exec")
     take_ms = timer.elapsed_ms("arx_take")
@@ -208,7 +484,8 @@ def run_filter_take(args, rank, world, device):
         "config": {
             "workload": f"Filter+Take int64[{n}] + validity ({args.null_p:.0%} null), boolean mask "
                         f"{args.selectivity:.0%} true, FilterOptions::DROP; take indices = "
-                        "GetTakeIndices(mask) (uint32, monotonic), no boundscheck",
+                        "GetTakeIndices(mask) (uint32, monotonic), no boundscheck; inputs = splitmix64 streams "
+                        "of SURVEY.md 8(d) (seeds 1,2,3)",
             "rows": n, "selected_rows": int(selected), "parallelism": "replicas" if world > 1 else "single-gpu",
         },
         "roofline": {
@@ -217,21 +494,19 @@ def run_filter_take(args, rank, world, device):
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "avg_kernel_ms": round(avg_filter_ms, 4),
-            "traffic": load_measured_traffic(n),
+            "traffic": load_traffic("filter", n),
         },
         "kernel_ms": {"arx_filter_exec": round(avg_filter_ms, 4),
                       "arx_mask_to_indices": round(float(np.mean(m2i_ms)), 4),
                       "arx_take": round(float(np.mean(take_ms)), 4),
-                      "take_algorithmic_GBps": round(take_bytes / (float(np.mean(take_ms)) * 1e-3) / 1e9, 1)},
+                      "take_algorithmic_GBps": round(take_bytes / max(float(np.mean(take_ms)), 1e-9) / 1e6, 1)},
     }
     if rank == 0 and world == 1:
         result["parity_spot_check"] = "ok" if parity_spot_check(amd, values, validity, mask, n) else "MISMATCH"
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_filter_take(values, validity, mask, n,
                                                               args.cpu_sample_rows, args.cpu_budget_s)
-        if args.extras:
-            del out, idx, tk
-            result["other_paths"] = run_extras(amd, device)
+    del out, idx, tk
     watchdog = None
     if args.extras and world > 1:
         # The sharded legs below are the only part of this file that depends on collectives with
@@ -240,28 +515,27 @@ def run_filter_take(args, rank, world, device):
         watchdog = _ExtrasWatchdog(rank, result, args.extras_timeout)
         watchdog.start()
     if args.extras:
+        del values, validity, mask, dv, dm
+        if not EMU:
+            torch.cuda.empty_cache()
+        if rank == 0 and world == 1:
+            try:
+                result["other_paths"] = run_other_paths(amd, device, args)
+            except Exception as e:
+                result["other_paths"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if not EMU:
+                torch.cuda.empty_cache()
         # the second half of BASELINE.json's metric: hash_sum group-by, 4B rows / 10M keys, rows
         # sharded over the N ranks (strong scaling), outside the timed region of `value`
         try:
-            out = idx = tk = None
-            del values, validity, mask, dv, dm
-            torch.cuda.empty_cache()
-            sec, rows, groups_out, checksum, ok = measure_hash_sum(rank, world, device, args.hash_sum_rows,
-                                                                   args.groups, 3, 1)
-            result["hash_sum"] = {"rows": rows, "groups": groups_out, "n_gpus": world,
-                                  "ms": round(sec * 1e3, 3), "mrows_per_s": round(rows / sec / 1e6, 1),
-                                  "scaling": "strong", "algorithmic_GBps_per_gpu": round(12 * rows / world / sec / 1e9, 1),
-                                  "checksum_matches_sum_of_values": ok}
+            result["hash_sum"] = hash_sum_leg(args, rank, world, device, args.hash_sum_rows, 3, 1)
         except Exception as e:  # never lose the headline line to the secondary measurement
             result["hash_sum"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         # configs[4]: array_sort_indices of a 2B-row uint64 array sharded over the N ranks
         try:
-            torch.cuda.empty_cache()
-            sec, rows, ok = measure_sort(rank, world, device, args.sort_rows, 2, 1)
-            result["sort_indices"] = {"rows": rows, "n_gpus": world, "ms": round(sec * 1e3, 3),
-                                      "mrows_per_s": round(rows / sec / 1e6, 1), "scaling": "strong",
-                                      "algorithmic_GBps_per_gpu": round(16 * rows / world / sec / 1e9, 1),
-                                      "permutation_and_order_checks": ok}
+            if not EMU:
+                torch.cuda.empty_cache()
+            result["sort_indices"] = sort_leg(args, rank, world, device, args.sort_rows, 2, 1)
         except Exception as e:
             result["sort_indices"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if watchdog is not None:
@@ -298,85 +572,213 @@ class _ExtrasWatchdog:
         os._exit(0)
 
 
-def load_measured_traffic(n):
-    """HBM bytes per launch from the committed PMC pass (profiles/), or null."""
-    p = os.path.join(ROOT, "profiles", "filter_traffic.json")
-    try:
-        d = json.load(open(p))
-        if int(d.get("rows", -1)) == int(n):
-            return d.get("hbm_bytes_per_launch")
-    except Exception:
-        pass
-    return None
-
-
-def _time_gpu(fn, reps=5, warm=2):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    s = torch.cuda.Event(enable_timing=True)
-    e = torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(reps):
-        fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / reps
-
-
-def run_extras(amd, device):
-    """Informational single-GPU numbers for the other rows of SURVEY.md section 8 (not `value`)."""
+def run_other_paths(amd, device, args):
+    """Single-GPU numbers for the other rows of SURVEY.md section 8 (not `value`): config 3 at its stated size
+    with the survey's value mix, the secondary configurations of 8(d), and the same calls through the Arrow
+    plugin (CallFunction on device-resident pyarrow arrays)."""
     out = {}
-    g = torch.Generator(device=device).manual_seed(99)
-    n = 1 << 28
-    x = torch.randn(n, dtype=torch.float64, device=device, generator=g)
-    y = torch.randn(n, dtype=torch.float64, device=device, generator=g)
+    n = args.stream_rows
+    # ---- config 3a: cast(float64 -> float32), survey mix (overflow -> inf, float32 subnormals, NaN, +-0)
+    x = gen_cast_mix(n, device)
     ax = amd.Array(amd.array.float64, n, [None, x.view(torch.uint8)], 0, 0)
-    ay = amd.Array(amd.array.float64, n, [None, y.view(torch.uint8)], 0, 0)
     ms = _time_gpu(lambda: amd.compute.cast(ax, amd.array.float32))
-    out["cast_f64_f32"] = {"rows": n, "ms": round(ms, 4), "algorithmic_GBps": round(12 * n / ms / 1e6, 1)}
-    ms = _time_gpu(lambda: amd.compute.greater(ax, ay))
-    out["greater_f64"] = {"rows": n, "ms": round(ms, 4), "algorithmic_GBps": round(16.125 * n / ms / 1e6, 1)}
-    del x, y, ax, ay
-    n = 1 << 27
-    k = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=device, generator=g)
-    ak = amd.Array(amd.array.uint64, n, [None, k.view(torch.uint8)], 0, 0)
+    f = amd.compute.cast(ax, amd.array.float32).data[: 4 * min(n, 1 << 20)].view(torch.float32)
+    ref = x[: min(n, 1 << 20)].to(torch.float32)      # v_cvt_f32_f64 twin in torch: plumbing for the check only
+    same = bool(((f == ref) | (torch.isnan(f) & torch.isnan(ref))).all())
+    out["cast_f64_f32"] = {"rows": n, "ms": round(ms, 4), "algorithmic_GBps": round(12 * n / ms / 1e6, 1),
+                           "roofline_frac": round(12 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+                           "values": "survey 8(d) 3a mix (90% N(0,1), 5% >FLT_MAX, 4% f32-subnormal, 1% special)",
+                           "bit_exact_vs_round_to_nearest_even_sample": same}
+    del x, ax, f, ref
+    # ---- config 3b: greater(float64, float64)
+    a = gen_normal(n, device, 6)
+    b = gen_normal(n, device, 7)
+    aa = amd.Array(amd.array.float64, n, [None, a.view(torch.uint8)], 0, 0)
+    ab = amd.Array(amd.array.float64, n, [None, b.view(torch.uint8)], 0, 0)
+    ms = _time_gpu(lambda: amd.compute.greater(aa, ab))
+    out["greater_f64"] = {"rows": n, "ms": round(ms, 4), "algorithmic_GBps": round(16.125 * n / ms / 1e6, 1),
+                          "roofline_frac": round(16.125 * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    del a, b, aa, ab
+    if not EMU:
+        torch.cuda.empty_cache()
+    # ---- secondary configurations of 8(d) on the 1B-row source
+    n = args.rows
+    values, validity, mask, mvalid = gen_filter_inputs(n, device, 0, args.null_p, args.selectivity, mask_null_p=0.05)
+    dv = amd.Array(amd.array.int64, n, [validity, values], -1, 0)
+    dm = amd.Array(amd.array.bool_, n, [None, mask], 0, 0)
+    dmn = amd.Array(amd.array.bool_, n, [mvalid, mask], -1, 0)
+    mono = amd.compute.get_take_indices(dm)
+    S = mono.length
+    m_rand = min(100_000_000, max(1, n // 10))
+    ridx = gen_stream(m_rand, device, 0, 5, modulo=n, dtype=torch.int64).to(torch.int32)   # uint32 bit patterns
+    di = amd.Array(amd.array.uint32, m_rand, [None, ridx.view(torch.uint8)], 0, 0)
+    sec = {}
+
+    def t(name, fn, bytes_alg):
+        ms_ = _time_gpu(fn, reps=5, warm=2)
+        sec[name] = {"ms": round(ms_, 4), "algorithmic_GBps": round(bytes_alg / ms_ / 1e6, 1),
+                     "roofline_frac": round(bytes_alg / ms_ / 1e6 / HBM_PEAK_GBS, 4)}
+
+    t("filter_drop_5pct_mask_nulls", lambda: amd.compute.filter(dv, dmn), 8 * n + 3 * n / 8 + 8.125 * 0.95 * S)
+    t("filter_emit_null_5pct_mask_nulls", lambda: amd.compute.filter(dv, dmn, "emit_null"),
+      8 * n + 3 * n / 8 + 8.125 * (0.95 * S + 0.05 * n))
+    t("take_monotonic_boundscheck", lambda: amd.compute.take(dv, mono, boundscheck=True), 20.25 * S)
+    t("take_random_uint32", lambda: amd.compute.take(dv, di, boundscheck=False), 20.25 * m_rand)
+    for sel in (0.25, 0.50):
+        _, _, msel, _ = gen_filter_inputs(n, device, 0, args.null_p, sel)
+        dms = amd.Array(amd.array.bool_, n, [None, msel], 0, 0)
+        ssel = amd.compute.filter(dv, dms).length
+        t(f"filter_drop_selectivity_{int(sel * 100)}pct", lambda: amd.compute.filter(dv, dms),
+          8 * n + n / 4 + 8.125 * ssel)
+        del msel, dms
+    out["secondary_configs"] = {"rows": n, "selected_rows": int(S), **sec}
+    del mvalid, dv, dm, dmn, mono, ridx, di
+    if not EMU:
+        try:
+            out["callfunction"] = callfunction_leg(args, values, validity, mask, device)
+        except Exception as e:
+            out["callfunction"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    del values, validity, mask
+    if not EMU:
+        torch.cuda.empty_cache()
+    # ---- sort / hash_sum with 1 % nulls (secondary of configs 4 and 5), single GPU, 2^28 rows
+    n2 = min(1 << 28, max(1024, args.sort_rows))
+    k = gen_stream(n2, device, 0, 10)
+    kv = gen_validity(n2, device, 0, 11, 1)
+    ak = amd.Array(amd.array.uint64, n2, [kv, k.view(torch.uint8)], -1, 0)
     ms = _time_gpu(lambda: amd.compute.sort_indices(ak), reps=2, warm=1)
-    out["sort_indices_u64"] = {"rows": n, "ms": round(ms, 3), "mrows_per_s": round(n / ms / 1e3, 1),
-                               "algorithmic_GBps": round(16 * n / ms / 1e6, 1)}
-    del k, ak
-    n = 1 << 28
-    keys = torch.randint(0, 10_000_000, (n,), dtype=torch.int32, device=device, generator=g)
-    vals = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=device, generator=g)
-    kk = amd.Array(amd.array.int32, n, [None, keys.view(torch.uint8)], 0, 0)
-    vv = amd.Array(amd.array.int64, n, [None, vals.view(torch.uint8)], 0, 0)
-    ms = _time_gpu(lambda: amd.compute.group_by_sum(kk, vv, capacity=1 << 25), reps=2, warm=1)
-    out["hash_sum_i64_by_i32"] = {"rows": n, "groups": 10_000_000, "ms": round(ms, 3),
-                                  "mrows_per_s": round(n / ms / 1e3, 1),
-                                  "algorithmic_GBps": round(12 * n / ms / 1e6, 1)}
+    out["sort_indices_u64_1pct_nulls"] = {"rows": n2, "ms": round(ms, 3), "mrows_per_s": round(n2 / ms / 1e3, 1)}
+    ms = _time_gpu(lambda: amd.compute.sort_indices(ak, order="descending"), reps=2, warm=1)
+    out["sort_indices_u64_1pct_nulls_descending"] = {"rows": n2, "ms": round(ms, 3), "mrows_per_s": round(n2 / ms / 1e3, 1)}
+    del k, kv, ak
+    keys = gen_stream(n2, device, 0, 8, modulo=args.groups, dtype=torch.int32)
+    vals = gen_stream(n2, device, 0, 9)
+    kvb = gen_validity(n2, device, 0, 12, 0)      # 0.1 % null keys would need a per-mille stream: use values' 1 %
+    vvb = gen_validity(n2, device, 0, 13, 1)
+    kk = amd.Array(amd.array.int32, n2, [kvb, keys.view(torch.uint8)], -1, 0)
+    vv = amd.Array(amd.array.int64, n2, [vvb, vals.view(torch.uint8)], -1, 0)
+    cap = 1
+    while cap < 2 * args.groups + 2:
+        cap <<= 1
+    ms = _time_gpu(lambda: amd.compute.group_by_sum(kk, vv, capacity=cap), reps=2, warm=1)
+    out["hash_sum_1pct_null_values"] = {"rows": n2, "groups": args.groups, "ms": round(ms, 3),
+                                        "mrows_per_s": round(n2 / ms / 1e3, 1)}
+    del keys, vals, kvb, vvb, kk, vv
+    if not EMU:
+        torch.cuda.empty_cache()
     return out
 
 
-def _sync(device):
-    if torch.device(device).type == "cuda":
-        torch.cuda.synchronize(device)
+def callfunction_leg(args, values, validity, mask, device):
+    """The same kernels driven by UNMODIFIED pyarrow.compute / Acero on device-resident pyarrow arrays through the
+    registration shim (libarrow_amd_plugin.so): wall ms per call, i.e. Arrow's dispatch + output allocation + the
+    host-visible count sync on top of the C-ABI figure."""
+    import ctypes
+
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    from pyarrow import acero
+
+    from arrow_amd.plugin_build import build_plugin
+
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(k) for k in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    n = min(args.rows, args.callfunction_rows)
+    n -= n % 64
+    # host copies of the same HBM buffers (D2H once; the device-resident pyarrow arrays are then made from them
+    # through the plugin's own copy_to_device, i.e. the route an Arrow user takes)
+    hv = pa.Array.from_buffers(pa.int64(), n, [pa.py_buffer(validity[: n // 8].cpu().numpy()),
+                                               pa.py_buffer(values[: n * 8].cpu().numpy())], null_count=-1)
+    hm = pa.Array.from_buffers(pa.bool_(), n, [None, pa.py_buffer(mask[: n // 8].cpu().numpy())], null_count=0)
+    dv, dm = to_device(hv), to_device(hm)
+    res = {"rows": n}
+
+    def timeit(name, fn, reps=5):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+            del r
+        res[name] = {"ms_min": round(min(ts) * 1e3, 3), "ms_median": round(sorted(ts)[len(ts) // 2] * 1e3, 3)}
+
+    g0 = {f: lib.arrow_amd_plugin_calls(f, 1) for f in (b"array_filter", b"array_take")}
+    timeit("pc.filter(device int64, device mask 10%)", lambda: pc.filter(dv, dm))
+    idx = pc.filter(to_device(pa.array(np.arange(n, dtype=np.uint32))), dm)
+    timeit("pc.take(device int64, device uint32 indices)", lambda: pc.take(dv, idx, boundscheck=False))
+    res["gpu_kernel_calls"] = {f.decode(): int(lib.arrow_amd_plugin_calls(f, 1) - g0[f]) for f in g0}
+    del dv, dm, idx, hv, hm
+    # group-by through Acero: table_source -> aggregate_rocm (the fused device operator) on device-resident columns
+    m = min(n, 1 << 28)
+    k = pa.array(gen_stream(m, device, 0, 8, modulo=args.groups, dtype=torch.int32).cpu().numpy())
+    v = pa.array(gen_stream(m, device, 0, 9).cpu().numpy())
+    dt = pa.table({"k": to_device(k), "v": to_device(v)})
+    plan = acero.Declaration.from_sequence([
+        acero.Declaration("table_source", acero.TableSourceNodeOptions(dt)),
+        acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"]))])
+    timeit(f"acero table_source -> aggregate_rocm (hash_sum, {m} device rows, {args.groups} keys)",
+           lambda: plan.to_table(use_threads=False), reps=3)
+    return res
+
+
+def hash_sum_leg(args, rank, world, device, rows_total, steps, warmup):
+    sec, rows, groups_out, checksum, ok = measure_hash_sum(rank, world, device, rows_total, args.groups, steps, warmup)
+    per_gpu = 12 * rows / world / sec / 1e9
+    leg = {"rows": rows, "groups": groups_out, "n_gpus": world, "ms": round(sec * 1e3, 3),
+           "mrows_per_s": round(rows / sec / 1e6, 1), "scaling": "strong",
+           "exchange": "local aggregate -> 1 count exchange + ONE all-to-all(v) of 24-byte partials -> merge" if world > 1 else "none (one rank)",
+           "checksum_matches_sum_of_values": ok,
+           "roofline": {"bound": "hbm", "kernel": "arx_groupby_sum_i64_consume (gbp_hist + 2 scatter levels + LDS aggregate)",
+                        "achieved": round(per_gpu, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 12,
+                        "traffic": load_traffic("groupby", rows // world)}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not EMU:
+        try:
+            leg["cpu_baseline"] = cpu_baseline_hash_sum(min(rows, args.cpu_groupby_rows), args.groups, args.cpu_budget_s)
+        except Exception as e:
+            leg["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return leg
+
+
+def sort_leg(args, rank, world, device, rows_total, steps, warmup):
+    sec, rows, ok = measure_sort(rank, world, device, rows_total, steps, warmup)
+    per_gpu = 16 * rows / world / sec / 1e9
+    leg = {"rows": rows, "n_gpus": world, "ms": round(sec * 1e3, 3), "mrows_per_s": round(rows / sec / 1e6, 1),
+           "scaling": "strong",
+           "exchange": "1 all-reduce (splitter histogram) + 1 count exchange + ONE all-to-all(v) of 12-byte records" if world > 1 else "none (one rank)",
+           "permutation_and_order_checks": ok,
+           "roofline": {"bound": "hbm", "kernel": "arx_sort_indices (msd_hist + scatter levels + LDS bucket finish)",
+                        "achieved": round(per_gpu, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 16,
+                        "traffic": load_traffic("sort", rows // world)}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not EMU:
+        try:
+            leg["cpu_baseline"] = cpu_baseline_sort(min(rows, args.cpu_sort_rows))
+        except Exception as e:
+            leg["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return leg
 
 
 def measure_hash_sum(rank, world, device, rows_total, groups, steps, warmup):
-    """Sharded group-by: each rank owns rows_total // world contiguous rows.  Returns
-    (seconds per step [max over ranks], rows actually processed, groups out, checksum)."""
+    """Sharded group-by: rank g owns rows [g n, (g+1) n) of the streams (n = rows_total // world).  Returns
+    (seconds per step [max over ranks], rows actually processed, groups out, checksum, ok)."""
     import arrow_amd as amd
     from arrow_amd import parallel
 
     n = rows_total // world
-    g = torch.Generator(device=device).manual_seed(4321 + rank)
-    keys = torch.empty(n, dtype=torch.int32, device=device)
-    vals = torch.empty(n, dtype=torch.int64, device=device)
-    chunk = 1 << 26
-    for b in range(0, n, chunk):
-        e = min(n, b + chunk)
-        keys[b:e] = torch.randint(0, groups, (e - b,), dtype=torch.int32, device=device, generator=g)
-        vals[b:e] = torch.randint(-2**63, 2**63 - 1, (e - b,), dtype=torch.int64, device=device, generator=g)
+    keys = gen_stream(n, device, rank * n, 8, modulo=groups, dtype=torch.int32)
+    vals = gen_stream(n, device, rank * n, 9)
     kk = amd.Array(amd.array.int32, n, [None, keys.view(torch.uint8)], 0, 0)
     vv = amd.Array(amd.array.int64, n, [None, vals.view(torch.uint8)], 0, 0)
     cap = 1
@@ -386,22 +788,17 @@ def measure_hash_sum(rank, world, device, rows_total, groups, steps, warmup):
     def step():
         return parallel.sharded_group_by_sum(kk, vv, cap)
 
+    res = None
     for _ in range(warmup):
         res = step()
-    if world > 1:
-        torch.distributed.barrier()
+    _barrier(world)
     _sync(device)
     t0 = time.perf_counter()
     for _ in range(steps):
         res = step()
     _sync(device)
-    if world > 1:
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    _barrier(world)
+    elapsed = _max_over_ranks(time.perf_counter() - t0, world, device)
     # parity property independent of the sharding: sum of all group sums == wrap-around sum of
     # all values; number of groups == distinct keys
     sums = res[2]
@@ -423,33 +820,24 @@ def measure_sort(rank, world, device, rows_total, steps, warmup):
     from arrow_amd import parallel
 
     n = rows_total // world
-    g = torch.Generator(device=device).manual_seed(1010 + rank)
-    keys = torch.empty(n, dtype=torch.int64, device=device)
-    chunk = 1 << 26
-    for b in range(0, n, chunk):
-        e = min(n, b + chunk)
-        keys[b:e] = torch.randint(-2**63, 2**63 - 1, (e - b,), dtype=torch.int64, device=device, generator=g)
+    keys = gen_stream(n, device, rank * n, 10)
     ak = amd.Array(amd.array.uint64, n, [None, keys.view(torch.uint8)], 0, 0)
+    chunk = 1 << 26
 
     def step():
         return parallel.sharded_sort_indices(ak)
 
+    rows = start = None
     for _ in range(warmup):
         rows, start = step()
-    if world > 1:
-        torch.distributed.barrier()
+    _barrier(world)
     _sync(device)
     t0 = time.perf_counter()
     for _ in range(steps):
         rows, start = step()
     _sync(device)
-    if world > 1:
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    _barrier(world)
+    elapsed = _max_over_ranks(time.perf_counter() - t0, world, device)
     total = n * world
     m = int(rows.numel())
     s1, s2 = 0, 0
@@ -469,7 +857,6 @@ def measure_sort(rank, world, device, rows_total, steps, warmup):
         torch.distributed.all_gather(parts, cs)
     else:
         parts = [cs]
-    mask64 = (1 << 64) - 1
     got_s1 = sum(int(p[1].item()) for p in parts)
     got_s2 = sum(int(p[2].item()) for p in parts)
     ok = sum(int(p[0].item()) for p in parts) == total
@@ -491,57 +878,131 @@ def measure_sort(rank, world, device, rows_total, steps, warmup):
 
 
 def run_hash_sum(args, rank, world, device):
-    sec, rows, groups_out, checksum, ok = measure_hash_sum(rank, world, device, args.rows, args.groups,
-                                                           args.steps, args.warmup)
-    ms = sec * 1e3
+    leg = hash_sum_leg(args, rank, world, device, args.rows, args.steps, args.warmup)
     return {
-        "metric": "hash_sum_mrows_per_s", "value": round(rows / sec / 1e6, 2),
+        "metric": "hash_sum_mrows_per_s", "value": leg["mrows_per_s"],
         "unit": "Mrows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": leg["ms"], "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-        "config": {"workload": f"hash_sum(int64) GROUP BY int32, {rows} rows, {args.groups} distinct keys",
-                   "rows": rows, "groups_out": groups_out,
-                   "sum_of_sums_checksum": checksum, "checksum_matches_sum_of_values": ok,
-                   "parallelism": f"row shards x{world} + partition + all-to-all of partials"},
-        "roofline": {"bound": "hbm", "kernel": "gbp_scatter1/2 + gbp_aggregate (whole consume)",
-                     "achieved": round(12 * rows / world / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(12 * rows / world / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
+        "config": {"workload": f"hash_sum(int64) GROUP BY int32, {leg['rows']} rows, {args.groups} distinct keys "
+                               "(splitmix64 streams, seeds 8/9)",
+                   "rows": leg["rows"], "groups_out": leg["groups"],
+                   "checksum_matches_sum_of_values": leg["checksum_matches_sum_of_values"],
+                   "parallelism": f"row shards x{world} + one all-to-all of partials"},
+        "roofline": leg["roofline"], **({"cpu_baseline": leg["cpu_baseline"]} if "cpu_baseline" in leg else {}),
     }
 
 
+def run_sort(args, rank, world, device):
+    leg = sort_leg(args, rank, world, device, args.rows, args.steps, args.warmup)
+    return {
+        "metric": "sort_indices_mrows_per_s", "value": leg["mrows_per_s"],
+        "unit": "Mrows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": leg["ms"], "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "uint64", "data": "synthetic",
+        "config": {"workload": f"array_sort_indices uint64[{leg['rows']}] (splitmix64 stream, seed 10)",
+                   "rows": leg["rows"], "permutation_and_order_checks": leg["permutation_and_order_checks"],
+                   "parallelism": f"row shards x{world} + one all-to-all of (key, row) records"},
+        "roofline": leg["roofline"], **({"cpu_baseline": leg["cpu_baseline"]} if "cpu_baseline" in leg else {}),
+    }
+
+
+# ------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks: int, argv: list) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks (one process per GPU), pass rank 0's
+    stdout through (the JSON line), wait for all; a failing rank ends the others (by PID)."""
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = set(range(n_ranks))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                log(f"[bench launcher] rank {r} exited with {code}; stopping the other ranks")
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
+    global EMU
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="filter_take", choices=["filter_take", "hash_sum"])
+    ap.add_argument("--workload", default="filter_take", choices=["filter_take", "hash_sum", "sort_indices"])
     ap.add_argument("--rows", type=int, default=None)
     ap.add_argument("--groups", type=int, default=10_000_000)
     ap.add_argument("--hash-sum-rows", dest="hash_sum_rows", type=int, default=4_000_000_000)
     ap.add_argument("--sort-rows", dest="sort_rows", type=int, default=2_000_000_000)
+    ap.add_argument("--stream-rows", dest="stream_rows", type=int, default=1_000_000_000,
+                    help="rows of the cast / greater legs (config 3)")
+    ap.add_argument("--callfunction-rows", dest="callfunction_rows", type=int, default=1_000_000_000)
     ap.add_argument("--extras-timeout", dest="extras_timeout", type=float, default=300.0)
     ap.add_argument("--selectivity", type=float, default=0.10)
     ap.add_argument("--null-p", dest="null_p", type=float, default=0.10)
     ap.add_argument("--cpu-sample-rows", type=int, default=250_000_000)
+    ap.add_argument("--cpu-groupby-rows", dest="cpu_groupby_rows", type=int, default=50_000_000)
+    ap.add_argument("--cpu-sort-rows", dest="cpu_sort_rows", type=int, default=30_000_000)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", dest="extras", action="store_false")
     ap.add_argument("--option", action="append", default=[], help="name=value for arx_set_option")
+    ap.add_argument("--backend", default="hip", choices=["hip", "emu"],
+                    help="emu = CPU tensors + gloo + the SIMT emulator of tests/emu (plumbing tests only)")
     args = ap.parse_args()
     if args.rows is None:
-        args.rows = 1_000_000_000 if args.workload == "filter_take" else 4_000_000_000
+        args.rows = {"filter_take": 1_000_000_000, "hash_sum": 4_000_000_000, "sort_indices": 2_000_000_000}[args.workload]
+    EMU = args.backend == "emu"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not EMU:
+            assert torch.cuda.is_available(), "bench.py needs HIP devices (no CPU fallback exists)"
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                log(f"[bench launcher] --gpus {args.gpus} but only {have} device(s) visible")
+                sys.exit(2)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback exists)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)
+    if EMU:
+        device = torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+        import arrow_amd as amd
+        from arrow_amd import _lib, array
+        from tests.emu.build_emu import build as build_emu      # test plumbing: kernel sources under the emulator
 
-    import arrow_amd as amd
+        _lib._lib = _lib.load(build_emu())
+        array.set_default_device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback exists)"
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.distributed.init_process_group("nccl", device_id=device)
+        import arrow_amd as amd
     lib = amd._lib.get_lib()
     for kv in args.option:
         k, v = kv.split("=")
@@ -549,8 +1010,10 @@ def main():
 
     if args.workload == "filter_take":
         result = run_filter_take(args, rank, world, device)
-    else:
+    elif args.workload == "hash_sum":
         result = run_hash_sum(args, rank, world, device)
+    else:
+        result = run_sort(args, rank, world, device)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ARX_ABI_VERSION 2
+#define ARX_ABI_VERSION 3
 
 /* arrow::StatusCode twins (cpp/src/arrow/status.h:83-107). */
 typedef enum ArxStatus {
@@ -391,6 +391,26 @@ int arx_sort_partition_by_bins(const ArxSpan* values, int is_signed, int order, 
 int arx_bitmap_to_indices(const void* bits, int64_t bit_offset, int64_t length, int invert, void* ws,
                           size_t ws_bytes, uint32_t* out_indices, int64_t* out_count /* host */,
                           void* stream);
+/* The same exchange with ONE buffer per peer.  arx_sort_partition_records = arx_sort_partition_by_bins with the
+ * output packed as 12-byte records {order-transformed key, local row}, destination-major; the shard's null rows
+ * (row order kept, keys 0) ride in the same buffer — after all valid records (ARX_NULLS_AT_END: they belong to the
+ * last rank's block) or before them (ARX_NULLS_AT_START: the first rank's block); *out_num_valid (host) tells the
+ * two parts apart.  arx_sort_unpack_records is the receiver: `records` = the blocks of all source ranks in rank
+ * order, block_meta (device int64[num_blocks][3]) = {valid records, null records, global row number of the source's
+ * row 0}; it writes the valid records' keys and GLOBAL rows compacted in source order (what keeps equal keys in
+ * global row order) and the null rows' global numbers likewise.  Asynchronous. */
+typedef struct ArxSortRecord {
+  uint32_t key_lo, key_hi; /* order-transformed key: unsigned ascending order = the requested order */
+  uint32_t row;            /* row number inside the sender's shard */
+} ArxSortRecord;
+int arx_sort_partition_records(const ArxSpan* values, int is_signed, int order, int null_placement, int bits,
+                               const uint32_t* splitter_bins /* host */, int num_parts, void* ws, size_t ws_bytes,
+                               ArxSortRecord* out_records /* values->length entries */,
+                               int64_t* out_counts /* device int64[num_parts]: valid records per destination */,
+                               int64_t* out_num_valid /* host */, void* stream);
+int arx_sort_unpack_records(const ArxSortRecord* records, int64_t num_records, const int64_t* block_meta,
+                            int num_blocks, int nulls_first, uint64_t* out_keys, int64_t* out_rows,
+                            int64_t* out_null_rows, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Group-by hash_sum(int64) BY int32 key — replaces, as one fused device operator,
@@ -478,6 +498,25 @@ int arx_groupby_partition(const int32_t* keys, const uint8_t* key_is_valid, cons
                           int num_parts, void* ws, size_t ws_bytes, int32_t* out_keys,
                           uint8_t* out_key_is_valid, int64_t* out_sums, int64_t* out_counts,
                           uint8_t* out_no_nulls, int64_t* out_part_counts, void* stream);
+
+/* The same exchange with ONE buffer per peer: a state's groups leave as 24-byte records grouped by
+ * destination rank (no dense column export in between), so the multi-GPU group-by is one count
+ * exchange + one all-to-all(v) of bytes; the receiver folds the records in with Merge semantics
+ * (hash_aggregate_numeric.cc:85-107).  out_records needs arx_groupby_num_groups entries.
+ * export: synchronous on entry (reads the header), kernels asynchronous.  merge: asynchronous. */
+typedef struct ArxGroupPartial {
+  int64_t sum;          /* wrap-around partial sum */
+  int64_t count;        /* valid values folded into it */
+  int32_t key;
+  uint8_t key_is_valid; /* 0 = the null-key group */
+  uint8_t no_nulls;     /* 0 once a null value hit the group */
+  uint8_t pad[2];
+} ArxGroupPartial;
+int arx_groupby_export_partitioned(void* state, int num_parts, void* ws /* arx_groupby_partition_workspace_bytes */,
+                                   size_t ws_bytes, ArxGroupPartial* out_records,
+                                   int64_t* out_part_counts /* device int64[num_parts] */, void* stream);
+int arx_groupby_sum_i64_merge_records(void* state, int64_t capacity, const ArxGroupPartial* records,
+                                      int64_t num_records, void* stream);
 
 /* ---------------------------------------------------------------------------
  * hash_sum(int64, uint32 group id) — the HashAggregateKernel boundary itself

@@ -28,18 +28,17 @@ for it in range(3):
     t[0].record()
     local = GroupBySum(cap, dev); t[1].record()
     local.consume(kk, vv); t[2].record()
-    partial = local.export(); t[3].record()
-    parts, counts = parallel.partition_partials(partial, world, dev); t[4].record()
+    t[3].record()
+    records, counts = parallel.export_partitioned(local, world); t[4].record()
     c = counts.cpu().tolist()
-    # emulate the received partials: `world` slices of the size this rank would receive
-    off = 0; recv = []
-    mine = {k_: v_[: c[0]] for k_, v_ in parts.items()}
+    # emulate the received partials: `world` blocks of the size this rank would receive
+    mine = records[: c[0] * parallel.RECORD_BYTES]
     owned = GroupBySum(max(16, 2 * world * c[0] + 2), dev)
     for r in range(world):
-        owned.merge(mine)
+        parallel.merge_records(owned, mine)
     t[5].record()
     out = owned.finalize(); t[6].record()
     torch.cuda.synchronize()
-    names = ["init", "consume", "export", "partition", "merge(8x)+init", "finalize"]
+    names = ["init", "consume", "-", "export_partitioned", "merge(8x)+init", "finalize"]
     print(" | ".join(f"{nm} {t[i].elapsed_time(t[i+1]):.2f}" for i, nm in enumerate(names)),
           "| total %.2f ms" % t[0].elapsed_time(t[6]), "| groups/rank", c[0], flush=True)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import arrow_amd as amd, bench
 dev = torch.device("cuda", 0)
 n = 1_000_000_000
-values, validity, mask = bench.gen_filter_inputs(n, dev, 1234, 0.10, 0.10)
+values, validity, mask, _ = bench.gen_filter_inputs(n, dev, 0, 0.10, 0.10)
 a = amd.Array(amd.array.int64, n, [validity, values], -1, 0)
 agg = amd.compute.Int64Aggregator(dev)
 agg.consume(a); torch.cuda.synchronize()

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} is declared in include/arrow_amd.h but not exported"
     loaded = _lib.load()
-    assert loaded.arx_abi_version() == 2
+    assert loaded.arx_abi_version() == 3
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -429,7 +429,7 @@ def test_sharded_sort_single_rank_pieces(gpu_ctx, order, placement):
 
 def test_groupby_virtual_ranks_on_one_gpu(gpu_ctx):
     """The multi-GPU hash_sum data path with P = 4 virtual ranks on one device: per-rank local
-    aggregate -> device partition of the partials by hash(key) % P -> exchange (slicing stands in
+    aggregate -> partials exported as records grouped by hash(key) % P -> exchange (slicing stands in
     for the all-to-all) -> merge -> finalize; the union must be the oracle's result and every key
     must be owned by exactly one rank."""
     import torch
@@ -448,16 +448,17 @@ def test_groupby_virtual_ranks_on_one_gpu(gpu_ctx):
     for k, v in shards:
         local = amd.compute.GroupBySum(1 << 18, k.to_device(amd).device)
         local.consume(k.to_device(amd), v.to_device(amd))
-        pr, cnt = parallel.partition_partials(local.export(), P_, local.device)
-        parts.append(pr)
+        records, cnt = parallel.export_partitioned(local, P_)      # 24-byte records, destination-major
+        parts.append(records)
         counts.append([int(x) for x in cnt.cpu().tolist()])
+        assert records.numel() == parallel.RECORD_BYTES * sum(counts[-1]) == parallel.RECORD_BYTES * local.num_groups()
     got = {}
     for dst in range(P_):
-        owned = amd.compute.GroupBySum(1 << 18, parts[0]["keys"].device)
+        owned = amd.compute.GroupBySum(1 << 18, parts[0].device)
         for src in range(P_):
-            lo = sum(counts[src][:dst])
-            hi = lo + counts[src][dst]
-            owned.merge({name: col[lo:hi].contiguous() for name, col in parts[src].items()})
+            lo = sum(counts[src][:dst]) * parallel.RECORD_BYTES
+            hi = lo + counts[src][dst] * parallel.RECORD_BYTES
+            parallel.merge_records(owned, parts[src][lo:hi])
         gk, gkv, gs, gvalid = owned.finalize()
         for key, kv, s, ok in zip(gk.cpu().tolist(), gkv.cpu().tolist(), gs.cpu().tolist(), gvalid.cpu().tolist()):
             ident = (bool(kv), key if kv else 0)
@@ -600,6 +601,82 @@ def test_sort_virtual_ranks_on_one_gpu(gpu_ctx):
     want = O.sort_indices_64(np.ascontiguousarray(vals), O.pack_bits(valid), 0, len(vals))
     n_valid = int(valid.sum())
     assert (got == want[:n_valid]).all()        # nulls travel separately (row numbers only)
+
+
+@pytest.mark.parametrize("placement", ["at_end", "at_start"])
+def test_sort_records_virtual_ranks_on_one_gpu(gpu_ctx, placement):
+    """The ONE-buffer exchange of the sharded sort with P = 3 virtual ranks: arx_sort_partition_records packs
+    {transformed key, local row} records destination-major with the shard's null rows in the last / first rank's
+    block; slicing stands in for the all-to-all(v); arx_sort_unpack_records rebuilds keys + global rows in source
+    order; local stable sort + gather.  Concatenated over ranks = the oracle's argsort, nulls included."""
+    import ctypes as C
+
+    import torch
+
+    amd = gpu_ctx
+    lib = amd._lib.get_lib()
+    from arrow_amd import parallel
+    from arrow_amd.array import alloc, current_stream
+
+    P_, bits = 3, 12
+    nulls_first = placement == "at_start"
+    target = 0 if nulls_first else P_ - 1
+    rng = rng_for("vsortrec", placement)
+    shards = [U.random_array(rng, np.int64, 200_000 + 5_003 * r, null_p=0.03 if r != 1 else 0.0, offset=r + 2) for r in range(P_)]
+    for a in shards:
+        a.values[a.offset:a.offset + a.length:3] %= 50
+    dev = [a.to_device(amd) for a in shards]
+    device = dev[0].device
+    stream = current_stream(device)
+    offsets = [int(x) for x in np.cumsum([0] + [a.length for a in shards])]
+    hist = torch.zeros(1 << bits, dtype=torch.int64, device=device)
+    for d in dev:
+        sp = d.span()
+        amd._lib.check(lib.arx_sort_key_histogram(C.byref(sp), 1, 1, bits, hist.data_ptr(), stream))
+    cum = torch.cumsum(hist, 0).cpu().numpy()
+    total = int(cum[-1])
+    split = [int(np.searchsorted(cum, (total * p + P_ - 1) // P_) + 1) for p in range(1, P_)]
+    split_arr = (C.c_uint32 * len(split))(*split)
+    sent = []
+    for r, d in enumerate(dev):
+        n = d.length
+        ws = alloc(lib.arx_sort_indices_workspace_bytes(n) + 256, device)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        rec = torch.empty(n * parallel.SORT_RECORD_BYTES, dtype=torch.uint8, device=device)
+        counts = torch.zeros(P_, dtype=torch.int64, device=device)
+        nv = C.c_int64(0)
+        sp = d.span()
+        amd._lib.check(lib.arx_sort_partition_records(C.byref(sp), 1, 1, 0 if nulls_first else 1, bits, split_arr, P_,
+                                                      ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()), rec.data_ptr(),
+                                                      counts.data_ptr(), C.byref(nv), stream))
+        torch.cuda.synchronize()
+        sent.append((rec, counts.cpu().tolist(), nv.value, n - nv.value))
+    out = []
+    for dst in range(P_):
+        blocks, meta = [], []
+        for src, (rec, counts, nv, nnull) in enumerate(sent):
+            send = [counts[p] + (nnull if p == target else 0) for p in range(P_)]
+            lo = sum(send[:dst]) * parallel.SORT_RECORD_BYTES
+            blocks.append(rec[lo: lo + send[dst] * parallel.SORT_RECORD_BYTES])
+            meta.append([counts[dst], nnull if dst == target else 0, offsets[src]])
+        got = torch.cat(blocks).contiguous()
+        mv, mn = sum(m[0] for m in meta), sum(m[1] for m in meta)
+        meta_t = torch.tensor(meta, dtype=torch.int64).to(device)
+        keys = torch.empty(max(mv, 1), dtype=torch.int64, device=device)
+        grows = torch.empty(max(mv, 1), dtype=torch.int64, device=device)
+        nrows = torch.empty(max(mn, 1), dtype=torch.int64, device=device)
+        amd._lib.check(lib.arx_sort_unpack_records(got.data_ptr(), mv + mn, meta_t.data_ptr(), P_, int(nulls_first),
+                                                   keys.data_ptr(), grows.data_ptr(), nrows.data_ptr(), stream))
+        karr = amd.Array(amd.array.uint64, mv, [None, keys.view(torch.uint8)], 0, 0)
+        perm = amd.compute.sort_indices(karr).data[: mv * 8].view(torch.int64)
+        piece = grows[:mv][perm]
+        out.append(torch.cat([nrows[:mn], piece]) if nulls_first else torch.cat([piece, nrows[:mn]]))
+    got = torch.cat(out).cpu().numpy().astype(np.uint64)
+    vals = np.concatenate([a.values[a.offset:a.offset + a.length] for a in shards])
+    valid = np.concatenate([np.ones(a.length, bool) if a.valid is None else a.valid[a.offset:a.offset + a.length] for a in shards])
+    want = O.sort_indices_64(np.ascontiguousarray(vals), O.pack_bits(valid), 0, len(vals), descending=True,
+                             nulls_at_start=nulls_first)
+    assert (got == want).all()
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.uint64, np.int32])

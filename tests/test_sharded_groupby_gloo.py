@@ -169,45 +169,66 @@ def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement):
     assert min(len(r["rows"]) for r in ranks) > len(vals) // 4, "splitters should balance the ranks"
 
 
-BENCH_WORKER = textwrap.dedent(r'''
-    import os, sys, json
-    import torch, torch.distributed as dist
-    sys.path.insert(0, ROOT)
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from arrow_amd import _lib, array
-    from tests.emu.build_emu import build
-    _lib._lib = _lib.load(build())
-    array.set_default_device("cpu")
+def test_bench_launcher_starts_two_ranks_end_to_end():
+    """`python bench.py --gpus 2` with NO launcher around it (WORLD_SIZE unset): bench.py must start the two ranks
+    itself, rendezvous on 127.0.0.1, run the replica headline and both sharded legs (hash_sum: one all-to-all of
+    partial records; sort_indices: one all-to-all of (key, row) records) and rank 0 must print ONE JSON line with
+    n_gpus = 2.  The emulated backend (CPU tensors + gloo + kernel sources under the SIMT emulator) stands in for
+    HIP + RCCL: same file, same code path above the device."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "emu", "--rows", "20000",
+           "--steps", "1", "--warmup", "1", "--hash-sum-rows", "40000", "--groups", "700", "--sort-rows", "30000",
+           "--stream-rows", "20000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "replicas"
+    assert line["hash_sum"]["n_gpus"] == 2 and line["hash_sum"]["rows"] == 40000 and line["hash_sum"]["groups"] == 700
+    assert line["hash_sum"]["checksum_matches_sum_of_values"] is True
+    assert "ONE all-to-all" in line["hash_sum"]["exchange"]
+    assert line["sort_indices"]["n_gpus"] == 2 and line["sort_indices"]["rows"] == 30000
+    assert line["sort_indices"]["permutation_and_order_checks"] is True
+    for leg in ("hash_sum", "sort_indices"):
+        assert line[leg]["roofline"]["bound"] == "hbm"
+
+
+def test_bench_single_rank_line_has_every_leg():
+    """N = 1 on the emulated backend: the JSON line carries roofline, the secondary configurations of SURVEY.md 8(d)
+    and both sharded legs; the device streams equal their numpy twins (parity_spot_check covers that)."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "emu", "--rows", "20000", "--steps", "1",
+           "--warmup", "1", "--hash-sum-rows", "20000", "--groups", "300", "--sort-rows", "10000", "--stream-rows",
+           "10000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["parity_spot_check"] == "ok"
+    other = line["other_paths"]
+    assert other["cast_f64_f32"]["bit_exact_vs_round_to_nearest_even_sample"] is True
+    for name in ("filter_drop_5pct_mask_nulls", "filter_emit_null_5pct_mask_nulls", "take_random_uint32",
+                 "take_monotonic_boundscheck", "filter_drop_selectivity_25pct", "filter_drop_selectivity_50pct"):
+        assert name in other["secondary_configs"]
+    assert {"greater_f64", "sort_indices_u64_1pct_nulls", "hash_sum_1pct_null_values"} <= set(other)
+    assert line["hash_sum"]["checksum_matches_sum_of_values"] and line["sort_indices"]["permutation_and_order_checks"]
+
+
+def test_bench_streams_match_their_numpy_twins():
+    import numpy as np
+    import torch
+
     import bench
-    sec, rows, groups_out, checksum, ok = bench.measure_hash_sum(rank, world, torch.device("cpu"), 40000, 700, 1, 1)
-    assert ok and rows == 40000 and groups_out == 700, (ok, rows, groups_out)
-    sec, srows, sok = bench.measure_sort(rank, world, torch.device("cpu"), 30000, 1, 1)
-    assert sok and srows == 30000, (sok, srows)
-    if rank == 0:
-        print("BENCH_HASH_SUM_OK", json.dumps(dict(rows=rows, groups=groups_out, sort_rows=srows)))
-    dist.barrier()
-    dist.destroy_process_group()
-''')
 
-
-def test_bench_measure_hash_sum_world2_gloo():
-    """bench.py's own multi-rank hash_sum and sort_indices legs (the code the driver's --gpus N run executes),
-    world_size 2 over gloo: rows sharded, partials exchanged, checksum == sum of all values."""
-    code = f"ROOT = {ROOT!r}\n" + BENCH_WORKER
-    port = 33500 + (os.getpid() % 2000)
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, cwd=ROOT,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    logs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=600)
-        except subprocess.TimeoutExpired:
-            p.kill()
-            o, _ = p.communicate()
-        logs.append(o)
-    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
-    assert any("BENCH_HASH_SUM_OK" in l for l in logs)
+    for first, seed in ((0, 1), (12345, 9), (2**40 + 7, 10)):
+        dev = bench.splitmix64(first, 1000, seed, torch.device("cpu")).numpy().view(np.uint64)
+        assert (dev == bench.splitmix64_np(first, 1000, seed)).all()
+    z = bench.splitmix64(0, 5000, 2, torch.device("cpu"))
+    assert (bench.umod(z, 100).numpy() == (bench.splitmix64_np(0, 5000, 2) % np.uint64(100)).astype(np.int64)).all()
+    x = bench.gen_cast_mix(20000, torch.device("cpu")).numpy()
+    big = np.abs(x[np.isfinite(x)]) > 3.4028234663852886e38
+    assert 0.03 < big.mean() < 0.08 and np.isnan(x).any() and np.isinf(x).any()
