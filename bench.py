@@ -299,9 +299,8 @@ def cpu_baseline_filter_take(values, validity, mask, n_total: int, sample_rows: 
     varr = pa.Array.from_buffers(pa.int64(), n, [pa.py_buffer(hval), pa.py_buffer(hv)], null_count=-1)
     marr = pa.Array.from_buffers(pa.bool_(), n, [None, pa.py_buffer(hm)], null_count=0)
     table = pa.table({"v": varr})
-    saved = pa.cpu_count()
-    # (i) one thread
-    pa.set_cpu_count(1)
+    # (i) one thread: a CallFunction on one contiguous array never leaves the calling thread (exec.cc:1144).
+    # (The CPU pool is never resized here: Acero sizes its per-thread state once, at first use.)
     reps, t_total = 0, 0.0
     while reps < 2 or (t_total < budget_s / 2 and reps < 8):
         t0 = time.perf_counter()
@@ -312,8 +311,7 @@ def cpu_baseline_filter_take(values, validity, mask, n_total: int, sample_rows: 
         del a, b
     single = n * reps / t_total / 1e6
     # (ii) Acero, all cores: the same two results (filtered column twice) from one threaded plan per path
-    threads = max(1, min(cores_all, 64))
-    pa.set_cpu_count(threads)
+    threads = pa.cpu_count()
     tm = pa.table({"v": varr, "m": marr})
     plan = acero.Declaration.from_sequence([
         acero.Declaration("table_source", acero.TableSourceNodeOptions(tm)),
@@ -332,7 +330,6 @@ def cpu_baseline_filter_take(values, validity, mask, n_total: int, sample_rows: 
     except Exception as e:  # pragma: no cover - informational
         multi, reps2 = 0.0, 0
         log(f"[cpu_baseline] Acero plan failed: {e}")
-    pa.set_cpu_count(saved)
     best = max(single, multi)
     return {"value": round(best, 2), "unit": "Mrows/s", "cores": 1 if single >= multi else threads,
             "kind": "reference",
@@ -355,17 +352,14 @@ def cpu_baseline_hash_sum(rows: int, groups: int, budget_s: float):
     v = splitmix64_np(0, n, 9).view(np.int64)
     t = pa.table({"k": pa.array(k), "v": pa.array(v)})
     res = {}
-    saved = pa.cpu_count()
     cores_all = _host_cores()
-    for name, threads in (("single_thread", 1), ("multi_thread", max(1, min(cores_all, 64)))):
-        pa.set_cpu_count(threads)
+    for name, threads in (("single_thread", 1), ("multi_thread", pa.cpu_count())):
         t0 = time.perf_counter()
         out = t.group_by("k", use_threads=threads > 1).aggregate([("v", "sum")])
         dt = time.perf_counter() - t0
         res[name] = (n / dt / 1e6, threads, out.num_rows)
         if dt > budget_s:
             break
-    pa.set_cpu_count(saved)
     best = max(res.values(), key=lambda x: x[0])
     return {"value": round(best[0], 2), "unit": "Mrows/s", "cores": best[1], "kind": "reference",
             "sample": f"DOWN-SCALED: first {n} rows of the same streams ({best[2]} groups), pyarrow {pa.__version__} "
@@ -381,12 +375,9 @@ def cpu_baseline_sort(rows: int):
         return None
     k = splitmix64_np(0, rows, 10)
     arr = pa.array(k)
-    saved = pa.cpu_count()
-    pa.set_cpu_count(1)
     t0 = time.perf_counter()
-    out = pc.sort_indices(arr)
+    out = pc.sort_indices(arr)       # one contiguous array: runs on the calling thread
     dt = time.perf_counter() - t0
-    pa.set_cpu_count(saved)
     del out
     return {"value": round(rows / dt / 1e6, 2), "unit": "Mrows/s", "cores": 1, "kind": "reference",
             "sample": f"DOWN-SCALED: first {rows} rows of the same stream, pyarrow {pa.__version__} pc.sort_indices "
@@ -540,6 +531,15 @@ def run_filter_take(args, rank, world, device):
             result["sort_indices"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if watchdog is not None:
         watchdog.cancel()
+    if args.extras and rank == 0 and world == 1 and not EMU:
+        # LAST: registering the plugin re-routes pyarrow's own kernels to the GPU for the rest of the process,
+        # so every CPU baseline above had to be taken first
+        try:
+            torch.cuda.empty_cache()
+            values, validity, mask, _ = gen_filter_inputs(args.rows, device, 0, args.null_p, args.selectivity)
+            result.setdefault("other_paths", {})["callfunction"] = callfunction_leg(args, values, validity, mask, device)
+        except Exception as e:
+            result.setdefault("other_paths", {})["callfunction"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return result
 
 
@@ -632,13 +632,7 @@ def run_other_paths(amd, device, args):
           8 * n + n / 4 + 8.125 * ssel)
         del msel, dms
     out["secondary_configs"] = {"rows": n, "selected_rows": int(S), **sec}
-    del mvalid, dv, dm, dmn, mono, ridx, di
-    if not EMU:
-        try:
-            out["callfunction"] = callfunction_leg(args, values, validity, mask, device)
-        except Exception as e:
-            out["callfunction"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-    del values, validity, mask
+    del values, validity, mask, mvalid, dv, dm, dmn, mono, ridx, di
     if not EMU:
         torch.cuda.empty_cache()
     # ---- sort / hash_sum with 1 % nulls (secondary of configs 4 and 5), single GPU, 2^28 rows
@@ -790,11 +784,13 @@ def measure_hash_sum(rank, world, device, rows_total, groups, steps, warmup):
 
     res = None
     for _ in range(warmup):
+        res = None          # the previous result is released first: its buffers are what the next call reuses
         res = step()
     _barrier(world)
     _sync(device)
     t0 = time.perf_counter()
     for _ in range(steps):
+        res = None
         res = step()
     _sync(device)
     _barrier(world)
@@ -829,11 +825,13 @@ def measure_sort(rank, world, device, rows_total, steps, warmup):
 
     rows = start = None
     for _ in range(warmup):
+        rows = None         # release the previous 8 B/row result first: the next call reuses its buffer
         rows, start = step()
     _barrier(world)
     _sync(device)
     t0 = time.perf_counter()
     for _ in range(steps):
+        rows = None
         rows, start = step()
     _sync(device)
     _barrier(world)
