@@ -35,8 +35,9 @@ static int g_sort_msd_min_rows = 1 << 22;
 static int g_sort_msd_sampled = 1;     // skewed keys: bucket boundaries from a sorted sample
 static int g_sort_msd_fused = 1;       // finish LDS-sized level-2 buckets in one workgroup (msd_bucket_kernel)
 static int64_t g_sort_msd_segment_rows = int64_t(1) << 27;  // above this: an extra top-bits level cuts segments
-static int g_sort_msd_final_rows_log2 = 3;  // log2 of the rows aimed at per final sub-bucket (rank loop length); 4 is 7-10 % slower at >= 2^30 rows
+static int g_sort_msd_final_rows_log2 = 1;  // log2 of the rows aimed at per final sub-bucket (rank loop length); with the 4096-bin finish 1 beats 2 / 3 / 4 by 3 / 9 / 18 % at 2e9 rows
 static int g_sort_msd_small_bucket = 1;  // 512-thread / 5120-row bucket kernel when every bucket fits it
+static int g_sort_msd_bucket_v2 = 1;     // single-atomic-pass bucket finish with up to 4096 sub-buckets (msd_bucket2_kernel)
 static int g_sort_msd_seg_min_bits = 1;  // floor of the segment level's bits (more bins = fewer LDS atomic collisions)
 static int g_sort_msd_global_bits = 14;  // (= kMsdMaxBits) cap of the two global levels (tests lower it to reach level 3)
 static int g_sort_fuse_prep = 1;    // first pass reads the caller's column directly (no prep pass)
@@ -1175,6 +1176,132 @@ __global__ __launch_bounds__(T) void msd_bucket_kernel(MsdArgs a, const uint64_t
   }
 }
 
+// Second form of the LDS-resident finish (default; sort_msd_bucket_v2 = 0 selects the one above).  Same result,
+// cheaper phases:
+//   * ONE pass of LDS atomics: the returning add that counts a sub-bucket also hands the row its arrival rank
+//     inside it, so after the scan the row's LDS slot is start[digit] + rank (no second cursor pass);
+//   * up to 4096 (T = 1024) / 2048 (T = 512) sub-buckets instead of 1024, counters scanned in place: sub-buckets
+//     of ~2-4 rows make the final ranking loop one short iteration for almost every row (it was the dominant
+//     phase at ~8 rows: LDS reads grow with the square of the sub-bucket size).
+template <int T>
+struct __attribute__((aligned(16))) MsdBucket2Lds {
+  uint64_t keys[T * kBktRows];
+  uint32_t idx[T * kBktRows];
+  uint32_t start[4 * T + 1];     // counts, then exclusive starts (+ sentinel)
+  uint32_t wave_tot[T / 64];
+};
+
+template <bool SPL, int T>
+__global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ idx) {
+  __shared__ MsdBucket2Lds<T> w;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t q = blockIdx.x;
+  const int64_t lo = a.part_start[q];
+  const int m = static_cast<int>(static_cast<int64_t>(a.part_start[q + 1]) - lo);
+  if (m == 0) return;  // workgroup-uniform
+  if (m > T * kBktRows) {
+    if (tid == 0) atomicOr(a.overflow, 2u);
+    return;
+  }
+  const int nb = 1 << a.b3;   // <= NB (host)
+  const int dshift = 64 - a.bits - a.b3;
+  const uint32_t dmask = static_cast<uint32_t>(nb - 1);
+  uint64_t klo = 0;
+  double kinv = 0.0;
+  if constexpr (SPL) {
+    const uint32_t nparts = 1u << a.bits;
+    klo = q > 0 ? a.spl[q - 1] : 0;
+    const uint64_t khi = q + 1 < nparts ? a.spl[q] : ~uint64_t(0);
+    const double range = static_cast<double>(khi - klo) + 1.0;
+    kinv = static_cast<double>(nb) / range;
+  }
+  auto digit_of = [&](uint64_t k) -> uint32_t {
+    if constexpr (SPL) {
+      const uint32_t d = static_cast<uint32_t>(static_cast<double>(k - klo) * kinv);
+      return d < static_cast<uint32_t>(nb) ? d : static_cast<uint32_t>(nb - 1);
+    } else {
+      return a.b3 == 0 ? 0u : (static_cast<uint32_t>((k << a.kshift) >> dshift) & dmask);
+    }
+  };
+  for (int i = tid; i < nb; i += T) w.start[i] = 0;
+  uint64_t key[kBktRows];
+  uint32_t id[kBktRows];
+#pragma unroll
+  for (int i = 0; i < kBktRows; ++i) {   // unconditional loads (clamped): all round trips overlap
+    const int p = i * T + tid;
+    const int64_t r = lo + (p < m ? p : m - 1);
+    key[i] = keys[r];
+    id[i] = idx[r];
+  }
+  __syncthreads();
+  uint32_t dig[kBktRows], rank[kBktRows];
+#pragma unroll
+  for (int i = 0; i < kBktRows; ++i) {
+    dig[i] = digit_of(key[i]);
+    rank[i] = 0;
+    if (i * T + tid < m) rank[i] = atomicAdd(&w.start[dig[i]], 1u);
+  }
+  __syncthreads();
+  // in-place exclusive scan of nb <= 4 T counters: 4 consecutive counters per thread
+  uint32_t c[4];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int b = tid * 4 + k;
+    c[k] = b < nb ? w.start[b] : 0u;
+    mine += c[k];
+  }
+  const uint32_t incl = wave_inclusive_scan_u32(mine);
+  if (lane == 63) w.wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t pre = incl - mine;
+  for (int k = 0; k < wave; ++k) pre += w.wave_tot[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int b = tid * 4 + k;
+    if (b < nb) w.start[b] = pre;
+    pre += c[k];
+  }
+  if (tid == 0) w.start[nb] = static_cast<uint32_t>(m);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kBktRows; ++i) {
+    if (i * T + tid < m) {
+      const uint32_t pos = w.start[dig[i]] + rank[i];
+      w.keys[pos] = key[i];
+      w.idx[pos] = id[i];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < m; i += T) {
+    const uint64_t ki = w.keys[i];
+    const uint32_t ii = w.idx[i];
+    const uint32_t d = digit_of(ki);
+    const int bs = static_cast<int>(w.start[d]);
+    const int be = static_cast<int>(w.start[d + 1]);
+    int rk = 0;
+    for (int j = bs; j < be; j += 4) {
+      uint64_t kj[4];
+      uint32_t ij[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int jj = (j + u) < be ? (j + u) : (be - 1);
+        kj[u] = w.keys[jj];
+        ij[u] = w.idx[jj];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool less = kj[u] < ki || (kj[u] == ki && ij[u] < ii);
+        rk += (less && (j + u) < be) ? 1 : 0;
+      }
+    }
+    a.out_final[lo + bs + rk] = ii;
+  }
+}
+
 // part_count + part_start + cursor2 (2^14 + 1 each), hist1 (128 x 2048), l1_start, l2_tile_start, flag
 constexpr int kMsdSplBits = 15;  // sampled-splitter mode: up to 2^15 buckets
 constexpr size_t kMsdTableWords = (size_t(1) << kMsdSplBits) + 64;
@@ -1227,6 +1354,10 @@ int set_sort_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "sort_msd_final_rows_log2") == 0) {
     g_sort_msd_final_rows_log2 = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, 8)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_bucket_v2") == 0) {
+    g_sort_msd_bucket_v2 = value != 0;
     return 1;
   }
   if (strcmp(name, "sort_msd_small_bucket") == 0) {
@@ -1337,14 +1468,26 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   ARX_CHECK_LAUNCH("msd_scatter2_kernel");
   // level-2 buckets that fit LDS: finish each one in a single workgroup (b3 may use 10 bits there)
   if (fused) {
-    a.b3 = std::max(0, std::min(std::min(lg - (g_sort_msd_final_rows_log2 - 1) - a.bits, 10),
-                                64 - kshift - a.bits));  // default: ~4-8 rows per sub-bucket
-    if (g_sort_msd_small_bucket != 0 && max_part <= static_cast<unsigned int>(kBktCapSmall)) {
-      hipLaunchKernelGGL((msd_bucket_kernel<false, kBktThreadsSmall>), dim3(static_cast<unsigned>(nparts)),
-                         dim3(kBktThreadsSmall), 0, st, a, keys_y, idx_y);
+    const bool small = g_sort_msd_small_bucket != 0 && max_part <= static_cast<unsigned int>(kBktCapSmall);
+    const int want_b3 = lg - (g_sort_msd_final_rows_log2 - 1) - a.bits;   // default: ~4 rows per sub-bucket
+    if (g_sort_msd_bucket_v2) {
+      a.b3 = std::max(0, std::min(std::min(want_b3, small ? 11 : 12), 64 - kshift - a.bits));
+      if (small) {
+        hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsSmall>), dim3(static_cast<unsigned>(nparts)),
+                           dim3(kBktThreadsSmall), 0, st, a, keys_y, idx_y);
+      } else {
+        hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreads>), dim3(static_cast<unsigned>(nparts)),
+                           dim3(kBktThreads), 0, st, a, keys_y, idx_y);
+      }
     } else {
-      hipLaunchKernelGGL((msd_bucket_kernel<false, kBktThreads>), dim3(static_cast<unsigned>(nparts)),
-                         dim3(kBktThreads), 0, st, a, keys_y, idx_y);
+      a.b3 = std::max(0, std::min(std::min(want_b3, 10), 64 - kshift - a.bits));
+      if (small) {
+        hipLaunchKernelGGL((msd_bucket_kernel<false, kBktThreadsSmall>), dim3(static_cast<unsigned>(nparts)),
+                           dim3(kBktThreadsSmall), 0, st, a, keys_y, idx_y);
+      } else {
+        hipLaunchKernelGGL((msd_bucket_kernel<false, kBktThreads>), dim3(static_cast<unsigned>(nparts)),
+                           dim3(kBktThreads), 0, st, a, keys_y, idx_y);
+      }
     }
     ARX_CHECK_LAUNCH("msd_bucket_kernel");
   } else {
@@ -1514,7 +1657,7 @@ static int run_msd_sort_segmented(const uint64_t* src_keys, const uint32_t* src_
                                   uint64_t* keys_p, uint32_t* idx_p, uint64_t* keys_q, uint32_t* idx_q,
                                   uint8_t* tables, uint64_t* out_final, hipStream_t st, int* overflowed) {
   int b0 = 1;
-  while ((n >> b0) > (int64_t(1) << 27) && b0 < 7) ++b0;
+  while ((n >> b0) > std::min<int64_t>(g_sort_msd_segment_rows, int64_t(1) << 27) && b0 < 7) ++b0;
   b0 = std::max(b0, std::min(g_sort_msd_seg_min_bits, 7));
   MsdArgs a{};
   a.src_keys = src_keys;

@@ -499,24 +499,25 @@ def test_add_and_greater_with_a_scalar_operand(emu_ctx):
     P.check_scalar_operand_ops(emu_ctx, rng_for("scalarops"), n=5000)
 
 
-@pytest.mark.parametrize("small_bucket,final_rows_log2,seg_min_bits", [(0, 4, 1), (1, 2, 1), (1, 3, 5)])
-def test_sort_msd_bucket_variants_and_segment_fanout(emu_ctx, small_bucket, final_rows_log2, seg_min_bits):
+@pytest.mark.parametrize("small_bucket,final_rows_log2,seg_min_bits,v2", [(0, 4, 1, 1), (1, 2, 1, 1), (1, 3, 5, 0), (0, 1, 1, 0)])
+def test_sort_msd_bucket_variants_and_segment_fanout(emu_ctx, small_bucket, final_rows_log2, seg_min_bits, v2):
     """Tuning knobs of the MSD sort never change results: the 1024- vs 512-thread bucket kernel, the
     sub-bucket size and the fan-out of the segment level (segmented form forced on)."""
     lib = emu_ctx._lib.get_lib()
     opts = {b"sort_msd": 1, b"sort_msd_small_bucket": small_bucket, b"sort_msd_final_rows_log2": final_rows_log2,
-            b"sort_msd_seg_min_bits": seg_min_bits, b"sort_msd_segment_rows": 2048 if seg_min_bits > 1 else 1 << 27}
+            b"sort_msd_seg_min_bits": seg_min_bits, b"sort_msd_segment_rows": 2048 if seg_min_bits > 1 else 1 << 27,
+            b"sort_msd_bucket_v2": v2}
     for k, v in opts.items():
         assert lib.arx_set_option(k, v) == 0
     try:
-        rng = rng_for("msdknobs", small_bucket, final_rows_log2, seg_min_bits)
+        rng = rng_for("msdknobs", small_bucket, final_rows_log2, seg_min_bits, v2)
         n = 6000   # (the emulator runs a 1024-thread workgroup as 1024 fibers)
         a = U.random_array(rng, np.uint64, n, null_p=0.02, offset=1)
         a.values[a.offset:a.offset + n - 1:7] = a.values[a.offset + 1:a.offset + n:7]  # ties
         P.check_sort_indices(emu_ctx, a, "descending", "at_start", use_pyarrow=False)
     finally:
-        for k, v in {b"sort_msd": -1, b"sort_msd_small_bucket": 1, b"sort_msd_final_rows_log2": 3,
-                     b"sort_msd_seg_min_bits": 1, b"sort_msd_segment_rows": 1 << 27}.items():
+        for k, v in {b"sort_msd": -1, b"sort_msd_small_bucket": 1, b"sort_msd_final_rows_log2": 1,
+                     b"sort_msd_seg_min_bits": 1, b"sort_msd_segment_rows": 1 << 27, b"sort_msd_bucket_v2": 1}.items():
             lib.arx_set_option(k, v)
 
 

@@ -603,6 +603,31 @@ def test_sort_virtual_ranks_on_one_gpu(gpu_ctx):
     assert (got == want[:n_valid]).all()        # nulls travel separately (row numbers only)
 
 
+@pytest.mark.parametrize("small_bucket,final_rows_log2,seg_rows,v2", [(0, 4, 1 << 27, 1), (1, 1, 1 << 27, 1), (1, 3, 1 << 20, 0),
+                                                                     (0, 1, 1 << 27, 0), (1, 2, 1 << 19, 1)])
+def test_sort_msd_bucket_variants_on_gpu(gpu_ctx, small_bucket, final_rows_log2, seg_rows, v2):
+    """Tuning knobs of the MSD sort never change results on the device either: both LDS bucket finishes
+    (msd_bucket_kernel / msd_bucket2_kernel: one LDS-atomic pass, up to 4096 sub-buckets), 1024- vs 512-thread
+    form, sub-bucket size, segmented form."""
+    lib = gpu_ctx._lib.get_lib()
+    opts = {b"sort_msd": 1, b"sort_msd_small_bucket": small_bucket, b"sort_msd_final_rows_log2": final_rows_log2,
+            b"sort_msd_segment_rows": seg_rows, b"sort_msd_bucket_v2": v2}
+    for k, v in opts.items():
+        assert lib.arx_set_option(k, v) == 0
+    try:
+        rng = rng_for("msdknobs-gpu", small_bucket, final_rows_log2, seg_rows, v2)
+        n = 5_000_011
+        a = U.random_array(rng, np.uint64, n, null_p=0.02, offset=1)
+        a.values[a.offset:a.offset + n - 1:7] = a.values[a.offset + 1:a.offset + n:7]  # ties
+        P.check_sort_indices(gpu_ctx, a, "descending", "at_start", use_pyarrow=False)
+        b = U.random_array(rng, np.int64, n, offset=0)
+        P.check_sort_indices(gpu_ctx, b, "ascending", "at_end", use_pyarrow=False)
+    finally:
+        for k, v in {b"sort_msd": -1, b"sort_msd_small_bucket": 1, b"sort_msd_final_rows_log2": 1,
+                     b"sort_msd_segment_rows": 1 << 27, b"sort_msd_bucket_v2": 1}.items():
+            lib.arx_set_option(k, v)
+
+
 @pytest.mark.parametrize("placement", ["at_end", "at_start"])
 def test_sort_records_virtual_ranks_on_one_gpu(gpu_ctx, placement):
     """The ONE-buffer exchange of the sharded sort with P = 3 virtual ranks: arx_sort_partition_records packs
