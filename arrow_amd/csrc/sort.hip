@@ -37,6 +37,7 @@ static int g_sort_msd_fused = 1;       // finish LDS-sized level-2 buckets in on
 static int64_t g_sort_msd_segment_rows = int64_t(1) << 27;  // above this: an extra top-bits level cuts segments
 static int g_sort_msd_final_rows_log2 = 1;  // log2 of the rows aimed at per final sub-bucket (rank loop length); with the 4096-bin finish 1 beats 2 / 3 / 4 by 3 / 9 / 18 % at 2e9 rows
 static int g_sort_msd_small_bucket = 1;  // 512-thread / 5120-row bucket kernel when every bucket fits it
+static int g_sort_msd_wide = 1;          // inputs beyond sort_msd_segment_rows: the wide two-level form (run_msd_sort_wide) before the segmented one
 static int g_sort_msd_bucket_v2 = 1;     // single-atomic-pass bucket finish with up to 4096 sub-buckets (msd_bucket2_kernel)
 static int g_sort_msd_seg_min_bits = 1;  // floor of the segment level's bits (more bins = fewer LDS atomic collisions)
 static int g_sort_msd_global_bits = 14;  // (= kMsdMaxBits) cap of the two global levels (tests lower it to reach level 3)
@@ -1307,6 +1308,11 @@ constexpr int kMsdSplBits = 15;  // sampled-splitter mode: up to 2^15 buckets
 constexpr size_t kMsdTableWords = (size_t(1) << kMsdSplBits) + 64;
 constexpr size_t kMsdTableBytes = (3 * kMsdTableWords + size_t(128) * kMsdMaxChunks + 2 * 192 + 64) * 4 + (size_t(1) << kMsdSplBits) * 8;
 
+// tables of the wide two-level form (run_msd_sort_wide): 3 arrays of 2^20 buckets + 6 of 1024 level-1 entries
+constexpr int kMsdwMaxBins = 1024;
+constexpr int kMsdwMaxBits = 20;
+constexpr size_t kMsdwTableBytes = (3 * ((size_t(1) << kMsdwMaxBits) + 64) + 6 * (kMsdwMaxBins + 64)) * 4;
+
 struct SortPlan {
   int64_t n;          // rows to sort (non-null)
   int64_t ntiles;
@@ -1331,7 +1337,7 @@ static SortPlan make_plan(int64_t length) {
   p.off_hist = o; o = align(o + static_cast<size_t>(kDigits) * kMaxChunks * 4);
   p.off_totals = o; o = align(o + static_cast<size_t>(kDigits) * 4);
   p.off_split = o; o = align(o + static_cast<size_t>(kDigits) * 4);
-  p.off_msd = o; o = align(o + kMsdTableBytes);
+  p.off_msd = o; o = align(o + std::max(kMsdTableBytes, kMsdwTableBytes));
   p.off_float_bits = o; o = align(o + 2 * (n / 64 + 2) * 8);  // sortable / NaN bitmaps of float keys
   p.off_rows = o; o = align(o + n * 4);  // row ids of the non-null / null partitions
   p.off_sel_ws = o; o = align(o + selection_workspace_bytes(length));
@@ -1354,6 +1360,10 @@ int set_sort_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "sort_msd_final_rows_log2") == 0) {
     g_sort_msd_final_rows_log2 = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, 8)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide") == 0) {
+    g_sort_msd_wide = value != 0;
     return 1;
   }
   if (strcmp(name, "sort_msd_bucket_v2") == 0) {
@@ -1650,6 +1660,395 @@ static int run_msd_sort_sampled(const uint64_t* src_keys, const uint32_t* src_id
   return ARX_OK;
 }
 
+// =====================================================================================
+// Wide two-level form for inputs beyond 2^27 rows (configs[4]: 2e9 rows).  The segmented form below moves
+// 104 B/row (an extra histogram + scatter level per segment and one pipeline launch sequence per segment); this
+// one covers bits = ceil(log2 n) - 12 (<= 20) key bits with TWO scatter levels of up to 1024 bins each and moves
+// 8 + 20 + 8 + 24 + 20 = 80 B/row in seven launches:
+//   W1 msdw_hist0     top b1 bits (LDS histogram per chunk, <= 1024 atomics per workgroup)          8 B/row
+//   W2 msdw_scan0     level-1 starts + cursors, tile map and histogram-unit map of level 2
+//   W3 msdw_scatter1  level 1 over the whole input: 8192-row tiles (1024 threads), one returning global atomic
+//                     per (tile, digit) — consecutive tiles extend the same <= 1024 output runs    8 + 12 B/row
+//   W4 msdw_hist1     next b2 bits inside every level-1 bucket, work units of <= 2^19 rows of ONE bucket   8 B/row
+//   W5 msdw_scan1     one workgroup per level-1 bucket: bucket starts, cursors, largest bucket
+//   W6 msdw_scatter2  level 2 INSIDE each level-1 bucket (reads and writes stay within the bucket's few tens of
+//                     MB — measured 25 % faster per byte than a scatter whose bins span the whole array) 12 + 12 B/row
+//   W7 msd_bucket2    LDS finish of the 2^bits buckets (~2-4K rows each)                          12 + 8 B/row
+// Neither level is stable: the finish orders by (key, row id) (see the header of the MSD-hybrid path).
+// Skewed keys: the largest bucket is read back after W5; one that does not fit LDS sends the caller to the
+// segmented / sampled / LSD forms.
+// =====================================================================================
+constexpr int kMsdwThreads = 1024;
+constexpr int kMsdwRows = 8;
+constexpr int kMsdwTile = kMsdwThreads * kMsdwRows;   // 8192 rows
+constexpr int64_t kMsdwUnit = int64_t(1) << 19;        // rows per level-2 histogram work unit
+
+struct MsdwArgs {
+  const uint64_t* src_keys;
+  const uint32_t* src_idx;
+  int raw;
+  int64_t n;
+  int bits, b1, b2;
+  int64_t chunk_rows;      // hist0 chunk
+  uint32_t* l1_count;      // [2^b1]
+  uint32_t* l1_start;      // [2^b1 + 1]
+  uint32_t* cursor1;       // [2^b1]
+  uint32_t* l2_tile_start; // [2^b1 + 1]
+  uint32_t* unit_start;    // [2^b1 + 1]
+  uint32_t* count2;        // [2^bits]
+  uint32_t* part_start;    // [2^bits + 1]
+  uint32_t* cursor2;       // [2^bits]
+  uint32_t* flags;         // [0] overflow bits, [1] largest bucket
+  uint64_t* keys_x;
+  uint32_t* idx_x;
+  uint64_t* keys_y;
+  uint32_t* idx_y;
+};
+
+template <bool RAW>
+__global__ __launch_bounds__(kMsdThreads) void msdw_hist0_kernel(MsdwArgs a) {
+  __shared__ uint32_t h[kMsdwMaxBins];
+  const int tid = threadIdx.x;
+  const int nb = 1 << a.b1;
+  for (int i = tid; i < nb; i += kMsdThreads) h[i] = 0;
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * a.chunk_rows;
+  const int64_t end = begin + a.chunk_rows < a.n ? begin + a.chunk_rows : a.n;
+  const int shift = 64 - a.b1;
+  constexpr int U = 8;
+  int64_t r = begin + tid;
+  for (; r + (U - 1) * kMsdThreads < end; r += U * kMsdThreads) {
+    uint64_t kk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      kk[u] = RAW ? load_key_typed(a.src_keys, r + u * kMsdThreads, a.raw) : a.src_keys[r + u * kMsdThreads];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) atomicAdd(&h[kk[u] >> shift], 1u);
+  }
+  for (; r < end; r += kMsdThreads) {
+    const uint64_t k = RAW ? load_key_typed(a.src_keys, r, a.raw) : a.src_keys[r];
+    atomicAdd(&h[k >> shift], 1u);
+  }
+  __syncthreads();
+  for (int i = tid; i < nb; i += kMsdThreads) {
+    const uint32_t c = h[i];
+    if (c != 0) atomicAdd(&a.l1_count[i], c);
+  }
+}
+
+// one workgroup of 1024 threads (one level-1 bucket per thread)
+__global__ __launch_bounds__(1024) void msdw_scan0_kernel(MsdwArgs a) {
+  __shared__ uint32_t wt[3][16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nb = 1 << a.b1;
+  const uint32_t c = tid < nb ? a.l1_count[tid] : 0u;
+  const uint32_t tiles = (c + kMsdwTile - 1) / kMsdwTile;
+  const uint32_t units = static_cast<uint32_t>((static_cast<int64_t>(c) + kMsdwUnit - 1) / kMsdwUnit);
+  const uint32_t i0 = wave_inclusive_scan_u32(c);
+  const uint32_t i1 = wave_inclusive_scan_u32(tiles);
+  const uint32_t i2 = wave_inclusive_scan_u32(units);
+  if (lane == 63) {
+    wt[0][wave] = i0;
+    wt[1][wave] = i1;
+    wt[2][wave] = i2;
+  }
+  __syncthreads();
+  uint32_t p0 = i0 - c, p1 = i1 - tiles, p2 = i2 - units;
+  for (int k = 0; k < wave; ++k) {
+    p0 += wt[0][k];
+    p1 += wt[1][k];
+    p2 += wt[2][k];
+  }
+  if (tid < nb) {
+    a.l1_start[tid] = p0;
+    a.cursor1[tid] = p0;
+    a.l2_tile_start[tid] = p1;
+    a.unit_start[tid] = p2;
+  }
+  if (tid == nb - 1) {
+    a.l1_start[nb] = p0 + c;
+    a.l2_tile_start[nb] = p1 + tiles;
+    a.unit_start[nb] = p2 + units;
+  }
+}
+
+struct __attribute__((aligned(16))) MsdwScatterLds {
+  uint64_t keys[kMsdwTile];
+  uint32_t idx[kMsdwTile];
+  uint32_t cnt[kMsdwMaxBins];
+  uint32_t start[kMsdwMaxBins];
+  uint32_t gbase[kMsdwMaxBins];
+  uint32_t wave_tot[kMsdwThreads / 64];
+  uint32_t part;
+};
+
+// Scatter one tile of <= 8192 rows by digit = (key >> dshift) & (nb - 1); run bases from one returning atomic per
+// digit on gcursor[].  1024 threads, nb <= 1024 (one counter per thread in the scan).
+template <bool RAW>
+__device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatterLds& lds, const uint64_t* __restrict__ kin,
+                                                  const uint32_t* __restrict__ iin, int64_t row0, int nrows, int nb,
+                                                  int dshift, uint32_t* __restrict__ gcursor,
+                                                  uint64_t* __restrict__ kout, uint32_t* __restrict__ iout) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t dmask = static_cast<uint32_t>(nb - 1);
+  if (tid < nb) lds.cnt[tid] = 0;
+  uint64_t key[kMsdwRows];
+  uint32_t idx[kMsdwRows];
+#pragma unroll
+  for (int i = 0; i < kMsdwRows; ++i) {   // unconditional (clamped) loads: all in flight together
+    const int p = i * kMsdwThreads + tid;
+    const int64_t r = row0 + (p < nrows ? p : nrows - 1);
+    if constexpr (RAW) {
+      key[i] = load_key_typed(kin, r, a.raw);
+      idx[i] = static_cast<uint32_t>(r);
+    } else {
+      key[i] = kin[r];
+      idx[i] = iin[r];
+    }
+  }
+  __syncthreads();
+  uint32_t dig[kMsdwRows], rank[kMsdwRows];
+#pragma unroll
+  for (int i = 0; i < kMsdwRows; ++i) {
+    dig[i] = static_cast<uint32_t>(key[i] >> dshift) & dmask;
+    rank[i] = 0;
+    if (i * kMsdwThreads + tid < nrows) rank[i] = atomicAdd(&lds.cnt[dig[i]], 1u);
+  }
+  __syncthreads();
+  const uint32_t c = tid < nb ? lds.cnt[tid] : 0u;
+  const uint32_t incl = wave_inclusive_scan_u32(c);
+  if (lane == 63) lds.wave_tot[wave] = incl;
+  __syncthreads();
+  if (tid < nb) {
+    uint32_t pre = incl - c;
+    for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
+    lds.start[tid] = pre;
+    lds.gbase[tid] = c != 0 ? atomicAdd(&gcursor[tid], c) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kMsdwRows; ++i) {
+    if (i * kMsdwThreads + tid < nrows) {
+      const uint32_t pos = lds.start[dig[i]] + rank[i];
+      lds.keys[pos] = key[i];
+      lds.idx[pos] = idx[i];
+    }
+  }
+  __syncthreads();
+  for (int p = tid; p < nrows; p += kMsdwThreads) {
+    const uint64_t k = lds.keys[p];
+    const uint32_t d = static_cast<uint32_t>(k >> dshift) & dmask;
+    const uint32_t dst = lds.gbase[d] + (static_cast<uint32_t>(p) - lds.start[d]);
+    kout[dst] = k;
+    iout[dst] = lds.idx[p];
+  }
+}
+
+template <bool RAW>
+__global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1_kernel(MsdwArgs a) {
+  __shared__ MsdwScatterLds lds;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kMsdwTile;
+  const int nrows = static_cast<int>(a.n - row0 < kMsdwTile ? a.n - row0 : kMsdwTile);
+  msdw_scatter_tile<RAW>(a, lds, a.src_keys, a.src_idx, row0, nrows, 1 << a.b1, 64 - a.b1, a.cursor1, a.keys_x,
+                         a.idx_x);
+}
+
+// index of the last entry of start[0..nb] (nb + 1 entries, non-decreasing, start[0] == 0) that is <= g, computed by
+// the first wave and returned to every thread through *slot
+__device__ __forceinline__ uint32_t msdw_owner(const uint32_t* __restrict__ start, int nb, uint32_t g, uint32_t* slot) {
+  if (threadIdx.x < 64) {
+    uint32_t below = 0;
+    for (int p = threadIdx.x; p < nb; p += 64) below += (start[p] <= g) ? 1u : 0u;
+    below = wave_reduce_sum_u32(below);
+    if (threadIdx.x == 0) *slot = below - 1;
+  }
+  __syncthreads();
+  return *slot;
+}
+
+// W4: counts of the next b2 bits inside level-1 buckets; work unit = <= kMsdwUnit rows of one bucket
+__global__ __launch_bounds__(kMsdThreads) void msdw_hist1_kernel(MsdwArgs a) {
+  __shared__ uint32_t h[kMsdwMaxBins];
+  __shared__ uint32_t part_s;
+  const int tid = threadIdx.x;
+  const int nb1 = 1 << a.b1;
+  const uint32_t u = blockIdx.x;
+  if (u >= a.unit_start[nb1]) return;  // over-provisioned grid
+  const int nb2 = 1 << a.b2;
+  for (int i = tid; i < nb2; i += kMsdThreads) h[i] = 0;
+  const uint32_t p = msdw_owner(a.unit_start, nb1, u, &part_s);
+  const int64_t begin = static_cast<int64_t>(a.l1_start[p]) + static_cast<int64_t>(u - a.unit_start[p]) * kMsdwUnit;
+  const int64_t bucket_end = a.l1_start[p + 1];
+  const int64_t end = begin + kMsdwUnit < bucket_end ? begin + kMsdwUnit : bucket_end;
+  const int shift = 64 - a.bits;
+  const uint32_t mask = static_cast<uint32_t>(nb2 - 1);
+  constexpr int U = 8;
+  int64_t r = begin + tid;
+  for (; r + (U - 1) * kMsdThreads < end; r += U * kMsdThreads) {
+    uint64_t kk[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) kk[q] = a.keys_x[r + q * kMsdThreads];
+#pragma unroll
+    for (int q = 0; q < U; ++q) atomicAdd(&h[static_cast<uint32_t>(kk[q] >> shift) & mask], 1u);
+  }
+  for (; r < end; r += kMsdThreads) atomicAdd(&h[static_cast<uint32_t>(a.keys_x[r] >> shift) & mask], 1u);
+  __syncthreads();
+  uint32_t* dst = a.count2 + (static_cast<size_t>(p) << a.b2);
+  for (int i = tid; i < nb2; i += kMsdThreads) {
+    const uint32_t c = h[i];
+    if (c != 0) atomicAdd(&dst[i], c);
+  }
+}
+
+// W5: one workgroup (1024 threads) per level-1 bucket: starts and cursors of its 2^b2 level-2 buckets
+__global__ __launch_bounds__(1024) void msdw_scan1_kernel(MsdwArgs a) {
+  __shared__ uint32_t wt[16];
+  __shared__ uint32_t wmax[16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t p = blockIdx.x;
+  const int nb2 = 1 << a.b2;
+  const size_t base = static_cast<size_t>(p) << a.b2;
+  const uint32_t c = tid < nb2 ? a.count2[base + tid] : 0u;
+  const uint32_t incl = wave_inclusive_scan_u32(c);
+  uint32_t mx = c;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = __shfl_xor(mx, d, 64);
+    mx = mx > o ? mx : o;
+  }
+  if (lane == 63) wt[wave] = incl;
+  if (lane == 0) wmax[wave] = mx;
+  __syncthreads();
+  uint32_t pre = a.l1_start[p] + incl - c;
+  for (int k = 0; k < wave; ++k) pre += wt[k];
+  if (tid < nb2) {
+    a.part_start[base + tid] = pre;
+    a.cursor2[base + tid] = pre;
+  }
+  if (tid == 0) {
+    uint32_t m = 0;
+    for (int k = 0; k < 16; ++k) m = m > wmax[k] ? m : wmax[k];
+    atomicMax(&a.flags[1], m);
+    if (p + 1 == gridDim.x) a.part_start[base + nb2] = a.l1_start[p + 1];
+  }
+}
+
+// W6: level 2 inside the level-1 buckets (tile map: l2_tile_start)
+__global__ __launch_bounds__(kMsdwThreads) void msdw_scatter2_kernel(MsdwArgs a) {
+  __shared__ MsdwScatterLds lds;
+  const int nb1 = 1 << a.b1;
+  const uint32_t g = blockIdx.x;
+  if (g >= a.l2_tile_start[nb1]) return;  // over-provisioned grid
+  const uint32_t p = msdw_owner(a.l2_tile_start, nb1, g, &lds.part);
+  const int64_t lo = a.l1_start[p];
+  const int64_t hi = a.l1_start[p + 1];
+  const int64_t row0 = lo + static_cast<int64_t>(g - a.l2_tile_start[p]) * kMsdwTile;
+  const int nrows = static_cast<int>(hi - row0 < kMsdwTile ? hi - row0 : kMsdwTile);
+  msdw_scatter_tile<false>(a, lds, a.keys_x, a.idx_x, row0, nrows, 1 << a.b2, 64 - a.bits,
+                           a.cursor2 + (static_cast<size_t>(p) << a.b2), a.keys_y, a.idx_y);
+}
+
+
+static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n,
+                             uint64_t* keys_x, uint32_t* idx_x, uint64_t* keys_y, uint32_t* idx_y, uint8_t* tables,
+                             uint64_t* out_final, hipStream_t st, int* overflowed) {
+  *overflowed = 0;
+  if (n == 0) return ARX_OK;
+  int lg = 0;
+  while ((int64_t(1) << lg) < n) ++lg;   // ceil(log2 n)
+  MsdwArgs a{};
+  a.src_keys = src_keys;
+  a.src_idx = src_idx;
+  a.raw = raw;
+  a.n = n;
+  a.bits = std::max(2, std::min(lg - 12, kMsdwMaxBits));   // 2048 < average bucket <= 4096 rows
+  a.b1 = a.bits / 2;
+  a.b2 = a.bits - a.b1;
+  const int64_t ntiles0 = ceil_div(n, kMsdTile);
+  a.chunk_rows = std::max<int64_t>(1, ceil_div(ntiles0, kMsdMaxChunks)) * kMsdTile;
+  const unsigned nch = static_cast<unsigned>(ceil_div(n, a.chunk_rows));
+  uint32_t* t = reinterpret_cast<uint32_t*>(tables);
+  const size_t big = (size_t(1) << kMsdwMaxBits) + 64;
+  const size_t small = kMsdwMaxBins + 64;
+  a.count2 = t;
+  a.part_start = t + big;
+  a.cursor2 = t + 2 * big;
+  a.l1_count = t + 3 * big;
+  a.l1_start = a.l1_count + small;
+  a.cursor1 = a.l1_start + small;
+  a.l2_tile_start = a.cursor1 + small;
+  a.unit_start = a.l2_tile_start + small;
+  a.flags = a.unit_start + small;
+  a.keys_x = keys_x;
+  a.idx_x = idx_x;
+  a.keys_y = keys_y;
+  a.idx_y = idx_y;
+  const int nb1 = 1 << a.b1;
+  const size_t nparts = size_t(1) << a.bits;
+  ARX_HIP(hipMemsetAsync(a.l1_count, 0, static_cast<size_t>(nb1) * 4, st));
+  ARX_HIP(hipMemsetAsync(a.count2, 0, nparts * 4, st));
+  ARX_HIP(hipMemsetAsync(a.flags, 0, 8, st));
+  if (raw) {
+    hipLaunchKernelGGL((msdw_hist0_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((msdw_hist0_kernel<false>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+  }
+  ARX_CHECK_LAUNCH("msdw_hist0_kernel");
+  hipLaunchKernelGGL(msdw_scan0_kernel, dim3(1), dim3(1024), 0, st, a);
+  ARX_CHECK_LAUNCH("msdw_scan0_kernel");
+  const unsigned grid1 = static_cast<unsigned>(ceil_div(n, kMsdwTile));
+  if (raw) {
+    hipLaunchKernelGGL((msdw_scatter1_kernel<true>), dim3(grid1), dim3(kMsdwThreads), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((msdw_scatter1_kernel<false>), dim3(grid1), dim3(kMsdwThreads), 0, st, a);
+  }
+  ARX_CHECK_LAUNCH("msdw_scatter1_kernel");
+  const unsigned units = static_cast<unsigned>(ceil_div(n, kMsdwUnit) + nb1);
+  hipLaunchKernelGGL(msdw_hist1_kernel, dim3(units), dim3(kMsdThreads), 0, st, a);
+  ARX_CHECK_LAUNCH("msdw_hist1_kernel");
+  hipLaunchKernelGGL(msdw_scan1_kernel, dim3(static_cast<unsigned>(nb1)), dim3(1024), 0, st, a);
+  ARX_CHECK_LAUNCH("msdw_scan1_kernel");
+  unsigned int max_part = 0;
+  ARX_HIP(hipMemcpyAsync(&max_part, a.flags + 1, 4, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  if (max_part > static_cast<unsigned int>(kBktCap)) {   // skewed keys: a bucket would not fit LDS
+    *overflowed = 1;
+    return ARX_OK;
+  }
+  const unsigned grid2 = grid1 + static_cast<unsigned>(nb1);
+  hipLaunchKernelGGL(msdw_scatter2_kernel, dim3(grid2), dim3(kMsdwThreads), 0, st, a);
+  ARX_CHECK_LAUNCH("msdw_scatter2_kernel");
+  MsdArgs f{};
+  f.n = n;
+  f.bits = a.bits;
+  f.kshift = 0;
+  f.part_start = a.part_start;
+  f.overflow = a.flags;
+  f.out_final = out_final;
+  const bool small_bkt = max_part <= static_cast<unsigned int>(kBktCapSmall);
+  f.b3 = std::max(0, std::min(std::min(lg - (g_sort_msd_final_rows_log2 - 1) - a.bits, small_bkt ? 11 : 12), 64 - a.bits));
+  if (small_bkt) {
+    hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsSmall>), dim3(static_cast<unsigned>(nparts)),
+                       dim3(kBktThreadsSmall), 0, st, f, keys_y, idx_y);
+  } else {
+    hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreads>), dim3(static_cast<unsigned>(nparts)),
+                       dim3(kBktThreads), 0, st, f, keys_y, idx_y);
+  }
+  ARX_CHECK_LAUNCH("msd_bucket2_kernel");
+  unsigned int flag = 0;
+  ARX_HIP(hipMemcpyAsync(&flag, a.flags, 4, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  *overflowed = flag != 0;
+  return ARX_OK;
+}
+
 // Inputs beyond ~2^28 rows: one extra unstable level on the top b0 bits cuts the array into
 // 2^b0 segments of ~2^27 rows (32 B/row), then every segment runs the pipeline above on the bits
 // below (kshift = b0).  Synchronous.
@@ -1847,20 +2246,38 @@ int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_pl
     uint8_t* tables = w + plan.off_msd;
     int overflowed = 0;
     int rc;
+    const bool wide = segmented && g_sort_msd_wide != 0 && key_width == 8;
     if (valid_rows == nullptr) {
       const uint64_t* src = reinterpret_cast<const uint64_t*>(vals);
-      rc = segmented ? run_msd_sort_segmented(src, nullptr, xf, n_valid, keys_a, idx_a, keys_b, idx_b, tables,
-                                              final_dst, st, &overflowed)
-                     : run_msd_sort(src, nullptr, xf, n_valid, keys_a, idx_a, keys_b, idx_b, tables, final_dst, st,
-                                    &overflowed);
+      overflowed = 1;
+      rc = ARX_OK;
+      if (wide) rc = run_msd_sort_wide(src, nullptr, xf, n_valid, keys_a, idx_a, keys_b, idx_b, tables, final_dst, st, &overflowed);
+      if (rc == ARX_OK && overflowed) {
+        rc = segmented ? run_msd_sort_segmented(src, nullptr, xf, n_valid, keys_a, idx_a, keys_b, idx_b, tables,
+                                                final_dst, st, &overflowed)
+                       : run_msd_sort(src, nullptr, xf, n_valid, keys_a, idx_a, keys_b, idx_b, tables, final_dst, st,
+                                      &overflowed);
+      }
     } else {
       hipLaunchKernelGGL(sort_prep_kernel, dim3(gprep), dim3(kBlock), 0, st, vals, valid_rows, n_valid, xf, 0,
                          keys_a, idx_a);
       ARX_CHECK_LAUNCH("sort_prep_kernel");
-      rc = segmented ? run_msd_sort_segmented(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables,
-                                              final_dst, st, &overflowed)
-                     : run_msd_sort(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables, final_dst, st,
-                                    &overflowed);
+      overflowed = 1;
+      rc = ARX_OK;
+      // the wide form reads its source twice (level 1, then the histogram reads level-1 output): x = b, y = a is
+      // safe because level 2 only starts after level 1 has consumed the source
+      if (wide) rc = run_msd_sort_wide(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables, final_dst, st, &overflowed);
+      if (rc == ARX_OK && overflowed) {
+        if (wide) {   // a failed wide attempt may have overwritten the prepped source: rebuild it
+          hipLaunchKernelGGL(sort_prep_kernel, dim3(gprep), dim3(kBlock), 0, st, vals, valid_rows, n_valid, xf, 0,
+                             keys_a, idx_a);
+          ARX_CHECK_LAUNCH("sort_prep_kernel");
+        }
+        rc = segmented ? run_msd_sort_segmented(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables,
+                                                final_dst, st, &overflowed)
+                       : run_msd_sort(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables, final_dst, st,
+                                      &overflowed);
+      }
     }
     if (rc != ARX_OK) return rc;
     if (!overflowed) return ARX_OK;

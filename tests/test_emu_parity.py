@@ -359,6 +359,9 @@ def test_sort_msd_hybrid_path(emu_ctx, global_bits, fused):
     if global_bits < 0:   # the segmented form: an extra level on the top bits, then one pipeline per segment
         global_bits = -global_bits
         assert lib.arx_set_option(b"sort_msd_segment_rows", 4096) == 0
+        # beyond the segment size the wide two-level form (run_msd_sort_wide) runs first; fused = 0 switches it off so
+        # that the segmented form itself stays covered
+        assert lib.arx_set_option(b"sort_msd_wide", fused) == 0
     assert lib.arx_set_option(b"sort_msd_global_bits", global_bits) == 0
     try:
         n = 14000   # (the emulator runs every workgroup as fibers on one core)
@@ -376,6 +379,7 @@ def test_sort_msd_hybrid_path(emu_ctx, global_bits, fused):
         lib.arx_set_option(b"sort_msd", -1)
         lib.arx_set_option(b"sort_msd_global_bits", 14)
         lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
+        lib.arx_set_option(b"sort_msd_wide", 1)
         lib.arx_set_option(b"sort_msd_fused", 1)
 
 
@@ -506,7 +510,7 @@ def test_sort_msd_bucket_variants_and_segment_fanout(emu_ctx, small_bucket, fina
     lib = emu_ctx._lib.get_lib()
     opts = {b"sort_msd": 1, b"sort_msd_small_bucket": small_bucket, b"sort_msd_final_rows_log2": final_rows_log2,
             b"sort_msd_seg_min_bits": seg_min_bits, b"sort_msd_segment_rows": 2048 if seg_min_bits > 1 else 1 << 27,
-            b"sort_msd_bucket_v2": v2}
+            b"sort_msd_bucket_v2": v2, b"sort_msd_wide": v2}
     for k, v in opts.items():
         assert lib.arx_set_option(k, v) == 0
     try:
@@ -517,7 +521,7 @@ def test_sort_msd_bucket_variants_and_segment_fanout(emu_ctx, small_bucket, fina
         P.check_sort_indices(emu_ctx, a, "descending", "at_start", use_pyarrow=False)
     finally:
         for k, v in {b"sort_msd": -1, b"sort_msd_small_bucket": 1, b"sort_msd_final_rows_log2": 1,
-                     b"sort_msd_seg_min_bits": 1, b"sort_msd_segment_rows": 1 << 27, b"sort_msd_bucket_v2": 1}.items():
+                     b"sort_msd_seg_min_bits": 1, b"sort_msd_segment_rows": 1 << 27, b"sort_msd_bucket_v2": 1, b"sort_msd_wide": 1}.items():
             lib.arx_set_option(k, v)
 
 
