@@ -584,7 +584,6 @@ constexpr int kGbMaxBins = 256;           // per level
 constexpr int kGbMaxBits = 14;
 constexpr int kGbMaxChunks = 4096;      // upper bound of level-1 chunks (sizes hist1)
 constexpr int kGbSlots = 4096;            // LDS table slots per partition
-constexpr int kGbAggChunk = 1 << 16;      // rows per aggregate work unit
 constexpr uint32_t kGbHashMul = 0x9E3779B1u;     // odd => k -> k * M mod 2^32 is a bijection
 constexpr uint32_t kGbHashInv = 0x0E8B2F51u;     // M * Minv == 1 mod 2^32
 static_assert(static_cast<uint32_t>(kGbHashMul * kGbHashInv) == 1u, "hash inverse");
@@ -614,6 +613,7 @@ struct GbpArgs {
   int32_t* keys_b;
   int64_t* vals_b;
   int agg_pipe;            // software-pipelined loads in the LDS aggregate kernel (A/B knob)
+  uint32_t agg_chunk;      // rows per aggregate work unit (a power of two)
 };
 
 template <bool HAS_NULLS>
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(1024) void gbp_scan_a_kernel(GbpArgs a) {
   // aggregate work units: every partition is cut into pieces of <= kGbAggChunk rows
   __syncthreads();
   uint32_t usum = 0;
-  for (int i = b; i < e; ++i) usum += (ps[i + 1] - ps[i] + kGbAggChunk - 1) / kGbAggChunk;
+  for (int i = b; i < e; ++i) usum += (ps[i + 1] - ps[i] + a.agg_chunk - 1) / a.agg_chunk;
   const uint32_t uincl = wave_inclusive_scan_u32(usum);
   if (lane == 63) wave_tot[wave] = uincl;
   __syncthreads();
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(1024) void gbp_scan_a_kernel(GbpArgs a) {
   for (int k = 0; k < wave; ++k) uprefix += wave_tot[k];
   for (int i = b; i < e; ++i) {
     a.agg_unit_start[i] = uprefix;
-    uprefix += (ps[i + 1] - ps[i] + kGbAggChunk - 1) / kGbAggChunk;
+    uprefix += (ps[i + 1] - ps[i] + a.agg_chunk - 1) / a.agg_chunk;
   }
   if (tid == 1023) a.agg_unit_start[nparts] = uprefix;
 }
@@ -984,8 +984,8 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
   int64_t lo, hi;
   uint32_t q = 0;
   if constexpr (DIRECT) {
-    lo = static_cast<int64_t>(blockIdx.x) * kGbAggChunk;
-    hi = lo + kGbAggChunk < a.n ? lo + kGbAggChunk : a.n;
+    lo = static_cast<int64_t>(blockIdx.x) * a.agg_chunk;
+    hi = lo + a.agg_chunk < a.n ? lo + a.agg_chunk : a.n;
   } else {
     // which partition owns work unit u: the last q with agg_unit_start[q] <= u.  Two rounds of a
     // 64-lane search (coarse stride, then inside the stride) by the first wave.
@@ -1005,11 +1005,11 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
       below = wave_reduce_sum_u32(below);
       if (lane == 0) {
         const uint32_t part = static_cast<uint32_t>(coarse) + below - 1;
-        const uint32_t first = a.part_start[part] + (u - a.agg_unit_start[part]) * kGbAggChunk;
+        const uint32_t first = a.part_start[part] + (u - a.agg_unit_start[part]) * a.agg_chunk;
         const uint32_t end = a.part_start[part + 1];
         t.part = part;
         t.row_lo = first;
-        t.row_hi = first + kGbAggChunk < end ? first + kGbAggChunk : end;
+        t.row_hi = (end - first) > a.agg_chunk ? first + a.agg_chunk : end;
       }
     }
   }
@@ -1143,7 +1143,7 @@ static int g_gbp_bits = -1;           // -1 = from the capacity hint
 static int g_gbp_agg_pipe = 1;
 static int g_gbp_b1 = -1;             // level-1 bits override (-1: half of the partition bits)
 static int g_gbp_chunks = 2048;       // level-1 chunks = workgroups of the hist / scatter1 kernels
-static int g_gbp_l1_global = 0;       // level 1 with global cursors (one tile per workgroup) instead of chunked exact offsets
+static int g_gbp_l1_global = 1;       // level 1 with global cursors (one tile per workgroup; +3 % at 4e9 rows) instead of chunked exact offsets
 
 static int gbp_bits_for(int64_t capacity) {
   if (g_gbp_bits >= 0) return std::min(g_gbp_bits, kGbMaxBits);
@@ -1194,6 +1194,8 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity) {
 
 constexpr int64_t kGbMaxSlice = int64_t(1) << 30;  // row positions inside a slice are 32-bit
 static int64_t g_gbp_max_slice = kGbMaxSlice;     // A/B knob groupby_max_slice_rows
+constexpr int64_t kGbHardMaxSlice = (int64_t(1) << 32) - (int64_t(1) << 24);
+static int g_gbp_agg_chunk = 1 << 18;             // A/B knob groupby_agg_chunk_rows (2^16: every group of a partition is flushed 2-8x per slice; 2^18: +4 %)
 
 // Largest slice (multiple of the tile) whose plan fits `ws_bytes`; 0 if not even one chunk fits.
 static int64_t gbp_slice_for(size_t ws_bytes, int64_t n, int64_t capacity) {
@@ -1217,7 +1219,7 @@ static int gbp_run_slice(const GroupbyView& v, GbpArgs a, const GbpPlan& plan, h
     ARX_CHECK_LAUNCH("gbp_null_rows_kernel");
   }
   if (a.bits == 0) {
-    const unsigned units = static_cast<unsigned>(ceil_div(a.n, kGbAggChunk));
+    const unsigned units = static_cast<unsigned>(ceil_div(a.n, a.agg_chunk));
     hipLaunchKernelGGL((gbp_aggregate_kernel<true, HAS_NULLS>), dim3(units), dim3(kGbThreads), 0, st, v, a,
                        a.keys, a.values);
     ARX_CHECK_LAUNCH("gbp_aggregate_kernel");
@@ -1248,7 +1250,7 @@ static int gbp_run_slice(const GroupbyView& v, GbpArgs a, const GbpPlan& plan, h
     fk = a.keys_b;
     fv = a.vals_b;
   }
-  const unsigned units = static_cast<unsigned>(ceil_div(a.n, kGbAggChunk) + nparts);
+  const unsigned units = static_cast<unsigned>(ceil_div(a.n, a.agg_chunk) + nparts);
   hipLaunchKernelGGL((gbp_aggregate_kernel<false, false>), dim3(units), dim3(kGbThreads), 0, st, v, a, fk, fv);
   ARX_CHECK_LAUNCH("gbp_aggregate_kernel");
   return ARX_OK;
@@ -1270,7 +1272,13 @@ int set_groupby_option(const char* name, int64_t value) {
     return 1;
   }
   if (strcmp(name, "groupby_max_slice_rows") == 0) {
-    g_gbp_max_slice = std::max<int64_t>(kGbTile, std::min<int64_t>(value, kGbMaxSlice)) / kGbTile * kGbTile;
+    g_gbp_max_slice = std::max<int64_t>(kGbTile, std::min<int64_t>(value, kGbHardMaxSlice)) / kGbTile * kGbTile;
+    return 1;
+  }
+  if (strcmp(name, "groupby_agg_chunk_rows") == 0) {
+    int lg = 12;
+    while (lg < 24 && (int64_t(1) << lg) < value) ++lg;
+    g_gbp_agg_chunk = 1 << lg;
     return 1;
   }
   if (strcmp(name, "groupby_l1_global") == 0) {
@@ -1337,7 +1345,7 @@ static int state_capacity(void* state, int64_t* cap, hipStream_t st) {
 
 size_t arx_groupby_consume_workspace_bytes(int64_t length, int64_t capacity) {
   if (length < g_gbp_min_rows || length <= 0) return 0;
-  return gbp_plan(std::min<int64_t>(length, kGbMaxSlice), capacity).total;
+  return gbp_plan(std::min<int64_t>(length, g_gbp_max_slice), capacity).total;
 }
 
 int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* keys_i32,
@@ -1394,6 +1402,7 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
       a.l2_tile_start = reinterpret_cast<uint32_t*>(w + plan.off_l2_tile_start);
       a.agg_unit_start = reinterpret_cast<uint32_t*>(w + plan.off_agg_unit_start);
       a.agg_pipe = g_gbp_agg_pipe;
+      a.agg_chunk = static_cast<uint32_t>(g_gbp_agg_chunk);
       const int rc = (kbm != nullptr || vbm != nullptr) ? gbp_run_slice<true>(v, a, plan, st)
                                                         : gbp_run_slice<false>(v, a, plan, st);
       if (rc != ARX_OK) return rc;

@@ -427,6 +427,31 @@ def test_sharded_sort_single_rank_pieces(gpu_ctx, order, placement):
     assert (rows.cpu().numpy().astype(np.uint64) == want).all()
 
 
+@pytest.mark.parametrize("l1_global,agg_chunk,bits", [(0, 1 << 16, 9), (1, 1 << 12, 9), (0, 1 << 20, 5), (1, 1 << 18, 11)])
+def test_groupby_partition_knobs(gpu_ctx, l1_global, agg_chunk, bits):
+    """Tuning knobs of the partitioned consume never change results: level 1 with chunked exact offsets vs global
+    cursors, the rows per LDS-aggregate work unit (how often a partition's groups are flushed)."""
+    lib = gpu_ctx._lib.get_lib()
+    opts = {b"groupby_partition_min_rows": 0, b"groupby_partition_bits": bits, b"groupby_l1_global": l1_global,
+            b"groupby_agg_chunk_rows": agg_chunk}
+    for k_, v_ in opts.items():
+        assert lib.arx_set_option(k_, v_) == 0
+    try:
+        rng = rng_for("gbpknobs", l1_global, agg_chunk, bits)
+        n = 3000000
+        k = U.random_array(rng, np.int32, n, null_p=0.02, offset=3, lo=-2**31, hi=2**31 - 1)
+        k.values[: n // 2] = k.values[: n // 2] % 1777
+        v = U.random_array(rng, np.int64, n, null_p=0.1, offset=1)
+        P.check_groupby_sum(gpu_ctx, k, v, skip_nulls=True, min_count=1, batches=2, use_pyarrow=False)
+        k2 = U.random_array(rng, np.int32, n, lo=0, hi=50000)
+        v2 = U.random_array(rng, np.int64, n)
+        P.check_groupby_sum(gpu_ctx, k2, v2, use_pyarrow=False)
+    finally:
+        for k_, v_ in {b"groupby_partition_min_rows": 1 << 17, b"groupby_partition_bits": -1, b"groupby_l1_global": 1,
+                       b"groupby_agg_chunk_rows": 1 << 18}.items():
+            lib.arx_set_option(k_, v_)
+
+
 def test_groupby_virtual_ranks_on_one_gpu(gpu_ctx):
     """The multi-GPU hash_sum data path with P = 4 virtual ranks on one device: per-rank local
     aggregate -> partials exported as records grouped by hash(key) % P -> exchange (slicing stands in
