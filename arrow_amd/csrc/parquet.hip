@@ -258,10 +258,20 @@ int arx_rle_scan_runs(const void* data, size_t nbytes, int bit_width, int64_t nu
       return ARX_INVALID;
     }
     if (h & 1) {  // literal run: (h >> 1) groups of 8 bit-packed values
+      // the group count is bounded before it is multiplied (a 2^62-group header must not wrap the byte count), and
+      // only the run that reaches num_values may be cut short — by exactly the bytes its needed values do not use
+      // (RleBitPackedDecoder reads no further either, rle_encoding_internal.h)
+      if ((h >> 1) == 0 || (h >> 1) > (uint64_t(1) << 40)) {
+        set_error("Parquet: literal run exceeds the RLE block (corrupt data page?)");
+        return ARX_INVALID;
+      }
       const int64_t groups = static_cast<int64_t>(h >> 1);
       const int64_t count = groups * 8;
       const size_t lbytes = static_cast<size_t>(groups) * bit_width;
-      if (groups == 0 || pos + lbytes > nbytes + 8) {  // (the last group may be cut short by some writers)
+      const int64_t needed = std::min<int64_t>(count, num_values - done);
+      const size_t need_bytes = (static_cast<size_t>(needed) * bit_width + 7) / 8;
+      const bool reaches_end = done + count >= num_values;
+      if (pos > nbytes || (reaches_end ? need_bytes : lbytes) > nbytes - pos) {
         set_error("Parquet: literal run exceeds the RLE block (corrupt data page?)");
         return ARX_INVALID;
       }
@@ -360,8 +370,11 @@ int arx_delta_scan_miniblocks(const void* data, size_t nbytes, uint64_t byte_bas
   const uint64_t per_block = varint();
   const uint64_t total = varint();
   const int64_t first = zigzag();
-  if (bad || per_block == 0 || block_size == 0 || block_size % 128 != 0 || block_size % per_block != 0 ||
-      (block_size / per_block) % 32 != 0 || total > (uint64_t(1) << 40)) {
+  // DeltaBitPackDecoder reads the three header fields as uint32 (decoder.cc); a block of more than 2^20 values per
+  // miniblock is no writer's output, and bounding it keeps every byte count below far from wrapping
+  if (bad || per_block == 0 || block_size == 0 || block_size > 0xFFFFFFFFull || per_block > 0xFFFFFFFFull ||
+      total > 0xFFFFFFFFull || block_size % 128 != 0 || block_size % per_block != 0 ||
+      (block_size / per_block) % 32 != 0 || block_size / per_block > (uint64_t(1) << 20)) {
     set_error("Parquet: bad DELTA_BINARY_PACKED header (corrupt data page?)");
     return ARX_INVALID;
   }
@@ -377,8 +390,11 @@ int arx_delta_scan_miniblocks(const void* data, size_t nbytes, uint64_t byte_bas
     pos += per_block;
     for (uint64_t m = 0; m < per_block && remaining > 0; ++m) {
       const uint32_t bw = widths[m];
-      const size_t mbytes = static_cast<size_t>(vpm) * bw / 8;
-      if (bw > 64 || pos + mbytes > nbytes) {
+      const size_t mbytes = static_cast<size_t>(vpm) * bw / 8;   // vpm <= 2^20, bw <= 64: no wrap
+      // the last miniblock need not be padded to its full size: only the deltas it still holds must be there
+      // (the reference decodes no more than it needs)
+      const size_t need = remaining >= vpm ? mbytes : (static_cast<size_t>(remaining) * bw + 7) / 8;
+      if (bw > 64 || pos > nbytes || need > nbytes - pos) {
         set_error("Parquet: DELTA_BINARY_PACKED miniblock runs past the page (corrupt data page?)");
         return ARX_INVALID;
       }
@@ -390,7 +406,7 @@ int arx_delta_scan_miniblocks(const void* data, size_t nbytes, uint64_t byte_bas
         out[nmb] = ArxDeltaMiniblock{(byte_base + pos) * 8, min_delta, bw, 0u};
       }
       ++nmb;
-      pos += mbytes;
+      pos += std::min(mbytes, nbytes - pos);
       remaining -= vpm;
     }
   }

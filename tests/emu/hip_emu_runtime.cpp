@@ -41,11 +41,15 @@ State& st() { return g_state; }
 static constexpr size_t kStack = 256 * 1024;
 static std::vector<void*> g_stacks;
 
+// Every fiber stack sits above one PROT_NONE guard page: a kernel whose per-thread locals (or -O1 recursion)
+// outgrow kStack faults there instead of silently scribbling over the neighbouring fiber's stack.
+static constexpr size_t kGuard = 4096;
 static void* stack_for(size_t i) {
   while (g_stacks.size() <= i) {
-    void* p = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    void* p = mmap(nullptr, kStack + kGuard, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (p == MAP_FAILED) { perror("mmap"); abort(); }
-    g_stacks.push_back(p);
+    if (mprotect(p, kGuard, PROT_NONE) != 0) { perror("mprotect"); abort(); }
+    g_stacks.push_back(static_cast<char*>(p) + kGuard);
   }
   return g_stacks[i];
 }

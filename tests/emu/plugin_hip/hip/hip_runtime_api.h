@@ -29,3 +29,6 @@ static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret_cast<hipStream_t>(1); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum { hipErrorNotReady = 600 };
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }   // synchronous streams are always idle
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
