@@ -271,6 +271,60 @@ def test_delta_binary_packed_oracle_pinned_to_the_reference_writer(tmp_path):
         assert np.array_equal(got.astype(want.dtype), want), name
 
 
+def _varint(x):
+    out = bytearray()
+    while x >= 0x80:
+        out.append((x & 0x7F) | 0x80)
+        x >>= 7
+    out.append(x)
+    return bytes(out)
+
+
+def test_corrupt_run_and_block_headers_are_rejected_not_wrapped():
+    """Crafted headers whose byte counts would wrap around size_t (a 2^62-group literal run, a 2^62-value block with
+    one miniblock) are refused — DeltaBitPackDecoder reads its header fields as uint32 and RleBitPackedDecoder
+    bounds every bit read — and a literal run may only be short where it reaches the last value."""
+    from arrow_amd import _lib
+    from arrow_amd import parquet as P
+
+    # DELTA_BINARY_PACKED: block_size = 2^62, 1 miniblock per block, 1000 values, first = 0
+    evil = _varint(1 << 62) + _varint(1) + _varint(1000) + _varint(0) + _varint(0) + bytes([1]) + bytes(64)
+    with pytest.raises(_lib.ArrowInvalid):
+        P.scan_delta_miniblocks(evil)
+    evil = _varint(128) + _varint(1 << 40) + _varint(1000) + _varint(0)
+    with pytest.raises(_lib.ArrowInvalid):
+        P.scan_delta_miniblocks(evil)
+    # RLE hybrid, bit width 3: a literal run announcing 2^62 groups
+    with pytest.raises(_lib.ArrowInvalid):
+        P.scan_rle_runs(_varint(((1 << 62) << 1) | 1) + bytes(16), 3, 100)
+    # a literal run in the MIDDLE of the block that is cut short must fail even though 8 slack bytes would cover it
+    block = _varint((2 << 1) | 1) + bytes(4) + _varint(10 << 1) + bytes([1])      # 16 values need 6 bytes, 4 present
+    with pytest.raises(_lib.ArrowInvalid):
+        P.scan_rle_runs(block, 3, 26)
+    # ... while the LAST run may stop where its needed values stop: 2 groups announced, 9 values needed = 4 bytes
+    runs, _ = P.scan_rle_runs(_varint((2 << 1) | 1) + bytes(4), 3, 9)
+    assert len(runs) == 1
+
+
+def test_delta_last_miniblock_need_not_be_padded():
+    """A final miniblock holding fewer values than its size may be cut after the bytes those values use (the
+    reference decodes only what it needs); the walk accepts it and the restatement decodes the same values."""
+    from arrow_amd import parquet as P
+
+    vals = np.arange(0, 40 * 7, 7, dtype=np.int64) ** 2          # 40 values: one block, 39 deltas in miniblocks 0 and 1
+    page = O.delta_binary_packed_encode(vals, 128, 4)
+    mbs, vpm, total, first, used = P.scan_delta_miniblocks(page)
+    assert (vpm, total, used) == (32, 40, len(page)) and len(mbs) == 2
+    bw = int(mbs[1]["bit_width"]) if "bit_width" in mbs.dtype.names else None
+    # cut the padding of the last miniblock: 7 deltas live in it
+    if bw:
+        keep = len(page) - (32 * bw // 8) + (7 * bw + 7) // 8
+        mbs2, vpm2, total2, first2, used2 = P.scan_delta_miniblocks(page[:keep])
+        assert (vpm2, total2, first2, used2) == (vpm, total, first, keep) and len(mbs2) == 2
+        with pytest.raises(Exception):
+            P.scan_delta_miniblocks(page[:keep - 1])
+
+
 @pytest.mark.emu
 @pytest.mark.parametrize("block_size,miniblocks", [(128, 4), (256, 8), (128, 1), (1024, 4)])
 def test_delta_decode_kernel_vs_restatement(emu_ctx, block_size, miniblocks):
