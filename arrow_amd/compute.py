@@ -1312,6 +1312,30 @@ class GroupBySum:
                                               int(self.options.skip_nulls), valid.data_ptr(), stream))
         return keys[:g], kv[:g], mins[:g], maxs[:g], valid[:g]
 
+    def finalize_mean(self):
+        """hash_mean(int64): (keys, key_is_valid, means f64, valid).  Needs the rows in BOTH consume() and
+        consume_min_max() (the extrema bound the partial sums).  GroupedMeanImpl sums doubles in row order
+        (hash_aggregate_numeric.cc:352-430); that equals (double)sum / count in any order exactly when every
+        partial sum is an exact integer, i.e. count * max|value| < 2^53 for every group — otherwise the
+        reference's own result depends on row order and this declines."""
+        lib, stream = _lib_and_stream(self.device)
+        if getattr(self, "minmax", None) is None:
+            raise ArrowInvalid("finalize_mean without consume_min_max")
+        p = self.export_min_max()
+        g = int(p["keys"].numel())
+        means = torch.empty(max(g, 1), dtype=torch.float64, device=self.device)
+        valid = torch.empty(max(g, 1), dtype=torch.uint8, device=self.device)
+        inexact = torch.zeros(1, dtype=torch.int32, device=self.device)
+        check(lib.arx_groupby_mean_i64_finalize(p["sums"].data_ptr(), p["counts"].data_ptr(), p["mins"].data_ptr(),
+                                                p["maxs"].data_ptr(), p["no_nulls"].data_ptr(), g,
+                                                int(self.options.skip_nulls), self.options.min_count,
+                                                means.data_ptr(), valid.data_ptr(), inexact.data_ptr(), stream))
+        if int(inexact.item()) != 0:
+            raise ArrowNotImplementedError(
+                "hash_mean(int64): a group's partial sums exceed 2^53, where the reference's row-order double "
+                "accumulation is not associative (its result depends on row order); not reproducible bit for bit")
+        return p["keys"], p["key_is_valid"], means[:g], valid[:g]
+
     def num_groups(self) -> int:
         lib, stream = _lib_and_stream(self.device)
         n = C.c_int64(0)
@@ -1356,6 +1380,16 @@ class GroupBySum:
                                                int(self.options.skip_nulls), self.options.min_count,
                                                valid.data_ptr(), stream))
         return p["keys"], p["key_is_valid"], p["sums"], valid[:g]
+
+
+def group_by_mean(keys: Array, values: Array, capacity: int | None = None,
+                  options: ScalarAggregateOptions | None = None):
+    """Table.group_by(k).aggregate([(v, 'mean')]) for one int32 key and one int64 value (see finalize_mean)."""
+    cap = capacity or max(16, 2 * keys.length + 2)
+    op = GroupBySum(cap, keys.device, options)
+    op.consume(keys, values)
+    op.consume_min_max(keys, values)
+    return op.finalize_mean()
 
 
 def _groups_by_first_row(arr: Array, capacity: int | None, with_counts: bool):

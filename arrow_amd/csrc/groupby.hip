@@ -384,6 +384,38 @@ __global__ __launch_bounds__(kBlock) void groupby_merge_records_kernel(GroupbyVi
   gb_publish_new_groups(v, fresh);
 }
 
+// ---- hash_mean(int64): GroupedMeanImpl (kernels/hash_aggregate_numeric.cc:352-430) accumulates DOUBLES in row
+// order (GroupedMeanAccType: every number type sums in double), which a parallel reduction cannot reproduce bit for
+// bit in general.  It can whenever every partial sum of a group is exactly representable: then double addition is
+// exact in any order and equals the int64 sum.  |partial sums| <= count * max(|min|, |max|), so with that product
+// below 2^53 the mean is (double)sum / count exactly as the reference computes it (DoMean :397-400); a group that
+// breaks the bound raises *inexact and the caller declines with the reason.
+__global__ __launch_bounds__(kBlock) void groupby_mean_finalize_kernel(
+    const int64_t* __restrict__ sums, const int64_t* __restrict__ counts, const int64_t* __restrict__ mins,
+    const int64_t* __restrict__ maxs, const uint8_t* __restrict__ no_nulls, int64_t n, int skip_nulls,
+    uint32_t min_count, double* __restrict__ out_means, uint8_t* __restrict__ out_valid, unsigned int* inexact) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  bool bad = false;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t c = counts[i];
+    bool ok = c >= static_cast<int64_t>(min_count);
+    // Finish :402-420: the mean is computed wherever count >= min_count (0 / 0 = NaN with min_count = 0), 0 elsewhere
+    out_means[i] = ok ? static_cast<double>(sums[i]) / static_cast<double>(c) : 0.0;
+    if (!skip_nulls) ok = ok && no_nulls[i] != 0;
+    out_valid[i] = ok ? 1 : 0;
+    if (c > 0) {
+      const int64_t lo = mins[i], hi = maxs[i];
+      const uint64_t alo = lo < 0 ? static_cast<uint64_t>(0) - static_cast<uint64_t>(lo) : static_cast<uint64_t>(lo);
+      const uint64_t ahi = hi < 0 ? static_cast<uint64_t>(0) - static_cast<uint64_t>(hi) : static_cast<uint64_t>(hi);
+      const uint64_t amax = alo > ahi ? alo : ahi;
+      const uint64_t uc = static_cast<uint64_t>(c);
+      // count * amax < 2^53 without a 128-bit product: both factors below 2^53 and amax < 2^53 / count
+      if (uc >= (uint64_t(1) << 53) || amax >= (uint64_t(1) << 53) / uc + (((uint64_t(1) << 53) % uc) != 0 ? 1 : 0)) bad = true;
+    }
+  }
+  if (__any(bad) && lane_id() == 0) atomicOr(inexact, 1u);
+}
+
 // ---- lookup: out[i] = the sum column of keys[i]'s group, -1 if the key is not in the table
 // (read-only probe; what dictionary_encode uses to turn rows into dictionary indices once the
 // groups' dense ids have been merged in as their "sums")
@@ -1779,6 +1811,25 @@ int arx_groupby_sum_i64_merge_records(void* state, int64_t capacity, const ArxGr
   hipLaunchKernelGGL(groupby_merge_records_kernel, dim3(gb_grid(num_records)), dim3(kBlock), 0, as_stream(stream),
                      v, records, num_records);
   ARX_CHECK_LAUNCH("groupby_merge_records_kernel");
+  return ARX_OK;
+}
+
+int arx_groupby_mean_i64_finalize(const int64_t* sums, const int64_t* counts, const int64_t* mins, const int64_t* maxs,
+                                  const uint8_t* no_nulls, int64_t num_groups, int skip_nulls, uint32_t min_count,
+                                  double* out_means, uint8_t* out_valid, uint32_t* out_inexact, void* stream) {
+  if (num_groups < 0 || out_inexact == nullptr) {
+    set_error("bad arguments to arx_groupby_mean_i64_finalize");
+    return ARX_INVALID;
+  }
+  if (num_groups == 0) return ARX_OK;
+  if (sums == nullptr || counts == nullptr || mins == nullptr || maxs == nullptr || out_means == nullptr ||
+      out_valid == nullptr || (!skip_nulls && no_nulls == nullptr)) {
+    set_error("NULL buffer passed to arx_groupby_mean_i64_finalize");
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(groupby_mean_finalize_kernel, dim3(gb_grid(num_groups)), dim3(kBlock), 0, as_stream(stream), sums,
+                     counts, mins, maxs, no_nulls, num_groups, skip_nulls, min_count, out_means, out_valid, out_inexact);
+  ARX_CHECK_LAUNCH("groupby_mean_finalize_kernel");
   return ARX_OK;
 }
 

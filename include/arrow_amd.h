@@ -489,6 +489,16 @@ int arx_groupby_minmax_finalize(const int64_t* mins, const int64_t* maxs, const 
 int arx_groupby_sum_i64_finalize(const int64_t* counts, const uint8_t* no_nulls,
                                  int64_t num_groups, int skip_nulls, uint32_t min_count,
                                  uint8_t* out_valid, void* stream);
+/* hash_mean(int64) — GroupedMeanImpl (hash_aggregate_numeric.cc:352-430): the reference sums DOUBLES in row order,
+ * which is reproducible by a parallel reduction exactly when every partial sum of a group is an exactly
+ * representable integer: count * max(|min|, |max|) < 2^53.  Inputs = the columns of arx_groupby_export WITH the
+ * extrema (the rows must also have gone through arx_groupby_minmax_i64_consume).  out_means[g] = (double)sum / count
+ * where count >= min_count (0 / 0 = NaN as in the reference), else 0; out_valid as for the sum; *out_inexact
+ * (device, caller-zeroed) is set if any group breaks the bound — the caller must then decline (the result would
+ * depend on row order in the reference too).  Asynchronous. */
+int arx_groupby_mean_i64_finalize(const int64_t* sums, const int64_t* counts, const int64_t* mins, const int64_t* maxs,
+                                  const uint8_t* no_nulls, int64_t num_groups, int skip_nulls, uint32_t min_count,
+                                  double* out_means, uint8_t* out_valid, uint32_t* out_inexact, void* stream);
 /* Radix partition of partial aggregates by hash(key) % num_parts for the multi-GPU
  * exchange: rows are written grouped by destination (order inside a
  * destination unspecified); out_part_counts = device int64[num_parts].  Asynchronous. */

@@ -413,6 +413,40 @@ def groupby_sum_i64(keys, key_valid, key_off, values, val_valid, val_off, length
                 no_nulls=onn[:ng], valid=ov[:ng])
 
 
+def groupby_mean_i64(keys, key_valid, key_off, values, val_valid, val_off, length, skip_nulls=True, min_count=1):
+    """GroupedMeanImpl<Int64Type> (kernels/hash_aggregate_numeric.cc:352-430) over an int32 key, row at a time:
+    the accumulator is a DOUBLE (GroupedMeanAccType :352-356), Consume adds static_cast<double>(v) in row order
+    (Reduce :371-375 through GroupedReducingAggregator::Consume :70-83), Finish :402-425 writes
+    reduced / count where count >= min_count (else 0 and null), and with !skip_nulls nulls groups that saw a null.
+    Groups in first-occurrence order; the null key is one group.  Returns dict(keys, key_is_valid, means, valid)."""
+    kv = unpack_bits(key_valid, key_off, length) if key_valid is not None else np.ones(length, bool)
+    vv = unpack_bits(val_valid, val_off, length) if val_valid is not None else np.ones(length, bool)
+    k = np.asarray(keys)[key_off: key_off + length]
+    v = np.asarray(values)[val_off: val_off + length]
+    index, out_keys, out_kv, acc, cnt, nn = {}, [], [], [], [], []
+    for i in range(length):
+        gkey = int(k[i]) if kv[i] else None
+        g = index.get(gkey)
+        if g is None:
+            g = index[gkey] = len(out_keys)
+            out_keys.append(0 if gkey is None else gkey)
+            out_kv.append(0 if gkey is None else 1)
+            acc.append(np.float64(0.0)); cnt.append(0); nn.append(True)
+        if vv[i]:
+            acc[g] = np.float64(acc[g] + np.float64(v[i]))
+            cnt[g] += 1
+        else:
+            nn[g] = False
+    means, valid = [], []
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for g in range(len(out_keys)):
+            ok = cnt[g] >= min_count
+            means.append(np.float64(acc[g]) / np.float64(cnt[g]) if ok else np.float64(0.0))
+            valid.append(ok and (skip_nulls or nn[g]))
+    return dict(keys=np.array(out_keys, dtype=np.int32), key_is_valid=np.array(out_kv, dtype=np.uint8),
+                means=np.array(means, dtype=np.float64), valid=np.array(valid, dtype=np.uint8))
+
+
 def groupby_minmax_i64(keys, key_valid, key_off, values, val_valid, val_off, length, skip_nulls=True):
     """GroupedMinMaxImpl<Int64Type> (kernels/hash_aggregate.cc:330-419) over an int32 key:
     Resize :346-354 (mins = max(), maxes = lowest(), has_values = has_nulls = false), Consume

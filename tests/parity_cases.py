@@ -779,6 +779,51 @@ def check_groupby_min_max(amd, keys: HostArray, values: HostArray, skip_nulls=Tr
     return got
 
 
+def check_groupby_mean(amd, keys: HostArray, values: HostArray, skip_nulls=True, min_count=1, capacity=None,
+                       use_pyarrow=True, batches=1, expect_decline=False):
+    """hash_mean(int64) on the fused table vs the oracle's row-order double accumulation (and pyarrow's hash_mean):
+    bit-exact doubles wherever every partial sum is an exact integer; declines (NotImplemented) otherwise."""
+    opts = amd.compute.ScalarAggregateOptions(skip_nulls, min_count)
+    dk, dv = keys.to_device(amd), values.to_device(amd)
+    cap = capacity or max(16, 2 * keys.length + 2)
+    op = amd.compute.GroupBySum(cap, dk.device, opts)
+    n = keys.length
+    step = max(1, (n + batches - 1) // batches)
+    for b in range(0, max(n, 1), step):
+        ks, vs = dk.slice(b, min(step, n - b)), dv.slice(b, min(step, n - b))
+        op.consume(ks, vs)
+        op.consume_min_max(ks, vs)
+    if expect_decline:
+        import pytest
+
+        with pytest.raises(NotImplementedError, match="2\\^53"):
+            op.finalize_mean()
+        return None
+    gk, gkv, gmean, gvalid = (x.cpu().numpy() for x in op.finalize_mean())
+    w = O.groupby_mean_i64(np.ascontiguousarray(keys.values), keys.valid_bitmap(), keys.offset,
+                           np.ascontiguousarray(values.values), values.valid_bitmap(), values.offset, n, skip_nulls,
+                           min_count)
+
+    def rows(k, kv, m, valid):
+        out = [(int(a) if b else None, np.float64(c).tobytes() if e else None) for a, b, c, e in zip(k, kv, m, valid)]
+        return sorted(out, key=lambda r: (r[0] is None, r[0] or 0))
+
+    got, want = rows(gk, gkv, gmean, gvalid), rows(w["keys"], w["key_is_valid"], w["means"], w["valid"])
+    tag = f"groupby_mean[n={n},skip_nulls={skip_nulls},min_count={min_count},batches={batches}]"
+    assert len(got) == len(want), f"{tag}: {len(got)} groups vs {len(want)}"
+    for i, (g, x) in enumerate(zip(got, want)):
+        assert g == x, f"{tag}: group {i}: got {g} want {x} (bit patterns of the float64 means)"
+    if use_pyarrow and pa is not None and n > 0:
+        t = pa.table({"k": keys.to_pyarrow(), "v": values.to_pyarrow()})
+        r = t.group_by("k", use_threads=False).aggregate(
+            [("v", "mean", pc.ScalarAggregateOptions(skip_nulls=skip_nulls, min_count=min_count))])
+        rk, rm = r.column("k").combine_chunks(), r.column("v_mean").combine_chunks()
+        ref = sorted(((a, None if b is None else np.float64(b).tobytes()) for a, b in zip(rk.to_pylist(), rm.to_pylist())),
+                     key=lambda r: (r[0] is None, r[0] or 0))
+        assert got == ref, tag + " vs pyarrow hash_mean"
+    return got
+
+
 def check_unique_and_value_counts(amd, arr: HostArray, use_pyarrow=True):
     """unique / value_counts (first-appearance order) vs the oracle and pyarrow."""
     d = arr.to_device(amd)

@@ -419,6 +419,26 @@ ACERO_SCRIPT = textwrap.dedent(r'''
         assert mm.column("k").equals(ref.column("k"))
         for i, name in enumerate(["lo", "s", "hi3", "c", "hi"]):
             assert mm.column(name).equals(ref.column(1 + i)), (name, mm.column(name).slice(0, 5), ref.column(1 + i).slice(0, 5))
+    # hash_mean(int64): float64 column, bit-equal to the reference's row-order double accumulation while the partial
+    # sums stay exact integers (values below 2^31 here); declined with the reason for full-range values
+    tsmall = pa.table({"k": tn.column("k"), "v": pa.array(rng.integers(-2**31, 2**31, n), mask=rng.random(n) < 0.2)})
+    for o_mean in (None, pc.ScalarAggregateOptions(skip_nulls=False, min_count=2)):
+        mean = acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tsmall)),
+            acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions(
+                [("v", "hash_mean", o_mean, "m"), ("v", "hash_sum", None, "s")], keys=["k"])),
+        ]).to_table().sort_by("k")
+        ref = tsmall.group_by("k", use_threads=False).aggregate([("v", "mean", o_mean), ("v", "sum")]).sort_by("k")
+        assert mean.schema.field("m").type == pa.float64()
+        assert mean.column("k").equals(ref.column("k")) and mean.column("s").equals(ref.column(2))
+        assert mean.column("m").equals(ref.column(1)), (mean.column("m").slice(0, 5), ref.column(1).slice(0, 5))
+    try:
+        acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tn)),
+            acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_mean", None, "m")], keys=["k"]))]).to_table()
+        raise SystemExit("expected NotImplemented for hash_mean over full-range int64")
+    except pa.lib.ArrowNotImplementedError as e:
+        assert "2^53" in str(e)
     try:
         fused_bad = acero.Declaration.from_sequence([
             acero.Declaration("table_source", acero.TableSourceNodeOptions(tn)),

@@ -840,6 +840,27 @@ def test_groupby_min_max(gpu_ctx, skip_nulls, knull, vnull, batches, groups):
     P.check_groupby_min_max(gpu_ctx, k, v, skip_nulls, batches=batches, use_pyarrow=(groups <= 1000))
 
 
+@pytest.mark.parametrize("skip_nulls,min_count,knull,vnull,batches", [(True, 1, 0.0, 0.0, 1), (False, 1, 0.05, 0.2, 3),
+                                                                        (True, 0, 0.1, 1.0, 2), (True, 3, 0.02, 0.5, 1)])
+def test_groupby_mean_int64(gpu_ctx, skip_nulls, min_count, knull, vnull, batches):
+    """hash_mean(int64) (GroupedMeanImpl: doubles summed in row order) = (double)sum / count bit for bit while every
+    partial sum is an exact integer; all-null groups, min_count = 0 (0 / 0 = NaN), !skip_nulls."""
+    rng = rng_for("gmean", skip_nulls, min_count, knull, vnull, batches)
+    n = 2000000
+    k = U.random_array(rng, np.int32, n, null_p=knull, offset=2, lo=-40, hi=40)
+    v = U.random_array(rng, np.int64, n, null_p=vnull, offset=1, lo=-2**31, hi=2**31)
+    P.check_groupby_mean(gpu_ctx, k, v, skip_nulls, min_count, batches=batches)
+
+
+def test_groupby_mean_declines_where_the_reference_is_order_dependent(gpu_ctx):
+    """Values near 2^62: the reference's double partial sums are rounded differently for different row orders,
+    so there is nothing to be bit-exact with — NotImplemented with the reason, never a wrong number."""
+    rng = rng_for("gmean-big")
+    k = U.random_array(rng, np.int32, 5000, lo=0, hi=10)
+    v = U.random_array(rng, np.int64, 5000, lo=2**60, hi=2**62)
+    P.check_groupby_mean(gpu_ctx, k, v, expect_decline=True)
+
+
 def test_groupby_min_max_next_to_sum_and_merge(gpu_ctx):
     amd = gpu_ctx
     rng = rng_for("gbminmaxsum")
