@@ -23,7 +23,7 @@ import torch
 from . import _lib, tracing
 from ._lib import (ArrowIndexError, ArrowInvalid, ArrowNotImplementedError, check)  # noqa: F401
 from .array import (Array, DataType, Scalar, alloc, bitmap_nbytes, bool_, current_stream, float32,
-                    float64, int32, int64, kUnknownNullCount, uint8, uint16, uint32, uint64,
+                    float64, int8, int16, int32, int64, kUnknownNullCount, uint8, uint16, uint32, uint64,
                     INDEX_TYPE_ID, is_base_binary)
 
 # --------------------------------------------------------------------------- options
@@ -361,6 +361,32 @@ def _exec_cast_i64_f64(args, options):
                                ws.numel(), out.data_ptr(), stream))
     validity, nc = _propagate_validity([arr], n, dev)
     return Array(float64, n, [validity, out], nc, 0)
+
+
+# ARX_NUM_* of include/arrow_amd.h
+_NUM_TYPE_ID = {"int8": 0, "uint8": 1, "int16": 2, "uint16": 3, "int32": 4, "uint32": 5, "int64": 6, "uint64": 7,
+                "float": 8, "double": 9}
+_NUMERIC = lambda t: t.name in _NUM_TYPE_ID  # noqa: E731
+
+
+def _make_exec_cast_numeric(to_type: DataType):
+    def _exec(args, options):
+        """Any numeric pair (scalar_cast_numeric.cc:46-60, 190-207, 270-279): static_cast on every slot + the mode's
+        check on the valid ones (arx_cast_numeric)."""
+        (arr,) = args
+        dev = arr.device
+        lib, stream = _lib_and_stream(dev)
+        n = arr.length
+        out = alloc(n * to_type.byte_width, dev)
+        ws = _workspace(dev, 64, "cast")
+        sp = arr.span()
+        check(lib.arx_cast_numeric(C.byref(sp), _NUM_TYPE_ID[arr.type.name], _NUM_TYPE_ID[to_type.name],
+                                   int(bool(getattr(options, "allow_int_overflow", False))),
+                                   int(bool(getattr(options, "allow_float_truncate", False))),
+                                   ws.data_ptr(), ws.numel(), out.data_ptr(), stream))
+        validity, nc = _propagate_validity([arr], n, dev)
+        return Array(to_type, n, [validity, out], nc, 0)
+    return _exec
 
 
 def _exec_cast_i32_i64(args, options):
@@ -903,18 +929,16 @@ def _build_registry() -> FunctionRegistry:
     reg.add_function(f)
     reg.add_function(Function("take", Function.META, 2, TakeOptions(), _take_meta))
 
-    c = Function("cast_float", Function.SCALAR, 1)
-    c.add_kernel(Kernel((float64,), _exec_cast_f64_f32, float32))
-    _cast_table["float"] = c
-    c = Function("cast_int32", Function.SCALAR, 1)
-    c.add_kernel(Kernel((int64,), _exec_cast_i64_i32, int32))
-    _cast_table["int32"] = c
-    c = Function("cast_int64", Function.SCALAR, 1)
-    c.add_kernel(Kernel((int32,), _exec_cast_i32_i64, int64))
-    _cast_table["int64"] = c
-    c = Function("cast_double", Function.SCALAR, 1)
-    c.add_kernel(Kernel((int64,), _exec_cast_i64_f64, float64))
-    _cast_table["double"] = c
+    # one cast function per numeric target (GetCastFunction, cast.cc:207-214; kernels of
+    # scalar_cast_numeric.cc:797-858): the generic pair kernel first, the tuned ones after it (last match wins)
+    for to in (int8, uint8, int16, uint16, int32, uint32, int64, uint64, float32, float64):
+        c = Function("cast_" + to.name, Function.SCALAR, 1)
+        c.add_kernel(Kernel((_NUMERIC,), _make_exec_cast_numeric(to), to))
+        _cast_table[to.name] = c
+    _cast_table["float"].add_kernel(Kernel((float64,), _exec_cast_f64_f32, float32))
+    _cast_table["int32"].add_kernel(Kernel((int64,), _exec_cast_i64_i32, int32))
+    _cast_table["int64"].add_kernel(Kernel((int32,), _exec_cast_i32_i64, int64))
+    _cast_table["double"].add_kernel(Kernel((int64,), _exec_cast_i64_f64, float64))
     reg.add_function(Function("cast", Function.META, 1, None, _cast_meta))
 
     f = Function("greater", Function.SCALAR, 2)
@@ -1238,9 +1262,66 @@ class GroupBySum:
         self.state = alloc(lib.arx_groupby_state_bytes(self.capacity), self.device)
         check(lib.arx_groupby_init(self.state.data_ptr(), self.capacity, stream))
 
+    # ---- key / value types beyond (int32, int64): what the reference registers (Grouper key types,
+    # row/grouper.cc:559-611; hash_sum value types, hash_aggregate_numeric.cc:1188-1200) mapped onto the one device
+    # table by width-changing casts that are bijections on the values present
+    _KEY32_SIGNED = ("int8", "int16", "int32", "date32[day]", "time32[s]", "time32[ms]")
+    _KEY32_UNSIGNED = ("uint8", "uint16", "uint32")
+
+    def _normalise_key(self, keys: Array) -> Array:
+        name = keys.type.name
+        prev = getattr(self, "key_type", None)
+        if prev is not None and prev != keys.type:
+            raise ArrowInvalid(f"GroupBySum: key type changed from {prev.name} to {name}")
+        self.key_type = keys.type
+        if keys.type == int32:
+            return keys
+        if name in ("uint32", "date32[day]", "time32[s]", "time32[ms]"):
+            return Array(int32, keys.length, keys.buffers, keys.null_count, keys.offset)      # same bits, same equality
+        if name in ("int8", "int16", "uint8", "uint16"):
+            return cast(keys, int32)                                                          # value-preserving widening
+        if keys.type.bit_width == 64 and keys.type.name != "double":
+            # 64-bit integer / temporal keys: the device table holds 32-bit keys, so they are accepted when every
+            # valid key fits (a checked cast: the first one that does not names the error), declined otherwise
+            try:
+                if name == "uint64":
+                    return cast(keys, int32)
+                as_i64 = keys if keys.type == int64 else Array(int64, keys.length, keys.buffers, keys.null_count, keys.offset)
+                return cast(as_i64, int32)
+            except ArrowInvalid as e:
+                raise ArrowNotImplementedError(f"GroupBySum: {name} keys beyond the int32 range are not implemented "
+                                               f"(the device table holds 32-bit keys): {e}") from None
+        raise ArrowNotImplementedError(f"GroupBySum: keys of type {name}")
+
+    def _normalise_value(self, values: Array) -> Array:
+        name = values.type.name
+        prev = getattr(self, "value_type", None)
+        if prev is not None and prev != values.type:
+            raise ArrowInvalid(f"GroupBySum: value type changed from {prev.name} to {name}")
+        self.value_type = values.type
+        if values.type == int64:
+            return values
+        if name == "uint64":      # the accumulator of unsigned inputs is UInt64 (FindAccumulatorType): same wrap-around bits
+            return Array(int64, values.length, values.buffers, values.null_count, values.offset)
+        if name in ("int8", "int16", "int32"):
+            return cast(values, int64)
+        if name in ("uint8", "uint16", "uint32"):
+            w = cast(values, uint64)
+            return Array(int64, w.length, w.buffers, w.null_count, w.offset)
+        if name in ("float", "double"):
+            raise ArrowNotImplementedError(
+                f"GroupBySum: hash_sum({name}) accumulates doubles in row order in the reference "
+                "(hash_aggregate_numeric.cc:70-83), which a parallel reduction cannot reproduce bit for bit")
+        raise ArrowNotImplementedError(f"GroupBySum: values of type {name}")
+
+    @property
+    def sum_type(self) -> DataType:
+        """Output type of hash_sum for the consumed value type (FindAccumulatorType, aggregate_internal.h:41-44)."""
+        vt = getattr(self, "value_type", int64)
+        return uint64 if vt.name.startswith("uint") else int64
+
     def consume(self, keys: Array, values: Array) -> None:
-        if keys.type != int32 or values.type != int64:
-            raise ArrowNotImplementedError("GroupBySum: int32 keys and int64 values only")
+        keys, values = self._normalise_key(keys), self._normalise_value(values)
         lib, stream = _lib_and_stream(self.device)
         ks, vs = keys.span(), values.span()
         ws_bytes = lib.arx_groupby_consume_workspace_bytes(keys.length, self.capacity)
@@ -1256,8 +1337,9 @@ class GroupBySum:
     def consume_min_max(self, keys: Array, values: Array) -> None:
         """Folds the rows into per-group extrema; does not touch the sums, so the same rows may also
         go through consume()."""
-        if keys.type != int32 or values.type != int64:
-            raise ArrowNotImplementedError("GroupBySum: int32 keys and int64 values only")
+        keys = self._normalise_key(keys)
+        if values.type != int64:
+            raise ArrowNotImplementedError("GroupBySum: hash_min / hash_max over int64 values only")
         lib, stream = _lib_and_stream(self.device)
         if getattr(self, "minmax", None) is None:
             self.minmax = alloc(lib.arx_groupby_minmax_bytes(self.capacity), self.device)

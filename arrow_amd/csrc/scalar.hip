@@ -113,6 +113,53 @@ __global__ __launch_bounds__(kBlock) void cast_i32_i64_kernel(const int32_t* __r
   }
 }
 
+// ------------------------------------------------------------------ numeric casts, all 10 x 10 pairs
+// CastNumberToNumberUnsafe = static_cast on every slot (scalar_cast_internal.cc:41-53, 158-...), then/before the
+// mode's check on VALID slots only; the smallest offending row goes to *first_bad (the reference reports the first
+// offender in row order):
+//   MODE 1  IntegersInRange(lo, hi) — CastIntegerToInteger / CastIntegerToFloating (scalar_cast_numeric.cc:46-54,
+//           270-279; util/int_util.cc:594-665); bounds are values of the INPUT type
+//   MODE 2  WasTruncated: static_cast<In>(out) != in — CastFloatingToInteger (:62-207): out-of-range values and
+//           NaN fail it as well, like in the reference
+template <typename InT, typename OutT, int MODE>
+__global__ __launch_bounds__(kBlock) void cast_numeric_kernel(const InT* __restrict__ in, Bits valid, int64_t n,
+                                                              OutT* __restrict__ out, InT lo, InT hi,
+                                                              unsigned long long* __restrict__ first_bad) {
+  constexpr int U = 4;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x * U;
+  unsigned long long bad = ~0ull;
+  for (int64_t base = (static_cast<int64_t>(blockIdx.x) * blockDim.x) * U + threadIdx.x; base < n; base += stride) {
+    InT v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + static_cast<int64_t>(u) * blockDim.x;
+      v[u] = in[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + static_cast<int64_t>(u) * blockDim.x;
+      if (i >= n) continue;
+      const OutT o = static_cast<OutT>(v[u]);
+      out[i] = o;
+      bool fail = false;
+      if constexpr (MODE == 1) fail = v[u] < lo || v[u] > hi;
+      if constexpr (MODE == 2 && std::is_integral<OutT>::value) {
+        // the hardware conversion saturates where the reference's is undefined (x86 yields INT_MIN): an explicit range
+        // test keeps 2^31 / 2^63 / 2^64, which survive a saturated round trip, on the failing side as there
+        constexpr double kLo = static_cast<double>(std::numeric_limits<OutT>::lowest());
+        constexpr double kHi = 2.0 * static_cast<double>(OutT(1) << (std::numeric_limits<OutT>::digits - 1));
+        const double dv = static_cast<double>(v[u]);
+        fail = !(dv >= kLo && dv < kHi) || !(static_cast<InT>(o) == v[u]);
+      }
+      if (fail) {
+        const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1ull;
+        if (ok && static_cast<unsigned long long>(i) < bad) bad = static_cast<unsigned long long>(i);
+      }
+    }
+  }
+  if (MODE != 0 && bad != ~0ull) atomicMin(first_bad, bad);
+}
+
 // ------------------------------------------------------------------ compare (greater)
 // Each wave step covers 128 rows: lane l holds rows 2l, 2l+1 (one 16-byte load per operand).
 // The two ballots (even rows / odd rows) are interleaved with scalar bit-spreads into two
@@ -697,11 +744,155 @@ static int cast_i64_checked(const char* what, const ArxSpan* values, int uncheck
   return ARX_OK;
 }
 
+// ---- generic numeric cast (arx_cast_numeric)
+template <typename T> struct NumName;
+#define ARX_NUM_NAME(T, S) template <> struct NumName<T> { static const char* get() { return S; } }
+ARX_NUM_NAME(int8_t, "int8"); ARX_NUM_NAME(uint8_t, "uint8"); ARX_NUM_NAME(int16_t, "int16"); ARX_NUM_NAME(uint16_t, "uint16");
+ARX_NUM_NAME(int32_t, "int32"); ARX_NUM_NAME(uint32_t, "uint32"); ARX_NUM_NAME(int64_t, "int64"); ARX_NUM_NAME(uint64_t, "uint64");
+ARX_NUM_NAME(float, "float"); ARX_NUM_NAME(double, "double");
+#undef ARX_NUM_NAME
+
+template <typename T>
+static void format_num(char* buf, size_t cap, T v) {
+  if constexpr (std::is_floating_point<T>::value) {
+    snprintf(buf, cap, "%f", static_cast<double>(v));                       // std::to_string, as the reference's StringBuilder prints floats
+  } else if constexpr (std::is_signed<T>::value) {
+    snprintf(buf, cap, "%lld", static_cast<long long>(v));
+  } else {
+    snprintf(buf, cap, "%llu", static_cast<unsigned long long>(v));
+  }
+}
+
+template <typename InT, typename OutT>
+static int cast_numeric_pair(const ArxSpan* values, int allow_int_overflow, int allow_float_truncate, void* ws,
+                             size_t ws_bytes, void* out_v, hipStream_t st) {
+  const int64_t n = values->length;
+  const InT* in = static_cast<const InT*>(values->data) + values->offset;
+  OutT* out = static_cast<OutT*>(out_v);
+  const Bits valid = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
+  constexpr bool in_f = std::is_floating_point<InT>::value, out_f = std::is_floating_point<OutT>::value;
+  int mode = 0;
+  InT lo = std::numeric_limits<InT>::lowest(), hi = std::numeric_limits<InT>::max();
+  if constexpr (!in_f && !out_f) {
+    // GetSafeMinMax (util/int_util.cc:795-880): the part of the output range the input type can express
+    if (!allow_int_overflow && !std::is_same<InT, OutT>::value) {
+      constexpr bool in_s = std::is_signed<InT>::value, out_s = std::is_signed<OutT>::value;
+      if (in_s == out_s) {
+        if (sizeof(OutT) < sizeof(InT)) {
+          lo = static_cast<InT>(std::numeric_limits<OutT>::lowest());
+          hi = static_cast<InT>(std::numeric_limits<OutT>::max());
+        }
+      } else if (!in_s) {   // unsigned -> signed
+        lo = 0;
+        hi = sizeof(InT) < sizeof(OutT) ? std::numeric_limits<InT>::max() : static_cast<InT>(std::numeric_limits<OutT>::max());
+      } else {              // signed -> unsigned
+        lo = 0;
+        hi = sizeof(InT) <= sizeof(OutT) ? std::numeric_limits<InT>::max() : static_cast<InT>(std::numeric_limits<OutT>::max());
+      }
+      if (lo != std::numeric_limits<InT>::lowest() || hi != std::numeric_limits<InT>::max()) mode = 1;
+    }
+  } else if constexpr (!in_f && out_f) {
+    // CheckForIntegerToFloatingTruncation (scalar_cast_numeric.cc:229-268): 32/64-bit integers into float, 64-bit into double
+    if (!allow_float_truncate) {
+      const bool f32 = sizeof(OutT) == 4;
+      if (sizeof(InT) == 8 || (sizeof(InT) == 4 && f32)) {
+        const long long limit = f32 ? (1LL << 24) : (1LL << 53);
+        lo = std::is_signed<InT>::value ? static_cast<InT>(-limit) : static_cast<InT>(0);
+        hi = static_cast<InT>(limit);
+        mode = 1;
+      }
+    }
+  } else if constexpr (in_f && !out_f) {
+    if (!allow_float_truncate) mode = 2;
+  }
+  unsigned long long* first_bad = static_cast<unsigned long long*>(ws);
+  if (mode != 0) {
+    if (ws == nullptr || ws_bytes < 8) {
+      set_error("arx_cast_numeric: a checked cast needs >= 8 bytes of device workspace");
+      return ARX_INVALID;
+    }
+    ARX_HIP(hipMemsetAsync(first_bad, 0xFF, 8, st));
+  }
+  const unsigned grid = stream_grid(kBlock * 4, n);
+  if (mode == 0) {
+    hipLaunchKernelGGL((cast_numeric_kernel<InT, OutT, 0>), dim3(grid), dim3(kBlock), 0, st, in, valid, n, out, lo, hi, first_bad);
+  } else if (mode == 1) {
+    hipLaunchKernelGGL((cast_numeric_kernel<InT, OutT, 1>), dim3(grid), dim3(kBlock), 0, st, in, valid, n, out, lo, hi, first_bad);
+  } else {
+    hipLaunchKernelGGL((cast_numeric_kernel<InT, OutT, 2>), dim3(grid), dim3(kBlock), 0, st, in, valid, n, out, lo, hi, first_bad);
+  }
+  ARX_CHECK_LAUNCH("cast_numeric_kernel");
+  if (mode == 0) return ARX_OK;
+  unsigned long long bad = ~0ull;
+  ARX_HIP(hipMemcpyAsync(&bad, first_bad, 8, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  if (bad == ~0ull) return ARX_OK;
+  InT v{};
+  ARX_HIP(hipMemcpyAsync(&v, in + bad, sizeof(InT), hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  char sv[64], slo[64], shi[64];
+  format_num(sv, sizeof(sv), v);
+  if (mode == 1) {
+    format_num(slo, sizeof(slo), lo);
+    format_num(shi, sizeof(shi), hi);
+    set_error("Integer value %s not in range: %s to %s", sv, slo, shi);      // util/int_util.cc:607-611
+  } else {
+    set_error("Float value %s was truncated converting to %s", sv, NumName<OutT>::get());   // scalar_cast_numeric.cc:96-99
+  }
+  return ARX_INVALID;
+}
+
+template <typename InT>
+static int cast_numeric_from(int out_type, const ArxSpan* values, int aio, int aft, void* ws, size_t ws_bytes, void* out,
+                             hipStream_t st) {
+  switch (out_type) {
+    case ARX_NUM_INT8: return cast_numeric_pair<InT, int8_t>(values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_UINT8: return cast_numeric_pair<InT, uint8_t>(values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_INT16: return cast_numeric_pair<InT, int16_t>(values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_UINT16: return cast_numeric_pair<InT, uint16_t>(values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_INT32: return cast_numeric_pair<InT, int32_t>(values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_UINT32: return cast_numeric_pair<InT, uint32_t>(values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_INT64: return cast_numeric_pair<InT, int64_t>(values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_UINT64: return cast_numeric_pair<InT, uint64_t>(values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_FLOAT32: return cast_numeric_pair<InT, float>(values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_FLOAT64: return cast_numeric_pair<InT, double>(values, aio, aft, ws, ws_bytes, out, st);
+    default: set_error("arx_cast_numeric: unknown output type %d", out_type); return ARX_INVALID;
+  }
+}
+
 }  // namespace arx
 
 using namespace arx;
 
 extern "C" {
+
+int arx_cast_numeric(const ArxSpan* values, int in_type, int out_type, int allow_int_overflow, int allow_float_truncate,
+                     void* ws, size_t ws_bytes, void* out, void* stream) {
+  if (values == nullptr || values->length < 0 || values->offset < 0) {
+    set_error("bad arguments to arx_cast_numeric");
+    return ARX_INVALID;
+  }
+  if (values->length == 0) return ARX_OK;
+  if (values->data == nullptr || out == nullptr) {
+    set_error("NULL buffer passed to arx_cast_numeric");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  const int aio = allow_int_overflow, aft = allow_float_truncate;
+  switch (in_type) {
+    case ARX_NUM_INT8: return cast_numeric_from<int8_t>(out_type, values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_UINT8: return cast_numeric_from<uint8_t>(out_type, values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_INT16: return cast_numeric_from<int16_t>(out_type, values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_UINT16: return cast_numeric_from<uint16_t>(out_type, values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_INT32: return cast_numeric_from<int32_t>(out_type, values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_UINT32: return cast_numeric_from<uint32_t>(out_type, values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_INT64: return cast_numeric_from<int64_t>(out_type, values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_UINT64: return cast_numeric_from<uint64_t>(out_type, values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_FLOAT32: return cast_numeric_from<float>(out_type, values, aio, aft, ws, ws_bytes, out, st);
+    case ARX_NUM_FLOAT64: return cast_numeric_from<double>(out_type, values, aio, aft, ws, ws_bytes, out, st);
+    default: set_error("arx_cast_numeric: unknown input type %d", in_type); return ARX_INVALID;
+  }
+}
 
 int arx_cast_f64_f32(const double* in, int64_t length, float* out, void* stream) {
   if (length < 0 || (length > 0 && (in == nullptr || out == nullptr))) {

@@ -210,6 +210,26 @@ int arx_cast_i32_i64(const int32_t* values, int64_t length, int64_t* out, void* 
 int arx_cast_i64_f64(const ArxSpan* values, int allow_float_truncate, void* ws, size_t ws_bytes, double* out,
                      void* stream);
 
+/* Every numeric pair — CastIntegerToInteger / CastFloatingToInteger / CastIntegerToFloating / CastFloatingToFloating
+ * (scalar_cast_numeric.cc:46-60, 190-207, 270-279; registration :797-858): all slots go through static_cast
+ * (CastNumberToNumberUnsafe), and on the VALID slots
+ *   integer -> integer, unless allow_int_overflow: IntegersCanFit (util/int_util.cc:795-900) —
+ *       "Integer value V not in range: LO to HI" with the bounds GetSafeMinMax derives for the pair;
+ *   integer -> floating, unless allow_float_truncate: |V| <= 2^24 (float) / 2^53 (double) for the 32/64-bit inputs
+ *       the reference checks (:229-268), same message;
+ *   floating -> integer, unless allow_float_truncate: static_cast<In>(out) == in, else
+ *       "Float value V was truncated converting to TYPE" (out-of-range values and NaN fail it too).  With
+ *       allow_float_truncate an out-of-range value converts to an unspecified integer (undefined behaviour in the
+ *       reference as well).
+ * The first offender in row order names the error (ARX_INVALID; synchronous when a check applies, ws >= 8 device
+ * bytes).  in_type / out_type: ARX_NUM_*. */
+enum {
+  ARX_NUM_INT8 = 0, ARX_NUM_UINT8 = 1, ARX_NUM_INT16 = 2, ARX_NUM_UINT16 = 3, ARX_NUM_INT32 = 4, ARX_NUM_UINT32 = 5,
+  ARX_NUM_INT64 = 6, ARX_NUM_UINT64 = 7, ARX_NUM_FLOAT32 = 8, ARX_NUM_FLOAT64 = 9
+};
+int arx_cast_numeric(const ArxSpan* values, int in_type, int out_type, int allow_int_overflow, int allow_float_truncate,
+                     void* ws, size_t ws_bytes, void* out, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Compare — replaces ComparePrimitiveArrayArray/ArrayScalar/ScalarArray<DoubleType,
  * Greater> (cpp/src/arrow/compute/kernels/scalar_compare.cc:165-247): bit i =

@@ -779,6 +779,81 @@ def check_groupby_min_max(amd, keys: HostArray, values: HostArray, skip_nulls=Tr
     return got
 
 
+NUMERIC_TYPES = {"int8": np.int8, "uint8": np.uint8, "int16": np.int16, "uint16": np.uint16, "int32": np.int32,
+                 "uint32": np.uint32, "int64": np.int64, "uint64": np.uint64, "float": np.float32, "double": np.float64}
+
+
+def check_cast_numeric_pair(amd, rng, in_name: str, out_name: str, n: int = 3000):
+    """cast(in -> out), safe and unsafe, vs the reference build (pyarrow): values on valid slots bit for bit, and
+    the SAME error text ("Integer value V not in range: LO to HI" / "Float value V was truncated converting to T")
+    naming the first offender.  Unsafe float -> integer of an out-of-range value is undefined behaviour in the
+    reference: those slots are not compared."""
+    from arrow_amd import _lib
+
+    it, ot = NUMERIC_TYPES[in_name], NUMERIC_TYPES[out_name]
+    if np.dtype(it).kind == "f":
+        x = (rng.standard_normal(n) * 1e3).astype(it)
+        x[::7] = np.round(x[::7])
+        x[5::97] = np.nan
+        x[9::131] = np.inf
+    else:
+        info = np.iinfo(it)
+        x = rng.integers(info.min, info.max, n, dtype=it, endpoint=True)
+        x[::3] = (x[::3] % 100).astype(it)
+    for null_p, variant in ((0.1, "mixed"), (0.0, "small")):
+        valid = rng.random(n) > null_p
+        xs = x.copy()
+        if variant == "small":      # values every pair can hold: the no-error path of the safe cast
+            xs = (np.abs(np.nan_to_num(xs.astype(np.float64), nan=1, posinf=2, neginf=3)) % 100).astype(it)
+        for safe in (True, False):
+            a = amd.Array.from_numpy(xs, valid if null_p else None)
+            pa_in = pa.array(xs, mask=None if not null_p else ~valid)
+            try:
+                want, werr = pc.cast(pa_in, pa.from_numpy_dtype(np.dtype(ot)), safe=safe), None
+            except pa.lib.ArrowInvalid as e:
+                want, werr = None, str(e)
+            try:
+                got, gerr = amd.compute.cast(a, amd.array.type_from_name(out_name), safe=safe), None
+            except _lib.ArrowInvalid as e:
+                got, gerr = None, str(e)
+            tag = f"cast {in_name}->{out_name} safe={safe} {variant}"
+            assert werr == gerr, f"{tag}: reference error {werr!r} vs {gerr!r}"
+            if want is None:
+                continue
+            gv, gvalid = got.to_numpy()
+            m = valid.copy() if null_p else np.ones(n, bool)
+            if gvalid is not None:
+                assert_equal(gvalid, m, tag + " validity")
+            if np.dtype(it).kind == "f" and np.dtype(ot).kind in "iu" and not safe:
+                info = np.iinfo(ot)
+                with np.errstate(invalid="ignore"):
+                    m &= np.isfinite(xs) & (xs > info.min) & (xs < info.max)
+            w = np.asarray(want.fill_null(0)).astype(ot)
+            assert np.array_equal(gv[m].view(np.uint8), w[m].view(np.uint8)), tag + " values"
+
+
+def check_groupby_sum_typed(amd, rng, key_dtype, value_dtype, n=5000):
+    """hash_sum over the other integer key / value types the reference registers (Grouper key types,
+    row/grouper.cc:559-611; value types + accumulators, hash_aggregate_numeric.cc:1188-1200,
+    aggregate_internal.h:41-44) vs pyarrow's group_by: same groups, same sums, same output type."""
+    k = rng.integers(0, 100, n).astype(key_dtype)
+    info = np.iinfo(value_dtype)
+    v = rng.integers(info.min, info.max, n, dtype=value_dtype, endpoint=True)
+    kval, vval = rng.random(n) > 0.05, rng.random(n) > 0.1
+    dk, dv = amd.Array.from_numpy(k, kval), amd.Array.from_numpy(v, vval)
+    op = amd.compute.GroupBySum(1024, dk.device)
+    op.consume(dk, dv)
+    gk, gkv, gs, gvalid = (x.cpu().numpy() for x in op.finalize())
+    t = pa.table({"k": pa.array(k, mask=~kval), "v": pa.array(v, mask=~vval)})
+    r = t.group_by("k", use_threads=False).aggregate([("v", "sum")])
+    ref = {(None if a is None else int(a)): b for a, b in zip(r.column("k").to_pylist(), r.column("v_sum").to_pylist())}
+    st = np.uint64 if op.sum_type.name == "uint64" else np.int64
+    got = {(int(a) if b else None): (int(np.array(c).astype(np.int64).view(st)) if d else None)
+           for a, b, c, d in zip(gk, gkv, gs, gvalid)}
+    assert got == ref, (key_dtype, value_dtype)
+    assert str(r.column("v_sum").type) == op.sum_type.name
+
+
 def check_groupby_mean(amd, keys: HostArray, values: HostArray, skip_nulls=True, min_count=1, capacity=None,
                        use_pyarrow=True, batches=1, expect_decline=False):
     """hash_mean(int64) on the fused table vs the oracle's row-order double accumulation (and pyarrow's hash_mean):

@@ -861,6 +861,35 @@ def test_groupby_mean_declines_where_the_reference_is_order_dependent(gpu_ctx):
     P.check_groupby_mean(gpu_ctx, k, v, expect_decline=True)
 
 
+@pytest.mark.parametrize("in_name", list(P.NUMERIC_TYPES))
+def test_cast_every_numeric_pair(gpu_ctx, in_name):
+    """CastIntegerToInteger / CastFloatingToInteger / CastIntegerToFloating / CastFloatingToFloating
+    (scalar_cast_numeric.cc:46-60, 190-207, 270-279) for all 10 x 10 numeric pairs, safe and unsafe."""
+    rng = rng_for("castpair", in_name)
+    for out_name in P.NUMERIC_TYPES:
+        if out_name != in_name:
+            P.check_cast_numeric_pair(gpu_ctx, rng, in_name, out_name, n=300000)
+
+
+@pytest.mark.parametrize("key_dtype", [np.int8, np.uint16, np.uint32, np.int64, np.uint64])
+def test_groupby_sum_other_key_and_value_types(gpu_ctx, key_dtype):
+    rng = rng_for("gbtyped", str(key_dtype))
+    for value_dtype in (np.int8, np.int32, np.uint32, np.uint64, np.int64):
+        P.check_groupby_sum_typed(gpu_ctx, rng, key_dtype, value_dtype, n=400000)
+
+
+def test_groupby_declines_what_it_cannot_reproduce(gpu_ctx):
+    """64-bit keys beyond the int32 range (the device table holds 32-bit keys) and floating-point sums (row-order
+    double accumulation in the reference) are NotImplemented with the reason — never a wrong answer."""
+    amd = gpu_ctx
+    op = amd.compute.GroupBySum(64)
+    with pytest.raises(NotImplementedError, match="beyond the int32 range"):
+        op.consume(amd.Array.from_numpy(np.array([1, 2**40], dtype=np.int64)), amd.Array.from_numpy(np.array([1, 2], dtype=np.int64)))
+    op = amd.compute.GroupBySum(64)
+    with pytest.raises(NotImplementedError, match="row order"):
+        op.consume(amd.Array.from_numpy(np.array([1, 2], dtype=np.int32)), amd.Array.from_numpy(np.array([1.0, 2.0])))
+
+
 def test_groupby_min_max_next_to_sum_and_merge(gpu_ctx):
     amd = gpu_ctx
     rng = rng_for("gbminmaxsum")
