@@ -1464,6 +1464,26 @@ class GroupBySum:
         return p["keys"], p["key_is_valid"], p["sums"], valid[:g]
 
 
+def indices_nonzero(arr: Array) -> Array:
+    """compute::IndicesNonZero (kernels/vector_selection.cc:352, vector_selection.cc DoNonZero): the uint64 positions
+    of the elements that are valid and non-zero (true for booleans), ascending.  = GetTakeIndices of the mask
+    `arr != 0` (nulls dropped), widened to uint64."""
+    if arr.type == bool_:
+        mask = arr
+    elif arr.type.name in _NUM_TYPE_ID:
+        wide = arr
+        if arr.type not in (int64, float64):
+            wide = cast(arr, float64 if arr.type.name in ("float", "double") else
+                        (uint64 if arr.type.name.startswith("uint") else int64))
+            if wide.type == uint64:       # same zero-ness, same bits
+                wide = Array(int64, wide.length, wide.buffers, wide.null_count, wide.offset)
+        mask = call_function("not_equal", [wide, _wrap_scalar(0 if wide.type == int64 else 0.0, wide)])
+    else:
+        raise ArrowNotImplementedError(f"indices_nonzero: {arr.type.name} values")
+    idx = get_take_indices(mask)
+    return cast(idx, uint64)
+
+
 def group_by_mean(keys: Array, values: Array, capacity: int | None = None,
                   options: ScalarAggregateOptions | None = None):
     """Table.group_by(k).aggregate([(v, 'mean')]) for one int32 key and one int64 value (see finalize_mean)."""

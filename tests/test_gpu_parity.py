@@ -890,6 +890,21 @@ def test_groupby_declines_what_it_cannot_reproduce(gpu_ctx):
         op.consume(amd.Array.from_numpy(np.array([1, 2], dtype=np.int32)), amd.Array.from_numpy(np.array([1.0, 2.0])))
 
 
+@pytest.mark.parametrize("dtype", [np.bool_, np.int8, np.uint16, np.int32, np.uint64, np.int64, np.float32, np.float64])
+def test_indices_nonzero(gpu_ctx, dtype):
+    """IndicesNonZero (kernels/vector_selection.cc:352): uint64 positions of the valid, non-zero elements vs pyarrow."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+
+    rng = rng_for("nonzero", str(dtype))
+    for n in (0, 5, 70000, 3000001):
+        x = rng.integers(0, 3, n).astype(dtype) if dtype != np.bool_ else rng.random(n) < 0.3
+        valid = rng.random(n) > 0.1
+        got = gpu_ctx.compute.indices_nonzero(gpu_ctx.Array.from_numpy(x, valid if n else None))
+        want = pc.indices_nonzero(pa.array(x, mask=(~valid) if n else None))
+        assert got.type.name == "uint64" and np.array_equal(got.to_numpy()[0], want.to_numpy()), (dtype, n)
+
+
 def test_groupby_min_max_next_to_sum_and_merge(gpu_ctx):
     amd = gpu_ctx
     rng = rng_for("gbminmaxsum")
