@@ -854,6 +854,41 @@ def check_groupby_sum_typed(amd, rng, key_dtype, value_dtype, n=5000):
     assert str(r.column("v_sum").type) == op.sum_type.name
 
 
+def replay_golden_sort(amd, gold, dtype):
+    """The golden sort cases of tests/golden/reference_vectors.json (vector_sort_test.cc:640-724) on the device."""
+    ran = 0
+    for case in gold["sort_indices_integral"] + gold["sort_indices_real"]:
+        vals = case["values"]
+        kind = np.dtype(dtype).kind
+        if kind != "f" and any(x == "NaN" or (isinstance(x, float) and x != int(x)) for x in vals if x is not None):
+            continue
+        valid = np.array([x is not None for x in vals], dtype=bool)
+        arr = np.array([0 if x is None else (np.nan if x == "NaN" else x) for x in vals], dtype=dtype)
+        if len(vals) == 0:
+            d = amd.Array.from_numpy(np.zeros(0, dtype=dtype))
+        else:
+            d = amd.Array.from_numpy(arr, None if valid.all() else valid)
+        got = amd.compute.sort_indices(d, order=case["order"], null_placement=case["null_placement"])
+        assert got.to_numpy()[0].tolist() == case["want"], (case, dtype)
+        ran += 1
+    return ran
+
+
+def replay_golden_sum_only(amd, gold):
+    """SumOnly (acero/hash_aggregate_test.cc:839-883): one consume per batch, key-sorted result."""
+    g = gold["hash_sum_sum_only"]
+    op = amd.compute.GroupBySum(64)
+    for b in g["batches"]:
+        kv = np.array([x is not None for x in b["key"]])
+        vv = np.array([x is not None for x in b["argument"]])
+        op.consume(amd.Array.from_numpy(np.array([0 if x is None else x for x in b["key"]], dtype=np.int32), kv),
+                   amd.Array.from_numpy(np.array([0 if x is None else x for x in b["argument"]], dtype=np.int64), vv))
+    gk, gkv, gs, gvalid = (x.cpu().numpy() for x in op.finalize())
+    rows = sorted(((int(a) if b else None, int(c) if d else None) for a, b, c, d in zip(gk, gkv, gs, gvalid)),
+                  key=lambda r: (r[0] is None, r[0] or 0))
+    assert [list(r) for r in rows] == g["want_sorted_by_key"]
+
+
 def check_groupby_mean(amd, keys: HostArray, values: HostArray, skip_nulls=True, min_count=1, capacity=None,
                        use_pyarrow=True, batches=1, expect_decline=False):
     """hash_mean(int64) on the fused table vs the oracle's row-order double accumulation (and pyarrow's hash_mean):

@@ -629,6 +629,18 @@ def test_indices_nonzero(emu_ctx, dtype):
         assert got.type.name == "uint64" and np.array_equal(got.to_numpy()[0], want.to_numpy()), (dtype, n)
 
 
+@pytest.mark.parametrize("dtype", [np.int64, np.uint64, np.int32, np.uint32, np.float64, np.float32])
+def test_golden_sort_and_sum_only_replay(emu_ctx, dtype):
+    """The reference's own known-answer tests for the two sharded paths (vector_sort_test.cc:640-724,
+    acero/hash_aggregate_test.cc:839-883; tests/golden/reference_vectors.json) replayed on the kernels."""
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    assert P.replay_golden_sort(emu_ctx, gold, dtype) >= 20
+    P.replay_golden_sum_only(emu_ctx, gold)
+
+
 def test_groupby_min_max_next_to_sum(emu_ctx):
     rng = rng_for("gbminmaxsum")
     k = U.random_array(rng, np.int32, 3000, null_p=0.02, lo=0, hi=500)

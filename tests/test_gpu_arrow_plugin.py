@@ -348,6 +348,84 @@ def test_device_resident_arrays_through_callfunction():
     assert r.returncode == 0 and "DEVICE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+GOLDEN_SCRIPT = textwrap.dedent(r'''
+    import ctypes, json, os, sys
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    from pyarrow import acero
+    sys.path.insert(0, ROOT)
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(0))     # the golden arrays are tiny: send them to the GPU anyway
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(k) for k in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(k) for k in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    g0 = lib.arrow_amd_plugin_calls(b"array_sort_indices", 1)
+    ran = 0
+    for typ in (pa.int64(), pa.uint64(), pa.int32(), pa.uint32(), pa.float64(), pa.float32()):
+        is_f = pa.types.is_floating(typ)
+        for case in gold["sort_indices_integral"] + gold["sort_indices_real"]:
+            vals = case["values"]
+            if not is_f and any(x == "NaN" or (isinstance(x, float) and x != int(x)) for x in vals if x is not None):
+                continue
+            arr = pa.array([None if x is None else (float("nan") if x == "NaN" else x) for x in vals], type=typ)
+            for where in ("host", "device"):
+                if where == "device" and len(arr) == 0:
+                    continue
+                a = to_device(arr) if where == "device" else arr
+                # unmodified pyarrow.compute -> CallFunction -> the registered kernel
+                got = pc.array_sort_indices(a, order=case["order"], null_placement=case["null_placement"])
+                got = to_host(got) if where == "device" else got
+                assert got.to_pylist() == case["want"], (str(typ), where, case)
+                ran += 1
+    used = lib.arrow_amd_plugin_calls(b"array_sort_indices", 1) - g0
+    assert ran > 300 and used > 200, (ran, used)     # the cases really ran on the registered GPU kernel
+    # SumOnly through Acero: the registered hash_sum(int64, uint32) vtable (GroupByNode) and the fused aggregate_rocm node
+    s = gold["hash_sum_sum_only"]
+    batches = [pa.record_batch({"argument": pa.array(b["argument"], pa.int64()), "key": pa.array(b["key"], pa.int32())})
+               for b in s["batches"]]
+    tab = pa.Table.from_batches(batches)
+    for threads in (True, False):
+        r = tab.group_by("key", use_threads=threads).aggregate([("argument", "sum")]).sort_by("key")
+        assert [[k, v] for k, v in zip(r.column("key").to_pylist(), r.column("argument_sum").to_pylist())] == s["want_sorted_by_key"]
+        fused = acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
+            acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("argument", "hash_sum", None, "s")], keys=["key"])),
+        ]).to_table(use_threads=threads).sort_by("key")
+        assert [[k, v] for k, v in zip(fused.column("key").to_pylist(), fused.column("s").to_pylist())] == s["want_sorted_by_key"]
+    assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) > 0
+    print("GOLDEN_OK", ran, used)
+''')
+
+
+def test_reference_golden_vectors_through_callfunction():
+    """SURVEY.md 8(c): the reference's own known-answer tests for sort_indices (vector_sort_test.cc:640-724) and the
+    SumOnly group-by (acero/hash_aggregate_test.cc:839-883), replayed through unmodified pyarrow.compute / Acero with
+    the plugin registered — host arrays and device-resident arrays, every key type the path registers."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + GOLDEN_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "GOLDEN_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 ACERO_SCRIPT = textwrap.dedent(r'''
     import ctypes, os, sys
     import numpy as np
@@ -1181,3 +1259,79 @@ PARQUET_ENCODINGS_SCRIPT = textwrap.dedent(r'''
     assert lib.arrow_amd_plugin_calls(b"parquet", 1) > 0
     print("PARQUET_ENCODINGS_OK")
 ''')
+
+
+def test_boolean_values_filter_and_take_on_device_resident_arrays():
+    """Filter / take of BOOLEAN (bit-packed) device values through Arrow's CallFunction (arx_take_bits behind the
+    array_filter / array_take shims), incl. sliced operands and EMIT_NULL."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + BOOLEAN_VALUES_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "BOOLEAN_VALUES_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_parquet_column_chunks_through_the_plugin():
+    """SURVEY.md 8 (f4): parquet::PageReader (headers, decompression) + the C-ABI kernels (levels,
+    indices, dictionary gather, null expansion) -> device-resident arrays equal to the reference's reader."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + PARQUET_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "PARQUET_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_single_sync_filter_path_on_device_resident_arrays():
+    """The opt-in single-synchronisation device filter (arrow_amd_plugin_set_filter_morsel_rows): worst-case allocation,
+    count -> compact back to back, one read-back — identical output to the default path and to the reference."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + MORSEL_FILTER_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "MORSEL_FILTER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_filter_and_take_of_device_resident_batches_and_tables():
+    """FilterMetaFunction / TakeMetaFunction shapes (F4 / T4 of SURVEY.md 8a: record batch, table, chunked array) over
+    device-resident data: per-column array_filter / array_take in HBM, equal to the reference on the host copies;
+    multi-chunk device columns and uncovered device casts are refused instead of read from the CPU."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + SELECTION_META_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "SELECTION_META_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_divide_on_device_resident_arrays():
+    """divide / divide_checked (int64, double) on device arrays through CallFunction: values, validity, and the error the
+    last failing valid slot names ("divide by zero" / "overflow"), equal to the reference; `/` in an Acero projection."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + DIVIDE_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "DIVIDE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_scalar_aggregates_on_device_resident_columns():
+    """SumImpl / CountImpl / MinMaxImpl (aggregate_basic.inc.cc:49-110,776-860) as ScalarAggregateKernel shims: `sum`,
+    `count`, `min_max`, `min`, `max` of int64 device columns with every option combination, chunked input (state
+    merge), a refused host+device mix, and Acero's key-less `aggregate` node over a filtered device table."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + AGGREGATE_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "AGGREGATE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_acero_order_by_over_a_device_resident_table():
+    """SURVEY.md 8 (f2): OrderByNode (acero/order_by_node.cc:100-108) as `order_by_rocm`: table_source ->
+    [filter] -> order_by_rocm over device-resident and host tables, one to three sort keys with their own
+    direction and null placement (int32 / int64 / float64 with NaNs / timestamp), payload columns of int64,
+    utf8, boolean; equal to the stock `order_by` over the host table, with and without threads."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + ORDER_BY_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "ORDER_BY_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_parquet_delta_and_split_encodings_through_the_plugin():
+    """DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY and BYTE_STREAM_SPLIT column chunks through arrow_amd_parquet_read_column
+    (parquet::PageReader for the pages, the C-ABI kernels for the values), equal to the reference's reader."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + PARQUET_ENCODINGS_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "PARQUET_ENCODINGS_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

@@ -905,6 +905,18 @@ def test_indices_nonzero(gpu_ctx, dtype):
         assert got.type.name == "uint64" and np.array_equal(got.to_numpy()[0], want.to_numpy()), (dtype, n)
 
 
+@pytest.mark.parametrize("dtype", [np.int64, np.uint64, np.int32, np.uint32, np.float64, np.float32])
+def test_golden_sort_and_sum_only_replay(gpu_ctx, dtype):
+    """The reference's own known-answer tests for the two sharded paths (vector_sort_test.cc:640-724,
+    acero/hash_aggregate_test.cc:839-883; tests/golden/reference_vectors.json) replayed on the kernels."""
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    assert P.replay_golden_sort(gpu_ctx, gold, dtype) >= 20
+    P.replay_golden_sum_only(gpu_ctx, gold)
+
+
 def test_groupby_min_max_next_to_sum_and_merge(gpu_ctx):
     amd = gpu_ctx
     rng = rng_for("gbminmaxsum")
@@ -969,3 +981,72 @@ def test_dictionary_encode(gpu_ctx, null_p, offset):
     a = U.random_array(rng, np.int32, 500003, null_p=null_p, offset=offset, tail=2, lo=-40000, hi=40000)
     P.check_dictionary_encode(gpu_ctx, a)
     P.check_dictionary_encode(gpu_ctx, U.random_array(rng, np.int32, 0))
+
+
+# ------------------------------------------------------------------ boolean values, scalar aggregates, divide, concatenate, order_by
+@pytest.mark.parametrize("idx_dtype", [np.uint8, np.int32, np.int64])
+@pytest.mark.parametrize("vnull,inull,voff", [(0.0, 0.0, 0), (0.2, 0.1, 5), (1.0, 0.5, 67)])
+def test_boolean_values_take_and_filter(gpu_ctx, idx_dtype, vnull, inull, voff):
+    """filter / take on BOOLEAN values (1-bit Gather, gather_internal.h; PrimitiveFilter's bit-width-1 case)."""
+    rng = rng_for("booltake", str(idx_dtype), vnull, inull, voff)
+    nv = 200 if np.dtype(idx_dtype).itemsize == 1 else 500003
+    v = U.random_mask(rng, nv, 0.5, null_p=vnull, offset=voff, tail=3)
+    i = U.random_array(rng, idx_dtype, 500003, null_p=inull, offset=1, lo=0, hi=nv - 1)
+    m = U.random_mask(rng, nv, 0.3, null_p=0.05, offset=2)
+    P.check_boolean_take_and_filter(gpu_ctx, v, i, m)
+
+
+def test_scalar_aggregates_int64(gpu_ctx):
+    """SumImpl / CountImpl / MinMaxImpl (aggregate_basic.inc.cc): wrap-around sum, options, batches."""
+    P.check_scalar_aggregates(gpu_ctx, rng_for("scalaragg"), n=1000003)
+
+
+def test_divide_and_divide_checked(gpu_ctx):
+    """Divide / DivideChecked (base_arithmetic_internal.h:366-424) through the C ABI against the oracle and pyarrow."""
+    P.check_divide(gpu_ctx, rng_for("divide"), n=300_007)
+
+
+@pytest.mark.parametrize("kind", ["int64", "int8", "bool", "utf8", "binary_nonull"])
+def test_concat_arrays(gpu_ctx, kind):
+    """Concatenate (array/concatenate.cc): sliced chunks glued at arbitrary bit positions, empty chunks."""
+    rng = rng_for("concat", kind)
+    specs = [(77, 0.2, 3), (0, 0.0, 0), (1, 0.0, 0), (130_001, 0.0, 65), (64, 1.0, 7), (300_000, 0.1, 0), (5, 0.5, 1)]
+    if kind == "bool":
+        chunks = [U.random_mask(rng, n, 0.5, null_p=p, offset=o, tail=2) for n, p, o in specs]
+    elif kind in ("utf8", "binary_nonull"):
+        chunks = [U.random_binary(rng, n, null_p=0.0 if kind == "binary_nonull" else p, offset=o, tail=2, utf8=kind == "utf8")
+                  for n, p, o in specs]
+    else:
+        chunks = [U.random_array(rng, np.dtype(kind).type, n, null_p=p, offset=o, tail=2) for n, p, o in specs]
+    P.check_concat_arrays(gpu_ctx, chunks)
+    P.check_concat_arrays(gpu_ctx, chunks[1:2])
+    P.check_concat_arrays(gpu_ctx, [chunks[3]])
+
+
+@pytest.mark.parametrize("null_placement", ["at_end", "at_start"])
+def test_order_by_several_keys(gpu_ctx, null_placement):
+    """OrderByNode::DoFinish (acero/order_by_node.cc:100-108) with up to three keys of mixed direction and
+    per-key null placement; few distinct values per key, NaNs in the float key, payload columns ride along."""
+    rng = rng_for("orderby", null_placement)
+    sizes = [(32_768, 3), (0, 0), (32_768, 0), (20_001, 5)]
+
+    def col(make):
+        return [make(n, o) for n, o in sizes]
+
+    def fkey(n, o):
+        a = U.random_array(rng, np.float64, n, null_p=0.1, offset=o, tail=1)
+        a.values[:] = np.round(a.values * 2) / 2
+        a.values[rng.random(len(a.values)) < 0.1] = np.nan
+        return a
+
+    k0 = col(lambda n, o: U.random_array(rng, np.int32, n, null_p=0.1, offset=o, tail=1, lo=-30, hi=30))
+    k1 = col(lambda n, o: U.random_array(rng, np.int64, n, null_p=0.1, offset=o, tail=1, lo=0, hi=40))
+    k2 = col(fkey)
+    payload = col(lambda n, o: U.random_array(rng, np.int64, n, null_p=0.2, offset=o, tail=1))
+    strs = col(lambda n, o: U.random_binary(rng, n, null_p=0.1, offset=o, tail=1, utf8=True))
+    flags = col(lambda n, o: U.random_mask(rng, n, 0.5, null_p=0.1, offset=o, tail=1))
+    cols = [k0, k1, k2, payload, strs, flags]
+    P.check_order_by(gpu_ctx, cols, [(0, "ascending"), (1, "descending")], null_placement)
+    P.check_order_by(gpu_ctx, cols, [(2, "descending"), (0, "descending"), (1, "ascending")], null_placement)
+    other = "at_start" if null_placement == "at_end" else "at_end"
+    P.check_order_by(gpu_ctx, cols, [(0, "descending"), (2, "ascending")], [null_placement, other])

@@ -40,6 +40,16 @@ def o_filter(v: U.HostArray, m: U.HostArray, sel):
     return to_list(vals, bm, len(vals))
 
 
+def golden_sort_array(values, dtype):
+    """JSON list (None = null, "NaN") -> HostArray of `dtype`; None if the values do not fit the type."""
+    if any(isinstance(x, float) and x != int(x) for x in values if x is not None and x != "NaN") and np.dtype(dtype).kind != "f":
+        return None
+    if any(x == "NaN" for x in values) and np.dtype(dtype).kind != "f":
+        return None
+    vals = [np.nan if x == "NaN" else x for x in values]
+    return from_list(vals, dtype)
+
+
 # ------------------------------------------------------------------ 1. golden vectors
 @pytest.mark.parametrize("case", GOLD["get_take_indices"], ids=lambda c: c["cite"])
 def test_golden_get_take_indices(case):
@@ -559,3 +569,30 @@ def test_sort_indices_multi_vs_pyarrow(seed):
     assert np.array_equal(O.sort_indices_multi(keys[:1], desc[:1], start[0]),
                           pc.sort_indices(pa.table(cols), sort_keys=[("k0", "descending" if desc[0] else "ascending",
                                                                       "at_start" if start[0] else "at_end")]).to_numpy())
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.uint64, np.int32, np.uint32, np.float64, np.float32])
+@pytest.mark.parametrize("case", GOLD["sort_indices_integral"] + GOLD["sort_indices_real"],
+                         ids=lambda c: f"{c['cite'].split(' ')[0]}-{c['order']}-{c['null_placement']}-{c['values']}"[:90])
+def test_golden_sort_indices(case, dtype):
+    """vector_sort_test.cc:640-724: stability on ties, descending ties, null placement, NaNs between the values and
+    the nulls — the oracle's argsort equals the expected permutation for every key type the path registers."""
+    a = golden_sort_array(case["values"], dtype)
+    if a is None:
+        pytest.skip("values of this case do not fit the key type")
+    got = O.sort_indices(np.ascontiguousarray(a.values), a.valid_bitmap(), a.offset, a.length,
+                         descending=case["order"] == "descending", nulls_at_start=case["null_placement"] == "at_start")
+    assert got.tolist() == case["want"]
+
+
+def test_golden_hash_sum_sum_only():
+    """acero/hash_aggregate_test.cc:839-883 (SumOnly): three batches, null key = its own group, all-null group -> null."""
+    g = GOLD["hash_sum_sum_only"]
+    keys = [k for b in g["batches"] for k in b["key"]]
+    vals = [v for b in g["batches"] for v in b["argument"]]
+    k, v = from_list(keys, np.int32), from_list(vals, np.int64)
+    w = O.groupby_sum_i64(np.ascontiguousarray(k.values), k.valid_bitmap(), 0, np.ascontiguousarray(v.values), v.valid_bitmap(),
+                          0, len(keys))
+    rows = sorted(((int(a) if b else None, int(c) if d else None) for a, b, c, d in
+                   zip(w["keys"], w["key_is_valid"], w["sums"], w["valid"])), key=lambda r: (r[0] is None, r[0] or 0))
+    assert [list(r) for r in rows] == g["want_sorted_by_key"]

@@ -377,3 +377,29 @@ def test_ipc_file_and_stream_to_device(emu_ctx, tmp_path):
     got = emu_ctx.ipc.read_table(pa.BufferReader(sink.getvalue()), columns=["i64_few", "str"])
     assert [a.length for a in got["str"]] == [2500, 2500]
     assert pa.chunked_array([a.to_pyarrow() for a in got["i64_few"]]).equals(t.column("i64_few"))
+
+
+# ------------------------------------------------------------------ the delta / split encodings on the device
+@pytest.mark.gpu
+@pytest.mark.parametrize("null_p", [0.0, 0.1])
+def test_parquet_byte_stream_split_gpu(gpu_ctx, tmp_path, null_p):
+    _write_split_and_check(gpu_ctx, str(tmp_path), 600_000, null_p, 79, compression="snappy")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("null_p", [0.0, 0.1])
+def test_parquet_delta_length_byte_array_gpu(gpu_ctx, tmp_path, null_p):
+    _write_delta_length_and_check(gpu_ctx, str(tmp_path), 300_000, null_p, 83, compression="snappy")
+
+
+@pytest.mark.gpu
+def test_delta_decode_kernel_vs_restatement_gpu(gpu_ctx):
+    PC.check_delta_decode(gpu_ctx, np.random.default_rng(5), 128, 4)
+    PC.check_delta_decode(gpu_ctx, np.random.default_rng(6), 512, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("null_p", [0.0, 0.1])
+def test_parquet_delta_binary_packed_gpu(gpu_ctx, tmp_path, null_p):
+    _write_delta_and_check(gpu_ctx, str(tmp_path), 600_000, null_p, 77, compression="snappy")
+    _write_delta_and_check(gpu_ctx, str(tmp_path), 70_001, null_p, 78, data_page_version="2.0", data_page_size=8192)

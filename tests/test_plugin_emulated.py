@@ -72,3 +72,7 @@ def test_filter_and_take_of_device_batches_and_tables_emulated():
 
 def test_divide_on_device_resident_arrays_emulated():
     _run(G.DIVIDE_SCRIPT, "DIVIDE_OK", 0.02)
+
+
+def test_reference_golden_vectors_through_callfunction_emulated():
+    _run(G.GOLDEN_SCRIPT, "GOLDEN_OK", 1)
