@@ -776,9 +776,17 @@ def _hash_sum_consume(state: GroupedSumInt64State, batch) -> None:
         if values.length != n:
             raise ArrowInvalid("Array arguments must all be the same length")
         span, is_scalar, sv = values.span(), 0, 0
-    check(lib.arx_hash_sum_i64_consume(C.byref(span), is_scalar, sv, gids.values_ptr(), n,
-                                       state.sums.data_ptr(), state.counts.data_ptr(),
-                                       state.null_seen.data_ptr(), stream))
+    # with scratch the library partitions by group id and aggregates in LDS (large batches); without it every row is
+    # a device atomic
+    ws_bytes = lib.arx_hash_sum_consume_workspace_bytes(n, state.num_groups)
+    ws_ptr, ws_len = None, 0
+    if ws_bytes:
+        ws = _workspace(state.device, ws_bytes + 256, "groupby")
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        ws_len = ws.numel() - (ws_ptr - ws.data_ptr())
+    check(lib.arx_hash_sum_i64_consume_ws(C.byref(span), is_scalar, sv, gids.values_ptr(), n, state.num_groups,
+                                          state.sums.data_ptr(), state.counts.data_ptr(),
+                                          state.null_seen.data_ptr(), ws_ptr, ws_len, stream))
 
 
 def _hash_sum_merge(state: GroupedSumInt64State, other: GroupedSumInt64State, group_id_mapping) -> None:

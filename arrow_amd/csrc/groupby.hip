@@ -620,7 +620,7 @@ constexpr uint32_t kGbHashMul = 0x9E3779B1u;     // odd => k -> k * M mod 2^32 i
 constexpr uint32_t kGbHashInv = 0x0E8B2F51u;     // M * Minv == 1 mod 2^32
 static_assert(static_cast<uint32_t>(kGbHashMul * kGbHashInv) == 1u, "hash inverse");
 
-__device__ __forceinline__ uint32_t gbp_hash(int32_t key) {
+__device__ __forceinline__ uint32_t gbp_hash_keyed(int32_t key) {
   return static_cast<uint32_t>(key) * kGbHashMul;
 }
 
@@ -644,9 +644,24 @@ struct GbpArgs {
   int64_t* vals_a;
   int32_t* keys_b;
   int64_t* vals_b;
+  // dense-id form (the HashAggregateKernel boundary: "keys" are the caller's Grouper ids 0..G-1, never null).  The
+  // bijection is then id << dense_shl (the top bits of the id range pick the partition) and the partial aggregates
+  // are flushed straight into the caller's three state arrays instead of the keyed HBM table.
+  int dense;               // 0 = keyed table, 1 = dense ids
+  int dense_shl;           // 32 - ceil(log2(num_groups))
+  unsigned long long* dense_sums;
+  unsigned long long* dense_counts;
+  unsigned int* dense_null_seen;
   int agg_pipe;            // software-pipelined loads in the LDS aggregate kernel (A/B knob)
   uint32_t agg_chunk;      // rows per aggregate work unit (a power of two)
 };
+
+__device__ __forceinline__ uint32_t gbp_hash(const GbpArgs& a, int32_t key) {
+  return a.dense ? (static_cast<uint32_t>(key) << a.dense_shl) : gbp_hash_keyed(key);
+}
+__device__ __forceinline__ int32_t gbp_unhash(const GbpArgs& a, uint32_t h) {
+  return a.dense ? static_cast<int32_t>(h >> a.dense_shl) : static_cast<int32_t>(h * kGbHashInv);
+}
 
 template <bool HAS_NULLS>
 __device__ __forceinline__ bool gbp_streamed(const GbpArgs& a, int64_t r) {
@@ -680,9 +695,13 @@ __global__ __launch_bounds__(kBlock) void gbp_null_rows_kernel(GroupbyView v, Gb
       const bool kok = (kv >> lane) & 1ull;
       const bool vok = (vv >> lane) & 1ull;
       if (kok) {  // => value is null
-        const int64_t slot = gb_find_or_insert(v, a.keys[r], &fresh);
-        if (slot < 0) atomicExch(&v.hdr->overflow, 1u);
-        else atomicOr(&v.flags[slot], 1u);
+        if (a.dense) {
+          atomicOr(&a.dense_null_seen[static_cast<uint32_t>(a.keys[r])], 1u);
+        } else {
+          const int64_t slot = gb_find_or_insert(v, a.keys[r], &fresh);
+          if (slot < 0) atomicExch(&v.hdr->overflow, 1u);
+          else atomicOr(&v.flags[slot], 1u);
+        }
       } else {
         nseen = true;
         if (vok) {
@@ -694,6 +713,7 @@ __global__ __launch_bounds__(kBlock) void gbp_null_rows_kernel(GroupbyView v, Gb
       }
     }
   }
+  if (a.dense) return;   // group ids are never null
   gb_publish_new_groups(v, fresh);
   const bool any_seen = __any(nseen);
   if (!any_seen) return;
@@ -733,11 +753,11 @@ __global__ __launch_bounds__(kGbThreads) void gbp_hist_kernel(GbpArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (ok[u]) atomicAdd(&h[gbp_hash(kk[u]) >> shift], 1u);
+      if (ok[u]) atomicAdd(&h[gbp_hash(a, kk[u]) >> shift], 1u);
     }
   }
   for (; r < end; r += kGbThreads) {
-    if (gbp_streamed<HAS_NULLS>(a, r)) atomicAdd(&h[gbp_hash(a.keys[r]) >> shift], 1u);
+    if (gbp_streamed<HAS_NULLS>(a, r)) atomicAdd(&h[gbp_hash(a, a.keys[r]) >> shift], 1u);
   }
   __syncthreads();
   for (int i = tid; i < nparts; i += kGbThreads) {
@@ -895,7 +915,7 @@ __device__ __forceinline__ void gbp_scatter_tile(const GbpArgs& a, GbpScatterLds
     const int p = i * kGbThreads + tid;
     bool ok = p < nrows;
     if constexpr (LEVEL == 1 && HAS_NULLS) ok = ok && gbp_streamed<true>(a, row0 + (p < nrows ? p : nrows - 1));
-    dig[i] = ok ? static_cast<int>((gbp_hash(key[i]) >> dshift) & dmask) : -1;
+    dig[i] = ok ? static_cast<int>((gbp_hash(a, key[i]) >> dshift) & dmask) : -1;
   }
 #pragma unroll
   for (int i = 0; i < kGbRowsPerThread; ++i) {
@@ -939,7 +959,7 @@ __device__ __forceinline__ void gbp_scatter_tile(const GbpArgs& a, GbpScatterLds
   const int total = static_cast<int>(lds.start[nb - 1] + lds.cnt[nb - 1]);
   for (int p = tid; p < total; p += kGbThreads) {
     const uint32_t k = lds.keys[p];
-    const uint32_t d = (gbp_hash(static_cast<int32_t>(k)) >> dshift) & dmask;
+    const uint32_t d = (gbp_hash(a, static_cast<int32_t>(k)) >> dshift) & dmask;
     const uint32_t dst = lds.gbase[d] + (static_cast<uint32_t>(p) - lds.start[d]);
     kout[dst] = static_cast<int32_t>(k);
     vout[dst] = static_cast<int64_t>(lds.vals[p]);
@@ -1101,7 +1121,7 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
     if (!okbuf[u]) continue;
     const int32_t key = kbuf[u];
     const unsigned long long val = vbuf[u];
-    const uint32_t kp = gbp_hash(key);
+    const uint32_t kp = gbp_hash(a, key);
     const uint32_t tag = kp & low_mask;
     if (tag == 0) {
       atomicAdd(&t.zsum, val);
@@ -1122,6 +1142,9 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
     if (probes < kGbSlots) {
       atomicAdd(&t.sums[h], val);
       atomicAdd(&t.cnts[h], 1u);
+    } else if (a.dense) {  // more ids than the LDS table holds: straight to the caller's arrays, still exact
+      atomicAdd(&a.dense_sums[static_cast<uint32_t>(key)], val);
+      atomicAdd(&a.dense_counts[static_cast<uint32_t>(key)], 1ull);
     } else {  // more groups than the LDS table holds: slow path, still exact
       const int64_t slot = gb_find_or_insert(v, key, &fresh);
       if (slot < 0) {
@@ -1150,7 +1173,12 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
       sum = t.zsum;
       cnt = t.zcnt;
     }
-    const int32_t key = static_cast<int32_t>((hi_bits | tag) * kGbHashInv);
+    const int32_t key = gbp_unhash(a, hi_bits | tag);
+    if (a.dense) {
+      atomicAdd(&a.dense_sums[static_cast<uint32_t>(key)], sum);
+      atomicAdd(&a.dense_counts[static_cast<uint32_t>(key)], static_cast<unsigned long long>(cnt));
+      continue;
+    }
     const int64_t slot = gb_find_or_insert(v, key, &fresh);
     if (slot < 0) {
       atomicExch(&v.hdr->overflow, 1u);
@@ -1159,7 +1187,7 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
     atomicAdd(&v.sums[slot], sum);
     atomicAdd(&v.counts[slot], static_cast<unsigned long long>(cnt));
   }
-  gb_publish_new_groups(v, fresh);
+  if (!a.dense) gb_publish_new_groups(v, fresh);
 }
 
 // ---- plan: how a slice of rows is laid out in the caller's workspace
@@ -1411,6 +1439,7 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
       const int64_t m = std::min(slice, n - r0);
       const GbpPlan plan = gbp_plan(m, capacity);
       GbpArgs a{};
+      a.dense = 0;
       a.keys = k + r0;
       a.values = val + r0;
       a.kvalid = make_bits(kbm, keys_i32->offset + r0, m);
@@ -1830,6 +1859,85 @@ int arx_groupby_mean_i64_finalize(const int64_t* sums, const int64_t* counts, co
   hipLaunchKernelGGL(groupby_mean_finalize_kernel, dim3(gb_grid(num_groups)), dim3(kBlock), 0, as_stream(stream), sums,
                      counts, mins, maxs, no_nulls, num_groups, skip_nulls, min_count, out_means, out_valid, out_inexact);
   ARX_CHECK_LAUNCH("groupby_mean_finalize_kernel");
+  return ARX_OK;
+}
+
+// ---- hash_sum(int64, uint32 group id) with scratch: the radix-partitioned LDS aggregation keyed on the group id
+static int dense_id_bits(int64_t num_groups) {
+  int b = 1;
+  while (b < 32 && (int64_t(1) << b) < num_groups) ++b;
+  return b;
+}
+
+size_t arx_hash_sum_consume_workspace_bytes(int64_t length, int64_t num_groups) {
+  if (length <= 0 || num_groups <= 0) return 0;
+  const int64_t cap = int64_t(2) << dense_id_bits(num_groups);
+  return gbp_plan(std::min<int64_t>(length, g_gbp_max_slice), cap).total;
+}
+
+int arx_hash_sum_i64_consume_ws(const ArxSpan* values, int values_is_scalar, int64_t scalar_value,
+                                const uint32_t* group_ids, int64_t length, int64_t num_groups, int64_t* sums,
+                                int64_t* counts, uint32_t* null_seen, void* ws, size_t ws_bytes, void* stream) {
+  // broadcast scalars, small batches and calls without (enough) scratch keep the per-row device atomics
+  const bool partitioned = !values_is_scalar && values != nullptr && length >= g_gbp_min_rows && num_groups > 0 &&
+                           num_groups <= (int64_t(1) << 31) && ws != nullptr &&
+                           (reinterpret_cast<uint64_t>(ws) & 255) == 0;
+  const int64_t cap = partitioned ? (int64_t(2) << dense_id_bits(num_groups)) : 0;
+  const int64_t slice = partitioned ? gbp_slice_for(ws_bytes, length, cap) : 0;
+  if (!partitioned || slice < kGbTile || slice < std::min<int64_t>(length, 1 << 16)) {
+    return arx_hash_sum_i64_consume(values, values_is_scalar, scalar_value, group_ids, length, sums, counts, null_seen,
+                                    stream);
+  }
+  if (group_ids == nullptr || sums == nullptr || counts == nullptr || null_seen == nullptr || values->data == nullptr) {
+    set_error("NULL buffer passed to arx_hash_sum_i64_consume_ws");
+    return ARX_INVALID;
+  }
+  if (values->length != length) {
+    set_error("Array arguments must all be the same length (values %lld vs group ids %lld)",
+              static_cast<long long>(values->length), static_cast<long long>(length));
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  const int64_t* val = static_cast<const int64_t*>(values->data) + values->offset;
+  const void* vbm = values->null_count != 0 ? values->validity : nullptr;
+  const GroupbyView none{};   // the keyed table is not touched in the dense form
+  uint8_t* w = static_cast<uint8_t*>(ws);
+  for (int64_t r0 = 0; r0 < length; r0 += slice) {
+    const int64_t m = std::min(slice, length - r0);
+    const GbpPlan plan = gbp_plan(m, cap);
+    GbpArgs a{};
+    a.dense = 1;
+    a.dense_shl = 32 - dense_id_bits(num_groups);
+    a.dense_sums = reinterpret_cast<unsigned long long*>(sums);
+    a.dense_counts = reinterpret_cast<unsigned long long*>(counts);
+    a.dense_null_seen = null_seen;
+    a.keys = reinterpret_cast<const int32_t*>(group_ids) + r0;
+    a.values = val + r0;
+    a.kvalid = make_bits(nullptr, 0, m);
+    a.vvalid = make_bits(vbm, values->offset + r0, m);
+    a.n = m;
+    a.bits = plan.bits;
+    a.b1 = plan.b1;
+    a.b2 = plan.b2;
+    a.chunk_rows = plan.chunk_rows;
+    a.nchunks = plan.nchunks;
+    a.keys_a = reinterpret_cast<int32_t*>(w + plan.off_keys_a);
+    a.vals_a = reinterpret_cast<int64_t*>(w + plan.off_vals_a);
+    a.keys_b = reinterpret_cast<int32_t*>(w + plan.off_keys_b);
+    a.vals_b = reinterpret_cast<int64_t*>(w + plan.off_vals_b);
+    a.part_count = reinterpret_cast<uint32_t*>(w + plan.off_part_count);
+    a.part_start = reinterpret_cast<uint32_t*>(w + plan.off_part_start);
+    a.cursor2 = reinterpret_cast<uint32_t*>(w + plan.off_cursor2);
+    a.cursor1 = reinterpret_cast<uint32_t*>(w + plan.off_cursor1);
+    a.hist1 = reinterpret_cast<uint32_t*>(w + plan.off_hist1);
+    a.l1_start = reinterpret_cast<uint32_t*>(w + plan.off_l1_start);
+    a.l2_tile_start = reinterpret_cast<uint32_t*>(w + plan.off_l2_tile_start);
+    a.agg_unit_start = reinterpret_cast<uint32_t*>(w + plan.off_agg_unit_start);
+    a.agg_pipe = g_gbp_agg_pipe;
+    a.agg_chunk = static_cast<uint32_t>(g_gbp_agg_chunk);
+    const int rc = vbm != nullptr ? gbp_run_slice<true>(none, a, plan, st) : gbp_run_slice<false>(none, a, plan, st);
+    if (rc != ARX_OK) return rc;
+  }
   return ARX_OK;
 }
 

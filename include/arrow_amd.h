@@ -562,6 +562,15 @@ int arx_groupby_sum_i64_merge_records(void* state, int64_t capacity, const ArxGr
 int arx_hash_sum_i64_consume(const ArxSpan* values, int values_is_scalar, int64_t scalar_value,
                              const uint32_t* group_ids, int64_t length, int64_t* sums,
                              int64_t* counts, uint32_t* null_seen, void* stream);
+/* The same consume with scratch (256-byte aligned, arx_hash_sum_consume_workspace_bytes): rows are radix-partitioned by
+ * the top bits of the group id until a partition's ids fit an LDS table (<= 2048 ids: a perfect, probe-free layout),
+ * aggregated there with LDS atomics and flushed once per partition — device atomics into the state arrays run at
+ * ~12 Grows/s at best and collapse when a few groups are hot.  num_groups = current size of the state arrays
+ * (every id < num_groups).  Falls back to the per-row form for broadcast scalars, small batches or short scratch. */
+size_t arx_hash_sum_consume_workspace_bytes(int64_t length, int64_t num_groups);
+int arx_hash_sum_i64_consume_ws(const ArxSpan* values, int values_is_scalar, int64_t scalar_value,
+                                const uint32_t* group_ids, int64_t length, int64_t num_groups, int64_t* sums,
+                                int64_t* counts, uint32_t* null_seen, void* ws, size_t ws_bytes, void* stream);
 int arx_hash_sum_i64_merge(int64_t* sums, int64_t* counts, uint32_t* null_seen,
                            const int64_t* other_sums, const int64_t* other_counts,
                            const uint32_t* other_null_seen, const uint32_t* group_id_mapping,

@@ -289,6 +289,20 @@ def test_hash_sum_kernel_vtable(emu_ctx, skip_nulls, min_count):
                             skip_nulls=skip_nulls, min_count=min_count)
 
 
+@pytest.mark.parametrize("num_groups,n", [(37, 6000), (5000, 20000), (300000, 20000)])
+def test_hash_sum_kernel_partitioned_by_group_id(emu_ctx, num_groups, n):
+    """The scratch form of the vtable consume (arx_hash_sum_i64_consume_ws) forced on: rows partitioned by the top bits
+    of the dense group id, LDS aggregation, one flush per partition — no partition level (<= 2048 ids), one level,
+    two levels; null values, hot groups, several consumes into the same state.  Same results as the per-row form."""
+    lib = emu_ctx._lib.get_lib()
+    assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
+    try:
+        P.check_hash_sum_kernel(emu_ctx, rng_for("hskp", num_groups), n=n, num_groups=num_groups, null_p=0.1,
+                                use_pyarrow=False)
+    finally:
+        lib.arx_set_option(b"groupby_partition_min_rows", 1 << 17)
+
+
 def test_hash_sum_kernel_no_nulls_has_no_bitmap(emu_ctx):
     P.check_hash_sum_kernel(emu_ctx, rng_for("hsk0"), n=1500, num_groups=11, null_p=0.0)
 

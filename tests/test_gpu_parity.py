@@ -352,6 +352,20 @@ def test_hash_sum_kernel_vtable(gpu_ctx, skip_nulls, min_count):
                             skip_nulls=skip_nulls, min_count=min_count)
 
 
+@pytest.mark.parametrize("num_groups,n", [(100, 2_000_000), (100_000, 4_000_000), (10_000_000, 8_000_000)])
+def test_hash_sum_kernel_partitioned_by_group_id(gpu_ctx, num_groups, n):
+    """The scratch form of the vtable consume (arx_hash_sum_i64_consume_ws) forced on: rows partitioned by the top bits
+    of the dense group id, LDS aggregation, one flush per partition — no partition level (<= 2048 ids), one level,
+    two levels; null values, hot groups, several consumes into the same state.  Same results as the per-row form."""
+    lib = gpu_ctx._lib.get_lib()
+    assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
+    try:
+        P.check_hash_sum_kernel(gpu_ctx, rng_for("hskp", num_groups), n=n, num_groups=num_groups, null_p=0.1,
+                                use_pyarrow=False)
+    finally:
+        lib.arx_set_option(b"groupby_partition_min_rows", 1 << 17)
+
+
 def test_hash_sum_kernel_no_nulls_has_no_bitmap(gpu_ctx):
     P.check_hash_sum_kernel(gpu_ctx, rng_for("hsk0"), n=200000, num_groups=11, null_p=0.0)
 
