@@ -385,3 +385,24 @@ def array(obj, type: DataType | None = None, device=None) -> Array:
     if len(obj) == 0:
         vals = np.zeros(0, dtype=t.np_dtype)
     return Array.from_numpy(vals, None if valid.all() else valid, device, t)
+
+
+class RunEndEncoded:
+    """run_end_encoded<run_end_type, value_type> (docs/source/format/Columnar.rst "Run-End Encoded Layout"): two
+    children — run_ends (int16 / int32 / int64, strictly increasing, the last one >= offset + length) and values (one
+    per run) — plus a logical offset and length.  Only what the hot path needs: boolean values as a filter mask."""
+
+    def __init__(self, run_ends: Array, values: Array, length: int, offset: int = 0):
+        if run_ends.type.name not in ("int16", "int32", "int64"):
+            raise _lib.ArrowInvalid("run ends must be int16, int32 or int64")
+        self.run_ends, self.values, self.length, self.offset = run_ends, values, int(length), int(offset)
+        self.type = DataType(f"run_end_encoded<run_ends: {run_ends.type.name}, values: {values.type.name}>", 0, None)
+
+    @property
+    def device(self):
+        return self.values.device
+
+    @staticmethod
+    def from_pyarrow(arr, device=None) -> "RunEndEncoded":
+        return RunEndEncoded(Array.from_pyarrow(arr.run_ends, device), Array.from_pyarrow(arr.values, device), len(arr),
+                             arr.offset)

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib, tracing
 from ._lib import (ArrowIndexError, ArrowInvalid, ArrowNotImplementedError, check)  # noqa: F401
-from .array import (Array, DataType, Scalar, alloc, bitmap_nbytes, bool_, current_stream, float32,
+from .array import (Array, DataType, RunEndEncoded, Scalar, alloc, bitmap_nbytes, bool_, current_stream, float32,
                     float64, int8, int16, int32, int64, kUnknownNullCount, uint8, uint16, uint32, uint64,
                     INDEX_TYPE_ID, is_base_binary)
 
@@ -877,7 +877,29 @@ def _filter_meta(args, options):
         take_opts = TakeOptions(boundscheck=False)
         return RecordBatch({k: call_function("take", [c, indices], take_opts)
                             for k, c in values.columns.items()})
+    if isinstance(mask, RunEndEncoded):
+        mask = ree_mask_to_boolean(mask)
     return call_function("array_filter", [values, mask], options)
+
+
+def ree_mask_to_boolean(mask: RunEndEncoded) -> Array:
+    """A run_end_encoded<boolean> filter (the ree_filter input type of PopulateFilterKernels,
+    vector_selection_filter_internal.cc:1090) expanded on the device into the plain boolean layout: every row carries
+    its run's (valid, selected) pair, which is all VisitPlainxREEFilterOutputSegments reads."""
+    if mask.values.type != bool_:
+        raise ArrowNotImplementedError("filter: run-end-encoded masks must have boolean values")
+    dev = mask.device
+    lib, stream = _lib_and_stream(dev)
+    n = mask.length
+    bits = alloc(bitmap_nbytes(n), dev)
+    has_nulls = mask.values.may_have_nulls()
+    valid = alloc(bitmap_nbytes(n), dev) if has_nulls else None
+    vs = mask.values.span()
+    nruns = mask.run_ends.length
+    re_ptr = mask.run_ends.values_ptr()
+    check(lib.arx_ree_bool_expand(re_ptr, mask.run_ends.type.byte_width, nruns, C.byref(vs), mask.offset, n,
+                                  bits.data_ptr(), None if valid is None else valid.data_ptr(), stream))
+    return Array(bool_, n, [valid, bits], kUnknownNullCount if has_nulls else 0, 0)
 
 
 def _take_meta(args, options):

@@ -707,6 +707,45 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(CompactArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ run-end-encoded boolean masks
+// array_filter also registers run_end_encoded<boolean> filters (vector_selection_filter_internal.cc:1090, 1115-;
+// VisitPlainxREEFilterOutputSegments, vector_selection_internal.cc:79-153: every run contributes its value's
+// (valid, selected) pair to all its rows).  The device form expands the runs into the plain mask layout — one bitmap
+// of selection bits, one of validity bits — and hands it to the ordinary compaction: same output by construction.
+// One lane per 64-row output word: binary search for the run holding the word's first row, then a walk over the runs.
+template <typename R>
+__global__ __launch_bounds__(kBlock) void ree_bool_expand_kernel(const R* __restrict__ run_ends, int64_t num_runs,
+                                                                 Bits vsel, Bits vvalid, int64_t logical_offset,
+                                                                 int64_t length, uint64_t* __restrict__ out_bits,
+                                                                 uint64_t* __restrict__ out_valid) {
+  const int64_t nwords = (length + 63) >> 6;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < nwords; w += stride) {
+    const int64_t row0 = w << 6;
+    const int64_t rows = length - row0 < 64 ? length - row0 : 64;
+    const int64_t p0 = logical_offset + row0;          // physical position of the word's first row
+    int64_t lo = 0, hi = num_runs;                      // first run with run_end > p0
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (static_cast<int64_t>(run_ends[mid]) > p0) hi = mid; else lo = mid + 1;
+    }
+    uint64_t bits = 0, valid = 0;
+    int64_t done = 0;
+    for (int64_t r = lo; r < num_runs && done < rows; ++r) {
+      const int64_t end = static_cast<int64_t>(run_ends[r]) - p0;     // exclusive, relative to the word
+      const int64_t upto = end < rows ? end : rows;
+      if (upto > done) {
+        const uint64_t span = (upto - done >= 64 ? ~uint64_t(0) : ((uint64_t(1) << (upto - done)) - 1)) << done;
+        if ((load_word(vsel, r >> 6) >> (r & 63)) & 1ull) bits |= span;
+        if ((load_word(vvalid, r >> 6) >> (r & 63)) & 1ull) valid |= span;
+        done = upto;
+      }
+    }
+    out_bits[w] = bits;
+    if (out_valid != nullptr) out_valid[w] = valid;
+  }
+}
+
 // ------------------------------------------------------------------ take
 struct TakeArgs {
   const uint8_t* values;   // pre-offset to element 0
@@ -1436,6 +1475,40 @@ int arx_take_bits(const ArxSpan* values, const ArxSpan* indices, int index_type,
     default: hipLaunchKernelGGL((take_bits_kernel<uint64_t>), grid, block, 0, st, a, values->offset); break;
   }
   ARX_CHECK_LAUNCH("take_bits_kernel");
+  return ARX_OK;
+}
+
+int arx_ree_bool_expand(const void* run_ends, int run_end_width, int64_t num_runs, const ArxSpan* values,
+                        int64_t logical_offset, int64_t length, void* out_bits, void* out_validity, void* stream) {
+  if (length < 0 || num_runs < 0 || logical_offset < 0 || values == nullptr ||
+      (run_end_width != 2 && run_end_width != 4 && run_end_width != 8)) {
+    set_error("bad arguments to arx_ree_bool_expand");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  if (run_ends == nullptr || values->data == nullptr || out_bits == nullptr || num_runs == 0 ||
+      values->length < num_runs) {
+    set_error("arx_ree_bool_expand: NULL buffer or fewer run values than run ends");
+    return ARX_INVALID;
+  }
+  const Bits vsel = make_bits(values->data, values->offset, num_runs);
+  const Bits vvalid = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, num_runs);
+  const int64_t nwords = ceil_div(length, 64);
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(nwords, kBlock), 2048)));
+  hipStream_t st = as_stream(stream);
+  uint64_t* ob = static_cast<uint64_t*>(out_bits);
+  uint64_t* ov = static_cast<uint64_t*>(out_validity);
+  if (run_end_width == 2) {
+    hipLaunchKernelGGL((ree_bool_expand_kernel<int16_t>), dim3(grid), dim3(kBlock), 0, st, static_cast<const int16_t*>(run_ends),
+                       num_runs, vsel, vvalid, logical_offset, length, ob, ov);
+  } else if (run_end_width == 4) {
+    hipLaunchKernelGGL((ree_bool_expand_kernel<int32_t>), dim3(grid), dim3(kBlock), 0, st, static_cast<const int32_t*>(run_ends),
+                       num_runs, vsel, vvalid, logical_offset, length, ob, ov);
+  } else {
+    hipLaunchKernelGGL((ree_bool_expand_kernel<int64_t>), dim3(grid), dim3(kBlock), 0, st, static_cast<const int64_t*>(run_ends),
+                       num_runs, vsel, vvalid, logical_offset, length, ob, ov);
+  }
+  ARX_CHECK_LAUNCH("ree_bool_expand_kernel");
   return ARX_OK;
 }
 

@@ -360,6 +360,15 @@ int arx_boolean_invert(const void* bits, int64_t bit_offset, int64_t length, voi
 int arx_bitmap_popcount(const void* bits, int64_t bit_offset, int64_t length, void* ws,
                         size_t ws_bytes, int64_t* out_count, void* stream);
 
+/* run_end_encoded<boolean> filter masks (vector_selection_filter_internal.cc:1090,1115-; the run visitor
+ * VisitPlainxREEFilterOutputSegments, vector_selection_internal.cc:79-153): expands the runs covering the logical rows
+ * [logical_offset, logical_offset + length) into the plain mask layout — out_bits (selection) and out_validity (NULL
+ * allowed when the run values have no nulls), bit i = row i, whole 64-bit words written — which arx_filter_* then takes
+ * as an ordinary boolean mask: every row of a run carries its run's (valid, selected) pair, exactly what the reference
+ * visits.  run_ends: int16 / int32 / int64 (run_end_width 2 / 4 / 8), values: the boolean run values.  Asynchronous. */
+int arx_ree_bool_expand(const void* run_ends, int run_end_width, int64_t num_runs, const ArxSpan* values,
+                        int64_t logical_offset, int64_t length, void* out_bits, void* out_validity, void* stream);
+
 /* ---------------------------------------------------------------------------
  * array_sort_indices (uint64/int64 keys) — replaces ArraySortIndices<UInt64Type,
  * UInt64Type>::Exec -> ArrayCountOrCompareSorter / ArrayCompareSorter

@@ -931,6 +931,33 @@ def test_golden_sort_and_sum_only_replay(gpu_ctx, dtype):
     P.replay_golden_sum_only(gpu_ctx, gold)
 
 
+@pytest.mark.parametrize("run_end_type", ["int16", "int32", "int64"])
+def test_filter_with_a_run_end_encoded_mask(gpu_ctx, run_end_type):
+    """array_filter(values, run_end_encoded<boolean>) (vector_selection_filter_internal.cc:1090): sliced masks, null run
+    values, DROP and EMIT_NULL, vs the reference (pyarrow)."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+
+    amd = gpu_ctx
+    rng = rng_for("reemask", run_end_type)
+    ret = {"int16": pa.int16(), "int32": pa.int32(), "int64": pa.int64()}[run_end_type]
+    for n in (1, 64, 20000, 3_000_001):
+        if run_end_type == "int16" and n > 30000:
+            continue
+        lens = rng.integers(1, 200, max(8, n // 50))
+        ends = np.cumsum(lens)
+        ends = ends[ends < n + 300]
+        if len(ends) == 0 or ends[-1] < n + 7:
+            ends = np.append(ends, n + 7)
+        rv = pa.array(rng.random(len(ends)) < 0.4, mask=rng.random(len(ends)) < 0.2)
+        ree = pa.RunEndEncodedArray.from_arrays(pa.array(ends.astype(ret.to_pandas_dtype())), rv).slice(5, n)
+        vals = pa.array(rng.integers(-2**62, 2**62, n), mask=rng.random(n) < 0.1)
+        for sel in ("drop", "emit_null"):
+            want = pc.filter(vals, ree, null_selection_behavior=sel)
+            got = amd.compute.filter(amd.Array.from_pyarrow(vals), amd.array.RunEndEncoded.from_pyarrow(ree), sel)
+            assert got.to_pyarrow().equals(want), (run_end_type, n, sel)
+
+
 def test_groupby_min_max_next_to_sum_and_merge(gpu_ctx):
     amd = gpu_ctx
     rng = rng_for("gbminmaxsum")
