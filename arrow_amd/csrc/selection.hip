@@ -177,10 +177,16 @@ template <> struct ElemT<2> { using type = uint16_t; };
 template <> struct ElemT<4> { using type = uint32_t; };
 template <> struct ElemT<8> { using type = uint64_t; };
 template <> struct ElemT<16> { using type = uint4; };
+// 32-byte values (decimal256, fixed_size_binary(32); PrimitiveFilterExec / FixedWidthTakeExec's widest case,
+// vector_selection_filter_internal.cc:479-508): two 16-byte halves, moved by the gather forms only
+struct Elem32 { uint4 lo, hi; };
+template <> struct ElemT<32> { using type = Elem32; };
 
 template <int W>
 __device__ __forceinline__ typename ElemT<W>::type zero_elem() {
-  if constexpr (W == 16) {
+  if constexpr (W == 32) {
+    return Elem32{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+  } else if constexpr (W == 16) {
     return make_uint4(0, 0, 0, 0);
   } else {
     return 0;
@@ -1038,6 +1044,7 @@ static int launch_compact(bool iota, int W, const CompactArgs& a, hipStream_t st
       case 4: launch_sparse_w<4>(a, grid, st); break;
       case 8: launch_sparse_w<8>(a, grid, st); break;
       case 16: launch_sparse_w<16>(a, grid, st); break;
+      case 32: launch_sparse_w<32>(a, grid, st); break;
       default:
         set_error("unsupported byte width %d for the gfx950 filter", W);
         return ARX_NOT_IMPLEMENTED;
@@ -1423,6 +1430,7 @@ int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int 
     case 4: ARX_TAKE_W(4); break;
     case 8: ARX_TAKE_W(8); break;
     case 16: ARX_TAKE_W(16); break;
+    case 32: ARX_TAKE_W(32); break;
     default:
       set_error("Unsupported primitive type for take: byte width %d", byte_width);
       return ARX_NOT_IMPLEMENTED;

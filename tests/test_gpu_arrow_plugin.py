@@ -276,7 +276,7 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
         got_d = pc.drop_null(dv)
         assert not got_d.is_cpu
         assert to_host(got_d).equals(pc.drop_null(hv))
-    # the other fixed-width classes of match::Primitive() + decimal128 / fixed_size_binary (widths 2..16 bytes)
+    # the other fixed-width classes of match::Primitive() + decimal128 / decimal256 / fixed_size_binary (widths 2..32 bytes)
     import decimal
     nw = SC(200_003)
     wmask = pa.array(rng.random(nw) < 0.4, mask=rng.random(nw) < 0.03)
@@ -289,6 +289,10 @@ DEVICE_SCRIPT = textwrap.dedent(r'''
              pa.array((raw % 1000).astype(np.float16)),
              pa.Array.from_buffers(pa.decimal128(38, 4), nw // 2, [None, pa.py_buffer(raw[: nw // 2 * 2].tobytes())]),
              pa.Array.from_buffers(pa.binary(16), nw // 2, [None, pa.py_buffer(raw[: nw // 2 * 2].tobytes())]),
+             # 32-byte values (decimal256, fixed_size_binary(32)): the widest case of PrimitiveFilterExec / FixedWidthTakeExec
+             pa.Array.from_buffers(pa.decimal256(60, 4), nw // 4, [None, pa.py_buffer((raw[: nw // 4 * 4] % 10**15).tobytes())]),
+             pa.Array.from_buffers(pa.binary(32), nw // 4, [pa.py_buffer(np.packbits(rng.random(nw // 4 + 8) > 0.1, bitorder="little").tobytes()),
+                                                            pa.py_buffer(raw[: nw // 4 * 4].tobytes())]),
              pa.Array.from_buffers(pa.binary(2), nw, [None, pa.py_buffer(raw.astype(np.int16).tobytes())])]
     for hv in wides:
         dv = to_device(hv)
