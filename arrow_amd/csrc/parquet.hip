@@ -223,6 +223,101 @@ __global__ __launch_bounds__(kBlock) void byte_stream_split_kernel(const uint8_t
   }
 }
 
+// ------------------------------------------------------------------ Snappy page decompression
+// What SnappyCodec::Decompress -> snappy::RawUncompress does per page (cpp/src/arrow/util/compression_snappy.cc:42-62;
+// format: github.com/google/snappy format_description.txt, the bundled third-party codec is not in this tree): a varint
+// with the uncompressed length, then elements — literal (tag & 3 == 0: length - 1 in the tag's upper six bits, or in the
+// next 1..4 bytes when that field is 60..63) or copy (01: 3-bit length - 4, 11-bit offset; 10 / 11: 6-bit length - 1,
+// 16- / 32-bit offset).  The element stream is sequential, so ONE WAVE owns a page: every lane follows the same
+// (uniform) tag parse, the bytes of an element are moved by the 64 lanes together — a copy whose offset is shorter
+// than its length repeats the last `offset` bytes, i.e. byte j comes from out[op - offset + j % offset], which makes
+// even the self-overlapping case lane-parallel.  A copy that reads bytes this wave stored since the last fence waits for
+// them first.  Pages are independent: the grid is one wave per page (4 per workgroup).
+// status per page: 0 ok, 1 length mismatch / bad preamble, 2 element runs past the input or the output, 3 bad offset.
+__global__ __launch_bounds__(kBlock) void snappy_decode_kernel(const uint8_t* __restrict__ src, const ArxSnappyPage* __restrict__ pages,
+                                                               int64_t npages, uint8_t* dst, uint32_t* __restrict__ status) {
+  const int lane = lane_id();
+  const int64_t pg = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (pg >= npages) return;  // wave-uniform
+  const ArxSnappyPage p = pages[pg];
+  const uint8_t* in = src + p.src_offset;
+  uint8_t* out = dst + p.dst_offset;
+  const uint32_t n_in = p.src_size;
+  uint32_t ip = 0, ulen = 0, err = 0;
+  // preamble: varint32
+  {
+    int shift = 0;
+    for (;;) {
+      if (ip >= n_in || shift > 28) { err = 1; break; }
+      const uint32_t c = in[ip++];
+      ulen |= (c & 0x7Fu) << shift;
+      if ((c & 0x80u) == 0) break;
+      shift += 7;
+    }
+    if (!err && ulen != p.dst_size) err = 1;
+  }
+  uint32_t op = 0, pending = 0;
+  while (!err && ip < n_in) {
+    // tag + the up to four bytes that may follow it, fetched together (clamped: speculative, bounds are checked below)
+    uint32_t b[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) b[k] = in[(ip + k) < n_in ? (ip + k) : (n_in - 1)];
+    const uint32_t tag = b[0];
+    uint32_t len, off = 0, adv;
+    if ((tag & 3u) == 0) {
+      len = (tag >> 2) + 1;
+      adv = 1;
+      if (len > 60) {
+        const uint32_t nb = len - 60;
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < nb; ++k) v |= b[1 + k] << (8 * k);
+        len = v + 1;
+        adv = 1 + nb;
+        if (v == 0xFFFFFFFFu) { err = 2; break; }
+      }
+      if (ip + adv > n_in || len > n_in - (ip + adv) || len > ulen - op) { err = 2; break; }
+      ip += adv;
+      for (uint32_t j = lane; j < len; j += 64) out[op + j] = in[ip + j];
+      ip += len;
+    } else {
+      if ((tag & 3u) == 1) {
+        len = 4 + ((tag >> 2) & 7u);
+        off = ((tag >> 5) << 8) | b[1];
+        adv = 2;
+      } else if ((tag & 3u) == 2) {
+        len = 1 + (tag >> 2);
+        off = b[1] | (b[2] << 8);
+        adv = 3;
+      } else {
+        len = 1 + (tag >> 2);
+        off = b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24);
+        adv = 5;
+      }
+      if (ip + adv > n_in || len > ulen - op) { err = 2; break; }
+      if (off == 0 || off > op) { err = 3; break; }
+      ip += adv;
+      // the source range [op - off, op - off + min(len, off)) must not hold bytes still in flight
+      if (static_cast<int64_t>(off) - static_cast<int64_t>(len < off ? len : off) < static_cast<int64_t>(pending)) {
+        __threadfence_block();
+        pending = 0;
+      }
+      const uint8_t* from = out + (op - off);
+      if (off >= len) {
+        for (uint32_t j = lane; j < len; j += 64) out[op + j] = from[j];
+      } else {
+        for (uint32_t j = lane; j < len; j += 64) out[op + j] = from[j % off];
+      }
+    }
+    op += len;
+    pending += len;
+    // lanes move on to the next element together (a scheduling barrier on the GPU, where the wave runs in lockstep
+    // anyway; the rendezvous the SIMT emulator needs before a later copy reads these bytes)
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!err && op != ulen) err = 2;
+  if (lane == 0) status[pg] = err;
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -543,6 +638,24 @@ int arx_rle_decode_equals_bitmap(const void* bytes, size_t nbytes, const ArxRleR
                      static_cast<const uint8_t*>(bytes), static_cast<uint64_t>(nbytes), runs, nruns, bit_width,
                      num_values, equals, static_cast<uint32_t*>(nullptr), static_cast<uint64_t*>(out_bits));
   ARX_CHECK_LAUNCH("rle_decode_kernel");
+  return ARX_OK;
+}
+
+int arx_snappy_decompress_pages(const void* compressed, const ArxSnappyPage* pages, int64_t num_pages, void* out,
+                                uint32_t* status, void* stream) {
+  if (num_pages < 0) {
+    set_error("bad arguments to arx_snappy_decompress_pages");
+    return ARX_INVALID;
+  }
+  if (num_pages == 0) return ARX_OK;
+  if (compressed == nullptr || pages == nullptr || out == nullptr || status == nullptr) {
+    set_error("NULL buffer passed to arx_snappy_decompress_pages");
+    return ARX_INVALID;
+  }
+  const unsigned grid = static_cast<unsigned>(ceil_div(num_pages, kWavesPerBlock));
+  hipLaunchKernelGGL(snappy_decode_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                     static_cast<const uint8_t*>(compressed), pages, num_pages, static_cast<uint8_t*>(out), status);
+  ARX_CHECK_LAUNCH("snappy_decode_kernel");
   return ARX_OK;
 }
 

@@ -178,6 +178,14 @@ def scan_rle_runs(data, bit_width: int, num_values: int, out_base: int = 0, byte
     return runs[: nr.value], ones.value
 
 
+# Snappy pages whose uncompressed bytes the host never needs (PLAIN fixed-width values: data page V2 bodies — their
+# levels travel uncompressed — and V1 pages of required columns) are decompressed in HBM (arx_snappy_decompress_pages):
+# the COMPRESSED bytes cross PCIe and no host codec runs.  Pages with run headers to walk (levels inside a V1 block,
+# dictionary indices, delta blocks) still go through the host codec: the walk needs their bytes.
+DEVICE_SNAPPY = True
+SNAPPY_PAGE_DTYPE = np.dtype([("src_offset", "<u8"), ("src_size", "<u4"), ("dst_size", "<u4"), ("dst_offset", "<u8")])  # struct ArxSnappyPage
+
+
 # --------------------------------------------------------------------------- one column chunk
 def _decompress(codec: str, payload, uncompressed_size: int):
     if codec == "UNCOMPRESSED":
@@ -257,6 +265,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     level_bytes, level_runs = bytearray(), []
     index_bytes, index_runs = bytearray(), []
     plain_bytes = bytearray()
+    device_snappy_pages = []  # (compressed block, uncompressed size, byte position among the PLAIN values)
     plain_pages = []          # BYTE_ARRAY only: (page value bytes, number of values)
     bool_bytes, bool_runs = bytearray(), []   # BOOLEAN only: every page becomes runs of one shared table
     split_pages = []                            # BYTE_STREAM_SPLIT: (first dense slot, page bytes, count)
@@ -273,6 +282,14 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
         if ptype == _PAGE_DATA:
             dh = hdr[5]
             nvals, enc = dh[1], dh[2]
+            on_device = (DEVICE_SNAPPY and codec == "SNAPPY" and enc == _ENC_PLAIN and max_def_level == 0 and
+                         not is_binary and not is_bool and hdr[2] == nvals * width)
+            if on_device:
+                device_snappy_pages.append((bytes(payload), hdr[2], len(plain_bytes)))
+                plain_bytes += bytes(hdr[2])          # placeholder: the device writes these bytes
+                rows += nvals
+                dense += nvals
+                continue
             page = _decompress(codec, payload, hdr[2])
             pos = 0
             if max_def_level > 0:
@@ -289,6 +306,22 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
                 raise ArrowNotImplementedError("Parquet: repetition levels")
             levels = bytes(payload[:dl])                              # V2 levels are never compressed
             body = payload[dl:]
+            on_device = (DEVICE_SNAPPY and codec == "SNAPPY" and dh.get(7, True) and enc == _ENC_PLAIN and
+                         not is_binary and not is_bool)
+            if on_device:
+                valid_here = nvals
+                if max_def_level > 0:
+                    runs, ones = scan_rle_runs(levels, 1, nvals, out_base=rows, byte_base=len(level_bytes))
+                    valid_here = ones
+                if hdr[2] - dl == valid_here * width:
+                    if max_def_level > 0:
+                        level_runs.append(runs)
+                        level_bytes += levels
+                    device_snappy_pages.append((bytes(body), hdr[2] - dl, len(plain_bytes)))
+                    plain_bytes += bytes(hdr[2] - dl)
+                    rows += nvals
+                    dense += valid_here
+                    continue
             page = _decompress(codec, body, hdr[2] - dl) if dh.get(7, True) else bytes(body)
             pos = 0
         else:
@@ -389,6 +422,25 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
             raise ArrowNotImplementedError("Parquet: PLAIN and DELTA_BINARY_PACKED / BYTE_STREAM_SPLIT pages in one column chunk")
         host = torch.from_numpy(np.frombuffer(bytes(plain_bytes), dtype=np.uint8).copy())
         dense_buf[dense_from_dict * width: dense * width] = host.to(device)
+        if device_snappy_pages:
+            # one launch for all the chunk's device-decoded pages: the compressed blocks cross PCIe, one wave per page
+            # writes its values straight into the dense buffer (after the host-decoded pages' copy above)
+            table = np.zeros(len(device_snappy_pages), SNAPPY_PAGE_DTYPE)
+            at = 0
+            for i, (blk, usize, pos_) in enumerate(device_snappy_pages):
+                table[i] = (at, len(blk), usize, dense_from_dict * width + pos_)
+                at += len(blk)
+            d_src = to_device(np.frombuffer(b"".join(b for b, _, _ in device_snappy_pages) + b"\0", dtype=np.uint8), device)
+            d_table = to_device(table.view(np.uint8), device)
+            status = torch.zeros(len(device_snappy_pages), dtype=torch.int32, device=device)
+            check(lib.arx_snappy_decompress_pages(d_src.data_ptr(), d_table.data_ptr(), len(device_snappy_pages),
+                                                  dense_buf.data_ptr(), status.data_ptr(), stream))
+            bad = status.cpu().numpy()
+            if bad.any():
+                raise ArrowInvalid(f"Parquet: corrupt Snappy page (device decoder status {int(bad[bad != 0][0])} on page "
+                                   f"{int(np.nonzero(bad)[0][0])} of the chunk's device-decoded pages)")
+            if stats is not None:
+                stats["device_snappy_pages"] = stats.get("device_snappy_pages", 0) + len(device_snappy_pages)
     if delta_pages:
         # one byte buffer and one miniblock table for the chunk; a launch sequence (unpack + prefix sum) per page,
         # because every page restarts the recurrence at its own first value

@@ -656,6 +656,22 @@ int arx_rle_decode_equals_bitmap(const void* bytes, size_t nbytes, const ArxRleR
 int arx_expand_by_mask(const void* dense, int byte_width, const ArxSpan* mask, const void* ws, void* out_data,
                        void* stream);
 
+/* Snappy page decompression on the device — SnappyCodec::Decompress (cpp/src/arrow/util/compression_snappy.cc:42-62)
+ * for the pages of a column chunk in ONE launch: `compressed` holds the raw Snappy blocks (device), pages[i] says
+ * where block i sits, how many bytes it must produce and where they go in `out`; one wave decodes one page (the
+ * element stream is sequential, the bytes of every literal / copy are moved by 64 lanes).  status[i] (device): 0 ok,
+ * 1 bad preamble / length mismatch, 2 an element runs past the block or the output, 3 a copy offset outside the
+ * output so far — the caller must read it back before trusting the bytes (a corrupt page never writes outside its
+ * dst range).  Asynchronous. */
+typedef struct ArxSnappyPage {
+  uint64_t src_offset;  /* of the block inside `compressed` */
+  uint32_t src_size;
+  uint32_t dst_size;    /* the uncompressed size the page header announced */
+  uint64_t dst_offset;  /* inside `out` */
+} ArxSnappyPage;
+int arx_snappy_decompress_pages(const void* compressed, const ArxSnappyPage* pages, int64_t num_pages, void* out,
+                                uint32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

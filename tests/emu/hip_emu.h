@@ -154,6 +154,7 @@ inline uint64_t ballot(bool pred) {
 
 #define __syncthreads() hipemu::block_sync()
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
+static inline void __threadfence_block() {}
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))

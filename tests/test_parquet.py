@@ -71,6 +71,108 @@ def test_parquet_decode_emulator(emu_ctx, tmp_path, variant, null_p):
     _write_and_check(emu_ctx, str(tmp_path), 9000, null_p, VARIANTS[variant], 100 + variant)
 
 
+SNAPPY_PAGE = np.dtype([("src_offset", "<u8"), ("src_size", "<u4"), ("dst_size", "<u4"), ("dst_offset", "<u8")])
+
+
+def check_snappy_kernel(amd, rng, scale=1):
+    """arx_snappy_decompress_pages vs the reference codec (pyarrow's SnappyCodec = the bundled snappy): blocks written
+    by the reference compressor (empty, one byte, incompressible, periodic with every period length, long runs,
+    integers), a hand-made block with a 4-byte-offset copy and a two-byte literal length (compressors rarely emit
+    either), and corrupt blocks (offset beyond the output, truncated literal, wrong length) -> per-page status."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    codec = pa.Codec("snappy")
+
+    def run(raws, blocks=None):
+        blocks = blocks or [codec.compress(r).to_pybytes() for r in raws]
+        pages = np.zeros(len(blocks), SNAPPY_PAGE)
+        so = do = 0
+        for i, (r, b) in enumerate(zip(raws, blocks)):
+            pages[i] = (so, len(b), len(r), do)
+            so += len(b)
+            do += len(r)
+        src = to_device(np.frombuffer(b"".join(blocks) + b"\0", dtype=np.uint8), dev)
+        out = torch.zeros(max(do, 1) + 64, dtype=torch.uint8, device=dev)
+        st = torch.full((len(blocks),), 77, dtype=torch.int32, device=dev)
+        table = to_device(pages.view(np.uint8), dev)
+        _lib.check(lib.arx_snappy_decompress_pages(src.data_ptr(), table.data_ptr(), len(blocks), out.data_ptr(),
+                                                   st.data_ptr(), current_stream(dev)))
+        return out.cpu().numpy()[:do].tobytes(), st.cpu().numpy().tolist(), out.cpu().numpy()[do:].tolist()
+
+    raws = [b"", b"a", bytes(rng.integers(0, 256, 1000 * scale, dtype=np.uint8)), b"abcd" * 5000 * scale,
+            bytes(rng.integers(0, 4, 70000 * scale, dtype=np.uint8)), np.arange(30000 * scale, dtype=np.int64).tobytes(),
+            b"x" * 100000 * scale, (b"hello world, " * 300) + bytes(rng.integers(0, 256, 200, dtype=np.uint8))]
+    raws += [bytes(rng.integers(0, 256, period, dtype=np.uint8)) * (3000 // period + 2) for period in (1, 2, 3, 5, 7, 13, 63, 64, 65, 200)]
+    got, st, tail = run(raws)
+    assert st == [0] * len(raws), st
+    assert got == b"".join(raws) and not any(tail)
+    lit = bytes(rng.integers(0, 256, 300, dtype=np.uint8))
+    blk = bytes([0xB6, 0x02]) + bytes([61 << 2, 0x2B, 0x01]) + lit + bytes([(9 << 2) | 3, 0x2C, 0x01, 0, 0])
+    got, st, _ = run([lit + lit[:10]], [blk])
+    assert st == [0] and got == lit + lit[:10]
+    bad1 = bytes([0x05]) + bytes([(4 << 2) | 2, 0x10, 0x00])          # copy from before the start of the output
+    bad2 = bytes([0x0A]) + bytes([9 << 2]) + b"abc"                   # literal longer than the block
+    bad3 = codec.compress(b"abcdef").to_pybytes()                     # announces 6 bytes, the page says 7
+    _, st, _ = run([b"\0" * 5, b"\0" * 10, b"\0" * 7], [bad1, bad2, bad3])
+    assert st == [3, 2, 1], st
+
+
+@pytest.mark.emu
+def test_snappy_page_decoder_kernel(emu_ctx):
+    check_snappy_kernel(emu_ctx, np.random.default_rng(3))
+
+
+@pytest.mark.gpu
+def test_snappy_page_decoder_kernel_gpu(gpu_ctx):
+    check_snappy_kernel(gpu_ctx, np.random.default_rng(4), scale=20)
+
+
+def _snappy_plain_file(tmp_path, n, null_p, version):
+    rng = np.random.default_rng(n + int(null_p * 100))
+    mask = (rng.random(n) < null_p) if null_p else None
+    t = pa.table({"opt": pa.array(np.cumsum(rng.integers(-3, 4, n)), mask=mask),          # compressible int64
+                  "req": pa.array(rng.integers(0, 50, n).astype(np.int32)),
+                  "dbl": pa.array(np.round(rng.standard_normal(n), 1), mask=mask)})
+    fields = [pa.field(f.name, f.type, nullable=(f.name != "req")) for f in t.schema]
+    path = os.path.join(tmp_path, "snappy.parquet")
+    pq.write_table(t.cast(pa.schema(fields)), path, use_dictionary=False, compression="snappy", data_page_version=version,
+                   data_page_size=8192, row_group_size=n // 2 + 3)
+    return path
+
+
+@pytest.mark.emu
+@pytest.mark.parametrize("version,null_p", [("2.0", 0.0), ("2.0", 0.2), ("1.0", 0.0), ("1.0", 0.2)])
+def test_parquet_snappy_pages_decompressed_on_the_device(emu_ctx, tmp_path, version, null_p):
+    """PLAIN fixed-width pages under Snappy never touch a host codec: V2 page bodies (levels travel uncompressed) and V1
+    pages of required columns go through arx_snappy_decompress_pages; optional V1 pages (levels inside the block) keep
+    the host codec.  Equal to pyarrow.parquet either way; the stats say how many pages took the device route."""
+    path = _snappy_plain_file(str(tmp_path), 20000, null_p, version)
+    stats = {}
+    emu_ctx.parquet.read_table(path, stats=stats)
+    want_device = {"2.0": 3, "1.0": 1}[version]       # columns whose pages qualify
+    assert stats.get("device_snappy_pages", 0) >= 2 * want_device, stats
+    check_file(emu_ctx, path)
+    emu_ctx.parquet.DEVICE_SNAPPY = False
+    try:
+        check_file(emu_ctx, path)                      # the host-codec route stays covered
+    finally:
+        emu_ctx.parquet.DEVICE_SNAPPY = True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("version", ["2.0", "1.0"])
+def test_parquet_snappy_pages_decompressed_on_the_device_gpu(gpu_ctx, tmp_path, version):
+    path = _snappy_plain_file(str(tmp_path), 600_000, 0.1, version)
+    stats = {}
+    gpu_ctx.parquet.read_table(path, stats=stats)
+    assert stats.get("device_snappy_pages", 0) > 10, stats
+    check_file(gpu_ctx, path)
+
+
 @pytest.mark.emu
 @pytest.mark.parametrize("null_p", [0.0, 0.2])
 def test_parquet_dictionary_fallback_to_plain(emu_ctx, tmp_path, null_p):
@@ -352,18 +454,16 @@ def test_rle_run_walk_and_decode_vs_numpy_restatement():
 
 
 @pytest.mark.emu
-def test_ipc_file_and_stream_to_device(emu_ctx, tmp_path):
-    """IPC bodies are Arrow layout already: columns land on the device buffer by buffer and come back equal
-    (fixed width, boolean, utf8, nulls, several batches, LZ4 body compression)."""
+def _check_ipc(amd, tmp_path, n):
     rng = np.random.default_rng(3)
-    t = _table(rng, 5000, 0.1)
+    t = _table(rng, n, 0.1)
     for compression in (None, "lz4"):
         path = os.path.join(str(tmp_path), f"t_{compression}.arrow")
         opts = pa.ipc.IpcWriteOptions(compression=compression)
         with pa.ipc.new_file(path, t.schema, options=opts) as w:
-            for b in t.to_batches(max_chunksize=1700):
+            for b in t.to_batches(max_chunksize=n // 3 + 1):
                 w.write_batch(b)
-        got = emu_ctx.ipc.read_table(path)
+        got = amd.ipc.read_table(path)
         ref = pa.ipc.open_file(pa.memory_map(path, "r"))
         assert set(got) == set(t.schema.names)
         for name, chunks in got.items():
@@ -373,10 +473,34 @@ def test_ipc_file_and_stream_to_device(emu_ctx, tmp_path):
                 assert arr.to_pyarrow().equals(want) and arr.null_count == want.null_count, (name, i)
     sink = pa.BufferOutputStream()
     with pa.ipc.new_stream(sink, t.schema) as w:
-        w.write_table(t, max_chunksize=2500)
-    got = emu_ctx.ipc.read_table(pa.BufferReader(sink.getvalue()), columns=["i64_few", "str"])
-    assert [a.length for a in got["str"]] == [2500, 2500]
+        w.write_table(t, max_chunksize=n // 2)
+    got = amd.ipc.read_table(pa.BufferReader(sink.getvalue()), columns=["i64_few", "str"])
+    assert [a.length for a in got["str"]] == [n // 2, n // 2]
     assert pa.chunked_array([a.to_pyarrow() for a in got["i64_few"]]).equals(t.column("i64_few"))
+
+
+@pytest.mark.emu
+def test_ipc_file_and_stream_to_device(emu_ctx, tmp_path):
+    """IPC bodies are Arrow layout already: columns land on the device buffer by buffer and come back equal
+    (fixed width, boolean, utf8, nulls, several batches, LZ4 body compression)."""
+    _check_ipc(emu_ctx, tmp_path, 5000)
+
+
+@pytest.mark.gpu
+def test_ipc_file_and_stream_to_device_gpu(gpu_ctx, tmp_path):
+    """The same on an MI355X: every buffer of every record batch is in HBM afterwards (device tensors), equal to the
+    reference reader's arrays."""
+    _check_ipc(gpu_ctx, tmp_path, 600_000)
+    import torch
+
+    rng = np.random.default_rng(5)
+    t = _table(rng, 1000, 0.1)
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_stream(sink, t.schema) as w:
+        w.write_table(t)
+    for chunks in gpu_ctx.ipc.read_table(pa.BufferReader(sink.getvalue())).values():
+        for arr in chunks:
+            assert all(b is None or (isinstance(b, torch.Tensor) and b.is_cuda) for b in arr.buffers)
 
 
 # ------------------------------------------------------------------ the delta / split encodings on the device
