@@ -51,6 +51,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 EMU = False            # --backend emu
+_JSON_FD = [1]         # where the one JSON line goes (main() moves everything else that writes to fd 1 over to stderr)
 
 
 def log(*a):
@@ -566,7 +567,7 @@ class _ExtrasWatchdog:
             line = dict(self.result)
             for leg in ("hash_sum", "sort_indices"):
                 line.setdefault(leg, {"error": f"did not finish within {self.seconds} s (watchdog)"})
-            print(json.dumps(line), flush=True)
+            os.write(_JSON_FD[0], (json.dumps(line) + "\n").encode())
         else:
             time.sleep(2.0)   # let rank 0 print first
         os._exit(0)
@@ -675,7 +676,7 @@ def callfunction_leg(args, values, validity, mask, device):
 
     from arrow_amd.plugin_build import build_plugin
 
-    lib = ctypes.CDLL(build_plugin())
+    lib = ctypes.CDLL(build_plugin(verbose=False))
     lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
     lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
     lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
@@ -982,6 +983,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line — the JSON result.  Everything else any layer below may print there (a compiler
+    # command line when the plugin is rebuilt, library chatter) is sent to stderr for the whole run.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    _JSON_FD[0] = json_fd
     if EMU:
         device = torch.device("cpu")
         if world > 1:
@@ -1013,7 +1020,8 @@ def main():
     else:
         result = run_sort(args, rank, world, device)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -8,7 +8,9 @@ from arrow_amd import parquet as P
 n = int(os.environ.get("N", 20_000_000))
 rng = np.random.default_rng(1)
 t = pa.table({"k": pa.array(rng.integers(0, 5000, n), mask=rng.random(n) < 0.1),
-              "v": pa.array(rng.integers(-2**62, 2**62, n))})
+              "v": pa.array(rng.integers(-2**62, 2**62, n)),
+              "w": pa.array(np.cumsum(rng.integers(-3, 4, n)))})       # compressible PLAIN int64: the device Snappy route
+t = t.cast(pa.schema([pa.field("k", pa.int64()), pa.field("v", pa.int64()), pa.field("w", pa.int64(), nullable=False)]))
 path = os.path.join(tempfile.mkdtemp(), "t.parquet")
 pq.write_table(t, path, row_group_size=n, compression="snappy", use_dictionary=["k"],
                data_page_version=os.environ.get("PAGE_VERSION", "1.0"))
@@ -24,7 +26,7 @@ amd.parquet.read_table(path); torch.cuda.synchronize()
 t0 = time.perf_counter(); amd.parquet.read_table(path); torch.cuda.synchronize(); t_host_codec = time.perf_counter() - t0
 P.DEVICE_SNAPPY = True
 print(f"arrow_amd.parquet.read_table with the host Snappy codec for every page: {t_host_codec*1e3:.0f} ms")
-for name in ("k", "v"):
+for name in ("k", "v", "w"):
     assert got[name][0].to_pyarrow().equals(ref.column(name).combine_chunks()), name
 print(f"pyarrow read_table: {t_ref*1e3:.0f} ms (1 thread), {t_ref_mt*1e3:.0f} ms (threads) | arrow_amd.parquet.read_table: {t_all*1e3:.0f} ms "
       f"(host: metadata, page headers, snappy, run-header walk in Python; device: levels, indices, dictionary gather, expand)")

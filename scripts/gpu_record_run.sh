@@ -1,6 +1,7 @@
 #!/bin/bash
-# Round-1 record run: headline bench, rocprof kernel trace, PMC passes (+ FETCH_SIZE calibration on
-# a known byte count: selectivity 1.0 touches every value line exactly once).
+# Record run of a round: headline bench, rocprofv3 kernel trace of the same command, PMC passes (FETCH_SIZE /
+# WRITE_SIZE, separate passes) for the filter kernels + FETCH_SIZE calibration on a known byte count (selectivity 1.0
+# touches every value line exactly once), then kernel trace + PMC of the sort (2e9 rows) and group-by (4e9 rows) kernels.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/${RUN_TAG:-record}
@@ -20,9 +21,8 @@ echo "== PMC calibration: selectivity 1.0 (every 128-B value line read exactly o
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cal_sparse -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --selectivity 1.0 --option filter_sparse=1 > /dev/null 2> $OUT/cal_sparse.err
 echo "-- gather form (8 B/lane), selectivity 1.0" >> $OUT/pmc_summary.txt
 python scripts/rocprof_summary.py pmc $(find $OUT/cal_sparse -name "*.db" | head -1) >> $OUT/pmc_summary.txt 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cal_sweep -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --selectivity 1.0 > /dev/null 2> $OUT/cal_sweep.err
-echo "-- sweep form (16 B/lane), selectivity 1.0" >> $OUT/pmc_summary.txt
-python scripts/rocprof_summary.py pmc $(find $OUT/cal_sweep -name "*.db" | head -1) >> $OUT/pmc_summary.txt 2>&1
 cat $OUT/pmc_summary.txt
+echo "== sort 2e9 + group-by 4e9: kernel trace + PMC"
+RUN_TAG=${RUN_TAG:-record}/sg PMC=1 bash scripts/gpu_prof_sg.sh
 find $OUT -name "*.db" -delete
 du -sh $OUT
