@@ -3,7 +3,9 @@ and per-kernel counter means from --pmc runs.  Usage:
   python scripts/rocprof_summary.py trace <results.db> [name-filter]
   python scripts/rocprof_summary.py pmc   <results.db> [name-filter]
 Only dispatches longer than 1/4 of the kernel's longest dispatch are averaged in the `big_*`
-columns (bench.py also launches the same kernels on a small parity sample)."""
+columns (bench.py also launches the same kernels on a small parity sample); `big_med_us` is their median — one
+kernel template can serve several bench legs (the filter compaction runs the 10 % headline and the 25 / 50 % legs),
+the median is the duration of the leg with the most dispatches."""
 import sqlite3
 import sys
 from collections import defaultdict
@@ -22,11 +24,12 @@ def trace(db, flt):
         if flt in n:
             agg[n].append(d)
     total = sum(sum(v) for v in agg.values())
-    print(f"{'kernel':90s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'big_n':>6s} {'big_avg_us':>11s} {'big_min_us':>11s} {'pct':>6s}")
+    print(f"{'kernel':90s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'big_n':>6s} {'big_avg_us':>11s} {'big_min_us':>11s} {'big_med_us':>11s} {'pct':>6s}")
     for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         big = [x for x in v if x >= max(v) / 4]
+        med = sorted(big)[len(big) // 2]
         print(f"{short(n):90s} {len(v):6d} {sum(v) / 1e6:10.3f} {sum(v) / len(v) / 1e3:10.1f} {len(big):6d} "
-              f"{sum(big) / len(big) / 1e3:11.1f} {min(big) / 1e3:11.1f} {100 * sum(v) / total:6.1f}")
+              f"{sum(big) / len(big) / 1e3:11.1f} {min(big) / 1e3:11.1f} {med / 1e3:11.1f} {100 * sum(v) / total:6.1f}")
 
 
 def pmc(db, flt):
