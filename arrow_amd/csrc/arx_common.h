@@ -120,6 +120,16 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
   return v;
 }
 
+__device__ __forceinline__ uint64_t wave_inclusive_scan_u64(uint64_t v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint64_t n = __shfl_up(v, d, 64);
+    if (lane >= d) v += n;
+  }
+  return v;
+}
+
 __device__ __forceinline__ uint32_t wave_reduce_sum_u32(uint32_t v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);

@@ -37,6 +37,8 @@ static int g_sort_msd_fused = 1;       // finish LDS-sized level-2 buckets in on
 static int64_t g_sort_msd_segment_rows = int64_t(1) << 27;  // above this: an extra top-bits level cuts segments
 static int g_sort_msd_final_rows_log2 = 1;  // log2 of the rows aimed at per final sub-bucket (rank loop length); with the 4096-bin finish 1 beats 2 / 3 / 4 by 3 / 9 / 18 % at 2e9 rows
 static int g_sort_msd_small_bucket = 1;  // 512-thread / 5120-row bucket kernel when every bucket fits it
+static int g_sort_msd_wide_sample_shift = 4;  // wide form: level-1 capacities from a histogram of 1 tile in 2^shift (0 = exact histogram of every row)
+static int g_sort_msd_wide_sample_strict = 0; // tests: a sampled attempt that overflows is an error instead of a silent exact re-run
 static int g_sort_msd_wide = 1;          // inputs beyond sort_msd_segment_rows: the wide two-level form (run_msd_sort_wide) before the segmented one
 static int g_sort_msd_bucket_v2 = 1;     // single-atomic-pass bucket finish with up to 4096 sub-buckets (msd_bucket2_kernel)
 static int g_sort_msd_seg_min_bits = 1;  // floor of the segment level's bits (more bins = fewer LDS atomic collisions)
@@ -1308,10 +1310,16 @@ constexpr int kMsdSplBits = 15;  // sampled-splitter mode: up to 2^15 buckets
 constexpr size_t kMsdTableWords = (size_t(1) << kMsdSplBits) + 64;
 constexpr size_t kMsdTableBytes = (3 * kMsdTableWords + size_t(128) * kMsdMaxChunks + 2 * 192 + 64) * 4 + (size_t(1) << kMsdSplBits) * 8;
 
-// tables of the wide two-level form (run_msd_sort_wide): 3 arrays of 2^20 buckets + 6 of 1024 level-1 entries
+// tables of the wide two-level form (run_msd_sort_wide): 3 arrays of 2^20 buckets + 8 of 1024 level-1 entries
 constexpr int kMsdwMaxBins = 1024;
 constexpr int kMsdwMaxBits = 20;
-constexpr size_t kMsdwTableBytes = (3 * ((size_t(1) << kMsdwMaxBits) + 64) + 6 * (kMsdwMaxBins + 64)) * 4;
+constexpr size_t kMsdwTableBytes = (3 * ((size_t(1) << kMsdwMaxBits) + 64) + 8 * (kMsdwMaxBins + 64)) * 4;
+
+// Level-1 buckets of the wide form are laid out with room to spare when their sizes are only estimated (sampled
+// histogram): per bucket est/32 + min(est/8 + 1, 16384) rows, in total at most this many more than n.
+static inline int64_t msdw_slack_rows(int64_t n) {
+  return n / 32 + std::min<int64_t>(n / 8 + 1024, int64_t(1) << 24) + 1024;
+}
 
 struct SortPlan {
   int64_t n;          // rows to sort (non-null)
@@ -1330,10 +1338,11 @@ static SortPlan make_plan(int64_t length) {
   auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
   const size_t n = static_cast<size_t>(std::max<int64_t>(length, 1));
   size_t o = 0;
-  p.off_keys_a = o; o = align(o + n * 8);
-  p.off_keys_b = o; o = align(o + n * 8);
-  p.off_idx_a = o; o = align(o + n * 4);
-  p.off_idx_b = o; o = align(o + n * 4);
+  const size_t nx = n + static_cast<size_t>(msdw_slack_rows(static_cast<int64_t>(n)));  // gapped level-1 layout
+  p.off_keys_a = o; o = align(o + nx * 8);
+  p.off_keys_b = o; o = align(o + nx * 8);
+  p.off_idx_a = o; o = align(o + nx * 4);
+  p.off_idx_b = o; o = align(o + nx * 4);
   p.off_hist = o; o = align(o + static_cast<size_t>(kDigits) * kMaxChunks * 4);
   p.off_totals = o; o = align(o + static_cast<size_t>(kDigits) * 4);
   p.off_split = o; o = align(o + static_cast<size_t>(kDigits) * 4);
@@ -1360,6 +1369,14 @@ int set_sort_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "sort_msd_final_rows_log2") == 0) {
     g_sort_msd_final_rows_log2 = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, 8)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_sample_shift") == 0) {
+    g_sort_msd_wide_sample_shift = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 8)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_sample_strict") == 0) {
+    g_sort_msd_wide_sample_strict = value != 0;
     return 1;
   }
   if (strcmp(name, "sort_msd_wide") == 0) {
@@ -1690,15 +1707,19 @@ struct MsdwArgs {
   int64_t n;
   int bits, b1, b2;
   int64_t chunk_rows;      // hist0 chunk
-  uint32_t* l1_count;      // [2^b1]
-  uint32_t* l1_start;      // [2^b1 + 1]
+  int sample_shift;        // hist0 reads one chunk in 2^sample_shift (0: every row, exact level-1 sizes)
+  int64_t x_capacity;      // rows keys_x / idx_x can hold
+  uint32_t* l1_count;      // [2^b1] histogram (of the sample)
+  uint32_t* l1_start;      // [2^b1] first slot of a level-1 bucket in keys_x (buckets may be followed by unused room)
+  uint32_t* l1_end;        // [2^b1] end of its room (until msdw_scan0b), then end of its rows
+  uint32_t* l1_out;        // [2^b1 + 1] start of the bucket in the compact level-2 output
   uint32_t* cursor1;       // [2^b1]
   uint32_t* l2_tile_start; // [2^b1 + 1]
   uint32_t* unit_start;    // [2^b1 + 1]
   uint32_t* count2;        // [2^bits]
   uint32_t* part_start;    // [2^bits + 1]
   uint32_t* cursor2;       // [2^bits]
-  uint32_t* flags;         // [0] overflow bits, [1] largest bucket
+  uint32_t* flags;         // [0] overflow bits (4: a level-1 bucket outgrew its room), [1] largest bucket, [2] sampled rows
   uint64_t* keys_x;
   uint32_t* idx_x;
   uint64_t* keys_y;
@@ -1712,8 +1733,17 @@ __global__ __launch_bounds__(kMsdThreads) void msdw_hist0_kernel(MsdwArgs a) {
   const int nb = 1 << a.b1;
   for (int i = tid; i < nb; i += kMsdThreads) h[i] = 0;
   __syncthreads();
-  const int64_t begin = static_cast<int64_t>(blockIdx.x) * a.chunk_rows;
+  // sampled: workgroup g reads chunk (g << s) + a pseudo-random offset inside its group of 2^s chunks, so a
+  // periodic input cannot line up with the sample
+  int64_t chunk = blockIdx.x;
+  if (a.sample_shift > 0) {
+    const uint32_t mix = (static_cast<uint32_t>(blockIdx.x) * 2654435761u) >> (32 - a.sample_shift);
+    chunk = (chunk << a.sample_shift) + mix;
+  }
+  const int64_t begin = chunk * a.chunk_rows;
+  if (begin >= a.n) return;  // workgroup-uniform (last group of a sampled run)
   const int64_t end = begin + a.chunk_rows < a.n ? begin + a.chunk_rows : a.n;
+  if (a.sample_shift > 0 && tid == 0) atomicAdd(&a.flags[2], static_cast<uint32_t>(end - begin));
   const int shift = 64 - a.b1;
   constexpr int U = 8;
   int64_t r = begin + tid;
@@ -1737,14 +1767,63 @@ __global__ __launch_bounds__(kMsdThreads) void msdw_hist0_kernel(MsdwArgs a) {
   }
 }
 
-// one workgroup of 1024 threads (one level-1 bucket per thread)
+// One workgroup of 1024 threads (one level-1 bucket per thread): room for every level-1 bucket in keys_x.  Exact
+// histogram: room = rows.  Sampled histogram: rows are estimated (count * n / sampled rows) and get est/32 +
+// min(est/8 + 1, 16384) more; if that does not fit x_capacity nothing gets room, every tile of level 1 reports the
+// overflow and the host repeats the level with the exact histogram.
 __global__ __launch_bounds__(1024) void msdw_scan0_kernel(MsdwArgs a) {
-  __shared__ uint32_t wt[3][16];
+  __shared__ uint64_t wt[16];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int nb = 1 << a.b1;
   const uint32_t c = tid < nb ? a.l1_count[tid] : 0u;
+  uint64_t room = c;
+  if (a.sample_shift > 0) {
+    const uint32_t sampled = a.flags[2];
+    uint64_t est = 0;
+    if (sampled != 0 && c != 0) {
+      est = static_cast<uint64_t>(static_cast<double>(c) * static_cast<double>(a.n) / static_cast<double>(sampled)) + 1;
+      if (est > static_cast<uint64_t>(a.n)) est = static_cast<uint64_t>(a.n);
+    }
+    const uint64_t extra = est / 8 + 1 < 16384 ? est / 8 + 1 : 16384;
+    room = tid < nb ? est + est / 32 + extra : 0;
+  }
+  const uint64_t incl = wave_inclusive_scan_u64(room);
+  if (lane == 63) wt[wave] = incl;
+  __syncthreads();
+  uint64_t pre = incl - room, total = 0;
+  for (int k = 0; k < 16; ++k) {
+    if (k < wave) pre += wt[k];
+    total += wt[k];
+  }
+  const bool fits = total <= static_cast<uint64_t>(a.x_capacity);
+  if (tid < nb) {
+    a.l1_start[tid] = fits ? static_cast<uint32_t>(pre) : 0u;
+    a.cursor1[tid] = fits ? static_cast<uint32_t>(pre) : 0u;
+    a.l1_end[tid] = fits ? static_cast<uint32_t>(pre + room) : 0u;
+  }
+}
+
+// After level 1 (one workgroup, one level-1 bucket per thread): rows that arrived in every bucket -> tile / unit maps
+// of the level-2 kernels and the bucket's start in the compact level-2 output.
+__global__ __launch_bounds__(1024) void msdw_scan0b_kernel(MsdwArgs a) {
+  __shared__ uint32_t wt[3][16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nb = 1 << a.b1;
+  uint32_t c = 0;
+  if (tid < nb) {
+    const uint32_t lo = a.l1_start[tid], room_end = a.l1_end[tid], cur = a.cursor1[tid];
+    if (cur > room_end || cur < lo) {
+      atomicOr(&a.flags[0], 4u);
+      c = room_end - lo;
+    } else {
+      c = cur - lo;
+    }
+    a.l1_end[tid] = lo + c;
+  }
   const uint32_t tiles = (c + kMsdwTile - 1) / kMsdwTile;
   const uint32_t units = static_cast<uint32_t>((static_cast<int64_t>(c) + kMsdwUnit - 1) / kMsdwUnit);
   const uint32_t i0 = wave_inclusive_scan_u32(c);
@@ -1763,15 +1842,15 @@ __global__ __launch_bounds__(1024) void msdw_scan0_kernel(MsdwArgs a) {
     p2 += wt[2][k];
   }
   if (tid < nb) {
-    a.l1_start[tid] = p0;
-    a.cursor1[tid] = p0;
+    a.l1_out[tid] = p0;
     a.l2_tile_start[tid] = p1;
     a.unit_start[tid] = p2;
   }
   if (tid == nb - 1) {
-    a.l1_start[nb] = p0 + c;
+    a.l1_out[nb] = p0 + c;
     a.l2_tile_start[nb] = p1 + tiles;
     a.unit_start[nb] = p2 + units;
+    if (static_cast<int64_t>(p0) + c != a.n) atomicOr(&a.flags[0], 4u);   // rows were dropped by an overflowing tile
   }
 }
 
@@ -1787,10 +1866,12 @@ struct __attribute__((aligned(16))) MsdwScatterLds {
 
 // Scatter one tile of <= 8192 rows by digit = (key >> dshift) & (nb - 1); run bases from one returning atomic per
 // digit on gcursor[].  1024 threads, nb <= 1024 (one counter per thread in the scan).
-template <bool RAW>
+// CHECK: a run that does not fit its bucket's room (gend[]) is not written and sets flags[0] bit 4.
+template <bool RAW, bool CHECK>
 __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatterLds& lds, const uint64_t* __restrict__ kin,
                                                   const uint32_t* __restrict__ iin, int64_t row0, int nrows, int nb,
                                                   int dshift, uint32_t* __restrict__ gcursor,
+                                                  const uint32_t* __restrict__ gend,
                                                   uint64_t* __restrict__ kout, uint32_t* __restrict__ iout) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1828,7 +1909,14 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
     uint32_t pre = incl - c;
     for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
     lds.start[tid] = pre;
-    lds.gbase[tid] = c != 0 ? atomicAdd(&gcursor[tid], c) : 0u;
+    uint32_t base = c != 0 ? atomicAdd(&gcursor[tid], c) : 0u;
+    if constexpr (CHECK) {
+      if (c != 0 && (base + c > gend[tid] || base + c < base)) {
+        base = 0xFFFFFFFFu;
+        atomicOr(&a.flags[0], 4u);
+      }
+    }
+    lds.gbase[tid] = base;
   }
   __syncthreads();
 #pragma unroll
@@ -1843,7 +1931,9 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
   for (int p = tid; p < nrows; p += kMsdwThreads) {
     const uint64_t k = lds.keys[p];
     const uint32_t d = static_cast<uint32_t>(k >> dshift) & dmask;
-    const uint32_t dst = lds.gbase[d] + (static_cast<uint32_t>(p) - lds.start[d]);
+    const uint32_t gb = lds.gbase[d];
+    if (CHECK && gb == 0xFFFFFFFFu) continue;
+    const uint32_t dst = gb + (static_cast<uint32_t>(p) - lds.start[d]);
     kout[dst] = k;
     iout[dst] = lds.idx[p];
   }
@@ -1852,10 +1942,13 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
 template <bool RAW>
 __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1_kernel(MsdwArgs a) {
   __shared__ MsdwScatterLds lds;
+  // an earlier tile already found a bucket without room: the level will be repeated, do not finish this attempt
+  // (e.g. pre-sorted input, where a sample of tiles says little about where the bucket boundaries fall)
+  if (a.sample_shift > 0 && (__atomic_load_n(&a.flags[0], __ATOMIC_RELAXED) & 4u) != 0) return;
   const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kMsdwTile;
   const int nrows = static_cast<int>(a.n - row0 < kMsdwTile ? a.n - row0 : kMsdwTile);
-  msdw_scatter_tile<RAW>(a, lds, a.src_keys, a.src_idx, row0, nrows, 1 << a.b1, 64 - a.b1, a.cursor1, a.keys_x,
-                         a.idx_x);
+  msdw_scatter_tile<RAW, true>(a, lds, a.src_keys, a.src_idx, row0, nrows, 1 << a.b1, 64 - a.b1, a.cursor1, a.l1_end,
+                               a.keys_x, a.idx_x);
 }
 
 // index of the last entry of start[0..nb] (nb + 1 entries, non-decreasing, start[0] == 0) that is <= g, computed by
@@ -1883,7 +1976,7 @@ __global__ __launch_bounds__(kMsdThreads) void msdw_hist1_kernel(MsdwArgs a) {
   for (int i = tid; i < nb2; i += kMsdThreads) h[i] = 0;
   const uint32_t p = msdw_owner(a.unit_start, nb1, u, &part_s);
   const int64_t begin = static_cast<int64_t>(a.l1_start[p]) + static_cast<int64_t>(u - a.unit_start[p]) * kMsdwUnit;
-  const int64_t bucket_end = a.l1_start[p + 1];
+  const int64_t bucket_end = a.l1_end[p];
   const int64_t end = begin + kMsdwUnit < bucket_end ? begin + kMsdwUnit : bucket_end;
   const int shift = 64 - a.bits;
   const uint32_t mask = static_cast<uint32_t>(nb2 - 1);
@@ -1926,7 +2019,7 @@ __global__ __launch_bounds__(1024) void msdw_scan1_kernel(MsdwArgs a) {
   if (lane == 63) wt[wave] = incl;
   if (lane == 0) wmax[wave] = mx;
   __syncthreads();
-  uint32_t pre = a.l1_start[p] + incl - c;
+  uint32_t pre = a.l1_out[p] + incl - c;
   for (int k = 0; k < wave; ++k) pre += wt[k];
   if (tid < nb2) {
     a.part_start[base + tid] = pre;
@@ -1936,7 +2029,7 @@ __global__ __launch_bounds__(1024) void msdw_scan1_kernel(MsdwArgs a) {
     uint32_t m = 0;
     for (int k = 0; k < 16; ++k) m = m > wmax[k] ? m : wmax[k];
     atomicMax(&a.flags[1], m);
-    if (p + 1 == gridDim.x) a.part_start[base + nb2] = a.l1_start[p + 1];
+    if (p + 1 == gridDim.x) a.part_start[base + nb2] = a.l1_out[p + 1];
   }
 }
 
@@ -1948,11 +2041,11 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter2_kernel(MsdwArgs a)
   if (g >= a.l2_tile_start[nb1]) return;  // over-provisioned grid
   const uint32_t p = msdw_owner(a.l2_tile_start, nb1, g, &lds.part);
   const int64_t lo = a.l1_start[p];
-  const int64_t hi = a.l1_start[p + 1];
+  const int64_t hi = a.l1_end[p];
   const int64_t row0 = lo + static_cast<int64_t>(g - a.l2_tile_start[p]) * kMsdwTile;
   const int nrows = static_cast<int>(hi - row0 < kMsdwTile ? hi - row0 : kMsdwTile);
-  msdw_scatter_tile<false>(a, lds, a.keys_x, a.idx_x, row0, nrows, 1 << a.b2, 64 - a.bits,
-                           a.cursor2 + (static_cast<size_t>(p) << a.b2), a.keys_y, a.idx_y);
+  msdw_scatter_tile<false, false>(a, lds, a.keys_x, a.idx_x, row0, nrows, 1 << a.b2, 64 - a.bits,
+                                  a.cursor2 + (static_cast<size_t>(p) << a.b2), nullptr, a.keys_y, a.idx_y);
 }
 
 
@@ -1971,9 +2064,7 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   a.bits = std::max(2, std::min(lg - 12, kMsdwMaxBits));   // 2048 < average bucket <= 4096 rows
   a.b1 = a.bits / 2;
   a.b2 = a.bits - a.b1;
-  const int64_t ntiles0 = ceil_div(n, kMsdTile);
-  a.chunk_rows = std::max<int64_t>(1, ceil_div(ntiles0, kMsdMaxChunks)) * kMsdTile;
-  const unsigned nch = static_cast<unsigned>(ceil_div(n, a.chunk_rows));
+  a.x_capacity = n + msdw_slack_rows(n);
   uint32_t* t = reinterpret_cast<uint32_t*>(tables);
   const size_t big = (size_t(1) << kMsdwMaxBits) + 64;
   const size_t small = kMsdwMaxBins + 64;
@@ -1986,38 +2077,73 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   a.l2_tile_start = a.cursor1 + small;
   a.unit_start = a.l2_tile_start + small;
   a.flags = a.unit_start + small;
+  a.l1_end = a.flags + small;
+  a.l1_out = a.l1_end + small;
   a.keys_x = keys_x;
   a.idx_x = idx_x;
   a.keys_y = keys_y;
   a.idx_y = idx_y;
   const int nb1 = 1 << a.b1;
   const size_t nparts = size_t(1) << a.bits;
-  ARX_HIP(hipMemsetAsync(a.l1_count, 0, static_cast<size_t>(nb1) * 4, st));
-  ARX_HIP(hipMemsetAsync(a.count2, 0, nparts * 4, st));
-  ARX_HIP(hipMemsetAsync(a.flags, 0, 8, st));
-  if (raw) {
-    hipLaunchKernelGGL((msdw_hist0_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
-  } else {
-    hipLaunchKernelGGL((msdw_hist0_kernel<false>), dim3(nch), dim3(kMsdThreads), 0, st, a);
-  }
-  ARX_CHECK_LAUNCH("msdw_hist0_kernel");
-  hipLaunchKernelGGL(msdw_scan0_kernel, dim3(1), dim3(1024), 0, st, a);
-  ARX_CHECK_LAUNCH("msdw_scan0_kernel");
   const unsigned grid1 = static_cast<unsigned>(ceil_div(n, kMsdwTile));
-  if (raw) {
-    hipLaunchKernelGGL((msdw_scatter1_kernel<true>), dim3(grid1), dim3(kMsdwThreads), 0, st, a);
-  } else {
-    hipLaunchKernelGGL((msdw_scatter1_kernel<false>), dim3(grid1), dim3(kMsdwThreads), 0, st, a);
-  }
-  ARX_CHECK_LAUNCH("msdw_scatter1_kernel");
-  const unsigned units = static_cast<unsigned>(ceil_div(n, kMsdwUnit) + nb1);
-  hipLaunchKernelGGL(msdw_hist1_kernel, dim3(units), dim3(kMsdThreads), 0, st, a);
-  ARX_CHECK_LAUNCH("msdw_hist1_kernel");
-  hipLaunchKernelGGL(msdw_scan1_kernel, dim3(static_cast<unsigned>(nb1)), dim3(1024), 0, st, a);
-  ARX_CHECK_LAUNCH("msdw_scan1_kernel");
+  // Level-1 bucket sizes: estimated from 1 tile in 2^shift (the buckets then get room to spare and level 2 reads
+  // what actually arrived), or — shift 0, and whenever an estimate turned out too small — counted exactly.
+  int sample_shift = a.x_capacity < (int64_t(1) << 32) ? g_sort_msd_wide_sample_shift : 0;
+  while (sample_shift > 0 && (static_cast<int64_t>(grid1) >> sample_shift) < 8) --sample_shift;   // too few tiles to sample
   unsigned int max_part = 0;
-  ARX_HIP(hipMemcpyAsync(&max_part, a.flags + 1, 4, hipMemcpyDeviceToHost, st));
-  ARX_HIP(hipStreamSynchronize(st));
+  for (;;) {
+    a.sample_shift = sample_shift;
+    unsigned nch;
+    if (sample_shift > 0) {
+      a.chunk_rows = kMsdwTile;
+      nch = static_cast<unsigned>(ceil_div(static_cast<int64_t>(grid1), int64_t(1) << sample_shift));
+    } else {
+      const int64_t ntiles0 = ceil_div(n, kMsdTile);
+      a.chunk_rows = std::max<int64_t>(1, ceil_div(ntiles0, kMsdMaxChunks)) * kMsdTile;
+      nch = static_cast<unsigned>(ceil_div(n, a.chunk_rows));
+    }
+    ARX_HIP(hipMemsetAsync(a.l1_count, 0, static_cast<size_t>(nb1) * 4, st));
+    ARX_HIP(hipMemsetAsync(a.count2, 0, nparts * 4, st));
+    ARX_HIP(hipMemsetAsync(a.flags, 0, 16, st));
+    if (raw) {
+      hipLaunchKernelGGL((msdw_hist0_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((msdw_hist0_kernel<false>), dim3(nch), dim3(kMsdThreads), 0, st, a);
+    }
+    ARX_CHECK_LAUNCH("msdw_hist0_kernel");
+    hipLaunchKernelGGL(msdw_scan0_kernel, dim3(1), dim3(1024), 0, st, a);
+    ARX_CHECK_LAUNCH("msdw_scan0_kernel");
+    if (raw) {
+      hipLaunchKernelGGL((msdw_scatter1_kernel<true>), dim3(grid1), dim3(kMsdwThreads), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((msdw_scatter1_kernel<false>), dim3(grid1), dim3(kMsdwThreads), 0, st, a);
+    }
+    ARX_CHECK_LAUNCH("msdw_scatter1_kernel");
+    hipLaunchKernelGGL(msdw_scan0b_kernel, dim3(1), dim3(1024), 0, st, a);
+    ARX_CHECK_LAUNCH("msdw_scan0b_kernel");
+    const unsigned units = static_cast<unsigned>(ceil_div(n, kMsdwUnit) + nb1);
+    hipLaunchKernelGGL(msdw_hist1_kernel, dim3(units), dim3(kMsdThreads), 0, st, a);
+    ARX_CHECK_LAUNCH("msdw_hist1_kernel");
+    hipLaunchKernelGGL(msdw_scan1_kernel, dim3(static_cast<unsigned>(nb1)), dim3(1024), 0, st, a);
+    ARX_CHECK_LAUNCH("msdw_scan1_kernel");
+    unsigned int fl[2] = {0, 0};
+    ARX_HIP(hipMemcpyAsync(fl, a.flags, 8, hipMemcpyDeviceToHost, st));
+    ARX_HIP(hipStreamSynchronize(st));
+    if ((fl[0] & 4u) != 0) {   // a level-1 bucket outgrew its room; the source is untouched (level 2 has not run)
+      if (sample_shift == 0) {
+        set_error("array_sort_indices: internal error (exact level-1 histogram disagrees with the scatter)");
+        return ARX_INVALID;
+      }
+      if (g_sort_msd_wide_sample_strict) {
+        set_error("array_sort_indices: sampled level-1 histogram underestimated a bucket (sort_msd_wide_sample_strict)");
+        return ARX_INVALID;
+      }
+      sample_shift = 0;
+      continue;
+    }
+    max_part = fl[1];
+    break;
+  }
   if (max_part > static_cast<unsigned int>(kBktCap)) {   // skewed keys: a bucket would not fit LDS
     *overflowed = 1;
     return ARX_OK;

@@ -603,6 +603,47 @@ def check_sort_indices(amd, arr: HostArray, order="ascending", null_placement="a
     return out
 
 
+def check_sort_wide_sampled(amd, lib, rng, n, shift):
+    """The wide two-level sort with level-1 bucket sizes ESTIMATED from one tile in 2^shift (buckets get room to spare,
+    level 2 reads what arrived).  Uniform keys: the estimate must hold (strict mode turns a silent exact re-run into
+    an error).  Sorted / blocky inputs where the sampled tiles say little about the rest: the overflow is detected and
+    the level repeated with the exact histogram — same result; in strict mode the call must fail instead."""
+    opts = {b"sort_msd": 1, b"sort_msd_segment_rows": 4096, b"sort_msd_wide": 1,
+            b"sort_msd_wide_sample_shift": shift}
+    for k, v in opts.items():
+        assert lib.arx_set_option(k, v) == 0
+    try:
+        uniform = util.random_array(rng, np.uint64, n, offset=5)
+        assert lib.arx_set_option(b"sort_msd_wide_sample_strict", 1) == 0
+        check_sort_indices(amd, uniform, "ascending", "at_end", use_pyarrow=False)
+        signed = util.random_array(rng, np.int64, n, null_p=0.02)
+        check_sort_indices(amd, signed, "descending", "at_start", use_pyarrow=False)
+        # blocks of 8192 rows alternate between two narrow key ranges in a pattern the sample cannot see
+        blocky = util.random_array(rng, np.uint64, n)
+        v = blocky.values[blocky.offset:blocky.offset + n]
+        tile = np.arange(n) // 8192
+        low = (tile * 2654435761 % 7) < 3
+        v[low] >>= np.uint64(3)
+        ordered = util.random_array(rng, np.uint64, n)
+        ordered.values[ordered.offset:ordered.offset + n] = np.sort(ordered.values[ordered.offset:ordered.offset + n])
+        failed = 0
+        for arr in (blocky, ordered):
+            try:
+                check_sort_indices(amd, arr, "ascending", "at_end", use_pyarrow=False)
+            except Exception as e:   # strict: the underestimate is reported, never a wrong order
+                assert "underestimated" in str(e), e
+                failed += 1
+        assert lib.arx_set_option(b"sort_msd_wide_sample_strict", 0) == 0
+        for arr in (blocky, ordered):
+            check_sort_indices(amd, arr, "ascending", "at_end", use_pyarrow=False)
+        return failed
+    finally:
+        lib.arx_set_option(b"sort_msd_wide_sample_strict", 0)
+        lib.arx_set_option(b"sort_msd_wide_sample_shift", 4)
+        lib.arx_set_option(b"sort_msd", -1)
+        lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
+
+
 # ------------------------------------------------------------------ group-by
 def check_concat_arrays(amd, chunks, use_pyarrow=True):
     """Concatenate (array/concatenate.cc): chunks glued at arbitrary bit positions; values and validity equal
