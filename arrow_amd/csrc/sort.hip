@@ -38,6 +38,7 @@ static int64_t g_sort_msd_segment_rows = int64_t(1) << 27;  // above this: an ex
 static int g_sort_msd_final_rows_log2 = 1;  // log2 of the rows aimed at per final sub-bucket (rank loop length); with the 4096-bin finish 1 beats 2 / 3 / 4 by 3 / 9 / 18 % at 2e9 rows
 static int g_sort_msd_small_bucket = 1;  // 512-thread / 5120-row bucket kernel when every bucket fits it
 static int g_sort_msd_wide_sample_shift = 4;  // wide form: level-1 capacities from a histogram of 1 tile in 2^shift (0 = exact histogram of every row)
+static int g_sort_msd_wide_gap2 = 1;          // wide form: level-2 buckets get a fixed room each (bucket mean + 6 sigma + 64) instead of an exact histogram pass
 static int g_sort_msd_wide_sample_strict = 0; // tests: a sampled attempt that overflows is an error instead of a silent exact re-run
 static int g_sort_msd_wide = 1;          // inputs beyond sort_msd_segment_rows: the wide two-level form (run_msd_sort_wide) before the segmented one
 static int g_sort_msd_bucket_v2 = 1;     // single-atomic-pass bucket finish with up to 4096 sub-buckets (msd_bucket2_kernel)
@@ -515,7 +516,15 @@ struct MsdArgs {
   uint32_t* idx_y;
   uint64_t* out_final;
   unsigned int* overflow;
+  const uint32_t* part_in;    // record input of the bucket finish (AOS form): first record of every bucket
 };
+
+// (key, row id) as one 12-byte record: what the wide form's two scatter levels write and read (one output stream per
+// bin instead of two: 5-20 % faster scatters, scripts/micro/scatter_bench.hip)
+struct __attribute__((packed, aligned(4))) MsdRec {
+  uint32_t lo, hi, idx;
+};
+__device__ __forceinline__ uint64_t msd_rec_key(const MsdRec& r) { return (static_cast<uint64_t>(r.hi) << 32) | r.lo; }
 
 template <bool RAW>
 __device__ __forceinline__ uint64_t msd_load_key(const MsdArgs& a, int64_t i) {
@@ -1194,7 +1203,8 @@ struct __attribute__((aligned(16))) MsdBucket2Lds {
   uint32_t wave_tot[T / 64];
 };
 
-template <bool SPL, int T>
+// AOS: the bucket's rows are 12-byte records starting at record part_in[q] of `keys` (idx unused)
+template <bool SPL, int T, bool AOS = false>
 __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ idx) {
   __shared__ MsdBucket2Lds<T> w;
@@ -1204,6 +1214,8 @@ __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_
   const uint32_t q = blockIdx.x;
   const int64_t lo = a.part_start[q];
   const int m = static_cast<int>(static_cast<int64_t>(a.part_start[q + 1]) - lo);
+  const int64_t lo_in = AOS ? static_cast<int64_t>(a.part_in[q]) : lo;
+  const MsdRec* __restrict__ recs = reinterpret_cast<const MsdRec*>(keys);
   if (m == 0) return;  // workgroup-uniform
   if (m > T * kBktRows) {
     if (tid == 0) atomicOr(a.overflow, 2u);
@@ -1235,9 +1247,15 @@ __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_
 #pragma unroll
   for (int i = 0; i < kBktRows; ++i) {   // unconditional loads (clamped): all round trips overlap
     const int p = i * T + tid;
-    const int64_t r = lo + (p < m ? p : m - 1);
-    key[i] = keys[r];
-    id[i] = idx[r];
+    const int64_t r = lo_in + (p < m ? p : m - 1);
+    if constexpr (AOS) {
+      const MsdRec rr = recs[r];
+      key[i] = msd_rec_key(rr);
+      id[i] = rr.idx;
+    } else {
+      key[i] = keys[r];
+      id[i] = idx[r];
+    }
   }
   __syncthreads();
   uint32_t dig[kBktRows], rank[kBktRows];
@@ -1310,16 +1328,16 @@ constexpr int kMsdSplBits = 15;  // sampled-splitter mode: up to 2^15 buckets
 constexpr size_t kMsdTableWords = (size_t(1) << kMsdSplBits) + 64;
 constexpr size_t kMsdTableBytes = (3 * kMsdTableWords + size_t(128) * kMsdMaxChunks + 2 * 192 + 64) * 4 + (size_t(1) << kMsdSplBits) * 8;
 
-// tables of the wide two-level form (run_msd_sort_wide): 3 arrays of 2^20 buckets + 8 of 1024 level-1 entries
+// tables of the wide two-level form (run_msd_sort_wide): 3 arrays of 2^20 buckets + 10 of 1024 level-1 entries
 constexpr int kMsdwMaxBins = 1024;
 constexpr int kMsdwMaxBits = 20;
-constexpr size_t kMsdwTableBytes = (3 * ((size_t(1) << kMsdwMaxBits) + 64) + 8 * (kMsdwMaxBins + 64)) * 4;
+constexpr size_t kMsdwTableBytes = (3 * ((size_t(1) << kMsdwMaxBits) + 64) + 10 * (kMsdwMaxBins + 64)) * 4;
 
-// Level-1 buckets of the wide form are laid out with room to spare when their sizes are only estimated (sampled
-// histogram): per bucket est/32 + min(est/8 + 1, 16384) rows, in total at most this many more than n.
-static inline int64_t msdw_slack_rows(int64_t n) {
-  return n / 32 + std::min<int64_t>(n / 8 + 1024, int64_t(1) << 24) + 1024;
-}
+// The wide form lays its buckets out with room to spare instead of counting them exactly first: level-1 buckets
+// sized from a sampled histogram get est/32 + min(est/8 + 1, 16384) more rows, level-2 buckets a fixed room of
+// mean + 6 sqrt(mean) + 64 rows (mean > 2048: at most 22 % more).  Both fit n + this many records, checked on the
+// device; what does not fit falls back to exact counts.
+static inline int64_t msdw_slack_rows(int64_t n) { return n / 4 + 4096; }
 
 struct SortPlan {
   int64_t n;          // rows to sort (non-null)
@@ -1338,10 +1356,11 @@ static SortPlan make_plan(int64_t length) {
   auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
   const size_t n = static_cast<size_t>(std::max<int64_t>(length, 1));
   size_t o = 0;
-  const size_t nx = n + static_cast<size_t>(msdw_slack_rows(static_cast<int64_t>(n)));  // gapped level-1 layout
+  // (keys_a, idx_a) and (keys_b, idx_b) are adjacent: the wide form uses either pair as ONE array of nx 12-byte records
+  const size_t nx = n + static_cast<size_t>(msdw_slack_rows(static_cast<int64_t>(n)));
   p.off_keys_a = o; o = align(o + nx * 8);
-  p.off_keys_b = o; o = align(o + nx * 8);
   p.off_idx_a = o; o = align(o + nx * 4);
+  p.off_keys_b = o; o = align(o + nx * 8);
   p.off_idx_b = o; o = align(o + nx * 4);
   p.off_hist = o; o = align(o + static_cast<size_t>(kDigits) * kMaxChunks * 4);
   p.off_totals = o; o = align(o + static_cast<size_t>(kDigits) * 4);
@@ -1373,6 +1392,10 @@ int set_sort_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "sort_msd_wide_sample_shift") == 0) {
     g_sort_msd_wide_sample_shift = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 8)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_gap2") == 0) {
+    g_sort_msd_wide_gap2 = value != 0;
     return 1;
   }
   if (strcmp(name, "sort_msd_wide_sample_strict") == 0) {
@@ -1708,22 +1731,25 @@ struct MsdwArgs {
   int bits, b1, b2;
   int64_t chunk_rows;      // hist0 chunk
   int sample_shift;        // hist0 reads one chunk in 2^sample_shift (0: every row, exact level-1 sizes)
-  int64_t x_capacity;      // rows keys_x / idx_x can hold
+  int gap2;                // level-2 buckets get a fixed room each (no level-2 histogram)
+  int64_t capacity;        // records rec_x / rec_y can hold
   uint32_t* l1_count;      // [2^b1] histogram (of the sample)
-  uint32_t* l1_start;      // [2^b1] first slot of a level-1 bucket in keys_x (buckets may be followed by unused room)
+  uint32_t* l1_start;      // [2^b1] first record of a level-1 bucket in rec_x (buckets may be followed by unused room)
   uint32_t* l1_end;        // [2^b1] end of its room (until msdw_scan0b), then end of its rows
-  uint32_t* l1_out;        // [2^b1 + 1] start of the bucket in the compact level-2 output
+  uint32_t* l1_out;        // [2^b1 + 1] first FINAL position of the bucket's rows
   uint32_t* cursor1;       // [2^b1]
   uint32_t* l2_tile_start; // [2^b1 + 1]
   uint32_t* unit_start;    // [2^b1 + 1]
-  uint32_t* count2;        // [2^bits]
-  uint32_t* part_start;    // [2^bits + 1]
+  uint32_t* room2;         // [2^b1] gap2: room of every level-2 bucket of this level-1 bucket
+  uint32_t* y_base;        // [2^b1] gap2: first record of the level-1 bucket's level-2 rooms in rec_y
+  uint32_t* count2;        // [2^bits] exact form: level-2 histogram;  gap2: part_in (first record of the bucket in rec_y)
+  uint32_t* part_start;    // [2^bits + 1] first FINAL position of every level-2 bucket
   uint32_t* cursor2;       // [2^bits]
-  uint32_t* flags;         // [0] overflow bits (4: a level-1 bucket outgrew its room), [1] largest bucket, [2] sampled rows
-  uint64_t* keys_x;
-  uint32_t* idx_x;
-  uint64_t* keys_y;
-  uint32_t* idx_y;
+  uint32_t* flags;         // [0] bits: 2 a bucket does not fit LDS, 4 a level-1 bucket outgrew its room, 8 fixed level-2
+                           //     rooms are not possible here, 16 a level-2 bucket outgrew its room; [1] largest bucket;
+                           //     [2] sampled rows
+  MsdRec* rec_x;           // level-1 output
+  MsdRec* rec_y;           // level-2 output
 };
 
 template <bool RAW>
@@ -1767,9 +1793,9 @@ __global__ __launch_bounds__(kMsdThreads) void msdw_hist0_kernel(MsdwArgs a) {
   }
 }
 
-// One workgroup of 1024 threads (one level-1 bucket per thread): room for every level-1 bucket in keys_x.  Exact
+// One workgroup of 1024 threads (one level-1 bucket per thread): room for every level-1 bucket in rec_x.  Exact
 // histogram: room = rows.  Sampled histogram: rows are estimated (count * n / sampled rows) and get est/32 +
-// min(est/8 + 1, 16384) more; if that does not fit x_capacity nothing gets room, every tile of level 1 reports the
+// min(est/8 + 1, 16384) more; if that does not fit the buffer nothing gets room, every tile of level 1 reports the
 // overflow and the host repeats the level with the exact histogram.
 __global__ __launch_bounds__(1024) void msdw_scan0_kernel(MsdwArgs a) {
   __shared__ uint64_t wt[16];
@@ -1797,7 +1823,7 @@ __global__ __launch_bounds__(1024) void msdw_scan0_kernel(MsdwArgs a) {
     if (k < wave) pre += wt[k];
     total += wt[k];
   }
-  const bool fits = total <= static_cast<uint64_t>(a.x_capacity);
+  const bool fits = total <= static_cast<uint64_t>(a.capacity);
   if (tid < nb) {
     a.l1_start[tid] = fits ? static_cast<uint32_t>(pre) : 0u;
     a.cursor1[tid] = fits ? static_cast<uint32_t>(pre) : 0u;
@@ -1806,9 +1832,12 @@ __global__ __launch_bounds__(1024) void msdw_scan0_kernel(MsdwArgs a) {
 }
 
 // After level 1 (one workgroup, one level-1 bucket per thread): rows that arrived in every bucket -> tile / unit maps
-// of the level-2 kernels and the bucket's start in the compact level-2 output.
+// of the level-2 kernels and the bucket's first final position.  gap2: the room of the bucket's level-2 buckets
+// (their mean + 6 sqrt(mean) + 64 rows; keys that are uniform inside the level-1 bucket stay below it) and where the
+// rooms start in rec_y — flags bit 8 when a room would not fit LDS or all rooms do not fit the buffer.
 __global__ __launch_bounds__(1024) void msdw_scan0b_kernel(MsdwArgs a) {
   __shared__ uint32_t wt[3][16];
+  __shared__ uint64_t wy[16];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -1826,31 +1855,58 @@ __global__ __launch_bounds__(1024) void msdw_scan0b_kernel(MsdwArgs a) {
   }
   const uint32_t tiles = (c + kMsdwTile - 1) / kMsdwTile;
   const uint32_t units = static_cast<uint32_t>((static_cast<int64_t>(c) + kMsdwUnit - 1) / kMsdwUnit);
+  uint32_t room = 0;
+  if (a.gap2 && c != 0) {
+    const uint32_t mean = (c + (1u << a.b2) - 1) >> a.b2;
+    uint32_t root = 0;   // ceil(sqrt(mean)), integer
+    for (int b = 15; b >= 0; --b) {
+      const uint32_t t = root | (1u << b);
+      if (static_cast<uint64_t>(t) * t < mean) root = t;
+    }
+    root += 1;
+    room = mean > static_cast<uint32_t>(kBktCapSmall) ? 0xFFFFFFFFu : mean + 6u * root + 64u;
+    if (room > static_cast<uint32_t>(kBktCapSmall)) {
+      atomicOr(&a.flags[0], 8u);
+      room = 0;
+    }
+  }
+  const uint64_t yrows = static_cast<uint64_t>(room) << a.b2;
   const uint32_t i0 = wave_inclusive_scan_u32(c);
   const uint32_t i1 = wave_inclusive_scan_u32(tiles);
   const uint32_t i2 = wave_inclusive_scan_u32(units);
+  const uint64_t i3 = wave_inclusive_scan_u64(yrows);
   if (lane == 63) {
     wt[0][wave] = i0;
     wt[1][wave] = i1;
     wt[2][wave] = i2;
+    wy[wave] = i3;
   }
   __syncthreads();
   uint32_t p0 = i0 - c, p1 = i1 - tiles, p2 = i2 - units;
-  for (int k = 0; k < wave; ++k) {
-    p0 += wt[0][k];
-    p1 += wt[1][k];
-    p2 += wt[2][k];
+  uint64_t p3 = i3 - yrows, ytotal = 0;
+  for (int k = 0; k < 16; ++k) {
+    if (k < wave) {
+      p0 += wt[0][k];
+      p1 += wt[1][k];
+      p2 += wt[2][k];
+      p3 += wy[k];
+    }
+    ytotal += wy[k];
   }
+  const bool yfits = ytotal <= static_cast<uint64_t>(a.capacity);
   if (tid < nb) {
     a.l1_out[tid] = p0;
     a.l2_tile_start[tid] = p1;
     a.unit_start[tid] = p2;
+    a.room2[tid] = yfits ? room : 0u;
+    a.y_base[tid] = yfits ? static_cast<uint32_t>(p3) : 0u;
   }
   if (tid == nb - 1) {
     a.l1_out[nb] = p0 + c;
     a.l2_tile_start[nb] = p1 + tiles;
     a.unit_start[nb] = p2 + units;
     if (static_cast<int64_t>(p0) + c != a.n) atomicOr(&a.flags[0], 4u);   // rows were dropped by an overflowing tile
+    if (a.gap2 && !yfits) atomicOr(&a.flags[0], 8u);
   }
 }
 
@@ -1865,14 +1921,17 @@ struct __attribute__((aligned(16))) MsdwScatterLds {
 };
 
 // Scatter one tile of <= 8192 rows by digit = (key >> dshift) & (nb - 1); run bases from one returning atomic per
-// digit on gcursor[].  1024 threads, nb <= 1024 (one counter per thread in the scan).
-// CHECK: a run that does not fit its bucket's room (gend[]) is not written and sets flags[0] bit 4.
-template <bool RAW, bool CHECK>
+// digit on gcursor[]; output = 12-byte records.  1024 threads, nb <= 1024 (one counter per thread in the scan).
+// SRC: 0 raw column (row id = position), 1 transformed keys + row ids, 2 records.
+// CHECK: a run that does not fit its bucket's room is not written and sets `overflow_bit` in flags[0] — 1: room ends
+// at gend[digit]; 2: digit d owns [room_base + d * room, + room).
+template <int SRC, int CHECK>
 __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatterLds& lds, const uint64_t* __restrict__ kin,
-                                                  const uint32_t* __restrict__ iin, int64_t row0, int nrows, int nb,
-                                                  int dshift, uint32_t* __restrict__ gcursor,
-                                                  const uint32_t* __restrict__ gend,
-                                                  uint64_t* __restrict__ kout, uint32_t* __restrict__ iout) {
+                                                  const uint32_t* __restrict__ iin, const MsdRec* __restrict__ rin,
+                                                  int64_t row0, int nrows, int nb, int dshift,
+                                                  uint32_t* __restrict__ gcursor, const uint32_t* __restrict__ gend,
+                                                  uint32_t room_base, uint32_t room, uint32_t overflow_bit,
+                                                  MsdRec* __restrict__ rout) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -1884,12 +1943,16 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
   for (int i = 0; i < kMsdwRows; ++i) {   // unconditional (clamped) loads: all in flight together
     const int p = i * kMsdwThreads + tid;
     const int64_t r = row0 + (p < nrows ? p : nrows - 1);
-    if constexpr (RAW) {
+    if constexpr (SRC == 0) {
       key[i] = load_key_typed(kin, r, a.raw);
       idx[i] = static_cast<uint32_t>(r);
-    } else {
+    } else if constexpr (SRC == 1) {
       key[i] = kin[r];
       idx[i] = iin[r];
+    } else {
+      const MsdRec rr = rin[r];
+      key[i] = msd_rec_key(rr);
+      idx[i] = rr.idx;
     }
   }
   __syncthreads();
@@ -1910,10 +1973,11 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
     for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
     lds.start[tid] = pre;
     uint32_t base = c != 0 ? atomicAdd(&gcursor[tid], c) : 0u;
-    if constexpr (CHECK) {
-      if (c != 0 && (base + c > gend[tid] || base + c < base)) {
+    if constexpr (CHECK != 0) {
+      const uint32_t end = CHECK == 1 ? gend[tid] : room_base + (static_cast<uint32_t>(tid) + 1u) * room;
+      if (c != 0 && (base + c > end || base + c < base)) {
         base = 0xFFFFFFFFu;
-        atomicOr(&a.flags[0], 4u);
+        atomicOr(&a.flags[0], overflow_bit);
       }
     }
     lds.gbase[tid] = base;
@@ -1932,10 +1996,12 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
     const uint64_t k = lds.keys[p];
     const uint32_t d = static_cast<uint32_t>(k >> dshift) & dmask;
     const uint32_t gb = lds.gbase[d];
-    if (CHECK && gb == 0xFFFFFFFFu) continue;
-    const uint32_t dst = gb + (static_cast<uint32_t>(p) - lds.start[d]);
-    kout[dst] = k;
-    iout[dst] = lds.idx[p];
+    if (CHECK != 0 && gb == 0xFFFFFFFFu) continue;
+    MsdRec rr;
+    rr.lo = static_cast<uint32_t>(k);
+    rr.hi = static_cast<uint32_t>(k >> 32);
+    rr.idx = lds.idx[p];
+    rout[gb + (static_cast<uint32_t>(p) - lds.start[d])] = rr;
   }
 }
 
@@ -1947,8 +2013,8 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1_kernel(MsdwArgs a)
   if (a.sample_shift > 0 && (__atomic_load_n(&a.flags[0], __ATOMIC_RELAXED) & 4u) != 0) return;
   const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kMsdwTile;
   const int nrows = static_cast<int>(a.n - row0 < kMsdwTile ? a.n - row0 : kMsdwTile);
-  msdw_scatter_tile<RAW, true>(a, lds, a.src_keys, a.src_idx, row0, nrows, 1 << a.b1, 64 - a.b1, a.cursor1, a.l1_end,
-                               a.keys_x, a.idx_x);
+  msdw_scatter_tile<RAW ? 0 : 1, 1>(a, lds, a.src_keys, a.src_idx, nullptr, row0, nrows, 1 << a.b1, 64 - a.b1,
+                                    a.cursor1, a.l1_end, 0u, 0u, 4u, a.rec_x);
 }
 
 // index of the last entry of start[0..nb] (nb + 1 entries, non-decreasing, start[0] == 0) that is <= g, computed by
@@ -1964,7 +2030,7 @@ __device__ __forceinline__ uint32_t msdw_owner(const uint32_t* __restrict__ star
   return *slot;
 }
 
-// W4: counts of the next b2 bits inside level-1 buckets; work unit = <= kMsdwUnit rows of one bucket
+// Exact form, W4: counts of the next b2 bits inside level-1 buckets; work unit = <= kMsdwUnit rows of one bucket
 __global__ __launch_bounds__(kMsdThreads) void msdw_hist1_kernel(MsdwArgs a) {
   __shared__ uint32_t h[kMsdwMaxBins];
   __shared__ uint32_t part_s;
@@ -1985,11 +2051,11 @@ __global__ __launch_bounds__(kMsdThreads) void msdw_hist1_kernel(MsdwArgs a) {
   for (; r + (U - 1) * kMsdThreads < end; r += U * kMsdThreads) {
     uint64_t kk[U];
 #pragma unroll
-    for (int q = 0; q < U; ++q) kk[q] = a.keys_x[r + q * kMsdThreads];
+    for (int q = 0; q < U; ++q) kk[q] = msd_rec_key(a.rec_x[r + q * kMsdThreads]);
 #pragma unroll
     for (int q = 0; q < U; ++q) atomicAdd(&h[static_cast<uint32_t>(kk[q] >> shift) & mask], 1u);
   }
-  for (; r < end; r += kMsdThreads) atomicAdd(&h[static_cast<uint32_t>(a.keys_x[r] >> shift) & mask], 1u);
+  for (; r < end; r += kMsdThreads) atomicAdd(&h[static_cast<uint32_t>(msd_rec_key(a.rec_x[r]) >> shift) & mask], 1u);
   __syncthreads();
   uint32_t* dst = a.count2 + (static_cast<size_t>(p) << a.b2);
   for (int i = tid; i < nb2; i += kMsdThreads) {
@@ -1998,7 +2064,9 @@ __global__ __launch_bounds__(kMsdThreads) void msdw_hist1_kernel(MsdwArgs a) {
   }
 }
 
-// W5: one workgroup (1024 threads) per level-1 bucket: starts and cursors of its 2^b2 level-2 buckets
+// One workgroup (1024 threads) per level-1 bucket: final positions of its 2^b2 level-2 buckets.
+// Exact form (W5, before level 2): from the level-2 histogram; the cursors start there too (rec_y is compact).
+// gap2 (after level 2): from the rows that arrived in every room; count2[] becomes part_in (the room's first record).
 __global__ __launch_bounds__(1024) void msdw_scan1_kernel(MsdwArgs a) {
   __shared__ uint32_t wt[16];
   __shared__ uint32_t wmax[16];
@@ -2008,7 +2076,23 @@ __global__ __launch_bounds__(1024) void msdw_scan1_kernel(MsdwArgs a) {
   const uint32_t p = blockIdx.x;
   const int nb2 = 1 << a.b2;
   const size_t base = static_cast<size_t>(p) << a.b2;
-  const uint32_t c = tid < nb2 ? a.count2[base + tid] : 0u;
+  uint32_t c = 0;
+  if (tid < nb2) {
+    if (a.gap2) {
+      const uint32_t room = a.room2[p];
+      const uint32_t lo = a.y_base[p] + static_cast<uint32_t>(tid) * room;
+      const uint32_t cur = a.cursor2[base + tid];
+      if (cur > lo + room || cur < lo) {
+        atomicOr(&a.flags[0], 16u);
+        c = room;
+      } else {
+        c = cur - lo;
+      }
+      a.count2[base + tid] = lo;
+    } else {
+      c = a.count2[base + tid];
+    }
+  }
   const uint32_t incl = wave_inclusive_scan_u32(c);
   uint32_t mx = c;
 #pragma unroll
@@ -2020,20 +2104,38 @@ __global__ __launch_bounds__(1024) void msdw_scan1_kernel(MsdwArgs a) {
   if (lane == 0) wmax[wave] = mx;
   __syncthreads();
   uint32_t pre = a.l1_out[p] + incl - c;
-  for (int k = 0; k < wave; ++k) pre += wt[k];
+  uint32_t total = 0;
+  for (int k = 0; k < 16; ++k) {
+    if (k < wave) pre += wt[k];
+    total += wt[k];
+  }
   if (tid < nb2) {
     a.part_start[base + tid] = pre;
-    a.cursor2[base + tid] = pre;
+    if (!a.gap2) {
+      a.cursor2[base + tid] = pre;
+      a.count2[base + tid] = pre;   // part_in of the bucket finish: rec_y is compact, record = final position
+    }
   }
   if (tid == 0) {
     uint32_t m = 0;
     for (int k = 0; k < 16; ++k) m = m > wmax[k] ? m : wmax[k];
     atomicMax(&a.flags[1], m);
     if (p + 1 == gridDim.x) a.part_start[base + nb2] = a.l1_out[p + 1];
+    if (a.gap2 && total != a.l1_out[p + 1] - a.l1_out[p]) atomicOr(&a.flags[0], 16u);   // rows dropped by an overflowing tile
+  }
+}
+
+// gap2: cursors of the level-2 rooms
+__global__ __launch_bounds__(1024) void msdw_init2_kernel(MsdwArgs a) {
+  const uint32_t p = blockIdx.x;
+  const int nb2 = 1 << a.b2;
+  if (static_cast<int>(threadIdx.x) < nb2) {
+    a.cursor2[(static_cast<size_t>(p) << a.b2) + threadIdx.x] = a.y_base[p] + threadIdx.x * a.room2[p];
   }
 }
 
 // W6: level 2 inside the level-1 buckets (tile map: l2_tile_start)
+template <bool GAP>
 __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter2_kernel(MsdwArgs a) {
   __shared__ MsdwScatterLds lds;
   const int nb1 = 1 << a.b1;
@@ -2044,14 +2146,17 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter2_kernel(MsdwArgs a)
   const int64_t hi = a.l1_end[p];
   const int64_t row0 = lo + static_cast<int64_t>(g - a.l2_tile_start[p]) * kMsdwTile;
   const int nrows = static_cast<int>(hi - row0 < kMsdwTile ? hi - row0 : kMsdwTile);
-  msdw_scatter_tile<false, false>(a, lds, a.keys_x, a.idx_x, row0, nrows, 1 << a.b2, 64 - a.bits,
-                                  a.cursor2 + (static_cast<size_t>(p) << a.b2), nullptr, a.keys_y, a.idx_y);
+  msdw_scatter_tile<2, GAP ? 2 : 0>(a, lds, nullptr, nullptr, a.rec_x, row0, nrows, 1 << a.b2, 64 - a.bits,
+                                    a.cursor2 + (static_cast<size_t>(p) << a.b2), nullptr,
+                                    GAP ? a.y_base[p] : 0u, GAP ? a.room2[p] : 0u, 16u, a.rec_y);
 }
 
-
-static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n,
-                             uint64_t* keys_x, uint32_t* idx_x, uint64_t* keys_y, uint32_t* idx_y, uint8_t* tables,
-                             uint64_t* out_final, hipStream_t st, int* overflowed) {
+// overflowed: 0 sorted; 1 the keys are too skewed for this form (a bucket does not fit LDS) — try the next form;
+// 2 a level-2 room overflowed (gap2 only): call again with gap2 = 0 (the source may have been overwritten when it
+// shares memory with rec_y).
+static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n, MsdRec* rec_x,
+                             MsdRec* rec_y, int64_t capacity, uint8_t* tables, uint64_t* out_final, int gap2,
+                             hipStream_t st, int* overflowed) {
   *overflowed = 0;
   if (n == 0) return ARX_OK;
   int lg = 0;
@@ -2064,7 +2169,8 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   a.bits = std::max(2, std::min(lg - 12, kMsdwMaxBits));   // 2048 < average bucket <= 4096 rows
   a.b1 = a.bits / 2;
   a.b2 = a.bits - a.b1;
-  a.x_capacity = n + msdw_slack_rows(n);
+  const bool roomy = capacity < (int64_t(1) << 32);   // record positions are 32-bit
+  a.capacity = roomy ? capacity : n;
   uint32_t* t = reinterpret_cast<uint32_t*>(tables);
   const size_t big = (size_t(1) << kMsdwMaxBits) + 64;
   const size_t small = kMsdwMaxBins + 64;
@@ -2079,18 +2185,18 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   a.flags = a.unit_start + small;
   a.l1_end = a.flags + small;
   a.l1_out = a.l1_end + small;
-  a.keys_x = keys_x;
-  a.idx_x = idx_x;
-  a.keys_y = keys_y;
-  a.idx_y = idx_y;
+  a.room2 = a.l1_out + small;
+  a.y_base = a.room2 + small;
+  a.rec_x = rec_x;
+  a.rec_y = rec_y;
+  a.gap2 = (gap2 != 0 && roomy) ? 1 : 0;
   const int nb1 = 1 << a.b1;
   const size_t nparts = size_t(1) << a.bits;
   const unsigned grid1 = static_cast<unsigned>(ceil_div(n, kMsdwTile));
   // Level-1 bucket sizes: estimated from 1 tile in 2^shift (the buckets then get room to spare and level 2 reads
   // what actually arrived), or — shift 0, and whenever an estimate turned out too small — counted exactly.
-  int sample_shift = a.x_capacity < (int64_t(1) << 32) ? g_sort_msd_wide_sample_shift : 0;
+  int sample_shift = roomy ? g_sort_msd_wide_sample_shift : 0;
   while (sample_shift > 0 && (static_cast<int64_t>(grid1) >> sample_shift) < 8) --sample_shift;   // too few tiles to sample
-  unsigned int max_part = 0;
   for (;;) {
     a.sample_shift = sample_shift;
     unsigned nch;
@@ -2103,7 +2209,6 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
       nch = static_cast<unsigned>(ceil_div(n, a.chunk_rows));
     }
     ARX_HIP(hipMemsetAsync(a.l1_count, 0, static_cast<size_t>(nb1) * 4, st));
-    ARX_HIP(hipMemsetAsync(a.count2, 0, nparts * 4, st));
     ARX_HIP(hipMemsetAsync(a.flags, 0, 16, st));
     if (raw) {
       hipLaunchKernelGGL((msdw_hist0_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
@@ -2121,15 +2226,11 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
     ARX_CHECK_LAUNCH("msdw_scatter1_kernel");
     hipLaunchKernelGGL(msdw_scan0b_kernel, dim3(1), dim3(1024), 0, st, a);
     ARX_CHECK_LAUNCH("msdw_scan0b_kernel");
-    const unsigned units = static_cast<unsigned>(ceil_div(n, kMsdwUnit) + nb1);
-    hipLaunchKernelGGL(msdw_hist1_kernel, dim3(units), dim3(kMsdThreads), 0, st, a);
-    ARX_CHECK_LAUNCH("msdw_hist1_kernel");
-    hipLaunchKernelGGL(msdw_scan1_kernel, dim3(static_cast<unsigned>(nb1)), dim3(1024), 0, st, a);
-    ARX_CHECK_LAUNCH("msdw_scan1_kernel");
-    unsigned int fl[2] = {0, 0};
-    ARX_HIP(hipMemcpyAsync(fl, a.flags, 8, hipMemcpyDeviceToHost, st));
+    if (sample_shift == 0 && a.gap2 == 0) break;   // exact counts all the way: nothing to look at yet
+    unsigned int fl = 0;
+    ARX_HIP(hipMemcpyAsync(&fl, a.flags, 4, hipMemcpyDeviceToHost, st));
     ARX_HIP(hipStreamSynchronize(st));
-    if ((fl[0] & 4u) != 0) {   // a level-1 bucket outgrew its room; the source is untouched (level 2 has not run)
+    if ((fl & 4u) != 0) {   // a level-1 bucket outgrew its room; the source is untouched (level 2 has not run)
       if (sample_shift == 0) {
         set_error("array_sort_indices: internal error (exact level-1 histogram disagrees with the scatter)");
         return ARX_INVALID;
@@ -2141,37 +2242,75 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
       sample_shift = 0;
       continue;
     }
-    max_part = fl[1];
+    if ((fl & 8u) != 0) {   // fixed level-2 rooms are not possible (a room beyond LDS, or no space): count exactly
+      a.gap2 = 0;
+      ARX_HIP(hipMemsetAsync(a.flags, 0, 4, st));
+    }
     break;
   }
-  if (max_part > static_cast<unsigned int>(kBktCap)) {   // skewed keys: a bucket would not fit LDS
-    *overflowed = 1;
-    return ARX_OK;
-  }
   const unsigned grid2 = grid1 + static_cast<unsigned>(nb1);
-  hipLaunchKernelGGL(msdw_scatter2_kernel, dim3(grid2), dim3(kMsdwThreads), 0, st, a);
-  ARX_CHECK_LAUNCH("msdw_scatter2_kernel");
+  unsigned int max_part = 0;
+  if (a.gap2) {
+    hipLaunchKernelGGL(msdw_init2_kernel, dim3(static_cast<unsigned>(nb1)), dim3(1024), 0, st, a);
+    ARX_CHECK_LAUNCH("msdw_init2_kernel");
+    hipLaunchKernelGGL((msdw_scatter2_kernel<true>), dim3(grid2), dim3(kMsdwThreads), 0, st, a);
+    ARX_CHECK_LAUNCH("msdw_scatter2_kernel");
+    hipLaunchKernelGGL(msdw_scan1_kernel, dim3(static_cast<unsigned>(nb1)), dim3(1024), 0, st, a);
+    ARX_CHECK_LAUNCH("msdw_scan1_kernel");
+    max_part = kBktCapSmall;   // rooms never exceed it
+  } else {
+    ARX_HIP(hipMemsetAsync(a.count2, 0, nparts * 4, st));
+    const unsigned units = static_cast<unsigned>(ceil_div(n, kMsdwUnit) + nb1);
+    hipLaunchKernelGGL(msdw_hist1_kernel, dim3(units), dim3(kMsdThreads), 0, st, a);
+    ARX_CHECK_LAUNCH("msdw_hist1_kernel");
+    hipLaunchKernelGGL(msdw_scan1_kernel, dim3(static_cast<unsigned>(nb1)), dim3(1024), 0, st, a);
+    ARX_CHECK_LAUNCH("msdw_scan1_kernel");
+    unsigned int fl[2] = {0, 0};
+    ARX_HIP(hipMemcpyAsync(fl, a.flags, 8, hipMemcpyDeviceToHost, st));
+    ARX_HIP(hipStreamSynchronize(st));
+    if ((fl[0] & 4u) != 0) {
+      set_error("array_sort_indices: internal error (exact level-1 histogram disagrees with the scatter)");
+      return ARX_INVALID;
+    }
+    max_part = fl[1];
+    if (max_part > static_cast<unsigned int>(kBktCap)) {   // skewed keys: a bucket would not fit LDS
+      *overflowed = 1;
+      return ARX_OK;
+    }
+    hipLaunchKernelGGL((msdw_scatter2_kernel<false>), dim3(grid2), dim3(kMsdwThreads), 0, st, a);
+    ARX_CHECK_LAUNCH("msdw_scatter2_kernel");
+  }
   MsdArgs f{};
   f.n = n;
   f.bits = a.bits;
   f.kshift = 0;
   f.part_start = a.part_start;
+  f.part_in = a.count2;
   f.overflow = a.flags;
   f.out_final = out_final;
   const bool small_bkt = max_part <= static_cast<unsigned int>(kBktCapSmall);
   f.b3 = std::max(0, std::min(std::min(lg - (g_sort_msd_final_rows_log2 - 1) - a.bits, small_bkt ? 11 : 12), 64 - a.bits));
+  const uint64_t* recs = reinterpret_cast<const uint64_t*>(rec_y);
   if (small_bkt) {
-    hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsSmall>), dim3(static_cast<unsigned>(nparts)),
-                       dim3(kBktThreadsSmall), 0, st, f, keys_y, idx_y);
+    hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsSmall, true>), dim3(static_cast<unsigned>(nparts)),
+                       dim3(kBktThreadsSmall), 0, st, f, recs, nullptr);
   } else {
-    hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreads>), dim3(static_cast<unsigned>(nparts)),
-                       dim3(kBktThreads), 0, st, f, keys_y, idx_y);
+    hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreads, true>), dim3(static_cast<unsigned>(nparts)),
+                       dim3(kBktThreads), 0, st, f, recs, nullptr);
   }
   ARX_CHECK_LAUNCH("msd_bucket2_kernel");
   unsigned int flag = 0;
   ARX_HIP(hipMemcpyAsync(&flag, a.flags, 4, hipMemcpyDeviceToHost, st));
   ARX_HIP(hipStreamSynchronize(st));
-  *overflowed = flag != 0;
+  if ((flag & 16u) != 0) {
+    if (g_sort_msd_wide_sample_strict) {
+      set_error("array_sort_indices: a level-2 room underestimated its bucket (sort_msd_wide_sample_strict)");
+      return ARX_INVALID;
+    }
+    *overflowed = 2;
+  } else {
+    *overflowed = flag != 0;
+  }
   return ARX_OK;
 }
 
@@ -2303,6 +2442,10 @@ int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_pl
   uint64_t* keys_b = reinterpret_cast<uint64_t*>(w + plan.off_keys_b);
   uint32_t* idx_a = reinterpret_cast<uint32_t*>(w + plan.off_idx_a);
   uint32_t* idx_b = reinterpret_cast<uint32_t*>(w + plan.off_idx_b);
+  // the same memory as arrays of 12-byte records (wide form): (keys, idx) pairs are adjacent in the plan
+  MsdRec* rec_a = reinterpret_cast<MsdRec*>(w + plan.off_keys_a);
+  MsdRec* rec_b = reinterpret_cast<MsdRec*>(w + plan.off_keys_b);
+  const int64_t rec_cap = std::max<int64_t>(len, 1) + msdw_slack_rows(std::max<int64_t>(len, 1));
   uint32_t* hist = reinterpret_cast<uint32_t*>(w + plan.off_hist);
   uint32_t* totals = reinterpret_cast<uint32_t*>(w + plan.off_totals);
   uint32_t* rows = reinterpret_cast<uint32_t*>(w + plan.off_rows);
@@ -2377,7 +2520,12 @@ int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_pl
       const uint64_t* src = reinterpret_cast<const uint64_t*>(vals);
       overflowed = 1;
       rc = ARX_OK;
-      if (wide) rc = run_msd_sort_wide(src, nullptr, xf, n_valid, keys_a, idx_a, keys_b, idx_b, tables, final_dst, st, &overflowed);
+      if (wide) {
+        rc = run_msd_sort_wide(src, nullptr, xf, n_valid, rec_a, rec_b, rec_cap, tables, final_dst, g_sort_msd_wide_gap2, st, &overflowed);
+        if (rc == ARX_OK && overflowed == 2) {
+          rc = run_msd_sort_wide(src, nullptr, xf, n_valid, rec_a, rec_b, rec_cap, tables, final_dst, 0, st, &overflowed);
+        }
+      }
       if (rc == ARX_OK && overflowed) {
         rc = segmented ? run_msd_sort_segmented(src, nullptr, xf, n_valid, keys_a, idx_a, keys_b, idx_b, tables,
                                                 final_dst, st, &overflowed)
@@ -2392,7 +2540,15 @@ int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_pl
       rc = ARX_OK;
       // the wide form reads its source twice (level 1, then the histogram reads level-1 output): x = b, y = a is
       // safe because level 2 only starts after level 1 has consumed the source
-      if (wide) rc = run_msd_sort_wide(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables, final_dst, st, &overflowed);
+      if (wide) {
+        rc = run_msd_sort_wide(keys_a, idx_a, 0, n_valid, rec_b, rec_a, rec_cap, tables, final_dst, g_sort_msd_wide_gap2, st, &overflowed);
+        if (rc == ARX_OK && overflowed == 2) {   // the level-2 records went over the prepped source: rebuild it
+          hipLaunchKernelGGL(sort_prep_kernel, dim3(gprep), dim3(kBlock), 0, st, vals, valid_rows, n_valid, xf, 0,
+                             keys_a, idx_a);
+          ARX_CHECK_LAUNCH("sort_prep_kernel");
+          rc = run_msd_sort_wide(keys_a, idx_a, 0, n_valid, rec_b, rec_a, rec_cap, tables, final_dst, 0, st, &overflowed);
+        }
+      }
       if (rc == ARX_OK && overflowed) {
         if (wide) {   // a failed wide attempt may have overwritten the prepped source: rebuild it
           hipLaunchKernelGGL(sort_prep_kernel, dim3(gprep), dim3(kBlock), 0, st, vals, valid_rows, n_valid, xf, 0,

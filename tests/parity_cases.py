@@ -603,13 +603,15 @@ def check_sort_indices(amd, arr: HostArray, order="ascending", null_placement="a
     return out
 
 
-def check_sort_wide_sampled(amd, lib, rng, n, shift):
+def check_sort_wide_sampled(amd, lib, rng, n, shift, gap2=1):
     """The wide two-level sort with level-1 bucket sizes ESTIMATED from one tile in 2^shift (buckets get room to spare,
-    level 2 reads what arrived).  Uniform keys: the estimate must hold (strict mode turns a silent exact re-run into
-    an error).  Sorted / blocky inputs where the sampled tiles say little about the rest: the overflow is detected and
-    the level repeated with the exact histogram — same result; in strict mode the call must fail instead."""
+    level 2 reads what arrived) and, gap2, level-2 buckets in fixed rooms (mean + 6 sigma) instead of a histogram
+    pass.  Uniform keys: the estimates must hold (strict mode turns a silent exact re-run into an error).  Sorted /
+    blocky inputs where the sampled tiles say little about the rest, or whose keys are not uniform inside a level-1
+    bucket: the overflow is detected and the level repeated with exact counts — same result; in strict mode the call
+    must fail instead."""
     opts = {b"sort_msd": 1, b"sort_msd_segment_rows": 4096, b"sort_msd_wide": 1,
-            b"sort_msd_wide_sample_shift": shift}
+            b"sort_msd_wide_sample_shift": shift, b"sort_msd_wide_gap2": gap2}
     for k, v in opts.items():
         assert lib.arx_set_option(k, v) == 0
     try:
@@ -640,6 +642,7 @@ def check_sort_wide_sampled(amd, lib, rng, n, shift):
     finally:
         lib.arx_set_option(b"sort_msd_wide_sample_strict", 0)
         lib.arx_set_option(b"sort_msd_wide_sample_shift", 4)
+        lib.arx_set_option(b"sort_msd_wide_gap2", 1)
         lib.arx_set_option(b"sort_msd", -1)
         lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
 

@@ -422,11 +422,14 @@ def test_sort_msd_hybrid_path(emu_ctx, global_bits, fused):
         lib.arx_set_option(b"sort_msd_fused", 1)
 
 
-@pytest.mark.parametrize("shift", [2, 0])
-def test_sort_wide_sampled_level1(emu_ctx, shift):
+@pytest.mark.parametrize("shift,gap2", [(2, 1), (2, 0), (0, 1), (0, 0)])
+def test_sort_wide_sampled_level1(emu_ctx, shift, gap2):
     lib = emu_ctx._lib.get_lib()
-    failed = P.check_sort_wide_sampled(emu_ctx, lib, rng_for("wide-sampled", shift), 300_000, shift)
-    assert failed == (2 if shift else 0)   # the exact histogram never overflows; this sample misses both crafted inputs
+    failed = P.check_sort_wide_sampled(emu_ctx, lib, rng_for("wide-sampled", shift, gap2), 300_000, shift, gap2)
+    if shift == 0 and gap2 == 0:
+        assert failed == 0   # exact counts never overflow
+    if shift:
+        assert failed == 2   # this sample misses both crafted inputs
 
 
 def test_null_count_bookkeeping(emu_ctx):

@@ -550,11 +550,12 @@ def test_sort_msd_hybrid_path(gpu_ctx, global_bits, fused):
         lib.arx_set_option(b"sort_msd_fused", 1)
 
 
-@pytest.mark.parametrize("shift", [4, 2, 0])
-def test_sort_wide_sampled_level1(gpu_ctx, shift):
+@pytest.mark.parametrize("shift,gap2", [(4, 1), (2, 1), (4, 0), (0, 1), (0, 0)])
+def test_sort_wide_sampled_level1(gpu_ctx, shift, gap2):
     lib = gpu_ctx._lib.get_lib()
-    failed = P.check_sort_wide_sampled(gpu_ctx, lib, rng_for("wide-sampled", shift), 6_000_011, shift)
-    assert shift > 0 or failed == 0   # the exact histogram never overflows
+    failed = P.check_sort_wide_sampled(gpu_ctx, lib, rng_for("wide-sampled", shift, gap2), 6_000_011, shift, gap2)
+    if shift == 0 and gap2 == 0:
+        assert failed == 0   # exact counts never overflow
 
 
 def test_null_count_bookkeeping(gpu_ctx):
