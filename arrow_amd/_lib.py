@@ -161,6 +161,14 @@ SIGNATURES = {
     "arx_groupby_export_partitioned": (_int, [_p, _int, _p, _sz, _p, _p, _p]),
     "arx_hash_sum_consume_workspace_bytes": (_sz, [_i64, _i64]),
     "arx_hash_sum_i64_consume_ws": (_int, [_span, _int, _i64, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
+    "arx_hash_mean_i64_finalize": (_int, [_p, _p, _i64, C.c_uint64, _p, _p, _p]),
+    "arx_grouper_state_bytes": (_sz, [_i64]),
+    "arx_grouper_init": (_int, [_p, _i64, _p]),
+    "arx_grouper_consume_workspace_bytes": (_sz, [_i64]),
+    "arx_grouper_consume": (_int, [_p, _i64, _p, _p, _int, _p, _sz, _p, _p]),
+    "arx_grouper_lookup": (_int, [_p, _i64, _p, _p, _int, _p, _sz, _p, _p, _p]),
+    "arx_grouper_num_groups": (_int, [_p, _p, _p]),
+    "arx_grouper_get_uniques": (_int, [_p, _i64, _p, _int, _int, _p, _p, _p, _p]),
     "arx_ree_bool_expand": (_int, [_p, _int, _i64, _span, _i64, _i64, _p, _p, _p]),
     "arx_snappy_decompress_pages": (_int, [_p, _p, _i64, _p, _p, _p]),
     "arx_cast_numeric": (_int, [_span, _int, _int, _int, _int, _p, _sz, _p, _p]),

@@ -1629,6 +1629,168 @@ def value_counts(arr: Array, capacity: int | None = None):
     return _first_occurrence_groups(arr, capacity, True)
 
 
+class Grouper:
+    """arrow::compute::Grouper (compute/row/grouper.h:104-137) over key columns that live in HBM: `consume(batch)`
+    -> uint32 group ids (:121), `lookup` (:126; unseen keys -> null), `populate` (:130), `get_uniques` (:134),
+    `num_groups` (:137), `reset` (:115).  Key rows = one or several fixed-width columns (byte widths 1, 2, 4, 8; at
+    most 8 columns and 16 bytes per row), compared by their bits with null as a key value of its own, as the
+    reference's row encoder does (GrouperFastImpl, row/grouper.cc:555-973).  The k-th distinct key row in row
+    order gets id k.  `max_groups` bounds the distinct rows over the Grouper's life."""
+
+    def __init__(self, key_types, max_groups: int, device=None):
+        from .array import default_device
+
+        self.key_types = list(key_types)
+        if not 1 <= len(self.key_types) <= 8:
+            raise ArrowNotImplementedError(f"Grouper: 1 to 8 key columns (got {len(self.key_types)})")
+        for t in self.key_types:
+            if t.bit_width not in (8, 16, 32, 64):
+                raise ArrowNotImplementedError(f"Grouper: keys of type {t.name}")
+        if builtins.sum(t.byte_width for t in self.key_types) > 16:
+            raise ArrowNotImplementedError("Grouper: the key columns take more than 16 bytes per row")
+        self.device = torch.device(device) if device is not None else default_device()
+        self.max_groups = max(1, int(max_groups))
+        self._widths = (C.c_int32 * len(self.key_types))(*[t.byte_width for t in self.key_types])
+        lib, stream = _lib_and_stream(self.device)
+        self.state = alloc(lib.arx_grouper_state_bytes(self.max_groups) + 256, self.device)
+        self._state_ptr = (self.state.data_ptr() + 255) & ~255
+        check(lib.arx_grouper_init(self._state_ptr, self.max_groups, stream))
+
+    @classmethod
+    def make(cls, key_types, max_groups: int, device=None) -> "Grouper":
+        """Grouper::Make (:110)."""
+        return cls(key_types, max_groups, device)
+
+    def reset(self) -> None:
+        lib, stream = _lib_and_stream(self.device)
+        check(lib.arx_grouper_init(self._state_ptr, self.max_groups, stream))
+
+    def _spans(self, batch):
+        cols = list(batch.values) if isinstance(batch, ExecBatch) else list(batch)
+        if len(cols) != len(self.key_types):
+            raise ArrowInvalid(f"Grouper: expected {len(self.key_types)} key columns, got {len(cols)}")
+        n = cols[0].length
+        for c, t in zip(cols, self.key_types):
+            if c.type != t:
+                raise ArrowInvalid(f"Grouper: key column of type {c.type.name}, expected {t.name}")
+            if c.length != n:
+                raise ArrowInvalid("Array arguments must all be the same length")
+        spans = (_lib.ArxSpan * len(cols))(*[c.span() for c in cols])
+        return cols, spans, n
+
+    def _run(self, batch, lookup: bool):
+        lib, stream = _lib_and_stream(self.device)
+        cols, spans, n = self._spans(batch)
+        ids = alloc(max(n, 1) * 4, self.device)
+        ws_bytes = lib.arx_grouper_consume_workspace_bytes(n)
+        ws = _workspace(self.device, ws_bytes + 256, "grouper")
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        ws_len = ws.numel() - (ws_ptr - ws.data_ptr())
+        if lookup:
+            valid = alloc(bitmap_nbytes(n), self.device, zero=True)
+            check(lib.arx_grouper_lookup(self._state_ptr, self.max_groups, spans, self._widths, len(cols), ws_ptr,
+                                         ws_len, ids.data_ptr(), valid.data_ptr(), stream))
+            return Array(uint32, n, [valid, ids], kUnknownNullCount, 0)
+        check(lib.arx_grouper_consume(self._state_ptr, self.max_groups, spans, self._widths, len(cols), ws_ptr, ws_len,
+                                      ids.data_ptr(), stream))
+        return Array(uint32, n, [None, ids], 0, 0)
+
+    def consume(self, batch) -> Array:
+        return self._run(batch, lookup=False)
+
+    def lookup(self, batch) -> Array:
+        return self._run(batch, lookup=True)
+
+    def populate(self, batch) -> None:
+        self._run(batch, lookup=False)
+
+    @property
+    def num_groups(self) -> int:
+        lib, stream = _lib_and_stream(self.device)
+        n = C.c_int64(0)
+        check(lib.arx_grouper_num_groups(self._state_ptr, C.byref(n), stream))
+        return n.value
+
+    def get_uniques(self):
+        """The unique key rows as one Array per key column, in group-id order."""
+        lib, stream = _lib_and_stream(self.device)
+        g = self.num_groups
+        out = []
+        for j, t in enumerate(self.key_types):
+            data = alloc(max(g, 1) * t.byte_width, self.device)
+            valid = alloc(bitmap_nbytes(g), self.device, zero=True)
+            nulls = C.c_int64(0)
+            check(lib.arx_grouper_get_uniques(self._state_ptr, self.max_groups, self._widths, len(self.key_types), j,
+                                              data.data_ptr(), valid.data_ptr(), C.byref(nulls), stream))
+            out.append(Array(t, g, [valid if nulls.value else None, data], nulls.value, 0))
+        return ExecBatch(out, g)
+
+
+_GROUP_BY_AGGREGATES = ("hash_sum", "hash_count", "hash_mean")
+
+
+def group_by(keys, aggregates, max_groups: int | None = None, options: ScalarAggregateOptions | None = None):
+    """What GroupByNode does with one batch (acero/groupby_aggregate_node.cc:210-337): Grouper::Consume over the key
+    columns, then every aggregate's {resize, consume} on (values, group ids), then finalize + GetUniques.
+    keys: list of Arrays (any fixed-width types up to 16 bytes per row — int64 keys, several key columns);
+    aggregates: list of (values Array, "hash_sum" | "hash_count" | "hash_mean") over int64 values.
+    Returns (unique key columns, [one result Array per aggregate]), rows in group-id order (first appearance)."""
+    keys = list(keys)
+    n = keys[0].length
+    g = Grouper([k.type for k in keys], max_groups or max(16, n), keys[0].device)
+    ids = g.consume(keys)
+    num_groups = g.num_groups
+    results = []
+    states = {}
+    for values, fn in aggregates:
+        if fn not in _GROUP_BY_AGGREGATES:
+            raise ArrowNotImplementedError(f"group_by: aggregate {fn}")
+        if id(values) not in states:   # sum / count / mean of one column share its state
+            st = _hash_sum_init(options, keys[0].device)
+            _hash_sum_resize(st, num_groups)
+            _hash_sum_consume(st, [GroupBySum._normalise_value(GroupBySum.__new__(GroupBySum), values), ids])
+            states[id(values)] = st
+        st = states[id(values)]
+        if fn == "hash_sum":
+            out = _hash_sum_finalize(st)
+            if values.type.name.startswith("uint"):
+                out = Array(uint64, out.length, out.buffers, out.null_count, out.offset)
+        elif fn == "hash_count":
+            out = Array(int64, num_groups, [None, st.counts[:num_groups].contiguous().view(torch.uint8)], 0, 0)
+        else:
+            out = _hash_mean_from_dense(st, values)
+        results.append(out)
+    return g.get_uniques(), results
+
+
+def _hash_mean_from_dense(st: "GroupedSumInt64State", values: Array) -> Array:
+    """hash_mean(int64) from the dense sums / counts: GroupedMeanImpl::Finalize (hash_aggregate_numeric.cc:352-430)
+    divides a sum that was accumulated as DOUBLES in row order; that equals double(exact sum) / count exactly when
+    every partial sum is an integer below 2^53 — guaranteed here when count * max|value| < 2^53 for every group,
+    which is checked with the column's extrema (a bound, not per group); otherwise declined."""
+    if values.type != int64:
+        raise ArrowNotImplementedError(f"group_by: hash_mean of {values.type.name}")
+    g = st.num_groups
+    mm = min_max(values)
+    lo, hi = mm if mm else (0, 0)
+    bound = builtins.max(abs(int(lo)), abs(int(hi)))
+    lib, stream = _lib_and_stream(st.device)
+    bits = alloc(bitmap_nbytes(g), st.device, zero=True)
+    counter = torch.zeros(8, dtype=torch.uint8, device=st.device)
+    check(lib.arx_hash_sum_i64_finalize(st.counts.data_ptr(), st.null_seen.data_ptr(), g, int(st.options.skip_nulls),
+                                        st.options.min_count, bits.data_ptr(), counter.data_ptr(), stream))
+    means = alloc(max(g, 1) * 8, st.device)
+    inexact = torch.zeros(1, dtype=torch.int32, device=st.device)
+    check(lib.arx_hash_mean_i64_finalize(st.sums.data_ptr(), st.counts.data_ptr(), g, bound, means.data_ptr(),
+                                         inexact.data_ptr(), stream))
+    if int(inexact.item()) != 0:
+        raise ArrowNotImplementedError(
+            "hash_mean(int64): a group's partial sums may exceed 2^53, where the reference's row-order double "
+            "accumulation is not associative (its result depends on row order); not reproducible bit for bit")
+    nulls = g - int(counter.cpu().view(torch.int64)[0])
+    return Array(float64, g, [bits if nulls else None, means], nulls, 0)
+
+
 def group_by_sum(keys: Array, values: Array, capacity: int | None = None,
                  options: ScalarAggregateOptions | None = None):
     """Table.group_by(k).aggregate([(v, 'sum')]) for one int32 key and one int64 value."""

@@ -585,6 +585,26 @@ __global__ __launch_bounds__(kBlock) void hash_sum_dense_finalize_kernel(
   if (valid_count != nullptr && lane == 0 && nvalid != 0) atomicAdd(valid_count, nvalid);
 }
 
+// hash_mean / hash_count over the dense per-group state of the hash_sum vtable: means[g] = double(sums[g]) / counts[g]
+// (one correctly rounded division), which is what GroupedMeanImpl's row-order double accumulation gives whenever every
+// partial sum is an integer below 2^53 — true when counts[g] * abs_bound < 2^53 (abs_bound >= |value| of every row);
+// a group where that does not hold sets *inexact.
+__global__ __launch_bounds__(kBlock) void hash_mean_dense_finalize_kernel(
+    const int64_t* __restrict__ sums, const int64_t* __restrict__ counts, int64_t n, uint64_t abs_bound,
+    double* __restrict__ means, unsigned int* __restrict__ inexact) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t c = counts[i];
+    double m = 0.0;
+    if (c > 0) {
+      // c * abs_bound < 2^53  <=>  abs_bound <= (2^53 - 1) / c
+      if (abs_bound > ((uint64_t(1) << 53) - 1) / static_cast<uint64_t>(c)) atomicOr(inexact, 1u);
+      m = static_cast<double>(sums[i]) / static_cast<double>(c);
+    }
+    means[i] = m;
+  }
+}
+
 static inline unsigned gb_grid(int64_t n) {
   return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock), 256 * 16)));
 }
@@ -1759,6 +1779,23 @@ int arx_hash_sum_i64_finalize(const int64_t* counts, const uint32_t* null_seen, 
                      static_cast<uint64_t*>(out_validity),
                      reinterpret_cast<unsigned long long*>(valid_count));
   ARX_CHECK_LAUNCH("hash_sum_dense_finalize_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_mean_i64_finalize(const int64_t* sums, const int64_t* counts, int64_t num_groups, uint64_t abs_bound,
+                               double* out_means, uint32_t* inexact, void* stream) {
+  if (num_groups < 0) {
+    set_error("negative num_groups");
+    return ARX_INVALID;
+  }
+  if (num_groups == 0) return ARX_OK;
+  if (sums == nullptr || counts == nullptr || out_means == nullptr || inexact == nullptr) {
+    set_error("NULL buffer passed to arx_hash_mean_i64_finalize");
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(hash_mean_dense_finalize_kernel, dim3(gb_grid(num_groups)), dim3(kBlock), 0, as_stream(stream), sums,
+                     counts, num_groups, abs_bound, out_means, inexact);
+  ARX_CHECK_LAUNCH("hash_mean_dense_finalize_kernel");
   return ARX_OK;
 }
 

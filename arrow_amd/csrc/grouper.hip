@@ -1,0 +1,554 @@
+// Grouper for key rows of up to 16 bytes (one or several fixed-width key columns): what arrow::compute::Grouper does
+// (cpp/src/arrow/compute/row/grouper.h:104-137; GrouperFastImpl::ConsumeImpl, row/grouper.cc:695-815 — encode the key
+// columns of a batch as rows, map every row through a hash table, hand out dense group ids in order of first
+// appearance, keep the unique rows for GetUniques :835-880), for batches that live in HBM.
+//
+// The table is open addressing over 32-byte slots {meta, key word 0, key word 1}.  A row claims an empty slot with one
+// 64-bit CAS on `meta`, writes its key, then publishes {state, null mask, group id} with a second store; rows that run
+// into a claimed-but-unpublished slot are not allowed to wait for it (lanes of one wave cannot wait for each other) —
+// they go to a pending list that the next launch drains, by which time every publication of the previous launch is
+// visible.  Rows of groups that already exist only read.
+//
+// Group ids are the reference's: the k-th distinct key row in ROW ORDER gets id k.  Concurrent insertion hands out
+// provisional ids in arrival order; every new group records its smallest row (atomicMin), the set of those rows is a
+// bitmap whose ascending positions (the filter machinery's bit -> row-number compaction) are the ranks, and the new
+// groups and the batch's ids are renumbered once.  Batches that add no group skip all of that.
+#include "arx_common.h"
+
+#include <algorithm>
+
+namespace arx {
+
+size_t selection_workspace_bytes(int64_t length);
+int selection_bit_positions(const void* bitmap, int64_t bit_offset, int64_t length, bool invert, void* ws,
+                            size_t ws_bytes, uint32_t* out, int64_t* out_count_host, hipStream_t st);
+
+constexpr int kGrouperMaxKeys = 8;
+constexpr unsigned long long kSlotEmpty = 0, kSlotClaimed = 1, kSlotPublished = 3;
+
+struct GrouperHeader {
+  int64_t max_groups;
+  int64_t slots;
+  unsigned long long num_groups;
+  unsigned int overflow;    // more than max_groups distinct key rows
+  unsigned int pending;     // rows deferred by the current launch
+  int64_t pad[4];
+};
+static_assert(sizeof(GrouperHeader) == 64, "one line");
+
+struct __attribute__((aligned(32))) GrouperSlot {
+  unsigned long long meta;  // bits 0-1 state, 8-15 null mask, 32-63 group id
+  unsigned long long k0, k1;
+  unsigned long long unused;
+};
+
+struct GrouperView {
+  GrouperHeader* hdr;
+  GrouperSlot* slots;
+  unsigned long long* uniq_k0;   // [max_groups]
+  unsigned long long* uniq_k1;   // [max_groups]
+  unsigned int* uniq_mask;       // [max_groups]
+  unsigned int* slot_of;         // [max_groups] slot of every group
+  int64_t nslots;
+  int lg;
+};
+
+static inline int64_t grouper_slots_for(int64_t max_groups) {
+  int64_t s = 1024;
+  while (s < 2 * max_groups) s <<= 1;
+  return s;
+}
+
+static inline GrouperView grouper_view(void* state, int64_t max_groups) {
+  GrouperView v;
+  uint8_t* p = static_cast<uint8_t*>(state);
+  v.hdr = reinterpret_cast<GrouperHeader*>(p);
+  v.nslots = grouper_slots_for(max_groups);
+  v.slots = reinterpret_cast<GrouperSlot*>(p + 64);
+  v.uniq_k0 = reinterpret_cast<unsigned long long*>(p + 64 + v.nslots * sizeof(GrouperSlot));
+  v.uniq_k1 = v.uniq_k0 + max_groups;
+  v.uniq_mask = reinterpret_cast<unsigned int*>(v.uniq_k1 + max_groups);
+  v.slot_of = v.uniq_mask + max_groups;
+  int lg = 0;
+  while ((int64_t(1) << lg) < v.nslots) ++lg;
+  v.lg = lg;
+  return v;
+}
+
+struct GrouperCols {
+  const uint8_t* data[kGrouperMaxKeys];
+  Bits valid[kGrouperMaxKeys];
+  int64_t offset[kGrouperMaxKeys];
+  int width[kGrouperMaxKeys];      // 1, 2, 4, 8
+  int byte_pos[kGrouperMaxKeys];   // position of the column inside the 16-byte key row
+  int num_keys;
+};
+
+struct GrouperKey {
+  unsigned long long k0, k1;
+  unsigned int mask;
+};
+
+// the key row of `row`: columns little-endian back to back, a null column contributes zeros and its bit in mask
+__device__ __forceinline__ GrouperKey grouper_load_key(const GrouperCols& c, int64_t row) {
+  GrouperKey k{0, 0, 0};
+  for (int j = 0; j < c.num_keys; ++j) {
+    bool valid = true;
+    if (c.valid[j].base != nullptr) {
+      const uint64_t w = load_word(c.valid[j], row >> 6);
+      valid = ((w >> (row & 63)) & 1) != 0;
+    }
+    if (!valid) {
+      k.mask |= 1u << j;
+      continue;
+    }
+    const uint8_t* p = c.data[j] + (c.offset[j] + row) * c.width[j];
+    unsigned long long v;
+    switch (c.width[j]) {
+      case 1: v = *p; break;
+      case 2: v = *reinterpret_cast<const uint16_t*>(p); break;
+      case 4: v = *reinterpret_cast<const uint32_t*>(p); break;
+      default: v = *reinterpret_cast<const unsigned long long*>(p); break;
+    }
+    const int pos = c.byte_pos[j];
+    if (pos < 8) {
+      k.k0 |= v << (8 * pos);
+      if (pos + c.width[j] > 8) k.k1 |= v >> (8 * (8 - pos));   // a column that straddles the two key words (pos > 0 here)
+    } else {
+      k.k1 |= v << (8 * (pos - 8));
+    }
+  }
+  return k;
+}
+
+__device__ __forceinline__ unsigned long long grouper_hash(const GrouperKey& k) {
+  unsigned long long z = k.k0 * 0x9E3779B97F4A7C15ull + (k.k1 ^ (static_cast<unsigned long long>(k.mask) << 56));
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z ^= k.k1 * 0xD6E8FEB86659FD93ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct GrouperArgs {
+  GrouperCols cols;
+  int64_t n;                    // rows of the batch
+  const uint32_t* todo;         // NULL: rows 0..n_todo; else the pending rows of the previous launch
+  int64_t n_todo;
+  uint32_t* next;               // pending rows for the next launch
+  uint32_t* out_ids;
+  uint32_t* first_row;          // [new groups of this batch] smallest row, by provisional id - base
+  unsigned long long base;      // groups before this batch
+  int64_t max_new;              // entries of first_row
+  int insert;                   // 0: Lookup
+  uint8_t* found_bits;          // Lookup: validity bitmap of out_ids (caller-zeroed, atomicOr per word) or NULL
+};
+
+__global__ __launch_bounds__(kBlock) void grouper_probe_kernel(GrouperView v, GrouperArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  const uint64_t smask = static_cast<uint64_t>(v.nslots - 1);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n_todo; i += stride) {
+    const int64_t row = a.todo ? static_cast<int64_t>(a.todo[i]) : i;
+    const GrouperKey key = grouper_load_key(a.cols, row);
+    uint64_t s = grouper_hash(key) >> (64 - v.lg);
+    for (int64_t probes = 0; probes < v.nslots; ++probes, s = (s + 1) & smask) {
+      GrouperSlot* slot = v.slots + s;
+      unsigned long long meta = __atomic_load_n(&slot->meta, __ATOMIC_RELAXED);
+      if (meta == kSlotEmpty) {
+        if (!a.insert) {
+          a.out_ids[row] = 0;   // Lookup: unseen key -> null
+          break;
+        }
+        meta = atomicCAS(&slot->meta, kSlotEmpty, kSlotClaimed);
+        if (meta == kSlotEmpty) {   // ours
+          const unsigned long long id = atomicAdd(&v.hdr->num_groups, 1ull);
+          if (id >= static_cast<unsigned long long>(v.hdr->max_groups)) {
+            atomicOr(&v.hdr->overflow, 1u);
+            a.out_ids[row] = 0;
+            break;   // the slot stays claimed: the call fails as a whole
+          }
+          slot->k0 = key.k0;
+          slot->k1 = key.k1;
+          v.slot_of[id] = static_cast<unsigned int>(s);
+          atomicMin(&a.first_row[id - a.base], static_cast<uint32_t>(row));
+          __threadfence();
+          __atomic_store_n(&slot->meta, kSlotPublished | (static_cast<unsigned long long>(key.mask) << 8) | (id << 32),
+                           __ATOMIC_RELAXED);
+          a.out_ids[row] = static_cast<uint32_t>(id);
+          break;
+        }
+      }
+      if ((meta & 3) == kSlotClaimed) {   // somebody is writing this slot: look again in the next launch
+        a.next[atomicAdd(&v.hdr->pending, 1u)] = static_cast<uint32_t>(row);
+        break;
+      }
+      __threadfence();
+      if (__atomic_load_n(&slot->k0, __ATOMIC_RELAXED) == key.k0 && __atomic_load_n(&slot->k1, __ATOMIC_RELAXED) == key.k1 &&
+          ((meta >> 8) & 0xFF) == key.mask) {
+        const unsigned long long id = meta >> 32;
+        if (a.insert) {
+          if (id >= a.base) atomicMin(&a.first_row[id - a.base], static_cast<uint32_t>(row));
+        } else if (a.found_bits != nullptr) {
+          atomicOr(reinterpret_cast<unsigned long long*>(a.found_bits) + (row >> 6), 1ull << (row & 63));
+        }
+        a.out_ids[row] = static_cast<uint32_t>(id);
+        break;
+      }
+    }
+  }
+}
+
+// first rows of the new groups -> bitmap over the batch's rows
+__global__ __launch_bounds__(kBlock) void grouper_mark_first_kernel(const uint32_t* __restrict__ first_row, int64_t m,
+                                                                    unsigned long long* __restrict__ bits) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (j >= m) return;
+  const uint32_t r = first_row[j];
+  atomicOr(&bits[r >> 6], 1ull << (r & 63));
+}
+
+// positions[k] = k-th first row (ascending): the group that row belongs to gets final id base + k
+__global__ __launch_bounds__(kBlock) void grouper_rank_kernel(GrouperView v, const uint32_t* __restrict__ positions,
+                                                              int64_t m, const uint32_t* __restrict__ ids,
+                                                              unsigned long long base, uint32_t* __restrict__ rank) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k >= m) return;
+  const uint32_t prov = ids[positions[k]];
+  rank[prov - base] = static_cast<uint32_t>(k);
+}
+
+// new groups: final id into the slot, key row into the uniques (slot_of is rebuilt in final-id order through tmp)
+__global__ __launch_bounds__(kBlock) void grouper_renumber_groups_kernel(GrouperView v, int64_t m, unsigned long long base,
+                                                                         const uint32_t* __restrict__ rank,
+                                                                         uint32_t* __restrict__ slot_tmp) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (j >= m) return;
+  const unsigned int s = v.slot_of[base + j];
+  const unsigned long long id = base + rank[j];
+  GrouperSlot* slot = v.slots + s;
+  const unsigned long long meta = slot->meta;
+  slot->meta = (meta & 0xFFFFFFFFull) | (id << 32);
+  v.uniq_k0[id] = slot->k0;
+  v.uniq_k1[id] = slot->k1;
+  v.uniq_mask[id] = static_cast<unsigned int>((meta >> 8) & 0xFF);
+  slot_tmp[rank[j]] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void grouper_copy_u32_kernel(const uint32_t* __restrict__ src, int64_t m,
+                                                                  unsigned int* __restrict__ dst) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (j < m) dst[j] = src[j];
+}
+
+__global__ __launch_bounds__(kBlock) void grouper_renumber_rows_kernel(uint32_t* __restrict__ ids, int64_t n,
+                                                                       unsigned long long base,
+                                                                       const uint32_t* __restrict__ rank) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    const uint32_t id = ids[i];
+    if (id >= base) ids[i] = static_cast<uint32_t>(base + rank[id - base]);
+  }
+}
+
+// GetUniques: column j of the unique key rows
+__global__ __launch_bounds__(kBlock) void grouper_uniques_kernel(GrouperView v, int64_t g, int col, int width, int byte_pos,
+                                                                 uint8_t* __restrict__ out,
+                                                                 unsigned long long* __restrict__ out_valid,
+                                                                 unsigned long long* __restrict__ null_count) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool in = i < g;
+  bool valid = false;
+  if (in) {
+    valid = ((v.uniq_mask[i] >> col) & 1) == 0;
+    unsigned long long w;
+    if (byte_pos < 8) {
+      w = v.uniq_k0[i] >> (8 * byte_pos);
+      if (byte_pos + width > 8) w |= v.uniq_k1[i] << (8 * (8 - byte_pos));   // a column that straddles the two key words
+    } else {
+      w = v.uniq_k1[i] >> (8 * (byte_pos - 8));
+    }
+    uint8_t* p = out + i * width;
+    switch (width) {
+      case 1: *p = static_cast<uint8_t>(w); break;
+      case 2: *reinterpret_cast<uint16_t*>(p) = static_cast<uint16_t>(w); break;
+      case 4: *reinterpret_cast<uint32_t*>(p) = static_cast<uint32_t>(w); break;
+      default: *reinterpret_cast<unsigned long long*>(p) = w; break;
+    }
+  }
+  const unsigned long long b = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && (i - (i & 63)) < g) {
+    out_valid[i >> 6] = b;
+    const int64_t rows = g - i < 64 ? g - i : 64;
+    const unsigned int nulls = static_cast<unsigned int>(rows) - static_cast<unsigned int>(__popcll(b));
+    if (nulls) atomicAdd(null_count, static_cast<unsigned long long>(nulls));
+  }
+}
+
+static int grouper_cols(const ArxSpan* cols, const int32_t* widths, int num_keys, GrouperCols* out, int64_t* length) {
+  if (num_keys < 1 || num_keys > kGrouperMaxKeys) {
+    set_error("Grouper: 1 to %d key columns (got %d)", kGrouperMaxKeys, num_keys);
+    return ARX_NOT_IMPLEMENTED;
+  }
+  int pos = 0;
+  int64_t n = cols[0].length;
+  out->num_keys = num_keys;
+  for (int j = 0; j < num_keys; ++j) {
+    const int w = widths[j];
+    if (w != 1 && w != 2 && w != 4 && w != 8) {
+      set_error("Grouper: key column %d has byte width %d (1, 2, 4 or 8)", j, w);
+      return ARX_NOT_IMPLEMENTED;
+    }
+    if (cols[j].length != n) {
+      set_error("Grouper: key columns must all be the same length");
+      return ARX_INVALID;
+    }
+    if (n > 0 && cols[j].data == nullptr) {
+      set_error("Grouper: key column %d has no data", j);
+      return ARX_INVALID;
+    }
+    out->data[j] = static_cast<const uint8_t*>(cols[j].data);
+    out->offset[j] = cols[j].offset;
+    const bool has_nulls = cols[j].validity != nullptr && cols[j].null_count != 0;
+    out->valid[j] = make_bits(has_nulls ? cols[j].validity : nullptr, cols[j].offset, n);
+    out->width[j] = w;
+    out->byte_pos[j] = pos;
+    pos += w;
+  }
+  if (pos > 16) {
+    set_error("Grouper: the key columns take %d bytes per row; the device table holds rows of up to 16 bytes", pos);
+    return ARX_NOT_IMPLEMENTED;
+  }
+  *length = n;
+  return ARX_OK;
+}
+
+static inline unsigned grouper_grid(int64_t n) {
+  return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, 16384)));
+}
+
+struct GrouperWs {
+  size_t off_first, off_rank, off_pos, off_bits, off_pend_a, off_pend_b, off_sel, total;
+};
+
+static GrouperWs grouper_ws(int64_t n) {
+  auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
+  const size_t rows = static_cast<size_t>(std::max<int64_t>(n, 1));
+  GrouperWs w{};
+  size_t o = 0;
+  w.off_first = o; o = align(o + rows * 4);
+  w.off_rank = o; o = align(o + rows * 4);
+  w.off_pos = o; o = align(o + rows * 4);
+  w.off_bits = o; o = align(o + (rows / 64 + 2) * 8);
+  w.off_pend_a = o; o = align(o + rows * 4);
+  w.off_pend_b = o; o = align(o + rows * 4);
+  w.off_sel = o; o = align(o + selection_workspace_bytes(n));
+  w.total = o;
+  return w;
+}
+
+}  // namespace arx
+
+using namespace arx;
+
+extern "C" {
+
+size_t arx_grouper_state_bytes(int64_t max_groups) {
+  if (max_groups < 1) max_groups = 1;
+  const int64_t s = grouper_slots_for(max_groups);
+  return 64 + static_cast<size_t>(s) * sizeof(GrouperSlot) + static_cast<size_t>(max_groups) * (8 + 8 + 4 + 4) + 256;
+}
+
+int arx_grouper_init(void* state, int64_t max_groups, void* stream) {
+  if (state == nullptr || max_groups < 1 || max_groups >= (int64_t(1) << 31)) {
+    set_error("Grouper: state is NULL or max_groups out of range");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  GrouperView v = grouper_view(state, max_groups);
+  ARX_HIP(hipMemsetAsync(state, 0, 64 + static_cast<size_t>(v.nslots) * sizeof(GrouperSlot), st));
+  GrouperHeader h{};
+  h.max_groups = max_groups;
+  h.slots = v.nslots;
+  ARX_HIP(hipMemcpyAsync(state, &h, sizeof(h), hipMemcpyHostToDevice, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  return ARX_OK;
+}
+
+size_t arx_grouper_consume_workspace_bytes(int64_t length) { return grouper_ws(length).total; }
+
+static int grouper_run(void* state, int64_t max_groups, const ArxSpan* key_columns, const int32_t* key_byte_widths,
+                       int num_keys, void* ws, size_t ws_bytes, uint32_t* out_group_ids, uint8_t* out_found_bits,
+                       int insert, void* stream) {
+  if (state == nullptr || key_columns == nullptr || key_byte_widths == nullptr) {
+    set_error("Grouper: NULL argument");
+    return ARX_INVALID;
+  }
+  GrouperArgs a{};
+  int64_t n = 0;
+  const int rc = grouper_cols(key_columns, key_byte_widths, num_keys, &a.cols, &n);
+  if (rc != ARX_OK) return rc;
+  if (n == 0) return ARX_OK;
+  if (n >= (int64_t(1) << 32) - 64) {
+    set_error("Grouper: at most 2^32 - 65 rows per batch");
+    return ARX_INVALID;
+  }
+  if (out_group_ids == nullptr) {
+    set_error("Grouper: out_group_ids is NULL");
+    return ARX_INVALID;
+  }
+  const GrouperWs plan = grouper_ws(n);
+  if (ws == nullptr || ws_bytes < plan.total || (reinterpret_cast<uint64_t>(ws) & 255) != 0) {
+    set_error("Grouper: workspace too small or not 256-byte aligned (%zu needed)", plan.total);
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  GrouperView v = grouper_view(state, max_groups);
+  GrouperHeader h{};
+  ARX_HIP(hipMemcpyAsync(&h, v.hdr, sizeof(h), hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  if (h.max_groups != max_groups) {
+    set_error("Grouper: state was initialised for %lld groups, called with %lld", static_cast<long long>(h.max_groups),
+              static_cast<long long>(max_groups));
+    return ARX_INVALID;
+  }
+  if (h.overflow) {
+    set_error("Grouper: the table overflowed in an earlier call");
+    return ARX_INVALID;
+  }
+  uint8_t* w = static_cast<uint8_t*>(ws);
+  uint32_t* first_row = reinterpret_cast<uint32_t*>(w + plan.off_first);
+  uint32_t* rank = reinterpret_cast<uint32_t*>(w + plan.off_rank);
+  uint32_t* positions = reinterpret_cast<uint32_t*>(w + plan.off_pos);
+  unsigned long long* bits = reinterpret_cast<unsigned long long*>(w + plan.off_bits);
+  uint32_t* pend[2] = {reinterpret_cast<uint32_t*>(w + plan.off_pend_a), reinterpret_cast<uint32_t*>(w + plan.off_pend_b)};
+  const unsigned long long base = h.num_groups;
+  const int64_t max_new = std::min<int64_t>(n, max_groups - static_cast<int64_t>(base));
+  a.n = n;
+  a.out_ids = out_group_ids;
+  a.first_row = first_row;
+  a.base = base;
+  a.max_new = max_new;
+  a.insert = insert;
+  a.found_bits = out_found_bits;
+  if (insert && max_new > 0) ARX_HIP(hipMemsetAsync(first_row, 0xFF, static_cast<size_t>(max_new) * 4, st));
+  if (!insert && out_found_bits != nullptr) {
+    ARX_HIP(hipMemsetAsync(out_found_bits, 0, static_cast<size_t>((n + 63) / 64) * 8, st));
+  }
+  // probe; rows that met a slot in the middle of being written are looked at again by the next launch
+  const uint32_t* todo = nullptr;
+  int64_t n_todo = n;
+  for (int round = 0; n_todo > 0; ++round) {
+    a.todo = todo;
+    a.n_todo = n_todo;
+    a.next = pend[round & 1];
+    hipLaunchKernelGGL(grouper_probe_kernel, dim3(grouper_grid(n_todo)), dim3(kBlock), 0, st, v, a);
+    ARX_CHECK_LAUNCH("grouper_probe_kernel");
+    ARX_HIP(hipMemcpyAsync(&h, v.hdr, sizeof(h), hipMemcpyDeviceToHost, st));
+    ARX_HIP(hipStreamSynchronize(st));
+    if (h.overflow) {
+      set_error("Grouper: more than %lld distinct key rows", static_cast<long long>(max_groups));
+      return ARX_INVALID;
+    }
+    n_todo = h.pending;
+    todo = pend[round & 1];
+    if (n_todo > 0) ARX_HIP(hipMemsetAsync(&v.hdr->pending, 0, 4, st));
+    if (round > 64) {
+      set_error("Grouper: internal error (pending rows do not drain)");
+      return ARX_INVALID;
+    }
+  }
+  const int64_t m = static_cast<int64_t>(h.num_groups - base);
+  if (!insert || m == 0) return ARX_OK;
+  // new groups in order of first appearance
+  ARX_HIP(hipMemsetAsync(bits, 0, static_cast<size_t>(n / 64 + 2) * 8, st));
+  const unsigned gm = static_cast<unsigned>((m + kBlock - 1) / kBlock);   // one thread per new group
+  hipLaunchKernelGGL(grouper_mark_first_kernel, dim3(gm), dim3(kBlock), 0, st, first_row, m, bits);
+  ARX_CHECK_LAUNCH("grouper_mark_first_kernel");
+  int64_t got = 0;
+  const int rc2 = selection_bit_positions(bits, 0, n, false, w + plan.off_sel, ws_bytes - plan.off_sel, positions, &got, st);
+  if (rc2 != ARX_OK) return rc2;
+  if (got != m) {
+    set_error("Grouper: internal error (%lld first rows for %lld new groups)", static_cast<long long>(got),
+              static_cast<long long>(m));
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(grouper_rank_kernel, dim3(gm), dim3(kBlock), 0, st, v, positions, m, out_group_ids, base, rank);
+  ARX_CHECK_LAUNCH("grouper_rank_kernel");
+  uint32_t* slot_tmp = first_row;   // (first rows are no longer needed)
+  hipLaunchKernelGGL(grouper_renumber_groups_kernel, dim3(gm), dim3(kBlock), 0, st, v, m, base, rank, slot_tmp);
+  ARX_CHECK_LAUNCH("grouper_renumber_groups_kernel");
+  hipLaunchKernelGGL(grouper_copy_u32_kernel, dim3(gm), dim3(kBlock), 0, st, slot_tmp, m, v.slot_of + base);
+  ARX_CHECK_LAUNCH("grouper_copy_u32_kernel");
+  hipLaunchKernelGGL(grouper_renumber_rows_kernel, dim3(grouper_grid(n)), dim3(kBlock), 0, st, out_group_ids, n, base, rank);
+  ARX_CHECK_LAUNCH("grouper_renumber_rows_kernel");
+  ARX_HIP(hipStreamSynchronize(st));
+  return ARX_OK;
+}
+
+int arx_grouper_consume(void* state, int64_t max_groups, const ArxSpan* key_columns, const int32_t* key_byte_widths,
+                        int num_keys, void* ws, size_t ws_bytes, uint32_t* out_group_ids, void* stream) {
+  return grouper_run(state, max_groups, key_columns, key_byte_widths, num_keys, ws, ws_bytes, out_group_ids, nullptr, 1,
+                     stream);
+}
+
+int arx_grouper_lookup(void* state, int64_t max_groups, const ArxSpan* key_columns, const int32_t* key_byte_widths,
+                       int num_keys, void* ws, size_t ws_bytes, uint32_t* out_group_ids, uint8_t* out_validity,
+                       void* stream) {
+  if (out_validity == nullptr || (reinterpret_cast<uint64_t>(out_validity) & 7) != 0) {
+    set_error("Grouper: out_validity must be an 8-byte aligned bitmap");
+    return ARX_INVALID;
+  }
+  return grouper_run(state, max_groups, key_columns, key_byte_widths, num_keys, ws, ws_bytes, out_group_ids, out_validity, 0,
+                     stream);
+}
+
+int arx_grouper_num_groups(void* state, int64_t* out_num_groups, void* stream) {
+  if (state == nullptr || out_num_groups == nullptr) {
+    set_error("Grouper: NULL argument");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  GrouperHeader h{};
+  ARX_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  *out_num_groups = static_cast<int64_t>(h.num_groups);
+  return ARX_OK;
+}
+
+int arx_grouper_get_uniques(void* state, int64_t max_groups, const int32_t* key_byte_widths, int num_keys, int key_index,
+                            void* out_values, uint8_t* out_validity, int64_t* out_null_count, void* stream) {
+  if (state == nullptr || key_byte_widths == nullptr || out_null_count == nullptr) {
+    set_error("Grouper: NULL argument");
+    return ARX_INVALID;
+  }
+  if (num_keys < 1 || num_keys > kGrouperMaxKeys || key_index < 0 || key_index >= num_keys) {
+    set_error("Grouper: key_index out of range");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  GrouperView v = grouper_view(state, max_groups);
+  GrouperHeader h{};
+  ARX_HIP(hipMemcpyAsync(&h, v.hdr, sizeof(h), hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  const int64_t g = static_cast<int64_t>(h.num_groups);
+  *out_null_count = 0;
+  if (g == 0) return ARX_OK;
+  if (out_values == nullptr || out_validity == nullptr || (reinterpret_cast<uint64_t>(out_validity) & 7) != 0) {
+    set_error("Grouper: out_values / out_validity (8-byte aligned bitmap of ceil(g / 64) words) are required");
+    return ARX_INVALID;
+  }
+  int pos = 0;
+  for (int j = 0; j < key_index; ++j) pos += key_byte_widths[j];
+  unsigned long long* counter = reinterpret_cast<unsigned long long*>(&v.hdr->pad[1]);   // scratch word of the header
+  ARX_HIP(hipMemsetAsync(counter, 0, 8, st));
+  const unsigned grid = static_cast<unsigned>(((g + 63) / 64 * 64 + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(grouper_uniques_kernel, dim3(grid), dim3(kBlock), 0, st, v, g, key_index, key_byte_widths[key_index],
+                     pos, static_cast<uint8_t*>(out_values), reinterpret_cast<unsigned long long*>(out_validity), counter);
+  ARX_CHECK_LAUNCH("grouper_uniques_kernel");
+  unsigned long long nulls = 0;
+  ARX_HIP(hipMemcpyAsync(&nulls, counter, 8, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  *out_null_count = static_cast<int64_t>(nulls);
+  return ARX_OK;
+}
+
+}  // extern "C"

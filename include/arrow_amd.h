@@ -580,6 +580,47 @@ size_t arx_hash_sum_consume_workspace_bytes(int64_t length, int64_t num_groups);
 int arx_hash_sum_i64_consume_ws(const ArxSpan* values, int values_is_scalar, int64_t scalar_value,
                                 const uint32_t* group_ids, int64_t length, int64_t num_groups, int64_t* sums,
                                 int64_t* counts, uint32_t* null_seen, void* ws, size_t ws_bytes, void* stream);
+/* hash_mean(int64) on the same dense state — GroupedMeanImpl::Finalize (hash_aggregate_numeric.cc:352-430) divides a
+ * sum accumulated as DOUBLES in row order; out_means[g] = double(sums[g]) / counts[g] equals it bit for bit when every
+ * partial sum is an integer below 2^53, guaranteed when counts[g] * abs_bound < 2^53 with abs_bound >= |value| of
+ * every consumed row (the caller's min_max of the column).  *inexact (device, caller-zeroed) is set when a group
+ * breaks the bound: the caller then declines, the reference's own result depends on row order there.  Validity of a
+ * group is arx_hash_sum_i64_finalize's.  Groups with count 0 get 0.0. */
+int arx_hash_mean_i64_finalize(const int64_t* sums, const int64_t* counts, int64_t num_groups, uint64_t abs_bound,
+                               double* out_means, uint32_t* inexact, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Grouper: key rows of one or several fixed-width columns -> dense group ids.
+ * arrow::compute::Grouper (cpp/src/arrow/compute/row/grouper.h:104-137): Consume :121, Lookup :126, GetUniques :134,
+ * num_groups :137; the implementation followed is GrouperFastImpl (row/grouper.cc:555-973: encode the key columns as
+ * rows, map rows through a hash table, ids in order of first appearance, ConsumeImpl :695-815; uniques decoded from
+ * the stored rows, GetUniques :835-880).  This is the piece GroupByNode calls before every hash_* kernel
+ * (acero/groupby_aggregate_node.cc:210-258), so with arx_hash_sum_i64_consume_ws & co. it covers the keys the fused
+ * 32-bit operator (arx_groupby_*) does not: int64 / uint64 keys over their whole range and several key columns.
+ *
+ * Key columns: byte widths 1, 2, 4 or 8 (integers, temporal types ... compared by their bits), at most 8 columns and
+ * 16 bytes per row in total.  A null is a key value of its own (all rows whose column j is null agree in column j),
+ * as in the reference.  Group ids are the reference's: the k-th distinct key row in row order gets id k, across
+ * calls.  max_groups bounds the distinct key rows over the Grouper's life; exceeding it fails the call with
+ * ARX_INVALID and leaves the state unusable (arx_grouper_init again).
+ * state: device, arx_grouper_state_bytes(max_groups), 256-byte aligned.  ws: device, 256-byte aligned.  Synchronous. */
+size_t arx_grouper_state_bytes(int64_t max_groups);
+int arx_grouper_init(void* state, int64_t max_groups, void* stream);
+size_t arx_grouper_consume_workspace_bytes(int64_t length);
+/* out_group_ids: device uint32[length]. */
+int arx_grouper_consume(void* state, int64_t max_groups, const ArxSpan* key_columns, const int32_t* key_byte_widths,
+                        int num_keys, void* ws, size_t ws_bytes, uint32_t* out_group_ids, void* stream);
+/* Lookup (:126): rows whose key has not been consumed get a null id: out_validity = bitmap of length bits (device,
+ * 8-byte aligned, ceil(length/64) words), bit clear = unseen (its id slot holds 0).  Adds no group. */
+int arx_grouper_lookup(void* state, int64_t max_groups, const ArxSpan* key_columns, const int32_t* key_byte_widths,
+                       int num_keys, void* ws, size_t ws_bytes, uint32_t* out_group_ids, uint8_t* out_validity,
+                       void* stream);
+int arx_grouper_num_groups(void* state, int64_t* out_num_groups, void* stream);
+/* GetUniques (:134), one key column per call: out_values = num_groups values of key_byte_widths[key_index] bytes in
+ * group-id order, out_validity = their validity bitmap (ceil(num_groups/64) words, 8-byte aligned). */
+int arx_grouper_get_uniques(void* state, int64_t max_groups, const int32_t* key_byte_widths, int num_keys, int key_index,
+                            void* out_values, uint8_t* out_validity, int64_t* out_null_count, void* stream);
+
 int arx_hash_sum_i64_merge(int64_t* sums, int64_t* counts, uint32_t* null_seen,
                            const int64_t* other_sums, const int64_t* other_counts,
                            const uint32_t* other_null_seen, const uint32_t* group_id_mapping,

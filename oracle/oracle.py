@@ -479,6 +479,94 @@ def groupby_minmax_i64(keys, key_valid, key_off, values, val_valid, val_off, len
                 mins=np.array(mins, np.int64), maxs=np.array(maxs, np.int64), valid=np.array(valid, np.uint8))
 
 
+class Grouper:
+    """arrow::compute::Grouper as GrouperImpl implements it (compute/row/grouper.cc:335-553): every key row is
+    encoded to bytes (one encoder per column, a null is part of the encoding: KeyEncoder::kNullByte / kValidByte
+    prefix, row/grouper.cc:60-120), an unordered_map from encoded row to group id hands out ids in order of first
+    appearance (VisitKeys :405-447: `num_groups_++` on insertion), Lookup (:126 of grouper.h) maps unseen rows to a
+    null id whose slot holds 0 (:507-510), GetUniques (:527-553) decodes the stored rows in id order.
+    Columns are (values ndarray, valid bool ndarray | None) pairs; floats are compared by their bytes like the encoder
+    does (so -0.0 != 0.0 and NaNs with equal payloads are one key, grouper_test.cc:898-910)."""
+
+    def __init__(self, num_keys: int):
+        self.num_keys = num_keys
+        self.index = {}
+        self.rows = []
+
+    @staticmethod
+    def _encode(columns, i):
+        out = []
+        for values, valid in columns:
+            if valid is not None and not valid[i]:
+                out.append(None)
+            else:
+                out.append(values[i:i + 1].tobytes())
+        return tuple(out)
+
+    def consume(self, columns, insert=True):
+        n = len(columns[0][0])
+        ids = np.zeros(n, dtype=np.uint32)
+        found = np.ones(n, dtype=bool)
+        for i in range(n):
+            row = self._encode(columns, i)
+            g = self.index.get(row)
+            if g is None:
+                if insert:
+                    g = self.index[row] = len(self.rows)
+                    self.rows.append(row)
+                else:
+                    g, found[i] = 0, False
+            ids[i] = g
+        return ids if insert else (ids, found)
+
+    def lookup(self, columns):
+        return self.consume(columns, insert=False)
+
+    @property
+    def num_groups(self):
+        return len(self.rows)
+
+    def uniques(self, dtypes):
+        """One (values, valid) pair per key column, in id order."""
+        out = []
+        for j, dt in enumerate(dtypes):
+            vals = np.zeros(len(self.rows), dtype=dt)
+            valid = np.ones(len(self.rows), dtype=bool)
+            for g, row in enumerate(self.rows):
+                if row[j] is None:
+                    valid[g] = False
+                else:
+                    vals[g] = np.frombuffer(row[j], dtype=dt)[0]
+            out.append((vals, valid))
+        return out
+
+
+def grouper_ids_one_batch(columns):
+    """The ids Grouper.consume gives a fresh Grouper for ONE batch, vectorised (for batches too long for the
+    row-at-a-time restatement above, which tests/test_oracle_pin.py holds it equal to): rows as fixed-size byte
+    records [null flags | column bytes with nulls zeroed], np.unique for the distinct records, ids renumbered by the
+    first row of every record.  Returns (ids uint32, first_rows int64 in id order)."""
+    n = len(columns[0][0])
+    if n == 0:
+        return np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.int64)
+    parts = []
+    for values, valid in columns:
+        v = np.ascontiguousarray(values).copy()
+        flag = np.zeros(n, dtype=np.uint8)
+        if valid is not None:
+            v[~valid] = 0
+            flag = (~valid).astype(np.uint8)
+        parts.append(flag.reshape(n, 1))
+        parts.append(v.view(np.uint8).reshape(n, -1))
+    rec = np.ascontiguousarray(np.concatenate(parts, axis=1))
+    key = rec.view(np.dtype((np.void, rec.shape[1]))).reshape(n)
+    _, first, inverse = np.unique(key, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")
+    rank = np.empty(len(first), dtype=np.int64)
+    rank[order] = np.arange(len(first))
+    return rank[inverse.reshape(n)].astype(np.uint32), first[order].astype(np.int64)
+
+
 def unique_i32(values, valid_bitmap, offset, length, with_counts=False):
     """UniqueAction / ValueCountsAction over RegularHashKernel (kernels/vector_hash.cc:65-120,274-330):
     distinct values in order of first appearance; all nulls are one entry, placed where the first null

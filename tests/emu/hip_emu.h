@@ -155,6 +155,9 @@ inline uint64_t ballot(bool pred) {
 #define __syncthreads() hipemu::block_sync()
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 static inline void __threadfence_block() {}
+// A device-scope fence is where a protocol hands data to other threads: the emulator lets the other fibers of the
+// workgroup run there, so that readers do see the state between "claimed" and "published" (grouper.hip).
+static inline void __threadfence() { hipemu::yield(); }
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))

@@ -933,6 +933,204 @@ def replay_golden_sum_only(amd, gold):
     assert [list(r) for r in rows] == g["want_sorted_by_key"]
 
 
+# ------------------------------------------------------------------ Grouper
+_GROUPER_NP = {"uint8": np.uint8, "int8": np.int8, "uint16": np.uint16, "int16": np.int16, "uint32": np.uint32,
+               "int32": np.int32, "uint64": np.uint64, "int64": np.int64, "float32": np.float32, "float64": np.float64}
+
+
+def _golden_key_columns(rows, dtypes):
+    """[[k0, k1, ...] per row] with None for null -> one (values, valid) pair per key column."""
+    cols = []
+    for j, dt in enumerate(dtypes):
+        vals = np.array([0 if r[j] is None else float(r[j]) if isinstance(r[j], str) else r[j] for r in rows], dtype=dt)
+        valid = np.array([r[j] is not None for r in rows], dtype=bool)
+        cols.append((vals, valid))
+    return cols
+
+
+def _uniques_rows(uniq_cols):
+    """(values, valid) per column -> list of rows with None for null, floats as their bytes."""
+    n = len(uniq_cols[0][0])
+    return [tuple(None if not valid[i] else vals[i:i + 1].tobytes() for vals, valid in uniq_cols) for i in range(n)]
+
+
+def replay_golden_grouper(gold, section, make_grouper, max_type_combos=None):
+    """Replays the reference's own Grouper tests (ExpectConsume / ExpectPopulate / ExpectLookup / ExpectUniques,
+    compute/row/grouper_test.cc) on `make_grouper(dtypes) -> (consume, lookup, uniques)`; used with the oracle and
+    with the device Grouper (emulator, GPU).  Returns the number of type combinations run."""
+    import itertools
+
+    g = gold[section]
+    width = len(g["sequences"][0][0]["keys"][0])
+    combos = list(itertools.product(g["types"], repeat=width))
+    combos = [c for c in combos if sum(np.dtype(_GROUPER_NP[t]).itemsize for t in c) <= 16]
+    if max_type_combos is not None:
+        step = max(1, len(combos) // max_type_combos)
+        combos = combos[::step]
+    for combo in combos:
+        dtypes = [_GROUPER_NP[t] for t in combo]
+        for seq in g["sequences"]:
+            consume, lookup, uniques = make_grouper(dtypes)
+            for step in seq:
+                cols = _golden_key_columns(step["keys"], dtypes)
+                tag = f"{section}{combo} {step['op']} {step['keys']}"
+                if step["op"] == "lookup":
+                    ids, found = lookup(cols)
+                    got = [int(i) if f else None for i, f in zip(ids, found)]
+                    assert got == step["ids"], tag
+                else:
+                    ids = consume(cols)
+                    if step["op"] == "consume":
+                        assert [int(i) for i in ids] == step["ids"], tag
+                if "uniques" in step:
+                    want = _uniques_rows(_golden_key_columns(step["uniques"], dtypes))
+                    assert _uniques_rows(uniques(dtypes)) == want, tag + " uniques"
+    return len(combos)
+
+
+def oracle_grouper_factory(dtypes):
+    g = O.Grouper(len(dtypes))
+    return (lambda cols: g.consume(cols)), (lambda cols: g.lookup(cols)), (lambda dts: g.uniques(dts))
+
+
+def device_grouper_factory(amd, max_groups=64):
+    def make(dtypes):
+        from arrow_amd.array import type_from_numpy
+
+        types = [type_from_numpy(np.dtype(dt)) for dt in dtypes]
+        g = amd.compute.Grouper(types, max_groups)
+
+        def up(cols):
+            return [amd.Array.from_numpy(v, valid if not valid.all() else None) for v, valid in cols]
+
+        def consume(cols):
+            return _data_np(g.consume(up(cols)), np.uint32)
+
+        def lookup(cols):
+            out = g.lookup(up(cols))
+            found, pad_ok = _logical_valid(out)
+            assert pad_ok
+            return _data_np(out, np.uint32), found
+
+        def uniques(dts):
+            batch = g.get_uniques()
+            assert batch.length == g.num_groups
+            return [(_data_np(a, dt).copy(), _logical_valid(a)[0]) for a, dt in zip(batch.values, dts)]
+
+        return consume, lookup, uniques
+
+    return make
+
+
+def check_grouper(amd, rng, dtypes, n, cardinality, null_p=0.0, batches=1, max_groups=None):
+    """Random key rows through the device Grouper in `batches` consumes: the ids equal the oracle's (first appearance
+    in row order, across batches), uniques[id] is the key row, num_groups matches; then a Lookup of a mix of seen and
+    unseen rows."""
+    from arrow_amd.array import type_from_numpy
+
+    cols = []
+    for dt in dtypes:
+        info = np.iinfo(dt) if np.issubdtype(dt, np.integer) else None
+        pool = (rng.integers(info.min, info.max, size=cardinality, dtype=dt, endpoint=True) if info is not None
+                else rng.standard_normal(cardinality).astype(dt))
+        vals = pool[rng.integers(0, cardinality, size=n)]
+        valid = rng.random(n) >= null_p if null_p else np.ones(n, dtype=bool)
+        cols.append((vals, valid))
+    want_ids, first = O.grouper_ids_one_batch(cols)
+    num_groups = len(first)
+    g = amd.compute.Grouper([type_from_numpy(np.dtype(dt)) for dt in dtypes], max_groups or max(16, num_groups))
+    step = max(1, (n + batches - 1) // batches)
+    got = []
+    for b in range(0, n, step):
+        part = [amd.Array.from_numpy(v[b:b + step], None if valid[b:b + step].all() else valid[b:b + step])
+                for v, valid in cols]
+        got.append(_data_np(g.consume(part), np.uint32).copy())
+    got = np.concatenate(got) if got else np.zeros(0, np.uint32)
+    tag = f"grouper[{[np.dtype(d).name for d in dtypes]},n={n},card={cardinality},null_p={null_p},batches={batches}]"
+    assert_equal(got, want_ids, tag + " ids")
+    assert g.num_groups == num_groups, tag
+    uniq = g.get_uniques()
+    for (vals, valid), arr, dt in zip(cols, uniq.values, dtypes):
+        uv, pad_ok = _logical_valid(arr)
+        assert pad_ok
+        assert_equal(uv, valid[first], tag + " uniques validity")
+        gotv = _data_np(arr, dt)
+        assert_equal(gotv[uv].view(np.uint8), vals[first][uv].view(np.uint8), tag + " uniques values")
+        assert arr.null_count == int((~valid[first]).sum())
+    # Lookup: every second row replaced by a fresh random row (almost surely unseen when the key space is wide)
+    if n:
+        probe = []
+        for (vals, valid), dt in zip(cols, dtypes):
+            v = vals.copy()
+            info = np.iinfo(dt) if np.issubdtype(dt, np.integer) else None
+            fresh = (rng.integers(info.min, info.max, size=n, dtype=dt, endpoint=True) if info is not None
+                     else rng.standard_normal(n).astype(dt))
+            v[::2] = fresh[::2]
+            probe.append((v, valid))
+        orc = O.Grouper(len(dtypes))
+        # (the oracle class is row-at-a-time; seed it with the unique rows in id order instead of all n rows)
+        orc.consume([(vals[first], valid[first]) for vals, valid in cols])
+        want_l, want_f = orc.lookup(probe)
+        out = g.lookup([amd.Array.from_numpy(v, None if valid.all() else valid) for v, valid in probe])
+        found, pad_ok = _logical_valid(out)
+        assert pad_ok
+        assert_equal(found, want_f, tag + " lookup validity")
+        assert_equal(_data_np(out, np.uint32)[found], want_l[want_f], tag + " lookup ids")
+        assert g.num_groups == num_groups   # Lookup adds nothing
+    return g
+
+
+def check_group_by_keys(amd, rng, key_dtypes, n, cardinality, null_p=0.0, use_pyarrow=True):
+    """compute.group_by over several / wide key columns (Grouper + the dense hash_sum state): sum, count and mean per
+    group equal the oracle's per-group reduction and pyarrow's Table.group_by(keys).aggregate (compared as a mapping
+    from key row to results: the reference's fast grouper does not promise an output order)."""
+    cols = []
+    for dt in key_dtypes:
+        info = np.iinfo(dt)
+        pool = rng.integers(info.min, info.max, size=cardinality, dtype=dt, endpoint=True)
+        vals = pool[rng.integers(0, cardinality, size=n)]
+        valid = rng.random(n) >= null_p if null_p else np.ones(n, dtype=bool)
+        cols.append((vals, valid))
+    values = rng.integers(-10**9, 10**9, size=n, dtype=np.int64)
+    vvalid = rng.random(n) >= 0.1
+    keys = [amd.Array.from_numpy(v, None if valid.all() else valid) for v, valid in cols]
+    varr = amd.Array.from_numpy(values, vvalid)
+    uniq, (sums, counts, means) = amd.compute.group_by(keys, [(varr, "hash_sum"), (varr, "hash_count"), (varr, "hash_mean")])
+    ids, first = O.grouper_ids_one_batch(cols)
+    g = len(first)
+    want_sum = np.zeros(g, dtype=np.int64)
+    np.add.at(want_sum, ids[vvalid], values[vvalid])
+    want_cnt = np.bincount(ids[vvalid], minlength=g).astype(np.int64)
+    tag = f"group_by[{[np.dtype(d).name for d in key_dtypes]},n={n},card={cardinality}]"
+    assert uniq.length == g and sums.length == g
+    for (vals, valid), arr, dt in zip(cols, uniq.values, key_dtypes):
+        uv, _ = _logical_valid(arr)
+        assert_equal(uv, valid[first], tag + " key validity")
+        assert_equal(_data_np(arr, dt)[uv], vals[first][uv], tag + " keys")
+    sv, _ = _logical_valid(sums)
+    assert_equal(sv, want_cnt >= 1, tag + " sum validity")      # min_count = 1: groups without a valid value are null
+    assert_equal(_data_np(sums, np.int64)[sv], want_sum[sv], tag + " sums")
+    assert_equal(_data_np(counts, np.int64), want_cnt, tag + " counts")
+    mv, _ = _logical_valid(means)
+    assert_equal(mv, want_cnt >= 1, tag + " mean validity")
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want_mean = want_sum.astype(np.float64) / want_cnt.astype(np.float64)
+    assert_equal(_data_np(means, np.float64)[mv].view(np.uint64), want_mean[mv].view(np.uint64), tag + " means")
+    if use_pyarrow and pa is not None:
+        names = [f"k{j}" for j in range(len(cols))]
+        t = pa.table({**{nm: pa.array(v, mask=~valid) for nm, (v, valid) in zip(names, cols)},
+                      "v": pa.array(values, mask=~vvalid)})
+        ref = t.group_by(names, use_threads=False).aggregate([("v", "sum"), ("v", "count"), ("v", "mean")]).to_pydict()
+        ref_map = {tuple(ref[nm][i] for nm in names): (ref["v_sum"][i], ref["v_count"][i], ref["v_mean"][i])
+                   for i in range(len(ref["v_sum"]))}
+        got_keys = [[None if not _logical_valid(a)[0][i] else int(_data_np(a, dt)[i]) for i in range(g)]
+                    for a, dt in zip(uniq.values, key_dtypes)]
+        gs, gc, gm = _data_np(sums, np.int64), _data_np(counts, np.int64), _data_np(means, np.float64)
+        got_map = {tuple(col[i] for col in got_keys): (int(gs[i]) if sv[i] else None, int(gc[i]),
+                                                       float(gm[i]) if mv[i] else None) for i in range(g)}
+        assert got_map == ref_map, tag + " vs pyarrow"
+
+
 def check_groupby_mean(amd, keys: HostArray, values: HostArray, skip_nulls=True, min_count=1, capacity=None,
                        use_pyarrow=True, batches=1, expect_decline=False):
     """hash_mean(int64) on the fused table vs the oracle's row-order double accumulation (and pyarrow's hash_mean):

@@ -834,3 +834,50 @@ def test_divide_and_divide_checked(emu_ctx):
     """Divide / DivideChecked (base_arithmetic_internal.h:366-424): truncating int64 division, zero divisors, INT64_MIN / -1,
     IEEE doubles, the last failing valid slot names the error, nulls hide failures."""
     P.check_divide(emu_ctx, rng_for("divide"), n=3000)
+
+
+@pytest.mark.parametrize("section,combos", [("grouper_numeric_key", None), ("grouper_floating_point_key", None),
+                                            ("grouper_multiple_int_keys", 40)])
+def test_reference_grouper_golden_vectors(emu_ctx, section, combos):
+    """grouper_test.cc's own expectations (exact ids in first-appearance order, uniques, Lookup nulls) on the device
+    Grouper; the three-column case samples the type combinations (every width pair still occurs)."""
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
+    assert P.replay_golden_grouper(gold, section, P.device_grouper_factory(emu_ctx), combos) > 0
+
+
+@pytest.mark.parametrize("dtypes,n,card,null_p,batches", [
+    ((np.int64,), 5000, 700, 0.05, 1), ((np.int64,), 5000, 4999, 0.0, 3), ((np.uint64,), 3000, 5, 0.3, 2),
+    ((np.int32, np.int32), 6000, 900, 0.1, 2), ((np.int64, np.int64), 4000, 300, 0.1, 1),
+    ((np.int8, np.int16, np.int32, np.int64), 3000, 2500, 0.05, 4), ((np.float64, np.uint8), 2000, 50, 0.2, 1),
+    ((np.int16,), 0, 1, 0.0, 1), ((np.uint8,) * 8, 2000, 100, 0.1, 2)])
+def test_grouper_ids_uniques_lookup(emu_ctx, dtypes, n, card, null_p, batches):
+    P.check_grouper(emu_ctx, rng_for("grouper", len(dtypes), n, card, batches), dtypes, n, card, null_p, batches)
+
+
+def test_grouper_hot_keys_take_the_pending_path(emu_ctx):
+    """9 distinct rows over 30000: while a row's slot is claimed but not yet published (the emulator's __threadfence is
+    a scheduling point) the other rows of the workgroup with that key must defer, not wait and not insert twice."""
+    P.check_grouper(emu_ctx, rng_for("grouper-hot"), (np.int64, np.int64), 30000, 3, 0.0, 2, max_groups=16)
+
+
+def test_grouper_declines_and_overflows(emu_ctx):
+    from arrow_amd.array import int64, bool_
+
+    with pytest.raises(NotImplementedError, match="16 bytes"):
+        emu_ctx.compute.Grouper([int64, int64, int64], 16)
+    with pytest.raises(NotImplementedError, match="keys of type bool"):
+        emu_ctx.compute.Grouper([bool_], 16)
+    g = emu_ctx.compute.Grouper([int64], 4)
+    g.consume([emu_ctx.Array.from_numpy(np.arange(4, dtype=np.int64))])
+    assert g.num_groups == 4
+    with pytest.raises(ValueError, match="more than 4 distinct key rows"):
+        g.consume([emu_ctx.Array.from_numpy(np.arange(10, dtype=np.int64))])
+
+
+@pytest.mark.parametrize("dtypes,n,card,null_p", [((np.int64,), 6000, 500, 0.05), ((np.int32, np.int32), 6000, 800, 0.1),
+                                                  ((np.int64, np.int16), 4000, 3500, 0.0)])
+def test_group_by_wide_and_multiple_keys(emu_ctx, dtypes, n, card, null_p):
+    P.check_group_by_keys(emu_ctx, rng_for("group_by_keys", len(dtypes), n, card), dtypes, n, card, null_p)

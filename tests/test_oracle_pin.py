@@ -596,3 +596,43 @@ def test_golden_hash_sum_sum_only():
     rows = sorted(((int(a) if b else None, int(c) if d else None) for a, b, c, d in
                    zip(w["keys"], w["key_is_valid"], w["sums"], w["valid"])), key=lambda r: (r[0] is None, r[0] or 0))
     assert [list(r) for r in rows] == g["want_sorted_by_key"]
+
+
+@pytest.mark.parametrize("section", ["grouper_numeric_key", "grouper_floating_point_key", "grouper_multiple_int_keys"])
+def test_golden_grouper(section):
+    """compute/row/grouper_test.cc:845-910, :1024-1057 — the reference's own Grouper expectations (exact ids, uniques,
+    Lookup nulls) replayed on the oracle's restatement of GrouperImpl."""
+    from tests import parity_cases as P
+
+    assert P.replay_golden_grouper(GOLD, section, P.oracle_grouper_factory) > 0
+
+
+def test_grouper_vectorised_oracle_equals_the_row_at_a_time_one():
+    """grouper_ids_one_batch (np.unique based, what the large parity cases use) against the dict restatement, and the
+    per-key sums of both against pyarrow's Table.group_by on two key columns with nulls."""
+    rng = np.random.default_rng(77)
+    for dtypes, n, card, null_p in (((np.int64,), 3000, 40, 0.1), ((np.int32, np.int16), 5000, 300, 0.2),
+                                    ((np.uint8, np.int64, np.uint16), 2000, 1500, 0.05), ((np.float64,), 1000, 12, 0.3)):
+        cols = []
+        for dt in dtypes:
+            pool = (rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, size=card, dtype=dt, endpoint=True)
+                    if np.issubdtype(dt, np.integer) else rng.standard_normal(card).astype(dt))
+            cols.append((pool[rng.integers(0, card, size=n)], rng.random(n) >= null_p))
+        ids, first = O.grouper_ids_one_batch(cols)
+        slow = O.Grouper(len(dtypes))
+        want = slow.consume(cols)
+        assert np.array_equal(ids, want)
+        assert np.array_equal(first, [int(np.flatnonzero(want == g)[0]) for g in range(slow.num_groups)])
+    if pa is not None:
+        cols = [(rng.integers(-3, 3, size=4000, dtype=np.int64), rng.random(4000) >= 0.1),
+                (rng.integers(0, 4, size=4000, dtype=np.int32), rng.random(4000) >= 0.1)]
+        v = rng.integers(-1000, 1000, size=4000, dtype=np.int64)
+        ids, first = O.grouper_ids_one_batch(cols)
+        sums = np.zeros(len(first), dtype=np.int64)
+        np.add.at(sums, ids, v)
+        t = pa.table({"a": pa.array(cols[0][0], mask=~cols[0][1]), "b": pa.array(cols[1][0], mask=~cols[1][1]), "v": v})
+        ref = t.group_by(["a", "b"], use_threads=False).aggregate([("v", "sum")]).to_pydict()
+        ref_map = {(a, b): s for a, b, s in zip(ref["a"], ref["b"], ref["v_sum"])}
+        got_map = {(int(cols[0][0][r]) if cols[0][1][r] else None, int(cols[1][0][r]) if cols[1][1][r] else None): int(sums[g])
+                   for g, r in enumerate(first)}
+        assert got_map == ref_map
