@@ -245,11 +245,12 @@ def _max_over_ranks(x: float, world, device) -> float:
     return x
 
 
-def load_traffic(name: str, rows: int):
-    """HBM bytes per launch / per run from the committed PMC pass (profiles/<name>_traffic.json), or null."""
+def load_traffic(name: str, rows: int, form: str | None = None):
+    """HBM bytes per launch / per run from the committed PMC pass (profiles/<name>_traffic.json), or null — also null
+    when the pass measured another form of the pipeline than the one that runs now (`form`)."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", f"{name}_traffic.json")))
-        if int(d.get("rows", -1)) == int(rows):
+        if int(d.get("rows", -1)) == int(rows) and d.get("form") == form:
             return d.get("hbm_bytes_per_launch")
     except Exception:
         pass
@@ -756,7 +757,7 @@ def sort_leg(args, rank, world, device, rows_total, steps, warmup):
            "roofline": {"bound": "hbm", "kernel": "arx_sort_indices (msd_hist + scatter levels + LDS bucket finish)",
                         "achieved": round(per_gpu, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 16,
-                        "traffic": load_traffic("sort", rows // world)}}
+                        "traffic": load_traffic("sort", rows // world, form="estimated")}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not EMU:
         try:
             leg["cpu_baseline"] = cpu_baseline_sort(min(rows, args.cpu_sort_rows))
