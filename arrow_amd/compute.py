@@ -907,9 +907,67 @@ def _take_meta(args, options):
     values, indices = args
     options = options or TakeOptions()
     if isinstance(values, RecordBatch):
-        return RecordBatch({k: call_function("array_take", [c, indices], options)
-                            for k, c in values.columns.items()})
+        # RAR (TakeRAR :619-633 runs TakeAAA per column): the fixed-width columns go through ONE launch that reads
+        # the indices once (arx_take_columns, groups of 16); boolean / var-width columns keep their own kernels
+        fused = {k: c for k, c in values.columns.items() if isinstance(c, Array) and c.type != bool_ and _FIXED_WIDTH(c.type)
+                 and c.type.byte_width in (1, 2, 4, 8, 16, 32)}
+        out = dict.fromkeys(values.columns)
+        if len(fused) >= 2 and isinstance(indices, Array) and indices.type.name in INDEX_TYPE_ID:
+            names = list(fused)
+            for b in range(0, len(names), 16):
+                part = names[b:b + 16]
+                for k, col in zip(part, take_columns([fused[k] for k in part], indices, options.boundscheck)):
+                    out[k] = col
+        for k, c in values.columns.items():
+            if out[k] is None:
+                out[k] = call_function("array_take", [c, indices], options)
+        return RecordBatch(out)
     return call_function("array_take", [values, indices], options)
+
+
+def take_columns(columns, indices: Array, boundscheck: bool = True):
+    """`take` of up to 16 fixed-width columns of equal length by one index array in one launch (arx_take_columns);
+    per column the result of array_take.  One bounds check for all columns."""
+    columns = list(columns)
+    n = columns[0].length
+    if any(c.length != n for c in columns):
+        raise ArrowInvalid("columns of a RecordBatch must have equal length")
+    dev = columns[0].device
+    lib, stream = _lib_and_stream(dev)
+    tid = INDEX_TYPE_ID[indices.type.name]
+    ispan = indices.span()
+    if boundscheck:
+        ws = _workspace(dev, lib.arx_take_workspace_bytes(), "take")
+        check(lib.arx_check_index_bounds(C.byref(ispan), tid, n, ws.data_ptr(), ws.numel(), stream))
+    m, k = indices.length, len(columns)
+    spans = (_lib.ArxSpan * k)(*[c.span() for c in columns])
+    widths = (C.c_int32 * k)(*[c.type.byte_width for c in columns])
+    out_data = [alloc(m * c.type.byte_width, dev) for c in columns]
+    need = [c.may_have_nulls() or indices.may_have_nulls() for c in columns]
+    out_valid = [alloc(bitmap_nbytes(m), dev) if nd else None for nd in need]
+    counters = torch.zeros(k, dtype=torch.int64, device=dev)
+    data_ptrs = (C.c_void_p * k)(*[t.data_ptr() for t in out_data])
+    valid_ptrs = (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in out_valid])
+    with tracing.span("arx_take_columns"):
+        check(lib.arx_take_columns(spans, widths, k, C.byref(ispan), tid, data_ptrs, valid_ptrs, counters.data_ptr(),
+                                   stream))
+    outs = []
+    for j, c in enumerate(columns):
+        a = Array(c.type, m, [out_valid[j], out_data[j]], 0, 0)
+        if need[j]:
+            a.set_lazy_null_count(_LazyColumnCount(m, counters, j))
+        outs.append(a)
+    return outs
+
+
+class _LazyColumnCount:
+    """null_count of column j from the per-column valid counters of arx_take_columns (read on first use)."""
+
+    def __init__(self, length, counters, j):
+        self.length, self.counters, self.j = length, counters, j
+
+    def __call__(self):
+        return self.length - int(self.counters[self.j].item())
 
 
 def _cast_meta(args, options):

@@ -837,6 +837,111 @@ __global__ __launch_bounds__(kBlock) void take_kernel(TakeArgs a) {
   if (a.valid_count != nullptr && lane == 0 && nvalid != 0) atomicAdd(a.valid_count, nvalid);
 }
 
+// Take of SEVERAL fixed-width columns by the same indices in one launch (TakeRAR, vector_selection_take_internal.cc:
+// 619-633, runs TakeAAA per column: every column re-reads the indices and their validity; here a wave reads them once
+// per 256 rows and gathers column after column).  Same per-column result as take_kernel.
+constexpr int kTakeMaxCols = 16;
+struct TakeColsArgs {
+  const uint8_t* values[kTakeMaxCols];          // pre-offset to element 0
+  const uint8_t* src_valid_bytes[kTakeMaxCols]; // source validity bitmap bytes or NULL
+  int64_t src_valid_offset[kTakeMaxCols];
+  uint8_t* out_data[kTakeMaxCols];
+  uint64_t* out_validity[kTakeMaxCols];         // may be NULL (then neither the column nor the indices have nulls)
+  int width[kTakeMaxCols];
+  int num_cols;
+  const uint8_t* indices;                       // pre-offset to element 0
+  Bits ivalid;
+  int64_t length;
+  unsigned long long* valid_counts;             // [num_cols] or NULL
+};
+
+template <int W, int U>
+__device__ __forceinline__ uint64_t take_one_column(const TakeColsArgs& a, int c, const int64_t (&pos)[U],
+                                                    const uint64_t (&idx)[U], const bool (&ok0)[U], int64_t base,
+                                                    int64_t last, int lane) {
+  using E = typename ElemT<W>::type;
+  const E* __restrict__ values = reinterpret_cast<const E*>(a.values[c]);
+  E* __restrict__ out = reinterpret_cast<E*>(a.out_data[c]);
+  const uint8_t* __restrict__ svb = a.src_valid_bytes[c];
+  const uint64_t svo = static_cast<uint64_t>(a.src_valid_offset[c]);
+  E val[U];
+  bool ok[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const E* src = ok0[u] ? (values + idx[u]) : (out + pos[u]);   // (a harmless in-bounds address when not gathering)
+    val[u] = *src;
+    ok[u] = ok0[u];
+  }
+  if (svb != nullptr) {   // wave-uniform
+    uint8_t vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) vb[u] = svb[(ok0[u] ? svo + idx[u] : 0) >> 3];
+#pragma unroll
+    for (int u = 0; u < U; ++u) ok[u] = ok[u] && ((vb[u] >> ((svo + idx[u]) & 7)) & 1);
+  }
+  uint64_t nvalid = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t p = base + u * 64 + lane;
+    if (p <= last) out[p] = ok[u] ? val[u] : zero_elem<W>();
+    const uint64_t vbal = __ballot(ok[u]);
+    nvalid += __popcll(vbal);
+    if (a.out_validity[c] != nullptr && lane == 0 && (base + u * 64) <= last) a.out_validity[c][(base >> 6) + u] = vbal;
+  }
+  return nvalid;
+}
+
+template <typename IdxT, bool HAS_IV>
+__global__ __launch_bounds__(kBlock) void take_columns_kernel(TakeColsArgs a) {
+  constexpr int U = 4;
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock +
+                         __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nchunks = (a.length + 64 * U - 1) / (64 * U);
+  const int64_t last = a.length - 1;
+  const IdxT* __restrict__ indices = reinterpret_cast<const IdxT*>(a.indices);
+  uint64_t nvalid[kTakeMaxCols];
+  for (int c = 0; c < kTakeMaxCols; ++c) nvalid[c] = 0;
+  for (int64_t ch = wave_g; ch < nchunks; ch += nwaves) {
+    const int64_t base = ch * (64 * U);
+    int64_t pos[U];
+    uint64_t idx[U];
+    bool ok0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t p = base + u * 64 + lane;
+      pos[u] = p <= last ? p : last;
+      idx[u] = static_cast<uint64_t>(indices[pos[u]]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ok0[u] = (base + u * 64 + lane) <= last;
+      if constexpr (HAS_IV) {
+        const uint64_t wbits = load_word_nb(a.ivalid, (base >> 6) + u);
+        ok0[u] = ok0[u] && ((wbits >> lane) & 1ull);
+      }
+    }
+    for (int c = 0; c < a.num_cols; ++c) {   // wave-uniform
+      uint64_t nv;
+      switch (a.width[c]) {
+        case 1: nv = take_one_column<1, U>(a, c, pos, idx, ok0, base, last, lane); break;
+        case 2: nv = take_one_column<2, U>(a, c, pos, idx, ok0, base, last, lane); break;
+        case 4: nv = take_one_column<4, U>(a, c, pos, idx, ok0, base, last, lane); break;
+        case 8: nv = take_one_column<8, U>(a, c, pos, idx, ok0, base, last, lane); break;
+        case 16: nv = take_one_column<16, U>(a, c, pos, idx, ok0, base, last, lane); break;
+        default: nv = take_one_column<32, U>(a, c, pos, idx, ok0, base, last, lane); break;
+      }
+      nvalid[c] += nv;
+    }
+  }
+  if (a.valid_counts != nullptr && lane == 0) {
+    for (int c = 0; c < a.num_cols; ++c) {
+      if (nvalid[c] != 0) atomicAdd(a.valid_counts + c, nvalid[c]);
+    }
+  }
+}
+
 // Take on BOOLEAN values (bit-packed): out bit i = value bit idx[i], 0 for a null slot
 // (Gather</*kValueWidthInBits=*/1>, gather_internal.h; the bit twin of take_kernel).  One output word
 // per wave step: the value bits and the validity are both packed by ballot.
@@ -1438,6 +1543,76 @@ int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int 
 #undef ARX_TAKE_W
 #undef ARX_TAKE_V
   ARX_CHECK_LAUNCH("take_kernel");
+  return ARX_OK;
+}
+
+int arx_take_columns(const ArxSpan* columns, const int32_t* byte_widths, int num_columns, const ArxSpan* indices,
+                     int index_type, void* const* out_data, void* const* out_validity, int64_t* valid_counts,
+                     void* stream) {
+  if (columns == nullptr || byte_widths == nullptr || indices == nullptr || out_data == nullptr || out_validity == nullptr) {
+    set_error("take_columns: NULL argument");
+    return ARX_INVALID;
+  }
+  if (num_columns < 1 || num_columns > kTakeMaxCols) {
+    set_error("take_columns: 1 to %d columns per call (got %d)", kTakeMaxCols, num_columns);
+    return ARX_INVALID;
+  }
+  if (index_type < 0 || index_type > 7) {
+    set_error("Unsupported index type %d for take", index_type);
+    return ARX_NOT_IMPLEMENTED;
+  }
+  if (indices->length == 0) return ARX_OK;
+  if (indices->data == nullptr) {
+    set_error("indices data buffer is NULL");
+    return ARX_INVALID;
+  }
+  static const int widths[8] = {1, 1, 2, 2, 4, 4, 8, 8};
+  const int iw = widths[index_type];
+  TakeColsArgs a{};
+  a.num_cols = num_columns;
+  a.indices = static_cast<const uint8_t*>(indices->data) + indices->offset * iw;
+  a.ivalid = make_bits(effective_validity(indices), indices->offset, indices->length);
+  a.length = indices->length;
+  a.valid_counts = reinterpret_cast<unsigned long long*>(valid_counts);
+  for (int c = 0; c < num_columns; ++c) {
+    const int w = byte_widths[c];
+    if (w != 1 && w != 2 && w != 4 && w != 8 && w != 16 && w != 32) {
+      set_error("Unsupported primitive type for take: byte width %d", w);
+      return ARX_NOT_IMPLEMENTED;
+    }
+    if (out_data[c] == nullptr) {
+      set_error("take_columns: out data buffer of column %d is NULL", c);
+      return ARX_INVALID;
+    }
+    a.width[c] = w;
+    a.values[c] = static_cast<const uint8_t*>(columns[c].data) + columns[c].offset * w;
+    a.src_valid_bytes[c] = static_cast<const uint8_t*>(effective_validity(&columns[c]));
+    a.src_valid_offset[c] = columns[c].offset;
+    a.out_data[c] = static_cast<uint8_t*>(out_data[c]);
+    a.out_validity[c] = static_cast<uint64_t*>(out_validity[c]);
+    if ((a.src_valid_bytes[c] != nullptr || a.ivalid.base != nullptr) && out_validity[c] == nullptr) {
+      set_error("take: inputs may have nulls but out_validity is NULL");
+      return ARX_INVALID;
+    }
+  }
+  hipStream_t st = as_stream(stream);
+  const int64_t nchunks = ceil_div(indices->length, 256);
+  const int64_t blocks = std::min<int64_t>(ceil_div(nchunks, kWavesPerBlock), 256 * 32);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(kBlock);
+  const bool has_iv = a.ivalid.base != nullptr;
+#define ARX_TAKEC(IT)                                                                                   \
+  do {                                                                                                  \
+    if (has_iv) hipLaunchKernelGGL((take_columns_kernel<IT, true>), grid, block, 0, st, a);             \
+    else hipLaunchKernelGGL((take_columns_kernel<IT, false>), grid, block, 0, st, a);                   \
+  } while (0)
+  switch (iw) {
+    case 1: ARX_TAKEC(uint8_t); break;
+    case 2: ARX_TAKEC(uint16_t); break;
+    case 4: ARX_TAKEC(uint32_t); break;
+    default: ARX_TAKEC(uint64_t); break;
+  }
+#undef ARX_TAKEC
+  ARX_CHECK_LAUNCH("take_columns_kernel");
   return ARX_OK;
 }
 

@@ -633,6 +633,19 @@ def run_other_paths(amd, device, args):
         t(f"filter_drop_selectivity_{int(sel * 100)}pct", lambda: amd.compute.filter(dv, dms),
           8 * n + n / 4 + 8.125 * ssel)
         del msel, dms
+    # take of a 4-column record batch by the monotonic indices (TakeRAR): one launch for all columns
+    # (arx_take_columns) vs array_take column after column; 3 more value columns of their own (distinct HBM lines)
+    try:
+        extra = [gen_stream(n, device, 0, 20 + j) for j in range(3)]
+        cols = {"c0": dv, **{f"c{j + 1}": amd.Array(amd.array.int64, n, [validity, e.view(torch.uint8)], -1, 0)
+                             for j, e in enumerate(extra)}}
+        batch = amd.compute.RecordBatch(cols)
+        t("take_record_batch_4_columns_one_launch", lambda: amd.compute.take(batch, mono, boundscheck=False), 4 * 16.25 * S + 4 * S)
+        t("take_record_batch_4_columns_per_column",
+          lambda: [amd.compute.take(c, mono, boundscheck=False) for c in cols.values()], 4 * 20.25 * S)
+        del extra, cols, batch
+    except Exception as e:   # (an out-of-memory here must not cost the rest of the line)
+        sec["take_record_batch_4_columns"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     out["secondary_configs"] = {"rows": n, "selected_rows": int(S), **sec}
     del values, validity, mask, mvalid, dv, dm, dmn, mono, ridx, di
     if not EMU:

@@ -152,6 +152,17 @@ int arx_check_index_bounds(const ArxSpan* indices, int index_type, uint64_t uppe
  * incremented by the number of valid output rows (caller zeroes it). */
 int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int index_type,
              void* out_data, void* out_validity, int64_t* valid_count, void* stream);
+
+/* The same gather for SEVERAL fixed-width columns by one index array in one launch — what TakeRAR / TakeTAT
+ * (vector_selection_take_internal.cc:619-660: `take` of a RecordBatch / Table) get by running TakeAAA column after
+ * column; here the indices and their validity are read once per row and every column is gathered behind them.
+ * columns / byte_widths / out_data / out_validity: arrays of num_columns (1..16) entries (host memory; the buffers they
+ * point to are device memory); out_validity[c] may be NULL iff neither column c nor the indices have a validity buffer;
+ * valid_counts: device int64[num_columns] (caller-zeroed) or NULL.  Per column the result is arx_take's.  Bounds are
+ * the caller's (arx_check_index_bounds against the shortest column, once).  Asynchronous. */
+int arx_take_columns(const ArxSpan* columns, const int32_t* byte_widths, int num_columns, const ArxSpan* indices,
+                     int index_type, void* const* out_data, void* const* out_validity, int64_t* valid_counts,
+                     void* stream);
 /* The same for BOOLEAN values (bit-packed data buffer, values->offset in bits): out bit i = value bit
  * idx[i], 0 for null slots (Gather with 1-bit values, gather_internal.h).  out_bits / out_validity:
  * ceil(M/64) 64-bit words, zero padded.  A filter on boolean values is arx_mask_to_indices + this. */

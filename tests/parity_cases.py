@@ -93,6 +93,51 @@ def check_take(amd, values: HostArray, indices: HostArray, boundscheck=True, use
     return out
 
 
+def check_take_record_batch(amd, rng, dtypes, n, m, idx_dtype=np.uint32, value_null_p=0.1, index_null_p=0.05,
+                            offsets=True, use_pyarrow=True):
+    """`take` of a RecordBatch (TakeRAR, vector_selection_take_internal.cc:619-633): the fixed-width columns go through
+    arx_take_columns (one launch); every column must equal the oracle's / pyarrow's per-column take — values, validity,
+    padding bits, null counts — including columns with and without nulls, different offsets, and an out-of-bounds index
+    reported once with the reference's text."""
+    cols, host = {}, {}
+    for j, dt in enumerate(dtypes):
+        h = util.random_array(rng, dt, n, null_p=(value_null_p if j % 3 != 1 else 0.0), offset=(j * 3 if offsets else 0))
+        host[f"c{j}"] = h
+        cols[f"c{j}"] = h.to_device(amd)
+    idx = util.random_array(rng, idx_dtype, m, null_p=index_null_p, offset=(2 if offsets else 0), lo=0, hi=max(n - 1, 0))
+    di = idx.to_device(amd)
+    out = amd.compute.take(amd.compute.RecordBatch(cols), di)
+    assert list(out.columns) == list(cols)
+    for name, h in host.items():
+        got = out.columns[name]
+        want, want_bm, want_vc = O.take(h.data_bytes(), h.valid_bitmap(), h.offset, np.ascontiguousarray(idx.values),
+                                        idx.valid_bitmap(), idx.offset, m, True)
+        tag = f"take_record_batch[{name}:{h.dtype},n={n},m={m}]"
+        assert got.length == m
+        assert_equal(_data_np(got, h.dtype), want, tag + " data bytes")
+        gv, pad_ok = _logical_valid(got)
+        assert pad_ok
+        assert_equal(gv, oracle_bitmap_to_bool(want_bm, m), tag + " validity")
+        assert got.null_count == m - want_vc, tag + " null_count"
+        if use_pyarrow and pc is not None:
+            ref = pc.take(h.to_pyarrow(), idx.to_pyarrow())
+            assert ref.null_count == got.null_count
+            rvalid = ~np.asarray(ref.is_null())
+            assert_equal(gv, rvalid, tag + " validity vs pyarrow")
+    if m:
+        bad = idx.values.copy()
+        pos = idx.offset + m // 2
+        bad[pos] = n + 7
+        valid2 = None
+        if idx.valid is not None:   # make sure the offending slot is a valid index
+            valid2 = idx.valid.copy()
+            valid2[pos] = True
+        idx2 = HostArray(bad, valid2, idx.offset, m)
+        with pytest.raises(amd.ArrowIndexError) as ei:
+            amd.compute.take(amd.compute.RecordBatch(cols), idx2.to_device(amd))
+        assert str(ei.value) == f"Index {n + 7} out of bounds", str(ei.value)
+
+
 def check_take_out_of_bounds(amd, values: HostArray, indices: HostArray):
     dv, di = values.to_device(amd), indices.to_device(amd)
     bad = O.check_index_bounds(np.ascontiguousarray(indices.values), indices.valid_bitmap(),

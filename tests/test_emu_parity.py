@@ -881,3 +881,18 @@ def test_grouper_declines_and_overflows(emu_ctx):
                                                   ((np.int64, np.int16), 4000, 3500, 0.0)])
 def test_group_by_wide_and_multiple_keys(emu_ctx, dtypes, n, card, null_p):
     P.check_group_by_keys(emu_ctx, rng_for("group_by_keys", len(dtypes), n, card), dtypes, n, card, null_p)
+
+
+@pytest.mark.parametrize("dtypes,n,m,idx_dtype", [
+    ((np.int64, np.int32, np.float64), 5000, 3000, np.uint32),
+    ((np.int8, np.int16, np.int64, np.uint64, np.float32), 777, 2000, np.int64),
+    ((np.int64,) * 17, 300, 500, np.uint16),        # more than one group of 16 columns
+    ((np.int32, np.int64), 1000, 0, np.int32), ((np.int64, np.int64), 64, 64, np.uint8)])
+def test_take_record_batch_in_one_launch(emu_ctx, dtypes, n, m, idx_dtype):
+    P.check_take_record_batch(emu_ctx, rng_for("take-rb", len(dtypes), n, m), dtypes, n, m, idx_dtype)
+
+
+def test_take_record_batch_without_nulls_has_no_bitmaps(emu_ctx):
+    rng = rng_for("take-rb-nonull")
+    P.check_take_record_batch(emu_ctx, rng, (np.int64, np.int32), 4000, 4096, np.uint32, value_null_p=0.0, index_null_p=0.0,
+                              offsets=False)

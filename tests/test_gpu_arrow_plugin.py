@@ -803,6 +803,7 @@ SELECTION_META_SCRIPT = textwrap.dedent(r'''
     h_batch, d_batch = pa.record_batch(cols), pa.record_batch(d_cols)
     h_table, d_table = pa.table(cols), pa.table(d_cols)
     f0, t0 = lib.arrow_amd_plugin_calls(b"array_filter", 1), lib.arrow_amd_plugin_calls(b"array_take", 1)
+    tc0 = lib.arrow_amd_plugin_calls(b"take_columns", 1)
     for sel in ("drop", "emit_null"):
         want = pc.filter(h_table, mask, null_selection_behavior=sel)
         got_b = dev_filter(d_batch, d_mask, sel)
@@ -819,6 +820,8 @@ SELECTION_META_SCRIPT = textwrap.dedent(r'''
     ncols = len(cols)
     assert lib.arrow_amd_plugin_calls(b"array_filter", 1) == f0 + 2 * (2 * ncols + 1)
     assert lib.arrow_amd_plugin_calls(b"array_take", 1) >= t0 + 2 * ncols + 1
+    # the four fixed-width columns of the batch and of the table went through ONE launch each (arx_take_columns)
+    assert lib.arrow_amd_plugin_calls(b"take_columns", 1) == tc0 + 2
     # bounds errors keep the reference's message
     try:
         dev_take(d_table, to_device(pa.array([0, n], pa.int64())))

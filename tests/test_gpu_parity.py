@@ -1153,3 +1153,18 @@ def test_grouper_hot_keys_and_overflow(gpu_ctx):
                                                   ((np.int64, np.int16), 600_000, 500_000, 0.0)])
 def test_group_by_wide_and_multiple_keys(gpu_ctx, dtypes, n, card, null_p):
     P.check_group_by_keys(gpu_ctx, rng_for("group_by_keys", len(dtypes), n, card), dtypes, n, card, null_p)
+
+
+@pytest.mark.parametrize("dtypes,n,m,idx_dtype", [
+    ((np.int64, np.int32, np.float64), 3_000_000, 1_000_003, np.uint32),
+    ((np.int8, np.int16, np.int64, np.uint64, np.float32), 77_777, 2_000_000, np.int64),
+    ((np.int64,) * 17, 30_000, 500_000, np.uint16),
+    ((np.int32, np.int64), 1000, 0, np.int32), ((np.int64, np.int64), 64, 64, np.uint8)])
+def test_take_record_batch_in_one_launch(gpu_ctx, dtypes, n, m, idx_dtype):
+    P.check_take_record_batch(gpu_ctx, rng_for("take-rb", len(dtypes), n, m), dtypes, n, m, idx_dtype)
+
+
+def test_take_record_batch_without_nulls_has_no_bitmaps(gpu_ctx):
+    rng = rng_for("take-rb-nonull")
+    P.check_take_record_batch(gpu_ctx, rng, (np.int64, np.int32), 400_000, 1 << 20, np.uint32, value_null_p=0.0,
+                              index_null_p=0.0, offsets=False)

@@ -212,7 +212,8 @@ def test_bench_single_rank_line_has_every_leg():
     other = line["other_paths"]
     assert other["cast_f64_f32"]["bit_exact_vs_round_to_nearest_even_sample"] is True
     for name in ("filter_drop_5pct_mask_nulls", "filter_emit_null_5pct_mask_nulls", "take_random_uint32",
-                 "take_monotonic_boundscheck", "filter_drop_selectivity_25pct", "filter_drop_selectivity_50pct"):
+                 "take_monotonic_boundscheck", "filter_drop_selectivity_25pct", "filter_drop_selectivity_50pct",
+                 "take_record_batch_4_columns_one_launch", "take_record_batch_4_columns_per_column"):
         assert name in other["secondary_configs"]
     assert {"greater_f64", "sort_indices_u64_1pct_nulls", "hash_sum_1pct_null_values"} <= set(other)
     assert line["hash_sum"]["checksum_matches_sum_of_values"] and line["sort_indices"]["permutation_and_order_checks"]
