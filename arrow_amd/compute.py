@@ -549,6 +549,76 @@ def _exec_compare(op_name):
     return run
 
 
+def _numeric_operands(left, right):
+    """(array operand, n, left ptr | None, right ptr | None, host scalar holders) for the *_numeric entry points."""
+    arr = left if isinstance(left, Array) else right
+    n = arr.length
+    if isinstance(left, Array) and isinstance(right, Array) and left.length != right.length:
+        raise ArrowInvalid("Array arguments must all be the same length")
+    dt = arr.type.np_dtype
+
+    def scalar_ptr(x):
+        if isinstance(x, Array):
+            return None, None
+        v = _scalar_value(x)
+        holder = np.zeros(1, dtype=dt)
+        if v is not None:
+            holder[0] = dt.type(v)
+        return holder, holder.ctypes.data
+
+    lh, lsp = scalar_ptr(left)
+    rh, rsp = scalar_ptr(right)
+    lp = left.values_ptr() if isinstance(left, Array) else None
+    rp = right.values_ptr() if isinstance(right, Array) else None
+    return arr, n, lp, lsp, rp, rsp, (lh, rh)
+
+
+def _exec_compare_numeric(op_name):
+    code = _CMP_CODE[op_name]
+
+    def run(args, options):
+        """CompareKernel<Type, Op>::Exec (scalar_compare.cc:259-298) for every numeric Type (registration :398-446)."""
+        left, right = args
+        arr, n, lp, lsp, rp, rsp, _keep = _numeric_operands(left, right)
+        dev = arr.device
+        lib, stream = _lib_and_stream(dev)
+        out = alloc(bitmap_nbytes(n), dev, zero=True)
+        with tracing.span("arx_compare_numeric"):
+            check(lib.arx_compare_numeric(code, _NUM_TYPE_ID[arr.type.name], lp, lsp, rp, rsp, n, out.data_ptr(), stream))
+        validity, nc = _propagate_validity([left, right], n, dev)
+        return Array(bool_, n, [validity, out], nc, 0)
+    return run
+
+
+def _exec_arith_numeric(op_name, checked):
+    code = _ARITH_CODE[op_name]
+
+    def run(args, options):
+        """ScalarBinary<T, T, T, Add|Subtract|Multiply> / ScalarBinaryNotNull<..., *Checked> for every numeric T
+        (base_arithmetic_internal.h:45-150,290-364)."""
+        left, right = args
+        arr, n, lp, lsp, rp, rsp, _keep = _numeric_operands(left, right)
+        dev = arr.device
+        lib, stream = _lib_and_stream(dev)
+        out = alloc(n * arr.type.byte_width, dev)
+        validity, nc = _propagate_validity([left, right], n, dev)
+        null_scalar = any(isinstance(a, Scalar) and not a.is_valid for a in (left, right))
+        is_f = arr.type.name in ("float", "double")
+        do_check = checked and not is_f and not null_scalar      # a null scalar makes every slot null: nothing to check
+        flag = torch.zeros(1, dtype=torch.int32, device=dev) if do_check else None
+
+        def vptr(a):
+            return (a.validity.data_ptr(), a.offset) if isinstance(a, Array) and a.may_have_nulls() else (None, 0)
+        (lvp, lvo), (rvp, rvo) = vptr(left), vptr(right)
+        with tracing.span("arx_arith_numeric"):
+            check(lib.arx_arith_numeric(code, 1 if do_check else 0, _NUM_TYPE_ID[arr.type.name], lp, lsp, lvp, lvo, rp, rsp,
+                                        rvp, rvo, n, out.data_ptr(), None if flag is None else flag.data_ptr(), stream))
+        if flag is not None and int(flag.cpu()[0]) != 0:
+            raise ArrowInvalid("overflow")   # AddChecked::Call, base_arithmetic_internal.h:77
+        return Array(arr.type, n, [validity, out], nc, 0)
+    return run
+
+
 def _exec_add(args, options):
     """ScalarBinary<..., Add> (codegen_internal.h:814, base_arithmetic_internal.h:45-80)."""
     left, right = args
@@ -1029,18 +1099,26 @@ def _build_registry() -> FunctionRegistry:
     _cast_table["double"].add_kernel(Kernel((int64,), _exec_cast_i64_f64, float64))
     reg.add_function(Function("cast", Function.META, 1, None, _cast_meta))
 
+    from .array import type_from_name
+    numeric_types = [type_from_name(nm) for nm in _NUM_TYPE_ID]
     f = Function("greater", Function.SCALAR, 2)
+    for t in numeric_types:      # every numeric type first; the tuned 64-bit kernels are added after them and win
+        f.add_kernel(Kernel((t, t), _exec_compare_numeric("greater"), bool_))
     f.add_kernel(Kernel((float64, float64), _exec_greater, bool_))
     f.add_kernel(Kernel((int64, int64), _exec_greater, bool_))
     reg.add_function(f)
 
     for name in ("equal", "not_equal", "greater_equal", "less", "less_equal"):
         f = Function(name, Function.SCALAR, 2)
+        for t in numeric_types:
+            f.add_kernel(Kernel((t, t), _exec_compare_numeric(name), bool_))
         f.add_kernel(Kernel((float64, float64), _exec_compare(name), bool_))
         f.add_kernel(Kernel((int64, int64), _exec_compare(name), bool_))
         reg.add_function(f)
 
     f = Function("add", Function.SCALAR, 2)
+    for t in numeric_types:
+        f.add_kernel(Kernel((t, t), _exec_arith_numeric("add", False), t))
     f.add_kernel(Kernel((int64, int64), _exec_add, int64))
     f.add_kernel(Kernel((float64, float64), _exec_add, float64))
     reg.add_function(f)
@@ -1048,6 +1126,8 @@ def _build_registry() -> FunctionRegistry:
                               ("add_checked", "add", True), ("subtract_checked", "subtract", True),
                               ("multiply_checked", "multiply", True)):
         f = Function(name, Function.SCALAR, 2)
+        for t in numeric_types:
+            f.add_kernel(Kernel((t, t), _exec_arith_numeric(op, checked), t))
         f.add_kernel(Kernel((int64, int64), _exec_arith(op, checked), int64))
         f.add_kernel(Kernel((float64, float64), _exec_arith(op, checked), float64))
         reg.add_function(f)

@@ -15,6 +15,8 @@
 
 #include <limits>
 
+#include <string.h>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -708,6 +710,94 @@ static int compare_any(int op, const T* left, T ls, const T* right, T rs, int64_
   }
 }
 
+// ------------------------------------------------------------------ compare / arithmetic on every numeric type
+// The comparison family and add / subtract / multiply (+ _checked) for the element types the 64-bit kernels above do
+// not take (int8 ... uint32, uint64, float): the same Call bodies (scalar_compare.cc:38-64,
+// base_arithmetic_internal.h:45-150,290-364) instantiated per type — unchecked integer results wrap in the type's
+// width, the checked forms report an overflow of THAT type (only where both operands are valid).
+// One lane per row and step, U steps in flight: a wave reads 64 * sizeof(T) contiguous bytes per load.
+template <typename T, int LK, int RK, int CMP>
+__global__ __launch_bounds__(kBlock) void compare_rows_kernel(const T* __restrict__ left, T lscalar,
+                                                              const T* __restrict__ right, T rscalar, int64_t n,
+                                                              uint64_t* __restrict__ out) {
+  constexpr int U = 8;
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwords = (n + 63) >> 6;
+  const int64_t niter = (nwords + U - 1) / U;
+  const int64_t last = n - 1;
+  for (int64_t it = wave_g; it < niter; it += nwaves) {
+    const int64_t w0 = it * U;
+    T l[U], r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = ((w0 + u) << 6) + lane;
+      const int64_t rc = row <= last ? row : last;   // unconditional (clamped) loads
+      l[u] = LK == kArray ? left[rc] : lscalar;
+      r[u] = RK == kArray ? right[rc] : rscalar;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = ((w0 + u) << 6) + lane;
+      const uint64_t bal = __ballot(row <= last && cmp_apply<CMP>(l[u], r[u]));
+      if (lane == 0 && (w0 + u) < nwords) out[w0 + u] = bal;
+    }
+  }
+}
+
+template <typename T, int CMP>
+static int compare_rows_shapes(const T* left, T ls, const T* right, T rs, int64_t n, uint64_t* out, hipStream_t st) {
+  const unsigned grid = stream_grid(kWavesPerBlock * 64 * 8, n);
+  if (left != nullptr && right != nullptr) {
+    hipLaunchKernelGGL((compare_rows_kernel<T, kArray, kArray, CMP>), dim3(grid), dim3(kBlock), 0, st, left, ls, right, rs, n, out);
+  } else if (left != nullptr) {
+    hipLaunchKernelGGL((compare_rows_kernel<T, kArray, kScalar, CMP>), dim3(grid), dim3(kBlock), 0, st, left, ls, right, rs, n, out);
+  } else if (right != nullptr) {
+    hipLaunchKernelGGL((compare_rows_kernel<T, kScalar, kArray, CMP>), dim3(grid), dim3(kBlock), 0, st, left, ls, right, rs, n, out);
+  } else {
+    set_error("compare: at least one operand must be an array");
+    return ARX_INVALID;
+  }
+  ARX_CHECK_LAUNCH("compare_rows_kernel");
+  return ARX_OK;
+}
+
+template <typename T>
+static int compare_rows_any(int op, const void* left, const void* lsp, const void* right, const void* rsp, int64_t n,
+                            uint64_t* out, hipStream_t st) {
+  const T* l = static_cast<const T*>(left);
+  const T* r = static_cast<const T*>(right);
+  T ls = T(0), rs = T(0);
+  if (l == nullptr && lsp != nullptr) memcpy(&ls, lsp, sizeof(T));
+  if (r == nullptr && rsp != nullptr) memcpy(&rs, rsp, sizeof(T));
+  switch (op) {
+    case ARX_CMP_EQUAL: return compare_rows_shapes<T, ARX_CMP_EQUAL>(l, ls, r, rs, n, out, st);
+    case ARX_CMP_NOT_EQUAL: return compare_rows_shapes<T, ARX_CMP_NOT_EQUAL>(l, ls, r, rs, n, out, st);
+    case ARX_CMP_GREATER: return compare_rows_shapes<T, ARX_CMP_GREATER>(l, ls, r, rs, n, out, st);
+    case ARX_CMP_GREATER_EQUAL: return compare_rows_shapes<T, ARX_CMP_GREATER_EQUAL>(l, ls, r, rs, n, out, st);
+    case ARX_CMP_LESS: return compare_rows_shapes<T, ARX_CMP_GREATER>(r, rs, l, ls, n, out, st);
+    case ARX_CMP_LESS_EQUAL: return compare_rows_shapes<T, ARX_CMP_GREATER_EQUAL>(r, rs, l, ls, n, out, st);
+    default:
+      set_error("unknown compare op %d", op);
+      return ARX_INVALID;
+  }
+}
+
+template <typename T>
+static int arith_numeric_any(int op, int checked, const void* left, const void* lsp, const Bits& lv, const void* right,
+                             const void* rsp, const Bits& rv, int64_t n, void* out, unsigned int* overflow, hipStream_t st) {
+  const T* l = static_cast<const T*>(left);
+  const T* r = static_cast<const T*>(right);
+  T ls = T(0), rs = T(0);
+  if (l == nullptr && lsp != nullptr) memcpy(&ls, lsp, sizeof(T));
+  if (r == nullptr && rsp != nullptr) memcpy(&rs, rsp, sizeof(T));
+  if (checked && std::is_integral<T>::value) {
+    return arith_any<T, true>(op, l, ls, r, rs, lv, rv, n, static_cast<T*>(out), overflow, st);
+  }
+  return arith_any<T, false>(op, l, ls, r, rs, lv, rv, n, static_cast<T*>(out), nullptr, st);
+}
+
 template <typename OutT>
 static int cast_i64_checked(const char* what, const ArxSpan* values, int unchecked, int64_t lo, int64_t hi, void* ws,
                             size_t ws_bytes, OutT* out, void* stream) {
@@ -992,6 +1082,69 @@ int arx_arith_checked_i64(int op, const int64_t* left, int64_t left_scalar, cons
   const Bits rv = make_bits(right_validity, right_offset, length);
   return arith_any<int64_t, true>(op, left, left_scalar, right, right_scalar, lv, rv, length, out, overflow_flag,
                                   as_stream(stream));
+}
+
+int arx_compare_numeric(int op, int num_type, const void* left, const void* left_scalar, const void* right,
+                        const void* right_scalar, int64_t length, uint64_t* out_bits, void* stream) {
+  if (length == 0) return ARX_OK;
+  if (length < 0 || out_bits == nullptr || (left == nullptr && left_scalar == nullptr) ||
+      (right == nullptr && right_scalar == nullptr)) {
+    set_error("bad arguments to compare");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  switch (num_type) {
+    case ARX_NUM_INT8: return compare_rows_any<int8_t>(op, left, left_scalar, right, right_scalar, length, out_bits, st);
+    case ARX_NUM_UINT8: return compare_rows_any<uint8_t>(op, left, left_scalar, right, right_scalar, length, out_bits, st);
+    case ARX_NUM_INT16: return compare_rows_any<int16_t>(op, left, left_scalar, right, right_scalar, length, out_bits, st);
+    case ARX_NUM_UINT16: return compare_rows_any<uint16_t>(op, left, left_scalar, right, right_scalar, length, out_bits, st);
+    case ARX_NUM_INT32: return compare_rows_any<int32_t>(op, left, left_scalar, right, right_scalar, length, out_bits, st);
+    case ARX_NUM_UINT32: return compare_rows_any<uint32_t>(op, left, left_scalar, right, right_scalar, length, out_bits, st);
+    case ARX_NUM_INT64: return compare_rows_any<int64_t>(op, left, left_scalar, right, right_scalar, length, out_bits, st);
+    case ARX_NUM_UINT64: return compare_rows_any<uint64_t>(op, left, left_scalar, right, right_scalar, length, out_bits, st);
+    case ARX_NUM_FLOAT32: return compare_rows_any<float>(op, left, left_scalar, right, right_scalar, length, out_bits, st);
+    case ARX_NUM_FLOAT64: return compare_rows_any<double>(op, left, left_scalar, right, right_scalar, length, out_bits, st);
+    default:
+      set_error("compare: unknown numeric type %d", num_type);
+      return ARX_NOT_IMPLEMENTED;
+  }
+}
+
+int arx_arith_numeric(int op, int checked, int num_type, const void* left, const void* left_scalar,
+                      const void* left_validity, int64_t left_offset, const void* right, const void* right_scalar,
+                      const void* right_validity, int64_t right_offset, int64_t length, void* out,
+                      uint32_t* overflow_flag, void* stream) {
+  if (length == 0) return ARX_OK;
+  if (length < 0 || out == nullptr || (left == nullptr && left_scalar == nullptr) ||
+      (right == nullptr && right_scalar == nullptr) || (left == nullptr && right == nullptr)) {
+    set_error("bad arguments to arithmetic");
+    return ARX_INVALID;
+  }
+  const bool is_float = num_type == ARX_NUM_FLOAT32 || num_type == ARX_NUM_FLOAT64;
+  if (checked && !is_float && overflow_flag == nullptr) {
+    set_error("arx_arith_numeric: overflow_flag is NULL");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  const Bits lv = make_bits(left_validity, left_offset, length);
+  const Bits rv = make_bits(right_validity, right_offset, length);
+#define ARX_ARITH_T(T) return arith_numeric_any<T>(op, checked, left, left_scalar, lv, right, right_scalar, rv, length, out, overflow_flag, st)
+  switch (num_type) {
+    case ARX_NUM_INT8: ARX_ARITH_T(int8_t);
+    case ARX_NUM_UINT8: ARX_ARITH_T(uint8_t);
+    case ARX_NUM_INT16: ARX_ARITH_T(int16_t);
+    case ARX_NUM_UINT16: ARX_ARITH_T(uint16_t);
+    case ARX_NUM_INT32: ARX_ARITH_T(int32_t);
+    case ARX_NUM_UINT32: ARX_ARITH_T(uint32_t);
+    case ARX_NUM_INT64: ARX_ARITH_T(int64_t);
+    case ARX_NUM_UINT64: ARX_ARITH_T(uint64_t);
+    case ARX_NUM_FLOAT32: ARX_ARITH_T(float);
+    case ARX_NUM_FLOAT64: ARX_ARITH_T(double);
+    default:
+      set_error("arithmetic: unknown numeric type %d", num_type);
+      return ARX_NOT_IMPLEMENTED;
+  }
+#undef ARX_ARITH_T
 }
 
 int arx_divide_i64(const int64_t* left, int64_t left_scalar, const void* left_validity, int64_t left_offset,

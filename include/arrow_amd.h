@@ -305,6 +305,21 @@ int arx_arith_checked_i64(int op, const int64_t* left, int64_t left_scalar, cons
                           int64_t left_offset, const int64_t* right, int64_t right_scalar,
                           const void* right_validity, int64_t right_offset, int64_t length, int64_t* out,
                           unsigned int* overflow_flag, void* stream);
+
+/* The comparison family and add / subtract / multiply (+ _checked) for EVERY numeric element type (num_type:
+ * ARX_NUM_*; both operands and, for arithmetic, the result have that type): the same Call bodies as above
+ * instantiated per type, as the reference registers them for all of NumericTypes() (scalar_compare.cc:398-446,
+ * scalar_arithmetic.cc AddArithmeticFunctions).  Unchecked integer results wrap in the type's width (the reference
+ * computes them in the unsigned type, base_arithmetic_internal.h:45-68; int16 / uint16 multiply through uint32,
+ * :303-325 — the same bits); the checked forms report an overflow of that type.  float / double: IEEE.
+ * left / right == NULL: that operand is the scalar *left_scalar / *right_scalar (host pointer to one value of the type).
+ * out_bits / out / overflow_flag / validity as for the 64-bit entry points above.  Asynchronous. */
+int arx_compare_numeric(int op, int num_type, const void* left, const void* left_scalar, const void* right,
+                        const void* right_scalar, int64_t length, uint64_t* out_bits, void* stream);
+int arx_arith_numeric(int op, int checked, int num_type, const void* left, const void* left_scalar,
+                      const void* left_validity, int64_t left_offset, const void* right, const void* right_scalar,
+                      const void* right_validity, int64_t right_offset, int64_t length, void* out,
+                      uint32_t* overflow_flag, void* stream);
 /* divide / divide_checked (Divide, DivideChecked, base_arithmetic_internal.h:366-424), visited only where both
  * operands are valid.  int64: truncating division; a zero divisor fails with "divide by zero" in both forms;
  * INT64_MIN / -1 is 0 unchecked and "overflow" checked.  double: IEEE division, the checked form fails on a zero

@@ -247,25 +247,34 @@ def add(left, right) -> np.ndarray:
     return out
 
 
-def arith(op: str, left, right, both_valid=None):
-    """add / subtract / multiply on int64 or float64 operands (arrays or python scalars).
-    Add / Subtract / Multiply (base_arithmetic_internal.h:45-68,98-120,290-330): integer results
-    wrap around (computed in unsigned arithmetic there); AddChecked / SubtractChecked /
-    MultiplyChecked (:70-96,121-150,341-364) give the same values and additionally report an
-    overflow, but only for slots the kernel visits, i.e. where both operands are valid.
+def arith(op: str, left, right, both_valid=None, dtype=None):
+    """add / subtract / multiply on operands of ONE numeric type (arrays or python scalars; `dtype` names it when
+    neither side is a typed array — default: int64 / float64 as numpy infers).
+    Add / Subtract / Multiply (base_arithmetic_internal.h:45-68,98-120,290-330): integer results wrap around in the
+    type's width (computed in the unsigned type there; 16-bit multiplies go through uint32, :303-325, same bits);
+    AddChecked / SubtractChecked / MultiplyChecked (:70-96,121-150,341-364) give the same values and additionally
+    report an overflow of that type, but only for slots the kernel visits, i.e. where both operands are valid.
+    Floats: the IEEE operation in the operand type (float32 stays float32).
     Returns (result, overflowed: bool)."""
     la, ra = np.asarray(left), np.asarray(right)
-    if la.dtype.kind == "f" or ra.dtype.kind == "f":
+    if dtype is None:
+        dtype = la.dtype if la.ndim else ra.dtype
+        if dtype.kind == "f" or la.dtype.kind == "f" or ra.dtype.kind == "f":
+            dtype = dtype if dtype.kind == "f" else np.dtype(np.float64)
+    dtype = np.dtype(dtype)
+    if dtype.kind == "f":
         with np.errstate(all="ignore"):
-            res = {"add": np.add, "subtract": np.subtract, "multiply": np.multiply}[op](la.astype(np.float64), ra.astype(np.float64))
-        return res, False
+            res = {"add": np.add, "subtract": np.subtract, "multiply": np.multiply}[op](la.astype(dtype), ra.astype(dtype))
+        return np.asarray(res, dtype=dtype), False
     n = max(la.size if la.ndim else 1, ra.size if ra.ndim else 1)
     lo = np.broadcast_to(la.astype(object), (n,))
     ro = np.broadcast_to(ra.astype(object), (n,))
     exact = [int(a) + int(b) if op == "add" else int(a) - int(b) if op == "subtract" else int(a) * int(b)
              for a, b in zip(lo, ro)]
-    wrapped = np.array([((x + 2**63) % 2**64) - 2**63 for x in exact], dtype=np.int64)
-    ovf = np.array([not (-2**63 <= x < 2**63) for x in exact], dtype=bool)
+    info = np.iinfo(dtype)
+    span = 1 << (8 * dtype.itemsize)
+    wrapped = np.array([((x - info.min) % span) + info.min for x in exact], dtype=object).astype(dtype)
+    ovf = np.array([not (info.min <= x <= info.max) for x in exact], dtype=bool)
     if both_valid is not None:
         ovf &= np.asarray(both_valid, bool)
     return wrapped, bool(ovf.any())

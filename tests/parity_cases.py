@@ -506,6 +506,90 @@ def check_arithmetic(amd, rng, n=8000, use_pyarrow=True):
         assert pc.add_checked(masked.to_pyarrow(), one.to_pyarrow()).to_pylist()[3:] == [8, -3]
 
 
+def check_numeric_compare_arith(amd, rng, dtype, n=6000, use_pyarrow=True):
+    """The comparison family and add / subtract / multiply (+ _checked) on ONE numeric element type (any of int8 ...
+    uint64, float32, float64): array x array and both scalar orders, sliced operands with nulls — bits / values equal
+    the oracle on every valid slot and pyarrow's result as a whole; integer results wrap in the type's width; the
+    checked forms raise "overflow" exactly when a slot with both operands valid overflows THAT type."""
+    dt = np.dtype(dtype)
+    is_int = dt.kind in "iu"
+    if is_int:
+        info = np.iinfo(dt)
+        small = int(min(info.max, 11))          # products of two values stay inside every type
+        lo = -small if dt.kind == "i" else 0
+        a = util.random_array(rng, dtype, n, null_p=0.1, offset=3, tail=2, lo=lo, hi=small)
+        b = util.random_array(rng, dtype, n, null_p=0.05, offset=1, tail=4, lo=lo, hi=small)
+        sc = dt.type(3)
+    else:
+        a = util.random_array(rng, dtype, n, null_p=0.1, offset=3, tail=2)
+        b = util.random_array(rng, dtype, n, null_p=0.05, offset=1, tail=4)
+        a.values[:] = np.round(a.values * 2) / 2
+        b.values[:] = np.round(b.values * 2) / 2
+        a.values[3:9] = [np.nan, np.inf, -np.inf, 0.0, -0.0, np.nan]
+        b.values[1:7] = [np.nan, np.inf, 1.0, -0.0, 0.0, 2.0]
+        sc = dt.type(0.5)
+    da, db = a.to_device(amd), b.to_device(amd)
+    la, lb = a.logical_values(), b.logical_values()
+    va, vb = a.logical_valid(), b.logical_valid()
+    uview = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[dt.itemsize]
+    for op in ("equal", "not_equal", "greater", "greater_equal", "less", "less_equal"):
+        fn = getattr(amd.compute, op)
+        for out, want_bits, want_valid in ((fn(da, db), O.compare(op, la, lb), va & vb),
+                                           (fn(da, sc.item()), O.compare(op, la, sc), va),
+                                           (fn(sc.item(), db), O.compare(op, sc, lb), vb)):
+            bits, pad_ok = device_bitmap_to_bool(out.data, n)
+            assert pad_ok
+            assert_equal(bits, want_bits, f"{op}[{dt.name}] bits")
+            assert_equal(_logical_valid(out)[0], want_valid, f"{op}[{dt.name}] validity")
+        if use_pyarrow and pc is not None:
+            assert fn(da, db).to_pyarrow().equals(getattr(pc, op)(a.to_pyarrow(), b.to_pyarrow())), (op, dt.name)
+    for op in ("add", "subtract", "multiply"):
+        if is_int and dt.kind == "u" and op == "subtract":
+            continue       # unsigned differences of random operands wrap / overflow: covered by the edge cases below
+        for checked in (False, True):
+            fn = getattr(amd.compute, op + ("_checked" if checked else ""))
+            for out, l, r, valid in ((fn(da, db), la, lb, va & vb), (fn(da, sc.item()), la, sc, va),
+                                     (fn(sc.item(), db), sc, lb, vb)):
+                want, ovf = O.arith(op, l, r, valid, dtype=dt)
+                assert not ovf
+                assert out.type.name == da.type.name
+                got, want = _data_np(out, dtype).copy(), np.asarray(want).copy()
+                if not is_int:       # a NaN result is a NaN; its sign / payload is the FPU's (x86 and gfx950 differ)
+                    got[np.isnan(got)] = np.nan
+                    want[np.isnan(want)] = np.nan
+                assert_equal(got.view(uview)[valid], want.view(uview)[valid], f"{op} checked={checked} {dt.name}")
+                assert_equal(_logical_valid(out)[0], valid, f"{op}[{dt.name}] validity")
+            if use_pyarrow and pc is not None:
+                ref = getattr(pc, op + ("_checked" if checked else ""))(a.to_pyarrow(), b.to_pyarrow())
+                assert fn(da, db).to_pyarrow().equals(ref, **({} if is_int else {"nans_equal": True})), (op, checked, dt.name)
+    if not is_int:
+        return
+    # edges of the type: unchecked wraps in ITS width; checked raises "overflow" — but not under a null
+    info = np.iinfo(dt)
+    edge = HostArray(np.array([info.max, info.min, info.max // 2 + 1, 5, 7], dtype=dt), None, 0, 5)
+    others = {"add": np.array([1, 0, info.max // 2 + 1, 3, 4], dtype=dt),
+              "subtract": np.array([0, 1, 0, 3, 4], dtype=dt),
+              "multiply": np.array([2, 1, 2, 3, 4], dtype=dt)}       # each overflows in slot 0, 1 or 2
+    de = edge.to_device(amd)
+    for op in ("add", "subtract", "multiply"):
+        other = HostArray(others[op], None, 0, 5)
+        do = other.to_device(amd)
+        want, ovf = O.arith(op, edge.values, other.values, dtype=dt)
+        assert ovf, (op, dt.name)
+        assert_equal(_data_np(getattr(amd.compute, op)(de, do), dtype), want, f"{op}[{dt.name}] wraps")
+        with pytest.raises(amd.ArrowInvalid, match="overflow"):
+            getattr(amd.compute, op + "_checked")(de, do)
+        if use_pyarrow and pc is not None:
+            assert getattr(amd.compute, op)(de, do).to_pyarrow().equals(getattr(pc, op)(edge.to_pyarrow(), other.to_pyarrow()))
+            with pytest.raises(pa.lib.ArrowInvalid, match="overflow"):
+                getattr(pc, op + "_checked")(edge.to_pyarrow(), other.to_pyarrow())
+        masked = HostArray(edge.values.copy(), np.array([False, False, False, True, True]), 0, 5)
+        out = getattr(amd.compute, op + "_checked")(masked.to_device(amd), do)
+        want, ovf = O.arith(op, masked.values, other.values, masked.valid, dtype=dt)
+        assert not ovf
+        assert_equal(_data_np(out, dtype)[masked.valid], want[masked.valid], f"{op}_checked[{dt.name}] with null overflow slots")
+
+
 def check_divide(amd, rng, n=6000, use_pyarrow=True):
     """divide / divide_checked (Divide / DivideChecked, base_arithmetic_internal.h:366-424) on int64 and float64, array
     and scalar operands: results at visited slots, validity, and the error the LAST failing valid slot names;

@@ -896,3 +896,9 @@ def test_take_record_batch_without_nulls_has_no_bitmaps(emu_ctx):
     rng = rng_for("take-rb-nonull")
     P.check_take_record_batch(emu_ctx, rng, (np.int64, np.int32), 4000, 4096, np.uint32, value_null_p=0.0, index_null_p=0.0,
                               offsets=False)
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64,
+                                   np.float32, np.float64])
+def test_compare_and_arithmetic_on_every_numeric_type(emu_ctx, dtype):
+    P.check_numeric_compare_arith(emu_ctx, rng_for("numeric-ops", np.dtype(dtype).name), dtype, n=3000)

@@ -1168,3 +1168,9 @@ def test_take_record_batch_without_nulls_has_no_bitmaps(gpu_ctx):
     rng = rng_for("take-rb-nonull")
     P.check_take_record_batch(gpu_ctx, rng, (np.int64, np.int32), 400_000, 1 << 20, np.uint32, value_null_p=0.0,
                               index_null_p=0.0, offsets=False)
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64,
+                                   np.float32, np.float64])
+def test_compare_and_arithmetic_on_every_numeric_type(gpu_ctx, dtype):
+    P.check_numeric_compare_arith(gpu_ctx, rng_for("numeric-ops", np.dtype(dtype).name), dtype, n=1000003)
