@@ -947,6 +947,106 @@ DIVIDE_SCRIPT = textwrap.dedent(r'''
 ''')
 
 
+NUMERIC_OPS_SCRIPT = textwrap.dedent(r'''
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))   # sizes shrink for the emulated run
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(n) for n in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(n) for n in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    from pyarrow import acero
+    rng = np.random.default_rng(43)
+    n = SC(1_000_003)
+    cmp_fns = ("equal", "not_equal", "greater", "greater_equal", "less", "less_equal")
+    ari_fns = ("add", "subtract", "multiply", "add_checked", "subtract_checked", "multiply_checked")
+    types = [pa.int8(), pa.uint8(), pa.int16(), pa.uint16(), pa.int32(), pa.uint32(), pa.uint64(), pa.float32()]
+    c0, a0 = lib.arrow_amd_plugin_calls(b"compare", 1) + lib.arrow_amd_plugin_calls(b"greater", 1), lib.arrow_amd_plugin_calls(b"add", 1)
+    ran_c = ran_a = 0
+    for t in types:
+        npdt = t.to_pandas_dtype()
+        if pa.types.is_floating(t):
+            la, lb = (np.round(rng.standard_normal(n) * 4) / 2).astype(npdt), (np.round(rng.standard_normal(n) * 4) / 2).astype(npdt)
+            sc = 0.5
+        else:
+            hi = 11        # sums, differences (signed) and products of two values stay inside every type
+            lo = -hi if pa.types.is_signed_integer(t) else 0
+            la, lb = rng.integers(lo, hi + 1, n).astype(npdt), rng.integers(lo, hi + 1, n).astype(npdt)
+            if not pa.types.is_signed_integer(t):
+                la = (la + hi).astype(npdt)      # a >= b: unsigned differences do not wrap / overflow
+            sc = 3
+        a = pa.array(la, t, mask=rng.random(n) < 0.08)
+        b = pa.array(lb, t, mask=rng.random(n) < 0.05)
+        da, db = to_device(a), to_device(b)
+        s = pa.scalar(sc, t)
+        for name in cmp_fns + ari_fns:
+            fn = lambda x, y: pc.call_function(name, [x, y])
+            for dev_out, host_out in ((fn(da, db), fn(a, b)), (fn(da, s), fn(a, s)),
+                                      (fn(da.slice(5, n - 9), db.slice(9, n - 9)), fn(a.slice(5, n - 9), b.slice(9, n - 9)))):
+                assert not dev_out.is_cpu, (name, t)
+                ho = to_host(dev_out)
+                assert ho.type == host_out.type and ho.equals(host_out) and ho.null_count == host_out.null_count, (name, t)
+            if name in cmp_fns: ran_c += 3
+            else: ran_a += 3
+        # the type's own overflow: unchecked wraps in ITS width, checked fails with the reference's text — unless the slot is null
+        if pa.types.is_integer(t):
+            info = np.iinfo(npdt)
+            edge, one = pa.array([info.max, 5, info.min], t), pa.array([1, 2, 0], t)
+            assert to_host(pc.add(to_device(edge), to_device(one))).equals(pc.add(edge, one))
+            ran_a += 1
+            for l, r in ((edge, one), (pa.array([info.max, 5, None], t), pa.array([None, 2, 1], t))):
+                try:
+                    want = pc.add_checked(l, r)
+                except pa.lib.ArrowInvalid as e:
+                    want = str(e)
+                try:
+                    got = to_host(pc.add_checked(to_device(l), to_device(r)))
+                    ran_a += 1
+                except pa.lib.ArrowInvalid as e:
+                    got = str(e)
+                assert (got == want) if isinstance(want, str) else got.equals(want), (t, got, want)
+    c1, a1 = lib.arrow_amd_plugin_calls(b"compare", 1) + lib.arrow_amd_plugin_calls(b"greater", 1), lib.arrow_amd_plugin_calls(b"add", 1)
+    assert c1 - c0 == ran_c and a1 - a0 == ran_a, (c1 - c0, ran_c, a1 - a0, ran_a)
+    # an Acero filter + projection over int32 / float32 device columns: (a > 3) & (b < 0.5f) -> a * a + a
+    ai = pa.array(rng.integers(-1000, 1000, n).astype(np.int32), mask=rng.random(n) < 0.05)
+    bf = pa.array((np.round(rng.standard_normal(n) * 4) / 2).astype(np.float32), mask=rng.random(n) < 0.05)
+    t_host, t_dev = pa.table({"a": ai, "b": bf}), pa.table({"a": to_device(ai), "b": to_device(bf)})
+    def plan(t):
+        return acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(t)),
+            acero.Declaration("filter", acero.FilterNodeOptions((pc.field("a") > pa.scalar(3, pa.int32())) & (pc.field("b") < pa.scalar(0.5, pa.float32())))),
+            acero.Declaration("project", acero.ProjectNodeOptions([pc.field("a") * pc.field("a") + pc.field("a"), pc.field("b") * pc.field("b")], ["x", "y"]))])
+    got = plan(t_dev).to_table(use_threads=False)
+    want = plan(t_host).to_table(use_threads=False)
+    assert got.num_rows == want.num_rows
+    for name in ("x", "y"):
+        g = pa.concat_arrays([c if c.is_cpu else to_host(c) for c in got.column(name).chunks])
+        assert g.equals(want.column(name).combine_chunks()), name
+    print("NUMERIC_OPS_OK")
+''')
+
+
 AGGREGATE_SCRIPT = textwrap.dedent(r'''
     import ctypes, os, sys, faulthandler
     faulthandler.enable()
@@ -1315,6 +1415,17 @@ def test_divide_on_device_resident_arrays():
     code = f"ROOT = {ROOT!r}\n" + DIVIDE_SCRIPT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "DIVIDE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_compare_and_arithmetic_on_every_numeric_type_through_callfunction():
+    """The comparison family and add / subtract / multiply (+ _checked) for int8 ... uint32, uint64 and float through
+    CallFunction on device-resident arrays (array x array, array x scalar, slices): results stay in HBM and equal the
+    reference's on the host copies — type, values, validity, null count; the type's own overflow wraps / fails with the
+    reference's text; an Acero filter + projection over int32 / float32 device columns."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + NUMERIC_OPS_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "NUMERIC_OPS_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 def test_scalar_aggregates_on_device_resident_columns():

@@ -76,3 +76,7 @@ def test_divide_on_device_resident_arrays_emulated():
 
 def test_reference_golden_vectors_through_callfunction_emulated():
     _run(G.GOLDEN_SCRIPT, "GOLDEN_OK", 1)
+
+
+def test_compare_and_arithmetic_on_every_numeric_type_emulated():
+    _run(G.NUMERIC_OPS_SCRIPT, "NUMERIC_OPS_OK", 0.01)
