@@ -43,6 +43,9 @@
 #include <parquet/schema.h>
 #include <parquet/arrow/schema.h>
 #include <arrow/util/ubsan.h>
+#include <arrow/util/compression.h>
+#include <arrow/io/file.h>
+#include <arrow/io/interfaces.h>
 
 #include <algorithm>
 #include <atomic>
@@ -186,6 +189,11 @@ int arrow_amd_parquet_read_column(const char* path, int row_group, int column, s
 void arrow_amd_plugin_set_min_rows(int64_t n) { g_min_rows.store(n); }
 // Device-resident filters of at most n rows use one synchronisation instead of three (0 = off, the default).
 void arrow_amd_plugin_set_filter_morsel_rows(int64_t n) { g_filter_morsel_rows.store(n); }
+// Parquet: 1 (default) = Snappy chunks of fixed-width columns are read raw and their PLAIN value pages decompressed
+// on the device; 0 = every page is decompressed by the reference's PageReader on the host
+void arrow_amd_plugin_set_parquet_device_snappy(int on) { g_parquet_device_snappy.store(on != 0); }
+// pages decompressed on the device so far
+int64_t arrow_amd_plugin_parquet_device_snappy_pages(void) { return g_parquet_device_snappy_pages.load(); }
 // The same threshold for the element-wise kernels (greater, cast); default: never stage them.
 void arrow_amd_plugin_set_min_rows_streaming(int64_t n) { g_min_rows_streaming.store(n); }
 

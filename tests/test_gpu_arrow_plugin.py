@@ -1275,6 +1275,54 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
                     w = ref.column(name).combine_chunks()
                     assert h.equals(w) and h.null_count == w.null_count, (variant, null_p, rg, name, h.slice(0, 5), w.slice(0, 5))
     assert lib.arrow_amd_plugin_calls(b"parquet", 1) > 0
+    # Snappy chunks are read raw and their PLAIN value pages decompressed on the device (V2 pages: the values behind the
+    # levels; V1 pages of required columns: the whole body); dictionary pages / V1 optional pages / other encodings are
+    # decompressed on the host behind the same raw reader.  Same arrays with the route switched off.
+    lib.arrow_amd_plugin_parquet_device_snappy_pages.restype = ctypes.c_int64
+    req = pa.table({"a": pa.array(np.cumsum(rng.integers(-3, 4, n))), "b": pa.array(rng.integers(0, 50, n).astype(np.int32)),
+                    "c": pa.array(np.round(rng.standard_normal(n), 1)), "d": pa.array(rng.integers(0, 7, n), mask=rng.random(n) < 0.1)})
+    req = req.cast(pa.schema([pa.field("a", pa.int64(), nullable=False), pa.field("b", pa.int32(), nullable=False),
+                              pa.field("c", pa.float64(), nullable=False), pa.field("d", pa.int64())]))
+    for variant in (dict(data_page_version="1.0", use_dictionary=False, data_page_size=16384),
+                    dict(data_page_version="2.0", use_dictionary=False, data_page_size=16384),
+                    dict(data_page_version="2.0", use_dictionary=["b", "d"]),
+                    dict(data_page_version="1.0", use_dictionary=["a"], dictionary_pagesize_limit=4096, data_page_size=8192)):
+        path = os.path.join(tempfile.mkdtemp(), "r.parquet")
+        pq.write_table(req, path, row_group_size=n // 2 + 11, compression="snappy", **variant)
+        pf = pq.ParquetFile(path)
+        for on in (1, 0):
+            lib.arrow_amd_plugin_set_parquet_device_snappy(on)
+            before = lib.arrow_amd_plugin_parquet_device_snappy_pages()
+            for rg in range(pf.metadata.num_row_groups):
+                ref = pf.read_row_group(rg)
+                for ci, name in enumerate(req.schema.names):
+                    h = to_host(read_column(path, rg, ci))
+                    w = ref.column(name).combine_chunks()
+                    assert h.equals(w) and h.null_count == w.null_count, (variant, on, rg, name)
+            used = lib.arrow_amd_plugin_parquet_device_snappy_pages() - before
+            assert (used > 0) if on else (used == 0), (variant, on, used)
+    lib.arrow_amd_plugin_set_parquet_device_snappy(1)
+    # a corrupt Snappy page is reported with the reference's text, whichever side decompresses it
+    path = os.path.join(tempfile.mkdtemp(), "bad.parquet")
+    pq.write_table(req.select(["a"]), path, compression="snappy", use_dictionary=False, data_page_version="2.0")
+    raw = bytearray(open(path, "rb").read())
+    off = pq.ParquetFile(path).metadata.row_group(0).column(0).data_page_offset
+    from arrow_amd.parquet import read_page_header
+    hdr, body = read_page_header(bytes(raw), off)      # the first data page: garble the middle of its compressed body
+    for k in range(body + hdr[3] // 3, body + 2 * hdr[3] // 3):
+        raw[k] ^= 0x5A
+    open(path, "wb").write(bytes(raw))
+    try:            # (Snappy has no checksum: garbage may also decode to other bytes — then both sides must agree on them)
+        want, ref_error = pq.ParquetFile(path).read_row_group(0).column("a").combine_chunks(), None
+    except Exception as e:
+        want, ref_error = None, str(e)
+    c_dev, c_schema = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72)
+    rc = lib.arrow_amd_parquet_read_column(path.encode(), 0, 0, ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+    if ref_error is not None:
+        assert "orrupt snappy" in ref_error, ref_error
+        assert rc != 0 and b"Corrupt snappy compressed data" in lib.arrow_amd_plugin_last_error(), lib.arrow_amd_plugin_last_error()
+    else:
+        assert rc == 0 and to_host(pa.Array._import_from_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))).equals(want)
     # a nested column is refused, not mis-decoded
     path = os.path.join(tempfile.mkdtemp(), "l.parquet")
     pq.write_table(pa.table({"l": pa.array([[1, 2], [3]])}), path)
