@@ -64,6 +64,6 @@ if os.environ.get("CPP_BINDING", "1") == "1":
         best = min(best, time.perf_counter() - t0)
     for j, name in enumerate(("k", "v", "w")):
         assert to_host(cols[j]).equals(ref.column(name).combine_chunks()), name
-    print(f"arrow_amd_parquet_read_column (C++ on parquet::PageReader, host decompression), 3 columns: {best*1e3:.0f} ms "
+    print(f"arrow_amd_parquet_read_column (C++ on parquet::PageReader; Snappy pages on the device unless ARROW_AMD_PARQUET_DEVICE_SNAPPY=0), 3 columns: {best*1e3:.0f} ms "
           f"(k dictionary+nulls {per_col[0]*1e3:.0f}, v PLAIN {per_col[1]*1e3:.0f}, w PLAIN {per_col[2]*1e3:.0f} ms)")
 from arrow_amd import tracing
