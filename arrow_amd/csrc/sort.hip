@@ -38,6 +38,7 @@ static int64_t g_sort_msd_segment_rows = int64_t(1) << 27;  // above this: an ex
 static int g_sort_msd_final_rows_log2 = 1;  // log2 of the rows aimed at per final sub-bucket (rank loop length); with the 4096-bin finish 1 beats 2 / 3 / 4 by 3 / 9 / 18 % at 2e9 rows
 static int g_sort_msd_small_bucket = 1;  // 512-thread / 5120-row bucket kernel when every bucket fits it
 static int g_sort_msd_wide_sample_shift = 4;  // wide form: level-1 capacities from a histogram of 1 tile in 2^shift (0 = exact histogram of every row)
+static int g_sort_msd_prefix = 1;             // MSD forms take their digits below the bits that ALL keys share (ids, timestamps, small ints: the top bits are equal)
 static int g_sort_msd_wide_gap2 = 1;          // wide form: level-2 buckets get a fixed room each (bucket mean + 6 sigma + 64) instead of an exact histogram pass
 static int g_sort_msd_wide_sample_strict = 0; // tests: a sampled attempt that overflows is an error instead of a silent exact re-run
 static int g_sort_msd_wide = 1;          // inputs beyond sort_msd_segment_rows: the wide two-level form (run_msd_sort_wide) before the segmented one
@@ -1394,6 +1395,10 @@ int set_sort_option(const char* name, int64_t value) {
     g_sort_msd_wide_sample_shift = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 8)));
     return 1;
   }
+  if (strcmp(name, "sort_msd_prefix") == 0) {
+    g_sort_msd_prefix = value != 0;
+    return 1;
+  }
   if (strcmp(name, "sort_msd_wide_gap2") == 0) {
     g_sort_msd_wide_gap2 = value != 0;
     return 1;
@@ -1443,6 +1448,71 @@ int set_sort_option(const char* name, int64_t value) {
 
 // Runs the MSD-hybrid path.  *overflowed = 1 if a bucket did not fit the final window (the caller
 // then falls back to the LSD path).  Synchronous (reads the flag back).
+// Bits in which the (order-transformed) keys differ from key 0, OR-ed into *out: the leading zeros of the result are
+// bits EVERY key shares — row ids, timestamps, small integers share most of their top bits, and an MSD digit taken
+// there puts every row into one bucket.  sample_shift > 0: only one tile of 8192 rows in 2^sample_shift is read (plus
+// the first and the last tile) — enough to say "no shared prefix" for free; a shared prefix seen in the sample is then
+// confirmed over all rows before anything relies on it.
+template <bool RAW>
+__global__ __launch_bounds__(kBlock) void sort_vary_kernel(const uint64_t* __restrict__ keys, int xf, int64_t n, int sample_shift,
+                                                           unsigned long long* __restrict__ out) {
+  constexpr int64_t kTile = 8192;
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  const uint64_t ref = RAW ? load_key_typed(keys, 0, xf) : keys[0];
+  unsigned long long vary = 0;
+  for (int64_t g = blockIdx.x; ; g += gridDim.x) {
+    int64_t tile = g;
+    if (sample_shift > 0) {
+      const int64_t groups = (ntiles + (int64_t(1) << sample_shift) - 1) >> sample_shift;
+      if (g >= groups + 1) break;
+      tile = g == groups ? ntiles - 1
+                         : (g << sample_shift) + ((static_cast<uint32_t>(g) * 2654435761u) >> (32 - sample_shift));
+      if (tile >= ntiles) tile = ntiles - 1;
+    } else if (g >= ntiles) {
+      break;
+    }
+    const int64_t begin = tile * kTile;
+    const int64_t end = begin + kTile < n ? begin + kTile : n;
+    for (int64_t r = begin + threadIdx.x; r < end; r += kBlock) {
+      const uint64_t k = RAW ? load_key_typed(keys, r, xf) : keys[r];
+      vary |= k ^ ref;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) vary |= __shfl_xor(vary, d, 64);
+  if ((threadIdx.x & 63) == 0 && vary != 0) atomicOr(out, vary);
+}
+
+// Leading bits shared by all n keys (0 when sort_msd_prefix is off, when there are none, or when all keys are equal).
+static int sort_shared_prefix_bits(const uint64_t* keys, int raw_xf, int64_t n, unsigned long long* d_word, hipStream_t st,
+                                   int* out_bits) {
+  *out_bits = 0;
+  if (!g_sort_msd_prefix || n < 2) return ARX_OK;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int sample_shift = pass == 0 && n > (int64_t(1) << 20) ? 4 : 0;
+    ARX_HIP(hipMemsetAsync(d_word, 0, 8, st));
+    const int64_t ntiles = ceil_div(n, 8192);
+    const int64_t work = sample_shift ? (ntiles >> sample_shift) + 2 : ntiles;
+    const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(work, 256 * 16)));
+    if (raw_xf != 0) {
+      hipLaunchKernelGGL((sort_vary_kernel<true>), dim3(grid), dim3(kBlock), 0, st, keys, raw_xf, n, sample_shift, d_word);
+    } else {
+      hipLaunchKernelGGL((sort_vary_kernel<false>), dim3(grid), dim3(kBlock), 0, st, keys, 0, n, sample_shift, d_word);
+    }
+    ARX_CHECK_LAUNCH("sort_vary_kernel");
+    unsigned long long vary = 0;
+    ARX_HIP(hipMemcpyAsync(&vary, d_word, 8, hipMemcpyDeviceToHost, st));
+    ARX_HIP(hipStreamSynchronize(st));
+    const int shared = vary == 0 ? 64 : __builtin_clzll(vary);
+    if (shared == 0) return ARX_OK;            // (also what a sample says for full-range keys: no second pass)
+    if (sample_shift == 0) {                   // exact
+      *out_bits = shared >= 64 ? 0 : shared;   // all keys equal: nothing to gain, the LSD passes sort them
+      return ARX_OK;
+    }
+  }
+  return ARX_OK;
+}
+
 static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n,
                         uint64_t* keys_x, uint32_t* idx_x, uint64_t* keys_y, uint32_t* idx_y,
                         uint8_t* tables, uint64_t* out_final, hipStream_t st, int* overflowed,
@@ -1730,6 +1800,7 @@ struct MsdwArgs {
   int64_t n;
   int bits, b1, b2;
   int64_t chunk_rows;      // hist0 chunk
+  int kshift;              // leading bits that every key shares: digits are taken from key << kshift
   int sample_shift;        // hist0 reads one chunk in 2^sample_shift (0: every row, exact level-1 sizes)
   int gap2;                // level-2 buckets get a fixed room each (no level-2 histogram)
   int64_t capacity;        // records rec_x / rec_y can hold
@@ -1780,11 +1851,11 @@ __global__ __launch_bounds__(kMsdThreads) void msdw_hist0_kernel(MsdwArgs a) {
       kk[u] = RAW ? load_key_typed(a.src_keys, r + u * kMsdThreads, a.raw) : a.src_keys[r + u * kMsdThreads];
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) atomicAdd(&h[kk[u] >> shift], 1u);
+    for (int u = 0; u < U; ++u) atomicAdd(&h[(kk[u] << a.kshift) >> shift], 1u);
   }
   for (; r < end; r += kMsdThreads) {
     const uint64_t k = RAW ? load_key_typed(a.src_keys, r, a.raw) : a.src_keys[r];
-    atomicAdd(&h[k >> shift], 1u);
+    atomicAdd(&h[(k << a.kshift) >> shift], 1u);
   }
   __syncthreads();
   for (int i = tid; i < nb; i += kMsdThreads) {
@@ -1959,7 +2030,7 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
   uint32_t dig[kMsdwRows], rank[kMsdwRows];
 #pragma unroll
   for (int i = 0; i < kMsdwRows; ++i) {
-    dig[i] = static_cast<uint32_t>(key[i] >> dshift) & dmask;
+    dig[i] = static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask;
     rank[i] = 0;
     if (i * kMsdwThreads + tid < nrows) rank[i] = atomicAdd(&lds.cnt[dig[i]], 1u);
   }
@@ -1994,7 +2065,7 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
   __syncthreads();
   for (int p = tid; p < nrows; p += kMsdwThreads) {
     const uint64_t k = lds.keys[p];
-    const uint32_t d = static_cast<uint32_t>(k >> dshift) & dmask;
+    const uint32_t d = static_cast<uint32_t>((k << a.kshift) >> dshift) & dmask;
     const uint32_t gb = lds.gbase[d];
     if (CHECK != 0 && gb == 0xFFFFFFFFu) continue;
     MsdRec rr;
@@ -2053,9 +2124,11 @@ __global__ __launch_bounds__(kMsdThreads) void msdw_hist1_kernel(MsdwArgs a) {
 #pragma unroll
     for (int q = 0; q < U; ++q) kk[q] = msd_rec_key(a.rec_x[r + q * kMsdThreads]);
 #pragma unroll
-    for (int q = 0; q < U; ++q) atomicAdd(&h[static_cast<uint32_t>(kk[q] >> shift) & mask], 1u);
+    for (int q = 0; q < U; ++q) atomicAdd(&h[static_cast<uint32_t>((kk[q] << a.kshift) >> shift) & mask], 1u);
   }
-  for (; r < end; r += kMsdThreads) atomicAdd(&h[static_cast<uint32_t>(msd_rec_key(a.rec_x[r]) >> shift) & mask], 1u);
+  for (; r < end; r += kMsdThreads) {
+    atomicAdd(&h[static_cast<uint32_t>((msd_rec_key(a.rec_x[r]) << a.kshift) >> shift) & mask], 1u);
+  }
   __syncthreads();
   uint32_t* dst = a.count2 + (static_cast<size_t>(p) << a.b2);
   for (int i = tid; i < nb2; i += kMsdThreads) {
@@ -2155,7 +2228,7 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter2_kernel(MsdwArgs a)
 // 2 a level-2 room overflowed (gap2 only): call again with gap2 = 0 (the source may have been overwritten when it
 // shares memory with rec_y).
 static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n, MsdRec* rec_x,
-                             MsdRec* rec_y, int64_t capacity, uint8_t* tables, uint64_t* out_final, int gap2,
+                             MsdRec* rec_y, int64_t capacity, uint8_t* tables, uint64_t* out_final, int gap2, int kshift,
                              hipStream_t st, int* overflowed) {
   *overflowed = 0;
   if (n == 0) return ARX_OK;
@@ -2166,7 +2239,8 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   a.src_idx = src_idx;
   a.raw = raw;
   a.n = n;
-  a.bits = std::max(2, std::min(lg - 12, kMsdwMaxBits));   // 2048 < average bucket <= 4096 rows
+  a.kshift = kshift;
+  a.bits = std::max(2, std::min(std::min(lg - 12, kMsdwMaxBits), 64 - kshift));   // 2048 < average bucket <= 4096 rows
   a.b1 = a.bits / 2;
   a.b2 = a.bits - a.b1;
   const bool roomy = capacity < (int64_t(1) << 32);   // record positions are 32-bit
@@ -2283,13 +2357,13 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   MsdArgs f{};
   f.n = n;
   f.bits = a.bits;
-  f.kshift = 0;
+  f.kshift = kshift;
   f.part_start = a.part_start;
   f.part_in = a.count2;
   f.overflow = a.flags;
   f.out_final = out_final;
   const bool small_bkt = max_part <= static_cast<unsigned int>(kBktCapSmall);
-  f.b3 = std::max(0, std::min(std::min(lg - (g_sort_msd_final_rows_log2 - 1) - a.bits, small_bkt ? 11 : 12), 64 - a.bits));
+  f.b3 = std::max(0, std::min(std::min(lg - (g_sort_msd_final_rows_log2 - 1) - a.bits, small_bkt ? 11 : 12), 64 - kshift - a.bits));
   const uint64_t* recs = reinterpret_cast<const uint64_t*>(rec_y);
   if (small_bkt) {
     hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsSmall, true>), dim3(static_cast<unsigned>(nparts)),
@@ -2319,7 +2393,7 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
 // below (kshift = b0).  Synchronous.
 static int run_msd_sort_segmented(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n,
                                   uint64_t* keys_p, uint32_t* idx_p, uint64_t* keys_q, uint32_t* idx_q,
-                                  uint8_t* tables, uint64_t* out_final, hipStream_t st, int* overflowed) {
+                                  uint8_t* tables, uint64_t* out_final, hipStream_t st, int* overflowed, int kshift = 0) {
   int b0 = 1;
   while ((n >> b0) > std::min<int64_t>(g_sort_msd_segment_rows, int64_t(1) << 27) && b0 < 7) ++b0;
   b0 = std::max(b0, std::min(g_sort_msd_seg_min_bits, 7));
@@ -2328,7 +2402,7 @@ static int run_msd_sort_segmented(const uint64_t* src_keys, const uint32_t* src_
   a.src_idx = src_idx;
   a.raw = raw;
   a.n = n;
-  a.kshift = 0;
+  a.kshift = kshift;
   a.bits = b0;
   a.b1 = b0;
   a.b2 = 0;
@@ -2374,7 +2448,7 @@ static int run_msd_sort_segmented(const uint64_t* src_keys, const uint32_t* src_
     int ovf = 0;
     // the segment's rows live in (keys_p, idx_p): levels ping-pong p -> q -> p -> q
     const int rc = run_msd_sort(keys_p + lo, idx_p + lo, 0, m, keys_q + lo, idx_q + lo, keys_p + lo, idx_p + lo,
-                                tables, out_final + lo, st, &ovf, b0);
+                                tables, out_final + lo, st, &ovf, kshift + b0);
     if (rc != ARX_OK) return rc;
     if (ovf) {
       *overflowed = 1;
@@ -2516,37 +2590,46 @@ int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_pl
     int overflowed = 0;
     int rc;
     const bool wide = segmented && g_sort_msd_wide != 0 && key_width == 8;
+    int ks = 0;   // leading key bits every row shares: the MSD digits start below them
     if (valid_rows == nullptr) {
       const uint64_t* src = reinterpret_cast<const uint64_t*>(vals);
+      if (key_width == 8) {
+        const int prc = sort_shared_prefix_bits(src, xf, n_valid, reinterpret_cast<unsigned long long*>(tables), st, &ks);
+        if (prc != ARX_OK) return prc;
+      }
       overflowed = 1;
       rc = ARX_OK;
       if (wide) {
-        rc = run_msd_sort_wide(src, nullptr, xf, n_valid, rec_a, rec_b, rec_cap, tables, final_dst, g_sort_msd_wide_gap2, st, &overflowed);
+        rc = run_msd_sort_wide(src, nullptr, xf, n_valid, rec_a, rec_b, rec_cap, tables, final_dst, g_sort_msd_wide_gap2, ks, st, &overflowed);
         if (rc == ARX_OK && overflowed == 2) {
-          rc = run_msd_sort_wide(src, nullptr, xf, n_valid, rec_a, rec_b, rec_cap, tables, final_dst, 0, st, &overflowed);
+          rc = run_msd_sort_wide(src, nullptr, xf, n_valid, rec_a, rec_b, rec_cap, tables, final_dst, 0, ks, st, &overflowed);
         }
       }
       if (rc == ARX_OK && overflowed) {
         rc = segmented ? run_msd_sort_segmented(src, nullptr, xf, n_valid, keys_a, idx_a, keys_b, idx_b, tables,
-                                                final_dst, st, &overflowed)
+                                                final_dst, st, &overflowed, ks)
                        : run_msd_sort(src, nullptr, xf, n_valid, keys_a, idx_a, keys_b, idx_b, tables, final_dst, st,
-                                      &overflowed);
+                                      &overflowed, ks);
       }
     } else {
       hipLaunchKernelGGL(sort_prep_kernel, dim3(gprep), dim3(kBlock), 0, st, vals, valid_rows, n_valid, xf, 0,
                          keys_a, idx_a);
       ARX_CHECK_LAUNCH("sort_prep_kernel");
+      if (key_width == 8) {
+        const int prc = sort_shared_prefix_bits(keys_a, 0, n_valid, reinterpret_cast<unsigned long long*>(tables), st, &ks);
+        if (prc != ARX_OK) return prc;
+      }
       overflowed = 1;
       rc = ARX_OK;
       // the wide form reads its source twice (level 1, then the histogram reads level-1 output): x = b, y = a is
       // safe because level 2 only starts after level 1 has consumed the source
       if (wide) {
-        rc = run_msd_sort_wide(keys_a, idx_a, 0, n_valid, rec_b, rec_a, rec_cap, tables, final_dst, g_sort_msd_wide_gap2, st, &overflowed);
+        rc = run_msd_sort_wide(keys_a, idx_a, 0, n_valid, rec_b, rec_a, rec_cap, tables, final_dst, g_sort_msd_wide_gap2, ks, st, &overflowed);
         if (rc == ARX_OK && overflowed == 2) {   // the level-2 records went over the prepped source: rebuild it
           hipLaunchKernelGGL(sort_prep_kernel, dim3(gprep), dim3(kBlock), 0, st, vals, valid_rows, n_valid, xf, 0,
                              keys_a, idx_a);
           ARX_CHECK_LAUNCH("sort_prep_kernel");
-          rc = run_msd_sort_wide(keys_a, idx_a, 0, n_valid, rec_b, rec_a, rec_cap, tables, final_dst, 0, st, &overflowed);
+          rc = run_msd_sort_wide(keys_a, idx_a, 0, n_valid, rec_b, rec_a, rec_cap, tables, final_dst, 0, ks, st, &overflowed);
         }
       }
       if (rc == ARX_OK && overflowed) {
@@ -2556,9 +2639,9 @@ int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_pl
           ARX_CHECK_LAUNCH("sort_prep_kernel");
         }
         rc = segmented ? run_msd_sort_segmented(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables,
-                                                final_dst, st, &overflowed)
+                                                final_dst, st, &overflowed, ks)
                        : run_msd_sort(keys_a, idx_a, 0, n_valid, keys_b, idx_b, keys_a, idx_a, tables, final_dst, st,
-                                      &overflowed);
+                                      &overflowed, ks);
       }
     }
     if (rc != ARX_OK) return rc;

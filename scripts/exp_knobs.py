@@ -36,7 +36,11 @@ def fill(t, lo, hi, seed):
 
 if what == "sort":
     k = torch.empty(rows, dtype=torch.int64, device=dev)
-    fill(k, -2**63, 2**63 - 1, 10)
+    rb = int(os.environ.get("RANGE_BITS", 64))     # keys uniform in [0, 2^RANGE_BITS): ids / timestamps share their top bits
+    if rb >= 64:
+        fill(k, -2**63, 2**63 - 1, 10)
+    else:
+        fill(k, 0, 2**rb, 10)
     ak = amd.Array(amd.array.uint64, rows, [None, k.view(torch.uint8)], 0, 0)
     run = lambda: amd.compute.sort_indices(ak)  # noqa: E731
     check = lambda out: int(out.data[: rows * 8].view(torch.int64)[:: max(1, rows // 1000)].sum().item())  # noqa: E731

@@ -784,6 +784,33 @@ def check_sort_wide_sampled(amd, lib, rng, n, shift, gap2=1):
         lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
 
 
+def check_sort_limited_range(amd, lib, rng, n, wide):
+    """Keys that share their top bits (row ids, timestamps, small or clustered integers): the MSD forms must take their
+    digits below the shared prefix (sort_msd_prefix) — same order as the oracle with the knob on and off, ascending and
+    descending, signed and unsigned, with nulls, for the hybrid form and (wide) the wide two-level form."""
+    opts = {b"sort_msd": 1, b"sort_msd_segment_rows": 4096 if wide else 1 << 27, b"sort_msd_wide": 1 if wide else 0}
+    for k, v in opts.items():
+        assert lib.arx_set_option(k, v) == 0
+    try:
+        cases = [(np.uint64, 0, 1 << 40), (np.uint64, (1 << 62) + 12345, 1 << 33), (np.int64, -(1 << 35), 1 << 36),
+                 (np.int64, 1_700_000_000_000_000, 86_400_000_000), (np.uint64, 0, 1 << 63), (np.int64, -5, 11),
+                 (np.uint64, 77, 1)]
+        for prefix in (1, 0):
+            assert lib.arx_set_option(b"sort_msd_prefix", prefix) == 0
+            for dtype, lo, span in cases:
+                vals = (rng.integers(0, span, size=n, dtype=np.uint64).astype(np.int64) + np.int64(lo)).astype(dtype) \
+                    if dtype == np.int64 else (rng.integers(0, span, size=n, dtype=np.uint64) + np.uint64(lo))
+                valid = None if span == 1 else rng.random(n) >= 0.02
+                arr = HostArray(vals.astype(dtype), valid, 0, n)
+                for order, placement in (("ascending", "at_end"), ("descending", "at_start")):
+                    check_sort_indices(amd, arr, order, placement, use_pyarrow=False)
+    finally:
+        lib.arx_set_option(b"sort_msd_prefix", 1)
+        lib.arx_set_option(b"sort_msd", -1)
+        lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
+        lib.arx_set_option(b"sort_msd_wide", 1)
+
+
 # ------------------------------------------------------------------ group-by
 def check_concat_arrays(amd, chunks, use_pyarrow=True):
     """Concatenate (array/concatenate.cc): chunks glued at arbitrary bit positions; values and validity equal

@@ -902,3 +902,9 @@ def test_take_record_batch_without_nulls_has_no_bitmaps(emu_ctx):
                                    np.float32, np.float64])
 def test_compare_and_arithmetic_on_every_numeric_type(emu_ctx, dtype):
     P.check_numeric_compare_arith(emu_ctx, rng_for("numeric-ops", np.dtype(dtype).name), dtype, n=3000)
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+def test_sort_keys_with_a_shared_prefix(emu_ctx, wide):
+    lib = emu_ctx._lib.get_lib()
+    P.check_sort_limited_range(emu_ctx, lib, rng_for("sort-prefix", wide), 9000, wide)

@@ -1174,3 +1174,9 @@ def test_take_record_batch_without_nulls_has_no_bitmaps(gpu_ctx):
                                    np.float32, np.float64])
 def test_compare_and_arithmetic_on_every_numeric_type(gpu_ctx, dtype):
     P.check_numeric_compare_arith(gpu_ctx, rng_for("numeric-ops", np.dtype(dtype).name), dtype, n=1000003)
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+def test_sort_keys_with_a_shared_prefix(gpu_ctx, wide):
+    lib = gpu_ctx._lib.get_lib()
+    P.check_sort_limited_range(gpu_ctx, lib, rng_for("sort-prefix", wide), 5000011, wide)
