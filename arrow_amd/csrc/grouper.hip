@@ -152,7 +152,9 @@ __global__ __launch_bounds__(kBlock) void grouper_probe_kernel(GrouperView v, Gr
     uint64_t s = grouper_hash(key) >> (64 - v.lg);
     for (int64_t probes = 0; probes < v.nslots; ++probes, s = (s + 1) & smask) {
       GrouperSlot* slot = v.slots + s;
-      unsigned long long meta = __atomic_load_n(&slot->meta, __ATOMIC_RELAXED);
+      // agent-scope acquire: pairs with the winner's fence + publishing store below; the key words are then read with
+      // agent-scope loads of their own (no device-wide fence per probing row)
+      unsigned long long meta = __hip_atomic_load(&slot->meta, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
       if (meta == kSlotEmpty) {
         if (!a.insert) {
           a.out_ids[row] = 0;   // Lookup: unseen key -> null
@@ -171,8 +173,8 @@ __global__ __launch_bounds__(kBlock) void grouper_probe_kernel(GrouperView v, Gr
           v.slot_of[id] = static_cast<unsigned int>(s);
           atomicMin(&a.first_row[id - a.base], static_cast<uint32_t>(row));
           __threadfence();
-          __atomic_store_n(&slot->meta, kSlotPublished | (static_cast<unsigned long long>(key.mask) << 8) | (id << 32),
-                           __ATOMIC_RELAXED);
+          __hip_atomic_store(&slot->meta, kSlotPublished | (static_cast<unsigned long long>(key.mask) << 8) | (id << 32),
+                             __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
           a.out_ids[row] = static_cast<uint32_t>(id);
           break;
         }
@@ -181,9 +183,8 @@ __global__ __launch_bounds__(kBlock) void grouper_probe_kernel(GrouperView v, Gr
         a.next[atomicAdd(&v.hdr->pending, 1u)] = static_cast<uint32_t>(row);
         break;
       }
-      __threadfence();
-      if (__atomic_load_n(&slot->k0, __ATOMIC_RELAXED) == key.k0 && __atomic_load_n(&slot->k1, __ATOMIC_RELAXED) == key.k1 &&
-          ((meta >> 8) & 0xFF) == key.mask) {
+      if (__hip_atomic_load(&slot->k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key.k0 &&
+          __hip_atomic_load(&slot->k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key.k1 && ((meta >> 8) & 0xFF) == key.mask) {
         const unsigned long long id = meta >> 32;
         if (a.insert) {
           if (id >= a.base) atomicMin(&a.first_row[id - a.base], static_cast<uint32_t>(row));

@@ -161,6 +161,7 @@ static inline void __threadfence() { hipemu::yield(); }
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))
+#define __hip_atomic_store(ptr, value, order, scope) (*(ptr) = (value))
 
 template <typename T> inline T __shfl(T v, int src, int = 64) { return hipemu::exchange(v, src); }
 template <typename T> inline T __shfl_up(T v, unsigned d, int = 64) {
