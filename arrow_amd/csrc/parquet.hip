@@ -201,6 +201,85 @@ __global__ __launch_bounds__(kBlock) void delta_write_kernel(Source src, int64_t
   }
 }
 
+// All DELTA_BINARY_PACKED pages of a column chunk in ONE launch sequence: every page restarts the recurrence at its own
+// first value, so tiles never span pages (page p owns tiles [first_tile, first_tile + ceil(count / 4096))) and a tile's
+// carry is the difference of two entries of the plain (unsegmented) scan of the tile totals: excl[tile] -
+// excl[first tile of its page] — the page's first value is the summand of its position 0.
+__device__ __forceinline__ int64_t delta_page_of(const ArxDeltaPage* __restrict__ pages, int64_t num_pages, int64_t tile) {
+  int64_t lo = 0, hi = num_pages - 1;     // last page with first_tile <= tile
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (pages[mid].first_tile <= tile) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ DeltaSource delta_page_source(const uint64_t* words, const ArxDeltaMiniblock* mbs, const ArxDeltaPage& pg) {
+  return DeltaSource{words, mbs + pg.first_miniblock, pg.values_per_miniblock, static_cast<long long>(pg.first_value)};
+}
+
+__global__ __launch_bounds__(kBlock) void delta_pages_tile_sums_kernel(const uint64_t* __restrict__ words,
+                                                                       const ArxDeltaMiniblock* __restrict__ mbs,
+                                                                       const ArxDeltaPage* __restrict__ pages, int64_t num_pages,
+                                                                       long long* __restrict__ tile_sums) {
+  __shared__ long long wave_sum[kWavesPerBlock];
+  const ArxDeltaPage pg = pages[delta_page_of(pages, num_pages, blockIdx.x)];
+  const DeltaSource src = delta_page_source(words, mbs, pg);
+  const int64_t base = (static_cast<int64_t>(blockIdx.x) - pg.first_tile) * kDeltaTile;
+  unsigned long long acc = 0;
+  for (int k = threadIdx.x; k < kDeltaTile; k += kBlock) {
+    const int64_t i = base + k;
+    if (i < pg.num_values) acc += static_cast<unsigned long long>(src.at(i));
+  }
+  acc = wave_reduce_sum_u64(acc);
+  if (lane_id() == 0) wave_sum[threadIdx.x >> 6] = static_cast<long long>(acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) t += static_cast<unsigned long long>(wave_sum[w]);
+    tile_sums[blockIdx.x] = static_cast<long long>(t);
+  }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(kBlock) void delta_pages_write_kernel(const uint64_t* __restrict__ words,
+                                                                   const ArxDeltaMiniblock* __restrict__ mbs,
+                                                                   const ArxDeltaPage* __restrict__ pages, int64_t num_pages,
+                                                                   const long long* __restrict__ tile_excl, OutT* __restrict__ out) {
+  __shared__ long long wave_tot[kWavesPerBlock];
+  __shared__ long long carry_s;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const ArxDeltaPage pg = pages[delta_page_of(pages, num_pages, blockIdx.x)];
+  const DeltaSource src = delta_page_source(words, mbs, pg);
+  const int64_t base = (static_cast<int64_t>(blockIdx.x) - pg.first_tile) * kDeltaTile;
+  OutT* __restrict__ dst = out + pg.out_start;
+  if (threadIdx.x == 0) {
+    carry_s = static_cast<long long>(static_cast<unsigned long long>(tile_excl[blockIdx.x]) -
+                                     static_cast<unsigned long long>(tile_excl[pg.first_tile]));
+  }
+  __syncthreads();
+  for (int k0 = 0; k0 < kDeltaTile; k0 += kBlock) {      // block-uniform trip count
+    const int64_t i = base + k0 + threadIdx.x;
+    const unsigned long long v = i < pg.num_values ? static_cast<unsigned long long>(src.at(i)) : 0;
+    unsigned long long x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long nb = __shfl_up(x, d, 64);
+      if (lane >= d) x += nb;
+    }
+    if (lane == 63) wave_tot[wave] = static_cast<long long>(x);
+    __syncthreads();
+    unsigned long long pre = 0;
+    for (int w = 0; w < wave; ++w) pre += static_cast<unsigned long long>(wave_tot[w]);
+    const unsigned long long carry = static_cast<unsigned long long>(carry_s);
+    if (i < pg.num_values) dst[i] = static_cast<OutT>(carry + pre + x);
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) carry_s = static_cast<long long>(carry + pre + x);
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- BYTE_STREAM_SPLIT
 // ByteStreamSplitDecoder (cpp/src/parquet/decoder.cc; arrow/util/byte_stream_split_internal.h): a page of n
 // W-byte values is stored as W streams of n bytes (stream k = byte k of every value).  One value per lane:
@@ -551,6 +630,41 @@ int arx_delta_decode(const void* bytes, const ArxDeltaMiniblock* miniblocks, int
                        src, num_values, sums, static_cast<int32_t*>(out));
   }
   ARX_CHECK_LAUNCH("delta_write_kernel");
+  return ARX_OK;
+}
+
+// The pages of a whole column chunk: `pages` (device) describes them, page p covering tiles [first_tile, next page's
+// first_tile) of 4096 values; total_tiles = their sum.  ws: arx_delta_decode_workspace_bytes(total_tiles * 4096).
+int arx_delta_decode_pages(const void* bytes, const ArxDeltaMiniblock* miniblocks, const ArxDeltaPage* pages, int64_t num_pages,
+                           int64_t total_tiles, int out_byte_width, void* ws, size_t ws_bytes, void* out, void* stream) {
+  if (num_pages < 0 || total_tiles < 0 || (out_byte_width != 4 && out_byte_width != 8) ||
+      (reinterpret_cast<uintptr_t>(bytes) & 7) != 0) {
+    set_error("bad arguments to arx_delta_decode_pages");
+    return ARX_INVALID;
+  }
+  if (num_pages == 0 || total_tiles == 0) return ARX_OK;
+  if (pages == nullptr || out == nullptr || ws == nullptr || total_tiles > (int64_t(1) << 31) - 1 ||
+      ws_bytes < arx_delta_decode_workspace_bytes(total_tiles * kDeltaTile)) {
+    set_error("arx_delta_decode_pages: %lld tiles need a page table, an output and %zu workspace bytes",
+              static_cast<long long>(total_tiles), arx_delta_decode_workspace_bytes(total_tiles * kDeltaTile));
+    return ARX_INVALID;
+  }
+  const uint64_t* words = static_cast<const uint64_t*>(bytes);
+  long long* sums = static_cast<long long*>(ws);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(delta_pages_tile_sums_kernel, dim3(static_cast<unsigned>(total_tiles)), dim3(kBlock), 0, st, words,
+                     miniblocks, pages, num_pages, sums);
+  ARX_CHECK_LAUNCH("delta_pages_tile_sums_kernel");
+  hipLaunchKernelGGL(delta_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, sums, total_tiles);
+  ARX_CHECK_LAUNCH("delta_scan_tiles_kernel");
+  if (out_byte_width == 8) {
+    hipLaunchKernelGGL((delta_pages_write_kernel<long long>), dim3(static_cast<unsigned>(total_tiles)), dim3(kBlock), 0, st,
+                       words, miniblocks, pages, num_pages, sums, static_cast<long long*>(out));
+  } else {
+    hipLaunchKernelGGL((delta_pages_write_kernel<int32_t>), dim3(static_cast<unsigned>(total_tiles)), dim3(kBlock), 0, st, words,
+                       miniblocks, pages, num_pages, sums, static_cast<int32_t*>(out));
+  }
+  ARX_CHECK_LAUNCH("delta_pages_write_kernel");
   return ARX_OK;
 }
 

@@ -36,6 +36,8 @@ _PHYSICAL = {"INT32": (int32, np.int32), "INT64": (int64, np.int64), "FLOAT": (f
 
 RUN_DTYPE = np.dtype([("out_start", "<u4"), ("kind", "<u4"), ("payload", "<u8")])   # struct ArxRleRun
 MINIBLOCK_DTYPE = np.dtype([("bit_start", "<u8"), ("min_delta", "<i8"), ("bit_width", "<u4"), ("reserved", "<u4")])   # struct ArxDeltaMiniblock
+DELTA_PAGE_DTYPE = np.dtype([("out_start", "<i8"), ("first_miniblock", "<i8"), ("values_per_miniblock", "<i8"),
+                             ("first_value", "<i8"), ("num_values", "<i8"), ("first_tile", "<i8")])   # ArxDeltaPage
 
 
 # --------------------------------------------------------------------------- Thrift compact protocol
@@ -442,18 +444,21 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
             if stats is not None:
                 stats["device_snappy_pages"] = stats.get("device_snappy_pages", 0) + len(device_snappy_pages)
     if delta_pages:
-        # one byte buffer and one miniblock table for the chunk; a launch sequence (unpack + prefix sum) per page,
-        # because every page restarts the recurrence at its own first value
+        # one byte buffer, one miniblock table and one page table for the chunk: ONE launch sequence (unpack + prefix
+        # sum) for all its pages — every page restarts the recurrence at its own first value, so pages own whole tiles
         d_bytes = to_device(np.frombuffer(bytes(delta_bytes) + b"\0" * 16, dtype=np.uint8), device)
         table = np.concatenate([p[1] for p in delta_pages]) if any(len(p[1]) for p in delta_pages) else np.zeros(1, MINIBLOCK_DTYPE)
         d_table = to_device(table.view(np.uint8), device)
-        ws = alloc(lib.arx_delta_decode_workspace_bytes(max(p[4] for p in delta_pages)), device)
-        at = 0
-        for start, mbs, vpm, first, count in delta_pages:
-            check(lib.arx_delta_decode(d_bytes.data_ptr(), d_table.data_ptr() + at * MINIBLOCK_DTYPE.itemsize, len(mbs), vpm,
-                                       first, count, width, ws.data_ptr(), ws.numel(),
-                                       dense_buf.data_ptr() + start * width, stream))
+        pages = np.zeros(len(delta_pages), dtype=DELTA_PAGE_DTYPE)
+        at = tiles = 0
+        for j, (start, mbs, vpm, first, count) in enumerate(delta_pages):
+            pages[j] = (start, at, max(vpm, 1), first, count, tiles)
             at += len(mbs)
+            tiles += (count + 4095) // 4096
+        d_pages = to_device(pages.view(np.uint8), device)
+        ws = alloc(lib.arx_delta_decode_workspace_bytes(max(tiles, 1) * 4096), device)
+        check(lib.arx_delta_decode_pages(d_bytes.data_ptr(), d_table.data_ptr(), d_pages.data_ptr(), len(delta_pages), tiles,
+                                         width, ws.data_ptr(), ws.numel(), dense_buf.data_ptr(), stream))
 
     if max_def_level == 0 or dense == rows:                         # required column, or optional without a single null
         return Array(atype, rows, [None, dense_buf], 0, 0)

@@ -703,6 +703,22 @@ size_t arx_delta_decode_workspace_bytes(int64_t num_values);
 int arx_delta_decode(const void* bytes, const ArxDeltaMiniblock* miniblocks, int64_t num_miniblocks,
                      int64_t values_per_miniblock, int64_t first_value, int64_t num_values,
                      int out_byte_width, void* ws, size_t ws_bytes, void* out, void* stream);
+
+/* All DELTA_BINARY_PACKED pages of a column chunk in ONE launch sequence (three launches whatever the page count;
+ * arx_delta_decode is one sequence per page).  Every page restarts at its own first value (DeltaBitPackDecoder::
+ * InitHeader per page, decoder.cc), so page p owns whole tiles of 4096 values: first_tile = tiles of the pages before
+ * it, total_tiles = their sum.  pages: DEVICE array; miniblocks: the chunk's table (first_miniblock indexes into it);
+ * values of page p land at out + out_start (in values).  ws: arx_delta_decode_workspace_bytes(total_tiles * 4096). */
+typedef struct ArxDeltaPage {
+  int64_t out_start;            /* first output value of the page */
+  int64_t first_miniblock;      /* index into `miniblocks` */
+  int64_t values_per_miniblock;
+  int64_t first_value;
+  int64_t num_values;
+  int64_t first_tile;
+} ArxDeltaPage;
+int arx_delta_decode_pages(const void* bytes, const ArxDeltaMiniblock* miniblocks, const ArxDeltaPage* pages, int64_t num_pages,
+                           int64_t total_tiles, int out_byte_width, void* ws, size_t ws_bytes, void* out, void* stream);
 /* DELTA_LENGTH_BYTE_ARRAY (DeltaLengthByteArrayDecoder, cpp/src/parquet/decoder.cc): the lengths are a
  * DELTA_BINARY_PACKED stream (arx_delta_decode, width 4), the offsets their running sum: out[0] = base,
  * out[i] = out[i-1] + lengths[i-1], i in [1, n].  ws: arx_delta_decode_workspace_bytes(n + 1).  Asynchronous. */
