@@ -194,6 +194,9 @@ void arrow_amd_plugin_set_filter_morsel_rows(int64_t n) { g_filter_morsel_rows.s
 void arrow_amd_plugin_set_parquet_device_snappy(int on) { g_parquet_device_snappy.store(on != 0); }
 // pages decompressed on the device so far
 int64_t arrow_amd_plugin_parquet_device_snappy_pages(void) { return g_parquet_device_snappy_pages.load(); }
+// aggregate_rocm: rows of pending device batches that trigger a copy into the staging columns; copies so far
+void arrow_amd_plugin_set_aggregate_flush_rows(int64_t rows) { g_aggregate_flush_rows.store(rows < 1 ? 1 : rows); }
+int64_t arrow_amd_plugin_aggregate_flushes(void) { return g_aggregate_flushes.load(); }
 // The same threshold for the element-wise kernels (greater, cast); default: never stage them.
 void arrow_amd_plugin_set_min_rows_streaming(int64_t n) { g_min_rows_streaming.store(n); }
 

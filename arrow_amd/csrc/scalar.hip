@@ -710,6 +710,33 @@ static int compare_any(int op, const T* left, T ls, const T* right, T rs, int64_
   }
 }
 
+// ------------------------------------------------------------------ many small device-to-device copies in one launch
+// Concatenate (array/concatenate.cc) of many small chunks — Acero hands operators 32K-row batches — costs a launch (or
+// a hipMemcpy) per chunk and column when done copy by copy; here a device table of {src, dst, nbytes} drives one
+// launch: `per_seg` workgroups per segment, each copying 64 KiB slices (16-byte accesses when both sides allow).
+__global__ __launch_bounds__(kBlock) void copy_segments_kernel(const ArxCopySeg* __restrict__ segs, int64_t nsegs, unsigned per_seg) {
+  constexpr uint64_t kSlice = 64 * 1024;
+  const int64_t sg = blockIdx.x / per_seg;
+  const unsigned part = blockIdx.x % per_seg;
+  if (sg >= nsegs) return;
+  const ArxCopySeg seg = segs[sg];
+  const uint8_t* __restrict__ src = static_cast<const uint8_t*>(seg.src);
+  uint8_t* __restrict__ dst = static_cast<uint8_t*>(seg.dst);
+  const bool wide = ((reinterpret_cast<uint64_t>(src) | reinterpret_cast<uint64_t>(dst)) & 15) == 0;
+  for (uint64_t base = static_cast<uint64_t>(part) * kSlice; base < seg.nbytes; base += static_cast<uint64_t>(per_seg) * kSlice) {
+    const uint64_t end = base + kSlice < seg.nbytes ? base + kSlice : seg.nbytes;
+    if (wide) {
+      const uint64_t end16 = base + ((end - base) & ~uint64_t(15));
+      for (uint64_t o = base + threadIdx.x * 16ull; o < end16; o += kBlock * 16ull) {
+        *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(src + o);
+      }
+      for (uint64_t o = end16 + threadIdx.x; o < end; o += kBlock) dst[o] = src[o];
+    } else {
+      for (uint64_t o = base + threadIdx.x; o < end; o += kBlock) dst[o] = src[o];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ compare / arithmetic on every numeric type
 // The comparison family and add / subtract / multiply (+ _checked) for the element types the 64-bit kernels above do
 // not take (int8 ... uint32, uint64, float): the same Call bodies (scalar_compare.cc:38-64,
@@ -1082,6 +1109,25 @@ int arx_arith_checked_i64(int op, const int64_t* left, int64_t left_scalar, cons
   const Bits rv = make_bits(right_validity, right_offset, length);
   return arith_any<int64_t, true>(op, left, left_scalar, right, right_scalar, lv, rv, length, out, overflow_flag,
                                   as_stream(stream));
+}
+
+int arx_copy_segments(const ArxCopySeg* segments, int64_t num_segments, uint64_t max_segment_bytes, void* stream) {
+  if (num_segments < 0 || (num_segments > 0 && segments == nullptr)) {
+    set_error("bad arguments to arx_copy_segments");
+    return ARX_INVALID;
+  }
+  if (num_segments == 0 || max_segment_bytes == 0) return ARX_OK;
+  constexpr uint64_t kSlice = 64 * 1024;   // bytes per workgroup
+  const uint64_t per_seg = std::min<uint64_t>((max_segment_bytes + kSlice - 1) / kSlice, 4096);
+  const uint64_t blocks = per_seg * static_cast<uint64_t>(num_segments);
+  if (blocks > (uint64_t(1) << 31) - 1) {
+    set_error("arx_copy_segments: too many segments for one launch (%lld)", static_cast<long long>(num_segments));
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(copy_segments_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, as_stream(stream), segments,
+                     num_segments, static_cast<unsigned>(per_seg));
+  ARX_CHECK_LAUNCH("copy_segments_kernel");
+  return ARX_OK;
 }
 
 int arx_compare_numeric(int op, int num_type, const void* left, const void* left_scalar, const void* right,

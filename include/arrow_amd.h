@@ -360,6 +360,18 @@ int arx_bitmap_and(const void* left, int64_t left_offset, const void* right,
  * out[i] = offsets[i] - offsets[0] + base for i in [0, length].  Asynchronous. */
 int arx_bitmap_copy_at(const void* bits, int64_t bit_offset, int64_t length, void* out,
                        int64_t out_bit_offset, void* stream);
+
+/* Many device-to-device copies in ONE launch: the data half of Concatenate (array/concatenate.cc ConcatenateBuffers)
+ * when the chunks are small and many — Acero hands an operator 32K-row batches (exec_plan.h kMaxBatchSize), and a
+ * hipMemcpy or a launch per batch and column is what bounds such plans.  segments: DEVICE array of {src, dst, nbytes}
+ * with absolute device addresses (so one table can fill several destination columns); max_segment_bytes sizes the
+ * grid (workgroups per segment).  Overlapping destinations are the caller's problem.  Asynchronous. */
+typedef struct ArxCopySeg {
+  const void* src;
+  void* dst;
+  uint64_t nbytes;
+} ArxCopySeg;
+int arx_copy_segments(const ArxCopySeg* segments, int64_t num_segments, uint64_t max_segment_bytes, void* stream);
 int arx_binary_rebase_offsets(const int32_t* offsets, int64_t length, int32_t base, int32_t* out,
                               void* stream);
 /* Scalar aggregates over an int64 column in one pass — the state SumImpl / CountImpl / MinMaxImpl keep

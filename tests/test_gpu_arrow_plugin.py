@@ -598,10 +598,22 @@ ACERO_DEVICE_SCRIPT = textwrap.dedent(r'''
         names = (b"greater", b"add", b"array_filter", b"hash_sum", b"boolean")
         gpu0 = {f: lib.arrow_amd_plugin_calls(f, 1) for f in names}
         stock0 = {f: lib.arrow_amd_plugin_calls(f, 0) for f in names}
+        lib.arrow_amd_plugin_aggregate_flushes.restype = ctypes.c_int64
+        lib.arrow_amd_plugin_set_aggregate_flush_rows.argtypes = [ctypes.c_int64]
         for threads in (False, True):
-            got = plan(dev, "aggregate_rocm").to_table(use_threads=threads).sort_by("k")
-            assert got.schema.names == ["k", "v_sum"]
-            assert got.equals(want), (null_p, threads, got.slice(0, 5), want.slice(0, 5))
+            # null-free device batches are remembered and copied into the node's staging columns many at a time by
+            # one launch (arx_copy_segments): with the default threshold (one copy at the end) and with a small one
+            # (several copies while batches still arrive)
+            for flush_rows in (1 << 21, max(1000, n // 40)):
+                lib.arrow_amd_plugin_set_aggregate_flush_rows(flush_rows)
+                f0 = lib.arrow_amd_plugin_aggregate_flushes()
+                got = plan(dev, "aggregate_rocm").to_table(use_threads=threads).sort_by("k")
+                assert got.schema.names == ["k", "v_sum"]
+                assert got.equals(want), (null_p, threads, flush_rows, got.slice(0, 5), want.slice(0, 5))
+                if null_p == 0.0:
+                    flushes = lib.arrow_amd_plugin_aggregate_flushes() - f0
+                    assert flushes >= 1 and (flush_rows >= n or flushes > 1), (flush_rows, flushes)
+        lib.arrow_amd_plugin_set_aggregate_flush_rows(1 << 21)
         for f in names:   # FilterNode's expression, its per-column Filter, the projection and the group-by all ran on the GPU
             assert lib.arrow_amd_plugin_calls(f, 1) > gpu0[f], f
             assert lib.arrow_amd_plugin_calls(f, 0) == stock0[f], f
