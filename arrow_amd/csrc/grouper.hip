@@ -9,7 +9,7 @@
 // they go to a pending list that the next launch drains, by which time every publication of the previous launch is
 // visible.  Rows of groups that already exist only read.
 //
-// Group ids are the reference's: the k-th distinct key row in ROW ORDER gets id k.  Concurrent insertion hands out
+// Group ids are in order of first appearance (GrouperImpl's order): the k-th distinct key row in ROW ORDER gets id k.  Concurrent insertion hands out
 // provisional ids in arrival order; every new group records its smallest row (atomicMin), the set of those rows is a
 // bitmap whose ascending positions (the filter machinery's bit -> row-number compaction) are the ranks, and the new
 // groups and the batch's ids are renumbered once.  Batches that add no group skip all of that.

@@ -638,8 +638,9 @@ int arx_hash_mean_i64_finalize(const int64_t* sums, const int64_t* counts, int64
  *
  * Key columns: byte widths 1, 2, 4 or 8 (integers, temporal types ... compared by their bits), at most 8 columns and
  * 16 bytes per row in total.  A null is a key value of its own (all rows whose column j is null agree in column j),
- * as in the reference.  Group ids are the reference's: the k-th distinct key row in row order gets id k, across
- * calls.  max_groups bounds the distinct key rows over the Grouper's life; exceeding it fails the call with
+ * as in the reference.  Group ids are in order of first appearance: the k-th distinct key row in row order gets id k,
+ * across calls (GrouperImpl's order and that of every expectation in grouper_test.cc; GrouperFastImpl's ids are a
+ * bijection away, which is what the reference's own AssertEquivalentIds accepts).  max_groups bounds the distinct key rows over the Grouper's life; exceeding it fails the call with
  * ARX_INVALID and leaves the state unusable (arx_grouper_init again).
  * state: device, arx_grouper_state_bytes(max_groups), 256-byte aligned.  ws: device, 256-byte aligned.  Synchronous. */
 size_t arx_grouper_state_bytes(int64_t max_groups);

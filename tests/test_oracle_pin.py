@@ -636,3 +636,97 @@ def test_grouper_vectorised_oracle_equals_the_row_at_a_time_one():
         got_map = {(int(cols[0][0][r]) if cols[0][1][r] else None, int(cols[1][0][r]) if cols[1][1][r] else None): int(sums[g])
                    for g, r in enumerate(first)}
         assert got_map == ref_map
+
+
+def _reference_grouper(cols, batch_rows):
+    """The reference's own Grouper (GrouperFastImpl in the wheel's libarrow_compute) on (values, valid) columns through
+    oracle/ref/grouper_probe.cc; returns (ids, [(unique values, valid)])."""
+    import subprocess
+    import tempfile
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.dirname(pa.__file__)
+    src = os.path.join(ROOT, "oracle", "ref", "grouper_probe.cc")
+    exe = os.path.join(ROOT, "oracle", "_build", "grouper_probe")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        libs = [os.path.join(d, f) for f in sorted(os.listdir(d))
+                if f.startswith(("libarrow.so.", "libarrow_compute.so.")) and f.count(".") == 2]
+        tmp = f"{exe}.tmp{os.getpid()}"
+        subprocess.check_call(["g++", "-std=c++20", "-O1", "-I", os.path.join(d, "include"), src, "-o", tmp, *libs,
+                               f"-Wl,-rpath,{d}"])
+        os.replace(tmp, exe)
+    n = len(cols[0][0])
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.array([n, len(cols), batch_rows], dtype=np.int64).tobytes())
+            for values, valid in cols:
+                f.write(np.array([values.dtype.itemsize, int(values.dtype.kind == "f")], dtype=np.int64).tobytes())
+                f.write(np.ascontiguousarray(values).tobytes())
+                f.write(np.ascontiguousarray(valid, dtype=np.uint8).tobytes())
+        subprocess.check_call([exe, fin, fout])
+        raw = open(fout, "rb").read()
+    g = int(np.frombuffer(raw, dtype=np.int64, count=1)[0])
+    ids = np.frombuffer(raw, dtype=np.uint32, count=n, offset=8)
+    off = 8 + 4 * n
+    uniq = []
+    for values, _ in cols:
+        w = values.dtype.itemsize
+        uv = np.frombuffer(raw, dtype=values.dtype, count=g, offset=off)
+        off += g * w
+        uvalid = np.frombuffer(raw, dtype=np.uint8, count=g, offset=off).astype(bool)
+        off += g
+        uniq.append((uv, uvalid))
+    return ids, uniq
+
+
+@pytest.mark.skipif(pa is None, reason="needs the pyarrow wheel (the reference build)")
+def test_oracle_grouper_against_the_reference_grouper_itself():
+    """oracle.Grouper vs arrow::compute::Grouper from the wheel on random key rows (1-4 fixed-width columns, nulls, several
+    Consume calls): the same partition of the rows into groups (ids equal up to a bijection — all that the reference's
+    own AssertEquivalentIds asks, grouper_test.cc:676-714), the same set of unique rows, uniques[id] = the row's key on
+    both sides, and — what the device Grouper additionally promises — whether the reference's ids are in order of first
+    appearance (they are for the generic GrouperImpl; the fast implementation hands out ids per 1024-row minibatch in
+    hash order, so only small batches show it)."""
+    rng = np.random.default_rng(2024)
+    cases = [((np.int64,), 5000, 300, 0.1, 5000), ((np.int32, np.int32), 20000, 700, 0.1, 4096),
+             ((np.uint8, np.int64, np.uint16), 8000, 5000, 0.05, 1000), ((np.float64, np.int32), 3000, 40, 0.2, 3000),
+             ((np.int16, np.int16, np.int16, np.int16), 12000, 9, 0.3, 777), ((np.int64,), 900, 900, 0.0, 100)]
+    first_appearance_seen = False
+    for dtypes, n, card, null_p, batch_rows in cases:
+        cols = []
+        for dt in dtypes:
+            pool = (rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, size=card, dtype=dt, endpoint=True)
+                    if np.issubdtype(dt, np.integer) else rng.standard_normal(card).astype(dt))
+            valid = rng.random(n) >= null_p
+            vals = pool[rng.integers(0, card, size=n)]
+            vals[~valid] = 0
+            cols.append((vals, valid))
+        # the probe declares unsigned / float types of the same width: the Grouper compares bytes either way
+        as_bytes = [(v.view({1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[v.dtype.itemsize])
+                     if v.dtype.kind != "f" else v, valid) for v, valid in cols]
+        ref_ids, ref_uniq = _reference_grouper(as_bytes, batch_rows)
+        mine = O.Grouper(len(cols))
+        my_ids = np.concatenate([mine.consume([(v[b:b + batch_rows], valid[b:b + batch_rows]) for v, valid in cols])
+                                 for b in range(0, n, batch_rows)])
+        g = int(ref_ids.max()) + 1
+        assert mine.num_groups == g == len(ref_uniq[0][0]), (dtypes, mine.num_groups, g)
+        # same partition: the pairs (my id, reference id) form a bijection
+        pairs = np.unique(np.stack([my_ids.astype(np.int64), ref_ids.astype(np.int64)], axis=1), axis=0)
+        assert len(pairs) == g and len(np.unique(pairs[:, 0])) == g and len(np.unique(pairs[:, 1])) == g, dtypes
+        # uniques[id] is the row's key, on both sides
+        my_uniq = mine.uniques([v.dtype for v, _ in cols])
+        for (vals, valid), (rv, rvalid), (mv, mvalid) in zip(cols, ref_uniq, my_uniq):
+            assert np.array_equal(rvalid[ref_ids], valid) and np.array_equal(mvalid[my_ids], valid)
+            assert np.array_equal(rv.view(np.uint8).reshape(g, -1)[ref_ids][valid], vals.view(np.uint8).reshape(n, -1)[valid])
+            assert np.array_equal(mv.view(np.uint8).reshape(g, -1)[my_ids][valid], vals.view(np.uint8).reshape(n, -1)[valid])
+        first_appearance_seen |= bool(np.array_equal(my_ids, ref_ids))
+    # the id ORDER: first appearance is what GrouperImpl produces and what every expectation of grouper_test.cc spells
+    # out; the fast implementation (the one Make picks for these key types) agrees on inputs of that size ...
+    tiny = [(np.array([3, 27, 3, 27, 0, 81, 27, 81], dtype=np.int64),
+             np.array([1, 1, 1, 1, 0, 1, 1, 1], dtype=bool))]
+    ref_ids, _ = _reference_grouper([(tiny[0][0].view(np.uint64), tiny[0][1])], 8)
+    assert O.Grouper(1).consume(tiny).tolist() == ref_ids.tolist() == [0, 1, 0, 1, 2, 3, 1, 3]
+    # ... and hands out ids in hash order inside its minibatches on larger ones (a bijection away, checked above)
+    assert not first_appearance_seen
