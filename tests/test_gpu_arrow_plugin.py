@@ -1040,6 +1040,39 @@ NUMERIC_OPS_SCRIPT = textwrap.dedent(r'''
                 assert (got == want) if isinstance(want, str) else got.equals(want), (t, got, want)
     c1, a1 = lib.arrow_amd_plugin_calls(b"compare", 1) + lib.arrow_amd_plugin_calls(b"greater", 1), lib.arrow_amd_plugin_calls(b"add", 1)
     assert c1 - c0 == ran_c and a1 - a0 == ran_a, (c1 - c0, ran_c, a1 - a0, ran_a)
+    # temporal types: the comparisons of timestamp / duration / time32 / time64 (per unit, any zone), date32, date64
+    c0 = lib.arrow_amd_plugin_calls(b"compare", 1)
+    ran_t = 0
+    for t in (pa.timestamp("us"), pa.timestamp("ns", tz="UTC"), pa.timestamp("s", tz="Europe/Paris"), pa.duration("ms"),
+              pa.time32("s"), pa.time64("ns"), pa.date32(), pa.date64()):
+        width = 4 if t in (pa.time32("s"), pa.date32()) else 8
+        raw = rng.integers(0, 80_000 if width == 4 else 10**6, n).astype(np.int32 if width == 4 else np.int64)
+        if t == pa.date64():
+            raw = raw * 86_400_000
+        a = pa.array(raw, pa.int32() if width == 4 else pa.int64(), mask=rng.random(n) < 0.06).cast(t)
+        b = pa.array(np.roll(raw, 7), pa.int32() if width == 4 else pa.int64(), mask=rng.random(n) < 0.04).cast(t)
+        da, db = to_device(a), to_device(b)
+        s = a[int(np.flatnonzero(np.asarray(a.is_valid()))[0])]
+        for name in cmp_fns:
+            fn = lambda x, y: pc.call_function(name, [x, y])
+            for dev_out, host_out in ((fn(da, db), fn(a, b)), (fn(da, s), fn(a, s)), (fn(s, db), fn(s, b)),
+                                      (fn(da.slice(3, n - 5), db.slice(5, n - 5)), fn(a.slice(3, n - 5), b.slice(5, n - 5)))):
+                assert not dev_out.is_cpu, (name, t)
+                ho = to_host(dev_out)
+                assert ho.equals(host_out) and ho.null_count == host_out.null_count, (name, t)
+            ran_t += 4
+    assert lib.arrow_amd_plugin_calls(b"compare", 1) - c0 == ran_t
+    # a zoned against a zone-less timestamp column is the reference's error, not a comparison of raw integers
+    zoned, naive = pa.array([1, 2], pa.timestamp("us", tz="UTC")), pa.array([1, 3], pa.timestamp("us"))
+    def message(call):
+        try:
+            call()
+            return None
+        except (pa.lib.ArrowInvalid, pa.lib.ArrowTypeError, pa.lib.ArrowNotImplementedError) as e:
+            return type(e).__name__ + ": " + str(e)
+    want = message(lambda: pc.call_function("less", [zoned, naive]))
+    got = message(lambda: pc.call_function("less", [to_device(zoned), to_device(naive)]))
+    assert want is not None and got == want, (got, want)
     # an Acero filter + projection over int32 / float32 device columns: (a > 3) & (b < 0.5f) -> a * a + a
     ai = pa.array(rng.integers(-1000, 1000, n).astype(np.int32), mask=rng.random(n) < 0.05)
     bf = pa.array((np.round(rng.standard_normal(n) * 4) / 2).astype(np.float32), mask=rng.random(n) < 0.05)
