@@ -573,6 +573,17 @@ def _numeric_operands(left, right):
     return arr, n, lp, lsp, rp, rsp, (lh, rh)
 
 
+def _num_type_id(t: DataType) -> int:
+    """ARX_NUM_* of a numeric type, or of the physical integer of a temporal one (timestamp / duration / time / date)."""
+    if t.name in _NUM_TYPE_ID:
+        return _NUM_TYPE_ID[t.name]
+    from .array import is_temporal
+
+    if is_temporal(t):
+        return _NUM_TYPE_ID["int64" if t.bit_width == 64 else "int32"]
+    raise ArrowNotImplementedError(f"no numeric kernel for {t.name}")
+
+
 def _exec_compare_numeric(op_name):
     code = _CMP_CODE[op_name]
 
@@ -584,7 +595,7 @@ def _exec_compare_numeric(op_name):
         lib, stream = _lib_and_stream(dev)
         out = alloc(bitmap_nbytes(n), dev, zero=True)
         with tracing.span("arx_compare_numeric"):
-            check(lib.arx_compare_numeric(code, _NUM_TYPE_ID[arr.type.name], lp, lsp, rp, rsp, n, out.data_ptr(), stream))
+            check(lib.arx_compare_numeric(code, _num_type_id(arr.type), lp, lsp, rp, rsp, n, out.data_ptr(), stream))
         validity, nc = _propagate_validity([left, right], n, dev)
         return Array(bool_, n, [validity, out], nc, 0)
     return run
@@ -1107,6 +1118,25 @@ def _build_registry() -> FunctionRegistry:
     f.add_kernel(Kernel((float64, float64), _exec_greater, bool_))
     f.add_kernel(Kernel((int64, int64), _exec_greater, bool_))
     reg.add_function(f)
+    # temporal operands (timestamp / duration / time / date): the comparisons of their physical integers; both sides of
+    # the same type and unit — the reference unifies units by implicit casts before dispatch (DispatchBest), and compares
+    # a zoned timestamp only with a zoned one (scalar_compare.cc:299-313)
+    from .array import is_temporal
+
+    def _temporal_pair_kernel(name):
+        run = _exec_compare_numeric(name)
+
+        def checked(args, options):
+            types = [a.type for a in args if isinstance(a, (Array, Scalar))]
+            if len({t.name.split(", tz=")[0].rstrip("]") for t in types}) > 1:
+                raise ArrowNotImplementedError(f"{name}: temporal operands of different types / units ({', '.join(t.name for t in types)})")
+            zoned = {", tz=" in t.name for t in types if t.name.startswith("timestamp")}
+            if len(zoned) > 1:
+                raise ArrowInvalid("Cannot compare timestamp with timezone to timestamp without timezone, got: "
+                                   + " and ".join(t.name for t in types))
+            return run(args, options)
+        return Kernel((is_temporal, is_temporal), checked, bool_)
+
 
     for name in ("equal", "not_equal", "greater_equal", "less", "less_equal"):
         f = Function(name, Function.SCALAR, 2)
@@ -1114,7 +1144,9 @@ def _build_registry() -> FunctionRegistry:
             f.add_kernel(Kernel((t, t), _exec_compare_numeric(name), bool_))
         f.add_kernel(Kernel((float64, float64), _exec_compare(name), bool_))
         f.add_kernel(Kernel((int64, int64), _exec_compare(name), bool_))
+        f.add_kernel(_temporal_pair_kernel(name))
         reg.add_function(f)
+    reg.get_function("greater").add_kernel(_temporal_pair_kernel("greater"))
 
     f = Function("add", Function.SCALAR, 2)
     for t in numeric_types:

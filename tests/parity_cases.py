@@ -598,6 +598,33 @@ def check_numeric_compare_arith(amd, rng, dtype, n=6000, use_pyarrow=True):
         assert_equal(_data_np(out, dtype)[masked.valid], want[masked.valid], f"{op}_checked[{dt.name}] with null overflow slots")
 
 
+def check_temporal_compare(amd, rng, n=4000):
+    """The comparison family on temporal columns (timestamp with / without zone, duration, time32 / time64, date32 /
+    date64): equal to pyarrow's on the same arrays — bits, validity, null count; operands of different units or a zoned
+    against a zone-less timestamp are refused like the reference refuses them."""
+    if pa is None:
+        pytest.skip("needs pyarrow")
+    for t in (pa.timestamp("us"), pa.timestamp("ns", "UTC"), pa.timestamp("s", "Europe/Paris"), pa.duration("ms"),
+              pa.time32("s"), pa.time64("ns"), pa.date32(), pa.date64()):
+        w = 4 if t in (pa.time32("s"), pa.date32()) else 8
+        raw = rng.integers(0, 80_000 if w == 4 else 10**6, n).astype(np.int32 if w == 4 else np.int64)
+        if t == pa.date64():
+            raw = raw * 86_400_000
+        a = pa.array(raw, pa.int32() if w == 4 else pa.int64(), mask=rng.random(n) < 0.08).cast(t)
+        b = pa.array(np.roll(raw, 5), pa.int32() if w == 4 else pa.int64(), mask=rng.random(n) < 0.05).cast(t)
+        da, db = amd.Array.from_pyarrow(a.slice(3)), amd.Array.from_pyarrow(b.slice(3))
+        for op in ("equal", "not_equal", "greater", "greater_equal", "less", "less_equal"):
+            got = amd.compute.call_function(op, [da, db])
+            want = getattr(pc, op)(a.slice(3), b.slice(3))
+            assert got.to_pyarrow().equals(want) and got.null_count in (want.null_count, -1), (str(t), op)
+    zoned = amd.Array.from_pyarrow(pa.array([1, 2], pa.timestamp("us", "UTC")))
+    naive = amd.Array.from_pyarrow(pa.array([1, 3], pa.timestamp("us")))
+    with pytest.raises(amd.ArrowInvalid, match="Cannot compare timestamp with timezone to timestamp without timezone"):
+        amd.compute.call_function("less", [zoned, naive])
+    with pytest.raises(NotImplementedError, match="different types / units"):
+        amd.compute.call_function("equal", [naive, amd.Array.from_pyarrow(pa.array([1, 3], pa.timestamp("ms")))])
+
+
 def check_divide(amd, rng, n=6000, use_pyarrow=True):
     """divide / divide_checked (Divide / DivideChecked, base_arithmetic_internal.h:366-424) on int64 and float64, array
     and scalar operands: results at visited slots, validity, and the error the LAST failing valid slot names;

@@ -908,3 +908,7 @@ def test_compare_and_arithmetic_on_every_numeric_type(emu_ctx, dtype):
 def test_sort_keys_with_a_shared_prefix(emu_ctx, wide):
     lib = emu_ctx._lib.get_lib()
     P.check_sort_limited_range(emu_ctx, lib, rng_for("sort-prefix", wide), 9000, wide)
+
+
+def test_compare_on_temporal_columns(emu_ctx):
+    P.check_temporal_compare(emu_ctx, rng_for("temporal-compare"), n=3000)

@@ -1180,3 +1180,7 @@ def test_compare_and_arithmetic_on_every_numeric_type(gpu_ctx, dtype):
 def test_sort_keys_with_a_shared_prefix(gpu_ctx, wide):
     lib = gpu_ctx._lib.get_lib()
     P.check_sort_limited_range(gpu_ctx, lib, rng_for("sort-prefix", wide), 5000011, wide)
+
+
+def test_compare_on_temporal_columns(gpu_ctx):
+    P.check_temporal_compare(gpu_ctx, rng_for("temporal-compare"), n=700003)
