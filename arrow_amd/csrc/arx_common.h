@@ -106,6 +106,18 @@ __device__ __forceinline__ uint64_t load_word_nb(const Bits& b, int64_t w) {
 }
 
 // ---------------------------------------------------------------------------
+// XCD-aware work mapping.  The dispatcher places workgroup b on XCD b % 8 (observed, not promised: only speed depends on
+// it).  xcd_contiguous(b, n) renumbers the n workgroups so that XCD x works on ONE contiguous range of work items
+// instead of every eighth one: work items that write the same region (the tiles of one partition) then share an L2.
+// Bijective for any n (cdna_hip_programming.md, "XCD swizzle must be bijective").
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n) {
+  const uint32_t xcd = b & 7u, q = n >> 3, r = n & 7u;
+  const uint32_t first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return first + (b >> 3);
+}
+
+// ---------------------------------------------------------------------------
 // Wave-level primitives (64 lanes)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

@@ -672,6 +672,7 @@ struct GbpArgs {
   unsigned long long* dense_sums;
   unsigned long long* dense_counts;
   unsigned int* dense_null_seen;
+  int xcd_map;             // bit 0: level-2 scatter, bit 1: aggregate, bit 2: level-1 scatter — XCD-contiguous work numbering
   int agg_pipe;            // software-pipelined loads in the LDS aggregate kernel (A/B knob)
   uint32_t agg_chunk;      // rows per aggregate work unit (a power of two)
 };
@@ -1007,7 +1008,8 @@ __global__ __launch_bounds__(kGbThreads, 6) void gbp_scatter1_kernel(GbpArgs a) 
 template <bool HAS_NULLS>
 __global__ __launch_bounds__(kGbThreads, 6) void gbp_scatter1g_kernel(GbpArgs a) {
   __shared__ GbpScatterLds lds;
-  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kGbTile;
+  const uint32_t tile = (a.xcd_map & 4) ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int64_t row0 = static_cast<int64_t>(tile) * kGbTile;
   const int nrows = static_cast<int>(a.n - row0 < kGbTile ? a.n - row0 : kGbTile);
   gbp_scatter_tile<1, HAS_NULLS, true>(a, lds, a.keys, a.values, row0, nrows, 0, a.keys_a, a.vals_a);
 }
@@ -1017,7 +1019,9 @@ __global__ __launch_bounds__(kGbThreads, 6) void gbp_scatter2_kernel(GbpArgs a) 
   __shared__ uint32_t part_s;
   const int tid = threadIdx.x;
   const int nb1 = 1 << a.b1;
-  const uint32_t g = blockIdx.x;
+  // XCD x takes a contiguous eighth of the tiles (whole level-1 partitions): a partition's (tile, digit) runs meet in
+  // one L2 instead of eight (sort: -18 % on the same kernel shape)
+  const uint32_t g = (a.xcd_map & 1) ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   if (g >= a.l2_tile_start[nb1]) return;  // over-provisioned grid
   // which level-1 partition owns tile g: the last p with l2_tile_start[p] <= g
   if (tid < 64) {
@@ -1061,7 +1065,7 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
   } else {
     // which partition owns work unit u: the last q with agg_unit_start[q] <= u.  Two rounds of a
     // 64-lane search (coarse stride, then inside the stride) by the first wave.
-    const uint32_t u = blockIdx.x;
+    const uint32_t u = (a.xcd_map & 2) ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
     const int nparts = 1 << a.bits;
     if (u >= a.agg_unit_start[nparts]) return;  // over-provisioned grid (workgroup-uniform)
     if (tid < 64) {
@@ -1221,6 +1225,7 @@ struct GbpPlan {
 static int g_gbp_min_rows = 1 << 17;  // below this the direct HBM-atomics kernel is used
 static int g_gbp_bits = -1;           // -1 = from the capacity hint
 static int g_gbp_agg_pipe = 1;
+static int g_gbp_xcd_map = 1;         // XCD-contiguous work numbering: bit 0 level-2 scatter (-2.6 ms at 4e9 rows), bit 1 aggregate (+5 ms: off), bit 2 level-1 scatter (no effect)
 static int g_gbp_b1 = -1;             // level-1 bits override (-1: half of the partition bits)
 static int g_gbp_chunks = 2048;       // level-1 chunks = workgroups of the hist / scatter1 kernels
 static int g_gbp_l1_global = 1;       // level 1 with global cursors (one tile per workgroup; +3 % at 4e9 rows) instead of chunked exact offsets
@@ -1369,6 +1374,10 @@ int set_groupby_option(const char* name, int64_t value) {
     g_gbp_b1 = static_cast<int>(value);
     return 1;
   }
+  if (strcmp(name, "groupby_xcd_map") == 0) {
+    g_gbp_xcd_map = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 7)));
+    return 1;
+  }
   if (strcmp(name, "groupby_agg_pipe") == 0) {
     g_gbp_agg_pipe = value != 0;
     return 1;
@@ -1483,6 +1492,7 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
       a.l2_tile_start = reinterpret_cast<uint32_t*>(w + plan.off_l2_tile_start);
       a.agg_unit_start = reinterpret_cast<uint32_t*>(w + plan.off_agg_unit_start);
       a.agg_pipe = g_gbp_agg_pipe;
+      a.xcd_map = g_gbp_xcd_map;
       a.agg_chunk = static_cast<uint32_t>(g_gbp_agg_chunk);
       const int rc = (kbm != nullptr || vbm != nullptr) ? gbp_run_slice<true>(v, a, plan, st)
                                                         : gbp_run_slice<false>(v, a, plan, st);
@@ -1971,6 +1981,7 @@ int arx_hash_sum_i64_consume_ws(const ArxSpan* values, int values_is_scalar, int
     a.l2_tile_start = reinterpret_cast<uint32_t*>(w + plan.off_l2_tile_start);
     a.agg_unit_start = reinterpret_cast<uint32_t*>(w + plan.off_agg_unit_start);
     a.agg_pipe = g_gbp_agg_pipe;
+      a.xcd_map = g_gbp_xcd_map;
     a.agg_chunk = static_cast<uint32_t>(g_gbp_agg_chunk);
     const int rc = vbm != nullptr ? gbp_run_slice<true>(none, a, plan, st) : gbp_run_slice<false>(none, a, plan, st);
     if (rc != ARX_OK) return rc;

@@ -38,6 +38,7 @@ static int64_t g_sort_msd_segment_rows = int64_t(1) << 27;  // above this: an ex
 static int g_sort_msd_final_rows_log2 = 1;  // log2 of the rows aimed at per final sub-bucket (rank loop length); with the 4096-bin finish 1 beats 2 / 3 / 4 by 3 / 9 / 18 % at 2e9 rows
 static int g_sort_msd_small_bucket = 1;  // 512-thread / 5120-row bucket kernel when every bucket fits it
 static int g_sort_msd_wide_sample_shift = 4;  // wide form: level-1 capacities from a histogram of 1 tile in 2^shift (0 = exact histogram of every row)
+static int g_sort_xcd_map = 1;                // wide form, XCD-contiguous work numbering: bit 0 level 2 (-2.1 ms at 2e9 rows: a bucket's runs meet in one L2), bit 1 bucket finish, bit 2 level 1 (both: no effect)
 static int g_sort_msd_prefix = 1;             // MSD forms take their digits below the bits that ALL keys share (ids, timestamps, small ints: the top bits are equal)
 static int g_sort_msd_wide_gap2 = 1;          // wide form: level-2 buckets get a fixed room each (bucket mean + 6 sigma + 64) instead of an exact histogram pass
 static int g_sort_msd_wide_sample_strict = 0; // tests: a sampled attempt that overflows is an error instead of a silent exact re-run
@@ -518,6 +519,7 @@ struct MsdArgs {
   uint64_t* out_final;
   unsigned int* overflow;
   const uint32_t* part_in;    // record input of the bucket finish (AOS form): first record of every bucket
+  int xcd_map;                // XCD-contiguous work numbering: bit 0 the level-2 scatter, bit 1 the bucket finish
 };
 
 // (key, row id) as one 12-byte record: what the wide form's two scatter levels write and read (one output stream per
@@ -779,7 +781,8 @@ __global__ __launch_bounds__(kMsdThreads, 6) void msd_scatter2_kernel(MsdArgs a)
   __shared__ uint32_t part_s;
   const int tid = threadIdx.x;
   const int nb1 = 1 << a.b1;
-  const uint32_t g = blockIdx.x;
+  // (a.xcd_map bit 0: XCD x takes a contiguous eighth of the tiles — a level-1 bucket's runs meet in one L2)
+  const uint32_t g = (a.xcd_map & 1) ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   if (g >= a.l2_tile_start[nb1]) return;  // over-provisioned grid
   if (tid < 64) {
     uint32_t below = 0;
@@ -1212,7 +1215,7 @@ __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const uint32_t q = blockIdx.x;
+  const uint32_t q = (a.xcd_map & 2) ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   const int64_t lo = a.part_start[q];
   const int m = static_cast<int>(static_cast<int64_t>(a.part_start[q + 1]) - lo);
   const int64_t lo_in = AOS ? static_cast<int64_t>(a.part_in[q]) : lo;
@@ -1395,6 +1398,10 @@ int set_sort_option(const char* name, int64_t value) {
     g_sort_msd_wide_sample_shift = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 8)));
     return 1;
   }
+  if (strcmp(name, "sort_xcd_map") == 0) {
+    g_sort_xcd_map = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 7)));
+    return 1;
+  }
   if (strcmp(name, "sort_msd_prefix") == 0) {
     g_sort_msd_prefix = value != 0;
     return 1;
@@ -1521,6 +1528,7 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   if (n == 0) return ARX_OK;
   MsdArgs a{};
   a.kshift = kshift;
+  a.xcd_map = g_sort_xcd_map;
   a.src_keys = src_keys;
   a.src_idx = src_idx;
   a.raw = raw;
@@ -1803,6 +1811,8 @@ struct MsdwArgs {
   int kshift;              // leading bits that every key shares: digits are taken from key << kshift
   int sample_shift;        // hist0 reads one chunk in 2^sample_shift (0: every row, exact level-1 sizes)
   int gap2;                // level-2 buckets get a fixed room each (no level-2 histogram)
+  int xcd_map;             // level 2: XCD-contiguous tile numbering
+  int xcd_map1;            // level 1 likewise (A/B)
   int64_t capacity;        // records rec_x / rec_y can hold
   uint32_t* l1_count;      // [2^b1] histogram (of the sample)
   uint32_t* l1_start;      // [2^b1] first record of a level-1 bucket in rec_x (buckets may be followed by unused room)
@@ -2082,7 +2092,8 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1_kernel(MsdwArgs a)
   // an earlier tile already found a bucket without room: the level will be repeated, do not finish this attempt
   // (e.g. pre-sorted input, where a sample of tiles says little about where the bucket boundaries fall)
   if (a.sample_shift > 0 && (__atomic_load_n(&a.flags[0], __ATOMIC_RELAXED) & 4u) != 0) return;
-  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kMsdwTile;
+  const uint32_t tile = a.xcd_map1 ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int64_t row0 = static_cast<int64_t>(tile) * kMsdwTile;
   const int nrows = static_cast<int>(a.n - row0 < kMsdwTile ? a.n - row0 : kMsdwTile);
   msdw_scatter_tile<RAW ? 0 : 1, 1>(a, lds, a.src_keys, a.src_idx, nullptr, row0, nrows, 1 << a.b1, 64 - a.b1,
                                     a.cursor1, a.l1_end, 0u, 0u, 4u, a.rec_x);
@@ -2212,7 +2223,9 @@ template <bool GAP>
 __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter2_kernel(MsdwArgs a) {
   __shared__ MsdwScatterLds lds;
   const int nb1 = 1 << a.b1;
-  const uint32_t g = blockIdx.x;
+  // a.xcd_map: XCD x takes a contiguous eighth of the tiles, i.e. whole level-1 buckets — the (tile, digit) runs of a
+  // bucket then meet in one L2 instead of eight
+  const uint32_t g = a.xcd_map ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   if (g >= a.l2_tile_start[nb1]) return;  // over-provisioned grid
   const uint32_t p = msdw_owner(a.l2_tile_start, nb1, g, &lds.part);
   const int64_t lo = a.l1_start[p];
@@ -2240,6 +2253,8 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   a.raw = raw;
   a.n = n;
   a.kshift = kshift;
+  a.xcd_map = (g_sort_xcd_map & 1) != 0;
+  a.xcd_map1 = (g_sort_xcd_map & 4) != 0;
   a.bits = std::max(2, std::min(std::min(lg - 12, kMsdwMaxBits), 64 - kshift));   // 2048 < average bucket <= 4096 rows
   a.b1 = a.bits / 2;
   a.b2 = a.bits - a.b1;
@@ -2358,6 +2373,7 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   f.n = n;
   f.bits = a.bits;
   f.kshift = kshift;
+  f.xcd_map = g_sort_xcd_map & 2;
   f.part_start = a.part_start;
   f.part_in = a.count2;
   f.overflow = a.flags;
