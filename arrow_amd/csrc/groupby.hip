@@ -1247,7 +1247,10 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity) {
     p.b1 = p.bits;
     p.b2 = 0;
   } else {
-    p.b1 = (p.bits + 1) / 2;
+    // As few level-1 bits as the 256-bin level 2 allows: level 1 scatters over the whole slice, where long runs pay
+    // (32 bins: ~128-record runs), level 2 works inside a partition whose short runs meet in one L2 (xcd_contiguous) —
+    // 4e9 rows / 1e7 keys: 7 + 6 bits 61.6 ms, 5 + 8 bits 54.4 ms; 1e6 keys: 5 + 4 bits 60.8 ms, 3 + 6 bits 54.0 ms
+    p.b1 = std::max(p.bits - 8, std::min(3, p.bits - 1));
     if (g_gbp_b1 > 0) p.b1 = std::max(p.bits - 8, std::min(g_gbp_b1, std::min(8, p.bits - 1)));
     p.b2 = p.bits - p.b1;
   }
