@@ -39,6 +39,8 @@ static int g_sort_msd_final_rows_log2 = 1;  // log2 of the rows aimed at per fin
 static int g_sort_msd_small_bucket = 1;  // 512-thread / 5120-row bucket kernel when every bucket fits it
 static int g_sort_msd_wide_sample_shift = 4;  // wide form: level-1 capacities from a histogram of 1 tile in 2^shift (0 = exact histogram of every row)
 static int g_sort_xcd_map = 1;                // wide form, XCD-contiguous work numbering: bit 0 level 2 (-2.1 ms at 2e9 rows: a bucket's runs meet in one L2), bit 1 bucket finish, bit 2 level 1 (both: no effect)
+static int g_sort_msd_wide_bits = 0;           // wide form: partition bits (0 = from the row count: buckets of 2048..4096 rows; tests force many bins on few rows)
+static int g_sort_msd_wide_b2max = 10;        // wide form: most partition bits given to level 2 (<= 12; 0 = the even split).  2e9 rows: 10 and 11 = the even split (34.8-35.0 ms), 12 = 42 ms (4096-bin scatter 19.3 ms vs 12); 2^28 rows: 10 is 3 % faster than even
 static int g_sort_msd_prefix = 1;             // MSD forms take their digits below the bits that ALL keys share (ids, timestamps, small ints: the top bits are equal)
 static int g_sort_msd_wide_gap2 = 1;          // wide form: level-2 buckets get a fixed room each (bucket mean + 6 sigma + 64) instead of an exact histogram pass
 static int g_sort_msd_wide_sample_strict = 0; // tests: a sampled attempt that overflows is an error instead of a silent exact re-run
@@ -1333,7 +1335,8 @@ constexpr size_t kMsdTableWords = (size_t(1) << kMsdSplBits) + 64;
 constexpr size_t kMsdTableBytes = (3 * kMsdTableWords + size_t(128) * kMsdMaxChunks + 2 * 192 + 64) * 4 + (size_t(1) << kMsdSplBits) * 8;
 
 // tables of the wide two-level form (run_msd_sort_wide): 3 arrays of 2^20 buckets + 10 of 1024 level-1 entries
-constexpr int kMsdwMaxBins = 1024;
+constexpr int kMsdwMaxBins = 1024;    // level 1 (one thread per bin in the one-workgroup scans)
+constexpr int kMsdwMaxBins2 = 4096;   // level 2 (inside a level-1 bucket: short runs are fine there, xcd_contiguous)
 constexpr int kMsdwMaxBits = 20;
 constexpr size_t kMsdwTableBytes = (3 * ((size_t(1) << kMsdwMaxBits) + 64) + 10 * (kMsdwMaxBins + 64)) * 4;
 
@@ -1400,6 +1403,14 @@ int set_sort_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "sort_xcd_map") == 0) {
     g_sort_xcd_map = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 7)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_bits") == 0) {
+    g_sort_msd_wide_bits = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, kMsdwMaxBits)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_b2max") == 0) {
+    g_sort_msd_wide_b2max = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 12)));
     return 1;
   }
   if (strcmp(name, "sort_msd_prefix") == 0) {
@@ -1994,9 +2005,9 @@ __global__ __launch_bounds__(1024) void msdw_scan0b_kernel(MsdwArgs a) {
 struct __attribute__((aligned(16))) MsdwScatterLds {
   uint64_t keys[kMsdwTile];
   uint32_t idx[kMsdwTile];
-  uint32_t cnt[kMsdwMaxBins];
-  uint32_t start[kMsdwMaxBins];
-  uint32_t gbase[kMsdwMaxBins];
+  uint32_t cnt[kMsdwMaxBins2];
+  uint32_t start[kMsdwMaxBins2];
+  uint32_t gbase[kMsdwMaxBins2];
   uint32_t wave_tot[kMsdwThreads / 64];
   uint32_t part;
 };
@@ -2017,7 +2028,7 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const uint32_t dmask = static_cast<uint32_t>(nb - 1);
-  if (tid < nb) lds.cnt[tid] = 0;
+  for (int b = tid; b < nb; b += kMsdwThreads) lds.cnt[b] = 0;
   uint64_t key[kMsdwRows];
   uint32_t idx[kMsdwRows];
 #pragma unroll
@@ -2045,23 +2056,38 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
     if (i * kMsdwThreads + tid < nrows) rank[i] = atomicAdd(&lds.cnt[dig[i]], 1u);
   }
   __syncthreads();
-  const uint32_t c = tid < nb ? lds.cnt[tid] : 0u;
-  const uint32_t incl = wave_inclusive_scan_u32(c);
+  // exclusive scan of nb <= 4096 counters: `per` consecutive counters per thread (1 up to 1024 bins)
+  const int per = (nb + kMsdwThreads - 1) / kMsdwThreads;
+  uint32_t cc[kMsdwMaxBins2 / kMsdwThreads];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < kMsdwMaxBins2 / kMsdwThreads; ++k) {
+    const int b = tid * per + k;
+    cc[k] = (k < per && b < nb) ? lds.cnt[b] : 0u;
+    mine += cc[k];
+  }
+  const uint32_t incl = wave_inclusive_scan_u32(mine);
   if (lane == 63) lds.wave_tot[wave] = incl;
   __syncthreads();
-  if (tid < nb) {
-    uint32_t pre = incl - c;
-    for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
-    lds.start[tid] = pre;
-    uint32_t base = c != 0 ? atomicAdd(&gcursor[tid], c) : 0u;
-    if constexpr (CHECK != 0) {
-      const uint32_t end = CHECK == 1 ? gend[tid] : room_base + (static_cast<uint32_t>(tid) + 1u) * room;
-      if (c != 0 && (base + c > end || base + c < base)) {
-        base = 0xFFFFFFFFu;
-        atomicOr(&a.flags[0], overflow_bit);
+  uint32_t pre = incl - mine;
+  for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
+#pragma unroll
+  for (int k = 0; k < kMsdwMaxBins2 / kMsdwThreads; ++k) {
+    const int b = tid * per + k;
+    if (k < per && b < nb) {
+      const uint32_t c = cc[k];
+      lds.start[b] = pre;
+      uint32_t base = c != 0 ? atomicAdd(&gcursor[b], c) : 0u;
+      if constexpr (CHECK != 0) {
+        const uint32_t end = CHECK == 1 ? gend[b] : room_base + (static_cast<uint32_t>(b) + 1u) * room;
+        if (c != 0 && (base + c > end || base + c < base)) {
+          base = 0xFFFFFFFFu;
+          atomicOr(&a.flags[0], overflow_bit);
+        }
       }
+      lds.gbase[b] = base;
+      pre += c;
     }
-    lds.gbase[tid] = base;
   }
   __syncthreads();
 #pragma unroll
@@ -2114,7 +2140,7 @@ __device__ __forceinline__ uint32_t msdw_owner(const uint32_t* __restrict__ star
 
 // Exact form, W4: counts of the next b2 bits inside level-1 buckets; work unit = <= kMsdwUnit rows of one bucket
 __global__ __launch_bounds__(kMsdThreads) void msdw_hist1_kernel(MsdwArgs a) {
-  __shared__ uint32_t h[kMsdwMaxBins];
+  __shared__ uint32_t h[kMsdwMaxBins2];
   __shared__ uint32_t part_s;
   const int tid = threadIdx.x;
   const int nb1 = 1 << a.b1;
@@ -2160,25 +2186,33 @@ __global__ __launch_bounds__(1024) void msdw_scan1_kernel(MsdwArgs a) {
   const uint32_t p = blockIdx.x;
   const int nb2 = 1 << a.b2;
   const size_t base = static_cast<size_t>(p) << a.b2;
-  uint32_t c = 0;
-  if (tid < nb2) {
-    if (a.gap2) {
-      const uint32_t room = a.room2[p];
-      const uint32_t lo = a.y_base[p] + static_cast<uint32_t>(tid) * room;
-      const uint32_t cur = a.cursor2[base + tid];
-      if (cur > lo + room || cur < lo) {
-        atomicOr(&a.flags[0], 16u);
-        c = room;
+  const int per = (nb2 + 1023) / 1024;   // consecutive level-2 buckets per thread (1 up to 1024 of them)
+  uint32_t cc[kMsdwMaxBins2 / 1024];
+  uint32_t c = 0, mx = 0;
+#pragma unroll
+  for (int k = 0; k < kMsdwMaxBins2 / 1024; ++k) {
+    const int d = tid * per + k;
+    cc[k] = 0;
+    if (k < per && d < nb2) {
+      if (a.gap2) {
+        const uint32_t room = a.room2[p];
+        const uint32_t lo = a.y_base[p] + static_cast<uint32_t>(d) * room;
+        const uint32_t cur = a.cursor2[base + d];
+        if (cur > lo + room || cur < lo) {
+          atomicOr(&a.flags[0], 16u);
+          cc[k] = room;
+        } else {
+          cc[k] = cur - lo;
+        }
+        a.count2[base + d] = lo;
       } else {
-        c = cur - lo;
+        cc[k] = a.count2[base + d];
       }
-      a.count2[base + tid] = lo;
-    } else {
-      c = a.count2[base + tid];
     }
+    c += cc[k];
+    mx = mx > cc[k] ? mx : cc[k];
   }
   const uint32_t incl = wave_inclusive_scan_u32(c);
-  uint32_t mx = c;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     const uint32_t o = __shfl_xor(mx, d, 64);
@@ -2193,11 +2227,16 @@ __global__ __launch_bounds__(1024) void msdw_scan1_kernel(MsdwArgs a) {
     if (k < wave) pre += wt[k];
     total += wt[k];
   }
-  if (tid < nb2) {
-    a.part_start[base + tid] = pre;
-    if (!a.gap2) {
-      a.cursor2[base + tid] = pre;
-      a.count2[base + tid] = pre;   // part_in of the bucket finish: rec_y is compact, record = final position
+#pragma unroll
+  for (int k = 0; k < kMsdwMaxBins2 / 1024; ++k) {
+    const int d = tid * per + k;
+    if (k < per && d < nb2) {
+      a.part_start[base + d] = pre;
+      if (!a.gap2) {
+        a.cursor2[base + d] = pre;
+        a.count2[base + d] = pre;   // part_in of the bucket finish: rec_y is compact, record = final position
+      }
+      pre += cc[k];
     }
   }
   if (tid == 0) {
@@ -2213,8 +2252,8 @@ __global__ __launch_bounds__(1024) void msdw_scan1_kernel(MsdwArgs a) {
 __global__ __launch_bounds__(1024) void msdw_init2_kernel(MsdwArgs a) {
   const uint32_t p = blockIdx.x;
   const int nb2 = 1 << a.b2;
-  if (static_cast<int>(threadIdx.x) < nb2) {
-    a.cursor2[(static_cast<size_t>(p) << a.b2) + threadIdx.x] = a.y_base[p] + threadIdx.x * a.room2[p];
+  for (int d = threadIdx.x; d < nb2; d += 1024) {
+    a.cursor2[(static_cast<size_t>(p) << a.b2) + d] = a.y_base[p] + static_cast<uint32_t>(d) * a.room2[p];
   }
 }
 
@@ -2256,8 +2295,17 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   a.xcd_map = (g_sort_xcd_map & 1) != 0;
   a.xcd_map1 = (g_sort_xcd_map & 4) != 0;
   a.bits = std::max(2, std::min(std::min(lg - 12, kMsdwMaxBits), 64 - kshift));   // 2048 < average bucket <= 4096 rows
-  a.b1 = a.bits / 2;
-  a.b2 = a.bits - a.b1;
+  if (g_sort_msd_wide_bits > 0) a.bits = std::max(2, std::min(g_sort_msd_wide_bits, 64 - kshift));
+  // level 2 takes up to b2max bits (<= 4096 bins, default 1024): level 1 scatters over the whole array, where fewer
+  // bins and longer runs pay; level 2 works inside a bucket whose short runs meet in one L2 (xcd_contiguous) — but a
+  // 4096-bin level 2 loses more there than level 1 gains (profiles/r02_ah)
+  a.b2 = g_sort_msd_wide_b2max > 0 ? std::min(std::min(g_sort_msd_wide_b2max, 12), a.bits - 1)
+                                   : a.bits - a.bits / 2;   // 0: the even split
+  a.b1 = a.bits - a.b2;
+  if (a.b1 > 10) {   // (level 1 has at most 1024 bins)
+    a.b1 = 10;
+    a.b2 = a.bits - a.b1;
+  }
   const bool roomy = capacity < (int64_t(1) << 32);   // record positions are 32-bit
   a.capacity = roomy ? capacity : n;
   uint32_t* t = reinterpret_cast<uint32_t*>(tables);

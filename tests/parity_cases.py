@@ -767,15 +767,16 @@ def check_sort_indices(amd, arr: HostArray, order="ascending", null_placement="a
     return out
 
 
-def check_sort_wide_sampled(amd, lib, rng, n, shift, gap2=1):
+def check_sort_wide_sampled(amd, lib, rng, n, shift, gap2=1, b2max=12):
     """The wide two-level sort with level-1 bucket sizes ESTIMATED from one tile in 2^shift (buckets get room to spare,
     level 2 reads what arrived) and, gap2, level-2 buckets in fixed rooms (mean + 6 sigma) instead of a histogram
     pass.  Uniform keys: the estimates must hold (strict mode turns a silent exact re-run into an error).  Sorted /
     blocky inputs where the sampled tiles say little about the rest, or whose keys are not uniform inside a level-1
     bucket: the overflow is detected and the level repeated with exact counts — same result; in strict mode the call
-    must fail instead."""
+    must fail instead.  b2max: how many of the partition bits level 2 may take (0 = half of them, 12 = up to 4096
+    second-level bins, several per thread of the scatter's counter scan)."""
     opts = {b"sort_msd": 1, b"sort_msd_segment_rows": 4096, b"sort_msd_wide": 1,
-            b"sort_msd_wide_sample_shift": shift, b"sort_msd_wide_gap2": gap2}
+            b"sort_msd_wide_sample_shift": shift, b"sort_msd_wide_gap2": gap2, b"sort_msd_wide_b2max": b2max}
     for k, v in opts.items():
         assert lib.arx_set_option(k, v) == 0
     try:
@@ -805,6 +806,38 @@ def check_sort_wide_sampled(amd, lib, rng, n, shift, gap2=1):
         return failed
     finally:
         lib.arx_set_option(b"sort_msd_wide_sample_strict", 0)
+        lib.arx_set_option(b"sort_msd_wide_sample_shift", 4)
+        lib.arx_set_option(b"sort_msd_wide_gap2", 1)
+        lib.arx_set_option(b"sort_msd_wide_b2max", 10)
+        lib.arx_set_option(b"sort_msd", -1)
+        lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
+
+
+def check_sort_wide_many_bins(amd, lib, rng, n, bits, b2max, combos=((2, 1), (0, 1), (0, 0))):
+    """The wide form with the partition bits FORCED (sort_msd_wide_bits), so that few rows meet many level-2 bins: up
+    to 4096 bins per level-1 partition, `per` = 2..4 counters per thread in the scatter's scan, in the bucket-start
+    scan and in the fixed-room setup.  Exact and sampled sizes, fixed rooms and counted buckets, a skewed input (whole
+    partitions empty, one bin holding a third of the rows), nulls, both orders."""
+    opts = {b"sort_msd": 1, b"sort_msd_segment_rows": 4096, b"sort_msd_wide": 1, b"sort_msd_wide_bits": bits,
+            b"sort_msd_wide_b2max": b2max}
+    for k, v in opts.items():
+        assert lib.arx_set_option(k, v) == 0
+    try:
+        for shift, gap2 in combos:
+            assert lib.arx_set_option(b"sort_msd_wide_sample_shift", shift) == 0
+            assert lib.arx_set_option(b"sort_msd_wide_gap2", gap2) == 0
+            uniform = util.random_array(rng, np.uint64, n, null_p=0.01, offset=3)
+            check_sort_indices(amd, uniform, "ascending", "at_end", use_pyarrow=False)
+            signed = util.random_array(rng, np.int64, n)
+            check_sort_indices(amd, signed, "descending", "at_start", use_pyarrow=False)
+            skew = util.random_array(rng, np.uint64, n)
+            v = skew.values[skew.offset:skew.offset + n]
+            v[: n // 3] = (v[: n // 3] & np.uint64((1 << 40) - 1)) | np.uint64(0x5A5A << 48)   # one bin, a third of the rows
+            v[n // 3: n // 2] >>= np.uint64(9)                                                  # the lowest partitions only
+            check_sort_indices(amd, skew, "ascending", "at_end", use_pyarrow=False)
+    finally:
+        lib.arx_set_option(b"sort_msd_wide_bits", 0)
+        lib.arx_set_option(b"sort_msd_wide_b2max", 10)
         lib.arx_set_option(b"sort_msd_wide_sample_shift", 4)
         lib.arx_set_option(b"sort_msd_wide_gap2", 1)
         lib.arx_set_option(b"sort_msd", -1)

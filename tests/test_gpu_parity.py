@@ -550,12 +550,20 @@ def test_sort_msd_hybrid_path(gpu_ctx, global_bits, fused):
         lib.arx_set_option(b"sort_msd_fused", 1)
 
 
-@pytest.mark.parametrize("shift,gap2", [(4, 1), (2, 1), (4, 0), (0, 1), (0, 0)])
-def test_sort_wide_sampled_level1(gpu_ctx, shift, gap2):
+@pytest.mark.parametrize("shift,gap2,b2max", [(4, 1, 12), (2, 1, 12), (4, 0, 12), (0, 1, 12), (0, 0, 12), (4, 1, 0),
+                                              (0, 0, 0)])
+def test_sort_wide_sampled_level1(gpu_ctx, shift, gap2, b2max):
     lib = gpu_ctx._lib.get_lib()
-    failed = P.check_sort_wide_sampled(gpu_ctx, lib, rng_for("wide-sampled", shift, gap2), 6_000_011, shift, gap2)
+    failed = P.check_sort_wide_sampled(gpu_ctx, lib, rng_for("wide-sampled", shift, gap2), 6_000_011, shift, gap2,
+                                       b2max)
     if shift == 0 and gap2 == 0:
         assert failed == 0   # exact counts never overflow
+
+
+@pytest.mark.parametrize("bits,b2max", [(13, 12), (16, 12), (20, 12), (19, 11), (19, 0)])
+def test_sort_wide_many_level2_bins(gpu_ctx, bits, b2max):
+    P.check_sort_wide_many_bins(gpu_ctx, gpu_ctx._lib.get_lib(), rng_for("wide-bins", bits, b2max), 5_000_003, bits,
+                                b2max)
 
 
 def test_null_count_bookkeeping(gpu_ctx):
