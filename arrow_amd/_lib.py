@@ -73,6 +73,12 @@ class ArxSpan(C.Structure):
     ]
 
 
+class ArxSortKeyWindow(C.Structure):
+    """struct ArxSortKeyWindow of include/arrow_amd.h (the key range the sharded sort takes its splitter bins from)."""
+
+    _fields_ = [("key_min", C.c_uint64), ("shift", C.c_int32), ("reserved", C.c_int32)]
+
+
 class ArxBinarySpan(C.Structure):
     """struct ArxBinarySpan of include/arrow_amd.h (binary / utf8 values, int32 offsets)."""
 
@@ -157,6 +163,10 @@ SIGNATURES = {
                                           C.POINTER(_i64), _p]),
     "arx_bitmap_to_indices": (_int, [_p, _i64, _i64, _int, _p, _sz, _p, C.POINTER(_i64), _p]),
     "arx_sort_partition_records": (_int, [_span, _int, _int, _int, _int, _p, _int, _p, _sz, _p, _p, C.POINTER(_i64), _p]),
+    "arx_sort_key_range": (_int, [_span, _int, _int, _p, _p]),
+    "arx_sort_key_histogram_window": (_int, [_span, _int, _int, _int, _p, _p, _p]),
+    "arx_sort_partition_records_window": (_int, [_span, _int, _int, _int, _int, _p, _p, _int, _p, _sz, _p, _p,
+                                                 C.POINTER(_i64), _p]),
     "arx_sort_unpack_records": (_int, [_p, _i64, _p, _int, _int, _p, _p, _p, _p]),
     "arx_groupby_export_partitioned": (_int, [_p, _int, _p, _sz, _p, _p, _p]),
     "arx_hash_sum_consume_workspace_bytes": (_sz, [_i64, _i64]),

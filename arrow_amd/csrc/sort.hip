@@ -357,9 +357,53 @@ __global__ __launch_bounds__(kBlock, 3) void radix_scatter_kernel(
 
 
 // ---- multi-GPU sort support: splitter histogram + stable partition by destination
+// The splitter bins are taken inside the WINDOW of the keys that exist: bin = top `bits` bits of (key - base) << shift,
+// base = the smallest transformed key of all shards, shift = leading zeros of (largest - smallest).  Ids, timestamps
+// and small integers share their top bits; bins of the raw key would send every row to one rank.
+__device__ __forceinline__ uint32_t sort_window_bin(uint64_t tk, uint64_t base, int shift, int bits) {
+  return static_cast<uint32_t>(((tk - base) << shift) >> (64 - bits));
+}
+
+// range[0] = max of ~key (= ~min), range[1] = max key over the non-null rows (both zero-initialised by the caller,
+// both combined by MAX — one all-reduce with one operator gives the global range)
+__global__ __launch_bounds__(kBlock) void sort_key_range_kernel(const uint64_t* __restrict__ values, Bits valid, int64_t n,
+                                                                int is_signed, int descending,
+                                                                unsigned long long* __restrict__ range) {
+  __shared__ unsigned long long s_lo[kWavesPerBlock], s_hi[kWavesPerBlock];
+  unsigned long long lo = 0, hi = 0;   // lo accumulates ~key
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1ull;
+    if (ok) {
+      const unsigned long long tk = key_transform(values[i], is_signed != 0, descending != 0);
+      lo = lo > ~tk ? lo : ~tk;
+      hi = hi > tk ? hi : tk;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long l2 = shfl_u64(lo, lane_id() ^ d), h2 = shfl_u64(hi, lane_id() ^ d);
+    lo = lo > l2 ? lo : l2;
+    hi = hi > h2 ? hi : h2;
+  }
+  if (lane_id() == 0) {
+    s_lo[threadIdx.x >> 6] = lo;
+    s_hi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kWavesPerBlock; ++w) {
+      lo = lo > s_lo[w] ? lo : s_lo[w];
+      hi = hi > s_hi[w] ? hi : s_hi[w];
+    }
+    if (lo != 0) atomicMax(&range[0], lo);
+    if (hi != 0) atomicMax(&range[1], hi);
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void sort_key_hist_kernel(const uint64_t* __restrict__ values,
                                                                Bits valid, int64_t n, int is_signed,
-                                                               int descending, int bits,
+                                                               int descending, int bits, uint64_t base, int shift,
                                                                unsigned long long* __restrict__ hist) {
   __shared__ uint32_t h[4096];
   const int nb = 1 << bits;
@@ -370,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void sort_key_hist_kernel(const uint64_t* _
     const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1ull;
     if (ok) {
       const uint64_t tk = key_transform(values[i], is_signed != 0, descending != 0);
-      atomicAdd(&h[tk >> (64 - bits)], 1u);
+      atomicAdd(&h[sort_window_bin(tk, base, shift, bits)], 1u);
     }
   }
   __syncthreads();
@@ -383,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void sort_key_hist_kernel(const uint64_t* _
 __global__ __launch_bounds__(kBlock) void sort_dest_prep_kernel(const uint64_t* __restrict__ values,
                                                                 const uint32_t* __restrict__ rows,
                                                                 int64_t n, int is_signed, int descending,
-                                                                int bits,
+                                                                int bits, uint64_t base, int shift,
                                                                 const uint32_t* __restrict__ split,
                                                                 int nsplit, uint64_t* __restrict__ dkeys,
                                                                 uint32_t* __restrict__ idx_out) {
@@ -391,7 +435,7 @@ __global__ __launch_bounds__(kBlock) void sort_dest_prep_kernel(const uint64_t* 
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     const uint32_t r = rows ? rows[i] : static_cast<uint32_t>(i);
     const uint64_t tk = key_transform(values[r], is_signed != 0, descending != 0);
-    const uint32_t bin = static_cast<uint32_t>(tk >> (64 - bits));
+    const uint32_t bin = sort_window_bin(tk, base, shift, bits);
     uint32_t d = 0;
     for (int j = 0; j < nsplit; ++j) d += (split[j] <= bin) ? 1u : 0u;
     dkeys[i] = d;
@@ -2789,10 +2833,22 @@ int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int nul
                           ws_bytes, out_indices, stream);
 }
 
-int arx_sort_key_histogram(const ArxSpan* values, int is_signed, int order, int bits,
-                           uint64_t* out_hist, void* stream) {
-  if (values == nullptr || out_hist == nullptr || bits < 1 || bits > 12) {
-    set_error("bad arguments to arx_sort_key_histogram (bits in [1,12])");
+static int sort_window_ok(const ArxSortKeyWindow* window, uint64_t* base, int* shift) {
+  *base = 0;
+  *shift = 0;
+  if (window == nullptr) return ARX_OK;
+  if (window->shift < 0 || window->shift > 63) {
+    set_error("sort key window: shift %d outside [0, 63]", window->shift);
+    return ARX_INVALID;
+  }
+  *base = window->key_min;
+  *shift = window->shift;
+  return ARX_OK;
+}
+
+int arx_sort_key_range(const ArxSpan* values, int is_signed, int order, uint64_t* out_range, void* stream) {
+  if (values == nullptr || out_range == nullptr) {
+    set_error("bad arguments to arx_sort_key_range");
     return ARX_INVALID;
   }
   const int64_t n = values->length;
@@ -2804,8 +2860,37 @@ int arx_sort_key_histogram(const ArxSpan* values, int is_signed, int order, int 
   const uint64_t* vals = static_cast<const uint64_t*>(values->data) + values->offset;
   const Bits vb = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
   const unsigned g = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock * 16), 2048)));
+  hipLaunchKernelGGL(sort_key_range_kernel, dim3(g), dim3(kBlock), 0, as_stream(stream), vals, vb, n, is_signed,
+                     order == ARX_SORT_DESCENDING, reinterpret_cast<unsigned long long*>(out_range));
+  ARX_CHECK_LAUNCH("sort_key_range_kernel");
+  return ARX_OK;
+}
+
+int arx_sort_key_histogram(const ArxSpan* values, int is_signed, int order, int bits,
+                           uint64_t* out_hist, void* stream) {
+  return arx_sort_key_histogram_window(values, is_signed, order, bits, nullptr, out_hist, stream);
+}
+
+int arx_sort_key_histogram_window(const ArxSpan* values, int is_signed, int order, int bits,
+                                  const ArxSortKeyWindow* window, uint64_t* out_hist, void* stream) {
+  if (values == nullptr || out_hist == nullptr || bits < 1 || bits > 12) {
+    set_error("bad arguments to arx_sort_key_histogram (bits in [1,12])");
+    return ARX_INVALID;
+  }
+  uint64_t base;
+  int shift;
+  if (sort_window_ok(window, &base, &shift) != ARX_OK) return ARX_INVALID;
+  const int64_t n = values->length;
+  if (n == 0) return ARX_OK;
+  if (values->data == nullptr) {
+    set_error("values buffer is NULL");
+    return ARX_INVALID;
+  }
+  const uint64_t* vals = static_cast<const uint64_t*>(values->data) + values->offset;
+  const Bits vb = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
+  const unsigned g = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock * 16), 2048)));
   hipLaunchKernelGGL(sort_key_hist_kernel, dim3(g), dim3(kBlock), 0, as_stream(stream), vals, vb, n,
-                     is_signed, order == ARX_SORT_DESCENDING, bits,
+                     is_signed, order == ARX_SORT_DESCENDING, bits, base, shift,
                      reinterpret_cast<unsigned long long*>(out_hist));
   ARX_CHECK_LAUNCH("sort_key_hist_kernel");
   return ARX_OK;
@@ -2814,6 +2899,7 @@ int arx_sort_key_histogram(const ArxSpan* values, int is_signed, int order, int 
 // Shared by the two forms below: the non-null rows in destination-major order (STABLE inside a destination)
 // as row ids in *rows_out (workspace memory), per-destination counts (device int64) in out_counts.
 static int sort_partition_rows(const ArxSpan* values, int is_signed, int order, int bits,
+                               const ArxSortKeyWindow* window,
                                const uint32_t* splitter_bins, int num_parts, void* ws, size_t ws_bytes,
                                int64_t* out_counts, int64_t* out_num_valid, hipStream_t st,
                                const uint32_t** rows_out, SortPlan* plan_out) {
@@ -2822,6 +2908,9 @@ static int sort_partition_rows(const ArxSpan* values, int is_signed, int order, 
     set_error("bad arguments to the sort partition");
     return ARX_INVALID;
   }
+  uint64_t base;
+  int shift;
+  if (sort_window_ok(window, &base, &shift) != ARX_OK) return ARX_INVALID;
   const int64_t len = values->length;
   if (len > static_cast<int64_t>(UINT32_MAX)) {
     set_error("sort partition: more than UINT32_MAX rows per shard is not implemented");
@@ -2871,7 +2960,7 @@ static int sort_partition_rows(const ArxSpan* values, int is_signed, int order, 
   plan = make_plan(n_valid);
   const unsigned g = static_cast<unsigned>(std::min<int64_t>(ceil_div(n_valid, kBlock), 2048));
   hipLaunchKernelGGL(sort_dest_prep_kernel, dim3(g), dim3(kBlock), 0, st, vals, valid_rows, n_valid,
-                     is_signed, order == ARX_SORT_DESCENDING, bits, split, num_parts - 1, keys_a, idx_a);
+                     is_signed, order == ARX_SORT_DESCENDING, bits, base, shift, split, num_parts - 1, keys_a, idx_a);
   ARX_CHECK_LAUNCH("sort_dest_prep_kernel");
   // one stable radix pass on the destination digit carries the row ids into destination-major order
   const int64_t chunk_keys = plan.chunk_tiles * kSortTile;
@@ -2895,7 +2984,7 @@ int arx_sort_partition_by_bins(const ArxSpan* values, int is_signed, int order, 
   hipStream_t st = as_stream(stream);
   const uint32_t* rows = nullptr;
   SortPlan plan{};
-  const int rc = sort_partition_rows(values, is_signed, order, bits, splitter_bins, num_parts, ws, ws_bytes,
+  const int rc = sort_partition_rows(values, is_signed, order, bits, nullptr, splitter_bins, num_parts, ws, ws_bytes,
                                      out_counts, out_num_valid, st, &rows, &plan);
   if (rc != ARX_OK || rows == nullptr) return rc;
   if (out_keys == nullptr || out_rows == nullptr) {
@@ -2917,6 +3006,14 @@ int arx_sort_partition_records(const ArxSpan* values, int is_signed, int order, 
                                const uint32_t* splitter_bins, int num_parts, void* ws, size_t ws_bytes,
                                ArxSortRecord* out_records, int64_t* out_counts, int64_t* out_num_valid,
                                void* stream) {
+  return arx_sort_partition_records_window(values, is_signed, order, null_placement, bits, nullptr, splitter_bins,
+                                           num_parts, ws, ws_bytes, out_records, out_counts, out_num_valid, stream);
+}
+
+int arx_sort_partition_records_window(const ArxSpan* values, int is_signed, int order, int null_placement, int bits,
+                                      const ArxSortKeyWindow* window, const uint32_t* splitter_bins, int num_parts,
+                                      void* ws, size_t ws_bytes, ArxSortRecord* out_records, int64_t* out_counts,
+                                      int64_t* out_num_valid, void* stream) {
   if (null_placement != ARX_NULLS_AT_START && null_placement != ARX_NULLS_AT_END) {
     set_error("bad null placement %d", null_placement);
     return ARX_INVALID;
@@ -2924,7 +3021,7 @@ int arx_sort_partition_records(const ArxSpan* values, int is_signed, int order, 
   hipStream_t st = as_stream(stream);
   const uint32_t* rows = nullptr;
   SortPlan plan{};
-  const int rc = sort_partition_rows(values, is_signed, order, bits, splitter_bins, num_parts, ws, ws_bytes,
+  const int rc = sort_partition_rows(values, is_signed, order, bits, window, splitter_bins, num_parts, ws, ws_bytes,
                                      out_counts, out_num_valid, st, &rows, &plan);
   if (rc != ARX_OK) return rc;
   const int64_t len = values->length;

@@ -26,6 +26,7 @@ from .compute import GroupBySum, ScalarAggregateOptions
 
 RECORD_BYTES = 24   # sizeof(ArxGroupPartial)
 SORT_RECORD_BYTES = 12   # sizeof(ArxSortRecord)
+_U64 = (1 << 64) - 1
 
 
 def _host_counts(*tensors):
@@ -106,7 +107,10 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
     ArraySortIndices' result (stable; nulls at the end or the start in row order,
     vector_array_sort.cc:524-540, vector_sort_internal.h:225-293).
 
-      1. ONE all-reduce: histogram of the top bits of the order-transformed keys (-> P-1 splitters, and every
+      0. one 16-byte all-reduce (MAX): the range [min, max] of the order-transformed keys of all shards.  Row ids,
+         timestamps and small integers share their top bits; splitter bins of the raw key would send every row to
+         one rank, so the bins are taken inside that window: bin = top bits of (key - min) << clz(max - min);
+      1. ONE all-reduce: histogram of those bins (-> P-1 splitters, and every
          rank's slice of the result) + the shard lengths (-> global row numbers) + the null counts;
       2. stable partition of the non-null rows by destination rank on the device, packed as 12-byte
          {transformed key, local row} records; the shard's null rows (row numbers only) ride in the same
@@ -136,11 +140,24 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
     nulls_first = null_placement == "at_start"
     target = 0 if nulls_first else world - 1
 
+    # 0. the key window: {max of ~key, max of key}, both by MAX; unsigned order as int64 = sign bit flipped
+    span = values.span()
+    key_range = torch.zeros(2, dtype=torch.int64, device=device)
+    check(lib.arx_sort_key_range(C.byref(span), is_signed, order_code, key_range.data_ptr(), stream))
+    sign = torch.iinfo(torch.int64).min
+    key_range ^= sign
+    dist.all_reduce(key_range, op=dist.ReduceOp.MAX, group=group)
+    inv_min, key_max = [int(x) ^ sign for x in key_range.tolist()]
+    key_min, key_max = ~inv_min & _U64, key_max & _U64
+    window = _lib.ArxSortKeyWindow(0, 0, 0)
+    if key_max > key_min:        # (no valid row anywhere: min = 2^64 - 1 > max = 0; one distinct key: nothing to split)
+        window = _lib.ArxSortKeyWindow(key_min, 64 - (key_max - key_min).bit_length(), 0)
+
     # 1. one all-reduce: [histogram (2^bits) | shard lengths (world) | valid rows per shard (world)]
     nbins = 1 << splitter_bits
     stats = torch.zeros(nbins + 2 * world, dtype=torch.int64, device=device)
-    span = values.span()
-    check(lib.arx_sort_key_histogram(C.byref(span), is_signed, order_code, splitter_bits, stats.data_ptr(), stream))
+    check(lib.arx_sort_key_histogram_window(C.byref(span), is_signed, order_code, splitter_bits, C.byref(window),
+                                            stats.data_ptr(), stream))
     stats[nbins + rank] = n
     stats[nbins + world + rank] = stats[:nbins].sum()
     dist.all_reduce(stats, group=group)
@@ -171,9 +188,10 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
     records = torch.empty(max(n, 1) * SORT_RECORD_BYTES, dtype=torch.uint8, device=device)
     counts = torch.zeros(world, dtype=torch.int64, device=device)
     n_valid = C.c_int64(0)
-    check(lib.arx_sort_partition_records(C.byref(span), is_signed, order_code, placement_code, splitter_bits,
-                                         split_arr, world, ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()),
-                                         records.data_ptr(), counts.data_ptr(), C.byref(n_valid), stream))
+    check(lib.arx_sort_partition_records_window(C.byref(span), is_signed, order_code, placement_code, splitter_bits,
+                                                C.byref(window), split_arr, world, ws_ptr,
+                                                ws.numel() - (ws_ptr - ws.data_ptr()), records.data_ptr(),
+                                                counts.data_ptr(), C.byref(n_valid), stream))
     n_null = n - n_valid.value
 
     # 3. block sizes, then the ONE data exchange

@@ -478,6 +478,27 @@ int arx_sort_partition_records(const ArxSpan* values, int is_signed, int order, 
 int arx_sort_unpack_records(const ArxSortRecord* records, int64_t num_records, const int64_t* block_meta,
                             int num_blocks, int nulls_first, uint64_t* out_keys, int64_t* out_rows,
                             int64_t* out_null_rows, void* stream);
+/* Splitter bins inside the WINDOW of the keys that exist.  Row ids, timestamps and small integers share their top
+ * bits: bins of the raw key would put every row of every shard into one bin and the whole sort onto one rank.
+ * arx_sort_key_range: out_range (device u64[2], caller-zeroed) = {max of ~key, max of key} over the shard's non-null
+ * order-transformed keys — both combine by MAX, so ONE 16-byte all-reduce (as int64 with the sign bit flipped) gives
+ * the global {~min, max}.  The window is then key_min = min, shift = leading zeros of (max - min), and
+ * bin = top `bits` bits of (key - key_min) << shift (monotone in the key: splitters stay valid).  The _window forms
+ * of the histogram and of the partition take it; window == NULL is the raw key (the plain forms above).
+ * (No reference counterpart: Arrow has no multi-device sort; the result is still ArraySortIndices' permutation,
+ * vector_array_sort.cc:524-540.) */
+typedef struct ArxSortKeyWindow {
+  uint64_t key_min; /* smallest order-transformed key of all shards */
+  int32_t shift;    /* 0..63 */
+  int32_t reserved;
+} ArxSortKeyWindow;
+int arx_sort_key_range(const ArxSpan* values, int is_signed, int order, uint64_t* out_range, void* stream);
+int arx_sort_key_histogram_window(const ArxSpan* values, int is_signed, int order, int bits,
+                                  const ArxSortKeyWindow* window, uint64_t* out_hist, void* stream);
+int arx_sort_partition_records_window(const ArxSpan* values, int is_signed, int order, int null_placement, int bits,
+                                      const ArxSortKeyWindow* window, const uint32_t* splitter_bins /* host */,
+                                      int num_parts, void* ws, size_t ws_bytes, ArxSortRecord* out_records,
+                                      int64_t* out_counts, int64_t* out_num_valid /* host */, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Group-by hash_sum(int64) BY int32 key — replaces, as one fused device operator,

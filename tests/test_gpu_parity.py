@@ -687,12 +687,16 @@ def test_sort_msd_bucket_variants_on_gpu(gpu_ctx, small_bucket, final_rows_log2,
             lib.arx_set_option(k, v)
 
 
-@pytest.mark.parametrize("placement", ["at_end", "at_start"])
-def test_sort_records_virtual_ranks_on_one_gpu(gpu_ctx, placement):
+@pytest.mark.parametrize("placement,window", [("at_end", None), ("at_start", None),
+                                              ("at_end", (1_700_000_000_000_000, 86_400_000_000)),
+                                              ("at_start", (-40_000, 100_000))])
+def test_sort_records_virtual_ranks_on_one_gpu(gpu_ctx, placement, window):
     """The ONE-buffer exchange of the sharded sort with P = 3 virtual ranks: arx_sort_partition_records packs
     {transformed key, local row} records destination-major with the shard's null rows in the last / first rank's
     block; slicing stands in for the all-to-all(v); arx_sort_unpack_records rebuilds keys + global rows in source
-    order; local stable sort + gather.  Concatenated over ranks = the oracle's argsort, nulls included."""
+    order; local stable sort + gather.  Concatenated over ranks = the oracle's argsort, nulls included.
+    window: every key inside [lo, lo + span) (timestamps, ids) — the splitter bins come from arx_sort_key_range's
+    window and every virtual rank must still get its share."""
     import ctypes as C
 
     import torch
@@ -709,14 +713,32 @@ def test_sort_records_virtual_ranks_on_one_gpu(gpu_ctx, placement):
     shards = [U.random_array(rng, np.int64, 200_000 + 5_003 * r, null_p=0.03 if r != 1 else 0.0, offset=r + 2) for r in range(P_)]
     for a in shards:
         a.values[a.offset:a.offset + a.length:3] %= 50
+        if window is not None:   # ties across the shards that do not pile up in one bin
+            v = a.values[a.offset:a.offset + a.length]
+            v[:] = (v.astype(np.uint64) % np.uint64(window[1])).astype(np.int64) + np.int64(window[0])
+            v[::3] = shards[0].values[shards[0].offset:shards[0].offset + len(v[::3])]
     dev = [a.to_device(amd) for a in shards]
     device = dev[0].device
     stream = current_stream(device)
     offsets = [int(x) for x in np.cumsum([0] + [a.length for a in shards])]
     hist = torch.zeros(1 << bits, dtype=torch.int64, device=device)
+    win = None
+    if window is not None:
+        rng_t = torch.zeros(2, dtype=torch.int64, device=device)   # atomicMax across the shards = the MAX all-reduce
+        for d in dev:
+            sp = d.span()
+            amd._lib.check(lib.arx_sort_key_range(C.byref(sp), 1, 1, rng_t.data_ptr(), stream))
+        inv_min, kmax = [int(x) & (2**64 - 1) for x in rng_t.cpu().tolist()]
+        kmin = ~inv_min & (2**64 - 1)
+        tk = np.concatenate([(~(a.values[a.offset:a.offset + a.length].view(np.uint64) ^ np.uint64(1 << 63)))
+                             [np.ones(a.length, bool) if a.valid is None else a.valid[a.offset:a.offset + a.length]]
+                             for a in shards])              # descending int64: transformed key = ~(key ^ sign)
+        assert (kmin, kmax) == (int(tk.min()), int(tk.max()))
+        win = amd._lib.ArxSortKeyWindow(kmin, 64 - (kmax - kmin).bit_length(), 0)
     for d in dev:
         sp = d.span()
-        amd._lib.check(lib.arx_sort_key_histogram(C.byref(sp), 1, 1, bits, hist.data_ptr(), stream))
+        amd._lib.check(lib.arx_sort_key_histogram_window(C.byref(sp), 1, 1, bits, C.byref(win) if win else None,
+                                                         hist.data_ptr(), stream))
     cum = torch.cumsum(hist, 0).cpu().numpy()
     total = int(cum[-1])
     split = [int(np.searchsorted(cum, (total * p + P_ - 1) // P_) + 1) for p in range(1, P_)]
@@ -730,9 +752,9 @@ def test_sort_records_virtual_ranks_on_one_gpu(gpu_ctx, placement):
         counts = torch.zeros(P_, dtype=torch.int64, device=device)
         nv = C.c_int64(0)
         sp = d.span()
-        amd._lib.check(lib.arx_sort_partition_records(C.byref(sp), 1, 1, 0 if nulls_first else 1, bits, split_arr, P_,
-                                                      ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()), rec.data_ptr(),
-                                                      counts.data_ptr(), C.byref(nv), stream))
+        amd._lib.check(lib.arx_sort_partition_records_window(
+            C.byref(sp), 1, 1, 0 if nulls_first else 1, bits, C.byref(win) if win else None, split_arr, P_, ws_ptr,
+            ws.numel() - (ws_ptr - ws.data_ptr()), rec.data_ptr(), counts.data_ptr(), C.byref(nv), stream))
         torch.cuda.synchronize()
         sent.append((rec, counts.cpu().tolist(), nv.value, n - nv.value))
     out = []
@@ -755,6 +777,8 @@ def test_sort_records_virtual_ranks_on_one_gpu(gpu_ctx, placement):
         perm = amd.compute.sort_indices(karr).data[: mv * 8].view(torch.int64)
         piece = grows[:mv][perm]
         out.append(torch.cat([nrows[:mn], piece]) if nulls_first else torch.cat([piece, nrows[:mn]]))
+    if window is not None:
+        assert min(int(o.numel()) for o in out) > sum(a.length for a in shards) // (2 * P_), "every rank gets its share"
     got = torch.cat(out).cpu().numpy().astype(np.uint64)
     vals = np.concatenate([a.values[a.offset:a.offset + a.length] for a in shards])
     valid = np.concatenate([np.ones(a.length, bool) if a.valid is None else a.valid[a.offset:a.offset + a.length] for a in shards])

@@ -117,6 +117,10 @@ SORT_WORKER = textwrap.dedent(r'''
     dt = np.int64 if SIGNED else np.uint64
     a = U.random_array(rng, dt, n, null_p=0.05, offset=rank + 1)
     a.values[a.offset:a.offset + n:3] = (a.values[a.offset:a.offset + n:3] % 40).astype(dt)  # many ties across ranks
+    if WINDOW is not None:   # ids / timestamps: every key inside [lo, lo + span) — the top bits say nothing
+        lo, span = WINDOW
+        v = a.values[a.offset:a.offset + n]
+        v[:] = (v.astype(np.uint64) % np.uint64(span)).astype(dt) + dt(lo)
     rows, start = parallel.sharded_sort_indices(a.to_device(arrow_amd), ORDER, PLACEMENT)
     mine = dict(rows=rows.numpy(), start=start, vals=a.values[a.offset:a.offset + n].copy(),
                 valid=None if a.valid is None else a.valid[a.offset:a.offset + n].copy())
@@ -130,10 +134,14 @@ SORT_WORKER = textwrap.dedent(r'''
 ''')
 
 
-@pytest.mark.parametrize("signed,order,placement", [(False, "ascending", "at_end"), (True, "descending", "at_start"),
-                                                    (False, "descending", "at_end")])
-def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement):
-    """One-exchange multi-rank sort_indices == the oracle's stable argsort of the concatenation."""
+@pytest.mark.parametrize("signed,order,placement,window", [
+    (False, "ascending", "at_end", None), (True, "descending", "at_start", None), (False, "descending", "at_end", None),
+    (True, "ascending", "at_end", (1_700_000_000_000_000, 86_400_000_000)),   # a day of microsecond timestamps
+    (True, "descending", "at_end", (-3000, 9000)), (False, "ascending", "at_start", ((1 << 40) - 700, 1500)),
+    (False, "ascending", "at_end", (12345, 1))])
+def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement, window):
+    """One-exchange multi-rank sort_indices == the oracle's stable argsort of the concatenation; keys that share their
+    top bits (window) must still be split between the ranks."""
     import pickle
 
     import numpy as np
@@ -142,7 +150,7 @@ def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement):
 
     out = str(tmp_path / "sort.pkl")
     code = (f"ROOT = {ROOT!r}\nOUT = {out!r}\nSIGNED = {signed!r}\nORDER = {order!r}\nPLACEMENT = {placement!r}\n"
-            + SORT_WORKER)
+            f"WINDOW = {window!r}\n" + SORT_WORKER)
     port = 31500 + (os.getpid() % 2000)
     procs = []
     for rank in range(2):
@@ -166,7 +174,8 @@ def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement):
     assert ranks[0]["start"] == 0 and ranks[1]["start"] == len(ranks[0]["rows"])
     got = np.concatenate([r["rows"] for r in ranks]).astype(np.uint64)
     assert (got == want).all()
-    assert min(len(r["rows"]) for r in ranks) > len(vals) // 4, "splitters should balance the ranks"
+    if window is None or window[1] > 1:   # (one distinct key cannot be split)
+        assert min(len(r["rows"]) for r in ranks) > len(vals) // 4, "splitters should balance the ranks"
 
 
 def test_bench_launcher_starts_two_ranks_end_to_end():
