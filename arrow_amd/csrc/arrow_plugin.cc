@@ -45,15 +45,19 @@
 #include <arrow/util/ubsan.h>
 #include <arrow/util/compression.h>
 #include <arrow/io/file.h>
+#include <arrow/io/memory.h>
 #include <arrow/io/interfaces.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <unordered_map>
 #include <vector>
@@ -192,8 +196,19 @@ void arrow_amd_plugin_set_filter_morsel_rows(int64_t n) { g_filter_morsel_rows.s
 // Parquet: 1 (default) = Snappy chunks of fixed-width columns are read raw and their PLAIN value pages decompressed
 // on the device; 0 = every page is decompressed by the reference's PageReader on the host
 void arrow_amd_plugin_set_parquet_device_snappy(int on) { g_parquet_device_snappy.store(on != 0); }
+// A/B switch: definition levels of all-V2 chunks walked on the device (default) or by the host's run scanner.
+void arrow_amd_plugin_set_parquet_device_levels(int on) { g_parquet_device_levels.store(on != 0); }
+// A/B switch: gather the compressed pages in page-locked host memory (default) or in a pageable vector.
+void arrow_amd_plugin_set_parquet_pinned_staging(int on) { g_parquet_pinned_staging.store(on != 0); }
+// threads that share the read of one column chunk, each reading at least min_part_bytes (default 4 x 8 MB; 1 = a single ReadAt)
+void arrow_amd_plugin_set_parquet_read_threads(int n, int64_t min_part_bytes) {
+  g_parquet_read_threads.store(n < 1 ? 1 : (n > 16 ? 16 : n));
+  g_parquet_read_part_bytes.store(min_part_bytes < 4096 ? 4096 : min_part_bytes);
+}
 // pages decompressed on the device so far
 int64_t arrow_amd_plugin_parquet_device_snappy_pages(void) { return g_parquet_device_snappy_pages.load(); }
+// device-route pages that had to be copied into the staging block (0: the page reader hands out slices of the chunk)
+int64_t arrow_amd_plugin_parquet_copied_pages(void) { return g_parquet_copied_pages.load(); }
 // aggregate_rocm: rows of pending device batches that trigger a copy into the staging columns; copies so far
 void arrow_amd_plugin_set_aggregate_flush_rows(int64_t rows) { g_aggregate_flush_rows.store(rows < 1 ? 1 : rows); }
 int64_t arrow_amd_plugin_aggregate_flushes(void) { return g_aggregate_flushes.load(); }

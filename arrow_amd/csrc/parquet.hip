@@ -397,6 +397,103 @@ __global__ __launch_bounds__(kBlock) void snappy_decode_kernel(const uint8_t* __
   if (lane == 0) status[pg] = err;
 }
 
+// ---- definition levels of a flat optional column (bit width 1) -> validity bits, run headers walked on the device.
+// One wave per page.  Every lane parses the same header bytes (uniform loads), then the 64 lanes share the run's bits:
+// a repeated run of ones sets a bit range, a bit-packed run ORs its payload bytes in at the page's bit position (pages
+// start at any row, so neighbours share words: atomicOr into a zeroed bitmap).  The checks are those of the host
+// walker (arx_rle_scan_runs): a header or payload that runs past the block marks the page corrupt.
+__global__ __launch_bounds__(kBlock) void rle_levels_bitmap_kernel(const uint8_t* __restrict__ bytes,
+                                                                   const ArxLevelPage* __restrict__ pages, int64_t num_pages,
+                                                                   unsigned long long* __restrict__ out_bits,
+                                                                   uint32_t* __restrict__ ones, uint32_t* __restrict__ status) {
+  const int64_t pg = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (pg >= num_pages) return;   // wave-uniform
+  const int lane = lane_id();
+  const ArxLevelPage page = pages[pg];
+  const uint8_t* p = bytes + page.byte_start;
+  const uint64_t nbytes = page.nbytes;
+  const int64_t num_values = page.num_values;
+  uint64_t pos = 0;
+  int64_t done = 0;
+  uint32_t my_ones = 0, bad = 0;
+  while (done < num_values) {
+    uint64_t h = 0;
+    int shift = 0;
+    for (;;) {   // varint header
+      if (pos >= nbytes || shift > 56) {
+        bad = 1;
+        break;
+      }
+      const uint8_t c = p[pos++];
+      h |= static_cast<uint64_t>(c & 0x7F) << shift;
+      if ((c & 0x80) == 0) break;
+      shift += 7;
+    }
+    if (bad) break;
+    const uint64_t bit0 = page.row_start + static_cast<uint64_t>(done);   // where this run's first value lands
+    if (h & 1) {   // bit-packed: (h >> 1) groups of 8 one-bit values = that many bytes
+      const uint64_t groups = h >> 1;
+      if (groups == 0 || groups > (uint64_t(1) << 40)) {
+        bad = 1;
+        break;
+      }
+      const int64_t count = static_cast<int64_t>(groups) * 8;
+      const int64_t needed = count < num_values - done ? count : num_values - done;
+      const uint64_t need_bytes = (static_cast<uint64_t>(needed) + 7) / 8;
+      const bool reaches_end = done + count >= num_values;
+      if ((reaches_end ? need_bytes : groups) > nbytes - pos) {
+        bad = 1;
+        break;
+      }
+      // lane l takes bytes [8 l, 8 l + 8) of every 512-byte stretch
+      for (uint64_t b0 = static_cast<uint64_t>(lane) * 8; b0 < need_bytes; b0 += 512) {
+        uint64_t w = 0;
+        const uint64_t nb = need_bytes - b0 < 8 ? need_bytes - b0 : 8;
+        for (uint64_t k = 0; k < nb; ++k) w |= static_cast<uint64_t>(p[pos + b0 + k]) << (8 * k);
+        const int64_t bits_here = needed - static_cast<int64_t>(b0 * 8) < 64 ? needed - static_cast<int64_t>(b0 * 8) : 64;
+        if (bits_here < 64) w &= (uint64_t(1) << bits_here) - 1;
+        if (w != 0) {
+          my_ones += static_cast<uint32_t>(__popcll(w));
+          const uint64_t at = bit0 + b0 * 8;
+          const int sh = static_cast<int>(at & 63);
+          atomicOr(&out_bits[at >> 6], static_cast<unsigned long long>(w << sh));
+          if (sh != 0 && (w >> (64 - sh)) != 0) atomicOr(&out_bits[(at >> 6) + 1], static_cast<unsigned long long>(w >> (64 - sh)));
+        }
+      }
+      pos += groups;
+      done += count;
+    } else {   // repeated: (h >> 1) copies of one byte-sized value
+      const int64_t count = static_cast<int64_t>(h >> 1);
+      if (count == 0 || pos + 1 > nbytes) {
+        bad = 1;
+        break;
+      }
+      const uint8_t value = p[pos];
+      pos += 1;
+      const int64_t take = count < num_values - done ? count : num_values - done;
+      if (value == 1) {
+        if (lane == 0) my_ones += static_cast<uint32_t>(take);
+        const uint64_t first = bit0, last = bit0 + static_cast<uint64_t>(take) - 1;   // inclusive
+        for (uint64_t wd = (first >> 6) + lane; wd <= (last >> 6); wd += 64) {
+          uint64_t m = ~uint64_t(0);
+          if (wd == (first >> 6)) m &= ~uint64_t(0) << (first & 63);
+          if (wd == (last >> 6)) m &= ~uint64_t(0) >> (63 - (last & 63));
+          atomicOr(&out_bits[wd], static_cast<unsigned long long>(m));
+        }
+      } else if (value > 1) {   // a level above the column's maximum
+        bad = 1;
+        break;
+      }
+      done += count;
+    }
+  }
+  const uint32_t total = wave_reduce_sum_u32(my_ones);
+  if (lane == 0) {
+    ones[pg] = total;
+    status[pg] = bad;
+  }
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -752,6 +849,26 @@ int arx_rle_decode_equals_bitmap(const void* bytes, size_t nbytes, const ArxRleR
                      static_cast<const uint8_t*>(bytes), static_cast<uint64_t>(nbytes), runs, nruns, bit_width,
                      num_values, equals, static_cast<uint32_t*>(nullptr), static_cast<uint64_t*>(out_bits));
   ARX_CHECK_LAUNCH("rle_decode_kernel");
+  return ARX_OK;
+}
+
+int arx_rle_levels_to_bitmap(const void* bytes, const ArxLevelPage* pages, int64_t num_pages, void* out_bits,
+                             uint32_t* ones, uint32_t* status, void* stream) {
+  if (num_pages < 0) {
+    set_error("bad arguments to arx_rle_levels_to_bitmap");
+    return ARX_INVALID;
+  }
+  if (num_pages == 0) return ARX_OK;
+  if (bytes == nullptr || pages == nullptr || out_bits == nullptr || ones == nullptr || status == nullptr ||
+      (reinterpret_cast<uintptr_t>(out_bits) & 7) != 0) {
+    set_error("arx_rle_levels_to_bitmap: NULL buffer or out_bits not 8-byte aligned");
+    return ARX_INVALID;
+  }
+  const unsigned grid = static_cast<unsigned>(ceil_div(num_pages, kWavesPerBlock));
+  hipLaunchKernelGGL(rle_levels_bitmap_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                     static_cast<const uint8_t*>(bytes), pages, num_pages, static_cast<unsigned long long*>(out_bits), ones,
+                     status);
+  ARX_CHECK_LAUNCH("rle_levels_bitmap_kernel");
   return ARX_OK;
 }
 

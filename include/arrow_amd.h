@@ -772,6 +772,20 @@ int arx_rle_decode_equals_bitmap(const void* bytes, size_t nbytes, const ArxRleR
                                  int bit_width, int64_t num_values, uint32_t equals, void* out_bits, void* stream);
 int arx_expand_by_mask(const void* dense, int byte_width, const ArxSpan* mask, const void* ws, void* out_data,
                        void* stream);
+/* Definition levels of a flat optional column (bit width 1; LevelDecoder, cpp/src/parquet/column_reader.cc:95-190) ->
+ * validity bits WITHOUT a host walk: `bytes` (device) holds the pages' level blocks where the chunk read put them,
+ * pages[i] (device) = {where block i starts, its length, the page's value count, the page's first row}; one wave
+ * walks the run headers of one page and the 64 lanes write the bits.  out_bits: caller-ZEROED bitmap over all rows
+ * (pages share words: atomicOr).  ones[i] = number of non-null values of page i, status[i] = 0 ok / 1 corrupt block
+ * (header or payload past the block, a level above 1) — read both back before trusting the bits.  Asynchronous. */
+typedef struct ArxLevelPage {
+  uint64_t byte_start;
+  uint32_t nbytes;
+  uint32_t num_values;
+  uint64_t row_start;
+} ArxLevelPage;
+int arx_rle_levels_to_bitmap(const void* bytes, const ArxLevelPage* pages, int64_t num_pages, void* out_bits,
+                             uint32_t* ones, uint32_t* status, void* stream);
 
 /* Snappy page decompression on the device — SnappyCodec::Decompress (cpp/src/arrow/util/compression_snappy.cc:42-62)
  * for the pages of a column chunk in ONE launch: `compressed` holds the raw Snappy blocks (device), pages[i] says

@@ -22,6 +22,9 @@ static inline hipError_t hipMalloc(void** p, size_t n) {
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+enum { hipHostMallocDefault = 0 };
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) std::memset(d, v, n); return hipSuccess; }

@@ -1335,18 +1335,25 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
         path = os.path.join(tempfile.mkdtemp(), "r.parquet")
         pq.write_table(req, path, row_group_size=n // 2 + 11, compression="snappy", **variant)
         pf = pq.ParquetFile(path)
-        for on in (1, 0):
+        # (pinned: the chunk's bytes in page-locked / pageable host memory; threads: the chunk read in that many parts)
+        for on, pinned, threads in ((1, 1, 1), (1, 1, 3), (1, 0, 2), (0, 1, 1)):
             lib.arrow_amd_plugin_set_parquet_device_snappy(on)
+            lib.arrow_amd_plugin_set_parquet_pinned_staging(pinned)
+            lib.arrow_amd_plugin_set_parquet_read_threads(threads, ctypes.c_int64(4096))
             before = lib.arrow_amd_plugin_parquet_device_snappy_pages()
             for rg in range(pf.metadata.num_row_groups):
                 ref = pf.read_row_group(rg)
                 for ci, name in enumerate(req.schema.names):
                     h = to_host(read_column(path, rg, ci))
                     w = ref.column(name).combine_chunks()
-                    assert h.equals(w) and h.null_count == w.null_count, (variant, on, rg, name)
+                    assert h.equals(w) and h.null_count == w.null_count, (variant, on, pinned, threads, rg, name)
             used = lib.arrow_amd_plugin_parquet_device_snappy_pages() - before
             assert (used > 0) if on else (used == 0), (variant, on, used)
     lib.arrow_amd_plugin_set_parquet_device_snappy(1)
+    lib.arrow_amd_plugin_set_parquet_pinned_staging(1)
+    lib.arrow_amd_plugin_set_parquet_read_threads(4, ctypes.c_int64(1 << 23))
+    lib.arrow_amd_plugin_parquet_copied_pages.restype = ctypes.c_int64
+    assert lib.arrow_amd_plugin_parquet_copied_pages() == 0    # every device-route page was used where the chunk read put it
     # a corrupt Snappy page is reported with the reference's text, whichever side decompresses it
     path = os.path.join(tempfile.mkdtemp(), "bad.parquet")
     pq.write_table(req.select(["a"]), path, compression="snappy", use_dictionary=False, data_page_version="2.0")

@@ -131,6 +131,85 @@ def test_snappy_page_decoder_kernel_gpu(gpu_ctx):
     check_snappy_kernel(gpu_ctx, np.random.default_rng(4), scale=20)
 
 
+LEVEL_PAGE = np.dtype([("byte_start", "<u8"), ("nbytes", "<u4"), ("num_values", "<u4"), ("row_start", "<u8")])
+
+
+def check_levels_bitmap_kernel(amd, rng, scale=1):
+    """arx_rle_levels_to_bitmap (run headers walked on the device, one wave per page) vs the levels themselves: blocks
+    written by the hybrid encoder for random nulls at several densities, long runs, all-null and all-valid pages, pages
+    of 1 / 7 / 8 / 9 / 504 / 505 values (partial groups; the 63-group limit of a literal run), pages that start at any
+    row (neighbours share bitmap words), padding between the blocks; a hand-made block whose last literal run is cut
+    short at the last needed byte; corrupt blocks (truncated, header past the block, a level of 2, a zero-length run)
+    -> status 1 for that page only."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+
+    def run(level_arrays, blocks=None, counts=None):
+        blocks = blocks or [O.rle_hybrid_encode(v, 1) for v in level_arrays]
+        counts = counts or [len(v) for v in level_arrays]
+        pages = np.zeros(len(blocks), LEVEL_PAGE)
+        buf, row = bytearray(), 0
+        for i, (b, c) in enumerate(zip(blocks, counts)):
+            buf += bytes(rng.integers(0, 256, int(rng.integers(0, 5)), dtype=np.uint8))   # (blocks sit anywhere)
+            pages[i] = (len(buf), len(b), c, row)
+            buf += b
+            row += c
+        src = to_device(np.frombuffer(bytes(buf) + b"\0" * 8, dtype=np.uint8), dev)
+        bits = torch.zeros((row + 63) // 64 + 2, dtype=torch.int64, device=dev)
+        ones = torch.full((len(blocks),), 77, dtype=torch.int32, device=dev)
+        st = torch.full((len(blocks),), 77, dtype=torch.int32, device=dev)
+        table = to_device(pages.view(np.uint8), dev)
+        _lib.check(lib.arx_rle_levels_to_bitmap(src.data_ptr(), table.data_ptr(), len(blocks), bits.data_ptr(),
+                                                ones.data_ptr(), st.data_ptr(), current_stream(dev)))
+        got = np.unpackbits(bits.cpu().numpy().view(np.uint8), bitorder="little")
+        return got, ones.cpu().numpy().tolist(), st.cpu().numpy().tolist(), row
+
+    n = 3000 * scale
+    levels = [(rng.random(n) >= p).astype(np.uint8) for p in (0.1, 0.5, 0.9, 0.01)]
+    levels += [np.ones(n, np.uint8), np.zeros(n, np.uint8), np.repeat(rng.integers(0, 2, n // 37 + 1), 37)[:n].astype(np.uint8)]
+    levels += [(rng.random(k) >= 0.3).astype(np.uint8) for k in (1, 7, 8, 9, 63, 64, 65, 504, 505, 511, 513, 4097)]
+    order = rng.permutation(len(levels))
+    levels = [levels[i] for i in order]
+    got, ones, st, rows = run(levels)
+    want = np.concatenate(levels)
+    assert st == [0] * len(levels), st
+    assert ones == [int(v.sum()) for v in levels]
+    assert (got[:rows] == want).all() and not got[rows:].any()
+    # the last literal run of a block may stop at the last byte its needed values use (RleBitPackedDecoder reads no further)
+    v = (rng.random(20) >= 0.4).astype(np.uint8)
+    full = O.rle_hybrid_encode(v, 1)          # one literal run of 3 groups: header + 3 bytes
+    assert len(full) == 4
+    got, ones, st, rows = run([v, v], [full, full], [20, 17])   # 17 values need 3 bytes as well
+    assert st == [0, 0] and ones == [int(v.sum()), int(v[:17].sum())]
+    assert (got[:37] == np.concatenate([v, v[:17]])).all() and not got[37:].any()
+    # corrupt blocks
+    good = (rng.random(100) >= 0.2).astype(np.uint8)
+    enc = O.rle_hybrid_encode(good, 1)
+    bad_trunc = enc[: len(enc) // 2]                   # ends before all its values
+    bad_header = bytes([0x80, 0x80, 0x80])             # a varint that never ends inside the block
+    bad_level = bytes([100 << 1, 2])                   # repeated run of the level 2
+    bad_zero = bytes([0x00, 0x01])                     # a repeated run of zero values
+    bad_groups = bytes([(60 << 1) | 1, 0xFF])          # a literal run far longer than the block
+    got, ones, st, rows = run([good] * 7, [enc, bad_trunc, bad_header, enc, bad_level, bad_zero, bad_groups], [100] * 7)
+    assert st == [0, 1, 1, 0, 1, 1, 1], st
+    assert ones[0] == ones[3] == int(good.sum())
+    assert (got[:100] == good).all() and (got[300:400] == good).all()
+
+
+@pytest.mark.emu
+def test_levels_bitmap_kernel(emu_ctx):
+    check_levels_bitmap_kernel(emu_ctx, np.random.default_rng(5))
+
+
+@pytest.mark.gpu
+def test_levels_bitmap_kernel_gpu(gpu_ctx):
+    check_levels_bitmap_kernel(gpu_ctx, np.random.default_rng(6), scale=40)
+
+
 def _snappy_plain_file(tmp_path, n, null_p, version):
     rng = np.random.default_rng(n + int(null_p * 100))
     mask = (rng.random(n) < null_p) if null_p else None
