@@ -3,7 +3,7 @@
 # pageable staging vs the host codec; V2 and V1 data pages.  Plugin parquet tests first.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/${RUN_TAG:-r02_ai}
+OUT=gpurun_out/${RUN_TAG:-r02_an}
 mkdir -p $OUT
 timeout 600 python -m pytest tests/test_gpu_arrow_plugin.py tests/test_parquet.py -x -q -m gpu -k "parquet or levels or snappy" > $OUT/tests.txt 2>&1; echo "tests rc=$?"; tail -3 $OUT/tests.txt
 for v in 2.0 1.0; do
