@@ -195,6 +195,13 @@ __device__ __forceinline__ uint4 buffer_load_b128(__amdgpu_buffer_rsrc_t r, uint
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_offset, 0, 0));
 }
 
+// 16 bytes from an address of any alignment (one global_load_dwordx4: global memory takes the unaligned address)
+__device__ __forceinline__ uint4 load16_unaligned(const uint8_t* p) {
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
+
 // Spread the low 32 bits of x to the even bit positions of a 64-bit word.
 __device__ __forceinline__ uint64_t spread32(uint64_t x) {
   x &= 0xffffffffull;

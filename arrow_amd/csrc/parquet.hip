@@ -313,6 +313,36 @@ __global__ __launch_bounds__(kBlock) void byte_stream_split_kernel(const uint8_t
 // even the self-overlapping case lane-parallel.  A copy that reads bytes this wave stored since the last fence waits for
 // them first.  Pages are independent: the grid is one wave per page (4 per workgroup).
 // status per page: 0 ok, 1 length mismatch / bad preamble, 2 element runs past the input or the output, 3 bad offset.
+// A literal of `len` bytes moved by the 64 lanes.  Long literals (incompressible pages are made of 64 KB ones) go 16
+// bytes per lane and four such loads in flight: the destination is brought to a 16-byte boundary first (bytewise, the
+// same few bytes for every lane count), the source is read wherever it is (global memory takes unaligned dwordx4 loads).
+__device__ __forceinline__ void snappy_copy_literal(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t len,
+                                                    int lane) {
+  if (len < 512) {
+    for (uint32_t j = lane; j < len; j += 64) dst[j] = src[j];
+    return;
+  }
+  const uint32_t head = static_cast<uint32_t>((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15);
+  if (static_cast<uint32_t>(lane) < head) dst[lane] = src[lane];
+  const uint32_t body = (len - head) & ~15u;   // whole 16-byte units
+  uint8_t* d = dst + head;
+  const uint8_t* s = src + head;
+  uint32_t j = static_cast<uint32_t>(lane) * 16;
+  for (; j + 3 * 1024 < body; j += 4 * 1024) {
+    const uint4 a = load16_unaligned(s + j);
+    const uint4 b = load16_unaligned(s + j + 1024);
+    const uint4 c = load16_unaligned(s + j + 2048);
+    const uint4 e = load16_unaligned(s + j + 3072);
+    *reinterpret_cast<uint4*>(d + j) = a;
+    *reinterpret_cast<uint4*>(d + j + 1024) = b;
+    *reinterpret_cast<uint4*>(d + j + 2048) = c;
+    *reinterpret_cast<uint4*>(d + j + 3072) = e;
+  }
+  for (; j < body; j += 1024) *reinterpret_cast<uint4*>(d + j) = load16_unaligned(s + j);
+  const uint32_t tail = len - head - body;     // < 16
+  if (static_cast<uint32_t>(lane) < tail) d[body + lane] = s[body + lane];
+}
+
 __global__ __launch_bounds__(kBlock) void snappy_decode_kernel(const uint8_t* __restrict__ src, const ArxSnappyPage* __restrict__ pages,
                                                                int64_t npages, uint8_t* dst, uint32_t* __restrict__ status) {
   const int lane = lane_id();
@@ -356,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void snappy_decode_kernel(const uint8_t* __
       }
       if (ip + adv > n_in || len > n_in - (ip + adv) || len > ulen - op) { err = 2; break; }
       ip += adv;
-      for (uint32_t j = lane; j < len; j += 64) out[op + j] = in[ip + j];
+      snappy_copy_literal(out + op, in + ip, len, lane);
       ip += len;
     } else {
       if ((tag & 3u) == 1) {

@@ -713,7 +713,7 @@ static int compare_any(int op, const T* left, T ls, const T* right, T rs, int64_
 // ------------------------------------------------------------------ many small device-to-device copies in one launch
 // Concatenate (array/concatenate.cc) of many small chunks — Acero hands operators 32K-row batches — costs a launch (or
 // a hipMemcpy) per chunk and column when done copy by copy; here a device table of {src, dst, nbytes} drives one
-// launch: `per_seg` workgroups per segment, each copying 64 KiB slices (16-byte accesses when both sides allow).
+// launch: `per_seg` workgroups per segment, each copying 64 KiB slices with 16-byte accesses (the destination side aligned, the source wherever it is).
 __global__ __launch_bounds__(kBlock) void copy_segments_kernel(const ArxCopySeg* __restrict__ segs, int64_t nsegs, unsigned per_seg) {
   constexpr uint64_t kSlice = 64 * 1024;
   const int64_t sg = blockIdx.x / per_seg;
@@ -731,8 +731,16 @@ __global__ __launch_bounds__(kBlock) void copy_segments_kernel(const ArxCopySeg*
         *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(src + o);
       }
       for (uint64_t o = end16 + threadIdx.x; o < end; o += kBlock) dst[o] = src[o];
-    } else {
-      for (uint64_t o = base + threadIdx.x; o < end; o += kBlock) dst[o] = src[o];
+    } else {   // any alignment: bytes up to the destination's 16-byte boundary, then aligned stores of unaligned loads
+      const uint64_t to_boundary = (16 - (reinterpret_cast<uint64_t>(dst + base) & 15)) & 15;
+      const uint64_t head = to_boundary < end - base ? to_boundary : end - base;
+      if (threadIdx.x < head) dst[base + threadIdx.x] = src[base + threadIdx.x];
+      const uint64_t b16 = base + head;
+      const uint64_t end16 = b16 + ((end - b16) & ~uint64_t(15));
+      for (uint64_t o = b16 + threadIdx.x * 16ull; o < end16; o += kBlock * 16ull) {
+        *reinterpret_cast<uint4*>(dst + o) = load16_unaligned(src + o);
+      }
+      for (uint64_t o = end16 + threadIdx.x; o < end; o += kBlock) dst[o] = src[o];
     }
   }
 }

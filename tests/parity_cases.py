@@ -1578,3 +1578,40 @@ def check_null_count_bookkeeping(amd, rng, n=10_000):
     tk = amd.compute.take(nv, amd.Array(base_i.type, 100, [None, base_i.buffers[1]], -1, 0))
     assert tk.validity is None and tk.null_count == 0
     assert_equal(_data_np(tk, np.int64), allv.logical_values()[idx.values[:100]], "take without bitmaps")
+
+
+COPY_SEG = np.dtype([("src", "<u8"), ("dst", "<u8"), ("nbytes", "<u8")])
+
+
+def check_copy_segments(amd, rng, scale=1):
+    """arx_copy_segments: many device-to-device copies in one launch, every combination of source / destination
+    alignment (the 16-byte path aligns the destination and reads the source wherever it is), lengths around the
+    16-byte and 64 KiB steps, empty segments; bytes between the destinations stay untouched."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    lengths = [0, 1, 15, 16, 17, 31, 33, 255, 4096, 65535, 65536, 65537, 70001 * scale, 3 * 65536 + 5]
+    segs = []
+    src_pos = dst_pos = 0
+    for i, n in enumerate(lengths * 2):
+        src_pos += int(rng.integers(0, 16)) + (i % 5 == 0) * 16
+        dst_pos += int(rng.integers(1, 16)) + 8          # a gap before every destination
+        segs.append((src_pos, dst_pos, n))
+        src_pos += n
+        dst_pos += n
+    src_h = rng.integers(0, 256, src_pos + 64, dtype=np.uint8)
+    dst_h = rng.integers(0, 256, dst_pos + 64, dtype=np.uint8)
+    src = to_device(src_h, dev)
+    dst = to_device(dst_h.copy(), dev)
+    table = np.zeros(len(segs), COPY_SEG)
+    for i, (a, b, n) in enumerate(segs):
+        table[i] = (src.data_ptr() + a, dst.data_ptr() + b, n)
+    d_table = to_device(table.view(np.uint8), dev)
+    _lib.check(lib.arx_copy_segments(d_table.data_ptr(), len(segs), max(n for _, _, n in segs), current_stream(dev)))
+    want = dst_h.copy()
+    for a, b, n in segs:
+        want[b:b + n] = src_h[a:a + n]
+    assert_equal(dst.cpu().numpy()[: len(want)], want, "copy_segments")

@@ -923,3 +923,7 @@ def test_sort_keys_with_a_shared_prefix(emu_ctx, wide):
 
 def test_compare_on_temporal_columns(emu_ctx):
     P.check_temporal_compare(emu_ctx, rng_for("temporal-compare"), n=3000)
+
+
+def test_copy_segments_any_alignment(emu_ctx):
+    P.check_copy_segments(emu_ctx, rng_for("copyseg"), 1)

@@ -1216,3 +1216,7 @@ def test_sort_keys_with_a_shared_prefix(gpu_ctx, wide):
 
 def test_compare_on_temporal_columns(gpu_ctx):
     P.check_temporal_compare(gpu_ctx, rng_for("temporal-compare"), n=700003)
+
+
+def test_copy_segments_any_alignment(gpu_ctx):
+    P.check_copy_segments(gpu_ctx, rng_for("copyseg"), 40)

@@ -107,6 +107,8 @@ def check_snappy_kernel(amd, rng, scale=1):
             bytes(rng.integers(0, 4, 70000 * scale, dtype=np.uint8)), np.arange(30000 * scale, dtype=np.int64).tobytes(),
             b"x" * 100000 * scale, (b"hello world, " * 300) + bytes(rng.integers(0, 256, 200, dtype=np.uint8))]
     raws += [bytes(rng.integers(0, 256, period, dtype=np.uint8)) * (3000 // period + 2) for period in (1, 2, 3, 5, 7, 13, 63, 64, 65, 200)]
+    # long literals (incompressible pages): the 16-bytes-per-lane copy with every head / tail length
+    raws += [bytes(rng.integers(0, 256, k, dtype=np.uint8)) for k in (511, 512, 513, 527, 4097, 65536 + 3, 70001 * scale)]
     got, st, tail = run(raws)
     assert st == [0] * len(raws), st
     assert got == b"".join(raws) and not any(tail)
