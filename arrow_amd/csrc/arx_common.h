@@ -23,6 +23,7 @@ int hip_fail(hipError_t e, const char* what);
 int set_selection_option(const char* name, int64_t value);
 int set_sort_option(const char* name, int64_t value);
 int set_groupby_option(const char* name, int64_t value);
+int set_parquet_option(const char* name, int64_t value);
 
 #define ARX_HIP(call)                                          \
   do {                                                         \

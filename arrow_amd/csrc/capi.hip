@@ -35,7 +35,7 @@ int arx_set_option(const char* name, int64_t value) {
     return ARX_INVALID;
   }
   if (arx::set_selection_option(name, value) || arx::set_sort_option(name, value) ||
-      arx::set_groupby_option(name, value)) {
+      arx::set_groupby_option(name, value) || arx::set_parquet_option(name, value)) {
     return ARX_OK;
   }
   arx::set_error("unknown option '%s'", name);

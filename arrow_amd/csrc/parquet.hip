@@ -13,6 +13,7 @@
 // run table; here every output value finds its run by binary search and reads its bits directly,
 // so the decode itself is embarrassingly parallel and reads the page bytes from HBM once.
 #include "arx_common.h"
+#include <string.h>
 
 #include <algorithm>
 
@@ -302,6 +303,18 @@ __global__ __launch_bounds__(kBlock) void byte_stream_split_kernel(const uint8_t
   }
 }
 
+// A/B knob snappy_lds: 1 = input window + recent output in LDS, 0 = every byte through global memory, -1 (default) =
+// by the page count: the LDS form is 8-25 % faster on pages of >= 160 KB (profiles/r02_aq) but its 70 KB of LDS per
+// workgroup halves the waves per CU, which costs 40-65 % when there are thousands of small pages to overlap
+static int g_snappy_lds = -1;
+int set_parquet_option(const char* name, int64_t value) {
+  if (strcmp(name, "snappy_lds") == 0) {
+    g_snappy_lds = value < 0 ? -1 : (value != 0);
+    return 1;
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------ Snappy page decompression
 // What SnappyCodec::Decompress -> snappy::RawUncompress does per page (cpp/src/arrow/util/compression_snappy.cc:42-62;
 // format: github.com/google/snappy format_description.txt, the bundled third-party codec is not in this tree): a varint
@@ -421,6 +434,149 @@ __global__ __launch_bounds__(kBlock) void snappy_decode_kernel(const uint8_t* __
     pending += len;
     // lanes move on to the next element together (a scheduling barrier on the GPU, where the wave runs in lockstep
     // anyway; the rendezvous the SIMT emulator needs before a later copy reads these bytes)
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!err && op != ulen) err = 2;
+  if (lane == 0) status[pg] = err;
+}
+
+// The same decoder with the two dependent global loads of every element taken out of its critical path: the next
+// kSnWin bytes of INPUT sit in LDS (tag bytes and short literals are LDS reads; refilled by the 64 lanes, 16 bytes
+// each) and so do the last kSnRing bytes of OUTPUT (a copy whose source lies there — offsets are mostly small — reads
+// LDS and needs no fence for the wave's own stores in flight).  Every output byte still goes to global memory; the
+// ring is a write-through cache of it.  Long literals keep the 16-bytes-per-lane global copy and just mark the ring as
+// not holding them (ring_lo); copies that reach behind the ring take the global path of the kernel above.
+constexpr uint32_t kSnWin = 1024;
+constexpr uint32_t kSnRing = 16384;
+struct __attribute__((aligned(16))) SnappyLds {
+  uint8_t win[kWavesPerBlock][kSnWin + 16];
+  uint8_t ring[kWavesPerBlock][kSnRing];
+};
+
+__global__ __launch_bounds__(kBlock) void snappy_decode_lds_kernel(const uint8_t* __restrict__ src, const ArxSnappyPage* __restrict__ pages,
+                                                                   int64_t npages, uint8_t* dst, uint32_t* __restrict__ status) {
+  __shared__ SnappyLds lds;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t pg = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  if (pg >= npages) return;  // wave-uniform (no workgroup barrier below)
+  const ArxSnappyPage p = pages[pg];
+  const uint8_t* in = src + p.src_offset;
+  uint8_t* out = dst + p.dst_offset;
+  uint8_t* win = lds.win[wave];
+  uint8_t* ring = lds.ring[wave];
+  const uint32_t n_in = p.src_size;
+  uint32_t ip = 0, ulen = 0, err = 0;
+  uint32_t wbase = 0, wlen = 0;   // the window holds input bytes [wbase, wbase + wlen)
+  // refill so that the window starts at `at` (called with the lanes together; `at` < n_in)
+  auto refill = [&](uint32_t at) {
+    __builtin_amdgcn_wave_barrier();   // (every lane is done reading the old window)
+    wbase = at;
+    wlen = n_in - at < kSnWin ? n_in - at : kSnWin;
+    const uint32_t k = static_cast<uint32_t>(lane) * 16;
+    if (k + 16 <= wlen) {
+      *reinterpret_cast<uint4*>(win + k) = load16_unaligned(in + at + k);
+    } else {
+      for (uint32_t b = k; b < wlen; ++b) win[b] = in[at + b];
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (n_in > 0) refill(0);
+  {  // preamble: varint32
+    int shift = 0;
+    for (;;) {
+      if (ip >= n_in || ip >= wlen || shift > 28) { err = 1; break; }
+      const uint32_t c = win[ip++];
+      ulen |= (c & 0x7Fu) << shift;
+      if ((c & 0x80u) == 0) break;
+      shift += 7;
+    }
+    if (!err && ulen != p.dst_size) err = 1;
+  }
+  uint32_t op = 0, pending = 0, ring_lo = 0;   // output bytes [ring_lo, op) younger than kSnRing are in the ring
+  while (!err && ip < n_in) {
+    if (ip + 5 > wbase + wlen && wbase + wlen < n_in) refill(ip);   // the tag and what may follow it
+    const uint8_t* w = win + (ip - wbase);
+    uint32_t b[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) b[k] = w[k];   // (past the input's end: stale window bytes, rejected by the checks below)
+    const uint32_t tag = b[0];
+    uint32_t len, off = 0, adv;
+    if ((tag & 3u) == 0) {
+      len = (tag >> 2) + 1;
+      adv = 1;
+      if (len > 60) {
+        const uint32_t nb = len - 60;
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < nb; ++k) v |= b[1 + k] << (8 * k);
+        len = v + 1;
+        adv = 1 + nb;
+        if (v == 0xFFFFFFFFu) { err = 2; break; }
+      }
+      if (ip + adv > n_in || len > n_in - (ip + adv) || len > ulen - op) { err = 2; break; }
+      ip += adv;
+      if (len >= 2048) {   // long literal: global to global, 16 bytes per lane; the ring does not get it
+        snappy_copy_literal(out + op, in + ip, len, lane);
+        ip += len;
+        op += len;
+        pending += len;
+        ring_lo = op;
+      } else {             // through the window, piece by piece
+        uint32_t left = len;
+        while (left > 0) {
+          if (ip >= wbase + wlen) refill(ip);
+          const uint32_t piece = left < wbase + wlen - ip ? left : wbase + wlen - ip;
+          const uint8_t* from = win + (ip - wbase);
+          for (uint32_t j = lane; j < piece; j += 64) {
+            const uint8_t c = from[j];
+            out[op + j] = c;
+            ring[(op + j) & (kSnRing - 1)] = c;
+          }
+          ip += piece;
+          op += piece;
+          pending += piece;
+          left -= piece;
+        }
+      }
+    } else {
+      if ((tag & 3u) == 1) {
+        len = 4 + ((tag >> 2) & 7u);
+        off = ((tag >> 5) << 8) | b[1];
+        adv = 2;
+      } else if ((tag & 3u) == 2) {
+        len = 1 + (tag >> 2);
+        off = b[1] | (b[2] << 8);
+        adv = 3;
+      } else {
+        len = 1 + (tag >> 2);
+        off = b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24);
+        adv = 5;
+      }
+      if (ip + adv > n_in || len > ulen - op) { err = 2; break; }
+      if (off == 0 || off > op) { err = 3; break; }
+      ip += adv;
+      if (off <= kSnRing && op - off >= ring_lo) {   // the source is in the ring (len <= 64: one step per lane)
+        const uint32_t j = lane;
+        if (j < len) {
+          const uint8_t c = ring[(op - off + (off >= len ? j : j % off)) & (kSnRing - 1)];
+          out[op + j] = c;
+          ring[(op + j) & (kSnRing - 1)] = c;
+        }
+      } else {
+        if (static_cast<int64_t>(off) - static_cast<int64_t>(len < off ? len : off) < static_cast<int64_t>(pending)) {
+          __threadfence_block();
+          pending = 0;
+        }
+        const uint8_t* from = out + (op - off);
+        for (uint32_t j = lane; j < len; j += 64) {
+          const uint8_t c = from[off >= len ? j : j % off];
+          out[op + j] = c;
+          ring[(op + j) & (kSnRing - 1)] = c;
+        }
+      }
+      op += len;
+      pending += len;
+    }
     __builtin_amdgcn_wave_barrier();
   }
   if (!err && op != ulen) err = 2;
@@ -914,8 +1070,13 @@ int arx_snappy_decompress_pages(const void* compressed, const ArxSnappyPage* pag
     return ARX_INVALID;
   }
   const unsigned grid = static_cast<unsigned>(ceil_div(num_pages, kWavesPerBlock));
-  hipLaunchKernelGGL(snappy_decode_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream),
-                     static_cast<const uint8_t*>(compressed), pages, num_pages, static_cast<uint8_t*>(out), status);
+  if (g_snappy_lds == 1 || (g_snappy_lds < 0 && num_pages < 4096)) {
+    hipLaunchKernelGGL(snappy_decode_lds_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                       static_cast<const uint8_t*>(compressed), pages, num_pages, static_cast<uint8_t*>(out), status);
+  } else {
+    hipLaunchKernelGGL(snappy_decode_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                       static_cast<const uint8_t*>(compressed), pages, num_pages, static_cast<uint8_t*>(out), status);
+  }
   ARX_CHECK_LAUNCH("snappy_decode_kernel");
   return ARX_OK;
 }

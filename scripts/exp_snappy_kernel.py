@@ -34,13 +34,20 @@ for kind in ("random int64", "cumsum of small ints", "zeros"):
         stream = current_stream(dev)
         def run():
             _lib.check(lib.arx_snappy_decompress_pages(src.data_ptr(), table.data_ptr(), npages, out.data_ptr(), st.data_ptr(), stream))
-        run(); torch.cuda.synchronize()
-        assert int(st.max().item()) == 0
-        got = out[: n64 * 8].cpu().numpy().tobytes()
-        assert got == one[0]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5): run()
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
-        print(f"{kind:22s} {npages:6d} pages x {page_bytes:8d} B ({so/1e6:7.1f} MB compressed): {ms:7.3f} ms  = {npages*n64*8/ms/1e6:8.1f} GB/s of output", flush=True)
+        res = []
+        for lds in (1, 0):
+            assert lib.arx_set_option(b"snappy_lds", lds) == 0
+            out.zero_()
+            run(); torch.cuda.synchronize()
+            assert int(st.max().item()) == 0
+            got = out[: n64 * 8].cpu().numpy().tobytes()
+            assert got == one[0]
+            last = out[(npages - 1) * n64 * 8: npages * n64 * 8].cpu().numpy().tobytes()
+            assert last == one[(npages - 1) % 8]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5): run()
+            e1.record(); torch.cuda.synchronize()
+            res.append(e0.elapsed_time(e1) / 5)
+        lib.arx_set_option(b"snappy_lds", -1)
+        print(f"{kind:22s} {npages:6d} pages x {page_bytes:8d} B ({so/1e6:7.1f} MB compressed): LDS form {res[0]:7.3f} ms = {npages*n64*8/res[0]/1e6:8.1f} GB/s of output | global form {res[1]:7.3f} ms", flush=True)

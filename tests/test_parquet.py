@@ -107,6 +107,10 @@ def check_snappy_kernel(amd, rng, scale=1):
             bytes(rng.integers(0, 4, 70000 * scale, dtype=np.uint8)), np.arange(30000 * scale, dtype=np.int64).tobytes(),
             b"x" * 100000 * scale, (b"hello world, " * 300) + bytes(rng.integers(0, 256, 200, dtype=np.uint8))]
     raws += [bytes(rng.integers(0, 256, period, dtype=np.uint8)) * (3000 // period + 2) for period in (1, 2, 3, 5, 7, 13, 63, 64, 65, 200)]
+    # copies that reach further back than the LDS ring holds (a 40 KB period), literals around the window size
+    far = bytes(rng.integers(0, 256, 40_000, dtype=np.uint8))
+    raws += [far * 3, bytes(rng.integers(0, 256, 30_000, dtype=np.uint8)) + bytes(1000) + far[:20_000] + far[:20_000]]
+    raws += [bytes(rng.integers(0, 256, k, dtype=np.uint8)) + b"ab" * 40 for k in (1000, 1023, 1024, 1025, 2047, 2048, 2049, 3000)]
     # long literals (incompressible pages): the 16-bytes-per-lane copy with every head / tail length
     raws += [bytes(rng.integers(0, 256, k, dtype=np.uint8)) for k in (511, 512, 513, 527, 4097, 65536 + 3, 70001 * scale)]
     got, st, tail = run(raws)
@@ -123,14 +127,26 @@ def check_snappy_kernel(amd, rng, scale=1):
     assert st == [3, 2, 1], st
 
 
+def _with_snappy_form(amd, lds, fn):
+    lib = amd._lib.get_lib()
+    assert lib.arx_set_option(b"snappy_lds", lds) == 0
+    try:
+        fn()
+    finally:
+        lib.arx_set_option(b"snappy_lds", -1)
+
+
 @pytest.mark.emu
-def test_snappy_page_decoder_kernel(emu_ctx):
-    check_snappy_kernel(emu_ctx, np.random.default_rng(3))
+@pytest.mark.parametrize("lds", [1, 0])
+def test_snappy_page_decoder_kernel(emu_ctx, lds):
+    """Both forms of the decoder: input window + recent output in LDS (default), and every byte through global memory."""
+    _with_snappy_form(emu_ctx, lds, lambda: check_snappy_kernel(emu_ctx, np.random.default_rng(3)))
 
 
 @pytest.mark.gpu
-def test_snappy_page_decoder_kernel_gpu(gpu_ctx):
-    check_snappy_kernel(gpu_ctx, np.random.default_rng(4), scale=20)
+@pytest.mark.parametrize("lds", [1, 0])
+def test_snappy_page_decoder_kernel_gpu(gpu_ctx, lds):
+    _with_snappy_form(gpu_ctx, lds, lambda: check_snappy_kernel(gpu_ctx, np.random.default_rng(4), scale=20))
 
 
 LEVEL_PAGE = np.dtype([("byte_start", "<u8"), ("nbytes", "<u4"), ("num_values", "<u4"), ("row_start", "<u8")])
