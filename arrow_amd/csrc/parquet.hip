@@ -486,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void snappy_decode_lds_kernel(const uint8_t
     int shift = 0;
     for (;;) {
       if (ip >= n_in || ip >= wlen || shift > 28) { err = 1; break; }
-      const uint32_t c = win[ip++];
+      const uint32_t c = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(win[ip++]));
       ulen |= (c & 0x7Fu) << shift;
       if ((c & 0x80u) == 0) break;
       shift += 7;
@@ -500,6 +500,9 @@ __global__ __launch_bounds__(kBlock) void snappy_decode_lds_kernel(const uint8_t
     uint32_t b[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) b[k] = w[k];   // (past the input's end: stale window bytes, rejected by the checks below)
+    // the bytes are the same in every lane: from here on the parse is scalar (SGPRs, SALU, scalar branches)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) b[k] = __builtin_amdgcn_readfirstlane(b[k]);
     const uint32_t tag = b[0];
     uint32_t len, off = 0, adv;
     if ((tag & 3u) == 0) {
