@@ -177,6 +177,7 @@ SIGNATURES = {
     "arx_arith_numeric": (_int, [_int, _int, _int, _p, _p, _p, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p]),
     "arx_delta_decode_pages": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _sz, _p, _p]),
     "arx_copy_segments": (_int, [_p, _i64, _u64, _p]),
+    "arx_bitmap_copy_segments": (_int, [_p, _i64, _i64, _p]),
     "arx_take_columns": (_int, [_p, _p, _int, _span, _int, _p, _p, _p, _p]),
     "arx_grouper_state_bytes": (_sz, [_i64]),
     "arx_grouper_init": (_int, [_p, _i64, _p]),

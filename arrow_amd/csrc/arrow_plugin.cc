@@ -210,6 +210,7 @@ int64_t arrow_amd_plugin_parquet_device_snappy_pages(void) { return g_parquet_de
 // device-route pages that had to be copied into the staging block (0: the page reader hands out slices of the chunk)
 int64_t arrow_amd_plugin_parquet_copied_pages(void) { return g_parquet_copied_pages.load(); }
 // aggregate_rocm: rows of pending device batches that trigger a copy into the staging columns; copies so far
+void arrow_amd_plugin_set_aggregate_stage_nulls(int on) { g_aggregate_stage_nulls.store(on != 0); }
 void arrow_amd_plugin_set_aggregate_flush_rows(int64_t rows) { g_aggregate_flush_rows.store(rows < 1 ? 1 : rows); }
 int64_t arrow_amd_plugin_aggregate_flushes(void) { return g_aggregate_flushes.load(); }
 // The same threshold for the element-wise kernels (greater, cast); default: never stage them.

@@ -71,6 +71,25 @@ static inline Bits make_bits(const void* bitmap, int64_t bit_offset, int64_t len
   return b;
 }
 
+// make_bits on the device (the bitmap's address comes out of a device-side table)
+__device__ __forceinline__ Bits make_bits_device(const void* bitmap, int64_t bit_offset, int64_t length) {
+  Bits b;
+  b.length = length;
+  if (bitmap == nullptr) {
+    b.base = nullptr;
+    b.nphys = 0;
+    b.shift = 0;
+    return b;
+  }
+  const uint64_t byte_addr = reinterpret_cast<uint64_t>(bitmap) + static_cast<uint64_t>(bit_offset >> 3);
+  const int bit_in_byte = static_cast<int>(bit_offset & 7);
+  const uint64_t aligned = byte_addr & ~uint64_t(7);
+  b.base = reinterpret_cast<const uint64_t*>(aligned);
+  b.shift = static_cast<int>((byte_addr - aligned) * 8) + bit_in_byte;
+  b.nphys = (static_cast<int64_t>(b.shift) + length + 63) >> 6;
+  return b;
+}
+
 __device__ __forceinline__ uint64_t low_mask64(int n) {  // n in [0,64]
   return n >= 64 ? ~uint64_t(0) : ((uint64_t(1) << n) - 1);
 }

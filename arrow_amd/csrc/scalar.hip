@@ -745,6 +745,28 @@ __global__ __launch_bounds__(kBlock) void copy_segments_kernel(const ArxCopySeg*
   }
 }
 
+// The validity half of the same concatenation: many bitmap ranges, each at its own bit offset, ORed into ZEROED
+// destination bitmaps at their own bit positions (ranges meet inside words: atomicOr).  src == NULL: all ones (a chunk
+// without a validity buffer).  One thread per 64 source bits.
+__global__ __launch_bounds__(kBlock) void bitmap_copy_segments_kernel(const ArxBitSeg* __restrict__ segs, int64_t nsegs,
+                                                                      unsigned per_seg) {
+  const int64_t sg = blockIdx.x / per_seg;
+  const unsigned part = blockIdx.x % per_seg;
+  if (sg >= nsegs) return;
+  const ArxBitSeg seg = segs[sg];
+  const Bits src = make_bits_device(seg.src, seg.src_bit_offset, seg.nbits);
+  unsigned long long* dst = static_cast<unsigned long long*>(seg.dst);
+  const int64_t nwords = (seg.nbits + 63) >> 6;
+  for (int64_t w = static_cast<int64_t>(part) * kBlock + threadIdx.x; w < nwords; w += static_cast<int64_t>(per_seg) * kBlock) {
+    const uint64_t v = load_word(src, w);   // bits past nbits read as zero; a NULL bitmap reads as ones
+    if (v == 0) continue;
+    const uint64_t at = static_cast<uint64_t>(seg.dst_bit_offset) + (static_cast<uint64_t>(w) << 6);
+    const int sh = static_cast<int>(at & 63);
+    atomicOr(&dst[at >> 6], static_cast<unsigned long long>(v << sh));
+    if (sh != 0 && (v >> (64 - sh)) != 0) atomicOr(&dst[(at >> 6) + 1], static_cast<unsigned long long>(v >> (64 - sh)));
+  }
+}
+
 // ------------------------------------------------------------------ compare / arithmetic on every numeric type
 // The comparison family and add / subtract / multiply (+ _checked) for the element types the 64-bit kernels above do
 // not take (int8 ... uint32, uint64, float): the same Call bodies (scalar_compare.cc:38-64,
@@ -1135,6 +1157,25 @@ int arx_copy_segments(const ArxCopySeg* segments, int64_t num_segments, uint64_t
   hipLaunchKernelGGL(copy_segments_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, as_stream(stream), segments,
                      num_segments, static_cast<unsigned>(per_seg));
   ARX_CHECK_LAUNCH("copy_segments_kernel");
+  return ARX_OK;
+}
+
+int arx_bitmap_copy_segments(const ArxBitSeg* segments, int64_t num_segments, int64_t max_segment_bits, void* stream) {
+  if (num_segments < 0 || max_segment_bits < 0 || (num_segments > 0 && segments == nullptr)) {
+    set_error("bad arguments to arx_bitmap_copy_segments");
+    return ARX_INVALID;
+  }
+  if (num_segments == 0 || max_segment_bits == 0) return ARX_OK;
+  const uint64_t words = (static_cast<uint64_t>(max_segment_bits) + 63) / 64;
+  const uint64_t per_seg = std::min<uint64_t>((words + kBlock - 1) / kBlock, 4096);
+  const uint64_t blocks = per_seg * static_cast<uint64_t>(num_segments);
+  if (blocks > (uint64_t(1) << 31) - 1) {
+    set_error("arx_bitmap_copy_segments: too many segments for one launch (%lld)", static_cast<long long>(num_segments));
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(bitmap_copy_segments_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, as_stream(stream),
+                     segments, num_segments, static_cast<unsigned>(per_seg));
+  ARX_CHECK_LAUNCH("bitmap_copy_segments_kernel");
   return ARX_OK;
 }
 

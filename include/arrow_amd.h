@@ -372,6 +372,18 @@ typedef struct ArxCopySeg {
   uint64_t nbytes;
 } ArxCopySeg;
 int arx_copy_segments(const ArxCopySeg* segments, int64_t num_segments, uint64_t max_segment_bytes, void* stream);
+/* The validity half of the same concatenation (ConcatenateBitmaps, array/concatenate.cc): bit ranges, each at its own
+ * bit offset, ORed into ZEROED destination bitmaps at their own bit positions (ranges may meet inside a word).
+ * src == NULL stands for a chunk without a validity buffer: all ones.  dst: 8-byte aligned, writable up to the 64-bit
+ * word that holds the range's last bit.  segments: DEVICE array.  Asynchronous. */
+typedef struct ArxBitSeg {
+  const void* src;
+  int64_t src_bit_offset;
+  void* dst;
+  int64_t dst_bit_offset;
+  int64_t nbits;
+} ArxBitSeg;
+int arx_bitmap_copy_segments(const ArxBitSeg* segments, int64_t num_segments, int64_t max_segment_bits, void* stream);
 int arx_binary_rebase_offsets(const int32_t* offsets, int64_t length, int32_t base, int32_t* out,
                               void* stream);
 /* Scalar aggregates over an int64 column in one pass — the state SumImpl / CountImpl / MinMaxImpl keep

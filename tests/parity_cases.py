@@ -1615,3 +1615,40 @@ def check_copy_segments(amd, rng, scale=1):
     for a, b, n in segs:
         want[b:b + n] = src_h[a:a + n]
     assert_equal(dst.cpu().numpy()[: len(want)], want, "copy_segments")
+
+
+BIT_SEG = np.dtype([("src", "<u8"), ("src_bit_offset", "<i8"), ("dst", "<u8"), ("dst_bit_offset", "<i8"), ("nbits", "<i8")])
+
+
+def check_bitmap_copy_segments(amd, rng, scale=1):
+    """arx_bitmap_copy_segments: bit ranges at any source bit offset ORed into zeroed bitmaps back to back (ranges meet
+    inside words), NULL sources (= all ones), empty ranges, two destination bitmaps in one launch."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    lengths = [0, 1, 7, 63, 64, 65, 127, 128, 129, 4096, 32768, 100003 * scale, 5]
+    src_bits_h = rng.integers(0, 2, 400_000 * scale + 64, dtype=np.uint8)
+    src = to_device(np.packbits(src_bits_h, bitorder="little"), dev)
+    total = sum(lengths) * 2
+    dsts = [torch.zeros((total + 63) // 64 + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+    want = [np.zeros(((total + 63) // 64 + 1) * 64, np.uint8) for _ in range(2)]
+    pos = [3, 0]                     # the first bitmap does not even start at a word boundary
+    segs = []
+    for i, n in enumerate(lengths * 2):
+        d = i % 2
+        null_src = i % 5 == 3
+        so = int(rng.integers(0, len(src_bits_h) - n - 1)) if n else int(rng.integers(0, 100))
+        segs.append((0 if null_src else src.data_ptr(), so, dsts[d].data_ptr(), pos[d], n))
+        want[d][pos[d]:pos[d] + n] = 1 if null_src else src_bits_h[so:so + n]
+        pos[d] += n
+    table = np.zeros(len(segs), BIT_SEG)
+    for i, sg in enumerate(segs):
+        table[i] = sg
+    d_table = to_device(table.view(np.uint8), dev)
+    _lib.check(lib.arx_bitmap_copy_segments(d_table.data_ptr(), len(segs), max(lengths), current_stream(dev)))
+    for d in range(2):
+        got = np.unpackbits(dsts[d].cpu().numpy().view(np.uint8), bitorder="little")
+        assert_equal(got[: len(want[d])], want[d], f"bitmap_copy_segments dst {d}")

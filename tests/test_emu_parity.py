@@ -927,3 +927,7 @@ def test_compare_on_temporal_columns(emu_ctx):
 
 def test_copy_segments_any_alignment(emu_ctx):
     P.check_copy_segments(emu_ctx, rng_for("copyseg"), 1)
+
+
+def test_bitmap_copy_segments(emu_ctx):
+    P.check_bitmap_copy_segments(emu_ctx, rng_for("bitseg"), 1)

@@ -610,13 +610,41 @@ ACERO_DEVICE_SCRIPT = textwrap.dedent(r'''
                 got = plan(dev, "aggregate_rocm").to_table(use_threads=threads).sort_by("k")
                 assert got.schema.names == ["k", "v_sum"]
                 assert got.equals(want), (null_p, threads, flush_rows, got.slice(0, 5), want.slice(0, 5))
-                if null_p == 0.0:
-                    flushes = lib.arrow_amd_plugin_aggregate_flushes() - f0
-                    assert flushes >= 1 and (flush_rows >= n or flushes > 1), (flush_rows, flushes)
+                # (batches WITH nulls are staged the same way, their validity by arx_bitmap_copy_segments)
+                flushes = lib.arrow_amd_plugin_aggregate_flushes() - f0
+                assert flushes >= 1 and (flush_rows >= n or flushes > 1), (null_p, flush_rows, flushes)
+            if null_p:   # the route before: every batch with nulls consumed on its own
+                lib.arrow_amd_plugin_set_aggregate_stage_nulls(0)
+                f0 = lib.arrow_amd_plugin_aggregate_flushes()
+                got = plan(dev, "aggregate_rocm").to_table(use_threads=threads).sort_by("k")
+                assert got.equals(want) and lib.arrow_amd_plugin_aggregate_flushes() == f0
+                lib.arrow_amd_plugin_set_aggregate_stage_nulls(1)
         lib.arrow_amd_plugin_set_aggregate_flush_rows(1 << 21)
         for f in names:   # FilterNode's expression, its per-column Filter, the projection and the group-by all ran on the GPU
             assert lib.arrow_amd_plugin_calls(f, 1) > gpu0[f], f
             assert lib.arrow_amd_plugin_calls(f, 0) == stock0[f], f
+
+    # a table whose first chunk has no validity at all and whose second has nulls: the staged validity starts in the
+    # middle of the plan (the rows staged before are marked valid afterwards), with flushes before and after the switch
+    m = SC(300_000)
+    ka, va = pa.array(rng.integers(-300, 300, m).astype(np.int32)), pa.array(rng.integers(-2**40, 2**40, m))
+    kb = pa.array(rng.integers(-300, 300, m).astype(np.int32), mask=rng.random(m) < 0.1)
+    vb = pa.array(rng.integers(-2**40, 2**40, m), mask=rng.random(m) < 0.2)
+    host2 = pa.table({"k": pa.chunked_array([ka, kb]), "v": pa.chunked_array([va, vb])})
+    dev2 = pa.table({"k": pa.chunked_array([to_device(ka), to_device(kb)]), "v": pa.chunked_array([to_device(va), to_device(vb)])})
+
+    def plan2(table, agg):
+        return acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(table)),
+            acero.Declaration(agg, acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum"), ("v", "hash_count", None, "v_n")], keys=["k"])),
+        ])
+
+    want2 = plan2(host2, "aggregate").to_table(use_threads=False).select(["k", "v_sum", "v_n"]).sort_by("k")
+    for flush_rows in (1 << 21, max(1000, m // 7)):
+        lib.arrow_amd_plugin_set_aggregate_flush_rows(flush_rows)
+        got2 = plan2(dev2, "aggregate_rocm").to_table(use_threads=False).select(["k", "v_sum", "v_n"]).sort_by("k")
+        assert got2.equals(want2), (flush_rows, got2.slice(0, 5), want2.slice(0, 5))
+    lib.arrow_amd_plugin_set_aggregate_flush_rows(1 << 21)
 
     print("ACERO_DEVICE_OK")
 ''')

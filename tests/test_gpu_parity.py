@@ -1220,3 +1220,7 @@ def test_compare_on_temporal_columns(gpu_ctx):
 
 def test_copy_segments_any_alignment(gpu_ctx):
     P.check_copy_segments(gpu_ctx, rng_for("copyseg"), 40)
+
+
+def test_bitmap_copy_segments(gpu_ctx):
+    P.check_bitmap_copy_segments(gpu_ctx, rng_for("bitseg"), 20)
