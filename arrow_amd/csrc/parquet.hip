@@ -586,6 +586,99 @@ __global__ __launch_bounds__(kBlock) void snappy_decode_lds_kernel(const uint8_t
   if (lane == 0) status[pg] = err;
 }
 
+// ------------------------------------------------------------------ LZ4 (the buffers of a compressed IPC record batch)
+// What Lz4FrameCodec::Decompress -> LZ4F_decompress does per buffer (cpp/src/arrow/util/compression_lz4.cc; the frame
+// and block formats are lz4's published lz4_Frame_format.md / lz4_Block_format.md, the bundled codec is not in this
+// tree).  The host walks the frame (magic, descriptor, block sizes: a few bytes per 64 KB..4 MB block) and hands over
+// one STREAM per buffer = its blocks in order; blocks of a frame may be linked (a match reaches into the previous
+// blocks' output), so one wave decodes a stream's blocks one after the other into the same output, and streams —
+// the buffers of all columns — are independent.  A block: sequences of {token (literal length : match length - 4, 15 =
+// more length bytes follow), literals, 2-byte offset, match}; the last sequence ends after its literals.
+// status per stream: 0 ok, 1 output length mismatch, 2 a sequence runs past the block or the output, 3 bad offset.
+__global__ __launch_bounds__(kBlock) void lz4_decode_kernel(const uint8_t* __restrict__ src, const ArxLz4Stream* __restrict__ streams,
+                                                            const ArxLz4Block* __restrict__ blocks, int64_t nstreams, uint8_t* dst,
+                                                            uint32_t* __restrict__ status) {
+  const int lane = lane_id();
+  const int64_t sid = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (sid >= nstreams) return;  // wave-uniform
+  const ArxLz4Stream stream = streams[sid];
+  uint8_t* out = dst + stream.dst_offset;
+  const uint64_t ulen = stream.dst_size;
+  uint64_t op = 0, pending = 0;
+  uint32_t err = 0;
+  for (uint32_t bi = 0; bi < stream.num_blocks && !err; ++bi) {
+    const ArxLz4Block blk = blocks[stream.first_block + bi];
+    const uint8_t* in = src + blk.src_offset;
+    const uint32_t n_in = blk.src_size;
+    if (blk.stored) {   // an incompressible block is kept as it is
+      if (n_in > ulen - op) { err = 2; break; }
+      snappy_copy_literal(out + op, in, n_in, lane);
+      op += n_in;
+      pending += n_in;
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+    uint32_t ip = 0;
+    while (ip < n_in) {
+      const uint32_t token = in[ip++];
+      // literals
+      uint64_t len = token >> 4;
+      if (len == 15) {
+        for (;;) {
+          if (ip >= n_in) { err = 2; break; }
+          const uint32_t c = in[ip++];
+          len += c;
+          if (c != 255) break;
+        }
+        if (err) break;
+      }
+      if (len > n_in - ip || len > ulen - op) { err = 2; break; }
+      if (len > 0) {
+        snappy_copy_literal(out + op, in + ip, static_cast<uint32_t>(len), lane);
+        ip += static_cast<uint32_t>(len);
+        op += len;
+        pending += len;
+        __builtin_amdgcn_wave_barrier();   // (the match below may read these bytes)
+      }
+      if (ip >= n_in) break;   // the block's last sequence has no match
+      // match
+      if (ip + 2 > n_in) { err = 2; break; }
+      const uint32_t off = in[ip] | (static_cast<uint32_t>(in[ip + 1]) << 8);
+      ip += 2;
+      uint64_t mlen = (token & 15u);
+      if (mlen == 15) {
+        for (;;) {
+          if (ip >= n_in) { err = 2; break; }
+          const uint32_t c = in[ip++];
+          mlen += c;
+          if (c != 255) break;
+        }
+        if (err) break;
+      }
+      mlen += 4;
+      if (off == 0 || off > op) { err = 3; break; }
+      if (mlen > ulen - op) { err = 2; break; }
+      // the source range must not hold bytes this wave stored since the last fence
+      if (static_cast<int64_t>(off) - static_cast<int64_t>(mlen < off ? mlen : off) < static_cast<int64_t>(pending)) {
+        __threadfence_block();
+        pending = 0;
+      }
+      const uint8_t* from = out + (op - off);
+      if (off >= mlen) {
+        for (uint64_t j = lane; j < mlen; j += 64) out[op + j] = from[j];
+      } else {
+        for (uint64_t j = lane; j < mlen; j += 64) out[op + j] = from[j % off];
+      }
+      op += mlen;
+      pending += mlen;
+      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!err && op != ulen) err = 1;
+  if (lane == 0) status[sid] = err;
+}
+
 // ---- definition levels of a flat optional column (bit width 1) -> validity bits, run headers walked on the device.
 // One wave per page.  Every lane parses the same header bytes (uniform loads), then the 64 lanes share the run's bits:
 // a repeated run of ones sets a bit range, a bit-packed run ORs its payload bytes in at the page's bit position (pages
@@ -1038,6 +1131,94 @@ int arx_rle_decode_equals_bitmap(const void* bytes, size_t nbytes, const ArxRleR
                      static_cast<const uint8_t*>(bytes), static_cast<uint64_t>(nbytes), runs, nruns, bit_width,
                      num_values, equals, static_cast<uint32_t*>(nullptr), static_cast<uint64_t*>(out_bits));
   ARX_CHECK_LAUNCH("rle_decode_kernel");
+  return ARX_OK;
+}
+
+// HOST: the blocks of one LZ4 frame (lz4_Frame_format.md): magic 0x184D2204, FLG (version 01, block independence,
+// block checksum, content size, content checksum, dictionary id), BD, optional 8-byte content size, optional 4-byte
+// dictionary id, header checksum byte; then {4-byte size (top bit: stored), data, optional 4-byte block checksum}
+// until a zero size (EndMark), then the optional content checksum.  Checksums are skipped, not verified.
+int arx_lz4_frame_scan(const void* data, size_t nbytes, uint64_t byte_base, ArxLz4Block* blocks, int64_t max_blocks,
+                       int64_t* num_blocks, uint64_t* content_size) {
+  if (data == nullptr || num_blocks == nullptr) {
+    set_error("bad arguments to arx_lz4_frame_scan");
+    return ARX_INVALID;
+  }
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  auto le32 = [&](size_t at) {
+    return static_cast<uint32_t>(p[at]) | (static_cast<uint32_t>(p[at + 1]) << 8) | (static_cast<uint32_t>(p[at + 2]) << 16) |
+           (static_cast<uint32_t>(p[at + 3]) << 24);
+  };
+  if (nbytes < 7 || le32(0) != 0x184D2204u) {
+    set_error("Lz4 compressed input contains less than one frame");   // (the reference's text for a body that is no frame)
+    return ARX_INVALID;
+  }
+  const uint8_t flg = p[4];
+  if ((flg >> 6) != 1) {
+    set_error("LZ4 frame: unsupported version %d", flg >> 6);
+    return ARX_NOT_IMPLEMENTED;
+  }
+  if (flg & 1) {
+    set_error("LZ4 frame: dictionaries are not supported");
+    return ARX_NOT_IMPLEMENTED;
+  }
+  const bool block_checksum = (flg >> 4) & 1, has_size = (flg >> 3) & 1;
+  size_t pos = 6;
+  uint64_t csize = 0;
+  if (has_size) {
+    if (pos + 8 > nbytes) {
+      set_error("LZ4 frame: truncated header");
+      return ARX_INVALID;
+    }
+    for (int k = 0; k < 8; ++k) csize |= static_cast<uint64_t>(p[pos + k]) << (8 * k);
+    pos += 8;
+  }
+  pos += 1;   // header checksum
+  int64_t nb = 0;
+  for (;;) {
+    if (pos + 4 > nbytes) {
+      set_error("LZ4 frame: truncated before its end mark");
+      return ARX_INVALID;
+    }
+    const uint32_t word = le32(pos);
+    pos += 4;
+    if (word == 0) break;   // EndMark
+    const uint32_t size = word & 0x7FFFFFFFu;
+    if (size > nbytes - pos) {
+      set_error("LZ4 frame: a block runs past the buffer");
+      return ARX_INVALID;
+    }
+    if (blocks != nullptr) {
+      if (nb >= max_blocks) {
+        set_error("arx_lz4_frame_scan: more than %lld blocks", static_cast<long long>(max_blocks));
+        return ARX_INVALID;
+      }
+      blocks[nb] = ArxLz4Block{byte_base + pos, size, word >> 31};
+    }
+    ++nb;
+    pos += size;
+    if (block_checksum) pos += 4;
+  }
+  *num_blocks = nb;
+  if (content_size != nullptr) *content_size = csize;
+  return ARX_OK;
+}
+
+int arx_lz4_decompress_streams(const void* compressed, const ArxLz4Stream* streams, const ArxLz4Block* blocks,
+                               int64_t num_streams, void* out, uint32_t* status, void* stream) {
+  if (num_streams < 0) {
+    set_error("bad arguments to arx_lz4_decompress_streams");
+    return ARX_INVALID;
+  }
+  if (num_streams == 0) return ARX_OK;
+  if (compressed == nullptr || streams == nullptr || blocks == nullptr || out == nullptr || status == nullptr) {
+    set_error("NULL buffer passed to arx_lz4_decompress_streams");
+    return ARX_INVALID;
+  }
+  const unsigned grid = static_cast<unsigned>(ceil_div(num_streams, kWavesPerBlock));
+  hipLaunchKernelGGL(lz4_decode_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), static_cast<const uint8_t*>(compressed),
+                     streams, blocks, num_streams, static_cast<uint8_t*>(out), status);
+  ARX_CHECK_LAUNCH("lz4_decode_kernel");
   return ARX_OK;
 }
 

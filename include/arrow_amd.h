@@ -784,6 +784,34 @@ int arx_rle_decode_equals_bitmap(const void* bytes, size_t nbytes, const ArxRleR
                                  int bit_width, int64_t num_values, uint32_t equals, void* out_bits, void* stream);
 int arx_expand_by_mask(const void* dense, int byte_width, const ArxSpan* mask, const void* ws, void* out_data,
                        void* stream);
+/* LZ4 frame bodies on the device — Lz4FrameCodec::Decompress (cpp/src/arrow/util/compression_lz4.cc; lz4 is a bundled
+ * third-party dependency, cpp/thirdparty/versions.txt, not vendored in the tree: frame and block formats restated from
+ * its published lz4_Frame_format.md / lz4_Block_format.md) as DecompressBuffers applies it to every buffer of a
+ * compressed IPC record batch (cpp/src/arrow/ipc/reader.cc).  The HOST walks each frame's header and block sizes; a
+ * stream = one buffer's blocks in order (blocks of a frame may reference the previous blocks' output, so one wave
+ * decodes a stream sequentially; streams are independent).  `compressed`, `streams`, `blocks`: device.  status[i]: 0 ok,
+ * 1 the stream did not produce dst_size bytes, 2 a sequence runs past its block or the output, 3 a match offset
+ * outside the output so far — read it back before trusting the bytes.  Asynchronous. */
+typedef struct ArxLz4Block {
+  uint64_t src_offset;  /* of the block's data inside `compressed` */
+  uint32_t src_size;
+  uint32_t stored;      /* 1: the block is not compressed (copied as it is) */
+} ArxLz4Block;
+typedef struct ArxLz4Stream {
+  uint64_t first_block; /* index into `blocks` */
+  uint32_t num_blocks;
+  uint32_t reserved;
+  uint64_t dst_offset;  /* where the buffer's bytes go inside `out` */
+  uint64_t dst_size;    /* the buffer's uncompressed length (the 8-byte prefix of the IPC body buffer) */
+} ArxLz4Stream;
+/* HOST function: the blocks of the LZ4 frame at [data, data + nbytes) (blocks may be NULL to only count); src_offset =
+ * byte_base + the block's position, so that the frames of many buffers can share one device copy and one table.
+ * *content_size = the frame's own content size field or 0.  Checksums are skipped. */
+int arx_lz4_frame_scan(const void* data, size_t nbytes, uint64_t byte_base, ArxLz4Block* blocks, int64_t max_blocks,
+                       int64_t* num_blocks, uint64_t* content_size);
+int arx_lz4_decompress_streams(const void* compressed, const ArxLz4Stream* streams, const ArxLz4Block* blocks,
+                               int64_t num_streams, void* out, uint32_t* status, void* stream);
+
 /* Definition levels of a flat optional column (bit width 1; LevelDecoder, cpp/src/parquet/column_reader.cc:95-190) ->
  * validity bits WITHOUT a host walk: `bytes` (device) holds the pages' level blocks where the chunk read put them,
  * pages[i] (device) = {where block i starts, its length, the page's value count, the page's first row}; one wave

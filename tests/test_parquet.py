@@ -149,6 +149,101 @@ def test_snappy_page_decoder_kernel_gpu(gpu_ctx, lds):
     _with_snappy_form(gpu_ctx, lds, lambda: check_snappy_kernel(gpu_ctx, np.random.default_rng(4), scale=20))
 
 
+LZ4_BLOCK = np.dtype([("src_offset", "<u8"), ("src_size", "<u4"), ("stored", "<u4")])
+LZ4_STREAM = np.dtype([("first_block", "<u8"), ("num_blocks", "<u4"), ("reserved", "<u4"), ("dst_offset", "<u8"), ("dst_size", "<u8")])
+
+
+def lz4_scan_frames(lib, frames):
+    """arx_lz4_frame_scan over several frames laid back to back: (concatenated bytes, blocks table, per-frame (first, n))."""
+    import ctypes as C
+
+    from arrow_amd import _lib
+
+    blocks, spans, base = [], [], 0
+    for f in frames:
+        nb = C.c_int64(0)
+        _lib.check(lib.arx_lz4_frame_scan(f, len(f), base, None, 0, C.byref(nb), None))
+        tab = np.zeros(max(nb.value, 1), LZ4_BLOCK)
+        _lib.check(lib.arx_lz4_frame_scan(f, len(f), base, tab.ctypes.data, nb.value, C.byref(nb), None))
+        spans.append((len(blocks), nb.value))
+        blocks.extend(tab[: nb.value].tolist())
+        base += len(f)
+    return b"".join(frames), np.array(blocks, LZ4_BLOCK) if blocks else np.zeros(1, LZ4_BLOCK), spans
+
+
+def check_lz4_kernel(amd, rng, scale=1):
+    """arx_lz4_frame_scan + arx_lz4_decompress_streams vs the reference codec (pyarrow's Lz4FrameCodec = the bundled lz4):
+    frames written by the reference compressor — empty, tiny, incompressible (stored blocks), periodic with every
+    period, long runs, buffers of several linked 64 KB blocks whose matches reach into the previous block — one stream
+    per frame; corrupt input (a block cut short, a match offset before the start of the output, a wrong announced
+    length) -> per-stream status."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    codec = pa.Codec("lz4")
+
+    def run(raws, frames=None, sizes=None):
+        frames = frames or [codec.compress(r).to_pybytes() for r in raws]
+        sizes = sizes or [len(r) for r in raws]
+        data, blocks, spans = lz4_scan_frames(lib, frames)
+        streams = np.zeros(len(frames), LZ4_STREAM)
+        do = 0
+        for i, ((first, nb), n) in enumerate(zip(spans, sizes)):
+            streams[i] = (first, nb, 0, do, n)
+            do += n
+        src = to_device(np.frombuffer(data + b"\0" * 8, dtype=np.uint8), dev)
+        out = torch.zeros(max(do, 1) + 64, dtype=torch.uint8, device=dev)
+        st = torch.full((len(frames),), 77, dtype=torch.int32, device=dev)
+        d_streams, d_blocks = to_device(streams.view(np.uint8), dev), to_device(blocks.view(np.uint8), dev)
+        _lib.check(lib.arx_lz4_decompress_streams(src.data_ptr(), d_streams.data_ptr(), d_blocks.data_ptr(), len(frames),
+                                                  out.data_ptr(), st.data_ptr(), current_stream(dev)))
+        o = out.cpu().numpy()
+        return o[:do].tobytes(), st.cpu().numpy().tolist(), o[do:].tolist(), spans
+
+    period = bytes(rng.integers(0, 256, 50_000, dtype=np.uint8))
+    raws = [b"", b"a", b"ab" * 7, bytes(rng.integers(0, 256, 1000 * scale, dtype=np.uint8)), b"abcd" * 5000 * scale,
+            bytes(rng.integers(0, 4, 70_000 * scale, dtype=np.uint8)), np.arange(30_000 * scale, dtype=np.int64).tobytes(),
+            b"x" * 300_000 * scale, period * 5, np.cumsum(rng.integers(-3, 4, 40_000 * scale)).tobytes(),
+            bytes(rng.integers(0, 256, 200_000, dtype=np.uint8))]
+    raws += [bytes(rng.integers(0, 256, p_, dtype=np.uint8)) * (3000 // p_ + 2) for p_ in (1, 2, 3, 5, 7, 13, 63, 64, 65, 200)]
+    got, st, tail, spans = run(raws)
+    assert st == [0] * len(raws), st
+    assert got == b"".join(raws) and not any(tail)
+    assert max(n for _, n in spans) > 3          # several linked blocks in one frame
+    # corrupt streams
+    good = codec.compress(b"hello world, " * 200).to_pybytes()
+    _, blocks, _ = lz4_scan_frames(lib, [good])
+    cut = bytearray(good)
+    cut_frame = bytes(cut[: int(blocks[0]["src_offset"]) + int(blocks[0]["src_size"]) // 2])      # (scan must reject it)
+    import ctypes as C
+    nb = C.c_int64(0)
+    assert lib.arx_lz4_frame_scan(cut_frame, len(cut_frame), 0, None, 0, C.byref(nb), None) != 0
+    assert lib.arx_lz4_frame_scan(b"\x00\x01\x02\x03\x04\x05\x06\x07", 8, 0, None, 0, C.byref(nb), None) != 0
+    hdr = good[:7]
+
+    def frame(block_bytes):
+        return hdr + len(block_bytes).to_bytes(4, "little") + block_bytes + (0).to_bytes(4, "little")
+
+    bad_offset = frame(bytes([0x10, 0x41, 0x05, 0x00]))               # 1 literal, then a match 5 bytes back
+    bad_literal = frame(bytes([0xF0, 0x10]) + b"abc")                 # 31 literals announced, 3 there
+    wrong_len = codec.compress(b"abcdef").to_pybytes()                # produces 6 bytes, the caller expects 7
+    _, st, _, _ = run([b"\0" * 5, b"\0" * 40, b"\0" * 7], [bad_offset, bad_literal, wrong_len], [5, 40, 7])
+    assert st == [3, 2, 1], st
+
+
+@pytest.mark.emu
+def test_lz4_stream_decoder_kernel(emu_ctx):
+    check_lz4_kernel(emu_ctx, np.random.default_rng(7))
+
+
+@pytest.mark.gpu
+def test_lz4_stream_decoder_kernel_gpu(gpu_ctx):
+    check_lz4_kernel(gpu_ctx, np.random.default_rng(8), scale=20)
+
+
 LEVEL_PAGE = np.dtype([("byte_start", "<u8"), ("nbytes", "<u4"), ("num_values", "<u4"), ("row_start", "<u8")])
 
 
@@ -554,13 +649,17 @@ def test_rle_run_walk_and_decode_vs_numpy_restatement():
 def _check_ipc(amd, tmp_path, n):
     rng = np.random.default_rng(3)
     t = _table(rng, n, 0.1)
-    for compression in (None, "lz4"):
+    for compression in (None, "lz4", "zstd"):
         path = os.path.join(str(tmp_path), f"t_{compression}.arrow")
         opts = pa.ipc.IpcWriteOptions(compression=compression)
         with pa.ipc.new_file(path, t.schema, options=opts) as w:
             for b in t.to_batches(max_chunksize=n // 3 + 1):
                 w.write_batch(b)
-        got = amd.ipc.read_table(path)
+        stats = {}
+        got = amd.ipc.read_table(path, stats=stats, device_decompress=True)
+        # LZ4_FRAME bodies: every buffer decompressed on the device (arx_lz4_decompress_streams); ZSTD and plain
+        # bodies through the reference's reader
+        assert stats["device_lz4_batches"] == (3 if compression == "lz4" else 0), (compression, stats)
         ref = pa.ipc.open_file(pa.memory_map(path, "r"))
         assert set(got) == set(t.schema.names)
         for name, chunks in got.items():
