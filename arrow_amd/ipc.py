@@ -119,8 +119,8 @@ def _plan_batch_lz4(lib, schema, info, body, columns, body_base, dst_base, strea
                 ulen = length - 8
                 raw_copies.append((dst, body_base + off + 8, ulen))
             else:
-                if ulen < 0:
-                    raise _lib.ArrowInvalid("IPC: negative uncompressed buffer length")
+                if ulen < 0 or ulen > 255 * length + (1 << 16):   # (LZ4 cannot expand more than 255 : 1)
+                    raise _lib.ArrowInvalid("IPC: implausible uncompressed buffer length")
                 frame = body_np[off + 8: off + length]
                 nblk = C.c_int64(0)
                 _lib.check(lib.arx_lz4_frame_scan(frame.ctypes.data, len(frame), body_base + off + 8, None, 0, C.byref(nblk), None))
@@ -251,7 +251,10 @@ def read_table(source, columns=None, device=None, device_decompress="auto", stat
     parsed, buf = _messages(source) if device_decompress else (None, None)
     if parsed is not None and parsed[0] is not None:
         schema, msgs = parsed
-        infos = [parse_record_batch_message(m.metadata.to_pybytes()) for m in msgs]
+        try:
+            infos = [parse_record_batch_message(m.metadata.to_pybytes()) for m in msgs]
+        except (struct.error, IndexError):      # metadata this parser cannot follow: the reference's reader decides
+            infos = []
         if infos and all(i is not None and i["codec"] == _CODEC_LZ4_FRAME for i in infos):
             names = schema.names if columns is None else list(columns)
             decoded = _decode_file_lz4(schema, msgs, infos, None if columns is None else set(columns), device,

@@ -675,6 +675,49 @@ def _check_ipc(amd, tmp_path, n):
     assert pa.chunked_array([a.to_pyarrow() for a in got["i64_few"]]).equals(t.column("i64_few"))
 
 
+def _check_ipc_corrupt_lz4_body(amd, tmp_path):
+    """A garbled LZ4 block inside an IPC body is reported (per-stream status -> OSError, the class pyarrow raises for
+    'LZ4 decompress failed'), an implausible uncompressed length is refused before anything is allocated."""
+    import struct
+
+    from arrow_amd import ipc as I
+
+    t = pa.table({"a": pa.array(np.arange(20_000, dtype=np.int64) // 7)})
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_file(sink, t.schema, options=pa.ipc.IpcWriteOptions(compression="lz4")) as w:
+        w.write_table(t)
+    raw = bytearray(sink.getvalue().to_pybytes())
+    msgs = [m for m in pa.ipc.MessageReader.open_stream(pa.BufferReader(bytes(raw[8:]))) if m.type == "record batch"]
+    info = I.parse_record_batch_message(msgs[0].metadata.to_pybytes())
+    assert info["codec"] == 0 and info["length"] == 20_000 and info["nodes"] == [(20_000, 0)]
+    body = msgs[0].body.to_pybytes()
+    at = raw.find(body[:64])
+    off, length = info["buffers"][1]
+    bad = bytearray(raw)
+    for k in range(at + off + 8 + 11 + 6, at + off + 8 + 11 + 40):      # inside the first block's sequences
+        bad[k] ^= 0xFF
+    try:
+        got = amd.ipc.read_table(pa.BufferReader(bytes(bad)), device_decompress=True)
+        # (LZ4 has no checksum here: garbage may decode to other bytes of the right length — then they differ)
+        assert not got["a"][0].to_pyarrow().equals(t.column("a").chunk(0))
+    except (OSError, amd._lib.ArrowInvalid):
+        pass
+    huge = bytearray(raw)
+    huge[at + off: at + off + 8] = struct.pack("<q", 1 << 50)
+    with pytest.raises(amd._lib.ArrowInvalid):
+        amd.ipc.read_table(pa.BufferReader(bytes(huge)), device_decompress=True)
+
+
+@pytest.mark.emu
+def test_ipc_corrupt_lz4_body(emu_ctx, tmp_path):
+    _check_ipc_corrupt_lz4_body(emu_ctx, tmp_path)
+
+
+@pytest.mark.gpu
+def test_ipc_corrupt_lz4_body_gpu(gpu_ctx, tmp_path):
+    _check_ipc_corrupt_lz4_body(gpu_ctx, tmp_path)
+
+
 @pytest.mark.emu
 def test_ipc_file_and_stream_to_device(emu_ctx, tmp_path):
     """IPC bodies are Arrow layout already: columns land on the device buffer by buffer and come back equal
