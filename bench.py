@@ -738,6 +738,59 @@ def callfunction_leg(args, values, validity, mask, device):
         acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"]))])
     timeit(f"acero table_source -> aggregate_rocm (hash_sum, {m} device rows, {args.groups} keys)",
            lambda: plan.to_table(use_threads=False), reps=3)
+    del dt, plan
+    # the same operator over columns WITH nulls: 32K-row batches are staged many at a time, their validity by
+    # arx_bitmap_copy_segments (before: every batch with nulls consumed on its own)
+    try:
+        m2 = min(m, 1 << 26)
+        rng = np.random.default_rng(11)
+        vn = pa.array(v.to_numpy()[:m2], mask=rng.random(m2) < 0.1)
+        dtn = pa.table({"k": to_device(k.slice(0, m2)), "v": to_device(vn)})
+        plan_n = acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(dtn)),
+            acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"]))])
+        timeit(f"acero table_source -> aggregate_rocm (hash_sum, {m2} device rows, 10 % null values)",
+               lambda: plan_n.to_table(use_threads=False), reps=3)
+        del dtn, plan_n, vn
+    except Exception as e:
+        res["aggregate_rocm with nulls"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    del k, v
+    # Parquet -> HBM through the plugin's column-chunk reader (f4): one Snappy file, three int64 columns (dictionary +
+    # nulls, full-range PLAIN, compressible PLAIN), against pyarrow's reader on all threads (host result)
+    try:
+        import tempfile
+
+        import pyarrow.parquet as pq
+
+        pn = 8_000_000
+        rng = np.random.default_rng(12)
+        pt = pa.table({"k": pa.array(rng.integers(0, 5000, pn), mask=rng.random(pn) < 0.1),
+                       "v": pa.array(rng.integers(-2**62, 2**62, pn)),
+                       "w": pa.array(np.cumsum(rng.integers(-3, 4, pn)))})
+        pt = pt.cast(pa.schema([pa.field("k", pa.int64()), pa.field("v", pa.int64()), pa.field("w", pa.int64(), nullable=False)]))
+        ppath = os.path.join(tempfile.mkdtemp(), "bench.parquet")
+        pq.write_table(pt, ppath, row_group_size=pn, compression="snappy", use_dictionary=["k"], data_page_version="2.0")
+        lib.arrow_amd_parquet_read_column.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+
+        def read_columns():
+            cols = []
+            for j in range(3):
+                c_dev, c_schema = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72)
+                rc = lib.arrow_amd_parquet_read_column(ppath.encode(), 0, j, ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+                assert rc == 0, lib.arrow_amd_plugin_last_error()
+                cols.append(pa.Array._import_from_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema)))
+            return cols
+
+        name = f"parquet -> HBM, arrow_amd_parquet_read_column, 3 x {pn} int64 rows, Snappy, {os.path.getsize(ppath) >> 20} MB file"
+        timeit(name, read_columns, reps=5)
+        t0 = time.perf_counter()
+        pq.read_table(ppath, use_threads=True)
+        t1 = time.perf_counter()
+        pq.read_table(ppath, use_threads=True)
+        res[name]["pyarrow_read_table_all_threads_ms"] = round(min(t1 - t0, time.perf_counter() - t1) * 1e3, 3)
+        os.remove(ppath)
+    except Exception as e:
+        res["parquet -> HBM"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return res
 
 
