@@ -54,6 +54,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -184,6 +186,110 @@ int arrow_amd_parquet_read_column(const char* path, int row_group, int column, s
   };
   const Status st = run();
   if (!st.ok()) {
+    t_error = st.ToString();
+    return -1;
+  }
+  return 0;
+}
+// Several column chunks of one row group at once.  A column chunk is decoded by one host thread and (for its Snappy
+// pages) one wave per page — with ~1000 pages that is one wave per SIMD and nothing to hide its latency behind — so
+// the chunks of a row group are given to a small pool of worker threads that live as long as the library: every
+// worker keeps its own stream, device scratch and page-locked / host buffers from call to call (what makes a chunk
+// cheap), and their kernels and copies overlap on the device.  Results in column order; the first error
+// wins.  arrow_amd_parquet_read_column stays the one-chunk form.
+namespace {
+class ChunkWorkers {
+ public:
+  static ChunkWorkers& Get() {
+#ifdef ARX_EMULATED_HIP_RUNTIME   // (tests/emu: the emulator runs one kernel at a time)
+    static ChunkWorkers* pool = new ChunkWorkers(1);
+#else
+    static ChunkWorkers* pool = new ChunkWorkers(4);   // (never destroyed: worker threads must not outlive their statics)
+#endif
+    return *pool;
+  }
+  // runs fn(i) for i in [0, n) on the workers; returns when all are done
+  void Run(int n, const std::function<void(int)>& fn) {
+    std::unique_lock<std::mutex> lock(mu_);
+    idle_.wait(lock, [&] { return !busy_; });          // one Run at a time
+    busy_ = true;
+    fn_ = &fn;
+    next_ = 0;
+    count_ = n;
+    left_ = n;
+    work_.notify_all();
+    done_.wait(lock, [&] { return left_ == 0; });
+    fn_ = nullptr;
+    busy_ = false;
+    idle_.notify_one();
+  }
+
+ private:
+  explicit ChunkWorkers(int k) {
+    for (int i = 0; i < k; ++i) std::thread([this] { Loop(); }).detach();
+  }
+  void Loop() {
+    std::unique_lock<std::mutex> lock(mu_);
+    for (;;) {
+      work_.wait(lock, [&] { return fn_ != nullptr && next_ < count_; });
+      const int i = next_++;
+      const std::function<void(int)>* fn = fn_;
+      lock.unlock();
+      (*fn)(i);
+      lock.lock();
+      if (--left_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable work_, done_, idle_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int next_ = 0, count_ = 0, left_ = 0;
+  bool busy_ = false;
+};
+}  // namespace
+
+int arrow_amd_parquet_read_columns(const char* path, int row_group, const int* columns, int num_columns,
+                                   struct ArrowDeviceArray* outs, struct ArrowSchema* out_schemas) {
+  if (path == nullptr || columns == nullptr || num_columns < 0 || (num_columns > 0 && (outs == nullptr || out_schemas == nullptr))) {
+    t_error = "arrow_amd_parquet_read_columns: NULL argument";
+    return -1;
+  }
+  std::vector<arrow::Result<std::shared_ptr<ArrayData>>> results(static_cast<size_t>(num_columns),
+                                                                  arrow::Result<std::shared_ptr<ArrayData>>(Status::UnknownError("not run")));
+  const std::string file(path);
+  int device = 0;
+  (void)hipGetDevice(&device);   // the workers decode on the caller's device
+  ChunkWorkers::Get().Run(num_columns, [&](int i) {
+    (void)hipSetDevice(device);
+    try {
+      results[i] = ParquetChunkToDevice(file, row_group, columns[i]);
+    } catch (const parquet::ParquetException& e) {
+      results[i] = Status::IOError("Parquet: ", e.what());
+    } catch (const std::exception& e) {
+      results[i] = Status::UnknownError(e.what());
+    }
+  });
+  for (int i = 0; i < num_columns; ++i) {
+    if (!results[i].ok()) {
+      t_error = results[i].status().ToString();
+      return -1;
+    }
+  }
+  int exported = 0;
+  Status st;
+  for (; exported < num_columns && st.ok(); ++exported) {
+    const std::shared_ptr<ArrayData>& data = *results[exported];
+    st = arrow::ExportType(*data->type, &out_schemas[exported]);
+    if (st.ok()) {
+      st = arrow::ExportDeviceArray(*arrow::MakeArray(data), nullptr, &outs[exported]);
+      if (!st.ok() && out_schemas[exported].release != nullptr) out_schemas[exported].release(&out_schemas[exported]);
+    }
+  }
+  if (!st.ok()) {   // give back what was already exported
+    for (int i = 0; i + 1 < exported; ++i) {
+      if (outs[i].array.release != nullptr) outs[i].array.release(&outs[i].array);
+      if (out_schemas[i].release != nullptr) out_schemas[i].release(&out_schemas[i]);
+    }
     t_error = st.ToString();
     return -1;
   }

@@ -783,6 +783,20 @@ def callfunction_leg(args, values, validity, mask, device):
 
         name = f"parquet -> HBM, arrow_amd_parquet_read_column, 3 x {pn} int64 rows, Snappy, {os.path.getsize(ppath) >> 20} MB file"
         timeit(name, read_columns, reps=5)
+        lib.arrow_amd_parquet_read_columns.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                       ctypes.c_void_p]
+
+        def read_columns_at_once():      # the three chunks on the plugin's worker threads, kernels and copies overlapping
+            c_devs, c_schemas = ctypes.create_string_buffer(128 * 3), ctypes.create_string_buffer(72 * 3)
+            rc = lib.arrow_amd_parquet_read_columns(ppath.encode(), 0, (ctypes.c_int * 3)(0, 1, 2), 3, ctypes.addressof(c_devs),
+                                                    ctypes.addressof(c_schemas))
+            assert rc == 0, lib.arrow_amd_plugin_last_error()
+            return [pa.Array._import_from_c_device(ctypes.addressof(c_devs) + 128 * i, ctypes.addressof(c_schemas) + 72 * i)
+                    for i in range(3)]
+
+        read_columns_at_once()
+        timeit(name.replace("arrow_amd_parquet_read_column,", "arrow_amd_parquet_read_columns (3 chunks at once),"),
+               read_columns_at_once, reps=5)
         t0 = time.perf_counter()
         pq.read_table(ppath, use_threads=True)
         t1 = time.perf_counter()

@@ -5,6 +5,7 @@
 // that Arrow nevertheless sees as non-CPU (the shim's RocmBuffer reports kROCM), streams are
 // synchronous.  Never shipped, never used by the product build.
 #pragma once
+#define ARX_EMULATED_HIP_RUNTIME 1   // the SIMT emulator behind it runs one kernel at a time
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -35,3 +36,4 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 enum { hipErrorNotReady = 600 };
 static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }   // synchronous streams are always idle
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }

@@ -1403,6 +1403,30 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
         assert rc != 0 and b"Corrupt snappy compressed data" in lib.arrow_amd_plugin_last_error(), lib.arrow_amd_plugin_last_error()
     else:
         assert rc == 0 and to_host(pa.Array._import_from_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))).equals(want)
+    # several chunks of a row group at once (a pool of worker threads, each with its own stream and buffers): the same
+    # arrays as one call per column, twice (the second call finds the workers' buffers warm); an error in one column
+    # fails the call
+    path = os.path.join(tempfile.mkdtemp(), "m.parquet")
+    pq.write_table(req, path, row_group_size=n // 2 + 11, compression="snappy", data_page_version="2.0", use_dictionary=["b", "d"])
+    pf = pq.ParquetFile(path)
+    ncol = len(req.schema.names)
+    IntArr = ctypes.c_int * (2 * ncol)
+    order = list(range(ncol)) + list(reversed(range(ncol)))          # (every column twice: more tasks than workers)
+    lib.arrow_amd_parquet_read_columns.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    for _ in range(2):
+        for rg in range(pf.metadata.num_row_groups):
+            ref = pf.read_row_group(rg)
+            c_devs, c_schemas = ctypes.create_string_buffer(128 * len(order)), ctypes.create_string_buffer(72 * len(order))
+            rc = lib.arrow_amd_parquet_read_columns(path.encode(), rg, IntArr(*order), len(order), ctypes.addressof(c_devs), ctypes.addressof(c_schemas))
+            assert rc == 0, lib.arrow_amd_plugin_last_error()
+            for i, ci in enumerate(order):
+                d = pa.Array._import_from_c_device(ctypes.addressof(c_devs) + 128 * i, ctypes.addressof(c_schemas) + 72 * i)
+                w = ref.column(req.schema.names[ci]).combine_chunks()
+                h = to_host(d)
+                assert h.equals(w) and h.null_count == w.null_count, (rg, ci)
+    c_devs, c_schemas = ctypes.create_string_buffer(128 * 3), ctypes.create_string_buffer(72 * 3)
+    assert lib.arrow_amd_parquet_read_columns(path.encode(), 0, (ctypes.c_int * 3)(0, 99, 1), 3, ctypes.addressof(c_devs), ctypes.addressof(c_schemas)) != 0
+    assert b"no row group" in lib.arrow_amd_plugin_last_error() or b"column" in lib.arrow_amd_plugin_last_error()
     # a nested column is refused, not mis-decoded
     path = os.path.join(tempfile.mkdtemp(), "l.parquet")
     pq.write_table(pa.table({"l": pa.array([[1, 2], [3]])}), path)
