@@ -437,10 +437,10 @@ def test_sort_wide_sampled_level1(emu_ctx, shift, gap2, b2max):
 
 @pytest.mark.parametrize("bits,b2max", [(13, 12)])
 def test_sort_wide_many_level2_bins(emu_ctx, bits, b2max):
-    # (each forced partition is a workgroup of fibers here: one shape, two of the three size modes; the GPU tier runs
-    #  the rest)
-    P.check_sort_wide_many_bins(emu_ctx, emu_ctx._lib.get_lib(), rng_for("wide-bins", bits, b2max), 40_000, bits,
-                                b2max, combos=((2, 1), (0, 0)))
+    # (each forced partition is a workgroup of fibers here: one shape, the default size mode — sampled level 1, fixed
+    #  level-2 rooms; the GPU tier runs the rest)
+    P.check_sort_wide_many_bins(emu_ctx, emu_ctx._lib.get_lib(), rng_for("wide-bins", bits, b2max), 30_000, bits,
+                                b2max, combos=((2, 1),))
 
 
 def test_null_count_bookkeeping(emu_ctx):
@@ -918,7 +918,7 @@ def test_compare_and_arithmetic_on_every_numeric_type(emu_ctx, dtype):
 @pytest.mark.parametrize("wide", [0, 1])
 def test_sort_keys_with_a_shared_prefix(emu_ctx, wide):
     lib = emu_ctx._lib.get_lib()
-    P.check_sort_limited_range(emu_ctx, lib, rng_for("sort-prefix", wide), 9000, wide)
+    P.check_sort_limited_range(emu_ctx, lib, rng_for("sort-prefix", wide), 9000 if wide else 5000, wide, light=not wide)
 
 
 def test_compare_on_temporal_columns(emu_ctx):
