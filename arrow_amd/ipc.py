@@ -36,6 +36,8 @@ class _Table:
     def __init__(self, buf: bytes, pos: int):
         self.buf, self.pos = buf, pos
         self.vt = pos - struct.unpack_from("<i", buf, pos)[0]
+        if self.vt < 0:
+            raise IndexError("flatbuffer vtable before the metadata")
         self.vt_size = struct.unpack_from("<H", buf, self.vt)[0]
 
     def _off(self, i: int) -> int:
@@ -60,6 +62,8 @@ class _Table:
         p = self.pos + o
         v = p + struct.unpack_from("<I", self.buf, p)[0]
         n = struct.unpack_from("<I", self.buf, v)[0]
+        if v + 4 + n * width > len(self.buf):
+            raise IndexError("flatbuffer vector runs past the metadata")
         return [struct.unpack_from(fmt, self.buf, v + 4 + k * width) for k in range(n)]
 
 
@@ -70,6 +74,8 @@ def parse_record_batch_message(metadata: bytes):
     if msg.scalar(1, "<B") != _MESSAGE_RECORD_BATCH:
         return None
     rb = msg.table(2)
+    if rb is None:
+        raise IndexError("record batch message without a header")
     comp = rb.table(3)
     return {"length": rb.scalar(0, "<q"), "nodes": rb.struct_vector(1, "<qq", 16), "buffers": rb.struct_vector(2, "<qq", 16),
             "codec": None if comp is None else comp.scalar(0, "<b"), "variadic": bool(rb._off(4))}

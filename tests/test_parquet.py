@@ -708,6 +708,46 @@ def _check_ipc_corrupt_lz4_body(amd, tmp_path):
         amd.ipc.read_table(pa.BufferReader(bytes(huge)), device_decompress=True)
 
 
+def test_ipc_record_batch_metadata_parser_against_pyarrow_and_garbage():
+    """The RecordBatch flatbuffer parser of arrow_amd/ipc.py: nodes / buffer table / codec equal what pyarrow's reader
+    reports for the same message; truncated or garbled metadata raises (struct.error / IndexError — the reader then
+    falls back to pyarrow), never returns half a table."""
+    import struct
+
+    from arrow_amd import ipc as I
+
+    rng = np.random.default_rng(9)
+    t = _table(rng, 3000, 0.1)
+    for compression in (None, "lz4", "zstd"):
+        sink = pa.BufferOutputStream()
+        with pa.ipc.new_stream(sink, t.schema, options=pa.ipc.IpcWriteOptions(compression=compression)) as w:
+            w.write_table(t, max_chunksize=1000)
+        msgs = [m for m in pa.ipc.MessageReader.open_stream(pa.BufferReader(sink.getvalue())) if m.type == "record batch"]
+        assert len(msgs) == 3
+        batches = list(pa.ipc.open_stream(pa.BufferReader(sink.getvalue())))
+        for m, b in zip(msgs, batches):
+            info = I.parse_record_batch_message(m.metadata.to_pybytes())
+            assert info["length"] == b.num_rows
+            assert info["codec"] == {None: None, "lz4": 0, "zstd": 1}[compression]
+            assert [n for n, _ in info["nodes"]] == [b.num_rows] * b.num_columns
+            assert [nc for _, nc in info["nodes"]] == [c.null_count for c in b.columns]
+            assert len(info["buffers"]) == sum(3 if pa.types.is_string(f.type) else 2 for f in b.schema)
+            assert all(off >= 0 and off + ln <= m.body.size for off, ln in info["buffers"])
+        meta = msgs[0].metadata.to_pybytes()
+        assert I.parse_record_batch_message(pa.ipc.MessageReader.open_stream(pa.BufferReader(sink.getvalue())).read_next_message()
+                                            .metadata.to_pybytes()) is None      # the schema message is not a record batch
+        for cut in (0, 3, 7, len(meta) // 2):
+            with pytest.raises((struct.error, IndexError)):
+                I.parse_record_batch_message(meta[:cut])
+        for _ in range(300):                      # random single-byte damage: an exception or a table, never a hang / crash
+            bad = bytearray(meta)
+            bad[int(rng.integers(0, len(bad)))] = int(rng.integers(0, 256))
+            try:
+                I.parse_record_batch_message(bytes(bad))
+            except (struct.error, IndexError, MemoryError, OverflowError):
+                pass
+
+
 @pytest.mark.emu
 def test_ipc_corrupt_lz4_body(emu_ctx, tmp_path):
     _check_ipc_corrupt_lz4_body(emu_ctx, tmp_path)
