@@ -708,6 +708,38 @@ def _check_ipc_corrupt_lz4_body(amd, tmp_path):
         amd.ipc.read_table(pa.BufferReader(bytes(huge)), device_decompress=True)
 
 
+def test_lz4_frame_scanner_on_damaged_frames():
+    """arx_lz4_frame_scan (a HOST function of the library) under random byte damage and truncation: it returns a status,
+    its blocks never reach outside the frame it was given."""
+    import ctypes as C
+
+    from arrow_amd import _lib
+
+    lib = _lib.get_lib()
+    rng = np.random.default_rng(21)
+    codec = pa.Codec("lz4")
+    frames = [codec.compress(bytes(rng.integers(0, 7, 200_000, dtype=np.uint8))).to_pybytes(),
+              codec.compress(bytes(rng.integers(0, 256, 150_000, dtype=np.uint8))).to_pybytes(), codec.compress(b"").to_pybytes()]
+    for f in frames:
+        nb = C.c_int64(0)
+        assert lib.arx_lz4_frame_scan(f, len(f), 0, None, 0, C.byref(nb), None) == 0
+        for trial in range(400):
+            bad = bytearray(f)
+            if trial % 3 == 0:
+                bad = bad[: int(rng.integers(0, len(bad)))]
+            else:
+                for _ in range(int(rng.integers(1, 4))):
+                    bad[int(rng.integers(0, min(len(bad), 64 if trial % 2 else len(bad))))] = int(rng.integers(0, 256))
+            bad = bytes(bad)
+            tab = np.zeros(64, LZ4_BLOCK)
+            nb = C.c_int64(0)
+            rc = lib.arx_lz4_frame_scan(bad, len(bad), 0, tab.ctypes.data, 64, C.byref(nb), None)
+            if rc == 0:
+                assert 0 <= nb.value <= 64
+                for b in tab[: nb.value]:
+                    assert int(b["src_offset"]) + int(b["src_size"]) <= len(bad)
+
+
 def test_ipc_record_batch_metadata_parser_against_pyarrow_and_garbage():
     """The RecordBatch flatbuffer parser of arrow_amd/ipc.py: nodes / buffer table / codec equal what pyarrow's reader
     reports for the same message; truncated or garbled metadata raises (struct.error / IndexError — the reader then
