@@ -708,6 +708,105 @@ def _check_ipc_corrupt_lz4_body(amd, tmp_path):
         amd.ipc.read_table(pa.BufferReader(bytes(huge)), device_decompress=True)
 
 
+@pytest.mark.emu
+@pytest.mark.parametrize("lds", [1, 0])
+def test_snappy_decoder_under_random_damage(emu_ctx, lds):
+    """Both decoder forms on blocks with random byte damage: every page ends with a status, a damaged page never
+    writes outside its own destination range (the bytes between and behind the ranges stay zero), undamaged pages of
+    the same launch still decode."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    def body():
+        lib, dev = _lib.get_lib(), default_device()
+        rng = np.random.default_rng(31 + lds)
+        codec = pa.Codec("snappy")
+        raws = [bytes(rng.integers(0, 5, 3000, dtype=np.uint8)), b"abcdefgh" * 500, np.arange(700, dtype=np.int64).tobytes(),
+                bytes(rng.integers(0, 256, 2500, dtype=np.uint8))]
+        good = [codec.compress(r).to_pybytes() for r in raws]
+        for trial in range(60):
+            blocks = []
+            for b in good:
+                b = bytearray(b)
+                if rng.random() < 0.7:
+                    for _ in range(int(rng.integers(1, 5))):
+                        b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+                blocks.append(bytes(b))
+            gap = 96
+            pages = np.zeros(len(blocks), SNAPPY_PAGE)
+            so = do = 0
+            for i, (r, b) in enumerate(zip(raws, blocks)):
+                pages[i] = (so, len(b), len(r), do)
+                so += len(b)
+                do += len(r) + gap
+            src = to_device(np.frombuffer(b"".join(blocks) + b"\0" * 8, dtype=np.uint8), dev)
+            out = torch.zeros(do + 64, dtype=torch.uint8, device=dev)
+            st = torch.full((len(blocks),), 77, dtype=torch.int32, device=dev)
+            table = to_device(pages.view(np.uint8), dev)
+            _lib.check(lib.arx_snappy_decompress_pages(src.data_ptr(), table.data_ptr(), len(blocks), out.data_ptr(),
+                                                       st.data_ptr(), current_stream(dev)))
+            o, status = out.cpu().numpy(), st.cpu().numpy().tolist()
+            at = 0
+            for i, r in enumerate(raws):
+                assert status[i] in (0, 1, 2, 3), status
+                if blocks[i] == good[i]:
+                    assert status[i] == 0 and o[at: at + len(r)].tobytes() == r
+                assert not o[at + len(r): at + len(r) + gap].any(), (trial, i, "wrote behind its range")
+                at += len(r) + gap
+
+    _with_snappy_form(emu_ctx, lds, body)
+
+
+@pytest.mark.emu
+def test_lz4_decoder_under_random_damage(emu_ctx):
+    """The same for the LZ4 stream decoder: damaged block bytes (the frame structure intact) never write outside the
+    stream's destination range."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    rng = np.random.default_rng(41)
+    codec = pa.Codec("lz4")
+    raws = [bytes(rng.integers(0, 5, 3000, dtype=np.uint8)), b"abcdefgh" * 500, np.arange(700, dtype=np.int64).tobytes(),
+            bytes(rng.integers(0, 4, 90_000, dtype=np.uint8))]
+    good = [codec.compress(r).to_pybytes() for r in raws]
+    for trial in range(40):
+        frames = []
+        for f in good:
+            _, blocks, _ = lz4_scan_frames(lib, [f])
+            f = bytearray(f)
+            if rng.random() < 0.7:
+                b = blocks[int(rng.integers(0, len(blocks)))]
+                for _ in range(int(rng.integers(1, 5))):
+                    f[int(b["src_offset"]) + int(rng.integers(0, int(b["src_size"])))] = int(rng.integers(0, 256))
+            frames.append(bytes(f))
+        data, blocks, spans = lz4_scan_frames(lib, frames)
+        gap = 96
+        streams = np.zeros(len(frames), LZ4_STREAM)
+        do = 0
+        for i, ((first, nb), r) in enumerate(zip(spans, raws)):
+            streams[i] = (first, nb, 0, do, len(r))
+            do += len(r) + gap
+        src = to_device(np.frombuffer(data + b"\0" * 8, dtype=np.uint8), dev)
+        out = torch.zeros(do + 64, dtype=torch.uint8, device=dev)
+        st = torch.full((len(frames),), 77, dtype=torch.int32, device=dev)
+        d_streams, d_blocks = to_device(streams.view(np.uint8), dev), to_device(blocks.view(np.uint8), dev)
+        _lib.check(lib.arx_lz4_decompress_streams(src.data_ptr(), d_streams.data_ptr(), d_blocks.data_ptr(), len(frames),
+                                                  out.data_ptr(), st.data_ptr(), current_stream(dev)))
+        o, status = out.cpu().numpy(), st.cpu().numpy().tolist()
+        at = 0
+        for i, r in enumerate(raws):
+            assert status[i] in (0, 1, 2, 3), status
+            if frames[i] == good[i]:
+                assert status[i] == 0 and o[at: at + len(r)].tobytes() == r
+            assert not o[at + len(r): at + len(r) + gap].any(), (trial, i, "wrote behind its range")
+            at += len(r) + gap
+
+
 def test_lz4_frame_scanner_on_damaged_frames():
     """arx_lz4_frame_scan (a HOST function of the library) under random byte damage and truncation: it returns a status,
     its blocks never reach outside the frame it was given."""
