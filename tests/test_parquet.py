@@ -314,6 +314,53 @@ def check_levels_bitmap_kernel(amd, rng, scale=1):
 
 
 @pytest.mark.emu
+def test_levels_bitmap_kernel_under_random_damage(emu_ctx):
+    """Damaged level blocks: a status per page, bits only inside the page's own row range (the neighbours' bits and the
+    rows behind the last page stay as the undamaged blocks set them / zero)."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    rng = np.random.default_rng(51)
+    levels = [(rng.random(k) >= p).astype(np.uint8) for k, p in ((700, 0.1), (513, 0.5), (64, 0.3), (2000, 0.02), (9, 0.5))]
+    good = [O.rle_hybrid_encode(v, 1) for v in levels]
+    for trial in range(60):
+        blocks, damaged = [], []
+        for b in good:
+            b = bytearray(b)
+            hit = rng.random() < 0.6
+            if hit:
+                for _ in range(int(rng.integers(1, 4))):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            blocks.append(bytes(b))
+            damaged.append(hit and bytes(b) != good[len(blocks) - 1])
+        pages = np.zeros(len(blocks), LEVEL_PAGE)
+        buf, row = bytearray(), 0
+        for i, (b, v) in enumerate(zip(blocks, levels)):
+            pages[i] = (len(buf), len(b), len(v), row)
+            buf += b
+            row += len(v)
+        src = to_device(np.frombuffer(bytes(buf) + b"\0" * 8, dtype=np.uint8), dev)
+        bits = torch.zeros((row + 63) // 64 + 4, dtype=torch.int64, device=dev)
+        ones = torch.full((len(blocks),), 77, dtype=torch.int32, device=dev)
+        st = torch.full((len(blocks),), 77, dtype=torch.int32, device=dev)
+        table = to_device(pages.view(np.uint8), dev)
+        _lib.check(lib.arx_rle_levels_to_bitmap(src.data_ptr(), table.data_ptr(), len(blocks), bits.data_ptr(),
+                                                ones.data_ptr(), st.data_ptr(), current_stream(dev)))
+        got = np.unpackbits(bits.cpu().numpy().view(np.uint8), bitorder="little")
+        status = st.cpu().numpy().tolist()
+        at = 0
+        for i, v in enumerate(levels):
+            assert status[i] in (0, 1)
+            if not damaged[i]:
+                assert status[i] == 0 and (got[at: at + len(v)] == v).all(), (trial, i)
+            at += len(v)
+        assert not got[row:].any()
+
+
+@pytest.mark.emu
 def test_levels_bitmap_kernel(emu_ctx):
     check_levels_bitmap_kernel(emu_ctx, np.random.default_rng(5))
 
