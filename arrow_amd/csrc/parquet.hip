@@ -558,7 +558,10 @@ __global__ __launch_bounds__(kBlock) void snappy_decode_lds_kernel(const uint8_t
       if (ip + adv > n_in || len > ulen - op) { err = 2; break; }
       if (off == 0 || off > op) { err = 3; break; }
       ip += adv;
-      if (off <= kSnRing && op - off >= ring_lo) {   // the source is in the ring (len <= 64: one step per lane)
+      // the source is in the ring (len <= 64: one step per lane) — and at least 64 slots away from the slots this element
+      // overwrites (positions op.. map onto op - kSnRing..): on the GPU every lane reads before any lane writes, but a
+      // copy must not depend on that
+      if (off + 64 <= kSnRing && op - off >= ring_lo) {
         const uint32_t j = lane;
         if (j < len) {
           const uint8_t c = ring[(op - off + (off >= len ? j : j % off)) & (kSnRing - 1)];

@@ -111,6 +111,8 @@ def check_snappy_kernel(amd, rng, scale=1):
     far = bytes(rng.integers(0, 256, 40_000, dtype=np.uint8))
     raws += [far * 3, bytes(rng.integers(0, 256, 30_000, dtype=np.uint8)) + bytes(1000) + far[:20_000] + far[:20_000]]
     raws += [bytes(rng.integers(0, 256, k, dtype=np.uint8)) + b"ab" * 40 for k in (1000, 1023, 1024, 1025, 2047, 2048, 2049, 3000)]
+    # copies whose source sits exactly one LDS ring (16 KB) behind, i.e. in the slots the copy itself overwrites
+    raws += [bytes(rng.integers(0, 256, p_, dtype=np.uint8)) * 3 for p_ in (16321, 16352, 16376, 16383, 16384, 16385, 16448)]
     # long literals (incompressible pages): the 16-bytes-per-lane copy with every head / tail length
     raws += [bytes(rng.integers(0, 256, k, dtype=np.uint8)) for k in (511, 512, 513, 527, 4097, 65536 + 3, 70001 * scale)]
     got, st, tail = run(raws)
