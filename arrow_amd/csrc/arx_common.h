@@ -214,6 +214,43 @@ constexpr uint32_t kBufferSkip = 0x80000000u;  // an offset no descriptor of our
 __device__ __forceinline__ uint4 buffer_load_b128(__amdgpu_buffer_rsrc_t r, uint32_t byte_offset) {
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_offset, 0, 0));
 }
+// the same load with the non-temporal policy (aux bit 1 = nt on gfx950)
+__device__ __forceinline__ uint4 buffer_load_b128_nt(__amdgpu_buffer_rsrc_t r, uint32_t byte_offset) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_offset, 0, 2));
+}
+
+// Non-temporal (streaming) loads and stores: `global_load/store ... nt`.  A one-pass stream read or written with the
+// default policy competes for the L2 with itself; with nt a one-shot grid reads at 7.3 TB/s instead of 6.6 and the
+// f64 -> f32 cast moves 6.4 TB/s instead of 5.6-6.1 (scripts/micro/stream_bench.hip, profiles/r03_a_*).  The raw
+// 16- / 8-byte carriers are native vectors (the builtin does not take HIP's struct vector types).
+typedef uint32_t arx_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t arx_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 nt_load16(const void* p) {
+  const arx_u32x4 v = __builtin_nontemporal_load(static_cast<const arx_u32x4*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nt_store16(void* p, uint4 q) {
+  arx_u32x4 v;
+  v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  __builtin_nontemporal_store(v, static_cast<arx_u32x4*>(p));
+}
+__device__ __forceinline__ uint2 nt_load8(const void* p) {
+  const arx_u32x2 v = __builtin_nontemporal_load(static_cast<const arx_u32x2*>(p));
+  return make_uint2(v[0], v[1]);
+}
+__device__ __forceinline__ void nt_store8(void* p, uint2 q) {
+  arx_u32x2 v;
+  v[0] = q.x; v[1] = q.y;
+  __builtin_nontemporal_store(v, static_cast<arx_u32x2*>(p));
+}
+template <typename T>
+__device__ __forceinline__ T nt_load(const T* p) {
+  return __builtin_nontemporal_load(p);
+}
+template <typename T>
+__device__ __forceinline__ void nt_store(T* p, T v) {
+  __builtin_nontemporal_store(v, p);
+}
 
 // 16 bytes from an address of any alignment (one global_load_dwordx4: global memory takes the unaligned address)
 __device__ __forceinline__ uint4 load16_unaligned(const uint8_t* p) {

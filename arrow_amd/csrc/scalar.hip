@@ -22,19 +22,23 @@
 
 namespace arx {
 
-constexpr int kStreamBlocks = 256 * 8;
-
+// One-shot grids: one block-iteration of work per workgroup.  A persistent grid of 256 x 8 workgroups striding over
+// the arrays measured 4.8-5.6 TB/s on the cast / compare shapes, the same kernels launched with one workgroup per
+// block-iteration 5.6-6.5 (blocks are dispatched in order, so the active ones cover a compact moving window of
+// memory instead of 2048 streams a stride apart; scripts/micro/stream_bench.hip, profiles/r03_a_stream_bench.txt).
+// The grid-stride loops stay: they run once, and keep the kernels correct for any grid.
 static inline unsigned stream_grid(int64_t work_items_per_block_iter, int64_t n) {
   const int64_t blocks = ceil_div(n, work_items_per_block_iter);
-  return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(blocks, kStreamBlocks)));
+  return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(blocks, int64_t(1) << 30)));
 }
 
 // ------------------------------------------------------------------ cast f64 -> f32
-// Per wave iteration: 4 x (64 lanes x 2 doubles) = 512 rows.
+// Per workgroup: 2 x (256 lanes x 2 doubles) = 1024 rows; 16-byte non-temporal loads, 8-byte non-temporal stores
+// (4 doubles per lane -> one 16-byte store measured no faster, in either lane arrangement: stream_bench cast4s / cast4x).
 template <bool ALIGNED>
 __global__ __launch_bounds__(kBlock) void cast_f64_f32_kernel(const double* __restrict__ in,
                                                               int64_t n, float* __restrict__ out) {
-  constexpr int U = 4;
+  constexpr int U = 2;
   const int64_t rows_per_block = kBlock * 2 * U;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * rows_per_block;
   for (int64_t base = static_cast<int64_t>(blockIdx.x) * rows_per_block; base < n; base += stride) {
@@ -45,10 +49,11 @@ __global__ __launch_bounds__(kBlock) void cast_f64_f32_kernel(const double* __re
       r[u] = base + (u * kBlock + threadIdx.x) * 2;
       if (r[u] + 1 < n) {
         if constexpr (ALIGNED) {
-          v[u] = *reinterpret_cast<const double2*>(in + r[u]);
+          const uint4 q = nt_load16(in + r[u]);
+          v[u] = __builtin_bit_cast(double2, q);
         } else {
-          v[u].x = in[r[u]];
-          v[u].y = in[r[u] + 1];
+          v[u].x = nt_load(in + r[u]);
+          v[u].y = nt_load(in + r[u] + 1);
         }
       } else if (r[u] < n) {
         v[u].x = in[r[u]];
@@ -62,10 +67,10 @@ __global__ __launch_bounds__(kBlock) void cast_f64_f32_kernel(const double* __re
         o.x = static_cast<float>(v[u].x);  // v_cvt_f32_f64: IEEE round-to-nearest-even
         o.y = static_cast<float>(v[u].y);
         if constexpr (ALIGNED) {
-          *reinterpret_cast<float2*>(out + r[u]) = o;
+          nt_store8(out + r[u], __builtin_bit_cast(uint2, o));
         } else {
-          out[r[u]] = o.x;
-          out[r[u] + 1] = o.y;
+          nt_store(out + r[u], o.x);
+          nt_store(out + r[u] + 1, o.y);
         }
       } else if (r[u] < n) {
         out[r[u]] = static_cast<float>(v[u].x);
@@ -180,7 +185,7 @@ __device__ __forceinline__ Pair<T> load_pair(const T* p, int64_t r, int64_t n) {
   v.y = T(0);
   if (r + 1 < n) {
     if constexpr (ALIGNED) {
-      const uint4 q = *reinterpret_cast<const uint4*>(p + r);
+      const uint4 q = nt_load16(p + r);
       const T* t = reinterpret_cast<const T*>(&q);
       v.x = t[0];
       v.y = t[1];
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void add_kernel(const T* __restrict__ left,
       if (row + 1 < n) {
         if constexpr (ALIGNED) {
           Pair<T> o{sx, sy};
-          *reinterpret_cast<uint4*>(out + row) = *reinterpret_cast<const uint4*>(&o);
+          nt_store16(out + row, *reinterpret_cast<const uint4*>(&o));
         } else {
           out[row] = sx;
           out[row + 1] = sy;
@@ -1050,7 +1055,7 @@ int arx_cast_f64_f32(const double* in, int64_t length, float* out, void* stream)
   hipStream_t st = as_stream(stream);
   const bool aligned =
       (reinterpret_cast<uint64_t>(in) & 15) == 0 && (reinterpret_cast<uint64_t>(out) & 7) == 0;
-  const unsigned grid = stream_grid(kBlock * 2 * 4, length);
+  const unsigned grid = stream_grid(kBlock * 2 * 2, length);
   if (aligned) {
     hipLaunchKernelGGL((cast_f64_f32_kernel<true>), dim3(grid), dim3(kBlock), 0, st, in, length, out);
   } else {

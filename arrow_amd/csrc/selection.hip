@@ -193,6 +193,34 @@ __device__ __forceinline__ typename ElemT<W>::type zero_elem() {
   }
 }
 
+// Cache policy of the selection kernels' one-pass streams (compile-time: the buffer-load policy is an immediate).
+// bit 0: value / index loads non-temporal, bit 1: output stores non-temporal, bit 2: take's gathers non-temporal.
+// A/B per build: scripts/gpu_r03_sel_nt_ab.sh -> profiles/r03_b_selection_nt_ab.txt.
+constexpr int kSelNt = 3;
+
+template <int W>
+__device__ __forceinline__ typename ElemT<W>::type sel_load(const typename ElemT<W>::type* p, bool nt) {
+  using E = typename ElemT<W>::type;
+  if constexpr (W == 32) {
+    return *p;
+  } else if constexpr (W == 16) {
+    return nt ? nt_load16(p) : *p;
+  } else {
+    return nt ? nt_load<E>(p) : *p;
+  }
+}
+template <int W>
+__device__ __forceinline__ void sel_store(typename ElemT<W>::type* p, typename ElemT<W>::type v) {
+  using E = typename ElemT<W>::type;
+  if constexpr (W == 32) {
+    *p = v;
+  } else if constexpr (W == 16) {
+    if constexpr ((kSelNt & 2) != 0) nt_store16(p, v); else *p = v;
+  } else {
+    if constexpr ((kSelNt & 2) != 0) nt_store<E>(p, v); else *p = v;
+  }
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS traffic of one wave is processed in order; this only pins the compiler's ordering.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -217,7 +245,7 @@ __device__ __forceinline__ void flush_region(const uint8_t* ring, uint8_t* gbase
     const uint8_t* src = ring + ring_off + g * 16;
     uint8_t* dst = gbase + gs;
     if (gs >= lo && ge <= hi) {
-      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+      sel_store<16>(reinterpret_cast<uint4*>(dst), *reinterpret_cast<const uint4*>(src));
     } else {
 #pragma unroll
       for (int e = 0; e < R; ++e) {
@@ -312,7 +340,7 @@ __device__ __forceinline__ void issue_batch(const TileCtx& c, int j0, Batch<W, B
         // the hardware returns 0 without a memory access, so 128-byte lines holding no selected
         // row are never fetched from HBM, and there is no branch to wait at.
         const uint32_t voff = b.bits[i] != 0 ? static_cast<uint32_t>(row_in_tile * W) : kBufferSkip;
-        const uint4 q = buffer_load_b128(c.rsrc, voff);
+        const uint4 q = (kSelNt & 1) ? buffer_load_b128_nt(c.rsrc, voff) : buffer_load_b128(c.rsrc, voff);
         if constexpr (W == 16) {
           b.v[i][0] = q;
         } else {
@@ -642,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void compact_sparse_kernel(CompactArgs a) {
         if constexpr (IOTA) {
           if constexpr (W <= 8) v[u] = static_cast<E>(t * kTileRows + r[u]);
         } else {
-          v[u] = values[r[u]];
+          v[u] = sel_load<W>(values + r[u], (kSelNt & 1) != 0);
         }
       }
 #pragma unroll
@@ -652,7 +680,7 @@ __global__ __launch_bounds__(kBlock) void compact_sparse_kernel(CompactArgs a) {
         if constexpr (EMIT) {
           if ((lds.zw[wave][r[u] >> 6] >> (r[u] & 63)) & 1ull) e = zero_elem<W>();
         }
-        if (act[u]) out[off + s[u]] = e;
+        if (act[u]) sel_store<W>(out + off + s[u], e);
         if (want_validity) {
           const bool vbit = act[u] && ((lds.vs[wave][r[u] >> 6] >> (r[u] & 63)) & 1ull);
           const uint64_t bal = __ballot(vbit);
@@ -794,7 +822,7 @@ __global__ __launch_bounds__(kBlock) void take_kernel(TakeArgs a) {
     for (int u = 0; u < U; ++u) {
       const int64_t p = base + u * 64 + lane;
       pos[u] = p <= last ? p : last;  // clamped: always a readable/writable slot
-      idx[u] = static_cast<uint64_t>(indices[pos[u]]);
+      idx[u] = static_cast<uint64_t>((kSelNt & 1) ? nt_load<IdxT>(indices + pos[u]) : indices[pos[u]]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -808,7 +836,7 @@ __global__ __launch_bounds__(kBlock) void take_kernel(TakeArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const E* src = ok[u] ? (values + idx[u]) : (out + pos[u]);
-      val[u] = *src;
+      val[u] = sel_load<W>(src, (kSelNt & 4) != 0);
     }
     if constexpr (HAS_SV) {
       uint8_t vb[U];
@@ -826,7 +854,7 @@ __global__ __launch_bounds__(kBlock) void take_kernel(TakeArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t p = base + u * 64 + lane;
-      if (p <= last) out[p] = ok[u] ? val[u] : zero_elem<W>();
+      if (p <= last) sel_store<W>(out + p, ok[u] ? val[u] : zero_elem<W>());
       const uint64_t vbal = __ballot(ok[u]);
       nvalid += __popcll(vbal);
       if (a.out_validity != nullptr && lane == 0 && (base + u * 64) <= last) {
@@ -1511,6 +1539,9 @@ int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int 
     return ARX_INVALID;
   }
   const int64_t nchunks = ceil_div(indices->length, 512);
+  // a persistent grid: the gathers are latency-bound (index load -> dependent gather), and a one-shot grid — the form
+  // that lifts the streaming kernels of scalar.hip — is 1.7x SLOWER here (2.63 vs 1.58 ms at 1e8 monotonic indices,
+  // 19.4 vs 6.1 ms for the 4-column form; profiles/r03_b_selection_nt_ab.txt)
   const int64_t blocks = std::min<int64_t>(ceil_div(nchunks, kWavesPerBlock), 256 * 32);
   const dim3 grid(static_cast<unsigned>(blocks)), block(kBlock);
   const bool has_iv = a.ivalid.base != nullptr;

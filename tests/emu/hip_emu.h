@@ -41,6 +41,7 @@ struct __attribute__((aligned(16))) longlong2 { long long x, y; };
 struct __attribute__((aligned(8))) float2 { float x, y; };
 struct __attribute__((aligned(8))) uint2 { uint32_t x, y; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 
 // ---------------------------------------------------------------- runtime API stubs
 typedef int hipError_t;
@@ -189,6 +190,11 @@ inline uint4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, uin
   return v;
 }
 // only ever applied to wave-uniform values in the kernels
+// non-temporal accesses are ordinary accesses here; the native-vector carriers of arx_common.h become GCC vectors
+// (4-byte elements only)
+#define ext_vector_type(n) vector_size(4 * (n))
+template <typename T> inline T __builtin_nontemporal_load(const T* p) { return *p; }
+template <typename T> inline void __builtin_nontemporal_store(T v, T* p) { *p = v; }
 template <typename T> inline T __builtin_amdgcn_readfirstlane(T v) { return v; }
 inline uint32_t __builtin_amdgcn_readlane(uint32_t v, int src) { return hipemu::exchange(v, src); }
 inline uint64_t __ballot(bool p) { return hipemu::ballot(p); }
