@@ -102,6 +102,7 @@ SIGNATURES = {
     "arx_abi_version": (_int, []),
     "arx_device_count": (_int, []),
     "arx_set_option": (_int, [C.c_char_p, _i64]),
+    "arx_get_counter": (_i64, [C.c_char_p]),
     "arx_filter_workspace_bytes": (_sz, [_i64]),
     "arx_filter_count": (_int, [_span, _int, _p, _sz, C.POINTER(_i64), _p]),
     "arx_filter_count_async": (_int, [_span, _int, _p, _sz, _p]),
@@ -142,6 +143,7 @@ SIGNATURES = {
     "arx_add_i64": (_int, [_p, _p, _i64, _p, _p]),
     "arx_add_f64": (_int, [_p, _p, _i64, _p, _p]),
     "arx_bitmap_copy": (_int, [_p, _i64, _i64, _p, _p]),
+    "arx_buffer_copy": (_int, [_p, _p, _i64, _p]),
     "arx_delta_scan_miniblocks": (_int, [_p, _sz, _u64, _p, _i64, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
                                          C.POINTER(_i64), C.POINTER(_sz)]),
     "arx_delta_decode_workspace_bytes": (_sz, [_i64]),

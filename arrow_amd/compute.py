@@ -106,6 +106,18 @@ def _lib_and_stream(device: torch.device):
     return _lib.get_lib(), current_stream(device)
 
 
+def copy_buffer(src: torch.Tensor, dst: torch.Tensor | None = None) -> torch.Tensor:
+    """Device-to-device copy of a uint8 buffer with the HIP kernel (arx_buffer_copy) — the kROCM -> kROCM leg of
+    MemoryManager::CopyBufferTo (cpp/src/arrow/device.h:214-222).  Returns `dst` (allocated when None)."""
+    lib, stream = _lib_and_stream(src.device)
+    if dst is None:
+        dst = alloc(src.numel(), src.device)
+    if dst.numel() < src.numel():
+        raise ValueError("copy_buffer: destination smaller than source")
+    check(lib.arx_buffer_copy(src.data_ptr(), dst.data_ptr(), src.numel(), stream))
+    return dst
+
+
 # --------------------------------------------------------------------------- kernels (exec)
 def _propagate_validity(args, length: int, device):
     """NullHandling::INTERSECTION (PropagateNullsSpans, exec.cc:1222-1281) on the device.

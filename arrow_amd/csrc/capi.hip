@@ -42,6 +42,13 @@ int arx_set_option(const char* name, int64_t value) {
   return ARX_INVALID;
 }
 
+int64_t arx_get_counter(const char* name) {
+  int64_t v = 0;
+  if (name != nullptr && arx::get_groupby_counter(name, &v)) return v;
+  arx::set_error("unknown counter '%s'", name == nullptr ? "(null)" : name);
+  return -1;
+}
+
 int arx_device_count(void) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);

@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 
 namespace arx {
 
@@ -636,6 +637,16 @@ constexpr int kGbMaxBins = 256;           // per level
 constexpr int kGbMaxBits = 14;
 constexpr int kGbMaxChunks = 4096;      // upper bound of level-1 chunks (sizes hist1)
 constexpr int kGbSlots = 4096;            // LDS table slots per partition
+// The wide one-level form (round 3): ONE flat scatter into up to 2048 bins + 8192-slot LDS tables.
+constexpr int kGbWideThreads = 1024;
+constexpr int kGbWideRpt = 24;            // rows a thread keeps in registers
+constexpr int kGbWideTile = kGbWideThreads * kGbWideRpt;   // 24576 rows per workgroup
+constexpr int kGbWideRounds = 3;          // the tile goes through the LDS reorder buffer in 3 rounds
+constexpr int kGbWideChunk = kGbWideTile / kGbWideRounds;  // 8192 records = 96 KiB of LDS
+constexpr int kGbWideMaxBits = 11;
+constexpr int kGbWideSlots = 8192;        // LDS table slots per partition (128 KiB)
+constexpr int kGbWideMaxGroups = 6144;    // groups a partition may hold (load factor 0.75)
+constexpr int kGbMaxProbes = 256;         // LDS slots a row looks at before it gives up on the LDS table
 constexpr uint32_t kGbHashMul = 0x9E3779B1u;     // odd => k -> k * M mod 2^32 is a bijection
 constexpr uint32_t kGbHashInv = 0x0E8B2F51u;     // M * Minv == 1 mod 2^32
 static_assert(static_cast<uint32_t>(kGbHashMul * kGbHashInv) == 1u, "hash inverse");
@@ -672,6 +683,8 @@ struct GbpArgs {
   unsigned long long* dense_sums;
   unsigned long long* dense_counts;
   unsigned int* dense_null_seen;
+  int wide;                // 1 = the wide one-level form: b1 == 0, b2 == bits <= 11, 12-byte records in `recs`
+  uint8_t* recs;           // [n] {key u32, value lo, value hi}
   int xcd_map;             // bit 0: level-2 scatter, bit 1: aggregate, bit 2: level-1 scatter — XCD-contiguous work numbering
   int agg_pipe;            // software-pipelined loads in the LDS aggregate kernel (A/B knob)
   uint32_t agg_chunk;      // rows per aggregate work unit (a power of two)
@@ -785,6 +798,7 @@ __global__ __launch_bounds__(kGbThreads) void gbp_hist_kernel(GbpArgs a) {
     const uint32_t c = h[i];
     if (c != 0) atomicAdd(&a.part_count[i], c);
   }
+  if (a.wide) return;   // (the flat level takes its offsets from the partition cursors)
   const int nb1 = 1 << a.b1;
   const int per = 1 << a.b2;
   for (int d = tid; d < nb1; d += kGbThreads) {
@@ -1039,22 +1053,136 @@ __global__ __launch_bounds__(kGbThreads, 6) void gbp_scatter2_kernel(GbpArgs a) 
   gbp_scatter_tile<2, false>(a, lds, a.keys_a, a.vals_a, row0, nrows, p, a.keys_b, a.vals_b);
 }
 
+// ---- K3w: the flat level of the wide form.  One workgroup = one tile of 24576 rows held in REGISTERS (24 per
+// thread): ranked with LDS atomics over up to 2048 bins, then moved through a 8192-record LDS buffer in three rounds,
+// so a (tile, bin) run is 12 records at 2048 bins — three times what an LDS-resident tile gives — and written as
+// 12-byte {key, value} records (one output stream per bin instead of two).  2^30 rows into 2048 bins: 7.9 ms
+// (3.3 TB/s of 24 B/row) against 5.2 + 4.4 ms for the two levels it replaces
+// (scripts/micro/wide_scatter_bench.hip, profiles/r03_a_wide_scatter_register_staged_tiles.txt).
+struct __attribute__((packed, aligned(4))) GbpRec {
+  uint32_t key, vlo, vhi;
+};
+static_assert(sizeof(GbpRec) == 12, "12-byte records");
+
+struct __attribute__((aligned(16))) GbpWideScatterLds {
+  uint64_t vals[kGbWideChunk];
+  uint32_t keys[kGbWideChunk];
+  uint32_t start[1 << kGbWideMaxBits];   // bin counts, then the bins' first positions inside the tile
+  uint32_t gbase[1 << kGbWideMaxBits];   // where the tile's run of a bin starts in the output
+  uint32_t wave_tot[kGbWideThreads / 64];
+  uint32_t total;
+};
+
+template <bool HAS_NULLS>
+__global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArgs a) {
+  __shared__ GbpWideScatterLds lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nb = 1 << a.bits;
+  const int dshift = 32 - a.bits;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kGbWideTile;
+  if (row0 >= a.n) return;   // workgroup-uniform
+  const int nrows = static_cast<int>(a.n - row0 < kGbWideTile ? a.n - row0 : kGbWideTile);
+  for (int b = tid; b < nb; b += kGbWideThreads) lds.start[b] = 0;
+  uint32_t key[kGbWideRpt];
+  int64_t val[kGbWideRpt];
+  // unconditional loads (rows past the tile's end re-read its last row): all in flight together
+#pragma unroll
+  for (int i = 0; i < kGbWideRpt; ++i) {
+    const int p = i * kGbWideThreads + tid;
+    const int64_t r = row0 + (p < nrows ? p : nrows - 1);
+    key[i] = static_cast<uint32_t>(a.keys[r]);
+    val[i] = a.values[r];
+  }
+  __syncthreads();
+  uint32_t pos[kGbWideRpt];
+#pragma unroll
+  for (int i = 0; i < kGbWideRpt; ++i) {
+    const int p = i * kGbWideThreads + tid;
+    bool ok = p < nrows;
+    if constexpr (HAS_NULLS) ok = ok && gbp_streamed<true>(a, row0 + (p < nrows ? p : nrows - 1));   // null rows: K0
+    pos[i] = ok ? atomicAdd(&lds.start[gbp_hash(a, static_cast<int32_t>(key[i])) >> dshift], 1u) : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  // exclusive scan of the bin counts: `per` consecutive bins per thread (1 or 2)
+  const int per = (nb + kGbWideThreads - 1) / kGbWideThreads;
+  uint32_t c[2] = {0, 0};
+  uint32_t mine = 0;
+  for (int k = 0; k < per; ++k) {
+    const int b = tid * per + k;
+    c[k] = b < nb ? lds.start[b] : 0u;
+    mine += c[k];
+  }
+  const uint32_t incl = wave_inclusive_scan_u32(mine);
+  if (lane == 63) lds.wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t pre = incl - mine;
+  for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
+  for (int k = 0; k < per; ++k) {
+    const int b = tid * per + k;
+    if (b < nb) {
+      lds.start[b] = pre;
+      lds.gbase[b] = c[k] != 0 ? atomicAdd(&a.cursor2[b], c[k]) : 0u;
+    }
+    pre += c[k];
+  }
+  if (tid == kGbWideThreads - 1) lds.total = pre;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kGbWideRpt; ++i) {
+    if (pos[i] != 0xFFFFFFFFu) pos[i] += lds.start[gbp_hash(a, static_cast<int32_t>(key[i])) >> dshift];
+  }
+  const int total = static_cast<int>(lds.total);
+  GbpRec* __restrict__ out = reinterpret_cast<GbpRec*>(a.recs);
+  for (int r = 0; r < kGbWideRounds; ++r) {
+    const uint32_t lo = static_cast<uint32_t>(r) * kGbWideChunk;
+    if (static_cast<int>(lo) >= total) break;   // workgroup-uniform
+#pragma unroll
+    for (int i = 0; i < kGbWideRpt; ++i) {
+      const uint32_t q = pos[i] - lo;   // (skipped rows: 0xFFFFFFFF - lo is never < the chunk)
+      if (q < static_cast<uint32_t>(kGbWideChunk)) {
+        lds.keys[q] = key[i];
+        lds.vals[q] = static_cast<uint64_t>(val[i]);
+      }
+    }
+    __syncthreads();
+    const int cnt = total - static_cast<int>(lo) < kGbWideChunk ? total - static_cast<int>(lo) : kGbWideChunk;
+    for (int p = tid; p < cnt; p += kGbWideThreads) {
+      const uint32_t k = lds.keys[p];
+      const uint32_t d = gbp_hash(a, static_cast<int32_t>(k)) >> dshift;
+      const uint64_t v = lds.vals[p];
+      GbpRec rec;
+      rec.key = k;
+      rec.vlo = static_cast<uint32_t>(v);
+      rec.vhi = static_cast<uint32_t>(v >> 32);
+      out[lds.gbase[d] + (lo + static_cast<uint32_t>(p) - lds.start[d])] = rec;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- K5: LDS aggregation.  One workgroup per work unit = <= kGbAggChunk rows of ONE partition
 // (DIRECT: of the caller's rows — the plan with bits == 0 used when all groups fit one table).
+template <int SLOTS>
 struct __attribute__((aligned(16))) GbpAggLds {
-  unsigned long long sums[kGbSlots];
-  uint32_t tags[kGbSlots];   // 0 = empty, else the low (32 - bits) bits of the key hash
-  uint32_t cnts[kGbSlots];
+  unsigned long long sums[SLOTS];
+  uint32_t tags[SLOTS];   // 0 = empty, else the low (32 - bits) bits of the key hash
+  uint32_t cnts[SLOTS];
   unsigned long long zsum;   // the one key whose tag is 0 has its own accumulator
   uint32_t zcnt;
   uint32_t part, row_lo, row_hi;
 };
 
-template <bool DIRECT, bool HAS_NULLS>
-__global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v, GbpArgs a,
-                                                                   const int32_t* __restrict__ keys,
-                                                                   const int64_t* __restrict__ vals) {
-  __shared__ GbpAggLds t;
+// SLOTS / THREADS: 4096 / 512 (two workgroups per CU), or the wide form's 8192 / 1024 (one per CU);
+// AOS: the rows are the wide scatter's 12-byte records (a.recs) instead of the keys / vals arrays.
+template <bool DIRECT, bool HAS_NULLS, int SLOTS = kGbSlots, int THREADS = kGbThreads, bool AOS = false, int U = 4>
+__global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, GbpArgs a,
+                                                                const int32_t* __restrict__ keys,
+                                                                const int64_t* __restrict__ vals) {
+  constexpr int kLgSlots = SLOTS == 8192 ? 13 : 12;
+  static_assert((1 << kLgSlots) == SLOTS, "table sizes: 4096 or 8192 slots");
+  __shared__ GbpAggLds<SLOTS> t;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   int64_t lo, hi;
@@ -1089,7 +1217,7 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
       }
     }
   }
-  for (int i = tid; i < kGbSlots; i += kGbThreads) {
+  for (int i = tid; i < SLOTS; i += THREADS) {
     t.sums[i] = 0;
     t.tags[i] = 0;
     t.cnts[i] = 0;
@@ -1106,11 +1234,12 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
   }
   const int low_bits = 32 - a.bits;
   const uint32_t low_mask = a.bits == 0 ? 0xFFFFFFFFu : ((1u << low_bits) - 1u);
-  const int hshift = low_bits > 12 ? low_bits - 12 : 0;
+  const int hshift = low_bits > kLgSlots ? low_bits - kLgSlots : 0;
   uint32_t fresh = 0;   // keys this thread inserted into the HBM table
-  constexpr int U = 4;  // rows in flight per thread
+  // U rows in flight per thread: 4 x 12 B x 1024 threads = 48 KB per CU is about what 6 TB/s x 2 us of latency asks of
+  // 256 CUs — the wide form keeps 8
   const int64_t span = hi - lo;
-  const int64_t nit = (span + kGbThreads - 1) / kGbThreads;
+  const int64_t nit = (span + THREADS - 1) / THREADS;
   // software pipeline: the loads of batch i+1 are issued before batch i goes through the LDS
   // table, so the HBM latency overlaps the (serial, atomic) LDS work of the same wave
   int32_t kbuf[U], knext[U];
@@ -1119,14 +1248,20 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
   auto load_batch = [&](int64_t it0, int32_t* kb, unsigned long long* vb, bool* ob) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t rr = lo + (it0 + u) * kGbThreads + tid;
+      const int64_t rr = lo + (it0 + u) * THREADS + tid;
       ob[u] = rr < hi;
       if constexpr (DIRECT && HAS_NULLS) {
         if (ob[u]) ob[u] = gbp_streamed<true>(a, rr);  // rows with a null were handled by K0
       }
       const int64_t rc = rr < hi ? rr : hi - 1;  // clamped: always readable
-      kb[u] = keys[rc];
-      vb[u] = static_cast<unsigned long long>(vals[rc]);
+      if constexpr (AOS) {
+        const GbpRec rec = reinterpret_cast<const GbpRec*>(a.recs)[rc];
+        kb[u] = static_cast<int32_t>(rec.key);
+        vb[u] = (static_cast<unsigned long long>(rec.vhi) << 32) | rec.vlo;
+      } else {
+        kb[u] = keys[rc];
+        vb[u] = static_cast<unsigned long long>(vals[rc]);
+      }
     }
   };
   const bool pipe = a.agg_pipe != 0;  // A/B knob groupby_agg_pipe (uniform)
@@ -1152,18 +1287,20 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
       atomicAdd(&t.zcnt, 1u);
       continue;
     }
-    uint32_t h = (kp >> hshift) & (kGbSlots - 1);
+    // (a key that is not settled within kGbMaxProbes slots of its home goes to the HBM table: a full LDS table then
+    //  costs a bounded number of probes per row, and both paths add into the same group in the end)
+    uint32_t h = (kp >> hshift) & (SLOTS - 1);
     int probes = 0;
-    for (; probes < kGbSlots; ++probes) {
+    for (; probes < kGbMaxProbes; ++probes) {
       uint32_t cur = t.tags[h];
       if (cur == 0) {
         cur = atomicCAS(&t.tags[h], 0u, tag);
         if (cur == 0) cur = tag;
       }
       if (cur == tag) break;
-      h = (h + 1) & (kGbSlots - 1);
+      h = (h + 1) & (SLOTS - 1);
     }
-    if (probes < kGbSlots) {
+    if (probes < kGbMaxProbes) {
       atomicAdd(&t.sums[h], val);
       atomicAdd(&t.cnts[h], 1u);
     } else if (a.dense) {  // more ids than the LDS table holds: straight to the caller's arrays, still exact
@@ -1182,11 +1319,11 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
   }
   __syncthreads();
   const uint32_t hi_bits = a.bits == 0 ? 0u : (q << low_bits);
-  for (int i = tid; i < kGbSlots + 1; i += kGbThreads) {
+  for (int i = tid; i < SLOTS + 1; i += THREADS) {
     uint32_t tag;
     unsigned long long sum;
     uint32_t cnt;
-    if (i < kGbSlots) {
+    if (i < SLOTS) {
       tag = t.tags[i];
       if (tag == 0) continue;
       sum = t.sums[i];
@@ -1217,6 +1354,7 @@ __global__ __launch_bounds__(kGbThreads) void gbp_aggregate_kernel(GroupbyView v
 // ---- plan: how a slice of rows is laid out in the caller's workspace
 struct GbpPlan {
   int bits, b1, b2;
+  int wide;                 // the wide one-level form (b1 == 0, b2 == bits)
   int64_t slice_rows, chunk_rows, nchunks;
   size_t off_keys_a, off_vals_a, off_keys_b, off_vals_b, off_part_count, off_part_start,
       off_cursor2, off_cursor1, off_hist1, off_l1_start, off_l2_tile_start, off_agg_unit_start, total;
@@ -1228,6 +1366,10 @@ static int g_gbp_agg_pipe = 1;
 static int g_gbp_xcd_map = 1;         // XCD-contiguous work numbering: bit 0 level-2 scatter (-2.6 ms at 4e9 rows), bit 1 aggregate (+5 ms: off), bit 2 level-1 scatter (no effect)
 static int g_gbp_b1 = -1;             // level-1 bits override (-1: half of the partition bits)
 static int g_gbp_chunks = 2048;       // level-1 chunks = workgroups of the hist / scatter1 kernels
+static int g_gbp_wide_max_bits = kGbWideMaxBits;   // bins of the flat level the planner may ask for (A/B knob groupby_wide_max_bits; tests lower it)
+static int g_gbp_wide = 1;            // the wide one-level form where the group estimate allows it (A/B knob groupby_wide)
+static int g_gbp_wide_agg_chunk = 1 << 20;   // rows per aggregate work unit of the wide form (A/B knob groupby_wide_agg_chunk_rows)
+static int64_t g_gbp_probe_rows = int64_t(1) << 26;   // rows of the probe slice that measures the group count (A/B knob groupby_probe_rows)
 static int g_gbp_l1_global = 1;       // level 1 with global cursors (one tile per workgroup; +3 % at 4e9 rows) instead of chunked exact offsets
 
 static int gbp_bits_for(int64_t capacity) {
@@ -1240,7 +1382,23 @@ static int gbp_bits_for(int64_t capacity) {
   return bits;
 }
 
-static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity) {
+constexpr int64_t kGbMaxSlice = int64_t(1) << 30;  // row positions inside a slice are 32-bit
+static int64_t g_gbp_max_slice = kGbMaxSlice;     // A/B knob groupby_max_slice_rows
+constexpr int64_t kGbHardMaxSlice = (int64_t(1) << 32) - (int64_t(1) << 24);
+static int g_gbp_agg_chunk = 1 << 18;             // A/B knob groupby_agg_chunk_rows (2^16: every group of a partition is flushed 2-8x per slice; 2^18: +4 %)
+
+// Partition bits of the wide form for `groups` distinct keys (<= kGbWideMaxGroups per 8192-slot LDS table), or -1 when
+// the flat level would need more than 2048 bins.
+static int gbp_wide_bits_for(int64_t groups) {
+  int bits = 1;
+  while (bits <= g_gbp_wide_max_bits && ((groups + (int64_t(1) << bits) - 1) >> bits) > kGbWideMaxGroups) ++bits;
+  return bits <= g_gbp_wide_max_bits ? bits : -1;
+}
+
+// groups_hint: distinct keys expected in the rows to come (< 0: unknown — the capacity is the only bound).  The
+// two-level plan is chosen from the capacity alone; the wide plan replaces it when the hint (or, without one, the
+// capacity bound) says its 2048 tables of 8192 slots are enough.
+static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity, int64_t groups_hint = -1, int dense_idbits = 0) {
   GbpPlan p{};
   p.bits = gbp_bits_for(capacity);
   if (p.bits <= 8) {
@@ -1254,6 +1412,26 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity) {
     if (g_gbp_b1 > 0) p.b1 = std::max(p.bits - 8, std::min(g_gbp_b1, std::min(8, p.bits - 1)));
     p.b2 = p.bits - p.b1;
   }
+  // the wide one-level plan replaces a two-level plan when its tables are known to be enough; groupby_wide = 2 forces
+  // it (tests / A-B) with groupby_partition_bits as its bin count
+  int wb = -1;
+  if (g_gbp_wide == 2) {
+    wb = g_gbp_bits >= 1 ? std::min(g_gbp_bits, kGbWideMaxBits) : kGbWideMaxBits;
+  } else if (g_gbp_wide && p.bits > 8 && g_gbp_bits < 0) {
+    wb = gbp_wide_bits_for(groups_hint >= 0 ? groups_hint : std::max<int64_t>(1, capacity / 2));
+    if (dense_idbits > 0) {
+      // dense ids: id << (32 - idbits) is the bijection, a partition's ids are consecutive and map to distinct slots
+      // of the table — what has to fit is the partition's slice of the id space
+      wb = std::max(1, dense_idbits - 13);
+      if (wb > g_gbp_wide_max_bits) wb = -1;
+    }
+  }
+  if (wb > 0) {
+    p.wide = 1;
+    p.bits = wb;
+    p.b1 = 0;
+    p.b2 = wb;
+  }
   p.slice_rows = slice_rows;
   const int64_t ntiles = ceil_div(std::max<int64_t>(slice_rows, 1), kGbTile);
   const int64_t chunk_tiles = std::max<int64_t>(1, ceil_div(ntiles, g_gbp_chunks));
@@ -1264,10 +1442,15 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity) {
   const size_t nparts = size_t(1) << p.bits;
   const size_t nb1 = size_t(1) << p.b1;
   size_t o = 0;
-  p.off_keys_a = o; o = align(o + (p.bits ? n * 4 : 0));
-  p.off_vals_a = o; o = align(o + (p.bits ? n * 8 : 0));
-  p.off_keys_b = o; o = align(o + (p.b2 ? n * 4 : 0));
-  p.off_vals_b = o; o = align(o + (p.b2 ? n * 8 : 0));
+  if (p.wide) {
+    p.off_keys_a = o; o = align(o + n * 12);   // the 12-byte records
+    p.off_vals_a = p.off_keys_b = p.off_vals_b = o;
+  } else {
+    p.off_keys_a = o; o = align(o + (p.bits ? n * 4 : 0));
+    p.off_vals_a = o; o = align(o + (p.bits ? n * 8 : 0));
+    p.off_keys_b = o; o = align(o + (p.b2 ? n * 4 : 0));
+    p.off_vals_b = o; o = align(o + (p.b2 ? n * 8 : 0));
+  }
   p.off_part_count = o; o = align(o + nparts * 4);
   p.off_part_start = o; o = align(o + (nparts + 1) * 4);
   p.off_cursor2 = o; o = align(o + nparts * 4);
@@ -1280,24 +1463,62 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity) {
   return p;
 }
 
-constexpr int64_t kGbMaxSlice = int64_t(1) << 30;  // row positions inside a slice are 32-bit
-static int64_t g_gbp_max_slice = kGbMaxSlice;     // A/B knob groupby_max_slice_rows
-constexpr int64_t kGbHardMaxSlice = (int64_t(1) << 32) - (int64_t(1) << 24);
-static int g_gbp_agg_chunk = 1 << 18;             // A/B knob groupby_agg_chunk_rows (2^16: every group of a partition is flushed 2-8x per slice; 2^18: +4 %)
+// The workspace pointers and knobs of a slice's plan.
+static void gbp_bind(GbpArgs& a, const GbpPlan& plan, uint8_t* w) {
+  a.bits = plan.bits;
+  a.b1 = plan.b1;
+  a.b2 = plan.b2;
+  a.wide = plan.wide;
+  a.chunk_rows = plan.chunk_rows;
+  a.nchunks = plan.nchunks;
+  a.recs = w + plan.off_keys_a;
+  a.keys_a = reinterpret_cast<int32_t*>(w + plan.off_keys_a);
+  a.vals_a = reinterpret_cast<int64_t*>(w + plan.off_vals_a);
+  a.keys_b = reinterpret_cast<int32_t*>(w + plan.off_keys_b);
+  a.vals_b = reinterpret_cast<int64_t*>(w + plan.off_vals_b);
+  a.part_count = reinterpret_cast<uint32_t*>(w + plan.off_part_count);
+  a.part_start = reinterpret_cast<uint32_t*>(w + plan.off_part_start);
+  a.cursor2 = reinterpret_cast<uint32_t*>(w + plan.off_cursor2);
+  a.cursor1 = reinterpret_cast<uint32_t*>(w + plan.off_cursor1);
+  a.hist1 = reinterpret_cast<uint32_t*>(w + plan.off_hist1);
+  a.l1_start = reinterpret_cast<uint32_t*>(w + plan.off_l1_start);
+  a.l2_tile_start = reinterpret_cast<uint32_t*>(w + plan.off_l2_tile_start);
+  a.agg_unit_start = reinterpret_cast<uint32_t*>(w + plan.off_agg_unit_start);
+  a.agg_pipe = g_gbp_agg_pipe;
+  a.xcd_map = g_gbp_xcd_map;
+  a.agg_chunk = static_cast<uint32_t>(plan.wide ? g_gbp_wide_agg_chunk : g_gbp_agg_chunk);
+}
 
 // Largest slice (multiple of the tile) whose plan fits `ws_bytes`; 0 if not even one chunk fits.
 static int64_t gbp_slice_for(size_t ws_bytes, int64_t n, int64_t capacity) {
+  // sized for the plan WITHOUT a group-count hint (the larger of the two: the probe slice runs it, and the wide
+  // plan a hint may select later needs half the row scratch)
   int64_t hi = std::min<int64_t>(n, g_gbp_max_slice);
   if (gbp_plan(hi, capacity).total <= ws_bytes) return hi;
   const size_t fixed = gbp_plan(kGbTile, capacity).total;
   if (fixed > ws_bytes) return 0;
   const GbpPlan probe = gbp_plan(kGbTile, capacity);
   if (probe.bits == 0) return hi;  // no row scratch at all
-  const int two = probe.b2 ? 2 : 1;
+  const int two = probe.b2 && !probe.wide ? 2 : 1;
   int64_t rows = static_cast<int64_t>((ws_bytes - fixed) / (12 * two));
   rows = rows / kGbTile * kGbTile;
   while (rows > 0 && gbp_plan(rows, capacity).total > ws_bytes) rows -= kGbTile;
   return std::min(rows, hi);
+}
+
+// Which plan the slices of the partitioned consume ran (arx_get_counter): the plan is chosen from estimates, and a test
+// or a bench that means to measure one plan must be able to see that it did.
+static std::atomic<int64_t> g_gbp_slices_direct{0}, g_gbp_slices_one_level{0}, g_gbp_slices_two_level{0},
+    g_gbp_slices_wide{0}, g_gbp_slices_probe{0};
+
+int get_groupby_counter(const char* name, int64_t* out) {
+  if (strcmp(name, "groupby_slices_direct") == 0) *out = g_gbp_slices_direct.load();
+  else if (strcmp(name, "groupby_slices_one_level") == 0) *out = g_gbp_slices_one_level.load();
+  else if (strcmp(name, "groupby_slices_two_level") == 0) *out = g_gbp_slices_two_level.load();
+  else if (strcmp(name, "groupby_slices_wide") == 0) *out = g_gbp_slices_wide.load();
+  else if (strcmp(name, "groupby_slices_probe") == 0) *out = g_gbp_slices_probe.load();
+  else return 0;
+  return 1;
 }
 
 template <bool HAS_NULLS>
@@ -1306,6 +1527,8 @@ static int gbp_run_slice(const GroupbyView& v, GbpArgs a, const GbpPlan& plan, h
     hipLaunchKernelGGL(gbp_null_rows_kernel, dim3(gb_grid(a.n / 8 + 1)), dim3(kBlock), 0, st, v, a);
     ARX_CHECK_LAUNCH("gbp_null_rows_kernel");
   }
+  (a.bits == 0 ? g_gbp_slices_direct : a.wide ? g_gbp_slices_wide : a.b2 > 0 ? g_gbp_slices_two_level : g_gbp_slices_one_level)
+      .fetch_add(1, std::memory_order_relaxed);
   if (a.bits == 0) {
     const unsigned units = static_cast<unsigned>(ceil_div(a.n, a.agg_chunk));
     hipLaunchKernelGGL((gbp_aggregate_kernel<true, HAS_NULLS>), dim3(units), dim3(kGbThreads), 0, st, v, a,
@@ -1320,6 +1543,16 @@ static int gbp_run_slice(const GroupbyView& v, GbpArgs a, const GbpPlan& plan, h
   ARX_CHECK_LAUNCH("gbp_hist_kernel");
   hipLaunchKernelGGL(gbp_scan_a_kernel, dim3(1), dim3(1024), 0, st, a);
   ARX_CHECK_LAUNCH("gbp_scan_a_kernel");
+  if (a.wide) {
+    hipLaunchKernelGGL((gbp_scatter_wide_kernel<HAS_NULLS>), dim3(static_cast<unsigned>(ceil_div(a.n, kGbWideTile))),
+                       dim3(kGbWideThreads), 0, st, a);
+    ARX_CHECK_LAUNCH("gbp_scatter_wide_kernel");
+    const unsigned wunits = static_cast<unsigned>(ceil_div(a.n, a.agg_chunk) + nparts);
+    hipLaunchKernelGGL((gbp_aggregate_kernel<false, false, kGbWideSlots, kGbWideThreads, true, 8>), dim3(wunits),
+                       dim3(kGbWideThreads), 0, st, v, a, nullptr, nullptr);
+    ARX_CHECK_LAUNCH("gbp_aggregate_kernel (wide)");
+    return ARX_OK;
+  }
   hipLaunchKernelGGL(gbp_scan_b_kernel, dim3(1u << a.b1), dim3(1024), 0, st, a);
   ARX_CHECK_LAUNCH("gbp_scan_b_kernel");
   if (g_gbp_l1_global) {
@@ -1367,6 +1600,24 @@ int set_groupby_option(const char* name, int64_t value) {
     int lg = 12;
     while (lg < 24 && (int64_t(1) << lg) < value) ++lg;
     g_gbp_agg_chunk = 1 << lg;
+    return 1;
+  }
+  if (strcmp(name, "groupby_wide") == 0) {
+    g_gbp_wide = value < 0 ? 0 : static_cast<int>(std::min<int64_t>(value, 2));
+    return 1;
+  }
+  if (strcmp(name, "groupby_wide_agg_chunk_rows") == 0) {
+    int lg = 14;
+    while (lg < 26 && (int64_t(1) << lg) < value) ++lg;
+    g_gbp_wide_agg_chunk = 1 << lg;
+    return 1;
+  }
+  if (strcmp(name, "groupby_wide_max_bits") == 0) {
+    g_gbp_wide_max_bits = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, kGbWideMaxBits)));
+    return 1;
+  }
+  if (strcmp(name, "groupby_probe_rows") == 0) {
+    g_gbp_probe_rows = std::max<int64_t>(kGbTile, value);
     return 1;
   }
   if (strcmp(name, "groupby_l1_global") == 0) {
@@ -1467,9 +1718,26 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
                             : 0;
   if (slice >= kGbTile && slice >= std::min<int64_t>(n, 1 << 16)) {
     uint8_t* w = static_cast<uint8_t*>(ws);
-    for (int64_t r0 = 0; r0 < n; r0 += slice) {
-      const int64_t m = std::min(slice, n - r0);
-      const GbpPlan plan = gbp_plan(m, capacity);
+    // The capacity only bounds the number of groups from above (a power of two > 2 G: G is anywhere in its upper half).
+    // When that bound asks for the two-level plan but the wide one-level plan is within reach, the first 2^26 rows run
+    // as a probe slice on the safe plan; the distinct keys the table holds after it — if the probe saw most of its
+    // keys more than once — are the estimate the remaining slices are planned with.  A wrong estimate costs time,
+    // never exactness (rows that find no room in an LDS table go to the HBM table).
+    const GbpPlan unhinted = gbp_plan(slice, capacity);
+    const int64_t probe_rows = std::max<int64_t>(kGbTile, g_gbp_probe_rows / kGbTile * kGbTile);
+    const bool probe = g_gbp_wide && g_gbp_bits < 0 && unhinted.b2 > 0 && !unhinted.wide && n >= 4 * probe_rows;
+    int64_t groups_hint = -1;
+    unsigned long long groups_before = 0;
+    if (probe) {
+      GroupbyHeader h0{};
+      const int rc0 = read_header(state, &h0, st);
+      if (rc0 != ARX_OK) return rc0;
+      groups_before = h0.num_groups;
+    }
+    for (int64_t r0 = 0; r0 < n;) {
+      const bool probing = probe && r0 == 0;
+      const int64_t m = std::min(probing ? probe_rows : slice, n - r0);
+      const GbpPlan plan = gbp_plan(m, capacity, groups_hint);
       GbpArgs a{};
       a.dense = 0;
       a.keys = k + r0;
@@ -1477,29 +1745,21 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
       a.kvalid = make_bits(kbm, keys_i32->offset + r0, m);
       a.vvalid = make_bits(vbm, values_i64->offset + r0, m);
       a.n = m;
-      a.bits = plan.bits;
-      a.b1 = plan.b1;
-      a.b2 = plan.b2;
-      a.chunk_rows = plan.chunk_rows;
-      a.nchunks = plan.nchunks;
-      a.keys_a = reinterpret_cast<int32_t*>(w + plan.off_keys_a);
-      a.vals_a = reinterpret_cast<int64_t*>(w + plan.off_vals_a);
-      a.keys_b = reinterpret_cast<int32_t*>(w + plan.off_keys_b);
-      a.vals_b = reinterpret_cast<int64_t*>(w + plan.off_vals_b);
-      a.part_count = reinterpret_cast<uint32_t*>(w + plan.off_part_count);
-      a.part_start = reinterpret_cast<uint32_t*>(w + plan.off_part_start);
-      a.cursor2 = reinterpret_cast<uint32_t*>(w + plan.off_cursor2);
-      a.cursor1 = reinterpret_cast<uint32_t*>(w + plan.off_cursor1);
-      a.hist1 = reinterpret_cast<uint32_t*>(w + plan.off_hist1);
-      a.l1_start = reinterpret_cast<uint32_t*>(w + plan.off_l1_start);
-      a.l2_tile_start = reinterpret_cast<uint32_t*>(w + plan.off_l2_tile_start);
-      a.agg_unit_start = reinterpret_cast<uint32_t*>(w + plan.off_agg_unit_start);
-      a.agg_pipe = g_gbp_agg_pipe;
-      a.xcd_map = g_gbp_xcd_map;
-      a.agg_chunk = static_cast<uint32_t>(g_gbp_agg_chunk);
+      gbp_bind(a, plan, w);
       const int rc = (kbm != nullptr || vbm != nullptr) ? gbp_run_slice<true>(v, a, plan, st)
                                                         : gbp_run_slice<false>(v, a, plan, st);
       if (rc != ARX_OK) return rc;
+      if (probing) {
+        g_gbp_slices_probe.fetch_add(1, std::memory_order_relaxed);
+        GroupbyHeader h1{};
+        const int rc1 = read_header(state, &h1, st);
+        if (rc1 != ARX_OK) return rc1;
+        const unsigned long long fresh = h1.num_groups - groups_before;
+        if (fresh * 2 < static_cast<unsigned long long>(m)) {   // most keys of the probe repeated: the count is near G
+          groups_hint = static_cast<int64_t>(h1.num_groups + h1.num_groups / 16 + 1024);
+        }
+      }
+      r0 += m;
     }
     return ARX_OK;
   }
@@ -1954,7 +2214,7 @@ int arx_hash_sum_i64_consume_ws(const ArxSpan* values, int values_is_scalar, int
   uint8_t* w = static_cast<uint8_t*>(ws);
   for (int64_t r0 = 0; r0 < length; r0 += slice) {
     const int64_t m = std::min(slice, length - r0);
-    const GbpPlan plan = gbp_plan(m, cap);
+    const GbpPlan plan = gbp_plan(m, cap, num_groups, dense_id_bits(num_groups));
     GbpArgs a{};
     a.dense = 1;
     a.dense_shl = 32 - dense_id_bits(num_groups);
@@ -1966,26 +2226,7 @@ int arx_hash_sum_i64_consume_ws(const ArxSpan* values, int values_is_scalar, int
     a.kvalid = make_bits(nullptr, 0, m);
     a.vvalid = make_bits(vbm, values->offset + r0, m);
     a.n = m;
-    a.bits = plan.bits;
-    a.b1 = plan.b1;
-    a.b2 = plan.b2;
-    a.chunk_rows = plan.chunk_rows;
-    a.nchunks = plan.nchunks;
-    a.keys_a = reinterpret_cast<int32_t*>(w + plan.off_keys_a);
-    a.vals_a = reinterpret_cast<int64_t*>(w + plan.off_vals_a);
-    a.keys_b = reinterpret_cast<int32_t*>(w + plan.off_keys_b);
-    a.vals_b = reinterpret_cast<int64_t*>(w + plan.off_vals_b);
-    a.part_count = reinterpret_cast<uint32_t*>(w + plan.off_part_count);
-    a.part_start = reinterpret_cast<uint32_t*>(w + plan.off_part_start);
-    a.cursor2 = reinterpret_cast<uint32_t*>(w + plan.off_cursor2);
-    a.cursor1 = reinterpret_cast<uint32_t*>(w + plan.off_cursor1);
-    a.hist1 = reinterpret_cast<uint32_t*>(w + plan.off_hist1);
-    a.l1_start = reinterpret_cast<uint32_t*>(w + plan.off_l1_start);
-    a.l2_tile_start = reinterpret_cast<uint32_t*>(w + plan.off_l2_tile_start);
-    a.agg_unit_start = reinterpret_cast<uint32_t*>(w + plan.off_agg_unit_start);
-    a.agg_pipe = g_gbp_agg_pipe;
-      a.xcd_map = g_gbp_xcd_map;
-    a.agg_chunk = static_cast<uint32_t>(g_gbp_agg_chunk);
+    gbp_bind(a, plan, w);
     const int rc = vbm != nullptr ? gbp_run_slice<true>(none, a, plan, st) : gbp_run_slice<false>(none, a, plan, st);
     if (rc != ARX_OK) return rc;
   }

@@ -232,6 +232,18 @@ def _time_gpu(fn, reps=5, warm=2):
     return s.elapsed_time(e) / reps
 
 
+def copy_ceiling(amd, device, nbytes=1 << 30):
+    """What this box's HBM gives a plain copy: arx_buffer_copy (16 bytes per lane, one-shot grid) of 1 GiB, read +
+    written bytes per second.  Every `frac` of the line is priced against the 8 TB/s spec peak; this figure says how
+    much of the distance to that peak is the box (MI355X_MICROARCH.md measures 6.29 TB/s for the same copy)."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    src.random_(0, 256)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    ms = min(_time_gpu(lambda: amd.compute.copy_buffer(src, dst), reps=5, warm=2) for _ in range(3))
+    del src, dst
+    return round(2 * nbytes / ms / 1e6, 1)
+
+
 def _barrier(world):
     if world > 1:
         torch.distributed.barrier()
@@ -494,6 +506,13 @@ def run_filter_take(args, rank, world, device):
                       "arx_take": round(float(np.mean(take_ms)), 4),
                       "take_algorithmic_GBps": round(take_bytes / max(float(np.mean(take_ms)), 1e-9) / 1e6, 1)},
     }
+    if rank == 0 and not EMU:
+        try:
+            ceiling = copy_ceiling(amd, device)
+            result["roofline"]["copy_ceiling_GBps"] = ceiling
+            result["roofline"]["frac_of_copy_ceiling"] = round(achieved / ceiling, 4)
+        except Exception as e:
+            result["roofline"]["copy_ceiling_GBps"] = f"{type(e).__name__}: {e}"[:200]
     if rank == 0 and world == 1:
         result["parity_spot_check"] = "ok" if parity_spot_check(amd, values, validity, mask, n) else "MISMATCH"
         if not args.no_cpu_baseline:

@@ -88,6 +88,10 @@ int arx_device_count(void);
  * "sort_msd", ...; the list is in DESIGN.md 4.8).  Never changes results.  Not part of the
  * reference interface. */
 int arx_set_option(const char* name, int64_t value);
+/* Process-wide diagnostic counters (monotonic): which plan the slices of the partitioned group-by consume ran —
+ * "groupby_slices_direct" / "_one_level" / "_two_level" / "_wide" / "_probe" (DESIGN.md 4.6).  -1 + arx_last_error() for
+ * an unknown name.  Not part of the reference interface. */
+int64_t arx_get_counter(const char* name);
 
 /* ---------------------------------------------------------------------------
  * Filter  — replaces PrimitiveFilterExec / PrimitiveFilterImpl<W>::Exec
@@ -347,6 +351,10 @@ int arx_add_f64_array_scalar(const double* left, double right, int64_t length, d
  * CopyBitmap, cpp/src/arrow/util/bitmap_ops.cc).  Inputs carry bit offsets,
  * outputs start at bit 0 and are zero-padded to a 64-bit boundary.
  * ------------------------------------------------------------------------- */
+/* Device-to-device copy of nbytes (ranges must not overlap) — the kROCM -> kROCM leg of MemoryManager::CopyBufferTo /
+ * CopyNonOwned (cpp/src/arrow/device.h:214-222, gpu/cuda_memory.cc's CopyBufferTo) as a kernel: 16 bytes per lane,
+ * one-shot grid.  bench.py times it on 1 GiB as the box's copy ceiling (`copy_ceiling_GBps`).  Asynchronous. */
+int arx_buffer_copy(const void* src, void* dst, int64_t nbytes, void* stream);
 int arx_bitmap_copy(const void* bits, int64_t bit_offset, int64_t length, void* out,
                     void* stream);
 int arx_bitmap_and(const void* left, int64_t left_offset, const void* right,

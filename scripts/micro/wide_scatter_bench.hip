@@ -337,6 +337,23 @@ int main(int argc, char** argv) {
     }
   }
   } else {
+    if (what[0] == 'o') {   // two workgroups per CU: small LDS chunks so that one's loads overlap the other's stores
+      for (int ncls : {1, 8}) {
+        run_big<11, 1024, 24, 3, false>(keys, vals, n, out, ncls, want);   // the product's form (112 KB: one per CU)
+        run_big<11, 512, 48, 6, false>(keys, vals, n, out, ncls, want);    // 64 KB
+        run_big<11, 512, 40, 5, false>(keys, vals, n, out, ncls, want);
+        run_big<11, 512, 32, 4, false>(keys, vals, n, out, ncls, want);
+        run_big<11, 512, 32, 8, false>(keys, vals, n, out, ncls, want);    // 40 KB: three per CU
+        run_big<11, 512, 24, 3, false>(keys, vals, n, out, ncls, want);
+        run_big<11, 256, 64, 4, false>(keys, vals, n, out, ncls, want);    // 256 threads x 64 rows, 64 KB
+        run_big<11, 1024, 24, 6, false>(keys, vals, n, out, ncls, want);
+        run_big<10, 512, 48, 6, false>(keys, vals, n, out, ncls, want);
+        run_big<10, 512, 32, 4, false>(keys, vals, n, out, ncls, want);
+        run_big<9, 512, 32, 4, false>(keys, vals, n, out, ncls, want);
+        run_big<9, 1024, 8, 1, false>(keys, vals, n, out, ncls, want);
+      }
+      return 0;
+    }
     for (int ncls : {8, 1}) {
       run_big<11, 1024, 8, 1, false>(keys, vals, n, out, ncls, want);
       run_big<11, 1024, 8, 1, true>(keys, vals, n, out, ncls, want);

@@ -1622,6 +1622,32 @@ def check_copy_segments(amd, rng, scale=1):
 BIT_SEG = np.dtype([("src", "<u8"), ("src_bit_offset", "<i8"), ("dst", "<u8"), ("dst_bit_offset", "<i8"), ("nbits", "<i8")])
 
 
+def check_buffer_copy(amd, rng, scale=1):
+    """arx_buffer_copy: byte ranges of every length around the 16-byte / 4-KiB boundaries, source and destination at
+    equal and at different 16-byte phases; bytes outside the destination range stay untouched."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    big = 3_000_017 * scale
+    src_h = rng.integers(0, 256, big + 64, dtype=np.uint8)
+    src = to_device(src_h, dev)
+    for n in [0, 1, 15, 16, 17, 255, 4095, 4096, 4097, 65536 + 3, big]:
+        for so, do in [(0, 0), (5, 5), (3, 19), (1, 2), (16, 7)]:
+            if so + n > len(src_h):
+                continue
+            dst = torch.full((n + 64,), 0xA5, dtype=torch.uint8, device=dev)
+            _lib.check(lib.arx_buffer_copy(src.data_ptr() + so, dst.data_ptr() + do, n, current_stream(dev)))
+            got = dst.cpu().numpy()
+            want = np.full(n + 64, 0xA5, np.uint8)
+            want[do:do + n] = src_h[so:so + n]
+            assert_equal(got, want, f"buffer_copy n={n} src+{so} dst+{do}")
+    out = amd.compute.copy_buffer(src)
+    assert_equal(out.cpu().numpy()[: len(src_h)], src_h, "copy_buffer")
+
+
 def check_bitmap_copy_segments(amd, rng, scale=1):
     """arx_bitmap_copy_segments: bit ranges at any source bit offset ORed into zeroed bitmaps back to back (ranges meet
     inside words), NULL sources (= all ones), empty ranges, two destination bitmaps in one launch."""

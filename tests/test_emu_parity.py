@@ -929,5 +929,68 @@ def test_copy_segments_any_alignment(emu_ctx):
     P.check_copy_segments(emu_ctx, rng_for("copyseg"), 1)
 
 
+def test_buffer_copy(emu_ctx):
+    P.check_buffer_copy(emu_ctx, rng_for("bufcopy"), 1)
+
+
 def test_bitmap_copy_segments(emu_ctx):
     P.check_bitmap_copy_segments(emu_ctx, rng_for("bitseg"), 1)
+
+
+@pytest.mark.parametrize("bits", [1, 4, 8, 11])
+def test_groupby_wide_one_level_form(emu_ctx, bits):
+    """The wide one-level plan forced on (groupby_wide = 2): ONE flat scatter of register-held 24576-row tiles into
+    2^bits bins of 12-byte records + 8192-slot LDS tables; null keys / null values / wrap-around, several consume
+    calls, partial last tiles, more groups than the LDS tables hold (rows spill to the HBM table, still exact)."""
+    lib = emu_ctx._lib.get_lib()
+    opts = {b"groupby_partition_min_rows": 0, b"groupby_wide": 2, b"groupby_partition_bits": bits,
+            b"groupby_wide_agg_chunk_rows": 1 << (14 + bits % 3)}
+    for k_, v_ in opts.items():
+        assert lib.arx_set_option(k_, v_) == 0
+    wide0 = lib.arx_get_counter(b"groupby_slices_wide")
+    try:
+        rng = rng_for("gbwide", bits)
+        n = 30000
+        k = U.random_array(rng, np.int32, n, null_p=0.02, offset=3, lo=-2**31, hi=2**31 - 1)
+        k.values[: n // 2] = k.values[: n // 2] % 1777          # many repeats + distinct tail
+        v = U.random_array(rng, np.int64, n, null_p=0.1, offset=1)
+        P.check_groupby_sum(emu_ctx, k, v, skip_nulls=(bits % 2 == 1), min_count=1, batches=2, use_pyarrow=(bits == 4))
+        k2 = U.random_array(rng, np.int32, n + 4097, lo=0, hi=50000)      # no nulls: the HAS_NULLS = false kernels
+        v2 = U.random_array(rng, np.int64, n + 4097)
+        P.check_groupby_sum(emu_ctx, k2, v2, use_pyarrow=False)
+        assert lib.arx_get_counter(b"groupby_slices_wide") >= wide0 + 3, "the wide plan did not run"
+    finally:
+        for k_, v_ in {b"groupby_partition_min_rows": 1 << 17, b"groupby_wide": 1, b"groupby_partition_bits": -1,
+                       b"groupby_wide_agg_chunk_rows": 1 << 19}.items():
+            lib.arx_set_option(k_, v_)
+
+
+@pytest.mark.parametrize("distinct", [900, 0])
+def test_groupby_probe_slice_selects_the_plan(emu_ctx, distinct):
+    """A capacity that only bounds the group count from above (two-level plan) + enough rows: the first slice is a
+    probe; few distinct keys seen twice -> the remaining rows run the wide plan, keys that do not repeat -> they stay on
+    the two-level plan.  Same groups either way; earlier groups in the table count towards the estimate."""
+    lib = emu_ctx._lib.get_lib()
+    assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
+    assert lib.arx_set_option(b"groupby_probe_rows", 4096) == 0
+    assert lib.arx_set_option(b"groupby_wide_max_bits", 3) == 0    # (so that the capacity bound alone cannot pick the wide plan)
+    names = (b"groupby_slices_probe", b"groupby_slices_wide", b"groupby_slices_two_level")
+    before = [lib.arx_get_counter(c) for c in names]
+    try:
+        rng = rng_for("gbprobe", distinct)
+        n = 9 * (4096) + 1234
+        hi = distinct if distinct else 2**31 - 1
+        k = U.random_array(rng, np.int32, n, null_p=0.01, lo=-5 if distinct else -2**31, hi=hi)
+        v = U.random_array(rng, np.int64, n, null_p=0.05)
+        P.check_groupby_sum(emu_ctx, k, v, capacity=1 << 21, batches=1, use_pyarrow=False)
+        P.check_groupby_sum(emu_ctx, k, v, capacity=1 << 21, batches=2, use_pyarrow=False)   # second consume: table not empty
+    finally:
+        lib.arx_set_option(b"groupby_partition_min_rows", 1 << 17)
+        lib.arx_set_option(b"groupby_probe_rows", 1 << 26)
+        lib.arx_set_option(b"groupby_wide_max_bits", 11)
+    probe, wide, two = (lib.arx_get_counter(c) - b for c, b in zip(names, before))
+    assert probe == 3, "one probe slice per consume call"
+    if distinct:
+        assert (wide, two) == (3, 3), (probe, wide, two)     # the probe slices on the two-level plan, the rest wide
+    else:
+        assert (wide, two) == (0, 6), (probe, wide, two)
