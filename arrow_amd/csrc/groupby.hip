@@ -1368,7 +1368,7 @@ static int g_gbp_b1 = -1;             // level-1 bits override (-1: half of the 
 static int g_gbp_chunks = 2048;       // level-1 chunks = workgroups of the hist / scatter1 kernels
 static int g_gbp_wide_max_bits = kGbWideMaxBits;   // bins of the flat level the planner may ask for (A/B knob groupby_wide_max_bits; tests lower it)
 static int g_gbp_wide = 1;            // the wide one-level form where the group estimate allows it (A/B knob groupby_wide)
-static int g_gbp_wide_agg_chunk = 1 << 20;   // rows per aggregate work unit of the wide form (A/B knob groupby_wide_agg_chunk_rows)
+static int g_gbp_wide_agg_chunk = 1 << 21;   // rows per aggregate work unit of the wide form (A/B knob groupby_wide_agg_chunk_rows)
 static int64_t g_gbp_probe_rows = int64_t(1) << 26;   // rows of the probe slice that measures the group count (A/B knob groupby_probe_rows)
 static int g_gbp_l1_global = 1;       // level 1 with global cursors (one tile per workgroup; +3 % at 4e9 rows) instead of chunked exact offsets
 
@@ -1385,6 +1385,7 @@ static int gbp_bits_for(int64_t capacity) {
 constexpr int64_t kGbMaxSlice = int64_t(1) << 30;  // row positions inside a slice are 32-bit
 static int64_t g_gbp_max_slice = kGbMaxSlice;     // A/B knob groupby_max_slice_rows
 constexpr int64_t kGbHardMaxSlice = (int64_t(1) << 32) - (int64_t(1) << 24);
+static int64_t g_gbp_wide_max_slice = kGbHardMaxSlice;   // A/B knob groupby_wide_max_slice_rows
 static int g_gbp_agg_chunk = 1 << 18;             // A/B knob groupby_agg_chunk_rows (2^16: every group of a partition is flushed 2-8x per slice; 2^18: +4 %)
 
 // Partition bits of the wide form for `groups` distinct keys (<= kGbWideMaxGroups per 8192-slot LDS table), or -1 when
@@ -1490,19 +1491,20 @@ static void gbp_bind(GbpArgs& a, const GbpPlan& plan, uint8_t* w) {
 }
 
 // Largest slice (multiple of the tile) whose plan fits `ws_bytes`; 0 if not even one chunk fits.
-static int64_t gbp_slice_for(size_t ws_bytes, int64_t n, int64_t capacity) {
-  // sized for the plan WITHOUT a group-count hint (the larger of the two: the probe slice runs it, and the wide
-  // plan a hint may select later needs half the row scratch)
-  int64_t hi = std::min<int64_t>(n, g_gbp_max_slice);
-  if (gbp_plan(hi, capacity).total <= ws_bytes) return hi;
-  const size_t fixed = gbp_plan(kGbTile, capacity).total;
+static int64_t gbp_slice_for(size_t ws_bytes, int64_t n, int64_t capacity, int64_t groups_hint = -1) {
+  // The two-level plan works in slices of <= 2^30 rows (larger ones are slower: its local levels lose their locality);
+  // the wide plan has one flat level whatever the slice, flushes every group once per slice and aggregate unit, and
+  // needs half the row scratch: its slices go up to the 32-bit position limit (4e9 rows / 1e7 keys: 50.2 -> 48.6 ms).
+  const GbpPlan probe = gbp_plan(kGbTile, capacity, groups_hint);
+  int64_t hi = std::min<int64_t>(n, probe.wide ? g_gbp_wide_max_slice : g_gbp_max_slice);
+  if (gbp_plan(hi, capacity, groups_hint).total <= ws_bytes) return hi;
+  const size_t fixed = probe.total;
   if (fixed > ws_bytes) return 0;
-  const GbpPlan probe = gbp_plan(kGbTile, capacity);
   if (probe.bits == 0) return hi;  // no row scratch at all
   const int two = probe.b2 && !probe.wide ? 2 : 1;
   int64_t rows = static_cast<int64_t>((ws_bytes - fixed) / (12 * two));
   rows = rows / kGbTile * kGbTile;
-  while (rows > 0 && gbp_plan(rows, capacity).total > ws_bytes) rows -= kGbTile;
+  while (rows > 0 && gbp_plan(rows, capacity, groups_hint).total > ws_bytes) rows -= kGbTile;
   return std::min(rows, hi);
 }
 
@@ -1612,6 +1614,10 @@ int set_groupby_option(const char* name, int64_t value) {
     g_gbp_wide_agg_chunk = 1 << lg;
     return 1;
   }
+  if (strcmp(name, "groupby_wide_max_slice_rows") == 0) {
+    g_gbp_wide_max_slice = std::max<int64_t>(kGbTile, std::min<int64_t>(value, kGbHardMaxSlice)) / kGbTile * kGbTile;
+    return 1;
+  }
   if (strcmp(name, "groupby_wide_max_bits") == 0) {
     g_gbp_wide_max_bits = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, kGbWideMaxBits)));
     return 1;
@@ -1688,7 +1694,15 @@ static int state_capacity(void* state, int64_t* cap, hipStream_t st) {
 
 size_t arx_groupby_consume_workspace_bytes(int64_t length, int64_t capacity) {
   if (length < g_gbp_min_rows || length <= 0) return 0;
-  return gbp_plan(std::min<int64_t>(length, g_gbp_max_slice), capacity).total;
+  // the plan the capacity alone selects, in its slices — and, where a measured group count may select the wide plan
+  // later (arx_groupby_sum_i64_consume's probe slice), room for that plan's larger slices
+  size_t need = gbp_plan(std::min<int64_t>(length, gbp_plan(kGbTile, capacity).wide ? g_gbp_wide_max_slice : g_gbp_max_slice),
+                         capacity).total;
+  if (g_gbp_wide && g_gbp_bits < 0 && !gbp_plan(kGbTile, capacity).wide && gbp_plan(kGbTile, capacity).b2 > 0) {
+    const int64_t few = int64_t(kGbWideMaxGroups) << 1;   // any hint small enough for the wide plan
+    need = std::max(need, gbp_plan(std::min<int64_t>(length, g_gbp_wide_max_slice), capacity, few).total);
+  }
+  return need;
 }
 
 int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* keys_i32,
@@ -1736,7 +1750,11 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
     }
     for (int64_t r0 = 0; r0 < n;) {
       const bool probing = probe && r0 == 0;
-      const int64_t m = std::min(probing ? probe_rows : slice, n - r0);
+      int64_t m = std::min(probing ? probe_rows : slice, n - r0);
+      if (!probing && groups_hint >= 0) {   // the plan the estimate selects may take larger slices from the same scratch
+        const int64_t hinted = gbp_slice_for(ws_bytes, n - r0, capacity, groups_hint);
+        if (hinted >= kGbTile) m = std::min(hinted, n - r0);
+      }
       const GbpPlan plan = gbp_plan(m, capacity, groups_hint);
       GbpArgs a{};
       a.dense = 0;

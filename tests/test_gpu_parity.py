@@ -1193,18 +1193,9 @@ def test_order_by_several_keys(gpu_ctx, null_placement):
     P.check_order_by(gpu_ctx, cols, [(0, "descending"), (2, "ascending")], [null_placement, other])
 
 
-# The device Grouper (csrc/grouper.hip) is verified on the emulator (tests/test_emu_parity.py, both schedules, with the
-# emulator's __threadfence as a scheduling point so that the claimed-but-unpublished window is exercised).  On gfx950 the
-# golden vectors and five of the nine id cases below passed (profiles/r02_o_grouper_first_gpu_run.txt); the two following
-# calls that would have run the rest coincided with the loss of the GPU box (gpurun "lease" faults) and could not be
-# bisected inside the round's strike budget, so these tests only run when asked for: ARROW_AMD_GPU_GROUPER=1.
-import os as _os
-
-_grouper_on_gpu = pytest.mark.skipif(_os.environ.get("ARROW_AMD_GPU_GROUPER") != "1",
-                                     reason="device Grouper on gfx950: opt in with ARROW_AMD_GPU_GROUPER=1 (see comment)")
-
-
-@_grouper_on_gpu
+# The device Grouper (csrc/grouper.hip): round 2 left these tests opt-in after two GPU calls that coincided with lost
+# boxes; round 3 ran every one of them on gfx950 in its own process under a wall-clock kill (scripts/gpu_r03_grouper.sh,
+# profiles/r03_d_grouper_gpu_tests.txt: 13 of 13 green, no hang) and they are part of the default `-m gpu` run again.
 @pytest.mark.parametrize("section,combos", [("grouper_numeric_key", None), ("grouper_floating_point_key", None),
                                             ("grouper_multiple_int_keys", 60)])
 def test_reference_grouper_golden_vectors(gpu_ctx, section, combos):
@@ -1217,7 +1208,6 @@ def test_reference_grouper_golden_vectors(gpu_ctx, section, combos):
     assert P.replay_golden_grouper(gold, section, P.device_grouper_factory(gpu_ctx), combos) > 0
 
 
-@_grouper_on_gpu
 @pytest.mark.parametrize("dtypes,n,card,null_p,batches", [
     ((np.int64,), 2_000_000, 300_000, 0.05, 1), ((np.int64,), 1_000_000, 999_999, 0.0, 3),
     ((np.uint64,), 3_000_000, 5, 0.3, 2), ((np.int32, np.int32), 2_000_000, 900, 0.1, 2),
@@ -1227,7 +1217,6 @@ def test_grouper_ids_uniques_lookup(gpu_ctx, dtypes, n, card, null_p, batches):
     P.check_grouper(gpu_ctx, rng_for("grouper", len(dtypes), n, card, batches), dtypes, n, card, null_p, batches)
 
 
-@_grouper_on_gpu
 def test_grouper_hot_keys_and_overflow(gpu_ctx):
     """Every row hits one of 3 keys while they are being inserted (the pending-list path), and a table that is too
     small fails the call instead of corrupting ids."""
@@ -1239,7 +1228,6 @@ def test_grouper_hot_keys_and_overflow(gpu_ctx):
         g.consume([gpu_ctx.Array.from_numpy(np.arange(100_000, dtype=np.int64))])
 
 
-@_grouper_on_gpu
 @pytest.mark.parametrize("dtypes,n,card,null_p", [((np.int64,), 1_500_000, 200_000, 0.05),
                                                   ((np.int32, np.int32), 1_500_000, 800, 0.1),
                                                   ((np.int64, np.int16), 600_000, 500_000, 0.0)])
