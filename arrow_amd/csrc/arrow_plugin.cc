@@ -82,6 +82,7 @@ namespace {
 #include "plugin/sort.inc"
 #include "plugin/cast.inc"
 #include "plugin/hash_aggregate.inc"
+#include "plugin/hash_aggregate_more.inc"
 #include "plugin/scalar_aggregate.inc"
 #include "plugin/acero_node.inc"
 #include "plugin/order_by_node.inc"

@@ -606,6 +606,93 @@ __global__ __launch_bounds__(kBlock) void hash_mean_dense_finalize_kernel(
   }
 }
 
+// hash_min / hash_max / hash_min_max over dense group ids — GroupedMinMaxImpl (kernels/hash_aggregate.cc:330-419):
+// per group a running minimum and maximum (initialised to the anti-extrema by Resize, :343-353), "saw a null".  A group
+// that saw no value keeps min = INT64_MAX > max = INT64_MIN, which is how Finalize tells (has_values_).  A plain read
+// comes first and the atomic only runs when it would change something — after a group's first few rows almost none does.
+__global__ __launch_bounds__(kBlock) void hash_minmax_dense_fill_kernel(long long* __restrict__ mins, long long* __restrict__ maxs,
+                                                                        int64_t first, int64_t count) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < count; i += stride) {
+    mins[first + i] = INT64_MAX;
+    maxs[first + i] = INT64_MIN;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hash_minmax_dense_consume_kernel(
+    const int64_t* __restrict__ values, int64_t scalar_value, int values_is_scalar, Bits vvalid,
+    const uint32_t* __restrict__ group_ids, int64_t n, long long* __restrict__ mins, long long* __restrict__ maxs,
+    unsigned int* __restrict__ null_seen) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t g = group_ids[i];
+    const bool ok = (load_word(vvalid, i >> 6) >> (i & 63)) & 1ull;
+    if (ok) {
+      const long long v = values_is_scalar ? scalar_value : values[i];
+      if (v < __hip_atomic_load(&mins[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mins[g], v);
+      if (v > __hip_atomic_load(&maxs[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxs[g], v);
+    } else if ((__hip_atomic_load(&null_seen[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) == 0) {
+      atomicOr(&null_seen[g], 1u);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hash_minmax_dense_merge_kernel(
+    const int64_t* __restrict__ other_mins, const int64_t* __restrict__ other_maxs,
+    const uint32_t* __restrict__ other_null_seen, const uint32_t* __restrict__ mapping, int64_t n,
+    long long* __restrict__ mins, long long* __restrict__ maxs, unsigned int* __restrict__ null_seen) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t g = mapping[i];
+    atomicMin(&mins[g], static_cast<long long>(other_mins[i]));
+    atomicMax(&maxs[g], static_cast<long long>(other_maxs[i]));
+    if (other_null_seen[i] & 1u) atomicOr(&null_seen[g], 1u);
+  }
+}
+
+// bit g = group g saw a value && (skip_nulls || saw no null)   (Finalize, hash_aggregate.cc:401-419)
+__global__ __launch_bounds__(kBlock) void hash_minmax_dense_finalize_kernel(
+    const int64_t* __restrict__ mins, const int64_t* __restrict__ maxs, const uint32_t* __restrict__ null_seen, int64_t n,
+    int skip_nulls, uint64_t* __restrict__ out_bits, unsigned long long* __restrict__ valid_count) {
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwords = (n + 63) >> 6;
+  uint64_t nvalid = 0;
+  for (int64_t w = wave_g; w < nwords; w += nwaves) {
+    const int64_t i = (w << 6) + lane;
+    bool ok = false;
+    if (i < n) {
+      ok = mins[i] <= maxs[i];
+      if (!skip_nulls) ok = ok && (null_seen[i] & 1u) == 0;
+    }
+    const uint64_t bal = __ballot(ok);
+    if (lane == 0) out_bits[w] = bal;
+    nvalid += __popcll(bal);
+  }
+  if (valid_count != nullptr && lane == 0 && nvalid != 0) atomicAdd(valid_count, nvalid);
+}
+
+// hash_count over dense group ids — GroupedCountImpl::Consume (kernels/hash_aggregate.cc:107-212): counts[g] += 1 for
+// every row of group g that is valid (ONLY_VALID), null (ONLY_NULL) or either (ALL); the value type does not matter.
+__global__ __launch_bounds__(kBlock) void hash_count_dense_consume_kernel(Bits vvalid, int mode, const uint32_t* __restrict__ group_ids,
+                                                                          int64_t n, unsigned long long* __restrict__ counts) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool ok = (load_word(vvalid, i >> 6) >> (i & 63)) & 1ull;
+    if (mode == 2 || (mode == 0) == ok) atomicAdd(&counts[group_ids[i]], 1ull);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hash_count_dense_merge_kernel(const int64_t* __restrict__ other_counts,
+                                                                        const uint32_t* __restrict__ mapping, int64_t n,
+                                                                        unsigned long long* __restrict__ counts) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    atomicAdd(&counts[mapping[i]], static_cast<unsigned long long>(other_counts[i]));
+  }
+}
+
 static inline unsigned gb_grid(int64_t n) {
   return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock), 256 * 16)));
 }
@@ -2025,6 +2112,141 @@ int arx_hash_sum_i64_consume(const ArxSpan* values, int values_is_scalar, int64_
                      reinterpret_cast<unsigned long long*>(sums),
                      reinterpret_cast<unsigned long long*>(counts), null_seen);
   ARX_CHECK_LAUNCH("hash_sum_dense_consume_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_minmax_i64_fill(int64_t* mins, int64_t* maxs, int64_t first_group, int64_t num_new_groups, void* stream) {
+  if (num_new_groups < 0 || first_group < 0 || (num_new_groups > 0 && (mins == nullptr || maxs == nullptr))) {
+    set_error("bad arguments to arx_hash_minmax_i64_fill");
+    return ARX_INVALID;
+  }
+  if (num_new_groups == 0) return ARX_OK;
+  hipLaunchKernelGGL(hash_minmax_dense_fill_kernel, dim3(gb_grid(num_new_groups)), dim3(kBlock), 0, as_stream(stream),
+                     reinterpret_cast<long long*>(mins), reinterpret_cast<long long*>(maxs), first_group, num_new_groups);
+  ARX_CHECK_LAUNCH("hash_minmax_dense_fill_kernel");
+  return ARX_OK;
+}
+
+// values / scalar conventions of arx_hash_sum_i64_consume
+static int dense_values(const char* what, const ArxSpan* values, int values_is_scalar, const uint32_t* group_ids,
+                        int64_t length, const int64_t** v, Bits* vb) {
+  if (values == nullptr || length < 0) {
+    set_error("bad arguments to %s", what);
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  if (group_ids == nullptr || (!values_is_scalar && values->data == nullptr)) {
+    set_error("NULL buffer passed to %s", what);
+    return ARX_INVALID;
+  }
+  if (!values_is_scalar && values->length != length) {
+    set_error("Array arguments must all be the same length (values %lld vs group ids %lld)",
+              static_cast<long long>(values->length), static_cast<long long>(length));
+    return ARX_INVALID;
+  }
+  *v = values_is_scalar ? nullptr : static_cast<const int64_t*>(values->data) + values->offset;
+  *vb = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, length);
+  if (values_is_scalar && values->null_count != 0) {   // a null scalar: every row reads as null
+    vb->base = nullptr;
+    vb->length = 0;
+  }
+  return ARX_OK;
+}
+
+int arx_hash_minmax_i64_consume(const ArxSpan* values, int values_is_scalar, int64_t scalar_value, const uint32_t* group_ids,
+                                int64_t length, int64_t* mins, int64_t* maxs, uint32_t* null_seen, void* stream) {
+  const int64_t* v = nullptr;
+  Bits vb{};
+  const int rc = dense_values("arx_hash_minmax_i64_consume", values, values_is_scalar, group_ids, length, &v, &vb);
+  if (rc != ARX_OK || length == 0) return rc;
+  if (mins == nullptr || maxs == nullptr || null_seen == nullptr) {
+    set_error("NULL state passed to arx_hash_minmax_i64_consume");
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(hash_minmax_dense_consume_kernel, dim3(gb_grid(length)), dim3(kBlock), 0, as_stream(stream), v,
+                     scalar_value, values_is_scalar, vb, group_ids, length, reinterpret_cast<long long*>(mins),
+                     reinterpret_cast<long long*>(maxs), null_seen);
+  ARX_CHECK_LAUNCH("hash_minmax_dense_consume_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_minmax_i64_merge(int64_t* mins, int64_t* maxs, uint32_t* null_seen, const int64_t* other_mins,
+                              const int64_t* other_maxs, const uint32_t* other_null_seen, const uint32_t* group_id_mapping,
+                              int64_t other_num_groups, void* stream) {
+  if (other_num_groups < 0) {
+    set_error("bad arguments to arx_hash_minmax_i64_merge");
+    return ARX_INVALID;
+  }
+  if (other_num_groups == 0) return ARX_OK;
+  if (mins == nullptr || maxs == nullptr || null_seen == nullptr || other_mins == nullptr || other_maxs == nullptr ||
+      other_null_seen == nullptr || group_id_mapping == nullptr) {
+    set_error("NULL buffer passed to arx_hash_minmax_i64_merge");
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(hash_minmax_dense_merge_kernel, dim3(gb_grid(other_num_groups)), dim3(kBlock), 0, as_stream(stream),
+                     other_mins, other_maxs, other_null_seen, group_id_mapping, other_num_groups,
+                     reinterpret_cast<long long*>(mins), reinterpret_cast<long long*>(maxs), null_seen);
+  ARX_CHECK_LAUNCH("hash_minmax_dense_merge_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_minmax_i64_finalize(const int64_t* mins, const int64_t* maxs, const uint32_t* null_seen, int64_t num_groups,
+                                 int skip_nulls, void* out_validity, int64_t* valid_count, void* stream) {
+  if (num_groups < 0) {
+    set_error("bad arguments to arx_hash_minmax_i64_finalize");
+    return ARX_INVALID;
+  }
+  if (num_groups == 0) return ARX_OK;
+  if (mins == nullptr || maxs == nullptr || null_seen == nullptr || out_validity == nullptr) {
+    set_error("NULL buffer passed to arx_hash_minmax_i64_finalize");
+    return ARX_INVALID;
+  }
+  const int64_t nwords = ceil_div(num_groups, 64);
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(nwords, kWavesPerBlock), 256 * 8)));
+  hipLaunchKernelGGL(hash_minmax_dense_finalize_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), mins, maxs, null_seen,
+                     num_groups, skip_nulls, static_cast<uint64_t*>(out_validity),
+                     reinterpret_cast<unsigned long long*>(valid_count));
+  ARX_CHECK_LAUNCH("hash_minmax_dense_finalize_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_count_consume(const void* values_validity, int64_t values_offset, int64_t values_null_count, int mode,
+                           const uint32_t* group_ids, int64_t length, int64_t* counts, void* stream) {
+  if (length < 0 || mode < 0 || mode > 2) {
+    set_error("bad arguments to arx_hash_count_consume");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  if (group_ids == nullptr || counts == nullptr) {
+    set_error("NULL buffer passed to arx_hash_count_consume");
+    return ARX_INVALID;
+  }
+  // values_null_count != 0 with a NULL bitmap = a null broadcast scalar: every row is null
+  Bits vb = make_bits(values_null_count != 0 ? values_validity : nullptr, values_offset, length);
+  if (values_null_count != 0 && values_validity == nullptr) {
+    vb.base = nullptr;
+    vb.length = 0;
+  }
+  hipLaunchKernelGGL(hash_count_dense_consume_kernel, dim3(gb_grid(length)), dim3(kBlock), 0, as_stream(stream), vb, mode,
+                     group_ids, length, reinterpret_cast<unsigned long long*>(counts));
+  ARX_CHECK_LAUNCH("hash_count_dense_consume_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_count_merge(int64_t* counts, const int64_t* other_counts, const uint32_t* group_id_mapping,
+                         int64_t other_num_groups, void* stream) {
+  if (other_num_groups < 0) {
+    set_error("bad arguments to arx_hash_count_merge");
+    return ARX_INVALID;
+  }
+  if (other_num_groups == 0) return ARX_OK;
+  if (counts == nullptr || other_counts == nullptr || group_id_mapping == nullptr) {
+    set_error("NULL buffer passed to arx_hash_count_merge");
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(hash_count_dense_merge_kernel, dim3(gb_grid(other_num_groups)), dim3(kBlock), 0, as_stream(stream),
+                     other_counts, group_id_mapping, other_num_groups, reinterpret_cast<unsigned long long*>(counts));
+  ARX_CHECK_LAUNCH("hash_count_dense_merge_kernel");
   return ARX_OK;
 }
 

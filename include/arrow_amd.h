@@ -668,6 +668,33 @@ int arx_hash_sum_i64_consume_ws(const ArxSpan* values, int values_is_scalar, int
 int arx_hash_mean_i64_finalize(const int64_t* sums, const int64_t* counts, int64_t num_groups, uint64_t abs_bound,
                                double* out_means, uint32_t* inexact, void* stream);
 
+/* hash_min / hash_max / hash_min_max(int64, uint32 group id) — GroupedMinMaxImpl (compute/kernels/hash_aggregate.cc:
+ * 330-419) on dense state arrays the caller owns: mins / maxs (arx_hash_minmax_i64_fill sets the anti-extrema of new
+ * groups — Resize, :343-353), null_seen (zero-initialised; bit 0 = a null value hit the group).  Consume :355-379, Merge
+ * :381-399, Finalize :401-419: out_validity bit g = the group saw a value && (skip_nulls || saw no null) — min_count is
+ * not consulted by the reference either; the data of a null group keeps the anti-extremum.  values / scalar conventions
+ * of arx_hash_sum_i64_consume.  All asynchronous. */
+int arx_hash_minmax_i64_fill(int64_t* mins, int64_t* maxs, int64_t first_group, int64_t num_new_groups, void* stream);
+int arx_hash_minmax_i64_consume(const ArxSpan* values, int values_is_scalar, int64_t scalar_value, const uint32_t* group_ids,
+                                int64_t length, int64_t* mins, int64_t* maxs, uint32_t* null_seen, void* stream);
+int arx_hash_minmax_i64_merge(int64_t* mins, int64_t* maxs, uint32_t* null_seen, const int64_t* other_mins,
+                              const int64_t* other_maxs, const uint32_t* other_null_seen, const uint32_t* group_id_mapping,
+                              int64_t other_num_groups, void* stream);
+int arx_hash_minmax_i64_finalize(const int64_t* mins, const int64_t* maxs, const uint32_t* null_seen, int64_t num_groups,
+                                 int skip_nulls, void* out_validity, int64_t* valid_count, void* stream);
+/* hash_count(any, uint32 group id) — GroupedCountImpl (compute/kernels/hash_aggregate.cc:107-212): counts[g] += 1 for
+ * the rows of group g whose value is valid (mode 0, CountOptions::ONLY_VALID), null (1, ONLY_NULL) or either (2, ALL).
+ * Only the values' validity is read: values_validity + values_offset (NULL: no nulls; values_null_count != 0 with a
+ * NULL bitmap: a null broadcast scalar, every row null).  counts: dense, caller-owned, zero-initialised.  Merge adds
+ * other_counts[i] to counts[group_id_mapping[i]] (:156-170); Finalize is the counts array itself, never null. */
+#define ARX_COUNT_ONLY_VALID 0
+#define ARX_COUNT_ONLY_NULL 1
+#define ARX_COUNT_ALL 2
+int arx_hash_count_consume(const void* values_validity, int64_t values_offset, int64_t values_null_count, int mode,
+                           const uint32_t* group_ids, int64_t length, int64_t* counts, void* stream);
+int arx_hash_count_merge(int64_t* counts, const int64_t* other_counts, const uint32_t* group_id_mapping,
+                         int64_t other_num_groups, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Grouper: key rows of one or several fixed-width columns -> dense group ids.
  * arrow::compute::Grouper (cpp/src/arrow/compute/row/grouper.h:104-137): Consume :121, Lookup :126, GetUniques :134,

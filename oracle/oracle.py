@@ -731,6 +731,92 @@ class HashSumState:
         return self.sums.copy(), v[: self.num_groups].astype(bool), int(nulls)
 
 
+def _valid_rows(val_valid, val_off, n):
+    """bool[n] from a validity bitmap (None: all valid) at bit offset val_off."""
+    if val_valid is None:
+        return np.ones(n, bool)
+    bits = np.unpackbits(np.frombuffer(np.ascontiguousarray(val_valid), np.uint8), bitorder="little")
+    return bits[val_off:val_off + n].astype(bool)
+
+
+class HashMinMaxState:
+    """GroupedMinMaxImpl<Int64Type> with dense group ids (kernels/hash_aggregate.cc:330-419): Resize :343-353 (new
+    groups start at the anti-extrema, no value / no null seen), Consume :355-379, Merge :381-399, Finalize :401-419
+    (a group is null when it saw no value, or — !skip_nulls — saw a null; min_count is not consulted).  Plain numpy."""
+
+    def __init__(self, skip_nulls=True):
+        self.skip_nulls = bool(skip_nulls)
+        self.mins = np.zeros(0, np.int64)
+        self.maxs = np.zeros(0, np.int64)
+        self.has_values = np.zeros(0, bool)
+        self.has_nulls = np.zeros(0, bool)
+
+    @property
+    def num_groups(self):
+        return len(self.mins)
+
+    def resize(self, n):
+        add = n - self.num_groups
+        self.mins = np.concatenate([self.mins, np.full(add, np.iinfo(np.int64).max, np.int64)])
+        self.maxs = np.concatenate([self.maxs, np.full(add, np.iinfo(np.int64).min, np.int64)])
+        self.has_values = np.concatenate([self.has_values, np.zeros(add, bool)])
+        self.has_nulls = np.concatenate([self.has_nulls, np.zeros(add, bool)])
+
+    def consume(self, values, val_valid, val_off, group_ids, scalar=None):
+        gids = np.asarray(group_ids, dtype=np.int64)
+        n = len(gids)
+        if scalar is None:
+            ok = _valid_rows(val_valid, val_off, n)
+            v = np.asarray(values)[val_off:val_off + n]
+        else:
+            ok = np.full(n, bool(scalar[1]))
+            v = np.full(n, int(scalar[0]), np.int64)
+        np.minimum.at(self.mins, gids[ok], v[ok])
+        np.maximum.at(self.maxs, gids[ok], v[ok])
+        self.has_values[gids[ok]] = True
+        self.has_nulls[gids[~ok]] = True
+
+    def merge(self, other: "HashMinMaxState", mapping):
+        m = np.asarray(mapping, dtype=np.int64)
+        np.minimum.at(self.mins, m, other.mins)
+        np.maximum.at(self.maxs, m, other.maxs)
+        np.logical_or.at(self.has_values, m, other.has_values)
+        np.logical_or.at(self.has_nulls, m, other.has_nulls)
+
+    def finalize(self):
+        """(mins, maxs, valid bool[G])."""
+        valid = self.has_values.copy()
+        if not self.skip_nulls:
+            valid &= ~self.has_nulls
+        return self.mins.copy(), self.maxs.copy(), valid
+
+
+class HashCountState:
+    """GroupedCountImpl with dense group ids (kernels/hash_aggregate.cc:107-212): mode "only_valid" / "only_null" /
+    "all" (CountOptions::CountMode); Merge adds (:156-170); the result is never null.  Plain numpy."""
+
+    def __init__(self, mode="only_valid"):
+        self.mode = mode
+        self.counts = np.zeros(0, np.int64)
+
+    @property
+    def num_groups(self):
+        return len(self.counts)
+
+    def resize(self, n):
+        self.counts = np.concatenate([self.counts, np.zeros(n - self.num_groups, np.int64)])
+
+    def consume(self, val_valid, val_off, group_ids, scalar_valid=None):
+        gids = np.asarray(group_ids, dtype=np.int64)
+        n = len(gids)
+        ok = _valid_rows(val_valid, val_off, n) if scalar_valid is None else np.full(n, bool(scalar_valid))
+        take = np.ones(n, bool) if self.mode == "all" else (ok if self.mode == "only_valid" else ~ok)
+        np.add.at(self.counts, gids[take], 1)
+
+    def merge(self, other: "HashCountState", mapping):
+        np.add.at(self.counts, np.asarray(mapping, dtype=np.int64), other.counts)
+
+
 def delta_binary_packed_encode(values, block_size: int = 128, miniblocks: int = 4) -> bytes:
     """A writer of DELTA_BINARY_PACKED (Encodings.md "Delta encoding"; DeltaBitPackEncoder, parquet/encoder.cc)
     for tests: any block size / miniblock count the format allows, int64 arithmetic modulo 2**64, trailing

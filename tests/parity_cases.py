@@ -1648,6 +1648,114 @@ def check_buffer_copy(amd, rng, scale=1):
     assert_equal(out.cpu().numpy()[: len(src_h)], src_h, "copy_buffer")
 
 
+def check_hash_minmax_count_kernels(amd, rng, n=5000, num_groups=37, null_p=0.2):
+    """The dense-id state kernels behind hash_min / hash_max / hash_min_max / hash_count, driven through the C ABI the
+    way GroupByNode drives a HashAggregateKernel: two states, resize (fill), consume (arrays at offsets, a broadcast
+    scalar, a null scalar), merge through a group_id_mapping, finalize; against the oracle's restatement and, end to
+    end, against pyarrow's own hash_min_max / hash_count on the same rows."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+    vals = util.random_array(rng, np.int64, n, null_p=null_p, offset=3)
+    vals_b = util.random_array(rng, np.int64, n, null_p=null_p, offset=0)
+    gid_a = rng.integers(0, num_groups, size=n).astype(np.uint32)
+    nb = max(1, num_groups // 2)
+    perm = rng.permutation(num_groups)[:nb].astype(np.uint32)
+    gid_b = rng.integers(0, nb, size=n).astype(np.uint32)
+    dva, dvb = vals.to_device(amd), vals_b.to_device(amd)
+    dga, dgb, dperm = to_device(gid_a, dev), to_device(gid_b, dev), to_device(perm, dev)
+
+    def state(g):
+        mins = torch.zeros(g, dtype=torch.int64, device=dev)
+        maxs = torch.zeros(g, dtype=torch.int64, device=dev)
+        seen = torch.zeros(g, dtype=torch.int32, device=dev)
+        return mins, maxs, seen
+
+    half = num_groups // 2 + 1
+    a_mins, a_maxs, a_seen = state(num_groups)
+    _lib.check(lib.arx_hash_minmax_i64_fill(a_mins.data_ptr(), a_maxs.data_ptr(), 0, min(half, num_groups), st))    # Resize in
+    _lib.check(lib.arx_hash_minmax_i64_fill(a_mins.data_ptr(), a_maxs.data_ptr(), min(half, num_groups),             # two steps
+                                            num_groups - min(half, num_groups), st))
+    b_mins, b_maxs, b_seen = state(nb)
+    _lib.check(lib.arx_hash_minmax_i64_fill(b_mins.data_ptr(), b_maxs.data_ptr(), 0, nb, st))
+    sp_a, sp_b = dva.span(), dvb.span()
+    _lib.check(lib.arx_hash_minmax_i64_consume(C.byref(sp_a), 0, 0, dga.data_ptr(), n, a_mins.data_ptr(), a_maxs.data_ptr(),
+                                               a_seen.data_ptr(), st))
+    _lib.check(lib.arx_hash_minmax_i64_consume(C.byref(sp_b), 0, 0, dgb.data_ptr(), n, b_mins.data_ptr(), b_maxs.data_ptr(),
+                                               b_seen.data_ptr(), st))
+    scal = _lib.ArxSpan(None, None, 0, 100, 0)
+    _lib.check(lib.arx_hash_minmax_i64_consume(C.byref(scal), 1, -7, dgb.data_ptr(), min(100, n), b_mins.data_ptr(),
+                                               b_maxs.data_ptr(), b_seen.data_ptr(), st))
+    nul = _lib.ArxSpan(None, None, 0, 3, 3)
+    _lib.check(lib.arx_hash_minmax_i64_consume(C.byref(nul), 1, 0, dgb.data_ptr() + 4 * min(100, n - 3), 3, b_mins.data_ptr(),
+                                               b_maxs.data_ptr(), b_seen.data_ptr(), st))
+    _lib.check(lib.arx_hash_minmax_i64_merge(a_mins.data_ptr(), a_maxs.data_ptr(), a_seen.data_ptr(), b_mins.data_ptr(),
+                                             b_maxs.data_ptr(), b_seen.data_ptr(), dperm.data_ptr(), nb, st))
+    oa, ob = O.HashMinMaxState(), O.HashMinMaxState()
+    oa.resize(num_groups)
+    ob.resize(nb)
+    oa.consume(vals.values, vals.valid_bitmap(), vals.offset, gid_a)
+    ob.consume(vals_b.values, vals_b.valid_bitmap(), vals_b.offset, gid_b)
+    ob.consume(None, None, 0, gid_b[:100], scalar=(-7, True))
+    ob.consume(None, None, 0, gid_b[min(100, n - 3):min(100, n - 3) + 3], scalar=(0, False))
+    oa.merge(ob, perm)
+    for skip_nulls in (True, False):
+        oa.skip_nulls = skip_nulls
+        wmin, wmax, wvalid = oa.finalize()
+        bits = torch.zeros((num_groups + 63) // 64, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        _lib.check(lib.arx_hash_minmax_i64_finalize(a_mins.data_ptr(), a_maxs.data_ptr(), a_seen.data_ptr(), num_groups,
+                                                    int(skip_nulls), bits.data_ptr(), cnt.data_ptr(), st))
+        got_valid = np.unpackbits(bits.cpu().numpy().view(np.uint8), bitorder="little")[:num_groups].astype(bool)
+        tag = f"hash_minmax[n={n},G={num_groups},skip_nulls={skip_nulls}]"
+        assert_equal(got_valid, wvalid, tag + " validity")
+        assert int(cnt.item()) == int(wvalid.sum()), tag + " valid count"
+        assert_equal(a_mins.cpu().numpy()[wvalid], wmin[wvalid], tag + " mins")
+        assert_equal(a_maxs.cpu().numpy()[wvalid], wmax[wvalid], tag + " maxs")
+    # ---- hash_count, the three modes
+    for mode, name in ((0, "only_valid"), (1, "only_null"), (2, "all")):
+        ca = torch.zeros(num_groups, dtype=torch.int64, device=dev)
+        cb = torch.zeros(nb, dtype=torch.int64, device=dev)
+        va = dva.validity.data_ptr() if dva.validity is not None and dva.null_count != 0 else None
+        vb = dvb.validity.data_ptr() if dvb.validity is not None and dvb.null_count != 0 else None
+        _lib.check(lib.arx_hash_count_consume(va, dva.offset, dva.null_count, mode, dga.data_ptr(), n, ca.data_ptr(), st))
+        _lib.check(lib.arx_hash_count_consume(vb, dvb.offset, dvb.null_count, mode, dgb.data_ptr(), n, cb.data_ptr(), st))
+        _lib.check(lib.arx_hash_count_consume(None, 0, 5, mode, dgb.data_ptr(), min(5, n), cb.data_ptr(), st))   # null scalar
+        _lib.check(lib.arx_hash_count_consume(None, 0, 0, mode, dgb.data_ptr(), min(7, n), cb.data_ptr(), st))   # valid scalar
+        _lib.check(lib.arx_hash_count_merge(ca.data_ptr(), cb.data_ptr(), dperm.data_ptr(), nb, st))
+        ha, hb = O.HashCountState(name), O.HashCountState(name)
+        ha.resize(num_groups)
+        hb.resize(nb)
+        ha.consume(vals.valid_bitmap(), vals.offset, gid_a)
+        hb.consume(vals_b.valid_bitmap(), vals_b.offset, gid_b)
+        hb.consume(None, 0, gid_b[:5], scalar_valid=False)
+        hb.consume(None, 0, gid_b[:7], scalar_valid=True)
+        ha.merge(hb, perm)
+        assert_equal(ca.cpu().numpy(), ha.counts, f"hash_count[{name},n={n},G={num_groups}]")
+    # ---- the oracle itself against the reference (pyarrow's hash kernels on the rows of state A)
+    if pa is not None and n > 0:
+        o1 = O.HashMinMaxState()
+        o1.resize(num_groups)
+        o1.consume(vals.values, vals.valid_bitmap(), vals.offset, gid_a)
+        t = pa.table({"g": pa.array(gid_a), "v": vals.to_pyarrow()})
+        r = t.group_by("g", use_threads=False).aggregate([("v", "min"), ("v", "max"), ("v", "count")]).sort_by("g")
+        gs = r.column("g").to_numpy()
+        mn, mx, valid = o1.finalize()
+        assert_equal(valid[gs], ~np.asarray(r.column("v_min").is_null()), "oracle hash_min validity vs pyarrow")
+        sel = valid[gs]
+        assert_equal(mn[gs][sel], r.column("v_min").drop_null().to_numpy(), "oracle hash_min vs pyarrow")
+        assert_equal(mx[gs][sel], r.column("v_max").drop_null().to_numpy(), "oracle hash_max vs pyarrow")
+        h1 = O.HashCountState("only_valid")
+        h1.resize(num_groups)
+        h1.consume(vals.valid_bitmap(), vals.offset, gid_a)
+        assert_equal(h1.counts[gs], r.column("v_count").to_numpy(), "oracle hash_count vs pyarrow")
+
+
 def check_bitmap_copy_segments(amd, rng, scale=1):
     """arx_bitmap_copy_segments: bit ranges at any source bit offset ORed into zeroed bitmaps back to back (ranges meet
     inside words), NULL sources (= all ones), empty ranges, two destination bitmaps in one launch."""

@@ -929,6 +929,11 @@ def test_copy_segments_any_alignment(emu_ctx):
     P.check_copy_segments(emu_ctx, rng_for("copyseg"), 1)
 
 
+@pytest.mark.parametrize("n,num_groups,null_p", [(4000, 37, 0.2), (2000, 5, 0.0), (300, 1, 1.0)])
+def test_hash_minmax_and_count_dense_kernels(emu_ctx, n, num_groups, null_p):
+    P.check_hash_minmax_count_kernels(emu_ctx, rng_for("hmmc", n, num_groups), n=n, num_groups=num_groups, null_p=null_p)
+
+
 def test_buffer_copy(emu_ctx):
     P.check_buffer_copy(emu_ctx, rng_for("bufcopy"), 1)
 

@@ -87,6 +87,91 @@ SCRIPT = textwrap.dedent(r'''
 ''')
 
 
+HASH_KERNELS_SCRIPT = textwrap.dedent(r'''
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    from pyarrow import acero
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    path = build_plugin()
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":
+        pa.set_cpu_count(1)      # the SIMT emulator runs one kernel at a time: thread-local states and Merge still happen
+        pa.set_io_thread_count(1)  # (use_threads=True), their consumes just never overlap
+    rng = np.random.default_rng(31)
+    n = SC(1_500_000)
+    k = pa.array(rng.integers(-400, 400, n), mask=rng.random(n) < 0.01)              # int64 keys: the stock CPU Grouper
+    v = pa.array(rng.integers(-2**40, 2**40, n), mask=rng.random(n) < 0.15)
+    big = pa.array(rng.integers(-2**62, 2**62, n), mask=rng.random(n) < 0.15)        # partial sums beyond 2^53
+    s = pa.array([("x%d" % (i % 97)) if i % 7 else None for i in range(n)])
+    f = pa.array(rng.standard_normal(n), mask=rng.random(n) < 0.3)
+    t = pa.table({"k": k, "v": v, "big": big, "s": s, "f": f})
+    tc = pa.concat_tables([t.slice(0, n // 3), t.slice(n // 3, n // 5), t.slice(n // 3 + n // 5)])   # several chunks
+    strict = pc.ScalarAggregateOptions(skip_nulls=False, min_count=2)
+    aggs = [("v", "min"), ("v", "max"), ("v", "mean"), ("big", "mean"), ("v", "count"),
+            ("v", "count", pc.CountOptions(mode="only_null")), ("v", "count", pc.CountOptions(mode="all")),
+            ("s", "count"), ("f", "count", pc.CountOptions(mode="only_null")),
+            ("v", "min", strict), ("v", "max", strict), ("v", "mean", strict), ("v", "sum")]
+    def run(tab, threads):
+        return tab.group_by("k", use_threads=threads).aggregate(aggs).sort_by("k")
+    # ---- the reference kernels first: registering the plugin re-routes these very calls
+    want = {(name, threads): run(tab, threads) for name, tab in (("t", t), ("tc", tc)) for threads in (False, True)}
+    lib = ctypes.CDLL(path)
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    gpu0, stock0 = lib.arrow_amd_plugin_calls(b"hash_sum", 1), lib.arrow_amd_plugin_calls(b"hash_sum", 0)
+    for (name, threads), w in want.items():
+        got = run(t if name == "t" else tc, threads)
+        assert got.schema.equals(w.schema), (got.schema, w.schema)
+        for col in range(w.num_columns):      # (by position: several aggregates of one column share their name)
+            assert got.column(col).equals(w.column(col)), (name, threads, w.schema.names[col], got.column(col).slice(0, 5), w.column(col).slice(0, 5))
+    gpu1, stock1 = lib.arrow_amd_plugin_calls(b"hash_sum", 1), lib.arrow_amd_plugin_calls(b"hash_sum", 0)
+    assert gpu1 - gpu0 >= 4 * 10, ("the hash_* vtables did not run on the device", gpu0, gpu1)
+    assert stock1 > stock0, "hash_mean of HOST values is the reference kernel's (bit-exact whatever the magnitudes)"
+
+    # ---- device-resident VALUE columns under the stock GroupByNode (host keys -> CPU Grouper -> ids; values in HBM)
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(m) for m in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+    m = SC(400_000)
+    th = t.slice(0, m).combine_chunks()
+    td = pa.table({"k": th.column("k").chunk(0), "v": to_device(th.column("v").chunk(0))})
+    daggs = [("v", "hash_min", None, "mn"), ("v", "hash_max", None, "mx"), ("v", "hash_mean", None, "me"),
+             ("v", "hash_count", None, "c"), ("v", "hash_count", pc.CountOptions(mode="only_null"), "cn"),
+             ("v", "hash_sum", None, "sm")]
+    def plan(tab):
+        return acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
+            acero.Declaration("aggregate", acero.AggregateNodeOptions(daggs, keys=["k"]))]).to_table(use_threads=False).sort_by("k")
+    wd = want[("t", False)]     # not the same rows: recompute the expectation on the slice with the (now plugged) host route,
+    wh = plan(pa.table({"k": th.column("k"), "v": th.column("v")}))   # which was just shown equal to the reference
+    stock2 = lib.arrow_amd_plugin_calls(b"hash_sum", 0)
+    gd = plan(td)
+    assert lib.arrow_amd_plugin_calls(b"hash_sum", 0) == stock2, "device-resident values must not reach a reference kernel"
+    for col in wh.schema.names:
+        assert gd.column(col).equals(wh.column(col)), (col, gd.column(col).slice(0, 5), wh.column(col).slice(0, 5))
+    # partial sums beyond 2^53 on the device route: refused loudly, not approximated
+    tb = pa.table({"k": th.column("k").chunk(0), "v": to_device(th.column("big").chunk(0))})
+    try:
+        acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tb)),
+            acero.Declaration("aggregate", acero.AggregateNodeOptions([("v", "hash_mean", None, "me")], keys=["k"]))]).to_table(use_threads=False)
+        raise SystemExit("hash_mean beyond 2^53 on device values did not fail")
+    except pa.ArrowNotImplementedError as e:
+        assert "2^53" in str(e), e
+    print("HASH_KERNELS_OK")
+''')
+
+
 def test_pyarrow_compute_dispatches_to_the_hip_kernels():
     pytest.importorskip("pyarrow")
     code = f"ROOT = {ROOT!r}\n" + SCRIPT
@@ -1624,3 +1709,19 @@ def test_parquet_delta_and_split_encodings_through_the_plugin():
     code = f"ROOT = {ROOT!r}\n" + PARQUET_ENCODINGS_SCRIPT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "PARQUET_ENCODINGS_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def _run(script, marker):
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + script
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and marker in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_hash_count_min_max_mean_vtables_under_the_stock_group_by_node():
+    """hash_count (three CountOptions modes, any value type with a physical bitmap) / hash_min / hash_max / hash_mean as
+    HashAggregateKernel vtables: the STOCK GroupByNode (pyarrow Table.group_by, Acero "aggregate") lands on the HIP
+    kernels — results equal to the reference kernels' taken before registration, single- and multi-threaded (Merge),
+    host and device-resident value columns; hash_mean keeps the reference kernel for host values and refuses device
+    values whose partial sums pass 2^53."""
+    _run(HASH_KERNELS_SCRIPT, "HASH_KERNELS_OK")

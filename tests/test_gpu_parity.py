@@ -1270,6 +1270,11 @@ def test_copy_segments_any_alignment(gpu_ctx):
     P.check_copy_segments(gpu_ctx, rng_for("copyseg"), 40)
 
 
+@pytest.mark.parametrize("n,num_groups,null_p", [(2000000, 300000, 0.2), (1000000, 5, 0.0), (300, 1, 1.0)])
+def test_hash_minmax_and_count_dense_kernels(gpu_ctx, n, num_groups, null_p):
+    P.check_hash_minmax_count_kernels(gpu_ctx, rng_for("hmmc", n, num_groups), n=n, num_groups=num_groups, null_p=null_p)
+
+
 def test_buffer_copy(gpu_ctx):
     P.check_buffer_copy(gpu_ctx, rng_for("bufcopy"), 40)
 

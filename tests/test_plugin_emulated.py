@@ -80,3 +80,7 @@ def test_reference_golden_vectors_through_callfunction_emulated():
 
 def test_compare_and_arithmetic_on_every_numeric_type_emulated():
     _run(G.NUMERIC_OPS_SCRIPT, "NUMERIC_OPS_OK", 0.01)
+
+
+def test_hash_count_min_max_mean_vtables_emulated():
+    _run(G.HASH_KERNELS_SCRIPT, "HASH_KERNELS_OK", 0.02)
