@@ -83,6 +83,7 @@ namespace {
 #include "plugin/cast.inc"
 #include "plugin/hash_aggregate.inc"
 #include "plugin/hash_aggregate_more.inc"
+#include "plugin/vector_hash.inc"
 #include "plugin/scalar_aggregate.inc"
 #include "plugin/acero_node.inc"
 #include "plugin/order_by_node.inc"
@@ -148,15 +149,26 @@ int arrow_amd_copy_to_host(struct ArrowDeviceArray* in, struct ArrowSchema* sche
                            struct ArrowSchema* out_schema) {
   auto run = [&]() -> Status {
     ARROW_ASSIGN_OR_RAISE(auto dev, arrow::ImportDeviceArray(in, schema));
-    std::vector<std::shared_ptr<Buffer>> bufs(dev->data()->buffers.size());
-    for (size_t i = 0; i < bufs.size(); ++i) {
-      const auto& b = dev->data()->buffers[i];
-      if (b != nullptr) {
-        ARROW_ASSIGN_OR_RAISE(bufs[i], arrow::MemoryManager::CopyBuffer(b, arrow::default_cpu_memory_manager()));
+    // buffers, children (struct: value_counts) and dictionary (dictionary_encode) alike
+    std::function<arrow::Result<std::shared_ptr<ArrayData>>(const ArrayData&)> to_host =
+        [&](const ArrayData& d) -> arrow::Result<std::shared_ptr<ArrayData>> {
+      std::vector<std::shared_ptr<Buffer>> bufs(d.buffers.size());
+      for (size_t i = 0; i < bufs.size(); ++i) {
+        if (d.buffers[i] != nullptr) {
+          ARROW_ASSIGN_OR_RAISE(bufs[i], arrow::MemoryManager::CopyBuffer(d.buffers[i], arrow::default_cpu_memory_manager()));
+        }
       }
-    }
-    auto data = ArrayData::Make(dev->type(), dev->length(), std::move(bufs), dev->data()->null_count.load(),
-                                dev->offset());
+      auto host = ArrayData::Make(d.type, d.length, std::move(bufs), d.null_count.load(), d.offset);
+      for (const auto& child : d.child_data) {
+        ARROW_ASSIGN_OR_RAISE(auto hc, to_host(*child));
+        host->child_data.push_back(std::move(hc));
+      }
+      if (d.dictionary != nullptr) {
+        ARROW_ASSIGN_OR_RAISE(host->dictionary, to_host(*d.dictionary));
+      }
+      return host;
+    };
+    ARROW_ASSIGN_OR_RAISE(auto data, to_host(*dev->data()));
     return arrow::ExportArray(*arrow::MakeArray(data), out, out_schema);
   };
   const Status st = run();

@@ -284,6 +284,16 @@ __global__ __launch_bounds__(kBlock) void grouper_uniques_kernel(GrouperView v, 
   }
 }
 
+// ids above `pivot` move down by one: DictionaryEncode with null_encoding = MASK drops the null's entry from the
+// dictionary (DictEncodeAction, kernels/vector_hash.cc:173-270), so the groups that appeared after it renumber
+__global__ __launch_bounds__(kBlock) void ids_skip_group_kernel(uint32_t* __restrict__ ids, int64_t n, uint32_t pivot) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    const uint32_t id = ids[i];
+    if (id > pivot) ids[i] = id - 1;
+  }
+}
+
 static int grouper_cols(const ArxSpan* cols, const int32_t* widths, int num_keys, GrouperCols* out, int64_t* length) {
   if (num_keys < 1 || num_keys > kGrouperMaxKeys) {
     set_error("Grouper: 1 to %d key columns (got %d)", kGrouperMaxKeys, num_keys);
@@ -500,6 +510,18 @@ int arx_grouper_lookup(void* state, int64_t max_groups, const ArxSpan* key_colum
   }
   return grouper_run(state, max_groups, key_columns, key_byte_widths, num_keys, ws, ws_bytes, out_group_ids, out_validity, 0,
                      stream);
+}
+
+int arx_group_ids_skip_group(uint32_t* group_ids, int64_t length, uint32_t skipped_id, void* stream) {
+  if (length < 0 || (length > 0 && group_ids == nullptr)) {
+    set_error("bad arguments to arx_group_ids_skip_group");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  hipLaunchKernelGGL(ids_skip_group_kernel, dim3(grouper_grid(length)), dim3(kBlock), 0, as_stream(stream), group_ids, length,
+                     skipped_id);
+  ARX_CHECK_LAUNCH("ids_skip_group_kernel");
+  return ARX_OK;
 }
 
 int arx_grouper_num_groups(void* state, int64_t* out_num_groups, void* stream) {

@@ -722,6 +722,9 @@ int arx_grouper_consume(void* state, int64_t max_groups, const ArxSpan* key_colu
 int arx_grouper_lookup(void* state, int64_t max_groups, const ArxSpan* key_columns, const int32_t* key_byte_widths,
                        int num_keys, void* ws, size_t ws_bytes, uint32_t* out_group_ids, uint8_t* out_validity,
                        void* stream);
+/* group_ids[i] -= 1 where group_ids[i] > skipped_id: the renumbering DictionaryEncode needs when the null's group is
+ * left out of the dictionary (null_encoding MASK; DictEncodeAction, kernels/vector_hash.cc:173-270).  Asynchronous. */
+int arx_group_ids_skip_group(uint32_t* group_ids, int64_t length, uint32_t skipped_id, void* stream);
 int arx_grouper_num_groups(void* state, int64_t* out_num_groups, void* stream);
 /* GetUniques (:134), one key column per call: out_values = num_groups values of key_byte_widths[key_index] bytes in
  * group-id order, out_validity = their validity bitmap (ceil(num_groups/64) words, 8-byte aligned). */

@@ -172,6 +172,148 @@ HASH_KERNELS_SCRIPT = textwrap.dedent(r'''
 ''')
 
 
+VECTOR_HASH_SCRIPT = textwrap.dedent(r'''
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    path = build_plugin()
+    rng = np.random.default_rng(41)
+    n = SC(800_000)
+    def col(dtype, card, null_p, typ=None):
+        if np.issubdtype(dtype, np.floating):
+            pool = rng.standard_normal(card).astype(dtype)
+            pool[: min(4, card)] = [0.0, -0.0, np.nan, np.inf][: min(4, card)]      # bits compared: 0.0 and -0.0 stay apart
+        else:
+            info = np.iinfo(dtype)
+            pool = rng.integers(info.min, info.max, card, dtype=dtype, endpoint=True)
+        v = pool[rng.integers(0, card, n)]
+        return pa.array(v, type=typ, mask=(rng.random(n) < null_p) if null_p else None)
+    cases = {"i64": col(np.int64, 5000, 0.05), "i32": col(np.int32, 70000, 0.0), "u8": col(np.uint8, 200, 0.2),
+             "i16": col(np.int16, 3, 0.5), "u64": col(np.uint64, n, 0.01), "f64": col(np.float64, 900, 0.1),
+             "f32": col(np.float32, 50, 0.0), "ts": col(np.int64, 1000, 0.1, pa.timestamp("us")),
+             "d32": col(np.int32, 1000, 0.02, pa.date32()), "allnull": pa.array([None] * 100, pa.int32()),
+             "empty": pa.array([], pa.int64()), "nullfirst": pa.array([None, 5, None, 7, 5, 9], pa.int64())}
+    enc = pc.DictionaryEncodeOptions(null_encoding="encode")
+    # ---- the reference kernels first (registering re-routes the device calls only, but keep the order honest)
+    want = {}
+    for name, a in cases.items():
+        sl = a.slice(3) if len(a) > 10 else a
+        want[name] = dict(u=pc.unique(a), vc=pc.value_counts(a), de=pc.dictionary_encode(a), dee=pc.dictionary_encode(a, options=enc),
+                          us=pc.unique(sl), des=pc.dictionary_encode(sl), dn=pc.drop_null(a), dns=pc.drop_null(sl))
+        if not pa.types.is_temporal(a.type):
+            want[name].update(nz=pc.indices_nonzero(a), nzs=pc.indices_nonzero(sl))
+    ca = pa.chunked_array([cases["i64"].slice(0, n // 3), cases["i64"].slice(n // 3, n // 2), cases["i64"].slice(n // 3 + n // 2)])
+    want_chunked = dict(u=pc.unique(ca), vc=pc.value_counts(ca), de=pc.dictionary_encode(ca))
+    boolean = pa.array(rng.random(n) < 0.3, mask=rng.random(n) < 0.1)
+    want_bool = dict(nz=pc.indices_nonzero(boolean), nzs=pc.indices_nonzero(boolean.slice(5)), dn=None)
+    num_types = [pa.int8(), pa.uint8(), pa.int16(), pa.uint16(), pa.int32(), pa.uint32(), pa.int64(), pa.uint64(), pa.float32(), pa.float64()]
+    small = pa.array(rng.integers(0, 100, n), mask=rng.random(n) < 0.1)        # fits every numeric type
+    want_cast = {(str(a), str(b)): pc.cast(pc.cast(small, a), b) for a in num_types for b in num_types}
+    wide = pa.array(rng.integers(-2**40, 2**40, n))
+    fr = pa.array(rng.standard_normal(n) * 1000)
+    lib = ctypes.CDLL(path)
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(m) for m in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(m) for m in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    def same(h, w):      # Array.equals with NaN == NaN (floats compare by their bits, like the kernels)
+        if h.type != w.type or len(h) != len(w):
+            return False
+        if pa.types.is_floating(h.type):
+            bits = pa.int64() if h.type == pa.float64() else pa.int32()
+            return h.view(bits).equals(w.view(bits))
+        if pa.types.is_struct(h.type):
+            return all(same(h.field(i), w.field(i)) for i in range(h.type.num_fields))
+        if pa.types.is_dictionary(h.type):
+            return h.indices.equals(w.indices) and same(h.dictionary, w.dictionary)
+        return h.equals(w)
+
+    def check(tag, got, w):
+        assert not got.is_cpu, ("output left the device", tag)
+        h = to_host(got)
+        h.validate(full=True)
+        assert same(h, w), (tag, h.slice(0, 8), w.slice(0, 8), len(h), len(w))
+
+    gpu0 = lib.arrow_amd_plugin_calls(b"unique", 1)
+    for name, a in cases.items():
+        d = to_device(a)
+        ds = d.slice(3) if len(a) > 10 else d
+        w = want[name]
+        check(name + " unique", pc.unique(d), w["u"])
+        check(name + " unique (sliced)", pc.unique(ds), w["us"])
+        check(name + " value_counts", pc.value_counts(d), w["vc"])
+        check(name + " dictionary_encode", pc.dictionary_encode(d), w["de"])
+        check(name + " dictionary_encode (sliced)", pc.dictionary_encode(ds), w["des"])
+        check(name + " dictionary_encode(encode)", pc.dictionary_encode(d, options=enc), w["dee"])
+        if a.null_count or len(a) == 0:
+            # (by name: drop_null is a MetaFunction, replaced in the registry; pyarrow's generated pc.drop_null wrapper
+            #  keeps the Function object it found at import time and would run the reference on HBM addresses)
+            check(name + " drop_null", pc.call_function("drop_null", [d]), w["dn"])
+            check(name + " drop_null (sliced)", pc.call_function("drop_null", [ds]), w["dns"])
+        if not pa.types.is_temporal(a.type):
+            check(name + " indices_nonzero", pc.indices_nonzero(d), w["nz"])
+            check(name + " indices_nonzero (sliced)", pc.indices_nonzero(ds), w["nzs"])
+    assert lib.arrow_amd_plugin_calls(b"unique", 1) - gpu0 >= 6 * (len(cases) - 2), "the hash vector kernels did not run on the device"
+    stock0 = lib.arrow_amd_plugin_calls(b"unique", 0)
+    assert pc.unique(cases["i64"]).equals(want["i64"]["u"]) and lib.arrow_amd_plugin_calls(b"unique", 0) == stock0 + 1   # host: the reference kernel
+    # several device chunks: one Grouper across the chunks (it grows by re-consuming its own uniques)
+    dca = pa.chunked_array([to_device(c) for c in ca.chunks])
+    check("chunked unique", pc.unique(dca), want_chunked["u"])
+    check("chunked value_counts", pc.value_counts(dca), want_chunked["vc"])
+    got = pc.dictionary_encode(dca)
+    assert got.num_chunks == want_chunked["de"].num_chunks
+    for g_chunk, w_chunk in zip(got.chunks, want_chunked["de"].chunks):
+        check("chunked dictionary_encode", g_chunk, w_chunk)
+    d_bool = to_device(boolean)
+    check("bool indices_nonzero", pc.indices_nonzero(d_bool), want_bool["nz"])
+    check("bool indices_nonzero (sliced)", pc.indices_nonzero(d_bool.slice(5)), want_bool["nzs"])
+    # ---- every numeric cast pair on device arrays (arx_cast_numeric), and the reference's refusals
+    c0 = lib.arrow_amd_plugin_calls(b"cast", 1)
+    d_small = {str(a): to_device(pc.cast(small, a)) for a in num_types}
+    for a in num_types:
+        for b in num_types:
+            if a == b:
+                continue
+            check(f"cast {a}->{b}", pc.cast(d_small[str(a)], b), want_cast[(str(a), str(b))])
+            check(f"cast {a}->{b} (sliced)", pc.cast(d_small[str(a)].slice(9), b), want_cast[(str(a), str(b))].slice(9))
+    assert lib.arrow_amd_plugin_calls(b"cast", 1) - c0 >= 150
+    d_wide, d_fr = to_device(wide), to_device(fr)
+    for src, host, target in ((d_wide, wide, pa.int16()), (d_fr, fr, pa.int32()), (d_wide, wide, pa.float32())):
+        try:
+            pc.cast(host, target)
+            raise SystemExit("the reference accepted this cast?")
+        except pa.ArrowInvalid as e:
+            ref_msg = str(e)
+        try:
+            pc.cast(src, target)
+            raise SystemExit(f"unsafe device cast to {target} did not fail")
+        except pa.ArrowInvalid as e:
+            assert str(e).split(" ")[0:2] == ref_msg.split(" ")[0:2], (str(e), ref_msg)
+        check(f"unsafe cast to {target}", pc.cast(src, target, safe=False), pc.cast(host, target, safe=False))
+    print("VECTOR_HASH_OK")
+''')
+
+
 def test_pyarrow_compute_dispatches_to_the_hip_kernels():
     pytest.importorskip("pyarrow")
     code = f"ROOT = {ROOT!r}\n" + SCRIPT
@@ -1725,3 +1867,11 @@ def test_hash_count_min_max_mean_vtables_under_the_stock_group_by_node():
     host and device-resident value columns; hash_mean keeps the reference kernel for host values and refuses device
     values whose partial sums pass 2^53."""
     _run(HASH_KERNELS_SCRIPT, "HASH_KERNELS_OK")
+
+
+def test_unique_value_counts_dictionary_encode_drop_null_nonzero_and_numeric_casts_on_device_arrays():
+    """pc.unique / value_counts / dictionary_encode (MASK and ENCODE) through the device Grouper, pc.drop_null,
+    pc.indices_nonzero and every numeric cast pair on device-resident arrays — equal to the reference kernels' results on
+    the same values (slices, several chunks, floats compared by bits, all-null / empty / null-first arrays), outputs
+    stay in HBM, host arrays still reach the reference kernels."""
+    _run(VECTOR_HASH_SCRIPT, "VECTOR_HASH_OK")

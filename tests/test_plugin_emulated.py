@@ -84,3 +84,7 @@ def test_compare_and_arithmetic_on_every_numeric_type_emulated():
 
 def test_hash_count_min_max_mean_vtables_emulated():
     _run(G.HASH_KERNELS_SCRIPT, "HASH_KERNELS_OK", 0.02)
+
+
+def test_vector_hash_kernels_and_numeric_casts_emulated():
+    _run(G.VECTOR_HASH_SCRIPT, "VECTOR_HASH_OK", 0.01)
