@@ -56,6 +56,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -86,6 +87,7 @@ namespace {
 #include "plugin/vector_hash.inc"
 #include "plugin/scalar_aggregate.inc"
 #include "plugin/acero_node.inc"
+#include "plugin/acero_node_general.inc"
 #include "plugin/order_by_node.inc"
 #include "plugin/parquet.inc"
 #include "plugin/registration.inc"

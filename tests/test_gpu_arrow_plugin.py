@@ -314,6 +314,92 @@ VECTOR_HASH_SCRIPT = textwrap.dedent(r'''
 ''')
 
 
+GENERAL_GROUP_BY_SCRIPT = textwrap.dedent(r'''
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    from pyarrow import acero
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    path = build_plugin()
+    rng = np.random.default_rng(51)
+    n = SC(2_000_000)
+    t = pa.table({
+        "k64": pa.array(rng.integers(-2**62, 2**62, 5000)[rng.integers(0, 5000, n)], mask=rng.random(n) < 0.01),   # the whole int64 range
+        "a": pa.array(rng.integers(-30, 30, n).astype(np.int32), mask=rng.random(n) < 0.02),
+        "b": pa.array(rng.integers(0, 40, n).astype(np.int16)),
+        "c": pa.array(rng.integers(0, 3, n).astype(np.uint8), mask=rng.random(n) < 0.1),
+        "d": pa.array(rng.integers(0, 20000, n).astype(np.int32), pa.date32()),
+        "v": pa.array(rng.integers(-2**40, 2**40, n), mask=rng.random(n) < 0.15),
+        "w": pa.array(rng.integers(-2**63, 2**63 - 1, n), mask=rng.random(n) < 0.05),
+        "flag": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.2),
+    })
+    strict = pc.ScalarAggregateOptions(skip_nulls=False, min_count=2)
+    plans = [
+        (["k64"], [("v", "hash_sum", None, "s"), ("w", "hash_sum", None, "sw"), ("v", "hash_min", None, "mn"), ("v", "hash_max", None, "mx"),
+                   ("v", "hash_mean", None, "me"), ("v", "hash_count", None, "c"), ("flag", "hash_count", pc.CountOptions(mode="only_null"), "fn"),
+                   ([], "hash_count_all", None, "all")]),
+        (["a", "b"], [("v", "hash_sum", strict, "s"), ("v", "hash_mean", strict, "me"), ("w", "hash_max", strict, "mx"), ("d", "hash_count", pc.CountOptions(mode="all"), "c")]),
+        (["d", "b", "c"], [("w", "hash_sum", None, "s"), ("v", "hash_min", None, "mn")]),
+        (["a"], [("v", "hash_sum", None, "s"), ("w", "hash_sum", None, "sw")]),      # int32 key but two value columns: not the fused operator's case
+    ]
+    def run(tab, node, keys, aggs):
+        return acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
+            acero.Declaration(node, acero.AggregateNodeOptions(aggs, keys=keys))]).to_table(use_threads=False).sort_by([(k, "ascending") for k in keys])
+    # ---- the reference GroupByNode with the reference kernels, before anything is registered
+    want = [run(t, "aggregate", keys, aggs) for keys, aggs in plans]
+    lib = ctypes.CDLL(path)
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(m) for m in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def same(got, w, tag):
+        assert got.schema.equals(w.schema), (tag, got.schema, w.schema)
+        for i in range(w.num_columns):
+            assert got.column(i).equals(w.column(i)), (tag, w.schema.names[i], got.column(i).slice(0, 5), w.column(i).slice(0, 5))
+
+    # several chunks so that several batches arrive; device-resident: every column in HBM, sliced chunks (offsets != 0)
+    chunks = [t.slice(0, n // 3), t.slice(n // 3, 7), t.slice(n // 3 + 7)]
+    tc = pa.concat_tables(chunks)
+    # (unsliced arrays: pyarrow's ChunkedArray constructor counts the nulls of a sliced array on the CPU; table_source
+    #  slices the chunks into <= 32Ki-row batches itself, so offsets != 0 arrive anyway)
+    td = pa.Table.from_batches([pa.RecordBatch.from_arrays([to_device(c.combine_chunks().column(j).chunk(0)) for j in range(t.num_columns)],
+                                                           names=t.schema.names)
+                                for c in (t.slice(0, n // 2 + 3), t.slice(n // 2 + 3))])
+    td_host = t
+    g0 = lib.arrow_amd_plugin_calls(b"hash_sum", 1)
+    for (keys, aggs), w in zip(plans, want):
+        same(run(tc, "aggregate_rocm", keys, aggs), w, ("host", keys))
+        same(run(td, "aggregate_rocm", keys, aggs), run(td_host, "aggregate_rocm", keys, aggs), ("device vs host", keys))
+    assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - g0 >= 3 * len(plans), "aggregate_rocm did not run the device Grouper"
+    # keys wider than the device Grouper's 16-byte rows, and value types it does not take: refused by name
+    for keys, aggs, needle in ((["k64", "a", "d", "b"], [("v", "hash_sum", None, "s")], "16 bytes"),
+                               (["a", "b"], [("flag", "hash_sum", None, "s")], "int64 values")):
+        try:
+            run(t, "aggregate_rocm", keys, aggs)
+            raise SystemExit("aggregate_rocm accepted " + str(keys))
+        except pa.ArrowNotImplementedError as e:
+            assert needle in str(e), e
+    # an empty input still produces the schema
+    e = run(t.slice(0, 0), "aggregate_rocm", ["a", "b"], [("v", "hash_sum", None, "s")])
+    assert e.num_rows == 0 and e.schema.names == ["a", "b", "s"], e.schema
+    print("GENERAL_GROUP_BY_OK")
+''')
+
+
 def test_pyarrow_compute_dispatches_to_the_hip_kernels():
     pytest.importorskip("pyarrow")
     code = f"ROOT = {ROOT!r}\n" + SCRIPT
@@ -1875,3 +1961,11 @@ def test_unique_value_counts_dictionary_encode_drop_null_nonzero_and_numeric_cas
     the same values (slices, several chunks, floats compared by bits, all-null / empty / null-first arrays), outputs
     stay in HBM, host arrays still reach the reference kernels."""
     _run(VECTOR_HASH_SCRIPT, "VECTOR_HASH_OK")
+
+
+def test_aggregate_rocm_with_int64_and_multi_column_keys_through_the_device_grouper():
+    """aggregate_rocm beyond the fused int32 -> int64 operator: int64 keys over their whole range, 2- and 3-column keys
+    (int32 / int16 / uint8 / date32, nulls as key values), several value columns, sum / mean / min / max / count (three
+    modes) / count_all — the device Grouper + dense hash kernels, equal to the reference GroupByNode with the reference
+    kernels (taken before registration); host batches and device-resident sliced batches."""
+    _run(GENERAL_GROUP_BY_SCRIPT, "GENERAL_GROUP_BY_OK")

@@ -88,3 +88,7 @@ def test_hash_count_min_max_mean_vtables_emulated():
 
 def test_vector_hash_kernels_and_numeric_casts_emulated():
     _run(G.VECTOR_HASH_SCRIPT, "VECTOR_HASH_OK", 0.01)
+
+
+def test_aggregate_rocm_general_keys_emulated():
+    _run(G.GENERAL_GROUP_BY_SCRIPT, "GENERAL_GROUP_BY_OK", 0.01)
