@@ -771,6 +771,9 @@ struct GbpArgs {
   unsigned long long* dense_counts;
   unsigned int* dense_null_seen;
   int wide;                // 1 = the wide one-level form: b1 == 0, b2 == bits <= 11, 12-byte records in `recs`
+  uint32_t room;           // != 0: the wide form WITHOUT a histogram pass — partition p owns records [p * room, (p + 1) * room)
+  uint32_t* part_end;      // [2^bits] one past a partition's last record (part_start[p + 1] with exact counts)
+  uint32_t* overflow;      // set by the wide scatter when a partition outgrows its room
   uint8_t* recs;           // [n] {key u32, value lo, value hi}
   int xcd_map;             // bit 0: level-2 scatter, bit 1: aggregate, bit 2: level-1 scatter — XCD-contiguous work numbering
   int agg_pipe;            // software-pipelined loads in the LDS aggregate kernel (A/B knob)
@@ -923,7 +926,10 @@ __global__ __launch_bounds__(1024) void gbp_scan_a_kernel(GbpArgs a) {
   for (int i = tid; i <= nparts; i += 1024) {
     const uint32_t s0 = ps[i];
     a.part_start[i] = s0;
-    if (i < nparts) a.cursor2[i] = s0;
+    if (i < nparts) {
+      a.cursor2[i] = s0;
+      a.part_end[i] = ps[i + 1];
+    }
   }
   const int nb1 = 1 << a.b1;
   for (int d = tid; d <= nb1; d += 1024) {
@@ -1140,6 +1146,51 @@ __global__ __launch_bounds__(kGbThreads, 6) void gbp_scatter2_kernel(GbpArgs a) 
   gbp_scatter_tile<2, false>(a, lds, a.keys_a, a.vals_a, row0, nrows, p, a.keys_b, a.vals_b);
 }
 
+// ---- K1r / K2r: the wide form without a histogram pass.  A bijective multiplicative hash spreads distinct keys evenly,
+// so partition sizes are binomial around n / 2^bits: every partition gets a ROOM of mean + 6 sigma + 64 records
+// (gbp_room_for) instead of its counted size, the scatter appends at the room's cursor and flags a partition that
+// outgrows its room (few hot keys: the slice is then redone with the counted plan, and the rest of the call stays on
+// it).  Saves the 4 B/row histogram pass: 2.6 of 43 ms at 4e9 rows.
+__global__ __launch_bounds__(1024) void gbp_rooms_init_kernel(GbpArgs a) {
+  const int nparts = 1 << a.bits;
+  for (int i = threadIdx.x; i <= nparts; i += 1024) {
+    a.part_start[i] = static_cast<uint32_t>(i) * a.room;
+    if (i < nparts) a.cursor2[i] = static_cast<uint32_t>(i) * a.room;
+  }
+  if (threadIdx.x == 0) *a.overflow = 0;
+}
+
+// after the scatter: records that arrived per partition, the ends of the partitions, the aggregate's work units
+__global__ __launch_bounds__(1024) void gbp_rooms_scan_kernel(GbpArgs a) {
+  __shared__ uint32_t wave_tot[16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nparts = 1 << a.bits;
+  const int per = (nparts + 1023) / 1024;
+  const int b = tid * per;
+  const int e = b + per < nparts ? b + per : nparts;
+  uint32_t usum = 0;
+  for (int i = b; i < e; ++i) {
+    const uint32_t lo = static_cast<uint32_t>(i) * a.room;
+    const uint32_t cur = a.cursor2[i];
+    const uint32_t cnt = (cur - lo) > a.room ? a.room : cur - lo;   // (an overflowed partition: the call is redone)
+    a.part_count[i] = cnt;
+    a.part_end[i] = lo + cnt;
+    usum += (cnt + a.agg_chunk - 1) / a.agg_chunk;
+  }
+  const uint32_t uincl = wave_inclusive_scan_u32(usum);
+  if (lane == 63) wave_tot[wave] = uincl;
+  __syncthreads();
+  uint32_t uprefix = uincl - usum;
+  for (int k = 0; k < wave; ++k) uprefix += wave_tot[k];
+  for (int i = b; i < e; ++i) {
+    a.agg_unit_start[i] = uprefix;
+    uprefix += (a.part_count[i] + a.agg_chunk - 1) / a.agg_chunk;
+  }
+  if (tid == 1023) a.agg_unit_start[nparts] = uprefix;
+}
+
 // ---- K3w: the flat level of the wide form.  One workgroup = one tile of 24576 rows held in REGISTERS (24 per
 // thread): ranked with LDS atomics over up to 2048 bins, then moved through a 8192-record LDS buffer in three rounds,
 // so a (tile, bin) run is 12 records at 2048 bins — three times what an LDS-resident tile gives — and written as
@@ -1210,7 +1261,9 @@ __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArg
     const int b = tid * per + k;
     if (b < nb) {
       lds.start[b] = pre;
-      lds.gbase[b] = c[k] != 0 ? atomicAdd(&a.cursor2[b], c[k]) : 0u;
+      const uint32_t g = c[k] != 0 ? atomicAdd(&a.cursor2[b], c[k]) : 0u;
+      lds.gbase[b] = g;
+      if (a.room != 0 && c[k] != 0 && (g - static_cast<uint32_t>(b) * a.room) + c[k] > a.room) atomicOr(a.overflow, 1u);
     }
     pre += c[k];
   }
@@ -1243,7 +1296,8 @@ __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArg
       rec.key = k;
       rec.vlo = static_cast<uint32_t>(v);
       rec.vhi = static_cast<uint32_t>(v >> 32);
-      out[lds.gbase[d] + (lo + static_cast<uint32_t>(p) - lds.start[d])] = rec;
+      const uint32_t dst = lds.gbase[d] + (lo + static_cast<uint32_t>(p) - lds.start[d]);
+      if (a.room == 0 || dst - d * a.room < a.room) out[dst] = rec;   // (never past a room: the slice is redone then)
     }
     __syncthreads();
   }
@@ -1297,7 +1351,7 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
       if (lane == 0) {
         const uint32_t part = static_cast<uint32_t>(coarse) + below - 1;
         const uint32_t first = a.part_start[part] + (u - a.agg_unit_start[part]) * a.agg_chunk;
-        const uint32_t end = a.part_start[part + 1];
+        const uint32_t end = a.part_end[part];
         t.part = part;
         t.row_lo = first;
         t.row_hi = (end - first) > a.agg_chunk ? first + a.agg_chunk : end;
@@ -1442,9 +1496,10 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
 struct GbpPlan {
   int bits, b1, b2;
   int wide;                 // the wide one-level form (b1 == 0, b2 == bits)
+  uint32_t room;            // wide form: records every partition's room holds (see gbp_room_for)
   int64_t slice_rows, chunk_rows, nchunks;
   size_t off_keys_a, off_vals_a, off_keys_b, off_vals_b, off_part_count, off_part_start,
-      off_cursor2, off_cursor1, off_hist1, off_l1_start, off_l2_tile_start, off_agg_unit_start, total;
+      off_cursor2, off_cursor1, off_hist1, off_l1_start, off_l2_tile_start, off_agg_unit_start, off_part_end, off_overflow, total;
 };
 
 static int g_gbp_min_rows = 1 << 17;  // below this the direct HBM-atomics kernel is used
@@ -1454,6 +1509,8 @@ static int g_gbp_xcd_map = 1;         // XCD-contiguous work numbering: bit 0 le
 static int g_gbp_b1 = -1;             // level-1 bits override (-1: half of the partition bits)
 static int g_gbp_chunks = 2048;       // level-1 chunks = workgroups of the hist / scatter1 kernels
 static int g_gbp_wide_max_bits = kGbWideMaxBits;   // bins of the flat level the planner may ask for (A/B knob groupby_wide_max_bits; tests lower it)
+static int g_gbp_room_min_mean = 1 << 14;   // rooms only for partitions of at least this many rows on average (knob groupby_wide_room_min_mean; tests lower it)
+static int g_gbp_wide_rooms = 1;      // the wide form without its histogram pass: fixed rooms per partition (A/B knob groupby_wide_rooms)
 static int g_gbp_wide = 1;            // the wide one-level form where the group estimate allows it (A/B knob groupby_wide)
 static int g_gbp_wide_agg_chunk = 1 << 21;   // rows per aggregate work unit of the wide form (A/B knob groupby_wide_agg_chunk_rows)
 static int64_t g_gbp_probe_rows = int64_t(1) << 26;   // rows of the probe slice that measures the group count (A/B knob groupby_probe_rows)
@@ -1471,7 +1528,7 @@ static int gbp_bits_for(int64_t capacity) {
 
 constexpr int64_t kGbMaxSlice = int64_t(1) << 30;  // row positions inside a slice are 32-bit
 static int64_t g_gbp_max_slice = kGbMaxSlice;     // A/B knob groupby_max_slice_rows
-constexpr int64_t kGbHardMaxSlice = (int64_t(1) << 32) - (int64_t(1) << 24);
+constexpr int64_t kGbHardMaxSlice = (int64_t(1) << 32) - (int64_t(1) << 26);   // (room for the rooms' slack below 2^32 positions)
 static int64_t g_gbp_wide_max_slice = kGbHardMaxSlice;   // A/B knob groupby_wide_max_slice_rows
 static int g_gbp_agg_chunk = 1 << 18;             // A/B knob groupby_agg_chunk_rows (2^16: every group of a partition is flushed 2-8x per slice; 2^18: +4 %)
 
@@ -1483,10 +1540,22 @@ static int gbp_wide_bits_for(int64_t groups) {
   return bits <= g_gbp_wide_max_bits ? bits : -1;
 }
 
+// Records a partition's room holds when the wide form runs without a histogram: the mean + 6 sigma of the binomial a
+// bijective hash of DISTINCT keys gives, + 64.  Only worth it when the slack is small (mean >= 2^14: <= 5 %).
+static uint32_t gbp_room_for(int64_t rows, int bits) {
+  const int64_t mean = (rows + (int64_t(1) << bits) - 1) >> bits;
+  if (mean < g_gbp_room_min_mean) return 0;
+  int64_t sd = 1;
+  while (sd * sd < mean) ++sd;
+  const int64_t room = mean + 6 * sd + 64;
+  return (room << bits) < (int64_t(1) << 32) ? static_cast<uint32_t>(room) : 0;
+}
+
 // groups_hint: distinct keys expected in the rows to come (< 0: unknown — the capacity is the only bound).  The
 // two-level plan is chosen from the capacity alone; the wide plan replaces it when the hint (or, without one, the
 // capacity bound) says its 2048 tables of 8192 slots are enough.
-static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity, int64_t groups_hint = -1, int dense_idbits = 0) {
+static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity, int64_t groups_hint = -1, int dense_idbits = 0,
+                        bool allow_rooms = true) {
   GbpPlan p{};
   p.bits = gbp_bits_for(capacity);
   if (p.bits <= 8) {
@@ -1530,8 +1599,12 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity, int64_t groups_hin
   const size_t nparts = size_t(1) << p.bits;
   const size_t nb1 = size_t(1) << p.b1;
   size_t o = 0;
+  // rooms need keys that spread like distinct hashed keys: the keyed table, never the dense ids of the hash_sum vtable
+  // (id << shift puts all rows of the low ids into the low partitions)
+  if (p.wide && g_gbp_wide_rooms && allow_rooms && dense_idbits == 0) p.room = gbp_room_for(slice_rows, p.bits);
   if (p.wide) {
-    p.off_keys_a = o; o = align(o + n * 12);   // the 12-byte records
+    const size_t recs = p.room ? (static_cast<size_t>(p.room) << p.bits) : n;
+    p.off_keys_a = o; o = align(o + recs * 12);   // the 12-byte records
     p.off_vals_a = p.off_keys_b = p.off_vals_b = o;
   } else {
     p.off_keys_a = o; o = align(o + (p.bits ? n * 4 : 0));
@@ -1547,6 +1620,8 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity, int64_t groups_hin
   p.off_l1_start = o; o = align(o + (nb1 + 1) * 4);
   p.off_l2_tile_start = o; o = align(o + (nb1 + 1) * 4);
   p.off_agg_unit_start = o; o = align(o + (nparts + 1) * 4);
+  p.off_part_end = o; o = align(o + nparts * 4);
+  p.off_overflow = o; o = align(o + 4);
   p.total = o;
   return p;
 }
@@ -1572,6 +1647,9 @@ static void gbp_bind(GbpArgs& a, const GbpPlan& plan, uint8_t* w) {
   a.l1_start = reinterpret_cast<uint32_t*>(w + plan.off_l1_start);
   a.l2_tile_start = reinterpret_cast<uint32_t*>(w + plan.off_l2_tile_start);
   a.agg_unit_start = reinterpret_cast<uint32_t*>(w + plan.off_agg_unit_start);
+  a.part_end = reinterpret_cast<uint32_t*>(w + plan.off_part_end);
+  a.overflow = reinterpret_cast<uint32_t*>(w + plan.off_overflow);
+  a.room = plan.room;
   a.agg_pipe = g_gbp_agg_pipe;
   a.xcd_map = g_gbp_xcd_map;
   a.agg_chunk = static_cast<uint32_t>(plan.wide ? g_gbp_wide_agg_chunk : g_gbp_agg_chunk);
@@ -1598,7 +1676,8 @@ static int64_t gbp_slice_for(size_t ws_bytes, int64_t n, int64_t capacity, int64
 // Which plan the slices of the partitioned consume ran (arx_get_counter): the plan is chosen from estimates, and a test
 // or a bench that means to measure one plan must be able to see that it did.
 static std::atomic<int64_t> g_gbp_slices_direct{0}, g_gbp_slices_one_level{0}, g_gbp_slices_two_level{0},
-    g_gbp_slices_wide{0}, g_gbp_slices_probe{0};
+    g_gbp_slices_wide{0}, g_gbp_slices_probe{0}, g_gbp_slices_rooms{0}, g_gbp_rooms_overflows{0};
+constexpr int kGbpRoomsOverflow = -1000;   // gbp_run_slice: a partition outgrew its room, nothing consumed yet
 
 int get_groupby_counter(const char* name, int64_t* out) {
   if (strcmp(name, "groupby_slices_direct") == 0) *out = g_gbp_slices_direct.load();
@@ -1606,18 +1685,21 @@ int get_groupby_counter(const char* name, int64_t* out) {
   else if (strcmp(name, "groupby_slices_two_level") == 0) *out = g_gbp_slices_two_level.load();
   else if (strcmp(name, "groupby_slices_wide") == 0) *out = g_gbp_slices_wide.load();
   else if (strcmp(name, "groupby_slices_probe") == 0) *out = g_gbp_slices_probe.load();
+  else if (strcmp(name, "groupby_slices_rooms") == 0) *out = g_gbp_slices_rooms.load();
+  else if (strcmp(name, "groupby_rooms_overflows") == 0) *out = g_gbp_rooms_overflows.load();
   else return 0;
   return 1;
 }
 
 template <bool HAS_NULLS>
-static int gbp_run_slice(const GroupbyView& v, GbpArgs a, const GbpPlan& plan, hipStream_t st) {
-  if (HAS_NULLS) {
+static int gbp_run_slice(const GroupbyView& v, GbpArgs a, const GbpPlan& plan, hipStream_t st, bool redo = false) {
+  if (HAS_NULLS && !redo) {   // (a slice redone after a rooms overflow: its null rows are in the table already)
     hipLaunchKernelGGL(gbp_null_rows_kernel, dim3(gb_grid(a.n / 8 + 1)), dim3(kBlock), 0, st, v, a);
     ARX_CHECK_LAUNCH("gbp_null_rows_kernel");
   }
   (a.bits == 0 ? g_gbp_slices_direct : a.wide ? g_gbp_slices_wide : a.b2 > 0 ? g_gbp_slices_two_level : g_gbp_slices_one_level)
       .fetch_add(1, std::memory_order_relaxed);
+  if (a.wide && a.room != 0) g_gbp_slices_rooms.fetch_add(1, std::memory_order_relaxed);
   if (a.bits == 0) {
     const unsigned units = static_cast<unsigned>(ceil_div(a.n, a.agg_chunk));
     hipLaunchKernelGGL((gbp_aggregate_kernel<true, HAS_NULLS>), dim3(units), dim3(kGbThreads), 0, st, v, a,
@@ -1627,6 +1709,28 @@ static int gbp_run_slice(const GroupbyView& v, GbpArgs a, const GbpPlan& plan, h
   }
   const unsigned nch = static_cast<unsigned>(a.nchunks);
   const int nparts = 1 << a.bits;
+  if (a.wide && a.room != 0) {
+    // no histogram: rooms -> scatter -> (the host looks at the overflow flag) -> ends + work units -> aggregate
+    hipLaunchKernelGGL(gbp_rooms_init_kernel, dim3(1), dim3(1024), 0, st, a);
+    ARX_CHECK_LAUNCH("gbp_rooms_init_kernel");
+    hipLaunchKernelGGL((gbp_scatter_wide_kernel<HAS_NULLS>), dim3(static_cast<unsigned>(ceil_div(a.n, kGbWideTile))),
+                       dim3(kGbWideThreads), 0, st, a);
+    ARX_CHECK_LAUNCH("gbp_scatter_wide_kernel");
+    uint32_t overflow = 0;
+    ARX_HIP(hipMemcpyAsync(&overflow, a.overflow, 4, hipMemcpyDeviceToHost, st));
+    ARX_HIP(hipStreamSynchronize(st));
+    if (overflow != 0) {
+      g_gbp_rooms_overflows.fetch_add(1, std::memory_order_relaxed);
+      return kGbpRoomsOverflow;   // nothing has touched the table yet: the caller redoes the slice with counted partitions
+    }
+    hipLaunchKernelGGL(gbp_rooms_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    ARX_CHECK_LAUNCH("gbp_rooms_scan_kernel");
+    const unsigned wunits = static_cast<unsigned>(ceil_div(a.n, a.agg_chunk) + nparts);
+    hipLaunchKernelGGL((gbp_aggregate_kernel<false, false, kGbWideSlots, kGbWideThreads, true, 8>), dim3(wunits),
+                       dim3(kGbWideThreads), 0, st, v, a, nullptr, nullptr);
+    ARX_CHECK_LAUNCH("gbp_aggregate_kernel (wide, rooms)");
+    return ARX_OK;
+  }
   ARX_HIP(hipMemsetAsync(a.part_count, 0, static_cast<size_t>(nparts) * 4, st));
   hipLaunchKernelGGL((gbp_hist_kernel<HAS_NULLS>), dim3(nch), dim3(kGbThreads), 0, st, a);
   ARX_CHECK_LAUNCH("gbp_hist_kernel");
@@ -1699,6 +1803,14 @@ int set_groupby_option(const char* name, int64_t value) {
     int lg = 14;
     while (lg < 26 && (int64_t(1) << lg) < value) ++lg;
     g_gbp_wide_agg_chunk = 1 << lg;
+    return 1;
+  }
+  if (strcmp(name, "groupby_wide_room_min_mean") == 0) {
+    g_gbp_room_min_mean = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, INT32_MAX)));
+    return 1;
+  }
+  if (strcmp(name, "groupby_wide_rooms") == 0) {
+    g_gbp_wide_rooms = value != 0;
     return 1;
   }
   if (strcmp(name, "groupby_wide_max_slice_rows") == 0) {
@@ -1828,6 +1940,7 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
     const int64_t probe_rows = std::max<int64_t>(kGbTile, g_gbp_probe_rows / kGbTile * kGbTile);
     const bool probe = g_gbp_wide && g_gbp_bits < 0 && unhinted.b2 > 0 && !unhinted.wide && n >= 4 * probe_rows;
     int64_t groups_hint = -1;
+    bool rooms_ok = true;
     unsigned long long groups_before = 0;
     if (probe) {
       GroupbyHeader h0{};
@@ -1842,7 +1955,7 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
         const int64_t hinted = gbp_slice_for(ws_bytes, n - r0, capacity, groups_hint);
         if (hinted >= kGbTile) m = std::min(hinted, n - r0);
       }
-      const GbpPlan plan = gbp_plan(m, capacity, groups_hint);
+      GbpPlan plan = gbp_plan(m, capacity, groups_hint, 0, rooms_ok);
       GbpArgs a{};
       a.dense = 0;
       a.keys = k + r0;
@@ -1851,8 +1964,16 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
       a.vvalid = make_bits(vbm, values_i64->offset + r0, m);
       a.n = m;
       gbp_bind(a, plan, w);
-      const int rc = (kbm != nullptr || vbm != nullptr) ? gbp_run_slice<true>(v, a, plan, st)
-                                                        : gbp_run_slice<false>(v, a, plan, st);
+      int rc = (kbm != nullptr || vbm != nullptr) ? gbp_run_slice<true>(v, a, plan, st)
+                                                  : gbp_run_slice<false>(v, a, plan, st);
+      if (rc == kGbpRoomsOverflow) {
+        // a partition outgrew its room (hot keys): this slice again with counted partitions, and the rest of the call too
+        rooms_ok = false;
+        plan = gbp_plan(m, capacity, groups_hint, 0, false);
+        gbp_bind(a, plan, w);
+        rc = (kbm != nullptr || vbm != nullptr) ? gbp_run_slice<true>(v, a, plan, st, true)
+                                                : gbp_run_slice<false>(v, a, plan, st, true);
+      }
       if (rc != ARX_OK) return rc;
       if (probing) {
         g_gbp_slices_probe.fetch_add(1, std::memory_order_relaxed);

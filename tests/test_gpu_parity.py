@@ -494,6 +494,37 @@ def test_groupby_wide_one_level_form(gpu_ctx, bits):
             lib.arx_set_option(k_, v_)
 
 
+@pytest.mark.parametrize("hot", [False, True])
+def test_groupby_wide_form_without_histogram(gpu_ctx, hot):
+    """The wide plan with fixed rooms instead of a histogram pass: evenly spread keys fit their rooms (no overflow);
+    a few hot keys outgrow one room — the slice is redone with counted partitions (null rows are not consumed twice)
+    and the call's later slices stay on the counted plan.  Results exact either way."""
+    lib = gpu_ctx._lib.get_lib()
+    opts = {b"groupby_partition_min_rows": 0, b"groupby_wide": 2, b"groupby_partition_bits": 11, b"groupby_wide_room_min_mean": 16,
+            b"groupby_wide_max_slice_rows": 2457600}
+    for k_, v_ in opts.items():
+        assert lib.arx_set_option(k_, v_) == 0
+    names = (b"groupby_slices_rooms", b"groupby_rooms_overflows")
+    before = [lib.arx_get_counter(c) for c in names]
+    try:
+        rng = rng_for("gbrooms", hot)
+        n = 6000000
+        k = U.random_array(rng, np.int32, n, null_p=0.02, lo=-2**31, hi=2**31 - 1)
+        if hot:
+            k.values[n // 3:] = 7            # two thirds of the rows in ONE group: its partition outgrows its room
+        v = U.random_array(rng, np.int64, n, null_p=0.1)
+        P.check_groupby_sum(gpu_ctx, k, v, skip_nulls=False, min_count=2, batches=1, use_pyarrow=not hot)
+    finally:
+        for k_, v_ in {b"groupby_partition_min_rows": 1 << 17, b"groupby_wide": 1, b"groupby_partition_bits": -1,
+                       b"groupby_wide_room_min_mean": 1 << 14, b"groupby_wide_max_slice_rows": (1 << 32) - (1 << 26)}.items():
+            lib.arx_set_option(k_, v_)
+    rooms, overflows = (lib.arx_get_counter(c) - b for c, b in zip(names, before))
+    assert rooms >= 1, "the plan without a histogram did not run"
+    assert (overflows >= 1) == hot, (rooms, overflows)
+    if hot:
+        assert rooms == 1, "after an overflow the call stays on the counted plan"
+
+
 @pytest.mark.parametrize("distinct", [200000, 0])
 def test_groupby_probe_slice_selects_the_plan(gpu_ctx, distinct):
     """A capacity that only bounds the group count from above (two-level plan) + enough rows: the first slice is a
