@@ -174,6 +174,8 @@ SIGNATURES = {
                                                  C.POINTER(_i64), _p]),
     "arx_sort_unpack_records": (_int, [_p, _i64, _p, _int, _int, _p, _p, _p, _p]),
     "arx_groupby_export_partitioned": (_int, [_p, _int, _p, _sz, _p, _p, _p]),
+    "arx_groupby_partition_rows": (_int, [_span, _span, _int, _p, _sz, _p, _p, _p]),
+    "arx_groupby_unpack_rows": (_int, [_p, _i64, _p, _p, _p, _p, _p]),
     "arx_hash_sum_consume_workspace_bytes": (_sz, [_i64, _i64]),
     "arx_hash_sum_i64_consume_ws": (_int, [_span, _int, _i64, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     "arx_hash_mean_i64_finalize": (_int, [_p, _p, _i64, C.c_uint64, _p, _p, _p]),

@@ -298,6 +298,79 @@ __global__ __launch_bounds__(kBlock) void partition_scatter_kernel(
   }
 }
 
+// ---- the ROW-level exchange (SURVEY.md 8e "row-level radix exchange", the variant BASELINE.json's north star words):
+// the rows themselves leave for the rank that owns their key — 16-byte records {key, flags, value}, flags bit 0 = key
+// valid, bit 1 = value valid — instead of one partial aggregate per local group.  Better than the partials exchange
+// only when nearly every row is its own group (G -> N / P); otherwise it moves N x 16 B instead of G x 24 B.
+struct ArxRowRecordDev {
+  int32_t key;
+  uint32_t flags;
+  int64_t value;
+};
+static_assert(sizeof(ArxRowRecordDev) == 16, "16-byte row records");
+
+template <bool SCATTER>
+__global__ __launch_bounds__(kBlock) void partition_rows_kernel(const int32_t* __restrict__ keys, Bits kvalid,
+                                                                const int64_t* __restrict__ values, Bits vvalid, int64_t n,
+                                                                int num_parts, unsigned long long* part_counts,
+                                                                unsigned long long* cursors, ArxRowRecordDev* __restrict__ out) {
+  __shared__ uint32_t cnt[kPartMaxParts];
+  __shared__ unsigned long long base[kPartMaxParts];
+  for (int p = threadIdx.x; p < num_parts; p += kBlock) cnt[p] = 0;
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * kPartChunk;
+  const int64_t end = begin + kPartChunk < n ? begin + kPartChunk : n;
+  for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) {
+    const bool kv = (load_word(kvalid, i >> 6) >> (i & 63)) & 1ull;
+    atomicAdd(&cnt[gb_dest(keys[i], kv, num_parts)], 1u);
+  }
+  __syncthreads();
+  if (!SCATTER) {
+    for (int p = threadIdx.x; p < num_parts; p += kBlock) {
+      if (cnt[p] != 0) atomicAdd(&part_counts[p], static_cast<unsigned long long>(cnt[p]));
+    }
+    return;
+  }
+  for (int p = threadIdx.x; p < num_parts; p += kBlock) {
+    base[p] = cnt[p] != 0 ? atomicAdd(&cursors[p], static_cast<unsigned long long>(cnt[p])) : 0ull;
+    cnt[p] = 0;
+  }
+  __syncthreads();
+  for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) {
+    const bool kv = (load_word(kvalid, i >> 6) >> (i & 63)) & 1ull;
+    const bool vv = (load_word(vvalid, i >> 6) >> (i & 63)) & 1ull;
+    const int d = gb_dest(keys[i], kv, num_parts);
+    const int64_t pos = static_cast<int64_t>(base[d]) + atomicAdd(&cnt[d], 1u);
+    out[pos] = ArxRowRecordDev{kv ? keys[i] : 0, (kv ? 1u : 0u) | (vv ? 2u : 0u), vv ? values[i] : 0};
+  }
+}
+
+// received row records -> key / value columns + their validity bitmaps (one ballot word per 64 rows)
+__global__ __launch_bounds__(kBlock) void unpack_rows_kernel(const ArxRowRecordDev* __restrict__ recs, int64_t n,
+                                                             int32_t* __restrict__ keys, int64_t* __restrict__ values,
+                                                             uint64_t* __restrict__ kbits, uint64_t* __restrict__ vbits) {
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwords = (n + 63) >> 6;
+  for (int64_t w = wave_g; w < nwords; w += nwaves) {
+    const int64_t i = (w << 6) + lane;
+    bool kv = false, vv = false;
+    if (i < n) {
+      const ArxRowRecordDev r = recs[i];
+      keys[i] = r.key;
+      values[i] = r.value;
+      kv = (r.flags & 1u) != 0;
+      vv = (r.flags & 2u) != 0;
+    }
+    const uint64_t kb = __ballot(kv), vb = __ballot(vv);
+    if (lane == 0) {
+      kbits[w] = kb;
+      vbits[w] = vb;
+    }
+  }
+}
+
 // ---- export straight into the multi-GPU exchange layout: one 24-byte record per group, grouped by
 // destination rank.  Two sweeps over the table slots (count per destination, then
 // reserve-and-write per workgroup), so the dense column export and its re-read are never materialised.
@@ -2466,6 +2539,61 @@ int arx_groupby_partition(const int32_t* keys, const uint8_t* key_is_valid, cons
                        out_key_is_valid, out_sums, out_counts, out_no_nulls);
     ARX_CHECK_LAUNCH("partition_scatter_kernel");
   }
+  return ARX_OK;
+}
+
+int arx_groupby_partition_rows(const ArxSpan* keys_i32, const ArxSpan* values_i64, int num_parts, void* ws, size_t ws_bytes,
+                               ArxRowRecord* out_records, int64_t* out_part_counts, void* stream) {
+  if (keys_i32 == nullptr || values_i64 == nullptr || num_parts < 1 || num_parts > kPartMaxParts || ws == nullptr ||
+      ws_bytes < arx_groupby_partition_workspace_bytes(num_parts) || out_part_counts == nullptr ||
+      keys_i32->length != values_i64->length) {
+    set_error("bad arguments to arx_groupby_partition_rows");
+    return ARX_INVALID;
+  }
+  const int64_t n = keys_i32->length;
+  hipStream_t st = as_stream(stream);
+  unsigned long long* part_counts = static_cast<unsigned long long*>(ws);
+  unsigned long long* cursors = part_counts + num_parts;
+  ARX_HIP(hipMemsetAsync(ws, 0, static_cast<size_t>(num_parts) * 16, st));
+  const int32_t* k = static_cast<const int32_t*>(keys_i32->data) + keys_i32->offset;
+  const int64_t* v = static_cast<const int64_t*>(values_i64->data) + values_i64->offset;
+  const Bits kb = make_bits(keys_i32->null_count != 0 ? keys_i32->validity : nullptr, keys_i32->offset, n);
+  const Bits vb = make_bits(values_i64->null_count != 0 ? values_i64->validity : nullptr, values_i64->offset, n);
+  ArxRowRecordDev* out = reinterpret_cast<ArxRowRecordDev*>(out_records);
+  const unsigned grid = static_cast<unsigned>(ceil_div(std::max<int64_t>(n, 1), kPartChunk));
+  if (n > 0) {
+    if (out == nullptr || k == nullptr || v == nullptr) {
+      set_error("NULL buffer passed to arx_groupby_partition_rows");
+      return ARX_INVALID;
+    }
+    hipLaunchKernelGGL((partition_rows_kernel<false>), dim3(grid), dim3(kBlock), 0, st, k, kb, v, vb, n, num_parts, part_counts,
+                       cursors, out);
+    ARX_CHECK_LAUNCH("partition_rows_kernel<count>");
+  }
+  hipLaunchKernelGGL(partition_offsets_kernel, dim3(1), dim3(64), 0, st, part_counts, num_parts, cursors, out_part_counts);
+  ARX_CHECK_LAUNCH("partition_offsets_kernel");
+  if (n > 0) {
+    hipLaunchKernelGGL((partition_rows_kernel<true>), dim3(grid), dim3(kBlock), 0, st, k, kb, v, vb, n, num_parts, part_counts,
+                       cursors, out);
+    ARX_CHECK_LAUNCH("partition_rows_kernel<scatter>");
+  }
+  return ARX_OK;
+}
+
+int arx_groupby_unpack_rows(const ArxRowRecord* records, int64_t num_records, int32_t* out_keys, int64_t* out_values,
+                            void* out_key_validity, void* out_value_validity, void* stream) {
+  if (num_records < 0 || (num_records > 0 && (records == nullptr || out_keys == nullptr || out_values == nullptr ||
+                                              out_key_validity == nullptr || out_value_validity == nullptr))) {
+    set_error("bad arguments to arx_groupby_unpack_rows");
+    return ARX_INVALID;
+  }
+  if (num_records == 0) return ARX_OK;
+  const int64_t nwords = ceil_div(num_records, 64);
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(nwords, kWavesPerBlock), 256 * 32)));
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                     reinterpret_cast<const ArxRowRecordDev*>(records), num_records, out_keys, out_values,
+                     static_cast<uint64_t*>(out_key_validity), static_cast<uint64_t*>(out_value_validity));
+  ARX_CHECK_LAUNCH("unpack_rows_kernel");
   return ARX_OK;
 }
 

@@ -72,32 +72,127 @@ def merge_records(owned: GroupBySum, records: torch.Tensor) -> None:
                                                     current_stream(owned.device)))
 
 
+class Stages:
+    """Per-stage wall milliseconds of one sharded call (consume / export / exchange / merge / finalize ...): the stream
+    is synchronised at every mark, so a `stages=` run is for diagnosis, not the timed run.  Each rank fills its own;
+    bench.py reports the maximum over the ranks."""
+
+    def __init__(self, device):
+        import time
+
+        self.device, self.ms, self._clock = device, {}, time.perf_counter
+        self._sync()
+        self._t = self._clock()
+
+    def _sync(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+    def mark(self, name: str) -> None:
+        self._sync()
+        now = self._clock()
+        self.ms[name] = self.ms.get(name, 0.0) + (now - self._t) * 1e3
+        self._t = now
+
+
+def _mark(stages, name):
+    if stages is not None:
+        stages.mark(name)
+
+
+ROW_RECORD_BYTES = 16   # sizeof(ArxRowRecord)
+
+
+def partition_rows(keys, values, num_parts: int):
+    """arx_groupby_partition_rows: this shard's ROWS as 16-byte records grouped by the rank that owns their key."""
+    lib = _lib.get_lib()
+    device = keys.device
+    stream = current_stream(device)
+    n = keys.length
+    ws = alloc(lib.arx_groupby_partition_workspace_bytes(num_parts), device)
+    records = torch.empty(max(n, 1) * ROW_RECORD_BYTES, dtype=torch.uint8, device=device)
+    part_counts = torch.zeros(num_parts, dtype=torch.int64, device=device)
+    ks, vs = keys.span(), values.span()
+    check(lib.arx_groupby_partition_rows(C.byref(ks), C.byref(vs), num_parts, ws.data_ptr(), ws.numel(), records.data_ptr(),
+                                         part_counts.data_ptr(), stream))
+    return records[: n * ROW_RECORD_BYTES], part_counts
+
+
+def unpack_rows(records: torch.Tensor):
+    """Received row records -> (keys Array int32, values Array int64) with validity bitmaps."""
+    from .array import Array, bitmap_nbytes, int32, int64
+
+    lib = _lib.get_lib()
+    device = records.device
+    n = records.numel() // ROW_RECORD_BYTES
+    keys = torch.empty(max(n, 1) * 4, dtype=torch.uint8, device=device)
+    vals = torch.empty(max(n, 1) * 8, dtype=torch.uint8, device=device)
+    kbits = torch.zeros(bitmap_nbytes(n), dtype=torch.uint8, device=device)
+    vbits = torch.zeros(bitmap_nbytes(n), dtype=torch.uint8, device=device)
+    if n:
+        check(lib.arx_groupby_unpack_rows(records.data_ptr(), n, keys.data_ptr(), vals.data_ptr(), kbits.data_ptr(),
+                                          vbits.data_ptr(), current_stream(device)))
+    return Array(int32, n, [kbits, keys], -1, 0), Array(int64, n, [vbits, vals], -1, 0)
+
+
 def sharded_group_by_sum(keys, values, capacity: int, options: ScalarAggregateOptions | None = None,
-                         group=None):
+                         group=None, exchange: str = "partials", stages: Stages | None = None):
     """keys/values: this rank's row shard (device Arrays).  Returns this rank's slice of the
     result: (keys, key_is_valid, sums, valid) device tensors over a disjoint set of keys.
 
-    Collectives on the data path: one exchange of the per-destination counts and ONE all-to-all(v) of
-    the 24-byte partial-aggregate records (the survey's "one RCCL all-to-all", 8e)."""
+    exchange = "partials" (default): local aggregate, then one exchange of the per-destination counts
+    and ONE all-to-all(v) of the 24-byte partial-aggregate records — G x 24 bytes leave a rank at most.
+    exchange = "rows" (the row-level radix exchange BASELINE.json's north star words): the rows themselves are
+    radix-partitioned by hash(key) % world_size, exchanged as 16-byte records (ONE all-to-all(v)) and aggregated by
+    the rank that owns their key — N x 16 bytes, the better plan only when almost every row is its own group.
+    Both give the same groups on the same ranks."""
     device = keys.device
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if exchange not in ("partials", "rows"):
+        raise ValueError("exchange must be 'partials' or 'rows'")
+    if world == 1:
+        local = GroupBySum(capacity, device, options)
+        local.consume(keys, values)
+        _mark(stages, "consume")
+        out = local.finalize()
+        _mark(stages, "finalize")
+        return out
+    if exchange == "rows":
+        records, counts = partition_rows(keys, values, world)
+        _mark(stages, "partition_rows")
+        recv_counts = torch.empty_like(counts)
+        dist.all_to_all_single(recv_counts, counts, group=group)
+        send, recv = _host_counts(counts, recv_counts)
+        mine = _all_to_all_bytes(records, send, recv, ROW_RECORD_BYTES, group)
+        _mark(stages, "exchange")
+        rk, rv = unpack_rows(mine)
+        owned = GroupBySum(capacity, device, options)
+        owned.consume(rk, rv)
+        _mark(stages, "consume")
+        out = owned.finalize()
+        _mark(stages, "finalize")
+        return out
     local = GroupBySum(capacity, device, options)
     local.consume(keys, values)
-    if world == 1:
-        return local.finalize()
+    _mark(stages, "consume")
     records, counts = export_partitioned(local, world)
+    _mark(stages, "export")
     recv_counts = torch.empty_like(counts)
     dist.all_to_all_single(recv_counts, counts, group=group)
     send, recv = _host_counts(counts, recv_counts)
     mine = _all_to_all_bytes(records, send, recv, RECORD_BYTES, group)
+    _mark(stages, "exchange")
     owned = GroupBySum(max(16, 2 * sum(recv) + 2), device, options)
     merge_records(owned, mine)
-    return owned.finalize()
+    _mark(stages, "merge")
+    out = owned.finalize()
+    _mark(stages, "finalize")
+    return out
 
 
 # --------------------------------------------------------------------------- sort_indices
 def sharded_sort_indices(values, order: str = "ascending", null_placement: str = "at_end", group=None,
-                         splitter_bits: int = 12):
+                         splitter_bits: int = 12, stages: Stages | None = None):
     """array_sort_indices over a row-sharded array, one exchange step.
 
     `values`: this rank's contiguous shard (uint64 / int64 device Array) of the global array
@@ -133,6 +228,7 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
     if world == 1:
         # one shard: no splitters, no exchange — the single-GPU kernel path as is
         perm = cp.call_function("array_sort_indices", [values], cp.ArraySortOptions(order, null_placement))
+        _mark(stages, "local_sort")
         return perm.data[: n * 8].view(torch.int64), 0
     order_code = _lib.SORT_DESCENDING if order == "descending" else _lib.SORT_ASCENDING
     placement_code = _lib.NULLS_AT_START if null_placement == "at_start" else _lib.NULLS_AT_END
@@ -162,6 +258,7 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
     stats[nbins + world + rank] = stats[:nbins].sum()
     dist.all_reduce(stats, group=group)
     stats_h = stats.cpu()
+    _mark(stages, "histogram")
     cum = torch.cumsum(stats_h[:nbins], 0)
     lens_h = [int(x) for x in stats_h[nbins:nbins + world].tolist()]
     valid_h = [int(x) for x in stats_h[nbins + world:].tolist()]
@@ -193,6 +290,7 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
                                                 ws.numel() - (ws_ptr - ws.data_ptr()), records.data_ptr(),
                                                 counts.data_ptr(), C.byref(n_valid), stream))
     n_null = n - n_valid.value
+    _mark(stages, "partition")
 
     # 3. block sizes, then the ONE data exchange
     recv_counts = torch.empty_like(counts)
@@ -202,6 +300,7 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
     recv_nulls = [(lens_h[s] - valid_h[s]) if rank == target else 0 for s in range(world)]
     recv = [recv_valid[s] + recv_nulls[s] for s in range(world)]
     got = _all_to_all_bytes(records[: n * SORT_RECORD_BYTES], send, recv, SORT_RECORD_BYTES, group)
+    _mark(stages, "exchange")
 
     # 4. unpack (keys + GLOBAL rows, compacted in source order), local stable sort, one gather
     m_valid, m_null = sum(recv_valid), sum(recv_nulls)
@@ -222,4 +321,5 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
         parts = [null_rows[:m_null], sorted_rows] if nulls_first else [sorted_rows, null_rows[:m_null]]
         sorted_rows = torch.cat(parts)   # buffer concatenation only (the target rank, shards with nulls)
     assert int(sorted_rows.numel()) == owned[rank], (int(sorted_rows.numel()), owned[rank])
+    _mark(stages, "local_sort")
     return sorted_rows, start

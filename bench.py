@@ -834,6 +834,7 @@ def hash_sum_leg(args, rank, world, device, rows_total, steps, warmup):
            "mrows_per_s": round(rows / sec / 1e6, 1), "scaling": "strong",
            "exchange": "local aggregate -> 1 count exchange + ONE all-to-all(v) of 24-byte partials -> merge" if world > 1 else "none (one rank)",
            "checksum_matches_sum_of_values": ok,
+           "stage_ms_max_over_ranks_untimed_run": _LAST_STAGES.get("hash_sum"),
            "roofline": {"bound": "hbm", "kernel": "arx_groupby_sum_i64_consume (gbp_hist + ONE flat 2048-bin scatter + 8192-slot LDS aggregate; probe slice on the two-level plan)",
                         "achieved": round(per_gpu, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 12,
@@ -853,6 +854,7 @@ def sort_leg(args, rank, world, device, rows_total, steps, warmup):
            "scaling": "strong",
            "exchange": "1 all-reduce (splitter histogram) + 1 count exchange + ONE all-to-all(v) of 12-byte records" if world > 1 else "none (one rank)",
            "permutation_and_order_checks": ok,
+           "stage_ms_max_over_ranks_untimed_run": _LAST_STAGES.get("sort_indices"),
            "roofline": {"bound": "hbm", "kernel": "arx_sort_indices (msd_hist + scatter levels + LDS bucket finish)",
                         "achieved": round(per_gpu, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 16,
@@ -863,6 +865,17 @@ def sort_leg(args, rank, world, device, rows_total, steps, warmup):
         except Exception as e:
             leg["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return leg
+
+
+_LAST_STAGES = {}      # per-stage ms (max over ranks) of the last sharded legs, filled by the measure_* functions
+
+
+def _stage_max(ms: dict, world, device) -> dict:
+    names = sorted(ms)
+    t = torch.tensor([ms[k] for k in names], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return {k: round(float(x), 3) for k, x in zip(names, t.tolist())}
 
 
 def measure_hash_sum(rank, world, device, rows_total, groups, steps, warmup):
@@ -903,6 +916,11 @@ def measure_hash_sum(rank, world, device, rows_total, groups, steps, warmup):
     if world > 1:
         torch.distributed.all_reduce(cs)
     ok = int(cs[0].item()) == int(cs[1].item())
+    # one more, UNTIMED run with the stream synchronised between the stages: where the time goes on every rank
+    res = None
+    st = parallel.Stages(device)
+    res = parallel.sharded_group_by_sum(kk, vv, cap, stages=st)
+    _LAST_STAGES["hash_sum"] = _stage_max(st.ms, world, device)
     del keys, vals, kk, vv, res
     return elapsed / steps, n * world, int(cs[2].item()), int(cs[0].item()), ok
 
@@ -937,6 +955,10 @@ def measure_sort(rank, world, device, rows_total, steps, warmup):
     _sync(device)
     _barrier(world)
     elapsed = _max_over_ranks(time.perf_counter() - t0, world, device)
+    rows = None
+    st = parallel.Stages(device)          # untimed: per-stage ms with the stream synchronised between the stages
+    rows, start = parallel.sharded_sort_indices(ak, stages=st)
+    _LAST_STAGES["sort_indices"] = _stage_max(st.ms, world, device)
     total = n * world
     m = int(rows.numel())
     s1, s2 = 0, 0

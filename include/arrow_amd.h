@@ -630,6 +630,21 @@ typedef struct ArxGroupPartial {
   uint8_t no_nulls;     /* 0 once a null value hit the group */
   uint8_t pad[2];
 } ArxGroupPartial;
+/* The ROW-level exchange of the same group-by (the variant BASELINE.json words as "shard by radix
+ * partition ... all-to-all"): the rows themselves are grouped by the rank that owns their key (the same hash(key) %
+ * num_parts) as 16-byte records, exchanged, unpacked into key / value columns with validity bitmaps and consumed by the
+ * receiver's own table.  Pays off only when almost every row is its own group; otherwise the partials exchange moves
+ * G x 24 bytes instead of N x 16.  flags: bit 0 = key valid, bit 1 = value valid.  Asynchronous. */
+typedef struct ArxRowRecord {
+  int32_t key;
+  uint32_t flags;
+  int64_t value;
+} ArxRowRecord;
+int arx_groupby_partition_rows(const ArxSpan* keys_i32, const ArxSpan* values_i64, int num_parts, void* ws, size_t ws_bytes,
+                               ArxRowRecord* out_records, int64_t* out_part_counts /* device int64[num_parts] */, void* stream);
+/* out_key_validity / out_value_validity: ceil(num_records / 64) 64-bit words each. */
+int arx_groupby_unpack_rows(const ArxRowRecord* records, int64_t num_records, int32_t* out_keys, int64_t* out_values,
+                            void* out_key_validity, void* out_value_validity, void* stream);
 int arx_groupby_export_partitioned(void* state, int num_parts, void* ws /* arx_groupby_partition_workspace_bytes */,
                                    size_t ws_bytes, ArxGroupPartial* out_records,
                                    int64_t* out_part_counts /* device int64[num_parts] */, void* stream);

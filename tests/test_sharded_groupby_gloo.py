@@ -39,8 +39,12 @@ WORKER = textwrap.dedent(r'''
     k = U.random_array(rng, np.int32, n, null_p=0.02, offset=rank, lo=-300, hi=300)
     v = U.random_array(rng, np.int64, n, null_p=0.15, offset=2)
     opts = arrow_amd.compute.ScalarAggregateOptions(skip_nulls=SKIP_NULLS, min_count=MIN_COUNT)
+    stages = parallel.Stages(torch.device("cpu"))
     gk, gkv, gs, gvalid = parallel.sharded_group_by_sum(k.to_device(arrow_amd), v.to_device(arrow_amd),
-                                                        2048, opts)
+                                                        2048, opts, exchange=EXCHANGE, stages=stages)
+    want_stages = {"partials": ["consume", "export", "exchange", "merge", "finalize"],
+                   "rows": ["partition_rows", "exchange", "consume", "finalize"]}[EXCHANGE]
+    assert list(stages.ms) == want_stages, stages.ms
     mine = dict(keys=gk.numpy(), key_is_valid=gkv.numpy(), sums=gs.numpy(), valid=gvalid.numpy(),
                 shard=(k.values[k.offset:k.offset + n].copy(), None if k.valid is None else k.valid[k.offset:k.offset + n].copy(),
                        v.values[v.offset:v.offset + n].copy(), None if v.valid is None else v.valid[v.offset:v.offset + n].copy()))
@@ -54,8 +58,9 @@ WORKER = textwrap.dedent(r'''
 ''')
 
 
-@pytest.mark.parametrize("skip_nulls,min_count", [(True, 1), (False, 2)])
-def test_sharded_group_by_sum_world2_gloo(tmp_path, skip_nulls, min_count):
+@pytest.mark.parametrize("skip_nulls,min_count,exchange", [(True, 1, "partials"), (False, 2, "partials"), (False, 2, "rows"),
+                                                           (True, 1, "rows")])
+def test_sharded_group_by_sum_world2_gloo(tmp_path, skip_nulls, min_count, exchange):
     import pickle
 
     import numpy as np
@@ -63,7 +68,7 @@ def test_sharded_group_by_sum_world2_gloo(tmp_path, skip_nulls, min_count):
     from oracle import oracle as O
 
     out = str(tmp_path / "result.pkl")
-    code = (f"ROOT = {ROOT!r}\nOUT = {out!r}\nSKIP_NULLS = {skip_nulls!r}\nMIN_COUNT = {min_count!r}\n" + WORKER)
+    code = (f"ROOT = {ROOT!r}\nOUT = {out!r}\nSKIP_NULLS = {skip_nulls!r}\nMIN_COUNT = {min_count!r}\nEXCHANGE = {exchange!r}\n" + WORKER)
     port = 29500 + (os.getpid() % 2000)
     procs = []
     for rank in range(2):
