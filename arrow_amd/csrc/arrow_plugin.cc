@@ -55,6 +55,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <dlfcn.h>
+
+#include <chrono>
 #include <functional>
 #include <map>
 #include <memory>
@@ -88,6 +91,7 @@ namespace {
 #include "plugin/scalar_aggregate.inc"
 #include "plugin/acero_node.inc"
 #include "plugin/acero_node_general.inc"
+#include "plugin/sharded.inc"
 #include "plugin/order_by_node.inc"
 #include "plugin/parquet.inc"
 #include "plugin/registration.inc"
@@ -172,6 +176,76 @@ int arrow_amd_copy_to_host(struct ArrowDeviceArray* in, struct ArrowSchema* sche
     };
     ARROW_ASSIGN_OR_RAISE(auto data, to_host(*dev->data()));
     return arrow::ExportArray(*arrow::MakeArray(data), out, out_schema);
+  };
+  const Status st = run();
+  if (!st.ok()) {
+    t_error = st.ToString();
+    return -1;
+  }
+  return 0;
+}
+// ---- the sharded hash_sum group-by over RCCL (plugin/sharded.inc): one process per GPU.
+// Rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the others by whatever channel the application has.
+int arrow_amd_sharded_unique_id(void* out_128_bytes) {
+  auto run = [&]() -> Status {
+    ARROW_ASSIGN_OR_RAISE(const RcclApi* api, Rccl());
+    RCCL_RETURN_NOT_OK(api, api->GetUniqueId(static_cast<NcclId*>(out_128_bytes)));
+    return Status::OK();
+  };
+  const Status st = run();
+  if (!st.ok()) {
+    t_error = st.ToString();
+    return -1;
+  }
+  return 0;
+}
+int arrow_amd_sharded_comm_create(const void* id_128_bytes, int world, int rank, void** out_comm) {
+  auto run = [&]() -> Status {
+    if (world < 1 || world > 1024 || rank < 0 || rank >= world) return Status::Invalid("bad world / rank");
+    ARROW_ASSIGN_OR_RAISE(const RcclApi* api, Rccl());
+    NcclId id;
+    std::memcpy(&id, id_128_bytes, sizeof(id));
+    auto c = std::make_unique<ShardedComm>();
+    c->world = world;
+    c->rank = rank;
+    RCCL_RETURN_NOT_OK(api, api->CommInitRank(&c->comm, world, id, rank));
+    *out_comm = c.release();
+    return Status::OK();
+  };
+  const Status st = run();
+  if (!st.ok()) {
+    t_error = st.ToString();
+    return -1;
+  }
+  return 0;
+}
+void arrow_amd_sharded_comm_destroy(void* comm) {
+  auto* c = static_cast<ShardedComm*>(comm);
+  if (c == nullptr) return;
+  auto api = Rccl();
+  if (api.ok() && c->comm != nullptr) (void)(*api)->CommDestroy(c->comm);
+  delete c;
+}
+// This rank's row shard (device arrays, C Device Data interface, consumed) -> this rank's groups.  exchange: 0 = the
+// partial aggregates (default), 1 = the rows.  stage_ms: NULL, or 5 doubles (consume / export / exchange / merge /
+// finalize; rows: partition_rows / exchange / consume / finalize / 0) — then the stream is synchronised per stage.
+int arrow_amd_sharded_group_by_sum(void* comm, struct ArrowDeviceArray* keys, struct ArrowSchema* keys_schema,
+                                   struct ArrowDeviceArray* values, struct ArrowSchema* values_schema, int skip_nulls,
+                                   uint32_t min_count, int exchange, struct ArrowDeviceArray* out_keys,
+                                   struct ArrowSchema* out_keys_schema, struct ArrowDeviceArray* out_sums,
+                                   struct ArrowSchema* out_sums_schema, double* stage_ms) {
+  auto run = [&]() -> Status {
+    if (comm == nullptr) return Status::Invalid("arrow_amd_sharded_group_by_sum: no communicator");
+    ARROW_ASSIGN_OR_RAISE(auto k, arrow::ImportDeviceArray(keys, keys_schema));
+    ARROW_ASSIGN_OR_RAISE(auto v, arrow::ImportDeviceArray(values, values_schema));
+    if (stage_ms != nullptr) std::fill(stage_ms, stage_ms + 5, 0.0);
+    std::shared_ptr<ArrayData> ok, os;
+    ARROW_RETURN_NOT_OK(ShardedGroupBySum(*static_cast<ShardedComm*>(comm), *k->data(), *v->data(), skip_nulls != 0, min_count,
+                                          exchange, &ok, &os, stage_ms));
+    ARROW_RETURN_NOT_OK(arrow::ExportType(*ok->type, out_keys_schema));
+    ARROW_RETURN_NOT_OK(arrow::ExportDeviceArray(*arrow::MakeArray(ok), nullptr, out_keys));
+    ARROW_RETURN_NOT_OK(arrow::ExportType(*os->type, out_sums_schema));
+    return arrow::ExportDeviceArray(*arrow::MakeArray(os), nullptr, out_sums);
   };
   const Status st = run();
   if (!st.ok()) {

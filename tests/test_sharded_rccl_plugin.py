@@ -1,0 +1,148 @@
+"""The plugin's sharded hash_sum group-by (arrow_amd/csrc/plugin/sharded.inc: RCCL called directly from C++, no torch).
+
+CPU tier: world_size 2, one process per rank, the shim built against the emulated kernels and a file-based stand-in for
+the RCCL entry points it resolves with dlsym (tests/emu/fake_rccl) — the real counts all-gather, the real per-peer
+send / recv group, the real merge.  The union of the ranks' groups must be pyarrow's group_by of the concatenated shards,
+every key owned by exactly one rank; both exchanges (partial aggregates, rows).
+GPU tier (-m gpu): the same entry points on ONE GPU over the real librccl (a one-rank communicator: the all-gather and
+the self send / recv go through RCCL)."""
+import os
+import pickle
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent(r'''
+    import ctypes, os, pickle, sys, time
+    import numpy as np
+    import pyarrow as pa
+    sys.path.insert(0, ROOT)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin(verbose=False))
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(m) for m in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(m) for m in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    # the unique id: rank 0 makes it, the others read it from a file (any channel will do)
+    id_file = OUT + ".id"
+    ident = ctypes.create_string_buffer(128)
+    if rank == 0:
+        assert lib.arrow_amd_sharded_unique_id(ident) == 0, lib.arrow_amd_plugin_last_error()
+        with open(id_file + ".tmp", "wb") as f:
+            f.write(ident.raw)
+        os.rename(id_file + ".tmp", id_file)
+    else:
+        for _ in range(6000):
+            if os.path.exists(id_file):
+                break
+            time.sleep(0.01)
+        ident = ctypes.create_string_buffer(open(id_file, "rb").read(), 128)
+    comm = ctypes.c_void_p()
+    assert lib.arrow_amd_sharded_comm_create(ident, world, rank, ctypes.byref(comm)) == 0, lib.arrow_amd_plugin_last_error()
+
+    rng = np.random.default_rng(2000 + rank)
+    n = N_ROWS + 777 * rank                       # ragged shards
+    k = pa.array(rng.integers(-KEY_RANGE, KEY_RANGE, n).astype(np.int32), mask=rng.random(n) < 0.02)
+    v = pa.array(rng.integers(-2**63, 2**63 - 1, n), mask=rng.random(n) < 0.15)
+    results = {}
+    lib.arrow_amd_sharded_group_by_sum.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_uint32, ctypes.c_int] + \
+        [ctypes.c_void_p] * 4 + [ctypes.c_void_p]
+    for exchange in (0, 1):
+        for skip_nulls, min_count in ((1, 1), (0, 2)):
+            dk, dv = to_device(k), to_device(v)
+            bufs = [ctypes.create_string_buffer(m) for m in (128, 72, 128, 72, 128, 72, 128, 72)]
+            dk._export_to_c_device(ctypes.addressof(bufs[0]), ctypes.addressof(bufs[1]))
+            dv._export_to_c_device(ctypes.addressof(bufs[2]), ctypes.addressof(bufs[3]))
+            stage_ms = (ctypes.c_double * 5)()
+            rc = lib.arrow_amd_sharded_group_by_sum(comm, *[ctypes.addressof(b) for b in bufs[:4]], skip_nulls, min_count, exchange,
+                                                    *[ctypes.addressof(b) for b in bufs[4:]], stage_ms)
+            assert rc == 0, lib.arrow_amd_plugin_last_error()
+            gk = pa.Array._import_from_c_device(ctypes.addressof(bufs[4]), ctypes.addressof(bufs[5]))
+            gs = pa.Array._import_from_c_device(ctypes.addressof(bufs[6]), ctypes.addressof(bufs[7]))
+            assert not gk.is_cpu and not gs.is_cpu
+            assert sum(1 for x in stage_ms if x > 0) >= 4, list(stage_ms)
+            results[(exchange, skip_nulls, min_count)] = (to_host(gk).to_pylist(), to_host(gs).to_pylist())
+    lib.arrow_amd_sharded_comm_destroy(comm)
+    with open(OUT + f".rank{rank}", "wb") as f:
+        pickle.dump(dict(keys=k.to_pylist(), values=v.to_pylist(), results=results), f)
+''')
+
+
+def _run_ranks(tmp_path, world, env_extra, n_rows, key_range):
+    out = str(tmp_path / "result")
+    code = f"ROOT = {ROOT!r}\nOUT = {out!r}\nN_ROWS = {n_rows}\nKEY_RANGE = {key_range}\n" + WORKER
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), **env_extra)
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    return [pickle.load(open(out + f".rank{r}", "rb")) for r in range(world)]
+
+
+def _check(ranks):
+    import pyarrow as pa
+    import pyarrow.compute as pc
+
+    keys = pa.array([x for r in ranks for x in r["keys"]], pa.int32())
+    vals = pa.array([x for r in ranks for x in r["values"]], pa.int64())
+    t = pa.table({"k": keys, "v": vals})
+    for (exchange, skip_nulls, min_count) in ranks[0]["results"]:
+        opts = pc.ScalarAggregateOptions(skip_nulls=bool(skip_nulls), min_count=min_count)
+        ref = t.group_by("k", use_threads=False).aggregate([("v", "sum", opts)])
+        want = dict(zip(ref.column("k").to_pylist(), ref.column("v_sum").to_pylist()))
+        got = {}
+        for r in ranks:
+            gk, gs = r["results"][(exchange, skip_nulls, min_count)]
+            for key, s in zip(gk, gs):
+                assert key not in got, f"key {key} owned by two ranks (exchange {exchange})"
+                got[key] = s
+        assert got == want, (exchange, skip_nulls, min_count, len(got), len(want))
+        if len(ranks) > 1:
+            assert all(len(r["results"][(exchange, skip_nulls, min_count)][0]) > 0 for r in ranks)
+
+
+@pytest.mark.emu
+def test_sharded_group_by_sum_cpp_world2_over_a_file_based_rccl_stand_in(tmp_path):
+    pytest.importorskip("pyarrow")
+    from tests.emu.build_plugin_emu import build_plugin
+
+    build_plugin(verbose=False)       # once, before the ranks start (they would race on the objects)
+    fake = os.path.join(ROOT, "tests", "emu", "_build", "libfake_rccl.so")
+    subprocess.check_call(["gcc", "-O1", "-fPIC", "-shared", "-o", fake, os.path.join(ROOT, "tests", "emu", "fake_rccl", "fake_rccl.c")])
+    ranks = _run_ranks(tmp_path, 2, dict(ARROW_AMD_PLUGIN_EMULATED="1", ARROW_AMD_RCCL_LIBRARY=fake), 6000, 300)
+    _check(ranks)
+
+
+@pytest.mark.gpu
+def test_sharded_group_by_sum_cpp_one_rank_over_the_real_rccl(tmp_path):
+    pytest.importorskip("pyarrow")
+    ranks = _run_ranks(tmp_path, 1, {}, 2_000_000, 70_000)
+    _check(ranks)
