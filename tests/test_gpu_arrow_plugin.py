@@ -400,6 +400,100 @@ GENERAL_GROUP_BY_SCRIPT = textwrap.dedent(r'''
 ''')
 
 
+DEVICE_INTERFACES_SCRIPT = textwrap.dedent(r'''
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    emulated = os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1"
+    if emulated:      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_sync_event_waits.restype = ctypes.c_int64
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(m) for m in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(m) for m in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    rng = np.random.default_rng(61)
+    n = 200_000 if emulated else 5_000_000
+    vals = pa.array(rng.integers(-2**62, 2**62, n), mask=rng.random(n) < 0.1)
+    mask = pa.array(rng.random(n) < 0.2)
+    d_vals, d_mask = to_device(vals), to_device(mask)
+    # ---- Device::Stream + SyncEvent: a producer that does NOT synchronise hands its array over with sync_event set;
+    # the importer's buffers carry the event and the shims make their stream wait for it before the kernels read
+    c_dev, c_schema, o_dev, o_schema = (ctypes.create_string_buffer(m) for m in (128, 72, 128, 72))
+    d_vals._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+    assert lib.arrow_amd_copy_on_stream_with_event(c_dev, c_schema, o_dev, o_schema) == 0, lib.arrow_amd_plugin_last_error()
+    sync_event = ctypes.cast(ctypes.addressof(o_dev) + 96, ctypes.POINTER(ctypes.c_void_p))[0]     # ArrowDeviceArray.sync_event
+    assert sync_event, "the exported array carries no sync event"
+    evented = pa.Array._import_from_c_device(ctypes.addressof(o_dev), ctypes.addressof(o_schema))
+    w0 = lib.arrow_amd_plugin_sync_event_waits()
+    got = pc.filter(evented, d_mask)
+    assert lib.arrow_amd_plugin_sync_event_waits() > w0, "the imported buffers' sync event was not waited for"
+    assert to_host(got).equals(pc.filter(vals, mask))
+    # ---- MemoryManager::GetBufferWriter / GetBufferReader
+    src = rng.integers(0, 256, 1_000_003, dtype=np.uint8)
+    dst = np.zeros_like(src)
+    assert lib.arrow_amd_device_buffer_round_trip(src.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(src)),
+                                                  dst.ctypes.data_as(ctypes.c_void_p)) == 0, lib.arrow_amd_plugin_last_error()
+    assert (src == dst).all()
+    # ---- DLPack: refusals everywhere; the zero-copy hand-over to PyTorch-ROCm on the GPU tier
+    lib.arrow_amd_export_dlpack.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    def dlpack(darr):
+        c_dev, c_schema = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72)
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        out = ctypes.c_void_p()
+        rc = lib.arrow_amd_export_dlpack(ctypes.addressof(c_dev), ctypes.addressof(c_schema), ctypes.byref(out))
+        return rc, out, lib.arrow_amd_plugin_last_error()
+    rc, _, msg = dlpack(d_vals)
+    assert rc != 0 and b"no nulls" in msg, msg
+    rc, _, msg = dlpack(d_mask)
+    assert rc != 0 and b"DLPack" in msg, msg
+    dense = pa.array(rng.integers(-2**62, 2**62, n))
+    d_dense = to_device(dense)
+    rc, ptr, msg = dlpack(d_dense.slice(5))
+    assert rc == 0, msg
+    class DLTensor(ctypes.Structure):
+        _fields_ = [("data", ctypes.c_void_p), ("device_type", ctypes.c_int32), ("device_id", ctypes.c_int32), ("ndim", ctypes.c_int32),
+                    ("code", ctypes.c_uint8), ("bits", ctypes.c_uint8), ("lanes", ctypes.c_uint16), ("shape", ctypes.POINTER(ctypes.c_int64)),
+                    ("strides", ctypes.c_void_p), ("byte_offset", ctypes.c_uint64)]
+    t = DLTensor.from_address(ptr.value)
+    assert (t.device_type, t.ndim, t.code, t.bits, t.lanes, t.shape[0], t.byte_offset) == (10, 1, 0, 64, 1, n - 5, 40), \
+        (t.device_type, t.ndim, t.code, t.bits, t.lanes, t.shape[0], t.byte_offset)
+    if emulated:
+        # nobody takes the capsule here: call the deleter ourselves (DLManagedTensor.deleter follows manager_ctx)
+        deleter = ctypes.cast(ctypes.c_void_p.from_address(ptr.value + ctypes.sizeof(DLTensor) + 8).value, ctypes.CFUNCTYPE(None, ctypes.c_void_p))
+        deleter(ptr.value)
+    else:
+        import torch
+        ctypes.pythonapi.PyCapsule_New.restype = ctypes.py_object
+        ctypes.pythonapi.PyCapsule_New.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p]
+        capsule = ctypes.pythonapi.PyCapsule_New(ptr, b"dltensor", None)
+        tensor = torch.from_dlpack(capsule)
+        assert tensor.is_cuda and tensor.dtype == torch.int64 and tensor.numel() == n - 5
+        assert tensor.data_ptr() == t.data + 40, "not zero-copy"
+        assert torch.equal(tensor.cpu(), torch.from_numpy(dense.to_numpy()[5:]))
+        # and the tensor outlives the Arrow array: the buffers stay alive until the tensor is dropped
+        del d_dense
+        assert int(tensor[123].item()) == int(dense[128].as_py())
+    print("DEVICE_INTERFACES_OK")
+''')
+
+
 def test_pyarrow_compute_dispatches_to_the_hip_kernels():
     pytest.importorskip("pyarrow")
     code = f"ROOT = {ROOT!r}\n" + SCRIPT
@@ -1971,3 +2065,11 @@ def test_aggregate_rocm_with_int64_and_multi_column_keys_through_the_device_grou
     modes) / count_all — the device Grouper + dense hash kernels, equal to the reference GroupByNode with the reference
     kernels (taken before registration); host batches and device-resident sliced batches."""
     _run(GENERAL_GROUP_BY_SCRIPT, "GENERAL_GROUP_BY_OK")
+
+
+def test_device_streams_sync_events_buffer_reader_writer_and_dlpack():
+    """SURVEY 8 (f1) completeness: Device::MakeStream / SyncEvent over hipStream_t / hipEvent_t, ArrowDeviceArray.sync_event
+    exported by a producer that does not synchronise and waited for (on the stream, not the host) before the shims' kernels
+    read the imported buffers, MemoryManager::GetBufferWriter / GetBufferReader, DLPack export of a device array into
+    PyTorch-ROCm: zero-copy (pointer equality), refused for nulls / non-numeric types like the reference."""
+    _run(DEVICE_INTERFACES_SCRIPT, "DEVICE_INTERFACES_OK")

@@ -92,3 +92,7 @@ def test_vector_hash_kernels_and_numeric_casts_emulated():
 
 def test_aggregate_rocm_general_keys_emulated():
     _run(G.GENERAL_GROUP_BY_SCRIPT, "GENERAL_GROUP_BY_OK", 0.01)
+
+
+def test_device_streams_events_reader_writer_dlpack_emulated():
+    _run(G.DEVICE_INTERFACES_SCRIPT, "DEVICE_INTERFACES_OK", 1)
