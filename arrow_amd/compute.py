@@ -1505,6 +1505,26 @@ class GroupBySum:
                                                f"(the device table holds 32-bit keys): {e}") from None
         raise ArrowNotImplementedError(f"GroupBySum: keys of type {name}")
 
+    def _typed_keys(self, keys_i32: torch.Tensor) -> torch.Tensor:
+        """The table's int32 keys in the CALLER's key type: the bit-reinterpreted 32-bit types get their own
+        view back (uint32 >= 2^31 would read as negative), the widened narrow integers are narrowed again (every value
+        fits: it came from that type), 64-bit keys that passed the checked cast are widened.  Temporal 32-bit types
+        keep their physical int32 values (days / seconds / milliseconds), 64-bit temporal types int64."""
+        kt = getattr(self, "key_type", None)
+        if kt is None or kt == int32:
+            return keys_i32
+        name = kt.name
+        if name == "uint32":
+            return keys_i32.view(torch.uint32)
+        if name in ("date32[day]", "time32[s]", "time32[ms]"):
+            return keys_i32
+        narrow = {"int8": torch.int8, "int16": torch.int16, "uint8": torch.uint8, "uint16": torch.uint16}
+        if name in narrow:
+            return keys_i32.to(narrow[name])
+        if name == "uint64":
+            return keys_i32.to(torch.int64).view(torch.uint64)      # (non-negative: it passed the checked cast)
+        return keys_i32.to(torch.int64)
+
     def _normalise_value(self, values: Array) -> Array:
         name = values.type.name
         prev = getattr(self, "value_type", None)
@@ -1604,7 +1624,7 @@ class GroupBySum:
                                      maxs.data_ptr(), stream))
         check(lib.arx_groupby_minmax_finalize(mins.data_ptr(), maxs.data_ptr(), nn.data_ptr(), g,
                                               int(self.options.skip_nulls), valid.data_ptr(), stream))
-        return keys[:g], kv[:g], mins[:g], maxs[:g], valid[:g]
+        return self._typed_keys(keys[:g]), kv[:g], mins[:g], maxs[:g], valid[:g]
 
     def finalize_mean(self):
         """hash_mean(int64): (keys, key_is_valid, means f64, valid).  Needs the rows in BOTH consume() and
@@ -1628,7 +1648,7 @@ class GroupBySum:
             raise ArrowNotImplementedError(
                 "hash_mean(int64): a group's partial sums exceed 2^53, where the reference's row-order double "
                 "accumulation is not associative (its result depends on row order); not reproducible bit for bit")
-        return p["keys"], p["key_is_valid"], means[:g], valid[:g]
+        return self._typed_keys(p["keys"]), p["key_is_valid"], means[:g], valid[:g]
 
     def num_groups(self) -> int:
         lib, stream = _lib_and_stream(self.device)
@@ -1673,7 +1693,7 @@ class GroupBySum:
         check(lib.arx_groupby_sum_i64_finalize(p["counts"].data_ptr(), p["no_nulls"].data_ptr(), g,
                                                int(self.options.skip_nulls), self.options.min_count,
                                                valid.data_ptr(), stream))
-        return p["keys"], p["key_is_valid"], p["sums"], valid[:g]
+        return self._typed_keys(p["keys"]), p["key_is_valid"], p["sums"], valid[:g]
 
 
 def indices_nonzero(arr: Array) -> Array:

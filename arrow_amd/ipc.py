@@ -211,10 +211,12 @@ def _messages(source):
     read one by one (then the whole source goes through pyarrow's reader)."""
     import pyarrow as pa
 
+    # the bytes are read ONCE, outside the try: a file-like source is consumed by read_buffer(), and the fallback must
+    # get the same bytes back (ADVICE r2: it used to re-read an exhausted stream)
+    if isinstance(source, str):
+        source = pa.memory_map(source, "r")
+    buf = source.read_buffer() if hasattr(source, "read_buffer") else pa.py_buffer(source)
     try:
-        if isinstance(source, str):
-            source = pa.memory_map(source, "r")
-        buf = source.read_buffer() if hasattr(source, "read_buffer") else pa.py_buffer(source)
         is_file = buf.size >= 8 and buf.slice(0, 6).to_pybytes() == b"ARROW1"
         reader = pa.ipc.MessageReader.open_stream(pa.BufferReader(buf.slice(8) if is_file else buf))
         schema, batches = None, []
@@ -226,8 +228,8 @@ def _messages(source):
             else:
                 return None, buf                                  # dictionary batches: pyarrow's reader
         return (schema, batches), buf
-    except Exception:
-        return None, None
+    except (pa.ArrowInvalid, OSError):
+        return None, buf                                          # the message walk failed: pyarrow's reader, same bytes
 
 
 def _batches(source):
@@ -257,6 +259,10 @@ def read_table(source, columns=None, device=None, device_decompress="auto", stat
     parsed, buf = _messages(source) if device_decompress else (None, None)
     if parsed is not None and parsed[0] is not None:
         schema, msgs = parsed
+        if columns is not None:
+            missing = [c for c in columns if c not in schema.names]
+            if missing:
+                raise KeyError(f"read_table: column(s) {missing} not in the file's schema {schema.names}")
         try:
             infos = [parse_record_batch_message(m.metadata.to_pybytes()) for m in msgs]
         except (struct.error, IndexError):      # metadata this parser cannot follow: the reference's reader decides

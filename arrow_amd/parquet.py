@@ -266,7 +266,8 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     dict_bytes, dict_count = None, 0
     level_bytes, level_runs = bytearray(), []
     index_bytes, index_runs = bytearray(), []
-    plain_bytes = bytearray()
+    plain_segments = []       # host-decoded PLAIN pages: (byte position among the PLAIN values, bytes)
+    plain_pos = 0             # bytes of PLAIN values so far (host- and device-decoded pages alike)
     device_snappy_pages = []  # (compressed block, uncompressed size, byte position among the PLAIN values)
     plain_pages = []          # BYTE_ARRAY only: (page value bytes, number of values)
     bool_bytes, bool_runs = bytearray(), []   # BOOLEAN only: every page becomes runs of one shared table
@@ -287,8 +288,8 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
             on_device = (DEVICE_SNAPPY and codec == "SNAPPY" and enc == _ENC_PLAIN and max_def_level == 0 and
                          not is_binary and not is_bool and hdr[2] == nvals * width)
             if on_device:
-                device_snappy_pages.append((bytes(payload), hdr[2], len(plain_bytes)))
-                plain_bytes += bytes(hdr[2])          # placeholder: the device writes these bytes
+                device_snappy_pages.append((bytes(payload), hdr[2], plain_pos))
+                plain_pos += hdr[2]                   # (the device writes these bytes: nothing is staged for them)
                 rows += nvals
                 dense += nvals
                 continue
@@ -319,8 +320,8 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
                     if max_def_level > 0:
                         level_runs.append(runs)
                         level_bytes += levels
-                    device_snappy_pages.append((bytes(body), hdr[2] - dl, len(plain_bytes)))
-                    plain_bytes += bytes(hdr[2] - dl)
+                    device_snappy_pages.append((bytes(body), hdr[2] - dl, plain_pos))
+                    plain_pos += hdr[2] - dl
                     rows += nvals
                     dense += valid_here
                     continue
@@ -336,7 +337,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
             valid_here = ones
         values = page[pos:]
         if enc in (_ENC_PLAIN_DICT, _ENC_RLE_DICT):
-            if len(plain_bytes) or plain_pages:
+            if plain_pos or plain_pages:
                 raise ArrowNotImplementedError("Parquet: a dictionary-encoded page after a PLAIN page in one column chunk")
             bw = values[0] if len(values) else 0
             if valid_here:
@@ -362,7 +363,8 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
             if is_binary:
                 plain_pages.append((bytes(values), valid_here, "plain"))      # offsets are built once the dictionary size is known
             else:
-                plain_bytes += values[: valid_here * width]
+                plain_segments.append((plain_pos, bytes(values[: valid_here * width])))
+                plain_pos += valid_here * width
         elif enc == _ENC_DELTA_LENGTH_BYTE_ARRAY and is_binary:
             plain_pages.append((bytes(values), valid_here, "delta_length"))
         elif enc == _ENC_BYTE_STREAM_SPLIT and not is_binary and not is_bool:
@@ -385,7 +387,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
 
     if stats is not None:
         stats["host_prep_s"] = stats.get("host_prep_s", 0.0) + (time.perf_counter() - t_start)
-        stats["encoded_bytes"] = stats.get("encoded_bytes", 0) + len(level_bytes) + len(index_bytes) + len(plain_bytes) + len(dict_bytes or b"")
+        stats["encoded_bytes"] = stats.get("encoded_bytes", 0) + len(level_bytes) + len(index_bytes) + sum(len(b) for _, b in plain_segments) + len(dict_bytes or b"")
     if is_bool:
         return _finish_boolean_chunk(lib, stream, device, bool_bytes, bool_runs, level_bytes, level_runs, rows, dense,
                                      max_def_level)
@@ -419,11 +421,21 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
             check(lib.arx_byte_stream_split_decode(d_split.data_ptr() + at, count, width, dense_buf.data_ptr() + start * width,
                                                    stream))
             at += len(data)
-    if len(plain_bytes):
+    if plain_pos:
         if delta_pages or split_pages:
             raise ArrowNotImplementedError("Parquet: PLAIN and DELTA_BINARY_PACKED / BYTE_STREAM_SPLIT pages in one column chunk")
-        host = torch.from_numpy(np.frombuffer(bytes(plain_bytes), dtype=np.uint8).copy())
-        dense_buf[dense_from_dict * width: dense * width] = host.to(device)
+        # only the HOST-decoded pages' bytes cross PCIe (zero placeholders for the device-decoded pages used to
+        # ride along, the whole uncompressed size on top of the compressed blocks); adjacent segments go in one copy
+        merged = []
+        for pos_, data in plain_segments:
+            if merged and merged[-1][0] + len(merged[-1][1]) == pos_:
+                merged[-1][1] += data
+            else:
+                merged.append([pos_, bytearray(data)])
+        for pos_, data in merged:
+            host = torch.from_numpy(np.frombuffer(bytes(data), dtype=np.uint8).copy())
+            at0 = dense_from_dict * width + pos_
+            dense_buf[at0: at0 + len(data)] = host.to(device)
         if device_snappy_pages:
             # one launch for all the chunk's device-decoded pages: the compressed blocks cross PCIe, one wave per page
             # writes its values straight into the dense buffer (after the host-decoded pages' copy above)

@@ -1102,18 +1102,35 @@ def check_cast_numeric_pair(amd, rng, in_name: str, out_name: str, n: int = 3000
             assert np.array_equal(gv[m].view(np.uint8), w[m].view(np.uint8)), tag + " values"
 
 
+def torch_dtype_as_signed(dt):
+    """torch's unsigned 16/32/64-bit dtypes have no numpy bridge: read them through the signed type of the same width."""
+    import torch
+
+    return {torch.uint16: torch.int16, torch.uint32: torch.int32, torch.uint64: torch.int64}.get(dt, dt)
+
+
 def check_groupby_sum_typed(amd, rng, key_dtype, value_dtype, n=5000):
     """hash_sum over the other integer key / value types the reference registers (Grouper key types,
     row/grouper.cc:559-611; value types + accumulators, hash_aggregate_numeric.cc:1188-1200,
     aggregate_internal.h:41-44) vs pyarrow's group_by: same groups, same sums, same output type."""
-    k = rng.integers(0, 100, n).astype(key_dtype)
+    # keys over the key type's own range where the 32-bit table can hold them (uint32 above 2^31, negative int64 that
+    # fits 32 bits): the groups must come back in the CALLER's type, not as raw int32 (ADVICE r2)
+    kinfo = np.iinfo(key_dtype)
+    lo, hi = max(int(kinfo.min), -2**31), min(int(kinfo.max), 2**31 - 1 if np.dtype(key_dtype).itemsize == 8 else int(kinfo.max))
+    pool = rng.integers(lo, hi, 100, dtype=np.int64, endpoint=True)
+    pool[:2] = [lo, hi]
+    k = pool[rng.integers(0, 100, n)].astype(key_dtype)
     info = np.iinfo(value_dtype)
     v = rng.integers(info.min, info.max, n, dtype=value_dtype, endpoint=True)
     kval, vval = rng.random(n) > 0.05, rng.random(n) > 0.1
     dk, dv = amd.Array.from_numpy(k, kval), amd.Array.from_numpy(v, vval)
     op = amd.compute.GroupBySum(1024, dk.device)
     op.consume(dk, dv)
-    gk, gkv, gs, gvalid = (x.cpu().numpy() for x in op.finalize())
+    fk, gkv, gs, gvalid = op.finalize()
+    assert str(fk.dtype).replace("torch.", "") == np.dtype(key_dtype).name, (fk.dtype, key_dtype)
+    gk = fk.cpu().view(torch_dtype_as_signed(fk.dtype)).numpy().view(key_dtype) if "uint" in str(fk.dtype) and np.dtype(key_dtype).itemsize > 1 \
+        else fk.cpu().numpy()
+    gkv, gs, gvalid = (x.cpu().numpy() for x in (gkv, gs, gvalid))
     t = pa.table({"k": pa.array(k, mask=~kval), "v": pa.array(v, mask=~vval)})
     r = t.group_by("k", use_threads=False).aggregate([("v", "sum")])
     ref = {(None if a is None else int(a)): b for a, b in zip(r.column("k").to_pylist(), r.column("v_sum").to_pylist())}
