@@ -94,6 +94,7 @@ namespace {
 #include "plugin/acero_node_general.inc"
 #include "plugin/sharded.inc"
 #include "plugin/order_by_node.inc"
+#include "plugin/acero_source.inc"
 #include "plugin/parquet.inc"
 #include "plugin/registration.inc"
 
@@ -214,8 +215,10 @@ int arrow_amd_export_dlpack(struct ArrowDeviceArray* in, struct ArrowSchema* sch
     };
     auto* ctx = new Ctx{arr, d.length, {}};
     DLTensor& t = ctx->tensor.dl_tensor;
-    t.data = reinterpret_cast<void*>(d.buffers[1]->address());
-    t.byte_offset = static_cast<uint64_t>(d.offset) * width;
+    // the slice offset goes into the pointer and byte_offset stays 0, as the reference's exporter does
+    // (c/dlpack.cc:108-116) — torch.from_dlpack refuses a non-zero byte_offset
+    t.data = reinterpret_cast<void*>(d.buffers[1]->address() + static_cast<uint64_t>(d.offset) * width);
+    t.byte_offset = 0;
     t.device = DLDevice{kDLROCM, static_cast<int32_t>(d.buffers[1]->device()->device_id())};
     t.ndim = 1;
     t.dtype = dt;
@@ -524,6 +527,11 @@ int64_t arrow_amd_plugin_parquet_copied_pages(void) { return g_parquet_copied_pa
 void arrow_amd_plugin_set_aggregate_stage_nulls(int on) { g_aggregate_stage_nulls.store(on != 0); }
 void arrow_amd_plugin_set_aggregate_flush_rows(int64_t rows) { g_aggregate_flush_rows.store(rows < 1 ? 1 : rows); }
 int64_t arrow_amd_plugin_aggregate_flushes(void) { return g_aggregate_flushes.load(); }
+// aggregate_rocm consumes a device batch of at least this many rows where it lies (no staging copy)
+void arrow_amd_plugin_set_aggregate_direct_rows(int64_t rows) { g_aggregate_direct_rows.store(rows < 1 ? 1 : rows); }
+int64_t arrow_amd_plugin_aggregate_direct_batches(void) { return g_aggregate_direct_batches.load(); }
+// table_source_rocm: rows per batch when TableSourceNodeOptions::max_batch_size is the default
+void arrow_amd_plugin_set_table_source_rows(int64_t rows) { g_table_source_rows.store(rows < 1 ? 1 : rows); }
 // The same threshold for the element-wise kernels (greater, cast); default: never stage them.
 void arrow_amd_plugin_set_min_rows_streaming(int64_t n) { g_min_rows_streaming.store(n); }
 

@@ -41,6 +41,10 @@ static int g_sort_msd_wide_sample_shift = 4;  // wide form: level-1 capacities f
 static int g_sort_xcd_map = 1;                // wide form, XCD-contiguous work numbering: bit 0 level 2 (-2.1 ms at 2e9 rows: a bucket's runs meet in one L2), bit 1 bucket finish, bit 2 level 1 (both: no effect)
 static int g_sort_msd_wide_bits = 0;           // wide form: partition bits (0 = from the row count: buckets of 2048..4096 rows; tests force many bins on few rows)
 static int g_sort_msd_wide_b2max = 10;        // wide form: most partition bits given to level 2 (<= 12; 0 = the even split).  2e9 rows: 10 and 11 = the even split (34.8-35.0 ms), 12 = 42 ms (4096-bin scatter 19.3 ms vs 12); 2^28 rows: 10 is 3 % faster than even
+static int g_sort_msd_wide_rpt1 = 24;         // wide form, level 1: rows per thread of a scatter tile (8: the tile lives in LDS; 16 / 24: in registers, moved through LDS in rounds)
+static int g_sort_msd_wide_rpt2 = 8;          // level 2 likewise
+static int g_sort_msd_tiny_bucket = 1;        // wide form: 256-thread / 2560-row bucket finish when every bucket fits it
+static int g_sort_msd_bucket_cpt = 4;         // wide form's bucket finish: sub-bucket counters per thread (4: <= 4 T sub-buckets, 8: <= 8 T)
 static int g_sort_msd_prefix = 1;             // MSD forms take their digits below the bits that ALL keys share (ids, timestamps, small ints: the top bits are equal)
 static int g_sort_msd_wide_gap2 = 1;          // wide form: level-2 buckets get a fixed room each (bucket mean + 6 sigma + 64) instead of an exact histogram pass
 static int g_sort_msd_wide_sample_strict = 0; // tests: a sampled attempt that overflows is an error instead of a silent exact re-run
@@ -91,6 +95,34 @@ __device__ __forceinline__ uint64_t load_key_typed(const void* base, int64_t i, 
   }
   if (xf & kXfDesc) k = ~k;
   return k;
+}
+// the same transform applied to bits already loaded (64-bit types: the value; 32-bit types: the value zero-extended)
+__device__ __forceinline__ uint64_t key_from_bits(uint64_t b, int xf) {
+  uint64_t k;
+  switch ((xf >> 4) & 7) {
+    case 0: k = b; break;
+    case 1: k = b ^ 0x8000000000000000ull; break;
+    case 2: k = b << 32; break;
+    case 3: k = (b ^ 0x80000000ull) << 32; break;
+    case 4: {
+      if ((b << 1) == 0) b = 0;
+      k = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+      break;
+    }
+    default: {
+      uint32_t w = static_cast<uint32_t>(b);
+      if ((w << 1) == 0) w = 0;
+      const uint32_t t = (w >> 31) ? ~w : (w | 0x80000000u);
+      k = static_cast<uint64_t>(t) << 32;
+      break;
+    }
+  }
+  if (xf & kXfDesc) k = ~k;
+  return k;
+}
+__device__ __forceinline__ bool key_type_is_64bit(int xf) {
+  const int kt = (xf >> 4) & 7;
+  return kt == 0 || kt == 1 || kt == 4;
 }
 // legacy form for the 64-bit-only multi-GPU helpers
 __device__ __forceinline__ uint64_t key_transform(uint64_t k, bool is_signed, bool descending) {
@@ -1107,6 +1139,8 @@ constexpr int kBktRows = 10;                       // per thread
 constexpr int kBktCap = kBktThreads * kBktRows;    // 10240 rows = 120 KiB of LDS
 constexpr int kBktThreadsSmall = 512;
 constexpr int kBktCapSmall = kBktThreadsSmall * kBktRows;
+constexpr int kBktThreadsTiny = 256;   // wide form with 2^20 buckets of ~2K rows: 34 KB of LDS, four finishes per CU
+constexpr int kBktCapTiny = kBktThreadsTiny * kBktRows;
 constexpr int kBktMaxBins = 1024;
 
 template <int T>
@@ -1245,19 +1279,20 @@ __global__ __launch_bounds__(T) void msd_bucket_kernel(MsdArgs a, const uint64_t
 //   * up to 4096 (T = 1024) / 2048 (T = 512) sub-buckets instead of 1024, counters scanned in place: sub-buckets
 //     of ~2-4 rows make the final ranking loop one short iteration for almost every row (it was the dominant
 //     phase at ~8 rows: LDS reads grow with the square of the sub-bucket size).
-template <int T>
+template <int T, int CPT = 4>
 struct __attribute__((aligned(16))) MsdBucket2Lds {
   uint64_t keys[T * kBktRows];
   uint32_t idx[T * kBktRows];
-  uint32_t start[4 * T + 1];     // counts, then exclusive starts (+ sentinel)
+  uint32_t start[CPT * T + 1];   // counts, then exclusive starts (+ sentinel)
   uint32_t wave_tot[T / 64];
 };
 
 // AOS: the bucket's rows are 12-byte records starting at record part_in[q] of `keys` (idx unused)
-template <bool SPL, int T, bool AOS = false>
+// CPT: sub-bucket counters per thread of the scan (sub-buckets <= CPT * T)
+template <bool SPL, int T, bool AOS = false, int CPT = 4>
 __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ idx) {
-  __shared__ MsdBucket2Lds<T> w;
+  __shared__ MsdBucket2Lds<T, CPT> w;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -1316,12 +1351,12 @@ __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_
     if (i * T + tid < m) rank[i] = atomicAdd(&w.start[dig[i]], 1u);
   }
   __syncthreads();
-  // in-place exclusive scan of nb <= 4 T counters: 4 consecutive counters per thread
-  uint32_t c[4];
+  // in-place exclusive scan of nb <= CPT * T counters: CPT consecutive counters per thread
+  uint32_t c[CPT];
   uint32_t mine = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int b = tid * 4 + k;
+  for (int k = 0; k < CPT; ++k) {
+    const int b = tid * CPT + k;
     c[k] = b < nb ? w.start[b] : 0u;
     mine += c[k];
   }
@@ -1331,8 +1366,8 @@ __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_
   uint32_t pre = incl - mine;
   for (int k = 0; k < wave; ++k) pre += w.wave_tot[k];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int b = tid * 4 + k;
+  for (int k = 0; k < CPT; ++k) {
+    const int b = tid * CPT + k;
     if (b < nb) w.start[b] = pre;
     pre += c[k];
   }
@@ -1347,32 +1382,35 @@ __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_
     }
   }
   __syncthreads();
+  // rank inside the sub-bucket (~2 rows): keys only, two per step; row ids are read only where a key repeats.  The
+  // finish is bound by its LDS traffic (profiles/r03_i): this loop was 9 of the ~13 LDS accesses per row when it read
+  // four (key, row id) pairs per step.
   for (int i = tid; i < m; i += T) {
     const uint64_t ki = w.keys[i];
-    const uint32_t ii = w.idx[i];
     const uint32_t d = digit_of(ki);
     const int bs = static_cast<int>(w.start[d]);
     const int be = static_cast<int>(w.start[d + 1]);
     int rk = 0;
-    for (int j = bs; j < be; j += 4) {
-      uint64_t kj[4];
-      uint32_t ij[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int jj = (j + u) < be ? (j + u) : (be - 1);
-        kj[u] = w.keys[jj];
-        ij[u] = w.idx[jj];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool less = kj[u] < ki || (kj[u] == ki && ij[u] < ii);
-        rk += (less && (j + u) < be) ? 1 : 0;
-      }
+    bool tie = false;
+    for (int j = bs; j < be; j += 2) {
+      const bool two = j + 1 < be;
+      const uint64_t k0 = w.keys[j];
+      const uint64_t k1 = w.keys[two ? j + 1 : j];
+      rk += (k0 < ki ? 1 : 0) + ((two && k1 < ki) ? 1 : 0);
+      tie = tie || (k0 == ki && j != i) || (two && k1 == ki && j + 1 != i);
+    }
+    const uint32_t ii = w.idx[i];
+    if (tie) {   // equal keys keep the order of their row ids
+      for (int j = bs; j < be; ++j) rk += (w.keys[j] == ki && w.idx[j] < ii) ? 1 : 0;
     }
     a.out_final[lo + bs + rk] = ii;
   }
 }
 
+// (A persistent form of this finish — workgroups walking buckets q, q + grid, ... and loading the next bucket's rows
+// into registers before ranking the current one — measured SLOWER: 13.7 ms against 11.4 ms for 2^19 buckets, and a
+// grid of one workgroup per CU instead of two 43 ms end to end instead of 36: the finish is bound by its LDS phases and
+// by how many workgroups interleave them, not by the latency of its loads.  profiles/r03_i_sort_persistent_bucket_ab.txt)
 // part_count + part_start + cursor2 (2^14 + 1 each), hist1 (128 x 2048), l1_start, l2_tile_start, flag
 constexpr int kMsdSplBits = 15;  // sampled-splitter mode: up to 2^15 buckets
 constexpr size_t kMsdTableWords = (size_t(1) << kMsdSplBits) + 64;
@@ -1455,6 +1493,19 @@ int set_sort_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "sort_msd_wide_b2max") == 0) {
     g_sort_msd_wide_b2max = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 12)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_rpt1") == 0 || strcmp(name, "sort_msd_wide_rpt2") == 0) {
+    const int rpt = value >= 24 ? 24 : value >= 16 ? 16 : 8;
+    (name[17] == '1' ? g_sort_msd_wide_rpt1 : g_sort_msd_wide_rpt2) = rpt;
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_bucket_cpt") == 0) {
+    g_sort_msd_bucket_cpt = value >= 8 ? 8 : 4;
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_tiny_bucket") == 0) {
+    g_sort_msd_tiny_bucket = value != 0;
     return 1;
   }
   if (strcmp(name, "sort_msd_prefix") == 0) {
@@ -1868,6 +1919,7 @@ struct MsdwArgs {
   int gap2;                // level-2 buckets get a fixed room each (no level-2 histogram)
   int xcd_map;             // level 2: XCD-contiguous tile numbering
   int xcd_map1;            // level 1 likewise (A/B)
+  int tile1, tile2;        // rows per scatter tile of level 1 / level 2: kMsdwTile, or 2x / 3x that held in registers
   int64_t capacity;        // records rec_x / rec_y can hold
   uint32_t* l1_count;      // [2^b1] histogram (of the sample)
   uint32_t* l1_start;      // [2^b1] first record of a level-1 bucket in rec_x (buckets may be followed by unused room)
@@ -1883,7 +1935,7 @@ struct MsdwArgs {
   uint32_t* cursor2;       // [2^bits]
   uint32_t* flags;         // [0] bits: 2 a bucket does not fit LDS, 4 a level-1 bucket outgrew its room, 8 fixed level-2
                            //     rooms are not possible here, 16 a level-2 bucket outgrew its room; [1] largest bucket;
-                           //     [2] sampled rows
+                           //     [2] sampled rows; [3] gap2: largest level-2 room
   MsdRec* rec_x;           // level-1 output
   MsdRec* rec_y;           // level-2 output
 };
@@ -1989,7 +2041,7 @@ __global__ __launch_bounds__(1024) void msdw_scan0b_kernel(MsdwArgs a) {
     }
     a.l1_end[tid] = lo + c;
   }
-  const uint32_t tiles = (c + kMsdwTile - 1) / kMsdwTile;
+  const uint32_t tiles = (c + static_cast<uint32_t>(a.tile2) - 1) / static_cast<uint32_t>(a.tile2);
   const uint32_t units = static_cast<uint32_t>((static_cast<int64_t>(c) + kMsdwUnit - 1) / kMsdwUnit);
   uint32_t room = 0;
   if (a.gap2 && c != 0) {
@@ -2005,6 +2057,7 @@ __global__ __launch_bounds__(1024) void msdw_scan0b_kernel(MsdwArgs a) {
       atomicOr(&a.flags[0], 8u);
       room = 0;
     }
+    atomicMax(&a.flags[3], room);   // picks the bucket finish (the smallest workgroup whose LDS holds every room)
   }
   const uint64_t yrows = static_cast<uint64_t>(room) << a.b2;
   const uint32_t i0 = wave_inclusive_scan_u32(c);
@@ -2156,17 +2209,174 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
   }
 }
 
-template <bool RAW>
+// The same scatter over a tile of RPT * 1024 rows (RPT = 16 or 24) held in REGISTERS: ranked with LDS atomics, then
+// moved through the 8192-record LDS buffer in RPT / 8 rounds.  A (tile, digit) run is RPT / 8 times as long as the
+// LDS-resident tile's — 48 records = 576 B at 512 bins and RPT 24 — which is what sets the rate of a scatter whose bins
+// span the whole array (scripts/micro/wide_scatter_bench.hip, profiles/r03_c_wide_scatter_small_lds_chunks.txt; the
+// group-by's flat level is the same kernel shape, groupby.hip K3w).
+template <int SRC, int CHECK, int RPT>
+__device__ __forceinline__ void msdw_scatter_big_tile(const MsdwArgs& a, MsdwScatterLds& lds, const uint64_t* __restrict__ kin,
+                                                      const uint32_t* __restrict__ iin, const MsdRec* __restrict__ rin,
+                                                      int64_t row0, int nrows, int nb, int dshift,
+                                                      uint32_t* __restrict__ gcursor, const uint32_t* __restrict__ gend,
+                                                      uint32_t room_base, uint32_t room, uint32_t overflow_bit,
+                                                      MsdRec* __restrict__ rout) {
+  static_assert(RPT % kMsdwRows == 0, "whole rounds of the LDS buffer");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t dmask = static_cast<uint32_t>(nb - 1);
+  for (int b = tid; b < nb; b += kMsdwThreads) lds.cnt[b] = 0;
+  uint64_t key[RPT];
+  uint32_t idx[SRC == 0 ? 1 : RPT];
+  // unconditional loads (rows past the tile's end re-read its last row), all in flight together; addresses = one
+  // uniform base + a 32-bit offset per row.  The caller's column is read once: non-temporal.
+  if constexpr (SRC == 0) {
+    if (key_type_is_64bit(a.raw)) {   // workgroup-uniform
+      const uint64_t* __restrict__ base = kin + row0;
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const uint32_t p = static_cast<uint32_t>(i * kMsdwThreads + tid);
+        key[i] = __builtin_nontemporal_load(base + (p < static_cast<uint32_t>(nrows) ? p : static_cast<uint32_t>(nrows - 1)));
+      }
+    } else {
+      const uint32_t* __restrict__ base = reinterpret_cast<const uint32_t*>(kin) + row0;
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const uint32_t p = static_cast<uint32_t>(i * kMsdwThreads + tid);
+        key[i] = __builtin_nontemporal_load(base + (p < static_cast<uint32_t>(nrows) ? p : static_cast<uint32_t>(nrows - 1)));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) key[i] = key_from_bits(key[i], a.raw);
+  } else {
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const uint32_t p0 = static_cast<uint32_t>(i * kMsdwThreads + tid);
+      const uint32_t p = p0 < static_cast<uint32_t>(nrows) ? p0 : static_cast<uint32_t>(nrows - 1);
+      if constexpr (SRC == 1) {
+        key[i] = (kin + row0)[p];
+        idx[i] = (iin + row0)[p];
+      } else {
+        const MsdRec rr = (rin + row0)[p];
+        key[i] = msd_rec_key(rr);
+        idx[i] = rr.idx;
+      }
+    }
+  }
+  __syncthreads();
+  // a row's place in the tile (< 24576) takes 16 bits: two per register, 0xFFFF = no row (past the tile's end)
+  static_assert(RPT % 2 == 0 && RPT * kMsdwThreads < 0xFFFF - kMsdwTile, "packed 16-bit tile positions");
+  uint32_t pos2[RPT / 2];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const uint32_t d = static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask;
+    const uint32_t pr = (i * kMsdwThreads + tid < nrows) ? atomicAdd(&lds.cnt[d], 1u) : 0xFFFFu;
+    pos2[i / 2] = (i & 1) ? (pos2[i / 2] | (pr << 16)) : pr;
+    if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);   // eight atomics in flight, not RPT (their addresses and results are registers)
+  }
+  __syncthreads();
+  const int per = (nb + kMsdwThreads - 1) / kMsdwThreads;
+  uint32_t cc[kMsdwMaxBins2 / kMsdwThreads];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < kMsdwMaxBins2 / kMsdwThreads; ++k) {
+    const int b = tid * per + k;
+    cc[k] = (k < per && b < nb) ? lds.cnt[b] : 0u;
+    mine += cc[k];
+  }
+  const uint32_t incl = wave_inclusive_scan_u32(mine);
+  if (lane == 63) lds.wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t pre = incl - mine;
+  for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
+#pragma unroll
+  for (int k = 0; k < kMsdwMaxBins2 / kMsdwThreads; ++k) {
+    const int b = tid * per + k;
+    if (k < per && b < nb) {
+      const uint32_t c = cc[k];
+      lds.start[b] = pre;
+      uint32_t base = c != 0 ? atomicAdd(&gcursor[b], c) : 0u;
+      if constexpr (CHECK != 0) {
+        const uint32_t end = CHECK == 1 ? gend[b] : room_base + (static_cast<uint32_t>(b) + 1u) * room;
+        if (c != 0 && (base + c > end || base + c < base)) {
+          base = 0xFFFFFFFFu;
+          atomicOr(&a.flags[0], overflow_bit);
+        }
+      }
+      lds.gbase[b] = base;
+      pre += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const uint32_t d = static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask;
+    const uint32_t pr = (pos2[i / 2] >> ((i & 1) * 16)) & 0xFFFFu;
+    const uint32_t at = pr != 0xFFFFu ? pr + lds.start[d] : 0xFFFFu;
+    pos2[i / 2] = (i & 1) ? ((pos2[i / 2] & 0xFFFFu) | (at << 16)) : ((pos2[i / 2] & 0xFFFF0000u) | at);
+    if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int r = 0; r < RPT / kMsdwRows; ++r) {
+    const uint32_t lo = static_cast<uint32_t>(r) * kMsdwTile;
+    if (static_cast<int>(lo) >= nrows) break;   // workgroup-uniform
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const uint32_t q = ((pos2[i / 2] >> ((i & 1) * 16)) & 0xFFFFu) - lo;   // (no row: 0xFFFF - lo is never inside the buffer)
+      if (q < static_cast<uint32_t>(kMsdwTile)) {
+        lds.keys[q] = key[i];
+        if constexpr (SRC == 0) {
+          lds.idx[q] = static_cast<uint32_t>(row0) + static_cast<uint32_t>(i * kMsdwThreads + tid);
+        } else {
+          lds.idx[q] = idx[i];
+        }
+      }
+    }
+    __syncthreads();
+    const int cnt = nrows - static_cast<int>(lo) < kMsdwTile ? nrows - static_cast<int>(lo) : kMsdwTile;
+    for (int p = tid; p < cnt; p += kMsdwThreads) {
+      const uint64_t k = lds.keys[p];
+      const uint32_t d = static_cast<uint32_t>((k << a.kshift) >> dshift) & dmask;
+      const uint32_t gb = lds.gbase[d];
+      if (CHECK != 0 && gb == 0xFFFFFFFFu) continue;
+      MsdRec rr;
+      rr.lo = static_cast<uint32_t>(k);
+      rr.hi = static_cast<uint32_t>(k >> 32);
+      rr.idx = lds.idx[p];
+      rout[gb + (lo + static_cast<uint32_t>(p) - lds.start[d])] = rr;
+    }
+    __syncthreads();
+  }
+}
+
+template <int SRC, int CHECK, int RPT>
+__device__ __forceinline__ void msdw_scatter_any_tile(const MsdwArgs& a, MsdwScatterLds& lds, const uint64_t* __restrict__ kin,
+                                                      const uint32_t* __restrict__ iin, const MsdRec* __restrict__ rin,
+                                                      int64_t row0, int nrows, int nb, int dshift,
+                                                      uint32_t* __restrict__ gcursor, const uint32_t* __restrict__ gend,
+                                                      uint32_t room_base, uint32_t room, uint32_t overflow_bit,
+                                                      MsdRec* __restrict__ rout) {
+  if constexpr (RPT == kMsdwRows) {
+    msdw_scatter_tile<SRC, CHECK>(a, lds, kin, iin, rin, row0, nrows, nb, dshift, gcursor, gend, room_base, room,
+                                  overflow_bit, rout);
+  } else {
+    msdw_scatter_big_tile<SRC, CHECK, RPT>(a, lds, kin, iin, rin, row0, nrows, nb, dshift, gcursor, gend, room_base, room,
+                                           overflow_bit, rout);
+  }
+}
+
+template <bool RAW, int RPT>
 __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1_kernel(MsdwArgs a) {
   __shared__ MsdwScatterLds lds;
   // an earlier tile already found a bucket without room: the level will be repeated, do not finish this attempt
   // (e.g. pre-sorted input, where a sample of tiles says little about where the bucket boundaries fall)
   if (a.sample_shift > 0 && (__atomic_load_n(&a.flags[0], __ATOMIC_RELAXED) & 4u) != 0) return;
+  constexpr int kTile = RPT * kMsdwThreads;
   const uint32_t tile = a.xcd_map1 ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int64_t row0 = static_cast<int64_t>(tile) * kMsdwTile;
-  const int nrows = static_cast<int>(a.n - row0 < kMsdwTile ? a.n - row0 : kMsdwTile);
-  msdw_scatter_tile<RAW ? 0 : 1, 1>(a, lds, a.src_keys, a.src_idx, nullptr, row0, nrows, 1 << a.b1, 64 - a.b1,
-                                    a.cursor1, a.l1_end, 0u, 0u, 4u, a.rec_x);
+  const int64_t row0 = static_cast<int64_t>(tile) * kTile;
+  const int nrows = static_cast<int>(a.n - row0 < kTile ? a.n - row0 : kTile);
+  msdw_scatter_any_tile<RAW ? 0 : 1, 1, RPT>(a, lds, a.src_keys, a.src_idx, nullptr, row0, nrows, 1 << a.b1, 64 - a.b1,
+                                             a.cursor1, a.l1_end, 0u, 0u, 4u, a.rec_x);
 }
 
 // index of the last entry of start[0..nb] (nb + 1 entries, non-decreasing, start[0] == 0) that is <= g, computed by
@@ -2302,8 +2512,9 @@ __global__ __launch_bounds__(1024) void msdw_init2_kernel(MsdwArgs a) {
 }
 
 // W6: level 2 inside the level-1 buckets (tile map: l2_tile_start)
-template <bool GAP>
+template <bool GAP, int RPT>
 __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter2_kernel(MsdwArgs a) {
+  constexpr int kTile = RPT * kMsdwThreads;
   __shared__ MsdwScatterLds lds;
   const int nb1 = 1 << a.b1;
   // a.xcd_map: XCD x takes a contiguous eighth of the tiles, i.e. whole level-1 buckets — the (tile, digit) runs of a
@@ -2313,11 +2524,11 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter2_kernel(MsdwArgs a)
   const uint32_t p = msdw_owner(a.l2_tile_start, nb1, g, &lds.part);
   const int64_t lo = a.l1_start[p];
   const int64_t hi = a.l1_end[p];
-  const int64_t row0 = lo + static_cast<int64_t>(g - a.l2_tile_start[p]) * kMsdwTile;
-  const int nrows = static_cast<int>(hi - row0 < kMsdwTile ? hi - row0 : kMsdwTile);
-  msdw_scatter_tile<2, GAP ? 2 : 0>(a, lds, nullptr, nullptr, a.rec_x, row0, nrows, 1 << a.b2, 64 - a.bits,
-                                    a.cursor2 + (static_cast<size_t>(p) << a.b2), nullptr,
-                                    GAP ? a.y_base[p] : 0u, GAP ? a.room2[p] : 0u, 16u, a.rec_y);
+  const int64_t row0 = lo + static_cast<int64_t>(g - a.l2_tile_start[p]) * kTile;
+  const int nrows = static_cast<int>(hi - row0 < kTile ? hi - row0 : kTile);
+  msdw_scatter_any_tile<2, GAP ? 2 : 0, RPT>(a, lds, nullptr, nullptr, a.rec_x, row0, nrows, 1 << a.b2, 64 - a.bits,
+                                             a.cursor2 + (static_cast<size_t>(p) << a.b2), nullptr,
+                                             GAP ? a.y_base[p] : 0u, GAP ? a.room2[p] : 0u, 16u, a.rec_y);
 }
 
 // overflowed: 0 sorted; 1 the keys are too skewed for this form (a bucket does not fit LDS) — try the next form;
@@ -2373,17 +2584,21 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   a.gap2 = (gap2 != 0 && roomy) ? 1 : 0;
   const int nb1 = 1 << a.b1;
   const size_t nparts = size_t(1) << a.bits;
-  const unsigned grid1 = static_cast<unsigned>(ceil_div(n, kMsdwTile));
+  a.tile1 = g_sort_msd_wide_rpt1 * kMsdwThreads;
+  a.tile2 = g_sort_msd_wide_rpt2 * kMsdwThreads;
+  const unsigned grid0 = static_cast<unsigned>(ceil_div(n, kMsdwTile));   // the sampled histogram reads 8192-row chunks
+  const unsigned grid1 = static_cast<unsigned>(ceil_div(n, a.tile1));
   // Level-1 bucket sizes: estimated from 1 tile in 2^shift (the buckets then get room to spare and level 2 reads
   // what actually arrived), or — shift 0, and whenever an estimate turned out too small — counted exactly.
+  unsigned int max_room = 0;
   int sample_shift = roomy ? g_sort_msd_wide_sample_shift : 0;
-  while (sample_shift > 0 && (static_cast<int64_t>(grid1) >> sample_shift) < 8) --sample_shift;   // too few tiles to sample
+  while (sample_shift > 0 && (static_cast<int64_t>(grid0) >> sample_shift) < 8) --sample_shift;   // too few chunks to sample
   for (;;) {
     a.sample_shift = sample_shift;
     unsigned nch;
     if (sample_shift > 0) {
       a.chunk_rows = kMsdwTile;
-      nch = static_cast<unsigned>(ceil_div(static_cast<int64_t>(grid1), int64_t(1) << sample_shift));
+      nch = static_cast<unsigned>(ceil_div(static_cast<int64_t>(grid0), int64_t(1) << sample_shift));
     } else {
       const int64_t ntiles0 = ceil_div(n, kMsdTile);
       a.chunk_rows = std::max<int64_t>(1, ceil_div(ntiles0, kMsdMaxChunks)) * kMsdTile;
@@ -2399,18 +2614,27 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
     ARX_CHECK_LAUNCH("msdw_hist0_kernel");
     hipLaunchKernelGGL(msdw_scan0_kernel, dim3(1), dim3(1024), 0, st, a);
     ARX_CHECK_LAUNCH("msdw_scan0_kernel");
+#define ARX_MSDW_SCATTER1(RAW)                                                                                      \
+  switch (g_sort_msd_wide_rpt1) {                                                                                  \
+    case 24: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 24>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break; \
+    case 16: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 16>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break; \
+    default: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break;  \
+  }
     if (raw) {
-      hipLaunchKernelGGL((msdw_scatter1_kernel<true>), dim3(grid1), dim3(kMsdwThreads), 0, st, a);
+      ARX_MSDW_SCATTER1(true)
     } else {
-      hipLaunchKernelGGL((msdw_scatter1_kernel<false>), dim3(grid1), dim3(kMsdwThreads), 0, st, a);
+      ARX_MSDW_SCATTER1(false)
     }
+#undef ARX_MSDW_SCATTER1
     ARX_CHECK_LAUNCH("msdw_scatter1_kernel");
     hipLaunchKernelGGL(msdw_scan0b_kernel, dim3(1), dim3(1024), 0, st, a);
     ARX_CHECK_LAUNCH("msdw_scan0b_kernel");
     if (sample_shift == 0 && a.gap2 == 0) break;   // exact counts all the way: nothing to look at yet
-    unsigned int fl = 0;
-    ARX_HIP(hipMemcpyAsync(&fl, a.flags, 4, hipMemcpyDeviceToHost, st));
+    unsigned int fl4[4] = {0, 0, 0, 0};
+    ARX_HIP(hipMemcpyAsync(fl4, a.flags, 16, hipMemcpyDeviceToHost, st));
     ARX_HIP(hipStreamSynchronize(st));
+    const unsigned int fl = fl4[0];
+    max_room = fl4[3];
     if ((fl & 4u) != 0) {   // a level-1 bucket outgrew its room; the source is untouched (level 2 has not run)
       if (sample_shift == 0) {
         set_error("array_sort_indices: internal error (exact level-1 histogram disagrees with the scatter)");
@@ -2429,16 +2653,22 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
     }
     break;
   }
-  const unsigned grid2 = grid1 + static_cast<unsigned>(nb1);
+  const unsigned grid2 = static_cast<unsigned>(ceil_div(n, a.tile2)) + static_cast<unsigned>(nb1);
+#define ARX_MSDW_SCATTER2(GAP)                                                                                      \
+  switch (g_sort_msd_wide_rpt2) {                                                                                  \
+    case 24: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 24>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break; \
+    case 16: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 16>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break; \
+    default: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 8>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break;  \
+  }
   unsigned int max_part = 0;
   if (a.gap2) {
     hipLaunchKernelGGL(msdw_init2_kernel, dim3(static_cast<unsigned>(nb1)), dim3(1024), 0, st, a);
     ARX_CHECK_LAUNCH("msdw_init2_kernel");
-    hipLaunchKernelGGL((msdw_scatter2_kernel<true>), dim3(grid2), dim3(kMsdwThreads), 0, st, a);
+    ARX_MSDW_SCATTER2(true)
     ARX_CHECK_LAUNCH("msdw_scatter2_kernel");
     hipLaunchKernelGGL(msdw_scan1_kernel, dim3(static_cast<unsigned>(nb1)), dim3(1024), 0, st, a);
     ARX_CHECK_LAUNCH("msdw_scan1_kernel");
-    max_part = kBktCapSmall;   // rooms never exceed it
+    max_part = max_room != 0 ? max_room : kBktCapSmall;   // rooms never exceed it
   } else {
     ARX_HIP(hipMemsetAsync(a.count2, 0, nparts * 4, st));
     const unsigned units = static_cast<unsigned>(ceil_div(n, kMsdwUnit) + nb1);
@@ -2458,9 +2688,10 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
       *overflowed = 1;
       return ARX_OK;
     }
-    hipLaunchKernelGGL((msdw_scatter2_kernel<false>), dim3(grid2), dim3(kMsdwThreads), 0, st, a);
+    ARX_MSDW_SCATTER2(false)
     ARX_CHECK_LAUNCH("msdw_scatter2_kernel");
   }
+#undef ARX_MSDW_SCATTER2
   MsdArgs f{};
   f.n = n;
   f.bits = a.bits;
@@ -2471,9 +2702,22 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   f.overflow = a.flags;
   f.out_final = out_final;
   const bool small_bkt = max_part <= static_cast<unsigned int>(kBktCapSmall);
-  f.b3 = std::max(0, std::min(std::min(lg - (g_sort_msd_final_rows_log2 - 1) - a.bits, small_bkt ? 11 : 12), 64 - kshift - a.bits));
+  const bool tiny_bkt = g_sort_msd_tiny_bucket != 0 && max_part <= static_cast<unsigned int>(kBktCapTiny);
+  const int cpt_bits = g_sort_msd_bucket_cpt == 8 && (tiny_bkt || small_bkt) ? 1 : 0;   // twice the sub-buckets
+  f.b3 = std::max(0, std::min(std::min(lg - (g_sort_msd_final_rows_log2 - 1) - a.bits,
+                                       (tiny_bkt ? 10 : small_bkt ? 11 : 12) + cpt_bits),
+                              64 - kshift - a.bits));
   const uint64_t* recs = reinterpret_cast<const uint64_t*>(rec_y);
-  if (small_bkt) {
+  if (tiny_bkt && cpt_bits) {
+    hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsTiny, true, 8>), dim3(static_cast<unsigned>(nparts)),
+                       dim3(kBktThreadsTiny), 0, st, f, recs, nullptr);
+  } else if (tiny_bkt) {
+    hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsTiny, true>), dim3(static_cast<unsigned>(nparts)),
+                       dim3(kBktThreadsTiny), 0, st, f, recs, nullptr);
+  } else if (small_bkt && cpt_bits) {
+    hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsSmall, true, 8>), dim3(static_cast<unsigned>(nparts)),
+                       dim3(kBktThreadsSmall), 0, st, f, recs, nullptr);
+  } else if (small_bkt) {
     hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsSmall, true>), dim3(static_cast<unsigned>(nparts)),
                        dim3(kBktThreadsSmall), 0, st, f, recs, nullptr);
   } else {

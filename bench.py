@@ -757,7 +757,37 @@ def callfunction_leg(args, values, validity, mask, device):
         acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"]))])
     timeit(f"acero table_source -> aggregate_rocm (hash_sum, {m} device rows, {args.groups} keys)",
            lambda: plan.to_table(use_threads=False), reps=3)
-    del dt, plan
+    # the same table through table_source_rocm (whole chunks instead of 32Ki-row batches: the nodes downstream run once),
+    # alone and with the STOCK FilterNode and ProjectNode in between; beside them the fused kernel on the same rows
+    agg_node = acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"]))
+    plan_r = acero.Declaration.from_sequence([acero.Declaration("table_source_rocm", acero.TableSourceNodeOptions(dt)), agg_node])
+    timeit(f"acero table_source_rocm -> aggregate_rocm (hash_sum, {m} device rows, {args.groups} keys)",
+           lambda: plan_r.to_table(use_threads=False), reps=3)
+    try:
+        x = pa.array(np.random.default_rng(13).random(m))
+        dtx = pa.table({"x": to_device(x), "k": dt.column("k").chunk(0), "v": dt.column("v").chunk(0)})
+        del x
+        stages = [acero.Declaration("filter", acero.FilterNodeOptions(pc.field("x") > 0.1)),
+                  acero.Declaration("project", acero.ProjectNodeOptions([pc.field("k"), pc.add(pc.field("v"), pc.field("v"))], ["k", "v"])),
+                  agg_node]
+        for source in ("table_source_rocm", "table_source"):
+            plan_f = acero.Declaration.from_sequence([acero.Declaration(source, acero.TableSourceNodeOptions(dtx))] + stages)
+            timeit(f"acero {source} -> filter(x > 0.1) -> project(k, v + v) -> aggregate_rocm ({m} device rows)",
+                   lambda: plan_f.to_table(use_threads=False), reps=3 if source == "table_source_rocm" else 1)
+            del plan_f
+        del dtx
+    except Exception as e:
+        res["table_source_rocm -> filter -> project -> aggregate_rocm"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    kt = gen_stream(m, device, 0, 8, modulo=args.groups, dtype=torch.int32)
+    vt = gen_stream(m, device, 0, 9)
+    kk = amd.Array(amd.array.int32, m, [None, kt.view(torch.uint8)], 0, 0)
+    vv = amd.Array(amd.array.int64, m, [None, vt.view(torch.uint8)], 0, 0)
+    cap = 1
+    while cap < 2 * args.groups + 2:
+        cap <<= 1
+    res[f"fused kernel on the same rows (arx_groupby_sum_i64, {m} rows)"] = {
+        "ms": round(_time_gpu(lambda: amd.compute.group_by_sum(kk, vv, capacity=cap), reps=3, warm=1), 3)}
+    del dt, plan, plan_r, kt, vt, kk, vv
     # the same operator over columns WITH nulls: 32K-row batches are staged many at a time, their validity by
     # arx_bitmap_copy_segments (before: every batch with nulls consumed on its own)
     try:

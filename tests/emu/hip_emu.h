@@ -51,6 +51,13 @@ enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMe
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+#ifndef HIPEMU_DEVICE_QUERY
+#define HIPEMU_DEVICE_QUERY
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+// few "CUs": persistent kernels walk several work items per workgroup here, as they do on the 256-CU part
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 2; return hipSuccess; }
+#endif
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
@@ -195,6 +202,7 @@ inline uint4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, uin
 #define ext_vector_type(n) vector_size(4 * (n))
 template <typename T> inline T __builtin_nontemporal_load(const T* p) { return *p; }
 template <typename T> inline void __builtin_nontemporal_store(T v, T* p) { *p = v; }
+inline void __builtin_amdgcn_sched_barrier(int) {}   // an instruction-scheduling fence: nothing to emulate
 template <typename T> inline T __builtin_amdgcn_readfirstlane(T v) { return v; }
 inline uint32_t __builtin_amdgcn_readlane(uint32_t v, int src) { return hipemu::exchange(v, src); }
 inline uint64_t __ballot(bool p) { return hipemu::ballot(p); }

@@ -42,5 +42,8 @@ static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuc
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }   // synchronous streams are always idle
+#ifndef HIPEMU_DEVICE_QUERY
+#define HIPEMU_DEVICE_QUERY
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+#endif
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }

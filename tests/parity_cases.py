@@ -767,16 +767,21 @@ def check_sort_indices(amd, arr: HostArray, order="ascending", null_placement="a
     return out
 
 
-def check_sort_wide_sampled(amd, lib, rng, n, shift, gap2=1, b2max=12):
+SORT_WIDE_RPT_DEFAULT = (24, 8)   # sort.hip g_sort_msd_wide_rpt1 / rpt2
+
+
+def check_sort_wide_sampled(amd, lib, rng, n, shift, gap2=1, b2max=12, rpt=(24, 8), typed_keys=False):
     """The wide two-level sort with level-1 bucket sizes ESTIMATED from one tile in 2^shift (buckets get room to spare,
     level 2 reads what arrived) and, gap2, level-2 buckets in fixed rooms (mean + 6 sigma) instead of a histogram
     pass.  Uniform keys: the estimates must hold (strict mode turns a silent exact re-run into an error).  Sorted /
     blocky inputs where the sampled tiles say little about the rest, or whose keys are not uniform inside a level-1
     bucket: the overflow is detected and the level repeated with exact counts — same result; in strict mode the call
     must fail instead.  b2max: how many of the partition bits level 2 may take (0 = half of them, 12 = up to 4096
-    second-level bins, several per thread of the scatter's counter scan)."""
+    second-level bins, several per thread of the scatter's counter scan).  rpt: rows per thread of the level-1 /
+    level-2 scatter tiles (8: LDS-resident tile; 16 / 24: register-staged, moved through LDS in rounds)."""
     opts = {b"sort_msd": 1, b"sort_msd_segment_rows": 4096, b"sort_msd_wide": 1,
-            b"sort_msd_wide_sample_shift": shift, b"sort_msd_wide_gap2": gap2, b"sort_msd_wide_b2max": b2max}
+            b"sort_msd_wide_sample_shift": shift, b"sort_msd_wide_gap2": gap2, b"sort_msd_wide_b2max": b2max,
+            b"sort_msd_wide_rpt1": rpt[0], b"sort_msd_wide_rpt2": rpt[1]}
     for k, v in opts.items():
         assert lib.arx_set_option(k, v) == 0
     try:
@@ -803,23 +808,29 @@ def check_sort_wide_sampled(amd, lib, rng, n, shift, gap2=1, b2max=12):
         assert lib.arx_set_option(b"sort_msd_wide_sample_strict", 0) == 0
         for arr in (blocky, ordered):
             check_sort_indices(amd, arr, "ascending", "at_end", use_pyarrow=False)
+        # the level-1 tiles read the caller's column themselves: every key type's loader (4- and 8-byte, float transforms)
+        for dtype in (np.float32, np.int32, np.float64, np.uint32) if typed_keys else ():
+            typed = util.random_array(rng, dtype, min(n, 2_000_000) // 8 + 17, null_p=0.02, offset=1)
+            check_sort_indices(amd, typed, "descending" if dtype == np.int32 else "ascending", "at_end", use_pyarrow=False)
         return failed
     finally:
         lib.arx_set_option(b"sort_msd_wide_sample_strict", 0)
         lib.arx_set_option(b"sort_msd_wide_sample_shift", 4)
         lib.arx_set_option(b"sort_msd_wide_gap2", 1)
+        lib.arx_set_option(b"sort_msd_wide_rpt1", SORT_WIDE_RPT_DEFAULT[0])
+        lib.arx_set_option(b"sort_msd_wide_rpt2", SORT_WIDE_RPT_DEFAULT[1])
         lib.arx_set_option(b"sort_msd_wide_b2max", 10)
         lib.arx_set_option(b"sort_msd", -1)
         lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
 
 
-def check_sort_wide_many_bins(amd, lib, rng, n, bits, b2max, combos=((2, 1), (0, 1), (0, 0))):
+def check_sort_wide_many_bins(amd, lib, rng, n, bits, b2max, combos=((2, 1), (0, 1), (0, 0)), rpt=(24, 8)):
     """The wide form with the partition bits FORCED (sort_msd_wide_bits), so that few rows meet many level-2 bins: up
     to 4096 bins per level-1 partition, `per` = 2..4 counters per thread in the scatter's scan, in the bucket-start
     scan and in the fixed-room setup.  Exact and sampled sizes, fixed rooms and counted buckets, a skewed input (whole
     partitions empty, one bin holding a third of the rows), nulls, both orders."""
     opts = {b"sort_msd": 1, b"sort_msd_segment_rows": 4096, b"sort_msd_wide": 1, b"sort_msd_wide_bits": bits,
-            b"sort_msd_wide_b2max": b2max}
+            b"sort_msd_wide_b2max": b2max, b"sort_msd_wide_rpt1": rpt[0], b"sort_msd_wide_rpt2": rpt[1]}
     for k, v in opts.items():
         assert lib.arx_set_option(k, v) == 0
     try:
@@ -838,6 +849,8 @@ def check_sort_wide_many_bins(amd, lib, rng, n, bits, b2max, combos=((2, 1), (0,
     finally:
         lib.arx_set_option(b"sort_msd_wide_bits", 0)
         lib.arx_set_option(b"sort_msd_wide_b2max", 10)
+        lib.arx_set_option(b"sort_msd_wide_rpt1", SORT_WIDE_RPT_DEFAULT[0])
+        lib.arx_set_option(b"sort_msd_wide_rpt2", SORT_WIDE_RPT_DEFAULT[1])
         lib.arx_set_option(b"sort_msd_wide_sample_shift", 4)
         lib.arx_set_option(b"sort_msd_wide_gap2", 1)
         lib.arx_set_option(b"sort_msd", -1)

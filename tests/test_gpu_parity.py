@@ -651,6 +651,20 @@ def test_sort_wide_sampled_level1(gpu_ctx, shift, gap2, b2max):
         assert failed == 0   # exact counts never overflow
 
 
+@pytest.mark.parametrize("rpt", [(8, 8), (8, 24), (16, 16), (24, 24)])
+def test_sort_wide_register_staged_tiles(gpu_ctx, rpt):
+    """Level-1 / level-2 scatter tiles of 8 (LDS-resident), 16 and 24 (register-staged) rows per thread."""
+    lib = gpu_ctx._lib.get_lib()
+    assert lib.arx_set_option(b"sort_msd_tiny_bucket", 0 if rpt[0] == 16 else 1) == 0   # (256- / 512-thread bucket finish)
+    assert lib.arx_set_option(b"sort_msd_bucket_cpt", 8 if rpt[1] == 16 else 4) == 0   # sub-bucket counters per thread of the finish
+    try:
+        P.check_sort_wide_sampled(gpu_ctx, lib, rng_for("wide-rpt", *rpt), 6_000_011, 4, 1, 12, rpt=rpt, typed_keys=True)
+        P.check_sort_wide_many_bins(gpu_ctx, lib, rng_for("wide-rpt-bins", *rpt), 3_000_003, 16, 12, combos=((0, 0), (2, 1)), rpt=rpt)
+    finally:
+        lib.arx_set_option(b"sort_msd_tiny_bucket", 1)
+        lib.arx_set_option(b"sort_msd_bucket_cpt", 4)
+
+
 @pytest.mark.parametrize("bits,b2max", [(13, 12), (16, 12), (20, 12), (19, 11), (19, 0)])
 def test_sort_wide_many_level2_bins(gpu_ctx, bits, b2max):
     P.check_sort_wide_many_bins(gpu_ctx, gpu_ctx._lib.get_lib(), rng_for("wide-bins", bits, b2max), 5_000_003, bits,

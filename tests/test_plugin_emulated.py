@@ -96,3 +96,7 @@ def test_aggregate_rocm_general_keys_emulated():
 
 def test_device_streams_events_reader_writer_dlpack_emulated():
     _run(G.DEVICE_INTERFACES_SCRIPT, "DEVICE_INTERFACES_OK", 1)
+
+
+def test_table_source_rocm_whole_chunk_batches_emulated():
+    _run(G.TABLE_SOURCE_SCRIPT, "TABLE_SOURCE_OK", 0.02)
