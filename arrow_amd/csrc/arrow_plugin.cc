@@ -530,6 +530,8 @@ int64_t arrow_amd_plugin_aggregate_flushes(void) { return g_aggregate_flushes.lo
 // aggregate_rocm consumes a device batch of at least this many rows where it lies (no staging copy)
 void arrow_amd_plugin_set_aggregate_direct_rows(int64_t rows) { g_aggregate_direct_rows.store(rows < 1 ? 1 : rows); }
 int64_t arrow_amd_plugin_aggregate_direct_batches(void) { return g_aggregate_direct_batches.load(); }
+// result columns >= 1 MB into pooled page-locked host buffers (default on)
+void arrow_amd_plugin_set_pinned_results(int on) { g_pinned_results.store(on != 0); }
 // table_source_rocm: rows per batch when TableSourceNodeOptions::max_batch_size is the default
 void arrow_amd_plugin_set_table_source_rows(int64_t rows) { g_table_source_rows.store(rows < 1 ? 1 : rows); }
 // The same threshold for the element-wise kernels (greater, cast); default: never stage them.

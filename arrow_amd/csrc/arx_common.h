@@ -3,10 +3,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 
 #include "../../include/arrow_amd.h"
 
 namespace arx {
+
+// A tuning knob (arx_set_option): written on any thread while launches on other threads read it.  Relaxed atomics — a
+// call in flight sees the old or the new value of each knob, never a torn one, and knobs never change results.
+template <typename T>
+struct Knob {
+  std::atomic<T> v;
+  constexpr explicit Knob(T init) : v(init) {}
+  operator T() const { return v.load(std::memory_order_relaxed); }
+  Knob& operator=(T x) {
+    v.store(x, std::memory_order_relaxed);
+    return *this;
+  }
+};
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;             // 4 waves per workgroup

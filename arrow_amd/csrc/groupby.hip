@@ -1575,22 +1575,22 @@ struct GbpPlan {
       off_cursor2, off_cursor1, off_hist1, off_l1_start, off_l2_tile_start, off_agg_unit_start, off_part_end, off_overflow, total;
 };
 
-static int g_gbp_min_rows = 1 << 17;  // below this the direct HBM-atomics kernel is used
-static int g_gbp_bits = -1;           // -1 = from the capacity hint
-static int g_gbp_agg_pipe = 1;
-static int g_gbp_xcd_map = 1;         // XCD-contiguous work numbering: bit 0 level-2 scatter (-2.6 ms at 4e9 rows), bit 1 aggregate (+5 ms: off), bit 2 level-1 scatter (no effect)
-static int g_gbp_b1 = -1;             // level-1 bits override (-1: half of the partition bits)
-static int g_gbp_chunks = 2048;       // level-1 chunks = workgroups of the hist / scatter1 kernels
-static int g_gbp_wide_max_bits = kGbWideMaxBits;   // bins of the flat level the planner may ask for (A/B knob groupby_wide_max_bits; tests lower it)
-static int g_gbp_room_min_mean = 1 << 14;   // rooms only for partitions of at least this many rows on average (knob groupby_wide_room_min_mean; tests lower it)
-static int g_gbp_wide_rooms = 1;      // the wide form without its histogram pass: fixed rooms per partition (A/B knob groupby_wide_rooms)
-static int g_gbp_wide = 1;            // the wide one-level form where the group estimate allows it (A/B knob groupby_wide)
-static int g_gbp_wide_agg_chunk = 1 << 21;   // rows per aggregate work unit of the wide form (A/B knob groupby_wide_agg_chunk_rows)
-static int64_t g_gbp_probe_rows = int64_t(1) << 26;   // rows of the probe slice that measures the group count (A/B knob groupby_probe_rows)
-static int g_gbp_l1_global = 1;       // level 1 with global cursors (one tile per workgroup; +3 % at 4e9 rows) instead of chunked exact offsets
+static Knob<int> g_gbp_min_rows{1 << 17};  // below this the direct HBM-atomics kernel is used
+static Knob<int> g_gbp_bits{-1};           // -1 = from the capacity hint
+static Knob<int> g_gbp_agg_pipe{1};
+static Knob<int> g_gbp_xcd_map{1};         // XCD-contiguous work numbering: bit 0 level-2 scatter (-2.6 ms at 4e9 rows), bit 1 aggregate (+5 ms: off), bit 2 level-1 scatter (no effect)
+static Knob<int> g_gbp_b1{-1};             // level-1 bits override (-1: half of the partition bits)
+static Knob<int> g_gbp_chunks{2048};       // level-1 chunks = workgroups of the hist / scatter1 kernels
+static Knob<int> g_gbp_wide_max_bits{kGbWideMaxBits};   // bins of the flat level the planner may ask for (A/B knob groupby_wide_max_bits; tests lower it)
+static Knob<int> g_gbp_room_min_mean{1 << 14};   // rooms only for partitions of at least this many rows on average (knob groupby_wide_room_min_mean; tests lower it)
+static Knob<int> g_gbp_wide_rooms{1};      // the wide form without its histogram pass: fixed rooms per partition (A/B knob groupby_wide_rooms)
+static Knob<int> g_gbp_wide{1};            // the wide one-level form where the group estimate allows it (A/B knob groupby_wide)
+static Knob<int> g_gbp_wide_agg_chunk{1 << 21};   // rows per aggregate work unit of the wide form (A/B knob groupby_wide_agg_chunk_rows)
+static Knob<int64_t> g_gbp_probe_rows{int64_t(1) << 26};   // rows of the probe slice that measures the group count (A/B knob groupby_probe_rows)
+static Knob<int> g_gbp_l1_global{1};       // level 1 with global cursors (one tile per workgroup; +3 % at 4e9 rows) instead of chunked exact offsets
 
 static int gbp_bits_for(int64_t capacity) {
-  if (g_gbp_bits >= 0) return std::min(g_gbp_bits, kGbMaxBits);
+  if (g_gbp_bits >= 0) return std::min(int(g_gbp_bits), kGbMaxBits);
   // capacity = slots of the HBM table ~ 2x the distinct keys expected; aim at <= 2048 groups
   // per 4096-slot LDS table.  bits == 0: everything fits one table, no partitioning at all.
   const int64_t groups = std::max<int64_t>(1, capacity / 2);
@@ -1600,10 +1600,10 @@ static int gbp_bits_for(int64_t capacity) {
 }
 
 constexpr int64_t kGbMaxSlice = int64_t(1) << 30;  // row positions inside a slice are 32-bit
-static int64_t g_gbp_max_slice = kGbMaxSlice;     // A/B knob groupby_max_slice_rows
+static Knob<int64_t> g_gbp_max_slice{kGbMaxSlice};     // A/B knob groupby_max_slice_rows
 constexpr int64_t kGbHardMaxSlice = (int64_t(1) << 32) - (int64_t(1) << 26);   // (room for the rooms' slack below 2^32 positions)
-static int64_t g_gbp_wide_max_slice = kGbHardMaxSlice;   // A/B knob groupby_wide_max_slice_rows
-static int g_gbp_agg_chunk = 1 << 18;             // A/B knob groupby_agg_chunk_rows (2^16: every group of a partition is flushed 2-8x per slice; 2^18: +4 %)
+static Knob<int64_t> g_gbp_wide_max_slice{kGbHardMaxSlice};   // A/B knob groupby_wide_max_slice_rows
+static Knob<int> g_gbp_agg_chunk{1 << 18};             // A/B knob groupby_agg_chunk_rows (2^16: every group of a partition is flushed 2-8x per slice; 2^18: +4 %)
 
 // Partition bits of the wide form for `groups` distinct keys (<= kGbWideMaxGroups per 8192-slot LDS table), or -1 when
 // the flat level would need more than 2048 bins.
@@ -1639,14 +1639,14 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity, int64_t groups_hin
     // (32 bins: ~128-record runs), level 2 works inside a partition whose short runs meet in one L2 (xcd_contiguous) —
     // 4e9 rows / 1e7 keys: 7 + 6 bits 61.6 ms, 5 + 8 bits 54.4 ms; 1e6 keys: 5 + 4 bits 60.8 ms, 3 + 6 bits 54.0 ms
     p.b1 = std::max(p.bits - 8, std::min(3, p.bits - 1));
-    if (g_gbp_b1 > 0) p.b1 = std::max(p.bits - 8, std::min(g_gbp_b1, std::min(8, p.bits - 1)));
+    if (g_gbp_b1 > 0) p.b1 = std::max(p.bits - 8, std::min(int(g_gbp_b1), std::min(8, p.bits - 1)));
     p.b2 = p.bits - p.b1;
   }
   // the wide one-level plan replaces a two-level plan when its tables are known to be enough; groupby_wide = 2 forces
   // it (tests / A-B) with groupby_partition_bits as its bin count
   int wb = -1;
   if (g_gbp_wide == 2) {
-    wb = g_gbp_bits >= 1 ? std::min(g_gbp_bits, kGbWideMaxBits) : kGbWideMaxBits;
+    wb = int(g_gbp_bits) >= 1 ? std::min(int(g_gbp_bits), kGbWideMaxBits) : kGbWideMaxBits;
   } else if (g_gbp_wide && p.bits > 8 && g_gbp_bits < 0) {
     wb = gbp_wide_bits_for(groups_hint >= 0 ? groups_hint : std::max<int64_t>(1, capacity / 2));
     if (dense_idbits > 0) {
@@ -1664,7 +1664,7 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity, int64_t groups_hin
   }
   p.slice_rows = slice_rows;
   const int64_t ntiles = ceil_div(std::max<int64_t>(slice_rows, 1), kGbTile);
-  const int64_t chunk_tiles = std::max<int64_t>(1, ceil_div(ntiles, g_gbp_chunks));
+  const int64_t chunk_tiles = std::max<int64_t>(1, ceil_div(ntiles, int(g_gbp_chunks)));
   p.chunk_rows = chunk_tiles * kGbTile;
   p.nchunks = ceil_div(ntiles, chunk_tiles);
   auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
@@ -1734,7 +1734,7 @@ static int64_t gbp_slice_for(size_t ws_bytes, int64_t n, int64_t capacity, int64
   // the wide plan has one flat level whatever the slice, flushes every group once per slice and aggregate unit, and
   // needs half the row scratch: its slices go up to the 32-bit position limit (4e9 rows / 1e7 keys: 50.2 -> 48.6 ms).
   const GbpPlan probe = gbp_plan(kGbTile, capacity, groups_hint);
-  int64_t hi = std::min<int64_t>(n, probe.wide ? g_gbp_wide_max_slice : g_gbp_max_slice);
+  int64_t hi = std::min<int64_t>(n, probe.wide ? int64_t(g_gbp_wide_max_slice) : int64_t(g_gbp_max_slice));
   if (gbp_plan(hi, capacity, groups_hint).total <= ws_bytes) return hi;
   const size_t fixed = probe.total;
   if (fixed > ws_bytes) return 0;
@@ -1968,11 +1968,11 @@ size_t arx_groupby_consume_workspace_bytes(int64_t length, int64_t capacity) {
   if (length < g_gbp_min_rows || length <= 0) return 0;
   // the plan the capacity alone selects, in its slices — and, where a measured group count may select the wide plan
   // later (arx_groupby_sum_i64_consume's probe slice), room for that plan's larger slices
-  size_t need = gbp_plan(std::min<int64_t>(length, gbp_plan(kGbTile, capacity).wide ? g_gbp_wide_max_slice : g_gbp_max_slice),
+  size_t need = gbp_plan(std::min<int64_t>(length, gbp_plan(kGbTile, capacity).wide ? int64_t(g_gbp_wide_max_slice) : int64_t(g_gbp_max_slice)),
                          capacity).total;
   if (g_gbp_wide && g_gbp_bits < 0 && !gbp_plan(kGbTile, capacity).wide && gbp_plan(kGbTile, capacity).b2 > 0) {
     const int64_t few = int64_t(kGbWideMaxGroups) << 1;   // any hint small enough for the wide plan
-    need = std::max(need, gbp_plan(std::min<int64_t>(length, g_gbp_wide_max_slice), capacity, few).total);
+    need = std::max(need, gbp_plan(std::min<int64_t>(length, int64_t(g_gbp_wide_max_slice)), capacity, few).total);
   }
   return need;
 }
@@ -2010,7 +2010,7 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
     // keys more than once — are the estimate the remaining slices are planned with.  A wrong estimate costs time,
     // never exactness (rows that find no room in an LDS table go to the HBM table).
     const GbpPlan unhinted = gbp_plan(slice, capacity);
-    const int64_t probe_rows = std::max<int64_t>(kGbTile, g_gbp_probe_rows / kGbTile * kGbTile);
+    const int64_t probe_rows = std::max<int64_t>(kGbTile, int64_t(g_gbp_probe_rows) / kGbTile * kGbTile);
     const bool probe = g_gbp_wide && g_gbp_bits < 0 && unhinted.b2 > 0 && !unhinted.wide && n >= 4 * probe_rows;
     int64_t groups_hint = -1;
     bool rooms_ok = true;
@@ -2671,7 +2671,7 @@ static int dense_id_bits(int64_t num_groups) {
 size_t arx_hash_sum_consume_workspace_bytes(int64_t length, int64_t num_groups) {
   if (length <= 0 || num_groups <= 0) return 0;
   const int64_t cap = int64_t(2) << dense_id_bits(num_groups);
-  return gbp_plan(std::min<int64_t>(length, g_gbp_max_slice), cap).total;
+  return gbp_plan(std::min<int64_t>(length, int64_t(g_gbp_max_slice)), cap).total;
 }
 
 int arx_hash_sum_i64_consume_ws(const ArxSpan* values, int values_is_scalar, int64_t scalar_value,

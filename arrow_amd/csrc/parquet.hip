@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void byte_stream_split_kernel(const uint8_t
 // A/B knob snappy_lds: 1 = input window + recent output in LDS, 0 = every byte through global memory, -1 (default) =
 // by the page count: the LDS form is 8-25 % faster on pages of >= 160 KB (profiles/r02_aq) but its 70 KB of LDS per
 // workgroup halves the waves per CU, which costs 40-65 % when there are thousands of small pages to overlap
-static int g_snappy_lds = -1;
+static Knob<int> g_snappy_lds{-1};
 int set_parquet_option(const char* name, int64_t value) {
   if (strcmp(name, "snappy_lds") == 0) {
     g_snappy_lds = value < 0 ? -1 : (value != 0);

@@ -583,6 +583,27 @@ __global__ __launch_bounds__(kBlock) void invert_kernel(Bits a, Bits ones, int64
   }
 }
 
+// One byte per row (0 = clear) -> LSB-first bitmap words: a wave packs 64 rows with one ballot (BytesToBits,
+// util/bitmap_builders.cc, for per-group validity bytes that are already in HBM); set bits are added to *set_count.
+__global__ __launch_bounds__(kBlock) void bytes_to_bitmap_kernel(const uint8_t* __restrict__ bytes, int64_t n,
+                                                                 uint64_t* __restrict__ out,
+                                                                 unsigned long long* __restrict__ set_count) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwords = (n + 63) / 64;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * kBlock) >> 6;
+  unsigned long long mine = 0;
+  for (int64_t w = wave; w < nwords; w += nwaves) {
+    const int64_t i = w * 64 + lane;
+    const uint64_t word = __ballot(i < n && bytes[i] != 0);
+    if (lane == 0) {
+      out[w] = word;
+      mine += static_cast<unsigned long long>(__popcll(word));
+    }
+  }
+  if (set_count != nullptr && lane == 0 && mine != 0) atomicAdd(set_count, mine);
+}
+
 __global__ __launch_bounds__(kBlock) void popcount_kernel(Bits a, int64_t nwords,
                                                           unsigned long long* total) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -1475,6 +1496,19 @@ int arx_boolean_invert(const void* bits, int64_t bit_offset, int64_t length, voi
   hipLaunchKernelGGL(invert_kernel, dim3(stream_grid(kBlock, nwords)), dim3(kBlock), 0, as_stream(stream), a, ones,
                      nwords, static_cast<uint64_t*>(out));
   ARX_CHECK_LAUNCH("invert_kernel");
+  return ARX_OK;
+}
+
+int arx_bytes_to_bitmap(const uint8_t* bytes, int64_t length, void* out_bits, int64_t* set_count, void* stream) {
+  if (length < 0 || (length > 0 && (bytes == nullptr || out_bits == nullptr))) {
+    set_error("bad arguments to arx_bytes_to_bitmap");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  const int64_t nwords = ceil_div(length, 64);
+  hipLaunchKernelGGL(bytes_to_bitmap_kernel, dim3(stream_grid(kBlock, nwords * 64)), dim3(kBlock), 0, as_stream(stream),
+                     bytes, length, static_cast<uint64_t*>(out_bits), reinterpret_cast<unsigned long long*>(set_count));
+  ARX_CHECK_LAUNCH("bytes_to_bitmap_kernel");
   return ARX_OK;
 }
 

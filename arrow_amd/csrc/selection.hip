@@ -1111,9 +1111,9 @@ static int launch_count(const ArxSpan* mask, int null_selection, void* ws, size_
 }
 
 // Tuning knobs (arx_set_option): filter_batch in {1,4}, filter_pipe in {0,1}.  Results never change.
-static int g_filter_batch = 4;
-static int g_filter_pipe = 1;
-static int g_filter_sparse = -1;  // -1 = auto (see launch_compact), 0 = never, 1 = always
+static Knob<int> g_filter_batch{4};
+static Knob<int> g_filter_pipe{1};
+static Knob<int> g_filter_sparse{-1};  // -1 = auto (see launch_compact), 0 = never, 1 = always
 
 template <int W, bool IOTA, bool EMIT, bool ALIGNED>
 static void launch_compact_e(const CompactArgs& a, unsigned grid, hipStream_t st) {

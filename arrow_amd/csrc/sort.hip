@@ -30,30 +30,30 @@ constexpr int kSortItems = 16;
 constexpr int kSortTile = kBlock * kSortItems;  // 4096 keys
 constexpr int kDigits = 256;
 constexpr int kMaxChunks = 16384;  // upper bound (sizes the histogram table)
-static int g_sort_msd = -1;            // -1 = auto (n >= g_sort_msd_min_rows), 0 = never, 1 = whenever possible
-static int g_sort_msd_min_rows = 1 << 22;
-static int g_sort_msd_sampled = 1;     // skewed keys: bucket boundaries from a sorted sample
-static int g_sort_msd_fused = 1;       // finish LDS-sized level-2 buckets in one workgroup (msd_bucket_kernel)
-static int64_t g_sort_msd_segment_rows = int64_t(1) << 27;  // above this: an extra top-bits level cuts segments
-static int g_sort_msd_final_rows_log2 = 1;  // log2 of the rows aimed at per final sub-bucket (rank loop length); with the 4096-bin finish 1 beats 2 / 3 / 4 by 3 / 9 / 18 % at 2e9 rows
-static int g_sort_msd_small_bucket = 1;  // 512-thread / 5120-row bucket kernel when every bucket fits it
-static int g_sort_msd_wide_sample_shift = 4;  // wide form: level-1 capacities from a histogram of 1 tile in 2^shift (0 = exact histogram of every row)
-static int g_sort_xcd_map = 1;                // wide form, XCD-contiguous work numbering: bit 0 level 2 (-2.1 ms at 2e9 rows: a bucket's runs meet in one L2), bit 1 bucket finish, bit 2 level 1 (both: no effect)
-static int g_sort_msd_wide_bits = 0;           // wide form: partition bits (0 = from the row count: buckets of 2048..4096 rows; tests force many bins on few rows)
-static int g_sort_msd_wide_b2max = 10;        // wide form: most partition bits given to level 2 (<= 12; 0 = the even split).  2e9 rows: 10 and 11 = the even split (34.8-35.0 ms), 12 = 42 ms (4096-bin scatter 19.3 ms vs 12); 2^28 rows: 10 is 3 % faster than even
-static int g_sort_msd_wide_rpt1 = 24;         // wide form, level 1: rows per thread of a scatter tile (8: the tile lives in LDS; 16 / 24: in registers, moved through LDS in rounds)
-static int g_sort_msd_wide_rpt2 = 8;          // level 2 likewise
-static int g_sort_msd_tiny_bucket = 1;        // wide form: 256-thread / 2560-row bucket finish when every bucket fits it
-static int g_sort_msd_bucket_cpt = 4;         // wide form's bucket finish: sub-bucket counters per thread (4: <= 4 T sub-buckets, 8: <= 8 T)
-static int g_sort_msd_prefix = 1;             // MSD forms take their digits below the bits that ALL keys share (ids, timestamps, small ints: the top bits are equal)
-static int g_sort_msd_wide_gap2 = 1;          // wide form: level-2 buckets get a fixed room each (bucket mean + 6 sigma + 64) instead of an exact histogram pass
-static int g_sort_msd_wide_sample_strict = 0; // tests: a sampled attempt that overflows is an error instead of a silent exact re-run
-static int g_sort_msd_wide = 1;          // inputs beyond sort_msd_segment_rows: the wide two-level form (run_msd_sort_wide) before the segmented one
-static int g_sort_msd_bucket_v2 = 1;     // single-atomic-pass bucket finish with up to 4096 sub-buckets (msd_bucket2_kernel)
-static int g_sort_msd_seg_min_bits = 1;  // floor of the segment level's bits (more bins = fewer LDS atomic collisions)
-static int g_sort_msd_global_bits = 14;  // (= kMsdMaxBits) cap of the two global levels (tests lower it to reach level 3)
-static int g_sort_fuse_prep = 1;    // first pass reads the caller's column directly (no prep pass)
-static int g_sort_chunks = 2048;    // chunks actually used (arx_set_option "sort_chunks")
+static Knob<int> g_sort_msd{-1};            // -1 = auto (n >= g_sort_msd_min_rows), 0 = never, 1 = whenever possible
+static Knob<int> g_sort_msd_min_rows{1 << 22};
+static Knob<int> g_sort_msd_sampled{1};     // skewed keys: bucket boundaries from a sorted sample
+static Knob<int> g_sort_msd_fused{1};       // finish LDS-sized level-2 buckets in one workgroup (msd_bucket_kernel)
+static Knob<int64_t> g_sort_msd_segment_rows{int64_t(1) << 27};  // above this: an extra top-bits level cuts segments
+static Knob<int> g_sort_msd_final_rows_log2{1};  // log2 of the rows aimed at per final sub-bucket (rank loop length); with the 4096-bin finish 1 beats 2 / 3 / 4 by 3 / 9 / 18 % at 2e9 rows
+static Knob<int> g_sort_msd_small_bucket{1};  // 512-thread / 5120-row bucket kernel when every bucket fits it
+static Knob<int> g_sort_msd_wide_sample_shift{4};  // wide form: level-1 capacities from a histogram of 1 tile in 2^shift (0 = exact histogram of every row)
+static Knob<int> g_sort_xcd_map{1};                // wide form, XCD-contiguous work numbering: bit 0 level 2 (-2.1 ms at 2e9 rows: a bucket's runs meet in one L2), bit 1 bucket finish, bit 2 level 1 (both: no effect)
+static Knob<int> g_sort_msd_wide_bits{0};           // wide form: partition bits (0 = from the row count: buckets of 2048..4096 rows; tests force many bins on few rows)
+static Knob<int> g_sort_msd_wide_b2max{11};        // wide form: most partition bits given to level 2 (<= 12; 0 = the even split).  2e9 rows, 20 bits: 9 + 11 with 16-row level-2 tiles 31.4 ms, 10 + 10 with 8-row tiles 34.2, 8 + 12 37.2 (profiles/r03_h, r03_i); 2^28 rows: 10 and 11 within 2 %
+static Knob<int> g_sort_msd_wide_rpt1{24};         // wide form, level 1: rows per thread of a scatter tile (8: the tile lives in LDS; 16 / 24: in registers, moved through LDS in rounds)
+static Knob<int> g_sort_msd_wide_rpt2{16};          // level 2 likewise
+static Knob<int> g_sort_msd_tiny_bucket{2};        // wide form: 256-thread / 2560-row bucket finish when every bucket fits it
+static Knob<int> g_sort_msd_bucket_cpt{4};         // wide form's bucket finish: sub-bucket counters per thread (4: <= 4 T sub-buckets, 8: <= 8 T)
+static Knob<int> g_sort_msd_prefix{1};             // MSD forms take their digits below the bits that ALL keys share (ids, timestamps, small ints: the top bits are equal)
+static Knob<int> g_sort_msd_wide_gap2{1};          // wide form: level-2 buckets get a fixed room each (bucket mean + 6 sigma + 64) instead of an exact histogram pass
+static Knob<int> g_sort_msd_wide_sample_strict{0}; // tests: a sampled attempt that overflows is an error instead of a silent exact re-run
+static Knob<int> g_sort_msd_wide{1};          // inputs beyond sort_msd_segment_rows: the wide two-level form (run_msd_sort_wide) before the segmented one
+static Knob<int> g_sort_msd_bucket_v2{1};     // single-atomic-pass bucket finish with up to 4096 sub-buckets (msd_bucket2_kernel)
+static Knob<int> g_sort_msd_seg_min_bits{1};  // floor of the segment level's bits (more bins = fewer LDS atomic collisions)
+static Knob<int> g_sort_msd_global_bits{14};  // (= kMsdMaxBits) cap of the two global levels (tests lower it to reach level 3)
+static Knob<int> g_sort_fuse_prep{1};    // first pass reads the caller's column directly (no prep pass)
+static Knob<int> g_sort_chunks{2048};    // chunks actually used (arx_set_option "sort_chunks")
 
 // Provided by selection.hip: ascending row numbers of the set (or clear) bits of a bitmap.
 int selection_bit_positions(const void* bitmap, int64_t bit_offset, int64_t length, bool invert,
@@ -1141,6 +1141,8 @@ constexpr int kBktThreadsSmall = 512;
 constexpr int kBktCapSmall = kBktThreadsSmall * kBktRows;
 constexpr int kBktThreadsTiny = 256;   // wide form with 2^20 buckets of ~2K rows: 34 KB of LDS, four finishes per CU
 constexpr int kBktCapTiny = kBktThreadsTiny * kBktRows;
+constexpr int kBktRowsTiny9 = 9;       // 2304 rows: under 32 KB of LDS, five finishes per CU
+constexpr int kBktCapTiny9 = kBktThreadsTiny * kBktRowsTiny9;
 constexpr int kBktMaxBins = 1024;
 
 template <int T>
@@ -1279,20 +1281,20 @@ __global__ __launch_bounds__(T) void msd_bucket_kernel(MsdArgs a, const uint64_t
 //   * up to 4096 (T = 1024) / 2048 (T = 512) sub-buckets instead of 1024, counters scanned in place: sub-buckets
 //     of ~2-4 rows make the final ranking loop one short iteration for almost every row (it was the dominant
 //     phase at ~8 rows: LDS reads grow with the square of the sub-bucket size).
-template <int T, int CPT = 4>
+template <int T, int CPT = 4, int R = kBktRows>
 struct __attribute__((aligned(16))) MsdBucket2Lds {
-  uint64_t keys[T * kBktRows];
-  uint32_t idx[T * kBktRows];
+  uint64_t keys[T * R];
+  uint32_t idx[T * R];
   uint32_t start[CPT * T + 1];   // counts, then exclusive starts (+ sentinel)
   uint32_t wave_tot[T / 64];
 };
 
 // AOS: the bucket's rows are 12-byte records starting at record part_in[q] of `keys` (idx unused)
-// CPT: sub-bucket counters per thread of the scan (sub-buckets <= CPT * T)
-template <bool SPL, int T, bool AOS = false, int CPT = 4>
+// CPT: sub-bucket counters per thread of the scan (sub-buckets <= CPT * T); R: rows per thread (bucket <= T * R rows)
+template <bool SPL, int T, bool AOS = false, int CPT = 4, int R = kBktRows>
 __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ idx) {
-  __shared__ MsdBucket2Lds<T, CPT> w;
+  __shared__ MsdBucket2Lds<T, CPT, R> w;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -1302,7 +1304,7 @@ __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_
   const int64_t lo_in = AOS ? static_cast<int64_t>(a.part_in[q]) : lo;
   const MsdRec* __restrict__ recs = reinterpret_cast<const MsdRec*>(keys);
   if (m == 0) return;  // workgroup-uniform
-  if (m > T * kBktRows) {
+  if (m > T * R) {
     if (tid == 0) atomicOr(a.overflow, 2u);
     return;
   }
@@ -1327,10 +1329,10 @@ __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_
     }
   };
   for (int i = tid; i < nb; i += T) w.start[i] = 0;
-  uint64_t key[kBktRows];
-  uint32_t id[kBktRows];
+  uint64_t key[R];
+  uint32_t id[R];
 #pragma unroll
-  for (int i = 0; i < kBktRows; ++i) {   // unconditional loads (clamped): all round trips overlap
+  for (int i = 0; i < R; ++i) {   // unconditional loads (clamped): all round trips overlap
     const int p = i * T + tid;
     const int64_t r = lo_in + (p < m ? p : m - 1);
     if constexpr (AOS) {
@@ -1343,9 +1345,9 @@ __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_
     }
   }
   __syncthreads();
-  uint32_t dig[kBktRows], rank[kBktRows];
+  uint32_t dig[R], rank[R];
 #pragma unroll
-  for (int i = 0; i < kBktRows; ++i) {
+  for (int i = 0; i < R; ++i) {
     dig[i] = digit_of(key[i]);
     rank[i] = 0;
     if (i * T + tid < m) rank[i] = atomicAdd(&w.start[dig[i]], 1u);
@@ -1374,7 +1376,7 @@ __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_
   if (tid == 0) w.start[nb] = static_cast<uint32_t>(m);
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < kBktRows; ++i) {
+  for (int i = 0; i < R; ++i) {
     if (i * T + tid < m) {
       const uint32_t pos = w.start[dig[i]] + rank[i];
       w.keys[pos] = key[i];
@@ -1440,7 +1442,7 @@ static SortPlan make_plan(int64_t length) {
   SortPlan p{};
   p.n = length;
   p.ntiles = ceil_div(std::max<int64_t>(length, 1), kSortTile);
-  p.chunk_tiles = std::max<int64_t>(1, ceil_div(p.ntiles, g_sort_chunks));
+  p.chunk_tiles = std::max<int64_t>(1, ceil_div(p.ntiles, int(g_sort_chunks)));
   p.nchunks = ceil_div(p.ntiles, p.chunk_tiles);
   auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
   const size_t n = static_cast<size_t>(std::max<int64_t>(length, 1));
@@ -1505,7 +1507,7 @@ int set_sort_option(const char* name, int64_t value) {
     return 1;
   }
   if (strcmp(name, "sort_msd_tiny_bucket") == 0) {
-    g_sort_msd_tiny_bucket = value != 0;
+    g_sort_msd_tiny_bucket = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 2)));   // 2: also the 9-rows-per-thread form
     return 1;
   }
   if (strcmp(name, "sort_msd_prefix") == 0) {
@@ -1643,7 +1645,7 @@ static int run_msd_sort(const uint64_t* src_keys, const uint32_t* src_idx, int r
   while ((int64_t(1) << (lg + 1)) <= n) ++lg;
   int total = lg - g_sort_msd_final_rows_log2;  // default 3: ~8-16 rows per final bucket
   total = std::max(2, std::min(total, std::min(kMsdMaxBits + 9, 64 - kshift)));
-  a.bits = std::max(2, std::min(total, g_sort_msd_global_bits));
+  a.bits = std::max(2, std::min(total, int(g_sort_msd_global_bits)));
   total = std::min(total, a.bits + 9);
   a.b1 = (a.bits + 1) / 2;
   a.b2 = a.bits - a.b1;
@@ -1814,7 +1816,7 @@ static int run_msd_sort_sampled(const uint64_t* src_keys, const uint32_t* src_id
   ARX_CHECK_LAUNCH("msd_sample_kernel");
   {
     const int64_t stiles = ceil_div(m, kSortTile);
-    const int64_t sct = std::max<int64_t>(1, ceil_div(stiles, g_sort_chunks));
+    const int64_t sct = std::max<int64_t>(1, ceil_div(stiles, int(g_sort_chunks)));
     const int64_t snch = ceil_div(stiles, sct);
     for (int pass = 0; pass < 8; ++pass) {
       hipLaunchKernelGGL(radix_hist_kernel, dim3(static_cast<unsigned>(snch)), dim3(kBlock), 0, st, s0, m, pass * 8,
@@ -2549,12 +2551,14 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   a.kshift = kshift;
   a.xcd_map = (g_sort_xcd_map & 1) != 0;
   a.xcd_map1 = (g_sort_xcd_map & 4) != 0;
-  a.bits = std::max(2, std::min(std::min(lg - 12, kMsdwMaxBits), 64 - kshift));   // 2048 < average bucket <= 4096 rows
-  if (g_sort_msd_wide_bits > 0) a.bits = std::max(2, std::min(g_sort_msd_wide_bits, 64 - kshift));
+  // 1024 < average bucket <= 2048 rows (up to 2^31 rows): the 256-thread finish holds them, four or five per CU.
+  // 2e9 rows: 2^20 buckets 31.5 ms, 2^19 buckets (512-thread finish) 32.9 ms (profiles/r03_k_sort_ab.txt)
+  a.bits = std::max(2, std::min(std::min(lg - 11, kMsdwMaxBits), 64 - kshift));
+  if (g_sort_msd_wide_bits > 0) a.bits = std::max(2, std::min(int(g_sort_msd_wide_bits), 64 - kshift));
   // level 2 takes up to b2max bits (<= 4096 bins, default 1024): level 1 scatters over the whole array, where fewer
   // bins and longer runs pay; level 2 works inside a bucket whose short runs meet in one L2 (xcd_contiguous) — but a
   // 4096-bin level 2 loses more there than level 1 gains (profiles/r02_ah)
-  a.b2 = g_sort_msd_wide_b2max > 0 ? std::min(std::min(g_sort_msd_wide_b2max, 12), a.bits - 1)
+  a.b2 = int(g_sort_msd_wide_b2max) > 0 ? std::min(std::min(int(g_sort_msd_wide_b2max), 12), a.bits - 1)
                                    : a.bits - a.bits / 2;   // 0: the even split
   a.b1 = a.bits - a.b2;
   if (a.b1 > 10) {   // (level 1 has at most 1024 bins)
@@ -2708,7 +2712,14 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
                                        (tiny_bkt ? 10 : small_bkt ? 11 : 12) + cpt_bits),
                               64 - kshift - a.bits));
   const uint64_t* recs = reinterpret_cast<const uint64_t*>(rec_y);
-  if (tiny_bkt && cpt_bits) {
+  const bool tiny9 = tiny_bkt && g_sort_msd_tiny_bucket >= 2 && max_part <= static_cast<unsigned int>(kBktCapTiny9);
+  if (tiny9 && cpt_bits) {
+    hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsTiny, true, 8, kBktRowsTiny9>), dim3(static_cast<unsigned>(nparts)),
+                       dim3(kBktThreadsTiny), 0, st, f, recs, nullptr);
+  } else if (tiny9) {
+    hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsTiny, true, 4, kBktRowsTiny9>), dim3(static_cast<unsigned>(nparts)),
+                       dim3(kBktThreadsTiny), 0, st, f, recs, nullptr);
+  } else if (tiny_bkt && cpt_bits) {
     hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsTiny, true, 8>), dim3(static_cast<unsigned>(nparts)),
                        dim3(kBktThreadsTiny), 0, st, f, recs, nullptr);
   } else if (tiny_bkt) {
@@ -2747,8 +2758,8 @@ static int run_msd_sort_segmented(const uint64_t* src_keys, const uint32_t* src_
                                   uint64_t* keys_p, uint32_t* idx_p, uint64_t* keys_q, uint32_t* idx_q,
                                   uint8_t* tables, uint64_t* out_final, hipStream_t st, int* overflowed, int kshift = 0) {
   int b0 = 1;
-  while ((n >> b0) > std::min<int64_t>(g_sort_msd_segment_rows, int64_t(1) << 27) && b0 < 7) ++b0;
-  b0 = std::max(b0, std::min(g_sort_msd_seg_min_bits, 7));
+  while ((n >> b0) > std::min<int64_t>(int64_t(g_sort_msd_segment_rows), int64_t(1) << 27) && b0 < 7) ++b0;
+  b0 = std::max(b0, std::min(int(g_sort_msd_seg_min_bits), 7));
   MsdArgs a{};
   a.src_keys = src_keys;
   a.src_idx = src_idx;

@@ -707,6 +707,7 @@ def callfunction_leg(args, values, validity, mask, device):
     import pyarrow.compute as pc
     from pyarrow import acero
 
+    import arrow_amd as amd
     from arrow_amd.plugin_build import build_plugin
 
     lib = ctypes.CDLL(build_plugin(verbose=False))

@@ -85,8 +85,10 @@ int arx_abi_version(void);
 /* Number of HIP devices visible, or a negative ArxStatus. */
 int arx_device_count(void);
 /* Process-wide tuning knobs for A/B measurements ("filter_sparse", "groupby_partition_bits",
- * "sort_msd", ...; the list is in DESIGN.md 4.8).  Never changes results.  Not part of the
- * reference interface. */
+ * "sort_msd", ...; the list is in DESIGN.md 4.8).  Never changes results.  May be called while
+ * other threads run kernels: every knob is a relaxed atomic, a call in flight uses the old or the
+ * new value of each knob it reads (which of the two is unspecified).  Not part of the reference
+ * interface. */
 int arx_set_option(const char* name, int64_t value);
 /* Process-wide diagnostic counters (monotonic): which plan the slices of the partitioned group-by consume ran —
  * "groupby_slices_direct" / "_one_level" / "_two_level" / "_wide" / "_probe" (DESIGN.md 4.6).  -1 + arx_last_error() for
@@ -414,6 +416,9 @@ int arx_boolean_kleene(int op, const ArxSpan* left, const ArxSpan* right, void* 
                        void* stream);
 /* out bit i = !bits[bit_offset + i] (validity is the caller's: arx_bitmap_copy). */
 int arx_boolean_invert(const void* bits, int64_t bit_offset, int64_t length, void* out, void* stream);
+/* BytesToBits (util/bitmap_builders.cc) on the device: out bit i = (bytes[i] != 0), whole 64-bit words written, zero
+ * padded; *set_count (device, may be NULL) is INCREMENTED by the number of set bits.  Asynchronous. */
+int arx_bytes_to_bitmap(const uint8_t* bytes, int64_t length, void* out_bits, int64_t* set_count, void* stream);
 /* Synchronous popcount of [bit_offset, bit_offset+length) (CountSetBits). */
 int arx_bitmap_popcount(const void* bits, int64_t bit_offset, int64_t length, void* ws,
                         size_t ws_bytes, int64_t* out_count, void* stream);

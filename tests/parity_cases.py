@@ -767,10 +767,10 @@ def check_sort_indices(amd, arr: HostArray, order="ascending", null_placement="a
     return out
 
 
-SORT_WIDE_RPT_DEFAULT = (24, 8)   # sort.hip g_sort_msd_wide_rpt1 / rpt2
+SORT_WIDE_RPT_DEFAULT = (24, 16)   # sort.hip g_sort_msd_wide_rpt1 / rpt2
 
 
-def check_sort_wide_sampled(amd, lib, rng, n, shift, gap2=1, b2max=12, rpt=(24, 8), typed_keys=False):
+def check_sort_wide_sampled(amd, lib, rng, n, shift, gap2=1, b2max=12, rpt=(24, 16), typed_keys=False):
     """The wide two-level sort with level-1 bucket sizes ESTIMATED from one tile in 2^shift (buckets get room to spare,
     level 2 reads what arrived) and, gap2, level-2 buckets in fixed rooms (mean + 6 sigma) instead of a histogram
     pass.  Uniform keys: the estimates must hold (strict mode turns a silent exact re-run into an error).  Sorted /
@@ -819,12 +819,12 @@ def check_sort_wide_sampled(amd, lib, rng, n, shift, gap2=1, b2max=12, rpt=(24, 
         lib.arx_set_option(b"sort_msd_wide_gap2", 1)
         lib.arx_set_option(b"sort_msd_wide_rpt1", SORT_WIDE_RPT_DEFAULT[0])
         lib.arx_set_option(b"sort_msd_wide_rpt2", SORT_WIDE_RPT_DEFAULT[1])
-        lib.arx_set_option(b"sort_msd_wide_b2max", 10)
+        lib.arx_set_option(b"sort_msd_wide_b2max", 11)
         lib.arx_set_option(b"sort_msd", -1)
         lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
 
 
-def check_sort_wide_many_bins(amd, lib, rng, n, bits, b2max, combos=((2, 1), (0, 1), (0, 0)), rpt=(24, 8)):
+def check_sort_wide_many_bins(amd, lib, rng, n, bits, b2max, combos=((2, 1), (0, 1), (0, 0)), rpt=(24, 16)):
     """The wide form with the partition bits FORCED (sort_msd_wide_bits), so that few rows meet many level-2 bins: up
     to 4096 bins per level-1 partition, `per` = 2..4 counters per thread in the scatter's scan, in the bucket-start
     scan and in the fixed-room setup.  Exact and sampled sizes, fixed rooms and counted buckets, a skewed input (whole
@@ -848,7 +848,7 @@ def check_sort_wide_many_bins(amd, lib, rng, n, bits, b2max, combos=((2, 1), (0,
             check_sort_indices(amd, skew, "ascending", "at_end", use_pyarrow=False)
     finally:
         lib.arx_set_option(b"sort_msd_wide_bits", 0)
-        lib.arx_set_option(b"sort_msd_wide_b2max", 10)
+        lib.arx_set_option(b"sort_msd_wide_b2max", 11)
         lib.arx_set_option(b"sort_msd_wide_rpt1", SORT_WIDE_RPT_DEFAULT[0])
         lib.arx_set_option(b"sort_msd_wide_rpt2", SORT_WIDE_RPT_DEFAULT[1])
         lib.arx_set_option(b"sort_msd_wide_sample_shift", 4)
@@ -1676,6 +1676,31 @@ def check_buffer_copy(amd, rng, scale=1):
             assert_equal(got, want, f"buffer_copy n={n} src+{so} dst+{do}")
     out = amd.compute.copy_buffer(src)
     assert_equal(out.cpu().numpy()[: len(src_h)], src_h, "copy_buffer")
+
+
+def check_bytes_to_bitmap(amd, rng, scale=1):
+    """arx_bytes_to_bitmap (BytesToBits, util/bitmap_builders.cc): one byte per row -> LSB-first bitmap, zero padding in the
+    last word, the set-bit count ADDED to a device counter; lengths around the 64-row word, source at odd addresses."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    for n in [0, 1, 63, 64, 65, 4095, 4097, 100_003 * scale]:
+        for shift, p in [(0, 0.5), (3, 0.02), (1, 1.0)]:
+            host = (rng.random(n + shift) < p).astype(np.uint8) * rng.integers(1, 256, n + shift, dtype=np.uint8)   # any non-zero byte is "set"
+            src = to_device(host, dev)
+            out = torch.full(((n + 63) // 64 * 8 + 16,), 0xA5, dtype=torch.uint8, device=dev)
+            counter = torch.full((1,), 1000, dtype=torch.int64, device=dev)
+            _lib.check(lib.arx_bytes_to_bitmap(src.data_ptr() + shift, n, out.data_ptr(), counter.data_ptr(), current_stream(dev)))
+            _lib.check(lib.arx_bytes_to_bitmap(src.data_ptr() + shift, n, out.data_ptr(), None, current_stream(dev)))   # no counter
+            want_bits = host[shift:] != 0
+            want = np.packbits(np.concatenate([want_bits, np.zeros((-n) % 64, bool)]), bitorder="little")
+            got = out.cpu().numpy()
+            assert_equal(got[: len(want)], want, f"bytes_to_bitmap n={n} shift={shift}")
+            assert (got[len(want):] == 0xA5).all(), "wrote past the last word"
+            assert int(counter.item()) == 1000 + int(want_bits.sum()), (n, shift)
 
 
 def check_hash_minmax_count_kernels(amd, rng, n=5000, num_groups=37, null_p=0.2):

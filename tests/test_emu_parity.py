@@ -435,18 +435,18 @@ def test_sort_wide_sampled_level1(emu_ctx, shift, gap2, b2max):
         assert failed == 2 if b2max == 0 else failed >= 1
 
 
-@pytest.mark.parametrize("rpt", [(8, 24), (16, 16)])   # (the default (24, 8) runs in the tests around this one)
+@pytest.mark.parametrize("rpt", [(8, 24), (16, 16)])   # (the default (24, 16) runs in the tests around this one)
 def test_sort_wide_register_staged_tiles(emu_ctx, rpt):
     """Level-1 / level-2 scatter tiles of 8 (LDS-resident), 16 and 24 (register-staged) rows per thread: ragged last
     tiles, level-2 tiles that end inside a round of the LDS buffer, rooms that overflow (sorted / blocky inputs)."""
     lib = emu_ctx._lib.get_lib()
     # the 256-thread bucket finish takes over whenever every bucket fits it (always, at these sizes): one case without
-    assert lib.arx_set_option(b"sort_msd_tiny_bucket", 0 if rpt[0] == 16 else 1) == 0
+    assert lib.arx_set_option(b"sort_msd_tiny_bucket", {16: 0, 8: 1}.get(rpt[0], 2)) == 0
     assert lib.arx_set_option(b"sort_msd_bucket_cpt", 8 if rpt[1] == 16 else 4) == 0   # sub-bucket counters per thread of the finish
     try:
         P.check_sort_wide_sampled(emu_ctx, lib, rng_for("wide-rpt", *rpt), 70_000, 2, 1, 12, rpt=rpt, typed_keys=True)
     finally:
-        lib.arx_set_option(b"sort_msd_tiny_bucket", 1)
+        lib.arx_set_option(b"sort_msd_tiny_bucket", 2)
         lib.arx_set_option(b"sort_msd_bucket_cpt", 4)
 
 
@@ -951,6 +951,10 @@ def test_hash_minmax_and_count_dense_kernels(emu_ctx, n, num_groups, null_p):
 
 def test_buffer_copy(emu_ctx):
     P.check_buffer_copy(emu_ctx, rng_for("bufcopy"), 1)
+
+
+def test_bytes_to_bitmap(emu_ctx):
+    P.check_bytes_to_bitmap(emu_ctx, rng_for("bytes-to-bitmap"))
 
 
 def test_bitmap_copy_segments(emu_ctx):

@@ -655,13 +655,13 @@ def test_sort_wide_sampled_level1(gpu_ctx, shift, gap2, b2max):
 def test_sort_wide_register_staged_tiles(gpu_ctx, rpt):
     """Level-1 / level-2 scatter tiles of 8 (LDS-resident), 16 and 24 (register-staged) rows per thread."""
     lib = gpu_ctx._lib.get_lib()
-    assert lib.arx_set_option(b"sort_msd_tiny_bucket", 0 if rpt[0] == 16 else 1) == 0   # (256- / 512-thread bucket finish)
+    assert lib.arx_set_option(b"sort_msd_tiny_bucket", {16: 0, 8: 1}.get(rpt[0], 2)) == 0   # (256- / 512-thread bucket finish)
     assert lib.arx_set_option(b"sort_msd_bucket_cpt", 8 if rpt[1] == 16 else 4) == 0   # sub-bucket counters per thread of the finish
     try:
         P.check_sort_wide_sampled(gpu_ctx, lib, rng_for("wide-rpt", *rpt), 6_000_011, 4, 1, 12, rpt=rpt, typed_keys=True)
         P.check_sort_wide_many_bins(gpu_ctx, lib, rng_for("wide-rpt-bins", *rpt), 3_000_003, 16, 12, combos=((0, 0), (2, 1)), rpt=rpt)
     finally:
-        lib.arx_set_option(b"sort_msd_tiny_bucket", 1)
+        lib.arx_set_option(b"sort_msd_tiny_bucket", 2)
         lib.arx_set_option(b"sort_msd_bucket_cpt", 4)
 
 
@@ -1322,6 +1322,10 @@ def test_hash_minmax_and_count_dense_kernels(gpu_ctx, n, num_groups, null_p):
 
 def test_buffer_copy(gpu_ctx):
     P.check_buffer_copy(gpu_ctx, rng_for("bufcopy"), 40)
+
+
+def test_bytes_to_bitmap(gpu_ctx):
+    P.check_bytes_to_bitmap(gpu_ctx, rng_for("bytes-to-bitmap"), scale=30)
 
 
 def test_bitmap_copy_segments(gpu_ctx):
