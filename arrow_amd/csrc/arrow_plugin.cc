@@ -125,24 +125,32 @@ int64_t arrow_amd_plugin_calls(const char* function, int gpu) {
 }
 // Host array (C Data interface, consumed) -> the same array with its buffers in HBM, exported
 // through the C Device Data interface (device_type = ARROW_DEVICE_ROCM).  Fixed-width, boolean
-// and binary / utf8 arrays without children.  0 on success.
+// and binary / utf8 arrays, and nested arrays of those (run_end_encoded, struct).  0 on success.
 int arrow_amd_copy_to_device(struct ArrowArray* in, struct ArrowSchema* schema, struct ArrowDeviceArray* out) {
   auto run = [&]() -> Status {
     ARROW_ASSIGN_OR_RAISE(auto host, arrow::ImportArray(in, schema));
-    if (!host->data()->child_data.empty() || host->data()->dictionary != nullptr || host->data()->buffers.size() > 3) {
-      return Status::NotImplemented("arrow_amd_copy_to_device: ", host->type()->ToString());
-    }
     ARROW_ASSIGN_OR_RAISE(auto mm, RocmMemoryManagerFor(0));
-    const int nbuf = static_cast<int>(host->data()->buffers.size());
-    std::vector<std::shared_ptr<Buffer>> bufs(nbuf);
-    for (int i = 0; i < nbuf; ++i) {
-      const auto& b = host->data()->buffers[i];
-      if (b != nullptr) {
-        ARROW_ASSIGN_OR_RAISE(bufs[i], arrow::MemoryManager::CopyBuffer(b, mm));
+    // buffers of the array and of its children (run_end_encoded: run ends + run values; struct); no dictionaries
+    std::function<arrow::Result<std::shared_ptr<ArrayData>>(const ArrayData&)> upload =
+        [&](const ArrayData& h) -> arrow::Result<std::shared_ptr<ArrayData>> {
+      if (h.dictionary != nullptr || h.buffers.size() > 3) {
+        return Status::NotImplemented("arrow_amd_copy_to_device: ", h.type->ToString());
       }
-    }
-    // null_count must be exact: nothing may popcount a device bitmap on the CPU later
-    auto data = ArrayData::Make(host->type(), host->length(), std::move(bufs), host->null_count(), host->offset());
+      std::vector<std::shared_ptr<Buffer>> bufs(h.buffers.size());
+      for (size_t i = 0; i < h.buffers.size(); ++i) {
+        if (h.buffers[i] != nullptr) {
+          ARROW_ASSIGN_OR_RAISE(bufs[i], arrow::MemoryManager::CopyBuffer(h.buffers[i], mm));
+        }
+      }
+      // null_count must be exact: nothing may popcount a device bitmap on the CPU later
+      auto data = ArrayData::Make(h.type, h.length, std::move(bufs), h.GetNullCount(), h.offset);
+      for (const auto& child : h.child_data) {
+        ARROW_ASSIGN_OR_RAISE(auto c, upload(*child));
+        data->child_data.push_back(std::move(c));
+      }
+      return data;
+    };
+    ARROW_ASSIGN_OR_RAISE(auto data, upload(*host->data()));
     return arrow::ExportDeviceArray(*arrow::MakeArray(data), nullptr, out);
   };
   const Status st = run();

@@ -1921,6 +1921,30 @@ int set_groupby_option(const char* name, int64_t value) {
   return 0;
 }
 
+// Smallest and largest int32 key of a column (slots of null keys included: they only widen the range).  A caller
+// that must size a table for "as many groups as rows" gets a much tighter bound from max - min + 1 when the keys are
+// ids or codes — the usual case for an int32 key column.
+__global__ __launch_bounds__(256) void groupby_key_range_kernel(const int32_t* __restrict__ keys, int64_t n,
+                                                               int32_t* __restrict__ out_min_max) {
+  int32_t lo = INT32_MAX, hi = INT32_MIN;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+    const int32_t k = keys[i];
+    lo = k < lo ? k : lo;
+    hi = k > hi ? k : hi;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int32_t ol = __shfl_xor(lo, d, 64), oh = __shfl_xor(hi, d, 64);
+    lo = ol < lo ? ol : lo;
+    hi = oh > hi ? oh : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&out_min_max[0], lo);
+    atomicMax(&out_min_max[1], hi);
+  }
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -2088,6 +2112,20 @@ int arx_groupby_sum_i64_merge(void* state, int64_t capacity, const int32_t* keys
   hipLaunchKernelGGL(groupby_merge_kernel, dim3(gb_grid(num_groups)), dim3(kBlock), 0,
                      as_stream(stream), v, keys, key_is_valid, sums, counts, no_nulls, num_groups);
   ARX_CHECK_LAUNCH("groupby_merge_kernel");
+  return ARX_OK;
+}
+
+int arx_groupby_key_range_i32(const ArxSpan* keys, int32_t* out_min_max, void* stream) {
+  if (keys == nullptr || out_min_max == nullptr || keys->length < 0 || (keys->length > 0 && keys->data == nullptr)) {
+    set_error("bad arguments to arx_groupby_key_range_i32");
+    return ARX_INVALID;
+  }
+  if (keys->length == 0) return ARX_OK;
+  const int32_t* k = static_cast<const int32_t*>(keys->data) + keys->offset;
+  const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(keys->length, int64_t(256) * 16), 256 * 16));
+  hipLaunchKernelGGL(groupby_key_range_kernel, dim3(std::max(grid, 1u)), dim3(256), 0, as_stream(stream), k, keys->length,
+                     out_min_max);
+  ARX_CHECK_LAUNCH("groupby_key_range_kernel");
   return ARX_OK;
 }
 

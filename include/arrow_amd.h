@@ -560,6 +560,11 @@ int arx_groupby_sum_i64_merge(void* state, int64_t capacity, const int32_t* keys
                               const uint8_t* key_is_valid, const int64_t* sums,
                               const int64_t* counts, const uint8_t* no_nulls,
                               int64_t num_groups, void* stream);
+/* out_min_max (device int32[2], initialised by the caller to {INT32_MAX, INT32_MIN}) = {min, max} of the key slots
+ * (null slots included: they only widen the range).  max - min + 1 bounds the number of groups, usually far below the
+ * number of rows for an int32 id / code column: what aggregate_rocm sizes its table from (the reference's Grouper grows
+ * its table instead, compute/row/grouper.cc).  Asynchronous. */
+int arx_groupby_key_range_i32(const ArxSpan* keys, int32_t* out_min_max, void* stream);
 /* Synchronous: number of groups currently in the table (host int64); ARX_INVALID if the
  * table overflowed. */
 int arx_groupby_num_groups(void* state, int64_t* out_num_groups, void* stream);

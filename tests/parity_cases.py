@@ -1703,6 +1703,36 @@ def check_bytes_to_bitmap(amd, rng, scale=1):
             assert int(counter.item()) == 1000 + int(want_bits.sum()), (n, shift)
 
 
+def check_groupby_key_range(amd, rng, scale=1):
+    """arx_groupby_key_range_i32: {min, max} of an int32 key column folded into the caller's pair (atomic min / max), at
+    offsets, for empty, tiny and large columns and keys at both ends of the int32 range."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    for n, lo, hi in [(0, 0, 1), (1, -5, -4), (63, 0, 10), (65, -2**31, 2**31), (1000, 7, 8), (200_003 * scale, -123456, 9_876_543)]:
+        for off in (0, 5):
+            host = rng.integers(lo, hi, n + off, dtype=np.int64).astype(np.int32)
+            keys = to_device(host, dev)
+            pair = torch.tensor([2**31 - 1, -2**31], dtype=torch.int32, device=dev)
+            span = _lib.ArxSpan(None, keys.data_ptr(), off, n, 0)
+            _lib.check(lib.arx_groupby_key_range_i32(span, pair.data_ptr(), current_stream(dev)))
+            got = pair.cpu().numpy()
+            if n == 0:
+                assert_equal(got, np.array([2**31 - 1, -2**31], np.int32), "key range of an empty column: untouched")
+            else:
+                assert_equal(got, np.array([host[off:].min(), host[off:].max()], np.int32), f"key range n={n} off={off}")
+            # folding: a second column only widens the pair
+            if n > 0:
+                g0, g1 = int(got[0]), int(got[1])
+                more = to_device(np.array([g0 + 1, g1 - 1, g1], np.int32) if g1 - g0 > 1 else host[off:off + 1], dev)
+                span2 = _lib.ArxSpan(None, more.data_ptr(), 0, more.numel(), 0)
+                _lib.check(lib.arx_groupby_key_range_i32(span2, pair.data_ptr(), current_stream(dev)))
+                assert_equal(pair.cpu().numpy(), got, "a narrower column must not move the pair")
+
+
 def check_hash_minmax_count_kernels(amd, rng, n=5000, num_groups=37, null_p=0.2):
     """The dense-id state kernels behind hash_min / hash_max / hash_min_max / hash_count, driven through the C ABI the
     way GroupByNode drives a HashAggregateKernel: two states, resize (fill), consume (arrays at offsets, a broadcast

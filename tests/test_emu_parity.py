@@ -957,6 +957,10 @@ def test_bytes_to_bitmap(emu_ctx):
     P.check_bytes_to_bitmap(emu_ctx, rng_for("bytes-to-bitmap"))
 
 
+def test_groupby_key_range(emu_ctx):
+    P.check_groupby_key_range(emu_ctx, rng_for("key-range"))
+
+
 def test_bitmap_copy_segments(emu_ctx):
     P.check_bitmap_copy_segments(emu_ctx, rng_for("bitseg"), 1)
 

@@ -2148,6 +2148,77 @@ TABLE_SOURCE_SCRIPT = textwrap.dedent(r'''
 ''')
 
 
+REE_FILTER_SCRIPT = textwrap.dedent(r'''
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    path = build_plugin()
+    rng = np.random.default_rng(91)
+    n = SC(1_000_000)
+    # runs of 1..40 rows, ~40 % selected, 10 % of the RUN VALUES null
+    lens = rng.integers(1, 41, n)
+    ends = np.cumsum(lens)
+    runs = int(np.searchsorted(ends, n)) + 1
+    ends = ends[:runs].copy(); ends[-1] = n
+    run_vals = pa.array(rng.random(runs) < 0.4, mask=rng.random(runs) < 0.1)
+    cases = []
+    for end_type in (pa.int16(), pa.int32(), pa.int64()):
+        m = n if end_type != pa.int16() else min(n, 30_000)
+        r = int(np.searchsorted(ends, m)) + 1
+        e = ends[:r].copy(); e[-1] = m
+        ree = pa.RunEndEncodedArray.from_arrays(pa.array(e, end_type), run_vals.slice(0, r))
+        vals = pa.array(rng.integers(-2**62, 2**62, m), mask=rng.random(m) < 0.05)
+        small = pa.array(rng.integers(-100, 100, m).astype(np.int16))
+        dbl = pa.array(rng.standard_normal(m))
+        for v in (vals, small, dbl):
+            for mode in ("drop", "emit_null"):
+                cases.append((v, ree, mode, pc.filter(v, ree, null_selection_behavior=mode)))
+                # a logical slice of both (the REE array keeps its runs and gets an offset)
+                o, l = m // 7 + 3, m // 2
+                cases.append((v.slice(o, l), ree.slice(o, l), mode, pc.filter(v.slice(o, l), ree.slice(o, l), null_selection_behavior=mode)))
+    lib = ctypes.CDLL(path)
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(k) for k in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+    def to_host(arr):
+        c_dev, c_schema, c_arr = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72), ctypes.create_string_buffer(80)
+        arr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, None) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), arr.type)
+    g0, s0 = lib.arrow_amd_plugin_calls(b"array_filter", 1), lib.arrow_amd_plugin_calls(b"array_filter", 0)
+    for v, ree, mode, want in cases:
+        got = pc.call_function("array_filter", [to_device(v), to_device(ree)], pc.FilterOptions(null_selection_behavior=mode))
+        got = to_host(got)
+        assert got.type == want.type and len(got) == len(want), (got.type, len(got), len(want))
+        assert got.equals(want), (str(v.type), str(ree.type), mode, v.offset)
+    assert lib.arrow_amd_plugin_calls(b"array_filter", 1) - g0 == len(cases), "the REE filters did not run on the device"
+    # host arrays with an REE filter keep the reference kernel (same exec serves both layouts)
+    v, ree, mode, want = cases[0]
+    assert pc.filter(v, ree, null_selection_behavior=mode).equals(want)
+    assert lib.arrow_amd_plugin_calls(b"array_filter", 0) > s0
+    # mixed residency is refused by name
+    try:
+        pc.call_function("array_filter", [to_device(v), ree], pc.FilterOptions())
+        raise SystemExit("mixed residency accepted")
+    except pa.ArrowNotImplementedError as e:
+        assert "both be device-resident" in str(e), e
+    print("REE_FILTER_OK")
+''')
+
+
 def _run(script, marker):
     pytest.importorskip("pyarrow")
     code = f"ROOT = {ROOT!r}\n" + script
@@ -2194,3 +2265,11 @@ def test_table_source_rocm_delivers_whole_chunks_to_the_stock_filter_and_project
     reference plan's taken before registration; aggregate_rocm consumes such batches where they lie (no staging copy),
     small and large batches mixed; the knob that replaces the options' default batch size; host tables; validation."""
     _run(TABLE_SOURCE_SCRIPT, "TABLE_SOURCE_OK")
+
+
+def test_run_end_encoded_filter_masks_on_device_arrays():
+    """array_filter with a run_end_encoded<int16/32/64, boolean> filter over device-resident values: the runs are expanded
+    on the device (arx_ree_bool_expand) and the ordinary filter kernels run — DROP and EMIT_NULL, null run values, logical
+    slices of the REE array, three value widths; equal to the reference's REE filter taken before registration; host
+    arrays keep the reference kernel; mixed residency refused by name."""
+    _run(REE_FILTER_SCRIPT, "REE_FILTER_OK")

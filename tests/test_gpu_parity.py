@@ -1328,5 +1328,9 @@ def test_bytes_to_bitmap(gpu_ctx):
     P.check_bytes_to_bitmap(gpu_ctx, rng_for("bytes-to-bitmap"), scale=30)
 
 
+def test_groupby_key_range(gpu_ctx):
+    P.check_groupby_key_range(gpu_ctx, rng_for("key-range"), scale=50)
+
+
 def test_bitmap_copy_segments(gpu_ctx):
     P.check_bitmap_copy_segments(gpu_ctx, rng_for("bitseg"), 20)

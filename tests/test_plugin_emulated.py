@@ -100,3 +100,7 @@ def test_device_streams_events_reader_writer_dlpack_emulated():
 
 def test_table_source_rocm_whole_chunk_batches_emulated():
     _run(G.TABLE_SOURCE_SCRIPT, "TABLE_SOURCE_OK", 0.02)
+
+
+def test_run_end_encoded_filter_masks_emulated():
+    _run(G.REE_FILTER_SCRIPT, "REE_FILTER_OK", 0.02)
