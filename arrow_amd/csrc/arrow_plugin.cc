@@ -538,6 +538,10 @@ int64_t arrow_amd_plugin_aggregate_flushes(void) { return g_aggregate_flushes.lo
 // aggregate_rocm consumes a device batch of at least this many rows where it lies (no staging copy)
 void arrow_amd_plugin_set_aggregate_direct_rows(int64_t rows) { g_aggregate_direct_rows.store(rows < 1 ? 1 : rows); }
 int64_t arrow_amd_plugin_aggregate_direct_batches(void) { return g_aggregate_direct_batches.load(); }
+// aggregate_rocm keeps the result of a plan over device-resident rows in HBM (default off: host arrays, as GroupByNode)
+void arrow_amd_plugin_set_aggregate_device_output(int on) { g_aggregate_device_output.store(on != 0); }
+// column-sized result copies by a kernel (arx_buffer_copy) instead of the copy engines (default on; A/B knob)
+void arrow_amd_plugin_set_results_kernel_copy(int on) { g_results_kernel_copy.store(on != 0); }
 // result columns >= 1 MB into pooled page-locked host buffers (default on)
 void arrow_amd_plugin_set_pinned_results(int on) { g_pinned_results.store(on != 0); }
 // table_source_rocm: rows per batch when TableSourceNodeOptions::max_batch_size is the default

@@ -1270,6 +1270,14 @@ __global__ __launch_bounds__(1024) void gbp_rooms_scan_kernel(GbpArgs a) {
 // 12-byte {key, value} records (one output stream per bin instead of two).  2^30 rows into 2048 bins: 7.9 ms
 // (3.3 TB/s of 24 B/row) against 5.2 + 4.4 ms for the two levels it replaces
 // (scripts/micro/wide_scatter_bench.hip, profiles/r03_a_wide_scatter_register_staged_tiles.txt).
+// Cache policy of the wide form's one-pass streams (A/B by rebuilding: scripts/build_gb_variants.sh): bit 0 the scatter's
+// key / value loads, bit 1 the aggregate's record loads, bit 2 the scatter's record stores are non-temporal.
+constexpr int kGbNt = 0;
+constexpr int kGbPairAtomics = 0;   // the flat level's cursors: 1 = one 64-bit atomic per pair of bins, 0 = one per bin.  A/B at 4e9 rows: 41.2 / 45.2 ms paired, 40.4 / 40.4 single (profiles/r03_t_groupby_paired_cursor_atomics_ab.txt): the level is not bound by its atomics
+template <typename T>
+__device__ __forceinline__ T gb_load(const T* p, bool nt) {
+  return nt ? __builtin_nontemporal_load(p) : *p;
+}
 struct __attribute__((packed, aligned(4))) GbpRec {
   uint32_t key, vlo, vhi;
 };
@@ -1303,8 +1311,8 @@ __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArg
   for (int i = 0; i < kGbWideRpt; ++i) {
     const int p = i * kGbWideThreads + tid;
     const int64_t r = row0 + (p < nrows ? p : nrows - 1);
-    key[i] = static_cast<uint32_t>(a.keys[r]);
-    val[i] = a.values[r];
+    key[i] = static_cast<uint32_t>(gb_load(a.keys + r, (kGbNt & 1) != 0));
+    val[i] = gb_load(a.values + r, (kGbNt & 1) != 0);
   }
   __syncthreads();
   uint32_t pos[kGbWideRpt];
@@ -1330,11 +1338,36 @@ __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArg
   __syncthreads();
   uint32_t pre = incl - mine;
   for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
+  // kGbPairAtomics: ONE returning 64-bit atomic per PAIR of adjacent bins (low half = the even bin's cursor; positions
+  // stay below 2^32, so the low half never carries).  Global atomics run at 24 G/s chip-wide and one per (tile, bin) is
+  // 3.3e8 of them for 4e9 rows — but halving them did not move the kernel: they overlap the tile's loads.
+  uint32_t gb[2] = {0, 0};
+  if constexpr (kGbPairAtomics == 0) {
+    for (int k = 0; k < per; ++k) {
+      const int b = tid * per + k;
+      if (b < nb && c[k] != 0) gb[k] = atomicAdd(&a.cursor2[b], c[k]);
+    }
+  } else if (per == 1) {   // (workgroup-uniform) the pair's bins sit in neighbouring lanes
+    const uint32_t cn = __shfl_xor(c[0], 1, 64);
+    unsigned long long old = 0;
+    if ((tid & 1) == 0 && tid < nb && (c[0] | cn) != 0) {
+      old = atomicAdd(reinterpret_cast<unsigned long long*>(a.cursor2 + tid),
+                      static_cast<unsigned long long>(c[0]) | (static_cast<unsigned long long>(cn) << 32));
+    }
+    const uint32_t from_even = __shfl_xor(static_cast<uint32_t>(old >> 32), 1, 64);
+    gb[0] = (tid & 1) == 0 ? static_cast<uint32_t>(old) : from_even;
+  } else if (tid * 2 < nb && (c[0] | c[1]) != 0) {
+    const unsigned long long old =
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.cursor2 + tid * 2),
+                  static_cast<unsigned long long>(c[0]) | (static_cast<unsigned long long>(c[1]) << 32));
+    gb[0] = static_cast<uint32_t>(old);
+    gb[1] = static_cast<uint32_t>(old >> 32);
+  }
   for (int k = 0; k < per; ++k) {
     const int b = tid * per + k;
     if (b < nb) {
       lds.start[b] = pre;
-      const uint32_t g = c[k] != 0 ? atomicAdd(&a.cursor2[b], c[k]) : 0u;
+      const uint32_t g = gb[k];
       lds.gbase[b] = g;
       if (a.room != 0 && c[k] != 0 && (g - static_cast<uint32_t>(b) * a.room) + c[k] > a.room) atomicOr(a.overflow, 1u);
     }
@@ -1370,7 +1403,16 @@ __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArg
       rec.vlo = static_cast<uint32_t>(v);
       rec.vhi = static_cast<uint32_t>(v >> 32);
       const uint32_t dst = lds.gbase[d] + (lo + static_cast<uint32_t>(p) - lds.start[d]);
-      if (a.room == 0 || dst - d * a.room < a.room) out[dst] = rec;   // (never past a room: the slice is redone then)
+      if (a.room == 0 || dst - d * a.room < a.room) {   // (never past a room: the slice is redone then)
+        if constexpr ((kGbNt & 4) != 0) {
+          uint32_t* o = reinterpret_cast<uint32_t*>(out + dst);
+          __builtin_nontemporal_store(rec.key, o);
+          __builtin_nontemporal_store(rec.vlo, o + 1);
+          __builtin_nontemporal_store(rec.vhi, o + 2);
+        } else {
+          out[dst] = rec;
+        }
+      }
     }
     __syncthreads();
   }
@@ -1469,9 +1511,10 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
       }
       const int64_t rc = rr < hi ? rr : hi - 1;  // clamped: always readable
       if constexpr (AOS) {
-        const GbpRec rec = reinterpret_cast<const GbpRec*>(a.recs)[rc];
-        kb[u] = static_cast<int32_t>(rec.key);
-        vb[u] = (static_cast<unsigned long long>(rec.vhi) << 32) | rec.vlo;
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const GbpRec*>(a.recs) + rc);
+        const uint32_t rk = gb_load(rp, (kGbNt & 2) != 0), rlo = gb_load(rp + 1, (kGbNt & 2) != 0), rhi = gb_load(rp + 2, (kGbNt & 2) != 0);
+        kb[u] = static_cast<int32_t>(rk);
+        vb[u] = (static_cast<unsigned long long>(rhi) << 32) | rlo;
       } else {
         kb[u] = keys[rc];
         vb[u] = static_cast<unsigned long long>(vals[rc]);
@@ -1939,7 +1982,18 @@ __global__ __launch_bounds__(256) void groupby_key_range_kernel(const int32_t* _
     lo = ol < lo ? ol : lo;
     hi = oh > hi ? oh : hi;
   }
+  // one atomic pair per workgroup (atomics on one address serialise behind the L2)
+  __shared__ int32_t wlo[4], whi[4];
   if ((threadIdx.x & 63) == 0) {
+    wlo[threadIdx.x >> 6] = lo;
+    whi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int wv = 1; wv < 4; ++wv) {
+      lo = wlo[wv] < lo ? wlo[wv] : lo;
+      hi = whi[wv] > hi ? whi[wv] : hi;
+    }
     atomicMin(&out_min_max[0], lo);
     atomicMax(&out_min_max[1], hi);
   }
@@ -2122,7 +2176,7 @@ int arx_groupby_key_range_i32(const ArxSpan* keys, int32_t* out_min_max, void* s
   }
   if (keys->length == 0) return ARX_OK;
   const int32_t* k = static_cast<const int32_t*>(keys->data) + keys->offset;
-  const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(keys->length, int64_t(256) * 16), 256 * 16));
+  const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(keys->length, int64_t(256) * 16), 256 * 8));
   hipLaunchKernelGGL(groupby_key_range_kernel, dim3(std::max(grid, 1u)), dim3(256), 0, as_stream(stream), k, keys->length,
                      out_min_max);
   ARX_CHECK_LAUNCH("groupby_key_range_kernel");

@@ -601,7 +601,16 @@ __global__ __launch_bounds__(kBlock) void bytes_to_bitmap_kernel(const uint8_t* 
       mine += static_cast<unsigned long long>(__popcll(word));
     }
   }
-  if (set_count != nullptr && lane == 0 && mine != 0) atomicAdd(set_count, mine);
+  // one atomic per WORKGROUP and a capped grid: atomics on one address serialise behind the L2 at ~12 ns each — one per
+  // wave of a one-shot grid was 1.9 ms for 10M rows, 40x the pass itself (profiles/r03_r_aggregate_rocm_result_phase.txt)
+  __shared__ unsigned long long part[kBlock / 64];
+  if (lane == 0) part[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (set_count != nullptr && threadIdx.x == 0) {
+    unsigned long long total = 0;
+    for (int wv = 0; wv < kBlock / 64; ++wv) total += part[wv];
+    if (total != 0) atomicAdd(set_count, total);
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void popcount_kernel(Bits a, int64_t nwords,
@@ -613,7 +622,15 @@ __global__ __launch_bounds__(kBlock) void popcount_kernel(Bits a, int64_t nwords
     c += __popcll(load_word(a, w));
   }
   c = wave_reduce_sum_u64(c);
-  if (lane_id() == 0 && c != 0) atomicAdd(total, static_cast<unsigned long long>(c));
+  // one atomic per workgroup of a capped grid (see bytes_to_bitmap_kernel: atomics on one address serialise, ~12 ns each)
+  __shared__ unsigned long long part[kBlock / 64];
+  if (lane_id() == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long sum = 0;
+    for (int wv = 0; wv < kBlock / 64; ++wv) sum += part[wv];
+    if (sum != 0) atomicAdd(total, sum);
+  }
 }
 
 template <typename T, int LK, int RK, int CMP = ARX_CMP_GREATER>
@@ -1336,7 +1353,7 @@ int arx_buffer_copy(const void* src, void* dst, int64_t nbytes, void* stream) {
   } else {
     head = nbytes;   // (byte loop; buffers from hipMalloc / the pool are 256-byte aligned, slices of them rarely differ in phase)
     if (nbytes > (1 << 20)) {
-      ARX_HIP(hipMemcpyAsync(dst, src, static_cast<size_t>(nbytes), hipMemcpyDeviceToDevice, as_stream(stream)));
+      ARX_HIP(hipMemcpyAsync(dst, src, static_cast<size_t>(nbytes), hipMemcpyDefault, as_stream(stream)));   // (either side may be mapped host memory)
       return ARX_OK;
     }
   }
@@ -1506,7 +1523,8 @@ int arx_bytes_to_bitmap(const uint8_t* bytes, int64_t length, void* out_bits, in
   }
   if (length == 0) return ARX_OK;
   const int64_t nwords = ceil_div(length, 64);
-  hipLaunchKernelGGL(bytes_to_bitmap_kernel, dim3(stream_grid(kBlock, nwords * 64)), dim3(kBlock), 0, as_stream(stream),
+  const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(nwords * 64, kBlock), 2048));
+  hipLaunchKernelGGL(bytes_to_bitmap_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream),
                      bytes, length, static_cast<uint64_t*>(out_bits), reinterpret_cast<unsigned long long*>(set_count));
   ARX_CHECK_LAUNCH("bytes_to_bitmap_kernel");
   return ARX_OK;
@@ -1526,7 +1544,7 @@ int arx_bitmap_popcount(const void* bits, int64_t bit_offset, int64_t length, vo
   const Bits a = make_bits(bits, bit_offset, length);
   const int64_t nwords = ceil_div(length, 64);
   ARX_HIP(hipMemsetAsync(ws, 0, 8, st));
-  const unsigned grid = stream_grid(kBlock, nwords);
+  const unsigned grid = std::min(stream_grid(kBlock, nwords), 2048u);   // (grid-stride loop; few atomics)
   hipLaunchKernelGGL(popcount_kernel, dim3(grid), dim3(kBlock), 0, st, a, nwords,
                      static_cast<unsigned long long*>(ws));
   ARX_CHECK_LAUNCH("popcount_kernel");

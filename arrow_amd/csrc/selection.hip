@@ -590,6 +590,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(CompactArgs a) {
 // Steps are aligned to 64-bit words of the OUTPUT bitmap, so the output validity of a step is
 // one __ballot: full words are stored, the tile's first/last partial words are OR-ed in.
 constexpr int kSparseWindow = 1024;  // emitted rows staged per round (a tile emits ~410 at 10 %)
+constexpr int kSparseU = 2;          // gather steps (64 rows each) in flight per wave: 2 is 3 % faster than 4 at 10 % selectivity, equal at 25 / 50 % (fewer registers, more waves; profiles/r03_q_filter_gather_steps_in_flight_ab.jsonl)
 
 struct __attribute__((aligned(16))) SparseLds {
   uint16_t sel[kWavesPerBlock][kSparseWindow];  // row-in-tile of the s-th emitted row of the window
@@ -601,7 +602,7 @@ struct __attribute__((aligned(16))) SparseLds {
 template <int W, bool EMIT, bool IOTA>
 __global__ __launch_bounds__(kBlock) void compact_sparse_kernel(CompactArgs a) {
   using E = typename ElemT<W>::type;
-  constexpr int U = 4;  // gather steps in flight
+  constexpr int U = kSparseU;  // gather steps in flight
   __shared__ SparseLds lds;
 
   const int lane = lane_id();

@@ -2111,6 +2111,43 @@ struct __attribute__((aligned(16))) MsdwScatterLds {
   uint32_t part;
 };
 
+// Where the tile's run of every digit starts in the output: ONE returning 64-bit atomic per PAIR of adjacent digits
+// (cursor[2j] in the low half, cursor[2j + 1] in the high half; positions are < 2^32 and stay so, so the low half never
+// carries).  Global atomics run at 24 G/s chip-wide whatever they touch (profiles/r03_a_atomics_rate_*) and a level of
+// 16384-row tiles over 2048 bins issues 2.5e8 of them for 2e9 rows; halving them was worth 0.2 ms of that level's 10
+// and 0.3 ms end to end (profiles/r03_s_sort_paired_cursor_atomics_ab.txt) — they mostly overlap the tile's loads.
+// cc[k] = rows of digit tid * per + k (0 beyond nb); per = 1, 2 or 4; cursor must be 8-byte aligned.
+__device__ __forceinline__ void msdw_reserve_runs(uint32_t* __restrict__ cursor, const uint32_t (&cc)[kMsdwMaxBins2 / kMsdwThreads],
+                                                  int per, int nb, uint32_t (&base)[kMsdwMaxBins2 / kMsdwThreads]) {
+  constexpr int K = kMsdwMaxBins2 / kMsdwThreads;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < K; ++k) base[k] = 0;
+  if (per == 1) {   // (workgroup-uniform) the pair's digits sit in neighbouring lanes
+    const uint32_t c = cc[0];
+    const uint32_t cn = __shfl_xor(c, 1, 64);
+    unsigned long long old = 0;
+    if ((tid & 1) == 0 && tid < nb && (c | cn) != 0) {
+      old = atomicAdd(reinterpret_cast<unsigned long long*>(cursor + tid),
+                      static_cast<unsigned long long>(c) | (static_cast<unsigned long long>(cn) << 32));
+    }
+    const uint32_t from_even = __shfl_xor(static_cast<uint32_t>(old >> 32), 1, 64);
+    base[0] = (tid & 1) == 0 ? static_cast<uint32_t>(old) : from_even;
+  } else {
+#pragma unroll
+    for (int k = 0; k + 1 < K; k += 2) {
+      const int b = tid * per + k;
+      if (k < per && b < nb && (cc[k] | cc[k + 1]) != 0) {
+        const unsigned long long old =
+            atomicAdd(reinterpret_cast<unsigned long long*>(cursor + b),
+                      static_cast<unsigned long long>(cc[k]) | (static_cast<unsigned long long>(cc[k + 1]) << 32));
+        base[k] = static_cast<uint32_t>(old);
+        base[k + 1] = static_cast<uint32_t>(old >> 32);
+      }
+    }
+  }
+}
+
 // Scatter one tile of <= 8192 rows by digit = (key >> dshift) & (nb - 1); run bases from one returning atomic per
 // digit on gcursor[]; output = 12-byte records.  1024 threads, nb <= 1024 (one counter per thread in the scan).
 // SRC: 0 raw column (row id = position), 1 transformed keys + row ids, 2 records.
@@ -2170,13 +2207,15 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
   __syncthreads();
   uint32_t pre = incl - mine;
   for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
+  uint32_t run_base[kMsdwMaxBins2 / kMsdwThreads];
+  msdw_reserve_runs(gcursor, cc, per, nb, run_base);
 #pragma unroll
   for (int k = 0; k < kMsdwMaxBins2 / kMsdwThreads; ++k) {
     const int b = tid * per + k;
     if (k < per && b < nb) {
       const uint32_t c = cc[k];
       lds.start[b] = pre;
-      uint32_t base = c != 0 ? atomicAdd(&gcursor[b], c) : 0u;
+      uint32_t base = run_base[k];
       if constexpr (CHECK != 0) {
         const uint32_t end = CHECK == 1 ? gend[b] : room_base + (static_cast<uint32_t>(b) + 1u) * room;
         if (c != 0 && (base + c > end || base + c < base)) {
@@ -2292,13 +2331,15 @@ __device__ __forceinline__ void msdw_scatter_big_tile(const MsdwArgs& a, MsdwSca
   __syncthreads();
   uint32_t pre = incl - mine;
   for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
+  uint32_t run_base[kMsdwMaxBins2 / kMsdwThreads];
+  msdw_reserve_runs(gcursor, cc, per, nb, run_base);
 #pragma unroll
   for (int k = 0; k < kMsdwMaxBins2 / kMsdwThreads; ++k) {
     const int b = tid * per + k;
     if (k < per && b < nb) {
       const uint32_t c = cc[k];
       lds.start[b] = pre;
-      uint32_t base = c != 0 ? atomicAdd(&gcursor[b], c) : 0u;
+      uint32_t base = run_base[k];
       if constexpr (CHECK != 0) {
         const uint32_t end = CHECK == 1 ? gend[b] : room_base + (static_cast<uint32_t>(b) + 1u) * room;
         if (c != 0 && (base + c > end || base + c < base)) {

@@ -376,7 +376,7 @@ def cpu_baseline_hash_sum(rows: int, groups: int, budget_s: float):
             break
     best = max(res.values(), key=lambda x: x[0])
     return {"value": round(best[0], 2), "unit": "Mrows/s", "cores": best[1], "kind": "reference",
-            "sample": f"DOWN-SCALED: first {n} rows of the same streams ({best[2]} groups), pyarrow {pa.__version__} "
+            "sample": f"SURVEY 8(d) sample: first {n} rows of the same streams ({best[2]} groups), pyarrow {pa.__version__} "
                       "Table.group_by(k).aggregate([(v, sum)])",
             **{f"{nm}_mrows_per_s": round(x[0], 2) for nm, x in res.items()}, "host_cpus": cores_all}
 
@@ -394,7 +394,7 @@ def cpu_baseline_sort(rows: int):
     dt = time.perf_counter() - t0
     del out
     return {"value": round(rows / dt / 1e6, 2), "unit": "Mrows/s", "cores": 1, "kind": "reference",
-            "sample": f"DOWN-SCALED: first {rows} rows of the same stream, pyarrow {pa.__version__} pc.sort_indices "
+            "sample": f"SURVEY 8(d) sample: first {rows} rows of the same stream, pyarrow {pa.__version__} pc.sort_indices "
                       "(std::stable_sort on indices, one thread)", "host_cpus": _host_cores()}
 
 
@@ -775,8 +775,22 @@ def callfunction_leg(args, values, validity, mask, device):
             plan_f = acero.Declaration.from_sequence([acero.Declaration(source, acero.TableSourceNodeOptions(dtx))] + stages)
             timeit(f"acero {source} -> filter(x > 0.1) -> project(k, v + v) -> aggregate_rocm ({m} device rows)",
                    lambda: plan_f.to_table(use_threads=False), reps=3 if source == "table_source_rocm" else 1)
+            if source == "table_source_rocm":
+                # the same plan with its result left in HBM (120 MB of keys and sums do not cross PCIe)
+                lib.arrow_amd_plugin_set_aggregate_device_output(1)
+                timeit(f"acero {source} -> filter(x > 0.1) -> project(k, v + v) -> aggregate_rocm ({m} device rows), result kept in HBM",
+                       lambda: plan_f.to_table(use_threads=False), reps=3)
+                timeit(f"acero {source} -> aggregate_rocm (hash_sum, {m} device rows, {args.groups} keys), result kept in HBM",
+                       lambda: plan_r.to_table(use_threads=False), reps=3)
+                lib.arrow_amd_plugin_set_aggregate_device_output(0)
             del plan_f
-        del dtx
+        # what a plan costs before it touches a row: the same four nodes over 1024 rows (plan construction, task
+        # scheduling, the sink and to_table included)
+        tiny = pa.table({name: dtx.column(name).chunk(0).slice(0, 1024) for name in ("x", "k", "v")})
+        plan_t = acero.Declaration.from_sequence([acero.Declaration("table_source_rocm", acero.TableSourceNodeOptions(tiny))] + stages)
+        timeit("acero table_source_rocm -> filter -> project -> aggregate_rocm over 1024 device rows (the plan's fixed cost)",
+               lambda: plan_t.to_table(use_threads=False), reps=5)
+        del dtx, tiny, plan_t
     except Exception as e:
         res["table_source_rocm -> filter -> project -> aggregate_rocm"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     kt = gen_stream(m, device, 0, 8, modulo=args.groups, dtype=torch.int32)
@@ -1111,8 +1125,8 @@ def main():
     ap.add_argument("--selectivity", type=float, default=0.10)
     ap.add_argument("--null-p", dest="null_p", type=float, default=0.10)
     ap.add_argument("--cpu-sample-rows", type=int, default=250_000_000)
-    ap.add_argument("--cpu-groupby-rows", dest="cpu_groupby_rows", type=int, default=50_000_000)
-    ap.add_argument("--cpu-sort-rows", dest="cpu_sort_rows", type=int, default=30_000_000)
+    ap.add_argument("--cpu-groupby-rows", dest="cpu_groupby_rows", type=int, default=100_000_000)
+    ap.add_argument("--cpu-sort-rows", dest="cpu_sort_rows", type=int, default=100_000_000)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", dest="extras", action="store_false")

@@ -8,5 +8,5 @@ mkdir -p $OUT
 echo "== smoke"
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
 echo "== pytest -m gpu"
-timeout 1500 python -m pytest tests -q -m gpu -x > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/pytest_gpu.log
+timeout 1500 python -m pytest tests -q -m gpu --durations=12 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -20 $OUT/pytest_gpu.log
 bash scripts/gpu_record_run.sh

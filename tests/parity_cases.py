@@ -1727,8 +1727,9 @@ def check_groupby_key_range(amd, rng, scale=1):
             # folding: a second column only widens the pair
             if n > 0:
                 g0, g1 = int(got[0]), int(got[1])
-                more = to_device(np.array([g0 + 1, g1 - 1, g1], np.int32) if g1 - g0 > 1 else host[off:off + 1], dev)
-                span2 = _lib.ArxSpan(None, more.data_ptr(), 0, more.numel(), 0)
+                inner = np.array([g0 + 1, g1 - 1, g1], np.int32) if g1 - g0 > 1 else host[off:off + 1]
+                more = to_device(inner, dev)      # (a padded byte buffer: the row count is inner's)
+                span2 = _lib.ArxSpan(None, more.data_ptr(), 0, len(inner), 0)
                 _lib.check(lib.arx_groupby_key_range_i32(span2, pair.data_ptr(), current_stream(dev)))
                 assert_equal(pair.cpu().numpy(), got, "a narrower column must not move the pair")
 

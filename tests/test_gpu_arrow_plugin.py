@@ -2131,6 +2131,14 @@ TABLE_SOURCE_SCRIPT = textwrap.dedent(r'''
     assert lib.arrow_amd_plugin_aggregate_direct_batches() - d0 == 1
     assert got.column("k").equals(want_groups.column("k")) and got.column("v_sum").equals(want_groups.column("v_sum"))
     lib.arrow_amd_plugin_set_aggregate_direct_rows(1 << 22)
+    # the result may stay in HBM when the rows came from there (off by default: GroupByNode's result is host memory)
+    lib.arrow_amd_plugin_set_aggregate_device_output(1)
+    got_d = plan("table_source_rocm", td, agg).to_table(use_threads=False)
+    lib.arrow_amd_plugin_set_aggregate_device_output(0)
+    assert all(not b.is_cpu for c in got_d.columns for chunk in c.chunks for b in chunk.buffers() if b is not None), "result buffers should be kROCM"
+    got = host_table(got_d).sort_by("k")
+    assert got.column("k").equals(want_groups.column("k")) and got.column("v_sum").equals(want_groups.column("v_sum"))
+    assert got.column("v_sum").null_count == want_groups.column("v_sum").null_count
     # a host table through the same source (whole-chunk host batches; the registered kernels take or decline them by size)
     got = plan("table_source_rocm", t, agg).to_table(use_threads=False).sort_by("k")
     assert got.column("k").equals(want_groups.column("k")) and got.column("v_sum").equals(want_groups.column("v_sum"))
