@@ -93,6 +93,7 @@ namespace {
 #include "plugin/acero_node.inc"
 #include "plugin/acero_node_general.inc"
 #include "plugin/sharded.inc"
+#include "plugin/sharded_sort.inc"
 #include "plugin/order_by_node.inc"
 #include "plugin/acero_source.inc"
 #include "plugin/parquet.inc"
@@ -382,6 +383,30 @@ int arrow_amd_sharded_group_by_sum(void* comm, struct ArrowDeviceArray* keys, st
   return 0;
 }
 // The caching device allocator: bytes parked on free lists, allocations served from them / by hipMalloc.
+
+// This rank's slice of array_sort_indices over the row shards of all ranks (uint64 / int64 keys): out_indices = global
+// row numbers (uint64, device-resident), *out_start = where the slice begins in the global result; stage_ms (4 doubles or
+// NULL): histogram / partition / exchange / local sort.
+int arrow_amd_sharded_sort_indices(void* comm, struct ArrowDeviceArray* values, struct ArrowSchema* values_schema, int descending,
+                                   int nulls_first, int splitter_bits, struct ArrowDeviceArray* out_indices,
+                                   struct ArrowSchema* out_schema, int64_t* out_start, double* stage_ms) {
+  auto run = [&]() -> Status {
+    if (comm == nullptr || out_start == nullptr) return Status::Invalid("arrow_amd_sharded_sort_indices: no communicator / out_start");
+    ARROW_ASSIGN_OR_RAISE(auto v, arrow::ImportDeviceArray(values, values_schema));
+    if (stage_ms != nullptr) std::fill(stage_ms, stage_ms + 4, 0.0);
+    std::shared_ptr<ArrayData> idx;
+    ARROW_RETURN_NOT_OK(ShardedSortIndices(*static_cast<ShardedComm*>(comm), *v->data(), descending != 0, nulls_first != 0,
+                                           splitter_bits, &idx, out_start, stage_ms));
+    ARROW_RETURN_NOT_OK(arrow::ExportType(*idx->type, out_schema));
+    return arrow::ExportDeviceArray(*arrow::MakeArray(idx), nullptr, out_indices);
+  };
+  const Status st = run();
+  if (!st.ok()) {
+    t_error = st.ToString();
+    return -1;
+  }
+  return 0;
+}
 void arrow_amd_plugin_pool_stats(int64_t* cached_bytes, int64_t* hits, int64_t* misses) {
   DevicePool::Get().Stats(cached_bytes, hits, misses);
 }

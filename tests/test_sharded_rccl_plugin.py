@@ -1,4 +1,5 @@
-"""The plugin's sharded hash_sum group-by (arrow_amd/csrc/plugin/sharded.inc: RCCL called directly from C++, no torch).
+"""The plugin's sharded hash_sum group-by and sharded array_sort_indices (arrow_amd/csrc/plugin/sharded.inc,
+sharded_sort.inc: RCCL called directly from C++, no torch).
 
 CPU tier: world_size 2, one process per rank, the shim built against the emulated kernels and a file-based stand-in for
 the RCCL entry points it resolves with dlsym (tests/emu/fake_rccl) — the real counts all-gather, the real per-peer
@@ -81,9 +82,37 @@ WORKER = textwrap.dedent(r'''
             assert not gk.is_cpu and not gs.is_cpu
             assert sum(1 for x in stage_ms if x > 0) >= 4, list(stage_ms)
             results[(exchange, skip_nulls, min_count)] = (to_host(gk).to_pylist(), to_host(gs).to_pylist())
+    # ---- the sharded sort: this rank's slice of array_sort_indices of the concatenated shards
+    lib.arrow_amd_sharded_sort_indices.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]
+    m = N_ROWS // 2 + 555 * rank
+    sort_inputs = {
+        "u64_full": pa.array(rng.integers(0, 2**64, m, dtype=np.uint64), mask=rng.random(m) < 0.03),
+        "i64_window": pa.array(1_700_000_000_000_000 + rng.integers(-5000, 5000, m), mask=rng.random(m) < 0.03),   # shared top bits, many ties
+        "i64_no_nulls": pa.array(rng.integers(-2**62, 2**62, m)),
+        "u64_all_null": pa.array([None] * 9, pa.uint64()),
+    }
+    sorts = {}
+    for name, arr in sort_inputs.items():
+        for descending, nulls_first, bits in ((0, 0, 12), (1, 1, 5)):
+            dv = to_device(arr)
+            bufs = [ctypes.create_string_buffer(sz) for sz in (128, 72, 128, 72)]
+            dv._export_to_c_device(ctypes.addressof(bufs[0]), ctypes.addressof(bufs[1]))
+            start = ctypes.c_int64(-1)
+            stage_ms = (ctypes.c_double * 4)()
+            rc = lib.arrow_amd_sharded_sort_indices(comm, ctypes.addressof(bufs[0]), ctypes.addressof(bufs[1]), descending, nulls_first,
+                                                    bits, ctypes.addressof(bufs[2]), ctypes.addressof(bufs[3]), ctypes.byref(start),
+                                                    stage_ms)
+            assert rc == 0, lib.arrow_amd_plugin_last_error()
+            idx = pa.Array._import_from_c_device(ctypes.addressof(bufs[2]), ctypes.addressof(bufs[3]))
+            assert not idx.is_cpu and idx.type == pa.uint64()
+            assert all(x >= 0 for x in stage_ms), list(stage_ms)
+            sorts[(name, descending, nulls_first)] = (start.value, to_host(idx).to_pylist())
     lib.arrow_amd_sharded_comm_destroy(comm)
     with open(OUT + f".rank{rank}", "wb") as f:
-        pickle.dump(dict(keys=k.to_pylist(), values=v.to_pylist(), results=results), f)
+        pickle.dump(dict(keys=k.to_pylist(), values=v.to_pylist(), results=results,
+                         sort_inputs={name: (str(a.type), a.to_pylist()) for name, a in sort_inputs.items()}, sorts=sorts), f)
 ''')
 
 
@@ -129,6 +158,30 @@ def _check(ranks):
             assert all(len(r["results"][(exchange, skip_nulls, min_count)][0]) > 0 for r in ranks)
 
 
+def _check_sorts(ranks):
+    """Concatenating the ranks' slices in rank order must give pyarrow's own array_sort_indices of the concatenated shards
+    (stable: equal keys in global row order; nulls at the chosen end, in row order)."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+
+    for (name, descending, nulls_first) in ranks[0]["sorts"]:
+        typ = pa.uint64() if ranks[0]["sort_inputs"][name][0] == "uint64" else pa.int64()
+        whole = pa.array([x for r in ranks for x in r["sort_inputs"][name][1]], typ)
+        want = pc.array_sort_indices(whole, order="descending" if descending else "ascending",
+                                     null_placement="at_start" if nulls_first else "at_end").to_pylist()
+        got = [None] * len(whole)
+        at = 0
+        for r in ranks:
+            start, idx = r["sorts"][(name, descending, nulls_first)]
+            assert start == at, (name, "slices must tile the result in rank order", start, at)
+            got[start:start + len(idx)] = idx
+            at += len(idx)
+        assert at == len(whole) and got == want, (name, descending, nulls_first, at, len(whole))
+        if len(ranks) > 1 and name in ("u64_full", "i64_no_nulls"):
+            sizes = [len(r["sorts"][(name, descending, nulls_first)][1]) for r in ranks]
+            assert min(sizes) > len(whole) // (3 * len(ranks)), ("splitters should balance the ranks", sizes)
+
+
 @pytest.mark.emu
 def test_sharded_group_by_sum_cpp_world2_over_a_file_based_rccl_stand_in(tmp_path):
     pytest.importorskip("pyarrow")
@@ -139,6 +192,7 @@ def test_sharded_group_by_sum_cpp_world2_over_a_file_based_rccl_stand_in(tmp_pat
     subprocess.check_call(["gcc", "-O1", "-fPIC", "-shared", "-o", fake, os.path.join(ROOT, "tests", "emu", "fake_rccl", "fake_rccl.c")])
     ranks = _run_ranks(tmp_path, 2, dict(ARROW_AMD_PLUGIN_EMULATED="1", ARROW_AMD_RCCL_LIBRARY=fake), 6000, 300)
     _check(ranks)
+    _check_sorts(ranks)
 
 
 @pytest.mark.gpu
@@ -146,3 +200,4 @@ def test_sharded_group_by_sum_cpp_one_rank_over_the_real_rccl(tmp_path):
     pytest.importorskip("pyarrow")
     ranks = _run_ranks(tmp_path, 1, {}, 2_000_000, 70_000)
     _check(ranks)
+    _check_sorts(ranks)
