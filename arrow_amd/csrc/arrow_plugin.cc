@@ -96,6 +96,7 @@ namespace {
 #include "plugin/sharded_sort.inc"
 #include "plugin/order_by_node.inc"
 #include "plugin/acero_source.inc"
+#include "plugin/acero_coalesce.inc"
 #include "plugin/parquet.inc"
 #include "plugin/registration.inc"
 
@@ -569,6 +570,9 @@ void arrow_amd_plugin_set_aggregate_device_output(int on) { g_aggregate_device_o
 void arrow_amd_plugin_set_results_kernel_copy(int on) { g_results_kernel_copy.store(on != 0); }
 // result columns >= 1 MB into pooled page-locked host buffers (default on)
 void arrow_amd_plugin_set_pinned_results(int on) { g_pinned_results.store(on != 0); }
+// coalesce_rocm: rows gathered into one batch (at least); morsels it has joined so far
+void arrow_amd_plugin_set_coalesce_rows(int64_t rows) { g_coalesce_rows.store(rows < 1 ? 1 : rows); }
+int64_t arrow_amd_plugin_coalesced_batches(void) { return g_coalesced_batches.load(); }
 // table_source_rocm: rows per batch when TableSourceNodeOptions::max_batch_size is the default
 void arrow_amd_plugin_set_table_source_rows(int64_t rows) { g_table_source_rows.store(rows < 1 ? 1 : rows); }
 // The same threshold for the element-wise kernels (greater, cast); default: never stage them.

@@ -775,6 +775,15 @@ def callfunction_leg(args, values, validity, mask, device):
             plan_f = acero.Declaration.from_sequence([acero.Declaration(source, acero.TableSourceNodeOptions(dtx))] + stages)
             timeit(f"acero {source} -> filter(x > 0.1) -> project(k, v + v) -> aggregate_rocm ({m} device rows)",
                    lambda: plan_f.to_table(use_threads=False), reps=3 if source == "table_source_rocm" else 1)
+            if source == "table_source":
+                # the stock source with coalesce_rocm behind it: its 32Ki-row batches are joined again (no copy: they
+                # are consecutive slices of the table's arrays) before the filter sees them
+                plan_c = acero.Declaration.from_sequence(
+                    [acero.Declaration(source, acero.TableSourceNodeOptions(dtx)),
+                     acero.Declaration("coalesce_rocm", acero.FilterNodeOptions(pc.scalar(True)))] + stages)
+                timeit(f"acero table_source -> coalesce_rocm -> filter(x > 0.1) -> project(k, v + v) -> aggregate_rocm ({m} device rows)",
+                       lambda: plan_c.to_table(use_threads=False), reps=3)
+                del plan_c
             if source == "table_source_rocm":
                 # the same plan with its result left in HBM (120 MB of keys and sums do not cross PCIe)
                 lib.arrow_amd_plugin_set_aggregate_device_output(1)

@@ -2116,6 +2116,27 @@ TABLE_SOURCE_SCRIPT = textwrap.dedent(r'''
     assert got.equals(want_rows)
     assert lib.arrow_amd_plugin_calls(b"array_filter", 1) - f0 > 2 * 3
     lib.arrow_amd_plugin_set_table_source_rows(1 << 27)
+    # ---- coalesce_rocm behind the STOCK source: its 32Ki-row batches are joined again before the filter sees them
+    # (consecutive slices of one device array: no copy); the rows, values and order of the reference plan
+    lib.arrow_amd_plugin_coalesced_batches.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_set_coalesce_rows.argtypes = [ctypes.c_int64]
+    any_options = acero.FilterNodeOptions(pc.scalar(True))      # (the node takes no options; pyarrow needs an object)
+    def coalesced(rows):
+        lib.arrow_amd_plugin_set_coalesce_rows(rows)
+        c0, f0 = lib.arrow_amd_plugin_coalesced_batches(), lib.arrow_amd_plugin_calls(b"array_filter", 1)
+        got = host_table(plan("table_source", td, [acero.Declaration("coalesce_rocm", any_options)] + filter_project()).to_table(use_threads=False))
+        return got, lib.arrow_amd_plugin_coalesced_batches() - c0, lib.arrow_amd_plugin_calls(b"array_filter", 1) - f0
+    stock_batches = -(-cut // 32768) + -(-(n - cut) // 32768)
+    got, joined, launches = coalesced(1 << 26)
+    assert got.equals(want_rows), "coalesce_rocm must not change rows, values or order"
+    assert joined == stock_batches and launches == 3, (joined, stock_batches, launches)     # one batch, one filter per column
+    got, joined, launches = coalesced(SC(500_000))
+    assert got.equals(want_rows) and 3 < launches <= 3 * stock_batches, (launches, stock_batches)    # several batches, fewer than the source's at full size
+    lib.arrow_amd_plugin_set_coalesce_rows(1 << 26)
+    # host batches pass through untouched (nothing is moved to the device behind the caller's back)
+    c0 = lib.arrow_amd_plugin_coalesced_batches()
+    got = plan("table_source", t, [acero.Declaration("coalesce_rocm", any_options)] + filter_project()).to_table(use_threads=False)
+    assert got.equals(want_rows) and lib.arrow_amd_plugin_coalesced_batches() == c0
     # ---- ... -> aggregate_rocm: large batches are consumed where they lie (no staging copy)
     lib.arrow_amd_plugin_set_aggregate_direct_rows(SC(100_000))
     agg = [acero.Declaration("filter", acero.FilterNodeOptions(pred)),
