@@ -1273,6 +1273,7 @@ __global__ __launch_bounds__(1024) void gbp_rooms_scan_kernel(GbpArgs a) {
 // Cache policy of the wide form's one-pass streams (A/B by rebuilding: scripts/build_gb_variants.sh): bit 0 the scatter's
 // key / value loads, bit 1 the aggregate's record loads, bit 2 the scatter's record stores are non-temporal.
 constexpr int kGbNt = 0;
+constexpr int kGbAosWide = 1;       // the wide form's aggregate reads four records per thread with three 16-byte loads (0: one 12-byte load per record).  4e9 rows: 40.9 / 38.9 ms against 41.8 / 40.3 (two boxes' worth of interleaved runs, profiles/r03_x_*)
 constexpr int kGbPairAtomics = 0;   // the flat level's cursors: 1 = one 64-bit atomic per pair of bins, 0 = one per bin.  A/B at 4e9 rows: 41.2 / 45.2 ms paired, 40.4 / 40.4 single (profiles/r03_t_groupby_paired_cursor_atomics_ab.txt): the level is not bound by its atomics
 template <typename T>
 __device__ __forceinline__ T gb_load(const T* p, bool nt) {
@@ -1495,13 +1496,49 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
   // U rows in flight per thread: 4 x 12 B x 1024 threads = 48 KB per CU is about what 6 TB/s x 2 us of latency asks of
   // 256 CUs — the wide form keeps 8
   const int64_t span = hi - lo;
-  const int64_t nit = (span + THREADS - 1) / THREADS;
+  // AOS && kGbAosWide: a thread takes FOUR consecutive 12-byte records with three 16-byte loads (48 bytes; dword-aligned
+  // is all a global load needs) instead of twelve dword loads spread over four strided rows
+  constexpr bool WIDE = AOS && kGbAosWide != 0 && (U % 4 == 0);
+  const int64_t nit = WIDE ? ((span + 4 * THREADS - 1) / (4 * THREADS)) * 4 : (span + THREADS - 1) / THREADS;
   // software pipeline: the loads of batch i+1 are issued before batch i goes through the LDS
   // table, so the HBM latency overlaps the (serial, atomic) LDS work of the same wave
   int32_t kbuf[U], knext[U];
   unsigned long long vbuf[U], vnext[U];
   bool okbuf[U], oknext[U];
   auto load_batch = [&](int64_t it0, int32_t* kb, unsigned long long* vb, bool* ob) {
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int g = 0; g < U / 4; ++g) {
+        const int64_t r0 = lo + ((it0 / 4 + g) * THREADS + tid) * 4;
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const GbpRec*>(a.recs) + (r0 < hi ? r0 : hi - 1));
+        uint32_t d[12];
+        if (r0 + 4 <= hi) {
+          typedef arx_u32x4 __attribute__((aligned(4))) RecQuad;   // (a record starts at any multiple of 12 bytes)
+          const RecQuad* q = reinterpret_cast<const RecQuad*>(rp);
+          const arx_u32x4 q0 = q[0], q1 = q[1], q2 = q[2];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            d[e] = q0[e];
+            d[4 + e] = q1[e];
+            d[8 + e] = q2[e];
+          }
+        } else {   // the partition's last few records: one by one, clamped
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int64_t rc = r0 + j < hi ? r0 + j : hi - 1;
+            const uint32_t* p1 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const GbpRec*>(a.recs) + rc);
+            d[3 * j] = p1[0]; d[3 * j + 1] = p1[1]; d[3 * j + 2] = p1[2];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ob[g * 4 + j] = r0 + j < hi;
+          kb[g * 4 + j] = static_cast<int32_t>(d[3 * j]);
+          vb[g * 4 + j] = (static_cast<unsigned long long>(d[3 * j + 2]) << 32) | d[3 * j + 1];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t rr = lo + (it0 + u) * THREADS + tid;
@@ -1629,7 +1666,7 @@ static Knob<int> g_gbp_room_min_mean{1 << 14};   // rooms only for partitions of
 static Knob<int> g_gbp_wide_rooms{1};      // the wide form without its histogram pass: fixed rooms per partition (A/B knob groupby_wide_rooms)
 static Knob<int> g_gbp_wide{1};            // the wide one-level form where the group estimate allows it (A/B knob groupby_wide)
 static Knob<int> g_gbp_wide_agg_chunk{1 << 21};   // rows per aggregate work unit of the wide form (A/B knob groupby_wide_agg_chunk_rows)
-static Knob<int64_t> g_gbp_probe_rows{int64_t(1) << 26};   // rows of the probe slice that measures the group count (A/B knob groupby_probe_rows)
+static Knob<int64_t> g_gbp_probe_rows{int64_t(1) << 25};   // rows of the probe slice that measures the group count (A/B knob groupby_probe_rows).  2^25: every group count the wide plan takes (<= 12.6M) still repeats most of its keys inside the probe; 0.5 ms less than 2^26 at 4e9 rows, 2^24 no better (profiles/r03_x_*)
 static Knob<int> g_gbp_l1_global{1};       // level 1 with global cursors (one tile per workgroup; +3 % at 4e9 rows) instead of chunked exact offsets
 
 static int gbp_bits_for(int64_t capacity) {

@@ -1045,7 +1045,7 @@ def test_groupby_probe_slice_selects_the_plan(emu_ctx, distinct):
         P.check_groupby_sum(emu_ctx, k, v, capacity=1 << 21, batches=2, use_pyarrow=False)   # second consume: table not empty
     finally:
         lib.arx_set_option(b"groupby_partition_min_rows", 1 << 17)
-        lib.arx_set_option(b"groupby_probe_rows", 1 << 26)
+        lib.arx_set_option(b"groupby_probe_rows", 1 << 25)
         lib.arx_set_option(b"groupby_wide_max_bits", 11)
     probe, wide, two = (lib.arx_get_counter(c) - b for c, b in zip(names, before))
     assert probe == 3, "one probe slice per consume call"
