@@ -2133,6 +2133,25 @@ TABLE_SOURCE_SCRIPT = textwrap.dedent(r'''
     got, joined, launches = coalesced(SC(500_000))
     assert got.equals(want_rows) and 3 < launches <= 3 * stock_batches, (launches, stock_batches)    # several batches, fewer than the source's at full size
     lib.arrow_amd_plugin_set_coalesce_rows(1 << 26)
+    # behind a FILTER the batches are separate buffers: the copying path of the concatenation — fixed-width values with
+    # nulls, bit-packed booleans, utf8 offsets rebased and bytes appended
+    m = SC(400_000)
+    t2 = pa.table({"x": pa.array(rng.random(m)),
+                   "i": pa.array(rng.integers(-2**62, 2**62, m), mask=rng.random(m) < 0.1),
+                   "b": pa.array(rng.random(m) < 0.5, mask=rng.random(m) < 0.2),
+                   "s": pa.array(["k%d" % (i % 1013) if i % 5 else None for i in range(m)])})
+    want2 = t2.filter(pc.greater(t2.column("x"), 0.5))
+    td2 = pa.Table.from_batches([pa.RecordBatch.from_arrays([to_device(t2.column(j).chunk(0)) for j in range(t2.num_columns)], names=t2.schema.names)])
+    lib.arrow_amd_plugin_set_coalesce_rows(1 << 26)
+    c0 = lib.arrow_amd_plugin_coalesced_batches()
+    got2 = plan("table_source", td2, [acero.Declaration("filter", acero.FilterNodeOptions(pc.field("x") > 0.5)),
+                                      acero.Declaration("coalesce_rocm", any_options)]).to_table(use_threads=False)
+    nb2 = -(-m // 32768)
+    assert got2.num_rows == want2.num_rows and all(c.num_chunks == 1 for c in got2.columns), "one batch out"
+    assert lib.arrow_amd_plugin_coalesced_batches() - c0 == (nb2 if nb2 > 1 else 0)      # (a single batch is handed on as it came)
+    got2 = host_table(got2)
+    for name in t2.schema.names:
+        assert got2.column(name).combine_chunks().equals(want2.column(name).combine_chunks()), name
     # host batches pass through untouched (nothing is moved to the device behind the caller's back)
     c0 = lib.arrow_amd_plugin_coalesced_batches()
     got = plan("table_source", t, [acero.Declaration("coalesce_rocm", any_options)] + filter_project()).to_table(use_threads=False)
