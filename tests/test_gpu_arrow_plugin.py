@@ -2253,6 +2253,29 @@ REE_FILTER_SCRIPT = textwrap.dedent(r'''
         assert got.type == want.type and len(got) == len(want), (got.type, len(got), len(want))
         assert got.equals(want), (str(v.type), str(ree.type), mode, v.offset)
     assert lib.arrow_amd_plugin_calls(b"array_filter", 1) - g0 == len(cases), "the REE filters did not run on the device"
+    # the reference's own filter vectors (vector_selection_test.cc:319-336), which its harness also runs with the filter
+    # run-end encoded (:88,134,310): here on device arrays, EMIT_NULL and DROP (= the emitted nulls removed)
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))
+    lib.arrow_amd_plugin_set_min_rows.argtypes = [ctypes.c_int64]
+    lib.arrow_amd_plugin_set_min_rows(0)
+    ran = 0
+    for case in gold["filter_emit_null"] + [dict(gold["filter_sliced_mask"], sliced=True)]:
+        vals = pa.array(case["values"], pa.int32())
+        if case.get("sliced"):
+            mask = pa.array(case["mask_full"], pa.bool_()).slice(case["mask_offset"], case["mask_length"])
+        else:
+            mask = pa.array(case["mask"], pa.bool_())
+        if len(vals) == 0:
+            continue
+        for end_type in ("int16", "int32", "int64"):
+            ree = pc.run_end_encode(mask, run_end_type=end_type)
+            got = to_host(pc.call_function("array_filter", [to_device(vals), to_device(ree)],
+                                           pc.FilterOptions(null_selection_behavior="emit_null")))
+            assert got.to_pylist() == case["want"], (case["cite"], end_type, got.to_pylist())
+            ran += 1
+    assert ran >= 30, ran
+    lib.arrow_amd_plugin_set_min_rows(1 << 16)
     # host arrays with an REE filter keep the reference kernel (same exec serves both layouts)
     v, ree, mode, want = cases[0]
     assert pc.filter(v, ree, null_selection_behavior=mode).equals(want)
