@@ -162,6 +162,7 @@ SIGNATURES = {
     "arx_bitmap_popcount": (_int, [_p, _i64, _i64, _p, _sz, C.POINTER(_i64), _p]),
     "arx_bytes_to_bitmap": (_int, [_p, _i64, _p, _p, _p]),
     "arx_groupby_key_range_i32": (_int, [_span, _p, _p]),
+    "arx_hash_bool_finalize": (_int, [_p, _p, _p, _i64, _int, _int, C.c_uint32, _p, _p, _p, _p]),
     "arx_sort_indices_workspace_bytes": (_sz, [_i64]),
     "arx_sort_indices": (_int, [_span, _int, _int, _int, _p, _sz, _p, _p]),
     "arx_sort_indices_64": (_int, [_span, _int, _int, _int, _p, _sz, _p, _p]),

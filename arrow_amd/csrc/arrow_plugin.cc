@@ -88,6 +88,7 @@ namespace {
 #include "plugin/cast.inc"
 #include "plugin/hash_aggregate.inc"
 #include "plugin/hash_aggregate_more.inc"
+#include "plugin/hash_aggregate_bool.inc"
 #include "plugin/vector_hash.inc"
 #include "plugin/scalar_aggregate.inc"
 #include "plugin/acero_node.inc"

@@ -2001,6 +2001,48 @@ int set_groupby_option(const char* name, int64_t value) {
   return 0;
 }
 
+// hash_any / hash_all Finalize (GroupedBooleanAggregator::Finalize, kernels/hash_aggregate.cc:1321-1350) from three dense
+// counts per group — valid rows, null rows, valid rows whose value is true: a wave packs 64 groups per ballot.
+//   value    any: a true was seen          all: no false was seen
+//   valid    counts >= min_count, and (unless skip_nulls) no null seen OR the value is already decided by what was seen
+//            (any: a true; all: a false) — AdjustForMinCount's BitmapOr / BitmapOrNot (:1376-1398)
+__global__ __launch_bounds__(256) void hash_bool_finalize_kernel(const long long* __restrict__ n_valid,
+                                                                const long long* __restrict__ n_null,
+                                                                const long long* __restrict__ n_true, int64_t g, int is_all,
+                                                                int skip_nulls, uint32_t min_count,
+                                                                uint64_t* __restrict__ out_values,
+                                                                uint64_t* __restrict__ out_validity,
+                                                                unsigned long long* __restrict__ valid_count) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwords = (g + 63) / 64;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * 256) >> 6;
+  unsigned long long mine = 0;
+  for (int64_t w = wave; w < nwords; w += nwaves) {
+    const int64_t i = w * 64 + lane;
+    bool value = false, valid = false;
+    if (i < g) {
+      const long long nv = n_valid[i], nn = n_null[i], nt = n_true[i];
+      value = is_all ? (nt == nv) : (nt > 0);
+      valid = nv >= static_cast<long long>(min_count);
+      if (!skip_nulls) valid = valid && (nn == 0 || (is_all ? !value : value));
+    }
+    const uint64_t vw = __ballot(value), ow = __ballot(valid);
+    if (lane == 0) {
+      out_values[w] = vw;
+      out_validity[w] = ow;
+      mine += static_cast<unsigned long long>(__popcll(ow));
+    }
+  }
+  __shared__ unsigned long long part[4];
+  if (lane == 0) part[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (valid_count != nullptr && threadIdx.x == 0) {
+    const unsigned long long total = part[0] + part[1] + part[2] + part[3];
+    if (total != 0) atomicAdd(valid_count, total);
+  }
+}
+
 // Smallest and largest int32 key of a column (slots of null keys included: they only widen the range).  A caller
 // that must size a table for "as many groups as rows" gets a much tighter bound from max - min + 1 when the keys are
 // ids or codes — the usual case for an int32 key column.
@@ -2203,6 +2245,28 @@ int arx_groupby_sum_i64_merge(void* state, int64_t capacity, const int32_t* keys
   hipLaunchKernelGGL(groupby_merge_kernel, dim3(gb_grid(num_groups)), dim3(kBlock), 0,
                      as_stream(stream), v, keys, key_is_valid, sums, counts, no_nulls, num_groups);
   ARX_CHECK_LAUNCH("groupby_merge_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_bool_finalize(const int64_t* n_valid, const int64_t* n_null, const int64_t* n_true, int64_t num_groups, int is_all,
+                           int skip_nulls, uint32_t min_count, void* out_values, void* out_validity, int64_t* valid_count,
+                           void* stream) {
+  if (num_groups < 0) {
+    set_error("bad arguments to arx_hash_bool_finalize");
+    return ARX_INVALID;
+  }
+  if (num_groups == 0) return ARX_OK;
+  if (n_valid == nullptr || n_null == nullptr || n_true == nullptr || out_values == nullptr || out_validity == nullptr) {
+    set_error("NULL buffer passed to arx_hash_bool_finalize");
+    return ARX_INVALID;
+  }
+  const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(num_groups, 256), 1024));
+  hipLaunchKernelGGL(hash_bool_finalize_kernel, dim3(grid), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const long long*>(n_valid), reinterpret_cast<const long long*>(n_null),
+                     reinterpret_cast<const long long*>(n_true), num_groups, is_all, skip_nulls, min_count,
+                     static_cast<uint64_t*>(out_values), static_cast<uint64_t*>(out_validity),
+                     reinterpret_cast<unsigned long long*>(valid_count));
+  ARX_CHECK_LAUNCH("hash_bool_finalize_kernel");
   return ARX_OK;
 }
 

@@ -720,6 +720,18 @@ int arx_hash_count_consume(const void* values_validity, int64_t values_offset, i
 int arx_hash_count_merge(int64_t* counts, const int64_t* other_counts, const uint32_t* group_id_mapping,
                          int64_t other_num_groups, void* stream);
 
+/* hash_any / hash_all(boolean, uint32 group id) — GroupedBooleanAggregator<GroupedAnyImpl / GroupedAllImpl>
+ * (compute/kernels/hash_aggregate.cc:1232-1398).  The state is three dense count arrays kept with arx_hash_count_consume /
+ * _merge: n_valid (the boolean column's validity, ARX_COUNT_ONLY_VALID), n_null (ONLY_NULL) and n_true (ONLY_VALID over
+ * the bitmap validity AND value, arx_bitmap_and) — counts[g] of the reference is n_valid, no_nulls[g] is n_null == 0,
+ * reduced[g] is n_true > 0 (any) or n_true == n_valid (all).  This call is Finalize (:1321-1350): out_values /
+ * out_validity = LSB-first bitmaps of num_groups bits (whole 64-bit words written); valid iff n_valid >= min_count and —
+ * unless skip_nulls — no null was seen or the value is already decided by what was seen (AdjustForMinCount, :1376-1398);
+ * *valid_count (device, may be NULL) is incremented by the number of valid groups.  Asynchronous. */
+int arx_hash_bool_finalize(const int64_t* n_valid, const int64_t* n_null, const int64_t* n_true, int64_t num_groups, int is_all,
+                           int skip_nulls, uint32_t min_count, void* out_values, void* out_validity, int64_t* valid_count,
+                           void* stream);
+
 /* ---------------------------------------------------------------------------
  * Grouper: key rows of one or several fixed-width columns -> dense group ids.
  * arrow::compute::Grouper (cpp/src/arrow/compute/row/grouper.h:104-137): Consume :121, Lookup :126, GetUniques :134,

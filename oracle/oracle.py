@@ -817,6 +817,63 @@ class HashCountState:
         np.add.at(self.counts, np.asarray(mapping, dtype=np.int64), other.counts)
 
 
+class HashBoolState:
+    """GroupedBooleanAggregator<GroupedAnyImpl / GroupedAllImpl> with dense group ids (kernels/hash_aggregate.cc:1232-1398),
+    restated as the reference keeps it: reduced (starts at NullValue: False for any, True for all), no_nulls, counts;
+    Consume :1250-1296, Merge :1298-1319, Finalize :1321-1350 with AdjustForMinCount :1376-1398.  Plain numpy."""
+
+    def __init__(self, is_all: bool, skip_nulls: bool = True, min_count: int = 1):
+        self.is_all, self.skip_nulls, self.min_count = bool(is_all), bool(skip_nulls), int(min_count)
+        self.reduced = np.zeros(0, bool)
+        self.no_nulls = np.zeros(0, bool)
+        self.counts = np.zeros(0, np.int64)
+
+    @property
+    def num_groups(self):
+        return len(self.counts)
+
+    def resize(self, n):
+        add = n - self.num_groups
+        self.reduced = np.concatenate([self.reduced, np.full(add, self.is_all)])
+        self.no_nulls = np.concatenate([self.no_nulls, np.ones(add, bool)])
+        self.counts = np.concatenate([self.counts, np.zeros(add, np.int64)])
+
+    def _update(self, gids, values):
+        if self.is_all:
+            self.reduced[gids[~values]] = False       # UpdateGroupWith: a false clears the group
+        else:
+            self.reduced[gids[values]] = True         # a true sets it
+
+    def consume(self, values, val_valid, val_off, group_ids, scalar=None):
+        """values: bool per row (ignored where the row is null); val_valid / val_off: validity bitmap as elsewhere;
+        scalar = (is_valid, value) for a broadcast scalar."""
+        gids = np.asarray(group_ids, dtype=np.int64)
+        n = len(gids)
+        if scalar is not None:
+            ok = np.full(n, bool(scalar[0]))
+            vals = np.full(n, bool(scalar[1]))
+        else:
+            ok = _valid_rows(val_valid, val_off, n)
+            vals = np.asarray(values, bool)
+        np.add.at(self.counts, gids[ok], 1)
+        self._update(gids[ok], vals[ok])
+        self.no_nulls[gids[~ok]] = False
+
+    def merge(self, other: "HashBoolState", mapping):
+        m = np.asarray(mapping, dtype=np.int64)
+        np.add.at(self.counts, m, other.counts)
+        self._update(m, other.reduced)
+        np.logical_and.at(self.no_nulls, m, other.no_nulls)
+
+    def finalize(self):
+        """(values, valid) per group."""
+        valid = self.counts >= self.min_count
+        if not self.skip_nulls:
+            decided = ~self.reduced if self.is_all else self.reduced      # BitmapOrNot / BitmapOr with `seen`
+            valid = valid & (self.no_nulls | decided)
+        return self.reduced.copy(), valid
+
+
 def delta_binary_packed_encode(values, block_size: int = 128, miniblocks: int = 4) -> bytes:
     """A writer of DELTA_BINARY_PACKED (Encodings.md "Delta encoding"; DeltaBitPackEncoder, parquet/encoder.cc)
     for tests: any block size / miniblock count the format allows, int64 arithmetic modulo 2**64, trailing

@@ -1703,6 +1703,85 @@ def check_bytes_to_bitmap(amd, rng, scale=1):
             assert int(counter.item()) == 1000 + int(want_bits.sum()), (n, shift)
 
 
+def check_hash_any_all_kernels(amd, rng, n=6000, num_groups=41, null_p=0.2):
+    """hash_any / hash_all as the plugin runs them: three dense counts per group (valid rows, null rows, valid AND true
+    rows — hash_count kernels, the third over arx_bitmap_and of validity and values), merged through a group_id_mapping,
+    finalized by arx_hash_bool_finalize; against the oracle's restatement of GroupedBooleanAggregator and, end to end,
+    against pyarrow's own hash_any / hash_all on the same rows; skip_nulls on / off, min_count 1 / 3, offsets."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+    from oracle import oracle as O
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    for off, p_true in ((0, 0.97), (5, 0.03), (3, 0.5)):
+        vals = rng.random(n + off) < p_true
+        ok = rng.random(n + off) >= null_p
+        gids = rng.integers(0, num_groups, n).astype(np.uint32)
+        gids[gids == 7] = 8                                    # group 7 stays empty
+        ok[off:][gids == 3] = False                            # group 3 sees only nulls
+        bits = lambda b: np.packbits(np.concatenate([b, np.zeros((-len(b)) % 64, bool)]), bitorder="little")
+        d_vals, d_valid, d_gids = to_device(bits(vals), dev), to_device(bits(ok), dev), to_device(gids, dev)
+        halves = [(0, n // 3), (n // 3, n)]                    # two states, merged through a mapping
+        for skip_nulls, min_count in ((True, 1), (False, 1), (True, 3), (False, 3)):
+            for is_all in (False, True):
+                states, oracles = [], []
+                for lo, hi in halves:
+                    cnt = [torch.zeros(num_groups, dtype=torch.int64, device=dev) for _ in range(3)]
+                    m = hi - lo
+                    both = torch.zeros((m + 63) // 64 * 8 + 16, dtype=torch.uint8, device=dev)
+                    g_ptr = d_gids.data_ptr() + lo * 4
+                    _lib.check(lib.arx_hash_count_consume(d_valid.data_ptr(), off + lo, -1, 0, g_ptr, m, cnt[0].data_ptr(), st))
+                    _lib.check(lib.arx_hash_count_consume(d_valid.data_ptr(), off + lo, -1, 1, g_ptr, m, cnt[1].data_ptr(), st))
+                    _lib.check(lib.arx_bitmap_and(d_valid.data_ptr(), off + lo, d_vals.data_ptr(), off + lo, m, both.data_ptr(), st))
+                    _lib.check(lib.arx_hash_count_consume(both.data_ptr(), 0, -1, 0, g_ptr, m, cnt[2].data_ptr(), st))
+                    states.append(cnt)
+                    o = O.HashBoolState(is_all, skip_nulls, min_count)
+                    o.resize(num_groups)
+                    o.consume(vals[off + lo:off + hi], bits(ok), off + lo, gids[lo:hi])
+                    oracles.append(o)
+                mapping = rng.permutation(num_groups).astype(np.uint32)
+                d_map = to_device(mapping, dev)
+                for a, b in zip(states[0], states[1]):
+                    _lib.check(lib.arx_hash_count_merge(a.data_ptr(), b.data_ptr(), d_map.data_ptr(), num_groups, st))
+                oracles[0].merge(oracles[1], mapping)
+                words = (num_groups + 63) // 64
+                out_v = torch.full((words * 8 + 8,), 0xA5, dtype=torch.uint8, device=dev)
+                out_ok = torch.full((words * 8 + 8,), 0xA5, dtype=torch.uint8, device=dev)
+                counter = torch.full((1,), 100, dtype=torch.int64, device=dev)
+                nv, nn, nt = states[0]
+                _lib.check(lib.arx_hash_bool_finalize(nv.data_ptr(), nn.data_ptr(), nt.data_ptr(), num_groups, int(is_all),
+                                                      int(skip_nulls), min_count, out_v.data_ptr(), out_ok.data_ptr(),
+                                                      counter.data_ptr(), st))
+                got_v = np.unpackbits(out_v.cpu().numpy()[: words * 8], bitorder="little")[:num_groups].astype(bool)
+                got_ok = np.unpackbits(out_ok.cpu().numpy()[: words * 8], bitorder="little")[:num_groups].astype(bool)
+                want_v, want_ok = oracles[0].finalize()
+                tag = f"hash_{'all' if is_all else 'any'} skip_nulls={skip_nulls} min_count={min_count} off={off}"
+                assert_equal(got_ok, want_ok, tag + " validity")
+                assert_equal(got_v[want_ok], want_v[want_ok], tag + " values")
+                assert int(counter.item()) == 100 + int(want_ok.sum()), tag
+                assert (out_v.cpu().numpy()[words * 8:] == 0xA5).all() and (out_ok.cpu().numpy()[words * 8:] == 0xA5).all()
+        # end to end against pyarrow itself (one state over all rows: rows = state 1's mapping applied to nothing)
+        col = pa.array(vals[off:], mask=~ok[off:])
+        tab = pa.table({"g": pa.array(gids), "b": col})
+        for skip_nulls, min_count in ((True, 1), (False, 2)):
+            opts = pc.ScalarAggregateOptions(skip_nulls=skip_nulls, min_count=min_count)
+            ref = tab.group_by("g", use_threads=False).aggregate([("b", "any", opts), ("b", "all", opts)]).sort_by("g")
+            for is_all, name in ((False, "b_any"), (True, "b_all")):
+                o = O.HashBoolState(is_all, skip_nulls, min_count)
+                o.resize(num_groups)
+                o.consume(vals[off:], bits(ok), off, gids)
+                v_, ok_ = o.finalize()
+                seen = np.asarray(ref.column("g"))
+                want = ref.column(name).to_pylist()
+                got = [bool(v_[g]) if ok_[g] else None for g in seen]
+                assert got == want, (name, skip_nulls, min_count)
+
+
 def check_groupby_key_range(amd, rng, scale=1):
     """arx_groupby_key_range_i32: {min, max} of an int32 key column folded into the caller's pair (atomic min / max), at
     offsets, for empty, tiny and large columns and keys at both ends of the int32 range."""

@@ -961,6 +961,10 @@ def test_groupby_key_range(emu_ctx):
     P.check_groupby_key_range(emu_ctx, rng_for("key-range"))
 
 
+def test_hash_any_all_dense_kernels(emu_ctx):
+    P.check_hash_any_all_kernels(emu_ctx, rng_for("hash-bool"))
+
+
 def test_bitmap_copy_segments(emu_ctx):
     P.check_bitmap_copy_segments(emu_ctx, rng_for("bitseg"), 1)
 

@@ -110,13 +110,19 @@ HASH_KERNELS_SCRIPT = textwrap.dedent(r'''
     big = pa.array(rng.integers(-2**62, 2**62, n), mask=rng.random(n) < 0.15)        # partial sums beyond 2^53
     s = pa.array([("x%d" % (i % 97)) if i % 7 else None for i in range(n)])
     f = pa.array(rng.standard_normal(n), mask=rng.random(n) < 0.3)
-    t = pa.table({"k": k, "v": v, "big": big, "s": s, "f": f})
+    # booleans for hash_any / hash_all: mostly-true and mostly-false columns (so that both outcomes occur per group), 15 % nulls
+    bt = pa.array(rng.random(n) < 0.995, mask=rng.random(n) < 0.15)
+    bf = pa.array(rng.random(n) < 0.005, mask=rng.random(n) < 0.15)
+    t = pa.table({"k": k, "v": v, "big": big, "s": s, "f": f, "bt": bt, "bf": bf})
     tc = pa.concat_tables([t.slice(0, n // 3), t.slice(n // 3, n // 5), t.slice(n // 3 + n // 5)])   # several chunks
     strict = pc.ScalarAggregateOptions(skip_nulls=False, min_count=2)
     aggs = [("v", "min"), ("v", "max"), ("v", "mean"), ("big", "mean"), ("v", "count"),
             ("v", "count", pc.CountOptions(mode="only_null")), ("v", "count", pc.CountOptions(mode="all")),
             ("s", "count"), ("f", "count", pc.CountOptions(mode="only_null")),
-            ("v", "min", strict), ("v", "max", strict), ("v", "mean", strict), ("v", "sum")]
+            ("v", "min", strict), ("v", "max", strict), ("v", "mean", strict), ("v", "sum"),
+            ("bt", "any"), ("bt", "all"), ("bf", "any"), ("bf", "all"),
+            ("bt", "any", strict), ("bt", "all", strict), ("bf", "any", strict), ("bf", "all", strict),
+            ("bf", "all", pc.ScalarAggregateOptions(skip_nulls=True, min_count=1600))]
     def run(tab, threads):
         return tab.group_by("k", use_threads=threads).aggregate(aggs).sort_by("k")
     # ---- the reference kernels first: registering the plugin re-routes these very calls

@@ -1332,5 +1332,9 @@ def test_groupby_key_range(gpu_ctx):
     P.check_groupby_key_range(gpu_ctx, rng_for("key-range"), scale=50)
 
 
+def test_hash_any_all_dense_kernels(gpu_ctx):
+    P.check_hash_any_all_kernels(gpu_ctx, rng_for("hash-bool"), n=600_000, num_groups=5000)
+
+
 def test_bitmap_copy_segments(gpu_ctx):
     P.check_bitmap_copy_segments(gpu_ctx, rng_for("bitseg"), 20)
