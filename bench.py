@@ -746,6 +746,18 @@ def callfunction_leg(args, values, validity, mask, device):
     timeit("pc.filter(device int64, device mask 10%)", lambda: pc.filter(dv, dm))
     idx = pc.filter(to_device(pa.array(np.arange(n, dtype=np.uint32))), dm)
     timeit("pc.take(device int64, device uint32 indices)", lambda: pc.take(dv, idx, boundscheck=False))
+    # the whole headline step through Arrow's own API, nothing of the Python mirror in it: filter, the mask's row numbers
+    # (indices_nonzero: what GetTakeIndices is to the reference's Take), take by them
+    def step():
+        out = pc.filter(dv, dm)
+        rows = pc.indices_nonzero(dm)
+        return out, pc.take(dv, rows, boundscheck=False)
+    try:
+        timeit("Filter+Take step through CallFunction: pc.filter + pc.indices_nonzero + pc.take (device arrays)", step)
+        res["Filter+Take step through CallFunction: pc.filter + pc.indices_nonzero + pc.take (device arrays)"]["mrows_per_s"] = round(
+            n / res["Filter+Take step through CallFunction: pc.filter + pc.indices_nonzero + pc.take (device arrays)"]["ms_min"] / 1e3, 1)
+    except Exception as e:
+        res["Filter+Take step through CallFunction"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     res["gpu_kernel_calls"] = {f.decode(): int(lib.arrow_amd_plugin_calls(f, 1) - g0[f]) for f in g0}
     del dv, dm, idx, hv, hm
     # group-by through Acero: table_source -> aggregate_rocm (the fused device operator) on device-resident columns
