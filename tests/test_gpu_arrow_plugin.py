@@ -113,7 +113,14 @@ HASH_KERNELS_SCRIPT = textwrap.dedent(r'''
     # booleans for hash_any / hash_all: mostly-true and mostly-false columns (so that both outcomes occur per group), 15 % nulls
     bt = pa.array(rng.random(n) < 0.995, mask=rng.random(n) < 0.15)
     bf = pa.array(rng.random(n) < 0.005, mask=rng.random(n) < 0.15)
-    t = pa.table({"k": k, "v": v, "big": big, "s": s, "f": f, "bt": bt, "bf": bf})
+    # hash_sum over every integer width: narrow values are widened on the device, unsigned sums come back as uint64
+    # (full-range uint64 / int64 sums wrap modulo 2^64 exactly as the reference's do)
+    ints = {"i8": pa.array(rng.integers(-128, 128, n).astype(np.int8), mask=rng.random(n) < 0.1),
+            "u16": pa.array(rng.integers(0, 2**16, n).astype(np.uint16)),
+            "i32": pa.array(rng.integers(-2**31, 2**31, n).astype(np.int32), mask=rng.random(n) < 0.1),
+            "u32": pa.array(rng.integers(0, 2**32, n).astype(np.uint32), mask=rng.random(n) < 0.5),
+            "u64": pa.array(rng.integers(0, 2**64, n, dtype=np.uint64), mask=rng.random(n) < 0.1)}
+    t = pa.table({"k": k, "v": v, "big": big, "s": s, "f": f, "bt": bt, "bf": bf, **ints})
     tc = pa.concat_tables([t.slice(0, n // 3), t.slice(n // 3, n // 5), t.slice(n // 3 + n // 5)])   # several chunks
     strict = pc.ScalarAggregateOptions(skip_nulls=False, min_count=2)
     aggs = [("v", "min"), ("v", "max"), ("v", "mean"), ("big", "mean"), ("v", "count"),
@@ -122,7 +129,10 @@ HASH_KERNELS_SCRIPT = textwrap.dedent(r'''
             ("v", "min", strict), ("v", "max", strict), ("v", "mean", strict), ("v", "sum"),
             ("bt", "any"), ("bt", "all"), ("bf", "any"), ("bf", "all"),
             ("bt", "any", strict), ("bt", "all", strict), ("bf", "any", strict), ("bf", "all", strict),
-            ("bf", "all", pc.ScalarAggregateOptions(skip_nulls=True, min_count=1600))]
+            ("bf", "all", pc.ScalarAggregateOptions(skip_nulls=True, min_count=1600)),
+            ("i8", "sum"), ("u16", "sum"), ("i32", "sum"), ("u32", "sum"), ("u64", "sum"), ("i32", "sum", strict), ("u32", "sum", strict),
+            ("i8", "min"), ("i8", "max"), ("u16", "min"), ("u16", "max"), ("i32", "min"), ("i32", "max", strict), ("u32", "min", strict), ("u32", "max"),
+            ("i8", "mean"), ("u16", "mean"), ("i32", "mean"), ("u32", "mean", strict)]
     def run(tab, threads):
         return tab.group_by("k", use_threads=threads).aggregate(aggs).sort_by("k")
     # ---- the reference kernels first: registering the plugin re-routes these very calls
@@ -156,16 +166,21 @@ HASH_KERNELS_SCRIPT = textwrap.dedent(r'''
         return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
     m = SC(400_000)
     th = t.slice(0, m).combine_chunks()
-    td = pa.table({"k": th.column("k").chunk(0), "v": to_device(th.column("v").chunk(0))})
+    td = pa.table({"k": th.column("k").chunk(0), "v": to_device(th.column("v").chunk(0)),
+                   "i32": to_device(th.column("i32").chunk(0)), "u64": to_device(th.column("u64").chunk(0)),
+                   "bt": to_device(th.column("bt").chunk(0))})
     daggs = [("v", "hash_min", None, "mn"), ("v", "hash_max", None, "mx"), ("v", "hash_mean", None, "me"),
              ("v", "hash_count", None, "c"), ("v", "hash_count", pc.CountOptions(mode="only_null"), "cn"),
-             ("v", "hash_sum", None, "sm")]
+             ("v", "hash_sum", None, "sm"), ("i32", "hash_sum", None, "s32"), ("u64", "hash_sum", None, "s64"),
+             ("i32", "hash_min", None, "mn32"), ("i32", "hash_max", None, "mx32"), ("i32", "hash_mean", None, "me32"),
+             ("bt", "hash_any", None, "any"), ("bt", "hash_all", strict, "all")]
     def plan(tab):
         return acero.Declaration.from_sequence([
             acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
             acero.Declaration("aggregate", acero.AggregateNodeOptions(daggs, keys=["k"]))]).to_table(use_threads=False).sort_by("k")
     wd = want[("t", False)]     # not the same rows: recompute the expectation on the slice with the (now plugged) host route,
-    wh = plan(pa.table({"k": th.column("k"), "v": th.column("v")}))   # which was just shown equal to the reference
+    wh = plan(pa.table({"k": th.column("k"), "v": th.column("v"), "i32": th.column("i32"), "u64": th.column("u64"),
+                        "bt": th.column("bt")}))   # which was just shown equal to the reference
     stock2 = lib.arrow_amd_plugin_calls(b"hash_sum", 0)
     gd = plan(td)
     assert lib.arrow_amd_plugin_calls(b"hash_sum", 0) == stock2, "device-resident values must not reach a reference kernel"
