@@ -367,6 +367,10 @@ GENERAL_GROUP_BY_SCRIPT = textwrap.dedent(r'''
         "v": pa.array(rng.integers(-2**36, 2**36, n), mask=rng.random(n) < 0.15),
         "w": pa.array(rng.integers(-2**63, 2**63 - 1, n), mask=rng.random(n) < 0.05),
         "flag": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.2),
+        # narrower integer VALUE columns (widened on the device; unsigned sums are uint64, extrema keep the column's type)
+        "i16": pa.array(rng.integers(-2**15, 2**15, n).astype(np.int16), mask=rng.random(n) < 0.1),
+        "u32": pa.array(rng.integers(0, 2**32, n).astype(np.uint32), mask=rng.random(n) < 0.3),
+        "u64": pa.array(rng.integers(0, 2**64, n, dtype=np.uint64), mask=rng.random(n) < 0.1),
     })
     strict = pc.ScalarAggregateOptions(skip_nulls=False, min_count=2)
     plans = [
@@ -376,6 +380,9 @@ GENERAL_GROUP_BY_SCRIPT = textwrap.dedent(r'''
         (["a", "b"], [("v", "hash_sum", strict, "s"), ("v", "hash_mean", strict, "me"), ("w", "hash_max", strict, "mx"), ("d", "hash_count", pc.CountOptions(mode="all"), "c")]),
         (["d", "b", "c"], [("w", "hash_sum", None, "s"), ("v", "hash_min", None, "mn")]),
         (["a"], [("v", "hash_sum", None, "s"), ("w", "hash_sum", None, "sw")]),      # int32 key but two value columns: not the fused operator's case
+        (["a", "c"], [("i16", "hash_sum", None, "s16"), ("i16", "hash_min", None, "mn16"), ("i16", "hash_max", strict, "mx16"), ("i16", "hash_mean", None, "me16"),
+                      ("u32", "hash_sum", strict, "s32"), ("u32", "hash_min", None, "mn32"), ("u32", "hash_max", None, "mx32"), ("u32", "hash_mean", strict, "me32"),
+                      ("u64", "hash_sum", None, "s64")]),
     ]
     def run(tab, node, keys, aggs):
         return acero.Declaration.from_sequence([
@@ -416,7 +423,8 @@ GENERAL_GROUP_BY_SCRIPT = textwrap.dedent(r'''
     assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - g0 >= 3 * len(plans), "aggregate_rocm did not run the device Grouper"
     # keys wider than the device Grouper's 16-byte rows, and value types it does not take: refused by name
     for keys, aggs, needle in ((["k64", "a", "d", "b"], [("v", "hash_sum", None, "s")], "16 bytes"),
-                               (["a", "b"], [("flag", "hash_sum", None, "s")], "int64 values")):
+                               (["a", "b"], [("flag", "hash_sum", None, "s")], "integer values"),
+                               (["a", "b"], [("u64", "hash_max", None, "s")], "uint64 only for hash_sum")):
         try:
             run(t, "aggregate_rocm", keys, aggs)
             raise SystemExit("aggregate_rocm accepted " + str(keys))
