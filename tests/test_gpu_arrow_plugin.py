@@ -1635,6 +1635,21 @@ AGGREGATE_SCRIPT = textwrap.dedent(r'''
                 assert pc.call_function(fn, [d_arr.slice(13, len(h_arr) - 100)]).equals(pc.call_function(fn, [h_arr.slice(13, len(h_arr) - 100)])), fn
         for mode in ("only_valid", "only_null", "all"):
             assert pc.count(d_arr, mode=mode).equals(pc.count(h_arr, mode=mode)), mode
+    # every integer width: narrow columns are widened on the device; sums are int64 / uint64, extrema keep the column's type
+    for np_t, lo, hi in ((np.int8, -128, 128), (np.uint8, 0, 256), (np.int16, -2**15, 2**15), (np.uint16, 0, 2**16),
+                         (np.int32, -2**31, 2**31), (np.uint32, 0, 2**32)):
+        h_arr = pa.array(rng.integers(lo, hi, n // 3).astype(np_t), mask=rng.random(n // 3) < 0.1)
+        d_arr = to_device(h_arr)
+        for opts in (None, pc.ScalarAggregateOptions(skip_nulls=False), pc.ScalarAggregateOptions(min_count=len(h_arr))):
+            for fn in ("sum", "min_max", "min", "max"):
+                g, w = pc.call_function(fn, [d_arr], opts), pc.call_function(fn, [h_arr], opts)
+                assert g.equals(w) and g.type == w.type, (str(h_arr.type), fn, opts, g, w)
+        assert pc.min_max(d_arr.slice(7, 1000)).equals(pc.min_max(h_arr.slice(7, 1000)))
+        for mode in ("only_valid", "only_null", "all"):
+            assert pc.count(d_arr, mode=mode).equals(pc.count(h_arr, mode=mode)), (str(h_arr.type), mode)
+    u64 = pa.array(rng.integers(0, 2**64, n // 3, dtype=np.uint64), mask=rng.random(n // 3) < 0.1)
+    d_u64 = to_device(u64)
+    assert pc.sum(d_u64).equals(pc.sum(u64)) and pc.count(d_u64).equals(pc.count(u64))      # (wraps modulo 2^64 like the reference)
     chunks = pa.chunked_array([to_device(vals.slice(0, 1000)), to_device(vals.slice(1000))])       # merge of per-batch states
     assert pc.sum(chunks).equals(pc.sum(vals)) and pc.min_max(chunks).equals(pc.min_max(vals))
     assert lib.arrow_amd_plugin_calls(b"reduce", 1) > red0 + 80
