@@ -901,7 +901,7 @@ def hash_sum_leg(args, rank, world, device, rows_total, steps, warmup):
            "exchange": "local aggregate -> 1 count exchange + ONE all-to-all(v) of 24-byte partials -> merge" if world > 1 else "none (one rank)",
            "checksum_matches_sum_of_values": ok,
            "stage_ms_max_over_ranks_untimed_run": _LAST_STAGES.get("hash_sum"),
-           "roofline": {"bound": "hbm", "kernel": "arx_groupby_sum_i64_consume (gbp_hist + ONE flat 2048-bin scatter + 8192-slot LDS aggregate; probe slice on the two-level plan)",
+           "roofline": {"bound": "hbm", "kernel": "arx_groupby_sum_i64_consume (ONE flat 2048-bin scatter into fixed rooms + 8192-slot LDS aggregate; 2^25-row probe slice on the two-level plan)",
                         "achieved": round(per_gpu, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 12,
                         "traffic": load_traffic("groupby", rows // world)}}
