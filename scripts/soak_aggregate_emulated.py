@@ -8,6 +8,9 @@ from tests.emu.build_plugin_emu import build_plugin
 lib = ctypes.CDLL(build_plugin(verbose=False))
 lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
 lib.arrow_amd_plugin_set_aggregate_flush_rows.argtypes = [ctypes.c_int64]
+lib.arrow_amd_plugin_set_aggregate_direct_rows.argtypes = [ctypes.c_int64]
+lib.arrow_amd_plugin_set_table_source_rows.argtypes = [ctypes.c_int64]
+lib.arrow_amd_plugin_set_coalesce_rows.argtypes = [ctypes.c_int64]
 assert lib.arrow_amd_register() == 0
 def to_device(arr):
     c_arr, c_schema, c_dev = (ctypes.create_string_buffer(n) for n in (80, 72, 128))
@@ -29,9 +32,18 @@ for trial in range(trials):
         hk.append(k); hv.append(v); dk.append(to_device(k)); dv.append(to_device(v))
     host = pa.table({"k": pa.chunked_array(hk), "v": pa.chunked_array(hv)})
     dev = pa.table({"k": pa.chunked_array(dk), "v": pa.chunked_array(dv)})
+    # round 3: the source (stock / whole-chunk / stock + coalesce_rocm), the rows above which a batch is consumed in place,
+    # the batch size of table_source_rocm and the coalescing target are random too
+    source = str(rng.choice(["table_source", "table_source_rocm", "coalesce"]))
+    lib.arrow_amd_plugin_set_aggregate_direct_rows(int(rng.choice([1 << 22, 1, 5_000, 40_000])))
+    lib.arrow_amd_plugin_set_table_source_rows(int(rng.choice([1 << 27, 7_000, 33_000])))
+    lib.arrow_amd_plugin_set_coalesce_rows(int(rng.choice([1 << 26, 20_000, 70_000])))
     def plan(t, agg):
-        return acero.Declaration.from_sequence([
-            acero.Declaration("table_source", acero.TableSourceNodeOptions(t)),
+        head = [acero.Declaration("table_source" if agg == "aggregate" or source == "coalesce" else source, acero.TableSourceNodeOptions(t))]
+        if agg != "aggregate" and source == "coalesce":
+            import pyarrow.compute as pc
+            head.append(acero.Declaration("coalesce_rocm", acero.FilterNodeOptions(pc.scalar(True))))
+        return acero.Declaration.from_sequence(head + [
             acero.Declaration(agg, acero.AggregateNodeOptions([("v", "hash_sum", None, "s"), ("v", "hash_count", None, "c"), ("v", "hash_min", None, "lo"), ("v", "hash_max", None, "hi")], keys=["k"]))])
     want = plan(host, "aggregate").to_table(use_threads=False).select(["k", "s", "c", "lo", "hi"]).sort_by("k")
     lib.arrow_amd_plugin_set_aggregate_flush_rows(int(rng.choice([1 << 21, 10_000, 50_000, 1])))
