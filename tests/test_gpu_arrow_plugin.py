@@ -371,9 +371,15 @@ GENERAL_GROUP_BY_SCRIPT = textwrap.dedent(r'''
         "i16": pa.array(rng.integers(-2**15, 2**15, n).astype(np.int16), mask=rng.random(n) < 0.1),
         "u32": pa.array(rng.integers(0, 2**32, n).astype(np.uint32), mask=rng.random(n) < 0.3),
         "u64": pa.array(rng.integers(0, 2**64, n, dtype=np.uint64), mask=rng.random(n) < 0.1),
+        # booleans for hash_any / hash_all: rarely true with nulls, almost always true without (so both outcomes occur per group)
+        "rare": pa.array(rng.random(n) < 0.01, mask=rng.random(n) < 0.1),
+        "sure": pa.array(rng.random(n) < 0.97),
     })
     strict = pc.ScalarAggregateOptions(skip_nulls=False, min_count=2)
     plans = [
+        (["d"], [("rare", "hash_any", None, "any"), ("rare", "hash_all", strict, "all"), ("sure", "hash_all", None, "sall"),
+                 ("sure", "hash_any", pc.ScalarAggregateOptions(skip_nulls=True, min_count=90), "sany"), ("flag", "hash_all", strict, "fall"),
+                 ("v", "hash_sum", None, "s")]),
         (["k64"], [("v", "hash_sum", None, "s"), ("w", "hash_sum", None, "sw"), ("v", "hash_min", None, "mn"), ("v", "hash_max", None, "mx"),
                    ("v", "hash_mean", None, "me"), ("v", "hash_count", None, "c"), ("flag", "hash_count", pc.CountOptions(mode="only_null"), "fn"),
                    ([], "hash_count_all", None, "all")]),
@@ -2240,6 +2246,91 @@ TABLE_SOURCE_SCRIPT = textwrap.dedent(r'''
 ''')
 
 
+GOLDEN_HASH_AGGREGATE_SCRIPT = textwrap.dedent(r'''
+    import ctypes, json, os, sys, faulthandler
+    faulthandler.enable()
+    import pyarrow as pa, pyarrow.compute as pc
+    from pyarrow import acero
+    sys.path.insert(0, ROOT)
+    from tests import golden_hash_aggregate as H
+    emulated = os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1"
+    if emulated:
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    path = build_plugin()
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))
+    # the transcription holds on the reference build itself (nothing registered yet)
+    assert H.replay(gold, H.stock_group_by(False)) == 28
+    lib = ctypes.CDLL(path)
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(0))     # the golden tables are tiny: send them to the GPU anyway
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(m) for m in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+
+    def device_table(table, columns):
+        # one device batch per chunk of the table (the reference tables have three), `columns` in HBM, the rest as they are
+        return pa.Table.from_batches([pa.RecordBatch.from_arrays(
+            [to_device(b.column(j)) if table.schema.names[j] in columns else b.column(j) for j in range(b.num_columns)],
+            names=table.schema.names) for b in table.to_batches()])
+
+    def device_values_stock(threads):
+        # the STOCK GroupByNode: host keys -> the CPU Grouper -> ids; value columns in HBM -> the registered hash_* kernels
+        inner = H.declaration_group_by("aggregate", threads)
+        def run(table, aggs):
+            cols = {c for c, _, _ in aggs if isinstance(c, str)}
+            return inner(device_table(table, cols), aggs)
+        return run
+
+    def device_fused(table, aggs):
+        # every column in HBM -> aggregate_rocm (the device Grouper + the dense kernels)
+        specs = [(col, "hash_" + fn, H.pc_options(opts), f"out{j}") for j, (col, fn, opts) in enumerate(aggs)]
+        r = acero.Declaration.from_sequence([
+            acero.Declaration("table_source_rocm", acero.TableSourceNodeOptions(device_table(table, set(table.schema.names)))),
+            acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions(specs, keys=["key"])),
+        ]).to_table(use_threads=False)
+        return r.column("key").to_pylist(), [r.column(f"out{j}").to_pylist() for j in range(len(aggs))]
+
+    signed_and_narrow = [pa.int8(), pa.uint8(), pa.int16(), pa.uint16(), pa.int32(), pa.uint32(), pa.int64()]
+    exact = [s for s in H.SECTIONS if s != "hash_mean_overflow"]
+    g0, s0 = lib.arrow_amd_plugin_calls(b"hash_sum", 1), lib.arrow_amd_plugin_calls(b"hash_sum", 0)
+    # 1. host tables under the stock GroupByNode: Table.group_by (serial and threaded/merged) and the "aggregate" node;
+    #    int64 and int32 keys; MeanOverflow included (host int64 means keep the reference kernel, whatever the magnitudes)
+    ran = 0
+    for threads in ((False,) if emulated else (False, True)):
+        ran += H.replay(gold, H.stock_group_by(threads), key_types=(pa.int64(), pa.int32()))
+        ran += H.replay(gold, H.declaration_group_by("aggregate", threads))
+    # 2. device-resident value columns under the stock GroupByNode (uint64 min / max stay with the reference kernel: host only)
+    ran += H.replay(gold, device_values_stock(False), int_types=signed_and_narrow, sections=exact)
+    # 3. aggregate_rocm: host batches and device-resident batches; int64 keys (the general node) and int32 keys (the fused
+    #    int32 -> int64 operator takes the sum / mean / min / max / count cases, the general node the rest)
+    ran += H.replay(gold, H.declaration_group_by("aggregate_rocm"), key_types=(pa.int64(), pa.int32()), int_types=signed_and_narrow, sections=exact)
+    ran += H.replay(gold, device_fused, key_types=(pa.int64(), pa.int32()), int_types=signed_and_narrow, sections=exact)
+    assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - g0 > 150, "the replay did not reach the HIP kernels"
+    # MeanOverflow off the host route: partial sums beyond 2^53 are refused loudly, not approximated (DESIGN.md 4.6)
+    for run in (device_values_stock(False), H.declaration_group_by("aggregate_rocm"), device_fused):
+        try:
+            H.replay(gold, run, sections=["hash_mean_overflow"])
+            raise SystemExit("hash_mean beyond 2^53 on the device route did not fail")
+        except pa.ArrowNotImplementedError as e:
+            assert "2^53" in str(e), e
+    # hash_min / hash_max of uint64: the reference kernel on host batches, refused by aggregate_rocm
+    try:
+        H.replay(gold, H.declaration_group_by("aggregate_rocm"), int_types=[pa.uint64()], sections=["hash_min_max_types"])
+        raise SystemExit("aggregate_rocm took hash_min(uint64)")
+    except pa.ArrowNotImplementedError as e:
+        assert "uint64" in str(e), e
+    print("GOLDEN_HASH_AGGREGATE_OK", ran)
+''')
+
+
 REE_FILTER_SCRIPT = textwrap.dedent(r'''
     import ctypes, os, sys, faulthandler
     faulthandler.enable()
@@ -2388,3 +2479,13 @@ def test_run_end_encoded_filter_masks_on_device_arrays():
     slices of the REE array, three value widths; equal to the reference's REE filter taken before registration; host
     arrays keep the reference kernel; mixed residency refused by name."""
     _run(REE_FILTER_SCRIPT, "REE_FILTER_OK")
+
+
+def test_reference_golden_grouped_aggregates_through_acero():
+    """the reference's own known-answer tests for the grouped aggregates — acero/hash_aggregate_test.cc
+    CountOnly :714, MeanOnly :959, MeanOverflow :1048, MinMaxOnly :1591, MinMaxTypes :1661, AnyAndAll :2071,
+    AnyAllSlicedNullableBoolean :2160, CountAndSum :3293, SumMeanProductKeepNulls :3481 (tests/golden/reference_vectors.json)
+    — replayed with the plugin registered: Table.group_by and the stock "aggregate" node over host tables (serial and
+    threaded) and over device-resident value columns, and aggregate_rocm over host and device-resident batches."""
+    pytest.importorskip("pyarrow")
+    _run(GOLDEN_HASH_AGGREGATE_SCRIPT, "GOLDEN_HASH_AGGREGATE_OK")

@@ -730,3 +730,130 @@ def test_oracle_grouper_against_the_reference_grouper_itself():
     assert O.Grouper(1).consume(tiny).tolist() == ref_ids.tolist() == [0, 1, 0, 1, 2, 3, 1, 3]
     # ... and hands out ids in hash order inside its minibatches on larger ones (a bijection away, checked above)
     assert not first_appearance_seen
+
+
+# ------------------------------------------------------------------ grouped aggregates: the reference's known answers
+def _oracle_group_by(two_states=False):
+    """golden_hash_aggregate.replay's `run` on the oracle: O.Grouper hands out dense ids batch by batch (one Grouper
+    for the table), one oracle kernel state per aggregate consumes them.  two_states: batches alternate between two
+    states per aggregate (each with its own Grouper) that are merged at the end through the Grouper mapping — the
+    reference's "parallel/merged" leg (GroupByNode::Merge, acero/groupby_aggregate_node.cc)."""
+    def run(table, aggs):
+        batches = table.to_batches()
+        key_dtype = table.schema.field("key").type.to_pandas_dtype()
+
+        def make_states():
+            out = []
+            for col, fn, opts in aggs:
+                skip = True if opts is None or fn == "count" else opts["skip_nulls"]
+                minc = 1 if opts is None or fn == "count" else opts["min_count"]
+                if fn == "count":
+                    out.append(O.HashCountState("only_valid" if opts is None else opts["mode"]))
+                elif fn == "count_all":
+                    out.append(O.HashCountState("all"))
+                elif fn == "sum":
+                    out.append(O.HashSumState(skip, minc))
+                elif fn in ("min", "max"):
+                    out.append(O.HashMinMaxState(skip))
+                elif fn in ("any", "all"):
+                    out.append(O.HashBoolState(fn == "all", skip, minc))
+                elif fn == "mean":
+                    out.append({"rows": [], "skip": skip, "minc": minc})      # groupby_mean_i64 is whole-table: rows are kept
+                else:
+                    raise AssertionError(fn)
+            return out
+
+        lanes = [(O.Grouper(1), make_states())] + ([(O.Grouper(1), make_states())] if two_states else [])
+        for bi, b in enumerate(batches):
+            grouper, states = lanes[bi % len(lanes)]
+            k = from_list(b.column("key").to_pylist(), key_dtype)
+            ids = grouper.consume([(np.ascontiguousarray(k.values), k.valid if k.valid is not None else None)])
+            for (col, fn, opts), st in zip(aggs, states):
+                if fn == "count_all":
+                    st.resize(grouper.num_groups)
+                    st.consume(None, 0, ids)
+                    continue
+                xs = b.column(col).to_pylist()
+                if fn in ("any", "all"):
+                    a = from_list(xs, np.bool_)
+                    st.resize(grouper.num_groups)
+                    st.consume(np.asarray(a.values, bool), a.valid_bitmap(), 0, ids)
+                elif fn == "count":
+                    a = from_list([None if x is None else 0 for x in xs], np.int64)
+                    st.resize(grouper.num_groups)
+                    st.consume(a.valid_bitmap(), 0, ids)
+                elif fn == "mean":
+                    st["rows"] += list(zip(ids.tolist(), xs))
+                else:
+                    a = from_list(xs, np.int64)
+                    st.resize(grouper.num_groups)
+                    st.consume(np.ascontiguousarray(a.values), a.valid_bitmap(), 0, ids)
+        grouper, states = lanes[0]
+        if two_states:
+            other_grouper, other_states = lanes[1]
+            uniq = other_grouper.uniques([key_dtype])
+            mapping = grouper.consume(uniq) if other_grouper.num_groups else np.zeros(0, np.uint32)
+            for (col, fn, opts), st, ot in zip(aggs, states, other_states):
+                if fn == "mean":
+                    st["rows"] += [(int(mapping[g]), x) for g, x in ot["rows"]]     # (double sums are order-dependent only in the last ulp; these fixtures are exact)
+                else:
+                    st.resize(grouper.num_groups)
+                    if ot.num_groups:
+                        st.merge(ot, mapping)
+        for st in states:
+            if not isinstance(st, dict):
+                st.resize(grouper.num_groups)
+        (kv, kvalid), = grouper.uniques([key_dtype])
+        keys = [int(v) if ok else None for v, ok in zip(kv, kvalid)]
+        outs = []
+        for (col, fn, opts), st in zip(aggs, states):
+            if fn in ("count", "count_all"):
+                outs.append(st.counts.tolist())
+            elif fn == "sum":
+                sums, valid, _ = st.finalize()
+                outs.append([int(s) if ok else None for s, ok in zip(sums, valid)])
+            elif fn in ("min", "max"):
+                mins, maxs, valid = st.finalize()
+                outs.append([int(s) if ok else None for s, ok in zip(mins if fn == "min" else maxs, valid)])
+            elif fn in ("any", "all"):
+                vals, valid = st.finalize()
+                outs.append([bool(s) if ok else None for s, ok in zip(vals, valid)])
+            else:
+                G = grouper.num_groups
+                # groups that never got a row of this aggregate's lane still exist: one null row each keeps them, in id order
+                rows = [(g, None) for g in range(G)] + st["rows"]
+                gid = from_list([g for g, _ in rows], np.int32)
+                v = from_list([x for _, x in rows], np.int64)
+                w = O.groupby_mean_i64(np.ascontiguousarray(gid.values), None, 0, np.ascontiguousarray(v.values), v.valid_bitmap(), 0,
+                                       len(rows), skip_nulls=True, min_count=st["minc"])
+                had_null = np.zeros(G, bool)
+                for g, x in st["rows"]:
+                    had_null[g] |= x is None
+                assert w["keys"].tolist() == list(range(G))
+                outs.append([float(m) if ok and (st["skip"] or not had_null[g]) else None
+                             for g, (m, ok) in enumerate(zip(w["means"], w["valid"]))])
+        return keys, outs
+    return run
+
+
+@pytest.mark.parametrize("two_states", [False, True], ids=["serial", "merged"])
+def test_golden_grouped_aggregates(two_states):
+    """acero/hash_aggregate_test.cc — CountOnly :714, MeanOnly :959, MeanOverflow :1048, MinMaxOnly :1591, MinMaxTypes :1661,
+    AnyAndAll :2071, AnyAllSlicedNullableBoolean :2160, CountAndSum :3293, SumMeanProductKeepNulls :3481 — replayed on the
+    oracle's kernel states (HashCountState / HashSumState / HashMinMaxState / HashBoolState, groupby_mean_i64) over
+    the oracle Grouper's ids, one state and two merged states."""
+    pytest.importorskip("pyarrow")
+    from . import golden_hash_aggregate as H
+
+    assert H.replay(GOLD, _oracle_group_by(two_states), key_types=(pa.int64(), pa.int32())) == 56
+
+
+@pytest.mark.parametrize("use_threads", [False, True])
+def test_golden_grouped_aggregates_transcription_holds_on_the_reference_build(use_threads):
+    """The same vectors through the stock pyarrow 25.0.0 build (Table.group_by and the "aggregate" exec node), so that a
+    transcription slip (the x8 restatement on int64, the hash_min_max -> hash_min + hash_max split) cannot hide."""
+    pytest.importorskip("pyarrow")
+    from . import golden_hash_aggregate as H
+
+    assert H.replay(GOLD, H.stock_group_by(use_threads), key_types=(pa.int64(), pa.int32())) == 56
+    assert H.replay(GOLD, H.declaration_group_by("aggregate", use_threads)) == 28

@@ -104,3 +104,7 @@ def test_table_source_rocm_whole_chunk_batches_emulated():
 
 def test_run_end_encoded_filter_masks_emulated():
     _run(G.REE_FILTER_SCRIPT, "REE_FILTER_OK", 0.02)
+
+
+def test_reference_golden_grouped_aggregates_through_acero_emulated():
+    _run(G.GOLDEN_HASH_AGGREGATE_SCRIPT, "GOLDEN_HASH_AGGREGATE_OK", 1)
