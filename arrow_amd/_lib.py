@@ -184,6 +184,7 @@ SIGNATURES = {
     "arx_hash_mean_i64_finalize": (_int, [_p, _p, _i64, C.c_uint64, _p, _p, _p]),
     "arx_compare_numeric": (_int, [_int, _int, _p, _p, _p, _p, _i64, _p, _p]),
     "arx_arith_numeric": (_int, [_int, _int, _int, _p, _p, _p, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p]),
+    "arx_divide_numeric": (_int, [_int, _int, _p, _p, _p, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p]),
     "arx_delta_decode_pages": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _sz, _p, _p]),
     "arx_copy_segments": (_int, [_p, _i64, _u64, _p]),
     "arx_bitmap_copy_segments": (_int, [_p, _i64, _i64, _p]),

@@ -642,6 +642,38 @@ def _exec_arith_numeric(op_name, checked):
     return run
 
 
+def _exec_divide_numeric(checked: bool):
+    def run(args, options):
+        """ScalarBinaryNotNull<T, T, T, Divide | DivideChecked> for every numeric T (base_arithmetic_internal.h:366-424,
+        DivideWithOverflowGeneric util/int_util_overflow.h:124-138): only slots where both operands are valid are
+        visited; the last failing slot names the error."""
+        left, right = args
+        arr, n, lp, lsp, rp, rsp, _keep = _numeric_operands(left, right)
+        dev = arr.device
+        lib, stream = _lib_and_stream(dev)
+        null_scalar = any(isinstance(a, Scalar) and not a.is_valid for a in (left, right))
+        if null_scalar and rp is None:      # every slot is null: nothing is visited (keep the kernel away from a 0 divisor)
+            _keep[1][0] = 1
+        out = alloc(n * arr.type.byte_width, dev)
+        validity, nc = _propagate_validity([left, right], n, dev)
+        errors = torch.zeros(2, dtype=torch.int64, device=dev)
+
+        def vptr(a):
+            return (a.validity.data_ptr(), a.offset) if isinstance(a, Array) and a.may_have_nulls() else (None, 0)
+        (lvp, lvo), (rvp, rvo) = vptr(left), vptr(right)
+        with tracing.span("arx_divide_numeric"):
+            check(lib.arx_divide_numeric(1 if checked else 0, _NUM_TYPE_ID[arr.type.name], lp, lsp, lvp, lvo, rp, rsp, rvp, rvo, n,
+                                         out.data_ptr(), errors.data_ptr(), stream))
+        if not null_scalar:
+            last_overflow, last_zero = errors.cpu().tolist()
+            if last_zero > last_overflow:
+                raise ArrowInvalid("divide by zero")
+            if last_overflow:
+                raise ArrowInvalid("overflow")
+        return Array(arr.type, n, [validity, out], nc, 0)
+    return run
+
+
 def _exec_add(args, options):
     """ScalarBinary<..., Add> (codegen_internal.h:814, base_arithmetic_internal.h:45-80)."""
     left, right = args
@@ -1178,6 +1210,8 @@ def _build_registry() -> FunctionRegistry:
 
     for name, checked in (("divide", False), ("divide_checked", True)):
         f = Function(name, Function.SCALAR, 2)
+        for t in numeric_types:
+            f.add_kernel(Kernel((t, t), _exec_divide_numeric(checked), t))
         f.add_kernel(Kernel((int64, int64), _exec_divide(checked), int64))
         f.add_kernel(Kernel((float64, float64), _exec_divide(checked), float64))
         reg.add_function(f)

@@ -399,9 +399,12 @@ __global__ __launch_bounds__(kBlock) void divide_kernel(const T* __restrict__ le
     T res = T(0);
     bool zero = false, overflow = false;
     if constexpr (std::is_integral<T>::value) {
+      // DivideWithOverflowGeneric (util/int_util_overflow.h:124-138): a zero divisor, and for the SIGNED types min / -1
+      bool min_by_minus_one = false;
+      if constexpr (std::is_signed<T>::value) min_by_minus_one = l == std::numeric_limits<T>::min() && r == T(-1);
       if (r == 0) zero = true;
-      else if (l == std::numeric_limits<T>::min() && r == T(-1)) overflow = true;    // (result 0 in the unchecked form)
-      else res = l / r;
+      else if (min_by_minus_one) overflow = true;    // (result 0 in the unchecked form)
+      else res = static_cast<T>(l / r);
     } else {
       if (CHECKED && r == T(0)) zero = true;
       else res = l / r;
@@ -1313,6 +1316,36 @@ int arx_divide_f64(const double* left, double left_scalar, const void* left_vali
                    int64_t length, int checked, double* out, uint64_t* errors, void* stream) {
   return divide_any<double>(left, left_scalar, left_validity, left_offset, right, right_scalar, right_validity,
                             right_offset, length, checked, out, errors, as_stream(stream));
+}
+
+int arx_divide_numeric(int checked, int num_type, const void* left, const void* left_scalar, const void* left_validity,
+                       int64_t left_offset, const void* right, const void* right_scalar, const void* right_validity,
+                       int64_t right_offset, int64_t length, void* out, uint64_t* errors, void* stream) {
+  if ((left == nullptr && left_scalar == nullptr) || (right == nullptr && right_scalar == nullptr)) {
+    set_error("divide: an operand is neither an array nor a scalar");
+    return ARX_INVALID;
+  }
+#define ARX_DIVIDE_T(T)                                                                                                    \
+  return divide_any<T>(static_cast<const T*>(left), left == nullptr ? *static_cast<const T*>(left_scalar) : T(0),          \
+                       left_validity, left_offset, static_cast<const T*>(right),                                           \
+                       right == nullptr ? *static_cast<const T*>(right_scalar) : T(0), right_validity, right_offset,        \
+                       length, checked, static_cast<T*>(out), errors, as_stream(stream))
+  switch (num_type) {
+    case ARX_NUM_INT8: ARX_DIVIDE_T(int8_t);
+    case ARX_NUM_UINT8: ARX_DIVIDE_T(uint8_t);
+    case ARX_NUM_INT16: ARX_DIVIDE_T(int16_t);
+    case ARX_NUM_UINT16: ARX_DIVIDE_T(uint16_t);
+    case ARX_NUM_INT32: ARX_DIVIDE_T(int32_t);
+    case ARX_NUM_UINT32: ARX_DIVIDE_T(uint32_t);
+    case ARX_NUM_INT64: ARX_DIVIDE_T(int64_t);
+    case ARX_NUM_UINT64: ARX_DIVIDE_T(uint64_t);
+    case ARX_NUM_FLOAT32: ARX_DIVIDE_T(float);
+    case ARX_NUM_FLOAT64: ARX_DIVIDE_T(double);
+    default:
+      set_error("divide: unknown numeric type %d", num_type);
+      return ARX_NOT_IMPLEMENTED;
+  }
+#undef ARX_DIVIDE_T
 }
 
 int arx_add_i64(const int64_t* left, const int64_t* right, int64_t length, int64_t* out,

@@ -340,6 +340,13 @@ int arx_divide_f64(const double* left, double left_scalar, const void* left_vali
                    const double* right, double right_scalar, const void* right_validity,
                    int64_t right_offset, int64_t length, int checked, double* out, uint64_t* errors,
                    void* stream);
+/* The same for EVERY numeric element type (num_type: ARX_NUM_*; the reference registers divide / divide_checked for all
+ * of NumericTypes(), scalar_arithmetic.cc): the signed integer types fail / give 0 on min / -1 of their own width, the
+ * unsigned ones only on a zero divisor (DivideWithOverflowGeneric, util/int_util_overflow.h:124-138), float like double.
+ * left / right == NULL: that operand is the scalar *left_scalar / *right_scalar (host pointer to one value of the type). */
+int arx_divide_numeric(int checked, int num_type, const void* left, const void* left_scalar, const void* left_validity,
+                       int64_t left_offset, const void* right, const void* right_scalar, const void* right_validity,
+                       int64_t right_offset, int64_t length, void* out, uint64_t* errors, void* stream);
 /* array + valid scalar (ScalarBinary::ArrayScalar, codegen_internal.h; add commutes, so
  * scalar + array is the same call) */
 int arx_add_i64_array_scalar(const int64_t* left, int64_t right, int64_t length, int64_t* out,

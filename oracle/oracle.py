@@ -280,35 +280,45 @@ def arith(op: str, left, right, both_valid=None, dtype=None):
     return wrapped, bool(ovf.any())
 
 
-def divide(left, right, both_valid=None, checked=False):
-    """divide / divide_checked on int64 or float64 operands (arrays or python scalars): Divide / DivideChecked,
+def divide(left, right, both_valid=None, checked=False, dtype=None):
+    """divide / divide_checked on operands of ONE numeric type (arrays or python scalars; `dtype` names it when neither
+    side is a typed array — default: int64 / float64 as numpy infers): Divide / DivideChecked,
     base_arithmetic_internal.h:366-424, visited only where both operands are valid (ScalarBinaryNotNull).
-    int64: C++ truncating division; zero divisor -> "divide by zero" in both forms; INT64_MIN / -1 -> 0 unchecked,
-    "overflow" checked.  float64: IEEE division; the checked form fails on a zero divisor.  The Status is overwritten by
+    Integers: C++ truncating division; zero divisor -> "divide by zero" in both forms; for the SIGNED types min / -1 of
+    the type's own width -> 0 unchecked, "overflow" checked (DivideWithOverflowGeneric, util/int_util_overflow.h:124-138).
+    Floats: IEEE division in the operand type; the checked form fails on a zero divisor.  The Status is overwritten by
     every failing slot, so the last one names the error.  Returns (result, error message or None); the result at slots
     that are not visited or failed is unspecified (0 here)."""
     la, ra = np.asarray(left), np.asarray(right)
-    is_f = la.dtype.kind == "f" or ra.dtype.kind == "f"
+    if dtype is None:
+        if la.dtype.kind == "f" or ra.dtype.kind == "f":
+            typed = la if (la.ndim and la.dtype.kind == "f") else ra if (ra.ndim and ra.dtype.kind == "f") else None
+            dtype = typed.dtype if typed is not None else np.dtype(np.float64)
+        else:
+            dtype = la.dtype if la.ndim else ra.dtype if ra.ndim else np.dtype(np.int64)
+    dtype = np.dtype(dtype)
+    is_f = dtype.kind == "f"
     n = max(la.size if la.ndim else 1, ra.size if ra.ndim else 1)
     lo, ro = np.broadcast_to(la, (n,)), np.broadcast_to(ra, (n,))
     visit = np.ones(n, bool) if both_valid is None else np.asarray(both_valid, bool)
-    out = np.zeros(n, dtype=np.float64 if is_f else np.int64)
+    out = np.zeros(n, dtype=dtype)
+    signed_min = int(np.iinfo(dtype).min) if dtype.kind == "i" else None
     error = None
     for i in range(n):
         if is_f:
-            a, b = float(lo[i]), float(ro[i])
+            a, b = dtype.type(lo[i]), dtype.type(ro[i])
             if checked and b == 0.0:
                 if visit[i]:
                     error = "divide by zero"
                 continue
             with np.errstate(all="ignore"):
-                out[i] = np.float64(a) / np.float64(b)
+                out[i] = a / b
         else:
             a, b = int(lo[i]), int(ro[i])
             if b == 0:
                 if visit[i]:
                     error = "divide by zero"
-            elif a == -2**63 and b == -1:
+            elif signed_min is not None and a == signed_min and b == -1:
                 if checked and visit[i]:
                     error = "overflow"
             else:

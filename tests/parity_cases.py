@@ -625,67 +625,71 @@ def check_temporal_compare(amd, rng, n=4000):
         amd.compute.call_function("equal", [naive, amd.Array.from_pyarrow(pa.array([1, 3], pa.timestamp("ms")))])
 
 
-def check_divide(amd, rng, n=6000, use_pyarrow=True):
-    """divide / divide_checked (Divide / DivideChecked, base_arithmetic_internal.h:366-424) on int64 and float64, array
-    and scalar operands: results at visited slots, validity, and the error the LAST failing valid slot names;
-    failing values hidden under nulls do not fail."""
-    MIN = -2**63
-    def operands(kind):
-        if kind == "f":
-            l = HostArray(np.round(rng.standard_normal(n + 5) * 8) / 4, rng.random(n + 5) >= 0.1, 3, n)
-            r = HostArray(np.where(rng.random(n + 9) < 0.3, 0.0, np.round(rng.standard_normal(n + 9) * 4) / 2), rng.random(n + 9) >= 0.1, 7, n)
+def check_divide(amd, rng, n=6000, use_pyarrow=True, dtypes=(np.int64, np.float64)):
+    """divide / divide_checked (Divide / DivideChecked, base_arithmetic_internal.h:366-424) on the numeric types in
+    `dtypes`, array and scalar operands: results at visited slots, validity, and the error the LAST failing valid slot
+    names; failing values hidden under nulls do not fail.  Signed integers: min / -1 of the type's OWN width."""
+    def operands(dt):
+        if dt.kind == "f":
+            l = HostArray((np.round(rng.standard_normal(n + 5) * 8) / 4).astype(dt), rng.random(n + 5) >= 0.1, 3, n)
+            r = HostArray(np.where(rng.random(n + 9) < 0.3, 0.0, np.round(rng.standard_normal(n + 9) * 4) / 2).astype(dt), rng.random(n + 9) >= 0.1, 7, n)
         else:
-            l = HostArray(rng.integers(-2**62, 2**62, n + 5), rng.random(n + 5) >= 0.1, 3, n)
-            r = HostArray(rng.integers(-50, 50, n + 9), rng.random(n + 9) >= 0.1, 7, n)
-            l.values[3 + 11], r.values[7 + 11] = MIN, -1
+            info = np.iinfo(dt)
+            l = HostArray(rng.integers(info.min // 2, info.max // 2, n + 5, dtype=dt, endpoint=True), rng.random(n + 5) >= 0.1, 3, n)
+            r = HostArray(rng.integers(max(info.min, -50), min(info.max, 50), n + 9).astype(dt), rng.random(n + 9) >= 0.1, 7, n)
+            if dt.kind == "i":
+                l.values[3 + 11], r.values[7 + 11] = info.min, -1
         return l, r
 
-    def run(fn_name, left, right, lhost, rhost, both, checked):
-        want, error = O.divide(lhost, rhost, both, checked)
+    def run(fn_name, left, right, lhost, rhost, both, checked, dt):
+        want, error = O.divide(lhost, rhost, both, checked, dtype=dt)
         fn = getattr(amd.compute, fn_name)
         if error is not None:
             with pytest.raises(amd.ArrowInvalid) as e:
                 fn(left, right)
-            assert str(e.value) == error, (fn_name, str(e.value), error)
+            assert str(e.value) == error, (fn_name, str(dt), str(e.value), error)
             return None
         out = fn(left, right)
         got = _data_np(out, want.dtype)
         ok = both & ~(np.isnan(want) if want.dtype.kind == "f" else np.zeros(len(want), bool))
-        assert_equal(got[ok], want[ok], fn_name)
+        assert_equal(got[ok], want[ok], f"{fn_name} {dt}")
         if want.dtype.kind == "f":
             assert np.array_equal(np.isnan(got[both]), np.isnan(want[both]))
         gv, _ = _logical_valid(out)
         assert_equal(gv, both, fn_name + " validity")
         return out
 
-    for kind in ("i", "f"):
-        l, r = operands(kind)
+    for dtype in dtypes:
+        dt = np.dtype(dtype)
+        is_int = dt.kind in "iu"
+        l, r = operands(dt)
         both = l.logical_valid() & r.logical_valid()
         dl, dr = l.to_device(amd), r.to_device(amd)
         for checked in (False, True):
             name = "divide_checked" if checked else "divide"
-            # zero divisors (and INT64_MIN / -1) present: the error of the last failing valid slot
-            run(name, dl, dr, l.logical_values(), r.logical_values(), both, checked)
+            # zero divisors (and min / -1) present: the error of the last failing valid slot
+            run(name, dl, dr, l.logical_values(), r.logical_values(), both, checked, dt)
             if use_pyarrow and pa is not None:
                 try:
                     getattr(pc, name)(l.to_pyarrow(), r.to_pyarrow())
                     ref_error = None
                 except pa.lib.ArrowInvalid as e:
                     ref_error = str(e)
-                assert ref_error == O.divide(l.logical_values(), r.logical_values(), both, checked)[1], (kind, checked, ref_error)
+                assert ref_error == O.divide(l.logical_values(), r.logical_values(), both, checked, dtype=dt)[1], (str(dt), checked, ref_error)
             # failing slots hidden under nulls: no error; every visited slot equals the oracle (and pyarrow)
             safe = HostArray(r.values.copy(), r.valid.copy(), r.offset, r.length)
-            bad = (safe.values == 0) | ((safe.values == -1) if kind == "i" else False)
+            bad = (safe.values == 0) | ((safe.values == -1) if dt.kind == "i" else False)
             safe.valid[bad] = False
             both2 = l.logical_valid() & safe.logical_valid()
-            out = run(name, dl, safe.to_device(amd), l.logical_values(), safe.logical_values(), both2, checked)
-            if use_pyarrow and pa is not None and kind == "i":
+            out = run(name, dl, safe.to_device(amd), l.logical_values(), safe.logical_values(), both2, checked, dt)
+            if use_pyarrow and pa is not None and is_int:
                 assert out.to_pyarrow().equals(getattr(pc, name)(l.to_pyarrow(), safe.to_pyarrow()))
             # scalar operands on either side
-            s = 7 if kind == "i" else 0.5
-            run(name, dl, s, l.logical_values(), np.asarray(s), l.logical_valid(), checked)
-            run(name, s, safe.to_device(amd), np.asarray(s), safe.logical_values(), safe.logical_valid(), checked)
-            run(name, dl, 0 if kind == "i" else 0.0, l.logical_values(), np.asarray(0 if kind == "i" else 0.0), l.logical_valid(), checked)
+            s = dt.type(7) if is_int else dt.type(0.5)
+            zero = dt.type(0)
+            run(name, dl, s.item(), l.logical_values(), np.asarray(s), l.logical_valid(), checked, dt)
+            run(name, s.item(), safe.to_device(amd), np.asarray(s), safe.logical_values(), safe.logical_valid(), checked, dt)
+            run(name, dl, zero.item(), l.logical_values(), np.asarray(zero), l.logical_valid(), checked, dt)
 
 
 def check_compare_family(amd, rng, n=10_000, use_pyarrow=True):

@@ -862,6 +862,13 @@ def test_divide_and_divide_checked(emu_ctx):
     P.check_divide(emu_ctx, rng_for("divide"), n=3000)
 
 
+@pytest.mark.parametrize("dtype", ["int8", "uint8", "int16", "uint16", "int32", "uint32", "uint64", "float32"])
+def test_divide_on_the_other_numeric_types(emu_ctx, dtype):
+    """arx_divide_numeric: the same Call bodies per element type (min / -1 of the type's own width, unsigned types fail
+    only on a zero divisor — DivideWithOverflowGeneric, util/int_util_overflow.h:124-138)."""
+    P.check_divide(emu_ctx, rng_for("divide-" + dtype), n=1500, dtypes=(np.dtype(dtype),))
+
+
 @pytest.mark.parametrize("section,combos", [("grouper_numeric_key", None), ("grouper_floating_point_key", None),
                                             ("grouper_multiple_int_keys", 40)])
 def test_reference_grouper_golden_vectors(emu_ctx, section, combos):

@@ -2331,6 +2331,65 @@ GOLDEN_HASH_AGGREGATE_SCRIPT = textwrap.dedent(r'''
 ''')
 
 
+GOLDEN_SCALAR_OPS_SCRIPT = textwrap.dedent(r'''
+    import ctypes, json, os, sys, faulthandler
+    faulthandler.enable()
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    from tests import golden_scalar_ops as S
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    path = build_plugin()
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors_scalar.json")))
+    # (cases whose operands are both scalars never reach a kernel of ours: the oracle and the stock build cover them)
+    cases = list(S.cases(gold, scalar_scalar=False))
+    # the reference build's own answers, before anything is registered: the transcription holds, and the bits to match
+    stock = [S.check(c, lambda fn, l, r: pc.call_function(fn, [l, r])) for c in cases]
+    lib = ctypes.CDLL(path)
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(0))     # the golden arrays are tiny: send them to the GPU anyway
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(m) for m in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+    def to_host(arr):
+        c_dev, c_schema, c_arr = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72), ctypes.create_string_buffer(80)
+        arr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, None) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), arr.type)
+    on_device = [0]
+    def device(fn, left, right):
+        # array operands in HBM (empty arrays have nothing to upload), scalars as they are; unmodified pyarrow.compute
+        dl, dr = (to_device(x) if isinstance(x, pa.Array) and len(x) else x for x in (left, right))
+        out = pc.call_function(fn, [dl, dr])
+        if isinstance(out, pa.Array) and any(b is not None and not b.is_cpu for b in out.buffers()):
+            on_device[0] += 1
+            out = to_host(out)
+        return out
+    counters = {f: lib.arrow_amd_plugin_calls(f.encode(), 1) for f in ("greater", "compare", "add")}
+    stock_before = {f: lib.arrow_amd_plugin_calls(f.encode(), 0) for f in ("greater", "compare", "add")}
+    for case, want in zip(cases, stock):
+        got = S.check(case, device)
+        if want is not None:      # bit for bit the reference build's result (floats included: IEEE, no reassociation)
+            assert S.matches(got, want, approx=False), (case["id"], case["cite"], S.as_list(got), S.as_list(want))
+    ran = sum(lib.arrow_amd_plugin_calls(f.encode(), 1) - v for f, v in counters.items())
+    assert len(cases) == 1950 and ran > 1500 and on_device[0] > 1400, (len(cases), ran, on_device[0])
+    assert all(lib.arrow_amd_plugin_calls(f.encode(), 0) == v for f, v in stock_before.items()), "a device operand reached a reference kernel"
+    # host arrays keep the reference kernels (below and above min_rows alike for these functions' tiny inputs): same answers
+    lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(1 << 20))
+    for case in cases[::7]:
+        S.check(case, lambda fn, l, r: pc.call_function(fn, [l, r]))
+    print("GOLDEN_SCALAR_OPS_OK", len(cases), ran, on_device[0])
+''')
+
+
 REE_FILTER_SCRIPT = textwrap.dedent(r'''
     import ctypes, os, sys, faulthandler
     faulthandler.enable()
@@ -2489,3 +2548,13 @@ def test_reference_golden_grouped_aggregates_through_acero():
     threaded) and over device-resident value columns, and aggregate_rocm over host and device-resident batches."""
     pytest.importorskip("pyarrow")
     _run(GOLDEN_HASH_AGGREGATE_SCRIPT, "GOLDEN_HASH_AGGREGATE_OK")
+
+
+def test_reference_golden_compare_and_arithmetic_through_callfunction():
+    """the reference's own known-answer tests for the comparison family (kernels/scalar_compare_test.cc
+    :251-456, every numeric type + timestamps) and add / subtract / multiply / divide with their checked forms
+    (kernels/scalar_arithmetic_test.cc:562-939: wrap-around, "overflow", overflow hidden under a null, "divide by zero",
+    min / -1, signed zeros, null scalars) — tests/golden/reference_vectors_scalar.json — replayed through unmodified
+    pyarrow.compute on device-resident arrays with the plugin registered; bit for bit the stock build's answers."""
+    pytest.importorskip("pyarrow")
+    _run(GOLDEN_SCALAR_OPS_SCRIPT, "GOLDEN_SCALAR_OPS_OK")

@@ -1192,6 +1192,12 @@ def test_divide_and_divide_checked(gpu_ctx):
     P.check_divide(gpu_ctx, rng_for("divide"), n=300_007)
 
 
+@pytest.mark.parametrize("dtype", ["int8", "uint8", "int16", "uint16", "int32", "uint32", "uint64", "float32"])
+def test_divide_on_the_other_numeric_types(gpu_ctx, dtype):
+    """arx_divide_numeric through the C ABI against the oracle and pyarrow, one element type at a time."""
+    P.check_divide(gpu_ctx, rng_for("divide-" + dtype), n=200_003, dtypes=(np.dtype(dtype),))
+
+
 @pytest.mark.parametrize("kind", ["int64", "int8", "bool", "utf8", "binary_nonull"])
 def test_concat_arrays(gpu_ctx, kind):
     """Concatenate (array/concatenate.cc): sliced chunks glued at arbitrary bit positions, empty chunks."""

@@ -857,3 +857,74 @@ def test_golden_grouped_aggregates_transcription_holds_on_the_reference_build(us
 
     assert H.replay(GOLD, H.stock_group_by(use_threads), key_types=(pa.int64(), pa.int32())) == 56
     assert H.replay(GOLD, H.declaration_group_by("aggregate", use_threads)) == 28
+
+
+# ------------------------------------------------------------------ comparisons and arithmetic: the reference's known answers
+SCALAR_GOLD = json.load(open(os.path.join(HERE, "golden", "reference_vectors_scalar.json")))
+
+
+def _oracle_scalar_op(fn, left, right):
+    """golden_scalar_ops' `run` on the oracle: O.compare / O.arith / O.divide see the values of every slot (what lies
+    under a null included, as the kernels do) plus "both operands valid"; the result validity is the AND of the operand
+    validities (PropagateNulls), a null scalar nulls everything; a failing slot raises the reference's Status text."""
+    def split(x):
+        if isinstance(x, pa.Scalar):
+            return (x.as_py() if x.is_valid else 0), None if x.is_valid else False
+        np_dtype = np.dtype(x.type.to_pandas_dtype()) if not pa.types.is_timestamp(x.type) else np.dtype(np.int64)
+        phys = x.cast(pa.int64()) if pa.types.is_timestamp(x.type) else x
+        vals = np.frombuffer(phys.buffers()[1], dtype=np_dtype, count=len(x) + x.offset)[x.offset:] if len(x) else np.zeros(0, np_dtype)
+        return vals, np.array([v is not None for v in x.to_pylist()], dtype=bool)
+
+    typ = left.type if isinstance(left, pa.Array) else right.type
+    both_scalar = isinstance(left, pa.Scalar) and isinstance(right, pa.Scalar)
+    n = 1 if both_scalar else len(left if isinstance(left, pa.Array) else right)
+    (lv, lok), (rv, rok) = split(left), split(right)
+    valid = np.ones(n, bool)
+    for ok in (lok, rok):
+        if ok is False:
+            valid[:] = False
+        elif ok is not None:
+            valid &= ok
+    np_dtype = np.dtype(np.int64) if pa.types.is_timestamp(typ) else np.dtype(typ.to_pandas_dtype())
+    if both_scalar:
+        lv, rv = np.array([lv], np_dtype), np.array([rv], np_dtype)
+    if fn in ("equal", "not_equal", "greater", "greater_equal", "less", "less_equal"):
+        cast = lambda v: v if isinstance(v, np.ndarray) else np_dtype.type(v)
+        data, out_type = O.compare(fn, cast(lv), cast(rv)), pa.bool_()
+        data = np.broadcast_to(data, (n,))
+    else:
+        op, checked = (fn[:-8], True) if fn.endswith("_checked") else (fn, False)
+        if op == "divide":
+            data, error = O.divide(lv, rv, valid, checked, dtype=np_dtype)
+            if error is not None:
+                raise pa.ArrowInvalid(error)
+        else:
+            data, overflowed = O.arith(op, lv, rv, valid, dtype=np_dtype)
+            if checked and overflowed:
+                raise pa.ArrowInvalid("overflow")
+        out_type = typ
+    out = pa.array(np.asarray(data), type=out_type, mask=~valid)
+    return out[0] if both_scalar else out
+
+
+def test_golden_compare_and_arithmetic_on_the_oracle():
+    """kernels/scalar_compare_test.cc:251-456 (SimpleCompareArrayScalar / ScalarArray / ArrayArray, TestNullScalar,
+    TestCompareTimestamps.Basics) and kernels/scalar_arithmetic_test.cc:562-939 (Add / Sub / Mul / Div of the integral,
+    signed, unsigned and floating fixtures: wrap-around, the checked forms' "overflow", overflow hidden under a null,
+    "divide by zero", min / -1), every numeric type — replayed on O.compare / O.arith / O.divide."""
+    pytest.importorskip("pyarrow")
+    from . import golden_scalar_ops as S
+
+    ran = 0
+    for case in S.cases(SCALAR_GOLD):
+        S.check(case, _oracle_scalar_op)
+        ran += 1
+    assert ran == 1982
+
+
+def test_golden_compare_and_arithmetic_transcription_holds_on_the_reference_build():
+    pytest.importorskip("pyarrow")
+    from . import golden_scalar_ops as S
+
+    ran = sum(1 for case in S.cases(SCALAR_GOLD) if S.check(case, lambda fn, l, r: pc.call_function(fn, [l, r])) is not None or True)
+    assert ran == 1982

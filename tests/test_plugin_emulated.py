@@ -108,3 +108,7 @@ def test_run_end_encoded_filter_masks_emulated():
 
 def test_reference_golden_grouped_aggregates_through_acero_emulated():
     _run(G.GOLDEN_HASH_AGGREGATE_SCRIPT, "GOLDEN_HASH_AGGREGATE_OK", 1)
+
+
+def test_reference_golden_compare_and_arithmetic_through_callfunction_emulated():
+    _run(G.GOLDEN_SCALAR_OPS_SCRIPT, "GOLDEN_SCALAR_OPS_OK", 1)
