@@ -1161,7 +1161,8 @@ def check_groupby_sum_typed(amd, rng, key_dtype, value_dtype, n=5000):
 def replay_golden_sort(amd, gold, dtype):
     """The golden sort cases of tests/golden/reference_vectors.json (vector_sort_test.cc:640-724) on the device."""
     ran = 0
-    for case in gold["sort_indices_integral"] + gold["sort_indices_real"]:
+    wide = gold["sort_indices_narrow_and_wide"]["int64"] if np.dtype(dtype) == np.dtype(np.int64) else []   # (SortInt64, :867-885)
+    for case in gold["sort_indices_integral"] + gold["sort_indices_real"] + wide:
         vals = case["values"]
         kind = np.dtype(dtype).kind
         if kind != "f" and any(x == "NaN" or (isinstance(x, float) and x != int(x)) for x in vals if x is not None):

@@ -840,13 +840,32 @@ GOLDEN_SCRIPT = textwrap.dedent(r'''
     emulated = os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1"
     # (the SIMT emulator is single-threaded and slow: two key types, no concurrent consumes there)
     types = (pa.int64(), pa.float64()) if emulated else (pa.int64(), pa.uint64(), pa.int32(), pa.uint32(), pa.float64(), pa.float32())
-    for typ in types:
+    # SortTemporal / TemporalTypeParameters (vector_sort_test.cc:754-781, :913-951) assert the integral vectors on the temporal
+    # types; the 8- and 16-bit integers sort on the device widened to 32 bits (host arrays of those keep the counting sort)
+    temporal = (pa.date32(), pa.date64(), pa.timestamp("s"), pa.timestamp("ns", tz="America/Phoenix"), pa.duration("ms"),
+                pa.time32("s"), pa.time32("ms"), pa.time64("us"), pa.time64("ns"))
+    narrow = (pa.int8(), pa.uint8(), pa.int16(), pa.uint16())
+    def physical(typ):
+        return pa.int32() if typ in (pa.date32(), pa.time32("s"), pa.time32("ms")) else pa.int64()
+    def cases_for(typ):
+        if typ in temporal or typ in narrow:
+            extra = gold["sort_indices_narrow_and_wide"].get(str(typ), [])
+            base = gold["sort_indices_integral"]
+            if emulated:      # (the SIMT emulator takes about a second per sort: the cases with nulls and ties only)
+                base = [c for c in base if len(c["values"]) > 2 and (None in c["values"] or 50 in c["values"])]
+            return base + extra
+        extra = gold["sort_indices_narrow_and_wide"]["int64"] if typ == pa.int64() else []
+        return gold["sort_indices_integral"] + gold["sort_indices_real"] + extra
+    for typ in types + ((temporal[2], narrow[0], narrow[1]) if emulated else temporal + narrow):
         is_f = pa.types.is_floating(typ)
-        for case in gold["sort_indices_integral"] + gold["sort_indices_real"]:
+        for case in cases_for(typ):
             vals = case["values"]
             if not is_f and any(x == "NaN" or (isinstance(x, float) and x != int(x)) for x in vals if x is not None):
                 continue
-            arr = pa.array([None if x is None else (float("nan") if x == "NaN" else x) for x in vals], type=typ)
+            if typ in temporal:
+                arr = pa.array(vals, type=physical(typ)).cast(typ)
+            else:
+                arr = pa.array([None if x is None else (float("nan") if x == "NaN" else x) for x in vals], type=typ)
             # (emulated: the device route only — the host route is the same kernels behind an upload, and the kernel-level
             #  replay of tests/test_emu_parity.py runs every vector on every key type)
             for where in (("device",) if emulated and len(arr) else ("host", "device")):
@@ -858,6 +877,21 @@ GOLDEN_SCRIPT = textwrap.dedent(r'''
                 got = to_host(got) if where == "device" else got
                 assert got.to_pylist() == case["want"], (str(typ), where, case)
                 ran += 1
+    # random 8- / 16-bit keys with nulls, sliced (bit offsets): the device route (widened to 32 bits) against the
+    # reference's counting sort, which host arrays of these types keep — stable, so the indices are identical
+    rng = np.random.default_rng(5)
+    m = 3000 if emulated else 300_000
+    for np_t, typ in ((np.int8, pa.int8()), (np.uint8, pa.uint8()), (np.int16, pa.int16()), (np.uint16, pa.uint16())):
+        info = np.iinfo(np_t)
+        host = pa.array(rng.integers(info.min, info.max, m, dtype=np_t, endpoint=True), typ, mask=rng.random(m) < 0.1)
+        dev = to_device(host)
+        for order, placement in ((("ascending", "at_end"),) if emulated else (("ascending", "at_end"), ("descending", "at_start"), ("descending", "at_end"))):
+            s0 = lib.arrow_amd_plugin_calls(b"array_sort_indices", 0)
+            want = pc.array_sort_indices(host.slice(5, m - 9), order=order, null_placement=placement)
+            assert lib.arrow_amd_plugin_calls(b"array_sort_indices", 0) == s0 + 1, "host int8 / int16 keys keep the reference kernel"
+            got = to_host(pc.array_sort_indices(dev.slice(5, m - 9), order=order, null_placement=placement))
+            assert got.equals(want), (str(typ), order, placement)
+            ran += 1
     used = lib.arrow_amd_plugin_calls(b"array_sort_indices", 1) - g0
     assert ran > (60 if emulated else 300) and used > (60 if emulated else 200), (ran, used)     # the cases really ran on the registered GPU kernel
     # SumOnly through Acero: the registered hash_sum(int64, uint32) vtable (GroupByNode) and the fused aggregate_rocm node

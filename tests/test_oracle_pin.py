@@ -585,6 +585,17 @@ def test_golden_sort_indices(case, dtype):
     assert got.tolist() == case["want"]
 
 
+@pytest.mark.parametrize("name", ["uint8", "int8", "int64"])
+def test_golden_sort_indices_of_the_8_bit_extremes_and_a_wide_int64_range(name):
+    """vector_sort_test.cc:839-885 (SortUInt8 / SortInt8 / SortInt64) on the oracle's argsort; the 8-bit keys as the
+    device route sorts them — widened to 32 bits."""
+    for case in GOLD["sort_indices_narrow_and_wide"][name]:
+        a = golden_sort_array(case["values"], {"uint8": np.uint32, "int8": np.int32, "int64": np.int64}[name])
+        got = O.sort_indices(np.ascontiguousarray(a.values), a.valid_bitmap(), a.offset, a.length,
+                             descending=case["order"] == "descending", nulls_at_start=case["null_placement"] == "at_start")
+        assert got.tolist() == case["want"], case
+
+
 def test_golden_hash_sum_sum_only():
     """acero/hash_aggregate_test.cc:839-883 (SumOnly): three batches, null key = its own group, all-null group -> null."""
     g = GOLD["hash_sum_sum_only"]
