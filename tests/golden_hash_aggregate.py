@@ -166,3 +166,42 @@ def declaration_group_by(factory, use_threads=False):
         ]).to_table(use_threads=use_threads)
         return r.column("key").to_pylist(), [r.column(f"out{j}").to_pylist() for j in range(len(aggs))]
     return run
+
+
+def replay_scalar_arguments(gold, run):
+    """The hash_scalar_arguments section: `run(case, aggs)` gets the case dict (batches with either a "scalar" or an
+    "argument" list beside "key") and the aggregates as (function, options) pairs, and returns (key_list, [output lists])."""
+    ran = 0
+    for case in gold["hash_scalar_arguments"]["cases"]:
+        aggs = [(fn, opts) for fn, opts in case["aggregates"]]
+        keys, outs = run(case, aggs)
+        got = _sorted_rows(keys, outs)
+        want = case["want_sorted_by_key"]
+        assert len(got) == len(want) and all(len(g) == len(w) and all(_close(a, b, 1e-15 if isinstance(b, float) else 0) for a, b in zip(g, w))
+                                             for g, w in zip(got, want)), (case["name"], got)
+        ran += 1
+    return ran
+
+
+def union_of_scalar_batches(factory, use_threads=False):
+    """Acero: every batch is its own table_source; the scalar ones go through a ProjectNode whose literal expression
+    leaves a SCALAR in the ExecBatch (ExecuteScalarExpression), a union joins them, <factory> aggregates."""
+    from pyarrow import acero
+
+    def run(case, aggs):
+        typ = pa.bool_() if case["argument_type"] == "bool" else getattr(pa, case["argument_type"])()
+        inputs = []
+        for b in case["batches"]:
+            if "scalar" in b:
+                src = acero.Declaration("table_source", acero.TableSourceNodeOptions(pa.table({"key": pa.array(b["key"], pa.int64())})))
+                proj = acero.Declaration("project", acero.ProjectNodeOptions([pc.scalar(pa.scalar(b["scalar"], typ)), pc.field("key")],
+                                                                             ["argument", "key"]), [src])
+                inputs.append(proj)
+            else:
+                t = pa.table({"argument": pa.array(b["argument"], typ), "key": pa.array(b["key"], pa.int64())})
+                inputs.append(acero.Declaration("table_source", acero.TableSourceNodeOptions(t)))
+        union = acero.Declaration("union", acero.ExecNodeOptions(), inputs)
+        specs = [("argument", "hash_" + fn, pc_options(opts), f"out{j}") for j, (fn, opts) in enumerate(aggs)]
+        r = acero.Declaration(factory, acero.AggregateNodeOptions(specs, keys=["key"]), [union]).to_table(use_threads=use_threads)
+        return r.column("key").to_pylist(), [r.column(f"out{j}").to_pylist() for j in range(len(aggs))]
+    return run

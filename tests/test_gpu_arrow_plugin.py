@@ -2355,6 +2355,15 @@ GOLDEN_HASH_AGGREGATE_SCRIPT = textwrap.dedent(r'''
             raise SystemExit("hash_mean beyond 2^53 on the device route did not fail")
         except pa.ArrowNotImplementedError as e:
             assert "2^53" in str(e), e
+    # batches whose ARGUMENT is a scalar (CountScalar, SumMeanProductScalar, MinMaxScalar, AnyAllScalar): the registered
+    # vtables' broadcast paths under the stock GroupByNode; aggregate_rocm refuses scalar columns by name
+    for threads in ((False,) if emulated else (False, True)):
+        ran += H.replay_scalar_arguments(gold, H.union_of_scalar_batches("aggregate", threads))
+    try:
+        H.replay_scalar_arguments(gold, H.union_of_scalar_batches("aggregate_rocm"))
+        raise SystemExit("aggregate_rocm took a scalar column")
+    except pa.ArrowNotImplementedError as e:
+        assert "scalar columns" in str(e), e
     # hash_min / hash_max of uint64: the reference kernel on host batches, refused by aggregate_rocm
     try:
         H.replay(gold, H.declaration_group_by("aggregate_rocm"), int_types=[pa.uint64()], sections=["hash_min_max_types"])

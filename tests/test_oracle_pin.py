@@ -939,3 +939,68 @@ def test_golden_compare_and_arithmetic_transcription_holds_on_the_reference_buil
 
     ran = sum(1 for case in S.cases(SCALAR_GOLD) if S.check(case, lambda fn, l, r: pc.call_function(fn, [l, r])) is not None or True)
     assert ran == 1982
+
+
+def _oracle_scalar_argument_batches(case, aggs):
+    """golden_hash_aggregate.replay_scalar_arguments' `run` on the oracle's kernel states: a scalar batch is consumed
+    through the states' `scalar=` form (the reference's ExecSpan with a scalar in slot 0)."""
+    grouper = O.Grouper(1)
+    states = []
+    for fn, opts in aggs:
+        skip = True if opts is None or fn == "count" else opts["skip_nulls"]
+        minc = 1 if opts is None or fn == "count" else opts["min_count"]
+        states.append(O.HashCountState(opts["mode"] if opts else "only_valid") if fn == "count" else
+                      O.HashSumState(skip, minc) if fn in ("sum", "mean") else
+                      O.HashMinMaxState(skip) if fn in ("min", "max") else O.HashBoolState(fn == "all", skip, minc))
+    mean_counts = {}
+    for b in case["batches"]:
+        k = from_list(b["key"], np.int64)
+        ids = grouper.consume([(np.ascontiguousarray(k.values), None)])
+        for (fn, opts), st in zip(aggs, states):
+            st.resize(grouper.num_groups)
+            if "scalar" in b:
+                v, ok = b["scalar"], b["scalar"] is not None
+                if fn == "count":
+                    st.consume(None, 0, ids, scalar_valid=ok)
+                elif fn in ("any", "all"):
+                    st.consume(None, None, 0, ids, scalar=(ok, bool(v)))
+                else:
+                    st.consume(None, None, 0, ids, scalar=(0 if v is None else v, ok))
+            else:
+                xs = b["argument"]
+                if fn == "count":
+                    a = from_list([None if x is None else 0 for x in xs], np.int64)
+                    st.consume(a.valid_bitmap(), 0, ids)
+                elif fn in ("any", "all"):
+                    a = from_list(xs, np.bool_)
+                    st.consume(np.asarray(a.values, bool), a.valid_bitmap(), 0, ids)
+                else:
+                    a = from_list(xs, np.int64)
+                    st.consume(np.ascontiguousarray(a.values), a.valid_bitmap(), 0, ids)
+    (kv, kvalid), = grouper.uniques([np.int64])
+    outs = []
+    for (fn, opts), st in zip(aggs, states):
+        if fn == "count":
+            outs.append(st.counts.tolist())
+        elif fn in ("sum", "mean"):
+            sums, valid, _ = st.finalize()
+            # hash_mean = double(sum) / count while the sums are exact (the int32 values here are tiny)
+            outs.append([(int(s) if fn == "sum" else float(s) / int(c)) if ok else None for s, c, ok in zip(sums, st.counts, valid)])
+        elif fn in ("min", "max"):
+            mins, maxs, valid = st.finalize()
+            outs.append([int(x) if ok else None for x, ok in zip(mins if fn == "min" else maxs, valid)])
+        else:
+            vals, valid = st.finalize()
+            outs.append([bool(x) if ok else None for x, ok in zip(vals, valid)])
+    return [int(v) for v in kv], outs
+
+
+def test_golden_grouped_aggregates_with_scalar_arguments():
+    """acero/hash_aggregate_test.cc CountScalar :799, SumMeanProductScalar :1010, MinMaxScalar :1970, AnyAllScalar :2198 —
+    on the oracle's kernel states (their scalar-broadcast consume) and on the stock wheel (union of projected literals)."""
+    pytest.importorskip("pyarrow")
+    from . import golden_hash_aggregate as H
+
+    assert H.replay_scalar_arguments(GOLD, _oracle_scalar_argument_batches) == 3
+    for threads in (False, True):
+        assert H.replay_scalar_arguments(GOLD, H.union_of_scalar_batches("aggregate", threads)) == 3
