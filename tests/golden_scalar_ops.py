@@ -145,3 +145,37 @@ def check(case, run):
     got = run(case["fn"], case["left"], case["right"])
     assert matches(got, case["want"]), (case["id"], case["cite"], as_list(got), as_list(case["want"]))
     return got
+
+
+def cast_cases(gold):
+    """The cast_numeric section (kernels/scalar_cast_test.cc:269-431): one dict per case with the input array (nulls
+    masked over live values, sliced as the test does), the target type, the CastOptions fields, and `want` (an array)
+    or `fails`."""
+    for c in gold["cast_numeric"]["cases"]:
+        frm, to = getattr(pa, c["from"])(), getattr(pa, c["to"])()
+        vals = c["values"]
+        if "mask_nulls_at" in c:
+            mask = np.zeros(len(vals), dtype=bool)
+            mask[c["mask_nulls_at"]] = True
+            arr = pa.array(np.array(vals, dtype=c["from"]), type=frm, mask=mask)
+        else:
+            arr = pa.array(vals, frm)
+        if "slice" in c:
+            arr = arr.slice(*c["slice"])
+        yield dict(id=f"cast {c['from']} -> {c['to']} {vals} {c.get('options', {})}", cite=c["cite"], input=arr, to=to,
+                   options=c.get("options", {}), fails=c.get("fails", False),
+                   want=None if c.get("fails") else pa.array(c["want"], to))
+
+
+def check_cast(case, run):
+    """run(array, target type, **CastOptions fields) -> array, or raises pa.ArrowInvalid.  Returns the result, or the
+    error text for the failing cases (so that two runners can be held to the same message)."""
+    if case["fails"]:
+        try:
+            got = run(case["input"], case["to"], **case["options"])
+        except pa.ArrowInvalid as e:
+            return str(e)
+        raise AssertionError((case["id"], case["cite"], "did not fail", as_list(got)))
+    got = run(case["input"], case["to"], **case["options"])
+    assert matches(got, case["want"], approx=False), (case["id"], case["cite"], as_list(got), as_list(case["want"]))
+    return got

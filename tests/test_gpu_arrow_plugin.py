@@ -2390,6 +2390,8 @@ GOLDEN_SCALAR_OPS_SCRIPT = textwrap.dedent(r'''
     cases = list(S.cases(gold, scalar_scalar=False))
     # the reference build's own answers, before anything is registered: the transcription holds, and the bits to match
     stock = [S.check(c, lambda fn, l, r: pc.call_function(fn, [l, r])) for c in cases]
+    casts = list(S.cast_cases(gold))
+    stock_casts = [S.check_cast(c, lambda arr, to, **o: pc.cast(arr, options=pc.CastOptions(target_type=to, **o))) for c in casts]
     lib = ctypes.CDLL(path)
     lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
     lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
@@ -2425,6 +2427,18 @@ GOLDEN_SCALAR_OPS_SCRIPT = textwrap.dedent(r'''
     ran = sum(lib.arrow_amd_plugin_calls(f.encode(), 1) - v for f, v in counters.items())
     assert len(cases) == 1950 and ran > 1500 and on_device[0] > 1400, (len(cases), ran, on_device[0])
     assert all(lib.arrow_amd_plugin_calls(f.encode(), 0) == v for f, v in stock_before.items()), "a device operand reached a reference kernel"
+    # the numeric casts (scalar_cast_test.cc:269-431): values bit for bit, and the failing ones with the reference's
+    # message ("Integer value V not in range: LO to HI", "Float value V was truncated converting to T")
+    c0 = lib.arrow_amd_plugin_calls(b"cast", 1)
+    def device_cast(arr, to, **o):
+        out = pc.cast(to_device(arr), options=pc.CastOptions(target_type=to, **o))
+        return to_host(out) if any(b is not None and not b.is_cpu for b in out.buffers()) else out
+    for case, want in zip(casts, stock_casts):
+        got = S.check_cast(case, device_cast)
+        if isinstance(want, str):
+            assert got == want, (case["id"], case["cite"], got, want)
+    # (the counter counts completed device casts: the 20 failing cases and the zero-copy same-type ones are not in it)
+    assert len(casts) == 51 and lib.arrow_amd_plugin_calls(b"cast", 1) - c0 >= 25, (len(casts), lib.arrow_amd_plugin_calls(b"cast", 1) - c0)
     # host arrays keep the reference kernels (below and above min_rows alike for these functions' tiny inputs): same answers
     lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(1 << 20))
     for case in cases[::7]:

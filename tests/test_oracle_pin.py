@@ -1004,3 +1004,15 @@ def test_golden_grouped_aggregates_with_scalar_arguments():
     assert H.replay_scalar_arguments(GOLD, _oracle_scalar_argument_batches) == 3
     for threads in (False, True):
         assert H.replay_scalar_arguments(GOLD, H.union_of_scalar_batches("aggregate", threads)) == 3
+
+
+def test_golden_numeric_casts_transcription_holds_on_the_reference_build():
+    """kernels/scalar_cast_test.cc:269-431 as data (tests/golden/reference_vectors_scalar.json, cast_numeric): the 51
+    cases hold on the stock wheel; the plugin replay (tests/test_gpu_arrow_plugin.py, GOLDEN_SCALAR_OPS_SCRIPT) holds the
+    device route to the same values and the same error texts."""
+    pytest.importorskip("pyarrow")
+    from . import golden_scalar_ops as S
+
+    results = [S.check_cast(c, lambda arr, to, **o: pc.cast(arr, options=pc.CastOptions(target_type=to, **o)))
+               for c in S.cast_cases(SCALAR_GOLD)]
+    assert len(results) == 51 and sum(isinstance(r, str) for r in results) == 20
