@@ -179,3 +179,50 @@ def check_cast(case, run):
     got = run(case["input"], case["to"], **case["options"])
     assert matches(got, case["want"], approx=False), (case["id"], case["cite"], as_list(got), as_list(case["want"]))
     return got
+
+
+def aggregate_cases(gold, types=None):
+    """The scalar_aggregates section (kernels/aggregate_test.cc): one dict per (case, type) with fn, the input as a list
+    of chunks (pyarrow arrays of the type under test), the options (a pyarrow options object or None) and `want` (a
+    pyarrow scalar: int64 / uint64 / double sums, int64 counts, double means, {min, max} structs)."""
+    import pyarrow.compute as pc
+
+    sec = gold["scalar_aggregates"]
+    names = [n for n in SIGNED + UNSIGNED + FLOATING if types is None or n in types]
+
+    def opts(o):
+        return None if o is None else pc.ScalarAggregateOptions(**o)
+
+    for name in names:
+        typ = getattr(pa, name)()
+        is_f, is_u = name in FLOATING, name in UNSIGNED
+        sum_type = pa.float64() if is_f else pa.uint64() if is_u else pa.int64()
+        for c in sec["sum"]:
+            yield dict(id=f"sum {name} {c['chunks']} {c['options']}", cite=c["cite"], fn="sum", chunks=[pa.array(x, typ) for x in c["chunks"]],
+                       type=typ, options=opts(c["options"]), want=pa.scalar(c["want"], sum_type))
+        for c in sec["count"]:
+            for mode, want in (("only_valid", c["want"][0]), ("only_null", c["want"][1]), ("all", sum(c["want"]))):
+                yield dict(id=f"count {mode} {name} {c['values']}", cite=c["cite"], fn="count", chunks=[pa.array(c["values"], typ)], type=typ,
+                           options=pc.CountOptions(mode=mode), want=pa.scalar(want, pa.int64()))
+        for c in sec["mean"]:
+            want = float("nan") if c["want"] == "NaN" else c["want"]
+            yield dict(id=f"mean {name} {c['chunks']} {c['options']}", cite=c["cite"], fn="mean", chunks=[pa.array(x, typ) for x in c["chunks"]],
+                       type=typ, options=opts(c["options"]), want=pa.scalar(want, pa.float64()))
+        if not is_f:
+            st = pa.struct([("min", typ), ("max", typ)])
+            for c in sec["min_max"]:
+                w = {"min": None, "max": None} if c["want"] is None else {"min": c["want"][0], "max": c["want"][1]}
+                yield dict(id=f"min_max {name} {c['chunks']} {c['options']}", cite=c["cite"], fn="min_max",
+                           chunks=[pa.array(x, typ) for x in c["chunks"]], type=typ, options=opts(c["options"]), want=pa.scalar(w, st))
+
+
+def check_aggregate(case, run):
+    """run(fn, chunked_array, options) -> pyarrow scalar."""
+    got = run(case["fn"], pa.chunked_array(case["chunks"], case["type"]), case["options"])
+    want = case["want"]
+    if case["fn"] == "min_max":
+        ok = got.type == want.type and got.as_py() == want.as_py()
+    else:
+        ok = got.type == want.type and _same_value(got.as_py(), want.as_py(), False, 0)
+    assert ok, (case["id"], case["cite"], got, want)
+    return got

@@ -173,6 +173,7 @@ HASH_KERNELS_SCRIPT = textwrap.dedent(r'''
              ("v", "hash_count", None, "c"), ("v", "hash_count", pc.CountOptions(mode="only_null"), "cn"),
              ("v", "hash_sum", None, "sm"), ("i32", "hash_sum", None, "s32"), ("u64", "hash_sum", None, "s64"),
              ("i32", "hash_min", None, "mn32"), ("i32", "hash_max", None, "mx32"), ("i32", "hash_mean", None, "me32"),
+             ("u64", "hash_min", None, "mn64"), ("u64", "hash_max", strict, "mx64"),     # (full-range uint64: on x + 2^63 as int64)
              ("bt", "hash_any", None, "any"), ("bt", "hash_all", strict, "all")]
     def plan(tab):
         return acero.Declaration.from_sequence([
@@ -371,6 +372,7 @@ GENERAL_GROUP_BY_SCRIPT = textwrap.dedent(r'''
         "i16": pa.array(rng.integers(-2**15, 2**15, n).astype(np.int16), mask=rng.random(n) < 0.1),
         "u32": pa.array(rng.integers(0, 2**32, n).astype(np.uint32), mask=rng.random(n) < 0.3),
         "u64": pa.array(rng.integers(0, 2**64, n, dtype=np.uint64), mask=rng.random(n) < 0.1),
+        "u64s": pa.array(rng.integers(0, 2**36, n, dtype=np.uint64), mask=rng.random(n) < 0.1),      # (means stay exact)
         # booleans for hash_any / hash_all: rarely true with nulls, almost always true without (so both outcomes occur per group)
         "rare": pa.array(rng.random(n) < 0.01, mask=rng.random(n) < 0.1),
         "sure": pa.array(rng.random(n) < 0.97),
@@ -388,7 +390,8 @@ GENERAL_GROUP_BY_SCRIPT = textwrap.dedent(r'''
         (["a"], [("v", "hash_sum", None, "s"), ("w", "hash_sum", None, "sw")]),      # int32 key but two value columns: not the fused operator's case
         (["a", "c"], [("i16", "hash_sum", None, "s16"), ("i16", "hash_min", None, "mn16"), ("i16", "hash_max", strict, "mx16"), ("i16", "hash_mean", None, "me16"),
                       ("u32", "hash_sum", strict, "s32"), ("u32", "hash_min", None, "mn32"), ("u32", "hash_max", None, "mx32"), ("u32", "hash_mean", strict, "me32"),
-                      ("u64", "hash_sum", None, "s64")]),
+                      ("u64", "hash_sum", None, "s64"), ("u64", "hash_min", None, "mn64"), ("u64", "hash_max", strict, "mx64"),
+                      ("u64s", "hash_mean", None, "me64"), ("u64s", "hash_min", strict, "mn64s")]),
     ]
     def run(tab, node, keys, aggs):
         return acero.Declaration.from_sequence([
@@ -429,8 +432,7 @@ GENERAL_GROUP_BY_SCRIPT = textwrap.dedent(r'''
     assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - g0 >= 3 * len(plans), "aggregate_rocm did not run the device Grouper"
     # keys wider than the device Grouper's 16-byte rows, and value types it does not take: refused by name
     for keys, aggs, needle in ((["k64", "a", "d", "b"], [("v", "hash_sum", None, "s")], "16 bytes"),
-                               (["a", "b"], [("flag", "hash_sum", None, "s")], "integer values"),
-                               (["a", "b"], [("u64", "hash_max", None, "s")], "uint64 only for hash_sum")):
+                               (["a", "b"], [("flag", "hash_sum", None, "s")], "integer values")):
         try:
             run(t, "aggregate_rocm", keys, aggs)
             raise SystemExit("aggregate_rocm accepted " + str(keys))
@@ -1681,7 +1683,7 @@ AGGREGATE_SCRIPT = textwrap.dedent(r'''
         h_arr = pa.array(rng.integers(lo, hi, n // 3).astype(np_t), mask=rng.random(n // 3) < 0.1)
         d_arr = to_device(h_arr)
         for opts in (None, pc.ScalarAggregateOptions(skip_nulls=False), pc.ScalarAggregateOptions(min_count=len(h_arr))):
-            for fn in ("sum", "min_max", "min", "max"):
+            for fn in ("sum", "min_max", "min", "max", "mean"):      # (mean: count x max|value| stays below 2^53 here)
                 g, w = pc.call_function(fn, [d_arr], opts), pc.call_function(fn, [h_arr], opts)
                 assert g.equals(w) and g.type == w.type, (str(h_arr.type), fn, opts, g, w)
         assert pc.min_max(d_arr.slice(7, 1000)).equals(pc.min_max(h_arr.slice(7, 1000)))
@@ -1690,6 +1692,10 @@ AGGREGATE_SCRIPT = textwrap.dedent(r'''
     u64 = pa.array(rng.integers(0, 2**64, n // 3, dtype=np.uint64), mask=rng.random(n // 3) < 0.1)
     d_u64 = to_device(u64)
     assert pc.sum(d_u64).equals(pc.sum(u64)) and pc.count(d_u64).equals(pc.count(u64))      # (wraps modulo 2^64 like the reference)
+    # the extrema of full-range uint64 (reduced as x + 2^63 read as int64) and the mean of small ones (exact below 2^53)
+    assert pc.min_max(d_u64).equals(pc.min_max(u64)) and pc.min(d_u64).equals(pc.min(u64)) and pc.max(d_u64).equals(pc.max(u64))
+    u64s = pa.array(rng.integers(0, 2**30, n // 3, dtype=np.uint64), mask=rng.random(n // 3) < 0.1)
+    assert pc.mean(to_device(u64s)).equals(pc.mean(u64s)) and pc.mean(to_device(u64s.slice(7, 1001))).equals(pc.mean(u64s.slice(7, 1001)))
     chunks = pa.chunked_array([to_device(vals.slice(0, 1000)), to_device(vals.slice(1000))])       # merge of per-batch states
     assert pc.sum(chunks).equals(pc.sum(vals)) and pc.min_max(chunks).equals(pc.min_max(vals))
     assert lib.arrow_amd_plugin_calls(b"reduce", 1) > red0 + 80
@@ -2332,7 +2338,6 @@ GOLDEN_HASH_AGGREGATE_SCRIPT = textwrap.dedent(r'''
         ]).to_table(use_threads=False)
         return r.column("key").to_pylist(), [r.column(f"out{j}").to_pylist() for j in range(len(aggs))]
 
-    signed_and_narrow = [pa.int8(), pa.uint8(), pa.int16(), pa.uint16(), pa.int32(), pa.uint32(), pa.int64()]
     exact = [s for s in H.SECTIONS if s != "hash_mean_overflow"]
     g0, s0 = lib.arrow_amd_plugin_calls(b"hash_sum", 1), lib.arrow_amd_plugin_calls(b"hash_sum", 0)
     # 1. host tables under the stock GroupByNode: Table.group_by (serial and threaded/merged) and the "aggregate" node;
@@ -2341,12 +2346,12 @@ GOLDEN_HASH_AGGREGATE_SCRIPT = textwrap.dedent(r'''
     for threads in ((False,) if emulated else (False, True)):
         ran += H.replay(gold, H.stock_group_by(threads), key_types=(pa.int64(), pa.int32()))
         ran += H.replay(gold, H.declaration_group_by("aggregate", threads))
-    # 2. device-resident value columns under the stock GroupByNode (uint64 min / max stay with the reference kernel: host only)
-    ran += H.replay(gold, device_values_stock(False), int_types=signed_and_narrow, sections=exact)
+    # 2. device-resident value columns under the stock GroupByNode (every integer type, uint64 included)
+    ran += H.replay(gold, device_values_stock(False), sections=exact)
     # 3. aggregate_rocm: host batches and device-resident batches; int64 keys (the general node) and int32 keys (the fused
     #    int32 -> int64 operator takes the sum / mean / min / max / count cases, the general node the rest)
-    ran += H.replay(gold, H.declaration_group_by("aggregate_rocm"), key_types=(pa.int64(), pa.int32()), int_types=signed_and_narrow, sections=exact)
-    ran += H.replay(gold, device_fused, key_types=(pa.int64(), pa.int32()), int_types=signed_and_narrow, sections=exact)
+    ran += H.replay(gold, H.declaration_group_by("aggregate_rocm"), key_types=(pa.int64(), pa.int32()), sections=exact)
+    ran += H.replay(gold, device_fused, key_types=(pa.int64(), pa.int32()), sections=exact)
     assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - g0 > 150, "the replay did not reach the HIP kernels"
     # MeanOverflow off the host route: partial sums beyond 2^53 are refused loudly, not approximated
     for run in (device_values_stock(False), H.declaration_group_by("aggregate_rocm"), device_fused):
@@ -2364,12 +2369,6 @@ GOLDEN_HASH_AGGREGATE_SCRIPT = textwrap.dedent(r'''
         raise SystemExit("aggregate_rocm took a scalar column")
     except pa.ArrowNotImplementedError as e:
         assert "scalar columns" in str(e), e
-    # hash_min / hash_max of uint64: the reference kernel on host batches, refused by aggregate_rocm
-    try:
-        H.replay(gold, H.declaration_group_by("aggregate_rocm"), int_types=[pa.uint64()], sections=["hash_min_max_types"])
-        raise SystemExit("aggregate_rocm took hash_min(uint64)")
-    except pa.ArrowNotImplementedError as e:
-        assert "uint64" in str(e), e
     print("GOLDEN_HASH_AGGREGATE_OK", ran)
 ''')
 
@@ -2390,6 +2389,8 @@ GOLDEN_SCALAR_OPS_SCRIPT = textwrap.dedent(r'''
     cases = list(S.cases(gold, scalar_scalar=False))
     # the reference build's own answers, before anything is registered: the transcription holds, and the bits to match
     stock = [S.check(c, lambda fn, l, r: pc.call_function(fn, [l, r])) for c in cases]
+    aggs = list(S.aggregate_cases(gold, types=S.SIGNED + S.UNSIGNED))
+    stock_aggs = [S.check_aggregate(c, lambda fn, x, o: pc.call_function(fn, [x], o)) for c in aggs]
     casts = list(S.cast_cases(gold))
     stock_casts = [S.check_cast(c, lambda arr, to, **o: pc.cast(arr, options=pc.CastOptions(target_type=to, **o))) for c in casts]
     lib = ctypes.CDLL(path)
@@ -2439,6 +2440,26 @@ GOLDEN_SCALAR_OPS_SCRIPT = textwrap.dedent(r'''
             assert got == want, (case["id"], case["cite"], got, want)
     # (the counter counts completed device casts: the 20 failing cases and the zero-copy same-type ones are not in it)
     assert len(casts) == 51 and lib.arrow_amd_plugin_calls(b"cast", 1) - c0 >= 25, (len(casts), lib.arrow_amd_plugin_calls(b"cast", 1) - c0)
+    # the scalar aggregates (aggregate_test.cc: SimpleSum / SimpleCount / SimpleMean / integer MinMax with their options)
+    # over device-resident chunks of every integer type; an empty chunk has nothing to upload and adds nothing
+    r0 = lib.arrow_amd_plugin_calls(b"reduce", 1)
+    def device_aggregate(fn, chunked, options):
+        chunks = [to_device(c) if len(c) else c for c in chunked.chunks]
+        return pc.call_function(fn, [pa.chunked_array(chunks, chunked.type)], options)
+    for case, want in zip(aggs, stock_aggs):
+        got = S.check_aggregate(case, device_aggregate)
+        assert got.type == want.type and (got.equals(want) or (got.as_py() != got.as_py() and want.as_py() != want.as_py())), (case["id"], got, want)
+    assert len(aggs) == 8 * (21 + 15 + 25 + 18) and lib.arrow_amd_plugin_calls(b"reduce", 1) - r0 > 400, (len(aggs), lib.arrow_amd_plugin_calls(b"reduce", 1) - r0)
+    # TestNumericMeanKernel.Overflow (:1349): exact on the host route (the reference kernel), refused on the device route
+    mo = gold["scalar_aggregates"]["mean_overflow"]
+    for name in mo["types"]:
+        arr = pa.array(mo["values"], getattr(pa, name)())
+        assert abs(pc.mean(arr).as_py() / mo["want"] - 1) < 1e-15
+        try:
+            pc.mean(to_device(arr))
+            raise SystemExit("mean beyond 2^53 on device values did not fail")
+        except pa.ArrowNotImplementedError as e:
+            assert "2^53" in str(e), e
     # host arrays keep the reference kernels (below and above min_rows alike for these functions' tiny inputs): same answers
     lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(1 << 20))
     for case in cases[::7]:
