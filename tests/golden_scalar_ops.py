@@ -226,3 +226,28 @@ def check_aggregate(case, run):
         ok = got.type == want.type and _same_value(got.as_py(), want.as_py(), False, 0)
     assert ok, (case["id"], case["cite"], got, want)
     return got
+
+
+def boolean_cases(gold):
+    """The boolean_kleene section (kernels/scalar_boolean_test.cc): (function, [operands], want) — the array x array
+    cases as written, and every left array against each boolean scalar on either side, where the expectation is the
+    function applied to the scalar broadcast to an array (CheckBooleanScalarArrayBinary) — computed here from the
+    Kleene truth table, so that it does not depend on the build under test."""
+    sec = gold["boolean_kleene"]
+    for c in sec["invert"]:
+        yield "invert", [pa.array(c["values"], pa.bool_())], pa.array(c["want"], pa.bool_())
+
+    def kleene(fn, a, b):
+        if fn == "and_kleene":
+            return False if (a is False or b is False) else (None if (a is None or b is None) else True)
+        return True if (a is True or b is True) else (None if (a is None or b is None) else False)
+
+    for fn in ("and_kleene", "or_kleene"):
+        for c in sec[fn]:
+            left, right = pa.array(c["left"], pa.bool_()), pa.array(c["right"], pa.bool_())
+            assert [kleene(fn, a, b) for a, b in zip(c["left"], c["right"])] == c["want"]      # (the table agrees with the transcription)
+            yield fn, [left, right], pa.array(c["want"], pa.bool_())
+            for sv in (None, True, False):
+                sc = pa.scalar(sv, pa.bool_())
+                yield fn, [sc, left], pa.array([kleene(fn, sv, a) for a in c["left"]], pa.bool_())
+                yield fn, [left, sc], pa.array([kleene(fn, a, sv) for a in c["left"]], pa.bool_())

@@ -2460,6 +2460,15 @@ GOLDEN_SCALAR_OPS_SCRIPT = textwrap.dedent(r'''
             raise SystemExit("mean beyond 2^53 on device values did not fail")
         except pa.ArrowNotImplementedError as e:
             assert "2^53" in str(e), e
+    # Kleene logic and invert (scalar_boolean_test.cc:54-152), every array also against each boolean scalar on either side
+    b0 = lib.arrow_amd_plugin_calls(b"boolean", 1)
+    nb = 0
+    for fn, args, want in S.boolean_cases(gold):
+        got = pc.call_function(fn, [to_device(x) if isinstance(x, pa.Array) else x for x in args])
+        got = to_host(got) if any(b is not None and not b.is_cpu for b in got.buffers()) else got
+        assert got.equals(want), (fn, [S.as_list(x) for x in args], S.as_list(got), S.as_list(want))
+        nb += 1
+    assert nb == 43 and lib.arrow_amd_plugin_calls(b"boolean", 1) - b0 == 43, (nb, lib.arrow_amd_plugin_calls(b"boolean", 1) - b0)
     # host arrays keep the reference kernels (below and above min_rows alike for these functions' tiny inputs): same answers
     lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(1 << 20))
     for case in cases[::7]:

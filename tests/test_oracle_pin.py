@@ -1016,3 +1016,24 @@ def test_golden_numeric_casts_transcription_holds_on_the_reference_build():
     results = [S.check_cast(c, lambda arr, to, **o: pc.cast(arr, options=pc.CastOptions(target_type=to, **o)))
                for c in S.cast_cases(SCALAR_GOLD)]
     assert len(results) == 51 and sum(isinstance(r, str) for r in results) == 20
+
+
+def test_golden_kleene_logic_on_the_oracle_and_the_reference_build():
+    """kernels/scalar_boolean_test.cc:54-152 (Invert, KleeneAnd, KleeneOr and their scalar forms): O.kleene and the stock
+    wheel against the transcription."""
+    pytest.importorskip("pyarrow")
+    from . import golden_scalar_ops as S
+
+    ran = 0
+    for fn, args, want in S.boolean_cases(SCALAR_GOLD):
+        assert pc.call_function(fn, args).equals(want), (fn, args)
+        if fn != "invert":
+            n = len(want)
+            cols = []
+            for x in args:
+                xs = x.to_pylist() if isinstance(x, pa.Array) else [x.as_py()] * n
+                cols.append((np.array([bool(v) for v in xs]), np.array([v is not None for v in xs])))
+            data, valid = O.kleene("and" if fn == "and_kleene" else "or", cols[0][0], cols[0][1], cols[1][0], cols[1][1])
+            assert [bool(d) if v else None for d, v in zip(data, valid)] == want.to_pylist(), (fn, args)
+        ran += 1
+    assert ran == 43
