@@ -99,6 +99,7 @@ namespace {
 #include "plugin/acero_source.inc"
 #include "plugin/acero_coalesce.inc"
 #include "plugin/parquet.inc"
+#include "plugin/device_guard.inc"
 #include "plugin/registration.inc"
 
 }  // namespace

