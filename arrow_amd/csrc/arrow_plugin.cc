@@ -100,6 +100,7 @@ namespace {
 #include "plugin/acero_coalesce.inc"
 #include "plugin/parquet.inc"
 #include "plugin/device_guard.inc"
+#include "plugin/validity.inc"
 #include "plugin/registration.inc"
 
 }  // namespace

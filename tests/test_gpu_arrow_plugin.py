@@ -2551,6 +2551,46 @@ DEVICE_GUARD_SCRIPT = textwrap.dedent(r'''
                     assert tn.split("[")[0] in got or str(arr.type) in got, (fn, tn, got)
                 refused += 1
     assert done > 150 and refused > 60, (done, refused)
+    # 3. is_valid / is_null / true_unless_null (plugin/validity.inc): the reference's kernels see no validity bitmap in a
+    #    device-resident array and answer "no nulls" — silently; the twins answer from the bitmap in HBM, result in HBM
+    def to_host(arr):
+        c_dev, c_schema, c_arr = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72), ctypes.create_string_buffer(80)
+        arr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, None) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), arr.type)
+    rng = np.random.default_rng(3)
+    m = 70_001
+    big = pa.array(rng.integers(-9, 9, m), mask=rng.random(m) < 0.3)
+    vcases = dict(types, big=big, no_nulls=pa.array(np.arange(1000)), f64=pa.array([1.0, float("nan"), None, 2.0]))
+    b0 = lib.arrow_amd_plugin_calls(b"boolean", 1)
+    for name, arr in vcases.items():
+        d = to_device(arr)
+        for fn in ("is_valid", "is_null", "true_unless_null"):
+            for host, dev in ((arr, d), (arr.slice(3, max(len(arr) - 4, 1)), d.slice(3, max(len(arr) - 4, 1)))):
+                got = pc.call_function(fn, [dev])
+                assert all(not b.is_cpu for b in got.buffers() if b is not None), (fn, name, "the result should stay in HBM")
+                assert to_host(got).equals(pc.call_function(fn, [host])), (fn, name)
+    assert lib.arrow_amd_plugin_calls(b"boolean", 1) - b0 == 6 * len(vcases)
+    # a plan over a device-resident table: filter(is_valid(v) and not is_null(k)) keeps exactly the rows the host plan keeps
+    from pyarrow import acero
+    tab = pa.table({"v": big, "k": pa.array(rng.integers(0, 5, m), mask=rng.random(m) < 0.1), "x": pa.array(rng.random(m))})
+    dtab = pa.Table.from_batches([pa.RecordBatch.from_arrays([to_device(tab.column(j).chunk(0)) for j in range(3)], names=tab.schema.names)])
+    pred = pc.field("v").is_valid() & ~pc.field("k").is_null()
+    def plan(source, t):
+        return acero.Declaration.from_sequence([acero.Declaration(source, acero.TableSourceNodeOptions(t)),
+                                                acero.Declaration("filter", acero.FilterNodeOptions(pred))]).to_table(use_threads=False)
+    want = plan("table_source", tab)
+    got = plan("table_source_rocm", dtab)
+    got = pa.table({n: pa.chunked_array([to_host(c) for c in got.column(n).chunks], got.schema.field(n).type) for n in got.schema.names})
+    assert 0 < want.num_rows < m and got.equals(want), (got.num_rows, want.num_rows)
+    # refused by name on the device route: nulls that are not the validity bitmap, NaN as null
+    for arr, kw, needle in ((pa.RunEndEncodedArray.from_arrays(pa.array([2, 3], pa.int32()), pa.array([1, None], pa.int64())), {}, "not its validity bitmap"),
+                            (pa.array([1.0, float("nan"), None]), {"nan_is_null": True}, "nan_is_null")):
+        try:
+            pc.is_null(to_device(arr), **kw)
+            raise SystemExit("is_null took " + str(arr.type) + str(kw))
+        except pa.ArrowNotImplementedError as e:
+            assert needle in str(e), e
     print("DEVICE_GUARD_OK", done, refused)
 ''')
 
