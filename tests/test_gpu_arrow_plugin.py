@@ -2546,8 +2546,7 @@ DEVICE_GUARD_SCRIPT = textwrap.dedent(r'''
             else:
                 host_kind, host_err = before[(fn, tn)]
                 assert host_kind == "err" or "arrow_amd" in got, (fn, tn, got)      # (errors the reference raises for host arrays too are fine)
-                if "no device kernel is registered" in got:
-                    assert fn.split("_scalar")[0].replace("sort_indices", "array_sort_indices").replace("array_array_", "array_") in got or True
+                if "no device kernel is registered" in got:      # (the guard names the type it refused)
                     assert tn.split("[")[0] in got or str(arr.type) in got, (fn, tn, got)
                 refused += 1
     assert done > 150 and refused > 60, (done, refused)
