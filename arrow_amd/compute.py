@@ -1865,25 +1865,14 @@ def value_counts(arr: Array, capacity: int | None = None):
     return _first_occurrence_groups(arr, capacity, True)
 
 
-class Grouper:
-    """arrow::compute::Grouper (compute/row/grouper.h:104-137) over key columns that live in HBM: `consume(batch)`
-    -> uint32 group ids (:121), `lookup` (:126; unseen keys -> null), `populate` (:130), `get_uniques` (:134),
-    `num_groups` (:137), `reset` (:115).  Key rows = one or several fixed-width columns (byte widths 1, 2, 4, 8; at
-    most 8 columns and 16 bytes per row), compared by their bits with null as a key value of its own, as the
-    reference's row encoder does (GrouperFastImpl, row/grouper.cc:555-973).  The k-th distinct key row in row
-    order gets id k.  `max_groups` bounds the distinct rows over the Grouper's life."""
+class _GrouperLevel:
+    """One device table of csrc/grouper.hip: key rows of up to 8 fixed-width columns and 16 bytes (`Grouper` below
+    chains several of these for wider rows)."""
 
     def __init__(self, key_types, max_groups: int, device=None):
         from .array import default_device
 
         self.key_types = list(key_types)
-        if not 1 <= len(self.key_types) <= 8:
-            raise ArrowNotImplementedError(f"Grouper: 1 to 8 key columns (got {len(self.key_types)})")
-        for t in self.key_types:
-            if t.bit_width not in (8, 16, 32, 64):
-                raise ArrowNotImplementedError(f"Grouper: keys of type {t.name}")
-        if builtins.sum(t.byte_width for t in self.key_types) > 16:
-            raise ArrowNotImplementedError("Grouper: the key columns take more than 16 bytes per row")
         self.device = torch.device(device) if device is not None else default_device()
         self.max_groups = max(1, int(max_groups))
         self._widths = (C.c_int32 * len(self.key_types))(*[t.byte_width for t in self.key_types])
@@ -1891,11 +1880,6 @@ class Grouper:
         self.state = alloc(lib.arx_grouper_state_bytes(self.max_groups) + 256, self.device)
         self._state_ptr = (self.state.data_ptr() + 255) & ~255
         check(lib.arx_grouper_init(self._state_ptr, self.max_groups, stream))
-
-    @classmethod
-    def make(cls, key_types, max_groups: int, device=None) -> "Grouper":
-        """Grouper::Make (:110)."""
-        return cls(key_types, max_groups, device)
 
     def reset(self) -> None:
         lib, stream = _lib_and_stream(self.device)
@@ -1960,6 +1944,117 @@ class Grouper:
                                               data.data_ptr(), valid.data_ptr(), C.byref(nulls), stream))
             out.append(Array(t, g, [valid if nulls.value else None, data], nulls.value, 0))
         return ExecBatch(out, g)
+
+
+kGrouperLevelBytes = 16   # csrc/grouper.hip: one table holds key rows of up to 16 bytes ...
+kGrouperLevelKeys = 8     # ... and 8 columns
+
+
+def _grouper_levels(widths):
+    """Key columns -> the levels of the chain: level 0 takes columns while they fit 16 bytes / 8 columns, every later
+    level takes the previous level's uint32 group id (4 bytes, never null) plus the columns that fit beside it."""
+    levels, cur, used = [], [], 0
+    for j, w in enumerate(widths):
+        if cur and (used + w > kGrouperLevelBytes or len(cur) + (1 if levels else 0) >= kGrouperLevelKeys):
+            levels.append(cur)
+            cur, used = [], 4
+        cur.append(j)
+        used += w
+    levels.append(cur)
+    return levels
+
+
+class Grouper:
+    """arrow::compute::Grouper (compute/row/grouper.h:104-137) over key columns that live in HBM: `consume(batch)`
+    -> uint32 group ids (:121), `lookup` (:126; unseen keys -> null), `populate` (:130), `get_uniques` (:134),
+    `num_groups` (:137), `reset` (:115).  Key rows = one or several fixed-width columns (byte widths 1, 2, 4, 8),
+    compared by their bits with null as a key value of its own, as the reference's row encoder does (GrouperFastImpl,
+    row/grouper.cc:555-973; any number of fixed-width columns, :559-611).  The k-th distinct key row in row order gets
+    id k.  `max_groups` bounds the distinct rows over the Grouper's life.
+
+    One device table holds rows of up to 16 bytes (32-byte slots, csrc/grouper.hip).  Wider rows go through a CHAIN of
+    tables instead of wider slots: level 0 maps the first columns to ids, level s maps (id of level s-1, next columns) —
+    a 4-byte id stands for everything to its left, so every slot stays 32 bytes whatever the row width, and the ids of
+    the last level are the ids of the whole row, in order of first appearance (a row's tuple (prefix id, columns)
+    appears first exactly where the row does).  GetUniques walks back: level s keeps its groups' level s-1 ids, so the
+    columns of level s are gathered through the composed id maps (`take`)."""
+
+    def __init__(self, key_types, max_groups: int, device=None):
+        from .array import default_device
+
+        self.key_types = list(key_types)
+        if not 1 <= len(self.key_types) <= 32:
+            raise ArrowNotImplementedError(f"Grouper: 1 to 32 key columns (got {len(self.key_types)})")
+        for t in self.key_types:
+            if t.bit_width not in (8, 16, 32, 64):
+                raise ArrowNotImplementedError(f"Grouper: keys of type {t.name}")
+        self.device = torch.device(device) if device is not None else default_device()
+        self.max_groups = max(1, int(max_groups))
+        self._level_cols = _grouper_levels([t.byte_width for t in self.key_types])
+        self._levels = []
+        for s, cols in enumerate(self._level_cols):
+            types = ([uint32] if s else []) + [self.key_types[j] for j in cols]
+            self._levels.append(_GrouperLevel(types, self.max_groups, self.device))
+
+    @classmethod
+    def make(cls, key_types, max_groups: int, device=None) -> "Grouper":
+        """Grouper::Make (:110)."""
+        return cls(key_types, max_groups, device)
+
+    @property
+    def num_levels(self) -> int:
+        return len(self._levels)
+
+    def reset(self) -> None:
+        for lv in self._levels:
+            lv.reset()
+
+    def _check(self, batch):
+        cols = list(batch.values) if isinstance(batch, ExecBatch) else list(batch)
+        if len(cols) != len(self.key_types):
+            raise ArrowInvalid(f"Grouper: expected {len(self.key_types)} key columns, got {len(cols)}")
+        n = cols[0].length
+        for c, t in zip(cols, self.key_types):
+            if c.type != t:
+                raise ArrowInvalid(f"Grouper: key column of type {c.type.name}, expected {t.name}")
+            if c.length != n:
+                raise ArrowInvalid("Array arguments must all be the same length")
+        return cols
+
+    def _run(self, batch, lookup: bool):
+        cols = self._check(batch)
+        ids = None
+        for lv, idx in zip(self._levels, self._level_cols):
+            # a Lookup's unseen prefix is a null id: no consumed row has one, so the next level does not find it either
+            part = ([ids] if ids is not None else []) + [cols[j] for j in idx]
+            ids = lv._run(part, lookup)
+        return ids
+
+    def consume(self, batch) -> Array:
+        return self._run(batch, lookup=False)
+
+    def lookup(self, batch) -> Array:
+        return self._run(batch, lookup=True)
+
+    def populate(self, batch) -> None:
+        self._run(batch, lookup=False)
+
+    @property
+    def num_groups(self) -> int:
+        return self._levels[-1].num_groups
+
+    def get_uniques(self):
+        """The unique key rows as one Array per key column, in group-id order."""
+        out = [None] * len(self.key_types)
+        to_level = None   # final group id -> group id of the level at hand (None: the identity, at the last level)
+        for s in range(len(self._levels) - 1, -1, -1):
+            u = self._levels[s].get_uniques().values
+            own = u[1:] if s else u
+            for j, a in zip(self._level_cols[s], own):
+                out[j] = a if to_level is None else take(a, to_level, boundscheck=False)
+            if s:
+                to_level = u[0] if to_level is None else take(u[0], to_level, boundscheck=False)
+        return ExecBatch(out, self.num_groups)
 
 
 _GROUP_BY_AGGREGATES = ("hash_sum", "hash_count", "hash_mean")

@@ -1341,6 +1341,49 @@ def check_grouper(amd, rng, dtypes, n, cardinality, null_p=0.0, batches=1, max_g
     return g
 
 
+def check_grouper_chain(amd):
+    """Key rows wider than one 16-byte table go through a chain of tables (arrow_amd.compute.Grouper): how the columns
+    are split, and Lookups of rows whose PREFIX is known but whose tail is not (and the other way round) — a level's
+    null id must make every later level miss."""
+    from arrow_amd.array import int64, int32, uint8
+    from arrow_amd.compute import _grouper_levels
+
+    assert _grouper_levels([8]) == [[0]] and _grouper_levels([8, 8]) == [[0, 1]]
+    assert _grouper_levels([8, 8, 8]) == [[0, 1], [2]]
+    assert _grouper_levels([8, 8, 8, 4, 8]) == [[0, 1], [2, 3], [4]]          # 4 + 8 + 4 = 16 fits, + 8 does not
+    assert _grouper_levels([1] * 20) == [list(range(8)), list(range(8, 15)), list(range(15, 20))]   # 8 columns a table
+    g = amd.compute.Grouper([int64, int64, int32, uint8], 64)
+    assert g.num_levels == 2
+
+    def up(rows, valid=None):
+        cols = [np.array([r[j] for r in rows], dtype=dt) for j, dt in enumerate((np.int64, np.int64, np.int32, np.uint8))]
+        return [amd.Array.from_numpy(c, None if valid is None else np.array([v[j] for v in valid])) for j, c in enumerate(cols)]
+
+    rows = [(1, 2, 3, 4), (1, 2, 3, 5), (9, 2, 3, 4), (1, 2, 3, 4), (9, 2, 3, 4), (1, 2, 7, 4)]
+    assert _data_np(g.consume(up(rows)), np.uint32).tolist() == [0, 1, 2, 0, 2, 3]
+    assert g.num_groups == 4
+    probes = [(1, 2, 3, 4), (1, 2, 3, 6), (8, 2, 3, 4), (9, 2, 3, 5), (9, 2, 3, 4), (1, 2, 7, 4), (2, 1, 7, 4)]
+    out = g.lookup(up(probes))
+    found, pad_ok = _logical_valid(out)
+    assert pad_ok and found.tolist() == [True, False, False, False, True, True, False]
+    assert _data_np(out, np.uint32)[found].tolist() == [0, 2, 3]
+    assert g.num_groups == 4
+    # a null is a key value of its own at every level; the second batch continues the numbering
+    more = [(1, 2, 3, 4), (1, 0, 3, 4), (1, 0, 3, 4), (0, 2, 3, 0), (1, 2, 3, 0)]
+    valid = [(1, 1, 1, 1), (1, 0, 1, 1), (1, 0, 1, 1), (0, 1, 1, 0), (1, 1, 1, 0)]
+    valid = [tuple(bool(x) for x in v) for v in valid]
+    assert _data_np(g.consume(up(more, valid)), np.uint32).tolist() == [0, 4, 4, 5, 6]
+    uniq = g.get_uniques()
+    want_rows = rows[:3] + [rows[5]] + more[1:2] + more[3:]
+    want_valid = [(True,) * 4] * 4 + [valid[1], valid[3], valid[4]]
+    for j, (arr, dt) in enumerate(zip(uniq.values, (np.int64, np.int64, np.int32, np.uint8))):
+        uv, pad_ok = _logical_valid(arr)
+        assert pad_ok and uv.tolist() == [v[j] for v in want_valid], j
+        assert _data_np(arr, dt)[uv].tolist() == [r[j] for r, v in zip(want_rows, want_valid) if v[j]], j
+    g.reset()
+    assert g.num_groups == 0 and _data_np(g.consume(up(rows[2:4])), np.uint32).tolist() == [0, 1]
+
+
 def check_group_by_keys(amd, rng, key_dtypes, n, cardinality, null_p=0.0, use_pyarrow=True):
     """compute.group_by over several / wide key columns (Grouper + the dense hash_sum state): sum, count and mean per
     group equal the oracle's per-group reduction and pyarrow's Table.group_by(keys).aggregate (compared as a mapping

@@ -885,7 +885,11 @@ def test_reference_grouper_golden_vectors(emu_ctx, section, combos):
     ((np.int64,), 5000, 700, 0.05, 1), ((np.int64,), 5000, 4999, 0.0, 3), ((np.uint64,), 3000, 5, 0.3, 2),
     ((np.int32, np.int32), 6000, 900, 0.1, 2), ((np.int64, np.int64), 4000, 300, 0.1, 1),
     ((np.int8, np.int16, np.int32, np.int64), 3000, 2500, 0.05, 4), ((np.float64, np.uint8), 2000, 50, 0.2, 1),
-    ((np.int16,), 0, 1, 0.0, 1), ((np.uint8,) * 8, 2000, 100, 0.1, 2)])
+    ((np.int16,), 0, 1, 0.0, 1), ((np.uint8,) * 8, 2000, 100, 0.1, 2),
+    # rows wider than one 16-byte table: the chain of tables (level s keys = id of level s-1 ++ the next columns)
+    ((np.int64, np.int64, np.int64), 4000, 600, 0.1, 2), ((np.int64,) * 5, 3000, 2900, 0.05, 3),
+    ((np.uint8,) * 20, 2500, 40, 0.2, 2), ((np.int32, np.int64, np.int16, np.float64, np.int8, np.int64), 3000, 30, 0.3, 1),
+    ((np.int64, np.int64, np.int32), 0, 1, 0.0, 1)])
 def test_grouper_ids_uniques_lookup(emu_ctx, dtypes, n, card, null_p, batches):
     P.check_grouper(emu_ctx, rng_for("grouper", len(dtypes), n, card, batches), dtypes, n, card, null_p, batches)
 
@@ -899,8 +903,8 @@ def test_grouper_hot_keys_take_the_pending_path(emu_ctx):
 def test_grouper_declines_and_overflows(emu_ctx):
     from arrow_amd.array import int64, bool_
 
-    with pytest.raises(NotImplementedError, match="16 bytes"):
-        emu_ctx.compute.Grouper([int64, int64, int64], 16)
+    with pytest.raises(NotImplementedError, match="1 to 32 key columns"):
+        emu_ctx.compute.Grouper([int64] * 33, 16)
     with pytest.raises(NotImplementedError, match="keys of type bool"):
         emu_ctx.compute.Grouper([bool_], 16)
     g = emu_ctx.compute.Grouper([int64], 4)
@@ -910,8 +914,13 @@ def test_grouper_declines_and_overflows(emu_ctx):
         g.consume([emu_ctx.Array.from_numpy(np.arange(10, dtype=np.int64))])
 
 
+def test_grouper_chain_levels_and_partial_lookups(emu_ctx):
+    P.check_grouper_chain(emu_ctx)
+
+
 @pytest.mark.parametrize("dtypes,n,card,null_p", [((np.int64,), 6000, 500, 0.05), ((np.int32, np.int32), 6000, 800, 0.1),
-                                                  ((np.int64, np.int16), 4000, 3500, 0.0)])
+                                                  ((np.int64, np.int16), 4000, 3500, 0.0),
+                                                  ((np.int64, np.int64, np.int64), 4000, 12, 0.1)])
 def test_group_by_wide_and_multiple_keys(emu_ctx, dtypes, n, card, null_p):
     P.check_group_by_keys(emu_ctx, rng_for("group_by_keys", len(dtypes), n, card), dtypes, n, card, null_p)
 
