@@ -2057,6 +2057,37 @@ class Grouper:
         return ExecBatch(out, self.num_groups)
 
 
+
+def binary_key_columns(arr: Array):
+    """A utf8 / binary KEY column as the fixed-width virtual key columns the chain of Grouper tables takes
+    (arx_binary_key_lengths / arx_binary_key_chunk; the var-length part of the reference's key rows,
+    row/grouper.cc:559-611): (lengths uint32 Array — 0xFFFFFFFF for a null, [(lo uint64 Array, hi uint32 Array) per
+    12-byte chunk, zero-padded past the string's end])."""
+    lib, stream = _lib_and_stream(arr.device)
+    n = arr.length
+    bspan = arr.binary_span()
+    lens = alloc(max(n, 1) * 4, arr.device)
+    ws = _workspace(arr.device, 256, "binary_key")
+    max_len = C.c_int64(0)
+    check(lib.arx_binary_key_lengths(C.byref(bspan), lens.data_ptr(), C.byref(max_len), ws.data_ptr(), stream))
+    chunks = []
+    for c in range((max_len.value + 11) // 12):
+        lo, hi = alloc(max(n, 1) * 8, arr.device), alloc(max(n, 1) * 4, arr.device)
+        check(lib.arx_binary_key_chunk(C.byref(bspan), c, lo.data_ptr(), hi.data_ptr(), stream))
+        chunks.append((Array(uint64, n, [None, lo], 0, 0), Array(uint32, n, [None, hi], 0, 0)))
+    return Array(uint32, n, [None, lens], 0, 0), chunks
+
+
+def group_first_rows(group_ids: Array, num_groups: int) -> Array:
+    """first_rows[g] = the smallest row whose group id is g (arx_group_first_rows): `take(keys, first_rows)` are the
+    unique key rows in group-id order — how var-width keys come back out of the chain of tables."""
+    lib, stream = _lib_and_stream(group_ids.device)
+    out = alloc(max(num_groups, 1) * 4, group_ids.device)
+    check(lib.arx_group_first_rows(group_ids.buffers[1].data_ptr() + 4 * group_ids.offset, group_ids.length, num_groups,
+                                   out.data_ptr(), stream))
+    return Array(uint32, num_groups, [None, out], 0, 0)
+
+
 _GROUP_BY_AGGREGATES = ("hash_sum", "hash_count", "hash_mean")
 
 

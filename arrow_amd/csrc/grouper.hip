@@ -360,6 +360,65 @@ static GrouperWs grouper_ws(int64_t n) {
 
 using namespace arx;
 
+// ---------------------------------------------------------------- var-width key columns
+// A utf8 / binary key column enters the chain of tables as FIXED-WIDTH virtual columns: its length (uint32; a null is
+// the length 0xFFFFFFFF, which no int32-offset string has — null stays a key value of its own, distinct from "") and
+// then 12 bytes of the string per table level, zero-padded past the end, as one uint64 and one uint32 column beside
+// the previous level's 4-byte id.  Equal rows agree in every virtual column; rows that differ differ in the length or
+// in some chunk (the reference compares length + bytes of its encoded row the same way, row/grouper.cc:559-611 with
+// the var-length part of RowTableEncoder).
+__global__ __launch_bounds__(kBlock) void binary_key_lengths_kernel(Bits valid, const int32_t* __restrict__ offsets,
+                                                                    int64_t n, uint32_t* __restrict__ out_len,
+                                                                    unsigned int* __restrict__ max_len) {
+  unsigned int mine = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1;
+    const unsigned int len = ok ? static_cast<unsigned int>(offsets[i + 1] - offsets[i]) : 0xFFFFFFFFu;
+    out_len[i] = len;
+    if (ok && len > mine) mine = len;
+  }
+  if (mine != 0) atomicMax(max_len, mine);
+}
+
+__global__ __launch_bounds__(kBlock) void binary_key_chunk_kernel(Bits valid, const int32_t* __restrict__ offsets,
+                                                                  const uint8_t* __restrict__ data, int64_t n,
+                                                                  int64_t chunk_pos, uint64_t* __restrict__ out_lo,
+                                                                  uint32_t* __restrict__ out_hi) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1;
+    const int64_t start = offsets[i];
+    const int64_t len = ok ? offsets[i + 1] - start : 0;
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    const int64_t have = len - chunk_pos;   // bytes of this string at and after the chunk
+    if (have > 0) {
+      const uint8_t* p = data + start + chunk_pos;
+      const int m = have < 12 ? static_cast<int>(have) : 12;
+      for (int b = 0; b < 8; ++b) {
+        if (b < m) lo |= static_cast<uint64_t>(p[b]) << (8 * b);
+      }
+      for (int b = 8; b < 12; ++b) {
+        if (b < m) hi |= static_cast<uint32_t>(p[b]) << (8 * (b - 8));
+      }
+    }
+    out_lo[i] = lo;
+    out_hi[i] = hi;
+  }
+}
+
+// first_rows[g] = the smallest row whose group id is g (caller fills first_rows with 0xFF bytes)
+__global__ __launch_bounds__(kBlock) void group_first_rows_kernel(const uint32_t* __restrict__ ids, int64_t n,
+                                                                  int64_t num_groups, unsigned int* __restrict__ first) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const uint32_t g = ids[i];
+    // rows of one group mostly lose: read before the atomic so that only candidates reach the L2's atomic units
+    if (g < num_groups && first[g] > static_cast<unsigned int>(i)) atomicMin(&first[g], static_cast<unsigned int>(i));
+  }
+}
+
 extern "C" {
 
 size_t arx_grouper_state_bytes(int64_t max_groups) {
@@ -571,6 +630,73 @@ int arx_grouper_get_uniques(void* state, int64_t max_groups, const int32_t* key_
   ARX_HIP(hipMemcpyAsync(&nulls, counter, 8, hipMemcpyDeviceToHost, st));
   ARX_HIP(hipStreamSynchronize(st));
   *out_null_count = static_cast<int64_t>(nulls);
+  return ARX_OK;
+}
+
+
+int arx_binary_key_lengths(const ArxBinarySpan* values, uint32_t* out_lengths, int64_t* out_max_length, void* ws,
+                           void* stream) {
+  if (values == nullptr || out_max_length == nullptr) {
+    set_error("binary key lengths: NULL argument");
+    return ARX_INVALID;
+  }
+  *out_max_length = 0;
+  const int64_t n = values->length;
+  if (n <= 0) return ARX_OK;
+  if (values->offsets == nullptr || out_lengths == nullptr || ws == nullptr) {
+    set_error("binary key lengths: NULL buffer");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  ARX_HIP(hipMemsetAsync(ws, 0, 8, st));
+  const Bits valid = make_bits(values->null_count == 0 ? nullptr : values->validity, values->offset, n);
+  hipLaunchKernelGGL(binary_key_lengths_kernel, dim3(grouper_grid(n)), dim3(kBlock), 0, st, valid,
+                     values->offsets + values->offset, n, out_lengths, static_cast<unsigned int*>(ws));
+  ARX_CHECK_LAUNCH("binary_key_lengths_kernel");
+  unsigned int m = 0;
+  ARX_HIP(hipMemcpyAsync(&m, ws, 4, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  *out_max_length = m;
+  return ARX_OK;
+}
+
+int arx_binary_key_chunk(const ArxBinarySpan* values, int64_t chunk_index, uint64_t* out_lo, uint32_t* out_hi,
+                         void* stream) {
+  if (values == nullptr || chunk_index < 0) {
+    set_error("binary key chunk: NULL values or negative chunk");
+    return ARX_INVALID;
+  }
+  const int64_t n = values->length;
+  if (n <= 0) return ARX_OK;
+  if (values->offsets == nullptr || out_lo == nullptr || out_hi == nullptr) {
+    set_error("binary key chunk: NULL buffer");
+    return ARX_INVALID;
+  }
+  const Bits valid = make_bits(values->null_count == 0 ? nullptr : values->validity, values->offset, n);
+  hipLaunchKernelGGL(binary_key_chunk_kernel, dim3(grouper_grid(n)), dim3(kBlock), 0, as_stream(stream), valid,
+                     values->offsets + values->offset, static_cast<const uint8_t*>(values->data), n, chunk_index * 12,
+                     out_lo, out_hi);
+  ARX_CHECK_LAUNCH("binary_key_chunk_kernel");
+  return ARX_OK;
+}
+
+int arx_group_first_rows(const uint32_t* group_ids, int64_t length, int64_t num_groups, uint32_t* out_first_rows,
+                         void* stream) {
+  if (num_groups <= 0) return ARX_OK;
+  if (out_first_rows == nullptr || (length > 0 && group_ids == nullptr)) {
+    set_error("group first rows: NULL buffer");
+    return ARX_INVALID;
+  }
+  if (length >= (int64_t(1) << 32) - 1) {
+    set_error("group first rows: row numbers are uint32");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  ARX_HIP(hipMemsetAsync(out_first_rows, 0xFF, static_cast<size_t>(num_groups) * 4, st));
+  if (length <= 0) return ARX_OK;
+  hipLaunchKernelGGL(group_first_rows_kernel, dim3(grouper_grid(length)), dim3(kBlock), 0, st, group_ids, length,
+                     num_groups, out_first_rows);
+  ARX_CHECK_LAUNCH("group_first_rows_kernel");
   return ARX_OK;
 }
 

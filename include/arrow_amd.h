@@ -777,6 +777,22 @@ int arx_grouper_num_groups(void* state, int64_t* out_num_groups, void* stream);
 int arx_grouper_get_uniques(void* state, int64_t max_groups, const int32_t* key_byte_widths, int num_keys, int key_index,
                             void* out_values, uint8_t* out_validity, int64_t* out_null_count, void* stream);
 
+/* Var-width (utf8 / binary, int32 offsets) KEY columns for the chain of Grouper tables — the var-length part of the
+ * reference's key rows (row/grouper.cc:559-611; RowTableEncoder's varbinary columns): the column becomes fixed-width
+ * virtual key columns, its LENGTH (uint32; 0xFFFFFFFF for a null, so that null is a key value of its own and differs
+ * from "") and then 12 bytes of the string per table level as one uint64 (bytes 0-7, little endian) and one uint32
+ * (bytes 8-11), zero-padded past the string's end; ceil(max_length / 12) chunks tell any two different strings apart.
+ * arx_binary_key_lengths: synchronous (returns the longest valid string's length); ws: >= 8 device bytes.
+ * arx_group_first_rows: out_first_rows[g] = the smallest row of group g (the row GetUniques reports for g): the
+ * unique strings are `take(values, first_rows)`.  length < 2^32 - 1. */
+int arx_binary_key_lengths(const ArxBinarySpan* values, uint32_t* out_lengths, int64_t* out_max_length, void* ws,
+                           void* stream);
+int arx_binary_key_chunk(const ArxBinarySpan* values, int64_t chunk_index, uint64_t* out_lo, uint32_t* out_hi,
+                         void* stream);
+int arx_group_first_rows(const uint32_t* group_ids, int64_t length, int64_t num_groups, uint32_t* out_first_rows,
+                         void* stream);
+
+
 int arx_hash_sum_i64_merge(int64_t* sums, int64_t* counts, uint32_t* null_seen,
                            const int64_t* other_sums, const int64_t* other_counts,
                            const uint32_t* other_null_seen, const uint32_t* group_id_mapping,

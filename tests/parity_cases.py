@@ -1384,6 +1384,49 @@ def check_grouper_chain(amd):
     assert g.num_groups == 0 and _data_np(g.consume(up(rows[2:4])), np.uint32).tolist() == [0, 1]
 
 
+def check_binary_key_columns(amd, values, rng):
+    """arx_binary_key_lengths / _chunk / arx_group_first_rows against their definition in numpy, then the use they are
+    made for: Grouper over (length, chunks...) of a utf8 / binary column groups exactly the equal strings (null a key of
+    its own, "" another), ids in order of first appearance, take(values, first_rows) = the unique strings."""
+    from arrow_amd.array import uint32, uint64
+
+    dv = values.to_device(amd)
+    lens, chunks = amd.compute.binary_key_columns(dv)
+    n, off = values.length, values.offset
+    o = values.offsets.astype(np.int64)
+    ok = values.logical_valid()
+    want_len = np.where(ok, o[off + 1:off + n + 1] - o[off:off + n], 0xFFFFFFFF).astype(np.uint32)
+    assert_equal(_data_np(lens, np.uint32), want_len, "binary key lengths")
+    max_len = int(want_len[ok].max()) if ok.any() else 0
+    assert len(chunks) == (max_len + 11) // 12
+    rows = [bytes(values.data[o[off + i]:o[off + i + 1]]) if ok[i] else None for i in range(n)]
+    for c, (lo, hi) in enumerate(chunks):
+        want = np.zeros((n, 12), dtype=np.uint8)
+        for i, r in enumerate(rows):
+            part = (r or b"")[12 * c:12 * c + 12]
+            want[i, :len(part)] = np.frombuffer(part, dtype=np.uint8)
+        assert_equal(_data_np(lo, np.uint64), want[:, :8].copy().view("<u8").ravel(), f"binary key chunk {c} lo")
+        assert_equal(_data_np(hi, np.uint32), want[:, 8:].copy().view("<u4").ravel(), f"binary key chunk {c} hi")
+    # the Grouper over the virtual columns
+    cols = [lens] + [h for pair in chunks for h in pair]
+    g = amd.compute.Grouper([c.type for c in cols], max(16, n))
+    ids = g.consume(cols)
+    first_of = {}
+    want_ids = np.array([first_of.setdefault(r, len(first_of)) for r in rows], dtype=np.uint32)
+    assert_equal(_data_np(ids, np.uint32), want_ids, "ids over the virtual key columns")
+    assert g.num_groups == len(first_of)
+    first = amd.compute.group_first_rows(ids, g.num_groups)
+    want_first = np.array([rows.index(r) for r in first_of], dtype=np.uint32)
+    assert_equal(_data_np(first, np.uint32), want_first, "group first rows")
+    if n:
+        uniq = amd.compute.take(dv, first, boundscheck=False)
+        uo = uniq.buffers[1].cpu().numpy().view(np.uint8)[:(uniq.length + 1) * 4].view(np.int32)
+        ud = uniq.buffers[2].cpu().numpy().view(np.uint8) if uniq.buffers[2] is not None else np.zeros(0, np.uint8)
+        uv, _ = _logical_valid(uniq)
+        got = [bytes(ud[uo[i]:uo[i + 1]]) if uv[i] else None for i in range(uniq.length)]
+        assert got == list(first_of), "unique strings"
+
+
 def check_group_by_keys(amd, rng, key_dtypes, n, cardinality, null_p=0.0, use_pyarrow=True):
     """compute.group_by over several / wide key columns (Grouper + the dense hash_sum state): sum, count and mean per
     group equal the oracle's per-group reduction and pyarrow's Table.group_by(keys).aggregate (compared as a mapping

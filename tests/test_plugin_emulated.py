@@ -100,6 +100,12 @@ def test_aggregate_rocm_key_rows_wider_than_16_bytes_emulated():
     _run(W.WIDE_KEYS_SCRIPT, "WIDE_KEYS_OK", 0.004)
 
 
+def test_aggregate_rocm_utf8_and_binary_keys_emulated():
+    from . import test_zz_gpu_wide_keys as W
+
+    _run(W.STRING_KEYS_SCRIPT, "STRING_KEYS_OK", 0.005)
+
+
 def test_device_streams_events_reader_writer_dlpack_emulated():
     _run(G.DEVICE_INTERFACES_SCRIPT, "DEVICE_INTERFACES_OK", 1)
 

@@ -164,6 +164,19 @@ class HostBinaryArray:
         return full.slice(self.offset, self.length)
 
 
+def random_binary_pool(rng, length, cardinality, null_p=0.0, offset=0, max_len=24) -> "HostBinaryArray":
+    """Strings drawn from a pool of `cardinality` distinct-ish values (group-by keys): shared prefixes, NUL bytes, "" included."""
+    pool = [b""] + [bytes(rng.integers(0, 3, size=int(rng.integers(0, max_len, endpoint=True))).astype(np.uint8)) for _ in range(max(1, cardinality))]
+    n = offset + length + 2
+    pick = rng.integers(0, len(pool), size=n)
+    lens = np.array([len(pool[i]) for i in pick], dtype=np.int64)
+    offsets = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(lens, out=offsets[1:])
+    data = np.frombuffer(b"".join(pool[i] for i in pick), dtype=np.uint8).copy()
+    valid = (rng.random(n) >= null_p) if null_p > 0 else None
+    return HostBinaryArray(offsets, data, valid, offset, length)
+
+
 def random_binary(rng, length, null_p=0.0, offset=0, tail=0, max_len=24, utf8=False, empty_p=0.1) -> HostBinaryArray:
     """RandomArrayGenerator::String-like (arrow/testing/random.h): lengths 0..max_len, some empty."""
     n = offset + length + tail
