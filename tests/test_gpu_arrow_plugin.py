@@ -1025,11 +1025,19 @@ ACERO_SCRIPT = textwrap.dedent(r'''
     empty = pa.table({"k": pa.array([], pa.int32()), "v": pa.array([], pa.int64())})
     assert fused(empty).num_rows == 0
     assert fused(pa.table({"k": pa.array([1.0, 2.0, 1.0]), "v": pa.array([1, 2, 3], pa.int64())})).sort_by("k").column("v_sum").to_pylist() == [4, 2]
+    # a utf8 key goes to the Grouper-based node too (round 3, commit 9c16ec1): equal to the stock GroupByNode, incl. the
+    # empty string vs null, NUL bytes and shared prefixes
+    ts = pa.table({"k": pa.array(["a", "", None, "a\x00", "a", "ab", None, "", "a\x00", "abcdefghijklmnopqrstuvwxyz"]),
+                   "v": pa.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10], pa.int64())})
+    got = fused(ts).sort_by("k")
+    ref = ts.group_by("k", use_threads=False).aggregate([("v", "sum")]).sort_by("k")
+    assert got.column("k").equals(ref.column("k")) and got.column("v_sum").equals(ref.column("v_sum")), (got, ref)
+    # what neither node takes is refused with the reason: a list key
     try:
-        fused(pa.table({"k": pa.array(["a"]), "v": pa.array([1], pa.int64())}))
-        raise SystemExit("expected NotImplemented")
-    except pa.lib.ArrowNotImplementedError:
-        pass
+        fused(pa.table({"k": pa.array([[1], [2]], pa.list_(pa.int32())), "v": pa.array([1, 2], pa.int64())}))
+        raise SystemExit("expected NotImplemented for a list key")
+    except pa.lib.ArrowNotImplementedError as e:
+        assert "key column" in str(e), e
     print("ACERO_OK")
 ''')
 
