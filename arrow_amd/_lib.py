@@ -226,6 +226,8 @@ SIGNATURES = {
     "arx_hash_minmax_i64_consume": (_int, [_span, _int, _i64, _p, _i64, _p, _p, _p, _p]),
     "arx_hash_minmax_i64_merge": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "arx_hash_minmax_i64_finalize": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p]),
+    "arx_hash_minmax_float_consume": (_int, [_span, _int, _int, C.c_double, _p, _i64, _p, _p, _p, _p]),
+    "arx_hash_minmax_float_finalize": (_int, [_p, _p, _p, _i64, _int, _int, _p, _p, _p, _p, _p]),
     "arx_hash_count_consume": (_int, [_p, _i64, _i64, _int, _p, _i64, _p, _p]),
     "arx_hash_count_merge": (_int, [_p, _p, _p, _i64, _p]),
     "arx_hash_sum_i64_finalize": (_int, [_p, _p, _i64, _int, _u32, _p, _p, _p]),

@@ -719,8 +719,75 @@ __global__ __launch_bounds__(kBlock) void hash_minmax_dense_merge_kernel(
     const uint32_t g = mapping[i];
     atomicMin(&mins[g], static_cast<long long>(other_mins[i]));
     atomicMax(&maxs[g], static_cast<long long>(other_maxs[i]));
-    if (other_null_seen[i] & 1u) atomicOr(&null_seen[g], 1u);
+    if (other_null_seen[i] & 3u) atomicOr(&null_seen[g], other_null_seen[i] & 3u);   // bit 0: saw a null; bit 1 (float states): saw a value
   }
+}
+
+// ---- float32 / float64 extrema (GroupedMinMaxImpl with MinMaxOp = fmin / fmax and NaN anti-extrema,
+// kernels/hash_aggregate.cc:306-326): the state arrays hold the values' ORDER KEYS — the int64 whose signed order is the
+// numeric order of the doubles (-0.0 just below +0.0, the one tie the reference leaves to row order) — so the integer
+// atomics and the merge kernel above serve them unchanged.  fmin / fmax skip NaNs: a NaN row only marks "saw a value"
+// (bit 1 of null_seen; mins <= maxs cannot say it for an all-NaN group), and Finalize turns the untouched anti-extrema
+// INT64_MAX / INT64_MIN — themselves the keys of NaN patterns — into the canonical quiet NaN, which is what fmin(NaN, NaN) leaves.
+__device__ __forceinline__ long long float_order_key(double v) {
+  const unsigned long long u = static_cast<unsigned long long>(__builtin_bit_cast(long long, v));
+  return static_cast<long long>((u >> 63) ? (~u ^ 0x8000000000000000ull) : u);
+}
+__device__ __forceinline__ double float_from_order_key(long long k) {
+  const unsigned long long s = static_cast<unsigned long long>(k);
+  const double v = __builtin_bit_cast(double, k >= 0 ? s : ~(s ^ 0x8000000000000000ull));
+  return v != v ? __builtin_bit_cast(double, 0x7FF8000000000000ull) : v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void hash_minmax_dense_consume_float_kernel(
+    const T* __restrict__ values, double scalar_value, int values_is_scalar, Bits vvalid,
+    const uint32_t* __restrict__ group_ids, int64_t n, long long* __restrict__ mins, long long* __restrict__ maxs,
+    unsigned int* __restrict__ null_seen) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t g = group_ids[i];
+    const bool ok = (load_word(vvalid, i >> 6) >> (i & 63)) & 1ull;
+    const unsigned int seen = __hip_atomic_load(&null_seen[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ok) {
+      const double d = values_is_scalar ? scalar_value : static_cast<double>(values[i]);   // (float -> double is exact and keeps the order)
+      if ((seen & 2u) == 0) atomicOr(&null_seen[g], 2u);
+      if (d == d) {
+        const long long v = float_order_key(d);
+        if (v < __hip_atomic_load(&mins[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mins[g], v);
+        if (v > __hip_atomic_load(&maxs[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxs[g], v);
+      }
+    } else if ((seen & 1u) == 0) {
+      atomicOr(&null_seen[g], 1u);
+    }
+  }
+}
+
+// values and validity of the float extrema: bit g = group g saw a value && (skip_nulls || saw no null)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void hash_minmax_dense_finalize_float_kernel(
+    const int64_t* __restrict__ mins, const int64_t* __restrict__ maxs, const uint32_t* __restrict__ null_seen, int64_t n,
+    int skip_nulls, T* __restrict__ out_mins, T* __restrict__ out_maxs, uint64_t* __restrict__ out_bits,
+    unsigned long long* __restrict__ valid_count) {
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwords = (n + 63) >> 6;
+  uint64_t nvalid = 0;
+  for (int64_t w = wave_g; w < nwords; w += nwaves) {
+    const int64_t i = (w << 6) + lane;
+    bool ok = false;
+    if (i < n) {
+      const uint32_t seen = null_seen[i];
+      ok = (seen & 2u) != 0 && (skip_nulls || (seen & 1u) == 0);
+      if (out_mins != nullptr) out_mins[i] = static_cast<T>(float_from_order_key(mins[i]));
+      if (out_maxs != nullptr) out_maxs[i] = static_cast<T>(float_from_order_key(maxs[i]));
+    }
+    const uint64_t bal = __ballot(ok);
+    if (lane == 0) out_bits[w] = bal;
+    nvalid += __popcll(bal);
+  }
+  if (valid_count != nullptr && lane == 0 && nvalid != 0) atomicAdd(valid_count, nvalid);
 }
 
 // bit g = group g saw a value && (skip_nulls || saw no null)   (Finalize, hash_aggregate.cc:401-419)
@@ -2594,6 +2661,63 @@ int arx_hash_minmax_i64_finalize(const int64_t* mins, const int64_t* maxs, const
                      num_groups, skip_nulls, static_cast<uint64_t*>(out_validity),
                      reinterpret_cast<unsigned long long*>(valid_count));
   ARX_CHECK_LAUNCH("hash_minmax_dense_finalize_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_minmax_float_consume(const ArxSpan* values, int num_type, int values_is_scalar, double scalar_value,
+                                  const uint32_t* group_ids, int64_t length, int64_t* mins, int64_t* maxs, uint32_t* null_seen,
+                                  void* stream) {
+  if (num_type != ARX_NUM_FLOAT32 && num_type != ARX_NUM_FLOAT64) {
+    set_error("arx_hash_minmax_float_consume: num_type %d is not float32 / float64", num_type);
+    return ARX_INVALID;
+  }
+  const int64_t* v = nullptr;   // (dense_values offsets 8-byte elements: redone below for the element type)
+  Bits vb{};
+  const int rc = dense_values("arx_hash_minmax_float_consume", values, values_is_scalar, group_ids, length, &v, &vb);
+  if (rc != ARX_OK || length == 0) return rc;
+  if (mins == nullptr || maxs == nullptr || null_seen == nullptr) {
+    set_error("NULL state passed to arx_hash_minmax_float_consume");
+    return ARX_INVALID;
+  }
+  if (num_type == ARX_NUM_FLOAT64) {
+    const double* d = values_is_scalar ? nullptr : static_cast<const double*>(values->data) + values->offset;
+    hipLaunchKernelGGL(hash_minmax_dense_consume_float_kernel<double>, dim3(gb_grid(length)), dim3(kBlock), 0, as_stream(stream),
+                       d, scalar_value, values_is_scalar, vb, group_ids, length, reinterpret_cast<long long*>(mins),
+                       reinterpret_cast<long long*>(maxs), null_seen);
+  } else {
+    const float* f = values_is_scalar ? nullptr : static_cast<const float*>(values->data) + values->offset;
+    hipLaunchKernelGGL(hash_minmax_dense_consume_float_kernel<float>, dim3(gb_grid(length)), dim3(kBlock), 0, as_stream(stream),
+                       f, scalar_value, values_is_scalar, vb, group_ids, length, reinterpret_cast<long long*>(mins),
+                       reinterpret_cast<long long*>(maxs), null_seen);
+  }
+  ARX_CHECK_LAUNCH("hash_minmax_dense_consume_float_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_minmax_float_finalize(const int64_t* mins, const int64_t* maxs, const uint32_t* null_seen, int64_t num_groups,
+                                   int skip_nulls, int num_type, void* out_mins, void* out_maxs, void* out_validity,
+                                   int64_t* valid_count, void* stream) {
+  if (num_groups < 0 || (num_type != ARX_NUM_FLOAT32 && num_type != ARX_NUM_FLOAT64)) {
+    set_error("bad arguments to arx_hash_minmax_float_finalize");
+    return ARX_INVALID;
+  }
+  if (num_groups == 0) return ARX_OK;
+  if (mins == nullptr || maxs == nullptr || null_seen == nullptr || out_validity == nullptr) {
+    set_error("NULL buffer passed to arx_hash_minmax_float_finalize");
+    return ARX_INVALID;
+  }
+  const int64_t nwords = ceil_div(num_groups, 64);
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(nwords, kWavesPerBlock), 256 * 8)));
+  if (num_type == ARX_NUM_FLOAT64) {
+    hipLaunchKernelGGL(hash_minmax_dense_finalize_float_kernel<double>, dim3(grid), dim3(kBlock), 0, as_stream(stream), mins, maxs,
+                       null_seen, num_groups, skip_nulls, static_cast<double*>(out_mins), static_cast<double*>(out_maxs),
+                       static_cast<uint64_t*>(out_validity), reinterpret_cast<unsigned long long*>(valid_count));
+  } else {
+    hipLaunchKernelGGL(hash_minmax_dense_finalize_float_kernel<float>, dim3(grid), dim3(kBlock), 0, as_stream(stream), mins, maxs,
+                       null_seen, num_groups, skip_nulls, static_cast<float*>(out_mins), static_cast<float*>(out_maxs),
+                       static_cast<uint64_t*>(out_validity), reinterpret_cast<unsigned long long*>(valid_count));
+  }
+  ARX_CHECK_LAUNCH("hash_minmax_dense_finalize_float_kernel");
   return ARX_OK;
 }
 

@@ -714,6 +714,19 @@ int arx_hash_minmax_i64_merge(int64_t* mins, int64_t* maxs, uint32_t* null_seen,
                               int64_t other_num_groups, void* stream);
 int arx_hash_minmax_i64_finalize(const int64_t* mins, const int64_t* maxs, const uint32_t* null_seen, int64_t num_groups,
                                  int skip_nulls, void* out_validity, int64_t* valid_count, void* stream);
+/* The same for float32 / float64 values (num_type ARX_NUM_FLOAT32 / _FLOAT64; MinMaxOp = fmin / fmax over NaN
+ * anti-extrema, hash_aggregate.cc:306-326).  The state arrays are the int64 arrays above and hold the values' ORDER KEYS
+ * (the int64 whose signed order is the doubles' numeric order; -0.0 sorts just below +0.0 — the tie the reference
+ * leaves to row order), so arx_hash_minmax_i64_fill and _merge serve them unchanged; null_seen bit 1 = the group saw a
+ * value (a NaN row sets only that: fmin / fmax skip NaNs).  Finalize writes the extrema back as num_type values
+ * (out_mins / out_maxs: either may be NULL; a group of NaNs only gets NaN) and the validity bit g = saw a value &&
+ * (skip_nulls || saw no null).  scalar_value: the broadcast value of a scalar column. */
+int arx_hash_minmax_float_consume(const ArxSpan* values, int num_type, int values_is_scalar, double scalar_value,
+                                  const uint32_t* group_ids, int64_t length, int64_t* mins, int64_t* maxs, uint32_t* null_seen,
+                                  void* stream);
+int arx_hash_minmax_float_finalize(const int64_t* mins, const int64_t* maxs, const uint32_t* null_seen, int64_t num_groups,
+                                   int skip_nulls, int num_type, void* out_mins, void* out_maxs, void* out_validity,
+                                   int64_t* valid_count, void* stream);
 /* hash_count(any, uint32 group id) — GroupedCountImpl (compute/kernels/hash_aggregate.cc:107-212): counts[g] += 1 for
  * the rows of group g whose value is valid (mode 0, CountOptions::ONLY_VALID), null (1, ONLY_NULL) or either (2, ALL).
  * Only the values' validity is read: values_validity + values_offset (NULL: no nulls; values_null_count != 0 with a

@@ -754,10 +754,15 @@ class HashMinMaxState:
     groups start at the anti-extrema, no value / no null seen), Consume :355-379, Merge :381-399, Finalize :401-419
     (a group is null when it saw no value, or — !skip_nulls — saw a null; min_count is not consulted).  Plain numpy."""
 
-    def __init__(self, skip_nulls=True):
+    def __init__(self, skip_nulls=True, dtype=np.int64):
+        """dtype float32 / float64: MinMaxOp = fmin / fmax over NaN anti-extrema (hash_aggregate.cc:306-326) — NaN rows
+        are skipped, a group of NaNs only ends as NaN; fmin(+0.0, -0.0) depends on the row order in the reference
+        (whichever zero came last), so callers compare zeros numerically."""
         self.skip_nulls = bool(skip_nulls)
-        self.mins = np.zeros(0, np.int64)
-        self.maxs = np.zeros(0, np.int64)
+        self.dtype = np.dtype(dtype)
+        self.is_float = self.dtype.kind == "f"
+        self.mins = np.zeros(0, self.dtype)
+        self.maxs = np.zeros(0, self.dtype)
         self.has_values = np.zeros(0, bool)
         self.has_nulls = np.zeros(0, bool)
 
@@ -767,6 +772,12 @@ class HashMinMaxState:
 
     def resize(self, n):
         add = n - self.num_groups
+        if self.is_float:
+            self.mins = np.concatenate([self.mins, np.full(add, np.nan, self.dtype)])
+            self.maxs = np.concatenate([self.maxs, np.full(add, np.nan, self.dtype)])
+            self.has_values = np.concatenate([self.has_values, np.zeros(add, bool)])
+            self.has_nulls = np.concatenate([self.has_nulls, np.zeros(add, bool)])
+            return
         self.mins = np.concatenate([self.mins, np.full(add, np.iinfo(np.int64).max, np.int64)])
         self.maxs = np.concatenate([self.maxs, np.full(add, np.iinfo(np.int64).min, np.int64)])
         self.has_values = np.concatenate([self.has_values, np.zeros(add, bool)])
@@ -780,16 +791,18 @@ class HashMinMaxState:
             v = np.asarray(values)[val_off:val_off + n]
         else:
             ok = np.full(n, bool(scalar[1]))
-            v = np.full(n, int(scalar[0]), np.int64)
-        np.minimum.at(self.mins, gids[ok], v[ok])
-        np.maximum.at(self.maxs, gids[ok], v[ok])
+            v = np.full(n, scalar[0], self.dtype)
+        lo, hi = (np.fmin, np.fmax) if self.is_float else (np.minimum, np.maximum)
+        lo.at(self.mins, gids[ok], v[ok])
+        hi.at(self.maxs, gids[ok], v[ok])
         self.has_values[gids[ok]] = True
         self.has_nulls[gids[~ok]] = True
 
     def merge(self, other: "HashMinMaxState", mapping):
         m = np.asarray(mapping, dtype=np.int64)
-        np.minimum.at(self.mins, m, other.mins)
-        np.maximum.at(self.maxs, m, other.maxs)
+        lo, hi = (np.fmin, np.fmax) if self.is_float else (np.minimum, np.maximum)
+        lo.at(self.mins, m, other.mins)
+        hi.at(self.maxs, m, other.maxs)
         np.logical_or.at(self.has_values, m, other.has_values)
         np.logical_or.at(self.has_nulls, m, other.has_nulls)
 

@@ -2012,6 +2012,110 @@ def check_hash_minmax_count_kernels(amd, rng, n=5000, num_groups=37, null_p=0.2)
         assert_equal(h1.counts[gs], r.column("v_count").to_numpy(), "oracle hash_count vs pyarrow")
 
 
+def check_hash_minmax_float_kernels(amd, rng, dtype=np.float64, n=5000, num_groups=37, null_p=0.2):
+    """arx_hash_minmax_float_consume / _finalize (float32 / float64 extrema as order keys in the int64 state arrays of
+    the integer kernels), driven like a HashAggregateKernel: two states, fill, consume (arrays at offsets, a broadcast
+    scalar, a null scalar, a NaN scalar), merge through a mapping, finalize — against the oracle's fmin / fmax
+    restatement (NaNs skipped, groups of NaNs end as NaN, zeros of either sign compare equal) and against pyarrow."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+    num_type = 9 if np.dtype(dtype) == np.float64 else 8
+    special = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, np.finfo(dtype).max, np.finfo(dtype).tiny, -np.finfo(dtype).tiny * 0.5], dtype)
+
+    def column(offset):
+        a = util.random_array(rng, dtype, n, null_p=null_p, offset=offset)
+        v = a.values
+        v *= (10.0 ** rng.integers(-30, 30, len(v))).astype(dtype)
+        hit = rng.random(len(v)) < 0.3
+        v[hit] = special[rng.integers(0, len(special), int(hit.sum()))]
+        return a
+
+    vals, vals_b = column(3), column(0)
+    gid_a = rng.integers(0, num_groups, size=n).astype(np.uint32)
+    if num_groups > 3 and n > 0:
+        vals.values[vals.offset:vals.offset + n][gid_a == 1] = np.nan      # a group of NaNs only
+    nb = max(1, num_groups // 2)
+    perm = rng.permutation(num_groups)[:nb].astype(np.uint32)
+    gid_b = rng.integers(0, nb, size=n).astype(np.uint32)
+    dva, dvb = vals.to_device(amd), vals_b.to_device(amd)
+    dga, dgb, dperm = to_device(gid_a, dev), to_device(gid_b, dev), to_device(perm, dev)
+
+    def state(g):
+        mins = torch.zeros(g, dtype=torch.int64, device=dev)
+        maxs = torch.zeros(g, dtype=torch.int64, device=dev)
+        seen = torch.zeros(g, dtype=torch.int32, device=dev)
+        _lib.check(lib.arx_hash_minmax_i64_fill(mins.data_ptr(), maxs.data_ptr(), 0, g, st))
+        return mins, maxs, seen
+
+    a_mins, a_maxs, a_seen = state(num_groups)
+    b_mins, b_maxs, b_seen = state(nb)
+    sp_a, sp_b = dva.span(), dvb.span()
+    _lib.check(lib.arx_hash_minmax_float_consume(C.byref(sp_a), num_type, 0, 0.0, dga.data_ptr(), n, a_mins.data_ptr(),
+                                                 a_maxs.data_ptr(), a_seen.data_ptr(), st))
+    _lib.check(lib.arx_hash_minmax_float_consume(C.byref(sp_b), num_type, 0, 0.0, dgb.data_ptr(), n, b_mins.data_ptr(),
+                                                 b_maxs.data_ptr(), b_seen.data_ptr(), st))
+    k = min(100, n)
+    scal = _lib.ArxSpan(None, None, 0, k, 0)
+    _lib.check(lib.arx_hash_minmax_float_consume(C.byref(scal), num_type, 1, -7.5, dgb.data_ptr(), k, b_mins.data_ptr(),
+                                                 b_maxs.data_ptr(), b_seen.data_ptr(), st))
+    nul = _lib.ArxSpan(None, None, 0, min(3, n), min(3, n))
+    _lib.check(lib.arx_hash_minmax_float_consume(C.byref(nul), num_type, 1, 0.0, dgb.data_ptr(), min(3, n), b_mins.data_ptr(),
+                                                 b_maxs.data_ptr(), b_seen.data_ptr(), st))
+    _lib.check(lib.arx_hash_minmax_float_consume(C.byref(scal), num_type, 1, float("nan"), dgb.data_ptr(), k, b_mins.data_ptr(),
+                                                 b_maxs.data_ptr(), b_seen.data_ptr(), st))
+    _lib.check(lib.arx_hash_minmax_i64_merge(a_mins.data_ptr(), a_maxs.data_ptr(), a_seen.data_ptr(), b_mins.data_ptr(),
+                                             b_maxs.data_ptr(), b_seen.data_ptr(), dperm.data_ptr(), nb, st))
+    oa, ob = O.HashMinMaxState(dtype=dtype), O.HashMinMaxState(dtype=dtype)
+    oa.resize(num_groups)
+    ob.resize(nb)
+    oa.consume(vals.values, vals.valid_bitmap(), vals.offset, gid_a)
+    ob.consume(vals_b.values, vals_b.valid_bitmap(), vals_b.offset, gid_b)
+    ob.consume(None, None, 0, gid_b[:k], scalar=(-7.5, True))
+    ob.consume(None, None, 0, gid_b[:min(3, n)], scalar=(0.0, False))
+    ob.consume(None, None, 0, gid_b[:k], scalar=(np.nan, True))
+    oa.merge(ob, perm)
+    tdt = torch.float64 if num_type == 9 else torch.float32
+    for skip_nulls in (True, False):
+        oa.skip_nulls = skip_nulls
+        wmin, wmax, wvalid = oa.finalize()
+        bits = torch.zeros((num_groups + 63) // 64, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        omin = torch.zeros(num_groups, dtype=tdt, device=dev)
+        omax = torch.zeros(num_groups, dtype=tdt, device=dev)
+        _lib.check(lib.arx_hash_minmax_float_finalize(a_mins.data_ptr(), a_maxs.data_ptr(), a_seen.data_ptr(), num_groups,
+                                                      int(skip_nulls), num_type, omin.data_ptr(), omax.data_ptr(), bits.data_ptr(),
+                                                      cnt.data_ptr(), st))
+        got_valid = np.unpackbits(bits.cpu().numpy().view(np.uint8), bitorder="little")[:num_groups].astype(bool)
+        tag = f"hash_minmax_float[{np.dtype(dtype).name},n={n},G={num_groups},skip_nulls={skip_nulls}]"
+        assert_equal(got_valid, wvalid, tag + " validity")
+        assert int(cnt.item()) == int(wvalid.sum()), tag + " valid count"
+        for got, want, what in ((omin.cpu().numpy(), wmin, "mins"), (omax.cpu().numpy(), wmax, "maxs")):
+            g, w = got[wvalid], want[wvalid]
+            assert_equal(np.isnan(g), np.isnan(w), tag + f" {what}: NaN groups")
+            assert bool((g[~np.isnan(g)] == w[~np.isnan(w)]).all()), tag + f" {what}"     # (numeric: -0.0 == +0.0)
+    if pa is not None and n > 0:      # the oracle itself against the reference
+        o1 = O.HashMinMaxState(dtype=dtype)
+        o1.resize(num_groups)
+        o1.consume(vals.values, vals.valid_bitmap(), vals.offset, gid_a)
+        t = pa.table({"g": pa.array(gid_a), "v": vals.to_pyarrow()})
+        r = t.group_by("g", use_threads=False).aggregate([("v", "min"), ("v", "max")]).sort_by("g")
+        gs = r.column("g").to_numpy()
+        mn, mx, valid = o1.finalize()
+        assert_equal(valid[gs], ~np.asarray(r.column("v_min").is_null()), "oracle float hash_min validity vs pyarrow")
+        sel = valid[gs]
+        for mine, col in ((mn, "v_min"), (mx, "v_max")):
+            ref = r.column(col).drop_null().to_numpy()
+            assert_equal(np.isnan(mine[gs][sel]), np.isnan(ref), f"oracle float {col}: NaN groups vs pyarrow")
+            ok = ~np.isnan(ref)
+            assert bool((mine[gs][sel][ok] == ref[ok]).all()), f"oracle float {col} vs pyarrow"
+
+
 def check_bitmap_copy_segments(amd, rng, scale=1):
     """arx_bitmap_copy_segments: bit ranges at any source bit offset ORed into zeroed bitmaps back to back (ranges meet
     inside words), NULL sources (= all ones), empty ranges, two destination bitmaps in one launch."""

@@ -972,6 +972,11 @@ def test_hash_minmax_and_count_dense_kernels(emu_ctx, n, num_groups, null_p):
     P.check_hash_minmax_count_kernels(emu_ctx, rng_for("hmmc", n, num_groups), n=n, num_groups=num_groups, null_p=null_p)
 
 
+@pytest.mark.parametrize("dtype,n,num_groups,null_p", [(np.float64, 4000, 37, 0.2), (np.float32, 2000, 5, 0.0), (np.float64, 300, 1, 1.0)])
+def test_hash_minmax_float_dense_kernels(emu_ctx, dtype, n, num_groups, null_p):
+    P.check_hash_minmax_float_kernels(emu_ctx, rng_for("hmmf", n, num_groups), dtype=dtype, n=n, num_groups=num_groups, null_p=null_p)
+
+
 def test_buffer_copy(emu_ctx):
     P.check_buffer_copy(emu_ctx, rng_for("bufcopy"), 1)
 

@@ -128,3 +128,7 @@ def test_reference_golden_compare_and_arithmetic_through_callfunction_emulated()
 
 def test_reference_kernels_of_the_extended_functions_refuse_device_arrays_emulated():
     _run(G.DEVICE_GUARD_SCRIPT, "DEVICE_GUARD_OK", 1)
+
+
+def test_hash_min_max_of_floats_and_temporal_types_emulated():
+    _run(G.FLOAT_EXTREMA_SCRIPT, "FLOAT_EXTREMA_OK", 0.02)
