@@ -157,6 +157,10 @@ SIGNATURES = {
     "arx_bitmap_and": (_int, [_p, _i64, _p, _i64, _i64, _p, _p]),
     "arx_reduce_i64_init": (_int, [_p, _p]),
     "arx_reduce_i64_consume": (_int, [_span, _p, _p]),
+    "arx_reduce_float_minmax": (_int, [_span, _int, _p, _p]),
+    "arx_coalesce2": (_int, [_int, _span, _span, _p, _i64, _p, _p, _p]),
+    "arx_sum_float_workspace_bytes": (_sz, [_i64, _i64]),
+    "arx_sum_float": (_int, [_span, _int, _p, _sz, C.POINTER(C.c_double), C.POINTER(_i64), _p]),
     "arx_boolean_kleene": (_int, [_int, _span, _span, _p, _p, _p]),
     "arx_boolean_invert": (_int, [_p, _i64, _i64, _p, _p]),
     "arx_bitmap_popcount": (_int, [_p, _i64, _i64, _p, _sz, C.POINTER(_i64), _p]),

@@ -91,6 +91,7 @@ namespace {
 #include "plugin/hash_aggregate_bool.inc"
 #include "plugin/vector_hash.inc"
 #include "plugin/scalar_aggregate.inc"
+#include "plugin/coalesce.inc"
 #include "plugin/acero_node.inc"
 #include "plugin/acero_node_general.inc"
 #include "plugin/sharded.inc"

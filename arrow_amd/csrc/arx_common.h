@@ -153,6 +153,19 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n) {
   return first + (b >> 3);
 }
 
+// The ORDER KEY of a double: the int64 whose signed order is the numeric order of the doubles (-0.0 just below +0.0, NaN
+// patterns at both ends) — float extrema ride on the integer min / max machinery through it (groupby.hip, reduce_float.hip).
+__device__ __forceinline__ long long float_order_key(double v) {
+  const unsigned long long u = static_cast<unsigned long long>(__builtin_bit_cast(long long, v));
+  return static_cast<long long>((u >> 63) ? (~u ^ 0x8000000000000000ull) : u);
+}
+__device__ __forceinline__ double float_from_order_key(long long k) {
+  const unsigned long long s = static_cast<unsigned long long>(k);
+  const double v = __builtin_bit_cast(double, k >= 0 ? s : ~(s ^ 0x8000000000000000ull));
+  return v != v ? __builtin_bit_cast(double, 0x7FF8000000000000ull) : v;
+}
+
+
 // ---------------------------------------------------------------------------
 // Wave-level primitives (64 lanes)
 // ---------------------------------------------------------------------------

@@ -729,16 +729,6 @@ __global__ __launch_bounds__(kBlock) void hash_minmax_dense_merge_kernel(
 // atomics and the merge kernel above serve them unchanged.  fmin / fmax skip NaNs: a NaN row only marks "saw a value"
 // (bit 1 of null_seen; mins <= maxs cannot say it for an all-NaN group), and Finalize turns the untouched anti-extrema
 // INT64_MAX / INT64_MIN — themselves the keys of NaN patterns — into the canonical quiet NaN, which is what fmin(NaN, NaN) leaves.
-__device__ __forceinline__ long long float_order_key(double v) {
-  const unsigned long long u = static_cast<unsigned long long>(__builtin_bit_cast(long long, v));
-  return static_cast<long long>((u >> 63) ? (~u ^ 0x8000000000000000ull) : u);
-}
-__device__ __forceinline__ double float_from_order_key(long long k) {
-  const unsigned long long s = static_cast<unsigned long long>(k);
-  const double v = __builtin_bit_cast(double, k >= 0 ? s : ~(s ^ 0x8000000000000000ull));
-  return v != v ? __builtin_bit_cast(double, 0x7FF8000000000000ull) : v;
-}
-
 template <typename T>
 __global__ __launch_bounds__(kBlock) void hash_minmax_dense_consume_float_kernel(
     const T* __restrict__ values, double scalar_value, int values_is_scalar, Bits vvalid,
@@ -1341,6 +1331,11 @@ __global__ __launch_bounds__(1024) void gbp_rooms_scan_kernel(GbpArgs a) {
 // key / value loads, bit 1 the aggregate's record loads, bit 2 the scatter's record stores are non-temporal.
 constexpr int kGbNt = 0;
 constexpr int kGbAosWide = 1;       // the wide form's aggregate reads four records per thread with three 16-byte loads (0: one 12-byte load per record).  4e9 rows: 40.9 / 38.9 ms against 41.8 / 40.3 (two boxes' worth of interleaved runs, profiles/r03_x_*)
+constexpr int kGbWideAggU = 12;     // records a thread of the wide form's aggregate keeps in flight (A/B by rebuilding: scripts/build_gb_variants.sh)
+constexpr int kGbAosRaw = 1;        // the wide form's aggregate keeps raw quads in its pipeline registers, loads unconditional (0: the round-3 form, whose loads were waited for inside their branch)
+constexpr int kGbAggQuadProbe = 0;  // the raw form reads a quad's four home slots together before it branches per row
+constexpr int kGbAggGroupProbe = 1;  // the LDS tables are probed by aligned groups of four slots (one ds_read_b128 per step)
+constexpr int kGbKeysFirst = 0;     // the flat level issues all key loads before the value loads: ranking starts while the values are in flight
 constexpr int kGbPairAtomics = 0;   // the flat level's cursors: 1 = one 64-bit atomic per pair of bins, 0 = one per bin.  A/B at 4e9 rows: 41.2 / 45.2 ms paired, 40.4 / 40.4 single (profiles/r03_t_groupby_paired_cursor_atomics_ab.txt): the level is not bound by its atomics
 template <typename T>
 __device__ __forceinline__ T gb_load(const T* p, bool nt) {
@@ -1360,6 +1355,20 @@ struct __attribute__((aligned(16))) GbpWideScatterLds {
   uint32_t total;
 };
 
+// -DARX_GBP_PROFILE (scripts/build_gb_variants2.sh, never the product build): phase timestamps of a few workgroups of the
+// flat level, read back through arx_debug_gbp_profile
+#ifdef ARX_GBP_PROFILE
+__device__ unsigned long long g_gbp_prof[64 * 8];
+#define GBP_STAMP(k)                                                                                     \
+  do {                                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x % 1009 == 7 && blockIdx.x / 1009 < 64) {                          \
+      g_gbp_prof[(blockIdx.x / 1009) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();                      \
+    }                                                                                                    \
+  } while (0)
+#else
+#define GBP_STAMP(k) do { } while (0)
+#endif
+
 template <bool HAS_NULLS>
 __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArgs a) {
   __shared__ GbpWideScatterLds lds;
@@ -1372,15 +1381,31 @@ __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArg
   if (row0 >= a.n) return;   // workgroup-uniform
   const int nrows = static_cast<int>(a.n - row0 < kGbWideTile ? a.n - row0 : kGbWideTile);
   for (int b = tid; b < nb; b += kGbWideThreads) lds.start[b] = 0;
+  GBP_STAMP(0);
   uint32_t key[kGbWideRpt];
   int64_t val[kGbWideRpt];
   // unconditional loads (rows past the tile's end re-read its last row): all in flight together
+  if constexpr (kGbKeysFirst != 0) {
 #pragma unroll
-  for (int i = 0; i < kGbWideRpt; ++i) {
-    const int p = i * kGbWideThreads + tid;
-    const int64_t r = row0 + (p < nrows ? p : nrows - 1);
-    key[i] = static_cast<uint32_t>(gb_load(a.keys + r, (kGbNt & 1) != 0));
-    val[i] = gb_load(a.values + r, (kGbNt & 1) != 0);
+    for (int i = 0; i < kGbWideRpt; ++i) {
+      const int p = i * kGbWideThreads + tid;
+      const int64_t r = row0 + (p < nrows ? p : nrows - 1);
+      key[i] = static_cast<uint32_t>(gb_load(a.keys + r, (kGbNt & 1) != 0));
+    }
+#pragma unroll
+    for (int i = 0; i < kGbWideRpt; ++i) {
+      const int p = i * kGbWideThreads + tid;
+      const int64_t r = row0 + (p < nrows ? p : nrows - 1);
+      val[i] = gb_load(a.values + r, (kGbNt & 1) != 0);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kGbWideRpt; ++i) {
+      const int p = i * kGbWideThreads + tid;
+      const int64_t r = row0 + (p < nrows ? p : nrows - 1);
+      key[i] = static_cast<uint32_t>(gb_load(a.keys + r, (kGbNt & 1) != 0));
+      val[i] = gb_load(a.values + r, (kGbNt & 1) != 0);
+    }
   }
   __syncthreads();
   uint32_t pos[kGbWideRpt];
@@ -1392,6 +1417,7 @@ __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArg
     pos[i] = ok ? atomicAdd(&lds.start[gbp_hash(a, static_cast<int32_t>(key[i])) >> dshift], 1u) : 0xFFFFFFFFu;
   }
   __syncthreads();
+  GBP_STAMP(1);
   // exclusive scan of the bin counts: `per` consecutive bins per thread (1 or 2)
   const int per = (nb + kGbWideThreads - 1) / kGbWideThreads;
   uint32_t c[2] = {0, 0};
@@ -1443,10 +1469,12 @@ __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArg
   }
   if (tid == kGbWideThreads - 1) lds.total = pre;
   __syncthreads();
+  GBP_STAMP(2);
 #pragma unroll
   for (int i = 0; i < kGbWideRpt; ++i) {
     if (pos[i] != 0xFFFFFFFFu) pos[i] += lds.start[gbp_hash(a, static_cast<int32_t>(key[i])) >> dshift];
   }
+  GBP_STAMP(3);
   const int total = static_cast<int>(lds.total);
   GbpRec* __restrict__ out = reinterpret_cast<GbpRec*>(a.recs);
   for (int r = 0; r < kGbWideRounds; ++r) {
@@ -1461,6 +1489,7 @@ __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArg
       }
     }
     __syncthreads();
+    if (r == 0) GBP_STAMP(4);
     const int cnt = total - static_cast<int>(lo) < kGbWideChunk ? total - static_cast<int>(lo) : kGbWideChunk;
     for (int p = tid; p < cnt; p += kGbWideThreads) {
       const uint32_t k = lds.keys[p];
@@ -1483,7 +1512,10 @@ __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArg
       }
     }
     __syncthreads();
+    if (r == 0) GBP_STAMP(5);
+    if (r == 1) GBP_STAMP(6);
   }
+  GBP_STAMP(7);
 }
 
 // ---- K5: LDS aggregation.  One workgroup per work unit = <= kGbAggChunk rows of ONE partition
@@ -1626,40 +1658,56 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
     }
   };
   const bool pipe = a.agg_pipe != 0;  // A/B knob groupby_agg_pipe (uniform)
-  if (pipe && nit > 0) load_batch(0, knext, vnext, oknext);
-  for (int64_t it0 = 0; it0 < nit; it0 += U) {
-    if (!pipe) load_batch(it0, knext, vnext, oknext);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      kbuf[u] = knext[u];
-      vbuf[u] = vnext[u];
-      okbuf[u] = oknext[u];
-    }
-    if (pipe && it0 + U < nit) load_batch(it0 + U, knext, vnext, oknext);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-    if (!okbuf[u]) continue;
-    const int32_t key = kbuf[u];
-    const unsigned long long val = vbuf[u];
+  auto process_row = [&](const int32_t key, const unsigned long long val) {
     const uint32_t kp = gbp_hash(a, key);
     const uint32_t tag = kp & low_mask;
     if (tag == 0) {
       atomicAdd(&t.zsum, val);
       atomicAdd(&t.zcnt, 1u);
-      continue;
+      return;
     }
     // (a key that is not settled within kGbMaxProbes slots of its home goes to the HBM table: a full LDS table then
     //  costs a bounded number of probes per row, and both paths add into the same group in the end)
     uint32_t h = (kp >> hshift) & (SLOTS - 1);
     int probes = 0;
-    for (; probes < kGbMaxProbes; ++probes) {
-      uint32_t cur = t.tags[h];
-      if (cur == 0) {
-        cur = atomicCAS(&t.tags[h], 0u, tag);
-        if (cur == 0) cur = tag;
+    if constexpr (kGbAggGroupProbe != 0) {
+      // Probing by aligned GROUPS of four slots, one 16-byte LDS read per step: a wave goes round this loop as often as
+      // its unluckiest lane, and at the wide form's load (0.6) the longest of 64 single-slot probe sequences is 8 - 10 steps
+      // — each a dependent LDS round trip — where the longest group sequence is 2 - 3.  A key lives in the first group of
+      // its sequence that had a free slot when it arrived (slots are never freed, tags never change): a step finds the
+      // tag among the four, or claims the group's first empty slot; a slot read as empty may have been taken since — the
+      // CAS then returns the owner, which is this key (found) or another (next slot).
+      uint32_t g = h >> 2;
+      bool found = false;
+      for (; probes < kGbMaxProbes / 4; ++probes) {
+        const arx_u32x4 four = *reinterpret_cast<const arx_u32x4*>(&t.tags[g << 2]);
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+          if (found) continue;
+          uint32_t cur = four[sidx];
+          if (cur == 0) {
+            cur = atomicCAS(&t.tags[(g << 2) + sidx], 0u, tag);
+            if (cur == 0) cur = tag;
+          }
+          if (cur == tag) {
+            h = (g << 2) + sidx;
+            found = true;
+          }
+        }
+        if (found) break;
+        g = (g + 1) & (SLOTS / 4 - 1);
       }
-      if (cur == tag) break;
-      h = (h + 1) & (SLOTS - 1);
+      if (!found) probes = kGbMaxProbes;
+    } else {
+      for (; probes < kGbMaxProbes; ++probes) {
+        uint32_t cur = t.tags[h];
+        if (cur == 0) {
+          cur = atomicCAS(&t.tags[h], 0u, tag);
+          if (cur == 0) cur = tag;
+        }
+        if (cur == tag) break;
+        h = (h + 1) & (SLOTS - 1);
+      }
     }
     if (probes < kGbMaxProbes) {
       atomicAdd(&t.sums[h], val);
@@ -1676,6 +1724,104 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
         atomicAdd(&v.counts[slot], 1ull);
       }
     }
+  };
+  if constexpr (WIDE && kGbAosRaw != 0) {
+    // The pipeline registers hold the RAW quads (three 16-byte loads = four records) and the loads are unconditional:
+    // a thread whose four records reach past the partition's end reads the window [hi - 4, hi) instead and shifts it
+    // when it consumes it.  (With the loads inside an `if (whole quad) ... else ...`, as the first form had them, the
+    // compiler waits for them before the branches join — `s_waitcnt vmcnt(0)` right behind the loads, no pipeline at all:
+    // the kernel ran at one memory round trip per quad, 12.3 ms for 48 GB, whatever the number of rows in flight.)
+    constexpr int G = U / 4;
+    typedef arx_u32x4 __attribute__((aligned(4))) RecQuad;   // (a record starts at any multiple of 12 bytes)
+    const int64_t hi4 = hi >= 4 ? hi - 4 : 0;
+    arx_u32x4 cur[G][3], nxt[G][3];
+    auto issue = [&](int64_t it0, arx_u32x4 (*raw)[3]) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int64_t r0 = lo + ((it0 / 4 + g) * THREADS + tid) * 4;
+        const int64_t ws = r0 + 4 <= hi ? r0 : hi4;
+        const RecQuad* q = reinterpret_cast<const RecQuad*>(reinterpret_cast<const GbpRec*>(a.recs) + ws);
+        raw[g][0] = q[0];
+        raw[g][1] = q[1];
+        raw[g][2] = q[2];
+      }
+    };
+    auto consume = [&](int64_t it0, arx_u32x4 (*raw)[3]) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int64_t r0 = lo + ((it0 / 4 + g) * THREADS + tid) * 4;
+        if (r0 >= hi) continue;
+        uint32_t d[12];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          d[e] = raw[g][0][e];
+          d[4 + e] = raw[g][1][e];
+          d[8 + e] = raw[g][2][e];
+        }
+        const int shift = r0 + 4 <= hi ? 0 : static_cast<int>(r0 - hi4);   // 1 .. 3 behind the partition's last whole quad
+        for (int k = 0; k < shift; ++k) {
+#pragma unroll
+          for (int e = 0; e < 9; ++e) d[e] = d[e + 3];
+        }
+        if constexpr (kGbAggQuadProbe != 0) {
+          // the four home slots are read together (one LDS round trip for the quad instead of one per row): a row whose
+          // home slot already carries its tag — most rows, once a partition's groups are in — goes straight to its two
+          // adds; the others take the probing path from their home slot
+          uint32_t home[4], tg[4], seen[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t kp = gbp_hash(a, static_cast<int32_t>(d[3 * j]));
+            tg[j] = kp & low_mask;
+            home[j] = (kp >> hshift) & (SLOTS - 1);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) seen[j] = t.tags[home[j]];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (r0 + j >= hi) continue;
+            const unsigned long long val = (static_cast<unsigned long long>(d[3 * j + 2]) << 32) | d[3 * j + 1];
+            if (tg[j] != 0 && seen[j] == tg[j]) {
+              atomicAdd(&t.sums[home[j]], val);
+              atomicAdd(&t.cnts[home[j]], 1u);
+            } else {
+              process_row(static_cast<int32_t>(d[3 * j]), val);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (r0 + j < hi) process_row(static_cast<int32_t>(d[3 * j]), (static_cast<unsigned long long>(d[3 * j + 2]) << 32) | d[3 * j + 1]);
+          }
+        }
+      }
+    };
+    if (pipe && nit > 0) issue(0, nxt);
+    for (int64_t it0 = 0; it0 < nit; it0 += U) {
+      if (!pipe) issue(it0, nxt);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        cur[g][0] = nxt[g][0];
+        cur[g][1] = nxt[g][1];
+        cur[g][2] = nxt[g][2];
+      }
+      if (pipe && it0 + U < nit) issue(it0 + U, nxt);
+      consume(it0, cur);
+    }
+  } else {
+    if (pipe && nit > 0) load_batch(0, knext, vnext, oknext);
+    for (int64_t it0 = 0; it0 < nit; it0 += U) {
+      if (!pipe) load_batch(it0, knext, vnext, oknext);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        kbuf[u] = knext[u];
+        vbuf[u] = vnext[u];
+        okbuf[u] = oknext[u];
+      }
+      if (pipe && it0 + U < nit) load_batch(it0 + U, knext, vnext, oknext);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (okbuf[u]) process_row(kbuf[u], vbuf[u]);
+      }
     }
   }
   __syncthreads();
@@ -1946,7 +2092,7 @@ static int gbp_run_slice(const GroupbyView& v, GbpArgs a, const GbpPlan& plan, h
     hipLaunchKernelGGL(gbp_rooms_scan_kernel, dim3(1), dim3(1024), 0, st, a);
     ARX_CHECK_LAUNCH("gbp_rooms_scan_kernel");
     const unsigned wunits = static_cast<unsigned>(ceil_div(a.n, a.agg_chunk) + nparts);
-    hipLaunchKernelGGL((gbp_aggregate_kernel<false, false, kGbWideSlots, kGbWideThreads, true, 8>), dim3(wunits),
+    hipLaunchKernelGGL((gbp_aggregate_kernel<false, false, kGbWideSlots, kGbWideThreads, true, kGbWideAggU>), dim3(wunits),
                        dim3(kGbWideThreads), 0, st, v, a, nullptr, nullptr);
     ARX_CHECK_LAUNCH("gbp_aggregate_kernel (wide, rooms)");
     return ARX_OK;
@@ -1961,7 +2107,7 @@ static int gbp_run_slice(const GroupbyView& v, GbpArgs a, const GbpPlan& plan, h
                        dim3(kGbWideThreads), 0, st, a);
     ARX_CHECK_LAUNCH("gbp_scatter_wide_kernel");
     const unsigned wunits = static_cast<unsigned>(ceil_div(a.n, a.agg_chunk) + nparts);
-    hipLaunchKernelGGL((gbp_aggregate_kernel<false, false, kGbWideSlots, kGbWideThreads, true, 8>), dim3(wunits),
+    hipLaunchKernelGGL((gbp_aggregate_kernel<false, false, kGbWideSlots, kGbWideThreads, true, kGbWideAggU>), dim3(wunits),
                        dim3(kGbWideThreads), 0, st, v, a, nullptr, nullptr);
     ARX_CHECK_LAUNCH("gbp_aggregate_kernel (wide)");
     return ARX_OK;
@@ -2663,6 +2809,16 @@ int arx_hash_minmax_i64_finalize(const int64_t* mins, const int64_t* maxs, const
   ARX_CHECK_LAUNCH("hash_minmax_dense_finalize_kernel");
   return ARX_OK;
 }
+
+#ifdef ARX_GBP_PROFILE
+// the phase timestamps of the flat level's sampled workgroups, 64 x 8 x u64, 100 MHz
+int arx_debug_gbp_profile(void* dst_host) {
+  void* sym = nullptr;
+  ARX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_gbp_prof)));
+  ARX_HIP(hipMemcpy(dst_host, sym, sizeof(unsigned long long) * 64 * 8, hipMemcpyDeviceToHost));
+  return ARX_OK;
+}
+#endif
 
 int arx_hash_minmax_float_consume(const ArxSpan* values, int num_type, int values_is_scalar, double scalar_value,
                                   const uint32_t* group_ids, int64_t length, int64_t* mins, int64_t* maxs, uint32_t* null_seen,

@@ -1,0 +1,522 @@
+// Scalar aggregates of float32 / float64 columns for gfx950: min_max by order keys, and a sum that equals the
+// reference's bit for bit.
+//
+// What it restates (semantics only):
+//   MinMaxState<floating>  cpp/src/arrow/compute/kernels/aggregate_basic.inc.cc:681-701   fmin / fmax over NaN anti-extrema
+//   SumArray (floating)    cpp/src/arrow/compute/kernels/aggregate_internal.h:155-232      pairwise summation
+//   SumImpl / MeanImpl     cpp/src/arrow/compute/kernels/aggregate_basic.inc.cc:49-110, 262-286
+//
+// The reference's float sum is not "any order": SumArray adds the valid values of every RUN of valid slots in BLOCKS of 16
+// (left to right, a run's last block may be shorter, a new run starts a new block) and merges the block sums with a binary
+// counter — block i joins the partial sum of its level, two partial sums of one level are added and move up —, folding the
+// levels left over at the end from the lowest up.  That is a fixed tree over the sequence of blocks, so a parallel machine
+// can evaluate exactly the same additions:
+//   * blocks: one thread per block start adds its <= 16 values in order (fsum_leaf_* / fsum_block_sums);
+//   * the tree: an aligned group of 2^11 consecutive entries of one level is one complete subtree — a workgroup adds
+//     neighbours pairwise in LDS (fsum_tree): level L entries -> level L + 11 entries; the entries behind the last complete
+//     group (< 2^11 of them) are handed to the host as they are;
+//   * the host replays the binary counter over what is left (a few thousand doubles): complete subtrees enter at their
+//     level, which leaves the counter in exactly the state 2^L single blocks would have.
+// With nulls the block boundaries depend on where the runs start: per 64-row validity word the carry "rows of the run so
+// far, mod 16" (64 = 0 mod 16, so an all-valid word passes it on unchanged) is resolved by a two-level scan, block
+// starts are counted and numbered the same way, and every word's thread then adds the blocks that start in it.
+// HBM traffic: the values once (8 or 4 B/row) + 8 B per block (0.5 B/row without nulls).
+#include "arx_common.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace arx {
+
+// ------------------------------------------------------------------ min_max of floats: order keys, NaNs skipped
+// acc = {unused, count of valid values, min key, max key} (4 x int64, arx_reduce_i64_init); a column of NaNs only
+// leaves the anti-extrema INT64_MAX / INT64_MIN, whose own pattern as an order key is a NaN.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void reduce_float_minmax_kernel(const T* __restrict__ in, Bits valid, int64_t n,
+                                                                     unsigned long long* __restrict__ acc) {
+  __shared__ unsigned long long s_cnt[kWavesPerBlock];
+  __shared__ long long s_min[kWavesPerBlock], s_max[kWavesPerBlock];
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  unsigned long long cnt = 0;
+  long long mn = INT64_MAX, mx = INT64_MIN;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1ull;
+    const double d = static_cast<double>(in[i]);
+    if (ok) {
+      ++cnt;
+      if (d == d) {
+        const long long k = float_order_key(d);
+        mn = k < mn ? k : mn;
+        mx = k > mx ? k : mx;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    cnt += __shfl_xor(cnt, d, 64);
+    const long long omn = __shfl_xor(mn, d, 64), omx = __shfl_xor(mx, d, 64);
+    mn = omn < mn ? omn : mn;
+    mx = omx > mx ? omx : mx;
+  }
+  const int wave = threadIdx.x >> 6;
+  if (lane_id() == 0) {
+    s_cnt[wave] = cnt;
+    s_min[wave] = mn;
+    s_max[wave] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < kWavesPerBlock; ++k) {
+      cnt += s_cnt[k];
+      mn = s_min[k] < mn ? s_min[k] : mn;
+      mx = s_max[k] > mx ? s_max[k] : mx;
+    }
+    if (cnt != 0) {
+      atomicAdd(&acc[1], cnt);
+      atomicMin(reinterpret_cast<long long*>(&acc[2]), mn);
+      atomicMax(reinterpret_cast<long long*>(&acc[3]), mx);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ the pairwise sum
+constexpr int kFsumBlock = 16;                   // kBlockSize, aggregate_internal.h:169
+constexpr int kFsumLg = 11;                      // levels one tree pass climbs
+constexpr int kFsumGroup = 1 << kFsumLg;         // entries of one complete subtree
+constexpr int kFsumThreads = 256;
+constexpr int kFsumTileWords = 256;              // validity words per workgroup of the scan kernels
+
+// adjacent-pair tree over the kFsumGroup doubles in `e` (LDS); the result ends up in e[0]
+__device__ __forceinline__ void fsum_tree_in_lds(double* e, int tid) {
+  for (int d = 1; d < kFsumGroup; d <<= 1) {
+    __syncthreads();
+    for (int j = tid; j < kFsumGroup / (2 * d); j += kFsumThreads) {
+      const int i = 2 * d * j;
+      e[i] = e[i] + e[i + d];
+    }
+  }
+  __syncthreads();
+}
+
+// no nulls: block b = rows [16 b, 16 b + 16).  One workgroup per group of kFsumGroup blocks: complete groups leave one
+// level-11 entry in out[g], the blocks of the last, incomplete group go to tail[] as they are.
+template <typename T>
+__global__ __launch_bounds__(kFsumThreads) void fsum_leaf_dense_kernel(const T* __restrict__ in, int64_t n, int64_t nblocks,
+                                                                       double* __restrict__ out, double* __restrict__ tail) {
+  __shared__ double e[kFsumGroup];
+  const int tid = threadIdx.x;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kFsumGroup;
+  const int64_t have = nblocks - b0 < kFsumGroup ? nblocks - b0 : kFsumGroup;
+  for (int j = tid; j < kFsumGroup; j += kFsumThreads) {
+    double s = 0;
+    if (j < have) {
+      const int64_t r0 = (b0 + j) * kFsumBlock;
+      const int len = n - r0 < kFsumBlock ? static_cast<int>(n - r0) : kFsumBlock;
+      for (int k = 0; k < len; ++k) s += static_cast<double>(in[r0 + k]);
+    }
+    e[j] = s;
+  }
+  if (have < kFsumGroup) {   // (workgroup-uniform) the last group: no tree
+    __syncthreads();
+    for (int j = tid; j < have; j += kFsumThreads) tail[j] = e[j];
+    return;
+  }
+  fsum_tree_in_lds(e, tid);
+  if (tid == 0) out[blockIdx.x] = e[0];
+}
+
+// one tree pass: entries of one level -> entries 11 levels up (+ the tail)
+__global__ __launch_bounds__(kFsumThreads) void fsum_tree_kernel(const double* __restrict__ in, int64_t count,
+                                                                 double* __restrict__ out, double* __restrict__ tail) {
+  __shared__ double e[kFsumGroup];
+  const int tid = threadIdx.x;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kFsumGroup;
+  const int64_t have = count - b0 < kFsumGroup ? count - b0 : kFsumGroup;
+  if (have < kFsumGroup) {
+    for (int j = tid; j < have; j += kFsumThreads) tail[j] = in[b0 + j];
+    return;
+  }
+  for (int j = tid; j < kFsumGroup; j += kFsumThreads) e[j] = in[b0 + j];
+  fsum_tree_in_lds(e, tid);
+  if (tid == 0) out[blockIdx.x] = e[0];
+}
+
+// ---- with nulls.  Per validity word w (rows 64 w ..): carry(w) = rows of the run that reaches into w, mod 16.
+// A word with a null slot "resets": the carry it hands on is its number of leading (top) valid slots mod 16.
+struct FsumScan {
+  Bits valid;
+  int64_t nwords, ntiles;
+  uint8_t* word_carry;     // [nwords] carry from a reset inside the tile, 0xFF = the tile's carry-in
+  uint8_t* tile_last;      // [ntiles] carry the tile hands on, 0xFF = none of its words resets
+  uint8_t* tile_carry;     // [ntiles] carry into the tile
+  uint32_t* word_blocks;   // [nwords] block starts before the word, inside its tile
+  uint32_t* tile_blocks;   // [ntiles] block starts of the tile
+  int64_t* tile_base;      // [ntiles] block starts before the tile
+  int64_t* totals;         // {blocks, valid rows}
+};
+
+__device__ __forceinline__ int fsum_top_ones16(uint64_t m) { return __builtin_clzll(~m) & 15; }   // (m != all ones)
+
+__global__ __launch_bounds__(kFsumTileWords) void fsum_word_carry_kernel(FsumScan a) {
+  __shared__ int last_reset[kFsumTileWords];
+  __shared__ uint8_t top[kFsumTileWords];
+  const int t = threadIdx.x;
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * kFsumTileWords + t;
+  const uint64_t m = w < a.nwords ? load_word(a.valid, w) : ~uint64_t(0);   // (words past the end pass the carry on: unused)
+  const bool reset = m != ~uint64_t(0);
+  top[t] = reset ? static_cast<uint8_t>(fsum_top_ones16(m)) : 0;
+  last_reset[t] = reset ? t : -1;
+  // inclusive max-scan of the reset positions (Hillis-Steele over the tile)
+  for (int d = 1; d < kFsumTileWords; d <<= 1) {
+    __syncthreads();
+    const int other = t >= d ? last_reset[t - d] : -1;
+    __syncthreads();
+    if (other > last_reset[t]) last_reset[t] = other;
+  }
+  __syncthreads();
+  const int before = t > 0 ? last_reset[t - 1] : -1;
+  if (w < a.nwords) a.word_carry[w] = before >= 0 ? top[before] : 0xFF;
+  if (t == kFsumTileWords - 1) a.tile_last[blockIdx.x] = last_reset[t] >= 0 ? top[last_reset[t]] : 0xFF;
+}
+
+// carries into the tiles: tile_carry[i] = the last tile_last[j] != 0xFF with j < i (0 when there is none: the column's
+// first run starts at row 0).  1024 threads, each walks a contiguous chunk; thread 0 chains the chunk summaries.
+__global__ __launch_bounds__(1024) void fsum_tile_carry_kernel(FsumScan a) {
+  __shared__ uint8_t chunk_last[1024];
+  __shared__ uint8_t chunk_in[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (a.ntiles + 1023) / 1024;
+  const int64_t lo = t * per, hi = lo + per < a.ntiles ? lo + per : a.ntiles;
+  uint8_t last = 0xFF;
+  for (int64_t i = lo; i < hi; ++i) {
+    const uint8_t v = a.tile_last[i];
+    if (v != 0xFF) last = v;
+  }
+  chunk_last[t] = last;
+  __syncthreads();
+  if (t == 0) {
+    uint8_t run = 0;
+    for (int k = 0; k < 1024; ++k) {
+      chunk_in[k] = run;
+      if (chunk_last[k] != 0xFF) run = chunk_last[k];
+    }
+  }
+  __syncthreads();
+  uint8_t run = chunk_in[t];
+  for (int64_t i = lo; i < hi; ++i) {
+    a.tile_carry[i] = run;
+    const uint8_t v = a.tile_last[i];
+    if (v != 0xFF) run = v;
+  }
+}
+
+// block starts of the first run of a word (length L0 from bit 0, carry c): positions p < L0 with (c + p) % 16 == 0
+__device__ __forceinline__ int fsum_first_run_starts(int c, int L0) { return (c + L0 + 15) / 16 - (c > 0 ? 1 : 0); }
+
+__device__ __forceinline__ int fsum_run_length(uint64_t m, int s) {   // valid slots from bit s on (bit s is set)
+  const uint64_t inv = ~(m >> s);
+  const int l = inv == 0 ? 64 : __builtin_ctzll(inv);
+  return l < 64 - s ? l : 64 - s;
+}
+
+__global__ __launch_bounds__(kFsumTileWords) void fsum_word_blocks_kernel(FsumScan a) {
+  __shared__ uint32_t cnt[kFsumTileWords];
+  __shared__ unsigned long long s_valid;
+  const int t = threadIdx.x;
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * kFsumTileWords + t;
+  if (t == 0) s_valid = 0;
+  uint32_t starts = 0;
+  uint64_t m = 0;
+  if (w < a.nwords) {
+    m = load_word(a.valid, w);
+    const uint8_t wc = a.word_carry[w];
+    const int c = wc == 0xFF ? a.tile_carry[blockIdx.x] : wc;
+    const int L0 = (m & 1) ? fsum_run_length(m, 0) : 0;
+    starts = static_cast<uint32_t>(fsum_first_run_starts(c, L0));
+    uint64_t x = L0 >= 64 ? 0 : (m >> L0) << L0;   // the runs behind the first
+    while (x != 0) {
+      const int s = __builtin_ctzll(x);
+      const int l = fsum_run_length(m, s);
+      starts += static_cast<uint32_t>((l + 15) / 16);
+      x = s + l >= 64 ? 0 : (x >> (s + l)) << (s + l);
+    }
+  }
+  cnt[t] = starts;
+  __syncthreads();
+  const unsigned long long pc = wave_reduce_sum_u64(static_cast<unsigned long long>(__popcll(m)));
+  if (lane_id() == 0 && pc != 0) atomicAdd(&s_valid, pc);
+  // exclusive scan of the starts inside the tile
+  for (int d = 1; d < kFsumTileWords; d <<= 1) {
+    const uint32_t other = t >= d ? cnt[t - d] : 0;
+    __syncthreads();
+    cnt[t] += other;
+    __syncthreads();
+  }
+  if (w < a.nwords) a.word_blocks[w] = cnt[t] - starts;
+  if (t == kFsumTileWords - 1) {
+    a.tile_blocks[blockIdx.x] = cnt[t];
+    if (s_valid != 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.totals + 1), s_valid);
+  }
+}
+
+__global__ __launch_bounds__(1024) void fsum_tile_base_kernel(FsumScan a) {
+  __shared__ unsigned long long chunk_sum[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (a.ntiles + 1023) / 1024;
+  const int64_t lo = t * per, hi = lo + per < a.ntiles ? lo + per : a.ntiles;
+  unsigned long long s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += a.tile_blocks[i];
+  chunk_sum[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    unsigned long long run = 0;
+    for (int k = 0; k < 1024; ++k) {
+      const unsigned long long c = chunk_sum[k];
+      chunk_sum[k] = run;
+      run += c;
+    }
+    a.totals[0] = static_cast<int64_t>(run);
+  }
+  __syncthreads();
+  unsigned long long run = chunk_sum[t];
+  for (int64_t i = lo; i < hi; ++i) {
+    a.tile_base[i] = static_cast<int64_t>(run);
+    run += a.tile_blocks[i];
+  }
+}
+
+// every word's thread adds the blocks that START in it (a block of <= 16 rows may reach into the next word)
+template <typename T>
+__global__ __launch_bounds__(kFsumTileWords) void fsum_block_sums_kernel(FsumScan a, const T* __restrict__ in,
+                                                                         double* __restrict__ block_sums) {
+  const int t = threadIdx.x;
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * kFsumTileWords + t;
+  if (w >= a.nwords) return;
+  const uint64_t m = load_word(a.valid, w);
+  if (m == 0) return;
+  const uint64_t m2 = w + 1 < a.nwords ? load_word(a.valid, w + 1) : 0;
+  const uint8_t wc = a.word_carry[w];
+  const int c = wc == 0xFF ? a.tile_carry[blockIdx.x] : wc;
+  int64_t o = a.tile_base[blockIdx.x] + a.word_blocks[w];
+  const int64_t row0 = w << 6;
+  auto emit = [&](int p) {   // the block that starts at bit p: its valid slots in a row, at most 16
+    const uint64_t seq = p == 0 ? m : ((m >> p) | (m2 << (64 - p)));
+    const uint64_t inv = ~seq;
+    int len = inv == 0 ? 64 : __builtin_ctzll(inv);
+    len = len < kFsumBlock ? len : kFsumBlock;
+    double s = 0;
+    for (int k = 0; k < len; ++k) s += static_cast<double>(in[row0 + p + k]);
+    block_sums[o++] = s;
+  };
+  const int L0 = (m & 1) ? fsum_run_length(m, 0) : 0;
+  for (int p = (16 - c) & 15; p < L0; p += kFsumBlock) emit(p);
+  uint64_t x = L0 >= 64 ? 0 : (m >> L0) << L0;
+  while (x != 0) {
+    const int s = __builtin_ctzll(x);
+    const int l = fsum_run_length(m, s);
+    for (int p = s; p < s + l; p += kFsumBlock) emit(p);
+    x = s + l >= 64 ? 0 : (x >> (s + l)) << (s + l);
+  }
+}
+
+// the reference's binary counter (aggregate_internal.h:170-231), with entries that may enter above level 0
+struct PairwiseCounter {
+  double sum[80];
+  uint64_t mask = 0;
+  int root_level = 0;
+  PairwiseCounter() { std::memset(sum, 0, sizeof(sum)); }
+  void reduce(int level, double v) {
+    int cur = level;
+    uint64_t cur_mask = uint64_t(1) << cur;
+    sum[cur] += v;
+    mask ^= cur_mask;
+    while ((mask & cur_mask) == 0) {
+      v = sum[cur];
+      sum[cur] = 0;
+      ++cur;
+      cur_mask <<= 1;
+      sum[cur] += v;
+      mask ^= cur_mask;
+    }
+    root_level = std::max(root_level, cur);
+  }
+  double finish() {
+    for (int i = 1; i <= root_level; ++i) sum[i] += sum[i - 1];
+    return sum[root_level];
+  }
+};
+
+static inline size_t fsum_align(size_t x) { return (x + 255) & ~size_t(255); }
+
+static int64_t fsum_max_blocks(int64_t n, int64_t null_count) {
+  if (null_count == 0) return ceil_div(n, kFsumBlock);
+  const int64_t nulls = null_count < 0 ? n : null_count;   // unknown: every slot may be one
+  return std::min<int64_t>(ceil_div(n, kFsumBlock) + nulls + 1, (n + 1) / 2 + 1);
+}
+
+extern "C" {
+
+int arx_reduce_float_minmax(const ArxSpan* values, int num_type, void* acc, void* stream) {
+  if (values == nullptr || acc == nullptr || values->length < 0 || (num_type != ARX_NUM_FLOAT32 && num_type != ARX_NUM_FLOAT64)) {
+    set_error("bad arguments to arx_reduce_float_minmax");
+    return ARX_INVALID;
+  }
+  const int64_t n = values->length;
+  if (n == 0) return ARX_OK;
+  if (values->data == nullptr) {
+    set_error("NULL data buffer passed to arx_reduce_float_minmax");
+    return ARX_INVALID;
+  }
+  const Bits valid = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock * 8), int64_t(1) << 20)));
+  if (num_type == ARX_NUM_FLOAT64) {
+    hipLaunchKernelGGL(reduce_float_minmax_kernel<double>, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                       static_cast<const double*>(values->data) + values->offset, valid, n, static_cast<unsigned long long*>(acc));
+  } else {
+    hipLaunchKernelGGL(reduce_float_minmax_kernel<float>, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                       static_cast<const float*>(values->data) + values->offset, valid, n, static_cast<unsigned long long*>(acc));
+  }
+  ARX_CHECK_LAUNCH("reduce_float_minmax_kernel");
+  return ARX_OK;
+}
+
+size_t arx_sum_float_workspace_bytes(int64_t length, int64_t null_count) {
+  if (length <= 0) return 256;
+  const int64_t nwords = ceil_div(length, 64), ntiles = ceil_div(nwords, kFsumTileWords);
+  const int64_t blocks = fsum_max_blocks(length, null_count);
+  size_t bytes = 256;                                            // totals
+  if (null_count != 0) {
+    bytes += fsum_align(nwords) + 2 * fsum_align(ntiles);        // word_carry, tile_last, tile_carry
+    bytes += fsum_align(nwords * 4) + fsum_align(ntiles * 4) + fsum_align(ntiles * 8);
+    bytes += fsum_align(blocks * 8);                             // the block sums
+  }
+  int64_t count = blocks;
+  while (count > 0) {                                            // one output + one tail per pass
+    bytes += fsum_align((count / kFsumGroup + 1) * 8) + fsum_align(kFsumGroup * 8);
+    if (count < kFsumGroup) break;
+    count /= kFsumGroup;
+  }
+  return bytes + 1024;
+}
+
+int arx_sum_float(const ArxSpan* values, int num_type, void* ws, size_t ws_bytes, double* out_sum, int64_t* out_count,
+                  void* stream) {
+  if (values == nullptr || out_sum == nullptr || out_count == nullptr || values->length < 0 ||
+      (num_type != ARX_NUM_FLOAT32 && num_type != ARX_NUM_FLOAT64)) {
+    set_error("bad arguments to arx_sum_float");
+    return ARX_INVALID;
+  }
+  const int64_t n = values->length;
+  *out_sum = 0;
+  *out_count = 0;
+  if (n == 0) return ARX_OK;
+  const bool has_nulls = values->null_count != 0 && values->validity != nullptr;
+  if (values->data == nullptr || ws == nullptr || ws_bytes < arx_sum_float_workspace_bytes(n, has_nulls ? values->null_count : 0)) {
+    set_error("arx_sum_float: NULL buffer or a workspace below arx_sum_float_workspace_bytes");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  uint8_t* p = static_cast<uint8_t*>(ws);
+  auto take = [&](size_t bytes) {
+    uint8_t* r = p;
+    p += fsum_align(bytes);
+    return r;
+  };
+  int64_t* totals = reinterpret_cast<int64_t*>(take(256));
+  const double* level = nullptr;   // the entries of the current level
+  int64_t count = 0;
+  // what the host gets: per pass its tail (level, entries), last the top array
+  struct Piece { int level; const double* dev; int64_t n; };
+  std::vector<Piece> pieces;
+  int cur_level = 0;
+  const int64_t max_blocks = fsum_max_blocks(n, has_nulls ? values->null_count : 0);
+  if (!has_nulls) {
+    count = ceil_div(n, kFsumBlock);
+    const int64_t groups = ceil_div(count, kFsumGroup);
+    double* out = reinterpret_cast<double*>(take((count / kFsumGroup + 1) * 8));
+    double* tail = reinterpret_cast<double*>(take(kFsumGroup * 8));
+    if (num_type == ARX_NUM_FLOAT64) {
+      hipLaunchKernelGGL(fsum_leaf_dense_kernel<double>, dim3(static_cast<unsigned>(groups)), dim3(kFsumThreads), 0, st,
+                         static_cast<const double*>(values->data) + values->offset, n, count, out, tail);
+    } else {
+      hipLaunchKernelGGL(fsum_leaf_dense_kernel<float>, dim3(static_cast<unsigned>(groups)), dim3(kFsumThreads), 0, st,
+                         static_cast<const float*>(values->data) + values->offset, n, count, out, tail);
+    }
+    ARX_CHECK_LAUNCH("fsum_leaf_dense_kernel");
+    if (count % kFsumGroup != 0) pieces.push_back({0, tail, count % kFsumGroup});
+    level = out;
+    count /= kFsumGroup;
+    cur_level = kFsumLg;
+    *out_count = n;
+  } else {
+    FsumScan a{};
+    a.valid = make_bits(values->validity, values->offset, n);
+    a.nwords = ceil_div(n, 64);
+    a.ntiles = ceil_div(a.nwords, kFsumTileWords);
+    a.word_carry = take(a.nwords);
+    a.tile_last = take(a.ntiles);
+    a.tile_carry = take(a.ntiles);
+    a.word_blocks = reinterpret_cast<uint32_t*>(take(a.nwords * 4));
+    a.tile_blocks = reinterpret_cast<uint32_t*>(take(a.ntiles * 4));
+    a.tile_base = reinterpret_cast<int64_t*>(take(a.ntiles * 8));
+    a.totals = totals;
+    double* block_sums = reinterpret_cast<double*>(take(max_blocks * 8));
+    ARX_HIP(hipMemsetAsync(totals, 0, 16, st));
+    const unsigned tiles = static_cast<unsigned>(a.ntiles);
+    hipLaunchKernelGGL(fsum_word_carry_kernel, dim3(tiles), dim3(kFsumTileWords), 0, st, a);
+    hipLaunchKernelGGL(fsum_tile_carry_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(fsum_word_blocks_kernel, dim3(tiles), dim3(kFsumTileWords), 0, st, a);
+    hipLaunchKernelGGL(fsum_tile_base_kernel, dim3(1), dim3(1024), 0, st, a);
+    if (num_type == ARX_NUM_FLOAT64) {
+      hipLaunchKernelGGL(fsum_block_sums_kernel<double>, dim3(tiles), dim3(kFsumTileWords), 0, st, a,
+                         static_cast<const double*>(values->data) + values->offset, block_sums);
+    } else {
+      hipLaunchKernelGGL(fsum_block_sums_kernel<float>, dim3(tiles), dim3(kFsumTileWords), 0, st, a,
+                         static_cast<const float*>(values->data) + values->offset, block_sums);
+    }
+    ARX_CHECK_LAUNCH("fsum_block_sums_kernel");
+    int64_t h[2];
+    ARX_HIP(hipMemcpyAsync(h, totals, 16, hipMemcpyDeviceToHost, st));
+    ARX_HIP(hipStreamSynchronize(st));
+    if (h[0] < 0 || h[0] > max_blocks) {
+      set_error("arx_sum_float: %lld blocks for a workspace of %lld (null_count understated?)", static_cast<long long>(h[0]),
+                static_cast<long long>(max_blocks));
+      return ARX_INVALID;
+    }
+    count = h[0];
+    *out_count = h[1];
+    level = block_sums;
+    cur_level = 0;
+  }
+  while (count >= kFsumGroup) {
+    const int64_t groups = ceil_div(count, kFsumGroup);
+    double* out = reinterpret_cast<double*>(take((count / kFsumGroup + 1) * 8));
+    double* tail = reinterpret_cast<double*>(take(kFsumGroup * 8));
+    hipLaunchKernelGGL(fsum_tree_kernel, dim3(static_cast<unsigned>(groups)), dim3(kFsumThreads), 0, st, level, count, out, tail);
+    ARX_CHECK_LAUNCH("fsum_tree_kernel");
+    if (count % kFsumGroup != 0) pieces.push_back({cur_level, tail, count % kFsumGroup});
+    level = out;
+    count /= kFsumGroup;
+    cur_level += kFsumLg;
+  }
+  if (count > 0) pieces.push_back({cur_level, level, count});
+  // block order: the top array's entries come first, then the tails from the highest level down
+  std::vector<std::vector<double>> host(pieces.size());
+  for (size_t i = 0; i < pieces.size(); ++i) {
+    host[i].resize(static_cast<size_t>(pieces[i].n));
+    ARX_HIP(hipMemcpyAsync(host[i].data(), pieces[i].dev, static_cast<size_t>(pieces[i].n) * 8, hipMemcpyDeviceToHost, st));
+  }
+  ARX_HIP(hipStreamSynchronize(st));
+  if (*out_count == 0) return ARX_OK;   // (data_size == 0: the sum is 0, :164-166)
+  PairwiseCounter counter;
+  for (size_t i = pieces.size(); i-- > 0;) {
+    for (double v : host[i]) counter.reduce(pieces[i].level, v);
+  }
+  *out_sum = counter.finish();
+  return ARX_OK;
+}
+
+}  // extern "C"
+
+}  // namespace arx

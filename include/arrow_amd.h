@@ -410,6 +410,28 @@ int arx_binary_rebase_offsets(const int32_t* offsets, int64_t length, int32_t ba
  * the caller from count and the inputs' null counts, as Finalize does.  Asynchronous. */
 int arx_reduce_i64_init(void* acc, void* stream);
 int arx_reduce_i64_consume(const ArxSpan* values, void* acc, void* stream);
+/* coalesce(values, fill) of ONE fixed-width type — what fill_null(values, fill_value) calls (CoalesceFunctor,
+ * compute/kernels/scalar_if_else.cc): out[i] = values[i] where valid, else fill[i] (fill != NULL: an array of the same
+ * length) or *fill_scalar (byte_width bytes; booleans: one byte 0 / 1); fill == NULL && fill_scalar == NULL: a null
+ * scalar (the values' own validity survives).  byte_width 1 / 2 / 4 / 8, or 0 for booleans (bitmaps).  out_validity
+ * (ceil(length / 64) words, always written) = valid(values) | valid(fill); null result slots are zeroed.  Asynchronous. */
+int arx_coalesce2(int byte_width, const ArxSpan* values, const ArxSpan* fill, const void* fill_scalar, int64_t length,
+                  void* out_data, void* out_validity, void* stream);
+/* min_max of a float32 / float64 column (num_type ARX_NUM_FLOAT32 / _FLOAT64) — MinMaxState<floating>
+ * (aggregate_basic.inc.cc:681-701: fmin / fmax over NaN anti-extrema): acc (arx_reduce_i64_init) gets [1] += the valid
+ * values, [2] / [3] = min / max of the ORDER KEYS of the valid non-NaN values (the int64 whose signed order is the
+ * doubles' numeric order, -0.0 just below +0.0); the untouched INT64_MAX / INT64_MIN read back as NaN.  Asynchronous. */
+int arx_reduce_float_minmax(const ArxSpan* values, int num_type, void* acc, void* stream);
+/* sum of a float32 / float64 column, BIT FOR BIT the reference's: SumArray's pairwise summation
+ * (compute/kernels/aggregate_internal.h:155-232 — the valid values of every run in blocks of 16, left to right; block sums
+ * merged by a binary counter; float32 values are widened to double first, as SumImpl's accumulator type asks) is a fixed tree
+ * of additions, evaluated here block by block and level by level on the device and finished on the host over the few
+ * thousand partial sums that are left.  *out_count = the valid values (MeanImpl divides by it).  One call = one
+ * Consume of one batch (the caller adds batch sums in batch order, as SumImpl does).  ws: device scratch of
+ * arx_sum_float_workspace_bytes(length, null_count) bytes (null_count < 0: unknown).  Synchronous. */
+size_t arx_sum_float_workspace_bytes(int64_t length, int64_t null_count);
+int arx_sum_float(const ArxSpan* values, int num_type, void* ws, size_t ws_bytes, double* out_sum, int64_t* out_count,
+                  void* stream);
 
 /* Kleene logic on boolean arrays — KleeneAndOp / KleeneOrOp (array, array) and InvertOp,
  * cpp/src/arrow/compute/kernels/scalar_boolean.cc:138-260.  left/right: boolean ArxSpans (data =

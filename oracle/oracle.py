@@ -814,6 +814,47 @@ class HashMinMaxState:
         return self.mins.copy(), self.maxs.copy(), valid
 
 
+def sum_float_pairwise(values, valid=None):
+    """SumArray for floating point (kernels/aggregate_internal.h:155-232) -> (sum: float64, count): the valid values of
+    every run of valid slots in blocks of 16 (a run's last block may be shorter), each block added left to right
+    from 0.0 in double, the block sums merged by the binary counter of :170-198 and the left-over levels folded from
+    the lowest up (:226-231).  `valid`: bool[n] or None.  numpy for the blocks (np.add.at applies its updates in index
+    order, i.e. left to right), a Python loop over the block sums for the counter."""
+    v = np.asarray(values).astype(np.float64)
+    n = len(v)
+    ok = np.ones(n, bool) if valid is None else np.asarray(valid, bool)
+    count = int(ok.sum())
+    if count == 0:
+        return 0.0, 0
+    idx = np.flatnonzero(ok)
+    prev_ok = np.concatenate([[False], ok[:-1]])
+    run_start = np.flatnonzero(ok & ~prev_ok)                       # first row of every run
+    start_of = run_start[np.searchsorted(run_start, idx, side="right") - 1]
+    pos = idx - start_of                                            # position inside the run
+    is_block_start = (pos % 16) == 0
+    block_id = np.cumsum(is_block_start) - 1
+    block_sums = np.zeros(int(block_id[-1]) + 1, np.float64)
+    np.add.at(block_sums, block_id, v[idx])
+    levels = max(1, int(count).bit_length()) + 1
+    sums = [0.0] * (levels + 1)
+    mask = 0
+    root = 0
+    for b in block_sums.tolist():
+        cur = 0
+        sums[0] += b
+        mask ^= 1
+        while (mask >> cur) & 1 == 0:
+            b = sums[cur]
+            sums[cur] = 0.0
+            cur += 1
+            sums[cur] += b
+            mask ^= 1 << cur
+        root = max(root, cur)
+    for i in range(1, root + 1):
+        sums[i] += sums[i - 1]
+    return sums[root], count
+
+
 class HashCountState:
     """GroupedCountImpl with dense group ids (kernels/hash_aggregate.cc:107-212): mode "only_valid" / "only_null" /
     "all" (CountOptions::CountMode); Merge adds (:156-170); the result is never null.  Plain numpy."""

@@ -2116,6 +2116,125 @@ def check_hash_minmax_float_kernels(amd, rng, dtype=np.float64, n=5000, num_grou
             assert bool((mine[gs][sel][ok] == ref[ok]).all()), f"oracle float {col} vs pyarrow"
 
 
+def check_sum_float(amd, rng, sizes, null_ps=(0.0, 0.01, 0.3, 0.97), dtypes=(np.float64, np.float32), oracle_max=300_000):
+    """arx_sum_float: the float sum equals the reference's BIT FOR BIT (SumArray's pairwise summation is a fixed tree of
+    additions) — against the oracle's restatement (sizes up to oracle_max) and against pyarrow's own pc.sum on the same
+    host array; slices at odd offsets, all-null and all-valid bitmaps, NaN / inf / -0.0 among the values; and
+    arx_reduce_float_minmax (order keys) against numpy's fmin / fmax."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+    for dtype in dtypes:
+        num_type = 9 if np.dtype(dtype) == np.float64 else 8
+        for n in sizes:
+            for null_p in null_ps:
+                offset = int(rng.integers(0, 70)) if n else 0
+                a = util.random_array(rng, dtype, n, null_p=null_p, offset=offset, tail=5)
+                a.values *= (10.0 ** rng.integers(-15, 15, len(a.values))).astype(dtype)
+                if n > 40:
+                    a.values[offset + 7] = -0.0
+                    if null_p == 0.01:
+                        a.values[offset + 11] = np.inf
+                    if null_p == 0.3 and n > 3000:
+                        a.values[offset + 1000] = np.nan
+                d = a.to_device(amd)
+                sp = d.span()
+                nulls = d.null_count if d.null_count is not None else -1
+                ws_bytes = lib.arx_sum_float_workspace_bytes(n, nulls)
+                ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+                out_sum, out_count = C.c_double(0), C.c_int64(0)
+                _lib.check(lib.arx_sum_float(C.byref(sp), num_type, ws.data_ptr(), ws_bytes, C.byref(out_sum), C.byref(out_count), st))
+                tag = f"sum_float[{np.dtype(dtype).name},n={n},null_p={null_p},offset={offset}]"
+                vals = a.values[offset:offset + n]
+                valid = None if a.valid is None else a.valid[offset:offset + n]
+                want_count = n if valid is None else int(valid.sum())
+                assert out_count.value == want_count, (tag, out_count.value, want_count)
+                got = np.float64(out_sum.value)
+                if n <= oracle_max:
+                    want, _ = O.sum_float_pairwise(vals, valid)
+                    assert got.tobytes() == np.float64(want).tobytes() or (np.isnan(got) and np.isnan(want)), (tag, "oracle", got, want)
+                if pa is not None:
+                    ref = pc.sum(pa.array(vals, mask=None if valid is None else ~valid), min_count=0).as_py()
+                    assert got.tobytes() == np.float64(ref).tobytes() or (np.isnan(got) and np.isnan(ref)), (tag, "pyarrow", got, ref)
+                # min / max by order keys
+                acc = torch.zeros(4, dtype=torch.int64, device=dev)
+                _lib.check(lib.arx_reduce_i64_init(acc.data_ptr(), st))
+                _lib.check(lib.arx_reduce_float_minmax(C.byref(sp), num_type, acc.data_ptr(), st))
+                h = acc.cpu().numpy()
+                ok = np.ones(n, bool) if valid is None else valid
+                assert int(h[1]) == want_count, (tag, "minmax count")
+                live = vals[ok].astype(np.float64)
+                live = live[~np.isnan(live)]
+                if len(live):
+                    def unkey(k):
+                        k = np.int64(k)
+                        u = np.uint64(k) if k >= 0 else ~(np.uint64(k) ^ np.uint64(1 << 63))
+                        return np.array([u], np.uint64).view(np.float64)[0]
+                    assert unkey(h[2]) == live.min() and unkey(h[3]) == live.max(), (tag, unkey(h[2]), live.min(), unkey(h[3]), live.max())
+                else:
+                    assert int(h[2]) == np.iinfo(np.int64).max and int(h[3]) == np.iinfo(np.int64).min, (tag, "anti-extrema")
+
+
+def check_coalesce2(amd, rng, n=5000):
+    """arx_coalesce2 (fill_null's kernel): every fixed width and boolean; fill = an array with nulls of its own, a
+    valid scalar, a null scalar; values with and without a bitmap, at offsets — against numpy's where() and pyarrow's
+    own coalesce on the same host arrays."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+    for dtype in (np.bool_, np.int8, np.uint16, np.int32, np.float32, np.int64, np.float64):
+        width = 0 if dtype == np.bool_ else np.dtype(dtype).itemsize
+        for null_p in (0.0, 0.3, 1.0):
+            for fill_kind in ("array", "scalar", "null_scalar"):
+                a = util.random_array(rng, dtype, n, null_p=null_p, offset=int(rng.integers(0, 70)), tail=3)
+                b = util.random_array(rng, dtype, n, null_p=0.2, offset=int(rng.integers(0, 70)), tail=3)
+                da, db = a.to_device(amd), b.to_device(amd)
+                sa, sb = da.span(), db.span()
+                words = (n + 63) // 64
+                out = torch.zeros(words * 8 + 8 if width == 0 else max(n * width, 8), dtype=torch.uint8, device=dev)
+                ov = torch.zeros(words + 1, dtype=torch.int64, device=dev)
+                sc_host = np.array([b.values[b.offset]], dtype=np.uint8 if width == 0 else dtype)
+                fill_ptr = C.byref(sb) if fill_kind == "array" else None
+                sc_ptr = sc_host.ctypes.data_as(C.c_void_p) if fill_kind == "scalar" else None
+                _lib.check(lib.arx_coalesce2(width, C.byref(sa), fill_ptr, sc_ptr, n, out.data_ptr(), ov.data_ptr(), st))
+                av = np.ones(n, bool) if a.valid is None else a.valid[a.offset:a.offset + n]
+                avals = a.values[a.offset:a.offset + n]
+                if fill_kind == "array":
+                    bv = np.ones(n, bool) if b.valid is None else b.valid[b.offset:b.offset + n]
+                    bvals = b.values[b.offset:b.offset + n]
+                elif fill_kind == "scalar":
+                    bv, bvals = np.ones(n, bool), np.full(n, b.values[b.offset], dtype)
+                else:
+                    bv, bvals = np.zeros(n, bool), np.zeros(n, dtype)
+                want_valid = av | bv
+                want = np.where(av, avals, bvals)
+                got_valid = np.unpackbits(ov.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
+                tag = f"coalesce2[{np.dtype(dtype).name},null_p={null_p},{fill_kind}]"
+                assert_equal(got_valid, want_valid, tag + " validity")
+                if width == 0:
+                    got = np.unpackbits(out.cpu().numpy(), bitorder="little")[:n].astype(bool)
+                else:
+                    got = out.cpu().numpy()[: n * width].view(dtype)
+                assert_equal(got[want_valid].view(np.uint8 if width == 0 else f"u{width}"),
+                             want[want_valid].view(np.uint8 if width == 0 else f"u{width}"), tag + " values")
+                if pa is not None:
+                    pa_a = pa.array(avals, mask=~av)
+                    pa_b = pa.array(bvals, mask=~bv) if fill_kind == "array" else pa.scalar(None if fill_kind == "null_scalar" else bvals[0].item(), pa_a.type)
+                    ref = pc.coalesce(pa_a, pa_b)
+                    assert_equal(np.asarray(ref.is_valid()), got_valid, tag + " validity vs pyarrow")
+                    assert pa.array(got, mask=~got_valid).equals(ref), tag + " vs pyarrow"
+
+
 def check_bitmap_copy_segments(amd, rng, scale=1):
     """arx_bitmap_copy_segments: bit ranges at any source bit offset ORed into zeroed bitmaps back to back (ranges meet
     inside words), NULL sources (= all ones), empty ranges, two destination bitmaps in one launch."""

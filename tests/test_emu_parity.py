@@ -977,6 +977,14 @@ def test_hash_minmax_float_dense_kernels(emu_ctx, dtype, n, num_groups, null_p):
     P.check_hash_minmax_float_kernels(emu_ctx, rng_for("hmmf", n, num_groups), dtype=dtype, n=n, num_groups=num_groups, null_p=null_p)
 
 
+def test_float_sum_is_the_references_bit_for_bit_and_float_min_max(emu_ctx):
+    P.check_sum_float(emu_ctx, rng_for("fsum"), [0, 1, 15, 16, 17, 63, 64, 65, 1000, 4097, 16385, 40001])
+
+
+def test_coalesce_of_two_operands_is_fill_null(emu_ctx):
+    P.check_coalesce2(emu_ctx, rng_for("coalesce2"), n=3000)
+
+
 def test_buffer_copy(emu_ctx):
     P.check_buffer_copy(emu_ctx, rng_for("bufcopy"), 1)
 

@@ -1331,6 +1331,14 @@ def test_hash_minmax_float_dense_kernels(gpu_ctx, dtype, n, num_groups, null_p):
     P.check_hash_minmax_float_kernels(gpu_ctx, rng_for("hmmf", n, num_groups), dtype=dtype, n=n, num_groups=num_groups, null_p=null_p)
 
 
+def test_float_sum_is_the_references_bit_for_bit_and_float_min_max(gpu_ctx):
+    P.check_sum_float(gpu_ctx, rng_for("fsum"), [0, 1, 17, 4097, 32768, 32769, 1000003, 67108864 + 12345])
+
+
+def test_coalesce_of_two_operands_is_fill_null(gpu_ctx):
+    P.check_coalesce2(gpu_ctx, rng_for("coalesce2"), n=1000003)
+
+
 def test_buffer_copy(gpu_ctx):
     P.check_buffer_copy(gpu_ctx, rng_for("bufcopy"), 40)
 

@@ -132,3 +132,11 @@ def test_reference_kernels_of_the_extended_functions_refuse_device_arrays_emulat
 
 def test_hash_min_max_of_floats_and_temporal_types_emulated():
     _run(G.FLOAT_EXTREMA_SCRIPT, "FLOAT_EXTREMA_OK", 0.02)
+
+
+def test_scalar_aggregates_of_float_boolean_and_temporal_device_columns_emulated():
+    _run(G.FLOAT_AGGREGATE_SCRIPT, "FLOAT_AGGREGATE_OK", 0.02)
+
+
+def test_fill_null_on_device_resident_arrays_emulated():
+    _run(G.FILL_NULL_SCRIPT, "FILL_NULL_OK", 0.02)
