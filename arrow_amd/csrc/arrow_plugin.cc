@@ -166,6 +166,43 @@ int arrow_amd_copy_to_device(struct ArrowArray* in, struct ArrowSchema* schema, 
   }
   return 0;
 }
+// Device memory the CALLER owns (a torch tensor, a hipMalloc'd block) as an Arrow array, without a copy: a fixed-width or
+// boolean array of `schema`'s type (consumed) over `data` (+ `validity`, NULL = no nulls) in HBM, exported through the C
+// Device Data interface.  The buffers are borrowed: the memory must outlive every array made from the export (results
+// of kernels are new buffers).  null_count < 0: counted here (arx_bitmap_popcount), because nothing may count a device
+// bitmap on the CPU later.  0 on success.
+int arrow_amd_wrap_device_memory(struct ArrowSchema* schema, int64_t length, int64_t null_count, const void* validity,
+                                 const void* data, struct ArrowDeviceArray* out) {
+  auto run = [&]() -> Status {
+    ARROW_ASSIGN_OR_RAISE(auto type, arrow::ImportType(schema));
+    const int width = type->id() == Type::BOOL ? 0 : FixedByteWidth(*type);
+    if (type->id() != Type::BOOL && width == 0) return Status::NotImplemented("arrow_amd_wrap_device_memory: ", type->ToString());
+    if (length < 0 || (length > 0 && data == nullptr)) return Status::Invalid("arrow_amd_wrap_device_memory: bad length / data");
+    ARROW_ASSIGN_OR_RAISE(auto mm, RocmMemoryManagerFor(0));
+    const int64_t data_bytes = width == 0 ? arrow::bit_util::BytesForBits(length) : length * width;
+    auto values = std::make_shared<Buffer>(static_cast<const uint8_t*>(data), data_bytes, mm);
+    std::shared_ptr<Buffer> bitmap;
+    if (validity != nullptr) {
+      bitmap = std::make_shared<Buffer>(static_cast<const uint8_t*>(validity), arrow::bit_util::BytesForBits(length), mm);
+      if (null_count < 0) {
+        hipStream_t st;
+        ARROW_RETURN_NOT_OK(t_scratch.Stream(&st));
+        ARROW_ASSIGN_OR_RAISE(null_count, DeviceNullCount(*bitmap, length, st));
+      }
+      if (null_count == 0) bitmap = nullptr;
+    } else {
+      null_count = 0;
+    }
+    auto arr = arrow::MakeArray(ArrayData::Make(std::move(type), length, {std::move(bitmap), std::move(values)}, null_count));
+    return arrow::ExportDeviceArray(*arr, nullptr, out);
+  };
+  const Status st = run();
+  if (!st.ok()) {
+    t_error = st.ToString();
+    return -1;
+  }
+  return 0;
+}
 // Device array (C Device Data interface, consumed) -> host array (C Data interface).
 int arrow_amd_copy_to_host(struct ArrowDeviceArray* in, struct ArrowSchema* schema, struct ArrowArray* out,
                            struct ArrowSchema* out_schema) {

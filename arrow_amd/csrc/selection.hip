@@ -1165,9 +1165,10 @@ static int launch_compact(bool iota, int W, const CompactArgs& a, hipStream_t st
                         (W >= 8 || (out_length >= 0 && out_length * 4 <= a.length))));
   // GetTakeIndices: the gather form (row numbers instead of gathered values) unless the bitmap is
   // being inverted for the sort's null partition
-  if (iota && !a.invert && g_filter_sparse != 0 && (W == 2 || W == 4)) {
+  if (iota && !a.invert && g_filter_sparse != 0 && (W == 2 || W == 4 || W == 8)) {
     if (W == 2) launch_sparse_w<2, true>(a, grid, st);
-    else launch_sparse_w<4, true>(a, grid, st);
+    else if (W == 4) launch_sparse_w<4, true>(a, grid, st);
+    else launch_sparse_w<8, true>(a, grid, st);
     ARX_CHECK_LAUNCH("compact_sparse_kernel<IOTA>");
     return ARX_OK;
   }
@@ -1407,9 +1408,15 @@ int arx_mask_to_indices(const ArxSpan* mask, int null_selection, const void* ws,
     set_error("ws is NULL");
     return ARX_INVALID;
   }
-  if (index_width != 2 && index_width != 4) {
-    set_error("index_width must be 2 or 4");
+  if (index_width != 2 && index_width != 4 && index_width != 8) {
+    set_error("index_width must be 2, 4 or 8");
     return ARX_INVALID;
+  }
+  // 8: the uint64 row numbers indices_nonzero returns (DoNonZero, kernels/vector_selection.cc:228-300), written by the
+  // gather form directly instead of widened from uint32 in a second pass
+  if (index_width == 8 && (g_filter_sparse == 0 || null_selection == ARX_FILTER_EMIT_NULL)) {
+    set_error("index_width 8 is served by the gather form with DROP only");
+    return ARX_NOT_IMPLEMENTED;
   }
   // GetTakeIndicesFromBitmap: uint16 up to 65535 rows, uint32 up to UINT32_MAX, else
   // NotImplemented (vector_selection_take_internal.cc:258-272)

@@ -430,6 +430,56 @@ def parity_spot_check(amd, values, validity, mask, n_total: int):
 
 
 # ------------------------------------------------------------------ legs
+# ------------------------------------------------------------------ the drop-in route: pyarrow.compute on device arrays
+class PluginSession:
+    """libarrow_amd_plugin.so loaded and registered in this process: from here on pyarrow.compute / Acero calls on
+    device-resident arrays run the HIP kernels behind Arrow's own FunctionRegistry (and host calls of the extended
+    functions pass through the shim to the reference kernels), so every CPU baseline is taken BEFORE this is made."""
+
+    def __init__(self):
+        import ctypes
+
+        import pyarrow as pa
+
+        from arrow_amd.plugin_build import build_plugin
+
+        self.ctypes, self.pa = ctypes, pa
+        self.lib = ctypes.CDLL(build_plugin(verbose=False))
+        self.lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+        self.lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+        self.lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        self.lib.arrow_amd_wrap_device_memory.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                                          ctypes.c_void_p, ctypes.c_void_p]
+        assert self.lib.arrow_amd_register() == 0, self.lib.arrow_amd_plugin_last_error()
+
+    def wrap(self, pa_type, length, data: torch.Tensor, validity: torch.Tensor = None, null_count: int = 0):
+        """A torch tensor's HBM as a device-resident pyarrow array, zero-copy (arrow_amd_wrap_device_memory)."""
+        ct, pa = self.ctypes, self.pa
+        c_schema, c_dev = ct.create_string_buffer(72), ct.create_string_buffer(128)
+        pa_type._export_to_c(ct.addressof(c_schema))
+        rc = self.lib.arrow_amd_wrap_device_memory(ct.addressof(c_schema), length, null_count,
+                                                   validity.data_ptr() if validity is not None else None, data.data_ptr(),
+                                                   ct.addressof(c_dev))
+        assert rc == 0, self.lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ct.addressof(c_dev), pa_type)
+
+    def to_device(self, arr):
+        ct, pa = self.ctypes, self.pa
+        c_arr, c_schema, c_dev = (ct.create_string_buffer(k) for k in (80, 72, 128))
+        arr._export_to_c(ct.addressof(c_arr), ct.addressof(c_schema))
+        assert self.lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, self.lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ct.addressof(c_dev), arr.type)
+
+
+_PLUGIN = [None]
+
+
+def plugin_session():
+    if _PLUGIN[0] is None:
+        _PLUGIN[0] = PluginSession()
+    return _PLUGIN[0]
+
+
 def run_filter_take(args, rank, world, device):
     import arrow_amd as amd
     from arrow_amd import tracing
@@ -443,6 +493,20 @@ def run_filter_take(args, rank, world, device):
     dv = amd.Array(amd.array.int64, n, [validity, values], -1, 0)
     dm = amd.Array(amd.array.bool_, n, [None, mask], 0, 0)
 
+    # ---- the reference's CPU kernels FIRST (rank 0, N = 1): registering the plugin re-routes pyarrow's own functions
+    cpu = {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu["filter_take"] = cpu_baseline_filter_take(values, validity, mask, n, args.cpu_sample_rows, args.cpu_budget_s)
+        if args.extras and not EMU:
+            for name, fn in (("hash_sum", lambda: cpu_baseline_hash_sum(min(args.hash_sum_rows, args.cpu_groupby_rows), args.groups, args.cpu_budget_s)),
+                             ("sort_indices", lambda: cpu_baseline_sort(min(args.sort_rows, args.cpu_sort_rows)))):
+                try:
+                    cpu[name] = fn()
+                except Exception as e:
+                    cpu[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    _CPU_PRE.update(cpu)
+
+    # ---- the Python mirror of the C ABI (arrow_amd.compute): the loop the kernel events are taken in
     def step():
         out = amd.compute.filter(dv, dm)
         idx = amd.compute.get_take_indices(dm)
@@ -461,10 +525,51 @@ def run_filter_take(args, rank, world, device):
         out, idx, tk = step()
     _sync(device)
     _barrier(world)
-    elapsed = time.perf_counter() - t0
+    mirror_elapsed = time.perf_counter() - t0
     tracing.install(None)
     selected = out.length
-    elapsed = _max_over_ranks(elapsed, world, device)
+    mirror_elapsed = _max_over_ranks(mirror_elapsed, world, device)
+
+    # ---- the drop-in route: the same step through UNMODIFIED pyarrow.compute on device-resident
+    # arrays — Arrow's dispatch, executors and output allocation in the timed region; this is `value`.  The arrays are
+    # the very HBM buffers above, wrapped without a copy.
+    elapsed, api, api_error, cf_check = mirror_elapsed, "arrow_amd.compute (Python mirror of the C ABI)", None, None
+    if not EMU:
+        try:
+            import pyarrow as pa
+            import pyarrow.compute as pc
+
+            plug = plugin_session()
+            pdv = plug.wrap(pa.int64(), n, values, validity, -1)
+            pdm = plug.wrap(pa.bool_(), n, mask)
+
+            def cf_step():
+                o = pc.filter(pdv, pdm)                      # array_filter
+                rows = pc.indices_nonzero(pdm)               # the mask's row numbers (uint64): what GetTakeIndices is to Take
+                return o, rows, pc.take(pdv, rows, boundscheck=False)
+
+            res = None
+            for _ in range(args.warmup):
+                res = cf_step()
+            g0 = {f: plug.lib.arrow_amd_plugin_calls(f, 1) for f in (b"array_filter", b"array_take")}
+            _barrier(world)
+            _sync(device)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                res = cf_step()
+            _sync(device)
+            _barrier(world)
+            elapsed = _max_over_ranks(time.perf_counter() - t0, world, device)
+            calls = {f.decode(): plug.lib.arrow_amd_plugin_calls(f, 1) - g0[f] for f in g0}
+            assert calls["array_filter"] >= 2 * args.steps and calls["array_take"] >= args.steps, calls
+            # the two routes agree: lengths, null counts, wrap-around sums of the valid values (device reductions)
+            o, rows, t2 = res
+            cf_check = bool(len(o) == selected == len(t2) == len(rows) and
+                            pc.sum(o).as_py() == pc.sum(t2).as_py() == pc.sum(plug.wrap(pa.int64(), selected, out.data, out.validity, -1)).as_py())
+            api = "pyarrow.compute on device-resident arrays through libarrow_amd_plugin.so: pc.filter + pc.indices_nonzero + pc.take"
+            del res, o, rows, t2
+        except Exception as e:
+            api_error = f"{type(e).__name__}: {e}"[:300]
 
     filt_ms = timer.elapsed_ms("arx_filter_exec")
     take_ms = timer.elapsed_ms("arx_take")
@@ -486,11 +591,17 @@ def run_filter_take(args, rank, world, device):
         "vs_baseline": None,
         "dtype": "int64",
         "data": "synthetic",
+        "api": api,
+        **({"api_error_fell_back_to_the_mirror": api_error} if api_error else {}),
+        **({"callfunction_results_equal_the_mirrors": cf_check} if cf_check is not None else {}),
+        "python_mirror": {"what": "the same step through arrow_amd.compute (ctypes over the C ABI): filter + get_take_indices (uint32) + take",
+                          "ms_per_step": round(mirror_elapsed / args.steps * 1e3, 4),
+                          "mrows_per_s": round(world * n * args.steps / mirror_elapsed / 1e6, 2)},
         "config": {
             "workload": f"Filter+Take int64[{n}] + validity ({args.null_p:.0%} null), boolean mask "
-                        f"{args.selectivity:.0%} true, FilterOptions::DROP; take indices = "
-                        "GetTakeIndices(mask) (uint32, monotonic), no boundscheck; inputs = splitmix64 streams "
-                        "of SURVEY.md 8(d) (seeds 1,2,3)",
+                        f"{args.selectivity:.0%} true, FilterOptions::DROP; take indices = the mask's row numbers "
+                        "(monotonic; indices_nonzero: uint64 through CallFunction, GetTakeIndices: uint32 in the mirror), "
+                        "no boundscheck; inputs = splitmix64 streams of SURVEY.md 8(d) (seeds 1,2,3)",
             "rows": n, "selected_rows": int(selected), "parallelism": "replicas" if world > 1 else "single-gpu",
         },
         "roofline": {
@@ -500,6 +611,7 @@ def run_filter_take(args, rank, world, device):
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "avg_kernel_ms": round(avg_filter_ms, 4),
             "traffic": load_traffic("filter", n),
+            "timed_in": "HIP events around the C-ABI calls of the mirror loop (the plugin launches the same entry point on its own stream)",
         },
         "kernel_ms": {"arx_filter_exec": round(avg_filter_ms, 4),
                       "arx_mask_to_indices": round(float(np.mean(m2i_ms)), 4),
@@ -510,14 +622,17 @@ def run_filter_take(args, rank, world, device):
         try:
             ceiling = copy_ceiling(amd, device)
             result["roofline"]["copy_ceiling_GBps"] = ceiling
-            result["roofline"]["frac_of_copy_ceiling"] = round(achieved / ceiling, 4)
+            # real bytes over a real-bytes ceiling (lines without a selected row are never fetched: the counter traffic,
+            # not the full-scan convention, is what the copy ceiling compares with)
+            tr = result["roofline"]["traffic"]
+            if isinstance(tr, (int, float)) and tr:
+                result["roofline"]["real_bytes_frac_of_copy_ceiling"] = round(tr / (avg_filter_ms * 1e-3) / 1e9 / ceiling, 4)
         except Exception as e:
             result["roofline"]["copy_ceiling_GBps"] = f"{type(e).__name__}: {e}"[:200]
     if rank == 0 and world == 1:
         result["parity_spot_check"] = "ok" if parity_spot_check(amd, values, validity, mask, n) else "MISMATCH"
-        if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_filter_take(values, validity, mask, n,
-                                                              args.cpu_sample_rows, args.cpu_budget_s)
+        if "filter_take" in cpu:
+            result["cpu_baseline"] = cpu["filter_take"]
     del out, idx, tk
     watchdog = None
     if args.extras and world > 1:
@@ -708,28 +823,15 @@ def callfunction_leg(args, values, validity, mask, device):
     from pyarrow import acero
 
     import arrow_amd as amd
-    from arrow_amd.plugin_build import build_plugin
 
-    lib = ctypes.CDLL(build_plugin(verbose=False))
-    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
-    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
-    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
-    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
-
-    def to_device(arr):
-        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(k) for k in (80, 72, 128))
-        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
-        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
-        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+    plug = plugin_session()
+    lib, to_device = plug.lib, plug.to_device
 
     n = min(args.rows, args.callfunction_rows)
     n -= n % 64
-    # host copies of the same HBM buffers (D2H once; the device-resident pyarrow arrays are then made from them
-    # through the plugin's own copy_to_device, i.e. the route an Arrow user takes)
-    hv = pa.Array.from_buffers(pa.int64(), n, [pa.py_buffer(validity[: n // 8].cpu().numpy()),
-                                               pa.py_buffer(values[: n * 8].cpu().numpy())], null_count=-1)
-    hm = pa.Array.from_buffers(pa.bool_(), n, [None, pa.py_buffer(mask[: n // 8].cpu().numpy())], null_count=0)
-    dv, dm = to_device(hv), to_device(hm)
+    # the HBM buffers themselves as device-resident pyarrow arrays (arrow_amd_wrap_device_memory: no copy)
+    dv = plug.wrap(pa.int64(), n, values, validity, -1)
+    dm = plug.wrap(pa.bool_(), n, mask)
     res = {"rows": n}
 
     def timeit(name, fn, reps=5):
@@ -759,7 +861,7 @@ def callfunction_leg(args, values, validity, mask, device):
     except Exception as e:
         res["Filter+Take step through CallFunction"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     res["gpu_kernel_calls"] = {f.decode(): int(lib.arrow_amd_plugin_calls(f, 1) - g0[f]) for f in g0}
-    del dv, dm, idx, hv, hm
+    del dv, dm, idx
     # group-by through Acero: table_source -> aggregate_rocm (the fused device operator) on device-resident columns
     m = min(n, 1 << 28)
     k = pa.array(gen_stream(m, device, 0, 8, modulo=args.groups, dtype=torch.int32).cpu().numpy())
@@ -906,10 +1008,13 @@ def hash_sum_leg(args, rank, world, device, rows_total, steps, warmup):
                         "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 12,
                         "traffic": load_traffic("groupby", rows // world)}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not EMU:
-        try:
-            leg["cpu_baseline"] = cpu_baseline_hash_sum(min(rows, args.cpu_groupby_rows), args.groups, args.cpu_budget_s)
-        except Exception as e:
-            leg["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        if "hash_sum" in _CPU_PRE:      # taken before the plugin was registered (run_filter_take)
+            leg["cpu_baseline"] = _CPU_PRE["hash_sum"]
+        else:
+            try:
+                leg["cpu_baseline"] = cpu_baseline_hash_sum(min(rows, args.cpu_groupby_rows), args.groups, args.cpu_budget_s)
+            except Exception as e:
+                leg["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return leg
 
 
@@ -926,13 +1031,17 @@ def sort_leg(args, rank, world, device, rows_total, steps, warmup):
                         "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 16,
                         "traffic": load_traffic("sort", rows // world, form="estimated")}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not EMU:
-        try:
-            leg["cpu_baseline"] = cpu_baseline_sort(min(rows, args.cpu_sort_rows))
-        except Exception as e:
-            leg["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        if "sort_indices" in _CPU_PRE:
+            leg["cpu_baseline"] = _CPU_PRE["sort_indices"]
+        else:
+            try:
+                leg["cpu_baseline"] = cpu_baseline_sort(min(rows, args.cpu_sort_rows))
+            except Exception as e:
+                leg["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return leg
 
 
+_CPU_PRE = {}          # CPU baselines taken before the plugin was registered (run_filter_take)
 _LAST_STAGES = {}      # per-stage ms (max over ranks) of the last sharded legs, filled by the measure_* functions
 
 
@@ -1145,7 +1254,7 @@ def main():
     ap.add_argument("--extras-timeout", dest="extras_timeout", type=float, default=300.0)
     ap.add_argument("--selectivity", type=float, default=0.10)
     ap.add_argument("--null-p", dest="null_p", type=float, default=0.10)
-    ap.add_argument("--cpu-sample-rows", type=int, default=250_000_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000_000)   # the same N where RAM allows (8 GB)
     ap.add_argument("--cpu-groupby-rows", dest="cpu_groupby_rows", type=int, default=100_000_000)
     ap.add_argument("--cpu-sort-rows", dest="cpu_sort_rows", type=int, default=100_000_000)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)

@@ -133,7 +133,9 @@ int arx_filter_exec(const ArxSpan* values, int byte_width, const ArxSpan* mask,
 /* GetTakeIndices — replaces GetTakeIndicesFromBitmapImpl<UInt16/UInt32>
  * (cpp/src/arrow/compute/kernels/vector_selection_take_internal.cc:62-168,258-305).
  * index_width is 2 (length <= 65535) or 4; EMIT_NULL writes 0 + null for null
- * mask slots (out_validity required then, otherwise may be NULL). */
+ * mask slots (out_validity required then, otherwise may be NULL).  index_width 8 (DROP only): the uint64 row numbers
+ * indices_nonzero returns (DoNonZero, compute/kernels/vector_selection.cc:228-300) in one pass; ARX_NOT_IMPLEMENTED
+ * where only the 2 / 4-byte forms apply (the caller widens then). */
 int arx_mask_to_indices(const ArxSpan* mask, int null_selection, const void* ws,
                         int64_t out_length, int index_width, void* out_indices,
                         void* out_validity, void* stream);

@@ -3153,3 +3153,86 @@ def test_fill_null_on_device_resident_arrays():
     code = f"ROOT = {ROOT!r}\n" + FILL_NULL_SCRIPT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "FILL_NULL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+WRAP_SCRIPT = textwrap.dedent(r"""
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
+    EMULATED = os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1"
+    if EMULATED:
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.arrow_amd_wrap_device_memory.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    lib.arrow_amd_plugin_set_min_rows(ctypes.c_int64(0))
+    # arrow_amd_wrap_device_memory: memory the caller owns (a torch tensor on the GPU; a numpy array under the emulated HIP
+    # runtime, whose "device" memory is host memory) becomes a device-resident pyarrow array without a copy — the route
+    # bench.py takes from its generated HBM buffers to pyarrow.compute
+    if EMULATED:
+        keep = []
+        def device_memory(a):
+            a = np.ascontiguousarray(a)
+            keep.append(a)
+            return a.ctypes.data
+    else:
+        import torch
+        keep = []
+        def device_memory(a):
+            t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).copy()).cuda()
+            keep.append(t)
+            return t.data_ptr()
+    def wrap(arr):
+        bufs = arr.buffers()
+        assert arr.offset == 0
+        nbytes = lambda b: np.frombuffer(b, np.uint8)
+        vptr = device_memory(np.concatenate([nbytes(bufs[0]), np.zeros(8, np.uint8)])) if bufs[0] is not None else None
+        dptr = device_memory(np.concatenate([nbytes(bufs[1]), np.zeros(8, np.uint8)]))
+        c_schema, c_dev = ctypes.create_string_buffer(72), ctypes.create_string_buffer(128)
+        arr.type._export_to_c(ctypes.addressof(c_schema))
+        assert lib.arrow_amd_wrap_device_memory(ctypes.addressof(c_schema), len(arr), -1, vptr, dptr, ctypes.addressof(c_dev)) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+    def to_host(x):
+        c_dev, c_schema, c_arr = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72), ctypes.create_string_buffer(80)
+        x._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, None) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), x.type)
+    rng = np.random.default_rng(71)
+    n = SC(1_000_003)
+    vals = pa.array(rng.integers(-2**62, 2**62, n), mask=rng.random(n) < 0.1)
+    dense = pa.array(rng.standard_normal(n))
+    mask = pa.array(rng.random(n) < 0.1)
+    flags = pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.2)
+    dv, dd, dm, df = wrap(vals), wrap(dense), wrap(mask), wrap(flags)
+    for d, h in ((dv, vals), (dd, dense), (dm, mask), (df, flags)):
+        assert not d.buffers()[1].is_cpu and len(d) == len(h)
+        assert to_host(d).equals(h) and to_host(d).null_count == h.null_count
+    g0 = lib.arrow_amd_plugin_calls(b"array_filter", 1)
+    out = pc.filter(dv, dm)
+    rows = pc.indices_nonzero(dm)
+    tk = pc.take(dv, rows, boundscheck=False)
+    assert lib.arrow_amd_plugin_calls(b"array_filter", 1) > g0
+    assert rows.type == pa.uint64() and to_host(rows).equals(pc.indices_nonzero(mask))
+    assert to_host(out).equals(pc.filter(vals, mask)) and to_host(tk).equals(pc.filter(vals, mask))
+    assert pc.sum(dd).equals(pc.sum(dense)) and pc.min_max(dv).equals(pc.min_max(vals))
+    assert to_host(pc.fill_null(df, False)).equals(pc.fill_null(flags, False))
+    assert to_host(pc.indices_nonzero(df)).equals(pc.indices_nonzero(flags))     # (nulls are not "non-zero")
+    print("WRAP_OK")
+""")
+
+
+def test_wrap_device_memory_zero_copy_and_uint64_row_numbers():
+    """arrow_amd_wrap_device_memory (caller-owned HBM as a device-resident pyarrow array, no copy) and indices_nonzero
+    writing its uint64 row numbers in one pass."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + WRAP_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "WRAP_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

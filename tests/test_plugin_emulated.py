@@ -140,3 +140,7 @@ def test_scalar_aggregates_of_float_boolean_and_temporal_device_columns_emulated
 
 def test_fill_null_on_device_resident_arrays_emulated():
     _run(G.FILL_NULL_SCRIPT, "FILL_NULL_OK", 0.02)
+
+
+def test_wrap_device_memory_zero_copy_and_uint64_row_numbers_emulated():
+    _run(G.WRAP_SCRIPT, "WRAP_OK", 0.02)
