@@ -580,6 +580,10 @@ int arrow_amd_parquet_read_columns(const char* path, int row_group, const int* c
 }
 // Inputs shorter than this stay on the stock CPU kernels (PCIe staging does not pay).
 void arrow_amd_plugin_set_min_rows(int64_t n) { g_min_rows.store(n); }
+// aggregate_rocm's var-width keys: bits of the strings' hash (64; 0 = the exact 12-byte chunk columns only; a few bits
+// force collisions, for tests) and how many batches were regrouped after a verified collision
+void arrow_amd_plugin_set_string_key_hash_bits(int64_t bits) { g_string_key_hash_bits.store(bits < 0 ? 0 : (bits > 64 ? 64 : bits)); }
+int64_t arrow_amd_plugin_string_key_hash_collisions(void) { return g_string_key_hash_collisions.load(); }
 // Device-resident filters of at most n rows use one synchronisation instead of three (0 = off, the default).
 void arrow_amd_plugin_set_filter_morsel_rows(int64_t n) { g_filter_morsel_rows.store(n); }
 // Parquet: 1 (default) = Snappy chunks of fixed-width columns are read raw and their PLAIN value pages decompressed

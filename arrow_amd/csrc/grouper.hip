@@ -408,6 +408,117 @@ __global__ __launch_bounds__(kBlock) void binary_key_chunk_kernel(Bits valid, co
   }
 }
 
+// ---- var-width keys in ONE pass (round 4): instead of ceil(longest / 12) table levels, a string enters the tables as
+// its length and a 64-bit hash of its bytes (12 bytes, one level whatever the lengths); the groups are then VERIFIED —
+// every row's bytes against the bytes of its group's first row — and only a batch in which two different strings of
+// one length share a hash (about d^2 / 2^65 for d distinct strings) is grouped again by the exact chunk columns above.
+// The reference hashes the encoded var-length row once as well and compares rows on a hash match
+// (row/grouper.cc:695-815, key_map / key_compare).  Bytes are read as the aligned 8-byte words that hold them: a word
+// is loaded only if it holds a byte of the string, so nothing outside the value buffer's words is touched.
+// bytes [pos, pos + 8) of the string data[start, start + len), zero past its end (pos < len, pos a multiple of 8): the one
+// or two aligned words that hold them, the second only if it holds a byte of the string
+__device__ __forceinline__ uint64_t string_word(const uint8_t* data, int64_t start, int64_t len, int64_t pos) {
+  const uint64_t addr = reinterpret_cast<uint64_t>(data) + static_cast<uint64_t>(start + pos);
+  const uint64_t* wp = reinterpret_cast<const uint64_t*>(addr & ~uint64_t(7));
+  const int sh = static_cast<int>(addr & 7) * 8;
+  uint64_t w = wp[0] >> sh;
+  const int64_t rem = len - pos;
+  if (sh != 0 && (8 - (sh >> 3)) < rem) w |= wp[1] << (64 - sh);
+  if (rem < 8) w &= (uint64_t(1) << (8 * rem)) - 1;
+  return w;
+}
+
+// The hash is a XOR over the string's 8-byte words of a mix of (word, word number), finished with the length: the words
+// can be folded in any order, so a lane folds a short string alone and a whole wave folds a long one 512 bytes a step
+// (coalesced) — one kernel for columns of any mix of lengths, cost proportional to the bytes.
+__device__ __forceinline__ uint64_t string_word_mix(uint64_t w, int64_t k) {
+  uint64_t x = (w ^ (static_cast<uint64_t>(k + 1) * 0x9E3779B97F4A7C15ull)) * 0x9FB21C651E98DF25ull;
+  x ^= x >> 32;
+  return x * 0xD6E8FEB86659FD93ull;
+}
+__device__ __forceinline__ uint64_t string_hash_finish(uint64_t acc, int64_t len) {
+  uint64_t h = acc ^ (static_cast<uint64_t>(len) * 0xC2B2AE3D27D4EB4Full) ^ 0x9E3779B97F4A7C15ull;
+  h = (h ^ (h >> 33)) * 0xFF51AFD7ED558CCDull;
+  h = (h ^ (h >> 33)) * 0xC4CEB9FE1A85EC53ull;
+  return h ^ (h >> 33);
+}
+constexpr int64_t kStringLaneBytes = 64;   // longer strings are folded by the whole wave
+
+__device__ __forceinline__ uint64_t wave_xor_u64(uint64_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v ^= shfl_u64(v, lane_id() ^ d);
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void binary_key_hash_kernel(Bits valid, const int32_t* __restrict__ offsets,
+                                                                 const uint8_t* __restrict__ data, int64_t n, uint64_t keep_mask,
+                                                                 uint64_t* __restrict__ out_hash) {
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t base = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)) * 64; base < n; base += nwaves * 64) {
+    const int64_t i = base + lane;
+    const bool ok = i < n && ((load_word(valid, i >> 6) >> (i & 63)) & 1);
+    const int64_t start = ok ? offsets[i] : 0;
+    const int64_t len = ok ? offsets[i + 1] - start : 0;
+    uint64_t acc = 0;
+    if (ok && len <= kStringLaneBytes) {
+      for (int64_t pos = 0; pos < len; pos += 8) acc ^= string_word_mix(string_word(data, start, len, pos), pos >> 3);
+    }
+    uint64_t longs = __ballot(ok && len > kStringLaneBytes);
+    while (longs != 0) {
+      const int src = __ffsll(static_cast<unsigned long long>(longs)) - 1;
+      longs &= longs - 1;
+      const int64_t s0 = shfl_u64(static_cast<uint64_t>(start), src);
+      const int64_t sl = shfl_u64(static_cast<uint64_t>(len), src);
+      uint64_t part = 0;
+      for (int64_t pos = static_cast<int64_t>(lane) * 8; pos < sl; pos += 512) part ^= string_word_mix(string_word(data, s0, sl, pos), pos >> 3);
+      part = wave_xor_u64(part);
+      if (lane == src) acc = part;
+    }
+    if (i < n) out_hash[i] = ok ? (string_hash_finish(acc, len) & keep_mask) : 0;
+  }
+}
+
+// mismatches += rows whose bytes differ from the bytes of the first row of their group (the validity and the length are
+// compared too, although the length is a key column of its own)
+__global__ __launch_bounds__(kBlock) void binary_key_verify_kernel(Bits valid, const int32_t* __restrict__ offsets,
+                                                                   const uint8_t* __restrict__ data, int64_t n,
+                                                                   const uint32_t* __restrict__ ids, const uint32_t* __restrict__ first_rows,
+                                                                   unsigned long long* __restrict__ mismatches) {
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  unsigned int bad = 0;
+  for (int64_t base = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)) * 64; base < n; base += nwaves * 64) {
+    const int64_t i = base + lane;
+    const int64_t f = i < n ? static_cast<int64_t>(first_rows[ids[i]]) : 0;
+    const bool check = i < n && f != i;
+    const bool ok = check && ((load_word(valid, i >> 6) >> (i & 63)) & 1);
+    const bool fok = check && ((load_word(valid, f >> 6) >> (f & 63)) & 1);
+    const int64_t a0 = ok ? offsets[i] : 0, b0 = fok ? offsets[f] : 0;
+    const int64_t len = ok ? offsets[i + 1] - a0 : 0;
+    const int64_t flen = fok ? offsets[f + 1] - b0 : 0;
+    bool differs = check && (ok != fok || len != flen);
+    const bool bytes = check && ok && !differs;
+    if (bytes && len <= kStringLaneBytes) {
+      for (int64_t pos = 0; pos < len && !differs; pos += 8) differs = string_word(data, a0, len, pos) != string_word(data, b0, len, pos);
+    }
+    uint64_t longs = __ballot(bytes && len > kStringLaneBytes);
+    while (longs != 0) {
+      const int src = __ffsll(static_cast<unsigned long long>(longs)) - 1;
+      longs &= longs - 1;
+      const int64_t sa = shfl_u64(static_cast<uint64_t>(a0), src), sb = shfl_u64(static_cast<uint64_t>(b0), src);
+      const int64_t sl = shfl_u64(static_cast<uint64_t>(len), src);
+      bool d = false;
+      for (int64_t pos = static_cast<int64_t>(lane) * 8; pos < sl && !d; pos += 512) d = string_word(data, sa, sl, pos) != string_word(data, sb, sl, pos);
+      const bool any = __ballot(d) != 0;
+      if (lane == src) differs = any;
+    }
+    bad += differs ? 1u : 0u;
+  }
+  const unsigned int total = wave_reduce_sum_u32(bad);
+  if (lane == 0 && total != 0) atomicAdd(mismatches, static_cast<unsigned long long>(total));
+}
+
 // first_rows[g] = the smallest row whose group id is g (caller fills first_rows with 0xFF bytes)
 __global__ __launch_bounds__(kBlock) void group_first_rows_kernel(const uint32_t* __restrict__ ids, int64_t n,
                                                                   int64_t num_groups, unsigned int* __restrict__ first) {
@@ -677,6 +788,49 @@ int arx_binary_key_chunk(const ArxBinarySpan* values, int64_t chunk_index, uint6
                      values->offsets + values->offset, static_cast<const uint8_t*>(values->data), n, chunk_index * 12,
                      out_lo, out_hi);
   ARX_CHECK_LAUNCH("binary_key_chunk_kernel");
+  return ARX_OK;
+}
+
+int arx_binary_key_hash(const ArxBinarySpan* values, int hash_bits, uint64_t* out_hash, void* stream) {
+  if (values == nullptr || hash_bits < 1 || hash_bits > 64) {
+    set_error("binary key hash: NULL values or hash_bits outside 1 .. 64");
+    return ARX_INVALID;
+  }
+  const int64_t n = values->length;
+  if (n <= 0) return ARX_OK;
+  if (values->offsets == nullptr || out_hash == nullptr) {
+    set_error("binary key hash: NULL buffer");
+    return ARX_INVALID;
+  }
+  const Bits valid = make_bits(values->null_count == 0 ? nullptr : values->validity, values->offset, n);
+  const uint64_t keep = hash_bits >= 64 ? ~uint64_t(0) : ((uint64_t(1) << hash_bits) - 1);
+  hipLaunchKernelGGL(binary_key_hash_kernel, dim3(grouper_grid(n)), dim3(kBlock), 0, as_stream(stream), valid,
+                     values->offsets + values->offset, static_cast<const uint8_t*>(values->data), n, keep, out_hash);
+  ARX_CHECK_LAUNCH("binary_key_hash_kernel");
+  return ARX_OK;
+}
+
+int arx_binary_key_verify(const ArxBinarySpan* values, const uint32_t* group_ids, const uint32_t* first_rows,
+                          int64_t* out_mismatches, void* ws, void* stream) {
+  if (values == nullptr || out_mismatches == nullptr || ws == nullptr) {
+    set_error("binary key verify: NULL argument");
+    return ARX_INVALID;
+  }
+  *out_mismatches = 0;
+  const int64_t n = values->length;
+  if (n <= 0) return ARX_OK;
+  if (values->offsets == nullptr || group_ids == nullptr || first_rows == nullptr) {
+    set_error("binary key verify: NULL buffer");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  ARX_HIP(hipMemsetAsync(ws, 0, 8, st));
+  const Bits valid = make_bits(values->null_count == 0 ? nullptr : values->validity, values->offset, n);
+  hipLaunchKernelGGL(binary_key_verify_kernel, dim3(grouper_grid(n)), dim3(kBlock), 0, st, valid, values->offsets + values->offset,
+                     static_cast<const uint8_t*>(values->data), n, group_ids, first_rows, static_cast<unsigned long long*>(ws));
+  ARX_CHECK_LAUNCH("binary_key_verify_kernel");
+  ARX_HIP(hipMemcpyAsync(out_mismatches, ws, 8, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
   return ARX_OK;
 }
 

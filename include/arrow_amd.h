@@ -826,6 +826,16 @@ int arx_binary_key_lengths(const ArxBinarySpan* values, uint32_t* out_lengths, i
                            void* stream);
 int arx_binary_key_chunk(const ArxBinarySpan* values, int64_t chunk_index, uint64_t* out_lo, uint32_t* out_hi,
                          void* stream);
+/* Var-width keys in ONE pass: out_hash[i] = a 64-bit hash of the bytes of string i (0 for a null; only the low
+ * hash_bits bits are kept — 64 in production, fewer to force collisions in tests); with the length column
+ * (arx_binary_key_lengths) that is a 12-byte stand-in for the string whatever its length.  arx_binary_key_verify then
+ * counts the rows whose bytes differ from the bytes of their group's first row (first_rows: arx_group_first_rows) —
+ * 0 means the hashed groups are the exact groups (the reference compares the encoded rows on a hash match the same way,
+ * compute/row/grouper.cc:695-815); otherwise the caller groups by the exact chunk columns instead.  verify is
+ * synchronous; ws: >= 8 device bytes. */
+int arx_binary_key_hash(const ArxBinarySpan* values, int hash_bits, uint64_t* out_hash, void* stream);
+int arx_binary_key_verify(const ArxBinarySpan* values, const uint32_t* group_ids, const uint32_t* first_rows,
+                          int64_t* out_mismatches, void* ws, void* stream);
 int arx_group_first_rows(const uint32_t* group_ids, int64_t length, int64_t num_groups, uint32_t* out_first_rows,
                          void* stream);
 

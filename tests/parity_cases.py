@@ -1407,15 +1407,19 @@ def check_binary_key_columns(amd, values, rng):
             want[i, :len(part)] = np.frombuffer(part, dtype=np.uint8)
         assert_equal(_data_np(lo, np.uint64), want[:, :8].copy().view("<u8").ravel(), f"binary key chunk {c} lo")
         assert_equal(_data_np(hi, np.uint32), want[:, 8:].copy().view("<u4").ravel(), f"binary key chunk {c} hi")
-    # the Grouper over the virtual columns
+    # the Grouper over the virtual columns (the mirror's Grouper chains up to 32 columns: strings of <= 180 bytes; longer
+    # ones only go through the one-pass route below, over ids made here)
     cols = [lens] + [h for pair in chunks for h in pair]
-    g = amd.compute.Grouper([c.type for c in cols], max(16, n))
-    ids = g.consume(cols)
     first_of = {}
     want_ids = np.array([first_of.setdefault(r, len(first_of)) for r in rows], dtype=np.uint32)
-    assert_equal(_data_np(ids, np.uint32), want_ids, "ids over the virtual key columns")
-    assert g.num_groups == len(first_of)
-    first = amd.compute.group_first_rows(ids, g.num_groups)
+    if len(cols) <= 32:
+        g = amd.compute.Grouper([c.type for c in cols], max(16, n))
+        ids = g.consume(cols)
+        assert_equal(_data_np(ids, np.uint32), want_ids, "ids over the virtual key columns")
+        assert g.num_groups == len(first_of)
+    else:
+        ids = amd.Array.from_numpy(want_ids)
+    first = amd.compute.group_first_rows(ids, len(first_of))
     want_first = np.array([rows.index(r) for r in first_of], dtype=np.uint32)
     assert_equal(_data_np(first, np.uint32), want_first, "group first rows")
     if n:
@@ -1425,6 +1429,41 @@ def check_binary_key_columns(amd, values, rng):
         uv, _ = _logical_valid(uniq)
         got = [bytes(ud[uo[i]:uo[i + 1]]) if uv[i] else None for i in range(uniq.length)]
         assert got == list(first_of), "unique strings"
+    # ---- round 4: one pass whatever the lengths — (length, 64-bit hash) + verification against the first rows' bytes
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+    sp = dv.binary_span() if hasattr(dv, "binary_span") else None
+    if sp is None:
+        sp = _lib.ArxBinarySpan(dv.buffers[0].data_ptr() if dv.buffers[0] is not None and dv.null_count != 0 else None, dv.buffers[1].data_ptr(),
+                                dv.buffers[2].data_ptr() if dv.buffers[2] is not None else None, dv.offset, n, dv.null_count if dv.null_count is not None else -1)
+    hashes = torch.zeros(max(n, 1), dtype=torch.int64, device=dev)
+    _lib.check(lib.arx_binary_key_hash(C.byref(sp), 64, hashes.data_ptr(), st))
+    h = hashes.cpu().numpy()[:n].view(np.uint64)
+    by_row = {}
+    for i, r in enumerate(rows):
+        if r is None:
+            assert h[i] == 0, "a null hashes to 0"
+        else:
+            assert by_row.setdefault(r, h[i]) == h[i], "equal strings, different hashes"
+    assert len(set(by_row.values())) == len(by_row), "64-bit hashes of a few thousand distinct strings collide"
+    if n:
+        ws = torch.zeros(8, dtype=torch.int64, device=dev)
+        bad = C.c_int64(-1)
+        _lib.check(lib.arx_binary_key_verify(C.byref(sp), ids.data.data_ptr(), first.data.data_ptr(), C.byref(bad), ws.data_ptr(), st))
+        assert bad.value == 0, ("exact groups fail the verification", bad.value)
+        # every row in ONE group: exactly the rows that differ from row 0 are reported
+        zeros = torch.zeros(n, dtype=torch.int32, device=dev)
+        _lib.check(lib.arx_binary_key_verify(C.byref(sp), zeros.data_ptr(), zeros.data_ptr(), C.byref(bad), ws.data_ptr(), st))
+        assert bad.value == sum(1 for r in rows if r != rows[0]), ("verification count", bad.value)
+        # a 2-bit hash: still equal for equal strings
+        _lib.check(lib.arx_binary_key_hash(C.byref(sp), 2, hashes.data_ptr(), st))
+        assert int(hashes.cpu().numpy()[:n].view(np.uint64).max()) < 4
 
 
 def check_group_by_keys(amd, rng, key_dtypes, n, cardinality, null_p=0.0, use_pyarrow=True):

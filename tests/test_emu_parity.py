@@ -915,7 +915,7 @@ def test_grouper_declines_and_overflows(emu_ctx):
 
 
 @pytest.mark.parametrize("n,null_p,offset,max_len,card", [(0, 0.0, 0, 8, 1), (3000, 0.1, 0, 30, 40), (2500, 0.0, 5, 11, 2000),
-                                                         (2000, 0.3, 3, 50, 7), (1000, 1.0, 0, 5, 5)])
+                                                         (2000, 0.3, 3, 50, 7), (1000, 1.0, 0, 5, 5), (1500, 0.1, 2, 700, 300)])
 def test_binary_key_columns_and_first_rows(emu_ctx, n, null_p, offset, max_len, card):
     P.check_binary_key_columns(emu_ctx, U.random_binary_pool(rng_for("bkey", n, max_len), n, card, null_p, offset, max_len),
                                rng_for("bkey2", n))
