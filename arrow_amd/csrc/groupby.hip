@@ -21,6 +21,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
+#include <vector>
 
 namespace arx {
 
@@ -1876,6 +1878,7 @@ static Knob<int> g_gbp_b1{-1};             // level-1 bits override (-1: half of
 static Knob<int> g_gbp_chunks{2048};       // level-1 chunks = workgroups of the hist / scatter1 kernels
 static Knob<int> g_gbp_wide_max_bits{kGbWideMaxBits};   // bins of the flat level the planner may ask for (A/B knob groupby_wide_max_bits; tests lower it)
 static Knob<int> g_gbp_room_min_mean{1 << 14};   // rooms only for partitions of at least this many rows on average (knob groupby_wide_room_min_mean; tests lower it)
+static Knob<int> g_gbp_sketch{1};          // the group count from a HyperLogLog sketch of the first groupby_probe_rows keys (0: round 3's probe slice on the two-level plan; A/B knob groupby_sketch)
 static Knob<int> g_gbp_wide_rooms{1};      // the wide form without its histogram pass: fixed rooms per partition (A/B knob groupby_wide_rooms)
 static Knob<int> g_gbp_wide{1};            // the wide one-level form where the group estimate allows it (A/B knob groupby_wide)
 static Knob<int> g_gbp_wide_agg_chunk{1 << 21};   // rows per aggregate work unit of the wide form (A/B knob groupby_wide_agg_chunk_rows)
@@ -2136,6 +2139,57 @@ static int gbp_run_slice(const GroupbyView& v, GbpArgs a, const GbpPlan& plan, h
   return ARX_OK;
 }
 
+// ---- how many DISTINCT keys?  A HyperLogLog sketch of a prefix of the key column (round 4): 2^14 registers, per
+// workgroup in LDS (ds_max), folded into the global registers by the few lanes that raise one.  The capacity only bounds
+// the group count from above; round 3 measured it by running the first 2^25 rows as a "probe slice" on the safe two-level
+// plan (2.4 ms whatever n: a third of one rank's time at N / 8 rows) — the sketch reads those keys once (128 MB, ~0.05 ms)
+// and aggregates nothing, so the prefix goes through the plan the estimate selects like every other row.
+constexpr int kHllBits = 14;
+constexpr int kHllRegs = 1 << kHllBits;
+
+__global__ __launch_bounds__(1024) void gbp_hll_kernel(const int32_t* __restrict__ keys, int64_t n, unsigned int* __restrict__ regs) {
+  __shared__ unsigned int local[kHllRegs];
+  for (int i = threadIdx.x; i < kHllRegs; i += 1024) local[i] = 0;
+  __syncthreads();
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 1024;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 1024 + threadIdx.x; i < n; i += stride) {
+    uint64_t z = static_cast<uint64_t>(static_cast<uint32_t>(keys[i])) + 0x9E3779B97F4A7C15ull;   // splitmix64 of the key
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const unsigned int idx = static_cast<unsigned int>(z >> (64 - kHllBits));
+    const unsigned int rank = static_cast<unsigned int>(__builtin_clzll((z << kHllBits) | (uint64_t(1) << (kHllBits - 1)))) + 1u;
+    if (local[idx] < rank) atomicMax(&local[idx], rank);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kHllRegs; i += 1024) {
+    const unsigned int r = local[i];
+    if (r != 0 && regs[i] < r) atomicMax(&regs[i], r);
+  }
+}
+
+// the sketch's estimate of the distinct keys among keys[0, n) (regs: kHllRegs x 4 device bytes, synchronous)
+static int gbp_estimate_distinct(const int32_t* keys, int64_t n, unsigned int* regs, int64_t* out, hipStream_t st) {
+  ARX_HIP(hipMemsetAsync(regs, 0, sizeof(unsigned int) * kHllRegs, st));
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 1024 * 64), 1024)));
+  hipLaunchKernelGGL(gbp_hll_kernel, dim3(grid), dim3(1024), 0, st, keys, n, regs);
+  ARX_CHECK_LAUNCH("gbp_hll_kernel");
+  std::vector<unsigned int> h(kHllRegs);
+  ARX_HIP(hipMemcpyAsync(h.data(), regs, sizeof(unsigned int) * kHllRegs, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  double sum = 0;
+  int zeros = 0;
+  for (unsigned int r : h) {
+    sum += std::ldexp(1.0, -static_cast<int>(r));
+    zeros += r == 0;
+  }
+  const double m = kHllRegs;
+  double e = 0.7213 / (1.0 + 1.079 / m) * m * m / sum;
+  if (e <= 2.5 * m && zeros != 0) e = m * std::log(m / zeros);   // linear counting for small cardinalities
+  *out = static_cast<int64_t>(e);
+  return ARX_OK;
+}
+
 static int read_header(void* state, GroupbyHeader* h, hipStream_t st) {
   ARX_HIP(hipMemcpyAsync(h, state, sizeof(GroupbyHeader), hipMemcpyDeviceToHost, st));
   ARX_HIP(hipStreamSynchronize(st));
@@ -2173,6 +2227,10 @@ int set_groupby_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "groupby_wide_room_min_mean") == 0) {
     g_gbp_room_min_mean = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, INT32_MAX)));
+    return 1;
+  }
+  if (strcmp(name, "groupby_sketch") == 0) {
+    g_gbp_sketch = value != 0;
     return 1;
   }
   if (strcmp(name, "groupby_wide_rooms") == 0) {
@@ -2381,7 +2439,8 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
     // never exactness (rows that find no room in an LDS table go to the HBM table).
     const GbpPlan unhinted = gbp_plan(slice, capacity);
     const int64_t probe_rows = std::max<int64_t>(kGbTile, int64_t(g_gbp_probe_rows) / kGbTile * kGbTile);
-    const bool probe = g_gbp_wide && g_gbp_bits < 0 && unhinted.b2 > 0 && !unhinted.wide && n >= 4 * probe_rows;
+    const bool sketch = g_gbp_sketch != 0 && g_gbp_wide && g_gbp_bits < 0 && unhinted.b2 > 0 && !unhinted.wide && n >= 2 * probe_rows;
+    const bool probe = !sketch && g_gbp_wide && g_gbp_bits < 0 && unhinted.b2 > 0 && !unhinted.wide && n >= 4 * probe_rows;
     int64_t groups_hint = -1;
     bool rooms_ok = true;
     unsigned long long groups_before = 0;
@@ -2390,6 +2449,16 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
       const int rc0 = read_header(state, &h0, st);
       if (rc0 != ARX_OK) return rc0;
       groups_before = h0.num_groups;
+    }
+    if (sketch) {
+      // (round 4) the first probe_rows keys through a HyperLogLog sketch instead of through the two-level plan: the same
+      // question — did most of these keys repeat, and how many are there —, nothing aggregated, one 64 KB read-back.  The
+      // registers sit at the top of the caller's scratch, which no slice touches before the first plan is bound.
+      int64_t distinct = 0;
+      const int rc0 = gbp_estimate_distinct(k, probe_rows, reinterpret_cast<unsigned int*>(w), &distinct, st);
+      if (rc0 != ARX_OK) return rc0;
+      g_gbp_slices_probe.fetch_add(1, std::memory_order_relaxed);
+      if (distinct * 2 < probe_rows) groups_hint = distinct + distinct / 16 + 1024;
     }
     for (int64_t r0 = 0; r0 < n;) {
       const bool probing = probe && r0 == 0;

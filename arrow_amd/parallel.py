@@ -166,7 +166,9 @@ def sharded_group_by_sum(keys, values, capacity: int, options: ScalarAggregateOp
         mine = _all_to_all_bytes(records, send, recv, ROW_RECORD_BYTES, group)
         _mark(stages, "exchange")
         rk, rv = unpack_rows(mine)
-        owned = GroupBySum(capacity, device, options)
+        # the owner's table is sized from what ARRIVED (as the partials path and the C++ ShardedGroupBySum do): a rank can
+        # own more distinct keys than its own shard held, which the caller's per-shard capacity says nothing about
+        owned = GroupBySum(max(capacity, 16, 2 * sum(recv) + 2), device, options)
         owned.consume(rk, rv)
         _mark(stages, "consume")
         out = owned.finalize()

@@ -14,6 +14,15 @@
 #include <time.h>
 #include <unistd.h>
 
+/* -DFAKE_RCCL_DEVICE (the GPU tier's world-2-on-ONE-GPU test, tests/test_sharded_rccl_plugin.py): the buffers are HBM.
+ * A send waits for the caller's stream, stages the bytes through host memory and writes the file; a receive reads the
+ * file and copies it up with a blocking hipMemcpy (complete before anything enqueued afterwards runs).  The real librccl
+ * refuses two ranks on one device; this lets the C++ exchange run with a peer that is not itself on real kernels. */
+#ifdef FAKE_RCCL_DEVICE
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#endif
+
 typedef struct { char bytes[128]; } ncclUniqueId;
 typedef struct FakeComm {
   int nranks, rank;
@@ -30,7 +39,30 @@ static size_t type_size(int dtype) {
 static void msg_path(FakeComm* c, int src, int dst, uint64_t seq, const char* suffix, char* out, size_t n) {
   snprintf(out, n, "%s/m_%d_%d_%llu%s", c->dir, src, dst, (unsigned long long)seq, suffix);
 }
+static int do_send_host(FakeComm* c, const void* buf, size_t bytes, int peer);
+static int do_recv_host(FakeComm* c, void* buf, size_t bytes, int peer);
+#ifdef FAKE_RCCL_DEVICE
 static int do_send(FakeComm* c, const void* buf, size_t bytes, int peer) {
+  void* host = malloc(bytes ? bytes : 1);
+  if (!host) return 2;
+  if (bytes && hipMemcpy(host, buf, bytes, hipMemcpyDeviceToHost) != hipSuccess) { free(host); return 2; }
+  const int rc = do_send_host(c, host, bytes, peer);
+  free(host);
+  return rc;
+}
+static int do_recv(FakeComm* c, void* buf, size_t bytes, int peer) {
+  void* host = malloc(bytes ? bytes : 1);
+  if (!host) return 2;
+  int rc = do_recv_host(c, host, bytes, peer);
+  if (!rc && bytes && hipMemcpy(buf, host, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = 2;
+  free(host);
+  return rc;
+}
+#else
+static int do_send(FakeComm* c, const void* buf, size_t bytes, int peer) { return do_send_host(c, buf, bytes, peer); }
+static int do_recv(FakeComm* c, void* buf, size_t bytes, int peer) { return do_recv_host(c, buf, bytes, peer); }
+#endif
+static int do_send_host(FakeComm* c, const void* buf, size_t bytes, int peer) {
   char tmp[256], fin[256];
   const uint64_t seq = c->send_seq[peer]++;
   msg_path(c, c->rank, peer, seq, ".tmp", tmp, sizeof tmp);
@@ -41,7 +73,7 @@ static int do_send(FakeComm* c, const void* buf, size_t bytes, int peer) {
   fclose(f);
   return rename(tmp, fin) == 0 ? 0 : 2;
 }
-static int do_recv(FakeComm* c, void* buf, size_t bytes, int peer) {
+static int do_recv_host(FakeComm* c, void* buf, size_t bytes, int peer) {
   char fin[256];
   const uint64_t seq = c->recv_seq[peer]++;
   msg_path(c, peer, c->rank, seq, "", fin, sizeof fin);
@@ -88,19 +120,26 @@ int ncclCommDestroy(void* comm) {
   return 0;
 }
 int ncclGroupStart(void) { ++g_depth; return 0; }
+static void wait_stream(void* stream) {
+#ifdef FAKE_RCCL_DEVICE
+  (void)hipStreamSynchronize((hipStream_t)stream);   /* what the caller enqueued before the call is what gets sent */
+#else
+  (void)stream;
+#endif
+}
 int ncclGroupEnd(void) { return --g_depth == 0 ? flush_ops() : 0; }
 int ncclSend(const void* buf, size_t count, int dtype, int peer, void* comm, void* stream) {
-  (void)stream;
+  wait_stream(stream);
   if (g_depth > 0) { g_ops[g_nops++] = (Op){1, (void*)buf, count * type_size(dtype), peer, (FakeComm*)comm}; return 0; }
   return do_send((FakeComm*)comm, buf, count * type_size(dtype), peer);
 }
 int ncclRecv(void* buf, size_t count, int dtype, int peer, void* comm, void* stream) {
-  (void)stream;
+  wait_stream(stream);
   if (g_depth > 0) { g_ops[g_nops++] = (Op){0, buf, count * type_size(dtype), peer, (FakeComm*)comm}; return 0; }
   return do_recv((FakeComm*)comm, buf, count * type_size(dtype), peer);
 }
 int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* comm, void* stream) {
-  (void)stream;
+  wait_stream(stream);
   FakeComm* c = (FakeComm*)comm;
   const size_t bytes = count * type_size(dtype);
   int rc = 0;

@@ -1066,9 +1066,9 @@ def test_groupby_wide_form_without_histogram(emu_ctx, hot):
 
 @pytest.mark.parametrize("distinct", [900, 0])
 def test_groupby_probe_slice_selects_the_plan(emu_ctx, distinct):
-    """A capacity that only bounds the group count from above (two-level plan) + enough rows: the first slice is a
-    probe; few distinct keys seen twice -> the remaining rows run the wide plan, keys that do not repeat -> they stay on
-    the two-level plan.  Same groups either way; earlier groups in the table count towards the estimate."""
+    """A capacity that only bounds the group count from above (two-level plan) + enough rows: a HyperLogLog sketch of
+    the first groupby_probe_rows keys estimates the distinct keys; few of them, seen often -> the rows run the wide plan, keys
+    that do not repeat -> the two-level plan.  Same groups either way."""
     lib = emu_ctx._lib.get_lib()
     assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
     assert lib.arx_set_option(b"groupby_probe_rows", 4096) == 0
@@ -1088,8 +1088,8 @@ def test_groupby_probe_slice_selects_the_plan(emu_ctx, distinct):
         lib.arx_set_option(b"groupby_probe_rows", 1 << 25)
         lib.arx_set_option(b"groupby_wide_max_bits", 11)
     probe, wide, two = (lib.arx_get_counter(c) - b for c, b in zip(names, before))
-    assert probe == 3, "one probe slice per consume call"
+    assert probe == 3, "one sketch (round 3: one probe slice) per consume call"
     if distinct:
-        assert (wide, two) == (3, 3), (probe, wide, two)     # the probe slices on the two-level plan, the rest wide
+        assert (wide, two) == (3, 0), (probe, wide, two)     # round 4: the sketch aggregates nothing, every row runs the wide plan
     else:
-        assert (wide, two) == (0, 6), (probe, wide, two)
+        assert (wide, two) == (0, 3), (probe, wide, two)

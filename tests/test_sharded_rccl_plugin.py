@@ -201,3 +201,18 @@ def test_sharded_group_by_sum_cpp_one_rank_over_the_real_rccl(tmp_path):
     ranks = _run_ranks(tmp_path, 1, {}, 2_000_000, 70_000)
     _check(ranks)
     _check_sorts(ranks)
+
+
+@pytest.mark.gpu
+def test_sharded_group_by_and_sort_cpp_world2_on_one_gpu(tmp_path):
+    """the C++ sharded group-by and sort with MORE than a self send — two processes on the one GPU
+    of the box, real HIP kernels, the exchange over the file transport staged through host memory (the real librccl
+    refuses two ranks on one device).  Same checks as the CPU tier's world-2 run."""
+    pytest.importorskip("pyarrow")
+    fake = str(tmp_path / "libfake_rccl_device.so")
+    subprocess.check_call(["gcc", "-O1", "-fPIC", "-shared", "-DFAKE_RCCL_DEVICE", "-I/opt/rocm/include", "-o", fake,
+                           os.path.join(ROOT, "tests", "emu", "fake_rccl", "fake_rccl.c"), "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    ranks = _run_ranks(tmp_path, 2, dict(ARROW_AMD_RCCL_LIBRARY=fake), 1_000_000, 70_000)
+    _check(ranks)
+    _check_sorts(ranks)
