@@ -99,6 +99,7 @@ namespace {
 #include "plugin/order_by_node.inc"
 #include "plugin/acero_source.inc"
 #include "plugin/acero_coalesce.inc"
+#include "plugin/acero_override.inc"
 #include "plugin/parquet.inc"
 #include "plugin/device_guard.inc"
 #include "plugin/validity.inc"
@@ -579,6 +580,17 @@ int arrow_amd_parquet_read_columns(const char* path, int row_group, const int* c
   return 0;
 }
 // Inputs shorter than this stay on the stock CPU kernels (PCIe staging does not pay).
+// OPT-IN: unmodified Acero plans (table_source / aggregate / order_by by their stock names) over device-resident tables
+// land on the plugin's nodes; 0 puts the stock factories back.  -1 with arrow_amd_plugin_last_error() when the default
+// registry of this Arrow build was not recognised (nothing is changed then).  plugin/acero_override.inc
+int arrow_amd_override_acero_factories(int on) {
+  const Status st = OverrideAceroFactories(on != 0);
+  if (!st.ok()) {
+    t_error = st.ToString();
+    return -1;
+  }
+  return 0;
+}
 void arrow_amd_plugin_set_min_rows(int64_t n) { g_min_rows.store(n); }
 // aggregate_rocm's var-width keys: bits of the strings' hash (64; 0 = the exact 12-byte chunk columns only; a few bits
 // force collisions, for tests) and how many batches were regrouped after a verified collision

@@ -907,6 +907,20 @@ def callfunction_leg(args, values, validity, mask, device):
                        lambda: plan_r.to_table(use_threads=False), reps=3)
                 lib.arrow_amd_plugin_set_aggregate_device_output(0)
             del plan_f
+        # the UNMODIFIED plan — stock node names only — once arrow_amd_override_acero_factories(1) re-routed table_source /
+        # aggregate over device-resident tables (plugin/acero_override.inc)
+        if lib.arrow_amd_override_acero_factories(1) == 0:
+            plan_s = acero.Declaration.from_sequence(
+                [acero.Declaration("table_source", acero.TableSourceNodeOptions(dtx)),
+                 acero.Declaration("filter", acero.FilterNodeOptions(pc.field("x") > 0.1)),
+                 acero.Declaration("project", acero.ProjectNodeOptions([pc.field("k"), pc.add(pc.field("v"), pc.field("v"))], ["k", "v"])),
+                 acero.Declaration("aggregate", acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"]))])
+            timeit(f"acero table_source -> filter(x > 0.1) -> project(k, v + v) -> aggregate, STOCK node names, factory override on ({m} device rows)",
+                   lambda: plan_s.to_table(use_threads=False), reps=3)
+            lib.arrow_amd_override_acero_factories(0)
+            del plan_s
+        else:
+            res["acero stock node names with the factory override"] = {"error": lib.arrow_amd_plugin_last_error().decode()[:300]}
         # what a plan costs before it touches a row: the same four nodes over 1024 rows (plan construction, task
         # scheduling, the sink and to_table included)
         tiny = pa.table({name: dtx.column(name).chunk(0).slice(0, 1024) for name in ("x", "k", "v")})

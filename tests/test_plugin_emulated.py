@@ -144,3 +144,7 @@ def test_fill_null_on_device_resident_arrays_emulated():
 
 def test_wrap_device_memory_zero_copy_and_uint64_row_numbers_emulated():
     _run(G.WRAP_SCRIPT, "WRAP_OK", 0.02)
+
+
+def test_stock_acero_plans_land_on_the_plugin_nodes_after_the_factory_override_emulated():
+    _run(G.ACERO_OVERRIDE_SCRIPT, "ACERO_OVERRIDE_OK", 0.05)
