@@ -115,6 +115,9 @@ SIGNATURES = {
     "arx_binary_take_workspace_bytes": (_sz, [_i64]),
     "arx_binary_take_offsets": (_int, [_bspan, _span, _int, _p, _sz, _p, _p, _p, C.POINTER(_i64), _p]),
     "arx_binary_take_data": (_int, [_bspan, _i64, _p, _sz, _p, _i64, _p, _p]),
+    "arx_large_binary_take_workspace_bytes": (_sz, [_i64]),
+    "arx_large_binary_take_offsets": (_int, [_bspan, _span, _int, _p, _sz, _p, _p, _p, C.POINTER(_i64), _p]),
+    "arx_large_binary_take_data": (_int, [_bspan, _i64, _p, _sz, _p, _i64, _p, _p]),
     "arx_plain_byte_array_offsets": (_int, [_p, _sz, _i64, C.c_int32, _p]),
     "arx_rle_scan_runs": (_int, [_p, _sz, _int, _i64, _u32, _u64, _p, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "arx_rle_decode_u32": (_int, [_p, _sz, _p, _i64, _int, _i64, _p, _p]),

@@ -23,7 +23,7 @@ namespace arx {
 constexpr int kBinRows = kBlock * 16;  // output slots per workgroup
 
 struct BinTakeArgs {
-  const int32_t* offsets;   // element 0 of the logical values array
+  const void* offsets;      // element 0 of the logical values array: int32 (utf8 / binary) or int64 (large_utf8 / large_binary) entries
   const uint8_t* data;
   const uint8_t* src_valid_bytes;  // source validity bitmap bytes or NULL
   int64_t src_valid_offset;
@@ -59,8 +59,10 @@ __device__ __forceinline__ bool bin_slot(const BinTakeArgs& a, int64_t i, uint64
   return ok;
 }
 
-__global__ __launch_bounds__(kBlock) void bin_lengths_kernel(BinTakeArgs a, int32_t* __restrict__ lens,
-                                                             int32_t* __restrict__ src_start,
+// O: the offsets' type — int32_t, or int64_t for the large_ types (round 4: same kernels, wider offsets)
+template <typename O>
+__global__ __launch_bounds__(kBlock) void bin_lengths_kernel(BinTakeArgs a, O* __restrict__ lens,
+                                                             O* __restrict__ src_start,
                                                              uint64_t* __restrict__ out_validity,
                                                              unsigned long long* __restrict__ valid_count,
                                                              long long* __restrict__ block_sums) {
@@ -87,16 +89,17 @@ __global__ __launch_bounds__(kBlock) void bin_lengths_kernel(BinTakeArgs a, int3
       ok[it] = ok[it] && ((a.src_valid_bytes[bit >> 3] >> (bit & 7)) & 1);
     }
   }
-  int32_t start[16], end[16];
+  O start[16], end[16];
+  const O* __restrict__ offs = static_cast<const O*>(a.offsets);
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
-    start[it] = ok[it] ? a.offsets[idx[it]] : 0;
-    end[it] = ok[it] ? a.offsets[idx[it] + 1] : 0;
+    start[it] = ok[it] ? offs[idx[it]] : 0;
+    end[it] = ok[it] ? offs[idx[it] + 1] : 0;
   }
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int64_t i = base + it * kBlock + tid;
-    const int32_t len = end[it] - start[it];
+    const O len = end[it] - start[it];
     if (i < a.length) {
       lens[i] = len;
       src_start[i] = start[it];
@@ -152,35 +155,36 @@ __global__ __launch_bounds__(1024) void bin_scan_blocks_kernel(long long* sums, 
 }
 
 // lens (in out_offsets) -> exclusive offsets, per workgroup of 4096 slots
-__global__ __launch_bounds__(kBlock) void bin_offsets_kernel(int32_t* __restrict__ out_offsets, int64_t length,
+template <typename O>
+__global__ __launch_bounds__(kBlock) void bin_offsets_kernel(O* __restrict__ out_offsets, int64_t length,
                                                              const long long* __restrict__ block_base) {
-  __shared__ uint32_t wave_tot[kWavesPerBlock];
+  __shared__ uint64_t wave_tot[kWavesPerBlock];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kBinRows;
   // thread t owns 16 CONSECUTIVE slots so that the scan order is the slot order
-  uint32_t v[16];
-  uint32_t mine = 0;
+  uint64_t v[16];
+  uint64_t mine = 0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int64_t i = base + tid * 16 + k;
-    v[k] = i < length ? static_cast<uint32_t>(out_offsets[i]) : 0u;
+    v[k] = i < length ? static_cast<uint64_t>(out_offsets[i]) : 0u;
     mine += v[k];
   }
-  const uint32_t incl = wave_inclusive_scan_u32(mine);
+  const uint64_t incl = wave_inclusive_scan_u64(mine);
   if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();
-  uint32_t pre = incl - mine;
+  uint64_t pre = incl - mine;
   for (int k = 0; k < wave; ++k) pre += wave_tot[k];
   long long run = block_base[blockIdx.x] + pre;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int64_t i = base + tid * 16 + k;
-    if (i < length) out_offsets[i] = static_cast<int32_t>(run);
+    if (i < length) out_offsets[i] = static_cast<O>(run);
     run += v[k];
   }
-  if (blockIdx.x == gridDim.x - 1 && tid == kBlock - 1) out_offsets[length] = static_cast<int32_t>(block_base[gridDim.x]);
+  if (blockIdx.x == gridDim.x - 1 && tid == kBlock - 1) out_offsets[length] = static_cast<O>(block_base[gridDim.x]);
 }
 
 // Output-centric copy: one workgroup per kBinChunk output bytes.  It finds the rows overlapping
@@ -192,7 +196,8 @@ __global__ __launch_bounds__(kBlock) void bin_offsets_kernel(int32_t* __restrict
 constexpr int kBinChunk = 16384;   // output bytes per workgroup
 constexpr int kBinBatch = 2048;    // rows staged per pass
 
-__device__ __forceinline__ int64_t bin_row_of(const int32_t* __restrict__ out_offsets, int64_t m, int32_t pos) {
+template <typename O>
+__device__ __forceinline__ int64_t bin_row_of(const O* __restrict__ out_offsets, int64_t m, int64_t pos) {
   // largest r in [0, m) with out_offsets[r] <= pos  (pos < out_offsets[m])
   int64_t lo = 0, hi = m;  // invariant: out_offsets[lo] <= pos < out_offsets[hi]
   while (hi - lo > 1) {
@@ -202,17 +207,18 @@ __device__ __forceinline__ int64_t bin_row_of(const int32_t* __restrict__ out_of
   return lo;
 }
 
+template <typename O>
 __global__ __launch_bounds__(kBlock) void bin_copy_kernel(const uint8_t* __restrict__ data,
-                                                          const int32_t* __restrict__ src_start,
-                                                          const int32_t* __restrict__ out_offsets, int64_t m,
+                                                          const O* __restrict__ src_start,
+                                                          const O* __restrict__ out_offsets, int64_t m,
                                                           int64_t total, uint8_t* __restrict__ out_data) {
-  __shared__ int32_t s_out[kBinBatch + 1];
-  __shared__ int32_t s_src[kBinBatch];
+  __shared__ O s_out[kBinBatch + 1];
+  __shared__ O s_src[kBinBatch];
   const int tid = threadIdx.x;
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kBinChunk;
   const int64_t b1 = b0 + kBinChunk < total ? b0 + kBinChunk : total;
-  const int64_t rlo = bin_row_of(out_offsets, m, static_cast<int32_t>(b0));
-  const int64_t rhi = bin_row_of(out_offsets, m, static_cast<int32_t>(b1 - 1));
+  const int64_t rlo = bin_row_of<O>(out_offsets, m, b0);
+  const int64_t rhi = bin_row_of<O>(out_offsets, m, b1 - 1);
   for (int64_t rb = rlo; rb <= rhi; rb += kBinBatch) {
     const int nb = static_cast<int>(rhi + 1 - rb < kBinBatch ? rhi + 1 - rb : kBinBatch);
     __syncthreads();
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void bin_copy_kernel(const uint8_t* __restr
         if (s_out[mid] <= first) l = mid; else h = mid;
       }
       int r = l;
-      int32_t r_out = s_out[r], r_end = s_out[r + 1], r_src = s_src[r];
+      O r_out = s_out[r], r_end = s_out[r + 1], r_src = s_src[r];
       uint32_t word = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void bin_copy_kernel(const uint8_t* __restr
   }
 }
 
-static int make_args(const ArxBinarySpan* values, const ArxSpan* indices, int index_type, BinTakeArgs* a) {
+static int make_args(const ArxBinarySpan* values, const ArxSpan* indices, int index_type, BinTakeArgs* a, int offset_width = 4) {
   if (values == nullptr || indices == nullptr) {
     set_error("values/indices is NULL");
     return ARX_INVALID;
@@ -271,7 +277,7 @@ static int make_args(const ArxBinarySpan* values, const ArxSpan* indices, int in
     return ARX_INVALID;
   }
   static const int widths[8] = {1, 1, 2, 2, 4, 4, 8, 8};
-  a->offsets = values->offsets + values->offset;
+  a->offsets = reinterpret_cast<const uint8_t*>(values->offsets) + values->offset * offset_width;
   a->data = static_cast<const uint8_t*>(values->data);
   a->src_valid_bytes = values->null_count != 0 ? static_cast<const uint8_t*>(values->validity) : nullptr;
   a->src_valid_offset = values->offset;
@@ -286,23 +292,20 @@ static int make_args(const ArxBinarySpan* values, const ArxSpan* indices, int in
 
 using namespace arx;
 
-extern "C" {
-
-// workspace: [workgroup byte totals, 64-bit][source start of every output slot, int32]
+// workspace: [workgroup byte totals, 64-bit][source start of every output slot, one offset each]
 static size_t bin_sums_bytes(int64_t num_indices) {
   return (static_cast<size_t>(ceil_div(num_indices, kBinRows) + 2) * 8 + 63) & ~static_cast<size_t>(63);
 }
-
-size_t arx_binary_take_workspace_bytes(int64_t num_indices) {
+static size_t bin_workspace_bytes(int64_t num_indices, int offset_width) {
   if (num_indices < 0) num_indices = 0;
-  return bin_sums_bytes(num_indices) + static_cast<size_t>(num_indices) * 4 + 64;
+  return bin_sums_bytes(num_indices) + static_cast<size_t>(num_indices) * offset_width + 64;
 }
 
-int arx_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices, int index_type, void* ws,
-                            size_t ws_bytes, int32_t* out_offsets, void* out_validity, int64_t* valid_count,
-                            int64_t* out_total_bytes, void* stream) {
+template <typename O>
+static int binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices, int index_type, void* ws, size_t ws_bytes,
+                               O* out_offsets, void* out_validity, int64_t* valid_count, int64_t* out_total_bytes, void* stream) {
   BinTakeArgs a{};
-  const int rc = make_args(values, indices, index_type, &a);
+  const int rc = make_args(values, indices, index_type, &a, static_cast<int>(sizeof(O)));
   if (rc != ARX_OK) return rc;
   if (out_offsets == nullptr || out_total_bytes == nullptr) {
     set_error("out_offsets / out_total_bytes is NULL");
@@ -311,10 +314,10 @@ int arx_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices,
   hipStream_t st = as_stream(stream);
   *out_total_bytes = 0;
   if (a.length == 0) {
-    ARX_HIP(hipMemsetAsync(out_offsets, 0, 4, st));
+    ARX_HIP(hipMemsetAsync(out_offsets, 0, sizeof(O), st));
     return ARX_OK;
   }
-  if (ws == nullptr || ws_bytes < arx_binary_take_workspace_bytes(a.length) || (reinterpret_cast<uint64_t>(ws) & 7) != 0) {
+  if (ws == nullptr || ws_bytes < bin_workspace_bytes(a.length, static_cast<int>(sizeof(O))) || (reinterpret_cast<uint64_t>(ws) & 7) != 0) {
     set_error("binary take workspace too small / unaligned");
     return ARX_INVALID;
   }
@@ -325,8 +328,8 @@ int arx_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices,
   }
   const int64_t nblocks = ceil_div(a.length, kBinRows);
   long long* sums = static_cast<long long*>(ws);
-  int32_t* src_start = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(ws) + bin_sums_bytes(a.length));
-  hipLaunchKernelGGL(bin_lengths_kernel, dim3(static_cast<unsigned>(nblocks)), dim3(kBlock), 0, st, a, out_offsets,
+  O* src_start = reinterpret_cast<O*>(static_cast<uint8_t*>(ws) + bin_sums_bytes(a.length));
+  hipLaunchKernelGGL(bin_lengths_kernel<O>, dim3(static_cast<unsigned>(nblocks)), dim3(kBlock), 0, st, a, out_offsets,
                      src_start, static_cast<uint64_t*>(out_validity), reinterpret_cast<unsigned long long*>(valid_count), sums);
   ARX_CHECK_LAUNCH("bin_lengths_kernel");
   hipLaunchKernelGGL(bin_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, sums, nblocks);
@@ -334,42 +337,76 @@ int arx_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices,
   long long total = 0;
   ARX_HIP(hipMemcpyAsync(&total, sums + nblocks, 8, hipMemcpyDeviceToHost, st));
   ARX_HIP(hipStreamSynchronize(st));
-  if (total > 2147483647LL) {
+  if (sizeof(O) == 4 && total > 2147483647LL) {
     // the reference's offset builder overflows the same way (int32 offsets)
     set_error("offset overflow while taking from a binary array: %lld bytes do not fit int32 offsets", total);
     return ARX_INVALID;
   }
-  hipLaunchKernelGGL(bin_offsets_kernel, dim3(static_cast<unsigned>(nblocks)), dim3(kBlock), 0, st, out_offsets,
+  hipLaunchKernelGGL(bin_offsets_kernel<O>, dim3(static_cast<unsigned>(nblocks)), dim3(kBlock), 0, st, out_offsets,
                      a.length, sums);
   ARX_CHECK_LAUNCH("bin_offsets_kernel");
   *out_total_bytes = total;
   return ARX_OK;
 }
 
-int arx_binary_take_data(const ArxBinarySpan* values, int64_t num_indices, const void* ws, size_t ws_bytes,
-                         const int32_t* out_offsets, int64_t total_bytes, void* out_data, void* stream) {
+template <typename O>
+static int binary_take_data(const ArxBinarySpan* values, int64_t num_indices, const void* ws, size_t ws_bytes,
+                            const O* out_offsets, int64_t total_bytes, void* out_data, void* stream) {
   if (values == nullptr) {
     set_error("values is NULL");
     return ARX_INVALID;
   }
   if (num_indices <= 0 || total_bytes <= 0) return ARX_OK;
   if (out_offsets == nullptr || out_data == nullptr || values->data == nullptr || ws == nullptr ||
-      ws_bytes < arx_binary_take_workspace_bytes(num_indices)) {
-    set_error("binary take: NULL buffer or workspace too small (pass the workspace of arx_binary_take_offsets)");
+      ws_bytes < bin_workspace_bytes(num_indices, static_cast<int>(sizeof(O)))) {
+    set_error("binary take: NULL buffer or workspace too small (pass the workspace of the offsets call)");
     return ARX_INVALID;
   }
-  if (total_bytes > 2147483647LL) {
+  if (sizeof(O) == 4 && total_bytes > 2147483647LL) {
     set_error("binary take: total_bytes does not fit int32 offsets");
     return ARX_INVALID;
   }
-  const int32_t* src_start =
-      reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(ws) + bin_sums_bytes(num_indices));
-  const unsigned grid = static_cast<unsigned>(ceil_div(total_bytes, kBinChunk));
-  hipLaunchKernelGGL(bin_copy_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+  const O* src_start = reinterpret_cast<const O*>(static_cast<const uint8_t*>(ws) + bin_sums_bytes(num_indices));
+  const int64_t chunks = ceil_div(total_bytes, kBinChunk);
+  if (chunks > 0x7FFFFFFFll) {
+    set_error("binary take: %lld output bytes are more than one launch takes", static_cast<long long>(total_bytes));
+    return ARX_NOT_IMPLEMENTED;
+  }
+  hipLaunchKernelGGL(bin_copy_kernel<O>, dim3(static_cast<unsigned>(chunks)), dim3(kBlock), 0, as_stream(stream),
                      static_cast<const uint8_t*>(values->data), src_start, out_offsets, num_indices, total_bytes,
                      static_cast<uint8_t*>(out_data));
   ARX_CHECK_LAUNCH("bin_copy_kernel");
   return ARX_OK;
+}
+
+extern "C" {
+
+size_t arx_binary_take_workspace_bytes(int64_t num_indices) { return bin_workspace_bytes(num_indices, 4); }
+size_t arx_large_binary_take_workspace_bytes(int64_t num_indices) { return bin_workspace_bytes(num_indices, 8); }
+
+int arx_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices, int index_type, void* ws,
+                            size_t ws_bytes, int32_t* out_offsets, void* out_validity, int64_t* valid_count,
+                            int64_t* out_total_bytes, void* stream) {
+  return binary_take_offsets<int32_t>(values, indices, index_type, ws, ws_bytes, out_offsets, out_validity, valid_count,
+                                      out_total_bytes, stream);
+}
+
+int arx_binary_take_data(const ArxBinarySpan* values, int64_t num_indices, const void* ws, size_t ws_bytes,
+                         const int32_t* out_offsets, int64_t total_bytes, void* out_data, void* stream) {
+  return binary_take_data<int32_t>(values, num_indices, ws, ws_bytes, out_offsets, total_bytes, out_data, stream);
+}
+
+// large_utf8 / large_binary: values->offsets points at int64 entries
+int arx_large_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices, int index_type, void* ws,
+                                  size_t ws_bytes, int64_t* out_offsets, void* out_validity, int64_t* valid_count,
+                                  int64_t* out_total_bytes, void* stream) {
+  return binary_take_offsets<int64_t>(values, indices, index_type, ws, ws_bytes, out_offsets, out_validity, valid_count,
+                                      out_total_bytes, stream);
+}
+
+int arx_large_binary_take_data(const ArxBinarySpan* values, int64_t num_indices, const void* ws, size_t ws_bytes,
+                               const int64_t* out_offsets, int64_t total_bytes, void* out_data, void* stream) {
+  return binary_take_data<int64_t>(values, num_indices, ws, ws_bytes, out_offsets, total_bytes, out_data, stream);
 }
 
 }  // extern "C"

@@ -206,6 +206,15 @@ int arx_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices,
                             int64_t* out_total_bytes, void* stream);
 int arx_binary_take_data(const ArxBinarySpan* values, int64_t num_indices, const void* ws, size_t ws_bytes,
                          const int32_t* out_offsets, int64_t total_bytes, void* out_data, void* stream);
+/* The same for large_utf8 / large_binary (int64 offsets, vector_selection_take_internal.cc / _filter_internal.cc register
+ * the large types with the same VarBinary implementations): values->offsets points at int64_t entries, the output offsets
+ * are int64_t, and there is no 2 GB limit. */
+size_t arx_large_binary_take_workspace_bytes(int64_t num_indices);
+int arx_large_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indices, int index_type, void* ws,
+                                  size_t ws_bytes, int64_t* out_offsets, void* out_validity, int64_t* valid_count,
+                                  int64_t* out_total_bytes, void* stream);
+int arx_large_binary_take_data(const ArxBinarySpan* values, int64_t num_indices, const void* ws, size_t ws_bytes,
+                               const int64_t* out_offsets, int64_t total_bytes, void* out_data, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Cast float64 -> float32 — replaces CastPrimitive<FloatType,DoubleType>::Exec

@@ -148,3 +148,7 @@ def test_wrap_device_memory_zero_copy_and_uint64_row_numbers_emulated():
 
 def test_stock_acero_plans_land_on_the_plugin_nodes_after_the_factory_override_emulated():
     _run(G.ACERO_OVERRIDE_SCRIPT, "ACERO_OVERRIDE_OK", 0.05)
+
+
+def test_filter_and_take_of_large_utf8_and_large_binary_on_device_arrays_emulated():
+    _run(G.LARGE_BINARY_SCRIPT, "LARGE_BINARY_OK", 0.02)
