@@ -2629,8 +2629,11 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   a.gap2 = (gap2 != 0 && roomy) ? 1 : 0;
   const int nb1 = 1 << a.b1;
   const size_t nparts = size_t(1) << a.bits;
-  a.tile1 = g_sort_msd_wide_rpt1 * kMsdwThreads;
-  a.tile2 = g_sort_msd_wide_rpt2 * kMsdwThreads;
+  // (each knob is read ONCE: the tile sizes, the grids and the template dispatch below must agree even if arx_set_option runs
+  //  beside this call — ADVICE r3)
+  const int rpt1 = g_sort_msd_wide_rpt1, rpt2 = g_sort_msd_wide_rpt2;
+  a.tile1 = rpt1 * kMsdwThreads;
+  a.tile2 = rpt2 * kMsdwThreads;
   const unsigned grid0 = static_cast<unsigned>(ceil_div(n, kMsdwTile));   // the sampled histogram reads 8192-row chunks
   const unsigned grid1 = static_cast<unsigned>(ceil_div(n, a.tile1));
   // Level-1 bucket sizes: estimated from 1 tile in 2^shift (the buckets then get room to spare and level 2 reads
@@ -2660,7 +2663,7 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
     hipLaunchKernelGGL(msdw_scan0_kernel, dim3(1), dim3(1024), 0, st, a);
     ARX_CHECK_LAUNCH("msdw_scan0_kernel");
 #define ARX_MSDW_SCATTER1(RAW)                                                                                      \
-  switch (g_sort_msd_wide_rpt1) {                                                                                  \
+  switch (rpt1) {                                                                                  \
     case 24: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 24>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break; \
     case 16: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 16>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break; \
     default: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break;  \
@@ -2700,7 +2703,7 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   }
   const unsigned grid2 = static_cast<unsigned>(ceil_div(n, a.tile2)) + static_cast<unsigned>(nb1);
 #define ARX_MSDW_SCATTER2(GAP)                                                                                      \
-  switch (g_sort_msd_wide_rpt2) {                                                                                  \
+  switch (rpt2) {                                                                                  \
     case 24: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 24>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break; \
     case 16: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 16>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break; \
     default: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 8>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break;  \
