@@ -2399,8 +2399,13 @@ size_t arx_groupby_consume_workspace_bytes(int64_t length, int64_t capacity) {
   size_t need = gbp_plan(std::min<int64_t>(length, gbp_plan(kGbTile, capacity).wide ? int64_t(g_gbp_wide_max_slice) : int64_t(g_gbp_max_slice)),
                          capacity).total;
   if (g_gbp_wide && g_gbp_bits < 0 && !gbp_plan(kGbTile, capacity).wide && gbp_plan(kGbTile, capacity).b2 > 0) {
-    const int64_t few = int64_t(kGbWideMaxGroups) << 1;   // any hint small enough for the wide plan
-    need = std::max(need, gbp_plan(std::min<int64_t>(length, int64_t(g_gbp_wide_max_slice)), capacity, few).total);
+    // (the rooms' slack grows with the partition count: size for the fewest and for the most partitions a hint can select,
+    //  so that ONE slice takes all the rows whatever the estimate — round 3 sized for the fewest only, which fit because
+    //  the probe slice had taken 2^25 rows first)
+    const int64_t few = int64_t(kGbWideMaxGroups) << 1;
+    const int64_t many = int64_t(kGbWideMaxGroups) << std::min<int>(int(g_gbp_wide_max_bits), kGbWideMaxBits);
+    const int64_t rows = std::min<int64_t>(length, int64_t(g_gbp_wide_max_slice));
+    need = std::max({need, gbp_plan(rows, capacity, few).total, gbp_plan(rows, capacity, many).total});
   }
   return need;
 }
