@@ -904,6 +904,7 @@ struct GbpArgs {
   unsigned int* dense_null_seen;
   int wide;                // 1 = the wide one-level form: b1 == 0, b2 == bits <= 11, 12-byte records in `recs`
   uint32_t room;           // != 0: the wide form WITHOUT a histogram pass — partition p owns records [p * room, (p + 1) * room)
+  int stripe_lg;           // != 0 (rooms only): record `off` of partition p lives at ((off >> lg) << (bits + lg)) + (p << lg) + (off & (2^lg - 1)) — see gbp_rec_phys
   uint32_t* part_end;      // [2^bits] one past a partition's last record (part_start[p + 1] with exact counts)
   uint32_t* overflow;      // set by the wide scatter when a partition outgrows its room
   uint8_t* recs;           // [n] {key u32, value lo, value hi}
@@ -917,6 +918,20 @@ __device__ __forceinline__ uint32_t gbp_hash(const GbpArgs& a, int32_t key) {
 }
 __device__ __forceinline__ int32_t gbp_unhash(const GbpArgs& a, uint32_t h) {
   return a.dense ? static_cast<int32_t>(h >> a.dense_shl) : static_cast<int32_t>(h * kGbHashInv);
+}
+
+// STRIPED rooms.  The flat scatter appends to 2^bits rooms that lie room * 12 bytes (24 MB at 4e9 rows) apart: every
+// (tile, bin) run is in another translation of the per-CU TLB — 31 % of the kernel's UTCL1 requests miss (8e8 misses
+// for 4e9 rows; a streaming copy: 7e4), while its DRAM credit stalls per ms are a quarter of the copy's
+// (profiles/r04_w_*): the pass waits for address translation, not for memory.  With stripes, chunk c (2^lg records) of
+// EVERY room lies in the same 2^(bits + lg) records (6 MB): distinct keys fill the rooms in step, so all frontiers of
+// the moment share a few translations.  Logical record numbers (p * room + off) stay what cursors, counts and work
+// units are kept in; only the two kernels that touch `recs` map them.
+__device__ __forceinline__ int64_t gbp_rec_phys(const GbpArgs& a, uint32_t part, uint32_t logical) {
+  if (a.stripe_lg == 0) return logical;
+  const uint32_t off = logical - part * a.room;
+  return (static_cast<int64_t>(off >> a.stripe_lg) << (a.bits + a.stripe_lg)) + (static_cast<int64_t>(part) << a.stripe_lg) +
+         (off & ((1u << a.stripe_lg) - 1u));
 }
 
 template <bool HAS_NULLS>
@@ -1503,13 +1518,14 @@ __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArg
       rec.vhi = static_cast<uint32_t>(v >> 32);
       const uint32_t dst = lds.gbase[d] + (lo + static_cast<uint32_t>(p) - lds.start[d]);
       if (a.room == 0 || dst - d * a.room < a.room) {   // (never past a room: the slice is redone then)
+        const int64_t at = gbp_rec_phys(a, d, dst);
         if constexpr ((kGbNt & 4) != 0) {
-          uint32_t* o = reinterpret_cast<uint32_t*>(out + dst);
+          uint32_t* o = reinterpret_cast<uint32_t*>(out + at);
           __builtin_nontemporal_store(rec.key, o);
           __builtin_nontemporal_store(rec.vlo, o + 1);
           __builtin_nontemporal_store(rec.vhi, o + 2);
         } else {
-          out[dst] = rec;
+          out[at] = rec;
         }
       }
     }
@@ -1611,9 +1627,10 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
 #pragma unroll
       for (int g = 0; g < U / 4; ++g) {
         const int64_t r0 = lo + ((it0 / 4 + g) * THREADS + tid) * 4;
-        const uint32_t* rp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const GbpRec*>(a.recs) + (r0 < hi ? r0 : hi - 1));
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const GbpRec*>(a.recs) +
+                                                               gbp_rec_phys(a, q, static_cast<uint32_t>(r0 < hi ? r0 : hi - 1)));
         uint32_t d[12];
-        if (r0 + 4 <= hi) {
+        if (r0 + 4 <= hi) {   // (striped rooms: a quad never crosses a chunk, r0 - room start and the chunk are multiples of 4)
           typedef arx_u32x4 __attribute__((aligned(4))) RecQuad;   // (a record starts at any multiple of 12 bytes)
           const RecQuad* q = reinterpret_cast<const RecQuad*>(rp);
           const arx_u32x4 q0 = q[0], q1 = q[1], q2 = q[2];
@@ -1627,7 +1644,7 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int64_t rc = r0 + j < hi ? r0 + j : hi - 1;
-            const uint32_t* p1 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const GbpRec*>(a.recs) + rc);
+            const uint32_t* p1 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const GbpRec*>(a.recs) + gbp_rec_phys(a, q, static_cast<uint32_t>(rc)));
             d[3 * j] = p1[0]; d[3 * j + 1] = p1[1]; d[3 * j + 2] = p1[2];
           }
         }
@@ -1649,7 +1666,7 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
       }
       const int64_t rc = rr < hi ? rr : hi - 1;  // clamped: always readable
       if constexpr (AOS) {
-        const uint32_t* rp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const GbpRec*>(a.recs) + rc);
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const GbpRec*>(a.recs) + gbp_rec_phys(a, q, static_cast<uint32_t>(rc)));
         const uint32_t rk = gb_load(rp, (kGbNt & 2) != 0), rlo = gb_load(rp + 1, (kGbNt & 2) != 0), rhi = gb_load(rp + 2, (kGbNt & 2) != 0);
         kb[u] = static_cast<int32_t>(rk);
         vb[u] = (static_cast<unsigned long long>(rhi) << 32) | rlo;
@@ -1741,11 +1758,13 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const int64_t r0 = lo + ((it0 / 4 + g) * THREADS + tid) * 4;
-        const int64_t ws = r0 + 4 <= hi ? r0 : hi4;
-        const RecQuad* q = reinterpret_cast<const RecQuad*>(reinterpret_cast<const GbpRec*>(a.recs) + ws);
-        raw[g][0] = q[0];
-        raw[g][1] = q[1];
-        raw[g][2] = q[2];
+        // striped rooms: the thread's own aligned quad — it never crosses a chunk, and what it reads past `hi` is still
+        // inside the chunk (rooms are whole chunks); a thread with nothing left re-reads the unit's first quad
+        const int64_t ws = a.stripe_lg != 0 ? gbp_rec_phys(a, q, static_cast<uint32_t>(r0 < hi ? r0 : lo)) : (r0 + 4 <= hi ? r0 : hi4);
+        const RecQuad* rq = reinterpret_cast<const RecQuad*>(reinterpret_cast<const GbpRec*>(a.recs) + ws);
+        raw[g][0] = rq[0];
+        raw[g][1] = rq[1];
+        raw[g][2] = rq[2];
       }
     };
     auto consume = [&](int64_t it0, arx_u32x4 (*raw)[3]) {
@@ -1760,7 +1779,7 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
           d[4 + e] = raw[g][1][e];
           d[8 + e] = raw[g][2][e];
         }
-        const int shift = r0 + 4 <= hi ? 0 : static_cast<int>(r0 - hi4);   // 1 .. 3 behind the partition's last whole quad
+        const int shift = (a.stripe_lg != 0 || r0 + 4 <= hi) ? 0 : static_cast<int>(r0 - hi4);   // 1 .. 3 behind the partition's last whole quad
         for (int k = 0; k < shift; ++k) {
 #pragma unroll
           for (int e = 0; e < 9; ++e) d[e] = d[e + 3];
@@ -1865,6 +1884,7 @@ struct GbpPlan {
   int bits, b1, b2;
   int wide;                 // the wide one-level form (b1 == 0, b2 == bits)
   uint32_t room;            // wide form: records every partition's room holds (see gbp_room_for)
+  int stripe_lg;            // rooms laid out in stripes of 2^stripe_lg records per partition (gbp_rec_phys); 0 = room after room
   int64_t slice_rows, chunk_rows, nchunks;
   size_t off_keys_a, off_vals_a, off_keys_b, off_vals_b, off_part_count, off_part_start,
       off_cursor2, off_cursor1, off_hist1, off_l1_start, off_l2_tile_start, off_agg_unit_start, off_part_end, off_overflow, total;
@@ -1879,6 +1899,7 @@ static Knob<int> g_gbp_chunks{2048};       // level-1 chunks = workgroups of the
 static Knob<int> g_gbp_wide_max_bits{kGbWideMaxBits};   // bins of the flat level the planner may ask for (A/B knob groupby_wide_max_bits; tests lower it)
 static Knob<int> g_gbp_room_min_mean{1 << 14};   // rooms only for partitions of at least this many rows on average (knob groupby_wide_room_min_mean; tests lower it)
 static Knob<int> g_gbp_sketch{1};          // the group count from a HyperLogLog sketch of the first groupby_probe_rows keys (0: round 3's probe slice on the two-level plan; A/B knob groupby_sketch)
+static Knob<int> g_gbp_stripe_lg{0};       // rooms in stripes of 2^lg records (A/B knob groupby_stripe_lg; 0 = off, else 2 .. 16)
 static Knob<int> g_gbp_wide_rooms{1};      // the wide form without its histogram pass: fixed rooms per partition (A/B knob groupby_wide_rooms)
 static Knob<int> g_gbp_wide{1};            // the wide one-level form where the group estimate allows it (A/B knob groupby_wide)
 static Knob<int> g_gbp_wide_agg_chunk{1 << 21};   // rows per aggregate work unit of the wide form (A/B knob groupby_wide_agg_chunk_rows)
@@ -1911,12 +1932,13 @@ static int gbp_wide_bits_for(int64_t groups) {
 
 // Records a partition's room holds when the wide form runs without a histogram: the mean + 6 sigma of the binomial a
 // bijective hash of DISTINCT keys gives, + 64.  Only worth it when the slack is small (mean >= 2^14: <= 5 %).
-static uint32_t gbp_room_for(int64_t rows, int bits) {
+static uint32_t gbp_room_for(int64_t rows, int bits, int stripe_lg) {
   const int64_t mean = (rows + (int64_t(1) << bits) - 1) >> bits;
   if (mean < g_gbp_room_min_mean) return 0;
   int64_t sd = 1;
   while (sd * sd < mean) ++sd;
-  const int64_t room = mean + 6 * sd + 64;
+  int64_t room = mean + 6 * sd + 64;
+  if (stripe_lg > 0) room = ((room >> stripe_lg) + 1) << stripe_lg;   // whole chunks (the aggregate over-reads inside a chunk)
   return (room << bits) < (int64_t(1) << 32) ? static_cast<uint32_t>(room) : 0;
 }
 
@@ -1970,7 +1992,11 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity, int64_t groups_hin
   size_t o = 0;
   // rooms need keys that spread like distinct hashed keys: the keyed table, never the dense ids of the hash_sum vtable
   // (id << shift puts all rows of the low ids into the low partitions)
-  if (p.wide && g_gbp_wide_rooms && allow_rooms && dense_idbits == 0) p.room = gbp_room_for(slice_rows, p.bits);
+  if (p.wide && g_gbp_wide_rooms && allow_rooms && dense_idbits == 0) {
+    const int lg = g_gbp_stripe_lg;
+    p.room = gbp_room_for(slice_rows, p.bits, lg);
+    p.stripe_lg = p.room != 0 ? lg : 0;
+  }
   if (p.wide) {
     const size_t recs = p.room ? (static_cast<size_t>(p.room) << p.bits) : n;
     p.off_keys_a = o; o = align(o + recs * 12);   // the 12-byte records
@@ -2019,6 +2045,7 @@ static void gbp_bind(GbpArgs& a, const GbpPlan& plan, uint8_t* w) {
   a.part_end = reinterpret_cast<uint32_t*>(w + plan.off_part_end);
   a.overflow = reinterpret_cast<uint32_t*>(w + plan.off_overflow);
   a.room = plan.room;
+  a.stripe_lg = plan.room != 0 ? plan.stripe_lg : 0;
   a.agg_pipe = g_gbp_agg_pipe;
   a.xcd_map = g_gbp_xcd_map;
   a.agg_chunk = static_cast<uint32_t>(plan.wide ? g_gbp_wide_agg_chunk : g_gbp_agg_chunk);
@@ -2231,6 +2258,10 @@ int set_groupby_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "groupby_sketch") == 0) {
     g_gbp_sketch = value != 0;
+    return 1;
+  }
+  if (strcmp(name, "groupby_stripe_lg") == 0) {
+    g_gbp_stripe_lg = value <= 0 ? 0 : static_cast<int>(std::max<int64_t>(2, std::min<int64_t>(value, 16)));
     return 1;
   }
   if (strcmp(name, "groupby_wide_rooms") == 0) {

@@ -37,6 +37,15 @@ def timed(fn):
     return (time.perf_counter() - t0) * 1e3, out
 
 
+if what == "copy":   # the same counters on a plain streaming copy (arx_buffer_copy, 16 GB moved twice): the baseline
+    src = torch.empty(sort_rows * 8, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    src.view(torch.int64).fill_(7)
+    for i in range(runs + 1):
+        ms, _ = timed(lambda: amd.compute.copy_buffer(src, dst))
+        print(f"copy {src.numel()} bytes run {i}: {ms:.3f} ms = {2 * src.numel() / ms / 1e6:.0f} GB/s", flush=True)
+    del src, dst
+    torch.cuda.empty_cache()
 if what in ("sort", "both"):
     k = torch.empty(sort_rows, dtype=torch.int64, device=dev)
     fill(k, -2**63, 2**63 - 1, 10)

@@ -1,10 +1,7 @@
-"""Key rows wider than one device Grouper table (16 bytes / 8 columns) and utf8 / binary keys: the chain of tables.
-
-Added at the end of round 3 after the round's GPU minutes were spent: everything here is green on the SIMT emulator
-(tests/test_emu_parity.py, tests/test_plugin_emulated.py run the same checks), and composes only kernels the GPU tier
-already exercises (arx_grouper_consume / get_uniques on (uint32, columns...) rows, arx_take by uint32 indices) — but it has
-not yet run on gfx950, so it sits in a file that sorts LAST: a failure here cannot hide another test's result under
-`pytest -x`.  Fold into test_gpu_parity.py / test_gpu_arrow_plugin.py once a GPU run is on record."""
+"""Key rows wider than one device Grouper table (16 bytes / 8 columns) and utf8 / binary keys: the chain of tables, and
+the one-pass (length, hash) form of var-width keys with its verification and forced-collision fallback.  (Written at the
+end of round 3 in a last-sorting file because it had not yet run on gfx950; green there since round 4 —
+profiles/r04_c_*, r04_e_* — and named like its siblings since.  The emulator tier runs the same checks.)"""
 import subprocess
 import sys
 import textwrap

@@ -95,13 +95,13 @@ def test_aggregate_rocm_general_keys_emulated():
 
 
 def test_aggregate_rocm_key_rows_wider_than_16_bytes_emulated():
-    from . import test_zz_gpu_wide_keys as W
+    from . import test_gpu_group_keys as W
 
     _run(W.WIDE_KEYS_SCRIPT, "WIDE_KEYS_OK", 0.004)
 
 
 def test_aggregate_rocm_utf8_and_binary_keys_emulated():
-    from . import test_zz_gpu_wide_keys as W
+    from . import test_gpu_group_keys as W
 
     _run(W.STRING_KEYS_SCRIPT, "STRING_KEYS_OK", 0.005)
 
