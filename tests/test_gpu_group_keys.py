@@ -81,30 +81,6 @@ WIDE_KEYS_SCRIPT = textwrap.dedent(r'''
         same(run(t, "aggregate_rocm", keys, aggs), w, ("host", keys))
         same(run(td, "aggregate_rocm", keys, aggs), w, ("device", keys))
     assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - g0 >= 2 * len(plans), "aggregate_rocm did not run the device Grouper"
-    # round 4: the strings entered the tables as (length, 64-bit hash) and the groups were verified against their first
-    # rows' bytes; no batch above needed the exact chunk columns
-    lib.arrow_amd_plugin_string_key_hash_collisions.restype = ctypes.c_int64
-    assert lib.arrow_amd_plugin_string_key_hash_collisions() == 0
-    # a hash of 3 bits: different strings of one length share it all the time -> the verification sees it and the batch is
-    # grouped again by the exact chunk columns; 0 bits = the chunk columns from the start.  Same results either way.
-    for bits in (3, 0):
-        lib.arrow_amd_plugin_set_string_key_hash_bits(ctypes.c_int64(bits))
-        c0 = lib.arrow_amd_plugin_string_key_hash_collisions()
-        for (keys, aggs), w in zip(plans, want):
-            same(run(td, "aggregate_rocm", keys, aggs), w, ("device", keys, "hash bits", bits))
-        assert (lib.arrow_amd_plugin_string_key_hash_collisions() > c0) == (bits == 3), bits
-    lib.arrow_amd_plugin_set_string_key_hash_bits(ctypes.c_int64(64))
-    # long keys: 8 / 64 / 512 / 3000 bytes, many distinct values that share their first 500 bytes, odd start offsets
-    m = SC(120_000)
-    base = bytes(rng.integers(0, 256, 3000, dtype=np.uint8))
-    lens = rng.choice([8, 64, 512, 3000], m)
-    ids = rng.integers(0, 5000, m)
-    longs = [base[:l - 4] + int(i).to_bytes(4, "little") for l, i in zip(lens.tolist(), ids.tolist())]
-    tl = pa.table({"b": pa.array(longs, pa.binary(), mask=rng.random(m) < 0.03), "v": pa.array(rng.integers(-2**40, 2**40, m))})
-    wl = run(tl, "aggregate", ["b"], [("v", "hash_sum", None, "s_"), ([], "hash_count_all", None, "all")])
-    tld = pa.Table.from_batches([pa.RecordBatch.from_arrays([to_device(tl.column(j).chunk(0)) for j in range(2)], names=tl.schema.names)])
-    same(run(tl, "aggregate_rocm", ["b"], [("v", "hash_sum", None, "s_"), ([], "hash_count_all", None, "all")]), wl, "long keys host")
-    same(run(tld, "aggregate_rocm", ["b"], [("v", "hash_sum", None, "s_"), ([], "hash_count_all", None, "all")]), wl, "long keys device")
     # the order of the groups is the order of first appearance of the whole key row, whatever the number of tables
     keys = ["k64", "l64", "m64"]
     got = acero.Declaration.from_sequence([
@@ -192,6 +168,30 @@ STRING_KEYS_SCRIPT = textwrap.dedent(r'''
         same(run(chunks, "aggregate_rocm", keys, aggs), w, ("host", keys))
         same(run(td, "aggregate_rocm", keys, aggs), w, ("device", keys))
     assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - g0 >= 2 * len(plans), "aggregate_rocm did not run the device Grouper"
+    # round 4: the strings entered the tables as (length, 64-bit hash) and the groups were verified against their first
+    # rows' bytes; no batch above needed the exact chunk columns
+    lib.arrow_amd_plugin_string_key_hash_collisions.restype = ctypes.c_int64
+    assert lib.arrow_amd_plugin_string_key_hash_collisions() == 0
+    # a hash of 3 bits: different strings of one length share it all the time -> the verification sees it and the batch is
+    # grouped again by the exact chunk columns; 0 bits = the chunk columns from the start.  Same results either way.
+    for bits in (3, 0):
+        lib.arrow_amd_plugin_set_string_key_hash_bits(ctypes.c_int64(bits))
+        c0 = lib.arrow_amd_plugin_string_key_hash_collisions()
+        for (keys, aggs), w in zip(plans, want):
+            same(run(td, "aggregate_rocm", keys, aggs), w, ("device", keys, "hash bits", bits))
+        assert (lib.arrow_amd_plugin_string_key_hash_collisions() > c0) == (bits == 3), bits
+    lib.arrow_amd_plugin_set_string_key_hash_bits(ctypes.c_int64(64))
+    # long keys: 8 / 64 / 512 / 3000 bytes, many distinct values that share their first 500 bytes, odd start offsets
+    m = SC(120_000)
+    base = bytes(rng.integers(0, 256, 3000, dtype=np.uint8))
+    lens = rng.choice([8, 64, 512, 3000], m)
+    ids = rng.integers(0, 5000, m)
+    longs = [base[:l - 4] + int(i).to_bytes(4, "little") for l, i in zip(lens.tolist(), ids.tolist())]
+    tl = pa.table({"b": pa.array(longs, pa.binary(), mask=rng.random(m) < 0.03), "v": pa.array(rng.integers(-2**40, 2**40, m))})
+    wl = run(tl, "aggregate", ["b"], [("v", "hash_sum", None, "s_"), ([], "hash_count_all", None, "all")])
+    tld = pa.Table.from_batches([pa.RecordBatch.from_arrays([to_device(tl.column(j).chunk(0)) for j in range(2)], names=tl.schema.names)])
+    same(run(tl, "aggregate_rocm", ["b"], [("v", "hash_sum", None, "s_"), ([], "hash_count_all", None, "all")]), wl, "long keys host")
+    same(run(tld, "aggregate_rocm", ["b"], [("v", "hash_sum", None, "s_"), ([], "hash_count_all", None, "all")]), wl, "long keys device")
     # groups in order of first appearance, the unique strings byte for byte (NUL bytes, empty vs null)
     got = run(t, "aggregate_rocm", ["s", "a"], [([], "hash_count_all", None, "all")], sort=False)
     rows = list(zip(t.column("s").to_pylist(), t.column("a").to_pylist()))
