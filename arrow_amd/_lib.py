@@ -153,6 +153,8 @@ SIGNATURES = {
     "arx_delta_decode": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p, _sz, _p, _p]),
     "arx_lengths_to_offsets_i32": (_int, [_p, _i64, C.c_int32, _p, _p, _sz, _p]),
     "arx_byte_stream_split_decode": (_int, [_p, _i64, _int, _p, _p]),
+    "arx_delta_byte_array_lengths": (_int, [_p, _p, _i64, _p, _i64, _p, _p, _p]),
+    "arx_delta_byte_array_expand": (_int, [_p, _p, _p, _i64, _p, C.c_int32, _p, _p, _i64, _p, _p, _p]),
     "arx_divide_i64": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _int, _p, _p, _p]),
     "arx_divide_f64": (_int, [_p, C.c_double, _p, _i64, _p, C.c_double, _p, _i64, _i64, _int, _p, _p, _p]),
     "arx_bitmap_copy_at": (_int, [_p, _i64, _i64, _p, _i64, _p]),

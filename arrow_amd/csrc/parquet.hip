@@ -779,6 +779,117 @@ __global__ __launch_bounds__(kBlock) void rle_levels_bitmap_kernel(const uint8_t
   }
 }
 
+
+// ---- DELTA_BYTE_ARRAY (DeltaByteArrayDecoderImpl, cpp/src/parquet/decoder.cc:1974-2204): value i = the first
+// prefix[i] bytes of value i - 1 ++ suffix i; the prefix lengths are a DELTA_BINARY_PACKED stream, the suffixes a
+// DELTA_LENGTH_BYTE_ARRAY block (both decoded by the kernels above), and every page starts from the empty string
+// (SetData: last_value_.clear(), :2017).  The recurrence runs over whole values, so a page is ONE wave's sequential
+// walk — pages are the parallel axis, as they are the reference's unit of decoding — with the lanes as the byte axis:
+// the current value's first kDbaWindow bytes live in LDS (a value keeps its prefix there and overwrites the rest
+// with its suffix), the suffix bytes of 64 values at a time are staged through LDS with one round trip, and every
+// output byte is written once.
+constexpr int kDbaWindow = 8192;   // bytes of the current value kept in LDS (longer prefixes are re-read from the output)
+constexpr int kDbaStage = 8192;    // suffix bytes of a group of 64 values staged in LDS
+
+__device__ __forceinline__ int64_t dba_page_of(const int64_t* __restrict__ page_first, int64_t npages, int64_t i) {
+  int64_t lo = 0, hi = npages;   // the last page whose first value is <= i
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (page_first[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// out_len[i] = prefix[i] + suffix_len[i], and the checks of :2096-2107 / BuildBufferInternal :2039: status bit 0 =
+// negative prefix length, bit 1 = prefix longer than the previous value (the first value of a page: longer than ""),
+// bit 2 = negative suffix length, bit 3 = a value past the int32 offsets
+__global__ __launch_bounds__(kBlock) void dba_lengths_kernel(const int32_t* __restrict__ prefix, const int32_t* __restrict__ suffix_len,
+                                                             int64_t n, const int64_t* __restrict__ page_first, int64_t npages,
+                                                             int32_t* __restrict__ out_len, unsigned long long* __restrict__ state) {
+  uint32_t bad = 0;
+  unsigned long long bytes = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int32_t p = prefix[i], s = suffix_len[i];
+    if (p < 0) bad |= 1u;
+    if (s < 0) bad |= 4u;
+    const bool first = page_first[dba_page_of(page_first, npages, i)] == i;
+    const int64_t before = first ? 0 : static_cast<int64_t>(prefix[i - 1]) + suffix_len[i - 1];
+    if (p > before) bad |= 2u;
+    const int64_t len = static_cast<int64_t>(p) + s;
+    if (len > INT32_MAX) bad |= 8u;
+    const int32_t kept = static_cast<int32_t>(len < 0 ? 0 : (len > INT32_MAX ? INT32_MAX : len));
+    out_len[i] = kept;
+    bytes += static_cast<unsigned long long>(kept);
+  }
+  if (bad != 0) atomicOr(&state[0], static_cast<unsigned long long>(bad));
+  bytes = wave_reduce_sum_u64(bytes);
+  if (lane_id() == 0 && bytes != 0) atomicAdd(&state[1], bytes);
+}
+
+struct DbaLds {
+  uint8_t cur[kDbaWindow];
+  uint32_t stage[kDbaStage / 4 + 2];
+};
+
+__global__ __launch_bounds__(64) void dba_expand_kernel(const int32_t* __restrict__ prefix, const int32_t* __restrict__ suffix_off,
+                                                        const uint8_t* __restrict__ suffix, int64_t suffix_size,
+                                                        const int32_t* __restrict__ out_off, int32_t out_base,
+                                                        const int64_t* __restrict__ page_first,
+                                                        const int64_t* __restrict__ page_suffix_first, unsigned long long* __restrict__ state,
+                                                        uint8_t* out) {
+  __shared__ DbaLds lds;
+  const int lane = threadIdx.x;
+  const int64_t v0 = page_first[blockIdx.x], v1 = page_first[blockIdx.x + 1];
+  if (v0 >= v1) return;
+  // the page's suffix lengths must add up to the suffix bytes it carries (else its values would read their neighbours')
+  if (page_suffix_first != nullptr &&
+      (suffix_off[v0] != page_suffix_first[blockIdx.x] || suffix_off[v1] != page_suffix_first[blockIdx.x + 1])) {
+    if (lane == 0) atomicOr(&state[0], 16ull);
+    return;
+  }
+  const uint8_t* stage_bytes = reinterpret_cast<const uint8_t*>(lds.stage);
+  int64_t prev_out = 0;   // where the previous value starts in `out` (prefixes past the LDS window are read there)
+  for (int64_t g = v0; g < v1; g += 64) {
+    const int64_t i = g + lane < v1 ? g + lane : v1 - 1;
+    const int32_t my_p = prefix[i], my_so = suffix_off[i], my_se = suffix_off[i + 1], my_oo = out_off[i];
+    const int cnt = static_cast<int>(v1 - g < 64 ? v1 - g : 64);
+    // the group's suffix bytes are one contiguous range of the stream: staged with aligned dword loads when they fit
+    const int64_t s_lo = __shfl(my_so, 0, 64), s_hi = __shfl(my_se, cnt - 1, 64);
+    const int64_t a_lo = s_lo & ~int64_t(3);
+    const bool staged = s_hi - a_lo <= kDbaStage && ((s_hi + 3) & ~int64_t(3)) <= ((suffix_size + 3) & ~int64_t(3));
+    __syncthreads();   // (one wave: the previous group's reads of the stage come before it is overwritten)
+    if (staged) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(suffix + a_lo);
+      const int nd = static_cast<int>((s_hi - a_lo + 3) >> 2);
+      for (int k = lane; k < nd; k += 64) lds.stage[k] = src[k];
+    }
+    __syncthreads();
+    for (int j = 0; j < cnt; ++j) {
+      const int32_t p = __shfl(my_p, j, 64);
+      const int64_t so = __shfl(my_so, j, 64);
+      const int32_t sl = __shfl(my_se, j, 64) - static_cast<int32_t>(so);
+      const int64_t oo = static_cast<int64_t>(__shfl(my_oo, j, 64)) - out_base;
+      // (a) the part of the prefix past the LDS window: from the previous value's bytes in the output (rare: > 8 KB)
+      if (p > kDbaWindow) {
+        __threadfence();
+        for (int b = kDbaWindow + lane; b < p; b += 64) out[oo + b] = out[prev_out + b];
+      }
+      // (b) the prefix inside the window, as the previous value left it
+      const int pw = p < kDbaWindow ? p : kDbaWindow;
+      for (int b = lane; b < pw; b += 64) out[oo + b] = lds.cur[b];
+      // (c) the suffix: to the output and, where it falls inside the window, over the tail of the previous value
+      for (int b = lane; b < sl; b += 64) {
+        const uint8_t byte = staged ? stage_bytes[so - a_lo + b] : suffix[so + b];
+        const int q = p + b;
+        out[oo + q] = byte;
+        if (q < kDbaWindow) lds.cur[q] = byte;
+      }
+      prev_out = oo;
+      __syncthreads();   // the next value reads what this one wrote into the window
+    }
+  }
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -1073,6 +1184,44 @@ int arx_lengths_to_offsets_i32(const int32_t* lengths, int64_t n, int32_t base, 
   hipLaunchKernelGGL((delta_write_kernel<int32_t, LengthSource>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, src,
                      count, sums, out);
   ARX_CHECK_LAUNCH("delta_write_kernel");
+  return ARX_OK;
+}
+
+int arx_delta_byte_array_lengths(const int32_t* prefix, const int32_t* suffix_len, int64_t n, const int64_t* page_first,
+                                 int64_t num_pages, int32_t* out_len, uint64_t* state, void* stream) {
+  if (n < 0 || num_pages < 0 || state == nullptr || (n > 0 && (prefix == nullptr || suffix_len == nullptr || out_len == nullptr ||
+                                                                 page_first == nullptr || num_pages == 0))) {
+    set_error("bad arguments to arx_delta_byte_array_lengths (%lld values, %lld pages)", static_cast<long long>(n),
+              static_cast<long long>(num_pages));
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  ARX_HIP(hipMemsetAsync(state, 0, 16, st));
+  if (n == 0) return ARX_OK;
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock), 256 * 8)));
+  hipLaunchKernelGGL(dba_lengths_kernel, dim3(grid), dim3(kBlock), 0, st, prefix, suffix_len, n, page_first, num_pages, out_len,
+                     reinterpret_cast<unsigned long long*>(state));
+  ARX_CHECK_LAUNCH("dba_lengths_kernel");
+  return ARX_OK;
+}
+
+int arx_delta_byte_array_expand(const int32_t* prefix, const int32_t* suffix_offsets, const void* suffix_bytes, int64_t suffix_size,
+                                const int32_t* out_offsets, int32_t out_base, const int64_t* page_first,
+                                const int64_t* page_suffix_first, int64_t num_pages, void* out_data, uint64_t* state, void* stream) {
+  if (num_pages < 0 || suffix_size < 0 || (num_pages > 0 && (prefix == nullptr || suffix_offsets == nullptr || out_offsets == nullptr ||
+                                                               page_first == nullptr || (page_suffix_first != nullptr && state == nullptr)))) {
+    set_error("bad arguments to arx_delta_byte_array_expand (%lld pages)", static_cast<long long>(num_pages));
+    return ARX_INVALID;
+  }
+  if (num_pages == 0) return ARX_OK;
+  if ((reinterpret_cast<uintptr_t>(suffix_bytes) & 3) != 0) {
+    set_error("arx_delta_byte_array_expand: the suffix bytes must start on a 4-byte boundary");
+    return ARX_INVALID;
+  }
+  hipLaunchKernelGGL(dba_expand_kernel, dim3(static_cast<unsigned>(num_pages)), dim3(64), 0, as_stream(stream), prefix, suffix_offsets,
+                     static_cast<const uint8_t*>(suffix_bytes), suffix_size, out_offsets, out_base, page_first, page_suffix_first,
+                     reinterpret_cast<unsigned long long*>(state), static_cast<uint8_t*>(out_data));
+  ARX_CHECK_LAUNCH("dba_expand_kernel");
   return ARX_OK;
 }
 

@@ -3,7 +3,7 @@
 Scope: flat columns of physical type INT32 / INT64 / FLOAT / DOUBLE (PLAIN and PLAIN_DICTIONARY /
 RLE_DICTIONARY encodings, incl. the dictionary -> PLAIN fallback inside a chunk; DELTA_BINARY_PACKED for
 INT32 / INT64; BYTE_STREAM_SPLIT), BOOLEAN (PLAIN, RLE) and
-BYTE_ARRAY columns (utf8 / binary; dictionary-encoded, PLAIN and DELTA_LENGTH_BYTE_ARRAY pages); required or optional (max definition level <= 1, no repetition),
+BYTE_ARRAY columns (utf8 / binary; dictionary-encoded, PLAIN, DELTA_LENGTH_BYTE_ARRAY and DELTA_BYTE_ARRAY pages); required or optional (max definition level <= 1, no repetition),
 data pages V1 and V2, any page compression pyarrow's codecs can undo.
 
 Division of labour (what the reference does in cpp/src/parquet/column_reader.cc:740-1000 and
@@ -30,7 +30,7 @@ from .array import Array, alloc, bitmap_nbytes, current_stream, default_device, 
 # parquet.thrift enums
 _PAGE_DATA, _PAGE_INDEX, _PAGE_DICT, _PAGE_DATA_V2 = 0, 1, 2, 3
 _ENC_PLAIN, _ENC_PLAIN_DICT, _ENC_RLE, _ENC_BIT_PACKED, _ENC_RLE_DICT = 0, 2, 3, 4, 8
-_ENC_DELTA_BINARY_PACKED, _ENC_DELTA_LENGTH_BYTE_ARRAY, _ENC_BYTE_STREAM_SPLIT = 5, 6, 9
+_ENC_DELTA_BINARY_PACKED, _ENC_DELTA_LENGTH_BYTE_ARRAY, _ENC_DELTA_BYTE_ARRAY, _ENC_BYTE_STREAM_SPLIT = 5, 6, 7, 9
 _PHYSICAL = {"INT32": (int32, np.int32), "INT64": (int64, np.int64), "FLOAT": (float32, np.float32),
              "DOUBLE": (float64, np.float64)}
 
@@ -159,6 +159,116 @@ def decode_delta_binary_packed(data, byte_width: int = 8, device=None) -> Array:
     check(lib.arx_delta_decode(d_bytes.data_ptr(), d_table.data_ptr(), len(mbs), vpm, first, total, byte_width,
                                ws.data_ptr(), ws.numel(), out.data_ptr(), stream))
     return Array(atype, total, [None, out], 0, 0)
+
+
+def decode_delta_streams(streams, byte_width: int, device=None):
+    """Several DELTA_BINARY_PACKED streams (the head of each byte string) decoded into ONE device buffer, stream after
+    stream, by one launch sequence (arx_delta_decode_pages: every stream owns whole 4096-value tiles).  Returns (the uint8
+    tensor of all values, [(values in the stream, bytes it takes)])."""
+    device = torch.device(device) if device is not None else default_device()
+    lib, stream = _lib.get_lib(), current_stream(device)
+    delta_bytes, tables, info = bytearray(), [], []
+    pages = np.zeros(max(len(streams), 1), dtype=DELTA_PAGE_DTYPE)
+    start = at = tiles = 0
+    for j, data in enumerate(streams):
+        mbs, vpm, total, first, used = scan_delta_miniblocks(data, byte_base=len(delta_bytes))
+        pages[j] = (start, at, max(vpm, 1), first, total, tiles)
+        tables.append(mbs)
+        delta_bytes += bytes(data[:used])
+        delta_bytes += b"\0" * (-len(delta_bytes) % 8)      # the next stream starts on a 64-bit word
+        info.append((total, used))
+        start += total
+        at += len(mbs)
+        tiles += (total + 4095) // 4096
+    out = alloc(max(start, 1) * byte_width, device)
+    if start:
+        d_bytes = to_device(np.frombuffer(bytes(delta_bytes) + b"\0" * 16, dtype=np.uint8), device)
+        table = np.concatenate(tables) if at else np.zeros(1, MINIBLOCK_DTYPE)
+        d_table = to_device(table.view(np.uint8), device)
+        d_pages = to_device(pages.view(np.uint8), device)
+        ws = alloc(lib.arx_delta_decode_workspace_bytes(max(tiles, 1) * 4096), device)
+        check(lib.arx_delta_decode_pages(d_bytes.data_ptr(), d_table.data_ptr(), d_pages.data_ptr(), len(streams), tiles, byte_width,
+                                         ws.data_ptr(), ws.numel(), out.data_ptr(), stream))
+    return out, info
+
+
+_DBA_STATUS = ((1, "negative prefix length in DELTA_BYTE_ARRAY"), (2, "prefix length too large in DELTA_BYTE_ARRAY"),
+               (4, "negative suffix length in DELTA_BYTE_ARRAY"), (8, "excess expansion in DELTA_BYTE_ARRAY"),
+               (16, "DELTA_BYTE_ARRAY suffix lengths do not add up to the bytes their page carries"))
+
+
+def expand_delta_byte_array(pages, base: int = 0, offsets_out: torch.Tensor | None = None, device=None):
+    """DELTA_BYTE_ARRAY data pages (DeltaByteArrayDecoderImpl, parquet/decoder.cc:1974-2204) -> offsets + bytes in HBM.
+    `pages`: [(value bytes of the page, number of values)], one column chunk's pages in order.  Host: the two
+    DELTA_BINARY_PACKED header walks per page (prefix lengths; the suffix block's lengths).  Device: both length
+    streams (arx_delta_decode), value lengths + the decoder's checks (arx_delta_byte_array_lengths), the two offset
+    scans (arx_lengths_to_offsets_i32) and the expansion, one wave per page (arx_delta_byte_array_expand).
+    Returns (offsets int32 tensor view of count + 1 entries starting at `base` — written into `offsets_out` when given —,
+    the expanded bytes as a uint8 tensor, count)."""
+    device = torch.device(device) if device is not None else default_device()
+    lib, stream = _lib.get_lib(), current_stream(device)
+    pages = [(bytes(page), count) for page, count in pages if count]
+    # both length streams of every page in ONE launch sequence: [prefix lengths of page 0, 1, ... | suffix lengths of page 0, 1, ...]
+    heads = [page for page, _ in pages]
+    rests = []
+    for page in heads:                      # the suffix block starts where the prefix stream ends
+        _, _, _, _, used = scan_delta_miniblocks(page)
+        rests.append(page[used:])
+    lens, info = decode_delta_streams(heads + rests, 4, device)
+    npages = len(pages)
+    firsts, suffix_starts, suffix_parts = [0], [0], []
+    for (page, count), (ptotal, _), (stotal, sused), rest in zip(pages, info[:npages], info[npages:], rests):
+        if ptotal != count:
+            raise ArrowInvalid(f"Parquet: DELTA_BYTE_ARRAY page holds {ptotal} prefix lengths, its header says {count}")
+        if stotal != count:
+            raise ArrowInvalid(f"Parquet: DELTA_BYTE_ARRAY page holds {stotal} suffix lengths and {count} prefix lengths")
+        suffix_parts.append(rest[sused:])
+        firsts.append(firsts[-1] + count)
+        suffix_starts.append(suffix_starts[-1] + len(rest) - sused)
+    n = firsts[-1]
+    if offsets_out is None:
+        offsets_out = alloc((n + 1) * 4, device)
+    if n == 0:
+        offsets_out.view(torch.int32)[0] = base
+        return offsets_out.view(torch.int32)[:1], alloc(0, device), 0
+    if suffix_starts[-1] > 2**31 - 1:
+        raise ArrowInvalid("Parquet: column chunk exceeds the int32 offset range")
+    prefix, slen = lens[: n * 4], lens[n * 4: 2 * n * 4]
+    d_first = to_device(np.asarray(firsts, dtype=np.int64).view(np.uint8), device)
+    out_len = alloc(n * 4, device)
+    state = alloc(16, device)      # [status bits, bytes of all values]
+    check(lib.arx_delta_byte_array_lengths(prefix.data_ptr(), slen.data_ptr(), n, d_first.data_ptr(), npages, out_len.data_ptr(),
+                                           state.data_ptr(), stream))
+    ws = alloc(lib.arx_delta_decode_workspace_bytes(n + 1), device)
+    soff = alloc((n + 1) * 4, device)
+    check(lib.arx_lengths_to_offsets_i32(slen.data_ptr(), n, 0, soff.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+    check(lib.arx_lengths_to_offsets_i32(out_len.data_ptr(), n, base, offsets_out.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+    total = int(state.view(torch.int64)[1].item())
+    if base + total > 2**31 - 1:
+        raise ArrowInvalid("Parquet: column chunk exceeds the int32 offset range")
+    end = base + total
+    suffix = b"".join(suffix_parts)
+    d_suffix = to_device(np.frombuffer(suffix + b"\0" * (8 + (-len(suffix) % 8)), dtype=np.uint8), device)
+    d_sfirst = to_device(np.asarray(suffix_starts, dtype=np.int64).view(np.uint8), device)
+    out = alloc(max(end - base, 1), device)
+    check(lib.arx_delta_byte_array_expand(prefix.data_ptr(), soff.data_ptr(), d_suffix.data_ptr(), len(suffix), offsets_out.data_ptr(),
+                                          base, d_first.data_ptr(), d_sfirst.data_ptr(), npages, out.data_ptr(), state.data_ptr(),
+                                          stream))
+    bad = int(state.view(torch.int64)[0].item())
+    for bit, text in _DBA_STATUS:
+        if bad & bit:
+            raise ArrowInvalid("Parquet: " + text)
+    return offsets_out.view(torch.int32)[: n + 1], out[: end - base], n
+
+
+def decode_delta_byte_array(pages, atype=None, device=None) -> Array:
+    """The values of DELTA_BYTE_ARRAY pages as one binary (or `atype`) device array — see expand_delta_byte_array."""
+    from .array import binary
+
+    offs, data, n = expand_delta_byte_array(pages, 0, None, device)
+    if data.numel() == 0:
+        data = alloc(1, offs.device)
+    return Array(atype or binary, n, [None, offs.view(torch.uint8), data], 0, 0)
 
 
 def scan_rle_runs(data, bit_width: int, num_values: int, out_base: int = 0, byte_base: int = 0):
@@ -367,6 +477,8 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
                 plain_pos += valid_here * width
         elif enc == _ENC_DELTA_LENGTH_BYTE_ARRAY and is_binary:
             plain_pages.append((bytes(values), valid_here, "delta_length"))
+        elif enc == _ENC_DELTA_BYTE_ARRAY and is_binary:
+            plain_pages.append((bytes(values), valid_here, "delta_byte_array"))
         elif enc == _ENC_BYTE_STREAM_SPLIT and not is_binary and not is_bool:
             if len(values) < valid_here * width:
                 raise ArrowInvalid("Parquet: BYTE_STREAM_SPLIT page shorter than its values")
@@ -541,13 +653,26 @@ def _finish_binary_chunk(lib, stream, device, atype, dict_bytes, dict_count, ind
 
     offs, data = _parse_byte_array_dictionary(dict_bytes or b"", dict_count)
     # ---- the source array: [dictionary entries][entries of every non-dictionary page, in page order]
+    # (DELTA_BYTE_ARRAY pages are expanded on the device: their entries — and bytes — come LAST in the source, whatever
+    #  their place among the pages; the indices say which entry a slot reads)
+    dba_pages = [(page, c) for page, c, kind in plain_pages if kind == "delta_byte_array"]
+    dba_total = sum(c for _, c in dba_pages)
     total_entries = dict_count + sum(2 * c if kind == "plain" else c for _, c, kind in plain_pages)
+    host_entries = total_entries - dba_total
     d_offs = alloc((total_entries + 1) * 4, device)
     d_offs[: (dict_count + 1) * 4] = to_device(offs.view(np.uint8), device)[: (dict_count + 1) * 4]
     data_parts, base, epos = [data], len(data), dict_count
     idx = alloc(max(dense, 1) * 4, device)
     ipos = dense_from_dict                                   # dense slot of the next non-dictionary value
+    dba_epos = host_entries
     for page, count, kind in plain_pages:
+        if kind == "delta_byte_array":
+            if count:
+                seq = torch.arange(dba_epos, dba_epos + count, dtype=torch.int32, device=device)
+                idx[ipos * 4: (ipos + count) * 4] = seq.view(torch.uint8)
+            dba_epos += count
+            ipos += count
+            continue
         if kind == "plain":
             # alternating {4-byte length prefix, value} entries; the values are the odd ones
             o = np.zeros(2 * count + 1, dtype=np.int32)
@@ -582,10 +707,15 @@ def _finish_binary_chunk(lib, stream, device, atype, dict_bytes, dict_count, ind
     if base > 2**31 - 1:
         raise ArrowInvalid("Parquet: column chunk exceeds the int32 offset range")
     if any(kind == "delta_length" for _, _, kind in plain_pages):
-        end = int(d_offs.view(torch.int32)[total_entries].item())
+        end = int(d_offs.view(torch.int32)[host_entries].item())
         if end != base:      # the lengths must add up to the bytes the pages carry
             raise ArrowInvalid(f"Parquet: DELTA_LENGTH_BYTE_ARRAY lengths sum to {end - len(data)}, the pages carry {base - len(data)} bytes")
     d_data = to_device(np.frombuffer(b"".join(data_parts) or b"\0", dtype=np.uint8), device)
+    if dba_total:
+        if host_entries == 0:
+            d_offs.view(torch.int32)[0] = 0
+        _, expanded, _ = expand_delta_byte_array(dba_pages, base, d_offs[host_entries * 4:], device)
+        d_data = torch.cat([d_data[:base], expanded]) if expanded.numel() else d_data
     dvals = Array(atype, total_entries, [None, d_offs, d_data], 0, 0)
     if dense_from_dict:
         runs = np.concatenate(index_runs)

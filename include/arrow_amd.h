@@ -926,6 +926,29 @@ int arx_delta_decode_pages(const void* bytes, const ArxDeltaMiniblock* miniblock
  * out[i] = out[i-1] + lengths[i-1], i in [1, n].  ws: arx_delta_decode_workspace_bytes(n + 1).  Asynchronous. */
 int arx_lengths_to_offsets_i32(const int32_t* lengths, int64_t n, int32_t base, int32_t* out, void* ws,
                                size_t ws_bytes, void* stream);
+/* DELTA_BYTE_ARRAY (DeltaByteArrayDecoderImpl, cpp/src/parquet/decoder.cc:1974-2204): value i = the first prefix[i]
+ * bytes of value i - 1 ++ suffix i, every page starting from the empty string (SetData :1988-2018).  The prefix lengths
+ * are a DELTA_BINARY_PACKED stream and the suffixes a DELTA_LENGTH_BYTE_ARRAY block: arx_delta_decode (width 4) gives
+ * `prefix` and `suffix_len` — the pages of a column chunk one after the other, page p holding values
+ * [page_first[p], page_first[p + 1]) (device array of num_pages + 1 entries).
+ *   _lengths: out_len[i] = prefix[i] + suffix_len[i] and the decoder's checks.  state (device, 2 x uint64, zeroed
+ *             here): state[0] bit 0 "negative prefix length in DELTA_BYTE_ARRAY" (:2096), bit 1 "prefix length too large in
+ *             DELTA_BYTE_ARRAY" (:2039: longer than the previous value; a page's first value: than ""), bit 2 a negative
+ *             suffix length, bit 3 "excess expansion" (:2105: a value past the int32 offsets); state[1] = the bytes all
+ *             values take (64-bit: what the int32 offsets must be able to hold).
+ *   _expand:  suffix_offsets / out_offsets = arx_lengths_to_offsets_i32 of suffix_len (base 0) / out_len (any base;
+ *             out_data[0] is the byte at offset out_base; out_data holds state[1] bytes); suffix_bytes: the pages' suffix
+ *             bytes one after the other, 4-byte aligned and readable up to the next multiple of 4 past suffix_size;
+ *             page_suffix_first (device, num_pages + 1, or NULL): where each page's suffix bytes start — a page whose
+ *             suffix lengths do not add up to that is skipped and ORs bit 4 into state[0] (not zeroed here).  One wave
+ *             walks a page value by value, the lanes copy bytes.  With state[1] within the int32 range it stays inside
+ *             its buffers whatever the lengths say, so state[0] may be read once, after both calls.  Asynchronous. */
+int arx_delta_byte_array_lengths(const int32_t* prefix, const int32_t* suffix_len, int64_t n, const int64_t* page_first,
+                                 int64_t num_pages, int32_t* out_len, uint64_t* state, void* stream);
+int arx_delta_byte_array_expand(const int32_t* prefix, const int32_t* suffix_offsets, const void* suffix_bytes,
+                                int64_t suffix_size, const int32_t* out_offsets, int32_t out_base, const int64_t* page_first,
+                                const int64_t* page_suffix_first, int64_t num_pages, void* out_data, uint64_t* state,
+                                void* stream);
 /* BYTE_STREAM_SPLIT (ByteStreamSplitDecoder, cpp/src/parquet/decoder.cc; arrow/util/byte_stream_split_internal.h):
  * `in` holds byte_width streams of num_values bytes each (stream k = byte k of every value); out[i] is value i.
  * byte_width 2, 4 or 8; `out` aligned to it.  Asynchronous. */

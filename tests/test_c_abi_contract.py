@@ -183,3 +183,38 @@ def test_concatenate_and_delta_argument_checks(emu_ctx):
     assert lib.arx_lengths_to_offsets_i32(lens.data_ptr(), 4, 0, None, ws.data_ptr(), ws.numel(), None) == INVALID
     assert lib.arx_lengths_to_offsets_i32(lens.data_ptr(), 4, 0, offs.data_ptr(), ws.data_ptr(), 0, None) == INVALID
     assert lib.arx_lengths_to_offsets_i32(lens.data_ptr(), -1, 0, offs.data_ptr(), ws.data_ptr(), ws.numel(), None) == INVALID
+    # DELTA_BYTE_ARRAY: ["apple", "apply", "", "b"] then a second page ["x", "xy"]
+    prefix = torch.tensor([0, 4, 0, 0, 0, 1], dtype=torch.int32)
+    slen = torch.tensor([5, 1, 0, 1, 1, 1], dtype=torch.int32)
+    suffix = torch.tensor(list(b"appleybxy") + [0] * 7, dtype=torch.uint8)
+    first = torch.tensor([0, 4, 6], dtype=torch.int64)
+    sfirst = torch.tensor([0, 7, 9], dtype=torch.int64)
+    vlen = torch.zeros(6, dtype=torch.int32)
+    state = torch.zeros(2, dtype=torch.int64)
+    soff, ooff = torch.zeros(7, dtype=torch.int32), torch.zeros(7, dtype=torch.int32)
+    assert lib.arx_delta_byte_array_lengths(prefix.data_ptr(), slen.data_ptr(), 6, first.data_ptr(), 2, vlen.data_ptr(), state.data_ptr(), None) == OK
+    assert vlen.tolist() == [5, 5, 0, 1, 1, 2] and state.tolist() == [0, 14]
+    assert lib.arx_lengths_to_offsets_i32(slen.data_ptr(), 6, 0, soff.data_ptr(), ws.data_ptr(), ws.numel(), None) == OK
+    assert lib.arx_lengths_to_offsets_i32(vlen.data_ptr(), 6, 100, ooff.data_ptr(), ws.data_ptr(), ws.numel(), None) == OK
+    data = torch.zeros(16, dtype=torch.uint8)
+    assert lib.arx_delta_byte_array_expand(prefix.data_ptr(), soff.data_ptr(), suffix.data_ptr(), 9, ooff.data_ptr(), 100, first.data_ptr(),
+                                           sfirst.data_ptr(), 2, data.data_ptr(), state.data_ptr(), None) == OK
+    assert bytes(data[:14].tolist()) == b"appleapplybxxy" and state[0].item() == 0
+    sfirst[1] = 6                                              # the first page's suffix lengths add up to 7, not 6: both pages are off
+    assert lib.arx_delta_byte_array_expand(prefix.data_ptr(), soff.data_ptr(), suffix.data_ptr(), 9, ooff.data_ptr(), 100, first.data_ptr(),
+                                           sfirst.data_ptr(), 2, data.data_ptr(), state.data_ptr(), None) == OK
+    assert state[0].item() == 16
+    prefix[4] = 1                                              # a page's first value has nothing before it
+    assert lib.arx_delta_byte_array_lengths(prefix.data_ptr(), slen.data_ptr(), 6, first.data_ptr(), 2, vlen.data_ptr(), state.data_ptr(), None) == OK
+    assert state[0].item() == 2
+    prefix[4], prefix[1] = 0, -1
+    assert lib.arx_delta_byte_array_lengths(prefix.data_ptr(), slen.data_ptr(), 6, first.data_ptr(), 2, vlen.data_ptr(), state.data_ptr(), None) == OK
+    assert state[0].item() == 1
+    assert lib.arx_delta_byte_array_lengths(None, None, 0, None, 0, None, state.data_ptr(), None) == OK and state.tolist() == [0, 0]
+    assert lib.arx_delta_byte_array_lengths(prefix.data_ptr(), slen.data_ptr(), 6, first.data_ptr(), 2, vlen.data_ptr(), None, None) == INVALID
+    assert lib.arx_delta_byte_array_lengths(prefix.data_ptr(), slen.data_ptr(), 6, None, 2, vlen.data_ptr(), state.data_ptr(), None) == INVALID
+    assert lib.arx_delta_byte_array_expand(None, None, None, 0, None, 0, None, None, 0, None, None, None) == OK
+    assert lib.arx_delta_byte_array_expand(prefix.data_ptr(), soff.data_ptr(), suffix.data_ptr() + 1, 8, ooff.data_ptr(), 100, first.data_ptr(),
+                                           None, 2, data.data_ptr(), None, None) == INVALID                   # misaligned suffix bytes
+    assert lib.arx_delta_byte_array_expand(prefix.data_ptr(), soff.data_ptr(), suffix.data_ptr(), 9, ooff.data_ptr(), 100, first.data_ptr(),
+                                           sfirst.data_ptr(), 2, data.data_ptr(), None, None) == INVALID      # a check without a state word

@@ -2037,6 +2037,27 @@ PARQUET_ENCODINGS_SCRIPT = textwrap.dedent(r'''
                 h = to_host(read_column(path, rg, ci))
                 w = ref.column(name).combine_chunks()
                 assert h.equals(w) and h.null_count == w.null_count, ("delta_length", null_p, rg, name)
+        # DELTA_BYTE_ARRAY (DeltaByteArrayDecoderImpl): sorted keys with long shared prefixes, repeats and shrinking values,
+        # values longer than the kernel's 8 KB LDS window; many small pages (every page starts from the empty string)
+        long_ = bytes(rng.integers(97, 123, 20000, dtype=np.uint8))
+        bt = pa.table({"sorted": pa.array(sorted("key/%08d/%s" % (int(k), "x" * int(k % 7)) for k in rng.integers(0, 10 * n, n)),
+                                          type=pa.string(), mask=m(null_p)),
+                       "mixed": pa.array([[b"", b"a", b"ab", b"abc" * 11, b"abc" * 11 + b"d"][int(i)] for i in rng.integers(0, 5, n)],
+                                         type=pa.binary(), mask=m(null_p)),
+                       "long": pa.array([long_[: int(k)] + bytes([65 + int(k) % 26])
+                                         for k in rng.choice([10, 8191, 8192, 8193, 19999], n, p=[0.96, 0.01, 0.01, 0.01, 0.01])], type=pa.binary())})
+        for variant in (dict(compression="snappy", data_page_size=16384), dict(compression="none", data_page_version="2.0", data_page_size=4096)):
+            path = os.path.join(tempfile.mkdtemp(), "dba.parquet")
+            pq.write_table(bt, path, row_group_size=n // 2 + 11, use_dictionary=False,
+                           column_encoding={name: "DELTA_BYTE_ARRAY" for name in bt.schema.names}, **variant)
+            pf = pq.ParquetFile(path)
+            for rg in range(pf.metadata.num_row_groups):
+                ref = pf.read_row_group(rg)
+                for ci, name in enumerate(bt.schema.names):
+                    assert "DELTA_BYTE_ARRAY" in pf.metadata.row_group(rg).column(ci).encodings
+                    h = to_host(read_column(path, rg, ci))
+                    w = ref.column(name).combine_chunks()
+                    assert h.equals(w) and h.null_count == w.null_count, ("delta_byte_array", variant, null_p, rg, name)
         # BYTE_STREAM_SPLIT floating-point and integer columns
         st = pa.table({"f32": pa.array(rng.standard_normal(n).astype(np.float32), mask=m(null_p)),
                        "f64": pa.array(rng.standard_normal(n) * 1e100, mask=m(null_p)),

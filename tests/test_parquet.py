@@ -573,6 +573,119 @@ def test_parquet_delta_length_byte_array_emulator(emu_ctx, tmp_path, n, kw, null
 
 
 
+# ---- DELTA_BYTE_ARRAY (DeltaByteArrayDecoderImpl, parquet/decoder.cc:1974-2204)
+def _dba_words(rng, n, kind):
+    if kind == "sorted":          # what the encoding is for: sorted keys sharing long prefixes
+        return sorted(("key/%08d/%s" % (int(k), "x" * int(k % 7))).encode() for k in rng.integers(0, 10 * max(n, 1), n))
+    if kind == "random":          # no shared prefixes at all, empty values in between
+        return [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) if k else b"" for k in rng.integers(0, 40, n)]
+    if kind == "repeat":          # whole values repeated (prefix = the whole previous value, empty suffix), and shrinking
+        base = [b"", b"a", b"ab", b"abc", b"abcd" * 9, b"abcd" * 9 + b"e"]
+        return [base[int(i)] for i in rng.integers(0, len(base), n)]
+    long_ = bytes(rng.integers(97, 123, 20000, dtype=np.uint8))      # values longer than the kernel's 8 KB LDS window
+    return [long_[: int(k)] + bytes([65 + int(k) % 26]) for k in rng.choice([10, 5000, 8191, 8192, 8193, 12000, 19999], n)]
+
+
+def _dba_pages(path, column):
+    """(value bytes, number of non-null values) of every DELTA_BYTE_ARRAY data page of row group 0 (required columns)."""
+    from arrow_amd import parquet as P
+
+    col = pq.ParquetFile(path).metadata.row_group(0).column(column)
+    raw = open(path, "rb").read()
+    pages = []
+    for hdr, payload in P._column_chunk_pages(raw, col):
+        if hdr[1] == P._PAGE_DATA:
+            assert hdr[5][2] == P._ENC_DELTA_BYTE_ARRAY
+            pages.append((bytes(P._decompress(col.compression, payload, hdr[2])), hdr[5][1]))
+    return pages
+
+
+def test_delta_byte_array_oracle_pinned_to_the_reference_writer(tmp_path):
+    """The restatement decodes the pages the reference's DeltaByteArrayEncoder wrote to pyarrow's own values (every page
+    starts from the empty string), and refuses what the reference's decoder refuses."""
+    rng = np.random.default_rng(5)
+    n = 4000
+    cols = {k: _dba_words(rng, n, k) for k in ("sorted", "random", "repeat")}
+    cols["long"] = _dba_words(rng, 40, "long") * 100
+    path = os.path.join(str(tmp_path), "pin.parquet")
+    schema = pa.schema([pa.field(k, pa.binary(), nullable=False) for k in cols])
+    pq.write_table(pa.table({k: pa.array(v, pa.binary()) for k, v in cols.items()}).cast(schema), path, use_dictionary=False,
+                   compression="none", column_encoding={k: "DELTA_BYTE_ARRAY" for k in cols}, data_page_size=4096)
+    for ci, (name, want) in enumerate(cols.items()):
+        pages = _dba_pages(path, ci)
+        assert len(pages) > 1, name
+        got = []
+        for page, count in pages:
+            vals = O.delta_byte_array_decode(page)
+            assert len(vals) == count
+            got += vals
+        assert got == want, name
+    page = O.delta_byte_array_encode([b"abc", b"abd"])
+    assert O.delta_byte_array_decode(page) == [b"abc", b"abd"]
+    bad = O.delta_binary_packed_encode(np.array([1, 0], dtype=np.int64)) + O.delta_binary_packed_encode(np.array([2, 1], dtype=np.int64)) + b"xyz"
+    with pytest.raises(ValueError, match="prefix length too large"):      # the first value of a page has nothing before it
+        O.delta_byte_array_decode(bad)
+    bad = O.delta_binary_packed_encode(np.array([0, -1], dtype=np.int64)) + O.delta_binary_packed_encode(np.array([2, 1], dtype=np.int64)) + b"xyz"
+    with pytest.raises(ValueError, match="negative prefix length"):
+        O.delta_byte_array_decode(bad)
+
+
+def _check_dba_kernels(amd):
+    """arx_delta_byte_array_lengths / _expand (through arrow_amd.parquet.decode_delta_byte_array) against the restatement:
+    several pages in one launch, counts around the 64-value groups, values around the 8 KB LDS window, suffix groups
+    larger than the staging buffer, block shapes the reference writer never produces — and the decoder's errors."""
+    from arrow_amd import _lib
+
+    rng = np.random.default_rng(17)
+    for kind, counts, shape in (("sorted", (1, 63, 64, 65, 129, 1000), (128, 4)), ("random", (2, 64, 300), (256, 8)),
+                                ("repeat", (5, 128, 777), (128, 1)), ("long", (3, 70), (128, 4))):
+        pages, want = [], []
+        for c in counts:
+            vals = _dba_words(rng, c, kind)
+            pages.append((O.delta_byte_array_encode(vals, *shape), c))
+            assert O.delta_byte_array_decode(pages[-1][0]) == vals
+            want += vals
+        pages.insert(1, (b"", 0))                       # a page without values (all nulls) carries nothing
+        arr = amd.parquet.decode_delta_byte_array(pages)
+        assert arr.to_pyarrow().to_pylist() == want, kind
+    two = lambda p, s, tail: (O.delta_binary_packed_encode(np.array(p, dtype=np.int64)) +
+                              O.delta_binary_packed_encode(np.array(s, dtype=np.int64)) + tail)
+    for page, text in ((two([1, 0], [2, 1], b"xyz"), "prefix length too large"), (two([0, 3], [2, 1], b"xyz"), "prefix length too large"),
+                       (two([0, -1], [2, 1], b"xyz"), "negative prefix length"), (two([0, 1], [2, 5], b"xyz"), "do not add up")):
+        with pytest.raises(_lib.ArrowInvalid, match=text):
+            amd.parquet.decode_delta_byte_array([(O.delta_byte_array_encode([b"ok", b"okay"]), 2), (page, 2)])
+
+
+@pytest.mark.emu
+def test_delta_byte_array_kernels_vs_restatement(emu_ctx):
+    _check_dba_kernels(emu_ctx)
+
+
+def _write_dba_and_check(amd, tmp_path, n, null_p, seed, **kw):
+    rng = np.random.default_rng(seed)
+    mask = (lambda: rng.random(n) < null_p) if null_p else (lambda: None)
+    t = pa.table({"sorted": pa.array([w.decode() for w in _dba_words(rng, n, "sorted")], pa.string(), mask=mask()),
+                  "random": pa.array(_dba_words(rng, n, "random"), pa.binary(), mask=mask()),
+                  "repeat": pa.array([w.decode() for w in _dba_words(rng, n, "repeat")], pa.string(), mask=mask()),
+                  "long": pa.array((_dba_words(rng, 7, "long") * (n // 7 + 1))[:n], pa.binary(), mask=mask())})
+    path = os.path.join(tmp_path, "dba.parquet")
+    pq.write_table(t, path, use_dictionary=False, column_encoding={name: "DELTA_BYTE_ARRAY" for name in t.schema.names},
+                   row_group_size=max(1, n // 2 + 7), **kw)
+    md = pq.ParquetFile(path).metadata
+    assert all("DELTA_BYTE_ARRAY" in md.row_group(0).column(i).encodings for i in range(md.num_columns))
+    check_file(amd, path)
+
+
+@pytest.mark.emu
+@pytest.mark.parametrize("null_p", [0.0, 0.2])
+@pytest.mark.parametrize("n,kw", [(3000, dict(data_page_size=2048, compression="snappy")), (1, {}), (65, {}),
+                                  (2049, dict(data_page_version="2.0", compression="none"))])
+def test_parquet_delta_byte_array_emulator(emu_ctx, tmp_path, n, kw, null_p):
+    """DELTA_BYTE_ARRAY column chunks (DeltaByteArrayDecoderImpl) end to end: sorted keys with long shared prefixes, values
+    without any, repeated values, values longer than the LDS window; utf8 and binary, many small pages, V1 / V2, nulls."""
+    _write_dba_and_check(emu_ctx, str(tmp_path), n, null_p, 91 + n, **kw)
+
+
 def _delta_page_bytes(path, column):
     """The value bytes of every DELTA_BINARY_PACKED data page of one column chunk, read with this package's page walk."""
     from arrow_amd import parquet as P
@@ -986,3 +1099,15 @@ def test_delta_decode_kernel_vs_restatement_gpu(gpu_ctx):
 def test_parquet_delta_binary_packed_gpu(gpu_ctx, tmp_path, null_p):
     _write_delta_and_check(gpu_ctx, str(tmp_path), 600_000, null_p, 77, compression="snappy")
     _write_delta_and_check(gpu_ctx, str(tmp_path), 70_001, null_p, 78, data_page_version="2.0", data_page_size=8192)
+
+
+@pytest.mark.gpu
+def test_delta_byte_array_kernels_vs_restatement_gpu(gpu_ctx):
+    _check_dba_kernels(gpu_ctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("null_p", [0.0, 0.1])
+def test_parquet_delta_byte_array_gpu(gpu_ctx, tmp_path, null_p):
+    _write_dba_and_check(gpu_ctx, str(tmp_path), 200_000, null_p, 93, compression="snappy")
+    _write_dba_and_check(gpu_ctx, str(tmp_path), 30_001, null_p, 94, data_page_version="2.0", data_page_size=8192)
