@@ -712,6 +712,8 @@ def run_other_paths(amd, device, args):
     """Single-GPU numbers for the other rows of SURVEY.md section 8 (not `value`): config 3 at its stated size
     with the survey's value mix, the secondary configurations of 8(d), and the same calls through the Arrow
     plugin (CallFunction on device-resident pyarrow arrays)."""
+    from arrow_amd import tracing
+
     out = {}
     n = args.stream_rows
     # ---- config 3a: cast(float64 -> float32), survey mix (overflow -> inf, float32 subnormals, NaN, +-0)
@@ -750,22 +752,39 @@ def run_other_paths(amd, device, args):
     di = amd.Array(amd.array.uint32, m_rand, [None, ridx.view(torch.uint8)], 0, 0)
     sec = {}
 
-    def t(name, fn, bytes_alg):
+    def t(name, fn, bytes_alg, span=None):
+        """`ms` / `roofline_frac`: the whole operation (count + read-back + allocation + the kernel), as a caller sees it;
+        `kernel_ms` / `kernel_roofline_frac` (span given): the dominant kernel alone between HIP events on its stream, the
+        way the headline's `roofline` is taken — the difference is the operation's fixed cost, not bandwidth."""
         ms_ = _time_gpu(fn, reps=5, warm=2)
         sec[name] = {"ms": round(ms_, 4), "algorithmic_GBps": round(bytes_alg / ms_ / 1e6, 1),
                      "roofline_frac": round(bytes_alg / ms_ / 1e6 / HBM_PEAK_GBS, 4)}
+        if span is not None and not EMU:
+            timer = tracing.KernelTimer(device)
+            tracing.install(timer)
+            try:
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                spans = timer.elapsed_ms(span)
+            finally:
+                tracing.install(None)
+            if spans:
+                k = sum(spans) / len(spans)
+                sec[name].update({"kernel": span, "kernel_ms": round(k, 4),
+                                  "kernel_roofline_frac": round(bytes_alg / k / 1e6 / HBM_PEAK_GBS, 4)})
 
-    t("filter_drop_5pct_mask_nulls", lambda: amd.compute.filter(dv, dmn), 8 * n + 3 * n / 8 + 8.125 * 0.95 * S)
+    t("filter_drop_5pct_mask_nulls", lambda: amd.compute.filter(dv, dmn), 8 * n + 3 * n / 8 + 8.125 * 0.95 * S, "arx_filter_exec")
     t("filter_emit_null_5pct_mask_nulls", lambda: amd.compute.filter(dv, dmn, "emit_null"),
-      8 * n + 3 * n / 8 + 8.125 * (0.95 * S + 0.05 * n))
+      8 * n + 3 * n / 8 + 8.125 * (0.95 * S + 0.05 * n), "arx_filter_exec")
     t("take_monotonic_boundscheck", lambda: amd.compute.take(dv, mono, boundscheck=True), 20.25 * S)
-    t("take_random_uint32", lambda: amd.compute.take(dv, di, boundscheck=False), 20.25 * m_rand)
+    t("take_random_uint32", lambda: amd.compute.take(dv, di, boundscheck=False), 20.25 * m_rand, "arx_take")
     for sel in (0.25, 0.50):
         _, _, msel, _ = gen_filter_inputs(n, device, 0, args.null_p, sel)
         dms = amd.Array(amd.array.bool_, n, [None, msel], 0, 0)
         ssel = amd.compute.filter(dv, dms).length
         t(f"filter_drop_selectivity_{int(sel * 100)}pct", lambda: amd.compute.filter(dv, dms),
-          8 * n + n / 4 + 8.125 * ssel)
+          8 * n + n / 4 + 8.125 * ssel, "arx_filter_exec")
         del msel, dms
     # take of a 4-column record batch by the monotonic indices (TakeRAR): one launch for all columns
     # (arx_take_columns) vs array_take column after column; 3 more value columns of their own (distinct HBM lines)
