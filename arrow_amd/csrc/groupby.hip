@@ -904,7 +904,7 @@ struct GbpArgs {
   unsigned int* dense_null_seen;
   int wide;                // 1 = the wide one-level form: b1 == 0, b2 == bits <= 11, 12-byte records in `recs`
   uint32_t room;           // != 0: the wide form WITHOUT a histogram pass — partition p owns records [p * room, (p + 1) * room)
-  int stripe_lg;           // != 0 (rooms only): record `off` of partition p lives at ((off >> lg) << (bits + lg)) + (p << lg) + (off & (2^lg - 1)) — see gbp_rec_phys
+  uint32_t stripe;         // != 0 (rooms only): chunks of `stripe` records — record `off` of partition p lives at ((off / stripe) * 2^bits + p) * stripe + off % stripe, see gbp_rec_phys
   uint32_t* part_end;      // [2^bits] one past a partition's last record (part_start[p + 1] with exact counts)
   uint32_t* overflow;      // set by the wide scatter when a partition outgrows its room
   uint8_t* recs;           // [n] {key u32, value lo, value hi}
@@ -923,15 +923,15 @@ __device__ __forceinline__ int32_t gbp_unhash(const GbpArgs& a, uint32_t h) {
 // STRIPED rooms.  The flat scatter appends to 2^bits rooms that lie room * 12 bytes (24 MB at 4e9 rows) apart: every
 // (tile, bin) run is in another translation of the per-CU TLB — 31 % of the kernel's UTCL1 requests miss (8e8 misses
 // for 4e9 rows; a streaming copy: 7e4), while its DRAM credit stalls per ms are a quarter of the copy's
-// (profiles/r04_w_*): the pass waits for address translation, not for memory.  With stripes, chunk c (2^lg records) of
-// EVERY room lies in the same 2^(bits + lg) records (6 MB): distinct keys fill the rooms in step, so all frontiers of
+// (profiles/r04_w_*): the pass waits for address translation, not for memory.  With stripes, chunk c (`stripe` records) of
+// EVERY room lies in the same 2^bits * stripe records (6 MB at 256): distinct keys fill the rooms in step, so all frontiers of
 // the moment share a few translations.  Logical record numbers (p * room + off) stay what cursors, counts and work
 // units are kept in; only the two kernels that touch `recs` map them.
 __device__ __forceinline__ int64_t gbp_rec_phys(const GbpArgs& a, uint32_t part, uint32_t logical) {
-  if (a.stripe_lg == 0) return logical;
+  if (a.stripe == 0) return logical;
   const uint32_t off = logical - part * a.room;
-  return (static_cast<int64_t>(off >> a.stripe_lg) << (a.bits + a.stripe_lg)) + (static_cast<int64_t>(part) << a.stripe_lg) +
-         (off & ((1u << a.stripe_lg) - 1u));
+  const uint32_t chunk = off / a.stripe;
+  return ((static_cast<int64_t>(chunk) << a.bits) + part) * a.stripe + (off - chunk * a.stripe);
 }
 
 template <bool HAS_NULLS>
@@ -1760,7 +1760,7 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
         const int64_t r0 = lo + ((it0 / 4 + g) * THREADS + tid) * 4;
         // striped rooms: the thread's own aligned quad — it never crosses a chunk, and what it reads past `hi` is still
         // inside the chunk (rooms are whole chunks); a thread with nothing left re-reads the unit's first quad
-        const int64_t ws = a.stripe_lg != 0 ? gbp_rec_phys(a, q, static_cast<uint32_t>(r0 < hi ? r0 : lo)) : (r0 + 4 <= hi ? r0 : hi4);
+        const int64_t ws = a.stripe != 0 ? gbp_rec_phys(a, q, static_cast<uint32_t>(r0 < hi ? r0 : lo)) : (r0 + 4 <= hi ? r0 : hi4);
         const RecQuad* rq = reinterpret_cast<const RecQuad*>(reinterpret_cast<const GbpRec*>(a.recs) + ws);
         raw[g][0] = rq[0];
         raw[g][1] = rq[1];
@@ -1779,7 +1779,7 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
           d[4 + e] = raw[g][1][e];
           d[8 + e] = raw[g][2][e];
         }
-        const int shift = (a.stripe_lg != 0 || r0 + 4 <= hi) ? 0 : static_cast<int>(r0 - hi4);   // 1 .. 3 behind the partition's last whole quad
+        const int shift = (a.stripe != 0 || r0 + 4 <= hi) ? 0 : static_cast<int>(r0 - hi4);   // 1 .. 3 behind the partition's last whole quad
         for (int k = 0; k < shift; ++k) {
 #pragma unroll
           for (int e = 0; e < 9; ++e) d[e] = d[e + 3];
@@ -1884,7 +1884,7 @@ struct GbpPlan {
   int bits, b1, b2;
   int wide;                 // the wide one-level form (b1 == 0, b2 == bits)
   uint32_t room;            // wide form: records every partition's room holds (see gbp_room_for)
-  int stripe_lg;            // rooms laid out in stripes of 2^stripe_lg records per partition (gbp_rec_phys); 0 = room after room
+  uint32_t stripe;          // rooms laid out in stripes of `stripe` records per partition (gbp_rec_phys); 0 = room after room
   int64_t slice_rows, chunk_rows, nchunks;
   size_t off_keys_a, off_vals_a, off_keys_b, off_vals_b, off_part_count, off_part_start,
       off_cursor2, off_cursor1, off_hist1, off_l1_start, off_l2_tile_start, off_agg_unit_start, off_part_end, off_overflow, total;
@@ -1899,7 +1899,7 @@ static Knob<int> g_gbp_chunks{2048};       // level-1 chunks = workgroups of the
 static Knob<int> g_gbp_wide_max_bits{kGbWideMaxBits};   // bins of the flat level the planner may ask for (A/B knob groupby_wide_max_bits; tests lower it)
 static Knob<int> g_gbp_room_min_mean{1 << 14};   // rooms only for partitions of at least this many rows on average (knob groupby_wide_room_min_mean; tests lower it)
 static Knob<int> g_gbp_sketch{1};          // the group count from a HyperLogLog sketch of the first groupby_probe_rows keys (0: round 3's probe slice on the two-level plan; A/B knob groupby_sketch)
-static Knob<int> g_gbp_stripe_lg{0};       // rooms in stripes of 2^lg records (A/B knob groupby_stripe_lg; 0 = off, else 2 .. 16)
+static Knob<int> g_gbp_stripe{0};          // rooms in stripes of this many records, a multiple of 4 (A/B knob groupby_stripe; 0 = off)
 static Knob<int> g_gbp_wide_rooms{1};      // the wide form without its histogram pass: fixed rooms per partition (A/B knob groupby_wide_rooms)
 static Knob<int> g_gbp_wide{1};            // the wide one-level form where the group estimate allows it (A/B knob groupby_wide)
 static Knob<int> g_gbp_wide_agg_chunk{1 << 21};   // rows per aggregate work unit of the wide form (A/B knob groupby_wide_agg_chunk_rows)
@@ -1932,13 +1932,13 @@ static int gbp_wide_bits_for(int64_t groups) {
 
 // Records a partition's room holds when the wide form runs without a histogram: the mean + 6 sigma of the binomial a
 // bijective hash of DISTINCT keys gives, + 64.  Only worth it when the slack is small (mean >= 2^14: <= 5 %).
-static uint32_t gbp_room_for(int64_t rows, int bits, int stripe_lg) {
+static uint32_t gbp_room_for(int64_t rows, int bits, int64_t stripe) {
   const int64_t mean = (rows + (int64_t(1) << bits) - 1) >> bits;
   if (mean < g_gbp_room_min_mean) return 0;
   int64_t sd = 1;
   while (sd * sd < mean) ++sd;
   int64_t room = mean + 6 * sd + 64;
-  if (stripe_lg > 0) room = ((room >> stripe_lg) + 1) << stripe_lg;   // whole chunks (the aggregate over-reads inside a chunk)
+  if (stripe > 0) room = (room / stripe + 1) * stripe;   // whole chunks (the aggregate over-reads inside a chunk)
   return (room << bits) < (int64_t(1) << 32) ? static_cast<uint32_t>(room) : 0;
 }
 
@@ -1993,9 +1993,9 @@ static GbpPlan gbp_plan(int64_t slice_rows, int64_t capacity, int64_t groups_hin
   // rooms need keys that spread like distinct hashed keys: the keyed table, never the dense ids of the hash_sum vtable
   // (id << shift puts all rows of the low ids into the low partitions)
   if (p.wide && g_gbp_wide_rooms && allow_rooms && dense_idbits == 0) {
-    const int lg = g_gbp_stripe_lg;
-    p.room = gbp_room_for(slice_rows, p.bits, lg);
-    p.stripe_lg = p.room != 0 ? lg : 0;
+    const int stripe = g_gbp_stripe;
+    p.room = gbp_room_for(slice_rows, p.bits, stripe);
+    p.stripe = p.room != 0 ? static_cast<uint32_t>(stripe) : 0u;
   }
   if (p.wide) {
     const size_t recs = p.room ? (static_cast<size_t>(p.room) << p.bits) : n;
@@ -2045,7 +2045,7 @@ static void gbp_bind(GbpArgs& a, const GbpPlan& plan, uint8_t* w) {
   a.part_end = reinterpret_cast<uint32_t*>(w + plan.off_part_end);
   a.overflow = reinterpret_cast<uint32_t*>(w + plan.off_overflow);
   a.room = plan.room;
-  a.stripe_lg = plan.room != 0 ? plan.stripe_lg : 0;
+  a.stripe = plan.room != 0 ? plan.stripe : 0u;
   a.agg_pipe = g_gbp_agg_pipe;
   a.xcd_map = g_gbp_xcd_map;
   a.agg_chunk = static_cast<uint32_t>(plan.wide ? g_gbp_wide_agg_chunk : g_gbp_agg_chunk);
@@ -2260,8 +2260,8 @@ int set_groupby_option(const char* name, int64_t value) {
     g_gbp_sketch = value != 0;
     return 1;
   }
-  if (strcmp(name, "groupby_stripe_lg") == 0) {
-    g_gbp_stripe_lg = value <= 0 ? 0 : static_cast<int>(std::max<int64_t>(2, std::min<int64_t>(value, 16)));
+  if (strcmp(name, "groupby_stripe") == 0) {
+    g_gbp_stripe = value <= 0 ? 0 : static_cast<int>(std::max<int64_t>(4, std::min<int64_t>(value & ~int64_t(3), 1 << 20)));
     return 1;
   }
   if (strcmp(name, "groupby_wide_rooms") == 0) {

@@ -494,18 +494,18 @@ def test_groupby_wide_one_level_form(gpu_ctx, bits):
             lib.arx_set_option(k_, v_)
 
 
-GROUPBY_STRIPE_LG_DEFAULT = 0   # arrow_amd/csrc/groupby.hip g_gbp_stripe_lg
+GROUPBY_STRIPE_DEFAULT = 0   # arrow_amd/csrc/groupby.hip g_gbp_stripe
 
 
-@pytest.mark.parametrize("stripe_lg", [0, 8])
+@pytest.mark.parametrize("stripe", [0, 276])
 @pytest.mark.parametrize("hot", [False, True])
-def test_groupby_wide_form_without_histogram(gpu_ctx, hot, stripe_lg):
+def test_groupby_wide_form_without_histogram(gpu_ctx, hot, stripe):
     """The wide plan with fixed rooms instead of a histogram pass: evenly spread keys fit their rooms (no overflow);
     a few hot keys outgrow one room — the slice is redone with counted partitions (null rows are not consumed twice)
     and the call's later slices stay on the counted plan.  Results exact either way — and whether the rooms lie one after
-    the other or in stripes of 2^stripe_lg records (groupby_stripe_lg)."""
+    the other or in stripes of `stripe` records (groupby_stripe)."""
     lib = gpu_ctx._lib.get_lib()
-    opts = {b"groupby_partition_min_rows": 0, b"groupby_wide": 2, b"groupby_partition_bits": 11, b"groupby_wide_room_min_mean": 16, b"groupby_stripe_lg": stripe_lg,
+    opts = {b"groupby_partition_min_rows": 0, b"groupby_wide": 2, b"groupby_partition_bits": 11, b"groupby_wide_room_min_mean": 16, b"groupby_stripe": stripe,
             b"groupby_wide_max_slice_rows": 2457600}
     for k_, v_ in opts.items():
         assert lib.arx_set_option(k_, v_) == 0
@@ -522,7 +522,7 @@ def test_groupby_wide_form_without_histogram(gpu_ctx, hot, stripe_lg):
     finally:
         for k_, v_ in {b"groupby_partition_min_rows": 1 << 17, b"groupby_wide": 1, b"groupby_partition_bits": -1,
                        b"groupby_wide_room_min_mean": 1 << 14, b"groupby_wide_max_slice_rows": (1 << 32) - (1 << 26),
-                       b"groupby_stripe_lg": GROUPBY_STRIPE_LG_DEFAULT}.items():
+                       b"groupby_stripe": GROUPBY_STRIPE_DEFAULT}.items():
             lib.arx_set_option(k_, v_)
     rooms, overflows = (lib.arx_get_counter(c) - b for c, b in zip(names, before))
     assert rooms >= 1, "the plan without a histogram did not run"
