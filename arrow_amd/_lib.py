@@ -111,6 +111,7 @@ SIGNATURES = {
     "arx_take_workspace_bytes": (_sz, []),
     "arx_check_index_bounds": (_int, [_span, _int, _u64, _p, _sz, _p]),
     "arx_take": (_int, [_span, _int, _span, _int, _p, _p, _p, _p]),
+    "arx_take_rows": (_int, [_span, _i64, _span, _int, _p, _p, _p, _p]),
     "arx_take_bits": (_int, [_span, _span, _int, _p, _p, _p, _p]),
     "arx_binary_take_workspace_bytes": (_sz, [_i64]),
     "arx_binary_take_offsets": (_int, [_bspan, _span, _int, _p, _sz, _p, _p, _p, C.POINTER(_i64), _p]),
@@ -118,6 +119,8 @@ SIGNATURES = {
     "arx_large_binary_take_workspace_bytes": (_sz, [_i64]),
     "arx_large_binary_take_offsets": (_int, [_bspan, _span, _int, _p, _sz, _p, _p, _p, C.POINTER(_i64), _p]),
     "arx_large_binary_take_data": (_int, [_bspan, _i64, _p, _sz, _p, _i64, _p, _p]),
+    "arx_list_take_data": (_int, [_bspan, _int, _i64, _p, _sz, _p, _i64, _p, _p]),
+    "arx_large_list_take_data": (_int, [_bspan, _int, _i64, _p, _sz, _p, _i64, _p, _p]),
     "arx_plain_byte_array_offsets": (_int, [_p, _sz, _i64, C.c_int32, _p]),
     "arx_rle_scan_runs": (_int, [_p, _sz, _int, _i64, _u32, _u64, _p, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "arx_rle_decode_u32": (_int, [_p, _sz, _p, _i64, _int, _i64, _p, _p]),

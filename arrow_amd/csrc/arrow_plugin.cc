@@ -82,6 +82,7 @@ namespace {
 #include "plugin/common.inc"
 #include "plugin/device.inc"
 #include "plugin/selection.inc"
+#include "plugin/selection_nested.inc"
 #include "plugin/selection_meta.inc"
 #include "plugin/scalar.inc"
 #include "plugin/sort.inc"

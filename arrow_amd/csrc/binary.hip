@@ -196,13 +196,15 @@ __global__ __launch_bounds__(kBlock) void bin_offsets_kernel(O* __restrict__ out
 constexpr int kBinChunk = 16384;   // output bytes per workgroup
 constexpr int kBinBatch = 2048;    // rows staged per pass
 
+// (SHIFT: the entries are list offsets in ELEMENTS of 2^SHIFT bytes — a list whose values are fixed-width and free of nulls
+//  is a binary array with offsets scaled by the element width; 0 for utf8 / binary.  Positions below are bytes.)
 template <typename O>
-__device__ __forceinline__ int64_t bin_row_of(const O* __restrict__ out_offsets, int64_t m, int64_t pos) {
+__device__ __forceinline__ int64_t bin_row_of(const O* __restrict__ out_offsets, int64_t m, int64_t pos, int shift) {
   // largest r in [0, m) with out_offsets[r] <= pos  (pos < out_offsets[m])
   int64_t lo = 0, hi = m;  // invariant: out_offsets[lo] <= pos < out_offsets[hi]
   while (hi - lo > 1) {
     const int64_t mid = (lo + hi) >> 1;
-    if (out_offsets[mid] <= pos) lo = mid; else hi = mid;
+    if ((static_cast<int64_t>(out_offsets[mid]) << shift) <= pos) lo = mid; else hi = mid;
   }
   return lo;
 }
@@ -211,19 +213,19 @@ template <typename O>
 __global__ __launch_bounds__(kBlock) void bin_copy_kernel(const uint8_t* __restrict__ data,
                                                           const O* __restrict__ src_start,
                                                           const O* __restrict__ out_offsets, int64_t m,
-                                                          int64_t total, uint8_t* __restrict__ out_data) {
-  __shared__ O s_out[kBinBatch + 1];
-  __shared__ O s_src[kBinBatch];
+                                                          int64_t total, uint8_t* __restrict__ out_data, int shift) {
+  __shared__ int64_t s_out[kBinBatch + 1];
+  __shared__ int64_t s_src[kBinBatch];
   const int tid = threadIdx.x;
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kBinChunk;
   const int64_t b1 = b0 + kBinChunk < total ? b0 + kBinChunk : total;
-  const int64_t rlo = bin_row_of<O>(out_offsets, m, b0);
-  const int64_t rhi = bin_row_of<O>(out_offsets, m, b1 - 1);
+  const int64_t rlo = bin_row_of<O>(out_offsets, m, b0, shift);
+  const int64_t rhi = bin_row_of<O>(out_offsets, m, b1 - 1, shift);
   for (int64_t rb = rlo; rb <= rhi; rb += kBinBatch) {
     const int nb = static_cast<int>(rhi + 1 - rb < kBinBatch ? rhi + 1 - rb : kBinBatch);
     __syncthreads();
-    for (int k = tid; k <= nb; k += kBlock) s_out[k] = out_offsets[rb + k];
-    for (int k = tid; k < nb; k += kBlock) s_src[k] = src_start[rb + k];
+    for (int k = tid; k <= nb; k += kBlock) s_out[k] = static_cast<int64_t>(out_offsets[rb + k]) << shift;
+    for (int k = tid; k < nb; k += kBlock) s_src[k] = static_cast<int64_t>(src_start[rb + k]) << shift;
     __syncthreads();
     const int64_t lo = s_out[0] > b0 ? s_out[0] : b0;
     const int64_t hi = s_out[nb] < b1 ? s_out[nb] : b1;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void bin_copy_kernel(const uint8_t* __restr
         if (s_out[mid] <= first) l = mid; else h = mid;
       }
       int r = l;
-      O r_out = s_out[r], r_end = s_out[r + 1], r_src = s_src[r];
+      int64_t r_out = s_out[r], r_end = s_out[r + 1], r_src = s_src[r];
       uint32_t word = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void bin_copy_kernel(const uint8_t* __restr
           r_end = s_out[r + 1];
           r_src = s_src[r];
         }
-        word |= static_cast<uint32_t>(data[static_cast<int64_t>(r_src) + (pos - r_out)]) << (8 * j);
+        word |= static_cast<uint32_t>(data[r_src + (pos - r_out)]) << (8 * j);
       }
       if (q >= lo && q + 4 <= hi) {
         *reinterpret_cast<uint32_t*>(out_data + q) = word;
@@ -349,9 +351,10 @@ static int binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* indic
   return ARX_OK;
 }
 
+// shift: see bin_copy_kernel — total_bytes stays what the offsets count (elements for a list), the copy moves it << shift
 template <typename O>
 static int binary_take_data(const ArxBinarySpan* values, int64_t num_indices, const void* ws, size_t ws_bytes,
-                            const O* out_offsets, int64_t total_bytes, void* out_data, void* stream) {
+                            const O* out_offsets, int64_t total_bytes, void* out_data, void* stream, int shift = 0) {
   if (values == nullptr) {
     set_error("values is NULL");
     return ARX_INVALID;
@@ -367,14 +370,15 @@ static int binary_take_data(const ArxBinarySpan* values, int64_t num_indices, co
     return ARX_INVALID;
   }
   const O* src_start = reinterpret_cast<const O*>(static_cast<const uint8_t*>(ws) + bin_sums_bytes(num_indices));
-  const int64_t chunks = ceil_div(total_bytes, kBinChunk);
+  const int64_t copy_bytes = total_bytes << shift;
+  const int64_t chunks = ceil_div(copy_bytes, kBinChunk);
   if (chunks > 0x7FFFFFFFll) {
     set_error("binary take: %lld output bytes are more than one launch takes", static_cast<long long>(total_bytes));
     return ARX_NOT_IMPLEMENTED;
   }
   hipLaunchKernelGGL(bin_copy_kernel<O>, dim3(static_cast<unsigned>(chunks)), dim3(kBlock), 0, as_stream(stream),
-                     static_cast<const uint8_t*>(values->data), src_start, out_offsets, num_indices, total_bytes,
-                     static_cast<uint8_t*>(out_data));
+                     static_cast<const uint8_t*>(values->data), src_start, out_offsets, num_indices, copy_bytes,
+                     static_cast<uint8_t*>(out_data), shift);
   ARX_CHECK_LAUNCH("bin_copy_kernel");
   return ARX_OK;
 }
@@ -407,6 +411,27 @@ int arx_large_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* in
 int arx_large_binary_take_data(const ArxBinarySpan* values, int64_t num_indices, const void* ws, size_t ws_bytes,
                                const int64_t* out_offsets, int64_t total_bytes, void* out_data, void* stream) {
   return binary_take_data<int64_t>(values, num_indices, ws, ws_bytes, out_offsets, total_bytes, out_data, stream);
+}
+
+// list<T> / large_list<T> with fixed-width T (2^elem_shift bytes) whose values have no nulls: values->offsets are the list
+// offsets (in elements), values->data element 0 of the nested values; the offsets call is arx_(large_)binary_take_offsets
+// as it is (it counts elements), this one copies the elements
+int arx_list_take_data(const ArxBinarySpan* values, int elem_shift, int64_t num_indices, const void* ws, size_t ws_bytes,
+                       const int32_t* out_offsets, int64_t total_elements, void* out_data, void* stream) {
+  if (elem_shift < 0 || elem_shift > 5) {
+    set_error("arx_list_take_data: elements of 2^%d bytes", elem_shift);
+    return ARX_INVALID;
+  }
+  return binary_take_data<int32_t>(values, num_indices, ws, ws_bytes, out_offsets, total_elements, out_data, stream, elem_shift);
+}
+
+int arx_large_list_take_data(const ArxBinarySpan* values, int elem_shift, int64_t num_indices, const void* ws, size_t ws_bytes,
+                             const int64_t* out_offsets, int64_t total_elements, void* out_data, void* stream) {
+  if (elem_shift < 0 || elem_shift > 5) {
+    set_error("arx_large_list_take_data: elements of 2^%d bytes", elem_shift);
+    return ARX_INVALID;
+  }
+  return binary_take_data<int64_t>(values, num_indices, ws, ws_bytes, out_offsets, total_elements, out_data, stream, elem_shift);
 }
 
 }  // extern "C"

@@ -866,6 +866,63 @@ __global__ __launch_bounds__(kBlock) void take_kernel(TakeArgs a) {
   if (a.valid_count != nullptr && lane == 0 && nvalid != 0) atomicAdd(a.valid_count, nvalid);
 }
 
+// Take of ROWS of row_bytes contiguous bytes — a fixed_size_list whose nested values are fixed-width and free of nulls, or
+// a fixed_size_binary of any width: what FSLTakeExec hands to FixedWidthTakeExec (vector_selection_internal.cc:991-1003;
+// util::IsFixedWidthLike) for ANY byte width, where the element kernels above stop at 32.  A wave owns 64 output rows: one
+// index (+ validity probe) per lane, then the rows' units of UB bytes (the largest power of two <= 16 that divides
+// row_bytes) are copied FLATTENED — lane t of step k copies unit (k * 64 + t) of the 64 * units-per-row units, taking its
+// row's source index from that row's lane — so the stores are one contiguous stream whatever the row size and a short row
+// (12 bytes) keeps 64 lanes busy; a null row is zero-filled (WriteZero, gather_internal.h:114-153).
+template <int UB> struct RowUnit;
+template <> struct RowUnit<1> { typedef uint8_t type; };
+template <> struct RowUnit<2> { typedef uint16_t type; };
+template <> struct RowUnit<4> { typedef uint32_t type; };
+template <> struct RowUnit<8> { typedef uint64_t type; };
+template <> struct RowUnit<16> { typedef arx_u32x4 type; };
+
+template <int UB, typename IdxT, bool HAS_IV, bool HAS_SV>
+__global__ __launch_bounds__(kBlock) void take_rows_kernel(TakeArgs a, uint32_t units_per_row) {
+  using E = typename RowUnit<UB>::type;
+  const int lane = lane_id();
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nchunks = (a.length + 63) >> 6;
+  const int64_t last = a.length - 1;
+  const IdxT* __restrict__ indices = reinterpret_cast<const IdxT*>(a.indices);
+  const E* __restrict__ values = reinterpret_cast<const E*>(a.values);
+  E* __restrict__ out = reinterpret_cast<E*>(a.out_data);
+  uint64_t nvalid = 0;
+  for (int64_t c = wave_g; c < nchunks; c += nwaves) {
+    const int64_t base = c << 6;
+    const int64_t p = base + lane <= last ? base + lane : last;
+    uint64_t idx = static_cast<uint64_t>(indices[p]);
+    bool ok = base + lane <= last;
+    if constexpr (HAS_IV) ok = ok && ((load_word_nb(a.ivalid, base >> 6) >> lane) & 1ull);
+    if constexpr (HAS_SV) {
+      const uint64_t bit = ok ? static_cast<uint64_t>(a.src_valid_offset) + idx : 0;
+      ok = ok && ((a.src_valid_bytes[bit >> 3] >> (bit & 7)) & 1);
+    }
+    if (!ok) idx = 0;
+    const uint64_t vbal = __ballot(ok);
+    nvalid += __popcll(vbal);
+    if (a.out_validity != nullptr && lane == 0) a.out_validity[base >> 6] = vbal;
+    const int rows_here = static_cast<int>(last - base + 1 < 64 ? last - base + 1 : 64);
+    const uint32_t total = static_cast<uint32_t>(rows_here) * units_per_row;
+    const uint32_t idx_lo = static_cast<uint32_t>(idx), idx_hi = static_cast<uint32_t>(idx >> 32);
+    for (uint32_t t = lane; t < ((total + 63u) & ~63u); t += 64) {   // (wave-uniform trip count: the shuffles below are whole)
+      const uint32_t tt = t < total ? t : total - 1;
+      const uint32_t row = tt / units_per_row;
+      const uint32_t j = tt - row * units_per_row;
+      const uint64_t src = (static_cast<uint64_t>(__shfl(idx_hi, static_cast<int>(row), 64)) << 32) | __shfl(idx_lo, static_cast<int>(row), 64);
+      const bool row_ok = (vbal >> row) & 1ull;
+      E v = values[src * units_per_row + j];     // (a null row reads row 0 of the values — addressable — and drops it)
+      if (!row_ok) v = E{};
+      if (t < total) out[(static_cast<uint64_t>(base) + row) * units_per_row + j] = v;
+    }
+  }
+  if (a.valid_count != nullptr && lane == 0 && nvalid != 0) atomicAdd(a.valid_count, nvalid);
+}
+
 // Take of SEVERAL fixed-width columns by the same indices in one launch (TakeRAR, vector_selection_take_internal.cc:
 // 619-633, runs TakeAAA per column: every column re-reads the indices and their validity; here a wave reads them once
 // per 256 rows and gathers column after column).  Same per-column result as take_kernel.
@@ -1582,6 +1639,77 @@ int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int 
 #undef ARX_TAKE_W
 #undef ARX_TAKE_V
   ARX_CHECK_LAUNCH("take_kernel");
+  return ARX_OK;
+}
+
+int arx_take_rows(const ArxSpan* values, int64_t row_bytes, const ArxSpan* indices, int index_type, void* out_data,
+                  void* out_validity, int64_t* valid_count, void* stream) {
+  if (values == nullptr || indices == nullptr) {
+    set_error("values/indices is NULL");
+    return ARX_INVALID;
+  }
+  if (index_type < 0 || index_type > 7) {
+    set_error("Unsupported index type %d for take", index_type);
+    return ARX_NOT_IMPLEMENTED;
+  }
+  if (row_bytes <= 0 || row_bytes > (int64_t(1) << 30)) {
+    set_error("arx_take_rows: rows of %lld bytes", static_cast<long long>(row_bytes));
+    return row_bytes == 0 ? ARX_NOT_IMPLEMENTED : ARX_INVALID;
+  }
+  if (indices->length == 0) return ARX_OK;
+  if (out_data == nullptr || indices->data == nullptr) {
+    set_error("indices/out data buffer is NULL");
+    return ARX_INVALID;
+  }
+  static const int widths[8] = {1, 1, 2, 2, 4, 4, 8, 8};
+  const int iw = widths[index_type];
+  TakeArgs a{};
+  a.values = static_cast<const uint8_t*>(values->data) + values->offset * row_bytes;
+  a.src_valid_bytes = static_cast<const uint8_t*>(effective_validity(values));
+  a.src_valid_offset = values->offset;
+  a.indices = static_cast<const uint8_t*>(indices->data) + indices->offset * iw;
+  a.ivalid = make_bits(effective_validity(indices), indices->offset, indices->length);
+  a.length = indices->length;
+  a.out_data = static_cast<uint8_t*>(out_data);
+  a.out_validity = static_cast<uint64_t*>(out_validity);
+  a.valid_count = reinterpret_cast<unsigned long long*>(valid_count);
+  const bool has_iv = a.ivalid.base != nullptr, has_sv = a.src_valid_bytes != nullptr;
+  if ((has_iv || has_sv) && out_validity == nullptr) {
+    set_error("take: inputs may have nulls but out_validity is NULL");
+    return ARX_INVALID;
+  }
+  // the copy unit: the largest power of two <= 16 that divides the row and both base addresses
+  int ub = 16;
+  while (ub > 1 && (row_bytes % ub != 0 || reinterpret_cast<uintptr_t>(a.values) % ub != 0 || reinterpret_cast<uintptr_t>(out_data) % ub != 0)) ub >>= 1;
+  const uint32_t upr = static_cast<uint32_t>(row_bytes / ub);
+  const int64_t nchunks = ceil_div(indices->length, 64);
+  const int64_t blocks = std::min<int64_t>(ceil_div(nchunks, kWavesPerBlock), 256 * 32);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(kBlock);
+  hipStream_t st = as_stream(stream);
+#define ARX_ROWS_V(UB, IT)                                                                                        \
+  do {                                                                                                            \
+    if (has_iv && has_sv) hipLaunchKernelGGL((take_rows_kernel<UB, IT, true, true>), grid, block, 0, st, a, upr);  \
+    else if (has_iv) hipLaunchKernelGGL((take_rows_kernel<UB, IT, true, false>), grid, block, 0, st, a, upr);      \
+    else if (has_sv) hipLaunchKernelGGL((take_rows_kernel<UB, IT, false, true>), grid, block, 0, st, a, upr);      \
+    else hipLaunchKernelGGL((take_rows_kernel<UB, IT, false, false>), grid, block, 0, st, a, upr);                 \
+  } while (0)
+#define ARX_ROWS_U(UB)                        \
+  switch (iw) {                               \
+    case 1: ARX_ROWS_V(UB, uint8_t); break;   \
+    case 2: ARX_ROWS_V(UB, uint16_t); break;  \
+    case 4: ARX_ROWS_V(UB, uint32_t); break;  \
+    default: ARX_ROWS_V(UB, uint64_t); break; \
+  }
+  switch (ub) {
+    case 16: ARX_ROWS_U(16); break;
+    case 8: ARX_ROWS_U(8); break;
+    case 4: ARX_ROWS_U(4); break;
+    case 2: ARX_ROWS_U(2); break;
+    default: ARX_ROWS_U(1); break;
+  }
+#undef ARX_ROWS_U
+#undef ARX_ROWS_V
+  ARX_CHECK_LAUNCH("take_rows_kernel");
   return ARX_OK;
 }
 

@@ -161,6 +161,13 @@ int arx_check_index_bounds(const ArxSpan* indices, int index_type, uint64_t uppe
 int arx_take(const ArxSpan* values, int byte_width, const ArxSpan* indices, int index_type,
              void* out_data, void* out_validity, int64_t* valid_count, void* stream);
 
+/* Take of rows of `row_bytes` contiguous bytes (any width): what FSLTakeExec hands to FixedWidthTakeExec for a
+ * fixed_size_list whose nested values are fixed-width and free of nulls (vector_selection_internal.cc:991-1003,
+ * util::IsFixedWidthLike), and fixed_size_binary of a width the element kernels of arx_take do not have.  values->data =
+ * row 0 of the nested values, values->offset / ->validity = the list array's; otherwise as arx_take.  Asynchronous. */
+int arx_take_rows(const ArxSpan* values, int64_t row_bytes, const ArxSpan* indices, int index_type, void* out_data,
+                  void* out_validity, int64_t* valid_count, void* stream);
+
 /* The same gather for SEVERAL fixed-width columns by one index array in one launch — what TakeRAR / TakeTAT
  * (vector_selection_take_internal.cc:619-660: `take` of a RecordBatch / Table) get by running TakeAAA column after
  * column; here the indices and their validity are read once per row and every column is gathered behind them.
@@ -215,6 +222,17 @@ int arx_large_binary_take_offsets(const ArxBinarySpan* values, const ArxSpan* in
                                   int64_t* out_total_bytes, void* stream);
 int arx_large_binary_take_data(const ArxBinarySpan* values, int64_t num_indices, const void* ws, size_t ws_bytes,
                                const int64_t* out_offsets, int64_t total_bytes, void* out_data, void* stream);
+
+/* list<T> / large_list<T> whose nested values are fixed-width (2^elem_shift bytes, elem_shift 0 .. 5) and free of nulls —
+ * ListSelectionImpl (vector_selection_internal.cc:620-760; ListTakeExec :975, ListFilterExec :910): such a list is a binary
+ * array whose offsets count elements.  values->offsets = the list offsets, values->data = element 0 of the nested
+ * values (the child's own offset applied); arx_(large_)binary_take_offsets computes the output offsets unchanged —
+ * total "bytes" is then the number of ELEMENTS —, these copy them.  Asynchronous. */
+int arx_list_take_data(const ArxBinarySpan* values, int elem_shift, int64_t num_indices, const void* ws, size_t ws_bytes,
+                       const int32_t* out_offsets, int64_t total_elements, void* out_data, void* stream);
+int arx_large_list_take_data(const ArxBinarySpan* values, int elem_shift, int64_t num_indices, const void* ws,
+                             size_t ws_bytes, const int64_t* out_offsets, int64_t total_elements, void* out_data,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------
  * Cast float64 -> float32 — replaces CastPrimitive<FloatType,DoubleType>::Exec

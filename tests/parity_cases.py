@@ -2306,3 +2306,128 @@ def check_bitmap_copy_segments(amd, rng, scale=1):
     for d in range(2):
         got = np.unpackbits(dsts[d].cpu().numpy().view(np.uint8), bitorder="little")
         assert_equal(got[: len(want[d])], want[d], f"bitmap_copy_segments dst {d}")
+
+
+def _pack_bits(valid: np.ndarray, offset: int = 0) -> np.ndarray:
+    """bool[n] -> LSB-first bitmap bytes with `offset` leading garbage-free bits, padded to whole 64-bit words"""
+    bits = np.concatenate([np.zeros(offset, dtype=bool), valid])
+    out = np.packbits(bits, bitorder="little")
+    return np.concatenate([out, np.zeros((-len(out)) % 8 + 8, dtype=np.uint8)])
+
+
+def check_take_rows(amd, rng, row_bytes_list=(1, 2, 3, 4, 12, 16, 20, 24, 48, 100, 512, 1000), n=3000, m=2500):
+    """arx_take_rows (rows of any byte width: fixed_size_list of fixed-width values without nulls, FSLTakeExec ->
+    FixedWidthTakeExec): every index type, null indices, null source rows at an offset, empty and single-row inputs; the
+    output rows, validity words (padding bits clear) and the valid count against numpy."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+    idx_types = [(np.uint8, 0), (np.int8, 1), (np.uint16, 2), (np.int16, 3), (np.uint32, 4), (np.int32, 5), (np.uint64, 6), (np.int64, 7)]
+    case = 0
+    for rb in row_bytes_list:
+        for mm in (m, 1, 0, 64, 65):
+            case += 1
+            idt, tid = idx_types[case % len(idx_types)]
+            voff = int(rng.integers(0, 9)) if case % 2 else 0
+            nn = max(1, min(n, np.iinfo(idt).max))
+            values = rng.integers(0, 256, (voff + nn) * rb + 32, dtype=np.uint8)
+            has_sv, has_iv = case % 3 != 0, case % 4 != 1
+            svalid = rng.random(nn) > 0.2 if has_sv else np.ones(nn, dtype=bool)
+            ivalid = rng.random(mm) > 0.1 if has_iv else np.ones(mm, dtype=bool)
+            idx = rng.integers(0, nn, mm).astype(idt)
+            ioff = 3 if case % 5 == 0 else 0
+            idx_buf = np.concatenate([np.zeros(ioff, dtype=idt), idx])
+            d_values = to_device(values, dev)
+            d_idx = to_device(idx_buf.view(np.uint8) if len(idx_buf) else np.zeros(8, dtype=np.uint8), dev)
+            d_sv = to_device(_pack_bits(svalid, voff), dev) if has_sv else None
+            d_iv = to_device(_pack_bits(ivalid, ioff), dev) if has_iv else None
+            vs = _lib.ArxSpan(d_sv.data_ptr() if has_sv else None, d_values.data_ptr(), voff, nn, -1 if has_sv else 0)
+            isp = _lib.ArxSpan(d_iv.data_ptr() if has_iv else None, d_idx.data_ptr(), ioff, mm, -1 if has_iv else 0)
+            out = torch.full((max(mm * rb, 1) + 64,), 0xAB, dtype=torch.uint8, device=dev)
+            ov = torch.full((((mm + 63) // 64) * 8 + 8,), 0xFF, dtype=torch.uint8, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+            need_valid = has_sv or has_iv
+            _lib.check(lib.arx_take_rows(C.byref(vs), rb, C.byref(isp), tid, out.data_ptr(), ov.data_ptr() if need_valid else None,
+                                         cnt.data_ptr(), st))
+            tag = f"take_rows[row_bytes={rb},m={mm},idx={np.dtype(idt).name},voff={voff},ioff={ioff},sv={has_sv},iv={has_iv}]"
+            ok = ivalid & svalid[idx.astype(np.int64)] if mm else np.zeros(0, dtype=bool)
+            rows = values[voff * rb: (voff + nn) * rb].reshape(nn, rb)
+            want = np.where(ok[:, None], rows[idx.astype(np.int64)], 0).astype(np.uint8) if mm else np.zeros((0, rb), dtype=np.uint8)
+            got = out.cpu().numpy()
+            assert_equal(got[: mm * rb].reshape(mm, rb), want, tag + " rows")
+            assert (got[mm * rb: mm * rb + 16] == 0xAB).all(), tag + " wrote past the output"
+            assert int(cnt.item()) == int(ok.sum()), (tag, int(cnt.item()), int(ok.sum()))
+            if need_valid and mm:
+                words = ov.cpu().numpy()[: ((mm + 63) // 64) * 8]
+                bits = np.unpackbits(words, bitorder="little")
+                assert_equal(bits[:mm].astype(bool), ok, tag + " validity")
+                assert not bits[mm:].any(), tag + " padding bits"
+    # argument checks
+    vs = _lib.ArxSpan(None, d_values.data_ptr(), 0, 1, 0)
+    isp = _lib.ArxSpan(None, d_idx.data_ptr(), 0, 1, 0)
+    assert lib.arx_take_rows(C.byref(vs), 0, C.byref(isp), 4, out.data_ptr(), None, None, st) == _lib.ARX_NOT_IMPLEMENTED
+    assert lib.arx_take_rows(C.byref(vs), -4, C.byref(isp), 4, out.data_ptr(), None, None, st) == _lib.ARX_INVALID
+    assert lib.arx_take_rows(C.byref(vs), 8, C.byref(isp), 9, out.data_ptr(), None, None, st) == _lib.ARX_NOT_IMPLEMENTED
+    assert lib.arx_take_rows(None, 8, C.byref(isp), 4, out.data_ptr(), None, None, st) == _lib.ARX_INVALID
+
+
+def check_list_take(amd, rng, n=2000, m=1700):
+    """arx_binary_take_offsets + arx_(large_)list_take_data: a list whose nested values are fixed-width and free of nulls
+    is a binary array whose offsets count elements (ListSelectionImpl, vector_selection_internal.cc:620-760) — element
+    widths 1 .. 32 bytes, int32 and int64 offsets, sliced lists, null lists, null indices, empty lists."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+    case = 0
+    for shift in range(6):
+        w = 1 << shift
+        for large in (False, True):
+            case += 1
+            odt = np.int64 if large else np.int32
+            voff = 5 if case % 2 else 0
+            lens = rng.integers(0, 9, voff + n)
+            lens[rng.random(voff + n) < 0.2] = 0
+            offs = np.concatenate([[7], 7 + np.cumsum(lens)]).astype(odt)       # (a sliced child: offsets need not start at 0)
+            child = rng.integers(0, 256, int(offs[-1]) * w + 64, dtype=np.uint8)
+            svalid = rng.random(n) > 0.15
+            ivalid = rng.random(m) > 0.1
+            idx = rng.integers(0, n, m).astype(np.uint32)
+            d_offs, d_child, d_idx = to_device(offs.view(np.uint8), dev), to_device(child, dev), to_device(idx.view(np.uint8), dev)
+            d_sv, d_iv = to_device(_pack_bits(svalid, voff), dev), to_device(_pack_bits(ivalid, 0), dev)
+            vs = _lib.ArxBinarySpan(d_sv.data_ptr(), d_offs.data_ptr(), d_child.data_ptr(), voff, n, -1)
+            isp = _lib.ArxSpan(d_iv.data_ptr(), d_idx.data_ptr(), 0, m, -1)
+            ws_bytes = (lib.arx_large_binary_take_workspace_bytes if large else lib.arx_binary_take_workspace_bytes)(m)
+            ws = torch.zeros(ws_bytes + 64, dtype=torch.uint8, device=dev)
+            out_offs = torch.zeros((m + 1) * offs.itemsize + 8, dtype=torch.uint8, device=dev)
+            ov = torch.zeros(((m + 63) // 64) * 8 + 8, dtype=torch.uint8, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+            total = C.c_int64(0)
+            f_off = lib.arx_large_binary_take_offsets if large else lib.arx_binary_take_offsets
+            _lib.check(f_off(C.byref(vs), C.byref(isp), 4, ws.data_ptr(), ws_bytes, out_offs.data_ptr(), ov.data_ptr(), cnt.data_ptr(),
+                             C.byref(total), st))
+            ok = ivalid & svalid[idx]
+            src = idx.astype(np.int64) + voff
+            want_lens = np.where(ok, lens[src], 0)
+            want_offs = np.concatenate([[0], np.cumsum(want_lens)]).astype(odt)
+            assert total.value == int(want_offs[-1]), (shift, large, total.value, int(want_offs[-1]))
+            got_offs = out_offs.cpu().numpy()[: (m + 1) * offs.itemsize].view(odt)
+            assert_equal(got_offs, want_offs, f"list_take offsets w={w} large={large}")
+            data = torch.full((max(total.value * w, 1) + 32,), 0xCD, dtype=torch.uint8, device=dev)
+            f_data = lib.arx_large_list_take_data if large else lib.arx_list_take_data
+            _lib.check(f_data(C.byref(vs), shift, m, ws.data_ptr(), ws_bytes, out_offs.data_ptr(), total.value, data.data_ptr(), st))
+            want = np.concatenate([child[int(offs[s]) * w: int(offs[s + 1]) * w] for s, o in zip(src, ok) if o] + [np.zeros(0, dtype=np.uint8)])
+            got = data.cpu().numpy()
+            assert_equal(got[: total.value * w], want, f"list_take data w={w} large={large}")
+            assert (got[total.value * w: total.value * w + 16] == 0xCD).all()
+            assert int(cnt.item()) == int(ok.sum())
+    assert lib.arx_list_take_data(C.byref(vs), 6, m, ws.data_ptr(), ws_bytes, out_offs.data_ptr(), 1, data.data_ptr(), st) == _lib.ARX_INVALID

@@ -985,6 +985,13 @@ def test_coalesce_of_two_operands_is_fill_null(emu_ctx):
     P.check_coalesce2(emu_ctx, rng_for("coalesce2"), n=3000)
 
 
+def test_take_of_rows_of_any_width_and_of_lists_with_fixed_width_values(emu_ctx):
+    """fixed_size_list / list / large_list selection where the nested values are fixed-width and free of nulls
+    (FSLTakeExec -> FixedWidthTakeExec; ListSelectionImpl): arx_take_rows and arx_(large_)list_take_data."""
+    P.check_take_rows(emu_ctx, rng_for("takerows"), n=700, m=600)
+    P.check_list_take(emu_ctx, rng_for("listtake"), n=700, m=600)
+
+
 def test_buffer_copy(emu_ctx):
     P.check_buffer_copy(emu_ctx, rng_for("bufcopy"), 1)
 

@@ -1345,6 +1345,13 @@ def test_coalesce_of_two_operands_is_fill_null(gpu_ctx):
     P.check_coalesce2(gpu_ctx, rng_for("coalesce2"), n=1000003)
 
 
+def test_take_of_rows_of_any_width_and_of_lists_with_fixed_width_values(gpu_ctx):
+    """fixed_size_list / list / large_list selection where the nested values are fixed-width and free of nulls
+    (FSLTakeExec -> FixedWidthTakeExec; ListSelectionImpl): arx_take_rows and arx_(large_)list_take_data."""
+    P.check_take_rows(gpu_ctx, rng_for("takerows"), n=300000, m=250000)
+    P.check_list_take(gpu_ctx, rng_for("listtake"), n=300000, m=250000)
+
+
 def test_buffer_copy(gpu_ctx):
     P.check_buffer_copy(gpu_ctx, rng_for("bufcopy"), 40)
 

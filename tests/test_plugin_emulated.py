@@ -152,3 +152,7 @@ def test_stock_acero_plans_land_on_the_plugin_nodes_after_the_factory_override_e
 
 def test_filter_and_take_of_large_utf8_and_large_binary_on_device_arrays_emulated():
     _run(G.LARGE_BINARY_SCRIPT, "LARGE_BINARY_OK", 0.02)
+
+
+def test_filter_and_take_of_fixed_size_list_and_list_on_device_arrays_emulated():
+    _run(G.NESTED_SELECTION_SCRIPT, "NESTED_SELECTION_OK", 0.02)
