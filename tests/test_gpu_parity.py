@@ -513,7 +513,7 @@ def test_groupby_wide_form_without_histogram(gpu_ctx, hot, stripe):
     before = [lib.arx_get_counter(c) for c in names]
     try:
         rng = rng_for("gbrooms", hot)
-        n = 6000000
+        n = 3200000
         k = U.random_array(rng, np.int32, n, null_p=0.02, lo=-2**31, hi=2**31 - 1)
         if hot:
             k.values[n // 3:] = 7            # two thirds of the rows in ONE group: its partition outgrows its room
@@ -531,24 +531,24 @@ def test_groupby_wide_form_without_histogram(gpu_ctx, hot, stripe):
         assert rooms == 1, "after an overflow the call stays on the counted plan"
 
 
-@pytest.mark.parametrize("distinct", [200000, 0])
+@pytest.mark.parametrize("distinct", [50000, 0])
 def test_groupby_probe_slice_selects_the_plan(gpu_ctx, distinct):
     """A capacity that only bounds the group count from above (two-level plan) + enough rows: a HyperLogLog sketch of
     the first groupby_probe_rows keys estimates the distinct keys; few of them, seen often -> the rows run the wide plan, keys
     that do not repeat -> the two-level plan.  Same groups either way."""
     lib = gpu_ctx._lib.get_lib()
     assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
-    assert lib.arx_set_option(b"groupby_probe_rows", 1048576) == 0
+    assert lib.arx_set_option(b"groupby_probe_rows", 262144) == 0
     assert lib.arx_set_option(b"groupby_wide_max_bits", 6) == 0    # (so that the capacity bound alone cannot pick the wide plan)
     names = (b"groupby_slices_probe", b"groupby_slices_wide", b"groupby_slices_two_level")
     before = [lib.arx_get_counter(c) for c in names]
     try:
         rng = rng_for("gbprobe", distinct)
-        n = 9 * 1048576 + 1234
+        n = 9 * 262144 + 1234
         hi = distinct if distinct else 2**31 - 1
         k = U.random_array(rng, np.int32, n, null_p=0.01, lo=-5 if distinct else -2**31, hi=hi)
         v = U.random_array(rng, np.int64, n, null_p=0.05)
-        cap = 1 << 21 if distinct else 1 << 25     # (9.4M distinct keys need the larger table)
+        cap = 1 << 21 if distinct else 1 << 23     # (2.4M distinct keys need the larger table)
         P.check_groupby_sum(gpu_ctx, k, v, capacity=cap, batches=1, use_pyarrow=False)
         P.check_groupby_sum(gpu_ctx, k, v, capacity=cap, batches=2, use_pyarrow=False)   # second consume: table not empty
     finally:
@@ -1285,9 +1285,9 @@ def test_grouper_hot_keys_and_overflow(gpu_ctx):
         g.consume([gpu_ctx.Array.from_numpy(np.arange(100_000, dtype=np.int64))])
 
 
-@pytest.mark.parametrize("dtypes,n,card,null_p", [((np.int64,), 1_500_000, 200_000, 0.05),
-                                                  ((np.int32, np.int32), 1_500_000, 800, 0.1),
-                                                  ((np.int64, np.int16), 600_000, 500_000, 0.0)])
+@pytest.mark.parametrize("dtypes,n,card,null_p", [((np.int64,), 600_000, 200_000, 0.05),      # (sizes: the row-by-row checker
+                                                  ((np.int32, np.int32), 150_000, 800, 0.1),    #  is what takes the time here)
+                                                  ((np.int64, np.int16), 250_000, 200_000, 0.0)])
 def test_group_by_wide_and_multiple_keys(gpu_ctx, dtypes, n, card, null_p):
     P.check_group_by_keys(gpu_ctx, rng_for("group_by_keys", len(dtypes), n, card), dtypes, n, card, null_p)
 
