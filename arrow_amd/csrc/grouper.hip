@@ -187,7 +187,12 @@ __global__ __launch_bounds__(kBlock) void grouper_probe_kernel(GrouperView v, Gr
           __hip_atomic_load(&slot->k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key.k1 && ((meta >> 8) & 0xFF) == key.mask) {
         const unsigned long long id = meta >> 32;
         if (a.insert) {
-          if (id >= a.base) atomicMin(&a.first_row[id - a.base], static_cast<uint32_t>(row));
+          // (the group's first row so far is read before it is lowered: with a few hot keys every row used to send an
+          //  atomicMin to one of a handful of addresses — 6.7e7 rows on 100 keys: 66 ms of serialised atomics; a stale,
+          //  larger value read here only costs the atomic it would have cost anyway)
+          if (id >= a.base && static_cast<uint32_t>(row) < __hip_atomic_load(&a.first_row[id - a.base], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            atomicMin(&a.first_row[id - a.base], static_cast<uint32_t>(row));
+          }
         } else if (a.found_bits != nullptr) {
           atomicOr(reinterpret_cast<unsigned long long*>(a.found_bits) + (row >> 6), 1ull << (row & 63));
         }

@@ -355,6 +355,175 @@ static int64_t fsum_max_blocks(int64_t n, int64_t null_count) {
   return std::min<int64_t>(ceil_div(n, kFsumBlock) + nulls + 1, (n + 1) / 2 + 1);
 }
 
+// ---- hash_sum / hash_mean of float32 / float64 values over dense group ids.  GroupedReducingAggregator<FloatType /
+// DoubleType, GroupedSumImpl | GroupedMeanImpl> (hash_aggregate_numeric.cc:44-152,352-430) adds every row to its group's
+// DOUBLE accumulator in ROW ORDER (Consume :70-83 -> VisitGroupedValues; Reduce = double(u) + double(v)) — a sum whose
+// value depends on the order, so "the same result" means the same order.  Here: the rows are stably sorted by group id
+// (arx_sort_indices keeps equal keys in row order), which makes every group one run of the permutation in row order, and
+// ONE thread walks a group's run adding from the group's running sum — the additions of the reference, group by group
+// instead of row by row.  No atomics: a group has one owner per call; batches continue where the last one stopped.
+constexpr int64_t kFsumLongRun = 1024;
+
+// the rows in (group id, row) order: group id, value as a double, validity — what the walkers then read sequentially
+template <typename T>
+__global__ __launch_bounds__(kBlock) void hash_fsum_gather_kernel(const T* __restrict__ values, Bits vvalid, int is_scalar, double scalar,
+                                                                  int scalar_valid, const uint32_t* __restrict__ gids,
+                                                                  const uint64_t* __restrict__ perm, int64_t n,
+                                                                  uint32_t* __restrict__ gs, double* __restrict__ vs,
+                                                                  uint8_t* __restrict__ oks) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const uint64_t r = perm[i];
+    gs[i] = gids[r];
+    if (is_scalar) {
+      vs[i] = scalar;
+      oks[i] = scalar_valid != 0 ? 1 : 0;
+    } else {
+      vs[i] = static_cast<double>(values[r]);
+      oks[i] = (vvalid.base == nullptr || ((load_word(vvalid, static_cast<int64_t>(r) >> 6) >> (r & 63)) & 1ull)) ? 1 : 0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hash_fsum_walk_kernel(const uint32_t* __restrict__ gs, const double* __restrict__ vs,
+                                                                const uint8_t* __restrict__ oks, int64_t n, double* __restrict__ sums,
+                                                                long long* __restrict__ counts, uint32_t* __restrict__ null_seen,
+                                                                unsigned long long* __restrict__ long_runs) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const uint32_t g = gs[i];
+    if (i > 0 && gs[i - 1] == g) continue;   // not the first row of its group's run
+    // a run of more than kFsumLongRun rows is left to a whole wave (hash_fsum_walk_long_kernel): long_runs[0] counts them
+    if (i + kFsumLongRun < n && gs[i + kFsumLongRun] == g) {
+      long_runs[1 + atomicAdd(&long_runs[0], 1ull)] = static_cast<unsigned long long>(i);
+      continue;
+    }
+    double acc = sums[g];
+    long long cnt = 0;
+    bool saw_null = false;
+    bool more = true;
+    for (int64_t j = i; j < n && more; j += 4) {
+      // four rows' loads in flight; the adds stay in row order
+      uint32_t gg[4];
+      double v[4];
+      uint8_t ok[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t q = j + k < n ? j + k : n - 1;
+        gg[k] = gs[q];
+        v[k] = vs[q];
+        ok[k] = oks[q];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!more || j + k >= n || gg[k] != g) {
+          more = false;
+        } else if (ok[k]) {
+          acc = acc + v[k];
+          ++cnt;
+        } else {
+          saw_null = true;
+        }
+      }
+    }
+    sums[g] = acc;
+    if (cnt != 0) counts[g] += cnt;
+    if (saw_null) null_seen[g] |= 1u;
+  }
+}
+
+// The long runs (few groups, many rows each): the same additions in the same order, by ONE wave per run that streams it —
+// kFsumAhead chunks of 64 rows in flight.  A row that does not count (null, or past the run's end) is replaced by -0.0, the
+// identity of IEEE addition (x + -0.0 == x bit for bit, for every x), so the serial part is nothing but a chain of adds: the
+// 64 values of a chunk go through LDS and come back as broadcast reads, all issued before the first add.  (Reading them lane by
+// lane with v_readlane cost ~120 cycles a row, with ds_bpermute more: 37 / 46 ms for 6.7e5-row runs.)
+constexpr int kFsumAhead = 8;
+__global__ __launch_bounds__(64) void hash_fsum_walk_long_kernel(const uint32_t* __restrict__ gs, const double* __restrict__ vs,
+                                                                 const uint8_t* __restrict__ oks, int64_t n, double* __restrict__ sums,
+                                                                 long long* __restrict__ counts, uint32_t* __restrict__ null_seen,
+                                                                 const unsigned long long* __restrict__ long_runs) {
+  __shared__ double stage[kFsumAhead][64];
+  const int lane = threadIdx.x;
+  const int64_t nruns = static_cast<int64_t>(long_runs[0]);
+  for (int64_t e = blockIdx.x; e < nruns; e += gridDim.x) {
+    const int64_t i = static_cast<int64_t>(long_runs[1 + e]);
+    const uint32_t g = gs[i];
+    double acc = sums[g];
+    long long cnt = 0;
+    bool saw_null = false;
+    bool more = true;
+    // the next round's rows are loaded into registers before this round's chain of adds runs (the barrier in between would
+    // otherwise keep the loads behind it)
+    uint32_t gg[kFsumAhead];
+    double vv[kFsumAhead];
+    uint8_t oo[kFsumAhead];
+    auto fetch = [&](int64_t j0) {
+#pragma unroll
+      for (int c = 0; c < kFsumAhead; ++c) {
+        const int64_t q = j0 + c * 64 + lane < n ? j0 + c * 64 + lane : n - 1;
+        gg[c] = gs[q];
+        vv[c] = vs[q];
+        oo[c] = oks[q];
+      }
+    };
+    fetch(i);
+    for (int64_t j = i; j < n && more; j += 64 * kFsumAhead) {
+      uint64_t run_mask[kFsumAhead], ok_mask[kFsumAhead];
+      __syncthreads();   // (one wave: the previous round's reads of the stage are done)
+#pragma unroll
+      for (int c = 0; c < kFsumAhead; ++c) {
+        const bool in_run = j + c * 64 + lane < n && gg[c] == g;
+        const bool ok = oo[c] != 0;
+        run_mask[c] = __ballot(in_run);
+        ok_mask[c] = __ballot(ok);
+        stage[c][lane] = (in_run && ok) ? vv[c] : -0.0;
+      }
+      __syncthreads();
+      if (j + 64 * kFsumAhead < n) fetch(j + 64 * kFsumAhead);
+#pragma unroll
+      for (int c = 0; c < kFsumAhead; ++c) {
+        if (!more) continue;   // (wave-uniform)
+        const int take = run_mask[c] == ~0ull ? 64 : __builtin_ctzll(~run_mask[c]);   // the run's rows are a prefix of the 64
+        const uint64_t prefix = take == 64 ? ~0ull : ((1ull << take) - 1ull);
+        // (a staged value past `take` is -0.0: the rows are sorted by group, the group does not come back)
+        double x[64];
+#pragma unroll
+        for (int l = 0; l < 64; ++l) x[l] = stage[c][l];
+#pragma unroll
+        for (int l = 0; l < 64; ++l) acc = acc + x[l];
+        cnt += __popcll(ok_mask[c] & prefix);
+        saw_null = saw_null || ((~ok_mask[c] & prefix) != 0);
+        if (take < 64) more = false;
+      }
+    }
+    if (lane == 0) {
+      sums[g] = acc;
+      if (cnt != 0) counts[g] += cnt;
+      if (saw_null) null_seen[g] |= 1u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hash_fsum_merge_kernel(double* __restrict__ sums, long long* __restrict__ counts,
+                                                                 uint32_t* __restrict__ null_seen, const double* __restrict__ other_sums,
+                                                                 const long long* __restrict__ other_counts,
+                                                                 const uint32_t* __restrict__ other_null_seen,
+                                                                 const uint32_t* __restrict__ mapping, int64_t m) {
+  // Merge (:85-107): group g of the other state lands on mapping[g], each target at most once per call
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; g < m; g += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const uint32_t t = mapping[g];
+    sums[t] = sums[t] + other_sums[g];
+    counts[t] += other_counts[g];
+    if (other_null_seen[g] & 1u) null_seen[t] |= 1u;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hash_fmean_finalize_kernel(const double* __restrict__ sums, const long long* __restrict__ counts,
+                                                                     int64_t m, double* __restrict__ out) {
+  // GroupedMeanImpl::DoMean (:381-385): double(reduced) / count; an empty group reads 0 (its slot is null)
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; g < m; g += static_cast<int64_t>(gridDim.x) * kBlock) {
+    out[g] = counts[g] > 0 ? sums[g] / static_cast<double>(counts[g]) : 0.0;
+  }
+}
+
 extern "C" {
 
 int arx_reduce_float_minmax(const ArxSpan* values, int num_type, void* acc, void* stream) {
@@ -514,6 +683,98 @@ int arx_sum_float(const ArxSpan* values, int num_type, void* ws, size_t ws_bytes
     for (double v : host[i]) counter.reduce(pieces[i].level, v);
   }
   *out_sum = counter.finish();
+  return ARX_OK;
+}
+
+size_t arx_hash_sum_float_workspace_bytes(int64_t length) {
+  if (length <= 0) return 0;
+  const size_t n = static_cast<size_t>(length);
+  return fsum_align(arx_sort_indices_workspace_bytes(length)) + fsum_align(n * 8) /* perm */ + fsum_align(n * 4) /* group ids */ +
+         fsum_align(n * 8) /* values */ + fsum_align(n) /* validity */ + fsum_align((n / kFsumLongRun + 2) * 8) + 512;
+}
+
+int arx_hash_sum_float_consume(const ArxSpan* values, int num_type, int values_is_scalar, double scalar_value,
+                               const uint32_t* group_ids, int64_t length, void* ws, size_t ws_bytes, double* sums,
+                               int64_t* counts, uint32_t* null_seen, void* stream) {
+  if (values == nullptr || length < 0 || (num_type != ARX_NUM_FLOAT32 && num_type != ARX_NUM_FLOAT64)) {
+    set_error("bad arguments to arx_hash_sum_float_consume");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  if (group_ids == nullptr || sums == nullptr || counts == nullptr || null_seen == nullptr || ws == nullptr ||
+      ws_bytes < arx_hash_sum_float_workspace_bytes(length) || (!values_is_scalar && values->data == nullptr)) {
+    set_error("arx_hash_sum_float_consume: NULL buffer or a workspace below arx_hash_sum_float_workspace_bytes");
+    return ARX_INVALID;
+  }
+  const size_t n = static_cast<size_t>(length);
+  uint8_t* p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~uintptr_t(255));
+  const size_t sort_bytes = arx_sort_indices_workspace_bytes(length);
+  uint8_t* q = p + fsum_align(sort_bytes);
+  uint64_t* perm = reinterpret_cast<uint64_t*>(q); q += fsum_align(n * 8);
+  uint32_t* gs = reinterpret_cast<uint32_t*>(q); q += fsum_align(n * 4);
+  double* vs = reinterpret_cast<double*>(q); q += fsum_align(n * 8);
+  uint8_t* oks = q; q += fsum_align(n);
+  unsigned long long* long_runs = reinterpret_cast<unsigned long long*>(q);
+  const ArxSpan keys{nullptr, group_ids, 0, length, 0};
+  const int rc = arx_sort_indices(&keys, ARX_KEY_UINT32, ARX_SORT_ASCENDING, ARX_NULLS_AT_END, p, sort_bytes, perm, stream);
+  if (rc != ARX_OK) return rc;
+  hipStream_t st = as_stream(stream);
+  ARX_HIP(hipMemsetAsync(long_runs, 0, 8, st));
+  const bool has_nulls = !values_is_scalar && values->null_count != 0 && values->validity != nullptr;
+  const Bits vvalid = has_nulls ? make_bits(values->validity, values->offset, length) : Bits{};
+  const int scalar_valid = values->null_count == 0 ? 1 : 0;
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((length + kBlock - 1) / kBlock, 256 * 16)));
+  if (num_type == ARX_NUM_FLOAT64) {
+    const double* v = values_is_scalar ? nullptr : static_cast<const double*>(values->data) + values->offset;
+    hipLaunchKernelGGL((hash_fsum_gather_kernel<double>), dim3(grid), dim3(kBlock), 0, st, v, vvalid, values_is_scalar, scalar_value,
+                       scalar_valid, group_ids, perm, length, gs, vs, oks);
+  } else {
+    const float* v = values_is_scalar ? nullptr : static_cast<const float*>(values->data) + values->offset;
+    hipLaunchKernelGGL((hash_fsum_gather_kernel<float>), dim3(grid), dim3(kBlock), 0, st, v, vvalid, values_is_scalar, scalar_value,
+                       scalar_valid, group_ids, perm, length, gs, vs, oks);
+  }
+  ARX_CHECK_LAUNCH("hash_fsum_gather_kernel");
+  hipLaunchKernelGGL(hash_fsum_walk_kernel, dim3(grid), dim3(kBlock), 0, st, gs, vs, oks, length, sums, reinterpret_cast<long long*>(counts),
+                     null_seen, long_runs);
+  ARX_CHECK_LAUNCH("hash_fsum_walk_kernel");
+  if (length > kFsumLongRun) {
+    hipLaunchKernelGGL(hash_fsum_walk_long_kernel, dim3(256 * 8), dim3(64), 0, st, gs, vs, oks, length, sums,
+                       reinterpret_cast<long long*>(counts), null_seen, long_runs);
+    ARX_CHECK_LAUNCH("hash_fsum_walk_long_kernel");
+  }
+  return ARX_OK;
+}
+
+int arx_hash_sum_f64_merge(double* sums, int64_t* counts, uint32_t* null_seen, const double* other_sums, const int64_t* other_counts,
+                           const uint32_t* other_null_seen, const uint32_t* group_id_mapping, int64_t other_num_groups, void* stream) {
+  if (other_num_groups < 0) {
+    set_error("bad arguments to arx_hash_sum_f64_merge");
+    return ARX_INVALID;
+  }
+  if (other_num_groups == 0) return ARX_OK;
+  if (sums == nullptr || counts == nullptr || null_seen == nullptr || other_sums == nullptr || other_counts == nullptr ||
+      other_null_seen == nullptr || group_id_mapping == nullptr) {
+    set_error("arx_hash_sum_f64_merge: NULL buffer");
+    return ARX_INVALID;
+  }
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((other_num_groups + kBlock - 1) / kBlock, 256 * 8)));
+  hipLaunchKernelGGL(hash_fsum_merge_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), sums, reinterpret_cast<long long*>(counts),
+                     null_seen, other_sums, reinterpret_cast<const long long*>(other_counts), other_null_seen, group_id_mapping,
+                     other_num_groups);
+  ARX_CHECK_LAUNCH("hash_fsum_merge_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_mean_f64_finalize(const double* sums, const int64_t* counts, int64_t num_groups, double* out_means, void* stream) {
+  if (num_groups < 0 || (num_groups > 0 && (sums == nullptr || counts == nullptr || out_means == nullptr))) {
+    set_error("bad arguments to arx_hash_mean_f64_finalize");
+    return ARX_INVALID;
+  }
+  if (num_groups == 0) return ARX_OK;
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((num_groups + kBlock - 1) / kBlock, 256 * 8)));
+  hipLaunchKernelGGL(hash_fmean_finalize_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), sums,
+                     reinterpret_cast<const long long*>(counts), num_groups, out_means);
+  ARX_CHECK_LAUNCH("hash_fmean_finalize_kernel");
   return ARX_OK;
 }
 

@@ -867,6 +867,24 @@ int arx_group_first_rows(const uint32_t* group_ids, int64_t length, int64_t num_
                          void* stream);
 
 
+/* hash_sum / hash_mean of float32 / float64 values (num_type ARX_NUM_FLOAT32 / _FLOAT64) —
+ * GroupedReducingAggregator<FloatType / DoubleType, GroupedSumImpl | GroupedMeanImpl> (hash_aggregate_numeric.cc:44-152,
+ * 352-430): every row is added to its group's DOUBLE accumulator in ROW ORDER (Reduce = double(u) + double(v)); the value of
+ * such a sum depends on the order, so the device keeps it — the rows are stably sorted by group id and one thread walks each
+ * group's run from the group's running sum.  State: sums (double), counts, null_seen as for the integer kernels; batches
+ * continue where the last one stopped.  ws: arx_hash_sum_float_workspace_bytes(length).  A broadcast scalar: scalar_value,
+ * valid iff values->null_count == 0.  _merge: sums[mapping[g]] += other_sums[g] (each target once per call, :85-107);
+ * _mean_finalize: sums[g] / counts[g] (DoMean :381-385; 0 where the count is 0 — validity comes from
+ * arx_hash_sum_i64_finalize, which reads counts / null_seen only).  Asynchronous but for the sort's own synchronisation. */
+size_t arx_hash_sum_float_workspace_bytes(int64_t length);
+int arx_hash_sum_float_consume(const ArxSpan* values, int num_type, int values_is_scalar, double scalar_value,
+                               const uint32_t* group_ids, int64_t length, void* ws, size_t ws_bytes, double* sums,
+                               int64_t* counts, uint32_t* null_seen, void* stream);
+int arx_hash_sum_f64_merge(double* sums, int64_t* counts, uint32_t* null_seen, const double* other_sums,
+                           const int64_t* other_counts, const uint32_t* other_null_seen,
+                           const uint32_t* group_id_mapping, int64_t other_num_groups, void* stream);
+int arx_hash_mean_f64_finalize(const double* sums, const int64_t* counts, int64_t num_groups, double* out_means,
+                               void* stream);
 int arx_hash_sum_i64_merge(int64_t* sums, int64_t* counts, uint32_t* null_seen,
                            const int64_t* other_sums, const int64_t* other_counts,
                            const uint32_t* other_null_seen, const uint32_t* group_id_mapping,

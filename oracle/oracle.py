@@ -1072,3 +1072,24 @@ def delta_byte_array_decode(data: bytes):
         pos += n
         out.append(last)
     return out
+
+
+def hash_sum_float_row_order(values, valid, gids, num_groups, sums=None, counts=None, null_seen=None):
+    """GroupedReducingAggregator<FloatType / DoubleType, GroupedSumImpl>::Consume (hash_aggregate_numeric.cc:70-83) restated:
+    VisitGroupedValues walks the batch in ROW order, a valid value goes into its group's double accumulator with
+    Reduce = double(u) + double(v) (:196-206; the accumulator of float32 values is double too, FindAccumulatorType), a null
+    clears the group's no_nulls flag.  State arrays are continued when given (the next batch).  Pinned against
+    Table.group_by(..., use_threads=False) in tests (one thread = one state = this order)."""
+    sums = np.zeros(num_groups, dtype=np.float64) if sums is None else sums
+    counts = np.zeros(num_groups, dtype=np.int64) if counts is None else counts
+    null_seen = np.zeros(num_groups, dtype=bool) if null_seen is None else null_seen
+    v64 = np.asarray(values, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        for i in range(len(gids)):
+            g = int(gids[i])
+            if valid is None or valid[i]:
+                sums[g] = sums[g] + v64[i]
+                counts[g] += 1
+            else:
+                null_seen[g] = True
+    return sums, counts, null_seen

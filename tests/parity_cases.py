@@ -2431,3 +2431,98 @@ def check_list_take(amd, rng, n=2000, m=1700):
             assert (got[total.value * w: total.value * w + 16] == 0xCD).all()
             assert int(cnt.item()) == int(ok.sum())
     assert lib.arx_list_take_data(C.byref(vs), 6, m, ws.data_ptr(), ws_bytes, out_offs.data_ptr(), 1, data.data_ptr(), st) == _lib.ARX_INVALID
+
+
+def check_hash_sum_float(amd, rng, n=20000, groups=(1, 7, 300, 5000), dtypes=(np.float64, np.float32)):
+    """arx_hash_sum_float_consume / arx_hash_sum_f64_merge / arx_hash_mean_f64_finalize: the grouped float sum equals the
+    reference's BIT FOR BIT — row-order double accumulation per group — over several batches (the state continues), values
+    whose magnitudes differ by 30 orders (any other order of additions gives other bits), nulls at an offset, inf / NaN /
+    -0.0, a broadcast scalar; the oracle's restatement is pinned to Table.group_by(use_threads=False) on the same rows."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+    for dtype in dtypes:
+        num_type = 9 if np.dtype(dtype) == np.float64 else 8
+        for G in groups:
+            sums = torch.zeros(G, dtype=torch.float64, device=dev)
+            counts = torch.zeros(G, dtype=torch.int64, device=dev)
+            seen = torch.zeros(G, dtype=torch.int32, device=dev)
+            w_sums, w_counts, w_seen = np.zeros(G), np.zeros(G, dtype=np.int64), np.zeros(G, dtype=bool)
+            all_v, all_valid, all_g = [], [], []
+            for batch, nn in enumerate((n, 1, n // 3 + 5)):
+                voff = int(rng.integers(0, 70))
+                vals = (rng.standard_normal(voff + nn) * 10.0 ** rng.integers(-15, 15, voff + nn)).astype(dtype)
+                if nn > 50:
+                    vals[voff + 3], vals[voff + 11] = -0.0, np.float32(1e30) if dtype == np.float32 else 1e300
+                    if batch == 2 and G > 1:
+                        vals[voff + 17] = np.inf
+                valid = rng.random(nn) > (0.1 if batch != 1 else 0.0)
+                gids = rng.integers(0, G, nn).astype(np.uint32)
+                if G > 5 and nn > 4000:
+                    gids[rng.random(nn) < 0.6] = 3           # one long run (> 1024 rows: the wave-cooperative walker) among short ones
+                d_vals, d_valid, d_gids = to_device(vals, dev), to_device(_pack_bits(valid, voff), dev), to_device(gids.view(np.uint8), dev)
+                sp = _lib.ArxSpan(d_valid.data_ptr(), d_vals.data_ptr(), voff, nn, -1)
+                ws_bytes = lib.arx_hash_sum_float_workspace_bytes(nn)
+                ws = torch.zeros(ws_bytes + 256, dtype=torch.uint8, device=dev)
+                _lib.check(lib.arx_hash_sum_float_consume(C.byref(sp), num_type, 0, 0.0, d_gids.data_ptr(), nn, ws.data_ptr(), ws_bytes + 256,
+                                                          sums.data_ptr(), counts.data_ptr(), seen.data_ptr(), st))
+                O.hash_sum_float_row_order(vals[voff:], valid, gids, G, w_sums, w_counts, w_seen)
+                all_v.append(vals[voff:]); all_valid.append(valid); all_g.append(gids)
+                tag = f"hash_sum_float[{np.dtype(dtype).name},G={G},batch={batch}]"
+                got = sums.cpu().numpy()
+                same = (got.view(np.uint64) == w_sums.view(np.uint64)) | (np.isnan(got) & np.isnan(w_sums))
+                assert same.all(), (tag, np.nonzero(~same)[0][:5], got[~same][:3], w_sums[~same][:3])
+                assert_equal(counts.cpu().numpy(), w_counts, tag + " counts")
+                assert_equal(seen.cpu().numpy().astype(bool), w_seen, tag + " null_seen")
+            # a broadcast scalar: the same addend once per row, in row order
+            gids = rng.integers(0, G, 200).astype(np.uint32)
+            d_gids = to_device(gids.view(np.uint8), dev)
+            sp = _lib.ArxSpan(None, None, 0, 200, 0)
+            ws = torch.zeros(lib.arx_hash_sum_float_workspace_bytes(200) + 256, dtype=torch.uint8, device=dev)
+            _lib.check(lib.arx_hash_sum_float_consume(C.byref(sp), num_type, 1, 0.1, d_gids.data_ptr(), 200, ws.data_ptr(), ws.numel(),
+                                                      sums.data_ptr(), counts.data_ptr(), seen.data_ptr(), st))
+            O.hash_sum_float_row_order(np.full(200, 0.1), None, gids, G, w_sums, w_counts, w_seen)
+            got = sums.cpu().numpy()
+            assert ((got.view(np.uint64) == w_sums.view(np.uint64)) | (np.isnan(got) & np.isnan(w_sums))).all(), "scalar addend"
+            # mean = sum / count; merge into a second state through a mapping
+            means = torch.zeros(G, dtype=torch.float64, device=dev)
+            _lib.check(lib.arx_hash_mean_f64_finalize(sums.data_ptr(), counts.data_ptr(), G, means.data_ptr(), st))
+            with np.errstate(all="ignore"):
+                want_means = np.where(w_counts > 0, w_sums / np.maximum(w_counts, 1), 0.0)
+            gm = means.cpu().numpy()
+            assert ((gm.view(np.uint64) == want_means.view(np.uint64)) | (np.isnan(gm) & np.isnan(want_means))).all(), "means"
+            perm = rng.permutation(G + 3)[:G].astype(np.uint32)
+            t_sums = torch.full((G + 3,), 0.5, dtype=torch.float64, device=dev)
+            t_counts = torch.ones(G + 3, dtype=torch.int64, device=dev)
+            t_seen = torch.zeros(G + 3, dtype=torch.int32, device=dev)
+            d_map = to_device(perm.view(np.uint8), dev)
+            _lib.check(lib.arx_hash_sum_f64_merge(t_sums.data_ptr(), t_counts.data_ptr(), t_seen.data_ptr(), sums.data_ptr(), counts.data_ptr(),
+                                                  seen.data_ptr(), d_map.data_ptr(), G, st))
+            want_t = np.full(G + 3, 0.5)
+            with np.errstate(all="ignore"):
+                want_t[perm] = want_t[perm] + w_sums
+            gt = t_sums.cpu().numpy()
+            assert ((gt.view(np.uint64) == want_t.view(np.uint64)) | (np.isnan(gt) & np.isnan(want_t))).all(), "merge"
+            assert t_counts.cpu().numpy()[perm].tolist() == (w_counts + 1).tolist()
+            # the restatement itself against the reference: one thread, one batch = this row order
+            if pa is not None and G > 1:
+                v = np.concatenate(all_v)
+                ok = np.concatenate(all_valid)
+                g = np.concatenate(all_g)
+                t = pa.table({"k": pa.array(g), "v": pa.array(v, mask=~ok)})
+                ref = t.group_by("k", use_threads=False).aggregate([("v", "sum"), ("v", "mean")]).sort_by("k")
+                o_sums, o_counts, _ = O.hash_sum_float_row_order(v, ok, g, G)
+                keys = ref.column("k").to_numpy()
+                rs = ref.column("v_sum").to_numpy(zero_copy_only=False).astype(np.float64)
+                have = o_counts[keys] > 0
+                a, b = rs[have], o_sums[keys][have]
+                assert ((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))).all(), "oracle vs Table.group_by sum"
+                rm = ref.column("v_mean").to_numpy(zero_copy_only=False).astype(np.float64)[have]
+                with np.errstate(all="ignore"):
+                    om = (o_sums[keys] / np.maximum(o_counts[keys], 1))[have]
+                assert ((rm.view(np.uint64) == om.view(np.uint64)) | (np.isnan(rm) & np.isnan(om))).all(), "oracle vs Table.group_by mean"

@@ -992,6 +992,12 @@ def test_take_of_rows_of_any_width_and_of_lists_with_fixed_width_values(emu_ctx)
     P.check_list_take(emu_ctx, rng_for("listtake"), n=700, m=600)
 
 
+def test_grouped_float_sum_is_the_references_row_order_sum(emu_ctx):
+    """hash_sum / hash_mean of float32 / float64 values over dense group ids: the reference's row-order double accumulation
+    per group, bit for bit (stable sort by group id + one walker per group)."""
+    P.check_hash_sum_float(emu_ctx, rng_for("hashfsum"), n=3000, groups=(1, 7, 300))
+
+
 def test_buffer_copy(emu_ctx):
     P.check_buffer_copy(emu_ctx, rng_for("bufcopy"), 1)
 

@@ -3561,3 +3561,107 @@ def test_filter_and_take_of_fixed_size_list_and_list_on_device_arrays():
     code = f"ROOT = {ROOT!r}\n" + NESTED_SELECTION_SCRIPT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "NESTED_SELECTION_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+FLOAT_GROUPED_SUM_SCRIPT = textwrap.dedent(r"""
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    from pyarrow import acero
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    path = build_plugin()
+    # hash_sum / hash_mean of float32 / float64: GroupedReducingAggregator adds every row to its group's DOUBLE accumulator in row
+    # order (hash_aggregate_numeric.cc:70-83,196-206,352-430) — a sum whose bits depend on the order, so the comparison is with the
+    # reference on ONE thread (one state, batches in order); the values' magnitudes differ by 30 orders so that any other order of
+    # additions shows.  Under the stock GroupByNode (host and device-resident values) and in aggregate_rocm.
+    rng = np.random.default_rng(61)
+    n = SC(400_000)
+    k = pa.array(rng.integers(0, 300, n).astype(np.int32), mask=rng.random(n) < 0.01)
+    kw = pa.array(rng.integers(0, max(n // 3, 2), n))                      # many small groups
+    x = rng.standard_normal(n) * 10.0 ** rng.integers(-15, 15, n)
+    x[rng.random(n) < 0.03] = 0.0
+    x[rng.random(n) < 0.03] = -0.0
+    kk = np.asarray(k.fill_null(0))
+    xm = rng.random(n) < 0.15
+    xm[kk == 9] = True                                                      # a group of nulls only
+    f64 = pa.array(x, mask=xm)
+    f32 = pa.array((rng.standard_normal(n) * 10.0 ** rng.integers(-12, 12, n)).astype(np.float32), mask=rng.random(n) < 0.1)
+    big = rng.standard_normal(n) * 1e300
+    big[kk == 11] = 1e308                                                   # a group whose sum overflows to inf
+    f64b = pa.array(big)
+    t = pa.table({"k": k, "kw": kw, "f64": f64, "f32": f32, "big": f64b})
+    tc = pa.concat_tables([t.slice(0, n // 3), t.slice(n // 3, n // 5), t.slice(n // 3 + n // 5)])      # several batches, in order
+    strict = pc.ScalarAggregateOptions(skip_nulls=False, min_count=2)
+    aggs = [(c, fn, o) for c in ("f64", "f32", "big") for fn in ("sum", "mean") for o in (None, strict)]
+
+    def run(tab, key):
+        return tab.group_by(key, use_threads=False).aggregate(aggs).sort_by(key)
+
+    def same_bits(a, b, what):
+        a, b = (pa.concat_arrays(z.chunks) if isinstance(z, pa.ChunkedArray) else z for z in (a, b))
+        assert a.type == b.type == pa.float64(), (what, a.type, b.type)
+        assert a.is_null().equals(b.is_null()), (what, "validity", a.null_count, b.null_count)
+        x, y = (np.asarray(z.fill_null(0.0)).view(np.uint64) for z in (a, b))
+        bad = np.nonzero(x != y)[0]
+        assert len(bad) == 0, (what, len(bad), a.take(pa.array(bad[:4])), b.take(pa.array(bad[:4])))
+
+    want = {(name, key): run(tab, key) for name, tab in (("t", t), ("tc", tc)) for key in ("k", "kw")}
+    w0 = want[("t", "k")]
+    first = lambda tab, name: tab.column(tab.schema.names.index(name))      # (the same name twice: default and strict options)
+    assert np.isinf(first(w0, "big_sum")[w0.column("k").to_pylist().index(11)].as_py())
+    lib = ctypes.CDLL(path)
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    gpu0, stock0 = lib.arrow_amd_plugin_calls(b"hash_sum", 1), lib.arrow_amd_plugin_calls(b"hash_sum", 0)
+    for (name, key), w in want.items():
+        got = run(t if name == "t" else tc, key)
+        assert got.schema.equals(w.schema), (got.schema, w.schema)
+        assert got.column(key).equals(w.column(key))
+        for ci, col in enumerate(w.schema.names):
+            if col != key:
+                same_bits(got.column(ci), w.column(ci), (name, key, col, ci))
+    assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - gpu0 >= 4 * len(aggs), "the float sum vtables did not run on the device"
+    assert lib.arrow_amd_plugin_calls(b"hash_sum", 0) == stock0
+
+    # ---- device-resident value columns under the stock GroupByNode, and the aggregate_rocm node (host and device tables)
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(m) for m in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+    th = t.combine_chunks()
+    td_vals = pa.table({"k": th.column("k").chunk(0), **{c: to_device(th.column(c).chunk(0)) for c in ("f64", "f32", "big")}})
+    td_all = pa.table({c: to_device(th.column(c).chunk(0)) for c in ("k", "f64", "f32", "big")})
+    daggs = [(c, "hash_" + fn, o, "%s_%s" % (c, fn)) for c in ("f64", "f32", "big") for fn in ("sum", "mean") for o in (None,)]
+    def plan(tab, node="aggregate"):
+        return acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
+            acero.Declaration(node, acero.AggregateNodeOptions(daggs, keys=["k"]))]).to_table(use_threads=False).sort_by("k")
+    wh = want[("t", "k")]
+    for tab, node, what in ((td_vals, "aggregate", "device values, stock GroupByNode"), (th, "aggregate_rocm", "aggregate_rocm host"),
+                            (td_all, "aggregate_rocm", "aggregate_rocm device")):
+        g = plan(tab, node)
+        assert g.column("k").equals(wh.column("k")), what
+        for c in ("f64", "f32", "big"):
+            for fn in ("sum", "mean"):
+                same_bits(g.column("%s_%s" % (c, fn)), first(wh, "%s_%s" % (c, fn)), (what, c, fn))
+    assert lib.arrow_amd_plugin_calls(b"hash_sum", 0) == stock0, "a float sum reached a reference kernel"
+    print("FLOAT_GROUPED_SUM_OK")
+""")
+
+
+def test_hash_sum_and_mean_of_floats_are_the_references_row_order_sums():
+    """hash_sum / hash_mean of float32 / float64 — the reference's row-order double accumulation per group, bit for bit, under
+    the stock GroupByNode (host and device-resident values, several batches) and in aggregate_rocm."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + FLOAT_GROUPED_SUM_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "FLOAT_GROUPED_SUM_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

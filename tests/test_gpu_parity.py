@@ -1352,6 +1352,12 @@ def test_take_of_rows_of_any_width_and_of_lists_with_fixed_width_values(gpu_ctx)
     P.check_list_take(gpu_ctx, rng_for("listtake"), n=300000, m=250000)
 
 
+def test_grouped_float_sum_is_the_references_row_order_sum(gpu_ctx):
+    """hash_sum / hash_mean of float32 / float64 values over dense group ids: the reference's row-order double accumulation
+    per group, bit for bit (stable sort by group id + one walker per group)."""
+    P.check_hash_sum_float(gpu_ctx, rng_for("hashfsum"), n=300000, groups=(1, 7, 300, 100000))
+
+
 def test_buffer_copy(gpu_ctx):
     P.check_buffer_copy(gpu_ctx, rng_for("bufcopy"), 40)
 
