@@ -99,6 +99,26 @@ def test_sort_and_groupby_argument_checks(emu_ctx):
     assert lib.arx_groupby_export(state.data_ptr(), None, k32.data_ptr(), k32.data_ptr(), v64.data_ptr(), v64.data_ptr(),
                                   k32.data_ptr(), v64.data_ptr(), v64.data_ptr(), None) == INVALID   # extrema wanted, no minmax buffer
     del mm
+    # grouped float sums (row order) and rows / list elements of any width
+    gids, sums, cnts, seen = _buf(n * 4), _buf(64 * 8), _buf(64 * 8), _buf(64 * 4)
+    fv = _span(L, v64, length=n)
+    fneed = lib.arx_hash_sum_float_workspace_bytes(n)
+    fws = _buf(fneed + 512)
+    args = (gids.data_ptr(), n, fws.data_ptr(), fneed + 512, sums.data_ptr(), cnts.data_ptr(), seen.data_ptr(), None)
+    assert lib.arx_hash_sum_float_consume(C.byref(fv), 6, 0, 0.0, *args) == INVALID                       # int64 is not a float type
+    assert lib.arx_hash_sum_float_consume(C.byref(fv), 9, 0, 0.0, gids.data_ptr(), n, fws.data_ptr(), 64, sums.data_ptr(), cnts.data_ptr(),
+                                          seen.data_ptr(), None) == INVALID                             # short workspace
+    assert "workspace" in _err(lib)
+    assert lib.arx_hash_sum_float_consume(C.byref(fv), 9, 0, 0.0, None, n, fws.data_ptr(), fneed + 512, sums.data_ptr(), cnts.data_ptr(),
+                                          seen.data_ptr(), None) == INVALID
+    assert lib.arx_hash_sum_float_consume(C.byref(fv), 9, 0, 0.0, gids.data_ptr(), 0, None, 0, None, None, None, None) == OK
+    assert lib.arx_hash_sum_float_consume(C.byref(fv), 9, 0, 0.0, *args) == OK                             # all rows in group 0
+    assert lib.arx_hash_sum_float_workspace_bytes(0) == 0
+    assert lib.arx_hash_sum_f64_merge(sums.data_ptr(), cnts.data_ptr(), seen.data_ptr(), None, cnts.data_ptr(), seen.data_ptr(),
+                                      gids.data_ptr(), 4, None) == INVALID
+    assert lib.arx_hash_sum_f64_merge(None, None, None, None, None, None, None, 0, None) == OK
+    assert lib.arx_hash_mean_f64_finalize(sums.data_ptr(), None, 4, sums.data_ptr(), None) == INVALID
+    assert lib.arx_hash_mean_f64_finalize(None, None, 0, None, None) == OK
 
 
 def test_scalar_kernel_argument_checks(emu_ctx):
