@@ -3665,3 +3665,87 @@ def test_hash_sum_and_mean_of_floats_are_the_references_row_order_sums():
     code = f"ROOT = {ROOT!r}\n" + FLOAT_GROUPED_SUM_SCRIPT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "FLOAT_GROUPED_SUM_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+COUNT_DISTINCT_SCRIPT = textwrap.dedent(r"""
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    from pyarrow import acero
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    path = build_plugin()
+    # hash_count_distinct in aggregate_rocm: GroupedCountDistinctImpl (kernels/hash_aggregate.cc:1400-1478) is a Grouper over
+    # (value, group id) pairs whose uniques are counted per group — the device Grouper does the same over the staged value column
+    # and the rows' group ids; the three CountOptions modes; -0.0 / 0.0 and NaN payloads are distinct by their bytes, as there
+    rng = np.random.default_rng(71)
+    n = SC(300_000)
+    f = (rng.integers(0, 9, n).astype(np.float64) / 4)
+    f[rng.random(n) < 0.05] = -0.0
+    f[rng.random(n) < 0.05] = np.nan
+    t = pa.table({
+        "k": pa.array(rng.integers(0, 300, n).astype(np.int32), mask=rng.random(n) < 0.02),
+        "k2": pa.array(rng.integers(0, 3, n).astype(np.int8)),
+        "s": pa.array(["key%d" % i for i in rng.integers(0, 50, n)], pa.utf8()),
+        "i64": pa.array(rng.integers(0, 40, n), mask=rng.random(n) < 0.1),
+        "wide": pa.array(rng.integers(-2**62, 2**62, n)),                  # almost every pair distinct
+        "i8": pa.array(rng.integers(-3, 3, n).astype(np.int8), mask=rng.random(n) < 0.3),
+        "f64": pa.array(f, mask=rng.random(n) < 0.05),
+        "d32": pa.array(rng.integers(0, 5, n).astype(np.int32), pa.date32()),
+        "ts": pa.array(rng.integers(0, 7, n) * 10**9, pa.timestamp("ns")),
+    })
+    vals = ["i64", "wide", "i8", "f64", "d32", "ts"]
+    aggs = [(c, "hash_count_distinct", pc.CountOptions(mode=m), "%s_%s" % (c, m)) for c in vals for m in ("only_valid", "only_null", "all")]
+    aggs += [("i64", "hash_sum", None, "sum"), ([], "hash_count_all", None, "rows")]
+    def plan(tab, node, keys):
+        return acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
+            acero.Declaration(node, acero.AggregateNodeOptions(aggs, keys=keys))]).to_table(use_threads=False).sort_by([(k, "ascending") for k in keys])
+    key_sets = (["k"], ["k2", "k"], ["s"])
+    want = {tuple(ks): plan(t, "aggregate", ks) for ks in key_sets}
+    lib = ctypes.CDLL(path)
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(m) for m in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+    td = pa.Table.from_batches([pa.RecordBatch.from_arrays([to_device(c.combine_chunks().column(j).chunk(0)) for j in range(t.num_columns)],
+                                                           names=t.schema.names)
+                                for c in (t.slice(0, n // 2 + 3), t.slice(n // 2 + 3))])
+    g0 = lib.arrow_amd_plugin_calls(b"hash_sum", 1)
+    for ks in key_sets:
+        w = want[tuple(ks)]
+        for tab, what in ((t, "host"), (td, "device")):
+            g = plan(tab, "aggregate_rocm", ks)
+            assert g.schema.equals(w.schema), (g.schema, w.schema)
+            for ci, name in enumerate(w.schema.names):
+                assert g.column(ci).equals(w.column(ci)), (what, ks, name, g.column(ci).slice(0, 6), w.column(ci).slice(0, 6))
+    assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - g0 >= 2 * len(key_sets)
+    for bad, text in ((pa.table({"k": [1, 2], "v": ["a", "b"]}), "fixed-width"), (pa.table({"k": [1, 2], "v": pa.array([1, 2], pa.decimal128(20, 2))}), "fixed-width")):
+        try:
+            acero.Declaration.from_sequence([
+                acero.Declaration("table_source", acero.TableSourceNodeOptions(bad)),
+                acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_count_distinct", None, "c")], keys=["k"]))]).to_table()
+            raise SystemExit("expected NotImplemented")
+        except pa.ArrowNotImplementedError as e:
+            assert text in str(e), e
+    print("COUNT_DISTINCT_OK")
+""")
+
+
+def test_hash_count_distinct_in_aggregate_rocm():
+    """hash_count_distinct through aggregate_rocm (a second device Grouper over (value, group id) pairs), host and
+    device-resident tables, the three CountOptions modes, fixed-width value types; equal to the reference's GroupByNode."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + COUNT_DISTINCT_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "COUNT_DISTINCT_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

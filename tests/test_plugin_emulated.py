@@ -160,3 +160,7 @@ def test_filter_and_take_of_fixed_size_list_and_list_on_device_arrays_emulated()
 
 def test_hash_sum_and_mean_of_floats_are_the_references_row_order_sums_emulated():
     _run(G.FLOAT_GROUPED_SUM_SCRIPT, "FLOAT_GROUPED_SUM_OK", 0.02)
+
+
+def test_hash_count_distinct_in_aggregate_rocm_emulated():
+    _run(G.COUNT_DISTINCT_SCRIPT, "COUNT_DISTINCT_OK", 0.02)
