@@ -432,7 +432,7 @@ GENERAL_GROUP_BY_SCRIPT = textwrap.dedent(r'''
     assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - g0 >= 3 * len(plans), "aggregate_rocm did not run the device Grouper"
     # value types it does not take: refused by name (key rows wider than one 16-byte Grouper table go through a chain of
     # tables: tests/test_gpu_group_keys.py)
-    for keys, aggs, needle in ((["a", "b"], [("flag", "hash_sum", None, "s")], "integer values"),):
+    for keys, aggs, needle in ((["a", "b"], [("flag", "hash_sum", None, "s")], "integer or floating-point values"),):
         try:
             run(t, "aggregate_rocm", keys, aggs)
             raise SystemExit("aggregate_rocm accepted " + str(keys))
