@@ -885,6 +885,22 @@ int arx_hash_sum_f64_merge(double* sums, int64_t* counts, uint32_t* null_seen, c
                            const uint32_t* group_id_mapping, int64_t other_num_groups, void* stream);
 int arx_hash_mean_f64_finalize(const double* sums, const int64_t* counts, int64_t num_groups, double* out_means,
                                void* stream);
+/* hash_sum of decimal128 values (16 bytes a value, little-endian two's complement) —
+ * GroupedReducingAggregator<Decimal128Type, GroupedSumImpl> (hash_aggregate_numeric.cc:44-152,189-215): a Decimal128 per
+ * group, Reduce = BasicDecimal128 addition, i.e. modulo 2^128 — associative and commutative, kept with atomics: the low word
+ * first, the carry (seen by exactly one row per wrap) into the high word's addend.  State: sums_lo / sums_hi / counts /
+ * null_seen, zero-initialised and grown by the caller; a broadcast scalar: (scalar_lo, scalar_hi), valid iff
+ * values->null_count == 0.  _merge: each target group once per call (:85-107).  arx_dec128_pack: (lo, hi) -> 16-byte values
+ * (the output's type is the input's widened to precision 38, :165-167; validity from arx_hash_sum_i64_finalize).
+ * Asynchronous. */
+int arx_hash_sum_dec128_consume(const ArxSpan* values, int values_is_scalar, uint64_t scalar_lo, uint64_t scalar_hi,
+                                const uint32_t* group_ids, int64_t length, uint64_t* sums_lo, uint64_t* sums_hi,
+                                int64_t* counts, uint32_t* null_seen, void* stream);
+int arx_hash_sum_dec128_merge(uint64_t* sums_lo, uint64_t* sums_hi, int64_t* counts, uint32_t* null_seen,
+                              const uint64_t* other_lo, const uint64_t* other_hi, const int64_t* other_counts,
+                              const uint32_t* other_null_seen, const uint32_t* group_id_mapping,
+                              int64_t other_num_groups, void* stream);
+int arx_dec128_pack(const uint64_t* lo, const uint64_t* hi, int64_t n, void* out_values, void* stream);
 int arx_hash_sum_i64_merge(int64_t* sums, int64_t* counts, uint32_t* null_seen,
                            const int64_t* other_sums, const int64_t* other_counts,
                            const uint32_t* other_null_seen, const uint32_t* group_id_mapping,

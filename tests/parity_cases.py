@@ -2526,3 +2526,92 @@ def check_hash_sum_float(amd, rng, n=20000, groups=(1, 7, 300, 5000), dtypes=(np
                 with np.errstate(all="ignore"):
                     om = (o_sums[keys] / np.maximum(o_counts[keys], 1))[have]
                 assert ((rm.view(np.uint64) == om.view(np.uint64)) | (np.isnan(rm) & np.isnan(om))).all(), "oracle vs Table.group_by mean"
+
+
+def check_hash_sum_dec128(amd, rng, n=20000, groups=(1, 13, 4000)):
+    """arx_hash_sum_dec128_consume / _merge / arx_dec128_pack: per-group sums of 128-bit two's-complement values modulo 2^128
+    (BasicDecimal128 addition) — words that make the low half wrap on most additions, negative values, a hot group, nulls at an
+    offset, several batches, a broadcast scalar — against Python integers; and Table.group_by's decimal128 sum on the same rows."""
+    import decimal
+
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+    M = 1 << 128
+    for G in groups:
+        lo = torch.zeros(G, dtype=torch.int64, device=dev)
+        hi = torch.zeros(G, dtype=torch.int64, device=dev)
+        counts = torch.zeros(G, dtype=torch.int64, device=dev)
+        seen = torch.zeros(G, dtype=torch.int32, device=dev)
+        want = [0] * G
+        w_counts, w_seen = np.zeros(G, dtype=np.int64), np.zeros(G, dtype=bool)
+        rows = []
+        for batch, nn in enumerate((n, 1, n // 2 + 3)):
+            voff = int(rng.integers(0, 70))
+            words = rng.integers(0, 2**64, (voff + nn, 2), dtype=np.uint64)          # [lo, hi]
+            if batch == 0:
+                words[voff:, 1] = np.where(rng.random(nn) < 0.5, 0, 2**64 - 1).astype(np.uint64)   # small magnitudes of both signs
+            valid = rng.random(nn) > 0.1
+            gids = rng.integers(0, G, nn).astype(np.uint32)
+            if G > 5:
+                gids[rng.random(nn) < 0.4] = 2                                     # a hot group
+            d_vals, d_valid, d_gids = to_device(words.view(np.uint8).reshape(-1), dev), to_device(_pack_bits(valid, voff), dev), to_device(gids.view(np.uint8), dev)
+            sp = _lib.ArxSpan(d_valid.data_ptr(), d_vals.data_ptr(), voff, nn, -1)
+            _lib.check(lib.arx_hash_sum_dec128_consume(C.byref(sp), 0, 0, 0, d_gids.data_ptr(), nn, lo.data_ptr(), hi.data_ptr(), counts.data_ptr(),
+                                                       seen.data_ptr(), st))
+            for i in range(nn):
+                g = int(gids[i])
+                if valid[i]:
+                    want[g] = (want[g] + int(words[voff + i, 0]) + (int(words[voff + i, 1]) << 64)) % M
+                    w_counts[g] += 1
+                else:
+                    w_seen[g] = True
+            rows.append((words[voff:], valid, gids))
+            got = [(int(a) % 2**64) + ((int(b) % 2**64) << 64) for a, b in zip(lo.cpu().numpy().tolist(), hi.cpu().numpy().tolist())]
+            assert got == want, (G, batch, [i for i in range(G) if got[i] != want[i]][:4])
+            assert_equal(counts.cpu().numpy(), w_counts, f"dec128 counts G={G}")
+            assert_equal(seen.cpu().numpy().astype(bool), w_seen, f"dec128 null_seen G={G}")
+        # a broadcast scalar (-1: every addition of the low word wraps), 300 rows
+        gids = rng.integers(0, G, 300).astype(np.uint32)
+        d_gids = to_device(gids.view(np.uint8), dev)
+        sp = _lib.ArxSpan(None, None, 0, 300, 0)
+        _lib.check(lib.arx_hash_sum_dec128_consume(C.byref(sp), 1, 2**64 - 1, 2**64 - 1, d_gids.data_ptr(), 300, lo.data_ptr(), hi.data_ptr(),
+                                                   counts.data_ptr(), seen.data_ptr(), st))
+        for g in gids.tolist():
+            want[g] = (want[g] - 1) % M
+        got = [(int(a) % 2**64) + ((int(b) % 2**64) << 64) for a, b in zip(lo.cpu().numpy().tolist(), hi.cpu().numpy().tolist())]
+        assert got == want, "scalar addend"
+        # merge through a mapping, then pack
+        perm = rng.permutation(G + 3)[:G].astype(np.uint32)
+        t_lo = torch.full((G + 3,), -1, dtype=torch.int64, device=dev)
+        t_hi = torch.full((G + 3,), 7, dtype=torch.int64, device=dev)
+        t_counts = torch.ones(G + 3, dtype=torch.int64, device=dev)
+        t_seen = torch.zeros(G + 3, dtype=torch.int32, device=dev)
+        d_map = to_device(perm.view(np.uint8), dev)
+        _lib.check(lib.arx_hash_sum_dec128_merge(t_lo.data_ptr(), t_hi.data_ptr(), t_counts.data_ptr(), t_seen.data_ptr(), lo.data_ptr(), hi.data_ptr(),
+                                                 counts.data_ptr(), seen.data_ptr(), d_map.data_ptr(), G, st))
+        base = (2**64 - 1) + (7 << 64)
+        want_t = [base] * (G + 3)
+        for g in range(G):
+            want_t[int(perm[g])] = (base + want[g]) % M
+        packed = torch.zeros((G + 3) * 16, dtype=torch.uint8, device=dev)
+        _lib.check(lib.arx_dec128_pack(t_lo.data_ptr(), t_hi.data_ptr(), G + 3, packed.data_ptr(), st))
+        pw = packed.cpu().numpy().view(np.uint64).reshape(-1, 2)
+        assert [int(a) + (int(b) << 64) for a, b in pw.tolist()] == want_t, "merge + pack"
+        # the reference on the same kind of rows (values small enough for precision 38)
+        if pa is not None and G > 1:
+            words, valid, gids = rows[0]
+            ints = [int(w[0]) - (1 << 64) * (1 if w[1] else 0) for w in words.tolist()]          # hi is 0 or all ones in batch 0
+            arr = pa.array([decimal.Decimal(x).scaleb(-3) if ok else None for x, ok in zip(ints, valid)], pa.decimal128(25, 3))
+            ref = pa.table({"k": pa.array(gids), "v": arr}).group_by("k", use_threads=False).aggregate([("v", "sum")]).sort_by("k")
+            sums = {}
+            for x, ok, g in zip(ints, valid, gids.tolist()):
+                if ok:
+                    sums[g] = sums.get(g, 0) + x
+            for k, v in zip(ref.column("k").to_pylist(), ref.column("v_sum").to_pylist()):
+                assert (v is None and k not in sums) or int(v.scaleb(3)) == sums[k], (k, v)

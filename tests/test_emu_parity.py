@@ -998,6 +998,11 @@ def test_grouped_float_sum_is_the_references_row_order_sum(emu_ctx):
     P.check_hash_sum_float(emu_ctx, rng_for("hashfsum"), n=3000, groups=(1, 7, 300))
 
 
+def test_grouped_decimal128_sum(emu_ctx):
+    """hash_sum of decimal128 values over dense group ids: 128-bit sums modulo 2^128 kept with two atomics per row."""
+    P.check_hash_sum_dec128(emu_ctx, rng_for("hashdec"), n=3000, groups=(1, 13, 400))
+
+
 def test_buffer_copy(emu_ctx):
     P.check_buffer_copy(emu_ctx, rng_for("bufcopy"), 1)
 

@@ -3749,3 +3749,97 @@ def test_hash_count_distinct_in_aggregate_rocm():
     code = f"ROOT = {ROOT!r}\n" + COUNT_DISTINCT_SCRIPT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "COUNT_DISTINCT_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+DECIMAL_SUM_SCRIPT = textwrap.dedent(r"""
+    import ctypes, decimal, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    from pyarrow import acero
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    path = build_plugin()
+    # hash_sum of decimal128 columns: GroupedSumImpl<Decimal128Type> keeps a Decimal128 per group, adds modulo 2^128 and widens the
+    # output to precision 38 (hash_aggregate_numeric.cc:44-215) — under the stock GroupByNode (host and device-resident values,
+    # several batches, threads: the sum does not depend on the order) and in aggregate_rocm
+    rng = np.random.default_rng(83)
+    n = SC(300_000)
+    def dec(lo, hi, scale, prec, null_p):
+        ints = rng.integers(lo, hi, n)
+        return pa.array([decimal.Decimal(int(x)).scaleb(-scale) for x in ints], pa.decimal128(prec, scale), mask=rng.random(n) < null_p)
+    big = [decimal.Decimal(int(a) * 10**18 + int(b)).scaleb(-4) for a, b in zip(rng.integers(-10**15, 10**15, n), rng.integers(0, 10**18, n))]
+    kk = rng.integers(0, 300, n)
+    pmask = rng.random(n) < 0.15
+    pmask[kk == 9] = True                                                 # a group of nulls only
+    t = pa.table({
+        "k": pa.array(kk.astype(np.int32), mask=rng.random(n) < 0.01),
+        "kw": pa.array(rng.integers(0, max(n // 3, 2), n)),
+        "price": pa.array([decimal.Decimal(int(x)).scaleb(-2) for x in rng.integers(-10**11, 10**11, n)], pa.decimal128(15, 2), mask=pmask),
+        "big": pa.array(big, pa.decimal128(38, 4)),                      # group sums beyond 64 bits
+        "tiny": dec(-5, 5, 0, 3, 0.0),
+    })
+    tc = pa.concat_tables([t.slice(0, n // 3), t.slice(n // 3, n // 5), t.slice(n // 3 + n // 5)])
+    strict = pc.ScalarAggregateOptions(skip_nulls=False, min_count=2)
+    aggs = [(c, "sum", o) for c in ("price", "big", "tiny") for o in (None, strict)]
+    def run(tab, key, threads):
+        return tab.group_by(key, use_threads=threads).aggregate(aggs).sort_by(key)
+    want = {(name, key): run(tab, key, False) for name, tab in (("t", t), ("tc", tc)) for key in ("k", "kw")}
+    assert want[("t", "k")].schema.field(1).type == pa.decimal128(38, 2)
+    lib = ctypes.CDLL(path)
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_calls.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    gpu0, stock0 = lib.arrow_amd_plugin_calls(b"hash_sum", 1), lib.arrow_amd_plugin_calls(b"hash_sum", 0)
+    for (name, key), w in want.items():
+        for threads in (False, True):
+            got = run(t if name == "t" else tc, key, threads)
+            assert got.schema.equals(w.schema), (got.schema, w.schema)
+            for ci in range(w.num_columns):
+                assert got.column(ci).equals(w.column(ci)), (name, key, threads, w.schema.names[ci], got.column(ci).slice(0, 4), w.column(ci).slice(0, 4))
+    assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - gpu0 >= 8 * len(aggs), "the decimal sum vtable did not run on the device"
+    assert lib.arrow_amd_plugin_calls(b"hash_sum", 0) == stock0
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(m) for m in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+    th = t.combine_chunks()
+    td_vals = pa.table({"k": th.column("k").chunk(0), **{c: to_device(th.column(c).chunk(0)) for c in ("price", "big", "tiny")}})
+    td_all = pa.table({c: to_device(th.column(c).chunk(0)) for c in ("k", "price", "big", "tiny")})
+    daggs = [(c, "hash_sum", None, c + "_sum") for c in ("price", "big", "tiny")]
+    def plan(tab, node):
+        return acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
+            acero.Declaration(node, acero.AggregateNodeOptions(daggs, keys=["k"]))]).to_table(use_threads=False).sort_by("k")
+    wh = plan(th, "aggregate")
+    for tab, node, what in ((td_vals, "aggregate", "device values, stock GroupByNode"), (th, "aggregate_rocm", "aggregate_rocm host"),
+                            (td_all, "aggregate_rocm", "aggregate_rocm device")):
+        g = plan(tab, node)
+        assert g.schema.equals(wh.schema), (what, g.schema, wh.schema)
+        for c in wh.schema.names:
+            assert g.column(c).equals(wh.column(c)), (what, c, g.column(c).slice(0, 4), wh.column(c).slice(0, 4))
+    assert lib.arrow_amd_plugin_calls(b"hash_sum", 0) == stock0, "a decimal sum reached a reference kernel"
+    try:
+        acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(th)),
+            acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("price", "hash_mean", None, "m")], keys=["k"]))]).to_table()
+        raise SystemExit("expected NotImplemented")
+    except pa.ArrowNotImplementedError as e:
+        assert "hash_mean of decimal128" in str(e), e
+    print("DECIMAL_SUM_OK")
+""")
+
+
+def test_hash_sum_of_decimal128():
+    """hash_sum of decimal128 columns — 128-bit sums modulo 2^128 on the device, the output widened to precision 38 — under the
+    stock GroupByNode (host and device-resident values, batches, threads) and in aggregate_rocm."""
+    pytest.importorskip("pyarrow")
+    code = f"ROOT = {ROOT!r}\n" + DECIMAL_SUM_SCRIPT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "DECIMAL_SUM_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

@@ -1358,6 +1358,11 @@ def test_grouped_float_sum_is_the_references_row_order_sum(gpu_ctx):
     P.check_hash_sum_float(gpu_ctx, rng_for("hashfsum"), n=300000, groups=(1, 7, 300, 100000))
 
 
+def test_grouped_decimal128_sum(gpu_ctx):
+    """hash_sum of decimal128 values over dense group ids: 128-bit sums modulo 2^128 kept with two atomics per row."""
+    P.check_hash_sum_dec128(gpu_ctx, rng_for("hashdec"), n=60000, groups=(1, 13, 4000))
+
+
 def test_buffer_copy(gpu_ctx):
     P.check_buffer_copy(gpu_ctx, rng_for("bufcopy"), 40)
 

@@ -164,3 +164,7 @@ def test_hash_sum_and_mean_of_floats_are_the_references_row_order_sums_emulated(
 
 def test_hash_count_distinct_in_aggregate_rocm_emulated():
     _run(G.COUNT_DISTINCT_SCRIPT, "COUNT_DISTINCT_OK", 0.02)
+
+
+def test_hash_sum_of_decimal128_emulated():
+    _run(G.DECIMAL_SUM_SCRIPT, "DECIMAL_SUM_OK", 0.02)
