@@ -3764,6 +3764,9 @@ DECIMAL_SUM_SCRIPT = textwrap.dedent(r"""
     else:
         from arrow_amd.plugin_build import build_plugin
     path = build_plugin()
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # (the emulated device is one fiber scheduler: one Acero thread)
+        pa.set_cpu_count(1)
+        pa.set_io_thread_count(1)
     # hash_sum of decimal128 columns: GroupedSumImpl<Decimal128Type> keeps a Decimal128 per group, adds modulo 2^128 and widens the
     # output to precision 38 (hash_aggregate_numeric.cc:44-215) — under the stock GroupByNode (host and device-resident values,
     # several batches, threads: the sum does not depend on the order) and in aggregate_rocm
