@@ -3,8 +3,8 @@
 Every call runs in a forked child (a CPU kernel handed HBM pointers dies with SIGSEGV inside libarrow), so one run prints
 the whole map: `ok`, `refused:<error class>` or `CRASH(sig N)` per pair.  Round 3 used it to find the pairs that are now
 served on the device (divide on every numeric type, 8- / 16-bit sort keys, uint64 extrema, mean, is_valid / is_null) or
-refused by the guards of plugin/device_guard.inc; what still crashes is outside the functions the shim extends (fill_null,
-the scalar aggregates of float / boolean / decimal / temporal columns).
+refused by the guards of plugin/device_guard.inc; round 4 closed the rest of its list (fill_null, the scalar aggregates of
+float / boolean / temporal columns: served; decimals: refused by name) — the map printed at the end of round 4 has no CRASH cell.
 
     ARROW_AMD_PLUGIN_EMULATED=1 python scripts/sweep_device_types.py [function ...]     # GPU-less: the emulated shim
     python scripts/sweep_device_types.py                                               # on an MI355X: the real one
