@@ -901,6 +901,17 @@ int arx_hash_sum_dec128_merge(uint64_t* sums_lo, uint64_t* sums_hi, int64_t* cou
                               const uint32_t* other_null_seen, const uint32_t* group_id_mapping,
                               int64_t other_num_groups, void* stream);
 int arx_dec128_pack(const uint64_t* lo, const uint64_t* hi, int64_t n, void* out_values, void* stream);
+/* hash_min / hash_max of decimal128 values — GroupedMinMaxImpl<Decimal128Type> (kernels/hash_aggregate.cc:330-419): per group
+ * the smallest and largest value in signed 128-bit order.  No 128-bit atomics: the rows are stably sorted by group id, every
+ * group is one run, one owner per group (a thread, or a wave for runs > 1024 rows) folds the run into the state.  State the
+ * caller owns: mins / maxs (16 bytes a group, any content), seen (zeroed: bit 0 = a null hit the group, bit 1 = the group has a
+ * value and mins / maxs hold its extrema); ws: arx_hash_minmax_dec128_workspace_bytes(length).  _finalize: validity =
+ * has a value && (skip_nulls || no null) (:401-419), valid_count (device, caller-zeroed, may be NULL) += popcount. */
+size_t arx_hash_minmax_dec128_workspace_bytes(int64_t length);
+int arx_hash_minmax_dec128_consume(const ArxSpan* values, const uint32_t* group_ids, int64_t length, void* ws, size_t ws_bytes,
+                                   void* mins, void* maxs, uint32_t* seen, void* stream);
+int arx_hash_minmax_dec128_finalize(const uint32_t* seen, int64_t num_groups, int skip_nulls, void* out_validity,
+                                    int64_t* valid_count, void* stream);
 int arx_hash_sum_i64_merge(int64_t* sums, int64_t* counts, uint32_t* null_seen,
                            const int64_t* other_sums, const int64_t* other_counts,
                            const uint32_t* other_null_seen, const uint32_t* group_id_mapping,

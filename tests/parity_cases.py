@@ -2615,3 +2615,66 @@ def check_hash_sum_dec128(amd, rng, n=20000, groups=(1, 13, 4000)):
                     sums[g] = sums.get(g, 0) + x
             for k, v in zip(ref.column("k").to_pylist(), ref.column("v_sum").to_pylist()):
                 assert (v is None and k not in sums) or int(v.scaleb(3)) == sums[k], (k, v)
+
+
+def check_hash_minmax_dec128(amd, rng, n=20000, groups=(1, 13, 4000)):
+    """arx_hash_minmax_dec128_consume / _finalize: per-group extrema of 128-bit two's-complement values in signed order —
+    values of both signs whose halves disagree in order, a long run (the wave walker), all-null groups, nulls at an offset,
+    several batches continuing the state — against Python integers."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+
+    def signed(lo, hi):
+        x = int(lo) + (int(hi) << 64)
+        return x - (1 << 128) if x >= (1 << 127) else x
+
+    for G in groups:
+        mins = torch.full((G * 2,), 0x5A5A5A5A, dtype=torch.int64, device=dev)       # (any content: `seen` says what holds a value)
+        maxs = torch.full((G * 2,), 0x5A5A5A5A, dtype=torch.int64, device=dev)
+        seen = torch.zeros(G, dtype=torch.int32, device=dev)
+        w_min, w_max, w_null = [None] * G, [None] * G, np.zeros(G, dtype=bool)
+        for batch, nn in enumerate((n, 1, n // 2 + 3)):
+            voff = int(rng.integers(0, 70))
+            words = rng.integers(0, 2**64, (voff + nn, 2), dtype=np.uint64)          # [lo, hi]
+            words[voff:, 1] = rng.choice(np.array([0, 1, 2**63 - 1, 2**63, 2**64 - 1, 2**64 - 2], dtype=np.uint64), nn)   # few high words: the low word decides
+            valid = rng.random(nn) > 0.1
+            gids = rng.integers(0, G, nn).astype(np.uint32)
+            if G > 5:
+                gids[rng.random(nn) < 0.4] = 2                                     # a long run
+                valid[gids == 4] = False                                          # a group of nulls only
+            d_vals, d_valid, d_gids = to_device(words.view(np.uint8).reshape(-1), dev), to_device(_pack_bits(valid, voff), dev), to_device(gids.view(np.uint8), dev)
+            sp = _lib.ArxSpan(d_valid.data_ptr(), d_vals.data_ptr(), voff, nn, -1)
+            ws_bytes = lib.arx_hash_minmax_dec128_workspace_bytes(nn)
+            ws = torch.zeros(ws_bytes + 256, dtype=torch.uint8, device=dev)
+            _lib.check(lib.arx_hash_minmax_dec128_consume(C.byref(sp), d_gids.data_ptr(), nn, ws.data_ptr(), ws_bytes + 256, mins.data_ptr(),
+                                                          maxs.data_ptr(), seen.data_ptr(), st))
+            for i in range(nn):
+                g = int(gids[i])
+                if valid[i]:
+                    x = signed(words[voff + i, 0], words[voff + i, 1])
+                    w_min[g] = x if w_min[g] is None else min(w_min[g], x)
+                    w_max[g] = x if w_max[g] is None else max(w_max[g], x)
+                else:
+                    w_null[g] = True
+            gs, gmn, gmx = seen.cpu().numpy(), mins.cpu().numpy().view(np.uint64).reshape(-1, 2), maxs.cpu().numpy().view(np.uint64).reshape(-1, 2)
+            for g in range(G):
+                assert bool(gs[g] & 2) == (w_min[g] is not None) and bool(gs[g] & 1) == bool(w_null[g]), (G, batch, g, int(gs[g]))
+                if w_min[g] is not None:
+                    assert signed(*gmn[g]) == w_min[g] and signed(*gmx[g]) == w_max[g], (G, batch, g)
+        for skip in (1, 0):
+            bits = torch.full((((G + 63) // 64) * 8 + 8,), 0xFF, dtype=torch.uint8, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+            _lib.check(lib.arx_hash_minmax_dec128_finalize(seen.data_ptr(), G, skip, bits.data_ptr(), cnt.data_ptr(), st))
+            want = np.array([w_min[g] is not None and (skip == 1 or not w_null[g]) for g in range(G)])
+            got = np.unpackbits(bits.cpu().numpy()[: ((G + 63) // 64) * 8], bitorder="little")
+            assert_equal(got[:G].astype(bool), want, f"dec128 minmax validity G={G} skip={skip}")
+            assert not got[G:].any() and int(cnt.item()) == int(want.sum())
+    assert lib.arx_hash_minmax_dec128_workspace_bytes(0) == 0
+    assert lib.arx_hash_minmax_dec128_consume(C.byref(sp), d_gids.data_ptr(), nn, ws.data_ptr(), 16, mins.data_ptr(), maxs.data_ptr(), seen.data_ptr(),
+                                              st) == _lib.ARX_INVALID

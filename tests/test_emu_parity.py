@@ -999,8 +999,10 @@ def test_grouped_float_sum_is_the_references_row_order_sum(emu_ctx):
 
 
 def test_grouped_decimal128_sum(emu_ctx):
-    """hash_sum of decimal128 values over dense group ids: 128-bit sums modulo 2^128 kept with two atomics per row."""
+    """hash_sum / hash_min / hash_max of decimal128 values over dense group ids: 128-bit sums modulo 2^128 kept with two atomics
+    per row; extrema in signed 128-bit order by one owner per group over the rows sorted by group id."""
     P.check_hash_sum_dec128(emu_ctx, rng_for("hashdec"), n=3000, groups=(1, 13, 400))
+    P.check_hash_minmax_dec128(emu_ctx, rng_for("hashdecmm"), n=3000, groups=(1, 13, 400))
 
 
 def test_buffer_copy(emu_ctx):

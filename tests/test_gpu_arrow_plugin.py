@@ -3828,6 +3828,22 @@ DECIMAL_SUM_SCRIPT = textwrap.dedent(r"""
         for c in wh.schema.names:
             assert g.column(c).equals(wh.column(c)), (what, c, g.column(c).slice(0, 4), wh.column(c).slice(0, 4))
     assert lib.arrow_amd_plugin_calls(b"hash_sum", 0) == stock0, "a decimal sum reached a reference kernel"
+    # hash_min / hash_max of decimal128 in aggregate_rocm (GroupedMinMaxImpl<Decimal128Type>: signed 128-bit order; the rows
+    # sorted by group id, one owner per group), default and strict options, host and device tables, two key shapes
+    mm = [(c, "hash_" + fn, o, "%s_%s_%d" % (c, fn, o is strict)) for c in ("price", "big", "tiny") for fn in ("min", "max") for o in (None, strict)]
+    def plan_mm(tab, node, keys):
+        return acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
+            acero.Declaration(node, acero.AggregateNodeOptions(mm, keys=keys))]).to_table(use_threads=False).sort_by([(k, "ascending") for k in keys])
+    thw = pa.table({"kw": th.column("kw").chunk(0), **{c: th.column(c).chunk(0) for c in ("price", "big", "tiny")}})
+    tdw = pa.table({"kw": to_device(th.column("kw").chunk(0)), **{c: td_all.column(c).chunk(0) for c in ("price", "big", "tiny")}})
+    for keys, host_tab, dev_tab in ((["k"], th, td_all), (["kw"], thw, tdw)):
+        wm = plan_mm(host_tab, "aggregate", keys)
+        for tab, what in ((host_tab, "host"), (dev_tab, "device")):
+            gm = plan_mm(tab, "aggregate_rocm", keys)
+            assert gm.schema.equals(wm.schema), (what, gm.schema, wm.schema)
+            for c in wm.schema.names:
+                assert gm.column(c).equals(wm.column(c)), ("decimal extrema", what, keys, c, gm.column(c).slice(0, 4), wm.column(c).slice(0, 4))
     try:
         acero.Declaration.from_sequence([
             acero.Declaration("table_source", acero.TableSourceNodeOptions(th)),
@@ -3841,7 +3857,8 @@ DECIMAL_SUM_SCRIPT = textwrap.dedent(r"""
 
 def test_hash_sum_of_decimal128():
     """hash_sum of decimal128 columns — 128-bit sums modulo 2^128 on the device, the output widened to precision 38 — under the
-    stock GroupByNode (host and device-resident values, batches, threads) and in aggregate_rocm."""
+    stock GroupByNode (host and device-resident values, batches, threads) and in aggregate_rocm; hash_min / hash_max of
+    decimal128 in aggregate_rocm."""
     pytest.importorskip("pyarrow")
     code = f"ROOT = {ROOT!r}\n" + DECIMAL_SUM_SCRIPT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
