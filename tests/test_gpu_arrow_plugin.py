@@ -3751,6 +3751,8 @@ def test_hash_count_distinct_in_aggregate_rocm():
     assert r.returncode == 0 and "COUNT_DISTINCT_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+    assert wh.schema.field("price_mean").type == pa.decimal128(15, 2) and wh.schema.field("price_sum").type == pa.decimal128(38, 2)
+    assert any(x is not None and x != 0 and (x.as_tuple().digits[-1] % 2) for x in wh.column("tiny_mean").to_pylist())   # (means that needed rounding)
 DECIMAL_SUM_SCRIPT = textwrap.dedent(r"""
     import ctypes, decimal, os, sys, faulthandler
     faulthandler.enable()
@@ -3788,7 +3790,9 @@ DECIMAL_SUM_SCRIPT = textwrap.dedent(r"""
     })
     tc = pa.concat_tables([t.slice(0, n // 3), t.slice(n // 3, n // 5), t.slice(n // 3 + n // 5)])
     strict = pc.ScalarAggregateOptions(skip_nulls=False, min_count=2)
-    aggs = [(c, "sum", o) for c in ("price", "big", "tiny") for o in (None, strict)]
+    # (+ the mean: the same sums divided by the counts, truncating, then rounded half away from zero — GroupedMeanImpl::DoMean;
+    #  the mean keeps the input's decimal type)
+    aggs = [(c, fn, o) for c in ("price", "big", "tiny") for fn in ("sum", "mean") for o in (None, strict)]
     def run(tab, key, threads):
         return tab.group_by(key, use_threads=threads).aggregate(aggs).sort_by(key)
     want = {(name, key): run(tab, key, False) for name, tab in (("t", t), ("tc", tc)) for key in ("k", "kw")}
@@ -3815,7 +3819,7 @@ DECIMAL_SUM_SCRIPT = textwrap.dedent(r"""
     th = t.combine_chunks()
     td_vals = pa.table({"k": th.column("k").chunk(0), **{c: to_device(th.column(c).chunk(0)) for c in ("price", "big", "tiny")}})
     td_all = pa.table({c: to_device(th.column(c).chunk(0)) for c in ("k", "price", "big", "tiny")})
-    daggs = [(c, "hash_sum", None, c + "_sum") for c in ("price", "big", "tiny")]
+    daggs = [(c, "hash_" + fn, None, c + "_" + fn) for c in ("price", "big", "tiny") for fn in ("sum", "mean")]
     def plan(tab, node):
         return acero.Declaration.from_sequence([
             acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
@@ -3844,13 +3848,6 @@ DECIMAL_SUM_SCRIPT = textwrap.dedent(r"""
             assert gm.schema.equals(wm.schema), (what, gm.schema, wm.schema)
             for c in wm.schema.names:
                 assert gm.column(c).equals(wm.column(c)), ("decimal extrema", what, keys, c, gm.column(c).slice(0, 4), wm.column(c).slice(0, 4))
-    try:
-        acero.Declaration.from_sequence([
-            acero.Declaration("table_source", acero.TableSourceNodeOptions(th)),
-            acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("price", "hash_mean", None, "m")], keys=["k"]))]).to_table()
-        raise SystemExit("expected NotImplemented")
-    except pa.ArrowNotImplementedError as e:
-        assert "hash_mean of decimal128" in str(e), e
     print("DECIMAL_SUM_OK")
 """)
 
