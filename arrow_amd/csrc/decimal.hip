@@ -10,6 +10,7 @@
 #include "arx_common.h"
 
 #include <algorithm>
+#include <vector>
 
 namespace arx {
 
@@ -182,6 +183,55 @@ __global__ __launch_bounds__(kBlock) void dec128_minmax_finalize_kernel(const ui
   if (valid_count != nullptr && lane == 0 && total != 0) atomicAdd(valid_count, total);
 }
 
+// ---- sum / mean / min_max of a decimal128 COLUMN: SumImpl / MeanImpl / MinMaxImpl<Decimal128Type>
+// (kernels/aggregate_basic.inc.cc:49-110,229-258,776-860) keep {sum modulo 2^128, count of valid values, min, max}; a batch is
+// folded by every thread over its strided rows, the lanes of a wave meet in a shuffle reduction (all four are associative and
+// commutative), and every wave leaves one 64-byte partial for the host to combine — a few thousand, whatever the length.
+struct DecPartial {
+  uint64_t sum_lo, sum_hi, count, any;
+  Dec128 mn, mx;
+};
+
+__device__ __forceinline__ uint64_t dec_shfl_xor_u64(uint64_t v, int mask) {
+  return (static_cast<uint64_t>(__shfl_xor(static_cast<uint32_t>(v >> 32), mask, 64)) << 32) | __shfl_xor(static_cast<uint32_t>(v), mask, 64);
+}
+
+__global__ __launch_bounds__(kBlock) void dec128_reduce_kernel(const Dec128* __restrict__ values, Bits vvalid, int64_t n,
+                                                               DecPartial* __restrict__ partials) {
+  const int lane = lane_id();
+  DecFold f{Dec128{0, 0}, Dec128{0, 0}, false, false};
+  uint64_t slo = 0, shi = 0, cnt = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const bool ok = vvalid.base == nullptr || ((load_word(vvalid, i >> 6) >> (i & 63)) & 1ull);
+    if (!ok) continue;
+    const Dec128 v = values[i];
+    const uint64_t before = slo;
+    slo += v.lo;
+    shi += v.hi + (slo < before ? 1ull : 0ull);
+    ++cnt;
+    dec_fold_row(f, v, true);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const uint64_t olo = dec_shfl_xor_u64(slo, m), ohi = dec_shfl_xor_u64(shi, m);
+    const uint64_t before = slo;
+    slo += olo;
+    shi += ohi + (slo < before ? 1ull : 0ull);
+    cnt += dec_shfl_xor_u64(cnt, m);
+    const Dec128 omn = dec_shfl_xor(f.mn, m), omx = dec_shfl_xor(f.mx, m);
+    const bool oany = __shfl_xor(f.any ? 1 : 0, m, 64) != 0;
+    if (oany && (!f.any || dec128_less(omn, f.mn))) f.mn = omn;
+    if (oany && (!f.any || dec128_less(f.mx, omx))) f.mx = omx;
+    f.any = f.any || oany;
+  }
+  if (lane == 0) {
+    const int64_t wave_g = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    partials[wave_g] = DecPartial{slo, shi, cnt, f.any ? 1ull : 0ull, f.mn, f.mx};
+  }
+}
+
+constexpr int kDecReduceBlocks = 1024;
+
 static inline unsigned dec_grid(int64_t n) {
   return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, 256 * 16)));
 }
@@ -302,6 +352,56 @@ int arx_hash_minmax_dec128_finalize(const uint32_t* seen, int64_t num_groups, in
   hipLaunchKernelGGL(dec128_minmax_finalize_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), seen, num_groups, skip_nulls,
                      static_cast<uint64_t*>(out_validity), reinterpret_cast<unsigned long long*>(valid_count));
   ARX_CHECK_LAUNCH("dec128_minmax_finalize_kernel");
+  return ARX_OK;
+}
+
+size_t arx_reduce_dec128_workspace_bytes(void) { return static_cast<size_t>(kDecReduceBlocks) * kWavesPerBlock * sizeof(DecPartial) + 256; }
+
+int arx_reduce_dec128(const ArxSpan* values, void* ws, size_t ws_bytes, uint64_t* out8, void* stream) {
+  if (values == nullptr || out8 == nullptr || values->length < 0) {
+    set_error("bad arguments to arx_reduce_dec128");
+    return ARX_INVALID;
+  }
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  const int64_t n = values->length;
+  if (n == 0) return ARX_OK;
+  if (values->data == nullptr || ws == nullptr || ws_bytes < arx_reduce_dec128_workspace_bytes()) {
+    set_error("arx_reduce_dec128: NULL buffer or a workspace below arx_reduce_dec128_workspace_bytes");
+    return ARX_INVALID;
+  }
+  DecPartial* partials = reinterpret_cast<DecPartial*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~uintptr_t(255));
+  const int blocks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, kDecReduceBlocks)));
+  const bool has_nulls = values->null_count != 0 && values->validity != nullptr;
+  const Bits vvalid = has_nulls ? make_bits(values->validity, values->offset, n) : Bits{};
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(dec128_reduce_kernel, dim3(blocks), dim3(kBlock), 0, st, static_cast<const Dec128*>(values->data) + values->offset, vvalid, n,
+                     partials);
+  ARX_CHECK_LAUNCH("dec128_reduce_kernel");
+  std::vector<DecPartial> host(static_cast<size_t>(blocks) * kWavesPerBlock);
+  ARX_HIP(hipMemcpyAsync(host.data(), partials, host.size() * sizeof(DecPartial), hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  unsigned __int128 sum = 0;
+  __int128 mn = 0, mx = 0;
+  uint64_t count = 0;
+  bool any = false;
+  for (const DecPartial& p : host) {
+    sum += (static_cast<unsigned __int128>(p.sum_hi) << 64) | p.sum_lo;
+    count += p.count;
+    if (p.any == 0) continue;
+    const __int128 pmn = static_cast<__int128>((static_cast<unsigned __int128>(p.mn.hi) << 64) | p.mn.lo);
+    const __int128 pmx = static_cast<__int128>((static_cast<unsigned __int128>(p.mx.hi) << 64) | p.mx.lo);
+    if (!any || pmn < mn) mn = pmn;
+    if (!any || pmx > mx) mx = pmx;
+    any = true;
+  }
+  out8[0] = static_cast<uint64_t>(sum);
+  out8[1] = static_cast<uint64_t>(sum >> 64);
+  out8[2] = count;
+  out8[3] = any ? 1 : 0;
+  out8[4] = static_cast<uint64_t>(static_cast<unsigned __int128>(mn));
+  out8[5] = static_cast<uint64_t>(static_cast<unsigned __int128>(mn) >> 64);
+  out8[6] = static_cast<uint64_t>(static_cast<unsigned __int128>(mx));
+  out8[7] = static_cast<uint64_t>(static_cast<unsigned __int128>(mx) >> 64);
   return ARX_OK;
 }
 

@@ -912,6 +912,11 @@ int arx_hash_minmax_dec128_consume(const ArxSpan* values, const uint32_t* group_
                                    void* mins, void* maxs, uint32_t* seen, void* stream);
 int arx_hash_minmax_dec128_finalize(const uint32_t* seen, int64_t num_groups, int skip_nulls, void* out_validity,
                                     int64_t* valid_count, void* stream);
+/* sum / mean / min_max of a decimal128 column — SumImpl / MeanImpl / MinMaxImpl<Decimal128Type>
+ * (kernels/aggregate_basic.inc.cc:49-110,229-258,776-860): out8 (HOST) = {sum lo, sum hi (modulo 2^128), count of valid values,
+ * 1 if any, min lo, min hi, max lo, max hi}.  ws: arx_reduce_dec128_workspace_bytes() device bytes.  Synchronous. */
+size_t arx_reduce_dec128_workspace_bytes(void);
+int arx_reduce_dec128(const ArxSpan* values, void* ws, size_t ws_bytes, uint64_t* out8, void* stream);
 int arx_hash_sum_i64_merge(int64_t* sums, int64_t* counts, uint32_t* null_seen,
                            const int64_t* other_sums, const int64_t* other_counts,
                            const uint32_t* other_null_seen, const uint32_t* group_id_mapping,

@@ -2678,3 +2678,40 @@ def check_hash_minmax_dec128(amd, rng, n=20000, groups=(1, 13, 4000)):
     assert lib.arx_hash_minmax_dec128_workspace_bytes(0) == 0
     assert lib.arx_hash_minmax_dec128_consume(C.byref(sp), d_gids.data_ptr(), nn, ws.data_ptr(), 16, mins.data_ptr(), maxs.data_ptr(), seen.data_ptr(),
                                               st) == _lib.ARX_INVALID
+
+
+def check_reduce_dec128(amd, rng, sizes=(0, 1, 63, 64, 65, 5000, 70001)):
+    """arx_reduce_dec128: {sum modulo 2^128, count, min, max} of a decimal128 column — full-range words, nulls at an offset,
+    all-null and empty inputs — against Python integers."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+    ws_bytes = lib.arx_reduce_dec128_workspace_bytes()
+    ws = torch.zeros(ws_bytes + 256, dtype=torch.uint8, device=dev)
+
+    def signed(x):
+        return x - (1 << 128) if x >= (1 << 127) else x
+
+    for n in sizes:
+        for null_p in (0.0, 0.2, 1.0):
+            voff = int(rng.integers(0, 70)) if n else 0
+            words = rng.integers(0, 2**64, (voff + max(n, 1), 2), dtype=np.uint64)
+            valid = rng.random(n) >= null_p if null_p < 1.0 else np.zeros(n, dtype=bool)
+            d_vals = to_device(words.view(np.uint8).reshape(-1), dev)
+            d_valid = to_device(_pack_bits(valid, voff), dev)
+            sp = _lib.ArxSpan(d_valid.data_ptr() if null_p else None, d_vals.data_ptr(), voff, n, -1 if null_p else 0)
+            out = (C.c_uint64 * 8)()
+            _lib.check(lib.arx_reduce_dec128(C.byref(sp), ws.data_ptr(), ws_bytes + 256, out, st))
+            vals = [int(words[voff + i, 0]) + (int(words[voff + i, 1]) << 64) for i in range(n) if valid[i]]
+            tag = f"reduce_dec128[n={n},null_p={null_p}]"
+            assert out[2] == len(vals) and out[3] == (1 if vals else 0), (tag, out[2], out[3])
+            assert out[0] + (out[1] << 64) == sum(vals) % (1 << 128), tag
+            if vals:
+                sv = [signed(v) for v in vals]
+                assert signed(out[4] + (out[5] << 64)) == min(sv) and signed(out[6] + (out[7] << 64)) == max(sv), tag
+    assert lib.arx_reduce_dec128(C.byref(sp), ws.data_ptr(), 16, out, st) == _lib.ARX_INVALID

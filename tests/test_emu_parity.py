@@ -1003,6 +1003,7 @@ def test_grouped_decimal128_sum(emu_ctx):
     per row; extrema in signed 128-bit order by one owner per group over the rows sorted by group id."""
     P.check_hash_sum_dec128(emu_ctx, rng_for("hashdec"), n=3000, groups=(1, 13, 400))
     P.check_hash_minmax_dec128(emu_ctx, rng_for("hashdecmm"), n=3000, groups=(1, 13, 400))
+    P.check_reduce_dec128(emu_ctx, rng_for("reducedec"), sizes=(0, 1, 63, 64, 65, 5000))
 
 
 def test_buffer_copy(emu_ctx):

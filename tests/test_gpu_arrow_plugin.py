@@ -3055,11 +3055,16 @@ FLOAT_AGGREGATE_SCRIPT = textwrap.dedent(r"""
         except pa.lib.ArrowNotImplementedError as e:
             assert "device-resident" in str(e), e
     import decimal
-    dd = to_device(pa.array([decimal.Decimal("1.5"), None, decimal.Decimal("-2.25")], pa.decimal128(10, 2)))
+    # decimal128 is served since late round 4 (DECIMAL_SUM_SCRIPT has the cases); decimal256 has no device form: refused by name
+    hd = pa.array([decimal.Decimal("1.5"), None, decimal.Decimal("-2.25")], pa.decimal128(10, 2))
+    dd = to_device(hd)
+    for fn in ("sum", "mean", "min_max"):
+        assert pc.call_function(fn, [dd]).equals(pc.call_function(fn, [hd])), fn
+    d256 = to_device(pa.array([decimal.Decimal("1.5"), None], pa.decimal256(40, 2)))
     for fn in ("sum", "mean", "min_max"):
         try:
-            pc.call_function(fn, [dd])
-            raise SystemExit("expected NotImplemented for " + fn + " of device decimals")
+            pc.call_function(fn, [d256])
+            raise SystemExit("expected NotImplemented for " + fn + " of device decimal256")
         except pa.lib.ArrowNotImplementedError as e:
             assert "device-resident" in str(e), e
     try:
@@ -3848,14 +3853,35 @@ DECIMAL_SUM_SCRIPT = textwrap.dedent(r"""
             assert gm.schema.equals(wm.schema), (what, gm.schema, wm.schema)
             for c in wm.schema.names:
                 assert gm.column(c).equals(wm.column(c)), ("decimal extrema", what, keys, c, gm.column(c).slice(0, 4), wm.column(c).slice(0, 4))
+    # ---- the scalar aggregates of decimal128 device columns (SumImpl / MeanImpl / MinMaxImpl<Decimal128Type>): sum widened to
+    # precision 38, mean in the input's type (truncating division, rounded half away from zero; null for no value), min_max /
+    # min / max; chunked device arrays (several batches, merged states), options, all-null and empty columns
+    r0 = lib.arrow_amd_plugin_calls(b"reduce", 1)
+    scalar_cols = {c: th.column(c).chunk(0) for c in ("price", "big", "tiny")}
+    scalar_cols["nulls"] = pa.array([None] * 100, pa.decimal128(12, 3))
+    scalar_cols["empty"] = pa.array([], pa.decimal128(7, 1))
+    for c, host in scalar_cols.items():
+        dev_arr = to_device(host)
+        half = len(host) // 2
+        dev_chunked = pa.chunked_array([to_device(host.slice(0, half)), to_device(host.slice(half))]) if len(host) > 1 else None
+        for opt in (None, pc.ScalarAggregateOptions(skip_nulls=False, min_count=1), pc.ScalarAggregateOptions(skip_nulls=True, min_count=len(host) + 1),
+                    pc.ScalarAggregateOptions(skip_nulls=True, min_count=0)):
+            for fn in (pc.sum, pc.mean, pc.min_max, pc.min, pc.max):
+                w = fn(host, options=opt)
+                for d in (dev_arr, dev_chunked):
+                    if d is None:
+                        continue
+                    g = fn(d, options=opt)
+                    assert g.type == w.type and g.equals(w), (c, fn.__name__, opt, g, w)
+    assert lib.arrow_amd_plugin_calls(b"reduce", 1) - r0 >= 5 * 4 * 3
     print("DECIMAL_SUM_OK")
 """)
 
 
 def test_hash_sum_of_decimal128():
     """hash_sum of decimal128 columns — 128-bit sums modulo 2^128 on the device, the output widened to precision 38 — under the
-    stock GroupByNode (host and device-resident values, batches, threads) and in aggregate_rocm; hash_min / hash_max of
-    decimal128 in aggregate_rocm."""
+    stock GroupByNode (host and device-resident values, batches, threads) and in aggregate_rocm; hash_mean; hash_min / hash_max of
+    decimal128 in aggregate_rocm; the scalar sum / mean / min_max / min / max of decimal128 device columns."""
     pytest.importorskip("pyarrow")
     code = f"ROOT = {ROOT!r}\n" + DECIMAL_SUM_SCRIPT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)

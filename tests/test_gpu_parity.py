@@ -1363,6 +1363,7 @@ def test_grouped_decimal128_sum(gpu_ctx):
     per row; extrema in signed 128-bit order by one owner per group over the rows sorted by group id."""
     P.check_hash_sum_dec128(gpu_ctx, rng_for("hashdec"), n=60000, groups=(1, 13, 4000))
     P.check_hash_minmax_dec128(gpu_ctx, rng_for("hashdecmm"), n=60000, groups=(1, 13, 4000))
+    P.check_reduce_dec128(gpu_ctx, rng_for("reducedec"), sizes=(0, 1, 65, 70001, 3000017))
 
 
 def test_buffer_copy(gpu_ctx):
