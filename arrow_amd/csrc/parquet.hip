@@ -869,6 +869,9 @@ __global__ __launch_bounds__(64) void dba_expand_kernel(const int32_t* __restric
       const int64_t so = __shfl(my_so, j, 64);
       const int32_t sl = __shfl(my_se, j, 64) - static_cast<int32_t>(so);
       const int64_t oo = static_cast<int64_t>(__shfl(my_oo, j, 64)) - out_base;
+      // (a negative length is corrupt data the lengths kernel has flagged — callers stop there; a value is never written
+      //  before its own start all the same)
+      if (p < 0 || sl < 0 || so < 0 || so + sl > suffix_size) continue;
       // (a) the part of the prefix past the LDS window: from the previous value's bytes in the output (rare: > 8 KB)
       if (p > kDbaWindow) {
         __threadfence();

@@ -243,7 +243,10 @@ def expand_delta_byte_array(pages, base: int = 0, offsets_out: torch.Tensor | No
     soff = alloc((n + 1) * 4, device)
     check(lib.arx_lengths_to_offsets_i32(slen.data_ptr(), n, 0, soff.data_ptr(), ws.data_ptr(), ws.numel(), stream))
     check(lib.arx_lengths_to_offsets_i32(out_len.data_ptr(), n, base, offsets_out.data_ptr(), ws.data_ptr(), ws.numel(), stream))
-    total = int(state.view(torch.int64)[1].item())
+    flags, total = (int(x) for x in state.view(torch.int64)[:2].cpu().numpy())
+    for bit, text in _DBA_STATUS:      # corrupt lengths stop here: the expansion only ever sees lengths that passed the checks
+        if flags & bit:
+            raise ArrowInvalid("Parquet: " + text)
     if base + total > 2**31 - 1:
         raise ArrowInvalid("Parquet: column chunk exceeds the int32 offset range")
     end = base + total

@@ -1009,8 +1009,9 @@ int arx_lengths_to_offsets_i32(const int32_t* lengths, int64_t n, int32_t base, 
  *             bytes one after the other, 4-byte aligned and readable up to the next multiple of 4 past suffix_size;
  *             page_suffix_first (device, num_pages + 1, or NULL): where each page's suffix bytes start — a page whose
  *             suffix lengths do not add up to that is skipped and ORs bit 4 into state[0] (not zeroed here).  One wave
- *             walks a page value by value, the lanes copy bytes.  With state[1] within the int32 range it stays inside
- *             its buffers whatever the lengths say, so state[0] may be read once, after both calls.  Asynchronous. */
+ *             walks a page value by value, the lanes copy bytes.  Call it only when _lengths left state[0] == 0 and
+ *             state[1] fits the int32 offsets (the caller reads both to size out_data anyway); a value with a negative
+ *             length or a suffix outside suffix_bytes is skipped rather than written.  Asynchronous. */
 int arx_delta_byte_array_lengths(const int32_t* prefix, const int32_t* suffix_len, int64_t n, const int64_t* page_first,
                                  int64_t num_pages, int32_t* out_len, uint64_t* state, void* stream);
 int arx_delta_byte_array_expand(const int32_t* prefix, const int32_t* suffix_offsets, const void* suffix_bytes,
