@@ -1652,9 +1652,9 @@ int arx_take_rows(const ArxSpan* values, int64_t row_bytes, const ArxSpan* indic
     set_error("Unsupported index type %d for take", index_type);
     return ARX_NOT_IMPLEMENTED;
   }
-  if (row_bytes <= 0 || row_bytes > (int64_t(1) << 30)) {
-    set_error("arx_take_rows: rows of %lld bytes", static_cast<long long>(row_bytes));
-    return row_bytes == 0 ? ARX_NOT_IMPLEMENTED : ARX_INVALID;
+  if (row_bytes <= 0 || row_bytes > (int64_t(1) << 24)) {   // (64 rows x units-per-row is counted in 32 bits)
+    set_error("arx_take_rows: rows of %lld bytes (1 .. 2^24)", static_cast<long long>(row_bytes));
+    return row_bytes < 0 ? ARX_INVALID : ARX_NOT_IMPLEMENTED;
   }
   if (indices->length == 0) return ARX_OK;
   if (out_data == nullptr || indices->data == nullptr) {
