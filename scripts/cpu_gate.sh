@@ -7,7 +7,8 @@ set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 LOG=gpurun_out/cpu_gate.log
-python -c "import __graft_entry__ as g; g.build()" > $LOG 2>&1 || { echo "cpu_gate: build() FAILED"; tail -20 $LOG; exit 1; }
+python scripts/lint_names.py > $LOG 2>&1 || { echo "cpu_gate: lint_names FAILED (a name used in a test / script body is bound nowhere)"; tail -20 $LOG; exit 1; }
+python -c "import __graft_entry__ as g; g.build()" >> $LOG 2>&1 || { echo "cpu_gate: build() FAILED"; tail -20 $LOG; exit 1; }
 python -m pytest tests -q -m "not gpu" -p no:cacheprovider "$@" >> $LOG 2>&1
 rc=$?
 tail -5 $LOG
