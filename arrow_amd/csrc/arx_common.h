@@ -40,6 +40,7 @@ int set_groupby_option(const char* name, int64_t value);
 int set_parquet_option(const char* name, int64_t value);
 // Per-file diagnostic counters read by arx_get_counter (return 1 if the name was recognised).
 int get_groupby_counter(const char* name, int64_t* out);
+int get_sort_counter(const char* name, int64_t* out);
 
 #define ARX_HIP(call)                                          \
   do {                                                         \

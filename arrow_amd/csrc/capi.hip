@@ -44,7 +44,7 @@ int arx_set_option(const char* name, int64_t value) {
 
 int64_t arx_get_counter(const char* name) {
   int64_t v = 0;
-  if (name != nullptr && arx::get_groupby_counter(name, &v)) return v;
+  if (name != nullptr && (arx::get_groupby_counter(name, &v) || arx::get_sort_counter(name, &v))) return v;
   arx::set_error("unknown counter '%s'", name == nullptr ? "(null)" : name);
   return -1;
 }

@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 
 namespace arx {
 
@@ -47,6 +48,8 @@ static Knob<int> g_sort_msd_tiny_bucket{2};        // wide form: 256-thread / 25
 static Knob<int> g_sort_msd_bucket_cpt{4};         // wide form's bucket finish: sub-bucket counters per thread (4: <= 4 T sub-buckets, 8: <= 8 T)
 static Knob<int> g_sort_msd_prefix{1};             // MSD forms take their digits below the bits that ALL keys share (ids, timestamps, small ints: the top bits are equal)
 static Knob<int> g_sort_msd_wide_gap2{1};          // wide form: level-2 buckets get a fixed room each (bucket mean + 6 sigma + 64) instead of an exact histogram pass
+static Knob<int> g_sort_msd_wide_rec8{1};           // wide form over the caller's own column: 8-byte {32 key bits below the level-1 digit, row id} records through both levels and the finish (48.5 B/row instead of 64.5); rows whose 32 bits tie read their full keys from the column
+static Knob<int> g_sort_msd_wide_rec8_tie_shift{6};  // ... given up (and repeated with 12-byte records) once more than n >> shift rows tied (duplicate-heavy keys: every tie is two random 8-byte reads)
 static Knob<int> g_sort_msd_wide_sample_strict{0}; // tests: a sampled attempt that overflows is an error instead of a silent exact re-run
 static Knob<int> g_sort_msd_wide{1};          // inputs beyond sort_msd_segment_rows: the wide two-level form (run_msd_sort_wide) before the segmented one
 static Knob<int> g_sort_msd_bucket_v2{1};     // single-atomic-pass bucket finish with up to 4096 sub-buckets (msd_bucket2_kernel)
@@ -598,6 +601,7 @@ struct MsdArgs {
   unsigned int* overflow;
   const uint32_t* part_in;    // record input of the bucket finish (AOS form): first record of every bucket
   int xcd_map;                // XCD-contiguous work numbering: bit 0 the level-2 scatter, bit 1 the bucket finish
+  uint32_t tie_limit;         // rec8 finish: give up (overflow bit 32) once more rows than this read their full key
 };
 
 // (key, row id) as one 12-byte record: what the wide form's two scatter levels write and read (one output stream per
@@ -1409,6 +1413,117 @@ __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_
   }
 }
 
+// The same finish over rec8 words (msdw_word: 32 key bits above the row id).  A bucket is T * R words of LDS — a third
+// less than (key, row id) pairs, one LDS access per row where the pair form made two — and ranking compares whole words:
+// inside a sub-bucket that is the order of (key bits in the word, row id).  Rows whose 32 key bits tie with another row
+// of their sub-bucket (2e9 uniform keys: 0.9 per 1000) read the full keys of both from the caller's column and correct
+// their rank by the bits below; when the word already holds every remaining key bit (32-bit key types, shared prefixes)
+// a tie is a tie.  Every such row counts itself in overflow[4]; past tie_limit rows, or at a row with more than
+// kMsdwMaxTied tied neighbours, the kernel gives up (bit 32) and the host repeats the sort with full records —
+// duplicate-heavy keys would pay 1 + (tied neighbours) random 8-byte reads per row here.
+constexpr int kMsdwMaxTied = 16;   // rec8 finish: a row with more tied neighbours than this gives the attempt up
+template <int T, int CPT = 4, int R = kBktRows>
+struct __attribute__((aligned(16))) MsdBucket2wLds {
+  uint64_t words[T * R];
+  uint32_t start[CPT * T + 1];   // counts, then exclusive starts (+ sentinel)
+  uint32_t wave_tot[T / 64];
+};
+
+template <int T, int CPT = 4, int R = kBktRows>
+__global__ __launch_bounds__(T) void msd_bucket2w_kernel(MsdArgs a, const uint64_t* __restrict__ words_in) {
+  __shared__ MsdBucket2wLds<T, CPT, R> w;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  if ((__atomic_load_n(a.overflow, __ATOMIC_RELAXED) & 32u) != 0) return;   // given up: the call is repeated
+  const uint32_t q = (a.xcd_map & 2) ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int64_t lo = a.part_start[q];
+  const int m = static_cast<int>(static_cast<int64_t>(a.part_start[q + 1]) - lo);
+  const int64_t lo_in = static_cast<int64_t>(a.part_in[q]);
+  if (m == 0) return;  // workgroup-uniform
+  if (m > T * R) {
+    if (tid == 0) atomicOr(a.overflow, 2u);
+    return;
+  }
+  const int nb = 1 << a.b3;   // <= CPT * T (host)
+  const int dsh = 64 - a.b3;
+  auto digit_of = [&](uint64_t wd) -> uint32_t { return a.b3 == 0 ? 0u : static_cast<uint32_t>((wd << a.b2) >> dsh); };
+  const bool bits_below = a.kshift + a.b1 + 32 < 64;   // key bits the words do not hold
+  for (int i = tid; i < nb; i += T) w.start[i] = 0;
+  uint64_t wd[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {   // unconditional loads (clamped): all round trips overlap
+    const int p = i * T + tid;
+    wd[i] = words_in[lo_in + (p < m ? p : m - 1)];
+  }
+  __syncthreads();
+  uint32_t dig[R], rank[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    dig[i] = digit_of(wd[i]);
+    rank[i] = 0;
+    if (i * T + tid < m) rank[i] = atomicAdd(&w.start[dig[i]], 1u);
+  }
+  __syncthreads();
+  uint32_t c[CPT];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int b = tid * CPT + k;
+    c[k] = b < nb ? w.start[b] : 0u;
+    mine += c[k];
+  }
+  const uint32_t incl = wave_inclusive_scan_u32(mine);
+  if (lane == 63) w.wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t pre = incl - mine;
+  for (int k = 0; k < wave; ++k) pre += w.wave_tot[k];
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int b = tid * CPT + k;
+    if (b < nb) w.start[b] = pre;
+    pre += c[k];
+  }
+  if (tid == 0) w.start[nb] = static_cast<uint32_t>(m);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    if (i * T + tid < m) w.words[w.start[dig[i]] + rank[i]] = wd[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < m; i += T) {
+    const uint64_t wi = w.words[i];
+    const uint32_t d = digit_of(wi);
+    const int bs = static_cast<int>(w.start[d]);
+    const int be = static_cast<int>(w.start[d + 1]);
+    int rk = 0;
+    int tied = 0;   // other rows of the sub-bucket with the same 32 key bits
+    for (int j = bs; j < be; j += 2) {
+      const bool two = j + 1 < be;
+      const uint64_t w0 = w.words[j];
+      const uint64_t w1 = w.words[two ? j + 1 : j];
+      rk += (w0 < wi ? 1 : 0) + ((two && w1 < wi) ? 1 : 0);
+      tied += ((((w0 ^ wi) >> 32) == 0 && j != i) ? 1 : 0) + ((two && ((w1 ^ wi) >> 32) == 0 && j + 1 != i) ? 1 : 0);
+    }
+    if (tied > kMsdwMaxTied && bits_below) {   // a run of equal words: quadratic in column reads — not this form's input
+      atomicOr(a.overflow, 32u);
+    } else if (tied != 0 && bits_below) {   // (rare) the bits below decide before the row ids do
+      const uint64_t ki = load_key_typed(a.src_keys, static_cast<int64_t>(static_cast<uint32_t>(wi)), a.raw);
+      for (int j = bs; j < be; ++j) {
+        const uint64_t wj = w.words[j];
+        if (j != i && ((wj ^ wi) >> 32) == 0) {
+          const uint64_t kj = load_key_typed(a.src_keys, static_cast<int64_t>(static_cast<uint32_t>(wj)), a.raw);
+          const bool counted = wj < wi;
+          const bool before = kj < ki || (kj == ki && counted);
+          rk += (before ? 1 : 0) - (counted ? 1 : 0);
+        }
+      }
+      if (atomicAdd(&a.overflow[4], 1u) >= a.tie_limit) atomicOr(a.overflow, 32u);
+    }
+    a.out_final[lo + bs + rk] = static_cast<uint32_t>(wi);
+  }
+}
+
 // (A persistent form of this finish — workgroups walking buckets q, q + grid, ... and loading the next bucket's rows
 // into registers before ranking the current one — measured SLOWER: 13.7 ms against 11.4 ms for 2^19 buckets, and a
 // grid of one workgroup per CU instead of two 43 ms end to end instead of 36: the finish is bound by its LDS phases and
@@ -1464,6 +1579,18 @@ static SortPlan make_plan(int64_t length) {
   return p;
 }
 
+// which record form the wide sorts of this process ran with (arx_get_counter; tests and the bench's parity leg)
+static std::atomic<int64_t> g_sort_wide_runs{0}, g_sort_wide_rec8_runs{0}, g_sort_wide_rec8_ties{0}, g_sort_wide_rec8_given_up{0};
+
+int get_sort_counter(const char* name, int64_t* out) {
+  if (strcmp(name, "sort_wide_runs") == 0) *out = g_sort_wide_runs.load();
+  else if (strcmp(name, "sort_wide_rec8_runs") == 0) *out = g_sort_wide_rec8_runs.load();
+  else if (strcmp(name, "sort_wide_rec8_ties") == 0) *out = g_sort_wide_rec8_ties.load();
+  else if (strcmp(name, "sort_wide_rec8_given_up") == 0) *out = g_sort_wide_rec8_given_up.load();
+  else return 0;
+  return 1;
+}
+
 int set_sort_option(const char* name, int64_t value) {
   if (strcmp(name, "sort_msd") == 0) {
     g_sort_msd = value < 0 ? -1 : (value != 0);
@@ -1516,6 +1643,14 @@ int set_sort_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "sort_msd_wide_gap2") == 0) {
     g_sort_msd_wide_gap2 = value != 0;
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_rec8") == 0) {
+    g_sort_msd_wide_rec8 = value != 0;
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_rec8_tie_shift") == 0) {
+    g_sort_msd_wide_rec8_tie_shift = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 40)));
     return 1;
   }
   if (strcmp(name, "sort_msd_wide_sample_strict") == 0) {
@@ -1922,6 +2057,7 @@ struct MsdwArgs {
   int xcd_map;             // level 2: XCD-contiguous tile numbering
   int xcd_map1;            // level 1 likewise (A/B)
   int tile1, tile2;        // rows per scatter tile of level 1 / level 2: kMsdwTile, or 2x / 3x that held in registers
+  int rec8;                // records are 8-byte words {the 32 key bits below the level-1 digit, row id} (msdw_word)
   int64_t capacity;        // records rec_x / rec_y can hold
   uint32_t* l1_count;      // [2^b1] histogram (of the sample)
   uint32_t* l1_start;      // [2^b1] first record of a level-1 bucket in rec_x (buckets may be followed by unused room)
@@ -1936,8 +2072,9 @@ struct MsdwArgs {
   uint32_t* part_start;    // [2^bits + 1] first FINAL position of every level-2 bucket
   uint32_t* cursor2;       // [2^bits]
   uint32_t* flags;         // [0] bits: 2 a bucket does not fit LDS, 4 a level-1 bucket outgrew its room, 8 fixed level-2
-                           //     rooms are not possible here, 16 a level-2 bucket outgrew its room; [1] largest bucket;
-                           //     [2] sampled rows; [3] gap2: largest level-2 room
+                           //     rooms are not possible here, 16 a level-2 bucket outgrew its room, 32 rec8: too many rows
+                           //     tied in their 32 record bits; [1] largest bucket; [2] sampled rows; [3] gap2: largest
+                           //     level-2 room; [4] rec8: rows that read their full key
   MsdRec* rec_x;           // level-1 output
   MsdRec* rec_y;           // level-2 output
 };
@@ -2148,12 +2285,23 @@ __device__ __forceinline__ void msdw_reserve_runs(uint32_t* __restrict__ cursor,
   }
 }
 
+// rec8: a row as ONE 8-byte word — the 32 key bits below the level-1 digit (of key << kshift) above its row id.  Inside a
+// level-1 bucket the unsigned order of the words is the order of (those 41 + kshift leading key bits, row id): level 2
+// and the finish take their digits from the top of the word, the finish ranks whole words, and only rows whose 32 bits
+// tie inside a sub-bucket go back to the column for the bits below (msd_bucket2w_kernel).
+__device__ __forceinline__ uint64_t msdw_word(uint64_t key, uint32_t id, int kshift, int b1) {
+  const int sh = kshift + b1;
+  const uint64_t below = sh < 64 ? key << sh : 0;
+  return (below & 0xFFFFFFFF00000000ull) | id;
+}
+
 // Scatter one tile of <= 8192 rows by digit = (key >> dshift) & (nb - 1); run bases from one returning atomic per
 // digit on gcursor[]; output = 12-byte records.  1024 threads, nb <= 1024 (one counter per thread in the scan).
-// SRC: 0 raw column (row id = position), 1 transformed keys + row ids, 2 records.
+// SRC: 0 raw column (row id = position), 1 transformed keys + row ids, 2 records, 3 rec8 words (digits from the word's
+// top, no shared-prefix shift: msdw_word already applied it).  OUT8: the output is rec8 words.
 // CHECK: a run that does not fit its bucket's room is not written and sets `overflow_bit` in flags[0] — 1: room ends
 // at gend[digit]; 2: digit d owns [room_base + d * room, + room).
-template <int SRC, int CHECK>
+template <int SRC, int CHECK, bool OUT8 = false>
 __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatterLds& lds, const uint64_t* __restrict__ kin,
                                                   const uint32_t* __restrict__ iin, const MsdRec* __restrict__ rin,
                                                   int64_t row0, int nrows, int nb, int dshift,
@@ -2177,17 +2325,21 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
     } else if constexpr (SRC == 1) {
       key[i] = kin[r];
       idx[i] = iin[r];
-    } else {
+    } else if constexpr (SRC == 2) {
       const MsdRec rr = rin[r];
       key[i] = msd_rec_key(rr);
       idx[i] = rr.idx;
+    } else {
+      key[i] = reinterpret_cast<const uint64_t*>(rin)[r];
+      idx[i] = 0;
     }
   }
   __syncthreads();
+  const int ksh = SRC == 3 ? 0 : a.kshift;
   uint32_t dig[kMsdwRows], rank[kMsdwRows];
 #pragma unroll
   for (int i = 0; i < kMsdwRows; ++i) {
-    dig[i] = static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask;
+    dig[i] = static_cast<uint32_t>((key[i] << ksh) >> dshift) & dmask;
     rank[i] = 0;
     if (i * kMsdwThreads + tid < nrows) rank[i] = atomicAdd(&lds.cnt[dig[i]], 1u);
   }
@@ -2233,20 +2385,25 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
     if (i * kMsdwThreads + tid < nrows) {
       const uint32_t pos = lds.start[dig[i]] + rank[i];
       lds.keys[pos] = key[i];
-      lds.idx[pos] = idx[i];
+      if constexpr (SRC != 3) lds.idx[pos] = idx[i];
     }
   }
   __syncthreads();
   for (int p = tid; p < nrows; p += kMsdwThreads) {
     const uint64_t k = lds.keys[p];
-    const uint32_t d = static_cast<uint32_t>((k << a.kshift) >> dshift) & dmask;
+    const uint32_t d = static_cast<uint32_t>((k << ksh) >> dshift) & dmask;
     const uint32_t gb = lds.gbase[d];
     if (CHECK != 0 && gb == 0xFFFFFFFFu) continue;
-    MsdRec rr;
-    rr.lo = static_cast<uint32_t>(k);
-    rr.hi = static_cast<uint32_t>(k >> 32);
-    rr.idx = lds.idx[p];
-    rout[gb + (static_cast<uint32_t>(p) - lds.start[d])] = rr;
+    const uint32_t at = gb + (static_cast<uint32_t>(p) - lds.start[d]);
+    if constexpr (OUT8) {
+      reinterpret_cast<uint64_t*>(rout)[at] = SRC == 3 ? k : msdw_word(k, lds.idx[p], a.kshift, a.b1);
+    } else {
+      MsdRec rr;
+      rr.lo = static_cast<uint32_t>(k);
+      rr.hi = static_cast<uint32_t>(k >> 32);
+      rr.idx = lds.idx[p];
+      rout[at] = rr;
+    }
   }
 }
 
@@ -2255,7 +2412,7 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
 // LDS-resident tile's — 48 records = 576 B at 512 bins and RPT 24 — which is what sets the rate of a scatter whose bins
 // span the whole array (scripts/micro/wide_scatter_bench.hip, profiles/r03_c_wide_scatter_small_lds_chunks.txt; the
 // group-by's flat level is the same kernel shape, groupby.hip K3w).
-template <int SRC, int CHECK, int RPT>
+template <int SRC, int CHECK, int RPT, bool OUT8 = false>
 __device__ __forceinline__ void msdw_scatter_big_tile(const MsdwArgs& a, MsdwScatterLds& lds, const uint64_t* __restrict__ kin,
                                                       const uint32_t* __restrict__ iin, const MsdRec* __restrict__ rin,
                                                       int64_t row0, int nrows, int nb, int dshift,
@@ -2269,7 +2426,8 @@ __device__ __forceinline__ void msdw_scatter_big_tile(const MsdwArgs& a, MsdwSca
   const uint32_t dmask = static_cast<uint32_t>(nb - 1);
   for (int b = tid; b < nb; b += kMsdwThreads) lds.cnt[b] = 0;
   uint64_t key[RPT];
-  uint32_t idx[SRC == 0 ? 1 : RPT];
+  uint32_t idx[(SRC == 0 || SRC == 3) ? 1 : RPT];
+  const int ksh = SRC == 3 ? 0 : a.kshift;
   // unconditional loads (rows past the tile's end re-read its last row), all in flight together; addresses = one
   // uniform base + a 32-bit offset per row.  The caller's column is read once: non-temporal.
   if constexpr (SRC == 0) {
@@ -2298,10 +2456,12 @@ __device__ __forceinline__ void msdw_scatter_big_tile(const MsdwArgs& a, MsdwSca
       if constexpr (SRC == 1) {
         key[i] = (kin + row0)[p];
         idx[i] = (iin + row0)[p];
-      } else {
+      } else if constexpr (SRC == 2) {
         const MsdRec rr = (rin + row0)[p];
         key[i] = msd_rec_key(rr);
         idx[i] = rr.idx;
+      } else {
+        key[i] = (reinterpret_cast<const uint64_t*>(rin) + row0)[p];
       }
     }
   }
@@ -2311,7 +2471,7 @@ __device__ __forceinline__ void msdw_scatter_big_tile(const MsdwArgs& a, MsdwSca
   uint32_t pos2[RPT / 2];
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const uint32_t d = static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask;
+    const uint32_t d = static_cast<uint32_t>((key[i] << ksh) >> dshift) & dmask;
     const uint32_t pr = (i * kMsdwThreads + tid < nrows) ? atomicAdd(&lds.cnt[d], 1u) : 0xFFFFu;
     pos2[i / 2] = (i & 1) ? (pos2[i / 2] | (pr << 16)) : pr;
     if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);   // eight atomics in flight, not RPT (their addresses and results are registers)
@@ -2354,7 +2514,7 @@ __device__ __forceinline__ void msdw_scatter_big_tile(const MsdwArgs& a, MsdwSca
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const uint32_t d = static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask;
+    const uint32_t d = static_cast<uint32_t>((key[i] << ksh) >> dshift) & dmask;
     const uint32_t pr = (pos2[i / 2] >> ((i & 1) * 16)) & 0xFFFFu;
     const uint32_t at = pr != 0xFFFFu ? pr + lds.start[d] : 0xFFFFu;
     pos2[i / 2] = (i & 1) ? ((pos2[i / 2] & 0xFFFFu) | (at << 16)) : ((pos2[i / 2] & 0xFFFF0000u) | at);
@@ -2370,7 +2530,7 @@ __device__ __forceinline__ void msdw_scatter_big_tile(const MsdwArgs& a, MsdwSca
         lds.keys[q] = key[i];
         if constexpr (SRC == 0) {
           lds.idx[q] = static_cast<uint32_t>(row0) + static_cast<uint32_t>(i * kMsdwThreads + tid);
-        } else {
+        } else if constexpr (SRC != 3) {
           lds.idx[q] = idx[i];
         }
       }
@@ -2379,20 +2539,25 @@ __device__ __forceinline__ void msdw_scatter_big_tile(const MsdwArgs& a, MsdwSca
     const int cnt = nrows - static_cast<int>(lo) < kMsdwTile ? nrows - static_cast<int>(lo) : kMsdwTile;
     for (int p = tid; p < cnt; p += kMsdwThreads) {
       const uint64_t k = lds.keys[p];
-      const uint32_t d = static_cast<uint32_t>((k << a.kshift) >> dshift) & dmask;
+      const uint32_t d = static_cast<uint32_t>((k << ksh) >> dshift) & dmask;
       const uint32_t gb = lds.gbase[d];
       if (CHECK != 0 && gb == 0xFFFFFFFFu) continue;
-      MsdRec rr;
-      rr.lo = static_cast<uint32_t>(k);
-      rr.hi = static_cast<uint32_t>(k >> 32);
-      rr.idx = lds.idx[p];
-      rout[gb + (lo + static_cast<uint32_t>(p) - lds.start[d])] = rr;
+      const uint32_t at = gb + (lo + static_cast<uint32_t>(p) - lds.start[d]);
+      if constexpr (OUT8) {
+        reinterpret_cast<uint64_t*>(rout)[at] = SRC == 3 ? k : msdw_word(k, lds.idx[p], a.kshift, a.b1);
+      } else {
+        MsdRec rr;
+        rr.lo = static_cast<uint32_t>(k);
+        rr.hi = static_cast<uint32_t>(k >> 32);
+        rr.idx = lds.idx[p];
+        rout[at] = rr;
+      }
     }
     __syncthreads();
   }
 }
 
-template <int SRC, int CHECK, int RPT>
+template <int SRC, int CHECK, int RPT, bool OUT8 = false>
 __device__ __forceinline__ void msdw_scatter_any_tile(const MsdwArgs& a, MsdwScatterLds& lds, const uint64_t* __restrict__ kin,
                                                       const uint32_t* __restrict__ iin, const MsdRec* __restrict__ rin,
                                                       int64_t row0, int nrows, int nb, int dshift,
@@ -2400,15 +2565,15 @@ __device__ __forceinline__ void msdw_scatter_any_tile(const MsdwArgs& a, MsdwSca
                                                       uint32_t room_base, uint32_t room, uint32_t overflow_bit,
                                                       MsdRec* __restrict__ rout) {
   if constexpr (RPT == kMsdwRows) {
-    msdw_scatter_tile<SRC, CHECK>(a, lds, kin, iin, rin, row0, nrows, nb, dshift, gcursor, gend, room_base, room,
-                                  overflow_bit, rout);
+    msdw_scatter_tile<SRC, CHECK, OUT8>(a, lds, kin, iin, rin, row0, nrows, nb, dshift, gcursor, gend, room_base, room,
+                                        overflow_bit, rout);
   } else {
-    msdw_scatter_big_tile<SRC, CHECK, RPT>(a, lds, kin, iin, rin, row0, nrows, nb, dshift, gcursor, gend, room_base, room,
-                                           overflow_bit, rout);
+    msdw_scatter_big_tile<SRC, CHECK, RPT, OUT8>(a, lds, kin, iin, rin, row0, nrows, nb, dshift, gcursor, gend, room_base,
+                                                 room, overflow_bit, rout);
   }
 }
 
-template <bool RAW, int RPT>
+template <bool RAW, int RPT, bool OUT8 = false>
 __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1_kernel(MsdwArgs a) {
   __shared__ MsdwScatterLds lds;
   // an earlier tile already found a bucket without room: the level will be repeated, do not finish this attempt
@@ -2418,8 +2583,8 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1_kernel(MsdwArgs a)
   const uint32_t tile = a.xcd_map1 ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   const int64_t row0 = static_cast<int64_t>(tile) * kTile;
   const int nrows = static_cast<int>(a.n - row0 < kTile ? a.n - row0 : kTile);
-  msdw_scatter_any_tile<RAW ? 0 : 1, 1, RPT>(a, lds, a.src_keys, a.src_idx, nullptr, row0, nrows, 1 << a.b1, 64 - a.b1,
-                                             a.cursor1, a.l1_end, 0u, 0u, 4u, a.rec_x);
+  msdw_scatter_any_tile<RAW ? 0 : 1, 1, RPT, OUT8>(a, lds, a.src_keys, a.src_idx, nullptr, row0, nrows, 1 << a.b1, 64 - a.b1,
+                                                   a.cursor1, a.l1_end, 0u, 0u, 4u, a.rec_x);
 }
 
 // index of the last entry of start[0..nb] (nb + 1 entries, non-decreasing, start[0] == 0) that is <= g, computed by
@@ -2453,6 +2618,10 @@ __global__ __launch_bounds__(kMsdThreads) void msdw_hist1_kernel(MsdwArgs a) {
   const uint32_t mask = static_cast<uint32_t>(nb2 - 1);
   constexpr int U = 8;
   int64_t r = begin + tid;
+  if (a.rec8) {   // (workgroup-uniform) words: the level-2 digit is their top b2 bits
+    const uint64_t* __restrict__ words = reinterpret_cast<const uint64_t*>(a.rec_x);
+    for (; r < end; r += kMsdThreads) atomicAdd(&h[static_cast<uint32_t>(words[r] >> (64 - a.b2)) & mask], 1u);
+  }
   for (; r + (U - 1) * kMsdThreads < end; r += U * kMsdThreads) {
     uint64_t kk[U];
 #pragma unroll
@@ -2555,7 +2724,7 @@ __global__ __launch_bounds__(1024) void msdw_init2_kernel(MsdwArgs a) {
 }
 
 // W6: level 2 inside the level-1 buckets (tile map: l2_tile_start)
-template <bool GAP, int RPT>
+template <bool GAP, int RPT, bool REC8 = false>
 __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter2_kernel(MsdwArgs a) {
   constexpr int kTile = RPT * kMsdwThreads;
   __shared__ MsdwScatterLds lds;
@@ -2569,17 +2738,21 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter2_kernel(MsdwArgs a)
   const int64_t hi = a.l1_end[p];
   const int64_t row0 = lo + static_cast<int64_t>(g - a.l2_tile_start[p]) * kTile;
   const int nrows = static_cast<int>(hi - row0 < kTile ? hi - row0 : kTile);
-  msdw_scatter_any_tile<2, GAP ? 2 : 0, RPT>(a, lds, nullptr, nullptr, a.rec_x, row0, nrows, 1 << a.b2, 64 - a.bits,
-                                             a.cursor2 + (static_cast<size_t>(p) << a.b2), nullptr,
-                                             GAP ? a.y_base[p] : 0u, GAP ? a.room2[p] : 0u, 16u, a.rec_y);
+  // (rec8: records are words whose top b2 bits are the level-2 digit; rows are numbered in records either way)
+  msdw_scatter_any_tile<REC8 ? 3 : 2, GAP ? 2 : 0, RPT, REC8>(a, lds, nullptr, nullptr, a.rec_x, row0, nrows, 1 << a.b2,
+                                                              REC8 ? 64 - a.b2 : 64 - a.bits,
+                                                              a.cursor2 + (static_cast<size_t>(p) << a.b2), nullptr,
+                                                              GAP ? a.y_base[p] : 0u, GAP ? a.room2[p] : 0u, 16u, a.rec_y);
 }
 
 // overflowed: 0 sorted; 1 the keys are too skewed for this form (a bucket does not fit LDS) — try the next form;
 // 2 a level-2 room overflowed (gap2 only): call again with gap2 = 0 (the source may have been overwritten when it
 // shares memory with rec_y).
-static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n, MsdRec* rec_x,
-                             MsdRec* rec_y, int64_t capacity, uint8_t* tables, uint64_t* out_final, int gap2, int kshift,
-                             hipStream_t st, int* overflowed) {
+// 3 (rec8 only) too many rows tied in the 32 key bits of their words: call again with rec8 = 0 (the source is the
+// caller's column, untouched).
+static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n, MsdRec* rec_x,
+                                  MsdRec* rec_y, int64_t capacity, uint8_t* tables, uint64_t* out_final, int gap2, int kshift,
+                                  int rec8, hipStream_t st, int* overflowed) {
   *overflowed = 0;
   if (n == 0) return ARX_OK;
   int lg = 0;
@@ -2627,6 +2800,7 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
   a.rec_x = rec_x;
   a.rec_y = rec_y;
   a.gap2 = (gap2 != 0 && roomy) ? 1 : 0;
+  a.rec8 = (rec8 != 0 && raw != 0 && src_idx == nullptr) ? 1 : 0;   // (ties go back to the column: row id = position)
   const int nb1 = 1 << a.b1;
   const size_t nparts = size_t(1) << a.bits;
   // (each knob is read ONCE: the tile sizes, the grids and the template dispatch below must agree even if arx_set_option runs
@@ -2653,7 +2827,7 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
       nch = static_cast<unsigned>(ceil_div(n, a.chunk_rows));
     }
     ARX_HIP(hipMemsetAsync(a.l1_count, 0, static_cast<size_t>(nb1) * 4, st));
-    ARX_HIP(hipMemsetAsync(a.flags, 0, 16, st));
+    ARX_HIP(hipMemsetAsync(a.flags, 0, 32, st));
     if (raw) {
       hipLaunchKernelGGL((msdw_hist0_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
     } else {
@@ -2662,16 +2836,18 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
     ARX_CHECK_LAUNCH("msdw_hist0_kernel");
     hipLaunchKernelGGL(msdw_scan0_kernel, dim3(1), dim3(1024), 0, st, a);
     ARX_CHECK_LAUNCH("msdw_scan0_kernel");
-#define ARX_MSDW_SCATTER1(RAW)                                                                                      \
+#define ARX_MSDW_SCATTER1(RAW, OUT8)                                                                                      \
   switch (rpt1) {                                                                                  \
-    case 24: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 24>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break; \
-    case 16: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 16>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break; \
-    default: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break;  \
+    case 24: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 24, OUT8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break; \
+    case 16: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 16, OUT8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break; \
+    default: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 8, OUT8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break;  \
   }
-    if (raw) {
-      ARX_MSDW_SCATTER1(true)
+    if (a.rec8) {
+      ARX_MSDW_SCATTER1(true, true)
+    } else if (raw) {
+      ARX_MSDW_SCATTER1(true, false)
     } else {
-      ARX_MSDW_SCATTER1(false)
+      ARX_MSDW_SCATTER1(false, false)
     }
 #undef ARX_MSDW_SCATTER1
     ARX_CHECK_LAUNCH("msdw_scatter1_kernel");
@@ -2702,11 +2878,17 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
     break;
   }
   const unsigned grid2 = static_cast<unsigned>(ceil_div(n, a.tile2)) + static_cast<unsigned>(nb1);
-#define ARX_MSDW_SCATTER2(GAP)                                                                                      \
+#define ARX_MSDW_SCATTER2_(GAP, REC8)                                                                                      \
   switch (rpt2) {                                                                                  \
-    case 24: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 24>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break; \
-    case 16: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 16>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break; \
-    default: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 8>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break;  \
+    case 24: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 24, REC8>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break; \
+    case 16: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 16, REC8>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break; \
+    default: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 8, REC8>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break;  \
+  }
+#define ARX_MSDW_SCATTER2(GAP) \
+  if (a.rec8) {                \
+    ARX_MSDW_SCATTER2_(GAP, true) \
+  } else {                     \
+    ARX_MSDW_SCATTER2_(GAP, false) \
   }
   unsigned int max_part = 0;
   if (a.gap2) {
@@ -2740,6 +2922,7 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
     ARX_CHECK_LAUNCH("msdw_scatter2_kernel");
   }
 #undef ARX_MSDW_SCATTER2
+#undef ARX_MSDW_SCATTER2_
   MsdArgs f{};
   f.n = n;
   f.bits = a.bits;
@@ -2757,7 +2940,32 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
                               64 - kshift - a.bits));
   const uint64_t* recs = reinterpret_cast<const uint64_t*>(rec_y);
   const bool tiny9 = tiny_bkt && g_sort_msd_tiny_bucket >= 2 && max_part <= static_cast<unsigned int>(kBktCapTiny9);
-  if (tiny9 && cpt_bits) {
+  if (a.rec8) {
+    f.src_keys = src_keys;
+    f.raw = raw;
+    f.b1 = a.b1;
+    f.b2 = a.b2;
+    const int tie_shift = g_sort_msd_wide_rec8_tie_shift;
+    f.tie_limit = static_cast<uint32_t>(std::min<int64_t>(n >> std::min(tie_shift, 40), 0xFFFFFFF0ll));
+#define ARX_BUCKET2W(T, CPT, R) \
+  hipLaunchKernelGGL((msd_bucket2w_kernel<T, CPT, R>), dim3(static_cast<unsigned>(nparts)), dim3(T), 0, st, f, recs)
+    if (tiny9 && cpt_bits) {
+      ARX_BUCKET2W(kBktThreadsTiny, 8, kBktRowsTiny9);
+    } else if (tiny9) {
+      ARX_BUCKET2W(kBktThreadsTiny, 4, kBktRowsTiny9);
+    } else if (tiny_bkt && cpt_bits) {
+      ARX_BUCKET2W(kBktThreadsTiny, 8, kBktRows);
+    } else if (tiny_bkt) {
+      ARX_BUCKET2W(kBktThreadsTiny, 4, kBktRows);
+    } else if (small_bkt && cpt_bits) {
+      ARX_BUCKET2W(kBktThreadsSmall, 8, kBktRows);
+    } else if (small_bkt) {
+      ARX_BUCKET2W(kBktThreadsSmall, 4, kBktRows);
+    } else {
+      ARX_BUCKET2W(kBktThreads, 4, kBktRows);
+    }
+#undef ARX_BUCKET2W
+  } else if (tiny9 && cpt_bits) {
     hipLaunchKernelGGL((msd_bucket2_kernel<false, kBktThreadsTiny, true, 8, kBktRowsTiny9>), dim3(static_cast<unsigned>(nparts)),
                        dim3(kBktThreadsTiny), 0, st, f, recs, nullptr);
   } else if (tiny9) {
@@ -2780,10 +2988,19 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
                        dim3(kBktThreads), 0, st, f, recs, nullptr);
   }
   ARX_CHECK_LAUNCH("msd_bucket2_kernel");
-  unsigned int flag = 0;
-  ARX_HIP(hipMemcpyAsync(&flag, a.flags, 4, hipMemcpyDeviceToHost, st));
+  unsigned int fl8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  ARX_HIP(hipMemcpyAsync(fl8, a.flags, 32, hipMemcpyDeviceToHost, st));
   ARX_HIP(hipStreamSynchronize(st));
-  if ((flag & 16u) != 0) {
+  const unsigned int flag = fl8[0];
+  g_sort_wide_runs.fetch_add(1, std::memory_order_relaxed);
+  if (a.rec8) {
+    g_sort_wide_rec8_runs.fetch_add(1, std::memory_order_relaxed);
+    g_sort_wide_rec8_ties.fetch_add(fl8[4], std::memory_order_relaxed);
+  }
+  if ((flag & 32u) != 0 && (flag & ~32u) == 0) {
+    g_sort_wide_rec8_given_up.fetch_add(1, std::memory_order_relaxed);
+    *overflowed = 3;
+  } else if ((flag & 16u) != 0) {
     if (g_sort_msd_wide_sample_strict) {
       set_error("array_sort_indices: a level-2 room underestimated its bucket (sort_msd_wide_sample_strict)");
       return ARX_INVALID;
@@ -2793,6 +3010,19 @@ static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, 
     *overflowed = flag != 0;
   }
   return ARX_OK;
+}
+
+static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n, MsdRec* rec_x,
+                             MsdRec* rec_y, int64_t capacity, uint8_t* tables, uint64_t* out_final, int gap2, int kshift,
+                             hipStream_t st, int* overflowed) {
+  const int rec8 = g_sort_msd_wide_rec8;
+  int rc = run_msd_sort_wide_form(src_keys, src_idx, raw, n, rec_x, rec_y, capacity, tables, out_final, gap2, kshift, rec8, st,
+                                  overflowed);
+  if (rc == ARX_OK && *overflowed == 3) {
+    rc = run_msd_sort_wide_form(src_keys, src_idx, raw, n, rec_x, rec_y, capacity, tables, out_final, gap2, kshift, 0, st,
+                                overflowed);
+  }
+  return rc;
 }
 
 // Inputs beyond ~2^28 rows: one extra unstable level on the top b0 bits cuts the array into

@@ -375,6 +375,11 @@ def cpu_baseline_hash_sum(rows: int, groups: int, budget_s: float):
         if dt > budget_s:
             break
     best = max(res.values(), key=lambda x: x[0])
+    # the reference's answer on this prefix, key-sorted (acero/hash_aggregate_test.cc:262-280 sorts, then compares): kept for
+    # the parity leg, which runs the device plan the bench times on the same rows and diffs
+    rk, rs = out.column("k").to_numpy(), out.column("v_sum").to_numpy()
+    o = np.argsort(rk, kind="stable")
+    _CPU_REF["hash_sum"] = (n, groups, rk[o].copy(), rs[o].copy())
     return {"value": round(best[0], 2), "unit": "Mrows/s", "cores": best[1], "kind": "reference",
             "sample": f"SURVEY 8(d) sample: first {n} rows of the same streams ({best[2]} groups), pyarrow {pa.__version__} "
                       "Table.group_by(k).aggregate([(v, sum)])",
@@ -392,10 +397,83 @@ def cpu_baseline_sort(rows: int):
     t0 = time.perf_counter()
     out = pc.sort_indices(arr)       # one contiguous array: runs on the calling thread
     dt = time.perf_counter() - t0
+    _CPU_REF["sort_indices"] = (rows, out.to_numpy(zero_copy_only=False).astype(np.int64, copy=False))   # kept for the parity leg
     del out
     return {"value": round(rows / dt / 1e6, 2), "unit": "Mrows/s", "cores": 1, "kind": "reference",
             "sample": f"SURVEY 8(d) sample: first {rows} rows of the same stream, pyarrow {pa.__version__} pc.sort_indices "
                       "(std::stable_sort on indices, one thread)", "host_cpus": _host_cores()}
+
+
+# ------------------------------------------------------------------ parity of the sharded legs' timed plans (outside the timed region)
+_CPU_REF = {}          # the reference's results on the 1e8-row prefixes, kept by the cpu_baseline_* functions
+
+
+def _counters(lib, names):
+    return {n: int(lib.arx_get_counter(n.encode())) for n in names}
+
+
+def parity_hash_sum_prefix(device, groups_arg):
+    """The device group-by — the SAME plan the 4e9-row leg is timed on (the plan follows the group count, not the row count;
+    the counters say which ran, and the wide plan is forced if the estimate chose another) — on the first 1e8 rows of
+    streams 8 / 9, diffed against pyarrow's Table.group_by on the same rows: key-sorted (key, sum) equality."""
+    import arrow_amd as amd
+    from arrow_amd import parallel
+
+    n, groups, ref_k, ref_s = _CPU_REF["hash_sum"]
+    assert groups == groups_arg
+    lib = amd._lib.get_lib()
+    keys = gen_stream(n, device, 0, 8, modulo=groups, dtype=torch.int32)
+    vals = gen_stream(n, device, 0, 9)
+    kk = amd.Array(amd.array.int32, n, [None, keys.view(torch.uint8)], 0, 0)
+    vv = amd.Array(amd.array.int64, n, [None, vals.view(torch.uint8)], 0, 0)
+    cap = 1
+    while cap < 2 * groups + 2:
+        cap <<= 1
+    names = ("groupby_slices_wide", "groupby_slices_rooms", "groupby_slices_two_level", "groupby_slices_one_level", "groupby_slices_direct")
+    forced = False
+    for attempt in (0, 1):
+        c0 = _counters(lib, names)
+        gk, gk_valid, gs, gs_valid = parallel.sharded_group_by_sum(kk, vv, cap)[:4]
+        _sync(device)
+        plan = {k: v - c0[k] for k, v in _counters(lib, names).items() if v != c0[k]}
+        if plan.get("groupby_slices_wide", 0) > 0 or attempt == 1:
+            break
+        assert lib.arx_set_option(b"groupby_wide", 2) == 0 and lib.arx_set_option(b"groupby_partition_bits", 11) == 0
+        forced = True
+    if forced:
+        lib.arx_set_option(b"groupby_wide", 1)
+        lib.arx_set_option(b"groupby_partition_bits", -1)
+    hk = gk.cpu().numpy().view(np.int32)
+    hs = gs.cpu().numpy().view(np.int64)
+    o = np.argsort(hk, kind="stable")
+    equal = bool(len(hk) == len(ref_k) and bool(gk_valid.all().item()) and bool(gs_valid.all().item()) and
+                 (hk[o] == ref_k).all() and (hs[o] == ref_s).all())
+    return ("equal" if equal else "MISMATCH"), {"rows": n, "groups": int(len(hk)), "wide_plan_forced": forced, **plan}
+
+
+def parity_sort_prefix(device):
+    """array_sort_indices on the first 1e8 rows of stream 10 with the WIDE form forced (the form the 2e9-row leg is timed
+    on is chosen by row count: sort_msd_segment_rows lowers its threshold here), diffed against pyarrow's sort_indices:
+    exact index equality (vector_sort_test.cc:971-1062 compares indices)."""
+    import arrow_amd as amd
+    from arrow_amd import parallel
+
+    n, ref = _CPU_REF["sort_indices"]
+    lib = amd._lib.get_lib()
+    keys = gen_stream(n, device, 0, 10)
+    ak = amd.Array(amd.array.uint64, n, [None, keys.view(torch.uint8)], 0, 0)
+    names = ("sort_wide_runs", "sort_wide_rec8_runs", "sort_wide_rec8_ties", "sort_wide_rec8_given_up")
+    c0 = _counters(lib, names)
+    assert lib.arx_set_option(b"sort_msd_segment_rows", 4096) == 0
+    try:
+        rows, _ = parallel.sharded_sort_indices(ak)
+        _sync(device)
+    finally:
+        lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
+    plan = {k: v - c0[k] for k, v in _counters(lib, names).items()}
+    want = torch.from_numpy(ref).to(device)
+    equal = bool(rows.numel() == want.numel() and torch.equal(rows, want)) and plan["sort_wide_runs"] >= 1
+    return ("equal" if equal else "MISMATCH"), {"rows": n, **plan}
 
 
 # ------------------------------------------------------------------ parity spot check (outside the timed region)
@@ -667,6 +745,14 @@ def run_filter_take(args, rank, world, device):
             result["sort_indices"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if watchdog is not None:
         watchdog.cancel()
+    if args.extras and rank == 0 and world == 1:
+        # VERDICT r4 "Next round" 2a: the kernels the two legs above are timed on, diffed with the reference's own answer
+        hs, so = result.get("hash_sum", {}), result.get("sort_indices", {})
+        if "parity_prefix" in hs or "parity_prefix" in so:
+            result["parity"] = {"hash_sum_prefix": hs.get("parity_prefix", "not run"), "sort_prefix": so.get("parity_prefix", "not run"),
+                                "plan": {"hash_sum": hs.get("parity_plan"), "sort_indices": so.get("parity_plan")},
+                                "what": "device result of the timed plan on the first 1e8 rows of the legs' streams vs pyarrow "
+                                        "(Table.group_by key-sorted (key, sum); sort_indices index for index)"}
     if args.extras and rank == 0 and world == 1 and not EMU:
         # LAST: registering the plugin re-routes pyarrow's own kernels to the GPU for the rest of the process,
         # so every CPU baseline above had to be taken first
@@ -1048,6 +1134,11 @@ def hash_sum_leg(args, rank, world, device, rows_total, steps, warmup):
                 leg["cpu_baseline"] = cpu_baseline_hash_sum(min(rows, args.cpu_groupby_rows), args.groups, args.cpu_budget_s)
             except Exception as e:
                 leg["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        if "hash_sum" in _CPU_REF:
+            try:
+                leg["parity_prefix"], leg["parity_plan"] = parity_hash_sum_prefix(device, args.groups)
+            except Exception as e:
+                leg["parity_prefix"] = f"ERROR {type(e).__name__}: {e}"[:300]
     return leg
 
 
@@ -1071,6 +1162,11 @@ def sort_leg(args, rank, world, device, rows_total, steps, warmup):
                 leg["cpu_baseline"] = cpu_baseline_sort(min(rows, args.cpu_sort_rows))
             except Exception as e:
                 leg["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        if "sort_indices" in _CPU_REF:
+            try:
+                leg["parity_prefix"], leg["parity_plan"] = parity_sort_prefix(device)
+            except Exception as e:
+                leg["parity_prefix"] = f"ERROR {type(e).__name__}: {e}"[:300]
     return leg
 
 

@@ -861,6 +861,81 @@ def check_sort_wide_many_bins(amd, lib, rng, n, bits, b2max, combos=((2, 1), (0,
         lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
 
 
+def check_sort_wide_rec8(amd, lib, rng, n, bits=0, gap2=1, shift=0, rpt=(24, 16)):
+    """The wide form over the caller's own column moves 8-byte words {32 key bits below the level-1 digit, row id}
+    (sort_msd_wide_rec8, the default): level 2 and the finish take their digits from the word, the finish ranks whole
+    words, and rows whose 32 bits tie read their full keys from the column.  Cases: uniform keys (almost no tie); keys
+    that agree in their top 41+ bits and differ only BELOW the word (every row of a sub-bucket ties: the order is decided by
+    the column reads alone); exact duplicates (ties that stay ties: row-id order); signed descending; float64 bit patterns;
+    a shared prefix that leaves no bit below the word (no column reads at all); the tie budget spent at once (the call is
+    repeated with full records: same order); and rec8 switched off.  Counters say which form really ran."""
+    opts = {b"sort_msd": 1, b"sort_msd_segment_rows": 4096, b"sort_msd_wide": 1, b"sort_msd_wide_bits": bits,
+            b"sort_msd_wide_gap2": gap2, b"sort_msd_wide_sample_shift": shift, b"sort_msd_wide_rpt1": rpt[0],
+            b"sort_msd_wide_rpt2": rpt[1], b"sort_msd_wide_rec8": 1, b"sort_msd_wide_rec8_tie_shift": 0}
+    for k, v in opts.items():
+        assert lib.arx_set_option(k, v) == 0
+    ctr = lambda name: int(lib.arx_get_counter(name))
+
+    def run(arr, order="ascending", placement="at_end"):
+        before = {c: ctr(c) for c in (b"sort_wide_runs", b"sort_wide_rec8_runs", b"sort_wide_rec8_ties", b"sort_wide_rec8_given_up")}
+        check_sort_indices(amd, arr, order, placement, use_pyarrow=False)
+        return {c.decode()[10:]: ctr(c) - v for c, v in before.items()}
+
+    try:
+        uniform = util.random_array(rng, np.uint64, n, offset=3)
+        d = run(uniform)
+        assert d["runs"] == 1 and d["rec8_runs"] == 1 and d["rec8_given_up"] == 0, d
+        # hb uniform top bits (about one row per value), zero bits down to bit 20, 20 random bits: rows that share their top
+        # bits tie in the word and differ below it
+        hb = max(8, int(np.ceil(np.log2(n))))
+        hi = rng.integers(0, 1 << hb, size=n, dtype=np.uint64) << np.uint64(64 - hb)
+        below = HostArray(hi | rng.integers(0, 1 << 20, size=n, dtype=np.uint64), None, 0, n)
+        d = run(below)
+        assert d["rec8_runs"] == 1 and d["rec8_given_up"] == 0 and d["rec8_ties"] > n // 4, d
+        d = run(HostArray(below.values.view(np.int64).copy(), None, 0, n), "descending", "at_start")
+        assert d["rec8_runs"] == 1 and d["rec8_given_up"] == 0 and d["rec8_ties"] > n // 4, d
+        pool = rng.integers(0, 1 << 64, size=n, dtype=np.uint64)
+        dups = HostArray(pool[rng.integers(0, len(pool), size=n)], None, 0, n)
+        d = run(dups)
+        assert d["rec8_runs"] == 1 and d["rec8_given_up"] == 0 and d["rec8_ties"] > n // 4, d
+        # runs of ~60 rows that agree in the word: too many column reads per row — given up at once, full records sort them
+        hi = rng.integers(0, 1 << (hb - 6), size=n, dtype=np.uint64) << np.uint64(64 - (hb - 6))
+        d = run(HostArray(hi | rng.integers(0, 1 << 20, size=n, dtype=np.uint64), None, 0, n))
+        assert d["runs"] == 2 and d["rec8_runs"] == 1 and d["rec8_given_up"] == 1, d
+        fbits = rng.integers(0, 1 << 64, size=n, dtype=np.uint64)
+        fbits[(fbits >> np.uint64(52)) & np.uint64(0x7FF) == np.uint64(0x7FF)] = np.uint64(0x3FF0000000000000)   # (NaN / inf -> 1.0)
+        fbits[::7] &= np.uint64(0xFFFFFFFFFFF00000)
+        d = run(HostArray(fbits.view(np.float64).copy(), None, 0, n))
+        assert d["rec8_runs"] == 1, d
+        # 32 shared leading bits + the level-1 digit + 32 bits in the word >= 64: a tie in the word is a tie of the keys
+        narrow = HostArray((np.uint64(0xABCDEF12) << np.uint64(32)) | rng.integers(0, 1 << 32, size=n, dtype=np.uint64), None, 0, n)
+        d = run(narrow)
+        assert d["rec8_runs"] == 1 and d["rec8_ties"] == 0, d
+        # the tie budget: n >> 40 = 0 rows -> the first tied row gives the attempt up, the call runs again with full records
+        assert lib.arx_set_option(b"sort_msd_wide_rec8_tie_shift", 40) == 0
+        d = run(below)
+        assert d["runs"] == 2 and d["rec8_runs"] == 1 and d["rec8_given_up"] == 1, d
+        d = run(uniform)            # (a handful of ties at most: with none the budget is never looked at)
+        assert d["rec8_runs"] == 1 and d["runs"] == 1 + d["rec8_given_up"], d
+        assert lib.arx_set_option(b"sort_msd_wide_rec8_tie_shift", 0) == 0
+        with_nulls = util.random_array(rng, np.uint64, n, null_p=0.03)      # a row-id column beside the keys: full records
+        d = run(with_nulls)
+        assert d["runs"] == 1 and d["rec8_runs"] == 0, d
+        assert lib.arx_set_option(b"sort_msd_wide_rec8", 0) == 0
+        d = run(below)
+        assert d["runs"] == 1 and d["rec8_runs"] == 0, d
+    finally:
+        lib.arx_set_option(b"sort_msd_wide_rec8", 1)
+        lib.arx_set_option(b"sort_msd_wide_rec8_tie_shift", 5)
+        lib.arx_set_option(b"sort_msd_wide_bits", 0)
+        lib.arx_set_option(b"sort_msd_wide_rpt1", SORT_WIDE_RPT_DEFAULT[0])
+        lib.arx_set_option(b"sort_msd_wide_rpt2", SORT_WIDE_RPT_DEFAULT[1])
+        lib.arx_set_option(b"sort_msd_wide_sample_shift", 4)
+        lib.arx_set_option(b"sort_msd_wide_gap2", 1)
+        lib.arx_set_option(b"sort_msd", -1)
+        lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
+
+
 def check_sort_limited_range(amd, lib, rng, n, wide, light=False):
     """Keys that share their top bits (row ids, timestamps, small or clustered integers): the MSD forms must take their
     digits below the shared prefix (sort_msd_prefix) — same order as the oracle with the knob on and off, ascending and

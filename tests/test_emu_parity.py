@@ -458,6 +458,13 @@ def test_sort_wide_many_level2_bins(emu_ctx, bits, b2max):
                                 b2max, combos=((2, 1),))
 
 
+@pytest.mark.parametrize("bits,gap2,shift,rpt", [(0, 1, 0, (24, 16)), (12, 0, 2, (8, 8)), (6, 1, 2, (16, 24))])
+def test_sort_wide_rec8_words(emu_ctx, bits, gap2, shift, rpt):
+    """8-byte {key bits, row id} words through the wide form: ties below the word, duplicates, the tie budget, fall-backs."""
+    P.check_sort_wide_rec8(emu_ctx, emu_ctx._lib.get_lib(), rng_for("wide-rec8", bits, gap2), 120_000 if bits == 0 else 40_000,
+                           bits=bits, gap2=gap2, shift=shift, rpt=rpt)
+
+
 def test_null_count_bookkeeping(emu_ctx):
     P.check_null_count_bookkeeping(emu_ctx, rng_for("nullcount"))
 

@@ -671,6 +671,14 @@ def test_sort_wide_register_staged_tiles(gpu_ctx, rpt):
         lib.arx_set_option(b"sort_msd_bucket_cpt", 4)
 
 
+@pytest.mark.parametrize("n,bits,gap2,shift,rpt", [(6_000_011, 0, 1, 4, (24, 16)), (3_000_003, 14, 0, 2, (8, 8)), (2_000_003, 8, 1, 0, (16, 24)),
+                                                   (40_000_003, 0, 1, 4, (24, 16))])
+def test_sort_wide_rec8_words(gpu_ctx, n, bits, gap2, shift, rpt):
+    """8-byte {key bits, row id} words through the wide form (the form the 2e9-row bench runs): ties below the word,
+    duplicates, the tie budget, fall-backs; counters prove which form ran."""
+    P.check_sort_wide_rec8(gpu_ctx, gpu_ctx._lib.get_lib(), rng_for("wide-rec8", n, bits), n, bits=bits, gap2=gap2, shift=shift, rpt=rpt)
+
+
 @pytest.mark.parametrize("bits,b2max", [(13, 12), (16, 12), (20, 12), (19, 11), (19, 0)])
 def test_sort_wide_many_level2_bins(gpu_ctx, bits, b2max):
     P.check_sort_wide_many_bins(gpu_ctx, gpu_ctx._lib.get_lib(), rng_for("wide-bins", bits, b2max), 5_000_003, bits,
