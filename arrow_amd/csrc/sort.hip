@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <vector>
 
 namespace arx {
 
@@ -49,7 +50,9 @@ static Knob<int> g_sort_msd_bucket_cpt{4};         // wide form's bucket finish:
 static Knob<int> g_sort_msd_prefix{1};             // MSD forms take their digits below the bits that ALL keys share (ids, timestamps, small ints: the top bits are equal)
 static Knob<int> g_sort_msd_wide_gap2{1};          // wide form: level-2 buckets get a fixed room each (bucket mean + 6 sigma + 64) instead of an exact histogram pass
 static Knob<int> g_sort_msd_wide_rec8{1};           // wide form over the caller's own column: 8-byte {32 key bits below the level-1 digit, row id} records through both levels and the finish (48.5 B/row instead of 64.5); rows whose 32 bits tie read their full keys from the column
-static Knob<int> g_sort_msd_wide_rec8_tie_shift{6};  // ... given up (and repeated with 12-byte records) once more than n >> shift rows tied (duplicate-heavy keys: every tie is two random 8-byte reads)
+static Knob<int> g_sort_msd_wide_rec8_tie_shift{4};  // ... given up (and repeated with 12-byte records) once more than (rows >> shift) rows of ONE bucket tied (duplicate-heavy keys: every tie is two random 8-byte reads; 2e9 uniform keys: 0.9 per 1000)
+static Knob<int> g_sort_msd_wide_wc{256};          // rec8 form: level 1 write-combined by this many persistent workgroups (0 = the tile-at-a-time level 1)
+static Knob<int> g_sort_msd_wide_wc_prefetch{1};   // ... with 16-row tiles and the next tile's keys requested before the current one's words leave
 static Knob<int> g_sort_msd_wide_sample_strict{0}; // tests: a sampled attempt that overflows is an error instead of a silent exact re-run
 static Knob<int> g_sort_msd_wide{1};          // inputs beyond sort_msd_segment_rows: the wide two-level form (run_msd_sort_wide) before the segmented one
 static Knob<int> g_sort_msd_bucket_v2{1};     // single-atomic-pass bucket finish with up to 4096 sub-buckets (msd_bucket2_kernel)
@@ -601,7 +604,7 @@ struct MsdArgs {
   unsigned int* overflow;
   const uint32_t* part_in;    // record input of the bucket finish (AOS form): first record of every bucket
   int xcd_map;                // XCD-contiguous work numbering: bit 0 the level-2 scatter, bit 1 the bucket finish
-  uint32_t tie_limit;         // rec8 finish: give up (overflow bit 32) once more rows than this read their full key
+  int tie_shift;              // rec8 finish: a bucket gives up (overflow bit 32) once more than (its rows >> tie_shift) rows tied
 };
 
 // (key, row id) as one 12-byte record: what the wide form's two scatter levels write and read (one output stream per
@@ -1418,15 +1421,18 @@ __global__ __launch_bounds__(T) void msd_bucket2_kernel(MsdArgs a, const uint64_
 // inside a sub-bucket that is the order of (key bits in the word, row id).  Rows whose 32 key bits tie with another row
 // of their sub-bucket (2e9 uniform keys: 0.9 per 1000) read the full keys of both from the caller's column and correct
 // their rank by the bits below; when the word already holds every remaining key bit (32-bit key types, shared prefixes)
-// a tie is a tie.  Every such row counts itself in overflow[4]; past tie_limit rows, or at a row with more than
-// kMsdwMaxTied tied neighbours, the kernel gives up (bit 32) and the host repeats the sort with full records —
-// duplicate-heavy keys would pay 1 + (tied neighbours) random 8-byte reads per row here.
+// a tie is a tie.  A bucket in which more than (its rows >> tie_shift) rows tie, or a row with more than kMsdwMaxTied tied
+// neighbours, gives the attempt up (bit 32: later workgroups return at once) and the host repeats the sort with full
+// records — duplicate-heavy keys would pay 1 + (tied neighbours) random 8-byte reads per row here.
+constexpr int kMsdwTieSlot0 = 64;   // flags[64 + 32 k], k < 32: tie counts (one 128-byte line each)
+constexpr int kMsdwFlagWords = kMsdwTieSlot0 + 32 * 32;
 constexpr int kMsdwMaxTied = 16;   // rec8 finish: a row with more tied neighbours than this gives the attempt up
 template <int T, int CPT = 4, int R = kBktRows>
 struct __attribute__((aligned(16))) MsdBucket2wLds {
   uint64_t words[T * R];
   uint32_t start[CPT * T + 1];   // counts, then exclusive starts (+ sentinel)
   uint32_t wave_tot[T / 64];
+  uint32_t ties;                 // rows of this bucket that read their full key
 };
 
 template <int T, int CPT = 4, int R = kBktRows>
@@ -1435,7 +1441,13 @@ __global__ __launch_bounds__(T) void msd_bucket2w_kernel(MsdArgs a, const uint64
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  if ((__atomic_load_n(a.overflow, __ATOMIC_RELAXED) & 32u) != 0) return;   // given up: the call is repeated
+  // given up: the call is repeated.  ONE thread looks and tells the others — the bit may appear between the loads of two
+  // threads, and a workgroup of which some threads left ranks garbage and reads the column at garbage row ids
+  // (profiles/r05_e: "illegal memory access" on a few runs in ten)
+  if (tid == 0) w.ties = __atomic_load_n(a.overflow, __ATOMIC_RELAXED) & 32u;
+  __syncthreads();
+  if (w.ties != 0) return;   // workgroup-uniform
+  __syncthreads();           // (everyone has read it before thread 0 reuses the word as the tie counter)
   const uint32_t q = (a.xcd_map & 2) ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   const int64_t lo = a.part_start[q];
   const int m = static_cast<int>(static_cast<int64_t>(a.part_start[q + 1]) - lo);
@@ -1449,6 +1461,9 @@ __global__ __launch_bounds__(T) void msd_bucket2w_kernel(MsdArgs a, const uint64
   const int dsh = 64 - a.b3;
   auto digit_of = [&](uint64_t wd) -> uint32_t { return a.b3 == 0 ? 0u : static_cast<uint32_t>((wd << a.b2) >> dsh); };
   const bool bits_below = a.kshift + a.b1 + 32 < 64;   // key bits the words do not hold
+  // this bucket's share of the tie budget: m >> tie_shift rows (one counter per address serialises at ~40 ns per
+  // returning atomic — 1.8e6 tied rows of 2e9 cost 69 ms that way, profiles/r05_a — so the budget is kept per bucket, in LDS)
+  const uint32_t tie_limit = a.tie_shift >= 31 ? 0u : static_cast<uint32_t>(m) >> a.tie_shift;
   for (int i = tid; i < nb; i += T) w.start[i] = 0;
   uint64_t wd[R];
 #pragma unroll
@@ -1506,7 +1521,7 @@ __global__ __launch_bounds__(T) void msd_bucket2w_kernel(MsdArgs a, const uint64
       tied += ((((w0 ^ wi) >> 32) == 0 && j != i) ? 1 : 0) + ((two && ((w1 ^ wi) >> 32) == 0 && j + 1 != i) ? 1 : 0);
     }
     if (tied > kMsdwMaxTied && bits_below) {   // a run of equal words: quadratic in column reads — not this form's input
-      atomicOr(a.overflow, 32u);
+      if ((__atomic_load_n(a.overflow, __ATOMIC_RELAXED) & 32u) == 0) atomicOr(a.overflow, 32u);
     } else if (tied != 0 && bits_below) {   // (rare) the bits below decide before the row ids do
       const uint64_t ki = load_key_typed(a.src_keys, static_cast<int64_t>(static_cast<uint32_t>(wi)), a.raw);
       for (int j = bs; j < be; ++j) {
@@ -1518,10 +1533,15 @@ __global__ __launch_bounds__(T) void msd_bucket2w_kernel(MsdArgs a, const uint64
           rk += (before ? 1 : 0) - (counted ? 1 : 0);
         }
       }
-      if (atomicAdd(&a.overflow[4], 1u) >= a.tie_limit) atomicOr(a.overflow, 32u);
+      if (atomicAdd(&w.ties, 1u) == tie_limit && (__atomic_load_n(a.overflow, __ATOMIC_RELAXED) & 32u) == 0) {
+        atomicOr(a.overflow, 32u);   // (once per bucket at most)
+      }
     }
     a.out_final[lo + bs + rk] = static_cast<uint32_t>(wi);
   }
+  __syncthreads();
+  // statistics only (arx_get_counter "sort_wide_rec8_ties"): one atomic per bucket with ties, spread over 32 lines
+  if (tid == 0 && w.ties != 0) atomicAdd(&a.overflow[kMsdwTieSlot0 + 32 * (q & 31u)], w.ties);
 }
 
 // (A persistent form of this finish — workgroups walking buckets q, q + grid, ... and loading the next bucket's rows
@@ -1580,13 +1600,15 @@ static SortPlan make_plan(int64_t length) {
 }
 
 // which record form the wide sorts of this process ran with (arx_get_counter; tests and the bench's parity leg)
-static std::atomic<int64_t> g_sort_wide_runs{0}, g_sort_wide_rec8_runs{0}, g_sort_wide_rec8_ties{0}, g_sort_wide_rec8_given_up{0};
+static std::atomic<int64_t> g_sort_wide_runs{0}, g_sort_wide_rec8_runs{0}, g_sort_wide_rec8_ties{0}, g_sort_wide_rec8_given_up{0},
+    g_sort_wide_wc_runs{0};
 
 int get_sort_counter(const char* name, int64_t* out) {
   if (strcmp(name, "sort_wide_runs") == 0) *out = g_sort_wide_runs.load();
   else if (strcmp(name, "sort_wide_rec8_runs") == 0) *out = g_sort_wide_rec8_runs.load();
   else if (strcmp(name, "sort_wide_rec8_ties") == 0) *out = g_sort_wide_rec8_ties.load();
   else if (strcmp(name, "sort_wide_rec8_given_up") == 0) *out = g_sort_wide_rec8_given_up.load();
+  else if (strcmp(name, "sort_wide_wc_runs") == 0) *out = g_sort_wide_wc_runs.load();
   else return 0;
   return 1;
 }
@@ -1647,6 +1669,14 @@ int set_sort_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "sort_msd_wide_rec8") == 0) {
     g_sort_msd_wide_rec8 = value != 0;
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_wc") == 0) {
+    g_sort_msd_wide_wc = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 4096)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_wc_prefetch") == 0) {
+    g_sort_msd_wide_wc_prefetch = value != 0;
     return 1;
   }
   if (strcmp(name, "sort_msd_wide_rec8_tie_shift") == 0) {
@@ -2058,6 +2088,8 @@ struct MsdwArgs {
   int xcd_map1;            // level 1 likewise (A/B)
   int tile1, tile2;        // rows per scatter tile of level 1 / level 2: kMsdwTile, or 2x / 3x that held in registers
   int rec8;                // records are 8-byte words {the 32 key bits below the level-1 digit, row id} (msdw_word)
+  int wc1;                 // rec8, level 1 write-combined (msdw_scatter1wc_kernel): > 0 = its persistent workgroups; buckets
+                           // start on 128-byte lines, hold kMsdwPad words, and l1_count[] becomes their exact row counts
   int64_t capacity;        // records rec_x / rec_y can hold
   uint32_t* l1_count;      // [2^b1] histogram (of the sample)
   uint32_t* l1_start;      // [2^b1] first record of a level-1 bucket in rec_x (buckets may be followed by unused room)
@@ -2074,7 +2106,7 @@ struct MsdwArgs {
   uint32_t* flags;         // [0] bits: 2 a bucket does not fit LDS, 4 a level-1 bucket outgrew its room, 8 fixed level-2
                            //     rooms are not possible here, 16 a level-2 bucket outgrew its room, 32 rec8: too many rows
                            //     tied in their 32 record bits; [1] largest bucket; [2] sampled rows; [3] gap2: largest
-                           //     level-2 room; [4] rec8: rows that read their full key
+                           //     level-2 room; [64 + 32 k] rec8: rows that read their full key (32 partial counts)
   MsdRec* rec_x;           // level-1 output
   MsdRec* rec_y;           // level-2 output
 };
@@ -2142,6 +2174,10 @@ __global__ __launch_bounds__(1024) void msdw_scan0_kernel(MsdwArgs a) {
     const uint64_t extra = est / 8 + 1 < 16384 ? est / 8 + 1 : 16384;
     room = tid < nb ? est + est / 32 + extra : 0;
   }
+  if (a.wc1 > 0) {   // whole lines; every workgroup ends with at most one padded line per bucket
+    room = tid < nb ? ((room + 15) & ~uint64_t(15)) + 16u * static_cast<uint64_t>(a.wc1) : 0;
+    if (tid < nb) a.l1_count[tid] = 0;   // from here on: rows that arrived (msdw_scatter1wc_kernel adds them up)
+  }
   const uint64_t incl = wave_inclusive_scan_u64(room);
   if (lane == 63) wt[wave] = incl;
   __syncthreads();
@@ -2169,19 +2205,21 @@ __global__ __launch_bounds__(1024) void msdw_scan0b_kernel(MsdwArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int nb = 1 << a.b1;
-  uint32_t c = 0;
+  uint32_t c = 0;      // rows of the bucket
+  uint32_t span = 0;   // records it occupies (write-combined level 1: its rows + pads)
   if (tid < nb) {
     const uint32_t lo = a.l1_start[tid], room_end = a.l1_end[tid], cur = a.cursor1[tid];
     if (cur > room_end || cur < lo) {
       atomicOr(&a.flags[0], 4u);
-      c = room_end - lo;
+      span = room_end - lo;
     } else {
-      c = cur - lo;
+      span = cur - lo;
     }
-    a.l1_end[tid] = lo + c;
+    a.l1_end[tid] = lo + span;
+    c = a.wc1 > 0 ? a.l1_count[tid] : span;
   }
-  const uint32_t tiles = (c + static_cast<uint32_t>(a.tile2) - 1) / static_cast<uint32_t>(a.tile2);
-  const uint32_t units = static_cast<uint32_t>((static_cast<int64_t>(c) + kMsdwUnit - 1) / kMsdwUnit);
+  const uint32_t tiles = (span + static_cast<uint32_t>(a.tile2) - 1) / static_cast<uint32_t>(a.tile2);
+  const uint32_t units = static_cast<uint32_t>((static_cast<int64_t>(span) + kMsdwUnit - 1) / kMsdwUnit);
   uint32_t room = 0;
   if (a.gap2 && c != 0) {
     const uint32_t mean = (c + (1u << a.b2) - 1) >> a.b2;
@@ -2289,6 +2327,7 @@ __device__ __forceinline__ void msdw_reserve_runs(uint32_t* __restrict__ cursor,
 // level-1 bucket the unsigned order of the words is the order of (those 41 + kshift leading key bits, row id): level 2
 // and the finish take their digits from the top of the word, the finish ranks whole words, and only rows whose 32 bits
 // tie inside a sub-bucket go back to the column for the bits below (msd_bucket2w_kernel).
+constexpr uint64_t kMsdwPad = ~uint64_t(0);   // no row: a row id of 2^32 - 1 is never a row (the forms stop below 2^32 - 4096 rows)
 __device__ __forceinline__ uint64_t msdw_word(uint64_t key, uint32_t id, int kshift, int b1) {
   const int sh = kshift + b1;
   const uint64_t below = sh < 64 ? key << sh : 0;
@@ -2340,8 +2379,8 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
 #pragma unroll
   for (int i = 0; i < kMsdwRows; ++i) {
     dig[i] = static_cast<uint32_t>((key[i] << ksh) >> dshift) & dmask;
-    rank[i] = 0;
-    if (i * kMsdwThreads + tid < nrows) rank[i] = atomicAdd(&lds.cnt[dig[i]], 1u);
+    rank[i] = 0xFFFFFFFFu;   // no row: past the tile's end, or (words) a pad of the write-combined level 1
+    if (i * kMsdwThreads + tid < nrows && (SRC != 3 || key[i] != kMsdwPad)) rank[i] = atomicAdd(&lds.cnt[dig[i]], 1u);
   }
   __syncthreads();
   // exclusive scan of nb <= 4096 counters: `per` consecutive counters per thread (1 up to 1024 bins)
@@ -2382,14 +2421,15 @@ __device__ __forceinline__ void msdw_scatter_tile(const MsdwArgs& a, MsdwScatter
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < kMsdwRows; ++i) {
-    if (i * kMsdwThreads + tid < nrows) {
+    if (rank[i] != 0xFFFFFFFFu) {
       const uint32_t pos = lds.start[dig[i]] + rank[i];
       lds.keys[pos] = key[i];
       if constexpr (SRC != 3) lds.idx[pos] = idx[i];
     }
   }
   __syncthreads();
-  for (int p = tid; p < nrows; p += kMsdwThreads) {
+  const int nplaced = SRC == 3 ? static_cast<int>(lds.start[nb - 1] + lds.cnt[nb - 1]) : nrows;   // (pads take no place)
+  for (int p = tid; p < nplaced; p += kMsdwThreads) {
     const uint64_t k = lds.keys[p];
     const uint32_t d = static_cast<uint32_t>((k << ksh) >> dshift) & dmask;
     const uint32_t gb = lds.gbase[d];
@@ -2472,7 +2512,7 @@ __device__ __forceinline__ void msdw_scatter_big_tile(const MsdwArgs& a, MsdwSca
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const uint32_t d = static_cast<uint32_t>((key[i] << ksh) >> dshift) & dmask;
-    const uint32_t pr = (i * kMsdwThreads + tid < nrows) ? atomicAdd(&lds.cnt[d], 1u) : 0xFFFFu;
+    const uint32_t pr = (i * kMsdwThreads + tid < nrows && (SRC != 3 || key[i] != kMsdwPad)) ? atomicAdd(&lds.cnt[d], 1u) : 0xFFFFu;
     pos2[i / 2] = (i & 1) ? (pos2[i / 2] | (pr << 16)) : pr;
     if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);   // eight atomics in flight, not RPT (their addresses and results are registers)
   }
@@ -2520,9 +2560,10 @@ __device__ __forceinline__ void msdw_scatter_big_tile(const MsdwArgs& a, MsdwSca
     pos2[i / 2] = (i & 1) ? ((pos2[i / 2] & 0xFFFFu) | (at << 16)) : ((pos2[i / 2] & 0xFFFF0000u) | at);
     if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
   }
+  const int nplaced = SRC == 3 ? static_cast<int>(lds.start[nb - 1] + lds.cnt[nb - 1]) : nrows;   // (pads take no place)
   for (int r = 0; r < RPT / kMsdwRows; ++r) {
     const uint32_t lo = static_cast<uint32_t>(r) * kMsdwTile;
-    if (static_cast<int>(lo) >= nrows) break;   // workgroup-uniform
+    if (static_cast<int>(lo) >= nplaced) break;   // workgroup-uniform
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const uint32_t q = ((pos2[i / 2] >> ((i & 1) * 16)) & 0xFFFFu) - lo;   // (no row: 0xFFFF - lo is never inside the buffer)
@@ -2536,7 +2577,7 @@ __device__ __forceinline__ void msdw_scatter_big_tile(const MsdwArgs& a, MsdwSca
       }
     }
     __syncthreads();
-    const int cnt = nrows - static_cast<int>(lo) < kMsdwTile ? nrows - static_cast<int>(lo) : kMsdwTile;
+    const int cnt = nplaced - static_cast<int>(lo) < kMsdwTile ? nplaced - static_cast<int>(lo) : kMsdwTile;
     for (int p = tid; p < cnt; p += kMsdwThreads) {
       const uint64_t k = lds.keys[p];
       const uint32_t d = static_cast<uint32_t>((k << ksh) >> dshift) & dmask;
@@ -2577,14 +2618,227 @@ template <bool RAW, int RPT, bool OUT8 = false>
 __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1_kernel(MsdwArgs a) {
   __shared__ MsdwScatterLds lds;
   // an earlier tile already found a bucket without room: the level will be repeated, do not finish this attempt
-  // (e.g. pre-sorted input, where a sample of tiles says little about where the bucket boundaries fall)
-  if (a.sample_shift > 0 && (__atomic_load_n(&a.flags[0], __ATOMIC_RELAXED) & 4u) != 0) return;
+  // (e.g. pre-sorted input, where a sample of tiles says little about where the bucket boundaries fall).  One thread
+  // looks for the whole workgroup: the bit may appear between two threads' loads, and half a workgroup scatters garbage
+  if (a.sample_shift > 0) {
+    if (threadIdx.x == 0) lds.part = __atomic_load_n(&a.flags[0], __ATOMIC_RELAXED) & 4u;
+    __syncthreads();
+    if (lds.part != 0) return;   // workgroup-uniform
+    __syncthreads();
+  }
   constexpr int kTile = RPT * kMsdwThreads;
   const uint32_t tile = a.xcd_map1 ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   const int64_t row0 = static_cast<int64_t>(tile) * kTile;
   const int nrows = static_cast<int>(a.n - row0 < kTile ? a.n - row0 : kTile);
   msdw_scatter_any_tile<RAW ? 0 : 1, 1, RPT, OUT8>(a, lds, a.src_keys, a.src_idx, nullptr, row0, nrows, 1 << a.b1, 64 - a.b1,
                                                    a.cursor1, a.l1_end, 0u, 0u, 4u, a.rec_x);
+}
+
+// Level 1 of the rec8 form, WRITE-COMBINED (VERDICT r4 "Next round" 3).  What bounds a scatter whose bins span the whole
+// array is the partial 128-byte lines at both ends of every (tile, bin) run, not its bytes: the same level ran 12.6 ms
+// writing 8-byte words and 11.9 ms writing 12-byte records (profiles/r05_a).  Here a PERSISTENT workgroup keeps one
+// line (16 words) per bin in LDS: a tile's run of bin d follows what the bin has left over from the workgroup's earlier
+// tiles, whole lines go out at line-aligned positions (buckets start on lines, the cursors move in lines), the rest
+// stays for the next tile.  After its last tile a workgroup writes each left-over as ONE line filled up with kMsdwPad
+// words, which level 2 and the exact level-2 histogram skip; the buckets' exact row counts are added up in l1_count[].
+// nb <= kMsdwWcBins (one thread per bin; the lines are 64 KB of LDS).
+constexpr int kMsdwWcBins = 512;
+struct __attribute__((aligned(16))) MsdwWcBin {
+  uint32_t start;     // the bin's first place in the sorted tile
+  uint32_t oldleft;   // words it had left over before this tile
+  uint32_t full;      // words of (left-over ++ run) that leave as whole lines
+  uint32_t gbase;     // where those go (0xFFFFFFFF: no room — dropped, flags bit 4)
+};
+struct __attribute__((aligned(16))) MsdwWcLds {
+  uint64_t words[kMsdwTile];          // one round of the tile, sorted by bin
+  uint64_t line[kMsdwWcBins][16];     // what every bin has left over
+  MsdwWcBin info[kMsdwWcBins];        // (one 16-byte read per emitted word)
+  uint16_t bin[kMsdwTile];            // bin of words[q]
+  uint32_t cnt[kMsdwWcBins];
+  uint32_t left[kMsdwWcBins];         // words left over after this tile
+  uint32_t wave_tot[kMsdwThreads / 64];
+  uint32_t stop;
+};
+
+// keys of one tile -> registers (unconditional loads, rows past the tile's end re-read its last row; the caller's column
+// is read once: non-temporal)
+template <int RPT>
+__device__ __forceinline__ void msdw_wc_load(const MsdwArgs& a, int64_t row0, int nrows, uint64_t (&key)[RPT]) {
+  const int tid = threadIdx.x;
+  if (key_type_is_64bit(a.raw)) {   // workgroup-uniform
+    const uint64_t* __restrict__ base = a.src_keys + row0;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const uint32_t p = static_cast<uint32_t>(i * kMsdwThreads + tid);
+      key[i] = __builtin_nontemporal_load(base + (p < static_cast<uint32_t>(nrows) ? p : static_cast<uint32_t>(nrows - 1)));
+    }
+  } else {
+    const uint32_t* __restrict__ base = reinterpret_cast<const uint32_t*>(a.src_keys) + row0;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const uint32_t p = static_cast<uint32_t>(i * kMsdwThreads + tid);
+      key[i] = __builtin_nontemporal_load(base + (p < static_cast<uint32_t>(nrows) ? p : static_cast<uint32_t>(nrows - 1)));
+    }
+  }
+}
+
+// PREFETCH: the next tile's keys are requested before this tile's words move through LDS and out (one workgroup of
+// 1024 threads is all a CU holds of this kernel — 156 KB of LDS — so nothing else would overlap its phases; workgroup
+// barriers do not wait for global loads on gfx950, the loads stay in flight across them)
+template <int RPT, bool PREFETCH>
+__global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1wc_kernel(MsdwArgs a) {
+  static_assert(RPT % kMsdwRows == 0 && RPT % 2 == 0 && RPT * kMsdwThreads < 0xFFFF - kMsdwTile, "rounds; packed 16-bit places");
+  __shared__ MsdwWcLds lds;
+  constexpr int kTile = RPT * kMsdwThreads;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nb = 1 << a.b1;
+  const int dshift = 64 - a.b1;
+  const uint32_t dmask = static_cast<uint32_t>(nb - 1);
+  uint64_t* __restrict__ out = reinterpret_cast<uint64_t*>(a.rec_x);
+  if (tid < nb) lds.left[tid] = 0;
+  uint32_t my_rows = 0;   // rows of bin `tid` this workgroup has seen
+  const int64_t ntiles = (a.n + kTile - 1) / kTile;
+  bool abandoned = false;
+  uint64_t key[RPT];
+  uint64_t nxt[PREFETCH ? RPT : 1];
+  if (static_cast<int64_t>(blockIdx.x) >= ntiles) return;   // (more workgroups than tiles: nothing left over, no rows seen)
+  if constexpr (PREFETCH) {
+    const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kTile;
+    msdw_wc_load<RPT>(a, row0, static_cast<int>(a.n - row0 < kTile ? a.n - row0 : kTile), key);
+  }
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // an earlier tile already found a bucket without room: the level will be repeated, do not finish this attempt
+    if (a.sample_shift > 0) {
+      if (tid == 0) lds.stop = __atomic_load_n(&a.flags[0], __ATOMIC_RELAXED) & 4u;
+      __syncthreads();
+      abandoned = lds.stop != 0;   // workgroup-uniform
+      if (abandoned) break;
+    }
+    const int64_t row0 = tile * kTile;
+    const int nrows = static_cast<int>(a.n - row0 < kTile ? a.n - row0 : kTile);
+    if (tid < nb) lds.cnt[tid] = 0;
+    if constexpr (!PREFETCH) msdw_wc_load<RPT>(a, row0, nrows, key);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) key[i] = key_from_bits(key[i], a.raw);
+    __syncthreads();
+    uint32_t pos2[RPT / 2];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const uint32_t d = static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask;
+      const uint32_t pr = (i * kMsdwThreads + tid < nrows) ? atomicAdd(&lds.cnt[d], 1u) : 0xFFFFu;
+      pos2[i / 2] = (i & 1) ? (pos2[i / 2] | (pr << 16)) : pr;
+      if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    // one thread per bin: its place in the sorted tile, what leaves as whole lines, where those go
+    const uint32_t c = tid < nb ? lds.cnt[tid] : 0u;
+    const uint32_t incl = wave_inclusive_scan_u32(c);
+    if (lane == 63) lds.wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t pre = incl - c;
+    for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
+    const uint32_t old = tid < nb ? lds.left[tid] : 0u;
+    const uint32_t tot = old + c;
+    uint32_t cc[kMsdwMaxBins2 / kMsdwThreads] = {};
+    uint32_t run_base[kMsdwMaxBins2 / kMsdwThreads];
+    cc[0] = tot & ~15u;
+    msdw_reserve_runs(a.cursor1, cc, 1, nb, run_base);
+    if (tid < nb) {
+      uint32_t base = run_base[0];
+      if (cc[0] != 0 && (base + cc[0] > a.l1_end[tid] || base + cc[0] < base)) {
+        base = 0xFFFFFFFFu;
+        atomicOr(&a.flags[0], 4u);
+      }
+      MsdwWcBin b;
+      b.start = pre;
+      b.oldleft = old;
+      b.full = cc[0];
+      b.gbase = base;
+      lds.info[tid] = b;
+      lds.left[tid] = tot & 15u;
+      my_rows += c;
+    }
+    if constexpr (PREFETCH) {
+      // (unconditional: past the workgroup's last tile it requests this tile again — `nxt` is never read uninitialised,
+      //  which the compiler may otherwise take as licence to run the loads of a tile that does not exist)
+      const int64_t tn = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
+      const int64_t rn = tn * kTile;
+      msdw_wc_load<RPT>(a, rn, static_cast<int>(a.n - rn < kTile ? a.n - rn : kTile), nxt);
+    }
+    __syncthreads();
+    // the left-overs of bins that now fill lines leave first (their slots take this tile's left-overs below)
+    for (int slot = tid; slot < nb * 16; slot += kMsdwThreads) {
+      const int d = slot >> 4, j = slot & 15;
+      const MsdwWcBin b = lds.info[d];
+      if (b.full != 0 && static_cast<uint32_t>(j) < b.oldleft && b.gbase != 0xFFFFFFFFu) out[b.gbase + static_cast<uint32_t>(j)] = lds.line[d][j];
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const uint32_t d = static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask;
+      const uint32_t pr = (pos2[i / 2] >> ((i & 1) * 16)) & 0xFFFFu;
+      const uint32_t at = pr != 0xFFFFu ? pr + lds.info[d].start : 0xFFFFu;
+      pos2[i / 2] = (i & 1) ? ((pos2[i / 2] & 0xFFFFu) | (at << 16)) : ((pos2[i / 2] & 0xFFFF0000u) | at);
+      if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    for (int r = 0; r < RPT / kMsdwRows; ++r) {
+      const uint32_t lo = static_cast<uint32_t>(r) * kMsdwTile;
+      if (static_cast<int>(lo) >= nrows) break;   // workgroup-uniform
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const uint32_t q = ((pos2[i / 2] >> ((i & 1) * 16)) & 0xFFFFu) - lo;   // (no row: 0xFFFF - lo is never inside the buffer)
+        if (q < static_cast<uint32_t>(kMsdwTile)) {
+          lds.words[q] = msdw_word(key[i], static_cast<uint32_t>(row0) + static_cast<uint32_t>(i * kMsdwThreads + tid), a.kshift, a.b1);
+          lds.bin[q] = static_cast<uint16_t>(static_cast<uint32_t>((key[i] << a.kshift) >> dshift) & dmask);
+        }
+      }
+      __syncthreads();
+      const int cnt = nrows - static_cast<int>(lo) < kMsdwTile ? nrows - static_cast<int>(lo) : kMsdwTile;
+      for (int p = tid; p < cnt; p += kMsdwThreads) {
+        const uint32_t d = lds.bin[p];
+        const MsdwWcBin b = lds.info[d];
+        const uint32_t sp = b.oldleft + (lo + static_cast<uint32_t>(p) - b.start);   // place in (left-over ++ run)
+        if (sp < b.full) {
+          if (b.gbase != 0xFFFFFFFFu) out[b.gbase + sp] = lds.words[p];
+        } else {
+          lds.line[d][sp - b.full] = lds.words[p];
+        }
+      }
+      __syncthreads();
+    }
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) key[i] = nxt[i];
+    }
+  }
+  if (abandoned) return;
+  // what is still left over: one line per bin, filled up with pads
+  {
+    __syncthreads();
+    const uint32_t old = tid < nb ? lds.left[tid] : 0u;
+    uint32_t cc[kMsdwMaxBins2 / kMsdwThreads] = {};
+    uint32_t run_base[kMsdwMaxBins2 / kMsdwThreads];
+    cc[0] = old != 0 ? 16u : 0u;
+    msdw_reserve_runs(a.cursor1, cc, 1, nb, run_base);
+    if (tid < nb) {
+      uint32_t base = run_base[0];
+      if (cc[0] != 0 && (base + 16u > a.l1_end[tid] || base + 16u < base)) {
+        base = 0xFFFFFFFFu;
+        atomicOr(&a.flags[0], 4u);
+      }
+      lds.info[tid].gbase = base;
+      if (my_rows != 0) atomicAdd(&a.l1_count[tid], my_rows);
+    }
+    __syncthreads();
+    for (int slot = tid; slot < nb * 16; slot += kMsdwThreads) {
+      const int d = slot >> 4, j = slot & 15;
+      const uint32_t l = lds.left[d];
+      const uint32_t gb = lds.info[d].gbase;
+      if (l != 0 && gb != 0xFFFFFFFFu) out[gb + static_cast<uint32_t>(j)] = static_cast<uint32_t>(j) < l ? lds.line[d][j] : kMsdwPad;
+    }
+  }
 }
 
 // index of the last entry of start[0..nb] (nb + 1 entries, non-decreasing, start[0] == 0) that is <= g, computed by
@@ -2620,7 +2874,10 @@ __global__ __launch_bounds__(kMsdThreads) void msdw_hist1_kernel(MsdwArgs a) {
   int64_t r = begin + tid;
   if (a.rec8) {   // (workgroup-uniform) words: the level-2 digit is their top b2 bits
     const uint64_t* __restrict__ words = reinterpret_cast<const uint64_t*>(a.rec_x);
-    for (; r < end; r += kMsdThreads) atomicAdd(&h[static_cast<uint32_t>(words[r] >> (64 - a.b2)) & mask], 1u);
+    for (; r < end; r += kMsdThreads) {
+      const uint64_t wd = words[r];
+      if (wd != kMsdwPad) atomicAdd(&h[static_cast<uint32_t>(wd >> (64 - a.b2)) & mask], 1u);
+    }
   }
   for (; r + (U - 1) * kMsdThreads < end; r += U * kMsdThreads) {
     uint64_t kk[U];
@@ -2810,6 +3067,10 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
   a.tile2 = rpt2 * kMsdwThreads;
   const unsigned grid0 = static_cast<unsigned>(ceil_div(n, kMsdwTile));   // the sampled histogram reads 8192-row chunks
   const unsigned grid1 = static_cast<unsigned>(ceil_div(n, a.tile1));
+  // rec8: level 1 write-combined by persistent workgroups when its bins fit their LDS lines and the pads (one line per
+  // bin and workgroup at most) fit half of the buffers' slack
+  const int64_t wc_groups = std::min<int64_t>(int(g_sort_msd_wide_wc), grid1);
+  a.wc1 = (a.rec8 && roomy && wc_groups > 0 && nb1 <= kMsdwWcBins && 2 * 16 * wc_groups * nb1 <= a.capacity - n) ? static_cast<int>(wc_groups) : 0;
   // Level-1 bucket sizes: estimated from 1 tile in 2^shift (the buckets then get room to spare and level 2 reads
   // what actually arrived), or — shift 0, and whenever an estimate turned out too small — counted exactly.
   unsigned int max_room = 0;
@@ -2827,7 +3088,7 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
       nch = static_cast<unsigned>(ceil_div(n, a.chunk_rows));
     }
     ARX_HIP(hipMemsetAsync(a.l1_count, 0, static_cast<size_t>(nb1) * 4, st));
-    ARX_HIP(hipMemsetAsync(a.flags, 0, 32, st));
+    ARX_HIP(hipMemsetAsync(a.flags, 0, kMsdwFlagWords * 4, st));
     if (raw) {
       hipLaunchKernelGGL((msdw_hist0_kernel<true>), dim3(nch), dim3(kMsdThreads), 0, st, a);
     } else {
@@ -2842,7 +3103,21 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
     case 16: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 16, OUT8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break; \
     default: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 8, OUT8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break;  \
   }
-    if (a.rec8) {
+    if (a.wc1 > 0) {
+      // tiles of 16 rows per thread with the next tile's keys prefetched (sort_msd_wide_wc_prefetch), or rpt1 rows without
+      const int wc_rpt = g_sort_msd_wide_wc_prefetch ? (rpt1 >= 16 ? 16 : 8) : rpt1;
+      if (g_sort_msd_wide_wc_prefetch && wc_rpt == 16) {
+        hipLaunchKernelGGL((msdw_scatter1wc_kernel<16, true>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (g_sort_msd_wide_wc_prefetch) {
+        hipLaunchKernelGGL((msdw_scatter1wc_kernel<8, true>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (wc_rpt == 24) {
+        hipLaunchKernelGGL((msdw_scatter1wc_kernel<24, false>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (wc_rpt == 16) {
+        hipLaunchKernelGGL((msdw_scatter1wc_kernel<16, false>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else {
+        hipLaunchKernelGGL((msdw_scatter1wc_kernel<8, false>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      }
+    } else if (a.rec8) {
       ARX_MSDW_SCATTER1(true, true)
     } else if (raw) {
       ARX_MSDW_SCATTER1(true, false)
@@ -2877,7 +3152,9 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
     }
     break;
   }
-  const unsigned grid2 = static_cast<unsigned>(ceil_div(n, a.tile2)) + static_cast<unsigned>(nb1);
+  // (write-combined level 1: the buckets hold up to one padded line per bin and workgroup beside their rows)
+  const int64_t spanned = n + (a.wc1 > 0 ? int64_t(16) * a.wc1 * nb1 : 0);
+  const unsigned grid2 = static_cast<unsigned>(ceil_div(spanned, a.tile2)) + static_cast<unsigned>(nb1);
 #define ARX_MSDW_SCATTER2_(GAP, REC8)                                                                                      \
   switch (rpt2) {                                                                                  \
     case 24: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 24, REC8>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break; \
@@ -2901,7 +3178,7 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
     max_part = max_room != 0 ? max_room : kBktCapSmall;   // rooms never exceed it
   } else {
     ARX_HIP(hipMemsetAsync(a.count2, 0, nparts * 4, st));
-    const unsigned units = static_cast<unsigned>(ceil_div(n, kMsdwUnit) + nb1);
+    const unsigned units = static_cast<unsigned>(ceil_div(spanned, kMsdwUnit) + nb1);
     hipLaunchKernelGGL(msdw_hist1_kernel, dim3(units), dim3(kMsdThreads), 0, st, a);
     ARX_CHECK_LAUNCH("msdw_hist1_kernel");
     hipLaunchKernelGGL(msdw_scan1_kernel, dim3(static_cast<unsigned>(nb1)), dim3(1024), 0, st, a);
@@ -2945,8 +3222,7 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
     f.raw = raw;
     f.b1 = a.b1;
     f.b2 = a.b2;
-    const int tie_shift = g_sort_msd_wide_rec8_tie_shift;
-    f.tie_limit = static_cast<uint32_t>(std::min<int64_t>(n >> std::min(tie_shift, 40), 0xFFFFFFF0ll));
+    f.tie_shift = g_sort_msd_wide_rec8_tie_shift;
 #define ARX_BUCKET2W(T, CPT, R) \
   hipLaunchKernelGGL((msd_bucket2w_kernel<T, CPT, R>), dim3(static_cast<unsigned>(nparts)), dim3(T), 0, st, f, recs)
     if (tiny9 && cpt_bits) {
@@ -2988,14 +3264,18 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
                        dim3(kBktThreads), 0, st, f, recs, nullptr);
   }
   ARX_CHECK_LAUNCH("msd_bucket2_kernel");
-  unsigned int fl8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  ARX_HIP(hipMemcpyAsync(fl8, a.flags, 32, hipMemcpyDeviceToHost, st));
+  static_assert(kMsdwFlagWords <= kMsdwMaxBins + 64, "the flag block is one `small` table");
+  std::vector<unsigned int> flw(a.rec8 ? kMsdwFlagWords : 1, 0u);
+  ARX_HIP(hipMemcpyAsync(flw.data(), a.flags, flw.size() * 4, hipMemcpyDeviceToHost, st));
   ARX_HIP(hipStreamSynchronize(st));
-  const unsigned int flag = fl8[0];
+  const unsigned int flag = flw[0];
   g_sort_wide_runs.fetch_add(1, std::memory_order_relaxed);
   if (a.rec8) {
+    int64_t ties = 0;
+    for (int k = 0; k < 32; ++k) ties += flw[kMsdwTieSlot0 + 32 * k];
     g_sort_wide_rec8_runs.fetch_add(1, std::memory_order_relaxed);
-    g_sort_wide_rec8_ties.fetch_add(fl8[4], std::memory_order_relaxed);
+    g_sort_wide_rec8_ties.fetch_add(ties, std::memory_order_relaxed);
+    if (a.wc1 > 0) g_sort_wide_wc_runs.fetch_add(1, std::memory_order_relaxed);
   }
   if ((flag & 32u) != 0 && (flag & ~32u) == 0) {
     g_sort_wide_rec8_given_up.fetch_add(1, std::memory_order_relaxed);
@@ -3012,13 +3292,15 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
   return ARX_OK;
 }
 
+// *rec8: in, whether to try the word form; out, cleared once an attempt gave up (the caller's later attempts — counted
+// level-2 buckets after a room overflow — then start with full records)
 static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n, MsdRec* rec_x,
                              MsdRec* rec_y, int64_t capacity, uint8_t* tables, uint64_t* out_final, int gap2, int kshift,
-                             hipStream_t st, int* overflowed) {
-  const int rec8 = g_sort_msd_wide_rec8;
-  int rc = run_msd_sort_wide_form(src_keys, src_idx, raw, n, rec_x, rec_y, capacity, tables, out_final, gap2, kshift, rec8, st,
+                             hipStream_t st, int* overflowed, int* rec8) {
+  int rc = run_msd_sort_wide_form(src_keys, src_idx, raw, n, rec_x, rec_y, capacity, tables, out_final, gap2, kshift, *rec8, st,
                                   overflowed);
   if (rc == ARX_OK && *overflowed == 3) {
+    *rec8 = 0;
     rc = run_msd_sort_wide_form(src_keys, src_idx, raw, n, rec_x, rec_y, capacity, tables, out_final, gap2, kshift, 0, st,
                                 overflowed);
   }
@@ -3237,9 +3519,10 @@ int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_pl
       overflowed = 1;
       rc = ARX_OK;
       if (wide) {
-        rc = run_msd_sort_wide(src, nullptr, xf, n_valid, rec_a, rec_b, rec_cap, tables, final_dst, g_sort_msd_wide_gap2, ks, st, &overflowed);
+        int rec8 = g_sort_msd_wide_rec8;
+        rc = run_msd_sort_wide(src, nullptr, xf, n_valid, rec_a, rec_b, rec_cap, tables, final_dst, g_sort_msd_wide_gap2, ks, st, &overflowed, &rec8);
         if (rc == ARX_OK && overflowed == 2) {
-          rc = run_msd_sort_wide(src, nullptr, xf, n_valid, rec_a, rec_b, rec_cap, tables, final_dst, 0, ks, st, &overflowed);
+          rc = run_msd_sort_wide(src, nullptr, xf, n_valid, rec_a, rec_b, rec_cap, tables, final_dst, 0, ks, st, &overflowed, &rec8);
         }
       }
       if (rc == ARX_OK && overflowed) {
@@ -3261,12 +3544,13 @@ int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_pl
       // the wide form reads its source twice (level 1, then the histogram reads level-1 output): x = b, y = a is
       // safe because level 2 only starts after level 1 has consumed the source
       if (wide) {
-        rc = run_msd_sort_wide(keys_a, idx_a, 0, n_valid, rec_b, rec_a, rec_cap, tables, final_dst, g_sort_msd_wide_gap2, ks, st, &overflowed);
+        int rec8 = 0;   // (a prepped source: row ids are not positions in the column)
+        rc = run_msd_sort_wide(keys_a, idx_a, 0, n_valid, rec_b, rec_a, rec_cap, tables, final_dst, g_sort_msd_wide_gap2, ks, st, &overflowed, &rec8);
         if (rc == ARX_OK && overflowed == 2) {   // the level-2 records went over the prepped source: rebuild it
           hipLaunchKernelGGL(sort_prep_kernel, dim3(gprep), dim3(kBlock), 0, st, vals, valid_rows, n_valid, xf, 0,
                              keys_a, idx_a);
           ARX_CHECK_LAUNCH("sort_prep_kernel");
-          rc = run_msd_sort_wide(keys_a, idx_a, 0, n_valid, rec_b, rec_a, rec_cap, tables, final_dst, 0, ks, st, &overflowed);
+          rc = run_msd_sort_wide(keys_a, idx_a, 0, n_valid, rec_b, rec_a, rec_cap, tables, final_dst, 0, ks, st, &overflowed, &rec8);
         }
       }
       if (rc == ARX_OK && overflowed) {

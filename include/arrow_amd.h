@@ -93,7 +93,7 @@ int arx_set_option(const char* name, int64_t value);
 /* Process-wide diagnostic counters (monotonic): which plan the slices of the partitioned group-by consume ran —
  * "groupby_slices_direct" / "_one_level" / "_two_level" / "_wide" / "_probe" (DESIGN.md 4.6); which record form the wide
  * sorts ran with — "sort_wide_runs", "sort_wide_rec8_runs", "sort_wide_rec8_ties" (rows that read their full key),
- * "sort_wide_rec8_given_up" (DESIGN.md 4.5).  -1 + arx_last_error() for an unknown name.  Not part of the reference
+ * "sort_wide_rec8_given_up", "sort_wide_wc_runs" (write-combined level 1).  -1 + arx_last_error() for an unknown name.  Not part of the reference
  * interface. */
 int64_t arx_get_counter(const char* name);
 
