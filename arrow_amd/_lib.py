@@ -106,6 +106,7 @@ SIGNATURES = {
     "arx_filter_workspace_bytes": (_sz, [_i64]),
     "arx_filter_count": (_int, [_span, _int, _p, _sz, C.POINTER(_i64), _p]),
     "arx_filter_count_async": (_int, [_span, _int, _p, _sz, _p]),
+    "arx_filter_count_nulls": (_int, [_span, _span, _int, _p, _sz, C.POINTER(_i64), C.POINTER(_i64), _p]),
     "arx_filter_exec": (_int, [_span, _int, _span, _int, _p, _i64, _p, _p, _p]),
     "arx_mask_to_indices": (_int, [_span, _int, _p, _i64, _int, _p, _p, _p]),
     "arx_take_workspace_bytes": (_sz, []),

@@ -34,7 +34,8 @@ struct FilterWsHeader {
   int64_t ntiles;
   int64_t ngroups;
   int64_t length;
-  int64_t pad[4];
+  int64_t valid;     // emitted rows with a valid output slot (scan_kernel, when the count ran with the values' validity)
+  int64_t pad[3];
 };
 static_assert(sizeof(FilterWsHeader) == 64, "header is one 64-byte line");
 
@@ -43,6 +44,7 @@ struct FilterWsView {
   int64_t* group_excl;    // [ngroups]
   int64_t* group_total;   // [ngroups]
   uint32_t* tile_counts;  // [ngroups * 64]
+  int64_t* group_valid;   // [ngroups] emitted rows whose OUTPUT slot is valid (arx_filter_count_nulls)
 };
 
 static inline int64_t num_tiles(int64_t length) { return ceil_div(length, kTileRows); }
@@ -58,6 +60,7 @@ static inline FilterWsView ws_view(void* ws, int64_t length) {
   v.group_excl = reinterpret_cast<int64_t*>(p + 64);
   v.group_total = v.group_excl + ng;
   v.tile_counts = reinterpret_cast<uint32_t*>(v.group_total + ng);
+  v.group_valid = reinterpret_cast<int64_t*>(v.tile_counts + ng * kTilesPerGroup);
   return v;
 }
 
@@ -80,23 +83,32 @@ __device__ __forceinline__ uint64_t emit_word(const Bits& mask, const Bits& mval
 }
 
 // ------------------------------------------------------------------ K1: count
-__global__ __launch_bounds__(kBlock) void count_kernel(Bits mask, Bits mvalid, int emit_null,
+// VALID: also counts the emitted rows whose OUTPUT slot is valid — mask slot valid (a null mask slot emits a null under
+// EMIT_NULL) and value valid — so the output's null count comes back with its length, in the one read-back the caller
+// needs anyway for the allocation (the reference leaves null_count unknown and counts lazily on the host,
+// vector_selection_filter_internal.cc:462-467; a device array's bitmap cannot be counted there).
+template <bool VALID>
+__global__ __launch_bounds__(kBlock) void count_kernel(Bits mask, Bits mvalid, Bits vvalid, int emit_null,
                                                        int invert, int64_t ntiles,
                                                        uint32_t* tile_counts,
-                                                       int64_t* group_total) {
+                                                       int64_t* group_total, int64_t* group_valid) {
   __shared__ uint32_t wave_sums[kWavesPerBlock];
+  __shared__ uint32_t wave_valid[kWavesPerBlock];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int64_t group = blockIdx.x;
   const int64_t t0 = group * kTilesPerGroup + wave * 16;
   uint32_t mine = 0;
+  uint32_t kv = 0;
 #pragma unroll 4
   for (int i = 0; i < 16; ++i) {
     const int64_t t = t0 + i;
     uint32_t k = 0;
     if (t < ntiles) {
       uint64_t mv;
-      k = __popcll(emit_word(mask, mvalid, t * 64 + lane, emit_null != 0, invert != 0, &mv));
+      const uint64_t e = emit_word(mask, mvalid, t * 64 + lane, emit_null != 0, invert != 0, &mv);
+      k = __popcll(e);
+      if constexpr (VALID) kv += __popcll(e & mv & load_word(vvalid, t * 64 + lane));
     }
     const uint32_t s = wave_reduce_sum_u32(k);
     if (lane == i) mine = s;
@@ -104,24 +116,43 @@ __global__ __launch_bounds__(kBlock) void count_kernel(Bits mask, Bits mvalid, i
   if (lane < 16) tile_counts[t0 + lane] = mine;  // tile_counts is padded to ngroups*64
   const uint32_t wsum = wave_reduce_sum_u32(lane < 16 ? mine : 0u);
   if (lane == 0) wave_sums[wave] = wsum;
+  if constexpr (VALID) {
+    const uint32_t vsum = wave_reduce_sum_u32(kv);
+    if (lane == 0) wave_valid[wave] = vsum;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int64_t s = 0;
-    for (int i = 0; i < kWavesPerBlock; ++i) s += wave_sums[i];
+    int64_t s = 0, v = 0;
+    for (int i = 0; i < kWavesPerBlock; ++i) {
+      s += wave_sums[i];
+      if constexpr (VALID) v += wave_valid[i];
+    }
     group_total[group] = s;
+    if constexpr (VALID) group_valid[group] = v;
   }
 }
 
 // ------------------------------------------------------------------ K2: scan of group totals
 __global__ __launch_bounds__(1024) void scan_kernel(const int64_t* group_total, int64_t ngroups,
-                                                    int64_t* group_excl, FilterWsHeader* hdr) {
+                                                    int64_t* group_excl, FilterWsHeader* hdr,
+                                                    const int64_t* group_valid = nullptr) {
   __shared__ int64_t wave_tot[16];
   __shared__ int64_t carry_s;
+  __shared__ unsigned long long valid_s;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   if (tid == 0) carry_s = 0;
+  if (tid == 0) valid_s = 0;
   __syncthreads();
+  if (group_valid != nullptr) {   // (kernel-uniform) the sum of the groups' valid counts
+    int64_t mine = 0;
+    for (int64_t i = tid; i < ngroups; i += 1024) mine += group_valid[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if (lane == 0 && mine != 0) atomicAdd(&valid_s, static_cast<unsigned long long>(mine));
+    __syncthreads();
+  }
   for (int64_t base = 0; base < ngroups; base += 1024) {
     const int64_t i = base + tid;
     const int64_t v = i < ngroups ? group_total[i] : 0;
@@ -142,7 +173,10 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int64_t* group_total, 
     if (tid == 1023) carry_s = carry + wave_prefix + x;
     __syncthreads();
   }
-  if (tid == 0) hdr->total = carry_s;
+  if (tid == 0) {
+    hdr->total = carry_s;
+    hdr->valid = static_cast<int64_t>(valid_s);   // (the loop above ends with a barrier: every wave's add has landed)
+  }
 }
 
 // ------------------------------------------------------------------ K3: compaction
@@ -1135,7 +1169,7 @@ static inline const void* effective_validity(const ArxSpan* s) {
 }
 
 static int launch_count(const ArxSpan* mask, int null_selection, void* ws, size_t ws_bytes,
-                        hipStream_t st, int invert = 0) {
+                        hipStream_t st, int invert = 0, const ArxSpan* values = nullptr) {
   const int rc = check_mask(mask, null_selection);
   if (rc != ARX_OK) return rc;
   const size_t need = arx_filter_workspace_bytes(mask->length);
@@ -1159,11 +1193,20 @@ static int launch_count(const ArxSpan* mask, int null_selection, void* ws, size_
   if (mask->length == 0) return ARX_OK;
   const Bits mb = make_bits(mask->data, mask->offset, mask->length);
   const Bits mvb = make_bits(effective_validity(mask), mask->offset, mask->length);
-  hipLaunchKernelGGL(count_kernel, dim3(static_cast<unsigned>(ng)), dim3(kBlock), 0, st, mb, mvb,
-                     null_selection, invert, nt, v.tile_counts, v.group_total);
-  ARX_CHECK_LAUNCH("count_kernel");
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, v.group_total, ng, v.group_excl,
-                     v.hdr);
+  if (values != nullptr) {
+    const Bits vvb = make_bits(effective_validity(values), values->offset, mask->length);
+    hipLaunchKernelGGL((count_kernel<true>), dim3(static_cast<unsigned>(ng)), dim3(kBlock), 0, st, mb, mvb, vvb,
+                       null_selection, invert, nt, v.tile_counts, v.group_total, v.group_valid);
+    ARX_CHECK_LAUNCH("count_kernel");
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, v.group_total, ng, v.group_excl, v.hdr,
+                       static_cast<const int64_t*>(v.group_valid));
+  } else {
+    hipLaunchKernelGGL((count_kernel<false>), dim3(static_cast<unsigned>(ng)), dim3(kBlock), 0, st, mb, mvb, mvb,
+                       null_selection, invert, nt, v.tile_counts, v.group_total, static_cast<int64_t*>(nullptr));
+    ARX_CHECK_LAUNCH("count_kernel");
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, v.group_total, ng, v.group_excl, v.hdr,
+                       static_cast<const int64_t*>(nullptr));
+  }
   ARX_CHECK_LAUNCH("scan_kernel");
   return ARX_OK;
 }
@@ -1349,12 +1392,34 @@ extern "C" {
 size_t arx_filter_workspace_bytes(int64_t length) {
   if (length < 0) length = 0;
   const int64_t ng = num_groups(length);
-  return static_cast<size_t>(64 + ng * 16 + ng * kTilesPerGroup * 4 + 64);
+  return static_cast<size_t>(64 + ng * 16 + ng * kTilesPerGroup * 4 + ng * 8 + 64);
 }
 
 int arx_filter_count_async(const ArxSpan* mask, int null_selection, void* ws, size_t ws_bytes,
                            void* stream) {
   return launch_count(mask, null_selection, ws, ws_bytes, as_stream(stream));
+}
+
+int arx_filter_count_nulls(const ArxSpan* values, const ArxSpan* mask, int null_selection, void* ws, size_t ws_bytes,
+                           int64_t* out_length, int64_t* out_null_count, void* stream) {
+  if (out_length == nullptr || out_null_count == nullptr || values == nullptr) {
+    set_error("values / out_length / out_null_count is NULL");
+    return ARX_INVALID;
+  }
+  if (mask != nullptr && values->length != mask->length) {
+    set_error("filter values and mask differ in length (%lld vs %lld)", static_cast<long long>(values->length),
+              static_cast<long long>(mask->length));
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  const int rc = launch_count(mask, null_selection, ws, ws_bytes, st, 0, values);
+  if (rc != ARX_OK) return rc;
+  int64_t hdr[5] = {0, 0, 0, 0, 0};   // FilterWsHeader: total, ntiles, ngroups, length, valid
+  ARX_HIP(hipMemcpyAsync(hdr, ws, sizeof(hdr), hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  *out_length = hdr[0];
+  *out_null_count = mask->length == 0 ? 0 : hdr[0] - hdr[4];
+  return ARX_OK;
 }
 
 int arx_filter_count(const ArxSpan* mask, int null_selection, void* ws, size_t ws_bytes,

@@ -43,6 +43,21 @@ def check_filter(amd, values: HostArray, mask: HostArray, null_selection: str, u
     # allocate_validity rule + null_count bookkeeping (vector_selection_filter_internal.cc:462-472)
     if dv.null_count == 0 and dm.null_count == 0:
         assert out.validity is None and out.null_count == 0
+    # arx_filter_count_nulls: the output's length AND null count from the counting pass alone (what the plugin puts into
+    # the device-resident output instead of kUnknownNullCount)
+    import ctypes as C
+
+    from arrow_amd import _lib as L
+    from arrow_amd.array import alloc, current_stream
+
+    lib = L.get_lib()
+    ws = alloc(lib.arx_filter_workspace_bytes(mask.length) + 64, dv.device)
+    ws_ptr = (ws.data_ptr() + 63) & ~63
+    vspan, mspan = dv.span(), dm.span()
+    n_out, n_null = C.c_int64(-1), C.c_int64(-1)
+    L.check(lib.arx_filter_count_nulls(C.byref(vspan), C.byref(mspan), code, ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()),
+                                       C.byref(n_out), C.byref(n_null), current_stream(dv.device)))
+    assert n_out.value == out.length and n_null.value == int(out.length - got_valid.sum()), (tag, n_out.value, n_null.value, out.length, int(got_valid.sum()))
     if use_pyarrow and pc is not None:
         ref = pc.filter(values.to_pyarrow(), mask.to_pyarrow(), null_selection_behavior=null_selection)
         assert len(ref) == out.length

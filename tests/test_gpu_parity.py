@@ -672,8 +672,8 @@ def test_sort_wide_register_staged_tiles(gpu_ctx, rpt):
 
 
 @pytest.mark.parametrize("n,bits,gap2,shift,rpt,b2max,wc,prefetch", [(6_000_011, 0, 1, 4, (24, 16), 11, 256, 1), (3_000_003, 14, 0, 2, (8, 8), 11, 0, 1),
-                                                                     (2_000_003, 8, 1, 0, (16, 24), 11, 7, 0), (40_000_003, 0, 1, 4, (24, 16), 6, 256, 1),
-                                                                     (20_000_003, 18, 1, 4, (24, 16), 9, 256, 1), (20_000_003, 18, 1, 4, (24, 16), 9, 256, 0),
+                                                                     (2_000_003, 8, 1, 0, (16, 24), 11, 7, 0), (12_000_003, 0, 1, 4, (24, 16), 4, 96, 1),
+                                                                     (8_000_003, 18, 1, 4, (24, 16), 9, 48, 1), (8_000_003, 18, 1, 4, (24, 16), 9, 48, 0),
                                                                      (5_000_003, 14, 0, 0, (8, 16), 5, 64, 1)])
 def test_sort_wide_rec8_words(gpu_ctx, n, bits, gap2, shift, rpt, b2max, wc, prefetch):
     """8-byte {key bits, row id} words through the wide form (the form the 2e9-row bench runs): ties below the word,
