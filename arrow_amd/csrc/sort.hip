@@ -53,6 +53,7 @@ static Knob<int> g_sort_msd_wide_rec8{1};           // wide form over the caller
 static Knob<int> g_sort_msd_wide_rec8_tie_shift{4};  // ... given up (and repeated with 12-byte records) once more than (rows >> shift) rows of ONE bucket tied (duplicate-heavy keys: every tie is two random 8-byte reads; 2e9 uniform keys: 0.9 per 1000)
 static Knob<int> g_sort_msd_wide_wc{256};          // rec8 form: level 1 write-combined by this many persistent workgroups (0 = the tile-at-a-time level 1)
 static Knob<int> g_sort_msd_wide_wc_prefetch{1};   // ... with 16-row tiles and the next tile's keys requested before the current one's words leave
+static Knob<int> g_sort_msd_wide_l2w{3};           // rec8 form, level 2 in small workgroups (msdw_scatter2w_kernel): 1 = 512 threads x 16 rows, 4096-word stage (2 per CU); 2 = 512 x 16, 2048-word stage (3); 3 = 1024 x 8, 4096 (2); 0 = msdw_scatter2_kernel
 static Knob<int> g_sort_msd_wide_sample_strict{0}; // tests: a sampled attempt that overflows is an error instead of a silent exact re-run
 static Knob<int> g_sort_msd_wide{1};          // inputs beyond sort_msd_segment_rows: the wide two-level form (run_msd_sort_wide) before the segmented one
 static Knob<int> g_sort_msd_bucket_v2{1};     // single-atomic-pass bucket finish with up to 4096 sub-buckets (msd_bucket2_kernel)
@@ -1675,6 +1676,10 @@ int set_sort_option(const char* name, int64_t value) {
     g_sort_msd_wide_wc = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 4096)));
     return 1;
   }
+  if (strcmp(name, "sort_msd_wide_l2w") == 0) {
+    g_sort_msd_wide_l2w = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 3)));
+    return 1;
+  }
   if (strcmp(name, "sort_msd_wide_wc_prefetch") == 0) {
     g_sort_msd_wide_wc_prefetch = value != 0;
     return 1;
@@ -3002,6 +3007,126 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter2_kernel(MsdwArgs a)
                                                               GAP ? a.y_base[p] : 0u, GAP ? a.room2[p] : 0u, 16u, a.rec_y);
 }
 
+// Level 2 of the rec8 form in a workgroup SMALL enough for several to share a CU: words only (no row-id array), a staging
+// buffer of STAGE words, <= 2048 bins — 56 KB of LDS with 4096 words — and T threads.  The one-per-CU workgroups of
+// msdw_scatter2_kernel (147 KB: the LDS layout of the 12-byte records) run their phases — load, rank, scan, place, write —
+// one after the other with the memory pipes idle in between; two or three independent workgroups per CU overlap them.
+constexpr int kMsdwL2wBins = 2048;
+template <int STAGE>
+struct __attribute__((aligned(16))) MsdwL2wLds {
+  uint64_t words[STAGE];
+  uint32_t cnt[kMsdwL2wBins];
+  uint32_t start[kMsdwL2wBins];
+  uint32_t gbase[kMsdwL2wBins];
+  uint32_t wave_tot[16];
+  uint32_t part;
+};
+
+template <bool GAP, int T, int RPT, int STAGE>
+__global__ __launch_bounds__(T) void msdw_scatter2w_kernel(MsdwArgs a) {
+  constexpr int kTile = RPT * T;
+  constexpr int K = kMsdwL2wBins / T;   // bins per thread of the scan (at most)
+  static_assert(kTile % STAGE == 0 && kTile < 0xFFFF && RPT % 2 == 0 && K >= 1 && K <= kMsdwMaxBins2 / kMsdwThreads, "shape");
+  __shared__ MsdwL2wLds<STAGE> lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nb1 = 1 << a.b1;
+  const uint32_t g = a.xcd_map ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  if (g >= a.l2_tile_start[nb1]) return;  // over-provisioned grid
+  const uint32_t p = msdw_owner(a.l2_tile_start, nb1, g, &lds.part);
+  const int64_t lo_b = a.l1_start[p];
+  const int64_t hi_b = a.l1_end[p];
+  const int64_t row0 = lo_b + static_cast<int64_t>(g - a.l2_tile_start[p]) * kTile;
+  const int nrows = static_cast<int>(hi_b - row0 < kTile ? hi_b - row0 : kTile);
+  const int nb = 1 << a.b2;
+  const int dsh = 64 - a.b2;
+  uint32_t* __restrict__ gcursor = a.cursor2 + (static_cast<size_t>(p) << a.b2);
+  const uint64_t* __restrict__ in = reinterpret_cast<const uint64_t*>(a.rec_x) + row0;
+  uint64_t* __restrict__ out = reinterpret_cast<uint64_t*>(a.rec_y);
+  for (int b = tid; b < nb; b += T) lds.cnt[b] = 0;
+  uint64_t wd[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {   // unconditional (clamped) loads: all in flight together
+    const uint32_t q = static_cast<uint32_t>(i * T + tid);
+    wd[i] = in[q < static_cast<uint32_t>(nrows) ? q : static_cast<uint32_t>(nrows - 1)];
+  }
+  __syncthreads();
+  uint32_t pos2[RPT / 2];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const uint32_t d = static_cast<uint32_t>(wd[i] >> dsh);
+    const uint32_t pr = (i * T + tid < nrows && wd[i] != kMsdwPad) ? atomicAdd(&lds.cnt[d], 1u) : 0xFFFFu;
+    pos2[i / 2] = (i & 1) ? (pos2[i / 2] | (pr << 16)) : pr;
+    if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  const int per = (nb + T - 1) / T;
+  uint32_t cc[kMsdwMaxBins2 / kMsdwThreads];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < kMsdwMaxBins2 / kMsdwThreads; ++k) {
+    const int b = tid * per + k;
+    cc[k] = (k < per && b < nb) ? lds.cnt[b] : 0u;
+    mine += cc[k];
+  }
+  const uint32_t incl = wave_inclusive_scan_u32(mine);
+  if (lane == 63) lds.wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t pre = incl - mine;
+  for (int k = 0; k < wave; ++k) pre += lds.wave_tot[k];
+  uint32_t run_base[kMsdwMaxBins2 / kMsdwThreads];
+  msdw_reserve_runs(gcursor, cc, per, nb, run_base);
+  const uint32_t room_base = GAP ? a.y_base[p] : 0u, room = GAP ? a.room2[p] : 0u;
+#pragma unroll
+  for (int k = 0; k < kMsdwMaxBins2 / kMsdwThreads; ++k) {
+    const int b = tid * per + k;
+    if (k < per && b < nb) {
+      const uint32_t c = cc[k];
+      lds.start[b] = pre;
+      uint32_t base = run_base[k];
+      if constexpr (GAP) {
+        const uint32_t end = room_base + (static_cast<uint32_t>(b) + 1u) * room;
+        if (c != 0 && (base + c > end || base + c < base)) {
+          base = 0xFFFFFFFFu;
+          atomicOr(&a.flags[0], 16u);
+        }
+      }
+      lds.gbase[b] = base;
+      pre += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const uint32_t d = static_cast<uint32_t>(wd[i] >> dsh);
+    const uint32_t pr = (pos2[i / 2] >> ((i & 1) * 16)) & 0xFFFFu;
+    const uint32_t at = pr != 0xFFFFu ? pr + lds.start[d] : 0xFFFFu;
+    pos2[i / 2] = (i & 1) ? ((pos2[i / 2] & 0xFFFFu) | (at << 16)) : ((pos2[i / 2] & 0xFFFF0000u) | at);
+    if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+  }
+  const int nplaced = static_cast<int>(lds.start[nb - 1] + lds.cnt[nb - 1]);   // (pads take no place)
+  for (int r = 0; r < kTile / STAGE; ++r) {
+    const uint32_t lo = static_cast<uint32_t>(r) * STAGE;
+    if (static_cast<int>(lo) >= nplaced) break;   // workgroup-uniform
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const uint32_t q = ((pos2[i / 2] >> ((i & 1) * 16)) & 0xFFFFu) - lo;   // (no row: 0xFFFF - lo is never inside the buffer)
+      if (q < static_cast<uint32_t>(STAGE)) lds.words[q] = wd[i];
+    }
+    __syncthreads();
+    const int cnt = nplaced - static_cast<int>(lo) < STAGE ? nplaced - static_cast<int>(lo) : STAGE;
+    for (int q = tid; q < cnt; q += T) {
+      const uint64_t w = lds.words[q];
+      const uint32_t d = static_cast<uint32_t>(w >> dsh);
+      const uint32_t gb = lds.gbase[d];
+      if (GAP && gb == 0xFFFFFFFFu) continue;
+      out[gb + (lo + static_cast<uint32_t>(q) - lds.start[d])] = w;
+    }
+    __syncthreads();
+  }
+}
+
 // overflowed: 0 sorted; 1 the keys are too skewed for this form (a bucket does not fit LDS) — try the next form;
 // 2 a level-2 room overflowed (gap2 only): call again with gap2 = 0 (the source may have been overwritten when it
 // shares memory with rec_y).
@@ -3065,6 +3190,8 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
   const int rpt1 = g_sort_msd_wide_rpt1, rpt2 = g_sort_msd_wide_rpt2;
   a.tile1 = rpt1 * kMsdwThreads;
   a.tile2 = rpt2 * kMsdwThreads;
+  const int l2w = (a.rec8 && (1 << a.b2) <= kMsdwL2wBins) ? int(g_sort_msd_wide_l2w) : 0;
+  if (l2w == 1 || l2w == 2 || l2w == 3) a.tile2 = 8192;
   const unsigned grid0 = static_cast<unsigned>(ceil_div(n, kMsdwTile));   // the sampled histogram reads 8192-row chunks
   const unsigned grid1 = static_cast<unsigned>(ceil_div(n, a.tile1));
   // rec8: level 1 write-combined by persistent workgroups when its bins fit their LDS lines and the pads (one line per
@@ -3162,7 +3289,13 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
     default: hipLaunchKernelGGL((msdw_scatter2_kernel<GAP, 8, REC8>), dim3(grid2), dim3(kMsdwThreads), 0, st, a); break;  \
   }
 #define ARX_MSDW_SCATTER2(GAP) \
-  if (a.rec8) {                \
+  if (l2w == 1) {              \
+    hipLaunchKernelGGL((msdw_scatter2w_kernel<GAP, 512, 16, 4096>), dim3(grid2), dim3(512), 0, st, a); \
+  } else if (l2w == 2) {       \
+    hipLaunchKernelGGL((msdw_scatter2w_kernel<GAP, 512, 16, 2048>), dim3(grid2), dim3(512), 0, st, a); \
+  } else if (l2w == 3) {       \
+    hipLaunchKernelGGL((msdw_scatter2w_kernel<GAP, 1024, 8, 4096>), dim3(grid2), dim3(1024), 0, st, a); \
+  } else if (a.rec8) {         \
     ARX_MSDW_SCATTER2_(GAP, true) \
   } else {                     \
     ARX_MSDW_SCATTER2_(GAP, false) \

@@ -876,7 +876,7 @@ def check_sort_wide_many_bins(amd, lib, rng, n, bits, b2max, combos=((2, 1), (0,
         lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
 
 
-def check_sort_wide_rec8(amd, lib, rng, n, bits=0, gap2=1, shift=0, rpt=(24, 16), b2max=11, wc=256, prefetch=1):
+def check_sort_wide_rec8(amd, lib, rng, n, bits=0, gap2=1, shift=0, rpt=(24, 16), b2max=11, wc=256, prefetch=1, l2w=1):
     """The wide form over the caller's own column moves 8-byte words {32 key bits below the level-1 digit, row id}
     (sort_msd_wide_rec8, the default): level 2 and the finish take their digits from the word, the finish ranks whole
     words, and rows whose 32 bits tie read their full keys from the column.  Cases: uniform keys (almost no tie); keys
@@ -886,11 +886,13 @@ def check_sort_wide_rec8(amd, lib, rng, n, bits=0, gap2=1, shift=0, rpt=(24, 16)
     repeated with full records: same order); and rec8 switched off.  wc: level 1 write-combined by that many persistent
     workgroups (whole 128-byte lines per bin, pad words at the end of a workgroup's share; 0 = tile at a time), prefetch:
     with the next tile's keys requested early (16- or 8-row tiles) or rpt[0]-row tiles without; b2max moves partition bits
-    to level 1 (more bins there).  Counters say which form really ran."""
+    to level 1 (more bins there); l2w: level 2 in small workgroups (1 - 3: the shapes of msdw_scatter2w_kernel, 0: the
+    one-per-CU kernel of the 12-byte records reading words).  Counters say which form really ran."""
     opts = {b"sort_msd": 1, b"sort_msd_segment_rows": 4096, b"sort_msd_wide": 1, b"sort_msd_wide_bits": bits,
             b"sort_msd_wide_gap2": gap2, b"sort_msd_wide_sample_shift": shift, b"sort_msd_wide_rpt1": rpt[0],
             b"sort_msd_wide_rpt2": rpt[1], b"sort_msd_wide_rec8": 1, b"sort_msd_wide_rec8_tie_shift": 0,
-            b"sort_msd_wide_b2max": b2max, b"sort_msd_wide_wc": wc, b"sort_msd_wide_wc_prefetch": prefetch}
+            b"sort_msd_wide_b2max": b2max, b"sort_msd_wide_wc": wc, b"sort_msd_wide_wc_prefetch": prefetch,
+            b"sort_msd_wide_l2w": l2w}
     for k, v in opts.items():
         assert lib.arx_set_option(k, v) == 0
     ctr = lambda name: int(lib.arx_get_counter(name))
@@ -953,6 +955,7 @@ def check_sort_wide_rec8(amd, lib, rng, n, bits=0, gap2=1, shift=0, rpt=(24, 16)
         lib.arx_set_option(b"sort_msd_wide_rec8_tie_shift", 4)
         lib.arx_set_option(b"sort_msd_wide_wc", 256)
         lib.arx_set_option(b"sort_msd_wide_wc_prefetch", 1)
+        lib.arx_set_option(b"sort_msd_wide_l2w", 3)
         lib.arx_set_option(b"sort_msd_wide_b2max", 11)
         lib.arx_set_option(b"sort_msd_wide_bits", 0)
         lib.arx_set_option(b"sort_msd_wide_rpt1", SORT_WIDE_RPT_DEFAULT[0])

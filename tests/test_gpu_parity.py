@@ -671,16 +671,16 @@ def test_sort_wide_register_staged_tiles(gpu_ctx, rpt):
         lib.arx_set_option(b"sort_msd_bucket_cpt", 4)
 
 
-@pytest.mark.parametrize("n,bits,gap2,shift,rpt,b2max,wc,prefetch", [(6_000_011, 0, 1, 4, (24, 16), 11, 256, 1), (3_000_003, 14, 0, 2, (8, 8), 11, 0, 1),
-                                                                     (2_000_003, 8, 1, 0, (16, 24), 11, 7, 0), (12_000_003, 0, 1, 4, (24, 16), 4, 96, 1),
-                                                                     (8_000_003, 18, 1, 4, (24, 16), 9, 48, 1), (8_000_003, 18, 1, 4, (24, 16), 9, 48, 0),
-                                                                     (5_000_003, 14, 0, 0, (8, 16), 5, 64, 1)])
-def test_sort_wide_rec8_words(gpu_ctx, n, bits, gap2, shift, rpt, b2max, wc, prefetch):
+@pytest.mark.parametrize("n,bits,gap2,shift,rpt,b2max,wc,prefetch,l2w", [(6_000_011, 0, 1, 4, (24, 16), 11, 256, 1, 1), (3_000_003, 14, 0, 2, (8, 8), 11, 0, 1, 2),
+                                                                         (2_000_003, 8, 1, 0, (16, 24), 11, 7, 0, 0), (12_000_003, 0, 1, 4, (24, 16), 4, 96, 1, 1),
+                                                                         (8_000_003, 18, 1, 4, (24, 16), 9, 48, 1, 3), (8_000_003, 18, 1, 4, (24, 16), 9, 48, 0, 1),
+                                                                         (5_000_003, 14, 0, 0, (8, 16), 5, 64, 1, 2), (4_000_003, 20, 1, 4, (24, 16), 11, 32, 1, 1)])
+def test_sort_wide_rec8_words(gpu_ctx, n, bits, gap2, shift, rpt, b2max, wc, prefetch, l2w):
     """8-byte {key bits, row id} words through the wide form (the form the 2e9-row bench runs): ties below the word,
     duplicates, the tie budget, fall-backs; level 1 tile at a time and write-combined (2 to 512 bins — 9 + 9 bits is the
     2e9-row split's level 1); counters prove which form ran."""
     P.check_sort_wide_rec8(gpu_ctx, gpu_ctx._lib.get_lib(), rng_for("wide-rec8", n, bits), n, bits=bits, gap2=gap2, shift=shift, rpt=rpt,
-                           b2max=b2max, wc=wc, prefetch=prefetch)
+                           b2max=b2max, wc=wc, prefetch=prefetch, l2w=l2w)
 
 
 @pytest.mark.parametrize("bits,b2max", [(13, 12), (16, 12), (20, 12), (19, 11), (19, 0)])
