@@ -215,6 +215,7 @@ SIGNATURES = {
     "arx_binary_key_hash": (_int, [_bspan, _int, _p, _p]),
     "arx_binary_key_verify": (_int, [_bspan, _p, _p, C.POINTER(_i64), _p, _p]),
     "arx_group_first_rows": (_int, [_p, _i64, _i64, _p, _p]),
+    "arx_group_edge_rows": (_int, [_p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
     "arx_ree_bool_expand": (_int, [_p, _int, _i64, _span, _i64, _i64, _p, _p, _p]),
     "arx_snappy_decompress_pages": (_int, [_p, _p, _i64, _p, _p, _p]),
     "arx_cast_numeric": (_int, [_span, _int, _int, _int, _int, _p, _sz, _p, _p]),
@@ -248,6 +249,8 @@ SIGNATURES = {
     "arx_hash_sum_float_workspace_bytes": (_sz, [_i64]),
     "arx_hash_sum_float_consume": (_int, [_span, _int, _int, C.c_double, _p, _i64, _p, _sz, _p, _p, _p, _p]),
     "arx_hash_sum_f64_merge": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "arx_hash_product_init": (_int, [_p, _int, _i64, _p]),
+    "arx_hash_product_consume": (_int, [_span, _int, _p, _i64, _p, _sz, _p, _p, _p, _p]),
     "arx_hash_mean_f64_finalize": (_int, [_p, _p, _i64, _p, _p]),
     "arx_hash_minmax_i64_fill": (_int, [_p, _p, _i64, _i64, _p]),
     "arx_hash_minmax_i64_consume": (_int, [_span, _int, _i64, _p, _i64, _p, _p, _p, _p]),

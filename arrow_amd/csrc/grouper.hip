@@ -525,6 +525,38 @@ __global__ __launch_bounds__(kBlock) void binary_key_verify_kernel(Bits valid, c
 }
 
 // first_rows[g] = the smallest row whose group id is g (caller fills first_rows with 0xFF bytes)
+// The smallest (last = 0) or largest (last = 1) row of every group among the rows whose validity bit is set: what
+// GroupedFirstLastImpl / GroupedOneImpl keep per group is the first / last NON-NULL value in row order
+// (kernels/hash_aggregate.cc:775-808, :1575-1590) — here the row number of it, the value is one take away.  Largest rows
+// are kept as 0xFFFFFFFE - row so that both ends are one atomicMin and 0xFFFFFFFF stays "no row".
+__global__ __launch_bounds__(kBlock) void group_edge_rows_kernel(const uint32_t* __restrict__ ids, Bits valid, int64_t n,
+                                                                 int64_t num_groups, int last, unsigned int* __restrict__ rows) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const uint32_t g = ids[i];
+    if (g >= num_groups) continue;
+    if (valid.base != nullptr && ((load_word(valid, i >> 6) >> (i & 63)) & 1ull) == 0) continue;
+    const unsigned int mine = last ? 0xFFFFFFFEu - static_cast<unsigned int>(i) : static_cast<unsigned int>(i);
+    if (rows[g] > mine) atomicMin(&rows[g], mine);   // (read first: most rows of a group lose)
+  }
+}
+
+// rows[] back to row numbers, groups without a row to row 0 + a cleared bit of has_row (a validity bitmap for the take)
+__global__ __launch_bounds__(kBlock) void group_edge_rows_finish_kernel(unsigned int* __restrict__ rows, int64_t num_groups, int last,
+                                                                        uint64_t* __restrict__ has_row) {
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; g < (num_groups + 63) / 64 * 64;
+       g += static_cast<int64_t>(gridDim.x) * kBlock) {
+    bool has = false;
+    if (g < num_groups) {
+      const unsigned int r = rows[g];
+      has = r != 0xFFFFFFFFu;
+      rows[g] = !has ? 0u : (last ? 0xFFFFFFFEu - r : r);
+    }
+    const uint64_t word = __ballot(has);
+    if ((threadIdx.x & 63) == 0) has_row[g >> 6] = word;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void group_first_rows_kernel(const uint32_t* __restrict__ ids, int64_t n,
                                                                   int64_t num_groups, unsigned int* __restrict__ first) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
@@ -836,6 +868,31 @@ int arx_binary_key_verify(const ArxBinarySpan* values, const uint32_t* group_ids
   ARX_CHECK_LAUNCH("binary_key_verify_kernel");
   ARX_HIP(hipMemcpyAsync(out_mismatches, ws, 8, hipMemcpyDeviceToHost, st));
   ARX_HIP(hipStreamSynchronize(st));
+  return ARX_OK;
+}
+
+int arx_group_edge_rows(const uint32_t* group_ids, const void* validity, int64_t validity_offset, int64_t length,
+                        int64_t num_groups, int last, uint32_t* out_rows, void* out_has_row, void* stream) {
+  if (num_groups <= 0) return ARX_OK;
+  if (out_rows == nullptr || out_has_row == nullptr || (length > 0 && group_ids == nullptr)) {
+    set_error("group edge rows: NULL buffer");
+    return ARX_INVALID;
+  }
+  if (length >= (int64_t(1) << 32) - 2) {
+    set_error("group edge rows: row numbers are uint32");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  ARX_HIP(hipMemsetAsync(out_rows, 0xFF, static_cast<size_t>(num_groups) * 4, st));
+  if (length > 0) {
+    const Bits vb = make_bits(validity, validity_offset, length);
+    hipLaunchKernelGGL(group_edge_rows_kernel, dim3(grouper_grid(length)), dim3(kBlock), 0, st, group_ids, vb, length, num_groups,
+                       last != 0 ? 1 : 0, out_rows);
+    ARX_CHECK_LAUNCH("group_edge_rows_kernel");
+  }
+  hipLaunchKernelGGL(group_edge_rows_finish_kernel, dim3(grouper_grid((num_groups + 63) / 64 * 64)), dim3(kBlock), 0, st, out_rows,
+                     num_groups, last != 0 ? 1 : 0, static_cast<uint64_t*>(out_has_row));
+  ARX_CHECK_LAUNCH("group_edge_rows_finish_kernel");
   return ARX_OK;
 }
 

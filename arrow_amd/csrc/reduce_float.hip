@@ -364,7 +364,33 @@ static int64_t fsum_max_blocks(int64_t n, int64_t null_count) {
 // instead of row by row.  No atomics: a group has one owner per call; batches continue where the last one stopped.
 constexpr int64_t kFsumLongRun = 1024;
 
+// what a walker does with a row: A = double (sums and products of floats, in row order) or uint64_t (hash_product of the
+// integer types: MultiplyTraits multiplies in the unsigned type, wrapping — base_arithmetic_internal.h:303-325);
+// skip() is the value a row that does not count is replaced by, the operation's identity (x + -0.0 == x and x * 1.0 == x
+// bit for bit, for every x)
+template <typename A, bool PRODUCT>
+struct WalkOp;
+template <>
+struct WalkOp<double, false> {
+  static __device__ __forceinline__ double skip() { return -0.0; }
+  static __device__ __forceinline__ double apply(double acc, double v) { return acc + v; }
+};
+template <>
+struct WalkOp<double, true> {
+  static __device__ __forceinline__ double skip() { return 1.0; }
+  static __device__ __forceinline__ double apply(double acc, double v) { return acc * v; }
+};
+template <>
+struct WalkOp<uint64_t, true> {
+  static __device__ __forceinline__ uint64_t skip() { return 1; }
+  static __device__ __forceinline__ uint64_t apply(uint64_t acc, uint64_t v) { return acc * v; }
+};
+
 // the rows in (group id, row) order: group id, value as a double, validity — what the walkers then read sequentially
+__global__ __launch_bounds__(kBlock) void fill_u64_kernel(uint64_t* __restrict__ out, uint64_t value, int64_t n) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) out[i] = value;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void hash_fsum_gather_kernel(const T* __restrict__ values, Bits vvalid, int is_scalar, double scalar,
                                                                   int scalar_valid, const uint32_t* __restrict__ gids,
@@ -384,8 +410,22 @@ __global__ __launch_bounds__(kBlock) void hash_fsum_gather_kernel(const T* __res
   }
 }
 
-__global__ __launch_bounds__(kBlock) void hash_fsum_walk_kernel(const uint32_t* __restrict__ gs, const double* __restrict__ vs,
-                                                                const uint8_t* __restrict__ oks, int64_t n, double* __restrict__ sums,
+// the same for the integer types: the value widened to 64 bits (sign- or zero-extended: the product's accumulator type)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void hash_iprod_gather_kernel(const T* __restrict__ values, Bits vvalid, const uint32_t* __restrict__ gids,
+                                                                   const uint64_t* __restrict__ perm, int64_t n, uint32_t* __restrict__ gs,
+                                                                   uint64_t* __restrict__ vs, uint8_t* __restrict__ oks) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const uint64_t r = perm[i];
+    gs[i] = gids[r];
+    vs[i] = static_cast<uint64_t>(static_cast<int64_t>(values[r]));   // (unsigned T: zero-extended by the first cast)
+    oks[i] = (vvalid.base == nullptr || ((load_word(vvalid, static_cast<int64_t>(r) >> 6) >> (r & 63)) & 1ull)) ? 1 : 0;
+  }
+}
+
+template <typename A, bool PRODUCT>
+__global__ __launch_bounds__(kBlock) void hash_fsum_walk_kernel(const uint32_t* __restrict__ gs, const A* __restrict__ vs,
+                                                                const uint8_t* __restrict__ oks, int64_t n, A* __restrict__ sums,
                                                                 long long* __restrict__ counts, uint32_t* __restrict__ null_seen,
                                                                 unsigned long long* __restrict__ long_runs) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
@@ -396,14 +436,14 @@ __global__ __launch_bounds__(kBlock) void hash_fsum_walk_kernel(const uint32_t* 
       long_runs[1 + atomicAdd(&long_runs[0], 1ull)] = static_cast<unsigned long long>(i);
       continue;
     }
-    double acc = sums[g];
+    A acc = sums[g];
     long long cnt = 0;
     bool saw_null = false;
     bool more = true;
     for (int64_t j = i; j < n && more; j += 4) {
       // four rows' loads in flight; the adds stay in row order
       uint32_t gg[4];
-      double v[4];
+      A v[4];
       uint8_t ok[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -417,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void hash_fsum_walk_kernel(const uint32_t* 
         if (!more || j + k >= n || gg[k] != g) {
           more = false;
         } else if (ok[k]) {
-          acc = acc + v[k];
+          acc = WalkOp<A, PRODUCT>::apply(acc, v[k]);
           ++cnt;
         } else {
           saw_null = true;
@@ -436,24 +476,25 @@ __global__ __launch_bounds__(kBlock) void hash_fsum_walk_kernel(const uint32_t* 
 // 64 values of a chunk go through LDS and come back as broadcast reads, all issued before the first add.  (Reading them lane by
 // lane with v_readlane cost ~120 cycles a row, with ds_bpermute more: 37 / 46 ms for 6.7e5-row runs.)
 constexpr int kFsumAhead = 8;
-__global__ __launch_bounds__(64) void hash_fsum_walk_long_kernel(const uint32_t* __restrict__ gs, const double* __restrict__ vs,
-                                                                 const uint8_t* __restrict__ oks, int64_t n, double* __restrict__ sums,
+template <typename A, bool PRODUCT>
+__global__ __launch_bounds__(64) void hash_fsum_walk_long_kernel(const uint32_t* __restrict__ gs, const A* __restrict__ vs,
+                                                                 const uint8_t* __restrict__ oks, int64_t n, A* __restrict__ sums,
                                                                  long long* __restrict__ counts, uint32_t* __restrict__ null_seen,
                                                                  const unsigned long long* __restrict__ long_runs) {
-  __shared__ double stage[kFsumAhead][64];
+  __shared__ A stage[kFsumAhead][64];
   const int lane = threadIdx.x;
   const int64_t nruns = static_cast<int64_t>(long_runs[0]);
   for (int64_t e = blockIdx.x; e < nruns; e += gridDim.x) {
     const int64_t i = static_cast<int64_t>(long_runs[1 + e]);
     const uint32_t g = gs[i];
-    double acc = sums[g];
+    A acc = sums[g];
     long long cnt = 0;
     bool saw_null = false;
     bool more = true;
     // the next round's rows are loaded into registers before this round's chain of adds runs (the barrier in between would
     // otherwise keep the loads behind it)
     uint32_t gg[kFsumAhead];
-    double vv[kFsumAhead];
+    A vv[kFsumAhead];
     uint8_t oo[kFsumAhead];
     auto fetch = [&](int64_t j0) {
 #pragma unroll
@@ -474,7 +515,7 @@ __global__ __launch_bounds__(64) void hash_fsum_walk_long_kernel(const uint32_t*
         const bool ok = oo[c] != 0;
         run_mask[c] = __ballot(in_run);
         ok_mask[c] = __ballot(ok);
-        stage[c][lane] = (in_run && ok) ? vv[c] : -0.0;
+        stage[c][lane] = (in_run && ok) ? vv[c] : WalkOp<A, PRODUCT>::skip();
       }
       __syncthreads();
       if (j + 64 * kFsumAhead < n) fetch(j + 64 * kFsumAhead);
@@ -484,11 +525,11 @@ __global__ __launch_bounds__(64) void hash_fsum_walk_long_kernel(const uint32_t*
         const int take = run_mask[c] == ~0ull ? 64 : __builtin_ctzll(~run_mask[c]);   // the run's rows are a prefix of the 64
         const uint64_t prefix = take == 64 ? ~0ull : ((1ull << take) - 1ull);
         // (a staged value past `take` is -0.0: the rows are sorted by group, the group does not come back)
-        double x[64];
+        A x[64];
 #pragma unroll
         for (int l = 0; l < 64; ++l) x[l] = stage[c][l];
 #pragma unroll
-        for (int l = 0; l < 64; ++l) acc = acc + x[l];
+        for (int l = 0; l < 64; ++l) acc = WalkOp<A, PRODUCT>::apply(acc, x[l]);
         cnt += __popcll(ok_mask[c] & prefix);
         saw_null = saw_null || ((~ok_mask[c] & prefix) != 0);
         if (take < 64) more = false;
@@ -734,12 +775,108 @@ int arx_hash_sum_float_consume(const ArxSpan* values, int num_type, int values_i
                        scalar_valid, group_ids, perm, length, gs, vs, oks);
   }
   ARX_CHECK_LAUNCH("hash_fsum_gather_kernel");
-  hipLaunchKernelGGL(hash_fsum_walk_kernel, dim3(grid), dim3(kBlock), 0, st, gs, vs, oks, length, sums, reinterpret_cast<long long*>(counts),
-                     null_seen, long_runs);
+  hipLaunchKernelGGL((hash_fsum_walk_kernel<double, false>), dim3(grid), dim3(kBlock), 0, st, gs, static_cast<const double*>(vs), oks, length, sums,
+                     reinterpret_cast<long long*>(counts), null_seen, long_runs);
   ARX_CHECK_LAUNCH("hash_fsum_walk_kernel");
   if (length > kFsumLongRun) {
-    hipLaunchKernelGGL(hash_fsum_walk_long_kernel, dim3(256 * 8), dim3(64), 0, st, gs, vs, oks, length, sums,
-                       reinterpret_cast<long long*>(counts), null_seen, long_runs);
+    hipLaunchKernelGGL((hash_fsum_walk_long_kernel<double, false>), dim3(256 * 8), dim3(64), 0, st, gs, static_cast<const double*>(vs), oks, length,
+                       sums, reinterpret_cast<long long*>(counts), null_seen, long_runs);
+    ARX_CHECK_LAUNCH("hash_fsum_walk_long_kernel");
+  }
+  return ARX_OK;
+}
+
+// hash_product — GroupedProductImpl (kernels/hash_aggregate_numeric.cc:311-347): per group the product of the valid values IN
+// ROW ORDER from 1, in the accumulator type of the sum (int64 / uint64 wrapping, double).  Integer products do not depend on
+// the order, products of doubles do (and of two NaNs: the first payload wins), so every type takes the walkers above: rows
+// stably sorted by group id, one owner per group.  `products`: 8 bytes per group, filled with 1 / 1.0 by
+// arx_hash_product_init before the first batch; counts / null_seen as for the sums (the same finalize).
+int arx_hash_product_init(void* products, int num_type, int64_t num_groups, void* stream) {
+  if (num_groups <= 0) return ARX_OK;
+  if (products == nullptr) {
+    set_error("arx_hash_product_init: NULL buffer");
+    return ARX_INVALID;
+  }
+  const bool is_float = num_type == ARX_NUM_FLOAT32 || num_type == ARX_NUM_FLOAT64;
+  const double one = 1.0;
+  uint64_t bits = 1;
+  if (is_float) memcpy(&bits, &one, 8);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(fill_u64_kernel, dim3(static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((num_groups + kBlock - 1) / kBlock, 4096)))),
+                     dim3(kBlock), 0, st, static_cast<uint64_t*>(products), bits, num_groups);
+  ARX_CHECK_LAUNCH("fill_u64_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_product_consume(const ArxSpan* values, int num_type, const uint32_t* group_ids, int64_t length, void* ws, size_t ws_bytes,
+                             void* products, int64_t* counts, uint32_t* null_seen, void* stream) {
+  if (values == nullptr || length < 0 || num_type < ARX_NUM_INT8 || num_type > ARX_NUM_FLOAT64) {
+    set_error("bad arguments to arx_hash_product_consume");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  if (group_ids == nullptr || products == nullptr || counts == nullptr || null_seen == nullptr || ws == nullptr ||
+      ws_bytes < arx_hash_sum_float_workspace_bytes(length) || values->data == nullptr) {
+    set_error("arx_hash_product_consume: NULL buffer or a workspace below arx_hash_sum_float_workspace_bytes");
+    return ARX_INVALID;
+  }
+  const size_t n = static_cast<size_t>(length);
+  uint8_t* p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~uintptr_t(255));
+  const size_t sort_bytes = arx_sort_indices_workspace_bytes(length);
+  uint8_t* q = p + fsum_align(sort_bytes);
+  uint64_t* perm = reinterpret_cast<uint64_t*>(q); q += fsum_align(n * 8);
+  uint32_t* gs = reinterpret_cast<uint32_t*>(q); q += fsum_align(n * 4);
+  void* vs = q; q += fsum_align(n * 8);
+  uint8_t* oks = q; q += fsum_align(n);
+  unsigned long long* long_runs = reinterpret_cast<unsigned long long*>(q);
+  const ArxSpan keys{nullptr, group_ids, 0, length, 0};
+  const int rc = arx_sort_indices(&keys, ARX_KEY_UINT32, ARX_SORT_ASCENDING, ARX_NULLS_AT_END, p, sort_bytes, perm, stream);
+  if (rc != ARX_OK) return rc;
+  hipStream_t st = as_stream(stream);
+  ARX_HIP(hipMemsetAsync(long_runs, 0, 8, st));
+  const bool has_nulls = values->null_count != 0 && values->validity != nullptr;
+  const Bits vvalid = has_nulls ? make_bits(values->validity, values->offset, length) : Bits{};
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((length + kBlock - 1) / kBlock, 256 * 16)));
+  const bool is_float = num_type == ARX_NUM_FLOAT32 || num_type == ARX_NUM_FLOAT64;
+#define ARX_IPROD_GATHER(T)                                                                                                            \
+  hipLaunchKernelGGL((hash_iprod_gather_kernel<T>), dim3(grid), dim3(kBlock), 0, st, static_cast<const T*>(values->data) + values->offset, vvalid, \
+                     group_ids, perm, length, gs, static_cast<uint64_t*>(vs), oks)
+  switch (num_type) {
+    case ARX_NUM_INT8: ARX_IPROD_GATHER(int8_t); break;
+    case ARX_NUM_UINT8: ARX_IPROD_GATHER(uint8_t); break;
+    case ARX_NUM_INT16: ARX_IPROD_GATHER(int16_t); break;
+    case ARX_NUM_UINT16: ARX_IPROD_GATHER(uint16_t); break;
+    case ARX_NUM_INT32: ARX_IPROD_GATHER(int32_t); break;
+    case ARX_NUM_UINT32: ARX_IPROD_GATHER(uint32_t); break;
+    case ARX_NUM_INT64: ARX_IPROD_GATHER(int64_t); break;
+    case ARX_NUM_UINT64: ARX_IPROD_GATHER(uint64_t); break;
+    case ARX_NUM_FLOAT32:
+      hipLaunchKernelGGL((hash_fsum_gather_kernel<float>), dim3(grid), dim3(kBlock), 0, st, static_cast<const float*>(values->data) + values->offset,
+                         vvalid, 0, 0.0, 1, group_ids, perm, length, gs, static_cast<double*>(vs), oks);
+      break;
+    default:
+      hipLaunchKernelGGL((hash_fsum_gather_kernel<double>), dim3(grid), dim3(kBlock), 0, st, static_cast<const double*>(values->data) + values->offset,
+                         vvalid, 0, 0.0, 1, group_ids, perm, length, gs, static_cast<double*>(vs), oks);
+      break;
+  }
+#undef ARX_IPROD_GATHER
+  ARX_CHECK_LAUNCH("hash product gather kernel");
+  if (is_float) {
+    hipLaunchKernelGGL((hash_fsum_walk_kernel<double, true>), dim3(grid), dim3(kBlock), 0, st, gs, static_cast<const double*>(vs), oks, length,
+                       static_cast<double*>(products), reinterpret_cast<long long*>(counts), null_seen, long_runs);
+  } else {
+    hipLaunchKernelGGL((hash_fsum_walk_kernel<uint64_t, true>), dim3(grid), dim3(kBlock), 0, st, gs, static_cast<const uint64_t*>(vs), oks, length,
+                       static_cast<uint64_t*>(products), reinterpret_cast<long long*>(counts), null_seen, long_runs);
+  }
+  ARX_CHECK_LAUNCH("hash_fsum_walk_kernel");
+  if (length > kFsumLongRun) {
+    if (is_float) {
+      hipLaunchKernelGGL((hash_fsum_walk_long_kernel<double, true>), dim3(256 * 8), dim3(64), 0, st, gs, static_cast<const double*>(vs), oks, length,
+                         static_cast<double*>(products), reinterpret_cast<long long*>(counts), null_seen, long_runs);
+    } else {
+      hipLaunchKernelGGL((hash_fsum_walk_long_kernel<uint64_t, true>), dim3(256 * 8), dim3(64), 0, st, gs, static_cast<const uint64_t*>(vs), oks, length,
+                         static_cast<uint64_t*>(products), reinterpret_cast<long long*>(counts), null_seen, long_runs);
+    }
     ARX_CHECK_LAUNCH("hash_fsum_walk_long_kernel");
   }
   return ARX_OK;

@@ -872,6 +872,13 @@ int arx_binary_key_chunk(const ArxBinarySpan* values, int64_t chunk_index, uint6
 int arx_binary_key_hash(const ArxBinarySpan* values, int hash_bits, uint64_t* out_hash, void* stream);
 int arx_binary_key_verify(const ArxBinarySpan* values, const uint32_t* group_ids, const uint32_t* first_rows,
                           int64_t* out_mismatches, void* ws, void* stream);
+/* hash_first / hash_last / hash_one (GroupedFirstLastImpl kernels/hash_aggregate.cc:738-925, GroupedOneImpl :1556-1625 keep the
+ * first / last NON-NULL value of every group in row order): out_rows[g] = the smallest (last = 0) or largest (last != 0) row
+ * of group g whose bit in `validity` (NULL: every row) is set, 0 where the group has none; out_has_row = a bitmap of
+ * ceil(num_groups / 64) words saying which groups have one — the validity of the index array `take(values, out_rows)`
+ * is called with.  length < 2^32 - 2.  Asynchronous. */
+int arx_group_edge_rows(const uint32_t* group_ids, const void* validity, int64_t validity_offset, int64_t length,
+                        int64_t num_groups, int last, uint32_t* out_rows, void* out_has_row, void* stream);
 int arx_group_first_rows(const uint32_t* group_ids, int64_t length, int64_t num_groups, uint32_t* out_first_rows,
                          void* stream);
 
@@ -889,6 +896,13 @@ size_t arx_hash_sum_float_workspace_bytes(int64_t length);
 int arx_hash_sum_float_consume(const ArxSpan* values, int num_type, int values_is_scalar, double scalar_value,
                                const uint32_t* group_ids, int64_t length, void* ws, size_t ws_bytes, double* sums,
                                int64_t* counts, uint32_t* null_seen, void* stream);
+/* hash_product — GroupedProductImpl (kernels/hash_aggregate_numeric.cc:311-347): per group the product of the valid values in row
+ * order from 1, in the sum's accumulator type (int64 / uint64: MultiplyTraits wraps in the unsigned type; double).  products: 8
+ * bytes per group, arx_hash_product_init fills them with 1 / 1.0; counts / null_seen / workspace as for arx_hash_sum_float_consume
+ * (whose finalize serves min_count / skip_nulls here too).  num_type: any ARX_NUM_*.  Asynchronous. */
+int arx_hash_product_init(void* products, int num_type, int64_t num_groups, void* stream);
+int arx_hash_product_consume(const ArxSpan* values, int num_type, const uint32_t* group_ids, int64_t length, void* ws,
+                             size_t ws_bytes, void* products, int64_t* counts, uint32_t* null_seen, void* stream);
 int arx_hash_sum_f64_merge(double* sums, int64_t* counts, uint32_t* null_seen, const double* other_sums,
                            const int64_t* other_counts, const uint32_t* other_null_seen,
                            const uint32_t* group_id_mapping, int64_t other_num_groups, void* stream);

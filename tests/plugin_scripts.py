@@ -3856,7 +3856,7 @@ ACERO_GUARD_SCRIPT = textwrap.dedent(r"""
     assert lib.arrow_amd_plugin_acero_guard(1) == took1
     # 4. what aggregate_rocm does not serve is REFUSED by name (the stock node would have read the keys on the host)
     ref0 = lib.arrow_amd_plugin_acero_guard(2)
-    for fn in ("hash_product", "hash_tdigest"):
+    for fn in ("hash_variance", "hash_tdigest"):
         try:
             plan(td, [acero.Declaration("aggregate", acero.AggregateNodeOptions([("v", fn, None, "x")], keys=["k"]))])
             raise SystemExit("a keyed %s over device-resident keys was not refused" % fn)
@@ -3868,6 +3868,93 @@ ACERO_GUARD_SCRIPT = textwrap.dedent(r"""
     assert t.group_by("k", use_threads=False).aggregate(A1).sort_by("k").equals(want.rename_columns(["k", "v_sum", "v_count", "v_min"]))
     assert plan(td, [acero.Declaration("aggregate", acero.AggregateNodeOptions([("v", "sum", None, "s")]))]).column("s")[0].as_py() == pc.sum(t.column("v")).as_py()
     print("ACERO_GUARD_OK")
+""")
+
+
+FIRST_LAST_SCRIPT = textwrap.dedent(r"""
+    import ctypes, os, sys, faulthandler
+    faulthandler.enable()
+    import numpy as np
+    import pyarrow as pa, pyarrow.compute as pc
+    from pyarrow import acero
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    path = build_plugin()
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # (the emulated device is one fiber scheduler: one Acero thread)
+        pa.set_cpu_count(1)
+        pa.set_io_thread_count(1)
+    # hash_first / hash_last / hash_one in aggregate_rocm: the first / last NON-NULL value of a group in row order
+    # (GroupedFirstLastImpl kernels/hash_aggregate.cc:738-925, GroupedOneImpl :1556-1625), skip_nulls on and off, value types of
+    # 1 to 16 bytes, groups of nulls only, nulls before / after the values — equal to the reference's GroupByNode (which runs
+    # these ordered aggregates on one thread only), host and device-resident tables, several batches, int32 and utf8 keys
+    rng = np.random.default_rng(131)
+    n = SC(300_000)
+    kk = rng.integers(0, 700, n)
+    vmask = rng.random(n) < 0.3
+    vmask[kk == 5] = True                                    # a group of nulls only
+    import decimal
+    t = pa.table({
+        "k": pa.array(kk.astype(np.int32), mask=rng.random(n) < 0.01),
+        "s": pa.array(["key-%d" % (x % 50) for x in kk]),
+        "i64": pa.array(rng.integers(-2**60, 2**60, n), mask=vmask),
+        "i8": pa.array(rng.integers(-100, 100, n).astype(np.int8), mask=rng.random(n) < 0.5),
+        "u16": pa.array(rng.integers(0, 60000, n).astype(np.uint16)),
+        "f32": pa.array(rng.random(n).astype(np.float32), mask=rng.random(n) < 0.2),
+        "f64": pa.array(rng.standard_normal(n), mask=rng.random(n) < 0.2),
+        "ts": pa.array(rng.integers(0, 10**15, n), pa.timestamp("us"), mask=rng.random(n) < 0.1),
+        "d32": pa.array(rng.integers(0, 20000, n).astype(np.int32), pa.date32()),
+        "small": pa.array(rng.integers(-3, 4, n).astype(np.int32), mask=rng.random(n) < 0.1),   # (products that stay small, with zeros)
+        "dec": pa.array([decimal.Decimal(int(x)).scaleb(-3) for x in rng.integers(-10**12, 10**12, n)], pa.decimal128(20, 3), mask=rng.random(n) < 0.25),
+    })
+    tc = pa.concat_tables([t.slice(0, n // 7), t.slice(n // 7, n // 2), t.slice(n // 7 + n // 2)])
+    vals = ["i64", "i8", "u16", "f32", "f64", "ts", "d32"]      # (the reference's hash_first_last has no decimal kernel; hash_one has)
+    keep = pc.ScalarAggregateOptions(skip_nulls=False)
+    aggs = [(c, "hash_" + f, o, "%s_%s_%d" % (c, f, o is keep)) for c in vals for f in ("first", "last") for o in (None, keep)]
+    aggs += [(c, "hash_one", None, c + "_one") for c in vals + ["dec"]] + [("i64", "hash_sum", None, "sum"), ([], "hash_count_all", None, "rows")]
+    # hash_product (GroupedProductImpl kernels/hash_aggregate_numeric.cc:311-347): wrapping int64 / uint64 products, double
+    # products in ROW order (float32 values widened first), min_count / skip_nulls as the sums
+    strict = pc.ScalarAggregateOptions(skip_nulls=False, min_count=3)
+    aggs += [(c, "hash_product", o, "%s_prod_%d" % (c, o is strict)) for c in ("i64", "i8", "u16", "f32", "f64", "small") for o in (None, strict)]
+    def plan(tab, node, keys, threads=False):
+        return acero.Declaration.from_sequence([
+            acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
+            acero.Declaration(node, acero.AggregateNodeOptions(aggs, keys=keys))]).to_table(use_threads=threads).sort_by([(k, "ascending") for k in keys])
+    key_sets = (["k"], ["s"], ["s", "k"])
+    want = {tuple(ks): plan(t, "aggregate", ks) for ks in key_sets}
+    w = want[("k",)]
+    assert w.column("i64_first_0").null_count >= 1 and w.column("i64_first_1").null_count > w.column("i64_first_0").null_count   # (nulls first in some groups)
+    lib = ctypes.CDLL(path)
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+    def to_device(arr):
+        c_arr, c_schema, c_dev = (ctypes.create_string_buffer(m) for m in (80, 72, 128))
+        arr._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_device(c_arr, c_schema, c_dev) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), arr.type)
+    td = pa.Table.from_batches([pa.RecordBatch.from_arrays([to_device(c.combine_chunks().column(j).chunk(0)) for j in range(t.num_columns)],
+                                                           names=t.schema.names)
+                                for c in (t.slice(0, n // 3 + 1), t.slice(n // 3 + 1))])
+    threaded = os.environ.get("ARROW_AMD_PLUGIN_EMULATED") != "1"
+    for ks in key_sets:
+        w = want[tuple(ks)]
+        for tab, what, threads in ((t, "host", False), (tc, "host chunks", False), (td, "device", False)) + (((tc, "host chunks, threads", True),) if threaded else ()):
+            g = plan(tab, "aggregate_rocm", ks, threads)
+            assert g.schema.equals(w.schema), (g.schema, w.schema)
+            for ci, name in enumerate(w.schema.names):
+                assert g.column(ci).equals(w.column(ci)), (what, ks, name, g.column(ci).slice(0, 8), w.column(ci).slice(0, 8))
+    for bad in ("s",):
+        try:
+            acero.Declaration.from_sequence([
+                acero.Declaration("table_source", acero.TableSourceNodeOptions(t)),
+                acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([(bad, "hash_first", None, "x")], keys=["k"]))]).to_table()
+            raise SystemExit("expected NotImplemented")
+        except pa.ArrowNotImplementedError as e:
+            assert "fixed-width" in str(e), e
+    print("FIRST_LAST_OK")
 """)
 
 
@@ -3945,4 +4032,6 @@ CASES = [
      "aggregate_rocm over utf8 / binary key columns (alone, beside fixed-width keys, several of them): the string enters the chain of Grouper tables as its length and 12-byte chunks (arx_binary_key_lengths / _chunk), the unique strings are the strings of the groups' first rows (arx_group_first_rows + the binary take) — equal to the reference GroupByNode, strings that differ only in their last byte, only in length, in trailing NUL bytes, empty vs null."),
     ('stock_group_by_over_device_resident_key_columns_is_served_or_refused', ACERO_GUARD_SCRIPT, 'ACERO_GUARD_OK', 0.05,
      'VERDICT r4 item 8: table_source -> aggregate plans by their STOCK names (what Table.group_by builds) over a table whose KEY columns live in HBM return the reference\'s result (built as aggregate_rocm by the guard arrow_amd_register() installs in front of the CPU Grouper) or a NotImplemented Status; host keys over device values keep the stock GroupByNode; host tables untouched.'),
+    ('hash_first_last_one_and_product_in_aggregate_rocm', FIRST_LAST_SCRIPT, 'FIRST_LAST_OK', 0.03,
+     'VERDICT r4 missing 1: hash_first / hash_last (skip_nulls on and off) / hash_one in aggregate_rocm — the row of every group\'s first / last non-null value (arx_group_edge_rows) + one take — for value types of 1 to 16 bytes, and hash_product (wrapping integer products, double products in row order through the float sums\' walkers) — equal to the reference\'s GroupByNode; batches in batch.index order whatever the thread count.'),
 ]
