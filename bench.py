@@ -1153,7 +1153,7 @@ def sort_leg(args, rank, world, device, rows_total, steps, warmup):
            "roofline": {"bound": "hbm", "kernel": "arx_sort_indices (msd_hist + scatter levels + LDS bucket finish)",
                         "achieved": round(per_gpu, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 16,
-                        "traffic": load_traffic("sort", rows // world, form="estimated")}}
+                        "traffic": load_traffic("sort", rows // world, form="rec8")}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not EMU:
         if "sort_indices" in _CPU_PRE:
             leg["cpu_baseline"] = _CPU_PRE["sort_indices"]
