@@ -949,8 +949,9 @@ __global__ __launch_bounds__(kBlock) void take_rows_kernel(TakeArgs a, uint32_t 
       const uint32_t j = tt - row * units_per_row;
       const uint64_t src = (static_cast<uint64_t>(__shfl(idx_hi, static_cast<int>(row), 64)) << 32) | __shfl(idx_lo, static_cast<int>(row), 64);
       const bool row_ok = (vbal >> row) & 1ull;
-      E v = values[src * units_per_row + j];     // (a null row reads row 0 of the values — addressable — and drops it)
-      if (!row_ok) v = E{};
+      // (a null / out-of-range row reads nothing: the values may be an EMPTY child with no buffer at all — ADVICE r4)
+      E v = E{};
+      if (row_ok) v = values[src * units_per_row + j];
       if (t < total) out[(static_cast<uint64_t>(base) + row) * units_per_row + j] = v;
     }
   }

@@ -3919,6 +3919,11 @@ FIRST_LAST_SCRIPT = textwrap.dedent(r"""
     # products in ROW order (float32 values widened first), min_count / skip_nulls as the sums
     strict = pc.ScalarAggregateOptions(skip_nulls=False, min_count=3)
     aggs += [(c, "hash_product", o, "%s_prod_%d" % (c, o is strict)) for c in ("i64", "i8", "u16", "f32", "f64", "small") for o in (None, strict)]
+    # hash_first_last (a struct of the two), hash_list (every value of the group in row order, nulls included), hash_distinct
+    # (the distinct values in order of first appearance; CountOptions: without the null / only the null / with it)
+    aggs += [(c, "hash_first_last", o, "%s_fl_%d" % (c, o is keep)) for c in ("i64", "f32") for o in (None, keep)]
+    aggs += [(c, "hash_list", None, c + "_list") for c in ("i64", "i8", "f64", "ts")]
+    aggs += [(c, "hash_distinct", pc.CountOptions(mode=m), "%s_distinct_%s" % (c, m)) for c in ("small", "i8", "d32", "u16") for m in ("only_valid", "only_null", "all")]
     def plan(tab, node, keys, threads=False):
         return acero.Declaration.from_sequence([
             acero.Declaration("table_source", acero.TableSourceNodeOptions(tab)),
@@ -3945,6 +3950,12 @@ FIRST_LAST_SCRIPT = textwrap.dedent(r"""
             g = plan(tab, "aggregate_rocm", ks, threads)
             assert g.schema.equals(w.schema), (g.schema, w.schema)
             for ci, name in enumerate(w.schema.names):
+                if "_distinct_" in name:
+                    # "Order of sub-arrays is not stable" (acero/hash_aggregate_test.cc:2487: the reference's own test sorts every
+                    # list first — its order is the swiss table's insertion order, ours the order of first appearance)
+                    canon = lambda col: [None if x is None else sorted(x, key=lambda v: (v is None, 0 if v is None else v)) for x in col.to_pylist()]
+                    assert canon(g.column(ci)) == canon(w.column(ci)) and g.column(ci).type == w.column(ci).type, (what, ks, name)
+                    continue
                 assert g.column(ci).equals(w.column(ci)), (what, ks, name, g.column(ci).slice(0, 8), w.column(ci).slice(0, 8))
     for bad in ("s",):
         try:
@@ -4032,6 +4043,6 @@ CASES = [
      "aggregate_rocm over utf8 / binary key columns (alone, beside fixed-width keys, several of them): the string enters the chain of Grouper tables as its length and 12-byte chunks (arx_binary_key_lengths / _chunk), the unique strings are the strings of the groups' first rows (arx_group_first_rows + the binary take) — equal to the reference GroupByNode, strings that differ only in their last byte, only in length, in trailing NUL bytes, empty vs null."),
     ('stock_group_by_over_device_resident_key_columns_is_served_or_refused', ACERO_GUARD_SCRIPT, 'ACERO_GUARD_OK', 0.05,
      'VERDICT r4 item 8: table_source -> aggregate plans by their STOCK names (what Table.group_by builds) over a table whose KEY columns live in HBM return the reference\'s result (built as aggregate_rocm by the guard arrow_amd_register() installs in front of the CPU Grouper) or a NotImplemented Status; host keys over device values keep the stock GroupByNode; host tables untouched.'),
-    ('hash_first_last_one_and_product_in_aggregate_rocm', FIRST_LAST_SCRIPT, 'FIRST_LAST_OK', 0.03,
-     'VERDICT r4 missing 1: hash_first / hash_last (skip_nulls on and off) / hash_one in aggregate_rocm — the row of every group\'s first / last non-null value (arx_group_edge_rows) + one take — for value types of 1 to 16 bytes, and hash_product (wrapping integer products, double products in row order through the float sums\' walkers) — equal to the reference\'s GroupByNode; batches in batch.index order whatever the thread count.'),
+    ('hash_first_last_one_product_list_distinct_in_aggregate_rocm', FIRST_LAST_SCRIPT, 'FIRST_LAST_OK', 0.03,
+     'VERDICT r4 missing 1: hash_first / hash_last (skip_nulls on and off) / hash_one in aggregate_rocm — the row of every group\'s first / last non-null value (arx_group_edge_rows) + one take — for value types of 1 to 16 bytes, and hash_product (wrapping integer products, double products in row order through the float sums\' walkers) hash_first_last (struct), hash_list (values in row order) and hash_distinct (first-appearance order, three CountOptions modes) — equal to the reference\'s GroupByNode; batches in batch.index order whatever the thread count.'),
 ]
