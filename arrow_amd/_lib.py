@@ -241,6 +241,7 @@ SIGNATURES = {
     "arx_hash_sum_dec128_consume": (_int, [_span, _int, C.c_uint64, C.c_uint64, _p, _i64, _p, _p, _p, _p, _p]),
     "arx_hash_sum_dec128_merge": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "arx_dec128_pack": (_int, [_p, _p, _i64, _p, _p]),
+    "arx_dec128_split": (_int, [_p, _i64, _p, _p, _p]),
     "arx_reduce_dec128_workspace_bytes": (_sz, []),
     "arx_reduce_dec128": (_int, [_span, _p, _sz, _p, _p]),
     "arx_hash_minmax_dec128_workspace_bytes": (_sz, [_i64]),

@@ -63,6 +63,17 @@ __global__ __launch_bounds__(kBlock) void dec128_pack_kernel(const unsigned long
   }
 }
 
+// the two halves of every value as columns of their own: a decimal128 sort key is the pair (high word as int64, low word
+// as uint64) — the order of BasicDecimal128::operator< (util/basic_decimal.h) — sorted as two keys of the existing sort
+__global__ __launch_bounds__(kBlock) void dec128_split_kernel(const Dec128* __restrict__ in, int64_t m, unsigned long long* __restrict__ lo,
+                                                              unsigned long long* __restrict__ hi) {
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; g < m; g += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const Dec128 v = in[g];
+    lo[g] = v.lo;
+    hi[g] = v.hi;
+  }
+}
+
 // ---- hash_min / hash_max of decimal128 values: GroupedMinMaxImpl<Decimal128Type> (kernels/hash_aggregate.cc:330-419) — per
 // group the smallest and the largest value (signed 128-bit order), has_values and has_nulls.  There is no 128-bit atomic
 // min / max: the rows are stably sorted by group id (arx_sort_indices), which makes every group one run, and one owner per
@@ -293,6 +304,18 @@ int arx_dec128_pack(const uint64_t* lo, const uint64_t* hi, int64_t n, void* out
   hipLaunchKernelGGL(dec128_pack_kernel, dim3(dec_grid(n)), dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const unsigned long long*>(lo),
                      reinterpret_cast<const unsigned long long*>(hi), n, static_cast<Dec128*>(out_values));
   ARX_CHECK_LAUNCH("dec128_pack_kernel");
+  return ARX_OK;
+}
+
+int arx_dec128_split(const void* values, int64_t n, uint64_t* out_lo, uint64_t* out_hi, void* stream) {
+  if (n < 0 || (n > 0 && (values == nullptr || out_lo == nullptr || out_hi == nullptr))) {
+    set_error("bad arguments to arx_dec128_split");
+    return ARX_INVALID;
+  }
+  if (n == 0) return ARX_OK;
+  hipLaunchKernelGGL(dec128_split_kernel, dim3(dec_grid(n)), dim3(kBlock), 0, as_stream(stream), static_cast<const Dec128*>(values), n,
+                     reinterpret_cast<unsigned long long*>(out_lo), reinterpret_cast<unsigned long long*>(out_hi));
+  ARX_CHECK_LAUNCH("dec128_split_kernel");
   return ARX_OK;
 }
 

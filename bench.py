@@ -451,6 +451,39 @@ def parity_hash_sum_prefix(device, groups_arg):
     return ("equal" if equal else "MISMATCH"), {"rows": n, "groups": int(len(hk)), "wide_plan_forced": forced, **plan}
 
 
+def acero_hash_sum_full(device, rows, groups, reps=3):
+    """the SAME work as the hash_sum leg — every row of streams 8 / 9 — through the drop-in route instead of
+    the Python mirror: an Acero plan `table_source_rocm -> aggregate_rocm` (hash_sum, int32 key) over a device-resident pyarrow
+    table that wraps the HBM buffers without a copy; the result is a host table, as GroupByNode's is.  Checked: number of
+    groups, and the wrap-around sum of the group sums against the sum of the values."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    from pyarrow import acero
+
+    plug = plugin_session()
+    keys = gen_stream(rows, device, 0, 8, modulo=groups, dtype=torch.int32)
+    vals = gen_stream(rows, device, 0, 9)
+    tab = pa.table({"k": plug.wrap(pa.int32(), rows, keys.view(torch.uint8)), "v": plug.wrap(pa.int64(), rows, vals.view(torch.uint8))})
+    plan = acero.Declaration.from_sequence([
+        acero.Declaration("table_source_rocm", acero.TableSourceNodeOptions(tab)),
+        acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"]))])
+    out = plan.to_table(use_threads=False)      # warm-up (pools, first-use allocations)
+    ts = []
+    for _ in range(reps):
+        out = None
+        _sync(device)
+        t0 = time.perf_counter()
+        out = plan.to_table(use_threads=False)
+        ts.append(time.perf_counter() - t0)
+    want = int(vals.sum().item())
+    got = int(np.asarray(out.column("v_sum").to_numpy()).view(np.uint64).sum(dtype=np.uint64).view(np.int64)) if out.num_rows else 0
+    ms = sorted(ts)[len(ts) // 2] * 1e3
+    return {"what": "acero table_source_rocm -> aggregate_rocm (hash_sum) over the same rows as a device-resident pyarrow table "
+                    "(zero-copy wrap of the HBM buffers), host result table; median of %d" % reps,
+            "ms": round(ms, 3), "ms_min": round(min(ts) * 1e3, 3), "mrows_per_s": round(rows / ms / 1e3, 1),
+            "groups": out.num_rows, "checksum_matches_sum_of_values": bool(got == want)}
+
+
 def parity_sort_prefix(device):
     """array_sort_indices on the first 1e8 rows of stream 10 with the WIDE form forced (the form the 2e9-row leg is timed
     on is chosen by row count: sort_msd_segment_rows lowers its threshold here), diffed against pyarrow's sort_indices:
@@ -1139,6 +1172,12 @@ def hash_sum_leg(args, rank, world, device, rows_total, steps, warmup):
                 leg["parity_prefix"], leg["parity_plan"] = parity_hash_sum_prefix(device, args.groups)
             except Exception as e:
                 leg["parity_prefix"] = f"ERROR {type(e).__name__}: {e}"[:300]
+        if not EMU:
+            try:
+                torch.cuda.empty_cache()
+                leg["through_acero"] = acero_hash_sum_full(device, rows, args.groups)
+            except Exception as e:
+                leg["through_acero"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return leg
 
 

@@ -924,6 +924,10 @@ int arx_hash_sum_dec128_merge(uint64_t* sums_lo, uint64_t* sums_hi, int64_t* cou
                               const uint32_t* other_null_seen, const uint32_t* group_id_mapping,
                               int64_t other_num_groups, void* stream);
 int arx_dec128_pack(const uint64_t* lo, const uint64_t* hi, int64_t n, void* out_values, void* stream);
+/* The inverse: out_lo[i] / out_hi[i] = the low / high 64 bits of value i (`values`: pre-offset, 16 bytes a value).  A
+ * decimal128 SORT KEY is the pair (high word as int64, low word as uint64) — BasicDecimal128's order, what
+ * ConcreteColumnComparator<Decimal128Type> compares (kernels/vector_sort_internal.h) — and is sorted as those two keys. */
+int arx_dec128_split(const void* values, int64_t n, uint64_t* out_lo, uint64_t* out_hi, void* stream);
 /* hash_min / hash_max of decimal128 values — GroupedMinMaxImpl<Decimal128Type> (kernels/hash_aggregate.cc:330-419): per group
  * the smallest and largest value in signed 128-bit order.  No 128-bit atomics: the rows are stably sorted by group id, every
  * group is one run, one owner per group (a thread, or a wave for runs > 1024 rows) folds the run into the state.  State the
