@@ -1349,6 +1349,16 @@ SELECTION_META_SCRIPT = textwrap.dedent(r'''
     assert host_table(dev_take(d_table, got_idx)).equals(pc.take(h_table, want_idx))
     assert to_host(pc.call_function("sort_indices", [d_table.column("f64")], pc.SortOptions(sort_keys=[("", "descending")]))).equals(
         pc.sort_indices(h_table.column("f64"), sort_keys=[("", "descending")]))
+    # (round 5) a device column in SEVERAL chunks is concatenated in HBM first: indices into the logical column, as the
+    # reference's ChunkedArray sorters give them; also as the key column of a table in several chunks
+    cuts = [0, n // 3, n // 3 + n // 5, n]
+    host_chunked = pa.chunked_array([cols["f64"].slice(a, b - a) for a, b in zip(cuts, cuts[1:])])
+    dev_chunked = pa.chunked_array([to_device(c) for c in host_chunked.chunks])
+    assert to_host(pc.call_function("sort_indices", [dev_chunked], pc.SortOptions(sort_keys=[("", "descending")]))).equals(
+        pc.sort_indices(host_chunked, sort_keys=[("", "descending")]))
+    h3 = pa.Table.from_batches([h_table.slice(a, b - a).to_batches()[0] for a, b in zip(cuts, cuts[1:])])
+    d3 = pa.Table.from_batches([pa.RecordBatch.from_arrays([to_device(c) for c in rb.columns], names=rb.schema.names) for rb in h3.select(["i32", "ts", "i64"]).to_batches()])
+    assert to_host(pc.call_function("sort_indices", [d3], pc.SortOptions(sort_keys=sk))).equals(pc.sort_indices(h3, sort_keys=sk))
     try:
         pc.call_function("sort_indices", [d_table], pc.SortOptions(sort_keys=[("s", "ascending")]))
         raise SystemExit("expected NotImplemented for a string sort key")
