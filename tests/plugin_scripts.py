@@ -2162,6 +2162,21 @@ TABLE_SOURCE_SCRIPT = textwrap.dedent(r'''
     got = plan("table_source_rocm", td, agg).to_table(use_threads=False).sort_by("k")
     assert lib.arrow_amd_plugin_aggregate_direct_batches() - d0 == 1
     assert got.column("k").equals(want_groups.column("k")) and got.column("v_sum").equals(want_groups.column("v_sum"))
+    # (round 5) large batches that are CONSECUTIVE SLICES of one device column are one span: the source cuts the unfiltered
+    # table into several batches, aggregate_rocm runs ONE partitioned pass over all of them (hash_sum GPU calls: one per chunk
+    # of the table, not one per batch)
+    lib.arrow_amd_plugin_set_aggregate_direct_rows(SC(20_000))
+    lib.arrow_amd_plugin_set_table_source_rows(SC(50_000))
+    plain = [acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"]))]
+    want_plain = t.group_by("k", use_threads=False).aggregate([("v", "sum")]).sort_by("k")
+    d0, h0 = lib.arrow_amd_plugin_aggregate_direct_batches(), lib.arrow_amd_plugin_calls(b"hash_sum", 1)
+    got = plan("table_source_rocm", td, plain).to_table(use_threads=False).sort_by("k")
+    assert got.column("k").equals(want_plain.column("k")) and got.column("v_sum").equals(want_plain.column("v_sum"))
+    assert lib.arrow_amd_plugin_aggregate_direct_batches() - d0 >= 4, lib.arrow_amd_plugin_aggregate_direct_batches() - d0
+    # (+ 1: a chunk's last, short batch is staged with the small ones and consumed at the end)
+    assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - h0 <= td.column("k").num_chunks + 1 < lib.arrow_amd_plugin_aggregate_direct_batches() - d0, (
+        lib.arrow_amd_plugin_calls(b"hash_sum", 1) - h0, td.column("k").num_chunks, lib.arrow_amd_plugin_aggregate_direct_batches() - d0)
+    lib.arrow_amd_plugin_set_table_source_rows(1 << 27)
     lib.arrow_amd_plugin_set_aggregate_direct_rows(1 << 22)
     # the result may stay in HBM when the rows came from there (off by default: GroupByNode's result is host memory)
     lib.arrow_amd_plugin_set_aggregate_device_output(1)
