@@ -1093,3 +1093,45 @@ def hash_sum_float_row_order(values, valid, gids, num_groups, sums=None, counts=
             else:
                 null_seen[g] = True
     return sums, counts, null_seen
+
+
+def hash_product_row_order(values, valid, gids, num_groups, products=None, counts=None, null_seen=None):
+    """GroupedProductImpl (kernels/hash_aggregate_numeric.cc:311-347) restated: as the grouped sum, with Reduce =
+    MultiplyTraits<AccType>::Multiply — the accumulator of an integer column is int64 / uint64 and the product wraps in the
+    UNSIGNED type (base_arithmetic_internal.h:303-325: `to_unsigned(u) * to_unsigned(v)`), of a float column double; the state
+    starts at 1 (`NullValue` = MultiplyTraits::one).  Row order as VisitGroupedValues walks the batch.  Returns the products as
+    uint64 bit patterns (integers) or float64."""
+    is_float = np.asarray(values).dtype.kind == "f"
+    if products is None:
+        products = np.ones(num_groups, dtype=np.float64 if is_float else np.uint64)
+    counts = np.zeros(num_groups, dtype=np.int64) if counts is None else counts
+    null_seen = np.zeros(num_groups, dtype=bool) if null_seen is None else null_seen
+    if is_float:
+        v = np.asarray(values, dtype=np.float64)
+    else:
+        v = np.asarray(values).astype(np.int64).view(np.uint64) if np.asarray(values).dtype.kind == "i" else np.asarray(values).astype(np.uint64)
+    with np.errstate(all="ignore"):
+        for i in range(len(gids)):
+            g = int(gids[i])
+            if valid is None or valid[i]:
+                products[g] = products[g] * v[i]
+                counts[g] += 1
+            else:
+                null_seen[g] = True
+    return products, counts, null_seen
+
+
+def group_edge_rows(gids, valid, num_groups, last=False):
+    """What GroupedFirstLastImpl / GroupedOneImpl keep per group (kernels/hash_aggregate.cc:775-808, :1575-1590), as a ROW:
+    `firsts[g]` is set by the first NON-NULL value of group g that VisitGroupedValues meets, `lasts[g]` by every non-null
+    value (so the last one stays).  Returns (rows, has_row): the row of that value, 0 and False where the group has none."""
+    rows = np.zeros(num_groups, dtype=np.uint32)
+    has = np.zeros(num_groups, dtype=bool)
+    for i in range(len(gids)):
+        if valid is not None and not valid[i]:
+            continue
+        g = int(gids[i])
+        if last or not has[g]:
+            rows[g] = i
+            has[g] = True
+    return rows, has

@@ -2820,3 +2820,86 @@ def check_reduce_dec128(amd, rng, sizes=(0, 1, 63, 64, 65, 5000, 70001)):
                 sv = [signed(v) for v in vals]
                 assert signed(out[4] + (out[5] << 64)) == min(sv) and signed(out[6] + (out[7] << 64)) == max(sv), tag
     assert lib.arx_reduce_dec128(C.byref(sp), ws.data_ptr(), 16, out, st) == _lib.ARX_INVALID
+
+
+def check_hash_product_and_edge_rows(amd, rng, n=20000, groups=(1, 7, 300, 5000)):
+    """arx_hash_product_init / _consume (hash_product: wrapping integer products of every width, double products in ROW order —
+    bit for bit, several batches, one long run for the wave-cooperative walker, nulls at an offset, zeros / inf / NaN / -0.0)
+    and arx_group_edge_rows (the row of every group's first / last non-null value + the bitmap of groups that have one:
+    hash_first / hash_last / hash_one) and arx_dec128_split, each against the oracle's restatement of the reference."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+    num_types = {np.int8: 0, np.uint8: 1, np.int16: 2, np.uint16: 3, np.int32: 4, np.uint32: 5, np.int64: 6, np.uint64: 7, np.float32: 8, np.float64: 9}
+    for dtype in (np.int64, np.uint64, np.int8, np.uint16, np.int32, np.float64, np.float32):
+        is_float = np.dtype(dtype).kind == "f"
+        for G in groups:
+            prods = torch.zeros(G, dtype=torch.int64, device=dev)
+            counts = torch.zeros(G, dtype=torch.int64, device=dev)
+            seen = torch.zeros(G, dtype=torch.int32, device=dev)
+            _lib.check(lib.arx_hash_product_init(prods.data_ptr(), num_types[dtype], G, st))
+            w_p = w_c = w_s = None
+            for batch, nn in enumerate((n, 1, n // 3 + 5)):
+                voff = int(rng.integers(0, 70))
+                if is_float:
+                    vals = (1.0 + rng.standard_normal(voff + nn) * 0.5).astype(dtype)
+                    if nn > 50:
+                        vals[voff + 3], vals[voff + 11] = -0.0, dtype(1e30)
+                        if batch == 2 and G > 1:
+                            vals[voff + 17], vals[voff + 19] = np.inf, np.nan
+                else:
+                    info = np.iinfo(dtype)
+                    vals = rng.integers(max(info.min, -7), min(info.max, 9), voff + nn).astype(dtype)
+                    vals[rng.random(voff + nn) < 0.3] = dtype(info.max - 2) if info.max > 300 else dtype(3)     # (products that wrap many times)
+                valid = rng.random(nn) > (0.1 if batch != 1 else 0.0)
+                gids = rng.integers(0, G, nn).astype(np.uint32)
+                if G > 5 and nn > 4000:
+                    gids[rng.random(nn) < 0.6] = 3
+                d_vals, d_valid, d_gids = to_device(vals, dev), to_device(_pack_bits(valid, voff), dev), to_device(gids.view(np.uint8), dev)
+                sp = _lib.ArxSpan(d_valid.data_ptr(), d_vals.data_ptr(), voff, nn, -1)
+                ws_bytes = lib.arx_hash_sum_float_workspace_bytes(nn)
+                ws = torch.zeros(ws_bytes + 256, dtype=torch.uint8, device=dev)
+                _lib.check(lib.arx_hash_product_consume(C.byref(sp), num_types[dtype], d_gids.data_ptr(), nn, ws.data_ptr(), ws_bytes + 256,
+                                                        prods.data_ptr(), counts.data_ptr(), seen.data_ptr(), st))
+                w_p, w_c, w_s = O.hash_product_row_order(vals[voff:], valid, gids, G, w_p, w_c, w_s)
+                tag = f"hash_product[{np.dtype(dtype).name},G={G},batch={batch}]"
+                got = prods.cpu().numpy().view(np.uint64)
+                want = w_p.view(np.uint64)
+                same = (got == want) | (is_float & np.isnan(got.view(np.float64)) & np.isnan(want.view(np.float64)))
+                assert same.all(), (tag, np.nonzero(~same)[0][:5], got[~same][:3], want[~same][:3])
+                assert_equal(counts.cpu().numpy(), w_c, tag + " counts")
+                assert_equal(seen.cpu().numpy().astype(bool), w_s, tag + " null_seen")
+    # ---- arx_group_edge_rows
+    for G in groups:
+        for nn, null_p, voff in ((n, 0.3, 5), (n // 7 + 1, 0.0, 0), (200, 1.0, 3), (1, 0.0, 0)):
+            valid = rng.random(nn) >= null_p
+            gids = rng.integers(0, G, nn).astype(np.uint32)
+            d_gids = to_device(gids.view(np.uint8), dev)
+            d_valid = to_device(_pack_bits(valid, voff), dev)
+            for last in (0, 1):
+                for use_bits in (True, False):
+                    rows = torch.full((G,), 7, dtype=torch.int32, device=dev)
+                    has = torch.zeros((G + 63) // 64 * 8 + 8, dtype=torch.uint8, device=dev)
+                    _lib.check(lib.arx_group_edge_rows(d_gids.data_ptr(), d_valid.data_ptr() if use_bits else None, voff if use_bits else 0, nn, G, last,
+                                                       rows.data_ptr(), has.data_ptr(), st))
+                    w_rows, w_has = O.group_edge_rows(gids, valid if use_bits else None, G, last=bool(last))
+                    tag = f"group_edge_rows[G={G},n={nn},last={last},bits={use_bits}]"
+                    got_has = np.unpackbits(has.cpu().numpy(), bitorder="little")[:G].astype(bool)
+                    assert_equal(got_has, w_has, tag + " has_row")
+                    assert_equal(rows.cpu().numpy().view(np.uint32), w_rows, tag + " rows")
+                    assert not np.unpackbits(has.cpu().numpy(), bitorder="little")[G:(G + 63) // 64 * 64].any(), tag + " padding bits"
+    # ---- arx_dec128_split
+    for nn in (0, 1, 1000, n):
+        words = rng.integers(0, 1 << 64, size=2 * max(nn, 1), dtype=np.uint64)
+        d_in = to_device(words.view(np.uint8), dev)
+        lo = torch.zeros(max(nn, 1), dtype=torch.int64, device=dev)
+        hi = torch.zeros(max(nn, 1), dtype=torch.int64, device=dev)
+        _lib.check(lib.arx_dec128_split(d_in.data_ptr(), nn, lo.data_ptr(), hi.data_ptr(), st))
+        assert_equal(lo.cpu().numpy().view(np.uint64)[:nn], words[0:2 * nn:2], "dec128_split lo")
+        assert_equal(hi.cpu().numpy().view(np.uint64)[:nn], words[1:2 * nn:2], "dec128_split hi")
+

@@ -1131,3 +1131,10 @@ def test_groupby_probe_slice_selects_the_plan(emu_ctx, distinct):
         assert (wide, two) == (3, 0), (probe, wide, two)     # round 4: the sketch aggregates nothing, every row runs the wide plan
     else:
         assert (wide, two) == (0, 3), (probe, wide, two)
+
+
+def test_hash_product_group_edge_rows_and_dec128_split(emu_ctx):
+    """The C-ABI entry points behind hash_product / hash_first / hash_last / hash_one and the decimal128 sort keys against the
+    oracle's restatements of GroupedProductImpl, GroupedFirstLastImpl and GroupedOneImpl."""
+    P.check_hash_product_and_edge_rows(emu_ctx, rng_for("hashprod"), n=3000, groups=(1, 7, 300))
+

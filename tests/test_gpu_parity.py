@@ -1396,3 +1396,11 @@ def test_hash_any_all_dense_kernels(gpu_ctx):
 
 def test_bitmap_copy_segments(gpu_ctx):
     P.check_bitmap_copy_segments(gpu_ctx, rng_for("bitseg"), 20)
+
+
+@pytest.mark.gpu
+def test_hash_product_group_edge_rows_and_dec128_split(gpu_ctx):
+    """The C-ABI entry points behind hash_product / hash_first / hash_last / hash_one and the decimal128 sort keys against the
+    oracle's restatements of GroupedProductImpl, GroupedFirstLastImpl and GroupedOneImpl."""
+    P.check_hash_product_and_edge_rows(gpu_ctx, rng_for("hashprod"), n=200000, groups=(1, 7, 300, 50000))
+

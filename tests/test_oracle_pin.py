@@ -1037,3 +1037,60 @@ def test_golden_kleene_logic_on_the_oracle_and_the_reference_build():
             assert [bool(d) if v else None for d, v in zip(data, valid)] == want.to_pylist(), (fn, args)
         ran += 1
     assert ran == 43
+
+
+@pytest.mark.skipif(pa is None, reason="pyarrow (the reference build) is not installed")
+@pytest.mark.parametrize("dtype", [np.int64, np.uint64, np.int8, np.uint16, np.float32, np.float64])
+def test_hash_product_and_first_last_restatements_against_the_reference_build(dtype):
+    """O.hash_product_row_order and O.group_edge_rows — the restatements the kernel tier trusts for hash_product / hash_first /
+    hash_last / hash_one — against the reference's own GroupByNode on one thread (one state = row order): products bit for
+    bit (wrapping integers, doubles in row order), first / last non-null values, skip_nulls on and off."""
+    rng = np.random.default_rng(77 + np.dtype(dtype).itemsize + (np.dtype(dtype).kind == "f"))
+    n, G = 5000, 37
+    gids = rng.integers(0, G, n).astype(np.uint32)
+    valid = rng.random(n) > 0.25
+    valid[gids == 5] = False                                           # a group of nulls only
+    if np.dtype(dtype).kind == "f":
+        vals = (1.0 + rng.standard_normal(n) * 0.7).astype(dtype)
+        vals[7], vals[11] = -0.0, dtype(1e30)
+    else:
+        info = np.iinfo(dtype)
+        vals = rng.integers(max(info.min, -9), min(info.max, 11), n).astype(dtype)
+        vals[rng.random(n) < 0.2] = dtype(info.max - 2) if info.max > 300 else dtype(3)
+    t = pa.table({"g": pa.array(gids), "v": pa.array(vals, mask=~valid)})
+    ref = t.group_by("g", use_threads=False).aggregate([("v", "product"), ("v", "first"), ("v", "last"), ("v", "one"),
+                                                        ("v", "first", pc.ScalarAggregateOptions(skip_nulls=False)),
+                                                        ("v", "last", pc.ScalarAggregateOptions(skip_nulls=False))]).sort_by("g")
+    assert ref.num_rows == G
+    prods, counts, _seen = O.hash_product_row_order(vals, valid, gids, G)
+    want = ref.column("v_product")
+    for g in range(G):
+        w = want[g].as_py()
+        if counts[g] == 0:
+            assert w is None
+        elif np.dtype(dtype).kind == "f":
+            assert np.float64(w).view(np.uint64) == prods[g].view(np.uint64) or (np.isnan(w) and np.isnan(prods[g])), (g, w, prods[g])
+        else:
+            assert np.uint64(w % (1 << 64)) == prods[g], (g, w, prods[g])
+    first_rows, first_has = O.group_edge_rows(gids, valid, G, last=False)
+    last_rows, last_has = O.group_edge_rows(gids, valid, G, last=True)
+    any_first, _ = O.group_edge_rows(gids, None, G, last=False)
+    any_last, _ = O.group_edge_rows(gids, None, G, last=True)
+    cols = [ref.column(i) for i in range(ref.num_columns)]
+    names = ref.schema.names
+    first_c, last_c, one_c = cols[names.index("v_first")], cols[names.index("v_last")], cols[names.index("v_one")]
+    keep_first, keep_last = cols[-2], cols[-1]
+    same = (lambda a, b: np.asarray([a], dtype=dtype).view(np.uint8).tobytes() == np.asarray([b], dtype=dtype).view(np.uint8).tobytes())
+    for g in range(G):
+        for col, rows, has in ((first_c, first_rows, first_has), (last_c, last_rows, last_has), (one_c, first_rows, first_has)):
+            w = col[g].as_py()
+            assert (w is None) == (not has[g]), (g, w)
+            if has[g]:
+                assert same(w, vals[rows[g]]), (g, w, vals[rows[g]])
+        # skip_nulls = false: null where a null row comes before (after) the first (last) value
+        for col, rows, has, edge in ((keep_first, first_rows, first_has, any_first), (keep_last, last_rows, last_has, any_last)):
+            w = col[g].as_py()
+            want_valid = bool(has[g]) and rows[g] == edge[g]
+            assert (w is not None) == want_valid, (g, w, want_valid)
+            if want_valid:
+                assert same(w, vals[rows[g]])
