@@ -1189,7 +1189,7 @@ def sort_leg(args, rank, world, device, rows_total, steps, warmup):
            "exchange": "1 all-reduce (splitter histogram) + 1 count exchange + ONE all-to-all(v) of 12-byte records" if world > 1 else "none (one rank)",
            "permutation_and_order_checks": ok,
            "stage_ms_max_over_ranks_untimed_run": _LAST_STAGES.get("sort_indices"),
-           "roofline": {"bound": "hbm", "kernel": "arx_sort_indices (msd_hist + scatter levels + LDS bucket finish)",
+           "roofline": {"bound": "hbm", "kernel": "arx_sort_indices (wide form on 8-byte words: msdw_scatter1wc [write-combined level 1] + msdw_scatter2w + msd_bucket2w [LDS finish])",
                         "achieved": round(per_gpu, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 16,
                         "traffic": load_traffic("sort", rows // world, form="rec8")}}
