@@ -212,6 +212,7 @@ SIGNATURES = {
     "arx_grouper_get_uniques": (_int, [_p, _i64, _p, _int, _int, _p, _p, _p, _p]),
     "arx_binary_key_lengths": (_int, [_bspan, _p, _p, _p, _p]),
     "arx_binary_key_chunk": (_int, [_bspan, _i64, _p, _p, _p]),
+    "arx_binary_sort_chunk": (_int, [_bspan, _i64, _p, _p]),
     "arx_binary_key_hash": (_int, [_bspan, _int, _p, _p]),
     "arx_binary_key_verify": (_int, [_bspan, _p, _p, C.POINTER(_i64), _p, _p]),
     "arx_group_first_rows": (_int, [_p, _i64, _i64, _p, _p]),

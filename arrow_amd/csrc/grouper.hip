@@ -386,6 +386,31 @@ __global__ __launch_bounds__(kBlock) void binary_key_lengths_kernel(Bits valid, 
   if (mine != 0) atomicMax(max_len, mine);
 }
 
+// utf8 / binary SORT keys: bytes [chunk_pos, chunk_pos + 8) of every string as ONE big-endian uint64 (byte 0 in the top
+// byte), zero-padded past the string's end — the unsigned order of these words, chunk after chunk, then the length, is the
+// bytewise lexicographic order the reference compares strings in (std::string_view::compare: memcmp of the common prefix,
+// then the shorter first — kernels/vector_sort_internal.h, CompareTypeValues)
+__global__ __launch_bounds__(kBlock) void binary_sort_chunk_kernel(Bits valid, const int32_t* __restrict__ offsets,
+                                                                   const uint8_t* __restrict__ data, int64_t n, int64_t chunk_pos,
+                                                                   uint64_t* __restrict__ out) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1;
+    const int64_t start = offsets[i];
+    const int64_t len = ok ? offsets[i + 1] - start : 0;
+    uint64_t k = 0;
+    const int64_t have = len - chunk_pos;
+    if (have > 0) {
+      const uint8_t* p = data + start + chunk_pos;
+      const int m = have < 8 ? static_cast<int>(have) : 8;
+      for (int b = 0; b < 8; ++b) {
+        if (b < m) k |= static_cast<uint64_t>(p[b]) << (8 * (7 - b));
+      }
+    }
+    out[i] = k;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void binary_key_chunk_kernel(Bits valid, const int32_t* __restrict__ offsets,
                                                                   const uint8_t* __restrict__ data, int64_t n,
                                                                   int64_t chunk_pos, uint64_t* __restrict__ out_lo,
@@ -805,6 +830,24 @@ int arx_binary_key_lengths(const ArxBinarySpan* values, uint32_t* out_lengths, i
   ARX_HIP(hipMemcpyAsync(&m, ws, 4, hipMemcpyDeviceToHost, st));
   ARX_HIP(hipStreamSynchronize(st));
   *out_max_length = m;
+  return ARX_OK;
+}
+
+int arx_binary_sort_chunk(const ArxBinarySpan* values, int64_t chunk_index, uint64_t* out_keys, void* stream) {
+  if (values == nullptr || chunk_index < 0) {
+    set_error("binary sort chunk: NULL values or negative chunk");
+    return ARX_INVALID;
+  }
+  const int64_t n = values->length;
+  if (n <= 0) return ARX_OK;
+  if (values->offsets == nullptr || out_keys == nullptr) {
+    set_error("binary sort chunk: NULL buffer");
+    return ARX_INVALID;
+  }
+  const Bits valid = make_bits(values->null_count == 0 ? nullptr : values->validity, values->offset, n);
+  hipLaunchKernelGGL(binary_sort_chunk_kernel, dim3(grouper_grid(n)), dim3(kBlock), 0, as_stream(stream), valid,
+                     values->offsets + values->offset, static_cast<const uint8_t*>(values->data), n, chunk_index * 8, out_keys);
+  ARX_CHECK_LAUNCH("binary_sort_chunk_kernel");
   return ARX_OK;
 }
 

@@ -862,6 +862,11 @@ int arx_binary_key_lengths(const ArxBinarySpan* values, uint32_t* out_lengths, i
                            void* stream);
 int arx_binary_key_chunk(const ArxBinarySpan* values, int64_t chunk_index, uint64_t* out_lo, uint32_t* out_hi,
                          void* stream);
+/* utf8 / binary SORT keys (array_sort_indices of BaseBinary types, kernels/vector_array_sort.cc:144-178; strings compare
+ * bytewise, the shorter first on a common prefix): out_keys[i] = bytes [8 c, 8 c + 8) of string i as one BIG-endian uint64,
+ * zero-padded, 0 for a null.  The keys (chunk 0, chunk 1, ..., chunk ceil(max_length / 8) - 1, length) — lengths from
+ * arx_binary_key_lengths — ordered as unsigned integers are that order; sorted as a chain of stable sorts, last key first. */
+int arx_binary_sort_chunk(const ArxBinarySpan* values, int64_t chunk_index, uint64_t* out_keys, void* stream);
 /* Var-width keys in ONE pass: out_hash[i] = a 64-bit hash of the bytes of string i (0 for a null; only the low
  * hash_bits bits are kept — 64 in production, fewer to force collisions in tests); with the length column
  * (arx_binary_key_lengths) that is a 12-byte stand-in for the string whatever its length.  arx_binary_key_verify then

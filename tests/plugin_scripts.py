@@ -1359,11 +1359,11 @@ SELECTION_META_SCRIPT = textwrap.dedent(r'''
     h3 = pa.Table.from_batches([h_table.slice(a, b - a).to_batches()[0] for a, b in zip(cuts, cuts[1:])])
     d3 = pa.Table.from_batches([pa.RecordBatch.from_arrays([to_device(c) for c in rb.columns], names=rb.schema.names) for rb in h3.select(["i32", "ts", "i64"]).to_batches()])
     assert to_host(pc.call_function("sort_indices", [d3], pc.SortOptions(sort_keys=sk))).equals(pc.sort_indices(h3, sort_keys=sk))
-    try:
-        pc.call_function("sort_indices", [d_table], pc.SortOptions(sort_keys=[("s", "ascending")]))
-        raise SystemExit("expected NotImplemented for a string sort key")
-    except pa.lib.ArrowNotImplementedError:
-        pass
+    # (round 5) utf8 / binary sort keys: the string as (8-byte big-endian chunks, length) keys of the same chain
+    for keys in ([("s", "ascending")], [("s", "descending"), ("i32", "ascending")], [("i32", "descending", "at_start"), ("s", "ascending", "at_start")]):
+        want_idx = pc.sort_indices(h_table, sort_keys=keys)
+        got_idx = pc.call_function("sort_indices", [d_table], pc.SortOptions(sort_keys=keys))
+        assert to_host(got_idx).equals(want_idx), keys
     assert pc.sort_indices(h_table, sort_keys=sk).equals(pc.call_function("sort_indices", [h_table], pc.SortOptions(sort_keys=sk)))   # host: stock
     # host data: the stock meta-functions, untouched
     assert pc.filter(h_table, mask).equals(h_table.filter(mask)) and pc.take(h_batch, idx).equals(pa.record_batch(cols).take(idx))
@@ -1769,10 +1769,34 @@ ORDER_BY_SCRIPT = textwrap.dedent(r'''
         acero.Declaration("filter", acero.FilterNodeOptions(pc.field("k1") > 1000)),
         acero.Declaration("order_by_rocm", acero.OrderByNodeOptions([("k0","ascending")]))]).to_table()
     assert got.num_rows == 0 and got.schema == host.schema
-    # unsupported key type
+    # (round 5) utf8 keys: the string as (8-byte big-endian chunks, length) keys of the same chain; equal to the stock order_by
+    for keys in ([("s", "ascending")], [("s", "descending"), ("k0", "ascending")]):
+        want = plan(host, "order_by", keys).to_table(use_threads=False)
+        same(host_table(plan(dev, "order_by_rocm", keys).to_table(use_threads=False)), want)
+    # array_sort_indices / sort_indices of device-resident utf8 / binary ARRAYS: common prefixes longer than one chunk, strings
+    # that differ only in trailing NUL bytes or only in length, empty vs null, bytes >= 0x80 (unsigned order), both orders and
+    # null placements; a string beyond 256 bytes is refused by name
+    words = ["", "a", "ab", "ab\x00", "ab\x00\x00", "abcdefgh", "abcdefghi", "abcdefgh\x00", "abcdefghijklmnopq", "abcdefghijklmnopr",
+             "zz", "\u00e9t\u00e9", "\u4e2d\u6587", "Z", "abc", "abd", "ab" * 40, "ab" * 40 + "c"]
+    pick = rng.integers(0, len(words), 4000)
+    for typ in (pa.utf8(), pa.binary()):
+        vals = [words[i] if typ == pa.utf8() else words[i].encode("utf8") for i in pick]
+        harr = pa.array(vals, typ, mask=rng.random(len(vals)) < 0.1).slice(3)
+        darr = to_device(harr)
+        for order in ("ascending", "descending"):
+            for placement in ("at_end", "at_start"):
+                w = pc.array_sort_indices(harr, order=order, null_placement=placement)
+                g = to_host(pc.array_sort_indices(darr, order=order, null_placement=placement))
+                assert g.equals(w), (str(typ), order, placement, g.slice(0, 8), w.slice(0, 8))
+        assert to_host(pc.sort_indices(darr)).equals(pc.sort_indices(harr))
+    assert to_host(pc.array_sort_indices(to_device(pa.array([], pa.utf8())))).equals(pc.array_sort_indices(pa.array([], pa.utf8())))
+    assert to_host(pc.array_sort_indices(to_device(pa.array([None, None], pa.utf8())))).equals(pc.array_sort_indices(pa.array([None, None], pa.utf8())))
     try:
-        plan(dev, "order_by_rocm", [("s","ascending")]).to_table(); raise SystemExit("string key accepted")
-    except pa.ArrowNotImplementedError as ex: print("ok:", ex)
+        pc.array_sort_indices(to_device(pa.array(["x" * 300, "y"])))
+        raise SystemExit("a 300-byte sort key was accepted")
+    except pa.ArrowNotImplementedError as ex:
+        assert "256 bytes" in str(ex), ex
+    assert pc.array_sort_indices(pa.array(["x" * 300, "y"])).to_pylist() == [0, 1]          # host arrays: the reference's kernel
     print("ORDER_BY_OK")
 ''')
 
