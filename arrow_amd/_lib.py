@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libarrow_amd.so")
 ARX_OK = 0
 ARX_OUT_OF_MEMORY = -1
 ARX_INVALID = -4
+ARX_CAPACITY_ERROR = -6
 ARX_INDEX_ERROR = -7
 ARX_NOT_IMPLEMENTED = -10
 ARX_DEVICE_ERROR = -100
@@ -40,6 +41,10 @@ class ArrowIndexError(ArrowAmdError, IndexError):
     pass
 
 
+class ArrowCapacityError(ArrowAmdError):
+    pass
+
+
 class ArrowNotImplementedError(ArrowAmdError, NotImplementedError):
     pass
 
@@ -54,6 +59,7 @@ class ArrowMemoryError(ArrowAmdError, MemoryError):
 
 _ERRORS = {
     ARX_INVALID: ArrowInvalid,
+    ARX_CAPACITY_ERROR: ArrowCapacityError,
     ARX_INDEX_ERROR: ArrowIndexError,
     ARX_NOT_IMPLEMENTED: ArrowNotImplementedError,
     ARX_DEVICE_ERROR: ArrowDeviceError,
@@ -190,6 +196,8 @@ SIGNATURES = {
                                                  C.POINTER(_i64), _p]),
     "arx_sort_unpack_records": (_int, [_p, _i64, _p, _int, _int, _p, _p, _p, _p]),
     "arx_groupby_export_partitioned": (_int, [_p, _int, _p, _sz, _p, _p, _p]),
+    "arx_groupby_partials_capacity": (_i64, [_i64, _i64, _int]),
+    "arx_groupby_sum_i64_consume_partials": (_int, [_p, _i64, _span, _span, _p, _sz, _int, _p, _i64, _p, _p]),
     "arx_groupby_partition_rows": (_int, [_span, _span, _int, _p, _sz, _p, _p, _p]),
     "arx_groupby_unpack_rows": (_int, [_p, _i64, _p, _p, _p, _p, _p]),
     "arx_hash_sum_consume_workspace_bytes": (_sz, [_i64, _i64]),

@@ -911,7 +911,14 @@ struct GbpArgs {
   int xcd_map;             // bit 0: level-2 scatter, bit 1: aggregate, bit 2: level-1 scatter — XCD-contiguous work numbering
   int agg_pipe;            // software-pipelined loads in the LDS aggregate kernel (A/B knob)
   uint32_t agg_chunk;      // rows per aggregate work unit (a power of two)
+  // emit form (arx_groupby_sum_i64_consume_partials, the sharded group-by): a work unit's groups leave as ArxGroupPartial
+  // records in the region of the rank that owns their key instead of going into the HBM table
+  ArxGroupPartial* emit_records;        // NULL: the table
+  unsigned long long* emit_cursor;      // [emit_parts] records written to every region so far (may pass emit_capacity: overflow)
+  int emit_parts;                       // <= kGbEmitMaxParts
+  int64_t emit_capacity;                // records per region
 };
+constexpr int kGbEmitMaxParts = 64;
 
 __device__ __forceinline__ uint32_t gbp_hash(const GbpArgs& a, int32_t key) {
   return a.dense ? (static_cast<uint32_t>(key) << a.dense_shl) : gbp_hash_keyed(key);
@@ -1546,6 +1553,8 @@ struct __attribute__((aligned(16))) GbpAggLds {
   unsigned long long zsum;   // the one key whose tag is 0 has its own accumulator
   uint32_t zcnt;
   uint32_t part, row_lo, row_hi;
+  uint32_t emit_cnt[kGbEmitMaxParts];            // emit form: this unit's groups per owner rank ...
+  unsigned long long emit_base[kGbEmitMaxParts];  // ... and where they start in the owner's region
 };
 
 // SLOTS / THREADS: 4096 / 512 (two workgroups per CU), or the wide form's 8192 / 1024 (one per CU);
@@ -1600,6 +1609,7 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
     t.zsum = 0;
     t.zcnt = 0;
   }
+  if (tid < kGbEmitMaxParts) t.emit_cnt[tid] = 0;
   __syncthreads();
   if constexpr (!DIRECT) {
     q = t.part;
@@ -1734,6 +1744,18 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
     } else if (a.dense) {  // more ids than the LDS table holds: straight to the caller's arrays, still exact
       atomicAdd(&a.dense_sums[static_cast<uint32_t>(key)], val);
       atomicAdd(&a.dense_counts[static_cast<uint32_t>(key)], 1ull);
+    } else if (a.emit_records != nullptr) {  // emit form: the row itself leaves as a partial of one value
+      const int o = gb_dest(key, true, a.emit_parts);
+      const unsigned long long at = atomicAdd(&a.emit_cursor[o], 1ull);
+      if (at < static_cast<unsigned long long>(a.emit_capacity)) {
+        ArxGroupPartial r{};
+        r.sum = static_cast<int64_t>(val);
+        r.count = 1;
+        r.key = key;
+        r.key_is_valid = 1;
+        r.no_nulls = 1;
+        a.emit_records[static_cast<int64_t>(o) * a.emit_capacity + static_cast<int64_t>(at)] = r;
+      }
     } else {  // more groups than the LDS table holds: slow path, still exact
       const int64_t slot = gb_find_or_insert(v, key, &fresh);
       if (slot < 0) {
@@ -1847,6 +1869,48 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
   }
   __syncthreads();
   const uint32_t hi_bits = a.bits == 0 ? 0u : (q << low_bits);
+  if (a.emit_records != nullptr) {   // (kernel-uniform)
+    // the unit's groups as records, in the region of the rank that owns each key (hash(key) % ranks, as
+    // arx_groupby_export_partitioned assigns them): ranks inside the unit by LDS atomics, ONE global atomic per (unit,
+    // owner) for the place in the region — no probe of the HBM table, no two atomics per group, no export pass afterwards
+    constexpr int kMine = (SLOTS + 1 + THREADS - 1) / THREADS;
+    uint32_t rank[kMine];
+    int owner[kMine];
+#pragma unroll
+    for (int j = 0; j < kMine; ++j) {
+      const int i = tid + j * THREADS;
+      owner[j] = -1;
+      rank[j] = 0;
+      if (i > SLOTS) continue;
+      const bool live = i < SLOTS ? t.tags[i] != 0 : t.zcnt != 0;
+      if (!live) continue;
+      const uint32_t tag = i < SLOTS ? t.tags[i] : 0u;
+      owner[j] = gb_dest(gbp_unhash(a, hi_bits | tag), true, a.emit_parts);
+      rank[j] = atomicAdd(&t.emit_cnt[owner[j]], 1u);
+    }
+    __syncthreads();
+    if (tid < a.emit_parts) {
+      const uint32_t c = t.emit_cnt[tid];
+      t.emit_base[tid] = c != 0 ? atomicAdd(&a.emit_cursor[tid], static_cast<unsigned long long>(c)) : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kMine; ++j) {
+      const int i = tid + j * THREADS;
+      if (owner[j] < 0) continue;
+      const unsigned long long at = t.emit_base[owner[j]] + rank[j];
+      if (at >= static_cast<unsigned long long>(a.emit_capacity)) continue;   // (the host sees the cursor past the capacity)
+      const uint32_t tag = i < SLOTS ? t.tags[i] : 0u;
+      ArxGroupPartial r{};
+      r.sum = static_cast<int64_t>(i < SLOTS ? t.sums[i] : t.zsum);
+      r.count = static_cast<int64_t>(i < SLOTS ? t.cnts[i] : t.zcnt);
+      r.key = gbp_unhash(a, hi_bits | tag);
+      r.key_is_valid = 1;
+      r.no_nulls = 1;
+      a.emit_records[static_cast<int64_t>(owner[j]) * a.emit_capacity + static_cast<int64_t>(at)] = r;
+    }
+    return;
+  }
   for (int i = tid; i < SLOTS + 1; i += THREADS) {
     uint32_t tag;
     unsigned long long sum;
@@ -2441,9 +2505,69 @@ size_t arx_groupby_consume_workspace_bytes(int64_t length, int64_t capacity) {
   return need;
 }
 
+struct GbpEmit {   // where the emit form writes (arx_groupby_sum_i64_consume_partials)
+  ArxGroupPartial* records;
+  unsigned long long* cursor;
+  int parts;
+  int64_t capacity;
+};
+static int gb_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* keys_i32, const ArxSpan* values_i64, void* ws, size_t ws_bytes,
+                              void* stream, const GbpEmit* emit);
+
 int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* keys_i32,
                                 const ArxSpan* values_i64, void* ws, size_t ws_bytes,
                                 void* stream) {
+  return gb_sum_i64_consume(state, capacity, keys_i32, values_i64, ws, ws_bytes, stream, nullptr);
+}
+
+int64_t arx_groupby_partials_capacity(int64_t num_rows, int64_t capacity, int num_parts) {
+  if (num_parts < 1) return 0;
+  // a work unit of the aggregate writes every group it met once.  A partition's first unit: the groups, at most
+  // capacity / 2, once per slice; every further unit of a partition (one per 2^18 rows or more) at most the 4097 groups
+  // its LDS table holds: num_rows / 64.  hash(key) % num_parts spreads them evenly (+ 25 %, + 65536 for a few groups that
+  // all land on one rank).  Rows that find no place in an LDS table leave as records of their own; a shard with many of
+  // those overflows its regions and goes through the table (ARX_CAPACITY_ERROR).
+  const int64_t slices = std::max<int64_t>(1, (num_rows + kGbHardMaxSlice - 1) / kGbHardMaxSlice);
+  const int64_t bound = std::min<int64_t>(num_rows, slices * std::max<int64_t>(capacity / 2, 1) + num_rows / 64);
+  return bound / num_parts + bound / num_parts / 4 + 65536;
+}
+
+int arx_groupby_sum_i64_consume_partials(void* state, int64_t capacity, const ArxSpan* keys_i32, const ArxSpan* values_i64, void* ws,
+                                         size_t ws_bytes, int num_parts, ArxGroupPartial* out_records, int64_t records_per_part,
+                                         int64_t* out_part_counts, void* stream) {
+  if (state == nullptr || keys_i32 == nullptr || values_i64 == nullptr || out_records == nullptr || out_part_counts == nullptr) {
+    set_error("NULL argument to arx_groupby_sum_i64_consume_partials");
+    return ARX_INVALID;
+  }
+  if (num_parts < 1 || num_parts > kGbEmitMaxParts || records_per_part < 1) {
+    set_error("arx_groupby_sum_i64_consume_partials: 1 to %d parts, a positive region size", kGbEmitMaxParts);
+    return ARX_INVALID;
+  }
+  if ((keys_i32->null_count != 0 && keys_i32->validity != nullptr) || (values_i64->null_count != 0 && values_i64->validity != nullptr)) {
+    set_error("arx_groupby_sum_i64_consume_partials: rows with nulls go through the table (arx_groupby_sum_i64_consume + export)");
+    return ARX_NOT_IMPLEMENTED;
+  }
+  hipStream_t st = as_stream(stream);
+  // the cursors live in out_part_counts (device int64[num_parts]): zeroed here, read back at the end
+  ARX_HIP(hipMemsetAsync(out_part_counts, 0, static_cast<size_t>(num_parts) * 8, st));
+  GbpEmit emit{out_records, reinterpret_cast<unsigned long long*>(out_part_counts), num_parts, records_per_part};
+  const int rc = gb_sum_i64_consume(state, capacity, keys_i32, values_i64, ws, ws_bytes, stream, &emit);
+  if (rc != ARX_OK) return rc;
+  int64_t counts[kGbEmitMaxParts];
+  ARX_HIP(hipMemcpyAsync(counts, out_part_counts, static_cast<size_t>(num_parts) * 8, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  for (int p = 0; p < num_parts; ++p) {
+    if (counts[p] > records_per_part) {
+      set_error("arx_groupby_sum_i64_consume_partials: region %d holds %lld records, %lld arrived (use the table path)", p,
+                static_cast<long long>(records_per_part), static_cast<long long>(counts[p]));
+      return ARX_CAPACITY_ERROR;
+    }
+  }
+  return ARX_OK;
+}
+
+static int gb_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* keys_i32, const ArxSpan* values_i64, void* ws, size_t ws_bytes,
+                              void* stream, const GbpEmit* emit) {
   if (state == nullptr || keys_i32 == nullptr || values_i64 == nullptr) {
     set_error("NULL argument to arx_groupby_sum_i64_consume");
     return ARX_INVALID;
@@ -2476,7 +2600,7 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
     const GbpPlan unhinted = gbp_plan(slice, capacity);
     const int64_t probe_rows = std::max<int64_t>(kGbTile, int64_t(g_gbp_probe_rows) / kGbTile * kGbTile);
     const bool sketch = g_gbp_sketch != 0 && g_gbp_wide && g_gbp_bits < 0 && unhinted.b2 > 0 && !unhinted.wide && n >= 2 * probe_rows;
-    const bool probe = !sketch && g_gbp_wide && g_gbp_bits < 0 && unhinted.b2 > 0 && !unhinted.wide && n >= 4 * probe_rows;
+    const bool probe = emit == nullptr && !sketch && g_gbp_wide && g_gbp_bits < 0 && unhinted.b2 > 0 && !unhinted.wide && n >= 4 * probe_rows;   // (the probe reads the table's group count: the emit form leaves the table empty)
     int64_t groups_hint = -1;
     bool rooms_ok = true;
     unsigned long long groups_before = 0;
@@ -2512,6 +2636,12 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
       a.vvalid = make_bits(vbm, values_i64->offset + r0, m);
       a.n = m;
       gbp_bind(a, plan, w);
+      if (emit != nullptr) {
+        a.emit_records = emit->records;
+        a.emit_cursor = emit->cursor;
+        a.emit_parts = emit->parts;
+        a.emit_capacity = emit->capacity;
+      }
       int rc = (kbm != nullptr || vbm != nullptr) ? gbp_run_slice<true>(v, a, plan, st)
                                                   : gbp_run_slice<false>(v, a, plan, st);
       if (rc == kGbpRoomsOverflow) {
@@ -2538,6 +2668,10 @@ int arx_groupby_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* ke
     return ARX_OK;
   }
 
+  if (emit != nullptr) {
+    set_error("arx_groupby_sum_i64_consume_partials: a batch this small (or without scratch) goes through the table");
+    return ARX_NOT_IMPLEMENTED;
+  }
   // ---- direct path (small batches / no scratch): every row goes to the HBM table
   const Bits kb = make_bits(kbm, keys_i32->offset, n);
   const Bits vb = make_bits(vbm, values_i64->offset, n);

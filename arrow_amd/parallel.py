@@ -135,8 +135,24 @@ def unpack_rows(records: torch.Tensor):
     return Array(int32, n, [kbits, keys], -1, 0), Array(int64, n, [vbits, vals], -1, 0)
 
 
+def consume_partials(local: GroupBySum, keys, values, num_parts: int):
+    """The local pass WITHOUT the local table (arx_groupby_sum_i64_consume_partials): this shard's partial aggregates as
+    24-byte records grouped by owner, compacted for the all-to-all, + device int64[num_parts] counts; (None, None) when
+    the shard has to go through the table (`local` is untouched then, and otherwise only plans the pass).  A key may
+    appear in several records of a block (once per work unit that met it): the receiver's merge adds them up, as it adds
+    the partials of different ranks."""
+    out = local.consume_partials(keys, values, num_parts)
+    if out is None:
+        return None, None
+    regions, per_part, counts = out
+    host = [int(c) for c in counts.cpu().tolist()]
+    blocks = [regions[p * per_part * RECORD_BYTES: (p * per_part + host[p]) * RECORD_BYTES] for p in range(num_parts)]
+    return torch.cat(blocks), counts
+
+
 def sharded_group_by_sum(keys, values, capacity: int, options: ScalarAggregateOptions | None = None,
-                         group=None, exchange: str = "partials", stages: Stages | None = None):
+                         group=None, exchange: str = "partials", stages: Stages | None = None,
+                         local_table: bool | None = None):
     """keys/values: this rank's row shard (device Arrays).  Returns this rank's slice of the
     result: (keys, key_is_valid, sums, valid) device tensors over a disjoint set of keys.
 
@@ -145,7 +161,10 @@ def sharded_group_by_sum(keys, values, capacity: int, options: ScalarAggregateOp
     exchange = "rows" (the row-level radix exchange BASELINE.json's north star words): the rows themselves are
     radix-partitioned by hash(key) % world_size, exchanged as 16-byte records (ONE all-to-all(v)) and aggregated by
     the rank that owns their key — N x 16 bytes, the better plan only when almost every row is its own group.
-    Both give the same groups on the same ranks."""
+    Both give the same groups on the same ranks.
+    local_table (the "partials" exchange): None = the local pass writes its partials straight into per-owner record
+    regions (consume_partials: no local table, no export pass) and falls back to local table + export where that form
+    declines; True = always the local table (round 4's path); False = never (raises where the form declines)."""
     device = keys.device
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if exchange not in ("partials", "rows"):
@@ -175,10 +194,19 @@ def sharded_group_by_sum(keys, values, capacity: int, options: ScalarAggregateOp
         _mark(stages, "finalize")
         return out
     local = GroupBySum(capacity, device, options)
-    local.consume(keys, values)
-    _mark(stages, "consume")
-    records, counts = export_partitioned(local, world)
-    _mark(stages, "export")
+    records = None
+    if local_table is not True:
+        records, counts = consume_partials(local, keys, values, world)
+        if records is not None:
+            _mark(stages, "consume")
+        elif local_table is False:
+            raise _lib.ArrowNotImplementedError("sharded_group_by_sum(local_table=False): this shard needs the local table "
+                                                "(nulls, a small batch, or more partials than their regions hold)")
+    if records is None:
+        local.consume(keys, values)
+        _mark(stages, "consume")
+        records, counts = export_partitioned(local, world)
+        _mark(stages, "export")
     recv_counts = torch.empty_like(counts)
     dist.all_to_all_single(recv_counts, counts, group=group)
     send, recv = _host_counts(counts, recv_counts)

@@ -1214,11 +1214,14 @@ _LAST_STAGES = {}      # per-stage ms (max over ranks) of the last sharded legs,
 
 
 def _stage_max(ms: dict, world, device) -> dict:
-    names = sorted(ms)
-    t = torch.tensor([ms[k] for k in names], dtype=torch.float64, device=device)
+    # a fixed list: ranks may take different local passes (a shard that has to go through the local table has an
+    # "export" stage, the others do not), the all-reduce needs the same shape on every rank
+    names = ("consume", "export", "partition_rows", "histogram", "partition", "exchange", "merge", "local_sort", "finalize")
+    assert set(ms) <= set(names), sorted(ms)
+    t = torch.tensor([ms.get(k, -1.0) for k in names], dtype=torch.float64, device=device)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    return {k: round(float(x), 3) for k, x in zip(names, t.tolist())}
+    return {k: round(float(x), 3) for k, x in zip(names, t.tolist()) if x >= 0}
 
 
 def measure_hash_sum(rank, world, device, rows_total, groups, steps, warmup):

@@ -51,6 +51,7 @@ typedef enum ArxStatus {
   ARX_OK = 0,
   ARX_OUT_OF_MEMORY = -1,
   ARX_INVALID = -4,          /* Status::Invalid       */
+  ARX_CAPACITY_ERROR = -6,   /* Status::CapacityError (a caller-sized output region was too small; nothing else was touched) */
   ARX_INDEX_ERROR = -7,      /* Status::IndexError    */
   ARX_NOT_IMPLEMENTED = -10, /* Status::NotImplemented*/
   ARX_DEVICE_ERROR = -100    /* a hip* call failed    */
@@ -722,6 +723,20 @@ int arx_groupby_partition_rows(const ArxSpan* keys_i32, const ArxSpan* values_i6
 /* out_key_validity / out_value_validity: ceil(num_records / 64) 64-bit words each. */
 int arx_groupby_unpack_rows(const ArxRowRecord* records, int64_t num_records, int32_t* out_keys, int64_t* out_values,
                             void* out_key_validity, void* out_value_validity, void* stream);
+/* The sharded group-by's local pass WITHOUT the local table (round 5): the partitioned consume as
+ * arx_groupby_sum_i64_consume runs it, but a work unit's groups leave as ArxGroupPartial records written straight into the
+ * region of the rank that owns each key (hash(key) % num_parts — the owner arx_groupby_export_partitioned assigns) instead
+ * of being folded into the HBM table and exported afterwards: no table probe and two atomics per group, no export pass
+ * (ThreadLocalState + Merge of acero/groupby_aggregate_node.cc:211-337 with the "state" being the record stream itself).
+ * A key may appear in several records of a region (once per slice / work unit): the receiver's merge adds them up.
+ * out_records: num_parts regions of records_per_part records (arx_groupby_partials_capacity); out_part_counts (device
+ * int64[num_parts]): records in every region.  ARX_NOT_IMPLEMENTED: rows with nulls, or a batch too small for the
+ * partitioned consume — use the table path; ARX_CAPACITY_ERROR: a region overflowed (nothing else was touched: use the table path).
+ * `state` / `capacity` only plan the pass (the table stays empty).  Synchronous at its end (reads the counts). */
+int64_t arx_groupby_partials_capacity(int64_t num_rows, int64_t capacity, int num_parts);
+int arx_groupby_sum_i64_consume_partials(void* state, int64_t capacity, const ArxSpan* keys_i32, const ArxSpan* values_i64,
+                                         void* ws, size_t ws_bytes, int num_parts, ArxGroupPartial* out_records,
+                                         int64_t records_per_part, int64_t* out_part_counts, void* stream);
 int arx_groupby_export_partitioned(void* state, int num_parts, void* ws /* arx_groupby_partition_workspace_bytes */,
                                    size_t ws_bytes, ArxGroupPartial* out_records,
                                    int64_t* out_part_counts /* device int64[num_parts] */, void* stream);

@@ -2,7 +2,7 @@
 for P = 1, 2, 4, 8 VIRTUAL ranks on ONE GPU: one rank's shard (N / P rows) goes through every local stage of
 arrow_amd.parallel with the current kernels; what a rank would receive is emulated with its own blocks (same sizes: uniform
 keys).  The exchange itself needs P GPUs (its bytes per rank are printed); everything else is what bounds the scaling.
-VERDICT r3 next 5(i).  Output: one line per (workload, P) with the stage ms (best of 3) and the predicted speed-up."""
+VERDICT r3 next 5(i).  `hash_sum*` = the local pass without the local table (consume_partials, round 5).  Output: one line per (workload, P) with the stage ms (best of 3) and the predicted speed-up."""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,13 +33,19 @@ for world in (1, 2, 4, 8):
     fill(keys, 0, GROUPS, 8); fill(vals, -2**63, 2**63 - 1, 9)
     kk = Array(amd.array.int32, n, [None, keys.view(torch.uint8)], 0, 0); vv = Array(amd.array.int64, n, [None, vals.view(torch.uint8)], 0, 0)
     cap = 1 << 25
-    def gb():
+    def gb(direct):
         t = [ev() for _ in range(5)]
-        t[0].record(); local = GroupBySum(cap, dev); local.consume(kk, vv); t[1].record()
+        t[0].record(); local = GroupBySum(cap, dev)
         if world == 1:
+            local.consume(kk, vv); t[1].record()
             out = local.finalize(); t[2].record(); torch.cuda.synchronize()
             return {"consume": t[0].elapsed_time(t[1]), "export": 0.0, "merge": 0.0, "finalize": t[1].elapsed_time(t[2]), "exchange_MB_per_rank": 0.0}
-        records, counts = parallel.export_partitioned(local, world); t[2].record()
+        if direct:      # round 5: the partials leave the aggregate as records in the owners' regions (no local table, no export)
+            records, counts = parallel.consume_partials(local, kk, vv, world); t[1].record(); t[2].record()
+            assert records is not None
+        else:
+            local.consume(kk, vv); t[1].record()
+            records, counts = parallel.export_partitioned(local, world); t[2].record()
         c = counts.cpu().tolist()
         mine = records[: c[0] * parallel.RECORD_BYTES]
         owned = GroupBySum(max(16, 2 * world * c[0] + 2), dev)
@@ -48,17 +54,17 @@ for world in (1, 2, 4, 8):
         t[3].record(); out = owned.finalize(); t[4].record(); torch.cuda.synchronize()
         return {"consume": t[0].elapsed_time(t[1]), "export": t[1].elapsed_time(t[2]), "merge": t[2].elapsed_time(t[3]),
                 "finalize": t[3].elapsed_time(t[4]), "exchange_MB_per_rank": sum(c[1:]) * parallel.RECORD_BYTES / 1e6}
-    r = best(gb)
-    local_ms = r["consume"] + r["export"] + r["merge"] + r["finalize"]
-    xgmi_ms = r["exchange_MB_per_rank"] / 1e3 / (7 * 153 / 7) * 1e3 if world > 1 else 0.0    # one link's 153 GB/s per peer pair, all pairs at once: bytes to ONE peer / 153 GB/s
-    xgmi_ms = (r["exchange_MB_per_rank"] / max(world - 1, 1)) / 153e3 * 1e3 if world > 1 else 0.0
-    total = local_ms + xgmi_ms
-    base.setdefault("gb", total)
-    print(f"hash_sum  P={world}: rows/rank {n:>11d}  consume {r['consume']:7.2f}  export {r['export']:5.2f}  merge {r['merge']:5.2f}  finalize {r['finalize']:5.2f}"
-          f"  exchange {r['exchange_MB_per_rank']:6.1f} MB/rank ~{xgmi_ms:5.2f} ms  => {total:7.2f} ms/rank, speed-up x{base['gb'] / total:4.2f}, efficiency {base['gb'] / total / world:4.2f}", flush=True)
+    for direct in ((False,) if world == 1 else (False, True)):
+        r = best(lambda: gb(direct))
+        local_ms = r["consume"] + r["export"] + r["merge"] + r["finalize"]
+        xgmi_ms = (r["exchange_MB_per_rank"] / max(world - 1, 1)) / 153e3 * 1e3 if world > 1 else 0.0    # bytes to ONE peer / one link's 153 GB/s, all pairs at once
+        total = local_ms + xgmi_ms
+        base.setdefault("gb", total)
+        print(f"hash_sum{'*' if direct else ' '} P={world}: rows/rank {n:>11d}  consume {r['consume']:7.2f}  export {r['export']:5.2f}  merge {r['merge']:5.2f}  finalize {r['finalize']:5.2f}"
+              f"  exchange {r['exchange_MB_per_rank']:6.1f} MB/rank ~{xgmi_ms:5.2f} ms  => {total:7.2f} ms/rank, speed-up x{base['gb'] / total:4.2f}, efficiency {base['gb'] / total / world:4.2f}", flush=True)
     del keys, vals, kk, vv
     torch.cuda.empty_cache()
-for world in (1, 2, 4, 8):
+for world in (() if os.environ.get("SKIP_SORT") else (1, 2, 4, 8)):
     n = SORT_ROWS // world
     k = torch.empty(n, dtype=torch.int64, device=dev); fill(k, -2**63, 2**63 - 1, 10)
     arr = Array(uint64, n, [None, k.view(torch.uint8)], 0, 0)

@@ -1129,6 +1129,89 @@ def check_groupby_sum(amd, keys: HostArray, values: HostArray, skip_nulls=True, 
     return got
 
 
+GROUP_PARTIAL = np.dtype([("sum", "<i8"), ("count", "<i8"), ("key", "<i4"), ("key_is_valid", "u1"), ("no_nulls", "u1"), ("pad", "u1", 2)])
+
+
+def check_groupby_consume_partials(amd, keys: HostArray, values: HostArray, num_parts, capacity=None):
+    """arx_groupby_sum_i64_consume_partials (the sharded group-by's local pass without the local table): the records of
+    every region belong to that region's rank (the owner arx_groupby_export_partitioned assigns), the table stays empty,
+    the records of a key add up to the oracle's group (sum with wrap-around, count), and the owners' merges of their
+    blocks give the oracle's result with every key on one rank.  Returns the number of records written."""
+    import ctypes as C
+
+    import torch
+
+    from arrow_amd import parallel
+
+    assert GROUP_PARTIAL.itemsize == parallel.RECORD_BYTES
+    dk, dv = keys.to_device(amd), values.to_device(amd)
+    n = keys.length
+    cap = capacity or max(16, 2 * n + 2)
+    local = amd.compute.GroupBySum(cap, dk.device)
+    out = local.consume_partials(dk, dv, num_parts)
+    assert out is not None, "consume_partials declined"
+    regions, per_part, counts = out
+    assert local.num_groups() == 0, "the emit form touched the table"
+    counts = [int(c) for c in counts.cpu().tolist()]
+    assert all(0 <= c <= per_part for c in counts), (counts, per_part)
+    host = regions.cpu().numpy().view(GROUP_PARTIAL)
+    blocks = [host[p * per_part: p * per_part + counts[p]] for p in range(num_parts)]
+    # owners: the table path's export of the same rows
+    table = amd.compute.GroupBySum(cap, dk.device)
+    table.consume(dk, dv)
+    recs, cnt = parallel.export_partitioned(table, num_parts)
+    cnt = [int(c) for c in cnt.cpu().tolist()]
+    exported = recs.cpu().numpy().view(GROUP_PARTIAL)
+    owner, at = {}, 0
+    for p in range(num_parts):
+        for k in exported["key"][at: at + cnt[p]].tolist():
+            owner[k] = p
+        at += cnt[p]
+    w = O.groupby_sum_i64(np.ascontiguousarray(keys.values), keys.valid_bitmap(), keys.offset,
+                          np.ascontiguousarray(values.values), values.valid_bitmap(), values.offset, n, True, 0)
+    kv = np.asarray(keys.values[keys.offset: keys.offset + n])
+    want_sum = {int(k): int(s) for k, s in zip(w["keys"], w["sums"])}
+    uniq, cnts = np.unique(kv, return_counts=True)
+    want_count = dict(zip(uniq.tolist(), cnts.tolist()))
+    got_sum, got_count = {}, {}
+    for p, b in enumerate(blocks):
+        assert np.all(b["key_is_valid"] == 1) and np.all(b["no_nulls"] == 1) and np.all(b["count"] >= 1)
+        for k, s_, c_ in zip(b["key"].tolist(), b["sum"].tolist(), b["count"].tolist()):
+            assert owner[k] == p, f"key {k} in region {p}, its owner is {owner[k]}"
+            got_sum[k] = (got_sum.get(k, 0) + s_ + 2**63) % 2**64 - 2**63
+            got_count[k] = got_count.get(k, 0) + c_
+    assert got_count == want_count
+    assert got_sum == want_sum
+    # the receivers' side: merge_records of every block, finalize
+    got = []
+    for p in range(num_parts):
+        owned = amd.compute.GroupBySum(max(16, 2 * counts[p] + 2), dk.device)
+        block = regions[p * per_part * parallel.RECORD_BYTES: (p * per_part + counts[p]) * parallel.RECORD_BYTES]
+        parallel.merge_records(owned, block)
+        gk, gkv, gs, gvalid = owned.finalize()
+        got += _sorted_groups(gk.cpu().numpy(), gkv.cpu().numpy(), gs.cpu().numpy(), gvalid.cpu().numpy())
+    want = _sorted_groups(w["keys"], w["key_is_valid"], w["sums"], np.ones(len(w["keys"]), bool))
+    assert sorted(got, key=lambda r: (r[0], r[1])) == want
+    # a region too small for what arrives: ARX_CAPACITY_ERROR, not a write past the region
+    lib = amd._lib.get_lib()
+    stream = amd.array.current_stream(dk.device)
+    ws_bytes = lib.arx_groupby_consume_workspace_bytes(n, local.capacity)
+    ws = amd.array.alloc(ws_bytes + 256, dk.device)
+    ws_ptr = (ws.data_ptr() + 255) & ~255
+    small = max(1, max(counts) // 2)
+    guard = 64
+    buf = torch.full(((num_parts * small + guard) * parallel.RECORD_BYTES,), 0xA5, dtype=torch.uint8, device=dk.device)
+    cnt_dev = torch.zeros(num_parts, dtype=torch.int64, device=dk.device)
+    ks, vs = dk.span(), dv.span()
+    rc = lib.arx_groupby_sum_i64_consume_partials(local.state.data_ptr(), local.capacity, C.byref(ks), C.byref(vs), ws_ptr,
+                                                  ws.numel() - (ws_ptr - ws.data_ptr()), num_parts, buf.data_ptr(), small,
+                                                  cnt_dev.data_ptr(), stream)
+    if max(counts) >= 2:
+        assert rc == amd._lib.ARX_CAPACITY_ERROR, rc
+        assert bool((buf[num_parts * small * parallel.RECORD_BYTES:] == 0xA5).all()), "records written past the last region"
+    return sum(counts)
+
+
 def check_groupby_min_max(amd, keys: HostArray, values: HostArray, skip_nulls=True, capacity=None,
                           use_pyarrow=True, batches=1, with_sum=False):
     """hash_min / hash_max on the fused table vs the oracle (and pyarrow's hash_min_max)."""

@@ -1061,7 +1061,43 @@ def test_groupby_wide_one_level_form(emu_ctx, bits):
         assert lib.arx_get_counter(b"groupby_slices_wide") >= wide0 + 3, "the wide plan did not run"
     finally:
         for k_, v_ in {b"groupby_partition_min_rows": 1 << 17, b"groupby_wide": 1, b"groupby_partition_bits": -1,
-                       b"groupby_wide_agg_chunk_rows": 1 << 19}.items():
+                       b"groupby_wide_agg_chunk_rows": 1 << 21}.items():
+            lib.arx_set_option(k_, v_)
+
+
+@pytest.mark.parametrize("wide,bits,parts", [(0, 0, 2), (0, 1, 3), (0, 5, 8), (0, 9, 4), (2, 4, 8), (2, 8, 5), (2, 6, 64)])
+def test_groupby_consume_partials(emu_ctx, wide, bits, parts):
+    """The sharded group-by's local pass without the local table (arx_groupby_sum_i64_consume_partials), on every plan of
+    the partitioned consume: the unpartitioned aggregate, one- and two-level plans, the wide form with rooms and counted;
+    several work units per partition (a key in several records), more groups than the LDS tables hold (rows that leave as
+    records of their own), regions too small (ARX_CAPACITY_ERROR); shards with nulls or too small are declined."""
+    lib = emu_ctx._lib.get_lib()
+    opts = {b"groupby_partition_min_rows": 0, b"groupby_wide": wide or 1, b"groupby_partition_bits": bits,
+            b"groupby_agg_chunk_rows": 1 << 12, b"groupby_wide_agg_chunk_rows": 1 << 14, b"groupby_wide_room_min_mean": 16}
+    for k_, v_ in opts.items():
+        assert lib.arx_set_option(k_, v_) == 0
+    try:
+        rng = rng_for("gbemit", wide, bits, parts)
+        n = 40000
+        k = U.random_array(rng, np.int32, n, lo=-2**31, hi=2**31 - 1)
+        k.values[: n // 2] = k.values[: n // 2] % 1777          # many repeats + a distinct tail
+        v = U.random_array(rng, np.int64, n, offset=1)
+        records = P.check_groupby_consume_partials(emu_ctx, k, v, parts)
+        assert records >= 1777 + n // 2 - 64
+        k2 = U.random_array(rng, np.int32, n + 4097, lo=0, hi=50000, offset=5)
+        v2 = U.random_array(rng, np.int64, n + 4097)
+        P.check_groupby_consume_partials(emu_ctx, k2, v2, parts)
+        # declined: nulls, and a shard below the partitioned consume's row threshold
+        kn = U.random_array(rng, np.int32, n, null_p=0.01, lo=0, hi=100)
+        local = emu_ctx.compute.GroupBySum(1 << 12, kn.to_device(emu_ctx).device)
+        assert local.consume_partials(kn.to_device(emu_ctx), v.to_device(emu_ctx), parts) is None
+        assert lib.arx_set_option(b"groupby_partition_min_rows", 1 << 17) == 0
+        assert local.consume_partials(k.to_device(emu_ctx), v.to_device(emu_ctx), parts) is None
+        assert local.num_groups() == 0
+    finally:
+        for k_, v_ in {b"groupby_partition_min_rows": 1 << 17, b"groupby_wide": 1, b"groupby_partition_bits": -1,
+                       b"groupby_agg_chunk_rows": 1 << 18, b"groupby_wide_agg_chunk_rows": 1 << 21,
+                       b"groupby_wide_room_min_mean": 1 << 14}.items():
             lib.arx_set_option(k_, v_)
 
 

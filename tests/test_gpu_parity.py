@@ -490,7 +490,7 @@ def test_groupby_wide_one_level_form(gpu_ctx, bits):
         assert lib.arx_get_counter(b"groupby_slices_wide") >= wide0 + 3, "the wide plan did not run"
     finally:
         for k_, v_ in {b"groupby_partition_min_rows": 1 << 17, b"groupby_wide": 1, b"groupby_partition_bits": -1,
-                       b"groupby_wide_agg_chunk_rows": 1 << 19}.items():
+                       b"groupby_wide_agg_chunk_rows": 1 << 21}.items():
             lib.arx_set_option(k_, v_)
 
 
@@ -561,6 +561,28 @@ def test_groupby_probe_slice_selects_the_plan(gpu_ctx, distinct):
         assert (wide, two) == (3, 0), (probe, wide, two)     # round 4: the sketch aggregates nothing, every row runs the wide plan
     else:
         assert (wide, two) == (0, 3), (probe, wide, two)
+
+
+@pytest.mark.parametrize("wide,bits,parts,keys_hi", [(1, -1, 8, 300_000), (2, 8, 5, 300_000), (1, 0, 2, 1500), (1, 9, 64, 2_000_000)])
+def test_groupby_consume_partials(gpu_ctx, wide, bits, parts, keys_hi):
+    """The sharded group-by's local pass without the local table (arx_groupby_sum_i64_consume_partials) on the device: the
+    planner's own choice for 3 M rows, the wide form forced, the unpartitioned aggregate, a two-level plan with more groups
+    than its LDS tables hold; owners, sums, counts, the receivers' merges and the too-small-region status are checked by
+    check_groupby_consume_partials."""
+    lib = gpu_ctx._lib.get_lib()
+    opts = {b"groupby_wide": wide, b"groupby_partition_bits": bits, b"groupby_wide_room_min_mean": 16 if wide == 2 else 1 << 14}
+    for k_, v_ in opts.items():
+        assert lib.arx_set_option(k_, v_) == 0
+    try:
+        rng = rng_for("gbemit", wide, bits, parts)
+        n = 3_000_000
+        k = U.random_array(rng, np.int32, n, lo=0, hi=keys_hi, offset=3)
+        v = U.random_array(rng, np.int64, n, offset=1)
+        records = P.check_groupby_consume_partials(gpu_ctx, k, v, parts, capacity=1 << 23)
+        assert records >= keys_hi * (1 - np.exp(-n / keys_hi)) * 0.99      # (at least the distinct keys)
+    finally:
+        for k_, v_ in {b"groupby_wide": 1, b"groupby_partition_bits": -1, b"groupby_wide_room_min_mean": 1 << 14}.items():
+            lib.arx_set_option(k_, v_)
 
 
 def test_groupby_virtual_ranks_on_one_gpu(gpu_ctx):

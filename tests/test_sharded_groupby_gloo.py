@@ -36,13 +36,21 @@ WORKER = textwrap.dedent(r'''
     array.set_default_device("cpu")
     rng = np.random.default_rng(1000 + rank)
     n = 6000 + 500 * rank                    # ragged shards
-    k = U.random_array(rng, np.int32, n, null_p=0.02, offset=rank, lo=-300, hi=300)
-    v = U.random_array(rng, np.int64, n, null_p=0.15, offset=2)
+    direct = EXCHANGE == "partials_direct"    # shards without nulls, large enough for the partitioned consume: the
+    if direct:                                # local pass writes its partials straight into the owners' regions
+        lib = _lib.get_lib()
+        assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
+        assert lib.arx_set_option(b"groupby_partition_bits", 3 + 2 * rank) == 0
+        assert lib.arx_set_option(b"groupby_agg_chunk_rows", 1 << 12) == 0
+    k = U.random_array(rng, np.int32, n, null_p=0.0 if direct else 0.02, offset=rank, lo=-300, hi=300)
+    v = U.random_array(rng, np.int64, n, null_p=0.0 if direct else 0.15, offset=2)
     opts = arrow_amd.compute.ScalarAggregateOptions(skip_nulls=SKIP_NULLS, min_count=MIN_COUNT)
     stages = parallel.Stages(torch.device("cpu"))
     gk, gkv, gs, gvalid = parallel.sharded_group_by_sum(k.to_device(arrow_amd), v.to_device(arrow_amd),
-                                                        2048, opts, exchange=EXCHANGE, stages=stages)
-    want_stages = {"partials": ["consume", "export", "exchange", "merge", "finalize"],
+                                                        2048, opts, exchange="partials" if direct else EXCHANGE, stages=stages,
+                                                        local_table=False if direct else None)
+    want_stages = {"partials": ["consume", "export", "exchange", "merge", "finalize"],     # (nulls: through the local table)
+                   "partials_direct": ["consume", "exchange", "merge", "finalize"],
                    "rows": ["partition_rows", "exchange", "consume", "finalize"]}[EXCHANGE]
     assert list(stages.ms) == want_stages, stages.ms
     mine = dict(keys=gk.numpy(), key_is_valid=gkv.numpy(), sums=gs.numpy(), valid=gvalid.numpy(),
@@ -59,7 +67,8 @@ WORKER = textwrap.dedent(r'''
 
 
 @pytest.mark.parametrize("skip_nulls,min_count,exchange", [(True, 1, "partials"), (False, 2, "partials"), (False, 2, "rows"),
-                                                           (True, 1, "rows")])
+                                                           (True, 1, "rows"), (True, 1, "partials_direct"),
+                                                           (False, 8, "partials_direct")])
 def test_sharded_group_by_sum_world2_gloo(tmp_path, skip_nulls, min_count, exchange):
     import pickle
 
