@@ -1599,33 +1599,6 @@ class GroupBySum:
         check(lib.arx_groupby_sum_i64_consume(self.state.data_ptr(), self.capacity, C.byref(ks),
                                               C.byref(vs), ws_ptr, ws_len, stream))
 
-    def consume_partials(self, keys: Array, values: Array, num_parts: int):
-        """arx_groupby_sum_i64_consume_partials: the partitioned consume whose groups leave as 24-byte ArxGroupPartial
-        records in the region of the rank that owns each key (hash(key) % num_parts), the table untouched.  Returns
-        (records uint8 tensor of num_parts regions, records_per_part, counts device int64[num_parts]) or None when the
-        batch must go through the table (nulls, a small batch, a region that overflowed): the caller then runs
-        consume() + export as before — nothing of this state was modified."""
-        keys, values = self._normalise_key(keys), self._normalise_value(values)
-        lib, stream = _lib_and_stream(self.device)
-        if (keys.null_count != 0 and keys.buffers[0] is not None) or (values.null_count != 0 and values.buffers[0] is not None):
-            return None
-        ws_bytes = lib.arx_groupby_consume_workspace_bytes(keys.length, self.capacity)
-        if not ws_bytes:
-            return None
-        ws = _workspace(self.device, ws_bytes + 256, "groupby")
-        ws_ptr = (ws.data_ptr() + 255) & ~255
-        ws_len = ws.numel() - (ws_ptr - ws.data_ptr())
-        per_part = int(lib.arx_groupby_partials_capacity(keys.length, self.capacity, num_parts))
-        records = torch.empty(num_parts * per_part * 24, dtype=torch.uint8, device=self.device)
-        counts = torch.empty(num_parts, dtype=torch.int64, device=self.device)
-        ks, vs = keys.span(), values.span()
-        rc = lib.arx_groupby_sum_i64_consume_partials(self.state.data_ptr(), self.capacity, C.byref(ks), C.byref(vs), ws_ptr, ws_len,
-                                                      num_parts, records.data_ptr(), per_part, counts.data_ptr(), stream)
-        if rc in (_lib.ARX_NOT_IMPLEMENTED, _lib.ARX_CAPACITY_ERROR):
-            return None
-        check(rc)
-        return records, per_part, counts
-
     # -- hash_min / hash_max on the same table (GroupedMinMaxImpl, kernels/hash_aggregate.cc:330-419)
     def consume_min_max(self, keys: Array, values: Array) -> None:
         """Folds the rows into per-group extrema; does not touch the sums, so the same rows may also

@@ -2535,7 +2535,7 @@ int64_t arx_groupby_partials_capacity(int64_t num_rows, int64_t capacity, int nu
 int arx_groupby_sum_i64_consume_partials(void* state, int64_t capacity, const ArxSpan* keys_i32, const ArxSpan* values_i64, void* ws,
                                          size_t ws_bytes, int num_parts, ArxGroupPartial* out_records, int64_t records_per_part,
                                          int64_t* out_part_counts, void* stream) {
-  if (state == nullptr || keys_i32 == nullptr || values_i64 == nullptr || out_records == nullptr || out_part_counts == nullptr) {
+  if (keys_i32 == nullptr || values_i64 == nullptr || out_records == nullptr || out_part_counts == nullptr) {
     set_error("NULL argument to arx_groupby_sum_i64_consume_partials");
     return ARX_INVALID;
   }
@@ -2568,7 +2568,7 @@ int arx_groupby_sum_i64_consume_partials(void* state, int64_t capacity, const Ar
 
 static int gb_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* keys_i32, const ArxSpan* values_i64, void* ws, size_t ws_bytes,
                               void* stream, const GbpEmit* emit) {
-  if (state == nullptr || keys_i32 == nullptr || values_i64 == nullptr) {
+  if ((state == nullptr && emit == nullptr) || keys_i32 == nullptr || values_i64 == nullptr) {
     set_error("NULL argument to arx_groupby_sum_i64_consume");
     return ARX_INVALID;
   }
@@ -2580,7 +2580,8 @@ static int gb_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* keys
   const int64_t n = keys_i32->length;
   if (n == 0) return ARX_OK;
   hipStream_t st = as_stream(stream);
-  GroupbyView v = gb_view(state, capacity);
+  // (the emit form never touches the table — no null rows, no row or group that goes to it —: its view is empty)
+  GroupbyView v = emit != nullptr ? GroupbyView{} : gb_view(state, capacity);
   const int32_t* k = static_cast<const int32_t*>(keys_i32->data) + keys_i32->offset;
   const int64_t* val = static_cast<const int64_t*>(values_i64->data) + values_i64->offset;
   const void* kbm = keys_i32->null_count != 0 ? keys_i32->validity : nullptr;

@@ -135,13 +135,47 @@ def unpack_rows(records: torch.Tensor):
     return Array(int32, n, [kbits, keys], -1, 0), Array(int64, n, [vbits, vals], -1, 0)
 
 
-def consume_partials(local: GroupBySum, keys, values, num_parts: int):
-    """The local pass WITHOUT the local table (arx_groupby_sum_i64_consume_partials): this shard's partial aggregates as
-    24-byte records grouped by owner, compacted for the all-to-all, + device int64[num_parts] counts; (None, None) when
-    the shard has to go through the table (`local` is untouched then, and otherwise only plans the pass).  A key may
-    appear in several records of a block (once per work unit that met it): the receiver's merge adds them up, as it adds
-    the partials of different ranks."""
-    out = local.consume_partials(keys, values, num_parts)
+def consume_partials_regions(keys, values, capacity: int, num_parts: int):
+    """arx_groupby_sum_i64_consume_partials: the partitioned consume whose groups leave as 24-byte ArxGroupPartial records
+    in the region of the rank that owns each key (hash(key) % num_parts) — no local table at all (`capacity`, the slots
+    one would have, only plans the pass).  Returns (records uint8 tensor of num_parts regions, records_per_part, counts
+    device int64[num_parts]) or None when the shard must go through a local table: keys / values of other types than
+    (int32, int64), nulls, a small shard, a region that overflowed."""
+    from .array import int32, int64
+    from .compute import _next_pow2, _workspace
+
+    if keys.type != int32 or values.type != int64:
+        return None
+    if (keys.null_count != 0 and keys.buffers[0] is not None) or (values.null_count != 0 and values.buffers[0] is not None):
+        return None
+    lib = _lib.get_lib()
+    device = keys.device
+    stream = current_stream(device)
+    capacity = _next_pow2(max(2, int(capacity)))
+    ws_bytes = lib.arx_groupby_consume_workspace_bytes(keys.length, capacity)
+    if not ws_bytes:
+        return None
+    ws = _workspace(device, ws_bytes + 256, "groupby")
+    ws_ptr = (ws.data_ptr() + 255) & ~255
+    ws_len = ws.numel() - (ws_ptr - ws.data_ptr())
+    per_part = int(lib.arx_groupby_partials_capacity(keys.length, capacity, num_parts))
+    records = torch.empty(num_parts * per_part * RECORD_BYTES, dtype=torch.uint8, device=device)
+    counts = torch.empty(num_parts, dtype=torch.int64, device=device)
+    ks, vs = keys.span(), values.span()
+    rc = lib.arx_groupby_sum_i64_consume_partials(None, capacity, C.byref(ks), C.byref(vs), ws_ptr, ws_len, num_parts,
+                                                  records.data_ptr(), per_part, counts.data_ptr(), stream)
+    if rc in (_lib.ARX_NOT_IMPLEMENTED, _lib.ARX_CAPACITY_ERROR):
+        return None
+    check(rc)
+    return records, per_part, counts
+
+
+def consume_partials(keys, values, capacity: int, num_parts: int):
+    """The local pass WITHOUT the local table: this shard's partial aggregates as 24-byte records grouped by owner,
+    compacted for the all-to-all, + device int64[num_parts] counts; (None, None) when the shard has to go through a
+    local table.  A key may appear in several records of a block (once per work unit that met it): the receiver's merge
+    adds them up, as it adds the partials of different ranks."""
+    out = consume_partials_regions(keys, values, capacity, num_parts)
     if out is None:
         return None, None
     regions, per_part, counts = out
@@ -193,16 +227,16 @@ def sharded_group_by_sum(keys, values, capacity: int, options: ScalarAggregateOp
         out = owned.finalize()
         _mark(stages, "finalize")
         return out
-    local = GroupBySum(capacity, device, options)
     records = None
     if local_table is not True:
-        records, counts = consume_partials(local, keys, values, world)
+        records, counts = consume_partials(keys, values, capacity, world)
         if records is not None:
             _mark(stages, "consume")
         elif local_table is False:
             raise _lib.ArrowNotImplementedError("sharded_group_by_sum(local_table=False): this shard needs the local table "
                                                 "(nulls, a small batch, or more partials than their regions hold)")
     if records is None:
+        local = GroupBySum(capacity, device, options)
         local.consume(keys, values)
         _mark(stages, "consume")
         records, counts = export_partitioned(local, world)

@@ -732,7 +732,8 @@ int arx_groupby_unpack_rows(const ArxRowRecord* records, int64_t num_records, in
  * out_records: num_parts regions of records_per_part records (arx_groupby_partials_capacity); out_part_counts (device
  * int64[num_parts]): records in every region.  ARX_NOT_IMPLEMENTED: rows with nulls, or a batch too small for the
  * partitioned consume — use the table path; ARX_CAPACITY_ERROR: a region overflowed (nothing else was touched: use the table path).
- * `state` / `capacity` only plan the pass (the table stays empty).  Synchronous at its end (reads the counts). */
+ * `capacity` (the slots a local table WOULD have: > 2 x the distinct keys expected) only plans the pass; `state` is not
+ * used and may be NULL.  Synchronous at its end (reads the counts). */
 int64_t arx_groupby_partials_capacity(int64_t num_rows, int64_t capacity, int num_parts);
 int arx_groupby_sum_i64_consume_partials(void* state, int64_t capacity, const ArxSpan* keys_i32, const ArxSpan* values_i64,
                                          void* ws, size_t ws_bytes, int num_parts, ArxGroupPartial* out_records,

@@ -35,13 +35,15 @@ for world in (1, 2, 4, 8):
     cap = 1 << 25
     def gb(direct):
         t = [ev() for _ in range(5)]
-        t[0].record(); local = GroupBySum(cap, dev)
+        t[0].record()
+        if not direct:
+            local = GroupBySum(cap, dev)
         if world == 1:
             local.consume(kk, vv); t[1].record()
             out = local.finalize(); t[2].record(); torch.cuda.synchronize()
             return {"consume": t[0].elapsed_time(t[1]), "export": 0.0, "merge": 0.0, "finalize": t[1].elapsed_time(t[2]), "exchange_MB_per_rank": 0.0}
         if direct:      # round 5: the partials leave the aggregate as records in the owners' regions (no local table, no export)
-            records, counts = parallel.consume_partials(local, kk, vv, world); t[1].record(); t[2].record()
+            records, counts = parallel.consume_partials(kk, vv, cap, world); t[1].record(); t[2].record()
             assert records is not None
         else:
             local.consume(kk, vv); t[1].record()

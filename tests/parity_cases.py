@@ -1134,7 +1134,7 @@ GROUP_PARTIAL = np.dtype([("sum", "<i8"), ("count", "<i8"), ("key", "<i4"), ("ke
 
 def check_groupby_consume_partials(amd, keys: HostArray, values: HostArray, num_parts, capacity=None):
     """arx_groupby_sum_i64_consume_partials (the sharded group-by's local pass without the local table): the records of
-    every region belong to that region's rank (the owner arx_groupby_export_partitioned assigns), the table stays empty,
+    every region belong to that region's rank (the owner arx_groupby_export_partitioned assigns),
     the records of a key add up to the oracle's group (sum with wrap-around, count), and the owners' merges of their
     blocks give the oracle's result with every key on one rank.  Returns the number of records written."""
     import ctypes as C
@@ -1147,11 +1147,9 @@ def check_groupby_consume_partials(amd, keys: HostArray, values: HostArray, num_
     dk, dv = keys.to_device(amd), values.to_device(amd)
     n = keys.length
     cap = capacity or max(16, 2 * n + 2)
-    local = amd.compute.GroupBySum(cap, dk.device)
-    out = local.consume_partials(dk, dv, num_parts)
+    out = parallel.consume_partials_regions(dk, dv, cap, num_parts)
     assert out is not None, "consume_partials declined"
     regions, per_part, counts = out
-    assert local.num_groups() == 0, "the emit form touched the table"
     counts = [int(c) for c in counts.cpu().tolist()]
     assert all(0 <= c <= per_part for c in counts), (counts, per_part)
     host = regions.cpu().numpy().view(GROUP_PARTIAL)
@@ -1195,7 +1193,7 @@ def check_groupby_consume_partials(amd, keys: HostArray, values: HostArray, num_
     # a region too small for what arrives: ARX_CAPACITY_ERROR, not a write past the region
     lib = amd._lib.get_lib()
     stream = amd.array.current_stream(dk.device)
-    ws_bytes = lib.arx_groupby_consume_workspace_bytes(n, local.capacity)
+    ws_bytes = lib.arx_groupby_consume_workspace_bytes(n, table.capacity)
     ws = amd.array.alloc(ws_bytes + 256, dk.device)
     ws_ptr = (ws.data_ptr() + 255) & ~255
     small = max(1, max(counts) // 2)
@@ -1203,7 +1201,7 @@ def check_groupby_consume_partials(amd, keys: HostArray, values: HostArray, num_
     buf = torch.full(((num_parts * small + guard) * parallel.RECORD_BYTES,), 0xA5, dtype=torch.uint8, device=dk.device)
     cnt_dev = torch.zeros(num_parts, dtype=torch.int64, device=dk.device)
     ks, vs = dk.span(), dv.span()
-    rc = lib.arx_groupby_sum_i64_consume_partials(local.state.data_ptr(), local.capacity, C.byref(ks), C.byref(vs), ws_ptr,
+    rc = lib.arx_groupby_sum_i64_consume_partials(None, table.capacity, C.byref(ks), C.byref(vs), ws_ptr,
                                                   ws.numel() - (ws_ptr - ws.data_ptr()), num_parts, buf.data_ptr(), small,
                                                   cnt_dev.data_ptr(), stream)
     if max(counts) >= 2:

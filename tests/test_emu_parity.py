@@ -1089,11 +1089,13 @@ def test_groupby_consume_partials(emu_ctx, wide, bits, parts):
         P.check_groupby_consume_partials(emu_ctx, k2, v2, parts)
         # declined: nulls, and a shard below the partitioned consume's row threshold
         kn = U.random_array(rng, np.int32, n, null_p=0.01, lo=0, hi=100)
-        local = emu_ctx.compute.GroupBySum(1 << 12, kn.to_device(emu_ctx).device)
-        assert local.consume_partials(kn.to_device(emu_ctx), v.to_device(emu_ctx), parts) is None
+        from arrow_amd import parallel
+        assert parallel.consume_partials_regions(kn.to_device(emu_ctx), v.to_device(emu_ctx), 1 << 12, parts) is None
         assert lib.arx_set_option(b"groupby_partition_min_rows", 1 << 17) == 0
-        assert local.consume_partials(k.to_device(emu_ctx), v.to_device(emu_ctx), parts) is None
-        assert local.num_groups() == 0
+        assert parallel.consume_partials(k.to_device(emu_ctx), v.to_device(emu_ctx), 1 << 12, parts) == (None, None)
+        k16 = U.random_array(rng, np.int16, n, lo=0, hi=100)      # other key types: through the table (its casts)
+        assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
+        assert parallel.consume_partials_regions(k16.to_device(emu_ctx), v.to_device(emu_ctx), 1 << 12, parts) is None
     finally:
         for k_, v_ in {b"groupby_partition_min_rows": 1 << 17, b"groupby_wide": 1, b"groupby_partition_bits": -1,
                        b"groupby_agg_chunk_rows": 1 << 18, b"groupby_wide_agg_chunk_rows": 1 << 21,

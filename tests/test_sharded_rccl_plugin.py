@@ -82,6 +82,31 @@ WORKER = textwrap.dedent(r'''
             assert not gk.is_cpu and not gs.is_cpu
             assert sum(1 for x in stage_ms if x > 0) >= 4, list(stage_ms)
             results[(exchange, skip_nulls, min_count)] = (to_host(gk).to_pylist(), to_host(gs).to_pylist())
+    # ---- shards without nulls: the local pass writes its partials straight into the owners' regions (no local table,
+    # no export stage: stage_ms[1] is exactly 0) and the sends go out of the regions
+    k2 = pa.array(rng.integers(-KEY_RANGE, KEY_RANGE, n).astype(np.int32))
+    v2 = pa.array(rng.integers(-2**63, 2**63 - 1, n))
+    lib.arx_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    if n < (1 << 17):     # (the CPU tier's shards are below the partitioned consume's row threshold)
+        assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
+        assert lib.arx_set_option(b"groupby_partition_bits", 2 + 3 * rank) == 0     # the ranks need not agree on a plan
+    results2 = {}
+    for skip_nulls, min_count in ((1, 1), (0, 3)):
+        dk, dv = to_device(k2), to_device(v2)
+        bufs = [ctypes.create_string_buffer(m) for m in (128, 72, 128, 72, 128, 72, 128, 72)]
+        dk._export_to_c_device(ctypes.addressof(bufs[0]), ctypes.addressof(bufs[1]))
+        dv._export_to_c_device(ctypes.addressof(bufs[2]), ctypes.addressof(bufs[3]))
+        stage_ms = (ctypes.c_double * 5)()
+        rc = lib.arrow_amd_sharded_group_by_sum(comm, *[ctypes.addressof(b) for b in bufs[:4]], skip_nulls, min_count, 0,
+                                                *[ctypes.addressof(b) for b in bufs[4:]], stage_ms)
+        assert rc == 0, lib.arrow_amd_plugin_last_error()
+        assert stage_ms[0] > 0 and stage_ms[1] == 0.0, ("the direct local pass did not run", list(stage_ms))
+        gk = pa.Array._import_from_c_device(ctypes.addressof(bufs[4]), ctypes.addressof(bufs[5]))
+        gs = pa.Array._import_from_c_device(ctypes.addressof(bufs[6]), ctypes.addressof(bufs[7]))
+        results2[(0, skip_nulls, min_count)] = (to_host(gk).to_pylist(), to_host(gs).to_pylist())
+    if n < (1 << 17):
+        lib.arx_set_option(b"groupby_partition_min_rows", 1 << 17)
+        lib.arx_set_option(b"groupby_partition_bits", -1)
     # ---- the sharded sort: this rank's slice of array_sort_indices of the concatenated shards
     lib.arrow_amd_sharded_sort_indices.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
@@ -111,7 +136,7 @@ WORKER = textwrap.dedent(r'''
             sorts[(name, descending, nulls_first)] = (start.value, to_host(idx).to_pylist())
     lib.arrow_amd_sharded_comm_destroy(comm)
     with open(OUT + f".rank{rank}", "wb") as f:
-        pickle.dump(dict(keys=k.to_pylist(), values=v.to_pylist(), results=results,
+        pickle.dump(dict(keys=k.to_pylist(), values=v.to_pylist(), results=results, keys2=k2.to_pylist(), values2=v2.to_pylist(), results2=results2,
                          sort_inputs={name: (str(a.type), a.to_pylist()) for name, a in sort_inputs.items()}, sorts=sorts), f)
 ''')
 
@@ -136,26 +161,28 @@ def _run_ranks(tmp_path, world, env_extra, n_rows, key_range):
     return [pickle.load(open(out + f".rank{r}", "rb")) for r in range(world)]
 
 
-def _check(ranks):
+def _check(ranks, which=""):
     import pyarrow as pa
     import pyarrow.compute as pc
 
-    keys = pa.array([x for r in ranks for x in r["keys"]], pa.int32())
-    vals = pa.array([x for r in ranks for x in r["values"]], pa.int64())
+    if which == "":
+        _check(ranks, "2")      # the shards without nulls (the direct local pass)
+    keys = pa.array([x for r in ranks for x in r["keys" + which]], pa.int32())
+    vals = pa.array([x for r in ranks for x in r["values" + which]], pa.int64())
     t = pa.table({"k": keys, "v": vals})
-    for (exchange, skip_nulls, min_count) in ranks[0]["results"]:
+    for (exchange, skip_nulls, min_count) in ranks[0]["results" + which]:
         opts = pc.ScalarAggregateOptions(skip_nulls=bool(skip_nulls), min_count=min_count)
         ref = t.group_by("k", use_threads=False).aggregate([("v", "sum", opts)])
         want = dict(zip(ref.column("k").to_pylist(), ref.column("v_sum").to_pylist()))
         got = {}
         for r in ranks:
-            gk, gs = r["results"][(exchange, skip_nulls, min_count)]
+            gk, gs = r["results" + which][(exchange, skip_nulls, min_count)]
             for key, s in zip(gk, gs):
                 assert key not in got, f"key {key} owned by two ranks (exchange {exchange})"
                 got[key] = s
         assert got == want, (exchange, skip_nulls, min_count, len(got), len(want))
         if len(ranks) > 1:
-            assert all(len(r["results"][(exchange, skip_nulls, min_count)][0]) > 0 for r in ranks)
+            assert all(len(r["results" + which][(exchange, skip_nulls, min_count)][0]) > 0 for r in ranks)
 
 
 def _check_sorts(ranks):
