@@ -1545,7 +1545,7 @@ __global__ __launch_bounds__(kGbWideThreads) void gbp_scatter_wide_kernel(GbpArg
 
 // ---- K5: LDS aggregation.  One workgroup per work unit = <= kGbAggChunk rows of ONE partition
 // (DIRECT: of the caller's rows — the plan with bits == 0 used when all groups fit one table).
-template <int SLOTS>
+template <int SLOTS, int THREADS>
 struct __attribute__((aligned(16))) GbpAggLds {
   unsigned long long sums[SLOTS];
   uint32_t tags[SLOTS];   // 0 = empty, else the low (32 - bits) bits of the key hash
@@ -1553,8 +1553,8 @@ struct __attribute__((aligned(16))) GbpAggLds {
   unsigned long long zsum;   // the one key whose tag is 0 has its own accumulator
   uint32_t zcnt;
   uint32_t part, row_lo, row_hi;
-  uint32_t emit_cnt[kGbEmitMaxParts];            // emit form: this unit's groups per owner rank ...
-  unsigned long long emit_base[kGbEmitMaxParts];  // ... and where they start in the owner's region
+  uint32_t emit_wave[THREADS / 64][kGbEmitMaxParts];   // emit form: the groups of every owner rank among a wave's slots, then where they start in the unit's run ...
+  unsigned long long emit_base[kGbEmitMaxParts];       // ... and where the unit's run starts in the owner's region
 };
 
 // SLOTS / THREADS: 4096 / 512 (two workgroups per CU), or the wide form's 8192 / 1024 (one per CU);
@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
                                                                 const int64_t* __restrict__ vals) {
   constexpr int kLgSlots = SLOTS == 8192 ? 13 : 12;
   static_assert((1 << kLgSlots) == SLOTS, "table sizes: 4096 or 8192 slots");
-  __shared__ GbpAggLds<SLOTS> t;
+  __shared__ GbpAggLds<SLOTS, THREADS> t;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   int64_t lo, hi;
@@ -1609,7 +1609,7 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
     t.zsum = 0;
     t.zcnt = 0;
   }
-  if (tid < kGbEmitMaxParts) t.emit_cnt[tid] = 0;
+  for (int i = tid; i < (THREADS / 64) * kGbEmitMaxParts; i += THREADS) (&t.emit_wave[0][0])[i] = 0;
   __syncthreads();
   if constexpr (!DIRECT) {
     q = t.part;
@@ -1873,42 +1873,79 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
     // the unit's groups as records, in the region of the rank that owns each key (hash(key) % ranks, as
     // arx_groupby_export_partitioned assigns them): ranks inside the unit by LDS atomics, ONE global atomic per (unit,
     // owner) for the place in the region — no probe of the HBM table, no two atomics per group, no export pass afterwards
-    constexpr int kMine = (SLOTS + 1 + THREADS - 1) / THREADS;
-    uint32_t rank[kMine];
-    int owner[kMine];
+    // A region's records of one unit lie in SLOT order — the order of the keys' hashes, which is the order the receiver's
+    // table keeps them in: its merge then walks its table front to back (records in the order the atomics of 1024
+    // threads happen to arrive in cost the merge 23 % more, profiles/r05_l_*).  Wave w owns the slots [w S, (w + 1) S),
+    // S = SLOTS / waves, 64 at a time: first every wave counts its groups per owner, one scan over the waves gives every
+    // (wave, owner) its place, then the wave walks its slots again and ranks them.
+    constexpr int kWaves = THREADS / 64;
+    constexpr int kPer = SLOTS / kWaves / 64;      // passes of 64 slots per wave
+    const int wave = tid >> 6;
+    const uint64_t below = (uint64_t(1) << lane) - 1;
+    int owner[kPer];
 #pragma unroll
-    for (int j = 0; j < kMine; ++j) {
-      const int i = tid + j * THREADS;
-      owner[j] = -1;
-      rank[j] = 0;
-      if (i > SLOTS) continue;
-      const bool live = i < SLOTS ? t.tags[i] != 0 : t.zcnt != 0;
-      if (!live) continue;
-      const uint32_t tag = i < SLOTS ? t.tags[i] : 0u;
-      owner[j] = gb_dest(gbp_unhash(a, hi_bits | tag), true, a.emit_parts);
-      rank[j] = atomicAdd(&t.emit_cnt[owner[j]], 1u);
+    for (int j = 0; j < kPer; ++j) {
+      const int i = wave * (SLOTS / kWaves) + j * 64 + lane;
+      const uint32_t tag = t.tags[i];
+      owner[j] = tag != 0 ? gb_dest(gbp_unhash(a, hi_bits | tag), true, a.emit_parts) : -1;
+    }
+    const int zowner = t.zcnt != 0 ? gb_dest(gbp_unhash(a, hi_bits), true, a.emit_parts) : -1;   // the key whose tag is 0: the last wave's
+    auto walk = [&](bool place) {
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) {
+        uint32_t at = 0;
+        uint64_t todo = __ballot(owner[j] >= 0);
+        while (todo != 0) {
+          const int leader = __builtin_ctzll(todo);
+          const int o = __shfl(owner[j], leader);
+          const uint64_t same = __ballot(owner[j] == o);
+          uint32_t old = 0;
+          if (lane == leader) old = atomicAdd(&t.emit_wave[wave][o], static_cast<uint32_t>(__builtin_popcountll(same)));
+          old = __shfl(old, leader);
+          if (owner[j] == o) at = old + static_cast<uint32_t>(__builtin_popcountll(same & below));
+          todo &= ~same;
+        }
+        if (place && owner[j] >= 0) {
+          const int i = wave * (SLOTS / kWaves) + j * 64 + lane;
+          const unsigned long long to = t.emit_base[owner[j]] + at;
+          if (to < static_cast<unsigned long long>(a.emit_capacity)) {   // (else: the host sees the cursor past the capacity)
+            ArxGroupPartial r{};
+            r.sum = static_cast<int64_t>(t.sums[i]);
+            r.count = static_cast<int64_t>(t.cnts[i]);
+            r.key = gbp_unhash(a, hi_bits | t.tags[i]);
+            r.key_is_valid = 1;
+            r.no_nulls = 1;
+            a.emit_records[static_cast<int64_t>(owner[j]) * a.emit_capacity + static_cast<int64_t>(to)] = r;
+          }
+        }
+      }
+      if (wave == kWaves - 1 && lane == 0 && zowner >= 0) {
+        const uint32_t at = atomicAdd(&t.emit_wave[wave][zowner], 1u);
+        const unsigned long long to = t.emit_base[zowner] + at;
+        if (place && to < static_cast<unsigned long long>(a.emit_capacity)) {
+          ArxGroupPartial r{};
+          r.sum = static_cast<int64_t>(t.zsum);
+          r.count = static_cast<int64_t>(t.zcnt);
+          r.key = gbp_unhash(a, hi_bits);
+          r.key_is_valid = 1;
+          r.no_nulls = 1;
+          a.emit_records[static_cast<int64_t>(zowner) * a.emit_capacity + static_cast<int64_t>(to)] = r;
+        }
+      }
+    };
+    walk(false);      // t.emit_wave[w][o] (zero since the unit's start) = groups of owner o among wave w's slots
+    __syncthreads();
+    if (tid < a.emit_parts) {   // -> where wave w's groups of owner o start inside the unit's run; the run's place in the region
+      uint32_t run = 0;
+      for (int w = 0; w < kWaves; ++w) {
+        const uint32_t c = t.emit_wave[w][tid];
+        t.emit_wave[w][tid] = run;
+        run += c;
+      }
+      t.emit_base[tid] = run != 0 ? atomicAdd(&a.emit_cursor[tid], static_cast<unsigned long long>(run)) : 0ull;
     }
     __syncthreads();
-    if (tid < a.emit_parts) {
-      const uint32_t c = t.emit_cnt[tid];
-      t.emit_base[tid] = c != 0 ? atomicAdd(&a.emit_cursor[tid], static_cast<unsigned long long>(c)) : 0ull;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kMine; ++j) {
-      const int i = tid + j * THREADS;
-      if (owner[j] < 0) continue;
-      const unsigned long long at = t.emit_base[owner[j]] + rank[j];
-      if (at >= static_cast<unsigned long long>(a.emit_capacity)) continue;   // (the host sees the cursor past the capacity)
-      const uint32_t tag = i < SLOTS ? t.tags[i] : 0u;
-      ArxGroupPartial r{};
-      r.sum = static_cast<int64_t>(i < SLOTS ? t.sums[i] : t.zsum);
-      r.count = static_cast<int64_t>(i < SLOTS ? t.cnts[i] : t.zcnt);
-      r.key = gbp_unhash(a, hi_bits | tag);
-      r.key_is_valid = 1;
-      r.no_nulls = 1;
-      a.emit_records[static_cast<int64_t>(owner[j]) * a.emit_capacity + static_cast<int64_t>(at)] = r;
-    }
+    walk(true);
     return;
   }
   for (int i = tid; i < SLOTS + 1; i += THREADS) {
@@ -2243,15 +2280,25 @@ __global__ __launch_bounds__(1024) void gbp_hll_kernel(const int32_t* __restrict
   for (int i = threadIdx.x; i < kHllRegs; i += 1024) local[i] = 0;
   __syncthreads();
   const int64_t stride = static_cast<int64_t>(gridDim.x) * 1024;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 1024 + threadIdx.x; i < n; i += stride) {
-    uint64_t z = static_cast<uint64_t>(static_cast<uint32_t>(keys[i])) + 0x9E3779B97F4A7C15ull;   // splitmix64 of the key
+  auto fold = [&](int32_t key) {
+    uint64_t z = static_cast<uint64_t>(static_cast<uint32_t>(key)) + 0x9E3779B97F4A7C15ull;   // splitmix64 of the key
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
     const unsigned int idx = static_cast<unsigned int>(z >> (64 - kHllBits));
     const unsigned int rank = static_cast<unsigned int>(__builtin_clzll((z << kHllBits) | (uint64_t(1) << (kHllBits - 1)))) + 1u;
     if (local[idx] < rank) atomicMax(&local[idx], rank);
+  };
+  // eight keys in flight per thread (one per iteration left the kernel waiting for its own load: 134 MB in 155 us)
+  int64_t i = static_cast<int64_t>(blockIdx.x) * 1024 + threadIdx.x;
+  for (; i + 7 * stride < n; i += 8 * stride) {
+    int32_t k[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) k[u] = keys[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) fold(k[u]);
   }
+  for (; i < n; i += stride) fold(keys[i]);
   __syncthreads();
   for (int i = threadIdx.x; i < kHllRegs; i += 1024) {
     const unsigned int r = local[i];

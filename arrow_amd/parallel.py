@@ -180,8 +180,9 @@ def consume_partials(keys, values, capacity: int, num_parts: int):
         return None, None
     regions, per_part, counts = out
     host = [int(c) for c in counts.cpu().tolist()]
-    blocks = [regions[p * per_part * RECORD_BYTES: (p * per_part + host[p]) * RECORD_BYTES] for p in range(num_parts)]
-    return torch.cat(blocks), counts
+    words = regions.view(torch.int64)      # (a record = three 8-byte words: the copy moves words, not bytes)
+    blocks = [words[p * per_part * 3: (p * per_part + host[p]) * 3] for p in range(num_parts)]
+    return torch.cat(blocks).view(torch.uint8), counts
 
 
 def sharded_group_by_sum(keys, values, capacity: int, options: ScalarAggregateOptions | None = None,
