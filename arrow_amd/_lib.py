@@ -262,6 +262,8 @@ SIGNATURES = {
     "arx_hash_product_init": (_int, [_p, _int, _i64, _p]),
     "arx_hash_product_consume": (_int, [_span, _int, _p, _i64, _p, _sz, _p, _p, _p, _p]),
     "arx_hash_mean_f64_finalize": (_int, [_p, _p, _i64, _p, _p]),
+    "arx_group_central_power": (_int, [_span, _int, _p, _i64, _p, _p, _int, _p, _p]),
+    "arx_hash_moments_finalize": (_int, [_p, _p, _p, _p, _i64, _int, _int, _int, _p, _p]),
     "arx_hash_minmax_i64_fill": (_int, [_p, _p, _i64, _i64, _p]),
     "arx_hash_minmax_i64_consume": (_int, [_span, _int, _i64, _p, _i64, _p, _p, _p, _p]),
     "arx_hash_minmax_i64_merge": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _p]),

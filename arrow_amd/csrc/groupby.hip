@@ -1873,11 +1873,10 @@ __global__ __launch_bounds__(THREADS) void gbp_aggregate_kernel(GroupbyView v, G
     // the unit's groups as records, in the region of the rank that owns each key (hash(key) % ranks, as
     // arx_groupby_export_partitioned assigns them): ranks inside the unit by LDS atomics, ONE global atomic per (unit,
     // owner) for the place in the region — no probe of the HBM table, no two atomics per group, no export pass afterwards
-    // A region's records of one unit lie in SLOT order — the order of the keys' hashes, which is the order the receiver's
-    // table keeps them in: its merge then walks its table front to back (records in the order the atomics of 1024
-    // threads happen to arrive in cost the merge 23 % more, profiles/r05_l_*).  Wave w owns the slots [w S, (w + 1) S),
-    // S = SLOTS / waves, 64 at a time: first every wave counts its groups per owner, one scan over the waves gives every
-    // (wave, owner) its place, then the wave walks its slots again and ranks them.
+    // A region's records of one unit lie in SLOT order (the order of the keys' partition hashes; a fixed order whatever the
+    // waves' timing — it does not make the receiver's merge faster: 1.30 ms for 1e7 records either way, profiles/r05_l_*).
+    // Wave w owns the slots [w S, (w + 1) S), S = SLOTS / waves, 64 at a time: first every wave counts its groups per
+    // owner, one scan over the waves gives every (wave, owner) its place, then the wave walks its slots again and ranks them.
     constexpr int kWaves = THREADS / 64;
     constexpr int kPer = SLOTS / kWaves / 64;      // passes of 64 slots per wave
     const int wave = tid >> 6;

@@ -21,6 +21,7 @@
 // far, mod 16" (64 = 0 mod 16, so an all-valid word passes it on unchanged) is resolved by a two-level scan, block
 // starts are counted and numbered the same way, and every word's thread then adds the blocks that start in it.
 // HBM traffic: the values once (8 or 4 B/row) + 8 B per block (0.5 B/row without nulls).
+#include <cmath>
 #include "arx_common.h"
 
 #include <algorithm>
@@ -565,7 +566,113 @@ __global__ __launch_bounds__(kBlock) void hash_fmean_finalize_kernel(const doubl
   }
 }
 
+// ---- hash_variance / hash_stddev / hash_skew / hash_kurtosis: the second pass of the two-pass moments
+// (GroupedStatisticImpl::ConsumeGeneric, kernels/hash_aggregate_numeric.cc:555-615: mean = sum / count, then the sums of
+// (x - mean)^k).  out[i] = (x_i - mean of its group)^power for the valid rows (0 for the others: their validity bit keeps
+// them out of the sum that follows).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void group_central_power_kernel(const T* __restrict__ in, Bits valid, const uint32_t* __restrict__ ids,
+                                                                     int64_t n, const double* __restrict__ sums,
+                                                                     const long long* __restrict__ counts, int power,
+                                                                     double* __restrict__ out) {
+#pragma clang fp contract(off)   // (every product and difference rounded on its own, as the reference's scalar code)
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1ull;
+    double r = 0.0;
+    if (ok) {
+      const uint32_t g = ids[i];
+      const double d = static_cast<double>(in[i]) - sums[g] / static_cast<double>(counts[g]);   // (a valid row: counts[g] >= 1)
+      const double d2 = d * d;
+      r = power == 2 ? d2 : power == 3 ? d2 * d : d2 * d2;
+    }
+    out[i] = r;
+  }
+}
+
+// Moments::Variance / Stddev / Skew / Kurtosis (kernels/aggregate_var_std_internal.h:83-116) of (count, m2, m3, m4); a group
+// the reference leaves null (GroupedStatisticImpl::Finalize :747-775) reads 0
+__global__ __launch_bounds__(kBlock) void hash_moments_finalize_kernel(const long long* __restrict__ counts, const double* __restrict__ m2s,
+                                                                       const double* __restrict__ m3s, const double* __restrict__ m4s,
+                                                                       int64_t m, int stat, int ddof, int biased, double* __restrict__ out) {
+#pragma clang fp contract(off)
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; g < m; g += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const long long c = counts[g];
+    const double count = static_cast<double>(c);
+    double r = 0.0;
+    const bool defined = c > ddof && (stat != ARX_STAT_SKEW || biased || c > 2) && (stat != ARX_STAT_KURTOSIS || biased || c > 3);
+    if (defined) {
+      const double m2 = m2s[g];
+      if (stat == ARX_STAT_VARIANCE || stat == ARX_STAT_STDDEV) {
+        r = m2 / static_cast<double>(c - ddof);
+        if (stat == ARX_STAT_STDDEV) r = sqrt(r);
+      } else if (stat == ARX_STAT_SKEW) {
+        const double m3 = m3s[g];
+        if (biased) {
+          r = sqrt(count) * m3 / sqrt(m2 * m2 * m2);
+        } else {
+          const double m2_avg = m2 / count;
+          r = sqrt(count * (count - 1)) / (count - 2) * (m3 / count) / sqrt(m2_avg * m2_avg * m2_avg);
+        }
+      } else {
+        const double m4 = m4s[g];
+        if (biased) {
+          r = count * m4 / (m2 * m2) - 3;
+        } else {
+          const double m2_avg = m2 / count;
+          r = 1.0 / ((count - 2) * (count - 3)) * (((count * count) - 1.0) * (m4 / count) / (m2_avg * m2_avg) - 3 * ((count - 1) * (count - 1)));
+        }
+      }
+    }
+    out[g] = r;
+  }
+}
+
 extern "C" {
+
+int arx_group_central_power(const ArxSpan* values, int num_type, const uint32_t* group_ids, int64_t length, const double* sums,
+                            const int64_t* counts, int power, double* out, void* stream) {
+  if (values == nullptr || length < 0 || power < 2 || power > 4 || (num_type != ARX_NUM_FLOAT32 && num_type != ARX_NUM_FLOAT64)) {
+    set_error("bad arguments to arx_group_central_power (float32 / float64 values, power 2 to 4)");
+    return ARX_INVALID;
+  }
+  if (length == 0) return ARX_OK;
+  if (values->data == nullptr || group_ids == nullptr || sums == nullptr || counts == nullptr || out == nullptr) {
+    set_error("arx_group_central_power: NULL buffer");
+    return ARX_INVALID;
+  }
+  const Bits valid = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, length);
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((length + kBlock - 1) / kBlock, 256 * 16)));
+  if (num_type == ARX_NUM_FLOAT32) {
+    hipLaunchKernelGGL(group_central_power_kernel<float>, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                       static_cast<const float*>(values->data) + values->offset, valid, group_ids, length, sums,
+                       reinterpret_cast<const long long*>(counts), power, out);
+  } else {
+    hipLaunchKernelGGL(group_central_power_kernel<double>, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                       static_cast<const double*>(values->data) + values->offset, valid, group_ids, length, sums,
+                       reinterpret_cast<const long long*>(counts), power, out);
+  }
+  ARX_CHECK_LAUNCH("group_central_power_kernel");
+  return ARX_OK;
+}
+
+int arx_hash_moments_finalize(const int64_t* counts, const double* m2, const double* m3, const double* m4, int64_t num_groups, int stat,
+                              int ddof, int biased, double* out, void* stream) {
+  if (num_groups < 0 || stat < ARX_STAT_VARIANCE || stat > ARX_STAT_KURTOSIS || ddof < 0) {
+    set_error("bad arguments to arx_hash_moments_finalize");
+    return ARX_INVALID;
+  }
+  if (num_groups == 0) return ARX_OK;
+  if (counts == nullptr || m2 == nullptr || out == nullptr || (stat == ARX_STAT_SKEW && m3 == nullptr) || (stat == ARX_STAT_KURTOSIS && m4 == nullptr)) {
+    set_error("arx_hash_moments_finalize: NULL buffer");
+    return ARX_INVALID;
+  }
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((num_groups + kBlock - 1) / kBlock, 256 * 8)));
+  hipLaunchKernelGGL(hash_moments_finalize_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const long long*>(counts),
+                     m2, m3, m4, num_groups, stat, ddof, biased, out);
+  ARX_CHECK_LAUNCH("hash_moments_finalize_kernel");
+  return ARX_OK;
+}
 
 int arx_reduce_float_minmax(const ArxSpan* values, int num_type, void* acc, void* stream) {
   if (values == nullptr || acc == nullptr || values->length < 0 || (num_type != ARX_NUM_FLOAT32 && num_type != ARX_NUM_FLOAT64)) {

@@ -929,6 +929,21 @@ int arx_hash_sum_f64_merge(double* sums, int64_t* counts, uint32_t* null_seen, c
                            const uint32_t* group_id_mapping, int64_t other_num_groups, void* stream);
 int arx_hash_mean_f64_finalize(const double* sums, const int64_t* counts, int64_t num_groups, double* out_means,
                                void* stream);
+/* hash_variance / hash_stddev / hash_skew / hash_kurtosis — GroupedStatisticImpl (kernels/hash_aggregate_numeric.cc:457-843),
+ * the two-pass form of its ConsumeGeneric (:555-615) over ALL rows of the node at once: pass 1 is arx_hash_sum_float_consume
+ * (sums, counts: mean = sum / count); arx_group_central_power writes (x - mean of x's group)^power (power 2, 3 or 4; 0 for null
+ * rows, which keep their validity) as a float64 column whose arx_hash_sum_float_consume is the moment m2 / m3 / m4;
+ * arx_hash_moments_finalize applies Moments::Variance / Stddev / Skew / Kurtosis (kernels/aggregate_var_std_internal.h:83-116).
+ * The reference computes the same per batch and merges batches (Moments::Merge): equal up to floating-point rounding, not bit
+ * for bit — its own tests compare with a tolerance (hash_aggregate_test.cc VarianceAndStddev / SkewAndKurtosis).  A group the
+ * reference leaves null for its count (count <= ddof; unbiased skew: count <= 2, kurtosis: count <= 3) reads 0; the validity
+ * comes from arx_hash_sum_i64_finalize with min_count raised to that bound.  values: float32 / float64 (integers are cast to
+ * float64 first, ToDouble :537-539).  Asynchronous. */
+enum { ARX_STAT_VARIANCE = 0, ARX_STAT_STDDEV = 1, ARX_STAT_SKEW = 2, ARX_STAT_KURTOSIS = 3 };
+int arx_group_central_power(const ArxSpan* values, int num_type, const uint32_t* group_ids, int64_t length, const double* sums,
+                            const int64_t* counts, int power, double* out, void* stream);
+int arx_hash_moments_finalize(const int64_t* counts, const double* m2, const double* m3, const double* m4, int64_t num_groups,
+                              int stat, int ddof, int biased, double* out, void* stream);
 /* hash_sum of decimal128 values (16 bytes a value, little-endian two's complement) —
  * GroupedReducingAggregator<Decimal128Type, GroupedSumImpl> (hash_aggregate_numeric.cc:44-152,189-215): a Decimal128 per
  * group, Reduce = BasicDecimal128 addition, i.e. modulo 2^128 — associative and commutative, kept with atomics: the low word

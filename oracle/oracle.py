@@ -1121,6 +1121,97 @@ def hash_product_row_order(values, valid, gids, num_groups, products=None, count
     return products, counts, null_seen
 
 
+def _neumaier_sum(terms):
+    """arrow::internal::NeumaierSum (util/math_internal.h) of a few doubles."""
+    total, comp = 0.0, 0.0
+    for x in terms:
+        t = total + x
+        comp += (total - t) + x if abs(total) >= abs(x) else (x - t) + total
+        total = t
+    return total + comp
+
+
+def moments_merge(level, a, b):
+    """Moments::Merge (kernels/aggregate_var_std_internal.h:116-152); a, b = (count, mean, m2, m3, m4)."""
+    if a[0] == 0:
+        return b
+    if b[0] == 0:
+        return a
+    na, nb = a[0], b[0]
+    n = na + nb
+    mean = (a[1] * na + b[1] * nb) / n
+    m2 = _neumaier_sum([a[2], b[2], na * (a[1] - mean) * (a[1] - mean), nb * (b[1] - mean) * (b[1] - mean)])
+    m3 = m4 = 0.0
+    if level >= 3:
+        delta = b[1] - a[1]
+        delta2 = delta * delta
+        m3 = _neumaier_sum([a[3], b[3], delta2 * delta * na * nb * (na - nb) / (n * n), 3 * delta * (na * b[2] - nb * a[2]) / n])
+        if level >= 4:
+            m4 = _neumaier_sum([a[4], b[4], (delta2 * delta2) * na * nb * (na * na - na * nb + nb * nb) / (n * n * n),
+                                6 * delta2 * (na * na * b[2] + nb * nb * a[2]) / (n * n), 4 * delta * (na * b[3] - nb * a[3]) / n])
+    return (n, mean, m2, m3, m4)
+
+
+def grouped_moments(values, valid, gids, num_groups, level=4, state=None):
+    """GroupedStatisticImpl::ConsumeGeneric (kernels/hash_aggregate_numeric.cc:555-615) for ONE batch, merged into `state`
+    (:700-745): sums in the SumType in row order, mean = ToDouble(sum) / count, then the sums of (ToDouble(x) - mean)^k in row
+    order; the batch's moments are merged into the running ones group by group (Moments::Merge).  `state` / the result:
+    (list of (count, mean, m2, m3, m4) per group, null_seen).  (Integers of <= 4 bytes take ConsumeIntegral in the
+    reference for level 2 — exact integer sums, the same value up to rounding; this restates the generic path for all.)"""
+    v = np.asarray(values)
+    is_float = v.dtype.kind == "f"
+    sums = [0.0 if is_float else 0] * num_groups
+    counts = [0] * num_groups
+    moments, null_seen = state if state is not None else ([(0, 0.0, 0.0, 0.0, 0.0)] * num_groups, np.zeros(num_groups, dtype=bool))
+    moments = list(moments)
+    for i in range(len(gids)):
+        g = int(gids[i])
+        if valid is None or valid[i]:
+            sums[g] = sums[g] + (float(v[i]) if is_float else int(v[i]))
+            counts[g] += 1
+        else:
+            null_seen[g] = True
+    means = [float(sums[g]) / counts[g] if counts[g] else 0.0 for g in range(num_groups)]
+    m = [[0.0, 0.0, 0.0] for _ in range(num_groups)]
+    for i in range(len(gids)):
+        if valid is not None and not valid[i]:
+            continue
+        g = int(gids[i])
+        d = float(v[i]) - means[g]
+        d2 = d * d
+        if level >= 4:
+            m[g][2] += d2 * d2
+        if level >= 3:
+            m[g][1] += d2 * d
+        m[g][0] += d2
+    for g in range(num_groups):
+        moments[g] = moments_merge(level, moments[g], (counts[g], means[g], m[g][0], m[g][1], m[g][2]))
+    return moments, null_seen
+
+
+def moments_statistic(moment, stat, ddof=0, biased=True):
+    """Moments::Variance / Stddev / Skew / Kurtosis (aggregate_var_std_internal.h:83-114) where GroupedStatisticImpl::Finalize
+    (:747-775) computes one, else None.  stat: 0 variance, 1 stddev, 2 skew, 3 kurtosis."""
+    count, _, m2, m3, m4 = moment
+    if not (count > ddof and (stat != 2 or biased or count > 2) and (stat != 3 or biased or count > 3)):
+        return None
+    with np.errstate(all="ignore"):
+        c = np.float64(count)
+        m2, m3, m4 = np.float64(m2), np.float64(m3), np.float64(m4)
+        if stat in (0, 1):
+            var = m2 / np.float64(count - ddof)
+            return float(var if stat == 0 else np.sqrt(var))
+        if stat == 2:
+            if biased:
+                return float(np.sqrt(c) * m3 / np.sqrt(m2 * m2 * m2))
+            m2_avg = m2 / c
+            return float(np.sqrt(c * (c - 1)) / (c - 2) * (m3 / c) / np.sqrt(m2_avg * m2_avg * m2_avg))
+        if biased:
+            return float(c * m4 / (m2 * m2) - 3)
+        m2_avg = m2 / c
+        return float(1.0 / ((c - 2) * (c - 3)) * (((c * c) - 1.0) * (m4 / c) / (m2_avg * m2_avg) - 3 * ((c - 1) * (c - 1))))
+
+
 def group_edge_rows(gids, valid, num_groups, last=False):
     """What GroupedFirstLastImpl / GroupedOneImpl keep per group (kernels/hash_aggregate.cc:775-808, :1575-1590), as a ROW:
     `firsts[g]` is set by the first NON-NULL value of group g that VisitGroupedValues meets, `lasts[g]` by every non-null

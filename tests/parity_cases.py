@@ -2984,3 +2984,73 @@ def check_hash_product_and_edge_rows(amd, rng, n=20000, groups=(1, 7, 300, 5000)
         assert_equal(lo.cpu().numpy().view(np.uint64)[:nn], words[0:2 * nn:2], "dec128_split lo")
         assert_equal(hi.cpu().numpy().view(np.uint64)[:nn], words[1:2 * nn:2], "dec128_split hi")
 
+
+
+def check_group_moments(amd, rng, n=20000, groups=(1, 7, 300, 5000)):
+    """arx_group_central_power + arx_hash_moments_finalize (hash_variance / hash_stddev / hash_skew / hash_kurtosis): pass 1 =
+    the row-order float sum, pass 2 = the row-order sums of (x - mean)^k — over ONE batch that is the reference's
+    ConsumeGeneric operation for operation, so m2 and the variance / stddev are compared bit for bit with the oracle's
+    restatement (pinned on the reference build, tests/test_oracle_pin.py) and skew / kurtosis to 1e-12 (their last
+    subtraction may be fused on either side); nulls at an offset, a group of one value, of equal values (0 / 0 = NaN)."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    st = current_stream(dev)
+    C = _lib.C
+    for dtype, num_type in ((np.float64, 9), (np.float32, 8)):
+        for G in groups:
+            voff = int(rng.integers(0, 70))
+            vals = (1e3 + rng.standard_normal(voff + n) * 7).astype(dtype)
+            valid = rng.random(n) > 0.15
+            gids = rng.integers(0, G, n).astype(np.uint32)
+            if G > 5:
+                gids[rng.random(n) < 0.5] = 3                         # one long group (the wave-cooperative walker)
+                vals[voff:][gids == 4] = dtype(2.5)                   # a constant group: m2 = 0, skew / kurtosis 0 / 0
+                one = np.nonzero(gids == 5)[0]
+                valid[one[1:]] = False                                # a group of one value (and nulls)
+            d_vals, d_valid, d_gids = to_device(vals, dev), to_device(_pack_bits(valid, voff), dev), to_device(gids.view(np.uint8), dev)
+            sp = _lib.ArxSpan(d_valid.data_ptr(), d_vals.data_ptr(), voff, n, -1)
+            ws_bytes = lib.arx_hash_sum_float_workspace_bytes(n)
+            ws = torch.zeros(ws_bytes + 256, dtype=torch.uint8, device=dev)
+            z = lambda dt: torch.zeros(G, dtype=dt, device=dev)  # noqa: E731
+            sums, counts, seen = z(torch.float64), z(torch.int64), z(torch.int32)
+            _lib.check(lib.arx_hash_sum_float_consume(C.byref(sp), num_type, 0, 0.0, d_gids.data_ptr(), n, ws.data_ptr(), ws_bytes + 256,
+                                                      sums.data_ptr(), counts.data_ptr(), seen.data_ptr(), st))
+            dev_col = torch.empty(voff + n, dtype=torch.float64, device=dev)
+            m = {}
+            for power in (2, 3, 4):
+                _lib.check(lib.arx_group_central_power(C.byref(sp), num_type, d_gids.data_ptr(), n, sums.data_ptr(), counts.data_ptr(), power,
+                                                       dev_col.data_ptr() + 8 * voff, st))
+                dsp = _lib.ArxSpan(d_valid.data_ptr(), dev_col.data_ptr(), voff, n, -1)
+                m[power], c2, s2 = z(torch.float64), z(torch.int64), z(torch.int32)
+                _lib.check(lib.arx_hash_sum_float_consume(C.byref(dsp), 9, 0, 0.0, d_gids.data_ptr(), n, ws.data_ptr(), ws_bytes + 256,
+                                                          m[power].data_ptr(), c2.data_ptr(), s2.data_ptr(), st))
+                assert_equal(c2.cpu().numpy(), counts.cpu().numpy(), "moment counts")
+            want, _ = O.grouped_moments(vals[voff:], valid, gids, G, 4)
+            tag = f"group_moments[{np.dtype(dtype).name},G={G}]"
+            assert_equal(counts.cpu().numpy(), np.array([w[0] for w in want], dtype=np.int64), tag + " counts")
+            for power, idx in ((2, 2), (3, 3), (4, 4)):
+                got = m[power].cpu().numpy()
+                exp = np.array([w[idx] for w in want], dtype=np.float64)
+                assert (got.view(np.uint64) == exp.view(np.uint64)).all(), (tag, power, got[:4], exp[:4])
+            for stat, ddof, biased in ((0, 0, 1), (0, 1, 1), (1, 2, 1), (2, 0, 1), (2, 0, 0), (3, 0, 1), (3, 0, 0)):
+                out = torch.full((G,), 7.0, dtype=torch.float64, device=dev)
+                _lib.check(lib.arx_hash_moments_finalize(counts.data_ptr(), m[2].data_ptr(), m[3].data_ptr(), m[4].data_ptr(), G, stat, ddof,
+                                                         biased, out.data_ptr(), st))
+                got = out.cpu().numpy()
+                for g in range(G):
+                    w = O.moments_statistic(want[g], stat, ddof, bool(biased))
+                    if w is None:
+                        assert got[g] == 0.0, (tag, stat, g, got[g])
+                    elif np.isnan(w):
+                        assert np.isnan(got[g]), (tag, stat, g, got[g])
+                    elif stat <= 1:
+                        assert np.float64(got[g]).view(np.uint64) == np.float64(w).view(np.uint64), (tag, stat, ddof, g, got[g], w)
+                    else:
+                        assert abs(got[g] - w) <= 1e-12 * max(1.0, abs(w)), (tag, stat, biased, g, got[g], w)
+    # bad arguments are refused
+    assert lib.arx_group_central_power(None, 9, None, 5, None, None, 2, None, st) == _lib.ARX_INVALID
+    assert lib.arx_hash_moments_finalize(None, None, None, None, 3, 9, 0, 1, None, st) == _lib.ARX_INVALID

@@ -1176,3 +1176,9 @@ def test_hash_product_group_edge_rows_and_dec128_split(emu_ctx):
     oracle's restatements of GroupedProductImpl, GroupedFirstLastImpl and GroupedOneImpl."""
     P.check_hash_product_and_edge_rows(emu_ctx, rng_for("hashprod"), n=3000, groups=(1, 7, 300))
 
+
+
+def test_group_moments_variance_stddev_skew_kurtosis(emu_ctx):
+    """hash_variance / hash_stddev / hash_skew / hash_kurtosis: the two-pass moments kernels against the oracle's restatement
+    of GroupedStatisticImpl (kernels/hash_aggregate_numeric.cc:457-843)."""
+    P.check_group_moments(emu_ctx, rng_for("moments"), n=3000, groups=(1, 7, 300))

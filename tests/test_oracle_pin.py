@@ -1094,3 +1094,53 @@ def test_hash_product_and_first_last_restatements_against_the_reference_build(dt
             assert (w is not None) == want_valid, (g, w, want_valid)
             if want_valid:
                 assert same(w, vals[rows[g]])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int64, np.int16])
+def test_grouped_moments_restatement_against_the_reference_build(dtype):
+    """O.grouped_moments / O.moments_merge / O.moments_statistic — the restatement of GroupedStatisticImpl the kernel tier
+    compares the device moments with — against the reference's own GroupByNode on one thread over a table of two chunks
+    (= two batches: two-pass moments per batch, Moments::Merge between them): bit for bit where the reference takes its generic
+    path (floats, int64), to rounding for small integers (its ConsumeIntegral sums them exactly); nulls where Finalize leaves
+    a group null."""
+    rng = np.random.default_rng(99 + np.dtype(dtype).itemsize)
+    n, G = 6000, 41
+    gids = rng.integers(0, G, n).astype(np.uint32)
+    gids[:9] = [G, G, G, G, G + 1, G + 1, G + 1, G + 2, G + 2]         # groups of 4, 3 and 2 values (unbiased skew / kurtosis, ddof)
+    G += 3
+    valid = rng.random(n) > 0.2
+    valid[gids == 5] = False                                           # a group of nulls only
+    valid[:9] = True
+    vals = (1e4 + rng.standard_normal(n) * 30).astype(dtype) if np.dtype(dtype).kind == "f" else rng.integers(-3000, 3000, n).astype(dtype)
+    half = n // 2 + 7
+    chunks = [pa.table({"g": pa.array(gids[a:b]), "v": pa.array(vals[a:b], mask=~valid[a:b])}) for a, b in ((0, half), (half, n))]
+    t = pa.concat_tables(chunks)
+    V, S = pc.VarianceOptions, pc.SkewOptions
+    # (function, options, stat, ddof, biased, min_count, skip_nulls)
+    cases = [("variance", V(ddof=0), 0, 0, True, 0, True), ("variance", V(ddof=2, min_count=4), 0, 2, True, 4, True),
+             ("stddev", V(ddof=1, skip_nulls=False), 1, 1, True, 0, False), ("skew", S(), 2, 0, True, 0, True),
+             ("skew", S(biased=False), 2, 0, False, 0, True), ("kurtosis", S(biased=False, min_count=5), 3, 0, False, 5, True),
+             ("kurtosis", S(skip_nulls=False), 3, 0, True, 0, False)]
+    ref = t.group_by("g", use_threads=False).aggregate([("v", f, o) for f, o, *_ in cases]).sort_by("g")
+    assert ref.num_rows == G
+    state = None
+    for a, b in ((0, half), (half, n)):
+        state = O.grouped_moments(vals[a:b], valid[a:b], gids[a:b], G, 4, state)
+    moments, null_seen = state
+    exact = np.dtype(dtype).itemsize == 8 or np.dtype(dtype).kind == "f"
+    stat_cols = [i for i, name in enumerate(ref.schema.names) if name != "g"]      # (the key column comes first or last by version)
+    assert len(stat_cols) == len(cases)
+    for ci, (f, o, stat, ddof, biased, min_count, skip_nulls) in enumerate(cases):
+        col = ref.column(stat_cols[ci])
+        for g in range(G):
+            w = col[g].as_py()
+            mine = O.moments_statistic(moments[g], stat, ddof, biased)
+            if mine is not None and (moments[g][0] < min_count or (not skip_nulls and null_seen[g])):
+                mine = None
+            assert (w is None) == (mine is None), (f, g, w, mine, moments[g])
+            if w is None or (np.isnan(w) and np.isnan(mine)):
+                continue
+            if exact and stat <= 1:
+                assert np.float64(w).view(np.uint64) == np.float64(mine).view(np.uint64), (f, g, w, mine)
+            else:
+                assert abs(w - mine) <= 1e-9 * max(1.0, abs(w)), (f, g, w, mine)
