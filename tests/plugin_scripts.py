@@ -3937,7 +3937,7 @@ ACERO_GUARD_SCRIPT = textwrap.dedent(r"""
     assert lib.arrow_amd_plugin_acero_guard(1) == took1
     # 4. what aggregate_rocm does not serve is REFUSED by name (the stock node would have read the keys on the host)
     ref0 = lib.arrow_amd_plugin_acero_guard(2)
-    for fn in ("hash_variance", "hash_tdigest"):
+    for fn in ("hash_approximate_median", "hash_tdigest"):
         try:
             plan(td, [acero.Declaration("aggregate", acero.AggregateNodeOptions([("v", fn, None, "x")], keys=["k"]))])
             raise SystemExit("a keyed %s over device-resident keys was not refused" % fn)

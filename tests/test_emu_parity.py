@@ -1093,6 +1093,15 @@ def test_groupby_consume_partials(emu_ctx, wide, bits, parts):
         assert parallel.consume_partials_regions(kn.to_device(emu_ctx), v.to_device(emu_ctx), 1 << 12, parts) is None
         assert lib.arx_set_option(b"groupby_partition_min_rows", 1 << 17) == 0
         assert parallel.consume_partials(k.to_device(emu_ctx), v.to_device(emu_ctx), 1 << 12, parts) == (None, None)
+        # more records than the regions hold (every row its own group and a capacity that promises few groups: the rows that
+        # find no place in an LDS table leave as records of their own): declined, the caller goes through the table
+        assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
+        big = 400_000 if bits == 0 else 0
+        if big:
+            kd = U.random_array(rng, np.int32, big, lo=-2**31, hi=2**31 - 1)
+            vd = U.random_array(rng, np.int64, big)
+            assert parallel.consume_partials(kd.to_device(emu_ctx), vd.to_device(emu_ctx), 1 << 12, parts) == (None, None)
+            P.check_groupby_sum(emu_ctx, kd, vd, capacity=1 << 20, use_pyarrow=False)       # (the table path still serves it)
         k16 = U.random_array(rng, np.int16, n, lo=0, hi=100)      # other key types: through the table (its casts)
         assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
         assert parallel.consume_partials_regions(k16.to_device(emu_ctx), v.to_device(emu_ctx), 1 << 12, parts) is None
