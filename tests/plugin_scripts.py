@@ -3944,6 +3944,22 @@ ACERO_GUARD_SCRIPT = textwrap.dedent(r"""
         except pa.ArrowNotImplementedError as e:
             assert "device-resident" in str(e), e
     assert lib.arrow_amd_plugin_acero_guard(2) - ref0 == 2
+    # 4b. host keys (or none) over device VALUE columns: an aggregate whose kernel is the reference's own would read HBM through
+    # host pointers inside the stock node.  Served by aggregate_rocm where it can (hash_list: a takeover), refused by name
+    # where nothing serves it (hash_tdigest under a host key; the scalar variance / tdigest / first of a device column)
+    took2, ref1 = lib.arrow_amd_plugin_acero_guard(1), lib.arrow_amd_plugin_acero_guard(2)
+    got = plan(td, [acero.Declaration("aggregate", acero.AggregateNodeOptions([("v", "hash_list", None, "l")], keys=["s"]))]).sort_by("s")
+    wnt = plan(t, [acero.Declaration("aggregate", acero.AggregateNodeOptions([("v", "hash_list", None, "l")], keys=["s"]))]).sort_by("s")
+    assert got.equals(wnt)
+    assert lib.arrow_amd_plugin_acero_guard(1) == took2 + 1
+    for fn, keys in (("hash_tdigest", ["s"]), ("variance", None), ("tdigest", None), ("first", None)):
+        try:
+            plan(td, [acero.Declaration("aggregate", acero.AggregateNodeOptions([("v", fn, None, "x")], keys=keys))])
+            raise SystemExit("%s over device-resident values was not refused" % fn)
+        except pa.ArrowNotImplementedError as e:
+            assert "device-resident values" in str(e) and fn in str(e), e
+    assert lib.arrow_amd_plugin_acero_guard(2) - ref1 == 4
+    assert plan(t, [acero.Declaration("aggregate", acero.AggregateNodeOptions([("v", "variance", None, "x")]))]).num_rows == 1      # (host tables: the reference's)
     # 5. host tables are untouched, and so is a key-less aggregation over the device table
     assert gb(t, ["k"], A1).equals(want)
     assert t.group_by("k", use_threads=False).aggregate(A1).sort_by("k").equals(want.rename_columns(["k", "v_sum", "v_count", "v_min"]))
