@@ -1144,3 +1144,30 @@ def test_grouped_moments_restatement_against_the_reference_build(dtype):
                 assert np.float64(w).view(np.uint64) == np.float64(mine).view(np.uint64), (f, g, w, mine)
             else:
                 assert abs(w - mine) <= 1e-9 * max(1.0, abs(w)), (f, g, w, mine)
+
+
+def test_grouped_moments_restatement_against_the_references_golden_vectors():
+    """The known answers of the reference's own tests for the grouped moments (acero/hash_aggregate_test.cc:1080-1186:
+    GroupBy.VarianceAndStddev with hash_skew / hash_kurtosis, and GroupBy.VarianceAndStddevDdof with ddof = 2) through
+    O.grouped_moments / O.moments_statistic — the restatement the device kernels are compared with bit for bit."""
+    values = np.array([1, 0, 0, 0, 4, 3, 0, -1, 1, 0], dtype=np.float64)
+    valid = np.array([1, 0, 1, 0, 1, 1, 1, 1, 1, 0], dtype=bool)
+    # keys 1, 1, 2, 3, null, 1, 2, 2, null, 3 -> dense ids in order of first appearance: 1 -> 0, 2 -> 1, 3 -> 2, null -> 3
+    gids = np.array([0, 0, 1, 2, 3, 0, 1, 1, 3, 2], dtype=np.uint32)
+    for dtype in (np.float64, np.int32, np.int64):       # (the reference runs the table for float64 and int32)
+        moments, _ = O.grouped_moments(values.astype(dtype), valid, gids, 4, 4)
+        golden = {  # group: (variance, stddev, skew, kurtosis) with the default options
+            0: (1.0, 1.0, 0.0, -2.0), 1: (0.22222222222222224, 0.4714045207910317, -0.7071067811865478, -1.5), 2: None, 3: (2.25, 1.5, 0.0, -2.0)}
+        for g, want in golden.items():
+            got = [O.moments_statistic(moments[g], stat, 0, True) for stat in range(4)]
+            if want is None:
+                assert got == [None] * 4, (g, got)
+            else:
+                assert np.allclose(got, want, rtol=1e-12, atol=1e-15), (g, got, want)
+        ddof2 = {0: None, 1: (0.6666666666666667, 0.816496580927726), 2: None, 3: None}
+        for g, want in ddof2.items():
+            got = [O.moments_statistic(moments[g], stat, 2, True) for stat in (0, 1)]
+            if want is None:
+                assert got == [None, None], (g, got)
+            else:
+                assert np.allclose(got, want, rtol=1e-12), (g, got, want)
