@@ -582,9 +582,11 @@ int arrow_amd_parquet_read_columns(const char* path, int row_group, const int* c
   return 0;
 }
 // Inputs shorter than this stay on the stock CPU kernels (PCIe staging does not pay).
-// OPT-IN: unmodified Acero plans (table_source / aggregate / order_by by their stock names) over device-resident tables
-// land on the plugin's nodes; 0 switches that off again (the guard below stays).  -1 with arrow_amd_plugin_last_error() when the default
-// registry of this Arrow build was not recognised (nothing is changed then).  plugin/acero_override.inc
+// 1 = OPT-IN: unmodified Acero plans (table_source / aggregate / order_by by their stock names) over device-resident tables
+// land on the plugin's nodes; 0 = what arrow_amd_register() leaves: the guard below + stock `table_source` nodes over
+// device-resident tables deliver whole chunks instead of 32Ki-row morsels (round 6); -1 = the guard alone (the stock
+// source's morsels).  Returns -1 with arrow_amd_plugin_last_error() when the default registry of this Arrow build was
+// not recognised (nothing is changed then).  plugin/acero_override.inc
 // The guard of plugin/acero_override.inc: 1 = installed by arrow_amd_register() (a keyed aggregation over device-resident key
 // columns is built as aggregate_rocm or refused with a Status), 0 = the registry's layout was not recognised.  what = 1:
 // aggregations it turned into aggregate_rocm so far; what = 2: aggregations it refused.
@@ -592,7 +594,7 @@ int64_t arrow_amd_plugin_acero_guard(int what) {
   return what == 1 ? g_guard_takeovers.load() : what == 2 ? g_guard_refusals.load() : (g_acero_guard_installed.load() ? 1 : 0);
 }
 int arrow_amd_override_acero_factories(int on) {
-  const Status st = OverrideAceroFactories(on != 0);
+  const Status st = OverrideAceroFactories(on);
   if (!st.ok()) {
     t_error = st.ToString();
     return -1;
