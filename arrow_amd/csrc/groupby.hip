@@ -2175,6 +2175,8 @@ static std::atomic<int64_t> g_gbp_slices_direct{0}, g_gbp_slices_one_level{0}, g
     g_gbp_slices_wide{0}, g_gbp_slices_probe{0}, g_gbp_slices_rooms{0}, g_gbp_rooms_overflows{0};
 constexpr int kGbpRoomsOverflow = -1000;   // gbp_run_slice: a partition outgrew its room, nothing consumed yet
 
+static int get_groupby_lines_counter(const char* name, int64_t* out);   // groupby_lines.h
+
 int get_groupby_counter(const char* name, int64_t* out) {
   if (strcmp(name, "groupby_slices_direct") == 0) *out = g_gbp_slices_direct.load();
   else if (strcmp(name, "groupby_slices_one_level") == 0) *out = g_gbp_slices_one_level.load();
@@ -2183,7 +2185,7 @@ int get_groupby_counter(const char* name, int64_t* out) {
   else if (strcmp(name, "groupby_slices_probe") == 0) *out = g_gbp_slices_probe.load();
   else if (strcmp(name, "groupby_slices_rooms") == 0) *out = g_gbp_slices_rooms.load();
   else if (strcmp(name, "groupby_rooms_overflows") == 0) *out = g_gbp_rooms_overflows.load();
-  else return 0;
+  else return get_groupby_lines_counter(name, out);
   return 1;
 }
 
@@ -2333,7 +2335,10 @@ static int read_header(void* state, GroupbyHeader* h, hipStream_t st) {
   return ARX_OK;
 }
 
+static int set_groupby_lines_option(const char* name, int64_t value);   // groupby_lines.h
+
 int set_groupby_option(const char* name, int64_t value) {
+  if (set_groupby_lines_option(name, value)) return 1;
   if (strcmp(name, "groupby_partition_min_rows") == 0) {
     g_gbp_min_rows = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, INT32_MAX)));
     return 1;
@@ -2490,6 +2495,8 @@ __global__ __launch_bounds__(256) void groupby_key_range_kernel(const int32_t* _
   }
 }
 
+#include "groupby_lines.h"
+
 }  // namespace arx
 
 using namespace arx;
@@ -2548,7 +2555,7 @@ size_t arx_groupby_consume_workspace_bytes(int64_t length, int64_t capacity) {
     const int64_t rows = std::min<int64_t>(length, int64_t(g_gbp_wide_max_slice));
     need = std::max({need, gbp_plan(rows, capacity, few).total, gbp_plan(rows, capacity, many).total});
   }
-  return need;
+  return std::max(need, gbl_workspace_bytes(length));
 }
 
 struct GbpEmit {   // where the emit form writes (arx_groupby_sum_i64_consume_partials)
@@ -2639,6 +2646,15 @@ static int gb_sum_i64_consume(void* state, int64_t capacity, const ArxSpan* keys
                             : 0;
   if (slice >= kGbTile && slice >= std::min<int64_t>(n, 1 << 16)) {
     uint8_t* w = static_cast<uint8_t*>(ws);
+    // Round 6: keys from a narrow range (ids, codes) take the LINES plan — partitions are slices of the key range, every
+    // store of the scatter a whole 128-byte line, direct-indexed LDS tables (groupby_lines.h).  It declines (a range too
+    // wide, a room that overflowed, a hot key) before anything touched the table; the plans below take the rows then.
+    if (g_gbl && emit == nullptr && n >= g_gbl_min_rows) {
+      const Bits kb = make_bits(kbm, keys_i32->offset, n), vb = make_bits(vbm, values_i64->offset, n);
+      const int rc = (kbm != nullptr || vbm != nullptr) ? gbl_try<true>(v, k, val, kb, vb, n, w, ws_bytes, st)
+                                                          : gbl_try<false>(v, k, val, kb, vb, n, w, ws_bytes, st);
+      if (rc != kGblDeclined) return rc;
+    }
     // The capacity only bounds the number of groups from above (a power of two > 2 G: G is anywhere in its upper half).
     // When that bound asks for the two-level plan but the wide one-level plan is within reach, the first 2^26 rows run
     // as a probe slice on the safe plan; the distinct keys the table holds after it — if the probe saw most of its

@@ -6,6 +6,7 @@ from __future__ import annotations
 import os
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "libarrow_amd_plugin.so")
@@ -32,6 +33,7 @@ def build_plugin(force: bool = False, verbose: bool = True) -> str:
     deps += [os.path.join(parts, f) for f in sorted(os.listdir(parts)) if f.endswith(".inc")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(x) for x in deps):
         return OUT
+    started = time.time()
     cmd = ["g++", "-std=c++20", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
            "-I", pa.get_include(), "-I", "/opt/rocm/include", SRC, "-o", OUT,
            so["arrow"], so["arrow_compute"], so["arrow_acero"], so["parquet"], core, "-L/opt/rocm/lib", "-lamdhip64",
@@ -39,6 +41,7 @@ def build_plugin(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.utime(OUT, (started, started))   # a source edited WHILE this build ran must look newer than its output
     return OUT
 
 

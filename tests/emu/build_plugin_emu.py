@@ -4,6 +4,7 @@ that the shim's device-resident paths can be exercised without a GPU.  TEST INFR
 product build is arrow_amd/plugin_build.py."""
 import os
 import subprocess
+import time
 
 from .build_emu import build as build_emu, build_lock
 
@@ -36,12 +37,14 @@ def _build_plugin(core: str, force: bool, verbose: bool) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(x) for x in deps):
         return OUT
     tmp = OUT + f".tmp{os.getpid()}"
+    started = time.time()
     cmd = ["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-I", os.path.join(HERE, "plugin_hip"),
            "-I", pa.get_include(), src, "-o", tmp, so["arrow"], so["arrow_compute"], so["arrow_acero"], so["parquet"],
            core, f"-Wl,-rpath,{d}", f"-Wl,-rpath,{os.path.dirname(core)}"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.utime(tmp, (started, started))   # a source edited WHILE this (two-minute) build ran must look newer than its output
     os.replace(tmp, OUT)
     return OUT
 

@@ -2129,6 +2129,99 @@ def check_groupby_key_range(amd, rng, scale=1):
                 assert_equal(pair.cpu().numpy(), got, "a narrower column must not move the pair")
 
 
+def _gbl_sampled_unit(s, stride):
+    """gbl_sampled_unit of arrow_amd/csrc/groupby_lines.h (the unit of stratum s that the lines plan's samples read)."""
+    m = (1 << 64) - 1
+    z = (s * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z ^= z >> 29
+    return s * stride + z % stride
+
+
+def check_groupby_lines_plan(amd, rng_for, scale=1, wide_width=True):
+    """The LINES plan of the partitioned consume (groupby_lines.h: partitions = slices of the key range, a scatter whose
+    every store is a whole 128-byte line, direct-indexed LDS tables) forced on at small sizes, every case against the
+    oracle: one-shot and in several consumes, nulls in keys and values at offsets, negative ranges, a full and a
+    sampled histogram, rows outside the sampled range (their own pass), a hot key (rounds without end: the plan gives
+    the rows back untouched), a range too wide or too narrow (declined), the 12288-wide partitions.  The counters say
+    which way every case went."""
+    lib = amd._lib.get_lib()
+    ctr = lambda name: int(lib.arx_get_counter(name))      # noqa: E731
+    knobs = {b"groupby_partition_min_rows": 0, b"groupby_lines_min_rows": 1, b"groupby_lines_wgs": 2,
+             b"groupby_lines_unit_rows": 4096, b"groupby_lines_sample_rows": 1 << 26}
+    for k_, v_ in knobs.items():
+        assert lib.arx_set_option(k_, v_) == 0, k_
+    try:
+        n = 30000 * scale
+        # 1. uniform ids, no nulls, one consume: the plan runs (full histogram: n < the sample)
+        s0, f0, d0 = ctr(b"groupby_slices_lines"), ctr(b"groupby_lines_fallbacks"), ctr(b"groupby_lines_declined")
+        rng = rng_for("gbl", 1)
+        k = util.random_array(rng, np.int32, n, lo=0, hi=50000)
+        v = util.random_array(rng, np.int64, n)
+        check_groupby_sum(amd, k, v, use_pyarrow=False)
+        assert ctr(b"groupby_slices_lines") == s0 + 1 and ctr(b"groupby_lines_fallbacks") == f0, "uniform ids must take the lines plan"
+        # 2. nulls in keys and values, offsets, a range around zero, two consumes into one table, both null options
+        for skip_nulls, min_count in ((True, 1), (False, 2)):
+            rng = rng_for("gbl", 2, skip_nulls)
+            k = util.random_array(rng, np.int32, n, null_p=0.03, offset=3, lo=-30000, hi=30000)
+            v = util.random_array(rng, np.int64, n, null_p=0.1, offset=1)
+            s1 = ctr(b"groupby_slices_lines")
+            check_groupby_sum(amd, k, v, skip_nulls=skip_nulls, min_count=min_count, batches=2, use_pyarrow=skip_nulls)
+            assert ctr(b"groupby_slices_lines") == s1 + 2
+        # 3. a sampled histogram (one 64-row unit in 8) and rows outside the sampled range: keys far away in a unit the
+        #    sample does not read are counted by the scatter and consumed by their own pass
+        assert lib.arx_set_option(b"groupby_lines_sample_rows", max(64, n // 8)) == 0
+        stride = max(1, n // max(64, n // 8))
+        assert stride > 1
+        sampled = {_gbl_sampled_unit(s, stride) for s in range((n + 63) // 64 // stride + 2)}
+        unit = next(u for u in range(5, n // 64 - 1) if u not in sampled)
+        for null_p in (0.0, 0.05):
+            rng = rng_for("gbl", 3, null_p)
+            k = util.random_array(rng, np.int32, n, null_p=null_p, lo=1000, hi=200000)
+            v = util.random_array(rng, np.int64, n, null_p=null_p)
+            far = np.array([2**30 + 7, -2**31, 2**31 - 1, 2**30 + 7, -5], np.int32)
+            k.values[k.offset + unit * 64 + 3: k.offset + unit * 64 + 3 + len(far)] = far
+            s1, o1 = ctr(b"groupby_slices_lines"), ctr(b"groupby_lines_outlier_rows")
+            check_groupby_sum(amd, k, v, use_pyarrow=False)
+            assert ctr(b"groupby_slices_lines") == s1 + 1
+            assert ctr(b"groupby_lines_outlier_rows") - o1 >= (3 if null_p else 4), "the far keys are outside the sampled range"
+        assert lib.arx_set_option(b"groupby_lines_sample_rows", 1 << 26) == 0
+        # 4. a hot key: the scatter would need hundreds of rounds per batch — it gives up, nothing consumed, the other plans run
+        rng = rng_for("gbl", 4)
+        k = util.random_array(rng, np.int32, n, lo=0, hi=50000)
+        k.values[rng.random(len(k.values)) < 0.9] = 4242
+        v = util.random_array(rng, np.int64, n)
+        f1, s1 = ctr(b"groupby_lines_fallbacks"), ctr(b"groupby_slices_lines")
+        check_groupby_sum(amd, k, v, use_pyarrow=False)
+        assert ctr(b"groupby_lines_fallbacks") == f1 + 1 and ctr(b"groupby_slices_lines") == s1, "a hot key must send the rows to the other plans"
+        # 5. declined before anything runs: keys over the whole int32 range, and a range of a few keys
+        for lo, hi in ((-2**31, 2**31 - 1), (10, 500)):
+            rng = rng_for("gbl", 5, lo)
+            k = util.random_array(rng, np.int32, n // 2, lo=lo, hi=hi)
+            v = util.random_array(rng, np.int64, n // 2)
+            d1, s1 = ctr(b"groupby_lines_declined"), ctr(b"groupby_slices_lines")
+            check_groupby_sum(amd, k, v, use_pyarrow=False)
+            assert ctr(b"groupby_lines_declined") == d1 + 1 and ctr(b"groupby_slices_lines") == s1
+        # 6. partitions of 12288 keys (a range beyond 1216 x 8192) and of 8192
+        for hi in ((12_000_000, 9_500_000) if wide_width else ()):
+            rng = rng_for("gbl", 6, hi)
+            k = util.random_array(rng, np.int32, n, null_p=0.01, lo=-1000, hi=hi)
+            v = util.random_array(rng, np.int64, n)
+            s1 = ctr(b"groupby_slices_lines")
+            check_groupby_sum(amd, k, v, use_pyarrow=False)
+            assert ctr(b"groupby_slices_lines") == s1 + 1
+        # 7. wrap-around sums inside a few groups of a dense range
+        rng = rng_for("gbl", 7)
+        k = util.random_array(rng, np.int32, n, lo=100, hi=7000)
+        v = util.random_array(rng, np.int64, n, lo=2**62, hi=2**63 - 1)
+        check_groupby_sum(amd, k, v, use_pyarrow=False)
+        assert d0 <= ctr(b"groupby_lines_declined")
+    finally:
+        for k_, v_ in {b"groupby_partition_min_rows": 1 << 17, b"groupby_lines_min_rows": 1 << 22, b"groupby_lines_wgs": 0,
+                       b"groupby_lines_unit_rows": 1 << 21, b"groupby_lines_sample_rows": 1 << 26}.items():
+            lib.arx_set_option(k_, v_)
+
+
 def check_hash_minmax_count_kernels(amd, rng, n=5000, num_groups=37, null_p=0.2):
     """The dense-id state kernels behind hash_min / hash_max / hash_min_max / hash_count, driven through the C ABI the
     way GroupByNode drives a HashAggregateKernel: two states, resize (fill), consume (arrays at offsets, a broadcast

@@ -361,6 +361,11 @@ def test_groupby_partition_knobs(emu_ctx, l1_global, agg_chunk, bits):
             lib.arx_set_option(k_, v_)
 
 
+def test_groupby_lines_plan(emu_ctx):
+    """Round 6: the dense-range lines plan (write-combined whole-line scatter + direct-indexed LDS aggregate)."""
+    P.check_groupby_lines_plan(emu_ctx, rng_for, wide_width=False)
+
+
 @pytest.mark.parametrize("bits", [0, 1, 5, 9])   # (11 = a second two-level plan: GPU test only)
 def test_groupby_partitioned_path(emu_ctx, bits):
     """The radix-partitioned consume (hist -> scatter level 1 [-> level 2] -> LDS aggregate -> flush)

@@ -112,7 +112,10 @@ def test_config4_hash_sum_1b_rows_10m_keys(gpu_ctx):
         vals[b:e] = torch.randint(-2**63, 2**63 - 1, (e - b,), dtype=torch.int64, device="cuda", generator=g)
     kk = amd.Array(amd.array.int32, n, [None, keys.view(torch.uint8)], 0, 0)
     vv = amd.Array(amd.array.int64, n, [None, vals.view(torch.uint8)], 0, 0)
+    lib = amd._lib.get_lib()
+    lines0 = int(lib.arx_get_counter(b"groupby_slices_lines"))
     gk, gkv, gs, gvalid = amd.compute.group_by_sum(kk, vv, capacity=1 << 25)
+    assert int(lib.arx_get_counter(b"groupby_slices_lines")) == lines0 + 1, "ids from [0, 1e7) must take the lines plan (round 6)"
     assert gk.numel() == groups and bool(gkv.all()) and bool(gvalid.all())
     assert int(gs.sum()) == int(vals.sum())
     want = torch.zeros(groups, dtype=torch.int64, device="cuda")

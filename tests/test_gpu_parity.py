@@ -1412,6 +1412,12 @@ def test_groupby_key_range(gpu_ctx):
     P.check_groupby_key_range(gpu_ctx, rng_for("key-range"), scale=50)
 
 
+def test_groupby_lines_plan(gpu_ctx):
+    """Round 6: the dense-range lines plan (write-combined whole-line scatter + direct-indexed LDS aggregate) on gfx950:
+    every case of the emulated tier at 20x the rows, plus the 12288- and 8192-wide partitions."""
+    P.check_groupby_lines_plan(gpu_ctx, rng_for, scale=20, wide_width=True)
+
+
 def test_hash_any_all_dense_kernels(gpu_ctx):
     P.check_hash_any_all_kernels(gpu_ctx, rng_for("hash-bool"), n=600_000, num_groups=5000)
 
