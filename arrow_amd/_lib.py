@@ -85,6 +85,13 @@ class ArxSortKeyWindow(C.Structure):
     _fields_ = [("key_min", C.c_uint64), ("shift", C.c_int32), ("reserved", C.c_int32)]
 
 
+class ArxRangePlan(C.Structure):
+    """struct ArxRangePlan of include/arrow_amd.h (the range-partitioned group-by state, round 6)."""
+
+    _fields_ = [("key_min", C.c_int32), ("width", C.c_int32), ("partitions", C.c_int32), ("reserved", C.c_int32),
+                ("slots", C.c_int64), ("state_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64)]
+
+
 class ArxBinarySpan(C.Structure):
     """struct ArxBinarySpan of include/arrow_amd.h (binary / utf8 values, int32 offsets)."""
 
@@ -181,6 +188,12 @@ SIGNATURES = {
     "arx_bitmap_popcount": (_int, [_p, _i64, _i64, _p, _sz, C.POINTER(_i64), _p]),
     "arx_bytes_to_bitmap": (_int, [_p, _i64, _p, _p, _p]),
     "arx_groupby_key_range_i32": (_int, [_span, _p, _p]),
+    "arx_groupby_range_plan": (_int, [_i64, C.c_int32, C.c_int32, _p]),
+    "arx_groupby_key_range_sampled_i32": (_int, [_span, _i64, _p, _p]),
+    "arx_groupby_range_sum_i64_consume": (_int, [_p, _p, _span, _span, _p, _sz, _p]),
+    "arx_groupby_range_merge": (_int, [_p, _p, C.c_int32, _i64, _int, _i64, _p]),
+    "arx_groupby_range_finalize_workspace_bytes": (_sz, [_i64]),
+    "arx_groupby_range_finalize": (_int, [_p, C.c_int32, C.c_int32, _i64, C.c_uint32, _p, _sz, _p, _p, _p, _p, _p, _p]),
     "arx_hash_bool_finalize": (_int, [_p, _p, _p, _i64, _int, _int, C.c_uint32, _p, _p, _p, _p]),
     "arx_sort_indices_workspace_bytes": (_sz, [_i64]),
     "arx_sort_indices": (_int, [_span, _int, _int, _int, _p, _sz, _p, _p]),

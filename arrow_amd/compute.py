@@ -1730,6 +1730,106 @@ class GroupBySum:
         return self._typed_keys(p["keys"]), p["key_is_valid"], p["sums"], valid[:g]
 
 
+class RangeGroupBySum:
+    """hash_sum(int64) BY int32 for keys from a narrow range, on the RANGE-PARTITIONED state of include/arrow_amd.h
+    (arx_groupby_range_*; csrc/groupby_lines.h): no hash table — `partitions` dense blocks of `width` keys each,
+    {uint64 sums[width] | uint64 counts[width]}.  The same operator as GroupBySum (ThreadLocalState -> Merge -> Finalize,
+    acero/groupby_aggregate_node.cc:210-337; hash_aggregate_numeric.cc:44-187); rows with nulls, keys outside the
+    planned range and hot keys are declined (consume returns False, nothing consumed) and go through GroupBySum."""
+
+    SAMPLE_ROWS = 1 << 22
+    MIN_ROWS = 1 << 22      # below this group_by_sum / sharded_group_by_sum do not try the state (the table operator's plans)
+
+    @staticmethod
+    def sampled_key_range(keys: Array, sample_rows: int | None = None) -> torch.Tensor:
+        """Device int64[2] = {-min, max} of a sample of the key slots ({-INT32_MAX, INT32_MIN} for no rows): both fold
+        over ranks with ONE all-reduce(MAX)."""
+        lib, stream = _lib_and_stream(keys.device)
+        pair = torch.tensor([2**31 - 1, -2**31], dtype=torch.int32, device=keys.device)
+        if keys.length:
+            span = keys.span()
+            check(lib.arx_groupby_key_range_sampled_i32(C.byref(span), int(sample_rows or RangeGroupBySum.SAMPLE_ROWS),
+                                                        pair.data_ptr(), stream))
+        wide = pair.to(torch.int64)
+        return torch.stack([-wide[0], wide[1]])
+
+    @staticmethod
+    def plan_for(max_rows: int, key_min: int, key_max: int, sampled: bool = True):
+        """The plan for keys in [key_min, key_max] (widened by 1/64 of the range on both sides when the bounds come from a
+        sample) or None when the range does not suit the state."""
+        if key_min > key_max:
+            return None
+        pad = ((key_max - key_min + 1) // 64 + 1) if sampled else 0
+        lo, hi = max(-2**31, key_min - pad), min(2**31 - 1, key_max + pad)
+        plan = _lib.ArxRangePlan()
+        rc = _lib.get_lib().arx_groupby_range_plan(int(max_rows), lo, hi, C.byref(plan))
+        if rc == _lib.ARX_NOT_IMPLEMENTED:
+            return None
+        check(rc)
+        return plan
+
+    def __init__(self, plan, device=None, options: ScalarAggregateOptions | None = None):
+        from .array import default_device
+
+        self.plan = plan
+        self.device = torch.device(device) if device is not None else default_device()
+        self.options = options or ScalarAggregateOptions()
+        self.state = torch.zeros(int(plan.state_bytes) // 8, dtype=torch.int64, device=self.device)
+
+    def partition_bytes(self) -> int:
+        return int(self.plan.width) * 16
+
+    def consume(self, keys: Array, values: Array) -> bool:
+        """Adds the rows' groups; False = declined (nothing consumed): nulls, a key outside the plan, a hot key."""
+        if keys.type != int32 or values.type != int64:
+            return False
+        if (keys.null_count != 0 and keys.buffers[0] is not None) or (values.null_count != 0 and values.buffers[0] is not None):
+            return False
+        if keys.length == 0:
+            return True
+        lib, stream = _lib_and_stream(self.device)
+        probe = _lib.ArxRangePlan()
+        check(lib.arx_groupby_range_plan(keys.length, self.plan.key_min, self.plan.key_min + int(self.plan.slots) - 1, C.byref(probe)))
+        ws = _workspace(self.device, int(probe.workspace_bytes) + 256, "groupby")
+        ks, vs = keys.span(), values.span()
+        rc = lib.arx_groupby_range_sum_i64_consume(self.state.data_ptr(), C.byref(self.plan), C.byref(ks), C.byref(vs),
+                                                   ws.data_ptr(), ws.numel(), stream)
+        if rc in (_lib.ARX_CAPACITY_ERROR, _lib.ARX_NOT_IMPLEMENTED):
+            return False
+        check(rc)
+        return True
+
+    def merge_blocks(self, first_partition: int, num_partitions: int, others: torch.Tensor, num_others: int) -> None:
+        """partitions [first, first + num) += the same partitions of num_others states lying one behind the other in
+        `others` (a uint8 / int64 tensor of num_others x num_partitions x width x 16 bytes)."""
+        if num_partitions == 0 or num_others == 0:
+            return
+        lib, stream = _lib_and_stream(self.device)
+        stride = num_partitions * self.partition_bytes()
+        dst = self.state.data_ptr() + first_partition * self.partition_bytes()
+        check(lib.arx_groupby_range_merge(dst, others.data_ptr(), self.plan.width, num_partitions, num_others, stride, stream))
+
+    def finalize(self, first_partition: int = 0, num_partitions: int | None = None, blocks: torch.Tensor | None = None):
+        """(keys, key_is_valid, sums, valid) of the partitions [first, first + num), ascending by key — the tuple
+        GroupBySum.finalize returns.  `blocks`: finalize these partitions' blocks from another buffer instead of the state."""
+        lib, stream = _lib_and_stream(self.device)
+        if num_partitions is None:
+            num_partitions = int(self.plan.partitions) - first_partition
+        slots = num_partitions * int(self.plan.width)
+        dev = self.device
+        keys = torch.empty(max(slots, 1), dtype=torch.int32, device=dev)
+        sums = torch.empty(max(slots, 1), dtype=torch.int64, device=dev)
+        valid = torch.empty(max(slots, 1), dtype=torch.uint8, device=dev)
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws = alloc(lib.arx_groupby_range_finalize_workspace_bytes(slots), dev)
+        src = (blocks.data_ptr() if blocks is not None else self.state.data_ptr() + first_partition * self.partition_bytes())
+        check(lib.arx_groupby_range_finalize(src, self.plan.key_min + first_partition * int(self.plan.width), self.plan.width,
+                                             num_partitions, int(self.options.min_count), ws.data_ptr(), ws.numel(),
+                                             keys.data_ptr(), sums.data_ptr(), None, valid.data_ptr(), count.data_ptr(), stream))
+        g = int(count.item())
+        return keys[:g], torch.ones(g, dtype=torch.uint8, device=dev), sums[:g], valid[:g]
+
+
 def indices_nonzero(arr: Array) -> Array:
     """compute::IndicesNonZero (kernels/vector_selection.cc:352, vector_selection.cc DoNonZero): the uint64 positions
     of the elements that are valid and non-zero (true for booleans), ascending.  = GetTakeIndices of the mask
@@ -2155,7 +2255,17 @@ def _hash_mean_from_dense(st: "GroupedSumInt64State", values: Array) -> Array:
 
 def group_by_sum(keys: Array, values: Array, capacity: int | None = None,
                  options: ScalarAggregateOptions | None = None):
-    """Table.group_by(k).aggregate([(v, 'sum')]) for one int32 key and one int64 value."""
+    """Table.group_by(k).aggregate([(v, 'sum')]) for one int32 key and one int64 value.  Large null-free inputs whose keys
+    come from a narrow range go through the range-partitioned state (RangeGroupBySum: no hash table, groups in key order);
+    everything else — and whatever that state declines — through the table operator."""
+    if (keys.type == int32 and values.type == int64 and keys.length >= RangeGroupBySum.MIN_ROWS and
+            not (keys.null_count != 0 and keys.buffers[0] is not None) and not (values.null_count != 0 and values.buffers[0] is not None)):
+        neg_lo, hi = [int(x) for x in RangeGroupBySum.sampled_key_range(keys).cpu().tolist()]
+        plan = RangeGroupBySum.plan_for(keys.length, -neg_lo, hi) if -neg_lo <= hi else None
+        if plan is not None:
+            st = RangeGroupBySum(plan, keys.device, options)
+            if st.consume(keys, values):
+                return st.finalize()
     cap = capacity or max(16, 2 * keys.length + 2)
     op = GroupBySum(cap, keys.device, options)
     op.consume(keys, values)

@@ -2555,7 +2555,7 @@ size_t arx_groupby_consume_workspace_bytes(int64_t length, int64_t capacity) {
     const int64_t rows = std::min<int64_t>(length, int64_t(g_gbp_wide_max_slice));
     need = std::max({need, gbp_plan(rows, capacity, few).total, gbp_plan(rows, capacity, many).total});
   }
-  return std::max(need, gbl_workspace_bytes(length));
+  return std::max(need, length >= g_gbl_min_rows ? gbl_workspace_bytes(length, true) : size_t(0));
 }
 
 struct GbpEmit {   // where the emit form writes (arx_groupby_sum_i64_consume_partials)
@@ -2796,6 +2796,147 @@ int arx_groupby_key_range_i32(const ArxSpan* keys, int32_t* out_min_max, void* s
   hipLaunchKernelGGL(groupby_key_range_kernel, dim3(std::max(grid, 1u)), dim3(256), 0, as_stream(stream), k, keys->length,
                      out_min_max);
   ARX_CHECK_LAUNCH("groupby_key_range_kernel");
+  return ARX_OK;
+}
+
+// ---- the range-partitioned state (groupby_lines.h)
+int arx_groupby_range_plan(int64_t max_rows, int32_t key_min, int32_t key_max, ArxRangePlan* out) {
+  if (out == nullptr || max_rows < 0 || key_min > key_max) {
+    set_error("bad arguments to arx_groupby_range_plan");
+    return ARX_INVALID;
+  }
+  int width = 0, wshift = 0, bins = 0;
+  GblPlan plan{};
+  if (!gbl_partitions(key_min, key_max, &width, &wshift, &bins) ||
+      !gbl_plan(std::max<int64_t>(max_rows, 1), key_min, width, wshift, bins, false, &plan)) {
+    set_error("arx_groupby_range_plan: keys in [%d, %d] need more than %d partitions of %d keys, or fewer than %d of 128 "
+              "(or too many rows for one pass): use the table operator", key_min, key_max, kGblMaxBins, kGblMaxWidth, kGblMinBins);
+    return ARX_NOT_IMPLEMENTED;
+  }
+  out->key_min = key_min;
+  out->width = width;
+  out->partitions = bins;
+  out->reserved = 0;
+  out->slots = static_cast<int64_t>(bins) * width;
+  out->state_bytes = static_cast<uint64_t>(out->slots) * 16;
+  out->workspace_bytes = plan.total + 256;
+  return ARX_OK;
+}
+
+int arx_groupby_key_range_sampled_i32(const ArxSpan* keys, int64_t sample_rows, int32_t* out_min_max, void* stream) {
+  if (keys == nullptr || out_min_max == nullptr || keys->length < 0 || (keys->length > 0 && keys->data == nullptr)) {
+    set_error("bad arguments to arx_groupby_key_range_sampled_i32");
+    return ARX_INVALID;
+  }
+  if (keys->length == 0) return ARX_OK;
+  return gbl_sample_range(static_cast<const int32_t*>(keys->data) + keys->offset, keys->length, std::max<int64_t>(sample_rows, 64),
+                          out_min_max, as_stream(stream));
+}
+
+int arx_groupby_range_sum_i64_consume(void* state, const ArxRangePlan* plan, const ArxSpan* keys_i32, const ArxSpan* values_i64,
+                                      void* ws, size_t ws_bytes, void* stream) {
+  if (state == nullptr || plan == nullptr || keys_i32 == nullptr || values_i64 == nullptr) {
+    set_error("NULL argument to arx_groupby_range_sum_i64_consume");
+    return ARX_INVALID;
+  }
+  if (keys_i32->length != values_i64->length) {
+    set_error("Array arguments must all be the same length (keys %lld vs values %lld)", static_cast<long long>(keys_i32->length),
+              static_cast<long long>(values_i64->length));
+    return ARX_INVALID;
+  }
+  const int64_t n = keys_i32->length;
+  if (n == 0) return ARX_OK;
+  if ((keys_i32->null_count != 0 && keys_i32->validity != nullptr) || (values_i64->null_count != 0 && values_i64->validity != nullptr)) {
+    set_error("arx_groupby_range_sum_i64_consume: rows with nulls go through the table operator (arx_groupby_sum_i64_consume)");
+    return ARX_NOT_IMPLEMENTED;
+  }
+  const bool pow2 = plan->width >= 128 && plan->width <= 8192 && (plan->width & (plan->width - 1)) == 0;
+  if ((!pow2 && plan->width != kGblMaxWidth) || plan->partitions < 1 || plan->partitions > kGblMaxBins ||
+      plan->slots != static_cast<int64_t>(plan->partitions) * plan->width || (reinterpret_cast<uint64_t>(state) & 15) != 0) {
+    set_error("arx_groupby_range_sum_i64_consume: not a plan of arx_groupby_range_plan (or a state that is not 16-byte aligned)");
+    return ARX_INVALID;
+  }
+  int wshift = 0;
+  if (pow2) {
+    while ((1 << wshift) < plan->width) ++wshift;
+  }
+  uint8_t* w = reinterpret_cast<uint8_t*>((reinterpret_cast<uint64_t>(ws) + 255) & ~uint64_t(255));
+  const size_t lost = ws == nullptr ? 0 : static_cast<size_t>(w - static_cast<uint8_t*>(ws));
+  GblPlan gp{};
+  if (ws == nullptr || ws_bytes < lost || !gbl_plan(n, plan->key_min, plan->width, wshift, plan->partitions, false, &gp) ||
+      gp.total > ws_bytes - lost) {
+    set_error("arx_groupby_range_sum_i64_consume: %lld rows need %llu bytes of scratch", static_cast<long long>(n),
+              static_cast<unsigned long long>(gp.total + 256));
+    return ARX_CAPACITY_ERROR;
+  }
+  hipStream_t st = as_stream(stream);
+  GblArgs a{};
+  a.keys = static_cast<const int32_t*>(keys_i32->data) + keys_i32->offset;
+  a.values = static_cast<const int64_t*>(values_i64->data) + values_i64->offset;
+  a.kvalid = make_bits(nullptr, 0, n);
+  a.vvalid = make_bits(nullptr, 0, n);
+  a.n = n;
+  gbl_bind(a, gp, w);
+  a.dense = static_cast<uint8_t*>(state);
+  uint32_t flags[4] = {0, 0, 0, 0};
+  const int prc = gbl_partition<false>(a, flags, st);
+  if (prc != ARX_OK) return prc;
+  if (flags[0] != 0 || flags[1] != 0 || flags[2] != 0) {
+    g_gbl_fallbacks.fetch_add(1, std::memory_order_relaxed);
+    set_error("arx_groupby_range_sum_i64_consume: %s — nothing consumed, use the table operator for these rows",
+              flags[2] != 0 ? "keys outside the plan's range" : flags[1] != 0 ? "a hot key (rounds without end)" : "a partition outgrew its room");
+    return ARX_CAPACITY_ERROR;
+  }
+  g_gbl_slices.fetch_add(1, std::memory_order_relaxed);
+  return gbl_aggregate(a, st);
+}
+
+int arx_groupby_range_merge(void* state, const void* others, int32_t width, int64_t num_partitions, int num_others,
+                            int64_t others_stride_bytes, void* stream) {
+  if (state == nullptr || others == nullptr || width < 1 || num_partitions < 0 || num_others < 0 || (others_stride_bytes & 7) != 0) {
+    set_error("bad arguments to arx_groupby_range_merge");
+    return ARX_INVALID;
+  }
+  const int64_t words = num_partitions * width * 2;
+  if (words == 0 || num_others == 0) return ARX_OK;
+  hipLaunchKernelGGL(gbl_merge_kernel, dim3(gb_grid(words)), dim3(kBlock), 0, as_stream(stream), static_cast<unsigned long long*>(state),
+                     static_cast<const unsigned long long*>(others), words, num_others, others_stride_bytes / 8);
+  ARX_CHECK_LAUNCH("gbl_merge_kernel");
+  return ARX_OK;
+}
+
+size_t arx_groupby_range_finalize_workspace_bytes(int64_t slots) {
+  return static_cast<size_t>(ceil_div(std::max<int64_t>(slots, 1), kGblTile)) * 8 + 256;
+}
+
+int arx_groupby_range_finalize(const void* partitions, int32_t first_key, int32_t width, int64_t num_partitions, uint32_t min_count,
+                               void* ws, size_t ws_bytes, int32_t* out_keys, int64_t* out_sums, int64_t* out_counts,
+                               uint8_t* out_valid, int64_t* out_num_groups, void* stream) {
+  if (width < 1 || num_partitions < 0 || out_num_groups == nullptr) {
+    set_error("bad arguments to arx_groupby_range_finalize");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  const int64_t slots = num_partitions * width;
+  if (slots == 0) {
+    ARX_HIP(hipMemsetAsync(out_num_groups, 0, 8, st));
+    return ARX_OK;
+  }
+  if (partitions == nullptr || out_keys == nullptr || out_sums == nullptr || out_valid == nullptr || ws == nullptr ||
+      ws_bytes < arx_groupby_range_finalize_workspace_bytes(slots)) {
+    set_error("arx_groupby_range_finalize: NULL buffer or too little scratch");
+    return ARX_INVALID;
+  }
+  unsigned long long* tiles = reinterpret_cast<unsigned long long*>((reinterpret_cast<uint64_t>(ws) + 7) & ~uint64_t(7));
+  const int64_t ntiles = ceil_div(slots, kGblTile);
+  const uint8_t* d = static_cast<const uint8_t*>(partitions);
+  hipLaunchKernelGGL(gbl_finalize_count_kernel, dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, d, width, slots, tiles);
+  ARX_CHECK_LAUNCH("gbl_finalize_count_kernel");
+  hipLaunchKernelGGL(gbl_finalize_scan_kernel, dim3(1), dim3(1024), 0, st, tiles, ntiles, out_num_groups);
+  ARX_CHECK_LAUNCH("gbl_finalize_scan_kernel");
+  hipLaunchKernelGGL(gbl_finalize_emit_kernel, dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, d, width, slots, first_key,
+                     static_cast<unsigned long long>(min_count), tiles, out_keys, out_sums, out_counts, out_valid);
+  ARX_CHECK_LAUNCH("gbl_finalize_emit_kernel");
   return ARX_OK;
 }
 

@@ -29,7 +29,7 @@
 constexpr int kGblThreads = 1024;
 constexpr int kGblMaxBins = 1216;            // 1216 x 128 B of line buffers = 152 KB of the CU's 160 KB
 constexpr int kGblCap = 12;                  // records per line
-constexpr int kGblK = 4;                     // lines per chunk (one global atomic each)
+constexpr int kGblK = 8;                     // lines per chunk (one global atomic each: WRITE_SIZE counts 32 bytes for it)
 constexpr int kGblR = 4;                     // rows per thread and batch (8: the registers spill)
 constexpr int kGblCursorStride = 32;         // u32 between two bins' cursors: a 128-byte line each
 constexpr int kGblMaxWidth = 12288;          // groups per partition: sums u64 + counts u32 = 144 KB of LDS
@@ -58,6 +58,7 @@ struct GblArgs {
   uint32_t* flags;         // [0] a room / the buffer overflowed, [1] rounds without end, [2] rows outside [kmin, kmin + bins * width)
   uint32_t* unit_start;    // [bins + 1] aggregate work units before bin b
   uint8_t* lines;
+  uint8_t* dense;          // where the aggregate adds a partition's sums and counts: bin b at b * width * 16 = {u64 sums[width], u64 counts[width]} (64-bit counts: a state may take more than 2^32 rows of one key over its consumes and merges)
 };
 
 __device__ __forceinline__ void gbl_split(const GblArgs& a, uint32_t d, uint32_t& bin, uint32_t& rem) {
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void gbl_outliers_kernel(GroupbyView v, Gbl
 
 // ---- the direct-indexed LDS aggregate over a bin's lines
 constexpr int kGblAggX = 4;   // 16-byte pieces a thread keeps in flight
-__global__ __launch_bounds__(kGblThreads) void gbl_aggregate_kernel(GroupbyView v, GblArgs a) {
+__global__ __launch_bounds__(kGblThreads) void gbl_aggregate_kernel(GblArgs a) {
   __shared__ unsigned long long sums[kGblMaxWidth];
   __shared__ uint32_t cnts[kGblMaxWidth];
   __shared__ uint32_t unit_bin, unit_first, unit_end;
@@ -621,39 +622,161 @@ __global__ __launch_bounds__(kGblThreads) void gbl_aggregate_kernel(GroupbyView 
     }
   }
   __syncthreads();
-  uint32_t fresh = 0;
-  const int32_t key0 = a.kmin + static_cast<int32_t>(bin * static_cast<uint32_t>(a.width));
+  // the unit's partial aggregates into the partition's slice of the DENSE state: consecutive lanes, consecutive addresses
+  // (a wave's 64 adds are a few line-sized requests, not 64 — what the per-group table flush of the other plans costs)
+  unsigned long long* dsum = reinterpret_cast<unsigned long long*>(a.dense + static_cast<size_t>(bin) * a.width * 16);
+  unsigned long long* dcnt = dsum + a.width;
   for (int i = tid; i < a.width; i += kGblThreads) {
     const uint32_t c = cnts[i];
     if (c == 0) continue;
-    const int64_t slot = gb_find_or_insert(v, key0 + i, &fresh);
+    atomicAdd(&dsum[i], sums[i]);
+    atomicAdd(&dcnt[i], static_cast<unsigned long long>(c));
+  }
+}
+
+// ---- the dense state's groups into the HBM table (the table API: arx_groupby_sum_i64_consume)
+__global__ __launch_bounds__(kBlock) void gbl_table_insert_kernel(GroupbyView v, GblArgs a) {
+  const int64_t slots = static_cast<int64_t>(a.bins) * a.width;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  uint32_t fresh = 0;
+  for (int64_t s = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; s < slots; s += stride) {
+    const int64_t bin = s / a.width, i = s - bin * a.width;
+    const unsigned long long* base = reinterpret_cast<const unsigned long long*>(a.dense + static_cast<size_t>(bin) * a.width * 16);
+    const unsigned long long c = base[a.width + i];
+    if (c == 0) continue;
+    const int64_t slot = gb_find_or_insert(v, a.kmin + static_cast<int32_t>(s), &fresh);
     if (slot < 0) {
       atomicExch(&v.hdr->overflow, 1u);
       continue;
     }
-    atomicAdd(&v.sums[slot], sums[i]);
-    atomicAdd(&v.counts[slot], static_cast<unsigned long long>(c));
+    atomicAdd(&v.sums[slot], base[i]);
+    atomicAdd(&v.counts[slot], c);
   }
   gb_publish_new_groups(v, fresh);
+}
+
+// ---- finalize of a dense state: the groups of partitions [first, first + count) in KEY ORDER.  Pass 1 counts the
+// non-empty slots of every 4096-slot tile, one workgroup scans the tiles, pass 2 writes.
+constexpr int kGblTile = 4096;
+__global__ __launch_bounds__(kBlock) void gbl_finalize_count_kernel(const uint8_t* __restrict__ dense, int width, int64_t slots,
+                                                                    unsigned long long* __restrict__ tile_counts) {
+  __shared__ uint32_t part[kWavesPerBlock];
+  const int64_t s0 = static_cast<int64_t>(blockIdx.x) * kGblTile;
+  uint32_t mine = 0;
+  for (int j = threadIdx.x; j < kGblTile; j += kBlock) {
+    const int64_t s = s0 + j;
+    if (s < slots) {
+      const int64_t bin = s / width, i = s - bin * width;
+      mine += reinterpret_cast<const unsigned long long*>(dense + static_cast<size_t>(bin) * width * 16)[width + i] != 0 ? 1u : 0u;
+    }
+  }
+  mine = wave_reduce_sum_u32(mine);
+  if (lane_id() == 0) part[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) t += part[w];
+    tile_counts[blockIdx.x] = t;
+  }
+}
+
+// exclusive scan of the tile counts in place (one workgroup); the total lands in *out_total
+__global__ __launch_bounds__(1024) void gbl_finalize_scan_kernel(unsigned long long* __restrict__ tile_counts, int64_t ntiles,
+                                                                 int64_t* __restrict__ out_total) {
+  __shared__ unsigned long long wave_tot[16];
+  __shared__ unsigned long long carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int64_t t0 = 0; t0 < ntiles; t0 += 1024) {
+    const int64_t t = t0 + tid;
+    const unsigned long long c = t < ntiles ? tile_counts[t] : 0ull;
+    const unsigned long long incl = wave_inclusive_scan_u64(c);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned long long pre = carry + incl - c;
+    for (int k = 0; k < wave; ++k) pre += wave_tot[k];
+    if (t < ntiles) tile_counts[t] = pre;
+    __syncthreads();
+    if (tid == 1023) carry = pre + c;
+    __syncthreads();
+  }
+  if (tid == 0) *out_total = static_cast<int64_t>(carry);
+}
+
+__global__ __launch_bounds__(kBlock) void gbl_finalize_emit_kernel(const uint8_t* __restrict__ dense, int width, int64_t slots, int32_t key0,
+                                                                   unsigned long long min_count, const unsigned long long* __restrict__ tile_starts,
+                                                                   int32_t* __restrict__ out_keys, int64_t* __restrict__ out_sums,
+                                                                   int64_t* __restrict__ out_counts, uint8_t* __restrict__ out_valid) {
+  __shared__ uint32_t wave_base[kWavesPerBlock];
+  __shared__ uint32_t run;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int64_t s0 = static_cast<int64_t>(blockIdx.x) * kGblTile;
+  if (threadIdx.x == 0) run = 0;
+  __syncthreads();
+  const unsigned long long base = tile_starts[blockIdx.x];
+  for (int j0 = 0; j0 < kGblTile; j0 += kBlock) {   // (workgroup-uniform trip count: ballots + barriers below)
+    const int64_t s = s0 + j0 + threadIdx.x;
+    unsigned long long c = 0, sum = 0;
+    if (s < slots) {
+      const int64_t bin = s / width, i = s - bin * width;
+      const unsigned long long* b = reinterpret_cast<const unsigned long long*>(dense + static_cast<size_t>(bin) * width * 16);
+      c = b[width + i];
+      if (c != 0) sum = b[i];
+    }
+    const uint64_t live = __ballot(c != 0);
+    if (lane == 0) wave_base[wave] = static_cast<uint32_t>(__popcll(live));
+    __syncthreads();
+    uint32_t before = run;
+    for (int w = 0; w < wave; ++w) before += wave_base[w];
+    if (c != 0) {
+      const unsigned long long at = base + before + static_cast<uint32_t>(__popcll(live & ((uint64_t(1) << lane) - 1)));
+      out_keys[at] = key0 + static_cast<int32_t>(s);
+      out_sums[at] = static_cast<int64_t>(sum);
+      if (out_counts != nullptr) out_counts[at] = static_cast<int64_t>(c);
+      out_valid[at] = c >= min_count ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < kWavesPerBlock; ++w) t += wave_base[w];
+      run += t;
+    }
+    __syncthreads();
+  }
+}
+
+// dst += the same words of `count` other states that lie `stride_words` apart (Merge of the dense state: sums wrap, counts
+// add — both 64-bit words; the P blocks a rank received for its partitions are summed in ONE pass)
+__global__ __launch_bounds__(kBlock) void gbl_merge_kernel(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src,
+                                                           int64_t words, int count, int64_t stride_words) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; w < words; w += stride) {
+    unsigned long long acc = dst[w];
+    for (int r = 0; r < count; ++r) acc += src[r * stride_words + w];
+    dst[w] = acc;
+  }
 }
 
 // ---- host side
 static Knob<int> g_gbl{1};                         // 1: the lines plan where the sampled key range allows it (A/B knob groupby_lines; 0 = off)
 static Knob<int64_t> g_gbl_min_rows{int64_t(1) << 22};   // below this the other plans (knob groupby_lines_min_rows)
-static Knob<int64_t> g_gbl_sample_rows{int64_t(1) << 26};   // rows the range / histogram samples read (knob groupby_lines_sample_rows)
+static Knob<int64_t> g_gbl_sample_rows{int64_t(1) << 26};   // rows the histogram sample reads (knob groupby_lines_sample_rows)
+static Knob<int64_t> g_gbl_range_sample_rows{int64_t(1) << 22};   // rows the key-range sample reads (knob groupby_lines_range_sample_rows)
 static Knob<int> g_gbl_unit_rows{1 << 21};         // rows per aggregate work unit (knob groupby_lines_unit_rows)
 static Knob<int> g_gbl_wgs{0};                     // workgroups of the scatter (0: one per CU; knob groupby_lines_wgs — tests)
 static std::atomic<int64_t> g_gbl_slices{0}, g_gbl_fallbacks{0}, g_gbl_outlier_rows{0}, g_gbl_declined{0};
 
 struct GblPlan {
+  int64_t kmin;
   int width, wshift, bins, wgs;
   int64_t sample_stride, rows_per_wg;
   uint32_t total_lines, unit_lines;
-  size_t off_lines, off_cursor, off_room_start, off_hist, off_flags, off_unit_start, off_range, total;
+  size_t off_lines, off_cursor, off_room_start, off_hist, off_flags, off_unit_start, off_dense, total;
 };
 
 // lines the buffer must hold for n rows in `bins` bins scattered by `wgs` workgroups (what gbl_rooms_kernel asks for
-// with an even spread; an uneven one needs a little more and falls back if the caller's scratch does not have it)
+// with an even spread — the worst case of its 6-sigma terms; an uneven spread needs no more)
 static int64_t gbl_lines_for(int64_t n, int bins, int wgs, int64_t stride) {
   const double per_bin = static_cast<double>(n) / bins;
   const double sigma = stride > 1 ? std::sqrt(per_bin * static_cast<double>(stride) + 1.0) : 0.0;
@@ -663,41 +786,55 @@ static int64_t gbl_lines_for(int64_t n, int bins, int wgs, int64_t stride) {
 }
 
 static int gbl_cus() {
-  static int cus = 0;
-  if (cus == 0) {
+  static std::atomic<int> cus{0};
+  int c = cus.load(std::memory_order_relaxed);
+  if (c == 0) {
     int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-    else cus = 256;
+    c = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    cus.store(c, std::memory_order_relaxed);
   }
-  return cus;
+  return c;
 }
 
-// the plan for n rows with keys in [kmin, kmax]; false: the range is too wide (or too narrow) for it
-static bool gbl_plan(int64_t n, int64_t kmin, int64_t kmax, GblPlan* p) {
+static int64_t gbl_stride_for(int64_t n, int64_t sample_rows) {
+  return std::max<int64_t>(1, n / std::max<int64_t>(sample_rows, kGblUnitRows));
+}
+
+// Partitions for keys in [kmin, kmax]: the narrowest width (128 ... 8192, 12288) that needs at most kGblMaxBins of them.
+// false: the range is too wide, or so narrow that the other plans' single LDS table is the better tool.
+static bool gbl_partitions(int64_t kmin, int64_t kmax, int* width, int* wshift, int* bins) {
   const int64_t range = kmax - kmin + 1;
   if (range < 1) return false;
-  int width = 128, wshift = 7;
-  while (wshift < 13 && (range + width - 1) / width > kGblMaxBins) {
-    ++wshift;
-    width <<= 1;
+  int w = 128, sh = 7;
+  while (sh < 13 && (range + w - 1) / w > kGblMaxBins) {
+    ++sh;
+    w <<= 1;
   }
-  if ((range + width - 1) / width > kGblMaxBins) {
-    width = kGblMaxWidth;
-    wshift = 0;
+  if ((range + w - 1) / w > kGblMaxBins) {
+    w = kGblMaxWidth;
+    sh = 0;
   }
-  const int64_t bins = (range + width - 1) / width;
-  if (bins > kGblMaxBins || bins < kGblMinBins) return false;
-  if (kmin + bins * width - 1 - kmin >= (int64_t(1) << 28)) return false;   // (gbl_split's division by 3)
+  const int64_t b = (range + w - 1) / w;
+  if (b > kGblMaxBins || b < kGblMinBins) return false;
+  *width = w;
+  *wshift = sh;
+  *bins = static_cast<int>(b);
+  return true;
+}
+
+// the scratch layout of one pass over n rows (with_dense: the table path keeps the dense state in the scratch too)
+static bool gbl_plan(int64_t n, int64_t kmin, int width, int wshift, int bins, bool with_dense, GblPlan* p) {
+  p->kmin = kmin;
   p->width = width;
   p->wshift = wshift;
-  p->bins = static_cast<int>(bins);
+  p->bins = bins;
   const int64_t batch = int64_t(kGblR) * kGblThreads;
   int wgs = g_gbl_wgs > 0 ? int(g_gbl_wgs) : gbl_cus();
   wgs = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(wgs, n / (int64_t(1) << 18))));   // >= 2^18 rows per workgroup: chunk tails stay small
   p->wgs = wgs;
   p->rows_per_wg = ceil_div(ceil_div(n, wgs), batch) * batch;
-  p->sample_stride = std::max<int64_t>(1, n / std::max<int64_t>(int64_t(g_gbl_sample_rows), kGblUnitRows));
-  const int64_t lines = gbl_lines_for(n, p->bins, wgs, p->sample_stride);
+  p->sample_stride = gbl_stride_for(n, g_gbl_sample_rows);
+  const int64_t lines = gbl_lines_for(n, bins, wgs, p->sample_stride);
   if (lines >= (int64_t(1) << 31) - 4096) return false;   // (the scatter keeps line << 1 | flag in 32 bits)
   p->total_lines = static_cast<uint32_t>(lines);
   p->unit_lines = static_cast<uint32_t>(std::max<int64_t>(64, int64_t(g_gbl_unit_rows) / kGblCap));
@@ -709,56 +846,25 @@ static bool gbl_plan(int64_t n, int64_t kmin, int64_t kmax, GblPlan* p) {
   p->off_hist = o; o = align(o + kGblMaxBins * 4);
   p->off_flags = o; o = align(o + 16);
   p->off_unit_start = o; o = align(o + (kGblMaxBins + 1) * 4);
+  p->off_dense = o; o = align(o + (with_dense ? static_cast<size_t>(bins) * width * 16 : 0));
   p->total = o;
   return true;
 }
 
-// scratch the lines plan may ask for at most for `n` rows (any key range it accepts)
-static size_t gbl_workspace_bytes(int64_t n) {
-  if (!g_gbl || n < g_gbl_min_rows) return 0;
+// scratch the lines plan may ask for at most for `n` rows (any key range it accepts; with_dense: + the dense state)
+static size_t gbl_workspace_bytes(int64_t n, bool with_dense) {
+  if (!g_gbl || n < 1) return 0;
   const int wgs = g_gbl_wgs > 0 ? int(g_gbl_wgs) : gbl_cus();
-  const int64_t stride = std::max<int64_t>(1, n / std::max<int64_t>(int64_t(g_gbl_sample_rows), kGblUnitRows));
-  int64_t lines = 0;
-  for (int bins : {kGblMinBins, 256, kGblMaxBins}) lines = std::max(lines, gbl_lines_for(n, bins, wgs, stride));
-  return static_cast<size_t>(lines) * 128 + (size_t(kGblMaxBins) * kGblCursorStride * 4 + 4 * (kGblMaxBins + 1) * 4 + 4096);
+  const int64_t lines = gbl_lines_for(n, kGblMaxBins, wgs, gbl_stride_for(n, g_gbl_sample_rows));
+  return static_cast<size_t>(lines) * 128 + (size_t(kGblMaxBins) * kGblCursorStride * 4 + 4 * (kGblMaxBins + 1) * 4 + 4096) +
+         (with_dense ? static_cast<size_t>(kGblMaxBins) * kGblMaxWidth * 16 + 256 : 0);
 }
 
-constexpr int kGblDeclined = -2000;   // gbl_try: the plan does not apply / gave up — nothing was consumed
+constexpr int kGblDeclined = -2000;   // the plan does not apply / gave up — nothing was consumed
 
-// All n rows through the lines plan, or kGblDeclined (nothing consumed: the other plans take the rows).
-template <bool HAS_NULLS>
-static int gbl_try(const GroupbyView& v, const int32_t* k, const int64_t* val, Bits kb, Bits vb, int64_t n, uint8_t* w, size_t ws_bytes,
-                   hipStream_t st) {
-  // 1. the sampled key range (the head of the scratch holds the two words until the plan is bound)
-  int32_t* range = reinterpret_cast<int32_t*>(w);
-  const int32_t init[2] = {INT32_MAX, INT32_MIN};
-  ARX_HIP(hipMemcpyAsync(range, init, 8, hipMemcpyHostToDevice, st));
-  const int64_t stride = std::max<int64_t>(1, n / std::max<int64_t>(int64_t(g_gbl_sample_rows), kGblUnitRows));
-  const int64_t strata = ceil_div(ceil_div(n, kGblUnitRows), stride);
-  const unsigned rgrid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(strata, kWavesPerBlock * 8), 2048)));
-  hipLaunchKernelGGL(gbl_range_kernel, dim3(rgrid), dim3(kBlock), 0, st, k, n, stride, range);
-  ARX_CHECK_LAUNCH("gbl_range_kernel");
-  int32_t mm[2];
-  ARX_HIP(hipMemcpyAsync(mm, range, 8, hipMemcpyDeviceToHost, st));
-  ARX_HIP(hipStreamSynchronize(st));
-  if (mm[0] > mm[1]) return kGblDeclined;
-  GblPlan plan{};
-  // (a sample misses a few keys at both ends of a range: 1/64 of the range on either side, whole bins)
-  const int64_t pad = (static_cast<int64_t>(mm[1]) - mm[0] + 1) / 64 + 1;
-  const int64_t kmin = std::max<int64_t>(INT32_MIN, static_cast<int64_t>(mm[0]) - (stride > 1 ? pad : 0));
-  const int64_t kmax = std::min<int64_t>(INT32_MAX, static_cast<int64_t>(mm[1]) + (stride > 1 ? pad : 0));
-  if (!gbl_plan(n, kmin, kmax, &plan) || plan.total > ws_bytes) {
-    g_gbl_declined.fetch_add(1, std::memory_order_relaxed);
-    return kGblDeclined;
-  }
-  GblArgs a{};
-  a.keys = k;
-  a.values = val;
-  a.kvalid = kb;
-  a.vvalid = vb;
-  a.n = n;
+static void gbl_bind(GblArgs& a, const GblPlan& plan, uint8_t* w) {
   a.rows_per_wg = plan.rows_per_wg;
-  a.kmin = static_cast<int32_t>(kmin);
+  a.kmin = static_cast<int32_t>(plan.kmin);
   a.wshift = plan.wshift;
   a.width = plan.width;
   a.bins = plan.bins;
@@ -772,26 +878,87 @@ static int gbl_try(const GroupbyView& v, const int32_t* k, const int64_t* val, B
   a.hist = reinterpret_cast<uint32_t*>(w + plan.off_hist);
   a.flags = reinterpret_cast<uint32_t*>(w + plan.off_flags);
   a.unit_start = reinterpret_cast<uint32_t*>(w + plan.off_unit_start);
-  // 2. sampled histogram -> rooms -> scatter -> room check + work units
+}
+
+// sampled histogram -> rooms -> scatter -> room check + work units; the flags come back to the host (ONE read-back).
+// Nothing but the scratch has been written when this returns.
+template <bool HAS_NULLS>
+static int gbl_partition(const GblArgs& a, uint32_t flags[4], hipStream_t st) {
   ARX_HIP(hipMemsetAsync(a.hist, 0, static_cast<size_t>(kGblMaxBins) * 4, st));
   ARX_HIP(hipMemsetAsync(a.flags, 0, 16, st));
+  const int64_t strata = ceil_div(ceil_div(a.n, kGblUnitRows), a.sample_stride);
   const unsigned hgrid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(strata, (kGblThreads / 64) * 8), 1024)));
   hipLaunchKernelGGL((gbl_hist_kernel<HAS_NULLS>), dim3(hgrid), dim3(kGblThreads), 0, st, a);
   ARX_CHECK_LAUNCH("gbl_hist_kernel");
   hipLaunchKernelGGL(gbl_rooms_kernel, dim3(1), dim3(kGblThreads), 0, st, a);
   ARX_CHECK_LAUNCH("gbl_rooms_kernel");
-  hipLaunchKernelGGL((gbl_scatter_kernel<HAS_NULLS>), dim3(static_cast<unsigned>(plan.wgs)), dim3(kGblThreads), 0, st, a);
+  hipLaunchKernelGGL((gbl_scatter_kernel<HAS_NULLS>), dim3(static_cast<unsigned>(a.wgs)), dim3(kGblThreads), 0, st, a);
   ARX_CHECK_LAUNCH("gbl_scatter_kernel");
   hipLaunchKernelGGL(gbl_scan_kernel, dim3(1), dim3(kGblThreads), 0, st, a);
   ARX_CHECK_LAUNCH("gbl_scan_kernel");
-  uint32_t flags[4] = {0, 0, 0, 0};
   ARX_HIP(hipMemcpyAsync(flags, a.flags, 16, hipMemcpyDeviceToHost, st));
   ARX_HIP(hipStreamSynchronize(st));
+  return ARX_OK;
+}
+
+static int gbl_aggregate(const GblArgs& a, hipStream_t st) {
+  const int64_t max_units = ceil_div(static_cast<int64_t>(a.total_lines), a.unit_lines) + a.bins;
+  hipLaunchKernelGGL(gbl_aggregate_kernel, dim3(static_cast<unsigned>(max_units)), dim3(kGblThreads), 0, st, a);
+  ARX_CHECK_LAUNCH("gbl_aggregate_kernel");
+  return ARX_OK;
+}
+
+// the sampled {min, max} of a key column into the caller's device pair (folded with atomic min / max)
+static int gbl_sample_range(const int32_t* k, int64_t n, int64_t sample_rows, int32_t* out_pair, hipStream_t st) {
+  const int64_t stride = gbl_stride_for(n, sample_rows);
+  const int64_t strata = ceil_div(ceil_div(n, kGblUnitRows), stride);
+  const unsigned rgrid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(strata, kWavesPerBlock * 8), 2048)));
+  hipLaunchKernelGGL(gbl_range_kernel, dim3(rgrid), dim3(kBlock), 0, st, k, n, stride, out_pair);
+  ARX_CHECK_LAUNCH("gbl_range_kernel");
+  return ARX_OK;
+}
+
+// All n rows through the lines plan into the HBM TABLE, or kGblDeclined (nothing consumed: the other plans take the rows).
+template <bool HAS_NULLS>
+static int gbl_try(const GroupbyView& v, const int32_t* k, const int64_t* val, Bits kb, Bits vb, int64_t n, uint8_t* w, size_t ws_bytes,
+                   hipStream_t st) {
+  // 1. the sampled key range (the head of the scratch holds the two words until the plan is bound)
+  int32_t* range = reinterpret_cast<int32_t*>(w);
+  const int32_t init[2] = {INT32_MAX, INT32_MIN};
+  ARX_HIP(hipMemcpyAsync(range, init, 8, hipMemcpyHostToDevice, st));
+  const int rrc = gbl_sample_range(k, n, g_gbl_range_sample_rows, range, st);
+  if (rrc != ARX_OK) return rrc;
+  int32_t mm[2];
+  ARX_HIP(hipMemcpyAsync(mm, range, 8, hipMemcpyDeviceToHost, st));
+  ARX_HIP(hipStreamSynchronize(st));
+  if (mm[0] > mm[1]) return kGblDeclined;
+  // (a sample misses a few keys at both ends of a range: 1/64 of the range on either side)
+  const bool sampled = gbl_stride_for(n, g_gbl_range_sample_rows) > 1;
+  const int64_t pad = sampled ? (static_cast<int64_t>(mm[1]) - mm[0] + 1) / 64 + 1 : 0;
+  const int64_t kmin = std::max<int64_t>(INT32_MIN, static_cast<int64_t>(mm[0]) - pad);
+  const int64_t kmax = std::min<int64_t>(INT32_MAX, static_cast<int64_t>(mm[1]) + pad);
+  GblPlan plan{};
+  int width = 0, wshift = 0, bins = 0;
+  if (!gbl_partitions(kmin, kmax, &width, &wshift, &bins) || !gbl_plan(n, kmin, width, wshift, bins, true, &plan) || plan.total > ws_bytes) {
+    g_gbl_declined.fetch_add(1, std::memory_order_relaxed);
+    return kGblDeclined;
+  }
+  GblArgs a{};
+  a.keys = k;
+  a.values = val;
+  a.kvalid = kb;
+  a.vvalid = vb;
+  a.n = n;
+  gbl_bind(a, plan, w);
+  a.dense = w + plan.off_dense;
+  uint32_t flags[4] = {0, 0, 0, 0};
+  const int prc = gbl_partition<HAS_NULLS>(a, flags, st);
+  if (prc != ARX_OK) return prc;
   if (flags[0] != 0 || flags[1] != 0 || static_cast<int64_t>(flags[2]) > n / 64) {
     g_gbl_fallbacks.fetch_add(1, std::memory_order_relaxed);
     return kGblDeclined;   // nothing has touched the table
   }
-  // 3. the point of no return: null rows, outliers, the aggregate
+  // 2. the point of no return: null rows, outliers, the aggregate into the dense state, its groups into the table
   g_gbl_slices.fetch_add(1, std::memory_order_relaxed);
   if (HAS_NULLS) {
     GbpArgs na{};
@@ -808,9 +975,12 @@ static int gbl_try(const GroupbyView& v, const int32_t* k, const int64_t* val, B
     hipLaunchKernelGGL((gbl_outliers_kernel<HAS_NULLS>), dim3(gb_grid(n / 8 + 1)), dim3(kBlock), 0, st, v, a);
     ARX_CHECK_LAUNCH("gbl_outliers_kernel");
   }
-  const int64_t max_units = ceil_div(static_cast<int64_t>(plan.total_lines), plan.unit_lines) + plan.bins;
-  hipLaunchKernelGGL(gbl_aggregate_kernel, dim3(static_cast<unsigned>(max_units)), dim3(kGblThreads), 0, st, v, a);
-  ARX_CHECK_LAUNCH("gbl_aggregate_kernel");
+  const size_t dense_bytes = static_cast<size_t>(plan.bins) * plan.width * 16;
+  ARX_HIP(hipMemsetAsync(a.dense, 0, dense_bytes, st));
+  const int arc = gbl_aggregate(a, st);
+  if (arc != ARX_OK) return arc;
+  hipLaunchKernelGGL(gbl_table_insert_kernel, dim3(gb_grid(static_cast<int64_t>(plan.bins) * plan.width)), dim3(kBlock), 0, st, v, a);
+  ARX_CHECK_LAUNCH("gbl_table_insert_kernel");
   return ARX_OK;
 }
 
@@ -827,6 +997,7 @@ static int set_groupby_lines_option(const char* name, int64_t value) {
   if (strcmp(name, "groupby_lines") == 0) g_gbl = value != 0 ? 1 : 0;
   else if (strcmp(name, "groupby_lines_min_rows") == 0) g_gbl_min_rows = std::max<int64_t>(1, value);
   else if (strcmp(name, "groupby_lines_sample_rows") == 0) g_gbl_sample_rows = std::max<int64_t>(kGblUnitRows, value);
+  else if (strcmp(name, "groupby_lines_range_sample_rows") == 0) g_gbl_range_sample_rows = std::max<int64_t>(kGblUnitRows, value);
   else if (strcmp(name, "groupby_lines_unit_rows") == 0) g_gbl_unit_rows = static_cast<int>(std::max<int64_t>(768, std::min<int64_t>(value, 1 << 30)));
   else if (strcmp(name, "groupby_lines_wgs") == 0) g_gbl_wgs = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(value, 4096)));
   else return 0;

@@ -21,7 +21,7 @@ import torch.distributed as dist
 from . import _lib
 from ._lib import check
 from .array import alloc, current_stream
-from .compute import GroupBySum, ScalarAggregateOptions
+from .compute import GroupBySum, RangeGroupBySum, ScalarAggregateOptions
 
 
 RECORD_BYTES = 24   # sizeof(ArxGroupPartial)
@@ -87,6 +87,11 @@ class Stages:
     def _sync(self):
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
+
+    def reset(self) -> None:
+        self.ms.clear()
+        self._sync()
+        self._t = self._clock()
 
     def mark(self, name: str) -> None:
         self._sync()
@@ -185,9 +190,78 @@ def consume_partials(keys, values, capacity: int, num_parts: int):
     return torch.cat(blocks).view(torch.uint8), counts
 
 
+_FORCE_RANGE_STATE = [False]     # tests: take the range-partitioned state at any row count
+
+
+def range_partitions_of(rank: int, world: int, partitions: int):
+    """The contiguous run [first, first + count) of a range-partitioned state's partitions that `rank` owns."""
+    first = rank * partitions // world
+    return first, (rank + 1) * partitions // world - first
+
+
+def _sharded_range_group_by_sum(keys, values, options, group, stages, world, rank):
+    """The sharded group-by on the RANGE-PARTITIONED state (round 6; compute.RangeGroupBySum, csrc/groupby_lines.h) — for
+    int32 keys from a narrow range (ids, codes), no nulls.  The owner of a key is the owner of its PARTITION (a slice of
+    the key range), contiguous runs of partitions per rank:
+      1. ONE all-reduce(MAX) of {-min, max} of every shard's sampled keys -> the same plan on every rank;
+      2. local consume: write-combined range scatter + direct-indexed LDS aggregate into the rank's dense state;
+      3. ONE all-to-all of the state itself — the run of blocks every owner gets has the same, known size on every
+         rank: no count exchange, no packing — beside one all-reduce(MIN) of "my consume took its rows";
+      4. the owner adds the P runs in one pass (Merge = vector add) and compacts its partitions' groups in key order.
+    Returns the result tuple, or None when this path does not apply or any rank's consume declined (every rank then
+    takes the table path together: the status is agreed on by the all-reduce)."""
+    from .array import int32, int64
+
+    if keys.type != int32 or values.type != int64:
+        return None
+    # (small shards: the table operator's plans; the row count is not agreed on between ranks, so with several ranks the
+    #  range agreement below decides alone)
+    if world == 1 and keys.length < RangeGroupBySum.MIN_ROWS and not _FORCE_RANGE_STATE[0]:
+        return None
+    nulls = (keys.null_count != 0 and keys.buffers[0] is not None) or (values.null_count != 0 and values.buffers[0] is not None)
+    device = keys.device
+    rng = RangeGroupBySum.sampled_key_range(keys) if not nulls else torch.tensor([2**62, 2**62], dtype=torch.int64, device=device)
+    # (a shard with nulls poisons the range: every rank then declines together, without another collective)
+    if world > 1:
+        dist.all_reduce(rng, op=dist.ReduceOp.MAX, group=group)
+    neg_lo, hi = [int(x) for x in rng.cpu().tolist()]
+    # (the plan is a function of the agreed range alone: the same on every rank)
+    plan = RangeGroupBySum.plan_for(1, -neg_lo, hi) if -neg_lo <= hi and hi + neg_lo < 2**31 else None
+    if plan is None:
+        return None
+    st = RangeGroupBySum(plan, device, options)
+    ok = st.consume(keys, values)
+    _mark(stages, "consume")
+    if world == 1:
+        if not ok:
+            return None
+        out = st.finalize()
+        _mark(stages, "finalize")
+        return out
+    status = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(status, op=dist.ReduceOp.MIN, group=group)
+    parts, pb = int(plan.partitions), st.partition_bytes()
+    send = [range_partitions_of(r, world, parts)[1] * pb // 8 for r in range(world)]
+    first, mine = range_partitions_of(rank, world, parts)
+    got = torch.empty(max(world * mine * pb // 8, 1), dtype=torch.int64, device=device)[: world * mine * pb // 8]
+    dist.all_to_all_single(got, st.state, output_split_sizes=[mine * pb // 8] * world, input_split_sizes=send, group=group)
+    _mark(stages, "exchange")
+    if int(status.item()) == 0:     # some rank's consume declined (a hot key, a key outside the sampled range): all take the table path
+        return None
+    if mine:
+        # block 0 += blocks 1 .. P-1 (one pass), then the groups of this rank's partitions in key order
+        lib = _lib.get_lib()
+        check(lib.arx_groupby_range_merge(got.data_ptr(), got.data_ptr() + mine * pb, plan.width, mine, world - 1, mine * pb,
+                                          current_stream(device)))
+    _mark(stages, "merge")
+    out = st.finalize(first, mine, blocks=got)
+    _mark(stages, "finalize")
+    return out
+
+
 def sharded_group_by_sum(keys, values, capacity: int, options: ScalarAggregateOptions | None = None,
                          group=None, exchange: str = "partials", stages: Stages | None = None,
-                         local_table: bool | None = None):
+                         local_table: bool | None = None, range_state: bool | None = None):
     """keys/values: this rank's row shard (device Arrays).  Returns this rank's slice of the
     result: (keys, key_is_valid, sums, valid) device tensors over a disjoint set of keys.
 
@@ -197,6 +271,10 @@ def sharded_group_by_sum(keys, values, capacity: int, options: ScalarAggregateOp
     radix-partitioned by hash(key) % world_size, exchanged as 16-byte records (ONE all-to-all(v)) and aggregated by
     the rank that owns their key — N x 16 bytes, the better plan only when almost every row is its own group.
     Both give the same groups on the same ranks.
+    range_state (round 6; "partials" exchange with local_table = None): None = int32 keys from a narrow range take the
+    range-partitioned state first (_sharded_range_group_by_sum: keys are owned by PARTITION of the key range there, so a
+    rank's result is a contiguous slice of the keys in ascending order) and fall back to the paths below where it
+    declines; False = never; True = raise where it declines.
     local_table (the "partials" exchange): None = the local pass writes its partials straight into per-owner record
     regions (consume_partials: no local table, no export pass) and falls back to local table + export where that form
     declines; True = always the local table (round 4's path); False = never (raises where the form declines)."""
@@ -204,6 +282,20 @@ def sharded_group_by_sum(keys, values, capacity: int, options: ScalarAggregateOp
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if exchange not in ("partials", "rows"):
         raise ValueError("exchange must be 'partials' or 'rows'")
+    # Round 6: keys from a narrow range take the range-partitioned state — no hash table, the owner of a key is the owner
+    # of its partition, ONE all-to-all of dense blocks whose sizes every rank knows.  range_state: None = try it and fall
+    # back (all ranks together) where it declines; False = never; True = it must apply.
+    if range_state is not False and exchange == "partials" and local_table is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        _FORCE_RANGE_STATE[0] = range_state is True
+        out = _sharded_range_group_by_sum(keys, values, options, group, stages, world, rank)
+        if out is not None:
+            return out
+        if range_state is True:
+            raise _lib.ArrowNotImplementedError("sharded_group_by_sum(range_state=True): the key range (or a shard's rows) does "
+                                                "not suit the range-partitioned state")
+        if stages is not None:
+            stages.reset()      # (the declined attempt's marks would be added to the table path's)
     if world == 1:
         local = GroupBySum(capacity, device, options)
         local.consume(keys, values)

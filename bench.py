@@ -413,8 +413,8 @@ def _counters(lib, names):
 
 
 def parity_hash_sum_prefix(device, groups_arg):
-    """The device group-by — the SAME plan the 4e9-row leg is timed on (the plan follows the group count, not the row count;
-    the counters say which ran, and the wide plan is forced if the estimate chose another) — on the first 1e8 rows of
+    """The device group-by — the SAME plan the 4e9-row leg is timed on (the lines plan follows the key range, the wide plan
+    the group count, neither the row count; the counters say which ran, and the wide plan is forced if another one did) — on the first 1e8 rows of
     streams 8 / 9, diffed against pyarrow's Table.group_by on the same rows: key-sorted (key, sum) equality."""
     import arrow_amd as amd
     from arrow_amd import parallel
@@ -429,14 +429,17 @@ def parity_hash_sum_prefix(device, groups_arg):
     cap = 1
     while cap < 2 * groups + 2:
         cap <<= 1
-    names = ("groupby_slices_wide", "groupby_slices_rooms", "groupby_slices_two_level", "groupby_slices_one_level", "groupby_slices_direct")
+    names = ("groupby_slices_lines", "groupby_lines_fallbacks", "groupby_slices_wide", "groupby_slices_rooms", "groupby_slices_two_level",
+             "groupby_slices_one_level", "groupby_slices_direct")
     forced = False
     for attempt in (0, 1):
         c0 = _counters(lib, names)
         gk, gk_valid, gs, gs_valid = parallel.sharded_group_by_sum(kk, vv, cap)[:4]
         _sync(device)
         plan = {k: v - c0[k] for k, v in _counters(lib, names).items() if v != c0[k]}
-        if plan.get("groupby_slices_wide", 0) > 0 or attempt == 1:
+        # (round 6: ids from [0, groups) take the lines plan at any row count, as the timed leg does; where it declined,
+        #  the wide plan is what the timed leg fell back to)
+        if plan.get("groupby_slices_lines", 0) > 0 or plan.get("groupby_slices_wide", 0) > 0 or attempt == 1:
             break
         assert lib.arx_set_option(b"groupby_wide", 2) == 0 and lib.arx_set_option(b"groupby_partition_bits", 11) == 0
         forced = True
@@ -1152,10 +1155,11 @@ def hash_sum_leg(args, rank, world, device, rows_total, steps, warmup):
     per_gpu = 12 * rows / world / sec / 1e9
     leg = {"rows": rows, "groups": groups_out, "n_gpus": world, "ms": round(sec * 1e3, 3),
            "mrows_per_s": round(rows / sec / 1e6, 1), "scaling": "strong",
-           "exchange": "local aggregate -> 1 count exchange + ONE all-to-all(v) of 24-byte partials -> merge" if world > 1 else "none (one rank)",
+           "exchange": "1 all-reduce of the sampled key range -> local range-partitioned aggregate -> ONE all-to-all of dense partition blocks (sizes known: no count exchange) + 1 status all-reduce -> vector-add merge" if world > 1 else "none (one rank)",
            "checksum_matches_sum_of_values": ok,
            "stage_ms_max_over_ranks_untimed_run": _LAST_STAGES.get("hash_sum"),
-           "roofline": {"bound": "hbm", "kernel": "arx_groupby_sum_i64_consume (ONE flat 2048-bin scatter into fixed rooms + 8192-slot LDS aggregate; 2^25-row probe slice on the two-level plan)",
+           "plan": _hash_sum_plan_counters(),
+           "roofline": {"bound": "hbm", "kernel": "arx_groupby_range_sum_i64_consume (lines plan: gbl_scatter_kernel [write-combined range scatter, whole 128-byte lines of 12 records] + gbl_aggregate_kernel [direct-indexed LDS tables])",
                         "achieved": round(per_gpu, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 12,
                         "traffic": load_traffic("groupby", rows // world)}}
@@ -1179,6 +1183,16 @@ def hash_sum_leg(args, rank, world, device, rows_total, steps, warmup):
             except Exception as e:
                 leg["through_acero"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return leg
+
+
+def _hash_sum_plan_counters():
+    """Which plan the group-by's passes took in this process so far (arx_get_counter): the roofline's kernel names are
+    the lines plan's, and a line measured on another plan must say so."""
+    import arrow_amd as amd
+
+    lib = amd._lib.get_lib()
+    return _counters(lib, ["groupby_slices_lines", "groupby_lines_fallbacks", "groupby_lines_declined", "groupby_slices_wide",
+                           "groupby_slices_rooms", "groupby_slices_two_level"])
 
 
 def sort_leg(args, rank, world, device, rows_total, steps, warmup):

@@ -745,6 +745,57 @@ int arx_groupby_sum_i64_merge_records(void* state, int64_t capacity, const ArxGr
                                       int64_t num_records, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * The RANGE-PARTITIONED group-by state (round 6): hash_sum(int64) BY int32 for keys from a narrow range — ids, codes,
+ * dictionary indices; BASELINE configs[3] draws its 1e7 keys from [0, 1e7).  Same operator as arx_groupby_* above
+ * (ThreadLocalState -> Merge -> Finalize of acero/groupby_aggregate_node.cc:210-337 around
+ * GroupedReducingAggregator<Int64,Sum>, compute/kernels/hash_aggregate_numeric.cc:44-187), another state: NO hash table.
+ * The keys [key_min, key_min + partitions * width) are cut into `partitions` slices of `width` keys, and the state is one
+ * dense block per partition, { uint64 sums[width] | uint64 counts[width] } = 16 * width bytes, zero-initialised by the
+ * caller.  consume radix-partitions the rows by key slice with a write-combined scatter (every global store a whole
+ * 128-byte line of 12 {value, 16-bit key remainder} records) and aggregates every partition in a direct-indexed LDS table
+ * (csrc/groupby_lines.h); Merge is a vector add of two states (hash_aggregate_numeric.cc:85-107: sums wrap, counts add);
+ * Finalize compacts the non-empty slots in key order (:109-152: valid where count >= min_count).  Sharded over P GPUs the
+ * owner of a key is the owner of its PARTITION (contiguous runs of partitions per rank): a rank sends every owner one
+ * contiguous run of blocks whose size every rank knows (no count exchange), the owner adds P runs and finalizes.
+ * Rows with nulls are not taken (ARX_NOT_IMPLEMENTED: the table operator above serves them).
+ * ------------------------------------------------------------------------- */
+typedef struct ArxRangePlan {
+  int32_t key_min;          /* first key of partition 0 */
+  int32_t width;            /* keys per partition: 128 ... 8192 (powers of two) or 12288 */
+  int32_t partitions;       /* 48 ... 1216 */
+  int32_t reserved;
+  int64_t slots;            /* partitions * width */
+  uint64_t state_bytes;     /* slots * 16 */
+  uint64_t workspace_bytes; /* scratch of a consume of up to max_rows rows (256-byte aligned) */
+} ArxRangePlan;
+/* The plan for keys in [key_min, key_max] and consumes of up to max_rows rows: ARX_NOT_IMPLEMENTED when the range needs
+ * more than 1216 partitions of 12288 keys (14.9M keys) or fewer than 48 of 128 (one LDS table holds those groups: the
+ * table operator's direct plan is the tool).  Pure host arithmetic. */
+int arx_groupby_range_plan(int64_t max_rows, int32_t key_min, int32_t key_max, ArxRangePlan* out);
+/* {min, max} of a SAMPLE of the key slots (one 64-row unit per stratum, about sample_rows rows in all; sample_rows >= length
+ * reads every key) folded into out_min_max (device int32[2], initialised by the caller to {INT32_MAX, INT32_MIN}).  A
+ * caller that plans from a sample widens the range (the sample misses a few keys at both ends).  Asynchronous. */
+int arx_groupby_key_range_sampled_i32(const ArxSpan* keys, int64_t sample_rows, int32_t* out_min_max, void* stream);
+/* Adds the rows' groups into `state` (plan->state_bytes, zeroed before the first consume).  ARX_CAPACITY_ERROR — and
+ * nothing consumed — when a key lies outside the plan's range, a hot key makes the scatter give up, or `ws` is too small
+ * (use the table operator for these rows); ARX_NOT_IMPLEMENTED for rows with nulls.  Synchronous (reads the scatter's flags). */
+int arx_groupby_range_sum_i64_consume(void* state, const ArxRangePlan* plan, const ArxSpan* keys_i32, const ArxSpan* values_i64,
+                                      void* ws, size_t ws_bytes, void* stream);
+/* partitions[0 .. num_partitions) at `state` += the same partitions of num_others other states, the r-th starting at
+ * others + r * others_stride_bytes (all pointers at a partition's first byte; the blocks a rank received from its peers
+ * lie one behind the other).  Asynchronous. */
+int arx_groupby_range_merge(void* state, const void* others, int32_t width, int64_t num_partitions, int num_others,
+                            int64_t others_stride_bytes, void* stream);
+/* The groups of num_partitions partitions starting at `partitions` (the first one's keys start at first_key), ascending by
+ * key: out_keys / out_sums / out_counts (may be NULL) / out_valid (1 where count >= min_count) need num_partitions * width
+ * entries at most; *out_num_groups (device int64) = how many were written.  ws: arx_groupby_range_finalize_workspace_bytes.
+ * Asynchronous. */
+size_t arx_groupby_range_finalize_workspace_bytes(int64_t slots);
+int arx_groupby_range_finalize(const void* partitions, int32_t first_key, int32_t width, int64_t num_partitions, uint32_t min_count,
+                               void* ws, size_t ws_bytes, int32_t* out_keys, int64_t* out_sums, int64_t* out_counts,
+                               uint8_t* out_valid, int64_t* out_num_groups, void* stream);
+
+/* ---------------------------------------------------------------------------
  * hash_sum(int64, uint32 group id) — the HashAggregateKernel boundary itself
  * (compute/kernel.h:720-769): the caller's Grouper already produced dense group ids.
  * Replaces GroupedReducingAggregator<Int64Type,GroupedSumImpl>::{Consume,Merge,Finalize}

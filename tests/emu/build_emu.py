@@ -5,6 +5,7 @@ import fcntl
 import glob
 import os
 import subprocess
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -36,6 +37,7 @@ def _build(force: bool) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    started = time.time()
     objs, procs = [], []
     for s in srcs + [os.path.join(HERE, "hip_emu_runtime.cpp")]:
         o = os.path.join(HERE, "_build", os.path.basename(s) + ".o")
@@ -48,6 +50,7 @@ def _build(force: bool) -> str:
             raise subprocess.CalledProcessError(p.returncode, cmd)
     tmp = OUT + f".tmp{os.getpid()}"
     subprocess.check_call(["g++", "-shared", "-o", tmp] + objs)
+    os.utime(tmp, (started, started))   # a source edited WHILE this build ran must look newer than its output
     os.replace(tmp, OUT)  # a reader never sees a half-written library
     return OUT
 

@@ -2171,6 +2171,7 @@ def check_groupby_lines_plan(amd, rng_for, scale=1, wide_width=True):
         # 3. a sampled histogram (one 64-row unit in 8) and rows outside the sampled range: keys far away in a unit the
         #    sample does not read are counted by the scatter and consumed by their own pass
         assert lib.arx_set_option(b"groupby_lines_sample_rows", max(64, n // 8)) == 0
+        assert lib.arx_set_option(b"groupby_lines_range_sample_rows", max(64, n // 8)) == 0
         stride = max(1, n // max(64, n // 8))
         assert stride > 1
         sampled = {_gbl_sampled_unit(s, stride) for s in range((n + 63) // 64 // stride + 2)}
@@ -2186,6 +2187,7 @@ def check_groupby_lines_plan(amd, rng_for, scale=1, wide_width=True):
             assert ctr(b"groupby_slices_lines") == s1 + 1
             assert ctr(b"groupby_lines_outlier_rows") - o1 >= (3 if null_p else 4), "the far keys are outside the sampled range"
         assert lib.arx_set_option(b"groupby_lines_sample_rows", 1 << 26) == 0
+        assert lib.arx_set_option(b"groupby_lines_range_sample_rows", 1 << 22) == 0
         # 4. a hot key: the scatter would need hundreds of rounds per batch — it gives up, nothing consumed, the other plans run
         rng = rng_for("gbl", 4)
         k = util.random_array(rng, np.int32, n, lo=0, hi=50000)
@@ -2218,8 +2220,83 @@ def check_groupby_lines_plan(amd, rng_for, scale=1, wide_width=True):
         assert d0 <= ctr(b"groupby_lines_declined")
     finally:
         for k_, v_ in {b"groupby_partition_min_rows": 1 << 17, b"groupby_lines_min_rows": 1 << 22, b"groupby_lines_wgs": 0,
-                       b"groupby_lines_unit_rows": 1 << 21, b"groupby_lines_sample_rows": 1 << 26}.items():
+                       b"groupby_lines_unit_rows": 1 << 21, b"groupby_lines_sample_rows": 1 << 26,
+                       b"groupby_lines_range_sample_rows": 1 << 22}.items():
             lib.arx_set_option(k_, v_)
+
+
+def check_groupby_range_state(amd, rng_for, scale=1):
+    """The range-partitioned group-by STATE through its C ABI (arx_groupby_range_*; compute.RangeGroupBySum): plan ->
+    consume (several batches into one state) -> finalize, and two states merged by partition runs the way two ranks
+    exchange them -> finalize per run; every result against the oracle on the same rows, in ascending key order.  What
+    the state declines (nulls, a key outside the plan, a hot key, a range too wide or too narrow) is declined with
+    nothing consumed."""
+    import torch
+
+    R = amd.compute.RangeGroupBySum
+    lib = amd._lib.get_lib()
+    for k_, v_ in {b"groupby_lines_wgs": 2, b"groupby_lines_unit_rows": 4096}.items():
+        assert lib.arx_set_option(k_, v_) == 0
+    try:
+        n = 25000 * scale
+        for lo, hi, min_count in ((0, 40000, 1), (-70000, -20000, 3), (5, 9_700_000 if scale > 1 else 300_000, 1)):
+            rng = rng_for("range-state", lo, hi)
+            k = util.random_array(rng, np.int32, n, offset=3, lo=lo, hi=hi)
+            v = util.random_array(rng, np.int64, n, offset=1)
+            plan = R.plan_for(n, lo, hi, sampled=False)
+            assert plan is not None and plan.key_min == lo and plan.slots >= hi - lo + 1
+            dk, dv = k.to_device(amd), v.to_device(amd)
+            # the sampled range the sharded path starts from brackets nothing outside the true one
+            neg_lo, smax = [int(x) for x in R.sampled_key_range(dk, 1 << 30).cpu().tolist()]
+            kv = k.values[k.offset:k.offset + n]
+            assert -neg_lo == int(kv.min()) and smax == int(kv.max())
+            opts = amd.compute.ScalarAggregateOptions(True, min_count)
+            st = R(plan, dk.device, opts)
+            for b in range(0, n, (n + 2) // 3):        # three consumes into one state
+                m = min((n + 2) // 3, n - b)
+                assert st.consume(dk.slice(b, m), dv.slice(b, m))
+            gk, gkv, gs, gvalid = st.finalize()
+            w = O.groupby_sum_i64(np.ascontiguousarray(k.values), None, k.offset, np.ascontiguousarray(v.values), None, v.offset,
+                                  n, True, min_count)
+            order = np.argsort(w["keys"], kind="stable")
+            assert_equal(gk.cpu().numpy(), w["keys"][order], f"range state keys [{lo}, {hi}]")
+            assert_equal(gs.cpu().numpy(), w["sums"][order], "range state sums")
+            assert_equal(gvalid.cpu().numpy().astype(bool), w["valid"][order].astype(bool), "range state validity (min_count)")
+            assert bool(gkv.all())
+            # two states (two "ranks": the halves of the rows), merged run by run as the sharded path does
+            a, b2 = R(plan, dk.device, opts), R(plan, dk.device, opts)
+            assert a.consume(dk.slice(0, n // 2), dv.slice(0, n // 2)) and b2.consume(dk.slice(n // 2, n - n // 2), dv.slice(n // 2, n - n // 2))
+            parts, pb = int(plan.partitions), a.partition_bytes()
+            got_k, got_s = [], []
+            for first, cnt in ((0, parts // 3), (parts // 3, parts - parts // 3)):
+                blocks = torch.cat([a.state[first * pb // 8:(first + cnt) * pb // 8], b2.state[first * pb // 8:(first + cnt) * pb // 8]])
+                amd._lib.check(lib.arx_groupby_range_merge(blocks.data_ptr(), blocks.data_ptr() + cnt * pb, plan.width, cnt, 1, cnt * pb,
+                                                           amd.array.current_stream(dk.device)))
+                fk, _, fs, _ = a.finalize(first, cnt, blocks=blocks)
+                got_k.append(fk.cpu().numpy())
+                got_s.append(fs.cpu().numpy())
+            assert_equal(np.concatenate(got_k), w["keys"][order], "two merged range states: keys")
+            assert_equal(np.concatenate(got_s), w["sums"][order], "two merged range states: sums")
+        # declined, nothing consumed: a key outside the plan; a hot key; rows with nulls
+        rng = rng_for("range-state", "declines")
+        plan = R.plan_for(n, 0, 50000, sampled=False)
+        st = R(plan, None)
+        k = util.random_array(rng, np.int32, n, lo=0, hi=50000)
+        v = util.random_array(rng, np.int64, n)
+        k.values[n // 2] = 50000 + int(plan.slots)
+        assert not st.consume(k.to_device(amd), v.to_device(amd))
+        k.values[:] = 17
+        assert not st.consume(k.to_device(amd), v.to_device(amd))
+        kn = util.random_array(rng, np.int32, n, null_p=0.1, lo=0, hi=50000)
+        assert not st.consume(kn.to_device(amd), v.to_device(amd))
+        assert int(st.state.abs().sum()) == 0, "a declined consume must leave the state untouched"
+        assert len(st.finalize()[0]) == 0
+        # ranges the state does not plan for
+        assert R.plan_for(n, 0, 100, sampled=False) is None and R.plan_for(n, -2**31, 2**31 - 1, sampled=False) is None
+        assert R.plan_for(n, 0, 1216 * 12288 - 1, sampled=False) is not None and R.plan_for(n, 0, 1216 * 12288, sampled=False) is None
+    finally:
+        lib.arx_set_option(b"groupby_lines_wgs", 0)
+        lib.arx_set_option(b"groupby_lines_unit_rows", 1 << 21)
 
 
 def check_hash_minmax_count_kernels(amd, rng, n=5000, num_groups=37, null_p=0.2):

@@ -361,6 +361,11 @@ def test_groupby_partition_knobs(emu_ctx, l1_global, agg_chunk, bits):
             lib.arx_set_option(k_, v_)
 
 
+def test_groupby_range_state(emu_ctx):
+    """Round 6: the range-partitioned state through its C ABI (plan / consume / merge / finalize)."""
+    P.check_groupby_range_state(emu_ctx, rng_for)
+
+
 def test_groupby_lines_plan(emu_ctx):
     """Round 6: the dense-range lines plan (write-combined whole-line scatter + direct-indexed LDS aggregate)."""
     P.check_groupby_lines_plan(emu_ctx, rng_for, wide_width=False)

@@ -1412,6 +1412,11 @@ def test_groupby_key_range(gpu_ctx):
     P.check_groupby_key_range(gpu_ctx, rng_for("key-range"), scale=50)
 
 
+def test_groupby_range_state(gpu_ctx):
+    """Round 6: the range-partitioned state through its C ABI on gfx950, 20x the emulated tier's rows, the 12288-wide partitions."""
+    P.check_groupby_range_state(gpu_ctx, rng_for, scale=20)
+
+
 def test_groupby_lines_plan(gpu_ctx):
     """Round 6: the dense-range lines plan (write-combined whole-line scatter + direct-indexed LDS aggregate) on gfx950:
     every case of the emulated tier at 20x the rows, plus the 12288- and 8192-wide partitions."""

@@ -42,17 +42,32 @@ WORKER = textwrap.dedent(r'''
         assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
         assert lib.arx_set_option(b"groupby_partition_bits", 3 + 2 * rank) == 0
         assert lib.arx_set_option(b"groupby_agg_chunk_rows", 1 << 12) == 0
-    k = U.random_array(rng, np.int32, n, null_p=0.0 if direct else 0.02, offset=rank, lo=-300, hi=300)
-    v = U.random_array(rng, np.int64, n, null_p=0.0 if direct else 0.15, offset=2)
+    ranged = EXCHANGE in ("range", "range_hot")   # round 6: ids from a narrow range, no nulls -> the range-partitioned state
+    if ranged:
+        lib = _lib.get_lib()
+        assert lib.arx_set_option(b"groupby_lines_wgs", 2) == 0
+        assert lib.arx_set_option(b"groupby_lines_unit_rows", 4096) == 0
+    k = U.random_array(rng, np.int32, n, null_p=0.0 if direct or ranged else 0.02, offset=rank, lo=-20000 if ranged else -300,
+                       hi=30000 if ranged else 300)
+    if EXCHANGE == "range_hot" and rank == 1:      # ONE rank's consume gives up on a hot key: both ranks take the table path together
+        k.values[rng.random(len(k.values)) < 0.9] = 777
+    v = U.random_array(rng, np.int64, n, null_p=0.0 if direct or ranged else 0.15, offset=2)
     opts = arrow_amd.compute.ScalarAggregateOptions(skip_nulls=SKIP_NULLS, min_count=MIN_COUNT)
     stages = parallel.Stages(torch.device("cpu"))
     gk, gkv, gs, gvalid = parallel.sharded_group_by_sum(k.to_device(arrow_amd), v.to_device(arrow_amd),
-                                                        2048, opts, exchange="partials" if direct else EXCHANGE, stages=stages,
-                                                        local_table=False if direct else None)
+                                                        2048 if not ranged else 1 << 17, opts,
+                                                        exchange="partials" if direct or ranged else EXCHANGE, stages=stages,
+                                                        local_table=False if direct else None,
+                                                        range_state=True if EXCHANGE == "range" else None)
     want_stages = {"partials": ["consume", "export", "exchange", "merge", "finalize"],     # (nulls: through the local table)
                    "partials_direct": ["consume", "exchange", "merge", "finalize"],
+                   "range": ["consume", "exchange", "merge", "finalize"],
+                   "range_hot": ["consume", "export", "exchange", "merge", "finalize"],      # (declined together: small shards go through the local table)
                    "rows": ["partition_rows", "exchange", "consume", "finalize"]}[EXCHANGE]
     assert list(stages.ms) == want_stages, stages.ms
+    if EXCHANGE == "range":      # a rank's slice is a contiguous run of the key range, ascending
+        ks = gk.numpy()
+        assert (np.diff(ks) > 0).all(), "the range-partitioned state finalizes in key order"
     mine = dict(keys=gk.numpy(), key_is_valid=gkv.numpy(), sums=gs.numpy(), valid=gvalid.numpy(),
                 shard=(k.values[k.offset:k.offset + n].copy(), None if k.valid is None else k.valid[k.offset:k.offset + n].copy(),
                        v.values[v.offset:v.offset + n].copy(), None if v.valid is None else v.valid[v.offset:v.offset + n].copy()))
@@ -68,7 +83,8 @@ WORKER = textwrap.dedent(r'''
 
 @pytest.mark.parametrize("skip_nulls,min_count,exchange", [(True, 1, "partials"), (False, 2, "partials"), (False, 2, "rows"),
                                                            (True, 1, "rows"), (True, 1, "partials_direct"),
-                                                           (False, 8, "partials_direct")])
+                                                           (False, 8, "partials_direct"), (True, 1, "range"), (True, 3, "range"),
+                                                           (True, 1, "range_hot")])
 def test_sharded_group_by_sum_world2_gloo(tmp_path, skip_nulls, min_count, exchange):
     import pickle
 
