@@ -1737,7 +1737,7 @@ class RangeGroupBySum:
     acero/groupby_aggregate_node.cc:210-337; hash_aggregate_numeric.cc:44-187); rows with nulls, keys outside the
     planned range and hot keys are declined (consume returns False, nothing consumed) and go through GroupBySum."""
 
-    SAMPLE_ROWS = 1 << 22
+    SAMPLE_ROWS = 1 << 20
     MIN_ROWS = 1 << 22      # below this group_by_sum / sharded_group_by_sum do not try the state (the table operator's plans)
 
     @staticmethod

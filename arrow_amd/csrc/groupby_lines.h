@@ -124,9 +124,23 @@ __global__ __launch_bounds__(kBlock) void gbl_range_kernel(const int32_t* __rest
     lo = ol < lo ? ol : lo;
     hi = oh > hi ? oh : hi;
   }
-  if (lane == 0 && lo <= hi) {
-    atomicMin(&out_min_max[0], lo);
-    atomicMax(&out_min_max[1], hi);
+  // ONE atomic pair per workgroup (same-address atomics queue up behind the L2 at ~10 ns apiece: a pair per wave of a
+  // 2048-workgroup grid was 160 of this kernel's 190 us, profiles/r06_g_*)
+  __shared__ int32_t wlo[kWavesPerBlock], whi[kWavesPerBlock];
+  if (lane == 0) {
+    wlo[threadIdx.x >> 6] = lo;
+    whi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int wv = 1; wv < kWavesPerBlock; ++wv) {
+      lo = wlo[wv] < lo ? wlo[wv] : lo;
+      hi = whi[wv] > hi ? whi[wv] : hi;
+    }
+    if (lo <= hi) {
+      atomicMin(&out_min_max[0], lo);
+      atomicMax(&out_min_max[1], hi);
+    }
   }
 }
 
@@ -761,8 +775,8 @@ __global__ __launch_bounds__(kBlock) void gbl_merge_kernel(unsigned long long* _
 // ---- host side
 static Knob<int> g_gbl{1};                         // 1: the lines plan where the sampled key range allows it (A/B knob groupby_lines; 0 = off)
 static Knob<int64_t> g_gbl_min_rows{int64_t(1) << 22};   // below this the other plans (knob groupby_lines_min_rows)
-static Knob<int64_t> g_gbl_sample_rows{int64_t(1) << 26};   // rows the histogram sample reads (knob groupby_lines_sample_rows)
-static Knob<int64_t> g_gbl_range_sample_rows{int64_t(1) << 22};   // rows the key-range sample reads (knob groupby_lines_range_sample_rows)
+static Knob<int64_t> g_gbl_sample_rows{int64_t(1) << 24};   // rows the histogram sample reads (knob groupby_lines_sample_rows): 6 sigma of the rooms = 4 % at any n
+static Knob<int64_t> g_gbl_range_sample_rows{int64_t(1) << 20};   // rows the key-range sample reads (knob groupby_lines_range_sample_rows)
 static Knob<int> g_gbl_unit_rows{1 << 21};         // rows per aggregate work unit (knob groupby_lines_unit_rows)
 static Knob<int> g_gbl_wgs{0};                     // workgroups of the scatter (0: one per CU; knob groupby_lines_wgs — tests)
 static std::atomic<int64_t> g_gbl_slices{0}, g_gbl_fallbacks{0}, g_gbl_outlier_rows{0}, g_gbl_declined{0};
@@ -887,7 +901,8 @@ static int gbl_partition(const GblArgs& a, uint32_t flags[4], hipStream_t st) {
   ARX_HIP(hipMemsetAsync(a.hist, 0, static_cast<size_t>(kGblMaxBins) * 4, st));
   ARX_HIP(hipMemsetAsync(a.flags, 0, 16, st));
   const int64_t strata = ceil_div(ceil_div(a.n, kGblUnitRows), a.sample_stride);
-  const unsigned hgrid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(strata, (kGblThreads / 64) * 8), 1024)));
+  // (every workgroup folds its LDS histogram into the global one: bins atomics per workgroup on the same `bins` addresses)
+  const unsigned hgrid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(strata, (kGblThreads / 64) * 8), 256)));
   hipLaunchKernelGGL((gbl_hist_kernel<HAS_NULLS>), dim3(hgrid), dim3(kGblThreads), 0, st, a);
   ARX_CHECK_LAUNCH("gbl_hist_kernel");
   hipLaunchKernelGGL(gbl_rooms_kernel, dim3(1), dim3(kGblThreads), 0, st, a);
@@ -912,7 +927,7 @@ static int gbl_aggregate(const GblArgs& a, hipStream_t st) {
 static int gbl_sample_range(const int32_t* k, int64_t n, int64_t sample_rows, int32_t* out_pair, hipStream_t st) {
   const int64_t stride = gbl_stride_for(n, sample_rows);
   const int64_t strata = ceil_div(ceil_div(n, kGblUnitRows), stride);
-  const unsigned rgrid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(strata, kWavesPerBlock * 8), 2048)));
+  const unsigned rgrid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(strata, kWavesPerBlock * 8), 512)));
   hipLaunchKernelGGL(gbl_range_kernel, dim3(rgrid), dim3(kBlock), 0, st, k, n, stride, out_pair);
   ARX_CHECK_LAUNCH("gbl_range_kernel");
   return ARX_OK;

@@ -1162,7 +1162,8 @@ def hash_sum_leg(args, rank, world, device, rows_total, steps, warmup):
            "roofline": {"bound": "hbm", "kernel": "arx_groupby_range_sum_i64_consume (lines plan: gbl_scatter_kernel [write-combined range scatter, whole 128-byte lines of 12 records] + gbl_aggregate_kernel [direct-indexed LDS tables])",
                         "achieved": round(per_gpu, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 12,
-                        "traffic": load_traffic("groupby", rows // world)}}
+                        "traffic": load_traffic("groupby", rows // world, form="lines"),
+                        "traffic_source": "profiles/groupby_traffic.json (this round's FETCH_SIZE x 2 + WRITE_SIZE passes: profiles/r06_g_groupby_pmc_fetch_write.txt)"}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not EMU:
         if "hash_sum" in _CPU_PRE:      # taken before the plugin was registered (run_filter_take)
             leg["cpu_baseline"] = _CPU_PRE["hash_sum"]

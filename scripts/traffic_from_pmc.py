@@ -8,7 +8,7 @@ import sys
 
 name, path, runs, rows, source = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 form = sys.argv[6] if len(sys.argv) > 6 else None
-prefix = {"groupby": ("arx::gbp_", "arx::groupby_"), "sort": ("arx::msd", "arx::sort_", "arx::msdw_")}[name]
+prefix = {"groupby": ("arx::gbp_", "arx::groupby_", "arx::gbl_"), "sort": ("arx::msd", "arx::sort_", "arx::msdw_")}[name]
 kern = {}
 for line in open(path):
     m = re.match(r"^(arx::\S+?)[<(].*\s(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$", line)

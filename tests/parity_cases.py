@@ -2148,7 +2148,7 @@ def check_groupby_lines_plan(amd, rng_for, scale=1, wide_width=True):
     lib = amd._lib.get_lib()
     ctr = lambda name: int(lib.arx_get_counter(name))      # noqa: E731
     knobs = {b"groupby_partition_min_rows": 0, b"groupby_lines_min_rows": 1, b"groupby_lines_wgs": 2,
-             b"groupby_lines_unit_rows": 4096, b"groupby_lines_sample_rows": 1 << 26}
+             b"groupby_lines_unit_rows": 4096, b"groupby_lines_sample_rows": 1 << 24}
     for k_, v_ in knobs.items():
         assert lib.arx_set_option(k_, v_) == 0, k_
     try:
@@ -2186,8 +2186,8 @@ def check_groupby_lines_plan(amd, rng_for, scale=1, wide_width=True):
             check_groupby_sum(amd, k, v, use_pyarrow=False)
             assert ctr(b"groupby_slices_lines") == s1 + 1
             assert ctr(b"groupby_lines_outlier_rows") - o1 >= (3 if null_p else 4), "the far keys are outside the sampled range"
-        assert lib.arx_set_option(b"groupby_lines_sample_rows", 1 << 26) == 0
-        assert lib.arx_set_option(b"groupby_lines_range_sample_rows", 1 << 22) == 0
+        assert lib.arx_set_option(b"groupby_lines_sample_rows", 1 << 24) == 0
+        assert lib.arx_set_option(b"groupby_lines_range_sample_rows", 1 << 20) == 0
         # 4. a hot key: the scatter would need hundreds of rounds per batch — it gives up, nothing consumed, the other plans run
         rng = rng_for("gbl", 4)
         k = util.random_array(rng, np.int32, n, lo=0, hi=50000)
@@ -2220,8 +2220,8 @@ def check_groupby_lines_plan(amd, rng_for, scale=1, wide_width=True):
         assert d0 <= ctr(b"groupby_lines_declined")
     finally:
         for k_, v_ in {b"groupby_partition_min_rows": 1 << 17, b"groupby_lines_min_rows": 1 << 22, b"groupby_lines_wgs": 0,
-                       b"groupby_lines_unit_rows": 1 << 21, b"groupby_lines_sample_rows": 1 << 26,
-                       b"groupby_lines_range_sample_rows": 1 << 22}.items():
+                       b"groupby_lines_unit_rows": 1 << 21, b"groupby_lines_sample_rows": 1 << 24,
+                       b"groupby_lines_range_sample_rows": 1 << 20}.items():
             lib.arx_set_option(k_, v_)
 
 
