@@ -2809,7 +2809,7 @@ int arx_groupby_range_plan(int64_t max_rows, int32_t key_min, int32_t key_max, A
   GblPlan plan{};
   if (!gbl_partitions(key_min, key_max, &width, &wshift, &bins) ||
       !gbl_plan(std::max<int64_t>(max_rows, 1), key_min, width, wshift, bins, false, &plan)) {
-    set_error("arx_groupby_range_plan: keys in [%d, %d] need more than %d partitions of %d keys, or fewer than %d of 128 "
+    set_error("arx_groupby_range_plan: keys in [%d, %d] need more than %d partitions of %d keys, or fewer than %d of 8 "
               "(or too many rows for one pass): use the table operator", key_min, key_max, kGblMaxBins, kGblMaxWidth, kGblMinBins);
     return ARX_NOT_IMPLEMENTED;
   }
@@ -2850,7 +2850,7 @@ int arx_groupby_range_sum_i64_consume(void* state, const ArxRangePlan* plan, con
     set_error("arx_groupby_range_sum_i64_consume: rows with nulls go through the table operator (arx_groupby_sum_i64_consume)");
     return ARX_NOT_IMPLEMENTED;
   }
-  const bool pow2 = plan->width >= 128 && plan->width <= 8192 && (plan->width & (plan->width - 1)) == 0;
+  const bool pow2 = plan->width >= 8 && plan->width <= 8192 && (plan->width & (plan->width - 1)) == 0;
   if ((!pow2 && plan->width != kGblMaxWidth) || plan->partitions < 1 || plan->partitions > kGblMaxBins ||
       plan->slots != static_cast<int64_t>(plan->partitions) * plan->width || (reinterpret_cast<uint64_t>(state) & 15) != 0) {
     set_error("arx_groupby_range_sum_i64_consume: not a plan of arx_groupby_range_plan (or a state that is not 16-byte aligned)");

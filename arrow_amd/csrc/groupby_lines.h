@@ -33,7 +33,7 @@ constexpr int kGblK = 8;                     // lines per chunk (one global atom
 constexpr int kGblR = 4;                     // rows per thread and batch (8: the registers spill)
 constexpr int kGblCursorStride = 32;         // u32 between two bins' cursors: a 128-byte line each
 constexpr int kGblMaxWidth = 12288;          // groups per partition: sums u64 + counts u32 = 144 KB of LDS
-constexpr int kGblMinBins = 48;              // fewer bins: the cursors' lines are too few to take the chunk atomics
+constexpr int kGblMinBins = 384;             // fewer bins: a batch of 4096 rows brings a bin many times the 12 slots of its ONE line (round after round)
 constexpr uint32_t kGblSkip = 0xFFFFFFFFu;
 constexpr uint32_t kGblNever = 0xFFFFFFFEu;  // state of a bin this workgroup never wrote a line of
 constexpr int kGblUnitRows = 64;             // rows of a sampling unit (one wave load)
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(kGblThreads) void gbl_rooms_kernel(GblArgs a) {
       const double est = static_cast<double>(a.hist[b]) * static_cast<double>(a.sample_stride);
       const double sigma = a.sample_stride > 1 ? sqrt(est * static_cast<double>(a.sample_stride) + 1.0) : 0.0;
       const double rows = est + 6.0 * sigma + est / 64.0 + 64.0 * static_cast<double>(a.sample_stride > 1 ? a.sample_stride : 0);
-      double lines = rows / kGblCap + static_cast<double>(a.wgs) * (kGblK + 1) + 2.0;
+      // (a workgroup leaves at most two chunks' worth of pads in a bin: its last chunk's tail and the chunk it reserved ahead)
+      double lines = rows / kGblCap + static_cast<double>(a.wgs) * (2 * kGblK) + 2.0;
       lines = lines < 4.0e9 ? lines : 4.0e9;
       need[k] = (static_cast<uint32_t>(lines) + kGblK - 1) / kGblK * kGblK;
       mine += need[k];
@@ -795,7 +796,7 @@ static int64_t gbl_lines_for(int64_t n, int bins, int wgs, int64_t stride) {
   const double per_bin = static_cast<double>(n) / bins;
   const double sigma = stride > 1 ? std::sqrt(per_bin * static_cast<double>(stride) + 1.0) : 0.0;
   const double rows = per_bin + 6.0 * sigma + per_bin / 64.0 + 64.0 * static_cast<double>(stride > 1 ? stride : 0);
-  const double lines = rows / kGblCap + static_cast<double>(wgs) * (kGblK + 1) + 2.0 + kGblK;
+  const double lines = rows / kGblCap + static_cast<double>(wgs) * (2 * kGblK) + 2.0 + kGblK;
   return static_cast<int64_t>(lines * bins * 1.002) + 1024;
 }
 
@@ -814,12 +815,12 @@ static int64_t gbl_stride_for(int64_t n, int64_t sample_rows) {
   return std::max<int64_t>(1, n / std::max<int64_t>(sample_rows, kGblUnitRows));
 }
 
-// Partitions for keys in [kmin, kmax]: the narrowest width (128 ... 8192, 12288) that needs at most kGblMaxBins of them.
+// Partitions for keys in [kmin, kmax]: the narrowest width (8 ... 8192, 12288) that needs at most kGblMaxBins of them.
 // false: the range is too wide, or so narrow that the other plans' single LDS table is the better tool.
 static bool gbl_partitions(int64_t kmin, int64_t kmax, int* width, int* wshift, int* bins) {
   const int64_t range = kmax - kmin + 1;
   if (range < 1) return false;
-  int w = 128, sh = 7;
+  int w = 8, sh = 3;
   while (sh < 13 && (range + w - 1) / w > kGblMaxBins) {
     ++sh;
     w <<= 1;

@@ -52,6 +52,8 @@ static Knob<int> g_sort_msd_wide_gap2{1};          // wide form: level-2 buckets
 static Knob<int> g_sort_msd_wide_rec8{1};           // wide form over the caller's own column: 8-byte {32 key bits below the level-1 digit, row id} records through both levels and the finish (48.5 B/row instead of 64.5); rows whose 32 bits tie read their full keys from the column
 static Knob<int> g_sort_msd_wide_rec8_tie_shift{4};  // ... given up (and repeated with 12-byte records) once more than (rows >> shift) rows of ONE bucket tied (duplicate-heavy keys: every tie is two random 8-byte reads; 2e9 uniform keys: 0.9 per 1000)
 static Knob<int> g_sort_msd_wide_wc{256};          // rec8 form: level 1 write-combined by this many persistent workgroups (0 = the tile-at-a-time level 1)
+static Knob<int> g_sort_msd_wide_wc_form{2};       // 2: round 6's append kernel (every store a whole line); 1: round 5's rank-and-stage kernel (A/B knob sort_msd_wide_wc_form)
+static Knob<int> g_sort_msd_wide_wc_min_rows{1 << 17};   // form 2: rows a persistent workgroup must have (fewer workgroups for small inputs; knob sort_msd_wide_wc_min_rows — tests)
 static Knob<int> g_sort_msd_wide_wc_prefetch{1};   // ... with 16-row tiles and the next tile's keys requested before the current one's words leave
 static Knob<int> g_sort_msd_wide_l2w{3};           // rec8 form, level 2 in small workgroups (msdw_scatter2w_kernel): 1 = 512 threads x 16 rows, 4096-word stage (2 per CU); 2 = 512 x 16, 2048-word stage (3); 3 = 1024 x 8, 4096 (2); 0 = msdw_scatter2_kernel
 static Knob<int> g_sort_msd_wide_sample_strict{0}; // tests: a sampled attempt that overflows is an error instead of a silent exact re-run
@@ -1558,7 +1560,7 @@ constexpr size_t kMsdTableBytes = (3 * kMsdTableWords + size_t(128) * kMsdMaxChu
 constexpr int kMsdwMaxBins = 1024;    // level 1 (one thread per bin in the one-workgroup scans)
 constexpr int kMsdwMaxBins2 = 4096;   // level 2 (inside a level-1 bucket: short runs are fine there, xcd_contiguous)
 constexpr int kMsdwMaxBits = 20;
-constexpr size_t kMsdwTableBytes = (3 * ((size_t(1) << kMsdwMaxBits) + 64) + 10 * (kMsdwMaxBins + 64)) * 4;
+constexpr size_t kMsdwTableBytes = (3 * ((size_t(1) << kMsdwMaxBits) + 64) + 10 * (kMsdwMaxBins + 64) + kMsdwMaxBins * 32) * 4;   // (+ the write-combined level 1's cursors, a 128-byte line each)
 
 // The wide form lays its buckets out with room to spare instead of counting them exactly first: level-1 buckets
 // sized from a sampled histogram get est/32 + min(est/8 + 1, 16384) more rows, level-2 buckets a fixed room of
@@ -1602,7 +1604,7 @@ static SortPlan make_plan(int64_t length) {
 
 // which record form the wide sorts of this process ran with (arx_get_counter; tests and the bench's parity leg)
 static std::atomic<int64_t> g_sort_wide_runs{0}, g_sort_wide_rec8_runs{0}, g_sort_wide_rec8_ties{0}, g_sort_wide_rec8_given_up{0},
-    g_sort_wide_wc_runs{0};
+    g_sort_wide_wc_runs{0}, g_sort_wide_wc_given_up{0};
 
 int get_sort_counter(const char* name, int64_t* out) {
   if (strcmp(name, "sort_wide_runs") == 0) *out = g_sort_wide_runs.load();
@@ -1610,6 +1612,7 @@ int get_sort_counter(const char* name, int64_t* out) {
   else if (strcmp(name, "sort_wide_rec8_ties") == 0) *out = g_sort_wide_rec8_ties.load();
   else if (strcmp(name, "sort_wide_rec8_given_up") == 0) *out = g_sort_wide_rec8_given_up.load();
   else if (strcmp(name, "sort_wide_wc_runs") == 0) *out = g_sort_wide_wc_runs.load();
+  else if (strcmp(name, "sort_wide_wc_given_up") == 0) *out = g_sort_wide_wc_given_up.load();
   else return 0;
   return 1;
 }
@@ -1682,6 +1685,14 @@ int set_sort_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "sort_msd_wide_wc_prefetch") == 0) {
     g_sort_msd_wide_wc_prefetch = value != 0;
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_wc_min_rows") == 0) {
+    g_sort_msd_wide_wc_min_rows = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, 1 << 30)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_wc_form") == 0) {
+    g_sort_msd_wide_wc_form = value == 1 ? 1 : 2;
     return 1;
   }
   if (strcmp(name, "sort_msd_wide_rec8_tie_shift") == 0) {
@@ -2078,6 +2089,11 @@ constexpr int kMsdwThreads = 1024;
 constexpr int kMsdwRows = 8;
 constexpr int kMsdwTile = kMsdwThreads * kMsdwRows;   // 8192 rows
 constexpr int64_t kMsdwUnit = int64_t(1) << 19;        // rows per level-2 histogram work unit
+// the append form of the write-combined level 1 (msdw_scatter1wc2_kernel)
+constexpr int kMsdwWcK = 4;                  // lines per chunk (one returning global atomic each)
+constexpr int kMsdwWcR = 4;                  // rows per thread and batch
+constexpr int kMsdwWc2MinBins = 256;
+constexpr int kMsdwWcCursorStride = 32;      // u32 between two buckets' cursors: a 128-byte line each
 
 struct MsdwArgs {
   const uint64_t* src_keys;
@@ -2095,6 +2111,11 @@ struct MsdwArgs {
   int rec8;                // records are 8-byte words {the 32 key bits below the level-1 digit, row id} (msdw_word)
   int wc1;                 // rec8, level 1 write-combined (msdw_scatter1wc_kernel): > 0 = its persistent workgroups; buckets
                            // start on 128-byte lines, hold kMsdwPad words, and l1_count[] becomes their exact row counts
+  int wc_form;             // 1: round 5's rank-and-stage kernel; 2: round 6's append kernel (msdw_scatter1wc2_kernel): every
+                           // store a whole line, places from chunks of kMsdwWcK lines, l1_count[] = the PAD words of a bucket
+  uint32_t* wc_cursor;     // form 2: [2^b1 * kMsdwWcCursorStride] next free LINE of every bucket (a 128-byte line per cursor)
+  int64_t wc_rows_per_wg;  // form 2: rows of a workgroup's contiguous share
+  int wc_k;                // form 2: lines per chunk (1, 2 or 4: the largest whose pads fit the buffers' slack)
   int64_t capacity;        // records rec_x / rec_y can hold
   uint32_t* l1_count;      // [2^b1] histogram (of the sample)
   uint32_t* l1_start;      // [2^b1] first record of a level-1 bucket in rec_x (buckets may be followed by unused room)
@@ -2179,7 +2200,11 @@ __global__ __launch_bounds__(1024) void msdw_scan0_kernel(MsdwArgs a) {
     const uint64_t extra = est / 8 + 1 < 16384 ? est / 8 + 1 : 16384;
     room = tid < nb ? est + est / 32 + extra : 0;
   }
-  if (a.wc1 > 0) {   // whole lines; every workgroup ends with at most one padded line per bucket
+  if (a.wc1 > 0 && a.wc_form == 2) {   // whole chunks of lines; a workgroup leaves at most one padded line + one chunk's tail per bucket
+    const uint64_t chunk = 16u * static_cast<uint64_t>(a.wc_k);
+    room = tid < nb ? (room + chunk - 1) / chunk * chunk + chunk * 2 * static_cast<uint64_t>(a.wc1) : 0;
+    if (tid < nb) a.l1_count[tid] = 0;   // from here on: PAD words of the bucket (msdw_scatter1wc2_kernel adds them up)
+  } else if (a.wc1 > 0) {   // whole lines; every workgroup ends with at most one padded line per bucket
     room = tid < nb ? ((room + 15) & ~uint64_t(15)) + 16u * static_cast<uint64_t>(a.wc1) : 0;
     if (tid < nb) a.l1_count[tid] = 0;   // from here on: rows that arrived (msdw_scatter1wc_kernel adds them up)
   }
@@ -2196,6 +2221,7 @@ __global__ __launch_bounds__(1024) void msdw_scan0_kernel(MsdwArgs a) {
     a.l1_start[tid] = fits ? static_cast<uint32_t>(pre) : 0u;
     a.cursor1[tid] = fits ? static_cast<uint32_t>(pre) : 0u;
     a.l1_end[tid] = fits ? static_cast<uint32_t>(pre + room) : 0u;
+    if (a.wc1 > 0 && a.wc_form == 2) a.wc_cursor[tid * kMsdwWcCursorStride] = fits ? static_cast<uint32_t>(pre >> 4) : 0u;
   }
 }
 
@@ -2213,7 +2239,10 @@ __global__ __launch_bounds__(1024) void msdw_scan0b_kernel(MsdwArgs a) {
   uint32_t c = 0;      // rows of the bucket
   uint32_t span = 0;   // records it occupies (write-combined level 1: its rows + pads)
   if (tid < nb) {
-    const uint32_t lo = a.l1_start[tid], room_end = a.l1_end[tid], cur = a.cursor1[tid];
+    const bool form2 = a.wc1 > 0 && a.wc_form == 2;
+    const uint32_t lo = a.l1_start[tid], room_end = a.l1_end[tid];
+    const uint64_t cur64 = form2 ? static_cast<uint64_t>(a.wc_cursor[tid * kMsdwWcCursorStride]) << 4 : a.cursor1[tid];
+    const uint32_t cur = cur64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(cur64);
     if (cur > room_end || cur < lo) {
       atomicOr(&a.flags[0], 4u);
       span = room_end - lo;
@@ -2221,7 +2250,7 @@ __global__ __launch_bounds__(1024) void msdw_scan0b_kernel(MsdwArgs a) {
       span = cur - lo;
     }
     a.l1_end[tid] = lo + span;
-    c = a.wc1 > 0 ? a.l1_count[tid] : span;
+    c = form2 ? span - (a.l1_count[tid] < span ? a.l1_count[tid] : span) : a.wc1 > 0 ? a.l1_count[tid] : span;
   }
   const uint32_t tiles = (span + static_cast<uint32_t>(a.tile2) - 1) / static_cast<uint32_t>(a.tile2);
   const uint32_t units = static_cast<uint32_t>((static_cast<int64_t>(span) + kMsdwUnit - 1) / kMsdwUnit);
@@ -2846,6 +2875,283 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1wc_kernel(MsdwArgs 
   }
 }
 
+// Level 1 of the rec8 form, write-combined by APPENDING (round 6; the form the group-by's lines plan found,
+// csrc/groupby_lines.h, scripts/micro/wc_lines_bench.hip).  Round 5's kernel above ranks a tile, stages it through LDS and
+// still splits the line a bin's left-over shares with the tile's first words into two partial stores (19.06 GB written
+// for 16 GB of words, 3.3 TB/s: profiles/sort_traffic.json); with whole lines only the memory side alone takes 12 B read +
+// lines written to 814 frontiers at 5.1 TB/s (profiles/r06_c_*).  Here a row takes its slot in its bin's ONE line with a
+// returning LDS atomic on the bin's fill counter (all of a batch's atomics issued before the first dependent store), the
+// row that takes slot 15 queues the bin, and after a barrier 8 lanes copy each queued line out, 16 bytes each: every
+// global store is a whole 128-byte line.  A line's place comes from the workgroup's chunk of kMsdwWcK lines of the
+// bucket — one returning global atomic per chunk on a cursor that has a 128-byte line to itself, issued when the chunk's
+// last line leaves and picked up before the next flush.  A row that finds its line full is carried into the next batch
+// (two per thread); a thread with more falls back to append / flush rounds.  At its end a workgroup fills its partial
+// lines and the rest of its chunks with kMsdwPad words and adds their number to l1_count[] (rows = span - pads).
+// A bucket that outgrows its room writes into its neighbour's — msdw_scan0b_kernel sees the cursor past the room's end
+// (flags bit 4) and the level is repeated with exact counts; only the end of the buffer is never passed.
+constexpr uint32_t kMsdwWcSkip = 0xFFFFFFFFu;
+constexpr uint32_t kMsdwWcNever = 0xFFFFFFFEu;
+
+template <int R>
+__global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1wc2_kernel(MsdwArgs a) {
+  __shared__ uint64_t vals[kMsdwMaxBins * 16];
+  // state = next line (absolute) << 1 | the workgroup holds that line (rooms and chunks start at multiples of kMsdwWcK lines)
+  __shared__ uint32_t fill[kMsdwMaxBins], state[kMsdwMaxBins];
+  __shared__ uint16_t list[2][kMsdwMaxBins];
+  __shared__ uint32_t nlist[2], again[2];
+  const uint32_t K = static_cast<uint32_t>(a.wc_k);   // 1, 2 or 4
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nb = 1 << a.b1;
+  const int dshift = 64 - a.b1;
+  const uint32_t dmask = static_cast<uint32_t>(nb - 1);
+  const uint32_t total_lines = static_cast<uint32_t>(a.capacity >> 4);
+  uint64_t* __restrict__ out = reinterpret_cast<uint64_t*>(a.rec_x);
+  if (tid < nb) {
+    fill[tid] = 0;
+    state[tid] = kMsdwWcNever;
+  }
+  if (tid < 2) {
+    nlist[tid] = 0;
+    again[tid] = 0;
+  }
+  __syncthreads();
+  const int64_t lo = static_cast<int64_t>(blockIdx.x) * a.wc_rows_per_wg;
+  const int64_t hi = lo + a.wc_rows_per_wg < a.n ? lo + a.wc_rows_per_wg : a.n;
+  if (lo >= hi) return;
+  const bool wide_keys = key_type_is_64bit(a.raw);   // workgroup-uniform
+  uint64_t kc[R], kn[R];
+  auto issue = [&](int64_t r0) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      int64_t r = r0 + i * kMsdwThreads + tid;
+      r = r < hi ? r : hi - 1;
+      kn[i] = wide_keys ? __builtin_nontemporal_load(a.src_keys + r)
+                        : static_cast<uint64_t>(__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.src_keys) + r));
+    }
+  };
+  int cur = 0;
+  auto place = [&](uint32_t bin, uint32_t slot, uint64_t word) {
+    vals[bin * 16 + slot] = word;
+    if (slot == 15) list[cur][atomicAdd(&nlist[cur], 1u)] = static_cast<uint16_t>(bin);
+  };
+  auto next_line = [&](uint32_t bin) -> uint32_t {
+    uint32_t s = state[bin];
+    if ((s & 1u) == 0) s = (atomicAdd(&a.wc_cursor[bin * kMsdwWcCursorStride], K) << 1) | 1u;
+    const uint32_t line = s >> 1;
+    state[bin] = ((line + 1) << 1) | (((line + 1) & (K - 1)) != 0 ? 1u : 0u);
+    return line;
+  };
+  auto store_piece = [&](uint32_t line, int sub, arx_u32x4 d) {
+    if (line >= total_lines) {
+      atomicOr(&a.flags[0], 4u);
+      return;
+    }
+    *reinterpret_cast<arx_u32x4*>(out + static_cast<size_t>(line) * 16 + sub * 2) = d;
+  };
+  bool rf = false;   // the chunk this thread's bin (tid) waits for
+  uint32_t rv = 0;
+  auto flush_phase = [&]() -> uint32_t {
+    if (rf) {
+      state[tid] = (rv << 1) | 1u;
+      rf = false;
+    }
+    __syncthreads();
+    const uint32_t go = again[cur];
+    const uint32_t nf = nlist[cur];
+    if (tid == 0) {
+      nlist[cur ^ 1] = 0;
+      again[cur ^ 1] = 0;
+    }
+    const int sub = tid & 7;
+    for (uint32_t g0 = 0; g0 < nf; g0 += kMsdwThreads / 8) {   // (workgroup-uniform trip count: the shuffle below)
+      const uint32_t g = g0 + (tid >> 3);
+      const bool on = g < nf;
+      const uint32_t bin = on ? list[cur][g] : 0u;
+      uint32_t line = 0;
+      if (on && sub == 0) line = next_line(bin);
+      line = __shfl(line, lane & ~7, 64);
+      if (on) {
+        store_piece(line, sub, *reinterpret_cast<const arx_u32x4*>(&vals[bin * 16 + sub * 2]));
+        if (sub == 0) fill[bin] = 0;
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+    if (tid < nb) {
+      const uint32_t s = state[tid];
+      if ((s & 1u) == 0 && s != kMsdwWcNever) {
+        rv = atomicAdd(&a.wc_cursor[tid * kMsdwWcCursorStride], K);
+        rf = true;
+      }
+    }
+    return go;
+  };
+  uint64_t pw0 = 0, pw1 = 0;   // carried rows: their words and bins
+  uint32_t pb0 = 0, pb1 = 0, np = 0;
+  bool gave_up = false;
+  issue(lo);
+  for (int64_t r0 = lo; r0 < hi && !gave_up; r0 += static_cast<int64_t>(R) * kMsdwThreads) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) kc[i] = kn[i];
+    if (r0 + static_cast<int64_t>(R) * kMsdwThreads < hi) issue(r0 + static_cast<int64_t>(R) * kMsdwThreads);
+    uint32_t bn[R], sl[R];
+    uint64_t wd[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const uint64_t key = key_from_bits(kc[i], a.raw);
+      bn[i] = static_cast<uint32_t>((key << a.kshift) >> dshift) & dmask;
+      wd[i] = msdw_word(key, static_cast<uint32_t>(r0) + static_cast<uint32_t>(i * kMsdwThreads + tid), a.kshift, a.b1);
+    }
+    uint32_t cs0 = kMsdwWcSkip, cs1 = kMsdwWcSkip;
+#pragma unroll
+    for (int i = 0; i < R; ++i) sl[i] = r0 + i * kMsdwThreads + tid < hi ? atomicAdd(&fill[bn[i]], 1u) : kMsdwWcSkip;
+    if (np > 0) cs0 = atomicAdd(&fill[pb0], 1u);
+    if (np > 1) cs1 = atomicAdd(&fill[pb1], 1u);
+    uint32_t pend = 0, cpend = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      if (sl[i] < 16u) place(bn[i], sl[i], wd[i]);
+      else if (sl[i] != kMsdwWcSkip) pend |= 1u << i;
+    }
+    if (cs0 < 16u) place(pb0, cs0, pw0);
+    else if (cs0 != kMsdwWcSkip) cpend |= 1u;
+    if (cs1 < 16u) place(pb1, cs1, pw1);
+    else if (cs1 != kMsdwWcSkip) cpend |= 2u;
+    if (__builtin_popcount(pend) + __builtin_popcount(cpend) > 2) again[cur] = 1;
+    uint32_t go = flush_phase();
+    int rounds = 0;
+    while (go) {   // (workgroup-uniform) some thread holds more than two rows: rounds until nobody holds any
+      uint32_t still = 0, cstill = 0;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        if ((pend >> i) & 1u) {
+          const uint32_t s = atomicAdd(&fill[bn[i]], 1u);
+          if (s < 16u) place(bn[i], s, wd[i]);
+          else still |= 1u << i;
+        }
+      }
+      if (cpend & 1u) {
+        const uint32_t s = atomicAdd(&fill[pb0], 1u);
+        if (s < 16u) place(pb0, s, pw0);
+        else cstill |= 1u;
+      }
+      if (cpend & 2u) {
+        const uint32_t s = atomicAdd(&fill[pb1], 1u);
+        if (s < 16u) place(pb1, s, pw1);
+        else cstill |= 2u;
+      }
+      pend = still;
+      cpend = cstill;
+      if (pend | cpend) again[cur] = 1;
+      go = flush_phase();
+      if (++rounds > 64) {   // one digit takes most of the rows: 16 per round would take forever — flags bit 64, the level is
+        gave_up = true;      // repeated by the tile-at-a-time kernel
+        break;
+      }
+    }
+    uint64_t nw0 = 0, nw1 = 0;
+    uint32_t nb0 = 0, nb1 = 0, c = 0;
+    auto push = [&](uint64_t w, uint32_t b) {
+      if (c == 0) {
+        nw0 = w;
+        nb0 = b;
+      } else {
+        nw1 = w;
+        nb1 = b;
+      }
+      ++c;
+    };
+    if (cpend & 1u) push(pw0, pb0);
+    if (cpend & 2u) push(pw1, pb1);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      if ((pend >> i) & 1u) push(wd[i], bn[i]);
+    }
+    pw0 = nw0;
+    pb0 = nb0;
+    pw1 = nw1;
+    pb1 = nb1;
+    np = c < 2 ? c : 2;
+  }
+  if (gave_up) {   // (workgroup-uniform)
+    if (tid == 0) atomicOr(&a.flags[0], 64u);
+    return;
+  }
+  for (int rounds = 0;; ++rounds) {   // drain the carried rows
+    uint64_t nw0 = 0, nw1 = 0;
+    uint32_t nb0 = 0, nb1 = 0, c = 0;
+    auto retry = [&](uint64_t w, uint32_t b) {
+      const uint32_t s = atomicAdd(&fill[b], 1u);
+      if (s < 16u) {
+        place(b, s, w);
+        return;
+      }
+      if (c == 0) {
+        nw0 = w;
+        nb0 = b;
+      } else {
+        nw1 = w;
+        nb1 = b;
+      }
+      ++c;
+    };
+    if (np > 0) retry(pw0, pb0);
+    if (np > 1) retry(pw1, pb1);
+    pw0 = nw0;
+    pb0 = nb0;
+    pw1 = nw1;
+    pb1 = nb1;
+    np = c;
+    if (np != 0) again[cur] = 1;
+    if (!flush_phase()) break;
+    if (rounds > 4096) {
+      if (tid == 0) atomicOr(&a.flags[0], 64u);
+      return;
+    }
+  }
+  if (rf) state[tid] = (rv << 1) | 1u;
+  __syncthreads();
+  // the workgroup's partial lines filled up with pads, then whole lines of pads to the end of its last chunk of every bucket
+  const int sub = tid & 7;
+  for (int b0 = 0; b0 < nb; b0 += kMsdwThreads / 8) {   // (workgroup-uniform trip count: the shuffles below)
+    const int b = b0 + (tid >> 3);
+    const bool on = b < nb;
+    const uint32_t f = on ? fill[b] : 0u;
+    uint32_t line = 0;
+    if (on && f != 0 && sub == 0) line = next_line(static_cast<uint32_t>(b));
+    line = __shfl(line, lane & ~7, 64);
+    if (on && f != 0) {
+      arx_u32x4 d = *reinterpret_cast<const arx_u32x4*>(&vals[b * 16 + sub * 2]);
+      if (static_cast<uint32_t>(sub * 2) >= f) {
+        d[0] = 0xFFFFFFFFu;
+        d[1] = 0xFFFFFFFFu;
+      }
+      if (static_cast<uint32_t>(sub * 2 + 1) >= f) {
+        d[2] = 0xFFFFFFFFu;
+        d[3] = 0xFFFFFFFFu;
+      }
+      store_piece(line, sub, d);
+    }
+    uint32_t s = kMsdwWcNever;
+    if (on && sub == 0) s = state[b];
+    s = __shfl(s, lane & ~7, 64);
+    if ((s & 1u) != 0) {   // the rest of the workgroup's last chunk
+      const uint32_t first = s >> 1, left = K - (first & (K - 1));
+      for (uint32_t l = 0; l < left; ++l) {
+        arx_u32x4 z = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        store_piece(first + l, sub, z);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < nb) {   // (thread per bucket: consecutive addresses, one request per wave)
+    const uint32_t f = fill[tid], s = state[tid];
+    uint32_t pads = f != 0 ? 16u - f : 0u;
+    if ((s & 1u) != 0) pads += 16u * (K - ((s >> 1) & (K - 1)));
+    if (pads != 0) atomicAdd(&a.l1_count[tid], pads);
+  }
+}
+
 // index of the last entry of start[0..nb] (nb + 1 entries, non-decreasing, start[0] == 0) that is <= g, computed by
 // the first wave and returned to every thread through *slot
 __device__ __forceinline__ uint32_t msdw_owner(const uint32_t* __restrict__ start, int nb, uint32_t g, uint32_t* slot) {
@@ -3179,6 +3485,7 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
   a.l1_out = a.l1_end + small;
   a.room2 = a.l1_out + small;
   a.y_base = a.room2 + small;
+  a.wc_cursor = a.y_base + small;
   a.rec_x = rec_x;
   a.rec_y = rec_y;
   a.gap2 = (gap2 != 0 && roomy) ? 1 : 0;
@@ -3196,13 +3503,36 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
   const unsigned grid1 = static_cast<unsigned>(ceil_div(n, a.tile1));
   // rec8: level 1 write-combined by persistent workgroups when its bins fit their LDS lines and the pads (one line per
   // bin and workgroup at most) fit half of the buffers' slack
-  const int64_t wc_groups = std::min<int64_t>(int(g_sort_msd_wide_wc), grid1);
-  a.wc1 = (a.rec8 && roomy && wc_groups > 0 && nb1 <= kMsdwWcBins && 2 * 16 * wc_groups * nb1 <= a.capacity - n) ? static_cast<int>(wc_groups) : 0;
   // Level-1 bucket sizes: estimated from 1 tile in 2^shift (the buckets then get room to spare and level 2 reads
   // what actually arrived), or — shift 0, and whenever an estimate turned out too small — counted exactly.
   unsigned int max_room = 0;
   int sample_shift = roomy ? g_sort_msd_wide_sample_shift : 0;
   while (sample_shift > 0 && (static_cast<int64_t>(grid0) >> sample_shift) < 8) --sample_shift;   // too few chunks to sample
+  // (the append form keeps ONE line per bin: with few bins a batch of 4096 rows brings a bin many times its 16 slots and the
+  //  batch needs round after round — below 256 bins the rank-and-stage kernel of round 5)
+  a.wc_form = (g_sort_msd_wide_wc_form == 1 || nb1 < kMsdwWc2MinBins) ? 1 : 2;
+  // (form 2: contiguous shares of >= 2^17 rows per workgroup keep the chunk tails small; its pads — two chunks per bucket and
+  //  workgroup at most, + the rooms rounded up to chunks — must fit a third of the buffers' slack: the sampled rooms take up
+  //  to n / 32 + n / 8 of the n / 4)
+  const int64_t wc_groups = a.wc_form == 2 ? std::max<int64_t>(1, std::min<int64_t>(int(g_sort_msd_wide_wc), n / std::max<int64_t>(1, int64_t(g_sort_msd_wide_wc_min_rows))))
+                                           : std::min<int64_t>(int(g_sort_msd_wide_wc), grid1);
+  int64_t wc_slack = int64_t(16) * wc_groups * nb1;
+  a.wc_k = 0;
+  if (a.wc_form == 2) {
+    for (int k : {kMsdwWcK, 2, 1}) {
+      wc_slack = int64_t(16) * k * 2 * wc_groups * nb1 + int64_t(16) * k * nb1;
+      if ((sample_shift > 0 ? 3 : 1) * wc_slack <= a.capacity - n) {
+        a.wc_k = k;
+        break;
+      }
+    }
+  }
+  a.wc1 = (a.rec8 && roomy && int(g_sort_msd_wide_wc) > 0 && wc_groups > 0 &&
+           (a.wc_form == 2 ? nb1 <= kMsdwMaxBins && a.wc_k > 0 : nb1 <= kMsdwWcBins && 2 * wc_slack <= a.capacity - n)) ? static_cast<int>(wc_groups) : 0;
+  if (a.wc1 > 0 && a.wc_form == 2) {
+    const int64_t batch = int64_t(kMsdwWcR) * kMsdwThreads;
+    a.wc_rows_per_wg = ceil_div(ceil_div(n, a.wc1), batch) * batch;
+  }
   for (;;) {
     a.sample_shift = sample_shift;
     unsigned nch;
@@ -3230,7 +3560,9 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
     case 16: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 16, OUT8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break; \
     default: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 8, OUT8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break;  \
   }
-    if (a.wc1 > 0) {
+    if (a.wc1 > 0 && a.wc_form == 2) {
+      hipLaunchKernelGGL((msdw_scatter1wc2_kernel<kMsdwWcR>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+    } else if (a.wc1 > 0) {
       // tiles of 16 rows per thread with the next tile's keys prefetched (sort_msd_wide_wc_prefetch), or rpt1 rows without
       const int wc_rpt = g_sort_msd_wide_wc_prefetch ? (rpt1 >= 16 ? 16 : 8) : rpt1;
       if (g_sort_msd_wide_wc_prefetch && wc_rpt == 16) {
@@ -3255,12 +3587,17 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
     ARX_CHECK_LAUNCH("msdw_scatter1_kernel");
     hipLaunchKernelGGL(msdw_scan0b_kernel, dim3(1), dim3(1024), 0, st, a);
     ARX_CHECK_LAUNCH("msdw_scan0b_kernel");
-    if (sample_shift == 0 && a.gap2 == 0) break;   // exact counts all the way: nothing to look at yet
+    if (sample_shift == 0 && a.gap2 == 0 && !(a.wc1 > 0 && a.wc_form == 2)) break;   // exact counts all the way: nothing to look at yet
     unsigned int fl4[4] = {0, 0, 0, 0};
     ARX_HIP(hipMemcpyAsync(fl4, a.flags, 16, hipMemcpyDeviceToHost, st));
     ARX_HIP(hipStreamSynchronize(st));
     const unsigned int fl = fl4[0];
     max_room = fl4[3];
+    if ((fl & 64u) != 0) {   // the append form gave up on a hot digit (rounds without end): the tile-at-a-time level 1 instead
+      a.wc1 = 0;
+      g_sort_wide_wc_given_up.fetch_add(1, std::memory_order_relaxed);
+      continue;
+    }
     if ((fl & 4u) != 0) {   // a level-1 bucket outgrew its room; the source is untouched (level 2 has not run)
       if (sample_shift == 0) {
         set_error("array_sort_indices: internal error (exact level-1 histogram disagrees with the scatter)");
@@ -3280,7 +3617,7 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
     break;
   }
   // (write-combined level 1: the buckets hold up to one padded line per bin and workgroup beside their rows)
-  const int64_t spanned = n + (a.wc1 > 0 ? int64_t(16) * a.wc1 * nb1 : 0);
+  const int64_t spanned = n + (a.wc1 > 0 ? wc_slack : 0);
   const unsigned grid2 = static_cast<unsigned>(ceil_div(spanned, a.tile2)) + static_cast<unsigned>(nb1);
 #define ARX_MSDW_SCATTER2_(GAP, REC8)                                                                                      \
   switch (rpt2) {                                                                                  \

@@ -761,16 +761,16 @@ int arx_groupby_sum_i64_merge_records(void* state, int64_t capacity, const ArxGr
  * ------------------------------------------------------------------------- */
 typedef struct ArxRangePlan {
   int32_t key_min;          /* first key of partition 0 */
-  int32_t width;            /* keys per partition: 128 ... 8192 (powers of two) or 12288 */
-  int32_t partitions;       /* 48 ... 1216 */
+  int32_t width;            /* keys per partition: 8 ... 8192 (powers of two) or 12288 */
+  int32_t partitions;       /* 384 ... 1216 */
   int32_t reserved;
   int64_t slots;            /* partitions * width */
   uint64_t state_bytes;     /* slots * 16 */
   uint64_t workspace_bytes; /* scratch of a consume of up to max_rows rows (256-byte aligned) */
 } ArxRangePlan;
 /* The plan for keys in [key_min, key_max] and consumes of up to max_rows rows: ARX_NOT_IMPLEMENTED when the range needs
- * more than 1216 partitions of 12288 keys (14.9M keys) or fewer than 48 of 128 (one LDS table holds those groups: the
- * table operator's direct plan is the tool).  Pure host arithmetic. */
+ * more than 1216 partitions of 12288 keys (14.9M keys) or fewer than 384 of 8 (3072 keys: one LDS table holds those
+ * groups — the table operator's direct plan is the tool).  Pure host arithmetic. */
 int arx_groupby_range_plan(int64_t max_rows, int32_t key_min, int32_t key_max, ArxRangePlan* out);
 /* {min, max} of a SAMPLE of the key slots (one 64-row unit per stratum, about sample_rows rows in all; sample_rows >= length
  * reads every key) folded into out_min_max (device int32[2], initialised by the caller to {INT32_MAX, INT32_MIN}).  A

@@ -876,7 +876,8 @@ def check_sort_wide_many_bins(amd, lib, rng, n, bits, b2max, combos=((2, 1), (0,
         lib.arx_set_option(b"sort_msd_segment_rows", 1 << 27)
 
 
-def check_sort_wide_rec8(amd, lib, rng, n, bits=0, gap2=1, shift=0, rpt=(24, 16), b2max=11, wc=256, prefetch=1, l2w=1):
+def check_sort_wide_rec8(amd, lib, rng, n, bits=0, gap2=1, shift=0, rpt=(24, 16), b2max=11, wc=256, prefetch=1, l2w=1, wc_form=2,
+                         wc_min_rows=1 << 17):
     """The wide form over the caller's own column moves 8-byte words {32 key bits below the level-1 digit, row id}
     (sort_msd_wide_rec8, the default): level 2 and the finish take their digits from the word, the finish ranks whole
     words, and rows whose 32 bits tie read their full keys from the column.  Cases: uniform keys (almost no tie); keys
@@ -887,12 +888,14 @@ def check_sort_wide_rec8(amd, lib, rng, n, bits=0, gap2=1, shift=0, rpt=(24, 16)
     workgroups (whole 128-byte lines per bin, pad words at the end of a workgroup's share; 0 = tile at a time), prefetch:
     with the next tile's keys requested early (16- or 8-row tiles) or rpt[0]-row tiles without; b2max moves partition bits
     to level 1 (more bins there); l2w: level 2 in small workgroups (1 - 3: the shapes of msdw_scatter2w_kernel, 0: the
-    one-per-CU kernel of the 12-byte records reading words).  Counters say which form really ran."""
+    one-per-CU kernel of the 12-byte records reading words).  wc_form: 2 = round 6's append kernel (every store a whole
+    line; wc_min_rows: rows a workgroup must have, lowered so that small inputs still run several), 1 = round 5's
+    rank-and-stage kernel.  Counters say which form really ran."""
     opts = {b"sort_msd": 1, b"sort_msd_segment_rows": 4096, b"sort_msd_wide": 1, b"sort_msd_wide_bits": bits,
             b"sort_msd_wide_gap2": gap2, b"sort_msd_wide_sample_shift": shift, b"sort_msd_wide_rpt1": rpt[0],
             b"sort_msd_wide_rpt2": rpt[1], b"sort_msd_wide_rec8": 1, b"sort_msd_wide_rec8_tie_shift": 0,
             b"sort_msd_wide_b2max": b2max, b"sort_msd_wide_wc": wc, b"sort_msd_wide_wc_prefetch": prefetch,
-            b"sort_msd_wide_l2w": l2w}
+            b"sort_msd_wide_l2w": l2w, b"sort_msd_wide_wc_form": wc_form, b"sort_msd_wide_wc_min_rows": wc_min_rows}
     for k, v in opts.items():
         assert lib.arx_set_option(k, v) == 0
     ctr = lambda name: int(lib.arx_get_counter(name))
@@ -955,6 +958,8 @@ def check_sort_wide_rec8(amd, lib, rng, n, bits=0, gap2=1, shift=0, rpt=(24, 16)
         lib.arx_set_option(b"sort_msd_wide_rec8_tie_shift", 4)
         lib.arx_set_option(b"sort_msd_wide_wc", 256)
         lib.arx_set_option(b"sort_msd_wide_wc_prefetch", 1)
+        lib.arx_set_option(b"sort_msd_wide_wc_form", 2)
+        lib.arx_set_option(b"sort_msd_wide_wc_min_rows", 1 << 17)
         lib.arx_set_option(b"sort_msd_wide_l2w", 3)
         lib.arx_set_option(b"sort_msd_wide_b2max", 11)
         lib.arx_set_option(b"sort_msd_wide_bits", 0)
@@ -2197,7 +2202,7 @@ def check_groupby_lines_plan(amd, rng_for, scale=1, wide_width=True):
         check_groupby_sum(amd, k, v, use_pyarrow=False)
         assert ctr(b"groupby_lines_fallbacks") == f1 + 1 and ctr(b"groupby_slices_lines") == s1, "a hot key must send the rows to the other plans"
         # 5. declined before anything runs: keys over the whole int32 range, and a range of a few keys
-        for lo, hi in ((-2**31, 2**31 - 1), (10, 500)):
+        for lo, hi in ((-2**31, 2**31 - 1), (10, 2500)):
             rng = rng_for("gbl", 5, lo)
             k = util.random_array(rng, np.int32, n // 2, lo=lo, hi=hi)
             v = util.random_array(rng, np.int64, n // 2)
@@ -2292,7 +2297,8 @@ def check_groupby_range_state(amd, rng_for, scale=1):
         assert int(st.state.abs().sum()) == 0, "a declined consume must leave the state untouched"
         assert len(st.finalize()[0]) == 0
         # ranges the state does not plan for
-        assert R.plan_for(n, 0, 100, sampled=False) is None and R.plan_for(n, -2**31, 2**31 - 1, sampled=False) is None
+        assert R.plan_for(n, 0, 3000, sampled=False) is None and R.plan_for(n, -2**31, 2**31 - 1, sampled=False) is None
+        assert R.plan_for(n, 0, 3071, sampled=False).width == 8
         assert R.plan_for(n, 0, 1216 * 12288 - 1, sampled=False) is not None and R.plan_for(n, 0, 1216 * 12288, sampled=False) is None
     finally:
         lib.arx_set_option(b"groupby_lines_wgs", 0)

@@ -468,15 +468,17 @@ def test_sort_wide_many_level2_bins(emu_ctx, bits, b2max):
                                 b2max, combos=((2, 1),))
 
 
-@pytest.mark.parametrize("n,bits,gap2,shift,rpt,b2max,wc,prefetch,l2w", [(120_000, 0, 1, 0, (24, 16), 11, 256, 1, 1), (40_000, 12, 0, 2, (8, 8), 11, 0, 1, 2),
-                                                                         (40_000, 6, 1, 2, (16, 24), 11, 1, 0, 0), (120_000, 10, 1, 2, (24, 16), 4, 3, 1, 3),
-                                                                         (120_000, 10, 1, 2, (24, 16), 4, 2, 0, 1), (160_000, 12, 0, 0, (8, 16), 3, 2, 1, 2),
-                                                                         (60_000, 12, 1, 2, (24, 16), 11, 4, 1, 3)])
-def test_sort_wide_rec8_words(emu_ctx, n, bits, gap2, shift, rpt, b2max, wc, prefetch, l2w):
+@pytest.mark.parametrize("n,bits,gap2,shift,rpt,b2max,wc,prefetch,l2w,wc_form", [
+    (120_000, 0, 1, 0, (24, 16), 11, 256, 1, 1, 2), (40_000, 12, 0, 2, (8, 8), 11, 0, 1, 2, 2),
+    (40_000, 6, 1, 2, (16, 24), 11, 1, 0, 0, 2), (120_000, 10, 1, 2, (24, 16), 4, 3, 1, 3, 2),
+    (120_000, 10, 1, 2, (24, 16), 4, 2, 0, 1, 1), (160_000, 12, 0, 0, (8, 16), 3, 2, 1, 2, 2),
+    (160_000, 12, 0, 0, (8, 16), 3, 2, 1, 2, 1), (60_000, 12, 1, 2, (24, 16), 11, 4, 1, 3, 2)])
+def test_sort_wide_rec8_words(emu_ctx, n, bits, gap2, shift, rpt, b2max, wc, prefetch, l2w, wc_form):
     """8-byte {key bits, row id} words through the wide form: ties below the word, duplicates, the tie budget, fall-backs;
-    level 1 tile at a time and write-combined (2 to 512 bins, sampled and exact rooms, counted and fixed level-2 buckets)."""
+    level 1 tile at a time and write-combined — round 6's append kernel (wc_form 2) and round 5's rank-and-stage kernel
+    (2 to 512 bins, sampled and exact rooms, chunks of 4 / 2 / 1 lines, counted and fixed level-2 buckets)."""
     P.check_sort_wide_rec8(emu_ctx, emu_ctx._lib.get_lib(), rng_for("wide-rec8", bits, gap2), n, bits=bits, gap2=gap2, shift=shift,
-                           rpt=rpt, b2max=b2max, wc=wc, prefetch=prefetch, l2w=l2w)
+                           rpt=rpt, b2max=b2max, wc=wc, prefetch=prefetch, l2w=l2w, wc_form=wc_form, wc_min_rows=1 << 13)
 
 
 def test_null_count_bookkeeping(emu_ctx):
