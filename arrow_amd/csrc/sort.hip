@@ -51,8 +51,10 @@ static Knob<int> g_sort_msd_prefix{1};             // MSD forms take their digit
 static Knob<int> g_sort_msd_wide_gap2{1};          // wide form: level-2 buckets get a fixed room each (bucket mean + 6 sigma + 64) instead of an exact histogram pass
 static Knob<int> g_sort_msd_wide_rec8{1};           // wide form over the caller's own column: 8-byte {32 key bits below the level-1 digit, row id} records through both levels and the finish (48.5 B/row instead of 64.5); rows whose 32 bits tie read their full keys from the column
 static Knob<int> g_sort_msd_wide_rec8_tie_shift{4};  // ... given up (and repeated with 12-byte records) once more than (rows >> shift) rows of ONE bucket tied (duplicate-heavy keys: every tie is two random 8-byte reads; 2e9 uniform keys: 0.9 per 1000)
+constexpr int kMsdwWcRDefault = 4;
 static Knob<int> g_sort_msd_wide_wc{256};          // rec8 form: level 1 write-combined by this many persistent workgroups (0 = the tile-at-a-time level 1)
 static Knob<int> g_sort_msd_wide_wc_form{2};       // 2: round 6's append kernel (every store a whole line); 1: round 5's rank-and-stage kernel (A/B knob sort_msd_wide_wc_form)
+static Knob<int> g_sort_msd_wide_wc_rows{kMsdwWcRDefault};   // form 2: rows per thread and batch, 4 / 6 / 8 (A/B knob sort_msd_wide_wc_rows)
 static Knob<int> g_sort_msd_wide_wc_min_rows{1 << 17};   // form 2: rows a persistent workgroup must have (fewer workgroups for small inputs; knob sort_msd_wide_wc_min_rows — tests)
 static Knob<int> g_sort_msd_wide_wc_prefetch{1};   // ... with 16-row tiles and the next tile's keys requested before the current one's words leave
 static Knob<int> g_sort_msd_wide_l2w{3};           // rec8 form, level 2 in small workgroups (msdw_scatter2w_kernel): 1 = 512 threads x 16 rows, 4096-word stage (2 per CU); 2 = 512 x 16, 2048-word stage (3); 3 = 1024 x 8, 4096 (2); 0 = msdw_scatter2_kernel
@@ -1687,6 +1689,10 @@ int set_sort_option(const char* name, int64_t value) {
     g_sort_msd_wide_wc_prefetch = value != 0;
     return 1;
   }
+  if (strcmp(name, "sort_msd_wide_wc_rows") == 0) {
+    g_sort_msd_wide_wc_rows = value == 8 ? 8 : value == 6 ? 6 : 4;
+    return 1;
+  }
   if (strcmp(name, "sort_msd_wide_wc_min_rows") == 0) {
     g_sort_msd_wide_wc_min_rows = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, 1 << 30)));
     return 1;
@@ -2091,7 +2097,6 @@ constexpr int kMsdwTile = kMsdwThreads * kMsdwRows;   // 8192 rows
 constexpr int64_t kMsdwUnit = int64_t(1) << 19;        // rows per level-2 histogram work unit
 // the append form of the write-combined level 1 (msdw_scatter1wc2_kernel)
 constexpr int kMsdwWcK = 4;                  // lines per chunk (one returning global atomic each)
-constexpr int kMsdwWcR = 4;                  // rows per thread and batch
 constexpr int kMsdwWc2MinBins = 256;
 constexpr int kMsdwWcCursorStride = 32;      // u32 between two buckets' cursors: a 128-byte line each
 
@@ -3002,6 +3007,8 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1wc2_kernel(MsdwArgs
       bn[i] = static_cast<uint32_t>((key << a.kshift) >> dshift) & dmask;
       wd[i] = msdw_word(key, static_cast<uint32_t>(r0) + static_cast<uint32_t>(i * kMsdwThreads + tid), a.kshift, a.b1);
     }
+    // (a branch-free form of this phase — dummy bins for what does not apply, one branch for the queueing — measured no
+    //  faster, 24.8 against 24.3 ms end to end: the kernel does not wait for its instruction stream, profiles/r06_j_*)
     uint32_t cs0 = kMsdwWcSkip, cs1 = kMsdwWcSkip;
 #pragma unroll
     for (int i = 0; i < R; ++i) sl[i] = r0 + i * kMsdwThreads + tid < hi ? atomicAdd(&fill[bn[i]], 1u) : kMsdwWcSkip;
@@ -3514,23 +3521,27 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
   // (form 2: contiguous shares of >= 2^17 rows per workgroup keep the chunk tails small; its pads — two chunks per bucket and
   //  workgroup at most, + the rooms rounded up to chunks — must fit a third of the buffers' slack: the sampled rooms take up
   //  to n / 32 + n / 8 of the n / 4)
-  const int64_t wc_groups = a.wc_form == 2 ? std::max<int64_t>(1, std::min<int64_t>(int(g_sort_msd_wide_wc), n / std::max<int64_t>(1, int64_t(g_sort_msd_wide_wc_min_rows))))
-                                           : std::min<int64_t>(int(g_sort_msd_wide_wc), grid1);
+  int64_t wc_groups = std::min<int64_t>(int(g_sort_msd_wide_wc), grid1);
   int64_t wc_slack = int64_t(16) * wc_groups * nb1;
   a.wc_k = 0;
   if (a.wc_form == 2) {
+    const int64_t groups2 = std::max<int64_t>(1, std::min<int64_t>(int(g_sort_msd_wide_wc), n / std::max<int64_t>(1, int64_t(g_sort_msd_wide_wc_min_rows))));
     for (int k : {kMsdwWcK, 2, 1}) {
-      wc_slack = int64_t(16) * k * 2 * wc_groups * nb1 + int64_t(16) * k * nb1;
-      if ((sample_shift > 0 ? 3 : 1) * wc_slack <= a.capacity - n) {
+      const int64_t slack2 = int64_t(16) * k * 2 * groups2 * nb1 + int64_t(16) * k * nb1;
+      if ((sample_shift > 0 ? 3 : 1) * slack2 <= a.capacity - n) {
         a.wc_k = k;
+        wc_groups = groups2;
+        wc_slack = slack2;
         break;
       }
     }
+    if (a.wc_k == 0) a.wc_form = 1;   // (its pads do not fit this input's slack: round 5's kernel pads one line per bin and workgroup)
   }
   a.wc1 = (a.rec8 && roomy && int(g_sort_msd_wide_wc) > 0 && wc_groups > 0 &&
-           (a.wc_form == 2 ? nb1 <= kMsdwMaxBins && a.wc_k > 0 : nb1 <= kMsdwWcBins && 2 * wc_slack <= a.capacity - n)) ? static_cast<int>(wc_groups) : 0;
+           (a.wc_form == 2 ? nb1 <= kMsdwMaxBins : nb1 <= kMsdwWcBins && 2 * wc_slack <= a.capacity - n)) ? static_cast<int>(wc_groups) : 0;
+  const int wc_r = g_sort_msd_wide_wc_rows == 8 ? 8 : g_sort_msd_wide_wc_rows == 6 ? 6 : 4;   // (read once: the grid's shares and the kernel must agree)
   if (a.wc1 > 0 && a.wc_form == 2) {
-    const int64_t batch = int64_t(kMsdwWcR) * kMsdwThreads;
+    const int64_t batch = int64_t(wc_r) * kMsdwThreads;
     a.wc_rows_per_wg = ceil_div(ceil_div(n, a.wc1), batch) * batch;
   }
   for (;;) {
@@ -3561,7 +3572,13 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
     default: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 8, OUT8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break;  \
   }
     if (a.wc1 > 0 && a.wc_form == 2) {
-      hipLaunchKernelGGL((msdw_scatter1wc2_kernel<kMsdwWcR>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      if (wc_r == 8) {
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<8>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (wc_r == 6) {
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<6>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else {
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<4>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      }
     } else if (a.wc1 > 0) {
       // tiles of 16 rows per thread with the next tile's keys prefetched (sort_msd_wide_wc_prefetch), or rpt1 rows without
       const int wc_rpt = g_sort_msd_wide_wc_prefetch ? (rpt1 >= 16 ? 16 : 8) : rpt1;

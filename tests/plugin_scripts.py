@@ -1061,6 +1061,9 @@ ACERO_DEVICE_SCRIPT = textwrap.dedent(r'''
         stock0 = {f: lib.arrow_amd_plugin_calls(f, 0) for f in names}
         lib.arrow_amd_plugin_aggregate_flushes.restype = ctypes.c_int64
         lib.arrow_amd_plugin_set_aggregate_flush_rows.argtypes = [ctypes.c_int64]
+        # (round 6: a stock table_source over a device table delivers whole chunks by default; this case is about the node's
+        #  staging of MANY small batches, so the reference SourceNode's 32Ki-row morsels are asked for: the opt-out)
+        assert lib.arrow_amd_override_acero_factories(-1) == 0, lib.arrow_amd_plugin_last_error()
         for threads in (False, True):
             # null-free device batches are remembered and copied into the node's staging columns many at a time by
             # one launch (arx_copy_segments): with the default threshold (one copy at the end) and with a small one
@@ -1081,6 +1084,7 @@ ACERO_DEVICE_SCRIPT = textwrap.dedent(r'''
                 assert got.equals(want) and lib.arrow_amd_plugin_aggregate_flushes() == f0
                 lib.arrow_amd_plugin_set_aggregate_stage_nulls(1)
         lib.arrow_amd_plugin_set_aggregate_flush_rows(1 << 21)
+        assert lib.arrow_amd_override_acero_factories(0) == 0
         for f in names:   # FilterNode's expression, its per-column Filter, the projection and the group-by all ran on the GPU
             assert lib.arrow_amd_plugin_calls(f, 1) > gpu0[f], f
             assert lib.arrow_amd_plugin_calls(f, 0) == stock0[f], f
@@ -2132,6 +2136,9 @@ TABLE_SOURCE_SCRIPT = textwrap.dedent(r'''
     assert got.equals(want_rows)
     assert lib.arrow_amd_plugin_calls(b"array_filter", 1) - f0 > 2 * 3
     lib.arrow_amd_plugin_set_table_source_rows(1 << 27)
+    # (round 6: the stock table_source delivers whole chunks of a device table by default; the opt-out brings the reference
+    #  SourceNode's morsels back for this part)
+    assert lib.arrow_amd_override_acero_factories(-1) == 0, lib.arrow_amd_plugin_last_error()
     # ---- coalesce_rocm behind the STOCK source: its 32Ki-row batches are joined again before the filter sees them
     # (consecutive slices of one device array: no copy); the rows, values and order of the reference plan
     lib.arrow_amd_plugin_coalesced_batches.restype = ctypes.c_int64
@@ -2172,6 +2179,7 @@ TABLE_SOURCE_SCRIPT = textwrap.dedent(r'''
     c0 = lib.arrow_amd_plugin_coalesced_batches()
     got = plan("table_source", t, [acero.Declaration("coalesce_rocm", any_options)] + filter_project()).to_table(use_threads=False)
     assert got.equals(want_rows) and lib.arrow_amd_plugin_coalesced_batches() == c0
+    assert lib.arrow_amd_override_acero_factories(0) == 0
     # ---- ... -> aggregate_rocm: large batches are consumed where they lie (no staging copy)
     lib.arrow_amd_plugin_set_aggregate_direct_rows(SC(100_000))
     agg = [acero.Declaration("filter", acero.FilterNodeOptions(pred)),
