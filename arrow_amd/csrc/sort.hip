@@ -552,6 +552,128 @@ __global__ __launch_bounds__(kBlock) void sort_unpack_records_kernel(const ArxSo
   }
 }
 
+// ---- round 6: the sharded sort's partition WITHOUT a stable pass.  The records carry GLOBAL row numbers and the receiver
+// sorts them by (key, row) (arx_sort_records), so the order inside a destination's block is free: rows go straight from the
+// column to their destination's block.  (arx_sort_partition_records orders rows by destination with a stable LSD pass over
+// {destination, row} pairs + a gather: 5 GB moved at 0.8 TB/s for 2.5e8 rows, profiles/r04_u_*.)
+constexpr int kSortPartMax = 64;          // destinations
+constexpr int kSortPartThreads = 1024;
+constexpr int kSortPartRows = 8;          // rows per thread: 8192-row tiles
+
+__device__ __forceinline__ uint32_t sort_dest_of(uint32_t bin, const uint32_t* __restrict__ split, int nsplit) {
+  uint32_t d = 0;
+  for (int j = 0; j < nsplit; ++j) d += (split[j] <= bin) ? 1u : 0u;
+  return d;
+}
+
+// counts[d] += rows of destination d (one LDS histogram per workgroup)
+__global__ __launch_bounds__(kSortPartThreads) void sort_part_count_kernel(const uint64_t* __restrict__ values, int64_t n, int is_signed,
+                                                                          int descending, int bits, uint64_t base, int shift,
+                                                                          const uint32_t* __restrict__ split, int num_parts,
+                                                                          unsigned long long* __restrict__ counts) {
+  __shared__ uint32_t h[kSortPartMax], sp[kSortPartMax];
+  const int tid = threadIdx.x;
+  if (tid < kSortPartMax) {
+    h[tid] = 0;
+    sp[tid] = tid < num_parts - 1 ? split[tid] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kSortPartThreads;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kSortPartThreads + tid; i < n; i += stride) {
+    const uint64_t tk = key_transform(values[i], is_signed != 0, descending != 0);
+    atomicAdd(&h[sort_dest_of(sort_window_bin(tk, base, shift, bits), sp, num_parts - 1)], 1u);
+  }
+  __syncthreads();
+  if (tid < num_parts && h[tid] != 0) atomicAdd(&counts[tid], static_cast<unsigned long long>(h[tid]));
+}
+
+// cursor[d] = first record of destination d's block (exclusive scan of the counts)
+__global__ void sort_part_scan_kernel(const unsigned long long* __restrict__ counts, int num_parts, unsigned long long* __restrict__ cursor) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    unsigned long long run = 0;
+    for (int d = 0; d < num_parts; ++d) {
+      cursor[d] = run;
+      run += counts[d];
+    }
+  }
+}
+
+// one tile of 8192 rows per workgroup: ranks inside the tile by LDS atomics, ONE returning global atomic per (tile,
+// destination) for the tile's run in the destination's block, records {transformed key, row_base + row} written in runs
+__global__ __launch_bounds__(kSortPartThreads) void sort_part_scatter_kernel(const uint64_t* __restrict__ values, int64_t n, int is_signed,
+                                                                            int descending, int bits, uint64_t base, int shift,
+                                                                            const uint32_t* __restrict__ split, int num_parts,
+                                                                            uint32_t row_base, unsigned long long* __restrict__ cursor,
+                                                                            ArxSortRecord* __restrict__ out) {
+  __shared__ uint32_t h[kSortPartMax], sp[kSortPartMax];
+  __shared__ unsigned long long gbase[kSortPartMax];
+  const int tid = threadIdx.x;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * (kSortPartThreads * kSortPartRows);
+  if (tid < kSortPartMax) {
+    h[tid] = 0;
+    sp[tid] = tid < num_parts - 1 ? split[tid] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  uint64_t tk[kSortPartRows];
+  uint32_t dest[kSortPartRows], rank[kSortPartRows];
+#pragma unroll
+  for (int i = 0; i < kSortPartRows; ++i) {
+    const int64_t r = row0 + i * kSortPartThreads + tid;
+    tk[i] = key_transform(values[r < n ? r : n - 1], is_signed != 0, descending != 0);
+  }
+#pragma unroll
+  for (int i = 0; i < kSortPartRows; ++i) {
+    const int64_t r = row0 + i * kSortPartThreads + tid;
+    dest[i] = sort_dest_of(sort_window_bin(tk[i], base, shift, bits), sp, num_parts - 1);
+    rank[i] = r < n ? atomicAdd(&h[dest[i]], 1u) : 0u;
+  }
+  __syncthreads();
+  if (tid < num_parts) gbase[tid] = h[tid] != 0 ? atomicAdd(&cursor[tid], static_cast<unsigned long long>(h[tid])) : 0ull;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kSortPartRows; ++i) {
+    const int64_t r = row0 + i * kSortPartThreads + tid;
+    if (r < n) {
+      ArxSortRecord rec;
+      rec.key_lo = static_cast<uint32_t>(tk[i]);
+      rec.key_hi = static_cast<uint32_t>(tk[i] >> 32);
+      rec.row = row_base + static_cast<uint32_t>(r);
+      out[gbase[dest[i]] + rank[i]] = rec;
+    }
+  }
+}
+
+// {row as the key, position} of every record / the records at the given positions: what puts the records in row order
+// before the LSD passes of arx_sort_records (stable on the key alone)
+__global__ __launch_bounds__(kBlock) void sort_records_rows_kernel(const ArxSortRecord* __restrict__ rec, int64_t n,
+                                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ pos) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    keys[i] = rec[i].row;
+    pos[i] = static_cast<uint32_t>(i);
+  }
+}
+__global__ __launch_bounds__(kBlock) void sort_records_gather_kernel(const ArxSortRecord* __restrict__ rec, const uint32_t* __restrict__ pos,
+                                                                     int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const ArxSortRecord r = rec[pos[i]];
+    keys[i] = (static_cast<uint64_t>(r.key_hi) << 32) | r.key_lo;
+    idx[i] = r.row;
+  }
+}
+
+// records -> the (keys, row ids) pair of arrays the sorts read
+__global__ __launch_bounds__(kBlock) void sort_split_records_kernel(const ArxSortRecord* __restrict__ rec, int64_t n,
+                                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const ArxSortRecord r = rec[i];
+    keys[i] = (static_cast<uint64_t>(r.key_hi) << 32) | r.key_lo;
+    idx[i] = r.row;
+  }
+}
+
 __global__ void widen_counts_kernel(const uint32_t* __restrict__ in, int n, int64_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i];
@@ -4373,6 +4495,178 @@ int arx_sort_unpack_records(const ArxSortRecord* records, int64_t num_records, c
   hipLaunchKernelGGL(sort_unpack_records_kernel, dim3(g), dim3(kBlock), 0, as_stream(stream), records, num_records,
                      block_meta, num_blocks, nulls_first, out_keys, out_rows, out_null_rows);
   ARX_CHECK_LAUNCH("sort_unpack_records_kernel");
+  return ARX_OK;
+}
+
+int arx_sort_partition_records_global(const ArxSpan* values, int is_signed, int order, int bits, const ArxSortKeyWindow* window,
+                                      const uint32_t* splitter_bins, int num_parts, uint32_t row_base, void* ws, size_t ws_bytes,
+                                      ArxSortRecord* out_records, int64_t* out_counts, void* stream) {
+  if (values == nullptr || num_parts < 1 || num_parts > kSortPartMax || bits < 1 || bits > 12 || out_counts == nullptr ||
+      (num_parts > 1 && splitter_bins == nullptr)) {
+    set_error("bad arguments to arx_sort_partition_records_global (1 to %d destinations)", kSortPartMax);
+    return ARX_INVALID;
+  }
+  if (values->null_count != 0 && values->validity != nullptr) {
+    set_error("arx_sort_partition_records_global: shards with nulls go through arx_sort_partition_records_window");
+    return ARX_NOT_IMPLEMENTED;
+  }
+  uint64_t base;
+  int shift;
+  if (sort_window_ok(window, &base, &shift) != ARX_OK) return ARX_INVALID;
+  const int64_t len = values->length;
+  if (len < 0 || static_cast<int64_t>(row_base) + len > (int64_t(1) << 32)) {
+    set_error("arx_sort_partition_records_global: global row numbers must fit 32 bits");
+    return ARX_NOT_IMPLEMENTED;
+  }
+  hipStream_t st = as_stream(stream);
+  ARX_HIP(hipMemsetAsync(out_counts, 0, static_cast<size_t>(num_parts) * 8, st));
+  if (len == 0) return ARX_OK;
+  if (values->data == nullptr || out_records == nullptr || ws == nullptr || ws_bytes < 1024 || (reinterpret_cast<uint64_t>(ws) & 7) != 0) {
+    set_error("arx_sort_partition_records_global: NULL buffer or no scratch (1 KB, 8-byte aligned)");
+    return ARX_INVALID;
+  }
+  uint32_t* split = static_cast<uint32_t*>(ws);                                                      // [64]
+  unsigned long long* cursor = reinterpret_cast<unsigned long long*>(static_cast<uint8_t*>(ws) + 256);   // [64]
+  if (num_parts > 1) {
+    ARX_HIP(hipMemcpyAsync(split, splitter_bins, static_cast<size_t>(num_parts - 1) * 4, hipMemcpyHostToDevice, st));
+    ARX_HIP(hipStreamSynchronize(st));   // the caller's host array may go away after we return
+  }
+  const uint64_t* vals = static_cast<const uint64_t*>(values->data) + values->offset;
+  const int desc = order == ARX_SORT_DESCENDING ? 1 : 0;
+  const unsigned gc = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(len, kSortPartThreads * 8), 1024)));
+  hipLaunchKernelGGL(sort_part_count_kernel, dim3(gc), dim3(kSortPartThreads), 0, st, vals, len, is_signed, desc, bits, base, shift,
+                     split, num_parts, reinterpret_cast<unsigned long long*>(out_counts));
+  ARX_CHECK_LAUNCH("sort_part_count_kernel");
+  hipLaunchKernelGGL(sort_part_scan_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned long long*>(out_counts), num_parts, cursor);
+  ARX_CHECK_LAUNCH("sort_part_scan_kernel");
+  const unsigned gs = static_cast<unsigned>(ceil_div(len, kSortPartThreads * kSortPartRows));
+  hipLaunchKernelGGL(sort_part_scatter_kernel, dim3(gs), dim3(kSortPartThreads), 0, st, vals, len, is_signed, desc, bits, base, shift,
+                     split, num_parts, row_base, cursor, out_records);
+  ARX_CHECK_LAUNCH("sort_part_scatter_kernel");
+  return ARX_OK;
+}
+
+// records by (key, row) ascending -> their rows, widened to 64 bits.  The flow of arx_sort_indices over a PREPPED source
+// (keys + row ids beside the column): wide form > segmented / hybrid MSD > sampled splitters > LSD passes.
+int arx_sort_records(const ArxSortRecord* records, int64_t num_records, void* ws, size_t ws_bytes, uint64_t* out_rows, void* stream) {
+  if (num_records < 0) {
+    set_error("arx_sort_records: negative length");
+    return ARX_INVALID;
+  }
+  if (num_records == 0) return ARX_OK;
+  if (num_records > static_cast<int64_t>(UINT32_MAX)) {
+    set_error("arx_sort_records: more than UINT32_MAX records is not implemented");
+    return ARX_NOT_IMPLEMENTED;
+  }
+  SortPlan plan = make_plan(num_records);
+  if (records == nullptr || out_rows == nullptr || ws == nullptr || ws_bytes < plan.total || (reinterpret_cast<uint64_t>(ws) & 255) != 0) {
+    set_error("arx_sort_records: NULL buffer, or the workspace is too small (arx_sort_indices_workspace_bytes) / not 256-byte aligned");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  const int64_t n = num_records;
+  uint8_t* w = static_cast<uint8_t*>(ws);
+  uint64_t* keys_a = reinterpret_cast<uint64_t*>(w + plan.off_keys_a);
+  uint64_t* keys_b = reinterpret_cast<uint64_t*>(w + plan.off_keys_b);
+  uint32_t* idx_a = reinterpret_cast<uint32_t*>(w + plan.off_idx_a);
+  uint32_t* idx_b = reinterpret_cast<uint32_t*>(w + plan.off_idx_b);
+  MsdRec* rec_a = reinterpret_cast<MsdRec*>(w + plan.off_keys_a);
+  MsdRec* rec_b = reinterpret_cast<MsdRec*>(w + plan.off_keys_b);
+  const int64_t rec_cap = n + msdw_slack_rows(n);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(w + plan.off_hist);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(w + plan.off_totals);
+  uint8_t* tables = w + plan.off_msd;
+  const unsigned gprep = static_cast<unsigned>(std::min<int64_t>(ceil_div(n, kBlock), 2048));
+  auto prep = [&]() -> int {   // (a failed attempt may have written over the prepped source: the records are untouched)
+    hipLaunchKernelGGL(sort_split_records_kernel, dim3(gprep), dim3(kBlock), 0, st, records, n, keys_a, idx_a);
+    ARX_CHECK_LAUNCH("sort_split_records_kernel");
+    return ARX_OK;
+  };
+  int rc = prep();
+  if (rc != ARX_OK) return rc;
+  const bool try_msd = g_sort_msd != 0 && n < (int64_t(1) << 32) - kMsdTile && (g_sort_msd == 1 ? n >= 256 : n >= g_sort_msd_min_rows);
+  const bool segmented = n > g_sort_msd_segment_rows;
+  if (try_msd && g_sort_msd_sampled != 2) {
+    int ks = 0, overflowed = 1;
+    rc = sort_shared_prefix_bits(keys_a, 0, n, reinterpret_cast<unsigned long long*>(tables), st, &ks);
+    if (rc != ARX_OK) return rc;
+    const bool wide = segmented && g_sort_msd_wide != 0;
+    if (wide) {
+      int rec8 = 0;   // (row ids are not positions in a column: full records)
+      rc = run_msd_sort_wide(keys_a, idx_a, 0, n, rec_b, rec_a, rec_cap, tables, out_rows, g_sort_msd_wide_gap2, ks, st, &overflowed, &rec8);
+      if (rc == ARX_OK && overflowed == 2) {
+        rc = prep();
+        if (rc == ARX_OK) rc = run_msd_sort_wide(keys_a, idx_a, 0, n, rec_b, rec_a, rec_cap, tables, out_rows, 0, ks, st, &overflowed, &rec8);
+      }
+      if (rc == ARX_OK && overflowed) rc = prep();
+    }
+    if (rc == ARX_OK && overflowed) {
+      rc = segmented ? run_msd_sort_segmented(keys_a, idx_a, 0, n, keys_b, idx_b, keys_a, idx_a, tables, out_rows, st, &overflowed, ks)
+                     : run_msd_sort(keys_a, idx_a, 0, n, keys_b, idx_b, keys_a, idx_a, tables, out_rows, st, &overflowed, ks);
+    }
+    if (rc != ARX_OK) return rc;
+    if (!overflowed) return ARX_OK;
+    rc = prep();
+    if (rc != ARX_OK) return rc;
+  }
+  if ((try_msd || g_sort_msd_sampled == 2) && g_sort_msd_sampled != 0 && n >= (g_sort_msd_sampled == 2 ? 1024 : (int64_t(1) << 18)) &&
+      n <= (int64_t(3) << 26)) {
+    int overflowed = 0;
+    rc = run_msd_sort_sampled(keys_a, idx_a, 0, n, keys_b, idx_b, keys_a, idx_a, tables, hist, totals, out_rows, st, &overflowed);
+    if (rc != ARX_OK) return rc;
+    if (!overflowed) return ARX_OK;
+    rc = prep();
+    if (rc != ARX_OK) return rc;
+  }
+  // LSD passes.  They are stable on the KEY alone and the records arrive in no particular order, so the rows are put in row
+  // order first: four passes over {row, position}, one gather of the records by the positions, then the eight key passes.
+  const int64_t chunk_keys = plan.chunk_tiles * kSortTile;
+  const unsigned nch = static_cast<unsigned>(plan.nchunks);
+  const uint64_t* kin = keys_a;
+  uint64_t* kout = keys_b;
+  const uint32_t* iin = idx_a;
+  uint32_t* iout = idx_b;
+  hipLaunchKernelGGL(sort_records_rows_kernel, dim3(gprep), dim3(kBlock), 0, st, records, n, keys_a, idx_a);
+  ARX_CHECK_LAUNCH("sort_records_rows_kernel");
+  for (int pass = 0; pass < 4; ++pass) {
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nch), dim3(kBlock), 0, st, kin, n, pass * 8, chunk_keys, plan.nchunks, hist, 0);
+    hipLaunchKernelGGL(radix_digit_totals_kernel, dim3(kDigits), dim3(64), 0, st, hist, plan.nchunks, totals);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(kDigits), dim3(64), 0, st, hist, plan.nchunks, totals);
+    hipLaunchKernelGGL((radix_scatter_kernel<false>), dim3(nch), dim3(kBlock), 0, st, kin, iin, n, pass * 8, plan.chunk_tiles, plan.nchunks,
+                       hist, kout, iout, static_cast<uint64_t*>(nullptr), 0, 0);
+    ARX_CHECK_LAUNCH("radix pass over the rows");
+    uint64_t* knext = (kout == keys_b) ? keys_a : keys_b;
+    uint32_t* inext = (iout == idx_b) ? idx_a : idx_b;
+    kin = kout;
+    iin = iout;
+    kout = knext;
+    iout = inext;
+  }
+  // (four passes: the positions in row order are back in idx_a) -> the records in row order into (keys_b, idx_b)
+  hipLaunchKernelGGL(sort_records_gather_kernel, dim3(gprep), dim3(kBlock), 0, st, records, idx_a, n, keys_b, idx_b);
+  ARX_CHECK_LAUNCH("sort_records_gather_kernel");
+  kin = keys_b;
+  iin = idx_b;
+  kout = keys_a;
+  iout = idx_a;
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = pass * 8;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nch), dim3(kBlock), 0, st, kin, n, shift, chunk_keys, plan.nchunks, hist, 0);
+    ARX_CHECK_LAUNCH("radix_hist_kernel");
+    hipLaunchKernelGGL(radix_digit_totals_kernel, dim3(kDigits), dim3(64), 0, st, hist, plan.nchunks, totals);
+    ARX_CHECK_LAUNCH("radix_digit_totals_kernel");
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(kDigits), dim3(64), 0, st, hist, plan.nchunks, totals);
+    ARX_CHECK_LAUNCH("radix_scan_kernel");
+    hipLaunchKernelGGL((radix_scatter_kernel<false>), dim3(nch), dim3(kBlock), 0, st, kin, iin, n, shift, plan.chunk_tiles, plan.nchunks,
+                       hist, kout, iout, out_rows, pass == 7 ? 1 : 0, 0);
+    ARX_CHECK_LAUNCH("radix_scatter_kernel");
+    uint64_t* knext = (kout == keys_b) ? keys_a : keys_b;
+    uint32_t* inext = (iout == idx_b) ? idx_a : idx_b;
+    kin = kout;
+    iin = iout;
+    kout = knext;
+    iout = inext;
+  }
   return ARX_OK;
 }
 

@@ -349,7 +349,7 @@ def sharded_group_by_sum(keys, values, capacity: int, options: ScalarAggregateOp
 
 # --------------------------------------------------------------------------- sort_indices
 def sharded_sort_indices(values, order: str = "ascending", null_placement: str = "at_end", group=None,
-                         splitter_bits: int = 12, stages: Stages | None = None):
+                         splitter_bits: int = 12, stages: Stages | None = None, records_form: bool | None = None):
     """array_sort_indices over a row-sharded array, one exchange step.
 
     `values`: this rank's contiguous shard (uint64 / int64 device Array) of the global array
@@ -371,6 +371,11 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
          order, so equal keys stay in global row order;
       4. arx_sort_unpack_records rebuilds keys + global rows, then the local stable sort (arx_sort_indices_64)
          and one gather of the global rows.
+    records_form (round 6): None = when no shard has a null and the global rows fit 32 bits, steps 2 - 4 are the records
+    form — the partition writes {key, GLOBAL row} straight from the column with no stable pass
+    (arx_sort_partition_records_global), the receiver sorts its records by (key, row) (arx_sort_records: the order a
+    stable sort of the keys gives) — no unpack, no column sort, no gather; False = always the steps above; True = raise
+    where the form does not apply.
     """
     from . import compute as cp
     from .array import Array, int64, uint64
@@ -434,6 +439,35 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
     owned = [owned_valid[r] + (total_nulls if r == target else 0) for r in range(world)]
     start = sum(owned[:rank])
     offsets = [sum(lens_h[:r]) for r in range(world)]
+
+    # Round 6: no nulls anywhere and global rows that fit 32 bits — the records carry GLOBAL rows, the partition needs no
+    # stable pass (arx_sort_partition_records_global: one tile-level pass from the column) and the receiver sorts its
+    # records by (key, row) (arx_sort_records): no unpack, no column sort + gather.
+    if records_form is True and not (total_nulls == 0 and sum(lens_h) < 2**32):
+        raise _lib.ArrowNotImplementedError("sharded_sort_indices(records_form=True): a shard has nulls, or the global rows pass 2^32")
+    if records_form is not False and total_nulls == 0 and sum(lens_h) < 2**32:
+        records = torch.empty(max(n, 1) * SORT_RECORD_BYTES, dtype=torch.uint8, device=device)
+        counts = torch.zeros(world, dtype=torch.int64, device=device)
+        pws = alloc(1024, device)
+        check(lib.arx_sort_partition_records_global(C.byref(span), is_signed, order_code, splitter_bits, C.byref(window), split_arr,
+                                                    world, offsets[rank], pws.data_ptr(), pws.numel(), records.data_ptr(),
+                                                    counts.data_ptr(), stream))
+        _mark(stages, "partition")
+        recv_counts = torch.empty_like(counts)
+        dist.all_to_all_single(recv_counts, counts, group=group)
+        send, recv = _host_counts(counts, recv_counts)
+        got = _all_to_all_bytes(records[: n * SORT_RECORD_BYTES], send, recv, SORT_RECORD_BYTES, group)
+        _mark(stages, "exchange")
+        m = sum(recv)
+        assert m == owned[rank], (m, owned[rank])
+        sorted_rows = torch.empty(max(m, 1), dtype=torch.int64, device=device)[:m]
+        if m:
+            ws_bytes = lib.arx_sort_indices_workspace_bytes(m) + 256
+            ws = alloc(ws_bytes, device)
+            ws_ptr = (ws.data_ptr() + 255) & ~255
+            check(lib.arx_sort_records(got.data_ptr(), m, ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()), sorted_rows.data_ptr(), stream))
+        _mark(stages, "local_sort")
+        return sorted_rows, start
 
     # 2. stable partition by destination, packed records (+ this shard's null rows)
     ws_bytes = lib.arx_sort_indices_workspace_bytes(n) + 256

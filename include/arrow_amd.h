@@ -592,6 +592,19 @@ int arx_sort_partition_records_window(const ArxSpan* values, int is_signed, int 
                                       const ArxSortKeyWindow* window, const uint32_t* splitter_bins /* host */,
                                       int num_parts, void* ws, size_t ws_bytes, ArxSortRecord* out_records,
                                       int64_t* out_counts, int64_t* out_num_valid /* host */, void* stream);
+/* Round 6: the exchange WITHOUT a stable pass.  arx_sort_partition_records_global writes a null-free shard's records with
+ * GLOBAL row numbers (row_base + row < 2^32), grouped by destination in no particular order inside a block (one tile-level
+ * pass straight from the column: counts, then runs reserved with one atomic per tile and destination); the receiver sorts
+ * what it got by (key, row) with arx_sort_records — the same order a stable sort of the keys gives (ArraySortIndices:
+ * kernels/vector_array_sort.cc:524-540, ties in row order) without unpack, without a gather.  out_counts: device
+ * int64[num_parts]; ws: 1 KB, 8-byte aligned.  Shards with nulls: ARX_NOT_IMPLEMENTED (the stable form above).  Asynchronous
+ * but for the copy of the splitters.
+ * arx_sort_records: out_rows[i] = row of the i-th smallest (key, row) record, widened; ws = arx_sort_indices_workspace_bytes(
+ * num_records), 256-byte aligned. */
+int arx_sort_partition_records_global(const ArxSpan* values, int is_signed, int order, int bits, const ArxSortKeyWindow* window,
+                                      const uint32_t* splitter_bins /* host */, int num_parts, uint32_t row_base, void* ws,
+                                      size_t ws_bytes, ArxSortRecord* out_records, int64_t* out_counts, void* stream);
+int arx_sort_records(const ArxSortRecord* records, int64_t num_records, void* ws, size_t ws_bytes, uint64_t* out_rows, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Group-by hash_sum(int64) BY int32 key — replaces, as one fused device operator,

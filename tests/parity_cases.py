@@ -1091,14 +1091,52 @@ def check_delta_decode(amd, rng, block_size=128, miniblocks=4):
             assert_equal(_data_np(out32, np.int32), v.astype(np.int32), f"delta int32 {kind} n={n}")
 
 
+class _Groups:
+    """Canonical form of a group-by result: rows sorted by (key_is_null, key) (tests sort too,
+    acero/hash_aggregate_test.cc:262-280), as numpy columns — the tuple-per-group form this replaced took most of the GPU
+    tier's group-by time (a Python sort of 1.5M tuples per result).  Compares like the list of
+    (key_is_null, key, sum or None) tuples it stands for; rows() builds those tuples for a message."""
+
+    def __init__(self, null_flag, key, total, valid):
+        self.null_flag, self.key, self.total, self.valid = null_flag, key, total, valid
+
+    def __len__(self):
+        return len(self.key)
+
+    def __eq__(self, other):
+        if isinstance(other, (list, tuple)):      # (the tuple form, as a golden vector spells it)
+            return self.rows() == [tuple(r) for r in other]
+        return (len(self) == len(other) and bool((self.null_flag == other.null_flag).all()) and bool((self.key == other.key).all())
+                and bool((self.valid == other.valid).all()) and bool((self.total == other.total).all()))
+
+    def __add__(self, other):       # (several ranks' slices, compared as one sorted result)
+        if isinstance(other, list) and not other:
+            return self
+        return _sorted_groups(np.concatenate([self.key, other.key]), np.concatenate([1 - self.null_flag, 1 - other.null_flag]).astype(bool),
+                              np.concatenate([self.total, other.total]), np.concatenate([self.valid, other.valid]))
+
+    __radd__ = __add__
+
+    def rows(self, lo=0, hi=None):
+        hi = len(self) if hi is None else hi
+        return [(int(self.null_flag[i]), int(self.key[i]), int(self.total[i]) if self.valid[i] else None) for i in range(lo, min(hi, len(self)))]
+
+    def first_difference(self, other):
+        m = min(len(self), len(other))
+        bad = (self.null_flag[:m] != other.null_flag[:m]) | (self.key[:m] != other.key[:m]) | (self.valid[:m] != other.valid[:m]) | \
+              (self.total[:m] != other.total[:m])
+        i = int(np.argmax(bad)) if bad.any() else m
+        return i, self.rows(i, i + 1), other.rows(i, i + 1)
+
+
 def _sorted_groups(keys, key_valid, sums, valid):
-    """Canonical form: rows sorted by (key_is_null, key) -> list of tuples (tests sort too,
-    acero/hash_aggregate_test.cc:262-280)."""
-    rows = []
-    for k, kv, s, v in zip(keys.tolist(), key_valid.tolist(), sums.tolist(), valid.tolist()):
-        rows.append((0 if kv else 1, k if kv else 0, s if v else None))
-    rows.sort(key=lambda r: (r[0], r[1]))
-    return rows
+    key_valid = np.asarray(key_valid).astype(bool)
+    valid = np.asarray(valid).astype(bool)
+    null_flag = (~key_valid).astype(np.uint8)
+    key = np.where(key_valid, np.asarray(keys).astype(np.int64), 0)
+    total = np.where(valid, np.asarray(sums).astype(np.int64), 0)
+    order = np.lexsort((key, null_flag))
+    return _Groups(null_flag[order], key[order], total[order], valid[order])
 
 
 def check_groupby_sum(amd, keys: HostArray, values: HostArray, skip_nulls=True, min_count=1,
@@ -1119,8 +1157,7 @@ def check_groupby_sum(amd, keys: HostArray, values: HostArray, skip_nulls=True, 
     want = _sorted_groups(w["keys"], w["key_is_valid"], w["sums"], w["valid"])
     tag = f"groupby_sum[n={n},skip_nulls={skip_nulls},min_count={min_count}]"
     assert len(got) == len(want), f"{tag}: {len(got)} groups vs {len(want)}"
-    for i, (g, x) in enumerate(zip(got, want)):
-        assert g == x, f"{tag}: group {i}: got {g} want {x}"
+    assert got == want, f"{tag}: first difference (index, got, want): {got.first_difference(want)}"
     if use_pyarrow and pa is not None and n > 0:
         t = pa.table({"k": keys.to_pyarrow(), "v": values.to_pyarrow()})
         r = t.group_by("k", use_threads=False).aggregate(
@@ -1194,7 +1231,7 @@ def check_groupby_consume_partials(amd, keys: HostArray, values: HostArray, num_
         gk, gkv, gs, gvalid = owned.finalize()
         got += _sorted_groups(gk.cpu().numpy(), gkv.cpu().numpy(), gs.cpu().numpy(), gvalid.cpu().numpy())
     want = _sorted_groups(w["keys"], w["key_is_valid"], w["sums"], np.ones(len(w["keys"]), bool))
-    assert sorted(got, key=lambda r: (r[0], r[1])) == want
+    assert got == want      # (_Groups.__add__ keeps the concatenation of the owners' results sorted)
     # a region too small for what arrives: ARX_CAPACITY_ERROR, not a write past the region
     lib = amd._lib.get_lib()
     stream = amd.array.current_stream(dk.device)
@@ -1241,8 +1278,7 @@ def check_groupby_min_max(amd, keys: HostArray, values: HostArray, skip_nulls=Tr
     got, want = rows(gk, gkv, gmin, gmax, gvalid), rows(w["keys"], w["key_is_valid"], w["mins"], w["maxs"], w["valid"])
     tag = f"groupby_min_max[n={n},skip_nulls={skip_nulls},batches={batches}]"
     assert len(got) == len(want), f"{tag}: {len(got)} groups vs {len(want)}"
-    for i, (g, x) in enumerate(zip(got, want)):
-        assert g == x, f"{tag}: group {i}: got {g} want {x}"
+    assert got == want, f"{tag}: first difference (index, got, want): {got.first_difference(want)}"
     if with_sum:
         _, _, sums, _ = op.finalize()   # every valid value is in exactly one group's sum
         assert int(sums.sum().item()) == int(values.logical_values()[values.logical_valid()].astype(np.int64).sum())
@@ -1700,8 +1736,11 @@ def check_group_by_keys(amd, rng, key_dtypes, n, cardinality, null_p=0.0, use_py
         ref = t.group_by(names, use_threads=False).aggregate([("v", "sum"), ("v", "count"), ("v", "mean")]).to_pydict()
         ref_map = {tuple(ref[nm][i] for nm in names): (ref["v_sum"][i], ref["v_count"][i], ref["v_mean"][i])
                    for i in range(len(ref["v_sum"]))}
-        got_keys = [[None if not _logical_valid(a)[0][i] else int(_data_np(a, dt)[i]) for i in range(g)]
-                    for a, dt in zip(uniq.values, key_dtypes)]
+        got_keys = []
+        for a, dt in zip(uniq.values, key_dtypes):      # (ONE device read-back per column: it used to be one per row)
+            col = _data_np(a, dt)[:g].astype(object)
+            col[~_logical_valid(a)[0][:g]] = None
+            got_keys.append(col.tolist())
         gs, gc, gm = _data_np(sums, np.int64), _data_np(counts, np.int64), _data_np(means, np.float64)
         got_map = {tuple(col[i] for col in got_keys): (int(gs[i]) if sv[i] else None, int(gc[i]),
                                                        float(gm[i]) if mv[i] else None) for i in range(g)}
@@ -2132,6 +2171,45 @@ def check_groupby_key_range(amd, rng, scale=1):
                 span2 = _lib.ArxSpan(None, more.data_ptr(), 0, len(inner), 0)
                 _lib.check(lib.arx_groupby_key_range_i32(span2, pair.data_ptr(), current_stream(dev)))
                 assert_equal(pair.cpu().numpy(), got, "a narrower column must not move the pair")
+
+
+SORT_RECORD = np.dtype([("key_lo", "<u4"), ("key_hi", "<u4"), ("row", "<u4")])
+
+
+def check_sort_records(amd, rng, n, options=(), ties=True):
+    """arx_sort_records: 12-byte {key, row} records in NO particular order -> their rows by (key, row) ascending (what the
+    receiver of the sharded sort's records form runs; = the order a stable sort of the keys gives when the rows are the
+    global row numbers).  Against numpy's lexsort on the same records: keys with many ties, rows a shuffled run of
+    distinct 32-bit numbers starting high (so that a kernel that took them for positions would fault or misorder)."""
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import alloc, current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+    for k_, v_ in options:
+        assert lib.arx_set_option(k_, v_) == 0, k_
+    try:
+        keys = rng.integers(0, 2**64, size=n, dtype=np.uint64)
+        if ties:
+            keys[::3] = keys[::3] % np.uint64(50)
+            keys[1::7] = keys[(1 + 7 * (np.arange(len(keys[1::7])) // 2 * 2)) % n]      # exact duplicates of other rows' keys
+        rows = (np.uint64(2**32 - 1 - n) + rng.permutation(n).astype(np.uint64)).astype(np.uint32)
+        rec = np.empty(n, SORT_RECORD)
+        rec["key_lo"], rec["key_hi"], rec["row"] = (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32), (keys >> np.uint64(32)).astype(np.uint32), rows
+        want = rows[np.lexsort((rows, keys))].astype(np.uint64)
+        drec = to_device(rec.view(np.uint8), dev)
+        out = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        ws_bytes = lib.arx_sort_indices_workspace_bytes(n) + 256
+        ws = alloc(ws_bytes, dev)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        _lib.check(lib.arx_sort_records(drec.data_ptr(), n, ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()), out.data_ptr(), current_stream(dev)))
+        got = out[:n].cpu().numpy().view(np.uint64)
+        assert_equal(got, want, f"arx_sort_records n={n} options={options}")
+    finally:
+        for k_, v_ in options:
+            lib.arx_set_option(k_, {b"sort_msd": -1, b"sort_msd_sampled": 1, b"sort_msd_segment_rows": 1 << 27, b"sort_msd_wide": 1,
+                                    b"sort_msd_wide_bits": 0}.get(k_, 0))
 
 
 def _gbl_sampled_unit(s, stride):

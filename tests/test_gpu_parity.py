@@ -693,10 +693,10 @@ def test_sort_wide_register_staged_tiles(gpu_ctx, rpt):
         lib.arx_set_option(b"sort_msd_bucket_cpt", 4)
 
 
-@pytest.mark.parametrize("n,bits,gap2,shift,rpt,b2max,wc,prefetch,l2w", [(6_000_011, 0, 1, 4, (24, 16), 11, 256, 1, 1), (3_000_003, 14, 0, 2, (8, 8), 11, 0, 1, 2),
-                                                                         (2_000_003, 8, 1, 0, (16, 24), 11, 7, 0, 0), (12_000_003, 0, 1, 4, (24, 16), 4, 96, 1, 1),
-                                                                         (8_000_003, 18, 1, 4, (24, 16), 9, 48, 1, 3), (8_000_003, 18, 1, 4, (24, 16), 9, 48, 0, 1),
-                                                                         (5_000_003, 14, 0, 0, (8, 16), 5, 64, 1, 2), (4_000_003, 20, 1, 4, (24, 16), 11, 32, 1, 1)])
+@pytest.mark.parametrize("n,bits,gap2,shift,rpt,b2max,wc,prefetch,l2w", [(3_000_011, 0, 1, 4, (24, 16), 11, 256, 1, 1), (3_000_003, 14, 0, 2, (8, 8), 11, 0, 1, 2),
+                                                                         (2_000_003, 8, 1, 0, (16, 24), 11, 7, 0, 0), (6_000_003, 0, 1, 4, (24, 16), 4, 48, 1, 1),
+                                                                         (4_000_003, 18, 1, 4, (24, 16), 9, 24, 1, 3), (4_000_003, 18, 1, 4, (24, 16), 9, 24, 0, 1),
+                                                                         (3_000_003, 14, 0, 0, (8, 16), 5, 32, 1, 2), (4_000_003, 20, 1, 4, (24, 16), 11, 32, 1, 1)])
 def test_sort_wide_rec8_words(gpu_ctx, n, bits, gap2, shift, rpt, b2max, wc, prefetch, l2w):
     """8-byte {key bits, row id} words through the wide form (the form the 2e9-row bench runs): ties below the word,
     duplicates, the tie budget, fall-backs; level 1 tile at a time and write-combined (2 to 512 bins — 9 + 9 bits is the
@@ -1344,13 +1344,13 @@ def test_take_record_batch_without_nulls_has_no_bitmaps(gpu_ctx):
 @pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64,
                                    np.float32, np.float64])
 def test_compare_and_arithmetic_on_every_numeric_type(gpu_ctx, dtype):
-    P.check_numeric_compare_arith(gpu_ctx, rng_for("numeric-ops", np.dtype(dtype).name), dtype, n=1000003)
+    P.check_numeric_compare_arith(gpu_ctx, rng_for("numeric-ops", np.dtype(dtype).name), dtype, n=300007)
 
 
 @pytest.mark.parametrize("wide", [0, 1])
 def test_sort_keys_with_a_shared_prefix(gpu_ctx, wide):
     lib = gpu_ctx._lib.get_lib()
-    P.check_sort_limited_range(gpu_ctx, lib, rng_for("sort-prefix", wide), 5000011, wide)
+    P.check_sort_limited_range(gpu_ctx, lib, rng_for("sort-prefix", wide), 2000003, wide)
 
 
 def test_compare_on_temporal_columns(gpu_ctx):
@@ -1410,6 +1410,12 @@ def test_bytes_to_bitmap(gpu_ctx):
 
 def test_groupby_key_range(gpu_ctx):
     P.check_groupby_key_range(gpu_ctx, rng_for("key-range"), scale=50)
+
+
+@pytest.mark.parametrize("n", [100_003, 6_000_011, 150_000_001])
+def test_sort_records(gpu_ctx, n):
+    """Round 6: arx_sort_records on gfx950 — the LSD fallback, the MSD hybrid (> 4M records) and the wide form (> 2^27)."""
+    P.check_sort_records(gpu_ctx, rng_for("sort-records", n), n)
 
 
 def test_groupby_range_state(gpu_ctx):

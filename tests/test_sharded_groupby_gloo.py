@@ -145,13 +145,14 @@ SORT_WORKER = textwrap.dedent(r'''
     rng = np.random.default_rng(77 + rank)
     n = 5000 + 700 * rank
     dt = np.int64 if SIGNED else np.uint64
-    a = U.random_array(rng, dt, n, null_p=0.05, offset=rank + 1)
+    a = U.random_array(rng, dt, n, null_p=0.05 if NULLS else 0.0, offset=rank + 1)
     a.values[a.offset:a.offset + n:3] = (a.values[a.offset:a.offset + n:3] % 40).astype(dt)  # many ties across ranks
     if WINDOW is not None:   # ids / timestamps: every key inside [lo, lo + span) — the top bits say nothing
         lo, span = WINDOW
         v = a.values[a.offset:a.offset + n]
         v[:] = (v.astype(np.uint64) % np.uint64(span)).astype(dt) + dt(lo)
-    rows, start = parallel.sharded_sort_indices(a.to_device(arrow_amd), ORDER, PLACEMENT)
+    # (no shard has a null: round 6's records form — global rows in the records, no stable pass, the receiver sorts by (key, row))
+    rows, start = parallel.sharded_sort_indices(a.to_device(arrow_amd), ORDER, PLACEMENT, records_form=None if NULLS else True)
     mine = dict(rows=rows.numpy(), start=start, vals=a.values[a.offset:a.offset + n].copy(),
                 valid=None if a.valid is None else a.valid[a.offset:a.offset + n].copy())
     out = [None] * world
@@ -164,12 +165,14 @@ SORT_WORKER = textwrap.dedent(r'''
 ''')
 
 
-@pytest.mark.parametrize("signed,order,placement,window", [
-    (False, "ascending", "at_end", None), (True, "descending", "at_start", None), (False, "descending", "at_end", None),
-    (True, "ascending", "at_end", (1_700_000_000_000_000, 86_400_000_000)),   # a day of microsecond timestamps
-    (True, "descending", "at_end", (-3000, 9000)), (False, "ascending", "at_start", ((1 << 40) - 700, 1500)),
-    (False, "ascending", "at_end", (12345, 1))])
-def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement, window):
+@pytest.mark.parametrize("signed,order,placement,window,nulls", [
+    (False, "ascending", "at_end", None, True), (True, "descending", "at_start", None, True), (False, "descending", "at_end", None, True),
+    (True, "ascending", "at_end", (1_700_000_000_000_000, 86_400_000_000), True),   # a day of microsecond timestamps
+    (True, "descending", "at_end", (-3000, 9000), True), (False, "ascending", "at_start", ((1 << 40) - 700, 1500), True),
+    (False, "ascending", "at_end", (12345, 1), True),
+    (False, "ascending", "at_end", None, False), (True, "descending", "at_start", None, False),
+    (True, "ascending", "at_end", (1_700_000_000_000_000, 86_400_000_000), False), (False, "descending", "at_end", (12345, 1), False)])
+def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement, window, nulls):
     """One-exchange multi-rank sort_indices == the oracle's stable argsort of the concatenation; keys that share their
     top bits (window) must still be split between the ranks."""
     import pickle
@@ -180,7 +183,7 @@ def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement, wi
 
     out = str(tmp_path / "sort.pkl")
     code = (f"ROOT = {ROOT!r}\nOUT = {out!r}\nSIGNED = {signed!r}\nORDER = {order!r}\nPLACEMENT = {placement!r}\n"
-            f"WINDOW = {window!r}\n" + SORT_WORKER)
+            f"WINDOW = {window!r}\nNULLS = {nulls!r}\n" + SORT_WORKER)
     port = 31500 + (os.getpid() % 2000)
     procs = []
     for rank in range(2):
