@@ -1315,15 +1315,27 @@ def _hash_sum_plan_counters():
                            "groupby_slices_rooms", "groupby_slices_two_level"])
 
 
+# ranks at which the sharded array_sort_indices is SLOWER than the single-GPU sort by this repo's own stage measurements
+# (profiles/r06_l_virtual_rank_stage_table_sort_records.txt: per rank 41.4 ms at P = 2 against 24.0 ms on one GPU — every row
+# crosses the wire as a 12-byte record and the receiver sorts records, not words; 22.0 ms at P = 4, 11.7 ms at P = 8): the
+# leg declines there instead of printing a slower number (VERDICT r5 "Next round" 2).  --force-sharded-sort runs it anyway.
+SORT_DECLINED_WORLDS = {2: "per-rank stages 41.4 ms (histogram 3.4 + partition 5.7 + exchange of 6 GB ~5.6 + record sort 26.6) against "
+                           "24.0 ms for the whole sort on one GPU (profiles/r06_l_virtual_rank_stage_table_sort_records.txt)"}
+
+
 def sort_leg(args, rank, world, device, rows_total, steps, warmup):
+    if world in SORT_DECLINED_WORLDS and not getattr(args, "force_sharded_sort", False):
+        return {"declined": f"array_sort_indices sharded over {world} GPUs loses to one GPU: " + SORT_DECLINED_WORLDS[world] +
+                            "; the sharded sort is for 4 or more ranks (or inputs that are already sharded): --force-sharded-sort measures it anyway",
+                "rows": rows_total, "n_gpus": world}
     sec, rows, ok = measure_sort(rank, world, device, rows_total, steps, warmup)
     per_gpu = 16 * rows / world / sec / 1e9
     leg = {"rows": rows, "n_gpus": world, "ms": round(sec * 1e3, 3), "mrows_per_s": round(rows / sec / 1e6, 1),
            "scaling": "strong",
-           "exchange": "1 all-reduce (splitter histogram) + 1 count exchange + ONE all-to-all(v) of 12-byte records" if world > 1 else "none (one rank)",
+           "exchange": "1 all-reduce (key window) + 1 all-reduce (splitter histogram) + 1 count exchange + ONE all-to-all(v) of 12-byte {key, global row} records; the receiver sorts its records (arx_sort_records)" if world > 1 else "none (one rank)",
            "permutation_and_order_checks": ok,
            "stage_ms_max_over_ranks_untimed_run": _LAST_STAGES.get("sort_indices"),
-           "roofline": {"bound": "hbm", "kernel": "arx_sort_indices (wide form on 8-byte words: msdw_scatter1wc [write-combined level 1] + msdw_scatter2w + msd_bucket2w [LDS finish])",
+           "roofline": {"bound": "hbm", "kernel": "arx_sort_indices (wide form on 8-byte words: msdw_scatter1wc2 [level 1 write-combined by appending: whole 128-byte lines] + msdw_scatter2w + msd_bucket2w [LDS finish])",
                         "achieved": round(per_gpu, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 16,
                         "traffic": load_traffic("sort", rows // world, form="rec8")}}
@@ -1495,6 +1507,7 @@ def run_hash_sum(args, rank, world, device):
 
 
 def run_sort(args, rank, world, device):
+    args.force_sharded_sort = True      # (--workload sort_indices asks for this very measurement)
     leg = sort_leg(args, rank, world, device, args.rows, args.steps, args.warmup)
     return {
         "metric": "sort_indices_mrows_per_s", "value": leg["mrows_per_s"],
@@ -1565,6 +1578,8 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", dest="extras", action="store_false")
+    ap.add_argument("--force-sharded-sort", dest="force_sharded_sort", action="store_true",
+                    help="measure the sharded sort_indices leg at rank counts where it is known to lose to one GPU")
     ap.add_argument("--option", action="append", default=[], help="name=value for arx_set_option")
     ap.add_argument("--backend", default="hip", choices=["hip", "emu"],
                     help="emu = CPU tensors + gloo + the SIMT emulator of tests/emu (plumbing tests only)")

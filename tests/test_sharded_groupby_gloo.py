@@ -223,7 +223,13 @@ def test_bench_launcher_starts_two_ranks_end_to_end():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "emu", "--rows", "20000",
            "--steps", "1", "--warmup", "1", "--hash-sum-rows", "40000", "--groups", "700", "--sort-rows", "30000",
            "--stream-rows", "20000", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    # (round 6: at two ranks the sharded sort loses to one GPU and the leg DECLINES — checked first; --force-sharded-sort
+    #  runs the leg for the rest of this test)
+    r = subprocess.run(cmd + ["--no-extras"][:0], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    declined = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["sort_indices"]
+    assert "declined" in declined and "loses to one GPU" in declined["declined"] and declined["n_gpus"] == 2, declined
+    r = subprocess.run(cmd + ["--force-sharded-sort"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
