@@ -1590,7 +1590,10 @@ __global__ __launch_bounds__(T) void msd_bucket2w_kernel(MsdArgs a, const uint64
   const bool bits_below = a.kshift + a.b1 + 32 < 64;   // key bits the words do not hold
   // this bucket's share of the tie budget: m >> tie_shift rows (one counter per address serialises at ~40 ns per
   // returning atomic — 1.8e6 tied rows of 2e9 cost 69 ms that way, profiles/r05_a — so the budget is kept per bucket, in LDS)
-  const uint32_t tie_limit = a.tie_shift >= 31 ? 0u : static_cast<uint32_t>(m) >> a.tie_shift;
+  // (a floor of 64 rows — m >> shift is 0 for a bucket of a few rows, and ONE duplicated outlier key in such a
+  //  bucket would then abandon rec8 for the whole input; tie_shift >= 31 keeps its meaning of "no budget at all": tests)
+  const uint32_t tie_share = static_cast<uint32_t>(m) >> (a.tie_shift < 31 ? a.tie_shift : 31);
+  const uint32_t tie_limit = a.tie_shift >= 31 ? 0u : (tie_share > 64u ? tie_share : 64u);
   for (int i = tid; i < nb; i += T) w.start[i] = 0;
   uint64_t wd[R];
 #pragma unroll

@@ -2197,15 +2197,29 @@ def check_sort_records(amd, rng, n, options=(), ties=True):
         rows = (np.uint64(2**32 - 1 - n) + rng.permutation(n).astype(np.uint64)).astype(np.uint32)
         rec = np.empty(n, SORT_RECORD)
         rec["key_lo"], rec["key_hi"], rec["row"] = (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32), (keys >> np.uint64(32)).astype(np.uint32), rows
-        want = rows[np.lexsort((rows, keys))].astype(np.uint64)
+        big = n > 20_000_000      # (numpy's lexsort of 1.5e8 pairs takes a minute of the GPU gate: beyond 2e7 the order is checked on the device)
+        want = None if big else rows[np.lexsort((rows, keys))].astype(np.uint64)
         drec = to_device(rec.view(np.uint8), dev)
         out = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
         ws_bytes = lib.arx_sort_indices_workspace_bytes(n) + 256
         ws = alloc(ws_bytes, dev)
         ws_ptr = (ws.data_ptr() + 255) & ~255
         _lib.check(lib.arx_sort_records(drec.data_ptr(), n, ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()), out.data_ptr(), current_stream(dev)))
-        got = out[:n].cpu().numpy().view(np.uint64)
-        assert_equal(got, want, f"arx_sort_records n={n} options={options}")
+        if big:
+            # the rows come back as a permutation of the records' rows, and (key, row) never decreases along it
+            base = int(2**32 - 1 - n)
+            pos = torch.empty(n, dtype=torch.int64, device=dev)
+            pos[torch.from_numpy((rows.astype(np.int64) - base)).to(dev)] = torch.arange(n, dtype=torch.int64, device=dev)   # row -> record
+            got_rows = out[:n]
+            seen = torch.zeros(n, dtype=torch.bool, device=dev)
+            seen[got_rows - base] = True
+            assert bool(seen.all()), "arx_sort_records: the output is not a permutation of the rows"
+            ks = torch.from_numpy(keys.view(np.int64)).to(dev)[pos[got_rows - base]] ^ torch.iinfo(torch.int64).min   # unsigned order as signed
+            ok = (ks[1:] > ks[:-1]) | ((ks[1:] == ks[:-1]) & (got_rows[1:] > got_rows[:-1]))
+            assert bool(ok.all()), f"arx_sort_records n={n}: (key, row) decreases at {int((~ok).nonzero()[0])}"
+        else:
+            got = out[:n].cpu().numpy().view(np.uint64)
+            assert_equal(got, want, f"arx_sort_records n={n} options={options}")
     finally:
         for k_, v_ in options:
             lib.arx_set_option(k_, {b"sort_msd": -1, b"sort_msd_sampled": 1, b"sort_msd_segment_rows": 1 << 27, b"sort_msd_wide": 1,
