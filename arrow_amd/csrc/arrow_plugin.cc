@@ -631,6 +631,12 @@ int64_t arrow_amd_plugin_aggregate_flushes(void) { return g_aggregate_flushes.lo
 // aggregate_rocm consumes a device batch of at least this many rows where it lies (no staging copy)
 void arrow_amd_plugin_set_aggregate_direct_rows(int64_t rows) { g_aggregate_direct_rows.store(rows < 1 ? 1 : rows); }
 int64_t arrow_amd_plugin_aggregate_direct_batches(void) { return g_aggregate_direct_batches.load(); }
+// aggregate_rocm's range-partitioned state for a plan that is one run of device slices (default on); its row floor; how many
+// plans went through it / how many it declined to the table (a wide range, a key the sample missed, a hot key)
+void arrow_amd_plugin_set_aggregate_range_state(int on) { g_aggregate_range_state.store(on != 0); }
+void arrow_amd_plugin_set_aggregate_range_min_rows(int64_t rows) { g_aggregate_range_min_rows.store(rows < 1 ? 1 : rows); }
+int64_t arrow_amd_plugin_aggregate_range_plans(void) { return g_aggregate_range_plans.load(); }
+int64_t arrow_amd_plugin_aggregate_range_declined(void) { return g_aggregate_range_declined.load(); }
 // aggregate_rocm keeps the result of a plan over device-resident rows in HBM (default off: host arrays, as GroupByNode)
 void arrow_amd_plugin_set_aggregate_device_output(int on) { g_aggregate_device_output.store(on != 0); }
 // column-sized result copies by a kernel (arx_buffer_copy) instead of the copy engines (default on; A/B knob)

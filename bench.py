@@ -509,6 +509,9 @@ def acero_hash_sum_full(device, rows, groups, reps=3):
         acero.Declaration("table_source_rocm", acero.TableSourceNodeOptions(tab)),
         acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions([("v", "hash_sum", None, "v_sum")], keys=["k"]))])
     out = plan.to_table(use_threads=False)      # warm-up (pools, first-use allocations)
+    for f in ("arrow_amd_plugin_aggregate_range_plans", "arrow_amd_plugin_aggregate_range_declined"):
+        getattr(plug.lib, f).restype = plug.ctypes.c_int64
+    r0, x0 = plug.lib.arrow_amd_plugin_aggregate_range_plans(), plug.lib.arrow_amd_plugin_aggregate_range_declined()
     ts = []
     for _ in range(reps):
         out = None
@@ -516,13 +519,15 @@ def acero_hash_sum_full(device, rows, groups, reps=3):
         t0 = time.perf_counter()
         out = plan.to_table(use_threads=False)
         ts.append(time.perf_counter() - t0)
+    state = {"range_partitioned_state_plans": plug.lib.arrow_amd_plugin_aggregate_range_plans() - r0,
+             "declined_to_the_table": plug.lib.arrow_amd_plugin_aggregate_range_declined() - x0, "plans": reps}
     want = int(vals.sum().item())
     got = int(np.asarray(out.column("v_sum").to_numpy()).view(np.uint64).sum(dtype=np.uint64).view(np.int64)) if out.num_rows else 0
     ms = sorted(ts)[len(ts) // 2] * 1e3
     return {"what": "acero table_source_rocm -> aggregate_rocm (hash_sum) over the same rows as a device-resident pyarrow table "
                     "(zero-copy wrap of the HBM buffers), host result table; median of %d" % reps,
             "ms": round(ms, 3), "ms_min": round(min(ts) * 1e3, 3), "mrows_per_s": round(rows / ms / 1e3, 1),
-            "groups": out.num_rows, "checksum_matches_sum_of_values": bool(got == want)}
+            "groups": out.num_rows, "checksum_matches_sum_of_values": bool(got == want), "state": state}
 
 
 def parity_sort_prefix(device):

@@ -2208,6 +2208,45 @@ TABLE_SOURCE_SCRIPT = textwrap.dedent(r'''
     # (+ 1: a chunk's last, short batch is staged with the small ones and consumed at the end)
     assert lib.arrow_amd_plugin_calls(b"hash_sum", 1) - h0 <= td.column("k").num_chunks + 1 < lib.arrow_amd_plugin_aggregate_direct_batches() - d0, (
         lib.arrow_amd_plugin_calls(b"hash_sum", 1) - h0, td.column("k").num_chunks, lib.arrow_amd_plugin_aggregate_direct_batches() - d0)
+    # (round 6) a plan that is ONE run of device slices without nulls, sums and counts only: the range-partitioned state
+    # (arx_groupby_range_*) — sampled key range, no table; what it declines (a wide key range here) goes through the table.
+    # Same groups, sums, counts and min_count validity as the reference either way.
+    for f in ("arrow_amd_plugin_aggregate_range_plans", "arrow_amd_plugin_aggregate_range_declined"):
+        getattr(lib, f).restype = ctypes.c_int64
+    lib.arrow_amd_plugin_set_aggregate_range_min_rows.argtypes = [ctypes.c_int64]
+    lib.arx_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    for name, value in ((b"groupby_lines_wgs", 2), (b"groupby_lines_unit_rows", 4096)):      # (sized for this test's rows)
+        assert lib.arx_set_option(name, value) == 0
+    m3 = SC(120_000)
+    lib.arrow_amd_plugin_set_aggregate_range_min_rows(m3 // 2)
+    opts3 = pc.ScalarAggregateOptions(min_count=9)
+    agg3 = [acero.Declaration("aggregate_rocm", acero.AggregateNodeOptions(
+        [("v", "hash_sum", opts3, "v_sum"), ("v", "hash_count", None, "v_count"), ("v", "hash_sum", None, "v_all")], keys=["k"]))]
+    for lo, hi, through_range in ((-5000, 5000, True), (-2**31, 2**31 - 1, False)):
+        t3 = pa.table({"k": pa.array(rng.integers(lo, hi, m3).astype(np.int32)), "v": pa.array(rng.integers(-2**60, 2**60, m3))})
+        want3 = t3.group_by("k", use_threads=False).aggregate([("v", "sum", opts3), ("v", "count"), ("v", "sum")]).sort_by("k")
+        td3 = pa.Table.from_batches([pa.RecordBatch.from_arrays([to_device(t3.column(j).chunk(0)) for j in range(2)], names=t3.schema.names)])
+        r0, x0 = lib.arrow_amd_plugin_aggregate_range_plans(), lib.arrow_amd_plugin_aggregate_range_declined()
+        got3 = plan("table_source_rocm", td3, agg3).to_table(use_threads=False).sort_by("k")
+        assert lib.arrow_amd_plugin_aggregate_range_plans() - r0 == (1 if through_range else 0), (lo, hi)
+        assert got3.column("k").equals(want3.column("k")), (lo, hi)
+        # (want3's aggregate columns: v_sum, v_count, v_sum again — in that order, before or behind the key column)
+        w_sum, w_count, w_all = [want3.column(j) for j, name in enumerate(want3.schema.names) if name != "k"]
+        assert got3.column("v_sum").equals(w_sum), (lo, hi, got3.column("v_sum").null_count, w_sum.null_count)
+        assert got3.column("v_count").equals(w_count), (lo, hi)
+        assert got3.column("v_all").equals(w_all), (lo, hi)
+        assert w_sum.null_count > 0 and w_all.null_count == 0      # (min_count = 9 bites: ~12 rows a group at most)
+    # a hot key makes the scatter give up: declined, and the table takes the rows
+    t3 = pa.table({"k": pa.array(np.where(rng.random(m3) < 0.9, 17, rng.integers(0, 9000, m3)).astype(np.int32)), "v": pa.array(rng.integers(-2**60, 2**60, m3))})
+    want3 = t3.group_by("k", use_threads=False).aggregate([("v", "sum")]).sort_by("k")
+    td3 = pa.Table.from_batches([pa.RecordBatch.from_arrays([to_device(t3.column(j).chunk(0)) for j in range(2)], names=t3.schema.names)])
+    r0, x0 = lib.arrow_amd_plugin_aggregate_range_plans(), lib.arrow_amd_plugin_aggregate_range_declined()
+    got3 = plan("table_source_rocm", td3, plain).to_table(use_threads=False).sort_by("k")
+    assert got3.column("k").equals(want3.column("k")) and got3.column("v_sum").equals(want3.column("v_sum"))
+    assert lib.arrow_amd_plugin_aggregate_range_plans() - r0 + lib.arrow_amd_plugin_aggregate_range_declined() - x0 == 1
+    lib.arrow_amd_plugin_set_aggregate_range_min_rows(1 << 22)
+    for name, value in ((b"groupby_lines_wgs", 0), (b"groupby_lines_unit_rows", 1 << 21)):
+        assert lib.arx_set_option(name, value) == 0
     lib.arrow_amd_plugin_set_table_source_rows(1 << 27)
     lib.arrow_amd_plugin_set_aggregate_direct_rows(1 << 22)
     # the result may stay in HBM when the rows came from there (off by default: GroupByNode's result is host memory)
