@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 #include <vector>
 
 namespace arx {
@@ -39,7 +40,7 @@ static Knob<int> g_sort_msd_fused{1};       // finish LDS-sized level-2 buckets 
 static Knob<int64_t> g_sort_msd_segment_rows{int64_t(1) << 27};  // above this: an extra top-bits level cuts segments
 static Knob<int> g_sort_msd_final_rows_log2{1};  // log2 of the rows aimed at per final sub-bucket (rank loop length); with the 4096-bin finish 1 beats 2 / 3 / 4 by 3 / 9 / 18 % at 2e9 rows
 static Knob<int> g_sort_msd_small_bucket{1};  // 512-thread / 5120-row bucket kernel when every bucket fits it
-static Knob<int> g_sort_msd_wide_sample_shift{4};  // wide form: level-1 capacities from a histogram of 1 tile in 2^shift (0 = exact histogram of every row)
+static Knob<int> g_sort_msd_wide_sample_shift{6};  // wide form: level-1 capacities from a histogram of 1 tile in 2^shift (0 = exact histogram of every row)
 static Knob<int> g_sort_xcd_map{1};                // wide form, XCD-contiguous work numbering: bit 0 level 2 (-2.1 ms at 2e9 rows: a bucket's runs meet in one L2), bit 1 bucket finish, bit 2 level 1 (both: no effect)
 static Knob<int> g_sort_msd_wide_bits{0};           // wide form: partition bits (0 = from the row count: buckets of 2048..4096 rows; tests force many bins on few rows)
 static Knob<int> g_sort_msd_wide_b2max{11};        // wide form: most partition bits given to level 2 (<= 12; 0 = the even split).  2e9 rows, 20 bits: 9 + 11 with 16-row level-2 tiles 31.4 ms, 10 + 10 with 8-row tiles 34.2, 8 + 12 37.2 (profiles/r03_h, r03_i); 2^28 rows: 10 and 11 within 2 %
@@ -53,6 +54,8 @@ static Knob<int> g_sort_msd_wide_rec8{1};           // wide form over the caller
 static Knob<int> g_sort_msd_wide_rec8_tie_shift{4};  // ... given up (and repeated with 12-byte records) once more than (rows >> shift) rows of ONE bucket tied (duplicate-heavy keys: every tie is two random 8-byte reads; 2e9 uniform keys: 0.9 per 1000)
 constexpr int kMsdwWcRDefault = 4;
 static Knob<int> g_sort_msd_wide_wc{256};          // rec8 form: level 1 write-combined by this many persistent workgroups (0 = the tile-at-a-time level 1)
+static Knob<int> g_sort_vary_sample_shift{6};      // the shared-prefix probe reads one tile of 8192 rows in 2^shift first (knob sort_vary_sample_shift; round 6: 4 -> 6, 0.34 -> 0.22 ms at 2e9 rows)
+static Knob<int> g_sort_msd_wide_wc_typed{1};      // the append kernel compiled for the key type (uint64 / int64 / double); 0: the run-time switch (A/B knob sort_msd_wide_wc_typed)
 static Knob<int> g_sort_msd_wide_wc_form{2};       // 2: round 6's append kernel (every store a whole line); 1: round 5's rank-and-stage kernel (A/B knob sort_msd_wide_wc_form)
 static Knob<int> g_sort_msd_wide_wc_rows{kMsdwWcRDefault};   // form 2: rows per thread and batch, 4 / 6 / 8 (A/B knob sort_msd_wide_wc_rows)
 static Knob<int> g_sort_msd_wide_wc_min_rows{1 << 17};   // form 2: rows a persistent workgroup must have (fewer workgroups for small inputs; knob sort_msd_wide_wc_min_rows — tests)
@@ -1595,19 +1598,26 @@ __global__ __launch_bounds__(T) void msd_bucket2w_kernel(MsdArgs a, const uint64
   const uint32_t tie_share = static_cast<uint32_t>(m) >> (a.tie_shift < 31 ? a.tie_shift : 31);
   const uint32_t tie_limit = a.tie_shift >= 31 ? 0u : (tie_share > 64u ? tie_share : 64u);
   for (int i = tid; i < nb; i += T) w.start[i] = 0;
+  // (round 6: the kernel's VALU is its bound — SQ_ACTIVE_INST_VALU is 14 % of the wave cycles with seven waves a SIMD,
+  //  profiles/r06_j_* — and a bucket fills 40 % of the T * R slots on average: the slot loops skip the rounds i * T >= m,
+  //  a workgroup-uniform test, instead of running all R of them over clamped duplicates)
   uint64_t wd[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) {   // unconditional loads (clamped): all round trips overlap
+  for (int i = 0; i < R; ++i) {   // unconditional loads (clamped) inside a round: all round trips overlap
     const int p = i * T + tid;
-    wd[i] = words_in[lo_in + (p < m ? p : m - 1)];
+    wd[i] = 0;
+    if (i * T < m) wd[i] = words_in[lo_in + (p < m ? p : m - 1)];
   }
   __syncthreads();
   uint32_t dig[R], rank[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    dig[i] = digit_of(wd[i]);
+    dig[i] = 0;
     rank[i] = 0;
-    if (i * T + tid < m) rank[i] = atomicAdd(&w.start[dig[i]], 1u);
+    if (i * T < m) {
+      dig[i] = digit_of(wd[i]);
+      if (i * T + tid < m) rank[i] = atomicAdd(&w.start[dig[i]], 1u);
+    }
   }
   __syncthreads();
   uint32_t c[CPT];
@@ -1633,7 +1643,9 @@ __global__ __launch_bounds__(T) void msd_bucket2w_kernel(MsdArgs a, const uint64
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    if (i * T + tid < m) w.words[w.start[dig[i]] + rank[i]] = wd[i];
+    if (i * T < m) {
+      if (i * T + tid < m) w.words[w.start[dig[i]] + rank[i]] = wd[i];
+    }
   }
   __syncthreads();
   for (int i = tid; i < m; i += T) {
@@ -1822,6 +1834,14 @@ int set_sort_option(const char* name, int64_t value) {
     g_sort_msd_wide_wc_min_rows = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, 1 << 30)));
     return 1;
   }
+  if (strcmp(name, "sort_vary_sample_shift") == 0) {
+    g_sort_vary_sample_shift = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, 8)));
+    return 1;
+  }
+  if (strcmp(name, "sort_msd_wide_wc_typed") == 0) {
+    g_sort_msd_wide_wc_typed = value == 2 ? 2 : (value != 0 ? 1 : 0);
+    return 1;
+  }
   if (strcmp(name, "sort_msd_wide_wc_form") == 0) {
     g_sort_msd_wide_wc_form = value == 1 ? 1 : 2;
     return 1;
@@ -1916,7 +1936,7 @@ static int sort_shared_prefix_bits(const uint64_t* keys, int raw_xf, int64_t n, 
   *out_bits = 0;
   if (!g_sort_msd_prefix || n < 2) return ARX_OK;
   for (int pass = 0; pass < 2; ++pass) {
-    const int sample_shift = pass == 0 && n > (int64_t(1) << 20) ? 4 : 0;
+    const int sample_shift = pass == 0 && n > (int64_t(1) << 20) ? int(g_sort_vary_sample_shift) : 0;
     ARX_HIP(hipMemsetAsync(d_word, 0, 8, st));
     const int64_t ntiles = ceil_div(n, 8192);
     const int64_t work = sample_shift ? (ntiles >> sample_shift) + 2 : ntiles;
@@ -3022,13 +3042,20 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1wc_kernel(MsdwArgs 
 constexpr uint32_t kMsdwWcSkip = 0xFFFFFFFFu;
 constexpr uint32_t kMsdwWcNever = 0xFFFFFFFEu;
 
-template <int R>
+// KT: the key type when the host knows it at compile time (0 .. 5 of the C ABI's ARX_KEY_*; the transform of a key is then
+// straight-line code and the loads have one width), -1: a.raw at run time.  Round 6, after profiles/r06_j_*: the kernel's
+// waves issue for a third of their time and the four of a SIMD share one VALU and one scalar unit (52 % / 44 % busy), so the
+// instructions of a batch are part of its duration — the per-element switch over the key type, the 64-bit row arithmetic
+// and the end-of-span checks in EVERY batch were a sixth of them (only a workgroup's last batch can be short).
+template <int R, int KT, bool LISTQ = false>
 __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1wc2_kernel(MsdwArgs a) {
   __shared__ uint64_t vals[kMsdwMaxBins * 16];
   // state = next line (absolute) << 1 | the workgroup holds that line (rooms and chunks start at multiples of kMsdwWcK lines)
   __shared__ uint32_t fill[kMsdwMaxBins], state[kMsdwMaxBins];
-  __shared__ uint16_t list[2][kMsdwMaxBins];
-  __shared__ uint32_t nlist[2], again[2];
+  __shared__ uint16_t wlist[kMsdwMaxBins];   // per wave: which of its 64 bins have a full line (flush_phase)
+  __shared__ uint16_t list[LISTQ ? 2 : 1][LISTQ ? kMsdwMaxBins : 1];   // LISTQ (A/B only): the first form's queue of full lines
+  __shared__ uint32_t nlist[2];
+  __shared__ uint32_t again[2];
   const uint32_t K = static_cast<uint32_t>(a.wc_k);   // 1, 2 or 4
   const int tid = threadIdx.x, lane = tid & 63;
   const int nb = 1 << a.b1;
@@ -3041,28 +3068,41 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1wc2_kernel(MsdwArgs
     state[tid] = kMsdwWcNever;
   }
   if (tid < 2) {
-    nlist[tid] = 0;
     again[tid] = 0;
+    nlist[tid] = 0;
   }
   __syncthreads();
   const int64_t lo = static_cast<int64_t>(blockIdx.x) * a.wc_rows_per_wg;
   const int64_t hi = lo + a.wc_rows_per_wg < a.n ? lo + a.wc_rows_per_wg : a.n;
   if (lo >= hi) return;
-  const bool wide_keys = key_type_is_64bit(a.raw);   // workgroup-uniform
+  const int xf = KT < 0 ? a.raw : ((a.raw & ~(7 << 4)) | (KT << 4));
+  const bool wide_keys = KT < 0 ? key_type_is_64bit(a.raw) : (KT == 0 || KT == 1 || KT == 4);   // workgroup-uniform
+  const uint32_t span = static_cast<uint32_t>(hi - lo);   // (a workgroup's rows: far below 2^32)
+  const uint64_t* __restrict__ src64 = a.src_keys + lo;
+  const uint32_t* __restrict__ src32 = reinterpret_cast<const uint32_t*>(a.src_keys) + lo;
+  constexpr uint32_t kBatch = static_cast<uint32_t>(R) * kMsdwThreads;
   uint64_t kc[R], kn[R];
-  auto issue = [&](int64_t r0) {
+  // the keys of the batch at `rel` (rows from the workgroup's first); FULL: the whole batch lies inside the span
+  auto issue = [&](uint32_t rel, auto full) {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      int64_t r = r0 + i * kMsdwThreads + tid;
-      r = r < hi ? r : hi - 1;
-      kn[i] = wide_keys ? __builtin_nontemporal_load(a.src_keys + r)
-                        : static_cast<uint64_t>(__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.src_keys) + r));
+      uint32_t r = rel + static_cast<uint32_t>(i * kMsdwThreads + tid);
+      if constexpr (!decltype(full)::value) r = r < span ? r : span - 1;
+      kn[i] = wide_keys ? __builtin_nontemporal_load(src64 + r) : static_cast<uint64_t>(__builtin_nontemporal_load(src32 + r));
     }
   };
+  auto issue_at = [&](uint32_t rel) {
+    if (rel + kBatch <= span) issue(rel, std::true_type{});
+    else issue(rel, std::false_type{});
+  };
   int cur = 0;
+  // (the row that takes slot 15 used to queue its bin in a list — a wave-aggregated returning LDS atomic and a wait for it
+  //  behind every row of a batch, since some lane of 64 nearly always takes a slot 15; the flush finds the full lines itself now)
   auto place = [&](uint32_t bin, uint32_t slot, uint64_t word) {
     vals[bin * 16 + slot] = word;
-    if (slot == 15) list[cur][atomicAdd(&nlist[cur], 1u)] = static_cast<uint16_t>(bin);
+    if constexpr (LISTQ) {
+      if (slot == 15) list[cur][atomicAdd(&nlist[cur], 1u)] = static_cast<uint16_t>(bin);
+    }
   };
   auto next_line = [&](uint32_t bin) -> uint32_t {
     uint32_t s = state[bin];
@@ -3087,22 +3127,42 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1wc2_kernel(MsdwArgs
     }
     __syncthreads();
     const uint32_t go = again[cur];
-    const uint32_t nf = nlist[cur];
-    if (tid == 0) {
-      nlist[cur ^ 1] = 0;
-      again[cur ^ 1] = 0;
-    }
+    if (tid == 0) again[cur ^ 1] = 0;
+    // a wave flushes the full lines of ITS 64 bins (bin = thread): which ones, compacted through the wave's piece of wlist
+    // (written and read by this wave only — its LDS operations execute in order), then 8 lanes a line, 16 bytes each
     const int sub = tid & 7;
-    for (uint32_t g0 = 0; g0 < nf; g0 += kMsdwThreads / 8) {   // (workgroup-uniform trip count: the shuffle below)
-      const uint32_t g = g0 + (tid >> 3);
-      const bool on = g < nf;
-      const uint32_t bin = on ? list[cur][g] : 0u;
-      uint32_t line = 0;
-      if (on && sub == 0) line = next_line(bin);
-      line = __shfl(line, lane & ~7, 64);
-      if (on) {
-        store_piece(line, sub, *reinterpret_cast<const arx_u32x4*>(&vals[bin * 16 + sub * 2]));
-        if (sub == 0) fill[bin] = 0;
+    if constexpr (LISTQ) {
+      const uint32_t nfl = nlist[cur];
+      if (tid == 0) nlist[cur ^ 1] = 0;
+      for (uint32_t g0 = 0; g0 < nfl; g0 += kMsdwThreads / 8) {   // (workgroup-uniform trip count: the shuffle below)
+        const uint32_t g = g0 + (tid >> 3);
+        const bool on = g < nfl;
+        const uint32_t bin = on ? list[cur][g] : 0u;
+        uint32_t line = 0;
+        if (on && sub == 0) line = next_line(bin);
+        line = __shfl(line, lane & ~7, 64);
+        if (on) {
+          store_piece(line, sub, *reinterpret_cast<const arx_u32x4*>(&vals[bin * 16 + sub * 2]));
+          if (sub == 0) fill[bin] = 0;
+        }
+      }
+    } else {
+      const bool full = tid < nb && fill[tid] >= 16u;
+      const uint64_t fmask = __ballot(full);
+      const uint32_t nf = static_cast<uint32_t>(__popcll(fmask));   // (wave-uniform)
+      if (full) wlist[(tid & ~63) + __popcll(fmask & ((uint64_t(1) << lane) - 1))] = static_cast<uint16_t>(tid);
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t g0 = 0; g0 < nf; g0 += 8) {
+        const uint32_t g = g0 + static_cast<uint32_t>(lane >> 3);
+        const bool on = g < nf;
+        const uint32_t bin = on ? wlist[(tid & ~63) + g] : 0u;
+        uint32_t line = 0;
+        if (on && sub == 0) line = next_line(bin);
+        line = __shfl(line, lane & ~7, 64);
+        if (on) {
+          store_piece(line, sub, *reinterpret_cast<const arx_u32x4*>(&vals[bin * 16 + sub * 2]));
+          if (sub == 0) fill[bin] = 0;
+        }
       }
     }
     __syncthreads();
@@ -3119,24 +3179,28 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1wc2_kernel(MsdwArgs
   uint64_t pw0 = 0, pw1 = 0;   // carried rows: their words and bins
   uint32_t pb0 = 0, pb1 = 0, np = 0;
   bool gave_up = false;
-  issue(lo);
-  for (int64_t r0 = lo; r0 < hi && !gave_up; r0 += static_cast<int64_t>(R) * kMsdwThreads) {
+  const uint32_t row0 = static_cast<uint32_t>(lo);   // (row ids are 32 bits in this form)
+  // One batch of R rows per thread; FULL: every row of it lies inside the span.  Returns false when the workgroup gives up.
+  auto batch = [&](uint32_t rel, auto full) -> bool {
 #pragma unroll
     for (int i = 0; i < R; ++i) kc[i] = kn[i];
-    if (r0 + static_cast<int64_t>(R) * kMsdwThreads < hi) issue(r0 + static_cast<int64_t>(R) * kMsdwThreads);
+    if (rel + kBatch < span) issue_at(rel + kBatch);
     uint32_t bn[R], sl[R];
     uint64_t wd[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const uint64_t key = key_from_bits(kc[i], a.raw);
+      const uint64_t key = key_from_bits(kc[i], xf);
       bn[i] = static_cast<uint32_t>((key << a.kshift) >> dshift) & dmask;
-      wd[i] = msdw_word(key, static_cast<uint32_t>(r0) + static_cast<uint32_t>(i * kMsdwThreads + tid), a.kshift, a.b1);
+      wd[i] = msdw_word(key, row0 + rel + static_cast<uint32_t>(i * kMsdwThreads + tid), a.kshift, a.b1);
     }
     // (a branch-free form of this phase — dummy bins for what does not apply, one branch for the queueing — measured no
-    //  faster, 24.8 against 24.3 ms end to end: the kernel does not wait for its instruction stream, profiles/r06_j_*)
+    //  faster, 24.8 against 24.3 ms end to end, profiles/r06_j_*)
     uint32_t cs0 = kMsdwWcSkip, cs1 = kMsdwWcSkip;
 #pragma unroll
-    for (int i = 0; i < R; ++i) sl[i] = r0 + i * kMsdwThreads + tid < hi ? atomicAdd(&fill[bn[i]], 1u) : kMsdwWcSkip;
+    for (int i = 0; i < R; ++i) {
+      if constexpr (decltype(full)::value) sl[i] = atomicAdd(&fill[bn[i]], 1u);
+      else sl[i] = rel + static_cast<uint32_t>(i * kMsdwThreads + tid) < span ? atomicAdd(&fill[bn[i]], 1u) : kMsdwWcSkip;
+    }
     if (np > 0) cs0 = atomicAdd(&fill[pb0], 1u);
     if (np > 1) cs1 = atomicAdd(&fill[pb1], 1u);
     uint32_t pend = 0, cpend = 0;
@@ -3176,11 +3240,8 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1wc2_kernel(MsdwArgs
       cpend = cstill;
       if (pend | cpend) again[cur] = 1;
       go = flush_phase();
-      if (++rounds > 64) {   // one digit takes most of the rows: 16 per round would take forever — flags bit 64, the level is
-        gave_up = true;      // repeated by the tile-at-a-time kernel
-        break;
-      }
-    }
+      if (++rounds > 64) return false;   // one digit takes most of the rows: 16 per round would take forever — flags bit 64,
+    }                                    // the level is repeated by the tile-at-a-time kernel
     uint64_t nw0 = 0, nw1 = 0;
     uint32_t nb0 = 0, nb1 = 0, c = 0;
     auto push = [&](uint64_t w, uint32_t b) {
@@ -3204,6 +3265,12 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1wc2_kernel(MsdwArgs
     pw1 = nw1;
     pb1 = nb1;
     np = c < 2 ? c : 2;
+    return true;
+  };
+  issue_at(0);
+  for (uint32_t rel = 0; rel < span && !gave_up; rel += kBatch) {
+    if (rel + kBatch <= span) gave_up = !batch(rel, std::true_type{});
+    else gave_up = !batch(rel, std::false_type{});
   }
   if (gave_up) {   // (workgroup-uniform)
     if (tid == 0) atomicOr(&a.flags[0], 64u);
@@ -3697,12 +3764,31 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
     default: hipLaunchKernelGGL((msdw_scatter1_kernel<RAW, 8, OUT8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break;  \
   }
     if (a.wc1 > 0 && a.wc_form == 2) {
-      if (wc_r == 8) {
-        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<8>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      const int kt = (a.raw >> 4) & 7;
+      if (wc_r == 8 && kt == 0) {
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<8, 0>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (wc_r == 6 && kt == 0) {
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<6, 0>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (wc_r == 8) {
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<8, -1>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
       } else if (wc_r == 6) {
-        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<6>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<6, -1>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (kt == 0 && g_sort_msd_wide_wc_typed == 2) {   // (A/B: the queue of full lines)
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<4, 0, true>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (kt == 0 && g_sort_msd_wide_wc_typed) {
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<4, 0>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (kt == 1 && g_sort_msd_wide_wc_typed) {
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<4, 1>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (kt == 4 && g_sort_msd_wide_wc_typed) {
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<4, 4>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (kt == 2 && g_sort_msd_wide_wc_typed) {
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<4, 2>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (kt == 3 && g_sort_msd_wide_wc_typed) {
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<4, 3>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      } else if (kt == 5 && g_sort_msd_wide_wc_typed) {
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<4, 5>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
       } else {
-        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<4>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+        hipLaunchKernelGGL((msdw_scatter1wc2_kernel<4, -1>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
       }
     } else if (a.wc1 > 0) {
       // tiles of 16 rows per thread with the next tile's keys prefetched (sort_msd_wide_wc_prefetch), or rpt1 rows without
