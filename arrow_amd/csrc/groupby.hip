@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 namespace arx {

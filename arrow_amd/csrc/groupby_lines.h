@@ -235,18 +235,15 @@ __global__ __launch_bounds__(kGblThreads) void gbl_scatter_kernel(GblArgs a) {
   // state = next line (absolute) << 1 | the workgroup holds that line: rooms and chunks start at multiples of kGblK, so
   // the line that ends a chunk is the one before a multiple of kGblK (31 bits of line numbers: 2.5e10 rows)
   __shared__ uint32_t fill[kGblMaxBins], state[kGblMaxBins];
-  __shared__ uint16_t list[2][kGblMaxBins];
-  __shared__ uint32_t nlist[2], again[2], stop;
+  __shared__ uint16_t wlist[kGblThreads];   // per wave: which of its bins have a full line (flush_phase)
+  __shared__ uint32_t again[2], stop;
   constexpr int R = kGblR, K = kGblK;
   const int tid = threadIdx.x, lane = tid & 63;
   for (int b = tid; b < a.bins; b += kGblThreads) {
     fill[b] = 0;
     state[b] = kGblNever;
   }
-  if (tid < 2) {
-    nlist[tid] = 0;
-    again[tid] = 0;
-  }
+  if (tid < 2) again[tid] = 0;
   if (tid == 0) stop = a.flags[0];   // (the rooms did not fit: nothing to do; one thread reads the flag for the workgroup)
   __syncthreads();
   if (stop != 0) return;
@@ -254,23 +251,35 @@ __global__ __launch_bounds__(kGblThreads) void gbl_scatter_kernel(GblArgs a) {
   const int64_t hi = lo + a.rows_per_wg < a.n ? lo + a.rows_per_wg : a.n;
   if (lo >= hi) return;
   const uint32_t span = static_cast<uint32_t>(a.bins) * static_cast<uint32_t>(a.width);
+  // (round 6, after the same change to the sort's level 1 — profiles/r06_p_*: the waves of these kernels issue for a third
+  //  of their time and four of them share a SIMD's VALU, so a batch's instructions are part of its duration.  Rows are
+  //  addressed by 32-bit offsets from the workgroup's first; only a workgroup's last batch checks for the end of its rows;
+  //  and the flush finds the full lines itself instead of every row that takes a line's last slot queueing its bin with
+  //  a returning LDS atomic and a wait — some lane of 64 nearly always does)
+  const uint32_t wg_rows = static_cast<uint32_t>(hi - lo);
+  const int32_t* __restrict__ keys0 = a.keys + lo;
+  const int64_t* __restrict__ values0 = a.values + lo;
+  constexpr uint32_t kBatch = static_cast<uint32_t>(R) * kGblThreads;
   int32_t kc[R], kn[R];
   int64_t vc[R], vn[R];
-  auto issue = [&](int64_t r0) {
+  auto issue = [&](uint32_t rel, auto full) {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      int64_t r = r0 + i * kGblThreads + tid;
-      r = r < hi ? r : hi - 1;
-      kn[i] = __builtin_nontemporal_load(a.keys + r);
-      vn[i] = __builtin_nontemporal_load(a.values + r);
+      uint32_t r = rel + static_cast<uint32_t>(i * kGblThreads + tid);
+      if constexpr (!decltype(full)::value) r = r < wg_rows ? r : wg_rows - 1;
+      kn[i] = __builtin_nontemporal_load(keys0 + r);
+      vn[i] = __builtin_nontemporal_load(values0 + r);
     }
+  };
+  auto issue_at = [&](uint32_t rel) {
+    if (rel + kBatch <= wg_rows) issue(rel, std::true_type{});
+    else issue(rel, std::false_type{});
   };
   int cur = 0;
   uint32_t outliers = 0;
   auto place = [&](uint32_t bin, uint32_t slot, uint32_t rem, int64_t val) {
     vals[bin * kGblCap + slot] = static_cast<uint64_t>(val);
     rems[bin * kGblCap + slot] = static_cast<uint16_t>(rem);
-    if (slot == kGblCap - 1) list[cur][atomicAdd(&nlist[cur], 1u)] = static_cast<uint16_t>(bin);
   };
   auto next_line = [&](uint32_t bin) -> uint32_t {
     uint32_t s = state[bin];
@@ -309,23 +318,30 @@ __global__ __launch_bounds__(kGblThreads) void gbl_scatter_kernel(GblArgs a) {
     }
     __syncthreads();
     const uint32_t go = again[cur];
-    const uint32_t nf = nlist[cur];
-    if (tid == 0) {
-      nlist[cur ^ 1] = 0;
-      again[cur ^ 1] = 0;
-    }
+    if (tid == 0) again[cur ^ 1] = 0;
+    // a wave flushes the full lines of ITS bins (bin = thread, then thread + 1024): which ones, compacted through the wave's
+    // piece of wlist (written and read by this wave only — its LDS operations execute in order), 8 lanes a line
     const int sub = tid & 7;
-    for (uint32_t g0 = 0; g0 < nf; g0 += kGblThreads / 8) {   // (workgroup-uniform trip count: the shuffle below)
-      const uint32_t g = g0 + (tid >> 3);
-      const bool on = g < nf;
-      const uint32_t bin = on ? list[cur][g] : 0u;
-      uint32_t line = 0;
-      if (on && sub == 0) line = next_line(bin);
-      line = __shfl(line, lane & ~7, 64);
-      if (on) {
-        store_piece(line, sub, piece(bin, sub, 6, 6));
-        if (sub == 0) fill[bin] = 0;
+    for (int first = 0; first < a.bins; first += kGblThreads) {   // (workgroup-uniform)
+      const int mine = first + tid;
+      const bool full = mine < a.bins && fill[mine] >= static_cast<uint32_t>(kGblCap);
+      const uint64_t fmask = __ballot(full);
+      const uint32_t nf = static_cast<uint32_t>(__popcll(fmask));   // (wave-uniform)
+      if (full) wlist[(tid & ~63) + __popcll(fmask & ((uint64_t(1) << lane) - 1))] = static_cast<uint16_t>(mine);
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t g0 = 0; g0 < nf; g0 += 8) {
+        const uint32_t g = g0 + static_cast<uint32_t>(lane >> 3);
+        const bool on = g < nf;
+        const uint32_t bin = on ? wlist[(tid & ~63) + g] : 0u;
+        uint32_t line = 0;
+        if (on && sub == 0) line = next_line(bin);
+        line = __shfl(line, lane & ~7, 64);
+        if (on) {
+          store_piece(line, sub, piece(bin, sub, 6, 6));
+          if (sub == 0) fill[bin] = 0;
+        }
       }
+      __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     cur ^= 1;
@@ -349,21 +365,25 @@ __global__ __launch_bounds__(kGblThreads) void gbl_scatter_kernel(GblArgs a) {
   int64_t pv0 = 0, pv1 = 0;
   uint32_t np = 0;
   bool gave_up = false;
-  issue(lo);
-  for (int64_t r0 = lo; r0 < hi && !gave_up; r0 += static_cast<int64_t>(R) * kGblThreads) {
+  // One batch of R rows per thread; FULL: every row of it lies inside the workgroup's rows.  false: the workgroup gives up.
+  auto batch = [&](uint32_t rel, auto full_tag) -> bool {
+    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       kc[i] = kn[i];
       vc[i] = vn[i];
     }
-    if (r0 + static_cast<int64_t>(R) * kGblThreads < hi) issue(r0 + static_cast<int64_t>(R) * kGblThreads);
+    if (rel + kBatch < wg_rows) issue_at(rel + kBatch);
     uint32_t bn[R], rm[R], sl[R];
     bool act[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const int64_t r = r0 + i * kGblThreads + tid;
-      act[i] = r < hi;
-      if constexpr (HAS_NULLS) act[i] = act[i] && gbl_row_streamed<true>(a, r < hi ? r : hi - 1);   // null rows: K0
+      const uint32_t rr = rel + static_cast<uint32_t>(i * kGblThreads + tid);
+      act[i] = FULL || rr < wg_rows;
+      if constexpr (HAS_NULLS) {   // null rows: K0
+        const int64_t r = lo + rr;
+        act[i] = act[i] && gbl_row_streamed<true>(a, r < hi ? r : hi - 1);
+      }
       const uint32_t d = static_cast<uint32_t>(kc[i] - a.kmin);
       if (act[i] && d >= span) {   // outside the sampled range: counted here, consumed by gbl_outliers_kernel
         act[i] = false;
@@ -415,10 +435,7 @@ __global__ __launch_bounds__(kGblThreads) void gbl_scatter_kernel(GblArgs a) {
       cpend = cstill;
       if (pend | cpend) again[cur] = 1;
       go = flush_phase();
-      if (++rounds > 64) {   // a hot key: 12 rows per round would take forever — the other plans take the rows
-        gave_up = true;
-        break;
-      }
+      if (++rounds > 64) return false;   // a hot key: 12 rows per round would take forever — the other plans take the rows
     }
     // what is still pending rides along with the next batch
     int32_t nk0 = 0, nk1 = 0;
@@ -445,6 +462,12 @@ __global__ __launch_bounds__(kGblThreads) void gbl_scatter_kernel(GblArgs a) {
     pk1 = nk1;
     pv1 = nv1;
     np = c < 2 ? c : 2;
+    return true;
+  };
+  issue_at(0);
+  for (uint32_t rel = 0; rel < wg_rows && !gave_up; rel += kBatch) {
+    if (rel + kBatch <= wg_rows) gave_up = !batch(rel, std::true_type{});
+    else gave_up = !batch(rel, std::false_type{});
   }
   if (gave_up) {   // (workgroup-uniform)
     if (tid == 0) atomicOr(&a.flags[1], 1u);
@@ -848,6 +871,7 @@ static bool gbl_plan(int64_t n, int64_t kmin, int width, int wshift, int bins, b
   wgs = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(wgs, n / (int64_t(1) << 18))));   // >= 2^18 rows per workgroup: chunk tails stay small
   p->wgs = wgs;
   p->rows_per_wg = ceil_div(ceil_div(n, wgs), batch) * batch;
+  if (p->rows_per_wg >= (int64_t(1) << 31)) return false;   // (the scatter addresses a workgroup's rows by 32-bit offsets)
   p->sample_stride = gbl_stride_for(n, g_gbl_sample_rows);
   const int64_t lines = gbl_lines_for(n, bins, wgs, p->sample_stride);
   if (lines >= (int64_t(1) << 31) - 4096) return false;   // (the scatter keeps line << 1 | flag in 32 bits)
