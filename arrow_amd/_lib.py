@@ -199,6 +199,8 @@ SIGNATURES = {
     "arx_sort_partition_records_global": (_int, [_span, _int, _int, _int, _p, _p, _int, C.c_uint32, _p, _sz, _p, _p, _p]),
     "arx_sort_records": (_int, [_p, _i64, _p, _sz, _p, _p]),
     "arx_sort_indices": (_int, [_span, _int, _int, _int, _p, _sz, _p, _p]),
+    "arx_rank_workspace_bytes": (_sz, [_i64]),
+    "arx_rank": (_int, [_span, _int, _p, _int, _p, _sz, _p, _p]),
     "arx_sort_indices_64": (_int, [_span, _int, _int, _int, _p, _sz, _p, _p]),
     "arx_sort_key_histogram": (_int, [_span, _int, _int, _int, _p, _p]),
     "arx_sort_partition_by_bins": (_int, [_span, _int, _int, _int, _p, _int, _p, _sz, _p, _p, _p,

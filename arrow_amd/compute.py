@@ -1406,6 +1406,65 @@ def sort_indices_by_keys(keys, orders=None, null_placement="at_end") -> Array:
     return perm
 
 
+# RankOptions::Tiebreaker (api_vector.h:201-212) = ARX_RANK_* of include/arrow_amd.h; "quantile": rank_quantile
+_RANK_TIEBREAKER = {"min": 0, "max": 1, "first": 2, "dense": 3, "quantile": 4}
+
+
+def _rank(arr: Array, order: str, null_placement: str, tiebreaker: str) -> Array:
+    """RankMetaFunctionBase::Rank (kernels/vector_rank.cc:386-420): sort the indices with the array sorter, then one
+    walk of the sorted order (arx_rank)."""
+    if arr.type.name not in _SORT_KEY_TYPE:
+        raise ArrowNotImplementedError(f"rank: {arr.type.name} values")
+    if tiebreaker not in _RANK_TIEBREAKER:
+        raise ArrowInvalid(f"rank: tiebreaker {tiebreaker!r}")
+    dev = arr.device
+    lib, stream = _lib_and_stream(dev)
+    n = arr.length
+    sorted_rows = call_function("array_sort_indices", [arr], ArraySortOptions(order, null_placement))
+    out = alloc(n * 8, dev)
+    ws_bytes = lib.arx_rank_workspace_bytes(n)
+    ws = _workspace(dev, ws_bytes + 256, "rank")
+    base = ws.data_ptr()
+    aligned = (base + 255) & ~255
+    span = arr.span()
+    check(lib.arx_rank(C.byref(span), _SORT_KEY_TYPE[arr.type.name], sorted_rows.data.data_ptr(), _RANK_TIEBREAKER[tiebreaker],
+                       aligned, ws.numel() - (aligned - base), out.data_ptr(), stream))
+    return Array(float64 if tiebreaker == "quantile" else uint64, n, [None, out], 0, 0)
+
+
+def rank(arr: Array, order: str = "ascending", null_placement: str = "at_end", tiebreaker: str = "first") -> Array:
+    """compute "rank" (RankMetaFunction, kernels/vector_rank.cc:422-441; RankOptions api_vector.h:195-240): 1-based uint64
+    ranks, never null; nulls and NaNs are ranked where the sort puts them, all nulls tie, all NaNs tie."""
+    return _rank(arr, order, null_placement, tiebreaker)
+
+
+def rank_quantile(arr: Array, order: str = "ascending", null_placement: str = "at_end") -> Array:
+    """compute "rank_quantile" (RankQuantileMetaFunction, kernels/vector_rank.cc:443-462): (rows below the row's run of
+    ties + half the run) / length, float64."""
+    return _rank(arr, order, null_placement, "quantile")
+
+
+def partition_nth_indices(arr: Array, pivot: int, null_placement: str = "at_end") -> Array:
+    """compute "partition_nth_indices" (PartitionNthToIndices, kernels/vector_array_sort.cc:56-95): uint64 indices such
+    that the `pivot` first ones point at values no greater than the others; nulls and NaNs at the chosen end.  The
+    reference runs std::nth_element (any valid partition is a right answer); a full sort is one such partition."""
+    if pivot > arr.length:
+        raise ArrowIndexError("NthToIndices index out of bound")
+    return call_function("array_sort_indices", [arr], ArraySortOptions("ascending", null_placement))
+
+
+def select_k_unstable(arr: Array, k: int, order: str = "ascending", null_placement: str = "at_end") -> Array:
+    """compute "select_k_unstable" on an array (ArraySelector, kernels/vector_select_k.cc:156-232): the indices of the
+    first k rows of the sorted order — non-nulls, NaNs, nulls taken in that sequence (or the reverse, at_start:
+    CalculateOutputRangesByNullLikeness, :82-100).  "Unstable": the order of equal values is not promised; this one
+    keeps them in row order."""
+    if k < 0:
+        raise ArrowInvalid("select_k_unstable requires a nonnegative `k`, got " + str(k))
+    perm = call_function("array_sort_indices", [arr], ArraySortOptions(order, null_placement))
+    k = min(k, arr.length)
+    return Array(uint64, k, [None, perm.data[: k * 8]], 0, 0)
+
+
 def order_by(columns, sort_keys, null_placement="at_end"):
     """OrderByNode::DoFinish (acero/order_by_node.cc:100-108): concatenate the accumulated batches,
     SortIndices on the sort keys, Take on every column.  `columns` = list of columns, each a list of chunks;

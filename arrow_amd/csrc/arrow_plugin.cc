@@ -99,6 +99,7 @@ namespace {
 #include "plugin/sharded.inc"
 #include "plugin/sharded_sort.inc"
 #include "plugin/order_by_node.inc"
+#include "plugin/rank.inc"
 #include "plugin/acero_source.inc"
 #include "plugin/acero_coalesce.inc"
 #include "plugin/acero_override.inc"

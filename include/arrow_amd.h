@@ -519,6 +519,17 @@ enum {
 size_t arx_sort_indices_workspace_bytes(int64_t length);
 int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_placement, void* ws,
                      size_t ws_bytes, uint64_t* out_indices, void* stream);
+/* rank / rank_quantile of a column from its sorted order — the second half of RankMetaFunction
+ * (compute/kernels/vector_rank.cc:36-245: MarkDuplicates :40-72, OrdinalRanker::CreateRankings :203-263,
+ * BaseQuantileRanker::CreateRankings :163-196).  sorted_rows = arx_sort_indices(values, key_type, order, null_placement):
+ * the order and the null placement are in it; all NaNs tie, all nulls tie, -0.0 ties with 0.0.  out: uint64[length]
+ * 1-based ranks (ARX_RANK_MIN / MAX / FIRST / DENSE = RankOptions::Tiebreaker, api_vector.h:201-212) or, ARX_RANK_QUANTILE,
+ * double[length] = (rows below the row's run of ties + half the run) / length.  ws: arx_rank_workspace_bytes(length),
+ * 256-byte aligned (not used by ARX_RANK_FIRST).  Asynchronous. */
+enum { ARX_RANK_MIN = 0, ARX_RANK_MAX = 1, ARX_RANK_FIRST = 2, ARX_RANK_DENSE = 3, ARX_RANK_QUANTILE = 4 };
+size_t arx_rank_workspace_bytes(int64_t length);
+int arx_rank(const ArxSpan* values, int key_type, const uint64_t* sorted_rows, int tiebreaker, void* ws, size_t ws_bytes,
+             void* out, void* stream);
 /* 64-bit integer keys (is_signed: 0 = uint64, 1 = int64): same as arx_sort_indices. */
 int arx_sort_indices_64(const ArxSpan* values, int is_signed, int order, int null_placement,
                         void* ws, size_t ws_bytes, uint64_t* out_indices, void* stream);

@@ -414,6 +414,41 @@ def sort_indices_multi(keys, descending=None, nulls_at_start=False):
     return np.lexsort(tuple(reversed(columns))).astype(np.uint64)
 
 
+def rank(values, valid, descending=False, nulls_at_start=False, tiebreaker="first"):
+    """compute "rank" / "rank_quantile" (kernels/vector_rank.cc): the array sorter's order (sort_indices_multi with one
+    key: values, NaNs, nulls at_end — or reversed at_start —, ties in row order), MarkDuplicates (:40-72: an index is a
+    duplicate when its value equals the one before it; every NaN after the first and every null after the first are
+    duplicates), then OrdinalRanker::CreateRankings (:203-263) for min / max / first / dense and
+    BaseQuantileRanker::CreateRankings (:163-196) for "quantile".  `values` over the logical rows, `valid` a bool array
+    or None.  uint64 ranks (float64 for "quantile")."""
+    values = np.asarray(values)
+    n = len(values)
+    order = sort_indices_multi([(values, valid)], [descending], nulls_at_start).astype(np.int64)
+    is_null = np.zeros(n, bool) if valid is None else ~np.asarray(valid, bool)
+    is_nan = np.isnan(values) & ~is_null if values.dtype.kind == "f" else np.zeros(n, bool)
+    cls = np.where(is_null, 2, np.where(is_nan, 1, 0))[order]
+    plain = np.where(is_null | is_nan, values.dtype.type(0), values)[order]
+    dup = np.zeros(n, bool)
+    if n > 1:
+        dup[1:] = (cls[1:] == cls[:-1]) & ((cls[1:] != 0) | (plain[1:] == plain[:-1]))
+    pos = np.arange(n, dtype=np.int64)
+    starts = np.where(~dup, pos, 0)
+    run_start = np.maximum.accumulate(starts) if n else starts              # position of the run's first row
+    nxt = np.where(~dup, pos, n)
+    run_end = np.empty(n, np.int64)                                          # position after the run's last row
+    if n:
+        run_end[:-1] = np.minimum.accumulate(nxt[::-1])[::-1][1:]
+        run_end[-1] = n
+    if tiebreaker == "quantile":
+        out = np.empty(n, np.float64)
+        out[order] = (run_start + 0.5 * (run_end - run_start)) / float(n) if n else 0.0
+        return out
+    ranks = {"first": pos + 1, "min": run_start + 1, "max": run_end, "dense": np.cumsum(~dup)}[tiebreaker]
+    out = np.empty(n, np.uint64)
+    out[order] = ranks.astype(np.uint64)
+    return out
+
+
 def groupby_sum_i64(keys, key_valid, key_off, values, val_valid, val_off, length,
                     skip_nulls=True, min_count=1):
     """Returns dict(keys, key_is_valid, sums, counts, no_nulls, valid) in first-occurrence order."""

@@ -4,6 +4,8 @@ arrow_amd.compute -> C ABI and compares with the C oracle (bit-exact) and, when 
 is importable, with the reference's own build (pyarrow)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pytest
 
@@ -3322,3 +3324,138 @@ def check_group_moments(amd, rng, n=20000, groups=(1, 7, 300, 5000)):
     # bad arguments are refused
     assert lib.arx_group_central_power(None, 9, None, 5, None, None, 2, None, st) == _lib.ARX_INVALID
     assert lib.arx_hash_moments_finalize(None, None, None, None, 3, 9, 0, 1, None, st) == _lib.ARX_INVALID
+
+# --------------------------------------------------------------------------- rank / select_k / partition_nth
+def rank_golden_cases():
+    """(values, valid, order, null_placement, tiebreaker, expected) of tests/golden/rank_vectors.json — the known answers
+    of the reference's TestRank (vector_sort_test.cc:2408-2507)."""
+    import json
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rank_vectors.json")) as f:
+        g = json.load(f)
+    def arr(block, dtype):
+        v = np.array([np.nan if x == "NaN" else x for x in block["values"]], dtype=dtype)
+        return v, (None if block["valid"] is None else np.array(block["valid"], bool))
+    out = []
+    for dtype in (np.float64, np.float32):
+        v, valid = arr(g["simple"], dtype)
+        for place in ("at_end", "at_start"):
+            for tb in ("min", "max", "first", "dense"):
+                out.append((v, valid, "ascending", place, tb, g["simple"]["ascending"]))
+                out.append((v, valid, "descending", place, tb, g["simple"]["descending"]))
+        for name in ("all_tiebreakers", "nans_and_nulls"):
+            v, valid = arr(g[name], dtype)
+            out += [(v, valid, o, p, t, e) for o, p, t, e in g[name]["expected"]]
+    # TestRank.Integral (:2509-2525) uses the same expected ranks on [2, 3, 1, 0, 5] and [1, 0, 5, null, 5, null, 0]
+    for dtype in (np.int64, np.uint64, np.int32, np.uint32):
+        v = np.array([2, 3, 1, 0, 5], dtype)
+        for place in ("at_end", "at_start"):
+            for tb in ("min", "max", "first", "dense"):
+                out.append((v, None, "ascending", place, tb, g["simple"]["ascending"]))
+                out.append((v, None, "descending", place, tb, g["simple"]["descending"]))
+        v = np.array([1, 0, 5, 0, 5, 0, 0], dtype)
+        valid = np.array(g["all_tiebreakers"]["valid"], bool)
+        out += [(v, valid, o, p, t, e) for o, p, t, e in g["all_tiebreakers"]["expected"]]
+    return out
+
+
+def check_rank(amd, rng_for, scale=1, light=False):
+    """rank / rank_quantile on the device (arx_sort_indices + arx_rank) against the oracle's restatement of
+    vector_rank.cc — bit-exact, quantile ranks included — on the reference's own known answers and on seeded arrays:
+    all six key types, every tiebreaker, both orders and null placements, nulls, NaNs, signed zeros, long runs of ties
+    that span tiles, sliced inputs, lengths around the tile size, empty."""
+    for v, valid, order, place, tb, expected in rank_golden_cases():
+        if light and v.dtype not in (np.float64, np.int32):      # (the emulated tier: two of the six types)
+            continue
+        d = util.HostArray(v, valid, 0, len(v)).to_device(amd)
+        got = _data_np(amd.compute.rank(d, order, place, tb), np.uint64)
+        assert_equal(got, np.array(expected, np.uint64), f"rank golden [{v.dtype},{order},{place},{tb}]")
+    sizes = [0, 1, 2049, 4500] if light else [0, 1, 2047, 2048, 2049, 5000 * scale, 40_000 * scale]
+    combos = [(o, p_) for o in ("ascending", "descending") for p_ in ("at_end", "at_start")]
+    for dtype in (np.uint64, np.int64, np.uint32, np.int32, np.float64, np.float32):
+        for n in sizes:
+            rng = rng_for("rank", np.dtype(dtype).name, n)
+            # (light — the emulated tier: one order / placement per array, every tiebreaker; all four on the GPU)
+            chosen = [combos[int(rng.integers(0, 4))]] if light else combos
+            kind = np.dtype(dtype).kind
+            distinct = int(rng.choice([1, 3, 50, 1 << 30]))         # (1: one run over every tile; 3: runs of thousands)
+            if kind == "f":
+                vals = rng.integers(-distinct, distinct, n + 5, endpoint=True).astype(dtype) * dtype(0.5)
+                vals[rng.random(n + 5) < 0.1] = np.nan
+                vals[rng.random(n + 5) < 0.05] = dtype(-0.0)
+            else:
+                lo = 0 if kind == "u" else -distinct
+                vals = rng.integers(lo, distinct, n + 5, endpoint=True).astype(dtype)
+            null_p = float(rng.choice([0.0, 0.2]))
+            valid = rng.random(n + 5) >= null_p if null_p else None
+            arr = util.HostArray(vals, valid, 3, n)
+            d = arr.to_device(amd)
+            lv = arr.logical_values()
+            lvalid = None if valid is None else arr.logical_valid()
+            for order, place in chosen:
+                if True:
+                    for tb in ("min", "max", "first", "dense"):
+                        got = amd.compute.rank(d, order, place, tb)
+                        assert got.type == amd.array.uint64 and got.null_count == 0 and got.length == n
+                        want = O.rank(lv, lvalid, order == "descending", place == "at_start", tb)
+                        assert_equal(_data_np(got, np.uint64), want, f"rank[{np.dtype(dtype).name},n={n},{order},{place},{tb}]")
+                    gq = amd.compute.rank_quantile(d, order, place)
+                    wq = O.rank(lv, lvalid, order == "descending", place == "at_start", "quantile")
+                    assert gq.type == amd.array.float64
+                    assert_equal(_data_np(gq, np.float64).view(np.uint64), wq.view(np.uint64), f"rank_quantile[{np.dtype(dtype).name},n={n},{order},{place}]")
+    if pc is not None:     # the restatement itself against the reference build, on the way
+        a = pa.array([1.5, None, float("nan"), -0.0, 0.0, 1.5])
+        v = np.array([1.5, 0, np.nan, -0.0, 0.0, 1.5])
+        valid = np.array([True, False, True, True, True, True])
+        for tb in ("min", "max", "first", "dense"):
+            assert_equal(O.rank(v, valid, False, False, tb), pc.rank(a, sort_keys="ascending", tiebreaker=tb).to_numpy(), "oracle vs pyarrow")
+
+
+def check_select_k_partition_nth(amd, rng_for, scale=1, light=False):
+    """select_k_unstable and partition_nth_indices on the device.  Both promise a property, not one permutation
+    (std::nth_element / heaps in the reference, vector_array_sort.cc:56-95, vector_select_k.cc:103-232): checked are
+    the VALUES at the returned indices against the oracle's sorted order (select_k) and the partition property
+    itself (partition_nth): a permutation, the pivot first ones no greater than the rest, null-likes at their end."""
+    for dtype in ((np.int64, np.float32) if light else (np.int64, np.uint32, np.float64, np.float32)):
+        for n in ((0, 1, 3000) if light else (0, 1, 777, 30_000 * scale)):
+            rng = rng_for("selectk", np.dtype(dtype).name, n)
+            if np.dtype(dtype).kind == "f":
+                vals = rng.integers(-40, 40, n + 2).astype(dtype)
+                vals[rng.random(n + 2) < 0.1] = np.nan
+            else:
+                vals = rng.integers(0, 80, n + 2).astype(dtype)
+            valid = rng.random(n + 2) >= 0.15
+            arr = util.HostArray(vals, valid, 1, n)
+            d = arr.to_device(amd)
+            lv, lvalid = arr.logical_values(), arr.logical_valid()
+            null_like = ~lvalid | (np.isnan(lv) if lv.dtype.kind == "f" else np.zeros(n, bool))
+            for place in ("at_end", "at_start"):
+                for order in ("ascending", "descending"):
+                    full = O.sort_indices(np.ascontiguousarray(arr.values), arr.valid_bitmap(), arr.offset, n,
+                                          descending=(order == "descending"), nulls_at_start=(place == "at_start")).astype(np.int64)
+                    for k in sorted({n // 3, n + 5} if light else {0, 1, n // 3, n, n + 5}):
+                        got = _data_np(amd.compute.select_k_unstable(d, k, order, place), np.uint64).astype(np.int64)
+                        want = full[:k]
+                        assert len(got) == min(k, n)
+                        # same values (and same null / NaN classes) position by position; indices may differ inside ties
+                        assert_equal(lvalid[got], lvalid[want], "select_k validity")
+                        both = lvalid[got]
+                        gv, wv = lv[got][both], lv[want][both]
+                        assert_equal(np.isnan(gv) if gv.dtype.kind == "f" else gv, np.isnan(wv) if wv.dtype.kind == "f" else wv, "select_k NaNs")
+                        ok = ~np.isnan(gv) if gv.dtype.kind == "f" else np.ones(len(gv), bool)
+                        assert_equal(gv[ok], wv[ok], f"select_k values [{np.dtype(dtype).name},n={n},k={k},{order},{place}]")
+                for pivot in sorted({n // 2, n} if light else {0, n // 2, max(n - 1, 0), n}):
+                    got = _data_np(amd.compute.partition_nth_indices(d, pivot, place), np.uint64).astype(np.int64)
+                    assert_equal(np.sort(got), np.arange(n), "partition_nth: a permutation")
+                    nl = null_like[got]
+                    cnt = int(null_like.sum())
+                    if place == "at_end":
+                        assert not nl[:n - cnt].any() and nl[n - cnt:].all()
+                        body, at = got[:n - cnt], pivot
+                    else:
+                        assert nl[:cnt].all() and not nl[cnt:].any()
+                        body, at = got[cnt:], pivot - cnt
+                    if 0 <= at < len(body):
+                        assert (lv[body[:at]] <= lv[body[at]]).all() and (lv[body[at:]] >= lv[body[at]]).all(), "partition property"
+            with pytest.raises(amd.ArrowIndexError):
+                amd.compute.partition_nth_indices(d, n + 1)

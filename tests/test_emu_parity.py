@@ -1212,3 +1212,13 @@ def test_group_moments_variance_stddev_skew_kurtosis(emu_ctx):
     """hash_variance / hash_stddev / hash_skew / hash_kurtosis: the two-pass moments kernels against the oracle's restatement
     of GroupedStatisticImpl (kernels/hash_aggregate_numeric.cc:457-843)."""
     P.check_group_moments(emu_ctx, rng_for("moments"), n=3000, groups=(1, 7, 300))
+
+def test_rank(emu_ctx):
+    """Round 6 (f3): rank / rank_quantile = arx_sort_indices + arx_rank against the oracle's restatement of vector_rank.cc and the
+    known answers of the reference's TestRank."""
+    P.check_rank(emu_ctx, rng_for, light=True)
+
+
+def test_select_k_and_partition_nth(emu_ctx):
+    """Round 6 (f3): select_k_unstable / partition_nth_indices on the sort skeleton — the promised properties."""
+    P.check_select_k_partition_nth(emu_ctx, rng_for, light=True)

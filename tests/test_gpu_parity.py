@@ -1449,3 +1449,13 @@ def test_group_moments_variance_stddev_skew_kurtosis(gpu_ctx):
     """hash_variance / hash_stddev / hash_skew / hash_kurtosis: the two-pass moments kernels against the oracle's restatement
     of GroupedStatisticImpl (kernels/hash_aggregate_numeric.cc:457-843)."""
     P.check_group_moments(gpu_ctx, rng_for("moments"))
+
+def test_rank(gpu_ctx):
+    """Round 6 (f3): rank / rank_quantile = arx_sort_indices + arx_rank against the oracle's restatement of vector_rank.cc and the
+    known answers of the reference's TestRank."""
+    P.check_rank(gpu_ctx, rng_for, scale=10)
+
+
+def test_select_k_and_partition_nth(gpu_ctx):
+    """Round 6 (f3): select_k_unstable / partition_nth_indices on the sort skeleton — the promised properties."""
+    P.check_select_k_partition_nth(gpu_ctx, rng_for, scale=10)

@@ -1171,3 +1171,43 @@ def test_grouped_moments_restatement_against_the_references_golden_vectors():
                 assert got == [None, None], (g, got)
             else:
                 assert np.allclose(got, want, rtol=1e-12), (g, got, want)
+
+
+def test_oracle_rank_against_the_references_known_answers_and_pyarrow():
+    """Round 6: the oracle's restatement of vector_rank.cc — pinned on the known answers of the reference's own TestRank
+    (tests/golden/rank_vectors.json: vector_sort_test.cc:2408-2507, floats and integers) and, where pyarrow is importable,
+    against the reference build on seeded arrays (every tiebreaker, order, null placement; quantile ranks bit for bit)."""
+    from . import parity_cases as P
+
+    cases = P.rank_golden_cases()
+    assert len(cases) == 200
+    for v, valid, order, place, tb, expected in cases:
+        got = O.rank(v, valid, order == "descending", place == "at_start", tb)
+        assert got.tolist() == expected, (v.dtype, order, place, tb, got.tolist(), expected)
+    pa = pytest.importorskip("pyarrow")
+    import warnings
+
+    import pyarrow.compute as pc
+
+    rng = np.random.default_rng(20260930)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", FutureWarning)      # (null_placement in RankOptions: deprecated in 25.0, same result)
+        for dt in (np.int64, np.uint32, np.float64, np.float32):
+            for n in (0, 1, 7, 600):
+                for null_p in (0.0, 0.3):
+                    if np.dtype(dt).kind == "f":
+                        v = rng.integers(-5, 5, n).astype(dt)
+                        v[rng.random(n) < 0.2] = np.nan
+                        v[rng.random(n) < 0.1] = -0.0
+                    else:
+                        v = rng.integers(0, 9, n).astype(dt)
+                    valid = rng.random(n) >= null_p if null_p else None
+                    a = pa.array(v, mask=None if valid is None else ~valid)
+                    for order in ("ascending", "descending"):
+                        for place in ("at_end", "at_start"):
+                            for tb in ("first", "min", "max", "dense"):
+                                w = pc.rank(a, sort_keys=order, null_placement=place, tiebreaker=tb).to_numpy()
+                                assert (w == O.rank(v, valid, order == "descending", place == "at_start", tb)).all(), (dt, n, order, place, tb)
+                            w = pc.rank_quantile(a, sort_keys=order, null_placement=place).to_numpy()
+                            g = O.rank(v, valid, order == "descending", place == "at_start", "quantile")
+                            assert (w.view(np.uint64) == g.view(np.uint64)).all(), (dt, n, order, place, "quantile")
