@@ -755,6 +755,26 @@ def _exec_array_sort_indices(args, options):
     return Array(uint64, n, [None, out], 0, 0)
 
 
+def _exec_array_sort_indices_bool(args, options):
+    """array_sort_indices(boolean): the reference counts (ArrayCountSorter<BooleanType>, vector_array_sort.cc:360-400) —
+    the rows of the falses, of the trues (descending: trues first) and of the nulls at their end, each class in row
+    order: three GetTakeIndices over the value bitmap, its inverse and the inverted validity."""
+    (arr,) = args
+    options = options or ArraySortOptions()
+    n = arr.length
+    if n == 0:
+        return Array(uint64, 0, [None, alloc(8, arr.device)], 0, 0)
+    trues = indices_nonzero(arr)
+    falses = indices_nonzero(invert(arr))
+    parts = [trues, falses] if options.order == "descending" else [falses, trues]
+    if arr.validity is not None and arr.null_count != 0:
+        nulls = indices_nonzero(invert(Array(bool_, n, [None, arr.validity], 0, arr.offset)))
+        parts = [nulls] + parts if options.null_placement == "at_start" else parts + [nulls]
+    out = torch.cat([p.data[: p.length * 8] for p in parts])
+    assert out.numel() == n * 8
+    return Array(uint64, n, [None, out], 0, 0)
+
+
 # --------------------------------------------------------------------------- registry
 class Kernel:
     """arrow::compute::Kernel twin: a signature (tuple of DataType or None = any) + exec."""
@@ -1227,6 +1247,7 @@ def _build_registry() -> FunctionRegistry:
     f = Function("array_sort_indices", Function.VECTOR, 1, ArraySortOptions())
     for key_type in (uint64, int64, uint32, int32, float64, float32):
         f.add_kernel(Kernel((key_type,), _exec_array_sort_indices, uint64))
+    f.add_kernel(Kernel((bool_,), _exec_array_sort_indices_bool, uint64))
     reg.add_function(f)
     reg.add_function(Function("sort_indices", Function.META, 1, SortOptions(), _sort_indices_meta))
 

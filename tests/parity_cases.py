@@ -3411,6 +3411,25 @@ def check_rank(amd, rng_for, scale=1, light=False):
             assert_equal(O.rank(v, valid, False, False, tb), pc.rank(a, sort_keys="ascending", tiebreaker=tb).to_numpy(), "oracle vs pyarrow")
 
 
+def check_sort_boolean_keys(amd, rng_for, scale=1):
+    """array_sort_indices of boolean arrays (the reference's counting sort) — exact indices against pyarrow and the
+    oracle's multi-key restatement: nulls, slices with bit offsets, every order / placement, all-null, empty."""
+    for n in (0, 1, 63, 64, 65, 5000 * scale):
+        rng = rng_for("sort-bool", n)
+        for null_p in (0.0, 0.2, 1.0):
+            arr = util.random_array(rng, np.bool_, n, null_p=null_p, offset=int(rng.integers(0, 70)), tail=3)
+            d = arr.to_device(amd)
+            for order in ("ascending", "descending"):
+                for place in ("at_end", "at_start"):
+                    got = _data_np(amd.compute.sort_indices(d, order, place), np.uint64)
+                    want = O.sort_indices_multi([(arr.logical_values().astype(np.uint8), arr.logical_valid() if arr.valid is not None else None)],
+                                                [order == "descending"], place == "at_start")
+                    assert_equal(got, want, f"sort_indices[bool,n={n},nulls={null_p},{order},{place}]")
+                    if pc is not None:
+                        ref = pc.array_sort_indices(arr.to_pyarrow(), order=order, null_placement=place)
+                        assert_equal(got, ref.to_numpy(), "boolean sort vs pyarrow")
+
+
 def check_select_k_partition_nth(amd, rng_for, scale=1, light=False):
     """select_k_unstable and partition_nth_indices on the device.  Both promise a property, not one permutation
     (std::nth_element / heaps in the reference, vector_array_sort.cc:56-95, vector_select_k.cc:103-232): checked are

@@ -1222,3 +1222,8 @@ def test_rank(emu_ctx):
 def test_select_k_and_partition_nth(emu_ctx):
     """Round 6 (f3): select_k_unstable / partition_nth_indices on the sort skeleton — the promised properties."""
     P.check_select_k_partition_nth(emu_ctx, rng_for, light=True)
+
+
+def test_sort_boolean_keys(emu_ctx):
+    """Round 6 (f3): boolean sort keys — the counting sort as three GetTakeIndices."""
+    P.check_sort_boolean_keys(emu_ctx, rng_for)

@@ -1459,3 +1459,8 @@ def test_rank(gpu_ctx):
 def test_select_k_and_partition_nth(gpu_ctx):
     """Round 6 (f3): select_k_unstable / partition_nth_indices on the sort skeleton — the promised properties."""
     P.check_select_k_partition_nth(gpu_ctx, rng_for, scale=10)
+
+
+def test_sort_boolean_keys(gpu_ctx):
+    """Round 6 (f3): boolean sort keys — the counting sort as three GetTakeIndices."""
+    P.check_sort_boolean_keys(gpu_ctx, rng_for, scale=100)
