@@ -4402,6 +4402,17 @@ RANK_SELECT_SCRIPT = textwrap.dedent(r"""
             got = pc.array_sort_indices(darr, order=o, null_placement=p)
             want = pc.array_sort_indices(arr, order=o, null_placement=p)
             assert (to_host(got) if len(arr) else got).equals(want), (o, p, len(arr))
+    # ---- dictionary sort keys (round 6): the reference's algorithm — ranks of the dictionary values, Take, sort of the ranks
+    for name in ("i64", "f64"):
+        dd = pc.dictionary_encode(dev[name])                 # a dictionary array whose indices AND dictionary live in HBM
+        hd = pc.dictionary_encode(cols[name])
+        assert pa.types.is_dictionary(dd.type) and not dd.is_cpu
+        for o, p in combos:
+            got = pc.array_sort_indices(dd, order=o, null_placement=p)
+            assert not got.is_cpu and to_host(got).equals(pc.array_sort_indices(hd, order=o, null_placement=p)), (name, o, p)
+    dd = pc.dictionary_encode(dev["i64"])
+    sl = dd.slice(7, n // 2)
+    assert to_host(pc.array_sort_indices(sl, order="descending")).equals(pc.array_sort_indices(pc.dictionary_encode(cols["i64"]).slice(7, n // 2), order="descending"))
     tb_dev = pa.table({"b": to_device(bools), "a": dev["i64"]})
     tb_host = pa.table({"b": bools, "a": cols["i64"]})
     for keys in ([("b", "descending"), ("a", "ascending")], [("a", "descending", "at_start"), ("b", "ascending", "at_start")]):
