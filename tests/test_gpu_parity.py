@@ -694,9 +694,9 @@ def test_sort_wide_register_staged_tiles(gpu_ctx, rpt):
 
 
 @pytest.mark.parametrize("n,bits,gap2,shift,rpt,b2max,wc,prefetch,l2w", [(3_000_011, 0, 1, 4, (24, 16), 11, 256, 1, 1), (3_000_003, 14, 0, 2, (8, 8), 11, 0, 1, 2),
-                                                                         (2_000_003, 8, 1, 0, (16, 24), 11, 7, 0, 0), (6_000_003, 0, 1, 4, (24, 16), 4, 48, 1, 1),
-                                                                         (4_000_003, 18, 1, 4, (24, 16), 9, 24, 1, 3), (4_000_003, 18, 1, 4, (24, 16), 9, 24, 0, 1),
-                                                                         (3_000_003, 14, 0, 0, (8, 16), 5, 32, 1, 2), (4_000_003, 20, 1, 4, (24, 16), 11, 32, 1, 1)])
+                                                                         (2_000_003, 8, 1, 0, (16, 24), 11, 7, 0, 0), (4_000_003, 0, 1, 4, (24, 16), 4, 48, 1, 1),
+                                                                         (3_000_003, 18, 1, 4, (24, 16), 9, 24, 1, 3), (3_000_003, 18, 1, 4, (24, 16), 9, 24, 0, 1),
+                                                                         (3_000_003, 14, 0, 0, (8, 16), 5, 32, 1, 2), (3_000_003, 20, 1, 4, (24, 16), 11, 32, 1, 1)])
 def test_sort_wide_rec8_words(gpu_ctx, n, bits, gap2, shift, rpt, b2max, wc, prefetch, l2w):
     """8-byte {key bits, row id} words through the wide form (the form the 2e9-row bench runs): ties below the word,
     duplicates, the tie budget, fall-backs; level 1 tile at a time and write-combined (2 to 512 bins — 9 + 9 bits is the
