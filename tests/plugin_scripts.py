@@ -4413,6 +4413,15 @@ RANK_SELECT_SCRIPT = textwrap.dedent(r"""
     dd = pc.dictionary_encode(dev["i64"])
     sl = dd.slice(7, n // 2)
     assert to_host(pc.array_sort_indices(sl, order="descending")).equals(pc.array_sort_indices(pc.dictionary_encode(cols["i64"]).slice(7, n // 2), order="descending"))
+    # ---- large_utf8 / large_binary sort keys (round 6): offsets narrowed on the device, then the utf8 chain
+    words = [None if i % 13 == 0 else "w%05d" % int(x) if i % 3 else "w%d" % int(x) for i, x in enumerate(rng.integers(0, 3000, SC(60_000)))]
+    for typ in (pa.large_utf8(), pa.large_binary()):
+        ls = pa.array(words if typ == pa.large_utf8() else [None if w is None else w.encode() for w in words], typ)
+        for arr in (ls, ls.slice(11, len(ls) // 2)):
+            darr = to_device(ls) if arr.offset == 0 else to_device(ls).slice(arr.offset, len(arr))
+            for o, p in (combos[:1] + combos[3:] if light else combos):
+                got = pc.array_sort_indices(darr, order=o, null_placement=p)
+                assert not got.is_cpu and to_host(got).equals(pc.array_sort_indices(arr, order=o, null_placement=p)), (str(typ), o, p)
     tb_dev = pa.table({"b": to_device(bools), "a": dev["i64"]})
     tb_host = pa.table({"b": bools, "a": cols["i64"]})
     for keys in ([("b", "descending"), ("a", "ascending")], [("a", "descending", "at_start"), ("b", "ascending", "at_start")]):
