@@ -769,7 +769,7 @@ def run_filter_take(args, rank, world, device):
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "avg_kernel_ms": round(avg_filter_ms, 4),
             "traffic": load_traffic("filter", n),
-            "traffic_source": "profiles/filter_traffic.json",
+            "traffic_source": "profiles/filter_traffic.json (this round's record run: profiles/r06_record_pmc_fetch_write_and_calibration.txt)",
             "timed_in": "HIP events around the C-ABI calls of the mirror loop (the plugin launches the same entry point on its own stream)",
         },
         "kernel_ms": {"arx_filter_exec": round(avg_filter_ms, 4),
@@ -1287,7 +1287,7 @@ def hash_sum_leg(args, rank, world, device, rows_total, steps, warmup):
                         "achieved": round(per_gpu, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(per_gpu / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_row": 12,
                         "traffic": load_traffic("groupby", rows // world, form="lines"),
-                        "traffic_source": "profiles/groupby_traffic.json (this round's FETCH_SIZE x 2 + WRITE_SIZE passes: profiles/r06_g_groupby_pmc_fetch_write.txt)"}}
+                        "traffic_source": "profiles/groupby_traffic.json (this round's FETCH_SIZE x 2 + WRITE_SIZE passes: profiles/r06_record_sort_groupby_pmc_fetch_write.txt)"}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not EMU:
         if "hash_sum" in _CPU_PRE:      # taken before the plugin was registered (run_filter_take)
             leg["cpu_baseline"] = _CPU_PRE["hash_sum"]
