@@ -54,6 +54,7 @@ static Knob<int> g_sort_msd_wide_rec8{1};           // wide form over the caller
 static Knob<int> g_sort_msd_wide_rec8_tie_shift{4};  // ... given up (and repeated with 12-byte records) once more than (rows >> shift) rows of ONE bucket tied (duplicate-heavy keys: every tie is two random 8-byte reads; 2e9 uniform keys: 0.9 per 1000)
 constexpr int kMsdwWcRDefault = 4;
 static Knob<int> g_sort_msd_wide_wc{256};          // rec8 form: level 1 write-combined by this many persistent workgroups (0 = the tile-at-a-time level 1)
+static Knob<int> g_sort_records_in_place{1};       // arx_sort_records: the wide form's level 1 reads the records themselves (0: split into key / row arrays first; A/B knob sort_records_in_place)
 static Knob<int> g_sort_vary_sample_shift{6};      // the shared-prefix probe reads one tile of 8192 rows in 2^shift first (knob sort_vary_sample_shift; round 6: 4 -> 6, 0.34 -> 0.22 ms at 2e9 rows)
 static Knob<int> g_sort_msd_wide_wc_typed{1};      // the append kernel compiled for the key type (uint64 / int64 / double); 0: the run-time switch (A/B knob sort_msd_wide_wc_typed)
 static Knob<int> g_sort_msd_wide_wc_form{2};       // 2: round 6's append kernel (every store a whole line); 1: round 5's rank-and-stage kernel (A/B knob sort_msd_wide_wc_form)
@@ -1834,6 +1835,10 @@ int set_sort_option(const char* name, int64_t value) {
     g_sort_msd_wide_wc_min_rows = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, 1 << 30)));
     return 1;
   }
+  if (strcmp(name, "sort_records_in_place") == 0) {
+    g_sort_records_in_place = value != 0 ? 1 : 0;
+    return 1;
+  }
   if (strcmp(name, "sort_vary_sample_shift") == 0) {
     g_sort_vary_sample_shift = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(value, 8)));
     return 1;
@@ -1900,12 +1905,13 @@ int set_sort_option(const char* name, int64_t value) {
 // there puts every row into one bucket.  sample_shift > 0: only one tile of 8192 rows in 2^sample_shift is read (plus
 // the first and the last tile) — enough to say "no shared prefix" for free; a shared prefix seen in the sample is then
 // confirmed over all rows before anything relies on it.
+// (keys == nullptr, !RAW: the keys are those of the 12-byte records `recs` — the sharded sort's receiver, round 6)
 template <bool RAW>
 __global__ __launch_bounds__(kBlock) void sort_vary_kernel(const uint64_t* __restrict__ keys, int xf, int64_t n, int sample_shift,
-                                                           unsigned long long* __restrict__ out) {
+                                                           unsigned long long* __restrict__ out, const MsdRec* __restrict__ recs = nullptr) {
   constexpr int64_t kTile = 8192;
   const int64_t ntiles = (n + kTile - 1) / kTile;
-  const uint64_t ref = RAW ? load_key_typed(keys, 0, xf) : keys[0];
+  const uint64_t ref = RAW ? load_key_typed(keys, 0, xf) : (keys != nullptr ? keys[0] : msd_rec_key(recs[0]));
   unsigned long long vary = 0;
   for (int64_t g = blockIdx.x; ; g += gridDim.x) {
     int64_t tile = g;
@@ -1921,7 +1927,7 @@ __global__ __launch_bounds__(kBlock) void sort_vary_kernel(const uint64_t* __res
     const int64_t begin = tile * kTile;
     const int64_t end = begin + kTile < n ? begin + kTile : n;
     for (int64_t r = begin + threadIdx.x; r < end; r += kBlock) {
-      const uint64_t k = RAW ? load_key_typed(keys, r, xf) : keys[r];
+      const uint64_t k = RAW ? load_key_typed(keys, r, xf) : (keys != nullptr ? keys[r] : msd_rec_key(recs[r]));
       vary |= k ^ ref;
     }
   }
@@ -1932,7 +1938,7 @@ __global__ __launch_bounds__(kBlock) void sort_vary_kernel(const uint64_t* __res
 
 // Leading bits shared by all n keys (0 when sort_msd_prefix is off, when there are none, or when all keys are equal).
 static int sort_shared_prefix_bits(const uint64_t* keys, int raw_xf, int64_t n, unsigned long long* d_word, hipStream_t st,
-                                   int* out_bits) {
+                                   int* out_bits, const MsdRec* recs = nullptr) {
   *out_bits = 0;
   if (!g_sort_msd_prefix || n < 2) return ARX_OK;
   for (int pass = 0; pass < 2; ++pass) {
@@ -1944,7 +1950,7 @@ static int sort_shared_prefix_bits(const uint64_t* keys, int raw_xf, int64_t n, 
     if (raw_xf != 0) {
       hipLaunchKernelGGL((sort_vary_kernel<true>), dim3(grid), dim3(kBlock), 0, st, keys, raw_xf, n, sample_shift, d_word);
     } else {
-      hipLaunchKernelGGL((sort_vary_kernel<false>), dim3(grid), dim3(kBlock), 0, st, keys, 0, n, sample_shift, d_word);
+      hipLaunchKernelGGL((sort_vary_kernel<false>), dim3(grid), dim3(kBlock), 0, st, keys, 0, n, sample_shift, d_word, recs);
     }
     ARX_CHECK_LAUNCH("sort_vary_kernel");
     unsigned long long vary = 0;
@@ -2248,6 +2254,7 @@ constexpr int kMsdwWcCursorStride = 32;      // u32 between two buckets' cursors
 struct MsdwArgs {
   const uint64_t* src_keys;
   const uint32_t* src_idx;
+  const MsdRec* src_rec;   // !raw, src_keys == NULL: level 1 reads {transformed key, row id} records instead of the two arrays (arx_sort_records)
   int raw;
   int64_t n;
   int bits, b1, b2;
@@ -2312,13 +2319,14 @@ __global__ __launch_bounds__(kMsdThreads) void msdw_hist0_kernel(MsdwArgs a) {
     uint64_t kk[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      kk[u] = RAW ? load_key_typed(a.src_keys, r + u * kMsdThreads, a.raw) : a.src_keys[r + u * kMsdThreads];
+      kk[u] = RAW ? load_key_typed(a.src_keys, r + u * kMsdThreads, a.raw)
+                  : (a.src_keys != nullptr ? a.src_keys[r + u * kMsdThreads] : msd_rec_key(a.src_rec[r + u * kMsdThreads]));
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) atomicAdd(&h[(kk[u] << a.kshift) >> shift], 1u);
   }
   for (; r < end; r += kMsdThreads) {
-    const uint64_t k = RAW ? load_key_typed(a.src_keys, r, a.raw) : a.src_keys[r];
+    const uint64_t k = RAW ? load_key_typed(a.src_keys, r, a.raw) : (a.src_keys != nullptr ? a.src_keys[r] : msd_rec_key(a.src_rec[r]));
     atomicAdd(&h[(k << a.kshift) >> shift], 1u);
   }
   __syncthreads();
@@ -2816,6 +2824,26 @@ __global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1_kernel(MsdwArgs a)
   const int nrows = static_cast<int>(a.n - row0 < kTile ? a.n - row0 : kTile);
   msdw_scatter_any_tile<RAW ? 0 : 1, 1, RPT, OUT8>(a, lds, a.src_keys, a.src_idx, nullptr, row0, nrows, 1 << a.b1, 64 - a.b1,
                                                    a.cursor1, a.l1_end, 0u, 0u, 4u, a.rec_x);
+}
+
+// Level 1 reading {transformed key, row id} RECORDS (a.src_rec): what the receiver of the sharded sort holds (arx_sort_records) —
+// the same tile scatter with the source form level 2 uses; no split of the records into a key and a row array first
+// (2.5 ms of a rank's 13.2 at 5e8 records, profiles/r06_t_*).
+template <int RPT>
+__global__ __launch_bounds__(kMsdwThreads) void msdw_scatter1r_kernel(MsdwArgs a) {
+  __shared__ MsdwScatterLds lds;
+  if (a.sample_shift > 0) {   // (as msdw_scatter1_kernel: an earlier tile found a bucket without room)
+    if (threadIdx.x == 0) lds.part = __atomic_load_n(&a.flags[0], __ATOMIC_RELAXED) & 4u;
+    __syncthreads();
+    if (lds.part != 0) return;   // workgroup-uniform
+    __syncthreads();
+  }
+  constexpr int kTile = RPT * kMsdwThreads;
+  const uint32_t tile = a.xcd_map1 ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int64_t row0 = static_cast<int64_t>(tile) * kTile;
+  const int nrows = static_cast<int>(a.n - row0 < kTile ? a.n - row0 : kTile);
+  msdw_scatter_any_tile<2, 1, RPT, false>(a, lds, nullptr, nullptr, a.src_rec, row0, nrows, 1 << a.b1, 64 - a.b1, a.cursor1, a.l1_end,
+                                          0u, 0u, 4u, a.rec_x);
 }
 
 // Level 1 of the rec8 form, WRITE-COMBINED (VERDICT r4 "Next round" 3).  What bounds a scatter whose bins span the whole
@@ -3639,7 +3667,7 @@ __global__ __launch_bounds__(T) void msdw_scatter2w_kernel(MsdwArgs a) {
 // caller's column, untouched).
 static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n, MsdRec* rec_x,
                                   MsdRec* rec_y, int64_t capacity, uint8_t* tables, uint64_t* out_final, int gap2, int kshift,
-                                  int rec8, hipStream_t st, int* overflowed) {
+                                  int rec8, hipStream_t st, int* overflowed, const MsdRec* src_rec = nullptr) {
   *overflowed = 0;
   if (n == 0) return ARX_OK;
   int lg = 0;
@@ -3647,6 +3675,7 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
   MsdwArgs a{};
   a.src_keys = src_keys;
   a.src_idx = src_idx;
+  a.src_rec = src_rec;
   a.raw = raw;
   a.n = n;
   a.kshift = kshift;
@@ -3688,7 +3717,7 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
   a.rec_x = rec_x;
   a.rec_y = rec_y;
   a.gap2 = (gap2 != 0 && roomy) ? 1 : 0;
-  a.rec8 = (rec8 != 0 && raw != 0 && src_idx == nullptr) ? 1 : 0;   // (ties go back to the column: row id = position)
+  a.rec8 = (rec8 != 0 && raw != 0 && src_idx == nullptr && src_rec == nullptr) ? 1 : 0;   // (ties go back to the column: row id = position)
   const int nb1 = 1 << a.b1;
   const size_t nparts = size_t(1) << a.bits;
   // (each knob is read ONCE: the tile sizes, the grids and the template dispatch below must agree even if arx_set_option runs
@@ -3803,6 +3832,12 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
         hipLaunchKernelGGL((msdw_scatter1wc_kernel<16, false>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
       } else {
         hipLaunchKernelGGL((msdw_scatter1wc_kernel<8, false>), dim3(a.wc1), dim3(kMsdwThreads), 0, st, a);
+      }
+    } else if (a.src_rec != nullptr) {
+      switch (rpt1) {
+        case 24: hipLaunchKernelGGL((msdw_scatter1r_kernel<24>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break;
+        case 16: hipLaunchKernelGGL((msdw_scatter1r_kernel<16>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break;
+        default: hipLaunchKernelGGL((msdw_scatter1r_kernel<8>), dim3(grid1), dim3(kMsdwThreads), 0, st, a); break;
       }
     } else if (a.rec8) {
       ARX_MSDW_SCATTER1(true, true)
@@ -3994,13 +4029,13 @@ static int run_msd_sort_wide_form(const uint64_t* src_keys, const uint32_t* src_
 // level-2 buckets after a room overflow — then start with full records)
 static int run_msd_sort_wide(const uint64_t* src_keys, const uint32_t* src_idx, int raw, int64_t n, MsdRec* rec_x,
                              MsdRec* rec_y, int64_t capacity, uint8_t* tables, uint64_t* out_final, int gap2, int kshift,
-                             hipStream_t st, int* overflowed, int* rec8) {
+                             hipStream_t st, int* overflowed, int* rec8, const MsdRec* src_rec = nullptr) {
   int rc = run_msd_sort_wide_form(src_keys, src_idx, raw, n, rec_x, rec_y, capacity, tables, out_final, gap2, kshift, *rec8, st,
-                                  overflowed);
+                                  overflowed, src_rec);
   if (rc == ARX_OK && *overflowed == 3) {
     *rec8 = 0;
     rc = run_msd_sort_wide_form(src_keys, src_idx, raw, n, rec_x, rec_y, capacity, tables, out_final, gap2, kshift, 0, st,
-                                overflowed);
+                                overflowed, src_rec);
   }
   return rc;
 }
@@ -4671,21 +4706,29 @@ int arx_sort_records(const ArxSortRecord* records, int64_t num_records, void* ws
     ARX_CHECK_LAUNCH("sort_split_records_kernel");
     return ARX_OK;
   };
-  int rc = prep();
-  if (rc != ARX_OK) return rc;
+  int rc = ARX_OK;
   const bool try_msd = g_sort_msd != 0 && n < (int64_t(1) << 32) - kMsdTile && (g_sort_msd == 1 ? n >= 256 : n >= g_sort_msd_min_rows);
   const bool segmented = n > g_sort_msd_segment_rows;
+  const bool wide = try_msd && g_sort_msd_sampled != 2 && segmented && g_sort_msd_wide != 0;
+  // the wide form reads the records where they lie (level 1 takes 12-byte records as level 2 does): no split into a key
+  // and a row array first — every other form starts from the split arrays (knob sort_records_in_place = 0: the split always)
+  const MsdRec* in_place = wide && g_sort_records_in_place ? reinterpret_cast<const MsdRec*>(records) : nullptr;
+  if (in_place == nullptr) {
+    rc = prep();
+    if (rc != ARX_OK) return rc;
+  }
   if (try_msd && g_sort_msd_sampled != 2) {
     int ks = 0, overflowed = 1;
-    rc = sort_shared_prefix_bits(keys_a, 0, n, reinterpret_cast<unsigned long long*>(tables), st, &ks);
+    rc = sort_shared_prefix_bits(in_place != nullptr ? nullptr : keys_a, 0, n, reinterpret_cast<unsigned long long*>(tables), st, &ks, in_place);
     if (rc != ARX_OK) return rc;
-    const bool wide = segmented && g_sort_msd_wide != 0;
     if (wide) {
       int rec8 = 0;   // (row ids are not positions in a column: full records)
-      rc = run_msd_sort_wide(keys_a, idx_a, 0, n, rec_b, rec_a, rec_cap, tables, out_rows, g_sort_msd_wide_gap2, ks, st, &overflowed, &rec8);
+      const uint64_t* wk = in_place != nullptr ? nullptr : keys_a;
+      const uint32_t* wi = in_place != nullptr ? nullptr : idx_a;
+      rc = run_msd_sort_wide(wk, wi, 0, n, rec_b, rec_a, rec_cap, tables, out_rows, g_sort_msd_wide_gap2, ks, st, &overflowed, &rec8, in_place);
       if (rc == ARX_OK && overflowed == 2) {
-        rc = prep();
-        if (rc == ARX_OK) rc = run_msd_sort_wide(keys_a, idx_a, 0, n, rec_b, rec_a, rec_cap, tables, out_rows, 0, ks, st, &overflowed, &rec8);
+        if (in_place == nullptr) rc = prep();
+        if (rc == ARX_OK) rc = run_msd_sort_wide(wk, wi, 0, n, rec_b, rec_a, rec_cap, tables, out_rows, 0, ks, st, &overflowed, &rec8, in_place);
       }
       if (rc == ARX_OK && overflowed) rc = prep();
     }

@@ -1321,11 +1321,11 @@ def _hash_sum_plan_counters():
 
 
 # ranks at which the sharded array_sort_indices is SLOWER than the single-GPU sort by this repo's own stage measurements
-# (profiles/r06_l_virtual_rank_stage_table_sort_records.txt: per rank 41.4 ms at P = 2 against 24.0 ms on one GPU — every row
-# crosses the wire as a 12-byte record and the receiver sorts records, not words; 22.0 ms at P = 4, 11.7 ms at P = 8): the
+# (profiles/r06_u_virtual_rank_stage_table_sort_records_in_place.txt: per rank 33.1 ms at P = 2 against 22.6 ms on one GPU — every
+# row crosses the wire as a 12-byte record and the receiver sorts records, not words; 18.0 ms at P = 4, 9.7 ms at P = 8): the
 # leg declines there instead of printing a slower number (VERDICT r5 "Next round" 2).  --force-sharded-sort runs it anyway.
-SORT_DECLINED_WORLDS = {2: "per-rank stages 41.4 ms (histogram 3.4 + partition 5.7 + exchange of 6 GB ~5.6 + record sort 26.6) against "
-                           "24.0 ms for the whole sort on one GPU (profiles/r06_l_virtual_rank_stage_table_sort_records.txt)"}
+SORT_DECLINED_WORLDS = {2: "per-rank stages 33.1 ms (histogram 3.3 + partition 5.6 + exchange of 6 GB ~5.6 + record sort 18.6) against "
+                           "22.6 ms for the whole sort on one GPU (profiles/r06_u_virtual_rank_stage_table_sort_records_in_place.txt)"}
 
 
 def sort_leg(args, rank, world, device, rows_total, steps, warmup):

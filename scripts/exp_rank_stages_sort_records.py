@@ -21,7 +21,7 @@ ROWS = int(os.environ.get("SORT_ROWS", 2_000_000_000))
 XGMI_GBS = 7 * 153.0
 base = None
 print(f"array_sort_indices {ROWS} uint64 rows, records form: per-rank stage ms, best of 4 (wall clock, stream synchronised at every mark)")
-for world in (1, 2, 4, 8):
+for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
     n = ROWS // world
     k = torch.empty(n, dtype=torch.int64, device=dev); fill(k, 10)
     arr = Array(uint64, n, [None, k.view(torch.uint8)], 0, 0)

@@ -363,7 +363,9 @@ def test_groupby_partition_knobs(emu_ctx, l1_global, agg_chunk, bits):
 
 @pytest.mark.parametrize("n,options", [(0, ()), (1, ()), (9000, ()), (30000, ((b"sort_msd", 1),)),
                                        (30000, ((b"sort_msd", 1), (b"sort_msd_sampled", 2))),
-                                       (40000, ((b"sort_msd", 1), (b"sort_msd_segment_rows", 4096), (b"sort_msd_wide", 1), (b"sort_msd_wide_bits", 8)))])
+                                       (40000, ((b"sort_msd", 1), (b"sort_msd_segment_rows", 4096), (b"sort_msd_wide", 1), (b"sort_msd_wide_bits", 8))),
+                                       (40000, ((b"sort_msd", 1), (b"sort_msd_segment_rows", 4096), (b"sort_msd_wide", 1), (b"sort_msd_wide_bits", 8),
+                                                (b"sort_records_in_place", 0)))])
 def test_sort_records(emu_ctx, n, options):
     """Round 6: arx_sort_records (the receiver of the sharded sort's records form) — LSD fallback, MSD hybrid, sampled
     splitters, the wide form on 12-byte records."""
