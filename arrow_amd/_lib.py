@@ -209,6 +209,8 @@ SIGNATURES = {
     "arx_sort_partition_records": (_int, [_span, _int, _int, _int, _int, _p, _int, _p, _sz, _p, _p, C.POINTER(_i64), _p]),
     "arx_sort_key_range": (_int, [_span, _int, _int, _p, _p]),
     "arx_sort_key_histogram_window": (_int, [_span, _int, _int, _int, _p, _p, _p]),
+    "arx_sort_key_range_sampled": (_int, [_span, _int, _int, _int, _p, _p]),
+    "arx_sort_key_histogram_window_sampled": (_int, [_span, _int, _int, _int, _p, _int, _p, _p]),
     "arx_sort_partition_records_window": (_int, [_span, _int, _int, _int, _int, _p, _p, _int, _p, _sz, _p, _p,
                                                  C.POINTER(_i64), _p]),
     "arx_sort_unpack_records": (_int, [_p, _i64, _p, _int, _int, _p, _p, _p, _p]),

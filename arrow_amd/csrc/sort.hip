@@ -407,19 +407,36 @@ __global__ __launch_bounds__(kBlock, 3) void radix_scatter_kernel(
 // The splitter bins are taken inside the WINDOW of the keys that exist: bin = top `bits` bits of (key - base) << shift,
 // base = the smallest transformed key of all shards, shift = leading zeros of (largest - smallest).  Ids, timestamps
 // and small integers share their top bits; bins of the raw key would send every row to one rank.
+// A key OUTSIDE the window (a window taken from a sample of the rows, round 6) falls into the first / the last bin: the bin
+// stays a non-decreasing function of the key, which is all the partition needs.
 __device__ __forceinline__ uint32_t sort_window_bin(uint64_t tk, uint64_t base, int shift, int bits) {
-  return static_cast<uint32_t>(((tk - base) << shift) >> (64 - bits));
+  if (tk < base) return 0u;
+  const uint64_t d = tk - base;
+  if (shift > 0 && (d >> (64 - shift)) != 0) return (1u << bits) - 1u;
+  return static_cast<uint32_t>((d << shift) >> (64 - bits));
+}
+
+// row i of a grid-stride loop over a SAMPLE of the rows: one tile of 8192 rows in 2^sample_shift, the tile picked inside its
+// group by a hash of the group (a periodic input cannot line up with the sample).  sample_shift 0: every row.
+__device__ __forceinline__ int64_t sort_sampled_row(int64_t i, int sample_shift) {
+  if (sample_shift == 0) return i;
+  const int64_t g = i >> 13;
+  const uint32_t pick = (static_cast<uint32_t>(g) * 2654435761u) >> (32 - sample_shift);
+  return (((g << sample_shift) + pick) << 13) + (i & 8191);
 }
 
 // range[0] = max of ~key (= ~min), range[1] = max key over the non-null rows (both zero-initialised by the caller,
 // both combined by MAX — one all-reduce with one operator gives the global range)
 __global__ __launch_bounds__(kBlock) void sort_key_range_kernel(const uint64_t* __restrict__ values, Bits valid, int64_t n,
                                                                 int is_signed, int descending,
-                                                                unsigned long long* __restrict__ range) {
+                                                                unsigned long long* __restrict__ range, int sample_shift = 0) {
   __shared__ unsigned long long s_lo[kWavesPerBlock], s_hi[kWavesPerBlock];
   unsigned long long lo = 0, hi = 0;   // lo accumulates ~key
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+  const int64_t work = sample_shift == 0 ? n : ((((n + 8191) >> 13) + (int64_t(1) << sample_shift) - 1) >> sample_shift) << 13;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < work; j += stride) {
+    const int64_t i = sort_sampled_row(j, sample_shift);
+    if (i >= n) continue;
     const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1ull;
     if (ok) {
       const unsigned long long tk = key_transform(values[i], is_signed != 0, descending != 0);
@@ -451,13 +468,16 @@ __global__ __launch_bounds__(kBlock) void sort_key_range_kernel(const uint64_t* 
 __global__ __launch_bounds__(kBlock) void sort_key_hist_kernel(const uint64_t* __restrict__ values,
                                                                Bits valid, int64_t n, int is_signed,
                                                                int descending, int bits, uint64_t base, int shift,
-                                                               unsigned long long* __restrict__ hist) {
+                                                               unsigned long long* __restrict__ hist, int sample_shift = 0) {
   __shared__ uint32_t h[4096];
   const int nb = 1 << bits;
   for (int i = threadIdx.x; i < nb; i += kBlock) h[i] = 0;
   __syncthreads();
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+  const int64_t work = sample_shift == 0 ? n : ((((n + 8191) >> 13) + (int64_t(1) << sample_shift) - 1) >> sample_shift) << 13;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < work; j += stride) {
+    const int64_t i = sort_sampled_row(j, sample_shift);
+    if (i >= n) continue;
     const bool ok = (load_word(valid, i >> 6) >> (i & 63)) & 1ull;
     if (ok) {
       const uint64_t tk = key_transform(values[i], is_signed != 0, descending != 0);
@@ -4393,7 +4413,11 @@ static int sort_window_ok(const ArxSortKeyWindow* window, uint64_t* base, int* s
 }
 
 int arx_sort_key_range(const ArxSpan* values, int is_signed, int order, uint64_t* out_range, void* stream) {
-  if (values == nullptr || out_range == nullptr) {
+  return arx_sort_key_range_sampled(values, is_signed, order, 0, out_range, stream);
+}
+
+int arx_sort_key_range_sampled(const ArxSpan* values, int is_signed, int order, int sample_shift, uint64_t* out_range, void* stream) {
+  if (values == nullptr || out_range == nullptr || sample_shift < 0 || sample_shift > 8) {
     set_error("bad arguments to arx_sort_key_range");
     return ARX_INVALID;
   }
@@ -4405,9 +4429,9 @@ int arx_sort_key_range(const ArxSpan* values, int is_signed, int order, uint64_t
   }
   const uint64_t* vals = static_cast<const uint64_t*>(values->data) + values->offset;
   const Bits vb = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
-  const unsigned g = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock * 16), 2048)));
+  const unsigned g = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n >> sample_shift, kBlock * 16), 2048)));
   hipLaunchKernelGGL(sort_key_range_kernel, dim3(g), dim3(kBlock), 0, as_stream(stream), vals, vb, n, is_signed,
-                     order == ARX_SORT_DESCENDING, reinterpret_cast<unsigned long long*>(out_range));
+                     order == ARX_SORT_DESCENDING, reinterpret_cast<unsigned long long*>(out_range), sample_shift);
   ARX_CHECK_LAUNCH("sort_key_range_kernel");
   return ARX_OK;
 }
@@ -4419,7 +4443,12 @@ int arx_sort_key_histogram(const ArxSpan* values, int is_signed, int order, int 
 
 int arx_sort_key_histogram_window(const ArxSpan* values, int is_signed, int order, int bits,
                                   const ArxSortKeyWindow* window, uint64_t* out_hist, void* stream) {
-  if (values == nullptr || out_hist == nullptr || bits < 1 || bits > 12) {
+  return arx_sort_key_histogram_window_sampled(values, is_signed, order, bits, window, 0, out_hist, stream);
+}
+
+int arx_sort_key_histogram_window_sampled(const ArxSpan* values, int is_signed, int order, int bits,
+                                          const ArxSortKeyWindow* window, int sample_shift, uint64_t* out_hist, void* stream) {
+  if (values == nullptr || out_hist == nullptr || bits < 1 || bits > 12 || sample_shift < 0 || sample_shift > 8) {
     set_error("bad arguments to arx_sort_key_histogram (bits in [1,12])");
     return ARX_INVALID;
   }
@@ -4434,10 +4463,10 @@ int arx_sort_key_histogram_window(const ArxSpan* values, int is_signed, int orde
   }
   const uint64_t* vals = static_cast<const uint64_t*>(values->data) + values->offset;
   const Bits vb = make_bits(values->null_count != 0 ? values->validity : nullptr, values->offset, n);
-  const unsigned g = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock * 16), 2048)));
+  const unsigned g = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(n >> sample_shift, kBlock * 16), 2048)));
   hipLaunchKernelGGL(sort_key_hist_kernel, dim3(g), dim3(kBlock), 0, as_stream(stream), vals, vb, n,
                      is_signed, order == ARX_SORT_DESCENDING, bits, base, shift,
-                     reinterpret_cast<unsigned long long*>(out_hist));
+                     reinterpret_cast<unsigned long long*>(out_hist), sample_shift);
   ARX_CHECK_LAUNCH("sort_key_hist_kernel");
   return ARX_OK;
 }

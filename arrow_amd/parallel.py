@@ -26,6 +26,8 @@ from .compute import GroupBySum, RangeGroupBySum, ScalarAggregateOptions
 
 RECORD_BYTES = 24   # sizeof(ArxGroupPartial)
 SORT_RECORD_BYTES = 12   # sizeof(ArxSortRecord)
+SORT_SAMPLE_SHIFT = 4      # the sharded sort's sampled key range / splitter histogram: one tile of 8192 rows in 16 (0: never sampled)
+SORT_SAMPLE_MIN_ROWS = 1 << 20   # ... when the longest shard has at least this many rows (tests lower both)
 _U64 = (1 << 64) - 1
 
 
@@ -398,15 +400,30 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
     nulls_first = null_placement == "at_start"
     target = 0 if nulls_first else world - 1
 
-    # 0. the key window: {max of ~key, max of key}, both by MAX; unsigned order as int64 = sign bit flipped
+    # 0. the key window: {max of ~key, max of key}, both by MAX; unsigned order as int64 = sign bit flipped.  The same
+    #    all-reduce carries what decides the round-6 SAMPLED form for every rank alike: "this shard may have nulls" and the
+    #    shard's length (MAX: no shard has nulls, and world x the longest shard < 2^32 rows) — then the records form is certain,
+    #    nothing below needs exact per-bin counts, and the range and the histogram are taken from 1 tile of 8192 rows in 16
+    #    (two passes over every key were 1.8 of a rank's 18 ms at P = 4, profiles/r06_u_*).
     span = values.span()
-    key_range = torch.zeros(2, dtype=torch.int64, device=device)
-    check(lib.arx_sort_key_range(C.byref(span), is_signed, order_code, key_range.data_ptr(), stream))
+    may_have_nulls = int(values.buffers[0] is not None and values.null_count != 0)
+    key_range = torch.zeros(4, dtype=torch.int64, device=device)
+    sample_shift = SORT_SAMPLE_SHIFT if (records_form is not False and not may_have_nulls and n >= SORT_SAMPLE_MIN_ROWS) else 0
+    check(lib.arx_sort_key_range_sampled(C.byref(span), is_signed, order_code, sample_shift, key_range.data_ptr(), stream))
     sign = torch.iinfo(torch.int64).min
-    key_range ^= sign
+    key_range[:2] ^= sign
+    key_range[2] = 1 if (may_have_nulls or records_form is False) else 0
+    key_range[3] = n
     dist.all_reduce(key_range, op=dist.ReduceOp.MAX, group=group)
-    inv_min, key_max = [int(x) ^ sign for x in key_range.tolist()]
+    reduced = key_range.tolist()
+    inv_min, key_max = [int(x) ^ sign for x in reduced[:2]]
     key_min, key_max = ~inv_min & _U64, key_max & _U64
+    # (a rank that sampled its range while the ranks together take the exact form: its range may miss keys — they fall into
+    #  the window's end bins, in the histogram and in the partition alike, so every count stays exact)
+    sampled = SORT_SAMPLE_SHIFT > 0 and reduced[2] == 0 and int(reduced[3]) * world < 2**32 and int(reduced[3]) >= SORT_SAMPLE_MIN_ROWS
+    if sampled and key_max > key_min:      # a sample misses a few keys at both ends: widen (keys outside fall into the end bins)
+        margin = ((key_max - key_min) >> 6) + 1
+        key_min, key_max = max(0, key_min - margin), min(_U64, key_max + margin)
     window = _lib.ArxSortKeyWindow(0, 0, 0)
     if key_max > key_min:        # (no valid row anywhere: min = 2^64 - 1 > max = 0; one distinct key: nothing to split)
         window = _lib.ArxSortKeyWindow(key_min, 64 - (key_max - key_min).bit_length(), 0)
@@ -414,18 +431,18 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
     # 1. one all-reduce: [histogram (2^bits) | shard lengths (world) | valid rows per shard (world)]
     nbins = 1 << splitter_bits
     stats = torch.zeros(nbins + 2 * world, dtype=torch.int64, device=device)
-    check(lib.arx_sort_key_histogram_window(C.byref(span), is_signed, order_code, splitter_bits, C.byref(window),
-                                            stats.data_ptr(), stream))
+    check(lib.arx_sort_key_histogram_window_sampled(C.byref(span), is_signed, order_code, splitter_bits, C.byref(window),
+                                                    SORT_SAMPLE_SHIFT if sampled else 0, stats.data_ptr(), stream))
     stats[nbins + rank] = n
-    stats[nbins + world + rank] = stats[:nbins].sum()
+    stats[nbins + world + rank] = n if sampled else stats[:nbins].sum()
     dist.all_reduce(stats, group=group)
     stats_h = stats.cpu()
     _mark(stages, "histogram")
     cum = torch.cumsum(stats_h[:nbins], 0)
     lens_h = [int(x) for x in stats_h[nbins:nbins + world].tolist()]
     valid_h = [int(x) for x in stats_h[nbins + world:].tolist()]
-    total_valid = int(cum[-1])
-    total_nulls = sum(lens_h) - total_valid
+    total_valid = int(cum[-1])           # (sampled: the rows of the SAMPLE — the splitters are its quantiles)
+    total_nulls = 0 if sampled else sum(lens_h) - total_valid
     split = []
     for p in range(1, world):
         want = (total_valid * p + world - 1) // world
@@ -453,9 +470,16 @@ def sharded_sort_indices(values, order: str = "ascending", null_placement: str =
                                                     world, offsets[rank], pws.data_ptr(), pws.numel(), records.data_ptr(),
                                                     counts.data_ptr(), stream))
         _mark(stages, "partition")
-        recv_counts = torch.empty_like(counts)
-        dist.all_to_all_single(recv_counts, counts, group=group)
-        send, recv = _host_counts(counts, recv_counts)
+        # the block sizes: every rank's counts to every rank (one all-gather of world numbers — what the count exchange moved
+        # before —: a rank's row is what it receives, the column sums are what every rank will own, exact whatever placed
+        # the splitters)
+        rows_of = [torch.empty_like(counts) for _ in range(world)]
+        dist.all_gather(rows_of, counts, group=group)
+        matrix_h = torch.stack(rows_of).cpu()
+        send = [int(x) for x in matrix_h[rank].tolist()]
+        recv = [int(x) for x in matrix_h[:, rank].tolist()]
+        owned = [int(x) for x in matrix_h.sum(dim=0).tolist()]
+        start = sum(owned[:rank])
         got = _all_to_all_bytes(records[: n * SORT_RECORD_BYTES], send, recv, SORT_RECORD_BYTES, group)
         _mark(stages, "exchange")
         m = sum(recv)

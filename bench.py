@@ -1321,11 +1321,11 @@ def _hash_sum_plan_counters():
 
 
 # ranks at which the sharded array_sort_indices is SLOWER than the single-GPU sort by this repo's own stage measurements
-# (profiles/r06_u_virtual_rank_stage_table_sort_records_in_place.txt: per rank 33.1 ms at P = 2 against 22.6 ms on one GPU — every
-# row crosses the wire as a 12-byte record and the receiver sorts records, not words; 18.0 ms at P = 4, 9.7 ms at P = 8): the
+# (profiles/r06_v_virtual_rank_stage_table_sort_records_sampled_splitters.txt: per rank 30.2 ms at P = 2 against 23.1 ms on one GPU —
+# every row crosses the wire as a 12-byte record and the receiver sorts records, not words; 16.5 ms at P = 4, 9.0 ms at P = 8): the
 # leg declines there instead of printing a slower number (VERDICT r5 "Next round" 2).  --force-sharded-sort runs it anyway.
-SORT_DECLINED_WORLDS = {2: "per-rank stages 33.1 ms (histogram 3.3 + partition 5.6 + exchange of 6 GB ~5.6 + record sort 18.6) against "
-                           "22.6 ms for the whole sort on one GPU (profiles/r06_u_virtual_rank_stage_table_sort_records_in_place.txt)"}
+SORT_DECLINED_WORLDS = {2: "per-rank stages 30.2 ms (sampled window + splitters 0.4 + partition 5.9 + exchange of 6 GB ~5.6 + record sort 18.3) "
+                           "against 23.1 ms for the whole sort on one GPU (profiles/r06_v_virtual_rank_stage_table_sort_records_sampled_splitters.txt)"}
 
 
 def sort_leg(args, rank, world, device, rows_total, steps, warmup):
@@ -1337,7 +1337,7 @@ def sort_leg(args, rank, world, device, rows_total, steps, warmup):
     per_gpu = 16 * rows / world / sec / 1e9
     leg = {"rows": rows, "n_gpus": world, "ms": round(sec * 1e3, 3), "mrows_per_s": round(rows / sec / 1e6, 1),
            "scaling": "strong",
-           "exchange": "1 all-reduce (key window) + 1 all-reduce (splitter histogram) + 1 count exchange + ONE all-to-all(v) of 12-byte {key, global row} records; the receiver sorts its records (arx_sort_records)" if world > 1 else "none (one rank)",
+           "exchange": "1 all-reduce (sampled key window) + 1 all-reduce (sampled splitter histogram) + 1 all-gather of the block sizes + ONE all-to-all(v) of 12-byte {key, global row} records; the receiver sorts its records where they lie (arx_sort_records)" if world > 1 else "none (one rank)",
            "permutation_and_order_checks": ok,
            "stage_ms_max_over_ranks_untimed_run": _LAST_STAGES.get("sort_indices"),
            "roofline": {"bound": "hbm", "kernel": "arx_sort_indices (wide form on 8-byte words: msdw_scatter1wc2 [level 1 write-combined by appending: whole 128-byte lines] + msdw_scatter2w + msd_bucket2w [LDS finish])",

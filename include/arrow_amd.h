@@ -597,8 +597,15 @@ typedef struct ArxSortKeyWindow {
   int32_t reserved;
 } ArxSortKeyWindow;
 int arx_sort_key_range(const ArxSpan* values, int is_signed, int order, uint64_t* out_range, void* stream);
+/* The same two over a SAMPLE of the rows (round 6): one tile of 8192 rows in 2^sample_shift (0 .. 8; 0 = every row).  A window
+ * built from a sampled range is widened by its caller, and keys outside a window fall into its first / last bin (the bin stays
+ * monotone in the key: destinations stay ordered); a sampled histogram places the splitters, the exact per-destination
+ * counts come from the partition. */
+int arx_sort_key_range_sampled(const ArxSpan* values, int is_signed, int order, int sample_shift, uint64_t* out_range, void* stream);
 int arx_sort_key_histogram_window(const ArxSpan* values, int is_signed, int order, int bits,
                                   const ArxSortKeyWindow* window, uint64_t* out_hist, void* stream);
+int arx_sort_key_histogram_window_sampled(const ArxSpan* values, int is_signed, int order, int bits,
+                                          const ArxSortKeyWindow* window, int sample_shift, uint64_t* out_hist, void* stream);
 int arx_sort_partition_records_window(const ArxSpan* values, int is_signed, int order, int null_placement, int bits,
                                       const ArxSortKeyWindow* window, const uint32_t* splitter_bins /* host */,
                                       int num_parts, void* ws, size_t ws_bytes, ArxSortRecord* out_records,

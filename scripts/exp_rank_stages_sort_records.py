@@ -35,14 +35,17 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
             ms = [0.0, 0.0, (t[1] - t[0]) * 1e3]
         else:
             span = arr.span()
-            key_range = torch.zeros(2, dtype=torch.int64, device=dev)
-            _lib.check(lib.arx_sort_key_range(C.byref(span), 0, _lib.SORT_ASCENDING, key_range.data_ptr(), st))
+            # (as parallel.sharded_sort_indices since the second half of round 6: range and splitter histogram from 1 tile in 16)
+            SHIFT = int(os.environ.get("SAMPLE_SHIFT", 4))
+            key_range = torch.zeros(4, dtype=torch.int64, device=dev)
+            _lib.check(lib.arx_sort_key_range_sampled(C.byref(span), 0, _lib.SORT_ASCENDING, SHIFT, key_range.data_ptr(), st))
             kr = key_range.cpu().tolist()
             window = _lib.ArxSortKeyWindow(0, 0, 0)
             stats = torch.zeros(4096, dtype=torch.int64, device=dev)
-            _lib.check(lib.arx_sort_key_histogram_window(C.byref(span), 0, _lib.SORT_ASCENDING, 12, C.byref(window), stats.data_ptr(), st))
+            _lib.check(lib.arx_sort_key_histogram_window_sampled(C.byref(span), 0, _lib.SORT_ASCENDING, 12, C.byref(window), SHIFT, stats.data_ptr(), st))
             cum = torch.cumsum(stats.cpu(), 0)
-            split = [min(int(torch.searchsorted(cum, torch.tensor(n * p // world, dtype=cum.dtype)).item()) + 1, 4096) for p in range(1, world)]
+            sampled_rows = int(cum[-1])
+            split = [min(int(torch.searchsorted(cum, torch.tensor(sampled_rows * p // world, dtype=cum.dtype)).item()) + 1, 4096) for p in range(1, world)]
             split_arr = (C.c_uint32 * len(split))(*split)
             mark()                                    # key range + histogram + splitters
             records = torch.empty(n * 12, dtype=torch.uint8, device=dev)

@@ -144,6 +144,11 @@ SORT_WORKER = textwrap.dedent(r'''
     array.set_default_device("cpu")
     rng = np.random.default_rng(77 + rank)
     n = 5000 + 700 * rank
+    if SAMPLE:      # round 6: key range and splitter histogram from a sample of the tiles (1 tile of 8192 rows in 2^SAMPLE)
+        parallel.SORT_SAMPLE_SHIFT, parallel.SORT_SAMPLE_MIN_ROWS = SAMPLE, 0
+        n = 40000 + 700 * rank
+    else:
+        parallel.SORT_SAMPLE_SHIFT = 0
     dt = np.int64 if SIGNED else np.uint64
     a = U.random_array(rng, dt, n, null_p=0.05 if NULLS else 0.0, offset=rank + 1)
     a.values[a.offset:a.offset + n:3] = (a.values[a.offset:a.offset + n:3] % 40).astype(dt)  # many ties across ranks
@@ -165,14 +170,17 @@ SORT_WORKER = textwrap.dedent(r'''
 ''')
 
 
-@pytest.mark.parametrize("signed,order,placement,window,nulls", [
-    (False, "ascending", "at_end", None, True), (True, "descending", "at_start", None, True), (False, "descending", "at_end", None, True),
-    (True, "ascending", "at_end", (1_700_000_000_000_000, 86_400_000_000), True),   # a day of microsecond timestamps
-    (True, "descending", "at_end", (-3000, 9000), True), (False, "ascending", "at_start", ((1 << 40) - 700, 1500), True),
-    (False, "ascending", "at_end", (12345, 1), True),
-    (False, "ascending", "at_end", None, False), (True, "descending", "at_start", None, False),
-    (True, "ascending", "at_end", (1_700_000_000_000_000, 86_400_000_000), False), (False, "descending", "at_end", (12345, 1), False)])
-def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement, window, nulls):
+@pytest.mark.parametrize("signed,order,placement,window,nulls,sample", [
+    (False, "ascending", "at_end", None, True, 0), (True, "descending", "at_start", None, True, 0), (False, "descending", "at_end", None, True, 0),
+    (True, "ascending", "at_end", (1_700_000_000_000_000, 86_400_000_000), True, 0),   # a day of microsecond timestamps
+    (True, "descending", "at_end", (-3000, 9000), True, 0), (False, "ascending", "at_start", ((1 << 40) - 700, 1500), True, 0),
+    (False, "ascending", "at_end", (12345, 1), True, 0),
+    (False, "ascending", "at_end", None, False, 0), (True, "descending", "at_start", None, False, 0),
+    (True, "ascending", "at_end", (1_700_000_000_000_000, 86_400_000_000), False, 0), (False, "descending", "at_end", (12345, 1), False, 0),
+    # sampled window + splitters (records form): full-range keys, a narrow window, and a sample asked for while a shard has nulls
+    (False, "ascending", "at_end", None, False, 1), (True, "descending", "at_start", (-3000, 9000), False, 2),
+    (True, "ascending", "at_end", (1_700_000_000_000_000, 86_400_000_000), True, 1)])
+def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement, window, nulls, sample):
     """One-exchange multi-rank sort_indices == the oracle's stable argsort of the concatenation; keys that share their
     top bits (window) must still be split between the ranks."""
     import pickle
@@ -183,7 +191,7 @@ def test_sharded_sort_indices_world2_gloo(tmp_path, signed, order, placement, wi
 
     out = str(tmp_path / "sort.pkl")
     code = (f"ROOT = {ROOT!r}\nOUT = {out!r}\nSIGNED = {signed!r}\nORDER = {order!r}\nPLACEMENT = {placement!r}\n"
-            f"WINDOW = {window!r}\nNULLS = {nulls!r}\n" + SORT_WORKER)
+            f"WINDOW = {window!r}\nNULLS = {nulls!r}\nSAMPLE = {sample!r}\n" + SORT_WORKER)
     port = 31500 + (os.getpid() % 2000)
     procs = []
     for rank in range(2):
