@@ -453,6 +453,13 @@ int arrow_amd_sharded_sort_indices(void* comm, struct ArrowDeviceArray* values, 
   }
   return 0;
 }
+// the sharded sort's records form (on / off), its sample (shift 0 .. 8, 0 = exact; the longest shard's row floor), how often it ran
+void arrow_amd_plugin_set_sharded_sort_records(int on) { g_sharded_sort_records.store(on != 0); }
+void arrow_amd_plugin_set_sharded_sort_sample(int shift, int64_t min_rows) {
+  g_sharded_sort_sample_shift.store(shift < 0 ? 0 : (shift > 8 ? 8 : shift));
+  g_sharded_sort_sample_min_rows.store(min_rows < 0 ? 0 : min_rows);
+}
+int64_t arrow_amd_plugin_sharded_sort_records_runs(void) { return g_sharded_sort_records_runs.load(); }
 void arrow_amd_plugin_pool_stats(int64_t* cached_bytes, int64_t* hits, int64_t* misses) {
   DevicePool::Get().Stats(cached_bytes, hits, misses);
 }

@@ -119,7 +119,14 @@ WORKER = textwrap.dedent(r'''
         "u64_all_null": pa.array([None] * 9, pa.uint64()),
     }
     sorts = {}
+    lib.arrow_amd_plugin_sharded_sort_records_runs.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_set_sharded_sort_sample.argtypes = [ctypes.c_int, ctypes.c_int64]
+    # round 6: the null-free input once more with the key window and the splitters from a SAMPLE (1 tile of 8192 rows in 4,
+    # forced at this size) — the records form either way; every other input keeps the exact form
+    sort_inputs["i64_no_nulls_sampled"] = sort_inputs["i64_no_nulls"]
     for name, arr in sort_inputs.items():
+        lib.arrow_amd_plugin_set_sharded_sort_sample(2 if name.endswith("_sampled") else 4, 0 if name.endswith("_sampled") else 1 << 20)
+        runs0 = lib.arrow_amd_plugin_sharded_sort_records_runs()
         for descending, nulls_first, bits in ((0, 0, 12), (1, 1, 5)):
             dv = to_device(arr)
             bufs = [ctypes.create_string_buffer(sz) for sz in (128, 72, 128, 72)]
@@ -134,6 +141,7 @@ WORKER = textwrap.dedent(r'''
             assert not idx.is_cpu and idx.type == pa.uint64()
             assert all(x >= 0 for x in stage_ms), list(stage_ms)
             sorts[(name, descending, nulls_first)] = (start.value, to_host(idx).to_pylist())
+        assert lib.arrow_amd_plugin_sharded_sort_records_runs() - runs0 == (2 if name.startswith("i64_no_nulls") else 0), name
     lib.arrow_amd_sharded_comm_destroy(comm)
     with open(OUT + f".rank{rank}", "wb") as f:
         pickle.dump(dict(keys=k.to_pylist(), values=v.to_pylist(), results=results, keys2=k2.to_pylist(), values2=v2.to_pylist(), results2=results2,
