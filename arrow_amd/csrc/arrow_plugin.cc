@@ -453,6 +453,13 @@ int arrow_amd_sharded_sort_indices(void* comm, struct ArrowDeviceArray* values, 
   }
   return 0;
 }
+// the sharded group-by's range-partitioned state (on / off; the row floor of a single rank), how often it ran / was declined together
+void arrow_amd_plugin_set_sharded_range_state(int on, int64_t min_rows) {
+  g_sharded_range_state.store(on != 0);
+  g_sharded_range_min_rows.store(min_rows < 0 ? 0 : min_rows);
+}
+int64_t arrow_amd_plugin_sharded_range_runs(void) { return g_sharded_range_runs.load(); }
+int64_t arrow_amd_plugin_sharded_range_declined(void) { return g_sharded_range_declined.load(); }
 // the sharded sort's records form (on / off), its sample (shift 0 .. 8, 0 = exact; the longest shard's row floor), how often it ran
 void arrow_amd_plugin_set_sharded_sort_records(int on) { g_sharded_sort_records.store(on != 0); }
 void arrow_amd_plugin_set_sharded_sort_sample(int shift, int64_t min_rows) {

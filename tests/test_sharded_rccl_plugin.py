@@ -91,6 +91,9 @@ WORKER = textwrap.dedent(r'''
         assert lib.arx_set_option(b"groupby_partition_min_rows", 0) == 0
         assert lib.arx_set_option(b"groupby_partition_bits", 2 + 3 * rank) == 0     # the ranks need not agree on a plan
     results2 = {}
+    lib.arrow_amd_plugin_set_sharded_range_state.argtypes = [ctypes.c_int, ctypes.c_int64]
+    lib.arrow_amd_plugin_sharded_range_runs.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_set_sharded_range_state(0, 1 << 22)      # (this block is about the records path: the range-partitioned state comes next)
     for skip_nulls, min_count in ((1, 1), (0, 3)):
         dk, dv = to_device(k2), to_device(v2)
         bufs = [ctypes.create_string_buffer(m) for m in (128, 72, 128, 72, 128, 72, 128, 72)]
@@ -107,6 +110,31 @@ WORKER = textwrap.dedent(r'''
     if n < (1 << 17):
         lib.arx_set_option(b"groupby_partition_min_rows", 1 << 17)
         lib.arx_set_option(b"groupby_partition_bits", -1)
+    # ---- round 6: the same null-free shards on the RANGE-PARTITIONED state (keys from a narrow range): the owner of a key is
+    # the owner of its slice of the key range, one exchange of dense blocks of known size, groups come back in key order
+    lib.arrow_amd_plugin_set_sharded_range_state(1, 0)
+    if n < (1 << 22):     # (sized for small shards: two scatter workgroups, small aggregate units)
+        assert lib.arx_set_option(b"groupby_lines_wgs", 2) == 0 and lib.arx_set_option(b"groupby_lines_unit_rows", 4096) == 0
+    runs0 = lib.arrow_amd_plugin_sharded_range_runs()
+    k3 = pa.array(rng.integers(-20 * KEY_RANGE, 20 * KEY_RANGE, n).astype(np.int32))      # (a range the state plans for: >= 3072 keys)
+    v3 = pa.array(rng.integers(-2**63, 2**63 - 1, n))
+    results3 = {}
+    for skip_nulls, min_count in ((1, 1), (0, 3)):
+        dk, dv = to_device(k3), to_device(v3)
+        bufs = [ctypes.create_string_buffer(m) for m in (128, 72, 128, 72, 128, 72, 128, 72)]
+        dk._export_to_c_device(ctypes.addressof(bufs[0]), ctypes.addressof(bufs[1]))
+        dv._export_to_c_device(ctypes.addressof(bufs[2]), ctypes.addressof(bufs[3]))
+        stage_ms = (ctypes.c_double * 5)()
+        rc = lib.arrow_amd_sharded_group_by_sum(comm, *[ctypes.addressof(b) for b in bufs[:4]], skip_nulls, min_count, 0,
+                                                *[ctypes.addressof(b) for b in bufs[4:]], stage_ms)
+        assert rc == 0, lib.arrow_amd_plugin_last_error()
+        gk = pa.Array._import_from_c_device(ctypes.addressof(bufs[4]), ctypes.addressof(bufs[5]))
+        gs = pa.Array._import_from_c_device(ctypes.addressof(bufs[6]), ctypes.addressof(bufs[7]))
+        got_keys = to_host(gk).to_pylist()
+        assert got_keys == sorted(got_keys), "the range-partitioned state's groups come back in key order"
+        results3[(0, skip_nulls, min_count)] = (got_keys, to_host(gs).to_pylist())
+    assert lib.arrow_amd_plugin_sharded_range_runs() - runs0 == 2, "the range-partitioned state did not run"
+    assert lib.arx_set_option(b"groupby_lines_wgs", 0) == 0 and lib.arx_set_option(b"groupby_lines_unit_rows", 1 << 21) == 0
     # ---- the sharded sort: this rank's slice of array_sort_indices of the concatenated shards
     lib.arrow_amd_sharded_sort_indices.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
@@ -144,7 +172,7 @@ WORKER = textwrap.dedent(r'''
         assert lib.arrow_amd_plugin_sharded_sort_records_runs() - runs0 == (2 if name.startswith("i64_no_nulls") else 0), name
     lib.arrow_amd_sharded_comm_destroy(comm)
     with open(OUT + f".rank{rank}", "wb") as f:
-        pickle.dump(dict(keys=k.to_pylist(), values=v.to_pylist(), results=results, keys2=k2.to_pylist(), values2=v2.to_pylist(), results2=results2,
+        pickle.dump(dict(keys=k.to_pylist(), values=v.to_pylist(), results=results, keys2=k2.to_pylist(), values2=v2.to_pylist(), results2=results2, keys3=k3.to_pylist(), values3=v3.to_pylist(), results3=results3,
                          sort_inputs={name: (str(a.type), a.to_pylist()) for name, a in sort_inputs.items()}, sorts=sorts), f)
 ''')
 
@@ -175,6 +203,7 @@ def _check(ranks, which=""):
 
     if which == "":
         _check(ranks, "2")      # the shards without nulls (the direct local pass)
+        _check(ranks, "3")      # ... and on the range-partitioned state (round 6)
     keys = pa.array([x for r in ranks for x in r["keys" + which]], pa.int32())
     vals = pa.array([x for r in ranks for x in r["values" + which]], pa.int64())
     t = pa.table({"k": keys, "v": vals})
