@@ -453,6 +453,9 @@ int arrow_amd_sharded_sort_indices(void* comm, struct ArrowDeviceArray* values, 
   }
   return 0;
 }
+// select_k_unstable by a threshold (no sort of the column): the row floor; how often it ran
+void arrow_amd_plugin_set_select_k_min_rows(int64_t rows) { g_select_k_min_rows.store(rows < 0 ? 0 : rows); }
+int64_t arrow_amd_plugin_select_k_threshold_runs(void) { return g_select_k_threshold_runs.load(); }
 // the sharded group-by's range-partitioned state (on / off; the row floor of a single rank), how often it ran / was declined together
 void arrow_amd_plugin_set_sharded_range_state(int on, int64_t min_rows) {
   g_sharded_range_state.store(on != 0);

@@ -3478,3 +3478,26 @@ def check_select_k_partition_nth(amd, rng_for, scale=1, light=False):
                         assert (lv[body[:at]] <= lv[body[at]]).all() and (lv[body[at:]] >= lv[body[at]]).all(), "partition property"
             with pytest.raises(amd.ArrowIndexError):
                 amd.compute.partition_nth_indices(d, n + 1)
+    # select_k by a THRESHOLD (no sort of the column): forced at these sizes; the result is index for index the head of the
+    # stable sort — full-range keys, keys from a narrow window (shared top bits), many ties, nulls at the end
+    saved = amd.compute.SELECT_K_MIN_ROWS
+    amd.compute.SELECT_K_MIN_ROWS = 0
+    try:
+        for dtype in (np.int64, np.uint64):
+            for lo, hi in ((None, None), (1_700_000_000_000, 1_700_000_900_000), (0, 50), (0, 2)):
+                n = (20_000 if light else 60_000 * scale)
+                rng = rng_for("selectk-threshold", np.dtype(dtype).name, lo)
+                arr = util.random_array(rng, dtype, n, null_p=0.1, offset=5, lo=lo, hi=hi)
+                d = arr.to_device(amd)
+                for order in ("ascending", "descending"):
+                    full = O.sort_indices(np.ascontiguousarray(arr.values), arr.valid_bitmap(), arr.offset, n,
+                                          descending=(order == "descending"), nulls_at_start=False)
+                    for k in (1, 37, n // 20):
+                        before = dict(amd.compute._SELECT_COUNTERS)
+                        got = _data_np(amd.compute.select_k_unstable(d, k, order, "at_end"), np.uint64)
+                        assert_equal(got, full[:k], f"select_k by threshold [{np.dtype(dtype).name},{lo},{order},k={k}]")
+                        took = {name: amd.compute._SELECT_COUNTERS[name] - before[name] for name in before}
+                        # (3 distinct keys: one bin holds more than a quarter of the rows — the sort is the better plan and is taken)
+                        assert took == ({"threshold": 0, "sorted": 1} if hi == 2 else {"threshold": 1, "sorted": 0}), (took, lo, hi, k)
+    finally:
+        amd.compute.SELECT_K_MIN_ROWS = saved

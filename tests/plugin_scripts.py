@@ -4365,6 +4365,26 @@ RANK_SELECT_SCRIPT = textwrap.dedent(r"""
                 assert len(idx) == min(k, n)
                 want = pc.array_sort_indices(cols[name], order=o, null_placement=p).slice(0, min(k, n))
                 same_values(values_at(cols[name], idx), values_at(cols[name], want))
+    # select_k by a THRESHOLD (round 6): no sort of the column — histogram, one comparison, the candidates' sort; index for
+    # index the head of the stable sort (forced at this size; a key with few distinct values takes the sort instead)
+    lib.arrow_amd_plugin_set_select_k_min_rows.argtypes = [ctypes.c_int64]
+    lib.arrow_amd_plugin_select_k_threshold_runs.restype = ctypes.c_int64
+    lib.arrow_amd_plugin_set_select_k_min_rows(0)
+    wide = pa.array(rng.integers(-2**62, 2**62, n), mask=rng.random(n) < 0.1)
+    dwide = to_device(wide)
+    for arr, darr, name in ((wide, dwide, "wide"), (cols["ts"], dev["ts"], "ts")):
+        for o in ("ascending", "descending"):
+            for k in (1, 50, n // 20):
+                t0 = lib.arrow_amd_plugin_select_k_threshold_runs()
+                got = to_host(select_k(darr, k, [("x", o)]))
+                want = pc.array_sort_indices(arr, order=o).slice(0, k)
+                assert got.equals(want), (name, o, k)
+                assert lib.arrow_amd_plugin_select_k_threshold_runs() - t0 == 1, (name, o, k)
+    t0 = lib.arrow_amd_plugin_select_k_threshold_runs()
+    few = pa.array(rng.integers(0, 3, n))
+    assert to_host(select_k(to_device(few), 5, [("x", "ascending")])).equals(pc.array_sort_indices(few).slice(0, 5))
+    assert lib.arrow_amd_plugin_select_k_threshold_runs() == t0
+    lib.arrow_amd_plugin_set_select_k_min_rows(1 << 22)
     # a device-resident table with two keys
     tdev = pa.table({"a": dev["i64"], "b": dev["u32"]})
     thost = pa.table({"a": cols["i64"], "b": cols["u32"]})
