@@ -141,6 +141,10 @@ SIGNATURES = {
     "arx_rle_decode_equals_bitmap": (_int, [_p, _sz, _p, _i64, _int, _i64, _u32, _p, _p]),
     "arx_expand_by_mask": (_int, [_p, _int, _span, _p, _p, _p]),
     "arx_rle_levels_to_bitmap": (_int, [_p, _p, _i64, _p, _p, _p, _p]),
+    "arx_rle_scan_runs_equals": (_int, [_p, _sz, _int, _i64, _u32, _u32, _u64, _p, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "arx_levels_to_list_workspace_bytes": (_sz, [_i64]),
+    "arx_def_rep_levels_to_list": (_int, [_p, _p, _i64, _int, _int, _int, _i64, _p, _p, _p, _p, _sz, _p]),
+    "arx_levels_ge_bitmap": (_int, [_p, _i64, _u32, _p, _p, _p]),
     "arx_lz4_decompress_streams": (_int, [_p, _p, _p, _i64, _p, _p, _p]),
     "arx_lz4_frame_scan": (_int, [_p, _sz, _u64, _p, _i64, C.POINTER(_i64), C.POINTER(_u64)]),
     "arx_cast_f64_f32": (_int, [_p, _i64, _p, _p]),

@@ -171,6 +171,45 @@ def unpack_validity(bitmap: np.ndarray, offset: int, length: int) -> np.ndarray:
     return bits[offset: offset + length].astype(bool)
 
 
+class ListArray:
+    """arrow::ListArray twin on the device: buffers = [validity or None, int32 offsets (length + 1)], one child (an Array
+    or another ListArray).  `type` is the pyarrow list type (it names the item field).  What the Parquet reader hands
+    back for repeated columns."""
+
+    def __init__(self, pa_type, length: int, buffers, child, null_count: int = 0, offset: int = 0):
+        self.type = pa_type
+        self.length = int(length)
+        self.buffers = list(buffers)
+        self.child = child
+        self.null_count = int(null_count)
+        self.offset = int(offset)
+
+    @property
+    def device(self) -> torch.device:
+        return self.buffers[1].device
+
+    def __len__(self):
+        return self.length
+
+    def to_pyarrow(self):
+        import pyarrow as pa
+
+        offs = self.buffers[1].cpu().numpy().view(np.int32)[: self.offset + self.length + 1]
+        vb = None
+        if self.buffers[0] is not None:
+            vb = pa.py_buffer(self.buffers[0].cpu().numpy()[: (self.offset + self.length + 7) // 8].tobytes())
+        child = self.child.to_pyarrow()
+        want = self.type.value_field.type
+        if child.type != want:
+            child = child.cast(want)
+        return pa.Array.from_buffers(self.type, self.length, [vb, pa.py_buffer(offs.tobytes())],
+                                     null_count=self.null_count if vb is not None else 0, offset=self.offset,
+                                     children=[child])
+
+    def to_pylist(self):
+        return self.to_pyarrow().to_pylist()
+
+
 def _ptr(t: torch.Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 

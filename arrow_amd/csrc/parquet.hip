@@ -893,6 +893,122 @@ __global__ __launch_bounds__(64) void dba_expand_kernel(const int32_t* __restric
   }
 }
 
+// ---------------------------------------------------------------------------
+// Repeated columns: DefRepLevelsToList (cpp/src/parquet/level_conversion.cc:40-124) and DefLevelsToBitmap over the
+// decoded level arrays.  The reference walks the levels once, one at a time; here every level slot classifies itself —
+//   kept   = def >= repeated_ancestor_def_level && rep <= rep_level     (level_conversion.cc:52-55)
+//   start  = kept && rep <  rep_level   (a new list entry: one offset, one validity bit)
+//   elem   = kept && (rep == rep_level || def >= def_level)   (the entry's offset grows by one, :57-66 and :86-92)
+// — and two running counts (starts, elems) carried by a tile scan give entry j its offset (the elems before its
+// start slot) and its bit (def >= def_level - 1, :98-106).  Starts in the high and elems in the low half of one
+// 64-bit word: one scan for both (both are below 2^31 by the entry check).
+constexpr int kListTile = 4096;
+
+struct ListLevels {
+  const uint32_t* def;
+  const uint32_t* rep;
+  uint32_t def_level, rep_level, ancestor;
+  __device__ __forceinline__ unsigned long long at(int64_t i, uint32_t* d_out) const {
+    const uint32_t d = def[i];
+    const uint32_t r = rep != nullptr ? rep[i] : 0u;
+    *d_out = d;
+    if (d < ancestor || r > rep_level) return 0ull;
+    if (r == rep_level) return 1ull;                               // a continuation of the current list
+    return (1ull << 32) | (d >= def_level ? 1ull : 0ull);           // a start (with or without a first element)
+  }
+};
+
+__global__ __launch_bounds__(kBlock) void list_tile_sums_kernel(ListLevels lv, int64_t n, long long* __restrict__ tile_sums) {
+  __shared__ long long wave_sum[kWavesPerBlock];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kListTile;
+  unsigned long long acc = 0;
+  for (int k = threadIdx.x; k < kListTile; k += kBlock) {
+    const int64_t i = base + k;
+    uint32_t d;
+    if (i < n) acc += lv.at(i, &d);
+  }
+  acc = wave_reduce_sum_u64(acc);
+  if (lane_id() == 0) wave_sum[threadIdx.x >> 6] = static_cast<long long>(acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) t += static_cast<unsigned long long>(wave_sum[w]);
+    tile_sums[blockIdx.x] = static_cast<long long>(t);
+  }
+}
+
+// counts (device): [0] entries, [1] elements, [2] null entries, [3] 1 if more than max_entries entries
+__global__ __launch_bounds__(kBlock) void list_write_kernel(ListLevels lv, int64_t n, const long long* __restrict__ tile_carry,
+                                                            int64_t max_entries, int32_t* __restrict__ offsets,
+                                                            uint32_t* __restrict__ valid_bits,
+                                                            unsigned long long* __restrict__ counts) {
+  __shared__ long long wave_tot[kWavesPerBlock];
+  __shared__ long long carry_s;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kListTile;
+  if (threadIdx.x == 0) carry_s = tile_carry[blockIdx.x];
+  __syncthreads();
+  uint32_t nulls = 0;
+  for (int k0 = 0; k0 < kListTile; k0 += kBlock) {      // block-uniform trip count
+    const int64_t i = base + k0 + threadIdx.x;
+    uint32_t d = 0;
+    const unsigned long long v = i < n ? lv.at(i, &d) : 0ull;
+    const unsigned long long x = wave_inclusive_scan_u64(v);
+    if (lane == 63) wave_tot[wave] = static_cast<long long>(x);
+    __syncthreads();
+    unsigned long long pre = 0;
+    for (int w = 0; w < wave; ++w) pre += static_cast<unsigned long long>(wave_tot[w]);
+    const unsigned long long carry = static_cast<unsigned long long>(carry_s);
+    const unsigned long long excl = carry + pre + x - v;
+    if (v >> 32) {
+      const int64_t j = static_cast<int64_t>(excl >> 32);
+      if (j < max_entries) {
+        offsets[j] = static_cast<int32_t>(excl & 0xFFFFFFFFull);
+        if (valid_bits != nullptr) {
+          if (d + 1 >= lv.def_level) atomicOr(&valid_bits[j >> 5], 1u << (j & 31));
+          else ++nulls;
+        }
+      }
+    }
+    if (i == n - 1) {
+      const unsigned long long tot = excl + v;
+      const int64_t entries = static_cast<int64_t>(tot >> 32);
+      counts[0] = static_cast<unsigned long long>(entries);
+      counts[1] = tot & 0xFFFFFFFFull;
+      if (entries > max_entries) counts[3] = 1;
+      else offsets[entries] = static_cast<int32_t>(tot & 0xFFFFFFFFull);
+    }
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) carry_s = static_cast<long long>(carry + pre + x);
+    __syncthreads();
+  }
+  nulls = wave_reduce_sum_u32(nulls);
+  if (lane == 0 && nulls != 0) atomicAdd(&counts[2], static_cast<unsigned long long>(nulls));
+}
+
+// bit i = levels[i] >= threshold (every slot keeps its place: DefLevelsToBitmap for a column without a repeated
+// ancestor, level_conversion_inc.h, and the "slot exists" mask of one with); ones (device, may be NULL) += set bits
+__global__ __launch_bounds__(kBlock) void levels_ge_bitmap_kernel(const uint32_t* __restrict__ levels, int64_t n, uint32_t threshold,
+                                                                  uint64_t* __restrict__ out_bits,
+                                                                  unsigned long long* __restrict__ ones) {
+  const int lane = lane_id();
+  const int64_t nwords = (n + 63) >> 6;
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  unsigned long long local = 0;
+  for (int64_t w = wave0; w < nwords; w += stride) {
+    const int64_t i = w * 64 + lane;
+    const bool bit = i < n && levels[i] >= threshold;
+    const uint64_t word = __ballot(bit);
+    if (lane == 0) {
+      out_bits[w] = word;
+      local += static_cast<unsigned long long>(__popcll(word));
+    }
+  }
+  if (ones != nullptr && lane == 0 && local != 0) atomicAdd(ones, local);
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -900,8 +1016,10 @@ using namespace arx;
 extern "C" {
 
 // Host-side walk over the run headers (no device work): the only sequential part of the hybrid.
-int arx_rle_scan_runs(const void* data, size_t nbytes, int bit_width, int64_t num_values, uint32_t out_base,
-                      uint64_t byte_base, ArxRleRun* runs, int64_t max_runs, int64_t* num_runs, int64_t* ones) {
+// `equals`: the value *ones counts (bit width 1: popcounts of the literal bytes; wider levels: value by value)
+static int rle_scan_runs_impl(const void* data, size_t nbytes, int bit_width, int64_t num_values, uint32_t out_base,
+                              uint64_t byte_base, ArxRleRun* runs, int64_t max_runs, int64_t* num_runs, int64_t* ones,
+                              uint32_t equals) {
   if (num_values < 0 || bit_width < 0 || bit_width > 32 || num_runs == nullptr || (num_values > 0 && data == nullptr)) {
     set_error("bad arguments to arx_rle_scan_runs");
     return ARX_INVALID;
@@ -946,12 +1064,24 @@ int arx_rle_scan_runs(const void* data, size_t nbytes, int bit_width, int64_t nu
         return ARX_INVALID;
       }
       if (runs != nullptr) runs[nr] = ArxRleRun{static_cast<uint32_t>(out_base + done), 1u, byte_base + pos};
-      if (ones != nullptr && bit_width == 1) {
+      if (ones != nullptr && bit_width == 1 && equals == 1) {
         const int64_t take = std::min<int64_t>(count, num_values - done);
         for (int64_t b = 0; b < take; b += 8) {
           uint8_t byte = (pos + (b >> 3)) < nbytes ? p[pos + (b >> 3)] : 0;
           if (take - b < 8) byte &= static_cast<uint8_t>((1u << (take - b)) - 1u);
           count_ones += __builtin_popcount(byte);
+        }
+      } else if (ones != nullptr && bit_width >= 1 && bit_width <= 16) {
+        const int64_t take = std::min<int64_t>(count, num_values - done);
+        const uint32_t vmask = (1u << bit_width) - 1u;
+        for (int64_t k = 0; k < take; ++k) {
+          const uint64_t bit = static_cast<uint64_t>(k) * bit_width;
+          uint32_t acc = 0;
+          for (int b = 0; b < 3; ++b) {   // (bit & 7) + 16 bits <= 3 bytes
+            const size_t at = pos + (bit >> 3) + b;
+            acc |= static_cast<uint32_t>(at < nbytes ? p[at] : 0) << (8 * b);
+          }
+          if (((acc >> (bit & 7)) & vmask) == equals) ++count_ones;
         }
       }
       pos += lbytes;
@@ -966,13 +1096,88 @@ int arx_rle_scan_runs(const void* data, size_t nbytes, int bit_width, int64_t nu
       for (int k = 0; k < vbytes; ++k) value |= static_cast<uint64_t>(p[pos + k]) << (8 * k);
       pos += vbytes;
       if (runs != nullptr) runs[nr] = ArxRleRun{static_cast<uint32_t>(out_base + done), 0u, value};
-      if (ones != nullptr && bit_width == 1 && value == 1) count_ones += std::min<int64_t>(count, num_values - done);
+      if (ones != nullptr && bit_width <= 16 && value == equals) count_ones += std::min<int64_t>(count, num_values - done);
       done += count;
     }
     ++nr;
   }
   *num_runs = nr;
   if (ones != nullptr) *ones = count_ones;
+  return ARX_OK;
+}
+
+int arx_rle_scan_runs(const void* data, size_t nbytes, int bit_width, int64_t num_values, uint32_t out_base,
+                      uint64_t byte_base, ArxRleRun* runs, int64_t max_runs, int64_t* num_runs, int64_t* ones) {
+  if (bit_width != 1 && ones != nullptr) *ones = 0;
+  return rle_scan_runs_impl(data, nbytes, bit_width, num_values, out_base, byte_base, runs, max_runs, num_runs,
+                            bit_width == 1 ? ones : nullptr, 1u);
+}
+
+int arx_rle_scan_runs_equals(const void* data, size_t nbytes, int bit_width, int64_t num_values, uint32_t equals,
+                             uint32_t out_base, uint64_t byte_base, ArxRleRun* runs, int64_t max_runs, int64_t* num_runs,
+                             int64_t* count) {
+  if (bit_width > 16 && count != nullptr) {
+    set_error("arx_rle_scan_runs_equals counts levels of at most 16 bits");
+    return ARX_INVALID;
+  }
+  if (bit_width == 0 && count != nullptr) {   // a block of zero-width values: every value is 0
+    const int rc = rle_scan_runs_impl(data, nbytes, bit_width, num_values, out_base, byte_base, runs, max_runs, num_runs,
+                                      nullptr, 0u);
+    if (rc == ARX_OK) *count = equals == 0 ? num_values : 0;
+    return rc;
+  }
+  return rle_scan_runs_impl(data, nbytes, bit_width, num_values, out_base, byte_base, runs, max_runs, num_runs, count,
+                            equals);
+}
+
+size_t arx_levels_to_list_workspace_bytes(int64_t num_levels) {
+  return static_cast<size_t>(ceil_div(std::max<int64_t>(num_levels, 1), kListTile)) * sizeof(long long) + 64;
+}
+
+int arx_def_rep_levels_to_list(const uint32_t* def_levels, const uint32_t* rep_levels, int64_t num_levels, int def_level,
+                               int rep_level, int repeated_ancestor_def_level, int64_t max_entries, int32_t* offsets,
+                               void* valid_bits, uint64_t* counts, void* ws, size_t ws_bytes, void* stream) {
+  if (num_levels < 0 || num_levels > INT32_MAX || max_entries < 0 || offsets == nullptr || counts == nullptr ||
+      def_level < 1 || rep_level < 0 || repeated_ancestor_def_level < 0 || (num_levels > 0 && def_levels == nullptr) ||
+      (rep_level > 0 && num_levels > 0 && rep_levels == nullptr)) {
+    set_error("bad arguments to arx_def_rep_levels_to_list");
+    return ARX_INVALID;
+  }
+  hipStream_t st = as_stream(stream);
+  ARX_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(uint64_t), st));
+  ARX_HIP(hipMemsetAsync(offsets, 0, sizeof(int32_t), st));          // offsets[0] (and the whole answer for no level)
+  if (num_levels == 0) return ARX_OK;
+  const int64_t ntiles = ceil_div(num_levels, kListTile);
+  if (ws == nullptr || ws_bytes < static_cast<size_t>(ntiles) * sizeof(long long)) {
+    set_error("arx_def_rep_levels_to_list: workspace too small");
+    return ARX_INVALID;
+  }
+  long long* sums = static_cast<long long*>(ws);
+  const ListLevels lv{def_levels, rep_levels, static_cast<uint32_t>(def_level), static_cast<uint32_t>(rep_level),
+                      static_cast<uint32_t>(repeated_ancestor_def_level)};
+  hipLaunchKernelGGL(list_tile_sums_kernel, dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, lv, num_levels, sums);
+  ARX_CHECK_LAUNCH("list_tile_sums_kernel");
+  hipLaunchKernelGGL(delta_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, sums, ntiles);
+  ARX_CHECK_LAUNCH("delta_scan_tiles_kernel");
+  hipLaunchKernelGGL(list_write_kernel, dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, st, lv, num_levels,
+                     static_cast<const long long*>(sums), max_entries, offsets, static_cast<uint32_t*>(valid_bits),
+                     reinterpret_cast<unsigned long long*>(counts));
+  ARX_CHECK_LAUNCH("list_write_kernel");
+  return ARX_OK;
+}
+
+int arx_levels_ge_bitmap(const uint32_t* levels, int64_t num_levels, uint32_t threshold, void* out_bits, uint64_t* ones,
+                         void* stream) {
+  if (num_levels < 0 || (num_levels > 0 && (levels == nullptr || out_bits == nullptr))) {
+    set_error("bad arguments to arx_levels_ge_bitmap");
+    return ARX_INVALID;
+  }
+  if (num_levels == 0) return ARX_OK;
+  const int64_t nwords = ceil_div(num_levels, 64);
+  const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(nwords, kWavesPerBlock), 256 * 16)));
+  hipLaunchKernelGGL(levels_ge_bitmap_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), levels, num_levels, threshold,
+                     static_cast<uint64_t*>(out_bits), reinterpret_cast<unsigned long long*>(ones));
+  ARX_CHECK_LAUNCH("levels_ge_bitmap_kernel");
   return ARX_OK;
 }
 

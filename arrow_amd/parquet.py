@@ -274,17 +274,26 @@ def decode_delta_byte_array(pages, atype=None, device=None) -> Array:
     return Array(atype or binary, n, [None, offs.view(torch.uint8), data], 0, 0)
 
 
-def scan_rle_runs(data, bit_width: int, num_values: int, out_base: int = 0, byte_base: int = 0):
+def scan_rle_runs(data, bit_width: int, num_values: int, out_base: int = 0, byte_base: int = 0, equals: int | None = None):
     """Walks the run headers of an RLE / bit-packed hybrid block (rle_encoding_internal.h:40-90) until
     `num_values` values are covered — the host function arx_rle_scan_runs of the library (the walk is
     sequential and touches a few bytes per run).  Returns (runs, ones): a RUN_DTYPE array whose
     out_start / payload are shifted by out_base / byte_base (so the pages of a chunk share one table)
-    and, for bit_width == 1, the number of values equal to 1 (the non-null count of a level block)."""
+    and, for bit_width == 1, the number of values equal to 1 (the non-null count of a level block).  `equals`
+    (levels of a nested column, any width up to 16 bits): count the values equal to it instead
+    (arx_rle_scan_runs_equals)."""
     lib = _lib.get_lib()
     buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
     nbytes = len(buf)
     ptr = buf.ctypes.data if nbytes else None
     nr, ones = C.c_int64(0), C.c_int64(0)
+    if equals is not None:
+        check(lib.arx_rle_scan_runs_equals(ptr, nbytes, bit_width, num_values, equals, out_base, byte_base, None, 0,
+                                           C.byref(nr), C.byref(ones)))
+        runs = np.zeros(max(nr.value, 1), dtype=RUN_DTYPE)
+        check(lib.arx_rle_scan_runs_equals(ptr, nbytes, bit_width, num_values, equals, out_base, byte_base,
+                                           runs.ctypes.data, nr.value, C.byref(nr), None))
+        return runs[: nr.value], ones.value
     check(lib.arx_rle_scan_runs(ptr, nbytes, bit_width, num_values, out_base, byte_base, None, 0,
                                 C.byref(nr), C.byref(ones)))                      # pass 1: count
     runs = np.zeros(max(nr.value, 1), dtype=RUN_DTYPE)
@@ -351,9 +360,13 @@ def _parse_byte_array_dictionary(page: bytes, count: int):
 
 
 def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | None = None,
-                      binary_type=None) -> Array:
+                      binary_type=None, nested: dict | None = None) -> Array:
     """Decodes one column chunk (all its pages) into a device Array.  `stats` (optional) accumulates
-    host_prep_s: seconds spent on the host before the first device call (headers, decompression, run walk)."""
+    host_prep_s: seconds spent on the host before the first device call (headers, decompression, run walk).
+    `nested` (a repeated column; {"max_rep": its maximum repetition level}): the Array that comes back has one slot per
+    LEVEL (valid where def == max_def_level: the values spread over all level slots), and the dict receives the level
+    blocks and run tables of the chunk ("def_bytes", "def_runs", "rep_bytes", "rep_runs", "levels") for
+    assemble_list_column."""
     import time
 
     t_start = time.perf_counter()
@@ -362,8 +375,12 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     is_bool = col.physical_type == "BOOLEAN"
     if col.physical_type not in _PHYSICAL and not is_binary and not is_bool:
         raise ArrowNotImplementedError(f"Parquet physical type {col.physical_type} is not on the gfx950 path")
-    if max_def_level > 1:
+    if max_def_level > 1 and nested is None:
         raise ArrowNotImplementedError("Parquet: nested / repeated columns are not on the gfx950 path")
+    max_rep_level = nested["max_rep"] if nested is not None else 0
+    def_bw, rep_bw = max(1, int(max_def_level).bit_length()), int(max_rep_level).bit_length()
+    def_equals = max_def_level if nested is not None else None     # (flat columns keep the bit-width-1 popcount walk)
+    rep_bytes, rep_runs = bytearray(), []
     if is_binary:
         atype, width = binary_type, 1          # values live in the dictionary; data pages carry indices only
     elif is_bool:
@@ -399,7 +416,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
             dh = hdr[5]
             nvals, enc = dh[1], dh[2]
             on_device = (DEVICE_SNAPPY and codec == "SNAPPY" and enc == _ENC_PLAIN and max_def_level == 0 and
-                         not is_binary and not is_bool and hdr[2] == nvals * width)
+                         max_rep_level == 0 and not is_binary and not is_bool and hdr[2] == nvals * width)
             if on_device:
                 device_snappy_pages.append((bytes(payload), hdr[2], plain_pos))
                 plain_pos += hdr[2]                   # (the device writes these bytes: nothing is staged for them)
@@ -408,46 +425,60 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
                 continue
             page = _decompress(codec, payload, hdr[2])
             pos = 0
+            if max_rep_level > 0:                                  # repetition levels come first (column_reader.cc:784-)
+                if dh[4] != _ENC_RLE:
+                    raise ArrowNotImplementedError("Parquet: BIT_PACKED repetition levels")
+                (nbytes,) = struct.unpack_from("<i", page, 0)
+                rlevels = page[4: 4 + nbytes]
+                pos = 4 + nbytes
             if max_def_level > 0:
                 if dh[3] != _ENC_RLE:
                     raise ArrowNotImplementedError("Parquet: BIT_PACKED definition levels")
-                (nbytes,) = struct.unpack_from("<i", page, 0)      # LevelDecoder::SetData, column_reader.cc:139
-                levels = page[4: 4 + nbytes]
-                pos = 4 + nbytes
+                (nbytes,) = struct.unpack_from("<i", page, pos)    # LevelDecoder::SetData, column_reader.cc:139
+                levels = page[pos + 4: pos + 4 + nbytes]
+                pos += 4 + nbytes
         elif ptype == _PAGE_DATA_V2:
             dh = hdr[8]
             nvals, enc = dh[1], dh[4]
             dl, rl = dh.get(5, 0), dh.get(6, 0)
-            if rl:
+            if rl and max_rep_level == 0:
                 raise ArrowNotImplementedError("Parquet: repetition levels")
-            levels = bytes(payload[:dl])                              # V2 levels are never compressed
-            body = payload[dl:]
+            rlevels = bytes(payload[:rl])                             # V2 levels are never compressed: repetition,
+            levels = bytes(payload[rl: rl + dl])                      # then definition levels, then the values
+            body = payload[rl + dl:]
             on_device = (DEVICE_SNAPPY and codec == "SNAPPY" and dh.get(7, True) and enc == _ENC_PLAIN and
                          not is_binary and not is_bool)
             if on_device:
                 valid_here = nvals
                 if max_def_level > 0:
-                    runs, ones = scan_rle_runs(levels, 1, nvals, out_base=rows, byte_base=len(level_bytes))
+                    runs, ones = scan_rle_runs(levels, def_bw, nvals, out_base=rows, byte_base=len(level_bytes),
+                                               equals=def_equals)
                     valid_here = ones
-                if hdr[2] - dl == valid_here * width:
+                if hdr[2] - dl - rl == valid_here * width:
                     if max_def_level > 0:
                         level_runs.append(runs)
                         level_bytes += levels
-                    device_snappy_pages.append((bytes(body), hdr[2] - dl, plain_pos))
-                    plain_pos += hdr[2] - dl
+                    if max_rep_level > 0:
+                        rep_runs.append(scan_rle_runs(rlevels, rep_bw, nvals, out_base=rows, byte_base=len(rep_bytes))[0])
+                        rep_bytes += rlevels
+                    device_snappy_pages.append((bytes(body), hdr[2] - dl - rl, plain_pos))
+                    plain_pos += hdr[2] - dl - rl
                     rows += nvals
                     dense += valid_here
                     continue
-            page = _decompress(codec, body, hdr[2] - dl) if dh.get(7, True) else bytes(body)
+            page = _decompress(codec, body, hdr[2] - dl - rl) if dh.get(7, True) else bytes(body)
             pos = 0
         else:
             continue                                                  # index pages etc.
         valid_here = nvals
         if max_def_level > 0:
-            runs, ones = scan_rle_runs(levels, 1, nvals, out_base=rows, byte_base=len(level_bytes))
+            runs, ones = scan_rle_runs(levels, def_bw, nvals, out_base=rows, byte_base=len(level_bytes), equals=def_equals)
             level_runs.append(runs)
             level_bytes += levels
             valid_here = ones
+        if max_rep_level > 0:
+            rep_runs.append(scan_rle_runs(rlevels, rep_bw, nvals, out_base=rows, byte_base=len(rep_bytes))[0])
+            rep_bytes += rlevels
         values = page[pos:]
         if enc in (_ENC_PLAIN_DICT, _ENC_RLE_DICT):
             if plain_pos or plain_pages:
@@ -500,6 +531,9 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
         rows += nvals
         dense += valid_here
 
+    if nested is not None:
+        nested.update(def_bytes=bytes(level_bytes), def_runs=list(level_runs), rep_bytes=bytes(rep_bytes),
+                      rep_runs=rep_runs, levels=rows, def_bw=def_bw, rep_bw=rep_bw)
     if stats is not None:
         stats["host_prep_s"] = stats.get("host_prep_s", 0.0) + (time.perf_counter() - t_start)
         stats["encoded_bytes"] = stats.get("encoded_bytes", 0) + len(level_bytes) + len(index_bytes) + sum(len(b) for _, b in plain_segments) + len(dict_bytes or b"")
@@ -602,8 +636,9 @@ def _validity_and_ws(lib, stream, device, level_bytes, level_runs, rows, dense, 
     d_lbytes = to_device(np.frombuffer(bytes(level_bytes) or b"\0", dtype=np.uint8), device)
     d_lruns = _device_runs(runs, device)
     validity = alloc(bitmap_nbytes(rows), device, zero=True)
-    check(lib.arx_rle_decode_equals_bitmap(d_lbytes.data_ptr(), len(level_bytes), d_lruns.data_ptr(), len(runs), 1,
-                                           rows, max_def_level, validity.data_ptr(), stream))
+    check(lib.arx_rle_decode_equals_bitmap(d_lbytes.data_ptr(), len(level_bytes), d_lruns.data_ptr(), len(runs),
+                                           max(1, int(max_def_level).bit_length()), rows, max_def_level,
+                                           validity.data_ptr(), stream))
     mask = _lib.ArxSpan(None, validity.data_ptr(), 0, rows, 0)
     ws = alloc(lib.arx_filter_workspace_bytes(rows) + 64, device)
     cnt = C.c_int64(0)
@@ -736,6 +771,88 @@ def _finish_binary_chunk(lib, stream, device, atype, dict_bytes, dict_count, ind
     return cp.take(dvals, didx, boundscheck=True)
 
 
+def list_level_infos(field):
+    """LevelInfo of every list level and of the leaf of a chain list<list<...<primitive>>> (the 3-level LIST encoding) —
+    what the reference's schema walk computes (cpp/src/parquet/arrow/schema.cc ListToSchemaField, LevelInfo::Increment /
+    IncrementRepeated, level_conversion.h:31-135).  Returns ([(def_level, rep_level, repeated_ancestor_def_level) per list
+    level, outermost first], the leaf's triple, the leaf's pyarrow type)."""
+    import pyarrow as pa
+
+    d = r = anc = 0
+    lists = []
+    t, nullable = field.type, field.nullable
+    while pa.types.is_list(t):
+        if nullable:
+            d += 1                      # the optional group that carries the LIST annotation
+        d += 1                          # the repeated group: IncrementRepeated returns the ancestor level so far ...
+        r += 1
+        lists.append((d, r, anc))
+        anc = d                         # ... and every descendant's repeated ancestor is this list
+        t, nullable = t.value_field.type, t.value_field.nullable
+    if pa.types.is_nested(t) or pa.types.is_large_list(t) or pa.types.is_fixed_size_list(t):
+        raise ArrowNotImplementedError(f"Parquet: {field.type} columns are not on the gfx950 path (lists of primitives are)")
+    if nullable:
+        d += 1
+    return lists, (d, r, anc), t
+
+
+def assemble_list_column(leaf: Array, nested: dict, field, num_rows: int, device=None):
+    """A list column from its leaf values and levels: DefRepLevelsToList per list level (outermost first; the entries of a
+    level are the elements of the one above), the leaf's slots = the level slots whose def level reaches its repeated
+    ancestor (a DROP filter of the values spread over all level slots).  The reference: parquet/arrow/reader.cc
+    ListReader::BuildArray over level_conversion.cc:40-146."""
+    from . import compute as cp
+    from .array import ListArray, bool_
+
+    device = torch.device(device) if device is not None else default_device()
+    lib, stream = _lib.get_lib(), current_stream(device)
+    lists, (leaf_def, _leaf_rep, leaf_anc), _ = list_level_infos(field)
+    n = nested["levels"]
+
+    def decode(level_bytes, runs_list, bw):
+        out = alloc(max(n, 1) * 4, device)
+        if n == 0 or bw == 0:
+            out.zero_()
+            return out
+        runs = np.concatenate(runs_list)
+        d_bytes = to_device(np.frombuffer(level_bytes or b"\0", dtype=np.uint8), device)
+        d_runs = _device_runs(runs, device)
+        check(lib.arx_rle_decode_u32(d_bytes.data_ptr(), len(level_bytes), d_runs.data_ptr(), len(runs), bw, n,
+                                     out.data_ptr(), stream))
+        return out
+
+    d_def = decode(nested["def_bytes"], nested["def_runs"], nested["def_bw"])
+    d_rep = decode(nested["rep_bytes"], nested["rep_runs"], nested["rep_bw"])
+    ws = alloc(lib.arx_levels_to_list_workspace_bytes(n), device)
+    counts = torch.zeros(4, dtype=torch.int64, device=device)
+    levels_out = []
+    entries = num_rows
+    for (dl, rl, anc) in lists:
+        offsets = alloc((entries + 1) * 4, device)
+        valid = alloc(bitmap_nbytes(max(entries, 1)), device, zero=True)
+        check(lib.arx_def_rep_levels_to_list(d_def.data_ptr(), d_rep.data_ptr(), n, dl, rl, anc, entries, offsets.data_ptr(),
+                                             valid.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        got, elems, nulls, over = (int(x) for x in counts.cpu().tolist())
+        if over or got != entries:
+            raise ArrowInvalid(f"Parquet: the levels hold {got} list entries where {entries} are expected (corrupt page?)")
+        levels_out.append((entries, offsets, valid if nulls else None, nulls))
+        entries = elems
+    # the leaf: keep the level slots that exist below the innermost list
+    keep = alloc(bitmap_nbytes(max(n, 1)), device, zero=True)
+    check(lib.arx_levels_ge_bitmap(d_def.data_ptr(), n, leaf_anc, keep.data_ptr(), None, stream))
+    child = cp.filter(leaf, Array(bool_, n, [None, keep], 0, 0))
+    if child.length != entries:
+        raise ArrowInvalid(f"Parquet: {child.length} leaf slots for {entries} list elements (corrupt page?)")
+    ftype = field.type
+    types = []
+    while len(types) < len(lists):
+        types.append(ftype)
+        ftype = ftype.value_field.type
+    for (length, offsets, valid, nulls), pa_type in zip(reversed(levels_out), reversed(types)):
+        child = ListArray(pa_type, length, [valid, offsets], child, nulls)
+    return child
+
+
 def _lib_uint32():
     from .array import uint32
 
@@ -756,13 +873,27 @@ def read_table(path: str, columns=None, device=None, stats: dict | None = None) 
     for name in wanted:
         ci = names.index(name)
         max_def = md.schema.column(ci).max_definition_level
-        if md.schema.column(ci).max_repetition_level:
-            raise ArrowNotImplementedError("Parquet: repeated columns are not on the gfx950 path")
+        max_rep = md.schema.column(ci).max_repetition_level
         binary_type = None
         if md.schema.column(ci).physical_type == "BYTE_ARRAY":
             from .array import binary, utf8
 
             binary_type = utf8 if str(md.schema.column(ci).logical_type).upper().startswith("STRING") else binary
+        if max_rep:
+            # a repeated column: lists (of lists ...) of a primitive, addressed by the name of its top-level field
+            top = name.split(".")[0]
+            field = pf.schema_arrow.field(top)
+            lists, leaf_info, _ = list_level_infos(field)
+            if not lists or leaf_info[0] != max_def or leaf_info[1] != max_rep or \
+                    sum(1 for nm in names if nm.split(".")[0] == top) != 1:
+                raise ArrowNotImplementedError(f"Parquet: column {name} is not a 3-level LIST chain over one primitive")
+            chunks = []
+            for rg in range(md.num_row_groups):
+                nested = {"max_rep": max_rep}
+                leaf = read_column_chunk(raw, md.row_group(rg).column(ci), max_def, device, stats, binary_type, nested)
+                chunks.append(assemble_list_column(leaf, nested, field, md.row_group(rg).num_rows, device))
+            out[name] = chunks
+            continue
         chunks = [read_column_chunk(raw, md.row_group(rg).column(ci), max_def, device, stats, binary_type)
                   for rg in range(md.num_row_groups)]
         # logical types whose Arrow layout is the physical layout (timestamp, date32, time32 / time64): same bytes,

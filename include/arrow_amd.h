@@ -1220,6 +1220,36 @@ typedef struct ArxLevelPage {
 int arx_rle_levels_to_bitmap(const void* bytes, const ArxLevelPage* pages, int64_t num_pages, void* out_bits,
                              uint32_t* ones, uint32_t* status, void* stream);
 
+/* Repeated (list) columns — DefRepLevelsToList and DefLevelsToBitmap, cpp/src/parquet/level_conversion.cc:40-124,126-146
+ * and level_conversion.h:31-135 (LevelInfo: def_level, rep_level, repeated_ancestor_def_level), over level arrays the
+ * hybrid decoder (arx_rle_decode_u32) left in HBM.
+ *   arx_rle_scan_runs_equals   : HOST, arx_rle_scan_runs for levels of any width up to 16 bits: *count = values equal to
+ *                                `equals` (the number of values a page of a nested column stores: def == max level).
+ *   arx_def_rep_levels_to_list : one list level of the column.  A level slot is skipped when def < repeated_ancestor_def_
+ *                                level or rep > rep_level, continues the current entry when rep == rep_level (its offset
+ *                                grows by one) and starts an entry otherwise (offset grows by one when def >= def_level;
+ *                                the entry is valid when def >= def_level - 1).  offsets: max_entries + 1 int32 (device),
+ *                                valid_bits: caller-ZEROED bitmap of max_entries bits padded to 32-bit words, or NULL;
+ *                                counts (device, 4 words): entries, elements, null entries, 1 if the levels hold more than
+ *                                max_entries entries (the reference's "Definition levels exceeded upper bound") — read it
+ *                                back before trusting the rest.  rep_levels may be NULL when rep_level == 0 never occurs
+ *                                (every slot then starts an entry).  Asynchronous.
+ *   arx_levels_ge_bitmap       : bit i = levels[i] >= threshold, every slot in place (out_bits: ceil(n / 64) words, all
+ *                                written); *ones (device, caller-zeroed, may be NULL) += the set bits.  With threshold =
+ *                                the leaf's def_level this is its validity over ALL level slots, with threshold = its
+ *                                repeated_ancestor_def_level the slots that exist in the leaf array at all — a filter by
+ *                                the second (arx_filter_*, DROP) is DefLevelsToBitmap<has_repeated_parent> plus the
+ *                                compaction of the values.  Asynchronous. */
+int arx_rle_scan_runs_equals(const void* data, size_t nbytes, int bit_width, int64_t num_values, uint32_t equals,
+                             uint32_t out_base, uint64_t byte_base, ArxRleRun* runs, int64_t max_runs, int64_t* num_runs,
+                             int64_t* count);
+size_t arx_levels_to_list_workspace_bytes(int64_t num_levels);
+int arx_def_rep_levels_to_list(const uint32_t* def_levels, const uint32_t* rep_levels, int64_t num_levels, int def_level,
+                               int rep_level, int repeated_ancestor_def_level, int64_t max_entries, int32_t* offsets,
+                               void* valid_bits, uint64_t* counts, void* ws, size_t ws_bytes, void* stream);
+int arx_levels_ge_bitmap(const uint32_t* levels, int64_t num_levels, uint32_t threshold, void* out_bits, uint64_t* ones,
+                         void* stream);
+
 /* Snappy page decompression on the device — SnappyCodec::Decompress (cpp/src/arrow/util/compression_snappy.cc:42-62)
  * for the pages of a column chunk in ONE launch: `compressed` holds the raw Snappy blocks (device), pages[i] says
  * where block i sits, how many bytes it must produce and where they go in `out`; one wave decodes one page (the

@@ -729,6 +729,32 @@ def rle_hybrid_decode(data: bytes, runs, bit_width: int, num_values: int) -> np.
     return out
 
 
+def def_rep_levels_to_list(def_levels, rep_levels, def_level: int, rep_level: int, repeated_ancestor_def_level: int = 0):
+    """DefRepLevelsToListInfo (cpp/src/parquet/level_conversion.cc:40-124), one level slot at a time as the reference
+    walks them: a slot below the repeated ancestor's level or above this list's repetition level is skipped (:52-55), a
+    slot at the list's repetition level continues the current entry (:57-66), anything else starts one (:67-107) — with
+    an element when def >= def_level, valid when def >= def_level - 1.  Returns (offsets, validity bools, null_count)."""
+    offsets, valid = [0], []
+    for d, r in zip(def_levels, rep_levels):
+        if d < repeated_ancestor_def_level or r > rep_level:
+            continue
+        if r == rep_level:
+            offsets[-1] += 1
+        else:
+            offsets.append(offsets[-1] + (1 if d >= def_level else 0))
+            valid.append(d >= def_level - 1)
+    return np.asarray(offsets, np.int32), np.asarray(valid, bool), int(len(valid) - sum(valid))
+
+
+def def_levels_to_bitmap(def_levels, def_level: int, repeated_ancestor_def_level: int = 0, has_repeated_parent: bool = False):
+    """DefLevelsToBitmapSimd (cpp/src/parquet/level_conversion_inc.h:296-353): with a repeated parent only the slots
+    whose def level reaches the ancestor's exist; a slot is valid when def >= def_level.  Returns validity bools."""
+    d = np.asarray(def_levels)
+    if has_repeated_parent:
+        d = d[d >= repeated_ancestor_def_level]
+    return d >= def_level
+
+
 class HashSumState:
     """GroupedReducingAggregator<Int64Type, GroupedSumImpl> with dense group ids:
     resize / consume / merge / finalize (hash_aggregate_numeric.cc:61-152)."""

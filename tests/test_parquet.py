@@ -1141,3 +1141,186 @@ def test_delta_byte_array_kernels_vs_restatement_gpu(gpu_ctx):
 def test_parquet_delta_byte_array_gpu(gpu_ctx, tmp_path, null_p):
     _write_dba_and_check(gpu_ctx, str(tmp_path), 200_000, null_p, 93, compression="snappy")
     _write_dba_and_check(gpu_ctx, str(tmp_path), 30_001, null_p, 94, data_page_version="2.0", data_page_size=8192)
+
+
+# --------------------------------------------------------------------------- repeated columns (lists)
+# The reference's own known answers for DefRepLevelsToList / DefLevelsToBitmap:
+# cpp/src/parquet/level_conversion_test.cc:142-161 (TriplyNestedList), :204-276 (outermost / middle / innermost list),
+# :278-315 (SimpleLongList), :116-139 (WithRepetitionLevelFiltersOutEmptyListValues).
+TRIPLY_DEF = [2, 7, 6, 7, 5, 3, 5, 5, 7, 7, 2, 7, 0, 1]
+TRIPLY_REP = [0, 1, 3, 3, 2, 1, 0, 1, 2, 3, 1, 1, 0, 0]
+LIST_VECTORS = [   # (def_level, rep_level, repeated_ancestor_def_level, offsets, validity, null_count)
+    (2, 1, 0, [0, 3, 7, 7, 7], "1101", 1),
+    (4, 2, 2, [0, 0, 2, 2, 3, 5, 5, 6], "0111101", 2),
+    (6, 3, 4, [0, 3, 3, 3, 3, 5, 6], "111111", 0),
+]
+
+
+def test_oracle_list_levels_against_the_references_vectors():
+    for dl, rl, anc, offsets, bits, nulls in LIST_VECTORS:
+        got_off, got_valid, got_nulls = O.def_rep_levels_to_list(TRIPLY_DEF, TRIPLY_REP, dl, rl, anc)
+        assert got_off.tolist() == offsets and "".join("1" if v else "0" for v in got_valid) == bits and got_nulls == nulls
+    off, valid, nulls = O.def_rep_levels_to_list([2] * (65 * 9), ([0] + [1] * 8) * 65, 2, 1, 0)
+    assert off.tolist() == [9 * x for x in range(66)] and valid.all() and len(valid) == 65 and nulls == 0
+    got = O.def_levels_to_bitmap([0, 0, 0, 2, 2, 1, 0, 2], 2, 1, has_repeated_parent=True)
+    assert "".join("1" if v else "0" for v in got) == "1101"       # (the test's bitmap "01101000" starts at bit 1)
+
+
+def check_list_levels_kernel(amd, rng, scale=1):
+    """arx_def_rep_levels_to_list / arx_levels_ge_bitmap against the oracle's slot-by-slot walk: the reference's vectors,
+    then random level arrays (valid or not: the walk is defined for any input) of every size around the tile borders."""
+    import ctypes as C
+
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import alloc, to_device
+
+    lib = _lib.get_lib()
+    dev = amd.array.default_device()
+
+    def run(d, r, dl, rl, anc, max_entries=None):
+        n = len(d)
+        d_def = to_device(np.asarray(d, np.uint32), dev)
+        d_rep = to_device(np.asarray(r, np.uint32), dev)
+        want_off, want_valid, want_nulls = O.def_rep_levels_to_list(d, r, dl, rl, anc)
+        cap = len(want_valid) if max_entries is None else max_entries
+        offsets = alloc((cap + 1) * 4, dev)
+        valid = alloc((cap + 63) // 64 * 8 + 8, dev, zero=True)
+        counts = torch.zeros(4, dtype=torch.int64, device=dev)
+        ws = alloc(lib.arx_levels_to_list_workspace_bytes(n), dev)
+        _lib.check(lib.arx_def_rep_levels_to_list(d_def.data_ptr(), d_rep.data_ptr(), n, dl, rl, anc, cap, offsets.data_ptr(),
+                                                  valid.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), None))
+        got = counts.cpu().numpy()
+        assert got[0] == len(want_valid) and got[1] == want_off[-1], (got, len(want_valid), want_off[-1])
+        if cap < len(want_valid):
+            assert got[3] == 1
+            return
+        assert got[3] == 0 and got[2] == want_nulls
+        assert np.array_equal(offsets.cpu().numpy().view(np.int32)[: cap + 1], want_off)
+        bits = np.unpackbits(valid.cpu().numpy(), bitorder="little")
+        assert np.array_equal(bits[:cap].astype(bool), want_valid) and not bits[cap:].any()
+        for thr in (anc, dl):
+            out = alloc((n + 63) // 64 * 8 + 8, dev)
+            ones = torch.zeros(1, dtype=torch.int64, device=dev)
+            _lib.check(lib.arx_levels_ge_bitmap(d_def.data_ptr(), n, thr, out.data_ptr(), ones.data_ptr(), None))
+            want = np.asarray(d) >= thr
+            have = np.unpackbits(out.cpu().numpy()[: (n + 63) // 64 * 8], bitorder="little")
+            assert np.array_equal(have[:n].astype(bool), want) and not have[n:].any() and int(ones.item()) == want.sum()
+
+    for dl, rl, anc, *_ in LIST_VECTORS:
+        run(TRIPLY_DEF, TRIPLY_REP, dl, rl, anc)
+    run([2] * (65 * 9), ([0] + [1] * 8) * 65, 2, 1, 0)
+    run(TRIPLY_DEF, TRIPLY_REP, 2, 1, 0, max_entries=3)                    # "Definition levels exceeded upper bound"
+    run([], [], 2, 1, 0)
+    for n in [1, 63, 64, 255, 256, 257, 4095, 4096, 4097, 8192 + 5, 30_000 * scale]:
+        for dl, rl, anc, max_def in [(2, 1, 0, 3), (1, 1, 0, 1), (4, 2, 2, 5), (6, 3, 4, 7)]:
+            d = rng.integers(0, max_def + 1, n)
+            r = rng.integers(0, rl + 2, n)
+            r[0] = 0
+            if n > 100:                # long lists and long stretches of skipped slots
+                r[n // 3: n // 3 + n // 7] = rl
+                d[n // 2: n // 2 + n // 9] = 0
+            run(d, r, dl, rl, anc)
+
+
+@pytest.mark.emu
+def test_list_levels_kernel_emulator(emu_ctx):
+    check_list_levels_kernel(emu_ctx, np.random.default_rng(12))
+
+
+@pytest.mark.gpu
+def test_list_levels_kernel_gpu(gpu_ctx):
+    check_list_levels_kernel(gpu_ctx, np.random.default_rng(13), scale=40)
+
+
+def _lists_of(rng, n, make_child, list_null_p, max_len, child_type):
+    lens = rng.integers(0, max_len + 1, n)
+    lens[rng.random(n) < 0.15] = 0                                     # empty lists next to null ones
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    child = make_child(int(offsets[-1]))
+    mask = pa.array(rng.random(n) < list_null_p) if list_null_p else None
+    return pa.ListArray.from_arrays(pa.array(offsets), child, type=child_type, mask=mask)
+
+
+def _list_table(rng, n, null_p):
+    def ints(k):
+        return pa.array(rng.integers(-1000, 1000, k), mask=(rng.random(k) < null_p) if null_p else None)
+
+    def strs(k):
+        words = np.array(["", "a", "bb", "gfx950", "MI355X", "ünïcödé"], dtype=object)
+        return pa.array(words[rng.integers(0, 6, k)], type=pa.string(), mask=(rng.random(k) < null_p) if null_p else None)
+
+    def f64(k):
+        return pa.array(np.round(rng.standard_normal(k), 1), mask=(rng.random(k) < null_p) if null_p else None)
+
+    def flags(k):
+        return pa.array(rng.random(k) < 0.4, type=pa.bool_(), mask=(rng.random(k) < null_p) if null_p else None)
+
+    def i32_required(k):
+        return pa.array(rng.integers(0, 50, k).astype(np.int32))
+
+    def inner_lists(k):
+        return _lists_of(rng, k, ints, null_p, 4, pa.list_(pa.field("element", pa.int64())))
+
+    el = lambda t, nullable=True: pa.list_(pa.field("element", t, nullable=nullable))   # noqa: E731
+    cols = {
+        "l_i64": _lists_of(rng, n, ints, null_p, 6, el(pa.int64())),
+        "l_str": _lists_of(rng, n, strs, null_p, 3, el(pa.string())),
+        "l_f64": _lists_of(rng, n, f64, null_p, 5, el(pa.float64())),
+        "l_flag": _lists_of(rng, n, flags, null_p, 9, el(pa.bool_())),
+        "l_req": _lists_of(rng, n, i32_required, 0.0, 4, el(pa.int32(), nullable=False)),
+        "ll_i64": _lists_of(rng, n, inner_lists, null_p, 3, el(el(pa.int64()))),
+        "flat": pa.array(rng.integers(0, 9, n), mask=(rng.random(n) < null_p) if null_p else None),
+    }
+    fields = [pa.field(k, v.type, nullable=(k != "l_req")) for k, v in cols.items()]
+    return pa.table(list(cols.values()), schema=pa.schema(fields))
+
+
+LIST_VARIANTS = [dict(compression="snappy", data_page_version="1.0", use_dictionary=True),
+                 dict(compression="none", data_page_version="2.0", use_dictionary=False, data_page_size=2048),
+                 dict(compression="snappy", data_page_version="2.0", use_dictionary=["l_str", "l_i64"], data_page_size=4096),
+                 dict(compression="zstd", data_page_version="1.0", use_dictionary=False, data_page_size=1024)]
+
+
+def _write_and_check_lists(amd, tmp_path, n, null_p, variant, seed):
+    rng = np.random.default_rng(seed)
+    path = os.path.join(tmp_path, "lists.parquet")
+    pq.write_table(_list_table(rng, n, null_p), path, row_group_size=max(1, n // 2 + 3), **variant)
+    pf = pq.ParquetFile(path)
+    names = [pf.metadata.schema.column(i).path for i in range(pf.metadata.num_columns)]
+    got = amd.parquet.read_table(path)
+    assert sorted(got) == sorted(names)
+    for name, chunks in got.items():
+        top = name.split(".")[0]
+        for rg, arr in enumerate(chunks):
+            want = pf.read_row_group(rg, columns=[top]).column(top).combine_chunks()
+            have = arr.to_pyarrow()
+            have.validate(full=True)
+            assert have.type == want.type and len(have) == len(want) and have.null_count == want.null_count, (name, rg, have.type, want.type)
+            assert have.equals(want), (name, rg, have.slice(0, 6), want.slice(0, 6))
+
+
+@pytest.mark.emu
+@pytest.mark.parametrize("variant", range(len(LIST_VARIANTS)))
+@pytest.mark.parametrize("null_p", [0.0, 0.2])
+def test_parquet_list_columns_emulator(emu_ctx, tmp_path, variant, null_p):
+    """Repeated columns — list<T> and list<list<T>> of int64 / utf8 / float64 / bool / required int32 with null lists,
+    empty lists and null elements, data pages V1 / V2 — equal to the reference reader's ListArrays."""
+    _write_and_check_lists(emu_ctx, str(tmp_path), 3000, null_p, LIST_VARIANTS[variant], 300 + variant)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", range(len(LIST_VARIANTS)))
+def test_parquet_list_columns_gpu(gpu_ctx, tmp_path, variant):
+    _write_and_check_lists(gpu_ctx, str(tmp_path), 200_000, 0.1 if variant % 2 else 0.0, LIST_VARIANTS[variant], 400 + variant)
+
+
+def test_parquet_struct_columns_are_refused_by_name(tmp_path):
+    """What is NOT on the device path says so before any device call: structs (and lists of them)."""
+    import arrow_amd
+
+    path = os.path.join(str(tmp_path), "s.parquet")
+    pq.write_table(pa.table({"s": pa.array([{"a": 1, "b": [1, 2]}, None])}), path)
+    with pytest.raises(arrow_amd._lib.ArrowNotImplementedError, match="3-level LIST chain|not on the gfx950 path"):
+        arrow_amd.parquet.read_table(path, columns=["s.b.list.element"], device="cpu")
