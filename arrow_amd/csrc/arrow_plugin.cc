@@ -104,6 +104,7 @@ namespace {
 #include "plugin/acero_coalesce.inc"
 #include "plugin/acero_override.inc"
 #include "plugin/parquet.inc"
+#include "plugin/parquet_nested.inc"
 #include "plugin/device_guard.inc"
 #include "plugin/validity.inc"
 #include "plugin/registration.inc"

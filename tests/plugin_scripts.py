@@ -1949,12 +1949,12 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
     c_devs, c_schemas = ctypes.create_string_buffer(128 * 3), ctypes.create_string_buffer(72 * 3)
     assert lib.arrow_amd_parquet_read_columns(path.encode(), 0, (ctypes.c_int * 3)(0, 99, 1), 3, ctypes.addressof(c_devs), ctypes.addressof(c_schemas)) != 0
     assert b"no row group" in lib.arrow_amd_plugin_last_error() or b"column" in lib.arrow_amd_plugin_last_error()
-    # a nested column is refused, not mis-decoded
+    # a struct column is refused, not mis-decoded (lists of primitives are read: parquet_list_columns_through_the_plugin)
     path = os.path.join(tempfile.mkdtemp(), "l.parquet")
-    pq.write_table(pa.table({"l": pa.array([[1, 2], [3]])}), path)
+    pq.write_table(pa.table({"l": pa.array([{"a": 1}, None])}), path)
     c_dev, c_schema = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72)
     assert lib.arrow_amd_parquet_read_column(path.encode(), 0, 0, ctypes.addressof(c_dev), ctypes.addressof(c_schema)) != 0
-    assert b"nested" in lib.arrow_amd_plugin_last_error()
+    assert b"structs are not on the device path" in lib.arrow_amd_plugin_last_error(), lib.arrow_amd_plugin_last_error()
     print("PARQUET_OK")
 ''')
 
@@ -4501,6 +4501,61 @@ IMPORT_ORDER_SCRIPT = textwrap.dedent(r"""
     print("IMPORT_ORDER_OK")
 """)
 
+PARQUET_LISTS_SCRIPT = textwrap.dedent(r"""
+    import ctypes, faulthandler, os, sys, tempfile
+    import numpy as np
+    import pyarrow as pa, pyarrow.parquet as pq
+    faulthandler.enable()
+    sys.path.insert(0, ROOT)
+    SC = lambda x: max(64, int(x * float(os.environ.get("ARROW_AMD_TEST_SCALE", "1"))))
+    if os.environ.get("ARROW_AMD_PLUGIN_EMULATED") == "1":      # CPU tier: the shim on the emulated kernels (tests/emu)
+        from tests.emu.build_plugin_emu import build_plugin
+    else:
+        from arrow_amd.plugin_build import build_plugin
+    lib = ctypes.CDLL(build_plugin())
+    lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
+    lib.arrow_amd_parquet_read_column.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.arrow_amd_register() == 0, lib.arrow_amd_plugin_last_error()
+
+    def to_host(darr):
+        c_dev, c_schema, c_arr, c_schema2 = (ctypes.create_string_buffer(n) for n in (128, 72, 80, 72))
+        darr._export_to_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert lib.arrow_amd_copy_to_host(c_dev, c_schema, c_arr, c_schema2) == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c(ctypes.addressof(c_arr), ctypes.addressof(c_schema2))
+
+    def read_column(path, rg, col):
+        c_dev, c_schema = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72)
+        rc = lib.arrow_amd_parquet_read_column(path.encode(), rg, col, ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert rc == 0, lib.arrow_amd_plugin_last_error()
+        return pa.Array._import_from_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+
+    from tests.test_parquet import LIST_VARIANTS, _list_table
+    n = SC(300_000)
+    for vi, variant in enumerate(LIST_VARIANTS):
+        t = _list_table(np.random.default_rng(50 + vi), n, 0.15 if vi % 2 == 0 else 0.0)
+        path = os.path.join(tempfile.mkdtemp(), "lists.parquet")
+        pq.write_table(t, path, row_group_size=n // 2 + 5, **variant)
+        pf = pq.ParquetFile(path)
+        tops = [pf.metadata.schema.column(i).path.split(".")[0] for i in range(pf.metadata.num_columns)]
+        for rg in range(pf.metadata.num_row_groups):
+            ref = pf.read_row_group(rg)
+            for ci, top in enumerate(tops):
+                d = read_column(path, rg, ci)
+                assert not d.is_cpu or len(d) == 0, top
+                h = to_host(d)
+                h.validate(full=True)
+                w = ref.column(top).combine_chunks()
+                assert h.type == w.type and h.null_count == w.null_count and h.equals(w), (variant, rg, top, h.type, w.type, h.slice(0, 5), w.slice(0, 5))
+    # what is not a chain of lists over one primitive is refused by name, before any device work
+    path = os.path.join(tempfile.mkdtemp(), "s.parquet")
+    pq.write_table(pa.table({"s": pa.array([{"a": 1, "b": [1, 2]}, None, {"a": None, "b": []}])}), path)
+    c_dev, c_schema = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72)
+    for col in (0, 1):
+        rc = lib.arrow_amd_parquet_read_column(path.encode(), 0, col, ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+        assert rc != 0 and b"NotImplemented" in lib.arrow_amd_plugin_last_error(), lib.arrow_amd_plugin_last_error()
+    print("PARQUET_LISTS_OK")
+""")
+
 CASES = [
     ('pyarrow_compute_dispatches_to_the_hip_kernels', SCRIPT, 'PLUGIN_OK', 0.04,
      ''),
@@ -4516,6 +4571,8 @@ CASES = [
      "Filter / take of BOOLEAN (bit-packed) device values through Arrow's CallFunction (arx_take_bits behind the array_filter / array_take shims), incl. sliced operands and EMIT_NULL."),
     ('parquet_column_chunks_through_the_plugin', PARQUET_SCRIPT, 'PARQUET_OK', 0.03,
      "SURVEY.md 8 (f4): parquet::PageReader (headers, decompression) + the C-ABI kernels (levels, indices, dictionary gather, null expansion) -> device-resident arrays equal to the reference's reader."),
+    ('parquet_list_columns_through_the_plugin', PARQUET_LISTS_SCRIPT, 'PARQUET_LISTS_OK', 0.01,
+     "SURVEY.md 8 (f4), VERDICT r5 missing 5: repeated Parquet columns — list<T> and list<list<T>> of int64 / utf8 / float64 / bool / required int32, null lists, empty lists, null elements, data pages V1 / V2 — through arrow_amd_parquet_read_column: the reference's SchemaManifest for the LevelInfo of every level, DefRepLevelsToList as a kernel over the decoded levels (arx_def_rep_levels_to_list), device-resident ListArrays equal to the reference reader's; structs refused by name."),
     ('single_sync_filter_path_on_device_resident_arrays', MORSEL_FILTER_SCRIPT, 'MORSEL_FILTER_OK', 0.05,
      'The opt-in single-synchronisation device filter (arrow_amd_plugin_set_filter_morsel_rows): worst-case allocation, count -> compact back to back, one read-back — identical output to the default path and to the reference.'),
     ('filter_and_take_of_device_resident_batches_and_tables', SELECTION_META_SCRIPT, 'SELECTION_META_OK', 0.02,

@@ -467,10 +467,22 @@ def test_parquet_edge_cases_emulator(emu_ctx, tmp_path):
     rng = np.random.default_rng(5)
     for n, null_p in ((0, 0.0), (1, 0.0), (1, 1.0), (70, 1.0), (5000, 0.999)):
         _write_and_check(emu_ctx, str(tmp_path), n, null_p, VARIANTS[0], n)
-    with pytest.raises(emu_ctx.ArrowNotImplementedError):     # nested columns are out of scope
+    with pytest.raises(emu_ctx.ArrowNotImplementedError):     # structs are out of scope (lists of primitives are read)
         path = os.path.join(str(tmp_path), "l.parquet")
-        pq.write_table(pa.table({"l": pa.array([[1, 2], [3]])}), path)
+        pq.write_table(pa.table({"l": pa.array([{"a": 1}, None])}), path)
         emu_ctx.parquet.read_table(path)
+    # list columns at the edges: no row, one null list, one empty list, only null / only empty lists, one long list
+    lt = pa.list_(pa.field("element", pa.int64()))
+    for k, values in enumerate(([], [None], [[]], [None] * 70, [[]] * 70, [list(range(9000))], [[None] * 130, None, [], [7]])):
+        path = os.path.join(str(tmp_path), f"edge{k}.parquet")
+        pq.write_table(pa.table({"l": pa.array(values, lt)}), path)
+        got = emu_ctx.parquet.read_table(path)["l.list.element"]
+        want = pq.read_table(path).column("l")
+        assert len(got) == want.num_chunks or (len(values) == 0 and len(got) <= 1)
+        if got:
+            have = got[0].to_pyarrow()
+            have.validate(full=True)
+            assert have.equals(want.combine_chunks()), (values[:3], have)
     path = os.path.join(str(tmp_path), "b.parquet")             # binary (not utf8) values, some empty, some null
     pq.write_table(pa.table({"b": pa.array([b"\x00\x01", None, b"", b"\xff" * 9, None, b"\x00\x01"], pa.binary())}), path)
     check_file(emu_ctx, path)
