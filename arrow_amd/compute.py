@@ -1427,8 +1427,9 @@ def sort_indices_by_keys(keys, orders=None, null_placement="at_end") -> Array:
     return perm
 
 
-# RankOptions::Tiebreaker (api_vector.h:201-212) = ARX_RANK_* of include/arrow_amd.h; "quantile": rank_quantile
-_RANK_TIEBREAKER = {"min": 0, "max": 1, "first": 2, "dense": 3, "quantile": 4}
+# RankOptions::Tiebreaker (api_vector.h:201-212) = ARX_RANK_* of include/arrow_amd.h; "quantile": rank_quantile, "normal":
+# rank_normal
+_RANK_TIEBREAKER = {"min": 0, "max": 1, "first": 2, "dense": 3, "quantile": 4, "normal": 5}
 
 
 def _rank(arr: Array, order: str, null_placement: str, tiebreaker: str) -> Array:
@@ -1450,7 +1451,7 @@ def _rank(arr: Array, order: str, null_placement: str, tiebreaker: str) -> Array
     span = arr.span()
     check(lib.arx_rank(C.byref(span), _SORT_KEY_TYPE[arr.type.name], sorted_rows.data.data_ptr(), _RANK_TIEBREAKER[tiebreaker],
                        aligned, ws.numel() - (aligned - base), out.data_ptr(), stream))
-    return Array(float64 if tiebreaker == "quantile" else uint64, n, [None, out], 0, 0)
+    return Array(float64 if tiebreaker in ("quantile", "normal") else uint64, n, [None, out], 0, 0)
 
 
 def rank(arr: Array, order: str = "ascending", null_placement: str = "at_end", tiebreaker: str = "first") -> Array:
@@ -1463,6 +1464,12 @@ def rank_quantile(arr: Array, order: str = "ascending", null_placement: str = "a
     """compute "rank_quantile" (RankQuantileMetaFunction, kernels/vector_rank.cc:443-462): (rows below the row's run of
     ties + half the run) / length, float64."""
     return _rank(arr, order, null_placement, "quantile")
+
+
+def rank_normal(arr: Array, order: str = "ascending", null_placement: str = "at_end") -> Array:
+    """compute "rank_normal" (RankNormalMetaFunction, kernels/vector_rank.cc:424-441): the normal percent-point function
+    (NormalPPF, util/math_internal.cc:26-137 — Wichura's AS 241) of the quantile rank, float64."""
+    return _rank(arr, order, null_placement, "normal")
 
 
 def partition_nth_indices(arr: Array, pivot: int, null_placement: str = "at_end") -> Array:

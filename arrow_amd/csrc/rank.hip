@@ -12,6 +12,7 @@
 // Algorithmic bytes per row: 8 (sorted index) + 8 (key gather: a 128-byte line for 8 wanted bytes, as every take) +
 // 8 (sorted index again) + 8 (rank scatter, same remark) — HBM-bound on the two random accesses.
 #include "arx_common.h"
+#include <math.h>
 
 #include <string.h>
 
@@ -247,6 +248,52 @@ __global__ __launch_bounds__(kRankScanThreads) void rank_scan_kernel(RankArgs a)
   }
 }
 
+// NormalRanker::TransformValue (vector_rank.cc:204-209) = arrow::internal::NormalPPF (util/math_internal.cc:26-137): Wichura's
+// Algorithm AS 241 (PPND16; Applied Statistics 37(3), 1988 — the published coefficients).  A rational function of
+// 0.180625 - q^2 for |q = p - 1/2| < 0.425, of sqrt(-log(min(p, 1 - p))) - 1.6 (or - 5) in the tails; Horner form in the
+// reference's order of operations with contraction OFF — the reference build has no fused multiply-add, so every product
+// and every sum rounds as it does there: the centre comes out bit for bit, the tails within the two libraries' log().
+__device__ __forceinline__ double ppf_horner(const double (&c)[8], double r) {
+#pragma clang fp contract(off)
+  double acc = c[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) acc = acc * r + c[k];
+  return acc;
+}
+
+__device__ __attribute__((noinline)) double normal_ppf(double p) {
+#pragma clang fp contract(off)
+  constexpr double A[8] = {2.5090809287301226727e3, 3.3430575583588128105e4, 6.7265770927008700853e4, 4.5921953931549871457e4,
+                           1.3731693765509461125e4, 1.9715909503065514427e3, 1.3314166789178437745e2, 3.3871328727963666080e0};
+  constexpr double B[8] = {5.2264952788528545610e3, 2.8729085735721942674e4, 3.9307895800092710610e4, 2.1213794301586595867e4,
+                           5.3941960214247511077e3, 6.8718700749205790830e2, 4.2313330701600911252e1, 1.0};
+  constexpr double C[8] = {7.74545014278341407640e-4, 2.27238449892691845833e-2, 2.41780725177450611770e-1, 1.27045825245236838258e0,
+                           3.64784832476320460504e0, 5.76949722146069140550e0, 4.63033784615654529590e0, 1.42343711074968357734e0};
+  constexpr double D[8] = {1.05075007164441684324e-9, 5.47593808499534494600e-4, 1.51986665636164571966e-2, 1.48103976427480074590e-1,
+                           6.89767334985100004550e-1, 1.67638483018380384940e0, 2.05319162663775882187e0, 1.0};
+  constexpr double E[8] = {2.01033439929228813265e-7, 2.71155556874348757815e-5, 1.24266094738807843860e-3, 2.65321895265761230930e-2,
+                           2.96560571828504891230e-1, 1.78482653991729133580e0, 5.46378491116411436990e0, 6.65790464350110377720e0};
+  constexpr double F[8] = {2.04426310338993978564e-15, 1.42151175831644588870e-7, 1.84631831751005468180e-5, 7.86869131145613259100e-4,
+                           1.48753612908506148525e-2, 1.36929880922735805310e-1, 5.99832206555887937690e-1, 1.0};
+  if (p == 0.0) return -HUGE_VAL;
+  if (p == 1.0) return HUGE_VAL;
+  const double q = p - 0.5;
+  if (fabs(q) < 0.425) {
+    const double r = 0.180625 - q * q;
+    return q * ppf_horner(A, r) / ppf_horner(B, r);
+  }
+  double r = sqrt(-log(q < 0.0 ? p : 1.0 - p));
+  if (r < 5.0) {
+    r -= 1.6;
+    r = ppf_horner(C, r) / ppf_horner(D, r);
+  } else {
+    r -= 5.0;
+    r = ppf_horner(E, r) / ppf_horner(F, r);
+  }
+  return copysign(r, q);
+}
+
+
 __global__ __launch_bounds__(kRankThreads) void rank_emit_kernel(RankArgs a) {
   __shared__ uint32_t w_count[kRankThreads / 64];
   __shared__ int64_t w_first[kRankThreads / 64], w_last[kRankThreads / 64];
@@ -316,7 +363,8 @@ __global__ __launch_bounds__(kRankThreads) void rank_emit_kernel(RankArgs a) {
       case ARX_RANK_DENSE: static_cast<uint64_t*>(a.out)[row] = dense; break;
       default: {   // quantile: (rows below the run + half the run) / n  (BaseQuantileRanker, vector_rank.cc:183-186)
         const double freq = static_cast<double>(ends[j] - run_start);
-        static_cast<double*>(a.out)[row] = (static_cast<double>(run_start) + 0.5 * freq) / length;
+        const double quantile = (static_cast<double>(run_start) + 0.5 * freq) / length;
+        static_cast<double*>(a.out)[row] = a.tiebreaker == ARX_RANK_NORMAL ? normal_ppf(quantile) : quantile;
         break;
       }
     }
@@ -354,7 +402,7 @@ int arx_rank(const ArxSpan* values, int key_type, const uint64_t* sorted_rows, i
     set_error("arx_rank: key type %d", key_type);
     return ARX_NOT_IMPLEMENTED;
   }
-  if (tiebreaker < ARX_RANK_MIN || tiebreaker > ARX_RANK_QUANTILE) {
+  if (tiebreaker < ARX_RANK_MIN || tiebreaker > ARX_RANK_NORMAL) {
     set_error("arx_rank: tiebreaker %d", tiebreaker);
     return ARX_INVALID;
   }

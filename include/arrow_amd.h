@@ -524,9 +524,12 @@ int arx_sort_indices(const ArxSpan* values, int key_type, int order, int null_pl
  * BaseQuantileRanker::CreateRankings :163-196).  sorted_rows = arx_sort_indices(values, key_type, order, null_placement):
  * the order and the null placement are in it; all NaNs tie, all nulls tie, -0.0 ties with 0.0.  out: uint64[length]
  * 1-based ranks (ARX_RANK_MIN / MAX / FIRST / DENSE = RankOptions::Tiebreaker, api_vector.h:201-212) or, ARX_RANK_QUANTILE,
- * double[length] = (rows below the row's run of ties + half the run) / length.  ws: arx_rank_workspace_bytes(length),
- * 256-byte aligned (not used by ARX_RANK_FIRST).  Asynchronous. */
-enum { ARX_RANK_MIN = 0, ARX_RANK_MAX = 1, ARX_RANK_FIRST = 2, ARX_RANK_DENSE = 3, ARX_RANK_QUANTILE = 4 };
+ * double[length] = (rows below the row's run of ties + half the run) / length, or, ARX_RANK_NORMAL ("rank_normal",
+ * NormalRanker :204-209), the normal percent-point function of that quantile (arrow::internal::NormalPPF,
+ * util/math_internal.cc:26-137 = Wichura's AS 241, evaluated without fused multiply-add: bit for bit in the centre of the
+ * distribution, within the log() of the two math libraries in the tails — the reference's own test bar is 4 ULPs).
+ * ws: arx_rank_workspace_bytes(length), 256-byte aligned (not used by ARX_RANK_FIRST).  Asynchronous. */
+enum { ARX_RANK_MIN = 0, ARX_RANK_MAX = 1, ARX_RANK_FIRST = 2, ARX_RANK_DENSE = 3, ARX_RANK_QUANTILE = 4, ARX_RANK_NORMAL = 5 };
 size_t arx_rank_workspace_bytes(int64_t length);
 int arx_rank(const ArxSpan* values, int key_type, const uint64_t* sorted_rows, int tiebreaker, void* ws, size_t ws_bytes,
              void* out, void* stream);

@@ -414,13 +414,53 @@ def sort_indices_multi(keys, descending=None, nulls_at_start=False):
     return np.lexsort(tuple(reversed(columns))).astype(np.uint64)
 
 
+# Wichura (1988), Algorithm AS 241 (PPND16), Applied Statistics 37(3): the published coefficients, highest power first
+_PPF_A = (2.5090809287301226727e3, 3.3430575583588128105e4, 6.7265770927008700853e4, 4.5921953931549871457e4,
+          1.3731693765509461125e4, 1.9715909503065514427e3, 1.3314166789178437745e2, 3.3871328727963666080e0)
+_PPF_B = (5.2264952788528545610e3, 2.8729085735721942674e4, 3.9307895800092710610e4, 2.1213794301586595867e4,
+          5.3941960214247511077e3, 6.8718700749205790830e2, 4.2313330701600911252e1, 1.0)
+_PPF_C = (7.74545014278341407640e-4, 2.27238449892691845833e-2, 2.41780725177450611770e-1, 1.27045825245236838258e0,
+          3.64784832476320460504e0, 5.76949722146069140550e0, 4.63033784615654529590e0, 1.42343711074968357734e0)
+_PPF_D = (1.05075007164441684324e-9, 5.47593808499534494600e-4, 1.51986665636164571966e-2, 1.48103976427480074590e-1,
+          6.89767334985100004550e-1, 1.67638483018380384940e0, 2.05319162663775882187e0, 1.0)
+_PPF_E = (2.01033439929228813265e-7, 2.71155556874348757815e-5, 1.24266094738807843860e-3, 2.65321895265761230930e-2,
+          2.96560571828504891230e-1, 1.78482653991729133580e0, 5.46378491116411436990e0, 6.65790464350110377720e0)
+_PPF_F = (2.04426310338993978564e-15, 1.42151175831644588870e-7, 1.84631831751005468180e-5, 7.86869131145613259100e-4,
+          1.48753612908506148525e-2, 1.36929880922735805310e-1, 5.99832206555887937690e-1, 1.0)
+
+
+def normal_ppf(p):
+    """arrow::internal::NormalPPF (cpp/src/arrow/util/math_internal.cc:26-137): Wichura's AS 241 — a rational function of
+    0.180625 - q^2 in the centre (|q = p - 1/2| < 0.425), of sqrt(-log(min(p, 1 - p))) in the tails, Horner form in the
+    reference's order of operations (no fused multiply-add: numpy rounds every product and every sum); -inf / +inf at 0 / 1."""
+    p = np.asarray(p, np.float64)
+
+    def horner(coef, r):
+        acc = np.full_like(r, coef[0])
+        for c in coef[1:]:
+            acc = acc * r + c
+        return acc
+
+    q = p - 0.5
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rc = 0.180625 - q * q
+        centre = q * horner(_PPF_A, rc) / horner(_PPF_B, rc)
+        r = np.sqrt(-np.log(np.where(q < 0.0, p, 1.0 - p)))
+        mid = horner(_PPF_C, r - 1.6) / horner(_PPF_D, r - 1.6)
+        far = horner(_PPF_E, r - 5.0) / horner(_PPF_F, r - 5.0)
+        tail = np.copysign(np.where(r < 5.0, mid, far), q)
+    out = np.where(np.abs(q) < 0.425, centre, tail)
+    out = np.where(p == 0.0, -np.inf, np.where(p == 1.0, np.inf, out))
+    return out
+
+
 def rank(values, valid, descending=False, nulls_at_start=False, tiebreaker="first"):
     """compute "rank" / "rank_quantile" (kernels/vector_rank.cc): the array sorter's order (sort_indices_multi with one
     key: values, NaNs, nulls at_end — or reversed at_start —, ties in row order), MarkDuplicates (:40-72: an index is a
     duplicate when its value equals the one before it; every NaN after the first and every null after the first are
     duplicates), then OrdinalRanker::CreateRankings (:203-263) for min / max / first / dense and
     BaseQuantileRanker::CreateRankings (:163-196) for "quantile".  `values` over the logical rows, `valid` a bool array
-    or None.  uint64 ranks (float64 for "quantile")."""
+    or None.  uint64 ranks (float64 for "quantile" and for "normal" = rank_normal)."""
     values = np.asarray(values)
     n = len(values)
     order = sort_indices_multi([(values, valid)], [descending], nulls_at_start).astype(np.int64)
@@ -439,9 +479,10 @@ def rank(values, valid, descending=False, nulls_at_start=False, tiebreaker="firs
     if n:
         run_end[:-1] = np.minimum.accumulate(nxt[::-1])[::-1][1:]
         run_end[-1] = n
-    if tiebreaker == "quantile":
+    if tiebreaker in ("quantile", "normal"):      # "normal": NormalRanker::TransformValue (:204-209) of the quantile rank
         out = np.empty(n, np.float64)
-        out[order] = (run_start + 0.5 * (run_end - run_start)) / float(n) if n else 0.0
+        quantile = (run_start + 0.5 * (run_end - run_start)) / float(n) if n else np.zeros(0)
+        out[order] = normal_ppf(quantile) if tiebreaker == "normal" else quantile
         return out
     ranks = {"first": pos + 1, "min": run_start + 1, "max": run_end, "dense": np.cumsum(~dup)}[tiebreaker]
     out = np.empty(n, np.uint64)

@@ -3359,6 +3359,24 @@ def rank_golden_cases():
     return out
 
 
+# rank_normal: the reference's own bar for NormalPPF is EXPECT_DOUBLE_EQ = 4 ULPs (util/math_test.cc:28-82; its rank_normal
+# test accepts 1e-8 absolute, vector_sort_test.cc:2656-2660).  The centre of the distribution is +, *, / only and comes out
+# bit for bit; the tails go through log(), where the device's and the host's libraries may round differently.
+RANK_NORMAL_ULPS = 4
+
+
+def max_ulps(a, b) -> int:
+    """Largest distance in units of the last place between two float64 arrays (equal infinities and equal zeros: 0)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0
+    assert not (np.isnan(a).any() or np.isnan(b).any())
+    ia, ib = a.view(np.int64).copy(), b.view(np.int64).copy()
+    ia[ia < 0] = np.iinfo(np.int64).min - ia[ia < 0]          # two's-complement order of the doubles
+    ib[ib < 0] = np.iinfo(np.int64).min - ib[ib < 0]
+    return int(np.abs(ia.astype(object) - ib.astype(object)).max())
+
+
 def check_rank(amd, rng_for, scale=1, light=False):
     """rank / rank_quantile on the device (arx_sort_indices + arx_rank) against the oracle's restatement of
     vector_rank.cc — bit-exact, quantile ranks included — on the reference's own known answers and on seeded arrays:
@@ -3403,6 +3421,10 @@ def check_rank(amd, rng_for, scale=1, light=False):
                     wq = O.rank(lv, lvalid, order == "descending", place == "at_start", "quantile")
                     assert gq.type == amd.array.float64
                     assert_equal(_data_np(gq, np.float64).view(np.uint64), wq.view(np.uint64), f"rank_quantile[{np.dtype(dtype).name},n={n},{order},{place}]")
+                    gn = amd.compute.rank_normal(d, order, place)
+                    wn = O.rank(lv, lvalid, order == "descending", place == "at_start", "normal")
+                    assert gn.type == amd.array.float64 and gn.null_count == 0
+                    assert max_ulps(_data_np(gn, np.float64), wn) <= RANK_NORMAL_ULPS, f"rank_normal[{np.dtype(dtype).name},n={n},{order},{place}]"
     if pc is not None:     # the restatement itself against the reference build, on the way
         a = pa.array([1.5, None, float("nan"), -0.0, 0.0, 1.5])
         v = np.array([1.5, 0, np.nan, -0.0, 0.0, 1.5])

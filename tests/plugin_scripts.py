@@ -4288,12 +4288,13 @@ RANK_SELECT_SCRIPT = textwrap.dedent(r"""
     }
     combos = [(o, p) for o in ("ascending", "descending") for p in ("at_end", "at_start")]
     # ---- the reference: stock kernels, before anything is registered
-    want_rank, want_q = {}, {}
+    want_rank, want_q, want_n = {}, {}, {}
     for name, a in cols.items():
         for o, p in combos:
             for tb in ("min", "max", "first", "dense"):
                 want_rank[name, o, p, tb] = pc.rank(a, sort_keys=o, null_placement=p, tiebreaker=tb)
             want_q[name, o, p] = pc.rank_quantile(a, sort_keys=o, null_placement=p)
+            want_n[name, o, p] = pc.rank_normal(a, sort_keys=o, null_placement=p)
     lib = ctypes.CDLL(build_plugin())
     lib.arrow_amd_plugin_last_error.restype = ctypes.c_char_p
     lib.arrow_amd_plugin_calls.restype = ctypes.c_int64
@@ -4316,6 +4317,7 @@ RANK_SELECT_SCRIPT = textwrap.dedent(r"""
     # unlike the kernels of a VectorFunction) is reached by name: CallFunction in C++, pc.call_function here
     def rank(x, o, p, tb): return pc.call_function("rank", [x], pc.RankOptions(sort_keys=o, null_placement=p, tiebreaker=tb))
     def rank_quantile(x, o, p): return pc.call_function("rank_quantile", [x], pc.RankQuantileOptions(sort_keys=o, null_placement=p))
+    def rank_normal(x, o, p): return pc.call_function("rank_normal", [x], pc.RankQuantileOptions(sort_keys=o, null_placement=p))
     def select_k(x, k, keys): return pc.call_function("select_k_unstable", [x], pc.SelectKOptions(k, keys))
     def partition_nth(x, pivot, p="at_end"): return pc.call_function("partition_nth_indices", [x], pc.PartitionNthOptions(pivot, null_placement=p))
     picked = combos[:1] + combos[3:] if light else combos
@@ -4331,7 +4333,14 @@ RANK_SELECT_SCRIPT = textwrap.dedent(r"""
             assert not gq.is_cpu and gq.type == pa.float64()
             a, b = (np.asarray(x).view(np.uint64) for x in (to_host(gq), want_q[name, o, p]))
             assert np.array_equal(a, b), (name, o, p, "rank_quantile")
-    assert lib.arrow_amd_plugin_calls(b"array_sort_indices", 1) - g0 >= len(cols) * len(picked) * 5
+            # rank_normal: NormalPPF of the quantile rank — within the reference's own bar for it (4 ULPs, util/math_test.cc)
+            gn = rank_normal(dev[name], o, p)
+            assert not gn.is_cpu and gn.type == pa.float64()
+            from tests.parity_cases import max_ulps
+            hn = to_host(gn)
+            assert hn.null_count == 0 and max_ulps(np.asarray(hn), np.asarray(want_n[name, o, p])) <= 4, (name, o, p, "rank_normal")
+    assert lib.arrow_amd_plugin_calls(b"array_sort_indices", 1) - g0 >= len(cols) * len(picked) * 6
+    assert rank_normal(cols["f64"], "ascending", "at_end").equals(want_n["f64", "ascending", "at_end"])      # host: stock
     # chunked device input: ranks number the rows of the logical column
     cut = n // 3 + 1
     chunked = pa.chunked_array([to_device(cols["i64"].slice(0, cut)), to_device(cols["i64"].slice(cut))])
@@ -4433,6 +4442,25 @@ RANK_SELECT_SCRIPT = textwrap.dedent(r"""
     dd = pc.dictionary_encode(dev["i64"])
     sl = dd.slice(7, n // 2)
     assert to_host(pc.array_sort_indices(sl, order="descending")).equals(pc.array_sort_indices(pc.dictionary_encode(cols["i64"]).slice(7, n // 2), order="descending"))
+    # ---- struct sort keys (round 6): the null structs to their end in row order, the others by their fields in turn
+    # (ArrayCompareSorter<StructType> -> SortStructArray); fields with nulls of their own, a sliced struct, no null struct
+    st_type = pa.struct([("a", pa.int64()), ("b", pa.float64()), ("s", pa.utf8()), ("h", pa.int16())])
+    m = SC(40_000)
+    fields_h = [pa.array(rng.integers(0, 6, m), mask=rng.random(m) < 0.1),
+                pa.array(np.round(rng.standard_normal(m), 1), mask=rng.random(m) < 0.1),
+                pa.array(np.array(["", "a", "ab", "b"], dtype=object)[rng.integers(0, 4, m)], pa.utf8(), mask=rng.random(m) < 0.1),
+                pa.array(rng.integers(-3, 3, m).astype(np.int16))]
+    fields_d = [to_device(f) for f in fields_h]
+    for null_p in (0.15, 0.0):
+        valid = pa.array(rng.random(m) >= null_p)
+        host_struct = pa.StructArray.from_arrays(fields_h, fields=list(st_type), mask=pc.invert(valid) if null_p else None)
+        bufs = [to_device(valid).buffers()[1]] if null_p else [None]
+        dev_struct = pa.Array.from_buffers(st_type, m, bufs, null_count=host_struct.null_count, children=fields_d)
+        for hs, ds in ((host_struct, dev_struct), (host_struct.slice(9, m // 2), dev_struct.slice(9, m // 2))):
+            for o, p in (combos[:1] + combos[3:] if light else combos):
+                got = pc.array_sort_indices(ds, order=o, null_placement=p)
+                want = pc.array_sort_indices(hs, order=o, null_placement=p)
+                assert not got.is_cpu and to_host(got).equals(want), ("struct", null_p, hs.offset, o, p)
     # ---- large_utf8 / large_binary sort keys (round 6): offsets narrowed on the device, then the utf8 chain
     words = [None if i % 13 == 0 else "w%05d" % int(x) if i % 3 else "w%d" % int(x) for i, x in enumerate(rng.integers(0, 3000, SC(60_000)))]
     for typ in (pa.large_utf8(), pa.large_binary()):

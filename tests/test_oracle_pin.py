@@ -1211,3 +1211,46 @@ def test_oracle_rank_against_the_references_known_answers_and_pyarrow():
                             w = pc.rank_quantile(a, sort_keys=order, null_placement=place).to_numpy()
                             g = O.rank(v, valid, order == "descending", place == "at_start", "quantile")
                             assert (w.view(np.uint64) == g.view(np.uint64)).all(), (dt, n, order, place, "quantile")
+                            w = pc.rank_normal(a, sort_keys=order, null_placement=place).to_numpy()
+                            g = O.rank(v, valid, order == "descending", place == "at_start", "normal")
+                            assert P.max_ulps(w, g) <= P.RANK_NORMAL_ULPS, (dt, n, order, place, "normal")
+
+
+# NormalPPF's known answers in the reference: cpp/src/arrow/util/math_test.cc:28-82 (Scipy's norm.ppf and Wichura's paper;
+# EXPECT_DOUBLE_EQ = within 4 ULPs), and the rank_normal answers of TestRankQuantile, kernels/vector_sort_test.cc:2726-2790
+# (compared with atol 1e-8 there, :2656-2660).
+PPF_VECTORS = [(0.0, -np.inf), (0.001, -3.090232306167813), (0.01, -2.3263478740408408), (0.02, -2.053748910631823),
+               (0.03, -1.880793608151251), (0.04, -1.75068607125217), (0.05, -1.6448536269514729), (0.06, -1.5547735945968535),
+               (0.07, -1.4757910281791706), (0.08, -1.4050715603096329), (0.09, -1.3407550336902165), (0.1, -1.2815515655446004),
+               (0.2, -0.8416212335729142), (0.3, -0.5244005127080409), (0.4, -0.2533471031357997), (0.5, 0.0),
+               (0.6, 0.2533471031357997), (0.7, 0.5244005127080407), (0.8, 0.8416212335729143), (0.9, 1.2815515655446004),
+               (0.91, 1.3407550336902165), (0.92, 1.4050715603096329), (0.93, 1.475791028179171), (0.94, 1.5547735945968535),
+               (0.95, 1.6448536269514722), (0.96, 1.7506860712521692), (0.97, 1.8807936081512509), (0.98, 2.0537489106318225),
+               (0.99, 2.3263478740408408), (0.999, 3.090232306167813), (1.0, np.inf),
+               (0.25, -0.6744897501960817), (0.001, -3.090232306167814), (1e-20, -9.262340089798408)]
+RANK_NORMAL_VECTORS = [   # (values, valid, order, null placement, expected)
+    ([1, 2, 1, 2, 1], None, "ascending", "at_end", [-0.5244005127080409, 0.8416212335729143, -0.5244005127080409, 0.8416212335729143, -0.5244005127080409]),
+    ([1, 2, 1, 2, 1], None, "descending", "at_start", [0.5244005127080407, -0.8416212335729142, 0.5244005127080407, -0.8416212335729142, 0.5244005127080407]),
+    ([0, 1, 0, 2, 0], [0, 1, 0, 1, 0], "ascending", "at_start", [-0.5244005127080409, 0.5244005127080407, -0.5244005127080409, 1.2815515655446004, -0.5244005127080409]),
+    ([0, 1, 0, 2, 0], [0, 1, 0, 1, 0], "ascending", "at_end", [0.5244005127080407, -1.2815515655446004, 0.5244005127080407, -0.5244005127080409, 0.5244005127080407]),
+    ([0, 1, 0, 2, 0], [0, 1, 0, 1, 0], "descending", "at_start", [-0.5244005127080409, 1.2815515655446004, -0.5244005127080409, 0.5244005127080407, -0.5244005127080409]),
+    ([0, 1, 0, 2, 0], [0, 1, 0, 1, 0], "descending", "at_end", [0.5244005127080407, -0.5244005127080409, 0.5244005127080407, -1.2815515655446004, 0.5244005127080407]),
+    ([7, 5, 5, 4, 4, 3, 3, 3, 2, 1], None, "ascending", "at_end",
+     [1.6448536269514722, 0.8416212335729143, 0.8416212335729143, 0.2533471031357997, 0.2533471031357997, -0.38532046640756773,
+      -0.38532046640756773, -0.38532046640756773, -1.0364333894937898, -1.6448536269514729]),
+    ([7, 5, 5, 4, 4, 3, 3, 3, 2, 1], None, "descending", "at_start",
+     [-1.6448536269514729, -0.8416212335729142, -0.8416212335729142, -0.2533471031357997, -0.2533471031357997, 0.38532046640756773,
+      0.38532046640756773, 0.38532046640756773, 1.0364333894937898, 1.6448536269514722]),
+    ([0], [0], "ascending", "at_end", [0.0]),
+]
+
+
+def test_oracle_normal_ppf_and_rank_normal_against_the_references_known_answers():
+    from . import parity_cases as P
+
+    for p, want in PPF_VECTORS:
+        got = float(O.normal_ppf(np.array([p]))[0])
+        assert P.max_ulps([got], [want]) <= 4, (p, got, want)
+    for v, valid, order, place, want in RANK_NORMAL_VECTORS:
+        got = O.rank(np.array(v, np.int64), None if valid is None else np.array(valid, bool), order == "descending", place == "at_start", "normal")
+        assert np.allclose(got, want, rtol=0, atol=1e-8) and P.max_ulps(got, want) <= 4, (v, order, place, got)
