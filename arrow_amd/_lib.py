@@ -250,6 +250,7 @@ SIGNATURES = {
     "arx_group_edge_rows": (_int, [_p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
     "arx_ree_bool_expand": (_int, [_p, _int, _i64, _span, _i64, _i64, _p, _p, _p]),
     "arx_snappy_decompress_pages": (_int, [_p, _p, _i64, _p, _p, _p]),
+    "arx_gzip_decompress_pages": (_int, [_p, _p, _i64, _p, _p, _p]),
     "arx_cast_numeric": (_int, [_span, _int, _int, _int, _int, _p, _sz, _p, _p]),
     "arx_groupby_mean_i64_finalize": (_int, [_p, _p, _p, _p, _p, _i64, _int, _u32, _p, _p, _p, _p]),
     "arx_groupby_sum_i64_merge_records": (_int, [_p, _i64, _p, _i64, _p]),

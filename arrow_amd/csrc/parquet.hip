@@ -1009,6 +1009,349 @@ __global__ __launch_bounds__(kBlock) void levels_ge_bitmap_kernel(const uint32_t
   if (ones != nullptr && lane == 0 && local != 0) atomicAdd(ones, local);
 }
 
+// ---------------------------------------------------------------------------
+// GZIP / zlib page decompression on the device — GZipCodec::Decompress (cpp/src/arrow/util/compression_zlib.cc:88-180:
+// inflateInit2 with window bits 15 | 32 = header auto-detection).  zlib is a bundled third-party dependency
+// (cpp/thirdparty/versions.txt:122 pins 1.3.1), not vendored in the tree: the formats are restated from their published
+// specifications — RFC 1952 (gzip member: 10-byte header, optional FEXTRA / FNAME / FCOMMENT / FHCRC, deflate stream,
+// CRC-32 + ISIZE), RFC 1950 (zlib: CMF / FLG, deflate stream, Adler-32) and RFC 1951 (deflate: stored, fixed-Huffman and
+// dynamic-Huffman blocks; canonical codes packed most-significant bit first into a least-significant-bit-first stream;
+// length / distance symbols with extra bits; a 32 KB window).  Checksums are skipped, ISIZE is checked.
+//
+// One wave per page, as for Snappy: the symbol stream is sequential, so all 64 lanes decode it in lockstep (uniform control
+// flow, every lane holds the same bit buffer) out of an input window staged in LDS; a literal is one byte store by lane 0, a
+// match is copied by the 64 lanes.  Per wave in LDS: the input window, a 10-bit lookup table for the literal / length code
+// and a 9-bit one for the distance code (entry = symbol << 4 | code length; the bit-reversed code is the index, every
+// longer code falls back to the canonical walk over count[] / symbol[]), the code lengths being read.
+constexpr uint32_t kInfWin = 2048;          // bytes of input staged per wave
+constexpr int kInfLitBits = 10;
+constexpr int kInfDistBits = 9;
+struct __attribute__((aligned(16))) InflateLds {
+  uint8_t win[kWavesPerBlock][kInfWin + 16];
+  uint16_t lit_lut[kWavesPerBlock][1 << kInfLitBits];
+  uint16_t dist_lut[kWavesPerBlock][1 << kInfDistBits];
+  uint16_t lit_sym[kWavesPerBlock][288];     // symbols sorted by (code length, symbol): the canonical walk's table
+  uint16_t dist_sym[kWavesPerBlock][32];
+  uint16_t lit_count[kWavesPerBlock][16];    // codes per length
+  uint16_t dist_count[kWavesPerBlock][16];
+  uint8_t lengths[kWavesPerBlock][320];      // code lengths of the block being set up (288 + 32)
+  uint8_t staged[kWavesPerBlock][320];       // ... as the code-length code delivers them (literal / length, then distance)
+};
+
+struct InflateBits {
+  const uint8_t* in;        // the page's compressed bytes (global)
+  uint8_t* win;             // this wave's LDS window: win[k] = in[win_base + k]
+  uint32_t n_in, win_base, ip;   // ip: next input byte not yet in the bit buffer
+  uint64_t buf;             // bit buffer, next bit = bit 0
+  int cnt;                  // valid bits in buf
+  int lane;
+  uint32_t overrun;         // bits requested past the end of the input
+};
+
+// the window covers [win_base, win_base + kInfWin); refilled by the 64 lanes (16 bytes each, twice) when ip leaves it
+__device__ __forceinline__ void inflate_stage(InflateBits& b) {
+  b.win_base = b.ip;
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t k = static_cast<uint32_t>(b.lane) * 16; k < kInfWin + 16; k += 64 * 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t at = b.win_base + k + j;
+      b.win[k + j] = at < b.n_in ? b.in[at] : 0;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void inflate_refill(InflateBits& b) {
+  while (b.cnt <= 56) {
+    if (b.ip - b.win_base >= kInfWin) inflate_stage(b);
+    const uint64_t byte = b.ip < b.n_in ? b.win[b.ip - b.win_base] : 0;   // (past the end: zeros, counted by `overrun` when used)
+    b.buf |= byte << b.cnt;
+    b.cnt += 8;
+    ++b.ip;
+  }
+}
+
+__device__ __forceinline__ uint32_t inflate_take(InflateBits& b, int n) {   // n <= 32
+  if (b.cnt < n) inflate_refill(b);
+  const uint32_t v = static_cast<uint32_t>(b.buf & ((1ull << n) - 1ull));
+  b.buf >>= n;
+  b.cnt -= n;
+  return v;
+}
+
+// bytes the decoder has really consumed: what went into the bit buffer minus the whole bytes still in it
+__device__ __forceinline__ uint32_t inflate_consumed(const InflateBits& b) { return b.ip - static_cast<uint32_t>(b.cnt >> 3); }
+
+// canonical walk (any code length up to 15) over the next bits; returns the symbol or 0xFFFF for an unassigned code
+__device__ __forceinline__ uint32_t inflate_walk(InflateBits& b, const uint16_t* count, const uint16_t* symbol) {
+  if (b.cnt < 15) inflate_refill(b);
+  uint32_t code = 0, first = 0, index = 0;
+  uint64_t w = b.buf;
+  for (int len = 1; len <= 15; ++len) {
+    code |= static_cast<uint32_t>(w & 1u);
+    w >>= 1;
+    const uint32_t c = count[len];
+    if (code < first + c) {
+      b.buf >>= len;
+      b.cnt -= len;
+      return symbol[index + (code - first)];
+    }
+    index += c;
+    first = (first + c) << 1;
+    code <<= 1;
+  }
+  return 0xFFFFu;
+}
+
+// Builds count[] / symbol[] and the lookup table of one code from lengths[0, n).  Returns 0, or 4 for an over-subscribed
+// code (an incomplete code is accepted, as zlib accepts the single-code distance tables real encoders emit; its unassigned
+// codes fail when they are met).  Wave-uniform; lane 0 writes the serial tables, all lanes fill the lookup table.
+__device__ __forceinline__ uint32_t inflate_build(const uint8_t* lengths, int n, uint16_t* count, uint16_t* symbol, uint16_t* lut,
+                                                   int lut_bits, int lane) {
+  __builtin_amdgcn_wave_barrier();
+  uint32_t cnt[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) cnt[l] = 0;
+  for (int s = 0; s < n; ++s) ++cnt[lengths[s]];
+  int left = 1;
+  for (int l = 1; l <= 15; ++l) {
+    left = (left << 1) - static_cast<int>(cnt[l]);
+    if (left < 0) return 4;
+  }
+  uint32_t offs[16], next_code[16];
+  offs[1] = 0;
+  next_code[0] = 0;
+  next_code[1] = 0;
+  for (int l = 1; l < 15; ++l) {
+    offs[l + 1] = offs[l] + cnt[l];
+    next_code[l + 1] = (next_code[l] + cnt[l]) << 1;
+  }
+  if (lane == 0) {
+    count[0] = 0;
+    for (int l = 1; l <= 15; ++l) count[l] = static_cast<uint16_t>(cnt[l]);
+  }
+  for (uint32_t k = lane; k < (1u << lut_bits); k += 64) lut[k] = 0;
+  __builtin_amdgcn_wave_barrier();
+  // serial: a symbol's code is next_code[its length] + the number of earlier symbols of that length
+  for (int s = 0; s < n; ++s) {
+    const int l = lengths[s];
+    if (l == 0) continue;
+    const uint32_t code = next_code[l]++;
+    const uint32_t at = offs[l]++;
+    if (lane == 0) symbol[at] = static_cast<uint16_t>(s);
+    if (l <= lut_bits) {
+      uint32_t rev = 0;
+      for (int k = 0; k < l; ++k) rev |= ((code >> k) & 1u) << (l - 1 - k);
+      const uint16_t entry = static_cast<uint16_t>((s << 4) | l);
+      for (uint32_t k = rev + (static_cast<uint32_t>(lane) << l); k < (1u << lut_bits); k += 64u << l) lut[k] = entry;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  return 0;
+}
+
+__device__ __forceinline__ uint32_t inflate_symbol(InflateBits& b, const uint16_t* lut, int lut_bits, const uint16_t* count,
+                                                   const uint16_t* symbol) {
+  if (b.cnt < 15) inflate_refill(b);
+  const uint16_t e = lut[b.buf & ((1u << lut_bits) - 1u)];
+  const int l = e & 15;
+  if (l != 0) {
+    b.buf >>= l;
+    b.cnt -= l;
+    return e >> 4;
+  }
+  return inflate_walk(b, count, symbol);
+}
+
+// status: 0 ok, 1 bad gzip / zlib header or the stream does not produce dst_size bytes, 2 the stream runs past its block or
+// the output, 3 a distance reaches before the output, 4 an invalid Huffman code (over-subscribed table, unassigned code,
+// bad block type or stored-block length)
+__global__ __launch_bounds__(kBlock) void inflate_pages_kernel(const uint8_t* __restrict__ src, const ArxSnappyPage* __restrict__ pages,
+                                                               int64_t npages, uint8_t* dst, uint32_t* __restrict__ status) {
+  __shared__ InflateLds lds;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t pg = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  if (pg >= npages) return;   // wave-uniform
+  const ArxSnappyPage p = pages[pg];
+  const uint8_t* in = src + p.src_offset;
+  uint8_t* out = dst + p.dst_offset;
+  const uint32_t n_in = p.src_size, ulen = p.dst_size;
+  uint32_t err = 0, start = 0, trailer = 0;
+  // ---- container header (auto-detection, as inflateInit2 with 15 | 32)
+  if (n_in >= 18 && in[0] == 0x1F && in[1] == 0x8B) {          // gzip member (RFC 1952)
+    const uint32_t flg = in[3];
+    if (in[2] != 8 || (flg & 0xE0u) != 0) err = 1;
+    uint32_t at = 10;
+    if (!err && (flg & 4u)) {                                  // FEXTRA: 2-byte length + that many bytes
+      if (at + 2 > n_in) err = 1; else at += 2 + (in[at] | (static_cast<uint32_t>(in[at + 1]) << 8));
+    }
+    for (uint32_t bit = 8; bit <= 16 && !err; bit <<= 1) {     // FNAME, FCOMMENT: zero-terminated
+      if (flg & bit) {
+        while (at < n_in && in[at] != 0) ++at;
+        ++at;
+      }
+    }
+    if (!err && (flg & 2u)) at += 2;                           // FHCRC
+    if (at + 8 > n_in) err = 1;
+    start = at;
+    trailer = 8;
+    if (!err) {
+      const uint32_t isize = in[n_in - 4] | (static_cast<uint32_t>(in[n_in - 3]) << 8) | (static_cast<uint32_t>(in[n_in - 2]) << 16) |
+                             (static_cast<uint32_t>(in[n_in - 1]) << 24);
+      if (isize != ulen) err = 1;
+    }
+  } else if (n_in >= 6 && (in[0] & 0x0Fu) == 8 && ((static_cast<uint32_t>(in[0]) << 8) | in[1]) % 31u == 0 && (in[1] & 0x20u) == 0) {
+    start = 2;                                                 // zlib stream (RFC 1950), no preset dictionary
+    trailer = 4;
+  } else {
+    err = 1;
+  }
+  InflateBits b{in, lds.win[wave], err ? 0u : n_in - trailer, start, start, 0, 0, lane, 0};
+  uint16_t* lit_lut = lds.lit_lut[wave];
+  uint16_t* dist_lut = lds.dist_lut[wave];
+  uint8_t* lengths = lds.lengths[wave];
+  uint8_t* staged = lds.staged[wave];
+  uint32_t op = 0;
+  bool pending = false;       // output bytes stored since the last fence (a match may read them)
+  if (!err) inflate_stage(b);
+  bool last = false;
+  while (!err && !last) {
+    last = inflate_take(b, 1) != 0;
+    const uint32_t type = inflate_take(b, 2);
+    if (type == 0) {
+      // stored: to the next byte boundary, LEN, ~LEN, LEN bytes
+      const int drop = b.cnt & 7;
+      b.buf >>= drop;
+      b.cnt -= drop;
+      const uint32_t len = inflate_take(b, 16), nlen = inflate_take(b, 16);
+      if ((len ^ 0xFFFFu) != nlen) { err = 4; break; }
+      const uint32_t from = inflate_consumed(b);
+      if (from > b.n_in || len > b.n_in - from || len > ulen - op) { err = 2; break; }
+      for (uint32_t j = lane; j < len; j += 64) out[op + j] = in[from + j];
+      op += len;
+      pending = true;
+      b.ip = from + len;       // the bit buffer is dropped: the next block starts at a byte boundary
+      b.buf = 0;
+      b.cnt = 0;
+      inflate_stage(b);
+      continue;
+    }
+    if (type == 3) { err = 4; break; }
+    int nlit = 288, ndist = 30;
+    if (type == 1) {
+      // fixed code (RFC 1951 3.2.6): 8 bits for 0-143, 9 for 144-255, 7 for 256-279, 8 for 280-287; 5 bits for every distance
+      __builtin_amdgcn_wave_barrier();
+      for (int s = lane; s < 288; s += 64) lengths[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+      for (int s = lane; s < 32; s += 64) lengths[288 + s] = 5;
+      ndist = 32;
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      nlit = static_cast<int>(inflate_take(b, 5)) + 257;
+      ndist = static_cast<int>(inflate_take(b, 5)) + 1;
+      const int ncode = static_cast<int>(inflate_take(b, 4)) + 4;
+      if (nlit > 286 || ndist > 30) { err = 4; break; }
+      // the code-length code: 3 bits each, in the order of 3.2.7
+      const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 19) lengths[lane] = 0;
+      __builtin_amdgcn_wave_barrier();
+      for (int k = 0; k < ncode; ++k) {
+        const uint32_t l = inflate_take(b, 3);
+        if (lane == 0) lengths[order[k]] = static_cast<uint8_t>(l);
+      }
+      __builtin_amdgcn_wave_barrier();
+      // (its tables live where the distance code's will: both are rebuilt below)
+      err = inflate_build(lengths, 19, lds.dist_count[wave], lds.dist_sym[wave], dist_lut, 7, lane);
+      if (err) break;
+      int at = 0;
+      uint32_t prev = 0;
+      while (at < nlit + ndist && !err) {
+        const uint32_t sym = inflate_symbol(b, dist_lut, 7, lds.dist_count[wave], lds.dist_sym[wave]);
+        uint32_t value = 0, repeat = 1;
+        if (sym < 16) {
+          value = sym;
+        } else if (sym == 16) {
+          if (at == 0) { err = 4; break; }
+          value = prev;
+          repeat = 3 + inflate_take(b, 2);
+        } else if (sym == 17) {
+          repeat = 3 + inflate_take(b, 3);
+        } else if (sym == 18) {
+          repeat = 11 + inflate_take(b, 7);
+        } else {
+          err = 4;
+          break;
+        }
+        if (at + static_cast<int>(repeat) > nlit + ndist) { err = 4; break; }
+        for (uint32_t r = 0; r < repeat; ++r, ++at) {
+          if (lane == 0) staged[at] = static_cast<uint8_t>(value);
+        }
+        prev = value;
+      }
+      if (err) break;
+      __builtin_amdgcn_wave_barrier();
+      // lengths[0, nlit) literal / length, lengths[288, 288 + ndist) distance; the end-of-block symbol needs a code
+      for (int s = lane; s < 288; s += 64) lengths[s] = s < nlit ? staged[s] : 0;
+      for (int s = lane; s < 32; s += 64) lengths[288 + s] = s < ndist ? staged[nlit + s] : 0;
+      __builtin_amdgcn_wave_barrier();
+      if (lengths[256] == 0) { err = 4; break; }
+      nlit = 288;
+      ndist = 32;
+    }
+    err = inflate_build(lengths, nlit, lds.lit_count[wave], lds.lit_sym[wave], lit_lut, kInfLitBits, lane);
+    if (err) break;
+    err = inflate_build(lengths + 288, ndist, lds.dist_count[wave], lds.dist_sym[wave], dist_lut, kInfDistBits, lane);
+    if (err) break;
+    // ---- the block's symbols
+    for (;;) {
+      const uint32_t sym = inflate_symbol(b, lit_lut, kInfLitBits, lds.lit_count[wave], lds.lit_sym[wave]);
+      if (sym < 256) {
+        if (op >= ulen) { err = 2; break; }
+        if (lane == 0) out[op] = static_cast<uint8_t>(sym);
+        ++op;
+        pending = true;
+        continue;
+      }
+      if (sym == 256) break;
+      if (sym > 285) { err = 4; break; }
+      // length: base + extra bits (3.2.5)
+      const uint32_t ls = sym - 257;
+      uint32_t len, lextra;
+      if (ls < 8) { len = 3 + ls; lextra = 0; }
+      else if (ls == 28) { len = 258; lextra = 0; }
+      else { lextra = (ls >> 2) - 1; len = 3 + ((4u + (ls & 3u)) << lextra); }
+      if (lextra) len += inflate_take(b, static_cast<int>(lextra));
+      const uint32_t ds = inflate_symbol(b, dist_lut, kInfDistBits, lds.dist_count[wave], lds.dist_sym[wave]);
+      if (ds > 29) { err = 4; break; }
+      uint32_t dist, dextra;
+      if (ds < 4) { dist = 1 + ds; dextra = 0; }
+      else { dextra = (ds >> 1) - 1; dist = 1 + ((2u + (ds & 1u)) << dextra); }
+      if (dextra) dist += inflate_take(b, static_cast<int>(dextra));
+      if (dist > op) { err = 3; break; }
+      if (len > ulen - op) { err = 2; break; }
+      // the source bytes may be literals lane 0 stored, or the previous match's bytes from any lane: made visible, and (the
+      // SIMT emulator runs lanes in any order between rendezvous points) every lane past its stores, before they are read
+      if (pending) {
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        pending = false;
+      }
+      const uint8_t* from = out + (op - dist);
+      if (dist >= len) {
+        for (uint32_t j = lane; j < len; j += 64) out[op + j] = from[j];
+      } else {
+        for (uint32_t j = lane; j < len; j += 64) out[op + j] = from[j % dist];
+      }
+      op += len;
+      pending = true;
+    }
+  }
+  if (!err && (op != ulen || inflate_consumed(b) > b.n_in)) err = op != ulen ? 1 : 2;
+  if (lane == 0) status[pg] = err;
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -1622,6 +1965,20 @@ int arx_snappy_decompress_pages(const void* compressed, const ArxSnappyPage* pag
                        static_cast<const uint8_t*>(compressed), pages, num_pages, static_cast<uint8_t*>(out), status);
   }
   ARX_CHECK_LAUNCH("snappy_decode_kernel");
+  return ARX_OK;
+}
+
+int arx_gzip_decompress_pages(const void* compressed, const ArxSnappyPage* pages, int64_t num_pages, void* out,
+                              uint32_t* status, void* stream) {
+  if (num_pages < 0 || (num_pages > 0 && (compressed == nullptr || pages == nullptr || out == nullptr || status == nullptr))) {
+    set_error("bad arguments to arx_gzip_decompress_pages");
+    return ARX_INVALID;
+  }
+  if (num_pages == 0) return ARX_OK;
+  const unsigned grid = static_cast<unsigned>(ceil_div(num_pages, kWavesPerBlock));
+  hipLaunchKernelGGL(inflate_pages_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), static_cast<const uint8_t*>(compressed),
+                     pages, num_pages, static_cast<uint8_t*>(out), status);
+  ARX_CHECK_LAUNCH("inflate_pages_kernel");
   return ARX_OK;
 }
 

@@ -307,6 +307,8 @@ def scan_rle_runs(data, bit_width: int, num_values: int, out_base: int = 0, byte
 # the COMPRESSED bytes cross PCIe and no host codec runs.  Pages with run headers to walk (levels inside a V1 block,
 # dictionary indices, delta blocks) still go through the host codec: the walk needs their bytes.
 DEVICE_SNAPPY = True
+# GZIP pages of the same kinds go the same way (arx_gzip_decompress_pages: RFC 1952 / 1950 / 1951 on the device).
+DEVICE_GZIP = True
 SNAPPY_PAGE_DTYPE = np.dtype([("src_offset", "<u8"), ("src_size", "<u4"), ("dst_size", "<u4"), ("dst_offset", "<u8")])  # struct ArxSnappyPage
 
 
@@ -399,6 +401,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
     plain_segments = []       # host-decoded PLAIN pages: (byte position among the PLAIN values, bytes)
     plain_pos = 0             # bytes of PLAIN values so far (host- and device-decoded pages alike)
     device_snappy_pages = []  # (compressed block, uncompressed size, byte position among the PLAIN values)
+    device_codec = (DEVICE_SNAPPY and codec == "SNAPPY") or (DEVICE_GZIP and codec == "GZIP")   # pages decompressed in HBM
     plain_pages = []          # BYTE_ARRAY only: (page value bytes, number of values)
     bool_bytes, bool_runs = bytearray(), []   # BOOLEAN only: every page becomes runs of one shared table
     split_pages = []                            # BYTE_STREAM_SPLIT: (first dense slot, page bytes, count)
@@ -415,7 +418,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
         if ptype == _PAGE_DATA:
             dh = hdr[5]
             nvals, enc = dh[1], dh[2]
-            on_device = (DEVICE_SNAPPY and codec == "SNAPPY" and enc == _ENC_PLAIN and max_def_level == 0 and
+            on_device = (device_codec and enc == _ENC_PLAIN and max_def_level == 0 and
                          max_rep_level == 0 and not is_binary and not is_bool and hdr[2] == nvals * width)
             if on_device:
                 device_snappy_pages.append((bytes(payload), hdr[2], plain_pos))
@@ -446,7 +449,7 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
             rlevels = bytes(payload[:rl])                             # V2 levels are never compressed: repetition,
             levels = bytes(payload[rl: rl + dl])                      # then definition levels, then the values
             body = payload[rl + dl:]
-            on_device = (DEVICE_SNAPPY and codec == "SNAPPY" and dh.get(7, True) and enc == _ENC_PLAIN and
+            on_device = (device_codec and dh.get(7, True) and enc == _ENC_PLAIN and
                          not is_binary and not is_bool)
             if on_device:
                 valid_here = nvals
@@ -596,14 +599,17 @@ def read_column_chunk(raw, col, max_def_level: int, device=None, stats: dict | N
             d_src = to_device(np.frombuffer(b"".join(b for b, _, _ in device_snappy_pages) + b"\0", dtype=np.uint8), device)
             d_table = to_device(table.view(np.uint8), device)
             status = torch.zeros(len(device_snappy_pages), dtype=torch.int32, device=device)
-            check(lib.arx_snappy_decompress_pages(d_src.data_ptr(), d_table.data_ptr(), len(device_snappy_pages),
-                                                  dense_buf.data_ptr(), status.data_ptr(), stream))
+            decompress = lib.arx_gzip_decompress_pages if codec == "GZIP" else lib.arx_snappy_decompress_pages
+            check(decompress(d_src.data_ptr(), d_table.data_ptr(), len(device_snappy_pages),
+                             dense_buf.data_ptr(), status.data_ptr(), stream))
             bad = status.cpu().numpy()
             if bad.any():
-                raise ArrowInvalid(f"Parquet: corrupt Snappy page (device decoder status {int(bad[bad != 0][0])} on page "
+                name = "GZIP" if codec == "GZIP" else "Snappy"
+                raise ArrowInvalid(f"Parquet: corrupt {name} page (device decoder status {int(bad[bad != 0][0])} on page "
                                    f"{int(np.nonzero(bad)[0][0])} of the chunk's device-decoded pages)")
             if stats is not None:
-                stats["device_snappy_pages"] = stats.get("device_snappy_pages", 0) + len(device_snappy_pages)
+                key = "device_gzip_pages" if codec == "GZIP" else "device_snappy_pages"
+                stats[key] = stats.get(key, 0) + len(device_snappy_pages)
     if delta_pages:
         # one byte buffer, one miniblock table and one page table for the chunk: ONE launch sequence (unpack + prefix
         # sum) for all its pages — every page restarts the recurrence at its own first value, so pages own whole tiles

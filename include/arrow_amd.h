@@ -1269,6 +1269,18 @@ typedef struct ArxSnappyPage {
 int arx_snappy_decompress_pages(const void* compressed, const ArxSnappyPage* pages, int64_t num_pages, void* out,
                                 uint32_t* status, void* stream);
 
+/* GZIP page decompression on the device — GZipCodec::Decompress (cpp/src/arrow/util/compression_zlib.cc:88-180: inflateInit2
+ * with window bits 15 | 32, i.e. gzip / zlib header auto-detection).  zlib is a bundled third-party dependency
+ * (cpp/thirdparty/versions.txt:122 pins 1.3.1), not vendored in the tree: the formats are restated from RFC 1952 (gzip),
+ * RFC 1950 (zlib) and RFC 1951 (deflate: stored, fixed and dynamic Huffman blocks).  Same page table and calling convention
+ * as arx_snappy_decompress_pages (one wave decodes one page; the symbol stream is sequential, matches are copied by 64
+ * lanes); checksums are skipped, a gzip member's ISIZE must equal dst_size.  status[i] (device): 0 ok, 1 bad container header
+ * or the stream does not produce dst_size bytes, 2 the stream runs past its block or the output, 3 a distance before the
+ * start of the output, 4 an invalid Huffman code / block type / stored length — read it back before trusting the bytes (a
+ * corrupt page never writes outside its dst range).  Asynchronous. */
+int arx_gzip_decompress_pages(const void* compressed, const ArxSnappyPage* pages, int64_t num_pages, void* out,
+                              uint32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

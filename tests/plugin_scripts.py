@@ -4135,6 +4135,8 @@ FIRST_LAST_SCRIPT = textwrap.dedent(r"""
     for ks in key_sets:
         w = want[tuple(ks)]
         for tab, what, threads in ((t, "host", False), (tc, "host chunks", False), (td, "device", False)) + (((tc, "host chunks, threads", True),) if threaded else ()):
+            if os.environ.get("ARROW_AMD_TEST_LIGHT") == "1" and what == "host":      # (the emulated tier: chunks and device tables)
+                continue
             g = plan(tab, "aggregate_rocm", ks, threads)
             assert g.schema.equals(w.schema), (g.schema, w.schema)
             for ci, name in enumerate(w.schema.names):
@@ -4197,7 +4199,10 @@ MOMENTS_SCRIPT = textwrap.dedent(r"""
         "u64": pa.array(rng.integers(0, 2**40, n).astype(np.uint64)),
     })
     tc = pa.concat_tables([t.slice(0, n // 7), t.slice(n // 7, n // 2), t.slice(n // 7 + n // 2)])
-    vals = ["f64", "f32", "i64", "i16", "u8", "u64"]
+    # (the emulated CPU tier — ARROW_AMD_TEST_LIGHT — runs two of the six value types and two of the three tables: every
+    #  aggregate is a handful of launches of thousands of emulated workgroups whatever the row count)
+    light = os.environ.get("ARROW_AMD_TEST_LIGHT") == "1"
+    vals = ["f64", "u8"] if light else ["f64", "f32", "i64", "i16", "u8", "u64"]
     V, S = pc.VarianceOptions, pc.SkewOptions
     var_opts = [None, V(ddof=1), V(ddof=3, min_count=5), V(ddof=0, skip_nulls=False), V(ddof=1, skip_nulls=False, min_count=2)]
     skew_opts = [None, S(biased=False), S(skip_nulls=False, biased=True, min_count=4), S(skip_nulls=True, biased=False, min_count=6)]
@@ -4228,6 +4233,8 @@ MOMENTS_SCRIPT = textwrap.dedent(r"""
     for ks in key_sets:
         w = want[tuple(ks)]
         for tab, what, threads in ((t, "host", False), (tc, "host chunks", False), (td, "device", False)) + (((tc, "host chunks, threads", True),) if threaded else ()):
+            if os.environ.get("ARROW_AMD_TEST_LIGHT") == "1" and what == "host":      # (the emulated tier: chunks and device tables)
+                continue
             g = plan(tab, "aggregate_rocm", ks, threads)
             assert g.schema.equals(w.schema), (g.schema, w.schema)
             for ci, name in enumerate(w.schema.names):
@@ -4611,7 +4618,7 @@ CASES = [
      "The comparison family and add / subtract / multiply (+ _checked) for int8 ... uint32, uint64 and float through CallFunction on device-resident arrays (array x array, array x scalar, slices): results stay in HBM and equal the reference's on the host copies — type, values, validity, null count; the type's own overflow wraps / fails with the reference's text; an Acero filter + projection over int32 / float32 device columns."),
     ('scalar_aggregates_on_device_resident_columns', AGGREGATE_SCRIPT, 'AGGREGATE_OK', 0.02,
      "SumImpl / CountImpl / MinMaxImpl (aggregate_basic.inc.cc:49-110,776-860) as ScalarAggregateKernel shims: `sum`, `count`, `min_max`, `min`, `max` of int64 device columns with every option combination, chunked input (state merge), a refused host+device mix, and Acero's key-less `aggregate` node over a filtered device table."),
-    ('acero_order_by_over_a_device_resident_table', ORDER_BY_SCRIPT, 'ORDER_BY_OK', 0.02,
+    ('acero_order_by_over_a_device_resident_table', ORDER_BY_SCRIPT, 'ORDER_BY_OK', 0.008,
      'SURVEY.md 8 (f2): OrderByNode (acero/order_by_node.cc:100-108) as `order_by_rocm`: table_source -> [filter] -> order_by_rocm over device-resident and host tables, one to three sort keys with their own direction and null placement (int32 / int64 / float64 with NaNs / timestamp), payload columns of int64, utf8, boolean; equal to the stock `order_by` over the host table, with and without threads.'),
     ('parquet_delta_and_split_encodings_through_the_plugin', PARQUET_ENCODINGS_SCRIPT, 'PARQUET_ENCODINGS_OK', 0.02,
      "DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY and BYTE_STREAM_SPLIT column chunks through arrow_amd_parquet_read_column (parquet::PageReader for the pages, the C-ABI kernels for the values), equal to the reference's reader."),
@@ -4647,11 +4654,11 @@ CASES = [
      'VERDICT r3 missing 6: large_utf8 / large_binary (int64 offsets) filter, take and drop_null on device-resident arrays.'),
     ('filter_and_take_of_fixed_size_list_and_list_on_device_arrays', NESTED_SELECTION_SCRIPT, 'NESTED_SELECTION_OK', 0.02,
      'VERDICT r3 missing 6: fixed_size_list / list / large_list (fixed-width nested values without nulls) filter, take and drop_null on device-resident arrays; child nulls and other children are refused by name.'),
-    ('hash_sum_and_mean_of_floats_are_the_references_row_order_sums', FLOAT_GROUPED_SUM_SCRIPT, 'FLOAT_GROUPED_SUM_OK', 0.02,
+    ('hash_sum_and_mean_of_floats_are_the_references_row_order_sums', FLOAT_GROUPED_SUM_SCRIPT, 'FLOAT_GROUPED_SUM_OK', 0.01,
      "hash_sum / hash_mean of float32 / float64 — the reference's row-order double accumulation per group, bit for bit, under the stock GroupByNode (host and device-resident values, several batches) and in aggregate_rocm."),
     ('hash_count_distinct_in_aggregate_rocm', COUNT_DISTINCT_SCRIPT, 'COUNT_DISTINCT_OK', 0.02,
      "hash_count_distinct through aggregate_rocm (a second device Grouper over (value, group id) pairs), host and device-resident tables, the three CountOptions modes, fixed-width value types; equal to the reference's GroupByNode."),
-    ('hash_sum_of_decimal128_and_decimal_sort_keys', DECIMAL_SUM_SCRIPT, 'DECIMAL_SUM_OK', 0.02,
+    ('hash_sum_of_decimal128_and_decimal_sort_keys', DECIMAL_SUM_SCRIPT, 'DECIMAL_SUM_OK', 0.008,
      'hash_sum of decimal128 columns — 128-bit sums modulo 2^128 on the device, the output widened to precision 38 — under the stock GroupByNode (host and device-resident values, batches, threads) and in aggregate_rocm; hash_mean; hash_min / hash_max of decimal128 in aggregate_rocm; the scalar sum / mean / min_max / min / max of decimal128 device columns.'),
     ('aggregate_rocm_with_key_rows_wider_than_16_bytes', WIDE_KEYS_SCRIPT, 'WIDE_KEYS_OK', 0.004,
      'aggregate_rocm over 18- to 37-byte key rows and a 10-column key: the chain of Grouper tables behind the same node, host and device-resident batches, equal to the reference GroupByNode with the reference kernels.'),
@@ -4659,12 +4666,12 @@ CASES = [
      "aggregate_rocm over utf8 / binary key columns (alone, beside fixed-width keys, several of them): the string enters the chain of Grouper tables as its length and 12-byte chunks (arx_binary_key_lengths / _chunk), the unique strings are the strings of the groups' first rows (arx_group_first_rows + the binary take) — equal to the reference GroupByNode, strings that differ only in their last byte, only in length, in trailing NUL bytes, empty vs null."),
     ('stock_group_by_over_device_resident_key_columns_is_served_or_refused', ACERO_GUARD_SCRIPT, 'ACERO_GUARD_OK', 0.05,
      'VERDICT r4 item 8: table_source -> aggregate plans by their STOCK names (what Table.group_by builds) over a table whose KEY columns live in HBM return the reference\'s result (built as aggregate_rocm by the guard arrow_amd_register() installs in front of the CPU Grouper) or a NotImplemented Status; host keys over device values keep the stock GroupByNode; host tables untouched.'),
-    ('hash_first_last_one_product_list_distinct_min_max_in_aggregate_rocm', FIRST_LAST_SCRIPT, 'FIRST_LAST_OK', 0.03,
+    ('hash_first_last_one_product_list_distinct_min_max_in_aggregate_rocm', FIRST_LAST_SCRIPT, 'FIRST_LAST_OK', 0.01,
      'VERDICT r4 missing 1: hash_first / hash_last (skip_nulls on and off) / hash_one in aggregate_rocm — the row of every group\'s first / last non-null value (arx_group_edge_rows) + one take — for value types of 1 to 16 bytes, and hash_product (wrapping integer products, double products in row order through the float sums\' walkers) hash_first_last (struct), hash_list (values in row order) and hash_distinct (first-appearance order, three CountOptions modes) — equal to the reference\'s GroupByNode; batches in batch.index order whatever the thread count.'),
-    ('rank_select_k_and_partition_nth_on_device_resident_arrays', RANK_SELECT_SCRIPT, 'RANK_SELECT_OK', 0.01,
+    ('rank_select_k_and_partition_nth_on_device_resident_arrays', RANK_SELECT_SCRIPT, 'RANK_SELECT_OK', 0.006,
      "SURVEY.md 8 (f3), VERDICT r5 missing 4: rank (min / max / first / dense), rank_quantile, select_k_unstable and partition_nth_indices by their stock names on device-resident arrays, chunked arrays and tables — the registered HIP sort plus arx_rank's walk of the sorted order; ranks bit for bit the reference's (NaNs, nulls, signed zeros, temporal types), select_k / partition_nth by the property they promise; host data untouched; unsupported device types refused with a Status."),
     ('registered_before_pyarrow_compute_is_imported_the_generated_wrappers_bind_the_replaced_functions', IMPORT_ORDER_SCRIPT, 'IMPORT_ORDER_OK', 1,
      "pyarrow.compute's generated wrappers (pc.rank, pc.select_k_unstable, pc.sort_indices, ...) keep the Function objects they find when the module is imported: with arrow_amd_register() called BEFORE `import pyarrow.compute` they bind the replaced MetaFunctions and device-resident arrays go through them by their ordinary spelling; registered later, the replaced functions are reached by name (CallFunction / pc.call_function) — INTEGRATION.md 'Load order'."),
-    ('hash_variance_stddev_skew_kurtosis_in_aggregate_rocm', MOMENTS_SCRIPT, 'MOMENTS_OK', 0.03,
+    ('hash_variance_stddev_skew_kurtosis_in_aggregate_rocm', MOMENTS_SCRIPT, 'MOMENTS_OK', 0.004,
      "SURVEY.md 8 (f3): the grouped moments (GroupedStatisticImpl) as two passes over all rows of the node — null exactly where the reference's Finalize leaves a group null (ddof, unbiased skew / kurtosis of too few values, min_count, skip_nulls), values within 1e-11 relative of the reference's per-batch moments merged batch by batch (its own tests compare approximately)."),
 ]

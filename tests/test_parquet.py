@@ -1336,3 +1336,129 @@ def test_parquet_struct_columns_are_refused_by_name(tmp_path):
     pq.write_table(pa.table({"s": pa.array([{"a": 1, "b": [1, 2]}, None])}), path)
     with pytest.raises(arrow_amd._lib.ArrowNotImplementedError, match="3-level LIST chain|not on the gfx950 path"):
         arrow_amd.parquet.read_table(path, columns=["s.b.list.element"], device="cpu")
+
+
+# --------------------------------------------------------------------------- GZIP pages on the device
+def check_gzip_kernel(amd, rng, scale=1):
+    """arx_gzip_decompress_pages vs the reference codec's library (zlib, what GZipCodec wraps): gzip members and zlib streams
+    (the codec auto-detects, compression_zlib.cc:88-95) at levels 0 (stored blocks), 1, 6, 9 and with the fixed Huffman code;
+    empty, one byte, incompressible, long runs, periodic data whose matches overlap their own output, integers; a gzip header
+    with every optional field; truncated / garbled / wrong-size blocks come back with a status and never write outside their
+    destination."""
+    import gzip
+    import zlib
+
+    import torch
+
+    from arrow_amd import _lib
+    from arrow_amd.array import current_stream, default_device, to_device
+
+    lib, dev = _lib.get_lib(), default_device()
+
+    def run(sizes, blocks):
+        pages = np.zeros(len(blocks), SNAPPY_PAGE)
+        so = do = 0
+        for i, (n, b) in enumerate(zip(sizes, blocks)):
+            pages[i] = (so, len(b), n, do)
+            so += len(b)
+            do += n
+        src = to_device(np.frombuffer(b"".join(blocks) + b"\0" * 8, dtype=np.uint8), dev)
+        out = torch.full((max(do, 1) + 64,), 0xEE, dtype=torch.uint8, device=dev)
+        st = torch.full((len(blocks),), 77, dtype=torch.int32, device=dev)
+        table = to_device(pages.view(np.uint8), dev)
+        _lib.check(lib.arx_gzip_decompress_pages(src.data_ptr(), table.data_ptr(), len(blocks), out.data_ptr(),
+                                                 st.data_ptr(), current_stream(dev)))
+        host = out.cpu().numpy()
+        return host[:do].tobytes(), st.cpu().numpy().tolist(), host[do:].tolist()
+
+    raws = [b"", b"a", b"hello hello hello hello", bytes(rng.integers(0, 256, 5000 * scale, dtype=np.uint8)),
+            bytes(np.repeat(rng.integers(0, 4, 300 * scale, dtype=np.uint8), 50)), np.cumsum(rng.integers(-3, 4, 20000 * scale)).tobytes(),
+            b"x" * 100000 * scale, bytes(rng.integers(0, 3, 70000 * scale, dtype=np.uint8)), ("the quick brown fox " * 3000).encode(),
+            np.round(rng.standard_normal(9000 * scale), 1).tobytes()]
+    raws += [bytes(rng.integers(0, 256, period, dtype=np.uint8)) * (3000 // period + 2) for period in (1, 2, 3, 7, 63, 64, 65, 200, 257, 258, 259)]
+    raws += [bytes(rng.integers(0, 256, 33_000, dtype=np.uint8)) * 2]          # matches at the far end of the 32 KB window
+    blocks, sizes, want = [], [], []
+    for r in raws:
+        for level in (1, 6, 9, 0):
+            blocks += [gzip.compress(r, level), zlib.compress(r, level)]
+        fixed = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED)        # the fixed Huffman code, gzip wrapper
+        blocks.append(fixed.compress(r) + fixed.flush())
+        several = zlib.compressobj(6, zlib.DEFLATED, 31)                       # several deflate blocks in one member
+        blocks.append(several.compress(r[: len(r) // 2]) + several.flush(zlib.Z_FULL_FLUSH) + several.compress(r[len(r) // 2:]) + several.flush())
+        sizes += [len(r)] * 10
+        want += [r] * 10
+    got, st, tail = run(sizes, blocks)
+    assert st == [0] * len(blocks), [(i, x) for i, x in enumerate(st) if x]
+    assert got == b"".join(want) and all(x == 0xEE for x in tail)
+    # a gzip header with FEXTRA, FNAME, FCOMMENT and FHCRC (RFC 1952 2.3.1)
+    body = zlib.compressobj(6, zlib.DEFLATED, -15)
+    payload = b"optional header fields " * 40
+    deflated = body.compress(payload) + body.flush()
+    import struct as _struct
+    member = (bytes([0x1F, 0x8B, 8, 0x1E, 0, 0, 0, 0, 0, 3]) + _struct.pack("<H", 5) + b"extra" + b"name.bin\0" + b"a comment\0" + b"\x12\x34" +
+              deflated + _struct.pack("<II", zlib.crc32(payload), len(payload)))
+    got, st, _ = run([len(payload)], [member])
+    assert st == [0] and got == payload
+    # corrupt input: a status, and nothing outside the page's destination
+    good = gzip.compress(raws[3], 6)
+    garbled = bytearray(good)
+    for k in range(len(good) // 3, len(good) // 3 + 40):
+        garbled[k] ^= 0x5A
+    cases = [(len(raws[3]), good[: len(good) // 2]),                 # truncated
+             (len(raws[3]) + 1, good),                               # the page header announces another size (ISIZE check)
+             (len(raws[3]), b"\x00\x01" + good[2:]),                 # neither a gzip nor a zlib header
+             (len(raws[3]), bytes(garbled)),
+             (10, bytes([0x78, 0x9C, 0x07]) + b"\0" * 8)]            # block type 3
+    _, st, tail = run([c[0] for c in cases], [c[1] for c in cases])
+    assert all(x != 0 for x in st[:3]) and st[4] == 4, st             # (garbage may decode to other bytes: then a size mismatch or not)
+    assert all(x == 0xEE for x in tail)
+
+
+@pytest.mark.emu
+def test_gzip_page_decoder_kernel(emu_ctx):
+    check_gzip_kernel(emu_ctx, np.random.default_rng(31))
+
+
+@pytest.mark.gpu
+def test_gzip_page_decoder_kernel_gpu(gpu_ctx):
+    check_gzip_kernel(gpu_ctx, np.random.default_rng(32), scale=10)
+
+
+def _gzip_plain_file(tmp_path, n, null_p, version):
+    rng = np.random.default_rng(n + int(null_p * 100) + 1)
+    mask = (rng.random(n) < null_p) if null_p else None
+    t = pa.table({"opt": pa.array(np.cumsum(rng.integers(-3, 4, n)), mask=mask),
+                  "req": pa.array(rng.integers(0, 50, n).astype(np.int32)),
+                  "dbl": pa.array(np.round(rng.standard_normal(n), 1), mask=mask)})
+    fields = [pa.field(f.name, f.type, nullable=(f.name != "req")) for f in t.schema]
+    path = os.path.join(tmp_path, "gzip.parquet")
+    pq.write_table(t.cast(pa.schema(fields)), path, use_dictionary=False, compression="gzip", data_page_version=version,
+                   data_page_size=8192, row_group_size=n // 2 + 3)
+    return path
+
+
+@pytest.mark.emu
+@pytest.mark.parametrize("version,null_p", [("2.0", 0.2), ("1.0", 0.0)])
+def test_parquet_gzip_pages_decompressed_on_the_device(emu_ctx, tmp_path, version, null_p):
+    """PLAIN fixed-width pages under GZIP take the Snappy pages' route (arx_gzip_decompress_pages); equal to pyarrow.parquet
+    with the device route on and off."""
+    path = _gzip_plain_file(str(tmp_path), 20000, null_p, version)
+    stats = {}
+    emu_ctx.parquet.read_table(path, stats=stats)
+    assert stats.get("device_gzip_pages", 0) >= 2 * {"2.0": 3, "1.0": 1}[version], stats
+    check_file(emu_ctx, path)
+    emu_ctx.parquet.DEVICE_GZIP = False
+    try:
+        check_file(emu_ctx, path)
+    finally:
+        emu_ctx.parquet.DEVICE_GZIP = True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("version", ["2.0", "1.0"])
+def test_parquet_gzip_pages_decompressed_on_the_device_gpu(gpu_ctx, tmp_path, version):
+    path = _gzip_plain_file(str(tmp_path), 600_000, 0.1, version)
+    stats = {}
+    gpu_ctx.parquet.read_table(path, stats=stats)
+    assert stats.get("device_gzip_pages", 0) > 10, stats
+    check_file(gpu_ctx, path)
