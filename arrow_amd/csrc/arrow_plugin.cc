@@ -641,6 +641,8 @@ void arrow_amd_plugin_set_parquet_read_threads(int n, int64_t min_part_bytes) {
 }
 // pages decompressed on the device so far
 int64_t arrow_amd_plugin_parquet_device_snappy_pages(void) { return g_parquet_device_snappy_pages.load(); }
+void arrow_amd_plugin_set_parquet_device_gzip(int on) { g_parquet_device_gzip.store(on != 0); }
+int64_t arrow_amd_plugin_parquet_device_gzip_pages(void) { return g_parquet_device_gzip_pages.load(); }
 // device-route pages that had to be copied into the staging block (0: the page reader hands out slices of the chunk)
 int64_t arrow_amd_plugin_parquet_copied_pages(void) { return g_parquet_copied_pages.load(); }
 // aggregate_rocm: rows of pending device batches that trigger a copy into the staging columns; copies so far

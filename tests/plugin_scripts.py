@@ -1902,6 +1902,46 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
     lib.arrow_amd_plugin_set_parquet_device_snappy(1)
     lib.arrow_amd_plugin_set_parquet_pinned_staging(1)
     lib.arrow_amd_plugin_set_parquet_read_threads(4, ctypes.c_int64(1 << 23))
+    # GZIP chunks take the same raw route (round 6: arx_gzip_decompress_pages — RFC 1952 / 1951 on the device); dictionary pages
+    # and V1 optional pages are inflated on the host behind the same reader.  Same arrays with the route switched off.
+    lib.arrow_amd_plugin_parquet_device_gzip_pages.restype = ctypes.c_int64
+    for variant in (dict(data_page_version="2.0", use_dictionary=False, data_page_size=16384),
+                    dict(data_page_version="1.0", use_dictionary=["b", "d"], data_page_size=16384)):
+        path = os.path.join(tempfile.mkdtemp(), "g.parquet")
+        pq.write_table(req, path, row_group_size=n // 2 + 11, compression="gzip", **variant)
+        pf = pq.ParquetFile(path)
+        for on in (1, 0):
+            lib.arrow_amd_plugin_set_parquet_device_gzip(on)
+            before = lib.arrow_amd_plugin_parquet_device_gzip_pages()
+            for rg in range(pf.metadata.num_row_groups):
+                ref = pf.read_row_group(rg)
+                for ci, name in enumerate(req.schema.names):
+                    h = to_host(read_column(path, rg, ci))
+                    w = ref.column(name).combine_chunks()
+                    assert h.equals(w) and h.null_count == w.null_count, ("gzip", variant, on, rg, name)
+            used = lib.arrow_amd_plugin_parquet_device_gzip_pages() - before
+            assert (used > 0) if on else (used == 0), ("gzip", variant, on, used)
+    lib.arrow_amd_plugin_set_parquet_device_gzip(1)
+    # a garbled GZIP page: an IOError that names zlib's inflate, from either side
+    path = os.path.join(tempfile.mkdtemp(), "badgz.parquet")
+    pq.write_table(req.select(["a"]), path, compression="gzip", use_dictionary=False, data_page_version="2.0")
+    raw = bytearray(open(path, "rb").read())
+    off = pq.ParquetFile(path).metadata.row_group(0).column(0).data_page_offset
+    from arrow_amd.parquet import read_page_header
+    hdr, body = read_page_header(bytes(raw), off)
+    for k in range(body + hdr[3] // 3, body + hdr[3] // 3 + 64):
+        raw[k] ^= 0x5A
+    open(path, "wb").write(bytes(raw))
+    try:
+        want, ref_error = pq.ParquetFile(path).read_row_group(0).column("a").combine_chunks(), None
+    except Exception as e:
+        want, ref_error = None, str(e)
+    c_dev, c_schema = ctypes.create_string_buffer(128), ctypes.create_string_buffer(72)
+    rc = lib.arrow_amd_parquet_read_column(path.encode(), 0, 0, ctypes.addressof(c_dev), ctypes.addressof(c_schema))
+    if ref_error is not None:
+        assert rc != 0 and b"zlib inflate failed" in lib.arrow_amd_plugin_last_error(), (ref_error, lib.arrow_amd_plugin_last_error())
+    else:
+        assert rc == 0 and to_host(pa.Array._import_from_c_device(ctypes.addressof(c_dev), ctypes.addressof(c_schema))).equals(want)
     lib.arrow_amd_plugin_parquet_copied_pages.restype = ctypes.c_int64
     assert lib.arrow_amd_plugin_parquet_copied_pages() == 0    # every device-route page was used where the chunk read put it
     # a corrupt Snappy page is reported with the reference's text, whichever side decompresses it
