@@ -1019,23 +1019,30 @@ __global__ __launch_bounds__(kBlock) void levels_ge_bitmap_kernel(const uint32_t
 // length / distance symbols with extra bits; a 32 KB window).  Checksums are skipped, ISIZE is checked.
 //
 // One wave per page, as for Snappy: the symbol stream is sequential, so all 64 lanes decode it in lockstep (uniform control
-// flow, every lane holds the same bit buffer) out of an input window staged in LDS; a literal is one byte store by lane 0, a
-// match is copied by the 64 lanes.  Per wave in LDS: the input window, a 10-bit lookup table for the literal / length code
-// and a 9-bit one for the distance code (entry = symbol << 4 | code length; the bit-reversed code is the index, every
-// longer code falls back to the canonical walk over count[] / symbol[]), the code lengths being read.
+// flow, every lane holds the same bit buffer) out of an input window staged in LDS.  The last 32 KB of OUTPUT — deflate's
+// whole window: every possible match source — live in an LDS ring as well (a write-through copy: every byte also goes to
+// global memory), so a match never reads global memory back and no store has to be waited for; a literal is one byte by
+// lane 0, a match is copied by the 64 lanes (read, rendezvous, write: source and destination may share ring slots when the
+// distance is within 258 bytes of the ring size).  Per wave (= per workgroup of 64 threads; 39 KB, four to a CU) in LDS: the
+// ring, the input window, a 10-bit lookup table for the literal / length code and a 9-bit one for the distance code (entry
+// = symbol << 4 | code length; the bit-reversed code is the index, every longer code falls back to the canonical walk
+// over count[] / symbol[]), the code lengths being read.
 constexpr uint32_t kInfWin = 2048;          // bytes of input staged per wave
+constexpr uint32_t kInfRing = 32768;        // deflate's window (RFC 1951: distances up to 32768)
 constexpr int kInfLitBits = 10;
 constexpr int kInfDistBits = 9;
+constexpr int kInfThreads = 64;
 struct __attribute__((aligned(16))) InflateLds {
-  uint8_t win[kWavesPerBlock][kInfWin + 16];
-  uint16_t lit_lut[kWavesPerBlock][1 << kInfLitBits];
-  uint16_t dist_lut[kWavesPerBlock][1 << kInfDistBits];
-  uint16_t lit_sym[kWavesPerBlock][288];     // symbols sorted by (code length, symbol): the canonical walk's table
-  uint16_t dist_sym[kWavesPerBlock][32];
-  uint16_t lit_count[kWavesPerBlock][16];    // codes per length
-  uint16_t dist_count[kWavesPerBlock][16];
-  uint8_t lengths[kWavesPerBlock][320];      // code lengths of the block being set up (288 + 32)
-  uint8_t staged[kWavesPerBlock][320];       // ... as the code-length code delivers them (literal / length, then distance)
+  uint8_t ring[kInfRing];
+  uint8_t win[kInfWin + 16];
+  uint16_t lit_lut[1 << kInfLitBits];
+  uint16_t dist_lut[1 << kInfDistBits];
+  uint16_t lit_sym[288];     // symbols sorted by (code length, symbol): the canonical walk's table
+  uint16_t dist_sym[32];
+  uint16_t lit_count[16];    // codes per length
+  uint16_t dist_count[16];
+  uint8_t lengths[320];      // code lengths of the block being set up (288 + 32)
+  uint8_t staged[320];       // ... as the code-length code delivers them (literal / length, then distance)
 };
 
 struct InflateBits {
@@ -1063,12 +1070,17 @@ __device__ __forceinline__ void inflate_stage(InflateBits& b) {
 }
 
 __device__ __forceinline__ void inflate_refill(InflateBits& b) {
-  while (b.cnt <= 56) {
-    if (b.ip - b.win_base >= kInfWin) inflate_stage(b);
-    const uint64_t byte = b.ip < b.n_in ? b.win[b.ip - b.win_base] : 0;   // (past the end: zeros, counted by `overrun` when used)
-    b.buf |= byte << b.cnt;
-    b.cnt += 8;
-    ++b.ip;
+  while (b.cnt <= 32) {   // four bytes at a time (the window holds 16 bytes beyond kInfWin, zeros beyond the input)
+    if (b.ip - b.win_base + 4 > kInfWin) inflate_stage(b);
+    // two ALIGNED 32-bit LDS reads and a shift (four byte reads get merged into one unaligned ds_read_b32, which this
+    // target's LDS does not serve: it returns the aligned word)
+    const uint32_t off = b.ip - b.win_base;
+    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(b.win);
+    const uint64_t pair = static_cast<uint64_t>(w32[off >> 2]) | (static_cast<uint64_t>(w32[(off >> 2) + 1]) << 32);
+    const uint64_t four = (pair >> ((off & 3u) * 8u)) & 0xFFFFFFFFull;
+    b.buf |= four << b.cnt;
+    b.cnt += 32;
+    b.ip += 4;
   }
 }
 
@@ -1167,13 +1179,12 @@ __device__ __forceinline__ uint32_t inflate_symbol(InflateBits& b, const uint16_
 // status: 0 ok, 1 bad gzip / zlib header or the stream does not produce dst_size bytes, 2 the stream runs past its block or
 // the output, 3 a distance reaches before the output, 4 an invalid Huffman code (over-subscribed table, unassigned code,
 // bad block type or stored-block length)
-__global__ __launch_bounds__(kBlock) void inflate_pages_kernel(const uint8_t* __restrict__ src, const ArxSnappyPage* __restrict__ pages,
+__global__ __launch_bounds__(kInfThreads) void inflate_pages_kernel(const uint8_t* __restrict__ src, const ArxSnappyPage* __restrict__ pages,
                                                                int64_t npages, uint8_t* dst, uint32_t* __restrict__ status) {
   __shared__ InflateLds lds;
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  const int64_t pg = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
-  if (pg >= npages) return;   // wave-uniform
+  const int lane = threadIdx.x;
+  const int64_t pg = blockIdx.x;
+  if (pg >= npages) return;
   const ArxSnappyPage p = pages[pg];
   const uint8_t* in = src + p.src_offset;
   uint8_t* out = dst + p.dst_offset;
@@ -1208,13 +1219,15 @@ __global__ __launch_bounds__(kBlock) void inflate_pages_kernel(const uint8_t* __
   } else {
     err = 1;
   }
-  InflateBits b{in, lds.win[wave], err ? 0u : n_in - trailer, start, start, 0, 0, lane, 0};
-  uint16_t* lit_lut = lds.lit_lut[wave];
-  uint16_t* dist_lut = lds.dist_lut[wave];
-  uint8_t* lengths = lds.lengths[wave];
-  uint8_t* staged = lds.staged[wave];
+  // (n_in - trailer unconditionally: trailer is 0 on the error paths.  `err ? 0 : n_in - trailer` compiled to s_add_i32 +
+  //  s_cselect on the add's own SCC with this toolchain — always 0: an empty window, every page "corrupt")
+  InflateBits b{in, lds.win, n_in - trailer, start, start, 0, 0, lane, 0};
+  uint16_t* lit_lut = lds.lit_lut;
+  uint16_t* dist_lut = lds.dist_lut;
+  uint8_t* lengths = lds.lengths;
+  uint8_t* staged = lds.staged;
   uint32_t op = 0;
-  bool pending = false;       // output bytes stored since the last fence (a match may read them)
+  uint8_t* ring = lds.ring;
   if (!err) inflate_stage(b);
   bool last = false;
   while (!err && !last) {
@@ -1229,9 +1242,13 @@ __global__ __launch_bounds__(kBlock) void inflate_pages_kernel(const uint8_t* __
       if ((len ^ 0xFFFFu) != nlen) { err = 4; break; }
       const uint32_t from = inflate_consumed(b);
       if (from > b.n_in || len > b.n_in - from || len > ulen - op) { err = 2; break; }
-      for (uint32_t j = lane; j < len; j += 64) out[op + j] = in[from + j];
+      for (uint32_t j = lane; j < len; j += 64) {
+        const uint8_t v = in[from + j];
+        out[op + j] = v;
+        ring[(op + j) & (kInfRing - 1)] = v;     // (a block longer than the ring overwrites itself in order: len <= 65535)
+      }
       op += len;
-      pending = true;
+      __builtin_amdgcn_wave_barrier();
       b.ip = from + len;       // the bit buffer is dropped: the next block starts at a byte boundary
       b.buf = 0;
       b.cnt = 0;
@@ -1263,12 +1280,12 @@ __global__ __launch_bounds__(kBlock) void inflate_pages_kernel(const uint8_t* __
       }
       __builtin_amdgcn_wave_barrier();
       // (its tables live where the distance code's will: both are rebuilt below)
-      err = inflate_build(lengths, 19, lds.dist_count[wave], lds.dist_sym[wave], dist_lut, 7, lane);
+      err = inflate_build(lengths, 19, lds.dist_count, lds.dist_sym, dist_lut, 7, lane);
       if (err) break;
       int at = 0;
       uint32_t prev = 0;
       while (at < nlit + ndist && !err) {
-        const uint32_t sym = inflate_symbol(b, dist_lut, 7, lds.dist_count[wave], lds.dist_sym[wave]);
+        const uint32_t sym = inflate_symbol(b, dist_lut, 7, lds.dist_count, lds.dist_sym);
         uint32_t value = 0, repeat = 1;
         if (sym < 16) {
           value = sym;
@@ -1300,18 +1317,20 @@ __global__ __launch_bounds__(kBlock) void inflate_pages_kernel(const uint8_t* __
       nlit = 288;
       ndist = 32;
     }
-    err = inflate_build(lengths, nlit, lds.lit_count[wave], lds.lit_sym[wave], lit_lut, kInfLitBits, lane);
+    err = inflate_build(lengths, nlit, lds.lit_count, lds.lit_sym, lit_lut, kInfLitBits, lane);
     if (err) break;
-    err = inflate_build(lengths + 288, ndist, lds.dist_count[wave], lds.dist_sym[wave], dist_lut, kInfDistBits, lane);
+    err = inflate_build(lengths + 288, ndist, lds.dist_count, lds.dist_sym, dist_lut, kInfDistBits, lane);
     if (err) break;
     // ---- the block's symbols
     for (;;) {
-      const uint32_t sym = inflate_symbol(b, lit_lut, kInfLitBits, lds.lit_count[wave], lds.lit_sym[wave]);
+      const uint32_t sym = inflate_symbol(b, lit_lut, kInfLitBits, lds.lit_count, lds.lit_sym);
       if (sym < 256) {
         if (op >= ulen) { err = 2; break; }
-        if (lane == 0) out[op] = static_cast<uint8_t>(sym);
+        if (lane == 0) {
+          out[op] = static_cast<uint8_t>(sym);
+          ring[op & (kInfRing - 1)] = static_cast<uint8_t>(sym);
+        }
         ++op;
-        pending = true;
         continue;
       }
       if (sym == 256) break;
@@ -1323,7 +1342,7 @@ __global__ __launch_bounds__(kBlock) void inflate_pages_kernel(const uint8_t* __
       else if (ls == 28) { len = 258; lextra = 0; }
       else { lextra = (ls >> 2) - 1; len = 3 + ((4u + (ls & 3u)) << lextra); }
       if (lextra) len += inflate_take(b, static_cast<int>(lextra));
-      const uint32_t ds = inflate_symbol(b, dist_lut, kInfDistBits, lds.dist_count[wave], lds.dist_sym[wave]);
+      const uint32_t ds = inflate_symbol(b, dist_lut, kInfDistBits, lds.dist_count, lds.dist_sym);
       if (ds > 29) { err = 4; break; }
       uint32_t dist, dextra;
       if (ds < 4) { dist = 1 + ds; dextra = 0; }
@@ -1331,21 +1350,22 @@ __global__ __launch_bounds__(kBlock) void inflate_pages_kernel(const uint8_t* __
       if (dextra) dist += inflate_take(b, static_cast<int>(dextra));
       if (dist > op) { err = 3; break; }
       if (len > ulen - op) { err = 2; break; }
-      // the source bytes may be literals lane 0 stored, or the previous match's bytes from any lane: made visible, and (the
-      // SIMT emulator runs lanes in any order between rendezvous points) every lane past its stores, before they are read
-      if (pending) {
-        __threadfence_block();
+      // the source is in the ring, whatever the distance; every lane past its earlier ring stores before any lane reads
+      // (lockstep on the GPU; the SIMT emulator runs lanes in any order between rendezvous points)
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t from = op - dist;
+      for (uint32_t j0 = 0; j0 < len; j0 += 64) {
+        const uint32_t j = j0 + static_cast<uint32_t>(lane);
+        const bool mine = j < len;
+        const uint8_t v = mine ? ring[(from + (dist >= len ? j : j % dist)) & (kInfRing - 1)] : 0;
+        __builtin_amdgcn_wave_barrier();           // (a destination slot may be another lane's source slot: dist near the ring size)
+        if (mine) {
+          ring[(op + j) & (kInfRing - 1)] = v;
+          out[op + j] = v;
+        }
         __builtin_amdgcn_wave_barrier();
-        pending = false;
-      }
-      const uint8_t* from = out + (op - dist);
-      if (dist >= len) {
-        for (uint32_t j = lane; j < len; j += 64) out[op + j] = from[j];
-      } else {
-        for (uint32_t j = lane; j < len; j += 64) out[op + j] = from[j % dist];
       }
       op += len;
-      pending = true;
     }
   }
   if (!err && (op != ulen || inflate_consumed(b) > b.n_in)) err = op != ulen ? 1 : 2;
@@ -1975,8 +1995,12 @@ int arx_gzip_decompress_pages(const void* compressed, const ArxSnappyPage* pages
     return ARX_INVALID;
   }
   if (num_pages == 0) return ARX_OK;
-  const unsigned grid = static_cast<unsigned>(ceil_div(num_pages, kWavesPerBlock));
-  hipLaunchKernelGGL(inflate_pages_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), static_cast<const uint8_t*>(compressed),
+  if (num_pages > INT32_MAX) {
+    set_error("arx_gzip_decompress_pages: more than 2^31 pages");
+    return ARX_INVALID;
+  }
+  const unsigned grid = static_cast<unsigned>(num_pages);      // one wave (a workgroup of 64 threads) per page
+  hipLaunchKernelGGL(inflate_pages_kernel, dim3(grid), dim3(kInfThreads), 0, as_stream(stream), static_cast<const uint8_t*>(compressed),
                      pages, num_pages, static_cast<uint8_t*>(out), status);
   ARX_CHECK_LAUNCH("inflate_pages_kernel");
   return ARX_OK;
