@@ -210,6 +210,38 @@ class ListArray:
         return self.to_pyarrow().to_pylist()
 
 
+class StructArray:
+    """arrow::StructArray twin on the device: buffers = [validity or None], one child per member.  `type` is the pyarrow
+    struct type.  What the Parquet reader hands back for struct columns."""
+
+    def __init__(self, pa_type, length: int, buffers, children, null_count: int = 0):
+        self.type = pa_type
+        self.length = int(length)
+        self.buffers = list(buffers)
+        self.children = list(children)
+        self.null_count = int(null_count)
+
+    def __len__(self):
+        return self.length
+
+    def to_pyarrow(self):
+        import pyarrow as pa
+
+        vb = None
+        if self.buffers[0] is not None:
+            vb = pa.py_buffer(self.buffers[0].cpu().numpy()[: (self.length + 7) // 8].tobytes())
+        kids = []
+        for j, child in enumerate(self.children):
+            arr = child.to_pyarrow()
+            want = self.type.field(j).type
+            kids.append(arr if arr.type == want else arr.cast(want))
+        return pa.Array.from_buffers(self.type, self.length, [vb], null_count=self.null_count if vb is not None else 0,
+                                     children=kids)
+
+    def to_pylist(self):
+        return self.to_pyarrow().to_pylist()
+
+
 def _ptr(t: torch.Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 

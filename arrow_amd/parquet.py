@@ -859,6 +859,71 @@ def assemble_list_column(leaf: Array, nested: dict, field, num_rows: int, device
     return child
 
 
+def _read_struct_column(pf, md, raw, names, top: str, device, stats):
+    """A struct column whose members are primitives: every member is a flat leaf with one more definition level when the
+    struct is nullable (LevelInfo::Increment, level_conversion.h; no repetition), decoded with one slot per row — valid where
+    def = its maximum level, which is what the reference's StructReader::BuildArray leaves in a member under a null struct —
+    and the struct's own validity is DefLevelsToBitmap of ANY member's levels at the struct's level (def >= 1;
+    parquet/arrow/reader.cc StructReader::GetDefLevels picks the first child with levels).  One StructArray per row group."""
+    import pyarrow as pa
+
+    from .array import StructArray, binary, is_temporal, type_from_name, utf8
+
+    field = pf.schema_arrow.field(top)
+    members = [i for i, nm in enumerate(names) if nm.split(".")[0] == top]
+    if not pa.types.is_struct(field.type) or len(members) != field.type.num_fields or \
+            any(pa.types.is_nested(field.type.field(j).type) for j in range(field.type.num_fields)):
+        raise ArrowNotImplementedError(f"Parquet: column {top} of type {field.type} is not on the gfx950 path "
+                                       "(structs of primitives and lists of primitives are)")
+    device = torch.device(device) if device is not None else default_device()
+    lib, stream = _lib.get_lib(), current_stream(device)
+    struct_def = 1 if field.nullable else 0
+    chunks = []
+    for rg in range(md.num_row_groups):
+        rows = md.row_group(rg).num_rows
+        children, validity, nulls = [], None, 0
+        for j, ci in enumerate(members):
+            col = md.schema.column(ci)
+            mfield = field.type.field(j)
+            want_def = struct_def + (1 if mfield.nullable else 0)
+            if col.max_definition_level != want_def or col.max_repetition_level:
+                raise ArrowNotImplementedError(f"Parquet: level layout of column {names[ci]}")
+            binary_type = None
+            if col.physical_type == "BYTE_ARRAY":
+                binary_type = utf8 if str(col.logical_type).upper().startswith("STRING") else binary
+            nested = {"max_rep": 0}
+            child = read_column_chunk(raw, md.row_group(rg).column(ci), want_def, device, stats, binary_type, nested)
+            if child.length != rows:
+                raise ArrowInvalid(f"Parquet: {child.length} levels in column {names[ci]} for {rows} rows (corrupt page?)")
+            if col.physical_type in ("INT32", "INT64"):
+                try:
+                    logical = type_from_name(str(mfield.type))
+                except ArrowNotImplementedError:
+                    logical = None
+                if logical is not None and is_temporal(logical) and child.type.bit_width == logical.bit_width:
+                    child.type = logical
+            children.append(child)
+            if struct_def and validity is None and want_def > 0 and nested["levels"] == rows:
+                # the struct's validity from this member's levels: def >= the struct's level
+                runs = np.concatenate(nested["def_runs"]) if nested["def_runs"] else np.zeros(0, RUN_DTYPE)
+                d_def = alloc(max(rows, 1) * 4, device)
+                if rows and len(runs):
+                    d_bytes = to_device(np.frombuffer(nested["def_bytes"] or b"\0", dtype=np.uint8), device)
+                    d_runs = _device_runs(runs, device)
+                    check(lib.arx_rle_decode_u32(d_bytes.data_ptr(), len(nested["def_bytes"]), d_runs.data_ptr(), len(runs),
+                                                 nested["def_bw"], rows, d_def.data_ptr(), stream))
+                else:
+                    d_def.zero_()
+                validity = alloc(bitmap_nbytes(max(rows, 1)), device, zero=True)
+                ones = torch.zeros(1, dtype=torch.int64, device=device)
+                check(lib.arx_levels_ge_bitmap(d_def.data_ptr(), rows, struct_def, validity.data_ptr(), ones.data_ptr(), stream))
+                nulls = rows - int(ones.item())
+                if nulls == 0:
+                    validity = None
+        chunks.append(StructArray(field.type, rows, [validity], children, nulls))
+    return chunks
+
+
 def _lib_uint32():
     from .array import uint32
 
@@ -866,7 +931,8 @@ def _lib_uint32():
 
 
 def read_table(path: str, columns=None, device=None, stats: dict | None = None) -> dict:
-    """{column name: [device Array per row group]} for the flat numeric columns of a Parquet file."""
+    """{column name: [device array per row group]}: flat columns by their name, list columns by the path of their leaf,
+    struct columns (of primitives) by the name of their top-level field."""
     import pyarrow.parquet as pq
 
     pf = pq.ParquetFile(path)
@@ -885,6 +951,12 @@ def read_table(path: str, columns=None, device=None, stats: dict | None = None) 
             from .array import binary, utf8
 
             binary_type = utf8 if str(md.schema.column(ci).logical_type).upper().startswith("STRING") else binary
+        if not max_rep and "." in name:
+            # a member of a struct column: the whole struct is assembled once, under the name of its top-level field
+            top = name.split(".")[0]
+            if top not in out:
+                out[top] = _read_struct_column(pf, md, raw, names, top, device, stats)
+            continue
         if max_rep:
             # a repeated column: lists (of lists ...) of a primitive, addressed by the name of its top-level field
             top = name.split(".")[0]

@@ -1908,7 +1908,8 @@ PARQUET_SCRIPT = textwrap.dedent(r'''
     for variant in (dict(data_page_version="2.0", use_dictionary=False, data_page_size=16384),
                     dict(data_page_version="1.0", use_dictionary=["b", "d"], data_page_size=16384)):
         path = os.path.join(tempfile.mkdtemp(), "g.parquet")
-        pq.write_table(req, path, row_group_size=n // 2 + 11, compression="gzip", **variant)
+        req_g = req.slice(0, n // 4)                 # (the host's deflate is the slow part of this check)
+        pq.write_table(req_g, path, row_group_size=n // 8 + 11, compression="gzip", **variant)
         pf = pq.ParquetFile(path)
         for on in (1, 0):
             lib.arrow_amd_plugin_set_parquet_device_gzip(on)
