@@ -496,6 +496,26 @@ int arrow_amd_parquet_read_column(const char* path, int row_group, int column, s
   }
   return 0;
 }
+// One TOP-LEVEL FIELD of a row group (flat column, list chain or struct of primitives) as a device-resident array: what the
+// reference's FileReader::ReadRowGroup assembles per schema field (parquet/arrow/reader.cc).
+int arrow_amd_parquet_read_field(const char* path, int row_group, int field, struct ArrowDeviceArray* out,
+                                 struct ArrowSchema* out_schema) {
+  auto run = [&]() -> Status {
+    try {
+      ARROW_ASSIGN_OR_RAISE(auto data, ParquetFieldToDevice(path, row_group, field));
+      ARROW_RETURN_NOT_OK(arrow::ExportType(*data->type, out_schema));
+      return arrow::ExportDeviceArray(*arrow::MakeArray(data), nullptr, out);
+    } catch (const parquet::ParquetException& e) {
+      return Status::IOError("Parquet: ", e.what());
+    }
+  };
+  const Status st = run();
+  if (!st.ok()) {
+    t_error = st.ToString();
+    return -1;
+  }
+  return 0;
+}
 // Several column chunks of one row group at once.  A column chunk is decoded by one host thread and (for its Snappy
 // pages) one wave per page — with ~1000 pages that is one wave per SIMD and nothing to hide its latency behind — so
 // the chunks of a row group are given to a small pool of worker threads that live as long as the library: every

@@ -812,8 +812,16 @@ def assemble_list_column(leaf: Array, nested: dict, field, num_rows: int, device
 
     device = torch.device(device) if device is not None else default_device()
     lib, stream = _lib.get_lib(), current_stream(device)
-    lists, (leaf_def, _leaf_rep, leaf_anc), _ = list_level_infos(field)
+    lists, (leaf_def, _leaf_rep, leaf_anc), leaf_pa_type = list_level_infos(field)
     n = nested["levels"]
+    try:        # logical types that share the physical layout (timestamp, date32, time32 / time64): labelled as the reference does
+        from .array import is_temporal, type_from_name
+
+        logical = type_from_name(str(leaf_pa_type))
+        if is_temporal(logical) and getattr(leaf.type, "bit_width", 0) == logical.bit_width:
+            leaf.type = logical
+    except ArrowNotImplementedError:
+        pass
 
     def decode(level_bytes, runs_list, bw):
         out = alloc(max(n, 1) * 4, device)

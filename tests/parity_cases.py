@@ -3388,7 +3388,7 @@ def check_rank(amd, rng_for, scale=1, light=False):
         d = util.HostArray(v, valid, 0, len(v)).to_device(amd)
         got = _data_np(amd.compute.rank(d, order, place, tb), np.uint64)
         assert_equal(got, np.array(expected, np.uint64), f"rank golden [{v.dtype},{order},{place},{tb}]")
-    sizes = [0, 1, 2049, 4500] if light else [0, 1, 2047, 2048, 2049, 5000 * scale, 40_000 * scale]
+    sizes = [0, 1, 2049] if light else [0, 1, 2047, 2048, 2049, 5000 * scale, 40_000 * scale]
     combos = [(o, p_) for o in ("ascending", "descending") for p_ in ("at_end", "at_start")]
     for dtype in (np.uint64, np.int64, np.uint32, np.int32, np.float64, np.float32):
         for n in sizes:

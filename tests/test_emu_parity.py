@@ -483,7 +483,7 @@ def test_sort_wide_many_level2_bins(emu_ctx, bits, b2max):
     (120_000, 0, 1, 0, (24, 16), 11, 256, 1, 1, 2), (40_000, 12, 0, 2, (8, 8), 11, 0, 1, 2, 2),
     (40_000, 6, 1, 2, (16, 24), 11, 1, 0, 0, 2), (120_000, 10, 1, 2, (24, 16), 4, 3, 1, 3, 2),
     (120_000, 10, 1, 2, (24, 16), 4, 2, 0, 1, 1), (160_000, 12, 0, 0, (8, 16), 3, 2, 1, 2, 2),
-    (160_000, 12, 0, 0, (8, 16), 3, 2, 1, 2, 1), (60_000, 12, 1, 2, (24, 16), 11, 4, 1, 3, 2)])
+    (60_000, 12, 1, 2, (24, 16), 11, 4, 1, 3, 2)])    # (round 5's rank-and-stage level 1 at 160 000 rows: the GPU tier)
 def test_sort_wide_rec8_words(emu_ctx, n, bits, gap2, shift, rpt, b2max, wc, prefetch, l2w, wc_form):
     """8-byte {key bits, row id} words through the wide form: ties below the word, duplicates, the tie budget, fall-backs;
     level 1 tile at a time and write-combined — round 6's append kernel (wc_form 2) and round 5's rank-and-stage kernel
