@@ -951,6 +951,11 @@ def read_table(path: str, columns=None, device=None, stats: dict | None = None) 
     wanted = names if columns is None else list(columns)
     out = {}
     for name in wanted:
+        if name not in names:            # a nested column by the name of its top-level field: (the first of) its leaves
+            under = [nm for nm in names if nm.split(".")[0] == name]
+            if not under:
+                raise ArrowInvalid(f"Parquet: no column {name!r} in {path}")
+            name = under[0]
         ci = names.index(name)
         max_def = md.schema.column(ci).max_definition_level
         max_rep = md.schema.column(ci).max_repetition_level

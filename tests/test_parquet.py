@@ -1490,6 +1490,7 @@ def _write_and_check_structs(amd, tmp_path, n, struct_null_p, member_null_p, var
     pf = pq.ParquetFile(path)
     got = amd.parquet.read_table(path)
     assert sorted(got) == ["flat", "r", "s"]
+    assert sorted(amd.parquet.read_table(path, columns=["s"])) == ["s"]          # (nested columns by their top-level name)
     for name, chunks in got.items():
         assert len(chunks) == pf.metadata.num_row_groups
         for rg, arr in enumerate(chunks):
